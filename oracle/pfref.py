@@ -1,0 +1,262 @@
+"""oracle/pfref.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/_ref/libpfref.so (the reference engine's own nav /
+ClearPath / movement code, built by oracle/ref/build_ref.py from the sources
+in place under /root/reference).  Only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TARGET_PORTAL, TARGET_TILE = 0, 1
+FACTION_ID_NONE = 0xF
+ISLAND_NONE = 0xFFFF
+PLANE_COST, PLANE_BLOCKERS, PLANE_ISLANDS, PLANE_LOCAL_ISLANDS, PLANE_FACTIONS = range(5)
+
+
+class FieldReq(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "layer", "type", "faction_id", "inout", "chunk_r", "chunk_c", "tile_r", "tile_c",
+        "port_r0", "port_c0", "port_r1", "port_c1", "next_chunk_r", "next_chunk_c",
+        "next_r0", "next_c0", "next_r1", "next_c1", "port_iid", "next_iid")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+FIELD_REQ_DTYPE = np.dtype([(n, np.int32) for n, _ in FieldReq._fields_])
+
+
+class Portal(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "chunk_r", "chunk_c", "r0", "c0", "r1", "c1", "conn_chunk_r", "conn_chunk_c",
+        "conn_r0", "conn_c0", "conn_r1", "conn_c1", "component_id")]
+
+
+class MoveWorld(C.Structure):
+    _fields_ = [
+        ("n", C.c_int), ("pos_xz", C.c_void_p), ("vel_xz", C.c_void_p), ("radius", C.c_void_p),
+        ("max_speed", C.c_void_p), ("speed", C.c_void_p), ("flags", C.c_void_p),
+        ("state", C.c_void_p), ("flock", C.c_void_p), ("has_dest_los", C.c_void_p),
+        ("n_flocks", C.c_int), ("flock_target_xz", C.c_void_p), ("flock_dest_id", C.c_void_p),
+        ("hz", C.c_int)]
+
+
+def available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libpfref.so"))
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "_ref", "libpfref.so")
+        if not os.path.exists(path):
+            from oracle.ref import build_ref
+            if build_ref.build(release=True) is None:
+                raise RuntimeError("oracle/_ref/libpfref.so missing and /root/reference absent")
+        L = C.CDLL(path)
+        L.pfref_nav_create.restype = C.c_void_p
+        L.pfref_nav_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint]
+        L.pfref_nav_destroy.argtypes = [C.c_void_p]
+        L.pfref_nav_set_blockers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.pfref_nav_blockers_circle.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                                C.c_int, C.c_uint32, C.c_int]
+        L.pfref_nav_flush_dirty.argtypes = [C.c_void_p]
+        L.pfref_nav_copy_plane.restype = C.c_size_t
+        L.pfref_nav_copy_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.pfref_nav_num_portals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.pfref_nav_get_portal.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(Portal)]
+        L.pfref_field_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pfref_field_bench.restype = C.c_double
+        L.pfref_field_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.pfref_request_path.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                         C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
+        L.pfref_trace_get.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pfref_desired_point_seek_velocity.argtypes = [C.c_void_p, C.c_uint32, C.c_float,
+                                                        C.c_float, C.c_float, C.c_float,
+                                                        C.c_void_p]
+        L.pfref_cached_field.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.pfref_has_dest_los.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float,
+                                         C.c_float, C.c_float]
+        L.pfref_position_pathable.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.pfref_position_blocked.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.pfref_map_pos.argtypes = [C.c_void_p, C.c_void_p]
+        for name, at, rt in (
+            ("pfref_clearpath_new_velocity", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_int, C.c_void_p], None),
+            ("pfref_spatial_query", [C.c_float] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                       C.c_float, C.c_int, C.c_void_p,
+                                                       C.c_void_p], None),
+            ("pfref_move_load", [C.c_void_p, C.POINTER(MoveWorld)], C.c_int),
+            ("pfref_move_velocity", [C.c_void_p, C.c_int, C.c_int, C.c_void_p], None),
+            ("pfref_move_unload", [], None),
+            ("pfref_move_vpref", [C.c_int, C.c_void_p, C.c_void_p], None),
+            ("pfref_move_forces", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+             None),
+            ("pfref_move_neighbours", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+             C.c_int),
+            ("pfref_move_bench", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+             C.c_double),
+        ):
+            if hasattr(L, name):
+                f = getattr(L, name)
+                f.argtypes = at
+                f.restype = rt
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class RefNav:
+    """The reference's `struct nav_private` built from explicit cost planes."""
+
+    def __init__(self, cost_base, layer_mask=1):
+        cost_base = np.ascontiguousarray(cost_base, dtype=np.uint8)
+        assert cost_base.ndim == 4 and cost_base.shape[2:] == (64, 64)
+        self.h, self.w = cost_base.shape[:2]
+        self.layer_mask = layer_mask
+        self._h = lib().pfref_nav_create(self.w, self.h, _p(cost_base), layer_mask)
+        if not self._h:
+            raise RuntimeError("pfref_nav_create failed")
+        mp = np.zeros(3, np.float32)
+        lib().pfref_map_pos(self._h, _p(mp))
+        self.map_pos = mp
+
+    def close(self):
+        if self._h:
+            lib().pfref_nav_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- planes ---------------------------------------------------------
+    def plane(self, which, layer=0):
+        dt = np.uint8 if which in (PLANE_COST, PLANE_FACTIONS) else np.uint16
+        shape = (self.h, self.w, 64, 64) if which != PLANE_FACTIONS else (self.h, self.w, 15, 64, 64)
+        out = np.zeros(shape, dt)
+        lib().pfref_nav_copy_plane(self._h, layer, which, _p(out))
+        return out
+
+    def set_blockers(self, blockers, layer=0):
+        b = np.ascontiguousarray(blockers, dtype=np.uint16)
+        assert b.shape == (self.h, self.w, 64, 64)
+        lib().pfref_nav_set_blockers(self._h, layer, _p(b))
+
+    def blockers_circle(self, x, z, rng, faction_id=0, flags=0, incref=True):
+        lib().pfref_nav_blockers_circle(self._h, x, z, rng, faction_id, flags, int(incref))
+
+    def flush_dirty(self):
+        lib().pfref_nav_flush_dirty(self._h)
+
+    def portals(self, chunk_r, chunk_c, layer=0):
+        n = lib().pfref_nav_num_portals(self._h, layer, chunk_r, chunk_c)
+        out = []
+        for i in range(n):
+            p = Portal()
+            lib().pfref_nav_get_portal(self._h, layer, chunk_r, chunk_c, i, C.byref(p))
+            out.append(p)
+        return out
+
+    # -- fields ---------------------------------------------------------
+    def field_update(self, req, inout=None, want_integ=False):
+        """req: FieldReq or a FIELD_REQ_DTYPE record.  Returns (dirs[64,64] u8, integ|None)."""
+        r = _to_req(req)
+        dirs = np.zeros((64, 64), np.uint8) if inout is None else \
+            np.ascontiguousarray(inout, dtype=np.uint8).reshape(64, 64).copy()
+        integ = np.zeros((64, 64), np.float32) if want_integ else None
+        rc = lib().pfref_field_update(self._h, C.byref(r), _p(dirs),
+                                      _p(integ) if want_integ else None)
+        if rc != 0:
+            raise ValueError("pfref_field_update: bad request")
+        return dirs, integ
+
+    def field_bench(self, reqs, reps=1, nthreads=1):
+        reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)
+        return lib().pfref_field_bench(self._h, _p(reqs), len(reqs), reps, nthreads)
+
+    # -- planner ----------------------------------------------------------
+    def request_path(self, src, dst, layer=0, faction_id=FACTION_ID_NONE, clear_cache=False):
+        did = C.c_uint32(0)
+        ok = lib().pfref_request_path(self._h, layer, faction_id, src[0], src[1], dst[0], dst[1],
+                                      int(clear_cache), C.byref(did))
+        return bool(ok), did.value
+
+    @staticmethod
+    def trace(clear=True):
+        L = lib()
+        n = L.pfref_trace_count()
+        reqs = np.zeros(n, FIELD_REQ_DTYPE)
+        before = np.zeros((n, 64, 64), np.uint8)
+        after = np.zeros((n, 64, 64), np.uint8)
+        for i in range(n):
+            L.pfref_trace_get(i, _p(reqs[i:i + 1]), _p(before[i]), _p(after[i]))
+        if clear:
+            L.pfref_trace_clear()
+        return reqs, before, after
+
+    def desired_velocity(self, dest_id, pos, dst):
+        out = np.zeros(2, np.float32)
+        lib().pfref_desired_point_seek_velocity(self._h, dest_id, pos[0], pos[1], dst[0], dst[1],
+                                                _p(out))
+        return out
+
+    def cached_field(self, dest_id, chunk_r, chunk_c):
+        out = np.zeros((64, 64), np.uint8)
+        ok = lib().pfref_cached_field(self._h, dest_id, chunk_r, chunk_c, _p(out))
+        return out if ok else None
+
+    def has_dest_los(self, dest_id, pos, dst):
+        return bool(lib().pfref_has_dest_los(self._h, dest_id, pos[0], pos[1], dst[0], dst[1]))
+
+    def position_pathable(self, pos, layer=0):
+        return bool(lib().pfref_position_pathable(self._h, layer, pos[0], pos[1]))
+
+    def position_blocked(self, pos, layer=0):
+        return bool(lib().pfref_position_blocked(self._h, layer, pos[0], pos[1]))
+
+
+def _to_req(req):
+    if isinstance(req, FieldReq):
+        return req
+    r = FieldReq()
+    if isinstance(req, dict):
+        for k, v in req.items():
+            setattr(r, k, int(v))
+    else:
+        for n in FIELD_REQ_DTYPE.names:
+            setattr(r, n, int(req[n]))
+    return r
+
+
+def clearpath_new_velocity(ent, des_v, dyn, stat):
+    ent = np.ascontiguousarray(ent, np.float32)
+    des_v = np.ascontiguousarray(des_v, np.float32)
+    dyn = np.ascontiguousarray(dyn, np.float32).reshape(-1, 5)
+    stat = np.ascontiguousarray(stat, np.float32).reshape(-1, 5)
+    out = np.zeros(2, np.float32)
+    lib().pfref_clearpath_new_velocity(_p(ent), _p(des_v), _p(dyn), len(dyn), _p(stat), len(stat),
+                                       _p(out))
+    return out
+
+
+def spatial_query(bounds, pos_xz, query_xz, rng, maxout):
+    pos_xz = np.ascontiguousarray(pos_xz, np.float32).reshape(-1, 2)
+    query_xz = np.ascontiguousarray(query_xz, np.float32).reshape(-1, 2)
+    counts = np.zeros(len(query_xz), np.int32)
+    ids = np.zeros((len(query_xz), maxout), np.uint32)
+    lib().pfref_spatial_query(bounds[0], bounds[1], bounds[2], bounds[3], _p(pos_xz), len(pos_xz),
+                              _p(query_xz), len(query_xz), rng, maxout, _p(counts), _p(ids))
+    return counts, ids

@@ -1,0 +1,171 @@
+/* oracle/ref/pfref.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Flat C API of oracle/_ref/libpfref.so: the reference engine's own
+ * navigation / ClearPath / movement translation units, compiled unmodified
+ * from where they lie under /root/reference/src and driven through a thin
+ * harness.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may call this.
+ *
+ * Every entry point names the reference function it drives.
+ */
+#ifndef PFREF_H
+#define PFREF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pfref_nav pfref_nav;
+
+/* Flattened `struct field_target` + call arguments of N_FlowFieldUpdate
+ * (field.h:85-109,146-152). */
+typedef struct pfref_field_req {
+    int32_t  layer;
+    int32_t  type;          /* TARGET_PORTAL = 0, TARGET_TILE = 1 (field.h:86-87) */
+    int32_t  faction_id;
+    int32_t  inout;         /* 1: N_FlowFieldUpdate ran on an existing field (nav.c:1998-2001) */
+    int32_t  chunk_r, chunk_c;
+    int32_t  tile_r, tile_c;
+    /* struct portal_desc (field.h:67-72) */
+    int32_t  port_r0, port_c0, port_r1, port_c1;
+    int32_t  next_chunk_r, next_chunk_c;
+    int32_t  next_r0, next_c0, next_r1, next_c1;
+    int32_t  port_iid, next_iid;
+} pfref_field_req;
+
+typedef struct pfref_portal {
+    int32_t chunk_r, chunk_c;
+    int32_t r0, c0, r1, c1;
+    int32_t conn_chunk_r, conn_chunk_c;
+    int32_t conn_r0, conn_c0, conn_r1, conn_c1;
+    int32_t component_id;
+} pfref_portal;
+
+/* --- context ------------------------------------------------------------ */
+
+/* Build a `struct nav_private` (nav_private.h:52) for the layers in
+ * `layer_mask` from explicit cost_base planes ([h][w][64][64] u8, the
+ * N_CopyCostBasePacked layout nav.c:2432), then run the reference's own
+ * n_update_portals / n_update_island_field / n_update_local_island_field
+ * (nav.c:1710,1731,986) exactly as N_NewCtxForMapData does (nav.c:2340-2343). */
+pfref_nav *pfref_nav_create(int w, int h, const uint8_t *cost_base, unsigned layer_mask);
+void       pfref_nav_destroy(pfref_nav *nav);
+void      *pfref_nav_private(pfref_nav *nav);   /* the struct nav_private* */
+int        pfref_nav_width(const pfref_nav *nav);
+int        pfref_nav_height(const pfref_nav *nav);
+
+/* Replace the blockers plane of one layer ([h][w][64][64] u16) and relabel
+ * local islands with the reference's n_update_local_island_field. */
+void pfref_nav_set_blockers(pfref_nav *nav, int layer, const uint16_t *blockers);
+/* N_BlockersIncref / N_BlockersDecref (nav.c:4663,4685) + N_Update-equivalent
+ * relabel of dirty local islands (nav.c:996). */
+void pfref_nav_blockers_circle(pfref_nav *nav, float x, float z, float range, int faction_id,
+                               uint32_t flags, int incref);
+void pfref_nav_flush_dirty(pfref_nav *nav);
+
+/* plane: 0 cost_base(u8) 1 blockers(u16) 2 islands(u16) 3 local_islands(u16)
+ *        4 factions (u8, [chunk][15][64][64]).  Layout [h][w][64][64]. */
+size_t pfref_nav_copy_plane(const pfref_nav *nav, int layer, int plane, void *out);
+
+int  pfref_nav_num_portals(const pfref_nav *nav, int layer, int chunk_r, int chunk_c);
+void pfref_nav_get_portal(const pfref_nav *nav, int layer, int chunk_r, int chunk_c, int idx,
+                          pfref_portal *out);
+
+/* --- flow fields -------------------------------------------------------- */
+
+/* N_FlowFieldInit (unless req->inout) + N_FlowFieldUpdate (field.c:2020,2030).
+ * inout_dirs: 4096 bytes, one dir_idx (0..8) per cell, row-major [64][64].
+ * out_integ (optional): the float integration field the reference computed
+ * for this call, captured by replaying N_FlowFieldUpdate's own sequence of
+ * static calls (field.c:2055-2077); INFINITY for unreached cells. */
+int pfref_field_update(pfref_nav *nav, const pfref_field_req *req,
+                       uint8_t *inout_dirs, float *out_integ);
+
+/* Time `reps` passes of N_FlowFieldInit+N_FlowFieldUpdate over `n` requests on
+ * `nthreads` pthreads (requests are independent; nav_private is read-only).
+ * Returns seconds of wall time (CLOCK_MONOTONIC). */
+double pfref_field_bench(pfref_nav *nav, const pfref_field_req *reqs, int n, int reps,
+                         int nthreads);
+
+/* --- planner trace ------------------------------------------------------ */
+
+/* n_request_path (nav.c:1774) from xz_src to xz_dst with the field cache
+ * cleared first when `clear_cache`; every N_FlowFieldUpdate call the planner
+ * makes is recorded.  Returns 1 when a path exists. */
+int    pfref_request_path(pfref_nav *nav, int layer, int faction_id,
+                          float src_x, float src_z, float dst_x, float dst_z,
+                          int clear_cache, uint32_t *out_dest_id);
+int    pfref_trace_count(void);
+void   pfref_trace_get(int idx, pfref_field_req *out_req, uint8_t *out_before, uint8_t *out_after);
+void   pfref_trace_clear(void);
+
+/* N_DesiredPointSeekVelocity (nav.c:3468): may call n_request_path on a miss. */
+void   pfref_desired_point_seek_velocity(pfref_nav *nav, uint32_t dest_id, float x, float z,
+                                         float dst_x, float dst_z, float out[2]);
+/* (dest,chunk) -> cached field (fieldcache.c): returns 1 and copies 4096 dirs */
+int    pfref_cached_field(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c,
+                          uint8_t *out_dirs);
+/* N_HasDestLOS (nav.c:4026) */
+int    pfref_has_dest_los(pfref_nav *nav, uint32_t dest_id, float x, float z, float dst_x, float dst_z);
+int    pfref_position_pathable(pfref_nav *nav, int layer, float x, float z);
+int    pfref_position_blocked(pfref_nav *nav, int layer, float x, float z);
+void   pfref_map_pos(const pfref_nav *nav, float out[3]);
+
+/* --- ClearPath ---------------------------------------------------------- */
+
+/* G_ClearPath_NewVelocity (clearpath.c:694).  ent/neighbours are
+ * `struct cp_ent` = {pos.x,pos.z,vel.x,vel.z,radius} (5 floats). */
+void pfref_clearpath_new_velocity(const float ent[5], const float des_v[2],
+                                  const float *dyn, int n_dyn,
+                                  const float *stat, int n_stat, float out[2]);
+
+/* --- spatial index ------------------------------------------------------ */
+
+/* bg_ent_init + inserts in index order + bg_ent_cleanup (position.c:283,
+ * bitmap_grid.h:1102,1477), then G_Pos_EntsInCircleFrom (position.c:379) for
+ * each query.  out_counts[q], out_ids[q*maxout + k]. */
+void pfref_spatial_query(float xmin, float xmax, float zmin, float zmax,
+                         const float *pos_xz, int n,
+                         const float *query_xz, int nq, float range, int maxout,
+                         int32_t *out_counts, uint32_t *out_ids);
+
+/* --- movement tick (velocity half + position accept) -------------------- */
+
+typedef struct pfref_move_world {
+    int            n;             /* agents; uid == index */
+    const float   *pos_xz;        /* [n][2]  */
+    const float   *vel_xz;        /* [n][2]  movestate.velocity */
+    const float   *radius;        /* [n]     selection radius   */
+    const float   *max_speed;     /* [n]     movestate.max_speed */
+    const float   *speed;         /* [n]     move_work_in.speed  */
+    const uint32_t*flags;         /* [n]     ENTITY_FLAG_*       */
+    const int32_t *state;         /* [n]     enum arrive_state   */
+    const int32_t *flock;         /* [n]     flock index or -1   */
+    const uint8_t *has_dest_los;  /* [n] */
+    int            n_flocks;
+    const float   *flock_target_xz; /* [n_flocks][2] */
+    const uint32_t*flock_dest_id;   /* [n_flocks]    */
+    int            hz;            /* 20/10/5/1 */
+} pfref_move_world;
+
+/* Drives movement.c's own static move_velocity_work (movement.c:3395) over
+ * agents [begin,end) after loading `world` into the movement module's
+ * snapshot tables, with ent_des_v taken from `vdes` (or, when vdes == NULL,
+ * from N_DesiredPointSeekVelocity).  out_vel[n][2], out_vpref optional. */
+int  pfref_move_load(pfref_nav *nav, const pfref_move_world *world);
+void pfref_move_velocity(const float *vdes, int begin, int end, float *out_vel);
+void pfref_move_unload(void);
+/* individual steering terms for unit tests (movement.c:1546,1653,1690,1870,2768) */
+void pfref_move_vpref(int uid, const float vdes[2], float out[2]);
+void pfref_move_forces(int uid, const float vdes[2], float out_arrive[2], float out_cohesion[2],
+                       float out_separation[2]);
+int  pfref_move_neighbours(int uid, float *out_dyn, int *n_dyn, float *out_stat, int *n_stat);
+double pfref_move_bench(const float *vdes, int begin, int end, int reps, int nthreads, float *out_vel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

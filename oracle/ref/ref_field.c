@@ -1,0 +1,204 @@
+/* oracle/ref/ref_field.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Pulls the reference's src/navigation/field.c into this translation unit
+ * (by #include, from where it lies under /root/reference/src; nothing is
+ * copied) so that the harness can (a) call N_FlowFieldInit/N_FlowFieldUpdate
+ * and (b) replay N_FlowFieldUpdate's own sequence of *static* helpers
+ * (field.c:2055-2077) to capture the float integration field, which the
+ * reference never exposes.
+ */
+#include "navigation/field.c"
+
+#include "pfref.h"
+#include "ref_internal.h"
+
+#include <pthread.h>
+#include <time.h>
+
+static const struct portal *find_portal(const struct nav_chunk *chunk,
+                                        int r0, int c0, int r1, int c1)
+{
+    for(size_t i = 0; i < chunk->num_portals; i++) {
+        const struct portal *p = &chunk->portals[i];
+        if(p->endpoints[0].r == r0 && p->endpoints[0].c == c0
+        && p->endpoints[1].r == r1 && p->endpoints[1].c == c1)
+            return p;
+    }
+    return NULL;
+}
+
+bool pfref_make_target(const struct nav_private *priv, const pfref_field_req *req,
+                       struct field_target *out)
+{
+    memset(out, 0, sizeof(*out));
+    if(req->type == TARGET_TILE) {
+        out->type = TARGET_TILE;
+        out->tile = (struct coord){req->tile_r, req->tile_c};
+        return true;
+    }
+    if(req->type != TARGET_PORTAL)
+        return false;
+
+    const struct nav_chunk *chunk =
+        &priv->chunks[req->layer][IDX(req->chunk_r, priv->width, req->chunk_c)];
+    const struct portal *port = find_portal(chunk, req->port_r0, req->port_c0,
+                                            req->port_r1, req->port_c1);
+    if(!port)
+        return false;
+    const struct portal *next = n_portal(priv, req->layer, port->connected);
+    if(!next)
+        return false;
+    if(next->chunk.r != req->next_chunk_r || next->chunk.c != req->next_chunk_c
+    || next->endpoints[0].r != req->next_r0 || next->endpoints[0].c != req->next_c0
+    || next->endpoints[1].r != req->next_r1 || next->endpoints[1].c != req->next_c1)
+        return false;
+
+    out->type = TARGET_PORTAL;
+    out->pd = (struct portal_desc){
+        .port = port, .port_iid = (uint16_t)req->port_iid,
+        .next = next, .next_iid = (uint16_t)req->next_iid,
+    };
+    return true;
+}
+
+void pfref_req_from_target(struct coord chunk, int faction_id, enum nav_layer layer,
+                           const struct field_target *t, pfref_field_req *out)
+{
+    memset(out, 0, sizeof(*out));
+    out->layer = layer;
+    out->type = t->type;
+    out->faction_id = faction_id;
+    out->chunk_r = chunk.r;
+    out->chunk_c = chunk.c;
+    if(t->type == TARGET_TILE) {
+        out->tile_r = t->tile.r;
+        out->tile_c = t->tile.c;
+    }else if(t->type == TARGET_PORTAL) {
+        out->port_r0 = t->pd.port->endpoints[0].r; out->port_c0 = t->pd.port->endpoints[0].c;
+        out->port_r1 = t->pd.port->endpoints[1].r; out->port_c1 = t->pd.port->endpoints[1].c;
+        out->next_chunk_r = t->pd.next->chunk.r;   out->next_chunk_c = t->pd.next->chunk.c;
+        out->next_r0 = t->pd.next->endpoints[0].r; out->next_c0 = t->pd.next->endpoints[0].c;
+        out->next_r1 = t->pd.next->endpoints[1].r; out->next_c1 = t->pd.next->endpoints[1].c;
+        out->port_iid = t->pd.port_iid;
+        out->next_iid = t->pd.next_iid;
+    }
+}
+
+void pfref_dirs_to_ff(const uint8_t *dirs, struct flow_field *ff)
+{
+    for(int r = 0; r < FIELD_RES_R; r++)
+    for(int c = 0; c < FIELD_RES_C; c++)
+        ff->field[r][c].dir_idx = dirs[r * FIELD_RES_C + c] & 0xf;
+}
+
+void pfref_ff_to_dirs(const struct flow_field *ff, uint8_t *dirs)
+{
+    for(int r = 0; r < FIELD_RES_R; r++)
+    for(int c = 0; c < FIELD_RES_C; c++)
+        dirs[r * FIELD_RES_C + c] = ff->field[r][c].dir_idx;
+}
+
+int pfref_field_update(pfref_nav *nav, const pfref_field_req *req,
+                       uint8_t *inout_dirs, float *out_integ)
+{
+    const struct nav_private *priv = pfref_nav_private(nav);
+    struct field_target target;
+    if(!pfref_make_target(priv, req, &target))
+        return -1;
+
+    struct coord chunk_coord = {req->chunk_r, req->chunk_c};
+    struct flow_field ff;
+    memset(&ff, 0, sizeof(ff));
+    if(req->inout) {
+        pfref_dirs_to_ff(inout_dirs, &ff);
+        ff.chunk = chunk_coord;
+    }else{
+        N_FlowFieldInit(chunk_coord, &ff);
+    }
+    N_FlowFieldUpdate(chunk_coord, priv, req->faction_id, req->layer, target,
+                      priv->unit_query_ctx, &ff);
+    pfref_ff_to_dirs(&ff, inout_dirs);
+
+    if(out_integ) {
+        /* replay of field.c:2055-2077 with the reference's own static helpers */
+        const struct nav_chunk *chunk =
+            &priv->chunks[req->layer][IDX(chunk_coord.r, priv->width, chunk_coord.c)];
+        pq_coord_t frontier;
+        pq_coord_init(&frontier);
+
+        float (*integ)[FIELD_RES_C] = (float(*)[FIELD_RES_C])out_integ;
+        for(int r = 0; r < FIELD_RES_R; r++)
+        for(int c = 0; c < FIELD_RES_C; c++)
+            integ[r][c] = INFINITY;
+
+        static __thread struct coord init_frontier[FIELD_RES_R * FIELD_RES_C];
+        size_t ninit = field_initial_frontier(req->layer, target, chunk, priv, false,
+            req->faction_id, priv->unit_query_ctx, init_frontier, ARR_SIZE(init_frontier));
+        for(size_t i = 0; i < ninit; i++) {
+            struct coord curr = init_frontier[i];
+            pq_coord_push(&frontier, 0.0f, curr);
+            integ[curr.r][curr.c] = 0.0f;
+        }
+        field_build_integration(&frontier, chunk, req->faction_id, priv->unit_query_ctx, integ);
+        pq_coord_destroy(&frontier);
+    }
+    return 0;
+}
+
+struct bench_arg{
+    const struct nav_private *priv;
+    const pfref_field_req    *reqs;
+    struct field_target      *targets;
+    int                       begin, end, reps;
+    unsigned                  sink;
+};
+
+static void *bench_thread(void *p)
+{
+    struct bench_arg *a = p;
+    unsigned sink = 0;
+    for(int rep = 0; rep < a->reps; rep++) {
+        for(int i = a->begin; i < a->end; i++) {
+            const pfref_field_req *req = &a->reqs[i];
+            struct coord chunk_coord = {req->chunk_r, req->chunk_c};
+            struct flow_field ff;
+            N_FlowFieldInit(chunk_coord, &ff);
+            N_FlowFieldUpdate(chunk_coord, a->priv, req->faction_id, req->layer, a->targets[i],
+                              a->priv->unit_query_ctx, &ff);
+            sink += ff.field[rep & 63][i & 63].dir_idx;
+        }
+    }
+    a->sink = sink;
+    return NULL;
+}
+
+double pfref_field_bench(pfref_nav *nav, const pfref_field_req *reqs, int n, int reps,
+                         int nthreads)
+{
+    const struct nav_private *priv = pfref_nav_private(nav);
+    struct field_target *targets = malloc(sizeof(struct field_target) * (size_t)n);
+    for(int i = 0; i < n; i++) {
+        if(!pfref_make_target(priv, &reqs[i], &targets[i])) {
+            free(targets);
+            return -1.0;
+        }
+    }
+    if(nthreads < 1) nthreads = 1;
+    if(nthreads > 256) nthreads = 256;
+    pthread_t tids[256];
+    struct bench_arg args[256];
+
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for(int t = 0; t < nthreads; t++) {
+        args[t] = (struct bench_arg){priv, reqs, targets,
+            (int)((long)n * t / nthreads), (int)((long)n * (t + 1) / nthreads), reps, 0};
+        pthread_create(&tids[t], NULL, bench_thread, &args[t]);
+    }
+    for(int t = 0; t < nthreads; t++)
+        pthread_join(tids[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+
+    free(targets);
+    return (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+}

@@ -1,0 +1,287 @@
+/* oracle/ref/ref_nav.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Pulls the reference's src/navigation/nav.c into this translation unit (by
+ * #include from /root/reference/src; nothing is copied) so the harness can
+ * reach its static planner and map-preprocessing functions:
+ *   n_update_portals (nav.c:1710), n_update_island_field (:1731),
+ *   n_update_local_island_field (:986), n_update_dirty_local_islands (:996),
+ *   n_update_blockers (:1017), n_request_path (:1774).
+ * Every call nav.c makes to N_FlowFieldUpdate is routed through a recorder
+ * so that the planner's chunk-field request stream can be replayed against
+ * the HIP path.
+ */
+#define N_FlowFieldUpdate pfref_traced_N_FlowFieldUpdate
+#include "navigation/nav.c"
+#undef N_FlowFieldUpdate
+
+#include "pfref.h"
+#include "ref_internal.h"
+
+void N_FlowFieldUpdate(struct coord chunk_coord, const struct nav_private *priv, int faction_id,
+                       enum nav_layer layer, struct field_target target,
+                       struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow);
+
+/* ------------------------------------------------------------------------ */
+/* planner trace                                                            */
+/* ------------------------------------------------------------------------ */
+
+struct trace_rec{
+    pfref_field_req req;
+    uint8_t         before[FIELD_RES_R * FIELD_RES_C];
+    uint8_t         after[FIELD_RES_R * FIELD_RES_C];
+};
+
+static struct trace_rec *s_trace;
+static int               s_trace_n, s_trace_cap;
+static bool              s_trace_on;
+
+void pfref_traced_N_FlowFieldUpdate(struct coord chunk_coord, const struct nav_private *priv,
+                                    int faction_id, enum nav_layer layer,
+                                    struct field_target target,
+                                    struct nav_unit_query_ctx *ctx,
+                                    struct flow_field *inout_flow)
+{
+    bool rec = s_trace_on && (target.type == TARGET_TILE || target.type == TARGET_PORTAL);
+    struct trace_rec *tr = NULL;
+    if(rec) {
+        if(s_trace_n == s_trace_cap) {
+            s_trace_cap = s_trace_cap ? s_trace_cap * 2 : 256;
+            s_trace = realloc(s_trace, sizeof(struct trace_rec) * s_trace_cap);
+        }
+        tr = &s_trace[s_trace_n++];
+        pfref_req_from_target(chunk_coord, faction_id, layer, &target, &tr->req);
+        pfref_ff_to_dirs(inout_flow, tr->before);
+        bool any = false;
+        for(int i = 0; i < FIELD_RES_R * FIELD_RES_C; i++)
+            any |= (tr->before[i] != FD_NONE);
+        tr->req.inout = any;
+    }
+    N_FlowFieldUpdate(chunk_coord, priv, faction_id, layer, target, ctx, inout_flow);
+    if(rec) {
+        /* realloc may have moved the buffer only before this call; tr is still valid */
+        pfref_ff_to_dirs(inout_flow, tr->after);
+    }
+}
+
+int  pfref_trace_count(void) { return s_trace_n; }
+void pfref_trace_clear(void) { s_trace_n = 0; }
+void pfref_trace_get(int idx, pfref_field_req *out_req, uint8_t *out_before, uint8_t *out_after)
+{
+    *out_req = s_trace[idx].req;
+    if(out_before) memcpy(out_before, s_trace[idx].before, sizeof(s_trace[idx].before));
+    if(out_after)  memcpy(out_after,  s_trace[idx].after,  sizeof(s_trace[idx].after));
+}
+
+/* ------------------------------------------------------------------------ */
+/* context                                                                  */
+/* ------------------------------------------------------------------------ */
+
+static bool s_nav_inited;
+
+pfref_nav *pfref_nav_create(int w, int h, const uint8_t *cost_base, unsigned layer_mask)
+{
+    if(!s_nav_inited) {
+        if(!N_Init())
+            return NULL;
+        s_nav_inited = true;
+    }
+    pfref_nav *nav = calloc(1, sizeof(*nav));
+    if(!nav || !N_InitCtx(&nav->priv))
+        return NULL;
+    N_FC_ClearAll(nav->priv.fieldcache);
+
+    nav->priv.width = w;
+    nav->priv.height = h;
+    nav->layer_mask = layer_mask;
+    /* the engine centres the map on the origin (X grows to the left, tile.c:565) */
+    nav->map_pos = (vec3_t){
+        (w * TILES_PER_CHUNK_WIDTH  * X_COORDS_PER_TILE) / 2.0f, 0.0f,
+       -(h * TILES_PER_CHUNK_HEIGHT * Z_COORDS_PER_TILE) / 2.0f};
+
+    size_t nchunks = (size_t)w * h;
+    for(int layer = 0; layer < NAV_LAYER_MAX; layer++) {
+        if(!(layer_mask & (1u << layer)))
+            continue;
+        struct nav_chunk *chunks = calloc(nchunks, sizeof(struct nav_chunk));
+        if(!chunks)
+            return NULL;
+        nav->priv.chunks[layer] = chunks;
+        for(size_t i = 0; i < nchunks; i++) {
+            memcpy(chunks[i].cost_base, cost_base + i * FIELD_RES_R * FIELD_RES_C,
+                   FIELD_RES_R * FIELD_RES_C);
+        }
+        /* nav.c:2340-2343 minus the tile-derived cliff edges */
+        n_update_portals(&nav->priv, layer);
+        n_update_island_field(&nav->priv, layer);
+        n_update_local_island_field(&nav->priv, layer);
+    }
+    return nav;
+}
+
+void pfref_nav_destroy(pfref_nav *nav)
+{
+    if(!nav) return;
+    N_FC_ClearAll(nav->priv.fieldcache);
+    for(int layer = 0; layer < NAV_LAYER_MAX; layer++)
+        free(nav->priv.chunks[layer]);
+    N_DestroyCtx(&nav->priv);
+    free(nav);
+}
+
+void *pfref_nav_private(pfref_nav *nav)     { return &nav->priv; }
+int   pfref_nav_width(const pfref_nav *nav) { return (int)nav->priv.width; }
+int   pfref_nav_height(const pfref_nav *nav){ return (int)nav->priv.height; }
+void  pfref_map_pos(const pfref_nav *nav, float out[3])
+{
+    out[0] = nav->map_pos.x; out[1] = nav->map_pos.y; out[2] = nav->map_pos.z;
+}
+
+void pfref_nav_set_blockers(pfref_nav *nav, int layer, const uint16_t *blockers)
+{
+    struct nav_private *priv = &nav->priv;
+    size_t nchunks = priv->width * priv->height;
+    for(size_t i = 0; i < nchunks; i++) {
+        memcpy(priv->chunks[layer][i].blockers, blockers + i * FIELD_RES_R * FIELD_RES_C,
+               sizeof(priv->chunks[layer][i].blockers));
+    }
+    n_update_local_island_field(priv, layer);
+    n_update_all_edge_states(priv, layer);
+    N_FC_ClearAll(priv->fieldcache);
+}
+
+void pfref_nav_blockers_circle(pfref_nav *nav, float x, float z, float range, int faction_id,
+                               uint32_t flags, int incref)
+{
+    struct nav_private *priv = &nav->priv;
+    vec2_t xz = (vec2_t){x, z};
+    const unsigned ground = 0xfu, water = 0xf0u;
+    if(!(flags & ENTITY_FLAG_AIR)
+    && (nav->layer_mask & (ground | water)) == (ground | water)) {
+        if(incref) N_BlockersIncref(xz, range, faction_id, flags, nav->map_pos, priv);
+        else       N_BlockersDecref(xz, range, faction_id, flags, nav->map_pos, priv);
+        return;
+    }
+    /* only GROUND_1X1 is allocated: first statement pair of
+     * n_update_blockers_circle_ground (nav.c:1051-1055) */
+    struct tile_desc tds[1024];
+    int ntds = M_Tile_AllUnderCircle(n_res(priv), xz, range, nav->map_pos, tds, ARR_SIZE(tds));
+    n_update_blockers(priv, NAV_LAYER_GROUND_1X1, faction_id, tds, ntds, incref ? +1 : -1);
+}
+
+void pfref_nav_flush_dirty(pfref_nav *nav)
+{
+    struct nav_private *priv = &nav->priv;
+    for(int layer = 0; layer < NAV_LAYER_MAX; layer++) {
+        if(!(nav->layer_mask & (1u << layer)))
+            continue;
+        n_update_dirty_local_islands(priv, layer);
+        n_update_all_edge_states(priv, layer);
+        kh_clear(coord, priv->dirty_chunks[layer]);
+    }
+    N_FC_ClearAll(priv->fieldcache);
+}
+
+size_t pfref_nav_copy_plane(const pfref_nav *nav, int layer, int plane, void *out)
+{
+    const struct nav_private *priv = &nav->priv;
+    size_t nchunks = priv->width * priv->height;
+    const size_t cells = FIELD_RES_R * FIELD_RES_C;
+    size_t elem = (plane == 0) ? 1 : (plane == 4) ? MAX_FACTIONS : 2;
+    if(!out)
+        return nchunks * cells * elem;
+    for(size_t i = 0; i < nchunks; i++) {
+        const struct nav_chunk *ch = &priv->chunks[layer][i];
+        char *dst = (char*)out + i * cells * elem;
+        switch(plane) {
+        case 0: memcpy(dst, ch->cost_base,     cells);      break;
+        case 1: memcpy(dst, ch->blockers,      cells * 2);  break;
+        case 2: memcpy(dst, ch->islands,       cells * 2);  break;
+        case 3: memcpy(dst, ch->local_islands, cells * 2);  break;
+        case 4: memcpy(dst, ch->factions,      cells * MAX_FACTIONS); break;
+        default: return 0;
+        }
+    }
+    return nchunks * cells * elem;
+}
+
+int pfref_nav_num_portals(const pfref_nav *nav, int layer, int chunk_r, int chunk_c)
+{
+    const struct nav_private *priv = &nav->priv;
+    return (int)priv->chunks[layer][IDX(chunk_r, priv->width, chunk_c)].num_portals;
+}
+
+void pfref_nav_get_portal(const pfref_nav *nav, int layer, int chunk_r, int chunk_c, int idx,
+                          pfref_portal *out)
+{
+    const struct nav_private *priv = &nav->priv;
+    const struct portal *p = &priv->chunks[layer][IDX(chunk_r, priv->width, chunk_c)].portals[idx];
+    const struct portal *c = n_portal(priv, layer, p->connected);
+    *out = (pfref_portal){
+        p->chunk.r, p->chunk.c,
+        p->endpoints[0].r, p->endpoints[0].c, p->endpoints[1].r, p->endpoints[1].c,
+        c->chunk.r, c->chunk.c,
+        c->endpoints[0].r, c->endpoints[0].c, c->endpoints[1].r, c->endpoints[1].c,
+        p->component_id
+    };
+}
+
+/* ------------------------------------------------------------------------ */
+/* planner / sampling                                                       */
+/* ------------------------------------------------------------------------ */
+
+int pfref_request_path(pfref_nav *nav, int layer, int faction_id,
+                       float src_x, float src_z, float dst_x, float dst_z,
+                       int clear_cache, uint32_t *out_dest_id)
+{
+    struct nav_private *priv = &nav->priv;
+    if(clear_cache)
+        N_FC_ClearAll(priv->fieldcache);
+    dest_id_t id = 0;
+    s_trace_on = true;
+    bool ok = n_request_path(priv, (vec2_t){src_x, src_z}, (vec2_t){dst_x, dst_z}, faction_id,
+                             nav->map_pos, layer, &id);
+    s_trace_on = false;
+    if(out_dest_id)
+        *out_dest_id = id;
+    return ok;
+}
+
+void pfref_desired_point_seek_velocity(pfref_nav *nav, uint32_t dest_id, float x, float z,
+                                       float dst_x, float dst_z, float out[2])
+{
+    s_trace_on = true;
+    vec2_t v = N_DesiredPointSeekVelocity(dest_id, (vec2_t){x, z}, (vec2_t){dst_x, dst_z},
+                                          &nav->priv, nav->map_pos);
+    s_trace_on = false;
+    out[0] = v.x;
+    out[1] = v.z;
+}
+
+int pfref_cached_field(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c,
+                       uint8_t *out_dirs)
+{
+    struct nav_private *priv = &nav->priv;
+    ff_id_t ffid;
+    if(!N_FC_GetDestFFMapping(priv->fieldcache, dest_id, (struct coord){chunk_r, chunk_c}, &ffid))
+        return 0;
+    const struct flow_field *ff = N_FC_FlowFieldAt(priv->fieldcache, ffid);
+    if(!ff)
+        return 0;
+    pfref_ff_to_dirs(ff, out_dirs);
+    return 1;
+}
+
+int pfref_has_dest_los(pfref_nav *nav, uint32_t dest_id, float x, float z, float dst_x, float dst_z)
+{
+    return N_HasDestLOS(dest_id, (vec2_t){x, z}, &nav->priv, nav->map_pos, (vec2_t){dst_x, dst_z});
+}
+
+int pfref_position_pathable(pfref_nav *nav, int layer, float x, float z)
+{
+    return N_PositionPathable((vec2_t){x, z}, layer, &nav->priv, nav->map_pos);
+}
+
+int pfref_position_blocked(pfref_nav *nav, int layer, float x, float z)
+{
+    return N_PositionBlocked((vec2_t){x, z}, layer, &nav->priv, nav->map_pos);
+}
