@@ -1,0 +1,59 @@
+// navhip_internal.h -- shared by the HIP translation units of libnavhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "navhip.h"
+
+static_assert(sizeof(navhip_field_req) == 32, "navhip_field_req must stay 32 bytes");
+
+#define NH_CELLS   4096
+#define NH_RES     64
+#define NH_INF_U32 0x3fffffffu      /* "unreached" integration value (float INFINITY on output) */
+
+struct navhip_layer {
+    uint8_t  *cost;            // [nchunks][64][64]
+    uint16_t *blockers;        // [nchunks][64][64]
+    uint16_t *local_islands;   // [nchunks][64][64]
+    uint8_t  *factions;        // [nchunks][15][64][64]
+    // derived (rebuilt lazily for dirty chunks):
+    uint64_t *passmask;        // [nchunks][64]  bit c of word r = cell (r,c) passable, faction NONE
+                               //                (field_tile_passable, field.c:117)
+    uint8_t  *unit_cost;       // [nchunks]      1 when every cost != 0xff cell has cost 1
+    uint8_t  *dirty;           // host side: [nchunks] derived state stale
+    bool      any_dirty;
+};
+
+struct navhip_ctx {
+    int          device;
+    int          w, h, nchunks;
+    hipStream_t  stream;
+    navhip_layer layers[NAVHIP_NAV_LAYER_MAX];
+    int          field_kernel_mode;
+    // scratch for the host-buffer entry points
+    void        *d_reqs;      size_t d_reqs_cap;
+    uint8_t     *d_dirs;      size_t d_dirs_cap;
+    float       *d_integ;     size_t d_integ_cap;
+    uint64_t    *d_reqmask;   size_t d_reqmask_cap;   // per-request passability rows
+    uint32_t    *d_dirty_list; size_t d_dirty_cap;
+    std::string  last_error;
+};
+
+// launched by navhip_api.hip
+void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, int n,
+                      hipStream_t s);
+void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, uint8_t *d_dirs,
+                      float *d_integ, hipStream_t s);
+
+struct nh_layer_view {
+    const uint8_t  *cost;
+    const uint16_t *blockers;
+    const uint16_t *local_islands;
+    const uint8_t  *factions;
+    const uint64_t *passmask;
+    const uint8_t  *unit_cost;
+};
+struct nh_map_view {
+    int w, h;
+    nh_layer_view layers[NAVHIP_NAV_LAYER_MAX];
+};

@@ -1,0 +1,188 @@
+"""Host-side mirror of the reference's navigation interface over the C ABI of libnavhip.so.
+
+The product boundary is the C ABI (include/navhip.h); this module only loads it with ctypes
+and gives the entry points the names / argument meaning of the reference functions they stand
+in for (N_FlowFieldInit / N_FlowFieldUpdate / N_FlowFieldID, field.c:2020,2030,1952; the
+packed plane uploads of nav.c:2408-2490), so parity tests read like calls into the reference.
+PyTorch is used for device buffers / streams only (see `dev_ptr`).
+
+There is NO CPU fallback: if libnavhip.so is missing or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnavhip.so")
+
+OK = 0
+FIELD_RES = 64
+FIELD_CELLS = 4096
+COST_IMPASSABLE = 0xFF
+ISLAND_NONE = 0xFFFF
+FACTION_ID_NONE = 0xF
+TARGET_PORTAL, TARGET_TILE = 0, 1
+PLANE_COST_BASE, PLANE_BLOCKERS, PLANE_LOCAL_ISLANDS, PLANE_FACTIONS = 0, 1, 2, 3
+REQ_INOUT = 0x1
+FD_NONE, FD_NW, FD_N, FD_NE, FD_W, FD_E, FD_SW, FD_S, FD_SE = range(9)
+
+# navhip_field_req, include/navhip.h (32 bytes)
+FIELD_REQ_DTYPE = np.dtype([
+    ("layer", np.uint8), ("type", np.uint8), ("faction_id", np.uint8), ("flags", np.uint8),
+    ("enemies", np.uint16), ("chunk_r", np.uint16), ("chunk_c", np.uint16),
+    ("tile_r", np.uint8), ("tile_c", np.uint8),
+    ("port_r0", np.uint8), ("port_c0", np.uint8), ("port_r1", np.uint8), ("port_c1", np.uint8),
+    ("next_r0", np.uint8), ("next_c0", np.uint8), ("next_r1", np.uint8), ("next_c1", np.uint8),
+    ("next_chunk_r", np.uint16), ("next_chunk_c", np.uint16),
+    ("port_iid", np.uint16), ("next_iid", np.uint16), ("_pad", np.uint16, (2,)),
+], align=False)
+assert FIELD_REQ_DTYPE.itemsize == 32
+
+# exported symbols, checked by the CPU test-suite against include/navhip.h
+_SIGS = {
+    "navhip_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "navhip_ctx_destroy": (None, [C.c_void_p]),
+    "navhip_last_error": (C.c_char_p, [C.c_void_p]),
+    "navhip_device": (C.c_int, [C.c_void_p]),
+    "navhip_stream": (C.c_void_p, [C.c_void_p]),
+    "navhip_sync": (C.c_int, [C.c_void_p]),
+    "navhip_upload_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "navhip_upload_chunk": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_size_t]),
+    "navhip_plane_dev": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "navhip_build_fields": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "navhip_build_fields_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "navhip_flow_field_id": (C.c_uint64, [C.c_void_p]),
+    "navhip_set_field_kernel": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+class NavHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libnavhip.so (built in-tree by build.py).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NavHipError("libnavhip.so not built (run __graft_entry__.build()); "
+                              "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (rt, at) in _SIGS.items():
+            f = getattr(L, name)
+            f.restype = rt
+            f.argtypes = at
+        _lib = L
+    return _lib
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def dev_ptr(t):
+    """torch CUDA tensor -> void* for the *_dev entry points."""
+    return C.c_void_p(t.data_ptr())
+
+
+def make_reqs(n):
+    r = np.zeros(n, FIELD_REQ_DTYPE)
+    r["faction_id"] = FACTION_ID_NONE
+    return r
+
+
+def reqs_from_ref(ref_reqs):
+    """oracle FieldReq records (int32 fields) -> navhip_field_req records."""
+    out = make_reqs(len(ref_reqs))
+    for name in ("layer", "type", "faction_id", "chunk_r", "chunk_c", "tile_r", "tile_c",
+                 "port_r0", "port_c0", "port_r1", "port_c1", "next_r0", "next_c0", "next_r1",
+                 "next_c1", "next_chunk_r", "next_chunk_c", "port_iid", "next_iid"):
+        out[name] = ref_reqs[name]
+    out["flags"] = np.where(ref_reqs["inout"] != 0, REQ_INOUT, 0)
+    return out
+
+
+class NavContext:
+    """Device-resident navigation state of one map: the GPU counterpart of the planes of
+    `struct nav_private` (nav_private.h:52) that the hot path reads."""
+
+    def __init__(self, chunk_w, chunk_h, device=0):
+        self._h = C.c_void_p()
+        rc = lib().navhip_ctx_create(C.byref(self._h), chunk_w, chunk_h, device)
+        if rc != OK:
+            self._h = None
+            raise NavHipError("navhip_ctx_create failed (%d): no MI355X visible?" % rc)
+        self.w, self.h, self.device = chunk_w, chunk_h, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().navhip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != OK:
+            msg = lib().navhip_last_error(self._h)
+            raise NavHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    @property
+    def stream(self):
+        return lib().navhip_stream(self._h)
+
+    def sync(self):
+        self._chk(lib().navhip_sync(self._h), "navhip_sync")
+
+    # -- map state (N_CopyCostBasePacked / N_CopyBlockersPacked layouts, nav.c:2432,2470) ------
+    def upload_plane(self, layer, plane, array):
+        dt = np.uint8 if plane in (PLANE_COST_BASE, PLANE_FACTIONS) else np.uint16
+        a = np.ascontiguousarray(array, dtype=dt)
+        self._chk(lib().navhip_upload_plane(self._h, layer, plane, _hp(a), a.nbytes),
+                  "navhip_upload_plane")
+
+    def upload_chunk(self, layer, plane, chunk_r, chunk_c, array):
+        dt = np.uint8 if plane in (PLANE_COST_BASE, PLANE_FACTIONS) else np.uint16
+        a = np.ascontiguousarray(array, dtype=dt)
+        self._chk(lib().navhip_upload_chunk(self._h, layer, plane, chunk_r, chunk_c, _hp(a),
+                                            a.nbytes), "navhip_upload_chunk")
+
+    def set_field_kernel(self, mode):
+        self._chk(lib().navhip_set_field_kernel(self._h, mode), "navhip_set_field_kernel")
+
+    # -- flow fields ----------------------------------------------------------------------------
+    def N_FlowFieldUpdate(self, reqs, inout=None, want_integ=False):
+        """Batched N_FlowFieldInit + N_FlowFieldUpdate (field.c:2020,2030) through host buffers.
+        reqs: FIELD_REQ_DTYPE array.  inout: [n,64,64] u8 existing fields (rows used only for
+        requests flagged REQ_INOUT).  Returns (dirs [n,64,64] u8, integ [n,64,64] f32 | None)."""
+        reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)
+        n = len(reqs)
+        dirs = np.zeros((n, 64, 64), np.uint8)
+        if inout is not None:
+            dirs[...] = np.asarray(inout, np.uint8).reshape(n, 64, 64)
+        integ = np.zeros((n, 64, 64), np.float32) if want_integ else None
+        self._chk(lib().navhip_build_fields(self._h, _hp(reqs), n, _hp(dirs),
+                                            _hp(integ) if want_integ else None),
+                  "navhip_build_fields")
+        return dirs, integ
+
+    def build_fields_dev(self, d_reqs, n, d_dirs, d_integ=None, stream=None):
+        """Everything resident in HBM (torch tensors); asynchronous on `stream`."""
+        self._chk(lib().navhip_build_fields_dev(
+            self._h, dev_ptr(d_reqs), n, dev_ptr(d_dirs),
+            dev_ptr(d_integ) if d_integ is not None else None,
+            C.c_void_p(stream) if stream else None), "navhip_build_fields_dev")
+
+
+def N_FlowFieldID(req):
+    """N_FlowFieldID (field.c:1952) for one navhip_field_req record."""
+    r = np.ascontiguousarray(np.asarray(req, dtype=FIELD_REQ_DTYPE).reshape(1))
+    return int(lib().navhip_flow_field_id(_hp(r)))

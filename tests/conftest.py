@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def navlib():
+    """libnavhip.so, built on demand (hipcc cross-compiles without a GPU)."""
+    import __graft_entry__ as ge
+    ge.build_navhip()
+    from permafrost_engine_amd import navhip
+    return navhip

@@ -1,0 +1,53 @@
+"""GPU parity: HIP chunk-field build (through the C ABI) vs the reference's own
+N_FlowFieldUpdate (oracle/_ref).  Bit-exact flow directions AND integration values."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(navlib, grid, nav, reqs, before, mode, blockers=None):
+    exp_dirs, exp_integ = cases.ref_fields(nav, reqs, before)
+    ctx = navlib.NavContext(nav.w, nav.h)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(0))
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(1))
+    ctx.upload_plane(0, navlib.PLANE_LOCAL_ISLANDS, nav.plane(3))
+    ctx.set_field_kernel(mode)
+    hreqs = navlib.reqs_from_ref(reqs)
+    dirs, integ = ctx.N_FlowFieldUpdate(hreqs, inout=before, want_integ=True)
+    bad = np.argwhere((dirs != exp_dirs).reshape(len(reqs), -1).any(1)).ravel()
+    assert bad.size == 0, "flow dirs differ for requests %s (first: %s)" % (bad[:8], reqs[bad[0]])
+    assert np.array_equal(integ, exp_integ), "integration field differs"
+    # and without the integration output (other template instance of the BFS kernel)
+    dirs2, _ = ctx.N_FlowFieldUpdate(hreqs, inout=before, want_integ=False)
+    assert np.array_equal(dirs2, exp_dirs)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tile_fields_match_reference(navlib, mode):
+    grid, nav = cases.ref_nav_for(2, 2, seed=11)
+    reqs = cases.tile_requests(grid, 48, seed=5)
+    _check(navlib, grid, nav, reqs, None, mode)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_planner_request_stream_matches_reference(navlib, mode):
+    grid, nav = cases.ref_nav_for(4, 4, seed=1234)
+    reqs, before, after = cases.planner_requests(nav, grid, pairs=24, seed=9)
+    assert (reqs["type"] == 0).sum() > 20
+    _check(navlib, grid, nav, reqs, before, mode)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fields_with_blockers(navlib, mode):
+    grid = cases.synth.cost_grid(3, 3, seed=77)
+    blk = cases.random_blockers(grid, seed=3)
+    grid, nav = cases.ref_nav_for(3, 3, seed=77, blockers=blk)
+    reqs_t = cases.tile_requests(grid, 24, seed=6)
+    reqs_p, before, _ = cases.planner_requests(nav, grid, pairs=16, seed=10)
+    reqs = np.concatenate([reqs_t, reqs_p])
+    before = np.concatenate([np.zeros((len(reqs_t), 64, 64), np.uint8), before])
+    _check(navlib, grid, nav, reqs, before, mode)
