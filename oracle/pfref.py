@@ -260,3 +260,75 @@ def spatial_query(bounds, pos_xz, query_xz, rng, maxout):
     lib().pfref_spatial_query(bounds[0], bounds[1], bounds[2], bounds[3], _p(pos_xz), len(pos_xz),
                               _p(query_xz), len(query_xz), rng, maxout, _p(counts), _p(ids))
     return counts, ids
+
+
+STATE_MOVING, STATE_MOVING_IN_FORMATION, STATE_ARRIVED, STATE_SEEK_ENEMIES, STATE_WAITING, \
+    STATE_SURROUND_ENTITY, STATE_ENTER_ENTITY_RANGE, STATE_TURNING, STATE_ARRIVING_TO_CELL = range(9)
+ENTITY_FLAG_MOVABLE = 1 << 3
+ENTITY_FLAG_AIR = 1 << 15
+ENTITY_FLAG_GARRISONED = 1 << 18
+ENTITY_FLAG_COMBAT_HELD = 1 << 21
+
+
+class RefMove:
+    """movement.c's static velocity pipeline loaded with an explicit world snapshot."""
+
+    def __init__(self, nav, pos, vel, radius, max_speed, speed, flags, state, flock,
+                 has_dest_los, flock_target_xz, flock_dest_id, hz=20):
+        n = len(pos)
+        self.n = n
+        self._keep = dict(
+            pos=np.ascontiguousarray(pos, np.float32).reshape(n, 2),
+            vel=np.ascontiguousarray(vel, np.float32).reshape(n, 2),
+            radius=np.ascontiguousarray(radius, np.float32),
+            max_speed=np.ascontiguousarray(max_speed, np.float32),
+            speed=np.ascontiguousarray(speed, np.float32),
+            flags=np.ascontiguousarray(flags, np.uint32),
+            state=np.ascontiguousarray(state, np.int32),
+            flock=np.ascontiguousarray(flock, np.int32),
+            los=np.ascontiguousarray(has_dest_los, np.uint8),
+            ftgt=np.ascontiguousarray(flock_target_xz, np.float32).reshape(-1, 2),
+            fdest=np.ascontiguousarray(flock_dest_id, np.uint32))
+        k = self._keep
+        w = MoveWorld(n, _p(k["pos"]).value, _p(k["vel"]).value, _p(k["radius"]).value,
+                      _p(k["max_speed"]).value, _p(k["speed"]).value, _p(k["flags"]).value,
+                      _p(k["state"]).value, _p(k["flock"]).value, _p(k["los"]).value,
+                      len(k["fdest"]), _p(k["ftgt"]).value, _p(k["fdest"]).value, hz)
+        self.nav = nav
+        lib().pfref_move_load(nav._h, C.byref(w))
+
+    def velocity(self, vdes=None, begin=0, end=None):
+        end = self.n if end is None else end
+        out = np.zeros((self.n, 2), np.float32)
+        v = None if vdes is None else np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
+        lib().pfref_move_velocity(_p(v) if v is not None else None, begin, end, _p(out))
+        return out
+
+    def bench(self, vdes, reps=1, nthreads=1, begin=0, end=None):
+        end = self.n if end is None else end
+        v = np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
+        out = np.zeros((self.n, 2), np.float32)
+        return lib().pfref_move_bench(_p(v), begin, end, reps, nthreads, _p(out)), out
+
+    def vpref(self, uid, vdes):
+        out = np.zeros(2, np.float32)
+        v = np.ascontiguousarray(vdes, np.float32)
+        lib().pfref_move_vpref(uid, _p(v), _p(out))
+        return out
+
+    def forces(self, uid, vdes):
+        a, c, s = (np.zeros(2, np.float32) for _ in range(3))
+        v = np.ascontiguousarray(vdes, np.float32)
+        lib().pfref_move_forces(uid, _p(v), _p(a), _p(c), _p(s))
+        return a, c, s
+
+    def neighbours(self, uid):
+        dyn = np.zeros((32, 5), np.float32)
+        stat = np.zeros((32, 5), np.float32)
+        nd, ns = C.c_int(0), C.c_int(0)
+        lib().pfref_move_neighbours(uid, _p(dyn), C.byref(nd), _p(stat), C.byref(ns))
+        return dyn[:nd.value].copy(), stat[:ns.value].copy()
+
+    @staticmethod
+    def unload():
+        lib().pfref_move_unload()

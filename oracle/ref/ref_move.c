@@ -1,0 +1,336 @@
+/* oracle/ref/ref_move.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Pulls the reference's src/game/movement.c into this translation unit (by #include from
+ * /root/reference/src; nothing is copied) so the harness can drive its *static* per-agent
+ * velocity pipeline: move_velocity_work (movement.c:3395) -> point_seek_vpref (:1870) ->
+ * arrive/cohesion/separation forces (:1546,:1653,:1690), nullify_impass_components (:1831),
+ * find_neighbours (:2768) -> G_ClearPath_NewVelocity (clearpath.c:694) -> vec2_truncate.
+ *
+ * The engine services movement.c reads its snapshot through (flags / radius / faction table
+ * getters, the M_Nav* pass-through wrappers of map.c:787-815, Entity_NavLayerWithRadius) are
+ * given the minimal bodies below; the arrival module is inactive (NULL arrival state), which
+ * is the state of a flock that has not reached its destination region.
+ */
+#include "game/movement.c"
+
+#include "pfref.h"
+#include "ref_internal.h"
+
+#include <pthread.h>
+#include <time.h>
+
+/* ---- engine services movement.c links against ------------------------------------------- */
+
+uint32_t G_FlagsGetFrom(khash_t(id) *table, uint32_t uid)
+{
+    khiter_t k = kh_get(id, table, uid);
+    assert(k != kh_end(table));
+    return (uint32_t)kh_value(table, k);
+}
+
+float G_GetSelectionRadiusFrom(khash_t(range) *table, uint32_t uid)
+{
+    khiter_t k = kh_get(range, table, uid);
+    assert(k != kh_end(table));
+    return kh_value(table, k);
+}
+
+int G_GetFactionIDFrom(khash_t(id) *table, uint32_t uid)
+{
+    khiter_t k = kh_get(id, table, uid);
+    assert(k != kh_end(table));
+    return kh_value(table, k);
+}
+
+/* entity.c:554-575 */
+int Entity_NavLayerWithRadius(uint32_t flags, float radius)
+{
+    bool water = !!(flags & ENTITY_FLAG_WATER);
+    bool air = !!(flags & ENTITY_FLAG_AIR);
+    int base = water ? NAV_LAYER_WATER_1X1 : air ? NAV_LAYER_AIR_1X1 : NAV_LAYER_GROUND_1X1;
+    if(radius >= 15.0f) return base + 3;
+    if(radius >= 10.0f) return base + 2;
+    if(radius >= 5.0f)  return base + 1;
+    return base;
+}
+
+/* map.c:787-815 pass-through wrappers: `struct map*` is the harness's pfref_nav here */
+bool M_NavPositionPathable(const struct map *map, enum nav_layer layer, vec2_t xz_pos)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    return N_PositionPathable(xz_pos, layer, &nav->priv, nav->map_pos);
+}
+
+bool M_NavPositionBlocked(const struct map *map, enum nav_layer layer, vec2_t xz_pos)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    return N_PositionBlocked(xz_pos, layer, &nav->priv, nav->map_pos);
+}
+
+vec2_t M_NavDesiredPointSeekVelocity(const struct map *map, dest_id_t id, vec2_t curr_pos,
+                                     vec2_t xz_dest)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    return N_DesiredPointSeekVelocity(id, curr_pos, xz_dest, &nav->priv, nav->map_pos);
+}
+
+struct arrival_state *G_ArrivalGroup_ForLayer(const struct arrival_group *grp, enum nav_layer layer)
+{
+    (void)grp; (void)layer;
+    return NULL;
+}
+
+bool G_Arrival_NeighbourSettling(const struct arrival_unit_state *us, vec2_t neighb_pos,
+                                 float radius)
+{
+    (void)us; (void)neighb_pos; (void)radius;
+    return false;
+}
+
+/* ---- world loading ---------------------------------------------------------------------- */
+
+static struct {
+    bool        loaded;
+    int         n;
+    pfref_nav  *nav;
+    khash_t(id)    *flags;
+    khash_t(pos)   *positions;
+    khash_t(range) *radiuses;
+    khash_t(id)    *factions;
+    bg_ent_t       *postree;
+    vec_cp_ent_t   *vecs;       /* 2 per agent */
+    uint8_t        *los;
+    float          *speed;
+} s_w;
+
+static bool uid_eq(const uint32_t *a, const uint32_t *b) { return *a == *b; }
+
+void pfref_move_unload(void)
+{
+    if(!s_w.loaded)
+        return;
+    kh_destroy(id, s_w.flags);
+    kh_destroy(pos, s_w.positions);
+    kh_destroy(range, s_w.radiuses);
+    kh_destroy(id, s_w.factions);
+    bg_ent_destroy(s_w.postree);
+    free(s_w.postree);
+    for(int i = 0; i < 2 * s_w.n; i++)
+        vec_cp_ent_destroy(&s_w.vecs[i]);
+    free(s_w.vecs);
+    free(s_w.los);
+    free(s_w.speed);
+    free(s_move_work.in);
+    free(s_move_work.out);
+    for(int i = 0; i < vec_size(&s_flocks); i++)
+        kh_destroy(entity, vec_AT(&s_flocks, i).ents);
+    vec_flock_destroy(&s_flocks);
+    kh_destroy(state, s_entity_state_table);
+    memset(&s_w, 0, sizeof(s_w));
+}
+
+int pfref_move_load(pfref_nav *nav, const pfref_move_world *w)
+{
+    pfref_move_unload();
+    int n = w->n, ret;
+    s_w.n = n;
+    s_w.nav = nav;
+    s_w.flags = kh_init(id);
+    s_w.positions = kh_init(pos);
+    s_w.radiuses = kh_init(range);
+    s_w.factions = kh_init(id);
+    s_entity_state_table = kh_init(state);
+    vec_flock_init(&s_flocks);
+
+    for(int f = 0; f < w->n_flocks; f++) {
+        struct flock fl;
+        memset(&fl, 0, sizeof(fl));
+        fl.ents = kh_init(entity);
+        fl.target_xz = (vec2_t){w->flock_target_xz[2 * f], w->flock_target_xz[2 * f + 1]};
+        fl.dest_id = w->flock_dest_id[f];
+        vec_flock_push(&s_flocks, fl);
+    }
+
+    /* position.c:276-283: the grid spans the whole map, centred on the map centre */
+    float half_x = nav->priv.width  * TILES_PER_CHUNK_WIDTH  * X_COORDS_PER_TILE / 2.0f;
+    float half_z = nav->priv.height * TILES_PER_CHUNK_HEIGHT * Z_COORDS_PER_TILE / 2.0f;
+    float cx = nav->map_pos.x - half_x, cz = nav->map_pos.z + half_z;
+    s_w.postree = malloc(sizeof(bg_ent_t));
+    bg_ent_init(s_w.postree, cx - half_x, cx + half_x, cz - half_z, cz + half_z, uid_eq);
+    bg_ent_reserve(s_w.postree, n > 0 ? n : 1);
+
+    for(int i = 0; i < n; i++) {
+        khiter_t k;
+        k = kh_put(id, s_w.flags, i, &ret);        kh_value(s_w.flags, k) = (int)w->flags[i];
+        k = kh_put(range, s_w.radiuses, i, &ret);  kh_value(s_w.radiuses, k) = w->radius[i];
+        k = kh_put(id, s_w.factions, i, &ret);     kh_value(s_w.factions, k) = 0;
+        k = kh_put(pos, s_w.positions, i, &ret);
+        kh_value(s_w.positions, k) = (vec3_t){w->pos_xz[2 * i], 0.0f, w->pos_xz[2 * i + 1]};
+
+        struct movestate ms;
+        memset(&ms, 0, sizeof(ms));
+        ms.state = w->state[i];
+        ms.max_speed = w->max_speed[i];
+        ms.velocity = (vec2_t){w->vel_xz[2 * i], w->vel_xz[2 * i + 1]};
+        ms.prev_pos = ms.next_pos = kh_value(s_w.positions, k);
+        k = kh_put(state, s_entity_state_table, i, &ret);
+        kh_value(s_entity_state_table, k) = ms;
+
+        if(w->flock[i] >= 0) {
+            struct flock *fl = &vec_AT(&s_flocks, w->flock[i]);
+            kh_put(entity, fl->ents, i, &ret);
+        }
+        bg_ent_insert(s_w.postree, w->pos_xz[2 * i], w->pos_xz[2 * i + 1], (uint32_t)i);
+    }
+    bg_ent_cleanup(s_w.postree);     /* G_Pos_CopyBitmapGrid, position.c:359-371 */
+
+    memset(&s_move_work, 0, sizeof(s_move_work));
+    s_move_work.gamestate.flags = s_w.flags;
+    s_move_work.gamestate.positions = s_w.positions;
+    s_move_work.gamestate.postree = s_w.postree;
+    s_move_work.gamestate.sel_radiuses = s_w.radiuses;
+    s_move_work.gamestate.faction_ids = s_w.factions;
+    s_move_work.gamestate.map = (struct map*)nav;
+    s_map = (const struct map*)nav;
+    s_move_work.hz = (w->hz == 20) ? MOVE_HZ_20 : (w->hz == 10) ? MOVE_HZ_10
+                   : (w->hz == 5) ? MOVE_HZ_5 : MOVE_HZ_1;
+    s_move_work.in = calloc(n > 0 ? n : 1, sizeof(struct move_work_in));
+    s_move_work.out = calloc(n > 0 ? n : 1, sizeof(struct move_work_out));
+    s_move_work.nwork = n;
+
+    s_w.vecs = calloc(2 * (n > 0 ? n : 1), sizeof(vec_cp_ent_t));
+    s_w.los = malloc(n > 0 ? n : 1);
+    s_w.speed = malloc(sizeof(float) * (n > 0 ? n : 1));
+    for(int i = 0; i < n; i++) {
+        vec_cp_ent_init(&s_w.vecs[2 * i]);
+        vec_cp_ent_init(&s_w.vecs[2 * i + 1]);
+        vec_cp_ent_resize(&s_w.vecs[2 * i], MAX_NEIGHBOURS);
+        vec_cp_ent_resize(&s_w.vecs[2 * i + 1], MAX_NEIGHBOURS);
+        s_w.los[i] = w->has_dest_los[i];
+        s_w.speed[i] = w->speed[i];
+        /* movement.c:4350-4376 */
+        s_move_work.in[i] = (struct move_work_in){
+            .ent_uid = i,
+            .speed = w->speed[i],
+            .cp_ent = (struct cp_ent){
+                .xz_pos = (vec2_t){w->pos_xz[2 * i], w->pos_xz[2 * i + 1]},
+                .xz_vel = (vec2_t){w->vel_xz[2 * i], w->vel_xz[2 * i + 1]},
+                .radius = w->radius[i]},
+            .save_debug = false,
+            .dyn_neighbs = &s_w.vecs[2 * i],
+            .stat_neighbs = &s_w.vecs[2 * i + 1],
+            .has_dest_los = w->has_dest_los[i],
+        };
+    }
+    s_w.loaded = true;
+    return 0;
+}
+
+static void set_vdes(const float *vdes, int i)
+{
+    struct move_work_in *in = &s_move_work.in[i];
+    if(vdes) {
+        in->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
+    }else{
+        const struct movestate *ms = movestate_get(i);
+        const struct flock *fl = flock_for_ent(i);
+        (void)ms;
+        in->ent_des_v = fl ? M_NavDesiredPointSeekVelocity(s_move_work.gamestate.map, fl->dest_id,
+                                 in->cp_ent.xz_pos, fl->target_xz)
+                           : (vec2_t){0.0f, 0.0f};
+    }
+    in->dyn_neighbs->size = 0;
+    in->stat_neighbs->size = 0;
+}
+
+void pfref_move_velocity(const float *vdes, int begin, int end, float *out_vel)
+{
+    for(int i = begin; i < end; i++)
+        set_vdes(vdes, i);
+    if(end > begin)
+        move_velocity_work(begin, end - 1);
+    for(int i = begin; i < end; i++) {
+        out_vel[2 * i]     = s_move_work.out[i].ent_vel.x;
+        out_vel[2 * i + 1] = s_move_work.out[i].ent_vel.z;
+    }
+}
+
+void pfref_move_vpref(int uid, const float vdes[2], float out[2])
+{
+    const struct flock *fl = flock_for_ent(uid);
+    vec2_t v = point_seek_vpref(uid, fl, (vec2_t){vdes[0], vdes[1]}, s_w.los[uid], s_w.speed[uid]);
+    out[0] = v.x; out[1] = v.z;
+}
+
+void pfref_move_forces(int uid, const float vdes[2], float out_arrive[2], float out_cohesion[2],
+                       float out_separation[2])
+{
+    const struct flock *fl = flock_for_ent(uid);
+    vec2_t a = arrive_force_point(uid, fl->target_xz, (vec2_t){vdes[0], vdes[1]}, s_w.los[uid]);
+    vec2_t c = cohesion_force(uid, fl);
+    vec2_t s = separation_force(uid, SEPARATION_BUFFER_DIST);
+    out_arrive[0] = a.x; out_arrive[1] = a.z;
+    out_cohesion[0] = c.x; out_cohesion[1] = c.z;
+    out_separation[0] = s.x; out_separation[1] = s.z;
+}
+
+int pfref_move_neighbours(int uid, float *out_dyn, int *n_dyn, float *out_stat, int *n_stat)
+{
+    struct move_work_in *in = &s_move_work.in[uid];
+    in->dyn_neighbs->size = 0;
+    in->stat_neighbs->size = 0;
+    find_neighbours(uid, in->dyn_neighbs, in->stat_neighbs);
+    *n_dyn = vec_size(in->dyn_neighbs);
+    *n_stat = vec_size(in->stat_neighbs);
+    for(int i = 0; i < *n_dyn; i++)
+        memcpy(out_dyn + 5 * i, &vec_AT(in->dyn_neighbs, i), 5 * sizeof(float));
+    for(int i = 0; i < *n_stat; i++)
+        memcpy(out_stat + 5 * i, &vec_AT(in->stat_neighbs, i), 5 * sizeof(float));
+    return 0;
+}
+
+struct mbench_arg{ int begin, end, reps; };
+
+static void *mbench_thread(void *p)
+{
+    struct mbench_arg *a = p;
+    for(int r = 0; r < a->reps; r++) {
+        for(int i = a->begin; i < a->end; i++) {
+            s_move_work.in[i].dyn_neighbs->size = 0;
+            s_move_work.in[i].stat_neighbs->size = 0;
+        }
+        if(a->end > a->begin)
+            move_velocity_work(a->begin, a->end - 1);
+    }
+    return NULL;
+}
+
+double pfref_move_bench(const float *vdes, int begin, int end, int reps, int nthreads,
+                        float *out_vel)
+{
+    for(int i = begin; i < end; i++)
+        set_vdes(vdes, i);
+    if(nthreads < 1) nthreads = 1;
+    if(nthreads > 64) nthreads = 64;
+    pthread_t tids[64];
+    struct mbench_arg args[64];
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int n = end - begin;
+    /* same contiguous slab split as move_submit_cpu_work (movement.c:3756-3762) */
+    for(int t = 0; t < nthreads; t++) {
+        args[t] = (struct mbench_arg){begin + (int)((long)n * t / nthreads),
+                                      begin + (int)((long)n * (t + 1) / nthreads), reps};
+        pthread_create(&tids[t], NULL, mbench_thread, &args[t]);
+    }
+    for(int t = 0; t < nthreads; t++)
+        pthread_join(tids[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if(out_vel) {
+        for(int i = begin; i < end; i++) {
+            out_vel[2 * i]     = s_move_work.out[i].ent_vel.x;
+            out_vel[2 * i + 1] = s_move_work.out[i].ent_vel.z;
+        }
+    }
+    return (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+}

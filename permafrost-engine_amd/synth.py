@@ -92,3 +92,123 @@ def agents(grid, n, k_flocks, seed=7, radius=1.0, max_speed=20.0, hz=20):
         "flock": (np.arange(n) % k_flocks).astype(np.int32),
         "hz": hz,
     }
+
+
+# ------------------------------------------------------------------------------------------
+# synthetic request streams (what the reference's host-side planner would hand the kernels)
+# ------------------------------------------------------------------------------------------
+def local_islands(grid, blockers=None):
+    """Per-chunk 4-connected components of passable cells (cost != 0xff and blockers == 0);
+    u16 ids local to each chunk, ISLAND_NONE (0xffff) elsewhere.  Any consistent labelling
+    serves the kernels, which only test ids for equality (field.c:1151,1195)."""
+    from scipy import ndimage
+    ok = grid != COST_IMPASSABLE
+    if blockers is not None:
+        ok &= blockers == 0
+    h, w = grid.shape[0] // 64, grid.shape[1] // 64
+    out = np.full(grid.shape, 0xFFFF, np.uint16)
+    for cr in range(h):
+        for cc in range(w):
+            sl = (slice(cr * 64, cr * 64 + 64), slice(cc * 64, cc * 64 + 64))
+            lab, n = ndimage.label(ok[sl])
+            o = out[sl]
+            o[lab > 0] = (lab[lab > 0] - 1).astype(np.uint16)
+    return out
+
+
+def portals(grid):
+    """Maximal runs of mutually passable facing cells on every shared chunk edge (the portal
+    notion of n_link_chunks, nav.c:470-556).  Returns a list of dicts with both sides."""
+    ok = grid != COST_IMPASSABLE
+    h, w = grid.shape[0] // 64, grid.shape[1] // 64
+    out = []
+
+    def runs(mask):
+        idx = np.flatnonzero(mask)
+        if idx.size == 0:
+            return []
+        brk = np.flatnonzero(np.diff(idx) > 1)
+        starts = np.r_[idx[0], idx[brk + 1]]
+        ends = np.r_[idx[brk], idx[-1]]
+        return list(zip(starts.tolist(), ends.tolist()))
+
+    for cr in range(h):
+        for cc in range(w):
+            if cr + 1 < h:      # bottom edge of (cr,cc) / top edge of (cr+1,cc)
+                both = ok[cr * 64 + 63, cc * 64:cc * 64 + 64] & ok[cr * 64 + 64, cc * 64:cc * 64 + 64]
+                for a, b in runs(both):
+                    out.append(dict(a=(cr, cc), a_ep=(63, a, 63, b), b=(cr + 1, cc), b_ep=(0, a, 0, b)))
+            if cc + 1 < w:      # right edge of (cr,cc) / left edge of (cr,cc+1)
+                both = ok[cr * 64:cr * 64 + 64, cc * 64 + 63] & ok[cr * 64:cr * 64 + 64, cc * 64 + 64]
+                for a, b in runs(both):
+                    out.append(dict(a=(cr, cc), a_ep=(a, 63, b, 63), b=(cr, cc + 1), b_ep=(a, 0, b, 0)))
+    return out
+
+
+REQ_FIELDS = ("layer", "type", "faction_id", "flags", "enemies", "chunk_r", "chunk_c", "tile_r",
+              "tile_c", "port_r0", "port_c0", "port_r1", "port_c1", "next_r0", "next_c0",
+              "next_r1", "next_c1", "next_chunk_r", "next_chunk_c", "port_iid", "next_iid")
+
+
+def whole_map_requests(grid, dests, liid=None):
+    """For every destination cell: one chunk-field request per chunk of the map -- TARGET_TILE
+    in the destination chunk, TARGET_PORTAL (towards the neighbouring chunk that is one step
+    closer in chunk-BFS distance, through the portal nearest to the straight line) elsewhere
+    ('each destination expands to all chunks of the map').
+    Returns a dict of equal-length int arrays keyed by REQ_FIELDS."""
+    from collections import deque
+    h, w = grid.shape[0] // 64, grid.shape[1] // 64
+    if liid is None:
+        liid = local_islands(grid)
+    plist = portals(grid)
+    by_pair = {}
+    for p in plist:
+        by_pair.setdefault((p["a"], p["b"]), []).append((p["a_ep"], p["b_ep"]))
+        by_pair.setdefault((p["b"], p["a"]), []).append((p["b_ep"], p["a_ep"]))
+    cols = {k: [] for k in REQ_FIELDS}
+
+    def push(**kw):
+        for k in REQ_FIELDS:
+            cols[k].append(kw.get(k, 0))
+
+    for (R, Cc) in np.asarray(dests):
+        dchunk = (int(R) // 64, int(Cc) // 64)
+        dist = {dchunk: 0}
+        q = deque([dchunk])
+        while q:
+            cur = q.popleft()
+            for d in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                nb = (cur[0] + d[0], cur[1] + d[1])
+                if nb in dist or not (0 <= nb[0] < h and 0 <= nb[1] < w):
+                    continue
+                if (nb, cur) not in by_pair:
+                    continue
+                dist[nb] = dist[cur] + 1
+                q.append(nb)
+        for cr in range(h):
+            for cc in range(w):
+                ch = (cr, cc)
+                if ch == dchunk:
+                    push(type=1, faction_id=0xF, chunk_r=cr, chunk_c=cc,
+                         tile_r=int(R) % 64, tile_c=int(Cc) % 64)
+                    continue
+                if ch not in dist:
+                    continue
+                best = None
+                for d in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                    nb = (cr + d[0], cc + d[1])
+                    if dist.get(nb, 1 << 30) == dist[ch] - 1 and (ch, nb) in by_pair:
+                        for ep, nep in by_pair[(ch, nb)]:
+                            mr, mc = (ep[0] + ep[2]) / 2.0, (ep[1] + ep[3]) / 2.0
+                            gr, gc = cr * 64 + mr, cc * 64 + mc
+                            score = abs(gr - R) + abs(gc - Cc)
+                            if best is None or score < best[0]:
+                                best = (score, nb, ep, nep)
+                _, nb, ep, nep = best
+                push(type=0, faction_id=0xF, chunk_r=cr, chunk_c=cc,
+                     port_r0=ep[0], port_c0=ep[1], port_r1=ep[2], port_c1=ep[3],
+                     next_r0=nep[0], next_c0=nep[1], next_r1=nep[2], next_c1=nep[3],
+                     next_chunk_r=nb[0], next_chunk_c=nb[1],
+                     port_iid=int(liid[cr * 64 + ep[0], cc * 64 + ep[1]]),
+                     next_iid=int(liid[nb[0] * 64 + nep[0], nb[1] * 64 + nep[1]]))
+    return {k: np.asarray(v, np.int64) for k, v in cols.items()}
