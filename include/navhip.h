@@ -134,6 +134,87 @@ uint64_t navhip_flow_field_id(const navhip_field_req *req);
  * cell of the chunk has cost 1, generic relaxation otherwise), 1 = force generic. */
 int  navhip_set_field_kernel(navhip_ctx *ctx, int mode);
 
+/* ---- per-agent movement step ---------------------------------- */
+
+/* enum move_state, movement.c:113-143 */
+enum { NAVHIP_STATE_MOVING = 0, NAVHIP_STATE_MOVING_IN_FORMATION, NAVHIP_STATE_ARRIVED,
+       NAVHIP_STATE_SEEK_ENEMIES, NAVHIP_STATE_WAITING, NAVHIP_STATE_SURROUND_ENTITY,
+       NAVHIP_STATE_ENTER_ENTITY_RANGE, NAVHIP_STATE_TURNING, NAVHIP_STATE_ARRIVING_TO_CELL };
+
+/* ENTITY_FLAG_* bits the step reads, entity.h:56-82 */
+#define NAVHIP_ENTITY_FLAG_MOVABLE      (1u << 3)
+#define NAVHIP_ENTITY_FLAG_WATER        (1u << 14)
+#define NAVHIP_ENTITY_FLAG_AIR          (1u << 15)
+#define NAVHIP_ENTITY_FLAG_GARRISONED   (1u << 18)
+#define NAVHIP_ENTITY_FLAG_COMBAT_HELD  (1u << 21)
+
+/* navhip_step_out.status bits */
+#define NAVHIP_ST_MOVED        0x01  /* pos+vel accepted by the position test (movement.c:2356-2358) */
+#define NAVHIP_ST_FIELD_MISS   0x02  /* no flow field cached for the agent's chunk: the host must run
+                                        the planner (n_request_path, nav.c:3483-3492) and re-step    */
+#define NAVHIP_ST_FIELD_NONE   0x04  /* the field has FD_NONE under the agent (nav.c:3495-3554 path)  */
+#define NAVHIP_ST_UNSUPPORTED  0x80  /* formation states: not on the device path, velocity = 0       */
+
+/* The snapshot the movement tick works on: `struct move_gamestate` + `struct move_work_in` +
+ * flock table (movement.c:207-213,264-276,296-312) as structure-of-arrays; uid == array index.
+ * All pointers are HOST pointers for navhip_agent_step and DEVICE pointers for
+ * navhip_agent_step_dev. */
+typedef struct navhip_world {
+    int32_t  n_ents;                 /* every entity in the position snapshot                  */
+    int32_t  n_flocks;
+    int32_t  hz;                     /* movement tick rate: 20/10/5/1 (hz_count, movement.c:2210) */
+    int32_t  n_field_slots;
+    const float    *pos_xz;          /* [n][2]  G_Pos_GetXZFrom                                */
+    const float    *vel_xz;          /* [n][2]  movestate.velocity (world units per tick)      */
+    const float    *radius;          /* [n]     G_GetSelectionRadiusFrom                       */
+    const float    *max_speed;       /* [n]     movestate.max_speed                            */
+    const float    *speed;           /* [n]     move_work_in.speed                             */
+    const uint32_t *flags;           /* [n]     G_FlagsGetFrom                                 */
+    const uint8_t  *state;           /* [n]     movestate.state                                */
+    const uint8_t  *has_dest_los;    /* [n]     move_work_in.has_dest_los                      */
+    const int32_t  *flock;           /* [n]     index into the flock table, -1 = none          */
+    const float    *vdes_xz;         /* [n][2]  move_work_in.ent_des_v, or NULL: sample the flow
+                                                fields on the device (N_DesiredPointSeekVelocity) */
+    const float    *flock_target_xz; /* [F][2]  flock.target_xz                                */
+    const int32_t  *flock_offsets;   /* [F+1]   CSR offsets into flock_members                 */
+    const int32_t  *flock_members;   /* member uids, in kh_foreach order of flock.ents         */
+    const int32_t  *flock_field_slot;/* [F][chunks] slot of the (dest,chunk) flow field in
+                                                field_pool, -1 = not cached (N_FC_GetDestFFMapping) */
+    const uint8_t  *field_pool;      /* [slots][4096] flow fields (one dir_idx per byte)       */
+    float    map_pos_x, map_pos_z;   /* vec3 map_pos .x/.z handed to every N_* call            */
+    float    grid_xmin, grid_xmax, grid_zmin, grid_zmax;  /* bg_ent_init bounds, position.c:276-283 */
+} navhip_world;
+
+typedef struct navhip_step_out {
+    float   *vel_xz;        /* [n][2]  move_work_out.ent_vel (movement.c:3462-3464); 0 for still ents */
+    float   *new_pos_xz;    /* [n][2]  or NULL: pos+vel when accepted, else pos (movement.c:2336-2358) */
+    float   *vdes_xz;       /* [n][2]  or NULL: the desired direction used (debug / parity)    */
+    float   *vpref_xz;      /* [n][2]  or NULL: preferred velocity before ClearPath (debug / parity) */
+    uint8_t *status;        /* [n]     or NULL: NAVHIP_ST_*                                     */
+} navhip_step_out;
+
+/* One velocity step for every non-still entity: replaces the WORK_TYPE_CPU / WORK_TYPE_GPU arms of
+ * fork_join_velocity_computations (movement.c:4182-4194), i.e. move_velocity_work (:3395) for all
+ * work items, plus the position accept test of entity_compute_update (:2336-2358).
+ * Host-buffer form: uploads the snapshot, runs, downloads the outputs. */
+int  navhip_agent_step(navhip_ctx *ctx, const navhip_world *world, const navhip_step_out *out);
+/* Device-resident form (no PCIe in the call), asynchronous on `stream`. */
+int  navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *dev_world,
+                           const navhip_step_out *dev_out, void *stream);
+
+/* Device spatial index only (bg_ent insert-all + cleanup + inrange_circle, bitmap_grid.h:1376):
+ * for each query point the ids within `range`, in the reference's visiting order, capped at
+ * maxout.  Host buffers.  Used by the parity tests of the neighbour gather. */
+int  navhip_spatial_query(navhip_ctx *ctx, const navhip_world *world, const float *query_xz,
+                          int nq, float range, int maxout, int32_t *out_counts, uint32_t *out_ids);
+
+/* G_ClearPath_NewVelocity (clearpath.c:694) for nq independent problems, host buffers.
+ * ent: [nq][5] {pos.x,pos.z,vel.x,vel.z,radius}; des_v: [nq][2]; dyn/stat: [nq][32][5] with
+ * n_dyn/n_stat counts; out: [nq][2]. */
+int  navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                      const float *dyn, const int32_t *n_dyn, const float *stat,
+                      const int32_t *n_stat, float *out);
+
 #ifdef __cplusplus
 }
 #endif

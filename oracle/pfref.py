@@ -101,6 +101,8 @@ def lib():
              None),
             ("pfref_move_neighbours", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
              C.c_int),
+            ("pfref_move_get_vdes", [C.c_void_p], None),
+            ("pfref_move_flock_order", [C.c_int, C.c_void_p], C.c_int),
             ("pfref_move_bench", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
              C.c_double),
         ):
@@ -328,6 +330,16 @@ class RefMove:
         nd, ns = C.c_int(0), C.c_int(0)
         lib().pfref_move_neighbours(uid, _p(dyn), C.byref(nd), _p(stat), C.byref(ns))
         return dyn[:nd.value].copy(), stat[:ns.value].copy()
+
+    def vdes(self):
+        out = np.zeros((self.n, 2), np.float32)
+        lib().pfref_move_get_vdes(_p(out))
+        return out
+
+    def flock_order(self, f):
+        buf = np.zeros(self.n, np.uint32)
+        k = lib().pfref_move_flock_order(f, _p(buf))
+        return buf[:k].astype(np.int32)
 
     @staticmethod
     def unload():

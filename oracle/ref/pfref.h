@@ -163,6 +163,8 @@ void pfref_move_vpref(int uid, const float vdes[2], float out[2]);
 void pfref_move_forces(int uid, const float vdes[2], float out_arrive[2], float out_cohesion[2],
                        float out_separation[2]);
 int  pfref_move_neighbours(int uid, float *out_dyn, int *n_dyn, float *out_stat, int *n_stat);
+void pfref_move_get_vdes(float *out_vdes);
+int  pfref_move_flock_order(int flock, uint32_t *out_uids);
 double pfref_move_bench(const float *vdes, int begin, int end, int reps, int nthreads, float *out_vel);
 
 #ifdef __cplusplus

@@ -334,3 +334,24 @@ double pfref_move_bench(const float *vdes, int begin, int end, int reps, int nth
     }
     return (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
 }
+
+/* the ent_des_v each work item carried in the last pfref_move_velocity / _bench call */
+void pfref_move_get_vdes(float *out_vdes)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        out_vdes[2 * i]     = s_move_work.in[i].ent_des_v.x;
+        out_vdes[2 * i + 1] = s_move_work.in[i].ent_des_v.z;
+    }
+}
+
+/* kh_foreach order of flock->ents: the order cohesion_force (movement.c:1660) sums in */
+int pfref_move_flock_order(int flock, uint32_t *out_uids)
+{
+    struct flock *fl = &vec_AT(&s_flocks, flock);
+    int n = 0;
+    uint32_t curr;
+    kh_foreach_key(fl->ents, curr, {
+        out_uids[n++] = curr;
+    });
+    return n;
+}

@@ -1,0 +1,49 @@
+// agent_internal.h -- device-side views used by the agent-step kernels.
+#pragma once
+#include "navhip_internal.h"
+
+// bg_<name>_t geometry (bitmap_grid.h:959-990) + the cell-sorted element pool
+struct nh_grid {
+    int32_t origin_x, origin_y;      // BG_SCALE_F(xmin), BG_SCALE_F(ymin)
+    int     grid_w, grid_h;          // ceil(span / 16 wu)
+    int     n;
+    const int32_t *cell_start;       // [ncells+1]
+    const int32_t *sorted_id;        // [n] records[] of the packed pool
+    const int32_t *sx, *sy;          // [n] xs[] / ys[] of the packed pool (fixed point x256)
+};
+
+struct nh_spatial_scratch {
+    int32_t *ent_ix, *ent_iy, *ent_cell;     // [n]
+    int32_t *cell_count, *cell_fill;         // [ncells]
+    int32_t *cell_start;                     // [ncells+1]
+    int32_t *sorted_id, *sx, *sy;            // [n]
+};
+
+struct nh_step_params {
+    nh_map_view map;
+    nh_grid     grid;
+    float       map_x, map_z;
+    int         n_ents, n_flocks, hz;
+    const float    *pos_xz, *vel_xz, *radius, *max_speed, *speed;
+    const uint32_t *flags;
+    const uint8_t  *state, *has_dest_los;
+    const int32_t  *flock;
+    const float    *vdes_xz;
+    const float    *flock_target_xz;
+    const int32_t  *flock_offsets, *flock_members, *flock_field_slot;
+    const uint8_t  *field_pool;
+};
+
+struct nh_step_outs {
+    float   *vel_xz, *new_pos_xz, *vdes_xz, *vpref_xz;
+    uint8_t *status;
+};
+
+void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
+                             hipStream_t s);
+void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const nh_step_outs &O, hipStream_t s);
+void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,
+                             int32_t *d_counts, uint32_t *d_ids, hipStream_t s);
+void nh_launch_clearpath(int nq, const float *ent, const float *des_v, const float *dyn,
+                         const int32_t *n_dyn, const float *stat, const int32_t *n_stat, float *out,
+                         hipStream_t s);

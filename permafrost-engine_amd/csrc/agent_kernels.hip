@@ -1,0 +1,985 @@
+// agent_kernels.hip -- per-agent movement step for gfx950 (MI355X), hand-written HIP.
+//
+// Reference semantics (permafrost-engine):
+//   src/game/movement.c   move_velocity_work :3395, point_seek_vpref :1870, point_seek_total_force
+//                         :1745, arrive_force_point :1546, cohesion_force :1653, separation_force
+//                         :1690, nullify_impass_components :1831, find_neighbours :2768,
+//                         enemy_seek_vpref :1946, vec2_truncate :643, position accept :2336-2358
+//   src/game/clearpath.c  G_ClearPath_NewVelocity :694 and everything under it
+//   src/phys/collision.c  C_InfiniteLineIntersection :820, C_RayRayIntersection2D :854
+//   src/lib/public/bitmap_grid.h  bg_*_inrange_circle :1376 (candidate order + fixed-point test)
+//   src/navigation/nav.c  N_DesiredPointSeekVelocity :3468, n_interpolated_flow_dir :3407,
+//                         N_PositionPathable/Blocked :4055/:4070;  src/map/tile.c :356,:391,:547
+//
+// Arithmetic mirrors the reference's C expression by expression (same types, same order, no FMA
+// contraction, IEEE divide / sqrt, double-precision exp) so that results are reproducible against
+// the CPU path far inside the 1e-4 parity bound; all order-dependent float sums are evaluated in
+// the reference's own order.
+//
+// Kernels
+//   k_sp_*        device spatial hash: fixed-point cell binning, scan, scatter, per-cell ordering
+//                 (the layout bg_ent_cleanup produces after inserting uids 0..n-1).
+//   k_cohesion    one THREAD per flock member; the O(N*F) exp-weighted centroid, every thread
+//                 walking its flock's member list in order (lanes of a wave share the flock, so
+//                 member loads are wave-uniform broadcasts).
+//   k_agent_step  one WAVE per agent: flow sampling, arrive/separation forces, impassable-component
+//                 nullification, neighbour gather (lanes test 64 candidates at a time, ballot +
+//                 prefix-popcount compaction keeps the reference's order and caps), ClearPath with
+//                 lanes spread over ray pairs and a lexicographic wave arg-min that reproduces the
+//                 reference's first-wins tie-break, truncation and the position accept test.
+#include "navhip_internal.h"
+#include "agent_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// exact-arithmetic helpers (pf_math.c:58-94)
+// ---------------------------------------------------------------------------------------------
+struct v2 { float x, z; };
+
+__device__ __forceinline__ v2 mkv(float x, float z) { v2 r; r.x = x; r.z = z; return r; }
+__device__ __forceinline__ v2 vadd(v2 a, v2 b) { return mkv(a.x + b.x, a.z + b.z); }
+__device__ __forceinline__ v2 vsub(v2 a, v2 b) { return mkv(a.x - b.x, a.z - b.z); }
+__device__ __forceinline__ v2 vscale(v2 a, float s) { return mkv(a.x * s, a.z * s); }
+__device__ __forceinline__ float vdot(v2 a, v2 b) { return a.x * b.x + a.z * b.z; }
+// PFM_Vec2_Len: sqrt in double of a float sum, rounded to float == correctly rounded float sqrt.
+// __builtin_sqrtf is IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn is
+// NOT (it lowers to the native v_sqrt_f32 approximation in this ROCm).
+__device__ __forceinline__ float vlen(v2 a) { return __builtin_sqrtf(a.x * a.x + a.z * a.z); }
+__device__ __forceinline__ v2 vnormal(v2 a)
+{
+    float l = vlen(a);
+    return mkv(__fdiv_rn(a.x, l), __fdiv_rn(a.z, l));
+}
+// vec2_truncate, movement.c:643
+__device__ __forceinline__ v2 vtrunc(v2 a, float max_len)
+{
+    if(vlen(a) > max_len) {
+        a = vnormal(a);
+        a = vscale(a, max_len);
+    }
+    return a;
+}
+
+#define CP_EPS 0.0009765625f   /* 1.0/1024: exactly representable, so float compares == the
+                                  reference's float-vs-double compares */
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile lookups (tile.c:547 M_Tile_DescForPoint2D, nav.c:4055/4070)
+// ---------------------------------------------------------------------------------------------
+struct tiledesc { int chunk_r, chunk_c, tile_r, tile_c; };
+
+__device__ __forceinline__ bool tile_for_point(const nh_step_params &P, float x, float z, tiledesc &out)
+{
+    const float width = (float)(P.map.w * 256), height = (float)(P.map.h * 256);
+    if(x > P.map_x || x < P.map_x - width) return false;
+    if(z < P.map_z || z > P.map_z + height) return false;
+    int chunk_r = (int)(fabsf(P.map_z - z) / 256.0f);      // exact: division by a power of two
+    int chunk_c = (int)(fabsf(P.map_x - x) / 256.0f);
+    chunk_r = min(max(chunk_r, 0), P.map.h - 1);
+    chunk_c = min(max(chunk_c, 0), P.map.w - 1);
+    float base_x = P.map_x - (float)(chunk_c * 256);
+    float base_z = P.map_z + (float)(chunk_r * 256);
+    int tile_r = (int)(fabsf(base_z - z) / 4.0f);
+    int tile_c = (int)(fabsf(base_x - x) / 4.0f);
+    out.chunk_r = chunk_r; out.chunk_c = chunk_c;
+    out.tile_r = min(max(tile_r, 0), 63);
+    out.tile_c = min(max(tile_c, 0), 63);
+    return true;
+}
+
+// Entity_NavLayerWithRadius, entity.c:554
+__device__ __forceinline__ int nav_layer_for(uint32_t flags, float radius)
+{
+    int base = (flags & NAVHIP_ENTITY_FLAG_WATER) ? 4 : (flags & NAVHIP_ENTITY_FLAG_AIR) ? 8 : 0;
+    if(radius >= 15.0f) return base + 3;
+    if(radius >= 10.0f) return base + 2;
+    if(radius >= 5.0f)  return base + 1;
+    return base;
+}
+
+__device__ __forceinline__ bool pos_pathable(const nh_step_params &P, int layer, float x, float z)
+{
+    tiledesc t;
+    if(!tile_for_point(P, x, z, t)) return false;     // reference asserts; off-map = not pathable
+    const uint8_t *cost = P.map.layers[layer].cost;
+    return cost[((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c]
+           != NAVHIP_COST_IMPASSABLE;
+}
+
+__device__ __forceinline__ bool pos_blocked(const nh_step_params &P, int layer, float x, float z)
+{
+    tiledesc t;
+    if(!tile_for_point(P, x, z, t)) return false;
+    const uint16_t *bl = P.map.layers[layer].blockers;
+    if(!bl) return false;
+    return bl[((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c] > 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// flow-field sampling (nav.c:3407 n_interpolated_flow_dir, :3468 N_DesiredPointSeekVelocity)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ v2 flow_dir_vec(int dir)           // N_FlowDir, field.c:2428
+{
+    const float d = 0.70710678118654757f;                     // (float)(1.0f / sqrt(2.0f))
+    switch(dir) {
+    case NAVHIP_FD_NW: return mkv( d, -d);
+    case NAVHIP_FD_N:  return mkv( 0.0f, -1.0f);
+    case NAVHIP_FD_NE: return mkv(-d, -d);
+    case NAVHIP_FD_W:  return mkv( 1.0f, 0.0f);
+    case NAVHIP_FD_E:  return mkv(-1.0f, 0.0f);
+    case NAVHIP_FD_SW: return mkv( d,  d);
+    case NAVHIP_FD_S:  return mkv( 0.0f, 1.0f);
+    case NAVHIP_FD_SE: return mkv(-d,  d);
+    default:           return mkv(0.0f, 0.0f);
+    }
+}
+
+__device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &status)
+{
+    tiledesc t;
+    if(flock < 0 || !P.flock_field_slot || !P.field_pool || !tile_for_point(P, pos.x, pos.z, t)) {
+        status |= NAVHIP_ST_FIELD_MISS;
+        return mkv(0.0f, 0.0f);
+    }
+    const int nchunks = P.map.w * P.map.h;
+    const int32_t *slots = P.flock_field_slot + (size_t)flock * nchunks;
+    int slot = slots[t.chunk_r * P.map.w + t.chunk_c];
+    if(slot < 0) {
+        status |= NAVHIP_ST_FIELD_MISS;
+        return mkv(0.0f, 0.0f);
+    }
+    const uint8_t *base_ff = P.field_pool + ((size_t)slot << 12);
+    int base_dir = base_ff[t.tile_r * 64 + t.tile_c] & 0xf;
+    if(base_dir == NAVHIP_FD_NONE) status |= NAVHIP_ST_FIELD_NONE;
+
+    // M_Tile_Bounds (tile.c:356): two sequential float subtractions / additions
+    float bx = (P.map_x - (float)(t.chunk_c * 256)) - (float)(t.tile_c * 4);
+    float bz = (P.map_z + (float)(t.chunk_r * 256)) + (float)(t.tile_r * 4);
+    float cx = bx - 4.0f / 2.0f, cz = bz + 4.0f / 2.0f;
+    float dx = pos.x - cx, dz = pos.z - cz;
+    int dc = (dx < 0.0f) ? 1 : -1;
+    int dr = (dz > 0.0f) ? 1 : -1;
+    float wc = fminf(fabsf(dx) / 4.0f, 1.0f);
+    float wr = fminf(fabsf(dz) / 4.0f, 1.0f);
+    const int   sdc[4] = {0, dc, 0, dc};
+    const int   sdr[4] = {0, 0, dr, dr};
+    const float sw[4]  = {(1.0f - wc) * (1.0f - wr), wc * (1.0f - wr), (1.0f - wc) * wr, wc * wr};
+
+    v2 acc = mkv(0.0f, 0.0f);
+    float wsum = 0.0f;
+#pragma unroll
+    for(int i = 0; i < 4; i++) {
+        if(sw[i] <= 0.0f) continue;
+        // M_Tile_RelativeDesc, tile.c:391
+        int abs_r = t.chunk_r * 64 + t.tile_r + sdr[i];
+        int abs_c = t.chunk_c * 64 + t.tile_c + sdc[i];
+        if(abs_r < 0 || abs_r >= P.map.h * 64 || abs_c < 0 || abs_c >= P.map.w * 64) continue;
+        int cr = abs_r >> 6, cc = abs_c >> 6, tr = abs_r & 63, tc = abs_c & 63;
+        const uint8_t *ff = base_ff;
+        if(cr != t.chunk_r || cc != t.chunk_c) {
+            int s2 = slots[cr * P.map.w + cc];
+            if(s2 < 0) continue;
+            ff = P.field_pool + ((size_t)s2 << 12);
+        }
+        int dir = ff[tr * 64 + tc] & 0xf;
+        if(dir == NAVHIP_FD_NONE) continue;
+        v2 scaled = vscale(flow_dir_vec(dir), sw[i]);
+        acc = vadd(acc, scaled);
+        wsum += sw[i];
+    }
+    if(wsum < 1e-6f || vlen(acc) < 1e-6f)
+        return flow_dir_vec(base_dir);
+    return vnormal(acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// spatial hash (bitmap_grid.h): build
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t bg_scale(float v) { return __float2int_rn(v * 256.0f); }   // BG_SCALE_F
+
+__device__ __forceinline__ int sp_cell_of(const nh_grid &G, int32_t ix, int32_t iy)
+{
+    int cx = (ix - G.origin_x) >> 12;             // BG_CELL_LOG2_INT = 8 + 4
+    int cy = (iy - G.origin_y) >> 12;
+    cx = min(max(cx, 0), G.grid_w - 1);
+    cy = min(max(cy, 0), G.grid_h - 1);
+    return cy * G.grid_w + cx;
+}
+
+__global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz, int n,
+                                                  int32_t *ent_ix, int32_t *ent_iy,
+                                                  int32_t *ent_cell, int32_t *cell_count)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if(i >= n) return;
+    int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
+    int c = sp_cell_of(G, ix, iy);
+    ent_ix[i] = ix; ent_iy[i] = iy; ent_cell[i] = c;
+    atomicAdd(&cell_count[c], 1);
+}
+
+// exclusive scan of cell_count[0..ncells) -> cell_start[0..ncells]; single workgroup, chunked
+__global__ __launch_bounds__(1024) void k_sp_scan(const int32_t *cell_count, int32_t *cell_start,
+                                                  int ncells)
+{
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if(t == 0) carry = 0;
+    __syncthreads();
+    for(int base = 0; base < ncells; base += 1024) {
+        int i = base + t;
+        int32_t v = (i < ncells) ? cell_count[i] : 0;
+        int32_t incl = v;
+#pragma unroll
+        for(int d = 1; d < 64; d <<= 1) {
+            int32_t o = __shfl_up(incl, d);
+            if(lane >= d) incl += o;
+        }
+        if(lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int32_t woff = 0;
+        for(int k = 0; k < w; k++) woff += wsum[k];
+        int32_t excl = carry + woff + incl - v;
+        if(i < ncells) cell_start[i] = excl;
+        __syncthreads();
+        if(t == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if(t == 0) cell_start[ncells] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, int n,
+                                                    const int32_t *cell_start, int32_t *cell_fill,
+                                                    int32_t *sorted_id)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if(i >= n) return;
+    int c = ent_cell[i];
+    int slot = cell_start[c] + atomicAdd(&cell_fill[c], 1);
+    sorted_id[slot] = i;
+}
+
+// Per-cell order: bg_ent_insert pushes at the head of the cell's overflow chain and
+// bg_ent_cleanup copies the chain head-first (bitmap_grid.h:1102-1121,1515-1521), so after
+// inserting uids 0..n-1 each cell holds its elements in DESCENDING uid order.
+__global__ __launch_bounds__(256) void k_sp_order(const int32_t *cell_start, int ncells,
+                                                  int32_t *sorted_id, const int32_t *ent_ix,
+                                                  const int32_t *ent_iy, int32_t *sx, int32_t *sy)
+{
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if(c >= ncells) return;
+    int b = cell_start[c], e = cell_start[c + 1];
+    for(int i = b + 1; i < e; i++) {            // insertion sort, descending; cells are tiny
+        int32_t v = sorted_id[i];
+        int j = i - 1;
+        while(j >= b && sorted_id[j] < v) { sorted_id[j + 1] = sorted_id[j]; j--; }
+        sorted_id[j + 1] = v;
+    }
+    for(int i = b; i < e; i++) {
+        int32_t id = sorted_id[i];
+        sx[i] = ent_ix[id];
+        sy[i] = ent_iy[id];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// spatial hash: query.  All 64 lanes cooperate on ONE query; returns the number written (wave
+// uniform).  Visiting order == bg_*_inrange_circle (bitmap_grid.h:1408-1466): coarse 8x8 blocks
+// row-major, inside a block fine rows top to bottom, cells left to right, packed elements in
+// order.  Cells of one fine row are contiguous in the cell-sorted pool, so a (block,row) pair is
+// one contiguous range that the lanes test 64 elements at a time; ballot + prefix popcount
+// appends hits in order and enforces `maxout` exactly where the reference stops.
+// ---------------------------------------------------------------------------------------------
+__device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, int maxout,
+                             uint32_t *out_ids, int lane)
+{
+    if(maxout <= 0 || range < 0.0f) return 0;
+    const int32_t icx = bg_scale(x), icy = bg_scale(z), ir = bg_scale(range);
+    const int64_t ir2 = (int64_t)ir * (int64_t)ir;
+    const int32_t imnx = icx - ir, imxx = icx + ir, imny = icy - ir, imxy = icy + ir;
+    // _bg_cell_extent, bitmap_grid.h:1236
+    if(imxx < G.origin_x || imxy < G.origin_y) return 0;
+    const int32_t span_x = (int32_t)((uint32_t)G.grid_w << 12), span_y = (int32_t)((uint32_t)G.grid_h << 12);
+    if(imnx >= G.origin_x + span_x || imny >= G.origin_y + span_y) return 0;
+    int cx_lo = (imnx - G.origin_x) >> 12, cx_hi = (imxx - G.origin_x) >> 12;
+    int cy_lo = (imny - G.origin_y) >> 12, cy_hi = (imxy - G.origin_y) >> 12;
+    cx_lo = max(cx_lo, 0); cy_lo = max(cy_lo, 0);
+    cx_hi = min(cx_hi, G.grid_w - 1); cy_hi = min(cy_hi, G.grid_h - 1);
+
+    int written = 0;
+    if((int64_t)(cx_hi - cx_lo + 1) * (cy_hi - cy_lo + 1) * 4 >= (int64_t)G.grid_w * G.grid_h * 3) {
+        // wide-query fast path (bitmap_grid.h:1389-1397): the clean pool is scanned linearly
+        for(int base = 0; base < G.n; base += 64) {
+            int k = base + lane;
+            bool hit = false;
+            if(k < G.n) {
+                int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
+                hit = dx * dx + dy * dy <= ir2;
+            }
+            uint64_t m = __ballot(hit);
+            int p = written + __popcll(m & ((1ull << lane) - 1ull));
+            if(hit && p < maxout) out_ids[p] = (uint32_t)G.sorted_id[k];
+            written += __popcll(m);
+            if(written >= maxout) return maxout;
+        }
+        return written;
+    }
+    for(int cyc = cy_lo >> 3; cyc <= (cy_hi >> 3); cyc++) {
+        for(int cxc = cx_lo >> 3; cxc <= (cx_hi >> 3); cxc++) {
+            int fy0 = max(cyc * 8, cy_lo), fy1 = min(cyc * 8 + 8, cy_hi + 1);
+            int fx0 = max(cxc * 8, cx_lo), fx1 = min(cxc * 8 + 8, cx_hi + 1);
+            for(int fy = fy0; fy < fy1; fy++) {
+                int b = G.cell_start[fy * G.grid_w + fx0];
+                int e = G.cell_start[fy * G.grid_w + fx1];
+                for(int base = b; base < e; base += 64) {
+                    int k = base + lane;
+                    bool hit = false;
+                    if(k < e) {
+                        int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
+                        hit = dx * dx + dy * dy <= ir2;
+                    }
+                    uint64_t m = __ballot(hit);
+                    int p = written + __popcll(m & ((1ull << lane) - 1ull));
+                    if(hit && p < maxout) out_ids[p] = (uint32_t)G.sorted_id[k];
+                    written += __popcll(m);
+                    if(written >= maxout) return maxout;
+                }
+            }
+        }
+    }
+    return written;
+}
+
+// filter_garrisoned, position.c:100-119: walk backwards, overwrite with the current last
+__device__ int filter_garrisoned_wave(const uint32_t *flags, uint32_t *ids, int count, int lane)
+{
+    bool any = false;
+    for(int base = 0; base < count; base += 64) {
+        int k = base + lane;
+        any |= (k < count) && (flags[ids[k]] & NAVHIP_ENTITY_FLAG_GARRISONED);
+    }
+    if(!__any(any)) return count;
+    int ret = count;
+    if(lane == 0) {
+        for(int i = count - 1; i >= 0; i--) {
+            if(flags[ids[i]] & NAVHIP_ENTITY_FLAG_GARRISONED) {
+                ids[i] = ids[ret - 1];
+                ret--;
+            }
+        }
+    }
+    wave_sync();
+    return __shfl(ret, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ClearPath (clearpath.c), one wave per problem
+// ---------------------------------------------------------------------------------------------
+struct cpent { v2 pos, vel; float radius; };
+struct ray   { v2 point, dir; };
+
+// C_InfiniteLineIntersection, collision.c:820 (including the l2.point term of the
+// vertical-l2 branch, :840)
+__device__ __forceinline__ bool line_isect(const ray &l1, const ray &l2, v2 &out)
+{
+    const float nanv = __builtin_nanf("");
+    float s1 = fabsf(l1.dir.x) < CP_EPS ? nanv : __fdiv_rn(l1.dir.z, l1.dir.x);
+    float s2 = fabsf(l2.dir.x) < CP_EPS ? nanv : __fdiv_rn(l2.dir.z, l2.dir.x);
+    bool n1 = s1 != s1, n2 = s2 != s2;
+    if(n1 && n2) return false;
+    if(fabsf(s1 - s2) < CP_EPS) return false;
+    if(n1 && !n2) {
+        out.x = l1.point.x;
+        out.z = (l1.point.x - l2.point.x) * s2 + l2.point.z;
+    }else if(!n1 && n2) {
+        out.x = l2.point.x;
+        out.z = (l2.point.x - l1.point.x) * s1 + l2.point.z;
+    }else{
+        out.x = __fdiv_rn((s1 * l1.point.x - s2 * l2.point.x + l2.point.z - l1.point.z), (s1 - s2));
+        out.z = s2 * (out.x - l2.point.x) + l2.point.z;
+    }
+    return true;
+}
+
+// C_RayRayIntersection2D, collision.c:854
+__device__ __forceinline__ bool ray_isect(const ray &l1, const ray &l2, v2 &out)
+{
+    v2 p;
+    if(!line_isect(l1, l2, p)) return false;
+    if(__fdiv_rn(p.x - l1.point.x, l1.dir.x) < 0.0f) return false;
+    if(__fdiv_rn(p.z - l1.point.z, l1.dir.z) < 0.0f) return false;
+    if(__fdiv_rn(p.x - l2.point.x, l2.dir.x) < 0.0f) return false;
+    if(__fdiv_rn(p.z - l2.point.z, l2.dir.z) < 0.0f) return false;
+    out = p;
+    return true;
+}
+
+// compute_vo_edges, clearpath.c:130
+__device__ __forceinline__ void vo_edges(const cpent &ent, const cpent &nb, v2 &out_right, v2 &out_left)
+{
+    v2 e2n = vnormal(vsub(nb.pos, ent.pos));
+    v2 right = mkv(-e2n.z, e2n.x);
+    right = vscale(right, nb.radius + ent.radius + 0.0f);      // CLEARPATH_BUFFER_RADIUS
+    v2 right_tangent = vadd(nb.pos, right);
+    v2 left_tangent = vsub(nb.pos, right);
+    out_right = vnormal(vsub(right_tangent, ent.pos));
+    out_left = vnormal(vsub(left_tangent, ent.pos));
+}
+
+// compute_vo :153 / compute_hrvo :180 -> (apex, left, right)
+__device__ __forceinline__ void make_vo(const cpent &ent, const cpent &nb, v2 &apex, v2 &left, v2 &right)
+{
+    vo_edges(ent, nb, right, left);
+    apex = vadd(ent.pos, nb.vel);
+}
+
+__device__ __forceinline__ void make_hrvo(const cpent &ent, const cpent &nb, v2 &apex, v2 &left, v2 &right)
+{
+    vo_edges(ent, nb, right, left);
+    v2 apex_off = vscale(vadd(ent.vel, nb.vel), 0.5f);
+    v2 rvo_apex = vadd(ent.pos, apex_off);
+    v2 centerline = vadd(left, right);
+    v2 vo_apex = vadd(ent.pos, nb.vel);
+    float det = (centerline.x * ent.vel.z) - (centerline.z * ent.vel.x);
+    if(det > CP_EPS) {
+        ray l1 = {rvo_apex, left}, l2 = {vo_apex, right};
+        v2 p = rvo_apex;
+        line_isect(l1, l2, p);
+        apex = p;
+    }else if(det < -CP_EPS) {
+        ray l1 = {rvo_apex, right}, l2 = {vo_apex, left};
+        v2 p = rvo_apex;
+        line_isect(l1, l2, p);
+        apex = p;
+    }else{
+        apex = rvo_apex;
+    }
+}
+
+// inside_pcr, clearpath.c:249.  rays[] live in LDS as float4 {point.x, point.z, dir.x, dir.z}.
+__device__ __forceinline__ bool inside_pcr(const float4 *rays, int n_rays, v2 test)
+{
+    for(int i = 0; i < n_rays; i += 2) {
+        float4 L = rays[i];
+        v2 ptt = mkv(test.x - L.x, test.z - L.y);
+        if(vlen(ptt) < CP_EPS) continue;
+        ptt = vnormal(ptt);
+        float left_det = (ptt.z * L.z) - (ptt.x * L.w);
+        if(left_det < CP_EPS) continue;
+        float4 R = rays[i + 1];
+        ptt = mkv(test.x - R.x, test.z - R.y);
+        if(vlen(ptt) < CP_EPS) continue;
+        ptt = vnormal(ptt);
+        float right_det = (ptt.z * R.z) - (ptt.x * R.w);
+        if(right_det > -CP_EPS) continue;
+        return true;
+    }
+    return false;
+}
+
+// lexicographic (key, idx) wave arg-min; key = +inf means "no candidate"
+__device__ __forceinline__ void wave_argmin(float &key, int &idx)
+{
+#pragma unroll
+    for(int d = 32; d >= 1; d >>= 1) {
+        float ok = __shfl_xor(key, d);
+        int   oi = __shfl_xor(idx, d);
+        bool take = (ok < key) || (ok == key && oi < idx);
+        if(take) { key = ok; idx = oi; }
+    }
+}
+
+// G_ClearPath_NewVelocity (clearpath.c:694) for one agent on one wave.
+// dyn/stat: LDS arrays of 5 floats per neighbour (order matters); rays: LDS scratch, 128 float4.
+__device__ v2 clearpath_wave(const cpent &ent, v2 des_v, float *dyn, int n_dyn, float *stat,
+                             int n_stat, float4 *rays, int lane)
+{
+    // at most 64 neighbours can be removed; the bound only guards against a NaN-poisoned input
+    for(int guard = 0; guard < 66; guard++) {
+        // ---- HRVOs for dynamic, VOs for static neighbours -> rays (rays_repr :291) -----------
+        // lanes 0..31 dynamic, 32..63 static; same_position neighbours are skipped (:216-246)
+        bool isdyn = lane < 32;
+        int  k = isdyn ? lane : lane - 32;
+        bool have = isdyn ? (k < n_dyn) : (k < n_stat);
+        cpent nb; nb.pos = mkv(0, 0); nb.vel = mkv(0, 0); nb.radius = 0;
+        if(have) {
+            const float *src = (isdyn ? dyn : stat) + 5 * k;
+            nb.pos = mkv(src[0], src[1]); nb.vel = mkv(src[2], src[3]); nb.radius = src[4];
+        }
+        bool use = have && !(vlen(vsub(nb.pos, ent.pos)) < CP_EPS);
+        v2 apex = mkv(0, 0), left = mkv(0, 0), right = mkv(0, 0);
+        if(use) {
+            if(isdyn) make_hrvo(ent, nb, apex, left, right);
+            else      make_vo(ent, nb, apex, left, right);
+        }
+        uint64_t m = __ballot(use);
+        int slot = __popcll(m & ((1ull << lane) - 1ull));      // hrvos first, then vos, in order
+        int n_cones = __popcll(m);
+        int n_rays = 2 * n_cones;
+        wave_sync();
+        if(use) {
+            rays[2 * slot]     = make_float4(apex.x, apex.z, left.x, left.z);
+            rays[2 * slot + 1] = make_float4(apex.x, apex.z, right.x, right.z);
+        }
+        wave_sync();
+
+        v2 des_ws = vadd(ent.pos, des_v);
+        if(!inside_pcr(rays, n_rays, des_ws))                  // wave-uniform inputs
+            return des_v;
+
+        // ---- candidate points: ray-pair intersections (i-major, :321) then projections (:344)
+        float best = __builtin_inff();
+        int   best_idx = 0x7fffffff;
+        v2    best_pt = mkv(0, 0);
+        bool  any_pt = false;
+        const int npairs = n_rays * n_rays;
+        for(int p0 = 0; p0 < npairs; p0 += 64) {
+            int p = p0 + lane;
+            if(p < npairs) {
+                int i = p / n_rays, j = p - i * n_rays;
+                if(i != j) {
+                    float4 a = rays[i], b = rays[j];
+                    ray ri = {mkv(a.x, a.y), mkv(a.z, a.w)}, rj = {mkv(b.x, b.y), mkv(b.z, b.w)};
+                    v2 pt;
+                    if(ray_isect(ri, rj, pt) && !inside_pcr(rays, n_rays, pt)) {
+                        any_pt = true;
+                        v2 curr = vsub(pt, ent.pos);
+                        float len = vlen(vsub(des_v, curr));
+                        if(len < best) { best = len; best_idx = p; best_pt = curr; }
+                    }
+                }
+            }
+        }
+        for(int i0 = 0; i0 < n_rays; i0 += 64) {
+            int i = i0 + lane;
+            if(i < n_rays) {
+                float4 a = rays[i];
+                v2 dir = mkv(a.z, a.w), point = mkv(a.x, a.y);
+                float len = vdot(dir, des_v);
+                v2 proj = vadd(point, vscale(dir, len));
+                if(!inside_pcr(rays, n_rays, proj)) {
+                    any_pt = true;
+                    v2 curr = vsub(proj, ent.pos);
+                    float l2 = vlen(vsub(des_v, curr));
+                    if(l2 < best) { best = l2; best_idx = npairs + i; best_pt = curr; }
+                }
+            }
+        }
+        if(__any(any_pt)) {
+            // compute_vnew :368: first strictly-smaller distance wins, i.e. min (len, order index)
+            float key = best; int idx = best_idx;
+            wave_argmin(key, idx);
+            if(!(key < __builtin_inff())) return mkv(0.0f, 0.0f);   // only NaN distances: ret stays 0
+            int owner = __ffsll((unsigned long long)__ballot(best_idx == idx && best == key)) - 1;
+            return mkv(__shfl(best_pt.x, owner), __shfl(best_pt.z, owner));
+        }
+
+        // ---- no admissible point: remove_furthest (:390) and retry while both lists non-empty
+        float dist = -__builtin_inff();
+        int   ord = 0x7fffffff;                 // dyn entries precede stat entries in the scan
+        if(have) {
+            dist = vlen(vsub(ent.pos, nb.pos));
+            ord = isdyn ? k : 32 + k;
+        }
+        // first strict maximum in scan order == min over (-dist, ord)
+        float nk = -dist; int ni = ord;
+        if(!have || !(dist == dist)) { nk = __builtin_inff(); }   // NaN never passes `len > max_dist`
+        wave_argmin(nk, ni);
+        wave_sync();
+        if(nk < __builtin_inff() && lane == 0) {
+            if(ni < 32) { n_dyn--;  for(int q = 0; q < 5; q++) dyn[5 * ni + q] = dyn[5 * n_dyn + q]; }
+            else        { int s = ni - 32; n_stat--; for(int q = 0; q < 5; q++) stat[5 * s + q] = stat[5 * n_stat + q]; }
+        }
+        wave_sync();
+        n_dyn = __shfl(n_dyn, 0);
+        n_stat = __shfl(n_stat, 0);
+        if(!(n_dyn > 0 && n_stat > 0))
+            return mkv(0.0f, 0.0f);
+    }
+    return mkv(0.0f, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cohesion_force (movement.c:1653): one thread per flock member
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool state_is_still(int s)
+{
+    return s == NAVHIP_STATE_ARRIVED || s == NAVHIP_STATE_WAITING;     // ent_still, movement.c:652
+}
+__device__ __forceinline__ bool state_uses_point_seek(int s)
+{
+    return s == NAVHIP_STATE_MOVING || s == NAVHIP_STATE_SURROUND_ENTITY
+        || s == NAVHIP_STATE_ENTER_ENTITY_RANGE;
+}
+
+__global__ __launch_bounds__(256) void k_cohesion(nh_step_params P, float *coh_xz)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int total = P.flock_offsets[P.n_flocks];
+    if(g >= total) return;
+    // flock of entry g: binary search over the CSR offsets
+    int lo = 0, hi = P.n_flocks;
+    while(hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if(P.flock_offsets[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int uid = P.flock_members[g];
+    if(!state_uses_point_seek(P.state[uid]) || (P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD))
+        return;
+    const int b = P.flock_offsets[lo], e = P.flock_offsets[lo + 1];
+    const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+    const float scaled_max_force = (float)((double)(0.75f / (float)P.hz) * 20.0);
+
+    v2 com = mkv(0.0f, 0.0f);
+    int count = 0;
+    for(int j = b; j < e; j++) {
+        int curr = P.flock_members[j];
+        if(curr == uid) continue;
+        v2 cp = mkv(P.pos_xz[2 * curr], P.pos_xz[2 * curr + 1]);
+        v2 diff = vsub(cp, me);
+        // float t = (len - 50.0f*0.75) / 50.0f   evaluated in double, rounded to float
+        float t = (float)(((double)vlen(diff) - (double)50.0f * 0.75) / (double)50.0f);
+        float scale = (float)exp((double)(-6.0f * t));
+        cp = vscale(cp, scale);
+        com = vadd(com, cp);
+        count++;
+    }
+    v2 ret = mkv(0.0f, 0.0f);
+    if(count > 0) {
+        com = vscale(com, 1.0f / (float)count);
+        ret = vtrunc(vsub(com, me), scaled_max_force);
+    }
+    coh_xz[2 * uid] = ret.x;
+    coh_xz[2 * uid + 1] = ret.z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_agent_step: one wave per entity
+// ---------------------------------------------------------------------------------------------
+#define AG_WAVES 4
+struct wave_lds {
+    uint32_t ids30[128];                       // separation query result (cap 128, :1695)
+    union {
+        uint32_t ids10[512];                   // ClearPath neighbour query result (cap 512, :2779)
+        float4   rays[128];                    // later: the combined obstacle as rays
+        float    sep[256];                     // earlier: separation terms x[128], z[128]
+    } u;
+    float dyn[32 * 5];
+    float stat[32 * 5];
+};
+
+// separation_force, movement.c:1690.  ids30/n30 already gathered; wave-uniform result.
+__device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_radius,
+                              uint32_t my_flags, const uint32_t *ids30, int n30, float *sep,
+                              float scaled_max_force, int lane)
+{
+    if(n30 == 0) return mkv(0.0f, 0.0f);
+    for(int base = 0; base < n30; base += 64) {
+        int k = base + lane;
+        if(k < n30) {
+            uint32_t curr = ids30[k];
+            uint32_t fl = P.flags[curr];
+            v2 term = mkv(0.0f, 0.0f);
+            bool skip = (curr == (uint32_t)uid) || !(fl & NAVHIP_ENTITY_FLAG_MOVABLE)
+                     || ((my_flags & NAVHIP_ENTITY_FLAG_AIR) != (fl & NAVHIP_ENTITY_FLAG_AIR));
+            if(!skip) {
+                v2 cp = mkv(P.pos_xz[2 * curr], P.pos_xz[2 * curr + 1]);
+                float radius = my_radius + P.radius[curr] + 0.0f;          // SEPARATION_BUFFER_DIST
+                v2 diff = vsub(cp, me);
+                float len = vlen(diff);
+                if(!(len < CP_EPS)) {
+                    float t = __fdiv_rn(len - radius * 0.85f, len);
+                    float scale = (float)exp((double)fminf(-20.0f * t, 40.0f));
+                    term = vscale(diff, scale);
+                }
+            }
+            sep[k] = term.x;
+            sep[128 + k] = term.z;
+        }
+    }
+    wave_sync();
+    // ret += diff, strictly in candidate order (every lane evaluates the same chain)
+    v2 ret = mkv(0.0f, 0.0f);
+    for(int k = 0; k < n30; k++)
+        ret = vadd(ret, mkv(sep[k], sep[128 + k]));
+    wave_sync();
+    ret = vscale(ret, -1.0f);
+    return vtrunc(ret, scaled_max_force);
+}
+
+// arrive_force_point, movement.c:1546
+__device__ __forceinline__ v2 arrive_force(v2 me, v2 vel, v2 target, v2 vdes, bool los,
+                                           float max_speed, int hz, float scaled_max_force)
+{
+    v2 desired;
+    if(los) {
+        desired = vsub(target, me);
+        float distance = vlen(desired);
+        desired = vnormal(desired);
+        desired = vscale(desired, max_speed / (float)hz);
+        if(distance < 10.0f)
+            desired = vscale(desired, distance / 10.0f);
+    }else{
+        desired = vscale(vdes, max_speed / (float)hz);
+    }
+    return vtrunc(vsub(desired, vel), scaled_max_force);
+}
+
+// nullify_impass_components, movement.c:1831
+__device__ __forceinline__ v2 nullify_impass(const nh_step_params &P, int layer, v2 pos, v2 f)
+{
+    bool on_blocked = pos_blocked(P, layer, pos.x, pos.z);
+    if(f.x > 0 && (!pos_pathable(P, layer, pos.x + 4.0f, pos.z)
+               || (!on_blocked && pos_blocked(P, layer, pos.x + 4.0f, pos.z)))) f.x = 0.0f;
+    if(f.x < 0 && (!pos_pathable(P, layer, pos.x - 4.0f, pos.z)
+               || (!on_blocked && pos_blocked(P, layer, pos.x - 4.0f, pos.z)))) f.x = 0.0f;
+    if(f.z > 0 && (!pos_pathable(P, layer, pos.x, pos.z + 4.0f)
+               || (!on_blocked && pos_blocked(P, layer, pos.x, pos.z + 4.0f)))) f.z = 0.0f;
+    if(f.z < 0 && (!pos_pathable(P, layer, pos.x, pos.z - 4.0f)
+               || (!on_blocked && pos_blocked(P, layer, pos.x, pos.z - 4.0f)))) f.z = 0.0f;
+    return f;
+}
+
+// find_neighbours, movement.c:2768: classify the r=10 query result into dynamic / static lists
+__device__ void classify_neighbours(const nh_step_params &P, int uid, uint32_t my_flags,
+                                    const uint32_t *ids10, int n10, float *dyn, int &n_dyn,
+                                    float *stat, int &n_stat, int lane)
+{
+    n_dyn = 0; n_stat = 0;
+    for(int base = 0; base < n10; base += 64) {
+        int k = base + lane;
+        int cls = 0;                              // 0 skip, 1 dynamic, 2 static
+        float rec[5] = {0, 0, 0, 0, 0};
+        if(k < n10) {
+            uint32_t curr = ids10[k];
+            uint32_t fl = P.flags[curr];
+            float rad = P.radius[curr];
+            bool skip = (curr == (uint32_t)uid) || !(fl & NAVHIP_ENTITY_FLAG_MOVABLE) || (rad == 0.0f)
+                     || ((my_flags & NAVHIP_ENTITY_FLAG_AIR) != (fl & NAVHIP_ENTITY_FLAG_AIR));
+            if(!skip) {
+                v2 vel = mkv(P.vel_xz[2 * curr], P.vel_xz[2 * curr + 1]);
+                rec[0] = P.pos_xz[2 * curr]; rec[1] = P.pos_xz[2 * curr + 1];
+                rec[4] = rad;
+                if(state_is_still(P.state[curr]) || vlen(vel) < 0.3f) {   // CLEARPATH_STILL_SPEED
+                    cls = 2;                       // static: velocity forced to zero (:2817)
+                }else{
+                    cls = 1;
+                    rec[2] = vel.x; rec[3] = vel.z;
+                }
+            }
+        }
+        uint64_t md = __ballot(cls == 1), ms = __ballot(cls == 2);
+        uint64_t lt = (1ull << lane) - 1ull;
+        if(cls == 1) {
+            int p = n_dyn + __popcll(md & lt);
+            if(p < 32) { for(int q = 0; q < 5; q++) dyn[5 * p + q] = rec[q]; }     // MAX_NEIGHBOURS
+        }else if(cls == 2) {
+            int p = n_stat + __popcll(ms & lt);
+            if(p < 32) { for(int q = 0; q < 5; q++) stat[5 * p + q] = rec[q]; }
+        }
+        n_dyn = min(32, n_dyn + __popcll(md));
+        n_stat = min(32, n_stat + __popcll(ms));
+    }
+    wave_sync();
+}
+
+__global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const float *coh_xz,
+                                                    nh_step_outs O)
+{
+    __shared__ wave_lds lds[AG_WAVES];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int uid = blockIdx.x * AG_WAVES + wib;
+    if(uid >= P.n_ents) return;
+    wave_lds &W = lds[wib];
+
+    const int state = P.state[uid];
+    const uint32_t my_flags = P.flags[uid];
+    const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+    const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+    const float my_radius = P.radius[uid];
+    const float max_speed = P.max_speed[uid];
+    const float speed = P.speed[uid];
+    const int flock = P.flock[uid];
+    const int hz = P.hz;
+    uint32_t status = 0;
+    v2 out_vel = mkv(0.0f, 0.0f), vdes = mkv(0.0f, 0.0f), vpref = mkv(0.0f, 0.0f);
+    bool active = !state_is_still(state);
+
+    if(active && !(my_flags & NAVHIP_ENTITY_FLAG_COMBAT_HELD)) {
+        const float scaled_max_force = (float)((double)(0.75f / (float)hz) * 20.0);   // SCALED_MAX_FORCE
+        const double force_thresh = ((double)(0.75f / (float)hz) * 20.0) * 0.01;
+        const int layer = nav_layer_for(my_flags, my_radius);
+        bool supported = true;
+
+        if(state == NAVHIP_STATE_TURNING) {
+            vpref = mkv(0.0f, 0.0f);
+        }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_uses_point_seek(state)) {
+            const bool point_seek = state_uses_point_seek(state);
+            if(P.vdes_xz) vdes = mkv(P.vdes_xz[2 * uid], P.vdes_xz[2 * uid + 1]);
+            else          vdes = sample_flow(P, flock, me, status);
+
+            // separation (used by priority 0 and 1): r = 30 query, cap 128
+            int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane);
+            wave_sync();
+            n30 = filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
+            const v2 separation = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
+                                                  W.u.sep, scaled_max_force, lane);
+            v2 steer;
+            if(point_seek) {
+                const bool los = P.has_dest_los[uid] != 0;
+                const v2 target = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1])
+                                               : me;
+                const v2 arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
+                const v2 cohesion = (flock >= 0) ? mkv(coh_xz[2 * uid], coh_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
+                // point_seek_vpref :1870, priorities 0..2
+                for(int prio = 0; prio < 3; prio++) {
+                    if(prio == 0) {
+                        v2 a = vscale(arrive, 0.5f), c = vscale(cohesion, 0.15f), s = vscale(separation, 0.6f);
+                        v2 ret = mkv(0.0f, 0.0f);
+                        ret = vadd(ret, a); ret = vadd(ret, s); ret = vadd(ret, c);
+                        steer = vtrunc(ret, scaled_max_force);
+                    }else if(prio == 1) {
+                        steer = separation;
+                    }else{
+                        steer = arrive;
+                    }
+                    steer = nullify_impass(P, layer, me, steer);
+                    if((double)vlen(steer) > force_thresh) break;
+                }
+            }else{
+                // enemy_seek_vpref :1946 (no priorities, no nullify)
+                v2 desired = vscale(vdes, max_speed / (float)hz);
+                v2 arrive = vtrunc(vsub(desired, vel), scaled_max_force);
+                v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
+                v2 ret = mkv(0.0f, 0.0f);
+                ret = vadd(ret, a); ret = vadd(ret, s);
+                steer = vtrunc(ret, scaled_max_force);
+            }
+            v2 accel = vscale(steer, 1.0f / 1.0f);
+            vpref = vtrunc(vadd(vel, accel), speed / (float)hz);
+        }else{
+            supported = false;                      // formation states stay on the host path
+            status |= NAVHIP_ST_UNSUPPORTED;
+        }
+
+        if(supported) {
+            // find_neighbours :2768: r = 10 query, cap 512
+            int n10 = sp_query_wave(P.grid, me.x, me.z, 10.0f, 512, W.u.ids10, lane);
+            wave_sync();
+            n10 = filter_garrisoned_wave(P.flags, W.u.ids10, n10, lane);
+            int n_dyn, n_stat;
+            classify_neighbours(P, uid, my_flags, W.u.ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
+            cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
+            v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, W.u.rays, lane);
+            out_vel = vtrunc(nv, max_speed / (float)hz);                   // :3464
+        }
+    }
+
+    // position accept test, entity_compute_update :2336-2358 (heading gate stays on the host)
+    v2 new_pos = me;
+    if(active) {
+        const int layer = nav_layer_for(my_flags, my_radius);
+        v2 cand = vadd(me, out_vel);
+        bool on_blocked = pos_blocked(P, layer, me.x, me.z);
+        if(vlen(out_vel) > 0 && pos_pathable(P, layer, cand.x, cand.z)
+        && (on_blocked || !pos_blocked(P, layer, cand.x, cand.z))) {
+            new_pos = cand;
+            status |= NAVHIP_ST_MOVED;
+        }
+    }
+    if(lane == 0) {
+        O.vel_xz[2 * uid] = out_vel.x; O.vel_xz[2 * uid + 1] = out_vel.z;
+        if(O.new_pos_xz) { O.new_pos_xz[2 * uid] = new_pos.x; O.new_pos_xz[2 * uid + 1] = new_pos.z; }
+        if(O.vdes_xz)  { O.vdes_xz[2 * uid] = vdes.x;  O.vdes_xz[2 * uid + 1] = vdes.z; }
+        if(O.vpref_xz) { O.vpref_xz[2 * uid] = vpref.x; O.vpref_xz[2 * uid + 1] = vpref.z; }
+        if(O.status) O.status[uid] = (uint8_t)status;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// test / utility kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spatial_query(nh_grid G, const float *query_xz, int nq,
+                                                       float range, int maxout, int32_t *out_counts,
+                                                       uint32_t *out_ids)
+{
+    const int q = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if(q >= nq) return;
+    int n = sp_query_wave(G, query_xz[2 * q], query_xz[2 * q + 1], range, maxout,
+                          out_ids + (size_t)q * maxout, lane);
+    if(lane == 0) out_counts[q] = n;
+}
+
+__global__ __launch_bounds__(256) void k_clearpath(int nq, const float *ent, const float *des_v,
+                                                   const float *dyn, const int32_t *n_dyn,
+                                                   const float *stat, const int32_t *n_stat,
+                                                   float *out)
+{
+    __shared__ wave_lds lds[AG_WAVES];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * AG_WAVES + wib;
+    if(q >= nq) return;
+    wave_lds &W = lds[wib];
+    for(int i = lane; i < 160; i += 64) {
+        W.dyn[i] = dyn[(size_t)q * 160 + i];
+        W.stat[i] = stat[(size_t)q * 160 + i];
+    }
+    wave_sync();
+    cpent e; e.pos = mkv(ent[5 * q], ent[5 * q + 1]); e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]);
+    e.radius = ent[5 * q + 4];
+    v2 r = clearpath_wave(e, mkv(des_v[2 * q], des_v[2 * q + 1]), W.dyn, n_dyn[q], W.stat, n_stat[q],
+                          W.u.rays, lane);
+    if(lane == 0) { out[2 * q] = r.x; out[2 * q + 1] = r.z; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
+                             hipStream_t s)
+{
+    const int n = G.n, ncells = G.grid_w * G.grid_h;
+    hipMemsetAsync(S.cell_count, 0, sizeof(int32_t) * (size_t)ncells, s);
+    hipMemsetAsync(S.cell_fill, 0, sizeof(int32_t) * (size_t)ncells, s);
+    if(n > 0)
+        hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
+                           S.ent_ix, S.ent_iy, S.ent_cell, S.cell_count);
+    hipLaunchKernelGGL(k_sp_scan, dim3(1), dim3(1024), 0, s, S.cell_count, S.cell_start, ncells);
+    if(n > 0)
+        hipLaunchKernelGGL(k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, S.ent_cell, n,
+                           S.cell_start, S.cell_fill, S.sorted_id);
+    hipLaunchKernelGGL(k_sp_order, dim3((ncells + 255) / 256), dim3(256), 0, s, S.cell_start, ncells,
+                       S.sorted_id, S.ent_ix, S.ent_iy, S.sx, S.sy);
+}
+
+void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const nh_step_outs &O, hipStream_t s)
+{
+    const int n = P.n_ents;
+    if(n <= 0) return;
+    if(P.n_flocks > 0)
+        hipLaunchKernelGGL(k_cohesion, dim3((n + 255) / 256), dim3(256), 0, s, P, d_coh);
+    hipLaunchKernelGGL(k_agent_step, dim3((n + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, P, d_coh, O);
+}
+
+void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,
+                             int32_t *d_counts, uint32_t *d_ids, hipStream_t s)
+{
+    if(nq > 0)
+        hipLaunchKernelGGL(k_spatial_query, dim3((nq + 3) / 4), dim3(256), 0, s, G, d_query, nq, range,
+                           maxout, d_counts, d_ids);
+}
+
+void nh_launch_clearpath(int nq, const float *ent, const float *des_v, const float *dyn,
+                         const int32_t *n_dyn, const float *stat, const int32_t *n_stat, float *out,
+                         hipStream_t s)
+{
+    if(nq > 0)
+        hipLaunchKernelGGL(k_clearpath, dim3((nq + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, nq, ent,
+                           des_v, dyn, n_dyn, stat, n_stat, out);
+}

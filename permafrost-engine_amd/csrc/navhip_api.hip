@@ -11,6 +11,8 @@
 //   passmask      u64 [chunks][64]           derived: row bitmasks of field_tile_passable
 //   unit_cost     u8  [chunks]               derived: BFS kernel eligibility
 #include "navhip_internal.h"
+#include "agent_internal.h"
+#include <cmath>
 
 #include <cstdio>
 #include <cstdlib>
@@ -84,6 +86,9 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->d_integ = nullptr; ctx->d_integ_cap = 0;
     ctx->d_reqmask = nullptr; ctx->d_reqmask_cap = 0;
     ctx->d_dirty_list = nullptr; ctx->d_dirty_cap = 0;
+    memset(ctx->sp, 0, sizeof(ctx->sp));
+    memset(&ctx->coh, 0, sizeof(ctx->coh));
+    memset(ctx->stage, 0, sizeof(ctx->stage));
     if(hipSetDevice(device) != hipSuccess
     || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -106,6 +111,9 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     }
     hipFree(ctx->d_reqs); hipFree(ctx->d_dirs); hipFree(ctx->d_integ); hipFree(ctx->d_reqmask);
     hipFree(ctx->d_dirty_list);
+    for(auto &b : ctx->sp) hipFree(b.p);
+    for(auto &b : ctx->stage) hipFree(b.p);
+    hipFree(ctx->coh.p);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -307,6 +315,225 @@ int navhip_build_fields(navhip_ctx *ctx, const navhip_field_req *reqs, int n,
     if(out_integ)
         HIPCHK(ctx, hipMemcpyAsync(out_integ, ctx->d_integ, (size_t)n * NH_CELLS * sizeof(float),
                                    hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// agent step
+// ---------------------------------------------------------------------------------------------
+static int ensure_buf(navhip_ctx *ctx, navhip_ctx::buf &b, size_t need)
+{
+    return ensure_cap(ctx, &b.p, &b.cap, need ? need : 16);
+}
+
+// bg_<name>_init geometry, bitmap_grid.h:959-990
+static bool grid_geometry(const navhip_world *w, nh_grid *g)
+{
+    int32_t ox = (int32_t)lrintf(w->grid_xmin * 256.0f), oy = (int32_t)lrintf(w->grid_zmin * 256.0f);
+    int32_t span_x = (int32_t)lrintf(w->grid_xmax * 256.0f) - ox;
+    int32_t span_y = (int32_t)lrintf(w->grid_zmax * 256.0f) - oy;
+    if(span_x <= 0 || span_y <= 0) return false;
+    g->origin_x = ox; g->origin_y = oy;
+    g->grid_w = (int)(((uint32_t)span_x + 4095u) >> 12);
+    g->grid_h = (int)(((uint32_t)span_y + 4095u) >> 12);
+    if(g->grid_w < 1) g->grid_w = 1;
+    if(g->grid_h < 1) g->grid_h = 1;
+    return true;
+}
+
+static void fill_map_view(const navhip_ctx *ctx, nh_map_view *mv)
+{
+    mv->w = ctx->w; mv->h = ctx->h;
+    for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
+        const navhip_layer &L = ctx->layers[l];
+        mv->layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
+                                      L.passmask, L.unit_cost};
+    }
+}
+
+static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hipStream_t s)
+{
+    if(!grid_geometry(w, g)) {
+        ctx->last_error = "agent step: empty spatial-grid bounds";
+        return NAVHIP_ERR_INVALID;
+    }
+    const size_t n = (size_t)w->n_ents, ncells = (size_t)g->grid_w * g->grid_h;
+    const size_t sizes[9] = {n, n, n, ncells, ncells, ncells + 1, n, n, n};
+    for(int i = 0; i < 9; i++) {
+        int rc = ensure_buf(ctx, ctx->sp[i], sizes[i] * sizeof(int32_t));
+        if(rc) return rc;
+    }
+    nh_spatial_scratch S = {(int32_t*)ctx->sp[0].p, (int32_t*)ctx->sp[1].p, (int32_t*)ctx->sp[2].p,
+                            (int32_t*)ctx->sp[3].p, (int32_t*)ctx->sp[4].p, (int32_t*)ctx->sp[5].p,
+                            (int32_t*)ctx->sp[6].p, (int32_t*)ctx->sp[7].p, (int32_t*)ctx->sp[8].p};
+    g->n = w->n_ents;
+    g->cell_start = S.cell_start; g->sorted_id = S.sorted_id; g->sx = S.sx; g->sy = S.sy;
+    nh_launch_spatial_build(*g, w->pos_xz, S, s);
+    return NAVHIP_OK;
+}
+
+int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_step_out *out,
+                          void *stream)
+{
+    if(!ctx || !w || !out || w->n_ents < 0 || !out->vel_xz
+    || (w->hz != 20 && w->hz != 10 && w->hz != 5 && w->hz != 1))
+        return NAVHIP_ERR_INVALID;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    if(!w->pos_xz || !w->vel_xz || !w->radius || !w->max_speed || !w->speed || !w->flags
+    || !w->state || !w->has_dest_los || !w->flock
+    || (w->n_flocks > 0 && (!w->flock_target_xz || !w->flock_offsets || !w->flock_members)))
+        return NAVHIP_ERR_INVALID;
+    if(!ctx->layers[0].cost && !ctx->layers[4].cost && !ctx->layers[8].cost) {
+        ctx->last_error = "agent step: no cost_base plane uploaded";
+        return NAVHIP_ERR_NOT_UPLOADED;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+
+    nh_step_params P;
+    memset(&P, 0, sizeof(P));
+    fill_map_view(ctx, &P.map);
+    int rc = spatial_build(ctx, w, &P.grid, s);
+    if(rc) return rc;
+    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
+    if(rc) return rc;
+    P.map_x = w->map_pos_x; P.map_z = w->map_pos_z;
+    P.n_ents = w->n_ents; P.n_flocks = w->n_flocks; P.hz = w->hz;
+    P.pos_xz = w->pos_xz; P.vel_xz = w->vel_xz; P.radius = w->radius; P.max_speed = w->max_speed;
+    P.speed = w->speed; P.flags = w->flags; P.state = w->state; P.has_dest_los = w->has_dest_los;
+    P.flock = w->flock; P.vdes_xz = w->vdes_xz; P.flock_target_xz = w->flock_target_xz;
+    P.flock_offsets = w->flock_offsets; P.flock_members = w->flock_members;
+    P.flock_field_slot = w->flock_field_slot; P.field_pool = w->field_pool;
+    nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
+    nh_launch_agent_step(P, (float*)ctx->coh.p, O, s);
+    HIPCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+// copy a host array to a staging buffer; returns device pointer through *dst (NULL stays NULL)
+static int stage_in(navhip_ctx *ctx, int slot, const void *host, size_t bytes, const void **dst,
+                    hipStream_t s)
+{
+    *dst = nullptr;
+    if(!host) return NAVHIP_OK;
+    int rc = ensure_buf(ctx, ctx->stage[slot], bytes);
+    if(rc) return rc;
+    if(bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->stage[slot].p, host, bytes, hipMemcpyHostToDevice, s));
+    *dst = ctx->stage[slot].p;
+    return NAVHIP_OK;
+}
+
+static int stage_world(navhip_ctx *ctx, const navhip_world *w, navhip_world *d, hipStream_t s)
+{
+    *d = *w;
+    const size_t n = (size_t)w->n_ents, F = (size_t)w->n_flocks;
+    size_t nmembers = 0;
+    if(F > 0 && w->flock_offsets) nmembers = (size_t)w->flock_offsets[F];
+    const size_t nchunks = (size_t)ctx->nchunks;
+    int rc = 0;
+#define ST(slot, field, bytes) \
+    if(!rc) rc = stage_in(ctx, slot, w->field, (bytes), (const void**)&d->field, s)
+    ST(0, pos_xz, n * 8);        ST(1, vel_xz, n * 8);       ST(2, radius, n * 4);
+    ST(3, max_speed, n * 4);     ST(4, speed, n * 4);        ST(5, flags, n * 4);
+    ST(6, state, n);             ST(7, has_dest_los, n);     ST(8, flock, n * 4);
+    ST(9, vdes_xz, n * 8);       ST(10, flock_target_xz, F * 8);
+    ST(11, flock_offsets, (F + 1) * 4);                      ST(12, flock_members, nmembers * 4);
+    ST(13, flock_field_slot, F * nchunks * 4);
+    ST(14, field_pool, (size_t)w->n_field_slots * NH_CELLS);
+#undef ST
+    return rc;
+}
+
+int navhip_agent_step(navhip_ctx *ctx, const navhip_world *w, const navhip_step_out *out)
+{
+    if(!ctx || !w || !out || !out->vel_xz) return NAVHIP_ERR_INVALID;
+    if(w->n_ents <= 0) return w->n_ents == 0 ? NAVHIP_OK : NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    navhip_world d;
+    int rc = stage_world(ctx, w, &d, s);
+    if(rc) return rc;
+    const size_t n = (size_t)w->n_ents;
+    navhip_step_out dout = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    struct { void **dev; void *host; size_t bytes; int slot; } outs[5] = {
+        {(void**)&dout.vel_xz,     out->vel_xz,     n * 8, 15},
+        {(void**)&dout.new_pos_xz, out->new_pos_xz, n * 8, 16},
+        {(void**)&dout.vdes_xz,    out->vdes_xz,    n * 8, 17},
+        {(void**)&dout.vpref_xz,   out->vpref_xz,   n * 8, 18},
+        {(void**)&dout.status,     out->status,     n,     19}};
+    for(auto &o : outs) {
+        if(!o.host) continue;
+        rc = ensure_buf(ctx, ctx->stage[o.slot], o.bytes);
+        if(rc) return rc;
+        *o.dev = ctx->stage[o.slot].p;
+    }
+    rc = navhip_agent_step_dev(ctx, &d, &dout, s);
+    if(rc) return rc;
+    for(auto &o : outs)
+        if(o.host) HIPCHK(ctx, hipMemcpyAsync(o.host, *o.dev, o.bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+int navhip_spatial_query(navhip_ctx *ctx, const navhip_world *w, const float *query_xz, int nq,
+                         float range, int maxout, int32_t *out_counts, uint32_t *out_ids)
+{
+    if(!ctx || !w || !w->pos_xz || w->n_ents < 0 || nq < 0 || maxout < 1 || !query_xz
+    || !out_counts || !out_ids)
+        return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    navhip_world d = *w;
+    int rc = stage_in(ctx, 0, w->pos_xz, (size_t)w->n_ents * 8, (const void**)&d.pos_xz, s);
+    if(rc) return rc;
+    const float *dq; 
+    rc = stage_in(ctx, 20, query_xz, (size_t)nq * 8, (const void**)&dq, s);
+    if(rc) return rc;
+    rc = ensure_buf(ctx, ctx->stage[21], (size_t)nq * 4);
+    if(rc) return rc;
+    rc = ensure_buf(ctx, ctx->stage[22], (size_t)nq * maxout * 4);
+    if(rc) return rc;
+    nh_grid g;
+    rc = spatial_build(ctx, &d, &g, s);
+    if(rc) return rc;
+    nh_launch_spatial_query(g, dq, nq, range, maxout, (int32_t*)ctx->stage[21].p,
+                            (uint32_t*)ctx->stage[22].p, s);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->stage[21].p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(out_ids, ctx->stage[22].p, (size_t)nq * maxout * 4,
+                               hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+int navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                     const float *dyn, const int32_t *n_dyn, const float *stat,
+                     const int32_t *n_stat, float *out)
+{
+    if(!ctx || nq < 0 || !ent || !des_v || !dyn || !n_dyn || !stat || !n_stat || !out)
+        return NAVHIP_ERR_INVALID;
+    if(nq == 0) return NAVHIP_OK;
+    for(int i = 0; i < nq; i++)
+        if(n_dyn[i] < 0 || n_dyn[i] > 32 || n_stat[i] < 0 || n_stat[i] > 32) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const void *d[6];
+    const void *h[6] = {ent, des_v, dyn, n_dyn, stat, n_stat};
+    const size_t b[6] = {(size_t)nq * 20, (size_t)nq * 8, (size_t)nq * 640, (size_t)nq * 4,
+                         (size_t)nq * 640, (size_t)nq * 4};
+    for(int i = 0; i < 6; i++) {
+        int rc = stage_in(ctx, i, h[i], b[i], &d[i], s);
+        if(rc) return rc;
+    }
+    int rc = ensure_buf(ctx, ctx->stage[15], (size_t)nq * 8);
+    if(rc) return rc;
+    nh_launch_clearpath(nq, (const float*)d[0], (const float*)d[1], (const float*)d[2],
+                        (const int32_t*)d[3], (const float*)d[4], (const int32_t*)d[5],
+                        (float*)ctx->stage[15].p, s);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage[15].p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;
 }

@@ -36,6 +36,12 @@ struct navhip_ctx {
     float       *d_integ;     size_t d_integ_cap;
     uint64_t    *d_reqmask;   size_t d_reqmask_cap;   // per-request passability rows
     uint32_t    *d_dirty_list; size_t d_dirty_cap;
+    // agent-step scratch (grown on demand, reused every tick)
+    struct buf { void *p; size_t cap; };
+    buf          sp[9];        // spatial hash: ent_ix, ent_iy, ent_cell, cell_count, cell_fill,
+                               //               cell_start, sorted_id, sx, sy
+    buf          coh;          // cohesion force per entity
+    buf          stage[24];    // device copies of host buffers for the host-pointer entry points
     std::string  last_error;
 };
 

@@ -186,3 +186,156 @@ def N_FlowFieldID(req):
     """N_FlowFieldID (field.c:1952) for one navhip_field_req record."""
     r = np.ascontiguousarray(np.asarray(req, dtype=FIELD_REQ_DTYPE).reshape(1))
     return int(lib().navhip_flow_field_id(_hp(r)))
+
+
+# ---------------------------------------------------------------------------------------------
+# per-agent movement step
+# ---------------------------------------------------------------------------------------------
+STATE_MOVING, STATE_MOVING_IN_FORMATION, STATE_ARRIVED, STATE_SEEK_ENEMIES, STATE_WAITING, \
+    STATE_SURROUND_ENTITY, STATE_ENTER_ENTITY_RANGE, STATE_TURNING, STATE_ARRIVING_TO_CELL = range(9)
+ENTITY_FLAG_MOVABLE = 1 << 3
+ENTITY_FLAG_WATER = 1 << 14
+ENTITY_FLAG_AIR = 1 << 15
+ENTITY_FLAG_GARRISONED = 1 << 18
+ENTITY_FLAG_COMBAT_HELD = 1 << 21
+ST_MOVED, ST_FIELD_MISS, ST_FIELD_NONE, ST_UNSUPPORTED = 0x01, 0x02, 0x04, 0x80
+
+
+class World(C.Structure):
+    """navhip_world, include/navhip.h"""
+    _fields_ = [
+        ("n_ents", C.c_int32), ("n_flocks", C.c_int32), ("hz", C.c_int32),
+        ("n_field_slots", C.c_int32),
+        ("pos_xz", C.c_void_p), ("vel_xz", C.c_void_p), ("radius", C.c_void_p),
+        ("max_speed", C.c_void_p), ("speed", C.c_void_p), ("flags", C.c_void_p),
+        ("state", C.c_void_p), ("has_dest_los", C.c_void_p), ("flock", C.c_void_p),
+        ("vdes_xz", C.c_void_p), ("flock_target_xz", C.c_void_p), ("flock_offsets", C.c_void_p),
+        ("flock_members", C.c_void_p), ("flock_field_slot", C.c_void_p), ("field_pool", C.c_void_p),
+        ("map_pos_x", C.c_float), ("map_pos_z", C.c_float),
+        ("grid_xmin", C.c_float), ("grid_xmax", C.c_float), ("grid_zmin", C.c_float),
+        ("grid_zmax", C.c_float)]
+
+
+class StepOut(C.Structure):
+    """navhip_step_out, include/navhip.h"""
+    _fields_ = [("vel_xz", C.c_void_p), ("new_pos_xz", C.c_void_p), ("vdes_xz", C.c_void_p),
+                ("vpref_xz", C.c_void_p), ("status", C.c_void_p)]
+
+
+_SIGS.update({
+    "navhip_agent_step": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut)]),
+    "navhip_agent_step_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut), C.c_void_p]),
+    "navhip_spatial_query": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p, C.c_int, C.c_float,
+                                       C.c_int, C.c_void_p, C.c_void_p]),
+    "navhip_clearpath": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+})
+
+_WORLD_ARRAYS = (
+    ("pos_xz", np.float32), ("vel_xz", np.float32), ("radius", np.float32),
+    ("max_speed", np.float32), ("speed", np.float32), ("flags", np.uint32), ("state", np.uint8),
+    ("has_dest_los", np.uint8), ("flock", np.int32), ("vdes_xz", np.float32),
+    ("flock_target_xz", np.float32), ("flock_offsets", np.int32), ("flock_members", np.int32),
+    ("flock_field_slot", np.int32), ("field_pool", np.uint8))
+
+
+def flock_csr(flock, n_flocks, order=None):
+    """CSR member lists from a per-entity flock index (members in ascending uid order unless
+    `order` -- a list of per-flock uid arrays, e.g. the reference's kh_foreach order -- is given)."""
+    flock = np.asarray(flock)
+    lists = order if order is not None else [np.flatnonzero(flock == f) for f in range(n_flocks)]
+    offs = np.zeros(n_flocks + 1, np.int32)
+    offs[1:] = np.cumsum([len(l) for l in lists])
+    members = np.concatenate(lists).astype(np.int32) if n_flocks else np.zeros(0, np.int32)
+    return offs, members
+
+
+def grid_bounds(chunk_w, chunk_h):
+    """bg_ent_init bounds the engine uses (position.c:276-283): the map, centred on the origin."""
+    hx, hz = chunk_w * 128.0, chunk_h * 128.0
+    return (-hx, hx, -hz, hz)
+
+
+def make_world(chunk_w, chunk_h, arrays, hz=20, xp=None):
+    """Build a navhip_world from a dict of numpy arrays (host form) or torch CUDA tensors
+    (device form).  Returns (World, keepalive)."""
+    w = World()
+    keep = {}
+    n = len(arrays["pos_xz"])
+    w.n_ents = n
+    w.n_flocks = len(arrays["flock_target_xz"]) if arrays.get("flock_target_xz") is not None else 0
+    w.hz = hz
+    for name, dt in _WORLD_ARRAYS:
+        a = arrays.get(name)
+        if a is None:
+            setattr(w, name, None)
+            continue
+        if hasattr(a, "data_ptr"):          # torch tensor on the GPU
+            keep[name] = a
+            setattr(w, name, a.data_ptr())
+        else:
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep[name] = a
+            setattr(w, name, a.ctypes.data)
+    fp = arrays.get("field_pool")
+    w.n_field_slots = 0 if fp is None else int(fp.shape[0])
+    w.map_pos_x = chunk_w * 128.0
+    w.map_pos_z = -chunk_h * 128.0
+    w.grid_xmin, w.grid_xmax, w.grid_zmin, w.grid_zmax = grid_bounds(chunk_w, chunk_h)
+    return w, keep
+
+
+def _ctx_agent_step(self, arrays, hz=20, want=("vel_xz", "new_pos_xz", "vdes_xz", "vpref_xz", "status")):
+    """Host-buffer velocity step: move_velocity_work (movement.c:3395) for every non-still entity.
+    arrays: dict of numpy arrays named after navhip_world members.  Returns dict of outputs."""
+    w, keep = make_world(self.w, self.h, arrays, hz)
+    n = w.n_ents
+    out = {}
+    so = StepOut()
+    for name in ("vel_xz", "new_pos_xz", "vdes_xz", "vpref_xz"):
+        if name in want or name == "vel_xz":
+            out[name] = np.zeros((n, 2), np.float32)
+            setattr(so, name, out[name].ctypes.data)
+    if "status" in want:
+        out["status"] = np.zeros(n, np.uint8)
+        so.status = out["status"].ctypes.data
+    self._chk(lib().navhip_agent_step(self._h, C.byref(w), C.byref(so)), "navhip_agent_step")
+    return out
+
+
+def _ctx_agent_step_dev(self, world, stepout, stream=None):
+    self._chk(lib().navhip_agent_step_dev(self._h, C.byref(world), C.byref(stepout),
+                                          C.c_void_p(stream) if stream else None),
+              "navhip_agent_step_dev")
+
+
+def _ctx_spatial_query(self, pos_xz, query_xz, rng, maxout):
+    """G_Pos_EntsInCircleFrom candidate lists (bitmap_grid.h:1376 order) for each query."""
+    w, keep = make_world(self.w, self.h, {"pos_xz": np.ascontiguousarray(pos_xz, np.float32)})
+    q = np.ascontiguousarray(query_xz, np.float32).reshape(-1, 2)
+    counts = np.zeros(len(q), np.int32)
+    ids = np.zeros((len(q), maxout), np.uint32)
+    self._chk(lib().navhip_spatial_query(self._h, C.byref(w), _hp(q), len(q), rng, maxout,
+                                         _hp(counts), _hp(ids)), "navhip_spatial_query")
+    return counts, ids
+
+
+def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat):
+    """G_ClearPath_NewVelocity (clearpath.c:694) for a batch of independent problems."""
+    ent = np.ascontiguousarray(ent, np.float32).reshape(-1, 5)
+    nq = len(ent)
+    des_v = np.ascontiguousarray(des_v, np.float32).reshape(nq, 2)
+    dyn = np.ascontiguousarray(dyn, np.float32).reshape(nq, 32, 5)
+    stat = np.ascontiguousarray(stat, np.float32).reshape(nq, 32, 5)
+    n_dyn = np.ascontiguousarray(n_dyn, np.int32)
+    n_stat = np.ascontiguousarray(n_stat, np.int32)
+    out = np.zeros((nq, 2), np.float32)
+    self._chk(lib().navhip_clearpath(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
+                                     _hp(stat), _hp(n_stat), _hp(out)), "navhip_clearpath")
+    return out
+
+
+NavContext.agent_step = _ctx_agent_step
+NavContext.agent_step_dev = _ctx_agent_step_dev
+NavContext.spatial_query = _ctx_spatial_query
+NavContext.G_ClearPath_NewVelocity = _ctx_clearpath
