@@ -183,6 +183,9 @@ typedef struct navhip_world {
     const uint8_t  *field_pool;      /* [slots][4096] flow fields (one dir_idx per byte)       */
     float    map_pos_x, map_pos_z;   /* vec3 map_pos .x/.z handed to every N_* call            */
     float    grid_xmin, grid_xmax, grid_zmin, grid_zmax;  /* bg_ent_init bounds, position.c:276-283 */
+    int32_t  work_begin, work_end;   /* the slab [begin,end) of uids this call computes (the index
+                                        slabs of move_submit_cpu_work, movement.c:3759-3762); every
+                                        entity still acts as a neighbour.  0,0 = all entities      */
 } navhip_world;
 
 typedef struct navhip_step_out {

@@ -311,9 +311,9 @@ double pfref_move_bench(const float *vdes, int begin, int end, int reps, int nth
     for(int i = begin; i < end; i++)
         set_vdes(vdes, i);
     if(nthreads < 1) nthreads = 1;
-    if(nthreads > 64) nthreads = 64;
-    pthread_t tids[64];
-    struct mbench_arg args[64];
+    if(nthreads > 256) nthreads = 256;
+    pthread_t tids[256];
+    struct mbench_arg args[256];
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     int n = end - begin;

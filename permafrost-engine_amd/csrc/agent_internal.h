@@ -24,6 +24,7 @@ struct nh_step_params {
     nh_grid     grid;
     float       map_x, map_z;
     int         n_ents, n_flocks, hz;
+    int         work_begin, work_end;
     const float    *pos_xz, *vel_xz, *radius, *max_speed, *speed;
     const uint32_t *flags;
     const uint8_t  *state, *has_dest_los;

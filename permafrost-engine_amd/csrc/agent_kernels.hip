@@ -630,6 +630,7 @@ __global__ __launch_bounds__(256) void k_cohesion(nh_step_params P, float *coh_x
         if(P.flock_offsets[mid] <= g) lo = mid; else hi = mid;
     }
     const int uid = P.flock_members[g];
+    if(uid < P.work_begin || uid >= P.work_end) return;
     if(!state_uses_point_seek(P.state[uid]) || (P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD))
         return;
     const int b = P.flock_offsets[lo], e = P.flock_offsets[lo + 1];
@@ -794,8 +795,8 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
 {
     __shared__ wave_lds lds[AG_WAVES];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int uid = blockIdx.x * AG_WAVES + wib;
-    if(uid >= P.n_ents) return;
+    const int uid = P.work_begin + blockIdx.x * AG_WAVES + wib;
+    if(uid >= P.work_end) return;
     wave_lds &W = lds[wib];
 
     const int state = P.state[uid];
@@ -964,7 +965,10 @@ void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const nh_step_o
     if(n <= 0) return;
     if(P.n_flocks > 0)
         hipLaunchKernelGGL(k_cohesion, dim3((n + 255) / 256), dim3(256), 0, s, P, d_coh);
-    hipLaunchKernelGGL(k_agent_step, dim3((n + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, P, d_coh, O);
+    const int nwork = P.work_end - P.work_begin;
+    if(nwork > 0)
+        hipLaunchKernelGGL(k_agent_step, dim3((nwork + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, P,
+                           d_coh, O);
 }
 
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,

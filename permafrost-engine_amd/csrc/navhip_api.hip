@@ -401,6 +401,10 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(rc) return rc;
     P.map_x = w->map_pos_x; P.map_z = w->map_pos_z;
     P.n_ents = w->n_ents; P.n_flocks = w->n_flocks; P.hz = w->hz;
+    P.work_begin = w->work_begin; P.work_end = w->work_end;
+    if(P.work_begin == 0 && P.work_end == 0) P.work_end = w->n_ents;
+    if(P.work_begin < 0 || P.work_end > w->n_ents || P.work_begin > P.work_end)
+        return NAVHIP_ERR_INVALID;
     P.pos_xz = w->pos_xz; P.vel_xz = w->vel_xz; P.radius = w->radius; P.max_speed = w->max_speed;
     P.speed = w->speed; P.flags = w->flags; P.state = w->state; P.has_dest_los = w->has_dest_los;
     P.flock = w->flock; P.vdes_xz = w->vdes_xz; P.flock_target_xz = w->flock_target_xz;

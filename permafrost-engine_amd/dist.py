@@ -1,0 +1,66 @@
+"""One-process-per-GPU sharding of the navigation tick.
+
+The path shards two ways, both along boundaries the reference already has:
+  * chunk-field requests are independent given the replicated cost/blockers planes
+    (the <=256 independent field_task jobs of nav.c:2049) -> contiguous request slices per rank;
+  * the velocity step is fork-joined over contiguous uid slabs (move_submit_cpu_work,
+    movement.c:3756-3762) -> one slab per rank, every rank holding the full position snapshot.
+There are exactly two exchange steps per tick, both all-gathers (no reductions):
+  * the baked 4 KB flow tiles, so any rank's agents can sample any field;
+  * the slab results (new position + velocity, 16 B per agent), so every rank starts the next
+    tick with the full snapshot.
+`backend="nccl"` is RCCL over xGMI on the MI355X node; the CPU test-suite runs the same code on
+`gloo` with world_size 2.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), \
+        int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def slab(n_items, rank, world):
+    """Contiguous [begin, end) share of n_items for `rank` (ceil split like movement.c:3759)."""
+    per = -(-n_items // world)
+    b = min(rank * per, n_items)
+    return b, min(b + per, n_items)
+
+
+def all_gather_rows(full, rank, world, rows_per_rank):
+    """In-place all-gather of equally sized row slabs of `full` ([world*rows_per_rank, ...]):
+    rank r contributes full[r*rows_per_rank:(r+1)*rows_per_rank] and receives the others."""
+    if world == 1:
+        return
+    mine = full[rank * rows_per_rank:(rank + 1) * rows_per_rank]
+    dist.all_gather_into_tensor(full, mine.contiguous())
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

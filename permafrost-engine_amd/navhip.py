@@ -213,7 +213,7 @@ class World(C.Structure):
         ("flock_members", C.c_void_p), ("flock_field_slot", C.c_void_p), ("field_pool", C.c_void_p),
         ("map_pos_x", C.c_float), ("map_pos_z", C.c_float),
         ("grid_xmin", C.c_float), ("grid_xmax", C.c_float), ("grid_zmin", C.c_float),
-        ("grid_zmax", C.c_float)]
+        ("grid_zmax", C.c_float), ("work_begin", C.c_int32), ("work_end", C.c_int32)]
 
 
 class StepOut(C.Structure):

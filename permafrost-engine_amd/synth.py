@@ -155,7 +155,7 @@ def whole_map_requests(grid, dests, liid=None):
     in the destination chunk, TARGET_PORTAL (towards the neighbouring chunk that is one step
     closer in chunk-BFS distance, through the portal nearest to the straight line) elsewhere
     ('each destination expands to all chunks of the map').
-    Returns a dict of equal-length int arrays keyed by REQ_FIELDS."""
+    Returns a dict of equal-length int arrays keyed by REQ_FIELDS, plus 'dest' (index into dests)."""
     from collections import deque
     h, w = grid.shape[0] // 64, grid.shape[1] // 64
     if liid is None:
@@ -165,13 +165,14 @@ def whole_map_requests(grid, dests, liid=None):
     for p in plist:
         by_pair.setdefault((p["a"], p["b"]), []).append((p["a_ep"], p["b_ep"]))
         by_pair.setdefault((p["b"], p["a"]), []).append((p["b_ep"], p["a_ep"]))
-    cols = {k: [] for k in REQ_FIELDS}
+    cols = {k: [] for k in REQ_FIELDS + ("dest",)}
 
     def push(**kw):
         for k in REQ_FIELDS:
             cols[k].append(kw.get(k, 0))
+        cols["dest"].append(di)
 
-    for (R, Cc) in np.asarray(dests):
+    for di, (R, Cc) in enumerate(np.asarray(dests)):
         dchunk = (int(R) // 64, int(Cc) // 64)
         dist = {dchunk: 0}
         q = deque([dchunk])

@@ -1,0 +1,170 @@
+"""The benchmark / demo driver of one navigation tick, everything resident in HBM.
+
+One tick = (1) rebuild every chunk field of this rank's share of the flow fields into the field
+pool, (2) [multi-GPU] all-gather the baked tiles, (3) velocity step + position accept for this
+rank's slab of agents, sampling the pool on the device, (4) [multi-GPU] all-gather the slab
+results, (5) advance the snapshot (pos <- new_pos, vel <- new velocity).  Nothing is cached
+between ticks: the worst case of the reference's tick, where every cached field was invalidated
+(N_ApplyDeferredInvalidations, nav.c:2208).
+
+PyTorch supplies device buffers, the stream and torch.distributed; all compute is libnavhip.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import dist as pdist
+from . import navhip, synth
+
+
+class NavTick:
+    def __init__(self, chunk_w=16, fields_per_rank=64, agents_per_rank=100_000, rank=0, world=1,
+                 device=0, hz=20, seed_map=1234, verbose=False):
+        self.rank, self.world, self.device_index = rank, world, device
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.W = chunk_w
+        self.nchunks = chunk_w * chunk_w
+        self.K = fields_per_rank * world            # flow fields (destinations) in the whole job
+        self.N = agents_per_rank * world            # agents in the whole job
+        self.hz = hz
+        t0 = time.time()
+
+        # ---- synthetic map + request stream, identical on every rank --------
+        grid = synth.cost_grid(chunk_w, chunk_w, seed=seed_map)
+        liid = synth.local_islands(grid)
+        dests = synth.destinations(grid, self.K, seed=42)
+        cols = synth.whole_map_requests(grid, dests, liid)
+        n_req = len(cols["type"])
+        reqs = navhip.make_reqs(n_req)
+        for k in synth.REQ_FIELDS:
+            reqs[k] = cols[k]
+        # requests are emitted destination-major: field slot = position in the stream
+        dest_of_req = cols["dest"]
+        self.n_req_total = n_req
+        self._dest_of_req = dest_of_req
+        slot_tbl = -np.ones((self.K, self.nchunks), np.int32)
+        slot_tbl[dest_of_req, cols["chunk_r"] * chunk_w + cols["chunk_c"]] = np.arange(n_req)
+        # this rank's slice of the request stream: whole destinations, contiguous
+        d0, d1 = pdist.slab(self.K, rank, world)
+        sel = np.flatnonzero((dest_of_req >= d0) & (dest_of_req < d1))
+        self.req_begin, self.req_end = (int(sel[0]), int(sel[-1]) + 1) if len(sel) else (0, 0)
+        self.n_req_local = self.req_end - self.req_begin
+        self.equal_req_slices = (n_req % world == 0) and self.n_req_local == n_req // world \
+            and self.req_begin == rank * (n_req // world)
+
+        ag = synth.agents(grid, self.N, self.K, seed=7, hz=hz)
+        offs, members = navhip.flock_csr(ag["flock"], self.K)
+        targets = synth.cell_centre(chunk_w, chunk_w, dests[:, 0], dests[:, 1])
+        self.a0, self.a1 = pdist.slab(self.N, rank, world)
+        self.grid = grid
+        self.map_cells = grid.size
+
+        # ---- device state ----------------------------------------------------------------------
+        self.ctx = navhip.NavContext(chunk_w, chunk_w, device=device)
+        self.ctx.upload_plane(0, navhip.PLANE_COST_BASE, synth.to_chunks(grid))
+        self.ctx.upload_plane(0, navhip.PLANE_BLOCKERS, np.zeros((chunk_w, chunk_w, 64, 64), np.uint16))
+        self.ctx.upload_plane(0, navhip.PLANE_LOCAL_ISLANDS, synth.to_chunks(liid))
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+
+        self.d_reqs = dev(reqs.view(np.uint8).reshape(n_req, 32))
+        self.pool = torch.zeros((n_req, 4096), dtype=torch.uint8, device=self.dev)
+        n = self.N
+        self.t = {
+            "pos_xz": dev(ag["pos"]), "vel_xz": dev(ag["vel"]), "radius": dev(ag["radius"]),
+            "max_speed": dev(ag["max_speed"]), "speed": dev(ag["speed"]),
+            "flags": dev(np.full(n, navhip.ENTITY_FLAG_MOVABLE, np.uint32)),
+            "state": dev(np.zeros(n, np.uint8)), "has_dest_los": dev(np.zeros(n, np.uint8)),
+            "flock": dev(ag["flock"]), "flock_target_xz": dev(targets.astype(np.float32)),
+            "flock_offsets": dev(offs), "flock_members": dev(members),
+            "flock_field_slot": dev(slot_tbl), "field_pool": self.pool,
+        }
+        self.new_pos = torch.zeros((n, 2), dtype=torch.float32, device=self.dev)
+        self.new_vel = torch.zeros((n, 2), dtype=torch.float32, device=self.dev)
+        self.status = torch.zeros(n, dtype=torch.uint8, device=self.dev)
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self._make_structs()
+        self.ev = []                   # (phase, start_event, end_event) of the timed steps
+        self.record = False
+        if verbose:
+            print("[rank %d] setup %.1fs: %d chunk-field requests (%d local), %d agents (%d local)"
+                  % (rank, time.time() - t0, n_req, self.n_req_local, n, self.a1 - self.a0), flush=True)
+
+    def _make_structs(self):
+        arrays = dict(self.t)
+        self.world_s, self._keep = navhip.make_world(self.W, self.W, arrays, hz=self.hz)
+        self.world_s.work_begin, self.world_s.work_end = self.a0, self.a1
+        self.out_s = navhip.StepOut()
+        self.out_s.vel_xz = self.new_vel.data_ptr()
+        self.out_s.new_pos_xz = self.new_pos.data_ptr()
+        self.out_s.status = self.status.data_ptr()
+
+    def _mark(self, name):
+        if not self.record:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(self.stream)
+        return (name, e)
+
+    def step(self):
+        """One tick, asynchronous on self.stream."""
+        s = self.stream
+        marks = []
+        with torch.cuda.stream(s):
+            marks.append(self._mark("fields"))
+            if self.n_req_local:
+                self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
+                                          self.pool[self.req_begin:self.req_end], stream=s.cuda_stream)
+            marks.append(self._mark("gather_tiles"))
+            if self.world > 1:
+                if self.equal_req_slices:
+                    pdist.all_gather_rows(self.pool, self.rank, self.world, self.n_req_local)
+                else:       # ragged slices: broadcast each rank's slice
+                    for r in range(self.world):
+                        b, e = self._req_slice_of(r)
+                        torch.distributed.broadcast(self.pool[b:e], src=r)
+            marks.append(self._mark("agents"))
+            self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
+            marks.append(self._mark("gather_agents"))
+            if self.world > 1:
+                per = self.a1 - self.a0
+                if per * self.world == self.N:
+                    pdist.all_gather_rows(self.new_pos, self.rank, self.world, per)
+                    pdist.all_gather_rows(self.new_vel, self.rank, self.world, per)
+                else:
+                    for r in range(self.world):
+                        b, e = pdist.slab(self.N, r, self.world)
+                        torch.distributed.broadcast(self.new_pos[b:e], src=r)
+                        torch.distributed.broadcast(self.new_vel[b:e], src=r)
+            marks.append(self._mark("end"))
+            # advance the snapshot: ping-pong the position / velocity buffers
+            self.t["pos_xz"], self.new_pos = self.new_pos, self.t["pos_xz"]
+            self.t["vel_xz"], self.new_vel = self.new_vel, self.t["vel_xz"]
+            self._make_structs()
+        if self.record:
+            self.ev.append(marks)
+
+    def _req_slice_of(self, r):
+        d0, d1 = pdist.slab(self.K, r, self.world)
+        sel = np.flatnonzero((self._dest_of_req >= d0) & (self._dest_of_req < d1))
+        return (int(sel[0]), int(sel[-1]) + 1) if len(sel) else (0, 0)
+
+    def phase_ms(self):
+        """Average HIP-event duration of every phase over the recorded steps."""
+        out = {}
+        for marks in self.ev:
+            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+                out.setdefault(n0, []).append(e0.elapsed_time(e1))
+        return {k: float(np.mean(v)) for k, v in out.items()}
+
+    def sync(self):
+        self.stream.synchronize()
+        torch.cuda.synchronize(self.dev)
+
+    def close(self):
+        self.sync()
+        self.ctx.close()
