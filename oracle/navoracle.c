@@ -1,0 +1,1139 @@
+/* oracle/navoracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference's algorithm for the navigation hot path (SURVEY.md
+ * section 8a), written from the reference's behaviour; every function cites the reference
+ * file:line (under the reference's src/) it follows.  Sequential, one agent / one chunk field
+ * at a time, same C types and expression order as the reference so that float results are
+ * reproducible.
+ *
+ * Pinning: the reference has no golden vectors or unit tests for this path, so
+ * this restatement is pinned against OUTPUTS OF THE REFERENCE ITSELF: oracle/_ref/libpfref.so
+ * (the reference's own translation units compiled in place) in tests/test_oracle_cpu.py, and
+ * the committed fixtures under tests/golden/ that scripts/make_golden.py generated from it.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.  It uses
+ * the PODs of include/navhip.h (the boundary under test) for its inputs so that the same
+ * request / snapshot records feed both sides; it shares no code with the product.
+ *
+ * Build: gcc -std=c99 -O2 -fPIC -shared -ffp-contract=off  (oracle/build_oracle.py)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdbool.h>
+#include <pthread.h>
+#include <time.h>
+
+#include "navhip.h"
+
+#define RES            64
+#define CELLS          4096
+#define COST_IMPASS    0xff
+#define ISLAND_NONE    0xffff
+#define FACTION_NONE   0xf
+#define MAX_FACTIONS   15
+#define NLAYERS        12
+
+/* the planes of `struct nav_chunk` (nav_data.h:118-158) the path reads, per layer, in the packed
+ * upload layout [h][w][64][64] (N_CopyCostBasePacked, nav.c:2432) */
+typedef struct no_map {
+    int32_t         w, h;
+    const uint8_t  *cost[NLAYERS];
+    const uint16_t *blockers[NLAYERS];
+    const uint16_t *local_islands[NLAYERS];
+    const uint8_t  *factions[NLAYERS];       /* [chunk][15][64][64] */
+} no_map;
+
+/* ===========================================================================================
+ * chunk flow fields
+ * =========================================================================================== */
+
+/* field_tile_passable (field.c:117) / field_tile_passable_no_enemies (field.c:179) */
+static bool tile_passable(const no_map *m, int layer, int chunk, int r, int c, int faction_id,
+                          unsigned enemies)
+{
+    size_t i = ((size_t)chunk << 12) + (size_t)r * RES + c;
+    if(m->cost[layer][i] == COST_IMPASS)
+        return false;
+    uint16_t blk = m->blockers[layer] ? m->blockers[layer][i] : 0;
+    if(faction_id == FACTION_NONE)
+        return blk == 0;
+    bool enemies_only = true;
+    if(m->factions[layer]) {
+        const uint8_t *fp = m->factions[layer] + ((size_t)chunk * MAX_FACTIONS << 12) + r * RES + c;
+        for(int f = 0; f < MAX_FACTIONS; f++) {
+            if(fp[(size_t)f << 12] && !(enemies & (1u << f))) {
+                enemies_only = false;
+                break;
+            }
+        }
+    }
+    if(enemies_only)
+        return true;
+    return blk == 0;
+}
+
+/* binary min-heap on a float priority (pqueue.h:112-191); any correct PQ yields the same
+ * integration values, ties included, because the values are a fixpoint of the relaxation */
+typedef struct { float prio; uint16_t cell; } pq_ent;
+typedef struct { pq_ent *a; int n, cap; } pq_t;
+
+static void pq_push(pq_t *q, float prio, int cell)
+{
+    if(q->n == q->cap) {
+        q->cap = q->cap ? q->cap * 2 : 256;
+        q->a = realloc(q->a, (size_t)q->cap * sizeof(pq_ent));
+    }
+    int i = q->n++;
+    while(i > 0) {
+        int p = (i - 1) / 2;
+        if(q->a[p].prio <= prio) break;
+        q->a[i] = q->a[p];
+        i = p;
+    }
+    q->a[i].prio = prio;
+    q->a[i].cell = (uint16_t)cell;
+}
+
+static int pq_pop(pq_t *q)
+{
+    int ret = q->a[0].cell;
+    pq_ent last = q->a[--q->n];
+    int i = 0;
+    for(;;) {
+        int l = 2 * i + 1, r = l + 1, s = i;
+        float best = last.prio;
+        if(l < q->n && q->a[l].prio < best) { s = l; best = q->a[l].prio; }
+        if(r < q->n && q->a[r].prio < best) { s = r; }
+        if(s == i) break;
+        q->a[i] = q->a[s];
+        i = s;
+    }
+    if(q->n > 0) q->a[i] = last;
+    return ret;
+}
+
+/* field_tile_adjacent_to_next_iid (field.c:1131): scan the tiles of the `next` portal for one
+ * at Manhattan distance 1 (M_Tile_Distance, tile.c:414) that lies on local island next_iid */
+static bool adjacent_to_next_iid(const no_map *m, const navhip_field_req *rq, int r, int c)
+{
+    const uint16_t *li = m->local_islands[rq->layer];
+    int next_chunk = rq->next_chunk_r * m->w + rq->next_chunk_c;
+    for(int r2 = rq->next_r0; r2 <= rq->next_r1; r2++) {
+    for(int c2 = rq->next_c0; c2 <= rq->next_c1; c2++) {
+        int dr = (rq->next_chunk_r * RES + r2) - (rq->chunk_r * RES + r);
+        int dc = (rq->next_chunk_c * RES + c2) - (rq->chunk_c * RES + c);
+        if(abs(dr) + abs(dc) == 1) {
+            if(li[((size_t)next_chunk << 12) + r2 * RES + c2] == rq->next_iid)
+                return true;
+        }
+    }}
+    return false;
+}
+
+/* field_flow_dir (field.c:355): min over the 4 cardinals, diagonals admitted only when both
+ * side tiles are finite, then first match in the order N,S,E,W,NW,NE,SW,SE */
+static int flow_dir(const float *f, int r, int c)
+{
+    const int rdim = RES, cdim = RES;
+    float min_cost = INFINITY;
+#define F(rr, cc) f[(rr) * rdim + (cc)]
+#define MINF(a, b) ((a) < (b) ? (a) : (b))
+    if(r > 0)          min_cost = MINF(min_cost, F(r - 1, c));
+    if(r < rdim - 1)   min_cost = MINF(min_cost, F(r + 1, c));
+    if(c > 0)          min_cost = MINF(min_cost, F(r, c - 1));
+    if(c < cdim - 1)   min_cost = MINF(min_cost, F(r, c + 1));
+    if(r > 0 && c > 0 && F(r - 1, c) < INFINITY && F(r, c - 1) < INFINITY)
+        min_cost = MINF(min_cost, F(r - 1, c - 1));
+    if(r > 0 && c < cdim - 1 && F(r - 1, c) < INFINITY && F(r, c + 1) < INFINITY)
+        min_cost = MINF(min_cost, F(r - 1, c + 1));
+    if(r < rdim - 1 && c > 0 && F(r + 1, c) < INFINITY && F(r, c - 1) < INFINITY)
+        min_cost = MINF(min_cost, F(r + 1, c - 1));
+    if(r < rdim - 1 && c < cdim - 1 && F(r + 1, c) < INFINITY && F(r, c + 1) < INFINITY)
+        min_cost = MINF(min_cost, F(r + 1, c + 1));
+
+    if(r > 0 && F(r - 1, c) == min_cost)                          return NAVHIP_FD_N;
+    else if(r < rdim - 1 && F(r + 1, c) == min_cost)              return NAVHIP_FD_S;
+    else if(c < cdim - 1 && F(r, c + 1) == min_cost)              return NAVHIP_FD_E;
+    else if(c > 0 && F(r, c - 1) == min_cost)                     return NAVHIP_FD_W;
+    else if(r > 0 && c > 0 && F(r - 1, c - 1) == min_cost)        return NAVHIP_FD_NW;
+    else if(r > 0 && c < cdim - 1 && F(r - 1, c + 1) == min_cost) return NAVHIP_FD_NE;
+    else if(r < rdim - 1 && c > 0 && F(r + 1, c - 1) == min_cost) return NAVHIP_FD_SW;
+    else if(r < rdim - 1 && c < rdim - 1 && F(r + 1, c + 1) == min_cost) return NAVHIP_FD_SE;
+    return NAVHIP_FD_NONE;      /* the reference asserts here */
+#undef F
+#undef MINF
+}
+
+/* N_FlowFieldInit (field.c:2020, unless NAVHIP_REQ_INOUT) + N_FlowFieldUpdate (field.c:2030) for
+ * TARGET_TILE / TARGET_PORTAL.  Returns 0, or -1 for a malformed request. */
+int no_field_update(const no_map *m, const navhip_field_req *rq, uint8_t *inout_dirs,
+                    float *out_integ)
+{
+    if(rq->layer >= NLAYERS || !m->cost[rq->layer] || rq->chunk_r >= m->h || rq->chunk_c >= m->w)
+        return -1;
+    const int layer = rq->layer, chunk = rq->chunk_r * m->w + rq->chunk_c;
+    const int faction_id = rq->faction_id;
+    const unsigned enemies = rq->enemies;
+    const uint8_t *cost = m->cost[layer] + ((size_t)chunk << 12);
+
+    if(!(rq->flags & NAVHIP_REQ_INOUT))
+        memset(inout_dirs, NAVHIP_FD_NONE, CELLS);                     /* N_FlowFieldInit */
+
+    static __thread float integ[CELLS];
+    for(int i = 0; i < CELLS; i++) integ[i] = INFINITY;                /* field.c:2059-2063 */
+    pq_t q = {0};
+
+    /* field_initial_frontier, field.c:1372 */
+    if(rq->type == NAVHIP_TARGET_TILE) {                               /* field.c:1096 */
+        if(tile_passable(m, layer, chunk, rq->tile_r, rq->tile_c, faction_id, enemies)) {
+            int i = rq->tile_r * RES + rq->tile_c;
+            pq_push(&q, 0.0f, i);
+            integ[i] = 0.0f;
+        }
+    }else if(rq->type == NAVHIP_TARGET_PORTAL) {                       /* field.c:1160 */
+        const uint16_t *li = m->local_islands[layer];
+        if(!li) { free(q.a); return -1; }
+        for(int r = rq->port_r0; r <= rq->port_r1; r++) {
+        for(int c = rq->port_c0; c <= rq->port_c1; c++) {
+            if(!tile_passable(m, layer, chunk, r, c, faction_id, enemies))
+                continue;
+            if(rq->port_iid != ISLAND_NONE && li[((size_t)chunk << 12) + r * RES + c] != rq->port_iid)
+                continue;
+            if(!adjacent_to_next_iid(m, rq, r, c))
+                continue;
+            pq_push(&q, 0.0f, r * RES + c);
+            integ[r * RES + c] = 0.0f;
+        }}
+    }else{
+        free(q.a);
+        return -1;
+    }
+
+    /* field_build_integration, field.c:539: Dijkstra, 4-connected (field_neighbours_grid :203
+     * skips diagonals), step cost = cost_base of the neighbour, passable neighbours only */
+    static const int dr4[4] = {-1, 0, 0, 1}, dc4[4] = {0, -1, 1, 0};
+    while(q.n > 0) {
+        int cur = pq_pop(&q);
+        int r = cur >> 6, c = cur & 63;
+        for(int k = 0; k < 4; k++) {
+            int nr = r + dr4[k], nc = c + dc4[k];
+            if(nr < 0 || nr >= RES || nc < 0 || nc >= RES) continue;
+            if(!tile_passable(m, layer, chunk, nr, nc, faction_id, enemies)) continue;
+            float total = integ[cur] + (float)cost[nr * RES + nc];
+            if(total < integ[nr * RES + nc]) {
+                integ[nr * RES + nc] = total;
+                pq_push(&q, total, nr * RES + nc);
+            }
+        }
+    }
+    free(q.a);
+
+    /* field_build_flow, field.c:734: unreached cells are left untouched, cost-0 cells NONE */
+    for(int r = 0; r < RES; r++) {
+    for(int c = 0; c < RES; c++) {
+        float v = integ[r * RES + c];
+        if(v == INFINITY) continue;
+        if(v == 0.0f) { inout_dirs[r * RES + c] = NAVHIP_FD_NONE; continue; }
+        inout_dirs[r * RES + c] = (uint8_t)flow_dir(integ, r, c);
+    }}
+
+    /* field_fixup -> field_fixup_portal_edges, field.c:1408,830 */
+    if(rq->type == NAVHIP_TARGET_PORTAL) {
+        int d;
+        if(rq->next_chunk_r < rq->chunk_r)      d = NAVHIP_FD_N;
+        else if(rq->next_chunk_r > rq->chunk_r) d = NAVHIP_FD_S;
+        else if(rq->next_chunk_c < rq->chunk_c) d = NAVHIP_FD_W;
+        else                                    d = NAVHIP_FD_E;
+        for(int i = 0; i < CELLS; i++)
+            if(integ[i] == 0.0f) inout_dirs[i] = (uint8_t)d;
+    }
+    if(out_integ) memcpy(out_integ, integ, sizeof(float) * CELLS);
+    return 0;
+}
+
+int no_build_fields(const no_map *m, const navhip_field_req *reqs, int n, uint8_t *inout_dirs,
+                    float *out_integ)
+{
+    for(int i = 0; i < n; i++) {
+        int rc = no_field_update(m, &reqs[i], inout_dirs + (size_t)i * CELLS,
+                                 out_integ ? out_integ + (size_t)i * CELLS : NULL);
+        if(rc) return rc;
+    }
+    return 0;
+}
+
+/* ===========================================================================================
+ * vec2 arithmetic (pf_math.c:58-94) -- float ops, sqrt evaluated in double then rounded
+ * =========================================================================================== */
+typedef struct { float x, z; } v2;
+
+static v2 mkv(float x, float z) { v2 r = {x, z}; return r; }
+static v2 vadd(v2 a, v2 b) { return mkv(a.x + b.x, a.z + b.z); }
+static v2 vsub(v2 a, v2 b) { return mkv(a.x - b.x, a.z - b.z); }
+static v2 vscale(v2 a, float s) { return mkv(a.x * s, a.z * s); }
+static float vdot(v2 a, v2 b) { return a.x * b.x + a.z * b.z; }
+static float vlen(v2 a) { return (float)sqrt(a.x * a.x + a.z * a.z); }
+static v2 vnormal(v2 a) { float l = vlen(a); return mkv(a.x / l, a.z / l); }
+
+/* vec2_truncate, movement.c:643 */
+static v2 vtrunc(v2 a, float max_len)
+{
+    if(vlen(a) > max_len) {
+        a = vnormal(a);
+        a = vscale(a, max_len);
+    }
+    return a;
+}
+
+#define EPS (1.0 / 1024)      /* clearpath.c:76, collision.c EPSILON */
+
+/* ===========================================================================================
+ * spatial index (lib/public/bitmap_grid.h), as the harness builds it: bg_ent_init over the
+ * grid bounds, insert uids 0..n-1, bg_ent_cleanup
+ * =========================================================================================== */
+typedef struct no_grid {
+    int32_t origin_x, origin_y;
+    int     grid_w, grid_h, n;
+    int32_t *cell_start;          /* [ncells + 1] */
+    int32_t *ids, *xs, *ys;       /* the clean pool: cells row-major (bitmap_grid.h:1506-1535) */
+} no_grid;
+
+static int32_t bg_scale(float v) { return (int32_t)lrintf(v * 256.0f); }    /* BG_SCALE_F :196 */
+
+static int grid_cell(const no_grid *g, int32_t ix, int32_t iy)
+{
+    int cx = (ix - g->origin_x) >> 12, cy = (iy - g->origin_y) >> 12;    /* BG_CELL_LOG2_INT */
+    if(cx < 0) cx = 0;
+    if(cy < 0) cy = 0;
+    if(cx >= g->grid_w) cx = g->grid_w - 1;
+    if(cy >= g->grid_h) cy = g->grid_h - 1;
+    return cy * g->grid_w + cx;
+}
+
+static int grid_build(no_grid *g, const navhip_world *w)
+{
+    memset(g, 0, sizeof(*g));
+    /* bg_<name>_init, bitmap_grid.h:959-990 */
+    g->origin_x = bg_scale(w->grid_xmin);
+    g->origin_y = bg_scale(w->grid_zmin);
+    int32_t span_x = bg_scale(w->grid_xmax) - g->origin_x;
+    int32_t span_y = bg_scale(w->grid_zmax) - g->origin_y;
+    if(span_x <= 0 || span_y <= 0) return -1;
+    g->grid_w = (int)(((uint32_t)span_x + 4095u) >> 12);
+    g->grid_h = (int)(((uint32_t)span_y + 4095u) >> 12);
+    if(g->grid_w < 1) g->grid_w = 1;
+    if(g->grid_h < 1) g->grid_h = 1;
+    g->n = w->n_ents;
+    int ncells = g->grid_w * g->grid_h, n = g->n;
+    g->cell_start = calloc((size_t)ncells + 1, sizeof(int32_t));
+    g->ids = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    g->xs = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    g->ys = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int32_t *cell = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    for(int i = 0; i < n; i++) {
+        cell[i] = grid_cell(g, bg_scale(w->pos_xz[2 * i]), bg_scale(w->pos_xz[2 * i + 1]));
+        g->cell_start[cell[i] + 1]++;
+    }
+    for(int c = 0; c < ncells; c++) g->cell_start[c + 1] += g->cell_start[c];
+    /* bg_insert pushes at the HEAD of the cell's overflow chain (:1102-1121) and cleanup copies
+     * the chain head first (:1515-1521): inserting 0..n-1 leaves each cell in DESCENDING uid
+     * order.  Fill every cell from its end while walking uids upwards. */
+    int32_t *fill = malloc(sizeof(int32_t) * (size_t)ncells);
+    for(int c = 0; c < ncells; c++) fill[c] = g->cell_start[c + 1];
+    for(int i = 0; i < n; i++) {
+        int slot = --fill[cell[i]];
+        g->ids[slot] = i;
+        g->xs[slot] = bg_scale(w->pos_xz[2 * i]);
+        g->ys[slot] = bg_scale(w->pos_xz[2 * i + 1]);
+    }
+    free(fill);
+    free(cell);
+    return 0;
+}
+
+static void grid_free(no_grid *g)
+{
+    free(g->cell_start); free(g->ids); free(g->xs); free(g->ys);
+    memset(g, 0, sizeof(*g));
+}
+
+/* bg_<name>_inrange_circle, bitmap_grid.h:1376: inclusive int64 distance test on the x256
+ * fixed-point coordinates; coarse 8x8 blocks row-major, fine rows, cells left to right */
+static int grid_query(const no_grid *g, float x, float z, float range, uint32_t *out, int maxout)
+{
+    if(maxout <= 0 || range < 0.0f) return 0;
+    int32_t icx = bg_scale(x), icy = bg_scale(z), ir = bg_scale(range);
+    int64_t ir2 = (int64_t)ir * (int64_t)ir;
+    int32_t imnx = icx - ir, imxx = icx + ir, imny = icy - ir, imxy = icy + ir;
+    /* _bg_cell_extent :1236 */
+    if(imxx < g->origin_x || imxy < g->origin_y) return 0;
+    int32_t span_x = (int32_t)((uint32_t)g->grid_w << 12), span_y = (int32_t)((uint32_t)g->grid_h << 12);
+    if(imnx >= g->origin_x + span_x || imny >= g->origin_y + span_y) return 0;
+    int cx_lo = (imnx - g->origin_x) >> 12, cx_hi = (imxx - g->origin_x) >> 12;
+    int cy_lo = (imny - g->origin_y) >> 12, cy_hi = (imxy - g->origin_y) >> 12;
+    if(cx_lo < 0) cx_lo = 0;
+    if(cy_lo < 0) cy_lo = 0;
+    if(cx_hi >= g->grid_w) cx_hi = g->grid_w - 1;
+    if(cy_hi >= g->grid_h) cy_hi = g->grid_h - 1;
+
+    int written = 0;
+    int64_t extent = (int64_t)(cx_hi - cx_lo + 1) * (int64_t)(cy_hi - cy_lo + 1);
+    int64_t total = (int64_t)g->grid_w * (int64_t)g->grid_h;
+    if(extent * 4 >= total * 3) {                 /* wide-query path on a clean pool :1389-1397 */
+        for(int k = 0; k < g->n; k++) {
+            int64_t dx = (int64_t)g->xs[k] - icx, dy = (int64_t)g->ys[k] - icy;
+            if(dx * dx + dy * dy <= ir2) {
+                out[written++] = (uint32_t)g->ids[k];
+                if(written >= maxout) return written;
+            }
+        }
+        return written;
+    }
+    for(int cyc = cy_lo >> 3; cyc <= (cy_hi >> 3); cyc++) {
+    for(int cxc = cx_lo >> 3; cxc <= (cx_hi >> 3); cxc++) {
+        int fy0 = cyc * 8, fy1 = fy0 + 8, fx0 = cxc * 8, fx1 = fx0 + 8;
+        if(fy0 < cy_lo) fy0 = cy_lo;
+        if(fy1 > cy_hi + 1) fy1 = cy_hi + 1;
+        if(fx0 < cx_lo) fx0 = cx_lo;
+        if(fx1 > cx_hi + 1) fx1 = cx_hi + 1;
+        for(int fy = fy0; fy < fy1; fy++) {
+        for(int fx = fx0; fx < fx1; fx++) {
+            int ci = fy * g->grid_w + fx;
+            for(int k = g->cell_start[ci]; k < g->cell_start[ci + 1]; k++) {
+                int64_t dx = (int64_t)g->xs[k] - icx, dy = (int64_t)g->ys[k] - icy;
+                if(dx * dx + dy * dy <= ir2) {
+                    out[written++] = (uint32_t)g->ids[k];
+                    if(written >= maxout) return written;
+                }
+            }
+        }}
+    }}
+    return written;
+}
+
+/* filter_garrisoned, position.c:100 */
+static int filter_garrisoned(const uint32_t *flags, uint32_t *cand, int count)
+{
+    int ret = count;
+    for(int i = count - 1; i >= 0; i--) {
+        if(flags[cand[i]] & NAVHIP_ENTITY_FLAG_GARRISONED) {
+            cand[i] = cand[ret - 1];
+            ret--;
+        }
+    }
+    return ret;
+}
+
+/* G_Pos_EntsInCircleFrom, position.c:379 */
+static int ents_in_circle(const no_grid *g, const uint32_t *flags, v2 p, float range,
+                          uint32_t *out, int maxout)
+{
+    int n = grid_query(g, p.x, p.z, range, out, maxout);
+    return flags ? filter_garrisoned(flags, out, n) : n;
+}
+
+int no_spatial_query(const navhip_world *w, const float *query_xz, int nq, float range,
+                     int maxout, int32_t *out_counts, uint32_t *out_ids)
+{
+    no_grid g;
+    if(grid_build(&g, w)) return -1;
+    for(int q = 0; q < nq; q++)
+        out_counts[q] = grid_query(&g, query_xz[2 * q], query_xz[2 * q + 1], range,
+                                   out_ids + (size_t)q * maxout, maxout);
+    grid_free(&g);
+    return 0;
+}
+
+/* ===========================================================================================
+ * ClearPath (game/clearpath.c) + the two collision.c primitives under it
+ * =========================================================================================== */
+typedef struct { v2 pos, vel; float radius; } cpent;
+typedef struct { v2 point, dir; } line2d;
+
+/* C_InfiniteLineIntersection, collision.c:820 (the vertical-l2 branch really adds l2.point.z) */
+static bool line_isect(line2d l1, line2d l2, v2 *out)
+{
+    float s1 = fabs(l1.dir.x) < EPS ? NAN : (l1.dir.z / l1.dir.x);
+    float s2 = fabs(l2.dir.x) < EPS ? NAN : (l2.dir.z / l2.dir.x);
+    if(isnan(s1) && isnan(s2)) return false;
+    if(fabs(s1 - s2) < EPS) return false;
+    if(isnan(s1) && !isnan(s2)) {
+        out->x = l1.point.x;
+        out->z = (l1.point.x - l2.point.x) * s2 + l2.point.z;
+    }else if(!isnan(s1) && isnan(s2)) {
+        out->x = l2.point.x;
+        out->z = (l2.point.x - l1.point.x) * s1 + l2.point.z;
+    }else{
+        out->x = (s1 * l1.point.x - s2 * l2.point.x + l2.point.z - l1.point.z) / (s1 - s2);
+        out->z = s2 * (out->x - l2.point.x) + l2.point.z;
+    }
+    return true;
+}
+
+/* C_RayRayIntersection2D, collision.c:854 */
+static bool ray_isect(line2d l1, line2d l2, v2 *out)
+{
+    v2 p;
+    if(!line_isect(l1, l2, &p)) return false;
+    if((p.x - l1.point.x) / l1.dir.x < 0.0f) return false;
+    if((p.z - l1.point.z) / l1.dir.z < 0.0f) return false;
+    if((p.x - l2.point.x) / l2.dir.x < 0.0f) return false;
+    if((p.z - l2.point.z) / l2.dir.z < 0.0f) return false;
+    *out = p;
+    return true;
+}
+
+/* compute_vo_edges, clearpath.c:130 */
+static void vo_edges(cpent ent, cpent nb, v2 *out_right, v2 *out_left)
+{
+    v2 e2n = vnormal(vsub(nb.pos, ent.pos));
+    v2 right = mkv(-e2n.z, e2n.x);
+    right = vscale(right, nb.radius + ent.radius + 0.0f);      /* CLEARPATH_BUFFER_RADIUS 0 */
+    v2 right_tangent = vadd(nb.pos, right), left_tangent = vsub(nb.pos, right);
+    *out_right = vnormal(vsub(right_tangent, ent.pos));
+    *out_left = vnormal(vsub(left_tangent, ent.pos));
+}
+
+/* inside_pcr, clearpath.c:249; rays[] = (left, right) pairs */
+static bool inside_pcr(const line2d *rays, int n_rays, v2 test)
+{
+    for(int i = 0; i < n_rays; i += 2) {
+        v2 ptt = vsub(test, rays[i].point);
+        if(vlen(ptt) < EPS) continue;
+        ptt = vnormal(ptt);
+        float left_det = (ptt.z * rays[i].dir.x) - (ptt.x * rays[i].dir.z);
+        if(left_det < EPS) continue;
+        ptt = vsub(test, rays[i + 1].point);
+        if(vlen(ptt) < EPS) continue;
+        ptt = vnormal(ptt);
+        float right_det = (ptt.z * rays[i + 1].dir.x) - (ptt.x * rays[i + 1].dir.z);
+        if(right_det > -EPS) continue;
+        return true;
+    }
+    return false;
+}
+
+/* clearpath_new_velocity, clearpath.c:552 */
+static bool cp_new_velocity(cpent ent, v2 des_v, const cpent *dyn, int n_dyn, const cpent *stat,
+                            int n_stat, v2 *out)
+{
+    line2d rays[2 * 64];
+    int n_rays = 0;
+    for(int i = 0; i < n_dyn; i++) {                           /* compute_all_hrvos :232 */
+        if(vlen(vsub(dyn[i].pos, ent.pos)) < EPS) continue;   /* same_position :123 */
+        /* compute_hrvo :180 over compute_rvo :166 */
+        v2 right, left;
+        vo_edges(ent, dyn[i], &right, &left);
+        v2 rvo_apex = vadd(ent.pos, vscale(vadd(ent.vel, dyn[i].vel), 0.5f));
+        v2 centerline = vadd(left, right);
+        v2 vo_apex = vadd(ent.pos, dyn[i].vel);
+        v2 apex;
+        float det = (centerline.x * ent.vel.z) - (centerline.z * ent.vel.x);
+        if(det > EPS) {
+            line2d l1 = {rvo_apex, left}, l2 = {vo_apex, right};
+            apex = rvo_apex;        /* the reference asserts the lines meet; keep a defined value */
+            line_isect(l1, l2, &apex);
+        }else if(det < -EPS) {
+            line2d l1 = {rvo_apex, right}, l2 = {vo_apex, left};
+            apex = rvo_apex;
+            line_isect(l1, l2, &apex);
+        }else{
+            apex = rvo_apex;
+        }
+        rays[n_rays].point = apex;     rays[n_rays].dir = left;        /* rays_repr :291 */
+        rays[n_rays + 1].point = apex; rays[n_rays + 1].dir = right;
+        n_rays += 2;
+    }
+    for(int i = 0; i < n_stat; i++) {                          /* compute_all_vos :216 */
+        if(vlen(vsub(stat[i].pos, ent.pos)) < EPS) continue;
+        v2 right, left;
+        vo_edges(ent, stat[i], &right, &left);                 /* compute_vo :153 */
+        v2 apex = vadd(ent.pos, stat[i].vel);
+        rays[n_rays].point = apex;     rays[n_rays].dir = left;
+        rays[n_rays + 1].point = apex; rays[n_rays + 1].dir = right;
+        n_rays += 2;
+    }
+
+    v2 des_ws = vadd(ent.pos, des_v);
+    if(!inside_pcr(rays, n_rays, des_ws)) {
+        *out = des_v;
+        return true;
+    }
+
+    /* compute_vo_xpoints :321, compute_vdes_proj_points :344, compute_vnew :368 fused: the
+     * candidates are visited in the order the reference pushes them, first strict minimum wins */
+    float min_dist = INFINITY;
+    v2 ret = mkv(0.0f, 0.0f);
+    int npoints = 0;
+    for(int i = 0; i < n_rays; i++) {
+    for(int j = 0; j < n_rays; j++) {
+        if(i == j) continue;
+        v2 pt;
+        if(!ray_isect(rays[i], rays[j], &pt)) continue;
+        if(inside_pcr(rays, n_rays, pt)) continue;
+        npoints++;
+        v2 curr = vsub(pt, ent.pos);
+        float len = vlen(vsub(des_v, curr));
+        if(len < min_dist) { min_dist = len; ret = curr; }
+    }}
+    for(int i = 0; i < n_rays; i++) {
+        float len = vdot(rays[i].dir, des_v);
+        v2 proj = vadd(rays[i].point, vscale(rays[i].dir, len));
+        if(inside_pcr(rays, n_rays, proj)) continue;
+        npoints++;
+        v2 curr = vsub(proj, ent.pos);
+        float l2 = vlen(vsub(des_v, curr));
+        if(l2 < min_dist) { min_dist = l2; ret = curr; }
+    }
+    if(npoints == 0) return false;
+    *out = ret;
+    return true;
+}
+
+/* G_ClearPath_NewVelocity, clearpath.c:694 (+ remove_furthest :390, vec del = swap with last) */
+static v2 cp_solve(cpent ent, v2 des_v, cpent *dyn, int n_dyn, cpent *stat, int n_stat)
+{
+    do {
+        v2 ret;
+        if(cp_new_velocity(ent, des_v, dyn, n_dyn, stat, n_stat, &ret))
+            return ret;
+        float max_dist = -INFINITY;
+        int del_list = -1, del_idx = -1;
+        for(int l = 0; l < 2; l++) {
+            const cpent *v = l == 0 ? dyn : stat;
+            int n = l == 0 ? n_dyn : n_stat;
+            for(int j = 0; j < n; j++) {
+                float len = vlen(vsub(ent.pos, v[j].pos));
+                if(len > max_dist) { max_dist = len; del_list = l; del_idx = j; }
+            }
+        }
+        if(max_dist > -INFINITY) {
+            if(del_list == 0) dyn[del_idx] = dyn[--n_dyn];
+            else              stat[del_idx] = stat[--n_stat];
+        }
+    } while(n_dyn > 0 && n_stat > 0);
+    return mkv(0.0f, 0.0f);
+}
+
+int no_clearpath(int nq, const float *ent, const float *des_v, const float *dyn,
+                 const int32_t *n_dyn, const float *stat, const int32_t *n_stat, float *out)
+{
+    for(int q = 0; q < nq; q++) {
+        cpent e = {mkv(ent[5 * q], ent[5 * q + 1]), mkv(ent[5 * q + 2], ent[5 * q + 3]), ent[5 * q + 4]};
+        cpent d[32], s[32];
+        if(n_dyn[q] < 0 || n_dyn[q] > 32 || n_stat[q] < 0 || n_stat[q] > 32) return -1;
+        for(int k = 0; k < n_dyn[q]; k++) {
+            const float *p = dyn + ((size_t)q * 32 + k) * 5;
+            d[k].pos = mkv(p[0], p[1]); d[k].vel = mkv(p[2], p[3]); d[k].radius = p[4];
+        }
+        for(int k = 0; k < n_stat[q]; k++) {
+            const float *p = stat + ((size_t)q * 32 + k) * 5;
+            s[k].pos = mkv(p[0], p[1]); s[k].vel = mkv(p[2], p[3]); s[k].radius = p[4];
+        }
+        v2 r = cp_solve(e, mkv(des_v[2 * q], des_v[2 * q + 1]), d, n_dyn[q], s, n_stat[q]);
+        out[2 * q] = r.x; out[2 * q + 1] = r.z;
+    }
+    return 0;
+}
+
+/* ===========================================================================================
+ * tile lookups, flow sampling
+ * =========================================================================================== */
+typedef struct { int chunk_r, chunk_c, tile_r, tile_c; } tiledesc;
+
+#define CLAMPI(v, lo, hi) ((v) < (lo) ? (lo) : (v) > (hi) ? (hi) : (v))
+
+/* M_Tile_DescForPoint2D, tile.c:547, at the nav resolution n_res (nav.c:247): 64x64 tiles of
+ * 4 wu per 256-wu chunk */
+static bool tile_for_point(const no_map *m, float map_x, float map_z, v2 p, tiledesc *out)
+{
+    float width = (float)(size_t)(m->w * 256), height = (float)(size_t)(m->h * 256);
+    if(p.x > map_x || p.x < map_x - width) return false;
+    if(p.z < map_z || p.z > map_z + height) return false;
+    int chunk_r = (int)(fabs(map_z - p.z) / 256);
+    int chunk_c = (int)(fabs(map_x - p.x) / 256);
+    chunk_r = CLAMPI(chunk_r, 0, m->h - 1);
+    chunk_c = CLAMPI(chunk_c, 0, m->w - 1);
+    float base_x = map_x - (chunk_c * 256);
+    float base_z = map_z + (chunk_r * 256);
+    int tile_r = (int)(fabs(base_z - p.z) / 4);
+    int tile_c = (int)(fabs(base_x - p.x) / 4);
+    out->chunk_r = chunk_r; out->chunk_c = chunk_c;
+    out->tile_r = CLAMPI(tile_r, 0, 63);
+    out->tile_c = CLAMPI(tile_c, 0, 63);
+    return true;
+}
+
+/* Entity_NavLayerWithRadius, entity.c:554 */
+static int nav_layer_for(uint32_t flags, float radius)
+{
+    int base = (flags & NAVHIP_ENTITY_FLAG_WATER) ? 4 : (flags & NAVHIP_ENTITY_FLAG_AIR) ? 8 : 0;
+    if(radius >= 15.0f) return base + 3;
+    if(radius >= 10.0f) return base + 2;
+    if(radius >= 5.0f)  return base + 1;
+    return base;
+}
+
+/* N_PositionPathable nav.c:4055 / N_PositionBlocked nav.c:4070 (off-map: the reference asserts;
+ * reported as not pathable / not blocked) */
+static bool pos_pathable(const no_map *m, const navhip_world *w, int layer, v2 p)
+{
+    tiledesc t;
+    if(!tile_for_point(m, w->map_pos_x, w->map_pos_z, p, &t)) return false;
+    return m->cost[layer][((size_t)(t.chunk_r * m->w + t.chunk_c) << 12) + t.tile_r * RES + t.tile_c]
+           != COST_IMPASS;
+}
+
+static bool pos_blocked(const no_map *m, const navhip_world *w, int layer, v2 p)
+{
+    tiledesc t;
+    if(!tile_for_point(m, w->map_pos_x, w->map_pos_z, p, &t)) return false;
+    if(!m->blockers[layer]) return false;
+    return m->blockers[layer][((size_t)(t.chunk_r * m->w + t.chunk_c) << 12) + t.tile_r * RES + t.tile_c] > 0;
+}
+
+/* N_FlowDir, field.c:2428 */
+static v2 flow_dir_vec(int dir)
+{
+    const float d = (float)(1.0f / sqrt(2.0f));
+    switch(dir) {
+    case NAVHIP_FD_NW: return mkv( d, -d);
+    case NAVHIP_FD_N:  return mkv( 0.0f, -1.0f);
+    case NAVHIP_FD_NE: return mkv(-d, -d);
+    case NAVHIP_FD_W:  return mkv( 1.0f, 0.0f);
+    case NAVHIP_FD_E:  return mkv(-1.0f, 0.0f);
+    case NAVHIP_FD_SW: return mkv( d,  d);
+    case NAVHIP_FD_S:  return mkv( 0.0f, 1.0f);
+    case NAVHIP_FD_SE: return mkv(-d,  d);
+    default:           return mkv(0.0f, 0.0f);
+    }
+}
+
+/* N_DesiredPointSeekVelocity (nav.c:3468) on a cache HIT + n_interpolated_flow_dir (nav.c:3407).
+ * The (dest, chunk) -> field mapping of the field cache is the flock_field_slot table; a miss or
+ * an FD_NONE base tile is reported through *status for the host planner (nav.c:3483-3554). */
+static v2 sample_flow(const no_map *m, const navhip_world *w, int flock, v2 pos, unsigned *status)
+{
+    tiledesc t;
+    if(flock < 0 || !w->flock_field_slot || !w->field_pool
+    || !tile_for_point(m, w->map_pos_x, w->map_pos_z, pos, &t)) {
+        *status |= NAVHIP_ST_FIELD_MISS;
+        return mkv(0.0f, 0.0f);
+    }
+    const int nchunks = m->w * m->h;
+    const int32_t *slots = w->flock_field_slot + (size_t)flock * nchunks;
+    int slot = slots[t.chunk_r * m->w + t.chunk_c];
+    if(slot < 0) {
+        *status |= NAVHIP_ST_FIELD_MISS;
+        return mkv(0.0f, 0.0f);
+    }
+    const uint8_t *base_ff = w->field_pool + ((size_t)slot << 12);
+    int base_dir = base_ff[t.tile_r * RES + t.tile_c] & 0xf;
+    if(base_dir == NAVHIP_FD_NONE) *status |= NAVHIP_ST_FIELD_NONE;
+
+    /* M_Tile_Bounds, tile.c:356 */
+    float bx = w->map_pos_x - t.chunk_c * 256 - t.tile_c * 4;
+    float bz = w->map_pos_z + t.chunk_r * 256 + t.tile_r * 4;
+    float bw = 4, bh = 4;
+    v2 centre = mkv(bx - bw / 2.0f, bz + bh / 2.0f);
+    float dx = pos.x - centre.x, dz = pos.z - centre.z;
+    int dc = (dx < 0.0f) ? 1 : -1;
+    int dr = (dz > 0.0f) ? 1 : -1;
+    float wc = (float)fmin(fabs(dx) / bw, 1.0f);
+    float wr = (float)fmin(fabs(dz) / bh, 1.0f);
+    const int   sdc[4] = {0, dc, 0, dc};
+    const int   sdr[4] = {0, 0, dr, dr};
+    const float sw[4]  = {(1.0f - wc) * (1.0f - wr), wc * (1.0f - wr), (1.0f - wc) * wr, wc * wr};
+
+    v2 acc = mkv(0.0f, 0.0f);
+    float wsum = 0.0f;
+    for(int i = 0; i < 4; i++) {
+        if(sw[i] <= 0.0f) continue;
+        /* M_Tile_RelativeDesc, tile.c:391 */
+        int abs_r = t.chunk_r * RES + t.tile_r + sdr[i];
+        int abs_c = t.chunk_c * RES + t.tile_c + sdc[i];
+        if(abs_r < 0 || abs_r >= m->h * RES || abs_c < 0 || abs_c >= m->w * RES) continue;
+        int cr = abs_r / RES, cc = abs_c / RES, tr = abs_r % RES, tc = abs_c % RES;
+        const uint8_t *ff = base_ff;
+        if(cr != t.chunk_r || cc != t.chunk_c) {
+            int s2 = slots[cr * m->w + cc];
+            if(s2 < 0) continue;
+            ff = w->field_pool + ((size_t)s2 << 12);
+        }
+        int dir = ff[tr * RES + tc] & 0xf;
+        if(dir == NAVHIP_FD_NONE) continue;
+        v2 scaled = vscale(flow_dir_vec(dir), sw[i]);
+        acc = vadd(acc, scaled);
+        wsum += sw[i];
+    }
+    if(wsum < 1e-6f || vlen(acc) < 1e-6f)
+        return flow_dir_vec(base_dir);
+    return vnormal(acc);
+}
+
+/* ===========================================================================================
+ * movement step (game/movement.c)
+ * =========================================================================================== */
+typedef struct step_ctx {
+    const no_map *m;
+    const navhip_world *w;
+    const no_grid *g;
+    float  scaled_max_force_f;       /* SCALED_MAX_FORCE (movement.c:93) converted to float */
+    double scaled_max_force;
+} step_ctx;
+
+static v2 wpos(const navhip_world *w, int uid) { return mkv(w->pos_xz[2 * uid], w->pos_xz[2 * uid + 1]); }
+static v2 wvel(const navhip_world *w, int uid) { return mkv(w->vel_xz[2 * uid], w->vel_xz[2 * uid + 1]); }
+
+static bool state_still(int s) { return s == NAVHIP_STATE_ARRIVED || s == NAVHIP_STATE_WAITING; }   /* :652 */
+
+/* arrive_force_point, movement.c:1546 */
+static v2 arrive_force_point(const step_ctx *c, int uid, v2 target, v2 vdes, bool los)
+{
+    const navhip_world *w = c->w;
+    v2 desired;
+    if(los) {
+        desired = vsub(target, wpos(w, uid));
+        float distance = vlen(desired);
+        desired = vnormal(desired);
+        desired = vscale(desired, w->max_speed[uid] / w->hz);
+        if(distance < 10.0f)                                        /* ARRIVE_SLOWING_RADIUS */
+            desired = vscale(desired, distance / 10.0f);
+    }else{
+        desired = vscale(vdes, w->max_speed[uid] / w->hz);
+    }
+    return vtrunc(vsub(desired, wvel(w, uid)), c->scaled_max_force_f);
+}
+
+/* cohesion_force, movement.c:1653: exp-weighted centroid of the WHOLE flock, in member order */
+static v2 cohesion_force(const step_ctx *c, int uid, int flock)
+{
+    const navhip_world *w = c->w;
+    v2 com = mkv(0.0f, 0.0f);
+    size_t count = 0;
+    v2 me = wpos(w, uid);
+    for(int j = w->flock_offsets[flock]; j < w->flock_offsets[flock + 1]; j++) {
+        int curr = w->flock_members[j];
+        if(curr == uid) continue;
+        v2 cp = wpos(w, curr);
+        v2 diff = vsub(cp, me);
+        float t = (vlen(diff) - 50.0f * 0.75) / 50.0f;             /* COHESION_NEIGHBOUR_RADIUS */
+        float scale = exp(-6.0f * t);
+        cp = vscale(cp, scale);
+        com = vadd(com, cp);
+        count++;
+    }
+    if(count == 0) return mkv(0.0f, 0.0f);
+    com = vscale(com, 1.0f / count);
+    return vtrunc(vsub(com, me), c->scaled_max_force_f);
+}
+
+/* separation_force, movement.c:1690 */
+static v2 separation_force(const step_ctx *c, int uid)
+{
+    const navhip_world *w = c->w;
+    v2 ret = mkv(0.0f, 0.0f);
+    uint32_t ent_flags = w->flags[uid];
+    uint32_t near_ents[128];
+    v2 me = wpos(w, uid);
+    int num_near = ents_in_circle(c->g, w->flags, me, 30.0f, near_ents, 128);   /* SEPARATION_NEIGHB_RADIUS */
+    for(int i = 0; i < num_near; i++) {
+        uint32_t curr = near_ents[i];
+        uint32_t flags = w->flags[curr];
+        if((int)curr == uid) continue;
+        if(!(flags & NAVHIP_ENTITY_FLAG_MOVABLE)) continue;
+        if((ent_flags & NAVHIP_ENTITY_FLAG_AIR) != (flags & NAVHIP_ENTITY_FLAG_AIR)) continue;
+        float radius = w->radius[uid] + w->radius[curr] + 0.0f;   /* SEPARATION_BUFFER_DIST */
+        v2 diff = vsub(wpos(w, (int)curr), me);
+        if(vlen(diff) < EPS) continue;
+        float eq = 0.85f, steep = 20.0f;
+        float t = (vlen(diff) - radius * eq) / vlen(diff);
+        float a = -steep * t;
+        float scale = exp(a < 40.0f ? a : 40.0f);
+        diff = vscale(diff, scale);
+        ret = vadd(ret, diff);
+    }
+    if(num_near == 0) return mkv(0.0f, 0.0f);
+    ret = vscale(ret, -1.0f);
+    return vtrunc(ret, c->scaled_max_force_f);
+}
+
+/* nullify_impass_components, movement.c:1831 (N_TileDims = 4 x 4 wu, nav.c:4653) */
+static v2 nullify_impass(const step_ctx *c, int uid, v2 f)
+{
+    const navhip_world *w = c->w;
+    int layer = nav_layer_for(w->flags[uid], w->radius[uid]);
+    v2 pos = wpos(w, uid);
+    v2 left = mkv(pos.x + 4.0f, pos.z), right = mkv(pos.x - 4.0f, pos.z);
+    v2 top = mkv(pos.x, pos.z + 4.0f), bot = mkv(pos.x, pos.z - 4.0f);
+    bool on_blocked = pos_blocked(c->m, w, layer, pos);
+    if(f.x > 0 && (!pos_pathable(c->m, w, layer, left) || (!on_blocked && pos_blocked(c->m, w, layer, left))))
+        f.x = 0.0f;
+    if(f.x < 0 && (!pos_pathable(c->m, w, layer, right) || (!on_blocked && pos_blocked(c->m, w, layer, right))))
+        f.x = 0.0f;
+    if(f.z > 0 && (!pos_pathable(c->m, w, layer, top) || (!on_blocked && pos_blocked(c->m, w, layer, top))))
+        f.z = 0.0f;
+    if(f.z < 0 && (!pos_pathable(c->m, w, layer, bot) || (!on_blocked && pos_blocked(c->m, w, layer, bot))))
+        f.z = 0.0f;
+    return f;
+}
+
+/* point_seek_total_force :1745 + point_seek_vpref :1870 (arrival module inactive: the seek
+ * target is flock->target_xz) */
+static v2 point_seek_vpref(const step_ctx *c, int uid, int flock, v2 vdes, bool los, float speed)
+{
+    const navhip_world *w = c->w;
+    v2 target = flock >= 0 ? mkv(w->flock_target_xz[2 * flock], w->flock_target_xz[2 * flock + 1])
+                           : wpos(w, uid);
+    v2 steer = mkv(0.0f, 0.0f);
+    for(int prio = 0; prio < 3; prio++) {
+        switch(prio) {
+        case 0: {
+            v2 arrive = arrive_force_point(c, uid, target, vdes, los);
+            v2 cohesion = flock >= 0 ? cohesion_force(c, uid, flock) : mkv(0.0f, 0.0f);
+            v2 separation = separation_force(c, uid);
+            arrive = vscale(arrive, 0.5f);                 /* MOVE_ARRIVE_FORCE_SCALE */
+            cohesion = vscale(cohesion, 0.15f);            /* MOVE_COHESION_FORCE_SCALE */
+            separation = vscale(separation, 0.6f);         /* SEPARATION_FORCE_SCALE */
+            v2 ret = mkv(0.0f, 0.0f);
+            ret = vadd(ret, arrive);
+            ret = vadd(ret, separation);
+            ret = vadd(ret, cohesion);
+            steer = vtrunc(ret, c->scaled_max_force_f);
+            break;
+        }
+        case 1: steer = separation_force(c, uid); break;
+        case 2: steer = arrive_force_point(c, uid, target, vdes, los); break;
+        }
+        steer = nullify_impass(c, uid, steer);
+        if(vlen(steer) > c->scaled_max_force * 0.01)
+            break;
+    }
+    v2 accel = vscale(steer, 1.0f / 1.0f);                  /* ENTITY_MASS */
+    v2 new_vel = vadd(wvel(w, uid), accel);
+    return vtrunc(new_vel, speed / w->hz);
+}
+
+/* enemy_seek_vpref :1946 over enemy_seek_total_force :1815 / arrive_force_enemies :1593 */
+static v2 enemy_seek_vpref(const step_ctx *c, int uid, float speed, v2 vdes)
+{
+    const navhip_world *w = c->w;
+    v2 desired = vscale(vdes, w->max_speed[uid] / w->hz);
+    v2 arrive = vtrunc(vsub(desired, wvel(w, uid)), c->scaled_max_force_f);
+    v2 separation = separation_force(c, uid);
+    arrive = vscale(arrive, 0.5f);
+    separation = vscale(separation, 0.6f);
+    v2 ret = mkv(0.0f, 0.0f);
+    ret = vadd(ret, arrive);
+    ret = vadd(ret, separation);
+    v2 steer = vtrunc(ret, c->scaled_max_force_f);
+    v2 accel = vscale(steer, 1.0f / 1.0f);
+    return vtrunc(vadd(wvel(w, uid), accel), speed / w->hz);
+}
+
+/* find_neighbours, movement.c:2768 (arrival slots inactive) */
+static void find_neighbours(const step_ctx *c, int uid, cpent *dyn, int *n_dyn, cpent *stat, int *n_stat)
+{
+    const navhip_world *w = c->w;
+    uint32_t ent_flags = w->flags[uid];
+    uint32_t near_ents[512];
+    int num_near = ents_in_circle(c->g, w->flags, wpos(w, uid), 10.0f, near_ents, 512);
+    *n_dyn = *n_stat = 0;
+    for(int i = 0; i < num_near; i++) {
+        uint32_t curr = near_ents[i];
+        uint32_t flags = w->flags[curr];
+        if((int)curr == uid) continue;
+        if(!(flags & NAVHIP_ENTITY_FLAG_MOVABLE)) continue;
+        if(w->radius[curr] == 0.0f) continue;
+        if((ent_flags & NAVHIP_ENTITY_FLAG_AIR) != (flags & NAVHIP_ENTITY_FLAG_AIR)) continue;
+        cpent nd = {wpos(w, (int)curr), wvel(w, (int)curr), w->radius[curr]};
+        if(state_still(w->state[curr]) || vlen(nd.vel) < 0.3f) {        /* CLEARPATH_STILL_SPEED */
+            nd.vel = mkv(0.0f, 0.0f);
+            if(*n_stat < 32) stat[(*n_stat)++] = nd;                    /* MAX_NEIGHBOURS */
+        }else{
+            if(*n_dyn < 32) dyn[(*n_dyn)++] = nd;
+        }
+    }
+}
+
+static bool state_point_seek(int s)
+{
+    return s == NAVHIP_STATE_MOVING || s == NAVHIP_STATE_SURROUND_ENTITY
+        || s == NAVHIP_STATE_ENTER_ENTITY_RANGE;
+}
+
+/* move_velocity_work (movement.c:3395) for one entity + the position accept test of
+ * entity_compute_update (movement.c:2336-2358), with the output conventions of
+ * navhip_agent_step (include/navhip.h) */
+static void step_one(const step_ctx *c, int uid, const navhip_step_out *o)
+{
+    const navhip_world *w = c->w;
+    const int state = w->state[uid];
+    const uint32_t flags = w->flags[uid];
+    unsigned status = 0;
+    v2 out_vel = mkv(0.0f, 0.0f), vdes = mkv(0.0f, 0.0f), vpref = mkv(0.0f, 0.0f);
+    const bool active = !state_still(state);
+    const v2 me = wpos(w, uid);
+
+    if(active && !(flags & NAVHIP_ENTITY_FLAG_COMBAT_HELD)) {
+        bool supported = true;
+        if(state == NAVHIP_STATE_TURNING) {
+            vpref = mkv(0.0f, 0.0f);
+        }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_point_seek(state)) {
+            if(w->vdes_xz) vdes = mkv(w->vdes_xz[2 * uid], w->vdes_xz[2 * uid + 1]);
+            else           vdes = sample_flow(c->m, w, w->flock[uid], me, &status);
+            if(state == NAVHIP_STATE_SEEK_ENEMIES)
+                vpref = enemy_seek_vpref(c, uid, w->speed[uid], vdes);
+            else
+                vpref = point_seek_vpref(c, uid, w->flock[uid], vdes, w->has_dest_los[uid] != 0,
+                                         w->speed[uid]);
+        }else{
+            supported = false;
+            status |= NAVHIP_ST_UNSUPPORTED;
+        }
+        if(supported) {
+            cpent dyn[32], stat[32];
+            int n_dyn, n_stat;
+            find_neighbours(c, uid, dyn, &n_dyn, stat, &n_stat);
+            cpent ent = {me, wvel(w, uid), w->radius[uid]};
+            v2 nv = cp_solve(ent, vpref, dyn, n_dyn, stat, n_stat);
+            out_vel = vtrunc(nv, w->max_speed[uid] / w->hz);
+        }
+    }
+
+    v2 new_pos = me;
+    if(active) {
+        int layer = nav_layer_for(flags, w->radius[uid]);
+        v2 cand = vadd(me, out_vel);
+        bool on_blocked = pos_blocked(c->m, w, layer, me);
+        if(vlen(out_vel) > 0 && pos_pathable(c->m, w, layer, cand)
+        && (on_blocked || !pos_blocked(c->m, w, layer, cand))) {
+            new_pos = cand;
+            status |= NAVHIP_ST_MOVED;
+        }
+    }
+    o->vel_xz[2 * uid] = out_vel.x; o->vel_xz[2 * uid + 1] = out_vel.z;
+    if(o->new_pos_xz) { o->new_pos_xz[2 * uid] = new_pos.x; o->new_pos_xz[2 * uid + 1] = new_pos.z; }
+    if(o->vdes_xz)    { o->vdes_xz[2 * uid] = vdes.x;    o->vdes_xz[2 * uid + 1] = vdes.z; }
+    if(o->vpref_xz)   { o->vpref_xz[2 * uid] = vpref.x;  o->vpref_xz[2 * uid + 1] = vpref.z; }
+    if(o->status) o->status[uid] = (uint8_t)status;
+}
+
+typedef struct { const step_ctx *c; const navhip_step_out *o; int begin, end; } step_job;
+
+static void *step_thread(void *arg)
+{
+    step_job *j = arg;
+    for(int uid = j->begin; uid < j->end; uid++)
+        step_one(j->c, uid, j->o);
+    return NULL;
+}
+
+/* The velocity step for entities [work_begin, work_end) (0,0 = all), fork-joined over
+ * `nthreads` contiguous slabs like move_submit_cpu_work (movement.c:3746-3774). */
+int no_agent_step(const no_map *m, const navhip_world *w, const navhip_step_out *o, int nthreads)
+{
+    if(!m || !w || !o || !o->vel_xz || w->n_ents < 0) return -1;
+    if(w->hz != 20 && w->hz != 10 && w->hz != 5 && w->hz != 1) return -1;
+    if(w->n_ents == 0) return 0;
+    no_grid g;
+    if(grid_build(&g, w)) return -1;
+    step_ctx c = {m, w, &g, 0, 0};
+    c.scaled_max_force = (0.75f / w->hz * 20.0);
+    c.scaled_max_force_f = (float)c.scaled_max_force;
+    int b = w->work_begin, e = w->work_end;
+    if(b == 0 && e == 0) e = w->n_ents;
+    if(nthreads < 1) nthreads = 1;
+    if(nthreads > 256) nthreads = 256;
+    if(nthreads == 1) {
+        step_job j = {&c, o, b, e};
+        step_thread(&j);
+    }else{
+        pthread_t th[256];
+        step_job jobs[256];
+        int per = (e - b + nthreads - 1) / nthreads;
+        for(int t = 0; t < nthreads; t++) {
+            int jb = b + t * per, je = jb + per;
+            if(jb > e) jb = e;
+            if(je > e) je = e;
+            jobs[t] = (step_job){&c, o, jb, je};
+            pthread_create(&th[t], NULL, step_thread, &jobs[t]);
+        }
+        for(int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    grid_free(&g);
+    return 0;
+}
+
+/* individual terms, for stage-by-stage parity tests */
+int no_agent_forces(const no_map *m, const navhip_world *w, int uid, const float vdes[2],
+                    float out_arrive[2], float out_cohesion[2], float out_separation[2])
+{
+    no_grid g;
+    if(grid_build(&g, w)) return -1;
+    step_ctx c = {m, w, &g, 0, 0};
+    c.scaled_max_force = (0.75f / w->hz * 20.0);
+    c.scaled_max_force_f = (float)c.scaled_max_force;
+    int flock = w->flock[uid];
+    v2 target = flock >= 0 ? mkv(w->flock_target_xz[2 * flock], w->flock_target_xz[2 * flock + 1]) : wpos(w, uid);
+    v2 a = arrive_force_point(&c, uid, target, mkv(vdes[0], vdes[1]), w->has_dest_los[uid] != 0);
+    v2 co = flock >= 0 ? cohesion_force(&c, uid, flock) : mkv(0.0f, 0.0f);
+    v2 s = separation_force(&c, uid);
+    out_arrive[0] = a.x; out_arrive[1] = a.z;
+    out_cohesion[0] = co.x; out_cohesion[1] = co.z;
+    out_separation[0] = s.x; out_separation[1] = s.z;
+    grid_free(&g);
+    return 0;
+}
+
+/* ===========================================================================================
+ * timing helpers for bench.py's cpu_baseline leg ("port" kind)
+ * =========================================================================================== */
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+typedef struct { const no_map *m; const navhip_field_req *reqs; int begin, end, reps; uint8_t *scratch; } fjob;
+
+static void *field_thread(void *arg)
+{
+    fjob *j = arg;
+    for(int r = 0; r < j->reps; r++)
+        for(int i = j->begin; i < j->end; i++)
+            no_field_update(j->m, &j->reqs[i], j->scratch, NULL);
+    return NULL;
+}
+
+double no_field_bench(const no_map *m, const navhip_field_req *reqs, int n, int reps, int nthreads)
+{
+    if(nthreads < 1) nthreads = 1;
+    if(nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    fjob jobs[256];
+    uint8_t *scratch = malloc((size_t)nthreads * CELLS);
+    int per = (n + nthreads - 1) / nthreads;
+    double t0 = now_s();
+    for(int t = 0; t < nthreads; t++) {
+        int b = t * per, e = b + per;
+        if(b > n) b = n;
+        if(e > n) e = n;
+        jobs[t] = (fjob){m, reqs, b, e, reps, scratch + (size_t)t * CELLS};
+        pthread_create(&th[t], NULL, field_thread, &jobs[t]);
+    }
+    for(int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    double dt = now_s() - t0;
+    free(scratch);
+    return dt;
+}
+
+double no_agent_bench(const no_map *m, const navhip_world *w, const navhip_step_out *o, int nthreads)
+{
+    double t0 = now_s();
+    no_agent_step(m, w, o, nthreads);
+    return now_s() - t0;
+}

@@ -44,6 +44,37 @@ def slab(n_items, rank, world):
     return b, min(b + per, n_items)
 
 
+def request_slices(dest_of_req, n_dests, world):
+    """Per-rank [begin, end) slices of a destination-major chunk-field request stream: rank r
+    builds every chunk field of the destinations slab(n_dests, r, world)."""
+    import numpy as np
+    dest_of_req = np.asarray(dest_of_req)
+    out = []
+    for r in range(world):
+        d0, d1 = slab(n_dests, r, world)
+        sel = np.flatnonzero((dest_of_req >= d0) & (dest_of_req < d1))
+        out.append((int(sel[0]), int(sel[-1]) + 1) if len(sel) else (0, 0))
+    return out
+
+
+def exchange_rows(full, bounds, rank, world):
+    """The tick's exchange step: rank r has just produced rows bounds[r] = [begin, end) of `full`
+    (baked 4 KB flow tiles, or a slab of agent results); afterwards every rank holds every row.
+    Equal contiguous shares go through ONE all-gather (RCCL ring over xGMI on the GPUs); ragged
+    shares fall back to one broadcast per rank."""
+    if world == 1:
+        return
+    sizes = [e - b for b, e in bounds]
+    equal = len(set(sizes)) == 1 and all(bounds[r][0] == r * sizes[0] for r in range(world)) \
+        and sizes[0] * world == full.shape[0]
+    if equal:
+        all_gather_rows(full, rank, world, sizes[0])
+    else:
+        for r, (b, e) in enumerate(bounds):
+            if e > b:
+                dist.broadcast(full[b:e], src=r)
+
+
 def all_gather_rows(full, rank, world, rows_per_rank):
     """In-place all-gather of equally sized row slabs of `full` ([world*rows_per_rank, ...]):
     rank r contributes full[r*rows_per_rank:(r+1)*rows_per_rank] and receives the others."""

@@ -96,17 +96,6 @@ def make_reqs(n):
     return r
 
 
-def reqs_from_ref(ref_reqs):
-    """oracle FieldReq records (int32 fields) -> navhip_field_req records."""
-    out = make_reqs(len(ref_reqs))
-    for name in ("layer", "type", "faction_id", "chunk_r", "chunk_c", "tile_r", "tile_c",
-                 "port_r0", "port_c0", "port_r1", "port_c1", "next_r0", "next_c0", "next_r1",
-                 "next_c1", "next_chunk_r", "next_chunk_c", "port_iid", "next_iid"):
-        out[name] = ref_reqs[name]
-    out["flags"] = np.where(ref_reqs["inout"] != 0, REQ_INOUT, 0)
-    return out
-
-
 class NavContext:
     """Device-resident navigation state of one map: the GPU counterpart of the planes of
     `struct nav_private` (nav_private.h:52) that the hot path reads."""

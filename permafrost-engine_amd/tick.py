@@ -48,12 +48,10 @@ class NavTick:
         slot_tbl = -np.ones((self.K, self.nchunks), np.int32)
         slot_tbl[dest_of_req, cols["chunk_r"] * chunk_w + cols["chunk_c"]] = np.arange(n_req)
         # this rank's slice of the request stream: whole destinations, contiguous
-        d0, d1 = pdist.slab(self.K, rank, world)
-        sel = np.flatnonzero((dest_of_req >= d0) & (dest_of_req < d1))
-        self.req_begin, self.req_end = (int(sel[0]), int(sel[-1]) + 1) if len(sel) else (0, 0)
+        self.req_bounds = pdist.request_slices(dest_of_req, self.K, world)
+        self.req_begin, self.req_end = self.req_bounds[rank]
         self.n_req_local = self.req_end - self.req_begin
-        self.equal_req_slices = (n_req % world == 0) and self.n_req_local == n_req // world \
-            and self.req_begin == rank * (n_req // world)
+        self.agent_bounds = [pdist.slab(self.N, r, world) for r in range(world)]
 
         ag = synth.agents(grid, self.N, self.K, seed=7, hz=hz)
         offs, members = navhip.flock_csr(ag["flock"], self.K)
@@ -120,26 +118,12 @@ class NavTick:
                 self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
                                           self.pool[self.req_begin:self.req_end], stream=s.cuda_stream)
             marks.append(self._mark("gather_tiles"))
-            if self.world > 1:
-                if self.equal_req_slices:
-                    pdist.all_gather_rows(self.pool, self.rank, self.world, self.n_req_local)
-                else:       # ragged slices: broadcast each rank's slice
-                    for r in range(self.world):
-                        b, e = self._req_slice_of(r)
-                        torch.distributed.broadcast(self.pool[b:e], src=r)
+            pdist.exchange_rows(self.pool, self.req_bounds, self.rank, self.world)
             marks.append(self._mark("agents"))
             self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
             marks.append(self._mark("gather_agents"))
-            if self.world > 1:
-                per = self.a1 - self.a0
-                if per * self.world == self.N:
-                    pdist.all_gather_rows(self.new_pos, self.rank, self.world, per)
-                    pdist.all_gather_rows(self.new_vel, self.rank, self.world, per)
-                else:
-                    for r in range(self.world):
-                        b, e = pdist.slab(self.N, r, self.world)
-                        torch.distributed.broadcast(self.new_pos[b:e], src=r)
-                        torch.distributed.broadcast(self.new_vel[b:e], src=r)
+            pdist.exchange_rows(self.new_pos, self.agent_bounds, self.rank, self.world)
+            pdist.exchange_rows(self.new_vel, self.agent_bounds, self.rank, self.world)
             marks.append(self._mark("end"))
             # advance the snapshot: ping-pong the position / velocity buffers
             self.t["pos_xz"], self.new_pos = self.new_pos, self.t["pos_xz"]
@@ -147,11 +131,6 @@ class NavTick:
             self._make_structs()
         if self.record:
             self.ev.append(marks)
-
-    def _req_slice_of(self, r):
-        d0, d1 = pdist.slab(self.K, r, self.world)
-        sel = np.flatnonzero((self._dest_of_req >= d0) & (self._dest_of_req < d1))
-        return (int(sel[0]), int(sel[-1]) + 1) if len(sel) else (0, 0)
 
     def phase_ms(self):
         """Average HIP-event duration of every phase over the recorded steps."""

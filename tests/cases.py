@@ -2,7 +2,7 @@
 (oracle/_ref, i.e. the reference's own code).  Test infrastructure only."""
 import numpy as np
 
-from oracle import pfref
+from oracle import navoracle, pfref
 from permafrost_engine_amd import synth
 
 
@@ -52,6 +52,30 @@ def planner_requests(nav, grid, pairs, seed):
         reqs, before, after = nav.trace()
         all_reqs.append(reqs); all_before.append(before); all_after.append(after)
     return np.concatenate(all_reqs), np.concatenate(all_before), np.concatenate(all_after)
+
+
+def with_inplace(reqs, before, seed, count=8):
+    """Append `count` copies of random requests flagged in-place (N_FlowFieldUpdate on an EXISTING
+    field: unreached cells keep their bytes, field.c:737-751; the planner does this when a path
+    re-enters a chunk, nav.c:1987-2011, which random queries rarely trigger) with random
+    existing fields."""
+    rng = np.random.RandomState(seed)
+    pick = rng.randint(0, len(reqs), size=count)
+    extra = reqs[pick].copy()
+    extra["inout"] = 1
+    extra_before = rng.randint(0, 9, size=(count, 64, 64)).astype(np.uint8)
+    return np.concatenate([reqs, extra]), np.concatenate([before, extra_before])
+
+
+def reqs_from_ref(navlib, ref_reqs):
+    """Reference-harness request records (int32 fields) -> navhip_field_req records."""
+    out = navlib.make_reqs(len(ref_reqs))
+    for name in ("layer", "type", "faction_id", "chunk_r", "chunk_c", "tile_r", "tile_c",
+                 "port_r0", "port_c0", "port_r1", "port_c1", "next_r0", "next_c0", "next_r1",
+                 "next_c1", "next_chunk_r", "next_chunk_c", "port_iid", "next_iid"):
+        out[name] = ref_reqs[name]
+    out["flags"] = np.where(ref_reqs["inout"] != 0, navlib.REQ_INOUT, 0)
+    return out
 
 
 def ref_fields(nav, reqs, before=None, want_integ=True):
@@ -142,3 +166,96 @@ def ref_move_for(nav, world, hz=20):
                        world["has_dest_los"], world["flock_target_xz"], np.array(dest_ids, np.uint32),
                        hz=hz)
     return mv, dest_ids
+
+
+def step_arrays(world, vdes, flock_order=None):
+    """navhip_world member arrays for a make_agents() world.  flock_order: per-flock uid arrays in
+    the reference's kh_foreach order (RefMove.flock_order); ascending uid when None."""
+    k = len(world["flock_target_xz"])
+    lists = flock_order if flock_order is not None else \
+        [np.flatnonzero(world["flock"] == f) for f in range(k)]
+    offs = np.zeros(k + 1, np.int32)
+    offs[1:] = np.cumsum([len(l) for l in lists])
+    members = np.concatenate(lists).astype(np.int32) if k else np.zeros(0, np.int32)
+    a = {n: world[n] for n in ("pos_xz", "vel_xz", "radius", "max_speed", "speed", "flags", "state",
+                               "has_dest_los", "flock", "flock_target_xz")}
+    a["flock_offsets"], a["flock_members"] = offs, members
+    a["vdes_xz"] = vdes
+    return a
+
+
+def oracle_nav_from_ref(nav, layer=0):
+    """The restatement oracle over the SAME planes the reference context holds."""
+    return navoracle.OracleNav(nav.plane(pfref.PLANE_COST, layer), nav.plane(pfref.PLANE_BLOCKERS, layer),
+                               nav.plane(pfref.PLANE_LOCAL_ISLANDS, layer), layer=layer)
+
+
+def cols_to_reqs(cols, dtype):
+    """synth.whole_map_requests() columns -> request records of `dtype`."""
+    n = len(cols["type"])
+    reqs = np.zeros(n, dtype)
+    for k in synth.REQ_FIELDS:
+        reqs[k] = cols[k]
+    return reqs
+
+
+class Oracle:
+    """Single-process answers for a synthetic job, from the C restatement (oracle/navoracle.c)."""
+
+    def __init__(self, grid, blockers=None):
+        self.grid = grid
+        self.h, self.w = grid.shape[0] // 64, grid.shape[1] // 64
+        self.liid = synth.local_islands(grid)
+        blk = np.zeros((self.h, self.w, 64, 64), np.uint16) if blockers is None else blockers
+        self.nav = navoracle.OracleNav(synth.to_chunks(grid), blk, synth.to_chunks(self.liid))
+
+    def fields(self, cols):
+        dirs, _ = self.nav.build_fields(cols_to_reqs(cols, navoracle.FIELD_REQ_DTYPE))
+        return dirs
+
+    def step(self, world, vdes=None):
+        """(velocities, new positions) of one tick; desired directions = unit +x unless given."""
+        n = len(world["pos_xz"])
+        if vdes is None:
+            vdes = np.zeros((n, 2), np.float32)
+            vdes[:, 0] = 1.0
+        out = self.nav.agent_step(step_arrays(world, vdes))
+        return out["vel_xz"], out["new_pos_xz"]
+
+
+def cp_problems(seed, nq, max_dyn, max_stat, spread):
+    rng = np.random.RandomState(seed)
+    ent = np.zeros((nq, 5), np.float32)
+    ent[:, 0:2] = rng.uniform(-200, 200, size=(nq, 2))
+    ent[:, 2:4] = rng.normal(0, 0.5, size=(nq, 2))
+    ent[:, 4] = rng.choice([1.0, 1.5, 2.5], size=nq)
+    des = rng.normal(0, 0.7, size=(nq, 2)).astype(np.float32)
+    dyn = np.zeros((nq, 32, 5), np.float32)
+    stat = np.zeros((nq, 32, 5), np.float32)
+    nd = rng.randint(0, max_dyn + 1, size=nq).astype(np.int32)
+    ns = rng.randint(0, max_stat + 1, size=nq).astype(np.int32)
+    for arr, moving in ((dyn, True), (stat, False)):
+        arr[:, :, 0:2] = ent[:, None, 0:2] + rng.uniform(-spread, spread, size=(nq, 32, 2))
+        if moving:
+            arr[:, :, 2:4] = rng.normal(0, 0.6, size=(nq, 32, 2))
+        arr[:, :, 4] = rng.choice([1.0, 1.5, 2.5], size=(nq, 32))
+    # a few degenerate cases: neighbour exactly on top of the agent, axis-aligned offsets
+    dyn[0, 0, 0:2] = ent[0, 0:2]
+    stat[1, 0, 0:2] = ent[1, 0:2] + [0.0, 3.0]
+    dyn[2, 0, 0:2] = ent[2, 0:2] + [3.0, 0.0]
+    return ent, des, dyn, nd, stat, ns
+
+
+def cached_field_table(nav, dest_ids, w, h):
+    """The (dest, chunk) -> field mapping + field pool the reference's cache holds."""
+    k = len(dest_ids)
+    slots = -np.ones((k, w * h), np.int32)
+    pool = []
+    for f, did in enumerate(dest_ids):
+        for cr in range(h):
+            for cc in range(w):
+                ff = nav.cached_field(did, cr, cc)
+                if ff is not None:
+                    slots[f, cr * w + cc] = len(pool)
+                    pool.append(ff.reshape(-1))
+    return slots, np.stack(pool).astype(np.uint8)

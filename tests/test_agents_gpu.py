@@ -38,34 +38,11 @@ def test_spatial_query_order_and_caps(navlib):
     ctx.close()
 
 
-def _cp_problems(seed, nq, max_dyn, max_stat, spread):
-    rng = np.random.RandomState(seed)
-    ent = np.zeros((nq, 5), np.float32)
-    ent[:, 0:2] = rng.uniform(-200, 200, size=(nq, 2))
-    ent[:, 2:4] = rng.normal(0, 0.5, size=(nq, 2))
-    ent[:, 4] = rng.choice([1.0, 1.5, 2.5], size=nq)
-    des = rng.normal(0, 0.7, size=(nq, 2)).astype(np.float32)
-    dyn = np.zeros((nq, 32, 5), np.float32)
-    stat = np.zeros((nq, 32, 5), np.float32)
-    nd = rng.randint(0, max_dyn + 1, size=nq).astype(np.int32)
-    ns = rng.randint(0, max_stat + 1, size=nq).astype(np.int32)
-    for arr, moving in ((dyn, True), (stat, False)):
-        arr[:, :, 0:2] = ent[:, None, 0:2] + rng.uniform(-spread, spread, size=(nq, 32, 2))
-        if moving:
-            arr[:, :, 2:4] = rng.normal(0, 0.6, size=(nq, 32, 2))
-        arr[:, :, 4] = rng.choice([1.0, 1.5, 2.5], size=(nq, 32))
-    # a few degenerate cases: neighbour exactly on top of the agent, axis-aligned offsets
-    dyn[0, 0, 0:2] = ent[0, 0:2]
-    stat[1, 0, 0:2] = ent[1, 0:2] + [0.0, 3.0]
-    dyn[2, 0, 0:2] = ent[2, 0:2] + [3.0, 0.0]
-    return ent, des, dyn, nd, stat, ns
-
-
 @pytest.mark.parametrize("seed,max_dyn,max_stat,spread", [(1, 6, 3, 9.0), (2, 32, 32, 9.5), (3, 12, 0, 5.0),
                                                          (4, 0, 12, 5.0), (5, 3, 3, 2.5)])
 def test_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread):
     nq = 400 if max_dyn < 32 else 60
-    ent, des, dyn, nd, stat, ns = _cp_problems(seed, nq, max_dyn, max_stat, spread)
+    ent, des, dyn, nd, stat, ns = cases.cp_problems(seed, nq, max_dyn, max_stat, spread)
     exp = np.zeros((nq, 2), np.float32)
     for i in range(nq):
         exp[i] = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
@@ -91,13 +68,7 @@ def _upload(navlib, nav):
 
 def _step_arrays(world, mv, vdes):
     k = len(world["flock_target_xz"])
-    offs, members = __import__("permafrost_engine_amd").navhip.flock_csr(
-        world["flock"], k, order=[mv.flock_order(f) for f in range(k)])
-    a = {n: world[n] for n in ("pos_xz", "vel_xz", "radius", "max_speed", "speed", "flags", "state",
-                               "has_dest_los", "flock", "flock_target_xz")}
-    a["flock_offsets"], a["flock_members"] = offs, members
-    a["vdes_xz"] = vdes
-    return a
+    return cases.step_arrays(world, vdes, [mv.flock_order(f) for f in range(k)])
 
 
 @pytest.mark.parametrize("clustered,n,k,blk", [(False, 1500, 4, False), (True, 1200, 3, False),
@@ -142,20 +113,10 @@ def test_device_flow_sampling_matches_reference(navlib):
     mv.velocity(None)                    # first pass populates / merges the reference's field cache
     exp_vel = mv.velocity(None)          # second pass samples the now-stable cache
     vdes = mv.vdes()
-    # the (dest, chunk) -> field table the reference's cache holds after those queries
-    k = len(dest_ids)
-    slots = -np.ones((k, 16), np.int32)
-    pool = []
-    for f, did in enumerate(dest_ids):
-        for cr in range(4):
-            for cc in range(4):
-                ff = nav.cached_field(did, cr, cc)
-                if ff is not None:
-                    slots[f, cr * 4 + cc] = len(pool)
-                    pool.append(ff.reshape(-1))
+    slots, pool_arr = cases.cached_field_table(nav, dest_ids, 4, 4)
     a = _step_arrays(world, mv, None)
     a["flock_field_slot"] = slots
-    a["field_pool"] = np.stack(pool).astype(np.uint8)
+    a["field_pool"] = pool_arr
     ctx = _upload(navlib, nav)
     out = ctx.agent_step(a)
     ctx.close()

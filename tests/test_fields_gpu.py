@@ -15,7 +15,7 @@ def _check(navlib, grid, nav, reqs, before, mode, blockers=None):
     ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(1))
     ctx.upload_plane(0, navlib.PLANE_LOCAL_ISLANDS, nav.plane(3))
     ctx.set_field_kernel(mode)
-    hreqs = navlib.reqs_from_ref(reqs)
+    hreqs = cases.reqs_from_ref(navlib, reqs)
     dirs, integ = ctx.N_FlowFieldUpdate(hreqs, inout=before, want_integ=True)
     bad = np.argwhere((dirs != exp_dirs).reshape(len(reqs), -1).any(1)).ravel()
     assert bad.size == 0, "flow dirs differ for requests %s (first: %s)" % (bad[:8], reqs[bad[0]])
@@ -37,7 +37,8 @@ def test_tile_fields_match_reference(navlib, mode):
 def test_planner_request_stream_matches_reference(navlib, mode):
     grid, nav = cases.ref_nav_for(4, 4, seed=1234)
     reqs, before, after = cases.planner_requests(nav, grid, pairs=24, seed=9)
-    assert (reqs["type"] == 0).sum() > 20
+    reqs, before = cases.with_inplace(reqs, before, seed=2, count=12)
+    assert (reqs["type"] == 0).sum() > 20 and (reqs["inout"] != 0).sum() >= 12
     _check(navlib, grid, nav, reqs, before, mode)
 
 

@@ -1,0 +1,193 @@
+"""Pinning the oracle.  The reference holds no golden vectors for this path, so
+the C restatement (oracle/navoracle.c) is pinned against OUTPUTS OF THE REFERENCE ITSELF:
+  * live, against oracle/_ref/libpfref.so (the reference's own nav/field/clearpath/movement
+    translation units compiled in place) -- these tests need /root/reference or a prebuilt _ref;
+  * against the committed fixtures tests/golden/*.npz that scripts/make_golden.py produced from
+    _ref -- these run anywhere.
+Integer work is compared bit for bit; float velocities are compared bit for bit too (same
+compiler, same expression order), far inside BASELINE.json's 1e-4 relative bound."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import navoracle, pfref
+from tests import cases
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+needs_ref = pytest.mark.skipif(not (pfref.available() or os.path.isdir("/root/reference")),
+                               reason="oracle/_ref not built and /root/reference absent")
+
+
+def _o_reqs(ref_reqs):
+    out = np.zeros(len(ref_reqs), navoracle.FIELD_REQ_DTYPE)
+    out["faction_id"] = 0xF
+    for name in ("layer", "type", "faction_id", "chunk_r", "chunk_c", "tile_r", "tile_c",
+                 "port_r0", "port_c0", "port_r1", "port_c1", "next_r0", "next_c0", "next_r1",
+                 "next_c1", "next_chunk_r", "next_chunk_c", "port_iid", "next_iid"):
+        out[name] = ref_reqs[name]
+    out["flags"] = np.where(ref_reqs["inout"] != 0, 1, 0)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# live against the reference
+# ---------------------------------------------------------------------------------------------
+@needs_ref
+@pytest.mark.parametrize("seed,w,blk", [(11, 2, False), (1234, 4, False), (77, 3, True)])
+def test_fields_restatement_matches_reference(seed, w, blk):
+    grid = cases.synth.cost_grid(w, w, seed=seed)
+    blockers = cases.random_blockers(grid, seed=3) if blk else None
+    grid, nav = cases.ref_nav_for(w, w, seed=seed, blockers=blockers)
+    reqs_t = cases.tile_requests(grid, 24, seed=5)
+    reqs_p, before, _after = cases.planner_requests(nav, grid, pairs=12, seed=9)
+    reqs = np.concatenate([reqs_t, reqs_p])
+    before = np.concatenate([np.zeros((len(reqs_t), 64, 64), np.uint8), before])
+    n_plan = len(reqs)
+    reqs, before = cases.with_inplace(reqs, before, seed=seed)
+    exp_dirs, exp_integ = cases.ref_fields(nav, reqs, before)
+    onav = cases.oracle_nav_from_ref(nav)
+    dirs, integ = onav.build_fields(_o_reqs(reqs), inout=before, want_integ=True)
+    assert np.array_equal(dirs, exp_dirs)
+    assert np.array_equal(integ, exp_integ)
+    # the planner's own after-images are what N_FlowFieldUpdate left in the cache
+    assert np.array_equal(dirs[len(reqs_t):n_plan], _after)
+    assert (reqs["type"] == 0).sum() > 8 and (reqs["inout"] != 0).sum() >= 8
+
+
+@needs_ref
+def test_spatial_query_restatement_matches_reference():
+    rng = np.random.RandomState(4)
+    pos = np.concatenate([rng.uniform(-510, 510, size=(2500, 2)),
+                          rng.normal([100, -200], 6.0, size=(700, 2)),
+                          rng.normal([-300, 250], 14.0, size=(700, 2)),
+                          [[-512.0, -512.0], [512.0, 512.0], [511.99, -3.0]]]).astype(np.float32)
+    q = np.concatenate([pos[::9], [[100, -200], [-300, 250], [-512, 512], [0, 0]]]).astype(np.float32)
+    bounds = (-512.0, 512.0, -512.0, 512.0)
+    for r, cap in ((30.0, 128), (10.0, 512), (10.0, 7), (1400.0, 256)):
+        ec, ei = pfref.spatial_query(bounds, pos, q, r, cap)
+        gc, gi = navoracle.spatial_query(4, 4, pos, q, r, cap)
+        assert np.array_equal(ec, gc), (r, cap)
+        for k in range(len(q)):
+            assert np.array_equal(ei[k, :ec[k]], gi[k, :gc[k]]), (r, cap, k)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,max_dyn,max_stat,spread", [(1, 6, 3, 9.0), (2, 32, 32, 9.5),
+                                                         (3, 12, 0, 5.0), (4, 0, 12, 5.0), (5, 3, 3, 2.5)])
+def test_clearpath_restatement_matches_reference(seed, max_dyn, max_stat, spread):
+    nq = 300 if max_dyn < 32 else 40
+    ent, des, dyn, nd, stat, ns = cases.cp_problems(seed, nq, max_dyn, max_stat, spread)
+    exp = np.zeros((nq, 2), np.float32)
+    for i in range(nq):
+        exp[i] = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
+    got = navoracle.clearpath(ent, des, dyn, nd, stat, ns)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))      # bit for bit, NaNs included
+
+
+@needs_ref
+@pytest.mark.parametrize("clustered,n,k,blk", [(False, 900, 4, False), (True, 800, 3, False),
+                                               (True, 900, 2, True)])
+def test_velocity_step_restatement_matches_reference(clustered, n, k, blk):
+    grid = cases.synth.cost_grid(4, 4, seed=21)
+    blockers = cases.random_blockers(grid, seed=8, frac=0.02) if blk else None
+    grid, nav = cases.ref_nav_for(4, 4, seed=21, blockers=blockers)
+    world = cases.make_agents(grid, n, k, seed=31 + n, clustered=clustered)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    exp_vel = mv.velocity(None)
+    vdes = mv.vdes()
+    onav = cases.oracle_nav_from_ref(nav)
+    arrays = cases.step_arrays(world, vdes, [mv.flock_order(f) for f in range(k)])
+    out = onav.agent_step(arrays)
+    moving = ~np.isin(world["state"], (2, 4))
+    assert np.array_equal(out["vel_xz"][moving].view(np.uint32), exp_vel[moving].view(np.uint32))
+    assert np.all(out["vel_xz"][~moving] == 0)
+    # individual steering terms and the preferred velocity
+    ps = np.flatnonzero(np.isin(world["state"], (0, 5, 6)))
+    for uid in ps[:40]:
+        ea, ec, es = mv.forces(int(uid), vdes[uid])
+        ga, gc, gs = onav.forces(arrays, int(uid), vdes[uid])
+        assert np.array_equal(ea, ga) and np.array_equal(ec, gc) and np.array_equal(es, gs), uid
+        assert np.array_equal(mv.vpref(int(uid), vdes[uid]), out["vpref_xz"][uid]), uid
+    # position accept test vs N_PositionPathable / N_PositionBlocked
+    for uid in np.flatnonzero(moving)[:150]:
+        v = exp_vel[uid]
+        npos = world["pos_xz"][uid] + v
+        on_blocked = nav.position_blocked(world["pos_xz"][uid])
+        acc = (np.linalg.norm(v) > 0) and nav.position_pathable(npos) and \
+            (on_blocked or not nav.position_blocked(npos))
+        assert bool(out["status"][uid] & 1) == bool(acc), uid
+    # threads split the slab without changing anything
+    out4 = onav.agent_step(arrays, nthreads=4)
+    assert np.array_equal(out4["vel_xz"].view(np.uint32), out["vel_xz"].view(np.uint32))
+    pfref.RefMove.unload()
+
+
+@needs_ref
+def test_flow_sampling_restatement_matches_reference():
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    world = cases.make_agents(grid, 600, 3, seed=77, clustered=False)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    mv.velocity(None)
+    exp_vel = mv.velocity(None)
+    vdes = mv.vdes()
+    slots, pool = cases.cached_field_table(nav, dest_ids, 4, 4)
+    arrays = cases.step_arrays(world, None, [mv.flock_order(f) for f in range(3)])
+    arrays["flock_field_slot"], arrays["field_pool"] = slots, pool
+    out = cases.oracle_nav_from_ref(nav).agent_step(arrays)
+    ps = np.isin(world["state"], (0, 5, 6))
+    clean = ps & ((out["status"] & 0x06) == 0)
+    assert clean.sum() > 250
+    assert np.array_equal(out["vdes_xz"][clean], vdes[clean])
+    assert np.array_equal(out["vel_xz"][clean], exp_vel[clean])
+    pfref.RefMove.unload()
+
+
+# ---------------------------------------------------------------------------------------------
+# against the committed fixtures (generated from the reference by scripts/make_golden.py)
+# ---------------------------------------------------------------------------------------------
+def _gold(name):
+    path = os.path.join(GOLD, name)
+    assert os.path.exists(path), "missing fixture %s (run scripts/make_golden.py)" % name
+    return np.load(path)
+
+
+def test_golden_fields():
+    g = _gold("fields_3x3.npz")
+    onav = navoracle.OracleNav(g["cost"], g["blockers"], g["local_islands"])
+    dirs, integ = onav.build_fields(g["reqs"].view(navoracle.FIELD_REQ_DTYPE).reshape(-1),
+                                    inout=g["before"], want_integ=True)
+    assert np.array_equal(dirs, g["dirs"])
+    assert np.array_equal(integ, g["integ"])
+
+
+def test_golden_spatial_and_clearpath():
+    g = _gold("agents_4x4.npz")
+    for key in ("r30", "r10", "wide"):
+        c, ids = navoracle.spatial_query(4, 4, g["pos_xz"], g["sq_query"], float(g["sq_" + key + "_range"]),
+                                         int(g["sq_" + key + "_cap"]))
+        ec, ei = g["sq_" + key + "_counts"], g["sq_" + key + "_ids"]
+        assert np.array_equal(c, ec)
+        for k in range(len(c)):
+            assert np.array_equal(ids[k, :c[k]], ei[k, :ec[k]]), (key, k)
+    got = navoracle.clearpath(g["cp_ent"], g["cp_des"], g["cp_dyn"], g["cp_nd"], g["cp_stat"], g["cp_ns"])
+    assert np.array_equal(got.view(np.uint32), g["cp_out"].view(np.uint32))
+
+
+def test_golden_velocity_step():
+    g = _gold("agents_4x4.npz")
+    onav = navoracle.OracleNav(g["cost"], g["blockers"], g["local_islands"])
+    arrays = {k: g[k] for k in ("pos_xz", "vel_xz", "radius", "max_speed", "speed", "flags", "state",
+                                "has_dest_los", "flock", "flock_target_xz", "flock_offsets",
+                                "flock_members")}
+    arrays["vdes_xz"] = g["vdes_xz"]
+    out = onav.agent_step(arrays)
+    moving = ~np.isin(g["state"], (2, 4))
+    assert np.array_equal(out["vel_xz"][moving].view(np.uint32), g["ref_vel"][moving].view(np.uint32))
+    # sampling the reference's cached fields on the fly gives the reference's desired directions
+    arrays["vdes_xz"] = None
+    arrays["flock_field_slot"], arrays["field_pool"] = g["flock_field_slot"], g["field_pool"]
+    out2 = onav.agent_step(arrays)
+    clean = np.isin(g["state"], (0, 5, 6)) & ((out2["status"] & 0x06) == 0)
+    assert clean.sum() > 200
+    assert np.array_equal(out2["vdes_xz"][clean], g["ref_vdes_sampled"][clean])
