@@ -205,6 +205,12 @@ int  navhip_agent_step(navhip_ctx *ctx, const navhip_world *world, const navhip_
 int  navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *dev_world,
                            const navhip_step_out *dev_out, void *stream);
 
+/* Per-kernel-group timing of the agent step with HIP events on the launch stream (bench.py's
+ * roofline line).  After a profiled navhip_agent_step[_dev], navhip_last_step_ms returns
+ * {spatial-hash build, k_cohesion, k_agent_step} in milliseconds (it waits for the step). */
+int  navhip_set_profiling(navhip_ctx *ctx, int on);
+int  navhip_last_step_ms(navhip_ctx *ctx, float out_ms[3]);
+
 /* Device spatial index only (bg_ent insert-all + cleanup + inrange_circle, bitmap_grid.h:1376):
  * for each query point the ids within `range`, in the reference's visiting order, capped at
  * maxout.  Host buffers.  Used by the parity tests of the neighbour gather. */

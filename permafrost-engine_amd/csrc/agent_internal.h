@@ -17,6 +17,7 @@ struct nh_spatial_scratch {
     int32_t *cell_count, *cell_fill;         // [ncells]
     int32_t *cell_start;                     // [ncells+1]
     int32_t *sorted_id, *sx, *sy;            // [n]
+    int32_t *block_sum;                      // [ceil(ncells/1024)] scan scratch
 };
 
 struct nh_step_params {
@@ -24,6 +25,7 @@ struct nh_step_params {
     nh_grid     grid;
     float       map_x, map_z;
     int         n_ents, n_flocks, hz;
+    int         n_members;           // upper bound of flock_offsets[n_flocks] (launch size)
     int         work_begin, work_end;
     const float    *pos_xz, *vel_xz, *radius, *max_speed, *speed;
     const uint32_t *flags;
@@ -42,6 +44,7 @@ struct nh_step_outs {
 
 void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
                              hipStream_t s);
+void nh_launch_cohesion(const nh_step_params &P, float *d_coh, hipStream_t s);
 void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const nh_step_outs &O, hipStream_t s);
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,
                              int32_t *d_counts, uint32_t *d_ids, hipStream_t s);

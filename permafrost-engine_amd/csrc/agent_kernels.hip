@@ -223,35 +223,64 @@ __global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz
     atomicAdd(&cell_count[c], 1);
 }
 
-// exclusive scan of cell_count[0..ncells) -> cell_start[0..ncells]; single workgroup, chunked
-__global__ __launch_bounds__(1024) void k_sp_scan(const int32_t *cell_count, int32_t *cell_start,
-                                                  int ncells)
+// exclusive scan of cell_count[0..ncells) -> cell_start[0..ncells], two passes over 1024-cell
+// blocks: (1) block-local exclusive scan + block totals, (2) add the sum of the preceding totals.
+__global__ __launch_bounds__(1024) void k_sp_scan_local(const int32_t *cell_count, int32_t *cell_start,
+                                                        int32_t *block_sum, int ncells)
 {
     __shared__ int32_t wsum[16];
-    __shared__ int32_t carry;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if(t == 0) carry = 0;
-    __syncthreads();
-    for(int base = 0; base < ncells; base += 1024) {
-        int i = base + t;
-        int32_t v = (i < ncells) ? cell_count[i] : 0;
-        int32_t incl = v;
+    const int i = blockIdx.x * 1024 + t;
+    int32_t v = (i < ncells) ? cell_count[i] : 0;
+    int32_t incl = v;
 #pragma unroll
-        for(int d = 1; d < 64; d <<= 1) {
-            int32_t o = __shfl_up(incl, d);
-            if(lane >= d) incl += o;
-        }
-        if(lane == 63) wsum[w] = incl;
-        __syncthreads();
-        int32_t woff = 0;
-        for(int k = 0; k < w; k++) woff += wsum[k];
-        int32_t excl = carry + woff + incl - v;
-        if(i < ncells) cell_start[i] = excl;
-        __syncthreads();
-        if(t == 1023) carry = excl + v;
-        __syncthreads();
+    for(int d = 1; d < 64; d <<= 1) {
+        int32_t o = __shfl_up(incl, d);
+        if(lane >= d) incl += o;
     }
-    if(t == 0) cell_start[ncells] = carry;
+    if(lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int32_t woff = 0, tot = 0;
+#pragma unroll
+    for(int k = 0; k < 16; k++) {
+        int32_t x = wsum[k];
+        if(k < w) woff += x;
+        tot += x;
+    }
+    if(i < ncells) cell_start[i] = woff + incl - v;
+    if(t == 0) block_sum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void k_sp_scan_add(int32_t *cell_start, const int32_t *block_sum,
+                                                      int ncells, int nblocks)
+{
+    __shared__ int32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // sum of the totals of the blocks before this one (and, in the last block, of all blocks)
+    int32_t part = 0, all = 0;
+    for(int k = t; k < nblocks; k += 1024) {
+        int32_t x = block_sum[k];
+        all += x;
+        if(k < (int)blockIdx.x) part += x;
+    }
+    const bool last = (int)blockIdx.x == nblocks - 1;
+    int32_t red = last ? all : part;          // the last block needs both: two reductions
+#pragma unroll
+    for(int d = 32; d >= 1; d >>= 1) { red += __shfl_xor(red, d); part += __shfl_xor(part, d); }
+    if(lane == 0) wsum[w] = red;
+    __syncthreads();
+    int32_t tot = 0;
+#pragma unroll
+    for(int k = 0; k < 16; k++) tot += wsum[k];
+    __syncthreads();
+    if(lane == 0) wsum[w] = part;
+    __syncthreads();
+    int32_t off = 0;
+#pragma unroll
+    for(int k = 0; k < 16; k++) off += wsum[k];
+    const int i = blockIdx.x * 1024 + t;
+    if(i < ncells) cell_start[i] += off;
+    if(last && t == 0) cell_start[ncells] = tot;
 }
 
 __global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, int n,
@@ -618,46 +647,150 @@ __device__ __forceinline__ bool state_uses_point_seek(int s)
         || s == NAVHIP_STATE_ENTER_ENTITY_RANGE;
 }
 
+// 2^(j/64), j = 0..63, correctly rounded doubles
+__constant__ double c_exp2_64[64] = {
+    0x1p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92dep+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cdp+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e5p+0,
+    0x1.9c49182a3f09p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e454p+0, 0x1.fa7c1819e90d8p+0};
+
+// (float)exp((double)a) for a in (-inf, ~80]: the reference evaluates libm's double exp on a
+// float argument and rounds to float (movement.c:1671,1731).  Table-driven double evaluation,
+// exp(a) = 2^(k/64) * exp(r), |r| <= ln2/128, degree-5 polynomial: < 2 ulp in double, so the
+// float rounding agrees with a correctly rounded exp except with probability ~1e-8 per call
+// (0 mismatches in 4e8 random arguments against glibc).  tab = 64-entry table in LDS.
+__device__ __forceinline__ float exp_f32_via_f64(float a, const double *tab)
+{
+    // branch free so that independent evaluations interleave: evaluate on a clamped argument,
+    // select +0 where exp(a) < 2^-150 (rounds to +0 in float)
+    const double x = (double)fmaxf(a, -104.0f);
+    const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);          // 64/ln2
+    const int k = (int)kd;
+    double r = __builtin_fma(-kd, 0x1.62e42fefa0000p-7, x);              // ln2/64, high part
+    r = __builtin_fma(-kd, 0x1.cf79abc9e3b3ap-46, r);                    //         low part
+    double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
+    p = __builtin_fma(p, r, 1.0 / 6);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const float res = (float)__builtin_ldexp(tab[k & 63] * p, k >> 6);
+    return (a <= -103.98f) ? 0.0f : res;
+}
+
+// cohesion weight of one flock member seen from `me` (movement.c:1668-1671)
+__device__ __forceinline__ float cohesion_scale(v2 cp, v2 me, const double *tab)
+{
+    const v2 diff = vsub(cp, me);
+    // float t = (len - 50.0f*0.75) / 50.0f, evaluated in double: the division by 50 as reciprocal
+    // multiply + one FMA correction (Markstein), correctly rounded for this divisor
+    const double r50 = 1.0 / 50.0;
+    const double x = (double)vlen(diff) - (double)50.0f * 0.75;
+    const double q0 = x * r50;
+    const double tq = __builtin_fma(__builtin_fma(-q0, 50.0, x), r50, q0);
+    return exp_f32_via_f64(-6.0f * (float)tq, tab);
+}
+
+// k_cohesion: 256 consecutive CSR entries (flock members) per workgroup, thread = member.
+// The flock's member positions are staged through LDS 256 at a time (coalesced gather) and every
+// thread walks them IN MEMBER ORDER (float sums are order dependent; LDS reads are wave-uniform
+// broadcasts), so the only global traffic in the O(N*F) loop is the staging itself.
 __global__ __launch_bounds__(256) void k_cohesion(nh_step_params P, float *coh_xz)
 {
-    const int g = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double tab[64];
+    __shared__ float2 spos[256];
+    const int t = threadIdx.x;
     const int total = P.flock_offsets[P.n_flocks];
-    if(g >= total) return;
-    // flock of entry g: binary search over the CSR offsets
-    int lo = 0, hi = P.n_flocks;
-    while(hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if(P.flock_offsets[mid] <= g) lo = mid; else hi = mid;
+    const int g0 = blockIdx.x * 256;
+    if(g0 >= total) return;
+    if(t < 64) tab[t] = c_exp2_64[t];
+    const int g = g0 + t;
+    const int gend = min(g0 + 256, total);
+    // flock of the block's first entry: binary search over the CSR offsets (uniform)
+    int f = 0;
+    {
+        int lo = 0, hi = P.n_flocks;
+        while(hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if(P.flock_offsets[mid] <= g0) lo = mid; else hi = mid;
+        }
+        f = lo;
     }
-    const int uid = P.flock_members[g];
-    if(uid < P.work_begin || uid >= P.work_end) return;
-    if(!state_uses_point_seek(P.state[uid]) || (P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD))
-        return;
-    const int b = P.flock_offsets[lo], e = P.flock_offsets[lo + 1];
-    const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
     const float scaled_max_force = (float)((double)(0.75f / (float)P.hz) * 20.0);
 
-    v2 com = mkv(0.0f, 0.0f);
-    int count = 0;
-    for(int j = b; j < e; j++) {
-        int curr = P.flock_members[j];
-        if(curr == uid) continue;
-        v2 cp = mkv(P.pos_xz[2 * curr], P.pos_xz[2 * curr + 1]);
-        v2 diff = vsub(cp, me);
-        // float t = (len - 50.0f*0.75) / 50.0f   evaluated in double, rounded to float
-        float t = (float)(((double)vlen(diff) - (double)50.0f * 0.75) / (double)50.0f);
-        float scale = (float)exp((double)(-6.0f * t));
-        cp = vscale(cp, scale);
-        com = vadd(com, cp);
-        count++;
+    for(;; f++) {
+        const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
+        const bool mine = g >= b && g < e && g < total;
+        const int uid = mine ? P.flock_members[g] : -1;
+        bool act = mine && uid >= P.work_begin && uid < P.work_end;
+        if(act) act = state_uses_point_seek(P.state[uid]) && !(P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD);
+        const v2 me = act ? mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
+        v2 com = mkv(0.0f, 0.0f);
+        if(__syncthreads_or(act)) {
+            for(int jb = b; jb < e; jb += 256) {
+                __syncthreads();
+                if(jb + t < e) {
+                    const int m = P.flock_members[jb + t];
+                    spos[t] = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
+                }
+                __syncthreads();
+                const int cnt = min(256, e - jb);
+                if(act) {
+                    // COH_U independent weight evaluations in flight (the chain sqrt -> double
+                    // divide -> exp is ~45 dependent instructions), then the ordered float sums
+                    constexpr int COH_U = 8;
+                    int jj = 0;
+                    for(; jj + COH_U <= cnt; jj += COH_U) {
+                        v2 cp[COH_U];
+                        float sc[COH_U];
+#pragma unroll
+                        for(int u = 0; u < COH_U; u++) {
+                            const float2 c2 = spos[jj + u];
+                            cp[u] = mkv(c2.x, c2.y);
+                            sc[u] = cohesion_scale(cp[u], me, tab);
+                        }
+#pragma unroll
+                        for(int u = 0; u < COH_U; u++) {
+                            const v2 sum = vadd(com, vscale(cp[u], sc[u]));
+                            const bool self = (jb + jj + u == g);        // curr == uid: skipped
+                            com.x = self ? com.x : sum.x;
+                            com.z = self ? com.z : sum.z;
+                        }
+                    }
+                    for(; jj < cnt; jj++) {
+                        const float2 c2 = spos[jj];
+                        const v2 cp = mkv(c2.x, c2.y);
+                        const v2 sum = vadd(com, vscale(cp, cohesion_scale(cp, me, tab)));
+                        const bool self = (jb + jj == g);
+                        com.x = self ? com.x : sum.x;
+                        com.z = self ? com.z : sum.z;
+                    }
+                }
+            }
+        }
+        if(act) {
+            const int count = (e - b) - 1;
+            v2 ret = mkv(0.0f, 0.0f);
+            if(count > 0) {
+                com = vscale(com, 1.0f / (float)count);
+                ret = vtrunc(vsub(com, me), scaled_max_force);
+            }
+            coh_xz[2 * uid] = ret.x;
+            coh_xz[2 * uid + 1] = ret.z;
+        }
+        if(e >= gend) break;
     }
-    v2 ret = mkv(0.0f, 0.0f);
-    if(count > 0) {
-        com = vscale(com, 1.0f / (float)count);
-        ret = vtrunc(vsub(com, me), scaled_max_force);
-    }
-    coh_xz[2 * uid] = ret.x;
-    coh_xz[2 * uid + 1] = ret.z;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -951,7 +1084,11 @@ void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
                            S.ent_ix, S.ent_iy, S.ent_cell, S.cell_count);
-    hipLaunchKernelGGL(k_sp_scan, dim3(1), dim3(1024), 0, s, S.cell_count, S.cell_start, ncells);
+    const int nblocks = (ncells + 1023) / 1024;
+    hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(1024), 0, s, S.cell_count, S.cell_start,
+                       S.block_sum, ncells);
+    hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(1024), 0, s, S.cell_start, S.block_sum, ncells,
+                       nblocks);
     if(n > 0)
         hipLaunchKernelGGL(k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, S.ent_cell, n,
                            S.cell_start, S.cell_fill, S.sorted_id);
@@ -959,14 +1096,16 @@ void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial
                        S.sorted_id, S.ent_ix, S.ent_iy, S.sx, S.sy);
 }
 
+void nh_launch_cohesion(const nh_step_params &P, float *d_coh, hipStream_t s)
+{
+    if(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0)
+        hipLaunchKernelGGL(k_cohesion, dim3((P.n_members + 255) / 256), dim3(256), 0, s, P, d_coh);
+}
+
 void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const nh_step_outs &O, hipStream_t s)
 {
-    const int n = P.n_ents;
-    if(n <= 0) return;
-    if(P.n_flocks > 0)
-        hipLaunchKernelGGL(k_cohesion, dim3((n + 255) / 256), dim3(256), 0, s, P, d_coh);
     const int nwork = P.work_end - P.work_begin;
-    if(nwork > 0)
+    if(P.n_ents > 0 && nwork > 0)
         hipLaunchKernelGGL(k_agent_step, dim3((nwork + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, P,
                            d_coh, O);
 }

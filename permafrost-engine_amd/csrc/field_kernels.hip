@@ -56,14 +56,14 @@ __device__ __forceinline__ u64x from_e(u64x v)
 // lane r <- lane r-1 : the NORTH neighbour row (row r-1); lane 0 reads 0.  DPP wave_shr:1.
 __device__ __forceinline__ u64x from_n(u64x v)
 {
-    return u64x{(uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.lo, 0x138, 0xf, 0xf, false),
-                (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.hi, 0x138, 0xf, 0xf, false)};
+    return u64x{(uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.lo, 0x138, 0xf, 0xf, true),
+                (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.hi, 0x138, 0xf, 0xf, true)};
 }
 // lane r <- lane r+1 : the SOUTH neighbour row (row r+1); lane 63 reads 0.  DPP wave_shl:1.
 __device__ __forceinline__ u64x from_s(u64x v)
 {
-    return u64x{(uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.lo, 0x130, 0xf, 0xf, false),
-                (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.hi, 0x130, 0xf, 0xf, false)};
+    return u64x{(uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.lo, 0x130, 0xf, 0xf, true),
+                (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.hi, 0x130, 0xf, 0xf, true)};
 }
 
 __device__ __forceinline__ bool req_uses_bfs(const nh_map_view &map, const navhip_field_req &rq,
@@ -204,21 +204,36 @@ __global__ __launch_bounds__(256) void k_field_bfs(nh_map_view map, const navhip
 #pragma unroll
     for(int k = 0; k < NH_MAXP; k++) pl[k] = u64x{0, 0};
 
+    // One BFS level: expand the frontier, stop when nothing new is reached, bump the shared
+    // bit-sliced counter of the still-open cells (bits 0..ctz(level) flip), retire the newly
+    // reached cells.  The loop is unrolled by 8 so that the number of low planes that flip is a
+    // compile-time constant (1,2,1,3,1,2,1,3+): ~2 plane updates per level instead of a
+    // predicated update of all 12.
     int level = 0;
-    for(;;) {
-        u64x nb = from_w(frontier) | from_e(frontier) | from_n(frontier) | from_s(frontier);
-        u64x nw = nb & open;
-        if(!__any(nz(nw))) break;
-        level++;
-        // increment the shared counter of all open cells: bits 0..ctz(level) flip
-        int tz = __builtin_ctz(level);
-#pragma unroll
-        for(int k = 0; k < NH_MAXP; k++) {
-            if(k <= tz) pl[k] = pl[k] ^ open;
-        }
-        open = andn(open, nw);
-        frontier = nw;
+#define NH_BFS_LEVEL(NLOW)                                                                   \
+    {                                                                                        \
+        u64x nb = from_w(frontier) | from_e(frontier) | from_n(frontier) | from_s(frontier); \
+        u64x nw = nb & open;                                                                 \
+        if(!__any(nz(nw))) break;                                                            \
+        level++;                                                                             \
+        pl[0] = pl[0] ^ open;                                                                \
+        if(NLOW > 1) pl[1] = pl[1] ^ open;                                                   \
+        if(NLOW > 2) pl[2] = pl[2] ^ open;                                                   \
+        if(NLOW > 3) {                                                                       \
+            const int tz = __builtin_ctz(level);      /* wave-uniform: scalar branches */    \
+            _Pragma("unroll")                                                                \
+            for(int k = 3; k < NH_MAXP; k++) {                                               \
+                if(k <= tz) pl[k] = pl[k] ^ open;                                            \
+            }                                                                                \
+        }                                                                                    \
+        open = andn(open, nw);                                                               \
+        frontier = nw;                                                                       \
     }
+    for(;;) {
+        NH_BFS_LEVEL(1) NH_BFS_LEVEL(2) NH_BFS_LEVEL(1) NH_BFS_LEVEL(3)
+        NH_BFS_LEVEL(1) NH_BFS_LEVEL(2) NH_BFS_LEVEL(1) NH_BFS_LEVEL(4)
+    }
+#undef NH_BFS_LEVEL
     const u64x reach = andn(pass, open);          // finite integration value
     // planes of never-reached cells hold garbage: clear them
 #pragma unroll

@@ -89,6 +89,8 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(ctx->sp, 0, sizeof(ctx->sp));
     memset(&ctx->coh, 0, sizeof(ctx->coh));
     memset(ctx->stage, 0, sizeof(ctx->stage));
+    ctx->profiling = false; ctx->ev_valid = false;
+    memset(ctx->ev, 0, sizeof(ctx->ev));
     if(hipSetDevice(device) != hipSuccess
     || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -114,6 +116,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(auto &b : ctx->sp) hipFree(b.p);
     for(auto &b : ctx->stage) hipFree(b.p);
     hipFree(ctx->coh.p);
+    for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -360,14 +363,15 @@ static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hip
         return NAVHIP_ERR_INVALID;
     }
     const size_t n = (size_t)w->n_ents, ncells = (size_t)g->grid_w * g->grid_h;
-    const size_t sizes[9] = {n, n, n, ncells, ncells, ncells + 1, n, n, n};
-    for(int i = 0; i < 9; i++) {
+    const size_t sizes[10] = {n, n, n, ncells, ncells, ncells + 1, n, n, n, (ncells + 1023) / 1024};
+    for(int i = 0; i < 10; i++) {
         int rc = ensure_buf(ctx, ctx->sp[i], sizes[i] * sizeof(int32_t));
         if(rc) return rc;
     }
     nh_spatial_scratch S = {(int32_t*)ctx->sp[0].p, (int32_t*)ctx->sp[1].p, (int32_t*)ctx->sp[2].p,
                             (int32_t*)ctx->sp[3].p, (int32_t*)ctx->sp[4].p, (int32_t*)ctx->sp[5].p,
-                            (int32_t*)ctx->sp[6].p, (int32_t*)ctx->sp[7].p, (int32_t*)ctx->sp[8].p};
+                            (int32_t*)ctx->sp[6].p, (int32_t*)ctx->sp[7].p, (int32_t*)ctx->sp[8].p,
+                            (int32_t*)ctx->sp[9].p};
     g->n = w->n_ents;
     g->cell_start = S.cell_start; g->sorted_id = S.sorted_id; g->sx = S.sx; g->sy = S.sy;
     nh_launch_spatial_build(*g, w->pos_xz, S, s);
@@ -395,12 +399,19 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     nh_step_params P;
     memset(&P, 0, sizeof(P));
     fill_map_view(ctx, &P.map);
+    const bool prof = ctx->profiling;
+    if(prof) {
+        for(auto &e : ctx->ev) if(!e) HIPCHK(ctx, hipEventCreate(&e));
+        HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
+    }
     int rc = spatial_build(ctx, w, &P.grid, s);
     if(rc) return rc;
+    if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
     if(rc) return rc;
     P.map_x = w->map_pos_x; P.map_z = w->map_pos_z;
     P.n_ents = w->n_ents; P.n_flocks = w->n_flocks; P.hz = w->hz;
+    P.n_members = w->n_ents;          // every entity belongs to at most one flock
     P.work_begin = w->work_begin; P.work_end = w->work_end;
     if(P.work_begin == 0 && P.work_end == 0) P.work_end = w->n_ents;
     if(P.work_begin < 0 || P.work_end > w->n_ents || P.work_begin > P.work_end)
@@ -411,8 +422,28 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     P.flock_offsets = w->flock_offsets; P.flock_members = w->flock_members;
     P.flock_field_slot = w->flock_field_slot; P.field_pool = w->field_pool;
     nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
+    nh_launch_cohesion(P, (float*)ctx->coh.p, s);
+    if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     nh_launch_agent_step(P, (float*)ctx->coh.p, O, s);
+    if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], s)); ctx->ev_valid = true; }
     HIPCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_set_profiling(navhip_ctx *ctx, int on)
+{
+    if(!ctx) return NAVHIP_ERR_INVALID;
+    ctx->profiling = on != 0;
+    ctx->ev_valid = false;
+    return NAVHIP_OK;
+}
+
+int navhip_last_step_ms(navhip_ctx *ctx, float out_ms[3])
+{
+    if(!ctx || !out_ms || !ctx->ev_valid) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+    for(int i = 0; i < 3; i++)
+        HIPCHK(ctx, hipEventElapsedTime(&out_ms[i], ctx->ev[i], ctx->ev[i + 1]));
     return NAVHIP_OK;
 }
 

@@ -38,10 +38,14 @@ struct navhip_ctx {
     uint32_t    *d_dirty_list; size_t d_dirty_cap;
     // agent-step scratch (grown on demand, reused every tick)
     struct buf { void *p; size_t cap; };
-    buf          sp[9];        // spatial hash: ent_ix, ent_iy, ent_cell, cell_count, cell_fill,
-                               //               cell_start, sorted_id, sx, sy
+    buf          sp[10];       // spatial hash: ent_ix, ent_iy, ent_cell, cell_count, cell_fill,
+                               //               cell_start, sorted_id, sx, sy, block_sum
     buf          coh;          // cohesion force per entity
     buf          stage[24];    // device copies of host buffers for the host-pointer entry points
+    // optional per-kernel-group timing of the agent step (navhip_set_profiling)
+    bool         profiling;
+    hipEvent_t   ev[4];        // start | spatial hash built | cohesion done | agent step done
+    bool         ev_valid;
     std::string  last_error;
 };
 

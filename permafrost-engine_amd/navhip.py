@@ -216,6 +216,8 @@ _SIGS.update({
     "navhip_agent_step_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut), C.c_void_p]),
     "navhip_spatial_query": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p, C.c_int, C.c_float,
                                        C.c_int, C.c_void_p, C.c_void_p]),
+    "navhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3)]),
     "navhip_clearpath": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 })
@@ -324,6 +326,19 @@ def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat):
     return out
 
 
+def _ctx_set_profiling(self, on):
+    self._chk(lib().navhip_set_profiling(self._h, int(bool(on))), "navhip_set_profiling")
+
+
+def _ctx_last_step_ms(self):
+    """(spatial hash, k_cohesion, k_agent_step) milliseconds of the last profiled agent step."""
+    out = (C.c_float * 3)()
+    self._chk(lib().navhip_last_step_ms(self._h, C.byref(out)), "navhip_last_step_ms")
+    return tuple(float(x) for x in out)
+
+
+NavContext.set_profiling = _ctx_set_profiling
+NavContext.last_step_ms = _ctx_last_step_ms
 NavContext.agent_step = _ctx_agent_step
 NavContext.agent_step_dev = _ctx_agent_step_dev
 NavContext.spatial_query = _ctx_spatial_query
