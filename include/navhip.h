@@ -66,6 +66,16 @@ enum {
                                     the bytes already in the output slot (field.c:737-751,
                                     nav.c:1998-2008) instead of starting from N_FlowFieldInit */
 
+#define NAVHIP_REQ_IF_CHANGED 0x2 /* incremental repair: build only when the request's chunk (or, for a
+                                    portal target, the next chunk) is flagged changed by the blocker
+                                    updates since the last navhip_clear_changed; otherwise the slot
+                                    is left untouched (the cached field stays valid, the device image
+                                    of N_ApplyDeferredInvalidations, nav.c:2208) */
+#define NAVHIP_REQ_LIVE_IIDS  0x4 /* portal targets: re-read port_iid / next_iid on the device from the
+                                    CURRENT local_islands plane at the first endpoint tile of the
+                                    port / next portal (for request lists that outlive a relabel, as
+                                    in the device-resident incremental-repair benchmark) */
+
 /* One chunk-field build: the arguments of
  *   N_FlowFieldUpdate(chunk, priv, faction_id, layer, target, ctx, inout)   field.c:2030
  * with `struct field_target` / `struct portal_desc` (field.h:67-72,85-101) flattened so the
@@ -108,6 +118,42 @@ int  navhip_upload_chunk(navhip_ctx *ctx, int layer, int plane, int chunk_r, int
                          const void *host, size_t bytes);
 /* Device pointer of a resident plane (NULL when never uploaded); for zero-copy producers. */
 void *navhip_plane_dev(navhip_ctx *ctx, int layer, int plane);
+
+/* Read a resident plane back (tests; host mirrors after device-side blocker updates). */
+int  navhip_download_plane(navhip_ctx *ctx, int layer, int plane, void *host, size_t bytes);
+
+/* ---- dynamic obstacles -------------------------------------------- */
+
+/* One N_BlockersIncref (delta = +1) / N_BlockersDecref (delta = -1) call, nav.c:4663,4685:
+ * (xz_pos, range, faction_id, flags).  24 bytes. */
+typedef struct navhip_circle {
+    float    x, z;          /* xz_pos                                                      */
+    float    radius;        /* range; the device path takes ceil(radius/4) <= 28 tiles     */
+    int32_t  faction_id;    /* 0..14                                                       */
+    uint32_t flags;         /* ENTITY_FLAG_AIR selects the air layers, else water + ground */
+    int32_t  delta;         /* +1 incref, -1 decref                                        */
+} navhip_circle;
+
+/* Apply n incref/decref calls to the resident blockers (+ factions) planes of every resident
+ * layer of the affected domains, with the reference's tile sets: tiles under the circle
+ * (M_Tile_AllUnderCircle, tile.c:687) on the 1x1 layer, plus 1/2/3 successive contours
+ * (M_Tile_Contour, tile.c:759) on the 3x3/5x5/7x7 layers (n_update_blockers_circle_*,
+ * nav.c:1051-1133).  Afterwards, on the device and without a host round trip: the derived
+ * passability of every touched chunk is rebuilt, chunks whose passability CHANGED are flagged
+ * (the dirty_chunks set of n_update_blockers, nav.c:1033-1046, restricted to real changes) and
+ * their local-island labels recomputed (n_update_local_islands, nav.c:967).
+ * map_pos_x/z: the vec3 map_pos .x/.z handed to every N_* call. */
+int  navhip_blockers_circles(navhip_ctx *ctx, const navhip_circle *circles, int n,
+                             float map_pos_x, float map_pos_z);
+int  navhip_blockers_circles_dev(navhip_ctx *ctx, const navhip_circle *dev_circles, int n,
+                                 float map_pos_x, float map_pos_z, void *stream);
+/* n_update_local_island_field (nav.c:986) for one layer on the device, from the resident
+ * cost_base + blockers planes (allocates the local_islands plane when it was never uploaded). */
+int  navhip_relabel_local_islands(navhip_ctx *ctx, int layer);
+/* The changed-chunk flags of one layer ([chunk_h*chunk_w] bytes, 1 = passability changed);
+ * clear != 0 resets them afterwards. */
+int  navhip_changed_chunks(navhip_ctx *ctx, int layer, uint8_t *host_flags, int clear);
+int  navhip_clear_changed(navhip_ctx *ctx, void *stream);
 
 /* ---- chunk flow fields ---------------------------------------- */
 

@@ -173,6 +173,15 @@ int no_field_update(const no_map *m, const navhip_field_req *rq, uint8_t *inout_
 {
     if(rq->layer >= NLAYERS || !m->cost[rq->layer] || rq->chunk_r >= m->h || rq->chunk_c >= m->w)
         return -1;
+    navhip_field_req live;
+    if((rq->flags & NAVHIP_REQ_LIVE_IIDS) && rq->type == NAVHIP_TARGET_PORTAL && m->local_islands[rq->layer]) {
+        /* island ids re-read from the current labels at the first endpoint tiles (include/navhip.h) */
+        const uint16_t *li0 = m->local_islands[rq->layer];
+        live = *rq;
+        live.port_iid = li0[((size_t)(rq->chunk_r * m->w + rq->chunk_c) << 12) + rq->port_r0 * RES + rq->port_c0];
+        live.next_iid = li0[((size_t)(rq->next_chunk_r * m->w + rq->next_chunk_c) << 12) + rq->next_r0 * RES + rq->next_c0];
+        rq = &live;
+    }
     const int layer = rq->layer, chunk = rq->chunk_r * m->w + rq->chunk_c;
     const int faction_id = rq->faction_id;
     const unsigned enemies = rq->enemies;
@@ -1085,6 +1094,242 @@ int no_agent_forces(const no_map *m, const navhip_world *w, int uid, const float
     out_cohesion[0] = co.x; out_cohesion[1] = co.z;
     out_separation[0] = s.x; out_separation[1] = s.z;
     grid_free(&g);
+    return 0;
+}
+
+/* ===========================================================================================
+ * dynamic obstacles: N_BlockersIncref / N_BlockersDecref (nav.c:4663,4685) and the local-island
+ * relabel that follows a blocker change (n_update_local_islands, nav.c:967)
+ * =========================================================================================== */
+
+/* C_LineCircleIntersection, collision.c:960 */
+static bool line_circle(float ax, float az, float bx, float bz, v2 center, float radius)
+{
+    float cx = center.x, cz = center.z;
+    float dx = bx - ax, dz = bz - az;
+    float A = pow(dx, 2) + pow(dz, 2);
+    float B = 2 * (dx * (ax - cx) + dz * (az - cz));
+    float C = pow(ax - cx, 2) + pow(az - cz, 2) - pow(radius, 2);
+    float det = pow(B, 2) - (4 * A * C);
+    float t;
+    if(det < 0.0f || A < (1.0f / 1024.0f)) {
+        return false;
+    }else if(det == 0.0f) {
+        t = -B / (2 * A);
+    }else{
+        float t1 = (-B + sqrt(det)) / (2 * A);
+        float t2 = (-B - sqrt(det)) / (2 * A);
+        t = t1 < t2 ? t1 : t2;
+    }
+    if(t < 0.0f || t > 1.0f)
+        return false;
+    return true;
+}
+
+/* C_PointInsideRect2D, collision.c:756 */
+static bool point_in_rect(v2 p, v2 a, v2 b, v2 c, v2 d)
+{
+    (void)c;
+    v2 ap = vsub(p, a), ab = vsub(b, a), ad = vsub(d, a);
+    float ap_ab = vdot(ap, ab), ap_ad = vdot(ap, ad);
+    return (ap_ab >= 0.0f && ap_ab <= vdot(ab, ab)) && (ap_ad >= 0.0f && ap_ad <= vdot(ad, ad));
+}
+
+/* C_CircleRectIntersection, collision.c:997; rect = {x, z, width, height}, x decreasing rightwards */
+static bool circle_rect(v2 center, float radius, float rx, float rz, float rw, float rh)
+{
+    v2 corners[4] = {mkv(rx - rw, rz), mkv(rx, rz), mkv(rx, rz + rh), mkv(rx - rw, rz + rh)};
+    if(point_in_rect(center, corners[0], corners[1], corners[2], corners[3]))
+        return true;
+    for(int i = 0; i < 4; i++)
+        if(vlen(vsub(corners[i], center)) <= radius) return true;
+    for(int i = 0; i < 4; i++) {
+        int j = (i + 1) % 4;
+        if(line_circle(corners[i].x, corners[i].z, corners[j].x, corners[j].z, center, radius))
+            return true;
+    }
+    return false;
+}
+
+/* M_Tile_AllUnderCircle, tile.c:687 (nav resolution: 4-wu tiles) */
+static int tiles_under_circle(const no_map *m, float map_x, float map_z, v2 center, float radius,
+                              tiledesc *out, int maxout)
+{
+    tiledesc tile;
+    if(!tile_for_point(m, map_x, map_z, center, &tile))
+        return 0;
+    int tile_len = 4;
+    int ntiles = ceil(radius / tile_len);
+    int ret = 0;
+    for(int dr = -ntiles; dr <= ntiles; dr++) {
+    for(int dc = -ntiles; dc <= ntiles; dc++) {
+        /* M_Tile_RelativeDesc, tile.c:391 */
+        int abs_r = tile.chunk_r * RES + tile.tile_r + dr;
+        int abs_c = tile.chunk_c * RES + tile.tile_c + dc;
+        if(abs_r < 0 || abs_r >= m->h * RES || abs_c < 0 || abs_c >= m->w * RES)
+            continue;
+        tiledesc curr = {abs_r / RES, abs_c / RES, abs_r % RES, abs_c % RES};
+        /* M_Tile_Bounds, tile.c:356 */
+        float bx = map_x - curr.chunk_c * 256 - curr.tile_c * 4;
+        float bz = map_z + curr.chunk_r * 256 + curr.tile_r * 4;
+        if(!circle_rect(center, radius, bx, bz, 4, 4))
+            continue;
+        out[ret++] = curr;
+        if(ret == maxout)
+            return ret;
+    }}
+    return ret;
+}
+
+/* M_Tile_Contour, tile.c:759 */
+static int tiles_contour(const no_map *m, int ntds, const tiledesc *tds, tiledesc *out, int maxout)
+{
+    if(ntds == 0) return 0;
+    int minr = 1 << 30, minc = 1 << 30, maxr = -(1 << 30), maxc = -(1 << 30);
+    for(int i = 0; i < ntds; i++) {
+        int absr = tds[i].chunk_r * RES + tds[i].tile_r, absc = tds[i].chunk_c * RES + tds[i].tile_c;
+        if(absr < minr) minr = absr;
+        if(absc < minc) minc = absc;
+        if(absr > maxr) maxr = absr;
+        if(absc > maxc) maxc = absc;
+    }
+    int dr = maxr - minr + 1, dc = maxc - minc + 1;
+    int width = dc + 2, height = dr + 2;
+    uint8_t *marked = calloc((size_t)width * height, 1);
+    for(int i = 0; i < ntds; i++) {
+        int absr = tds[i].chunk_r * RES + tds[i].tile_r, absc = tds[i].chunk_c * RES + tds[i].tile_c;
+        marked[(absr - minr + 1) * width + (absc - minc + 1)] = 1;
+    }
+    int ret = 0;
+    for(int r = minr - 1; r <= maxr + 1; r++) {
+    for(int c = minc - 1; c <= maxc + 1; c++) {
+        if(r < 0 || r >= m->h * RES) continue;
+        if(c < 0 || c >= m->w * RES) continue;
+        int relr = r - minr + 1, relc = c - minc + 1;
+        bool contour = false;
+        if(marked[relr * width + relc]) continue;
+        if(ret == maxout) goto out;
+        if((relr > 0 && marked[(relr - 1) * width + relc])
+        || (relr < dr && marked[(relr + 1) * width + relc])
+        || (relc > 0 && marked[relr * width + (relc - 1)])
+        || (relc < dc && marked[relr * width + (relc + 1)]))
+            contour = true;
+        if((relr > 0 && relc > 0 && marked[(relr - 1) * width + (relc - 1)])
+        || (relr > 0 && relc < dc && marked[(relr - 1) * width + (relc + 1)])
+        || (relr < dr && relc > 0 && marked[(relr + 1) * width + (relc - 1)])
+        || (relr < dr && relc < dc && marked[(relr + 1) * width + (relc + 1)]))
+            contour = true;
+        if(contour) {
+            tiledesc td = {r / RES, c / RES, r % RES, c % RES};
+            out[ret++] = td;
+        }
+    }}
+out:
+    free(marked);
+    return ret;
+}
+
+/* n_update_blockers, nav.c:1017 (dirty: the chunk changed between occupied / non-occupied) */
+static void update_blockers(const no_map *m, int layer, int faction_id, const tiledesc *tds, int ntds,
+                            int ref_delta, uint8_t *dirty)
+{
+    uint16_t *bl = (uint16_t*)m->blockers[layer];
+    uint8_t *fa = (uint8_t*)m->factions[layer];
+    if(!bl) return;
+    for(int i = 0; i < ntds; i++) {
+        int chunk = tds[i].chunk_r * m->w + tds[i].chunk_c;
+        size_t cell = ((size_t)chunk << 12) + tds[i].tile_r * RES + tds[i].tile_c;
+        int prev = bl[cell];
+        bl[cell] = (uint16_t)(bl[cell] + ref_delta);
+        if(fa)
+            fa[((size_t)chunk * MAX_FACTIONS << 12) + ((size_t)faction_id << 12) + tds[i].tile_r * RES + tds[i].tile_c] += ref_delta;
+        int val = bl[cell];
+        if(!!val != !!prev && dirty)
+            dirty[(size_t)layer * m->w * m->h + chunk] = 1;
+    }
+}
+
+/* n_update_blockers_circle_{ground,water,air}, nav.c:1051-1133, for the layers base..base+3 */
+static void update_blockers_circle(const no_map *m, int base, v2 xz, float range, int faction_id,
+                                   float map_x, float map_z, int ref_delta, uint8_t *dirty)
+{
+    static __thread tiledesc tds[1024], o3[1024], o5[1024], o7[1024];
+    int ntds = tiles_under_circle(m, map_x, map_z, xz, range, tds, 1024);
+    update_blockers(m, base + 0, faction_id, tds, ntds, ref_delta, dirty);
+
+    int n3 = tiles_contour(m, ntds, tds, o3, 1024);
+    update_blockers(m, base + 1, faction_id, tds, ntds, ref_delta, dirty);
+    update_blockers(m, base + 1, faction_id, o3, n3, ref_delta, dirty);
+
+    int n5 = tiles_contour(m, n3, o3, o5, 1024);
+    update_blockers(m, base + 2, faction_id, tds, ntds, ref_delta, dirty);
+    update_blockers(m, base + 2, faction_id, o3, n3, ref_delta, dirty);
+    update_blockers(m, base + 2, faction_id, o5, n5, ref_delta, dirty);
+
+    int n7 = tiles_contour(m, n5, o5, o7, 1024);
+    update_blockers(m, base + 3, faction_id, tds, ntds, ref_delta, dirty);
+    update_blockers(m, base + 3, faction_id, o3, n3, ref_delta, dirty);
+    update_blockers(m, base + 3, faction_id, o5, n5, ref_delta, dirty);
+    update_blockers(m, base + 3, faction_id, o7, n7, ref_delta, dirty);
+}
+
+/* N_BlockersIncref / N_BlockersDecref for a list of circles, applied in order to the (mutable)
+ * blockers / factions planes of `m`; layers without a blockers plane are skipped.
+ * dirty: [12][h*w] bytes or NULL. */
+int no_blockers_circles(const no_map *m, const navhip_circle *circles, int n, float map_x,
+                        float map_z, uint8_t *dirty)
+{
+    for(int i = 0; i < n; i++) {
+        const navhip_circle *c = &circles[i];
+        v2 xz = mkv(c->x, c->z);
+        if(c->flags & NAVHIP_ENTITY_FLAG_AIR) {
+            update_blockers_circle(m, 8, xz, c->radius, c->faction_id, map_x, map_z, c->delta, dirty);
+        }else{
+            update_blockers_circle(m, 4, xz, c->radius, c->faction_id, map_x, map_z, c->delta, dirty);
+            update_blockers_circle(m, 0, xz, c->radius, c->faction_id, map_x, map_z, c->delta, dirty);
+        }
+    }
+    return 0;
+}
+
+/* n_update_local_islands (nav.c:967) + n_visit_island_local (nav.c:901) for every chunk of one
+ * layer (only: per-chunk filter or NULL).  out: [h][w][64][64] u16. */
+int no_local_islands(const no_map *m, int layer, uint16_t *out, const uint8_t *only)
+{
+    if(!m->cost[layer]) return -1;
+    static __thread int queue[CELLS * 5];
+    for(int chunk = 0; chunk < m->w * m->h; chunk++) {
+        if(only && !only[chunk]) continue;
+        const uint8_t *cost = m->cost[layer] + ((size_t)chunk << 12);
+        const uint16_t *bl = m->blockers[layer] ? m->blockers[layer] + ((size_t)chunk << 12) : NULL;
+        uint16_t *li = out + ((size_t)chunk << 12);
+        memset(li, 0xff, CELLS * sizeof(uint16_t));
+        int local_iid = 0;
+        for(int r = 0; r < RES; r++) {
+        for(int c = 0; c < RES; c++) {
+            if(li[r * RES + c] != ISLAND_NONE) continue;
+            if(cost[r * RES + c] == COST_IMPASS) continue;
+            if(bl && bl[r * RES + c] > 0) continue;
+            int id = ++local_iid;
+            int head = 0, tail = 0;
+            queue[tail++] = r * RES + c;
+            while(head < tail) {
+                int cur = queue[head++];
+                int cr = cur >> 6, cc = cur & 63;
+                if(cost[cur] == COST_IMPASS) continue;
+                if(bl && bl[cur] > 0) continue;
+                if(li[cur] != ISLAND_NONE) continue;
+                li[cur] = (uint16_t)id;
+                static const int d4[4][2] = {{0, -1}, {0, 1}, {-1, 0}, {1, 0}};
+                for(int k = 0; k < 4; k++) {
+                    int nr = cr + d4[k][0], nc = cc + d4[k][1];
+                    if(nr < 0 || nr >= RES || nc < 0 || nc >= RES) continue;     /* other chunk */
+                    if(li[nr * RES + nc] != ISLAND_NONE) continue;   /* (cheap pre-filter) */
+                    if(tail < CELLS * 5) queue[tail++] = nr * RES + nc;
+                }
+            }
+        }}
+    }
     return 0;
 }
 

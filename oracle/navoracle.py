@@ -26,6 +26,10 @@ FIELD_REQ_DTYPE = np.dtype([
 ], align=False)
 
 
+CIRCLE_DTYPE = np.dtype([("x", np.float32), ("z", np.float32), ("radius", np.float32),
+                         ("faction_id", np.int32), ("flags", np.uint32), ("delta", np.int32)])
+
+
 class Map(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32),
                 ("cost", C.c_void_p * NLAYERS), ("blockers", C.c_void_p * NLAYERS),
@@ -78,6 +82,9 @@ def lib():
         L.no_agent_step.argtypes = [C.POINTER(Map), C.POINTER(World), C.POINTER(StepOut), C.c_int]
         L.no_agent_forces.argtypes = [C.POINTER(Map), C.POINTER(World), C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        L.no_blockers_circles.argtypes = [C.POINTER(Map), C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                          C.c_void_p]
+        L.no_local_islands.argtypes = [C.POINTER(Map), C.c_int, C.c_void_p, C.c_void_p]
         L.no_field_bench.restype = C.c_double
         L.no_field_bench.argtypes = [C.POINTER(Map), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.no_agent_bench.restype = C.c_double
@@ -137,6 +144,28 @@ class OracleNav:
             a = np.ascontiguousarray(arr, dt)
             self._planes[(layer, name)] = a
             getattr(self._map, name)[layer] = a.ctypes.data
+
+    def plane(self, layer, name):
+        return self._planes[(layer, name)]
+
+    # -- dynamic obstacles ----------------------------------------------------------------
+    def blockers_circles(self, circles):
+        """N_BlockersIncref / N_BlockersDecref on this object's (mutable) blockers / factions
+        planes; returns the reference-style dirty flags [12][h][w] (tile toggled occupied/free)."""
+        c = np.ascontiguousarray(circles, CIRCLE_DTYPE)
+        dirty = np.zeros((NLAYERS, self.h, self.w), np.uint8)
+        lib().no_blockers_circles(C.byref(self._map), _p(c), len(c), self.w * 128.0, -self.h * 128.0,
+                                  _p(dirty))
+        return dirty
+
+    def local_islands(self, layer=0, only=None, into=None):
+        """n_update_local_island_field over the current cost + blockers planes."""
+        out = np.zeros((self.h, self.w, 64, 64), np.uint16) if into is None else into
+        o = None if only is None else np.ascontiguousarray(only, np.uint8)
+        rc = lib().no_local_islands(C.byref(self._map), layer, _p(out), _p(o) if o is not None else None)
+        if rc:
+            raise ValueError("no_local_islands: layer has no cost plane")
+        return out
 
     # -- fields ---------------------------------------------------------------------------
     def build_fields(self, reqs, inout=None, want_integ=False):

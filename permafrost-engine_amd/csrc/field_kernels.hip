@@ -28,43 +28,7 @@
 // int->float conversion of the optional integration output, which is exact anyway).
 #include "navhip_internal.h"
 
-// ---------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------
-struct u64x { uint32_t lo, hi; };
-
-__device__ __forceinline__ u64x mk(uint64_t v) { return u64x{(uint32_t)v, (uint32_t)(v >> 32)}; }
-__device__ __forceinline__ uint64_t to64(u64x v) { return ((uint64_t)v.hi << 32) | v.lo; }
-__device__ __forceinline__ u64x operator|(u64x a, u64x b) { return u64x{a.lo | b.lo, a.hi | b.hi}; }
-__device__ __forceinline__ u64x operator&(u64x a, u64x b) { return u64x{a.lo & b.lo, a.hi & b.hi}; }
-__device__ __forceinline__ u64x operator^(u64x a, u64x b) { return u64x{a.lo ^ b.lo, a.hi ^ b.hi}; }
-__device__ __forceinline__ u64x operator~(u64x a) { return u64x{~a.lo, ~a.hi}; }
-__device__ __forceinline__ bool nz(u64x a) { return (a.lo | a.hi) != 0; }
-// a & ~b
-__device__ __forceinline__ u64x andn(u64x a, u64x b) { return u64x{a.lo & ~b.lo, a.hi & ~b.hi}; }
-
-// bit c <- bit c-1 : the value of the WEST neighbour (column c-1) aligned on column c
-__device__ __forceinline__ u64x from_w(u64x v)
-{
-    return u64x{v.lo << 1, __builtin_amdgcn_alignbit(v.hi, v.lo, 31)};
-}
-// bit c <- bit c+1 : the value of the EAST neighbour (column c+1)
-__device__ __forceinline__ u64x from_e(u64x v)
-{
-    return u64x{__builtin_amdgcn_alignbit(v.hi, v.lo, 1), v.hi >> 1};
-}
-// lane r <- lane r-1 : the NORTH neighbour row (row r-1); lane 0 reads 0.  DPP wave_shr:1.
-__device__ __forceinline__ u64x from_n(u64x v)
-{
-    return u64x{(uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.lo, 0x138, 0xf, 0xf, true),
-                (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.hi, 0x138, 0xf, 0xf, true)};
-}
-// lane r <- lane r+1 : the SOUTH neighbour row (row r+1); lane 63 reads 0.  DPP wave_shl:1.
-__device__ __forceinline__ u64x from_s(u64x v)
-{
-    return u64x{(uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.lo, 0x130, 0xf, 0xf, true),
-                (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.hi, 0x130, 0xf, 0xf, true)};
-}
+#include "wave_bits.h"
 
 __device__ __forceinline__ bool req_uses_bfs(const nh_map_view &map, const navhip_field_req &rq,
                                              int force_generic)
@@ -73,6 +37,27 @@ __device__ __forceinline__ bool req_uses_bfs(const nh_map_view &map, const navhi
     if(rq.faction_id != NAVHIP_FACTION_ID_NONE) return false;
     const nh_layer_view &L = map.layers[rq.layer];
     return L.unit_cost[(int)rq.chunk_r * map.w + rq.chunk_c] != 0;
+}
+
+// Request flags that are resolved on the device: NAVHIP_REQ_IF_CHANGED (skip unless the chunk, or
+// the next chunk of a portal target, changed) and NAVHIP_REQ_LIVE_IIDS (island ids re-read from
+// the current labels).  Returns false when the request is to be skipped.
+__device__ __forceinline__ bool req_prepare(const nh_map_view &map, navhip_field_req &rq)
+{
+    const nh_layer_view &L = map.layers[rq.layer];
+    const bool portal = rq.type == NAVHIP_TARGET_PORTAL;
+    if((rq.flags & NAVHIP_REQ_IF_CHANGED) && L.changed) {
+        bool ch = L.changed[(int)rq.chunk_r * map.w + rq.chunk_c] != 0;
+        if(portal) ch |= L.changed[(int)rq.next_chunk_r * map.w + rq.next_chunk_c] != 0;
+        if(!ch) return false;
+    }
+    if((rq.flags & NAVHIP_REQ_LIVE_IIDS) && portal && L.local_islands) {
+        rq.port_iid = L.local_islands[((size_t)((int)rq.chunk_r * map.w + rq.chunk_c) << 12)
+                                      + rq.port_r0 * 64 + rq.port_c0];
+        rq.next_iid = L.local_islands[((size_t)((int)rq.next_chunk_r * map.w + rq.next_chunk_c) << 12)
+                                      + rq.next_r0 * 64 + rq.next_c0];
+    }
+    return true;
 }
 
 // Is the cell (r2,c2) of the chunk (cr2,cc2) a tile of the `next` portal that lies on local
@@ -169,6 +154,7 @@ __global__ __launch_bounds__(256) void k_field_bfs(nh_map_view map, const navhip
 
     navhip_field_req rq = reqs[wave];
     if(!req_uses_bfs(map, rq, force_generic)) return;
+    if(!req_prepare(map, rq)) return;
 
     const nh_layer_view &L = map.layers[rq.layer];
     const int chunk = (int)rq.chunk_r * map.w + rq.chunk_c;
@@ -376,8 +362,9 @@ __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const na
     const int t = threadIdx.x;
     const int ri = blockIdx.x;
     if(ri >= n) return;
-    const navhip_field_req rq = reqs[ri];
+    navhip_field_req rq = reqs[ri];
     if(req_uses_bfs(map, rq, force_generic)) return;      // the BFS kernel owns this request
+    if(!req_prepare(map, rq)) return;
 
     const nh_layer_view &L = map.layers[rq.layer];
     const size_t cbase = (size_t)((int)rq.chunk_r * map.w + rq.chunk_c) << 12;
@@ -509,7 +496,7 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         const navhip_layer &L = ctx->layers[l];
         mv.layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
-                                     L.passmask, L.unit_cost};
+                                     L.passmask, L.unit_cost, L.changed};
     }
     const int force_generic = ctx->field_kernel_mode == 1;
     if(!force_generic) {

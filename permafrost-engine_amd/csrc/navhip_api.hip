@@ -29,6 +29,9 @@
         }                                                                                   \
     } while(0)
 
+static int refresh_derived(navhip_ctx *ctx, hipStream_t s);
+static int ensure_buf(navhip_ctx *ctx, navhip_ctx::buf &b, size_t need);
+
 static size_t plane_elem_bytes(int plane)
 {
     switch(plane) {
@@ -108,7 +111,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         navhip_layer &L = ctx->layers[l];
         hipFree(L.cost); hipFree(L.blockers); hipFree(L.local_islands); hipFree(L.factions);
-        hipFree(L.passmask); hipFree(L.unit_cost);
+        hipFree(L.passmask); hipFree(L.unit_cost); hipFree(L.touched); hipFree(L.changed);
         free(L.dirty);
     }
     hipFree(ctx->d_reqs); hipFree(ctx->d_dirs); hipFree(ctx->d_integ); hipFree(ctx->d_reqmask);
@@ -152,6 +155,10 @@ static int layer_prepare(navhip_ctx *ctx, int layer, int plane)
     if(!L.passmask) {
         HIPCHK(ctx, hipMalloc((void**)&L.passmask, (size_t)ctx->nchunks * 64 * sizeof(uint64_t)));
         HIPCHK(ctx, hipMalloc((void**)&L.unit_cost, (size_t)ctx->nchunks));
+        HIPCHK(ctx, hipMalloc((void**)&L.touched, (size_t)ctx->nchunks));
+        HIPCHK(ctx, hipMalloc((void**)&L.changed, (size_t)ctx->nchunks));
+        HIPCHK(ctx, hipMemsetAsync(L.touched, 0, (size_t)ctx->nchunks, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(L.changed, 0, (size_t)ctx->nchunks, ctx->stream));
         L.dirty = (uint8_t*)calloc(ctx->nchunks, 1);
         if(!L.dirty) return NAVHIP_ERR_NOMEM;
     }
@@ -244,6 +251,107 @@ static int refresh_derived(navhip_ctx *ctx, hipStream_t s)
     return NAVHIP_OK;
 }
 
+int navhip_download_plane(navhip_ctx *ctx, int layer, int plane, void *host, size_t bytes)
+{
+    if(!ctx || !host || layer < 0 || layer >= NAVHIP_NAV_LAYER_MAX
+    || plane < 0 || plane >= NAVHIP_PLANE_COUNT)
+        return NAVHIP_ERR_INVALID;
+    void *src = *plane_slot(ctx->layers[layer], plane);
+    if(!src) return NAVHIP_ERR_NOT_UPLOADED;
+    if(bytes != (size_t)ctx->nchunks * NH_CELLS * plane_elem_bytes(plane)) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NAVHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dynamic obstacles
+// ---------------------------------------------------------------------------------------------
+int navhip_blockers_circles_dev(navhip_ctx *ctx, const navhip_circle *dev_circles, int n,
+                                float map_pos_x, float map_pos_z, void *stream)
+{
+    if(!ctx || n < 0 || (n > 0 && !dev_circles)) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = refresh_derived(ctx, s);          // the "before" masks must be current
+    if(rc) return rc;
+    bool any = false;
+    for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) any |= ctx->layers[l].blockers != nullptr;
+    if(!any) {
+        ctx->last_error = "navhip_blockers_circles: no blockers plane resident";
+        return NAVHIP_ERR_NOT_UPLOADED;
+    }
+    nh_launch_blockers_circles(ctx, dev_circles, n, map_pos_x, map_pos_z, s);
+    HIPCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_blockers_circles(navhip_ctx *ctx, const navhip_circle *circles, int n,
+                            float map_pos_x, float map_pos_z)
+{
+    if(!ctx || n < 0 || (n > 0 && !circles)) return NAVHIP_ERR_INVALID;
+    for(int i = 0; i < n; i++) {
+        const navhip_circle &c = circles[i];
+        if(!(c.radius >= 0.0f) || std::ceil((double)(c.radius / 4)) > 28.0
+        || (c.delta != 1 && c.delta != -1) || c.faction_id < 0 || c.faction_id >= NAVHIP_MAX_FACTIONS) {
+            ctx->last_error = "navhip_blockers_circles: circle " + std::to_string(i)
+                            + " outside the device path (radius > 112, delta != +-1 or bad faction)";
+            return NAVHIP_ERR_INVALID;
+        }
+    }
+    if(n == 0) return NAVHIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_buf(ctx, ctx->stage[23], (size_t)n * sizeof(navhip_circle));
+    if(rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[23].p, circles, (size_t)n * sizeof(navhip_circle),
+                               hipMemcpyHostToDevice, ctx->stream));
+    rc = navhip_blockers_circles_dev(ctx, (const navhip_circle*)ctx->stage[23].p, n, map_pos_x,
+                                     map_pos_z, ctx->stream);
+    if(rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NAVHIP_OK;
+}
+
+int navhip_relabel_local_islands(navhip_ctx *ctx, int layer)
+{
+    if(!ctx || layer < 0 || layer >= NAVHIP_NAV_LAYER_MAX) return NAVHIP_ERR_INVALID;
+    if(!ctx->layers[layer].cost) return NAVHIP_ERR_NOT_UPLOADED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = layer_prepare(ctx, layer, NAVHIP_PLANE_LOCAL_ISLANDS);
+    if(rc) return rc;
+    rc = refresh_derived(ctx, ctx->stream);
+    if(rc) return rc;
+    nh_launch_local_islands(ctx, layer, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NAVHIP_OK;
+}
+
+int navhip_changed_chunks(navhip_ctx *ctx, int layer, uint8_t *host_flags, int clear)
+{
+    if(!ctx || !host_flags || layer < 0 || layer >= NAVHIP_NAV_LAYER_MAX) return NAVHIP_ERR_INVALID;
+    navhip_layer &L = ctx->layers[layer];
+    if(!L.changed) { memset(host_flags, 0, (size_t)ctx->nchunks); return NAVHIP_OK; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(host_flags, L.changed, (size_t)ctx->nchunks, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    if(clear) HIPCHK(ctx, hipMemsetAsync(L.changed, 0, (size_t)ctx->nchunks, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NAVHIP_OK;
+}
+
+int navhip_clear_changed(navhip_ctx *ctx, void *stream)
+{
+    if(!ctx) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++)
+        if(ctx->layers[l].changed)
+            HIPCHK(ctx, hipMemsetAsync(ctx->layers[l].changed, 0, (size_t)ctx->nchunks, s));
+    return NAVHIP_OK;
+}
+
 static int validate_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
 {
     for(int i = 0; i < n; i++) {
@@ -306,7 +414,8 @@ int navhip_build_fields(navhip_ctx *ctx, const navhip_field_req *reqs, int n,
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_reqs, reqs, (size_t)n * sizeof(navhip_field_req),
                                hipMemcpyHostToDevice, s));
     bool any_inout = false;
-    for(int i = 0; i < n; i++) any_inout |= (reqs[i].flags & NAVHIP_REQ_INOUT) != 0;
+    for(int i = 0; i < n; i++)      // skipped (IF_CHANGED) slots must come back unchanged too
+        any_inout |= (reqs[i].flags & (NAVHIP_REQ_INOUT | NAVHIP_REQ_IF_CHANGED)) != 0;
     if(any_inout)
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_dirs, inout_dirs, (size_t)n * NH_CELLS,
                                    hipMemcpyHostToDevice, s));
@@ -352,7 +461,7 @@ static void fill_map_view(const navhip_ctx *ctx, nh_map_view *mv)
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         const navhip_layer &L = ctx->layers[l];
         mv->layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
-                                      L.passmask, L.unit_cost};
+                                      L.passmask, L.unit_cost, L.changed};
     }
 }
 

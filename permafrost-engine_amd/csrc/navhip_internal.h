@@ -20,6 +20,8 @@ struct navhip_layer {
     uint64_t *passmask;        // [nchunks][64]  bit c of word r = cell (r,c) passable, faction NONE
                                //                (field_tile_passable, field.c:117)
     uint8_t  *unit_cost;       // [nchunks]      1 when every cost != 0xff cell has cost 1
+    uint8_t  *touched;         // [nchunks]      device: blockers modified since the last refresh
+    uint8_t  *changed;         // [nchunks]      device: passability changed since navhip_clear_changed
     uint8_t  *dirty;           // host side: [nchunks] derived state stale
     bool      any_dirty;
 };
@@ -55,6 +57,10 @@ void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, 
 void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, uint8_t *d_dirs,
                       float *d_integ, hipStream_t s);
 
+void nh_launch_blockers_circles(navhip_ctx *ctx, const navhip_circle *d_circles, int n, float map_x,
+                                float map_z, hipStream_t s);
+void nh_launch_local_islands(navhip_ctx *ctx, int layer, hipStream_t s);
+
 struct nh_layer_view {
     const uint8_t  *cost;
     const uint16_t *blockers;
@@ -62,6 +68,7 @@ struct nh_layer_view {
     const uint8_t  *factions;
     const uint64_t *passmask;
     const uint8_t  *unit_cost;
+    const uint8_t  *changed;
 };
 struct nh_map_view {
     int w, h;

@@ -24,7 +24,7 @@ ISLAND_NONE = 0xFFFF
 FACTION_ID_NONE = 0xF
 TARGET_PORTAL, TARGET_TILE = 0, 1
 PLANE_COST_BASE, PLANE_BLOCKERS, PLANE_LOCAL_ISLANDS, PLANE_FACTIONS = 0, 1, 2, 3
-REQ_INOUT = 0x1
+REQ_INOUT, REQ_IF_CHANGED, REQ_LIVE_IIDS = 0x1, 0x2, 0x4
 FD_NONE, FD_NW, FD_N, FD_NE, FD_W, FD_E, FD_SW, FD_S, FD_SE = range(9)
 
 # navhip_field_req, include/navhip.h (32 bytes)
@@ -39,6 +39,11 @@ FIELD_REQ_DTYPE = np.dtype([
 ], align=False)
 assert FIELD_REQ_DTYPE.itemsize == 32
 
+# navhip_circle, include/navhip.h (24 bytes)
+CIRCLE_DTYPE = np.dtype([("x", np.float32), ("z", np.float32), ("radius", np.float32),
+                         ("faction_id", np.int32), ("flags", np.uint32), ("delta", np.int32)])
+assert CIRCLE_DTYPE.itemsize == 24
+
 # exported symbols, checked by the CPU test-suite against include/navhip.h
 _SIGS = {
     "navhip_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
@@ -51,6 +56,13 @@ _SIGS = {
     "navhip_upload_chunk": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_size_t]),
     "navhip_plane_dev": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "navhip_download_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "navhip_blockers_circles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]),
+    "navhip_blockers_circles_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                              C.c_void_p]),
+    "navhip_relabel_local_islands": (C.c_int, [C.c_void_p, C.c_int]),
+    "navhip_changed_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "navhip_clear_changed": (C.c_int, [C.c_void_p, C.c_void_p]),
     "navhip_build_fields": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_build_fields_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
@@ -143,6 +155,44 @@ class NavContext:
         a = np.ascontiguousarray(array, dtype=dt)
         self._chk(lib().navhip_upload_chunk(self._h, layer, plane, chunk_r, chunk_c, _hp(a),
                                             a.nbytes), "navhip_upload_chunk")
+
+    def download_plane(self, layer, plane):
+        dt = np.uint8 if plane in (PLANE_COST_BASE, PLANE_FACTIONS) else np.uint16
+        shape = (self.h, self.w, 64, 64) if plane != PLANE_FACTIONS else (self.h, self.w, 15, 64, 64)
+        out = np.zeros(shape, dt)
+        self._chk(lib().navhip_download_plane(self._h, layer, plane, _hp(out), out.nbytes),
+                  "navhip_download_plane")
+        return out
+
+    # -- dynamic obstacles (N_BlockersIncref / N_BlockersDecref, nav.c:4663,4685) -----------------
+    def map_pos(self):
+        return self.w * 128.0, -self.h * 128.0
+
+    def N_BlockersUpdate(self, circles):
+        """circles: CIRCLE_DTYPE records (delta +1 = N_BlockersIncref, -1 = N_BlockersDecref)."""
+        c = np.ascontiguousarray(circles, dtype=CIRCLE_DTYPE)
+        mx, mz = self.map_pos()
+        self._chk(lib().navhip_blockers_circles(self._h, _hp(c), len(c), mx, mz),
+                  "navhip_blockers_circles")
+
+    def blockers_circles_dev(self, d_circles, n, stream=None):
+        mx, mz = self.map_pos()
+        self._chk(lib().navhip_blockers_circles_dev(self._h, dev_ptr(d_circles), n, mx, mz,
+                                                    C.c_void_p(stream) if stream else None),
+                  "navhip_blockers_circles_dev")
+
+    def relabel_local_islands(self, layer=0):
+        self._chk(lib().navhip_relabel_local_islands(self._h, layer), "navhip_relabel_local_islands")
+
+    def changed_chunks(self, layer=0, clear=False):
+        out = np.zeros(self.w * self.h, np.uint8)
+        self._chk(lib().navhip_changed_chunks(self._h, layer, _hp(out), int(clear)),
+                  "navhip_changed_chunks")
+        return out.reshape(self.h, self.w)
+
+    def clear_changed(self, stream=None):
+        self._chk(lib().navhip_clear_changed(self._h, C.c_void_p(stream) if stream else None),
+                  "navhip_clear_changed")
 
     def set_field_kernel(self, mode):
         self._chk(lib().navhip_set_field_kernel(self._h, mode), "navhip_set_field_kernel")

@@ -24,7 +24,7 @@ def _declared():
 def test_header_symbols_exported_and_bound(navlib):
     L = navlib.lib()
     names = _declared()
-    assert len(names) >= 17
+    assert len(names) >= 25
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, "declared in include/navhip.h but not exported: %s" % missing
     unbound = [n for n in names if n not in navlib._SIGS]
@@ -46,6 +46,8 @@ int main(void){
     printf("sizeof.navhip_field_req %zu\n", sizeof(navhip_field_req));
     printf("sizeof.navhip_world %zu\n", sizeof(navhip_world));
     printf("sizeof.navhip_step_out %zu\n", sizeof(navhip_step_out));
+    printf("sizeof.navhip_circle %zu\n", sizeof(navhip_circle));
+    P(navhip_circle, radius); P(navhip_circle, faction_id); P(navhip_circle, delta);
     P(navhip_field_req, enemies); P(navhip_field_req, chunk_r); P(navhip_field_req, tile_r);
     P(navhip_field_req, port_r0); P(navhip_field_req, next_r0); P(navhip_field_req, next_chunk_r);
     P(navhip_field_req, port_iid); P(navhip_field_req, next_iid);
@@ -66,6 +68,9 @@ int main(void){
         assert got["navhip_field_req." + f] == dt.fields[f][1], f
     assert got["sizeof.navhip_world"] == C.sizeof(navlib.World)
     assert got["sizeof.navhip_step_out"] == C.sizeof(navlib.StepOut)
+    assert got["sizeof.navhip_circle"] == navlib.CIRCLE_DTYPE.itemsize == 24
+    for f in ("radius", "faction_id", "delta"):
+        assert got["navhip_circle." + f] == navlib.CIRCLE_DTYPE.fields[f][1], f
     for f in ("pos_xz", "vdes_xz", "field_pool", "map_pos_x", "grid_xmin", "work_begin"):
         assert got["navhip_world." + f] == getattr(navlib.World, f).offset, f
     assert got["navhip_step_out.status"] == navlib.StepOut.status.offset

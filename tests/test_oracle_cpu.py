@@ -191,3 +191,51 @@ def test_golden_velocity_step():
     clean = np.isin(g["state"], (0, 5, 6)) & ((out2["status"] & 0x06) == 0)
     assert clean.sum() > 200
     assert np.array_equal(out2["vdes_xz"][clean], g["ref_vdes_sampled"][clean])
+
+
+# ---------------------------------------------------------------------------------------------
+# dynamic obstacles: N_BlockersIncref / Decref + local-island relabel
+# ---------------------------------------------------------------------------------------------
+def _random_circles(grid, n, seed, air_frac=0.0, max_radius=9.0):
+    rng = np.random.RandomState(seed)
+    h, w = grid.shape[0] // 64, grid.shape[1] // 64
+    c = np.zeros(n, navoracle.CIRCLE_DTYPE)
+    c["x"] = rng.uniform(-w * 128.0 + 0.5, w * 128.0 - 0.5, n)
+    c["z"] = rng.uniform(-h * 128.0 + 0.5, h * 128.0 - 0.5, n)
+    c["radius"] = rng.choice([0.5, 1.0, 2.0, 3.25, 4.0, 6.0, max_radius], size=n)
+    c["faction_id"] = rng.randint(0, 4, n)
+    c["flags"] = np.where(rng.rand(n) < air_frac, 1 << 15, 0)
+    c["delta"] = 1
+    # a few on the map edges / corners, and exact tile-boundary positions
+    c["x"][0], c["z"][0] = w * 128.0, -h * 128.0
+    c["x"][1], c["z"][1] = -w * 128.0, h * 128.0
+    c["x"][2], c["z"][2] = 4.0 * 7, -4.0 * 9
+    return c
+
+
+@needs_ref
+def test_blockers_and_local_islands_restatement_matches_reference():
+    grid = cases.synth.cost_grid(2, 2, seed=13)
+    nav = pfref.RefNav(cases.synth.to_chunks(grid), layer_mask=0xff)        # ground + water layers
+    onav = navoracle.OracleNav(cases.synth.to_chunks(grid))
+    for layer in range(8):
+        onav.set_layer(layer, cost=nav.plane(pfref.PLANE_COST, layer),
+                       blockers=np.zeros((2, 2, 64, 64), np.uint16),
+                       local_islands=nav.plane(pfref.PLANE_LOCAL_ISLANDS, layer),
+                       factions=np.zeros((2, 2, 15, 64, 64), np.uint8))
+    circles = _random_circles(grid, 90, seed=2, max_radius=22.0)
+    circles["radius"][5], circles["radius"][6] = 100.0, 75.0     # the 1024-tile scratch caps bind
+    undo = circles[::3].copy()
+    undo["delta"] = -1
+    for batch in (circles, undo):
+        for c in batch:
+            nav.blockers_circle(float(c["x"]), float(c["z"]), float(c["radius"]), int(c["faction_id"]),
+                                int(c["flags"]), incref=(c["delta"] > 0))
+        onav.blockers_circles(batch)
+        for layer in range(8):
+            assert np.array_equal(onav.plane(layer, "blockers"), nav.plane(pfref.PLANE_BLOCKERS, layer)), layer
+            assert np.array_equal(onav.plane(layer, "factions"), nav.plane(pfref.PLANE_FACTIONS, layer)), layer
+    assert onav.plane(3, "blockers").sum() > onav.plane(0, "blockers").sum() > 0     # contours on 7x7
+    nav.flush_dirty()                                        # n_update_dirty_local_islands
+    for layer in range(8):
+        assert np.array_equal(onav.local_islands(layer), nav.plane(pfref.PLANE_LOCAL_ISLANDS, layer)), layer
