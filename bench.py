@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--map", type=int, default=16, help="map side in chunks (16 = 1024x1024 cells)")
     ap.add_argument("--fields", type=int, default=64, help="whole-map flow fields per GPU")
     ap.add_argument("--agents", type=int, default=100_000, help="agents per GPU")
+    ap.add_argument("--obstacles", type=int, default=0,
+                    help="configs[4]: dynamic obstacles, 1%% moved per tick, incremental field repair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -143,7 +145,8 @@ def main():
     torch.cuda.set_device(local)
 
     T = tick.NavTick(chunk_w=args.map, fields_per_rank=args.fields, agents_per_rank=args.agents,
-                     rank=rank, world=world, device=local, verbose=(rank == 0 and False))
+                     rank=rank, world=world, device=local, verbose=(rank == 0 and False),
+                     obstacles=args.obstacles, obstacle_ticks=args.warmup + args.steps + 8)
     for _ in range(args.warmup):
         T.step()
     T.sync()
@@ -222,14 +225,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64-bitmask/u8 fields, f32 agents",
             "data": "synthetic",
-            "config": {"workload": "configs[2]: %dx%d-cell map (%dx%d chunks), %d flow fields "
+            "config": {"workload": ("configs[4] (dynamic obstacles, incremental repair): " if args.obstacles else "")
+                                   + "configs[2]: %dx%d-cell map (%dx%d chunks), %d flow fields "
                                    "(%d chunk fields) + %d agents per GPU, fields rebuilt + agents "
                                    "stepped every tick" % (args.map * 64, args.map * 64, args.map, args.map,
                                                            args.fields, T.n_req_local, args.agents),
                        "map_chunks": args.map, "flow_fields_per_gpu": args.fields,
-                       "agents_per_gpu": args.agents, "hz": 20,
+                       "agents_per_gpu": args.agents, "hz": 20, "dynamic_obstacles": args.obstacles,
                        "parallelism": "requests+agent-slabs sharded x%d, all-gather tiles/slabs" % world},
-            "flow_field_cells_per_s": cells_total * args.steps / dt,
+            ("flow_field_cells_kept_valid_per_s" if args.obstacles else "flow_field_cells_per_s"):
+                cells_total * args.steps / dt,
             "flow_field_cells_per_s_kernel": (T.n_req_local * 4096 * world) / (f_ms * 1e-3) if f_ms > 0 else None,
             "agent_steps_per_s_kernel": agents_total / (a_ms * 1e-3) if a_ms > 0 else None,
             "phase_ms": phases,

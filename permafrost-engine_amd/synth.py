@@ -74,11 +74,12 @@ def destinations(grid, k, seed=42):
     return cells[idx]
 
 
-def agents(grid, n, k_flocks, seed=7, radius=1.0, max_speed=20.0, hz=20):
-    """N agents at random passable cell centres + U(-1.5,1.5) jitter, round-robin flocks."""
+def agents(grid, n, k_flocks, seed=7, radius=1.0, max_speed=20.0, hz=20, blockers=None):
+    """N agents at random passable (and unblocked) cell centres + U(-1.5,1.5) jitter, round-robin
+    flocks."""
     rng = np.random.RandomState(seed)
     h, w = grid.shape[0] // 64, grid.shape[1] // 64
-    cells = passable_cells(grid)
+    cells = passable_cells(grid, blockers)
     idx = rng.randint(0, len(cells), size=n)
     pos = cell_centre(w, h, cells[idx, 0], cells[idx, 1])
     pos += rng.uniform(-1.5, 1.5, size=pos.shape).astype(np.float32)
