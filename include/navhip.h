@@ -199,7 +199,7 @@ enum { NAVHIP_STATE_MOVING = 0, NAVHIP_STATE_MOVING_IN_FORMATION, NAVHIP_STATE_A
 #define NAVHIP_ST_FIELD_MISS   0x02  /* no flow field cached for the agent's chunk: the host must run
                                         the planner (n_request_path, nav.c:3483-3492) and re-step    */
 #define NAVHIP_ST_FIELD_NONE   0x04  /* the field has FD_NONE under the agent (nav.c:3495-3554 path)  */
-#define NAVHIP_ST_UNSUPPORTED  0x80  /* formation states: not on the device path, velocity = 0       */
+#define NAVHIP_ST_UNSUPPORTED  0x80  /* formation state without formation inputs: velocity = 0        */
 
 /* The snapshot the movement tick works on: `struct move_gamestate` + `struct move_work_in` +
  * flock table (movement.c:207-213,264-276,296-312) as structure-of-arrays; uid == array index.
@@ -220,7 +220,9 @@ typedef struct navhip_world {
     const uint8_t  *has_dest_los;    /* [n]     move_work_in.has_dest_los                      */
     const int32_t  *flock;           /* [n]     index into the flock table, -1 = none          */
     const float    *vdes_xz;         /* [n][2]  move_work_in.ent_des_v, or NULL: sample the flow
-                                                fields on the device (N_DesiredPointSeekVelocity) */
+                                                fields on the device (N_DesiredPointSeekVelocity).
+                                                With a non-NULL array, an entry whose x is NaN is
+                                                sampled on the device as well                       */
     const float    *flock_target_xz; /* [F][2]  flock.target_xz                                */
     const int32_t  *flock_offsets;   /* [F+1]   CSR offsets into flock_members                 */
     const int32_t  *flock_members;   /* member uids, in kh_foreach order of flock.ents         */
@@ -232,6 +234,14 @@ typedef struct navhip_world {
     int32_t  work_begin, work_end;   /* the slab [begin,end) of uids this call computes (the index
                                         slabs of move_submit_cpu_work, movement.c:3759-3762); every
                                         entity still acts as a neighbour.  0,0 = all entities      */
+    /* Formation inputs, computed by the host's formation module (struct formation_state,
+     * movement.c:215-225; move_work_in.cell_pos, :268).  form_ready == NULL: entities in
+     * STATE_MOVING_IN_FORMATION / STATE_ARRIVING_TO_CELL are reported NAVHIP_ST_UNSUPPORTED. */
+    const uint8_t  *form_ready;      /* [n]     fstate.assignment_ready                          */
+    const float    *cell_pos_xz;     /* [n][2]  move_work_in.cell_pos                            */
+    const float    *form_cohesion_xz;/* [n][2]  fstate.normal_cohesion_force                     */
+    const float    *form_align_xz;   /* [n][2]  fstate.normal_align_force                        */
+    const float    *form_drag_xz;    /* [n][2]  fstate.normal_drag_force                         */
 } navhip_world;
 
 typedef struct navhip_step_out {

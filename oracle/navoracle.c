@@ -967,6 +967,80 @@ static void find_neighbours(const step_ctx *c, int uid, cpent *dyn, int *n_dyn, 
     }
 }
 
+/* arrive_force_cell, movement.c:1574 */
+static v2 arrive_force_cell(const step_ctx *c, int uid, v2 cell_xz, v2 vdes)
+{
+    const navhip_world *w = c->w;
+    v2 desired = vsub(cell_xz, wpos(w, uid));
+    float distance = vlen(desired);
+    if(distance < 10.0f)
+        desired = vscale(desired, distance / 10.0f);
+    else
+        desired = vscale(vdes, w->max_speed[uid] / w->hz);
+    return desired;
+}
+
+/* cell_arrival_seek_vpref :1908 over cell_seek_total_force :1773, and formation_seek_vpref :1985
+ * over formation_point_seek_total_force :1962; the formation forces are host inputs */
+static v2 formation_vpref(const step_ctx *c, int uid, int flock, v2 vdes, bool to_cell)
+{
+    const navhip_world *w = c->w;
+    v2 cell = mkv(w->cell_pos_xz[2 * uid], w->cell_pos_xz[2 * uid + 1]);
+    v2 cohesion = mkv(w->form_cohesion_xz[2 * uid], w->form_cohesion_xz[2 * uid + 1]);
+    v2 alignment = mkv(w->form_align_xz[2 * uid], w->form_align_xz[2 * uid + 1]);
+    v2 drag = mkv(w->form_drag_xz[2 * uid], w->form_drag_xz[2 * uid + 1]);
+    v2 target = flock >= 0 ? mkv(w->flock_target_xz[2 * flock], w->flock_target_xz[2 * flock + 1]) : wpos(w, uid);
+    bool los = w->has_dest_los[uid] != 0;
+    float speed = w->speed[uid];
+    v2 steer = mkv(0.0f, 0.0f);
+    for(int prio = 0; prio < 3; prio++) {
+        switch(prio) {
+        case 0: {
+            v2 arrive = to_cell ? arrive_force_cell(c, uid, cell, vdes)
+                                : arrive_force_point(c, uid, target, vdes, los);
+            v2 separation = separation_force(c, uid);
+            v2 co = vscale(cohesion, 0.15f), al = vscale(alignment, 0.15f);
+            arrive = vscale(arrive, 0.5f);
+            separation = vscale(separation, 0.6f);
+            v2 ret = mkv(0.0f, 0.0f);
+            ret = vadd(ret, arrive);
+            ret = vadd(ret, separation);
+            if(to_cell) {
+                v2 delta = vsub(cell, wpos(w, uid));
+                if(vlen(delta) > 30.0f) {                        /* CELL_ARRIVAL_RADIUS */
+                    ret = vadd(ret, co);
+                    ret = vadd(ret, al);
+                }
+            }else{
+                ret = vadd(ret, co);
+            }
+            steer = vtrunc(ret, c->scaled_max_force_f);
+            break;
+        }
+        case 1: steer = separation_force(c, uid); break;
+        case 2: steer = to_cell ? arrive_force_cell(c, uid, cell, vdes)
+                                : arrive_force_point(c, uid, target, vdes, los);
+                break;
+        }
+        steer = nullify_impass(c, uid, steer);
+        if(vlen(steer) > c->scaled_max_force * 0.01)
+            break;
+    }
+    v2 accel = vscale(steer, 1.0f / 1.0f);
+    v2 new_vel = vtrunc(vadd(wvel(w, uid), accel), speed / w->hz);
+    if(vlen(drag) > (1.0f / 1024))
+        new_vel = vtrunc(new_vel, (speed * 0.75) / w->hz);
+    return new_vel;
+}
+
+static v2 load_vdes(const step_ctx *c, int uid, v2 me, unsigned *status)
+{
+    const navhip_world *w = c->w;
+    if(w->vdes_xz && !isnan(w->vdes_xz[2 * uid]))
+        return mkv(w->vdes_xz[2 * uid], w->vdes_xz[2 * uid + 1]);
+    return sample_flow(c->m, w, w->flock[uid], me, status);
+}
+
 static bool state_point_seek(int s)
 {
     return s == NAVHIP_STATE_MOVING || s == NAVHIP_STATE_SURROUND_ENTITY
@@ -991,13 +1065,20 @@ static void step_one(const step_ctx *c, int uid, const navhip_step_out *o)
         if(state == NAVHIP_STATE_TURNING) {
             vpref = mkv(0.0f, 0.0f);
         }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_point_seek(state)) {
-            if(w->vdes_xz) vdes = mkv(w->vdes_xz[2 * uid], w->vdes_xz[2 * uid + 1]);
-            else           vdes = sample_flow(c->m, w, w->flock[uid], me, &status);
+            vdes = load_vdes(c, uid, me, &status);
             if(state == NAVHIP_STATE_SEEK_ENEMIES)
                 vpref = enemy_seek_vpref(c, uid, w->speed[uid], vdes);
             else
                 vpref = point_seek_vpref(c, uid, w->flock[uid], vdes, w->has_dest_los[uid] != 0,
                                          w->speed[uid]);
+        }else if(w->form_ready && (state == NAVHIP_STATE_MOVING_IN_FORMATION
+                                  || state == NAVHIP_STATE_ARRIVING_TO_CELL)) {
+            if(!w->form_ready[uid]) {                       /* movement.c:3425,3437 */
+                vpref = mkv(0.0f, 0.0f);
+            }else{
+                vdes = load_vdes(c, uid, me, &status);
+                vpref = formation_vpref(c, uid, w->flock[uid], vdes, state == NAVHIP_STATE_ARRIVING_TO_CELL);
+            }
         }else{
             supported = false;
             status |= NAVHIP_ST_UNSUPPORTED;

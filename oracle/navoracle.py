@@ -48,7 +48,9 @@ class World(C.Structure):
         ("flock_members", C.c_void_p), ("flock_field_slot", C.c_void_p), ("field_pool", C.c_void_p),
         ("map_pos_x", C.c_float), ("map_pos_z", C.c_float),
         ("grid_xmin", C.c_float), ("grid_xmax", C.c_float), ("grid_zmin", C.c_float),
-        ("grid_zmax", C.c_float), ("work_begin", C.c_int32), ("work_end", C.c_int32)]
+        ("grid_zmax", C.c_float), ("work_begin", C.c_int32), ("work_end", C.c_int32),
+        ("form_ready", C.c_void_p), ("cell_pos_xz", C.c_void_p), ("form_cohesion_xz", C.c_void_p),
+        ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p)]
 
 
 class StepOut(C.Structure):
@@ -61,7 +63,9 @@ _WORLD_ARRAYS = (
     ("max_speed", np.float32), ("speed", np.float32), ("flags", np.uint32), ("state", np.uint8),
     ("has_dest_los", np.uint8), ("flock", np.int32), ("vdes_xz", np.float32),
     ("flock_target_xz", np.float32), ("flock_offsets", np.int32), ("flock_members", np.int32),
-    ("flock_field_slot", np.int32), ("field_pool", np.uint8))
+    ("flock_field_slot", np.int32), ("field_pool", np.uint8), ("form_ready", np.uint8),
+    ("cell_pos_xz", np.float32), ("form_cohesion_xz", np.float32), ("form_align_xz", np.float32),
+    ("form_drag_xz", np.float32))
 
 
 def available():

@@ -96,6 +96,7 @@ def lib():
             ("pfref_move_load", [C.c_void_p, C.POINTER(MoveWorld)], C.c_int),
             ("pfref_move_velocity", [C.c_void_p, C.c_int, C.c_int, C.c_void_p], None),
             ("pfref_move_unload", [], None),
+            ("pfref_move_set_formation", [C.c_void_p] * 5, None),
             ("pfref_move_vpref", [C.c_int, C.c_void_p, C.c_void_p], None),
             ("pfref_move_forces", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
              None),
@@ -305,6 +306,14 @@ class RefMove:
         v = None if vdes is None else np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
         lib().pfref_move_velocity(_p(v) if v is not None else None, begin, end, _p(out))
         return out
+
+    def set_formation(self, ready, cell_pos, cohesion, align, drag):
+        k = self._keep
+        k["f_ready"] = np.ascontiguousarray(ready, np.uint8)
+        for name, a in (("f_cell", cell_pos), ("f_coh", cohesion), ("f_align", align), ("f_drag", drag)):
+            k[name] = np.ascontiguousarray(a, np.float32).reshape(self.n, 2)
+        lib().pfref_move_set_formation(_p(k["f_ready"]), _p(k["f_cell"]), _p(k["f_coh"]),
+                                       _p(k["f_align"]), _p(k["f_drag"]))
 
     def bench(self, vdes, reps=1, nthreads=1, begin=0, end=None):
         end = self.n if end is None else end

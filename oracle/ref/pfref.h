@@ -157,6 +157,9 @@ typedef struct pfref_move_world {
  * from N_DesiredPointSeekVelocity).  out_vel[n][2], out_vpref optional. */
 int  pfref_move_load(pfref_nav *nav, const pfref_move_world *world);
 void pfref_move_velocity(const float *vdes, int begin, int end, float *out_vel);
+/* formation inputs of every work item: fstate.assignment_ready, cell_pos, fstate.normal_*_force */
+void pfref_move_set_formation(const uint8_t *ready, const float *cell_pos, const float *cohesion,
+                              const float *align, const float *drag);
 void pfref_move_unload(void);
 /* individual steering terms for unit tests (movement.c:1546,1653,1690,1870,2768) */
 void pfref_move_vpref(int uid, const float vdes[2], float out[2]);

@@ -226,6 +226,21 @@ int pfref_move_load(pfref_nav *nav, const pfref_move_world *w)
     return 0;
 }
 
+/* struct formation_state / cell_pos of every work item (movement.c:4377-4400 fills them from the
+ * formation module; here they are explicit inputs) */
+void pfref_move_set_formation(const uint8_t *ready, const float *cell_pos, const float *cohesion,
+                              const float *align, const float *drag)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        struct move_work_in *in = &s_move_work.in[i];
+        in->fstate.assignment_ready = ready[i];
+        in->cell_pos = (vec2_t){cell_pos[2 * i], cell_pos[2 * i + 1]};
+        in->fstate.normal_cohesion_force = (vec2_t){cohesion[2 * i], cohesion[2 * i + 1]};
+        in->fstate.normal_align_force = (vec2_t){align[2 * i], align[2 * i + 1]};
+        in->fstate.normal_drag_force = (vec2_t){drag[2 * i], drag[2 * i + 1]};
+    }
+}
+
 static void set_vdes(const float *vdes, int i)
 {
     struct move_work_in *in = &s_move_work.in[i];

@@ -35,6 +35,8 @@ struct nh_step_params {
     const float    *flock_target_xz;
     const int32_t  *flock_offsets, *flock_members, *flock_field_slot;
     const uint8_t  *field_pool;
+    const uint8_t  *form_ready;
+    const float    *cell_pos_xz, *form_cohesion_xz, *form_align_xz, *form_drag_xz;
 };
 
 struct nh_step_outs {

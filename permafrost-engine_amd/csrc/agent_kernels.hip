@@ -197,6 +197,18 @@ __device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &
     return vnormal(acc);
 }
 
+// move_work_in.ent_des_v: host supplied, or sampled from the device field pool (vdes_xz == NULL or
+// a NaN entry)
+__device__ __forceinline__ v2 load_vdes(const nh_step_params &P, int uid, int flock, v2 me,
+                                        uint32_t &status)
+{
+    if(P.vdes_xz) {
+        v2 v = mkv(P.vdes_xz[2 * uid], P.vdes_xz[2 * uid + 1]);
+        if(v.x == v.x) return v;
+    }
+    return sample_flow(P, flock, me, status);
+}
+
 // ---------------------------------------------------------------------------------------------
 // spatial hash (bitmap_grid.h): build
 // ---------------------------------------------------------------------------------------------
@@ -955,8 +967,7 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
             vpref = mkv(0.0f, 0.0f);
         }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_uses_point_seek(state)) {
             const bool point_seek = state_uses_point_seek(state);
-            if(P.vdes_xz) vdes = mkv(P.vdes_xz[2 * uid], P.vdes_xz[2 * uid + 1]);
-            else          vdes = sample_flow(P, flock, me, status);
+            vdes = load_vdes(P, uid, flock, me, status);
 
             // separation (used by priority 0 and 1): r = 30 query, cap 128
             int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane);
@@ -997,8 +1008,68 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
             }
             v2 accel = vscale(steer, 1.0f / 1.0f);
             vpref = vtrunc(vadd(vel, accel), speed / (float)hz);
+        }else if(P.form_ready && (state == NAVHIP_STATE_MOVING_IN_FORMATION
+                                 || state == NAVHIP_STATE_ARRIVING_TO_CELL)) {
+            // formation arms of move_velocity_work (movement.c:3423-3446); the formation forces are
+            // host inputs (struct formation_state)
+            if(!P.form_ready[uid]) {
+                vpref = mkv(0.0f, 0.0f);
+            }else{
+                vdes = load_vdes(P, uid, flock, me, status);
+                int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane);
+                wave_sync();
+                n30 = filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
+                const v2 separation = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
+                                                      W.u.sep, scaled_max_force, lane);
+                const v2 f_coh = mkv(P.form_cohesion_xz[2 * uid], P.form_cohesion_xz[2 * uid + 1]);
+                const v2 f_ali = mkv(P.form_align_xz[2 * uid], P.form_align_xz[2 * uid + 1]);
+                const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
+                const bool to_cell = state == NAVHIP_STATE_ARRIVING_TO_CELL;
+                const v2 cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
+                const bool los = P.has_dest_los[uid] != 0;
+                const v2 target = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]) : me;
+                // arrive_force_cell :1574 (no velocity term, no truncation) / arrive_force_point :1546
+                v2 arrive;
+                if(to_cell) {
+                    v2 desired = vsub(cell, me);
+                    float distance = vlen(desired);
+                    if(distance < 10.0f) desired = vscale(desired, distance / 10.0f);
+                    else                 desired = vscale(vdes, max_speed / (float)hz);
+                    arrive = desired;
+                }else{
+                    arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
+                }
+                v2 steer;
+                for(int prio = 0; prio < 3; prio++) {
+                    if(prio == 0) {
+                        // cell_seek_total_force :1773 / formation_point_seek_total_force :1962
+                        v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
+                        v2 c = vscale(f_coh, 0.15f), al = vscale(f_ali, 0.15f);
+                        v2 ret = mkv(0.0f, 0.0f);
+                        ret = vadd(ret, a); ret = vadd(ret, s);
+                        if(to_cell) {
+                            if(vlen(vsub(cell, me)) > 30.0f) {       // CELL_ARRIVAL_RADIUS
+                                ret = vadd(ret, c); ret = vadd(ret, al);
+                            }
+                        }else{
+                            ret = vadd(ret, c);
+                        }
+                        steer = vtrunc(ret, scaled_max_force);
+                    }else if(prio == 1) {
+                        steer = separation;
+                    }else{
+                        steer = arrive;
+                    }
+                    steer = nullify_impass(P, layer, me, steer);
+                    if((double)vlen(steer) > force_thresh) break;
+                }
+                v2 accel = vscale(steer, 1.0f / 1.0f);
+                vpref = vtrunc(vadd(vel, accel), speed / (float)hz);
+                if(vlen(f_drag) > CP_EPS)                            // :1935 / :2018
+                    vpref = vtrunc(vpref, (float)(((double)speed * 0.75) / (double)hz));
+            }
         }else{
-            supported = false;                      // formation states stay on the host path
+            supported = false;                      // formation state without formation inputs
             status |= NAVHIP_ST_UNSUPPORTED;
         }
 

@@ -530,6 +530,13 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     P.flock = w->flock; P.vdes_xz = w->vdes_xz; P.flock_target_xz = w->flock_target_xz;
     P.flock_offsets = w->flock_offsets; P.flock_members = w->flock_members;
     P.flock_field_slot = w->flock_field_slot; P.field_pool = w->field_pool;
+    P.form_ready = w->form_ready; P.cell_pos_xz = w->cell_pos_xz;
+    P.form_cohesion_xz = w->form_cohesion_xz; P.form_align_xz = w->form_align_xz;
+    P.form_drag_xz = w->form_drag_xz;
+    if(P.form_ready && (!P.cell_pos_xz || !P.form_cohesion_xz || !P.form_align_xz || !P.form_drag_xz)) {
+        ctx->last_error = "agent step: form_ready given without the other formation arrays";
+        return NAVHIP_ERR_INVALID;
+    }
     nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
     nh_launch_cohesion(P, (float*)ctx->coh.p, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
@@ -586,6 +593,8 @@ static int stage_world(navhip_ctx *ctx, const navhip_world *w, navhip_world *d, 
     ST(11, flock_offsets, (F + 1) * 4);                      ST(12, flock_members, nmembers * 4);
     ST(13, flock_field_slot, F * nchunks * 4);
     ST(14, field_pool, (size_t)w->n_field_slots * NH_CELLS);
+    ST(24, form_ready, n);       ST(25, cell_pos_xz, n * 8); ST(26, form_cohesion_xz, n * 8);
+    ST(27, form_align_xz, n * 8); ST(28, form_drag_xz, n * 8);
 #undef ST
     return rc;
 }

@@ -43,7 +43,7 @@ struct navhip_ctx {
     buf          sp[10];       // spatial hash: ent_ix, ent_iy, ent_cell, cell_count, cell_fill,
                                //               cell_start, sorted_id, sx, sy, block_sum
     buf          coh;          // cohesion force per entity
-    buf          stage[24];    // device copies of host buffers for the host-pointer entry points
+    buf          stage[32];    // device copies of host buffers for the host-pointer entry points
     // optional per-kernel-group timing of the agent step (navhip_set_profiling)
     bool         profiling;
     hipEvent_t   ev[4];        // start | spatial hash built | cohesion done | agent step done

@@ -259,3 +259,24 @@ def cached_field_table(nav, dest_ids, w, h):
                     slots[f, cr * w + cc] = len(pool)
                     pool.append(ff.reshape(-1))
     return slots, np.stack(pool).astype(np.uint8)
+
+
+def formation_inputs(world, seed):
+    """Random formation-module outputs (struct formation_state + cell_pos, movement.c:215-225,268)
+    and a state mix that puts ~40 % of the agents into the two formation states."""
+    rng = np.random.RandomState(seed)
+    n = len(world["pos_xz"])
+    state = world["state"].copy()
+    u = rng.rand(n)
+    moving = state == 0
+    state[moving & (u < 0.22)] = 1          # STATE_MOVING_IN_FORMATION
+    state[moving & (u >= 0.22) & (u < 0.44)] = 8   # STATE_ARRIVING_TO_CELL
+    f = {
+        "form_ready": (rng.rand(n) < 0.85).astype(np.uint8),
+        # cells both inside and outside CELL_ARRIVAL_RADIUS (30) / the slowing radius (10)
+        "cell_pos_xz": (world["pos_xz"] + rng.normal(0, 1, (n, 2)) * rng.choice([3.0, 12.0, 45.0], (n, 1))).astype(np.float32),
+        "form_cohesion_xz": rng.normal(0, 0.4, (n, 2)).astype(np.float32),
+        "form_align_xz": rng.normal(0, 0.4, (n, 2)).astype(np.float32),
+        "form_drag_xz": np.where(rng.rand(n, 1) < 0.5, rng.normal(0, 0.3, (n, 2)), 0.0).astype(np.float32),
+    }
+    return state, f

@@ -128,3 +128,32 @@ def test_device_flow_sampling_matches_reference(navlib):
     err = _vel_err(out["vel_xz"][clean], exp_vel[clean])
     assert (err <= REL_TOL).all()
     pfref.RefMove.unload()
+
+
+def test_formation_arms_match_reference(navlib):
+    """STATE_MOVING_IN_FORMATION / STATE_ARRIVING_TO_CELL (movement.c:3423-3446) with the formation
+    module's forces as inputs; NaN entries of vdes_xz are sampled on the device."""
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    world = cases.make_agents(grid, 1400, 3, seed=5, clustered=True)
+    world["state"], form = cases.formation_inputs(world, seed=6)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    mv.set_formation(form["form_ready"], form["cell_pos_xz"], form["form_cohesion_xz"],
+                     form["form_align_xz"], form["form_drag_xz"])
+    rng = np.random.RandomState(1)
+    vdes = rng.normal(0, 1, (1400, 2)).astype(np.float32)
+    vdes /= np.linalg.norm(vdes, axis=1, keepdims=True)
+    exp_vel = mv.velocity(vdes)
+    a = _step_arrays(world, mv, vdes)
+    a.update(form)
+    ctx = _upload(navlib, nav)
+    out = ctx.agent_step(a)
+    moving = ~np.isin(world["state"], (2, 4))
+    assert (out["status"] & navlib.ST_UNSUPPORTED).sum() == 0
+    err = _vel_err(out["vel_xz"][moving], exp_vel[moving])
+    assert (err <= REL_TOL).all(), "max rel %.3g" % err.max()
+    for k in form:
+        a[k] = None
+    out2 = ctx.agent_step(a)
+    assert ((out2["status"] & navlib.ST_UNSUPPORTED) != 0).sum() == np.isin(world["state"], (1, 8)).sum()
+    ctx.close()
+    pfref.RefMove.unload()

@@ -239,3 +239,30 @@ def test_blockers_and_local_islands_restatement_matches_reference():
     nav.flush_dirty()                                        # n_update_dirty_local_islands
     for layer in range(8):
         assert np.array_equal(onav.local_islands(layer), nav.plane(pfref.PLANE_LOCAL_ISLANDS, layer)), layer
+
+
+@needs_ref
+def test_formation_arms_restatement_matches_reference():
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    world = cases.make_agents(grid, 900, 3, seed=5, clustered=True)
+    world["state"], form = cases.formation_inputs(world, seed=6)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    mv.set_formation(form["form_ready"], form["cell_pos_xz"], form["form_cohesion_xz"],
+                     form["form_align_xz"], form["form_drag_xz"])
+    rng = np.random.RandomState(1)
+    vdes = rng.normal(0, 1, (900, 2)).astype(np.float32)
+    vdes /= np.linalg.norm(vdes, axis=1, keepdims=True)
+    exp_vel = mv.velocity(vdes)
+    arrays = cases.step_arrays(world, vdes, [mv.flock_order(f) for f in range(3)])
+    arrays.update(form)
+    out = cases.oracle_nav_from_ref(nav).agent_step(arrays)
+    moving = ~np.isin(world["state"], (2, 4))
+    assert np.isin(world["state"], (1, 8)).sum() > 250
+    assert (out["status"] & 0x80).sum() == 0
+    assert np.array_equal(out["vel_xz"][moving].view(np.uint32), exp_vel[moving].view(np.uint32))
+    # without the formation arrays the same agents are reported unsupported, not guessed
+    for k in form:
+        arrays[k] = None
+    out2 = cases.oracle_nav_from_ref(nav).agent_step(arrays)
+    assert ((out2["status"] & 0x80) != 0).sum() == np.isin(world["state"], (1, 8)).sum()
+    pfref.RefMove.unload()
