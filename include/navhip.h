@@ -49,8 +49,9 @@ extern "C" {
 enum { NAVHIP_FD_NONE = 0, NAVHIP_FD_NW, NAVHIP_FD_N, NAVHIP_FD_NE, NAVHIP_FD_W,
        NAVHIP_FD_E, NAVHIP_FD_SW, NAVHIP_FD_S, NAVHIP_FD_SE };
 
-/* field_target.type values, field.h:85-98 (only the chunk-aligned targets) */
-enum { NAVHIP_TARGET_PORTAL = 0, NAVHIP_TARGET_TILE = 1 };
+/* field_target.type values, field.h:85-98 (only the chunk-aligned targets), plus the repair build
+ * N_FlowFieldUpdateToNearestPathable (field.c:2247), which ignores the field's own target */
+enum { NAVHIP_TARGET_PORTAL = 0, NAVHIP_TARGET_TILE = 1, NAVHIP_TARGET_NEAREST_PATHABLE = 2 };
 
 /* per-layer planes held on the device (struct nav_chunk members, nav_data.h:118-158) */
 enum {
@@ -58,6 +59,9 @@ enum {
     NAVHIP_PLANE_BLOCKERS      = 1,   /* uint16_t [64][64] per chunk              */
     NAVHIP_PLANE_LOCAL_ISLANDS = 2,   /* uint16_t [64][64] per chunk              */
     NAVHIP_PLANE_FACTIONS      = 3,   /* uint8_t  [15][64][64] per chunk          */
+    NAVHIP_PLANE_ISLANDS       = 4,   /* uint16_t [64][64] per chunk (global island ids,
+                                         nav_chunk.islands nav_data.h:150; only read by
+                                         NAVHIP_REQ_ISLAND_NEAREST)                */
     NAVHIP_PLANE_COUNT
 };
 
@@ -76,6 +80,12 @@ enum {
                                     port / next portal (for request lists that outlive a relabel, as
                                     in the device-resident incremental-repair benchmark) */
 
+#define NAVHIP_REQ_ISLAND_NEAREST 0x8 /* N_FlowFieldUpdateIslandToNearest(aux_iid, ...) (field.c:2307) on
+                                    an existing TILE/PORTAL field: the frontier is moved to the tiles
+                                    of local island aux_iid nearest (Manhattan) to the target's own
+                                    frontier; always in place.  The repair the sampler runs when an
+                                    agent's tile is orphaned from its goal by blockers (nav.c:3540) */
+
 /* One chunk-field build: the arguments of
  *   N_FlowFieldUpdate(chunk, priv, faction_id, layer, target, ctx, inout)   field.c:2030
  * with `struct field_target` / `struct portal_desc` (field.h:67-72,85-101) flattened so the
@@ -87,12 +97,14 @@ typedef struct navhip_field_req {
     uint8_t  flags;          /* NAVHIP_REQ_*                                           */
     uint16_t enemies;        /* enemies_for_faction(faction_id) bitmask, field.c:166   */
     uint16_t chunk_r, chunk_c;
-    uint8_t  tile_r, tile_c;                       /* TARGET_TILE: target.tile        */
+    uint8_t  tile_r, tile_c;                       /* TARGET_TILE: target.tile;
+                                                      NEAREST_PATHABLE: the start tile  */
     uint8_t  port_r0, port_c0, port_r1, port_c1;   /* TARGET_PORTAL: pd.port->endpoints */
     uint8_t  next_r0, next_c0, next_r1, next_c1;   /*                pd.next->endpoints */
     uint16_t next_chunk_r, next_chunk_c;           /*                pd.next->chunk     */
     uint16_t port_iid, next_iid;                   /*                pd.port_iid/next_iid */
-    uint16_t _pad[2];
+    uint16_t aux_iid;                              /* NAVHIP_REQ_ISLAND_NEAREST: local_iid */
+    uint16_t _pad;
 } navhip_field_req;
 
 typedef struct navhip_ctx navhip_ctx;

@@ -43,6 +43,7 @@ typedef struct no_map {
     const uint16_t *blockers[NLAYERS];
     const uint16_t *local_islands[NLAYERS];
     const uint8_t  *factions[NLAYERS];       /* [chunk][15][64][64] */
+    const uint16_t *islands[NLAYERS];        /* global island ids (nav_chunk.islands) */
 } no_map;
 
 /* ===========================================================================================
@@ -166,6 +167,11 @@ static int flow_dir(const float *f, int r, int c)
 #undef MINF
 }
 
+static int field_nearest_pathable(const no_map *m, const navhip_field_req *rq, uint8_t *inout_dirs,
+                                  float *out_integ);
+static int closest_tiles_local(const no_map *m, int layer, int chunk, int target, unsigned local_iid,
+                               unsigned global_iid, int *out, int maxout);
+
 /* N_FlowFieldInit (field.c:2020, unless NAVHIP_REQ_INOUT) + N_FlowFieldUpdate (field.c:2030) for
  * TARGET_TILE / TARGET_PORTAL.  Returns 0, or -1 for a malformed request. */
 int no_field_update(const no_map *m, const navhip_field_req *rq, uint8_t *inout_dirs,
@@ -186,20 +192,26 @@ int no_field_update(const no_map *m, const navhip_field_req *rq, uint8_t *inout_
     const int faction_id = rq->faction_id;
     const unsigned enemies = rq->enemies;
     const uint8_t *cost = m->cost[layer] + ((size_t)chunk << 12);
+    if(rq->type == NAVHIP_TARGET_NEAREST_PATHABLE)
+        return field_nearest_pathable(m, rq, inout_dirs, out_integ);
+    const bool island_nearest = (rq->flags & NAVHIP_REQ_ISLAND_NEAREST) != 0;
 
-    if(!(rq->flags & NAVHIP_REQ_INOUT))
+    if(!(rq->flags & NAVHIP_REQ_INOUT) && !island_nearest)
         memset(inout_dirs, NAVHIP_FD_NONE, CELLS);                     /* N_FlowFieldInit */
 
     static __thread float integ[CELLS];
     for(int i = 0; i < CELLS; i++) integ[i] = INFINITY;                /* field.c:2059-2063 */
     pq_t q = {0};
+    static __thread int frontier0[CELLS];
+    int nfront = 0;
+#define SEED(i_) do { if(island_nearest) frontier0[nfront++] = (i_); \
+                      else { pq_push(&q, 0.0f, (i_)); integ[(i_)] = 0.0f; } } while(0)
 
     /* field_initial_frontier, field.c:1372 */
     if(rq->type == NAVHIP_TARGET_TILE) {                               /* field.c:1096 */
         if(tile_passable(m, layer, chunk, rq->tile_r, rq->tile_c, faction_id, enemies)) {
             int i = rq->tile_r * RES + rq->tile_c;
-            pq_push(&q, 0.0f, i);
-            integ[i] = 0.0f;
+            SEED(i);
         }
     }else if(rq->type == NAVHIP_TARGET_PORTAL) {                       /* field.c:1160 */
         const uint16_t *li = m->local_islands[layer];
@@ -212,12 +224,45 @@ int no_field_update(const no_map *m, const navhip_field_req *rq, uint8_t *inout_
                 continue;
             if(!adjacent_to_next_iid(m, rq, r, c))
                 continue;
-            pq_push(&q, 0.0f, r * RES + c);
-            integ[r * RES + c] = 0.0f;
+            SEED(r * RES + c);
         }}
     }else{
         free(q.a);
         return -1;
+    }
+#undef SEED
+
+    if(island_nearest) {
+        /* N_FlowFieldUpdateIslandToNearest, field.c:2307: move the frontier onto the tiles of
+         * local island aux_iid nearest to the target's own frontier */
+        if(!m->local_islands[layer]) { free(q.a); return -1; }
+        const unsigned local_iid = rq->aux_iid;
+        const uint16_t *li = m->local_islands[layer] + ((size_t)chunk << 12);
+        const uint16_t *gi = m->islands[layer] ? m->islands[layer] + ((size_t)chunk << 12) : NULL;
+        if(nfront == 0 && rq->type == NAVHIP_TARGET_TILE)               /* ignoreblock retry :2352 */
+            frontier0[nfront++] = rq->tile_r * RES + rq->tile_c;
+        static __thread int newf[CELLS * 2], tmp[CELLS];
+        int min_mh = 1 << 30, nnew = 0;
+        for(int i = 0; i < nfront; i++) {
+            int cur = frontier0[i];
+            unsigned cur_giid = gi ? gi[cur] : ISLAND_NONE;
+            if(li[cur] == local_iid) {
+                if(min_mh > 0) nnew = 0;
+                min_mh = 0;
+                newf[nnew++] = cur;
+                continue;
+            }
+            int nextra = closest_tiles_local(m, layer, chunk, cur, local_iid, cur_giid, tmp, CELLS);
+            if(!nextra) continue;
+            int mh = abs((tmp[0] >> 6) - (cur >> 6)) + abs((tmp[0] & 63) - (cur & 63));
+            if(mh < min_mh) { min_mh = mh; nnew = 0; }
+            if(mh > min_mh) continue;
+            for(int k = 0; k < nextra && nnew < CELLS * 2; k++) newf[nnew++] = tmp[k];
+        }
+        for(int i = 0; i < nnew; i++) {
+            pq_push(&q, 0.0f, newf[i]);
+            integ[newf[i]] = 0.0f;
+        }
     }
 
     /* field_build_integration, field.c:539: Dijkstra, 4-connected (field_neighbours_grid :203
@@ -260,6 +305,110 @@ int no_field_update(const no_map *m, const navhip_field_req *rq, uint8_t *inout_
     }
     if(out_integ) memcpy(out_integ, integ, sizeof(float) * CELLS);
     return 0;
+}
+
+/* field_tile_passable (field.c:117): faction agnostic */
+static bool plain_passable(const no_map *m, int layer, int chunk, int i)
+{
+    size_t k = ((size_t)chunk << 12) + i;
+    if(m->cost[layer][k] == COST_IMPASS) return false;
+    return !(m->blockers[layer] && m->blockers[layer][k] > 0);
+}
+
+/* N_FlowFieldUpdateToNearestPathable (field.c:2247): field_passable_frontier (:1441) BFS through the
+ * non-passable region of `start`, field_build_integration_nonpass (:643), in-place bake of the
+ * tiles with a finite non-zero value */
+static int field_nearest_pathable(const no_map *m, const navhip_field_req *rq, uint8_t *inout_dirs,
+                                  float *out_integ)
+{
+    const int layer = rq->layer, chunk = rq->chunk_r * m->w + rq->chunk_c;
+    const uint8_t *cost = m->cost[layer] + ((size_t)chunk << 12);
+    static __thread float integ[CELLS];
+    static __thread uint8_t visited[CELLS];
+    static __thread int queue[CELLS];
+    for(int i = 0; i < CELLS; i++) integ[i] = INFINITY;
+    memset(visited, 0, sizeof(visited));
+    pq_t q = {0};
+    int head = 0, tail = 0;
+    int start = rq->tile_r * RES + rq->tile_c;
+    queue[tail++] = start;
+    visited[start] = 1;
+    while(head < tail) {
+        int cur = queue[head++];
+        if(plain_passable(m, layer, chunk, cur)) {
+            pq_push(&q, 0.0f, cur);
+            integ[cur] = 0.0f;
+            continue;
+        }
+        static const int d4[4][2] = {{0, -1}, {0, 1}, {-1, 0}, {1, 0}};
+        for(int k = 0; k < 4; k++) {
+            int nr = (cur >> 6) + d4[k][0], nc = (cur & 63) + d4[k][1];
+            if(nr < 0 || nr >= RES || nc < 0 || nc >= RES) continue;     /* tile_outside_region */
+            if(visited[nr * RES + nc]) continue;
+            visited[nr * RES + nc] = 1;
+            queue[tail++] = nr * RES + nc;
+        }
+    }
+    static const int dr4[4] = {-1, 0, 0, 1}, dc4[4] = {0, -1, 1, 0};
+    while(q.n > 0) {
+        int cur = pq_pop(&q);
+        int r = cur >> 6, c = cur & 63;
+        for(int k = 0; k < 4; k++) {
+            int nr = r + dr4[k], nc = c + dc4[k];
+            if(nr < 0 || nr >= RES || nc < 0 || nc >= RES) continue;
+            int ni = nr * RES + nc;
+            if(plain_passable(m, layer, chunk, ni)) continue;
+            float total = integ[cur] + (float)cost[ni];
+            if(total < integ[ni]) {
+                integ[ni] = total;
+                pq_push(&q, total, ni);
+            }
+        }
+    }
+    free(q.a);
+    for(int r = 0; r < RES; r++) {
+    for(int c = 0; c < RES; c++) {
+        float v = integ[r * RES + c];
+        if(v == INFINITY || v == 0.0f) continue;
+        inout_dirs[r * RES + c] = (uint8_t)flow_dir(integ, r, c);
+    }}
+    if(out_integ) memcpy(out_integ, integ, sizeof(float) * CELLS);
+    return 0;
+}
+
+/* field_closest_tiles_local (field.c:1010): BFS over the whole chunk from `target` in Manhattan
+ * order; the qualifying tiles at the first distance where any qualifies */
+static int closest_tiles_local(const no_map *m, int layer, int chunk, int target, unsigned local_iid,
+                               unsigned global_iid, int *out, int maxout)
+{
+    static __thread uint8_t visited[CELLS];
+    static __thread int queue[CELLS];
+    memset(visited, 0, sizeof(visited));
+    const uint16_t *li = m->local_islands[layer] + ((size_t)chunk << 12);
+    const uint16_t *gi = m->islands[layer] ? m->islands[layer] + ((size_t)chunk << 12) : NULL;
+    int head = 0, tail = 0, ret = 0, first = -1;
+    queue[tail++] = target;
+    visited[target] = 1;
+    while(head < tail) {
+        int cur = queue[head++];
+        static const int d4[4][2] = {{0, -1}, {0, 1}, {-1, 0}, {1, 0}};
+        for(int k = 0; k < 4; k++) {
+            int nr = (cur >> 6) + d4[k][0], nc = (cur & 63) + d4[k][1];
+            if(nr < 0 || nr >= RES || nc < 0 || nc >= RES) continue;
+            if(visited[nr * RES + nc]) continue;
+            visited[nr * RES + nc] = 1;
+            queue[tail++] = nr * RES + nc;
+        }
+        int mh = abs((cur >> 6) - (target >> 6)) + abs((cur & 63) - (target & 63));
+        if(first > -1 && mh > first) break;
+        if(!plain_passable(m, layer, chunk, cur)) continue;
+        if(global_iid != ISLAND_NONE && gi && gi[cur] != global_iid) continue;
+        if(local_iid != ISLAND_NONE && li[cur] != local_iid) continue;
+        if(first == -1) first = mh;
+        out[ret++] = cur;
+        if(ret == maxout) break;
+    }
+    return ret;
 }
 
 int no_build_fields(const no_map *m, const navhip_field_req *reqs, int n, uint8_t *inout_dirs,

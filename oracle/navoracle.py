@@ -22,7 +22,7 @@ FIELD_REQ_DTYPE = np.dtype([
     ("port_r0", np.uint8), ("port_c0", np.uint8), ("port_r1", np.uint8), ("port_c1", np.uint8),
     ("next_r0", np.uint8), ("next_c0", np.uint8), ("next_r1", np.uint8), ("next_c1", np.uint8),
     ("next_chunk_r", np.uint16), ("next_chunk_c", np.uint16),
-    ("port_iid", np.uint16), ("next_iid", np.uint16), ("_pad", np.uint16, (2,)),
+    ("port_iid", np.uint16), ("next_iid", np.uint16), ("aux_iid", np.uint16), ("_pad", np.uint16),
 ], align=False)
 
 
@@ -33,7 +33,8 @@ CIRCLE_DTYPE = np.dtype([("x", np.float32), ("z", np.float32), ("radius", np.flo
 class Map(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32),
                 ("cost", C.c_void_p * NLAYERS), ("blockers", C.c_void_p * NLAYERS),
-                ("local_islands", C.c_void_p * NLAYERS), ("factions", C.c_void_p * NLAYERS)]
+                ("local_islands", C.c_void_p * NLAYERS), ("factions", C.c_void_p * NLAYERS),
+                ("islands", C.c_void_p * NLAYERS)]
 
 
 class World(C.Structure):
@@ -139,10 +140,11 @@ class OracleNav:
         self._map.w, self._map.h = self.w, self.h
         self.set_layer(layer, cost, blockers, local_islands, factions)
 
-    def set_layer(self, layer, cost=None, blockers=None, local_islands=None, factions=None):
+    def set_layer(self, layer, cost=None, blockers=None, local_islands=None, factions=None,
+                  islands=None):
         for name, arr, dt in (("cost", cost, np.uint8), ("blockers", blockers, np.uint16),
                               ("local_islands", local_islands, np.uint16),
-                              ("factions", factions, np.uint8)):
+                              ("factions", factions, np.uint8), ("islands", islands, np.uint16)):
             if arr is None:
                 continue
             a = np.ascontiguousarray(arr, dt)

@@ -73,6 +73,8 @@ def lib():
         L.pfref_nav_get_portal.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(Portal)]
         L.pfref_field_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pfref_field_nearest_pathable.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+        L.pfref_field_island_to_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.pfref_field_bench.restype = C.c_double
         L.pfref_field_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.pfref_request_path.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -185,6 +187,23 @@ class RefNav:
         if rc != 0:
             raise ValueError("pfref_field_update: bad request")
         return dirs, integ
+
+    def field_nearest_pathable(self, chunk_r, chunk_c, start_r, start_c, existing, layer=0,
+                               faction_id=FACTION_ID_NONE):
+        """N_FlowFieldUpdateToNearestPathable on a copy of `existing` ([64,64] u8)."""
+        dirs = np.ascontiguousarray(existing, np.uint8).reshape(64, 64).copy()
+        lib().pfref_field_nearest_pathable(self._h, layer, chunk_r, chunk_c, start_r, start_c,
+                                           faction_id, _p(dirs))
+        return dirs
+
+    def field_island_to_nearest(self, req, local_iid, existing):
+        """N_FlowFieldUpdateIslandToNearest(local_iid) on a copy of `existing`, whose target is req."""
+        r = _to_req(req)
+        dirs = np.ascontiguousarray(existing, np.uint8).reshape(64, 64).copy()
+        rc = lib().pfref_field_island_to_nearest(self._h, C.byref(r), int(local_iid), _p(dirs))
+        if rc != 0:
+            raise ValueError("pfref_field_island_to_nearest: bad request")
+        return dirs
 
     def field_bench(self, reqs, reps=1, nthreads=1):
         reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)

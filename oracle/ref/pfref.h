@@ -84,6 +84,12 @@ void pfref_nav_get_portal(const pfref_nav *nav, int layer, int chunk_r, int chun
 int pfref_field_update(pfref_nav *nav, const pfref_field_req *req,
                        uint8_t *inout_dirs, float *out_integ);
 
+/* the repair builds the sampler runs on an existing field (nav.c:3527-3547) */
+int pfref_field_nearest_pathable(pfref_nav *nav, int layer, int chunk_r, int chunk_c, int start_r,
+                                 int start_c, int faction_id, uint8_t *inout_dirs);
+int pfref_field_island_to_nearest(pfref_nav *nav, const pfref_field_req *req, int local_iid,
+                                  uint8_t *inout_dirs);
+
 /* Time `reps` passes of N_FlowFieldInit+N_FlowFieldUpdate over `n` requests on
  * `nthreads` pthreads (requests are independent; nav_private is read-only).
  * Returns seconds of wall time (CLOCK_MONOTONIC). */

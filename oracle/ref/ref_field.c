@@ -145,6 +145,40 @@ int pfref_field_update(pfref_nav *nav, const pfref_field_req *req,
     return 0;
 }
 
+/* N_FlowFieldUpdateToNearestPathable (field.c:2247) on an existing field */
+int pfref_field_nearest_pathable(pfref_nav *nav, int layer, int chunk_r, int chunk_c, int start_r,
+                                 int start_c, int faction_id, uint8_t *inout_dirs)
+{
+    const struct nav_private *priv = pfref_nav_private(nav);
+    struct flow_field ff;
+    memset(&ff, 0, sizeof(ff));
+    pfref_dirs_to_ff(inout_dirs, &ff);
+    ff.chunk = (struct coord){chunk_r, chunk_c};
+    N_FlowFieldUpdateToNearestPathable(priv, layer, (struct coord){chunk_r, chunk_c},
+        (struct coord){start_r, start_c}, faction_id, priv->unit_query_ctx, &ff);
+    pfref_ff_to_dirs(&ff, inout_dirs);
+    return 0;
+}
+
+/* N_FlowFieldUpdateIslandToNearest (field.c:2307) on an existing field whose target is `req` */
+int pfref_field_island_to_nearest(pfref_nav *nav, const pfref_field_req *req, int local_iid,
+                                  uint8_t *inout_dirs)
+{
+    const struct nav_private *priv = pfref_nav_private(nav);
+    struct field_target target;
+    if(!pfref_make_target(priv, req, &target))
+        return -1;
+    struct flow_field ff;
+    memset(&ff, 0, sizeof(ff));
+    pfref_dirs_to_ff(inout_dirs, &ff);
+    ff.chunk = (struct coord){req->chunk_r, req->chunk_c};
+    ff.target = target;
+    N_FlowFieldUpdateIslandToNearest((uint16_t)local_iid, priv, req->layer, req->faction_id,
+        priv->unit_query_ctx, &ff);
+    pfref_ff_to_dirs(&ff, inout_dirs);
+    return 0;
+}
+
 struct bench_arg{
     const struct nav_private *priv;
     const pfref_field_req    *reqs;

@@ -35,6 +35,7 @@ __device__ __forceinline__ bool req_uses_bfs(const nh_map_view &map, const navhi
 {
     if(force_generic) return false;
     if(rq.faction_id != NAVHIP_FACTION_ID_NONE) return false;
+    if(rq.type == NAVHIP_TARGET_NEAREST_PATHABLE || (rq.flags & NAVHIP_REQ_ISLAND_NEAREST)) return false;
     const nh_layer_view &L = map.layers[rq.layer];
     return L.unit_cost[(int)rq.chunk_r * map.w + rq.chunk_c] != 0;
 }
@@ -358,6 +359,9 @@ __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const na
 {
     __shared__ uint32_t dist[NH_CELLS];                                   // 16 KB
     __shared__ __attribute__((aligned(16))) uint8_t pc[NH_CELLS];         // cost, 0xff = not passable
+    __shared__ uint8_t raw[NH_CELLS];      // cost_base as stored
+    __shared__ uint8_t fl[NH_CELLS];       // bit0 field_tile_passable (faction agnostic), bit1 region
+    __shared__ int s_list[128], s_dmin[128], s_nlist, s_D;
 
     const int t = threadIdx.x;
     const int ri = blockIdx.x;
@@ -369,6 +373,10 @@ __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const na
     const nh_layer_view &L = map.layers[rq.layer];
     const size_t cbase = (size_t)((int)rq.chunk_r * map.w + rq.chunk_c) << 12;
     const bool faction = rq.faction_id != NAVHIP_FACTION_ID_NONE;
+    // repair builds: N_FlowFieldUpdateToNearestPathable (field.c:2247) and
+    // N_FlowFieldUpdateIslandToNearest (field.c:2307); both work on an existing field
+    const bool modeA = rq.type == NAVHIP_TARGET_NEAREST_PATHABLE;
+    const bool modeB = !modeA && (rq.flags & NAVHIP_REQ_ISLAND_NEAREST) != 0;
 
     // ---- stage cost + passability: cell index i = k*256 + t (conflict-free LDS layout) --------
 #pragma unroll 4
@@ -393,54 +401,172 @@ __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const na
             passable = enemies_only || (blk == 0);
         }
         pc[i] = passable ? (uint8_t)cst : (uint8_t)NAVHIP_COST_IMPASSABLE;
+        raw[i] = (uint8_t)cst;
+        fl[i] = (cst != NAVHIP_COST_IMPASSABLE && blk == 0) ? 1 : 0;
         dist[i] = NH_INF_U32;
     }
+    if(t == 0) { s_nlist = 0; s_D = 0x7fffffff; }
+    if(t < 128) s_dmin[t] = 0x7fffffff;
     __syncthreads();
 
-    // ---- seeds -------------------------------------------------------------------------------
-    if(rq.type == NAVHIP_TARGET_TILE) {
-        if(t == 0) {
-            int i = rq.tile_r * 64 + rq.tile_c;
-            if(pc[i] != NAVHIP_COST_IMPASSABLE) dist[i] = 0;
+    if(modeA) {
+        // ---- field_passable_frontier (field.c:1441): flood the NON-passable 4-connected region of
+        // the start tile; the passable tiles bordering it are the frontier
+        const int start = rq.tile_r * 64 + rq.tile_c;
+        if(t == 0) fl[start] |= 2;
+        __syncthreads();
+        if(!(fl[start] & 1)) {
+            for(;;) {
+                int changed = 0;
+#pragma unroll 4
+                for(int k = 0; k < 16; k++) {
+                    int i = k * 256 + t;
+                    if(fl[i] & 3) continue;                 // passable, or already in the region
+                    int r = i >> 6, c = i & 63;
+                    bool nb = (r > 0 && (fl[i - 64] & 2)) || (r < 63 && (fl[i + 64] & 2))
+                           || (c > 0 && (fl[i - 1] & 2)) || (c < 63 && (fl[i + 1] & 2));
+                    if(nb) { fl[i] |= 2; changed = 1; }
+                }
+                if(!__syncthreads_or(changed)) break;
+            }
+#pragma unroll 4
+            for(int k = 0; k < 16; k++) {
+                int i = k * 256 + t;
+                if(!(fl[i] & 1)) continue;
+                int r = i >> 6, c = i & 63;
+                bool nb = (r > 0 && (fl[i - 64] & 2)) || (r < 63 && (fl[i + 64] & 2))
+                       || (c > 0 && (fl[i - 1] & 2)) || (c < 63 && (fl[i + 1] & 2));
+                if(nb) dist[i] = 0;
+            }
+        }else if(t == 0) {
+            dist[start] = 0;                                // a passable start is its own frontier
+        }
+        __syncthreads();
+        // ---- field_build_integration_nonpass (field.c:643): relax only NON-passable tiles, step
+        // cost = cost_base of the tile entered
+        for(;;) {
+            int changed = 0;
+#pragma unroll 4
+            for(int k = 0; k < 16; k++) {
+                int i = k * 256 + t;
+                if(fl[i] & 1) continue;
+                int r = i >> 6, c = i & 63;
+                uint32_t m = NH_INF_U32;
+                if(r > 0)  m = min(m, dist[i - 64]);
+                if(r < 63) m = min(m, dist[i + 64]);
+                if(c > 0)  m = min(m, dist[i - 1]);
+                if(c < 63) m = min(m, dist[i + 1]);
+                if(m < NH_INF_U32) {
+                    uint32_t nd = m + raw[i];
+                    if(nd < dist[i]) { dist[i] = nd; changed = 1; }
+                }
+            }
+            if(!__syncthreads_or(changed)) break;
         }
     }else{
-        int nr = rq.port_r1 - rq.port_r0 + 1, nc = rq.port_c1 - rq.port_c0 + 1;
-        for(int j = t; j < nr * nc; j += 256) {
-            int r = rq.port_r0 + j / nc, c = rq.port_c0 + j % nc;
-            if(portal_seed(map, rq, r, c, pc[r * 64 + c] != NAVHIP_COST_IMPASSABLE))
-                dist[r * 64 + c] = 0;
-        }
-    }
-    __syncthreads();
-
-    // ---- chaotic (in-place) min-plus relaxation to the fixpoint ------------------------------
-    // d[x] = min(d[x], min_{4-nbrs y} d[y] + cost[x]) for passable x.  Values only decrease and
-    // never drop below the true shortest distance, so the fixpoint is the Dijkstra result of
-    // field_build_integration bit for bit; an iteration in which no thread lowered anything
-    // proves every read saw final values.
-    for(;;) {
-        int changed = 0;
-#pragma unroll 4
-        for(int k = 0; k < 16; k++) {
-            int i = k * 256 + t;
-            uint32_t cst = pc[i];
-            if(cst == NAVHIP_COST_IMPASSABLE) continue;
-            int r = i >> 6, c = i & 63;
-            uint32_t m = NH_INF_U32;
-            if(r > 0)  m = min(m, dist[i - 64]);
-            if(r < 63) m = min(m, dist[i + 64]);
-            if(c > 0)  m = min(m, dist[i - 1]);
-            if(c < 63) m = min(m, dist[i + 1]);
-            if(m < NH_INF_U32) {
-                uint32_t nd = m + cst;
-                if(nd < dist[i]) { dist[i] = nd; changed = 1; }
+        // ---- seeds (field_initial_frontier, field.c:1372); for the island repair they only form
+        // the frontier from which the nearest island tiles are looked up
+        if(rq.type == NAVHIP_TARGET_TILE) {
+            if(t == 0) {
+                int i = rq.tile_r * 64 + rq.tile_c;
+                if(pc[i] != NAVHIP_COST_IMPASSABLE) {
+                    if(modeB) s_list[s_nlist++] = i; else dist[i] = 0;
+                }
+            }
+        }else{
+            int nr = rq.port_r1 - rq.port_r0 + 1, nc = rq.port_c1 - rq.port_c0 + 1;
+            for(int j = t; j < nr * nc; j += 256) {
+                int r = rq.port_r0 + j / nc, c = rq.port_c0 + j % nc;
+                if(portal_seed(map, rq, r, c, pc[r * 64 + c] != NAVHIP_COST_IMPASSABLE)) {
+                    if(modeB) { int p = atomicAdd(&s_nlist, 1); if(p < 128) s_list[p] = r * 64 + c; }
+                    else dist[r * 64 + c] = 0;
+                }
             }
         }
-        if(!__syncthreads_or(changed)) break;
+        __syncthreads();
+        if(modeB) {
+            // completely blocked target: retry ignoring blockers (field.c:2352-2355; only the tile
+            // frontier honours ignoreblock, field.c:1112-1115)
+            if(t == 0 && s_nlist == 0 && rq.type == NAVHIP_TARGET_TILE)
+                s_list[s_nlist++] = rq.tile_r * 64 + rq.tile_c;
+            __syncthreads();
+            const int nl = min(s_nlist, 128);
+            const uint16_t *li = L.local_islands + cbase;
+            const uint16_t *gi = L.islands ? L.islands + cbase : nullptr;
+            const uint32_t want = rq.aux_iid;
+            // field_closest_tiles_local (field.c:1010) for every frontier tile: the qualifying tiles
+            // (passable, unblocked, local island `want`, same global island as the frontier tile) at
+            // the minimum Manhattan distance
+            for(int q = 0; q < nl; q++) {
+                const int f = s_list[q], fr = f >> 6, fc = f & 63;
+                const uint32_t giid = gi ? gi[f] : NAVHIP_ISLAND_NONE;
+                int best = 0x7fffffff;
+#pragma unroll 4
+                for(int k = 0; k < 16; k++) {
+                    int i = k * 256 + t;
+                    if(!(fl[i] & 1)) continue;
+                    if(want != NAVHIP_ISLAND_NONE && li[i] != want) continue;
+                    if(giid != NAVHIP_ISLAND_NONE && gi[i] != giid) continue;
+                    int d = abs((i >> 6) - fr) + abs((i & 63) - fc);
+                    best = min(best, d);
+                }
+                if(best < 0x7fffffff) atomicMin(&s_dmin[q], best);
+            }
+            __syncthreads();
+            if(t == 0) {
+                int D = 0x7fffffff;
+                for(int q = 0; q < nl; q++) D = min(D, s_dmin[q]);
+                s_D = D;
+            }
+            __syncthreads();
+            const int D = s_D;
+            if(D < 0x7fffffff) {
+                for(int q = 0; q < nl; q++) {
+                    if(s_dmin[q] != D) continue;
+                    const int f = s_list[q], fr = f >> 6, fc = f & 63;
+                    const uint32_t giid = gi ? gi[f] : NAVHIP_ISLAND_NONE;
+#pragma unroll 4
+                    for(int k = 0; k < 16; k++) {
+                        int i = k * 256 + t;
+                        if(!(fl[i] & 1)) continue;
+                        if(want != NAVHIP_ISLAND_NONE && li[i] != want) continue;
+                        if(giid != NAVHIP_ISLAND_NONE && gi[i] != giid) continue;
+                        if(abs((i >> 6) - fr) + abs((i & 63) - fc) == D) dist[i] = 0;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- chaotic (in-place) min-plus relaxation to the fixpoint --------------------------
+        // d[x] = min(d[x], min_{4-nbrs y} d[y] + cost[x]) for passable x.  Values only decrease and
+        // never drop below the true shortest distance, so the fixpoint is the Dijkstra result of
+        // field_build_integration bit for bit; an iteration in which no thread lowered anything
+        // proves every read saw final values.
+        for(;;) {
+            int changed = 0;
+#pragma unroll 4
+            for(int k = 0; k < 16; k++) {
+                int i = k * 256 + t;
+                uint32_t cst = pc[i];
+                if(cst == NAVHIP_COST_IMPASSABLE) continue;
+                int r = i >> 6, c = i & 63;
+                uint32_t m = NH_INF_U32;
+                if(r > 0)  m = min(m, dist[i - 64]);
+                if(r < 63) m = min(m, dist[i + 64]);
+                if(c > 0)  m = min(m, dist[i - 1]);
+                if(c < 63) m = min(m, dist[i + 1]);
+                if(m < NH_INF_U32) {
+                    uint32_t nd = m + cst;
+                    if(nd < dist[i]) { dist[i] = nd; changed = 1; }
+                }
+            }
+            if(!__syncthreads_or(changed)) break;
+        }
     }
 
     // ---- bake (field_flow_dir, field.c:355-433) + fixup; result staged in pc[] ----------------
-    const bool inout = (rq.flags & NAVHIP_REQ_INOUT) != 0;
+    const bool inout = (rq.flags & NAVHIP_REQ_INOUT) != 0 || modeA || modeB;
     uint8_t *out = dirs + ((size_t)ri << 12);
     const uint32_t fixdir = (rq.type == NAVHIP_TARGET_PORTAL) ? portal_fix_dir(rq) : NAVHIP_FD_NONE;
     uint8_t res[16];
@@ -453,7 +579,7 @@ __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const na
         if(d >= NH_INF_U32) {
             dir = inout ? out[i] : NAVHIP_FD_NONE;
         }else if(d == 0) {
-            dir = fixdir;
+            dir = modeA ? out[i] : fixdir;           // field.c:2297: frontier tiles are left alone
         }else{
             const uint32_t I = NH_INF_U32;
             uint32_t dn = r > 0  ? dist[i - 64] : I, ds = r < 63 ? dist[i + 64] : I;
@@ -496,7 +622,7 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         const navhip_layer &L = ctx->layers[l];
         mv.layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
-                                     L.passmask, L.unit_cost, L.changed};
+                                     L.passmask, L.unit_cost, L.changed, L.islands};
     }
     const int force_generic = ctx->field_kernel_mode == 1;
     if(!force_generic) {

@@ -39,6 +39,7 @@ static size_t plane_elem_bytes(int plane)
     case NAVHIP_PLANE_BLOCKERS:      return 2;
     case NAVHIP_PLANE_LOCAL_ISLANDS: return 2;
     case NAVHIP_PLANE_FACTIONS:      return NAVHIP_MAX_FACTIONS;
+    case NAVHIP_PLANE_ISLANDS:       return 2;
     default: return 0;
     }
 }
@@ -50,6 +51,7 @@ static void **plane_slot(navhip_layer &L, int plane)
     case NAVHIP_PLANE_BLOCKERS:      return (void**)&L.blockers;
     case NAVHIP_PLANE_LOCAL_ISLANDS: return (void**)&L.local_islands;
     case NAVHIP_PLANE_FACTIONS:      return (void**)&L.factions;
+    case NAVHIP_PLANE_ISLANDS:       return (void**)&L.islands;
     default: return nullptr;
     }
 }
@@ -111,6 +113,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         navhip_layer &L = ctx->layers[l];
         hipFree(L.cost); hipFree(L.blockers); hipFree(L.local_islands); hipFree(L.factions);
+        hipFree(L.islands);
         hipFree(L.passmask); hipFree(L.unit_cost); hipFree(L.touched); hipFree(L.changed);
         free(L.dirty);
     }
@@ -357,8 +360,9 @@ static int validate_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
     for(int i = 0; i < n; i++) {
         const navhip_field_req &r = reqs[i];
         bool ok = r.layer < NAVHIP_NAV_LAYER_MAX && r.chunk_r < ctx->h && r.chunk_c < ctx->w
-               && (r.type == NAVHIP_TARGET_TILE || r.type == NAVHIP_TARGET_PORTAL);
-        if(ok && r.type == NAVHIP_TARGET_TILE)
+               && (r.type == NAVHIP_TARGET_TILE || r.type == NAVHIP_TARGET_PORTAL
+                || r.type == NAVHIP_TARGET_NEAREST_PATHABLE);
+        if(ok && r.type != NAVHIP_TARGET_PORTAL)
             ok = r.tile_r < 64 && r.tile_c < 64;
         if(ok && r.type == NAVHIP_TARGET_PORTAL)
             ok = r.port_r0 <= r.port_r1 && r.port_r1 < 64 && r.port_c0 <= r.port_c1 && r.port_c1 < 64
@@ -370,6 +374,7 @@ static int validate_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
         }
         const navhip_layer &L = ctx->layers[r.layer];
         if(!L.cost || (r.type == NAVHIP_TARGET_PORTAL && !L.local_islands)
+        || ((r.flags & NAVHIP_REQ_ISLAND_NEAREST) && (!L.local_islands || !L.islands))
         || (r.faction_id != NAVHIP_FACTION_ID_NONE && !L.factions && L.blockers)) {
             ctx->last_error = "navhip_build_fields: request " + std::to_string(i)
                             + " needs a plane that was never uploaded";
@@ -415,7 +420,8 @@ int navhip_build_fields(navhip_ctx *ctx, const navhip_field_req *reqs, int n,
                                hipMemcpyHostToDevice, s));
     bool any_inout = false;
     for(int i = 0; i < n; i++)      // skipped (IF_CHANGED) slots must come back unchanged too
-        any_inout |= (reqs[i].flags & (NAVHIP_REQ_INOUT | NAVHIP_REQ_IF_CHANGED)) != 0;
+        any_inout |= (reqs[i].flags & (NAVHIP_REQ_INOUT | NAVHIP_REQ_IF_CHANGED | NAVHIP_REQ_ISLAND_NEAREST)) != 0
+                  || reqs[i].type == NAVHIP_TARGET_NEAREST_PATHABLE;
     if(any_inout)
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_dirs, inout_dirs, (size_t)n * NH_CELLS,
                                    hipMemcpyHostToDevice, s));
@@ -461,7 +467,7 @@ static void fill_map_view(const navhip_ctx *ctx, nh_map_view *mv)
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         const navhip_layer &L = ctx->layers[l];
         mv->layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
-                                      L.passmask, L.unit_cost, L.changed};
+                                      L.passmask, L.unit_cost, L.changed, L.islands};
     }
 }
 

@@ -16,6 +16,7 @@ struct navhip_layer {
     uint16_t *blockers;        // [nchunks][64][64]
     uint16_t *local_islands;   // [nchunks][64][64]
     uint8_t  *factions;        // [nchunks][15][64][64]
+    uint16_t *islands;         // [nchunks][64][64]  global island ids (ISLAND_NEAREST repair only)
     // derived (rebuilt lazily for dirty chunks):
     uint64_t *passmask;        // [nchunks][64]  bit c of word r = cell (r,c) passable, faction NONE
                                //                (field_tile_passable, field.c:117)
@@ -69,6 +70,7 @@ struct nh_layer_view {
     const uint64_t *passmask;
     const uint8_t  *unit_cost;
     const uint8_t  *changed;
+    const uint16_t *islands;
 };
 struct nh_map_view {
     int w, h;

@@ -22,9 +22,9 @@ FIELD_CELLS = 4096
 COST_IMPASSABLE = 0xFF
 ISLAND_NONE = 0xFFFF
 FACTION_ID_NONE = 0xF
-TARGET_PORTAL, TARGET_TILE = 0, 1
-PLANE_COST_BASE, PLANE_BLOCKERS, PLANE_LOCAL_ISLANDS, PLANE_FACTIONS = 0, 1, 2, 3
-REQ_INOUT, REQ_IF_CHANGED, REQ_LIVE_IIDS = 0x1, 0x2, 0x4
+TARGET_PORTAL, TARGET_TILE, TARGET_NEAREST_PATHABLE = 0, 1, 2
+PLANE_COST_BASE, PLANE_BLOCKERS, PLANE_LOCAL_ISLANDS, PLANE_FACTIONS, PLANE_ISLANDS = 0, 1, 2, 3, 4
+REQ_INOUT, REQ_IF_CHANGED, REQ_LIVE_IIDS, REQ_ISLAND_NEAREST = 0x1, 0x2, 0x4, 0x8
 FD_NONE, FD_NW, FD_N, FD_NE, FD_W, FD_E, FD_SW, FD_S, FD_SE = range(9)
 
 # navhip_field_req, include/navhip.h (32 bytes)
@@ -35,7 +35,7 @@ FIELD_REQ_DTYPE = np.dtype([
     ("port_r0", np.uint8), ("port_c0", np.uint8), ("port_r1", np.uint8), ("port_c1", np.uint8),
     ("next_r0", np.uint8), ("next_c0", np.uint8), ("next_r1", np.uint8), ("next_c1", np.uint8),
     ("next_chunk_r", np.uint16), ("next_chunk_c", np.uint16),
-    ("port_iid", np.uint16), ("next_iid", np.uint16), ("_pad", np.uint16, (2,)),
+    ("port_iid", np.uint16), ("next_iid", np.uint16), ("aux_iid", np.uint16), ("_pad", np.uint16),
 ], align=False)
 assert FIELD_REQ_DTYPE.itemsize == 32
 

@@ -52,3 +52,24 @@ def test_fields_with_blockers(navlib, mode):
     reqs = np.concatenate([reqs_t, reqs_p])
     before = np.concatenate([np.zeros((len(reqs_t), 64, 64), np.uint8), before])
     _check(navlib, grid, nav, reqs, before, mode)
+
+
+@pytest.mark.parametrize("seed", [3, 8])
+def test_repair_builds_match_reference(navlib, seed):
+    """N_FlowFieldUpdateToNearestPathable (field.c:2247) and N_FlowFieldUpdateIslandToNearest
+    (field.c:2307): the in-place repairs the sampler runs for agents on blocked / orphaned tiles."""
+    from tests.test_oracle_cpu import repair_cases, repair_reqs_to
+    from oracle import pfref
+    grid = cases.synth.cost_grid(3, 3, seed=40 + seed, frac_impassable=0.3)
+    blk = cases.random_blockers(grid, seed=seed, frac=0.06)
+    grid, nav = cases.ref_nav_for(3, 3, seed=40 + seed, blockers=blk, frac=0.3)
+    reqs, exist, exp = repair_cases(nav, grid, seed)
+    ctx = navlib.NavContext(3, 3)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(0))
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(1))
+    ctx.upload_plane(0, navlib.PLANE_LOCAL_ISLANDS, nav.plane(3))
+    ctx.upload_plane(0, navlib.PLANE_ISLANDS, nav.plane(pfref.PLANE_ISLANDS))
+    got, _ = ctx.N_FlowFieldUpdate(repair_reqs_to(navlib.FIELD_REQ_DTYPE, reqs), inout=exist)
+    bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exp[i])]
+    assert not bad, "repair builds differ: %s" % [(i, int(reqs[i][0]["type"]), reqs[i][1]) for i in bad[:6]]
+    ctx.close()

@@ -266,3 +266,73 @@ def test_formation_arms_restatement_matches_reference():
     out2 = cases.oracle_nav_from_ref(nav).agent_step(arrays)
     assert ((out2["status"] & 0x80) != 0).sum() == np.isin(world["state"], (1, 8)).sum()
     pfref.RefMove.unload()
+
+
+# ---------------------------------------------------------------------------------------------
+# repair builds: N_FlowFieldUpdateToNearestPathable / N_FlowFieldUpdateIslandToNearest
+# ---------------------------------------------------------------------------------------------
+def repair_cases(nav, grid, seed, n_each=10):
+    """(requests, existing fields, expected fields from the reference) for both repair builds on a
+    map with blockers: existing fields are real planner fields of the chunk."""
+    rng = np.random.RandomState(seed)
+    h, w = grid.shape[0] // 64, grid.shape[1] // 64
+    cost = nav.plane(pfref.PLANE_COST)
+    blk = nav.plane(pfref.PLANE_BLOCKERS)
+    li = nav.plane(pfref.PLANE_LOCAL_ISLANDS)
+    base_reqs, before, after = cases.planner_requests(nav, grid, pairs=14, seed=seed)
+    reqs, exist, exp = [], [], []
+    # (A) start tiles that are impassable or blocked
+    bad = np.argwhere((cost == 255) | (blk > 0))
+    for k in rng.choice(len(bad), n_each, replace=False):
+        cr, cc, r, c = (int(x) for x in bad[k])
+        pick = np.flatnonzero((base_reqs["chunk_r"] == cr) & (base_reqs["chunk_c"] == cc))
+        existing = after[pick[0]] if len(pick) else rng.randint(0, 9, (64, 64)).astype(np.uint8)
+        rq = np.zeros(1, pfref.FIELD_REQ_DTYPE)[0]
+        rq["type"], rq["chunk_r"], rq["chunk_c"], rq["tile_r"], rq["tile_c"] = 2, cr, cc, r, c
+        rq["faction_id"] = 15
+        reqs.append((rq, 0, 0))
+        exist.append(existing)
+        exp.append(nav.field_nearest_pathable(cr, cc, r, c, existing))
+    # (B) move the frontier of real planner fields to every local island of their chunk
+    order = rng.permutation(len(base_reqs))
+    nb = 0
+    for k in order:
+        rq = base_reqs[k]
+        ids = np.unique(li[rq["chunk_r"], rq["chunk_c"]])
+        ids = ids[ids != 0xFFFF]
+        for iid in ids[:3]:
+            reqs.append((rq.copy(), 8, int(iid)))
+            exist.append(after[k])
+            exp.append(nav.field_island_to_nearest(rq, int(iid), after[k]))
+            nb += 1
+        if nb >= 2 * n_each:
+            break
+    return reqs, np.stack(exist), np.stack(exp)
+
+
+def repair_reqs_to(dtype, reqs):
+    out = np.zeros(len(reqs), dtype)
+    for i, (rq, flag, iid) in enumerate(reqs):
+        for name in ("layer", "type", "faction_id", "chunk_r", "chunk_c", "tile_r", "tile_c",
+                     "port_r0", "port_c0", "port_r1", "port_c1", "next_r0", "next_c0", "next_r1",
+                     "next_c1", "next_chunk_r", "next_chunk_c", "port_iid", "next_iid"):
+            out[name][i] = rq[name]
+        out["flags"][i] = flag
+        out["aux_iid"][i] = iid
+    return out
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [3, 8])
+def test_repair_builds_restatement_matches_reference(seed):
+    grid = cases.synth.cost_grid(3, 3, seed=40 + seed, frac_impassable=0.3)
+    blk = cases.random_blockers(grid, seed=seed, frac=0.06)
+    grid, nav = cases.ref_nav_for(3, 3, seed=40 + seed, blockers=blk, frac=0.3)
+    reqs, exist, exp = repair_cases(nav, grid, seed)
+    onav = cases.oracle_nav_from_ref(nav)
+    onav.set_layer(0, islands=nav.plane(pfref.PLANE_ISLANDS))
+    got, _ = onav.build_fields(repair_reqs_to(navoracle.FIELD_REQ_DTYPE, reqs), inout=exist)
+    bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exp[i])]
+    assert not bad, "repair builds differ: %s" % [(i, int(reqs[i][0]["type"]), reqs[i][1]) for i in bad[:6]]
+    changed = sum(int(not np.array_equal(exp[i], exist[i])) for i in range(len(reqs)))
+    assert changed > len(reqs) // 3            # the repairs really rewrote something
