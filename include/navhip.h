@@ -184,6 +184,34 @@ int  navhip_build_fields(navhip_ctx *ctx, const navhip_field_req *reqs, int n,
 int  navhip_build_fields_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, int n,
                              uint8_t *dev_inout_dirs, float *dev_out_integ, void *stream);
 
+/* ---- line-of-sight fields ------------------------------------------------- */
+
+/* One N_LOSFieldCreate(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los) call
+ * (field.c:2085).  16 bytes.  layer / faction_id are N_DestLayer(id) / N_DestFactionID(id)
+ * (nav.c:5052,5057); prev_dr/prev_dc = prev_los->chunk - chunk_coord (0,0: the destination
+ * chunk, no previous field). */
+typedef struct navhip_los_req {
+    uint8_t  layer, faction_id;
+    uint16_t enemies;                       /* enemy_faction_from(faction_id), field.c:153 */
+    uint16_t chunk_r, chunk_c;
+    uint16_t target_chunk_r, target_chunk_c;
+    uint8_t  target_tile_r, target_tile_c;
+    int8_t   prev_dr, prev_dc;
+} navhip_los_req;
+
+/* Build n LOS fields.  A field is 4096 bytes, one per tile, row-major [64][64]:
+ * bit 0 = visible, bit 1 = wavefront_blocked (struct LOS_field, field.h:48-54).
+ *   prev_fields  host, n * 4096 bytes (slot i = prev_los of request i; ignored for requests
+ *                without a previous field) or NULL when no request has one
+ *   out_fields   host, n * 4096 bytes
+ * Bit-exact with the reference, including the pop order of its binary heap (pqueue.h). */
+int  navhip_build_los(navhip_ctx *ctx, const navhip_los_req *reqs, int n,
+                      const uint8_t *prev_fields, uint8_t *out_fields,
+                      float map_pos_x, float map_pos_z);
+int  navhip_build_los_dev(navhip_ctx *ctx, const navhip_los_req *dev_reqs, int n,
+                          const uint8_t *dev_prev_fields, uint8_t *dev_out_fields,
+                          float map_pos_x, float map_pos_z, void *stream);
+
 /* N_FlowFieldID (field.c:1952) for TILE / PORTAL targets: the 64-bit cache key the reference's
  * fieldcache uses; pure bit packing, host side. */
 uint64_t navhip_flow_field_id(const navhip_field_req *req);

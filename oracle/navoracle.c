@@ -448,6 +448,181 @@ static v2 vtrunc(v2 a, float max_len)
 #define EPS (1.0 / 1024)      /* clearpath.c:76, collision.c EPSILON */
 
 /* ===========================================================================================
+ * line-of-sight fields: N_LOSFieldCreate (field.c:2085)
+ * =========================================================================================== */
+
+/* the reference's binary heap, lib/public/pqueue.h: 1-based nodes, strict comparisons, push sifts
+ * the new node up past parents with a LARGER priority only (:150-171), pop moves the last node to
+ * the root and sifts the hole down preferring the left child on ties (:112-133,173-183).  The LOS
+ * wavefront depends on this exact pop order among equal priorities. */
+typedef struct { float prio; int cell; } rpq_node;
+typedef struct { rpq_node nodes[CELLS * 2 + 2]; int size; } rpq_t;
+
+static void rpq_push(rpq_t *q, float prio, int cell)
+{
+    int curr = q->size + 1, parent = curr / 2;
+    while(curr > 1 && q->nodes[parent].prio > prio) {
+        q->nodes[curr] = q->nodes[parent];
+        curr = parent;
+        parent = parent / 2;
+    }
+    q->nodes[curr].prio = prio;
+    q->nodes[curr].cell = cell;
+    q->size++;
+}
+
+static int rpq_pop(rpq_t *q)
+{
+    int out = q->nodes[1].cell;
+    q->nodes[1] = q->nodes[q->size--];
+    int root = 1;
+    while(root != q->size + 1) {
+        int target = q->size + 1, l = root * 2, r = l + 1;
+        if(l <= q->size && q->nodes[l].prio < q->nodes[target].prio) target = l;
+        if(r <= q->size && q->nodes[r].prio < q->nodes[target].prio) target = r;
+        q->nodes[root] = q->nodes[target];
+        root = target;
+    }
+    return out;
+}
+
+static bool rpq_contains(const rpq_t *q, int cell)
+{
+    for(int i = 1; i <= q->size; i++)
+        if(q->nodes[i].cell == cell) return true;
+    return false;
+}
+
+/* field_create_wavefront_blocked_line, field.c:463 */
+static void los_blocked_line(const navhip_los_req *rq, float map_x, float map_z, int corner_r,
+                             int corner_c, uint8_t *los)
+{
+    float tbx = map_x - rq->target_chunk_c * 256 - rq->target_tile_c * 4;
+    float tbz = map_z + rq->target_chunk_r * 256 + rq->target_tile_r * 4;
+    float cbx = map_x - rq->chunk_c * 256 - corner_c * 4;
+    float cbz = map_z + rq->chunk_r * 256 + corner_r * 4;
+    float bw = 4, bh = 4;
+    v2 target_center = mkv(tbx - bw / 2.0f, tbz + bh / 2.0f);
+    v2 corner_center = mkv(cbx - bw / 2.0f, cbz + bh / 2.0f);
+    v2 slope = vnormal(vsub(target_center, corner_center));
+    int dx = abs((int)(slope.x * 1000));
+    int dy = -abs((int)(slope.z * 1000));
+    int sx = slope.x > 0.0f ? 1 : -1;
+    int sy = slope.z < 0.0f ? 1 : -1;
+    int err = dx + dy, e2;
+    int r = corner_r, c = corner_c;
+    do {
+        los[r * RES + c] |= 2;
+        e2 = 2 * err;
+        if(e2 >= dy) { err += dy; c += sx; }
+        if(e2 <= dx) { err += dx; r += sy; }
+    } while(r >= 0 && r < RES && c >= 0 && c < RES);
+}
+
+/* N_LOSFieldCreate, field.c:2085.  prev / out: 4096 bytes, bit 0 visible, bit 1 wavefront_blocked. */
+int no_los_field(const no_map *m, const navhip_los_req *rq, const uint8_t *prev, uint8_t *out,
+                 float map_x, float map_z)
+{
+    if(rq->layer >= NLAYERS || !m->cost[rq->layer]) return -1;
+    const int layer = rq->layer, chunk = rq->chunk_r * m->w + rq->chunk_c;
+    const uint8_t *cost = m->cost[layer] + ((size_t)chunk << 12);
+    const uint16_t *bl = m->blockers[layer] ? m->blockers[layer] + ((size_t)chunk << 12) : NULL;
+    static __thread float integ[CELLS];
+    static __thread rpq_t q;
+    q.size = 0;
+    memset(out, 0, CELLS);
+    for(int i = 0; i < CELLS; i++) integ[i] = INFINITY;
+
+    if(rq->prev_dr == 0 && rq->prev_dc == 0) {                /* case 1: the destination chunk */
+        int t = rq->target_tile_r * RES + rq->target_tile_c;
+        rpq_push(&q, 0.0f, t);
+        integ[t] = 0.0f;
+    }else{                                                    /* case 2: carry the shared edge */
+        if(!prev) return -1;
+        bool horizontal;
+        int curr_edge, prev_edge;
+        if(rq->prev_dr < 0)      { horizontal = false; curr_edge = 0;       prev_edge = RES - 1; }
+        else if(rq->prev_dr > 0) { horizontal = false; curr_edge = RES - 1; prev_edge = 0; }
+        else if(rq->prev_dc < 0) { horizontal = true;  curr_edge = 0;       prev_edge = RES - 1; }
+        else                     { horizontal = true;  curr_edge = RES - 1; prev_edge = 0; }
+        for(int k = 0; k < RES; k++) {
+            int ci = horizontal ? k * RES + curr_edge : curr_edge * RES + k;
+            int pi = horizontal ? k * RES + prev_edge : prev_edge * RES + k;
+            out[ci] = prev[pi] & 3;
+            if(out[ci] & 2)
+                los_blocked_line(rq, map_x, map_z, ci >> 6, ci & 63, out);
+            if(out[ci] & 1) {
+                rpq_push(&q, 0.0f, ci);
+                integ[ci] = 0.0f;
+            }
+        }
+    }
+
+    while(q.size > 0) {
+        int cur = rpq_pop(&q);
+        int r = cur >> 6, c = cur & 63;
+        /* field_neighbours_grid_los, field.c:304 */
+        int nb[4], ncost[4], nn = 0;
+        for(int dr = -1; dr <= 1; dr++) {
+        for(int dc = -1; dc <= 1; dc++) {
+            int ar = r + dr, ac = c + dc;
+            if(ar < 0 || ar >= RES || ac < 0 || ac >= RES) continue;
+            if(dr == 0 && dc == 0) continue;
+            if(dr == dc || dr == -dc) continue;
+            if(out[ar * RES + ac] & 2) continue;
+            nb[nn] = ar * RES + ac;
+            ncost[nn] = cost[ar * RES + ac];
+            if(!tile_passable(m, layer, chunk, ar, ac, rq->faction_id, rq->enemies))
+                ncost[nn] = COST_IMPASS;
+            nn++;
+        }}
+        for(int i = 0; i < nn; i++) {
+            int ni = nb[i], nr = ni >> 6, nc = ni & 63;
+            if(ncost[i] > 1) {
+                /* field_is_los_corner, field.c:435 */
+                bool corner = false;
+#define RAWBLK(rr, cc) (cost[(rr) * RES + (cc)] == COST_IMPASS || (bl && bl[(rr) * RES + (cc)] > 0))
+                if(nr > 0 && nr < RES - 1 && (RAWBLK(nr - 1, nc) ^ RAWBLK(nr + 1, nc))) corner = true;
+                if(!corner && nc > 0 && nc < RES - 1 && (RAWBLK(nr, nc - 1) ^ RAWBLK(nr, nc + 1))) corner = true;
+#undef RAWBLK
+                if(!corner) continue;
+                los_blocked_line(rq, map_x, map_z, nr, nc, out);
+            }else{
+                float new_cost = integ[cur] + 1;
+                out[ni] |= 1;
+                if(new_cost < integ[ni]) {
+                    integ[ni] = new_cost;
+                    if(!rpq_contains(&q, ni))
+                        rpq_push(&q, new_cost, ni);
+                }
+            }
+        }
+    }
+    /* field_pad_wavefront, field.c:519 */
+    for(int r = 0; r < RES; r++) {
+    for(int c = 0; c < RES; c++) {
+        if(!(out[r * RES + c] & 2)) continue;
+        for(int rr = r - 1; rr <= r + 1; rr++) {
+        for(int cc = c - 1; cc <= c + 1; cc++) {
+            if(rr < 0 || rr > RES - 1 || cc < 0 || cc > RES - 1) continue;
+            out[rr * RES + cc] &= (uint8_t)~1;
+        }}
+    }}
+    return 0;
+}
+
+int no_build_los(const no_map *m, const navhip_los_req *reqs, int n, const uint8_t *prev,
+                 uint8_t *out, float map_x, float map_z)
+{
+    for(int i = 0; i < n; i++) {
+        int rc = no_los_field(m, &reqs[i], prev ? prev + (size_t)i * CELLS : NULL,
+                              out + (size_t)i * CELLS, map_x, map_z);
+        if(rc) return rc;
+    }
+    return 0;
+}
+
+/* ===========================================================================================
  * spatial index (lib/public/bitmap_grid.h), as the harness builds it: bg_ent_init over the
  * grid bounds, insert uids 0..n-1, bg_ent_cleanup
  * =========================================================================================== */

@@ -30,6 +30,13 @@ CIRCLE_DTYPE = np.dtype([("x", np.float32), ("z", np.float32), ("radius", np.flo
                          ("faction_id", np.int32), ("flags", np.uint32), ("delta", np.int32)])
 
 
+LOS_REQ_DTYPE = np.dtype([("layer", np.uint8), ("faction_id", np.uint8), ("enemies", np.uint16),
+                          ("chunk_r", np.uint16), ("chunk_c", np.uint16),
+                          ("target_chunk_r", np.uint16), ("target_chunk_c", np.uint16),
+                          ("target_tile_r", np.uint8), ("target_tile_c", np.uint8),
+                          ("prev_dr", np.int8), ("prev_dc", np.int8)])
+
+
 class Map(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32),
                 ("cost", C.c_void_p * NLAYERS), ("blockers", C.c_void_p * NLAYERS),
@@ -90,6 +97,8 @@ def lib():
         L.no_blockers_circles.argtypes = [C.POINTER(Map), C.c_void_p, C.c_int, C.c_float, C.c_float,
                                           C.c_void_p]
         L.no_local_islands.argtypes = [C.POINTER(Map), C.c_int, C.c_void_p, C.c_void_p]
+        L.no_build_los.argtypes = [C.POINTER(Map), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_float, C.c_float]
         L.no_field_bench.restype = C.c_double
         L.no_field_bench.argtypes = [C.POINTER(Map), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.no_agent_bench.restype = C.c_double
@@ -186,6 +195,18 @@ class OracleNav:
         if rc:
             raise ValueError("no_build_fields: malformed request")
         return dirs, integ
+
+    def build_los(self, reqs, prev=None):
+        """N_LOSFieldCreate for each request; prev: [n,64,64] previous fields or None."""
+        reqs = np.ascontiguousarray(reqs, LOS_REQ_DTYPE)
+        n = len(reqs)
+        out = np.zeros((n, 64, 64), np.uint8)
+        p = None if prev is None else np.ascontiguousarray(prev, np.uint8).reshape(n, 64, 64)
+        rc = lib().no_build_los(C.byref(self._map), _p(reqs), n, _p(p) if p is not None else None,
+                                _p(out), self.w * 128.0, -self.h * 128.0)
+        if rc:
+            raise ValueError("no_build_los: bad request")
+        return out
 
     def field_bench(self, reqs, reps=1, nthreads=1):
         reqs = np.ascontiguousarray(reqs, FIELD_REQ_DTYPE)

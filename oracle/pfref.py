@@ -75,6 +75,7 @@ def lib():
         L.pfref_field_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pfref_field_nearest_pathable.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         L.pfref_field_island_to_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.pfref_los_field.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p]
         L.pfref_field_bench.restype = C.c_double
         L.pfref_field_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.pfref_request_path.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -204,6 +205,16 @@ class RefNav:
         if rc != 0:
             raise ValueError("pfref_field_island_to_nearest: bad request")
         return dirs
+
+    def los_field(self, chunk, target, prev=None, prev_d=(0, 0), layer=0, faction_id=FACTION_ID_NONE):
+        """N_LOSFieldCreate: chunk=(r,c), target=(chunk_r,chunk_c,tile_r,tile_c); prev = previous
+        chunk's field ([64,64] u8) with prev_d = its chunk offset.  Returns [64,64] u8."""
+        out = np.zeros((64, 64), np.uint8)
+        p = None if prev is None else np.ascontiguousarray(prev, np.uint8)
+        lib().pfref_los_field(self._h, layer, faction_id, chunk[0], chunk[1], target[0], target[1],
+                              target[2], target[3], prev_d[0], prev_d[1],
+                              _p(p) if p is not None else None, _p(out))
+        return out
 
     def field_bench(self, reqs, reps=1, nthreads=1):
         reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)

@@ -90,6 +90,11 @@ int pfref_field_nearest_pathable(pfref_nav *nav, int layer, int chunk_r, int chu
 int pfref_field_island_to_nearest(pfref_nav *nav, const pfref_field_req *req, int local_iid,
                                   uint8_t *inout_dirs);
 
+/* N_LOSFieldCreate (field.c:2085); fields are 4096 bytes, bit 0 visible, bit 1 wavefront_blocked */
+int pfref_los_field(pfref_nav *nav, int layer, int faction_id, int chunk_r, int chunk_c,
+                    int tgt_chunk_r, int tgt_chunk_c, int tgt_tile_r, int tgt_tile_c,
+                    int prev_dr, int prev_dc, const uint8_t *prev, uint8_t *out);
+
 /* Time `reps` passes of N_FlowFieldInit+N_FlowFieldUpdate over `n` requests on
  * `nthreads` pthreads (requests are independent; nav_private is read-only).
  * Returns seconds of wall time (CLOCK_MONOTONIC). */

@@ -179,6 +179,34 @@ int pfref_field_island_to_nearest(pfref_nav *nav, const pfref_field_req *req, in
     return 0;
 }
 
+/* N_LOSFieldCreate (field.c:2085).  prev / out: 4096 bytes, bit 0 visible, bit 1
+ * wavefront_blocked; prev_dr/prev_dc: chunk offset of the previous field (0,0 = none). */
+int pfref_los_field(pfref_nav *nav, int layer, int faction_id, int chunk_r, int chunk_c,
+                    int tgt_chunk_r, int tgt_chunk_c, int tgt_tile_r, int tgt_tile_c,
+                    int prev_dr, int prev_dc, const uint8_t *prev, uint8_t *out)
+{
+    const struct nav_private *priv = pfref_nav_private(nav);
+    dest_id_t id = (dest_id_t)(((layer & 0xf) << 4) | (faction_id & 0xf));   /* nav.c:5052-5060 */
+    struct LOS_field lf, pl;
+    struct tile_desc target = {tgt_chunk_r, tgt_chunk_c, tgt_tile_r, tgt_tile_c};
+    bool has_prev = prev_dr != 0 || prev_dc != 0;
+    if(has_prev) {
+        memset(&pl, 0, sizeof(pl));
+        pl.chunk = (struct coord){chunk_r + prev_dr, chunk_c + prev_dc};
+        for(int r = 0; r < FIELD_RES_R; r++)
+        for(int c = 0; c < FIELD_RES_C; c++) {
+            pl.field[r][c].visible = prev[r * FIELD_RES_C + c] & 1;
+            pl.field[r][c].wavefront_blocked = (prev[r * FIELD_RES_C + c] >> 1) & 1;
+        }
+    }
+    N_LOSFieldCreate(id, (struct coord){chunk_r, chunk_c}, target, priv, nav->map_pos,
+                     priv->unit_query_ctx, &lf, has_prev ? &pl : NULL);
+    for(int r = 0; r < FIELD_RES_R; r++)
+    for(int c = 0; c < FIELD_RES_C; c++)
+        out[r * FIELD_RES_C + c] = (uint8_t)(lf.field[r][c].visible | (lf.field[r][c].wavefront_blocked << 1));
+    return 0;
+}
+
 struct bench_arg{
     const struct nav_private *priv;
     const pfref_field_req    *reqs;

@@ -1,0 +1,241 @@
+// los_kernels.hip -- line-of-sight fields for gfx950.
+//
+// Reference semantics: N_LOSFieldCreate, navigation/field.c:2085 (+ field_neighbours_grid_los :304,
+// field_is_los_corner :435, field_create_wavefront_blocked_line :463, field_pad_wavefront :519).
+// A wavefront expands from the destination tile (or from the visible tiles of the edge shared with
+// the previous chunk's LOS field); whenever it meets an impassable tile that is a LOS corner it
+// draws a Bresenham "wavefront blocked" line from that corner away from the destination, and tiles
+// on such lines are never entered.  The result depends on the ORDER in which tiles leave the
+// frontier: among tiles of equal distance it is the pop order of the reference's binary heap
+// (lib/public/pqueue.h:112-191, strict comparisons, hole-style sift-down).  To be bit-exact the
+// kernel therefore emulates that heap operation for operation: the wavefront is inherently
+// sequential, so ONE LANE runs it out of LDS while the wave's other lanes only help with the
+// staging, the final padding and the coalesced store.  Parallelism comes from the batch: one wave
+// per LOS field, 7 fields resident per CU (21 KB of LDS each).
+//
+// LOS fields are built once per (destination, chunk) when a path is planned and then cached
+// (nav.c:1840-1847,2026-2039), so this kernel is latency- not throughput-critical.
+#include "navhip_internal.h"
+
+#define LF_VISIBLE   0x01      /* struct LOS_field bit 0 (field.h:48-54)                     */
+#define LF_WFB       0x02      /* struct LOS_field bit 1: wavefront_blocked                  */
+#define LF_INHEAP    0x04
+#define LF_ASSIGNED  0x08      /* integration value finite                                    */
+#define LF_COSTLY    0x10      /* neighbour cost > 1: cost_base > 1 or not passable (:337-348) */
+#define LF_RAWBLK    0x20      /* cost_base == 0xff || blockers > 0 (field_is_los_corner)     */
+
+struct los_heap { int size; };      // nodes live in LDS: prio[1..size], cell[1..size]
+
+// pq_coord_push, pqueue.h:150
+__device__ __forceinline__ void lh_push(los_heap &h, uint16_t *prio, uint16_t *cell, int p, int c)
+{
+    int curr = h.size + 1, parent = curr / 2;
+    while(curr > 1 && prio[parent] > p) {
+        prio[curr] = prio[parent]; cell[curr] = cell[parent];
+        curr = parent;
+        parent = parent / 2;
+    }
+    prio[curr] = (uint16_t)p; cell[curr] = (uint16_t)c;
+    h.size++;
+}
+
+// pq_coord_pop + _pq_balance, pqueue.h:112-133,173-183
+__device__ __forceinline__ void lh_pop(los_heap &h, uint16_t *prio, uint16_t *cell)
+{
+    prio[1] = prio[h.size]; cell[1] = cell[h.size];
+    h.size--;
+    int root = 1;
+    const int last = h.size + 1;
+    while(root != last) {
+        int target = last;
+        const int l = root * 2, r = l + 1;
+        if(l <= h.size && prio[l] < prio[target]) target = l;
+        if(r <= h.size && prio[r] < prio[target]) target = r;
+        prio[root] = prio[target]; cell[root] = cell[target];
+        root = target;
+    }
+}
+
+__device__ __forceinline__ float los_len(float x, float z) { return __builtin_sqrtf(x * x + z * z); }
+
+// field_create_wavefront_blocked_line, field.c:463
+__device__ void los_blocked_line(uint8_t *fl, float map_x, float map_z, const navhip_los_req &rq,
+                                 int corner_r, int corner_c)
+{
+    // M_Tile_Bounds (tile.c:356) centres of the target and the corner tile
+    const float tbx = (map_x - (float)(rq.target_chunk_c * 256)) - (float)(rq.target_tile_c * 4);
+    const float tbz = (map_z + (float)(rq.target_chunk_r * 256)) + (float)(rq.target_tile_r * 4);
+    const float cbx = (map_x - (float)(rq.chunk_c * 256)) - (float)(corner_c * 4);
+    const float cbz = (map_z + (float)(rq.chunk_r * 256)) + (float)(corner_r * 4);
+    const float tcx = tbx - 4.0f / 2.0f, tcz = tbz + 4.0f / 2.0f;
+    const float ccx = cbx - 4.0f / 2.0f, ccz = cbz + 4.0f / 2.0f;
+    float sxf = tcx - ccx, szf = tcz - ccz;
+    const float len = los_len(sxf, szf);
+    sxf = __fdiv_rn(sxf, len);
+    szf = __fdiv_rn(szf, len);
+    const int dx = abs((int)(sxf * 1000));
+    const int dy = -abs((int)(szf * 1000));
+    const int sx = sxf > 0.0f ? 1 : -1;
+    const int sy = szf < 0.0f ? 1 : -1;
+    int err = dx + dy;
+    int r = corner_r, c = corner_c;
+    do {
+        fl[r * 64 + c] |= LF_WFB;
+        const int e2 = 2 * err;
+        if(e2 >= dy) { err += dy; c += sx; }
+        if(e2 <= dx) { err += dx; r += sy; }
+    } while(r >= 0 && r < 64 && c >= 0 && c < 64);
+}
+
+// field_is_los_corner, field.c:435
+__device__ __forceinline__ bool los_corner(const uint8_t *fl, int r, int c)
+{
+    if(r > 0 && r < 63) {
+        bool a = (fl[(r - 1) * 64 + c] & LF_RAWBLK) != 0, b = (fl[(r + 1) * 64 + c] & LF_RAWBLK) != 0;
+        if(a ^ b) return true;
+    }
+    if(c > 0 && c < 63) {
+        bool a = (fl[r * 64 + c - 1] & LF_RAWBLK) != 0, b = (fl[r * 64 + c + 1] & LF_RAWBLK) != 0;
+        if(a ^ b) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void k_los_field(nh_map_view map, const navhip_los_req *reqs, int n,
+                                                  const uint8_t *prev_fields, uint8_t *out_fields,
+                                                  float map_x, float map_z)
+{
+    __shared__ uint16_t h_prio[NH_CELLS + 2];
+    __shared__ uint16_t h_cell[NH_CELLS + 2];
+    __shared__ __attribute__((aligned(16))) uint8_t fl[NH_CELLS];
+    const int ri = blockIdx.x, lane = threadIdx.x;
+    if(ri >= n) return;
+    const navhip_los_req rq = reqs[ri];
+    const nh_layer_view &L = map.layers[rq.layer];
+    const size_t cbase = (size_t)((int)rq.chunk_r * map.w + rq.chunk_c) << 12;
+    const bool faction = rq.faction_id != NAVHIP_FACTION_ID_NONE;
+
+    // ---- stage the per-tile predicates (all lanes) ----------------------------------------------
+    for(int k = 0; k < 64; k++) {
+        const int i = k * 64 + lane;
+        const uint32_t cst = L.cost[cbase + i];
+        const uint32_t blk = L.blockers ? L.blockers[cbase + i] : 0;
+        bool passable;
+        if(cst == NAVHIP_COST_IMPASSABLE) {
+            passable = false;
+        }else if(!faction) {
+            passable = blk == 0;
+        }else{
+            bool enemies_only = true;
+            if(L.factions) {
+                const uint8_t *fp = L.factions + cbase * NAVHIP_MAX_FACTIONS + i;
+                for(int f = 0; f < NAVHIP_MAX_FACTIONS; f++)
+                    if(fp[(size_t)f << 12] && !(rq.enemies & (1u << f))) { enemies_only = false; break; }
+            }
+            passable = enemies_only || blk == 0;
+        }
+        uint8_t v = 0;
+        if(!passable || cst > 1) v |= LF_COSTLY;
+        if(cst == NAVHIP_COST_IMPASSABLE || blk > 0) v |= LF_RAWBLK;
+        fl[i] = v;
+    }
+    __syncthreads();
+
+    // ---- the sequential wavefront (lane 0) -------------------------------------------------------
+    if(lane == 0) {
+        los_heap H;
+        H.size = 0;
+        const bool first = rq.prev_dr == 0 && rq.prev_dc == 0;
+        if(first) {
+            // case 1, field.c:2111-2115: the destination chunk
+            const int t = rq.target_tile_r * 64 + rq.target_tile_c;
+            lh_push(H, h_prio, h_cell, 0, t);
+            fl[t] |= LF_ASSIGNED | LF_INHEAP;
+        }else{
+            // case 2, field.c:2122-2193: carry the shared edge over from the previous chunk's field
+            const uint8_t *prev = prev_fields + ((size_t)ri << 12);
+            const bool horizontal = rq.prev_dr == 0;
+            int curr_edge, prev_edge;
+            if(!horizontal) { curr_edge = rq.prev_dr < 0 ? 0 : 63; prev_edge = rq.prev_dr < 0 ? 63 : 0; }
+            else            { curr_edge = rq.prev_dc < 0 ? 0 : 63; prev_edge = rq.prev_dc < 0 ? 63 : 0; }
+            for(int k = 0; k < 64; k++) {
+                const int ci = horizontal ? k * 64 + curr_edge : curr_edge * 64 + k;
+                const int pi = horizontal ? k * 64 + prev_edge : prev_edge * 64 + k;
+                const uint8_t pv = prev[pi] & (LF_VISIBLE | LF_WFB);
+                fl[ci] = (uint8_t)((fl[ci] & ~(LF_VISIBLE | LF_WFB)) | pv);
+                if(pv & LF_WFB)
+                    los_blocked_line(fl, map_x, map_z, rq, ci >> 6, ci & 63);
+                if(fl[ci] & LF_VISIBLE) {
+                    lh_push(H, h_prio, h_cell, 0, ci);
+                    fl[ci] |= LF_ASSIGNED | LF_INHEAP;
+                }
+            }
+        }
+        while(H.size > 0) {
+            const int cur = h_cell[1], cprio = h_prio[1];
+            lh_pop(H, h_prio, h_cell);
+            fl[cur] &= (uint8_t)~LF_INHEAP;
+            const int r = cur >> 6, c = cur & 63;
+            // field_neighbours_grid_los :304: the 4 neighbours that are not wavefront blocked,
+            // collected BEFORE any of them is processed
+            int nb[4], nn = 0;
+            if(r > 0  && !(fl[cur - 64] & LF_WFB)) nb[nn++] = cur - 64;
+            if(c > 0  && !(fl[cur - 1]  & LF_WFB)) nb[nn++] = cur - 1;
+            if(c < 63 && !(fl[cur + 1]  & LF_WFB)) nb[nn++] = cur + 1;
+            if(r < 63 && !(fl[cur + 64] & LF_WFB)) nb[nn++] = cur + 64;
+            for(int k = 0; k < nn; k++) {
+                const int ni = nb[k];
+                if(fl[ni] & LF_COSTLY) {
+                    if(!los_corner(fl, ni >> 6, ni & 63)) continue;
+                    los_blocked_line(fl, map_x, map_z, rq, ni >> 6, ni & 63);
+                }else{
+                    fl[ni] |= LF_VISIBLE;
+                    // unit steps popped in non-decreasing order: `new_cost < integration[n]` holds
+                    // exactly when n has no value yet
+                    if(!(fl[ni] & LF_ASSIGNED)) {
+                        fl[ni] |= LF_ASSIGNED;
+                        if(!(fl[ni] & LF_INHEAP)) {
+                            lh_push(H, h_prio, h_cell, cprio + 1, ni);
+                            fl[ni] |= LF_INHEAP;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- field_pad_wavefront (:519): tiles within one tile of a blocked tile are not visible.
+    // In place: only VISIBLE bits are cleared while only WFB bits are read.
+    for(int k = 0; k < 64; k++) {
+        const int i = k * 64 + lane, r = k, c = lane;
+        bool near = false;
+        for(int rr = r - 1; rr <= r + 1; rr++)
+            for(int cc = c - 1; cc <= c + 1; cc++)
+                if(rr >= 0 && rr < 64 && cc >= 0 && cc < 64 && (fl[rr * 64 + cc] & LF_WFB)) near = true;
+        if(near) fl[i] &= (uint8_t)~LF_VISIBLE;
+    }
+    __syncthreads();
+    for(int k = 0; k < 64; k++) fl[k * 64 + lane] &= (uint8_t)(LF_VISIBLE | LF_WFB);
+    __syncthreads();
+    uint8_t *out = out_fields + ((size_t)ri << 12);
+#pragma unroll
+    for(int j = 0; j < 4; j++)
+        *(uint4*)(out + j * 1024 + lane * 16) = *(const uint4*)(fl + j * 1024 + lane * 16);
+}
+
+void nh_launch_los(navhip_ctx *ctx, const navhip_los_req *d_reqs, int n, const uint8_t *d_prev,
+                   uint8_t *d_out, float map_x, float map_z, hipStream_t s)
+{
+    nh_map_view mv;
+    mv.w = ctx->w;
+    mv.h = ctx->h;
+    for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
+        const navhip_layer &L = ctx->layers[l];
+        mv.layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
+                                     L.passmask, L.unit_cost, L.changed, L.islands};
+    }
+    if(n > 0)
+        hipLaunchKernelGGL(k_los_field, dim3(n), dim3(64), 0, s, mv, d_reqs, n, d_prev, d_out, map_x,
+                           map_z);
+}

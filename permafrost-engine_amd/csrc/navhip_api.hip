@@ -355,6 +355,67 @@ int navhip_clear_changed(navhip_ctx *ctx, void *stream)
     return NAVHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LOS fields
+// ---------------------------------------------------------------------------------------------
+int navhip_build_los_dev(navhip_ctx *ctx, const navhip_los_req *dev_reqs, int n,
+                         const uint8_t *dev_prev_fields, uint8_t *dev_out_fields,
+                         float map_pos_x, float map_pos_z, void *stream)
+{
+    if(!ctx || n < 0 || (n > 0 && (!dev_reqs || !dev_out_fields))) return NAVHIP_ERR_INVALID;
+    if(n == 0) return NAVHIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    nh_launch_los(ctx, dev_reqs, n, dev_prev_fields, dev_out_fields, map_pos_x, map_pos_z, s);
+    HIPCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_build_los(navhip_ctx *ctx, const navhip_los_req *reqs, int n,
+                     const uint8_t *prev_fields, uint8_t *out_fields,
+                     float map_pos_x, float map_pos_z)
+{
+    if(!ctx || n < 0 || (n > 0 && (!reqs || !out_fields))) return NAVHIP_ERR_INVALID;
+    if(n == 0) return NAVHIP_OK;
+    bool any_prev = false;
+    for(int i = 0; i < n; i++) {
+        const navhip_los_req &r = reqs[i];
+        const bool has_prev = r.prev_dr != 0 || r.prev_dc != 0;
+        bool ok = r.layer < NAVHIP_NAV_LAYER_MAX && r.chunk_r < ctx->h && r.chunk_c < ctx->w
+               && r.target_chunk_r < ctx->h && r.target_chunk_c < ctx->w
+               && r.target_tile_r < 64 && r.target_tile_c < 64
+               && (!has_prev || ((r.prev_dr == 0) != (r.prev_dc == 0)
+                                 && r.prev_dr >= -1 && r.prev_dr <= 1 && r.prev_dc >= -1 && r.prev_dc <= 1))
+               && (has_prev || (r.chunk_r == r.target_chunk_r && r.chunk_c == r.target_chunk_c));
+        if(!ok) {
+            ctx->last_error = "navhip_build_los: malformed request " + std::to_string(i);
+            return NAVHIP_ERR_INVALID;
+        }
+        if(!ctx->layers[r.layer].cost) return NAVHIP_ERR_NOT_UPLOADED;
+        any_prev |= has_prev;
+    }
+    if(any_prev && !prev_fields) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc = ensure_buf(ctx, ctx->stage[29], (size_t)n * sizeof(navhip_los_req));
+    if(!rc) rc = ensure_buf(ctx, ctx->stage[30], (size_t)n * NH_CELLS);
+    if(!rc) rc = ensure_buf(ctx, ctx->stage[31], (size_t)n * NH_CELLS);
+    if(rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[29].p, reqs, (size_t)n * sizeof(navhip_los_req),
+                               hipMemcpyHostToDevice, s));
+    if(any_prev)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->stage[30].p, prev_fields, (size_t)n * NH_CELLS,
+                                   hipMemcpyHostToDevice, s));
+    rc = navhip_build_los_dev(ctx, (const navhip_los_req*)ctx->stage[29].p, n,
+                              (const uint8_t*)ctx->stage[30].p, (uint8_t*)ctx->stage[31].p,
+                              map_pos_x, map_pos_z, s);
+    if(rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_fields, ctx->stage[31].p, (size_t)n * NH_CELLS,
+                               hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
 static int validate_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
 {
     for(int i = 0; i < n; i++) {

@@ -6,6 +6,7 @@
 #include "navhip.h"
 
 static_assert(sizeof(navhip_field_req) == 32, "navhip_field_req must stay 32 bytes");
+static_assert(sizeof(navhip_los_req) == 16, "navhip_los_req must stay 16 bytes");
 
 #define NH_CELLS   4096
 #define NH_RES     64
@@ -61,6 +62,8 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
 void nh_launch_blockers_circles(navhip_ctx *ctx, const navhip_circle *d_circles, int n, float map_x,
                                 float map_z, hipStream_t s);
 void nh_launch_local_islands(navhip_ctx *ctx, int layer, hipStream_t s);
+void nh_launch_los(navhip_ctx *ctx, const navhip_los_req *d_reqs, int n, const uint8_t *d_prev,
+                   uint8_t *d_out, float map_x, float map_z, hipStream_t s);
 
 struct nh_layer_view {
     const uint8_t  *cost;

@@ -44,6 +44,14 @@ CIRCLE_DTYPE = np.dtype([("x", np.float32), ("z", np.float32), ("radius", np.flo
                          ("faction_id", np.int32), ("flags", np.uint32), ("delta", np.int32)])
 assert CIRCLE_DTYPE.itemsize == 24
 
+# navhip_los_req, include/navhip.h (16 bytes)
+LOS_REQ_DTYPE = np.dtype([("layer", np.uint8), ("faction_id", np.uint8), ("enemies", np.uint16),
+                          ("chunk_r", np.uint16), ("chunk_c", np.uint16),
+                          ("target_chunk_r", np.uint16), ("target_chunk_c", np.uint16),
+                          ("target_tile_r", np.uint8), ("target_tile_c", np.uint8),
+                          ("prev_dr", np.int8), ("prev_dc", np.int8)])
+assert LOS_REQ_DTYPE.itemsize == 16
+
 # exported symbols, checked by the CPU test-suite against include/navhip.h
 _SIGS = {
     "navhip_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
@@ -63,6 +71,10 @@ _SIGS = {
     "navhip_relabel_local_islands": (C.c_int, [C.c_void_p, C.c_int]),
     "navhip_changed_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "navhip_clear_changed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "navhip_build_los": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_float, C.c_float]),
+    "navhip_build_los_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_float, C.c_float, C.c_void_p]),
     "navhip_build_fields": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_build_fields_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
@@ -212,6 +224,18 @@ class NavContext:
                                             _hp(integ) if want_integ else None),
                   "navhip_build_fields")
         return dirs, integ
+
+    def N_LOSFieldCreate(self, reqs, prev=None):
+        """Batched N_LOSFieldCreate (field.c:2085).  reqs: LOS_REQ_DTYPE; prev: [n,64,64] u8 previous
+        fields (bit0 visible, bit1 wavefront_blocked) or None.  Returns [n,64,64] u8."""
+        reqs = np.ascontiguousarray(reqs, dtype=LOS_REQ_DTYPE)
+        n = len(reqs)
+        out = np.zeros((n, 64, 64), np.uint8)
+        p = None if prev is None else np.ascontiguousarray(prev, np.uint8).reshape(n, 64, 64)
+        mx, mz = self.map_pos()
+        self._chk(lib().navhip_build_los(self._h, _hp(reqs), n, _hp(p) if p is not None else None,
+                                         _hp(out), mx, mz), "navhip_build_los")
+        return out
 
     def build_fields_dev(self, d_reqs, n, d_dirs, d_integ=None, stream=None):
         """Everything resident in HBM (torch tensors); asynchronous on `stream`."""

@@ -280,3 +280,48 @@ def formation_inputs(world, seed):
         "form_drag_xz": np.where(rng.rand(n, 1) < 0.5, rng.normal(0, 0.3, (n, 2)), 0.0).astype(np.float32),
     }
     return state, f
+
+
+def los_chains(nav, grid, n_dests, seed, max_chunks=6):
+    """LOS fields the way the planner chains them (nav.c:1840-1847,2026-2039): the destination
+    chunk first, then chunk by chunk outwards, each built from its predecessor's field.
+    Returns (requests as dicts, prev fields [n,64,64], expected fields [n,64,64]) from the reference."""
+    rng = np.random.RandomState(seed)
+    h, w = grid.shape[0] // 64, grid.shape[1] // 64
+    cells = synth.passable_cells(grid)
+    reqs, prevs, exps = [], [], []
+    for _ in range(n_dests):
+        R, Cc = cells[rng.randint(len(cells))]
+        tgt = (int(R) // 64, int(Cc) // 64, int(R) % 64, int(Cc) % 64)
+        done = {}
+        first = nav.los_field((tgt[0], tgt[1]), tgt)
+        done[(tgt[0], tgt[1])] = first
+        reqs.append(dict(chunk_r=tgt[0], chunk_c=tgt[1], target_chunk_r=tgt[0], target_chunk_c=tgt[1],
+                         target_tile_r=tgt[2], target_tile_c=tgt[3], prev_dr=0, prev_dc=0))
+        prevs.append(np.zeros((64, 64), np.uint8))
+        exps.append(first)
+        frontier = [(tgt[0], tgt[1])]
+        while frontier and len(done) < max_chunks:
+            cur = frontier.pop(0)
+            for d in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                nb = (cur[0] + d[0], cur[1] + d[1])
+                if nb in done or not (0 <= nb[0] < h and 0 <= nb[1] < w) or len(done) >= max_chunks:
+                    continue
+                prev_d = (cur[0] - nb[0], cur[1] - nb[1])
+                f = nav.los_field(nb, tgt, prev=done[cur], prev_d=prev_d)
+                done[nb] = f
+                frontier.append(nb)
+                reqs.append(dict(chunk_r=nb[0], chunk_c=nb[1], target_chunk_r=tgt[0], target_chunk_c=tgt[1],
+                                 target_tile_r=tgt[2], target_tile_c=tgt[3], prev_dr=prev_d[0], prev_dc=prev_d[1]))
+                prevs.append(done[cur])
+                exps.append(f)
+    return reqs, np.stack(prevs), np.stack(exps)
+
+
+def los_reqs_to(dtype, reqs):
+    out = np.zeros(len(reqs), dtype)
+    out["faction_id"] = 0xF
+    for i, r in enumerate(reqs):
+        for k, v in r.items():
+            out[k][i] = v
+    return out

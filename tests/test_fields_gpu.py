@@ -73,3 +73,20 @@ def test_repair_builds_match_reference(navlib, seed):
     bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exp[i])]
     assert not bad, "repair builds differ: %s" % [(i, int(reqs[i][0]["type"]), reqs[i][1]) for i in bad[:6]]
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,blk", [(2, False), (7, True)])
+def test_los_fields_match_reference(navlib, seed, blk):
+    """N_LOSFieldCreate (field.c:2085), chained chunk to chunk like the planner does; bit-exact,
+    which includes the pop order of the reference's binary heap."""
+    grid = cases.synth.cost_grid(3, 3, seed=60 + seed, frac_impassable=0.25)
+    blockers = cases.random_blockers(grid, seed=seed, frac=0.04) if blk else None
+    grid, nav = cases.ref_nav_for(3, 3, seed=60 + seed, blockers=blockers, frac=0.25)
+    reqs, prevs, exps = cases.los_chains(nav, grid, n_dests=8, seed=seed)
+    ctx = navlib.NavContext(3, 3)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(0))
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(1))
+    got = ctx.N_LOSFieldCreate(cases.los_reqs_to(navlib.LOS_REQ_DTYPE, reqs), prevs)
+    bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exps[i])]
+    assert not bad, "LOS fields differ: %s" % bad[:8]
+    ctx.close()

@@ -336,3 +336,20 @@ def test_repair_builds_restatement_matches_reference(seed):
     assert not bad, "repair builds differ: %s" % [(i, int(reqs[i][0]["type"]), reqs[i][1]) for i in bad[:6]]
     changed = sum(int(not np.array_equal(exp[i], exist[i])) for i in range(len(reqs)))
     assert changed > len(reqs) // 3            # the repairs really rewrote something
+
+
+# ---------------------------------------------------------------------------------------------
+# LOS fields (order-dependent wavefront: the restatement carries the reference's binary heap)
+# ---------------------------------------------------------------------------------------------
+@needs_ref
+@pytest.mark.parametrize("seed,blk", [(2, False), (7, True)])
+def test_los_restatement_matches_reference(seed, blk):
+    grid = cases.synth.cost_grid(3, 3, seed=60 + seed, frac_impassable=0.25)
+    blockers = cases.random_blockers(grid, seed=seed, frac=0.04) if blk else None
+    grid, nav = cases.ref_nav_for(3, 3, seed=60 + seed, blockers=blockers, frac=0.25)
+    reqs, prevs, exps = cases.los_chains(nav, grid, n_dests=5, seed=seed)
+    got = cases.oracle_nav_from_ref(nav).build_los(cases.los_reqs_to(navoracle.LOS_REQ_DTYPE, reqs), prevs)
+    bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exps[i])]
+    assert not bad, "LOS fields differ: %s" % bad[:8]
+    assert (exps & 1).mean() > 0.01 and (exps & 2).any()       # something visible, some lines drawn
+    assert sum(1 for r in reqs if r["prev_dr"] or r["prev_dc"]) > 10
