@@ -301,6 +301,13 @@ int  navhip_agent_step(navhip_ctx *ctx, const navhip_world *world, const navhip_
 int  navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *dev_world,
                            const navhip_step_out *dev_out, void *stream);
 
+/* Optional overlap: start the parts of the step that depend only on the snapshot (the spatial hash
+ * and the O(N*F) cohesion term) on the context's own side streams, forked from `stream`, and return
+ * at once.  Work enqueued on `stream` afterwards (e.g. the tick's field builds) then runs
+ * concurrently with them; the next navhip_agent_step_dev on the same snapshot arrays joins the side
+ * streams instead of recomputing.  Purely a scheduling hint: results are identical. */
+int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, void *stream);
+
 /* Per-kernel-group timing of the agent step with HIP events on the launch stream (bench.py's
  * roofline line).  After a profiled navhip_agent_step[_dev], navhip_last_step_ms returns
  * {spatial-hash build, k_cohesion, k_agent_step} in milliseconds (it waits for the step). */

@@ -139,6 +139,9 @@ __device__ __forceinline__ v2 flow_dir_vec(int dir)           // N_FlowDir, fiel
     }
 }
 
+// All 64 lanes call this with the same arguments; lanes 0..3 each fetch one of the four taps (slot
+// lookup -> direction byte: two dependent loads in total instead of up to eight), the blend is then
+// evaluated by every lane in the reference's tap order.
 __device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &status)
 {
     tiledesc t;
@@ -146,16 +149,9 @@ __device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &
         status |= NAVHIP_ST_FIELD_MISS;
         return mkv(0.0f, 0.0f);
     }
+    const int lane = threadIdx.x & 63;
     const int nchunks = P.map.w * P.map.h;
     const int32_t *slots = P.flock_field_slot + (size_t)flock * nchunks;
-    int slot = slots[t.chunk_r * P.map.w + t.chunk_c];
-    if(slot < 0) {
-        status |= NAVHIP_ST_FIELD_MISS;
-        return mkv(0.0f, 0.0f);
-    }
-    const uint8_t *base_ff = P.field_pool + ((size_t)slot << 12);
-    int base_dir = base_ff[t.tile_r * 64 + t.tile_c] & 0xf;
-    if(base_dir == NAVHIP_FD_NONE) status |= NAVHIP_ST_FIELD_NONE;
 
     // M_Tile_Bounds (tile.c:356): two sequential float subtractions / additions
     float bx = (P.map_x - (float)(t.chunk_c * 256)) - (float)(t.tile_c * 4);
@@ -166,28 +162,34 @@ __device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &
     int dr = (dz > 0.0f) ? 1 : -1;
     float wc = fminf(fabsf(dx) / 4.0f, 1.0f);
     float wr = fminf(fabsf(dz) / 4.0f, 1.0f);
-    const int   sdc[4] = {0, dc, 0, dc};
-    const int   sdr[4] = {0, 0, dr, dr};
     const float sw[4]  = {(1.0f - wc) * (1.0f - wr), wc * (1.0f - wr), (1.0f - wc) * wr, wc * wr};
+
+    // tap of this lane (lanes >= 4 mirror tap 0 and are ignored): M_Tile_RelativeDesc, tile.c:391
+    const int tap = lane & 3;
+    const int abs_r = t.chunk_r * 64 + t.tile_r + ((tap & 2) ? dr : 0);
+    const int abs_c = t.chunk_c * 64 + t.tile_c + ((tap & 1) ? dc : 0);
+    int my_dir = -1;                                   // -1: off map / chunk field not cached
+    int my_slot = -1;
+    if(abs_r >= 0 && abs_r < P.map.h * 64 && abs_c >= 0 && abs_c < P.map.w * 64) {
+        my_slot = slots[(abs_r >> 6) * P.map.w + (abs_c >> 6)];
+        if(my_slot >= 0)
+            my_dir = P.field_pool[((size_t)my_slot << 12) + (abs_r & 63) * 64 + (abs_c & 63)] & 0xf;
+    }
+    const int base_slot = __shfl(my_slot, 0);
+    if(base_slot < 0) {
+        status |= NAVHIP_ST_FIELD_MISS;
+        return mkv(0.0f, 0.0f);
+    }
+    const int base_dir = __shfl(my_dir, 0);
+    if(base_dir == NAVHIP_FD_NONE) status |= NAVHIP_ST_FIELD_NONE;
 
     v2 acc = mkv(0.0f, 0.0f);
     float wsum = 0.0f;
 #pragma unroll
     for(int i = 0; i < 4; i++) {
+        const int dir = __shfl(my_dir, i);
         if(sw[i] <= 0.0f) continue;
-        // M_Tile_RelativeDesc, tile.c:391
-        int abs_r = t.chunk_r * 64 + t.tile_r + sdr[i];
-        int abs_c = t.chunk_c * 64 + t.tile_c + sdc[i];
-        if(abs_r < 0 || abs_r >= P.map.h * 64 || abs_c < 0 || abs_c >= P.map.w * 64) continue;
-        int cr = abs_r >> 6, cc = abs_c >> 6, tr = abs_r & 63, tc = abs_c & 63;
-        const uint8_t *ff = base_ff;
-        if(cr != t.chunk_r || cc != t.chunk_c) {
-            int s2 = slots[cr * P.map.w + cc];
-            if(s2 < 0) continue;
-            ff = P.field_pool + ((size_t)s2 << 12);
-        }
-        int dir = ff[tr * 64 + tc] & 0xf;
-        if(dir == NAVHIP_FD_NONE) continue;
+        if(dir <= NAVHIP_FD_NONE) continue;            // off map, not cached, or FD_NONE
         v2 scaled = vscale(flow_dir_vec(dir), sw[i]);
         acc = vadd(acc, scaled);
         wsum += sw[i];
@@ -337,60 +339,114 @@ __global__ __launch_bounds__(256) void k_sp_order(const int32_t *cell_start, int
 // one contiguous range that the lanes test 64 elements at a time; ballot + prefix popcount
 // appends hits in order and enforces `maxout` exactly where the reference stops.
 // ---------------------------------------------------------------------------------------------
+// Extent of a query in fine cells + whether it takes the reference's wide-query path
+// (bitmap_grid.h:1389-1397); returns false when the query box misses the grid.
+struct sp_extent { int cx_lo, cx_hi, cy_lo, cy_hi; bool wide; };
+
+__device__ __forceinline__ bool sp_query_extent(const nh_grid &G, int32_t icx, int32_t icy, int32_t ir,
+                                                sp_extent &E)
+{
+    const int32_t imnx = icx - ir, imxx = icx + ir, imny = icy - ir, imxy = icy + ir;
+    // _bg_cell_extent, bitmap_grid.h:1236
+    if(imxx < G.origin_x || imxy < G.origin_y) return false;
+    const int32_t span_x = (int32_t)((uint32_t)G.grid_w << 12), span_y = (int32_t)((uint32_t)G.grid_h << 12);
+    if(imnx >= G.origin_x + span_x || imny >= G.origin_y + span_y) return false;
+    E.cx_lo = max((imnx - G.origin_x) >> 12, 0);
+    E.cy_lo = max((imny - G.origin_y) >> 12, 0);
+    E.cx_hi = min((imxx - G.origin_x) >> 12, G.grid_w - 1);
+    E.cy_hi = min((imxy - G.origin_y) >> 12, G.grid_h - 1);
+    E.wide = (int64_t)(E.cx_hi - E.cx_lo + 1) * (E.cy_hi - E.cy_lo + 1) * 4 >= (int64_t)G.grid_w * G.grid_h * 3;
+    return true;
+}
+
+// out_d2 (optional, [maxout]): squared fixed-point distance of every hit (fits int32 for the
+// ranges the movement tick uses), so that a narrower query around the same point can be derived
+// from this one without touching memory again.
 __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, int maxout,
-                             uint32_t *out_ids, int lane)
+                             uint32_t *out_ids, int lane, int32_t *out_d2 = nullptr)
 {
     if(maxout <= 0 || range < 0.0f) return 0;
     const int32_t icx = bg_scale(x), icy = bg_scale(z), ir = bg_scale(range);
     const int64_t ir2 = (int64_t)ir * (int64_t)ir;
-    const int32_t imnx = icx - ir, imxx = icx + ir, imny = icy - ir, imxy = icy + ir;
-    // _bg_cell_extent, bitmap_grid.h:1236
-    if(imxx < G.origin_x || imxy < G.origin_y) return 0;
-    const int32_t span_x = (int32_t)((uint32_t)G.grid_w << 12), span_y = (int32_t)((uint32_t)G.grid_h << 12);
-    if(imnx >= G.origin_x + span_x || imny >= G.origin_y + span_y) return 0;
-    int cx_lo = (imnx - G.origin_x) >> 12, cx_hi = (imxx - G.origin_x) >> 12;
-    int cy_lo = (imny - G.origin_y) >> 12, cy_hi = (imxy - G.origin_y) >> 12;
-    cx_lo = max(cx_lo, 0); cy_lo = max(cy_lo, 0);
-    cx_hi = min(cx_hi, G.grid_w - 1); cy_hi = min(cy_hi, G.grid_h - 1);
+    sp_extent E;
+    if(!sp_query_extent(G, icx, icy, ir, E)) return 0;
 
     int written = 0;
-    if((int64_t)(cx_hi - cx_lo + 1) * (cy_hi - cy_lo + 1) * 4 >= (int64_t)G.grid_w * G.grid_h * 3) {
+    if(E.wide) {
         // wide-query fast path (bitmap_grid.h:1389-1397): the clean pool is scanned linearly
         for(int base = 0; base < G.n; base += 64) {
             int k = base + lane;
             bool hit = false;
+            int64_t d2 = 0;
             if(k < G.n) {
                 int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
-                hit = dx * dx + dy * dy <= ir2;
+                d2 = dx * dx + dy * dy;
+                hit = d2 <= ir2;
             }
             uint64_t m = __ballot(hit);
             int p = written + __popcll(m & ((1ull << lane) - 1ull));
-            if(hit && p < maxout) out_ids[p] = (uint32_t)G.sorted_id[k];
+            if(hit && p < maxout) {
+                out_ids[p] = (uint32_t)G.sorted_id[k];
+                if(out_d2) out_d2[p] = (int32_t)d2;
+            }
             written += __popcll(m);
             if(written >= maxout) return maxout;
         }
         return written;
     }
-    for(int cyc = cy_lo >> 3; cyc <= (cy_hi >> 3); cyc++) {
-        for(int cxc = cx_lo >> 3; cxc <= (cx_hi >> 3); cxc++) {
-            int fy0 = max(cyc * 8, cy_lo), fy1 = min(cyc * 8 + 8, cy_hi + 1);
-            int fx0 = max(cxc * 8, cx_lo), fx1 = min(cxc * 8 + 8, cx_hi + 1);
-            for(int fy = fy0; fy < fy1; fy++) {
-                int b = G.cell_start[fy * G.grid_w + fx0];
-                int e = G.cell_start[fy * G.grid_w + fx1];
-                for(int base = b; base < e; base += 64) {
-                    int k = base + lane;
-                    bool hit = false;
-                    if(k < e) {
-                        int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
-                        hit = dx * dx + dy * dy <= ir2;
-                    }
-                    uint64_t m = __ballot(hit);
-                    int p = written + __popcll(m & ((1ull << lane) - 1ull));
-                    if(hit && p < maxout) out_ids[p] = (uint32_t)G.sorted_id[k];
-                    written += __popcll(m);
-                    if(written >= maxout) return maxout;
+
+    // Visiting order (bitmap_grid.h:1408-1466): coarse 8x8 blocks row-major; inside a block fine
+    // rows top to bottom, cells left to right, packed elements in order.  The cells of one fine
+    // row inside one coarse block are contiguous in the cell-sorted pool: a SEGMENT.  All segments
+    // of a coarse row are resolved in parallel (lane = segment: two cell_start loads), scanned,
+    // and their candidates tested 64 at a time -- two dependent memory round trips per coarse row
+    // instead of three per fine row.
+    const int cxc_lo = E.cx_lo >> 3, cxc_hi = E.cx_hi >> 3, ncx = cxc_hi - cxc_lo + 1;
+    for(int cyc = E.cy_lo >> 3; cyc <= (E.cy_hi >> 3); cyc++) {
+        const int fy0 = max(cyc * 8, E.cy_lo), fy1 = min(cyc * 8 + 8, E.cy_hi + 1);
+        const int rows = fy1 - fy0, nseg = rows * ncx;
+        for(int sbase = 0; sbase < nseg; sbase += 64) {
+            // segment of this lane: block-column major, then fine row
+            const int sidx = sbase + lane;
+            int b = 0, len = 0;
+            if(sidx < nseg) {
+                const int cxc = cxc_lo + sidx / rows, fy = fy0 + sidx % rows;
+                const int fx0 = max(cxc * 8, E.cx_lo), fx1 = min(cxc * 8 + 8, E.cx_hi + 1);
+                b = G.cell_start[fy * G.grid_w + fx0];
+                len = G.cell_start[fy * G.grid_w + fx1] - b;
+            }
+            int incl = len;
+#pragma unroll
+            for(int d = 1; d < 64; d <<= 1) {
+                int o = __shfl_up(incl, d);
+                if(lane >= d) incl += o;
+            }
+            const int off = incl - len;
+            const int total = __shfl(incl, 63);
+            const int nact = min(64, nseg - sbase);
+            for(int base = 0; base < total; base += 64) {
+                const int q = base + lane;
+                // candidate q -> (segment, position); every lane runs the shuffles (uniform loop)
+                int k = -1;
+                for(int sg = 0; sg < nact; sg++) {
+                    const int so = __shfl(off, sg), sl = __shfl(len, sg), sb = __shfl(b, sg);
+                    if(q < total && q >= so && q < so + sl) k = sb + (q - so);
                 }
+                bool hit = false;
+                int64_t d2 = 0;
+                if(k >= 0) {
+                    int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
+                    d2 = dx * dx + dy * dy;
+                    hit = d2 <= ir2;
+                }
+                uint64_t m = __ballot(hit);
+                int p = written + __popcll(m & ((1ull << lane) - 1ull));
+                if(hit && p < maxout) {
+                    out_ids[p] = (uint32_t)G.sorted_id[k];
+                    if(out_d2) out_d2[p] = (int32_t)d2;
+                }
+                written += __popcll(m);
+                if(written >= maxout) return maxout;
             }
         }
     }
@@ -818,12 +874,14 @@ struct wave_lds {
     } u;
     float dyn[32 * 5];
     float stat[32 * 5];
+    int32_t  d2_30[128];                       // squared fixed-point distances of the r=30 hits
+    uint32_t ids10d[128];                      // r=10 list derived from the r=30 list
 };
 
 // separation_force, movement.c:1690.  ids30/n30 already gathered; wave-uniform result.
 __device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_radius,
                               uint32_t my_flags, const uint32_t *ids30, int n30, float *sep,
-                              float scaled_max_force, int lane)
+                              float scaled_max_force, int lane, const double *exp_tab)
 {
     if(n30 == 0) return mkv(0.0f, 0.0f);
     for(int base = 0; base < n30; base += 64) {
@@ -841,7 +899,7 @@ __device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_
                 float len = vlen(diff);
                 if(!(len < CP_EPS)) {
                     float t = __fdiv_rn(len - radius * 0.85f, len);
-                    float scale = (float)exp((double)fminf(-20.0f * t, 40.0f));
+                    float scale = exp_f32_via_f64(fminf(-20.0f * t, 40.0f), exp_tab);
                     term = vscale(diff, scale);
                 }
             }
@@ -892,6 +950,45 @@ __device__ __forceinline__ v2 nullify_impass(const nh_step_params &P, int layer,
     return f;
 }
 
+// The five tile probes of nullify_impass_components (own tile, +-4 wu in x and z), issued together
+// at the start of the step instead of one dependent load after another.
+struct tile_probes { bool path[5], blk[5]; };     // 0 self, 1 x+4, 2 x-4, 3 z+4, 4 z-4
+
+__device__ __forceinline__ tile_probes probe_tiles(const nh_step_params &P, int layer, v2 pos)
+{
+    const float px[5] = {pos.x, pos.x + 4.0f, pos.x - 4.0f, pos.x, pos.x};
+    const float pz[5] = {pos.z, pos.z, pos.z, pos.z + 4.0f, pos.z - 4.0f};
+    tile_probes T;
+    uint32_t cst[5], blk[5];
+    bool ok[5];
+    const uint8_t *cost = P.map.layers[layer].cost;
+    const uint16_t *bl = P.map.layers[layer].blockers;
+#pragma unroll
+    for(int i = 0; i < 5; i++) {
+        tiledesc t;
+        ok[i] = tile_for_point(P, px[i], pz[i], t);
+        size_t idx = ok[i] ? ((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c : 0;
+        cst[i] = cost[idx];
+        blk[i] = bl ? bl[idx] : 0;
+    }
+#pragma unroll
+    for(int i = 0; i < 5; i++) {
+        T.path[i] = ok[i] && cst[i] != NAVHIP_COST_IMPASSABLE;
+        T.blk[i] = ok[i] && blk[i] > 0;
+    }
+    return T;
+}
+
+__device__ __forceinline__ v2 nullify_impass_pre(const tile_probes &T, v2 f)
+{
+    const bool on_blocked = T.blk[0];
+    if(f.x > 0 && (!T.path[1] || (!on_blocked && T.blk[1]))) f.x = 0.0f;
+    if(f.x < 0 && (!T.path[2] || (!on_blocked && T.blk[2]))) f.x = 0.0f;
+    if(f.z > 0 && (!T.path[3] || (!on_blocked && T.blk[3]))) f.z = 0.0f;
+    if(f.z < 0 && (!T.path[4] || (!on_blocked && T.blk[4]))) f.z = 0.0f;
+    return f;
+}
+
 // find_neighbours, movement.c:2768: classify the r=10 query result into dynamic / static lists
 __device__ void classify_neighbours(const nh_step_params &P, int uid, uint32_t my_flags,
                                     const uint32_t *ids10, int n10, float *dyn, int &n_dyn,
@@ -935,11 +1032,45 @@ __device__ void classify_neighbours(const nh_step_params &P, int uid, uint32_t m
     wave_sync();
 }
 
+// The r = 10 neighbour query (find_neighbours, movement.c:2779) as a filter of the r = 30 query of
+// the same agent (separation_force, :1695).  Valid when the r = 30 list is COMPLETE (its cap of 128
+// did not bind) and both queries scan in the same mode: every entity within 10 is then in the list,
+// and two entities keep their relative order in any query that returns both (the visiting key --
+// coarse block, fine row, cell, slot -- does not depend on the query).  Returns the derived count,
+// or -1 when the r = 10 query has to run on its own.  Must see the list BEFORE filter_garrisoned
+// permutes it.
+__device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const int32_t *d2_30,
+                          int n30raw, uint32_t *out, int lane)
+{
+    if(n30raw >= 128) return -1;
+    const int32_t icx = bg_scale(me.x), icy = bg_scale(me.z);
+    sp_extent E30, E10;
+    const bool ok30 = sp_query_extent(G, icx, icy, bg_scale(30.0f), E30);
+    const bool ok10 = sp_query_extent(G, icx, icy, bg_scale(10.0f), E10);
+    if(!ok30 || !ok10 || E30.wide != E10.wide) return -1;
+    const int32_t ir10 = bg_scale(10.0f);
+    const int32_t lim = ir10 * ir10;
+    int written = 0;
+    for(int base = 0; base < n30raw; base += 64) {
+        const int k = base + lane;
+        const bool hit = k < n30raw && d2_30[k] <= lim;
+        const uint64_t m = __ballot(hit);
+        const int p = written + __popcll(m & ((1ull << lane) - 1ull));
+        if(hit) out[p] = ids30[k];
+        written += __popcll(m);
+    }
+    wave_sync();
+    return written;
+}
+
 __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const float *coh_xz,
                                                     nh_step_outs O)
 {
     __shared__ wave_lds lds[AG_WAVES];
+    __shared__ double exp_tab[64];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
+    __syncthreads();
     const int uid = P.work_begin + blockIdx.x * AG_WAVES + wib;
     if(uid >= P.work_end) return;
     wave_lds &W = lds[wib];
@@ -962,6 +1093,8 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
         const double force_thresh = ((double)(0.75f / (float)hz) * 20.0) * 0.01;
         const int layer = nav_layer_for(my_flags, my_radius);
         bool supported = true;
+        const tile_probes probes = probe_tiles(P, layer, me);
+        int n30raw = -1;                 // size of the unfiltered r=30 list (-1: no such query)
 
         if(state == NAVHIP_STATE_TURNING) {
             vpref = mkv(0.0f, 0.0f);
@@ -970,11 +1103,14 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
             vdes = load_vdes(P, uid, flock, me, status);
 
             // separation (used by priority 0 and 1): r = 30 query, cap 128
-            int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane);
+            int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
             wave_sync();
+            n30raw = n30;
+            const int n10d = derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
             n30 = filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
+            if(n10d < 0) n30raw = -1; else n30raw = n10d;
             const v2 separation = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
-                                                  W.u.sep, scaled_max_force, lane);
+                                                  W.u.sep, scaled_max_force, lane, exp_tab);
             v2 steer;
             if(point_seek) {
                 const bool los = P.has_dest_los[uid] != 0;
@@ -994,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
                     }else{
                         steer = arrive;
                     }
-                    steer = nullify_impass(P, layer, me, steer);
+                    steer = nullify_impass_pre(probes, steer);
                     if((double)vlen(steer) > force_thresh) break;
                 }
             }else{
@@ -1016,11 +1152,14 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
                 vpref = mkv(0.0f, 0.0f);
             }else{
                 vdes = load_vdes(P, uid, flock, me, status);
-                int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane);
+                int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
                 wave_sync();
+                n30raw = n30;
+                const int n10d = derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
                 n30 = filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
+                if(n10d < 0) n30raw = -1; else n30raw = n10d;
                 const v2 separation = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
-                                                      W.u.sep, scaled_max_force, lane);
+                                                      W.u.sep, scaled_max_force, lane, exp_tab);
                 const v2 f_coh = mkv(P.form_cohesion_xz[2 * uid], P.form_cohesion_xz[2 * uid + 1]);
                 const v2 f_ali = mkv(P.form_align_xz[2 * uid], P.form_align_xz[2 * uid + 1]);
                 const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
@@ -1060,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
                     }else{
                         steer = arrive;
                     }
-                    steer = nullify_impass(P, layer, me, steer);
+                    steer = nullify_impass_pre(probes, steer);
                     if((double)vlen(steer) > force_thresh) break;
                 }
                 v2 accel = vscale(steer, 1.0f / 1.0f);
@@ -1074,12 +1213,20 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
         }
 
         if(supported) {
-            // find_neighbours :2768: r = 10 query, cap 512
-            int n10 = sp_query_wave(P.grid, me.x, me.z, 10.0f, 512, W.u.ids10, lane);
-            wave_sync();
-            n10 = filter_garrisoned_wave(P.flags, W.u.ids10, n10, lane);
+            // find_neighbours :2768: r = 10 query, cap 512 -- taken from the r = 30 list when that
+            // list is complete (n30raw now holds the derived count, -1 = not derivable)
+            uint32_t *ids10 = W.u.ids10;
+            int n10;
+            if(n30raw >= 0) {
+                ids10 = W.ids10d;
+                n10 = n30raw;
+            }else{
+                n10 = sp_query_wave(P.grid, me.x, me.z, 10.0f, 512, W.u.ids10, lane);
+                wave_sync();
+            }
+            n10 = filter_garrisoned_wave(P.flags, ids10, n10, lane);
             int n_dyn, n_stat;
-            classify_neighbours(P, uid, my_flags, W.u.ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
+            classify_neighbours(P, uid, my_flags, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
             cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
             v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, W.u.rays, lane);
             out_vel = vtrunc(nv, max_speed / (float)hz);                   // :3464
@@ -1091,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
     if(active) {
         const int layer = nav_layer_for(my_flags, my_radius);
         v2 cand = vadd(me, out_vel);
-        bool on_blocked = pos_blocked(P, layer, me.x, me.z);
+        bool on_blocked = pos_blocked(P, layer, me.x, me.z);     // (L2-hot: probed at the start)
         if(vlen(out_vel) > 0 && pos_pathable(P, layer, cand.x, cand.z)
         && (on_blocked || !pos_blocked(P, layer, cand.x, cand.z))) {
             new_pos = cand;

@@ -95,6 +95,8 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(&ctx->coh, 0, sizeof(ctx->coh));
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
+    ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
+    memset(&ctx->pre, 0, sizeof(ctx->pre));
     memset(ctx->ev, 0, sizeof(ctx->ev));
     if(hipSetDevice(device) != hipSuccess
     || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -123,6 +125,9 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(auto &b : ctx->stage) hipFree(b.p);
     hipFree(ctx->coh.p);
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
+    for(auto &a : ctx->aux) if(a) hipStreamDestroy(a);
+    if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -554,11 +559,9 @@ static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hip
     return NAVHIP_OK;
 }
 
-int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_step_out *out,
-                          void *stream)
+static int step_check_world(navhip_ctx *ctx, const navhip_world *w)
 {
-    if(!ctx || !w || !out || w->n_ents < 0 || !out->vel_xz
-    || (w->hz != 20 && w->hz != 10 && w->hz != 5 && w->hz != 1))
+    if(!w || w->n_ents < 0 || (w->hz != 20 && w->hz != 10 && w->hz != 5 && w->hz != 1))
         return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
     if(!w->pos_xz || !w->vel_xz || !w->radius || !w->max_speed || !w->speed || !w->flags
@@ -569,22 +572,14 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         ctx->last_error = "agent step: no cost_base plane uploaded";
         return NAVHIP_ERR_NOT_UPLOADED;
     }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    return NAVHIP_OK;
+}
 
-    nh_step_params P;
+static int step_fill_params(navhip_ctx *ctx, const navhip_world *w, nh_step_params *Pp)
+{
+    nh_step_params &P = *Pp;
     memset(&P, 0, sizeof(P));
     fill_map_view(ctx, &P.map);
-    const bool prof = ctx->profiling;
-    if(prof) {
-        for(auto &e : ctx->ev) if(!e) HIPCHK(ctx, hipEventCreate(&e));
-        HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
-    }
-    int rc = spatial_build(ctx, w, &P.grid, s);
-    if(rc) return rc;
-    if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
-    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
-    if(rc) return rc;
     P.map_x = w->map_pos_x; P.map_z = w->map_pos_z;
     P.n_ents = w->n_ents; P.n_flocks = w->n_flocks; P.hz = w->hz;
     P.n_members = w->n_ents;          // every entity belongs to at most one flock
@@ -604,7 +599,91 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         ctx->last_error = "agent step: form_ready given without the other formation arrays";
         return NAVHIP_ERR_INVALID;
     }
+    return NAVHIP_OK;
+}
+
+int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stream)
+{
+    if(!ctx) return NAVHIP_ERR_INVALID;
+    int rc = step_check_world(ctx, w);
+    if(rc) return rc;
+    ctx->pre.valid = false;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if(!ctx->aux[0]) {
+        for(auto &a : ctx->aux) HIPCHK(ctx, hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    nh_step_params P;
+    rc = step_fill_params(ctx, w, &P);
+    if(rc) return rc;
+    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
+    if(rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    rc = spatial_build(ctx, w, &P.grid, ctx->aux[0]);
+    if(rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+    nh_launch_cohesion(P, (float*)ctx->coh.p, ctx->aux[1]);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+    HIPCHK(ctx, hipGetLastError());
+    ctx->pre.valid = true;
+    ctx->pre.pos_xz = w->pos_xz; ctx->pre.flock_members = w->flock_members;
+    ctx->pre.n_ents = w->n_ents; ctx->pre.work_begin = P.work_begin; ctx->pre.work_end = P.work_end;
+    ctx->pre.g.origin_x = P.grid.origin_x; ctx->pre.g.origin_y = P.grid.origin_y;
+    ctx->pre.g.grid_w = P.grid.grid_w; ctx->pre.g.grid_h = P.grid.grid_h;
+    return NAVHIP_OK;
+}
+
+int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_step_out *out,
+                          void *stream)
+{
+    if(!ctx || !out || !out->vel_xz) return NAVHIP_ERR_INVALID;
+    int rc = step_check_world(ctx, w);
+    if(rc) return rc;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+
+    nh_step_params P;
+    rc = step_fill_params(ctx, w, &P);
+    if(rc) return rc;
+    const bool prof = ctx->profiling;
+    const bool joined = ctx->pre.valid && !prof && ctx->pre.pos_xz == w->pos_xz
+                     && ctx->pre.flock_members == w->flock_members && ctx->pre.n_ents == w->n_ents
+                     && ctx->pre.work_begin == P.work_begin && ctx->pre.work_end == P.work_end;
+    if(ctx->pre.valid && !joined) {
+        // a prefetch for another snapshot is in flight on the side streams: let it drain before
+        // its scratch buffers are reused
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
+    }
+    ctx->pre.valid = false;
     nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
+    if(joined) {
+        // spatial hash + cohesion were started by navhip_agent_prefetch_dev: just join them
+        if(!grid_geometry(w, &P.grid)) return NAVHIP_ERR_INVALID;
+        P.grid.n = w->n_ents;
+        P.grid.cell_start = (int32_t*)ctx->sp[5].p; P.grid.sorted_id = (int32_t*)ctx->sp[6].p;
+        P.grid.sx = (int32_t*)ctx->sp[7].p; P.grid.sy = (int32_t*)ctx->sp[8].p;
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
+        nh_launch_agent_step(P, (float*)ctx->coh.p, O, s);
+        HIPCHK(ctx, hipGetLastError());
+        return NAVHIP_OK;
+    }
+    if(prof) {
+        for(auto &e : ctx->ev) if(!e) HIPCHK(ctx, hipEventCreate(&e));
+        HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
+    }
+    rc = spatial_build(ctx, w, &P.grid, s);
+    if(rc) return rc;
+    if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
+    if(rc) return rc;
     nh_launch_cohesion(P, (float*)ctx->coh.p, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     nh_launch_agent_step(P, (float*)ctx->coh.p, O, s);

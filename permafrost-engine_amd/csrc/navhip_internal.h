@@ -46,6 +46,11 @@ struct navhip_ctx {
                                //               cell_start, sorted_id, sx, sy, block_sum
     buf          coh;          // cohesion force per entity
     buf          stage[32];    // device copies of host buffers for the host-pointer entry points
+    // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
+    hipStream_t  aux[2];
+    hipEvent_t   ev_fork, ev_join[2];
+    struct { bool valid; const float *pos_xz; const int32_t *flock_members; int n_ents, work_begin, work_end;
+             struct nh_grid_store { int32_t origin_x, origin_y; int grid_w, grid_h; } g; } pre;
     // optional per-kernel-group timing of the agent step (navhip_set_profiling)
     bool         profiling;
     hipEvent_t   ev[4];        // start | spatial hash built | cohesion done | agent step done

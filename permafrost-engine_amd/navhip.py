@@ -290,6 +290,7 @@ class StepOut(C.Structure):
 _SIGS.update({
     "navhip_agent_step": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut)]),
     "navhip_agent_step_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut), C.c_void_p]),
+    "navhip_agent_prefetch_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p]),
     "navhip_spatial_query": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p, C.c_int, C.c_float,
                                        C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
@@ -378,6 +379,12 @@ def _ctx_agent_step_dev(self, world, stepout, stream=None):
               "navhip_agent_step_dev")
 
 
+def _ctx_agent_prefetch_dev(self, world, stream=None):
+    self._chk(lib().navhip_agent_prefetch_dev(self._h, C.byref(world),
+                                              C.c_void_p(stream) if stream else None),
+              "navhip_agent_prefetch_dev")
+
+
 def _ctx_spatial_query(self, pos_xz, query_xz, rng, maxout):
     """G_Pos_EntsInCircleFrom candidate lists (bitmap_grid.h:1376 order) for each query."""
     w, keep = make_world(self.w, self.h, {"pos_xz": np.ascontiguousarray(pos_xz, np.float32)})
@@ -419,5 +426,6 @@ NavContext.set_profiling = _ctx_set_profiling
 NavContext.last_step_ms = _ctx_last_step_ms
 NavContext.agent_step = _ctx_agent_step
 NavContext.agent_step_dev = _ctx_agent_step_dev
+NavContext.agent_prefetch_dev = _ctx_agent_prefetch_dev
 NavContext.spatial_query = _ctx_spatial_query
 NavContext.G_ClearPath_NewVelocity = _ctx_clearpath

@@ -100,6 +100,7 @@ class NavTick:
             return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
 
         self.tick_no = 0
+        self.overlap = True
         if obstacles:
             self.d_moves = dev(self._moves_host.view(np.uint8).reshape(obstacle_ticks, self.n_moves, 24))
 
@@ -158,6 +159,10 @@ class NavTick:
                 marks.append(self._mark("blockers"))
                 t = self.tick_no % self.d_moves.shape[0]
                 self.ctx.blockers_circles_dev(self.d_moves[t], self.n_moves, stream=s.cuda_stream)
+            # snapshot-only parts of the agent step (spatial hash, cohesion) start now on the
+            # library's side streams and overlap with the field builds below
+            if self.overlap:
+                self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream)
             marks.append(self._mark("fields"))
             if self.n_req_local:
                 self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,

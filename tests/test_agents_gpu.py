@@ -157,3 +157,22 @@ def test_formation_arms_match_reference(navlib):
     assert ((out2["status"] & navlib.ST_UNSUPPORTED) != 0).sum() == np.isin(world["state"], (1, 8)).sum()
     ctx.close()
     pfref.RefMove.unload()
+
+
+def test_prefetch_overlap_gives_identical_results(navlib):
+    """navhip_agent_prefetch_dev is a scheduling hint only: stepping with the snapshot-only work
+    started early on the side streams must reproduce the plain step bit for bit, tick after tick."""
+    import torch
+    from permafrost_engine_amd import tick
+    res = []
+    for overlap in (False, True):
+        T = tick.NavTick(chunk_w=4, fields_per_rank=6, agents_per_rank=5000, device=0)
+        T.overlap = overlap
+        for _ in range(6):
+            T.step()
+        T.sync()
+        res.append((T.t["pos_xz"].cpu().numpy().copy(), T.t["vel_xz"].cpu().numpy().copy()))
+        T.close()
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    assert np.abs(res[0][1]).max() > 0
