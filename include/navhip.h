@@ -184,6 +184,40 @@ int  navhip_build_fields(navhip_ctx *ctx, const navhip_field_req *reqs, int n,
 int  navhip_build_fields_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, int n,
                              uint8_t *dev_inout_dirs, float *dev_out_integ, void *stream);
 
+/* ---- region flow fields ---------------------------------------------------- */
+
+/* One flow field over a square region of nav tiles that may straddle chunks (struct region,
+ * field.c; field_build_integration_region field.c:582).  Seeds and overlay-blocked tiles are
+ * (abs_r, abs_c) int16 pairs in absolute nav-tile coordinates (chunk * 64 + tile), handed over in
+ * two shared arrays.  32 bytes.
+ *   out_mode 0  whole region, two 4-bit directions per byte (field_build_flow_unaligned :800):
+ *               N_CellArrivalFieldCreate :2445 / N_GroupArrivalFieldCreate :2525; the caller
+ *               computes base_abs_* exactly as those functions do (:2475-2488 / :2558-2559)
+ *   out_mode 1  the 64x64 window at (roff, coff) of the region written IN PLACE into a chunk field
+ *               of one direction per byte (field_build_flow_region :763): field_update_enemies
+ *               :1537 / _entity :1615 / _zone :1822, whose frontiers the game side provides */
+typedef struct navhip_region_req {
+    uint8_t  layer;
+    uint8_t  out_mode;
+    uint16_t enemies;                 /* 0: field_tile_passable, else ..._no_enemies(enemies)   */
+    int16_t  base_abs_r, base_abs_c;  /* region.base; may lie outside the map                   */
+    uint16_t rdim, cdim;              /* even, rdim == cdim <= 128                              */
+    uint16_t roff, coff;              /* out_mode 1                                             */
+    uint32_t seed_begin, seed_count;
+    uint32_t overlay_begin, overlay_count;
+} navhip_region_req;
+
+/* out: n slots of out_stride bytes (>= rdim*cdim/2 for mode 0, >= 4096 for mode 1).  Mode 0
+ * slots are fully written; mode 1 slots are read-modify-write (unreached tiles keep their byte). */
+int  navhip_build_region_fields(navhip_ctx *ctx, const navhip_region_req *reqs, int n,
+                                const int16_t *seeds, size_t n_seeds,
+                                const int16_t *overlay, size_t n_overlay,
+                                uint8_t *inout, size_t out_stride);
+int  navhip_build_region_fields_dev(navhip_ctx *ctx, const navhip_region_req *dev_reqs, int n,
+                                    int max_dim, const int16_t *dev_seeds,
+                                    const int16_t *dev_overlay, uint8_t *dev_inout,
+                                    size_t out_stride, void *stream);
+
 /* ---- line-of-sight fields ------------------------------------------------- */
 
 /* One N_LOSFieldCreate(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los) call

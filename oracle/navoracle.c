@@ -448,6 +448,119 @@ static v2 vtrunc(v2 a, float max_len)
 #define EPS (1.0 / 1024)      /* clearpath.c:76, collision.c EPSILON */
 
 /* ===========================================================================================
+ * region flow fields: field_build_integration_region (field.c:582) + field_build_flow_unaligned
+ * (:800, N_CellArrivalFieldCreate :2445 / N_GroupArrivalFieldCreate :2525) or
+ * field_build_flow_region (:763, field_update_enemies/entity/zone :1537,:1615,:1822)
+ * =========================================================================================== */
+static int flow_dir_dim(const float *f, int rdim, int cdim, int r, int c)
+{
+    float min_cost = INFINITY;
+#define F(rr, cc) f[(rr) * rdim + (cc)]
+#define MINF(a, b) ((a) < (b) ? (a) : (b))
+    if(r > 0)          min_cost = MINF(min_cost, F(r - 1, c));
+    if(r < rdim - 1)   min_cost = MINF(min_cost, F(r + 1, c));
+    if(c > 0)          min_cost = MINF(min_cost, F(r, c - 1));
+    if(c < cdim - 1)   min_cost = MINF(min_cost, F(r, c + 1));
+    if(r > 0 && c > 0 && F(r - 1, c) < INFINITY && F(r, c - 1) < INFINITY)
+        min_cost = MINF(min_cost, F(r - 1, c - 1));
+    if(r > 0 && c < cdim - 1 && F(r - 1, c) < INFINITY && F(r, c + 1) < INFINITY)
+        min_cost = MINF(min_cost, F(r - 1, c + 1));
+    if(r < rdim - 1 && c > 0 && F(r + 1, c) < INFINITY && F(r, c - 1) < INFINITY)
+        min_cost = MINF(min_cost, F(r + 1, c - 1));
+    if(r < rdim - 1 && c < cdim - 1 && F(r + 1, c) < INFINITY && F(r, c + 1) < INFINITY)
+        min_cost = MINF(min_cost, F(r + 1, c + 1));
+    if(r > 0 && F(r - 1, c) == min_cost)                          return NAVHIP_FD_N;
+    else if(r < rdim - 1 && F(r + 1, c) == min_cost)              return NAVHIP_FD_S;
+    else if(c < cdim - 1 && F(r, c + 1) == min_cost)              return NAVHIP_FD_E;
+    else if(c > 0 && F(r, c - 1) == min_cost)                     return NAVHIP_FD_W;
+    else if(r > 0 && c > 0 && F(r - 1, c - 1) == min_cost)        return NAVHIP_FD_NW;
+    else if(r > 0 && c < cdim - 1 && F(r - 1, c + 1) == min_cost) return NAVHIP_FD_NE;
+    else if(r < rdim - 1 && c > 0 && F(r + 1, c - 1) == min_cost) return NAVHIP_FD_SW;
+    else if(r < rdim - 1 && c < rdim - 1 && F(r + 1, c + 1) == min_cost) return NAVHIP_FD_SE;
+    return NAVHIP_FD_NONE;
+#undef F
+#undef MINF
+}
+
+int no_region_field(const no_map *m, const navhip_region_req *rq, const int16_t *seeds,
+                    const int16_t *overlay, uint8_t *inout)
+{
+    const int rdim = rq->rdim, cdim = rq->cdim, layer = rq->layer;
+    if(rdim != cdim || rdim > 128 || (rdim & 1) || !m->cost[layer]) return -1;
+    const int H = m->h * RES, W = m->w * RES;
+    static __thread float integ[128 * 128];
+    static __thread uint8_t mask[128 * 128];
+    for(int i = 0; i < rdim * cdim; i++) integ[i] = INFINITY;
+    memset(mask, 0, (size_t)rdim * cdim);
+    pq_t q = {0};
+    for(uint32_t k = 0; k < rq->overlay_count; k++) {            /* build_overlay_mask :571 */
+        int dr = overlay[2 * (rq->overlay_begin + k)] - rq->base_abs_r;
+        int dc = overlay[2 * (rq->overlay_begin + k) + 1] - rq->base_abs_c;
+        if(dr >= 0 && dr < rdim && dc >= 0 && dc < cdim) mask[dr * rdim + dc] = 1;
+    }
+    for(uint32_t k = 0; k < rq->seed_count; k++) {
+        int dr = seeds[2 * (rq->seed_begin + k)] - rq->base_abs_r;
+        int dc = seeds[2 * (rq->seed_begin + k) + 1] - rq->base_abs_c;
+        if(dr < 0 || dr >= rdim || dc < 0 || dc >= cdim) continue;
+        pq_push(&q, 0.0f, dr * rdim + dc);
+        integ[dr * rdim + dc] = 0.0f;
+    }
+    static const int dr4[4] = {-1, 0, 0, 1}, dc4[4] = {0, -1, 1, 0};
+    while(q.n > 0) {                                             /* field_build_integration_region */
+        int cur = pq_pop(&q);
+        int r = cur / rdim, c = cur % rdim;
+        for(int k = 0; k < 4; k++) {
+            int nr = r + dr4[k], nc = c + dc4[k];
+            int ar = rq->base_abs_r + nr, ac = rq->base_abs_c + nc;
+            if(ar < 0 || ar >= H || ac < 0 || ac >= W) continue;              /* M_Tile_RelativeDesc */
+            int chunk = (ar / RES) * m->w + (ac / RES);
+            if(!tile_passable(m, layer, chunk, ar % RES, ac % RES,
+                              rq->enemies ? 0 : FACTION_NONE, rq->enemies)) continue;
+            if(nr < 0 || nr >= rdim || nc < 0 || nc >= cdim) continue;        /* tile_outside_region */
+            if(mask[nr * rdim + nc]) continue;
+            float total = integ[cur] + (float)m->cost[layer][((size_t)chunk << 12) + (ar % RES) * RES + (ac % RES)];
+            if(total < integ[nr * rdim + nc]) {
+                integ[nr * rdim + nc] = total;
+                pq_push(&q, total, nr * rdim + nc);
+            }
+        }
+    }
+    free(q.a);
+    if(rq->out_mode == 0) {                                      /* field_build_flow_unaligned :800 */
+        memset(inout, 0, (size_t)rdim * cdim / 2);
+        for(int r = 0; r < rdim; r++) {
+        for(int c = 0; c < cdim; c++) {
+            float v = integ[r * rdim + c];
+            if(v == INFINITY) continue;
+            int dir = (v == 0.0f) ? NAVHIP_FD_NONE : flow_dir_dim(integ, rdim, cdim, r, c);
+            size_t bi = (size_t)r * (rdim / 2) + (c - (c % 2)) / 2;          /* set_flow_cell :786 */
+            if(c % 2 == 1) inout[bi] = (uint8_t)((inout[bi] & 0xf0) | dir);
+            else           inout[bi] = (uint8_t)((inout[bi] & 0x0f) | (dir << 4));
+        }}
+    }else{                                                       /* field_build_flow_region :763 */
+        int lim_r = rdim < RES ? rdim : RES, lim_c = cdim < RES ? cdim : RES;
+        for(int r = 0; r < lim_r; r++) {
+        for(int c = 0; c < lim_c; c++) {
+            int ir = r + rq->roff, ic = c + rq->coff;
+            float v = integ[ir * rdim + ic];
+            if(v == INFINITY) continue;
+            inout[r * RES + c] = (v == 0.0f) ? NAVHIP_FD_NONE : (uint8_t)flow_dir_dim(integ, rdim, cdim, ir, ic);
+        }}
+    }
+    return 0;
+}
+
+int no_build_region_fields(const no_map *m, const navhip_region_req *reqs, int n, const int16_t *seeds,
+                           const int16_t *overlay, uint8_t *inout, size_t stride)
+{
+    for(int i = 0; i < n; i++) {
+        int rc = no_region_field(m, &reqs[i], seeds, overlay, inout + (size_t)i * stride);
+        if(rc) return rc;
+    }
+    return 0;
+}
+
+/* ===========================================================================================
  * line-of-sight fields: N_LOSFieldCreate (field.c:2085)
  * =========================================================================================== */
 

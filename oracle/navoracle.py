@@ -30,6 +30,11 @@ CIRCLE_DTYPE = np.dtype([("x", np.float32), ("z", np.float32), ("radius", np.flo
                          ("faction_id", np.int32), ("flags", np.uint32), ("delta", np.int32)])
 
 
+REGION_REQ_DTYPE = np.dtype([("layer", np.uint8), ("out_mode", np.uint8), ("enemies", np.uint16),
+                             ("base_abs_r", np.int16), ("base_abs_c", np.int16),
+                             ("rdim", np.uint16), ("cdim", np.uint16), ("roff", np.uint16),
+                             ("coff", np.uint16), ("seed_begin", np.uint32), ("seed_count", np.uint32),
+                             ("overlay_begin", np.uint32), ("overlay_count", np.uint32)])
 LOS_REQ_DTYPE = np.dtype([("layer", np.uint8), ("faction_id", np.uint8), ("enemies", np.uint16),
                           ("chunk_r", np.uint16), ("chunk_c", np.uint16),
                           ("target_chunk_r", np.uint16), ("target_chunk_c", np.uint16),
@@ -97,6 +102,8 @@ def lib():
         L.no_blockers_circles.argtypes = [C.POINTER(Map), C.c_void_p, C.c_int, C.c_float, C.c_float,
                                           C.c_void_p]
         L.no_local_islands.argtypes = [C.POINTER(Map), C.c_int, C.c_void_p, C.c_void_p]
+        L.no_build_region_fields.argtypes = [C.POINTER(Map), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_size_t]
         L.no_build_los.argtypes = [C.POINTER(Map), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_float, C.c_float]
         L.no_field_bench.restype = C.c_double
@@ -195,6 +202,22 @@ class OracleNav:
         if rc:
             raise ValueError("no_build_fields: malformed request")
         return dirs, integ
+
+    def build_region_fields(self, reqs, seeds, overlay=None, inout=None, out_stride=8192):
+        reqs = np.ascontiguousarray(reqs, REGION_REQ_DTYPE)
+        n = len(reqs)
+        seeds = np.ascontiguousarray(seeds, np.int16).reshape(-1, 2)
+        ov = np.zeros((1, 2), np.int16) if overlay is None or len(overlay) == 0 else \
+            np.ascontiguousarray(overlay, np.int16).reshape(-1, 2)
+        buf = np.zeros((n, out_stride), np.uint8)
+        if inout is not None:
+            a = np.asarray(inout, np.uint8).reshape(n, -1)
+            buf[:, :a.shape[1]] = a
+        rc = lib().no_build_region_fields(C.byref(self._map), _p(reqs), n, _p(seeds), _p(ov), _p(buf),
+                                          out_stride)
+        if rc:
+            raise ValueError("no_build_region_fields: bad request")
+        return buf
 
     def build_los(self, reqs, prev=None):
         """N_LOSFieldCreate for each request; prev: [n,64,64] previous fields or None."""

@@ -75,6 +75,11 @@ def lib():
         L.pfref_field_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pfref_field_nearest_pathable.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         L.pfref_field_island_to_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.pfref_cell_arrival_field.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_int, C.c_void_p]
+        L.pfref_group_arrival_field.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+        L.pfref_zone_field.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int,
+                                                                      C.c_void_p]
         L.pfref_los_field.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p]
         L.pfref_field_bench.restype = C.c_double
         L.pfref_field_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -205,6 +210,34 @@ class RefNav:
         if rc != 0:
             raise ValueError("pfref_field_island_to_nearest: bad request")
         return dirs
+
+    def cell_arrival_field(self, dim, target_abs, center_abs, blocked=None, layer=0, enemies=0):
+        out = np.zeros(dim * dim // 2, np.uint8)
+        b = np.zeros((0, 2), np.int16) if blocked is None else np.ascontiguousarray(blocked, np.int16)
+        lib().pfref_cell_arrival_field(self._h, dim, layer, enemies, target_abs[0], target_abs[1],
+                                       center_abs[0], center_abs[1], _p(b) if len(b) else None, len(b),
+                                       _p(out))
+        return out
+
+    def group_arrival_field(self, dim, targets_xz, center_xz, blocked=None, layer=0, enemies=0):
+        out = np.zeros(dim * dim // 2, np.uint8)
+        t = np.ascontiguousarray(targets_xz, np.float32).reshape(-1, 2)
+        b = np.zeros((0, 2), np.int16) if blocked is None else np.ascontiguousarray(blocked, np.int16)
+        lib().pfref_group_arrival_field(self._h, dim, layer, enemies, _p(t), len(t), center_xz[0],
+                                        center_xz[1], _p(b) if len(b) else None, len(b), _p(out))
+        return out
+
+    def zone_field(self, chunk, center_abs, radius, existing, layer=0):
+        """TARGET_ZONE chunk field on a copy of `existing`; returns (dirs, seeds [k,2] i16, geometry
+        dict of the padded region field_update_zone integrates over)."""
+        dirs = np.ascontiguousarray(existing, np.uint8).reshape(64, 64).copy()
+        seeds = np.zeros((128 * 128, 2), np.int16)
+        geom = (C.c_int * 6)()
+        n = lib().pfref_zone_field(self._h, layer, chunk[0], chunk[1], center_abs[0], center_abs[1],
+                                   radius, _p(dirs), _p(seeds), len(seeds), geom)
+        g = dict(base_abs_r=geom[0], base_abs_c=geom[1], rdim=geom[2], roff=geom[3], coff=geom[4],
+                 cdim=geom[5])
+        return dirs, seeds[:n].copy(), g
 
     def los_field(self, chunk, target, prev=None, prev_d=(0, 0), layer=0, faction_id=FACTION_ID_NONE):
         """N_LOSFieldCreate: chunk=(r,c), target=(chunk_r,chunk_c,tile_r,tile_c); prev = previous

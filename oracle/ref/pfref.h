@@ -90,6 +90,16 @@ int pfref_field_nearest_pathable(pfref_nav *nav, int layer, int chunk_r, int chu
 int pfref_field_island_to_nearest(pfref_nav *nav, const pfref_field_req *req, int local_iid,
                                   uint8_t *inout_dirs);
 
+/* region fields: N_CellArrivalFieldCreate :2445, N_GroupArrivalFieldCreate :2525, TARGET_ZONE */
+int pfref_cell_arrival_field(pfref_nav *nav, int dim, int layer, int enemies,
+                             int tgt_abs_r, int tgt_abs_c, int cen_abs_r, int cen_abs_c,
+                             const int16_t *blocked, int n_blocked, uint8_t *out);
+int pfref_group_arrival_field(pfref_nav *nav, int dim, int layer, int enemies, const float *targets_xz,
+                              int ntargets, float center_x, float center_z,
+                              const int16_t *blocked, int n_blocked, uint8_t *out);
+int pfref_zone_field(pfref_nav *nav, int layer, int chunk_r, int chunk_c, int cen_abs_r, int cen_abs_c,
+                     int radius, uint8_t *inout_dirs, int16_t *out_seeds, int max_seeds, int *out_geom);
+
 /* N_LOSFieldCreate (field.c:2085); fields are 4096 bytes, bit 0 visible, bit 1 wavefront_blocked */
 int pfref_los_field(pfref_nav *nav, int layer, int faction_id, int chunk_r, int chunk_c,
                     int tgt_chunk_r, int tgt_chunk_c, int tgt_tile_r, int tgt_tile_c,

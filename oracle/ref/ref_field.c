@@ -207,6 +207,95 @@ int pfref_los_field(pfref_nav *nav, int layer, int faction_id, int chunk_r, int 
     return 0;
 }
 
+/* N_CellArrivalFieldCreate (field.c:2445); blocked: n_blocked (abs_r, abs_c) pairs or NULL */
+int pfref_cell_arrival_field(pfref_nav *nav, int dim, int layer, int enemies,
+                             int tgt_abs_r, int tgt_abs_c, int cen_abs_r, int cen_abs_c,
+                             const int16_t *blocked, int n_blocked, uint8_t *out)
+{
+    struct nav_private *priv = pfref_nav_private(nav);
+    struct tile_desc target = {tgt_abs_r / FIELD_RES_R, tgt_abs_c / FIELD_RES_C, tgt_abs_r % FIELD_RES_R, tgt_abs_c % FIELD_RES_C};
+    struct tile_desc center = {cen_abs_r / FIELD_RES_R, cen_abs_c / FIELD_RES_C, cen_abs_r % FIELD_RES_R, cen_abs_c % FIELD_RES_C};
+    size_t ws = (sizeof(float) + sizeof(bool)) * dim * dim + 64;
+    void *work = malloc(ws);
+    struct tile_desc *tds = n_blocked ? malloc(sizeof(struct tile_desc) * n_blocked) : NULL;
+    for(int i = 0; i < n_blocked; i++)
+        tds[i] = (struct tile_desc){blocked[2 * i] / FIELD_RES_R, blocked[2 * i + 1] / FIELD_RES_C,
+                                    blocked[2 * i] % FIELD_RES_R, blocked[2 * i + 1] % FIELD_RES_C};
+    struct nav_cell_overlay ov = {tds, (size_t)n_blocked};
+    N_CellArrivalFieldCreate(priv, dim, dim, layer, (uint16_t)enemies, target, center, out, work, ws,
+                             n_blocked ? &ov : NULL);
+    free(work);
+    free(tds);
+    return 0;
+}
+
+/* N_GroupArrivalFieldCreate (field.c:2525): targets = world-space XZ points */
+int pfref_group_arrival_field(pfref_nav *nav, int dim, int layer, int enemies, const float *targets_xz,
+                              int ntargets, float center_x, float center_z,
+                              const int16_t *blocked, int n_blocked, uint8_t *out)
+{
+    struct nav_private *priv = pfref_nav_private(nav);
+    size_t ws = (sizeof(float) + sizeof(bool)) * dim * dim + 64;
+    void *work = malloc(ws);
+    struct tile_desc *tds = n_blocked ? malloc(sizeof(struct tile_desc) * n_blocked) : NULL;
+    for(int i = 0; i < n_blocked; i++)
+        tds[i] = (struct tile_desc){blocked[2 * i] / FIELD_RES_R, blocked[2 * i + 1] / FIELD_RES_C,
+                                    blocked[2 * i] % FIELD_RES_R, blocked[2 * i + 1] % FIELD_RES_C};
+    struct nav_cell_overlay ov = {tds, (size_t)n_blocked};
+    N_GroupArrivalFieldCreate(priv, dim, dim, layer, (uint16_t)enemies, nav->map_pos,
+                              (const vec2_t*)targets_xz, ntargets, (vec2_t){center_x, center_z}, out,
+                              work, ws, n_blocked ? &ov : NULL);
+    free(work);
+    free(tds);
+    return 0;
+}
+
+/* N_FlowFieldUpdate with a TARGET_ZONE target (field_update_zone, field.c:1822) on an existing
+ * field; also returns the zone's initial frontier (field_zone_initial_frontier :1682) as
+ * (abs_r, abs_c) pairs together with the padded region's geometry, i.e. what the game side would
+ * hand to a region-field builder. */
+int pfref_zone_field(pfref_nav *nav, int layer, int chunk_r, int chunk_c, int cen_abs_r, int cen_abs_c,
+                     int radius, uint8_t *inout_dirs, int16_t *out_seeds, int max_seeds,
+                     int *out_geom /* base_abs_r, base_abs_c, dim, roff, coff */)
+{
+    const struct nav_private *priv = pfref_nav_private(nav);
+    struct zone_desc zone = {{cen_abs_r / FIELD_RES_R, cen_abs_c / FIELD_RES_C, cen_abs_r % FIELD_RES_R,
+                              cen_abs_c % FIELD_RES_C}, (uint16_t)radius};
+    struct field_target target;
+    memset(&target, 0, sizeof(target));
+    target.type = TARGET_ZONE;
+    target.zone = zone;
+    struct flow_field ff;
+    memset(&ff, 0, sizeof(ff));
+    pfref_dirs_to_ff(inout_dirs, &ff);
+    ff.chunk = (struct coord){chunk_r, chunk_c};
+    N_FlowFieldUpdate(ff.chunk, priv, FACTION_ID_NONE, layer, target, priv->unit_query_ctx, &ff);
+    pfref_ff_to_dirs(&ff, inout_dirs);
+
+    /* the same geometry field_update_zone uses (:1835-1849,1880-1881) */
+    const int rdim = (priv->height > 1) ? FIELD_RES_R * 2 : FIELD_RES_R;
+    const int cdim = (priv->width  > 1) ? FIELD_RES_C * 2 : FIELD_RES_C;
+    struct tile_desc base = {
+        (chunk_r > 0) ? chunk_r - 1 : chunk_r, (chunk_c > 0) ? chunk_c - 1 : chunk_c,
+        (chunk_r > 0) ? FIELD_RES_R / 2 : 0, (chunk_c > 0) ? FIELD_RES_C / 2 : 0};
+    out_geom[0] = base.chunk_r * FIELD_RES_R + base.tile_r;
+    out_geom[1] = base.chunk_c * FIELD_RES_C + base.tile_c;
+    out_geom[2] = rdim; out_geom[3] = (chunk_r > 0) ? FIELD_RES_R / 2 : 0;
+    out_geom[4] = (chunk_c > 0) ? FIELD_RES_C / 2 : 0;
+    out_geom[5] = cdim;
+    size_t budget = (size_t)(M_PI * radius * radius + 0.5);
+    if(budget > (size_t)(rdim * cdim)) budget = rdim * cdim;
+    struct tile_desc *init = malloc(sizeof(struct tile_desc) * rdim * cdim);
+    size_t ninit = field_zone_initial_frontier(&zone, priv, base, rdim, cdim, layer, init, budget);
+    int n = 0;
+    for(size_t i = 0; i < ninit && n < max_seeds; i++, n++) {
+        out_seeds[2 * n] = (int16_t)(init[i].chunk_r * FIELD_RES_R + init[i].tile_r);
+        out_seeds[2 * n + 1] = (int16_t)(init[i].chunk_c * FIELD_RES_C + init[i].tile_c);
+    }
+    free(init);
+    return n;
+}
+
 struct bench_arg{
     const struct nav_private *priv;
     const pfref_field_req    *reqs;

@@ -361,6 +361,73 @@ int navhip_clear_changed(navhip_ctx *ctx, void *stream)
 }
 
 // ---------------------------------------------------------------------------------------------
+// region fields
+// ---------------------------------------------------------------------------------------------
+int navhip_build_region_fields_dev(navhip_ctx *ctx, const navhip_region_req *dev_reqs, int n,
+                                   int max_dim, const int16_t *dev_seeds, const int16_t *dev_overlay,
+                                   uint8_t *dev_inout, size_t out_stride, void *stream)
+{
+    if(!ctx || n < 0 || (n > 0 && (!dev_reqs || !dev_inout)) || max_dim < 2 || max_dim > 128)
+        return NAVHIP_ERR_INVALID;
+    if(n == 0) return NAVHIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    nh_launch_region_fields(ctx, dev_reqs, n, max_dim, dev_seeds, dev_overlay, dev_inout, out_stride, s);
+    HIPCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_build_region_fields(navhip_ctx *ctx, const navhip_region_req *reqs, int n,
+                               const int16_t *seeds, size_t n_seeds,
+                               const int16_t *overlay, size_t n_overlay,
+                               uint8_t *inout, size_t out_stride)
+{
+    if(!ctx || n < 0 || (n > 0 && (!reqs || !inout))) return NAVHIP_ERR_INVALID;
+    if(n == 0) return NAVHIP_OK;
+    int max_dim = 0;
+    bool any_window = false;
+    for(int i = 0; i < n; i++) {
+        const navhip_region_req &r = reqs[i];
+        bool ok = r.layer < NAVHIP_NAV_LAYER_MAX && r.out_mode <= 1 && r.rdim == r.cdim
+               && r.rdim >= 2 && r.rdim <= 128 && (r.rdim % 2) == 0
+               && (size_t)r.seed_begin + r.seed_count <= n_seeds
+               && (size_t)r.overlay_begin + r.overlay_count <= n_overlay
+               && (r.seed_count == 0 || seeds) && (r.overlay_count == 0 || overlay);
+        if(ok && r.out_mode == 1)
+            ok = r.roff + (r.rdim < 64 ? r.rdim : 64) <= r.rdim && r.coff + (r.cdim < 64 ? r.cdim : 64) <= r.cdim
+              && out_stride >= NH_CELLS;
+        if(ok && r.out_mode == 0) ok = out_stride >= (size_t)r.rdim * r.cdim / 2;
+        if(!ok) {
+            ctx->last_error = "navhip_build_region_fields: malformed request " + std::to_string(i);
+            return NAVHIP_ERR_INVALID;
+        }
+        if(!ctx->layers[r.layer].cost) return NAVHIP_ERR_NOT_UPLOADED;
+        max_dim = r.rdim > max_dim ? r.rdim : max_dim;
+        any_window |= r.out_mode == 1;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc = ensure_buf(ctx, ctx->stage[32], (size_t)n * sizeof(navhip_region_req));
+    if(!rc) rc = ensure_buf(ctx, ctx->stage[33], n_seeds * 4);
+    if(!rc) rc = ensure_buf(ctx, ctx->stage[34], n_overlay * 4);
+    if(!rc) rc = ensure_buf(ctx, ctx->stage[35], (size_t)n * out_stride);
+    if(rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[32].p, reqs, (size_t)n * sizeof(navhip_region_req),
+                               hipMemcpyHostToDevice, s));
+    if(n_seeds) HIPCHK(ctx, hipMemcpyAsync(ctx->stage[33].p, seeds, n_seeds * 4, hipMemcpyHostToDevice, s));
+    if(n_overlay) HIPCHK(ctx, hipMemcpyAsync(ctx->stage[34].p, overlay, n_overlay * 4, hipMemcpyHostToDevice, s));
+    if(any_window)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->stage[35].p, inout, (size_t)n * out_stride, hipMemcpyHostToDevice, s));
+    rc = navhip_build_region_fields_dev(ctx, (const navhip_region_req*)ctx->stage[32].p, n, max_dim,
+                                        (const int16_t*)ctx->stage[33].p, (const int16_t*)ctx->stage[34].p,
+                                        (uint8_t*)ctx->stage[35].p, out_stride, s);
+    if(rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(inout, ctx->stage[35].p, (size_t)n * out_stride, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // LOS fields
 // ---------------------------------------------------------------------------------------------
 int navhip_build_los_dev(navhip_ctx *ctx, const navhip_los_req *dev_reqs, int n,

@@ -45,7 +45,7 @@ struct navhip_ctx {
     buf          sp[10];       // spatial hash: ent_ix, ent_iy, ent_cell, cell_count, cell_fill,
                                //               cell_start, sorted_id, sx, sy, block_sum
     buf          coh;          // cohesion force per entity
-    buf          stage[32];    // device copies of host buffers for the host-pointer entry points
+    buf          stage[36];    // device copies of host buffers for the host-pointer entry points
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];
     hipEvent_t   ev_fork, ev_join[2];
@@ -67,6 +67,9 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
 void nh_launch_blockers_circles(navhip_ctx *ctx, const navhip_circle *d_circles, int n, float map_x,
                                 float map_z, hipStream_t s);
 void nh_launch_local_islands(navhip_ctx *ctx, int layer, hipStream_t s);
+void nh_launch_region_fields(navhip_ctx *ctx, const navhip_region_req *d_reqs, int n, int max_dim,
+                             const int16_t *d_seeds, const int16_t *d_overlay, uint8_t *d_out,
+                             size_t out_stride, hipStream_t s);
 void nh_launch_los(navhip_ctx *ctx, const navhip_los_req *d_reqs, int n, const uint8_t *d_prev,
                    uint8_t *d_out, float map_x, float map_z, hipStream_t s);
 

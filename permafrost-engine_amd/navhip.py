@@ -52,6 +52,14 @@ LOS_REQ_DTYPE = np.dtype([("layer", np.uint8), ("faction_id", np.uint8), ("enemi
                           ("prev_dr", np.int8), ("prev_dc", np.int8)])
 assert LOS_REQ_DTYPE.itemsize == 16
 
+# navhip_region_req, include/navhip.h (32 bytes)
+REGION_REQ_DTYPE = np.dtype([("layer", np.uint8), ("out_mode", np.uint8), ("enemies", np.uint16),
+                             ("base_abs_r", np.int16), ("base_abs_c", np.int16),
+                             ("rdim", np.uint16), ("cdim", np.uint16), ("roff", np.uint16),
+                             ("coff", np.uint16), ("seed_begin", np.uint32), ("seed_count", np.uint32),
+                             ("overlay_begin", np.uint32), ("overlay_count", np.uint32)])
+assert REGION_REQ_DTYPE.itemsize == 32
+
 # exported symbols, checked by the CPU test-suite against include/navhip.h
 _SIGS = {
     "navhip_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
@@ -71,6 +79,10 @@ _SIGS = {
     "navhip_relabel_local_islands": (C.c_int, [C.c_void_p, C.c_int]),
     "navhip_changed_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "navhip_clear_changed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "navhip_build_region_fields": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "navhip_build_region_fields_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "navhip_build_los": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_float, C.c_float]),
     "navhip_build_los_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -224,6 +236,26 @@ class NavContext:
                                             _hp(integ) if want_integ else None),
                   "navhip_build_fields")
         return dirs, integ
+
+    def build_region_fields(self, reqs, seeds, overlay=None, inout=None, out_stride=None):
+        """Region flow fields (N_CellArrivalFieldCreate / N_GroupArrivalFieldCreate in mode 0, the
+        padded-region builders behind TARGET_ENEMIES / ENTITY / ZONE in mode 1).  seeds / overlay:
+        [k, 2] int16 absolute (row, col) tiles.  Returns [n, out_stride] u8."""
+        reqs = np.ascontiguousarray(reqs, dtype=REGION_REQ_DTYPE)
+        n = len(reqs)
+        seeds = np.ascontiguousarray(seeds, np.int16).reshape(-1, 2)
+        ov = np.zeros((0, 2), np.int16) if overlay is None else \
+            np.ascontiguousarray(overlay, np.int16).reshape(-1, 2)
+        if out_stride is None:
+            out_stride = 8192
+        buf = np.zeros((n, out_stride), np.uint8)
+        if inout is not None:
+            a = np.asarray(inout, np.uint8).reshape(n, -1)
+            buf[:, :a.shape[1]] = a
+        self._chk(lib().navhip_build_region_fields(self._h, _hp(reqs), n, _hp(seeds), len(seeds),
+                                                   _hp(ov), len(ov), _hp(buf), out_stride),
+                  "navhip_build_region_fields")
+        return buf
 
     def N_LOSFieldCreate(self, reqs, prev=None):
         """Batched N_LOSFieldCreate (field.c:2085).  reqs: LOS_REQ_DTYPE; prev: [n,64,64] u8 previous

@@ -325,3 +325,67 @@ def los_reqs_to(dtype, reqs):
         for k, v in r.items():
             out[k][i] = v
     return out
+
+
+def region_cases(nav, grid, seed, n_each=6, dim=96):
+    """Region-field requests with the reference's answers: cell arrival (one target), group arrival
+    (many targets, world-space) and zone fields (seeds from the reference's own zone frontier).
+    Returns (request dicts, seeds [k,2] i16, overlay [k,2] i16, inout [n,8192] u8, expected [n,8192])."""
+    rng = np.random.RandomState(seed)
+    h, w = grid.shape[0] // 64, grid.shape[1] // 64
+    cells = synth.passable_cells(grid)
+    reqs, seeds, overlay, inout, exp = [], [], [], [], []
+
+    def push(req, sd, ov, io, ex):
+        req = dict(req, seed_begin=sum(len(x) for x in seeds), seed_count=len(sd),
+                   overlay_begin=sum(len(x) for x in overlay), overlay_count=len(ov))
+        reqs.append(req); seeds.append(np.asarray(sd, np.int16).reshape(-1, 2))
+        overlay.append(np.asarray(ov, np.int16).reshape(-1, 2))
+        a = np.zeros(8192, np.uint8); a[:len(io)] = io; inout.append(a)
+        b = np.zeros(8192, np.uint8); b[:len(ex)] = ex; exp.append(b)
+
+    for k in range(n_each):                               # N_CellArrivalFieldCreate
+        cen = cells[rng.randint(len(cells))]
+        tgt = np.clip(cen + rng.randint(-40, 41, 2), 0, [h * 64 - 1, w * 64 - 1])
+        base = cen - dim // 2                              # field.c:2475-2488
+        base = np.where(tgt - base >= dim, tgt - (dim - 1), base)
+        ov = np.zeros((0, 2), np.int16)
+        if k % 2:
+            ov = np.clip(cen + rng.randint(-30, 31, (25, 2)), 0, [h * 64 - 1, w * 64 - 1]).astype(np.int16)
+        ex = nav.cell_arrival_field(dim, tgt, cen, blocked=ov if len(ov) else None)
+        push(dict(out_mode=0, base_abs_r=int(base[0]), base_abs_c=int(base[1]), rdim=dim, cdim=dim),
+             [tgt], ov, np.zeros(0, np.uint8), ex)
+    for k in range(n_each):                               # N_GroupArrivalFieldCreate
+        cen = cells[rng.randint(len(cells))]
+        tg = cells[rng.randint(len(cells), size=40)]
+        tg = tg[(np.abs(tg - cen).max(1) < 60)]
+        tg = np.concatenate([tg, np.clip(cen + rng.randint(-20, 21, (6, 2)), 0, [h * 64 - 1, w * 64 - 1])])
+        txz = synth.cell_centre(w, h, tg[:, 0], tg[:, 1])
+        cxz = synth.cell_centre(w, h, cen[0], cen[1])
+        base = cen - dim // 2
+        inside = ((tg - base >= 0) & (tg - base < dim)).all(1)
+        ex = nav.group_arrival_field(dim, txz, cxz)
+        push(dict(out_mode=0, base_abs_r=int(base[0]), base_abs_c=int(base[1]), rdim=dim, cdim=dim),
+             tg[inside], np.zeros((0, 2), np.int16), np.zeros(0, np.uint8), ex)
+    for k in range(n_each):                               # TARGET_ZONE chunk fields
+        cen = cells[rng.randint(len(cells))]
+        chunk = (int(cen[0]) // 64, int(cen[1]) // 64)
+        if k % 2:                                         # a neighbouring chunk's field of the same zone
+            nb = (min(max(chunk[0] + rng.randint(-1, 2), 0), h - 1), min(max(chunk[1] + rng.randint(-1, 2), 0), w - 1))
+            chunk = nb
+        existing = rng.randint(0, 9, (64, 64)).astype(np.uint8)
+        ex, sd, g = nav.zone_field(chunk, cen, int(rng.randint(3, 14)), existing)
+        push(dict(out_mode=1, base_abs_r=g["base_abs_r"], base_abs_c=g["base_abs_c"], rdim=g["rdim"],
+                  cdim=g["cdim"], roff=g["roff"], coff=g["coff"]), sd, np.zeros((0, 2), np.int16),
+             existing.reshape(-1), ex.reshape(-1))
+    S = np.concatenate(seeds) if seeds else np.zeros((0, 2), np.int16)
+    O = np.concatenate(overlay) if overlay else np.zeros((0, 2), np.int16)
+    return reqs, S, O, np.stack(inout), np.stack(exp)
+
+
+def region_reqs_to(dtype, reqs):
+    out = np.zeros(len(reqs), dtype)
+    for i, r in enumerate(reqs):
+        for k, v in r.items():
+            out[k][i] = v
+    return out

@@ -90,3 +90,20 @@ def test_los_fields_match_reference(navlib, seed, blk):
     bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exps[i])]
     assert not bad, "LOS fields differ: %s" % bad[:8]
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,blk", [(4, False), (9, True)])
+def test_region_fields_match_reference(navlib, seed, blk):
+    """N_CellArrivalFieldCreate / N_GroupArrivalFieldCreate (96x96, 4-bit packed) and TARGET_ZONE
+    chunk fields (128x128 padded region, 64x64 window in place) through the region-field builder."""
+    grid = cases.synth.cost_grid(3, 3, seed=80 + seed, frac_impassable=0.2)
+    blockers = cases.random_blockers(grid, seed=seed, frac=0.03) if blk else None
+    grid, nav = cases.ref_nav_for(3, 3, seed=80 + seed, blockers=blockers)
+    reqs, S, O, inout, exp = cases.region_cases(nav, grid, seed)
+    ctx = navlib.NavContext(3, 3)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(0))
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(1))
+    got = ctx.build_region_fields(cases.region_reqs_to(navlib.REGION_REQ_DTYPE, reqs), S, O, inout=inout)
+    bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exp[i])]
+    assert not bad, "region fields differ: %s" % [(i, reqs[i]["out_mode"]) for i in bad[:8]]
+    ctx.close()

@@ -353,3 +353,20 @@ def test_los_restatement_matches_reference(seed, blk):
     assert not bad, "LOS fields differ: %s" % bad[:8]
     assert (exps & 1).mean() > 0.01 and (exps & 2).any()       # something visible, some lines drawn
     assert sum(1 for r in reqs if r["prev_dr"] or r["prev_dc"]) > 10
+
+
+# ---------------------------------------------------------------------------------------------
+# region fields (cell / group arrival, zone)
+# ---------------------------------------------------------------------------------------------
+@needs_ref
+@pytest.mark.parametrize("seed,blk", [(4, False), (9, True)])
+def test_region_fields_restatement_matches_reference(seed, blk):
+    grid = cases.synth.cost_grid(3, 3, seed=80 + seed, frac_impassable=0.2)
+    blockers = cases.random_blockers(grid, seed=seed, frac=0.03) if blk else None
+    grid, nav = cases.ref_nav_for(3, 3, seed=80 + seed, blockers=blockers)
+    reqs, S, O, inout, exp = cases.region_cases(nav, grid, seed)
+    got = cases.oracle_nav_from_ref(nav).build_region_fields(
+        cases.region_reqs_to(navoracle.REGION_REQ_DTYPE, reqs), S, O, inout=inout)
+    bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exp[i])]
+    assert not bad, "region fields differ: %s" % [(i, reqs[i]["out_mode"]) for i in bad[:8]]
+    assert (exp != 0).mean() > 0.2
