@@ -6,7 +6,12 @@ import pytest
 from oracle import pfref
 from tests import cases
 
-pytestmark = pytest.mark.gpu
+from oracle import pfref as _pfref
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not _pfref.available(),
+                                 reason="oracle/_ref (the reference build) is not present; the golden-"
+                                        "fixture and restatement GPU tests cover the same paths")]
 
 REL_TOL = 1e-4      # BASELINE.json: agent velocities within 1e-4 relative
 

@@ -5,7 +5,12 @@ import pytest
 
 from tests import cases
 
-pytestmark = pytest.mark.gpu
+from oracle import pfref as _pfref
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not _pfref.available(),
+                                 reason="oracle/_ref (the reference build) is not present; the golden-"
+                                        "fixture and restatement GPU tests cover the same paths")]
 
 
 def _check(navlib, grid, nav, reqs, before, mode, blockers=None):
