@@ -560,22 +560,62 @@ __device__ __forceinline__ void make_hrvo(const cpent &ent, const cpent &nb, v2 
 }
 
 // inside_pcr, clearpath.c:249.  rays[] live in LDS as float4 {point.x, point.z, dir.x, dir.z}.
+//
+// One cone, evaluated exactly as the reference does (two normalisations with IEEE sqrt/divide):
+// true when `test` is strictly inside the cone spanned by rays[i] (left) and rays[i+1] (right).
+__device__ __forceinline__ bool cone_contains_exact(float4 L, float4 R, v2 test)
+{
+    v2 ptt = mkv(test.x - L.x, test.z - L.y);
+    if(vlen(ptt) < CP_EPS) return false;
+    ptt = vnormal(ptt);
+    float left_det = (ptt.z * L.z) - (ptt.x * L.w);
+    if(left_det < CP_EPS) return false;
+    ptt = mkv(test.x - R.x, test.z - R.y);
+    if(vlen(ptt) < CP_EPS) return false;
+    ptt = vnormal(ptt);
+    float right_det = (ptt.z * R.z) - (ptt.x * R.w);
+    if(right_det > -CP_EPS) return false;
+    return true;
+}
+
+// The same verdict from cheap arithmetic (one v_rsq_f32 instead of a correctly rounded sqrt and two
+// IEEE divides per side) whenever every comparison is decided with a safety margin; 2 = too close
+// to a threshold, the caller falls back to the exact evaluation.  The exact determinant differs
+// from (p.z*d.x - p.x*d.z)/|p| by < 4e-7 (six roundings of magnitudes <= 1) and the cheap one by
+// < 1.5e-6, so a margin of 2e-5 around the +-1/1024 thresholds leaves an order of magnitude of
+// slack; the |p| < 1/1024 test gets a relative margin of 1e-4.  The decisions -- hence the result
+// of inside_pcr -- are identical to the exact evaluation by construction.
+__device__ __forceinline__ int cone_contains_fast(float4 L, float4 R, v2 test)
+{
+    const float MARG = 2e-5f;
+    float px = test.x - L.x, pz = test.z - L.y;
+    float s = px * px + pz * pz;
+    float inv = __builtin_amdgcn_rsqf(s);
+    float len = s * inv;
+    if(!(s > 0.0f) || !(s < 1e30f) || fabsf(len - CP_EPS) <= CP_EPS * 1e-4f) return 2;
+    if(len < CP_EPS) return 0;
+    float det = (pz * L.z - px * L.w) * inv;
+    if(fabsf(det - CP_EPS) <= MARG) return 2;
+    if(det < CP_EPS) return 0;
+    px = test.x - R.x; pz = test.z - R.y;
+    s = px * px + pz * pz;
+    inv = __builtin_amdgcn_rsqf(s);
+    len = s * inv;
+    if(!(s > 0.0f) || !(s < 1e30f) || fabsf(len - CP_EPS) <= CP_EPS * 1e-4f) return 2;
+    if(len < CP_EPS) return 0;
+    det = (pz * R.z - px * R.w) * inv;
+    if(fabsf(det + CP_EPS) <= MARG) return 2;
+    if(det > -CP_EPS) return 0;
+    return 1;
+}
+
 __device__ __forceinline__ bool inside_pcr(const float4 *rays, int n_rays, v2 test)
 {
     for(int i = 0; i < n_rays; i += 2) {
-        float4 L = rays[i];
-        v2 ptt = mkv(test.x - L.x, test.z - L.y);
-        if(vlen(ptt) < CP_EPS) continue;
-        ptt = vnormal(ptt);
-        float left_det = (ptt.z * L.z) - (ptt.x * L.w);
-        if(left_det < CP_EPS) continue;
-        float4 R = rays[i + 1];
-        ptt = mkv(test.x - R.x, test.z - R.y);
-        if(vlen(ptt) < CP_EPS) continue;
-        ptt = vnormal(ptt);
-        float right_det = (ptt.z * R.z) - (ptt.x * R.w);
-        if(right_det > -CP_EPS) continue;
-        return true;
+        const float4 L = rays[i], R = rays[i + 1];
+        int v = cone_contains_fast(L, R, test);
+        if(v == 2) v = cone_contains_exact(L, R, test) ? 1 : 0;
+        if(v == 1) return true;
     }
     return false;
 }

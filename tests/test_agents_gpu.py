@@ -60,7 +60,7 @@ def test_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread):
     assert nbad == 0, "%d/%d ClearPath results off (max rel %.3g, first %s)" % (
         nbad, nq, np.nanmax(err), np.flatnonzero(~(err <= REL_TOL))[:5])
     exact = np.array_equal(got.view(np.uint32)[~both_nan], exp.view(np.uint32)[~both_nan])
-    print("bit-exact:", exact)
+    assert exact, "ClearPath velocities are within tolerance but no longer bit-identical"
 
 
 def _upload(navlib, nav):
@@ -100,7 +100,8 @@ def test_velocity_step_matches_reference(navlib, clustered, n, k, blk):
     nbad = int((~(err <= REL_TOL)).sum())
     assert nbad == 0, "%d/%d velocities off (max rel %.3g)" % (nbad, int(moving.sum()), np.nanmax(err))
     assert np.all(out["vel_xz"][~moving] == 0)
-    print("bit-exact fraction:", float((out["vel_xz"][moving] == exp_vel[moving]).all(1).mean()))
+    exact_frac = float((out["vel_xz"][moving] == exp_vel[moving]).all(1).mean())
+    assert exact_frac == 1.0, "velocities within tolerance but only %.4f bit-identical" % exact_frac
     # position accept test vs N_PositionPathable / N_PositionBlocked
     for uid in np.flatnonzero(moving)[:200]:
         v = exp_vel[uid]
