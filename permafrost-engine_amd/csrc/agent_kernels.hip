@@ -994,28 +994,25 @@ __device__ __forceinline__ v2 nullify_impass(const nh_step_params &P, int layer,
 // at the start of the step instead of one dependent load after another.
 struct tile_probes { bool path[5], blk[5]; };     // 0 self, 1 x+4, 2 x-4, 3 z+4, 4 z-4
 
+// Lanes 0..4 each resolve one probe (tile lookup + two loads); two ballots hand the ten booleans
+// to every lane -- a fifth of the instructions of doing the five lookups one after another.
 __device__ __forceinline__ tile_probes probe_tiles(const nh_step_params &P, int layer, v2 pos)
 {
-    const float px[5] = {pos.x, pos.x + 4.0f, pos.x - 4.0f, pos.x, pos.x};
-    const float pz[5] = {pos.z, pos.z, pos.z, pos.z + 4.0f, pos.z - 4.0f};
-    tile_probes T;
-    uint32_t cst[5], blk[5];
-    bool ok[5];
-    const uint8_t *cost = P.map.layers[layer].cost;
+    const int lane = threadIdx.x & 63;
+    const int k = lane < 5 ? lane : 0;
+    const float px = pos.x + (k == 1 ? 4.0f : k == 2 ? -4.0f : 0.0f);
+    const float pz = pos.z + (k == 3 ? 4.0f : k == 4 ? -4.0f : 0.0f);
+    tiledesc t;
+    const bool ok = tile_for_point(P, px, pz, t);
+    const size_t idx = ok ? ((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c : 0;
     const uint16_t *bl = P.map.layers[layer].blockers;
+    const uint32_t cst = P.map.layers[layer].cost[idx];
+    const uint32_t blk = bl ? bl[idx] : 0;
+    const uint64_t mp = __ballot(ok && cst != NAVHIP_COST_IMPASSABLE);
+    const uint64_t mb = __ballot(ok && blk > 0);
+    tile_probes T;
 #pragma unroll
-    for(int i = 0; i < 5; i++) {
-        tiledesc t;
-        ok[i] = tile_for_point(P, px[i], pz[i], t);
-        size_t idx = ok[i] ? ((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c : 0;
-        cst[i] = cost[idx];
-        blk[i] = bl ? bl[idx] : 0;
-    }
-#pragma unroll
-    for(int i = 0; i < 5; i++) {
-        T.path[i] = ok[i] && cst[i] != NAVHIP_COST_IMPASSABLE;
-        T.blk[i] = ok[i] && blk[i] > 0;
-    }
+    for(int i = 0; i < 5; i++) { T.path[i] = (mp >> i) & 1; T.blk[i] = (mb >> i) & 1; }
     return T;
 }
 
@@ -1083,11 +1080,15 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
                           int n30raw, uint32_t *out, int lane)
 {
     if(n30raw >= 128) return -1;
-    const int32_t icx = bg_scale(me.x), icy = bg_scale(me.z);
-    sp_extent E30, E10;
-    const bool ok30 = sp_query_extent(G, icx, icy, bg_scale(30.0f), E30);
-    const bool ok10 = sp_query_extent(G, icx, icy, bg_scale(10.0f), E10);
-    if(!ok30 || !ok10 || E30.wide != E10.wide) return -1;
+    // an r=30 box covers at most 5x5 cells: on a grid of more than 33 cells neither query can take
+    // the wide path (25 * 4 < 34 * 3) and both scan in block order
+    if((int64_t)G.grid_w * G.grid_h <= 33) {
+        const int32_t icx = bg_scale(me.x), icy = bg_scale(me.z);
+        sp_extent E30, E10;
+        const bool ok30 = sp_query_extent(G, icx, icy, bg_scale(30.0f), E30);
+        const bool ok10 = sp_query_extent(G, icx, icy, bg_scale(10.0f), E10);
+        if(!ok30 || !ok10 || E30.wide != E10.wide) return -1;
+    }
     const int32_t ir10 = bg_scale(10.0f);
     const int32_t lim = ir10 * ir10;
     int written = 0;
@@ -1278,9 +1279,18 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
     if(active) {
         const int layer = nav_layer_for(my_flags, my_radius);
         v2 cand = vadd(me, out_vel);
-        bool on_blocked = pos_blocked(P, layer, me.x, me.z);     // (L2-hot: probed at the start)
-        if(vlen(out_vel) > 0 && pos_pathable(P, layer, cand.x, cand.z)
-        && (on_blocked || !pos_blocked(P, layer, cand.x, cand.z))) {
+        const bool on_blocked = pos_blocked(P, layer, me.x, me.z);
+        bool cand_path = false, cand_blk = false;
+        {
+            tiledesc t;
+            if(tile_for_point(P, cand.x, cand.z, t)) {               // one lookup, two planes
+                const size_t idx = ((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c;
+                const uint16_t *bl = P.map.layers[layer].blockers;
+                cand_path = P.map.layers[layer].cost[idx] != NAVHIP_COST_IMPASSABLE;
+                cand_blk = bl && bl[idx] > 0;
+            }
+        }
+        if(vlen(out_vel) > 0 && cand_path && (on_blocked || !cand_blk)) {
             new_pos = cand;
             status |= NAVHIP_ST_MOVED;
         }
