@@ -797,107 +797,206 @@ __device__ __forceinline__ float exp_f32_via_f64(float a, const double *tab)
     return (a <= -103.98f) ? 0.0f : res;
 }
 
-// cohesion weight of one flock member seen from `me` (movement.c:1668-1671)
-__device__ __forceinline__ float cohesion_scale(v2 cp, v2 me, const double *tab)
+// exp for the cohesion weights with as few f64 conversions as possible (they and v_ldexp_f64 issue
+// at quarter rate): the reduction index comes from an f32 product (any nearby index works, the
+// remainder is still < 0.0055), the final scaling by 2^(k>>6) is an integer add on the exponent
+// field (the result stays a normal double for every argument in [-104, 89]).
+__device__ __forceinline__ float exp_f32_lowconv(float a, const double *tab)
 {
-    const v2 diff = vsub(cp, me);
-    // float t = (len - 50.0f*0.75) / 50.0f, evaluated in double: the division by 50 as reciprocal
-    // multiply + one FMA correction (Markstein), correctly rounded for this divisor
-    const double r50 = 1.0 / 50.0;
-    const double x = (double)vlen(diff) - (double)50.0f * 0.75;
-    const double q0 = x * r50;
-    const double tq = __builtin_fma(__builtin_fma(-q0, 50.0, x), r50, q0);
-    return exp_f32_via_f64(-6.0f * (float)tq, tab);
+    const float ac = fmaxf(a, -104.0f);
+    const float kf = __builtin_rintf(ac * 0x1.715476p+6f);               // 64/ln2
+    const int k = (int)kf;
+    const double x = (double)ac, kd = (double)kf;
+    double r = __builtin_fma(-kd, 0x1.62e42fefa0000p-7, x);              // ln2/64, high part
+    r = __builtin_fma(-kd, 0x1.cf79abc9e3b3ap-46, r);                    //         low part
+    double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
+    p = __builtin_fma(p, r, 1.0 / 6);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double v = tab[k & 63] * p;
+    const long long bits = __double_as_longlong(v) + ((long long)(k >> 6) << 52);
+    const float res = (float)__longlong_as_double(bits);
+    return (a <= -103.98f) ? 0.0f : res;
 }
 
-// k_cohesion: 256 consecutive CSR entries (flock members) per workgroup, thread = member.
-// The flock's member positions are staged through LDS 256 at a time (coalesced gather) and every
-// thread walks them IN MEMBER ORDER (float sums are order dependent; LDS reads are wave-uniform
-// broadcasts), so the only global traffic in the O(N*F) loop is the staging itself.
-__global__ __launch_bounds__(256) void k_cohesion(nh_step_params P, float *coh_xz)
+// Correctly rounded sqrt for s == 0 or s in the normal range well away from its ends: v_sqrt_f32
+// (<= 1 ulp) plus the same one-ulp fix-up the compiler's IEEE expansion uses, without that
+// expansion's input scaling / class handling (which only matter for denormal, infinite or NaN s).
+__device__ __forceinline__ float sqrt_rn_normal(float s)
+{
+    float r = __builtin_amdgcn_sqrtf(s);
+    const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
+    const float em = __builtin_fmaf(-rm, r, s), ep = __builtin_fmaf(-rp, r, s);
+    r = (em <= 0.0f) ? rm : r;
+    r = (ep > 0.0f) ? rp : r;
+    return r;
+}
+
+// float t = (len - 50.0f*0.75) / 50.0f of movement.c:1668 (the reference evaluates it in double and
+// rounds to float).  For len >= 16 the f32 subtraction is exact and the division by 50 as
+// reciprocal multiply + one FMA correction (Markstein) reproduces the double-then-float result for
+// EVERY float in [16, 8192) (checked exhaustively on the CPU); beyond that the weight is 0 anyway.
+__device__ __forceinline__ float cohesion_t_f32(float len)
+{
+    const float r50f = 1.0f / 50.0f;
+    const float x = len - 37.5f;
+    const float q0 = x * r50f;
+    return __builtin_fmaf(__builtin_fmaf(-q0, 50.0f, x), r50f, q0);
+}
+
+// the same through double, for len < 16 where the f32 subtraction may round
+__device__ __forceinline__ float cohesion_t_f64(float len)
+{
+    const double r50 = 1.0 / 50.0;
+    const double x = (double)len - (double)50.0f * 0.75;
+    const double q0 = x * r50;
+    return (float)__builtin_fma(__builtin_fma(-q0, 50.0, x), r50, q0);
+}
+
+// k_coh_plan: wave_off[f] = number of 64-member waves of the flocks before f (exclusive scan of
+// ceil(size/64)); one workgroup, chunked.
+__global__ __launch_bounds__(256) void k_coh_plan(const int32_t *flock_offsets, int n_flocks,
+                                                  int32_t *wave_off)
+{
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t carry;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if(t == 0) carry = 0;
+    __syncthreads();
+    for(int base = 0; base < n_flocks; base += 256) {
+        const int f = base + t;
+        int32_t v = 0;
+        if(f < n_flocks) v = (flock_offsets[f + 1] - flock_offsets[f] + 63) >> 6;
+        int32_t incl = v;
+#pragma unroll
+        for(int d = 1; d < 64; d <<= 1) {
+            int32_t o = __shfl_up(incl, d);
+            if(lane >= d) incl += o;
+        }
+        if(lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int32_t woff = 0;
+        for(int k = 0; k < w; k++) woff += wsum[k];
+        const int32_t excl = carry + woff + incl - v;
+        if(f < n_flocks) wave_off[f] = excl;
+        __syncthreads();
+        if(t == 255) carry = excl + v;
+        __syncthreads();
+    }
+    if(t == 0) wave_off[n_flocks] = carry;
+}
+
+// k_cohesion: one WAVE (= one 64-thread workgroup) per 64 consecutive members of ONE flock, thread =
+// member.  A wave never straddles two flocks (a straddling workgroup would walk two whole flocks and
+// become the tail of the launch).  The flock's member positions are staged through LDS 256 at a
+// time (coalesced gather) and every thread walks them IN MEMBER ORDER (float sums are order
+// dependent; LDS reads are wave-uniform broadcasts), so the only global traffic in the O(N*F) loop
+// is the staging itself.
+__global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off, float *coh_xz)
 {
     __shared__ double tab[64];
     __shared__ float2 spos[256];
     const int t = threadIdx.x;
-    const int total = P.flock_offsets[P.n_flocks];
-    const int g0 = blockIdx.x * 256;
-    if(g0 >= total) return;
-    if(t < 64) tab[t] = c_exp2_64[t];
-    const int g = g0 + t;
-    const int gend = min(g0 + 256, total);
-    // flock of the block's first entry: binary search over the CSR offsets (uniform)
+    const int wv = blockIdx.x;
+    if(wv >= wave_off[P.n_flocks]) return;
+    tab[t] = c_exp2_64[t];
+    // flock of this wave: binary search over the wave prefix (uniform)
     int f = 0;
     {
         int lo = 0, hi = P.n_flocks;
         while(hi - lo > 1) {
             int mid = (lo + hi) >> 1;
-            if(P.flock_offsets[mid] <= g0) lo = mid; else hi = mid;
+            if(wave_off[mid] <= wv) lo = mid; else hi = mid;
         }
         f = lo;
     }
     const float scaled_max_force = (float)((double)(0.75f / (float)P.hz) * 20.0);
-
-    for(;; f++) {
-        const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
-        const bool mine = g >= b && g < e && g < total;
-        const int uid = mine ? P.flock_members[g] : -1;
-        bool act = mine && uid >= P.work_begin && uid < P.work_end;
-        if(act) act = state_uses_point_seek(P.state[uid]) && !(P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD);
-        const v2 me = act ? mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
-        v2 com = mkv(0.0f, 0.0f);
-        if(__syncthreads_or(act)) {
-            for(int jb = b; jb < e; jb += 256) {
-                __syncthreads();
-                if(jb + t < e) {
-                    const int m = P.flock_members[jb + t];
-                    spos[t] = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
-                }
-                __syncthreads();
-                const int cnt = min(256, e - jb);
-                if(act) {
-                    // COH_U independent weight evaluations in flight (the chain sqrt -> double
-                    // divide -> exp is ~45 dependent instructions), then the ordered float sums
-                    constexpr int COH_U = 8;
-                    int jj = 0;
-                    for(; jj + COH_U <= cnt; jj += COH_U) {
-                        v2 cp[COH_U];
-                        float sc[COH_U];
+    const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
+    const int g = b + (wv - wave_off[f]) * 64 + t;
+    const bool mine = g < e;
+    const int uid = mine ? P.flock_members[g] : -1;
+    bool act = mine && uid >= P.work_begin && uid < P.work_end;
+    if(act) act = state_uses_point_seek(P.state[uid]) && !(P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD);
+    if(!__syncthreads_or(act)) return;
+    const v2 me = act ? mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
+    v2 com = mkv(0.0f, 0.0f);
+    for(int jb = b; jb < e; jb += 256) {
+        __syncthreads();
 #pragma unroll
-                        for(int u = 0; u < COH_U; u++) {
-                            const float2 c2 = spos[jj + u];
-                            cp[u] = mkv(c2.x, c2.y);
-                            sc[u] = cohesion_scale(cp[u], me, tab);
-                        }
-#pragma unroll
-                        for(int u = 0; u < COH_U; u++) {
-                            const v2 sum = vadd(com, vscale(cp[u], sc[u]));
-                            const bool self = (jb + jj + u == g);        // curr == uid: skipped
-                            com.x = self ? com.x : sum.x;
-                            com.z = self ? com.z : sum.z;
-                        }
-                    }
-                    for(; jj < cnt; jj++) {
-                        const float2 c2 = spos[jj];
-                        const v2 cp = mkv(c2.x, c2.y);
-                        const v2 sum = vadd(com, vscale(cp, cohesion_scale(cp, me, tab)));
-                        const bool self = (jb + jj == g);
-                        com.x = self ? com.x : sum.x;
-                        com.z = self ? com.z : sum.z;
-                    }
-                }
+        for(int q = 0; q < 4; q++) {
+            const int j = jb + q * 64 + t;
+            if(j < e) {
+                const int m = P.flock_members[j];
+                spos[q * 64 + t] = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
             }
         }
+        __syncthreads();
+        const int cnt = min(256, e - jb);
         if(act) {
-            const int count = (e - b) - 1;
-            v2 ret = mkv(0.0f, 0.0f);
-            if(count > 0) {
-                com = vscale(com, 1.0f / (float)count);
-                ret = vtrunc(vsub(com, me), scaled_max_force);
+            // COH_U independent weight evaluations in flight (the chain sqrt -> double
+            // divide -> exp is ~45 dependent instructions), then the ordered float sums
+            constexpr int COH_U = 8;
+            int jj = 0;
+            for(; jj + COH_U <= cnt; jj += COH_U) {
+                v2 cp[COH_U];
+                float ss[COH_U], ln[COH_U], tt[COH_U], sc[COH_U];
+                bool close = false, odd = false;
+#pragma unroll
+                for(int u = 0; u < COH_U; u++) {
+                    const float2 c2 = spos[jj + u];
+                    cp[u] = mkv(c2.x, c2.y);
+                    const v2 d = vsub(cp[u], me);
+                    ss[u] = d.x * d.x + d.z * d.z;
+                    ln[u] = sqrt_rn_normal(ss[u]);
+                    // outside [2^-90, 2^90] (or NaN) and not exactly 0: leave it to the
+                    // general IEEE expansion
+                    odd |= !(ss[u] >= 0x1p-90f && ss[u] <= 0x1p90f) && ss[u] != 0.0f;
+                }
+                if(__any(odd)) {
+#pragma unroll
+                    for(int u = 0; u < COH_U; u++) ln[u] = __builtin_sqrtf(ss[u]);
+                }
+#pragma unroll
+                for(int u = 0; u < COH_U; u++) {
+                    tt[u] = cohesion_t_f32(ln[u]);
+                    close |= ln[u] < 16.0f;
+                }
+                if(__any(close)) {                // rare unless the flock is one dense cluster
+#pragma unroll
+                    for(int u = 0; u < COH_U; u++)
+                        if(ln[u] < 16.0f) tt[u] = cohesion_t_f64(ln[u]);
+                }
+#pragma unroll
+                for(int u = 0; u < COH_U; u++)
+                    sc[u] = exp_f32_lowconv(-6.0f * tt[u], tab);
+#pragma unroll
+                for(int u = 0; u < COH_U; u++) {
+                    // curr == uid is skipped by the reference: a zero weight adds +-0, which
+                    // leaves the (never negative-zero) running sum unchanged
+                    const float w = (jb + jj + u == g) ? 0.0f : sc[u];
+                    com = vadd(com, vscale(cp[u], w));
+                }
             }
-            coh_xz[2 * uid] = ret.x;
-            coh_xz[2 * uid + 1] = ret.z;
+            for(; jj < cnt; jj++) {
+                const float2 c2 = spos[jj];
+                const v2 cp = mkv(c2.x, c2.y);
+                const float ln = vlen(vsub(cp, me));
+                const float tt = ln < 16.0f ? cohesion_t_f64(ln) : cohesion_t_f32(ln);
+                const float w = (jb + jj == g) ? 0.0f : exp_f32_lowconv(-6.0f * tt, tab);
+                com = vadd(com, vscale(cp, w));
+            }
         }
-        if(e >= gend) break;
+    }
+    if(act) {
+        const int count = (e - b) - 1;
+        v2 ret = mkv(0.0f, 0.0f);
+        if(count > 0) {
+            com = vscale(com, 1.0f / (float)count);
+            ret = vtrunc(vsub(com, me), scaled_max_force);
+        }
+        coh_xz[2 * uid] = ret.x;
+        coh_xz[2 * uid + 1] = ret.z;
     }
 }
 
@@ -1364,10 +1463,14 @@ void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial
                        S.sorted_id, S.ent_ix, S.ent_iy, S.sx, S.sy);
 }
 
-void nh_launch_cohesion(const nh_step_params &P, float *d_coh, hipStream_t s)
+void nh_launch_cohesion(const nh_step_params &P, int32_t *d_wave_off, float *d_coh, hipStream_t s)
 {
-    if(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0)
-        hipLaunchKernelGGL(k_cohesion, dim3((P.n_members + 255) / 256), dim3(256), 0, s, P, d_coh);
+    if(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0) {
+        hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, P.flock_offsets, P.n_flocks, d_wave_off);
+        // upper bound of the number of 64-member waves; surplus waves exit at once
+        const int nwaves = (P.n_members + 63) / 64 + P.n_flocks;
+        hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)d_wave_off, d_coh);
+    }
 }
 
 void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const nh_step_outs &O, hipStream_t s)

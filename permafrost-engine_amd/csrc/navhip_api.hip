@@ -93,6 +93,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->d_dirty_list = nullptr; ctx->d_dirty_cap = 0;
     memset(ctx->sp, 0, sizeof(ctx->sp));
     memset(&ctx->coh, 0, sizeof(ctx->coh));
+    memset(&ctx->coh_plan, 0, sizeof(ctx->coh_plan));
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
@@ -123,7 +124,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     hipFree(ctx->d_dirty_list);
     for(auto &b : ctx->sp) hipFree(b.p);
     for(auto &b : ctx->stage) hipFree(b.p);
-    hipFree(ctx->coh.p);
+    hipFree(ctx->coh.p); hipFree(ctx->coh_plan.p);
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
     for(auto &a : ctx->aux) if(a) hipStreamDestroy(a);
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -687,6 +688,7 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     rc = step_fill_params(ctx, w, &P);
     if(rc) return rc;
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
+    if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, ((size_t)w->n_flocks + 1) * sizeof(int32_t));
     if(rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
@@ -694,7 +696,7 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     rc = spatial_build(ctx, w, &P.grid, ctx->aux[0]);
     if(rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
-    nh_launch_cohesion(P, (float*)ctx->coh.p, ctx->aux[1]);
+    nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, ctx->aux[1]);
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
     HIPCHK(ctx, hipGetLastError());
     ctx->pre.valid = true;
@@ -750,8 +752,9 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(rc) return rc;
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
+    if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, ((size_t)w->n_flocks + 1) * sizeof(int32_t));
     if(rc) return rc;
-    nh_launch_cohesion(P, (float*)ctx->coh.p, s);
+    nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     nh_launch_agent_step(P, (float*)ctx->coh.p, O, s);
     if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], s)); ctx->ev_valid = true; }
