@@ -402,15 +402,18 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
     // and their candidates tested 64 at a time -- two dependent memory round trips per coarse row
     // instead of three per fine row.
     const int cxc_lo = E.cx_lo >> 3, cxc_hi = E.cx_hi >> 3, ncx = cxc_hi - cxc_lo + 1;
+    // squared distances fit 32 bits when the box is small (r = 30: |d| <= 7680 + 4095)
+    const bool small = ir <= 16000;
     for(int cyc = E.cy_lo >> 3; cyc <= (E.cy_hi >> 3); cyc++) {
         const int fy0 = max(cyc * 8, E.cy_lo), fy1 = min(cyc * 8 + 8, E.cy_hi + 1);
-        const int rows = fy1 - fy0, nseg = rows * ncx;
-        for(int sbase = 0; sbase < nseg; sbase += 64) {
-            // segment of this lane: block-column major, then fine row
-            const int sidx = sbase + lane;
+        const int rows = fy1 - fy0;                                   // 1..8
+        // 8 block columns x 8 rows per pass: lane = (block column << 3) | row, so the lane order is
+        // the visiting order and no division is needed
+        for(int cbase = 0; cbase < ncx; cbase += 8) {
+            const int cxi = cbase + (lane >> 3), fyi = lane & 7;
             int b = 0, len = 0;
-            if(sidx < nseg) {
-                const int cxc = cxc_lo + sidx / rows, fy = fy0 + sidx % rows;
+            if(cxi < ncx && fyi < rows) {
+                const int cxc = cxc_lo + cxi, fy = fy0 + fyi;
                 const int fx0 = max(cxc * 8, E.cx_lo), fx1 = min(cxc * 8 + 8, E.cx_hi + 1);
                 b = G.cell_start[fy * G.grid_w + fx0];
                 len = G.cell_start[fy * G.grid_w + fx1] - b;
@@ -423,27 +426,39 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
             }
             const int off = incl - len;
             const int total = __shfl(incl, 63);
-            const int nact = min(64, nseg - sbase);
+            if(total == 0) continue;
+            const uint64_t segmask = __ballot(len > 0);               // non-empty segments, in order
             for(int base = 0; base < total; base += 64) {
                 const int q = base + lane;
                 // candidate q -> (segment, position); every lane runs the shuffles (uniform loop)
                 int k = -1;
-                for(int sg = 0; sg < nact; sg++) {
+                for(uint64_t m = segmask; m; m &= m - 1) {
+                    const int sg = __builtin_ctzll(m);
                     const int so = __shfl(off, sg), sl = __shfl(len, sg), sb = __shfl(b, sg);
                     if(q < total && q >= so && q < so + sl) k = sb + (q - so);
                 }
                 bool hit = false;
-                int64_t d2 = 0;
+                int32_t d2s = 0;
                 if(k >= 0) {
-                    int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
-                    d2 = dx * dx + dy * dy;
-                    hit = d2 <= ir2;
+                    if(small) {
+                        // (elements clamped into a border cell may be far away: range-check before
+                        // squaring in 32 bits)
+                        const int32_t dx = G.sx[k] - icx, dy = G.sy[k] - icy;
+                        const bool near = (uint32_t)(dx + 32767) < 65535u && (uint32_t)(dy + 32767) < 65535u;
+                        d2s = near ? dx * dx + dy * dy : 0x7fffffff;
+                        hit = d2s <= (int32_t)ir2;
+                    }else{
+                        const int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
+                        const int64_t d2 = dx * dx + dy * dy;
+                        hit = d2 <= ir2;
+                        d2s = (int32_t)d2;
+                    }
                 }
                 uint64_t m = __ballot(hit);
                 int p = written + __popcll(m & ((1ull << lane) - 1ull));
                 if(hit && p < maxout) {
                     out_ids[p] = (uint32_t)G.sorted_id[k];
-                    if(out_d2) out_d2[p] = (int32_t)d2;
+                    if(out_d2) out_d2[p] = d2s;
                 }
                 written += __popcll(m);
                 if(written >= maxout) return maxout;
@@ -936,7 +951,7 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
         if(act) {
             // COH_U independent weight evaluations in flight (the chain sqrt -> double
             // divide -> exp is ~45 dependent instructions), then the ordered float sums
-            constexpr int COH_U = 8;
+            constexpr int COH_U = 16;
             int jj = 0;
             for(; jj + COH_U <= cnt; jj += COH_U) {
                 v2 cp[COH_U];
