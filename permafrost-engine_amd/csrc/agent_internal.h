@@ -47,7 +47,10 @@ struct nh_step_outs {
 void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
                              hipStream_t s);
 void nh_launch_cohesion(const nh_step_params &P, int32_t *d_wave_off, float *d_coh, hipStream_t s);
-void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const nh_step_outs &O, hipStream_t s);
+size_t nh_pre_rec_bytes();
+void nh_launch_agent_pre(const nh_step_params &P, void *d_pre, const nh_step_outs &O, hipStream_t s);
+void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const void *d_pre, const nh_step_outs &O,
+                          hipStream_t s);
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,
                              int32_t *d_counts, uint32_t *d_ids, hipStream_t s);
 void nh_launch_clearpath(int nq, const float *ent, const float *des_v, const float *dyn,

@@ -139,9 +139,8 @@ __device__ __forceinline__ v2 flow_dir_vec(int dir)           // N_FlowDir, fiel
     }
 }
 
-// All 64 lanes call this with the same arguments; lanes 0..3 each fetch one of the four taps (slot
-// lookup -> direction byte: two dependent loads in total instead of up to eight), the blend is then
-// evaluated by every lane in the reference's tap order.
+// One thread per agent (k_agent_pre): the four taps are fetched one after the other; the latency is
+// hidden by the other agents of the wave instead of by the other lanes of a wave-per-agent kernel.
 __device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &status)
 {
     tiledesc t;
@@ -149,9 +148,16 @@ __device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &
         status |= NAVHIP_ST_FIELD_MISS;
         return mkv(0.0f, 0.0f);
     }
-    const int lane = threadIdx.x & 63;
     const int nchunks = P.map.w * P.map.h;
     const int32_t *slots = P.flock_field_slot + (size_t)flock * nchunks;
+    int slot = slots[t.chunk_r * P.map.w + t.chunk_c];
+    if(slot < 0) {
+        status |= NAVHIP_ST_FIELD_MISS;
+        return mkv(0.0f, 0.0f);
+    }
+    const uint8_t *base_ff = P.field_pool + ((size_t)slot << 12);
+    int base_dir = base_ff[t.tile_r * 64 + t.tile_c] & 0xf;
+    if(base_dir == NAVHIP_FD_NONE) status |= NAVHIP_ST_FIELD_NONE;
 
     // M_Tile_Bounds (tile.c:356): two sequential float subtractions / additions
     float bx = (P.map_x - (float)(t.chunk_c * 256)) - (float)(t.tile_c * 4);
@@ -162,34 +168,28 @@ __device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &
     int dr = (dz > 0.0f) ? 1 : -1;
     float wc = fminf(fabsf(dx) / 4.0f, 1.0f);
     float wr = fminf(fabsf(dz) / 4.0f, 1.0f);
+    const int   sdc[4] = {0, dc, 0, dc};
+    const int   sdr[4] = {0, 0, dr, dr};
     const float sw[4]  = {(1.0f - wc) * (1.0f - wr), wc * (1.0f - wr), (1.0f - wc) * wr, wc * wr};
-
-    // tap of this lane (lanes >= 4 mirror tap 0 and are ignored): M_Tile_RelativeDesc, tile.c:391
-    const int tap = lane & 3;
-    const int abs_r = t.chunk_r * 64 + t.tile_r + ((tap & 2) ? dr : 0);
-    const int abs_c = t.chunk_c * 64 + t.tile_c + ((tap & 1) ? dc : 0);
-    int my_dir = -1;                                   // -1: off map / chunk field not cached
-    int my_slot = -1;
-    if(abs_r >= 0 && abs_r < P.map.h * 64 && abs_c >= 0 && abs_c < P.map.w * 64) {
-        my_slot = slots[(abs_r >> 6) * P.map.w + (abs_c >> 6)];
-        if(my_slot >= 0)
-            my_dir = P.field_pool[((size_t)my_slot << 12) + (abs_r & 63) * 64 + (abs_c & 63)] & 0xf;
-    }
-    const int base_slot = __shfl(my_slot, 0);
-    if(base_slot < 0) {
-        status |= NAVHIP_ST_FIELD_MISS;
-        return mkv(0.0f, 0.0f);
-    }
-    const int base_dir = __shfl(my_dir, 0);
-    if(base_dir == NAVHIP_FD_NONE) status |= NAVHIP_ST_FIELD_NONE;
 
     v2 acc = mkv(0.0f, 0.0f);
     float wsum = 0.0f;
 #pragma unroll
     for(int i = 0; i < 4; i++) {
-        const int dir = __shfl(my_dir, i);
         if(sw[i] <= 0.0f) continue;
-        if(dir <= NAVHIP_FD_NONE) continue;            // off map, not cached, or FD_NONE
+        // M_Tile_RelativeDesc, tile.c:391
+        int abs_r = t.chunk_r * 64 + t.tile_r + sdr[i];
+        int abs_c = t.chunk_c * 64 + t.tile_c + sdc[i];
+        if(abs_r < 0 || abs_r >= P.map.h * 64 || abs_c < 0 || abs_c >= P.map.w * 64) continue;
+        int cr = abs_r >> 6, cc = abs_c >> 6, tr = abs_r & 63, tc = abs_c & 63;
+        const uint8_t *ff = base_ff;
+        if(cr != t.chunk_r || cc != t.chunk_c) {
+            int s2 = slots[cr * P.map.w + cc];
+            if(s2 < 0) continue;
+            ff = P.field_pool + ((size_t)s2 << 12);
+        }
+        int dir = ff[tr * 64 + tc] & 0xf;
+        if(dir == NAVHIP_FD_NONE) continue;
         v2 scaled = vscale(flow_dir_vec(dir), sw[i]);
         acc = vadd(acc, scaled);
         wsum += sw[i];
@@ -1108,25 +1108,30 @@ __device__ __forceinline__ v2 nullify_impass(const nh_step_params &P, int layer,
 // at the start of the step instead of one dependent load after another.
 struct tile_probes { bool path[5], blk[5]; };     // 0 self, 1 x+4, 2 x-4, 3 z+4, 4 z-4
 
-// Lanes 0..4 each resolve one probe (tile lookup + two loads); two ballots hand the ten booleans
-// to every lane -- a fifth of the instructions of doing the five lookups one after another.
-__device__ __forceinline__ tile_probes probe_tiles(const nh_step_params &P, int layer, v2 pos)
+// One thread per agent (k_agent_pre): ten booleans packed as bits 0-4 pathable, 5-9 blocked.
+__device__ __forceinline__ uint32_t probe_tiles_bits(const nh_step_params &P, int layer, v2 pos)
 {
-    const int lane = threadIdx.x & 63;
-    const int k = lane < 5 ? lane : 0;
-    const float px = pos.x + (k == 1 ? 4.0f : k == 2 ? -4.0f : 0.0f);
-    const float pz = pos.z + (k == 3 ? 4.0f : k == 4 ? -4.0f : 0.0f);
-    tiledesc t;
-    const bool ok = tile_for_point(P, px, pz, t);
-    const size_t idx = ok ? ((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c : 0;
+    const float px[5] = {pos.x, pos.x + 4.0f, pos.x - 4.0f, pos.x, pos.x};
+    const float pz[5] = {pos.z, pos.z, pos.z, pos.z + 4.0f, pos.z - 4.0f};
+    const uint8_t *cost = P.map.layers[layer].cost;
     const uint16_t *bl = P.map.layers[layer].blockers;
-    const uint32_t cst = P.map.layers[layer].cost[idx];
-    const uint32_t blk = bl ? bl[idx] : 0;
-    const uint64_t mp = __ballot(ok && cst != NAVHIP_COST_IMPASSABLE);
-    const uint64_t mb = __ballot(ok && blk > 0);
+    uint32_t bits = 0;
+#pragma unroll
+    for(int i = 0; i < 5; i++) {
+        tiledesc t;
+        if(!tile_for_point(P, px[i], pz[i], t)) continue;
+        const size_t idx = ((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c;
+        if(cost[idx] != NAVHIP_COST_IMPASSABLE) bits |= 1u << i;
+        if(bl && bl[idx] > 0) bits |= 32u << i;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ tile_probes unpack_probes(uint32_t bits)
+{
     tile_probes T;
 #pragma unroll
-    for(int i = 0; i < 5; i++) { T.path[i] = (mp >> i) & 1; T.blk[i] = (mb >> i) & 1; }
+    for(int i = 0; i < 5; i++) { T.path[i] = (bits >> i) & 1; T.blk[i] = (bits >> (5 + i)) & 1; }
     return T;
 }
 
@@ -1218,8 +1223,97 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
     return written;
 }
 
+// What the scalar pre-pass hands to the wave-per-agent kernel (24 bytes per entity)
+enum { AM_IDLE = 0,        // still or combat held: velocity 0, no neighbour work
+       AM_ZERO_VPREF,      // turning / formation assignment not ready: vpref = 0, ClearPath still runs
+       AM_POINT_SEEK, AM_ENEMY_SEEK, AM_FORM_CELL, AM_FORM_POINT,
+       AM_UNSUPPORTED };   // formation state without formation inputs
+struct nh_pre_rec {
+    float    vdes[2];
+    float    arrive[2];    // the arrive term of the state's steering force, already truncated
+    uint16_t probes;       // probe_tiles_bits
+    uint8_t  status;
+    uint8_t  mode;
+    uint32_t pad;
+};
+static_assert(sizeof(nh_pre_rec) == 24, "nh_pre_rec");
+
+// k_agent_pre: one THREAD per entity.  Everything of move_velocity_work that needs no neighbour
+// list and is the same for all 64 lanes of a wave-per-agent kernel -- desired direction (flow-field
+// sampling), the arrive force of the state's steering behaviour, the five tile probes of
+// nullify_impass_components -- is evaluated here with all lanes busy.
+__global__ __launch_bounds__(256) void k_agent_pre(nh_step_params P, nh_pre_rec *pre, nh_step_outs O)
+{
+    const int uid = P.work_begin + blockIdx.x * 256 + threadIdx.x;
+    if(uid >= P.work_end) return;
+    const int state = P.state[uid];
+    const uint32_t my_flags = P.flags[uid];
+    nh_pre_rec R;
+    R.vdes[0] = R.vdes[1] = R.arrive[0] = R.arrive[1] = 0.0f;
+    R.probes = 0; R.status = 0; R.mode = AM_IDLE; R.pad = 0;
+    if(!state_is_still(state) && !(my_flags & NAVHIP_ENTITY_FLAG_COMBAT_HELD)) {
+        const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+        const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+        const float my_radius = P.radius[uid], max_speed = P.max_speed[uid];
+        const int flock = P.flock[uid], hz = P.hz;
+        const float scaled_max_force = (float)((double)(0.75f / (float)hz) * 20.0);   // SCALED_MAX_FORCE
+        const int layer = nav_layer_for(my_flags, my_radius);
+        uint32_t status = 0;
+        v2 vdes = mkv(0.0f, 0.0f), arrive = mkv(0.0f, 0.0f);
+        const bool form = state == NAVHIP_STATE_MOVING_IN_FORMATION || state == NAVHIP_STATE_ARRIVING_TO_CELL;
+        if(state == NAVHIP_STATE_TURNING) {
+            R.mode = AM_ZERO_VPREF;
+        }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_uses_point_seek(state)) {
+            vdes = load_vdes(P, uid, flock, me, status);
+            if(state_uses_point_seek(state)) {
+                const bool los = P.has_dest_los[uid] != 0;
+                const v2 target = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]) : me;
+                arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
+                R.mode = AM_POINT_SEEK;
+            }else{
+                // arrive_force_enemies, movement.c:1593
+                v2 desired = vscale(vdes, max_speed / (float)hz);
+                arrive = vtrunc(vsub(desired, vel), scaled_max_force);
+                R.mode = AM_ENEMY_SEEK;
+            }
+        }else if(P.form_ready && form) {
+            if(!P.form_ready[uid]) {
+                R.mode = AM_ZERO_VPREF;
+            }else{
+                vdes = load_vdes(P, uid, flock, me, status);
+                if(state == NAVHIP_STATE_ARRIVING_TO_CELL) {
+                    // arrive_force_cell :1574 (no velocity term, no truncation)
+                    const v2 cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
+                    v2 desired = vsub(cell, me);
+                    float distance = vlen(desired);
+                    if(distance < 10.0f) desired = vscale(desired, distance / 10.0f);
+                    else                 desired = vscale(vdes, max_speed / (float)hz);
+                    arrive = desired;
+                    R.mode = AM_FORM_CELL;
+                }else{
+                    const bool los = P.has_dest_los[uid] != 0;
+                    const v2 target = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]) : me;
+                    arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
+                    R.mode = AM_FORM_POINT;
+                }
+            }
+        }else{
+            R.mode = AM_UNSUPPORTED;
+            status |= NAVHIP_ST_UNSUPPORTED;
+        }
+        if(R.mode >= AM_POINT_SEEK && R.mode <= AM_FORM_POINT)
+            R.probes = (uint16_t)probe_tiles_bits(P, layer, me);
+        R.vdes[0] = vdes.x; R.vdes[1] = vdes.z; R.arrive[0] = arrive.x; R.arrive[1] = arrive.z;
+        R.status = (uint8_t)status;
+    }
+    pre[uid] = R;
+    if(O.vdes_xz) { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
+}
+
+// k_agent_step: one WAVE per entity -- the neighbour-dependent part: r = 30 query + separation,
+// the priority ladder of the steering force, r = 10 neighbours, ClearPath, truncation.
 __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const float *coh_xz,
-                                                    nh_step_outs O)
+                                                    const nh_pre_rec *pre, nh_step_outs O)
 {
     __shared__ wave_lds lds[AG_WAVES];
     __shared__ double exp_tab[64];
@@ -1230,34 +1324,25 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
     if(uid >= P.work_end) return;
     wave_lds &W = lds[wib];
 
-    const int state = P.state[uid];
-    const uint32_t my_flags = P.flags[uid];
-    const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-    const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-    const float my_radius = P.radius[uid];
-    const float max_speed = P.max_speed[uid];
-    const float speed = P.speed[uid];
-    const int flock = P.flock[uid];
-    const int hz = P.hz;
-    uint32_t status = 0;
-    v2 out_vel = mkv(0.0f, 0.0f), vdes = mkv(0.0f, 0.0f), vpref = mkv(0.0f, 0.0f);
-    bool active = !state_is_still(state);
-
-    if(active && !(my_flags & NAVHIP_ENTITY_FLAG_COMBAT_HELD)) {
+    const nh_pre_rec R = pre[uid];
+    v2 out_vel = mkv(0.0f, 0.0f), vpref = mkv(0.0f, 0.0f);
+    if(R.mode != AM_IDLE && R.mode != AM_UNSUPPORTED) {
+        const uint32_t my_flags = P.flags[uid];
+        const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+        const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+        const float my_radius = P.radius[uid];
+        const float max_speed = P.max_speed[uid];
+        const float speed = P.speed[uid];
+        const int flock = P.flock[uid];
+        const int hz = P.hz;
         const float scaled_max_force = (float)((double)(0.75f / (float)hz) * 20.0);   // SCALED_MAX_FORCE
         const double force_thresh = ((double)(0.75f / (float)hz) * 20.0) * 0.01;
-        const int layer = nav_layer_for(my_flags, my_radius);
-        bool supported = true;
-        const tile_probes probes = probe_tiles(P, layer, me);
         int n30raw = -1;                 // size of the unfiltered r=30 list (-1: no such query)
 
-        if(state == NAVHIP_STATE_TURNING) {
-            vpref = mkv(0.0f, 0.0f);
-        }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_uses_point_seek(state)) {
-            const bool point_seek = state_uses_point_seek(state);
-            vdes = load_vdes(P, uid, flock, me, status);
-
-            // separation (used by priority 0 and 1): r = 30 query, cap 128
+        if(R.mode != AM_ZERO_VPREF) {
+            const tile_probes probes = unpack_probes(R.probes);
+            const v2 arrive = mkv(R.arrive[0], R.arrive[1]);
+            // separation (movement.c:1690): r = 30 query, cap 128
             int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
             wave_sync();
             n30raw = n30;
@@ -1267,78 +1352,27 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
             const v2 separation = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
                                                   W.u.sep, scaled_max_force, lane, exp_tab);
             v2 steer;
-            if(point_seek) {
-                const bool los = P.has_dest_los[uid] != 0;
-                const v2 target = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1])
-                                               : me;
-                const v2 arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
-                const v2 cohesion = (flock >= 0) ? mkv(coh_xz[2 * uid], coh_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
-                // point_seek_vpref :1870, priorities 0..2
-                for(int prio = 0; prio < 3; prio++) {
-                    if(prio == 0) {
-                        v2 a = vscale(arrive, 0.5f), c = vscale(cohesion, 0.15f), s = vscale(separation, 0.6f);
-                        v2 ret = mkv(0.0f, 0.0f);
-                        ret = vadd(ret, a); ret = vadd(ret, s); ret = vadd(ret, c);
-                        steer = vtrunc(ret, scaled_max_force);
-                    }else if(prio == 1) {
-                        steer = separation;
-                    }else{
-                        steer = arrive;
-                    }
-                    steer = nullify_impass_pre(probes, steer);
-                    if((double)vlen(steer) > force_thresh) break;
-                }
-            }else{
+            if(R.mode == AM_ENEMY_SEEK) {
                 // enemy_seek_vpref :1946 (no priorities, no nullify)
-                v2 desired = vscale(vdes, max_speed / (float)hz);
-                v2 arrive = vtrunc(vsub(desired, vel), scaled_max_force);
                 v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
                 v2 ret = mkv(0.0f, 0.0f);
                 ret = vadd(ret, a); ret = vadd(ret, s);
                 steer = vtrunc(ret, scaled_max_force);
-            }
-            v2 accel = vscale(steer, 1.0f / 1.0f);
-            vpref = vtrunc(vadd(vel, accel), speed / (float)hz);
-        }else if(P.form_ready && (state == NAVHIP_STATE_MOVING_IN_FORMATION
-                                 || state == NAVHIP_STATE_ARRIVING_TO_CELL)) {
-            // formation arms of move_velocity_work (movement.c:3423-3446); the formation forces are
-            // host inputs (struct formation_state)
-            if(!P.form_ready[uid]) {
-                vpref = mkv(0.0f, 0.0f);
             }else{
-                vdes = load_vdes(P, uid, flock, me, status);
-                int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
-                wave_sync();
-                n30raw = n30;
-                const int n10d = derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
-                n30 = filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
-                if(n10d < 0) n30raw = -1; else n30raw = n10d;
-                const v2 separation = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
-                                                      W.u.sep, scaled_max_force, lane, exp_tab);
-                const v2 f_coh = mkv(P.form_cohesion_xz[2 * uid], P.form_cohesion_xz[2 * uid + 1]);
-                const v2 f_ali = mkv(P.form_align_xz[2 * uid], P.form_align_xz[2 * uid + 1]);
-                const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
-                const bool to_cell = state == NAVHIP_STATE_ARRIVING_TO_CELL;
-                const v2 cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
-                const bool los = P.has_dest_los[uid] != 0;
-                const v2 target = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]) : me;
-                // arrive_force_cell :1574 (no velocity term, no truncation) / arrive_force_point :1546
-                v2 arrive;
-                if(to_cell) {
-                    v2 desired = vsub(cell, me);
-                    float distance = vlen(desired);
-                    if(distance < 10.0f) desired = vscale(desired, distance / 10.0f);
-                    else                 desired = vscale(vdes, max_speed / (float)hz);
-                    arrive = desired;
+                // point_seek_vpref :1870 / cell_arrival_seek_vpref :1908 / formation_seek_vpref :1985
+                const bool to_cell = R.mode == AM_FORM_CELL, form = R.mode != AM_POINT_SEEK;
+                v2 cohesion, align = mkv(0.0f, 0.0f), cell = mkv(0.0f, 0.0f);
+                if(form) {
+                    cohesion = mkv(P.form_cohesion_xz[2 * uid], P.form_cohesion_xz[2 * uid + 1]);
+                    align = mkv(P.form_align_xz[2 * uid], P.form_align_xz[2 * uid + 1]);
+                    cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
                 }else{
-                    arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
+                    cohesion = (flock >= 0) ? mkv(coh_xz[2 * uid], coh_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
                 }
-                v2 steer;
                 for(int prio = 0; prio < 3; prio++) {
                     if(prio == 0) {
-                        // cell_seek_total_force :1773 / formation_point_seek_total_force :1962
                         v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
-                        v2 c = vscale(f_coh, 0.15f), al = vscale(f_ali, 0.15f);
+                        v2 c = vscale(cohesion, 0.15f), al = vscale(align, 0.15f);
                         v2 ret = mkv(0.0f, 0.0f);
                         ret = vadd(ret, a); ret = vadd(ret, s);
                         if(to_cell) {
@@ -1357,41 +1391,53 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
                     steer = nullify_impass_pre(probes, steer);
                     if((double)vlen(steer) > force_thresh) break;
                 }
-                v2 accel = vscale(steer, 1.0f / 1.0f);
-                vpref = vtrunc(vadd(vel, accel), speed / (float)hz);
+            }
+            v2 accel = vscale(steer, 1.0f / 1.0f);
+            vpref = vtrunc(vadd(vel, accel), speed / (float)hz);
+            if(R.mode == AM_FORM_CELL || R.mode == AM_FORM_POINT) {
+                const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
                 if(vlen(f_drag) > CP_EPS)                            // :1935 / :2018
                     vpref = vtrunc(vpref, (float)(((double)speed * 0.75) / (double)hz));
             }
+        }
+
+        // find_neighbours :2768: r = 10 query, cap 512 -- taken from the r = 30 list when that list
+        // is complete (n30raw now holds the derived count, -1 = not derivable)
+        uint32_t *ids10 = W.u.ids10;
+        int n10;
+        if(n30raw >= 0) {
+            ids10 = W.ids10d;
+            n10 = n30raw;
         }else{
-            supported = false;                      // formation state without formation inputs
-            status |= NAVHIP_ST_UNSUPPORTED;
+            n10 = sp_query_wave(P.grid, me.x, me.z, 10.0f, 512, W.u.ids10, lane);
+            wave_sync();
         }
-
-        if(supported) {
-            // find_neighbours :2768: r = 10 query, cap 512 -- taken from the r = 30 list when that
-            // list is complete (n30raw now holds the derived count, -1 = not derivable)
-            uint32_t *ids10 = W.u.ids10;
-            int n10;
-            if(n30raw >= 0) {
-                ids10 = W.ids10d;
-                n10 = n30raw;
-            }else{
-                n10 = sp_query_wave(P.grid, me.x, me.z, 10.0f, 512, W.u.ids10, lane);
-                wave_sync();
-            }
-            n10 = filter_garrisoned_wave(P.flags, ids10, n10, lane);
-            int n_dyn, n_stat;
-            classify_neighbours(P, uid, my_flags, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
-            cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
-            v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, W.u.rays, lane);
-            out_vel = vtrunc(nv, max_speed / (float)hz);                   // :3464
-        }
+        n10 = filter_garrisoned_wave(P.flags, ids10, n10, lane);
+        int n_dyn, n_stat;
+        classify_neighbours(P, uid, my_flags, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
+        cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
+        v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, W.u.rays, lane);
+        out_vel = vtrunc(nv, max_speed / (float)hz);                   // :3464
     }
+    if(lane == 0) {
+        O.vel_xz[2 * uid] = out_vel.x; O.vel_xz[2 * uid + 1] = out_vel.z;
+        if(O.vpref_xz) { O.vpref_xz[2 * uid] = vpref.x; O.vpref_xz[2 * uid + 1] = vpref.z; }
+    }
+}
 
-    // position accept test, entity_compute_update :2336-2358 (heading gate stays on the host)
+// k_agent_post: one THREAD per entity -- the position accept test of entity_compute_update
+// (movement.c:2336-2358; the heading gate stays on the host) and the status byte.
+__global__ __launch_bounds__(256) void k_agent_post(nh_step_params P, const nh_pre_rec *pre, nh_step_outs O)
+{
+    const int uid = P.work_begin + blockIdx.x * 256 + threadIdx.x;
+    if(uid >= P.work_end) return;
+    const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+    uint32_t status = pre[uid].status;
     v2 new_pos = me;
-    if(active) {
-        const int layer = nav_layer_for(my_flags, my_radius);
+    if(!state_is_still(P.state[uid])) {
+        const uint32_t my_flags = P.flags[uid];
+        const v2 out_vel = mkv(O.vel_xz[2 * uid], O.vel_xz[2 * uid + 1]);
+        const int layer = nav_layer_for(my_flags, P.radius[uid]);
         v2 cand = vadd(me, out_vel);
         const bool on_blocked = pos_blocked(P, layer, me.x, me.z);
         bool cand_path = false, cand_blk = false;
@@ -1409,13 +1455,8 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
             status |= NAVHIP_ST_MOVED;
         }
     }
-    if(lane == 0) {
-        O.vel_xz[2 * uid] = out_vel.x; O.vel_xz[2 * uid + 1] = out_vel.z;
-        if(O.new_pos_xz) { O.new_pos_xz[2 * uid] = new_pos.x; O.new_pos_xz[2 * uid + 1] = new_pos.z; }
-        if(O.vdes_xz)  { O.vdes_xz[2 * uid] = vdes.x;  O.vdes_xz[2 * uid + 1] = vdes.z; }
-        if(O.vpref_xz) { O.vpref_xz[2 * uid] = vpref.x; O.vpref_xz[2 * uid + 1] = vpref.z; }
-        if(O.status) O.status[uid] = (uint8_t)status;
-    }
+    if(O.new_pos_xz) { O.new_pos_xz[2 * uid] = new_pos.x; O.new_pos_xz[2 * uid + 1] = new_pos.z; }
+    if(O.status) O.status[uid] = (uint8_t)status;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1488,12 +1529,27 @@ void nh_launch_cohesion(const nh_step_params &P, int32_t *d_wave_off, float *d_c
     }
 }
 
-void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const nh_step_outs &O, hipStream_t s)
+size_t nh_pre_rec_bytes() { return sizeof(nh_pre_rec); }
+
+// the scalar pre-pass needs only the snapshot and the field pool: it may run before the spatial
+// hash and the cohesion term are ready
+void nh_launch_agent_pre(const nh_step_params &P, void *d_pre, const nh_step_outs &O, hipStream_t s)
 {
     const int nwork = P.work_end - P.work_begin;
     if(P.n_ents > 0 && nwork > 0)
+        hipLaunchKernelGGL(k_agent_pre, dim3((nwork + 255) / 256), dim3(256), 0, s, P, (nh_pre_rec*)d_pre, O);
+}
+
+void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const void *d_pre, const nh_step_outs &O,
+                          hipStream_t s)
+{
+    const int nwork = P.work_end - P.work_begin;
+    if(P.n_ents > 0 && nwork > 0) {
         hipLaunchKernelGGL(k_agent_step, dim3((nwork + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, P,
-                           d_coh, O);
+                           d_coh, (const nh_pre_rec*)d_pre, O);
+        hipLaunchKernelGGL(k_agent_post, dim3((nwork + 255) / 256), dim3(256), 0, s, P,
+                           (const nh_pre_rec*)d_pre, O);
+    }
 }
 
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,

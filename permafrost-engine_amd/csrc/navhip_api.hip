@@ -94,6 +94,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(ctx->sp, 0, sizeof(ctx->sp));
     memset(&ctx->coh, 0, sizeof(ctx->coh));
     memset(&ctx->coh_plan, 0, sizeof(ctx->coh_plan));
+    memset(&ctx->prerec, 0, sizeof(ctx->prerec));
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
@@ -124,7 +125,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     hipFree(ctx->d_dirty_list);
     for(auto &b : ctx->sp) hipFree(b.p);
     for(auto &b : ctx->stage) hipFree(b.p);
-    hipFree(ctx->coh.p); hipFree(ctx->coh_plan.p);
+    hipFree(ctx->coh.p); hipFree(ctx->coh_plan.p); hipFree(ctx->prerec.p);
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
     for(auto &a : ctx->aux) if(a) hipStreamDestroy(a);
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -738,9 +739,12 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         P.grid.n = w->n_ents;
         P.grid.cell_start = (int32_t*)ctx->sp[5].p; P.grid.sorted_id = (int32_t*)ctx->sp[6].p;
         P.grid.sx = (int32_t*)ctx->sp[7].p; P.grid.sy = (int32_t*)ctx->sp[8].p;
+        rc = ensure_buf(ctx, ctx->prerec, (size_t)w->n_ents * nh_pre_rec_bytes());
+        if(rc) return rc;
+        nh_launch_agent_pre(P, ctx->prerec.p, O, s);          // overlaps with the side streams
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
-        nh_launch_agent_step(P, (float*)ctx->coh.p, O, s);
+        nh_launch_agent_step(P, (float*)ctx->coh.p, ctx->prerec.p, O, s);
         HIPCHK(ctx, hipGetLastError());
         return NAVHIP_OK;
     }
@@ -754,9 +758,12 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
     if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, ((size_t)w->n_flocks + 1) * sizeof(int32_t));
     if(rc) return rc;
+    if(!rc) rc = ensure_buf(ctx, ctx->prerec, (size_t)w->n_ents * nh_pre_rec_bytes());
+    if(rc) return rc;
     nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    nh_launch_agent_step(P, (float*)ctx->coh.p, O, s);
+    nh_launch_agent_pre(P, ctx->prerec.p, O, s);
+    nh_launch_agent_step(P, (float*)ctx->coh.p, ctx->prerec.p, O, s);
     if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], s)); ctx->ev_valid = true; }
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;

@@ -46,6 +46,7 @@ struct navhip_ctx {
                                //               cell_start, sorted_id, sx, sy, block_sum
     buf          coh;          // cohesion force per entity
     buf          coh_plan;     // [n_flocks + 1] wave prefix of the cohesion launch
+    buf          prerec;       // per-entity record of the scalar pre-pass (k_agent_pre)
     buf          stage[36];    // device copies of host buffers for the host-pointer entry points
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];
