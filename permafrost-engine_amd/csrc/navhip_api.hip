@@ -681,7 +681,12 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if(!ctx->aux[0]) {
-        for(auto &a : ctx->aux) HIPCHK(ctx, hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        // high priority: the cohesion launch is long but narrow (1.5 waves per SIMD) and sits on the
+        // critical path; it must not queue up behind the wide field kernels of the caller's stream
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        for(auto &a : ctx->aux)
+            HIPCHK(ctx, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, prio_hi));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
