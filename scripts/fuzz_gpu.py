@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle sweep (bit-exactness of velocities, fields, LOS, blockers) over many
+seeds and world shapes -- looks for rare divergences (fast-path margins, caps, edge tiles) that
+the fixed test cases might miss.  Prints one line per case and a summary; exit code 1 on a mismatch."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge            # noqa: E402
+ge.build_navhip()
+from permafrost_engine_amd import navhip, synth     # noqa: E402
+from oracle import navoracle                          # noqa: E402
+from tests import cases                               # noqa: E402
+
+
+def main(n_cases=24):
+    bad = 0
+    for case in range(n_cases):
+        rng = np.random.RandomState(1000 + case)
+        W = int(rng.choice([2, 3, 4]))
+        frac = float(rng.choice([0.1, 0.2, 0.35]))
+        grid = synth.cost_grid(W, W, seed=500 + case, frac_impassable=frac)
+        blk = cases.random_blockers(grid, seed=case, frac=float(rng.choice([0.0, 0.02, 0.06])))
+        chunks = synth.to_chunks(grid)
+        onav = navoracle.OracleNav(chunks, blk)
+        onav.set_layer(0, local_islands=onav.local_islands(0))
+        ctx = navhip.NavContext(W, W)
+        ctx.upload_plane(0, navhip.PLANE_COST_BASE, chunks)
+        ctx.upload_plane(0, navhip.PLANE_BLOCKERS, blk)
+        ctx.upload_plane(0, navhip.PLANE_LOCAL_ISLANDS, onav.plane(0, "local_islands"))
+        # fields
+        K = int(rng.choice([2, 3, 5]))
+        liid = synth.from_chunks(onav.plane(0, "local_islands"))
+        cells = synth.passable_cells(grid, synth.from_chunks(blk))
+        dests = cells[rng.choice(len(cells), K, replace=False)]
+        cols = synth.whole_map_requests(grid, dests, liid)
+        reqs = cases.cols_to_reqs(cols, navhip.FIELD_REQ_DTYPE)
+        dirs, integ = ctx.N_FlowFieldUpdate(reqs, want_integ=True)
+        ed, ei = onav.build_fields(reqs.view(navoracle.FIELD_REQ_DTYPE), want_integ=True)
+        ok_f = np.array_equal(dirs, ed) and np.array_equal(integ, ei)
+        # agents: clustered or spread, sampling the fields on the device
+        n = int(rng.choice([800, 2000, 4000]))
+        world = cases.make_agents(grid, n, K, seed=case, clustered=bool(rng.rand() < 0.6),
+                                  sigma=float(rng.choice([15.0, 40.0, 90.0])))
+        world["flock_target_xz"] = synth.cell_centre(W, W, dests[:, 0], dests[:, 1])
+        slot = -np.ones((K, W * W), np.int32)
+        slot[cols["dest"], cols["chunk_r"] * W + cols["chunk_c"]] = np.arange(len(reqs))
+        a = cases.step_arrays(world, None)
+        a["flock_field_slot"], a["field_pool"] = slot, dirs.reshape(len(dirs), 4096)
+        hz = int(rng.choice([20, 20, 10]))
+        out = ctx.agent_step(a, hz=hz)
+        exp = onav.agent_step(a, hz=hz, nthreads=8)
+        same = out["vel_xz"].view(np.uint32) == exp["vel_xz"].view(np.uint32)
+        nanboth = np.isnan(out["vel_xz"]) & np.isnan(exp["vel_xz"])
+        ok_v = bool((same | nanboth).all()) and np.array_equal(out["status"], exp["status"]) \
+            and np.array_equal(out["new_pos_xz"].view(np.uint32), exp["new_pos_xz"].view(np.uint32))
+        d = np.linalg.norm(out["vel_xz"].astype(np.float64) - exp["vel_xz"], axis=1)
+        rel = np.nanmax(d / np.maximum(np.linalg.norm(exp["vel_xz"].astype(np.float64), axis=1), 1e-3))
+        print("case %2d: W=%d K=%d n=%d hz=%d  fields %s  velocities %s (max rel %.2g, %d/%d bit-identical)"
+              % (case, W, K, n, hz, "ok" if ok_f else "DIFF", "ok" if ok_v else "DIFF", rel,
+                 int((same | nanboth).all(1).sum()), n), flush=True)
+        bad += (not ok_f) + (not ok_v)
+        ctx.close()
+    print("fuzz: %d mismatching cases of %d" % (bad, n_cases))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 24))
