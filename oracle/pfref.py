@@ -307,6 +307,13 @@ def _to_req(req):
     return r
 
 
+def set_enemy_factions(faction_id, mask):
+    """What G_GetEnemyFactions(faction_id) returns inside the reference (game.c:2744)."""
+    L = lib()
+    L.pfref_set_enemy_factions.argtypes = [C.c_int, C.c_uint]
+    L.pfref_set_enemy_factions(int(faction_id), int(mask))
+
+
 def clearpath_new_velocity(ent, des_v, dyn, stat):
     ent = np.ascontiguousarray(ent, np.float32)
     des_v = np.ascontiguousarray(des_v, np.float32)

@@ -74,6 +74,9 @@ int  pfref_nav_num_portals(const pfref_nav *nav, int layer, int chunk_r, int chu
 void pfref_nav_get_portal(const pfref_nav *nav, int layer, int chunk_r, int chunk_c, int idx,
                           pfref_portal *out);
 
+/* G_GetEnemyFactions(faction_id) as the harness answers it (game.c:2744): bit f = at war with f */
+void pfref_set_enemy_factions(int faction_id, unsigned mask);
+
 /* --- flow fields -------------------------------------------------------- */
 
 /* N_FlowFieldInit (unless req->inout) + N_FlowFieldUpdate (field.c:2020,2030).

@@ -89,6 +89,20 @@ char *pf_strlcat(char *dest, const char *src, size_t size)
     return dest;
 }
 
+/* game.c:2744 -- the diplomacy table is game state; the harness makes it an explicit input so that
+ * attacking paths (field_tile_passable_no_enemies, field.c:179) can be exercised */
+static uint16_t s_enemy_masks[16];
+
+uint16_t G_GetEnemyFactions(int faction_id)
+{
+    return s_enemy_masks[faction_id & 15];
+}
+
+void pfref_set_enemy_factions(int faction_id, unsigned mask)
+{
+    s_enemy_masks[faction_id & 15] = (uint16_t)mask;
+}
+
 void pfref_stub_abort(const char *name)
 {
     fprintf(stderr, "pfref: engine symbol '%s' is stubbed out in the oracle harness "

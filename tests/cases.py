@@ -389,3 +389,47 @@ def region_reqs_to(dtype, reqs):
         for k, v in r.items():
             out[k][i] = v
     return out
+
+
+def faction_cases(seed, n_circles=60, n_tile=20, n_portal=20):
+    """Attacking-path fields (faction_id != NONE, field_tile_passable_no_enemies field.c:179): units
+    of three factions block tiles; faction 0 is at war with faction 1 only, so its fields may run
+    through tiles blocked purely by faction-1 units.  Returns (grid, nav, reference request records,
+    enemies mask, expected dirs, expected integ)."""
+    rng = np.random.RandomState(seed)
+    grid = synth.cost_grid(3, 3, seed=90 + seed, frac_impassable=0.15)
+    nav = pfref.RefNav(synth.to_chunks(grid))
+    cells = synth.passable_cells(grid)
+    pos = synth.cell_centre(3, 3, *cells[rng.randint(len(cells), size=n_circles)].T)
+    for i in range(n_circles):
+        nav.blockers_circle(float(pos[i, 0]), float(pos[i, 1]), float(rng.uniform(3, 10)),
+                            faction_id=int(rng.randint(0, 3)), incref=True)
+    nav.flush_dirty()
+    enemies = 0b010
+    for f in range(16):
+        pfref.set_enemy_factions(f, enemies if f == 0 else 0)
+    li = nav.plane(pfref.PLANE_LOCAL_ISLANDS)
+    reqs = np.zeros(n_tile + n_portal, pfref.FIELD_REQ_DTYPE)
+    reqs["faction_id"] = 0
+    R = rng.randint(0, grid.shape[0], n_tile); Cc = rng.randint(0, grid.shape[1], n_tile)
+    reqs["type"][:n_tile] = pfref.TARGET_TILE
+    reqs["chunk_r"][:n_tile], reqs["tile_r"][:n_tile] = R // 64, R % 64
+    reqs["chunk_c"][:n_tile], reqs["tile_c"][:n_tile] = Cc // 64, Cc % 64
+    k = n_tile
+    while k < n_tile + n_portal:
+        cr, cc = rng.randint(0, 3, 2)
+        ports = nav.portals(int(cr), int(cc))
+        if not ports:
+            continue
+        p = ports[rng.randint(len(ports))]
+        q = reqs[k]
+        q["type"] = pfref.TARGET_PORTAL
+        q["chunk_r"], q["chunk_c"] = p.chunk_r, p.chunk_c
+        q["port_r0"], q["port_c0"], q["port_r1"], q["port_c1"] = p.r0, p.c0, p.r1, p.c1
+        q["next_chunk_r"], q["next_chunk_c"] = p.conn_chunk_r, p.conn_chunk_c
+        q["next_r0"], q["next_c0"], q["next_r1"], q["next_c1"] = p.conn_r0, p.conn_c0, p.conn_r1, p.conn_c1
+        q["port_iid"] = int(li[p.chunk_r, p.chunk_c, p.r0, p.c0])
+        q["next_iid"] = int(li[p.conn_chunk_r, p.conn_chunk_c, p.conn_r0, p.conn_c0])
+        k += 1
+    dirs, integ = ref_fields(nav, reqs, None)
+    return grid, nav, reqs, enemies, dirs, integ

@@ -112,3 +112,21 @@ def test_region_fields_match_reference(navlib, seed, blk):
     bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exp[i])]
     assert not bad, "region fields differ: %s" % [(i, reqs[i]["out_mode"]) for i in bad[:8]]
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_attacking_path_fields_match_reference(navlib, seed):
+    """faction_id != NONE: tiles blocked only by enemy factions are passable
+    (field_tile_passable_no_enemies, field.c:179); served by the generic kernel."""
+    from oracle import pfref
+    grid, nav, reqs, enemies, exp_dirs, exp_integ = cases.faction_cases(seed)
+    ctx = navlib.NavContext(3, 3)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(0))
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(1))
+    ctx.upload_plane(0, navlib.PLANE_LOCAL_ISLANDS, nav.plane(3))
+    ctx.upload_plane(0, navlib.PLANE_FACTIONS, nav.plane(pfref.PLANE_FACTIONS))
+    h = cases.reqs_from_ref(navlib, reqs)
+    h["faction_id"], h["enemies"] = 0, enemies
+    dirs, integ = ctx.N_FlowFieldUpdate(h, want_integ=True)
+    assert np.array_equal(dirs, exp_dirs) and np.array_equal(integ, exp_integ)
+    ctx.close()

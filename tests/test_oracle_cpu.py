@@ -370,3 +370,20 @@ def test_region_fields_restatement_matches_reference(seed, blk):
     bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exp[i])]
     assert not bad, "region fields differ: %s" % [(i, reqs[i]["out_mode"]) for i in bad[:8]]
     assert (exp != 0).mean() > 0.2
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [1, 2])
+def test_attacking_path_fields_restatement_matches_reference(seed):
+    grid, nav, reqs, enemies, exp_dirs, exp_integ = cases.faction_cases(seed)
+    onav = cases.oracle_nav_from_ref(nav)
+    onav.set_layer(0, factions=nav.plane(pfref.PLANE_FACTIONS))
+    o = _o_reqs(reqs)
+    o["faction_id"], o["enemies"] = 0, enemies
+    dirs, integ = onav.build_fields(o, want_integ=True)
+    assert np.array_equal(dirs, exp_dirs) and np.array_equal(integ, exp_integ)
+    # the faction really matters: a neutral request (FACTION_ID_NONE) sees more blocked tiles
+    o2 = o.copy()
+    o2["faction_id"], o2["enemies"] = 0xF, 0
+    d2, _ = onav.build_fields(o2)
+    assert not np.array_equal(d2, exp_dirs)
