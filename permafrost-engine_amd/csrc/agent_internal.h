@@ -46,7 +46,8 @@ struct nh_step_outs {
 
 void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
                              hipStream_t s);
-void nh_launch_cohesion(const nh_step_params &P, int32_t *d_wave_off, float *d_coh, hipStream_t s);
+size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members);
+void nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, hipStream_t s);
 size_t nh_pre_rec_bytes();
 void nh_launch_agent_pre(const nh_step_params &P, void *d_pre, const nh_step_outs &O, hipStream_t s);
 void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const void *d_pre, const nh_step_outs &O,

@@ -902,16 +902,77 @@ __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *flock_offsets, 
     if(t == 0) wave_off[n_flocks] = carry;
 }
 
-// k_cohesion: one WAVE (= one 64-thread workgroup) per 64 consecutive members of ONE flock, thread =
-// member.  A wave never straddles two flocks (a straddling workgroup would walk two whole flocks and
-// become the tail of the launch).  The flock's member positions are staged through LDS 256 at a
-// time (coalesced gather) and every thread walks them IN MEMBER ORDER (float sums are order
-// dependent; LDS reads are wave-uniform broadcasts), so the only global traffic in the O(N*F) loop
-// is the staging itself.
-__global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off, float *coh_xz)
+// k_coh_bin / k_coh_scatter: per-tick lane assignment of the cohesion launch.  Which thread handles
+// which member is free (each member's sum only depends on the flock's member ORDER, which the walk
+// keeps), so the members of a flock are regrouped by a 16x16 grid of map blocks in Morton order:
+// the 64 members of a wave are then close together and the wave can skip, exactly, every flock
+// mate that is too far from ALL of them to carry a non-zero weight (see k_cohesion).
+//   bin = flock * COH_BINS + morton(block);   perm[] = CSR entries ordered by bin (counting sort;
+//   the order inside a bin is whatever the atomics give -- it only moves members between lanes).
+// Members that take no cohesion force this tick (outside the work range, not point seeking, combat
+// hold) go to the flock's last bin: the lanes in use are packed at the front and the trailing waves
+// of a flock exit at once.
+#define COH_BINS 257
+__device__ __forceinline__ int coh_bin_of(const nh_step_params &P, int g, int *flock_out)
+{
+    int lo = 0, hi = P.n_flocks;
+    while(hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if(P.flock_offsets[mid] <= g) lo = mid; else hi = mid;
+    }
+    *flock_out = lo;
+    const int m = P.flock_members[g];
+    const bool act = m >= P.work_begin && m < P.work_end && state_uses_point_seek(P.state[m])
+                  && !(P.flags[m] & NAVHIP_ENTITY_FLAG_COMBAT_HELD);
+    if(!act) return lo * COH_BINS + 256;
+    const float ox = (float)P.grid.origin_x * (1.0f / 256.0f), oz = (float)P.grid.origin_y * (1.0f / 256.0f);
+    int bx = (int)((P.pos_xz[2 * m] - ox) / (float)P.grid.grid_w);           // span / 16 == grid_w wu
+    int bz = (int)((P.pos_xz[2 * m + 1] - oz) / (float)P.grid.grid_h);
+    bx = min(max(bx, 0), 15); bz = min(max(bz, 0), 15);
+    int mo = 0;
+#pragma unroll
+    for(int k = 0; k < 4; k++) mo |= (((bx >> k) & 1) << (2 * k)) | (((bz >> k) & 1) << (2 * k + 1));
+    return lo * COH_BINS + mo;
+}
+
+__global__ __launch_bounds__(256) void k_coh_bin(nh_step_params P, int32_t *bin_of, int32_t *bin_count)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if(g >= P.flock_offsets[P.n_flocks]) return;
+    int f;
+    const int bin = coh_bin_of(P, g, &f);
+    bin_of[g] = bin;
+    atomicAdd(&bin_count[bin], 1);
+}
+
+__global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int32_t *bin_of,
+                                                     const int32_t *bin_start, int32_t *bin_fill,
+                                                     int32_t *perm)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if(g >= P.flock_offsets[P.n_flocks]) return;
+    const int bin = bin_of[g];
+    perm[bin_start[bin] + atomicAdd(&bin_fill[bin], 1)] = g;
+}
+
+// exp(-6 t) rounds to +0 in float once the distance exceeds 904 wu (t >= 17.33); COH_FAR leaves a
+// margin for the roundings of the box test
+#define COH_FAR 906.0f
+
+// k_cohesion: one WAVE (= one 64-thread workgroup) per 64 members of ONE flock (perm[] order),
+// thread = member.  A wave never straddles two flocks (a straddling workgroup would walk two whole
+// flocks and become the tail of the launch).  The flock's member positions are staged through LDS
+// 256 at a time (coalesced gather); a lane-parallel pre-pass drops the staged members that lie more
+// than COH_FAR from the bounding box of the wave's own members (their weight is exactly 0 for every
+// lane, and adding +-0 leaves the never-negative-zero running sums unchanged), and every thread
+// walks the survivors IN MEMBER ORDER (float sums are order dependent; LDS reads are wave-uniform
+// broadcasts), so the only global traffic in the O(N*F) loop is the staging itself.
+__global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off,
+                                                 const int32_t *perm, float *coh_xz)
 {
     __shared__ double tab[64];
     __shared__ float2 spos[256];
+    __shared__ uint8_t near_ix[256];
     const int t = threadIdx.x;
     const int wv = blockIdx.x;
     if(wv >= wave_off[P.n_flocks]) return;
@@ -928,26 +989,46 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     }
     const float scaled_max_force = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
-    const int g = b + (wv - wave_off[f]) * 64 + t;
-    const bool mine = g < e;
+    const int gp = b + (wv - wave_off[f]) * 64 + t;
+    const bool mine = gp < e;
+    const int g = mine ? perm[gp] : -1;                  // CSR entry of this thread's member
     const int uid = mine ? P.flock_members[g] : -1;
     bool act = mine && uid >= P.work_begin && uid < P.work_end;
     if(act) act = state_uses_point_seek(P.state[uid]) && !(P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD);
     if(!__syncthreads_or(act)) return;
     const v2 me = act ? mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
+    // bounding box of the wave's active members
+    float bx0 = act ? me.x : INFINITY, bx1 = act ? me.x : -INFINITY;
+    float bz0 = act ? me.z : INFINITY, bz1 = act ? me.z : -INFINITY;
+#pragma unroll
+    for(int d = 1; d < 64; d <<= 1) {
+        bx0 = fminf(bx0, __shfl_xor(bx0, d)); bx1 = fmaxf(bx1, __shfl_xor(bx1, d));
+        bz0 = fminf(bz0, __shfl_xor(bz0, d)); bz1 = fmaxf(bz1, __shfl_xor(bz1, d));
+    }
+    const unsigned long long lt_mask = (1ull << t) - 1ull;
     v2 com = mkv(0.0f, 0.0f);
     for(int jb = b; jb < e; jb += 256) {
         __syncthreads();
+        int ncnt = 0;
 #pragma unroll
         for(int q = 0; q < 4; q++) {
             const int j = jb + q * 64 + t;
+            bool keep = false;
             if(j < e) {
                 const int m = P.flock_members[j];
-                spos[q * 64 + t] = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
+                const float2 c2 = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
+                spos[q * 64 + t] = c2;
+                const float dx = fmaxf(fmaxf(bx0 - c2.x, c2.x - bx1), 0.0f);
+                const float dz = fmaxf(fmaxf(bz0 - c2.y, c2.y - bz1), 0.0f);
+                keep = !(dx * dx + dz * dz > COH_FAR * COH_FAR);       // NaN stays in
             }
+            const unsigned long long mk = __ballot(keep);
+            if(keep) near_ix[ncnt + __popcll(mk & lt_mask)] = (uint8_t)(q * 64 + t);
+            ncnt += __popcll(mk);
         }
         __syncthreads();
-        const int cnt = min(256, e - jb);
+        const int cnt = ncnt;
+        const int gl = g - jb;                            // this member's own slot in the tile, if any
         if(act) {
             // COH_U independent weight evaluations in flight (the chain sqrt -> double
             // divide -> exp is ~45 dependent instructions), then the ordered float sums
@@ -955,11 +1036,13 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
             int jj = 0;
             for(; jj + COH_U <= cnt; jj += COH_U) {
                 v2 cp[COH_U];
+                int ix[COH_U];
                 float ss[COH_U], ln[COH_U], tt[COH_U], sc[COH_U];
                 bool close = false, odd = false;
 #pragma unroll
                 for(int u = 0; u < COH_U; u++) {
-                    const float2 c2 = spos[jj + u];
+                    ix[u] = near_ix[jj + u];
+                    const float2 c2 = spos[ix[u]];
                     cp[u] = mkv(c2.x, c2.y);
                     const v2 d = vsub(cp[u], me);
                     ss[u] = d.x * d.x + d.z * d.z;
@@ -989,16 +1072,17 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
                 for(int u = 0; u < COH_U; u++) {
                     // curr == uid is skipped by the reference: a zero weight adds +-0, which
                     // leaves the (never negative-zero) running sum unchanged
-                    const float w = (jb + jj + u == g) ? 0.0f : sc[u];
+                    const float w = (ix[u] == gl) ? 0.0f : sc[u];
                     com = vadd(com, vscale(cp[u], w));
                 }
             }
             for(; jj < cnt; jj++) {
-                const float2 c2 = spos[jj];
+                const int ix = near_ix[jj];
+                const float2 c2 = spos[ix];
                 const v2 cp = mkv(c2.x, c2.y);
                 const float ln = vlen(vsub(cp, me));
                 const float tt = ln < 16.0f ? cohesion_t_f64(ln) : cohesion_t_f32(ln);
-                const float w = (jb + jj == g) ? 0.0f : exp_f32_lowconv(-6.0f * tt, tab);
+                const float w = (ix == gl) ? 0.0f : exp_f32_lowconv(-6.0f * tt, tab);
                 com = vadd(com, vscale(cp, w));
             }
         }
@@ -1519,13 +1603,37 @@ void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial
                        S.sorted_id, S.ent_ix, S.ent_iy, S.sx, S.sy);
 }
 
-void nh_launch_cohesion(const nh_step_params &P, int32_t *d_wave_off, float *d_coh, hipStream_t s)
+// scratch of the cohesion launch: wave prefix | bin counts | bin fills | bin starts | scan block sums
+// | bin of each CSR entry | perm
+size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members)
+{
+    const size_t nb = (size_t)n_flocks * COH_BINS;
+    return sizeof(int32_t) * ((size_t)n_flocks + 1 + 3 * nb + 1 + (nb + 1023) / 1024 + 2 * (size_t)n_members);
+}
+
+void nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, hipStream_t s)
 {
     if(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0) {
-        hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, P.flock_offsets, P.n_flocks, d_wave_off);
+        const int nb = P.n_flocks * COH_BINS, nblocks = (nb + 1023) / 1024;
+        int32_t *wave_off = scratch;
+        int32_t *bin_count = wave_off + P.n_flocks + 1;
+        int32_t *bin_fill = bin_count + nb;
+        int32_t *bin_start = bin_fill + nb;               // [nb + 1]
+        int32_t *block_sum = bin_start + nb + 1;
+        int32_t *bin_of = block_sum + nblocks;
+        int32_t *perm = bin_of + P.n_members;
+        hipMemsetAsync(bin_count, 0, sizeof(int32_t) * 2 * (size_t)nb, s);
+        hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, P.flock_offsets, P.n_flocks, wave_off);
+        const int gm = (P.n_members + 255) / 256;
+        hipLaunchKernelGGL(k_coh_bin, dim3(gm), dim3(256), 0, s, P, bin_of, bin_count);
+        hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(1024), 0, s, bin_count, bin_start,
+                           block_sum, nb);
+        hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(1024), 0, s, bin_start, block_sum, nb, nblocks);
+        hipLaunchKernelGGL(k_coh_scatter, dim3(gm), dim3(256), 0, s, P, bin_of, bin_start, bin_fill, perm);
         // upper bound of the number of 64-member waves; surplus waves exit at once
         const int nwaves = (P.n_members + 63) / 64 + P.n_flocks;
-        hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)d_wave_off, d_coh);
+        hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)wave_off,
+                           (const int32_t*)perm, d_coh);
     }
 }
 

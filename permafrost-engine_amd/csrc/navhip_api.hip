@@ -694,7 +694,7 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     rc = step_fill_params(ctx, w, &P);
     if(rc) return rc;
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
-    if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, ((size_t)w->n_flocks + 1) * sizeof(int32_t));
+    if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, nh_cohesion_scratch_bytes(w->n_flocks, P.n_members));
     if(rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
@@ -761,7 +761,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(rc) return rc;
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
-    if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, ((size_t)w->n_flocks + 1) * sizeof(int32_t));
+    if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, nh_cohesion_scratch_bytes(w->n_flocks, P.n_members));
     if(rc) return rc;
     if(!rc) rc = ensure_buf(ctx, ctx->prerec, (size_t)w->n_ents * nh_pre_rec_bytes());
     if(rc) return rc;
