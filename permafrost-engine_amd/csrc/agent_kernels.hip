@@ -62,6 +62,34 @@ __device__ __forceinline__ v2 vtrunc(v2 a, float max_len)
 #define CP_EPS 0.0009765625f   /* 1.0/1024: exactly representable, so float compares == the
                                   reference's float-vs-double compares */
 
+// optional section timing of k_agent_step (scripts/section_prof.py builds a private copy of the
+// library with -DNH_SECTION_PROF; the shipped build carries none of it)
+#ifdef NH_SECTION_PROF
+__device__ unsigned long long nh_sec[1024 * 32];      // [slot = block & 1023][counter]
+#define SEC_BEGIN() unsigned long long _sec_t0 = __builtin_amdgcn_s_memtime()
+#define SEC_MARK(k) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
+        if(lane == 0) { unsigned long long *_b = nh_sec + (blockIdx.x & 1023) * 32; \
+                        atomicAdd(&_b[k], _n - _sec_t0); atomicAdd(&_b[16 + (k)], 1ull); } \
+        _sec_t0 = __builtin_amdgcn_s_memtime(); } while(0)
+extern "C" int navhip_debug_sections(unsigned long long *out, int reset)
+{
+    static unsigned long long h[1024 * 32];
+    if(hipMemcpyFromSymbol(h, HIP_SYMBOL(nh_sec), sizeof(h)) != hipSuccess) return 1;
+    for(int k = 0; k < 32; k++) { out[k] = 0; for(int b = 0; b < 1024; b++) out[k] += h[b * 32 + k]; }
+    if(reset) { for(auto &x : h) x = 0; hipMemcpyToSymbol(HIP_SYMBOL(nh_sec), h, sizeof(h)); }
+    return 0;
+}
+#else
+#define SEC_BEGIN()
+#define SEC_MARK(k)
+#endif
+// cost of one section under real contention: scripts/dup_prof.py builds private copies of the library
+// that run section NH_DUP twice (same results) and compares tick times
+#ifndef NH_DUP
+#define NH_DUP 0
+#endif
+#define DUP_BARRIER() asm volatile("" ::: "memory")
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -496,38 +524,60 @@ __device__ int filter_garrisoned_wave(const uint32_t *flags, uint32_t *ids, int 
 struct cpent { v2 pos, vel; float radius; };
 struct ray   { v2 point, dir; };
 
-// C_InfiniteLineIntersection, collision.c:820 (including the l2.point term of the
-// vertical-l2 branch, :840)
-__device__ __forceinline__ bool line_isect(const ray &l1, const ray &l2, v2 &out)
+// slope of a line as C_InfiniteLineIntersection takes it (collision.c:823-831): NaN = vertical
+__device__ __forceinline__ float line_slope(v2 dir)
 {
-    const float nanv = __builtin_nanf("");
-    float s1 = fabsf(l1.dir.x) < CP_EPS ? nanv : __fdiv_rn(l1.dir.z, l1.dir.x);
-    float s2 = fabsf(l2.dir.x) < CP_EPS ? nanv : __fdiv_rn(l2.dir.z, l2.dir.x);
+    return fabsf(dir.x) < CP_EPS ? __builtin_nanf("") : __fdiv_rn(dir.z, dir.x);
+}
+
+// C_InfiniteLineIntersection, collision.c:820 (including the l2.point term of the vertical-l2
+// branch, :840), with the two slopes s1/s2 = line_slope(dir) supplied by the caller (they only
+// depend on the line, and every line meets many others)
+__device__ __forceinline__ bool line_isect(v2 p1, float s1, v2 p2, float s2, v2 &out)
+{
     bool n1 = s1 != s1, n2 = s2 != s2;
     if(n1 && n2) return false;
     if(fabsf(s1 - s2) < CP_EPS) return false;
     if(n1 && !n2) {
-        out.x = l1.point.x;
-        out.z = (l1.point.x - l2.point.x) * s2 + l2.point.z;
+        out.x = p1.x;
+        out.z = (p1.x - p2.x) * s2 + p2.z;
     }else if(!n1 && n2) {
-        out.x = l2.point.x;
-        out.z = (l2.point.x - l1.point.x) * s1 + l2.point.z;
+        out.x = p2.x;
+        out.z = (p2.x - p1.x) * s1 + p2.z;
     }else{
-        out.x = __fdiv_rn((s1 * l1.point.x - s2 * l2.point.x + l2.point.z - l1.point.z), (s1 - s2));
-        out.z = s2 * (out.x - l2.point.x) + l2.point.z;
+        out.x = __fdiv_rn((s1 * p1.x - s2 * p2.x + p2.z - p1.z), (s1 - s2));
+        out.z = s2 * (out.x - p2.x) + p2.z;
     }
     return true;
 }
 
+// `a / b < 0.0f` of C_RayRayIntersection2D (collision.c:862-871) without the division when the sign
+// rule is safe: for finite a, b with a == 0 or |a| >= 2^-100 and |b| <= 2^20 the quotient cannot
+// underflow to -0, so it is negative exactly when a != 0 and the signs differ (b = +-0 included:
+// a/+-0 = +-inf).  ok = false -> the caller divides.
+__device__ __forceinline__ bool quot_neg_fast(float a, float b, bool &ok)
+{
+    const float aa = fabsf(a);
+    ok = ok && (aa >= 0x1p-100f || a == 0.0f) && aa < __builtin_inff() && fabsf(b) <= 0x1p20f;
+    return a != 0.0f && ((__float_as_int(a) ^ __float_as_int(b)) < 0);
+}
+
 // C_RayRayIntersection2D, collision.c:854
-__device__ __forceinline__ bool ray_isect(const ray &l1, const ray &l2, v2 &out)
+__device__ __forceinline__ bool ray_isect(v2 p1, v2 d1, float s1, v2 p2, v2 d2, float s2, v2 &out)
 {
     v2 p;
-    if(!line_isect(l1, l2, p)) return false;
-    if(__fdiv_rn(p.x - l1.point.x, l1.dir.x) < 0.0f) return false;
-    if(__fdiv_rn(p.z - l1.point.z, l1.dir.z) < 0.0f) return false;
-    if(__fdiv_rn(p.x - l2.point.x, l2.dir.x) < 0.0f) return false;
-    if(__fdiv_rn(p.z - l2.point.z, l2.dir.z) < 0.0f) return false;
+    if(!line_isect(p1, s1, p2, s2, p)) return false;
+    bool ok = true;
+    const float a1 = p.x - p1.x, a2 = p.z - p1.z, a3 = p.x - p2.x, a4 = p.z - p2.z;
+    bool neg = quot_neg_fast(a1, d1.x, ok);
+    neg |= quot_neg_fast(a2, d1.z, ok);
+    neg |= quot_neg_fast(a3, d2.x, ok);
+    neg |= quot_neg_fast(a4, d2.z, ok);
+    if(!ok) {
+        neg = __fdiv_rn(a1, d1.x) < 0.0f || __fdiv_rn(a2, d1.z) < 0.0f
+           || __fdiv_rn(a3, d2.x) < 0.0f || __fdiv_rn(a4, d2.z) < 0.0f;
+    }
+    if(neg) return false;
     out = p;
     return true;
 }
@@ -544,94 +594,86 @@ __device__ __forceinline__ void vo_edges(const cpent &ent, const cpent &nb, v2 &
     out_left = vnormal(vsub(left_tangent, ent.pos));
 }
 
-// compute_vo :153 / compute_hrvo :180 -> (apex, left, right)
-__device__ __forceinline__ void make_vo(const cpent &ent, const cpent &nb, v2 &apex, v2 &left, v2 &right)
+// compute_vo :153 / compute_hrvo :180 -> (apex, left, right) + the slopes of the two sides
+__device__ __forceinline__ void make_cone(const cpent &ent, const cpent &nb, bool hrvo, v2 &apex,
+                                          v2 &left, v2 &right, float &sl, float &sr)
 {
     vo_edges(ent, nb, right, left);
-    apex = vadd(ent.pos, nb.vel);
-}
-
-__device__ __forceinline__ void make_hrvo(const cpent &ent, const cpent &nb, v2 &apex, v2 &left, v2 &right)
-{
-    vo_edges(ent, nb, right, left);
-    v2 apex_off = vscale(vadd(ent.vel, nb.vel), 0.5f);
-    v2 rvo_apex = vadd(ent.pos, apex_off);
-    v2 centerline = vadd(left, right);
-    v2 vo_apex = vadd(ent.pos, nb.vel);
-    float det = (centerline.x * ent.vel.z) - (centerline.z * ent.vel.x);
-    if(det > CP_EPS) {
-        ray l1 = {rvo_apex, left}, l2 = {vo_apex, right};
-        v2 p = rvo_apex;
-        line_isect(l1, l2, p);
-        apex = p;
-    }else if(det < -CP_EPS) {
-        ray l1 = {rvo_apex, right}, l2 = {vo_apex, left};
-        v2 p = rvo_apex;
-        line_isect(l1, l2, p);
-        apex = p;
-    }else{
+    sl = line_slope(left); sr = line_slope(right);
+    const v2 vo_apex = vadd(ent.pos, nb.vel);
+    apex = vo_apex;
+    if(hrvo) {
+        v2 apex_off = vscale(vadd(ent.vel, nb.vel), 0.5f);
+        v2 rvo_apex = vadd(ent.pos, apex_off);
+        v2 centerline = vadd(left, right);
+        float det = (centerline.x * ent.vel.z) - (centerline.z * ent.vel.x);
         apex = rvo_apex;
+        if(det > CP_EPS || det < -CP_EPS) {
+            // :196-212: (rvo_apex, left) x (vo_apex, right) or the mirrored pair
+            const bool pos = det > CP_EPS;
+            v2 p = rvo_apex;
+            line_isect(rvo_apex, pos ? sl : sr, vo_apex, pos ? sr : sl, p);
+            apex = p;
+        }
     }
 }
 
-// inside_pcr, clearpath.c:249.  rays[] live in LDS as float4 {point.x, point.z, dir.x, dir.z}.
+// inside_pcr, clearpath.c:249.  The combined obstacle lives in LDS as two float4 per cone:
+//   cones[2c]   = {apex.x, apex.z, slope(left), slope(right)}
+//   cones[2c+1] = {left.x, left.z, right.x, right.z}
+// (both rays of a cone start at its apex, rays_repr :291; ray 2c is the left side, 2c+1 the right).
 //
-// One cone, evaluated exactly as the reference does (two normalisations with IEEE sqrt/divide):
-// true when `test` is strictly inside the cone spanned by rays[i] (left) and rays[i+1] (right).
-__device__ __forceinline__ bool cone_contains_exact(float4 L, float4 R, v2 test)
+// One cone, evaluated exactly as the reference does (normalisation with IEEE sqrt/divide; the
+// reference normalises test - apex once per ray, with identical operands both times):
+// true when `test` is strictly inside the cone.
+__device__ __forceinline__ bool cone_contains_exact(float4 A, float4 B, v2 test)
 {
-    v2 ptt = mkv(test.x - L.x, test.z - L.y);
+    v2 ptt = mkv(test.x - A.x, test.z - A.y);
     if(vlen(ptt) < CP_EPS) return false;
     ptt = vnormal(ptt);
-    float left_det = (ptt.z * L.z) - (ptt.x * L.w);
+    float left_det = (ptt.z * B.x) - (ptt.x * B.y);
     if(left_det < CP_EPS) return false;
-    ptt = mkv(test.x - R.x, test.z - R.y);
-    if(vlen(ptt) < CP_EPS) return false;
-    ptt = vnormal(ptt);
-    float right_det = (ptt.z * R.z) - (ptt.x * R.w);
+    float right_det = (ptt.z * B.z) - (ptt.x * B.w);
     if(right_det > -CP_EPS) return false;
     return true;
 }
 
 // The same verdict from cheap arithmetic (one v_rsq_f32 instead of a correctly rounded sqrt and two
-// IEEE divides per side) whenever every comparison is decided with a safety margin; 2 = too close
-// to a threshold, the caller falls back to the exact evaluation.  The exact determinant differs
-// from (p.z*d.x - p.x*d.z)/|p| by < 4e-7 (six roundings of magnitudes <= 1) and the cheap one by
+// IEEE divides) whenever every comparison is decided with a safety margin; 2 = too close to a
+// threshold, the caller falls back to the exact evaluation.  The exact determinant differs from
+// (p.z*d.x - p.x*d.z)/|p| by < 4e-7 (six roundings of magnitudes <= 1) and the cheap one by
 // < 1.5e-6, so a margin of 2e-5 around the +-1/1024 thresholds leaves an order of magnitude of
 // slack; the |p| < 1/1024 test gets a relative margin of 1e-4.  The decisions -- hence the result
 // of inside_pcr -- are identical to the exact evaluation by construction.
-__device__ __forceinline__ int cone_contains_fast(float4 L, float4 R, v2 test)
+__device__ __forceinline__ int cone_contains_fast(float4 A, float4 B, v2 test)
 {
     const float MARG = 2e-5f;
-    float px = test.x - L.x, pz = test.z - L.y;
-    float s = px * px + pz * pz;
-    float inv = __builtin_amdgcn_rsqf(s);
-    float len = s * inv;
+    const float px = test.x - A.x, pz = test.z - A.y;
+    const float s = px * px + pz * pz;
+    const float inv = __builtin_amdgcn_rsqf(s);
+    const float len = s * inv;
     if(!(s > 0.0f) || !(s < 1e30f) || fabsf(len - CP_EPS) <= CP_EPS * 1e-4f) return 2;
     if(len < CP_EPS) return 0;
-    float det = (pz * L.z - px * L.w) * inv;
-    if(fabsf(det - CP_EPS) <= MARG) return 2;
-    if(det < CP_EPS) return 0;
-    px = test.x - R.x; pz = test.z - R.y;
-    s = px * px + pz * pz;
-    inv = __builtin_amdgcn_rsqf(s);
-    len = s * inv;
-    if(!(s > 0.0f) || !(s < 1e30f) || fabsf(len - CP_EPS) <= CP_EPS * 1e-4f) return 2;
-    if(len < CP_EPS) return 0;
-    det = (pz * R.z - px * R.w) * inv;
-    if(fabsf(det + CP_EPS) <= MARG) return 2;
-    if(det > -CP_EPS) return 0;
+    const float detl = (pz * B.x - px * B.y) * inv;
+    if(fabsf(detl - CP_EPS) <= MARG) return 2;
+    if(detl < CP_EPS) return 0;
+    const float detr = (pz * B.z - px * B.w) * inv;
+    if(fabsf(detr + CP_EPS) <= MARG) return 2;
+    if(detr > -CP_EPS) return 0;
     return 1;
 }
 
-__device__ __forceinline__ bool inside_pcr(const float4 *rays, int n_rays, v2 test)
+__device__ __forceinline__ bool cone_contains(float4 A, float4 B, v2 test)
 {
-    for(int i = 0; i < n_rays; i += 2) {
-        const float4 L = rays[i], R = rays[i + 1];
-        int v = cone_contains_fast(L, R, test);
-        if(v == 2) v = cone_contains_exact(L, R, test) ? 1 : 0;
-        if(v == 1) return true;
-    }
+    int v = cone_contains_fast(A, B, test);
+    if(v == 2) v = cone_contains_exact(A, B, test) ? 1 : 0;
+    return v == 1;
+}
+
+__device__ __forceinline__ bool inside_pcr(const float4 *cones, int n_cones, v2 test)
+{
+    for(int c = 0; c < n_cones; c++)
+        if(cone_contains(cones[2 * c], cones[2 * c + 1], test)) return true;
     return false;
 }
 
@@ -647,11 +689,42 @@ __device__ __forceinline__ void wave_argmin(float &key, int &idx)
     }
 }
 
-// G_ClearPath_NewVelocity (clearpath.c:694) for one agent on one wave.
-// dyn/stat: LDS arrays of 5 floats per neighbour (order matters); rays: LDS scratch, 128 float4.
-__device__ v2 clearpath_wave(const cpent &ent, v2 des_v, float *dyn, int n_dyn, float *stat,
-                             int n_stat, float4 *rays, int lane)
+// LDS scratch of one ClearPath problem: the cones (2 float4 each, <= 64 cones) and a queue of
+// candidate points (<= 128 pending)
+struct cp_scratch {
+    float4  *cones;      // [128]
+    float   *qx, *qz;    // [128]
+    int32_t *qi;         // [128]
+};
+
+// compute_vnew :368 keeps the first strictly-smaller distance in candidate order, i.e. the minimum
+// of (distance, order index): candidates can be examined in any order.
+struct cp_best { float len; int idx; v2 pt; bool any; };
+
+// one candidate per lane: drop it when it lies inside the combined obstacle, else rank it
+__device__ __forceinline__ void cp_rank(const cpent &ent, v2 des_v, const float4 *cones, int n_cones,
+                                        bool have, v2 pt, int order, cp_best &B)
 {
+    if(have && !inside_pcr(cones, n_cones, pt)) {
+        B.any = true;
+        const v2 curr = vsub(pt, ent.pos);
+        const float len = vlen(vsub(des_v, curr));
+        if(len < B.len || (len == B.len && order < B.idx)) { B.len = len; B.idx = order; B.pt = curr; }
+    }
+}
+
+// G_ClearPath_NewVelocity (clearpath.c:694) for one agent on one wave.
+// dyn/stat: LDS arrays of 5 floats per neighbour (order matters).
+//
+// Candidate points (ray-pair intersections, :321, then the projections of des_v on every ray, :344)
+// are produced 64 at a time, one ordered pair per lane; the pairs whose rays do meet are compacted
+// into the queue and the expensive part -- is the point inside any cone? -- always runs on 64 real
+// candidates per pass.
+__device__ v2 clearpath_wave(const cpent &ent, v2 des_v, float *dyn, int n_dyn, float *stat,
+                             int n_stat, const cp_scratch &S, int lane)
+{
+    if(n_dyn + n_stat == 0) return des_v;          // no obstacle: inside_pcr of nothing is false
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
     // at most 64 neighbours can be removed; the bound only guards against a NaN-poisoned input
     for(int guard = 0; guard < 66; guard++) {
         // ---- HRVOs for dynamic, VOs for static neighbours -> rays (rays_repr :291) -----------
@@ -666,70 +739,81 @@ __device__ v2 clearpath_wave(const cpent &ent, v2 des_v, float *dyn, int n_dyn, 
         }
         bool use = have && !(vlen(vsub(nb.pos, ent.pos)) < CP_EPS);
         v2 apex = mkv(0, 0), left = mkv(0, 0), right = mkv(0, 0);
-        if(use) {
-            if(isdyn) make_hrvo(ent, nb, apex, left, right);
-            else      make_vo(ent, nb, apex, left, right);
-        }
+        float sl = 0.0f, sr = 0.0f;
+        if(use) make_cone(ent, nb, isdyn, apex, left, right, sl, sr);
         uint64_t m = __ballot(use);
-        int slot = __popcll(m & ((1ull << lane) - 1ull));      // hrvos first, then vos, in order
-        int n_cones = __popcll(m);
-        int n_rays = 2 * n_cones;
+        int slot = __popcll(m & lt_mask);                      // hrvos first, then vos, in order
+        const int n_cones = __popcll(m);
+        const int n_rays = 2 * n_cones;
         wave_sync();
         if(use) {
-            rays[2 * slot]     = make_float4(apex.x, apex.z, left.x, left.z);
-            rays[2 * slot + 1] = make_float4(apex.x, apex.z, right.x, right.z);
+            S.cones[2 * slot]     = make_float4(apex.x, apex.z, sl, sr);
+            S.cones[2 * slot + 1] = make_float4(left.x, left.z, right.x, right.z);
         }
         wave_sync();
 
-        v2 des_ws = vadd(ent.pos, des_v);
-        if(!inside_pcr(rays, n_rays, des_ws))                  // wave-uniform inputs
+        // des_v admissible as it is?  lane = cone
+        const v2 des_ws = vadd(ent.pos, des_v);
+        bool in = false;
+        if(lane < n_cones) in = cone_contains(S.cones[2 * lane], S.cones[2 * lane + 1], des_ws);
+        if(!__any(in))
             return des_v;
 
-        // ---- candidate points: ray-pair intersections (i-major, :321) then projections (:344)
-        float best = __builtin_inff();
-        int   best_idx = 0x7fffffff;
-        v2    best_pt = mkv(0, 0);
-        bool  any_pt = false;
+        cp_best B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.any = false;
+        int qn = 0;                                            // pending candidates (wave uniform)
         const int npairs = n_rays * n_rays;
-        for(int p0 = 0; p0 < npairs; p0 += 64) {
-            int p = p0 + lane;
+        const float inv_nr = 1.0f / (float)n_rays;
+        for(int p0 = 0; p0 < npairs + n_rays; p0 += 64) {
+            const int p = p0 + lane;
+            bool ok = false;
+            v2 pt = mkv(0, 0);
             if(p < npairs) {
-                int i = p / n_rays, j = p - i * n_rays;
+                // (i, j) = divmod(p, n_rays): float estimate + one correction step (p < 2^14)
+                int i = (int)((float)p * inv_nr);
+                int j = p - i * n_rays;
+                if(j < 0) { i--; j += n_rays; }
+                if(j >= n_rays) { i++; j -= n_rays; }
                 if(i != j) {
-                    float4 a = rays[i], b = rays[j];
-                    ray ri = {mkv(a.x, a.y), mkv(a.z, a.w)}, rj = {mkv(b.x, b.y), mkv(b.z, b.w)};
-                    v2 pt;
-                    if(ray_isect(ri, rj, pt) && !inside_pcr(rays, n_rays, pt)) {
-                        any_pt = true;
-                        v2 curr = vsub(pt, ent.pos);
-                        float len = vlen(vsub(des_v, curr));
-                        if(len < best) { best = len; best_idx = p; best_pt = curr; }
-                    }
+                    const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
+                    const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                    const bool ri = i & 1, rj = j & 1;
+                    ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
+                                   mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z,
+                                   pt);
                 }
+            }else if(p < npairs + n_rays) {
+                const int i = p - npairs;
+                const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
+                const v2 dir = (i & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
+                const float len = vdot(dir, des_v);
+                pt = vadd(point, vscale(dir, len));
+                ok = true;
+            }
+            const uint64_t mk = __ballot(ok);
+            if(ok) {
+                const int at = qn + __popcll(mk & lt_mask);
+                S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = p;
+            }
+            qn += __popcll(mk);
+            wave_sync();
+            if(qn >= 64) {
+                qn -= 64;
+                cp_rank(ent, des_v, S.cones, n_cones, true, mkv(S.qx[qn + lane], S.qz[qn + lane]),
+                        S.qi[qn + lane], B);
+                wave_sync();
             }
         }
-        for(int i0 = 0; i0 < n_rays; i0 += 64) {
-            int i = i0 + lane;
-            if(i < n_rays) {
-                float4 a = rays[i];
-                v2 dir = mkv(a.z, a.w), point = mkv(a.x, a.y);
-                float len = vdot(dir, des_v);
-                v2 proj = vadd(point, vscale(dir, len));
-                if(!inside_pcr(rays, n_rays, proj)) {
-                    any_pt = true;
-                    v2 curr = vsub(proj, ent.pos);
-                    float l2 = vlen(vsub(des_v, curr));
-                    if(l2 < best) { best = l2; best_idx = npairs + i; best_pt = curr; }
-                }
-            }
+        if(qn > 0) {
+            const bool mine = lane < qn;
+            cp_rank(ent, des_v, S.cones, n_cones, mine, mine ? mkv(S.qx[lane], S.qz[lane]) : mkv(0, 0),
+                    mine ? S.qi[lane] : 0, B);
         }
-        if(__any(any_pt)) {
-            // compute_vnew :368: first strictly-smaller distance wins, i.e. min (len, order index)
-            float key = best; int idx = best_idx;
+        if(__any(B.any)) {
+            float key = B.len; int idx = B.idx;
             wave_argmin(key, idx);
             if(!(key < __builtin_inff())) return mkv(0.0f, 0.0f);   // only NaN distances: ret stays 0
-            int owner = __ffsll((unsigned long long)__ballot(best_idx == idx && best == key)) - 1;
-            return mkv(__shfl(best_pt.x, owner), __shfl(best_pt.z, owner));
+            int owner = __ffsll((unsigned long long)__ballot(B.idx == idx && B.len == key)) - 1;
+            return mkv(__shfl(B.pt.x, owner), __shfl(B.pt.z, owner));
         }
 
         // ---- no admissible point: remove_furthest (:390) and retry while both lists non-empty
@@ -1107,7 +1191,7 @@ struct wave_lds {
     uint32_t ids30[128];                       // separation query result (cap 128, :1695)
     union {
         uint32_t ids10[512];                   // ClearPath neighbour query result (cap 512, :2779)
-        float4   rays[128];                    // later: the combined obstacle as rays
+        float4   rays[128];                    // later: the combined obstacle, two float4 per cone
         float    sep[256];                     // earlier: separation terms x[128], z[128]
     } u;
     float dyn[32 * 5];
@@ -1408,6 +1492,7 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
     if(uid >= P.work_end) return;
     wave_lds &W = lds[wib];
 
+    SEC_BEGIN();
     const nh_pre_rec R = pre[uid];
     v2 out_vel = mkv(0.0f, 0.0f), vpref = mkv(0.0f, 0.0f);
     if(R.mode != AM_IDLE && R.mode != AM_UNSUPPORTED) {
@@ -1427,14 +1512,35 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
             const tile_probes probes = unpack_probes(R.probes);
             const v2 arrive = mkv(R.arrive[0], R.arrive[1]);
             // separation (movement.c:1690): r = 30 query, cap 128
+            SEC_MARK(0);
+#if NH_DUP == 1
+            sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
+            wave_sync(); DUP_BARRIER();
+#endif
             int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
             wave_sync();
+            SEC_MARK(1);
             n30raw = n30;
+#if NH_DUP == 2
+            derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
+            filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
+            wave_sync(); DUP_BARRIER();
+#endif
             const int n10d = derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
             n30 = filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
             if(n10d < 0) n30raw = -1; else n30raw = n10d;
+            SEC_MARK(2);
+#if NH_DUP == 3
+            {
+                const v2 sdup = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
+                                                W.u.sep, scaled_max_force, lane, exp_tab);
+                if(sdup.x == 12345.678f) W.d2_30[0] = 1;        // keep it alive
+                wave_sync(); DUP_BARRIER();
+            }
+#endif
             const v2 separation = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
                                                   W.u.sep, scaled_max_force, lane, exp_tab);
+            SEC_MARK(3);
             v2 steer;
             if(R.mode == AM_ENEMY_SEEK) {
                 // enemy_seek_vpref :1946 (no priorities, no nullify)
@@ -1487,6 +1593,7 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
 
         // find_neighbours :2768: r = 10 query, cap 512 -- taken from the r = 30 list when that list
         // is complete (n30raw now holds the derived count, -1 = not derivable)
+        SEC_MARK(4);
         uint32_t *ids10 = W.u.ids10;
         int n10;
         if(n30raw >= 0) {
@@ -1498,9 +1605,25 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
         }
         n10 = filter_garrisoned_wave(P.flags, ids10, n10, lane);
         int n_dyn, n_stat;
+#if NH_DUP == 4
+        filter_garrisoned_wave(P.flags, ids10, n10, lane);
         classify_neighbours(P, uid, my_flags, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
+        wave_sync(); DUP_BARRIER();
+#endif
+        classify_neighbours(P, uid, my_flags, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
+        SEC_MARK(5);
         cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
-        v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, W.u.rays, lane);
+        // the neighbour lists are dead from here on: their LDS becomes the candidate queue
+        const cp_scratch cps = {W.u.rays, (float*)W.d2_30, (float*)W.ids10d, (int32_t*)W.ids30};
+#if NH_DUP == 5
+        {
+            v2 ndup = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, cps, lane);
+            if(ndup.x == 12345.678f) W.dyn[0] = 1.0f;
+            wave_sync(); DUP_BARRIER();
+        }
+#endif
+        v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, cps, lane);
+        SEC_MARK(6);
         out_vel = vtrunc(nv, max_speed / (float)hz);                   // :3464
     }
     if(lane == 0) {
@@ -1574,8 +1697,9 @@ __global__ __launch_bounds__(256) void k_clearpath(int nq, const float *ent, con
     wave_sync();
     cpent e; e.pos = mkv(ent[5 * q], ent[5 * q + 1]); e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]);
     e.radius = ent[5 * q + 4];
+    const cp_scratch cps = {W.u.rays, (float*)W.d2_30, (float*)W.ids10d, (int32_t*)W.ids30};
     v2 r = clearpath_wave(e, mkv(des_v[2 * q], des_v[2 * q + 1]), W.dyn, n_dyn[q], W.stat, n_stat[q],
-                          W.u.rays, lane);
+                          cps, lane);
     if(lane == 0) { out[2 * q] = r.x; out[2 * q + 1] = r.z; }
 }
 
