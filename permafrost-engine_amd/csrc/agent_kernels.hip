@@ -34,6 +34,8 @@
 // exact-arithmetic helpers (pf_math.c:58-94)
 // ---------------------------------------------------------------------------------------------
 struct v2 { float x, z; };
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ v2 mkv(float x, float z) { v2 r; r.x = x; r.z = z; return r; }
 __device__ __forceinline__ v2 vadd(v2 a, v2 b) { return mkv(a.x + b.x, a.z + b.z); }
@@ -919,6 +921,29 @@ __device__ __forceinline__ float exp_f32_lowconv(float a, const double *tab)
     return (a <= -103.98f) ? 0.0f : res;
 }
 
+// The same value with the reduction done in double: k = rint(x * 64/ln2) falls out of the low
+// mantissa bits of x * 64/ln2 + 1.5 * 2^52 (one FMA), and no final select is needed -- the clamped
+// argument -104 gives 6.8e-46, which the f64 -> f32 conversion rounds to +0 like every value below
+// half the smallest denormal (the true cut-off is a = -103.972).  Checked against glibc's exp on
+// 3e8 random arguments in [-110, 6] and on every float in [-104.5, -102]: no mismatch.
+__device__ __forceinline__ float exp_f32_magic(float a, const double *tab)
+{
+    const double x = (double)fmaxf(a, -104.0f);
+    const double z = __builtin_fma(x, 0x1.71547652b82fep+6, 0x1.8p52);   // 64/ln2
+    const double kd = z - 0x1.8p52;
+    const int k = (int)__double_as_longlong(z);
+    double r = __builtin_fma(-kd, 0x1.62e42fefa0000p-7, x);              // ln2/64, high part
+    r = __builtin_fma(-kd, 0x1.cf79abc9e3b3ap-46, r);                    //         low part
+    double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
+    p = __builtin_fma(p, r, 1.0 / 6);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double v = tab[k & 63] * p;
+    const long long bits = __double_as_longlong(v) + ((long long)(k >> 6) << 52);
+    return (float)__longlong_as_double(bits);
+}
+
 // Correctly rounded sqrt for s == 0 or s in the normal range well away from its ends: v_sqrt_f32
 // (<= 1 ulp) plus the same one-ulp fix-up the compiler's IEEE expansion uses, without that
 // expansion's input scaling / class handling (which only matter for denormal, infinite or NaN s).
@@ -1055,8 +1080,10 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
                                                  const int32_t *perm, float *coh_xz)
 {
     __shared__ double tab[64];
-    __shared__ float2 spos[256];
-    __shared__ uint8_t near_ix[256];
+    // the members of the current tile that survive the box test, in member order (+ carry-over)
+    __shared__ __attribute__((aligned(16))) float qx[272];
+    __shared__ __attribute__((aligned(16))) float qz[272];
+    __shared__ __attribute__((aligned(16))) f2 qxz[272];
     const int t = threadIdx.x;
     const int wv = blockIdx.x;
     if(wv >= wave_off[P.n_flocks]) return;
@@ -1090,93 +1117,136 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
         bz0 = fminf(bz0, __shfl_xor(bz0, d)); bz1 = fmaxf(bz1, __shfl_xor(bz1, d));
     }
     const unsigned long long lt_mask = (1ull << t) - 1ull;
-    v2 com = mkv(0.0f, 0.0f);
+    const f2 mex = {me.x, me.x}, mez = {me.z, me.z};
+    f2 com = {0.0f, 0.0f};                                // (x, z)
+    int self_k = -1;                                      // queue slot of this thread's own member
+    int pend = 0;                                         // members carried over from the last tile
+    // One member of the walk: distance -> weight -> ordered sum (the tail of the last tile only)
+    auto one = [&](int k) {
+        const f2 c = qxz[k];
+        const float ln = vlen(mkv(c.x - me.x, c.y - me.z));
+        const float tt = ln < 16.0f ? cohesion_t_f64(ln) : cohesion_t_f32(ln);
+        const float w = (k == self_k) ? 0.0f : exp_f32_magic(-6.0f * tt, tab);
+        com = com + c * w;
+    };
     for(int jb = b; jb < e; jb += 256) {
-        __syncthreads();
-        int ncnt = 0;
+        // ---- stage the tile: members that can matter to this wave, compacted in member order, as
+        // x[] / z[] (four members per 16-byte LDS read in the distance part) and as (x, z) pairs
+        // (the ordered sums); slots [0, pend) hold the carry-over of the previous tile
+        int ncnt = pend;
+        const int gl = act ? g - jb : -1;                 // own slot in the unfiltered tile, if any
 #pragma unroll
         for(int q = 0; q < 4; q++) {
             const int j = jb + q * 64 + t;
             bool keep = false;
+            float2 c2 = make_float2(0.0f, 0.0f);
             if(j < e) {
                 const int m = P.flock_members[j];
-                const float2 c2 = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
-                spos[q * 64 + t] = c2;
+                c2 = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
                 const float dx = fmaxf(fmaxf(bx0 - c2.x, c2.x - bx1), 0.0f);
                 const float dz = fmaxf(fmaxf(bz0 - c2.y, c2.y - bz1), 0.0f);
                 keep = !(dx * dx + dz * dz > COH_FAR * COH_FAR);       // NaN stays in
             }
             const unsigned long long mk = __ballot(keep);
-            if(keep) near_ix[ncnt + __popcll(mk & lt_mask)] = (uint8_t)(q * 64 + t);
+            const int at = ncnt + __popcll(mk & lt_mask);
+            if(keep) { qx[at] = c2.x; qz[at] = c2.y; qxz[at] = f2{c2.x, c2.y}; }
+            // (an active member lies inside the wave's box, so it is always kept)
+            const int at_self = __shfl(at, gl & 63);
+            if((gl >> 6) == q) self_k = at_self;          // gl < 0 or >= 256 never matches q = 0..3
             ncnt += __popcll(mk);
         }
         __syncthreads();
-        const int cnt = ncnt;
-        const int gl = g - jb;                            // this member's own slot in the tile, if any
+        const int cnt16 = ncnt & ~15;
         if(act) {
-            // COH_U independent weight evaluations in flight (the chain sqrt -> double
-            // divide -> exp is ~45 dependent instructions), then the ordered float sums
-            constexpr int COH_U = 16;
-            int jj = 0;
-            for(; jj + COH_U <= cnt; jj += COH_U) {
-                v2 cp[COH_U];
-                int ix[COH_U];
-                float ss[COH_U], ln[COH_U], tt[COH_U], sc[COH_U];
+            // 16 independent weight evaluations in flight (the chain sqrt -> divide -> exp is ~45
+            // dependent instructions), two members per packed f32 instruction where the operation
+            // exists in packed form, then the ordered float sums
+            for(int jj = 0; jj < cnt16; jj += 16) {
+                f2 ss[8], ln[8], tt[8];
+                float sc[16];
                 bool close = false, odd = false;
 #pragma unroll
-                for(int u = 0; u < COH_U; u++) {
-                    ix[u] = near_ix[jj + u];
-                    const float2 c2 = spos[ix[u]];
-                    cp[u] = mkv(c2.x, c2.y);
-                    const v2 d = vsub(cp[u], me);
-                    ss[u] = d.x * d.x + d.z * d.z;
-                    ln[u] = sqrt_rn_normal(ss[u]);
-                    // outside [2^-90, 2^90] (or NaN) and not exactly 0: leave it to the
-                    // general IEEE expansion
-                    odd |= !(ss[u] >= 0x1p-90f && ss[u] <= 0x1p90f) && ss[u] != 0.0f;
+                for(int v = 0; v < 4; v++) {
+                    const f4 xs = *(const f4*)&qx[jj + 4 * v], zs = *(const f4*)&qz[jj + 4 * v];
+                    const f2 dxa = f2{xs.x, xs.y} - mex, dxb = f2{xs.z, xs.w} - mex;
+                    const f2 dza = f2{zs.x, zs.y} - mez, dzb = f2{zs.z, zs.w} - mez;
+                    ss[2 * v] = dxa * dxa + dza * dza;
+                    ss[2 * v + 1] = dxb * dxb + dzb * dzb;
+                }
+#pragma unroll
+                for(int u = 0; u < 8; u++) {
+                    // sqrt_rn_normal on both halves
+                    f2 r = {__builtin_amdgcn_sqrtf(ss[u].x), __builtin_amdgcn_sqrtf(ss[u].y)};
+                    const f2 rm = {__int_as_float(__float_as_int(r.x) - 1), __int_as_float(__float_as_int(r.y) - 1)};
+                    const f2 rp = {__int_as_float(__float_as_int(r.x) + 1), __int_as_float(__float_as_int(r.y) + 1)};
+                    const f2 em = __builtin_elementwise_fma(-rm, r, ss[u]);
+                    const f2 ep = __builtin_elementwise_fma(-rp, r, ss[u]);
+                    r.x = (em.x <= 0.0f) ? rm.x : r.x;  r.y = (em.y <= 0.0f) ? rm.y : r.y;
+                    r.x = (ep.x > 0.0f) ? rp.x : r.x;   r.y = (ep.y > 0.0f) ? rp.y : r.y;
+                    ln[u] = r;
+                    // outside [2^-90, 2^90] (or NaN) and not exactly 0: leave it to the general
+                    // IEEE expansion
+                    odd |= !(ss[u].x >= 0x1p-90f && ss[u].x <= 0x1p90f) && ss[u].x != 0.0f;
+                    odd |= !(ss[u].y >= 0x1p-90f && ss[u].y <= 0x1p90f) && ss[u].y != 0.0f;
                 }
                 if(__any(odd)) {
+                    asm volatile("" ::: "memory");        // keep the expansion out of the common path
 #pragma unroll
-                    for(int u = 0; u < COH_U; u++) ln[u] = __builtin_sqrtf(ss[u]);
+                    for(int u = 0; u < 8; u++) ln[u] = f2{__builtin_sqrtf(ss[u].x), __builtin_sqrtf(ss[u].y)};
                 }
 #pragma unroll
-                for(int u = 0; u < COH_U; u++) {
-                    tt[u] = cohesion_t_f32(ln[u]);
-                    close |= ln[u] < 16.0f;
+                for(int u = 0; u < 8; u++) {
+                    // cohesion_t_f32 on both halves
+                    const f2 x = ln[u] - 37.5f;
+                    const f2 q0 = x * (1.0f / 50.0f);
+                    const f2 inner = __builtin_elementwise_fma(-q0, f2{50.0f, 50.0f}, x);
+                    tt[u] = __builtin_elementwise_fma(inner, f2{1.0f / 50.0f, 1.0f / 50.0f}, q0);
+                    close |= ln[u].x < 16.0f || ln[u].y < 16.0f;
                 }
                 if(__any(close)) {                // rare unless the flock is one dense cluster
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                    for(int u = 0; u < COH_U; u++)
-                        if(ln[u] < 16.0f) tt[u] = cohesion_t_f64(ln[u]);
+                    for(int u = 0; u < 8; u++) {
+                        if(ln[u].x < 16.0f) tt[u].x = cohesion_t_f64(ln[u].x);
+                        if(ln[u].y < 16.0f) tt[u].y = cohesion_t_f64(ln[u].y);
+                    }
                 }
 #pragma unroll
-                for(int u = 0; u < COH_U; u++)
-                    sc[u] = exp_f32_lowconv(-6.0f * tt[u], tab);
+                for(int u = 0; u < 8; u++) {
+                    const f2 a = tt[u] * -6.0f;
+                    sc[2 * u] = exp_f32_magic(a.x, tab);
+                    sc[2 * u + 1] = exp_f32_magic(a.y, tab);
+                }
 #pragma unroll
-                for(int u = 0; u < COH_U; u++) {
+                for(int u = 0; u < 16; u++) {
                     // curr == uid is skipped by the reference: a zero weight adds +-0, which
                     // leaves the (never negative-zero) running sum unchanged
-                    const float w = (ix[u] == gl) ? 0.0f : sc[u];
-                    com = vadd(com, vscale(cp[u], w));
+                    const float w = (jj + u == self_k) ? 0.0f : sc[u];
+                    com = com + qxz[jj + u] * w;
                 }
             }
-            for(; jj < cnt; jj++) {
-                const int ix = near_ix[jj];
-                const float2 c2 = spos[ix];
-                const v2 cp = mkv(c2.x, c2.y);
-                const float ln = vlen(vsub(cp, me));
-                const float tt = ln < 16.0f ? cohesion_t_f64(ln) : cohesion_t_f32(ln);
-                const float w = (ix == gl) ? 0.0f : exp_f32_lowconv(-6.0f * tt, tab);
-                com = vadd(com, vscale(cp, w));
-            }
+        }
+        // ---- carry the last (< 16) members over to the next tile, or finish them one by one
+        pend = ncnt - cnt16;
+        const bool last = jb + 256 >= e;
+        if(last) {
+            if(act) for(int k = cnt16; k < ncnt; k++) one(k);
+        }else{
+            float cx = 0.0f, cz = 0.0f;
+            if(t < pend) { cx = qx[cnt16 + t]; cz = qz[cnt16 + t]; }
+            __syncthreads();
+            if(t < pend) { qx[t] = cx; qz[t] = cz; qxz[t] = f2{cx, cz}; }
+            self_k = (self_k >= cnt16) ? self_k - cnt16 : -1;
+            __syncthreads();
         }
     }
+    const v2 comv = mkv(com.x, com.y);
     if(act) {
         const int count = (e - b) - 1;
         v2 ret = mkv(0.0f, 0.0f);
         if(count > 0) {
-            com = vscale(com, 1.0f / (float)count);
-            ret = vtrunc(vsub(com, me), scaled_max_force);
+            const v2 cm = vscale(comv, 1.0f / (float)count);
+            ret = vtrunc(vsub(cm, me), scaled_max_force);
         }
         coh_xz[2 * uid] = ret.x;
         coh_xz[2 * uid + 1] = ret.z;
