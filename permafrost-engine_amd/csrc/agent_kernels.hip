@@ -978,8 +978,8 @@ __device__ __forceinline__ float cohesion_t_f64(float len)
     return (float)__builtin_fma(__builtin_fma(-q0, 50.0, x), r50, q0);
 }
 
-// k_coh_plan: wave_off[f] = number of 64-member waves of the flocks before f (exclusive scan of
-// ceil(size/64)); one workgroup, chunked.
+// k_coh_plan: wave_off[f] = number of 16-member (COH_APW) waves of the flocks before f (exclusive
+// scan of ceil(size/16)); one workgroup, chunked.
 __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *flock_offsets, int n_flocks,
                                                   int32_t *wave_off)
 {
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *flock_offsets, 
     for(int base = 0; base < n_flocks; base += 256) {
         const int f = base + t;
         int32_t v = 0;
-        if(f < n_flocks) v = (flock_offsets[f + 1] - flock_offsets[f] + 63) >> 6;
+        if(f < n_flocks) v = (flock_offsets[f + 1] - flock_offsets[f] + 15) >> 4;      // COH_APW
         int32_t incl = v;
 #pragma unroll
         for(int d = 1; d < 64; d <<= 1) {
@@ -1068,23 +1068,129 @@ __global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int
 // margin for the roundings of the box test
 #define COH_FAR 906.0f
 
-// k_cohesion: one WAVE (= one 64-thread workgroup) per 64 members of ONE flock (perm[] order),
-// thread = member.  A wave never straddles two flocks (a straddling workgroup would walk two whole
-// flocks and become the tail of the launch).  The flock's member positions are staged through LDS
-// 256 at a time (coalesced gather); a lane-parallel pre-pass drops the staged members that lie more
-// than COH_FAR from the bounding box of the wave's own members (their weight is exactly 0 for every
-// lane, and adding +-0 leaves the never-negative-zero running sums unchanged), and every thread
-// walks the survivors IN MEMBER ORDER (float sums are order dependent; LDS reads are wave-uniform
-// broadcasts), so the only global traffic in the O(N*F) loop is the staging itself.
+// k_cohesion: one WAVE (= one 64-thread workgroup) per COH_APW = 16 members of ONE flock (perm[]
+// order); FOUR lanes share a member (lane = member << 2 | sub).  A wave never straddles two flocks.
+//
+// The flock's member positions are staged through LDS 256 at a time (coalesced gather); a
+// lane-parallel pre-pass drops the staged members that lie more than COH_FAR from the bounding box
+// of the wave's own members (their weight is exactly 0 for every lane, and adding +-0 leaves the
+// never-negative-zero running sums unchanged) and queues the survivors IN MEMBER ORDER.  Queue entry
+// k belongs to sub-lane k & 3: each lane evaluates the expensive part (distance -> t -> exp, ~36
+// instructions per entry) for a quarter of the entries only, eight at a time, two per packed f32
+// instruction.  The float sums are order dependent, so the products are then added strictly in
+// entry order: the sub-lane that owns entry k broadcasts its product to the quad (DPP quad_perm as
+// an operand of the add) and all four lanes keep the same running sum.
+//
+// Why four lanes per member: with one lane per member the launch was 1 600 long waves on 1 024 SIMDs
+// (one or two per SIMD, 25 000 instructions each, nothing to hide a wave's own scalar/LDS/
+// transcendental issue slots behind); 6 500 shorter waves fill every SIMD six deep for about the
+// same instruction total, and a 16-member box is tighter than a 64-member one.
+#define COH_APW 16
+#define COH_QS  72            /* queue slots per sub-lane: (256 staged + 31 carried) / 4 */
+
+__device__ __forceinline__ float quad_bcast(float v, int sub)
+{
+    // quad_perm:[sub,sub,sub,sub]
+    switch(sub) {
+    case 0:  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xf, 0xf, true));
+    case 1:  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55, 0xf, 0xf, true));
+    case 2:  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xaa, 0xf, 0xf, true));
+    default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xff, 0xf, 0xf, true));
+    }
+}
+
+// 32 queue entries starting at entry jj (a multiple of 32): this lane's eight are local slots
+// jj/4 .. jj/4+7 of its own quarter.  TAIL: entries >= n_valid are padding (weight 0).
+template <bool TAIL>
+__device__ __forceinline__ void coh_batch(const float *qx, const float *qz, const double *tab, int sub,
+                                          int jj, int n_valid, int self_k, v2 me, float &comx, float &comz)
+{
+    const f2 mex = {me.x, me.x}, mez = {me.z, me.z};
+    const int lo = sub * COH_QS + (jj >> 2);
+    f2 X[4], Z[4], ss[4], ln[4], tt[4], W[4];
+    bool close = false, odd = false;
+    {
+        const f4 xa = *(const f4*)&qx[lo], xb = *(const f4*)&qx[lo + 4];
+        const f4 za = *(const f4*)&qz[lo], zb = *(const f4*)&qz[lo + 4];
+        X[0] = f2{xa.x, xa.y}; X[1] = f2{xa.z, xa.w}; X[2] = f2{xb.x, xb.y}; X[3] = f2{xb.z, xb.w};
+        Z[0] = f2{za.x, za.y}; Z[1] = f2{za.z, za.w}; Z[2] = f2{zb.x, zb.y}; Z[3] = f2{zb.z, zb.w};
+    }
+#pragma unroll
+    for(int u = 0; u < 4; u++) {
+        const f2 dx = X[u] - mex, dz = Z[u] - mez;
+        ss[u] = dx * dx + dz * dz;
+        // sqrt_rn_normal on both halves
+        f2 r = {__builtin_amdgcn_sqrtf(ss[u].x), __builtin_amdgcn_sqrtf(ss[u].y)};
+        const f2 rm = {__int_as_float(__float_as_int(r.x) - 1), __int_as_float(__float_as_int(r.y) - 1)};
+        const f2 rp = {__int_as_float(__float_as_int(r.x) + 1), __int_as_float(__float_as_int(r.y) + 1)};
+        const f2 em = __builtin_elementwise_fma(-rm, r, ss[u]);
+        const f2 ep = __builtin_elementwise_fma(-rp, r, ss[u]);
+        r.x = (em.x <= 0.0f) ? rm.x : r.x;  r.y = (em.y <= 0.0f) ? rm.y : r.y;
+        r.x = (ep.x > 0.0f) ? rp.x : r.x;   r.y = (ep.y > 0.0f) ? rp.y : r.y;
+        ln[u] = r;
+        // outside [2^-90, 2^90] (or NaN) and not exactly 0: leave it to the general IEEE expansion
+        odd |= !(ss[u].x >= 0x1p-90f && ss[u].x <= 0x1p90f) && ss[u].x != 0.0f;
+        odd |= !(ss[u].y >= 0x1p-90f && ss[u].y <= 0x1p90f) && ss[u].y != 0.0f;
+    }
+    if(__any(odd)) {
+        asm volatile("" ::: "memory");        // keep the expansion out of the common path
+#pragma unroll
+        for(int u = 0; u < 4; u++) ln[u] = f2{__builtin_sqrtf(ss[u].x), __builtin_sqrtf(ss[u].y)};
+    }
+#pragma unroll
+    for(int u = 0; u < 4; u++) {
+        // cohesion_t_f32 on both halves
+        const f2 x = ln[u] - 37.5f;
+        const f2 q0 = x * (1.0f / 50.0f);
+        const f2 inner = __builtin_elementwise_fma(-q0, f2{50.0f, 50.0f}, x);
+        tt[u] = __builtin_elementwise_fma(inner, f2{1.0f / 50.0f, 1.0f / 50.0f}, q0);
+        close |= ln[u].x < 16.0f || ln[u].y < 16.0f;
+    }
+    if(__any(close)) {                // rare unless the flock is one dense cluster
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for(int u = 0; u < 4; u++) {
+            if(ln[u].x < 16.0f) tt[u].x = cohesion_t_f64(ln[u].x);
+            if(ln[u].y < 16.0f) tt[u].y = cohesion_t_f64(ln[u].y);
+        }
+    }
+    const int k0 = jj + sub;                  // entry number of this lane's first entry; then +4 each
+#pragma unroll
+    for(int u = 0; u < 4; u++) {
+        const f2 a = tt[u] * -6.0f;
+        float w0 = exp_f32_magic(a.x, tab), w1 = exp_f32_magic(a.y, tab);
+        // curr == uid is skipped by the reference: a zero weight adds +-0, which leaves the (never
+        // negative-zero) running sum unchanged; so does the padding of the last batch
+        const int ka = k0 + 8 * u, kb = ka + 4;
+        if(ka == self_k || (TAIL && ka >= n_valid)) w0 = 0.0f;
+        if(kb == self_k || (TAIL && kb >= n_valid)) w1 = 0.0f;
+        W[u] = f2{w0, w1};
+    }
+    // products, then the ordered sums: entry jj + 4*i + s is held by sub-lane s as element i
+#pragma unroll
+    for(int u = 0; u < 4; u++) {
+        const f2 px = X[u] * W[u], pz = Z[u] * W[u];
+#pragma unroll
+        for(int h = 0; h < 2; h++) {
+            const float tx = h ? px.y : px.x, tz = h ? pz.y : pz.x;
+#pragma unroll
+            for(int sb = 0; sb < 4; sb++) {
+                comx = comx + quad_bcast(tx, sb);
+                comz = comz + quad_bcast(tz, sb);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off,
                                                  const int32_t *perm, float *coh_xz)
 {
     __shared__ double tab[64];
-    // the members of the current tile that survive the box test, in member order (+ carry-over)
-    __shared__ __attribute__((aligned(16))) float qx[272];
-    __shared__ __attribute__((aligned(16))) float qz[272];
-    __shared__ __attribute__((aligned(16))) f2 qxz[272];
-    const int t = threadIdx.x;
+    // the members of the current tile that survive the box test, in member order (+ carry-over):
+    // entry k lives in slot (k & 3) * COH_QS + (k >> 2)
+    __shared__ __attribute__((aligned(16))) float qx[4 * COH_QS];
+    __shared__ __attribute__((aligned(16))) float qz[4 * COH_QS];
+    const int t = threadIdx.x, sub = t & 3;
     const int wv = blockIdx.x;
     if(wv >= wave_off[P.n_flocks]) return;
     tab[t] = c_exp2_64[t];
@@ -1100,9 +1206,9 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     }
     const float scaled_max_force = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
-    const int gp = b + (wv - wave_off[f]) * 64 + t;
+    const int gp = b + (wv - wave_off[f]) * COH_APW + (t >> 2);
     const bool mine = gp < e;
-    const int g = mine ? perm[gp] : -1;                  // CSR entry of this thread's member
+    const int g = mine ? perm[gp] : -1;                  // CSR entry of this quad's member
     const int uid = mine ? P.flock_members[g] : -1;
     bool act = mine && uid >= P.work_begin && uid < P.work_end;
     if(act) act = state_uses_point_seek(P.state[uid]) && !(P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD);
@@ -1112,27 +1218,16 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     float bx0 = act ? me.x : INFINITY, bx1 = act ? me.x : -INFINITY;
     float bz0 = act ? me.z : INFINITY, bz1 = act ? me.z : -INFINITY;
 #pragma unroll
-    for(int d = 1; d < 64; d <<= 1) {
+    for(int d = 4; d < 64; d <<= 1) {
         bx0 = fminf(bx0, __shfl_xor(bx0, d)); bx1 = fmaxf(bx1, __shfl_xor(bx1, d));
         bz0 = fminf(bz0, __shfl_xor(bz0, d)); bz1 = fmaxf(bz1, __shfl_xor(bz1, d));
     }
     const unsigned long long lt_mask = (1ull << t) - 1ull;
-    const f2 mex = {me.x, me.x}, mez = {me.z, me.z};
-    f2 com = {0.0f, 0.0f};                                // (x, z)
-    int self_k = -1;                                      // queue slot of this thread's own member
-    int pend = 0;                                         // members carried over from the last tile
-    // One member of the walk: distance -> weight -> ordered sum (the tail of the last tile only)
-    auto one = [&](int k) {
-        const f2 c = qxz[k];
-        const float ln = vlen(mkv(c.x - me.x, c.y - me.z));
-        const float tt = ln < 16.0f ? cohesion_t_f64(ln) : cohesion_t_f32(ln);
-        const float w = (k == self_k) ? 0.0f : exp_f32_magic(-6.0f * tt, tab);
-        com = com + c * w;
-    };
+    float comx = 0.0f, comz = 0.0f;
+    int self_k = -1;                                      // queue entry of this quad's own member
+    int pend = 0;                                         // entries carried over from the last tile
     for(int jb = b; jb < e; jb += 256) {
-        // ---- stage the tile: members that can matter to this wave, compacted in member order, as
-        // x[] / z[] (four members per 16-byte LDS read in the distance part) and as (x, z) pairs
-        // (the ordered sums); slots [0, pend) hold the carry-over of the previous tile
+        // ---- stage the tile behind the carry-over [0, pend)
         int ncnt = pend;
         const int gl = act ? g - jb : -1;                 // own slot in the unfiltered tile, if any
 #pragma unroll
@@ -1149,103 +1244,43 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
             }
             const unsigned long long mk = __ballot(keep);
             const int at = ncnt + __popcll(mk & lt_mask);
-            if(keep) { qx[at] = c2.x; qz[at] = c2.y; qxz[at] = f2{c2.x, c2.y}; }
+            if(keep) { const int sl = (at & 3) * COH_QS + (at >> 2); qx[sl] = c2.x; qz[sl] = c2.y; }
             // (an active member lies inside the wave's box, so it is always kept)
             const int at_self = __shfl(at, gl & 63);
             if((gl >> 6) == q) self_k = at_self;          // gl < 0 or >= 256 never matches q = 0..3
             ncnt += __popcll(mk);
         }
-        __syncthreads();
-        const int cnt16 = ncnt & ~15;
-        if(act) {
-            // 16 independent weight evaluations in flight (the chain sqrt -> divide -> exp is ~45
-            // dependent instructions), two members per packed f32 instruction where the operation
-            // exists in packed form, then the ordered float sums
-            for(int jj = 0; jj < cnt16; jj += 16) {
-                f2 ss[8], ln[8], tt[8];
-                float sc[16];
-                bool close = false, odd = false;
-#pragma unroll
-                for(int v = 0; v < 4; v++) {
-                    const f4 xs = *(const f4*)&qx[jj + 4 * v], zs = *(const f4*)&qz[jj + 4 * v];
-                    const f2 dxa = f2{xs.x, xs.y} - mex, dxb = f2{xs.z, xs.w} - mex;
-                    const f2 dza = f2{zs.x, zs.y} - mez, dzb = f2{zs.z, zs.w} - mez;
-                    ss[2 * v] = dxa * dxa + dza * dza;
-                    ss[2 * v + 1] = dxb * dxb + dzb * dzb;
-                }
-#pragma unroll
-                for(int u = 0; u < 8; u++) {
-                    // sqrt_rn_normal on both halves
-                    f2 r = {__builtin_amdgcn_sqrtf(ss[u].x), __builtin_amdgcn_sqrtf(ss[u].y)};
-                    const f2 rm = {__int_as_float(__float_as_int(r.x) - 1), __int_as_float(__float_as_int(r.y) - 1)};
-                    const f2 rp = {__int_as_float(__float_as_int(r.x) + 1), __int_as_float(__float_as_int(r.y) + 1)};
-                    const f2 em = __builtin_elementwise_fma(-rm, r, ss[u]);
-                    const f2 ep = __builtin_elementwise_fma(-rp, r, ss[u]);
-                    r.x = (em.x <= 0.0f) ? rm.x : r.x;  r.y = (em.y <= 0.0f) ? rm.y : r.y;
-                    r.x = (ep.x > 0.0f) ? rp.x : r.x;   r.y = (ep.y > 0.0f) ? rp.y : r.y;
-                    ln[u] = r;
-                    // outside [2^-90, 2^90] (or NaN) and not exactly 0: leave it to the general
-                    // IEEE expansion
-                    odd |= !(ss[u].x >= 0x1p-90f && ss[u].x <= 0x1p90f) && ss[u].x != 0.0f;
-                    odd |= !(ss[u].y >= 0x1p-90f && ss[u].y <= 0x1p90f) && ss[u].y != 0.0f;
-                }
-                if(__any(odd)) {
-                    asm volatile("" ::: "memory");        // keep the expansion out of the common path
-#pragma unroll
-                    for(int u = 0; u < 8; u++) ln[u] = f2{__builtin_sqrtf(ss[u].x), __builtin_sqrtf(ss[u].y)};
-                }
-#pragma unroll
-                for(int u = 0; u < 8; u++) {
-                    // cohesion_t_f32 on both halves
-                    const f2 x = ln[u] - 37.5f;
-                    const f2 q0 = x * (1.0f / 50.0f);
-                    const f2 inner = __builtin_elementwise_fma(-q0, f2{50.0f, 50.0f}, x);
-                    tt[u] = __builtin_elementwise_fma(inner, f2{1.0f / 50.0f, 1.0f / 50.0f}, q0);
-                    close |= ln[u].x < 16.0f || ln[u].y < 16.0f;
-                }
-                if(__any(close)) {                // rare unless the flock is one dense cluster
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for(int u = 0; u < 8; u++) {
-                        if(ln[u].x < 16.0f) tt[u].x = cohesion_t_f64(ln[u].x);
-                        if(ln[u].y < 16.0f) tt[u].y = cohesion_t_f64(ln[u].y);
-                    }
-                }
-#pragma unroll
-                for(int u = 0; u < 8; u++) {
-                    const f2 a = tt[u] * -6.0f;
-                    sc[2 * u] = exp_f32_magic(a.x, tab);
-                    sc[2 * u + 1] = exp_f32_magic(a.y, tab);
-                }
-#pragma unroll
-                for(int u = 0; u < 16; u++) {
-                    // curr == uid is skipped by the reference: a zero weight adds +-0, which
-                    // leaves the (never negative-zero) running sum unchanged
-                    const float w = (jj + u == self_k) ? 0.0f : sc[u];
-                    com = com + qxz[jj + u] * w;
-                }
-            }
-        }
-        // ---- carry the last (< 16) members over to the next tile, or finish them one by one
-        pend = ncnt - cnt16;
         const bool last = jb + 256 >= e;
-        if(last) {
-            if(act) for(int k = cnt16; k < ncnt; k++) one(k);
-        }else{
+        int cnt32 = ncnt & ~31;
+        if(last && cnt32 < ncnt) {
+            // pad the final batch with finite dummies (their weight is forced to 0)
+            const int k = ncnt + t;
+            if(k < cnt32 + 32) { const int sl = (k & 3) * COH_QS + (k >> 2); qx[sl] = 0.0f; qz[sl] = 0.0f; }
+        }
+        __syncthreads();
+        if(act) {
+            for(int jj = 0; jj < cnt32; jj += 32)
+                coh_batch<false>(qx, qz, tab, sub, jj, ncnt, self_k, me, comx, comz);
+            if(last && cnt32 < ncnt)
+                coh_batch<true>(qx, qz, tab, sub, cnt32, ncnt, self_k, me, comx, comz);
+        }
+        if(!last) {
+            // carry the last (< 32) entries over: entry k -> k - cnt32 keeps its sub-lane
+            pend = ncnt - cnt32;
             float cx = 0.0f, cz = 0.0f;
-            if(t < pend) { cx = qx[cnt16 + t]; cz = qz[cnt16 + t]; }
+            const int k = cnt32 + t;
+            if(t < pend) { const int sl = (k & 3) * COH_QS + (k >> 2); cx = qx[sl]; cz = qz[sl]; }
             __syncthreads();
-            if(t < pend) { qx[t] = cx; qz[t] = cz; qxz[t] = f2{cx, cz}; }
-            self_k = (self_k >= cnt16) ? self_k - cnt16 : -1;
+            if(t < pend) { const int sl = (t & 3) * COH_QS + (t >> 2); qx[sl] = cx; qz[sl] = cz; }
+            self_k = (self_k >= cnt32) ? self_k - cnt32 : -1;
             __syncthreads();
         }
     }
-    const v2 comv = mkv(com.x, com.y);
-    if(act) {
+    if(act && sub == 0) {
         const int count = (e - b) - 1;
         v2 ret = mkv(0.0f, 0.0f);
         if(count > 0) {
-            const v2 cm = vscale(comv, 1.0f / (float)count);
+            const v2 cm = vscale(mkv(comx, comz), 1.0f / (float)count);
             ret = vtrunc(vsub(cm, me), scaled_max_force);
         }
         coh_xz[2 * uid] = ret.x;
@@ -1824,8 +1859,8 @@ void nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh,
                            block_sum, nb);
         hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(1024), 0, s, bin_start, block_sum, nb, nblocks);
         hipLaunchKernelGGL(k_coh_scatter, dim3(gm), dim3(256), 0, s, P, bin_of, bin_start, bin_fill, perm);
-        // upper bound of the number of 64-member waves; surplus waves exit at once
-        const int nwaves = (P.n_members + 63) / 64 + P.n_flocks;
+        // upper bound of the number of 16-member (COH_APW) waves; surplus waves exit at once
+        const int nwaves = (P.n_members + 15) / 16 + P.n_flocks;
         hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)wave_off,
                            (const int32_t*)perm, d_coh);
     }

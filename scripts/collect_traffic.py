@@ -30,7 +30,7 @@ def main():
     fetch, nf = per_kernel(fpath, "FETCH_SIZE")
     write, nw = per_kernel(wpath, "WRITE_SIZE")
     fields_k = [k for k in fetch if k.startswith(("k_field_bfs", "k_field_generic"))]
-    agent_k = [k for k in fetch if k.startswith(("k_sp_", "k_cohesion", "k_agent_step"))]
+    agent_k = [k for k in fetch if k.startswith(("k_sp_", "k_coh", "k_agent_"))]
     known_write = nreq * 4096.0
     bfs = [k for k in write if k.startswith("k_field_bfs")]
     wcal = known_write / write[bfs[0]] if bfs and write[bfs[0]] > 0 else None
