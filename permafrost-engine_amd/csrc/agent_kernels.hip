@@ -45,7 +45,28 @@ __device__ __forceinline__ float vdot(v2 a, v2 b) { return a.x * b.x + a.z * b.z
 // PFM_Vec2_Len: sqrt in double of a float sum, rounded to float == correctly rounded float sqrt.
 // __builtin_sqrtf is IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn is
 // NOT (it lowers to the native v_sqrt_f32 approximation in this ROCm).
-__device__ __forceinline__ float vlen(v2 a) { return __builtin_sqrtf(a.x * a.x + a.z * a.z); }
+//
+// Correctly rounded sqrt for s == 0 or s in the normal range well away from its ends: v_sqrt_f32
+// (<= 1 ulp) plus the same one-ulp fix-up the compiler's IEEE expansion uses, without that
+// expansion's input scaling / class handling (which only matter for denormal, infinite or NaN s).
+__device__ __forceinline__ float sqrt_rn_normal(float s)
+{
+    float r = __builtin_amdgcn_sqrtf(s);
+    const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
+    const float em = __builtin_fmaf(-rm, r, s), ep = __builtin_fmaf(-rp, r, s);
+    r = (em <= 0.0f) ? rm : r;
+    r = (ep > 0.0f) ? rp : r;
+    return r;
+}
+__device__ __forceinline__ float vlen(v2 a)
+{
+    const float s = a.x * a.x + a.z * a.z;
+    if(!(s >= 0x1p-90f && s <= 0x1p90f) && s != 0.0f) {
+        asm volatile("" ::: "memory");      // a real branch: keep the expansion out of the common path
+        return __builtin_sqrtf(s);
+    }
+    return sqrt_rn_normal(s);
+}
 __device__ __forceinline__ v2 vnormal(v2 a)
 {
     float l = vlen(a);
@@ -944,19 +965,6 @@ __device__ __forceinline__ float exp_f32_magic(float a, const double *tab)
     return (float)__longlong_as_double(bits);
 }
 
-// Correctly rounded sqrt for s == 0 or s in the normal range well away from its ends: v_sqrt_f32
-// (<= 1 ulp) plus the same one-ulp fix-up the compiler's IEEE expansion uses, without that
-// expansion's input scaling / class handling (which only matter for denormal, infinite or NaN s).
-__device__ __forceinline__ float sqrt_rn_normal(float s)
-{
-    float r = __builtin_amdgcn_sqrtf(s);
-    const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
-    const float em = __builtin_fmaf(-rm, r, s), ep = __builtin_fmaf(-rp, r, s);
-    r = (em <= 0.0f) ? rm : r;
-    r = (ep > 0.0f) ? rp : r;
-    return r;
-}
-
 // float t = (len - 50.0f*0.75) / 50.0f of movement.c:1668 (the reference evaluates it in double and
 // rounds to float).  For len >= 16 the f32 subtraction is exact and the division by 50 as
 // reciprocal multiply + one FMA correction (Markstein) reproduces the double-then-float result for
@@ -1507,9 +1515,11 @@ struct nh_pre_rec {
     uint16_t probes;       // probe_tiles_bits
     uint8_t  status;
     uint8_t  mode;
+    float    vpref_cap;    // speed / hz      (movement.c:1880 and friends)
+    float    vel_cap;      // max_speed / hz  (movement.c:3464)
     uint32_t pad;
 };
-static_assert(sizeof(nh_pre_rec) == 24, "nh_pre_rec");
+static_assert(sizeof(nh_pre_rec) == 32, "nh_pre_rec");
 
 // k_agent_pre: one THREAD per entity.  Everything of move_velocity_work that needs no neighbour
 // list and is the same for all 64 lanes of a wave-per-agent kernel -- desired direction (flow-field
@@ -1524,6 +1534,8 @@ __global__ __launch_bounds__(256) void k_agent_pre(nh_step_params P, nh_pre_rec 
     nh_pre_rec R;
     R.vdes[0] = R.vdes[1] = R.arrive[0] = R.arrive[1] = 0.0f;
     R.probes = 0; R.status = 0; R.mode = AM_IDLE; R.pad = 0;
+    R.vpref_cap = P.speed[uid] / (float)P.hz;
+    R.vel_cap = P.max_speed[uid] / (float)P.hz;
     if(!state_is_still(state) && !(my_flags & NAVHIP_ENTITY_FLAG_COMBAT_HELD)) {
         const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
         const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
@@ -1586,7 +1598,8 @@ __global__ __launch_bounds__(256) void k_agent_pre(nh_step_params P, nh_pre_rec 
 // k_agent_step: one WAVE per entity -- the neighbour-dependent part: r = 30 query + separation,
 // the priority ladder of the steering force, r = 10 neighbours, ClearPath, truncation.
 __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const float *coh_xz,
-                                                    const nh_pre_rec *pre, nh_step_outs O)
+                                                    const nh_pre_rec *pre, nh_step_outs O,
+                                                    float scaled_max_force, double force_thresh)
 {
     __shared__ wave_lds lds[AG_WAVES];
     __shared__ double exp_tab[64];
@@ -1605,12 +1618,8 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
         const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
         const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
         const float my_radius = P.radius[uid];
-        const float max_speed = P.max_speed[uid];
-        const float speed = P.speed[uid];
         const int flock = P.flock[uid];
         const int hz = P.hz;
-        const float scaled_max_force = (float)((double)(0.75f / (float)hz) * 20.0);   // SCALED_MAX_FORCE
-        const double force_thresh = ((double)(0.75f / (float)hz) * 20.0) * 0.01;
         int n30raw = -1;                 // size of the unfiltered r=30 list (-1: no such query)
 
         if(R.mode != AM_ZERO_VPREF) {
@@ -1688,11 +1697,11 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
                 }
             }
             v2 accel = vscale(steer, 1.0f / 1.0f);
-            vpref = vtrunc(vadd(vel, accel), speed / (float)hz);
+            vpref = vtrunc(vadd(vel, accel), R.vpref_cap);
             if(R.mode == AM_FORM_CELL || R.mode == AM_FORM_POINT) {
                 const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
                 if(vlen(f_drag) > CP_EPS)                            // :1935 / :2018
-                    vpref = vtrunc(vpref, (float)(((double)speed * 0.75) / (double)hz));
+                    vpref = vtrunc(vpref, (float)(((double)P.speed[uid] * 0.75) / (double)hz));
             }
         }
 
@@ -1729,7 +1738,7 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
 #endif
         v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, cps, lane);
         SEC_MARK(6);
-        out_vel = vtrunc(nv, max_speed / (float)hz);                   // :3464
+        out_vel = nv;                     // k_agent_post truncates it to max_speed / hz (:3464)
     }
     if(lane == 0) {
         O.vel_xz[2 * uid] = out_vel.x; O.vel_xz[2 * uid + 1] = out_vel.z;
@@ -1744,11 +1753,15 @@ __global__ __launch_bounds__(256) void k_agent_post(nh_step_params P, const nh_p
     const int uid = P.work_begin + blockIdx.x * 256 + threadIdx.x;
     if(uid >= P.work_end) return;
     const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-    uint32_t status = pre[uid].status;
+    const nh_pre_rec R = pre[uid];
+    uint32_t status = R.status;
     v2 new_pos = me;
+    // vec2_truncate(new velocity, max_speed / hz), movement.c:3464 (k_agent_step leaves it raw:
+    // there one agent is one wave, here 64 agents share the instructions)
+    const v2 out_vel = vtrunc(mkv(O.vel_xz[2 * uid], O.vel_xz[2 * uid + 1]), R.vel_cap);
+    O.vel_xz[2 * uid] = out_vel.x; O.vel_xz[2 * uid + 1] = out_vel.z;
     if(!state_is_still(P.state[uid])) {
         const uint32_t my_flags = P.flags[uid];
-        const v2 out_vel = mkv(O.vel_xz[2 * uid], O.vel_xz[2 * uid + 1]);
         const int layer = nav_layer_for(my_flags, P.radius[uid]);
         v2 cand = vadd(me, out_vel);
         const bool on_blocked = pos_blocked(P, layer, me.x, me.z);
@@ -1882,8 +1895,11 @@ void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const void *d_p
 {
     const int nwork = P.work_end - P.work_begin;
     if(P.n_ents > 0 && nwork > 0) {
+        // SCALED_MAX_FORCE and the 1 % force threshold of movement.c:1870-1905 (same for every agent)
+        const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
+        const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
         hipLaunchKernelGGL(k_agent_step, dim3((nwork + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, P,
-                           d_coh, (const nh_pre_rec*)d_pre, O);
+                           d_coh, (const nh_pre_rec*)d_pre, O, smf, thresh);
         hipLaunchKernelGGL(k_agent_post, dim3((nwork + 255) / 256), dim3(256), 0, s, P,
                            (const nh_pre_rec*)d_pre, O);
     }
