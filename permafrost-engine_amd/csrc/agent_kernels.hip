@@ -392,6 +392,19 @@ __global__ __launch_bounds__(256) void k_sp_order(const int32_t *cell_start, int
 // ---------------------------------------------------------------------------------------------
 // Extent of a query in fine cells + whether it takes the reference's wide-query path
 // (bitmap_grid.h:1389-1397); returns false when the query box misses the grid.
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside each row of 16, then the two
+// row broadcasts (DPP; zero fill outside the row)
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 struct sp_extent { int cx_lo, cx_hi, cy_lo, cy_hi; bool wide; };
 
 __device__ __forceinline__ bool sp_query_extent(const nh_grid &G, int32_t icx, int32_t icy, int32_t ir,
@@ -448,46 +461,49 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
 
     // Visiting order (bitmap_grid.h:1408-1466): coarse 8x8 blocks row-major; inside a block fine
     // rows top to bottom, cells left to right, packed elements in order.  The cells of one fine
-    // row inside one coarse block are contiguous in the cell-sorted pool: a SEGMENT.  All segments
-    // of a coarse row are resolved in parallel (lane = segment: two cell_start loads), scanned,
-    // and their candidates tested 64 at a time -- two dependent memory round trips per coarse row
-    // instead of three per fine row.
+    // row inside one coarse block are contiguous in the cell-sorted pool: a SEGMENT.  One pass
+    // resolves 64 segments in visiting order -- lane = ((coarse row, block column) << 3) | fine row,
+    // with CB (a power of two) block columns and 8 / CB coarse rows per pass, so the r = 30 and
+    // r = 10 boxes of the movement tick (at most 2 x 2 coarse blocks) take a single pass: two
+    // cell_start loads per lane, a DPP prefix sum, then the candidates 64 at a time, each lane
+    // finding its segment by binary search over the prefix.
     const int cxc_lo = E.cx_lo >> 3, cxc_hi = E.cx_hi >> 3, ncx = cxc_hi - cxc_lo + 1;
+    const int cyc_lo = E.cy_lo >> 3, cyc_hi = E.cy_hi >> 3;
+    const int lgcb = ncx <= 1 ? 0 : ncx <= 2 ? 1 : ncx <= 4 ? 2 : 3;
+    const int CB = 1 << lgcb, CR = 8 >> lgcb;
     // squared distances fit 32 bits when the box is small (r = 30: |d| <= 7680 + 4095)
     const bool small = ir <= 16000;
-    for(int cyc = E.cy_lo >> 3; cyc <= (E.cy_hi >> 3); cyc++) {
-        const int fy0 = max(cyc * 8, E.cy_lo), fy1 = min(cyc * 8 + 8, E.cy_hi + 1);
-        const int rows = fy1 - fy0;                                   // 1..8
-        // 8 block columns x 8 rows per pass: lane = (block column << 3) | row, so the lane order is
-        // the visiting order and no division is needed
-        for(int cbase = 0; cbase < ncx; cbase += 8) {
-            const int cxi = cbase + (lane >> 3), fyi = lane & 7;
-            int b = 0, len = 0;
-            if(cxi < ncx && fyi < rows) {
-                const int cxc = cxc_lo + cxi, fy = fy0 + fyi;
-                const int fx0 = max(cxc * 8, E.cx_lo), fx1 = min(cxc * 8 + 8, E.cx_hi + 1);
-                b = G.cell_start[fy * G.grid_w + fx0];
-                len = G.cell_start[fy * G.grid_w + fx1] - b;
+    for(int cyc0 = cyc_lo; cyc0 <= cyc_hi; cyc0 += CR) {
+        for(int cbase = 0; cbase < ncx; cbase += CB) {
+            const int sg = lane >> 3, fyi = lane & 7;
+            const int cyc = cyc0 + (sg >> lgcb), cxi = cbase + (sg & (CB - 1));
+            int bb = 0, len = 0;
+            if(cyc <= cyc_hi && cxi < ncx) {
+                const int fy = cyc * 8 + fyi;
+                if(fy >= E.cy_lo && fy <= E.cy_hi) {
+                    const int cxc = cxc_lo + cxi;
+                    const int fx0 = max(cxc * 8, E.cx_lo), fx1 = min(cxc * 8 + 8, E.cx_hi + 1);
+                    bb = G.cell_start[fy * G.grid_w + fx0];
+                    len = G.cell_start[fy * G.grid_w + fx1] - bb;
+                }
             }
-            int incl = len;
-#pragma unroll
-            for(int d = 1; d < 64; d <<= 1) {
-                int o = __shfl_up(incl, d);
-                if(lane >= d) incl += o;
-            }
-            const int off = incl - len;
+            const int incl = wave_incl_scan(len);
             const int total = __shfl(incl, 63);
             if(total == 0) continue;
-            const uint64_t segmask = __ballot(len > 0);               // non-empty segments, in order
+            const int bo = bb - (incl - len);                         // pool index of candidate q: bo + q
             for(int base = 0; base < total; base += 64) {
                 const int q = base + lane;
-                // candidate q -> (segment, position); every lane runs the shuffles (uniform loop)
-                int k = -1;
-                for(uint64_t m = segmask; m; m &= m - 1) {
-                    const int sg = __builtin_ctzll(m);
-                    const int so = __shfl(off, sg), sl = __shfl(len, sg), sb = __shfl(b, sg);
-                    if(q < total && q >= so && q < so + sl) k = sb + (q - so);
+                // first lane whose inclusive prefix exceeds q = the segment of candidate q (empty
+                // segments are stepped over because the prefix does not move); every lane runs
+                // the shuffles
+                int lo = 0;
+#pragma unroll
+                for(int st = 32; st >= 1; st >>= 1) {
+                    const int pv = __shfl(incl, lo + st - 1);
+                    if(pv <= q) lo += st;
                 }
+                const int kk = __shfl(bo, lo & 63) + q;
+                const int k = (q < total) ? kk : -1;
                 bool hit = false;
                 int32_t d2s = 0;
                 if(k >= 0) {
