@@ -1543,7 +1543,7 @@ static_assert(sizeof(nh_pre_rec) == 32, "nh_pre_rec");
 // nullify_impass_components -- is evaluated here with all lanes busy.
 __global__ __launch_bounds__(256) void k_agent_pre(nh_step_params P, nh_pre_rec *pre, nh_step_outs O)
 {
-    const int uid = P.work_begin + blockIdx.x * 256 + threadIdx.x;
+    const int uid = P.work_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if(uid >= P.work_end) return;
     const int state = P.state[uid];
     const uint32_t my_flags = P.flags[uid];
@@ -1766,7 +1766,7 @@ __global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const floa
 // (movement.c:2336-2358; the heading gate stays on the host) and the status byte.
 __global__ __launch_bounds__(256) void k_agent_post(nh_step_params P, const nh_pre_rec *pre, nh_step_outs O)
 {
-    const int uid = P.work_begin + blockIdx.x * 256 + threadIdx.x;
+    const int uid = P.work_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if(uid >= P.work_end) return;
     const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
     const nh_pre_rec R = pre[uid];

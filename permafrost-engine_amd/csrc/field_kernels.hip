@@ -142,7 +142,7 @@ void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, 
 template <bool WANT_INTEG>
 __global__ __launch_bounds__(256) void k_field_bfs(nh_map_view map, const navhip_field_req *reqs,
                                                    int n, uint8_t *dirs, float *integ,
-                                                   int force_generic)
+                                                   int force_generic, int32_t *gen_list)
 {
     // 4 KB of LDS per wave: staging buffer to turn "lane owns a 64-byte row" into fully
     // coalesced 16 B/lane global accesses (both for the INOUT read and for the final write).
@@ -154,7 +154,11 @@ __global__ __launch_bounds__(256) void k_field_bfs(nh_map_view map, const navhip
     if(wave >= n) return;
 
     navhip_field_req rq = reqs[wave];
-    if(!req_uses_bfs(map, rq, force_generic)) return;
+    if(!req_uses_bfs(map, rq, force_generic)) {
+        // not a unit-cost BFS: hand the request to k_field_generic
+        if(lane == 0) gen_list[2 + atomicAdd(&gen_list[0], 1)] = wave;
+        return;
+    }
     if(!req_prepare(map, rq)) return;
 
     const nh_layer_view &L = map.layers[rq.layer];
@@ -353,19 +357,26 @@ __global__ __launch_bounds__(256) void k_field_bfs(nh_map_view map, const navhip
 // ---------------------------------------------------------------------------------------------
 // k_field_generic : one workgroup per request, arbitrary costs / faction passability
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const navhip_field_req *reqs,
-                                                       int n, uint8_t *dirs, float *integ,
-                                                       int force_generic)
+struct generic_lds {
+    uint32_t dist[NH_CELLS];                                   // 16 KB
+    __attribute__((aligned(16))) uint8_t pc[NH_CELLS];         // cost, 0xff = not passable
+    uint8_t raw[NH_CELLS];      // cost_base as stored
+    uint8_t fl[NH_CELLS];       // bit0 field_tile_passable (faction agnostic), bit1 region
+    int s_list[128], s_dmin[128], s_nlist, s_D;
+};
+
+__device__ void field_generic_one(generic_lds &S, const nh_map_view &map, const navhip_field_req *reqs,
+                                  int ri, uint8_t *dirs, float *integ, int force_generic)
 {
-    __shared__ uint32_t dist[NH_CELLS];                                   // 16 KB
-    __shared__ __attribute__((aligned(16))) uint8_t pc[NH_CELLS];         // cost, 0xff = not passable
-    __shared__ uint8_t raw[NH_CELLS];      // cost_base as stored
-    __shared__ uint8_t fl[NH_CELLS];       // bit0 field_tile_passable (faction agnostic), bit1 region
-    __shared__ int s_list[128], s_dmin[128], s_nlist, s_D;
+    uint32_t (&dist)[NH_CELLS] = S.dist;
+    uint8_t (&pc)[NH_CELLS] = S.pc;
+    uint8_t (&raw)[NH_CELLS] = S.raw;
+    uint8_t (&fl)[NH_CELLS] = S.fl;
+    int (&s_list)[128] = S.s_list;
+    int (&s_dmin)[128] = S.s_dmin;
+    int &s_nlist = S.s_nlist, &s_D = S.s_D;
 
     const int t = threadIdx.x;
-    const int ri = blockIdx.x;
-    if(ri >= n) return;
     navhip_field_req rq = reqs[ri];
     if(req_uses_bfs(map, rq, force_generic)) return;      // the BFS kernel owns this request
     if(!req_prepare(map, rq)) return;
@@ -612,9 +623,34 @@ __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const na
     *(uint4*)(out + t * 16) = *(const uint4*)(pc + t * 16);
 }
 
+// The launch is a fixed, small grid: workgroups stride over the list of requests the BFS kernel
+// declined (gen_list: count, done, ids...; gen_list == nullptr: every request, in order).  A tick
+// whose requests are all unit-cost BFS fields pays for a few hundred workgroups that read one
+// counter, not for one empty workgroup per request.  The last workgroup to finish zeroes the
+// header for the next launch.
+__global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const navhip_field_req *reqs,
+                                                       int n, uint8_t *dirs, float *integ,
+                                                       int force_generic, int32_t *gen_list)
+{
+    __shared__ generic_lds S;
+    const int count = gen_list ? gen_list[0] : n;
+    for(int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int ri = gen_list ? gen_list[2 + w] : w;
+        field_generic_one(S, map, reqs, ri, dirs, integ, force_generic);
+        __syncthreads();
+    }
+    if(gen_list) {
+        __syncthreads();
+        if(threadIdx.x == 0) {
+            __threadfence();
+            if(atomicAdd(&gen_list[1], 1) == (int)gridDim.x - 1) { gen_list[0] = 0; gen_list[1] = 0; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, uint8_t *d_dirs,
-                      float *d_integ, hipStream_t s)
+                      float *d_integ, int32_t *d_gen_list, hipStream_t s)
 {
     nh_map_view mv;
     mv.w = ctx->w;
@@ -629,11 +665,11 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
         dim3 grid((n + 3) / 4);
         if(d_integ)
             hipLaunchKernelGGL(k_field_bfs<true>, grid, dim3(256), 0, s, mv, d_reqs, n, d_dirs,
-                               d_integ, force_generic);
+                               d_integ, force_generic, d_gen_list);
         else
             hipLaunchKernelGGL(k_field_bfs<false>, grid, dim3(256), 0, s, mv, d_reqs, n, d_dirs,
-                               d_integ, force_generic);
+                               d_integ, force_generic, d_gen_list);
     }
-    hipLaunchKernelGGL(k_field_generic, dim3(n), dim3(256), 0, s, mv, d_reqs, n, d_dirs, d_integ,
-                       force_generic);
+    hipLaunchKernelGGL(k_field_generic, dim3(n < 1024 ? n : 1024), dim3(256), 0, s, mv, d_reqs, n, d_dirs,
+                       d_integ, force_generic, force_generic ? (int32_t*)nullptr : d_gen_list);
 }

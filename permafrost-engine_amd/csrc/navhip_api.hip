@@ -94,6 +94,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(ctx->sp, 0, sizeof(ctx->sp));
     memset(&ctx->coh, 0, sizeof(ctx->coh));
     memset(&ctx->coh_plan, 0, sizeof(ctx->coh_plan));
+    memset(&ctx->gen_list, 0, sizeof(ctx->gen_list));
     memset(&ctx->prerec, 0, sizeof(ctx->prerec));
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
@@ -125,7 +126,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     hipFree(ctx->d_dirty_list);
     for(auto &b : ctx->sp) hipFree(b.p);
     for(auto &b : ctx->stage) hipFree(b.p);
-    hipFree(ctx->coh.p); hipFree(ctx->coh_plan.p); hipFree(ctx->prerec.p);
+    hipFree(ctx->coh.p); hipFree(ctx->coh_plan.p); hipFree(ctx->prerec.p); hipFree(ctx->gen_list.p);
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
     for(auto &a : ctx->aux) if(a) hipStreamDestroy(a);
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -528,7 +529,12 @@ int navhip_build_fields_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, i
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     int rc = refresh_derived(ctx, s);
     if(rc) return rc;
-    nh_launch_fields(ctx, dev_reqs, n, dev_inout_dirs, dev_out_integ, s);
+    // work list of the generic kernel: the header is zero between launches (the kernel resets it)
+    const void *old_list = ctx->gen_list.p;
+    rc = ensure_buf(ctx, ctx->gen_list, ((size_t)n + 2) * sizeof(int32_t));
+    if(rc) return rc;
+    if(ctx->gen_list.p != old_list) HIPCHK(ctx, hipMemsetAsync(ctx->gen_list.p, 0, 2 * sizeof(int32_t), s));
+    nh_launch_fields(ctx, dev_reqs, n, dev_inout_dirs, dev_out_integ, (int32_t*)ctx->gen_list.p, s);
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
 }

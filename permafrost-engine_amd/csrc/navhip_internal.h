@@ -47,6 +47,7 @@ struct navhip_ctx {
     buf          coh;          // cohesion force per entity
     buf          coh_plan;     // [n_flocks + 1] wave prefix of the cohesion launch
     buf          prerec;       // per-entity record of the scalar pre-pass (k_agent_pre)
+    buf          gen_list;     // [2 + n] requests the BFS kernel left to k_field_generic: count, done, ids
     buf          stage[36];    // device copies of host buffers for the host-pointer entry points
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];
@@ -64,7 +65,7 @@ struct navhip_ctx {
 void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, int n,
                       hipStream_t s);
 void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, uint8_t *d_dirs,
-                      float *d_integ, hipStream_t s);
+                      float *d_integ, int32_t *d_gen_list, hipStream_t s);
 
 void nh_launch_blockers_circles(navhip_ctx *ctx, const navhip_circle *d_circles, int n, float map_x,
                                 float map_z, hipStream_t s);
