@@ -1315,7 +1315,11 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
 // ---------------------------------------------------------------------------------------------
 // k_agent_step: one wave per entity
 // ---------------------------------------------------------------------------------------------
-#define AG_WAVES 4
+// waves (= agents) per workgroup of k_agent_step; 2 measured best (1: 0.490, 2: 0.483, 4: 0.494,
+// 8: 0.521 ms/tick in one session, scripts/ab_lib.py)
+#ifndef AG_WAVES
+#define AG_WAVES 2
+#endif
 struct wave_lds {
     uint32_t ids30[128];                       // separation query result (cap 128, :1695)
     union {
@@ -1613,7 +1617,7 @@ __global__ __launch_bounds__(256) void k_agent_pre(nh_step_params P, nh_pre_rec 
 
 // k_agent_step: one WAVE per entity -- the neighbour-dependent part: r = 30 query + separation,
 // the priority ladder of the steering force, r = 10 neighbours, ClearPath, truncation.
-__global__ __launch_bounds__(256) void k_agent_step(nh_step_params P, const float *coh_xz,
+__global__ __launch_bounds__(AG_WAVES * 64) void k_agent_step(nh_step_params P, const float *coh_xz,
                                                     const nh_pre_rec *pre, nh_step_outs O,
                                                     float scaled_max_force, double force_thresh)
 {
@@ -1814,7 +1818,7 @@ __global__ __launch_bounds__(256) void k_spatial_query(nh_grid G, const float *q
     if(lane == 0) out_counts[q] = n;
 }
 
-__global__ __launch_bounds__(256) void k_clearpath(int nq, const float *ent, const float *des_v,
+__global__ __launch_bounds__(AG_WAVES * 64) void k_clearpath(int nq, const float *ent, const float *des_v,
                                                    const float *dyn, const int32_t *n_dyn,
                                                    const float *stat, const int32_t *n_stat,
                                                    float *out)
@@ -1914,7 +1918,7 @@ void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const void *d_p
         // SCALED_MAX_FORCE and the 1 % force threshold of movement.c:1870-1905 (same for every agent)
         const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
         const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
-        hipLaunchKernelGGL(k_agent_step, dim3((nwork + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, P,
+        hipLaunchKernelGGL(k_agent_step, dim3((nwork + AG_WAVES - 1) / AG_WAVES), dim3(AG_WAVES * 64), 0, s, P,
                            d_coh, (const nh_pre_rec*)d_pre, O, smf, thresh);
         hipLaunchKernelGGL(k_agent_post, dim3((nwork + 255) / 256), dim3(256), 0, s, P,
                            (const nh_pre_rec*)d_pre, O);
@@ -1934,6 +1938,6 @@ void nh_launch_clearpath(int nq, const float *ent, const float *des_v, const flo
                          hipStream_t s)
 {
     if(nq > 0)
-        hipLaunchKernelGGL(k_clearpath, dim3((nq + AG_WAVES - 1) / AG_WAVES), dim3(256), 0, s, nq, ent,
+        hipLaunchKernelGGL(k_clearpath, dim3((nq + AG_WAVES - 1) / AG_WAVES), dim3(AG_WAVES * 64), 0, s, nq, ent,
                            des_v, dyn, n_dyn, stat, n_stat, out);
 }

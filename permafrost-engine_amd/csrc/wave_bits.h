@@ -39,3 +39,4 @@ __device__ __forceinline__ u64x from_s(u64x v)
                 (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.hi, 0x130, 0xf, 0xf, true)};
 }
 
+

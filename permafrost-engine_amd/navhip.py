@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnavhip.so")
+# NAVHIP_LIB: load another build of the same library (A/B runs of kernel variants, scripts/ab_lib.py)
+LIB_PATH = os.environ.get("NAVHIP_LIB") or os.path.join(_HERE, "libnavhip.so")
 
 OK = 0
 FIELD_RES = 64
