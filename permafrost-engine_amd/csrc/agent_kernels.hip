@@ -912,57 +912,17 @@ __constant__ double c_exp2_64[64] = {
     0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
     0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e454p+0, 0x1.fa7c1819e90d8p+0};
 
-// (float)exp((double)a) for a in (-inf, ~80]: the reference evaluates libm's double exp on a
-// float argument and rounds to float (movement.c:1671,1731).  Table-driven double evaluation,
-// exp(a) = 2^(k/64) * exp(r), |r| <= ln2/128, degree-5 polynomial: < 2 ulp in double, so the
-// float rounding agrees with a correctly rounded exp except with probability ~1e-8 per call
-// (0 mismatches in 4e8 random arguments against glibc).  tab = 64-entry table in LDS.
-__device__ __forceinline__ float exp_f32_via_f64(float a, const double *tab)
-{
-    // branch free so that independent evaluations interleave: evaluate on a clamped argument,
-    // select +0 where exp(a) < 2^-150 (rounds to +0 in float)
-    const double x = (double)fmaxf(a, -104.0f);
-    const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);          // 64/ln2
-    const int k = (int)kd;
-    double r = __builtin_fma(-kd, 0x1.62e42fefa0000p-7, x);              // ln2/64, high part
-    r = __builtin_fma(-kd, 0x1.cf79abc9e3b3ap-46, r);                    //         low part
-    double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
-    p = __builtin_fma(p, r, 1.0 / 6);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    const float res = (float)__builtin_ldexp(tab[k & 63] * p, k >> 6);
-    return (a <= -103.98f) ? 0.0f : res;
-}
-
-// exp for the cohesion weights with as few f64 conversions as possible (they and v_ldexp_f64 issue
-// at quarter rate): the reduction index comes from an f32 product (any nearby index works, the
-// remainder is still < 0.0055), the final scaling by 2^(k>>6) is an integer add on the exponent
-// field (the result stays a normal double for every argument in [-104, 89]).
-__device__ __forceinline__ float exp_f32_lowconv(float a, const double *tab)
-{
-    const float ac = fmaxf(a, -104.0f);
-    const float kf = __builtin_rintf(ac * 0x1.715476p+6f);               // 64/ln2
-    const int k = (int)kf;
-    const double x = (double)ac, kd = (double)kf;
-    double r = __builtin_fma(-kd, 0x1.62e42fefa0000p-7, x);              // ln2/64, high part
-    r = __builtin_fma(-kd, 0x1.cf79abc9e3b3ap-46, r);                    //         low part
-    double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
-    p = __builtin_fma(p, r, 1.0 / 6);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    const double v = tab[k & 63] * p;
-    const long long bits = __double_as_longlong(v) + ((long long)(k >> 6) << 52);
-    const float res = (float)__longlong_as_double(bits);
-    return (a <= -103.98f) ? 0.0f : res;
-}
-
-// The same value with the reduction done in double: k = rint(x * 64/ln2) falls out of the low
+// (float)exp((double)a) for a in (-inf, ~88]: the reference evaluates libm's double exp on a float
+// argument and rounds to float (movement.c:1671,1731).  Table-driven double evaluation,
+// exp(a) = 2^(k/64) * exp(r), |r| <= ln2/128, degree-5 polynomial: < 2 ulp in double, so the float
+// rounding agrees with a correctly rounded exp except with probability ~1e-8 per call.  tab =
+// 64-entry table in LDS.  k = rint(x * 64/ln2) falls out of the low
 // mantissa bits of x * 64/ln2 + 1.5 * 2^52 (one FMA), and no final select is needed -- the clamped
 // argument -104 gives 6.8e-46, which the f64 -> f32 conversion rounds to +0 like every value below
-// half the smallest denormal (the true cut-off is a = -103.972).  Checked against glibc's exp on
-// 3e8 random arguments in [-110, 6] and on every float in [-104.5, -102]: no mismatch.
+// half the smallest denormal (the true cut-off is a = -103.972).  The final scaling by 2^(k>>6) is
+// an integer add on the exponent field (the result stays a normal double for every argument in
+// [-104, 89]).  Checked against glibc's exp on 3e8 random arguments in [-110, 6], 3e8 in [-21, 89]
+// and on every float in [-104.5, -102]: no mismatch.
 __device__ __forceinline__ float exp_f32_magic(float a, const double *tab)
 {
     const double x = (double)fmaxf(a, -104.0f);
@@ -1111,6 +1071,11 @@ __global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int
 // same instruction total, and a 16-member box is tighter than a 64-member one.
 #define COH_APW 16
 #define COH_QS  72            /* queue slots per sub-lane: (256 staged + 31 carried) / 4 */
+#ifndef COH_NP
+#define COH_NP  2             /* entry pairs per lane and batch: a batch is COH_G = 8 * COH_NP entries
+                                 (2 measured 1.3 % faster per tick than 4: fewer VGPRs, more waves) */
+#endif
+#define COH_G   (8 * COH_NP)
 
 __device__ __forceinline__ float quad_bcast(float v, int sub)
 {
@@ -1123,24 +1088,25 @@ __device__ __forceinline__ float quad_bcast(float v, int sub)
     }
 }
 
-// 32 queue entries starting at entry jj (a multiple of 32): this lane's eight are local slots
-// jj/4 .. jj/4+7 of its own quarter.  TAIL: entries >= n_valid are padding (weight 0).
+// COH_G queue entries starting at entry jj (a multiple of COH_G): this lane's 2 * COH_NP are local
+// slots jj/4 .. of its own quarter.  TAIL: entries >= n_valid are padding (weight 0).
 template <bool TAIL>
 __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, const double *tab, int sub,
                                           int jj, int n_valid, int self_k, v2 me, float &comx, float &comz)
 {
     const f2 mex = {me.x, me.x}, mez = {me.z, me.z};
     const int lo = sub * COH_QS + (jj >> 2);
-    f2 X[4], Z[4], ss[4], ln[4], tt[4], W[4];
+    constexpr int NP = COH_NP;
+    f2 X[NP], Z[NP], ss[NP], ln[NP], tt[NP], W[NP];
     bool close = false, odd = false;
-    {
-        const f4 xa = *(const f4*)&qx[lo], xb = *(const f4*)&qx[lo + 4];
-        const f4 za = *(const f4*)&qz[lo], zb = *(const f4*)&qz[lo + 4];
-        X[0] = f2{xa.x, xa.y}; X[1] = f2{xa.z, xa.w}; X[2] = f2{xb.x, xb.y}; X[3] = f2{xb.z, xb.w};
-        Z[0] = f2{za.x, za.y}; Z[1] = f2{za.z, za.w}; Z[2] = f2{zb.x, zb.y}; Z[3] = f2{zb.z, zb.w};
+#pragma unroll
+    for(int v = 0; v < NP / 2; v++) {
+        const f4 xa = *(const f4*)&qx[lo + 4 * v], za = *(const f4*)&qz[lo + 4 * v];
+        X[2 * v] = f2{xa.x, xa.y}; X[2 * v + 1] = f2{xa.z, xa.w};
+        Z[2 * v] = f2{za.x, za.y}; Z[2 * v + 1] = f2{za.z, za.w};
     }
 #pragma unroll
-    for(int u = 0; u < 4; u++) {
+    for(int u = 0; u < NP; u++) {
         const f2 dx = X[u] - mex, dz = Z[u] - mez;
         ss[u] = dx * dx + dz * dz;
         // sqrt_rn_normal on both halves
@@ -1159,10 +1125,10 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
     if(__any(odd)) {
         asm volatile("" ::: "memory");        // keep the expansion out of the common path
 #pragma unroll
-        for(int u = 0; u < 4; u++) ln[u] = f2{__builtin_sqrtf(ss[u].x), __builtin_sqrtf(ss[u].y)};
+        for(int u = 0; u < NP; u++) ln[u] = f2{__builtin_sqrtf(ss[u].x), __builtin_sqrtf(ss[u].y)};
     }
 #pragma unroll
-    for(int u = 0; u < 4; u++) {
+    for(int u = 0; u < NP; u++) {
         // cohesion_t_f32 on both halves
         const f2 x = ln[u] - 37.5f;
         const f2 q0 = x * (1.0f / 50.0f);
@@ -1173,14 +1139,14 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
     if(__any(close)) {                // rare unless the flock is one dense cluster
         asm volatile("" ::: "memory");
 #pragma unroll
-        for(int u = 0; u < 4; u++) {
+        for(int u = 0; u < NP; u++) {
             if(ln[u].x < 16.0f) tt[u].x = cohesion_t_f64(ln[u].x);
             if(ln[u].y < 16.0f) tt[u].y = cohesion_t_f64(ln[u].y);
         }
     }
     const int k0 = jj + sub;                  // entry number of this lane's first entry; then +4 each
 #pragma unroll
-    for(int u = 0; u < 4; u++) {
+    for(int u = 0; u < NP; u++) {
         const f2 a = tt[u] * -6.0f;
         float w0 = exp_f32_magic(a.x, tab), w1 = exp_f32_magic(a.y, tab);
         // curr == uid is skipped by the reference: a zero weight adds +-0, which leaves the (never
@@ -1192,7 +1158,7 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
     }
     // products, then the ordered sums: entry jj + 4*i + s is held by sub-lane s as element i
 #pragma unroll
-    for(int u = 0; u < 4; u++) {
+    for(int u = 0; u < NP; u++) {
         const f2 px = X[u] * W[u], pz = Z[u] * W[u];
 #pragma unroll
         for(int h = 0; h < 2; h++) {
@@ -1275,21 +1241,21 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
             ncnt += __popcll(mk);
         }
         const bool last = jb + 256 >= e;
-        int cnt32 = ncnt & ~31;
+        int cnt32 = ncnt & ~(COH_G - 1);                  // whole batches
         if(last && cnt32 < ncnt) {
             // pad the final batch with finite dummies (their weight is forced to 0)
             const int k = ncnt + t;
-            if(k < cnt32 + 32) { const int sl = (k & 3) * COH_QS + (k >> 2); qx[sl] = 0.0f; qz[sl] = 0.0f; }
+            if(k < cnt32 + COH_G) { const int sl = (k & 3) * COH_QS + (k >> 2); qx[sl] = 0.0f; qz[sl] = 0.0f; }
         }
         __syncthreads();
         if(act) {
-            for(int jj = 0; jj < cnt32; jj += 32)
+            for(int jj = 0; jj < cnt32; jj += COH_G)
                 coh_batch<false>(qx, qz, tab, sub, jj, ncnt, self_k, me, comx, comz);
             if(last && cnt32 < ncnt)
                 coh_batch<true>(qx, qz, tab, sub, cnt32, ncnt, self_k, me, comx, comz);
         }
         if(!last) {
-            // carry the last (< 32) entries over: entry k -> k - cnt32 keeps its sub-lane
+            // carry the last (< COH_G) entries over: entry k -> k - cnt32 keeps its sub-lane
             pend = ncnt - cnt32;
             float cx = 0.0f, cz = 0.0f;
             const int k = cnt32 + t;
@@ -1354,7 +1320,7 @@ __device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_
                 float len = vlen(diff);
                 if(!(len < CP_EPS)) {
                     float t = __fdiv_rn(len - radius * 0.85f, len);
-                    float scale = exp_f32_via_f64(fminf(-20.0f * t, 40.0f), exp_tab);
+                    float scale = exp_f32_magic(fminf(-20.0f * t, 40.0f), exp_tab);
                     term = vscale(diff, scale);
                 }
             }

@@ -138,18 +138,21 @@ void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, 
 // k_field_bfs : one wave per request, lane = row
 // ---------------------------------------------------------------------------------------------
 #define NH_MAXP 12   /* distance bit-planes: unit-cost distances are < 4096 */
+#ifndef BFS_WAVES
+#define BFS_WAVES 4    /* waves (= requests) per workgroup */
+#endif
 
 template <bool WANT_INTEG>
-__global__ __launch_bounds__(256) void k_field_bfs(nh_map_view map, const navhip_field_req *reqs,
+__global__ __launch_bounds__(BFS_WAVES * 64) void k_field_bfs(nh_map_view map, const navhip_field_req *reqs,
                                                    int n, uint8_t *dirs, float *integ,
                                                    int force_generic, int32_t *gen_list)
 {
     // 4 KB of LDS per wave: staging buffer to turn "lane owns a 64-byte row" into fully
     // coalesced 16 B/lane global accesses (both for the INOUT read and for the final write).
-    __shared__ __attribute__((aligned(16))) uint8_t stage[4][NH_CELLS];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[BFS_WAVES][NH_CELLS];
 
     const int wib  = threadIdx.x >> 6;
-    const int wave = blockIdx.x * 4 + wib;
+    const int wave = blockIdx.x * BFS_WAVES + wib;
     const int lane = threadIdx.x & 63;
     if(wave >= n) return;
 
@@ -662,12 +665,12 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
     }
     const int force_generic = ctx->field_kernel_mode == 1;
     if(!force_generic) {
-        dim3 grid((n + 3) / 4);
+        dim3 grid((n + BFS_WAVES - 1) / BFS_WAVES);
         if(d_integ)
-            hipLaunchKernelGGL(k_field_bfs<true>, grid, dim3(256), 0, s, mv, d_reqs, n, d_dirs,
+            hipLaunchKernelGGL(k_field_bfs<true>, grid, dim3(BFS_WAVES * 64), 0, s, mv, d_reqs, n, d_dirs,
                                d_integ, force_generic, d_gen_list);
         else
-            hipLaunchKernelGGL(k_field_bfs<false>, grid, dim3(256), 0, s, mv, d_reqs, n, d_dirs,
+            hipLaunchKernelGGL(k_field_bfs<false>, grid, dim3(BFS_WAVES * 64), 0, s, mv, d_reqs, n, d_dirs,
                                d_integ, force_generic, d_gen_list);
     }
     hipLaunchKernelGGL(k_field_generic, dim3(n < 1024 ? n : 1024), dim3(256), 0, s, mv, d_reqs, n, d_dirs,
