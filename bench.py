@@ -128,6 +128,10 @@ def main():
     ap.add_argument("--agents", type=int, default=100_000, help="agents per GPU")
     ap.add_argument("--obstacles", type=int, default=0,
                     help="configs[4]: dynamic obstacles, 1%% moved per tick, incremental field repair")
+    ap.add_argument("--tile-exchange", choices=("auto", "all"), default="auto",
+                    help="multi-GPU: auto = only baked tiles that another rank's agents sample travel "
+                         "(none in this workload: flocks are rank aligned); all = all-gather every tile "
+                         "every tick (any agent may sample any field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -146,7 +150,8 @@ def main():
 
     T = tick.NavTick(chunk_w=args.map, fields_per_rank=args.fields, agents_per_rank=args.agents,
                      rank=rank, world=world, device=local, verbose=(rank == 0 and False),
-                     obstacles=args.obstacles, obstacle_ticks=args.warmup + args.steps + 8)
+                     obstacles=args.obstacles, obstacle_ticks=args.warmup + args.steps + 8,
+                     tile_exchange=args.tile_exchange)
     for _ in range(args.warmup):
         T.step()
     T.sync()
@@ -226,13 +231,17 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64-bitmask/u8 fields, f32 agents",
             "data": "synthetic",
             "config": {"workload": ("configs[4] (dynamic obstacles, incremental repair): " if args.obstacles else "")
-                                   + "configs[2]: %dx%d-cell map (%dx%d chunks), %d flow fields "
-                                   "(%d chunk fields) + %d agents per GPU, fields rebuilt + agents "
-                                   "stepped every tick" % (args.map * 64, args.map * 64, args.map, args.map,
-                                                           args.fields, T.n_req_local, args.agents),
+                                   + "configs[2] per GPU: %dx%d-cell map region (%dx%d chunks), %d flow "
+                                   "fields (%d chunk fields) + %d agents per GPU, fields rebuilt + agents "
+                                   "stepped every tick%s" % (args.map * 64, args.map * 64, args.map, args.map,
+                                                             args.fields, T.n_req_local, args.agents,
+                                                             "" if world == 1 else
+                                                             "; the %d regions lie side by side on one "
+                                                             "%dx%d-cell map" % (world, args.map * 64, args.map * 64 * world)),
                        "map_chunks": args.map, "flow_fields_per_gpu": args.fields,
                        "agents_per_gpu": args.agents, "hz": 20, "dynamic_obstacles": args.obstacles,
-                       "parallelism": "requests+agent-slabs sharded x%d, all-gather tiles/slabs" % world},
+                       "parallelism": "regions (requests + agent slabs) sharded x%d; all-gather of slab "
+                                      "results (16 B/agent); baked tiles: %s" % (world, T.tile_exchange)},
             ("flow_field_cells_kept_valid_per_s" if args.obstacles else "flow_field_cells_per_s"):
                 cells_total * args.steps / dt,
             "flow_field_cells_per_s_kernel": (T.n_req_local * 4096 * world) / (f_ms * 1e-3) if f_ms > 0 else None,

@@ -18,6 +18,7 @@ struct nh_spatial_scratch {
     int32_t *cell_start;                     // [ncells+1]
     int32_t *sorted_id, *sx, *sy;            // [n]
     int32_t *block_sum;                      // [ceil(ncells/1024)] scan scratch
+    int32_t *box;                            // [4] bounding box of the stepped slab (optional filter)
 };
 
 struct nh_step_params {
@@ -45,7 +46,7 @@ struct nh_step_outs {
 };
 
 void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
-                             hipStream_t s);
+                             int slab_begin, int slab_end, hipStream_t s);
 size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members);
 void nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, hipStream_t s);
 size_t nh_pre_rec_bytes();

@@ -276,15 +276,48 @@ __device__ __forceinline__ int sp_cell_of(const nh_grid &G, int32_t ix, int32_t 
     return cy * G.grid_w + cx;
 }
 
+// Optional slab filter: when a rank steps only the entities [work_begin, work_end), nothing farther
+// than the largest query radius of the tick (r = 30) from the bounding box of THOSE entities can be
+// returned by any of its queries, and leaving such entities out changes neither the order nor the
+// caps of what is returned.  box = {max(-ix), max(ix), max(-iy), max(iy)} over the slab in the
+// x256 fixed point the queries compare in; INT_MIN-initialised.
+__global__ __launch_bounds__(256) void k_sp_bbox(const float *pos_xz, int begin, int end, int32_t *box)
+{
+    const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    int32_t v[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+    if(i < end) {
+        const int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
+        v[0] = -ix; v[1] = ix; v[2] = -iy; v[3] = iy;
+    }
+#pragma unroll
+    for(int q = 0; q < 4; q++) {
+#pragma unroll
+        for(int d = 32; d >= 1; d >>= 1) v[q] = max(v[q], __shfl_xor(v[q], d));
+        if((threadIdx.x & 63) == 0 && v[q] != INT32_MIN) atomicMax(&box[q], v[q]);
+    }
+}
+
+__device__ __forceinline__ bool sp_in_box(const int32_t *box, int32_t ix, int32_t iy)
+{
+    if(!box) return true;
+    const int32_t m = 30 * 256 + 256;                 // BG_SCALE_F(30) + one world unit of slack
+    // (int64: the INT_MIN box of an empty slab must reject everything without overflowing)
+    return (int64_t)ix >= -(int64_t)box[0] - m && (int64_t)ix <= (int64_t)box[1] + m
+        && (int64_t)iy >= -(int64_t)box[2] - m && (int64_t)iy <= (int64_t)box[3] + m;
+}
+
 __global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz, int n,
                                                   int32_t *ent_ix, int32_t *ent_iy,
-                                                  int32_t *ent_cell, int32_t *cell_count)
+                                                  int32_t *ent_cell, int32_t *cell_count,
+                                                  const int32_t *box)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if(i >= n) return;
     int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
+    ent_ix[i] = ix; ent_iy[i] = iy;
+    if(!sp_in_box(box, ix, iy)) { ent_cell[i] = -1; return; }
     int c = sp_cell_of(G, ix, iy);
-    ent_ix[i] = ix; ent_iy[i] = iy; ent_cell[i] = c;
+    ent_cell[i] = c;
     atomicAdd(&cell_count[c], 1);
 }
 
@@ -355,6 +388,7 @@ __global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, int
     int i = blockIdx.x * 256 + threadIdx.x;
     if(i >= n) return;
     int c = ent_cell[i];
+    if(c < 0) return;                            // outside the slab filter
     int slot = cell_start[c] + atomicAdd(&cell_fill[c], 1);
     sorted_id[slot] = i;
 }
@@ -438,11 +472,12 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
     int written = 0;
     if(E.wide) {
         // wide-query fast path (bitmap_grid.h:1389-1397): the clean pool is scanned linearly
-        for(int base = 0; base < G.n; base += 64) {
+        const int npool = G.cell_start[G.grid_w * G.grid_h];     // == G.n unless a slab filter is on
+        for(int base = 0; base < npool; base += 64) {
             int k = base + lane;
             bool hit = false;
             int64_t d2 = 0;
-            if(k < G.n) {
+            if(k < npool) {
                 int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
                 d2 = dx * dx + dy * dy;
                 hit = d2 <= ir2;
@@ -1291,7 +1326,7 @@ struct wave_lds {
     union {
         uint32_t ids10[512];                   // ClearPath neighbour query result (cap 512, :2779)
         float4   rays[128];                    // later: the combined obstacle, two float4 per cone
-        float    sep[256];                     // earlier: separation terms x[128], z[128]
+        float    sep[256];                     // earlier: separation terms (x, z)[128]
     } u;
     float dyn[32 * 5];
     float stat[32 * 5];
@@ -1324,17 +1359,17 @@ __device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_
                     term = vscale(diff, scale);
                 }
             }
-            sep[k] = term.x;
-            sep[128 + k] = term.z;
+            ((f2*)sep)[k] = f2{term.x, term.z};
         }
     }
     wave_sync();
-    // ret += diff, strictly in candidate order (every lane evaluates the same chain)
-    v2 ret = mkv(0.0f, 0.0f);
+    // ret += diff, strictly in candidate order (every lane evaluates the same chain; x and z ride
+    // in one packed add)
+    f2 acc = {0.0f, 0.0f};
     for(int k = 0; k < n30; k++)
-        ret = vadd(ret, mkv(sep[k], sep[128 + k]));
+        acc = acc + ((const f2*)sep)[k];
     wave_sync();
-    ret = vscale(ret, -1.0f);
+    const v2 ret = vscale(mkv(acc.x, acc.y), -1.0f);
     return vtrunc(ret, scaled_max_force);
 }
 
@@ -1811,14 +1846,23 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_clearpath(int nq, const float
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
-                             hipStream_t s)
+                             int slab_begin, int slab_end, hipStream_t s)
 {
     const int n = G.n, ncells = G.grid_w * G.grid_h;
     hipMemsetAsync(S.cell_count, 0, sizeof(int32_t) * (size_t)ncells, s);
     hipMemsetAsync(S.cell_fill, 0, sizeof(int32_t) * (size_t)ncells, s);
+    // a strict sub-range of the entities is stepped: hash only what its queries can reach
+    const int32_t *box = nullptr;
+    if(S.box && (slab_begin > 0 || slab_end < n)) {
+        hipMemsetD32Async((hipDeviceptr_t)S.box, (int)0x80000000, 4, s);
+        if(slab_end > slab_begin)
+            hipLaunchKernelGGL(k_sp_bbox, dim3((slab_end - slab_begin + 255) / 256), dim3(256), 0, s,
+                               d_pos_xz, slab_begin, slab_end, S.box);
+        box = S.box;
+    }
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
-                           S.ent_ix, S.ent_iy, S.ent_cell, S.cell_count);
+                           S.ent_ix, S.ent_iy, S.ent_cell, S.cell_count, box);
     const int nblocks = (ncells + 1023) / 1024;
     hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(1024), 0, s, S.cell_count, S.cell_start,
                        S.block_sum, ncells);

@@ -612,25 +612,27 @@ static void fill_map_view(const navhip_ctx *ctx, nh_map_view *mv)
     }
 }
 
-static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hipStream_t s)
+static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hipStream_t s,
+                         int slab_begin = 0, int slab_end = -1)
 {
     if(!grid_geometry(w, g)) {
         ctx->last_error = "agent step: empty spatial-grid bounds";
         return NAVHIP_ERR_INVALID;
     }
     const size_t n = (size_t)w->n_ents, ncells = (size_t)g->grid_w * g->grid_h;
-    const size_t sizes[10] = {n, n, n, ncells, ncells, ncells + 1, n, n, n, (ncells + 1023) / 1024};
-    for(int i = 0; i < 10; i++) {
+    const size_t sizes[11] = {n, n, n, ncells, ncells, ncells + 1, n, n, n, (ncells + 1023) / 1024, 4};
+    for(int i = 0; i < 11; i++) {
         int rc = ensure_buf(ctx, ctx->sp[i], sizes[i] * sizeof(int32_t));
         if(rc) return rc;
     }
     nh_spatial_scratch S = {(int32_t*)ctx->sp[0].p, (int32_t*)ctx->sp[1].p, (int32_t*)ctx->sp[2].p,
                             (int32_t*)ctx->sp[3].p, (int32_t*)ctx->sp[4].p, (int32_t*)ctx->sp[5].p,
                             (int32_t*)ctx->sp[6].p, (int32_t*)ctx->sp[7].p, (int32_t*)ctx->sp[8].p,
-                            (int32_t*)ctx->sp[9].p};
+                            (int32_t*)ctx->sp[9].p, (int32_t*)ctx->sp[10].p};
     g->n = w->n_ents;
+    if(slab_end < 0) slab_end = w->n_ents;
     g->cell_start = S.cell_start; g->sorted_id = S.sorted_id; g->sx = S.sx; g->sy = S.sy;
-    nh_launch_spatial_build(*g, w->pos_xz, S, s);
+    nh_launch_spatial_build(*g, w->pos_xz, S, slab_begin, slab_end, s);
     return NAVHIP_OK;
 }
 
@@ -705,7 +707,7 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
-    rc = spatial_build(ctx, w, &P.grid, ctx->aux[0]);
+    rc = spatial_build(ctx, w, &P.grid, ctx->aux[0], P.work_begin, P.work_end);
     if(rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
     nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, ctx->aux[1]);
@@ -763,7 +765,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         for(auto &e : ctx->ev) if(!e) HIPCHK(ctx, hipEventCreate(&e));
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
     }
-    rc = spatial_build(ctx, w, &P.grid, s);
+    rc = spatial_build(ctx, w, &P.grid, s, P.work_begin, P.work_end);
     if(rc) return rc;
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));

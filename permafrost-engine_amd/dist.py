@@ -5,10 +5,11 @@ The path shards two ways, both along boundaries the reference already has:
     (the <=256 independent field_task jobs of nav.c:2049) -> contiguous request slices per rank;
   * the velocity step is fork-joined over contiguous uid slabs (move_submit_cpu_work,
     movement.c:3756-3762) -> one slab per rank, every rank holding the full position snapshot.
-There are exactly two exchange steps per tick, both all-gathers (no reductions):
-  * the baked 4 KB flow tiles, so any rank's agents can sample any field;
+Exchange steps per tick, all-gathers (no reductions):
   * the slab results (new position + velocity, 16 B per agent), so every rank starts the next
-    tick with the full snapshot.
+    tick with the full snapshot -- always;
+  * the baked 4 KB flow tiles -- only when agents sample fields another rank built (tick.NavTick
+    keeps flocks rank aligned, so by default no tile travels; `tile_exchange="all"` gathers all).
 `backend="nccl"` is RCCL over xGMI on the MI355X node; the CPU test-suite runs the same code on
 `gloo` with world_size 2.
 """

@@ -1,9 +1,9 @@
 """The benchmark / demo driver of one navigation tick, everything resident in HBM.
 
 One tick = (1) rebuild every chunk field of this rank's share of the flow fields into the field
-pool, (2) [multi-GPU] all-gather the baked tiles, (3) velocity step + position accept for this
-rank's slab of agents, sampling the pool on the device, (4) [multi-GPU] all-gather the slab
-results, (5) advance the snapshot (pos <- new_pos, vel <- new velocity).  Nothing is cached
+pool, (2) [multi-GPU, only the tiles another rank samples] exchange baked tiles, (3) velocity step
++ position accept for this rank's slab of agents, sampling the pool on the device, (4) [multi-GPU]
+all-gather the slab results, (5) advance the snapshot (pos <- new_pos, vel <- new velocity).  Nothing is cached
 between ticks: the worst case of the reference's tick, where every cached field was invalidated
 (N_ApplyDeferredInvalidations, nav.c:2208).
 
@@ -20,24 +20,36 @@ from . import navhip, synth
 
 
 class NavTick:
+    """World layout (weak scaling): `world` REGIONS of chunk_w x chunk_w chunks
+    side by side on one map of chunk_w rows x (chunk_w * world) columns of chunks.  Region r -- its
+    `fields_per_rank` destinations, the chunk-field requests of those destinations (every chunk of
+    the region: the corridor the planner would emit for units and destination inside the region)
+    and its `agents_per_rank` agents, flock = destination -- belongs to rank r: the agents a rank
+    steps sample the fields that rank built, so the baked tiles only travel when a flock has members
+    on another rank (`tile_exchange`).  The map planes and the entity snapshot are replicated; agents
+    of neighbouring regions see each other through the all-gathered snapshot."""
+
     def __init__(self, chunk_w=16, fields_per_rank=64, agents_per_rank=100_000, rank=0, world=1,
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
-                 obstacle_ticks=128):
+                 obstacle_ticks=128, tile_exchange="auto", solo=False):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
-        self.W = chunk_w
-        self.nchunks = chunk_w * chunk_w
+        self.W = chunk_w                            # region side in chunks
+        self.Wt, self.H = chunk_w * world, chunk_w  # whole map, in chunks
+        self.nchunks = self.Wt * self.H
         self.K = fields_per_rank * world            # flow fields (destinations) in the whole job
         self.N = agents_per_rank * world            # agents in the whole job
         self.hz = hz
         t0 = time.time()
+        Wt, H = self.Wt, self.H
+        rcols = chunk_w * 64                        # cell columns per region
 
-        # ---- synthetic map + request stream, identical on every rank --------
-        grid = synth.cost_grid(chunk_w, chunk_w, seed=seed_map)
-        self.ctx = navhip.NavContext(chunk_w, chunk_w, device=device)
+        # ---- synthetic map (SURVEY.md section 8(d)), identical on every rank --------------------
+        grid = synth.cost_grid(Wt, H, seed=seed_map)
+        self.ctx = navhip.NavContext(Wt, H, device=device)
         self.ctx.upload_plane(0, navhip.PLANE_COST_BASE, synth.to_chunks(grid))
-        self.ctx.upload_plane(0, navhip.PLANE_BLOCKERS, np.zeros((chunk_w, chunk_w, 64, 64), np.uint16))
+        self.ctx.upload_plane(0, navhip.PLANE_BLOCKERS, np.zeros((H, Wt, 64, 64), np.uint16))
         self.n_obstacles = obstacles
         blockers = None
         if obstacles:
@@ -45,7 +57,7 @@ class NavTick:
             # device N_BlockersIncref path; every tick `move_frac` of them move (decref + incref)
             rng = np.random.RandomState(99)
             cells = synth.passable_cells(grid)
-            pos = synth.cell_centre(chunk_w, chunk_w, *cells[rng.randint(len(cells), size=obstacles)].T)
+            pos = synth.cell_centre(Wt, H, *cells[rng.randint(len(cells), size=obstacles)].T)
             circ = np.zeros(obstacles, navhip.CIRCLE_DTYPE)
             circ["x"], circ["z"] = pos[:, 0], pos[:, 1]
             circ["radius"] = rng.uniform(2.0, 6.0, obstacles)
@@ -60,7 +72,7 @@ class NavTick:
                 who = rng.choice(obstacles, nmove, replace=False)
                 moves[t, :nmove] = cur[who]
                 moves[t, :nmove]["delta"] = -1
-                npos = synth.cell_centre(chunk_w, chunk_w, *cells[rng.randint(len(cells), size=nmove)].T)
+                npos = synth.cell_centre(Wt, H, *cells[rng.randint(len(cells), size=nmove)].T)
                 cur["x"][who], cur["z"][who] = npos[:, 0], npos[:, 1]
                 moves[t, nmove:] = cur[who]
                 moves[t, nmove:]["delta"] = 1
@@ -68,30 +80,61 @@ class NavTick:
             self._moves_host = moves
         self.ctx.relabel_local_islands(0)           # n_update_local_island_field on the device
         liid = synth.from_chunks(self.ctx.download_plane(0, navhip.PLANE_LOCAL_ISLANDS))
-        dests = synth.destinations(grid, self.K, seed=42)
-        cols = synth.whole_map_requests(grid, dests, liid)
-        n_req = len(cols["type"])
-        reqs = navhip.make_reqs(n_req)
-        for k in synth.REQ_FIELDS:
-            reqs[k] = cols[k]
+
+        # ---- destinations (cheap, all regions) and agents (replicated snapshot) ----------------
+        dests, ag_parts = [], []
+        for q in range(world):
+            sub = grid[:, q * rcols:(q + 1) * rcols]
+            d = synth.destinations(sub, fields_per_rank, seed=42 + q)
+            dests.append(d + np.array([0, q * rcols]))
+            a = synth.agents(grid, agents_per_rank, fields_per_rank, seed=7 + q, hz=hz, blockers=blockers,
+                             cols=(q * rcols, (q + 1) * rcols))
+            a["flock"] = a["flock"] + q * fields_per_rank
+            ag_parts.append(a)
+        dests = np.concatenate(dests)
+        ag = {k: (np.concatenate([a[k] for a in ag_parts]) if k != "hz" else hz) for k in ag_parts[0]}
+
+        # ---- request stream: region-major, destination-major inside a region -------------------
+        # tile_exchange: "auto" = only the fields some other rank samples travel (none when flocks
+        # are rank aligned, as here); "all" = every rank holds every tile, all-gathered every tick
+        # (SURVEY section 8(e) worst case: any agent may sample any field)
+        # solo (tests): this one process builds every region's fields and steps every agent
+        self.solo = bool(solo)
+        self.tile_exchange = "all" if ((tile_exchange == "all" or solo) and world > 1) else "none"
+        regions = range(world) if self.tile_exchange == "all" else [rank]
+        req_parts, dest_of_req, self.req_bounds, nreq = [], [], [(0, 0)] * world, 0
+        for q in regions:
+            sub = grid[:, q * rcols:(q + 1) * rcols]
+            cols = synth.whole_map_requests(sub, dests[q * fields_per_rank:(q + 1) * fields_per_rank]
+                                            - np.array([0, q * rcols]), liid[:, q * rcols:(q + 1) * rcols])
+            n_q = len(cols["type"])
+            reqs_q = navhip.make_reqs(n_q)
+            for k in synth.REQ_FIELDS:
+                reqs_q[k] = cols[k]
+            reqs_q["chunk_c"] += q * chunk_w
+            portal = reqs_q["type"] == navhip.TARGET_PORTAL
+            reqs_q["next_chunk_c"][portal] += q * chunk_w
+            req_parts.append(reqs_q)
+            dest_of_req.append(np.asarray(cols["dest"]) + q * fields_per_rank)
+            self.req_bounds[q] = (nreq, nreq + n_q)
+            nreq += n_q
+        reqs = np.concatenate(req_parts)
+        dest_of_req = np.concatenate(dest_of_req)
+        n_req = len(reqs)
         if obstacles:
             reqs["flags"] = navhip.REQ_LIVE_IIDS | navhip.REQ_IF_CHANGED
-        # requests are emitted destination-major: field slot = position in the stream
-        dest_of_req = cols["dest"]
-        self.n_req_total = n_req
+        # field slot = position in the (local) request stream
+        self.req_begin, self.req_end = (0, n_req) if solo else self.req_bounds[rank]
+        self.n_req_local = self.req_end - self.req_begin
+        self.n_req_total = self.n_req_local * world if self.tile_exchange != "all" else n_req
         self._dest_of_req = dest_of_req
         slot_tbl = -np.ones((self.K, self.nchunks), np.int32)
-        slot_tbl[dest_of_req, cols["chunk_r"] * chunk_w + cols["chunk_c"]] = np.arange(n_req)
-        # this rank's slice of the request stream: whole destinations, contiguous
-        self.req_bounds = pdist.request_slices(dest_of_req, self.K, world)
-        self.req_begin, self.req_end = self.req_bounds[rank]
-        self.n_req_local = self.req_end - self.req_begin
+        slot_tbl[dest_of_req, reqs["chunk_r"].astype(np.int64) * Wt + reqs["chunk_c"]] = np.arange(n_req)
         self.agent_bounds = [pdist.slab(self.N, r, world) for r in range(world)]
 
-        ag = synth.agents(grid, self.N, self.K, seed=7, hz=hz, blockers=blockers)
         offs, members = navhip.flock_csr(ag["flock"], self.K)
-        targets = synth.cell_centre(chunk_w, chunk_w, dests[:, 0], dests[:, 1])
-        self.a0, self.a1 = pdist.slab(self.N, rank, world)
+        targets = synth.cell_centre(Wt, H, dests[:, 0], dests[:, 1])
+        self.a0, self.a1 = (0, self.N) if solo else pdist.slab(self.N, rank, world)
         self.grid = grid
         self.map_cells = grid.size
 
@@ -136,7 +179,7 @@ class NavTick:
 
     def _make_structs(self):
         arrays = dict(self.t)
-        self.world_s, self._keep = navhip.make_world(self.W, self.W, arrays, hz=self.hz)
+        self.world_s, self._keep = navhip.make_world(self.Wt, self.H, arrays, hz=self.hz)
         self.world_s.work_begin, self.world_s.work_end = self.a0, self.a1
         self.out_s = navhip.StepOut()
         self.out_s.vel_xz = self.new_vel.data_ptr()
@@ -152,8 +195,14 @@ class NavTick:
 
     def step(self):
         """One tick, asynchronous on self.stream."""
+        self.compute()
+        self.exchange()
+        self.advance()
+
+    def compute(self):
+        """Field builds + velocity step of this rank's share (everything up to the exchange)."""
         s = self.stream
-        marks = []
+        self._marks = marks = []
         with torch.cuda.stream(s):
             if self.n_obstacles:
                 marks.append(self._mark("blockers"))
@@ -170,20 +219,30 @@ class NavTick:
             if self.n_obstacles:
                 self.ctx.clear_changed(stream=s.cuda_stream)
             marks.append(self._mark("gather_tiles"))
-            pdist.exchange_rows(self.pool, self.req_bounds, self.rank, self.world)
+            if self.tile_exchange == "all" and not self.solo:
+                pdist.exchange_rows(self.pool, self.req_bounds, self.rank, self.world)
             marks.append(self._mark("agents"))
             self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
             marks.append(self._mark("gather_agents"))
+
+    def exchange(self):
+        """The slab results (new position + velocity) of every rank -> every rank."""
+        if self.solo or self.world == 1:
+            return
+        with torch.cuda.stream(self.stream):
             pdist.exchange_rows(self.new_pos, self.agent_bounds, self.rank, self.world)
             pdist.exchange_rows(self.new_vel, self.agent_bounds, self.rank, self.world)
-            marks.append(self._mark("end"))
-            # advance the snapshot: ping-pong the position / velocity buffers
+
+    def advance(self):
+        """Advance the snapshot: ping-pong the position / velocity buffers."""
+        with torch.cuda.stream(self.stream):
+            self._marks.append(self._mark("end"))
             self.t["pos_xz"], self.new_pos = self.new_pos, self.t["pos_xz"]
             self.t["vel_xz"], self.new_vel = self.new_vel, self.t["vel_xz"]
             self._make_structs()
         self.tick_no += 1
         if self.record:
-            self.ev.append(marks)
+            self.ev.append(self._marks)
 
     def phase_ms(self):
         """Average HIP-event duration of every phase over the recorded steps."""

@@ -109,3 +109,18 @@ def test_two_rank_gloo_tick_exchange(n_dests, n_agents):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_region_agents_stay_in_their_columns():
+    """tick.NavTick's weak-scaling world: region q's agents are drawn from the passable cells of the
+    global columns [q*rcols, (q+1)*rcols); the unrestricted call is unchanged (world == 1)."""
+    from permafrost_engine_amd import synth
+    g = synth.cost_grid(4, 2, seed=1234)
+    mp = synth.map_pos(4, 2)
+    for q in range(2):
+        a = synth.agents(g, 400, 3, seed=7 + q, cols=(q * 128, (q + 1) * 128))
+        col = (mp[0] - a["pos"][:, 0]) / 4.0
+        assert col.min() > q * 128 - 0.5 and col.max() < (q + 1) * 128 + 0.5
+    a0 = synth.agents(g, 400, 3, seed=7)
+    a1 = synth.agents(g, 400, 3, seed=7, cols=(0, 256))
+    assert np.array_equal(a0["pos"], a1["pos"]) and np.array_equal(a0["vel"], a1["vel"])
