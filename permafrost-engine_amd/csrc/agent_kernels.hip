@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *flock_offsets, 
 
 // k_coh_bin / k_coh_scatter: per-tick lane assignment of the cohesion launch.  Which thread handles
 // which member is free (each member's sum only depends on the flock's member ORDER, which the walk
-// keeps), so the members of a flock are regrouped by a 16x16 grid of map blocks in Morton order:
+// keeps), so the members of a flock are regrouped by 256-wu map blocks (16x16) in Morton order:
 // the 64 members of a wave are then close together and the wave can skip, exactly, every flock
 // mate that is too far from ALL of them to carry a non-zero weight (see k_cohesion).
 //   bin = flock * COH_BINS + morton(block);   perm[] = CSR entries ordered by bin (counting sort;
@@ -1054,9 +1054,10 @@ __device__ __forceinline__ int coh_bin_of(const nh_step_params &P, int g, int *f
                   && !(P.flags[m] & NAVHIP_ENTITY_FLAG_COMBAT_HELD);
     if(!act) return lo * COH_BINS + 256;
     const float ox = (float)P.grid.origin_x * (1.0f / 256.0f), oz = (float)P.grid.origin_y * (1.0f / 256.0f);
-    int bx = (int)((P.pos_xz[2 * m] - ox) / (float)P.grid.grid_w);           // span / 16 == grid_w wu
-    int bz = (int)((P.pos_xz[2 * m + 1] - oz) / (float)P.grid.grid_h);
-    bx = min(max(bx, 0), 15); bz = min(max(bz, 0), 15);
+    // 256-wu blocks, 16 x 16 of them before the pattern repeats (a flock spread over more than
+    // 4096 wu merely shares bins: the grouping is a locality heuristic, never a correctness matter)
+    const int bx = (int)floorf((P.pos_xz[2 * m] - ox) * (1.0f / 256.0f)) & 15;
+    const int bz = (int)floorf((P.pos_xz[2 * m + 1] - oz) * (1.0f / 256.0f)) & 15;
     int mo = 0;
 #pragma unroll
     for(int k = 0; k < 4; k++) mo |= (((bx >> k) & 1) << (2 * k)) | (((bz >> k) & 1) << (2 * k + 1));

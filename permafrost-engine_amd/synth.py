@@ -26,10 +26,13 @@ def cost_grid(w, h, seed=1234, frac_impassable=0.20):
     R, Cc = h * 64, w * 64
     imp = np.zeros((R, Cc), bool)
     target = frac_impassable * R * Cc
-    while imp.sum() < target:
+    count = 0                                   # == imp.sum(), kept incrementally (big maps)
+    while count < target:
         rh, rw = rng.randint(2, 13), rng.randint(2, 13)
         r0, c0 = rng.randint(1, R - rh - 1), rng.randint(1, Cc - rw - 1)
-        imp[r0:r0 + rh, c0:c0 + rw] = True
+        blk = imp[r0:r0 + rh, c0:c0 + rw]
+        count += blk.size - int(blk.sum())
+        blk[:] = True
     imp[0, :] = imp[-1, :] = False
     imp[:, 0] = imp[:, -1] = False
     lab, n = ndimage.label(~imp)          # 4-connectivity by default
