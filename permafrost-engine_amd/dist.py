@@ -27,9 +27,12 @@ def env_world():
 def init(backend=None):
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
     rank, world, local = env_world()
+    if torch.cuda.is_available():
+        # (more ranks than GPUs only happens in the single-GPU plumbing check, with gloo)
+        local = local % torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("NAVHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -81,6 +84,12 @@ def all_gather_rows(full, rank, world, rows_per_rank):
     rank r contributes full[r*rows_per_rank:(r+1)*rows_per_rank] and receives the others."""
     if world == 1:
         return
+    if full.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no GPU all-gather: stage through the host (plumbing checks on a single GPU only)
+        host = full.cpu()
+        dist.all_gather_into_tensor(host, host[rank * rows_per_rank:(rank + 1) * rows_per_rank].contiguous())
+        full.copy_(host)
+        return
     mine = full[rank * rows_per_rank:(rank + 1) * rows_per_rank]
     dist.all_gather_into_tensor(full, mine.contiguous())
 
@@ -93,6 +102,8 @@ def barrier():
 def max_over_ranks(value, device):
     if not dist.is_initialized():
         return value
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
