@@ -163,6 +163,14 @@ class NavTick:
         self.new_vel = torch.zeros((n, 2), dtype=torch.float32, device=self.dev)
         self.status = torch.zeros(n, dtype=torch.uint8, device=self.dev)
         self.stream = torch.cuda.Stream(device=self.dev)
+        # multi-GPU: the slab all-gather of tick t runs on its own stream and is only awaited by the
+        # snapshot consumers of tick t+1 (spatial hash + cohesion, then the agent step); the field
+        # builds of tick t+1 do not read positions and overlap with it
+        self.pipelined = world > 1 and not solo
+        self.comm = torch.cuda.Stream(device=self.dev) if self.pipelined else None
+        self.ev_step = torch.cuda.Event()
+        self.ev_comm = torch.cuda.Event()
+        self._comm_pending = False
         self._make_structs()
         if obstacles:
             # the pool starts fully built (untimed), afterwards only changed chunks are repaired
@@ -203,6 +211,10 @@ class NavTick:
         """Field builds + velocity step of this rank's share (everything up to the exchange)."""
         s = self.stream
         self._marks = marks = []
+        if self.pipelined and self.overlap:
+            # behind the previous tick's all-gather, concurrently with the field builds below
+            with torch.cuda.stream(self.comm):
+                self.ctx.agent_prefetch_dev(self.world_s, stream=self.comm.cuda_stream)
         with torch.cuda.stream(s):
             if self.n_obstacles:
                 marks.append(self._mark("blockers"))
@@ -210,7 +222,7 @@ class NavTick:
                 self.ctx.blockers_circles_dev(self.d_moves[t], self.n_moves, stream=s.cuda_stream)
             # snapshot-only parts of the agent step (spatial hash, cohesion) start now on the
             # library's side streams and overlap with the field builds below
-            if self.overlap:
+            if self.overlap and not self.pipelined:
                 self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream)
             marks.append(self._mark("fields"))
             if self.n_req_local:
@@ -222,16 +234,22 @@ class NavTick:
             if self.tile_exchange == "all" and not self.solo:
                 pdist.exchange_rows(self.pool, self.req_bounds, self.rank, self.world)
             marks.append(self._mark("agents"))
+            if self._comm_pending:
+                s.wait_event(self.ev_comm)            # the other ranks' rows of the snapshot
             self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
             marks.append(self._mark("gather_agents"))
+            self.ev_step.record(s)
 
     def exchange(self):
         """The slab results (new position + velocity) of every rank -> every rank."""
-        if self.solo or self.world == 1:
+        if not self.pipelined:
             return
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.ev_step)
             pdist.exchange_rows(self.new_pos, self.agent_bounds, self.rank, self.world)
             pdist.exchange_rows(self.new_vel, self.agent_bounds, self.rank, self.world)
+            self.ev_comm.record(self.comm)
+        self._comm_pending = True
 
     def advance(self):
         """Advance the snapshot: ping-pong the position / velocity buffers."""
@@ -253,6 +271,8 @@ class NavTick:
         return {k: float(np.mean(v)) for k, v in out.items()}
 
     def sync(self):
+        if self.comm is not None:
+            self.comm.synchronize()
         self.stream.synchronize()
         torch.cuda.synchronize(self.dev)
 

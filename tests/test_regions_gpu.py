@@ -27,6 +27,7 @@ def test_two_emulated_ranks_match_solo():
         for dst, src, (lo, hi) in ((T0, T1, (b0, b1)), (T1, T0, (a0, a1))):
             dst.new_pos[lo:hi] = src.new_pos[lo:hi]
             dst.new_vel[lo:hi] = src.new_vel[lo:hi]
+        torch.cuda.synchronize()               # (the copies ran on the default stream)
         T0.advance(); T1.advance()
         S.step(); S.sync()
         for T in (T0, T1):
