@@ -181,6 +181,7 @@ class NavTick:
             self.stream.synchronize()
         self.ev = []                   # (phase, start_event, end_event) of the timed steps
         self.record = False
+        self.mark_every = 4
         if verbose:
             print("[rank %d] setup %.1fs: %d chunk-field requests (%d local), %d agents (%d local)"
                   % (rank, time.time() - t0, n_req, self.n_req_local, n, self.a1 - self.a0), flush=True)
@@ -195,7 +196,10 @@ class NavTick:
         self.out_s.status = self.status.data_ptr()
 
     def _mark(self, name):
-        if not self.record:
+        # phase timing by HIP events on the launch stream, on every `mark_every`-th recorded tick:
+        # timing events are not free (a marker packet between back-to-back kernels; six per tick
+        # cost ~4 % of the tick when recorded every tick)
+        if not self.record or self.tick_no % self.mark_every:
             return None
         e = torch.cuda.Event(enable_timing=True)
         e.record(self.stream)
@@ -258,9 +262,9 @@ class NavTick:
             self.t["pos_xz"], self.new_pos = self.new_pos, self.t["pos_xz"]
             self.t["vel_xz"], self.new_vel = self.new_vel, self.t["vel_xz"]
             self._make_structs()
-        self.tick_no += 1
-        if self.record:
+        if self.record and self._marks and self._marks[0] is not None:
             self.ev.append(self._marks)
+        self.tick_no += 1
 
     def phase_ms(self):
         """Average HIP-event duration of every phase over the recorded steps."""
