@@ -198,6 +198,25 @@ def main():
             measured = json.load(open(tpath))
         except Exception:
             measured = {}
+    # What actually bounds these kernels is VALU issue, not HBM: next to the
+    # HBM figures, report the instruction-issue floor from the committed SQ counters.
+    sq = {}
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["kernels"]
+    except Exception:
+        sq = {}
+
+    def valu(names, measured_ms):
+        ks = [k for k in sq if k.startswith(names)]
+        if not ks or measured_ms <= 0:
+            return None
+        insts = sum(sq[k]["SQ_INSTS_VALU"] for k in ks)
+        floor_ms = insts / 1024 * 4 / 2.4e9 * 1e3
+        return {"valu_insts_per_launch": insts, "issue_floor_ms": floor_ms,
+                "frac_of_issue_peak": floor_ms / measured_ms,
+                "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, profiles/sq_counters.json) at "
+                        "one per 4 cycles per SIMD, 1024 SIMDs, 2.4 GHz, over the measured phase time"}
+
     dom = "agents" if a_ms >= f_ms else "fields"
     roof = {
         "bound": "hbm", "kernel": "k_agent_step (+k_cohesion, spatial hash)" if dom == "agents" else "k_field_bfs",
@@ -208,6 +227,7 @@ def main():
         "algorithmic_bytes_per_launch": a_bytes if dom == "agents" else f_bytes,
         "launch": "one navhip_agent_step_dev call" if dom == "agents" else "one navhip_build_fields_dev call",
         "kernels_ms": {"k_sp_*": k_sp, "k_cohesion": k_coh, "k_agent_step": k_step} if dom == "agents" else None,
+        "valu_issue": valu(("k_agent_",), a_ms) if dom == "agents" else valu(("k_field_", "k_coh", "k_sp_"), f_ms),
     }
     roof_other = {
         "bound": "hbm", "kernel": "k_field_bfs" if dom == "agents" else "k_agent_step (+k_cohesion, spatial hash)",
@@ -216,6 +236,7 @@ def main():
         "traffic": measured.get(("fields" if dom == "agents" else "agents") + "_bytes_per_launch"),
         "avg_launch_ms": f_ms if dom == "agents" else a_ms,
         "algorithmic_bytes_per_launch": f_bytes if dom == "agents" else a_bytes,
+        "valu_issue": valu(("k_field_", "k_coh", "k_sp_"), f_ms) if dom == "agents" else valu(("k_agent_",), a_ms),
     }
 
     cpu = None

@@ -47,9 +47,12 @@ def main():
         # 1024 SIMDs, 2.4 GHz
         d["valu_issue_floor_us"] = d["SQ_INSTS_VALU"] / 1024 * 4 / 2.4e3
         out[k] = d
-    json.dump({"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES on bench.py "
-                         "--steps 12 --warmup 3 (per-dispatch averages)", "kernels": out},
-              open(os.path.join(dst, "r01_sq_counters_%s.json" % suf), "w"), indent=1)
+    doc = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES on bench.py "
+                     "--steps 12 --warmup 3 (per-dispatch averages)",
+           "valu_issue_floor": "SQ_INSTS_VALU / 1024 SIMDs x 4 cycles per wave64 instruction / 2.4 GHz",
+           "kernels": out}
+    json.dump(doc, open(os.path.join(dst, "r01_sq_counters_%s.json" % suf), "w"), indent=1)
+    json.dump(doc, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)      # read by bench.py
     for k in ("k_agent_step", "k_cohesion", "k_field_bfs<false>", "k_agent_pre"):
         if k in out:
             print(k, "VALU/wave %.0f  waves %.0f  issue floor %.1f us" % (out[k]["valu_per_wave"], out[k]["SQ_WAVES"], out[k]["valu_issue_floor_us"]))
