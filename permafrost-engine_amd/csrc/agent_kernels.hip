@@ -997,9 +997,11 @@ __device__ __forceinline__ float cohesion_t_f64(float len)
     return (float)__builtin_fma(__builtin_fma(-q0, 50.0, x), r50, q0);
 }
 
+#define COH_BINS 257       /* 256 Morton blocks + 1 bin for members that take no cohesion force */
 // k_coh_plan: wave_off[f] = number of 16-member (COH_APW) waves of the flocks before f (exclusive
-// scan of ceil(size/16)); one workgroup, chunked.
-__global__ __launch_bounds__(256) void k_coh_plan(const int32_t *flock_offsets, int n_flocks,
+// scan of ceil(active members / 16), the active members being the bins before the flock's last one);
+// one workgroup, chunked.  Runs after the bin scan.
+__global__ __launch_bounds__(256) void k_coh_plan(const int32_t *bin_start, int n_flocks,
                                                   int32_t *wave_off)
 {
     __shared__ int32_t wsum[4];
@@ -1010,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *flock_offsets, 
     for(int base = 0; base < n_flocks; base += 256) {
         const int f = base + t;
         int32_t v = 0;
-        if(f < n_flocks) v = (flock_offsets[f + 1] - flock_offsets[f] + 15) >> 4;      // COH_APW
+        if(f < n_flocks) v = (bin_start[f * COH_BINS + 256] - bin_start[f * COH_BINS] + 15) >> 4;   // COH_APW
         int32_t incl = v;
 #pragma unroll
         for(int d = 1; d < 64; d <<= 1) {
@@ -1040,7 +1042,6 @@ __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *flock_offsets, 
 // Members that take no cohesion force this tick (outside the work range, not point seeking, combat
 // hold) go to the flock's last bin: the lanes in use are packed at the front and the trailing waves
 // of a flock exit at once.
-#define COH_BINS 257
 __device__ __forceinline__ int coh_bin_of(const nh_step_params &P, int g, int *flock_out)
 {
     int lo = 0, hi = P.n_flocks;
@@ -1896,12 +1897,12 @@ void nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh,
         int32_t *bin_of = block_sum + nblocks;
         int32_t *perm = bin_of + P.n_members;
         hipMemsetAsync(bin_count, 0, sizeof(int32_t) * 2 * (size_t)nb, s);
-        hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, P.flock_offsets, P.n_flocks, wave_off);
         const int gm = (P.n_members + 255) / 256;
         hipLaunchKernelGGL(k_coh_bin, dim3(gm), dim3(256), 0, s, P, bin_of, bin_count);
         hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(1024), 0, s, bin_count, bin_start,
                            block_sum, nb);
         hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(1024), 0, s, bin_start, block_sum, nb, nblocks);
+        hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)bin_start, P.n_flocks, wave_off);
         hipLaunchKernelGGL(k_coh_scatter, dim3(gm), dim3(256), 0, s, P, bin_of, bin_start, bin_fill, perm);
         // upper bound of the number of 16-member (COH_APW) waves; surplus waves exit at once
         const int nwaves = (P.n_members + 15) / 16 + P.n_flocks;
