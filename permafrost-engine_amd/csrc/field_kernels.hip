@@ -145,7 +145,7 @@ void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, 
 template <bool WANT_INTEG>
 __global__ __launch_bounds__(BFS_WAVES * 64) void k_field_bfs(nh_map_view map, const navhip_field_req *reqs,
                                                    int n, uint8_t *dirs, float *integ,
-                                                   int force_generic, int32_t *gen_list)
+                                                   int force_generic, int32_t *gen_list, int gen_slot)
 {
     // 4 KB of LDS per wave: staging buffer to turn "lane owns a 64-byte row" into fully
     // coalesced 16 B/lane global accesses (both for the INOUT read and for the final write).
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(BFS_WAVES * 64) void k_field_bfs(nh_map_view map, c
     navhip_field_req rq = reqs[wave];
     if(!req_uses_bfs(map, rq, force_generic)) {
         // not a unit-cost BFS: hand the request to k_field_generic
-        if(lane == 0) gen_list[2 + atomicAdd(&gen_list[0], 1)] = wave;
+        if(lane == 0) gen_list[2 + atomicAdd(&gen_list[gen_slot], 1)] = wave;
         return;
     }
     if(!req_prepare(map, rq)) return;
@@ -629,27 +629,22 @@ __device__ void field_generic_one(generic_lds &S, const nh_map_view &map, const 
 }
 
 // The launch is a fixed, small grid: workgroups stride over the list of requests the BFS kernel
-// declined (gen_list: count, done, ids...; gen_list == nullptr: every request, in order).  A tick
-// whose requests are all unit-cost BFS fields pays for a few hundred workgroups that read one
-// counter, not for one empty workgroup per request.  The last workgroup to finish zeroes the
-// header for the next launch.
+// declined (gen_list: two counters, then the ids; gen_list == nullptr: every request, in order).  A
+// tick whose requests are all unit-cost BFS fields pays for a few hundred workgroups that read one
+// counter, not for one empty workgroup per request.  The two counters alternate between launches:
+// this launch reads counter `gen_slot` and zeroes the other one for the next launch (which starts
+// after this one in stream order) -- no reset pass, no completion atomics.
 __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const navhip_field_req *reqs,
                                                        int n, uint8_t *dirs, float *integ,
-                                                       int force_generic, int32_t *gen_list)
+                                                       int force_generic, int32_t *gen_list, int gen_slot)
 {
     __shared__ generic_lds S;
-    const int count = gen_list ? gen_list[0] : n;
+    const int count = gen_list ? gen_list[gen_slot] : n;
+    if(gen_list && blockIdx.x == 0 && threadIdx.x == 0) gen_list[gen_slot ^ 1] = 0;
     for(int w = blockIdx.x; w < count; w += gridDim.x) {
         const int ri = gen_list ? gen_list[2 + w] : w;
         field_generic_one(S, map, reqs, ri, dirs, integ, force_generic);
         __syncthreads();
-    }
-    if(gen_list) {
-        __syncthreads();
-        if(threadIdx.x == 0) {
-            __threadfence();
-            if(atomicAdd(&gen_list[1], 1) == (int)gridDim.x - 1) { gen_list[0] = 0; gen_list[1] = 0; }
-        }
     }
 }
 
@@ -657,6 +652,7 @@ __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const na
 void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, uint8_t *d_dirs,
                       float *d_integ, int32_t *d_gen_list, hipStream_t s)
 {
+
     nh_map_view mv;
     mv.w = ctx->w;
     mv.h = ctx->h;
@@ -666,15 +662,17 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
                                      L.passmask, L.unit_cost, L.changed, L.islands};
     }
     const int force_generic = ctx->field_kernel_mode == 1;
+    // (only launches that use the list alternate its counters)
+    const int gen_slot = force_generic ? 0 : (int)(ctx->gen_launches++ & 1);
     if(!force_generic) {
         dim3 grid((n + BFS_WAVES - 1) / BFS_WAVES);
         if(d_integ)
             hipLaunchKernelGGL(k_field_bfs<true>, grid, dim3(BFS_WAVES * 64), 0, s, mv, d_reqs, n, d_dirs,
-                               d_integ, force_generic, d_gen_list);
+                               d_integ, force_generic, d_gen_list, gen_slot);
         else
             hipLaunchKernelGGL(k_field_bfs<false>, grid, dim3(BFS_WAVES * 64), 0, s, mv, d_reqs, n, d_dirs,
-                               d_integ, force_generic, d_gen_list);
+                               d_integ, force_generic, d_gen_list, gen_slot);
     }
-    hipLaunchKernelGGL(k_field_generic, dim3(n < 1024 ? n : 1024), dim3(256), 0, s, mv, d_reqs, n, d_dirs,
-                       d_integ, force_generic, force_generic ? (int32_t*)nullptr : d_gen_list);
+    hipLaunchKernelGGL(k_field_generic, dim3(n < 512 ? n : 512), dim3(256), 0, s, mv, d_reqs, n, d_dirs,
+                       d_integ, force_generic, force_generic ? (int32_t*)nullptr : d_gen_list, gen_slot);
 }

@@ -95,6 +95,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(&ctx->coh, 0, sizeof(ctx->coh));
     memset(&ctx->coh_plan, 0, sizeof(ctx->coh_plan));
     memset(&ctx->gen_list, 0, sizeof(ctx->gen_list));
+    ctx->gen_launches = 0;
     memset(&ctx->prerec, 0, sizeof(ctx->prerec));
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;

@@ -47,7 +47,8 @@ struct navhip_ctx {
     buf          coh;          // cohesion force per entity
     buf          coh_plan;     // [n_flocks + 1] wave prefix of the cohesion launch
     buf          prerec;       // per-entity record of the scalar pre-pass (k_agent_pre)
-    buf          gen_list;     // [2 + n] requests the BFS kernel left to k_field_generic: count, done, ids
+    buf          gen_list;     // [2 + n] requests the BFS kernel left to k_field_generic: 2 counters, ids
+    unsigned     gen_launches; // parity selects the counter of a launch
     buf          stage[36];    // device copies of host buffers for the host-pointer entry points
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];
