@@ -48,7 +48,11 @@ struct nh_step_outs {
 void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
                              int slab_begin, int slab_end, hipStream_t s);
 size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members);
-void nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, hipStream_t s);
+void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s);
+// returns true when the lane regrouping for the next tick is still to be launched
+// (nh_launch_cohesion_regroup, after the caller's "cohesion done" event)
+bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, int *parity, hipStream_t s);
+void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *parity, hipStream_t s);
 size_t nh_pre_rec_bytes();
 void nh_launch_agent_pre(const nh_step_params &P, void *d_pre, const nh_step_outs &O, hipStream_t s);
 void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const void *d_pre, const nh_step_outs &O,

@@ -999,20 +999,34 @@ __device__ __forceinline__ float cohesion_t_f64(float len)
 
 #define COH_BINS 257       /* 256 Morton blocks + 1 bin for members that take no cohesion force */
 // k_coh_plan: wave_off[f] = number of 16-member (COH_APW) waves of the flocks before f (exclusive
-// scan of ceil(active members / 16), the active members being the bins before the flock's last one);
-// one workgroup, chunked.  Runs after the bin scan.
-__global__ __launch_bounds__(256) void k_coh_plan(const int32_t *bin_start, int n_flocks,
-                                                  int32_t *wave_off)
+// scan); one workgroup, chunked.  Two forms:
+//  * bin_start != nullptr (fresh grouping, runs after the bin scan): ceil(active members / 16), the
+//    active members being the bins before the flock's last one;
+//  * bin_start == nullptr (grouping of the previous tick): ceil(flock size / 16) -- every member gets
+//    a lane, whatever its state was when the grouping was made -- and *perm_valid = the grouping
+//    was built for exactly these flock offsets (saved_offs).
+__global__ __launch_bounds__(256) void k_coh_plan(const int32_t *bin_start, const int32_t *flock_offsets,
+                                                  const int32_t *saved_offs, int n_flocks,
+                                                  int32_t *wave_off, int32_t *perm_valid)
 {
     __shared__ int32_t wsum[4];
     __shared__ int32_t carry;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if(t == 0) carry = 0;
     __syncthreads();
+    bool same = true;
     for(int base = 0; base < n_flocks; base += 256) {
         const int f = base + t;
         int32_t v = 0;
-        if(f < n_flocks) v = (bin_start[f * COH_BINS + 256] - bin_start[f * COH_BINS] + 15) >> 4;   // COH_APW
+        if(f < n_flocks) {
+            if(bin_start) {
+                v = (bin_start[f * COH_BINS + 256] - bin_start[f * COH_BINS] + 15) >> 4;   // COH_APW
+            }else{
+                const int32_t b = flock_offsets[f], e = flock_offsets[f + 1];
+                v = (e - b + 15) >> 4;
+                same = same && saved_offs[f] == b && saved_offs[f + 1] == e;
+            }
+        }
         int32_t incl = v;
 #pragma unroll
         for(int d = 1; d < 64; d <<= 1) {
@@ -1030,6 +1044,10 @@ __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *bin_start, int 
         __syncthreads();
     }
     if(t == 0) wave_off[n_flocks] = carry;
+    if(perm_valid) {
+        const int ok = __syncthreads_and(same);
+        if(t == 0) *perm_valid = ok;
+    }
 }
 
 // k_coh_bin / k_coh_scatter: per-tick lane assignment of the cohesion launch.  Which thread handles
@@ -1065,9 +1083,12 @@ __device__ __forceinline__ int coh_bin_of(const nh_step_params &P, int g, int *f
     return lo * COH_BINS + mo;
 }
 
-__global__ __launch_bounds__(256) void k_coh_bin(nh_step_params P, int32_t *bin_of, int32_t *bin_count)
+__global__ __launch_bounds__(256) void k_coh_bin(nh_step_params P, int32_t *bin_of, int32_t *bin_count,
+                                                 int32_t *saved_offs)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
+    if(saved_offs)
+        for(int f = g; f <= P.n_flocks; f += gridDim.x * 256) saved_offs[f] = P.flock_offsets[f];
     if(g >= P.flock_offsets[P.n_flocks]) return;
     int f;
     const int bin = coh_bin_of(P, g, &f);
@@ -1210,7 +1231,8 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
 }
 
 __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off,
-                                                 const int32_t *perm, float *coh_xz)
+                                                 const int32_t *perm, const int32_t *perm_valid,
+                                                 float *coh_xz)
 {
     __shared__ double tab[64];
     // the members of the current tile that survive the box test, in member order (+ carry-over):
@@ -1235,7 +1257,10 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
     const int gp = b + (wv - wave_off[f]) * COH_APW + (t >> 2);
     const bool mine = gp < e;
-    const int g = mine ? perm[gp] : -1;                  // CSR entry of this quad's member
+    // CSR entry of this quad's member (any permutation of the flock's entries serves; a grouping
+    // made for other flock offsets is ignored)
+    const bool use_perm = !perm_valid || *perm_valid != 0;
+    const int g = mine ? (use_perm ? perm[gp] : gp) : -1;
     const int uid = mine ? P.flock_members[g] : -1;
     bool act = mine && uid >= P.work_begin && uid < P.work_end;
     if(act) act = state_uses_point_seek(P.state[uid]) && !(P.flags[uid] & NAVHIP_ENTITY_FLAG_COMBAT_HELD);
@@ -1878,40 +1903,100 @@ void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial
 }
 
 // scratch of the cohesion launch: wave prefix | bin counts | bin fills | bin starts | scan block sums
-// | bin of each CSR entry | perm.
+// | bin of each CSR entry | perm x2 | flock offsets the two perms were built for x2 | perm-valid flag.
 // (Tried: scan + plan + re-zeroing fused into ONE single-workgroup kernel to shorten the chain of
 // dependent launches -- 0.465 vs 0.450 ms/tick in one session: the serial chunks of a single
 // workgroup take longer than three small parallel kernels.)
+struct coh_scratch {
+    int32_t *wave_off, *bin_count, *bin_fill, *bin_start, *block_sum, *bin_of, *perm[2], *saved[2], *valid;
+    int nb, nblocks;
+};
+static coh_scratch coh_layout(int32_t *scratch, int n_flocks, int n_members)
+{
+    coh_scratch C;
+    C.nb = n_flocks * COH_BINS; C.nblocks = (C.nb + 1023) / 1024;
+    C.wave_off = scratch;
+    C.bin_count = C.wave_off + n_flocks + 1;
+    C.bin_fill = C.bin_count + C.nb;
+    C.bin_start = C.bin_fill + C.nb;                      // [nb + 1]
+    C.block_sum = C.bin_start + C.nb + 1;
+    C.bin_of = C.block_sum + C.nblocks;
+    C.perm[0] = C.bin_of + n_members;
+    C.perm[1] = C.perm[0] + n_members;
+    C.saved[0] = C.perm[1] + n_members;
+    C.saved[1] = C.saved[0] + n_flocks + 1;
+    C.valid = C.saved[1] + n_flocks + 1;
+    return C;
+}
 size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members)
 {
     const size_t nb = (size_t)n_flocks * COH_BINS;
-    return sizeof(int32_t) * ((size_t)n_flocks + 1 + 3 * nb + 1 + (nb + 1023) / 1024 + 2 * (size_t)n_members);
+    return sizeof(int32_t) * (3 * ((size_t)n_flocks + 1) + 3 * nb + 1 + (nb + 1023) / 1024
+                              + 3 * (size_t)n_members + 1);
 }
 
-void nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, hipStream_t s)
+// after (re)allocation: no grouping has been built for any flock layout yet
+void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s)
 {
-    if(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0) {
-        const int nb = P.n_flocks * COH_BINS, nblocks = (nb + 1023) / 1024;
-        int32_t *wave_off = scratch;
-        int32_t *bin_count = wave_off + P.n_flocks + 1;
-        int32_t *bin_fill = bin_count + nb;
-        int32_t *bin_start = bin_fill + nb;               // [nb + 1]
-        int32_t *block_sum = bin_start + nb + 1;
-        int32_t *bin_of = block_sum + nblocks;
-        int32_t *perm = bin_of + P.n_members;
-        hipMemsetAsync(bin_count, 0, sizeof(int32_t) * 2 * (size_t)nb, s);
-        const int gm = (P.n_members + 255) / 256;
-        hipLaunchKernelGGL(k_coh_bin, dim3(gm), dim3(256), 0, s, P, bin_of, bin_count);
-        hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(1024), 0, s, bin_count, bin_start,
-                           block_sum, nb);
-        hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(1024), 0, s, bin_start, block_sum, nb, nblocks);
-        hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)bin_start, P.n_flocks, wave_off);
-        hipLaunchKernelGGL(k_coh_scatter, dim3(gm), dim3(256), 0, s, P, bin_of, bin_start, bin_fill, perm);
-        // upper bound of the number of 16-member (COH_APW) waves; surplus waves exit at once
-        const int nwaves = (P.n_members + 15) / 16 + P.n_flocks;
-        hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)wave_off,
-                           (const int32_t*)perm, d_coh);
+    const coh_scratch C = coh_layout(scratch, n_flocks, n_members);
+    hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 1), s);
+}
+
+// the counting sort that regroups the lanes of every flock (k_coh_bin .. k_coh_scatter) into perm[which]
+static void coh_regroup(const nh_step_params &P, const coh_scratch &C, int which, bool plan_from_bins,
+                        hipStream_t s)
+{
+    hipMemsetAsync(C.bin_count, 0, sizeof(int32_t) * 2 * (size_t)C.nb, s);
+    const int gm = (P.n_members + 255) / 256;
+    hipLaunchKernelGGL(k_coh_bin, dim3(gm), dim3(256), 0, s, P, C.bin_of, C.bin_count, C.saved[which]);
+    hipLaunchKernelGGL(k_sp_scan_local, dim3(C.nblocks), dim3(1024), 0, s, C.bin_count, C.bin_start,
+                       C.block_sum, C.nb);
+    hipLaunchKernelGGL(k_sp_scan_add, dim3(C.nblocks), dim3(1024), 0, s, C.bin_start, C.block_sum, C.nb,
+                       C.nblocks);
+    if(plan_from_bins)
+        hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start,
+                           P.flock_offsets, (const int32_t*)nullptr, P.n_flocks, C.wave_off, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_coh_scatter, dim3(gm), dim3(256), 0, s, P, C.bin_of, C.bin_start, C.bin_fill,
+                       C.perm[which]);
+}
+
+// The cohesion term of one tick.  *parity (in/out, kept by the context) = which of the two perm
+// buffers the NEXT regrouping writes.
+//  * A rank that steps only a slab regroups first (members outside the slab must not occupy lanes,
+//    and only a fresh count says how many waves that takes), then runs k_cohesion.
+//  * When every entity is stepped, k_cohesion starts at once on the grouping the PREVIOUS tick left
+//    behind (any permutation of a flock's entries is valid; the grouping only has to be spatially
+//    coherent, and agents move ~1 wu per tick; k_coh_plan checks that it was built for these flock
+//    offsets, else the identity is used), and the regrouping for the next tick follows it --
+//    nh_launch_cohesion_regroup, which the caller launches AFTER recording its "cohesion done"
+//    event: five dependent small launches leave the tick's critical path.
+bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, int *parity, hipStream_t s)
+{
+    if(!(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0)) return false;
+    const coh_scratch C = coh_layout(scratch, P.n_flocks, P.n_members);
+    // upper bound of the number of 16-member (COH_APW) waves; surplus waves exit at once
+    const int nwaves = (P.n_members + 15) / 16 + P.n_flocks;
+    const bool whole = P.work_begin == 0 && P.work_end == P.n_ents;
+    if(!whole) {
+        coh_regroup(P, C, *parity, true, s);
+        hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
+                           (const int32_t*)C.perm[*parity], (const int32_t*)nullptr, d_coh);
+        *parity ^= 1;
+        return false;
     }
+    const int prev = *parity ^ 1;
+    hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)nullptr, P.flock_offsets,
+                       (const int32_t*)C.saved[prev], P.n_flocks, C.wave_off, C.valid);
+    hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
+                       (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh);
+    return true;                                  // caller: record the event, then ..._regroup
+}
+
+void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *parity, hipStream_t s)
+{
+    const coh_scratch C = coh_layout(scratch, P.n_flocks, P.n_members);
+    coh_regroup(P, C, *parity, false, s);
+    *parity ^= 1;
 }
 
 size_t nh_pre_rec_bytes() { return sizeof(nh_pre_rec); }

@@ -96,6 +96,8 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(&ctx->coh_plan, 0, sizeof(ctx->coh_plan));
     memset(&ctx->gen_list, 0, sizeof(ctx->gen_list));
     ctx->gen_launches = 0;
+    ctx->coh_flocks = ctx->coh_members = -1;
+    ctx->coh_parity = 0;
     memset(&ctx->prerec, 0, sizeof(ctx->prerec));
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
@@ -588,6 +590,24 @@ static int ensure_buf(navhip_ctx *ctx, navhip_ctx::buf &b, size_t need)
     return ensure_cap(ctx, &b.p, &b.cap, need ? need : 16);
 }
 
+// cohesion scratch: grow on demand; a new buffer or another flock count has no lane grouping yet
+static int coh_scratch_ensure(navhip_ctx *ctx, int n_flocks, int n_members, hipStream_t s)
+{
+    const void *old = ctx->coh_plan.p;
+    int rc = ensure_buf(ctx, ctx->coh_plan, nh_cohesion_scratch_bytes(n_flocks, n_members));
+    if(rc) return rc;
+    if(ctx->coh_plan.p != old || ctx->coh_flocks != n_flocks || ctx->coh_members != n_members) {
+        // (scratch may still be in use by a regrouping on a side stream: order behind it)
+        if(ctx->aux[1] && s != ctx->aux[1]) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
+        }
+        nh_cohesion_scratch_reset((int32_t*)ctx->coh_plan.p, n_flocks, n_members, s);
+        ctx->coh_flocks = n_flocks; ctx->coh_members = n_members; ctx->coh_parity = 0;
+    }
+    return NAVHIP_OK;
+}
+
 // bg_<name>_init geometry, bitmap_grid.h:959-990
 static bool grid_geometry(const navhip_world *w, nh_grid *g)
 {
@@ -703,7 +723,7 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     rc = step_fill_params(ctx, w, &P);
     if(rc) return rc;
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
-    if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, nh_cohesion_scratch_bytes(w->n_flocks, P.n_members));
+    if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
     if(rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
@@ -711,8 +731,11 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     rc = spatial_build(ctx, w, &P.grid, ctx->aux[0], P.work_begin, P.work_end);
     if(rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
-    nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, ctx->aux[1]);
+    const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
+                                            ctx->aux[1]);
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+    // (behind the join event: the agent step does not wait for next tick's lane grouping)
+    if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, ctx->aux[1]);
     HIPCHK(ctx, hipGetLastError());
     ctx->pre.valid = true;
     ctx->pre.pos_xz = w->pos_xz; ctx->pre.flock_members = w->flock_members;
@@ -770,12 +793,13 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(rc) return rc;
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
-    if(!rc) rc = ensure_buf(ctx, ctx->coh_plan, nh_cohesion_scratch_bytes(w->n_flocks, P.n_members));
+    if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
     if(rc) return rc;
     if(!rc) rc = ensure_buf(ctx, ctx->prerec, (size_t)w->n_ents * nh_pre_rec_bytes());
     if(rc) return rc;
-    nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, s);
+    const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+    if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
     nh_launch_agent_pre(P, ctx->prerec.p, O, s);
     nh_launch_agent_step(P, (float*)ctx->coh.p, ctx->prerec.p, O, s);
     if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], s)); ctx->ev_valid = true; }

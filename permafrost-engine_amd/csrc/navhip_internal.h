@@ -49,6 +49,7 @@ struct navhip_ctx {
     buf          prerec;       // per-entity record of the scalar pre-pass (k_agent_pre)
     buf          gen_list;     // [2 + n] requests the BFS kernel left to k_field_generic: 2 counters, ids
     unsigned     gen_launches; // parity selects the counter of a launch
+    int          coh_flocks, coh_members, coh_parity;   // layout of coh_plan + which perm buffer is next
     buf          stage[36];    // device copies of host buffers for the host-pointer entry points
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];

@@ -182,3 +182,32 @@ def test_prefetch_overlap_gives_identical_results(navlib):
     assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
     assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
     assert np.abs(res[0][1]).max() > 0
+
+
+def test_lane_grouping_carried_between_ticks_is_only_a_hint(navlib):
+    """The cohesion launch reuses the lane grouping the previous step left behind (whole-range
+    steps).  It must be ignored when the flock layout changed in between, and using it must never
+    change a result: step worlds A, A', B (other flock sizes), A on ONE context and compare each
+    with a fresh context."""
+    grid = cases.synth.cost_grid(4, 4, seed=21)
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    n = 1600
+    worlds = []
+    for seed, k in ((5, 4), (6, 4), (7, 4), (5, 4)):
+        w = cases.make_agents(grid, n, k, seed=seed, clustered=False)
+        worlds.append(w)
+    # B: same number of flocks and members, different flock sizes
+    rng = np.random.RandomState(3)
+    worlds[2]["flock"] = np.sort(rng.randint(0, 4, n)).astype(np.int32)[rng.permutation(n)]
+    shared = _upload(navlib, nav)
+    for w in worlds:
+        vdes = np.zeros((n, 2), np.float32)
+        vdes[:, 0] = 1.0
+        a = cases.step_arrays(w, vdes)
+        got = shared.agent_step(a)
+        fresh = _upload(navlib, nav)
+        exp = fresh.agent_step(a)
+        fresh.close()
+        assert np.array_equal(got["vel_xz"].view(np.uint32), exp["vel_xz"].view(np.uint32))
+        assert np.abs(exp["vel_xz"]).max() > 0
+    shared.close()
