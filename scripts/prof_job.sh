@@ -9,5 +9,5 @@ rocprofv3 --pmc FETCH_SIZE -d gpurun_out/r01i/pmc_fetch -o f --output-format csv
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/r01i/pmc_write -o w --output-format csv -- python bench.py --steps 12 --warmup 3 > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d gpurun_out/r01i/pmc_sq -o q --output-format csv -- python bench.py --steps 12 --warmup 3 > /dev/null 2>&1
 find gpurun_out/r01i -name "*.csv" | head -20
-python scripts/fuzz_gpu.py > gpurun_out/r01i/fuzz.log 2>&1; tail -1 gpurun_out/r01i/fuzz.log
+python tests/tools/fuzz_gpu.py > gpurun_out/r01i/fuzz.log 2>&1; tail -1 gpurun_out/r01i/fuzz.log
 python -m pytest tests -m gpu -q > gpurun_out/r01i/pytest_gpu.log 2>&1; tail -2 gpurun_out/r01i/pytest_gpu.log

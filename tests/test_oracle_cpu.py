@@ -2,7 +2,7 @@
 the C restatement (oracle/navoracle.c) is pinned against OUTPUTS OF THE REFERENCE ITSELF:
   * live, against oracle/_ref/libpfref.so (the reference's own nav/field/clearpath/movement
     translation units compiled in place) -- these tests need /root/reference or a prebuilt _ref;
-  * against the committed fixtures tests/golden/*.npz that scripts/make_golden.py produced from
+  * against the committed fixtures tests/golden/*.npz that tests/tools/make_golden.py produced from
     _ref -- these run anywhere.
 Integer work is compared bit for bit; float velocities are compared bit for bit too (same
 compiler, same expression order), far inside BASELINE.json's 1e-4 relative bound."""
@@ -144,11 +144,11 @@ def test_flow_sampling_restatement_matches_reference():
 
 
 # ---------------------------------------------------------------------------------------------
-# against the committed fixtures (generated from the reference by scripts/make_golden.py)
+# against the committed fixtures (generated from the reference by tests/tools/make_golden.py)
 # ---------------------------------------------------------------------------------------------
 def _gold(name):
     path = os.path.join(GOLD, name)
-    assert os.path.exists(path), "missing fixture %s (run scripts/make_golden.py)" % name
+    assert os.path.exists(path), "missing fixture %s (run tests/tools/make_golden.py)" % name
     return np.load(path)
 
 

@@ -2,7 +2,7 @@
 """How many host cores does this box really give us?  (cpu_count vs affinity vs cgroup quota vs
 measured scaling of the reference's N_FlowFieldUpdate over pthreads.)"""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import pfref

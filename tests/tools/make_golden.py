@@ -3,7 +3,7 @@
 reference's own nav/field/clearpath/movement sources compiled in place from /root/reference).
 
 Run in the build container (needs /root/reference or a prebuilt oracle/_ref):
-    python scripts/make_golden.py
+    python tests/tools/make_golden.py
 The fixtures pin the oracle restatement (tests/test_oracle_cpu.py) and the HIP path
 (tests/test_golden_gpu.py) where the reference cannot travel.
 """
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle import navoracle, pfref          # noqa: E402
