@@ -220,14 +220,15 @@ class NavTick:
             with torch.cuda.stream(self.comm):
                 self.ctx.agent_prefetch_dev(self.world_s, stream=self.comm.cuda_stream)
         with torch.cuda.stream(s):
+            # snapshot-only parts of the agent step (spatial hash, cohesion: they read no nav plane)
+            # start now on the library's side streams and overlap with the blocker updates and the
+            # field builds below
+            if self.overlap and not self.pipelined:
+                self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream)
             if self.n_obstacles:
                 marks.append(self._mark("blockers"))
                 t = self.tick_no % self.d_moves.shape[0]
                 self.ctx.blockers_circles_dev(self.d_moves[t], self.n_moves, stream=s.cuda_stream)
-            # snapshot-only parts of the agent step (spatial hash, cohesion) start now on the
-            # library's side streams and overlap with the field builds below
-            if self.overlap and not self.pipelined:
-                self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream)
             marks.append(self._mark("fields"))
             if self.n_req_local:
                 self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
