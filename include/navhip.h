@@ -120,6 +120,7 @@ const char *navhip_last_error(const navhip_ctx *ctx);
 int  navhip_device(const navhip_ctx *ctx);
 /* the context's HIP stream, as void* (hipStream_t) */
 void *navhip_stream(const navhip_ctx *ctx);
+/* waits for the context's own stream and for the side streams of navhip_agent_prefetch_dev */
 int  navhip_sync(navhip_ctx *ctx);
 
 /* Upload one whole plane of one layer (all chunks).  Replaces N_CopyCostBasePacked /
@@ -339,7 +340,10 @@ int  navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *dev_world,
  * and the O(N*F) cohesion term) on the context's own side streams, forked from `stream`, and return
  * at once.  Work enqueued on `stream` afterwards (e.g. the tick's field builds) then runs
  * concurrently with them; the next navhip_agent_step_dev on the same snapshot arrays joins the side
- * streams instead of recomputing.  Purely a scheduling hint: results are identical. */
+ * streams instead of recomputing.  Purely a scheduling hint: results are identical.
+ * The side streams read the snapshot arrays until that step has completed on ITS stream (work the
+ * caller enqueues there afterwards is ordered behind the last read); a prefetch that is never
+ * followed by a step is drained by navhip_sync. */
 int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, void *stream);
 
 /* Per-kernel-group timing of the agent step with HIP events on the launch stream (bench.py's

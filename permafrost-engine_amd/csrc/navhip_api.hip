@@ -98,6 +98,8 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->gen_launches = 0;
     ctx->coh_flocks = ctx->coh_members = -1;
     ctx->coh_parity = 0;
+    ctx->ev_regroup = nullptr;
+    ctx->regroup_pending = false;
     memset(&ctx->prerec, 0, sizeof(ctx->prerec));
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
@@ -134,6 +136,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(auto &a : ctx->aux) if(a) hipStreamDestroy(a);
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
+    if(ctx->ev_regroup) hipEventDestroy(ctx->ev_regroup);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -146,6 +149,7 @@ int navhip_sync(navhip_ctx *ctx)
 {
     if(!ctx) return NAVHIP_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for(auto a : ctx->aux) if(a) HIPCHK(ctx, hipStreamSynchronize(a));       // prefetch side streams
     return NAVHIP_OK;
 }
 
@@ -734,8 +738,16 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
                                             ctx->aux[1]);
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
-    // (behind the join event: the agent step does not wait for next tick's lane grouping)
-    if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, ctx->aux[1]);
+    // (behind the join event: the agent step does not wait for next tick's lane grouping; but the
+    // caller's stream does, at the end of navhip_agent_step_dev, so that whatever the caller does
+    // to the snapshot arrays afterwards is ordered behind the last read of them)
+    ctx->regroup_pending = false;
+    if(regroup) {
+        nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, ctx->aux[1]);
+        if(!ctx->ev_regroup) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_regroup, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_regroup, ctx->aux[1]));
+        ctx->regroup_pending = true;
+    }
     HIPCHK(ctx, hipGetLastError());
     ctx->pre.valid = true;
     ctx->pre.pos_xz = w->pos_xz; ctx->pre.flock_members = w->flock_members;
@@ -767,6 +779,8 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         // its scratch buffers are reused
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
+        if(ctx->regroup_pending) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));
+        ctx->regroup_pending = false;
     }
     ctx->pre.valid = false;
     nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
@@ -782,6 +796,10 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         nh_launch_agent_step(P, (float*)ctx->coh.p, ctx->prerec.p, O, s);
+        if(ctx->regroup_pending) {
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));     // long finished by now
+            ctx->regroup_pending = false;
+        }
         HIPCHK(ctx, hipGetLastError());
         return NAVHIP_OK;
     }

@@ -53,7 +53,8 @@ struct navhip_ctx {
     buf          stage[36];    // device copies of host buffers for the host-pointer entry points
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];
-    hipEvent_t   ev_fork, ev_join[2];
+    hipEvent_t   ev_fork, ev_join[2], ev_regroup;
+    bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
     struct { bool valid; const float *pos_xz; const int32_t *flock_members; int n_ents, work_begin, work_end;
              struct nh_grid_store { int32_t origin_x, origin_y; int grid_w, grid_h; } g; } pre;
     // optional per-kernel-group timing of the agent step (navhip_set_profiling)
