@@ -276,6 +276,7 @@ __device__ __forceinline__ int sp_cell_of(const nh_grid &G, int32_t ix, int32_t 
     return cy * G.grid_w + cx;
 }
 
+#define SP_MAX_QUERY_R 30   /* largest query radius of the movement tick (separation, movement.c:1695) */
 // Optional slab filter: when a rank steps only the entities [work_begin, work_end), nothing farther
 // than the largest query radius of the tick (r = 30) from the bounding box of THOSE entities can be
 // returned by any of its queries, and leaving such entities out changes neither the order nor the
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void k_sp_bbox(const float *pos_xz, int begin,
 __device__ __forceinline__ bool sp_in_box(const int32_t *box, int32_t ix, int32_t iy)
 {
     if(!box) return true;
-    const int32_t m = 30 * 256 + 256;                 // BG_SCALE_F(30) + one world unit of slack
+    const int32_t m = SP_MAX_QUERY_R * 256 + 256;     // BG_SCALE_F(largest radius) + 1 wu of slack
     // (int64: the INT_MIN box of an empty slab must reject everything without overflowing)
     return (int64_t)ix >= -(int64_t)box[0] - m && (int64_t)ix <= (int64_t)box[1] + m
         && (int64_t)iy >= -(int64_t)box[2] - m && (int64_t)iy <= (int64_t)box[3] + m;
