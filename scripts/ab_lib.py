@@ -50,4 +50,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "--build":
         build(sys.argv[2], sys.argv[3:])
     elif sys.argv[1] == "--run":
-        run(sys.argv[2:])
+        names = [a for a in sys.argv[2:] if not a.startswith("--rounds=")]
+        rounds = [int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("--rounds=")]
+        run(names, rounds=rounds[0] if rounds else 3)
