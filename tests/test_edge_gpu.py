@@ -132,3 +132,35 @@ def test_largest_map_and_corner_chunks(navlib):
     with pytest.raises(navlib.NavHipError):
         navlib.NavContext(65, 1)
     ctx.close()
+
+
+def test_flock_sizes_around_the_cohesion_batch_and_tile_boundaries(navlib):
+    """k_cohesion queues a flock's members 256 at a time, evaluates them in batches of 16 split over
+    four lanes and carries the tail into the next tile: flocks of 1, 2, 15..17, 31..33, 63..65,
+    255..257, 300 and 513 members (some with idle members in between) hit every boundary.  Several
+    steps on one context, so that the lane grouping carried between steps is used as well."""
+    grid = cases.synth.cost_grid(4, 4, seed=21)
+    chunks = cases.synth.to_chunks(grid)
+    sizes = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 256, 257, 300, 513]
+    n, k = sum(sizes), len(sizes)
+    world = cases.make_agents(grid, n, k, seed=11, clustered=False)
+    rng = np.random.RandomState(17)
+    world["flock"] = np.repeat(np.arange(k), sizes).astype(np.int32)[rng.permutation(n)]
+    world["state"][:] = 0                               # all point seeking ...
+    world["state"][rng.rand(n) < 0.15] = 2              # ... except some arrived (idle) members
+    onav = navoracle.OracleNav(chunks)
+    ctx = navlib.NavContext(4, 4)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, chunks)
+    vdes = rng.normal(0, 1, (n, 2)).astype(np.float32)
+    vdes /= np.linalg.norm(vdes, axis=1, keepdims=True)
+    lists = [rng.permutation(np.flatnonzero(world["flock"] == f)) for f in range(k)]
+    for step in range(3):
+        a = cases.step_arrays(world, vdes, lists)
+        exp = onav.agent_step(a)
+        out = ctx.agent_step(a)
+        assert np.array_equal(out["vpref_xz"].view(np.uint32), exp["vpref_xz"].view(np.uint32)), step
+        assert np.array_equal(out["vel_xz"].view(np.uint32), exp["vel_xz"].view(np.uint32)), step
+        world["pos_xz"] = exp["new_pos_xz"].copy()
+        world["vel_xz"] = exp["vel_xz"].copy()
+    assert np.abs(exp["vel_xz"]).max() > 0
+    ctx.close()
