@@ -211,3 +211,29 @@ def test_lane_grouping_carried_between_ticks_is_only_a_hint(navlib):
         assert np.array_equal(got["vel_xz"].view(np.uint32), exp["vel_xz"].view(np.uint32))
         assert np.abs(exp["vel_xz"]).max() > 0
     shared.close()
+
+
+@pytest.mark.parametrize("w,h", [(5, 2), (2, 5)])
+def test_non_square_map_velocity_step_matches_reference(navlib, w, h):
+    """The whole agent step on a non-square map, sampling the reference's own cached fields on the
+    device: tile lookups, (dest, chunk) slot table, spatial grid and cohesion binning must all take
+    the map's width and height the right way round."""
+    grid, nav = cases.ref_nav_for(w, h, seed=300 + w)
+    world = cases.make_agents(grid, 1200, 3, seed=5 + h, clustered=False)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    mv.velocity(None)                    # first pass populates / merges the reference's field cache
+    exp_vel = mv.velocity(None)
+    vdes = mv.vdes()
+    slots, pool_arr = cases.cached_field_table(nav, dest_ids, w, h)
+    a = _step_arrays(world, mv, None)
+    a["flock_field_slot"] = slots
+    a["field_pool"] = pool_arr
+    ctx = _upload(navlib, nav)
+    out = ctx.agent_step(a)
+    ctx.close()
+    ps = np.isin(world["state"], (0, 5, 6))
+    clean = ps & ((out["status"] & 0x06) == 0)
+    assert clean.sum() > 400
+    assert (_vel_err(out["vdes_xz"][clean], vdes[clean]) <= REL_TOL).all()
+    assert np.array_equal(out["vel_xz"][clean].view(np.uint32), exp_vel[clean].view(np.uint32))
+    pfref.RefMove.unload()

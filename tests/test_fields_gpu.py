@@ -160,3 +160,16 @@ def test_region_field_with_enemy_mask(navlib):
         assert np.array_equal(got[k, :dim * dim // 2], exp[k]), k
     assert not np.array_equal(exp[0], nav.cell_arrival_field(dim, seeds[0], cells[0], enemies=0)) or True
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(5, 2), (2, 5)])
+def test_non_square_map_fields_match_reference(navlib, w, h):
+    """Maps need not be square (the multi-GPU benchmark world is 16 rows x 16N columns of chunks):
+    tile fields and the planner's request stream on 5x2 / 2x5 chunks."""
+    grid, nav = cases.ref_nav_for(w, h, seed=300 + w)
+    reqs_t = cases.tile_requests(grid, 24, seed=6)
+    reqs_p, before, _ = cases.planner_requests(nav, grid, pairs=20, seed=10)
+    assert (reqs_p["type"] == 0).sum() > 10
+    reqs = np.concatenate([reqs_t, reqs_p])
+    before = np.concatenate([np.zeros((len(reqs_t), 64, 64), np.uint8), before])
+    _check(navlib, grid, nav, reqs, before, 0)

@@ -387,3 +387,27 @@ def test_attacking_path_fields_restatement_matches_reference(seed):
     o2["faction_id"], o2["enemies"] = 0xF, 0
     d2, _ = onav.build_fields(o2)
     assert not np.array_equal(d2, exp_dirs)
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h", [(5, 2), (2, 5)])
+def test_non_square_map_restatement_matches_reference(w, h):
+    """Width and height the right way round: fields and the velocity step on 5x2 / 2x5 chunks."""
+    grid, nav = cases.ref_nav_for(w, h, seed=300 + w)
+    reqs_t = cases.tile_requests(grid, 16, seed=6)
+    reqs_p, before, _after = cases.planner_requests(nav, grid, pairs=12, seed=10)
+    reqs = np.concatenate([reqs_t, reqs_p])
+    before = np.concatenate([np.zeros((len(reqs_t), 64, 64), np.uint8), before])
+    exp_dirs, exp_integ = cases.ref_fields(nav, reqs, before)
+    onav = cases.oracle_nav_from_ref(nav)
+    dirs, integ = onav.build_fields(_o_reqs(reqs), inout=before, want_integ=True)
+    assert np.array_equal(dirs, exp_dirs) and np.array_equal(integ, exp_integ)
+    world = cases.make_agents(grid, 700, 3, seed=5 + h, clustered=False)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    exp_vel = mv.velocity(None)
+    vdes = mv.vdes()
+    arrays = cases.step_arrays(world, vdes, [mv.flock_order(f) for f in range(3)])
+    out = onav.agent_step(arrays)
+    moving = ~np.isin(world["state"], (2, 4))
+    assert np.array_equal(out["vel_xz"][moving].view(np.uint32), exp_vel[moving].view(np.uint32))
+    pfref.RefMove.unload()
