@@ -130,3 +130,29 @@ def test_incremental_field_repair_equals_full_rebuild(navlib):
     assert np.array_equal(repaired[~need], pool[~need])           # untouched slots
     assert need.sum() < len(reqs)
     ctx.close()
+
+
+@pytest.mark.skipif(not pfref.available(), reason="needs the reference build (oracle/_ref)")
+@pytest.mark.parametrize("w,h", [(3, 2), (2, 3)])
+def test_blockers_on_non_square_maps_match_reference(navlib, w, h):
+    """N_BlockersIncref / Decref on 3x2 and 2x3 chunks: refcount planes of the ground and water
+    layers against the reference itself, local islands against the restatement."""
+    grid = cases.synth.cost_grid(w, h, seed=40 + w)
+    layers = list(range(8))
+    ctx, onav = _setup(navlib, grid, layers)
+    ref = pfref.RefNav(cases.synth.to_chunks(grid), layer_mask=0xff)
+    circles = _random_circles(grid, 150, seed=6, air_frac=0.0, max_radius=30.0)
+    undo = circles[::4].copy()
+    undo["delta"] = -1
+    for batch in (circles, undo):
+        onav.blockers_circles(batch)
+        ctx.N_BlockersUpdate(batch.view(navlib.CIRCLE_DTYPE))
+        for c in batch:
+            ref.blockers_circle(float(c["x"]), float(c["z"]), float(c["radius"]), int(c["faction_id"]),
+                                int(c["flags"]), incref=(c["delta"] > 0))
+        for l in layers:
+            got = ctx.download_plane(l, navlib.PLANE_BLOCKERS)
+            assert np.array_equal(got, ref.plane(pfref.PLANE_BLOCKERS, l)), l
+            assert np.array_equal(ctx.download_plane(l, navlib.PLANE_LOCAL_ISLANDS), onav.local_islands(l)), l
+    assert ctx.download_plane(0, navlib.PLANE_BLOCKERS).sum() > 0
+    ctx.close()
