@@ -173,3 +173,22 @@ def test_non_square_map_fields_match_reference(navlib, w, h):
     reqs = np.concatenate([reqs_t, reqs_p])
     before = np.concatenate([np.zeros((len(reqs_t), 64, 64), np.uint8), before])
     _check(navlib, grid, nav, reqs, before, 0)
+
+
+@pytest.mark.parametrize("w,h", [(4, 2), (2, 4)])
+def test_non_square_map_los_and_region_fields_match_reference(navlib, w, h):
+    """LOS chains and region fields cross chunk borders by absolute coordinates: 4x2 / 2x4 chunks."""
+    blockers = cases.random_blockers(cases.synth.cost_grid(w, h, seed=70 + w, frac_impassable=0.22), seed=4, frac=0.03)
+    grid, nav = cases.ref_nav_for(w, h, seed=70 + w, blockers=blockers, frac=0.22)
+    ctx = navlib.NavContext(w, h)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(0))
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(1))
+    reqs, prevs, exps = cases.los_chains(nav, grid, n_dests=6, seed=3)
+    got = ctx.N_LOSFieldCreate(cases.los_reqs_to(navlib.LOS_REQ_DTYPE, reqs), prevs)
+    bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exps[i])]
+    assert not bad, "LOS fields differ: %s" % bad[:8]
+    reqs, S, O, inout, exp = cases.region_cases(nav, grid, 5)
+    got = ctx.build_region_fields(cases.region_reqs_to(navlib.REGION_REQ_DTYPE, reqs), S, O, inout=inout)
+    bad = [i for i in range(len(reqs)) if not np.array_equal(got[i], exp[i])]
+    assert not bad, "region fields differ: %s" % [(i, reqs[i]["out_mode"]) for i in bad[:8]]
+    ctx.close()
