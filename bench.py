@@ -257,8 +257,8 @@ def main():
                                    "stepped every tick%s" % (args.map * 64, args.map * 64, args.map, args.map,
                                                              args.fields, T.n_req_local, args.agents,
                                                              "" if world == 1 else
-                                                             "; the %d regions lie side by side on one "
-                                                             "%dx%d-cell map" % (world, args.map * 64, args.map * 64 * world)),
+                                                             "; the %d regions tile one %dx%d-cell map"
+                                                             % (world, T.H * 64, T.Wt * 64)),
                        "map_chunks": args.map, "flow_fields_per_gpu": args.fields,
                        "agents_per_gpu": args.agents, "hz": 20, "dynamic_obstacles": args.obstacles,
                        "parallelism": "regions (requests + agent slabs) sharded x%d; all-gather of slab "

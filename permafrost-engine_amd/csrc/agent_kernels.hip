@@ -282,19 +282,26 @@ __device__ __forceinline__ int sp_cell_of(const nh_grid &G, int32_t ix, int32_t 
 // returned by any of its queries, and leaving such entities out changes neither the order nor the
 // caps of what is returned.  box = {max(-ix), max(ix), max(-iy), max(iy)} over the slab in the
 // x256 fixed point the queries compare in; INT_MIN-initialised.
-__global__ __launch_bounds__(256) void k_sp_bbox(const float *pos_xz, int begin, int end, int32_t *box)
+__global__ __launch_bounds__(1024) void k_sp_bbox(const float *pos_xz, int begin, int end, int32_t *box)
 {
-    const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    // few, large workgroups striding over the slab: four atomics per workgroup, not per wave
+    __shared__ int32_t part[16][4];
     int32_t v[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
-    if(i < end) {
+    for(int i = begin + blockIdx.x * 1024 + threadIdx.x; i < end; i += gridDim.x * 1024) {
         const int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
-        v[0] = -ix; v[1] = ix; v[2] = -iy; v[3] = iy;
+        v[0] = max(v[0], -ix); v[1] = max(v[1], ix); v[2] = max(v[2], -iy); v[3] = max(v[3], iy);
     }
 #pragma unroll
     for(int q = 0; q < 4; q++) {
 #pragma unroll
         for(int d = 32; d >= 1; d >>= 1) v[q] = max(v[q], __shfl_xor(v[q], d));
-        if((threadIdx.x & 63) == 0 && v[q] != INT32_MIN) atomicMax(&box[q], v[q]);
+        if((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+    if(threadIdx.x < 4) {
+        int32_t m = INT32_MIN;
+        for(int w = 0; w < 16; w++) m = max(m, part[w][threadIdx.x]);
+        if(m != INT32_MIN) atomicMax(&box[threadIdx.x], m);
     }
 }
 
@@ -1084,6 +1091,29 @@ __device__ __forceinline__ int coh_bin_of(const nh_step_params &P, int g, int *f
     return lo * COH_BINS + mo;
 }
 
+// (The idle members of a flock all share one bin: on a rank that steps one slab of a large job that
+// is most members, and one atomic per member on the same address serialises -- 110 us for 800 k
+// members.  Lanes of a wave that hit the same idle bin are counted by ONE atomic of the first of
+// them; active members are spread over 256 bins and use plain atomics.)
+__device__ __forceinline__ int coh_grouped_add(int32_t *counter, int bin, bool idle)
+{
+    const int lane = threadIdx.x & 63;
+    int slot = 0;
+    unsigned long long rem = __ballot(idle);
+    while(rem) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const int b0 = __shfl(bin, leader);
+        const unsigned long long m = __ballot(idle && bin == b0);
+        int base = 0;
+        if(lane == leader) base = atomicAdd(&counter[b0], __popcll(m));
+        base = __shfl(base, leader);
+        if(idle && bin == b0) slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        rem &= ~m;
+    }
+    if(!idle) slot = atomicAdd(&counter[bin], 1);
+    return slot;
+}
+
 __global__ __launch_bounds__(256) void k_coh_bin(nh_step_params P, int32_t *bin_of, int32_t *bin_count,
                                                  int32_t *saved_offs)
 {
@@ -1094,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_coh_bin(nh_step_params P, int32_t *bin_
     int f;
     const int bin = coh_bin_of(P, g, &f);
     bin_of[g] = bin;
-    atomicAdd(&bin_count[bin], 1);
+    coh_grouped_add(bin_count, bin, bin - f * COH_BINS == 256);
 }
 
 __global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int32_t *bin_of,
@@ -1104,7 +1134,7 @@ __global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int
     const int g = blockIdx.x * 256 + threadIdx.x;
     if(g >= P.flock_offsets[P.n_flocks]) return;
     const int bin = bin_of[g];
-    perm[bin_start[bin] + atomicAdd(&bin_fill[bin], 1)] = g;
+    perm[bin_start[bin] + coh_grouped_add(bin_fill, bin, bin % COH_BINS == 256)] = g;
 }
 
 // exp(-6 t) rounds to +0 in float once the distance exceeds 904 wu (t >= 17.33); COH_FAR leaves a
@@ -1884,7 +1914,7 @@ void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial
     if(S.box && (slab_begin > 0 || slab_end < n)) {
         hipMemsetD32Async((hipDeviceptr_t)S.box, (int)0x80000000, 4, s);
         if(slab_end > slab_begin)
-            hipLaunchKernelGGL(k_sp_bbox, dim3((slab_end - slab_begin + 255) / 256), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_sp_bbox, dim3(min(64, (slab_end - slab_begin + 1023) / 1024)), dim3(1024), 0, s,
                                d_pos_xz, slab_begin, slab_end, S.box);
         box = S.box;
     }

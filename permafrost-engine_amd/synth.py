@@ -77,14 +77,18 @@ def destinations(grid, k, seed=42):
     return cells[idx]
 
 
-def agents(grid, n, k_flocks, seed=7, radius=1.0, max_speed=20.0, hz=20, blockers=None, cols=None):
+def agents(grid, n, k_flocks, seed=7, radius=1.0, max_speed=20.0, hz=20, blockers=None, cols=None,
+           rows=None):
     """N agents at random passable (and unblocked) cell centres + U(-1.5,1.5) jitter, round-robin
-    flocks.  cols = (c0, c1): only cells of the global columns [c0, c1) (one region of the map)."""
+    flocks.  cols = (c0, c1) / rows = (r0, r1): only cells of the global columns [c0, c1) and rows
+    [r0, r1) (one region of the map)."""
     rng = np.random.RandomState(seed)
     h, w = grid.shape[0] // 64, grid.shape[1] // 64
     cells = passable_cells(grid, blockers)
     if cols is not None and (cols[0] > 0 or cols[1] < grid.shape[1]):
         cells = cells[(cells[:, 1] >= cols[0]) & (cells[:, 1] < cols[1])]
+    if rows is not None and (rows[0] > 0 or rows[1] < grid.shape[0]):
+        cells = cells[(cells[:, 0] >= rows[0]) & (cells[:, 0] < rows[1])]
     idx = rng.randint(0, len(cells), size=n)
     pos = cell_centre(w, h, cells[idx, 0], cells[idx, 1])
     pos += rng.uniform(-1.5, 1.5, size=pos.shape).astype(np.float32)

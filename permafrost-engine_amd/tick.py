@@ -19,9 +19,19 @@ from . import dist as pdist
 from . import navhip, synth
 
 
+def region_grid(world):
+    """(rows, cols) of the region tiling for `world` ranks: cols = the smallest power of two that is
+    >= sqrt(world), rows = ceil(world / cols): 1x1, 1x2, 2x2, 2x4, 4x4."""
+    cols = 1
+    while cols * cols < world:
+        cols *= 2
+    return -(-world // cols), cols
+
+
 class NavTick:
     """World layout (weak scaling): `world` REGIONS of chunk_w x chunk_w chunks
-    side by side on one map of chunk_w rows x (chunk_w * world) columns of chunks.  Region r -- its
+    tiling one map (region_grid(world): 1x2, 2x2, 2x4, 4x4 ... regions; a map side is at most 64
+    chunks, the reference's 6-bit chunk ids).  Region r -- its
     `fields_per_rank` destinations, the chunk-field requests of those destinations (every chunk of
     the region: the corridor the planner would emit for units and destination inside the region)
     and its `agents_per_rank` agents, flock = destination -- belongs to rank r: the agents a rank
@@ -36,14 +46,21 @@ class NavTick:
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.W = chunk_w                            # region side in chunks
-        self.Wt, self.H = chunk_w * world, chunk_w  # whole map, in chunks
+        self.reg_rows, self.reg_cols = region_grid(world)
+        self.Wt, self.H = chunk_w * self.reg_cols, chunk_w * self.reg_rows   # whole map, in chunks
+        if max(self.Wt, self.H) > 64:
+            raise ValueError("%d regions of %d chunks do not fit a 64x64-chunk map" % (world, chunk_w))
         self.nchunks = self.Wt * self.H
         self.K = fields_per_rank * world            # flow fields (destinations) in the whole job
         self.N = agents_per_rank * world            # agents in the whole job
         self.hz = hz
         t0 = time.time()
         Wt, H = self.Wt, self.H
-        rcols = chunk_w * 64                        # cell columns per region
+        rcols = chunk_w * 64                        # cell rows / columns per region
+
+        def region_cells(q):                        # (row0, row1, col0, col1) of region q, in cells
+            qr, qc = divmod(q, self.reg_cols)
+            return qr * rcols, (qr + 1) * rcols, qc * rcols, (qc + 1) * rcols
 
         # ---- synthetic map, identical on every rank --------------------
         grid = synth.cost_grid(Wt, H, seed=seed_map)
@@ -84,11 +101,12 @@ class NavTick:
         # ---- destinations (cheap, all regions) and agents (replicated snapshot) ----------------
         dests, ag_parts = [], []
         for q in range(world):
-            sub = grid[:, q * rcols:(q + 1) * rcols]
+            r0, r1, c0, c1 = region_cells(q)
+            sub = grid[r0:r1, c0:c1]
             d = synth.destinations(sub, fields_per_rank, seed=42 + q)
-            dests.append(d + np.array([0, q * rcols]))
+            dests.append(d + np.array([r0, c0]))
             a = synth.agents(grid, agents_per_rank, fields_per_rank, seed=7 + q, hz=hz, blockers=blockers,
-                             cols=(q * rcols, (q + 1) * rcols))
+                             cols=(c0, c1), rows=(r0, r1))
             a["flock"] = a["flock"] + q * fields_per_rank
             ag_parts.append(a)
         dests = np.concatenate(dests)
@@ -104,16 +122,19 @@ class NavTick:
         regions = range(world) if self.tile_exchange == "all" else [rank]
         req_parts, dest_of_req, self.req_bounds, nreq = [], [], [(0, 0)] * world, 0
         for q in regions:
-            sub = grid[:, q * rcols:(q + 1) * rcols]
-            cols = synth.whole_map_requests(sub, dests[q * fields_per_rank:(q + 1) * fields_per_rank]
-                                            - np.array([0, q * rcols]), liid[:, q * rcols:(q + 1) * rcols])
+            r0, r1, c0, c1 = region_cells(q)
+            cols = synth.whole_map_requests(grid[r0:r1, c0:c1],
+                                            dests[q * fields_per_rank:(q + 1) * fields_per_rank]
+                                            - np.array([r0, c0]), liid[r0:r1, c0:c1])
             n_q = len(cols["type"])
             reqs_q = navhip.make_reqs(n_q)
             for k in synth.REQ_FIELDS:
                 reqs_q[k] = cols[k]
-            reqs_q["chunk_c"] += q * chunk_w
+            reqs_q["chunk_r"] += r0 // 64
+            reqs_q["chunk_c"] += c0 // 64
             portal = reqs_q["type"] == navhip.TARGET_PORTAL
-            reqs_q["next_chunk_c"][portal] += q * chunk_w
+            reqs_q["next_chunk_r"][portal] += r0 // 64
+            reqs_q["next_chunk_c"][portal] += c0 // 64
             req_parts.append(reqs_q)
             dest_of_req.append(np.asarray(cols["dest"]) + q * fields_per_rank)
             self.req_bounds[q] = (nreq, nreq + n_q)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-rank compute cost of the weak-scaling world on ONE GPU: build rank r of a `world`-rank job
+and time its share of the tick (field builds + slab step, no exchange; the snapshot is not advanced,
+so every tick is the same work).  Shows what the parts replicated on every rank (map planes, entity
+snapshot, hash grid, flock tables) cost as the job grows.
+    python scripts/rank_cost_probe.py 1 8"""
+import sys
+import time
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from permafrost_engine_amd import tick    # noqa: E402
+
+
+def main():
+    for world in [int(a) for a in sys.argv[1:]] or [1, 8]:
+        t0 = time.time()
+        T = tick.NavTick(rank=world // 2, world=world)
+        setup = time.time() - t0
+        for _ in range(4):
+            T.compute()
+        T.sync()
+        t0 = time.perf_counter()
+        n = 30
+        for _ in range(n):
+            T.compute()
+        T.sync()
+        dt = (time.perf_counter() - t0) / n
+        print("world %d rank %d: setup %.1f s, %d local requests, slab %d agents of %d: %.4f ms per tick "
+              "(compute only)" % (world, T.rank, setup, T.n_req_local, T.a1 - T.a0, T.N, dt * 1e3), flush=True)
+        T.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,5 +122,18 @@ def test_region_agents_stay_in_their_columns():
         col = (mp[0] - a["pos"][:, 0]) / 4.0
         assert col.min() > q * 128 - 0.5 and col.max() < (q + 1) * 128 + 0.5
     a0 = synth.agents(g, 400, 3, seed=7)
-    a1 = synth.agents(g, 400, 3, seed=7, cols=(0, 256))
+    a1 = synth.agents(g, 400, 3, seed=7, cols=(0, 256), rows=(0, 128))
     assert np.array_equal(a0["pos"], a1["pos"]) and np.array_equal(a0["vel"], a1["vel"])
+    # a region of a 2-D tiling: rows and columns restricted
+    a2 = synth.agents(g, 300, 3, seed=9, cols=(128, 256), rows=(64, 128))
+    col = (mp[0] - a2["pos"][:, 0]) / 4.0
+    row = (a2["pos"][:, 1] - mp[2]) / 4.0
+    assert col.min() > 127.5 and col.max() < 256.5 and row.min() > 63.5 and row.max() < 128.5
+
+
+def test_region_grid_fits_the_map_limit():
+    from permafrost_engine_amd.tick import region_grid
+    assert [region_grid(w) for w in (1, 2, 4, 8, 16)] == [(1, 1), (1, 2), (2, 2), (2, 4), (4, 4)]
+    for w in range(1, 17):
+        r, c = region_grid(w)
+        assert r * c >= w and max(r, c) * 16 <= 64
