@@ -10,6 +10,15 @@ struct nh_grid {
     const int32_t *cell_start;       // [ncells+1]
     const int32_t *sorted_id;        // [n] records[] of the packed pool
     const int32_t *sx, *sy;          // [n] xs[] / ys[] of the packed pool (fixed point x256)
+    const float4  *rec;              // [n][2] packed entity records of the inserted entities (agent
+                                     // step only): {pos.x, pos.z, radius, flags} | {vel.x, vel.z, state, -}
+};
+
+// structure-of-arrays sources of the entity records (all null: no records)
+struct nh_pack_src {
+    const float    *vel_xz, *radius;
+    const uint32_t *flags;
+    const uint8_t  *state;
 };
 
 struct nh_spatial_scratch {
@@ -19,6 +28,8 @@ struct nh_spatial_scratch {
     int32_t *sorted_id, *sx, *sy;            // [n]
     int32_t *block_sum;                      // [ceil(ncells/1024)] scan scratch
     int32_t *box;                            // [4] bounding box of the stepped slab (optional filter)
+    float4  *rec;                            // [n][2] entity records
+    nh_pack_src src;
 };
 
 struct nh_step_params {

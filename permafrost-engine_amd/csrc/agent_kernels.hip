@@ -314,19 +314,29 @@ __device__ __forceinline__ bool sp_in_box(const int32_t *box, int32_t ix, int32_
         && (int64_t)iy >= -(int64_t)box[2] - m && (int64_t)iy <= (int64_t)box[3] + m;
 }
 
+// Every inserted entity also gets a packed 32-byte RECORD -- {pos.x, pos.z, radius, flags} |
+// {vel.x, vel.z, state, -} -- so that the neighbour gathers of the agent step (separation, neighbour
+// classification, garrison filter) fetch one or two 16-byte halves of one line per neighbour instead
+// of 4-8 bytes from each of three to five structure-of-arrays lines.
 __global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz, int n,
                                                   int32_t *ent_ix, int32_t *ent_iy,
                                                   int32_t *ent_cell, int32_t *cell_count,
-                                                  const int32_t *box)
+                                                  const int32_t *box, nh_pack_src src, float4 *rec)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if(i >= n) return;
-    int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
+    const float px = pos_xz[2 * i], pz = pos_xz[2 * i + 1];
+    int32_t ix = bg_scale(px), iy = bg_scale(pz);
     ent_ix[i] = ix; ent_iy[i] = iy;
     if(!sp_in_box(box, ix, iy)) { ent_cell[i] = -1; return; }
     int c = sp_cell_of(G, ix, iy);
     ent_cell[i] = c;
     atomicAdd(&cell_count[c], 1);
+    if(rec) {
+        rec[2 * i]     = make_float4(px, pz, src.radius[i], __uint_as_float(src.flags[i]));
+        rec[2 * i + 1] = make_float4(src.vel_xz[2 * i], src.vel_xz[2 * i + 1],
+                                     __uint_as_float((uint32_t)src.state[i]), 0.0f);
+    }
 }
 
 // exclusive scan of cell_count[0..ncells) -> cell_start[0..ncells], two passes over 1024-cell
@@ -579,18 +589,23 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
 }
 
 // filter_garrisoned, position.c:100-119: walk backwards, overwrite with the current last
-__device__ int filter_garrisoned_wave(const uint32_t *flags, uint32_t *ids, int count, int lane)
+__device__ __forceinline__ uint32_t rec_flags(const float4 *rec, uint32_t id)
+{
+    return __float_as_uint(rec[2 * id].w);
+}
+
+__device__ int filter_garrisoned_wave(const float4 *rec, uint32_t *ids, int count, int lane)
 {
     bool any = false;
     for(int base = 0; base < count; base += 64) {
         int k = base + lane;
-        any |= (k < count) && (flags[ids[k]] & NAVHIP_ENTITY_FLAG_GARRISONED);
+        any |= (k < count) && (rec_flags(rec, ids[k]) & NAVHIP_ENTITY_FLAG_GARRISONED);
     }
     if(!__any(any)) return count;
     int ret = count;
     if(lane == 0) {
         for(int i = count - 1; i >= 0; i--) {
-            if(flags[ids[i]] & NAVHIP_ENTITY_FLAG_GARRISONED) {
+            if(rec_flags(rec, ids[i]) & NAVHIP_ENTITY_FLAG_GARRISONED) {
                 ids[i] = ids[ret - 1];
                 ret--;
             }
@@ -1402,13 +1417,14 @@ __device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_
         int k = base + lane;
         if(k < n30) {
             uint32_t curr = ids30[k];
-            uint32_t fl = P.flags[curr];
+            const float4 ra = P.grid.rec[2 * curr];                         // {pos, radius, flags}
+            uint32_t fl = __float_as_uint(ra.w);
             v2 term = mkv(0.0f, 0.0f);
             bool skip = (curr == (uint32_t)uid) || !(fl & NAVHIP_ENTITY_FLAG_MOVABLE)
                      || ((my_flags & NAVHIP_ENTITY_FLAG_AIR) != (fl & NAVHIP_ENTITY_FLAG_AIR));
             if(!skip) {
-                v2 cp = mkv(P.pos_xz[2 * curr], P.pos_xz[2 * curr + 1]);
-                float radius = my_radius + P.radius[curr] + 0.0f;          // SEPARATION_BUFFER_DIST
+                v2 cp = mkv(ra.x, ra.y);
+                float radius = my_radius + ra.z + 0.0f;                     // SEPARATION_BUFFER_DIST
                 v2 diff = vsub(cp, me);
                 float len = vlen(diff);
                 if(!(len < CP_EPS)) {
@@ -1517,15 +1533,17 @@ __device__ void classify_neighbours(const nh_step_params &P, int uid, uint32_t m
         float rec[5] = {0, 0, 0, 0, 0};
         if(k < n10) {
             uint32_t curr = ids10[k];
-            uint32_t fl = P.flags[curr];
-            float rad = P.radius[curr];
+            const float4 ra = P.grid.rec[2 * curr];                         // {pos, radius, flags}
+            uint32_t fl = __float_as_uint(ra.w);
+            float rad = ra.z;
             bool skip = (curr == (uint32_t)uid) || !(fl & NAVHIP_ENTITY_FLAG_MOVABLE) || (rad == 0.0f)
                      || ((my_flags & NAVHIP_ENTITY_FLAG_AIR) != (fl & NAVHIP_ENTITY_FLAG_AIR));
             if(!skip) {
-                v2 vel = mkv(P.vel_xz[2 * curr], P.vel_xz[2 * curr + 1]);
-                rec[0] = P.pos_xz[2 * curr]; rec[1] = P.pos_xz[2 * curr + 1];
+                const float4 rb = P.grid.rec[2 * curr + 1];                 // {vel, state, -}
+                v2 vel = mkv(rb.x, rb.y);
+                rec[0] = ra.x; rec[1] = ra.y;
                 rec[4] = rad;
-                if(state_is_still(P.state[curr]) || vlen(vel) < 0.3f) {   // CLEARPATH_STILL_SPEED
+                if(state_is_still((int)__float_as_uint(rb.z)) || vlen(vel) < 0.3f) {   // CLEARPATH_STILL_SPEED
                     cls = 2;                       // static: velocity forced to zero (:2817)
                 }else{
                     cls = 1;
@@ -1716,11 +1734,11 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_step(nh_step_params P, 
             n30raw = n30;
 #if NH_DUP == 2
             derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
-            filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
+            filter_garrisoned_wave(P.grid.rec, W.ids30, n30, lane);
             wave_sync(); DUP_BARRIER();
 #endif
             const int n10d = derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
-            n30 = filter_garrisoned_wave(P.flags, W.ids30, n30, lane);
+            n30 = filter_garrisoned_wave(P.grid.rec, W.ids30, n30, lane);
             if(n10d < 0) n30raw = -1; else n30raw = n10d;
             SEC_MARK(2);
 #if NH_DUP == 3
@@ -1796,10 +1814,10 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_step(nh_step_params P, 
             n10 = sp_query_wave(P.grid, me.x, me.z, 10.0f, 512, W.u.ids10, lane);
             wave_sync();
         }
-        n10 = filter_garrisoned_wave(P.flags, ids10, n10, lane);
+        n10 = filter_garrisoned_wave(P.grid.rec, ids10, n10, lane);
         int n_dyn, n_stat;
 #if NH_DUP == 4
-        filter_garrisoned_wave(P.flags, ids10, n10, lane);
+        filter_garrisoned_wave(P.grid.rec, ids10, n10, lane);
         classify_neighbours(P, uid, my_flags, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
         wave_sync(); DUP_BARRIER();
 #endif
@@ -1920,7 +1938,7 @@ void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial
     }
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
-                           S.ent_ix, S.ent_iy, S.ent_cell, S.cell_count, box);
+                           S.ent_ix, S.ent_iy, S.ent_cell, S.cell_count, box, S.src, S.src.flags ? S.rec : nullptr);
     const int nblocks = (ncells + 1023) / 1024;
     hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(1024), 0, s, S.cell_count, S.cell_start,
                        S.block_sum, ncells);

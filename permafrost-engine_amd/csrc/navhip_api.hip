@@ -638,22 +638,25 @@ static void fill_map_view(const navhip_ctx *ctx, nh_map_view *mv)
 }
 
 static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hipStream_t s,
-                         int slab_begin = 0, int slab_end = -1)
+                         int slab_begin = 0, int slab_end = -1, bool with_records = true)
 {
     if(!grid_geometry(w, g)) {
         ctx->last_error = "agent step: empty spatial-grid bounds";
         return NAVHIP_ERR_INVALID;
     }
     const size_t n = (size_t)w->n_ents, ncells = (size_t)g->grid_w * g->grid_h;
-    const size_t sizes[11] = {n, n, n, ncells, ncells, ncells + 1, n, n, n, (ncells + 1023) / 1024, 4};
-    for(int i = 0; i < 11; i++) {
+    const size_t sizes[12] = {n, n, n, ncells, ncells, ncells + 1, n, n, n, (ncells + 1023) / 1024, 4, 8 * n};
+    for(int i = 0; i < 12; i++) {
         int rc = ensure_buf(ctx, ctx->sp[i], sizes[i] * sizeof(int32_t));
         if(rc) return rc;
     }
     nh_spatial_scratch S = {(int32_t*)ctx->sp[0].p, (int32_t*)ctx->sp[1].p, (int32_t*)ctx->sp[2].p,
                             (int32_t*)ctx->sp[3].p, (int32_t*)ctx->sp[4].p, (int32_t*)ctx->sp[5].p,
                             (int32_t*)ctx->sp[6].p, (int32_t*)ctx->sp[7].p, (int32_t*)ctx->sp[8].p,
-                            (int32_t*)ctx->sp[9].p, (int32_t*)ctx->sp[10].p};
+                            (int32_t*)ctx->sp[9].p, (int32_t*)ctx->sp[10].p, (float4*)ctx->sp[11].p,
+                            {w->vel_xz, w->radius, w->flags, w->state}};
+    if(!with_records) S.src = nh_pack_src{nullptr, nullptr, nullptr, nullptr};   // (positions only)
+    g->rec = S.src.flags ? S.rec : nullptr;
     g->n = w->n_ents;
     if(slab_end < 0) slab_end = w->n_ents;
     g->cell_start = S.cell_start; g->sorted_id = S.sorted_id; g->sx = S.sx; g->sy = S.sy;
@@ -790,6 +793,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         P.grid.n = w->n_ents;
         P.grid.cell_start = (int32_t*)ctx->sp[5].p; P.grid.sorted_id = (int32_t*)ctx->sp[6].p;
         P.grid.sx = (int32_t*)ctx->sp[7].p; P.grid.sy = (int32_t*)ctx->sp[8].p;
+        P.grid.rec = (const float4*)ctx->sp[11].p;
         rc = ensure_buf(ctx, ctx->prerec, (size_t)w->n_ents * nh_pre_rec_bytes());
         if(rc) return rc;
         nh_launch_agent_pre(P, ctx->prerec.p, O, s);          // overlaps with the side streams
@@ -928,7 +932,7 @@ int navhip_spatial_query(navhip_ctx *ctx, const navhip_world *w, const float *qu
     rc = ensure_buf(ctx, ctx->stage[22], (size_t)nq * maxout * 4);
     if(rc) return rc;
     nh_grid g;
-    rc = spatial_build(ctx, &d, &g, s);
+    rc = spatial_build(ctx, &d, &g, s, 0, -1, false);
     if(rc) return rc;
     nh_launch_spatial_query(g, dq, nq, range, maxout, (int32_t*)ctx->stage[21].p,
                             (uint32_t*)ctx->stage[22].p, s);

@@ -42,8 +42,9 @@ struct navhip_ctx {
     uint32_t    *d_dirty_list; size_t d_dirty_cap;
     // agent-step scratch (grown on demand, reused every tick)
     struct buf { void *p; size_t cap; };
-    buf          sp[11];       // spatial hash: ent_ix, ent_iy, ent_cell, cell_count, cell_fill,
-                               //               cell_start, sorted_id, sx, sy, block_sum, slab box
+    buf          sp[12];       // spatial hash: ent_ix, ent_iy, ent_cell, cell_count, cell_fill,
+                               //               cell_start, sorted_id, sx, sy, block_sum, slab box,
+                               //               entity records
     buf          coh;          // cohesion force per entity
     buf          coh_plan;     // [n_flocks + 1] wave prefix of the cohesion launch
     buf          prerec;       // per-entity record of the scalar pre-pass (k_agent_pre)
