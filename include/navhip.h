@@ -308,7 +308,9 @@ typedef struct navhip_world {
     float    grid_xmin, grid_xmax, grid_zmin, grid_zmax;  /* bg_ent_init bounds, position.c:276-283 */
     int32_t  work_begin, work_end;   /* the slab [begin,end) of uids this call computes (the index
                                         slabs of move_submit_cpu_work, movement.c:3759-3762); every
-                                        entity still acts as a neighbour.  0,0 = all entities      */
+                                        entity still acts as a neighbour (internally only entities
+                                        within reach of the slab's queries are indexed, which does
+                                        not change any result).  0,0 = all entities               */
     /* Formation inputs, computed by the host's formation module (struct formation_state,
      * movement.c:215-225; move_work_in.cell_pos, :268).  form_ready == NULL: entities in
      * STATE_MOVING_IN_FORMATION / STATE_ARRIVING_TO_CELL are reported NAVHIP_ST_UNSUPPORTED. */
