@@ -152,8 +152,9 @@ def _gold(name):
     return np.load(path)
 
 
-def test_golden_fields():
-    g = _gold("fields_3x3.npz")
+@pytest.mark.parametrize("name", ["fields_3x3", "fields_5x2"])
+def test_golden_fields(name):
+    g = _gold(name + ".npz")
     onav = navoracle.OracleNav(g["cost"], g["blockers"], g["local_islands"])
     dirs, integ = onav.build_fields(g["reqs"].view(navoracle.FIELD_REQ_DTYPE).reshape(-1),
                                     inout=g["before"], want_integ=True)
@@ -161,10 +162,12 @@ def test_golden_fields():
     assert np.array_equal(integ, g["integ"])
 
 
-def test_golden_spatial_and_clearpath():
-    g = _gold("agents_4x4.npz")
+@pytest.mark.parametrize("name", ["agents_4x4", "agents_5x2"])
+def test_golden_spatial_and_clearpath(name):
+    g = _gold(name + ".npz")
+    h, w = g["cost"].shape[:2]
     for key in ("r30", "r10", "wide"):
-        c, ids = navoracle.spatial_query(4, 4, g["pos_xz"], g["sq_query"], float(g["sq_" + key + "_range"]),
+        c, ids = navoracle.spatial_query(w, h, g["pos_xz"], g["sq_query"], float(g["sq_" + key + "_range"]),
                                          int(g["sq_" + key + "_cap"]))
         ec, ei = g["sq_" + key + "_counts"], g["sq_" + key + "_ids"]
         assert np.array_equal(c, ec)
@@ -174,8 +177,9 @@ def test_golden_spatial_and_clearpath():
     assert np.array_equal(got.view(np.uint32), g["cp_out"].view(np.uint32))
 
 
-def test_golden_velocity_step():
-    g = _gold("agents_4x4.npz")
+@pytest.mark.parametrize("name", ["agents_4x4", "agents_5x2"])
+def test_golden_velocity_step(name):
+    g = _gold(name + ".npz")
     onav = navoracle.OracleNav(g["cost"], g["blockers"], g["local_islands"])
     arrays = {k: g[k] for k in ("pos_xz", "vel_xz", "radius", "max_speed", "speed", "flags", "state",
                                 "has_dest_los", "flock", "flock_target_xz", "flock_offsets",
@@ -189,7 +193,7 @@ def test_golden_velocity_step():
     arrays["flock_field_slot"], arrays["field_pool"] = g["flock_field_slot"], g["field_pool"]
     out2 = onav.agent_step(arrays)
     clean = np.isin(g["state"], (0, 5, 6)) & ((out2["status"] & 0x06) == 0)
-    assert clean.sum() > 200
+    assert clean.sum() > 150
     assert np.array_equal(out2["vdes_xz"][clean], g["ref_vdes_sampled"][clean])
 
 

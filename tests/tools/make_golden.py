@@ -31,45 +31,45 @@ def o_reqs(ref_reqs):
     return out
 
 
-def fields():
-    grid = cases.synth.cost_grid(3, 3, seed=77)
+def fields(w=3, h=3, seed=77, name="fields_3x3"):
+    grid = cases.synth.cost_grid(w, h, seed=seed)
     blk = cases.random_blockers(grid, seed=3)
-    grid, nav = cases.ref_nav_for(3, 3, seed=77, blockers=blk)
+    grid, nav = cases.ref_nav_for(w, h, seed=seed, blockers=blk)
     reqs_t = cases.tile_requests(grid, 16, seed=6)
     reqs_p, before, _ = cases.planner_requests(nav, grid, pairs=10, seed=10)
     reqs = np.concatenate([reqs_t, reqs_p])
     before = np.concatenate([np.zeros((len(reqs_t), 64, 64), np.uint8), before])
     reqs, before = cases.with_inplace(reqs, before, seed=4, count=8)
     dirs, integ = cases.ref_fields(nav, reqs, before)
-    np.savez_compressed(os.path.join(GOLD, "fields_3x3.npz"),
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"),
                         cost=nav.plane(pfref.PLANE_COST), blockers=nav.plane(pfref.PLANE_BLOCKERS),
                         local_islands=nav.plane(pfref.PLANE_LOCAL_ISLANDS),
                         reqs=o_reqs(reqs).view(np.uint8).reshape(len(reqs), 32), before=before,
                         dirs=dirs, integ=integ)
-    print("fields_3x3: %d requests (%d portal, %d in-place)" % (
-        len(reqs), int((reqs["type"] == 0).sum()), int((reqs["inout"] != 0).sum())))
+    print("%s: %d requests (%d portal, %d in-place)" % (
+        name, len(reqs), int((reqs["type"] == 0).sum()), int((reqs["inout"] != 0).sum())))
 
 
-def agents():
-    grid = cases.synth.cost_grid(4, 4, seed=21)
+def agents(w=4, h=4, seed=21, name="agents_4x4", n=700):
+    grid = cases.synth.cost_grid(w, h, seed=seed)
     blk = cases.random_blockers(grid, seed=8, frac=0.02)
-    grid, nav = cases.ref_nav_for(4, 4, seed=21, blockers=blk)
-    k, n = 3, 700
+    grid, nav = cases.ref_nav_for(w, h, seed=seed, blockers=blk)
+    k = 3
     world = cases.make_agents(grid, n, k, seed=99, clustered=True)
     mv, dest_ids = cases.ref_move_for(nav, world)
     mv.velocity(None)                        # first pass fills / merges the reference's field cache
     ref_vel = mv.velocity(None)
     vdes = mv.vdes()
-    slots, pool = cases.cached_field_table(nav, dest_ids, 4, 4)
+    slots, pool = cases.cached_field_table(nav, dest_ids, w, h)
     arrays = cases.step_arrays(world, vdes, [mv.flock_order(f) for f in range(k)])
     out = {k2: np.asarray(v) for k2, v in arrays.items()}
     out.update(ref_vel=ref_vel, ref_vdes_sampled=vdes, flock_field_slot=slots, field_pool=pool,
                cost=nav.plane(pfref.PLANE_COST), blockers=nav.plane(pfref.PLANE_BLOCKERS),
                local_islands=nav.plane(pfref.PLANE_LOCAL_ISLANDS))
     # spatial queries straight from bitmap_grid.h
-    q = np.concatenate([world["pos_xz"][::11], [[0, 0], [-512, 512]]]).astype(np.float32)
+    q = np.concatenate([world["pos_xz"][::11], [[0, 0], [-w * 128.0, h * 128.0]]]).astype(np.float32)
     out["sq_query"] = q
-    bounds = (-512.0, 512.0, -512.0, 512.0)
+    bounds = (-w * 128.0, w * 128.0, -h * 128.0, h * 128.0)
     for key, r, cap in (("r30", 30.0, 128), ("r10", 10.0, 512), ("wide", 1400.0, 200)):
         c, ids = pfref.spatial_query(bounds, world["pos_xz"], q, r, cap)
         out["sq_%s_range" % key], out["sq_%s_cap" % key] = np.float32(r), np.int32(cap)
@@ -80,12 +80,15 @@ def agents():
     for i in range(len(ent)):
         exp[i] = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
     out.update(cp_ent=ent, cp_des=des, cp_dyn=dyn, cp_nd=nd, cp_stat=stat, cp_ns=ns, cp_out=exp)
-    np.savez_compressed(os.path.join(GOLD, "agents_4x4.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     pfref.RefMove.unload()
-    print("agents_4x4: %d agents, %d flocks, %d cached fields" % (n, k, len(pool)))
+    print("%s: %d agents, %d flocks, %d cached fields" % (name, n, k, len(pool)))
 
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     fields()
     agents()
+    # non-square maps (the multi-GPU world is 32 x 64 chunks at 8 ranks)
+    fields(5, 2, seed=305, name="fields_5x2")
+    agents(5, 2, seed=305, name="agents_5x2", n=500)
