@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {0,1,2,3,4}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one navigation tick over one batch of synthetic input with everything resident in
-HBM: rebuild all chunk fields of the flow fields (64 whole-map flow fields = 16 384 chunk fields
-per GPU), then one velocity step (flow sampling -> steering forces -> neighbour gather ->
-ClearPath -> truncate -> position accept) for 100 000 agents per GPU, then advance the snapshot.
-At N=1 this is configs[2] of BASELINE.json ("1024x1024 map, 64 concurrent flow fields, 100 000
-agents, 1xMI355X"), the configuration the target (>=1e7 agent-steps/s) is quoted on.  At N>1 the
-job is weak-scaled: every GPU brings its own 64 flow fields and 100 000 agents on the same map;
-field requests and agent slabs are sharded, baked tiles and slab results are all-gathered (RCCL).
+HBM: rebuild every chunk field of the flow fields, then one velocity step (flow sampling ->
+steering forces -> neighbour gather -> ClearPath -> truncate -> position accept) for every agent,
+then advance the snapshot.  --config selects the BASELINE.json configuration:
 
-Prints ONE JSON line on rank 0.
+  0  256x256 map, 1 flow field, 1 000 agents: the reference's own CPU-runnable case.  The GPU path is
+     timed on it and the WHOLE workload is also run through the reference build on the host
+     (unsampled cpu_baseline + a full parity check of the first tick).
+  1  1024x1024 map, 16 flow fields, 50 000 agents
+  2  1024x1024 map, 64 flow fields (16 384 chunk fields), 100 000 agents -- the configuration the
+     target (>= 1e7 agent-steps/s) is quoted on; DEFAULT.  With --gpus N > 1 it is weak-scaled:
+     every GPU brings its own region of the map, 64 flow fields and 100 000 agents.
+  3  2048x2048 map, 128 flow fields, 200 000 agents in total, split over the N GPUs by
+     destination / agent slab (strong scaling); runs on one GPU too.
+  4  config 2 + 10 000 dynamic obstacles, 1 % moved per tick, incremental field repair.
+
+Prints ONE JSON line on rank 0.  `value` = agents x steps / wall time of the K timed steps (barrier +
+synchronize on both sides, max over ranks); the line also carries the MEDIAN tick (GPU timeline),
+ticks 5 / 50 / 100, a status histogram, the roofline of the dominant kernel, the reference's CPU
+rate on the same box, and (N = 1) a crowded-world secondary measurement.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,6 +40,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROAR
 BYTES_PER_CELL = 4             # 1 B cost + 2 B blockers read, 1 B direction written
 BYTES_PER_AGENT_STEP = 112     # 96 B record in, 8 B velocity + 8 B position out
 PLANE_BYTES_PER_MAP_CELL = 3   # per tick, once: cost (1) + blockers (2)
+
+CONFIGS = {      # map side in chunks, flow fields, agents, obstacles, shared map
+    0: dict(map=4, fields=1, agents=1_000, obstacles=0, shared=False),
+    1: dict(map=16, fields=16, agents=50_000, obstacles=0, shared=False),
+    2: dict(map=16, fields=64, agents=100_000, obstacles=0, shared=False),
+    3: dict(map=32, fields=128, agents=200_000, obstacles=0, shared=True),
+    4: dict(map=16, fields=64, agents=100_000, obstacles=10_000, shared=False),
+}
+
+
+def csrc_sha():
+    """Identity of the kernel sources: profiles/*.json measured on another tree are stale."""
+    d = os.path.join(ROOT, "permafrost-engine_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def usable_cores():
@@ -49,9 +79,9 @@ def usable_cores():
     return min(n, 256)
 
 
-def cpu_baseline(chunk_w, k_fields, n_agents, hz, budget_field_s=10.0, budget_agent_s=10.0):
-    """The reference's own code (oracle/_ref) timed on this box's host cores on a bounded sample of
-    the same workload.  Reported, never the target."""
+def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10.0, budget_agent_s=10.0):
+    """The reference's own code (oracle/_ref) timed on this box's host cores, on a bounded sample of
+    the SAME workload (whole=True: all of it, config 0).  Reported, never the target."""
     try:
         from oracle import pfref
         if not pfref.available():
@@ -62,32 +92,32 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, budget_field_s=10.0, budget_ag
         grid = synth.cost_grid(chunk_w, chunk_w, seed=1234)
         nav = pfref.RefNav(synth.to_chunks(grid))      # the reference's portal / island build
         dests = synth.destinations(grid, k_fields, seed=42)
-        # (i) chunk fields: the planner's own request stream for a sample of destinations
-        cells = synth.passable_cells(grid)
+        # (i) chunk fields: a random sample of the very request list the GPU builds every tick
+        liid = synth.from_chunks(nav.plane(pfref.PLANE_LOCAL_ISLANDS))
+        cols = synth.whole_map_requests(grid, dests, liid)
+        n_all = len(cols["type"])
+        reqs_all = np.zeros(n_all, pfref.FIELD_REQ_DTYPE)
+        for k in synth.REQ_FIELDS:
+            if k in reqs_all.dtype.names:
+                reqs_all[k] = cols[k]
         rng = np.random.RandomState(3)
-        reqs = []
-        for d in dests[:16]:
-            for _ in range(6):
-                a = cells[rng.randint(len(cells))]
-                nav.request_path(synth.cell_centre(chunk_w, chunk_w, a[0], a[1]),
-                                 synth.cell_centre(chunk_w, chunk_w, d[0], d[1]), clear_cache=True)
-                r, _, _ = nav.trace()
-                reqs.append(r)
-        reqs = np.concatenate(reqs)
-        reqs["inout"] = 0
-        t_f1 = nav.field_bench(reqs[:256], reps=1, nthreads=1)
-        n1 = min(len(reqs), 256)
-        cells_per_s_1 = n1 * 4096 / t_f1
-        # ~budget_field_s seconds of single-core work, spread over all cores
-        reps = max(1, int(budget_field_s / (t_f1 / n1 * len(reqs))))
+        probe = reqs_all[rng.choice(n_all, size=min(n_all, 256), replace=False)]
+        t_f1 = nav.field_bench(probe, reps=1, nthreads=1)
+        per_field = t_f1 / len(probe)
+        cells_per_s_1 = 4096 / per_field
+        if whole:
+            reqs, reps = reqs_all, 1
+        else:
+            m = int(min(n_all, max(cores * 16, budget_field_s / per_field)))
+            reqs, reps = reqs_all[rng.choice(n_all, size=m, replace=False)], 1
         t_f = nav.field_bench(reqs, reps=reps, nthreads=cores)
         cells_per_s = len(reqs) * reps * 4096 / t_f
-        # (ii) velocity step: the full 100k-agent snapshot loaded, a slab of it stepped
+        # (ii) velocity step: the full snapshot loaded, a slab of it stepped
         ag = synth.agents(grid, n_agents, k_fields, seed=7, hz=hz)
         targets = synth.cell_centre(chunk_w, chunk_w, dests[:, 0], dests[:, 1])
         dest_ids = []
         for f in range(k_fields):
-            ok, did = nav.request_path(ag["pos"][f], targets[f], clear_cache=(f == 0))
+            ok, did = nav.request_path(ag["pos"][f % n_agents], targets[f], clear_cache=(f == 0))
             dest_ids.append(did)
         nav.trace()
         mv = pfref.RefMove(nav, ag["pos"], ag["vel"], ag["radius"], ag["max_speed"], ag["speed"],
@@ -98,43 +128,106 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, budget_field_s=10.0, budget_ag
         vdes[:, 0] = 1.0
         t_1, _ = mv.bench(vdes, reps=1, nthreads=1, begin=0, end=min(400, n_agents))
         per_agent = t_1 / min(400, n_agents)
-        # ~budget_agent_s seconds of single-core work, spread over all cores
-        m = int(min(n_agents, max(cores * 8, budget_agent_s / per_agent)))
+        m = n_agents if whole else int(min(n_agents, max(cores * 8, budget_agent_s / per_agent)))
         t_a, _ = mv.bench(vdes, reps=1, nthreads=cores, begin=0, end=m)
         pfref.RefMove.unload()
         return {
             "value": m / t_a, "unit": "agent-steps/s", "cores": cores, "kind": "reference",
-            "sample": "reference movement.c move_velocity_work on %d of the %d agents (full snapshot "
-                      "loaded, desired directions given), %d pthreads; reference N_FlowFieldUpdate on "
-                      "%d planner-emitted chunk-field requests x%d" % (m, n_agents, cores, len(reqs), reps),
+            "sample": "reference movement.c move_velocity_work on %d of the %d agents (full snapshot loaded), "
+                      "%d pthreads; reference N_FlowFieldInit+N_FlowFieldUpdate on %d of the %d chunk-field "
+                      "requests the GPU builds every tick (random sample), %d pthreads"
+                      % (m, n_agents, cores, len(reqs), n_all, cores),
+            "skips": "flow-field sampling of the velocity step (desired directions are given: the reference's "
+                     "2 048-entry field cache cannot hold this workload's %d chunk fields, sampling would "
+                     "time its planner); the position accept test" % n_all,
             "flow_field_cells_per_s": cells_per_s, "flow_field_cells_per_s_1core": cells_per_s_1,
             "agent_steps_per_s_1core": 1.0 / per_agent,
             "cores_note": "threads = usable cores (min of affinity and the cgroup cpu.max quota); "
                           "os.cpu_count() = %d" % (os.cpu_count() or 0),
-            "cpu_work_s": {"fields": t_f1 / n1 * len(reqs) * reps, "agents": per_agent * m},
+            "cpu_work_s": {"fields": per_field * len(reqs) * reps, "agents": per_agent * m},
         }
     except Exception as exc:                      # the baseline is informational
         return {"value": None, "unit": "agent-steps/s", "cores": os.cpu_count(), "kind": "reference",
                 "sample": "unavailable: %r" % (exc,)}
 
 
+def parity_config0(T):
+    """config 0: the whole first tick against the reference build (every chunk field, every agent)."""
+    try:
+        from oracle import pfref
+        if not pfref.available():
+            return None
+        import numpy as np
+        sys.path.insert(0, ROOT)
+        from tests import cases
+        return cases.tick_parity(T, ticks=1)
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
+def status_histogram(T):
+    import numpy as np
+    from permafrost_engine_amd import navhip
+    st = T.status[T.a0:T.a1].cpu().numpy()
+    lists = T.ctx.last_step_lists()
+    n = max(1, len(st))
+    return {
+        "moved": float((st & navhip.ST_MOVED).astype(bool).mean()),
+        "field_miss": float((st & navhip.ST_FIELD_MISS).astype(bool).mean()),
+        "field_none": float((st & navhip.ST_FIELD_NONE).astype(bool).mean()),
+        "unsupported": float((st & navhip.ST_UNSUPPORTED).astype(bool).mean()),
+        "clearpath_search_thread": [x / n for x in lists[:4]],
+        "clearpath_search_wave": lists[4] / n, "whole_step_wave": lists[5] / n,
+    }
+
+
+def run_ticks(T, pdist, torch, warmup, steps):
+    import numpy as np
+    for _ in range(warmup):
+        T.step()
+    T.sync()
+    pdist.barrier()
+    torch.cuda.synchronize()
+    T.record = True
+    T.ev, T.tick_ev = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        T.step()
+    T.sync()
+    torch.cuda.synchronize()
+    pdist.barrier()
+    dt = time.perf_counter() - t0
+    T.record = False
+    dt = pdist.max_over_ranks(dt, T.dev)
+    ticks = np.array(T.tick_ms()) if steps > 1 else np.array([dt * 1e3])
+    return dt, ticks
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--map", type=int, default=16, help="map side in chunks (16 = 1024x1024 cells)")
-    ap.add_argument("--fields", type=int, default=64, help="whole-map flow fields per GPU")
-    ap.add_argument("--agents", type=int, default=100_000, help="agents per GPU")
-    ap.add_argument("--obstacles", type=int, default=0,
-                    help="configs[4]: dynamic obstacles, 1%% moved per tick, incremental field repair")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--map", type=int, default=None, help="override: map side in chunks (16 = 1024x1024 cells)")
+    ap.add_argument("--fields", type=int, default=None, help="override: whole-map flow fields (per GPU unless config 3)")
+    ap.add_argument("--agents", type=int, default=None, help="override: agents (per GPU unless config 3)")
+    ap.add_argument("--obstacles", type=int, default=None,
+                    help="override: dynamic obstacles, 1%% moved per tick, incremental field repair")
+    ap.add_argument("--crowded", action="store_true", help="the main run uses the crowded world")
+    ap.add_argument("--no-crowded", action="store_true", help="skip the crowded-world secondary measurement")
     ap.add_argument("--tile-exchange", choices=("auto", "all"), default="auto",
                     help="multi-GPU: auto = only baked tiles that another rank's agents sample travel "
                          "(none in this workload: flocks are rank aligned); all = all-gather every tile "
                          "every tick (any agent may sample any field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("map", "fields", "agents", "obstacles"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
 
+    import numpy as np
     import torch
     from permafrost_engine_amd import dist as pdist
     import __graft_entry__ as ge
@@ -148,134 +241,173 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libnavhip has no CPU fallback")
     torch.cuda.set_device(local)
 
-    T = tick.NavTick(chunk_w=args.map, fields_per_rank=args.fields, agents_per_rank=args.agents,
-                     rank=rank, world=world, device=local, verbose=(rank == 0 and False),
-                     obstacles=args.obstacles, obstacle_ticks=args.warmup + args.steps + 8,
-                     tile_exchange=args.tile_exchange)
-    for _ in range(args.warmup):
-        T.step()
-    T.sync()
-    pdist.barrier()
-    torch.cuda.synchronize()
-    T.record = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        T.step()
-    T.sync()
-    torch.cuda.synchronize()
-    pdist.barrier()
-    dt = time.perf_counter() - t0
-    dt = pdist.max_over_ranks(dt, T.dev)
+    shared = cfg["shared"]
+    f_rank = cfg["fields"] // world if shared else cfg["fields"]
+    a_rank = cfg["agents"] // world if shared else cfg["agents"]
+    CROWD = 17      # cells: a flock of ~1 600 packed into ~35 x 35 cells -> ~30 neighbours within r = 10
 
+    def make(crowd):
+        return tick.NavTick(chunk_w=cfg["map"], fields_per_rank=f_rank, agents_per_rank=a_rank,
+                            rank=rank, world=world, device=local, obstacles=cfg["obstacles"],
+                            obstacle_ticks=args.warmup + args.steps + 16, tile_exchange=args.tile_exchange,
+                            shared_map=shared, crowd_cells=CROWD if crowd else 0)
+
+    T = make(args.crowded)
+    parity = parity_config0(T) if (args.config == 0 and rank == 0 and world == 1) else None
+    dt, ticks = run_ticks(T, pdist, torch, args.warmup, args.steps)
     phases = T.phase_ms()
-    # per-kernel split of the agent phase: a few extra (untimed) ticks with the library's own HIP
-    # events between its kernels, on the launch stream
-    T.record = False
+    hist = status_histogram(T)
+
+    # per-kernel-group durations: a few extra (untimed) ticks with every group back to back on ONE
+    # stream (no overlap), the library's own HIP events between them
     T.ctx.set_profiling(True)
+    T.record, T.mark_every = True, 1
+    T.ev, T.tick_ev = [], []
     ksplit = []
-    for _ in range(5):
+    for _ in range(6):
         T.step()
         T.sync()
         ksplit.append(T.ctx.last_step_ms())
+    T.record = False
     T.ctx.set_profiling(False)
-    k_sp, k_coh, k_step = (float(sum(x[i] for x in ksplit) / len(ksplit)) for i in range(3))
+    serial = T.phase_ms()
+    from permafrost_engine_amd import navhip
+    groups = {name: float(np.mean([x[i] for x in ksplit[1:]])) for i, name in enumerate(navhip.STEP_PHASES)}
+    groups["fields"] = serial.get("fields", 0.0)
+
     agents_total = T.N
     cells_total = T.n_req_total * 4096
     ms_per_step = dt / args.steps * 1e3
     value = agents_total * args.steps / dt
 
-    # ---- roofline of the dominant kernel phase (HIP events on the launch stream) ---------------
-    f_ms, a_ms = phases.get("fields", 0.0), phases.get("agents", 0.0)
+    # ---- roofline (HBM bound; algorithmic bytes per launch) ---------------
     f_bytes = T.n_req_local * 4096 * BYTES_PER_CELL
     a_bytes = (T.a1 - T.a0) * BYTES_PER_AGENT_STEP + T.map_cells * PLANE_BYTES_PER_MAP_CELL
-    f_gbs = f_bytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
-    a_gbs = a_bytes / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    measured = {}
-    if os.path.exists(tpath):
-        try:
-            measured = json.load(open(tpath))
-        except Exception:
-            measured = {}
-    # What actually bounds these kernels is VALU issue, not HBM: next to the
-    # HBM figures, report the instruction-issue floor from the committed SQ counters.
+    a_ms = sum(groups[k] for k in ("sp_build", "agent_nbr", "cohesion", "agent_finish"))
+    f_ms = groups["fields"]
+    sha = csrc_sha()
+    measured, calib = {}, {}
+    try:
+        measured = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        pass
+    try:
+        calib = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_calib.json")))
+    except Exception:
+        pass
+    stale = measured.get("csrc_sha") != sha
     sq = {}
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["kernels"]
+        sqj = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
+        if sqj.get("csrc_sha") == sha:
+            sq = sqj["kernels"]
     except Exception:
-        sq = {}
+        pass
+    cyc = None
+    try:
+        cyc = float(calib["results"]["waves_per_simd_8"]["v_fma_f32"])
+    except Exception:
+        pass
 
-    def valu(names, measured_ms):
-        ks = [k for k in sq if k.startswith(names)]
-        if not ks or measured_ms <= 0:
+    def valu(prefixes, measured_ms):
+        ks = [k for k in sq if k.startswith(prefixes)]
+        if not ks or measured_ms <= 0 or cyc is None:
             return None
         insts = sum(sq[k]["SQ_INSTS_VALU"] for k in ks)
-        floor_ms = insts / 1024 * 4 / 2.4e9 * 1e3
-        return {"valu_insts_per_launch": insts, "issue_floor_ms": floor_ms,
+        floor_ms = insts / 1024 * cyc / 2.4e9 * 1e3
+        return {"valu_insts_per_launch": insts, "issue_floor_ms": floor_ms, "cycles_per_inst": cyc,
                 "frac_of_issue_peak": floor_ms / measured_ms,
-                "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, profiles/sq_counters.json) at "
-                        "one per 4 cycles per SIMD, 1024 SIMDs, 2.4 GHz, over the measured phase time"}
+                "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, profiles/sq_counters.json, same "
+                        "csrc tree) at the MEASURED v_fma_f32 issue cost (profiles/r02_valu_calib.json), "
+                        "1024 SIMDs, 2.4 GHz, over the measured launch time"}
+
+    def roof(which):
+        ms, by = (a_ms, a_bytes) if which == "agents" else (f_ms, f_bytes)
+        gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": None if stale else measured.get(which + "_bytes_per_launch"),
+            "traffic_stale": bool(stale and measured),
+            "kernel": ("navhip_agent_step_dev: k_sp_* + k_agent_nbr + k_cohesion + k_agent_mid/k_cp_*"
+                       if which == "agents" else "navhip_build_fields_dev: k_field_bfs"),
+            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by,
+            "launch_timing": "HIP events on the launch stream, kernel groups back to back on one stream "
+                             "(6 profiled ticks after the timed region)",
+            "kernels_ms": {k: groups[k] for k in ("sp_build", "agent_nbr", "cohesion", "coh_regroup", "agent_finish")}
+                          if which == "agents" else {"fields": f_ms},
+            "valu_issue": valu(("k_agent_", "k_cp_", "k_coh", "k_sp_"), ms) if which == "agents"
+                          else valu(("k_field_",), ms),
+        }
 
     dom = "agents" if a_ms >= f_ms else "fields"
-    roof = {
-        "bound": "hbm", "kernel": "k_agent_step (+k_cohesion, spatial hash)" if dom == "agents" else "k_field_bfs",
-        "achieved": a_gbs if dom == "agents" else f_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": (a_gbs if dom == "agents" else f_gbs) / HBM_PEAK_GBS,
-        "traffic": measured.get(dom + "_bytes_per_launch", traffic),
-        "avg_launch_ms": a_ms if dom == "agents" else f_ms,
-        "algorithmic_bytes_per_launch": a_bytes if dom == "agents" else f_bytes,
-        "launch": "one navhip_agent_step_dev call" if dom == "agents" else "one navhip_build_fields_dev call",
-        "kernels_ms": {"k_sp_*": k_sp, "k_cohesion": k_coh, "k_agent_step": k_step} if dom == "agents" else None,
-        "valu_issue": valu(("k_agent_",), a_ms) if dom == "agents" else valu(("k_field_", "k_coh", "k_sp_"), f_ms),
-    }
-    roof_other = {
-        "bound": "hbm", "kernel": "k_field_bfs" if dom == "agents" else "k_agent_step (+k_cohesion, spatial hash)",
-        "achieved": f_gbs if dom == "agents" else a_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": (f_gbs if dom == "agents" else a_gbs) / HBM_PEAK_GBS,
-        "traffic": measured.get(("fields" if dom == "agents" else "agents") + "_bytes_per_launch"),
-        "avg_launch_ms": f_ms if dom == "agents" else a_ms,
-        "algorithmic_bytes_per_launch": f_bytes if dom == "agents" else a_bytes,
-        "valu_issue": valu(("k_field_", "k_coh", "k_sp_"), f_ms) if dom == "agents" else valu(("k_agent_",), a_ms),
-    }
+    other = "fields" if dom == "agents" else "agents"
+
+    crowded = None
+    if rank == 0 and world == 1 and not args.no_crowded and not args.crowded and args.config in (1, 2):
+        T.close()
+        T = None
+        Tc = make(True)
+        cdt, cticks = run_ticks(Tc, pdist, torch, 3, 40)
+        chist = status_histogram(Tc)
+        crowded = {"what": "same config, every flock packed into ~35 x 35 cells (neighbour caps bind, "
+                           "ClearPath in its R^3 regime); 40 ticks after 3",
+                   "agent_steps_per_s": Tc.N * 40 / cdt, "ms_per_step": cdt / 40 * 1e3,
+                   "ms_per_step_median": float(np.median(cticks)), "status": chist}
+        Tc.close()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.map, args.fields, args.agents, 20)
+        cpu = cpu_baseline(cfg["map"], cfg["fields"], cfg["agents"], 20, whole=(args.config == 0))
 
     if rank == 0:
+        def at(i):
+            return float(ticks[i - 1]) if len(ticks) >= i else None
         line = {
-            "metric": "agent-steps/sec (+ flow-field cells/sec), 1024^2 map, 100k agents per GPU, "
-                      "64 whole-map flow fields per GPU rebuilt every tick",
+            "metric": "agent-steps/sec (+ flow-field cells/sec): every chunk field of every flow field rebuilt and "
+                      "every agent stepped each tick",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u64-bitmask/u8 fields, f32 agents",
-            "data": "synthetic",
-            "config": {"workload": ("configs[4] (dynamic obstacles, incremental repair): " if args.obstacles else "")
-                                   + "configs[2] per GPU: %dx%d-cell map region (%dx%d chunks), %d flow "
-                                   "fields (%d chunk fields) + %d agents per GPU, fields rebuilt + agents "
-                                   "stepped every tick%s" % (args.map * 64, args.map * 64, args.map, args.map,
-                                                             args.fields, T.n_req_local, args.agents,
-                                                             "" if world == 1 else
-                                                             "; the %d regions tile one %dx%d-cell map"
-                                                             % (world, T.H * 64, T.Wt * 64)),
-                       "map_chunks": args.map, "flow_fields_per_gpu": args.fields,
-                       "agents_per_gpu": args.agents, "hz": 20, "dynamic_obstacles": args.obstacles,
-                       "parallelism": "regions (requests + agent slabs) sharded x%d; all-gather of slab "
-                                      "results (16 B/agent); baked tiles: %s" % (world, T.tile_exchange)},
-            ("flow_field_cells_kept_valid_per_s" if args.obstacles else "flow_field_cells_per_s"):
+            "scaling": "strong" if shared else "weak", "vs_baseline": None,
+            "dtype": "u64-bitmask/u8 fields, f32 agents (f64 exp)", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d]%s: %dx%d-cell map (%dx%d chunks%s), %d flow fields "
+                                   "(%d chunk fields) + %d agents %s, fields rebuilt + agents stepped every tick%s%s"
+                                   % (args.config, " (crowded world)" if args.crowded else "",
+                                      T_dims(cfg, world, shared)[0], T_dims(cfg, world, shared)[1],
+                                      T_dims(cfg, world, shared)[2], T_dims(cfg, world, shared)[3],
+                                      "" if world == 1 or shared else ": %d regions of %dx%d chunks" % (world, cfg["map"], cfg["map"]),
+                                      cfg["fields"], cells_total // 4096 if shared else cells_total // 4096 // world,
+                                      cfg["agents"], "in total" if shared else "per GPU",
+                                      ", %d dynamic obstacles (1 %% moved per tick, incremental repair)" % cfg["obstacles"]
+                                      if cfg["obstacles"] else "", ""),
+                       "baseline_config": args.config, "map_chunks": cfg["map"], "flow_fields": cfg["fields"],
+                       "agents": cfg["agents"], "hz": 20, "dynamic_obstacles": cfg["obstacles"],
+                       "parallelism": "requests by destination + agent slabs x%d; one all-gather of slab results "
+                                      "(16 B/agent) per tick; baked tiles: %s" % (world, args.tile_exchange)},
+            "ms_per_step_median": float(np.median(ticks)),
+            "ms_tick_5_50_100": [at(5), at(50), at(min(100, len(ticks)))],
+            "agent_steps_per_s_median_tick": agents_total / (float(np.median(ticks)) * 1e-3),
+            ("flow_field_cells_kept_valid_per_s" if cfg["obstacles"] else "flow_field_cells_per_s"):
                 cells_total * args.steps / dt,
-            "flow_field_cells_per_s_kernel": (T.n_req_local * 4096 * world) / (f_ms * 1e-3) if f_ms > 0 else None,
-            "agent_steps_per_s_kernel": agents_total / (a_ms * 1e-3) if a_ms > 0 else None,
-            "phase_ms": phases,
-            "roofline": roof,
-            "roofline_secondary": roof_other,
+            "phase_ms_overlapped": phases,
+            "status": hist,
+            "roofline": roof(dom),
+            "roofline_secondary": roof(other),
+            "csrc_sha": sha,
+            "crowded_world": crowded,
+            "parity_first_tick": parity,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    T.close()
+    if T is not None:
+        T.close()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def T_dims(cfg, world, shared):
+    from permafrost_engine_amd import tick
+    rows, cols = (1, 1) if shared else tick.region_grid(world)
+    return cfg["map"] * cols * 64, cfg["map"] * rows * 64, cfg["map"] * cols, cfg["map"] * rows
 
 
 if __name__ == "__main__":

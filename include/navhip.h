@@ -319,6 +319,18 @@ typedef struct navhip_world {
     const float    *form_cohesion_xz;/* [n][2]  fstate.normal_cohesion_force                     */
     const float    *form_align_xz;   /* [n][2]  fstate.normal_align_force                        */
     const float    *form_drag_xz;    /* [n][2]  fstate.normal_drag_force                         */
+    /* Fine-arrival inputs (struct arrival_unit_state, arrival.h:105-128, kept per unit in
+     * movestate.arrival; struct arrival_state per flock and nav layer, arrival.h:66-91).  NULL (both):
+     * the arrival overlay is inactive for everyone.  The step reads them exactly where the reference
+     * does: the seek target of the arrive force is the unit's slot once bits 0 and 1 are set
+     * (G_Arrival_SeekTarget, arrival.c:1034; movement.c:1751-1753,1887-1889), and a NEIGHBOUR with bit 0
+     * set that stands within 1.5 radii of its slot is a static obstacle for ClearPath
+     * (G_Arrival_NeighbourSettling, arrival.c:1042; find_neighbours, movement.c:2815-2817). */
+    const float    *arrival_sink_xz; /* [n][2]  movestate.arrival.sink                           */
+    const uint8_t  *arrival_flags;   /* [n]     bit 0: substate is SEEK / SEEK_ARMED (unit_committed,
+                                                arrival.c:90) and sink_valid; bit 1: the flock's
+                                                arrival_state for the unit's nav layer exists and is in
+                                                ARRIVAL_PHASE_FILLING                                  */
 } navhip_world;
 
 typedef struct navhip_step_out {
@@ -349,10 +361,18 @@ int  navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *dev_world,
 int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, void *stream);
 
 /* Per-kernel-group timing of the agent step with HIP events on the launch stream (bench.py's
- * roofline line).  After a profiled navhip_agent_step[_dev], navhip_last_step_ms returns
- * {spatial-hash build, k_cohesion, k_agent_step} in milliseconds (it waits for the step). */
+ * roofline line).  A profiled navhip_agent_step[_dev] runs every kernel group back to back on the
+ * caller's stream (no side streams); navhip_last_step_ms then returns, in milliseconds,
+ * {spatial-hash build, neighbour walk (k_agent_nbr), k_cohesion, cohesion lane regrouping,
+ *  k_agent_mid + the ClearPath searches} (it waits for the step). */
+#define NAVHIP_STEP_PHASES 5
 int  navhip_set_profiling(navhip_ctx *ctx, int on);
-int  navhip_last_step_ms(navhip_ctx *ctx, float out_ms[3]);
+int  navhip_last_step_ms(navhip_ctx *ctx, float out_ms[NAVHIP_STEP_PHASES]);
+/* How the last agent step split its agents (waits for it): the number of agents whose ClearPath
+ * search ran on a thread ([0..3]: 1..4 neighbours), on a wave ([4]: more neighbours, or
+ * remove_furthest retries), and agents whose whole step ran on a wave ([5]: garrisoned neighbours /
+ * wide queries).  Everyone else finished in the thread-per-agent pass. */
+int  navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6]);
 
 /* Device spatial index only (bg_ent insert-all + cleanup + inrange_circle, bitmap_grid.h:1376):
  * for each query point the ids within `range`, in the reference's visiting order, capped at
@@ -366,6 +386,12 @@ int  navhip_spatial_query(navhip_ctx *ctx, const navhip_world *world, const floa
 int  navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
                       const float *dyn, const int32_t *n_dyn, const float *stat,
                       const int32_t *n_stat, float *out);
+/* The same problems through the thread-per-agent search the agent step uses for agents with at most
+ * 4 neighbours (n_dyn + n_stat <= 4).  found[q] = 0: no admissible candidate -- the step hands such
+ * agents to the wave path (remove_furthest + retry, clearpath.c:390,694-715); out[q] is then unset. */
+int  navhip_clearpath_light(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                            const float *dyn, const int32_t *n_dyn, const float *stat,
+                            const int32_t *n_stat, float *out, int32_t *found);
 
 #ifdef __cplusplus
 }

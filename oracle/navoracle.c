@@ -1531,7 +1531,9 @@ static void step_one(const step_ctx *c, int uid, const navhip_step_out *o)
     }
 
     v2 new_pos = me;
-    if(active) {
+    /* entity_compute_update returns before the position update for a garrisoned entity
+     * (movement.c:2341-2348) */
+    if(active && !(flags & NAVHIP_ENTITY_FLAG_GARRISONED)) {
         int layer = nav_layer_for(flags, w->radius[uid]);
         v2 cand = vadd(me, out_vel);
         bool on_blocked = pos_blocked(c->m, w, layer, me);

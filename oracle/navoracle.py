@@ -63,7 +63,10 @@ class World(C.Structure):
         ("grid_xmin", C.c_float), ("grid_xmax", C.c_float), ("grid_zmin", C.c_float),
         ("grid_zmax", C.c_float), ("work_begin", C.c_int32), ("work_end", C.c_int32),
         ("form_ready", C.c_void_p), ("cell_pos_xz", C.c_void_p), ("form_cohesion_xz", C.c_void_p),
-        ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p)]
+        ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p),
+        # fine-arrival inputs: the restatement does not model them (always NULL here; the arrival
+        # paths are checked against the reference build itself)
+        ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p)]
 
 
 class StepOut(C.Structure):

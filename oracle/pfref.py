@@ -81,6 +81,8 @@ def lib():
         L.pfref_zone_field.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int,
                                                                       C.c_void_p]
         L.pfref_los_field.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p]
+        L.pfref_field_update_many.restype = C.c_double
+        L.pfref_field_update_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.pfref_field_bench.restype = C.c_double
         L.pfref_field_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.pfref_request_path.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -105,6 +107,7 @@ def lib():
             ("pfref_move_velocity", [C.c_void_p, C.c_int, C.c_int, C.c_void_p], None),
             ("pfref_move_unload", [], None),
             ("pfref_move_set_formation", [C.c_void_p] * 5, None),
+            ("pfref_move_set_arrival", [C.c_void_p] * 2, None),
             ("pfref_move_vpref", [C.c_int, C.c_void_p, C.c_void_p], None),
             ("pfref_move_forces", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
              None),
@@ -253,6 +256,14 @@ class RefNav:
         reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)
         return lib().pfref_field_bench(self._h, _p(reqs), len(reqs), reps, nthreads)
 
+    def field_update_many(self, reqs, nthreads=8):
+        """N_FlowFieldInit + N_FlowFieldUpdate for every request (none in place), threaded; [n,64,64] u8."""
+        reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)
+        out = np.zeros((len(reqs), 64, 64), np.uint8)
+        t = lib().pfref_field_update_many(self._h, _p(reqs), len(reqs), nthreads, _p(out))
+        assert t >= 0
+        return out
+
     # -- planner ----------------------------------------------------------
     def request_path(self, src, dst, layer=0, faction_id=FACTION_ID_NONE, clear_cache=False):
         did = C.c_uint32(0)
@@ -384,6 +395,13 @@ class RefMove:
             k[name] = np.ascontiguousarray(a, np.float32).reshape(self.n, 2)
         lib().pfref_move_set_formation(_p(k["f_ready"]), _p(k["f_cell"]), _p(k["f_coh"]),
                                        _p(k["f_align"]), _p(k["f_drag"]))
+
+    def set_arrival(self, sink_xz, flags):
+        """Fine-arrival inputs: per-unit slot + flags (bit 0 committed to a valid slot, bit 1 the
+        flock's arrival region for the unit's layer is filling)."""
+        s = np.ascontiguousarray(sink_xz, np.float32).reshape(self.n, 2)
+        f = np.ascontiguousarray(flags, np.uint8)
+        lib().pfref_move_set_arrival(_p(s), _p(f))
 
     def bench(self, vdes, reps=1, nthreads=1, begin=0, end=None):
         end = self.n if end is None else end

@@ -113,6 +113,9 @@ int pfref_los_field(pfref_nav *nav, int layer, int faction_id, int chunk_r, int 
  * Returns seconds of wall time (CLOCK_MONOTONIC). */
 double pfref_field_bench(pfref_nav *nav, const pfref_field_req *reqs, int n, int reps,
                          int nthreads);
+/* The same build with the results kept (no in-place requests): out_dirs[n][4096]. */
+double pfref_field_update_many(pfref_nav *nav, const pfref_field_req *reqs, int n, int nthreads,
+                               uint8_t *out_dirs);
 
 /* --- planner trace ------------------------------------------------------ */
 
@@ -184,6 +187,9 @@ void pfref_move_velocity(const float *vdes, int begin, int end, float *out_vel);
 /* formation inputs of every work item: fstate.assignment_ready, cell_pos, fstate.normal_*_force */
 void pfref_move_set_formation(const uint8_t *ready, const float *cell_pos, const float *cohesion,
                               const float *align, const float *drag);
+/* fine-arrival inputs: sink [n][2], flags [n] (bit 0 unit committed to a valid slot, bit 1 the
+ * flock's arrival_state for the unit's layer is in ARRIVAL_PHASE_FILLING) */
+void pfref_move_set_arrival(const float *sink_xz, const uint8_t *flags);
 void pfref_move_unload(void);
 /* individual steering terms for unit tests (movement.c:1546,1653,1690,1870,2768) */
 void pfref_move_vpref(int uid, const float vdes[2], float out[2]);

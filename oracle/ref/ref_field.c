@@ -302,6 +302,7 @@ struct bench_arg{
     struct field_target      *targets;
     int                       begin, end, reps;
     unsigned                  sink;
+    uint8_t                  *out_dirs;     /* optional: n * 4096 dir bytes (full-size parity runs) */
 };
 
 static void *bench_thread(void *p)
@@ -317,14 +318,33 @@ static void *bench_thread(void *p)
             N_FlowFieldUpdate(chunk_coord, a->priv, req->faction_id, req->layer, a->targets[i],
                               a->priv->unit_query_ctx, &ff);
             sink += ff.field[rep & 63][i & 63].dir_idx;
+            if(a->out_dirs)
+                pfref_ff_to_dirs(&ff, a->out_dirs + (size_t)i * FIELD_RES_R * FIELD_RES_C);
         }
     }
     a->sink = sink;
     return NULL;
 }
 
+static double field_many(pfref_nav *nav, const pfref_field_req *reqs, int n, int reps,
+                         int nthreads, uint8_t *out_dirs);
+
 double pfref_field_bench(pfref_nav *nav, const pfref_field_req *reqs, int n, int reps,
                          int nthreads)
+{
+    return field_many(nav, reqs, n, reps, nthreads, NULL);
+}
+
+/* N_FlowFieldInit + N_FlowFieldUpdate for n independent requests on nthreads pthreads, results
+ * kept: out_dirs[n][4096] */
+double pfref_field_update_many(pfref_nav *nav, const pfref_field_req *reqs, int n, int nthreads,
+                               uint8_t *out_dirs)
+{
+    return field_many(nav, reqs, n, 1, nthreads, out_dirs);
+}
+
+static double field_many(pfref_nav *nav, const pfref_field_req *reqs, int n, int reps,
+                         int nthreads, uint8_t *out_dirs)
 {
     const struct nav_private *priv = pfref_nav_private(nav);
     struct field_target *targets = malloc(sizeof(struct field_target) * (size_t)n);
@@ -343,7 +363,7 @@ double pfref_field_bench(pfref_nav *nav, const pfref_field_req *reqs, int n, int
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for(int t = 0; t < nthreads; t++) {
         args[t] = (struct bench_arg){priv, reqs, targets,
-            (int)((long)n * t / nthreads), (int)((long)n * (t + 1) / nthreads), reps, 0};
+            (int)((long)n * t / nthreads), (int)((long)n * (t + 1) / nthreads), reps, 0, out_dirs};
         pthread_create(&tids[t], NULL, bench_thread, &args[t]);
     }
     for(int t = 0; t < nthreads; t++)

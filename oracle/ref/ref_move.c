@@ -8,8 +8,8 @@
  *
  * The engine services movement.c reads its snapshot through (flags / radius / faction table
  * getters, the M_Nav* pass-through wrappers of map.c:787-815, Entity_NavLayerWithRadius) are
- * given the minimal bodies below; the arrival module is inactive (NULL arrival state), which
- * is the state of a flock that has not reached its destination region.
+ * given the minimal bodies below.  The arrival module is the reference's own arrival.c; its
+ * per-unit / per-flock state is inactive unless a test sets it (pfref_move_set_arrival).
  */
 #include "game/movement.c"
 
@@ -74,19 +74,6 @@ vec2_t M_NavDesiredPointSeekVelocity(const struct map *map, dest_id_t id, vec2_t
     return N_DesiredPointSeekVelocity(id, curr_pos, xz_dest, &nav->priv, nav->map_pos);
 }
 
-struct arrival_state *G_ArrivalGroup_ForLayer(const struct arrival_group *grp, enum nav_layer layer)
-{
-    (void)grp; (void)layer;
-    return NULL;
-}
-
-bool G_Arrival_NeighbourSettling(const struct arrival_unit_state *us, vec2_t neighb_pos,
-                                 float radius)
-{
-    (void)us; (void)neighb_pos; (void)radius;
-    return false;
-}
-
 /* ---- world loading ---------------------------------------------------------------------- */
 
 static struct {
@@ -122,8 +109,11 @@ void pfref_move_unload(void)
     free(s_w.speed);
     free(s_move_work.in);
     free(s_move_work.out);
-    for(int i = 0; i < vec_size(&s_flocks); i++)
+    for(int i = 0; i < vec_size(&s_flocks); i++) {
         kh_destroy(entity, vec_AT(&s_flocks, i).ents);
+        for(int l = 0; l < NAV_LAYER_MAX; l++)
+            free(vec_AT(&s_flocks, i).arrival.layers[l]);
+    }
     vec_flock_destroy(&s_flocks);
     kh_destroy(state, s_entity_state_table);
     memset(&s_w, 0, sizeof(s_w));
@@ -238,6 +228,32 @@ void pfref_move_set_formation(const uint8_t *ready, const float *cell_pos, const
         in->fstate.normal_cohesion_force = (vec2_t){cohesion[2 * i], cohesion[2 * i + 1]};
         in->fstate.normal_align_force = (vec2_t){align[2 * i], align[2 * i + 1]};
         in->fstate.normal_drag_force = (vec2_t){drag[2 * i], drag[2 * i + 1]};
+    }
+}
+
+/* Per-unit fine-arrival state (struct arrival_unit_state, arrival.h:105) and the flocks' per-layer
+ * struct arrival_state, as explicit inputs: flags bit 0 = the unit is committed to a valid slot
+ * (substate SEEK, sink_valid), bit 1 = its flock's arrival_state for its nav layer exists and is
+ * filling.  G_Arrival_SeekTarget / G_Arrival_NeighbourSettling are the reference's own. */
+void pfref_move_set_arrival(const float *sink_xz, const uint8_t *flags)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        struct movestate *ms = movestate_get(i);
+        memset(&ms->arrival, 0, sizeof(ms->arrival));
+        ms->arrival.substate = (flags[i] & 1) ? ARRIVAL_SUBSTATE_SEEK : ARRIVAL_SUBSTATE_APPROACH;
+        ms->arrival.sink_valid = (flags[i] & 1) != 0;
+        ms->arrival.sink = (vec2_t){sink_xz[2 * i], sink_xz[2 * i + 1]};
+        struct flock *fl = flock_for_ent(i);
+        if(!fl || !(flags[i] & 2))
+            continue;
+        float radius = G_GetSelectionRadiusFrom(s_move_work.gamestate.sel_radiuses, i);
+        uint32_t eflags = G_FlagsGetFrom(s_move_work.gamestate.flags, i);
+        int layer = Entity_NavLayerWithRadius(eflags, radius);
+        if(!fl->arrival.layers[layer]) {
+            fl->arrival.layers[layer] = calloc(1, sizeof(struct arrival_state));
+            fl->arrival.layers[layer]->layer = layer;
+        }
+        fl->arrival.layers[layer]->phase = ARRIVAL_PHASE_FILLING;
     }
 }
 

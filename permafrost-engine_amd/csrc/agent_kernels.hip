@@ -11,271 +11,44 @@
 //   src/navigation/nav.c  N_DesiredPointSeekVelocity :3468, n_interpolated_flow_dir :3407,
 //                         N_PositionPathable/Blocked :4055/:4070;  src/map/tile.c :356,:391,:547
 //
-// Arithmetic mirrors the reference's C expression by expression (same types, same order, no FMA
-// contraction, IEEE divide / sqrt, double-precision exp) so that results are reproducible against
-// the CPU path far inside the 1e-4 parity bound; all order-dependent float sums are evaluated in
-// the reference's own order.
+// Arithmetic mirrors the reference's C expression by expression (agent_math.h); all
+// order-dependent float sums are evaluated in the reference's own order.
 //
-// Kernels
-//   k_sp_*        device spatial hash: fixed-point cell binning, scan, scatter, per-cell ordering
-//                 (the layout bg_ent_cleanup produces after inserting uids 0..n-1).
-//   k_cohesion    one THREAD per flock member; the O(N*F) exp-weighted centroid, every thread
-//                 walking its flock's member list in order (lanes of a wave share the flock, so
-//                 member loads are wave-uniform broadcasts).
-//   k_agent_step  one WAVE per agent: flow sampling, arrive/separation forces, impassable-component
-//                 nullification, neighbour gather (lanes test 64 candidates at a time, ballot +
-//                 prefix-popcount compaction keeps the reference's order and caps), ClearPath with
-//                 lanes spread over ray pairs and a lexicographic wave arg-min that reproduces the
-//                 reference's first-wins tie-break, truncation and the position accept test.
+// Kernels of one tick (navhip_api.hip wires the streams):
+//   k_sp_count .. k_sp_place   device spatial hash: fixed-point cell binning, scan, and the POOL -- one
+//                 16-byte record {pos, radius, flag bits | uid} + one velocity per inserted entity, in
+//                 the cell order and per-cell order bg_ent_cleanup produces after inserting uids
+//                 0..n-1, so that a query's candidates are contiguous runs and a hit needs no
+//                 second gather.
+//   k_agent_nbr   one THREAD per entity, pool order: separation force + ClearPath neighbour lists in
+//                 one walk (agent_thread.h).  Needs only the snapshot: runs beside the field builds.
+//   k_cohesion    the O(N*F) exp-weighted flock centroid, four lanes per member.
+//   k_agent_mid   one THREAD per entity: flow sampling, arrive force, priority ladder -> preferred
+//                 velocity; des_v admissible?  Finished agents are truncated + position-tested here;
+//                 the rest go to device-side work lists.
+//   k_cp_light    one THREAD per listed agent (<= 4 neighbours), lists grouped by neighbour count.
+//   k_cp_wave     one WAVE per listed agent (> 4 neighbours: >= 100 ray pairs x cone tests fill a
+//                 wave): ClearPath with lanes spread over ray pairs, a candidate queue and a
+//                 lexicographic wave arg-min that reproduces the reference's first-wins tie-break.
+//   k_agent_full  one WAVE per listed agent, the whole step (irregular gathers: garrisoned
+//                 neighbours, wide queries).
 #include "navhip_internal.h"
 #include "agent_internal.h"
+#include "agent_thread.h"
 
-// ---------------------------------------------------------------------------------------------
-// exact-arithmetic helpers (pf_math.c:58-94)
-// ---------------------------------------------------------------------------------------------
-struct v2 { float x, z; };
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ v2 mkv(float x, float z) { v2 r; r.x = x; r.z = z; return r; }
-__device__ __forceinline__ v2 vadd(v2 a, v2 b) { return mkv(a.x + b.x, a.z + b.z); }
-__device__ __forceinline__ v2 vsub(v2 a, v2 b) { return mkv(a.x - b.x, a.z - b.z); }
-__device__ __forceinline__ v2 vscale(v2 a, float s) { return mkv(a.x * s, a.z * s); }
-__device__ __forceinline__ float vdot(v2 a, v2 b) { return a.x * b.x + a.z * b.z; }
-// PFM_Vec2_Len: sqrt in double of a float sum, rounded to float == correctly rounded float sqrt.
-// __builtin_sqrtf is IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn is
-// NOT (it lowers to the native v_sqrt_f32 approximation in this ROCm).
-//
-// Correctly rounded sqrt for s == 0 or s in the normal range well away from its ends: v_sqrt_f32
-// (<= 1 ulp) plus the same one-ulp fix-up the compiler's IEEE expansion uses, without that
-// expansion's input scaling / class handling (which only matter for denormal, infinite or NaN s).
-__device__ __forceinline__ float sqrt_rn_normal(float s)
-{
-    float r = __builtin_amdgcn_sqrtf(s);
-    const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
-    const float em = __builtin_fmaf(-rm, r, s), ep = __builtin_fmaf(-rp, r, s);
-    r = (em <= 0.0f) ? rm : r;
-    r = (ep > 0.0f) ? rp : r;
-    return r;
-}
-__device__ __forceinline__ float vlen(v2 a)
-{
-    const float s = a.x * a.x + a.z * a.z;
-    if(!(s >= 0x1p-90f && s <= 0x1p90f) && s != 0.0f) {
-        asm volatile("" ::: "memory");      // a real branch: keep the expansion out of the common path
-        return __builtin_sqrtf(s);
-    }
-    return sqrt_rn_normal(s);
-}
-__device__ __forceinline__ v2 vnormal(v2 a)
-{
-    float l = vlen(a);
-    return mkv(__fdiv_rn(a.x, l), __fdiv_rn(a.z, l));
-}
-// vec2_truncate, movement.c:643
-__device__ __forceinline__ v2 vtrunc(v2 a, float max_len)
-{
-    if(vlen(a) > max_len) {
-        a = vnormal(a);
-        a = vscale(a, max_len);
-    }
-    return a;
-}
-
-#define CP_EPS 0.0009765625f   /* 1.0/1024: exactly representable, so float compares == the
-                                  reference's float-vs-double compares */
-
-// optional section timing of k_agent_step (scripts/section_prof.py builds a private copy of the
-// library with -DNH_SECTION_PROF; the shipped build carries none of it)
-#ifdef NH_SECTION_PROF
-__device__ unsigned long long nh_sec[1024 * 32];      // [slot = block & 1023][counter]
-#define SEC_BEGIN() unsigned long long _sec_t0 = __builtin_amdgcn_s_memtime()
-#define SEC_MARK(k) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
-        if(lane == 0) { unsigned long long *_b = nh_sec + (blockIdx.x & 1023) * 32; \
-                        atomicAdd(&_b[k], _n - _sec_t0); atomicAdd(&_b[16 + (k)], 1ull); } \
-        _sec_t0 = __builtin_amdgcn_s_memtime(); } while(0)
-extern "C" int navhip_debug_sections(unsigned long long *out, int reset)
-{
-    static unsigned long long h[1024 * 32];
-    if(hipMemcpyFromSymbol(h, HIP_SYMBOL(nh_sec), sizeof(h)) != hipSuccess) return 1;
-    for(int k = 0; k < 32; k++) { out[k] = 0; for(int b = 0; b < 1024; b++) out[k] += h[b * 32 + k]; }
-    if(reset) { for(auto &x : h) x = 0; hipMemcpyToSymbol(HIP_SYMBOL(nh_sec), h, sizeof(h)); }
-    return 0;
-}
-#else
-#define SEC_BEGIN()
-#define SEC_MARK(k)
-#endif
-// cost of one section under real contention: scripts/dup_prof.py builds private copies of the library
-// that run section NH_DUP twice (same results) and compares tick times
-#ifndef NH_DUP
-#define NH_DUP 0
-#endif
-#define DUP_BARRIER() asm volatile("" ::: "memory")
+__constant__ double c_exp2_64[64] = { NH_EXP2_64_TABLE };
 
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-
-// ---------------------------------------------------------------------------------------------
-// tile lookups (tile.c:547 M_Tile_DescForPoint2D, nav.c:4055/4070)
-// ---------------------------------------------------------------------------------------------
-struct tiledesc { int chunk_r, chunk_c, tile_r, tile_c; };
-
-__device__ __forceinline__ bool tile_for_point(const nh_step_params &P, float x, float z, tiledesc &out)
-{
-    const float width = (float)(P.map.w * 256), height = (float)(P.map.h * 256);
-    if(x > P.map_x || x < P.map_x - width) return false;
-    if(z < P.map_z || z > P.map_z + height) return false;
-    int chunk_r = (int)(fabsf(P.map_z - z) / 256.0f);      // exact: division by a power of two
-    int chunk_c = (int)(fabsf(P.map_x - x) / 256.0f);
-    chunk_r = min(max(chunk_r, 0), P.map.h - 1);
-    chunk_c = min(max(chunk_c, 0), P.map.w - 1);
-    float base_x = P.map_x - (float)(chunk_c * 256);
-    float base_z = P.map_z + (float)(chunk_r * 256);
-    int tile_r = (int)(fabsf(base_z - z) / 4.0f);
-    int tile_c = (int)(fabsf(base_x - x) / 4.0f);
-    out.chunk_r = chunk_r; out.chunk_c = chunk_c;
-    out.tile_r = min(max(tile_r, 0), 63);
-    out.tile_c = min(max(tile_c, 0), 63);
-    return true;
-}
-
-// Entity_NavLayerWithRadius, entity.c:554
-__device__ __forceinline__ int nav_layer_for(uint32_t flags, float radius)
-{
-    int base = (flags & NAVHIP_ENTITY_FLAG_WATER) ? 4 : (flags & NAVHIP_ENTITY_FLAG_AIR) ? 8 : 0;
-    if(radius >= 15.0f) return base + 3;
-    if(radius >= 10.0f) return base + 2;
-    if(radius >= 5.0f)  return base + 1;
-    return base;
-}
-
-__device__ __forceinline__ bool pos_pathable(const nh_step_params &P, int layer, float x, float z)
-{
-    tiledesc t;
-    if(!tile_for_point(P, x, z, t)) return false;     // reference asserts; off-map = not pathable
-    const uint8_t *cost = P.map.layers[layer].cost;
-    return cost[((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c]
-           != NAVHIP_COST_IMPASSABLE;
-}
-
-__device__ __forceinline__ bool pos_blocked(const nh_step_params &P, int layer, float x, float z)
-{
-    tiledesc t;
-    if(!tile_for_point(P, x, z, t)) return false;
-    const uint16_t *bl = P.map.layers[layer].blockers;
-    if(!bl) return false;
-    return bl[((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c] > 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// flow-field sampling (nav.c:3407 n_interpolated_flow_dir, :3468 N_DesiredPointSeekVelocity)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ v2 flow_dir_vec(int dir)           // N_FlowDir, field.c:2428
-{
-    const float d = 0.70710678118654757f;                     // (float)(1.0f / sqrt(2.0f))
-    switch(dir) {
-    case NAVHIP_FD_NW: return mkv( d, -d);
-    case NAVHIP_FD_N:  return mkv( 0.0f, -1.0f);
-    case NAVHIP_FD_NE: return mkv(-d, -d);
-    case NAVHIP_FD_W:  return mkv( 1.0f, 0.0f);
-    case NAVHIP_FD_E:  return mkv(-1.0f, 0.0f);
-    case NAVHIP_FD_SW: return mkv( d,  d);
-    case NAVHIP_FD_S:  return mkv( 0.0f, 1.0f);
-    case NAVHIP_FD_SE: return mkv(-d,  d);
-    default:           return mkv(0.0f, 0.0f);
-    }
-}
-
-// One thread per agent (k_agent_pre): the four taps are fetched one after the other; the latency is
-// hidden by the other agents of the wave instead of by the other lanes of a wave-per-agent kernel.
-__device__ v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &status)
-{
-    tiledesc t;
-    if(flock < 0 || !P.flock_field_slot || !P.field_pool || !tile_for_point(P, pos.x, pos.z, t)) {
-        status |= NAVHIP_ST_FIELD_MISS;
-        return mkv(0.0f, 0.0f);
-    }
-    const int nchunks = P.map.w * P.map.h;
-    const int32_t *slots = P.flock_field_slot + (size_t)flock * nchunks;
-    int slot = slots[t.chunk_r * P.map.w + t.chunk_c];
-    if(slot < 0) {
-        status |= NAVHIP_ST_FIELD_MISS;
-        return mkv(0.0f, 0.0f);
-    }
-    const uint8_t *base_ff = P.field_pool + ((size_t)slot << 12);
-    int base_dir = base_ff[t.tile_r * 64 + t.tile_c] & 0xf;
-    if(base_dir == NAVHIP_FD_NONE) status |= NAVHIP_ST_FIELD_NONE;
-
-    // M_Tile_Bounds (tile.c:356): two sequential float subtractions / additions
-    float bx = (P.map_x - (float)(t.chunk_c * 256)) - (float)(t.tile_c * 4);
-    float bz = (P.map_z + (float)(t.chunk_r * 256)) + (float)(t.tile_r * 4);
-    float cx = bx - 4.0f / 2.0f, cz = bz + 4.0f / 2.0f;
-    float dx = pos.x - cx, dz = pos.z - cz;
-    int dc = (dx < 0.0f) ? 1 : -1;
-    int dr = (dz > 0.0f) ? 1 : -1;
-    float wc = fminf(fabsf(dx) / 4.0f, 1.0f);
-    float wr = fminf(fabsf(dz) / 4.0f, 1.0f);
-    const int   sdc[4] = {0, dc, 0, dc};
-    const int   sdr[4] = {0, 0, dr, dr};
-    const float sw[4]  = {(1.0f - wc) * (1.0f - wr), wc * (1.0f - wr), (1.0f - wc) * wr, wc * wr};
-
-    v2 acc = mkv(0.0f, 0.0f);
-    float wsum = 0.0f;
-#pragma unroll
-    for(int i = 0; i < 4; i++) {
-        if(sw[i] <= 0.0f) continue;
-        // M_Tile_RelativeDesc, tile.c:391
-        int abs_r = t.chunk_r * 64 + t.tile_r + sdr[i];
-        int abs_c = t.chunk_c * 64 + t.tile_c + sdc[i];
-        if(abs_r < 0 || abs_r >= P.map.h * 64 || abs_c < 0 || abs_c >= P.map.w * 64) continue;
-        int cr = abs_r >> 6, cc = abs_c >> 6, tr = abs_r & 63, tc = abs_c & 63;
-        const uint8_t *ff = base_ff;
-        if(cr != t.chunk_r || cc != t.chunk_c) {
-            int s2 = slots[cr * P.map.w + cc];
-            if(s2 < 0) continue;
-            ff = P.field_pool + ((size_t)s2 << 12);
-        }
-        int dir = ff[tr * 64 + tc] & 0xf;
-        if(dir == NAVHIP_FD_NONE) continue;
-        v2 scaled = vscale(flow_dir_vec(dir), sw[i]);
-        acc = vadd(acc, scaled);
-        wsum += sw[i];
-    }
-    if(wsum < 1e-6f || vlen(acc) < 1e-6f)
-        return flow_dir_vec(base_dir);
-    return vnormal(acc);
-}
-
-// move_work_in.ent_des_v: host supplied, or sampled from the device field pool (vdes_xz == NULL or
-// a NaN entry)
-__device__ __forceinline__ v2 load_vdes(const nh_step_params &P, int uid, int flock, v2 me,
-                                        uint32_t &status)
-{
-    if(P.vdes_xz) {
-        v2 v = mkv(P.vdes_xz[2 * uid], P.vdes_xz[2 * uid + 1]);
-        if(v.x == v.x) return v;
-    }
-    return sample_flow(P, flock, me, status);
-}
-
 // ---------------------------------------------------------------------------------------------
 // spatial hash (bitmap_grid.h): build
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t bg_scale(float v) { return __float2int_rn(v * 256.0f); }   // BG_SCALE_F
-
-__device__ __forceinline__ int sp_cell_of(const nh_grid &G, int32_t ix, int32_t iy)
-{
-    int cx = (ix - G.origin_x) >> 12;             // BG_CELL_LOG2_INT = 8 + 4
-    int cy = (iy - G.origin_y) >> 12;
-    cx = min(max(cx, 0), G.grid_w - 1);
-    cy = min(max(cy, 0), G.grid_h - 1);
-    return cy * G.grid_w + cx;
-}
-
 #define SP_MAX_QUERY_R 30   /* largest query radius of the movement tick (separation, movement.c:1695) */
 // Optional slab filter: when a rank steps only the entities [work_begin, work_end), nothing farther
 // than the largest query radius of the tick (r = 30) from the bounding box of THOSE entities can be
@@ -313,30 +86,19 @@ __device__ __forceinline__ bool sp_in_box(const int32_t *box, int32_t ix, int32_
     return (int64_t)ix >= -(int64_t)box[0] - m && (int64_t)ix <= (int64_t)box[1] + m
         && (int64_t)iy >= -(int64_t)box[2] - m && (int64_t)iy <= (int64_t)box[3] + m;
 }
-
-// Every inserted entity also gets a packed 32-byte RECORD -- {pos.x, pos.z, radius, flags} |
-// {vel.x, vel.z, state, -} -- so that the neighbour gathers of the agent step (separation, neighbour
-// classification, garrison filter) fetch one or two 16-byte halves of one line per neighbour instead
-// of 4-8 bytes from each of three to five structure-of-arrays lines.
+// Pass 1: cell of every entity + its arrival rank in the cell (the counters are zero on entry:
+// cleared at allocation, then by k_sp_scan_add of the previous build).
 __global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz, int n,
-                                                  int32_t *ent_ix, int32_t *ent_iy,
-                                                  int32_t *ent_cell, int32_t *cell_count,
-                                                  const int32_t *box, nh_pack_src src, float4 *rec)
+                                                  int32_t *ent_cell, int32_t *ent_rank,
+                                                  int32_t *cell_count, const int32_t *box)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if(i >= n) return;
-    const float px = pos_xz[2 * i], pz = pos_xz[2 * i + 1];
-    int32_t ix = bg_scale(px), iy = bg_scale(pz);
-    ent_ix[i] = ix; ent_iy[i] = iy;
+    const int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
     if(!sp_in_box(box, ix, iy)) { ent_cell[i] = -1; return; }
-    int c = sp_cell_of(G, ix, iy);
+    const int c = sp_cell_of(G, ix, iy);
     ent_cell[i] = c;
-    atomicAdd(&cell_count[c], 1);
-    if(rec) {
-        rec[2 * i]     = make_float4(px, pz, src.radius[i], __uint_as_float(src.flags[i]));
-        rec[2 * i + 1] = make_float4(src.vel_xz[2 * i], src.vel_xz[2 * i + 1],
-                                     __uint_as_float((uint32_t)src.state[i]), 0.0f);
-    }
+    ent_rank[i] = atomicAdd(&cell_count[c], 1);
 }
 
 // exclusive scan of cell_count[0..ncells) -> cell_start[0..ncells], two passes over 1024-cell
@@ -368,7 +130,7 @@ __global__ __launch_bounds__(1024) void k_sp_scan_local(const int32_t *cell_coun
 }
 
 __global__ __launch_bounds__(1024) void k_sp_scan_add(int32_t *cell_start, const int32_t *block_sum,
-                                                      int ncells, int nblocks)
+                                                      int ncells, int nblocks, int32_t *zero_counts)
 {
     __shared__ int32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -396,42 +158,41 @@ __global__ __launch_bounds__(1024) void k_sp_scan_add(int32_t *cell_start, const
     for(int k = 0; k < 16; k++) off += wsum[k];
     const int i = blockIdx.x * 1024 + t;
     if(i < ncells) cell_start[i] += off;
+    if(zero_counts && i < ncells) zero_counts[i] = 0;     // consumed by k_sp_scan_local: clean for the next build
     if(last && t == 0) cell_start[ncells] = tot;
 }
-
-__global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, int n,
-                                                    const int32_t *cell_start, int32_t *cell_fill,
-                                                    int32_t *sorted_id)
+// Pass 3: entities into their cell's range in arrival order (no atomics: the rank is known)
+__global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, const int32_t *ent_rank, int n,
+                                                    const int32_t *cell_start, int32_t *tmp_id)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if(i >= n) return;
-    int c = ent_cell[i];
+    const int c = ent_cell[i];
     if(c < 0) return;                            // outside the slab filter
-    int slot = cell_start[c] + atomicAdd(&cell_fill[c], 1);
-    sorted_id[slot] = i;
+    tmp_id[cell_start[c] + ent_rank[i]] = i;
 }
 
-// Per-cell order: bg_ent_insert pushes at the head of the cell's overflow chain and
-// bg_ent_cleanup copies the chain head-first (bitmap_grid.h:1102-1121,1515-1521), so after
-// inserting uids 0..n-1 each cell holds its elements in DESCENDING uid order.
-__global__ __launch_bounds__(256) void k_sp_order(const int32_t *cell_start, int ncells,
-                                                  int32_t *sorted_id, const int32_t *ent_ix,
-                                                  const int32_t *ent_iy, int32_t *sx, int32_t *sy)
+// Pass 4: per-cell order + the pool records.  bg_ent_insert pushes at the head of the cell's
+// overflow chain and bg_ent_cleanup copies the chain head-first (bitmap_grid.h:1102-1121,
+// 1515-1521), so after inserting uids 0..n-1 each cell holds its elements in DESCENDING uid order:
+// the final slot of an element is its cell's start + the number of cell mates with a larger uid
+// (one thread per element counts them: cells hold a handful of elements).
+__global__ __launch_bounds__(256) void k_sp_place(nh_grid G, const float *pos_xz, nh_pack_src src,
+                                                  const int32_t *ent_cell, const int32_t *tmp_id,
+                                                  int npool_max, int work_begin, int work_end,
+                                                  float4 *recA, float2 *recV, int32_t *pool_of)
 {
-    int c = blockIdx.x * 256 + threadIdx.x;
-    if(c >= ncells) return;
-    int b = cell_start[c], e = cell_start[c + 1];
-    for(int i = b + 1; i < e; i++) {            // insertion sort, descending; cells are tiny
-        int32_t v = sorted_id[i];
-        int j = i - 1;
-        while(j >= b && sorted_id[j] < v) { sorted_id[j + 1] = sorted_id[j]; j--; }
-        sorted_id[j + 1] = v;
-    }
-    for(int i = b; i < e; i++) {
-        int32_t id = sorted_id[i];
-        sx[i] = ent_ix[id];
-        sy[i] = ent_iy[id];
-    }
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if(t >= npool_max) return;
+    if(t >= G.cell_start[G.grid_w * G.grid_h]) return;
+    const int i = tmp_id[t];
+    const int c = ent_cell[i];
+    const int b = G.cell_start[c], e = G.cell_start[c + 1];
+    int larger = 0;
+    for(int q = b; q < e; q++) larger += tmp_id[q] > i;
+    const int slot = b + larger;
+    pool_record(i, pos_xz, src, work_begin, work_end, recA[slot], recV[slot]);
+    pool_of[i] = slot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,9 +202,8 @@ __global__ __launch_bounds__(256) void k_sp_order(const int32_t *cell_start, int
 // order.  Cells of one fine row are contiguous in the cell-sorted pool, so a (block,row) pair is
 // one contiguous range that the lanes test 64 elements at a time; ballot + prefix popcount
 // appends hits in order and enforces `maxout` exactly where the reference stops.
+// The hits are POOL SLOTS (uid = recA[slot].w >> 8).
 // ---------------------------------------------------------------------------------------------
-// Extent of a query in fine cells + whether it takes the reference's wide-query path
-// (bitmap_grid.h:1389-1397); returns false when the query box misses the grid.
 // inclusive prefix sum over the 64 lanes: four row_shr steps inside each row of 16, then the two
 // row broadcasts (DPP; zero fill outside the row)
 __device__ __forceinline__ int wave_incl_scan(int v)
@@ -456,25 +216,6 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
-
-struct sp_extent { int cx_lo, cx_hi, cy_lo, cy_hi; bool wide; };
-
-__device__ __forceinline__ bool sp_query_extent(const nh_grid &G, int32_t icx, int32_t icy, int32_t ir,
-                                                sp_extent &E)
-{
-    const int32_t imnx = icx - ir, imxx = icx + ir, imny = icy - ir, imxy = icy + ir;
-    // _bg_cell_extent, bitmap_grid.h:1236
-    if(imxx < G.origin_x || imxy < G.origin_y) return false;
-    const int32_t span_x = (int32_t)((uint32_t)G.grid_w << 12), span_y = (int32_t)((uint32_t)G.grid_h << 12);
-    if(imnx >= G.origin_x + span_x || imny >= G.origin_y + span_y) return false;
-    E.cx_lo = max((imnx - G.origin_x) >> 12, 0);
-    E.cy_lo = max((imny - G.origin_y) >> 12, 0);
-    E.cx_hi = min((imxx - G.origin_x) >> 12, G.grid_w - 1);
-    E.cy_hi = min((imxy - G.origin_y) >> 12, G.grid_h - 1);
-    E.wide = (int64_t)(E.cx_hi - E.cx_lo + 1) * (E.cy_hi - E.cy_lo + 1) * 4 >= (int64_t)G.grid_w * G.grid_h * 3;
-    return true;
-}
-
 // out_d2 (optional, [maxout]): squared fixed-point distance of every hit (fits int32 for the
 // ranges the movement tick uses), so that a narrower query around the same point can be derived
 // from this one without touching memory again.
@@ -496,14 +237,15 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
             bool hit = false;
             int64_t d2 = 0;
             if(k < npool) {
-                int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
+                const float4 c = G.recA[k];
+                int64_t dx = (int64_t)bg_scale(c.x) - icx, dy = (int64_t)bg_scale(c.y) - icy;
                 d2 = dx * dx + dy * dy;
                 hit = d2 <= ir2;
             }
             uint64_t m = __ballot(hit);
             int p = written + __popcll(m & ((1ull << lane) - 1ull));
             if(hit && p < maxout) {
-                out_ids[p] = (uint32_t)G.sorted_id[k];
+                out_ids[p] = (uint32_t)k;
                 if(out_d2) out_d2[p] = (int32_t)d2;
             }
             written += __popcll(m);
@@ -512,11 +254,9 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
         return written;
     }
 
-    // Visiting order (bitmap_grid.h:1408-1466): coarse 8x8 blocks row-major; inside a block fine
-    // rows top to bottom, cells left to right, packed elements in order.  The cells of one fine
-    // row inside one coarse block are contiguous in the cell-sorted pool: a SEGMENT.  One pass
-    // resolves 64 segments in visiting order -- lane = ((coarse row, block column) << 3) | fine row,
-    // with CB (a power of two) block columns and 8 / CB coarse rows per pass, so the r = 30 and
+    // A SEGMENT = the cells of one fine row inside one coarse block, contiguous in the pool.  One
+    // pass resolves 64 segments in visiting order -- lane = ((coarse row, block column) << 3) | fine
+    // row, with CB (a power of two) block columns and 8 / CB coarse rows per pass, so the r = 30 and
     // r = 10 boxes of the movement tick (at most 2 x 2 coarse blocks) take a single pass: two
     // cell_start loads per lane, a DPP prefix sum, then the candidates 64 at a time, each lane
     // finding its segment by binary search over the prefix.
@@ -560,15 +300,17 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
                 bool hit = false;
                 int32_t d2s = 0;
                 if(k >= 0) {
+                    const float4 c = G.recA[k];
+                    const int32_t sx = bg_scale(c.x), sy = bg_scale(c.y);
                     if(small) {
                         // (elements clamped into a border cell may be far away: range-check before
                         // squaring in 32 bits)
-                        const int32_t dx = G.sx[k] - icx, dy = G.sy[k] - icy;
+                        const int32_t dx = sx - icx, dy = sy - icy;
                         const bool near = (uint32_t)(dx + 32767) < 65535u && (uint32_t)(dy + 32767) < 65535u;
                         d2s = near ? dx * dx + dy * dy : 0x7fffffff;
                         hit = d2s <= (int32_t)ir2;
                     }else{
-                        const int64_t dx = (int64_t)G.sx[k] - icx, dy = (int64_t)G.sy[k] - icy;
+                        const int64_t dx = (int64_t)sx - icx, dy = (int64_t)sy - icy;
                         const int64_t d2 = dx * dx + dy * dy;
                         hit = d2 <= ir2;
                         d2s = (int32_t)d2;
@@ -577,7 +319,7 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
                 uint64_t m = __ballot(hit);
                 int p = written + __popcll(m & ((1ull << lane) - 1ull));
                 if(hit && p < maxout) {
-                    out_ids[p] = (uint32_t)G.sorted_id[k];
+                    out_ids[p] = (uint32_t)k;
                     if(out_d2) out_d2[p] = d2s;
                 }
                 written += __popcll(m);
@@ -589,23 +331,23 @@ __device__ int sp_query_wave(const nh_grid &G, float x, float z, float range, in
 }
 
 // filter_garrisoned, position.c:100-119: walk backwards, overwrite with the current last
-__device__ __forceinline__ uint32_t rec_flags(const float4 *rec, uint32_t id)
+__device__ __forceinline__ uint32_t slot_bits(const nh_grid &G, uint32_t slot)
 {
-    return __float_as_uint(rec[2 * id].w);
+    return __float_as_uint(G.recA[slot].w);
 }
 
-__device__ int filter_garrisoned_wave(const float4 *rec, uint32_t *ids, int count, int lane)
+__device__ int filter_garrisoned_wave(const nh_grid &G, uint32_t *ids, int count, int lane)
 {
     bool any = false;
     for(int base = 0; base < count; base += 64) {
         int k = base + lane;
-        any |= (k < count) && (rec_flags(rec, ids[k]) & NAVHIP_ENTITY_FLAG_GARRISONED);
+        any |= (k < count) && (slot_bits(G, ids[k]) & NH_PB_GARRISONED);
     }
     if(!__any(any)) return count;
     int ret = count;
     if(lane == 0) {
         for(int i = count - 1; i >= 0; i--) {
-            if(rec_flags(rec, ids[i]) & NAVHIP_ENTITY_FLAG_GARRISONED) {
+            if(slot_bits(G, ids[i]) & NH_PB_GARRISONED) {
                 ids[i] = ids[ret - 1];
                 ret--;
             }
@@ -618,155 +360,6 @@ __device__ int filter_garrisoned_wave(const float4 *rec, uint32_t *ids, int coun
 // ---------------------------------------------------------------------------------------------
 // ClearPath (clearpath.c), one wave per problem
 // ---------------------------------------------------------------------------------------------
-struct cpent { v2 pos, vel; float radius; };
-struct ray   { v2 point, dir; };
-
-// slope of a line as C_InfiniteLineIntersection takes it (collision.c:823-831): NaN = vertical
-__device__ __forceinline__ float line_slope(v2 dir)
-{
-    return fabsf(dir.x) < CP_EPS ? __builtin_nanf("") : __fdiv_rn(dir.z, dir.x);
-}
-
-// C_InfiniteLineIntersection, collision.c:820 (including the l2.point term of the vertical-l2
-// branch, :840), with the two slopes s1/s2 = line_slope(dir) supplied by the caller (they only
-// depend on the line, and every line meets many others)
-__device__ __forceinline__ bool line_isect(v2 p1, float s1, v2 p2, float s2, v2 &out)
-{
-    bool n1 = s1 != s1, n2 = s2 != s2;
-    if(n1 && n2) return false;
-    if(fabsf(s1 - s2) < CP_EPS) return false;
-    if(n1 && !n2) {
-        out.x = p1.x;
-        out.z = (p1.x - p2.x) * s2 + p2.z;
-    }else if(!n1 && n2) {
-        out.x = p2.x;
-        out.z = (p2.x - p1.x) * s1 + p2.z;
-    }else{
-        out.x = __fdiv_rn((s1 * p1.x - s2 * p2.x + p2.z - p1.z), (s1 - s2));
-        out.z = s2 * (out.x - p2.x) + p2.z;
-    }
-    return true;
-}
-
-// `a / b < 0.0f` of C_RayRayIntersection2D (collision.c:862-871) without the division when the sign
-// rule is safe: for finite a, b with a == 0 or |a| >= 2^-100 and |b| <= 2^20 the quotient cannot
-// underflow to -0, so it is negative exactly when a != 0 and the signs differ (b = +-0 included:
-// a/+-0 = +-inf).  ok = false -> the caller divides.
-__device__ __forceinline__ bool quot_neg_fast(float a, float b, bool &ok)
-{
-    const float aa = fabsf(a);
-    ok = ok && (aa >= 0x1p-100f || a == 0.0f) && aa < __builtin_inff() && fabsf(b) <= 0x1p20f;
-    return a != 0.0f && ((__float_as_int(a) ^ __float_as_int(b)) < 0);
-}
-
-// C_RayRayIntersection2D, collision.c:854
-__device__ __forceinline__ bool ray_isect(v2 p1, v2 d1, float s1, v2 p2, v2 d2, float s2, v2 &out)
-{
-    v2 p;
-    if(!line_isect(p1, s1, p2, s2, p)) return false;
-    bool ok = true;
-    const float a1 = p.x - p1.x, a2 = p.z - p1.z, a3 = p.x - p2.x, a4 = p.z - p2.z;
-    bool neg = quot_neg_fast(a1, d1.x, ok);
-    neg |= quot_neg_fast(a2, d1.z, ok);
-    neg |= quot_neg_fast(a3, d2.x, ok);
-    neg |= quot_neg_fast(a4, d2.z, ok);
-    if(!ok) {
-        neg = __fdiv_rn(a1, d1.x) < 0.0f || __fdiv_rn(a2, d1.z) < 0.0f
-           || __fdiv_rn(a3, d2.x) < 0.0f || __fdiv_rn(a4, d2.z) < 0.0f;
-    }
-    if(neg) return false;
-    out = p;
-    return true;
-}
-
-// compute_vo_edges, clearpath.c:130
-__device__ __forceinline__ void vo_edges(const cpent &ent, const cpent &nb, v2 &out_right, v2 &out_left)
-{
-    v2 e2n = vnormal(vsub(nb.pos, ent.pos));
-    v2 right = mkv(-e2n.z, e2n.x);
-    right = vscale(right, nb.radius + ent.radius + 0.0f);      // CLEARPATH_BUFFER_RADIUS
-    v2 right_tangent = vadd(nb.pos, right);
-    v2 left_tangent = vsub(nb.pos, right);
-    out_right = vnormal(vsub(right_tangent, ent.pos));
-    out_left = vnormal(vsub(left_tangent, ent.pos));
-}
-
-// compute_vo :153 / compute_hrvo :180 -> (apex, left, right) + the slopes of the two sides
-__device__ __forceinline__ void make_cone(const cpent &ent, const cpent &nb, bool hrvo, v2 &apex,
-                                          v2 &left, v2 &right, float &sl, float &sr)
-{
-    vo_edges(ent, nb, right, left);
-    sl = line_slope(left); sr = line_slope(right);
-    const v2 vo_apex = vadd(ent.pos, nb.vel);
-    apex = vo_apex;
-    if(hrvo) {
-        v2 apex_off = vscale(vadd(ent.vel, nb.vel), 0.5f);
-        v2 rvo_apex = vadd(ent.pos, apex_off);
-        v2 centerline = vadd(left, right);
-        float det = (centerline.x * ent.vel.z) - (centerline.z * ent.vel.x);
-        apex = rvo_apex;
-        if(det > CP_EPS || det < -CP_EPS) {
-            // :196-212: (rvo_apex, left) x (vo_apex, right) or the mirrored pair
-            const bool pos = det > CP_EPS;
-            v2 p = rvo_apex;
-            line_isect(rvo_apex, pos ? sl : sr, vo_apex, pos ? sr : sl, p);
-            apex = p;
-        }
-    }
-}
-
-// inside_pcr, clearpath.c:249.  The combined obstacle lives in LDS as two float4 per cone:
-//   cones[2c]   = {apex.x, apex.z, slope(left), slope(right)}
-//   cones[2c+1] = {left.x, left.z, right.x, right.z}
-// (both rays of a cone start at its apex, rays_repr :291; ray 2c is the left side, 2c+1 the right).
-//
-// One cone, evaluated exactly as the reference does (normalisation with IEEE sqrt/divide; the
-// reference normalises test - apex once per ray, with identical operands both times):
-// true when `test` is strictly inside the cone.
-__device__ __forceinline__ bool cone_contains_exact(float4 A, float4 B, v2 test)
-{
-    v2 ptt = mkv(test.x - A.x, test.z - A.y);
-    if(vlen(ptt) < CP_EPS) return false;
-    ptt = vnormal(ptt);
-    float left_det = (ptt.z * B.x) - (ptt.x * B.y);
-    if(left_det < CP_EPS) return false;
-    float right_det = (ptt.z * B.z) - (ptt.x * B.w);
-    if(right_det > -CP_EPS) return false;
-    return true;
-}
-
-// The same verdict from cheap arithmetic (one v_rsq_f32 instead of a correctly rounded sqrt and two
-// IEEE divides) whenever every comparison is decided with a safety margin; 2 = too close to a
-// threshold, the caller falls back to the exact evaluation.  The exact determinant differs from
-// (p.z*d.x - p.x*d.z)/|p| by < 4e-7 (six roundings of magnitudes <= 1) and the cheap one by
-// < 1.5e-6, so a margin of 2e-5 around the +-1/1024 thresholds leaves an order of magnitude of
-// slack; the |p| < 1/1024 test gets a relative margin of 1e-4.  The decisions -- hence the result
-// of inside_pcr -- are identical to the exact evaluation by construction.
-__device__ __forceinline__ int cone_contains_fast(float4 A, float4 B, v2 test)
-{
-    const float MARG = 2e-5f;
-    const float px = test.x - A.x, pz = test.z - A.y;
-    const float s = px * px + pz * pz;
-    const float inv = __builtin_amdgcn_rsqf(s);
-    const float len = s * inv;
-    if(!(s > 0.0f) || !(s < 1e30f) || fabsf(len - CP_EPS) <= CP_EPS * 1e-4f) return 2;
-    if(len < CP_EPS) return 0;
-    const float detl = (pz * B.x - px * B.y) * inv;
-    if(fabsf(detl - CP_EPS) <= MARG) return 2;
-    if(detl < CP_EPS) return 0;
-    const float detr = (pz * B.z - px * B.w) * inv;
-    if(fabsf(detr + CP_EPS) <= MARG) return 2;
-    if(detr > -CP_EPS) return 0;
-    return 1;
-}
-
-__device__ __forceinline__ bool cone_contains(float4 A, float4 B, v2 test)
-{
-    int v = cone_contains_fast(A, B, test);
-    if(v == 2) v = cone_contains_exact(A, B, test) ? 1 : 0;
-    return v == 1;
-}
-
 __device__ __forceinline__ bool inside_pcr(const float4 *cones, int n_cones, v2 test)
 {
     for(int c = 0; c < n_cones; c++)
@@ -937,68 +530,9 @@ __device__ v2 clearpath_wave(const cpent &ent, v2 des_v, float *dyn, int n_dyn, 
     }
     return mkv(0.0f, 0.0f);
 }
-
 // ---------------------------------------------------------------------------------------------
-// cohesion_force (movement.c:1653): one thread per flock member
+// cohesion_force (movement.c:1653)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool state_is_still(int s)
-{
-    return s == NAVHIP_STATE_ARRIVED || s == NAVHIP_STATE_WAITING;     // ent_still, movement.c:652
-}
-__device__ __forceinline__ bool state_uses_point_seek(int s)
-{
-    return s == NAVHIP_STATE_MOVING || s == NAVHIP_STATE_SURROUND_ENTITY
-        || s == NAVHIP_STATE_ENTER_ENTITY_RANGE;
-}
-
-// 2^(j/64), j = 0..63, correctly rounded doubles
-__constant__ double c_exp2_64[64] = {
-    0x1p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
-    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92dep+0,
-    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
-    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
-    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
-    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cdp+0,
-    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
-    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
-    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
-    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e5p+0,
-    0x1.9c49182a3f09p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
-    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
-    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
-    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
-    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e454p+0, 0x1.fa7c1819e90d8p+0};
-
-// (float)exp((double)a) for a in (-inf, ~88]: the reference evaluates libm's double exp on a float
-// argument and rounds to float (movement.c:1671,1731).  Table-driven double evaluation,
-// exp(a) = 2^(k/64) * exp(r), |r| <= ln2/128, degree-5 polynomial: < 2 ulp in double, so the float
-// rounding agrees with a correctly rounded exp except with probability ~1e-8 per call.  tab =
-// 64-entry table in LDS.  k = rint(x * 64/ln2) falls out of the low
-// mantissa bits of x * 64/ln2 + 1.5 * 2^52 (one FMA), and no final select is needed -- the clamped
-// argument -104 gives 6.8e-46, which the f64 -> f32 conversion rounds to +0 like every value below
-// half the smallest denormal (the true cut-off is a = -103.972).  The final scaling by 2^(k>>6) is
-// an integer add on the exponent field (the result stays a normal double for every argument in
-// [-104, 89]).  Checked against glibc's exp on 3e8 random arguments in [-110, 6], 3e8 in [-21, 89]
-// and on every float in [-104.5, -102]: no mismatch.
-__device__ __forceinline__ float exp_f32_magic(float a, const double *tab)
-{
-    const double x = (double)fmaxf(a, -104.0f);
-    const double z = __builtin_fma(x, 0x1.71547652b82fep+6, 0x1.8p52);   // 64/ln2
-    const double kd = z - 0x1.8p52;
-    const int k = (int)__double_as_longlong(z);
-    double r = __builtin_fma(-kd, 0x1.62e42fefa0000p-7, x);              // ln2/64, high part
-    r = __builtin_fma(-kd, 0x1.cf79abc9e3b3ap-46, r);                    //         low part
-    double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
-    p = __builtin_fma(p, r, 1.0 / 6);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    const double v = tab[k & 63] * p;
-    const long long bits = __double_as_longlong(v) + ((long long)(k >> 6) << 52);
-    return (float)__longlong_as_double(bits);
-}
-
 // float t = (len - 50.0f*0.75) / 50.0f of movement.c:1668 (the reference evaluates it in double and
 // rounds to float).  For len >= 16 the f32 subtraction is exact and the division by 50 as
 // reciprocal multiply + one FMA correction (Markstein) reproduces the double-then-float result for
@@ -1385,12 +919,11 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
         coh_xz[2 * uid + 1] = ret.z;
     }
 }
-
 // ---------------------------------------------------------------------------------------------
-// k_agent_step: one wave per entity
+// wave-per-agent pieces (k_agent_full, k_cp_wave)
 // ---------------------------------------------------------------------------------------------
-// waves (= agents) per workgroup of k_agent_step; 2 measured best (1: 0.490, 2: 0.483, 4: 0.494,
-// 8: 0.521 ms/tick in one session, scripts/ab_lib.py)
+// waves (= agents) per workgroup of the wave-per-agent kernels; 2 measured best for the round-1
+// k_agent_step (1: 0.490, 2: 0.483, 4: 0.494, 8: 0.521 ms/tick in one session)
 #ifndef AG_WAVES
 #define AG_WAVES 2
 #endif
@@ -1407,9 +940,9 @@ struct wave_lds {
     uint32_t ids10d[128];                      // r=10 list derived from the r=30 list
 };
 
-// separation_force, movement.c:1690.  ids30/n30 already gathered; wave-uniform result.
-__device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_radius,
-                              uint32_t my_flags, const uint32_t *ids30, int n30, float *sep,
+// separation_force, movement.c:1690.  ids30/n30 already gathered (pool slots); wave-uniform result.
+__device__ v2 separation_wave(const nh_grid &G, uint32_t my_slot, v2 me, float my_radius,
+                              uint32_t my_bits, const uint32_t *ids30, int n30, float *sep,
                               float scaled_max_force, int lane, const double *exp_tab)
 {
     if(n30 == 0) return mkv(0.0f, 0.0f);
@@ -1417,21 +950,13 @@ __device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_
         int k = base + lane;
         if(k < n30) {
             uint32_t curr = ids30[k];
-            const float4 ra = P.grid.rec[2 * curr];                         // {pos, radius, flags}
+            const float4 ra = G.recA[curr];                                 // {pos, radius, bits}
             uint32_t fl = __float_as_uint(ra.w);
             v2 term = mkv(0.0f, 0.0f);
-            bool skip = (curr == (uint32_t)uid) || !(fl & NAVHIP_ENTITY_FLAG_MOVABLE)
-                     || ((my_flags & NAVHIP_ENTITY_FLAG_AIR) != (fl & NAVHIP_ENTITY_FLAG_AIR));
+            bool skip = (curr == my_slot) || !(fl & NH_PB_MOVABLE) || ((my_bits ^ fl) & NH_PB_AIR);
             if(!skip) {
-                v2 cp = mkv(ra.x, ra.y);
-                float radius = my_radius + ra.z + 0.0f;                     // SEPARATION_BUFFER_DIST
-                v2 diff = vsub(cp, me);
-                float len = vlen(diff);
-                if(!(len < CP_EPS)) {
-                    float t = __fdiv_rn(len - radius * 0.85f, len);
-                    float scale = exp_f32_magic(fminf(-20.0f * t, 40.0f), exp_tab);
-                    term = vscale(diff, scale);
-                }
+                v2 t2;
+                if(separation_term(me, my_radius, mkv(ra.x, ra.y), ra.z, exp_tab, t2)) term = t2;
             }
             ((f2*)sep)[k] = f2{term.x, term.z};
         }
@@ -1447,82 +972,8 @@ __device__ v2 separation_wave(const nh_step_params &P, int uid, v2 me, float my_
     return vtrunc(ret, scaled_max_force);
 }
 
-// arrive_force_point, movement.c:1546
-__device__ __forceinline__ v2 arrive_force(v2 me, v2 vel, v2 target, v2 vdes, bool los,
-                                           float max_speed, int hz, float scaled_max_force)
-{
-    v2 desired;
-    if(los) {
-        desired = vsub(target, me);
-        float distance = vlen(desired);
-        desired = vnormal(desired);
-        desired = vscale(desired, max_speed / (float)hz);
-        if(distance < 10.0f)
-            desired = vscale(desired, distance / 10.0f);
-    }else{
-        desired = vscale(vdes, max_speed / (float)hz);
-    }
-    return vtrunc(vsub(desired, vel), scaled_max_force);
-}
-
-// nullify_impass_components, movement.c:1831
-__device__ __forceinline__ v2 nullify_impass(const nh_step_params &P, int layer, v2 pos, v2 f)
-{
-    bool on_blocked = pos_blocked(P, layer, pos.x, pos.z);
-    if(f.x > 0 && (!pos_pathable(P, layer, pos.x + 4.0f, pos.z)
-               || (!on_blocked && pos_blocked(P, layer, pos.x + 4.0f, pos.z)))) f.x = 0.0f;
-    if(f.x < 0 && (!pos_pathable(P, layer, pos.x - 4.0f, pos.z)
-               || (!on_blocked && pos_blocked(P, layer, pos.x - 4.0f, pos.z)))) f.x = 0.0f;
-    if(f.z > 0 && (!pos_pathable(P, layer, pos.x, pos.z + 4.0f)
-               || (!on_blocked && pos_blocked(P, layer, pos.x, pos.z + 4.0f)))) f.z = 0.0f;
-    if(f.z < 0 && (!pos_pathable(P, layer, pos.x, pos.z - 4.0f)
-               || (!on_blocked && pos_blocked(P, layer, pos.x, pos.z - 4.0f)))) f.z = 0.0f;
-    return f;
-}
-
-// The five tile probes of nullify_impass_components (own tile, +-4 wu in x and z), issued together
-// at the start of the step instead of one dependent load after another.
-struct tile_probes { bool path[5], blk[5]; };     // 0 self, 1 x+4, 2 x-4, 3 z+4, 4 z-4
-
-// One thread per agent (k_agent_pre): ten booleans packed as bits 0-4 pathable, 5-9 blocked.
-__device__ __forceinline__ uint32_t probe_tiles_bits(const nh_step_params &P, int layer, v2 pos)
-{
-    const float px[5] = {pos.x, pos.x + 4.0f, pos.x - 4.0f, pos.x, pos.x};
-    const float pz[5] = {pos.z, pos.z, pos.z, pos.z + 4.0f, pos.z - 4.0f};
-    const uint8_t *cost = P.map.layers[layer].cost;
-    const uint16_t *bl = P.map.layers[layer].blockers;
-    uint32_t bits = 0;
-#pragma unroll
-    for(int i = 0; i < 5; i++) {
-        tiledesc t;
-        if(!tile_for_point(P, px[i], pz[i], t)) continue;
-        const size_t idx = ((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c;
-        if(cost[idx] != NAVHIP_COST_IMPASSABLE) bits |= 1u << i;
-        if(bl && bl[idx] > 0) bits |= 32u << i;
-    }
-    return bits;
-}
-
-__device__ __forceinline__ tile_probes unpack_probes(uint32_t bits)
-{
-    tile_probes T;
-#pragma unroll
-    for(int i = 0; i < 5; i++) { T.path[i] = (bits >> i) & 1; T.blk[i] = (bits >> (5 + i)) & 1; }
-    return T;
-}
-
-__device__ __forceinline__ v2 nullify_impass_pre(const tile_probes &T, v2 f)
-{
-    const bool on_blocked = T.blk[0];
-    if(f.x > 0 && (!T.path[1] || (!on_blocked && T.blk[1]))) f.x = 0.0f;
-    if(f.x < 0 && (!T.path[2] || (!on_blocked && T.blk[2]))) f.x = 0.0f;
-    if(f.z > 0 && (!T.path[3] || (!on_blocked && T.blk[3]))) f.z = 0.0f;
-    if(f.z < 0 && (!T.path[4] || (!on_blocked && T.blk[4]))) f.z = 0.0f;
-    return f;
-}
-
 // find_neighbours, movement.c:2768: classify the r=10 query result into dynamic / static lists
-__device__ void classify_neighbours(const nh_step_params &P, int uid, uint32_t my_flags,
+__device__ void classify_neighbours(const nh_grid &G, uint32_t my_slot, uint32_t my_bits,
                                     const uint32_t *ids10, int n10, float *dyn, int &n_dyn,
                                     float *stat, int &n_stat, int lane)
 {
@@ -1533,21 +984,20 @@ __device__ void classify_neighbours(const nh_step_params &P, int uid, uint32_t m
         float rec[5] = {0, 0, 0, 0, 0};
         if(k < n10) {
             uint32_t curr = ids10[k];
-            const float4 ra = P.grid.rec[2 * curr];                         // {pos, radius, flags}
+            const float4 ra = G.recA[curr];
             uint32_t fl = __float_as_uint(ra.w);
             float rad = ra.z;
-            bool skip = (curr == (uint32_t)uid) || !(fl & NAVHIP_ENTITY_FLAG_MOVABLE) || (rad == 0.0f)
-                     || ((my_flags & NAVHIP_ENTITY_FLAG_AIR) != (fl & NAVHIP_ENTITY_FLAG_AIR));
+            bool skip = (curr == my_slot) || !(fl & NH_PB_MOVABLE) || (rad == 0.0f)
+                     || ((my_bits ^ fl) & NH_PB_AIR);
             if(!skip) {
-                const float4 rb = P.grid.rec[2 * curr + 1];                 // {vel, state, -}
-                v2 vel = mkv(rb.x, rb.y);
                 rec[0] = ra.x; rec[1] = ra.y;
                 rec[4] = rad;
-                if(state_is_still((int)__float_as_uint(rb.z)) || vlen(vel) < 0.3f) {   // CLEARPATH_STILL_SPEED
-                    cls = 2;                       // static: velocity forced to zero (:2817)
+                if(fl & NH_PB_STATIC) {
+                    cls = 2;                       // static: velocity forced to zero (:2820)
                 }else{
+                    const float2 vel = G.recV[curr];
                     cls = 1;
-                    rec[2] = vel.x; rec[3] = vel.z;
+                    rec[2] = vel.x; rec[3] = vel.y;
                 }
             }
         }
@@ -1601,157 +1051,180 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
     return written;
 }
 
-// What the scalar pre-pass hands to the wave-per-agent kernel (24 bytes per entity)
-enum { AM_IDLE = 0,        // still or combat held: velocity 0, no neighbour work
-       AM_ZERO_VPREF,      // turning / formation assignment not ready: vpref = 0, ClearPath still runs
-       AM_POINT_SEEK, AM_ENEMY_SEEK, AM_FORM_CELL, AM_FORM_POINT,
-       AM_UNSUPPORTED };   // formation state without formation inputs
-struct nh_pre_rec {
-    float    vdes[2];
-    float    arrive[2];    // the arrive term of the state's steering force, already truncated
-    uint16_t probes;       // probe_tiles_bits
-    uint8_t  status;
-    uint8_t  mode;
-    float    vpref_cap;    // speed / hz      (movement.c:1880 and friends)
-    float    vel_cap;      // max_speed / hz  (movement.c:3464)
-    uint32_t pad;
-};
-static_assert(sizeof(nh_pre_rec) == 32, "nh_pre_rec");
-
-// k_agent_pre: one THREAD per entity.  Everything of move_velocity_work that needs no neighbour
-// list and is the same for all 64 lanes of a wave-per-agent kernel -- desired direction (flow-field
-// sampling), the arrive force of the state's steering behaviour, the five tile probes of
-// nullify_impass_components -- is evaluated here with all lanes busy.
-__global__ __launch_bounds__(256) void k_agent_pre(nh_step_params P, nh_pre_rec *pre, nh_step_outs O)
+// ---------------------------------------------------------------------------------------------
+// k_agent_nbr: one THREAD per pool slot
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
 {
-    const int uid = P.work_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if(uid >= P.work_end) return;
-    const int state = P.state[uid];
-    const uint32_t my_flags = P.flags[uid];
-    nh_pre_rec R;
-    R.vdes[0] = R.vdes[1] = R.arrive[0] = R.arrive[1] = 0.0f;
-    R.probes = 0; R.status = 0; R.mode = AM_IDLE; R.pad = 0;
-    R.vpref_cap = P.speed[uid] / (float)P.hz;
-    R.vel_cap = P.max_speed[uid] / (float)P.hz;
-    if(!state_is_still(state) && !(my_flags & NAVHIP_ENTITY_FLAG_COMBAT_HELD)) {
-        const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-        const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-        const float my_radius = P.radius[uid], max_speed = P.max_speed[uid];
-        const int flock = P.flock[uid], hz = P.hz;
-        const float scaled_max_force = (float)((double)(0.75f / (float)hz) * 20.0);   // SCALED_MAX_FORCE
-        const int layer = nav_layer_for(my_flags, my_radius);
-        uint32_t status = 0;
-        v2 vdes = mkv(0.0f, 0.0f), arrive = mkv(0.0f, 0.0f);
-        const bool form = state == NAVHIP_STATE_MOVING_IN_FORMATION || state == NAVHIP_STATE_ARRIVING_TO_CELL;
-        if(state == NAVHIP_STATE_TURNING) {
-            R.mode = AM_ZERO_VPREF;
-        }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_uses_point_seek(state)) {
-            vdes = load_vdes(P, uid, flock, me, status);
-            if(state_uses_point_seek(state)) {
-                const bool los = P.has_dest_los[uid] != 0;
-                const v2 target = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]) : me;
-                arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
-                R.mode = AM_POINT_SEEK;
-            }else{
-                // arrive_force_enemies, movement.c:1593
-                v2 desired = vscale(vdes, max_speed / (float)hz);
-                arrive = vtrunc(vsub(desired, vel), scaled_max_force);
-                R.mode = AM_ENEMY_SEEK;
-            }
-        }else if(P.form_ready && form) {
-            if(!P.form_ready[uid]) {
-                R.mode = AM_ZERO_VPREF;
-            }else{
-                vdes = load_vdes(P, uid, flock, me, status);
-                if(state == NAVHIP_STATE_ARRIVING_TO_CELL) {
-                    // arrive_force_cell :1574 (no velocity term, no truncation)
-                    const v2 cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
-                    v2 desired = vsub(cell, me);
-                    float distance = vlen(desired);
-                    if(distance < 10.0f) desired = vscale(desired, distance / 10.0f);
-                    else                 desired = vscale(vdes, max_speed / (float)hz);
-                    arrive = desired;
-                    R.mode = AM_FORM_CELL;
-                }else{
-                    const bool los = P.has_dest_los[uid] != 0;
-                    const v2 target = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]) : me;
-                    arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
-                    R.mode = AM_FORM_POINT;
-                }
-            }
-        }else{
-            R.mode = AM_UNSUPPORTED;
-            status |= NAVHIP_ST_UNSUPPORTED;
-        }
-        if(R.mode >= AM_POINT_SEEK && R.mode <= AM_FORM_POINT)
-            R.probes = (uint16_t)probe_tiles_bits(P, layer, me);
-        R.vdes[0] = vdes.x; R.vdes[1] = vdes.z; R.arrive[0] = arrive.x; R.arrive[1] = arrive.z;
-        R.status = (uint8_t)status;
-    }
-    pre[uid] = R;
-    if(O.vdes_xz) { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
+    __shared__ double exp_tab[64];
+    if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if(k >= npool_max || k >= G.cell_start[G.grid_w * G.grid_h]) return;
+    if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) return;         // no work item (or outside the slab)
+    nbr_walk_thread(G, k, scaled_max_force, exp_tab, NB);
 }
 
-// k_agent_step: one WAVE per entity -- the neighbour-dependent part: r = 30 query + separation,
-// the priority ladder of the steering force, r = 10 neighbours, ClearPath, truncation.
-__global__ __launch_bounds__(AG_WAVES * 64) void k_agent_step(nh_step_params P, const float *coh_xz,
-                                                    const nh_pre_rec *pre, nh_step_outs O,
-                                                    float scaled_max_force, double force_thresh)
+// wave-aggregated append to a device work list: one atomic per wave and list
+__device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which, bool want, int uid)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(want);
+    if(!m) return;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if(lane == leader) base = atomicAdd(&WL.count[which], __popcll(m));
+    base = __shfl(base, leader);
+    if(want) WL.ids[(size_t)which * WL.stride + base + __popcll(m & ((1ull << lane) - 1ull))] = uid;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_agent_mid: one THREAD per entity (uid order: every per-entity input / output is coalesced)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
+                                                   nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
+                                                   float scaled_max_force, double force_thresh)
+{
+    const int uid = P.work_begin + blockIdx.x * 256 + threadIdx.x;
+    const bool live = uid < P.work_end;
+    int disp = DISP_DONE;
+    if(live) {
+        nh_mid_rec R;
+        v2 out_vel;
+        disp = mid_thread(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R, out_vel);
+        if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
+        if(O.vpref_xz) { O.vpref_xz[2 * uid] = R.vpref[0]; O.vpref_xz[2 * uid + 1] = R.vpref[1]; }
+        if(disp == DISP_DONE) {
+            post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid],
+                        P.radius[uid], out_vel, R.vel_cap, R.status, O);
+        }else{
+            mid[uid] = R;
+        }
+    }
+#pragma unroll
+    for(int w = 0; w < NH_WL_COUNT; w++)
+        worklist_push(WL, w, live && disp == DISP_LIGHT1 + w, uid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_cp_light: one THREAD per listed agent.  The four light lists (1..4 neighbours) are laid out one
+// after the other in units of 64 entries, so a wave only holds agents with the same neighbour count.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cp_light(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                 nh_worklists WL, nh_step_outs O)
+{
+    __shared__ float4 cones[2 * NH_LIGHT_MAX * 64];
+    const int lane = threadIdx.x;
+    int cnt[4], nw[4], tot = 0;
+#pragma unroll
+    for(int w = 0; w < 4; w++) { cnt[w] = WL.count[NH_WL_LIGHT1 + w]; nw[w] = (cnt[w] + 63) >> 6; tot += nw[w]; }
+    for(int wv = blockIdx.x; wv < tot; wv += gridDim.x) {
+        int which = 0, rel = wv;
+#pragma unroll
+        for(int w = 0; w < 3; w++) if(which == w && rel >= nw[w]) { rel -= nw[w]; which = w + 1; }
+        const int idx = rel * 64 + lane;
+        bool punt = false;
+        int uid = -1;
+        if(idx < cnt[which]) {
+            uid = WL.ids[(size_t)(NH_WL_LIGHT1 + which) * WL.stride + idx];
+            const nh_mid_rec R = mid[uid];
+            const uint32_t c = NB.cnt[uid];
+            cpent ent;
+            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+            ent.radius = P.radius[uid];
+            v2 res;
+            const bool found = cp_light_thread(P.grid, ent, mkv(R.vpref[0], R.vpref[1]), (int)(c & 0xff),
+                                               (int)((c >> 8) & 0xff), NB.list + uid, (size_t)NB.stride,
+                                               cones + lane, 64, res);
+            if(found)
+                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, res, R.vel_cap, R.status, O);
+            punt = !found;
+        }
+        worklist_push(WL, NH_WL_WAVE, punt, uid);      // remove_furthest + retry run on a wave
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_cp_wave: one WAVE per listed agent -- ClearPath only (neighbour lists from k_agent_nbr)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AG_WAVES * 64) void k_cp_wave(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                           nh_worklists WL, nh_step_outs O)
+{
+    __shared__ wave_lds lds[AG_WAVES];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    wave_lds &W = lds[wib];
+    const int count = WL.count[NH_WL_WAVE];
+    for(int idx = blockIdx.x * AG_WAVES + wib; idx < count; idx += gridDim.x * AG_WAVES) {
+        const int uid = WL.ids[(size_t)NH_WL_WAVE * WL.stride + idx];
+        const nh_mid_rec R = mid[uid];
+        const uint32_t c = NB.cnt[uid];
+        const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+        cpent ent;
+        ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+        ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+        ent.radius = P.radius[uid];
+        wave_sync();
+        {   // lanes 0..31 dynamic, 32..63 static
+            const bool isdyn = lane < 32;
+            const int j = isdyn ? lane : lane - 32;
+            if(j < (isdyn ? n_dyn : n_stat)) {
+                const int slot = NB.list[(size_t)lane * NB.stride + uid];
+                const cpent nb = nbr_cpent(P.grid, slot, !isdyn);
+                float *dst = (isdyn ? W.dyn : W.stat) + 5 * j;
+                dst[0] = nb.pos.x; dst[1] = nb.pos.z; dst[2] = nb.vel.x; dst[3] = nb.vel.z; dst[4] = nb.radius;
+            }
+        }
+        wave_sync();
+        const cp_scratch cps = {W.u.rays, (float*)W.d2_30, (float*)W.ids10d, (int32_t*)W.ids30};
+        const v2 nv = clearpath_wave(ent, mkv(R.vpref[0], R.vpref[1]), W.dyn, n_dyn, W.stat, n_stat, cps, lane);
+        if(lane == 0)
+            post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_agent_full: one WAVE per listed agent, the whole neighbour-dependent part on the wave: r = 30
+// query + garrison filter + separation, the priority ladder, r = 10 neighbours, ClearPath.
+// (The exact path for what the thread-per-agent walk declines.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, const float *coh_xz,
+                                                              const nh_mid_rec *mid, nh_worklists WL,
+                                                              nh_step_outs O, float scaled_max_force,
+                                                              double force_thresh)
 {
     __shared__ wave_lds lds[AG_WAVES];
     __shared__ double exp_tab[64];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
     __syncthreads();
-    const int uid = P.work_begin + blockIdx.x * AG_WAVES + wib;
-    if(uid >= P.work_end) return;
     wave_lds &W = lds[wib];
-
-    SEC_BEGIN();
-    const nh_pre_rec R = pre[uid];
-    v2 out_vel = mkv(0.0f, 0.0f), vpref = mkv(0.0f, 0.0f);
-    if(R.mode != AM_IDLE && R.mode != AM_UNSUPPORTED) {
-        const uint32_t my_flags = P.flags[uid];
+    const nh_grid &G = P.grid;
+    const int count = WL.count[NH_WL_FULL];
+    for(int idx = blockIdx.x * AG_WAVES + wib; idx < count; idx += gridDim.x * AG_WAVES) {
+        const int uid = WL.ids[(size_t)NH_WL_FULL * WL.stride + idx];
+        const nh_mid_rec R = mid[uid];
+        const uint32_t my_slot = (uint32_t)G.pool_of[uid];
+        const uint32_t my_bits = slot_bits(G, my_slot);
         const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
         const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
         const float my_radius = P.radius[uid];
         const int flock = P.flock[uid];
         const int hz = P.hz;
         int n30raw = -1;                 // size of the unfiltered r=30 list (-1: no such query)
-
+        v2 vpref = mkv(0.0f, 0.0f);
+        wave_sync();
         if(R.mode != AM_ZERO_VPREF) {
-            const tile_probes probes = unpack_probes(R.probes);
             const v2 arrive = mkv(R.arrive[0], R.arrive[1]);
             // separation (movement.c:1690): r = 30 query, cap 128
-            SEC_MARK(0);
-#if NH_DUP == 1
-            sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
-            wave_sync(); DUP_BARRIER();
-#endif
-            int n30 = sp_query_wave(P.grid, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
+            int n30 = sp_query_wave(G, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
             wave_sync();
-            SEC_MARK(1);
             n30raw = n30;
-#if NH_DUP == 2
-            derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
-            filter_garrisoned_wave(P.grid.rec, W.ids30, n30, lane);
-            wave_sync(); DUP_BARRIER();
-#endif
-            const int n10d = derive_r10(P.grid, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
-            n30 = filter_garrisoned_wave(P.grid.rec, W.ids30, n30, lane);
+            const int n10d = derive_r10(G, me, W.ids30, W.d2_30, n30raw, W.ids10d, lane);
+            n30 = filter_garrisoned_wave(G, W.ids30, n30, lane);
             if(n10d < 0) n30raw = -1; else n30raw = n10d;
-            SEC_MARK(2);
-#if NH_DUP == 3
-            {
-                const v2 sdup = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
-                                                W.u.sep, scaled_max_force, lane, exp_tab);
-                if(sdup.x == 12345.678f) W.d2_30[0] = 1;        // keep it alive
-                wave_sync(); DUP_BARRIER();
-            }
-#endif
-            const v2 separation = separation_wave(P, uid, me, my_radius, my_flags, W.ids30, n30,
+            const v2 separation = separation_wave(G, my_slot, me, my_radius, my_bits, W.ids30, n30,
                                                   W.u.sep, scaled_max_force, lane, exp_tab);
-            SEC_MARK(3);
             v2 steer;
             if(R.mode == AM_ENEMY_SEEK) {
                 // enemy_seek_vpref :1946 (no priorities, no nullify)
@@ -1770,6 +1243,7 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_step(nh_step_params P, 
                 }else{
                     cohesion = (flock >= 0) ? mkv(coh_xz[2 * uid], coh_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
                 }
+                steer = mkv(0.0f, 0.0f);
                 for(int prio = 0; prio < 3; prio++) {
                     if(prio == 0) {
                         v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
@@ -1789,96 +1263,41 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_step(nh_step_params P, 
                     }else{
                         steer = arrive;
                     }
-                    steer = nullify_impass_pre(probes, steer);
+                    steer = nullify_impass_bits(R.probes, steer);
                     if((double)vlen(steer) > force_thresh) break;
                 }
             }
             v2 accel = vscale(steer, 1.0f / 1.0f);
-            vpref = vtrunc(vadd(vel, accel), R.vpref_cap);
+            vpref = vtrunc(vadd(vel, accel), P.speed[uid] / (float)hz);
             if(R.mode == AM_FORM_CELL || R.mode == AM_FORM_POINT) {
                 const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
                 if(vlen(f_drag) > CP_EPS)                            // :1935 / :2018
                     vpref = vtrunc(vpref, (float)(((double)P.speed[uid] * 0.75) / (double)hz));
             }
         }
-
         // find_neighbours :2768: r = 10 query, cap 512 -- taken from the r = 30 list when that list
         // is complete (n30raw now holds the derived count, -1 = not derivable)
-        SEC_MARK(4);
         uint32_t *ids10 = W.u.ids10;
         int n10;
         if(n30raw >= 0) {
             ids10 = W.ids10d;
             n10 = n30raw;
         }else{
-            n10 = sp_query_wave(P.grid, me.x, me.z, 10.0f, 512, W.u.ids10, lane);
+            n10 = sp_query_wave(G, me.x, me.z, 10.0f, 512, W.u.ids10, lane);
             wave_sync();
         }
-        n10 = filter_garrisoned_wave(P.grid.rec, ids10, n10, lane);
+        n10 = filter_garrisoned_wave(G, ids10, n10, lane);
         int n_dyn, n_stat;
-#if NH_DUP == 4
-        filter_garrisoned_wave(P.grid.rec, ids10, n10, lane);
-        classify_neighbours(P, uid, my_flags, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
-        wave_sync(); DUP_BARRIER();
-#endif
-        classify_neighbours(P, uid, my_flags, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
-        SEC_MARK(5);
+        classify_neighbours(G, my_slot, my_bits, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
         cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
         // the neighbour lists are dead from here on: their LDS becomes the candidate queue
         const cp_scratch cps = {W.u.rays, (float*)W.d2_30, (float*)W.ids10d, (int32_t*)W.ids30};
-#if NH_DUP == 5
-        {
-            v2 ndup = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, cps, lane);
-            if(ndup.x == 12345.678f) W.dyn[0] = 1.0f;
-            wave_sync(); DUP_BARRIER();
-        }
-#endif
-        v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, cps, lane);
-        SEC_MARK(6);
-        out_vel = nv;                     // k_agent_post truncates it to max_speed / hz (:3464)
-    }
-    if(lane == 0) {
-        O.vel_xz[2 * uid] = out_vel.x; O.vel_xz[2 * uid + 1] = out_vel.z;
-        if(O.vpref_xz) { O.vpref_xz[2 * uid] = vpref.x; O.vpref_xz[2 * uid + 1] = vpref.z; }
-    }
-}
-
-// k_agent_post: one THREAD per entity -- the position accept test of entity_compute_update
-// (movement.c:2336-2358; the heading gate stays on the host) and the status byte.
-__global__ __launch_bounds__(256) void k_agent_post(nh_step_params P, const nh_pre_rec *pre, nh_step_outs O)
-{
-    const int uid = P.work_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if(uid >= P.work_end) return;
-    const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-    const nh_pre_rec R = pre[uid];
-    uint32_t status = R.status;
-    v2 new_pos = me;
-    // vec2_truncate(new velocity, max_speed / hz), movement.c:3464 (k_agent_step leaves it raw:
-    // there one agent is one wave, here 64 agents share the instructions)
-    const v2 out_vel = vtrunc(mkv(O.vel_xz[2 * uid], O.vel_xz[2 * uid + 1]), R.vel_cap);
-    O.vel_xz[2 * uid] = out_vel.x; O.vel_xz[2 * uid + 1] = out_vel.z;
-    if(!state_is_still(P.state[uid])) {
-        const uint32_t my_flags = P.flags[uid];
-        const int layer = nav_layer_for(my_flags, P.radius[uid]);
-        v2 cand = vadd(me, out_vel);
-        const bool on_blocked = pos_blocked(P, layer, me.x, me.z);
-        bool cand_path = false, cand_blk = false;
-        {
-            tiledesc t;
-            if(tile_for_point(P, cand.x, cand.z, t)) {               // one lookup, two planes
-                const size_t idx = ((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 12) + t.tile_r * 64 + t.tile_c;
-                const uint16_t *bl = P.map.layers[layer].blockers;
-                cand_path = P.map.layers[layer].cost[idx] != NAVHIP_COST_IMPASSABLE;
-                cand_blk = bl && bl[idx] > 0;
-            }
-        }
-        if(vlen(out_vel) > 0 && cand_path && (on_blocked || !cand_blk)) {
-            new_pos = cand;
-            status |= NAVHIP_ST_MOVED;
+        const v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, cps, lane);
+        if(lane == 0) {
+            if(O.vpref_xz) { O.vpref_xz[2 * uid] = vpref.x; O.vpref_xz[2 * uid + 1] = vpref.z; }
+            post_thread(P, uid, me, P.state[uid], P.flags[uid], my_radius, nv, R.vel_cap, R.status, O);
         }
     }
-    if(O.new_pos_xz) { O.new_pos_xz[2 * uid] = new_pos.x; O.new_pos_xz[2 * uid + 1] = new_pos.z; }
-    if(O.status) O.status[uid] = (uint8_t)status;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1890,8 +1309,10 @@ __global__ __launch_bounds__(256) void k_spatial_query(nh_grid G, const float *q
 {
     const int q = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if(q >= nq) return;
-    int n = sp_query_wave(G, query_xz[2 * q], query_xz[2 * q + 1], range, maxout,
-                          out_ids + (size_t)q * maxout, lane);
+    uint32_t *mine = out_ids + (size_t)q * maxout;
+    int n = sp_query_wave(G, query_xz[2 * q], query_xz[2 * q + 1], range, maxout, mine, lane);
+    wave_sync();
+    for(int k = lane; k < n; k += 64) mine[k] = slot_bits(G, mine[k]) >> NH_PB_UID_SHIFT;   // slot -> uid
     if(lane == 0) out_counts[q] = n;
 }
 
@@ -1918,15 +1339,65 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_clearpath(int nq, const float
     if(lane == 0) { out[2 * q] = r.x; out[2 * q + 1] = r.z; }
 }
 
+// The thread-per-agent ClearPath search on the same problems (tests: the light path on its own).
+// n_dyn + n_stat <= NH_LIGHT_MAX; found[q] = 0 when the search punts (no admissible candidate).
+__global__ __launch_bounds__(64) void k_clearpath_light(int nq, const float *ent, const float *des_v,
+                                                        const float *dyn, const int32_t *n_dyn,
+                                                        const float *stat, const int32_t *n_stat,
+                                                        float *out, int32_t *found)
+{
+    __shared__ float4 cones[2 * NH_LIGHT_MAX * 64];
+    __shared__ float4 recA[2 * NH_LIGHT_MAX * 64];
+    __shared__ float2 recV[2 * NH_LIGHT_MAX * 64];
+    __shared__ int32_t list[64 * 64];
+    const int lane = threadIdx.x, q = blockIdx.x * 64 + lane;
+    if(q >= nq) return;
+    // a private little pool per thread: slots lane * 8 + j
+    nh_grid G = {};
+    G.recA = recA; G.recV = recV;
+    const int nd = n_dyn[q], ns = n_stat[q];
+    for(int j = 0; j < nd + ns; j++) {
+        const bool st = j >= nd;
+        const float *src = (st ? stat : dyn) + (size_t)q * 160 + 5 * (st ? j - nd : j);
+        recA[lane * 8 + j] = make_float4(src[0], src[1], src[4], 0.0f);
+        recV[lane * 8 + j] = make_float2(src[2], src[3]);
+        list[(st ? 32 + (j - nd) : j) * 64 + lane] = lane * 8 + j;
+    }
+    cpent e; e.pos = mkv(ent[5 * q], ent[5 * q + 1]); e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]);
+    e.radius = ent[5 * q + 4];
+    const v2 dv = mkv(des_v[2 * q], des_v[2 * q + 1]);
+    // admissible as it is? (mid_thread's test)
+    bool in = false;
+    for(int j = 0; j < nd + ns; j++) {
+        const bool st = j >= nd;
+        const cpent nb = nbr_cpent(G, lane * 8 + j, st);
+        if(vlen(vsub(nb.pos, e.pos)) < CP_EPS) continue;
+        v2 apex, left, right; float sl, sr;
+        make_cone(e, nb, !st, apex, left, right, sl, sr);
+        in = in || cone_contains(make_float4(apex.x, apex.z, sl, sr),
+                                 make_float4(left.x, left.z, right.x, right.z), vadd(e.pos, dv));
+    }
+    v2 r = dv;
+    bool ok = true;
+    if(in) ok = cp_light_thread(G, e, dv, nd, ns, list + lane, 64, cones + lane, 64, r);
+    out[2 * q] = r.x; out[2 * q + 1] = r.z;
+    found[q] = ok ? 1 : 0;
+}
+
+__global__ void k_wl_zero(int32_t *count)
+{
+    if(threadIdx.x < NH_WL_COUNT) count[threadIdx.x] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
+// Four dependent launches, no memset (cell_count is zeroed by k_sp_scan_add once it has been
+// consumed; the box of the slab filter is the exception).
+void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
                              int slab_begin, int slab_end, hipStream_t s)
 {
     const int n = G.n, ncells = G.grid_w * G.grid_h;
-    hipMemsetAsync(S.cell_count, 0, sizeof(int32_t) * (size_t)ncells, s);
-    hipMemsetAsync(S.cell_fill, 0, sizeof(int32_t) * (size_t)ncells, s);
     // a strict sub-range of the entities is stepped: hash only what its queries can reach
     const int32_t *box = nullptr;
     if(S.box && (slab_begin > 0 || slab_end < n)) {
@@ -1936,19 +1407,29 @@ void nh_launch_spatial_build(const nh_grid &G, const float *d_pos_xz, nh_spatial
                                d_pos_xz, slab_begin, slab_end, S.box);
         box = S.box;
     }
+    G.cell_start = S.cell_start; G.recA = S.recA; G.recV = S.recV; G.pool_of = S.pool_of;
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
-                           S.ent_ix, S.ent_iy, S.ent_cell, S.cell_count, box, S.src, S.src.flags ? S.rec : nullptr);
+                           S.ent_cell, S.ent_rank, S.cell_count, box);
     const int nblocks = (ncells + 1023) / 1024;
     hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(1024), 0, s, S.cell_count, S.cell_start,
                        S.block_sum, ncells);
     hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(1024), 0, s, S.cell_start, S.block_sum, ncells,
-                       nblocks);
-    if(n > 0)
-        hipLaunchKernelGGL(k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, S.ent_cell, n,
-                           S.cell_start, S.cell_fill, S.sorted_id);
-    hipLaunchKernelGGL(k_sp_order, dim3((ncells + 255) / 256), dim3(256), 0, s, S.cell_start, ncells,
-                       S.sorted_id, S.ent_ix, S.ent_iy, S.sx, S.sy);
+                       nblocks, S.cell_count);
+    if(n > 0) {
+        hipLaunchKernelGGL(k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, S.ent_cell, S.ent_rank, n,
+                           S.cell_start, S.tmp_id);
+        hipLaunchKernelGGL(k_sp_place, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, S.src,
+                           S.ent_cell, S.tmp_id, n, slab_begin, slab_end, S.recA, S.recV, S.pool_of);
+    }
+}
+
+void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t s)
+{
+    if(P.n_ents > 0 && P.work_end > P.work_begin) {
+        const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
+        hipLaunchKernelGGL(k_agent_nbr, dim3((P.n_ents + 255) / 256), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
+    }
 }
 
 // scratch of the cohesion launch: wave prefix | bin counts | bin fills | bin starts | scan block sums
@@ -2001,7 +1482,7 @@ static void coh_regroup(const nh_step_params &P, const coh_scratch &C, int which
     hipLaunchKernelGGL(k_sp_scan_local, dim3(C.nblocks), dim3(1024), 0, s, C.bin_count, C.bin_start,
                        C.block_sum, C.nb);
     hipLaunchKernelGGL(k_sp_scan_add, dim3(C.nblocks), dim3(1024), 0, s, C.bin_start, C.block_sum, C.nb,
-                       C.nblocks);
+                       C.nblocks, (int32_t*)nullptr);
     if(plan_from_bins)
         hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start,
                            P.flock_offsets, (const int32_t*)nullptr, P.n_flocks, C.wave_off, (int32_t*)nullptr);
@@ -2047,31 +1528,27 @@ void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *
     coh_regroup(P, C, *parity, false, s);
     *parity ^= 1;
 }
-
-size_t nh_pre_rec_bytes() { return sizeof(nh_pre_rec); }
-
-// the scalar pre-pass needs only the snapshot and the field pool: it may run before the spatial
-// hash and the cohesion term are ready
-void nh_launch_agent_pre(const nh_step_params &P, void *d_pre, const nh_step_outs &O, hipStream_t s)
+// k_agent_mid + the consumers of its work lists.  The list counters alternate between two sets:
+// a launch sequence uses one and zeroes the other for its successor (no memset on the stream).
+void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
+                            nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s)
 {
     const int nwork = P.work_end - P.work_begin;
-    if(P.n_ents > 0 && nwork > 0)
-        hipLaunchKernelGGL(k_agent_pre, dim3((nwork + 255) / 256), dim3(256), 0, s, P, (nh_pre_rec*)d_pre, O);
-}
-
-void nh_launch_agent_step(const nh_step_params &P, float *d_coh, const void *d_pre, const nh_step_outs &O,
-                          hipStream_t s)
-{
-    const int nwork = P.work_end - P.work_begin;
-    if(P.n_ents > 0 && nwork > 0) {
-        // SCALED_MAX_FORCE and the 1 % force threshold of movement.c:1870-1905 (same for every agent)
-        const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
-        const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
-        hipLaunchKernelGGL(k_agent_step, dim3((nwork + AG_WAVES - 1) / AG_WAVES), dim3(AG_WAVES * 64), 0, s, P,
-                           d_coh, (const nh_pre_rec*)d_pre, O, smf, thresh);
-        hipLaunchKernelGGL(k_agent_post, dim3((nwork + 255) / 256), dim3(256), 0, s, P,
-                           (const nh_pre_rec*)d_pre, O);
-    }
+    if(!(P.n_ents > 0 && nwork > 0)) return;
+    // SCALED_MAX_FORCE and the 1 % force threshold of movement.c:1870-1905 (same for every agent)
+    const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
+    const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
+    int32_t *other = WL.count + (parity ^ 1) * NH_WL_COUNT;
+    WL.count += parity * NH_WL_COUNT;
+    hipLaunchKernelGGL(k_wl_zero, dim3(1), dim3(64), 0, s, other);
+    hipLaunchKernelGGL(k_agent_mid, dim3((nwork + 255) / 256), dim3(256), 0, s, P, NB, (const float*)d_coh,
+                       d_mid, WL, O, smf, thresh);
+    const int grid_l = min(2048, (nwork + 63) / 64 + 4);
+    hipLaunchKernelGGL(k_cp_light, dim3(grid_l), dim3(64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O);
+    const int grid_w = min(4096, (nwork + AG_WAVES - 1) / AG_WAVES);
+    hipLaunchKernelGGL(k_cp_wave, dim3(grid_w), dim3(AG_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O);
+    hipLaunchKernelGGL(k_agent_full, dim3(min(grid_w, 1024)), dim3(AG_WAVES * 64), 0, s, P, (const float*)d_coh,
+                       (const nh_mid_rec*)d_mid, WL, O, smf, thresh);
 }
 
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,
@@ -2084,9 +1561,13 @@ void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, flo
 
 void nh_launch_clearpath(int nq, const float *ent, const float *des_v, const float *dyn,
                          const int32_t *n_dyn, const float *stat, const int32_t *n_stat, float *out,
-                         hipStream_t s)
+                         int32_t *light_found, hipStream_t s)
 {
-    if(nq > 0)
+    if(nq <= 0) return;
+    if(light_found)
+        hipLaunchKernelGGL(k_clearpath_light, dim3((nq + 63) / 64), dim3(64), 0, s, nq, ent, des_v, dyn,
+                           n_dyn, stat, n_stat, out, light_found);
+    else
         hipLaunchKernelGGL(k_clearpath, dim3((nq + AG_WAVES - 1) / AG_WAVES), dim3(AG_WAVES * 64), 0, s, nq, ent,
                            des_v, dyn, n_dyn, stat, n_stat, out);
 }

@@ -1,0 +1,449 @@
+// agent_thread.h -- the thread-per-agent bodies of the movement step (one THREAD = one agent).
+//
+//   nbr_walk_thread   the two neighbour gathers of move_velocity_work in ONE walk over the spatial
+//                     hash: separation_force (movement.c:1690, r = 30, cap 128) accumulated in the
+//                     reference's candidate order, and find_neighbours (movement.c:2768, r = 10, cap
+//                     512, 32 + 32) as lists of pool slots.  Needs only the entity snapshot.
+//   mid_thread        desired direction (flow sampling), arrive force, tile probes, the priority
+//                     ladder of point_seek_vpref (:1870) and friends -> preferred velocity; then the
+//                     first question of clearpath_new_velocity (clearpath.c:604): is des_v already
+//                     outside every velocity obstacle?  Most agents finish here.
+//   cp_light_thread   the ClearPath candidate search (compute_vo_xpoints :321,
+//                     compute_vdes_proj_points :344, compute_vnew :368) for agents with at most
+//                     NH_LIGHT_MAX neighbours, sequentially in the reference's own order.
+//   post_thread       vec2_truncate(v, max_speed / hz) (:3464) + the position accept test of
+//                     entity_compute_update (:2336-2358).
+//
+// Why a thread per agent: in the benchmark world an agent has ~35 separation candidates and ~2
+// ClearPath neighbours; a wave per agent left most lanes idle in every phase (1 017 wave
+// instructions per agent, round 1).  Agents that DO fill a wave -- more than NH_LIGHT_MAX ClearPath
+// neighbours: >= 100 ray pairs x cone tests -- go to the wave-per-agent kernels (agent_kernels.hip).
+//
+// No cross-lane operations here: compiles for the device and, with -DNH_HOSTSIM, for the host-side
+// unit tests (tests/hostsim).
+#pragma once
+#include "agent_math.h"
+
+enum { AM_IDLE = 0,        // still or combat held: velocity 0, no neighbour work
+       AM_ZERO_VPREF,      // turning / formation assignment not ready: vpref = 0, ClearPath still runs
+       AM_POINT_SEEK, AM_ENEMY_SEEK, AM_FORM_CELL, AM_FORM_POINT,
+       AM_UNSUPPORTED };   // formation state without formation inputs
+
+enum { DISP_DONE = 0,      // out_vel is final (before truncation)
+       DISP_LIGHT1, DISP_LIGHT2, DISP_LIGHT3, DISP_LIGHT4,     // candidate search, thread per agent
+       DISP_WAVE,          // candidate search, wave per agent
+       DISP_FULL };        // whole step on a wave (irregular gather)
+
+#define NH_SEP_CAP   128   /* near_ents[128],  movement.c:1695 */
+#define NH_NEAR_CAP  512   /* near_ents[512],  movement.c:2779 */
+#define NH_MAX_NEIGHBOURS 32
+
+// ---------------------------------------------------------------------------------------------
+// pool record of entity i (written by the last pass of the spatial-hash build)
+// ---------------------------------------------------------------------------------------------
+NH_FN void pool_record(int i, const float *pos_xz, const nh_pack_src &src, int work_begin, int work_end,
+                       float4 &recA, float2 &recV)
+{
+    uint32_t bits = (uint32_t)i << NH_PB_UID_SHIFT;
+    float radius = 0.0f;
+    v2 vel = mkv(0.0f, 0.0f);
+    const v2 pos = mkv(pos_xz[2 * i], pos_xz[2 * i + 1]);
+    if(src.flags) {
+        const uint32_t fl = src.flags[i];
+        const int state = src.state[i];
+        radius = src.radius[i];
+        vel = mkv(src.vel_xz[2 * i], src.vel_xz[2 * i + 1]);
+        if(fl & NAVHIP_ENTITY_FLAG_MOVABLE)    bits |= NH_PB_MOVABLE;
+        if(fl & NAVHIP_ENTITY_FLAG_AIR)        bits |= NH_PB_AIR;
+        if(fl & NAVHIP_ENTITY_FLAG_WATER)      bits |= NH_PB_WATER;
+        if(fl & NAVHIP_ENTITY_FLAG_GARRISONED) bits |= NH_PB_GARRISONED;
+        // find_neighbours :2815-2817: G_Arrival_NeighbourSettling (arrival.c:1042) -- committed to a
+        // valid slot and within 1.5 radii (ARRIVAL_SINK_TOLERANCE) of it
+        bool at_slot = false;
+        if(src.arrival_flags && (src.arrival_flags[i] & 1)) {
+            const v2 sink = mkv(src.arrival_sink_xz[2 * i], src.arrival_sink_xz[2 * i + 1]);
+            at_slot = vlen(vsub(sink, pos)) < radius * 1.5f;
+        }
+        if(state_is_still(state) || vlen(vel) < 0.3f || at_slot) bits |= NH_PB_STATIC;   // CLEARPATH_STILL_SPEED
+        if(state_is_still(state) || (fl & NAVHIP_ENTITY_FLAG_COMBAT_HELD) || i < work_begin || i >= work_end)
+            bits |= NH_PB_IDLE;
+    }
+    recA = make_float4(pos.x, pos.z, radius, nh_u2f(bits));
+    recV = make_float2(vel.x, vel.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// neighbour walk
+// ---------------------------------------------------------------------------------------------
+// Visiting order == bg_*_inrange_circle (bitmap_grid.h:1408-1466): coarse 8x8 blocks row-major,
+// inside a block fine rows top to bottom, cells left to right, packed elements in order.  The cells
+// of one fine row inside one coarse block are contiguous in the cell-sorted pool.
+//
+// The r = 10 query of find_neighbours is the r = 30 walk restricted to d <= 10: its box lies inside
+// the r = 30 box, the visiting key (coarse block, fine row, cell, slot) does not depend on the query,
+// and an element of a cell outside the r = 10 box fails the distance test anyway.  Both caps are
+// applied where the reference's two separate queries stop.
+//
+// Left to the wave-per-agent path (NH_NB_IRREGULAR): a garrisoned entity among the hits
+// (filter_garrisoned, position.c:100-119, permutes the list) and queries that take the reference's
+// wide linear scan or miss the grid.
+NH_FN void nbr_walk_thread(const nh_grid &G, int k, float scaled_max_force, const double *exp_tab,
+                           const nh_nbr &NB)
+{
+    const float4 me4 = G.recA[k];
+    const uint32_t mybits = nh_f2u(me4.w);
+    const int uid = (int)(mybits >> NH_PB_UID_SHIFT);
+    const v2 me = mkv(me4.x, me4.y);
+    const float my_radius = me4.z;
+    const int32_t icx = bg_scale(me.x), icy = bg_scale(me.z);
+    const int32_t ir30 = bg_scale(30.0f), ir10 = bg_scale(10.0f);
+    sp_extent E, E10;
+    if(!sp_query_extent(G, icx, icy, ir30, E) || !sp_query_extent(G, icx, icy, ir10, E10)
+    || E.wide || E10.wide) {
+        NB.cnt[uid] = (NH_NB_IRREGULAR | NH_NB_DONE) << 16;
+        return;
+    }
+    const int32_t lim30 = ir30 * ir30, lim10 = ir10 * ir10;
+    int raw30 = 0, raw10 = 0, n_dyn = 0, n_stat = 0;
+    bool irregular = false, stop = false;
+    v2 acc = mkv(0.0f, 0.0f);
+    const int cxc_lo = E.cx_lo >> 3, cxc_hi = E.cx_hi >> 3;
+    const int cyc_lo = E.cy_lo >> 3, cyc_hi = E.cy_hi >> 3;
+    for(int cyc = cyc_lo; cyc <= cyc_hi && !stop; cyc++) {
+    for(int cxc = cxc_lo; cxc <= cxc_hi && !stop; cxc++) {
+        const int fy0 = cyc * 8 > E.cy_lo ? cyc * 8 : E.cy_lo;
+        const int fy1 = cyc * 8 + 7 < E.cy_hi ? cyc * 8 + 7 : E.cy_hi;
+        const int fx0 = cxc * 8 > E.cx_lo ? cxc * 8 : E.cx_lo;
+        const int fx1 = cxc * 8 + 8 < E.cx_hi + 1 ? cxc * 8 + 8 : E.cx_hi + 1;
+        for(int fy = fy0; fy <= fy1 && !stop; fy++) {
+            const int b = G.cell_start[fy * G.grid_w + fx0], e = G.cell_start[fy * G.grid_w + fx1];
+            for(int q = b; q < e; q++) {
+                const float4 c = G.recA[q];
+                // (elements clamped into a border cell may be far away: range-check before squaring
+                // in 32 bits; r = 30: |d| <= 7680 + 4095 otherwise)
+                const int32_t dx = bg_scale(c.x) - icx, dy = bg_scale(c.y) - icy;
+                const bool nearby = (uint32_t)(dx + 32767) < 65535u && (uint32_t)(dy + 32767) < 65535u;
+                const int32_t d2 = nearby ? dx * dx + dy * dy : 0x7fffffff;
+                if(d2 > lim30) continue;
+                const bool hit30 = raw30 < NH_SEP_CAP;
+                const bool hit10 = d2 <= lim10 && raw10 < NH_NEAR_CAP;
+                if(!hit30 && !hit10) continue;
+                const uint32_t bits = nh_f2u(c.w);
+                if(bits & NH_PB_GARRISONED) { irregular = true; stop = true; break; }
+                const bool other = q != k && (bits & NH_PB_MOVABLE) && !((mybits ^ bits) & NH_PB_AIR);
+                if(hit30) {
+                    raw30++;
+                    if(other) {
+                        v2 term;
+                        if(separation_term(me, my_radius, mkv(c.x, c.y), c.z, exp_tab, term))
+                            acc = vadd(acc, term);
+                    }
+                }
+                if(hit10) {
+                    raw10++;
+                    if(other && c.z != 0.0f) {
+                        if(bits & NH_PB_STATIC) {
+                            if(n_stat < NH_MAX_NEIGHBOURS) { NB.list[(size_t)(32 + n_stat) * NB.stride + uid] = q; n_stat++; }
+                        }else{
+                            if(n_dyn < NH_MAX_NEIGHBOURS) { NB.list[(size_t)n_dyn * NB.stride + uid] = q; n_dyn++; }
+                        }
+                    }
+                }
+                if(raw30 >= NH_SEP_CAP && raw10 >= NH_NEAR_CAP) { stop = true; break; }
+            }
+        }
+    }}
+    if(irregular) {
+        NB.cnt[uid] = (NH_NB_IRREGULAR | NH_NB_DONE) << 16;
+        return;
+    }
+    v2 sep = mkv(0.0f, 0.0f);
+    if(raw30 > 0)                                   // `if(0 == num_near) return 0`, movement.c:1737
+        sep = vtrunc(vscale(acc, -1.0f), scaled_max_force);
+    NB.sep[uid] = make_float2(sep.x, sep.z);
+    NB.cnt[uid] = (uint32_t)n_dyn | ((uint32_t)n_stat << 8) | (NH_NB_DONE << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// position accept + outputs
+// ---------------------------------------------------------------------------------------------
+NH_FN void post_thread(const nh_step_params &P, int uid, v2 me, int state, uint32_t my_flags,
+                       float my_radius, v2 raw_vel, float vel_cap, uint32_t status, const nh_step_outs &O)
+{
+    v2 new_pos = me;
+    // vec2_truncate(new velocity, max_speed / hz), movement.c:3464
+    const v2 out_vel = vtrunc(raw_vel, vel_cap);
+    O.vel_xz[2 * uid] = out_vel.x; O.vel_xz[2 * uid + 1] = out_vel.z;
+    // entity_compute_update: a garrisoned entity returns before the position update (:2341-2348);
+    // the heading gate (:2322-2334) stays with the host's state machine
+    if(!state_is_still(state) && !(my_flags & NAVHIP_ENTITY_FLAG_GARRISONED)) {
+        const int layer = nav_layer_for(my_flags, my_radius);
+        v2 cand = vadd(me, out_vel);
+        const bool on_blocked = pos_blocked(P, layer, me.x, me.z);
+        bool cand_path = false, cand_blk = false;
+        tiledesc t;
+        if(tile_for_point(P, cand.x, cand.z, t)) {               // one lookup, two planes
+            const size_t idx = tile_index(P, t);
+            const uint16_t *bl = P.map.layers[layer].blockers;
+            cand_path = P.map.layers[layer].cost[idx] != NAVHIP_COST_IMPASSABLE;
+            cand_blk = bl && bl[idx] > 0;
+        }
+        if(vlen(out_vel) > 0 && cand_path && (on_blocked || !cand_blk)) {
+            new_pos = cand;
+            status |= NAVHIP_ST_MOVED;
+        }
+    }
+    if(O.new_pos_xz) { O.new_pos_xz[2 * uid] = new_pos.x; O.new_pos_xz[2 * uid + 1] = new_pos.z; }
+    if(O.status) O.status[uid] = (uint8_t)status;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ClearPath neighbour access: pool slot -> struct cp_ent (find_neighbours, movement.c:2799-2826)
+// ---------------------------------------------------------------------------------------------
+NH_FN cpent nbr_cpent(const nh_grid &G, int slot, bool is_static)
+{
+    const float4 a = G.recA[slot];
+    cpent nb;
+    nb.pos = mkv(a.x, a.y);
+    nb.radius = a.z;
+    nb.vel = mkv(0.0f, 0.0f);                      // static: velocity forced to zero (:2820)
+    if(!is_static) { const float2 v = G.recV[slot]; nb.vel = mkv(v.x, v.y); }
+    return nb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pre + priority ladder + admissibility of des_v
+// ---------------------------------------------------------------------------------------------
+NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
+                     float scaled_max_force, double force_thresh, nh_mid_rec &R, v2 &out_vel)
+{
+    const int state = P.state[uid];
+    const uint32_t my_flags = P.flags[uid];
+    out_vel = mkv(0.0f, 0.0f);
+    R.vpref[0] = R.vpref[1] = R.vdes[0] = R.vdes[1] = R.arrive[0] = R.arrive[1] = 0.0f;
+    R.probes = 0; R.status = 0; R.mode = AM_IDLE;
+    R.vel_cap = P.max_speed[uid] / (float)P.hz;
+    if(state_is_still(state) || (my_flags & NAVHIP_ENTITY_FLAG_COMBAT_HELD))
+        return DISP_DONE;
+
+    const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+    const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+    const float my_radius = P.radius[uid], max_speed = P.max_speed[uid];
+    const int flock = P.flock[uid], hz = P.hz;
+    const int layer = nav_layer_for(my_flags, my_radius);
+    uint32_t status = 0;
+    v2 vdes = mkv(0.0f, 0.0f), arrive = mkv(0.0f, 0.0f);
+    int mode;
+    const bool form = state == NAVHIP_STATE_MOVING_IN_FORMATION || state == NAVHIP_STATE_ARRIVING_TO_CELL;
+    // seek target: G_Arrival_SeekTarget (arrival.c:1034) -- the unit's slot once it is committed to
+    // it and the flock's arrival region is filling, else the flock target (movement.c:1751-1752)
+    v2 target = me;
+    if(flock >= 0) target = mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]);
+    if(flock >= 0 && P.arrival_flags && (P.arrival_flags[uid] & 3) == 3)
+        target = mkv(P.arrival_sink_xz[2 * uid], P.arrival_sink_xz[2 * uid + 1]);
+    if(state == NAVHIP_STATE_TURNING) {
+        mode = AM_ZERO_VPREF;
+    }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_uses_point_seek(state)) {
+        vdes = load_vdes(P, uid, flock, me, status);
+        if(state_uses_point_seek(state)) {
+            const bool los = P.has_dest_los[uid] != 0;
+            arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
+            mode = AM_POINT_SEEK;
+        }else{
+            // arrive_force_enemies, movement.c:1593
+            v2 desired = vscale(vdes, max_speed / (float)hz);
+            arrive = vtrunc(vsub(desired, vel), scaled_max_force);
+            mode = AM_ENEMY_SEEK;
+        }
+    }else if(P.form_ready && form) {
+        if(!P.form_ready[uid]) {
+            mode = AM_ZERO_VPREF;
+        }else{
+            vdes = load_vdes(P, uid, flock, me, status);
+            if(state == NAVHIP_STATE_ARRIVING_TO_CELL) {
+                // arrive_force_cell :1574 (no velocity term, no truncation)
+                const v2 cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
+                v2 desired = vsub(cell, me);
+                float distance = vlen(desired);
+                if(distance < 10.0f) desired = vscale(desired, distance / 10.0f);
+                else                 desired = vscale(vdes, max_speed / (float)hz);
+                arrive = desired;
+                mode = AM_FORM_CELL;
+            }else{
+                const bool los = P.has_dest_los[uid] != 0;
+                // formation_seek: the flock target itself (movement.c:1985-2002)
+                const v2 ftarget = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]) : me;
+                arrive = arrive_force(me, vel, ftarget, vdes, los, max_speed, hz, scaled_max_force);
+                mode = AM_FORM_POINT;
+            }
+        }
+    }else{
+        mode = AM_UNSUPPORTED;
+        status |= NAVHIP_ST_UNSUPPORTED;
+    }
+    R.mode = (uint8_t)mode;
+    R.vdes[0] = vdes.x; R.vdes[1] = vdes.z;
+    R.status = (uint8_t)status;
+    if(mode == AM_UNSUPPORTED)
+        return DISP_DONE;
+    uint32_t probes = 0;
+    if(mode >= AM_POINT_SEEK && mode <= AM_FORM_POINT)
+        probes = probe_tiles_bits(P, layer, me);
+
+    const uint32_t cnt = NB.cnt[uid];
+    if((cnt >> 16) & NH_NB_IRREGULAR) {
+        R.arrive[0] = arrive.x; R.arrive[1] = arrive.z;
+        R.probes = (uint16_t)probes;
+        return DISP_FULL;
+    }
+
+    v2 vpref = mkv(0.0f, 0.0f);
+    if(mode != AM_ZERO_VPREF) {
+        const float2 s2 = NB.sep[uid];
+        const v2 separation = mkv(s2.x, s2.y);
+        v2 steer;
+        if(mode == AM_ENEMY_SEEK) {
+            // enemy_seek_vpref :1946 (no priorities, no nullify)
+            v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
+            v2 ret = mkv(0.0f, 0.0f);
+            ret = vadd(ret, a); ret = vadd(ret, s);
+            steer = vtrunc(ret, scaled_max_force);
+        }else{
+            // point_seek_vpref :1870 / cell_arrival_seek_vpref :1908 / formation_seek_vpref :1985
+            const bool to_cell = mode == AM_FORM_CELL, formm = mode != AM_POINT_SEEK;
+            v2 cohesion, align = mkv(0.0f, 0.0f), cell = mkv(0.0f, 0.0f);
+            if(formm) {
+                cohesion = mkv(P.form_cohesion_xz[2 * uid], P.form_cohesion_xz[2 * uid + 1]);
+                align = mkv(P.form_align_xz[2 * uid], P.form_align_xz[2 * uid + 1]);
+                cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
+            }else{
+                cohesion = (flock >= 0) ? mkv(coh_xz[2 * uid], coh_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
+            }
+            steer = mkv(0.0f, 0.0f);
+            for(int prio = 0; prio < 3; prio++) {
+                if(prio == 0) {
+                    v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
+                    v2 c = vscale(cohesion, 0.15f), al = vscale(align, 0.15f);
+                    v2 ret = mkv(0.0f, 0.0f);
+                    ret = vadd(ret, a); ret = vadd(ret, s);
+                    if(to_cell) {
+                        if(vlen(vsub(cell, me)) > 30.0f) {       // CELL_ARRIVAL_RADIUS
+                            ret = vadd(ret, c); ret = vadd(ret, al);
+                        }
+                    }else{
+                        ret = vadd(ret, c);
+                    }
+                    steer = vtrunc(ret, scaled_max_force);
+                }else if(prio == 1) {
+                    steer = separation;
+                }else{
+                    steer = arrive;
+                }
+                steer = nullify_impass_bits(probes, steer);
+                if((double)vlen(steer) > force_thresh) break;
+            }
+        }
+        v2 accel = vscale(steer, 1.0f / 1.0f);
+        vpref = vtrunc(vadd(vel, accel), P.speed[uid] / (float)hz);
+        if(mode == AM_FORM_CELL || mode == AM_FORM_POINT) {
+            const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
+            if(vlen(f_drag) > CP_EPS)                            // :1935 / :2018
+                vpref = vtrunc(vpref, (float)(((double)P.speed[uid] * 0.75) / (double)hz));
+        }
+    }
+    R.vpref[0] = vpref.x; R.vpref[1] = vpref.z;
+
+    const int n_dyn = (int)(cnt & 0xff), n_stat = (int)((cnt >> 8) & 0xff);
+    const int n = n_dyn + n_stat;
+    if(n == 0) {                                       // inside_pcr of nothing is false
+        out_vel = vpref;
+        return DISP_DONE;
+    }
+    if(n > NH_LIGHT_MAX)
+        return DISP_WAVE;
+    // clearpath_new_velocity :604: des_v admissible as it is?  One cone at a time, no storage.
+    cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
+    const v2 des_ws = vadd(me, vpref);
+    bool in = false;
+    for(int j = 0; j < n; j++) {
+        const bool is_stat = j >= n_dyn;
+        const int slot = NB.list[(size_t)(is_stat ? 32 + (j - n_dyn) : j) * NB.stride + uid];
+        const cpent nb = nbr_cpent(P.grid, slot, is_stat);
+        if(vlen(vsub(nb.pos, ent.pos)) < CP_EPS) continue;       // same_position, :216-246
+        v2 apex, left, right; float sl, sr;
+        make_cone(ent, nb, !is_stat, apex, left, right, sl, sr);
+        in = in || cone_contains(make_float4(apex.x, apex.z, sl, sr),
+                                 make_float4(left.x, left.z, right.x, right.z), des_ws);
+    }
+    if(!in) {
+        out_vel = vpref;
+        return DISP_DONE;
+    }
+    return DISP_LIGHT1 + (n - 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ClearPath candidate search, sequential (<= NH_LIGHT_MAX neighbours)
+// ---------------------------------------------------------------------------------------------
+// cones: this thread's 2 * NH_LIGHT_MAX float4 at cones[i * cstride] (LDS, thread-interleaved, on
+// the device).  Returns false when no candidate lies outside the combined obstacle: the caller
+// hands the agent to the wave-per-agent kernel, which also runs remove_furthest (:390) and retries.
+NH_FN bool cp_light_thread(const nh_grid &G, const cpent &ent, v2 des_v, int n_dyn, int n_stat,
+                           const int32_t *list, size_t stride, float4 *cones, int cstride, v2 &result)
+{
+    int n_cones = 0;
+    const int n = n_dyn + n_stat;
+    for(int j = 0; j < n; j++) {
+        const bool is_stat = j >= n_dyn;
+        const int slot = list[(size_t)(is_stat ? 32 + (j - n_dyn) : j) * stride];
+        const cpent nb = nbr_cpent(G, slot, is_stat);
+        if(vlen(vsub(nb.pos, ent.pos)) < CP_EPS) continue;
+        v2 apex, left, right; float sl, sr;
+        make_cone(ent, nb, !is_stat, apex, left, right, sl, sr);
+        cones[(2 * n_cones) * cstride]     = make_float4(apex.x, apex.z, sl, sr);
+        cones[(2 * n_cones + 1) * cstride] = make_float4(left.x, left.z, right.x, right.z);
+        n_cones++;
+    }
+    const int n_rays = 2 * n_cones;
+    float best_len = INFINITY;
+    v2 best = mkv(0.0f, 0.0f);
+    bool any = false;
+    // (i, j) ray pairs in the reference's order, then the projections of des_v on every ray
+    for(int i = 0; i < n_rays; i++) {
+        const float4 Ai = cones[(i & ~1) * cstride], Bi = cones[(i | 1) * cstride];
+        const v2 pi = mkv(Ai.x, Ai.y), di = (i & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y);
+        const float si = (i & 1) ? Ai.w : Ai.z;
+        for(int j = 0; j < n_rays; j++) {
+            if(i == j) continue;
+            const float4 Aj = cones[(j & ~1) * cstride], Bj = cones[(j | 1) * cstride];
+            v2 pt;
+            if(!ray_isect(pi, di, si, mkv(Aj.x, Aj.y), (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y),
+                          (j & 1) ? Aj.w : Aj.z, pt))
+                continue;
+            bool inside = false;
+            for(int c = 0; c < n_cones && !inside; c++)
+                inside = cone_contains(cones[(2 * c) * cstride], cones[(2 * c + 1) * cstride], pt);
+            if(inside) continue;
+            any = true;
+            const v2 curr = vsub(pt, ent.pos);
+            const float len = vlen(vsub(des_v, curr));
+            if(len < best_len) { best_len = len; best = curr; }
+        }
+    }
+    for(int i = 0; i < n_rays; i++) {
+        const float4 Ai = cones[(i & ~1) * cstride], Bi = cones[(i | 1) * cstride];
+        const v2 dir = (i & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
+        const float plen = vdot(dir, des_v);
+        const v2 pt = vadd(point, vscale(dir, plen));
+        bool inside = false;
+        for(int c = 0; c < n_cones && !inside; c++)
+            inside = cone_contains(cones[(2 * c) * cstride], cones[(2 * c + 1) * cstride], pt);
+        if(inside) continue;
+        any = true;
+        const v2 curr = vsub(pt, ent.pos);
+        const float len = vlen(vsub(des_v, curr));
+        if(len < best_len) { best_len = len; best = curr; }
+    }
+    result = best;
+    return any;
+}

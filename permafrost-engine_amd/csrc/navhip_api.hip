@@ -100,7 +100,10 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->coh_parity = 0;
     ctx->ev_regroup = nullptr;
     ctx->regroup_pending = false;
-    memset(&ctx->prerec, 0, sizeof(ctx->prerec));
+    memset(&ctx->midrec, 0, sizeof(ctx->midrec));
+    memset(ctx->nbr, 0, sizeof(ctx->nbr));
+    memset(ctx->wl, 0, sizeof(ctx->wl));
+    ctx->wl_parity = 0;
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
@@ -131,7 +134,9 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     hipFree(ctx->d_dirty_list);
     for(auto &b : ctx->sp) hipFree(b.p);
     for(auto &b : ctx->stage) hipFree(b.p);
-    hipFree(ctx->coh.p); hipFree(ctx->coh_plan.p); hipFree(ctx->prerec.p); hipFree(ctx->gen_list.p);
+    hipFree(ctx->coh.p); hipFree(ctx->coh_plan.p); hipFree(ctx->midrec.p); hipFree(ctx->gen_list.p);
+    for(auto &b : ctx->nbr) hipFree(b.p);
+    for(auto &b : ctx->wl) hipFree(b.p);
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
     for(auto &a : ctx->aux) if(a) hipStreamDestroy(a);
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -637,6 +642,16 @@ static void fill_map_view(const navhip_ctx *ctx, nh_map_view *mv)
     }
 }
 
+// like ensure_buf, but a fresh allocation is zeroed (counters that the kernels keep at zero themselves)
+static int ensure_zeroed(navhip_ctx *ctx, navhip_ctx::buf &b, size_t need, hipStream_t s)
+{
+    const void *old = b.p;
+    int rc = ensure_buf(ctx, b, need);
+    if(rc) return rc;
+    if(b.p != old) HIPCHK(ctx, hipMemsetAsync(b.p, 0, b.cap, s));
+    return NAVHIP_OK;
+}
+
 static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hipStream_t s,
                          int slab_begin = 0, int slab_end = -1, bool with_records = true)
 {
@@ -645,22 +660,39 @@ static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hip
         return NAVHIP_ERR_INVALID;
     }
     const size_t n = (size_t)w->n_ents, ncells = (size_t)g->grid_w * g->grid_h;
-    const size_t sizes[12] = {n, n, n, ncells, ncells, ncells + 1, n, n, n, (ncells + 1023) / 1024, 4, 8 * n};
-    for(int i = 0; i < 12; i++) {
-        int rc = ensure_buf(ctx, ctx->sp[i], sizes[i] * sizeof(int32_t));
+    // ent_cell, ent_rank, cell_count, cell_start, tmp_id, block_sum, box, recA, recV, pool_of
+    const size_t bytes[10] = {4 * n, 4 * n, 4 * ncells, 4 * (ncells + 1), 4 * n, 4 * ((ncells + 1023) / 1024),
+                              16, 16 * n, 8 * n, 4 * n};
+    for(int i = 0; i < 10; i++) {
+        int rc = (i == 2) ? ensure_zeroed(ctx, ctx->sp[i], bytes[i], s) : ensure_buf(ctx, ctx->sp[i], bytes[i]);
         if(rc) return rc;
     }
     nh_spatial_scratch S = {(int32_t*)ctx->sp[0].p, (int32_t*)ctx->sp[1].p, (int32_t*)ctx->sp[2].p,
                             (int32_t*)ctx->sp[3].p, (int32_t*)ctx->sp[4].p, (int32_t*)ctx->sp[5].p,
-                            (int32_t*)ctx->sp[6].p, (int32_t*)ctx->sp[7].p, (int32_t*)ctx->sp[8].p,
-                            (int32_t*)ctx->sp[9].p, (int32_t*)ctx->sp[10].p, (float4*)ctx->sp[11].p,
-                            {w->vel_xz, w->radius, w->flags, w->state}};
-    if(!with_records) S.src = nh_pack_src{nullptr, nullptr, nullptr, nullptr};   // (positions only)
-    g->rec = S.src.flags ? S.rec : nullptr;
+                            (int32_t*)ctx->sp[6].p, (float4*)ctx->sp[7].p, (float2*)ctx->sp[8].p,
+                            (int32_t*)ctx->sp[9].p,
+                            {w->vel_xz, w->radius, w->flags, w->state, w->arrival_sink_xz, w->arrival_flags}};
+    if(!with_records) S.src = nh_pack_src{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (positions only)
     g->n = w->n_ents;
     if(slab_end < 0) slab_end = w->n_ents;
-    g->cell_start = S.cell_start; g->sorted_id = S.sorted_id; g->sx = S.sx; g->sy = S.sy;
     nh_launch_spatial_build(*g, w->pos_xz, S, slab_begin, slab_end, s);
+    return NAVHIP_OK;
+}
+
+// scratch of the neighbour walk and of the work lists
+static int step_scratch(navhip_ctx *ctx, int n_ents, nh_nbr *NB, nh_worklists *WL, hipStream_t s)
+{
+    const size_t n = (size_t)n_ents;
+    int rc = ensure_buf(ctx, ctx->nbr[0], 8 * n);
+    if(!rc) rc = ensure_zeroed(ctx, ctx->nbr[1], 4 * n, s);
+    if(!rc) rc = ensure_buf(ctx, ctx->nbr[2], 4 * 64 * n);
+    if(!rc) rc = ensure_buf(ctx, ctx->midrec, sizeof(nh_mid_rec) * n);
+    if(!rc) rc = ensure_zeroed(ctx, ctx->wl[0], 4 * 2 * NH_WL_COUNT, s);
+    if(!rc) rc = ensure_buf(ctx, ctx->wl[1], 4 * (size_t)NH_WL_COUNT * n);
+    if(rc) return rc;
+    NB->sep = (float2*)ctx->nbr[0].p; NB->cnt = (uint32_t*)ctx->nbr[1].p; NB->list = (int32_t*)ctx->nbr[2].p;
+    NB->stride = n_ents;
+    WL->count = (int32_t*)ctx->wl[0].p; WL->ids = (int32_t*)ctx->wl[1].p; WL->stride = n_ents;
     return NAVHIP_OK;
 }
 
@@ -669,6 +701,11 @@ static int step_check_world(navhip_ctx *ctx, const navhip_world *w)
     if(!w || w->n_ents < 0 || (w->hz != 20 && w->hz != 10 && w->hz != 5 && w->hz != 1))
         return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
+    if(w->n_ents >= (1 << 24)) {            // pool records carry the uid in 24 bits
+        ctx->last_error = "agent step: more than 2^24 entities";
+        return NAVHIP_ERR_INVALID;
+    }
+    if((w->arrival_flags != nullptr) != (w->arrival_sink_xz != nullptr)) return NAVHIP_ERR_INVALID;
     if(!w->pos_xz || !w->vel_xz || !w->radius || !w->max_speed || !w->speed || !w->flags
     || !w->state || !w->has_dest_los || !w->flock
     || (w->n_flocks > 0 && (!w->flock_target_xz || !w->flock_offsets || !w->flock_members)))
@@ -700,11 +737,38 @@ static int step_fill_params(navhip_ctx *ctx, const navhip_world *w, nh_step_para
     P.form_ready = w->form_ready; P.cell_pos_xz = w->cell_pos_xz;
     P.form_cohesion_xz = w->form_cohesion_xz; P.form_align_xz = w->form_align_xz;
     P.form_drag_xz = w->form_drag_xz;
+    P.arrival_sink_xz = w->arrival_sink_xz; P.arrival_flags = w->arrival_flags;
     if(P.form_ready && (!P.cell_pos_xz || !P.form_cohesion_xz || !P.form_align_xz || !P.form_drag_xz)) {
         ctx->last_error = "agent step: form_ready given without the other formation arrays";
         return NAVHIP_ERR_INVALID;
     }
     return NAVHIP_OK;
+}
+
+// what a prefetch was started for: the step that follows joins it only for the very same snapshot
+static void pre_key_fill(navhip_ctx *ctx, const navhip_world *w, const nh_step_params &P)
+{
+    auto &k = ctx->pre;
+    k.pos_xz = w->pos_xz; k.vel_xz = w->vel_xz; k.radius = w->radius; k.flags = w->flags;
+    k.state = w->state; k.flock_members = w->flock_members; k.flock_offsets = w->flock_offsets;
+    k.arrival_flags = w->arrival_flags; k.arrival_sink_xz = w->arrival_sink_xz;
+    k.n_ents = w->n_ents; k.n_flocks = w->n_flocks; k.hz = w->hz;
+    k.work_begin = P.work_begin; k.work_end = P.work_end;
+    k.g.origin_x = P.grid.origin_x; k.g.origin_y = P.grid.origin_y;
+    k.g.grid_w = P.grid.grid_w; k.g.grid_h = P.grid.grid_h;
+}
+
+static bool pre_key_matches(const navhip_ctx *ctx, const navhip_world *w, const nh_step_params &P,
+                            const nh_grid &g)
+{
+    const auto &k = ctx->pre;
+    return k.pos_xz == w->pos_xz && k.vel_xz == w->vel_xz && k.radius == w->radius && k.flags == w->flags
+        && k.state == w->state && k.flock_members == w->flock_members && k.flock_offsets == w->flock_offsets
+        && k.arrival_flags == w->arrival_flags && k.arrival_sink_xz == w->arrival_sink_xz
+        && k.n_ents == w->n_ents && k.n_flocks == w->n_flocks && k.hz == w->hz
+        && k.work_begin == P.work_begin && k.work_end == P.work_end
+        && k.g.origin_x == g.origin_x && k.g.origin_y == g.origin_y && k.g.grid_w == g.grid_w
+        && k.g.grid_h == g.grid_h;
 }
 
 int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stream)
@@ -717,8 +781,8 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if(!ctx->aux[0]) {
-        // high priority: the cohesion launch is long but narrow (1.5 waves per SIMD) and sits on the
-        // critical path; it must not queue up behind the wide field kernels of the caller's stream
+        // high priority: the side chains are narrow and sit on the critical path; they must not
+        // queue up behind the wide field kernels of the caller's stream
         int prio_lo = 0, prio_hi = 0;
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         for(auto &a : ctx->aux)
@@ -729,15 +793,20 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     nh_step_params P;
     rc = step_fill_params(ctx, w, &P);
     if(rc) return rc;
+    nh_nbr NB; nh_worklists WL;
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
     if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
+    if(!rc) rc = step_scratch(ctx, w->n_ents, &NB, &WL, s);
     if(rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    // side stream 0: spatial hash -> neighbour walk (separation force + ClearPath neighbour lists)
     rc = spatial_build(ctx, w, &P.grid, ctx->aux[0], P.work_begin, P.work_end);
     if(rc) return rc;
+    nh_launch_agent_nbr(P, NB, ctx->aux[0]);
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+    // side stream 1: cohesion
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
                                             ctx->aux[1]);
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
@@ -753,10 +822,7 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     }
     HIPCHK(ctx, hipGetLastError());
     ctx->pre.valid = true;
-    ctx->pre.pos_xz = w->pos_xz; ctx->pre.flock_members = w->flock_members;
-    ctx->pre.n_ents = w->n_ents; ctx->pre.work_begin = P.work_begin; ctx->pre.work_end = P.work_end;
-    ctx->pre.g.origin_x = P.grid.origin_x; ctx->pre.g.origin_y = P.grid.origin_y;
-    ctx->pre.g.grid_w = P.grid.grid_w; ctx->pre.g.grid_h = P.grid.grid_h;
+    pre_key_fill(ctx, w, P);
     return NAVHIP_OK;
 }
 
@@ -773,10 +839,12 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     nh_step_params P;
     rc = step_fill_params(ctx, w, &P);
     if(rc) return rc;
+    if(!grid_geometry(w, &P.grid)) {
+        ctx->last_error = "agent step: empty spatial-grid bounds";
+        return NAVHIP_ERR_INVALID;
+    }
     const bool prof = ctx->profiling;
-    const bool joined = ctx->pre.valid && !prof && ctx->pre.pos_xz == w->pos_xz
-                     && ctx->pre.flock_members == w->flock_members && ctx->pre.n_ents == w->n_ents
-                     && ctx->pre.work_begin == P.work_begin && ctx->pre.work_end == P.work_end;
+    const bool joined = ctx->pre.valid && !prof && pre_key_matches(ctx, w, P, P.grid);
     if(ctx->pre.valid && !joined) {
         // a prefetch for another snapshot is in flight on the side streams: let it drain before
         // its scratch buffers are reused
@@ -787,19 +855,18 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     }
     ctx->pre.valid = false;
     nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
+    nh_nbr NB; nh_worklists WL;
+    rc = step_scratch(ctx, w->n_ents, &NB, &WL, s);
+    if(rc) return rc;
     if(joined) {
-        // spatial hash + cohesion were started by navhip_agent_prefetch_dev: just join them
-        if(!grid_geometry(w, &P.grid)) return NAVHIP_ERR_INVALID;
+        // spatial hash + neighbour walk + cohesion were started by navhip_agent_prefetch_dev: join
         P.grid.n = w->n_ents;
-        P.grid.cell_start = (int32_t*)ctx->sp[5].p; P.grid.sorted_id = (int32_t*)ctx->sp[6].p;
-        P.grid.sx = (int32_t*)ctx->sp[7].p; P.grid.sy = (int32_t*)ctx->sp[8].p;
-        P.grid.rec = (const float4*)ctx->sp[11].p;
-        rc = ensure_buf(ctx, ctx->prerec, (size_t)w->n_ents * nh_pre_rec_bytes());
-        if(rc) return rc;
-        nh_launch_agent_pre(P, ctx->prerec.p, O, s);          // overlaps with the side streams
+        P.grid.cell_start = (int32_t*)ctx->sp[3].p; P.grid.recA = (const float4*)ctx->sp[7].p;
+        P.grid.recV = (const float2*)ctx->sp[8].p; P.grid.pool_of = (const int32_t*)ctx->sp[9].p;
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
-        nh_launch_agent_step(P, (float*)ctx->coh.p, ctx->prerec.p, O, s);
+        nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s);
+        ctx->wl_parity ^= 1;
         if(ctx->regroup_pending) {
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));     // long finished by now
             ctx->regroup_pending = false;
@@ -814,17 +881,18 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     rc = spatial_build(ctx, w, &P.grid, s, P.work_begin, P.work_end);
     if(rc) return rc;
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+    nh_launch_agent_nbr(P, NB, s);
+    if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
     if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
     if(rc) return rc;
-    if(!rc) rc = ensure_buf(ctx, ctx->prerec, (size_t)w->n_ents * nh_pre_rec_bytes());
-    if(rc) return rc;
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity, s);
-    if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+    if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
-    nh_launch_agent_pre(P, ctx->prerec.p, O, s);
-    nh_launch_agent_step(P, (float*)ctx->coh.p, ctx->prerec.p, O, s);
-    if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], s)); ctx->ev_valid = true; }
+    if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+    nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s);
+    ctx->wl_parity ^= 1;
+    if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[5], s)); ctx->ev_valid = true; }
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
 }
@@ -837,12 +905,23 @@ int navhip_set_profiling(navhip_ctx *ctx, int on)
     return NAVHIP_OK;
 }
 
-int navhip_last_step_ms(navhip_ctx *ctx, float out_ms[3])
+int navhip_last_step_ms(navhip_ctx *ctx, float out_ms[NAVHIP_STEP_PHASES])
 {
     if(!ctx || !out_ms || !ctx->ev_valid) return NAVHIP_ERR_INVALID;
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
-    for(int i = 0; i < 3; i++)
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[5]));
+    for(int i = 0; i < NAVHIP_STEP_PHASES; i++)
         HIPCHK(ctx, hipEventElapsedTime(&out_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    return NAVHIP_OK;
+}
+
+// the work-list sizes of the last agent step: {light 1..4, wave, full} (waits for the step)
+int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
+{
+    if(!ctx || !out_counts || !ctx->wl[0].p) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const int32_t *src = (const int32_t*)ctx->wl[0].p + (ctx->wl_parity ^ 1) * NH_WL_COUNT;
+    HIPCHK(ctx, hipMemcpy(out_counts, src, sizeof(int32_t) * NH_WL_COUNT, hipMemcpyDeviceToHost));
     return NAVHIP_OK;
 }
 
@@ -878,6 +957,7 @@ static int stage_world(navhip_ctx *ctx, const navhip_world *w, navhip_world *d, 
     ST(14, field_pool, (size_t)w->n_field_slots * NH_CELLS);
     ST(24, form_ready, n);       ST(25, cell_pos_xz, n * 8); ST(26, form_cohesion_xz, n * 8);
     ST(27, form_align_xz, n * 8); ST(28, form_drag_xz, n * 8);
+    ST(36, arrival_sink_xz, n * 8); ST(37, arrival_flags, n);
 #undef ST
     return rc;
 }
@@ -907,8 +987,16 @@ int navhip_agent_step(navhip_ctx *ctx, const navhip_world *w, const navhip_step_
     }
     rc = navhip_agent_step_dev(ctx, &d, &dout, s);
     if(rc) return rc;
-    for(auto &o : outs)
-        if(o.host) HIPCHK(ctx, hipMemcpyAsync(o.host, *o.dev, o.bytes, hipMemcpyDeviceToHost, s));
+    // only the rows of the stepped slab were written: a caller that issues one call per slab into
+    // the same output arrays (move_submit_cpu_work, movement.c:3759-3762) keeps its other slabs
+    size_t b = (size_t)w->work_begin, e = (size_t)w->work_end;
+    if(b == 0 && e == 0) e = n;
+    for(auto &o : outs) {
+        if(!o.host || e <= b) continue;
+        const size_t row = o.bytes / n;
+        HIPCHK(ctx, hipMemcpyAsync((char*)o.host + b * row, (char*)*o.dev + b * row, (e - b) * row,
+                                   hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;
 }
@@ -944,15 +1032,17 @@ int navhip_spatial_query(navhip_ctx *ctx, const navhip_world *w, const float *qu
     return NAVHIP_OK;
 }
 
-int navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
-                     const float *dyn, const int32_t *n_dyn, const float *stat,
-                     const int32_t *n_stat, float *out)
+static int clearpath_batch(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                           const float *dyn, const int32_t *n_dyn, const float *stat,
+                           const int32_t *n_stat, float *out, int32_t *light_found)
 {
     if(!ctx || nq < 0 || !ent || !des_v || !dyn || !n_dyn || !stat || !n_stat || !out)
         return NAVHIP_ERR_INVALID;
     if(nq == 0) return NAVHIP_OK;
-    for(int i = 0; i < nq; i++)
+    for(int i = 0; i < nq; i++) {
         if(n_dyn[i] < 0 || n_dyn[i] > 32 || n_stat[i] < 0 || n_stat[i] > 32) return NAVHIP_ERR_INVALID;
+        if(light_found && n_dyn[i] + n_stat[i] > NH_LIGHT_MAX) return NAVHIP_ERR_INVALID;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const void *d[6];
@@ -964,14 +1054,32 @@ int navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *des
         if(rc) return rc;
     }
     int rc = ensure_buf(ctx, ctx->stage[15], (size_t)nq * 8);
+    if(!rc && light_found) rc = ensure_buf(ctx, ctx->stage[16], (size_t)nq * 4);
     if(rc) return rc;
     nh_launch_clearpath(nq, (const float*)d[0], (const float*)d[1], (const float*)d[2],
                         (const int32_t*)d[3], (const float*)d[4], (const int32_t*)d[5],
-                        (float*)ctx->stage[15].p, s);
+                        (float*)ctx->stage[15].p, light_found ? (int32_t*)ctx->stage[16].p : nullptr, s);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage[15].p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    if(light_found)
+        HIPCHK(ctx, hipMemcpyAsync(light_found, ctx->stage[16].p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;
+}
+
+int navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                     const float *dyn, const int32_t *n_dyn, const float *stat,
+                     const int32_t *n_stat, float *out)
+{
+    return clearpath_batch(ctx, nq, ent, des_v, dyn, n_dyn, stat, n_stat, out, nullptr);
+}
+
+int navhip_clearpath_light(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                           const float *dyn, const int32_t *n_dyn, const float *stat,
+                           const int32_t *n_stat, float *out, int32_t *found)
+{
+    if(!found) return NAVHIP_ERR_INVALID;
+    return clearpath_batch(ctx, nq, ent, des_v, dyn, n_dyn, stat, n_stat, out, found);
 }
 
 uint64_t navhip_flow_field_id(const navhip_field_req *r)

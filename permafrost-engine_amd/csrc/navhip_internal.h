@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include "navhip.h"
+#include "map_view.h"
 
 static_assert(sizeof(navhip_field_req) == 32, "navhip_field_req must stay 32 bytes");
 static_assert(sizeof(navhip_los_req) == 16, "navhip_los_req must stay 16 bytes");
@@ -42,25 +43,30 @@ struct navhip_ctx {
     uint32_t    *d_dirty_list; size_t d_dirty_cap;
     // agent-step scratch (grown on demand, reused every tick)
     struct buf { void *p; size_t cap; };
-    buf          sp[12];       // spatial hash: ent_ix, ent_iy, ent_cell, cell_count, cell_fill,
-                               //               cell_start, sorted_id, sx, sy, block_sum, slab box,
-                               //               entity records
+    buf          sp[10];       // spatial hash: ent_cell, ent_rank, cell_count, cell_start, tmp_id,
+                               //               block_sum, slab box, recA, recV, pool_of
+    buf          nbr[3];       // neighbour walk: separation force, counts, neighbour lists
+    buf          midrec;       // per-entity record k_agent_mid leaves for the work-list consumers
+    buf          wl[2];        // work lists: 2 x NH_WL_COUNT counters (alternating), ids
+    int          wl_parity;
     buf          coh;          // cohesion force per entity
     buf          coh_plan;     // [n_flocks + 1] wave prefix of the cohesion launch
-    buf          prerec;       // per-entity record of the scalar pre-pass (k_agent_pre)
     buf          gen_list;     // [2 + n] requests the BFS kernel left to k_field_generic: 2 counters, ids
     unsigned     gen_launches; // parity selects the counter of a launch
     int          coh_flocks, coh_members, coh_parity;   // layout of coh_plan + which perm buffer is next
-    buf          stage[36];    // device copies of host buffers for the host-pointer entry points
+    buf          stage[48];    // device copies of host buffers for the host-pointer entry points
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];
     hipEvent_t   ev_fork, ev_join[2], ev_regroup;
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
-    struct { bool valid; const float *pos_xz; const int32_t *flock_members; int n_ents, work_begin, work_end;
+    // the snapshot a prefetch was started for: everything the side streams baked into their results
+    struct { bool valid; const float *pos_xz, *vel_xz, *radius, *arrival_sink_xz; const uint32_t *flags;
+             const uint8_t *state, *arrival_flags; const int32_t *flock_members, *flock_offsets;
+             int n_ents, n_flocks, hz, work_begin, work_end;
              struct nh_grid_store { int32_t origin_x, origin_y; int grid_w, grid_h; } g; } pre;
     // optional per-kernel-group timing of the agent step (navhip_set_profiling)
     bool         profiling;
-    hipEvent_t   ev[4];        // start | spatial hash built | cohesion done | agent step done
+    hipEvent_t   ev[6];        // start | hash built | neighbour walk | cohesion | regroup | finish
     bool         ev_valid;
     std::string  last_error;
 };
@@ -80,17 +86,3 @@ void nh_launch_region_fields(navhip_ctx *ctx, const navhip_region_req *d_reqs, i
 void nh_launch_los(navhip_ctx *ctx, const navhip_los_req *d_reqs, int n, const uint8_t *d_prev,
                    uint8_t *d_out, float map_x, float map_z, hipStream_t s);
 
-struct nh_layer_view {
-    const uint8_t  *cost;
-    const uint16_t *blockers;
-    const uint16_t *local_islands;
-    const uint8_t  *factions;
-    const uint64_t *passmask;
-    const uint8_t  *unit_cost;
-    const uint8_t  *changed;
-    const uint16_t *islands;
-};
-struct nh_map_view {
-    int w, h;
-    nh_layer_view layers[NAVHIP_NAV_LAYER_MAX];
-};

@@ -311,7 +311,8 @@ class World(C.Structure):
         ("grid_xmin", C.c_float), ("grid_xmax", C.c_float), ("grid_zmin", C.c_float),
         ("grid_zmax", C.c_float), ("work_begin", C.c_int32), ("work_end", C.c_int32),
         ("form_ready", C.c_void_p), ("cell_pos_xz", C.c_void_p), ("form_cohesion_xz", C.c_void_p),
-        ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p)]
+        ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p),
+        ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p)]
 
 
 class StepOut(C.Structure):
@@ -327,7 +328,10 @@ _SIGS.update({
     "navhip_spatial_query": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p, C.c_int, C.c_float,
                                        C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
-    "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3)]),
+    "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 5)]),
+    "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
+    "navhip_clearpath_light": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "navhip_clearpath": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 })
@@ -339,7 +343,7 @@ _WORLD_ARRAYS = (
     ("flock_target_xz", np.float32), ("flock_offsets", np.int32), ("flock_members", np.int32),
     ("flock_field_slot", np.int32), ("field_pool", np.uint8), ("form_ready", np.uint8),
     ("cell_pos_xz", np.float32), ("form_cohesion_xz", np.float32), ("form_align_xz", np.float32),
-    ("form_drag_xz", np.float32))
+    ("form_drag_xz", np.float32), ("arrival_sink_xz", np.float32), ("arrival_flags", np.uint8))
 
 
 def flock_csr(flock, n_flocks, order=None):
@@ -429,8 +433,9 @@ def _ctx_spatial_query(self, pos_xz, query_xz, rng, maxout):
     return counts, ids
 
 
-def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat):
-    """G_ClearPath_NewVelocity (clearpath.c:694) for a batch of independent problems."""
+def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, light=False):
+    """G_ClearPath_NewVelocity (clearpath.c:694) for a batch of independent problems.  light=True:
+    the thread-per-agent search (<= 4 neighbours); returns (out, found)."""
     ent = np.ascontiguousarray(ent, np.float32).reshape(-1, 5)
     nq = len(ent)
     des_v = np.ascontiguousarray(des_v, np.float32).reshape(nq, 2)
@@ -439,6 +444,12 @@ def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat):
     n_dyn = np.ascontiguousarray(n_dyn, np.int32)
     n_stat = np.ascontiguousarray(n_stat, np.int32)
     out = np.zeros((nq, 2), np.float32)
+    if light:
+        found = np.zeros(nq, np.int32)
+        self._chk(lib().navhip_clearpath_light(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
+                                               _hp(stat), _hp(n_stat), _hp(out), _hp(found)),
+                  "navhip_clearpath_light")
+        return out, found
     self._chk(lib().navhip_clearpath(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
                                      _hp(stat), _hp(n_stat), _hp(out)), "navhip_clearpath")
     return out
@@ -448,15 +459,26 @@ def _ctx_set_profiling(self, on):
     self._chk(lib().navhip_set_profiling(self._h, int(bool(on))), "navhip_set_profiling")
 
 
+STEP_PHASES = ("sp_build", "agent_nbr", "cohesion", "coh_regroup", "agent_finish")
+
+
 def _ctx_last_step_ms(self):
-    """(spatial hash, k_cohesion, k_agent_step) milliseconds of the last profiled agent step."""
-    out = (C.c_float * 3)()
+    """Milliseconds of the kernel groups STEP_PHASES of the last profiled agent step."""
+    out = (C.c_float * 5)()
     self._chk(lib().navhip_last_step_ms(self._h, C.byref(out)), "navhip_last_step_ms")
     return tuple(float(x) for x in out)
 
 
+def _ctx_last_step_lists(self):
+    """Agents per ClearPath work list of the last step: light 1..4 neighbours, wave, full-wave."""
+    out = (C.c_int32 * 6)()
+    self._chk(lib().navhip_last_step_lists(self._h, C.byref(out)), "navhip_last_step_lists")
+    return tuple(int(x) for x in out)
+
+
 NavContext.set_profiling = _ctx_set_profiling
 NavContext.last_step_ms = _ctx_last_step_ms
+NavContext.last_step_lists = _ctx_last_step_lists
 NavContext.agent_step = _ctx_agent_step
 NavContext.agent_step_dev = _ctx_agent_step_dev
 NavContext.agent_prefetch_dev = _ctx_agent_prefetch_dev

@@ -78,10 +78,12 @@ def destinations(grid, k, seed=42):
 
 
 def agents(grid, n, k_flocks, seed=7, radius=1.0, max_speed=20.0, hz=20, blockers=None, cols=None,
-           rows=None):
+           rows=None, crowd_cells=0):
     """N agents at random passable (and unblocked) cell centres + U(-1.5,1.5) jitter, round-robin
     flocks.  cols = (c0, c1) / rows = (r0, r1): only cells of the global columns [c0, c1) and rows
-    [r0, r1) (one region of the map)."""
+    [r0, r1) (one region of the map).  crowd_cells > 0: the crowded variant -- every flock starts
+    packed into the passable cells within `crowd_cells` (Chebyshev) of a random centre, so that the
+    neighbour caps of the movement tick (128 / 32 + 32) bind and ClearPath runs in its R^3 regime."""
     rng = np.random.RandomState(seed)
     h, w = grid.shape[0] // 64, grid.shape[1] // 64
     cells = passable_cells(grid, blockers)
@@ -89,7 +91,16 @@ def agents(grid, n, k_flocks, seed=7, radius=1.0, max_speed=20.0, hz=20, blocker
         cells = cells[(cells[:, 1] >= cols[0]) & (cells[:, 1] < cols[1])]
     if rows is not None and (rows[0] > 0 or rows[1] < grid.shape[0]):
         cells = cells[(cells[:, 0] >= rows[0]) & (cells[:, 0] < rows[1])]
-    idx = rng.randint(0, len(cells), size=n)
+    if crowd_cells > 0:
+        flock_of = np.arange(n) % k_flocks
+        idx = np.zeros(n, np.int64)
+        for f in range(k_flocks):
+            c = cells[rng.randint(len(cells))]
+            near = np.flatnonzero((np.abs(cells[:, 0] - c[0]) <= crowd_cells) & (np.abs(cells[:, 1] - c[1]) <= crowd_cells))
+            mine = np.flatnonzero(flock_of == f)
+            idx[mine] = near[rng.randint(0, len(near), size=len(mine))]
+    else:
+        idx = rng.randint(0, len(cells), size=n)
     pos = cell_centre(w, h, cells[idx, 0], cells[idx, 1])
     pos += rng.uniform(-1.5, 1.5, size=pos.shape).astype(np.float32)
     vel = rng.normal(0.0, 0.35, size=pos.shape).astype(np.float32)

@@ -41,12 +41,16 @@ class NavTick:
 
     def __init__(self, chunk_w=16, fields_per_rank=64, agents_per_rank=100_000, rank=0, world=1,
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
-                 obstacle_ticks=128, tile_exchange="auto", solo=False):
+                 obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
+                 debug_outputs=False):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.W = chunk_w                            # region side in chunks
-        self.reg_rows, self.reg_cols = region_grid(world)
+        # shared_map (BASELINE configs[3], strong scaling): ONE chunk_w x chunk_w map for every rank;
+        # destinations and agents are split over the ranks, anywhere on the map
+        self.shared_map = bool(shared_map)
+        self.reg_rows, self.reg_cols = (1, 1) if shared_map else region_grid(world)
         self.Wt, self.H = chunk_w * self.reg_cols, chunk_w * self.reg_rows   # whole map, in chunks
         if max(self.Wt, self.H) > 64:
             raise ValueError("%d regions of %d chunks do not fit a 64x64-chunk map" % (world, chunk_w))
@@ -59,6 +63,8 @@ class NavTick:
         rcols = chunk_w * 64                        # cell rows / columns per region
 
         def region_cells(q):                        # (row0, row1, col0, col1) of region q, in cells
+            if self.shared_map:
+                return 0, rcols, 0, rcols
             qr, qc = divmod(q, self.reg_cols)
             return qr * rcols, (qr + 1) * rcols, qc * rcols, (qc + 1) * rcols
 
@@ -106,7 +112,7 @@ class NavTick:
             d = synth.destinations(sub, fields_per_rank, seed=42 + q)
             dests.append(d + np.array([r0, c0]))
             a = synth.agents(grid, agents_per_rank, fields_per_rank, seed=7 + q, hz=hz, blockers=blockers,
-                             cols=(c0, c1), rows=(r0, r1))
+                             cols=(c0, c1), rows=(r0, r1), crowd_cells=crowd_cells)
             a["flock"] = a["flock"] + q * fields_per_rank
             ag_parts.append(a)
         dests = np.concatenate(dests)
@@ -183,6 +189,15 @@ class NavTick:
         self.new_pos = torch.zeros((n, 2), dtype=torch.float32, device=self.dev)
         self.new_vel = torch.zeros((n, 2), dtype=torch.float32, device=self.dev)
         self.status = torch.zeros(n, dtype=torch.uint8, device=self.dev)
+        self.res4 = torch.zeros((n, 4), dtype=torch.float32, device=self.dev) if world > 1 else None
+        # (parity tests: the desired direction / preferred velocity every agent was stepped with)
+        self.vdes_out = torch.zeros((n, 2), dtype=torch.float32, device=self.dev) if debug_outputs else None
+        self.vpref_out = torch.zeros((n, 2), dtype=torch.float32, device=self.dev) if debug_outputs else None
+        # host copies of what the job was built from (parity tests replay it through the reference)
+        self.host = {"reqs": reqs, "dest_of_req": dest_of_req, "slot_tbl": slot_tbl, "dests": dests,
+                     "targets": targets.astype(np.float32), "flock": ag["flock"], "flock_offsets": offs,
+                     "flock_members": members, "radius": ag["radius"], "max_speed": ag["max_speed"],
+                     "speed": ag["speed"], "liid": liid}
         self.stream = torch.cuda.Stream(device=self.dev)
         # multi-GPU: the slab all-gather of tick t runs on its own stream and is only awaited by the
         # snapshot consumers of tick t+1 (spatial hash + cohesion, then the agent step); the field
@@ -201,6 +216,7 @@ class NavTick:
             self.ctx.build_fields_dev(d_full, n_req, self.pool, stream=self.stream.cuda_stream)
             self.stream.synchronize()
         self.ev = []                   # (phase, start_event, end_event) of the timed steps
+        self.tick_ev = []              # one event at the start of every recorded tick
         self.record = False
         self.mark_every = 4
         if verbose:
@@ -215,6 +231,9 @@ class NavTick:
         self.out_s.vel_xz = self.new_vel.data_ptr()
         self.out_s.new_pos_xz = self.new_pos.data_ptr()
         self.out_s.status = self.status.data_ptr()
+        if self.vdes_out is not None:
+            self.out_s.vdes_xz = self.vdes_out.data_ptr()
+            self.out_s.vpref_xz = self.vpref_out.data_ptr()
 
     def _mark(self, name):
         # phase timing by HIP events on the launch stream, on every `mark_every`-th recorded tick:
@@ -228,6 +247,10 @@ class NavTick:
 
     def step(self):
         """One tick, asynchronous on self.stream."""
+        if self.record:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(self.stream)
+            self.tick_ev.append(e)
         self.compute()
         self.exchange()
         self.advance()
@@ -272,8 +295,14 @@ class NavTick:
             return
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ev_step)
-            pdist.exchange_rows(self.new_pos, self.agent_bounds, self.rank, self.world)
-            pdist.exchange_rows(self.new_vel, self.agent_bounds, self.rank, self.world)
+            # ONE collective per tick: this rank's rows of [new position | new velocity] (16 B per
+            # agent) packed into one buffer, all-gathered, unpacked
+            b, e = self.agent_bounds[self.rank]
+            self.res4[b:e, 0:2] = self.new_pos[b:e]
+            self.res4[b:e, 2:4] = self.new_vel[b:e]
+            pdist.exchange_rows(self.res4, self.agent_bounds, self.rank, self.world)
+            self.new_pos.copy_(self.res4[:, 0:2])
+            self.new_vel.copy_(self.res4[:, 2:4])
             self.ev_comm.record(self.comm)
         self._comm_pending = True
 
@@ -295,6 +324,10 @@ class NavTick:
             for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
                 out.setdefault(n0, []).append(e0.elapsed_time(e1))
         return {k: float(np.mean(v)) for k, v in out.items()}
+
+    def tick_ms(self):
+        """GPU-timeline duration of every recorded tick but the last (start event to start event)."""
+        return [a.elapsed_time(b) for a, b in zip(self.tick_ev[:-1], self.tick_ev[1:])]
 
     def sync(self):
         if self.comm is not None:

@@ -282,6 +282,21 @@ def formation_inputs(world, seed):
     return state, f
 
 
+def arrival_inputs(world, seed):
+    """Fine-arrival state (struct arrival_unit_state per unit, arrival_state per flock): some flocks'
+    arrival regions are filling (bit 1 for every member), ~45 % of all units are committed to a valid
+    slot (bit 0), the slots both inside and outside 1.5 radii (ARRIVAL_SINK_TOLERANCE) of the unit."""
+    rng = np.random.RandomState(seed)
+    n = len(world["pos_xz"])
+    k = len(world["flock_target_xz"])
+    filling = rng.rand(k) < 0.6
+    flags = np.where(filling[world["flock"]], 2, 0).astype(np.uint8)
+    flags |= (rng.rand(n) < 0.45).astype(np.uint8)
+    off = rng.normal(0, 1, (n, 2)) * (world["radius"] * rng.choice([0.4, 1.2, 4.0, 25.0], n))[:, None]
+    sink = (world["pos_xz"] + off).astype(np.float32)
+    return sink, flags
+
+
 def los_chains(nav, grid, n_dests, seed, max_chunks=6):
     """LOS fields the way the planner chains them (nav.c:1840-1847,2026-2039): the destination
     chunk first, then chunk by chunk outwards, each built from its predecessor's field.

@@ -1,0 +1,85 @@
+"""tests/hostsim -- TEST INFRASTRUCTURE ONLY: the thread-per-agent bodies of the movement step
+(csrc/agent_thread.h) compiled with g++ and driven serially, to check their logic against the
+reference on a machine without a GPU.  Never imported by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "permafrost-engine_amd", "csrc")
+LIB = os.path.join(HERE, "_hostsim.so")
+_lib = None
+
+
+def build():
+    src = os.path.join(HERE, "hostsim.cpp")
+    deps = [src] + [os.path.join(CSRC, f) for f in ("agent_thread.h", "agent_math.h", "agent_types.h", "map_view.h")]
+    deps.append(os.path.join(ROOT, "include", "navhip.h"))
+    if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    # same floating-point contract as the device build: no FMA contraction, IEEE everything
+    cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, src, "-o", LIB]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+class Map(C.Structure):
+    _fields_ = [("chunk_w", C.c_int32), ("chunk_h", C.c_int32),
+                ("cost", C.c_void_p * 12), ("blockers", C.c_void_p * 12)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+DISP_NAMES = {0: "done", 1: "light1", 2: "light2", 3: "light3", 4: "light4", 5: "wave", 6: "full"}
+
+
+def agent_step(navhip, w, h, cost, blockers, arrays, coh_xz, hz=20, layer=0):
+    """arrays: navhip_world member arrays (numpy).  Returns dict of outputs + 'disp' (per entity:
+    DISP_* of agent_thread.h, +16 = the light search punted to the wave path)."""
+    world, keep = navhip.make_world(w, h, arrays, hz)
+    n = world.n_ents
+    m = Map()
+    m.chunk_w, m.chunk_h = w, h
+    cost = np.ascontiguousarray(cost, np.uint8)
+    blockers = np.ascontiguousarray(blockers, np.uint16)
+    m.cost[layer] = cost.ctypes.data
+    m.blockers[layer] = blockers.ctypes.data
+    out = {k: np.zeros((n, 2), np.float32) for k in ("vel_xz", "new_pos_xz", "vdes_xz", "vpref_xz")}
+    out["status"] = np.zeros(n, np.uint8)
+    so = navhip.StepOut()
+    for k in out:
+        setattr(so, k, out[k].ctypes.data)
+    disp = np.zeros(n, np.uint8)
+    counts = np.zeros((n, 2), np.int32)
+    coh = np.ascontiguousarray(coh_xz, np.float32)
+    rc = lib().hostsim_agent_step(C.byref(m), C.byref(world), coh.ctypes.data_as(C.c_void_p), C.byref(so),
+                                  disp.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    out["disp"] = disp
+    out["counts"] = counts
+    return out
+
+
+def clearpath_light(ent, des_v, dyn, n_dyn, stat, n_stat):
+    ent = np.ascontiguousarray(ent, np.float32).reshape(-1, 5)
+    nq = len(ent)
+    des_v = np.ascontiguousarray(des_v, np.float32).reshape(nq, 2)
+    dyn = np.ascontiguousarray(dyn, np.float32).reshape(nq, 32, 5)
+    stat = np.ascontiguousarray(stat, np.float32).reshape(nq, 32, 5)
+    n_dyn = np.ascontiguousarray(n_dyn, np.int32)
+    n_stat = np.ascontiguousarray(n_stat, np.int32)
+    out = np.zeros((nq, 2), np.float32)
+    found = np.zeros(nq, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().hostsim_clearpath_light(nq, p(ent), p(des_v), p(dyn), p(n_dyn), p(stat), p(n_stat), p(out), p(found))
+    assert rc == 0
+    return out, found

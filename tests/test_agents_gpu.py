@@ -63,6 +63,25 @@ def test_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread):
     assert exact, "ClearPath velocities are within tolerance but no longer bit-identical"
 
 
+@pytest.mark.parametrize("seed,max_dyn,max_stat,spread", [(1, 2, 2, 9.0), (2, 4, 0, 6.0), (3, 0, 4, 5.0),
+                                                         (4, 3, 1, 2.5), (5, 1, 1, 4.0)])
+def test_light_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread):
+    """The thread-per-agent ClearPath search (agents with at most four neighbours) on its own."""
+    nq = 600
+    ent, des, dyn, nd, stat, ns = cases.cp_problems(seed, nq, max_dyn, max_stat, spread)
+    ctx = navlib.NavContext(1, 1)
+    got, found = ctx.G_ClearPath_NewVelocity(ent, des, dyn, nd, stat, ns, light=True)
+    wave = ctx.G_ClearPath_NewVelocity(ent, des, dyn, nd, stat, ns)
+    ctx.close()
+    assert found.sum() > nq * 0.8
+    for i in range(nq):
+        exp = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
+        nan = np.isnan(exp)
+        assert np.array_equal(np.where(nan, 0, wave[i]).view(np.uint32), np.where(nan, 0, exp).view(np.uint32)), i
+        if found[i]:
+            assert np.array_equal(np.where(nan, 0, got[i]).view(np.uint32), np.where(nan, 0, exp).view(np.uint32)), i
+
+
 def _upload(navlib, nav):
     ctx = navlib.NavContext(nav.w, nav.h)
     ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(0))
@@ -110,6 +129,82 @@ def test_velocity_step_matches_reference(navlib, clustered, n, k, blk):
         acc = (np.linalg.norm(v) > 0) and nav.position_pathable(npos) and (on_blocked or not nav.position_blocked(npos))
         assert bool(out["status"][uid] & 1) == bool(acc), uid
     pfref.RefMove.unload()
+
+
+def test_garrisoned_neighbours_take_the_wave_path(navlib):
+    """filter_garrisoned (position.c:100-119) permutes the candidate list: agents with a garrisoned
+    entity among their hits are stepped by the wave-per-agent kernel, bit-identical to the reference."""
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    n, k = 1500, 4
+    world = cases.make_agents(grid, n, k, seed=31 + n, clustered=False)
+    g = np.random.RandomState(5).rand(n) < 0.02
+    world["flags"] = np.where(g, world["flags"] | navlib.ENTITY_FLAG_GARRISONED, world["flags"]).astype(np.uint32)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    exp_vel = mv.velocity(None)
+    vdes = mv.vdes()
+    ctx = _upload(navlib, nav)
+    out = ctx.agent_step(_step_arrays(world, mv, vdes))
+    lists = ctx.last_step_lists()
+    ctx.close()
+    assert lists[5] > 20, lists                      # the irregular list was exercised
+    moving = ~np.isin(world["state"], (2, 4))
+    assert np.array_equal(out["vel_xz"][moving].view(np.uint32), exp_vel[moving].view(np.uint32))
+    # a garrisoned entity never gets a position update (entity_compute_update, movement.c:2341-2348)
+    assert not (out["status"][g] & navlib.ST_MOVED).any()
+    assert np.array_equal(out["new_pos_xz"][g], world["pos_xz"][g])
+    pfref.RefMove.unload()
+
+
+def test_arrival_state_inputs_match_reference(navlib):
+    """arrival_sink_xz / arrival_flags: the seek target of committed units (G_Arrival_SeekTarget) and
+    settling neighbours as static obstacles (G_Arrival_NeighbourSettling), against the reference's own
+    arrival.c in the harness."""
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    n, k = 1500, 4
+    world = cases.make_agents(grid, n, k, seed=31 + n, clustered=False)
+    sink, aflags = cases.arrival_inputs(world, seed=3)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    base_vel = mv.velocity(None)
+    vdes = mv.vdes()
+    mv.set_arrival(sink, aflags)
+    exp_vel = mv.velocity(vdes)
+    moving = ~np.isin(world["state"], (2, 4))
+    assert (exp_vel[moving] != base_vel[moving]).any(1).sum() > 50
+    a = _step_arrays(world, mv, vdes)
+    a["arrival_sink_xz"], a["arrival_flags"] = sink, aflags
+    ctx = _upload(navlib, nav)
+    out = ctx.agent_step(a)
+    ctx.close()
+    assert np.array_equal(out["vel_xz"][moving].view(np.uint32), exp_vel[moving].view(np.uint32))
+    pfref.RefMove.unload()
+
+
+def test_slab_calls_share_one_output_buffer(navlib):
+    """One host-buffer call per slab into the SAME output arrays (the move_submit_cpu_work pattern,
+    movement.c:3759-3762): a call must only write the rows of its slab."""
+    import ctypes as C_
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    n = 1500
+    world = cases.make_agents(grid, n, 3, seed=9, clustered=False)
+    vdes = np.zeros((n, 2), np.float32)
+    vdes[:, 0] = 1.0
+    a = cases.step_arrays(world, vdes)
+    ctx = _upload(navlib, nav)
+    whole = ctx.agent_step(a)
+    w, keep = navlib.make_world(4, 4, a)
+    vel = np.full((n, 2), np.nan, np.float32)
+    npos = np.full((n, 2), np.nan, np.float32)
+    st = np.full(n, 0xAA, np.uint8)
+    so = navlib.StepOut()
+    so.vel_xz, so.new_pos_xz, so.status = vel.ctypes.data, npos.ctypes.data, st.ctypes.data
+    for b, e in ((0, 400), (400, 1100), (1100, n)):
+        w.work_begin, w.work_end = b, e
+        assert navlib.lib().navhip_agent_step(ctx._h, C_.byref(w), C_.byref(so)) == 0
+        assert np.isnan(vel[e:]).all() and (st[e:] == 0xAA).all()
+    ctx.close()
+    assert np.array_equal(vel.view(np.uint32), whole["vel_xz"].view(np.uint32))
+    assert np.array_equal(npos.view(np.uint32), whole["new_pos_xz"].view(np.uint32))
+    assert np.array_equal(st, whole["status"])
 
 
 def test_device_flow_sampling_matches_reference(navlib):

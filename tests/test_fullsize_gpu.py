@@ -116,14 +116,12 @@ def test_full_size_agent_step_properties(navlib, job):
     w, keep = navlib.make_world(W, W, arrays)
     import ctypes as C_
     halves = np.zeros((N, 2), np.float32)
+    so = navlib.StepOut()
+    so.vel_xz = halves.ctypes.data                  # both slab calls write into the same array
     for b, e in ((0, N // 2), (N // 2, N)):
         w.work_begin, w.work_end = b, e
-        so = navlib.StepOut()
-        tmp = np.zeros((N, 2), np.float32)
-        so.vel_xz = tmp.ctypes.data
         rc = navlib.lib().navhip_agent_step(ctx._h, C_.byref(w), C_.byref(so))
         assert rc == 0
-        halves[b:e] = tmp[b:e]
     assert np.array_equal(halves.view(np.uint32), vel.view(np.uint32))
     # (4) a sampled slab against the oracle restatement on the SAME full snapshot
     onav = navoracle.OracleNav(synth.to_chunks(grid), np.zeros((W, W, 64, 64), np.uint16),

@@ -1,0 +1,119 @@
+"""BASELINE.json's full sizes against the REFERENCE ITSELF (oracle/_ref), every unit of work:
+all chunk fields of the tick through the reference's N_FlowFieldInit + N_FlowFieldUpdate, all agent
+velocities through its move_velocity_work -- on the initial snapshot and on the snapshot the device
+has evolved for 100 ticks -- plus a crowded world in which the neighbour caps (128 / 32 + 32) bind.
+The desired directions (flow sampling over the 16 384-field pool, which the reference's 2 048-entry
+field cache cannot hold) are checked bit for bit against the C restatement, which the CPU suite pins
+to the reference."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import navoracle, pfref
+from tests import cases
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not pfref.available(), reason="oracle/_ref (the reference build) is not present")]
+
+CORES = max(1, min(32, len(os.sched_getaffinity(0))))
+
+
+def _check_agents(navlib, T, nav, onav, pos, vel, out_vel, out_pos, status, vdes, label):
+    """One velocity step of the whole job: GPU outputs vs restatement (everything) and vs the
+    reference's move_velocity_work (velocities), bit for bit."""
+    H = T.host
+    n = len(pos)
+    arrays = {
+        "pos_xz": pos, "vel_xz": vel, "radius": H["radius"], "max_speed": H["max_speed"], "speed": H["speed"],
+        "flags": np.full(n, navlib.ENTITY_FLAG_MOVABLE, np.uint32), "state": np.zeros(n, np.uint8),
+        "has_dest_los": np.zeros(n, np.uint8), "flock": H["flock"], "flock_target_xz": H["targets"],
+        "flock_offsets": H["flock_offsets"], "flock_members": H["flock_members"],
+        "flock_field_slot": H["slot_tbl"], "field_pool": T.pool.cpu().numpy(), "vdes_xz": None,
+    }
+    exp = onav.agent_step(arrays, nthreads=CORES)
+    assert np.array_equal(vdes.view(np.uint32), exp["vdes_xz"].astype(np.float32).view(np.uint32)), label
+    assert np.array_equal(status, exp["status"]), label
+    assert np.array_equal(out_vel.view(np.uint32), exp["vel_xz"].astype(np.float32).view(np.uint32)), label
+    assert np.array_equal(out_pos.view(np.uint32), exp["new_pos_xz"].astype(np.float32).view(np.uint32)), label
+    # the reference itself, all agents, on the desired directions the device sampled
+    k = len(H["targets"])
+    mv = pfref.RefMove(nav, pos, vel, H["radius"], H["max_speed"], H["speed"], arrays["flags"],
+                       np.zeros(n, np.int32), H["flock"], arrays["has_dest_los"], H["targets"],
+                       np.zeros(k, np.uint32), hz=20)
+    # (flock member order: ascending uid here and in the reference's khash for dense small keys --
+    # checked, because the cohesion sum depends on it)
+    for f in (0, k - 1):
+        assert np.array_equal(mv.flock_order(f), H["flock_members"][H["flock_offsets"][f]:H["flock_offsets"][f + 1]])
+    _, ref_vel = mv.bench(vdes, reps=1, nthreads=CORES)
+    pfref.RefMove.unload()
+    bad = np.flatnonzero((out_vel.view(np.uint32) != ref_vel.view(np.uint32)).any(1))
+    assert len(bad) == 0, (label, len(bad), bad[:5], out_vel[bad[:3]], ref_vel[bad[:3]])
+    return exp
+
+
+def _job(navlib, W, K, N, crowd=0):
+    from permafrost_engine_amd import tick
+    T = tick.NavTick(chunk_w=W, fields_per_rank=K, agents_per_rank=N, device=0, debug_outputs=True,
+                     crowd_cells=crowd)
+    grid = T.grid
+    nav = pfref.RefNav(cases.synth.to_chunks(grid))
+    # the device's own local-island labelling is what the requests carry: it must be the reference's
+    assert np.array_equal(cases.synth.to_chunks(T.host["liid"]), nav.plane(pfref.PLANE_LOCAL_ISLANDS))
+    onav = navoracle.OracleNav(cases.synth.to_chunks(grid), np.zeros((W, W, 64, 64), np.uint16),
+                               cases.synth.to_chunks(T.host["liid"]))
+    return T, nav, onav
+
+
+def _snapshot(T):
+    return T.t["pos_xz"].cpu().numpy().copy(), T.t["vel_xz"].cpu().numpy().copy()
+
+
+def _tick_and_fetch(T):
+    pos, vel = _snapshot(T)
+    T.step()
+    T.sync()
+    return dict(pos=pos, vel=vel, out_vel=T.t["vel_xz"].cpu().numpy(), out_pos=T.t["pos_xz"].cpu().numpy(),
+                status=T.status.cpu().numpy(), vdes=T.vdes_out.cpu().numpy())
+
+
+@pytest.mark.parametrize("W,K,N,ticks", [(16, 16, 50_000, 0), (16, 64, 100_000, 100)])
+def test_whole_config_against_the_reference(navlib, W, K, N, ticks):
+    T, nav, onav = _job(navlib, W, K, N)
+    r = _tick_and_fetch(T)
+    # every chunk field of the tick through the reference (threaded N_FlowFieldInit + N_FlowFieldUpdate)
+    ref_reqs = np.zeros(len(T.host["reqs"]), pfref.FIELD_REQ_DTYPE)
+    for name in ref_reqs.dtype.names:
+        if name in T.host["reqs"].dtype.names:
+            ref_reqs[name] = T.host["reqs"][name]
+    ref_dirs = nav.field_update_many(ref_reqs, nthreads=CORES)
+    got = T.pool.cpu().numpy().reshape(-1, 64, 64)
+    bad = np.flatnonzero((got != ref_dirs).reshape(len(got), -1).any(1))
+    assert len(bad) == 0, "%d of %d chunk fields differ from the reference (first %s)" % (len(bad), len(got), bad[:5])
+    del ref_dirs
+    _check_agents(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"], r["vdes"], "tick 0")
+    assert (r["status"] & navlib.ST_MOVED).astype(bool).mean() > 0.5
+    if ticks:
+        for _ in range(ticks - 1):
+            T.step()
+        r = _tick_and_fetch(T)
+        _check_agents(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"], r["vdes"],
+                      "tick %d" % ticks)
+    T.close()
+
+
+def test_crowded_world_against_the_reference(navlib):
+    """Every flock packed into ~35 x 35 cells: the r = 30 cap (128) and the ClearPath caps (32 + 32)
+    bind, most agents take the wave-per-agent search."""
+    T, nav, onav = _job(navlib, 16, 16, 24_000, crowd=17)
+    r = _tick_and_fetch(T)
+    lists = T.ctx.last_step_lists()
+    assert lists[4] > 0.5 * 24_000, lists                      # the wave list carries the crowd
+    exp = _check_agents(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"],
+                        r["vdes"], "crowded tick 0")
+    for _ in range(3):
+        T.step()
+    r = _tick_and_fetch(T)
+    _check_agents(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"], r["vdes"],
+                  "crowded tick 4")
+    T.close()
