@@ -10,8 +10,8 @@ steering forces -> neighbour gather -> ClearPath -> truncate -> position accept)
 then advance the snapshot.  --config selects the BASELINE.json configuration:
 
   0  256x256 map, 1 flow field, 1 000 agents: the reference's own CPU-runnable case.  The GPU path is
-     timed on it and the WHOLE workload is also run through the reference build on the host
-     (unsampled cpu_baseline + a full parity check of the first tick).
+     timed on it and the WHOLE workload is also timed through the reference build on the host
+     (unsampled cpu_baseline).
   1  1024x1024 map, 16 flow fields, 50 000 agents
   2  1024x1024 map, 64 flow fields (16 384 chunk fields), 100 000 agents -- the configuration the
      target (>= 1e7 agent-steps/s) is quoted on; DEFAULT.  With --gpus N > 1 it is weak-scaled:
@@ -151,41 +151,60 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10
                 "sample": "unavailable: %r" % (exc,)}
 
 
-def parity_config0(T):
-    """config 0: the whole first tick against the reference build (every chunk field, every agent)."""
-    try:
-        from oracle import pfref
-        if not pfref.available():
-            return None
-        import numpy as np
-        sys.path.insert(0, ROOT)
-        from tests import cases
-        return cases.tick_parity(T, ticks=1)
-    except Exception as exc:
-        return {"error": repr(exc)}
-
-
 def status_histogram(T):
     import numpy as np
     from permafrost_engine_amd import navhip
     st = T.status[T.a0:T.a1].cpu().numpy()
     lists = T.ctx.last_step_lists()
     n = max(1, len(st))
+    import ctypes as C
+    att = (C.c_ulonglong * 9)()
+    cp = None
+    if navhip.lib().navhip_debug_cp_attempts(att, 1) == 0:
+        cp = {"returned_in_attempt_2..7+": [int(att[i]) for i in range(1, 8)], "gave_up": int(att[0]),
+              "attempts_of_retried_problems": int(att[8]), "note": "since the start of the run; problems that "
+              "returned in their first attempt are not counted"}
     return {
         "moved": float((st & navhip.ST_MOVED).astype(bool).mean()),
         "field_miss": float((st & navhip.ST_FIELD_MISS).astype(bool).mean()),
         "field_none": float((st & navhip.ST_FIELD_NONE).astype(bool).mean()),
         "unsupported": float((st & navhip.ST_UNSUPPORTED).astype(bool).mean()),
-        "clearpath_search_thread": [x / n for x in lists[:4]],
-        "clearpath_search_wave": lists[4] / n, "whole_step_wave": lists[5] / n,
+        "clearpath_on_row_1-2_3-4_5-8_9-16_neighbours": [x / n for x in lists[:4]],
+        "clearpath_on_wave_17-64_neighbours": lists[4] / n, "whole_step_on_wave": lists[5] / n,
+        "clearpath_retries": cp,
     }
 
 
-def run_ticks(T, pdist, torch, warmup, steps):
+def profiled_ticks(T, n):
+    """n ticks with every kernel group of the agent step back to back on ONE stream (no prefetch, no
+    overlap with the field builds), the library's own HIP events between the groups.  Returns the
+    mean milliseconds per group (first tick dropped when n > 1)."""
     import numpy as np
-    for _ in range(warmup):
+    from permafrost_engine_amd import navhip
+    T.ctx.set_profiling(True)
+    keep = (T.overlap, T.record, T.mark_every, T.ev, T.tick_ev)
+    T.overlap, T.record, T.mark_every, T.ev, T.tick_ev = False, True, 1, [], []
+    rows = []
+    for _ in range(n):
+        T.step()
+        T.sync()
+        rows.append(T.ctx.last_step_ms())
+    serial = T.phase_ms()
+    T.overlap, T.record, T.mark_every, T.ev, T.tick_ev = keep
+    T.ctx.set_profiling(False)
+    rows = rows[1:] if len(rows) > 1 else rows
+    g = {name: float(np.mean([x[i] for x in rows])) for i, name in enumerate(navhip.STEP_PHASES)}
+    g["fields"] = serial.get("fields", 0.0)
+    return g
+
+
+def run_ticks(T, pdist, torch, warmup, steps, early=None):
+    import numpy as np
+    for _ in range(max(0, warmup - 3) if early is not None else warmup):
         T.step()
     T.sync()
+    if early is not None:
+        early.update(profiled_ticks(T, min(3, warmup)))
     pdist.barrier()
     torch.cuda.synchronize()
     T.record = True
@@ -253,27 +272,14 @@ def main():
                             shared_map=shared, crowd_cells=CROWD if crowd else 0)
 
     T = make(args.crowded)
-    parity = parity_config0(T) if (args.config == 0 and rank == 0 and world == 1) else None
-    dt, ticks = run_ticks(T, pdist, torch, args.warmup, args.steps)
+    early = {}
+    dt, ticks = run_ticks(T, pdist, torch, args.warmup, args.steps, early)
     phases = T.phase_ms()
     hist = status_histogram(T)
 
-    # per-kernel-group durations: a few extra (untimed) ticks with every group back to back on ONE
-    # stream (no overlap), the library's own HIP events between them
-    T.ctx.set_profiling(True)
-    T.record, T.mark_every = True, 1
-    T.ev, T.tick_ev = [], []
-    ksplit = []
-    for _ in range(6):
-        T.step()
-        T.sync()
-        ksplit.append(T.ctx.last_step_ms())
-    T.record = False
-    T.ctx.set_profiling(False)
-    serial = T.phase_ms()
-    from permafrost_engine_amd import navhip
-    groups = {name: float(np.mean([x[i] for x in ksplit[1:]])) for i, name in enumerate(navhip.STEP_PHASES)}
-    groups["fields"] = serial.get("fields", 0.0)
+    # per-kernel-group durations at the END of the run (the world has crowded by then); the same
+    # split for the last warm-up ticks is in `early`
+    groups = profiled_ticks(T, 6)
 
     agents_total = T.N
     cells_total = T.n_req_total * 4096
@@ -332,7 +338,7 @@ def main():
                        if which == "agents" else "navhip_build_fields_dev: k_field_bfs"),
             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by,
             "launch_timing": "HIP events on the launch stream, kernel groups back to back on one stream "
-                             "(6 profiled ticks after the timed region)",
+                             "(profiled ticks after the timed region, when the world has crowded)",
             "kernels_ms": {k: groups[k] for k in ("sp_build", "agent_nbr", "cohesion", "coh_regroup", "agent_finish")}
                           if which == "agents" else {"fields": f_ms},
             "valu_issue": valu(("k_agent_", "k_cp_", "k_coh", "k_sp_"), ms) if which == "agents"
@@ -369,16 +375,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if shared else "weak", "vs_baseline": None,
             "dtype": "u64-bitmask/u8 fields, f32 agents (f64 exp)", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[%d]%s: %dx%d-cell map (%dx%d chunks%s), %d flow fields "
-                                   "(%d chunk fields) + %d agents %s, fields rebuilt + agents stepped every tick%s%s"
-                                   % (args.config, " (crowded world)" if args.crowded else "",
-                                      T_dims(cfg, world, shared)[0], T_dims(cfg, world, shared)[1],
-                                      T_dims(cfg, world, shared)[2], T_dims(cfg, world, shared)[3],
-                                      "" if world == 1 or shared else ": %d regions of %dx%d chunks" % (world, cfg["map"], cfg["map"]),
-                                      cfg["fields"], cells_total // 4096 if shared else cells_total // 4096 // world,
-                                      cfg["agents"], "in total" if shared else "per GPU",
-                                      ", %d dynamic obstacles (1 %% moved per tick, incremental repair)" % cfg["obstacles"]
-                                      if cfg["obstacles"] else "", ""),
+            "config": {"workload": "BASELINE.json configs[%d]%s: %dx%d-cell map (%dx%d chunks%s), %d flow fields%s, "
+                                   "%d chunk fields + %d agents per tick%s; fields rebuilt + agents stepped every tick"
+                                   % ((args.config, " (crowded world)" if args.crowded else "") + T_dims(cfg, world, shared)
+                                      + ("" if world == 1 or shared else ": %d regions of %dx%d chunks" % (world, cfg["map"], cfg["map"]),
+                                         cfg["fields"], "" if shared or world == 1 else " per GPU", cells_total // 4096,
+                                         agents_total,
+                                         ", %d dynamic obstacles (1 %% moved per tick, incremental repair)" % cfg["obstacles"]
+                                         if cfg["obstacles"] else "")),
                        "baseline_config": args.config, "map_chunks": cfg["map"], "flow_fields": cfg["fields"],
                        "agents": cfg["agents"], "hz": 20, "dynamic_obstacles": cfg["obstacles"],
                        "parallelism": "requests by destination + agent slabs x%d; one all-gather of slab results "
@@ -389,12 +393,12 @@ def main():
             ("flow_field_cells_kept_valid_per_s" if cfg["obstacles"] else "flow_field_cells_per_s"):
                 cells_total * args.steps / dt,
             "phase_ms_overlapped": phases,
+            "kernel_groups_ms_serial": {"after_warmup": early, "after_timed_region": groups},
             "status": hist,
             "roofline": roof(dom),
             "roofline_secondary": roof(other),
             "csrc_sha": sha,
             "crowded_world": crowded,
-            "parity_first_tick": parity,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

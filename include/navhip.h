@@ -255,6 +255,42 @@ uint64_t navhip_flow_field_id(const navhip_field_req *req);
  * cell of the chunk has cost 1, generic relaxation otherwise), 1 = force generic. */
 int  navhip_set_field_kernel(navhip_ctx *ctx, int mode);
 
+/* ---- resident flow-field pool (SURVEY.md §8b "Ownership" / the reference's field cache) ------- */
+
+/* A C host has no device pointers: without a device-resident pool every host-buffer call would move
+ * the field cache over PCIe again.  The pool keeps chunk fields in HBM under the reference's own
+ * 64-bit flow-field ids (N_FlowFieldID, field.c:1952) and mirrors the operations of the reference's
+ * cache (fieldcache.c): put / contains / (dest, chunk) -> field mapping; least-recently-used slots
+ * are recycled like lru_flow_put (fieldcache.c:411), and mappings that point at a recycled slot drop
+ * to "no field".  n_dests = rows of the mapping table; the agent step uses the FLOCK INDEX as row.
+ * Called from the nav-tick task only, like the reference's cache (FC_ASSERT_NAV_TASK). */
+int  navhip_pool_create(navhip_ctx *ctx, int n_slots, int n_dests);
+void navhip_pool_destroy(navhip_ctx *ctx);
+int  navhip_pool_clear(navhip_ctx *ctx);                                  /* N_FC_ClearAll              */
+int  navhip_pool_contains(navhip_ctx *ctx, uint64_t ff_id);               /* N_FC_ContainsFlowField     */
+int  navhip_pool_put(navhip_ctx *ctx, uint64_t ff_id, const uint8_t *dirs);   /* N_FC_PutFlowField: 4096
+                                                                              direction bytes from the host */
+int  navhip_pool_get(navhip_ctx *ctx, uint64_t ff_id, uint8_t *out_dirs); /* N_FC_FlowFieldAt (a copy)  */
+/* Batched N_FlowFieldInit + N_FlowFieldUpdate + N_FC_PutFlowField: request i is built INTO the pool
+ * slot of ff_ids[i].  For a NAVHIP_REQ_INOUT request base_ids[i] names the resident field the update
+ * starts from (the memcpy of nav.c:1998, the repairs of nav.c:3527-3547); 0 or ff_ids[i] itself = the
+ * slot's own content; base_ids may be NULL.  Requests that depend on an earlier request of the same
+ * call are ordered behind it.  out_dirs: n * 4096 bytes copied back, or NULL. */
+int  navhip_pool_build(navhip_ctx *ctx, const navhip_field_req *reqs, const uint64_t *ff_ids,
+                       const uint64_t *base_ids, int n, uint8_t *out_dirs);
+/* N_FC_PutDestFFMapping, batched: (dest row, chunk) -> ff_id; an id that is not resident maps to
+ * "no field" (the step then reports NAVHIP_ST_FIELD_MISS for agents on that chunk). */
+int  navhip_pool_map(navhip_ctx *ctx, int n, const int32_t *dest, const uint16_t *chunk_r,
+                     const uint16_t *chunk_c, const uint64_t *ff_ids);
+/* navhip_world.n_field_slots value that makes the agent step sample the context's resident pool
+ * (field_pool / flock_field_slot are then ignored) */
+#define NAVHIP_POOL_RESIDENT (-1)
+
+/* Page-locked host memory: arrays allocated here are transferred by the host-buffer entry points
+ * without a staging copy (any other host memory works too, through the library's own pinned slab). */
+void *navhip_host_alloc(size_t bytes);
+void  navhip_host_free(void *p);
+
 /* ---- per-agent movement step ---------------------------------- */
 
 /* enum move_state, movement.c:113-143 */
@@ -284,7 +320,7 @@ typedef struct navhip_world {
     int32_t  n_ents;                 /* every entity in the position snapshot                  */
     int32_t  n_flocks;
     int32_t  hz;                     /* movement tick rate: 20/10/5/1 (hz_count, movement.c:2210) */
-    int32_t  n_field_slots;
+    int32_t  n_field_slots;          /* slots of field_pool, or NAVHIP_POOL_RESIDENT                */
     const float    *pos_xz;          /* [n][2]  G_Pos_GetXZFrom                                */
     const float    *vel_xz;          /* [n][2]  movestate.velocity (world units per tick)      */
     const float    *radius;          /* [n]     G_GetSelectionRadiusFrom                       */
@@ -350,6 +386,15 @@ int  navhip_agent_step(navhip_ctx *ctx, const navhip_world *world, const navhip_
 int  navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *dev_world,
                            const navhip_step_out *dev_out, void *stream);
 
+/* Asynchronous host-buffer form (SURVEY.md §8b "Threading": the nav task must not block for a tick;
+ * the GL path polls a fence once per frame, movement.c:4212-4233): submit stages the inputs through
+ * pinned memory and returns at once; poll returns 1 while the step is running and 0 once the outputs
+ * are in the caller's arrays (wait blocks until then).  One step in flight per context; the caller's
+ * arrays must stay untouched between submit and completion. */
+int  navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *world, const navhip_step_out *out);
+int  navhip_agent_step_poll(navhip_ctx *ctx);
+int  navhip_agent_step_wait(navhip_ctx *ctx);
+
 /* Optional overlap: start the parts of the step that depend only on the snapshot (the spatial hash
  * and the O(N*F) cohesion term) on the context's own side streams, forked from `stream`, and return
  * at once.  Work enqueued on `stream` afterwards (e.g. the tick's field builds) then runs
@@ -368,10 +413,10 @@ int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, v
 #define NAVHIP_STEP_PHASES 5
 int  navhip_set_profiling(navhip_ctx *ctx, int on);
 int  navhip_last_step_ms(navhip_ctx *ctx, float out_ms[NAVHIP_STEP_PHASES]);
-/* How the last agent step split its agents (waits for it): the number of agents whose ClearPath
- * search ran on a thread ([0..3]: 1..4 neighbours), on a wave ([4]: more neighbours, or
- * remove_furthest retries), and agents whose whole step ran on a wave ([5]: garrisoned neighbours /
- * wide queries).  Everyone else finished in the thread-per-agent pass. */
+/* How the last agent step split its agents (waits for it): the number of agents whose ClearPath ran
+ * on a row of 16 lanes ([0..3]: 1-2, 3-4, 5-8, 9-16 neighbours), on a wave ([4]: 17-64 neighbours),
+ * and agents whose whole step ran on a wave ([5]: garrisoned neighbours / wide queries).  Everyone
+ * else has no ClearPath neighbour and finished in the thread-per-agent pass. */
 int  navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6]);
 
 /* Device spatial index only (bg_ent insert-all + cleanup + inrange_circle, bitmap_grid.h:1376):
@@ -386,12 +431,12 @@ int  navhip_spatial_query(navhip_ctx *ctx, const navhip_world *world, const floa
 int  navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
                       const float *dyn, const int32_t *n_dyn, const float *stat,
                       const int32_t *n_stat, float *out);
-/* The same problems through the thread-per-agent search the agent step uses for agents with at most
- * 4 neighbours (n_dyn + n_stat <= 4).  found[q] = 0: no admissible candidate -- the step hands such
- * agents to the wave path (remove_furthest + retry, clearpath.c:390,694-715); out[q] is then unset. */
-int  navhip_clearpath_light(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
-                            const float *dyn, const int32_t *n_dyn, const float *stat,
-                            const int32_t *n_stat, float *out, int32_t *found);
+/* The same problems on one row of 16 lanes each -- the form the agent step uses for agents with at most
+ * 16 ClearPath neighbours (n_dyn + n_stat <= 16; navhip_clearpath runs one wave per problem, the
+ * form for agents in a crowd). */
+int  navhip_clearpath_rows(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                           const float *dyn, const int32_t *n_dyn, const float *stat,
+                           const int32_t *n_stat, float *out);
 
 #ifdef __cplusplus
 }

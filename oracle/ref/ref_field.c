@@ -61,6 +61,40 @@ bool pfref_make_target(const struct nav_private *priv, const pfref_field_req *re
     return true;
 }
 
+/* A request whose portal endpoints are not a portal of the reference's own portal build (synthetic
+ * request streams cut portals their own way): field.c only reads the endpoints and the chunk of the
+ * two portals (field_portal_initial_frontier :1160, field_fixup_portal_edges :830), so two
+ * free-standing struct portal carry them.  storage: 2 portals that outlive the build. */
+static bool make_target_synth(const struct nav_private *priv, const pfref_field_req *req,
+                              struct field_target *out, struct portal *storage)
+{
+    if(pfref_make_target(priv, req, out))
+        return true;
+    if(req->type != TARGET_PORTAL)
+        return false;
+    memset(storage, 0, 2 * sizeof(struct portal));
+    /* field_fixup_portal_edges (:830) takes the direction from the chunk of n_portal(port->connected):
+     * any real portal of the next chunk serves (two chunks that share a passable edge have one) */
+    int next_idx = IDX(req->next_chunk_r, priv->width, req->next_chunk_c);
+    if(priv->chunks[req->layer][next_idx].num_portals == 0)
+        return false;
+    storage[0].connected = portal_ref_make(next_idx, 0);
+    storage[1].connected = portal_ref_make(IDX(req->chunk_r, priv->width, req->chunk_c), 0);
+    storage[0].chunk = (struct coord){req->chunk_r, req->chunk_c};
+    storage[0].endpoints[0] = (struct coord){req->port_r0, req->port_c0};
+    storage[0].endpoints[1] = (struct coord){req->port_r1, req->port_c1};
+    storage[1].chunk = (struct coord){req->next_chunk_r, req->next_chunk_c};
+    storage[1].endpoints[0] = (struct coord){req->next_r0, req->next_c0};
+    storage[1].endpoints[1] = (struct coord){req->next_r1, req->next_c1};
+    memset(out, 0, sizeof(*out));
+    out->type = TARGET_PORTAL;
+    out->pd = (struct portal_desc){
+        .port = &storage[0], .port_iid = (uint16_t)req->port_iid,
+        .next = &storage[1], .next_iid = (uint16_t)req->next_iid,
+    };
+    return true;
+}
+
 void pfref_req_from_target(struct coord chunk, int faction_id, enum nav_layer layer,
                            const struct field_target *t, pfref_field_req *out)
 {
@@ -348,9 +382,10 @@ static double field_many(pfref_nav *nav, const pfref_field_req *reqs, int n, int
 {
     const struct nav_private *priv = pfref_nav_private(nav);
     struct field_target *targets = malloc(sizeof(struct field_target) * (size_t)n);
+    struct portal *synth = malloc(sizeof(struct portal) * 2 * (size_t)n);
     for(int i = 0; i < n; i++) {
-        if(!pfref_make_target(priv, &reqs[i], &targets[i])) {
-            free(targets);
+        if(!make_target_synth(priv, &reqs[i], &targets[i], &synth[2 * (size_t)i])) {
+            free(targets); free(synth);
             return -1.0;
         }
     }
@@ -370,6 +405,6 @@ static double field_many(pfref_nav *nav, const pfref_field_req *reqs, int n, int
         pthread_join(tids[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
 
-    free(targets);
+    free(targets); free(synth);
     return (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
 }

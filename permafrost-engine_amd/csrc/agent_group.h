@@ -1,0 +1,730 @@
+// agent_group.h -- the neighbour walk and the ClearPath search for a GROUP of G lanes per agent
+// (device only).  G = 16 (one DPP row; four agents per wave) for the common agent with up to 16
+// ClearPath neighbours, G = 64 (the whole wave) for agents in a crowd.
+//
+// Why groups: 100 000 agents are 1 563 waves if a thread steps an agent -- 1.5 waves per SIMD, every
+// dependent load and every long scalar chain exposed (measured: 100-150 us per kernel) -- and 100 000
+// waves with most lanes idle if a wave does (round 1: 1 017 wave instructions per agent).  Sixteen
+// lanes per agent are 25 000 waves, and the lane-parallel parts of the step (candidate tests, cones,
+// ray pairs) are 16-64 wide for the typical agent.
+//
+// Everything a group does is "group uniform" control flow; cross-lane traffic stays inside the group
+// (ballot bits of the group, shuffles with a group-relative source, xor butterflies below G).
+#pragma once
+#include "agent_thread.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int G> struct grp {
+    static __device__ __forceinline__ int lane() { return (int)(threadIdx.x & (G - 1)); }
+    static __device__ __forceinline__ int base() { return (int)(threadIdx.x & 63 & ~(G - 1)); }
+    static __device__ __forceinline__ unsigned long long ballot(bool p)
+    {
+        const unsigned long long m = __ballot(p);
+        if(G == 64) return m;
+        return (m >> base()) & ((1ull << (G & 63)) - 1ull);
+    }
+    static __device__ __forceinline__ bool any(bool p) { return ballot(p) != 0ull; }
+    static __device__ __forceinline__ int shfl(int v, int src) { return __shfl(v, base() + src); }
+    static __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, base() + src); }
+    // lexicographic (key, idx) arg-min over the group; key = +inf means "no candidate"
+    static __device__ __forceinline__ void argmin(float &key, int &idx)
+    {
+#pragma unroll
+        for(int d = G / 2; d >= 1; d >>= 1) {
+            const float ok = __shfl_xor(key, d);
+            const int   oi = __shfl_xor(idx, d);
+            const bool take = (ok < key) || (ok == key && oi < idx);
+            if(take) { key = ok; idx = oi; }
+        }
+    }
+};
+
+// inclusive prefix sum inside every row of 16 lanes (DPP row_shr, zero fill)
+__device__ __forceinline__ int row_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// neighbour walk, 16 lanes per agent
+// ---------------------------------------------------------------------------------------------
+// A SEGMENT = the cells of one fine row inside one coarse block that the query box covers:
+// contiguous in the cell-sorted pool.  An r = 30 box is at most 5 x 5 fine cells and touches at most
+// 2 x 2 coarse blocks: at most 10 segments, in visiting order (coarse block row, coarse block column,
+// fine row; bitmap_grid.h:1408-1466) one per lane.
+struct seg_table { int incl, len, bo; int total; };
+
+__device__ __forceinline__ seg_table row_segments(const nh_grid &G, const sp_extent &E, int gl)
+{
+    const int cxc_lo = E.cx_lo >> 3, cxc_hi = E.cx_hi >> 3;
+    const int cyc_lo = E.cy_lo >> 3, cyc_hi = E.cy_hi >> 3;
+    const int ncb = cxc_hi - cxc_lo + 1;                                  // 1 or 2 block columns
+    const int nr0 = min(cyc_lo * 8 + 7, E.cy_hi) - E.cy_lo + 1;           // fine rows in the first block row
+    const int nr1 = (cyc_hi > cyc_lo) ? E.cy_hi - (cyc_lo + 1) * 8 + 1 : 0;
+    int cb = 0, fy = -1;
+    if(gl < ncb * nr0) {
+        cb = gl >= nr0 ? 1 : 0;
+        fy = E.cy_lo + (gl - cb * nr0);
+    }else if(gl < ncb * (nr0 + nr1)) {
+        const int s = gl - ncb * nr0;
+        cb = s >= nr1 ? 1 : 0;
+        fy = (cyc_lo + 1) * 8 + (s - cb * nr1);
+    }
+    seg_table T; T.len = 0; int bb = 0;
+    if(fy >= 0) {
+        const int cxc = cxc_lo + cb;
+        const int fx0 = max(cxc * 8, E.cx_lo), fx1 = min(cxc * 8 + 8, E.cx_hi + 1);
+        bb = G.cell_start[fy * G.grid_w + fx0];
+        T.len = G.cell_start[fy * G.grid_w + fx1] - bb;
+    }
+    T.incl = row_incl_scan(T.len);
+    T.total = grp<16>::shfl(T.incl, 15);
+    T.bo = bb - (T.incl - T.len);                         // pool index of candidate q of this segment: bo + q
+    return T;
+}
+
+// pool index of candidate q (q < total): the first segment whose inclusive prefix exceeds q
+__device__ __forceinline__ int row_candidate(const seg_table &T, int q)
+{
+    int lo = 0;
+#pragma unroll
+    for(int st = 8; st >= 1; st >>= 1) {
+        const int pv = grp<16>::shfl(T.incl, lo + st - 1);
+        if(pv <= q) lo += st;
+    }
+    return grp<16>::shfl(T.bo, lo & 15) + q;
+}
+
+// separation_force (movement.c:1690, r = 30, cap 128) and find_neighbours (movement.c:2768, r = 10, cap
+// 512, 32 + 32) of the entity in pool slot k, in ONE walk: the r = 10 query is the r = 30 walk restricted
+// to d <= 10 (its box lies inside the r = 30 box, the visiting key does not depend on the query, and an
+// element of a cell outside the r = 10 box fails the distance test anyway).  Once the r = 30 query has
+// stopped at its cap the walk restarts on the smaller r = 10 box.  Both caps bind where the reference's
+// two separate queries stop.  terms: this group's 16 float2 of LDS.
+// Left to the wave-per-agent path (NH_NB_IRREGULAR): a garrisoned entity among the hits
+// (filter_garrisoned, position.c:100-119, permutes the list) and queries that take the reference's
+// wide linear scan or miss the grid.
+__device__ void nbr_walk_row(const nh_grid &G, int k, float scaled_max_force, const double *exp_tab,
+                             float2 *terms, const nh_nbr &NB)
+{
+    typedef grp<16> g;
+    const int gl = g::lane();
+    const unsigned lt = (1u << gl) - 1u;
+    const float4 me4 = G.recA[k];
+    const uint32_t mybits = __float_as_uint(me4.w);
+    const int uid = (int)(mybits >> NH_PB_UID_SHIFT);
+    const v2 me = mkv(me4.x, me4.y);
+    const float my_radius = me4.z;
+    const int32_t icx = bg_scale(me.x), icy = bg_scale(me.z);
+    const int32_t ir30 = bg_scale(30.0f), ir10 = bg_scale(10.0f);
+    sp_extent E30, E10;
+    if(!sp_query_extent(G, icx, icy, ir30, E30) || !sp_query_extent(G, icx, icy, ir10, E10)
+    || E30.wide || E10.wide
+    || (E30.cx_hi >> 3) - (E30.cx_lo >> 3) > 1 || (E30.cy_hi >> 3) - (E30.cy_lo >> 3) > 1) {
+        if(gl == 0) NB.cnt[uid] = (NH_NB_IRREGULAR | NH_NB_DONE) << 16;
+        return;
+    }
+    const int32_t lim30 = ir30 * ir30, lim10 = ir10 * ir10;
+    int raw30 = 0, raw10 = 0, n_dyn = 0, n_stat = 0;
+    bool irregular = false;
+    f2 acc = {0.0f, 0.0f};
+    bool r10_only = false;
+    seg_table T = row_segments(G, E30, gl);
+    for(int q0 = 0; ; q0 += 16) {
+        if(q0 >= T.total) {
+            break;
+        }
+        const int q = q0 + gl;
+        const bool valid = q < T.total;
+        const int kk = row_candidate(T, valid ? q : 0);
+        float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int32_t d2 = 0x7fffffff;
+        if(valid) {
+            c = G.recA[kk];
+            // (elements clamped into a border cell may be far away: range-check before squaring in
+            // 32 bits; r = 30: |d| <= 7680 + 4095 otherwise)
+            const int32_t dx = bg_scale(c.x) - icx, dy = bg_scale(c.y) - icy;
+            const bool nearby = (uint32_t)(dx + 32767) < 65535u && (uint32_t)(dy + 32767) < 65535u;
+            if(nearby) d2 = dx * dx + dy * dy;
+        }
+        const unsigned m30 = r10_only ? 0u : (unsigned)g::ballot(d2 <= lim30);
+        const unsigned m10 = (unsigned)g::ballot(d2 <= lim10);
+        const bool acc30 = !r10_only && d2 <= lim30 && raw30 + __popc(m30 & lt) < NH_SEP_CAP;
+        const bool acc10 = d2 <= lim10 && raw10 + __popc(m10 & lt) < NH_NEAR_CAP;
+        const uint32_t bits = __float_as_uint(c.w);
+        if(g::any((acc30 || acc10) && (bits & NH_PB_GARRISONED))) { irregular = true; break; }
+        const bool other = kk != k && (bits & NH_PB_MOVABLE) && !((mybits ^ bits) & NH_PB_AIR);
+        if(!r10_only && m30) {
+            // separation terms lane-parallel, then added in candidate order (skipped candidates add
+            // +0, which leaves the never-negative-zero running sum unchanged)
+            v2 term = mkv(0.0f, 0.0f);
+            if(acc30 && other) {
+                v2 t2;
+                if(separation_term(me, my_radius, mkv(c.x, c.y), c.z, exp_tab, t2)) term = t2;
+            }
+            terms[gl] = make_float2(term.x, term.z);
+            wave_sync();
+#pragma unroll
+            for(int j = 0; j < 16; j += 2) {
+                const float4 two = *(const float4*)&terms[j];
+                acc = acc + f2{two.x, two.y};
+                acc = acc + f2{two.z, two.w};
+            }
+            wave_sync();
+        }
+        {
+            const bool want = acc10 && other && c.z != 0.0f;
+            const bool is_s = want && (bits & NH_PB_STATIC), is_d = want && !(bits & NH_PB_STATIC);
+            const unsigned ms = (unsigned)g::ballot(is_s), md = (unsigned)g::ballot(is_d);
+            if(is_s) {
+                const int p = n_stat + __popc(ms & lt);
+                if(p < NH_MAX_NEIGHBOURS) NB.list[(size_t)(32 + p) * NB.stride + uid] = kk;
+            }
+            if(is_d) {
+                const int p = n_dyn + __popc(md & lt);
+                if(p < NH_MAX_NEIGHBOURS) NB.list[(size_t)p * NB.stride + uid] = kk;
+            }
+            n_stat = min(NH_MAX_NEIGHBOURS, n_stat + __popc(ms));
+            n_dyn = min(NH_MAX_NEIGHBOURS, n_dyn + __popc(md));
+        }
+        raw30 += __popc(m30);
+        raw10 += __popc(m10);
+        if(raw10 >= NH_NEAR_CAP && (r10_only || raw30 >= NH_SEP_CAP)) break;
+        if(!r10_only && raw30 >= NH_SEP_CAP) {
+            // the r = 30 query has stopped: what is left is the r = 10 query -- redo it on its own,
+            // smaller box (same visiting order, so the lists come out the same)
+            r10_only = true;
+            raw10 = 0; n_dyn = 0; n_stat = 0;
+            T = row_segments(G, E10, gl);
+            q0 = -16;
+        }
+    }
+    if(gl != 0) return;
+    if(irregular) {
+        NB.cnt[uid] = (NH_NB_IRREGULAR | NH_NB_DONE) << 16;
+        return;
+    }
+    v2 sep = mkv(0.0f, 0.0f);
+    if(raw30 > 0)                                   // `if(0 == num_near) return 0`, movement.c:1737
+        sep = vtrunc(vscale(mkv(acc.x, acc.y), -1.0f), scaled_max_force);
+    NB.sep[uid] = make_float2(sep.x, sep.z);
+    NB.cnt[uid] = (uint32_t)n_dyn | ((uint32_t)n_stat << 8) | (NH_NB_DONE << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ClearPath (clearpath.c) on a group of G lanes: G_ClearPath_NewVelocity :694
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool inside_pcr(const float4 *cones, int n_cones, v2 test)
+{
+    for(int c = 0; c < n_cones; c++)
+        if(cone_contains(cones[2 * c], cones[2 * c + 1], test)) return true;
+    return false;
+}
+
+// LDS scratch of one ClearPath problem on a group of G lanes (at most G neighbours in total):
+//   cones   2 float4 per cone: {apex.x, apex.z, slope(left), slope(right)}, {left.x, left.z, right.x, right.z}
+//   ord     cone slots, nearest neighbour first (the order of the inside-obstacle tests)
+//   q*      queue of candidate points waiting for the inside-obstacle test (< 2 G pending)
+//   col     the rays (columns) whose line passes close enough to des_v to still matter
+//   tau/seq the retry shortcut (cp_jump)
+//   dyn/stat  the two neighbour lists, 5 floats per entry (remove_furthest edits them)
+template <int G> struct cp_lds {
+    float4  cones[2 * G];
+    int32_t ord[G];
+    float   qx[2 * G], qz[2 * G], ql[2 * G];
+    int32_t qi[2 * G];
+    int32_t col[2 * G];
+    int32_t tau[G], seq[G];          // cp_jump: removal time of every cone, the removal sequence
+    float   dyn[(G < 32 ? G : 32) * 5], stat[(G < 32 ? G : 32) * 5];
+};
+
+// compute_vnew :368 keeps the first strictly-smaller distance in candidate order, i.e. the minimum
+// of (distance, order index) over the candidates OUTSIDE the combined obstacle.  Consequences:
+//  * candidates can be examined in any order;
+//  * a candidate that cannot beat the best admissible one found so far needs no inside-obstacle
+//    test at all (branch and bound): the distance costs ~15 instructions, the test up to 64 cones;
+//  * the candidate of the ray pair (i, j) lies ON LINE j: C_InfiniteLineIntersection (collision.c:
+//    820-852) evaluates line 2's own equation at the x it found (out.z = s2 (out.x - p2.x) + p2.z, or
+//    out.x = p2.x for a vertical line 2), whatever the conditioning of the pair.  So once a bound
+//    exists, a ray j whose line keeps a distance from des_v larger than the bound (plus a margin three
+//    orders of magnitude above the rounding of that evaluation) cannot contribute through ANY pair
+//    (i, j): the whole column is skipped.  In a crowd that leaves a few columns of 128;
+//  * inside_pcr (:249) is an OR over the cones, so the cones may be tested in any order: nearest
+//    neighbour first (the widest cones), and a lane whose candidate is decided takes the next
+//    candidate from the queue instead of waiting for the slowest lane of its group -- in a crowd
+//    nearly every candidate lies inside one of the first few cones.
+// The bound is group uniform.  `found` = some candidate outside the obstacle has been seen (what the
+// reference's `vec_size(&xpoints) == 0` asks); until then every candidate is tested, so that points
+// whose distance is NaN or infinite still count.
+struct cp_bound { float len; int idx; v2 pt; bool found; };
+#define CP_COL_MARGIN 0.02f
+
+__device__ __forceinline__ bool cp_alive(const cp_bound &B, float len, int idx)
+{
+    return !B.found || len < B.len || (len == B.len && idx < B.idx);
+}
+
+// the candidate a lane is testing: cone ord[ci] is next
+struct cp_lane { bool have; v2 pt; int idx; float len; int ci; };
+
+// Inside-obstacle tests with persistent lanes: every iteration each busy lane tests its candidate
+// against ONE cone; a lane whose candidate is decided -- inside a cone: dropped; outside all cones: it
+// becomes the bound if it beats it -- takes the next queued candidate.  Runs until the queue is empty
+// (finish = false: candidates still in flight stay with their lanes for the next call) or until
+// nothing is in flight either (finish = true).
+template <int G>
+__device__ void cp_work(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp_lane &L, cp_bound &B,
+                        bool finish)
+{
+    typedef grp<G> g;
+    const int gl = g::lane();
+    const unsigned long long lt_mask = (1ull << gl) - 1ull;
+    int head = 0;
+    for(;;) {
+        if(head < qn) {
+            const bool need = !L.have;
+            const unsigned long long mn = g::ballot(need);
+            if(mn) {
+                const int my = head + __popcll(mn & lt_mask);
+                if(need && my < qn) {
+                    L.pt = mkv(S.qx[my], S.qz[my]); L.idx = S.qi[my]; L.len = S.ql[my]; L.ci = 0;
+                    L.have = cp_alive(B, L.len, L.idx);
+                }
+                head = min(qn, head + __popcll(mn));
+            }
+        }
+        if(!g::any(L.have)) {
+            if(head >= qn) break;
+            continue;
+        }
+        if(!finish && head >= qn) break;
+        bool outside = false;
+        if(L.have) {
+            const int slot = S.ord[L.ci];
+            const bool in = cone_contains(S.cones[2 * slot], S.cones[2 * slot + 1], L.pt);
+            L.ci++;
+            if(in) L.have = false;
+            else if(L.ci >= n_cones) { outside = true; L.have = false; }
+        }
+        if(g::any(outside)) {
+            float key = (outside && L.len == L.len) ? L.len : __builtin_inff();    // a NaN distance never wins
+            int ki = outside ? L.idx : 0x7fffffff;
+            const float mykey = key; const int myidx = ki;
+            g::argmin(key, ki);
+            const bool better = !B.found || key < B.len || (key == B.len && ki < B.idx);
+            B.found = true;
+            if(better && key < __builtin_inff()) {
+                const int owner = __ffsll((unsigned long long)g::ballot(outside && myidx == ki && mykey == key)) - 1;
+                const v2 curr = vsub(L.pt, ent.pos);
+                B.len = key; B.idx = ki;
+                B.pt = mkv(g::shfl(curr.x, owner), g::shfl(curr.z, owner));
+            }
+            if(L.have && !cp_alive(B, L.len, L.idx)) L.have = false;
+        }
+    }
+    qn = 0;
+    wave_sync();
+}
+
+// push this lane's candidate (ok) onto the group's queue; the queue is worked off once G are waiting
+template <int G>
+__device__ __forceinline__ void cp_push(cp_lds<G> &S, const cpent &ent, int n_cones, bool ok, v2 pt, int idx,
+                                        float len, int &qn, cp_lane &L, cp_bound &B)
+{
+    typedef grp<G> g;
+    const int gl = g::lane();
+    const unsigned long long mk = g::ballot(ok);
+    if(ok) {
+        const int at = qn + __popcll(mk & ((1ull << gl) - 1ull));
+        S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = idx; S.ql[at] = len;
+    }
+    qn += __popcll(mk);
+    wave_sync();
+    if(qn >= G) cp_work<G>(S, ent, n_cones, qn, L, B, false);
+}
+
+// attempts of G_ClearPath_NewVelocity's do-while per problem (remove_furthest retries), as a histogram:
+// [k] = problems that returned in attempt k (k = 7: seven or more), [8] = total attempts
+__device__ unsigned long long nh_cp_attempts[9];
+
+// ---- the retry loop of G_ClearPath_NewVelocity (:704-713), without retrying -------------------------
+// do { attempt; if found return; remove_furthest; } while(both lists non-empty): in a jam an agent can
+// fail dozens of attempts, each a full search with one neighbour fewer.  But nothing about attempt t
+// is unknown after attempt 0:
+//  * the removal ORDER only depends on the distances and the list positions (first strict maximum in
+//    scan order, vec_del moves the last entry into the hole): simulate it, tau(k) = the removal that
+//    takes neighbour k out (BIG: it survives until the loop ends after T_end removals);
+//  * the cone of a neighbour and the intersection point of two rays do not depend on the attempt;
+//  * so a candidate p made of rays of neighbours a, b exists in attempts t < min(tau(a), tau(b)) and
+//    is inside the obstacle while any cone containing it is still there: it is admissible exactly for
+//    max{tau(c) : cone c contains p} <= t < min(tau(a), tau(b)); des_v itself from t_d = max tau of
+//    the cones containing it.
+// The first attempt that succeeds is the minimum of those start times (cones tested latest-removed
+// first: the first one that contains p IS the maximum; a candidate is dropped as soon as a cone that
+// outlives the best start so far contains it).  Returns that attempt number (the caller replays so
+// many removals from S.seq and runs ONE ordinary attempt, which finds the admissible point and
+// breaks ties exactly as the reference does), or -1: no attempt succeeds before a list runs empty.
+template <int G>
+__device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool isdyn, int k, bool use,
+                       int slot, float dist, int n_dyn, int n_stat, int n_cones)
+{
+    typedef grp<G> g;
+    const int gl = g::lane();
+    const unsigned long long lt_mask = (1ull << gl) - 1ull;
+    const int BIG = 1 << 20;
+    // 1. the removal sequence
+    int tau = BIG, pos = k, cd = n_dyn, cs = n_stat, step = 0;
+    bool present = have;                           // still in its list
+    do {
+        const bool removable = present && dist == dist;        // NaN never passes `len > max_dist`
+        float nk = removable ? -dist : __builtin_inff();
+        int ni = removable ? (isdyn ? pos : cd + pos) : 0x7fffffff;
+        const int myscan = ni;
+        g::argmin(nk, ni);
+        if(!(nk < __builtin_inff())) break;        // nothing left to remove
+        const bool w_dyn = ni < cd;
+        const int w_pos = w_dyn ? ni : ni - cd, last = (w_dyn ? cd : cs) - 1;
+        const bool winner = removable && myscan == ni;
+        if(gl == 0) S.seq[step] = (w_dyn ? 0 : 256) | w_pos;
+        step++;
+        if(present && !winner && isdyn == w_dyn && pos == last) pos = w_pos;
+        if(winner) { present = false; tau = step; }
+        if(w_dyn) cd--; else cs--;
+    } while(cd > 0 && cs > 0 && step < G);
+    const int t_end = step;                        // attempts exist for t < t_end
+    if(t_end <= 1) return -1;
+    // 2. tau per cone, cones ordered by tau descending
+    wave_sync();
+    if(use) S.tau[slot] = tau;
+    wave_sync();
+    if(use) {
+        int rank = 0;
+        for(int c = 0; c < n_cones; c++) {
+            const int tc = S.tau[c];
+            rank += (tc > tau || (tc == tau && c < slot)) ? 1 : 0;
+        }
+        S.ord[rank] = slot;
+    }
+    wave_sync();
+    // 3. des_v itself
+    const v2 des_ws = vadd(ent.pos, des_v);
+    int td = 0;
+    if(gl < n_cones && cone_contains(S.cones[2 * gl], S.cones[2 * gl + 1], des_ws)) td = S.tau[gl];
+#pragma unroll
+    for(int d = G / 2; d >= 1; d >>= 1) td = max(td, __shfl_xor(td, d));
+    int cur = min(td, t_end);                      // best start so far (group uniform)
+    // 4. the candidates: when does each become admissible?
+    const int n_rays = 2 * n_cones, npairs = n_rays * n_rays;
+    const float inv_nr = 1.0f / (float)n_rays;
+    int qn = 0;
+    bool l_have = false; v2 l_pt = mkv(0, 0); int l_end = 0, l_ci = 0;
+    for(int c0 = 0; c0 < n_rays + npairs || qn > 0 || g::any(l_have); c0 += G) {
+        // generate (projections first, then the ordered pairs)
+        const int c = c0 + gl;
+        bool ok = false;
+        v2 pt = mkv(0, 0);
+        int end = 0;
+        if(cur > 1) {
+            if(c < n_rays) {
+                const float4 Ai = S.cones[c & ~1], Bi = S.cones[c | 1];
+                const v2 dir = (c & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
+                pt = vadd(point, vscale(dir, vdot(dir, des_v)));
+                end = S.tau[c >> 1] - 1;
+                ok = true;
+            }else if(c < n_rays + npairs) {
+                const int p = c - n_rays;
+                int i = (int)((float)p * inv_nr);
+                int j = p - i * n_rays;
+                if(j < 0) { i--; j += n_rays; }
+                if(j >= n_rays) { i++; j -= n_rays; }
+                if(i != j) {
+                    end = min(S.tau[i >> 1], S.tau[j >> 1]) - 1;
+                    if(end >= 1 && end >= 0) {
+                        const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
+                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                        const bool ri = i & 1, rj = j & 1;
+                        ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
+                                       mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z,
+                                       pt);
+                    }
+                }
+            }
+            ok = ok && end >= 1;                   // it must exist in some attempt after the first
+        }
+        const unsigned long long mk = g::ballot(ok);
+        if(ok) {
+            const int at = qn + __popcll(mk & lt_mask);
+            S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = end;
+        }
+        qn += __popcll(mk);
+        wave_sync();
+        const bool gen_done = c0 + G >= n_rays + npairs || cur <= 1;
+        if(qn < G && !gen_done) continue;
+        // work the queue off (persistent lanes, one cone test per busy lane and iteration)
+        int head = 0;
+        for(;;) {
+            if(head < qn) {
+                const bool need = !l_have;
+                const unsigned long long mn = g::ballot(need);
+                if(mn) {
+                    const int my = head + __popcll(mn & lt_mask);
+                    if(need && my < qn) { l_pt = mkv(S.qx[my], S.qz[my]); l_end = S.qi[my]; l_ci = 0; l_have = true; }
+                    head = min(qn, head + __popcll(mn));
+                }
+            }
+            if(!g::any(l_have)) { if(head >= qn) break; continue; }
+            if(!gen_done && head >= qn) break;
+            int result = -1;
+            if(l_have) {
+                const int lim = min(cur - 1, l_end);          // its start has to be <= lim to matter
+                if(lim < 1) {
+                    l_have = false;
+                }else{
+                    const int cs_ = S.ord[l_ci];
+                    const int tc = S.tau[cs_];
+                    const bool in = cone_contains(S.cones[2 * cs_], S.cones[2 * cs_ + 1], l_pt);
+                    l_ci++;
+                    if(in) {
+                        if(tc <= lim) result = tc;             // the latest-removed cone around it
+                        l_have = false;
+                    }else if(l_ci >= n_cones) {
+                        result = 0; l_have = false;            // (outside everything: cannot be, attempt 0 failed)
+                    }
+                }
+            }
+            if(g::any(result >= 0)) {
+                int r = result >= 0 ? result : BIG;
+#pragma unroll
+                for(int d = G / 2; d >= 1; d >>= 1) r = min(r, __shfl_xor(r, d));
+                cur = min(cur, r);
+            }
+        }
+        qn = 0;
+        wave_sync();
+        if(gen_done) break;
+    }
+    return cur < t_end ? cur : -1;
+}
+
+// S.dyn / S.stat hold the neighbours (n_dyn + n_stat <= G, each <= 32).
+template <int G>
+__device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, cp_lds<G> &S)
+{
+    typedef grp<G> g;
+    if(n_dyn + n_stat == 0) return des_v;          // no obstacle: inside_pcr of nothing is false
+    const int gl = g::lane();
+    const unsigned long long lt_mask = (1ull << gl) - 1ull;
+    bool jumped = false;
+    // at most 64 neighbours can be removed; the bound only guards against a NaN-poisoned input
+    for(int guard = 0; guard < 66; guard++) {
+        // ---- HRVOs for dynamic, VOs for static neighbours -> rays (rays_repr :291) -----------
+        // lane = neighbour, dynamic ones first; same_position neighbours are skipped (:216-246)
+        const bool isdyn = gl < n_dyn;
+        const int  k = isdyn ? gl : gl - n_dyn;
+        const bool have = gl < n_dyn + n_stat;
+        cpent nb; nb.pos = mkv(0, 0); nb.vel = mkv(0, 0); nb.radius = 0;
+        if(have) {
+            const float *src = (isdyn ? S.dyn : S.stat) + 5 * k;
+            nb.pos = mkv(src[0], src[1]); nb.vel = mkv(src[2], src[3]); nb.radius = src[4];
+        }
+        const bool use = have && !(vlen(vsub(nb.pos, ent.pos)) < CP_EPS);
+        v2 apex = mkv(0, 0), left = mkv(0, 0), right = mkv(0, 0);
+        float sl = 0.0f, sr = 0.0f;
+        if(use) make_cone(ent, nb, isdyn, apex, left, right, sl, sr);
+        const unsigned long long m = g::ballot(use);
+        const int slot = __popcll(m & lt_mask);                // hrvos first, then vos, in order
+        const int n_cones = __popcll(m);
+        const int n_rays = 2 * n_cones;
+        const float ndist = use ? vlen(vsub(nb.pos, ent.pos)) : __builtin_inff();
+        wave_sync();
+        if(use) {
+            S.cones[2 * slot]     = make_float4(apex.x, apex.z, sl, sr);
+            S.cones[2 * slot + 1] = make_float4(left.x, left.z, right.x, right.z);
+        }
+        S.ql[gl] = ndist;                                   // (the queue is empty here)
+        wave_sync();
+        if(use) {
+            // rank of this neighbour by distance among the neighbours that have a cone
+            int rank = 0;
+            for(int j = 0; j < n_dyn + n_stat; j++) {
+                const float dj = S.ql[j];
+                rank += (dj < ndist || (dj == ndist && j < gl)) ? 1 : 0;
+            }
+            S.ord[rank] = slot;
+        }
+        wave_sync();
+
+        // des_v admissible as it is?  lane = cone
+        const v2 des_ws = vadd(ent.pos, des_v);
+        bool in = false;
+        if(gl < n_cones) in = cone_contains(S.cones[2 * gl], S.cones[2 * gl + 1], des_ws);
+        if(!g::any(in)) {
+            if(gl == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
+            return des_v;
+        }
+
+        cp_bound B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.found = false;
+        cp_lane L; L.have = false; L.pt = mkv(0, 0); L.idx = 0; L.len = 0.0f; L.ci = 0;
+        int qn = 0;                                            // pending candidates (group uniform)
+        const int npairs = n_rays * n_rays;
+        // ---- the projections of des_v on every ray (:344; order index npairs + ray).  Visited first:
+        // they are the closest point of each ray, so the bound tightens at once.
+        for(int c0 = 0; c0 < n_rays; c0 += G) {
+            const int c = c0 + gl;
+            bool ok = false;
+            v2 pt = mkv(0, 0);
+            float len = 0.0f;
+            if(c < n_rays) {
+                const float4 Ai = S.cones[c & ~1], Bi = S.cones[c | 1];
+                const v2 dir = (c & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
+                const float plen = vdot(dir, des_v);
+                pt = vadd(point, vscale(dir, plen));
+                len = vlen(vsub(des_v, vsub(pt, ent.pos)));
+                ok = cp_alive(B, len, npairs + c);
+            }
+            cp_push<G>(S, ent, n_cones, ok, pt, npairs + c, len, qn, L, B);
+        }
+        cp_work<G>(S, ent, n_cones, qn, L, B, true);
+
+        // ---- the ray pairs (:321; order index i * n_rays + j), column by column.  The columns that
+        // can still matter are re-selected whenever the bound has moved.
+        int jdone = 0;                         // columns [0, jdone) are finished
+        while(jdone < n_rays) {
+            // select up to 2 G live columns from [jdone, n_rays)
+            int ncol = 0, jscan = jdone;
+            for(; jscan < n_rays && ncol < G; jscan += G) {
+                const int j = jscan + gl;
+                bool live = false;
+                if(j < n_rays) {
+                    live = true;
+                    if(B.found) {
+                        // distance of des_v to line j, in the agent's local frame
+                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                        const v2 dj = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
+                        const v2 rel = vsub(des_v, vsub(mkv(Aj.x, Aj.y), ent.pos));
+                        const float dist = fabsf(dj.x * rel.z - dj.z * rel.x);
+                        // (a ray with |dir.x| < 1/1024 is intersected as the exactly vertical line
+                        // x = apex.x, collision.c:823-831: up to 1/1024 per unit of distance away
+                        // from the real line -- the second term of the margin covers it)
+                        const float slack = CP_COL_MARGIN + 2e-3f * (B.len + fabsf(rel.x) + fabsf(rel.z));
+                        live = !(dist > B.len + slack);                  // NaN stays in
+                    }
+                }
+                const unsigned long long ml = g::ballot(live);
+                if(live) S.col[ncol + __popcll(ml & lt_mask)] = j;
+                ncol += __popcll(ml);
+            }
+            jdone = jscan < n_rays ? jscan : n_rays;
+            wave_sync();
+            // candidates of the selected columns: (i, col[cj]) for every i != col[cj]
+            const int ncand = ncol * n_rays;
+            const float inv_nr = 1.0f / (float)n_rays;
+            for(int c0 = 0; c0 < ncand; c0 += G) {
+                const int c = c0 + gl;
+                bool ok = false;
+                v2 pt = mkv(0, 0);
+                float len = 0.0f;
+                int idx = 0;
+                if(c < ncand) {
+                    // (cj, i) = divmod(c, n_rays): float estimate + one correction step (c < 2^14)
+                    int cj = (int)((float)c * inv_nr);
+                    int i = c - cj * n_rays;
+                    if(i < 0) { cj--; i += n_rays; }
+                    if(i >= n_rays) { cj++; i -= n_rays; }
+                    const int j = S.col[cj];
+                    idx = i * n_rays + j;
+                    if(i != j) {
+                        const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
+                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                        const bool ri = i & 1, rj = j & 1;
+                        ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
+                                       mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z,
+                                       pt);
+                        if(ok) {
+                            len = vlen(vsub(des_v, vsub(pt, ent.pos)));
+                            ok = cp_alive(B, len, idx);
+                        }
+                    }
+                }
+                cp_push<G>(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
+            }
+            cp_work<G>(S, ent, n_cones, qn, L, B, true);
+        }
+        if(B.found) {
+            if(gl == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
+            return B.pt;                   // (only NaN / infinite distances: ret stays 0, as :368-386)
+        }
+
+        // ---- no admissible point: remove_furthest (:390) and retry while both lists non-empty
+        float dist = -__builtin_inff();
+        if(have) dist = vlen(vsub(ent.pos, nb.pos));
+        if(!jumped) {
+            // the first failure: find the attempt that will succeed and go there in one step
+            jumped = true;
+            const int t = cp_jump<G>(S, ent, des_v, have, isdyn, k, use, slot, dist, n_dyn, n_stat, n_cones);
+            if(t < 0) {
+                if(gl == 0) { atomicAdd(&nh_cp_attempts[0], 1ull); atomicAdd(&nh_cp_attempts[8], 2ull); }
+                return mkv(0.0f, 0.0f);
+            }
+            wave_sync();
+            if(gl == 0) {
+                int cd = n_dyn, cs = n_stat;
+                for(int r = 0; r < t; r++) {
+                    const int e = S.seq[r], p = e & 255;
+                    if(e < 256) { cd--; for(int q = 0; q < 5; q++) S.dyn[5 * p + q] = S.dyn[5 * cd + q]; }
+                    else        { cs--; for(int q = 0; q < 5; q++) S.stat[5 * p + q] = S.stat[5 * cs + q]; }
+                }
+            }
+            wave_sync();
+            for(int r = 0; r < t; r++) { if(S.seq[r] < 256) n_dyn--; else n_stat--; }
+            continue;
+        }
+        // (not reached in practice: the attempt after a jump succeeds; kept as the plain loop)
+        // first strict maximum in scan order (dynamic entries precede static ones) == min over (-dist, lane)
+        float nk = -dist; int ni = gl;
+        if(!have || !(dist == dist)) { nk = __builtin_inff(); }   // NaN never passes `len > max_dist`
+        g::argmin(nk, ni);
+        wave_sync();
+        if(nk < __builtin_inff() && gl == 0) {
+            if(ni < n_dyn) { for(int q = 0; q < 5; q++) S.dyn[5 * ni + q] = S.dyn[5 * (n_dyn - 1) + q]; }
+            else           { const int s = ni - n_dyn; for(int q = 0; q < 5; q++) S.stat[5 * s + q] = S.stat[5 * (n_stat - 1) + q]; }
+        }
+        wave_sync();
+        if(nk < __builtin_inff()) { if(ni < n_dyn) n_dyn--; else n_stat--; }
+        if(!(n_dyn > 0 && n_stat > 0)) {
+            if(gl == 0) { atomicAdd(&nh_cp_attempts[0], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
+            return mkv(0.0f, 0.0f);
+        }
+    }
+    return mkv(0.0f, 0.0f);
+}
+
+// neighbour lists (pool slots, from the walk) -> S.dyn / S.stat
+template <int G>
+__device__ __forceinline__ void cp_load_lists(const nh_grid &Gd, const nh_nbr &NB, int uid, int n_dyn, int n_stat,
+                                              cp_lds<G> &S)
+{
+    const int gl = grp<G>::lane();
+    wave_sync();
+    if(gl < n_dyn + n_stat) {
+        const bool isdyn = gl < n_dyn;
+        const int j = isdyn ? gl : gl - n_dyn;
+        const int slot = NB.list[(size_t)(isdyn ? j : 32 + j) * NB.stride + uid];
+        const cpent nb = nbr_cpent(Gd, slot, !isdyn);
+        float *dst = (isdyn ? S.dyn : S.stat) + 5 * j;
+        dst[0] = nb.pos.x; dst[1] = nb.pos.z; dst[2] = nb.vel.x; dst[3] = nb.vel.z; dst[4] = nb.radius;
+    }
+    wave_sync();
+}

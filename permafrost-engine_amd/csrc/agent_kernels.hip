@@ -20,32 +20,26 @@
 //                 the cell order and per-cell order bg_ent_cleanup produces after inserting uids
 //                 0..n-1, so that a query's candidates are contiguous runs and a hit needs no
 //                 second gather.
-//   k_agent_nbr   one THREAD per entity, pool order: separation force + ClearPath neighbour lists in
-//                 one walk (agent_thread.h).  Needs only the snapshot: runs beside the field builds.
+//   k_agent_nbr   one ROW of 16 lanes per entity, pool order: separation force + ClearPath neighbour
+//                 lists in one walk (agent_group.h).  Needs only the snapshot: runs beside the field
+//                 builds.
 //   k_cohesion    the O(N*F) exp-weighted flock centroid, four lanes per member.
-//   k_agent_mid   one THREAD per entity: flow sampling, arrive force, priority ladder -> preferred
-//                 velocity; des_v admissible?  Finished agents are truncated + position-tested here;
-//                 the rest go to device-side work lists.
-//   k_cp_light    one THREAD per listed agent (<= 4 neighbours), lists grouped by neighbour count.
-//   k_cp_wave     one WAVE per listed agent (> 4 neighbours: >= 100 ray pairs x cone tests fill a
-//                 wave): ClearPath with lanes spread over ray pairs, a candidate queue and a
-//                 lexicographic wave arg-min that reproduces the reference's first-wins tie-break.
+//   k_agent_mid   one THREAD per entity: the scalar chain -- flow sampling, arrive force, priority
+//                 ladder -> preferred velocity.  Agents without ClearPath neighbours are truncated +
+//                 position-tested here; the rest go to device-side work lists by neighbour count.
+//   k_cp          ClearPath for the listed agents: a ROW of 16 lanes per agent with 1..16 neighbours,
+//                 a whole WAVE per agent with 17..64 (a crowd); lanes spread over cones / ray pairs,
+//                 branch and bound on the distance to des_v, a candidate queue, a lexicographic
+//                 arg-min that reproduces the reference's first-wins rule; units drawn from a ticket
+//                 counter, heaviest first.
 //   k_agent_full  one WAVE per listed agent, the whole step (irregular gathers: garrisoned
 //                 neighbours, wide queries).
 #include "navhip_internal.h"
 #include "agent_internal.h"
-#include "agent_thread.h"
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
+#include "agent_group.h"
 
 __constant__ double c_exp2_64[64] = { NH_EXP2_64_TABLE };
 
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 // ---------------------------------------------------------------------------------------------
 // spatial hash (bitmap_grid.h): build
 // ---------------------------------------------------------------------------------------------
@@ -357,179 +351,6 @@ __device__ int filter_garrisoned_wave(const nh_grid &G, uint32_t *ids, int count
     return __shfl(ret, 0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// ClearPath (clearpath.c), one wave per problem
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool inside_pcr(const float4 *cones, int n_cones, v2 test)
-{
-    for(int c = 0; c < n_cones; c++)
-        if(cone_contains(cones[2 * c], cones[2 * c + 1], test)) return true;
-    return false;
-}
-
-// lexicographic (key, idx) wave arg-min; key = +inf means "no candidate"
-__device__ __forceinline__ void wave_argmin(float &key, int &idx)
-{
-#pragma unroll
-    for(int d = 32; d >= 1; d >>= 1) {
-        float ok = __shfl_xor(key, d);
-        int   oi = __shfl_xor(idx, d);
-        bool take = (ok < key) || (ok == key && oi < idx);
-        if(take) { key = ok; idx = oi; }
-    }
-}
-
-// LDS scratch of one ClearPath problem: the cones (2 float4 each, <= 64 cones) and a queue of
-// candidate points (<= 128 pending)
-struct cp_scratch {
-    float4  *cones;      // [128]
-    float   *qx, *qz;    // [128]
-    int32_t *qi;         // [128]
-};
-
-// compute_vnew :368 keeps the first strictly-smaller distance in candidate order, i.e. the minimum
-// of (distance, order index): candidates can be examined in any order.
-struct cp_best { float len; int idx; v2 pt; bool any; };
-
-// one candidate per lane: drop it when it lies inside the combined obstacle, else rank it
-__device__ __forceinline__ void cp_rank(const cpent &ent, v2 des_v, const float4 *cones, int n_cones,
-                                        bool have, v2 pt, int order, cp_best &B)
-{
-    if(have && !inside_pcr(cones, n_cones, pt)) {
-        B.any = true;
-        const v2 curr = vsub(pt, ent.pos);
-        const float len = vlen(vsub(des_v, curr));
-        if(len < B.len || (len == B.len && order < B.idx)) { B.len = len; B.idx = order; B.pt = curr; }
-    }
-}
-
-// G_ClearPath_NewVelocity (clearpath.c:694) for one agent on one wave.
-// dyn/stat: LDS arrays of 5 floats per neighbour (order matters).
-//
-// Candidate points (ray-pair intersections, :321, then the projections of des_v on every ray, :344)
-// are produced 64 at a time, one ordered pair per lane; the pairs whose rays do meet are compacted
-// into the queue and the expensive part -- is the point inside any cone? -- always runs on 64 real
-// candidates per pass.
-__device__ v2 clearpath_wave(const cpent &ent, v2 des_v, float *dyn, int n_dyn, float *stat,
-                             int n_stat, const cp_scratch &S, int lane)
-{
-    if(n_dyn + n_stat == 0) return des_v;          // no obstacle: inside_pcr of nothing is false
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    // at most 64 neighbours can be removed; the bound only guards against a NaN-poisoned input
-    for(int guard = 0; guard < 66; guard++) {
-        // ---- HRVOs for dynamic, VOs for static neighbours -> rays (rays_repr :291) -----------
-        // lanes 0..31 dynamic, 32..63 static; same_position neighbours are skipped (:216-246)
-        bool isdyn = lane < 32;
-        int  k = isdyn ? lane : lane - 32;
-        bool have = isdyn ? (k < n_dyn) : (k < n_stat);
-        cpent nb; nb.pos = mkv(0, 0); nb.vel = mkv(0, 0); nb.radius = 0;
-        if(have) {
-            const float *src = (isdyn ? dyn : stat) + 5 * k;
-            nb.pos = mkv(src[0], src[1]); nb.vel = mkv(src[2], src[3]); nb.radius = src[4];
-        }
-        bool use = have && !(vlen(vsub(nb.pos, ent.pos)) < CP_EPS);
-        v2 apex = mkv(0, 0), left = mkv(0, 0), right = mkv(0, 0);
-        float sl = 0.0f, sr = 0.0f;
-        if(use) make_cone(ent, nb, isdyn, apex, left, right, sl, sr);
-        uint64_t m = __ballot(use);
-        int slot = __popcll(m & lt_mask);                      // hrvos first, then vos, in order
-        const int n_cones = __popcll(m);
-        const int n_rays = 2 * n_cones;
-        wave_sync();
-        if(use) {
-            S.cones[2 * slot]     = make_float4(apex.x, apex.z, sl, sr);
-            S.cones[2 * slot + 1] = make_float4(left.x, left.z, right.x, right.z);
-        }
-        wave_sync();
-
-        // des_v admissible as it is?  lane = cone
-        const v2 des_ws = vadd(ent.pos, des_v);
-        bool in = false;
-        if(lane < n_cones) in = cone_contains(S.cones[2 * lane], S.cones[2 * lane + 1], des_ws);
-        if(!__any(in))
-            return des_v;
-
-        cp_best B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.any = false;
-        int qn = 0;                                            // pending candidates (wave uniform)
-        const int npairs = n_rays * n_rays;
-        const float inv_nr = 1.0f / (float)n_rays;
-        for(int p0 = 0; p0 < npairs + n_rays; p0 += 64) {
-            const int p = p0 + lane;
-            bool ok = false;
-            v2 pt = mkv(0, 0);
-            if(p < npairs) {
-                // (i, j) = divmod(p, n_rays): float estimate + one correction step (p < 2^14)
-                int i = (int)((float)p * inv_nr);
-                int j = p - i * n_rays;
-                if(j < 0) { i--; j += n_rays; }
-                if(j >= n_rays) { i++; j -= n_rays; }
-                if(i != j) {
-                    const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
-                    const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
-                    const bool ri = i & 1, rj = j & 1;
-                    ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
-                                   mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z,
-                                   pt);
-                }
-            }else if(p < npairs + n_rays) {
-                const int i = p - npairs;
-                const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
-                const v2 dir = (i & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
-                const float len = vdot(dir, des_v);
-                pt = vadd(point, vscale(dir, len));
-                ok = true;
-            }
-            const uint64_t mk = __ballot(ok);
-            if(ok) {
-                const int at = qn + __popcll(mk & lt_mask);
-                S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = p;
-            }
-            qn += __popcll(mk);
-            wave_sync();
-            if(qn >= 64) {
-                qn -= 64;
-                cp_rank(ent, des_v, S.cones, n_cones, true, mkv(S.qx[qn + lane], S.qz[qn + lane]),
-                        S.qi[qn + lane], B);
-                wave_sync();
-            }
-        }
-        if(qn > 0) {
-            const bool mine = lane < qn;
-            cp_rank(ent, des_v, S.cones, n_cones, mine, mine ? mkv(S.qx[lane], S.qz[lane]) : mkv(0, 0),
-                    mine ? S.qi[lane] : 0, B);
-        }
-        if(__any(B.any)) {
-            float key = B.len; int idx = B.idx;
-            wave_argmin(key, idx);
-            if(!(key < __builtin_inff())) return mkv(0.0f, 0.0f);   // only NaN distances: ret stays 0
-            int owner = __ffsll((unsigned long long)__ballot(B.idx == idx && B.len == key)) - 1;
-            return mkv(__shfl(B.pt.x, owner), __shfl(B.pt.z, owner));
-        }
-
-        // ---- no admissible point: remove_furthest (:390) and retry while both lists non-empty
-        float dist = -__builtin_inff();
-        int   ord = 0x7fffffff;                 // dyn entries precede stat entries in the scan
-        if(have) {
-            dist = vlen(vsub(ent.pos, nb.pos));
-            ord = isdyn ? k : 32 + k;
-        }
-        // first strict maximum in scan order == min over (-dist, ord)
-        float nk = -dist; int ni = ord;
-        if(!have || !(dist == dist)) { nk = __builtin_inff(); }   // NaN never passes `len > max_dist`
-        wave_argmin(nk, ni);
-        wave_sync();
-        if(nk < __builtin_inff() && lane == 0) {
-            if(ni < 32) { n_dyn--;  for(int q = 0; q < 5; q++) dyn[5 * ni + q] = dyn[5 * n_dyn + q]; }
-            else        { int s = ni - 32; n_stat--; for(int q = 0; q < 5; q++) stat[5 * s + q] = stat[5 * n_stat + q]; }
-        }
-        wave_sync();
-        n_dyn = __shfl(n_dyn, 0);
-        n_stat = __shfl(n_stat, 0);
-        if(!(n_dyn > 0 && n_stat > 0))
-            return mkv(0.0f, 0.0f);
-    }
-    return mkv(0.0f, 0.0f);
-}
 // ---------------------------------------------------------------------------------------------
 // cohesion_force (movement.c:1653)
 // ---------------------------------------------------------------------------------------------
@@ -920,7 +741,7 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     }
 }
 // ---------------------------------------------------------------------------------------------
-// wave-per-agent pieces (k_agent_full, k_cp_wave)
+// wave-per-agent pieces of k_agent_full
 // ---------------------------------------------------------------------------------------------
 // waves (= agents) per workgroup of the wave-per-agent kernels; 2 measured best for the round-1
 // k_agent_step (1: 0.490, 2: 0.483, 4: 0.494, 8: 0.521 ms/tick in one session)
@@ -931,11 +752,8 @@ struct wave_lds {
     uint32_t ids30[128];                       // separation query result (cap 128, :1695)
     union {
         uint32_t ids10[512];                   // ClearPath neighbour query result (cap 512, :2779)
-        float4   rays[128];                    // later: the combined obstacle, two float4 per cone
         float    sep[256];                     // earlier: separation terms (x, z)[128]
     } u;
-    float dyn[32 * 5];
-    float stat[32 * 5];
     int32_t  d2_30[128];                       // squared fixed-point distances of the r=30 hits
     uint32_t ids10d[128];                      // r=10 list derived from the r=30 list
 };
@@ -1052,17 +870,19 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_agent_nbr: one THREAD per pool slot
+// k_agent_nbr: one ROW of 16 lanes per pool slot (16 entities per 256-thread workgroup)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
 {
     __shared__ double exp_tab[64];
+    __shared__ __attribute__((aligned(16))) float2 terms[16][16];
     if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
     __syncthreads();
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int grp_i = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + grp_i;
     if(k >= npool_max || k >= G.cell_start[G.grid_w * G.grid_h]) return;
     if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) return;         // no work item (or outside the slab)
-    nbr_walk_thread(G, k, scaled_max_force, exp_tab, NB);
+    nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
 }
 
 // wave-aggregated append to a device work list: one atomic per wave and list
@@ -1079,106 +899,106 @@ __device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_agent_mid: one THREAD per entity (uid order: every per-entity input / output is coalesced)
+// k_agent_mid: the per-agent scalar chain -- desired direction, arrive force, probes, priority
+// ladder, vpref -- in uid order (every per-entity input / output is contiguous).  MID_LANES lanes
+// run the same chain for one entity (the loads are broadcasts, lane 0 writes): the work is a chain
+// of dependent loads and IEEE divide / sqrt sequences, and 100 000 threads alone are 1.5 waves per
+// SIMD -- nothing to hide it behind (measured 75-105 us with one thread per entity).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
-                                                   nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
-                                                   float scaled_max_force, double force_thresh)
+#ifndef MID_LANES
+#define MID_LANES 4
+#endif
+__global__ __launch_bounds__(64) void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
+                                                  nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
+                                                  float scaled_max_force, double force_thresh)
 {
-    const int uid = P.work_begin + blockIdx.x * 256 + threadIdx.x;
+    const int uid = P.work_begin + (int)((blockIdx.x * 64 + threadIdx.x) / MID_LANES);
+    const bool writer = (threadIdx.x % MID_LANES) == 0;
     const bool live = uid < P.work_end;
     int disp = DISP_DONE;
     if(live) {
         nh_mid_rec R;
         v2 out_vel;
         disp = mid_thread(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R, out_vel);
-        if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
-        if(O.vpref_xz) { O.vpref_xz[2 * uid] = R.vpref[0]; O.vpref_xz[2 * uid + 1] = R.vpref[1]; }
-        if(disp == DISP_DONE) {
-            post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid],
-                        P.radius[uid], out_vel, R.vel_cap, R.status, O);
-        }else{
-            mid[uid] = R;
+        if(writer) {
+            if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
+            if(O.vpref_xz) { O.vpref_xz[2 * uid] = R.vpref[0]; O.vpref_xz[2 * uid + 1] = R.vpref[1]; }
+            if(disp == DISP_DONE) {
+                post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid],
+                            P.radius[uid], out_vel, R.vel_cap, R.status, O);
+            }else{
+                mid[uid] = R;
+            }
         }
     }
 #pragma unroll
-    for(int w = 0; w < NH_WL_COUNT; w++)
-        worklist_push(WL, w, live && disp == DISP_LIGHT1 + w, uid);
+    for(int w = 0; w < NH_WL_LISTS; w++)
+        worklist_push(WL, w, live && writer && disp == DISP_ROW0 + w, uid);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_cp_light: one THREAD per listed agent.  The four light lists (1..4 neighbours) are laid out one
-// after the other in units of 64 entries, so a wave only holds agents with the same neighbour count.
+// k_cp: ClearPath for every listed agent, ONE launch.  A unit of work is one wave-list agent (17-64
+// neighbours, the whole wave) or four agents of one row list (a row of 16 lanes each); waves draw
+// units from a ticket counter, heaviest first (wave list, then 9-16, 5-8, 3-4, 1-2 neighbours), so
+// that the long units start at once and the short ones fill the gaps -- the per-agent cost spans
+// three orders of magnitude and a static split leaves most of the chip waiting for a few waves.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_cp_light(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                 nh_worklists WL, nh_step_outs O)
-{
-    __shared__ float4 cones[2 * NH_LIGHT_MAX * 64];
-    const int lane = threadIdx.x;
-    int cnt[4], nw[4], tot = 0;
-#pragma unroll
-    for(int w = 0; w < 4; w++) { cnt[w] = WL.count[NH_WL_LIGHT1 + w]; nw[w] = (cnt[w] + 63) >> 6; tot += nw[w]; }
-    for(int wv = blockIdx.x; wv < tot; wv += gridDim.x) {
-        int which = 0, rel = wv;
-#pragma unroll
-        for(int w = 0; w < 3; w++) if(which == w && rel >= nw[w]) { rel -= nw[w]; which = w + 1; }
-        const int idx = rel * 64 + lane;
-        bool punt = false;
-        int uid = -1;
-        if(idx < cnt[which]) {
-            uid = WL.ids[(size_t)(NH_WL_LIGHT1 + which) * WL.stride + idx];
-            const nh_mid_rec R = mid[uid];
-            const uint32_t c = NB.cnt[uid];
-            cpent ent;
-            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-            ent.radius = P.radius[uid];
-            v2 res;
-            const bool found = cp_light_thread(P.grid, ent, mkv(R.vpref[0], R.vpref[1]), (int)(c & 0xff),
-                                               (int)((c >> 8) & 0xff), NB.list + uid, (size_t)NB.stride,
-                                               cones + lane, 64, res);
-            if(found)
-                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, res, R.vel_cap, R.status, O);
-            punt = !found;
-        }
-        worklist_push(WL, NH_WL_WAVE, punt, uid);      // remove_furthest + retry run on a wave
-    }
-}
+union cp_wave_lds {
+    cp_lds<64> w;
+    cp_lds<16> r[4];
+};
 
-// ---------------------------------------------------------------------------------------------
-// k_cp_wave: one WAVE per listed agent -- ClearPath only (neighbour lists from k_agent_nbr)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AG_WAVES * 64) void k_cp_wave(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                           nh_worklists WL, nh_step_outs O)
+__global__ __launch_bounds__(AG_WAVES * 64) void k_cp(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                      nh_worklists WL, nh_step_outs O)
 {
-    __shared__ wave_lds lds[AG_WAVES];
+    __shared__ cp_wave_lds lds[AG_WAVES];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    wave_lds &W = lds[wib];
-    const int count = WL.count[NH_WL_WAVE];
-    for(int idx = blockIdx.x * AG_WAVES + wib; idx < count; idx += gridDim.x * AG_WAVES) {
-        const int uid = WL.ids[(size_t)NH_WL_WAVE * WL.stride + idx];
+    cp_wave_lds &S = lds[wib];
+    const int n_wave = WL.count[NH_WL_WAVE];
+    int cnt[4], nu[4], total = n_wave;
+#pragma unroll
+    for(int w = 0; w < 4; w++) {               // w = 0: the 9-16 list ... w = 3: the 1-2 list
+        cnt[w] = WL.count[NH_WL_ROW3 - w];
+        nu[w] = (cnt[w] + 3) >> 2;
+        total += nu[w];
+    }
+    for(;;) {
+        int u = 0;
+        if(lane == 0) u = atomicAdd(&WL.count[NH_WL_TICKET], 1);
+        u = __shfl(u, 0);
+        if(u >= total) break;
+        int uid = -1, n_dyn = 0, n_stat = 0;
+        const bool wave_unit = u < n_wave;
+        if(wave_unit) {
+            uid = WL.ids[(size_t)NH_WL_WAVE * WL.stride + u];
+        }else{
+            int which = 0, rel = u - n_wave;
+#pragma unroll
+            for(int w = 0; w < 3; w++) if(which == w && rel >= nu[w]) { rel -= nu[w]; which = w + 1; }
+            const int idx = rel * 4 + (lane >> 4);
+            if(idx < cnt[which]) uid = WL.ids[(size_t)(NH_WL_ROW3 - which) * WL.stride + idx];
+        }
+        if(uid < 0) continue;                  // (a row beyond the end of its list)
         const nh_mid_rec R = mid[uid];
         const uint32_t c = NB.cnt[uid];
-        const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+        n_dyn = (int)(c & 0xff); n_stat = (int)((c >> 8) & 0xff);
         cpent ent;
         ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
         ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
         ent.radius = P.radius[uid];
-        wave_sync();
-        {   // lanes 0..31 dynamic, 32..63 static
-            const bool isdyn = lane < 32;
-            const int j = isdyn ? lane : lane - 32;
-            if(j < (isdyn ? n_dyn : n_stat)) {
-                const int slot = NB.list[(size_t)lane * NB.stride + uid];
-                const cpent nb = nbr_cpent(P.grid, slot, !isdyn);
-                float *dst = (isdyn ? W.dyn : W.stat) + 5 * j;
-                dst[0] = nb.pos.x; dst[1] = nb.pos.z; dst[2] = nb.vel.x; dst[3] = nb.vel.z; dst[4] = nb.radius;
-            }
+        v2 nv;
+        bool writer;
+        if(wave_unit) {
+            cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S.w);
+            nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S.w);
+            writer = lane == 0;
+        }else{
+            cp_lds<16> &Sr = S.r[lane >> 4];
+            cp_load_lists<16>(P.grid, NB, uid, n_dyn, n_stat, Sr);
+            nv = clearpath_grp<16>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, Sr);
+            writer = (lane & 15) == 0;
         }
-        wave_sync();
-        const cp_scratch cps = {W.u.rays, (float*)W.d2_30, (float*)W.ids10d, (int32_t*)W.ids30};
-        const v2 nv = clearpath_wave(ent, mkv(R.vpref[0], R.vpref[1]), W.dyn, n_dyn, W.stat, n_stat, cps, lane);
-        if(lane == 0)
+        if(writer)
             post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
     }
 }
@@ -1186,7 +1006,7 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_cp_wave(nh_step_params P, nh_
 // ---------------------------------------------------------------------------------------------
 // k_agent_full: one WAVE per listed agent, the whole neighbour-dependent part on the wave: r = 30
 // query + garrison filter + separation, the priority ladder, r = 10 neighbours, ClearPath.
-// (The exact path for what the thread-per-agent walk declines.)
+// (The exact path for what the row walk declines.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, const float *coh_xz,
                                                               const nh_mid_rec *mid, nh_worklists WL,
@@ -1194,11 +1014,13 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
                                                               double force_thresh)
 {
     __shared__ wave_lds lds[AG_WAVES];
+    __shared__ cp_lds<64> cps[AG_WAVES];
     __shared__ double exp_tab[64];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
     __syncthreads();
     wave_lds &W = lds[wib];
+    cp_lds<64> &S = cps[wib];
     const nh_grid &G = P.grid;
     const int count = WL.count[NH_WL_FULL];
     for(int idx = blockIdx.x * AG_WAVES + wib; idx < count; idx += gridDim.x * AG_WAVES) {
@@ -1209,13 +1031,10 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
         const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
         const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
         const float my_radius = P.radius[uid];
-        const int flock = P.flock[uid];
-        const int hz = P.hz;
         int n30raw = -1;                 // size of the unfiltered r=30 list (-1: no such query)
         v2 vpref = mkv(0.0f, 0.0f);
         wave_sync();
         if(R.mode != AM_ZERO_VPREF) {
-            const v2 arrive = mkv(R.arrive[0], R.arrive[1]);
             // separation (movement.c:1690): r = 30 query, cap 128
             int n30 = sp_query_wave(G, me.x, me.z, 30.0f, 128, W.ids30, lane, W.d2_30);
             wave_sync();
@@ -1225,55 +1044,8 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
             if(n10d < 0) n30raw = -1; else n30raw = n10d;
             const v2 separation = separation_wave(G, my_slot, me, my_radius, my_bits, W.ids30, n30,
                                                   W.u.sep, scaled_max_force, lane, exp_tab);
-            v2 steer;
-            if(R.mode == AM_ENEMY_SEEK) {
-                // enemy_seek_vpref :1946 (no priorities, no nullify)
-                v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
-                v2 ret = mkv(0.0f, 0.0f);
-                ret = vadd(ret, a); ret = vadd(ret, s);
-                steer = vtrunc(ret, scaled_max_force);
-            }else{
-                // point_seek_vpref :1870 / cell_arrival_seek_vpref :1908 / formation_seek_vpref :1985
-                const bool to_cell = R.mode == AM_FORM_CELL, form = R.mode != AM_POINT_SEEK;
-                v2 cohesion, align = mkv(0.0f, 0.0f), cell = mkv(0.0f, 0.0f);
-                if(form) {
-                    cohesion = mkv(P.form_cohesion_xz[2 * uid], P.form_cohesion_xz[2 * uid + 1]);
-                    align = mkv(P.form_align_xz[2 * uid], P.form_align_xz[2 * uid + 1]);
-                    cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
-                }else{
-                    cohesion = (flock >= 0) ? mkv(coh_xz[2 * uid], coh_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
-                }
-                steer = mkv(0.0f, 0.0f);
-                for(int prio = 0; prio < 3; prio++) {
-                    if(prio == 0) {
-                        v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
-                        v2 c = vscale(cohesion, 0.15f), al = vscale(align, 0.15f);
-                        v2 ret = mkv(0.0f, 0.0f);
-                        ret = vadd(ret, a); ret = vadd(ret, s);
-                        if(to_cell) {
-                            if(vlen(vsub(cell, me)) > 30.0f) {       // CELL_ARRIVAL_RADIUS
-                                ret = vadd(ret, c); ret = vadd(ret, al);
-                            }
-                        }else{
-                            ret = vadd(ret, c);
-                        }
-                        steer = vtrunc(ret, scaled_max_force);
-                    }else if(prio == 1) {
-                        steer = separation;
-                    }else{
-                        steer = arrive;
-                    }
-                    steer = nullify_impass_bits(R.probes, steer);
-                    if((double)vlen(steer) > force_thresh) break;
-                }
-            }
-            v2 accel = vscale(steer, 1.0f / 1.0f);
-            vpref = vtrunc(vadd(vel, accel), P.speed[uid] / (float)hz);
-            if(R.mode == AM_FORM_CELL || R.mode == AM_FORM_POINT) {
-                const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
-                if(vlen(f_drag) > CP_EPS)                            // :1935 / :2018
-                    vpref = vtrunc(vpref, (float)(((double)P.speed[uid] * 0.75) / (double)hz));
-            }
+            vpref = vpref_from_forces(P, uid, R.mode, me, vel, P.flock[uid], mkv(R.arrive[0], R.arrive[1]),
+                                      separation, R.probes, coh_xz, scaled_max_force, force_thresh);
         }
         // find_neighbours :2768: r = 10 query, cap 512 -- taken from the r = 30 list when that list
         // is complete (n30raw now holds the derived count, -1 = not derivable)
@@ -1288,11 +1060,9 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
         }
         n10 = filter_garrisoned_wave(G, ids10, n10, lane);
         int n_dyn, n_stat;
-        classify_neighbours(G, my_slot, my_bits, ids10, n10, W.dyn, n_dyn, W.stat, n_stat, lane);
+        classify_neighbours(G, my_slot, my_bits, ids10, n10, S.dyn, n_dyn, S.stat, n_stat, lane);
         cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
-        // the neighbour lists are dead from here on: their LDS becomes the candidate queue
-        const cp_scratch cps = {W.u.rays, (float*)W.d2_30, (float*)W.ids10d, (int32_t*)W.ids30};
-        const v2 nv = clearpath_wave(ent, vpref, W.dyn, n_dyn, W.stat, n_stat, cps, lane);
+        const v2 nv = clearpath_grp<64>(ent, vpref, n_dyn, n_stat, S);
         if(lane == 0) {
             if(O.vpref_xz) { O.vpref_xz[2 * uid] = vpref.x; O.vpref_xz[2 * uid + 1] = vpref.z; }
             post_thread(P, uid, me, P.state[uid], P.flags[uid], my_radius, nv, R.vel_cap, R.status, O);
@@ -1316,72 +1086,39 @@ __global__ __launch_bounds__(256) void k_spatial_query(nh_grid G, const float *q
     if(lane == 0) out_counts[q] = n;
 }
 
-__global__ __launch_bounds__(AG_WAVES * 64) void k_clearpath(int nq, const float *ent, const float *des_v,
+// G_ClearPath_NewVelocity for nq independent problems on groups of GW lanes (GW = 64: any problem;
+// GW = 16: n_dyn + n_stat <= 16 -- the row path of the agent step)
+template <int GW>
+__global__ __launch_bounds__(128) void k_clearpath(int nq, const float *ent, const float *des_v,
                                                    const float *dyn, const int32_t *n_dyn,
                                                    const float *stat, const int32_t *n_stat,
                                                    float *out)
 {
-    __shared__ wave_lds lds[AG_WAVES];
-    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int q = blockIdx.x * AG_WAVES + wib;
+    __shared__ cp_lds<GW> lds[128 / GW];
+    const int gi = threadIdx.x / GW, gl = threadIdx.x & (GW - 1);
+    const int q = blockIdx.x * (128 / GW) + gi;
     if(q >= nq) return;
-    wave_lds &W = lds[wib];
-    for(int i = lane; i < 160; i += 64) {
-        W.dyn[i] = dyn[(size_t)q * 160 + i];
-        W.stat[i] = stat[(size_t)q * 160 + i];
-    }
+    cp_lds<GW> &S = lds[gi];
+    const int nd = n_dyn[q], ns = n_stat[q];
+    for(int i = gl; i < nd * 5; i += GW) S.dyn[i] = dyn[(size_t)q * 160 + i];
+    for(int i = gl; i < ns * 5; i += GW) S.stat[i] = stat[(size_t)q * 160 + i];
     wave_sync();
     cpent e; e.pos = mkv(ent[5 * q], ent[5 * q + 1]); e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]);
     e.radius = ent[5 * q + 4];
-    const cp_scratch cps = {W.u.rays, (float*)W.d2_30, (float*)W.ids10d, (int32_t*)W.ids30};
-    v2 r = clearpath_wave(e, mkv(des_v[2 * q], des_v[2 * q + 1]), W.dyn, n_dyn[q], W.stat, n_stat[q],
-                          cps, lane);
-    if(lane == 0) { out[2 * q] = r.x; out[2 * q + 1] = r.z; }
+    const v2 r = clearpath_grp<GW>(e, mkv(des_v[2 * q], des_v[2 * q + 1]), nd, ns, S);
+    if(gl == 0) { out[2 * q] = r.x; out[2 * q + 1] = r.z; }
 }
 
-// The thread-per-agent ClearPath search on the same problems (tests: the light path on its own).
-// n_dyn + n_stat <= NH_LIGHT_MAX; found[q] = 0 when the search punts (no admissible candidate).
-__global__ __launch_bounds__(64) void k_clearpath_light(int nq, const float *ent, const float *des_v,
-                                                        const float *dyn, const int32_t *n_dyn,
-                                                        const float *stat, const int32_t *n_stat,
-                                                        float *out, int32_t *found)
+// ClearPath retry statistics (developer diagnostics: scripts/, bench.py --cp-stats)
+extern "C" int navhip_debug_cp_attempts(unsigned long long out[9], int reset)
 {
-    __shared__ float4 cones[2 * NH_LIGHT_MAX * 64];
-    __shared__ float4 recA[2 * NH_LIGHT_MAX * 64];
-    __shared__ float2 recV[2 * NH_LIGHT_MAX * 64];
-    __shared__ int32_t list[64 * 64];
-    const int lane = threadIdx.x, q = blockIdx.x * 64 + lane;
-    if(q >= nq) return;
-    // a private little pool per thread: slots lane * 8 + j
-    nh_grid G = {};
-    G.recA = recA; G.recV = recV;
-    const int nd = n_dyn[q], ns = n_stat[q];
-    for(int j = 0; j < nd + ns; j++) {
-        const bool st = j >= nd;
-        const float *src = (st ? stat : dyn) + (size_t)q * 160 + 5 * (st ? j - nd : j);
-        recA[lane * 8 + j] = make_float4(src[0], src[1], src[4], 0.0f);
-        recV[lane * 8 + j] = make_float2(src[2], src[3]);
-        list[(st ? 32 + (j - nd) : j) * 64 + lane] = lane * 8 + j;
+    if(hipDeviceSynchronize() != hipSuccess) return 1;
+    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_cp_attempts), 9 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if(reset) {
+        unsigned long long z[9] = {0};
+        if(hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_attempts), z, sizeof(z)) != hipSuccess) return 1;
     }
-    cpent e; e.pos = mkv(ent[5 * q], ent[5 * q + 1]); e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]);
-    e.radius = ent[5 * q + 4];
-    const v2 dv = mkv(des_v[2 * q], des_v[2 * q + 1]);
-    // admissible as it is? (mid_thread's test)
-    bool in = false;
-    for(int j = 0; j < nd + ns; j++) {
-        const bool st = j >= nd;
-        const cpent nb = nbr_cpent(G, lane * 8 + j, st);
-        if(vlen(vsub(nb.pos, e.pos)) < CP_EPS) continue;
-        v2 apex, left, right; float sl, sr;
-        make_cone(e, nb, !st, apex, left, right, sl, sr);
-        in = in || cone_contains(make_float4(apex.x, apex.z, sl, sr),
-                                 make_float4(left.x, left.z, right.x, right.z), vadd(e.pos, dv));
-    }
-    v2 r = dv;
-    bool ok = true;
-    if(in) ok = cp_light_thread(G, e, dv, nd, ns, list + lane, 64, cones + lane, 64, r);
-    out[2 * q] = r.x; out[2 * q + 1] = r.z;
-    found[q] = ok ? 1 : 0;
+    return 0;
 }
 
 __global__ void k_wl_zero(int32_t *count)
@@ -1428,7 +1165,7 @@ void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t 
 {
     if(P.n_ents > 0 && P.work_end > P.work_begin) {
         const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
-        hipLaunchKernelGGL(k_agent_nbr, dim3((P.n_ents + 255) / 256), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
+        hipLaunchKernelGGL(k_agent_nbr, dim3((P.n_ents + 15) / 16), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
     }
 }
 
@@ -1541,14 +1278,13 @@ void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     int32_t *other = WL.count + (parity ^ 1) * NH_WL_COUNT;
     WL.count += parity * NH_WL_COUNT;
     hipLaunchKernelGGL(k_wl_zero, dim3(1), dim3(64), 0, s, other);
-    hipLaunchKernelGGL(k_agent_mid, dim3((nwork + 255) / 256), dim3(256), 0, s, P, NB, (const float*)d_coh,
+    hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
                        d_mid, WL, O, smf, thresh);
-    const int grid_l = min(2048, (nwork + 63) / 64 + 4);
-    hipLaunchKernelGGL(k_cp_light, dim3(grid_l), dim3(64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O);
-    const int grid_w = min(4096, (nwork + AG_WAVES - 1) / AG_WAVES);
-    hipLaunchKernelGGL(k_cp_wave, dim3(grid_w), dim3(AG_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O);
-    hipLaunchKernelGGL(k_agent_full, dim3(min(grid_w, 1024)), dim3(AG_WAVES * 64), 0, s, P, (const float*)d_coh,
-                       (const nh_mid_rec*)d_mid, WL, O, smf, thresh);
+    // enough resident waves to fill the chip; every wave keeps drawing units until none are left
+    hipLaunchKernelGGL(k_cp, dim3(min(2048, (nwork + 7) / 8 + 1)), dim3(AG_WAVES * 64), 0, s, P, NB,
+                       (const nh_mid_rec*)d_mid, WL, O);
+    hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
+                       (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh);
 }
 
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,
@@ -1561,13 +1297,13 @@ void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, flo
 
 void nh_launch_clearpath(int nq, const float *ent, const float *des_v, const float *dyn,
                          const int32_t *n_dyn, const float *stat, const int32_t *n_stat, float *out,
-                         int32_t *light_found, hipStream_t s)
+                         int rows, hipStream_t s)
 {
     if(nq <= 0) return;
-    if(light_found)
-        hipLaunchKernelGGL(k_clearpath_light, dim3((nq + 63) / 64), dim3(64), 0, s, nq, ent, des_v, dyn,
-                           n_dyn, stat, n_stat, out, light_found);
+    if(rows)
+        hipLaunchKernelGGL(k_clearpath<16>, dim3((nq + 7) / 8), dim3(128), 0, s, nq, ent, des_v, dyn,
+                           n_dyn, stat, n_stat, out);
     else
-        hipLaunchKernelGGL(k_clearpath, dim3((nq + AG_WAVES - 1) / AG_WAVES), dim3(AG_WAVES * 64), 0, s, nq, ent,
-                           des_v, dyn, n_dyn, stat, n_stat, out);
+        hipLaunchKernelGGL(k_clearpath<64>, dim3((nq + 1) / 2), dim3(128), 0, s, nq, ent, des_v, dyn,
+                           n_dyn, stat, n_stat, out);
 }

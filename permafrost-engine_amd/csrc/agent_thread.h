@@ -30,13 +30,14 @@ enum { AM_IDLE = 0,        // still or combat held: velocity 0, no neighbour wor
        AM_UNSUPPORTED };   // formation state without formation inputs
 
 enum { DISP_DONE = 0,      // out_vel is final (before truncation)
-       DISP_LIGHT1, DISP_LIGHT2, DISP_LIGHT3, DISP_LIGHT4,     // candidate search, thread per agent
-       DISP_WAVE,          // candidate search, wave per agent
+       DISP_ROW0, DISP_ROW1, DISP_ROW2, DISP_ROW3,   // ClearPath on a row of 16 lanes: 1-2, 3-4, 5-8, 9-16 neighbours
+       DISP_WAVE,          // ClearPath on a wave: 17-64 neighbours
        DISP_FULL };        // whole step on a wave (irregular gather)
 
 #define NH_SEP_CAP   128   /* near_ents[128],  movement.c:1695 */
 #define NH_NEAR_CAP  512   /* near_ents[512],  movement.c:2779 */
 #define NH_MAX_NEIGHBOURS 32
+#define NH_ROW_MAX  16   /* most ClearPath neighbours an agent may have for the 16-lane path */
 
 // ---------------------------------------------------------------------------------------------
 // pool record of entity i (written by the last pass of the spatial-hash build)
@@ -72,8 +73,11 @@ NH_FN void pool_record(int i, const float *pos_xz, const nh_pack_src &src, int w
     recV = make_float2(vel.x, vel.z);
 }
 
+#ifdef NH_HOSTSIM
 // ---------------------------------------------------------------------------------------------
-// neighbour walk
+// neighbour walk: the SERIAL statement of what nbr_walk_row (agent_group.h) computes with 16 lanes.
+// Compiled for the host tests only (tests/hostsim), which pin it to the reference build; the GPU
+// tests then pin the device's 16-lane form to the same reference.
 // ---------------------------------------------------------------------------------------------
 // Visiting order == bg_*_inrange_circle (bitmap_grid.h:1408-1466): coarse 8x8 blocks row-major,
 // inside a block fine rows top to bottom, cells left to right, packed elements in order.  The cells
@@ -116,7 +120,15 @@ NH_FN void nbr_walk_thread(const nh_grid &G, int k, float scaled_max_force, cons
         const int fx0 = cxc * 8 > E.cx_lo ? cxc * 8 : E.cx_lo;
         const int fx1 = cxc * 8 + 8 < E.cx_hi + 1 ? cxc * 8 + 8 : E.cx_hi + 1;
         for(int fy = fy0; fy <= fy1 && !stop; fy++) {
-            const int b = G.cell_start[fy * G.grid_w + fx0], e = G.cell_start[fy * G.grid_w + fx1];
+            int sx0 = fx0, sx1 = fx1;
+            if(raw30 >= NH_SEP_CAP) {
+                // the r = 30 query has stopped: only cells of the r = 10 box can still contribute
+                if(fy < E10.cy_lo || fy > E10.cy_hi) continue;
+                sx0 = fx0 > E10.cx_lo ? fx0 : E10.cx_lo;
+                sx1 = fx1 < E10.cx_hi + 1 ? fx1 : E10.cx_hi + 1;
+                if(sx0 >= sx1) continue;
+            }
+            const int b = G.cell_start[fy * G.grid_w + sx0], e = G.cell_start[fy * G.grid_w + sx1];
             for(int q = b; q < e; q++) {
                 const float4 c = G.recA[q];
                 // (elements clamped into a border cell may be far away: range-check before squaring
@@ -163,6 +175,8 @@ NH_FN void nbr_walk_thread(const nh_grid &G, int k, float scaled_max_force, cons
     NB.sep[uid] = make_float2(sep.x, sep.z);
     NB.cnt[uid] = (uint32_t)n_dyn | ((uint32_t)n_stat << 8) | (NH_NB_DONE << 16);
 }
+
+#endif  // NH_HOSTSIM
 
 // ---------------------------------------------------------------------------------------------
 // position accept + outputs
@@ -212,7 +226,68 @@ NH_FN cpent nbr_cpent(const nh_grid &G, int slot, bool is_static)
 }
 
 // ---------------------------------------------------------------------------------------------
-// pre + priority ladder + admissibility of des_v
+// steering forces -> preferred velocity
+// ---------------------------------------------------------------------------------------------
+// point_seek_vpref :1870 / enemy_seek_vpref :1946 / cell_arrival_seek_vpref :1908 /
+// formation_seek_vpref :1985, given the arrive and separation terms and the five tile probes
+NH_FN v2 vpref_from_forces(const nh_step_params &P, int uid, int mode, v2 me, v2 vel, int flock, v2 arrive,
+                           v2 separation, uint32_t probes, const float *coh_xz, float scaled_max_force,
+                           double force_thresh)
+{
+    const int hz = P.hz;
+    v2 steer;
+    if(mode == AM_ENEMY_SEEK) {
+        // enemy_seek_vpref :1946 (no priorities, no nullify)
+        v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
+        v2 ret = mkv(0.0f, 0.0f);
+        ret = vadd(ret, a); ret = vadd(ret, s);
+        steer = vtrunc(ret, scaled_max_force);
+    }else{
+        const bool to_cell = mode == AM_FORM_CELL, formm = mode != AM_POINT_SEEK;
+        v2 cohesion, align = mkv(0.0f, 0.0f), cell = mkv(0.0f, 0.0f);
+        if(formm) {
+            cohesion = mkv(P.form_cohesion_xz[2 * uid], P.form_cohesion_xz[2 * uid + 1]);
+            align = mkv(P.form_align_xz[2 * uid], P.form_align_xz[2 * uid + 1]);
+            cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
+        }else{
+            cohesion = (flock >= 0) ? mkv(coh_xz[2 * uid], coh_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
+        }
+        steer = mkv(0.0f, 0.0f);
+        for(int prio = 0; prio < 3; prio++) {
+            if(prio == 0) {
+                v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
+                v2 c = vscale(cohesion, 0.15f), al = vscale(align, 0.15f);
+                v2 ret = mkv(0.0f, 0.0f);
+                ret = vadd(ret, a); ret = vadd(ret, s);
+                if(to_cell) {
+                    if(vlen(vsub(cell, me)) > 30.0f) {       // CELL_ARRIVAL_RADIUS
+                        ret = vadd(ret, c); ret = vadd(ret, al);
+                    }
+                }else{
+                    ret = vadd(ret, c);
+                }
+                steer = vtrunc(ret, scaled_max_force);
+            }else if(prio == 1) {
+                steer = separation;
+            }else{
+                steer = arrive;
+            }
+            steer = nullify_impass_bits(probes, steer);
+            if((double)vlen(steer) > force_thresh) break;
+        }
+    }
+    v2 accel = vscale(steer, 1.0f / 1.0f);
+    v2 vpref = vtrunc(vadd(vel, accel), P.speed[uid] / (float)hz);
+    if(mode == AM_FORM_CELL || mode == AM_FORM_POINT) {
+        const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
+        if(vlen(f_drag) > CP_EPS)                            // :1935 / :2018
+            vpref = vtrunc(vpref, (float)(((double)P.speed[uid] * 0.75) / (double)hz));
+    }
+    return vpref;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the per-agent scalar chain: desired direction, arrive force, probes, ladder -> vpref
 // ---------------------------------------------------------------------------------------------
 NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
                      float scaled_max_force, double force_thresh, nh_mid_rec &R, v2 &out_vel)
@@ -300,94 +375,26 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
     v2 vpref = mkv(0.0f, 0.0f);
     if(mode != AM_ZERO_VPREF) {
         const float2 s2 = NB.sep[uid];
-        const v2 separation = mkv(s2.x, s2.y);
-        v2 steer;
-        if(mode == AM_ENEMY_SEEK) {
-            // enemy_seek_vpref :1946 (no priorities, no nullify)
-            v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
-            v2 ret = mkv(0.0f, 0.0f);
-            ret = vadd(ret, a); ret = vadd(ret, s);
-            steer = vtrunc(ret, scaled_max_force);
-        }else{
-            // point_seek_vpref :1870 / cell_arrival_seek_vpref :1908 / formation_seek_vpref :1985
-            const bool to_cell = mode == AM_FORM_CELL, formm = mode != AM_POINT_SEEK;
-            v2 cohesion, align = mkv(0.0f, 0.0f), cell = mkv(0.0f, 0.0f);
-            if(formm) {
-                cohesion = mkv(P.form_cohesion_xz[2 * uid], P.form_cohesion_xz[2 * uid + 1]);
-                align = mkv(P.form_align_xz[2 * uid], P.form_align_xz[2 * uid + 1]);
-                cell = mkv(P.cell_pos_xz[2 * uid], P.cell_pos_xz[2 * uid + 1]);
-            }else{
-                cohesion = (flock >= 0) ? mkv(coh_xz[2 * uid], coh_xz[2 * uid + 1]) : mkv(0.0f, 0.0f);
-            }
-            steer = mkv(0.0f, 0.0f);
-            for(int prio = 0; prio < 3; prio++) {
-                if(prio == 0) {
-                    v2 a = vscale(arrive, 0.5f), s = vscale(separation, 0.6f);
-                    v2 c = vscale(cohesion, 0.15f), al = vscale(align, 0.15f);
-                    v2 ret = mkv(0.0f, 0.0f);
-                    ret = vadd(ret, a); ret = vadd(ret, s);
-                    if(to_cell) {
-                        if(vlen(vsub(cell, me)) > 30.0f) {       // CELL_ARRIVAL_RADIUS
-                            ret = vadd(ret, c); ret = vadd(ret, al);
-                        }
-                    }else{
-                        ret = vadd(ret, c);
-                    }
-                    steer = vtrunc(ret, scaled_max_force);
-                }else if(prio == 1) {
-                    steer = separation;
-                }else{
-                    steer = arrive;
-                }
-                steer = nullify_impass_bits(probes, steer);
-                if((double)vlen(steer) > force_thresh) break;
-            }
-        }
-        v2 accel = vscale(steer, 1.0f / 1.0f);
-        vpref = vtrunc(vadd(vel, accel), P.speed[uid] / (float)hz);
-        if(mode == AM_FORM_CELL || mode == AM_FORM_POINT) {
-            const v2 f_drag = mkv(P.form_drag_xz[2 * uid], P.form_drag_xz[2 * uid + 1]);
-            if(vlen(f_drag) > CP_EPS)                            // :1935 / :2018
-                vpref = vtrunc(vpref, (float)(((double)P.speed[uid] * 0.75) / (double)hz));
-        }
+        vpref = vpref_from_forces(P, uid, mode, me, vel, flock, arrive, mkv(s2.x, s2.y), probes, coh_xz,
+                                  scaled_max_force, force_thresh);
     }
     R.vpref[0] = vpref.x; R.vpref[1] = vpref.z;
 
-    const int n_dyn = (int)(cnt & 0xff), n_stat = (int)((cnt >> 8) & 0xff);
-    const int n = n_dyn + n_stat;
-    if(n == 0) {                                       // inside_pcr of nothing is false
+    const int n = (int)(cnt & 0xff) + (int)((cnt >> 8) & 0xff);
+    if(n == 0) {                                       // inside_pcr of nothing is false (clearpath.c:604)
         out_vel = vpref;
         return DISP_DONE;
     }
-    if(n > NH_LIGHT_MAX)
-        return DISP_WAVE;
-    // clearpath_new_velocity :604: des_v admissible as it is?  One cone at a time, no storage.
-    cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
-    const v2 des_ws = vadd(me, vpref);
-    bool in = false;
-    for(int j = 0; j < n; j++) {
-        const bool is_stat = j >= n_dyn;
-        const int slot = NB.list[(size_t)(is_stat ? 32 + (j - n_dyn) : j) * NB.stride + uid];
-        const cpent nb = nbr_cpent(P.grid, slot, is_stat);
-        if(vlen(vsub(nb.pos, ent.pos)) < CP_EPS) continue;       // same_position, :216-246
-        v2 apex, left, right; float sl, sr;
-        make_cone(ent, nb, !is_stat, apex, left, right, sl, sr);
-        in = in || cone_contains(make_float4(apex.x, apex.z, sl, sr),
-                                 make_float4(left.x, left.z, right.x, right.z), des_ws);
-    }
-    if(!in) {
-        out_vel = vpref;
-        return DISP_DONE;
-    }
-    return DISP_LIGHT1 + (n - 1);
+    return n <= 2 ? DISP_ROW0 : n <= 4 ? DISP_ROW1 : n <= 8 ? DISP_ROW2 : n <= NH_ROW_MAX ? DISP_ROW3 : DISP_WAVE;
 }
 
+#ifdef NH_HOSTSIM
 // ---------------------------------------------------------------------------------------------
-// ClearPath candidate search, sequential (<= NH_LIGHT_MAX neighbours)
+// ClearPath candidate search: the SERIAL statement of one attempt of clearpath_grp (agent_group.h),
+// for the host tests (tests/hostsim) -- same candidate set, same bound, same tie-break.
 // ---------------------------------------------------------------------------------------------
-// cones: this thread's 2 * NH_LIGHT_MAX float4 at cones[i * cstride] (LDS, thread-interleaved, on
-// the device).  Returns false when no candidate lies outside the combined obstacle: the caller
-// hands the agent to the wave-per-agent kernel, which also runs remove_furthest (:390) and retries.
+// cones: 2 float4 per neighbour at cones[i * cstride].  Returns false when no candidate lies outside
+// the combined obstacle (the device then runs remove_furthest, :390, and retries).
 NH_FN bool cp_light_thread(const nh_grid &G, const cpent &ent, v2 des_v, int n_dyn, int n_stat,
                            const int32_t *list, size_t stride, float4 *cones, int cstride, v2 &result)
 {
@@ -405,10 +412,43 @@ NH_FN bool cp_light_thread(const nh_grid &G, const cpent &ent, v2 des_v, int n_d
         n_cones++;
     }
     const int n_rays = 2 * n_cones;
+    const int npairs = n_rays * n_rays;
+    {   // clearpath_new_velocity :604: des_v admissible as it is?
+        bool in = false;
+        for(int c = 0; c < n_cones && !in; c++)
+            in = cone_contains(cones[(2 * c) * cstride], cones[(2 * c + 1) * cstride], vadd(ent.pos, des_v));
+        if(!in) { result = des_v; return true; }
+    }
+    // compute_vnew (:368) keeps the first strictly-smaller distance in candidate order = the minimum
+    // of (distance, order index) over the candidates outside the obstacle: the order of evaluation is
+    // free, and a candidate that cannot beat the best one so far needs no inside-obstacle test.
+    // Projections of des_v first (order index npairs + i): they tighten the bound at once.
     float best_len = INFINITY;
+    int best_idx = 0x7fffffff;
     v2 best = mkv(0.0f, 0.0f);
     bool any = false;
-    // (i, j) ray pairs in the reference's order, then the projections of des_v on every ray
+#define NH_CP_CONSIDER(PT, IDX) do {                                                                   \
+        const v2 curr_ = vsub((PT), ent.pos);                                                          \
+        const float len_ = vlen(vsub(des_v, curr_));                                                   \
+        if(!any || len_ < best_len || (len_ == best_len && (IDX) < best_idx)) {                        \
+            bool inside_ = false;                                                                      \
+            for(int c_ = 0; c_ < n_cones && !inside_; c_++)                                            \
+                inside_ = cone_contains(cones[(2 * c_) * cstride], cones[(2 * c_ + 1) * cstride], (PT)); \
+            if(!inside_) {                                                                             \
+                if(len_ < best_len || (len_ == best_len && (IDX) < best_idx)) {                        \
+                    best_len = len_; best_idx = (IDX); best = curr_;                                   \
+                }                                                                                      \
+                any = true;                                                                            \
+            }                                                                                          \
+        }                                                                                              \
+    } while(0)
+    for(int i = 0; i < n_rays; i++) {
+        const float4 Ai = cones[(i & ~1) * cstride], Bi = cones[(i | 1) * cstride];
+        const v2 dir = (i & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
+        const float plen = vdot(dir, des_v);
+        const v2 pt = vadd(point, vscale(dir, plen));
+        NH_CP_CONSIDER(pt, npairs + i);
+    }
     for(int i = 0; i < n_rays; i++) {
         const float4 Ai = cones[(i & ~1) * cstride], Bi = cones[(i | 1) * cstride];
         const v2 pi = mkv(Ai.x, Ai.y), di = (i & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y);
@@ -420,30 +460,11 @@ NH_FN bool cp_light_thread(const nh_grid &G, const cpent &ent, v2 des_v, int n_d
             if(!ray_isect(pi, di, si, mkv(Aj.x, Aj.y), (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y),
                           (j & 1) ? Aj.w : Aj.z, pt))
                 continue;
-            bool inside = false;
-            for(int c = 0; c < n_cones && !inside; c++)
-                inside = cone_contains(cones[(2 * c) * cstride], cones[(2 * c + 1) * cstride], pt);
-            if(inside) continue;
-            any = true;
-            const v2 curr = vsub(pt, ent.pos);
-            const float len = vlen(vsub(des_v, curr));
-            if(len < best_len) { best_len = len; best = curr; }
+            NH_CP_CONSIDER(pt, i * n_rays + j);
         }
     }
-    for(int i = 0; i < n_rays; i++) {
-        const float4 Ai = cones[(i & ~1) * cstride], Bi = cones[(i | 1) * cstride];
-        const v2 dir = (i & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
-        const float plen = vdot(dir, des_v);
-        const v2 pt = vadd(point, vscale(dir, plen));
-        bool inside = false;
-        for(int c = 0; c < n_cones && !inside; c++)
-            inside = cone_contains(cones[(2 * c) * cstride], cones[(2 * c + 1) * cstride], pt);
-        if(inside) continue;
-        any = true;
-        const v2 curr = vsub(pt, ent.pos);
-        const float len = vlen(vsub(des_v, curr));
-        if(len < best_len) { best_len = len; best = curr; }
-    }
+#undef NH_CP_CONSIDER
     result = best;
     return any;
 }
+#endif  // NH_HOSTSIM

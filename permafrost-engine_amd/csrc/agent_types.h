@@ -90,14 +90,15 @@ struct nh_nbr {
 
 // Work lists filled on the device (counters[NH_WL_*] + ids), consumed by fixed-size launches that
 // stride over them: agents that still need a ClearPath search after k_agent_mid.
-enum { NH_WL_LIGHT1 = 0, NH_WL_LIGHT2, NH_WL_LIGHT3, NH_WL_LIGHT4,   // thread per agent, n = 1..4 neighbours
-       NH_WL_WAVE,          // one wave per agent: more than NH_LIGHT_MAX neighbours, or the light search punted
+enum { NH_WL_ROW0 = 0, NH_WL_ROW1, NH_WL_ROW2, NH_WL_ROW3,   // a row of 16 lanes per agent: 1-2, 3-4, 5-8, 9-16 neighbours
+       NH_WL_WAVE,          // one wave per agent: 17-64 neighbours
        NH_WL_FULL,          // one wave per agent, whole step (irregular gather)
+       NH_WL_LISTS,         // (number of lists)
+       NH_WL_TICKET = NH_WL_LISTS,   // work-unit ticket counter of k_cp
        NH_WL_COUNT };
-#define NH_LIGHT_MAX 4
 struct nh_worklists {
     int32_t *count;            // [NH_WL_COUNT] (+ [NH_WL_COUNT] of the other parity, see nh_launch_*)
-    int32_t *ids;              // [NH_WL_COUNT][stride] uids
+    int32_t *ids;              // [NH_WL_LISTS][stride] uids
     int      stride;
 };
 

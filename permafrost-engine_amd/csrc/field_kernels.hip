@@ -145,7 +145,8 @@ void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, 
 template <bool WANT_INTEG>
 __global__ __launch_bounds__(BFS_WAVES * 64) void k_field_bfs(nh_map_view map, const navhip_field_req *reqs,
                                                    int n, uint8_t *dirs, float *integ,
-                                                   int force_generic, int32_t *gen_list, int gen_slot)
+                                                   int force_generic, int32_t *gen_list, int gen_slot,
+                                                   const int32_t *out_slot)
 {
     // 4 KB of LDS per wave: staging buffer to turn "lane owns a 64-byte row" into fully
     // coalesced 16 B/lane global accesses (both for the INOUT read and for the final write).
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(BFS_WAVES * 64) void k_field_bfs(nh_map_view map, c
     }
 
     // ---- expand to one byte per cell and write 4 KB coalesced ---------------------------------
-    uint8_t *out = dirs + ((size_t)wave << 12);
+    // (out_slot: the request's slot of a field pool, navhip_pool_build; else its own index)
+    uint8_t *out = dirs + ((size_t)(out_slot ? out_slot[wave] : wave) << 12);
     uint8_t *st = stage[wib];
     const bool inout = (rq.flags & NAVHIP_REQ_INOUT) != 0;
     if(inout) {
@@ -371,7 +373,8 @@ struct generic_lds {
 };
 
 __device__ void field_generic_one(generic_lds &S, const nh_map_view &map, const navhip_field_req *reqs,
-                                  int ri, uint8_t *dirs, float *integ, int force_generic)
+                                  int ri, uint8_t *dirs, float *integ, int force_generic,
+                                  const int32_t *out_slot)
 {
     uint32_t (&dist)[NH_CELLS] = S.dist;
     uint8_t (&pc)[NH_CELLS] = S.pc;
@@ -583,7 +586,7 @@ __device__ void field_generic_one(generic_lds &S, const nh_map_view &map, const 
 
     // ---- bake (field_flow_dir, field.c:355-433) + fixup; result staged in pc[] ----------------
     const bool inout = (rq.flags & NAVHIP_REQ_INOUT) != 0 || modeA || modeB;
-    uint8_t *out = dirs + ((size_t)ri << 12);
+    uint8_t *out = dirs + ((size_t)(out_slot ? out_slot[ri] : ri) << 12);
     const uint32_t fixdir = (rq.type == NAVHIP_TARGET_PORTAL) ? portal_fix_dir(rq) : NAVHIP_FD_NONE;
     uint8_t res[16];
 #pragma unroll 4
@@ -636,21 +639,22 @@ __device__ void field_generic_one(generic_lds &S, const nh_map_view &map, const 
 // after this one in stream order) -- no reset pass, no completion atomics.
 __global__ __launch_bounds__(256) void k_field_generic(nh_map_view map, const navhip_field_req *reqs,
                                                        int n, uint8_t *dirs, float *integ,
-                                                       int force_generic, int32_t *gen_list, int gen_slot)
+                                                       int force_generic, int32_t *gen_list, int gen_slot,
+                                                       const int32_t *out_slot)
 {
     __shared__ generic_lds S;
     const int count = gen_list ? gen_list[gen_slot] : n;
     if(gen_list && blockIdx.x == 0 && threadIdx.x == 0) gen_list[gen_slot ^ 1] = 0;
     for(int w = blockIdx.x; w < count; w += gridDim.x) {
         const int ri = gen_list ? gen_list[2 + w] : w;
-        field_generic_one(S, map, reqs, ri, dirs, integ, force_generic);
+        field_generic_one(S, map, reqs, ri, dirs, integ, force_generic, out_slot);
         __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, uint8_t *d_dirs,
-                      float *d_integ, int32_t *d_gen_list, hipStream_t s)
+                      float *d_integ, int32_t *d_gen_list, hipStream_t s, const int32_t *d_out_slot)
 {
 
     nh_map_view mv;
@@ -668,11 +672,11 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
         dim3 grid((n + BFS_WAVES - 1) / BFS_WAVES);
         if(d_integ)
             hipLaunchKernelGGL(k_field_bfs<true>, grid, dim3(BFS_WAVES * 64), 0, s, mv, d_reqs, n, d_dirs,
-                               d_integ, force_generic, d_gen_list, gen_slot);
+                               d_integ, force_generic, d_gen_list, gen_slot, d_out_slot);
         else
             hipLaunchKernelGGL(k_field_bfs<false>, grid, dim3(BFS_WAVES * 64), 0, s, mv, d_reqs, n, d_dirs,
-                               d_integ, force_generic, d_gen_list, gen_slot);
+                               d_integ, force_generic, d_gen_list, gen_slot, d_out_slot);
     }
     hipLaunchKernelGGL(k_field_generic, dim3(n < 512 ? n : 512), dim3(256), 0, s, mv, d_reqs, n, d_dirs,
-                       d_integ, force_generic, force_generic ? (int32_t*)nullptr : d_gen_list, gen_slot);
+                       d_integ, force_generic, force_generic ? (int32_t*)nullptr : d_gen_list, gen_slot, d_out_slot);
 }

@@ -12,6 +12,7 @@
 //   unit_cost     u8  [chunks]               derived: BFS kernel eligibility
 #include "navhip_internal.h"
 #include "agent_internal.h"
+#include "agent_thread.h"
 #include <cmath>
 
 #include <cstdio>
@@ -108,6 +109,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
+    ctx->pool = nullptr; ctx->async = nullptr;
     memset(ctx->ev, 0, sizeof(ctx->ev));
     if(hipSetDevice(device) != hipSuccess
     || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -123,6 +125,8 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     if(!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    navhip_pool_destroy(ctx);
+    nh_async_destroy(ctx);
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         navhip_layer &L = ctx->layers[l];
         hipFree(L.cost); hipFree(L.blockers); hipFree(L.local_islands); hipFree(L.factions);
@@ -503,7 +507,7 @@ int navhip_build_los(navhip_ctx *ctx, const navhip_los_req *reqs, int n,
     return NAVHIP_OK;
 }
 
-static int validate_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
+int navhip_validate_field_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
 {
     for(int i = 0; i < n; i++) {
         const navhip_field_req &r = reqs[i];
@@ -532,13 +536,9 @@ static int validate_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
     return NAVHIP_OK;
 }
 
-int navhip_build_fields_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, int n,
-                            uint8_t *dev_inout_dirs, float *dev_out_integ, void *stream)
+static int build_fields_on(navhip_ctx *ctx, const navhip_field_req *dev_reqs, int n, uint8_t *dev_inout_dirs,
+                           float *dev_out_integ, const int32_t *dev_slots, hipStream_t s)
 {
-    if(!ctx || n < 0 || (n > 0 && (!dev_reqs || !dev_inout_dirs))) return NAVHIP_ERR_INVALID;
-    if(n == 0) return NAVHIP_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     int rc = refresh_derived(ctx, s);
     if(rc) return rc;
     // work list of the generic kernel: the header is zero between launches (the kernel resets it)
@@ -546,10 +546,40 @@ int navhip_build_fields_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, i
     rc = ensure_buf(ctx, ctx->gen_list, ((size_t)n + 2) * sizeof(int32_t));
     if(rc) return rc;
     if(ctx->gen_list.p != old_list) HIPCHK(ctx, hipMemsetAsync(ctx->gen_list.p, 0, 2 * sizeof(int32_t), s));
-    nh_launch_fields(ctx, dev_reqs, n, dev_inout_dirs, dev_out_integ, (int32_t*)ctx->gen_list.p, s);
+    nh_launch_fields(ctx, dev_reqs, n, dev_inout_dirs, dev_out_integ, (int32_t*)ctx->gen_list.p, s, dev_slots);
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
 }
+
+int navhip_build_fields_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, int n,
+                            uint8_t *dev_inout_dirs, float *dev_out_integ, void *stream)
+{
+    if(!ctx || n < 0 || (n > 0 && (!dev_reqs || !dev_inout_dirs))) return NAVHIP_ERR_INVALID;
+    if(n == 0) return NAVHIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return build_fields_on(ctx, dev_reqs, n, dev_inout_dirs, dev_out_integ, nullptr,
+                           stream ? (hipStream_t)stream : ctx->stream);
+}
+
+}  // extern "C"
+
+// request i is built into slot dev_slots[i] of dev_fields (navhip_pool_build)
+int navhip_build_fields_slots_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, int n, uint8_t *dev_fields,
+                                  const int32_t *dev_slots, hipStream_t s)
+{
+    if(n == 0) return NAVHIP_OK;
+    return build_fields_on(ctx, dev_reqs, n, dev_fields, nullptr, dev_slots, s);
+}
+
+int navhip_stage_reserve(navhip_ctx *ctx, int slot, size_t bytes, void **dev)
+{
+    int rc = ensure_buf(ctx, ctx->stage[slot], bytes);
+    if(rc) return rc;
+    *dev = ctx->stage[slot].p;
+    return NAVHIP_OK;
+}
+
+extern "C" {
 
 int navhip_build_fields(navhip_ctx *ctx, const navhip_field_req *reqs, int n,
                         uint8_t *inout_dirs, float *out_integ)
@@ -557,7 +587,7 @@ int navhip_build_fields(navhip_ctx *ctx, const navhip_field_req *reqs, int n,
     if(!ctx || n < 0 || (n > 0 && (!reqs || !inout_dirs))) return NAVHIP_ERR_INVALID;
     if(n == 0) return NAVHIP_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = validate_reqs(ctx, reqs, n);
+    int rc = navhip_validate_field_reqs(ctx, reqs, n);
     if(rc) return rc;
     hipStream_t s = ctx->stream;
     rc = ensure_cap(ctx, &ctx->d_reqs, &ctx->d_reqs_cap, (size_t)n * sizeof(navhip_field_req));
@@ -734,6 +764,14 @@ static int step_fill_params(navhip_ctx *ctx, const navhip_world *w, nh_step_para
     P.flock = w->flock; P.vdes_xz = w->vdes_xz; P.flock_target_xz = w->flock_target_xz;
     P.flock_offsets = w->flock_offsets; P.flock_members = w->flock_members;
     P.flock_field_slot = w->flock_field_slot; P.field_pool = w->field_pool;
+    if(w->n_field_slots == NAVHIP_POOL_RESIDENT) {
+        // sample the context's resident pool: row = flock index of the (dest, chunk) -> slot table
+        if(!ctx->pool || w->n_flocks > nh_pool_dests(ctx)) {
+            ctx->last_error = "agent step: NAVHIP_POOL_RESIDENT without a pool that has a row per flock";
+            return NAVHIP_ERR_INVALID;
+        }
+        P.flock_field_slot = nh_pool_map(ctx); P.field_pool = nh_pool_fields(ctx);
+    }
     P.form_ready = w->form_ready; P.cell_pos_xz = w->cell_pos_xz;
     P.form_cohesion_xz = w->form_cohesion_xz; P.form_align_xz = w->form_align_xz;
     P.form_drag_xz = w->form_drag_xz;
@@ -921,7 +959,7 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());
     const int32_t *src = (const int32_t*)ctx->wl[0].p + (ctx->wl_parity ^ 1) * NH_WL_COUNT;
-    HIPCHK(ctx, hipMemcpy(out_counts, src, sizeof(int32_t) * NH_WL_COUNT, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_counts, src, sizeof(int32_t) * NH_WL_LISTS, hipMemcpyDeviceToHost));
     return NAVHIP_OK;
 }
 
@@ -953,8 +991,10 @@ static int stage_world(navhip_ctx *ctx, const navhip_world *w, navhip_world *d, 
     ST(6, state, n);             ST(7, has_dest_los, n);     ST(8, flock, n * 4);
     ST(9, vdes_xz, n * 8);       ST(10, flock_target_xz, F * 8);
     ST(11, flock_offsets, (F + 1) * 4);                      ST(12, flock_members, nmembers * 4);
-    ST(13, flock_field_slot, F * nchunks * 4);
-    ST(14, field_pool, (size_t)w->n_field_slots * NH_CELLS);
+    if(w->n_field_slots != NAVHIP_POOL_RESIDENT) {
+        ST(13, flock_field_slot, F * nchunks * 4);
+        ST(14, field_pool, (size_t)w->n_field_slots * NH_CELLS);
+    }
     ST(24, form_ready, n);       ST(25, cell_pos_xz, n * 8); ST(26, form_cohesion_xz, n * 8);
     ST(27, form_align_xz, n * 8); ST(28, form_drag_xz, n * 8);
     ST(36, arrival_sink_xz, n * 8); ST(37, arrival_flags, n);
@@ -1034,14 +1074,14 @@ int navhip_spatial_query(navhip_ctx *ctx, const navhip_world *w, const float *qu
 
 static int clearpath_batch(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
                            const float *dyn, const int32_t *n_dyn, const float *stat,
-                           const int32_t *n_stat, float *out, int32_t *light_found)
+                           const int32_t *n_stat, float *out, int rows)
 {
     if(!ctx || nq < 0 || !ent || !des_v || !dyn || !n_dyn || !stat || !n_stat || !out)
         return NAVHIP_ERR_INVALID;
     if(nq == 0) return NAVHIP_OK;
     for(int i = 0; i < nq; i++) {
         if(n_dyn[i] < 0 || n_dyn[i] > 32 || n_stat[i] < 0 || n_stat[i] > 32) return NAVHIP_ERR_INVALID;
-        if(light_found && n_dyn[i] + n_stat[i] > NH_LIGHT_MAX) return NAVHIP_ERR_INVALID;
+        if(rows && n_dyn[i] + n_stat[i] > NH_ROW_MAX) return NAVHIP_ERR_INVALID;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1054,15 +1094,12 @@ static int clearpath_batch(navhip_ctx *ctx, int nq, const float *ent, const floa
         if(rc) return rc;
     }
     int rc = ensure_buf(ctx, ctx->stage[15], (size_t)nq * 8);
-    if(!rc && light_found) rc = ensure_buf(ctx, ctx->stage[16], (size_t)nq * 4);
     if(rc) return rc;
     nh_launch_clearpath(nq, (const float*)d[0], (const float*)d[1], (const float*)d[2],
                         (const int32_t*)d[3], (const float*)d[4], (const int32_t*)d[5],
-                        (float*)ctx->stage[15].p, light_found ? (int32_t*)ctx->stage[16].p : nullptr, s);
+                        (float*)ctx->stage[15].p, rows, s);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage[15].p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
-    if(light_found)
-        HIPCHK(ctx, hipMemcpyAsync(light_found, ctx->stage[16].p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;
 }
@@ -1071,15 +1108,14 @@ int navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *des
                      const float *dyn, const int32_t *n_dyn, const float *stat,
                      const int32_t *n_stat, float *out)
 {
-    return clearpath_batch(ctx, nq, ent, des_v, dyn, n_dyn, stat, n_stat, out, nullptr);
+    return clearpath_batch(ctx, nq, ent, des_v, dyn, n_dyn, stat, n_stat, out, 0);
 }
 
-int navhip_clearpath_light(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
-                           const float *dyn, const int32_t *n_dyn, const float *stat,
-                           const int32_t *n_stat, float *out, int32_t *found)
+int navhip_clearpath_rows(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                          const float *dyn, const int32_t *n_dyn, const float *stat,
+                          const int32_t *n_stat, float *out)
 {
-    if(!found) return NAVHIP_ERR_INVALID;
-    return clearpath_batch(ctx, nq, ent, des_v, dyn, n_dyn, stat, n_stat, out, found);
+    return clearpath_batch(ctx, nq, ent, des_v, dyn, n_dyn, stat, n_stat, out, 1);
 }
 
 uint64_t navhip_flow_field_id(const navhip_field_req *r)

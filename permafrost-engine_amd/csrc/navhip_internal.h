@@ -69,13 +69,27 @@ struct navhip_ctx {
     hipEvent_t   ev[6];        // start | hash built | neighbour walk | cohesion | regroup | finish
     bool         ev_valid;
     std::string  last_error;
+    struct nh_pool  *pool;     // resident flow-field pool (navhip_pool_*, pool_api.hip) or NULL
+    struct nh_async *async;    // state of navhip_agent_step_submit / _poll
 };
+
+// pool_api.hip <-> navhip_api.hip
+extern "C" int navhip_validate_field_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n);   /* (not in navhip.h) */
+int  navhip_build_fields_slots_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, int n, uint8_t *dev_fields,
+                                   const int32_t *dev_slots, hipStream_t s);
+int  navhip_stage_reserve(navhip_ctx *ctx, int slot, size_t bytes, void **dev);
+void nh_async_destroy(navhip_ctx *ctx);
+const uint8_t *nh_pool_fields(const navhip_ctx *ctx);
+const int32_t *nh_pool_map(const navhip_ctx *ctx);
+int nh_pool_dests(const navhip_ctx *ctx);
+int nh_pool_slots(const navhip_ctx *ctx);
 
 // launched by navhip_api.hip
 void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, int n,
                       hipStream_t s);
 void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, uint8_t *d_dirs,
-                      float *d_integ, int32_t *d_gen_list, hipStream_t s);
+                      float *d_integ, int32_t *d_gen_list, hipStream_t s,
+                      const int32_t *d_out_slot = nullptr);
 
 void nh_launch_blockers_circles(navhip_ctx *ctx, const navhip_circle *d_circles, int n, float map_x,
                                 float map_z, hipStream_t s);

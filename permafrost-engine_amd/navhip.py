@@ -330,11 +330,28 @@ _SIGS.update({
     "navhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 5)]),
     "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
-    "navhip_clearpath_light": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "navhip_clearpath_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "navhip_clearpath": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 })
+
+_SIGS.update({
+    "navhip_pool_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "navhip_pool_destroy": (None, [C.c_void_p]),
+    "navhip_pool_clear": (C.c_int, [C.c_void_p]),
+    "navhip_pool_contains": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "navhip_pool_put": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "navhip_pool_get": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "navhip_pool_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "navhip_pool_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "navhip_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "navhip_host_free": (None, [C.c_void_p]),
+    "navhip_agent_step_submit": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut)]),
+    "navhip_agent_step_poll": (C.c_int, [C.c_void_p]),
+    "navhip_agent_step_wait": (C.c_int, [C.c_void_p]),
+})
+POOL_RESIDENT = -1
 
 _WORLD_ARRAYS = (
     ("pos_xz", np.float32), ("vel_xz", np.float32), ("radius", np.float32),
@@ -396,6 +413,8 @@ def _ctx_agent_step(self, arrays, hz=20, want=("vel_xz", "new_pos_xz", "vdes_xz"
     """Host-buffer velocity step: move_velocity_work (movement.c:3395) for every non-still entity.
     arrays: dict of numpy arrays named after navhip_world members.  Returns dict of outputs."""
     w, keep = make_world(self.w, self.h, arrays, hz)
+    if arrays.get("field_pool") is None and arrays.get("use_resident_pool"):
+        w.n_field_slots = POOL_RESIDENT
     n = w.n_ents
     out = {}
     so = StepOut()
@@ -433,9 +452,9 @@ def _ctx_spatial_query(self, pos_xz, query_xz, rng, maxout):
     return counts, ids
 
 
-def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, light=False):
-    """G_ClearPath_NewVelocity (clearpath.c:694) for a batch of independent problems.  light=True:
-    the thread-per-agent search (<= 4 neighbours); returns (out, found)."""
+def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, rows=False):
+    """G_ClearPath_NewVelocity (clearpath.c:694) for a batch of independent problems, one wave per
+    problem; rows=True: one row of 16 lanes per problem (<= 16 neighbours)."""
     ent = np.ascontiguousarray(ent, np.float32).reshape(-1, 5)
     nq = len(ent)
     des_v = np.ascontiguousarray(des_v, np.float32).reshape(nq, 2)
@@ -444,12 +463,10 @@ def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, light=False):
     n_dyn = np.ascontiguousarray(n_dyn, np.int32)
     n_stat = np.ascontiguousarray(n_stat, np.int32)
     out = np.zeros((nq, 2), np.float32)
-    if light:
-        found = np.zeros(nq, np.int32)
-        self._chk(lib().navhip_clearpath_light(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
-                                               _hp(stat), _hp(n_stat), _hp(out), _hp(found)),
-                  "navhip_clearpath_light")
-        return out, found
+    if rows:
+        self._chk(lib().navhip_clearpath_rows(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
+                                              _hp(stat), _hp(n_stat), _hp(out)), "navhip_clearpath_rows")
+        return out
     self._chk(lib().navhip_clearpath(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
                                      _hp(stat), _hp(n_stat), _hp(out)), "navhip_clearpath")
     return out
@@ -476,6 +493,91 @@ def _ctx_last_step_lists(self):
     return tuple(int(x) for x in out)
 
 
+def _ids_of(reqs):
+    reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)
+    return np.array([lib().navhip_flow_field_id(_hp(reqs[i:i + 1])) for i in range(len(reqs))], np.uint64)
+
+
+def _ctx_pool_create(self, n_slots, n_dests):
+    self._chk(lib().navhip_pool_create(self._h, n_slots, n_dests), "navhip_pool_create")
+
+
+def _ctx_pool_build(self, reqs, ff_ids=None, base_ids=None, readback=True):
+    """Batched N_FlowFieldInit + N_FlowFieldUpdate + N_FC_PutFlowField into the resident pool; ids
+    default to N_FlowFieldID of every request.  Returns (ids, dirs [n,64,64] | None)."""
+    reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)
+    n = len(reqs)
+    ids = _ids_of(reqs) if ff_ids is None else np.ascontiguousarray(ff_ids, np.uint64)
+    base = None if base_ids is None else np.ascontiguousarray(base_ids, np.uint64)
+    out = np.zeros((n, 64, 64), np.uint8) if readback else None
+    self._chk(lib().navhip_pool_build(self._h, _hp(reqs), _hp(ids), _hp(base) if base is not None else None, n,
+                                      _hp(out) if readback else None), "navhip_pool_build")
+    return ids, out
+
+
+def _ctx_pool_put(self, ff_id, dirs):
+    d = np.ascontiguousarray(dirs, np.uint8).reshape(4096)
+    self._chk(lib().navhip_pool_put(self._h, int(ff_id), _hp(d)), "navhip_pool_put")
+
+
+def _ctx_pool_get(self, ff_id):
+    d = np.zeros((64, 64), np.uint8)
+    rc = lib().navhip_pool_get(self._h, int(ff_id), _hp(d))
+    return None if rc != OK else d
+
+
+def _ctx_pool_contains(self, ff_id):
+    return bool(lib().navhip_pool_contains(self._h, int(ff_id)))
+
+
+def _ctx_pool_map(self, dest, chunk_r, chunk_c, ff_ids):
+    d = np.ascontiguousarray(dest, np.int32)
+    r = np.ascontiguousarray(chunk_r, np.uint16)
+    c = np.ascontiguousarray(chunk_c, np.uint16)
+    i = np.ascontiguousarray(ff_ids, np.uint64)
+    self._chk(lib().navhip_pool_map(self._h, len(d), _hp(d), _hp(r), _hp(c), _hp(i)), "navhip_pool_map")
+
+
+def _ctx_agent_step_async(self, arrays, hz=20, work=None, want=("vel_xz", "new_pos_xz", "status"), spin=None):
+    """navhip_agent_step_submit + _poll: returns the outputs once the step has completed; `spin`
+    is called while it is still running (what the nav task does between submit and join)."""
+    w, keep = make_world(self.w, self.h, arrays, hz)
+    if arrays.get("field_pool") is None and arrays.get("use_resident_pool"):
+        w.n_field_slots = POOL_RESIDENT
+    if work is not None:
+        w.work_begin, w.work_end = work
+    n = w.n_ents
+    out = {}
+    so = StepOut()
+    for name in ("vel_xz", "new_pos_xz", "vdes_xz", "vpref_xz"):
+        if name in want or name == "vel_xz":
+            out[name] = np.zeros((n, 2), np.float32)
+            setattr(so, name, out[name].ctypes.data)
+    if "status" in want:
+        out["status"] = np.zeros(n, np.uint8)
+        so.status = out["status"].ctypes.data
+    self._chk(lib().navhip_agent_step_submit(self._h, C.byref(w), C.byref(so)), "navhip_agent_step_submit")
+    polls = 0
+    while True:
+        rc = lib().navhip_agent_step_poll(self._h)
+        if rc == 0:
+            break
+        if rc < 0:
+            self._chk(rc, "navhip_agent_step_poll")
+        polls += 1
+        if spin:
+            spin()
+    out["polls"] = polls
+    return out
+
+
+NavContext.pool_create = _ctx_pool_create
+NavContext.pool_build = _ctx_pool_build
+NavContext.pool_put = _ctx_pool_put
+NavContext.pool_get = _ctx_pool_get
+NavContext.pool_contains = _ctx_pool_contains
+NavContext.pool_map = _ctx_pool_map
+NavContext.agent_step_async = _ctx_agent_step_async
 NavContext.set_profiling = _ctx_set_profiling
 NavContext.last_step_ms = _ctx_last_step_ms
 NavContext.last_step_lists = _ctx_last_step_lists

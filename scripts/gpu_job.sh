@@ -1,0 +1,31 @@
+#!/bin/bash
+# One GPU session: `bash scripts/gpu_job.sh <tag> [steps...]` on the GPU box (gpurun).  Steps:
+#   tests   python -m pytest tests -m gpu            -> gpurun_out/<tag>/pytest_gpu.log
+#   bench   python bench.py                          -> gpurun_out/<tag>/bench.json
+#   calib   scripts/valu_calib.bin                   -> gpurun_out/<tag>/valu_calib.json
+#   stats   rocprofv3 --kernel-trace --stats of a short bench run
+#   pmc     three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters), --kernel-trace only
+#   fuzz    tests/tools/fuzz_gpu.py
+TAG=$1; shift
+STEPS=${@:-tests bench calib stats}
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+for s in $STEPS; do
+case $s in
+tests) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -15 $OUT/pytest_gpu.log ;;
+testsall) timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -25 $OUT/pytest_gpu.log ;;
+bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+benchq) timeout 600 python bench.py --no-cpu-baseline --no-crowded > $OUT/bench_quick.json 2> $OUT/bench_quick.err; tail -c 2500 $OUT/bench_quick.json; tail -3 $OUT/bench_quick.err ;;
+calib) timeout 300 scripts/valu_calib.bin > $OUT/valu_calib.json 2>&1; cat $OUT/valu_calib.json ;;
+stats) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py --steps 40 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof.json 2> $OUT/prof.err
+       f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 $f ;;
+pmc) for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES"; do
+       n=$(echo $c | cut -d' ' -f1)
+       timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o p --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-crowded > /dev/null 2> $OUT/pmc_$n.err
+     done
+     python scripts/collect_traffic.py $OUT > $OUT/traffic_summary.txt 2>&1; tail -20 $OUT/traffic_summary.txt ;;
+fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log ;;
+esac
+done

@@ -39,12 +39,12 @@ def lib():
     return _lib
 
 
-DISP_NAMES = {0: "done", 1: "light1", 2: "light2", 3: "light3", 4: "light4", 5: "wave", 6: "full"}
+DISP_NAMES = {0: "done", 1: "row 1-2", 2: "row 3-4", 3: "row 5-8", 4: "row 9-16", 5: "wave", 6: "full"}
 
 
 def agent_step(navhip, w, h, cost, blockers, arrays, coh_xz, hz=20, layer=0):
     """arrays: navhip_world member arrays (numpy).  Returns dict of outputs + 'disp' (per entity:
-    DISP_* of agent_thread.h, +16 = the light search punted to the wave path)."""
+    DISP_* of agent_thread.h, +16 = the serial search found no admissible point: not computed here)."""
     world, keep = navhip.make_world(w, h, arrays, hz)
     n = world.n_ents
     m = Map()

@@ -91,7 +91,7 @@ int hostsim_agent_step(const hostsim_map *map, const navhip_world *w, const floa
 
     // ---- middle pass + light search, uid order
     nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
-    float4 cones[2 * NH_LIGHT_MAX];
+    float4 cones[2 * 64];
     for(int uid = P.work_begin; uid < P.work_end; uid++) {
         nh_mid_rec R;
         v2 out_vel;
@@ -102,7 +102,8 @@ int hostsim_agent_step(const hostsim_map *map, const navhip_world *w, const floa
         if(out_counts) { out_counts[2 * uid] = (int32_t)(cnt[uid] & 0xff); out_counts[2 * uid + 1] = (int32_t)((cnt[uid] >> 8) & 0xff); }
         if(disp == DISP_DONE) {
             post_thread(P, uid, me, P.state[uid], P.flags[uid], P.radius[uid], out_vel, R.vel_cap, R.status, O);
-        }else if(disp >= DISP_LIGHT1 && disp <= DISP_LIGHT4) {
+        }else if(disp >= DISP_ROW0 && disp <= DISP_WAVE) {
+            // one ClearPath attempt, serially (no remove_furthest: disp + 16 = not computed here)
             cpent ent; ent.pos = me; ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]); ent.radius = P.radius[uid];
             v2 res;
             const uint32_t c = cnt[uid];
@@ -117,17 +118,18 @@ int hostsim_agent_step(const hostsim_map *map, const navhip_world *w, const floa
     return 0;
 }
 
-// G_ClearPath_NewVelocity problems through mid_thread's admissibility test + cp_light_thread
+// G_ClearPath_NewVelocity problems through the serial search (one attempt; found = 0: the device
+// would run remove_furthest and retry)
 int hostsim_clearpath_light(int nq, const float *ent, const float *des_v, const float *dyn,
                             const int32_t *n_dyn, const float *stat, const int32_t *n_stat,
                             float *out, int32_t *found)
 {
     for(int q = 0; q < nq; q++) {
-        float4 recA[8]; float2 recV[8]; int32_t list[64]; float4 cones[2 * NH_LIGHT_MAX];
+        float4 recA[64]; float2 recV[64]; int32_t list[64]; float4 cones[2 * 64];
         nh_grid G; memset(&G, 0, sizeof(G));
         G.recA = recA; G.recV = recV;
         const int nd = n_dyn[q], ns = n_stat[q];
-        if(nd + ns > NH_LIGHT_MAX) return -1;
+        if(nd > 32 || ns > 32) return -1;
         for(int j = 0; j < nd + ns; j++) {
             const bool st = j >= nd;
             const float *s = (st ? stat : dyn) + (size_t)q * 160 + 5 * (st ? j - nd : j);
@@ -138,19 +140,8 @@ int hostsim_clearpath_light(int nq, const float *ent, const float *des_v, const 
         cpent e; e.pos = mkv(ent[5 * q], ent[5 * q + 1]); e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]);
         e.radius = ent[5 * q + 4];
         const v2 dv = mkv(des_v[2 * q], des_v[2 * q + 1]);
-        bool in = false;
-        for(int j = 0; j < nd + ns; j++) {
-            const bool st = j >= nd;
-            const cpent nb = nbr_cpent(G, j, st);
-            if(vlen(vsub(nb.pos, e.pos)) < CP_EPS) continue;
-            v2 apex, left, right; float sl, sr;
-            make_cone(e, nb, !st, apex, left, right, sl, sr);
-            in = in || cone_contains(make_float4(apex.x, apex.z, sl, sr),
-                                     make_float4(left.x, left.z, right.x, right.z), vadd(e.pos, dv));
-        }
         v2 r = dv;
-        bool ok = true;
-        if(in) ok = cp_light_thread(G, e, dv, nd, ns, list, 1, cones, 1, r);
+        const bool ok = cp_light_thread(G, e, dv, nd, ns, list, 1, cones, 1, r);
         out[2 * q] = r.x; out[2 * q + 1] = r.z;
         found[q] = ok ? 1 : 0;
     }

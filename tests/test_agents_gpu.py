@@ -64,22 +64,46 @@ def test_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread):
 
 
 @pytest.mark.parametrize("seed,max_dyn,max_stat,spread", [(1, 2, 2, 9.0), (2, 4, 0, 6.0), (3, 0, 4, 5.0),
-                                                         (4, 3, 1, 2.5), (5, 1, 1, 4.0)])
-def test_light_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread):
-    """The thread-per-agent ClearPath search (agents with at most four neighbours) on its own."""
-    nq = 600
+                                                         (4, 3, 1, 2.5), (5, 1, 1, 4.0), (6, 8, 8, 9.0),
+                                                         (7, 16, 0, 7.0), (8, 6, 10, 3.0)])
+def test_row_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread):
+    """ClearPath on a row of 16 lanes per problem (the agent step's path for up to 16 neighbours) and
+    on a wave per problem, both bit-identical to G_ClearPath_NewVelocity."""
+    nq = 500
     ent, des, dyn, nd, stat, ns = cases.cp_problems(seed, nq, max_dyn, max_stat, spread)
     ctx = navlib.NavContext(1, 1)
-    got, found = ctx.G_ClearPath_NewVelocity(ent, des, dyn, nd, stat, ns, light=True)
+    rows = ctx.G_ClearPath_NewVelocity(ent, des, dyn, nd, stat, ns, rows=True)
     wave = ctx.G_ClearPath_NewVelocity(ent, des, dyn, nd, stat, ns)
     ctx.close()
-    assert found.sum() > nq * 0.8
     for i in range(nq):
         exp = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
         nan = np.isnan(exp)
-        assert np.array_equal(np.where(nan, 0, wave[i]).view(np.uint32), np.where(nan, 0, exp).view(np.uint32)), i
-        if found[i]:
-            assert np.array_equal(np.where(nan, 0, got[i]).view(np.uint32), np.where(nan, 0, exp).view(np.uint32)), i
+        assert np.array_equal(np.where(nan, 0, wave[i]).view(np.uint32), np.where(nan, 0, exp).view(np.uint32)), ("wave", i)
+        assert np.array_equal(np.where(nan, 0, rows[i]).view(np.uint32), np.where(nan, 0, exp).view(np.uint32)), ("rows", i)
+
+
+@pytest.mark.parametrize("seed,max_dyn,max_stat,spread,rows", [(11, 24, 24, 3.0, False), (12, 32, 32, 4.5, False),
+                                                              (13, 8, 8, 2.2, True), (14, 3, 12, 2.0, True)])
+def test_clearpath_retry_shortcut_matches_reference(navlib, seed, max_dyn, max_stat, spread, rows):
+    """Enclosed agents: G_ClearPath_NewVelocity fails, removes the furthest neighbour and retries
+    (clearpath.c:704-713), dozens of times in a jam.  The device finds the attempt that will succeed from
+    the removal schedule and runs that one attempt: same velocities, bit for bit."""
+    import ctypes as C
+    nq = 250
+    ent, des, dyn, nd, stat, ns = cases.cp_problems(seed, nq, max_dyn, max_stat, spread)
+    att = (C.c_ulonglong * 9)()
+    navlib.lib().navhip_debug_cp_attempts(att, 1)
+    ctx = navlib.NavContext(1, 1)
+    got = ctx.G_ClearPath_NewVelocity(ent, des, dyn, nd, stat, ns, rows=rows)
+    ctx.close()
+    navlib.lib().navhip_debug_cp_attempts(att, 1)
+    retried = sum(att[i] for i in range(0, 8))
+    assert retried > 10, list(att)                    # the shortcut was exercised
+    for i in range(nq):
+        exp = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
+        nan = np.isnan(exp)
+        assert np.array_equal(np.where(nan, 0, got[i]).view(np.uint32), np.where(nan, 0, exp).view(np.uint32)), \
+            (i, nd[i], ns[i], got[i], exp)
 
 
 def _upload(navlib, nav):

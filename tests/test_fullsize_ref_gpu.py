@@ -41,13 +41,20 @@ def _check_agents(navlib, T, nav, onav, pos, vel, out_vel, out_pos, status, vdes
     mv = pfref.RefMove(nav, pos, vel, H["radius"], H["max_speed"], H["speed"], arrays["flags"],
                        np.zeros(n, np.int32), H["flock"], arrays["has_dest_los"], H["targets"],
                        np.zeros(k, np.uint32), hz=20)
-    # (flock member order: ascending uid here and in the reference's khash for dense small keys --
-    # checked, because the cohesion sum depends on it)
+    # (the cohesion sum depends on the flock member order: the job was given the reference's own)
     for f in (0, k - 1):
         assert np.array_equal(mv.flock_order(f), H["flock_members"][H["flock_offsets"][f]:H["flock_offsets"][f + 1]])
     _, ref_vel = mv.bench(vdes, reps=1, nthreads=CORES)
     pfref.RefMove.unload()
-    bad = np.flatnonzero((out_vel.view(np.uint32) != ref_vel.view(np.uint32)).any(1))
+    # Agents within 4 wu of the map edge are left out of THIS comparison (they are in the one above):
+    # nullify_impass_components probes pos +- 4 wu (movement.c:1839-1842), and for an off-map probe the
+    # reference reads an uninitialised tile_desc (the assert at nav.c:4062 is compiled out of a release
+    # build) -- undefined behaviour; it even crashes when called directly.  The device (and the
+    # restatement) treat an off-map probe as not pathable.
+    half = T.Wt * 128.0
+    edge = (np.abs(pos[:, 0]) > half - 4.0) | (np.abs(pos[:, 1]) > T.H * 128.0 - 4.0)
+    assert edge.sum() < 0.01 * n + 20, edge.sum()
+    bad = np.flatnonzero((out_vel.view(np.uint32) != ref_vel.view(np.uint32)).any(1) & ~edge)
     assert len(bad) == 0, (label, len(bad), bad[:5], out_vel[bad[:3]], ref_vel[bad[:3]])
     return exp
 
@@ -62,10 +69,26 @@ def _job(navlib, W, K, N, crowd=0):
     assert np.array_equal(cases.synth.to_chunks(T.host["liid"]), nav.plane(pfref.PLANE_LOCAL_ISLANDS))
     onav = navoracle.OracleNav(cases.synth.to_chunks(grid), np.zeros((W, W, 64, 64), np.uint16),
                                cases.synth.to_chunks(T.host["liid"]))
+    # flock member order = the reference's kh_foreach order of flock.ents (movement.c:1660): a property
+    # of the uid set, not of the positions, so one load of the reference's flock tables gives it
+    import torch
+    H = T.host
+    n, k = len(H["flock"]), len(H["targets"])
+    pos0 = T.t["pos_xz"].cpu().numpy()
+    mv = pfref.RefMove(nav, pos0, np.zeros((n, 2), np.float32), H["radius"], H["max_speed"], H["speed"],
+                       np.full(n, navlib.ENTITY_FLAG_MOVABLE, np.uint32), np.zeros(n, np.int32), H["flock"],
+                       np.zeros(n, np.uint8), H["targets"], np.zeros(k, np.uint32), hz=20)
+    members = np.concatenate([mv.flock_order(f) for f in range(k)]).astype(np.int32)
+    pfref.RefMove.unload()
+    assert len(members) == len(H["flock_members"])
+    H["flock_members"] = members
+    T.t["flock_members"] = torch.from_numpy(members).to(T.dev)
+    T._make_structs()
     return T, nav, onav
 
 
 def _snapshot(T):
+    T.sync()                 # (the ticks run on T.stream; .cpu() only orders behind torch's current stream)
     return T.t["pos_xz"].cpu().numpy().copy(), T.t["vel_xz"].cpu().numpy().copy()
 
 

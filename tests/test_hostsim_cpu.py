@@ -19,9 +19,10 @@ def navlib():
 
 
 @pytest.mark.parametrize("seed,max_dyn,max_stat,spread", [(1, 2, 2, 9.0), (2, 4, 0, 6.0), (3, 0, 4, 5.0),
-                                                         (4, 3, 1, 2.5), (5, 1, 1, 4.0)])
-def test_light_clearpath_matches_reference(seed, max_dyn, max_stat, spread):
-    nq = 600
+                                                         (4, 3, 1, 2.5), (5, 1, 1, 4.0), (6, 8, 8, 9.0),
+                                                         (7, 32, 32, 9.5)])
+def test_serial_clearpath_search_matches_reference(seed, max_dyn, max_stat, spread):
+    nq = 600 if max_dyn < 32 else 80
     ent, des, dyn, nd, stat, ns = cases.cp_problems(seed, nq, max_dyn, max_stat, spread)
     got, found = hostsim.clearpath_light(ent, des, dyn, nd, stat, ns)
     n_checked = 0
@@ -33,7 +34,7 @@ def test_light_clearpath_matches_reference(seed, max_dyn, max_stat, spread):
         assert np.array_equal(np.where(both_nan, 0, got[i]).view(np.uint32),
                               np.where(both_nan, 0, exp).view(np.uint32)), (i, nd[i], ns[i], got[i], exp)
         n_checked += 1
-    assert n_checked > nq * 0.8
+    assert n_checked > nq * (0.8 if max_dyn < 32 else 0.3)
 
 
 def _world(navlib, clustered, n, k, blk, seed=21, garrison=False, arrival=False):
@@ -62,9 +63,8 @@ def test_thread_step_matches_reference(navlib, clustered, n, k, blk, garrison):
         coh[uid] = mv.forces(int(uid), vdes[uid])[1]
     out = hostsim.agent_step(navlib, 4, 4, nav.plane(0), nav.plane(1), a, coh)
     disp = out["disp"]
-    computed = moving & (disp < 5)
-    # (clustered worlds: most agents have more than four ClearPath neighbours and go to the wave list)
-    assert computed.sum() > (0.15 if clustered else 0.6) * moving.sum(), np.bincount(disp[moving])
+    computed = moving & (disp < 6)
+    assert computed.sum() > 0.6 * moving.sum(), np.bincount(disp[moving])
     # ClearPath neighbour lists (counts) against find_neighbours
     for uid in np.flatnonzero(moving & (disp != 6))[:300]:
         dyn, stat = mv.neighbours(int(uid))
@@ -110,7 +110,7 @@ def test_thread_step_with_arrival_state_matches_reference(navlib):
     for uid in np.flatnonzero(np.isin(world["state"], (0, 5, 6))):
         coh[uid] = mv.forces(int(uid), vdes[uid])[1]
     out = hostsim.agent_step(navlib, 4, 4, nav.plane(0), nav.plane(1), a, coh)
-    computed = moving & (out["disp"] < 5)
+    computed = moving & (out["disp"] < 6)
     assert computed.sum() > 0.6 * moving.sum()
     for uid in np.flatnonzero(moving)[:300]:
         dyn, stat = mv.neighbours(int(uid))
