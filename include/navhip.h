@@ -310,6 +310,7 @@ enum { NAVHIP_STATE_MOVING = 0, NAVHIP_STATE_MOVING_IN_FORMATION, NAVHIP_STATE_A
 #define NAVHIP_ST_FIELD_MISS   0x02  /* no flow field cached for the agent's chunk: the host must run
                                         the planner (n_request_path, nav.c:3483-3492) and re-step    */
 #define NAVHIP_ST_FIELD_NONE   0x04  /* the field has FD_NONE under the agent (nav.c:3495-3554 path)  */
+#define NAVHIP_ST_LOS_MISS     0x08  /* NAVHIP_LOS_LOOKUP, but no LOS field is mapped for the agent's chunk   */
 #define NAVHIP_ST_UNSUPPORTED  0x80  /* formation state without formation inputs: velocity = 0        */
 
 /* The snapshot the movement tick works on: `struct move_gamestate` + `struct move_work_in` +
@@ -367,7 +368,19 @@ typedef struct navhip_world {
                                                 arrival.c:90) and sink_valid; bit 1: the flock's
                                                 arrival_state for the unit's nav layer exists and is in
                                                 ARRIVAL_PHASE_FILLING                                  */
+    /* Per-agent line of sight on the device (compute_los_state movement.c:4129 -> N_HasDestLOS
+     * nav.c:4026): an entry of has_dest_los equal to NAVHIP_LOS_LOOKUP is answered from the LOS fields
+     * of navhip_build_los -- `visible` of the agent's tile in the (destination, chunk) field.  No field
+     * mapped for the chunk: false, and NAVHIP_ST_LOS_MISS is reported so that the host can request the
+     * path (nav.c:4041-4047).  All three NULL / 0: every entry of has_dest_los is taken as given. */
+    const uint8_t  *los_pool;        /* [slots][4096] LOS fields (bit 0 visible, bit 1 wavefront_blocked) */
+    const int32_t  *flock_los_slot;  /* [F][chunks] slot of the (dest, chunk) LOS field, -1 = none       */
+    const float    *los_pos_xz;      /* [n][2]  the position the lookup uses: movestate.prev_pos
+                                                (movement.c:4137), or NULL = pos_xz                    */
+    int32_t  n_los_slots;
+    int32_t  _reserved;
 } navhip_world;
+#define NAVHIP_LOS_LOOKUP 0xff
 
 typedef struct navhip_step_out {
     float   *vel_xz;        /* [n][2]  move_work_out.ent_vel (movement.c:3462-3464); 0 for still ents */

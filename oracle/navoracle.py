@@ -66,7 +66,9 @@ class World(C.Structure):
         ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p),
         # fine-arrival inputs: the restatement does not model them (always NULL here; the arrival
         # paths are checked against the reference build itself)
-        ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p)]
+        ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p),
+        ("los_pool", C.c_void_p), ("flock_los_slot", C.c_void_p), ("los_pos_xz", C.c_void_p),
+        ("n_los_slots", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class StepOut(C.Structure):

@@ -81,6 +81,17 @@ def lib():
         L.pfref_zone_field.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int,
                                                                       C.c_void_p]
         L.pfref_los_field.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p]
+        L.pfref_hip_init.argtypes = [C.c_void_p]
+        L.pfref_hip_mode.argtypes = [C.c_int, C.c_int]
+        L.pfref_hip_sync_layer.argtypes = [C.c_void_p, C.c_int]
+        L.pfref_hip_stats.argtypes = [C.c_void_p]
+        L.pfref_desired_velocities.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_void_p]
+        L.pfref_dest_id.restype = C.c_uint32
+        L.pfref_dest_id.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.pfref_cache_clear.argtypes = [C.c_void_p]
+        L.pfref_move_velocity_hip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.pfref_move_velocity_hip.restype = C.c_int
         L.pfref_field_update_many.restype = C.c_double
         L.pfref_field_update_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.pfref_field_bench.restype = C.c_double
@@ -264,6 +275,54 @@ class RefNav:
         assert t >= 0
         return out
 
+    # -- the reference-side binding of libnavhip.so (oracle/ref/nav_hip.c) -------------------
+    def hip_init(self):
+        return bool(lib().pfref_hip_init(self._h))
+
+    @staticmethod
+    def hip_shutdown():
+        lib().pfref_hip_shutdown()
+
+    @staticmethod
+    def hip_mode(use_binding, backend=1):
+        lib().pfref_hip_mode(int(use_binding), int(backend))
+
+    def hip_sync_layer(self, layer=0):
+        return bool(lib().pfref_hip_sync_layer(self._h, layer))
+
+    @staticmethod
+    def hip_stats():
+        out = (C.c_long * 3)()
+        lib().pfref_hip_stats(out)
+        return {"device_builds": out[0], "batches": out[1], "requests": out[2]}
+
+    def dest_id(self, dst, layer=0, faction_id=FACTION_ID_NONE):
+        return int(lib().pfref_dest_id(self._h, layer, faction_id, float(dst[0]), float(dst[1])))
+
+    def cache_clear(self):
+        lib().pfref_cache_clear(self._h)
+
+    def desired_velocities(self, dest_ids, pos, dst, batched=False):
+        """N_DesiredPointSeekVelocity for every agent: serial calls in order, or the binding's
+        miss-collecting batched form."""
+        ids = np.ascontiguousarray(dest_ids, np.uint32)
+        p = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
+        d = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
+        out = np.zeros_like(p)
+        lib().pfref_desired_velocities(self._h, len(ids), _p(ids), _p(p), _p(d), int(batched), _p(out))
+        return out
+
+    def cache_dump(self, dest_ids):
+        """{(dest_id, chunk_r, chunk_c): dirs} of every field the cache maps for these destinations."""
+        out = {}
+        for did in sorted(set(int(x) for x in dest_ids)):
+            for cr in range(self.h):
+                for cc in range(self.w):
+                    ff = self.cached_field(did, cr, cc)
+                    if ff is not None:
+                        out[(did, cr, cc)] = ff.copy()
+        return out
+
     # -- planner ----------------------------------------------------------
     def request_path(self, src, dst, layer=0, faction_id=FACTION_ID_NONE, clear_cache=False):
         did = C.c_uint32(0)
@@ -395,6 +454,14 @@ class RefMove:
             k[name] = np.ascontiguousarray(a, np.float32).reshape(self.n, 2)
         lib().pfref_move_set_formation(_p(k["f_ready"]), _p(k["f_cell"]), _p(k["f_coh"]),
                                        _p(k["f_align"]), _p(k["f_drag"]))
+
+    def velocity_hip(self, vdes=None, begin=0, end=None):
+        """move_velocity_work through the WORK_TYPE_HIP arm of the binding (oracle/ref/move_hip.c)."""
+        end = self.n if end is None else end
+        out = np.zeros((self.n, 2), np.float32)
+        v = None if vdes is None else np.ascontiguousarray(vdes, np.float32)
+        ok = lib().pfref_move_velocity_hip(_p(v) if v is not None else None, begin, end, _p(out))
+        return out if ok else None
 
     def set_arrival(self, sink_xz, flags):
         """Fine-arrival inputs: per-unit slot + flags (bit 0 committed to a valid slot, bit 1 the

@@ -1,0 +1,170 @@
+/* oracle/ref/move_hip.c -- the WORK_TYPE_HIP arm of fork_join_velocity_computations, made real.
+ *
+ * What INTEGRATION.md tells a maintainer to add to src/game/movement.c next to the WORK_TYPE_CPU /
+ * WORK_TYPE_GPU arms (movement.c:315-318,3737,4182-4194): fill a navhip_world from the tick's
+ * snapshot tables (struct move_gamestate, :296) and work items (struct move_work_in, :264), run
+ * navhip_agent_step, copy the velocities into s_move_work.out[] like copy_gpu_results does
+ * (:4248-4261).  It lives in movement.c's translation unit because those tables are static; the
+ * test harness #includes it right after movement.c (oracle/ref/ref_move.c) -- TEST INFRASTRUCTURE.
+ */
+#include <navhip.h>
+
+navhip_ctx *N_HIP_Ctx(void);          /* nav_hip.c */
+
+static int cmp_u32(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return (x > y) - (x < y);
+}
+
+/* move_velocity_work(begin_idx, end_idx) for the work items [begin_idx, end_idx] on the device.
+ * Returns false when the library is not available (the caller runs the CPU arm). */
+static bool move_hip_velocity_work(int begin_idx, int end_idx)
+{
+    navhip_ctx *ctx = N_HIP_Ctx();
+    if(!ctx || end_idx < begin_idx)
+        return false;
+    const struct move_gamestate *gs = &s_move_work.gamestate;
+
+    /* dense entity order: every entity of the position snapshot, ascending uid (the GL path densifies
+     * uids the same way, ent_gpu_id_map :302) */
+    const int n = (int)kh_size(gs->positions);
+    uint32_t *uids = malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
+    {
+        int k = 0;
+        uint32_t key;
+        kh_foreach_key(gs->positions, key, { uids[k++] = key; });
+        qsort(uids, n, sizeof(uint32_t), cmp_u32);
+    }
+    khash_t(id) *dense = kh_init(id);
+    for(int i = 0; i < n; i++) {
+        int ret;
+        khiter_t k = kh_put(id, dense, uids[i], &ret);
+        kh_value(dense, k) = i;
+    }
+#define DENSE(uid) kh_value(dense, kh_get(id, dense, (uid)))
+
+    float *pos = calloc(2 * n, sizeof(float)), *vel = calloc(2 * n, sizeof(float));
+    float *radius = calloc(n, sizeof(float)), *max_speed = calloc(n, sizeof(float)), *speed = calloc(n, sizeof(float));
+    uint32_t *flags = calloc(n, sizeof(uint32_t));
+    uint8_t *state = calloc(n, 1), *los = calloc(n, 1), *form_ready = calloc(n, 1), *arr_flags = calloc(n, 1);
+    int32_t *flock = malloc(sizeof(int32_t) * n);
+    float *vdes = malloc(sizeof(float) * 2 * n), *cell_pos = calloc(2 * n, sizeof(float));
+    float *f_coh = calloc(2 * n, sizeof(float)), *f_align = calloc(2 * n, sizeof(float)), *f_drag = calloc(2 * n, sizeof(float));
+    float *sink = calloc(2 * n, sizeof(float));
+    bool any_arrival = false;
+
+    const size_t nflocks = vec_size(&s_flocks);
+    float *flock_target = calloc(2 * (nflocks ? nflocks : 1), sizeof(float));
+    int32_t *flock_offsets = calloc(nflocks + 1, sizeof(int32_t));
+    int32_t *flock_members = malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+
+    for(int i = 0; i < n; i++) {
+        const uint32_t uid = uids[i];
+        vec2_t p = G_Pos_GetXZFrom(gs->positions, uid);
+        pos[2 * i] = p.x; pos[2 * i + 1] = p.z;
+        flags[i] = G_FlagsGetFrom(gs->flags, uid);
+        radius[i] = G_GetSelectionRadiusFrom(gs->sel_radiuses, uid);
+        flock[i] = -1;
+        vdes[2 * i] = vdes[2 * i + 1] = 0.0f;
+        state[i] = STATE_ARRIVED;                  /* no movestate: a still obstacle */
+        khiter_t k = kh_get(state, s_entity_state_table, uid);
+        if(k == kh_end(s_entity_state_table))
+            continue;
+        const struct movestate *ms = &kh_value(s_entity_state_table, k);
+        state[i] = (uint8_t)ms->state;
+        vel[2 * i] = ms->velocity.x; vel[2 * i + 1] = ms->velocity.z;
+        max_speed[i] = ms->max_speed;
+        /* struct arrival_unit_state: committed to a valid slot (unit_committed, arrival.c:90) */
+        if((ms->arrival.substate == ARRIVAL_SUBSTATE_SEEK || ms->arrival.substate == ARRIVAL_SUBSTATE_SEEK_ARMED)
+        && ms->arrival.sink_valid) {
+            arr_flags[i] |= 1;
+            any_arrival = true;
+        }
+        sink[2 * i] = ms->arrival.sink.x; sink[2 * i + 1] = ms->arrival.sink.z;
+    }
+    /* flocks: members in kh_foreach order of flock->ents (the order cohesion_force sums in, :1660) */
+    {
+        int at = 0;
+        for(size_t f = 0; f < nflocks; f++) {
+            const struct flock *fl = &vec_AT(&s_flocks, f);
+            flock_target[2 * f] = fl->target_xz.x; flock_target[2 * f + 1] = fl->target_xz.z;
+            flock_offsets[f] = at;
+            uint32_t curr;
+            kh_foreach_key(fl->ents, curr, {
+                const int i = DENSE(curr);
+                flock_members[at++] = i;
+                flock[i] = (int32_t)f;
+                const struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,
+                    Entity_NavLayerWithRadius(flags[i], radius[i]));
+                if(as && as->phase == ARRIVAL_PHASE_FILLING) { arr_flags[i] |= 2; any_arrival = true; }
+            });
+        }
+        flock_offsets[nflocks] = at;
+    }
+    /* work items */
+    int lo = n, hi = -1;
+    bool any_form = false;
+    for(int w = begin_idx; w <= end_idx; w++) {
+        const struct move_work_in *in = &s_move_work.in[w];
+        const int i = DENSE(in->ent_uid);
+        vdes[2 * i] = in->ent_des_v.x; vdes[2 * i + 1] = in->ent_des_v.z;
+        speed[i] = in->speed;
+        los[i] = in->has_dest_los;
+        form_ready[i] = in->fstate.assignment_ready;
+        cell_pos[2 * i] = in->cell_pos.x; cell_pos[2 * i + 1] = in->cell_pos.z;
+        f_coh[2 * i] = in->fstate.normal_cohesion_force.x; f_coh[2 * i + 1] = in->fstate.normal_cohesion_force.z;
+        f_align[2 * i] = in->fstate.normal_align_force.x; f_align[2 * i + 1] = in->fstate.normal_align_force.z;
+        f_drag[2 * i] = in->fstate.normal_drag_force.x; f_drag[2 * i + 1] = in->fstate.normal_drag_force.z;
+        any_form = any_form || state[i] == STATE_MOVING_IN_FORMATION || state[i] == STATE_ARRIVING_TO_CELL;
+        if(i < lo) lo = i;
+        if(i > hi) hi = i;
+    }
+    /* the device steps the contiguous uid slab [lo, hi]; entities inside it that carry no work item
+     * (other slabs of a threaded split) are stepped too and their results dropped */
+    const struct nav_private *priv = NULL;
+    (void)priv;
+    navhip_world W;
+    memset(&W, 0, sizeof(W));
+    W.n_ents = n; W.n_flocks = (int32_t)nflocks; W.hz = hz_count(s_move_work.hz);
+    W.pos_xz = pos; W.vel_xz = vel; W.radius = radius; W.max_speed = max_speed; W.speed = speed;
+    W.flags = flags; W.state = state; W.has_dest_los = los; W.flock = flock; W.vdes_xz = vdes;
+    W.flock_target_xz = flock_target; W.flock_offsets = flock_offsets; W.flock_members = flock_members;
+    vec3_t map_pos = ((pfref_nav*)gs->map)->map_pos;           /* M_GetPos(map) */
+    W.map_pos_x = map_pos.x; W.map_pos_z = map_pos.z;
+    {
+        /* bg_ent_init bounds of the position snapshot (position.c:276-283) */
+        const struct nav_private *np = &((pfref_nav*)gs->map)->priv;
+        float half_x = np->width * TILES_PER_CHUNK_WIDTH * X_COORDS_PER_TILE / 2.0f;
+        float half_z = np->height * TILES_PER_CHUNK_HEIGHT * Z_COORDS_PER_TILE / 2.0f;
+        float cx = map_pos.x - half_x, cz = map_pos.z + half_z;
+        W.grid_xmin = cx - half_x; W.grid_xmax = cx + half_x; W.grid_zmin = cz - half_z; W.grid_zmax = cz + half_z;
+    }
+    W.work_begin = lo; W.work_end = hi + 1;
+    if(any_form) {
+        W.form_ready = form_ready; W.cell_pos_xz = cell_pos; W.form_cohesion_xz = f_coh;
+        W.form_align_xz = f_align; W.form_drag_xz = f_drag;
+    }
+    if(any_arrival) { W.arrival_sink_xz = sink; W.arrival_flags = arr_flags; }
+
+    float *out_vel = calloc(2 * n, sizeof(float));
+    uint8_t *status = calloc(n, 1);
+    navhip_step_out O = {out_vel, NULL, NULL, NULL, status};
+    bool ok = hi >= lo && navhip_agent_step_submit(ctx, &W, &O) == NAVHIP_OK;
+    /* (the nav task would Task_AwaitEvent(EVENT_UPDATE_START) here, like the GL path :4212-4233) */
+    if(ok) ok = navhip_agent_step_wait(ctx) == NAVHIP_OK;
+    if(ok) {
+        for(int w = begin_idx; w <= end_idx; w++) {
+            const int i = DENSE(s_move_work.in[w].ent_uid);
+            if(status[i] & NAVHIP_ST_UNSUPPORTED) { ok = false; break; }
+            s_move_work.out[w].ent_vel = (vec2_t){out_vel[2 * i], out_vel[2 * i + 1]};
+        }
+    }
+#undef DENSE
+    kh_destroy(id, dense);
+    free(uids); free(pos); free(vel); free(radius); free(max_speed); free(speed); free(flags); free(state);
+    free(los); free(form_ready); free(arr_flags); free(flock); free(vdes); free(cell_pos); free(f_coh);
+    free(f_align); free(f_drag); free(sink); free(flock_target); free(flock_offsets); free(flock_members);
+    free(out_vel); free(status);
+    return ok;
+}

@@ -1,0 +1,463 @@
+/* oracle/ref/nav_hip.c -- the reference-side binding of libnavhip.so, made real.
+ *
+ * This is the file INTEGRATION.md tells a maintainer of permafrost-engine to add as
+ * src/navigation/nav_hip.c (appended to nav.c's translation unit, because the batched sampler needs
+ * nav.c's static n_request_path and n_interpolated_flow_dir).  Here it is compiled against the
+ * reference's own headers and linked with its own objects inside the test harness
+ * (oracle/ref/ref_nav.c #includes it right after nav.c), so that the reference's planner, field
+ * cache and sampler drive the HIP library through include/navhip.h -- TEST INFRASTRUCTURE, like
+ * everything under oracle/.
+ *
+ * What it binds
+ *   N_HIP_FlowFieldUpdate                    same signature as N_FlowFieldUpdate (field.h:146): one
+ *   N_HIP_FlowFieldUpdateToNearestPathable   chunk field through the device, drop-in for the call
+ *   N_HIP_FlowFieldUpdateIslandToNearest     sites nav.c:1831,2001,2017,3530,3546
+ *   deferred mode                            the same three entry points only RECORD the build and
+ *                                            hand back a tagged placeholder; N_HIP_Flush() builds the
+ *                                            whole batch in one navhip_build_fields call (in-place
+ *                                            chains ordered into rounds) and puts the results into
+ *                                            the reference's field cache under their own ids
+ *   N_HIP_DesiredPointSeekVelocities         N_DesiredPointSeekVelocity (nav.c:3468) for n agents:
+ *                                            the miss-collecting pre-pass.  The serial control flow of
+ *                                            nav.c:3483-3554 runs unchanged per agent, but in PHASES
+ *                                            with one batched device build between them:
+ *                                            (A) missing (dest, chunk) mapping -> n_request_path,
+ *                                            (B) FD_NONE under the agent -> n_request_path again,
+ *                                            (C) repairs (blocked tile / orphaned island), one per
+ *                                                field and round,
+ *                                            then n_interpolated_flow_dir on the now complete cache.
+ * Backend 0 runs the same phases with the reference's own CPU builders -- the control of the tests.
+ */
+#include <navhip.h>
+
+enum { N_HIP_BACKEND_CPU = 0, N_HIP_BACKEND_HIP = 1 };
+
+static struct {
+    navhip_ctx *ctx;
+    int         backend;
+    bool        deferred;
+    /* pending builds (deferred mode) */
+    struct n_hip_pending{
+        ff_id_t             id;
+        struct coord        chunk;
+        struct field_target target;
+        int                 faction_id;
+        enum nav_layer      layer;
+        int                 kind;          /* 0 update, 1 nearest pathable, 2 island to nearest */
+        struct coord        start;         /* kind 1 */
+        uint16_t            local_iid;     /* kind 2 */
+        int                 base;          /* index of the pending build this one updates in place, -1 */
+        uint8_t             dirs[FIELD_RES_R * FIELD_RES_C];   /* existing content (base == -1) / result */
+        struct nav_private *priv;
+    }          *pend;
+    int         npend, cappend;
+    /* statistics */
+    long        n_builds, n_batches, n_requests;
+}s_hip;
+
+#define N_HIP_TAG 0xF    /* dir_idx value no real field holds: marks a placeholder */
+
+/* -------------------------------------------------------------------------------------------- */
+
+static void n_hip_pack_plane(const struct nav_private *priv, enum nav_layer layer, int plane, void *out)
+{
+    size_t nchunks = priv->width * priv->height;
+    const size_t cells = FIELD_RES_R * FIELD_RES_C;
+    for(size_t i = 0; i < nchunks; i++) {
+        const struct nav_chunk *ch = &priv->chunks[layer][i];
+        switch(plane) {
+        case NAVHIP_PLANE_COST_BASE:     memcpy((uint8_t*)out  + i * cells, ch->cost_base, cells); break;
+        case NAVHIP_PLANE_BLOCKERS:      memcpy((uint16_t*)out + i * cells, ch->blockers, cells * 2); break;
+        case NAVHIP_PLANE_LOCAL_ISLANDS: memcpy((uint16_t*)out + i * cells, ch->local_islands, cells * 2); break;
+        case NAVHIP_PLANE_ISLANDS:       memcpy((uint16_t*)out + i * cells, ch->islands, cells * 2); break;
+        case NAVHIP_PLANE_FACTIONS:      memcpy((uint8_t*)out  + i * cells * MAX_FACTIONS, ch->factions, cells * MAX_FACTIONS); break;
+        }
+    }
+}
+
+/* upload every plane of `layer` the field builders read (after N_NewCtxForMapData, and again after
+ * N_Update has applied blocker changes and relabelled the dirty local islands, nav.c:2119) */
+bool N_HIP_SyncLayer(const struct nav_private *priv, enum nav_layer layer)
+{
+    if(!s_hip.ctx || !priv->chunks[layer])
+        return false;
+    size_t nchunks = priv->width * priv->height;
+    const size_t cells = FIELD_RES_R * FIELD_RES_C;
+    void *buf = malloc(nchunks * cells * MAX_FACTIONS);
+    if(!buf)
+        return false;
+    static const int planes[] = {NAVHIP_PLANE_COST_BASE, NAVHIP_PLANE_BLOCKERS, NAVHIP_PLANE_LOCAL_ISLANDS,
+                                 NAVHIP_PLANE_ISLANDS, NAVHIP_PLANE_FACTIONS};
+    static const size_t elem[] = {1, 2, 2, 2, MAX_FACTIONS};
+    bool ok = true;
+    for(int p = 0; p < 5 && ok; p++) {
+        n_hip_pack_plane(priv, layer, planes[p], buf);
+        ok = navhip_upload_plane(s_hip.ctx, layer, planes[p], buf, nchunks * cells * elem[p]) == NAVHIP_OK;
+    }
+    free(buf);
+    return ok;
+}
+
+bool N_HIP_Init(const struct nav_private *priv)
+{
+    memset(&s_hip, 0, sizeof(s_hip));
+    if(navhip_ctx_create(&s_hip.ctx, priv->width, priv->height, 0) != NAVHIP_OK) {
+        s_hip.ctx = NULL;
+        return false;                          /* no GPU: the CPU path stays in charge */
+    }
+    for(int l = 0; l < NAV_LAYER_MAX; l++) {
+        if(priv->chunks[l] && !N_HIP_SyncLayer(priv, l))
+            return false;
+    }
+    s_hip.backend = N_HIP_BACKEND_HIP;
+    return true;
+}
+
+void N_HIP_Shutdown(void)
+{
+    if(s_hip.ctx)
+        navhip_ctx_destroy(s_hip.ctx);
+    free(s_hip.pend);
+    memset(&s_hip, 0, sizeof(s_hip));
+}
+
+void N_HIP_SetBackend(int backend) { s_hip.backend = backend; }
+navhip_ctx *N_HIP_Ctx(void)        { return s_hip.ctx; }
+void N_HIP_Stats(long out[3])      { out[0] = s_hip.n_builds; out[1] = s_hip.n_batches; out[2] = s_hip.n_requests; }
+
+/* struct field_target / portal_desc (field.h:67-101) -> navhip_field_req */
+static bool n_hip_make_req(const struct n_hip_pending *p, navhip_field_req *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->layer = p->layer;
+    r->faction_id = p->faction_id;
+    r->enemies = (p->faction_id == FACTION_ID_NONE) ? 0 : G_GetEnemyFactions(p->faction_id);   /* field.c:166 */
+    r->chunk_r = p->chunk.r; r->chunk_c = p->chunk.c;
+    r->flags = NAVHIP_REQ_INOUT;               /* an all-FD_NONE slot == N_FlowFieldInit */
+    if(p->target.type == TARGET_TILE) {
+        r->type = NAVHIP_TARGET_TILE;
+        r->tile_r = p->target.tile.r; r->tile_c = p->target.tile.c;
+    }else if(p->target.type == TARGET_PORTAL) {
+        const struct portal_desc *pd = &p->target.pd;
+        r->type = NAVHIP_TARGET_PORTAL;
+        r->port_r0 = pd->port->endpoints[0].r; r->port_c0 = pd->port->endpoints[0].c;
+        r->port_r1 = pd->port->endpoints[1].r; r->port_c1 = pd->port->endpoints[1].c;
+        r->next_r0 = pd->next->endpoints[0].r; r->next_c0 = pd->next->endpoints[0].c;
+        r->next_r1 = pd->next->endpoints[1].r; r->next_c1 = pd->next->endpoints[1].c;
+        r->next_chunk_r = pd->next->chunk.r;   r->next_chunk_c = pd->next->chunk.c;
+        r->port_iid = pd->port_iid;            r->next_iid = pd->next_iid;
+    }else{
+        return false;
+    }
+    if(p->kind == 1) {                         /* N_FlowFieldUpdateToNearestPathable: ignores the target */
+        r->type = NAVHIP_TARGET_NEAREST_PATHABLE;
+        r->tile_r = p->start.r; r->tile_c = p->start.c;
+    }else if(p->kind == 2) {                   /* N_FlowFieldUpdateIslandToNearest */
+        r->flags |= NAVHIP_REQ_ISLAND_NEAREST;
+        r->aux_iid = p->local_iid;
+    }
+    return true;
+}
+
+static void n_hip_ff_to_dirs(const struct flow_field *ff, uint8_t *dirs)
+{
+    for(int r = 0; r < FIELD_RES_R; r++)
+    for(int c = 0; c < FIELD_RES_C; c++)
+        dirs[r * FIELD_RES_C + c] = ff->field[r][c].dir_idx;
+}
+
+static void n_hip_dirs_to_ff(const uint8_t *dirs, struct flow_field *ff)
+{
+    for(int r = 0; r < FIELD_RES_R; r++)
+    for(int c = 0; c < FIELD_RES_C; c++)
+        ff->field[r][c].dir_idx = dirs[r * FIELD_RES_C + c];
+}
+
+/* the reference's own builders (nav.c's calls are renamed onto the hooks below by the harness, so
+ * these are reached through the real symbols) */
+static void n_hip_cpu_build(const struct n_hip_pending *p, struct flow_field *ff)
+{
+    switch(p->kind) {
+    case 0: (N_FlowFieldUpdate)(p->chunk, p->priv, p->faction_id, p->layer, p->target,
+                p->priv->unit_query_ctx, ff); break;
+    case 1: (N_FlowFieldUpdateToNearestPathable)(p->priv, p->layer, p->chunk, p->start, p->faction_id,
+                p->priv->unit_query_ctx, ff); break;
+    case 2: (N_FlowFieldUpdateIslandToNearest)(p->local_iid, p->priv, p->layer, p->faction_id,
+                p->priv->unit_query_ctx, ff); break;
+    }
+}
+
+/* one entry: record or build */
+static void n_hip_entry(struct n_hip_pending *p, struct flow_field *inout_flow)
+{
+    s_hip.n_requests++;
+    navhip_field_req req;
+    bool on_device = s_hip.backend == N_HIP_BACKEND_HIP && s_hip.ctx && n_hip_make_req(p, &req);
+    if(p->kind == 0)
+        inout_flow->target = p->target;        /* N_FlowFieldUpdate records its target (field.c:2076) */
+
+    if(s_hip.deferred) {
+        /* is the field we are asked to update itself a placeholder of this batch? */
+        p->base = -1;
+        if(inout_flow->field[0][0].dir_idx == N_HIP_TAG) {
+            int idx = 0;
+            for(int k = 0; k < 6; k++)
+                idx |= inout_flow->field[0][1 + k].dir_idx << (4 * k);
+            p->base = idx;
+        }else{
+            n_hip_ff_to_dirs(inout_flow, p->dirs);
+        }
+        if(s_hip.npend == s_hip.cappend) {
+            s_hip.cappend = s_hip.cappend ? s_hip.cappend * 2 : 256;
+            s_hip.pend = realloc(s_hip.pend, sizeof(*s_hip.pend) * s_hip.cappend);
+        }
+        int me = s_hip.npend++;
+        s_hip.pend[me] = *p;
+        /* the placeholder: tag + the index of this build; chunk stays what the caller set */
+        inout_flow->field[0][0].dir_idx = N_HIP_TAG;
+        for(int k = 0; k < 6; k++)
+            inout_flow->field[0][1 + k].dir_idx = (me >> (4 * k)) & 0xf;
+        return;
+    }
+    if(!on_device) {
+        n_hip_cpu_build(p, inout_flow);
+        return;
+    }
+    uint8_t dirs[FIELD_RES_R * FIELD_RES_C];
+    n_hip_ff_to_dirs(inout_flow, dirs);
+    if(navhip_build_fields(s_hip.ctx, &req, 1, dirs, NULL) != NAVHIP_OK) {
+        n_hip_cpu_build(p, inout_flow);        /* any error: the CPU path stays compiled in */
+        return;
+    }
+    s_hip.n_builds++; s_hip.n_batches++;
+    n_hip_dirs_to_ff(dirs, inout_flow);
+}
+
+/* ---- the three drop-in entry points (signatures of field.h:146-183) ------------------------- */
+
+void N_HIP_FlowFieldUpdate(struct coord chunk_coord, const struct nav_private *priv, int faction_id,
+                           enum nav_layer layer, struct field_target target,
+                           struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow)
+{
+    if(target.type != TARGET_TILE && target.type != TARGET_PORTAL) {
+        /* enemy / entity / zone fields: the region builders (host, or navhip_build_region_fields) */
+        (N_FlowFieldUpdate)(chunk_coord, priv, faction_id, layer, target, ctx, inout_flow);
+        return;
+    }
+    struct n_hip_pending p;
+    memset(&p, 0, sizeof(p));
+    p.id = N_FlowFieldID(chunk_coord, target, layer);
+    p.chunk = chunk_coord; p.target = target; p.faction_id = faction_id; p.layer = layer;
+    p.kind = 0; p.priv = (struct nav_private*)priv;
+    n_hip_entry(&p, inout_flow);
+}
+
+void N_HIP_FlowFieldUpdateToNearestPathable(const struct nav_private *priv, enum nav_layer layer,
+                                            struct coord chunk, struct coord start, int faction_id,
+                                            struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow)
+{
+    struct n_hip_pending p;
+    memset(&p, 0, sizeof(p));
+    p.chunk = chunk; p.target = inout_flow->target; p.faction_id = faction_id; p.layer = layer;
+    p.id = N_FlowFieldID(chunk, inout_flow->target, layer);
+    p.kind = 1; p.start = start; p.priv = (struct nav_private*)priv;
+    if(p.target.type != TARGET_TILE && p.target.type != TARGET_PORTAL) {
+        (N_FlowFieldUpdateToNearestPathable)(priv, layer, chunk, start, faction_id, ctx, inout_flow);
+        return;
+    }
+    n_hip_entry(&p, inout_flow);
+}
+
+void N_HIP_FlowFieldUpdateIslandToNearest(uint16_t local_iid, const struct nav_private *priv,
+                                          enum nav_layer layer, int faction_id,
+                                          struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow)
+{
+    struct n_hip_pending p;
+    memset(&p, 0, sizeof(p));
+    p.chunk = inout_flow->chunk; p.target = inout_flow->target; p.faction_id = faction_id; p.layer = layer;
+    p.id = N_FlowFieldID(inout_flow->chunk, inout_flow->target, layer);
+    p.kind = 2; p.local_iid = local_iid; p.priv = (struct nav_private*)priv;
+    if(p.target.type != TARGET_TILE && p.target.type != TARGET_PORTAL) {
+        (N_FlowFieldUpdateIslandToNearest)(local_iid, priv, layer, faction_id, ctx, inout_flow);
+        return;
+    }
+    n_hip_entry(&p, inout_flow);
+}
+
+/* ---- deferred mode --------------------------------------------------------------------------- */
+
+void N_HIP_BeginBatch(void) { s_hip.deferred = true; s_hip.npend = 0; }
+
+/* Build every recorded field -- one navhip_build_fields call per round (a build that updates another
+ * pending build in place waits for it) -- and put the results into the field cache. */
+bool N_HIP_Flush(void)
+{
+    s_hip.deferred = false;
+    const int n = s_hip.npend;
+    if(n == 0)
+        return true;
+    bool ok = true;
+    int *round = malloc(sizeof(int) * n);
+    int maxr = 0;
+    for(int i = 0; i < n; i++) {
+        round[i] = s_hip.pend[i].base < 0 ? 0 : round[s_hip.pend[i].base] + 1;     /* base < i always */
+        if(round[i] > maxr) maxr = round[i];
+    }
+    navhip_field_req *reqs = malloc(sizeof(navhip_field_req) * n);
+    uint8_t *dirs = malloc((size_t)n * FIELD_RES_R * FIELD_RES_C);
+    int *who = malloc(sizeof(int) * n);
+    for(int r = 0; r <= maxr; r++) {
+        int m = 0;
+        for(int i = 0; i < n; i++) {
+            if(round[i] != r) continue;
+            struct n_hip_pending *p = &s_hip.pend[i];
+            if(p->base >= 0)
+                memcpy(p->dirs, s_hip.pend[p->base].dirs, sizeof(p->dirs));
+            bool dev = s_hip.backend == N_HIP_BACKEND_HIP && s_hip.ctx && n_hip_make_req(p, &reqs[m]);
+            if(!dev) {
+                struct flow_field ff;
+                memset(&ff, 0, sizeof(ff));
+                ff.chunk = p->chunk; ff.target = p->target;
+                n_hip_dirs_to_ff(p->dirs, &ff);
+                n_hip_cpu_build(p, &ff);
+                n_hip_ff_to_dirs(&ff, p->dirs);
+                continue;
+            }
+            memcpy(dirs + (size_t)m * FIELD_RES_R * FIELD_RES_C, p->dirs, sizeof(p->dirs));
+            who[m++] = i;
+        }
+        if(m > 0) {
+            if(navhip_build_fields(s_hip.ctx, reqs, m, dirs, NULL) == NAVHIP_OK) {
+                s_hip.n_builds += m; s_hip.n_batches++;
+                for(int k = 0; k < m; k++)
+                    memcpy(s_hip.pend[who[k]].dirs, dirs + (size_t)k * FIELD_RES_R * FIELD_RES_C,
+                           sizeof(s_hip.pend[0].dirs));
+            }else{
+                for(int k = 0; k < m; k++) {               /* fall back to the CPU builders */
+                    struct n_hip_pending *p = &s_hip.pend[who[k]];
+                    struct flow_field ff;
+                    memset(&ff, 0, sizeof(ff));
+                    ff.chunk = p->chunk; ff.target = p->target;
+                    n_hip_dirs_to_ff(p->dirs, &ff);
+                    n_hip_cpu_build(p, &ff);
+                    n_hip_ff_to_dirs(&ff, p->dirs);
+                }
+                ok = false;
+            }
+        }
+    }
+    /* N_FC_PutFlowField (nav.c:1833,2008,2018,3533,3547) with the real contents, in request order
+     * (a later build of the same id is the one that stays, as in the serial run) */
+    for(int i = 0; i < n; i++) {
+        struct n_hip_pending *p = &s_hip.pend[i];
+        struct flow_field ff;
+        memset(&ff, 0, sizeof(ff));
+        ff.chunk = p->chunk; ff.target = p->target;
+        n_hip_dirs_to_ff(p->dirs, &ff);
+        N_FC_PutFlowField(p->priv->fieldcache, p->id, &ff);
+    }
+    free(round); free(reqs); free(dirs); free(who);
+    s_hip.npend = 0;
+    return ok;
+}
+
+/* ---- N_DesiredPointSeekVelocity for n agents (nav.c:3468-3559) ------------------------------- */
+
+static bool n_hip_tile(struct nav_private *priv, vec3_t map_pos, vec2_t pos, struct tile_desc *out)
+{
+    struct map_resolution res;
+    N_GetResolution(priv, &res);
+    return M_Tile_DescForPoint2D(res, map_pos, pos, out);
+}
+
+static const struct flow_field *n_hip_field_under(struct nav_private *priv, dest_id_t id, struct tile_desc tile,
+                                                 ff_id_t *out_ffid)
+{
+    if(!N_FC_GetDestFFMapping(priv->fieldcache, id, (struct coord){tile.chunk_r, tile.chunk_c}, out_ffid))
+        return NULL;
+    return N_FC_FlowFieldAt(priv->fieldcache, *out_ffid);
+}
+
+/* ids[i] / pos[i] / dest[i]: the arguments of the i-th N_DesiredPointSeekVelocity call; out[i] its
+ * return value (zero for the `return (vec2_t){0.0f}` exits of nav.c:3489,3501).
+ *
+ * Every agent walks through the serial code's own decisions, one decision per round, and every
+ * decision that builds fields only records them; the round's builds run as one batch.  An agent
+ * whose field is being rebuilt in the current round (tagged placeholder in the cache) waits for the
+ * next round, exactly as it would have seen the finished field in the serial run. */
+void N_HIP_DesiredPointSeekVelocities(struct nav_private *priv, vec3_t map_pos, int n, const dest_id_t *ids,
+                                      const vec2_t *pos, const vec2_t *dest, vec2_t *out)
+{
+    struct map_resolution res;
+    N_GetResolution(priv, &res);
+    enum { ST_A = 0, ST_B, ST_C, ST_SAMPLE, ST_ZERO };
+    uint8_t *st = calloc(n > 0 ? n : 1, 1);
+
+    for(int round = 0; round < 256; round++) {
+        int issued = 0, waiting = 0;
+        N_HIP_BeginBatch();
+        for(int i = 0; i < n; i++) {
+            if(st[i] >= ST_SAMPLE) continue;
+            struct tile_desc tile;
+            if(!n_hip_tile(priv, map_pos, pos[i], &tile)) { st[i] = ST_ZERO; continue; }
+            const struct coord chunk = (struct coord){tile.chunk_r, tile.chunk_c};
+            enum nav_layer layer = N_DestLayer(ids[i]);
+            int faction_id = N_DestFactionID(ids[i]);
+            ff_id_t ffid;
+            dest_id_t ret;
+            if(st[i] == ST_A) {
+                /* nav.c:3483-3492: no field mapped for the agent's chunk */
+                st[i] = ST_B;
+                if(!N_FC_GetDestFFMapping(priv->fieldcache, ids[i], chunk, &ffid)) {
+                    if(!n_request_path(priv, pos[i], dest[i], faction_id, map_pos, layer, &ret))
+                        st[i] = ST_ZERO;
+                    issued++;
+                    continue;
+                }
+            }
+            const struct flow_field *ff = n_hip_field_under(priv, ids[i], tile, &ffid);
+            if(ff && ff->field[0][0].dir_idx == N_HIP_TAG) { waiting++; continue; }
+            if(st[i] == ST_B) {
+                /* nav.c:3494-3504: evicted, or FD_NONE under the agent: ask the planner from here */
+                st[i] = ST_C;
+                if(!ff || ff->field[tile.tile_r][tile.tile_c].dir_idx == FD_NONE) {
+                    if(!n_request_path(priv, pos[i], dest[i], faction_id, map_pos, layer, &ret))
+                        st[i] = ST_ZERO;
+                    issued++;
+                    continue;
+                }
+            }
+            /* nav.c:3506-3554 */
+            st[i] = ST_SAMPLE;
+            if(!ff) { st[i] = ST_ZERO; continue; }
+            if(ff->field[tile.tile_r][tile.tile_c].dir_idx != FD_NONE)
+                continue;
+            const struct nav_chunk *nchunk = &priv->chunks[layer][IDX(tile.chunk_r, priv->width, tile.chunk_c)];
+            uint16_t local_iid = nchunk->local_islands[tile.tile_r][tile.tile_c];
+            struct flow_field exist_ff = *ff;
+            if(local_iid == ISLAND_NONE) {
+                N_HIP_FlowFieldUpdateToNearestPathable(priv, layer, chunk,
+                    (struct coord){tile.tile_r, tile.tile_c}, faction_id, priv->unit_query_ctx, &exist_ff);
+            }else{
+                N_HIP_FlowFieldUpdateIslandToNearest(local_iid, priv, layer, faction_id, priv->unit_query_ctx, &exist_ff);
+            }
+            N_FC_PutFlowField(priv->fieldcache, ffid, &exist_ff);
+            issued++;
+        }
+        N_HIP_Flush();
+        if(!issued && !waiting) break;
+    }
+
+    /* sampling (nav.c:3556-3558) */
+    for(int i = 0; i < n; i++) {
+        out[i] = (vec2_t){0.0f, 0.0f};
+        if(st[i] == ST_ZERO) continue;
+        struct tile_desc tile;
+        if(!n_hip_tile(priv, map_pos, pos[i], &tile)) continue;
+        ff_id_t ffid;
+        const struct flow_field *ff = n_hip_field_under(priv, ids[i], tile, &ffid);
+        if(!ff) continue;
+        out[i] = n_interpolated_flow_dir(priv, ids[i], res, map_pos, pos[i], ff, tile);
+    }
+    free(st);
+}

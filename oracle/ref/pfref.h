@@ -141,6 +141,25 @@ int    pfref_position_pathable(pfref_nav *nav, int layer, float x, float z);
 int    pfref_position_blocked(pfref_nav *nav, int layer, float x, float z);
 void   pfref_map_pos(const pfref_nav *nav, float out[3]);
 
+/* --- the reference-side binding of libnavhip.so (oracle/ref/nav_hip.c, move_hip.c) ------------- */
+
+/* N_HIP_Init: create the device context for this map and upload its planes.  0 = no GPU. */
+int  pfref_hip_init(pfref_nav *nav);
+void pfref_hip_shutdown(void);
+/* use_binding != 0: every N_FlowFieldUpdate / ...ToNearestPathable / ...IslandToNearest call nav.c makes
+ * goes through the binding; backend 0 = the reference's CPU builders behind it, 1 = libnavhip */
+void pfref_hip_mode(int use_binding, int backend);
+int  pfref_hip_sync_layer(pfref_nav *nav, int layer);        /* after blocker changes */
+void pfref_hip_stats(long out[3]);                           /* device builds, batches, requests */
+/* N_DesiredPointSeekVelocity for n agents: batched = 0 serial calls in order, 1 = the
+ * miss-collecting batched form (N_HIP_DesiredPointSeekVelocities) */
+void pfref_desired_velocities(pfref_nav *nav, int n, const uint32_t *dest_ids, const float *pos_xz,
+                              const float *dest_xz, int batched, float *out_xz);
+uint32_t pfref_dest_id(pfref_nav *nav, int layer, int faction_id, float dst_x, float dst_z);
+void pfref_cache_clear(pfref_nav *nav);
+/* move_velocity_work through the WORK_TYPE_HIP arm; 0 = the arm declined (no device) */
+int  pfref_move_velocity_hip(const float *vdes, int begin, int end, float *out_vel);
+
 /* --- ClearPath ---------------------------------------------------------- */
 
 /* G_ClearPath_NewVelocity (clearpath.c:694).  ent/neighbours are

@@ -320,6 +320,25 @@ int pfref_move_neighbours(int uid, float *out_dyn, int *n_dyn, float *out_stat, 
     return 0;
 }
 
+/* the WORK_TYPE_HIP arm (what a maintainer adds to movement.c) */
+#include "move_hip.c"
+
+/* like pfref_move_velocity, through move_hip_velocity_work; returns 0 when the device arm declined */
+int pfref_move_velocity_hip(const float *vdes, int begin, int end, float *out_vel)
+{
+    for(int i = begin; i < end; i++)
+        set_vdes(vdes, i);
+    if(end <= begin)
+        return 1;
+    if(!move_hip_velocity_work(begin, end - 1))
+        return 0;
+    for(int i = begin; i < end; i++) {
+        out_vel[2 * i]     = s_move_work.out[i].ent_vel.x;
+        out_vel[2 * i + 1] = s_move_work.out[i].ent_vel.z;
+    }
+    return 1;
+}
+
 struct mbench_arg{ int begin, end, reps; };
 
 static void *mbench_thread(void *p)

@@ -11,15 +11,46 @@
  * the HIP path.
  */
 #define N_FlowFieldUpdate pfref_traced_N_FlowFieldUpdate
+#define N_FlowFieldUpdateToNearestPathable pfref_hook_NearestPathable
+#define N_FlowFieldUpdateIslandToNearest pfref_hook_IslandToNearest
 #include "navigation/nav.c"
 #undef N_FlowFieldUpdate
+#undef N_FlowFieldUpdateToNearestPathable
+#undef N_FlowFieldUpdateIslandToNearest
 
 #include "pfref.h"
 #include "ref_internal.h"
 
+/* the real builders (field.c) */
 void N_FlowFieldUpdate(struct coord chunk_coord, const struct nav_private *priv, int faction_id,
                        enum nav_layer layer, struct field_target target,
                        struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow);
+void N_FlowFieldUpdateIslandToNearest(uint16_t local_iid, const struct nav_private *priv,
+                                      enum nav_layer layer, int faction_id,
+                                      struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow);
+void N_FlowFieldUpdateToNearestPathable(const struct nav_private *priv, enum nav_layer layer,
+                                        struct coord chunk, struct coord start, int faction_id,
+                                        struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow);
+
+/* The reference-side binding of libnavhip.so (what a maintainer appends to nav.c): every field build
+ * nav.c asks for goes through it while s_use_binding is set. */
+#include "nav_hip.c"
+static bool s_use_binding;
+
+void pfref_hook_NearestPathable(const struct nav_private *priv, enum nav_layer layer, struct coord chunk,
+                                struct coord start, int faction_id, struct nav_unit_query_ctx *ctx,
+                                struct flow_field *inout_flow)
+{
+    if(s_use_binding) N_HIP_FlowFieldUpdateToNearestPathable(priv, layer, chunk, start, faction_id, ctx, inout_flow);
+    else              N_FlowFieldUpdateToNearestPathable(priv, layer, chunk, start, faction_id, ctx, inout_flow);
+}
+
+void pfref_hook_IslandToNearest(uint16_t local_iid, const struct nav_private *priv, enum nav_layer layer,
+                                int faction_id, struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow)
+{
+    if(s_use_binding) N_HIP_FlowFieldUpdateIslandToNearest(local_iid, priv, layer, faction_id, ctx, inout_flow);
+    else              N_FlowFieldUpdateIslandToNearest(local_iid, priv, layer, faction_id, ctx, inout_flow);
+}
 
 /* ------------------------------------------------------------------------ */
 /* planner trace                                                            */
@@ -56,7 +87,8 @@ void pfref_traced_N_FlowFieldUpdate(struct coord chunk_coord, const struct nav_p
             any |= (tr->before[i] != FD_NONE);
         tr->req.inout = any;
     }
-    N_FlowFieldUpdate(chunk_coord, priv, faction_id, layer, target, ctx, inout_flow);
+    if(s_use_binding) N_HIP_FlowFieldUpdate(chunk_coord, priv, faction_id, layer, target, ctx, inout_flow);
+    else              N_FlowFieldUpdate(chunk_coord, priv, faction_id, layer, target, ctx, inout_flow);
     if(rec) {
         /* realloc may have moved the buffer only before this call; tr is still valid */
         pfref_ff_to_dirs(inout_flow, tr->after);
@@ -285,3 +317,71 @@ int pfref_position_blocked(pfref_nav *nav, int layer, float x, float z)
 {
     return N_PositionBlocked((vec2_t){x, z}, layer, &nav->priv, nav->map_pos);
 }
+
+
+/* ------------------------------------------------------------------------ */
+/* the binding (nav_hip.c) driven by the reference's own planner / sampler   */
+/* ------------------------------------------------------------------------ */
+
+int pfref_hip_init(pfref_nav *nav)
+{
+    return N_HIP_Init(&nav->priv) ? 1 : 0;
+}
+
+void pfref_hip_shutdown(void)
+{
+    s_use_binding = false;
+    N_HIP_Shutdown();
+}
+
+/* use_binding: nav.c's field builds go through N_HIP_*; backend 0 = the reference's CPU builders
+ * behind the binding (control), 1 = libnavhip */
+void pfref_hip_mode(int use_binding, int backend)
+{
+    s_use_binding = use_binding != 0;
+    N_HIP_SetBackend(backend);
+}
+
+int pfref_hip_sync_layer(pfref_nav *nav, int layer)
+{
+    return N_HIP_SyncLayer(&nav->priv, layer) ? 1 : 0;
+}
+
+void pfref_hip_stats(long out[3]) { N_HIP_Stats(out); }
+
+/* N_DesiredPointSeekVelocity for n agents: batched = 0 the reference's serial calls, in order;
+ * batched = 1 N_HIP_DesiredPointSeekVelocities (collect -> batch build -> sample) */
+void pfref_desired_velocities(pfref_nav *nav, int n, const uint32_t *dest_ids, const float *pos_xz,
+                              const float *dest_xz, int batched, float *out_xz)
+{
+    if(!batched) {
+        for(int i = 0; i < n; i++) {
+            vec2_t v = N_DesiredPointSeekVelocity(dest_ids[i], (vec2_t){pos_xz[2 * i], pos_xz[2 * i + 1]},
+                (vec2_t){dest_xz[2 * i], dest_xz[2 * i + 1]}, &nav->priv, nav->map_pos);
+            out_xz[2 * i] = v.x; out_xz[2 * i + 1] = v.z;
+        }
+        return;
+    }
+    vec2_t *pos = malloc(sizeof(vec2_t) * (n > 0 ? n : 1)), *dst = malloc(sizeof(vec2_t) * (n > 0 ? n : 1));
+    vec2_t *out = malloc(sizeof(vec2_t) * (n > 0 ? n : 1));
+    for(int i = 0; i < n; i++) {
+        pos[i] = (vec2_t){pos_xz[2 * i], pos_xz[2 * i + 1]};
+        dst[i] = (vec2_t){dest_xz[2 * i], dest_xz[2 * i + 1]};
+    }
+    N_HIP_DesiredPointSeekVelocities(&nav->priv, nav->map_pos, n, dest_ids, pos, dst, out);
+    for(int i = 0; i < n; i++) { out_xz[2 * i] = out[i].x; out_xz[2 * i + 1] = out[i].z; }
+    free(pos); free(dst); free(out);
+}
+
+/* n_dest_id (nav.c:848) of a destination position */
+uint32_t pfref_dest_id(pfref_nav *nav, int layer, int faction_id, float dst_x, float dst_z)
+{
+    struct map_resolution res;
+    N_GetResolution(&nav->priv, &res);
+    struct tile_desc td;
+    if(!M_Tile_DescForPoint2D(res, nav->map_pos, (vec2_t){dst_x, dst_z}, &td))
+        return 0;
+    return n_dest_id(td, layer, faction_id);
+}
+
+void pfref_cache_clear(pfref_nav *nav) { N_FC_ClearAll(nav->priv.fieldcache); }

@@ -18,7 +18,13 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wave_sync()
 {
+#ifdef CP_STRONG_SYNC
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile("" ::: "memory");
+#else
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -233,6 +239,24 @@ __device__ __forceinline__ bool inside_pcr(const float4 *cones, int n_cones, v2 
     return false;
 }
 
+// optional work counters of the ClearPath search (-DNH_CP_STATS builds only: scripts/cp_stats.py):
+// per neighbour-count bucket {problems, attempts, candidates generated, candidates queued, cone tests,
+// cp_work iterations, live columns, columns}
+#ifdef NH_CP_STATS
+__device__ unsigned long long nh_cp_cyc[8][8];       // cycles: {cones+admissible, projections, columns, jump, max unit, -, -, -}
+#define CP_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define CP_TMARK(b, k) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); if(grp<G>::lane() == 0) atomicAdd(&nh_cp_cyc[b][k], _n - _t0); _t0 = _n; } while(0)
+__device__ unsigned long long nh_cp_work[8][8];
+#define CP_STAT(b, k, v) do { if(grp<G>::lane() == 0) atomicAdd(&nh_cp_work[b][k], (unsigned long long)(v)); } while(0)
+__device__ __forceinline__ int cp_bucket(int n) { return n <= 2 ? 0 : n <= 4 ? 1 : n <= 8 ? 2 : n <= 16 ? 3 : n <= 32 ? 4 : 5; }
+#define CP_STAT_LANE(b, k, v) atomicAdd(&nh_cp_work[b][k], (unsigned long long)(v))
+#else
+#define CP_STAT(b, k, v)
+#define CP_STAT_LANE(b, k, v)
+#define CP_T0()
+#define CP_TMARK(b, k)
+#endif
+
 // LDS scratch of one ClearPath problem on a group of G lanes (at most G neighbours in total):
 //   cones   2 float4 per cone: {apex.x, apex.z, slope(left), slope(right)}, {left.x, left.z, right.x, right.z}
 //   ord     cone slots, nearest neighbour first (the order of the inside-obstacle tests)
@@ -245,7 +269,8 @@ template <int G> struct cp_lds {
     int32_t ord[G];
     float   qx[2 * G], qz[2 * G], ql[2 * G];
     int32_t qi[2 * G];
-    int32_t col[2 * G];
+    int32_t col[2 * G];              // rays (columns) in ascending key
+    float   ckey[2 * G];             // key of every ray: a lower bound of the distance of its candidates to des_v
     int32_t tau[G], seq[G];          // cp_jump: removal time of every cone, the removal sequence
     float   dyn[(G < 32 ? G : 32) * 5], stat[(G < 32 ? G : 32) * 5];
 };
@@ -268,16 +293,28 @@ template <int G> struct cp_lds {
 // The bound is group uniform.  `found` = some candidate outside the obstacle has been seen (what the
 // reference's `vec_size(&xpoints) == 0` asks); until then every candidate is tested, so that points
 // whose distance is NaN or infinite still count.
-struct cp_bound { float len; int idx; v2 pt; bool found; };
+struct cp_bound { float len; int idx; v2 pt; int nfound; int sb; };
+#ifdef CP_DEBUG
+__device__ unsigned long long nh_dbg[64];
+#define DBG_ON (blockIdx.x == 0 && threadIdx.x / G == 1 && grp<G>::lane() == 0)
+#define DBG_SET(k, v) do { if(DBG_ON) nh_dbg[k] = (unsigned long long)(long long)(v); } while(0)
+#define DBG_ADD(k, v) do { if(DBG_ON) nh_dbg[k] += (unsigned long long)(long long)(v); } while(0)
+#else
+#define DBG_SET(k, v)
+#define DBG_ADD(k, v)
+#endif
 #define CP_COL_MARGIN 0.02f
 
 __device__ __forceinline__ bool cp_alive(const cp_bound &B, float len, int idx)
 {
-    return !B.found || len < B.len || (len == B.len && idx < B.idx);
+    return B.nfound == 0 || len < B.len || (len == B.len && idx < B.idx);
 }
 
 // the candidate a lane is testing: cone ord[ci] is next
-struct cp_lane { bool have; v2 pt; int idx; float len; int ci; };
+// (no bool members: `nfound` counts and `ci < 0` means "no candidate" -- flags that live across the
+// group-divergent loops as 1-bit lane masks were miscompiled at -O3 once cp_work was inlined: the later
+// row of a wave lost its candidates.  Counters stay in VGPRs.)
+struct cp_lane { v2 pt; int idx; float len; int ci; };
 
 // Inside-obstacle tests with persistent lanes: every iteration each busy lane tests its candidate
 // against ONE cone; a lane whose candidate is decided -- inside a cone: dropped; outside all cones: it
@@ -294,44 +331,48 @@ __device__ void cp_work(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp
     int head = 0;
     for(;;) {
         if(head < qn) {
-            const bool need = !L.have;
+            const bool need = L.ci < 0;
             const unsigned long long mn = g::ballot(need);
             if(mn) {
                 const int my = head + __popcll(mn & lt_mask);
                 if(need && my < qn) {
-                    L.pt = mkv(S.qx[my], S.qz[my]); L.idx = S.qi[my]; L.len = S.ql[my]; L.ci = 0;
-                    L.have = cp_alive(B, L.len, L.idx);
+                    L.pt = mkv(S.qx[my], S.qz[my]); L.idx = S.qi[my]; L.len = S.ql[my];
+                    L.ci = cp_alive(B, L.len, L.idx) ? 0 : -1;
                 }
                 head = min(qn, head + __popcll(mn));
             }
         }
-        if(!g::any(L.have)) {
+        if(!g::any(L.ci >= 0)) {
             if(head >= qn) break;
             continue;
         }
         if(!finish && head >= qn) break;
+        CP_STAT(B.sb, 5, 1);
+        CP_STAT(B.sb, 4, __popcll(g::ballot(L.ci >= 0)));
         bool outside = false;
-        if(L.have) {
+        if(L.ci >= 0) {
             const int slot = S.ord[L.ci];
             const bool in = cone_contains(S.cones[2 * slot], S.cones[2 * slot + 1], L.pt);
             L.ci++;
-            if(in) L.have = false;
-            else if(L.ci >= n_cones) { outside = true; L.have = false; }
+            if(in) L.ci = -1;
+            else if(L.ci >= n_cones) { outside = true; L.ci = -1; }
         }
+        DBG_ADD(3, 1);
         if(g::any(outside)) {
+            DBG_ADD(4, 1);
             float key = (outside && L.len == L.len) ? L.len : __builtin_inff();    // a NaN distance never wins
             int ki = outside ? L.idx : 0x7fffffff;
             const float mykey = key; const int myidx = ki;
             g::argmin(key, ki);
-            const bool better = !B.found || key < B.len || (key == B.len && ki < B.idx);
-            B.found = true;
+            const bool better = B.nfound == 0 || key < B.len || (key == B.len && ki < B.idx);
+            B.nfound++;
             if(better && key < __builtin_inff()) {
                 const int owner = __ffsll((unsigned long long)g::ballot(outside && myidx == ki && mykey == key)) - 1;
                 const v2 curr = vsub(L.pt, ent.pos);
                 B.len = key; B.idx = ki;
                 B.pt = mkv(g::shfl(curr.x, owner), g::shfl(curr.z, owner));
             }
-            if(L.have && !cp_alive(B, L.len, L.idx)) L.have = false;
+            if(L.ci >= 0 && !cp_alive(B, L.len, L.idx)) L.ci = -1;
         }
     }
     qn = 0;
@@ -351,6 +392,8 @@ __device__ __forceinline__ void cp_push(cp_lds<G> &S, const cpent &ent, int n_co
         S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = idx; S.ql[at] = len;
     }
     qn += __popcll(mk);
+    DBG_ADD(2, __popcll(mk));
+    CP_STAT(B.sb, 3, __popcll(mk));
     wave_sync();
     if(qn >= G) cp_work<G>(S, ent, n_cones, qn, L, B, false);
 }
@@ -429,8 +472,8 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
     const int n_rays = 2 * n_cones, npairs = n_rays * n_rays;
     const float inv_nr = 1.0f / (float)n_rays;
     int qn = 0;
-    bool l_have = false; v2 l_pt = mkv(0, 0); int l_end = 0, l_ci = 0;
-    for(int c0 = 0; c0 < n_rays + npairs || qn > 0 || g::any(l_have); c0 += G) {
+    v2 l_pt = mkv(0, 0); int l_end = 0, l_ci = -1;         // l_ci < 0: this lane holds no candidate
+    for(int c0 = 0; c0 < n_rays + npairs || qn > 0 || g::any(l_ci >= 0); c0 += G) {
         // generate (projections first, then the ordered pairs)
         const int c = c0 + gl;
         bool ok = false;
@@ -476,21 +519,21 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
         int head = 0;
         for(;;) {
             if(head < qn) {
-                const bool need = !l_have;
+                const bool need = l_ci < 0;
                 const unsigned long long mn = g::ballot(need);
                 if(mn) {
                     const int my = head + __popcll(mn & lt_mask);
-                    if(need && my < qn) { l_pt = mkv(S.qx[my], S.qz[my]); l_end = S.qi[my]; l_ci = 0; l_have = true; }
+                    if(need && my < qn) { l_pt = mkv(S.qx[my], S.qz[my]); l_end = S.qi[my]; l_ci = 0; }
                     head = min(qn, head + __popcll(mn));
                 }
             }
-            if(!g::any(l_have)) { if(head >= qn) break; continue; }
+            if(!g::any(l_ci >= 0)) { if(head >= qn) break; continue; }
             if(!gen_done && head >= qn) break;
             int result = -1;
-            if(l_have) {
+            if(l_ci >= 0) {
                 const int lim = min(cur - 1, l_end);          // its start has to be <= lim to matter
                 if(lim < 1) {
-                    l_have = false;
+                    l_ci = -1;
                 }else{
                     const int cs_ = S.ord[l_ci];
                     const int tc = S.tau[cs_];
@@ -498,9 +541,9 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
                     l_ci++;
                     if(in) {
                         if(tc <= lim) result = tc;             // the latest-removed cone around it
-                        l_have = false;
+                        l_ci = -1;
                     }else if(l_ci >= n_cones) {
-                        result = 0; l_have = false;            // (outside everything: cannot be, attempt 0 failed)
+                        result = 0; l_ci = -1;                 // (outside everything: cannot be, attempt 0 failed)
                     }
                 }
             }
@@ -529,6 +572,10 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
     bool jumped = false;
     // at most 64 neighbours can be removed; the bound only guards against a NaN-poisoned input
     for(int guard = 0; guard < 66; guard++) {
+        CP_T0();
+#ifdef NH_CP_STATS
+        const int sb_ = cp_bucket(n_dyn + n_stat);
+#endif
         // ---- HRVOs for dynamic, VOs for static neighbours -> rays (rays_repr :291) -----------
         // lane = neighbour, dynamic ones first; same_position neighbours are skipped (:216-246)
         const bool isdyn = gl < n_dyn;
@@ -570,15 +617,22 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         const v2 des_ws = vadd(ent.pos, des_v);
         bool in = false;
         if(gl < n_cones) in = cone_contains(S.cones[2 * gl], S.cones[2 * gl + 1], des_ws);
+        CP_TMARK(sb_, 0);
         if(!g::any(in)) {
             if(gl == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
             return des_v;
         }
 
-        cp_bound B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.found = false;
-        cp_lane L; L.have = false; L.pt = mkv(0, 0); L.idx = 0; L.len = 0.0f; L.ci = 0;
+        cp_bound B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.nfound = 0; B.sb = 0;
+#ifdef NH_CP_STATS
+        B.sb = cp_bucket(n_dyn + n_stat);
+        CP_STAT(B.sb, 1, 1);
+        if(guard == 0) CP_STAT(B.sb, 0, 1);
+#endif
+        cp_lane L; L.pt = mkv(0, 0); L.idx = 0; L.len = 0.0f; L.ci = -1;
         int qn = 0;                                            // pending candidates (group uniform)
         const int npairs = n_rays * n_rays;
+        CP_STAT(B.sb, 7, n_rays);
         // ---- the projections of des_v on every ray (:344; order index npairs + ray).  Visited first:
         // they are the closest point of each ray, so the bound tightens at once.
         for(int c0 = 0; c0 < n_rays; c0 += G) {
@@ -598,71 +652,104 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         }
         cp_work<G>(S, ent, n_cones, qn, L, B, true);
 
-        // ---- the ray pairs (:321; order index i * n_rays + j), column by column.  The columns that
-        // can still matter are re-selected whenever the bound has moved.
-        int jdone = 0;                         // columns [0, jdone) are finished
-        while(jdone < n_rays) {
-            // select up to 2 G live columns from [jdone, n_rays)
-            int ncol = 0, jscan = jdone;
-            for(; jscan < n_rays && ncol < G; jscan += G) {
-                const int j = jscan + gl;
-                bool live = false;
+        CP_TMARK(sb_, 1);
+        DBG_SET(0, n_rays); DBG_SET(1, B.nfound); DBG_SET(8, guard);
+        // ---- the ray pairs (:321; order index i * n_rays + j), column by column, NEAREST LINE FIRST:
+        // a column's candidates all lie on its line, so its key -- the distance of des_v to that line,
+        // less the margins -- bounds them from below.  Columns are visited in ascending key; the search
+        // stops at the first column whose key exceeds the bound: every later one is farther still.
+        // In a crowd the best admissible velocity lies on one of the few lines next to des_v.
+        {
+            // keys of this lane's (up to two) rays
+            float mykey[2];
+#pragma unroll
+            for(int h = 0; h < 2; h++) {
+                const int j = gl + h * G;
+                mykey[h] = __builtin_inff();
                 if(j < n_rays) {
-                    live = true;
-                    if(B.found) {
-                        // distance of des_v to line j, in the agent's local frame
-                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
-                        const v2 dj = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
-                        const v2 rel = vsub(des_v, vsub(mkv(Aj.x, Aj.y), ent.pos));
-                        const float dist = fabsf(dj.x * rel.z - dj.z * rel.x);
-                        // (a ray with |dir.x| < 1/1024 is intersected as the exactly vertical line
-                        // x = apex.x, collision.c:823-831: up to 1/1024 per unit of distance away
-                        // from the real line -- the second term of the margin covers it)
-                        const float slack = CP_COL_MARGIN + 2e-3f * (B.len + fabsf(rel.x) + fabsf(rel.z));
-                        live = !(dist > B.len + slack);                  // NaN stays in
-                    }
+                    const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                    const v2 dj = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
+                    const v2 rel = vsub(des_v, vsub(mkv(Aj.x, Aj.y), ent.pos));
+                    const float dist = fabsf(dj.x * rel.z - dj.z * rel.x);
+                    // prunable once dist > B.len + CP_COL_MARGIN + 2e-3 (B.len + |rel|_1): the second
+                    // margin covers rays with |dir.x| < 1/1024, which are intersected as the exactly
+                    // vertical line x = apex.x (collision.c:823-831), up to 1/1024 per unit of distance
+                    // off the real line.  Solved for B.len, rounded down.
+                    const float k = (dist - CP_COL_MARGIN - 2e-3f * (fabsf(rel.x) + fabsf(rel.z))) * 0.99f;
+                    mykey[h] = (k == k) ? k : -__builtin_inff();        // NaN: never pruned
+                    S.ckey[j] = mykey[h];
                 }
-                const unsigned long long ml = g::ballot(live);
-                if(live) S.col[ncol + __popcll(ml & lt_mask)] = j;
-                ncol += __popcll(ml);
             }
-            jdone = jscan < n_rays ? jscan : n_rays;
             wave_sync();
-            // candidates of the selected columns: (i, col[cj]) for every i != col[cj]
-            const int ncand = ncol * n_rays;
+#pragma unroll
+            for(int h = 0; h < 2; h++) {
+                const int j = gl + h * G;
+                if(j < n_rays) {
+                    int rank = 0;
+                    for(int k = 0; k < n_rays; k++) {
+                        const float kk = S.ckey[k];
+                        rank += (kk < mykey[h] || (kk == mykey[h] && k < j)) ? 1 : 0;
+                    }
+#ifdef CP_NO_SORT
+                    S.col[j] = j;
+#else
+                    S.col[rank] = j;
+#endif
+                }
+            }
+            wave_sync();
+        }
+        {
+            // columns per batch: about four passes of candidates
+            const int kb = max(1, (4 * G) / n_rays);
             const float inv_nr = 1.0f / (float)n_rays;
-            for(int c0 = 0; c0 < ncand; c0 += G) {
-                const int c = c0 + gl;
-                bool ok = false;
-                v2 pt = mkv(0, 0);
-                float len = 0.0f;
-                int idx = 0;
-                if(c < ncand) {
-                    // (cj, i) = divmod(c, n_rays): float estimate + one correction step (c < 2^14)
-                    int cj = (int)((float)c * inv_nr);
-                    int i = c - cj * n_rays;
-                    if(i < 0) { cj--; i += n_rays; }
-                    if(i >= n_rays) { cj++; i -= n_rays; }
-                    const int j = S.col[cj];
-                    idx = i * n_rays + j;
-                    if(i != j) {
-                        const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
-                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
-                        const bool ri = i & 1, rj = j & 1;
-                        ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
-                                       mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z,
-                                       pt);
-                        if(ok) {
-                            len = vlen(vsub(des_v, vsub(pt, ent.pos)));
-                            ok = cp_alive(B, len, idx);
+            int jdone = 0;
+            while(jdone < n_rays) {
+#ifndef CP_NO_EARLY_BREAK
+                if(B.nfound && S.ckey[S.col[jdone]] > B.len) break;
+#endif
+                const int ncol = min(kb, n_rays - jdone);
+                const int ncand = ncol * n_rays;
+                DBG_SET(6, ncand); DBG_SET(7, kb); DBG_ADD(9, 1);
+                for(int z = 0; z < 8; z++) { DBG_SET(16 + z, S.col[z]); DBG_SET(24 + z, __float_as_int(S.ckey[z])); }
+                CP_STAT(B.sb, 6, ncol);
+                CP_STAT(B.sb, 2, ncand);
+                for(int c0 = 0; c0 < ncand; c0 += G) {
+                    const int c = c0 + gl;
+                    bool ok = false;
+                    v2 pt = mkv(0, 0);
+                    float len = 0.0f;
+                    int idx = 0;
+                    if(c < ncand) {
+                        // (cj, i) = divmod(c, n_rays): float estimate + one correction step (c < 2^14)
+                        int cj = (int)((float)c * inv_nr);
+                        int i = c - cj * n_rays;
+                        if(i < 0) { cj--; i += n_rays; }
+                        if(i >= n_rays) { cj++; i -= n_rays; }
+                        const int j = S.col[jdone + cj];
+                        idx = i * n_rays + j;
+                        if(i != j) {
+                            const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
+                            const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                            const bool ri = i & 1, rj = j & 1;
+                            ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
+                                           mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z,
+                                           pt);
+                            if(ok) {
+                                len = vlen(vsub(des_v, vsub(pt, ent.pos)));
+                                ok = cp_alive(B, len, idx);
+                            }
                         }
                     }
+                    cp_push<G>(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
                 }
-                cp_push<G>(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
+                jdone += ncol;
             }
             cp_work<G>(S, ent, n_cones, qn, L, B, true);
         }
-        if(B.found) {
+        CP_TMARK(sb_, 2);
+        DBG_SET(5, B.nfound); DBG_SET(10, __float_as_int(B.len));
+        if(B.nfound) {
             if(gl == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
             return B.pt;                   // (only NaN / infinite distances: ret stays 0, as :368-386)
         }
@@ -674,6 +761,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
             // the first failure: find the attempt that will succeed and go there in one step
             jumped = true;
             const int t = cp_jump<G>(S, ent, des_v, have, isdyn, k, use, slot, dist, n_dyn, n_stat, n_cones);
+            CP_TMARK(sb_, 3);
             if(t < 0) {
                 if(gl == 0) { atomicAdd(&nh_cp_attempts[0], 1ull); atomicAdd(&nh_cp_attempts[8], 2ull); }
                 return mkv(0.0f, 0.0f);

@@ -26,7 +26,8 @@ void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hi
 // (nh_launch_cohesion_regroup, after the caller's "cohesion done" event)
 bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, int *parity, hipStream_t s);
 void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *parity, hipStream_t s);
-// k_agent_mid -> k_cp_row -> k_cp_wave -> k_agent_full; WL.count holds 2 * NH_WL_COUNT counters
+// k_agent_mid -> k_cp -> k_agent_full; WL.count holds 2 * NH_WL_COUNTERS counters
+int nh_worklist_cap(int n_work);
 void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s);
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,

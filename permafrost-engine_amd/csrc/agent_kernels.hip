@@ -30,8 +30,8 @@
 //   k_cp          ClearPath for the listed agents: a ROW of 16 lanes per agent with 1..16 neighbours,
 //                 a whole WAVE per agent with 17..64 (a crowd); lanes spread over cones / ray pairs,
 //                 branch and bound on the distance to des_v, a candidate queue, a lexicographic
-//                 arg-min that reproduces the reference's first-wins rule; units drawn from a ticket
-//                 counter, heaviest first.
+//                 arg-min that reproduces the reference's first-wins rule; work units numbered
+//                 heaviest first and dealt out round robin.
 //   k_agent_full  one WAVE per listed agent, the whole step (irregular gathers: garrisoned
 //                 neighbours, wide queries).
 #include "navhip_internal.h"
@@ -745,6 +745,9 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
 // ---------------------------------------------------------------------------------------------
 // waves (= agents) per workgroup of the wave-per-agent kernels; 2 measured best for the round-1
 // k_agent_step (1: 0.490, 2: 0.483, 4: 0.494, 8: 0.521 ms/tick in one session)
+#ifndef NH_CP_ROW_CHUNK
+#define NH_CP_ROW_CHUNK 4
+#endif
 #ifndef AG_WAVES
 #define AG_WAVES 2
 #endif
@@ -885,17 +888,18 @@ __global__ __launch_bounds__(256) void k_agent_nbr(nh_grid G, int npool_max, nh_
     nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
 }
 
-// wave-aggregated append to a device work list: one atomic per wave and list
+// wave-aggregated append to a device work list: one atomic per wave and list, on the wave's sub-list
 __device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which, bool want, int uid)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long m = __ballot(want);
     if(!m) return;
+    const int sub = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (NH_WL_SUB - 1));
     const int leader = __ffsll((long long)m) - 1;
     int base = 0;
-    if(lane == leader) base = atomicAdd(&WL.count[which], __popcll(m));
+    if(lane == leader) base = atomicAdd(&WL.count[which * NH_WL_SUB + sub], __popcll(m));
     base = __shfl(base, leader);
-    if(want) WL.ids[(size_t)which * WL.stride + base + __popcll(m & ((1ull << lane) - 1ull))] = uid;
+    if(want) WL.ids[((size_t)which * NH_WL_SUB + sub) * WL.cap + base + __popcll(m & ((1ull << lane) - 1ull))] = uid;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -938,10 +942,10 @@ __global__ __launch_bounds__(64) void k_agent_mid(nh_step_params P, nh_nbr NB, c
 
 // ---------------------------------------------------------------------------------------------
 // k_cp: ClearPath for every listed agent, ONE launch.  A unit of work is one wave-list agent (17-64
-// neighbours, the whole wave) or four agents of one row list (a row of 16 lanes each); waves draw
-// units from a ticket counter, heaviest first (wave list, then 9-16, 5-8, 3-4, 1-2 neighbours), so
-// that the long units start at once and the short ones fill the gaps -- the per-agent cost spans
-// three orders of magnitude and a static split leaves most of the chip waiting for a few waves.
+// neighbours, the whole wave) or four agents of one row list (a row of 16 lanes each); the units are
+// numbered heaviest first (wave list, then 9-16, 5-8, 3-4, 1-2 neighbours) and drawn from a ticket
+// counter, so that the long units start at once and the short ones fill the gaps -- the per-agent
+// cost spans three orders of magnitude.
 // ---------------------------------------------------------------------------------------------
 union cp_wave_lds {
     cp_lds<64> w;
@@ -952,42 +956,96 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_cp(nh_step_params P, nh_nbr N
                                                       nh_worklists WL, nh_step_outs O)
 {
     __shared__ cp_wave_lds lds[AG_WAVES];
+    // the work units of the 5 x NH_WL_SUB sub-lists, heaviest list first: unit_end[k] = units of the
+    // sub-lists up to and including k (k = order * NH_WL_SUB + sub; order 0 = the wave list, 1 = the
+    // 9-16 list ... 4 = the 1-2 list)
+    __shared__ int32_t unit_end[5 * NH_WL_SUB];
+    __shared__ int32_t sub_cnt[5 * NH_WL_SUB];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     cp_wave_lds &S = lds[wib];
-    const int n_wave = WL.count[NH_WL_WAVE];
-    int cnt[4], nu[4], total = n_wave;
-#pragma unroll
-    for(int w = 0; w < 4; w++) {               // w = 0: the 9-16 list ... w = 3: the 1-2 list
-        cnt[w] = WL.count[NH_WL_ROW3 - w];
-        nu[w] = (cnt[w] + 3) >> 2;
-        total += nu[w];
+    for(int k = threadIdx.x; k < 5 * NH_WL_SUB; k += AG_WAVES * 64) {
+        const int order = k / NH_WL_SUB, sub = k % NH_WL_SUB;
+        const int list = order == 0 ? NH_WL_WAVE : NH_WL_ROW3 - (order - 1);
+        sub_cnt[k] = WL.count[list * NH_WL_SUB + sub];
     }
-    for(;;) {
-        int u = 0;
-        if(lane == 0) u = atomicAdd(&WL.count[NH_WL_TICKET], 1);
-        u = __shfl(u, 0);
-        if(u >= total) break;
-        int uid = -1, n_dyn = 0, n_stat = 0;
-        const bool wave_unit = u < n_wave;
-        if(wave_unit) {
-            uid = WL.ids[(size_t)NH_WL_WAVE * WL.stride + u];
-        }else{
-            int which = 0, rel = u - n_wave;
-#pragma unroll
-            for(int w = 0; w < 3; w++) if(which == w && rel >= nu[w]) { rel -= nu[w]; which = w + 1; }
-            const int idx = rel * 4 + (lane >> 4);
-            if(idx < cnt[which]) uid = WL.ids[(size_t)(NH_WL_ROW3 - which) * WL.stride + idx];
+    __syncthreads();
+    if(threadIdx.x == 0) {
+        int run = 0;
+        for(int k = 0; k < 5 * NH_WL_SUB; k++) {
+            run += k < NH_WL_SUB ? sub_cnt[k] : (sub_cnt[k] + 3) >> 2;
+            unit_end[k] = run;
         }
-        if(uid < 0) continue;                  // (a row beyond the end of its list)
+    }
+    __syncthreads();
+    const int total = unit_end[5 * NH_WL_SUB - 1];
+    // Units are drawn heaviest first, every wave on its own (no workgroup barrier: a wave that holds a
+    // long unit does not keep its neighbour waiting).  Two ticket counters: the wave units one at a
+    // time -- few, and up to milliseconds each --, then the row units NH_CP_ROW_CHUNK at a time (a
+    // ticket is an atomic on ONE address, ~5 ns each in a row: a ticket per row unit would cost more
+    // than the light units themselves, dealing them out statically left the chip waiting for the
+    // unluckiest waves).
+    const int n_wave_units = unit_end[NH_WL_SUB - 1], n_row_units = total - n_wave_units;
+    int32_t *tickets = WL.count + NH_WL_LISTS * NH_WL_SUB;
+    // the first unit / chunk of every wave is dealt statically (its global wave number), the tickets
+    // count from the number of waves on; a counter that is seen exhausted is not drawn from again
+    const int gw = blockIdx.x * AG_WAVES + wib, nw = gridDim.x * AG_WAVES;
+    int chunk_at = 0, chunk_end = 0;
+    int phase = 0;                                 // 0: first wave unit, 1: wave tickets, 2: first row chunk, 3: row tickets
+    for(;;) {
+        if(chunk_at >= chunk_end) {
+            int t = 0;
+            if(phase == 0) {
+                phase = 1;
+                if(gw < n_wave_units) { chunk_at = gw; chunk_end = gw + 1; }
+            }
+            if(phase == 1 && chunk_at >= chunk_end) {
+                phase = 2;
+                if(nw < n_wave_units && nw + __atomic_load_n(&tickets[0], __ATOMIC_RELAXED) < n_wave_units) {
+                    if(lane == 0) t = atomicAdd(&tickets[0], 1);
+                    t = nw + __builtin_amdgcn_readfirstlane(t);
+                    if(t < n_wave_units) { chunk_at = t; chunk_end = t + 1; phase = 1; }
+                }
+            }
+            if(phase == 2 && chunk_at >= chunk_end) {
+                phase = 3;
+                t = gw * NH_CP_ROW_CHUNK;
+                if(t < n_row_units) { chunk_at = n_wave_units + t; chunk_end = n_wave_units + min(n_row_units, t + NH_CP_ROW_CHUNK); }
+            }
+            if(phase == 3 && chunk_at >= chunk_end) {
+                const int base = nw * NH_CP_ROW_CHUNK;
+                if(!(base < n_row_units && base + __atomic_load_n(&tickets[1], __ATOMIC_RELAXED) < n_row_units)) break;
+                if(lane == 0) t = atomicAdd(&tickets[1], NH_CP_ROW_CHUNK);
+                t = base + __builtin_amdgcn_readfirstlane(t);
+                if(t >= n_row_units) break;
+                chunk_at = n_wave_units + t; chunk_end = n_wave_units + min(n_row_units, t + NH_CP_ROW_CHUNK);
+            }
+        }
+        const int u = chunk_at++;
+        // the sub-list of unit u: first k with unit_end[k] > u
+        int lo = 0, hi = 5 * NH_WL_SUB - 1;
+        while(lo < hi) {
+            const int m = (lo + hi) >> 1;
+            if(unit_end[m] > u) hi = m; else lo = m + 1;
+        }
+        const int k = lo, rel = u - (k ? unit_end[k - 1] : 0);
+        const int order = k / NH_WL_SUB, sub = k % NH_WL_SUB;
+        const bool wave_unit = order == 0;
+        const int list = wave_unit ? NH_WL_WAVE : NH_WL_ROW3 - (order - 1);
+        const int idx = wave_unit ? rel : rel * 4 + (lane >> 4);
+        if(idx >= sub_cnt[k]) continue;         // (a row beyond the end of its sub-list)
+        const int uid = WL.ids[((size_t)list * NH_WL_SUB + sub) * WL.cap + idx];
         const nh_mid_rec R = mid[uid];
         const uint32_t c = NB.cnt[uid];
-        n_dyn = (int)(c & 0xff); n_stat = (int)((c >> 8) & 0xff);
+        const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
         cpent ent;
         ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
         ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
         ent.radius = P.radius[uid];
         v2 nv;
         bool writer;
+#ifdef NH_CP_STATS
+        const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
+#endif
         if(wave_unit) {
             cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S.w);
             nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S.w);
@@ -1000,6 +1058,14 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_cp(nh_step_params P, nh_nbr N
         }
         if(writer)
             post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
+#ifdef NH_CP_STATS
+        if(lane == 0) {
+            const unsigned long long du = __builtin_amdgcn_s_memtime() - tu0;
+            atomicAdd(&nh_cp_cyc[wave_unit ? 5 : 3][5], du);
+            atomicAdd(&nh_cp_cyc[wave_unit ? 5 : 3][6], 1ull);
+            atomicMax(&nh_cp_cyc[wave_unit ? 5 : 3][7], du);
+        }
+#endif
     }
 }
 
@@ -1022,9 +1088,10 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
     wave_lds &W = lds[wib];
     cp_lds<64> &S = cps[wib];
     const nh_grid &G = P.grid;
-    const int count = WL.count[NH_WL_FULL];
+    for(int sub = 0; sub < NH_WL_SUB; sub++) {
+    const int count = WL.count[NH_WL_FULL * NH_WL_SUB + sub];
     for(int idx = blockIdx.x * AG_WAVES + wib; idx < count; idx += gridDim.x * AG_WAVES) {
-        const int uid = WL.ids[(size_t)NH_WL_FULL * WL.stride + idx];
+        const int uid = WL.ids[((size_t)NH_WL_FULL * NH_WL_SUB + sub) * WL.cap + idx];
         const nh_mid_rec R = mid[uid];
         const uint32_t my_slot = (uint32_t)G.pool_of[uid];
         const uint32_t my_bits = slot_bits(G, my_slot);
@@ -1067,6 +1134,7 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
             if(O.vpref_xz) { O.vpref_xz[2 * uid] = vpref.x; O.vpref_xz[2 * uid + 1] = vpref.z; }
             post_thread(P, uid, me, P.state[uid], P.flags[uid], my_radius, nv, R.vel_cap, R.status, O);
         }
+    }
     }
 }
 
@@ -1121,9 +1189,33 @@ extern "C" int navhip_debug_cp_attempts(unsigned long long out[9], int reset)
     return 0;
 }
 
+#ifdef CP_DEBUG
+extern "C" int navhip_debug_read(unsigned long long out[64])
+{
+    if(hipDeviceSynchronize() != hipSuccess) return 1;
+    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_dbg), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[64] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(nh_dbg), z, sizeof(z)) != hipSuccess;
+}
+#endif
+#ifdef NH_CP_STATS
+extern "C" int navhip_debug_cp_work(unsigned long long out[128], int reset)
+{
+    if(hipDeviceSynchronize() != hipSuccess) return 1;
+    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_cp_work), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if(hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(nh_cp_cyc), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if(reset) {
+        unsigned long long z[64] = {0};
+        if(hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_work), z, sizeof(z)) != hipSuccess) return 1;
+        if(hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_cyc), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 __global__ void k_wl_zero(int32_t *count)
 {
-    if(threadIdx.x < NH_WL_COUNT) count[threadIdx.x] = 0;
+    for(int i = threadIdx.x; i < NH_WL_COUNTERS; i += blockDim.x) count[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1265,6 +1357,14 @@ void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *
     coh_regroup(P, C, *parity, false, s);
     *parity ^= 1;
 }
+// entries a sub-list can receive: its producers are the k_agent_mid waves with index = sub (mod
+// NH_WL_SUB), each of which steps 64 / MID_LANES entities
+int nh_worklist_cap(int n_work)
+{
+    const int waves = (n_work * MID_LANES + 63) / 64;
+    return ((waves + NH_WL_SUB - 1) / NH_WL_SUB) * (64 / MID_LANES);
+}
+
 // k_agent_mid + the consumers of its work lists.  The list counters alternate between two sets:
 // a launch sequence uses one and zeroes the other for its successor (no memset on the stream).
 void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
@@ -1275,9 +1375,9 @@ void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     // SCALED_MAX_FORCE and the 1 % force threshold of movement.c:1870-1905 (same for every agent)
     const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
-    int32_t *other = WL.count + (parity ^ 1) * NH_WL_COUNT;
-    WL.count += parity * NH_WL_COUNT;
-    hipLaunchKernelGGL(k_wl_zero, dim3(1), dim3(64), 0, s, other);
+    int32_t *other = WL.count + (parity ^ 1) * NH_WL_COUNTERS;
+    WL.count += parity * NH_WL_COUNTERS;
+    hipLaunchKernelGGL(k_wl_zero, dim3(1), dim3(256), 0, s, other);
     hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
                        d_mid, WL, O, smf, thresh);
     // enough resident waves to fill the chip; every wave keeps drawing units until none are left

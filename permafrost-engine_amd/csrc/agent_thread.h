@@ -226,6 +226,23 @@ NH_FN cpent nbr_cpent(const nh_grid &G, int slot, bool is_static)
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-agent line of sight to the destination (N_HasDestLOS, nav.c:4026, cache-hit path)
+// ---------------------------------------------------------------------------------------------
+NH_FN bool dest_los(const nh_step_params &P, int uid, int flock, uint32_t &status)
+{
+    const uint8_t given = P.has_dest_los[uid];
+    if(given != NAVHIP_LOS_LOOKUP || !P.los_pool || !P.flock_los_slot)
+        return given != 0 && given != NAVHIP_LOS_LOOKUP;
+    if(flock < 0) return false;                       // (compute_los_state: no flock, no LOS)
+    const float *lp = P.los_pos_xz ? P.los_pos_xz : P.pos_xz;
+    tiledesc t;
+    if(!tile_for_point(P, lp[2 * uid], lp[2 * uid + 1], t)) return false;
+    const int slot = P.flock_los_slot[(size_t)flock * (P.map.w * P.map.h) + t.chunk_r * P.map.w + t.chunk_c];
+    if(slot < 0) { status |= NAVHIP_ST_LOS_MISS; return false; }
+    return (P.los_pool[((size_t)slot << 12) + t.tile_r * 64 + t.tile_c] & 1) != 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // steering forces -> preferred velocity
 // ---------------------------------------------------------------------------------------------
 // point_seek_vpref :1870 / enemy_seek_vpref :1946 / cell_arrival_seek_vpref :1908 /
@@ -321,7 +338,7 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
     }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state_uses_point_seek(state)) {
         vdes = load_vdes(P, uid, flock, me, status);
         if(state_uses_point_seek(state)) {
-            const bool los = P.has_dest_los[uid] != 0;
+            const bool los = dest_los(P, uid, flock, status);
             arrive = arrive_force(me, vel, target, vdes, los, max_speed, hz, scaled_max_force);
             mode = AM_POINT_SEEK;
         }else{
@@ -345,7 +362,7 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
                 arrive = desired;
                 mode = AM_FORM_CELL;
             }else{
-                const bool los = P.has_dest_los[uid] != 0;
+                const bool los = dest_los(P, uid, flock, status);
                 // formation_seek: the flock target itself (movement.c:1985-2002)
                 const v2 ftarget = (flock >= 0) ? mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]) : me;
                 arrive = arrive_force(me, vel, ftarget, vdes, los, max_speed, hz, scaled_max_force);

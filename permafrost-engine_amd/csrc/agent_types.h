@@ -66,6 +66,7 @@ struct nh_step_params {
     const uint8_t  *arrival_flags;
     const uint8_t  *los_pool;        // per-agent has_dest_los from the device LOS pool (optional)
     const int32_t  *flock_los_slot;
+    const float    *los_pos_xz;
 };
 
 struct nh_step_outs {
@@ -93,14 +94,17 @@ struct nh_nbr {
 enum { NH_WL_ROW0 = 0, NH_WL_ROW1, NH_WL_ROW2, NH_WL_ROW3,   // a row of 16 lanes per agent: 1-2, 3-4, 5-8, 9-16 neighbours
        NH_WL_WAVE,          // one wave per agent: 17-64 neighbours
        NH_WL_FULL,          // one wave per agent, whole step (irregular gather)
-       NH_WL_LISTS,         // (number of lists)
-       NH_WL_TICKET = NH_WL_LISTS,   // work-unit ticket counter of k_cp
-       NH_WL_COUNT };
+       NH_WL_LISTS };       // (number of lists)
+// Every list is kept as NH_WL_SUB sub-lists, one per group of producer waves (wave index mod
+// NH_WL_SUB): an append is one atomic per wave and list, and a few thousand atomics on ONE address
+// serialise at ~5 ns each (measured: they were most of k_agent_mid's time).
+#define NH_WL_SUB 64
 struct nh_worklists {
-    int32_t *count;            // [NH_WL_COUNT] (+ [NH_WL_COUNT] of the other parity, see nh_launch_*)
-    int32_t *ids;              // [NH_WL_LISTS][stride] uids
-    int      stride;
+    int32_t *count;            // [NH_WL_LISTS][NH_WL_SUB] entries + [2] tickets (+ the same again: other parity)
+    int32_t *ids;              // [NH_WL_LISTS][NH_WL_SUB][cap] uids
+    int      cap;              // entries a sub-list can hold (its producers cannot append more)
 };
+#define NH_WL_COUNTERS (NH_WL_LISTS * NH_WL_SUB + 2)
 
 // per-entity record k_agent_mid leaves for the list consumers (32 bytes, indexed by uid)
 struct nh_mid_rec {

@@ -717,12 +717,13 @@ static int step_scratch(navhip_ctx *ctx, int n_ents, nh_nbr *NB, nh_worklists *W
     if(!rc) rc = ensure_zeroed(ctx, ctx->nbr[1], 4 * n, s);
     if(!rc) rc = ensure_buf(ctx, ctx->nbr[2], 4 * 64 * n);
     if(!rc) rc = ensure_buf(ctx, ctx->midrec, sizeof(nh_mid_rec) * n);
-    if(!rc) rc = ensure_zeroed(ctx, ctx->wl[0], 4 * 2 * NH_WL_COUNT, s);
-    if(!rc) rc = ensure_buf(ctx, ctx->wl[1], 4 * (size_t)NH_WL_COUNT * n);
+    const int cap = nh_worklist_cap(n_ents);
+    if(!rc) rc = ensure_zeroed(ctx, ctx->wl[0], 4 * 2 * NH_WL_COUNTERS, s);
+    if(!rc) rc = ensure_buf(ctx, ctx->wl[1], 4 * (size_t)NH_WL_LISTS * NH_WL_SUB * cap);
     if(rc) return rc;
     NB->sep = (float2*)ctx->nbr[0].p; NB->cnt = (uint32_t*)ctx->nbr[1].p; NB->list = (int32_t*)ctx->nbr[2].p;
     NB->stride = n_ents;
-    WL->count = (int32_t*)ctx->wl[0].p; WL->ids = (int32_t*)ctx->wl[1].p; WL->stride = n_ents;
+    WL->count = (int32_t*)ctx->wl[0].p; WL->ids = (int32_t*)ctx->wl[1].p; WL->cap = cap;
     return NAVHIP_OK;
 }
 
@@ -776,6 +777,8 @@ static int step_fill_params(navhip_ctx *ctx, const navhip_world *w, nh_step_para
     P.form_cohesion_xz = w->form_cohesion_xz; P.form_align_xz = w->form_align_xz;
     P.form_drag_xz = w->form_drag_xz;
     P.arrival_sink_xz = w->arrival_sink_xz; P.arrival_flags = w->arrival_flags;
+    P.los_pool = w->los_pool; P.flock_los_slot = w->flock_los_slot; P.los_pos_xz = w->los_pos_xz;
+    if((P.los_pool != nullptr) != (P.flock_los_slot != nullptr)) return NAVHIP_ERR_INVALID;
     if(P.form_ready && (!P.cell_pos_xz || !P.form_cohesion_xz || !P.form_align_xz || !P.form_drag_xz)) {
         ctx->last_error = "agent step: form_ready given without the other formation arrays";
         return NAVHIP_ERR_INVALID;
@@ -958,8 +961,13 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
     if(!ctx || !out_counts || !ctx->wl[0].p) return NAVHIP_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());
-    const int32_t *src = (const int32_t*)ctx->wl[0].p + (ctx->wl_parity ^ 1) * NH_WL_COUNT;
-    HIPCHK(ctx, hipMemcpy(out_counts, src, sizeof(int32_t) * NH_WL_LISTS, hipMemcpyDeviceToHost));
+    const int32_t *src = (const int32_t*)ctx->wl[0].p + (ctx->wl_parity ^ 1) * NH_WL_COUNTERS;
+    int32_t h[NH_WL_COUNTERS];
+    HIPCHK(ctx, hipMemcpy(h, src, sizeof(h), hipMemcpyDeviceToHost));
+    for(int l = 0; l < NH_WL_LISTS; l++) {
+        out_counts[l] = 0;
+        for(int sb = 0; sb < NH_WL_SUB; sb++) out_counts[l] += h[l * NH_WL_SUB + sb];
+    }
     return NAVHIP_OK;
 }
 
@@ -998,6 +1006,8 @@ static int stage_world(navhip_ctx *ctx, const navhip_world *w, navhip_world *d, 
     ST(24, form_ready, n);       ST(25, cell_pos_xz, n * 8); ST(26, form_cohesion_xz, n * 8);
     ST(27, form_align_xz, n * 8); ST(28, form_drag_xz, n * 8);
     ST(36, arrival_sink_xz, n * 8); ST(37, arrival_flags, n);
+    ST(38, los_pool, (size_t)(w->n_los_slots > 0 ? w->n_los_slots : 0) * NH_CELLS);
+    ST(39, flock_los_slot, F * nchunks * 4); ST(40, los_pos_xz, n * 8);
 #undef ST
     return rc;
 }

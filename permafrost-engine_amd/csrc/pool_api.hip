@@ -377,6 +377,9 @@ int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhi
         {w->form_drag_xz, n * 8, 28, (const void**)&d.form_drag_xz},
         {w->arrival_sink_xz, n * 8, 36, (const void**)&d.arrival_sink_xz},
         {w->arrival_flags, n, 37, (const void**)&d.arrival_flags},
+        {w->los_pool, (size_t)(w->n_los_slots > 0 ? w->n_los_slots : 0) * NH_CELLS, 38, (const void**)&d.los_pool},
+        {w->flock_los_slot, F * (size_t)ctx->nchunks * 4, 39, (const void**)&d.flock_los_slot},
+        {w->los_pos_xz, n * 8, 40, (const void**)&d.los_pos_xz},
     };
     if(!resident) {
         items.push_back({w->flock_field_slot, F * (size_t)ctx->nchunks * 4, 13, (const void**)&d.flock_field_slot});

@@ -294,7 +294,8 @@ ENTITY_FLAG_WATER = 1 << 14
 ENTITY_FLAG_AIR = 1 << 15
 ENTITY_FLAG_GARRISONED = 1 << 18
 ENTITY_FLAG_COMBAT_HELD = 1 << 21
-ST_MOVED, ST_FIELD_MISS, ST_FIELD_NONE, ST_UNSUPPORTED = 0x01, 0x02, 0x04, 0x80
+ST_MOVED, ST_FIELD_MISS, ST_FIELD_NONE, ST_LOS_MISS, ST_UNSUPPORTED = 0x01, 0x02, 0x04, 0x08, 0x80
+LOS_LOOKUP = 0xFF
 
 
 class World(C.Structure):
@@ -312,7 +313,9 @@ class World(C.Structure):
         ("grid_zmax", C.c_float), ("work_begin", C.c_int32), ("work_end", C.c_int32),
         ("form_ready", C.c_void_p), ("cell_pos_xz", C.c_void_p), ("form_cohesion_xz", C.c_void_p),
         ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p),
-        ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p)]
+        ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p),
+        ("los_pool", C.c_void_p), ("flock_los_slot", C.c_void_p), ("los_pos_xz", C.c_void_p),
+        ("n_los_slots", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class StepOut(C.Structure):
@@ -360,7 +363,8 @@ _WORLD_ARRAYS = (
     ("flock_target_xz", np.float32), ("flock_offsets", np.int32), ("flock_members", np.int32),
     ("flock_field_slot", np.int32), ("field_pool", np.uint8), ("form_ready", np.uint8),
     ("cell_pos_xz", np.float32), ("form_cohesion_xz", np.float32), ("form_align_xz", np.float32),
-    ("form_drag_xz", np.float32), ("arrival_sink_xz", np.float32), ("arrival_flags", np.uint8))
+    ("form_drag_xz", np.float32), ("arrival_sink_xz", np.float32), ("arrival_flags", np.uint8),
+    ("los_pool", np.uint8), ("flock_los_slot", np.int32), ("los_pos_xz", np.float32))
 
 
 def flock_csr(flock, n_flocks, order=None):
@@ -403,6 +407,8 @@ def make_world(chunk_w, chunk_h, arrays, hz=20, xp=None):
             setattr(w, name, a.ctypes.data)
     fp = arrays.get("field_pool")
     w.n_field_slots = 0 if fp is None else int(fp.shape[0])
+    lp = arrays.get("los_pool")
+    w.n_los_slots = 0 if lp is None else int(lp.shape[0])
     w.map_pos_x = chunk_w * 128.0
     w.map_pos_z = -chunk_h * 128.0
     w.grid_xmin, w.grid_xmax, w.grid_zmin, w.grid_zmax = grid_bounds(chunk_w, chunk_h)
