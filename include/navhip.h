@@ -450,6 +450,11 @@ int  navhip_clearpath(navhip_ctx *ctx, int nq, const float *ent, const float *de
 int  navhip_clearpath_rows(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
                            const float *dyn, const int32_t *n_dyn, const float *stat,
                            const int32_t *n_stat, float *out);
+/* The same problems, each searched by the waves of one workgroup as a team -- the form the agent step
+ * uses for agents with 17..64 ClearPath neighbours. */
+int  navhip_clearpath_team(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                           const float *dyn, const int32_t *n_dyn, const float *stat,
+                           const int32_t *n_stat, float *out);
 
 #ifdef __cplusplus
 }

@@ -18,13 +18,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wave_sync()
 {
-#ifdef CP_STRONG_SYNC
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    asm volatile("" ::: "memory");
-#else
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -273,6 +267,9 @@ template <int G> struct cp_lds {
     float   ckey[2 * G];             // key of every ray: a lower bound of the distance of its candidates to des_v
     int32_t tau[G], seq[G];          // cp_jump: removal time of every cone, the removal sequence
     float   dyn[(G < 32 ? G : 32) * 5], stat[(G < 32 ? G : 32) * 5];
+#ifdef NH_CP_UNIT_HIST
+    int32_t dbg[4];                  // developer instrumentation: attempts, jump result, rays
+#endif
 };
 
 // compute_vnew :368 keeps the first strictly-smaller distance in candidate order, i.e. the minimum
@@ -294,15 +291,6 @@ template <int G> struct cp_lds {
 // reference's `vec_size(&xpoints) == 0` asks); until then every candidate is tested, so that points
 // whose distance is NaN or infinite still count.
 struct cp_bound { float len; int idx; v2 pt; int nfound; int sb; };
-#ifdef CP_DEBUG
-__device__ unsigned long long nh_dbg[64];
-#define DBG_ON (blockIdx.x == 0 && threadIdx.x / G == 1 && grp<G>::lane() == 0)
-#define DBG_SET(k, v) do { if(DBG_ON) nh_dbg[k] = (unsigned long long)(long long)(v); } while(0)
-#define DBG_ADD(k, v) do { if(DBG_ON) nh_dbg[k] += (unsigned long long)(long long)(v); } while(0)
-#else
-#define DBG_SET(k, v)
-#define DBG_ADD(k, v)
-#endif
 #define CP_COL_MARGIN 0.02f
 
 __device__ __forceinline__ bool cp_alive(const cp_bound &B, float len, int idx)
@@ -357,9 +345,7 @@ __device__ void cp_work(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp
             if(in) L.ci = -1;
             else if(L.ci >= n_cones) { outside = true; L.ci = -1; }
         }
-        DBG_ADD(3, 1);
         if(g::any(outside)) {
-            DBG_ADD(4, 1);
             float key = (outside && L.len == L.len) ? L.len : __builtin_inff();    // a NaN distance never wins
             int ki = outside ? L.idx : 0x7fffffff;
             const float mykey = key; const int myidx = ki;
@@ -392,7 +378,6 @@ __device__ __forceinline__ void cp_push(cp_lds<G> &S, const cpent &ent, int n_co
         S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = idx; S.ql[at] = len;
     }
     qn += __popcll(mk);
-    DBG_ADD(2, __popcll(mk));
     CP_STAT(B.sb, 3, __popcll(mk));
     wave_sync();
     if(qn >= G) cp_work<G>(S, ent, n_cones, qn, L, B, false);
@@ -419,9 +404,11 @@ __device__ unsigned long long nh_cp_attempts[9];
 // outlives the best start so far contains it).  Returns that attempt number (the caller replays so
 // many removals from S.seq and runs ONE ordinary attempt, which finds the admissible point and
 // breaks ties exactly as the reference does), or -1: no attempt succeeds before a list runs empty.
+// (part / nparts: this group's share of the candidates when a team searches; the team's answer is
+// the minimum of the shares' results, BIG standing for "none")
 template <int G>
 __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool isdyn, int k, bool use,
-                       int slot, float dist, int n_dyn, int n_stat, int n_cones)
+                       int slot, float dist, int n_dyn, int n_stat, int n_cones, int part, int nparts)
 {
     typedef grp<G> g;
     const int gl = g::lane();
@@ -473,7 +460,7 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
     const float inv_nr = 1.0f / (float)n_rays;
     int qn = 0;
     v2 l_pt = mkv(0, 0); int l_end = 0, l_ci = -1;         // l_ci < 0: this lane holds no candidate
-    for(int c0 = 0; c0 < n_rays + npairs || qn > 0 || g::any(l_ci >= 0); c0 += G) {
+    for(int c0 = part * G; c0 < n_rays + npairs || qn > 0 || g::any(l_ci >= 0); c0 += nparts * G) {
         // generate (projections first, then the ordered pairs)
         const int c = c0 + gl;
         bool ok = false;
@@ -513,7 +500,7 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
         }
         qn += __popcll(mk);
         wave_sync();
-        const bool gen_done = c0 + G >= n_rays + npairs || cur <= 1;
+        const bool gen_done = c0 + nparts * G >= n_rays + npairs || cur <= 1;
         if(qn < G && !gen_done) continue;
         // work the queue off (persistent lanes, one cone test per busy lane and iteration)
         int head = 0;
@@ -561,9 +548,43 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
     return cur < t_end ? cur : -1;
 }
 
-// S.dyn / S.stat hold the neighbours (n_dyn + n_stat <= G, each <= 32).
+
+// One problem searched by a TEAM: the waves of a workgroup (k_cp_heavy).  Every wave builds the same
+// cones and the same column order in its own LDS copy, tests the projections, and takes the columns
+// part, part + nparts, ... of that order with a bound of its own; the minima of (distance, order
+// index) over the waves' admissible candidates combine to exactly the single-group result (team_min).
+// Everything after that is decided on the combined result, so the waves stay in step: the retry
+// shortcut (cp_jump over the waves' shares of the candidates, minimum of the start times), the replay
+// of the removals (every wave on its own copy) and the attempt that succeeds, again shared.
+// The exchange goes through cp_team in LDS, two workgroup barriers per combine.
+#ifndef CP_TEAM_MAX
+#define CP_TEAM_MAX 4
+#endif
+struct cp_team { cp_bound B[CP_TEAM_MAX]; int t[CP_TEAM_MAX]; };
+
 template <int G>
-__device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, cp_lds<G> &S)
+__device__ __forceinline__ void team_min(cp_bound &B, cp_team &T, int part, int nparts)
+{
+    if(grp<G>::lane() == 0) T.B[part] = B;
+    __syncthreads();
+    cp_bound best = T.B[0];
+    int nfound = best.nfound;
+    for(int w = 1; w < nparts; w++) {
+        const cp_bound o = T.B[w];
+        nfound += o.nfound;
+        if(o.len < best.len || (o.len == best.len && o.idx < best.idx)) best = o;
+    }
+    best.nfound = nfound;
+    B = best;
+    __syncthreads();
+}
+
+// S.dyn / S.stat hold the neighbours (n_dyn + n_stat <= G, each <= 32).
+//   TEAM   every wave of the workgroup calls this with the same problem in its own S, part = its wave
+//          number, nparts = the waves of the workgroup, T = the team's exchange area
+template <int G, bool TEAM = false>
+__device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, cp_lds<G> &S,
+                            int part = 0, int nparts = 1, cp_team *T = nullptr)
 {
     typedef grp<G> g;
     if(n_dyn + n_stat == 0) return des_v;          // no obstacle: inside_pcr of nothing is false
@@ -572,6 +593,9 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
     bool jumped = false;
     // at most 64 neighbours can be removed; the bound only guards against a NaN-poisoned input
     for(int guard = 0; guard < 66; guard++) {
+#ifdef NH_CP_UNIT_HIST
+        if(gl == 0) { S.dbg[0] = guard; if(guard == 0) S.dbg[1] = -2; }
+#endif
         CP_T0();
 #ifdef NH_CP_STATS
         const int sb_ = cp_bucket(n_dyn + n_stat);
@@ -619,7 +643,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         if(gl < n_cones) in = cone_contains(S.cones[2 * gl], S.cones[2 * gl + 1], des_ws);
         CP_TMARK(sb_, 0);
         if(!g::any(in)) {
-            if(gl == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
+            if(gl == 0 && part == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
             return des_v;
         }
 
@@ -653,7 +677,6 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         cp_work<G>(S, ent, n_cones, qn, L, B, true);
 
         CP_TMARK(sb_, 1);
-        DBG_SET(0, n_rays); DBG_SET(1, B.nfound); DBG_SET(8, guard);
         // ---- the ray pairs (:321; order index i * n_rays + j), column by column, NEAREST LINE FIRST:
         // a column's candidates all lie on its line, so its key -- the distance of des_v to that line,
         // less the margins -- bounds them from below.  Columns are visited in ascending key; the search
@@ -690,11 +713,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                         const float kk = S.ckey[k];
                         rank += (kk < mykey[h] || (kk == mykey[h] && k < j)) ? 1 : 0;
                     }
-#ifdef CP_NO_SORT
-                    S.col[j] = j;
-#else
                     S.col[rank] = j;
-#endif
                 }
             }
             wave_sync();
@@ -703,15 +722,12 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
             // columns per batch: about four passes of candidates
             const int kb = max(1, (4 * G) / n_rays);
             const float inv_nr = 1.0f / (float)n_rays;
+            const int n_mine = (n_rays - part + nparts - 1) / nparts;      // columns part, part + nparts, ...
             int jdone = 0;
-            while(jdone < n_rays) {
-#ifndef CP_NO_EARLY_BREAK
-                if(B.nfound && S.ckey[S.col[jdone]] > B.len) break;
-#endif
-                const int ncol = min(kb, n_rays - jdone);
+            while(jdone < n_mine) {
+                if(B.nfound && S.ckey[S.col[jdone * nparts + part]] > B.len) break;
+                const int ncol = min(kb, n_mine - jdone);
                 const int ncand = ncol * n_rays;
-                DBG_SET(6, ncand); DBG_SET(7, kb); DBG_ADD(9, 1);
-                for(int z = 0; z < 8; z++) { DBG_SET(16 + z, S.col[z]); DBG_SET(24 + z, __float_as_int(S.ckey[z])); }
                 CP_STAT(B.sb, 6, ncol);
                 CP_STAT(B.sb, 2, ncand);
                 for(int c0 = 0; c0 < ncand; c0 += G) {
@@ -726,7 +742,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                         int i = c - cj * n_rays;
                         if(i < 0) { cj--; i += n_rays; }
                         if(i >= n_rays) { cj++; i -= n_rays; }
-                        const int j = S.col[jdone + cj];
+                        const int j = S.col[(jdone + cj) * nparts + part];
                         idx = i * n_rays + j;
                         if(i != j) {
                             const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
@@ -747,10 +763,10 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
             }
             cp_work<G>(S, ent, n_cones, qn, L, B, true);
         }
+        if(TEAM) team_min<G>(B, *T, part, nparts);
         CP_TMARK(sb_, 2);
-        DBG_SET(5, B.nfound); DBG_SET(10, __float_as_int(B.len));
         if(B.nfound) {
-            if(gl == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
+            if(gl == 0 && part == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
             return B.pt;                   // (only NaN / infinite distances: ret stays 0, as :368-386)
         }
 
@@ -760,10 +776,21 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         if(!jumped) {
             // the first failure: find the attempt that will succeed and go there in one step
             jumped = true;
-            const int t = cp_jump<G>(S, ent, des_v, have, isdyn, k, use, slot, dist, n_dyn, n_stat, n_cones);
+            int t = cp_jump<G>(S, ent, des_v, have, isdyn, k, use, slot, dist, n_dyn, n_stat, n_cones, part, nparts);
+            if(TEAM) {
+                if(gl == 0) T->t[part] = t < 0 ? (1 << 20) : t;
+                __syncthreads();
+                t = T->t[0];
+                for(int w = 1; w < nparts; w++) t = min(t, T->t[w]);
+                if(t >= (1 << 20)) t = -1;
+                __syncthreads();
+            }
+#ifdef NH_CP_UNIT_HIST
+            if(gl == 0) { S.dbg[1] = t; S.dbg[2] = n_rays; }
+#endif
             CP_TMARK(sb_, 3);
             if(t < 0) {
-                if(gl == 0) { atomicAdd(&nh_cp_attempts[0], 1ull); atomicAdd(&nh_cp_attempts[8], 2ull); }
+                if(gl == 0 && part == 0) { atomicAdd(&nh_cp_attempts[0], 1ull); atomicAdd(&nh_cp_attempts[8], 2ull); }
                 return mkv(0.0f, 0.0f);
             }
             wave_sync();
@@ -792,7 +819,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         wave_sync();
         if(nk < __builtin_inff()) { if(ni < n_dyn) n_dyn--; else n_stat--; }
         if(!(n_dyn > 0 && n_stat > 0)) {
-            if(gl == 0) { atomicAdd(&nh_cp_attempts[0], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
+            if(gl == 0 && part == 0) { atomicAdd(&nh_cp_attempts[0], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
             return mkv(0.0f, 0.0f);
         }
     }

@@ -26,13 +26,16 @@ void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hi
 // (nh_launch_cohesion_regroup, after the caller's "cohesion done" event)
 bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, int *parity, hipStream_t s);
 void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *parity, hipStream_t s);
-// k_agent_mid -> k_cp -> k_agent_full; WL.count holds 2 * NH_WL_COUNTERS counters
+// k_agent_mid -> k_cp_heavy | k_cp_rows -> k_agent_full; WL.count holds 2 * NH_WL_COUNTERS counters.
+// side / ev (or null): a second stream for the workgroup problems, two events
 int nh_worklist_cap(int n_work);
 void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
-                            nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s);
+                            nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
+                            hipStream_t side, hipEvent_t ev[2]);
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,
                              int32_t *d_counts, uint32_t *d_ids, hipStream_t s);
-// rows != 0: one row of 16 lanes per problem (n_dyn + n_stat <= 16), else one wave per problem
+// rows = 1: one row of 16 lanes per problem (n_dyn + n_stat <= 16); 2: a team of waves per problem (a
+// workgroup); 0: one wave per problem
 void nh_launch_clearpath(int nq, const float *ent, const float *des_v, const float *dyn,
                          const int32_t *n_dyn, const float *stat, const int32_t *n_stat, float *out,
                          int rows, hipStream_t s);

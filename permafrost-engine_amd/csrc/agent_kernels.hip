@@ -27,11 +27,13 @@
 //   k_agent_mid   one THREAD per entity: the scalar chain -- flow sampling, arrive force, priority
 //                 ladder -> preferred velocity.  Agents without ClearPath neighbours are truncated +
 //                 position-tested here; the rest go to device-side work lists by neighbour count.
-//   k_cp          ClearPath for the listed agents: a ROW of 16 lanes per agent with 1..16 neighbours,
-//                 a whole WAVE per agent with 17..64 (a crowd); lanes spread over cones / ray pairs,
-//                 branch and bound on the distance to des_v, a candidate queue, a lexicographic
-//                 arg-min that reproduces the reference's first-wins rule; work units numbered
-//                 heaviest first and dealt out round robin.
+//   k_cp_rows / k_cp_heavy
+//                 ClearPath for the listed agents: a ROW of 16 lanes per agent with 1..16 neighbours,
+//                 a WORKGROUP per agent with 17..64 (a crowd: its waves share the ray pairs); lanes
+//                 spread over cones / ray pairs, branch and bound on the distance to des_v, a
+//                 candidate queue, a lexicographic arg-min that reproduces the reference's first-wins
+//                 rule; work units numbered heaviest first, drawn by tickets.  The two launches run
+//                 side by side on two streams.
 //   k_agent_full  one WAVE per listed agent, the whole step (irregular gathers: garrisoned
 //                 neighbours, wide queries).
 #include "navhip_internal.h"
@@ -745,9 +747,6 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
 // ---------------------------------------------------------------------------------------------
 // waves (= agents) per workgroup of the wave-per-agent kernels; 2 measured best for the round-1
 // k_agent_step (1: 0.490, 2: 0.483, 4: 0.494, 8: 0.521 ms/tick in one session)
-#ifndef NH_CP_ROW_CHUNK
-#define NH_CP_ROW_CHUNK 4
-#endif
 #ifndef AG_WAVES
 #define AG_WAVES 2
 #endif
@@ -941,99 +940,173 @@ __global__ __launch_bounds__(64) void k_agent_mid(nh_step_params P, nh_nbr NB, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_cp: ClearPath for every listed agent, ONE launch.  A unit of work is one wave-list agent (17-64
-// neighbours, the whole wave) or four agents of one row list (a row of 16 lanes each); the units are
-// numbered heaviest first (wave list, then 9-16, 5-8, 3-4, 1-2 neighbours) and drawn from a ticket
-// counter, so that the long units start at once and the short ones fill the gaps -- the per-agent
-// cost spans three orders of magnitude.
+// ClearPath for every listed agent: two launches by problem size (the per-agent cost spans three
+// orders of magnitude; one kernel for all needed the registers of the largest and the LDS of each),
+// side by side on two streams.
 // ---------------------------------------------------------------------------------------------
-union cp_wave_lds {
-    cp_lds<64> w;
-    cp_lds<16> r[4];
-};
+#ifdef NH_CP_UNIT_HIST
+// developer instrumentation (scripts/cp_unit_hist.py): unit durations of the last launches in
+// s_memtime ticks, log2 buckets, [0] workgroup problems / [2] row units;
+// [3][8 k + 2..4] = summed lifetimes of all waves, waves, the longest lifetime of kernel k (0 heavy,
+// 2 rows)
+__device__ unsigned long long nh_cp_hist[4][32];
+#endif
+#ifndef CP_WAVES
+#define CP_WAVES 4
+#endif
 
-__global__ __launch_bounds__(AG_WAVES * 64) void k_cp(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                      nh_worklists WL, nh_step_outs O)
+// first k with end[k] > u
+__device__ __forceinline__ int first_above(const int32_t *end, int n, int u)
 {
-    __shared__ cp_wave_lds lds[AG_WAVES];
-    // the work units of the 5 x NH_WL_SUB sub-lists, heaviest list first: unit_end[k] = units of the
-    // sub-lists up to and including k (k = order * NH_WL_SUB + sub; order 0 = the wave list, 1 = the
-    // 9-16 list ... 4 = the 1-2 list)
-    __shared__ int32_t unit_end[5 * NH_WL_SUB];
-    __shared__ int32_t sub_cnt[5 * NH_WL_SUB];
-    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    cp_wave_lds &S = lds[wib];
-    for(int k = threadIdx.x; k < 5 * NH_WL_SUB; k += AG_WAVES * 64) {
-        const int order = k / NH_WL_SUB, sub = k % NH_WL_SUB;
-        const int list = order == 0 ? NH_WL_WAVE : NH_WL_ROW3 - (order - 1);
-        sub_cnt[k] = WL.count[list * NH_WL_SUB + sub];
+    int lo = 0, hi = n - 1;
+    while(lo < hi) {
+        const int m = (lo + hi) >> 1;
+        if(end[m] > u) hi = m; else lo = m + 1;
     }
+    return lo;
+}
+
+// Drawing work units, every wave on its own (no workgroup barrier: a wave that holds a long unit does
+// not keep its neighbours waiting).  The units are numbered heaviest first.  All but the last one to
+// two rounds are dealt out statically -- wave w takes units w, w + nw, ... : every wave gets the same
+// mix of heavy and light ones, and no atomics --; the rest, the lightest units, are drawn by ticket and
+// fill the gaps the uneven ones left.  Ticket unit v belongs to stripe v % NH_CP_STRIPES; a wave draws
+// from its stripe's counter (one unit per ticket) and moves on to the next stripe when one is
+// exhausted.  (One counter for everything was an atomic on ONE address per unit, ~5 ns each in a row,
+// and two memory round trips before every unit -- more than the light units themselves cost; purely
+// static dealing left the chip waiting for the unluckiest waves.)  The stripes' counters lie in
+// separate 128-byte lines; a counter seen exhausted by a plain load is not drawn from again.
+// Returns -1 when nothing is left.
+struct unit_draw { int stripe, abandoned, round; };
+__device__ __forceinline__ int next_unit(unit_draw &D, int32_t *counters, int total, int gw, int nw, int lane)
+{
+    const int static_rounds = max(0, total / nw - 1);
+    const int r = D.round++;
+    if(r < static_rounds) return gw + r * nw;
+    if(r == static_rounds) { D.stripe = gw % NH_CP_STRIPES; D.abandoned = 0; }
+    const int first = static_rounds * nw, rest = total - first;       // ticket units: first .. total-1
+    while(D.abandoned < NH_CP_STRIPES) {
+        const int st = D.stripe;
+        const int n_s = st < rest ? (rest - st + NH_CP_STRIPES - 1) / NH_CP_STRIPES : 0;
+        int32_t *cnt = counters + 32 * st;
+        if(__atomic_load_n(cnt, __ATOMIC_RELAXED) < n_s) {
+            int t = 0;
+            if(lane == 0) t = atomicAdd(cnt, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if(t < n_s) return first + t * NH_CP_STRIPES + st;
+        }
+        D.stripe = (st + 1) % NH_CP_STRIPES;
+        D.abandoned++;
+    }
+    return -1;
+}
+
+#ifdef NH_CP_UNIT_HIST
+#define HIST_T0() const unsigned long long hist_t0 = __builtin_amdgcn_s_memtime()
+#define HIST_UNIT(cls, t0) do { if((threadIdx.x & 63) == 0) atomicAdd(&nh_cp_hist[cls][63 - __builtin_clzll((__builtin_amdgcn_s_memtime() - (t0)) | 1ull)], 1ull); } while(0)
+#define HIST_WAVE(k) do { if((threadIdx.x & 63) == 0) { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - hist_t0; \
+    atomicAdd(&nh_cp_hist[3][8 * (k) + 2], d_); atomicAdd(&nh_cp_hist[3][8 * (k) + 3], 1ull); atomicMax(&nh_cp_hist[3][8 * (k) + 4], d_); } } while(0)
+#else
+#define HIST_T0()
+#define HIST_UNIT(cls, t0)
+#define HIST_WAVE(k)
+#endif
+
+// ---- k_cp_rows: the four row lists (1-16 neighbours), a row of 16 lanes per agent, four agents per
+// unit, the units numbered heaviest list first (9-16, 5-8, 3-4, 1-2 neighbours) ---------------------
+__global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                           nh_worklists WL, nh_step_outs O)
+{
+    __shared__ cp_lds<16> lds[CP_WAVES * 4];
+    // unit_end[k] = units of the sub-lists up to and including k (k = order * NH_WL_SUB + sub)
+    __shared__ int32_t unit_end[4 * NH_WL_SUB];
+    __shared__ int32_t sub_cnt[4 * NH_WL_SUB];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for(int k = threadIdx.x; k < 4 * NH_WL_SUB; k += CP_WAVES * 64)
+        sub_cnt[k] = WL.count[(NH_WL_ROW3 - k / NH_WL_SUB) * NH_WL_SUB + k % NH_WL_SUB];
     __syncthreads();
     if(threadIdx.x == 0) {
         int run = 0;
-        for(int k = 0; k < 5 * NH_WL_SUB; k++) {
-            run += k < NH_WL_SUB ? sub_cnt[k] : (sub_cnt[k] + 3) >> 2;
-            unit_end[k] = run;
+        for(int k = 0; k < 4 * NH_WL_SUB; k++) { run += (sub_cnt[k] + 3) >> 2; unit_end[k] = run; }
+    }
+    __syncthreads();
+    HIST_T0();
+    const int total = unit_end[4 * NH_WL_SUB - 1];
+    int32_t *counters = WL.count + NH_WL_LISTS * NH_WL_SUB + 32;
+    const int gw = blockIdx.x * CP_WAVES + wib, nw = gridDim.x * CP_WAVES;
+    cp_lds<16> &S = lds[wib * 4 + (lane >> 4)];
+    unit_draw D; D.round = 0;
+    for(;;) {
+        const int u = next_unit(D, counters, total, gw, nw, lane);
+        if(u < 0) break;
+        const int k = first_above(unit_end, 4 * NH_WL_SUB, u), rel = u - (k ? unit_end[k - 1] : 0);
+        const int list = NH_WL_ROW3 - k / NH_WL_SUB, sub = k % NH_WL_SUB;
+        const int idx = rel * 4 + (lane >> 4);
+#ifdef NH_CP_UNIT_HIST
+        const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
+#endif
+        if(idx < sub_cnt[k]) {                  // (else: a row beyond the end of its sub-list)
+            const int uid = WL.ids[((size_t)list * NH_WL_SUB + sub) * WL.cap + idx];
+            const nh_mid_rec R = mid[uid];
+            const uint32_t c = NB.cnt[uid];
+            const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+            cpent ent;
+            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+            ent.radius = P.radius[uid];
+            cp_load_lists<16>(P.grid, NB, uid, n_dyn, n_stat, S);
+            const v2 nv = clearpath_grp<16>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S);
+            if((lane & 15) == 0)
+                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
+        }
+        HIST_UNIT(2, tu0);
+    }
+    HIST_WAVE(2);
+}
+
+// ---- k_cp_heavy: the heavy list (33-64 neighbours), then the wave list (17-32), one problem per
+// WORKGROUP.  A search of up to 16 000 ray pairs on one wave takes hundreds of microseconds -- as long
+// as everything else of the tick --, and even among problems of 20-30 neighbours the cost spreads
+// over a factor of ten (how early an admissible candidate turns up decides how much is pruned): the
+// waves of the workgroup search a problem as a team (clearpath_grp<64, true>), so that no single
+// problem outlasts the launch.  The first problem of a workgroup is its block number,
+// then one ticket per workgroup and problem. ---
+__global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                            nh_worklists WL, nh_step_outs O)
+{
+    __shared__ cp_lds<64> lds[CP_WAVES];
+    __shared__ int32_t hv_end[2 * NH_WL_SUB];       // sub-lists of the heavy list, then of the wave list
+    __shared__ int32_t h_ticket;
+    __shared__ cp_team team;
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if(threadIdx.x == 0) {
+        int run = 0;
+        for(int k = 0; k < 2 * NH_WL_SUB; k++) {
+            run += WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB];
+            hv_end[k] = run;
         }
     }
     __syncthreads();
-    const int total = unit_end[5 * NH_WL_SUB - 1];
-    // Units are drawn heaviest first, every wave on its own (no workgroup barrier: a wave that holds a
-    // long unit does not keep its neighbour waiting).  Two ticket counters: the wave units one at a
-    // time -- few, and up to milliseconds each --, then the row units NH_CP_ROW_CHUNK at a time (a
-    // ticket is an atomic on ONE address, ~5 ns each in a row: a ticket per row unit would cost more
-    // than the light units themselves, dealing them out statically left the chip waiting for the
-    // unluckiest waves).
-    const int n_wave_units = unit_end[NH_WL_SUB - 1], n_row_units = total - n_wave_units;
-    int32_t *tickets = WL.count + NH_WL_LISTS * NH_WL_SUB;
-    // the first unit / chunk of every wave is dealt statically (its global wave number), the tickets
-    // count from the number of waves on; a counter that is seen exhausted is not drawn from again
-    const int gw = blockIdx.x * AG_WAVES + wib, nw = gridDim.x * AG_WAVES;
-    int chunk_at = 0, chunk_end = 0;
-    int phase = 0;                                 // 0: first wave unit, 1: wave tickets, 2: first row chunk, 3: row tickets
-    for(;;) {
-        if(chunk_at >= chunk_end) {
-            int t = 0;
-            if(phase == 0) {
-                phase = 1;
-                if(gw < n_wave_units) { chunk_at = gw; chunk_end = gw + 1; }
+    HIST_T0();
+    const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
+    int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
+    cp_lds<64> &S = lds[wib];
+    for(int round = 0; ; round++) {
+        int t = blockIdx.x;
+        if(round > 0) {
+            __syncthreads();
+            if(threadIdx.x == 0) {
+                int v = 0x7fffffff;
+                if((int)gridDim.x + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy)
+                    v = (int)gridDim.x + atomicAdd(ticket, 1);
+                h_ticket = v;
             }
-            if(phase == 1 && chunk_at >= chunk_end) {
-                phase = 2;
-                if(nw < n_wave_units && nw + __atomic_load_n(&tickets[0], __ATOMIC_RELAXED) < n_wave_units) {
-                    if(lane == 0) t = atomicAdd(&tickets[0], 1);
-                    t = nw + __builtin_amdgcn_readfirstlane(t);
-                    if(t < n_wave_units) { chunk_at = t; chunk_end = t + 1; phase = 1; }
-                }
-            }
-            if(phase == 2 && chunk_at >= chunk_end) {
-                phase = 3;
-                t = gw * NH_CP_ROW_CHUNK;
-                if(t < n_row_units) { chunk_at = n_wave_units + t; chunk_end = n_wave_units + min(n_row_units, t + NH_CP_ROW_CHUNK); }
-            }
-            if(phase == 3 && chunk_at >= chunk_end) {
-                const int base = nw * NH_CP_ROW_CHUNK;
-                if(!(base < n_row_units && base + __atomic_load_n(&tickets[1], __ATOMIC_RELAXED) < n_row_units)) break;
-                if(lane == 0) t = atomicAdd(&tickets[1], NH_CP_ROW_CHUNK);
-                t = base + __builtin_amdgcn_readfirstlane(t);
-                if(t >= n_row_units) break;
-                chunk_at = n_wave_units + t; chunk_end = n_wave_units + min(n_row_units, t + NH_CP_ROW_CHUNK);
-            }
+            __syncthreads();
+            t = h_ticket;
         }
-        const int u = chunk_at++;
-        // the sub-list of unit u: first k with unit_end[k] > u
-        int lo = 0, hi = 5 * NH_WL_SUB - 1;
-        while(lo < hi) {
-            const int m = (lo + hi) >> 1;
-            if(unit_end[m] > u) hi = m; else lo = m + 1;
-        }
-        const int k = lo, rel = u - (k ? unit_end[k - 1] : 0);
-        const int order = k / NH_WL_SUB, sub = k % NH_WL_SUB;
-        const bool wave_unit = order == 0;
-        const int list = wave_unit ? NH_WL_WAVE : NH_WL_ROW3 - (order - 1);
-        const int idx = wave_unit ? rel : rel * 4 + (lane >> 4);
-        if(idx >= sub_cnt[k]) continue;         // (a row beyond the end of its sub-list)
-        const int uid = WL.ids[((size_t)list * NH_WL_SUB + sub) * WL.cap + idx];
+        if(t >= n_heavy) break;
+        const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
+        const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
         const nh_mid_rec R = mid[uid];
         const uint32_t c = NB.cnt[uid];
         const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
@@ -1041,32 +1114,19 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_cp(nh_step_params P, nh_nbr N
         ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
         ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
         ent.radius = P.radius[uid];
-        v2 nv;
-        bool writer;
-#ifdef NH_CP_STATS
+        const v2 vpref = mkv(R.vpref[0], R.vpref[1]);
+#ifdef NH_CP_UNIT_HIST
         const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
 #endif
-        if(wave_unit) {
-            cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S.w);
-            nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S.w);
-            writer = lane == 0;
-        }else{
-            cp_lds<16> &Sr = S.r[lane >> 4];
-            cp_load_lists<16>(P.grid, NB, uid, n_dyn, n_stat, Sr);
-            nv = clearpath_grp<16>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, Sr);
-            writer = (lane & 15) == 0;
+        cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
+        const v2 nv = clearpath_grp<64, true>(ent, vpref, n_dyn, n_stat, S, wib, CP_WAVES, &team);
+        if(wib == 0) {
+            if(lane == 0)
+                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
+            HIST_UNIT(0, tu0);
         }
-        if(writer)
-            post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
-#ifdef NH_CP_STATS
-        if(lane == 0) {
-            const unsigned long long du = __builtin_amdgcn_s_memtime() - tu0;
-            atomicAdd(&nh_cp_cyc[wave_unit ? 5 : 3][5], du);
-            atomicAdd(&nh_cp_cyc[wave_unit ? 5 : 3][6], 1ull);
-            atomicMax(&nh_cp_cyc[wave_unit ? 5 : 3][7], du);
-        }
-#endif
     }
+    HIST_WAVE(0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1177,6 +1237,27 @@ __global__ __launch_bounds__(128) void k_clearpath(int nq, const float *ent, con
     if(gl == 0) { out[2 * q] = r.x; out[2 * q + 1] = r.z; }
 }
 
+// the same for a team of CP_WAVES waves per problem (what k_cp_heavy runs)
+__global__ __launch_bounds__(CP_WAVES * 64) void k_clearpath_team(int nq, const float *ent, const float *des_v,
+                                                                  const float *dyn, const int32_t *n_dyn,
+                                                                  const float *stat, const int32_t *n_stat,
+                                                                  float *out)
+{
+    __shared__ cp_lds<64> lds[CP_WAVES];
+    __shared__ cp_team team;
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x;
+    cp_lds<64> &S = lds[wib];
+    const int nd = n_dyn[q], ns = n_stat[q];
+    for(int i = lane; i < nd * 5; i += 64) S.dyn[i] = dyn[(size_t)q * 160 + i];
+    for(int i = lane; i < ns * 5; i += 64) S.stat[i] = stat[(size_t)q * 160 + i];
+    wave_sync();
+    cpent e; e.pos = mkv(ent[5 * q], ent[5 * q + 1]); e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]);
+    e.radius = ent[5 * q + 4];
+    const v2 r = clearpath_grp<64, true>(e, mkv(des_v[2 * q], des_v[2 * q + 1]), nd, ns, S, wib, CP_WAVES, &team);
+    if(threadIdx.x == 0) { out[2 * q] = r.x; out[2 * q + 1] = r.z; }
+}
+
 // ClearPath retry statistics (developer diagnostics: scripts/, bench.py --cp-stats)
 extern "C" int navhip_debug_cp_attempts(unsigned long long out[9], int reset)
 {
@@ -1189,13 +1270,13 @@ extern "C" int navhip_debug_cp_attempts(unsigned long long out[9], int reset)
     return 0;
 }
 
-#ifdef CP_DEBUG
-extern "C" int navhip_debug_read(unsigned long long out[64])
+#ifdef NH_CP_UNIT_HIST
+extern "C" int navhip_debug_cp_hist(unsigned long long out[128])
 {
     if(hipDeviceSynchronize() != hipSuccess) return 1;
-    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_dbg), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    unsigned long long z[64] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(nh_dbg), z, sizeof(z)) != hipSuccess;
+    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_cp_hist), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[128] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_hist), z, sizeof(z)) != hipSuccess;
 }
 #endif
 #ifdef NH_CP_STATS
@@ -1368,7 +1449,8 @@ int nh_worklist_cap(int n_work)
 // k_agent_mid + the consumers of its work lists.  The list counters alternate between two sets:
 // a launch sequence uses one and zeroes the other for its successor (no memset on the stream).
 void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
-                            nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s)
+                            nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
+                            hipStream_t side, hipEvent_t ev[2])
 {
     const int nwork = P.work_end - P.work_begin;
     if(!(P.n_ents > 0 && nwork > 0)) return;
@@ -1380,11 +1462,21 @@ void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     hipLaunchKernelGGL(k_wl_zero, dim3(1), dim3(256), 0, s, other);
     hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
                        d_mid, WL, O, smf, thresh);
-    // enough resident waves to fill the chip; every wave keeps drawing units until none are left
-    hipLaunchKernelGGL(k_cp, dim3(min(2048, (nwork + 7) / 8 + 1)), dim3(AG_WAVES * 64), 0, s, P, NB,
-                       (const nh_mid_rec*)d_mid, WL, O);
+    // the ClearPath launches: the workgroup problems on the side stream (when the caller has one),
+    // rows and the irregular agents on s; every wave / workgroup keeps drawing units until none are left
+    const bool fork = side && ev && ev[0] && ev[1];
+    hipStream_t sh = fork ? side : s;
+    if(fork) {
+        hipEventRecord(ev[0], s);
+        hipStreamWaitEvent(sh, ev[0], 0);
+    }
+    const int nblk = min(1024, (nwork + 15) / 16 + 1);
+    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
+    if(fork) hipEventRecord(ev[1], sh);
+    hipLaunchKernelGGL(k_cp_rows, dim3(nblk), dim3(CP_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
                        (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh);
+    if(fork) hipStreamWaitEvent(s, ev[1], 0);
 }
 
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,
@@ -1400,7 +1492,10 @@ void nh_launch_clearpath(int nq, const float *ent, const float *des_v, const flo
                          int rows, hipStream_t s)
 {
     if(nq <= 0) return;
-    if(rows)
+    if(rows == 2)
+        hipLaunchKernelGGL(k_clearpath_team, dim3(nq), dim3(CP_WAVES * 64), 0, s, nq, ent, des_v, dyn,
+                           n_dyn, stat, n_stat, out);
+    else if(rows)
         hipLaunchKernelGGL(k_clearpath<16>, dim3((nq + 7) / 8), dim3(128), 0, s, nq, ent, des_v, dyn,
                            n_dyn, stat, n_stat, out);
     else

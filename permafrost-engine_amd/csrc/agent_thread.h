@@ -31,7 +31,8 @@ enum { AM_IDLE = 0,        // still or combat held: velocity 0, no neighbour wor
 
 enum { DISP_DONE = 0,      // out_vel is final (before truncation)
        DISP_ROW0, DISP_ROW1, DISP_ROW2, DISP_ROW3,   // ClearPath on a row of 16 lanes: 1-2, 3-4, 5-8, 9-16 neighbours
-       DISP_WAVE,          // ClearPath on a wave: 17-64 neighbours
+       DISP_WAVE,          // ClearPath on a workgroup: 17-32 neighbours
+       DISP_HEAVY,         // ClearPath on a workgroup: 33-64 neighbours
        DISP_FULL };        // whole step on a wave (irregular gather)
 
 #define NH_SEP_CAP   128   /* near_ents[128],  movement.c:1695 */
@@ -402,7 +403,7 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
         out_vel = vpref;
         return DISP_DONE;
     }
-    return n <= 2 ? DISP_ROW0 : n <= 4 ? DISP_ROW1 : n <= 8 ? DISP_ROW2 : n <= NH_ROW_MAX ? DISP_ROW3 : DISP_WAVE;
+    return n <= 2 ? DISP_ROW0 : n <= 4 ? DISP_ROW1 : n <= 8 ? DISP_ROW2 : n <= NH_ROW_MAX ? DISP_ROW3 : n <= 32 ? DISP_WAVE : DISP_HEAVY;
 }
 
 #ifdef NH_HOSTSIM

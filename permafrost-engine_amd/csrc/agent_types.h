@@ -92,7 +92,8 @@ struct nh_nbr {
 // Work lists filled on the device (counters[NH_WL_*] + ids), consumed by fixed-size launches that
 // stride over them: agents that still need a ClearPath search after k_agent_mid.
 enum { NH_WL_ROW0 = 0, NH_WL_ROW1, NH_WL_ROW2, NH_WL_ROW3,   // a row of 16 lanes per agent: 1-2, 3-4, 5-8, 9-16 neighbours
-       NH_WL_WAVE,          // one wave per agent: 17-64 neighbours
+       NH_WL_WAVE,          // one workgroup per agent: 17-32 neighbours
+       NH_WL_HEAVY,         // one workgroup per agent: 33-64 neighbours (started first)
        NH_WL_FULL,          // one wave per agent, whole step (irregular gather)
        NH_WL_LISTS };       // (number of lists)
 // Every list is kept as NH_WL_SUB sub-lists, one per group of producer waves (wave index mod
@@ -100,11 +101,14 @@ enum { NH_WL_ROW0 = 0, NH_WL_ROW1, NH_WL_ROW2, NH_WL_ROW3,   // a row of 16 lane
 // serialise at ~5 ns each (measured: they were most of k_agent_mid's time).
 #define NH_WL_SUB 64
 struct nh_worklists {
-    int32_t *count;            // [NH_WL_LISTS][NH_WL_SUB] entries + [2] tickets (+ the same again: other parity)
+    int32_t *count;            // [NH_WL_LISTS][NH_WL_SUB] entries + the ticket counters of the ClearPath
+                               // kernels, one per 128-byte line: [0] workgroup problems, [1 + s] stripe s
+                               // of the row units (+ the same again: other parity)
     int32_t *ids;              // [NH_WL_LISTS][NH_WL_SUB][cap] uids
     int      cap;              // entries a sub-list can hold (its producers cannot append more)
 };
-#define NH_WL_COUNTERS (NH_WL_LISTS * NH_WL_SUB + 2)
+#define NH_CP_STRIPES 32
+#define NH_WL_COUNTERS (NH_WL_LISTS * NH_WL_SUB + 32 * (1 + NH_CP_STRIPES))
 
 // per-entity record k_agent_mid leaves for the list consumers (32 bytes, indexed by uid)
 struct nh_mid_rec {

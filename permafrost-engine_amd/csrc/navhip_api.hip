@@ -100,6 +100,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->coh_flocks = ctx->coh_members = -1;
     ctx->coh_parity = 0;
     ctx->ev_regroup = nullptr;
+    for(auto &e : ctx->ev_cp) e = nullptr;
     ctx->regroup_pending = false;
     memset(&ctx->midrec, 0, sizeof(ctx->midrec));
     memset(ctx->nbr, 0, sizeof(ctx->nbr));
@@ -146,6 +147,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
     if(ctx->ev_regroup) hipEventDestroy(ctx->ev_regroup);
+    for(auto &e : ctx->ev_cp) if(e) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -812,6 +814,23 @@ static bool pre_key_matches(const navhip_ctx *ctx, const navhip_world *w, const 
         && k.g.grid_h == g.grid_h;
 }
 
+// the side streams of the agent step (snapshot-only work beside the field builds; the ClearPath
+// launches beside each other) and their events
+static int ensure_side_streams(navhip_ctx *ctx)
+{
+    if(ctx->aux[0]) return NAVHIP_OK;
+    // high priority: the side chains are narrow and sit on the critical path; they must not
+    // queue up behind the wide field kernels of the caller's stream
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    for(auto &a : ctx->aux)
+        HIPCHK(ctx, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, prio_hi));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for(auto &e : ctx->ev_cp) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return NAVHIP_OK;
+}
+
 int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stream)
 {
     if(!ctx) return NAVHIP_ERR_INVALID;
@@ -821,16 +840,8 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     if(w->n_ents == 0) return NAVHIP_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    if(!ctx->aux[0]) {
-        // high priority: the side chains are narrow and sit on the critical path; they must not
-        // queue up behind the wide field kernels of the caller's stream
-        int prio_lo = 0, prio_hi = 0;
-        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        for(auto &a : ctx->aux)
-            HIPCHK(ctx, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, prio_hi));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    rc = ensure_side_streams(ctx);
+    if(rc) return rc;
     nh_step_params P;
     rc = step_fill_params(ctx, w, &P);
     if(rc) return rc;
@@ -898,6 +909,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
     nh_nbr NB; nh_worklists WL;
     rc = step_scratch(ctx, w->n_ents, &NB, &WL, s);
+    if(!rc) rc = ensure_side_streams(ctx);
     if(rc) return rc;
     if(joined) {
         // spatial hash + neighbour walk + cohesion were started by navhip_agent_prefetch_dev: join
@@ -906,7 +918,8 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         P.grid.recV = (const float2*)ctx->sp[8].p; P.grid.pool_of = (const int32_t*)ctx->sp[9].p;
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
-        nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s);
+        nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
+                               ctx->aux[0], ctx->ev_cp);
         ctx->wl_parity ^= 1;
         if(ctx->regroup_pending) {
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));     // long finished by now
@@ -931,7 +944,8 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
-    nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s);
+    nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
+                               ctx->aux[0], ctx->ev_cp);
     ctx->wl_parity ^= 1;
     if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[5], s)); ctx->ev_valid = true; }
     HIPCHK(ctx, hipGetLastError());
@@ -964,10 +978,11 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
     const int32_t *src = (const int32_t*)ctx->wl[0].p + (ctx->wl_parity ^ 1) * NH_WL_COUNTERS;
     int32_t h[NH_WL_COUNTERS];
     HIPCHK(ctx, hipMemcpy(h, src, sizeof(h), hipMemcpyDeviceToHost));
-    for(int l = 0; l < NH_WL_LISTS; l++) {
-        out_counts[l] = 0;
-        for(int sb = 0; sb < NH_WL_SUB; sb++) out_counts[l] += h[l * NH_WL_SUB + sb];
-    }
+    // (the wave and the heavy list are reported together: 17-64 neighbours)
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5};
+    for(int l = 0; l < 6; l++) out_counts[l] = 0;
+    for(int l = 0; l < NH_WL_LISTS; l++)
+        for(int sb = 0; sb < NH_WL_SUB; sb++) out_counts[slot_of[l]] += h[l * NH_WL_SUB + sb];
     return NAVHIP_OK;
 }
 
@@ -1091,7 +1106,7 @@ static int clearpath_batch(navhip_ctx *ctx, int nq, const float *ent, const floa
     if(nq == 0) return NAVHIP_OK;
     for(int i = 0; i < nq; i++) {
         if(n_dyn[i] < 0 || n_dyn[i] > 32 || n_stat[i] < 0 || n_stat[i] > 32) return NAVHIP_ERR_INVALID;
-        if(rows && n_dyn[i] + n_stat[i] > NH_ROW_MAX) return NAVHIP_ERR_INVALID;
+        if(rows == 1 && n_dyn[i] + n_stat[i] > NH_ROW_MAX) return NAVHIP_ERR_INVALID;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1126,6 +1141,13 @@ int navhip_clearpath_rows(navhip_ctx *ctx, int nq, const float *ent, const float
                           const int32_t *n_stat, float *out)
 {
     return clearpath_batch(ctx, nq, ent, des_v, dyn, n_dyn, stat, n_stat, out, 1);
+}
+
+int navhip_clearpath_team(navhip_ctx *ctx, int nq, const float *ent, const float *des_v,
+                          const float *dyn, const int32_t *n_dyn, const float *stat,
+                          const int32_t *n_stat, float *out)
+{
+    return clearpath_batch(ctx, nq, ent, des_v, dyn, n_dyn, stat, n_stat, out, 2);
 }
 
 uint64_t navhip_flow_field_id(const navhip_field_req *r)

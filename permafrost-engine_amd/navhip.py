@@ -335,6 +335,8 @@ _SIGS.update({
     "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
     "navhip_clearpath_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "navhip_clearpath_team": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "navhip_clearpath": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 })
@@ -460,7 +462,8 @@ def _ctx_spatial_query(self, pos_xz, query_xz, rng, maxout):
 
 def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, rows=False):
     """G_ClearPath_NewVelocity (clearpath.c:694) for a batch of independent problems, one wave per
-    problem; rows=True: one row of 16 lanes per problem (<= 16 neighbours)."""
+    problem; rows=True: one row of 16 lanes per problem (<= 16 neighbours); rows="team": the waves of a
+    workgroup per problem."""
     ent = np.ascontiguousarray(ent, np.float32).reshape(-1, 5)
     nq = len(ent)
     des_v = np.ascontiguousarray(des_v, np.float32).reshape(nq, 2)
@@ -469,6 +472,10 @@ def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, rows=False):
     n_dyn = np.ascontiguousarray(n_dyn, np.int32)
     n_stat = np.ascontiguousarray(n_stat, np.int32)
     out = np.zeros((nq, 2), np.float32)
+    if rows == "team":
+        self._chk(lib().navhip_clearpath_team(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
+                                              _hp(stat), _hp(n_stat), _hp(out)), "navhip_clearpath_team")
+        return out
     if rows:
         self._chk(lib().navhip_clearpath_rows(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
                                               _hp(stat), _hp(n_stat), _hp(out)), "navhip_clearpath_rows")

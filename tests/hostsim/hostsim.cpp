@@ -102,7 +102,7 @@ int hostsim_agent_step(const hostsim_map *map, const navhip_world *w, const floa
         if(out_counts) { out_counts[2 * uid] = (int32_t)(cnt[uid] & 0xff); out_counts[2 * uid + 1] = (int32_t)((cnt[uid] >> 8) & 0xff); }
         if(disp == DISP_DONE) {
             post_thread(P, uid, me, P.state[uid], P.flags[uid], P.radius[uid], out_vel, R.vel_cap, R.status, O);
-        }else if(disp >= DISP_ROW0 && disp <= DISP_WAVE) {
+        }else if(disp >= DISP_ROW0 && disp <= DISP_HEAVY) {
             // one ClearPath attempt, serially (no remove_furthest: disp + 16 = not computed here)
             cpent ent; ent.pos = me; ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]); ent.radius = P.radius[uid];
             v2 res;

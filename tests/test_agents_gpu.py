@@ -53,7 +53,10 @@ def test_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread):
         exp[i] = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
     ctx = navlib.NavContext(1, 1)
     got = ctx.G_ClearPath_NewVelocity(ent, des, dyn, nd, stat, ns)
+    team = ctx.G_ClearPath_NewVelocity(ent, des, dyn, nd, stat, ns, rows="team")
     ctx.close()
+    # a workgroup per problem (the agent step's form for 17..64 neighbours) == a wave per problem
+    assert np.array_equal(team.view(np.uint32), got.view(np.uint32)), np.flatnonzero((team.view(np.uint32) != got.view(np.uint32)).any(1))[:8]
     both_nan = np.isnan(exp) & np.isnan(got)
     err = _vel_err(np.where(both_nan, 0, got), np.where(both_nan, 0, exp))
     nbad = int((~(err <= REL_TOL)).sum())
@@ -83,7 +86,9 @@ def test_row_clearpath_matches_reference(navlib, seed, max_dyn, max_stat, spread
 
 
 @pytest.mark.parametrize("seed,max_dyn,max_stat,spread,rows", [(11, 24, 24, 3.0, False), (12, 32, 32, 4.5, False),
-                                                              (13, 8, 8, 2.2, True), (14, 3, 12, 2.0, True)])
+                                                              (13, 8, 8, 2.2, True), (14, 3, 12, 2.0, True),
+                                                              (11, 24, 24, 3.0, "team"), (12, 32, 32, 4.5, "team"),
+                                                              (15, 16, 16, 2.6, "team")])
 def test_clearpath_retry_shortcut_matches_reference(navlib, seed, max_dyn, max_stat, spread, rows):
     """Enclosed agents: G_ClearPath_NewVelocity fails, removes the furthest neighbour and retries
     (clearpath.c:704-713), dozens of times in a jam.  The device finds the attempt that will succeed from

@@ -37,6 +37,8 @@ def test_serial_clearpath_search_matches_reference(seed, max_dyn, max_stat, spre
     assert n_checked > nq * (0.8 if max_dyn < 32 else 0.3)
 
 
+DISP_FULL = 7      # agent_thread.h: DISP_DONE, ROW0..3, WAVE, HEAVY, FULL (the irregular gather)
+
 def _world(navlib, clustered, n, k, blk, seed=21, garrison=False, arrival=False):
     grid = cases.synth.cost_grid(4, 4, seed=seed)
     blockers = cases.random_blockers(grid, seed=8, frac=0.02) if blk else None
@@ -63,14 +65,14 @@ def test_thread_step_matches_reference(navlib, clustered, n, k, blk, garrison):
         coh[uid] = mv.forces(int(uid), vdes[uid])[1]
     out = hostsim.agent_step(navlib, 4, 4, nav.plane(0), nav.plane(1), a, coh)
     disp = out["disp"]
-    computed = moving & (disp < 6)
+    computed = moving & (disp < DISP_FULL)
     assert computed.sum() > 0.6 * moving.sum(), np.bincount(disp[moving])
     # ClearPath neighbour lists (counts) against find_neighbours
-    for uid in np.flatnonzero(moving & (disp != 6))[:300]:
+    for uid in np.flatnonzero(moving & (disp != DISP_FULL))[:300]:
         dyn, stat = mv.neighbours(int(uid))
         assert (len(dyn), len(stat)) == tuple(out["counts"][uid]), uid
     # preferred velocity of the point-seek agents, then the final velocities, bit for bit
-    ps = np.flatnonzero(np.isin(world["state"], (0, 5, 6)) & (disp != 6))
+    ps = np.flatnonzero(np.isin(world["state"], (0, 5, 6)) & (disp != DISP_FULL))
     for uid in ps[:80]:
         ev = mv.vpref(int(uid), vdes[uid])
         assert np.array_equal(out["vpref_xz"][uid].view(np.uint32), ev.view(np.uint32)), ("vpref", uid)
@@ -78,7 +80,7 @@ def test_thread_step_matches_reference(navlib, clustered, n, k, blk, garrison):
     assert len(bad) == 0, (bad[:10], disp[bad[:10]], out["vel_xz"][bad[:3]], exp_vel[bad[:3]])
     assert np.all(out["vel_xz"][~moving] == 0)
     if garrison:
-        assert (disp[moving] == 6).sum() > 0          # garrisoned neighbours -> the irregular list
+        assert (disp[moving] == DISP_FULL).sum() > 0          # garrisoned neighbours -> the irregular list
     # position accept
     for uid in np.flatnonzero(computed)[:200]:
         v = exp_vel[uid]
@@ -110,7 +112,7 @@ def test_thread_step_with_arrival_state_matches_reference(navlib):
     for uid in np.flatnonzero(np.isin(world["state"], (0, 5, 6))):
         coh[uid] = mv.forces(int(uid), vdes[uid])[1]
     out = hostsim.agent_step(navlib, 4, 4, nav.plane(0), nav.plane(1), a, coh)
-    computed = moving & (out["disp"] < 6)
+    computed = moving & (out["disp"] < DISP_FULL)
     assert computed.sum() > 0.6 * moving.sum()
     for uid in np.flatnonzero(moving)[:300]:
         dyn, stat = mv.neighbours(int(uid))
