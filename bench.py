@@ -182,15 +182,15 @@ def profiled_ticks(T, n):
     import numpy as np
     from permafrost_engine_amd import navhip
     T.ctx.set_profiling(True)
-    keep = (T.overlap, T.record, T.mark_every, T.ev, T.tick_ev)
-    T.overlap, T.record, T.mark_every, T.ev, T.tick_ev = False, True, 1, [], []
+    keep = (T.overlap, T.record, T.mark_every, T.ev, T.tick_ev, T.pipeline_fields, getattr(T, "fev", []))
+    T.overlap, T.record, T.mark_every, T.ev, T.tick_ev, T.pipeline_fields, T.fev = False, True, 1, [], [], False, []
     rows = []
     for _ in range(n):
         T.step()
         T.sync()
         rows.append(T.ctx.last_step_ms())
     serial = T.phase_ms()
-    T.overlap, T.record, T.mark_every, T.ev, T.tick_ev = keep
+    T.overlap, T.record, T.mark_every, T.ev, T.tick_ev, T.pipeline_fields, T.fev = keep
     T.ctx.set_profiling(False)
     rows = rows[1:] if len(rows) > 1 else rows
     g = {name: float(np.mean([x[i] for x in rows])) for i, name in enumerate(navhip.STEP_PHASES)}
@@ -208,7 +208,7 @@ def run_ticks(T, pdist, torch, warmup, steps, early=None):
     pdist.barrier()
     torch.cuda.synchronize()
     T.record = True
-    T.ev, T.tick_ev = [], []
+    T.ev, T.tick_ev, T.fev = [], [], []
     t0 = time.perf_counter()
     for _ in range(steps):
         T.step()
@@ -240,6 +240,9 @@ def main():
                          "(none in this workload: flocks are rank aligned); all = all-gather every tile "
                          "every tick (any agent may sample any field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline-fields", action="store_true",
+                    help="build a tick's fields inside that tick, in front of its agent step (default: the fields "
+                         "of tick t+1 are built during tick t, beside the agent step; same work, same results)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ("map", "fields", "agents", "obstacles"):
@@ -269,7 +272,8 @@ def main():
         return tick.NavTick(chunk_w=cfg["map"], fields_per_rank=f_rank, agents_per_rank=a_rank,
                             rank=rank, world=world, device=local, obstacles=cfg["obstacles"],
                             obstacle_ticks=args.warmup + args.steps + 16, tile_exchange=args.tile_exchange,
-                            shared_map=shared, crowd_cells=CROWD if crowd else 0)
+                            shared_map=shared, crowd_cells=CROWD if crowd else 0,
+                            pipeline_fields=not args.no_pipeline_fields)
 
     T = make(args.crowded)
     early = {}
@@ -386,7 +390,9 @@ def main():
                        "baseline_config": args.config, "map_chunks": cfg["map"], "flow_fields": cfg["fields"],
                        "agents": cfg["agents"], "hz": 20, "dynamic_obstacles": cfg["obstacles"],
                        "parallelism": "requests by destination + agent slabs x%d; one all-gather of slab results "
-                                      "(16 B/agent) per tick; baked tiles: %s" % (world, args.tile_exchange)},
+                                      "(16 B/agent) per tick; baked tiles: %s" % (world, args.tile_exchange),
+                       "schedule": ("fields of tick t+1 built during tick t beside the agent step (double-buffered pool)"
+                                    if T.pipeline_fields else "fields of tick t built in front of the agent step of tick t")},
             "ms_per_step_median": float(np.median(ticks)),
             "ms_tick_5_50_100": [at(5), at(50), at(min(100, len(ticks)))],
             "agent_steps_per_s_median_tick": agents_total / (float(np.median(ticks)) * 1e-3),

@@ -417,6 +417,20 @@ int  navhip_agent_step_wait(navhip_ctx *ctx);
  * caller enqueues there afterwards is ordered behind the last read); a prefetch that is never
  * followed by a step is drained by navhip_sync. */
 int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, void *stream);
+/* flags: NAVHIP_PREFETCH_FRONT_INLINE  the spatial hash and the neighbour walk stay on `stream` itself
+ * (only the cohesion term forks): for a caller that enqueues nothing wide on `stream` between this call
+ * and the step -- the chain then follows the previous step on the same stream without a hand-over. */
+#define NAVHIP_PREFETCH_FRONT_INLINE 0x1u
+int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world, void *stream, uint32_t flags);
+/* Scheduling hint for a caller that runs other wide work (the field builds of the NEXT tick, say)
+ * beside the agent step: make `stream` wait until the given stage of the step in flight is done, so
+ * that the narrow, serial front of the step is not slowed down by it.
+ *   NAVHIP_STAGE_NEIGHBOURS  spatial hash + neighbour walk of the last navhip_agent_prefetch_dev
+ *   NAVHIP_STAGE_LISTS       preferred velocities + work lists of the last navhip_agent_step_dev
+ * (NAVHIP_ERR_INVALID when that call has not been made). */
+#define NAVHIP_STAGE_NEIGHBOURS 0
+#define NAVHIP_STAGE_LISTS      1
+int  navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage);
 
 /* Per-kernel-group timing of the agent step with HIP events on the launch stream (bench.py's
  * roofline line).  A profiled navhip_agent_step[_dev] runs every kernel group back to back on the

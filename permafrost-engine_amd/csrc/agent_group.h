@@ -292,6 +292,9 @@ template <int G> struct cp_lds {
 // whose distance is NaN or infinite still count.
 struct cp_bound { float len; int idx; v2 pt; int nfound; int sb; };
 #define CP_COL_MARGIN 0.02f
+#ifndef CP_SMALL_RAYS
+#define CP_SMALL_RAYS 8          // up to this many rays (4 neighbours) a problem is searched without queue and bound
+#endif
 
 __device__ __forceinline__ bool cp_alive(const cp_bound &B, float len, int idx)
 {
@@ -653,10 +656,58 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         CP_STAT(B.sb, 1, 1);
         if(guard == 0) CP_STAT(B.sb, 0, 1);
 #endif
-        cp_lane L; L.pt = mkv(0, 0); L.idx = 0; L.len = 0.0f; L.ci = -1;
-        int qn = 0;                                            // pending candidates (group uniform)
         const int npairs = n_rays * n_rays;
         CP_STAT(B.sb, 7, n_rays);
+        if(!TEAM && n_rays <= CP_SMALL_RAYS) {
+        // ---- few neighbours (most agents outside a crowd): no queue, no bound -- every lane works its
+        // own few candidates through (point, distance, every cone), keeps its best, one arg-min at the
+        // end.  A handful of independent chains per lane instead of a dozen group-wide round trips.
+        int nf = 0;
+        float blen = __builtin_inff(); int bidx = 0x7fffffff; v2 bpt = mkv(0, 0);
+        for(int c = gl; c < npairs + n_rays; c += G) {
+            bool ok = false;
+            v2 pt = mkv(0, 0);
+            if(c >= npairs) {
+                const int r = c - npairs;
+                const float4 Ai = S.cones[r & ~1], Bi = S.cones[r | 1];
+                const v2 dir = (r & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
+                pt = vadd(point, vscale(dir, vdot(dir, des_v)));
+                ok = true;
+            }else{
+                const int i = c / n_rays, j = c - i * n_rays;
+                if(i != j) {
+                    const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
+                    const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                    const bool ri = i & 1, rj = j & 1;
+                    ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
+                                   mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z,
+                                   pt);
+                }
+            }
+            if(ok) {
+                bool inside = false;
+                for(int k2 = 0; k2 < n_cones; k2++)
+                    inside = inside || cone_contains(S.cones[2 * k2], S.cones[2 * k2 + 1], pt);
+                if(!inside) {
+                    const v2 curr = vsub(pt, ent.pos);
+                    const float len = vlen(vsub(des_v, curr));
+                    nf++;
+                    if(len < blen || (len == blen && c < bidx)) { blen = len; bidx = c; bpt = curr; }
+                }
+            }
+        }
+        // (a NaN or infinite distance never wins: blen stays +inf there, the answer stays 0 as :368-386)
+        float key = blen; int ki = bidx;
+        g::argmin(key, ki);
+        const int owner = __ffsll((unsigned long long)g::ballot(bidx == ki && blen == key)) - 1;
+        B.nfound = g::any(nf > 0) ? 1 : 0;
+        if(key < __builtin_inff()) {
+            B.len = key; B.idx = ki;
+            B.pt = mkv(g::shfl(bpt.x, owner), g::shfl(bpt.z, owner));
+        }
+        }else{
+        cp_lane L; L.pt = mkv(0, 0); L.idx = 0; L.len = 0.0f; L.ci = -1;
+        int qn = 0;                                            // pending candidates (group uniform)
         // ---- the projections of des_v on every ray (:344; order index npairs + ray).  Visited first:
         // they are the closest point of each ray, so the bound tightens at once.
         for(int c0 = 0; c0 < n_rays; c0 += G) {
@@ -762,6 +813,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                 jdone += ncol;
             }
             cp_work<G>(S, ent, n_cones, qn, L, B, true);
+        }
         }
         if(TEAM) team_min<G>(B, *T, part, nparts);
         CP_TMARK(sb_, 2);

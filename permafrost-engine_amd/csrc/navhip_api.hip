@@ -819,19 +819,20 @@ static bool pre_key_matches(const navhip_ctx *ctx, const navhip_world *w, const 
 static int ensure_side_streams(navhip_ctx *ctx)
 {
     if(ctx->aux[0]) return NAVHIP_OK;
-    // high priority: the side chains are narrow and sit on the critical path; they must not
-    // queue up behind the wide field kernels of the caller's stream
+    // high priority: the side chain is narrow and sits on the critical path; it must not queue up
+    // behind the wide field kernels of the caller's stream
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    for(auto &a : ctx->aux)
-        HIPCHK(ctx, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, prio_hi));
+    // (the cohesion term has slack -- it runs beside the whole front of the step --: low priority)
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[0], hipStreamNonBlocking, prio_hi));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[1], hipStreamNonBlocking, prio_lo));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for(auto &e : ctx->ev_cp) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return NAVHIP_OK;
 }
 
-int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stream)
+int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *stream, uint32_t flags)
 {
     if(!ctx) return NAVHIP_ERR_INVALID;
     int rc = step_check_world(ctx, w);
@@ -850,14 +851,18 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
     if(!rc) rc = step_scratch(ctx, w->n_ents, &NB, &WL, s);
     if(rc) return rc;
+    // the front of the step (spatial hash -> neighbour walk) is a chain of small launches on the
+    // critical path of the tick: NAVHIP_PREFETCH_FRONT_INLINE keeps it on the caller's stream, where it
+    // follows the previous step without a cross-stream hand-over (tens of microseconds each)
+    hipStream_t front = (flags & NAVHIP_PREFETCH_FRONT_INLINE) ? s : ctx->aux[0];
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+    if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
     // side stream 0: spatial hash -> neighbour walk (separation force + ClearPath neighbour lists)
-    rc = spatial_build(ctx, w, &P.grid, ctx->aux[0], P.work_begin, P.work_end);
+    rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end);
     if(rc) return rc;
-    nh_launch_agent_nbr(P, NB, ctx->aux[0]);
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+    nh_launch_agent_nbr(P, NB, front);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front));
     // side stream 1: cohesion
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
                                             ctx->aux[1]);
@@ -876,6 +881,11 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     ctx->pre.valid = true;
     pre_key_fill(ctx, w, P);
     return NAVHIP_OK;
+}
+
+int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stream)
+{
+    return navhip_agent_prefetch_dev_ex(ctx, w, stream, 0);
 }
 
 int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_step_out *out,
@@ -949,6 +959,16 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     ctx->wl_parity ^= 1;
     if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[5], s)); ctx->ev_valid = true; }
     HIPCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage)
+{
+    if(!ctx || !stream || !ctx->aux[0]) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if(stage == NAVHIP_STAGE_NEIGHBOURS)  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join[0], 0));
+    else if(stage == NAVHIP_STAGE_LISTS)  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cp[0], 0));
+    else return NAVHIP_ERR_INVALID;
     return NAVHIP_OK;
 }
 

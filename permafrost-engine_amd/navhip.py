@@ -328,9 +328,11 @@ _SIGS.update({
     "navhip_agent_step": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut)]),
     "navhip_agent_step_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut), C.c_void_p]),
     "navhip_agent_prefetch_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p]),
+    "navhip_agent_prefetch_dev_ex": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p, C.c_uint32]),
     "navhip_spatial_query": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p, C.c_int, C.c_float,
                                        C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "navhip_stream_wait_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 5)]),
     "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
     "navhip_clearpath_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -443,9 +445,12 @@ def _ctx_agent_step_dev(self, world, stepout, stream=None):
               "navhip_agent_step_dev")
 
 
-def _ctx_agent_prefetch_dev(self, world, stream=None):
-    self._chk(lib().navhip_agent_prefetch_dev(self._h, C.byref(world),
-                                              C.c_void_p(stream) if stream else None),
+PREFETCH_FRONT_INLINE = 1
+
+
+def _ctx_agent_prefetch_dev(self, world, stream=None, flags=0):
+    self._chk(lib().navhip_agent_prefetch_dev_ex(self._h, C.byref(world),
+                                                 C.c_void_p(stream) if stream else None, flags),
               "navhip_agent_prefetch_dev")
 
 
@@ -483,6 +488,14 @@ def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, rows=False):
     self._chk(lib().navhip_clearpath(self._h, nq, _hp(ent), _hp(des_v), _hp(dyn), _hp(n_dyn),
                                      _hp(stat), _hp(n_stat), _hp(out)), "navhip_clearpath")
     return out
+
+
+STAGE_NEIGHBOURS, STAGE_LISTS = 0, 1
+
+
+def _ctx_stream_wait_stage(self, stream, stage):
+    """Make `stream` (a hipStream_t value) wait for a stage of the agent step in flight."""
+    self._chk(lib().navhip_stream_wait_stage(self._h, C.c_void_p(stream), stage), "navhip_stream_wait_stage")
 
 
 def _ctx_set_profiling(self, on):
@@ -594,6 +607,7 @@ NavContext.agent_step_async = _ctx_agent_step_async
 NavContext.set_profiling = _ctx_set_profiling
 NavContext.last_step_ms = _ctx_last_step_ms
 NavContext.last_step_lists = _ctx_last_step_lists
+NavContext.stream_wait_stage = _ctx_stream_wait_stage
 NavContext.agent_step = _ctx_agent_step
 NavContext.agent_step_dev = _ctx_agent_step_dev
 NavContext.agent_prefetch_dev = _ctx_agent_prefetch_dev

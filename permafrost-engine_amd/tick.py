@@ -42,7 +42,7 @@ class NavTick:
     def __init__(self, chunk_w=16, fields_per_rank=64, agents_per_rank=100_000, rank=0, world=1,
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
-                 debug_outputs=False):
+                 debug_outputs=False, pipeline_fields=False):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -198,7 +198,7 @@ class NavTick:
                      "targets": targets.astype(np.float32), "flock": ag["flock"], "flock_offsets": offs,
                      "flock_members": members, "radius": ag["radius"], "max_speed": ag["max_speed"],
                      "speed": ag["speed"], "liid": liid}
-        self.stream = torch.cuda.Stream(device=self.dev)
+        self.stream = torch.cuda.Stream(device=self.dev, priority=-1)      # the agent chain: ahead of the field builds
         # multi-GPU: the slab all-gather of tick t runs on its own stream and is only awaited by the
         # snapshot consumers of tick t+1 (spatial hash + cohesion, then the agent step); the field
         # builds of tick t+1 do not read positions and overlap with it
@@ -214,6 +214,28 @@ class NavTick:
             full["flags"] = navhip.REQ_LIVE_IIDS
             d_full = dev(full.view(np.uint8).reshape(n_req, 32))
             self.ctx.build_fields_dev(d_full, n_req, self.pool, stream=self.stream.cuda_stream)
+            self.stream.synchronize()
+        # pipeline_fields: the fields tick t+1 samples are built DURING tick t, on their own stream, into
+        # the other half of a double-buffered pool, starting once the narrow, serial front of tick t's
+        # agent step (spatial hash + neighbour walk) is through.  Same work per tick -- one rebuild of
+        # every chunk field, one step of every agent --, same results (the static map does not depend on
+        # the agents); the field builds just stop gating the agent step of their own tick.  (With moving
+        # obstacles the blocker updates of tick t+1 would race with the probes of tick t: not pipelined.)
+        self.pipeline_fields = bool(pipeline_fields) and not obstacles
+        if self.pipeline_fields:
+            self.fstream = torch.cuda.Stream(device=self.dev)
+            # nothing wide is enqueued on self.stream between prefetch and step: the front stays on it
+            self.prefetch_flags = navhip.PREFETCH_FRONT_INLINE
+            self.pool_next = torch.zeros_like(self.pool)
+            self.ev_fields, self.ev_fields_next = torch.cuda.Event(), torch.cuda.Event()
+            self.fev = []
+            if self.n_req_local:                       # the fields of tick 0 (start-up, untimed)
+                self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
+                                          self.pool[self.req_begin:self.req_end], stream=self.stream.cuda_stream)
+            if self.tile_exchange == "all" and not self.solo:
+                with torch.cuda.stream(self.stream):
+                    pdist.exchange_rows(self.pool, self.req_bounds, self.rank, self.world)
+            self.ev_fields.record(self.stream)
             self.stream.synchronize()
         self.ev = []                   # (phase, start_event, end_event) of the timed steps
         self.tick_ev = []              # one event at the start of every recorded tick
@@ -263,6 +285,8 @@ class NavTick:
             # behind the previous tick's all-gather, concurrently with the field builds below
             with torch.cuda.stream(self.comm):
                 self.ctx.agent_prefetch_dev(self.world_s, stream=self.comm.cuda_stream)
+        if self.pipeline_fields:
+            return self._compute_pipelined(marks)
         with torch.cuda.stream(s):
             # snapshot-only parts of the agent step (spatial hash, cohesion: they read no nav plane)
             # start now on the library's side streams and overlap with the blocker updates and the
@@ -285,6 +309,40 @@ class NavTick:
             marks.append(self._mark("agents"))
             if self._comm_pending:
                 s.wait_event(self.ev_comm)            # the other ranks' rows of the snapshot
+            self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
+            marks.append(self._mark("gather_agents"))
+            self.ev_step.record(s)
+
+    def _compute_pipelined(self, marks):
+        s, f = self.stream, self.fstream
+        if not self.pipelined:
+            with torch.cuda.stream(s):
+                self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream, flags=self.prefetch_flags)
+        # the fields of the NEXT tick, behind the neighbour walk of this one
+        timed = self.record and self.tick_no % self.mark_every == 0
+        with torch.cuda.stream(f):
+            self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_NEIGHBOURS)
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(f)
+            if self.n_req_local:
+                self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
+                                          self.pool_next[self.req_begin:self.req_end], stream=f.cuda_stream)
+            if timed:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(f)
+            if self.tile_exchange == "all" and not self.solo:
+                pdist.exchange_rows(self.pool_next, self.req_bounds, self.rank, self.world)
+            if timed:
+                e2 = torch.cuda.Event(enable_timing=True)
+                e2.record(f)
+                self.fev.append((e0, e1, e2))
+            self.ev_fields_next.record(f)
+        with torch.cuda.stream(s):
+            marks.append(self._mark("agents"))
+            s.wait_event(self.ev_fields)                  # this tick's fields (built during the last one)
+            if self._comm_pending:
+                s.wait_event(self.ev_comm)
             self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
             marks.append(self._mark("gather_agents"))
             self.ev_step.record(s)
@@ -312,6 +370,10 @@ class NavTick:
             self._marks.append(self._mark("end"))
             self.t["pos_xz"], self.new_pos = self.new_pos, self.t["pos_xz"]
             self.t["vel_xz"], self.new_vel = self.new_vel, self.t["vel_xz"]
+            if self.pipeline_fields:
+                self.pool, self.pool_next = self.pool_next, self.pool
+                self.ev_fields, self.ev_fields_next = self.ev_fields_next, self.ev_fields
+                self.t["field_pool"] = self.pool
             self._make_structs()
         if self.record and self._marks and self._marks[0] is not None:
             self.ev.append(self._marks)
@@ -323,6 +385,9 @@ class NavTick:
         for marks in self.ev:
             for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
                 out.setdefault(n0, []).append(e0.elapsed_time(e1))
+        for e0, e1, e2 in getattr(self, "fev", []):
+            out.setdefault("fields", []).append(e0.elapsed_time(e1))
+            out.setdefault("gather_tiles", []).append(e1.elapsed_time(e2))
         return {k: float(np.mean(v)) for k, v in out.items()}
 
     def tick_ms(self):
@@ -332,6 +397,8 @@ class NavTick:
     def sync(self):
         if self.comm is not None:
             self.comm.synchronize()
+        if self.pipeline_fields:
+            self.fstream.synchronize()
         self.stream.synchronize()
         torch.cuda.synchronize(self.dev)
 

@@ -308,6 +308,24 @@ def test_prefetch_overlap_gives_identical_results(navlib):
     assert np.abs(res[0][1]).max() > 0
 
 
+def test_pipelined_field_builds_give_identical_results(navlib):
+    """tick.NavTick(pipeline_fields=True) builds the fields tick t+1 samples during tick t (own stream,
+    double-buffered pool, behind navhip_stream_wait_stage): a schedule, not a different computation."""
+    from permafrost_engine_amd import tick
+    res = []
+    for pipe in (False, True):
+        T = tick.NavTick(chunk_w=4, fields_per_rank=6, agents_per_rank=5000, device=0, pipeline_fields=pipe)
+        for _ in range(9):
+            T.step()
+        T.sync()
+        res.append((T.t["pos_xz"].cpu().numpy().copy(), T.t["vel_xz"].cpu().numpy().copy(),
+                    T.pool.cpu().numpy().copy()))
+        T.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.abs(res[0][1]).max() > 0 and (res[0][2] != 0).any()
+
+
 def test_lane_grouping_carried_between_ticks_is_only_a_hint(navlib):
     """The cohesion launch reuses the lane grouping the previous step left behind (whole-range
     steps).  It must be ignored when the flock layout changed in between, and using it must never
