@@ -1,5 +1,6 @@
 // agent_internal.h -- launch interface of agent_kernels.hip (used by navhip_api.hip).
 #pragma once
+#define NH_SCAN_T 256      /* threads (= cells) per block of the two-pass scans */
 #include "navhip_internal.h"
 #include "agent_types.h"
 
@@ -8,7 +9,7 @@ struct nh_spatial_scratch {
     int32_t *cell_count;                     // [ncells]   zero between builds
     int32_t *cell_start;                     // [ncells+1]
     int32_t *tmp_id;                         // [n] cell-sorted uids, arrival order inside a cell
-    int32_t *block_sum;                      // [ceil(ncells/1024)] scan scratch
+    int32_t *block_sum;                      // [ceil(ncells / NH_SCAN_T)] scan scratch
     int32_t *box;                            // [4] bounding box of the stepped slab (optional filter)
     float4  *recA;                           // [n] pool records
     float2  *recV;                           // [n]

@@ -97,14 +97,17 @@ __global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz
     ent_rank[i] = atomicAdd(&cell_count[c], 1);
 }
 
-// exclusive scan of cell_count[0..ncells) -> cell_start[0..ncells], two passes over 1024-cell
+// exclusive scan of cell_count[0..ncells) -> cell_start[0..ncells], two passes over NH_SCAN_T-cell
 // blocks: (1) block-local exclusive scan + block totals, (2) add the sum of the preceding totals.
-__global__ __launch_bounds__(1024) void k_sp_scan_local(const int32_t *cell_count, int32_t *cell_start,
-                                                        int32_t *block_sum, int ncells)
+// (Blocks of four waves: a 1024-thread block needs sixteen free wave slots on ONE compute unit at the
+// same moment, and beside the cohesion kernel's stream of one-wave blocks it waited for them for
+// 50 us -- on the critical path of the tick.)
+__global__ __launch_bounds__(NH_SCAN_T) void k_sp_scan_local(const int32_t *cell_count, int32_t *cell_start,
+                                                             int32_t *block_sum, int ncells)
 {
-    __shared__ int32_t wsum[16];
+    __shared__ int32_t wsum[NH_SCAN_T / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int i = blockIdx.x * 1024 + t;
+    const int i = blockIdx.x * NH_SCAN_T + t;
     int32_t v = (i < ncells) ? cell_count[i] : 0;
     int32_t incl = v;
 #pragma unroll
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(1024) void k_sp_scan_local(const int32_t *cell_coun
     __syncthreads();
     int32_t woff = 0, tot = 0;
 #pragma unroll
-    for(int k = 0; k < 16; k++) {
+    for(int k = 0; k < NH_SCAN_T / 64; k++) {
         int32_t x = wsum[k];
         if(k < w) woff += x;
         tot += x;
@@ -125,14 +128,14 @@ __global__ __launch_bounds__(1024) void k_sp_scan_local(const int32_t *cell_coun
     if(t == 0) block_sum[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(1024) void k_sp_scan_add(int32_t *cell_start, const int32_t *block_sum,
-                                                      int ncells, int nblocks, int32_t *zero_counts)
+__global__ __launch_bounds__(NH_SCAN_T) void k_sp_scan_add(int32_t *cell_start, const int32_t *block_sum,
+                                                           int ncells, int nblocks, int32_t *zero_counts)
 {
-    __shared__ int32_t wsum[16];
+    __shared__ int32_t wsum[NH_SCAN_T / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     // sum of the totals of the blocks before this one (and, in the last block, of all blocks)
     int32_t part = 0, all = 0;
-    for(int k = t; k < nblocks; k += 1024) {
+    for(int k = t; k < nblocks; k += NH_SCAN_T) {
         int32_t x = block_sum[k];
         all += x;
         if(k < (int)blockIdx.x) part += x;
@@ -145,14 +148,14 @@ __global__ __launch_bounds__(1024) void k_sp_scan_add(int32_t *cell_start, const
     __syncthreads();
     int32_t tot = 0;
 #pragma unroll
-    for(int k = 0; k < 16; k++) tot += wsum[k];
+    for(int k = 0; k < NH_SCAN_T / 64; k++) tot += wsum[k];
     __syncthreads();
     if(lane == 0) wsum[w] = part;
     __syncthreads();
     int32_t off = 0;
 #pragma unroll
-    for(int k = 0; k < 16; k++) off += wsum[k];
-    const int i = blockIdx.x * 1024 + t;
+    for(int k = 0; k < NH_SCAN_T / 64; k++) off += wsum[k];
+    const int i = blockIdx.x * NH_SCAN_T + t;
     if(i < ncells) cell_start[i] += off;
     if(zero_counts && i < ncells) zero_counts[i] = 0;     // consumed by k_sp_scan_local: clean for the next build
     if(last && t == 0) cell_start[ncells] = tot;
@@ -1321,10 +1324,10 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
                            S.ent_cell, S.ent_rank, S.cell_count, box);
-    const int nblocks = (ncells + 1023) / 1024;
-    hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(1024), 0, s, S.cell_count, S.cell_start,
+    const int nblocks = (ncells + NH_SCAN_T - 1) / NH_SCAN_T;
+    hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(NH_SCAN_T), 0, s, S.cell_count, S.cell_start,
                        S.block_sum, ncells);
-    hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(1024), 0, s, S.cell_start, S.block_sum, ncells,
+    hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(NH_SCAN_T), 0, s, S.cell_start, S.block_sum, ncells,
                        nblocks, S.cell_count);
     if(n > 0) {
         hipLaunchKernelGGL(k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, S.ent_cell, S.ent_rank, n,
@@ -1354,7 +1357,7 @@ struct coh_scratch {
 static coh_scratch coh_layout(int32_t *scratch, int n_flocks, int n_members)
 {
     coh_scratch C;
-    C.nb = n_flocks * COH_BINS; C.nblocks = (C.nb + 1023) / 1024;
+    C.nb = n_flocks * COH_BINS; C.nblocks = (C.nb + NH_SCAN_T - 1) / NH_SCAN_T;
     C.wave_off = scratch;
     C.bin_count = C.wave_off + n_flocks + 1;
     C.bin_fill = C.bin_count + C.nb;
@@ -1371,7 +1374,7 @@ static coh_scratch coh_layout(int32_t *scratch, int n_flocks, int n_members)
 size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members)
 {
     const size_t nb = (size_t)n_flocks * COH_BINS;
-    return sizeof(int32_t) * (3 * ((size_t)n_flocks + 1) + 3 * nb + 1 + (nb + 1023) / 1024
+    return sizeof(int32_t) * (3 * ((size_t)n_flocks + 1) + 3 * nb + 1 + (nb + NH_SCAN_T - 1) / NH_SCAN_T
                               + 3 * (size_t)n_members + 1);
 }
 
@@ -1382,16 +1385,22 @@ void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hi
     hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 1), s);
 }
 
+__global__ void k_zero_i32(int32_t *p, int n)
+{
+    for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
 // the counting sort that regroups the lanes of every flock (k_coh_bin .. k_coh_scatter) into perm[which]
 static void coh_regroup(const nh_step_params &P, const coh_scratch &C, int which, bool plan_from_bins,
                         hipStream_t s)
 {
-    hipMemsetAsync(C.bin_count, 0, sizeof(int32_t) * 2 * (size_t)C.nb, s);
+    // (one launch: hipMemsetAsync of an unaligned range is up to three fill kernels)
+    hipLaunchKernelGGL(k_zero_i32, dim3(min(64, (2 * C.nb + 255) / 256)), dim3(256), 0, s, C.bin_count, 2 * C.nb);
     const int gm = (P.n_members + 255) / 256;
     hipLaunchKernelGGL(k_coh_bin, dim3(gm), dim3(256), 0, s, P, C.bin_of, C.bin_count, C.saved[which]);
-    hipLaunchKernelGGL(k_sp_scan_local, dim3(C.nblocks), dim3(1024), 0, s, C.bin_count, C.bin_start,
+    hipLaunchKernelGGL(k_sp_scan_local, dim3(C.nblocks), dim3(NH_SCAN_T), 0, s, C.bin_count, C.bin_start,
                        C.block_sum, C.nb);
-    hipLaunchKernelGGL(k_sp_scan_add, dim3(C.nblocks), dim3(1024), 0, s, C.bin_start, C.block_sum, C.nb,
+    hipLaunchKernelGGL(k_sp_scan_add, dim3(C.nblocks), dim3(NH_SCAN_T), 0, s, C.bin_start, C.block_sum, C.nb,
                        C.nblocks, (int32_t*)nullptr);
     if(plan_from_bins)
         hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start,

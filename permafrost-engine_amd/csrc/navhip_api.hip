@@ -693,7 +693,7 @@ static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hip
     }
     const size_t n = (size_t)w->n_ents, ncells = (size_t)g->grid_w * g->grid_h;
     // ent_cell, ent_rank, cell_count, cell_start, tmp_id, block_sum, box, recA, recV, pool_of
-    const size_t bytes[10] = {4 * n, 4 * n, 4 * ncells, 4 * (ncells + 1), 4 * n, 4 * ((ncells + 1023) / 1024),
+    const size_t bytes[10] = {4 * n, 4 * n, 4 * ncells, 4 * (ncells + 1), 4 * n, 4 * ((ncells + NH_SCAN_T - 1) / NH_SCAN_T),
                               16, 16 * n, 8 * n, 4 * n};
     for(int i = 0; i < 10; i++) {
         int rc = (i == 2) ? ensure_zeroed(ctx, ctx->sp[i], bytes[i], s) : ensure_buf(ctx, ctx->sp[i], bytes[i]);

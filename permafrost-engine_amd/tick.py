@@ -345,7 +345,8 @@ class NavTick:
                 s.wait_event(self.ev_comm)
             self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
             marks.append(self._mark("gather_agents"))
-            self.ev_step.record(s)
+            if self.pipelined:
+                self.ev_step.record(s)
 
     def exchange(self):
         """The slab results (new position + velocity) of every rank -> every rank."""

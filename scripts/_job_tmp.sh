@@ -1,8 +1,8 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; OUT=gpurun_out/r02x; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; OUT=gpurun_out/r02y; mkdir -p $OUT
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/bench.json 2> $OUT/prof.err
 python - <<'PY'
 import csv,collections
-rows=list(csv.DictReader(open('gpurun_out/r02x/stats/s_kernel_trace.csv')))
+rows=list(csv.DictReader(open('gpurun_out/r02y/stats/s_kernel_trace.csv')))
 d=collections.defaultdict(list)
 for r in rows:
     n=r['Kernel_Name'].split('(')[0]
