@@ -378,7 +378,13 @@ typedef struct navhip_world {
     const float    *los_pos_xz;      /* [n][2]  the position the lookup uses: movestate.prev_pos
                                                 (movement.c:4137), or NULL = pos_xz                    */
     int32_t  n_los_slots;
-    int32_t  _reserved;
+    /* Host-buffer calls (navhip_agent_step, _submit) only: a caller that knows that the per-entity
+     * ATTRIBUTE tables -- radius, max_speed, flags, flock, flock_target_xz, flock_offsets,
+     * flock_members -- are the ones of its previous call on this context (no entity was added, removed
+     * or re-flocked) passes the same nonzero epoch again and those tables are not transferred a second
+     * time; 0 = transfer everything (the default).  The per-tick state (pos, vel, speed, state,
+     * has_dest_los, vdes, formation and arrival inputs) always travels. */
+    uint32_t static_epoch;
 } navhip_world;
 #define NAVHIP_LOS_LOOKUP 0xff
 

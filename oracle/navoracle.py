@@ -68,7 +68,7 @@ class World(C.Structure):
         # paths are checked against the reference build itself)
         ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p),
         ("los_pool", C.c_void_p), ("flock_los_slot", C.c_void_p), ("los_pos_xz", C.c_void_p),
-        ("n_los_slots", C.c_int32), ("_reserved", C.c_int32)]
+        ("n_los_slots", C.c_int32), ("static_epoch", C.c_uint32)]
 
 
 class StepOut(C.Structure):

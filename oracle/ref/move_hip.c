@@ -11,6 +11,17 @@
 
 navhip_ctx *N_HIP_Ctx(void);          /* nav_hip.c */
 
+/* The per-entity attribute tables (radius, max speed, flags, flock membership) only change when an
+ * entity is added, removed, re-flagged or re-flocked: movement.c bumps this epoch there (G_Move_AddEntity
+ * :4591, G_Move_RemoveEntity :4615, make_flock :789, the flock disbanding :742,:2859) and the library keeps the
+ * tables of an unchanged epoch on the device (navhip_world.static_epoch). */
+static uint32_t s_hip_attr_epoch = 1;
+static void move_hip_attrs_changed(void)      /* (declared ahead in the harness: ref_move.c) */
+{
+    if(++s_hip_attr_epoch == 0)
+        s_hip_attr_epoch = 1;
+}
+
 static int cmp_u32(const void *a, const void *b)
 {
     uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
@@ -146,6 +157,7 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
         W.form_align_xz = f_align; W.form_drag_xz = f_drag;
     }
     if(any_arrival) { W.arrival_sink_xz = sink; W.arrival_flags = arr_flags; }
+    W.static_epoch = s_hip_attr_epoch;
 
     float *out_vel = calloc(2 * n, sizeof(float));
     uint8_t *status = calloc(n, 1);

@@ -119,9 +119,12 @@ void pfref_move_unload(void)
     memset(&s_w, 0, sizeof(s_w));
 }
 
+static void move_hip_attrs_changed(void);      /* move_hip.c */
+
 int pfref_move_load(pfref_nav *nav, const pfref_move_world *w)
 {
     pfref_move_unload();
+    move_hip_attrs_changed();                  /* new entities, new flocks */
     int n = w->n, ret;
     s_w.n = n;
     s_w.nav = nav;

@@ -1010,6 +1010,7 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
 static int stage_in(navhip_ctx *ctx, int slot, const void *host, size_t bytes, const void **dst,
                     hipStream_t s)
 {
+    nh_async_invalidate_static(ctx);
     *dst = nullptr;
     if(!host) return NAVHIP_OK;
     int rc = ensure_buf(ctx, ctx->stage[slot], bytes);

@@ -80,6 +80,7 @@ int  navhip_build_fields_slots_dev(navhip_ctx *ctx, const navhip_field_req *dev_
                                    const int32_t *dev_slots, hipStream_t s);
 int  navhip_stage_reserve(navhip_ctx *ctx, int slot, size_t bytes, void **dev);
 void nh_async_destroy(navhip_ctx *ctx);
+void nh_async_invalidate_static(navhip_ctx *ctx);   // the staging buffers were used by someone else
 const uint8_t *nh_pool_fields(const navhip_ctx *ctx);
 const int32_t *nh_pool_map(const navhip_ctx *ctx);
 int nh_pool_dests(const navhip_ctx *ctx);

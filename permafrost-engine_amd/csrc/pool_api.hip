@@ -327,6 +327,8 @@ struct nh_async {
     char  *h_out; size_t h_out_cap;
     struct cp { void *dst; const void *src; size_t bytes; };
     std::vector<cp> finish;          // staging -> caller copies at completion
+    // the attribute tables on the device are those of this epoch / entity count / flock count
+    uint32_t static_epoch; int32_t static_n, static_f;
 };
 
 static int pinned_grow(navhip_ctx *ctx, char **p, size_t *cap, size_t need)
@@ -352,6 +354,7 @@ int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhi
         if(!ctx->async) return NAVHIP_ERR_NOMEM;
         ctx->async->pending = false; ctx->async->h_in = ctx->async->h_out = nullptr;
         ctx->async->h_in_cap = ctx->async->h_out_cap = 0;
+        ctx->async->static_epoch = 0; ctx->async->static_n = ctx->async->static_f = 0;
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->async->done, hipEventDisableTiming));
     }
     nh_async *A = ctx->async;
@@ -360,23 +363,23 @@ int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhi
     const size_t n = (size_t)w->n_ents, F = (size_t)w->n_flocks;
     size_t nmembers = (F > 0 && w->flock_offsets) ? (size_t)w->flock_offsets[F] : 0;
     const bool resident = w->n_field_slots == NAVHIP_POOL_RESIDENT;
-    struct item { const void *host; size_t bytes; int slot; const void **dev; };
+    struct item { const void *host; size_t bytes; int slot; const void **dev; bool attr; bool early; };
     navhip_world d = *w;
     std::vector<item> items = {
-        {w->pos_xz, n * 8, 0, (const void**)&d.pos_xz},       {w->vel_xz, n * 8, 1, (const void**)&d.vel_xz},
-        {w->radius, n * 4, 2, (const void**)&d.radius},       {w->max_speed, n * 4, 3, (const void**)&d.max_speed},
-        {w->speed, n * 4, 4, (const void**)&d.speed},         {w->flags, n * 4, 5, (const void**)&d.flags},
-        {w->state, n, 6, (const void**)&d.state},             {w->has_dest_los, n, 7, (const void**)&d.has_dest_los},
-        {w->flock, n * 4, 8, (const void**)&d.flock},         {w->vdes_xz, n * 8, 9, (const void**)&d.vdes_xz},
-        {w->flock_target_xz, F * 8, 10, (const void**)&d.flock_target_xz},
-        {w->flock_offsets, (F + 1) * 4, 11, (const void**)&d.flock_offsets},
-        {w->flock_members, nmembers * 4, 12, (const void**)&d.flock_members},
+        {w->pos_xz, n * 8, 0, (const void**)&d.pos_xz, false, true},       {w->vel_xz, n * 8, 1, (const void**)&d.vel_xz, false, true},
+        {w->radius, n * 4, 2, (const void**)&d.radius, true},       {w->max_speed, n * 4, 3, (const void**)&d.max_speed, true},
+        {w->speed, n * 4, 4, (const void**)&d.speed},         {w->flags, n * 4, 5, (const void**)&d.flags, true},
+        {w->state, n, 6, (const void**)&d.state, false, true},             {w->has_dest_los, n, 7, (const void**)&d.has_dest_los},
+        {w->flock, n * 4, 8, (const void**)&d.flock, true},         {w->vdes_xz, n * 8, 9, (const void**)&d.vdes_xz},
+        {w->flock_target_xz, F * 8, 10, (const void**)&d.flock_target_xz, true},
+        {w->flock_offsets, (F + 1) * 4, 11, (const void**)&d.flock_offsets, true},
+        {w->flock_members, nmembers * 4, 12, (const void**)&d.flock_members, true},
         {w->form_ready, n, 24, (const void**)&d.form_ready},  {w->cell_pos_xz, n * 8, 25, (const void**)&d.cell_pos_xz},
         {w->form_cohesion_xz, n * 8, 26, (const void**)&d.form_cohesion_xz},
         {w->form_align_xz, n * 8, 27, (const void**)&d.form_align_xz},
         {w->form_drag_xz, n * 8, 28, (const void**)&d.form_drag_xz},
-        {w->arrival_sink_xz, n * 8, 36, (const void**)&d.arrival_sink_xz},
-        {w->arrival_flags, n, 37, (const void**)&d.arrival_flags},
+        {w->arrival_sink_xz, n * 8, 36, (const void**)&d.arrival_sink_xz, false, true},
+        {w->arrival_flags, n, 37, (const void**)&d.arrival_flags, false, true},
         {w->los_pool, (size_t)(w->n_los_slots > 0 ? w->n_los_slots : 0) * NH_CELLS, 38, (const void**)&d.los_pool},
         {w->flock_los_slot, F * (size_t)ctx->nchunks * 4, 39, (const void**)&d.flock_los_slot},
         {w->los_pos_xz, n * 8, 40, (const void**)&d.los_pos_xz},
@@ -386,59 +389,100 @@ int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhi
         items.push_back({w->field_pool, (size_t)(w->n_field_slots > 0 ? w->n_field_slots : 0) * NH_CELLS, 14,
                          (const void**)&d.field_pool});
     }
-    // inputs: pageable arrays go through the pinned slab (one memcpy each), pinned ones
-    // (navhip_host_alloc) are transferred in place
+    // inputs: pageable arrays are packed into the pinned slab (one memcpy each) and cross the bus as ONE
+    // transfer into one device slab -- a dozen separate copies cost a dozen hand-overs to the copy
+    // engine, more than the bytes --; pinned ones (navhip_host_alloc) are transferred in place
+    // The attribute tables keep their own device buffers and stay there while the caller repeats its
+    // static_epoch.
+    const size_t AL = 256;
+    const bool attrs_resident = w->static_epoch != 0 && w->static_epoch == A->static_epoch
+                                && A->static_n == w->n_ents && A->static_f == w->n_flocks;
     size_t need = 0;
-    for(auto &it : items) if(it.host && !is_pinned(it.host)) need += (it.bytes + 255) & ~(size_t)255;
+    for(auto &it : items) if(it.host && !it.attr && !is_pinned(it.host)) need += (it.bytes + AL - 1) & ~(AL - 1);
     int rc = pinned_grow(ctx, &A->h_in, &A->h_in_cap, need);
     if(rc) return rc;
-    size_t off = 0;
-    for(auto &it : items) {
-        *it.dev = nullptr;
-        if(!it.host) continue;
-        rc = navhip_stage_reserve(ctx, it.slot, it.bytes, (void**)it.dev);
-        if(rc) return rc;
-        const void *src = it.host;
-        if(!is_pinned(it.host)) {
-            memcpy(A->h_in + off, it.host, it.bytes);
-            src = A->h_in + off;
-            off += (it.bytes + 255) & ~(size_t)255;
+    char *d_slab = nullptr;
+    if(need) { rc = navhip_stage_reserve(ctx, 44, need, (void**)&d_slab); if(rc) return rc; }
+    // Two passes: what the front of the step reads (positions, velocities, states, the attribute
+    // tables) goes first and the front is started on it (navhip_agent_prefetch_dev); the rest is packed
+    // and transferred while the spatial hash, the neighbour walk and the cohesion term run.
+    size_t off = 0, sent = 0;
+    for(auto &it : items) *it.dev = nullptr;
+    for(int pass = 0; pass < 2; pass++) {
+        for(auto &it : items) {
+            if(!it.host || (it.attr || it.early) != (pass == 0)) continue;
+            if(it.attr || is_pinned(it.host)) {
+                rc = navhip_stage_reserve(ctx, it.slot, it.bytes, (void**)it.dev);
+                if(rc) return rc;
+                if(it.attr && attrs_resident) continue;
+                if(it.bytes) HIPCHK(ctx, hipMemcpyAsync((void*)*it.dev, it.host, it.bytes, hipMemcpyHostToDevice, s));
+            }else{
+                memcpy(A->h_in + off, it.host, it.bytes);
+                *it.dev = d_slab + off;
+                off += (it.bytes + AL - 1) & ~(AL - 1);
+                // hand what has been packed to the copy engine about every megabyte: it moves that
+                // part while the next one is being packed
+                if(off - sent >= ((size_t)1 << 20)) {
+                    HIPCHK(ctx, hipMemcpyAsync(d_slab + sent, A->h_in + sent, off - sent, hipMemcpyHostToDevice, s));
+                    sent = off;
+                }
+            }
         }
-        if(it.bytes) HIPCHK(ctx, hipMemcpyAsync((void*)*it.dev, src, it.bytes, hipMemcpyHostToDevice, s));
+        if(off > sent) {
+            HIPCHK(ctx, hipMemcpyAsync(d_slab + sent, A->h_in + sent, off - sent, hipMemcpyHostToDevice, s));
+            sent = off;
+        }
+        if(pass == 0) {
+            // (device addresses of the late arrays: fixed before their contents arrive)
+            size_t o2 = off;
+            for(auto &it : items) {
+                if(!it.host || it.attr || it.early) continue;
+                if(is_pinned(it.host)) { rc = navhip_stage_reserve(ctx, it.slot, it.bytes, (void**)it.dev); if(rc) return rc; }
+                else { *it.dev = d_slab + o2; o2 += (it.bytes + AL - 1) & ~(AL - 1); }
+            }
+            rc = navhip_agent_prefetch_dev(ctx, &d, s);
+            if(rc) return rc;
+        }
     }
-    // outputs
+    A->static_epoch = w->static_epoch; A->static_n = w->n_ents; A->static_f = w->n_flocks;
+    // outputs: the same -- one device slab, one transfer, for the pageable ones
     size_t b = (size_t)w->work_begin, e = (size_t)w->work_end;
     if(b == 0 && e == 0) e = n;
     navhip_step_out dout = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    struct oitem { void **dev; void *host; size_t row; int slot; } outs[5] = {
-        {(void**)&dout.vel_xz, out->vel_xz, 8, 15},   {(void**)&dout.new_pos_xz, out->new_pos_xz, 8, 16},
-        {(void**)&dout.vdes_xz, out->vdes_xz, 8, 17}, {(void**)&dout.vpref_xz, out->vpref_xz, 8, 18},
-        {(void**)&dout.status, out->status, 1, 19}};
+    struct oitem { void **dev; void *host; size_t row; int slot; size_t off; } outs[5] = {
+        {(void**)&dout.vel_xz, out->vel_xz, 8, 15, 0},   {(void**)&dout.new_pos_xz, out->new_pos_xz, 8, 16, 0},
+        {(void**)&dout.vdes_xz, out->vdes_xz, 8, 17, 0}, {(void**)&dout.vpref_xz, out->vpref_xz, 8, 18, 0},
+        {(void**)&dout.status, out->status, 1, 19, 0}};
+    // (a pageable output lives in the slab as its rows [b, e): the kernels index by entity, so the
+    // array's device address is the slab position minus b rows)
     size_t oneed = 0;
-    for(auto &o : outs) if(o.host && !is_pinned(o.host)) oneed += ((e - b) * o.row + 255) & ~(size_t)255;
+    for(auto &o : outs) if(o.host && !is_pinned(o.host)) { o.off = oneed; oneed += ((e - b) * o.row + AL - 1) & ~(AL - 1); }
     rc = pinned_grow(ctx, &A->h_out, &A->h_out_cap, oneed);
     if(rc) return rc;
+    char *d_oslab = nullptr;
+    if(oneed) { rc = navhip_stage_reserve(ctx, 45, oneed, (void**)&d_oslab); if(rc) return rc; }
     for(auto &o : outs) {
         if(!o.host) continue;
-        rc = navhip_stage_reserve(ctx, o.slot, n * o.row, o.dev);
-        if(rc) return rc;
+        if(is_pinned(o.host)) {
+            rc = navhip_stage_reserve(ctx, o.slot, n * o.row, o.dev);
+            if(rc) return rc;
+        }else{
+            *o.dev = d_oslab + o.off - b * o.row;
+        }
     }
     rc = navhip_agent_step_dev(ctx, &d, &dout, s);
     if(rc) return rc;
     A->finish.clear();
-    size_t ooff = 0;
     for(auto &o : outs) {
         if(!o.host || e <= b) continue;
         const size_t bytes = (e - b) * o.row;
         char *dst = (char*)o.host + b * o.row;
-        if(is_pinned(o.host)) {
+        if(is_pinned(o.host))
             HIPCHK(ctx, hipMemcpyAsync(dst, (char*)*o.dev + b * o.row, bytes, hipMemcpyDeviceToHost, s));
-        }else{
-            HIPCHK(ctx, hipMemcpyAsync(A->h_out + ooff, (char*)*o.dev + b * o.row, bytes, hipMemcpyDeviceToHost, s));
-            A->finish.push_back({dst, A->h_out + ooff, bytes});
-            ooff += (bytes + 255) & ~(size_t)255;
-        }
+        else
+            A->finish.push_back({dst, A->h_out + o.off, bytes});
     }
+    if(oneed) HIPCHK(ctx, hipMemcpyAsync(A->h_out, d_oslab, oneed, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipEventRecord(A->done, s));
     A->pending = true;
     return NAVHIP_OK;
@@ -470,6 +514,8 @@ int navhip_agent_step_wait(navhip_ctx *ctx)
 }
 
 }  // extern "C"
+
+void nh_async_invalidate_static(navhip_ctx *ctx) { if(ctx->async) ctx->async->static_epoch = 0; }
 
 void nh_async_destroy(navhip_ctx *ctx)
 {

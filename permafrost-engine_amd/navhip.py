@@ -315,7 +315,7 @@ class World(C.Structure):
         ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p),
         ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p),
         ("los_pool", C.c_void_p), ("flock_los_slot", C.c_void_p), ("los_pos_xz", C.c_void_p),
-        ("n_los_slots", C.c_int32), ("_reserved", C.c_int32)]
+        ("n_los_slots", C.c_int32), ("static_epoch", C.c_uint32)]
 
 
 class StepOut(C.Structure):
@@ -564,6 +564,20 @@ def _ctx_pool_map(self, dest, chunk_r, chunk_c, ff_ids):
     self._chk(lib().navhip_pool_map(self._h, len(d), _hp(d), _hp(r), _hp(c), _hp(i)), "navhip_pool_map")
 
 
+def host_alloc(nbytes):
+    """navhip_host_alloc: pinned host memory as a writable buffer (freed with host_free(buf))."""
+    p = lib().navhip_host_alloc(nbytes)
+    if not p:
+        raise MemoryError("navhip_host_alloc(%d)" % nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    buf._navhip_ptr = p
+    return buf
+
+
+def host_free(buf):
+    lib().navhip_host_free(C.c_void_p(buf._navhip_ptr))
+
+
 def _ctx_agent_step_async(self, arrays, hz=20, work=None, want=("vel_xz", "new_pos_xz", "status"), spin=None):
     """navhip_agent_step_submit + _poll: returns the outputs once the step has completed; `spin`
     is called while it is still running (what the nav task does between submit and join)."""
@@ -572,6 +586,7 @@ def _ctx_agent_step_async(self, arrays, hz=20, work=None, want=("vel_xz", "new_p
         w.n_field_slots = POOL_RESIDENT
     if work is not None:
         w.work_begin, w.work_end = work
+    w.static_epoch = int(arrays.get("static_epoch") or 0)
     n = w.n_ents
     out = {}
     so = StepOut()

@@ -24,6 +24,8 @@ def timed(fn, reps=5):
 
 
 def main():
+    import torch
+    torch.cuda.init()          # (before libnavhip touches HIP: torch brings its own runtime)
     W, K, N = 16, 64, 100_000
     grid = synth.cost_grid(W, W, seed=1234)
     ctx = navhip.NavContext(W, W)
@@ -62,6 +64,74 @@ def main():
     arrays2["vdes_xz"] = np.tile(np.array([[1.0, 0.0]], np.float32), (N, 1))
     t = timed(lambda: ctx.agent_step(arrays2, want=("vel_xz", "new_pos_xz", "status")), reps=3)
     out["agents_host_api_given_vdes_steps_per_s"] = N / t
+    # the host-buffer step the binding uses (oracle/ref/move_hip.c): fields resident in the device pool
+    # (built there once; the step uploads the 3 MB entity snapshot and downloads 1.7 MB of results),
+    # navhip_agent_step_submit / _poll through the pinned staging area -- against the SAME step with
+    # everything already on the device (navhip_agent_step_dev)
+    ctx.pool_create(len(reqs) + 8, K)
+    ctx.pool_build(reqs, readback=False)
+    all_ids = np.array([navhip.N_FlowFieldID(reqs[i]) for i in range(len(reqs))], np.uint64)
+    ctx.pool_map(cols["dest"], cols["chunk_r"], cols["chunk_c"], all_ids)
+    arrays3 = dict(arrays)
+    arrays3["field_pool"] = None
+    arrays3["flock_field_slot"] = None
+    arrays3["use_resident_pool"] = True
+    import ctypes as C
+    L = navhip.lib()
+
+    def c_level(arr, outs, epoch=0):
+        """submit + wait on prebuilt structs: the C boundary itself, no Python per-call work"""
+        w, keep = navhip.make_world(W, W, arr, 20)
+        w.n_field_slots = navhip.POOL_RESIDENT
+        w.static_epoch = epoch
+        so = navhip.StepOut()
+        so.vel_xz, so.new_pos_xz, so.status = (o.ctypes.data for o in outs)
+
+        def call():
+            assert L.navhip_agent_step_submit(ctx._h, C.byref(w), C.byref(so)) == 0
+            assert L.navhip_agent_step_wait(ctx._h) == 0
+        return timed(call, reps=10), keep
+
+    outs = (np.zeros((N, 2), np.float32), np.zeros((N, 2), np.float32), np.zeros(N, np.uint8))
+    t_res, _k1 = c_level(arrays3, outs)
+    out["agents_host_resident_pool_ms"] = t_res * 1e3
+    out["agents_host_resident_pool_steps_per_s"] = N / t_res
+    outs_e = tuple(np.zeros_like(o) for o in outs)
+    t_ep, _k3 = c_level(arrays3, outs_e, epoch=7)
+    out["agents_host_resident_pool_static_epoch_ms"] = t_ep * 1e3
+    assert np.array_equal(outs_e[0].view(np.uint32), outs[0].view(np.uint32))
+    # the same with the caller's arrays in pinned memory (navhip_host_alloc): no staging memcpy
+    def pin(v):
+        v = np.ascontiguousarray(v)
+        buf = navhip.host_alloc(max(1, v.nbytes))
+        pv = np.frombuffer(buf, dtype=v.dtype, count=v.size).reshape(v.shape)
+        pv[...] = v
+        return pv
+    pinned = {k: (pin(v) if isinstance(v, np.ndarray) else v) for k, v in arrays3.items()}
+    pouts = tuple(pin(o) for o in outs)
+    t_pin, _k2 = c_level(pinned, pouts)
+    out["agents_host_resident_pool_pinned_arrays_ms"] = t_pin * 1e3
+    assert np.array_equal(pouts[0].view(np.uint32), outs[0].view(np.uint32))
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in arrays.items()
+         if isinstance(v, np.ndarray)}
+    d["flock_target_xz"] = d["flock_target_xz"].float()
+    wdev, keep = navhip.make_world(W, W, d, hz=20)
+    o_vel = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+    o_pos = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+    o_st = torch.zeros(N, dtype=torch.uint8, device=dev)
+    so = navhip.StepOut()
+    so.vel_xz, so.new_pos_xz, so.status = o_vel.data_ptr(), o_pos.data_ptr(), o_st.data_ptr()
+    st = torch.cuda.Stream(device=dev)
+
+    def step_dev():
+        ctx.agent_step_dev(wdev, so, stream=st.cuda_stream)
+        st.synchronize()
+    t_dev = timed(step_dev, reps=10)
+    out["agents_dev_same_world_ms"] = t_dev * 1e3
+    out["agents_host_resident_over_dev"] = t_res / t_dev
+    out["agents_host_resident_pinned_over_dev"] = t_pin / t_dev
+    out["agents_host_resident_static_epoch_over_dev"] = t_ep / t_dev
     # LOS: the destination-chunk field of 4096 random destinations
     rng = np.random.RandomState(1)
     cells = synth.passable_cells(grid)

@@ -3,7 +3,7 @@
 snapshot must be bit-identical to ONE process that builds every field and steps every agent
 (tick.NavTick(solo=True)) on the same world.
     NAVHIP_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \\
-        --master-addr 127.0.0.1 --master-port 29512 scripts/check_multirank.py [--tile-exchange all]
+        --master-addr 127.0.0.1 --master-port 29512 scripts/check_multirank.py [all] [--pipeline-fields]
 (on a single-GPU box the ranks share the GPU and gloo stages the exchange through the host)."""
 import os
 import sys
@@ -17,8 +17,9 @@ from permafrost_engine_amd import dist as pdist, tick        # noqa: E402
 def main():
     rank, world, local = pdist.init()
     mode = "all" if "all" in sys.argv else "auto"
+    pipe = "--pipeline-fields" in sys.argv
     kw = dict(chunk_w=4, fields_per_rank=6, agents_per_rank=12000, world=world, device=local)
-    T = tick.NavTick(rank=rank, tile_exchange=mode, **kw)
+    T = tick.NavTick(rank=rank, tile_exchange=mode, pipeline_fields=pipe, **kw)
     K = 6
     for _ in range(K):
         T.step()
@@ -29,8 +30,9 @@ def main():
     S.sync()
     ok = torch.equal(T.t["pos_xz"], S.t["pos_xz"]) and torch.equal(T.t["vel_xz"], S.t["vel_xz"])
     moved = (S.t["vel_xz"].abs().sum(1) > 0).float().mean().item()
-    print("rank %d/%d tile_exchange=%s pipelined=%s: %s (moving fraction %.2f)"
-          % (rank, world, T.tile_exchange, T.pipelined, "IDENTICAL to solo" if ok else "MISMATCH", moved), flush=True)
+    print("rank %d/%d backend=%s tile_exchange=%s pipelined=%s fields_ahead=%s: %s (moving fraction %.2f)"
+          % (rank, world, torch.distributed.get_backend() if world > 1 else "-", T.tile_exchange, T.pipelined,
+             T.pipeline_fields, "IDENTICAL to solo" if ok else "MISMATCH", moved), flush=True)
     pdist.barrier()
     T.close(); S.close()
     if torch.distributed.is_initialized():

@@ -128,3 +128,32 @@ def test_async_step_equals_the_blocking_one(navlib, small):
     N = small["N"]
     o1 = ctx.agent_step_async(a, work=(0, N // 3))
     assert np.array_equal(o1["vel_xz"][:N // 3], exp["vel_xz"][:N // 3]) and not o1["vel_xz"][N // 3:].any()
+
+
+def test_static_epoch_skips_the_attribute_tables_only(navlib, small):
+    """navhip_world.static_epoch: a repeated nonzero epoch means "radius / max_speed / flags / flock
+    tables are those of my previous call" -- they are not transferred again, the per-tick state is."""
+    ctx, reqs, cols, W, K = small["ctx"], small["reqs"], small["cols"], small["W"], small["K"]
+    ctx.pool_create(len(reqs), K)
+    ctx.pool_build(reqs[small["uniq"]], readback=False)
+    ctx.pool_map(cols["dest"], cols["chunk_r"], cols["chunk_c"], small["all_ids"])
+    a = dict(small["arrays"], use_resident_pool=True)
+    exp = ctx.agent_step_async(a)
+    keys = ("vel_xz", "new_pos_xz", "status")
+    first = ctx.agent_step_async(dict(a, static_epoch=5))
+    again = ctx.agent_step_async(dict(a, static_epoch=5))
+    assert all(np.array_equal(first[k], exp[k]) and np.array_equal(again[k], exp[k]) for k in keys)
+    # per-tick state moves on under the same epoch: it always travels
+    moved = dict(a, pos_xz=exp["new_pos_xz"], vel_xz=exp["vel_xz"])
+    exp2 = ctx.agent_step_async(moved)
+    got2 = ctx.agent_step_async(dict(moved, static_epoch=5))
+    assert all(np.array_equal(got2[k], exp2[k]) for k in keys) and not np.array_equal(exp2["vel_xz"], exp["vel_xz"])
+    # an attribute changes: the caller says so with a new epoch
+    fat = dict(moved, radius=(a["radius"] * 1.5).astype(np.float32))
+    exp3 = ctx.agent_step_async(fat)
+    got3 = ctx.agent_step_async(dict(fat, static_epoch=6))
+    assert all(np.array_equal(got3[k], exp3[k]) for k in keys) and not np.array_equal(exp3["vel_xz"], exp2["vel_xz"])
+    # another host-buffer entry point used the staging buffers in between: the epoch is forgotten
+    ctx.agent_step(a)
+    got4 = ctx.agent_step_async(dict(fat, static_epoch=6))
+    assert all(np.array_equal(got4[k], exp3[k]) for k in keys)
