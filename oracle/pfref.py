@@ -103,6 +103,7 @@ def lib():
                                                         C.c_float, C.c_float, C.c_float,
                                                         C.c_void_p]
         L.pfref_cached_field.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.pfref_cached_los.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.pfref_has_dest_los.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float,
                                          C.c_float, C.c_float]
         L.pfref_position_pathable.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
@@ -352,6 +353,12 @@ class RefNav:
     def cached_field(self, dest_id, chunk_r, chunk_c):
         out = np.zeros((64, 64), np.uint8)
         ok = lib().pfref_cached_field(self._h, dest_id, chunk_r, chunk_c, _p(out))
+        return out if ok else None
+
+    def cached_los(self, dest_id, chunk_r, chunk_c):
+        """The LOS field the field cache holds for (dest, chunk), [64,64] u8 (bit 0 visible), or None."""
+        out = np.zeros((64, 64), np.uint8)
+        ok = lib().pfref_cached_los(self._h, dest_id, chunk_r, chunk_c, _p(out))
         return out if ok else None
 
     def has_dest_los(self, dest_id, pos, dst):

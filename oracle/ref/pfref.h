@@ -133,6 +133,7 @@ void   pfref_trace_clear(void);
 void   pfref_desired_point_seek_velocity(pfref_nav *nav, uint32_t dest_id, float x, float z,
                                          float dst_x, float dst_z, float out[2]);
 /* (dest,chunk) -> cached field (fieldcache.c): returns 1 and copies 4096 dirs */
+int    pfref_cached_los(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c, uint8_t *out);
 int    pfref_cached_field(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c,
                           uint8_t *out_dirs);
 /* N_HasDestLOS (nav.c:4026) */

@@ -303,6 +303,22 @@ int pfref_cached_field(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_
     return 1;
 }
 
+/* the LOS field the field cache holds for (dest, chunk): bit 0 visible, bit 1 wavefront_blocked */
+int pfref_cached_los(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c, uint8_t *out)
+{
+    struct nav_private *priv = &nav->priv;
+    struct coord chunk = (struct coord){chunk_r, chunk_c};
+    if(!N_FC_ContainsLOSField(priv->fieldcache, dest_id, chunk))
+        return 0;
+    const struct LOS_field *lf = N_FC_LOSFieldAt(priv->fieldcache, dest_id, chunk);
+    if(!lf)
+        return 0;
+    for(int r = 0; r < FIELD_RES_R; r++)
+    for(int c = 0; c < FIELD_RES_C; c++)
+        out[r * FIELD_RES_C + c] = (uint8_t)(lf->field[r][c].visible | (lf->field[r][c].wavefront_blocked << 1));
+    return 1;
+}
+
 int pfref_has_dest_los(pfref_nav *nav, uint32_t dest_id, float x, float z, float dst_x, float dst_z)
 {
     return N_HasDestLOS(dest_id, (vec2_t){x, z}, &nav->priv, nav->map_pos, (vec2_t){dst_x, dst_z});

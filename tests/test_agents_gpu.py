@@ -160,6 +160,76 @@ def test_velocity_step_matches_reference(navlib, clustered, n, k, blk):
     pfref.RefMove.unload()
 
 
+@pytest.mark.parametrize("blk", [False, True])
+def test_device_los_lookup_matches_N_HasDestLOS(navlib, blk):
+    """has_dest_los = NAVHIP_LOS_LOOKUP: the step answers N_HasDestLOS (nav.c:4026) itself from the LOS
+    fields of the field cache.  The reference's own N_HasDestLOS for every agent (it builds what it
+    needs on demand), then the cache's LOS fields handed to the device as pool + (dest, chunk) table:
+    the step with lookups must equal the step with the reference's answers given explicitly."""
+    grid = cases.synth.cost_grid(4, 4, seed=21)
+    blockers = cases.random_blockers(grid, seed=8, frac=0.03) if blk else None
+    grid, nav = cases.ref_nav_for(4, 4, seed=21, blockers=blockers)
+    n, k = 1500, 4
+    world = cases.make_agents(grid, n, k, seed=77, clustered=False)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    vdes = mv.vdes()
+    tgt = world["flock_target_xz"]
+    ref_los = np.array([nav.has_dest_los(dest_ids[f], world["pos_xz"][i], tgt[f]) if f >= 0 else False
+                        for i, f in enumerate(world["flock"])])
+    assert ref_los.any() and not ref_los.all()
+    pool, slot = [], -np.ones((k, nav.w * nav.h), np.int32)
+    for f in range(k):
+        for r in range(nav.h):
+            for c in range(nav.w):
+                lf = nav.cached_los(dest_ids[f], r, c)
+                if lf is not None:
+                    slot[f, r * nav.w + c] = len(pool)
+                    pool.append(lf)
+    pool = np.stack(pool).reshape(len(pool), 4096)
+    a = _step_arrays(world, mv, vdes)
+    ctx = _upload(navlib, nav)
+    exp = ctx.agent_step(dict(a, has_dest_los=ref_los.astype(np.uint8)))
+    got = ctx.agent_step(dict(a, has_dest_los=np.full(n, navlib.LOS_LOOKUP, np.uint8), los_pool=pool,
+                              flock_los_slot=slot))
+    for key in ("vel_xz", "new_pos_xz", "vpref_xz"):
+        assert np.array_equal(got[key].view(np.uint32), exp[key].view(np.uint32)), key
+    assert ((got["status"] & navlib.ST_LOS_MISS) != 0).sum() == 0
+    assert not np.array_equal(exp["vel_xz"], ctx.agent_step(dict(a, has_dest_los=np.zeros(n, np.uint8)))["vel_xz"])
+    # the previous position as the lookup position (compute_los_state, movement.c:4137)
+    prev = (world["pos_xz"] - world["vel_xz"]).astype(np.float32)
+    ref_prev = np.array([nav.has_dest_los(dest_ids[f], prev[i], tgt[f]) if f >= 0 else False
+                         for i, f in enumerate(world["flock"])])
+    exp_p = ctx.agent_step(dict(a, has_dest_los=ref_prev.astype(np.uint8)))
+    # (N_HasDestLOS may have built more fields for the previous positions: dump again)
+    pool2, slot2 = [], -np.ones((k, nav.w * nav.h), np.int32)
+    for f in range(k):
+        for r in range(nav.h):
+            for c in range(nav.w):
+                lf = nav.cached_los(dest_ids[f], r, c)
+                if lf is not None:
+                    slot2[f, r * nav.w + c] = len(pool2)
+                    pool2.append(lf)
+    got_p = ctx.agent_step(dict(a, has_dest_los=np.full(n, navlib.LOS_LOOKUP, np.uint8),
+                                los_pool=np.stack(pool2).reshape(len(pool2), 4096), flock_los_slot=slot2,
+                                los_pos_xz=prev))
+    assert np.array_equal(got_p["vel_xz"].view(np.uint32), exp_p["vel_xz"].view(np.uint32))
+    # a flock whose LOS fields are not there: "false" + NAVHIP_ST_LOS_MISS (the host requests the path)
+    slot_miss = slot.copy()
+    slot_miss[0] = -1
+    miss = ctx.agent_step(dict(a, has_dest_los=np.full(n, navlib.LOS_LOOKUP, np.uint8), los_pool=pool,
+                               flock_los_slot=slot_miss))
+    in0 = world["flock"] == 0
+    flagged = (miss["status"] & navlib.ST_LOS_MISS) != 0
+    # (every agent of the flock whose state consults the line of sight: the point-seeking ones)
+    seek = np.isin(world["state"], (0, 5, 6))
+    assert flagged[in0 & seek].all() and flagged[in0].sum() > 50
+    assert flagged[~in0].sum() == 0
+    exp_m = ctx.agent_step(dict(a, has_dest_los=np.where(in0, 0, ref_los).astype(np.uint8)))
+    assert np.array_equal(miss["vel_xz"].view(np.uint32), exp_m["vel_xz"].view(np.uint32))
+    ctx.close()
+    pfref.RefMove.unload()
+
+
 def test_garrisoned_neighbours_take_the_wave_path(navlib):
     """filter_garrisoned (position.c:100-119) permutes the candidate list: agents with a garrisoned
     entity among their hits are stepped by the wave-per-agent kernel, bit-identical to the reference."""
