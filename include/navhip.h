@@ -76,9 +76,11 @@ enum {
                                     is left untouched (the cached field stays valid, the device image
                                     of N_ApplyDeferredInvalidations, nav.c:2208) */
 #define NAVHIP_REQ_LIVE_IIDS  0x4 /* portal targets: re-read port_iid / next_iid on the device from the
-                                    CURRENT local_islands plane at the first endpoint tile of the
-                                    port / next portal (for request lists that outlive a relabel, as
-                                    in the device-resident incremental-repair benchmark) */
+                                    CURRENT local_islands plane -- the label of the first tile of the
+                                    port / next portal that has one (a blocker leaves ISLAND_NONE); a
+                                    portal blocked from end to end leads nowhere: the slot is left
+                                    untouched (for request lists that outlive a relabel, as in the
+                                    device-resident incremental-repair benchmark) */
 
 #define NAVHIP_REQ_ISLAND_NEAREST 0x8 /* N_FlowFieldUpdateIslandToNearest(aux_iid, ...) (field.c:2307) on
                                     an existing TILE/PORTAL field: the frontier is moved to the tiles

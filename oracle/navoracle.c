@@ -181,11 +181,21 @@ int no_field_update(const no_map *m, const navhip_field_req *rq, uint8_t *inout_
         return -1;
     navhip_field_req live;
     if((rq->flags & NAVHIP_REQ_LIVE_IIDS) && rq->type == NAVHIP_TARGET_PORTAL && m->local_islands[rq->layer]) {
-        /* island ids re-read from the current labels at the first endpoint tiles (include/navhip.h) */
+        /* island ids re-read from the current labels: the first tile of each portal that has one; a
+         * portal without any leads nowhere and the request is skipped (include/navhip.h) */
         const uint16_t *li0 = m->local_islands[rq->layer];
         live = *rq;
-        live.port_iid = li0[((size_t)(rq->chunk_r * m->w + rq->chunk_c) << 12) + rq->port_r0 * RES + rq->port_c0];
-        live.next_iid = li0[((size_t)(rq->next_chunk_r * m->w + rq->next_chunk_c) << 12) + rq->next_r0 * RES + rq->next_c0];
+        live.port_iid = live.next_iid = NAVHIP_ISLAND_NONE;
+        const uint16_t *lp = li0 + ((size_t)(rq->chunk_r * m->w + rq->chunk_c) << 12);
+        for(int r = rq->port_r0; r <= rq->port_r1 && live.port_iid == NAVHIP_ISLAND_NONE; r++)
+            for(int c = rq->port_c0; c <= rq->port_c1 && live.port_iid == NAVHIP_ISLAND_NONE; c++)
+                live.port_iid = lp[r * RES + c];
+        const uint16_t *ln = li0 + ((size_t)(rq->next_chunk_r * m->w + rq->next_chunk_c) << 12);
+        for(int r = rq->next_r0; r <= rq->next_r1 && live.next_iid == NAVHIP_ISLAND_NONE; r++)
+            for(int c = rq->next_c0; c <= rq->next_c1 && live.next_iid == NAVHIP_ISLAND_NONE; c++)
+                live.next_iid = ln[r * RES + c];
+        if(live.port_iid == NAVHIP_ISLAND_NONE || live.next_iid == NAVHIP_ISLAND_NONE)
+            return 0;
         rq = &live;
     }
     const int layer = rq->layer, chunk = rq->chunk_r * m->w + rq->chunk_c;

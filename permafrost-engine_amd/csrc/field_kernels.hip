@@ -40,6 +40,17 @@ __device__ __forceinline__ bool req_uses_bfs(const nh_map_view &map, const navhi
     return L.unit_cost[(int)rq.chunk_r * map.w + rq.chunk_c] != 0;
 }
 
+// first local-island label that is not ISLAND_NONE along a portal (a row or a column of tiles)
+__device__ __forceinline__ uint16_t portal_first_iid(const uint16_t *li, int r0, int c0, int r1, int c1)
+{
+    for(int r = r0; r <= r1; r++)
+        for(int c = c0; c <= c1; c++) {
+            const uint16_t v = li[r * 64 + c];
+            if(v != NAVHIP_ISLAND_NONE) return v;
+        }
+    return NAVHIP_ISLAND_NONE;
+}
+
 // Request flags that are resolved on the device: NAVHIP_REQ_IF_CHANGED (skip unless the chunk, or
 // the next chunk of a portal target, changed) and NAVHIP_REQ_LIVE_IIDS (island ids re-read from
 // the current labels).  Returns false when the request is to be skipped.
@@ -53,10 +64,14 @@ __device__ __forceinline__ bool req_prepare(const nh_map_view &map, navhip_field
         if(!ch) return false;
     }
     if((rq.flags & NAVHIP_REQ_LIVE_IIDS) && portal && L.local_islands) {
-        rq.port_iid = L.local_islands[((size_t)((int)rq.chunk_r * map.w + rq.chunk_c) << 12)
-                                      + rq.port_r0 * 64 + rq.port_c0];
-        rq.next_iid = L.local_islands[((size_t)((int)rq.next_chunk_r * map.w + rq.next_chunk_c) << 12)
-                                      + rq.next_r0 * 64 + rq.next_c0];
+        // the label of the first tile of each portal that HAS one (a blocker on a portal tile leaves
+        // ISLAND_NONE there; the planner's ids come from reachable tiles, nav.c:1893-1907).  A portal
+        // that is blocked from end to end leads nowhere: the request is skipped.
+        rq.port_iid = portal_first_iid(L.local_islands + ((size_t)((int)rq.chunk_r * map.w + rq.chunk_c) << 12),
+                                       rq.port_r0, rq.port_c0, rq.port_r1, rq.port_c1);
+        rq.next_iid = portal_first_iid(L.local_islands + ((size_t)((int)rq.next_chunk_r * map.w + rq.next_chunk_c) << 12),
+                                       rq.next_r0, rq.next_c0, rq.next_r1, rq.next_c1);
+        if(rq.port_iid == NAVHIP_ISLAND_NONE || rq.next_iid == NAVHIP_ISLAND_NONE) return false;
     }
     return true;
 }
@@ -72,6 +87,7 @@ __device__ __forceinline__ bool next_tile_matches(const nh_map_view &map, const 
     if(cr2 != rq.next_chunk_r || cc2 != rq.next_chunk_c) return false;
     if(cr2 >= map.h || cc2 >= map.w) return false;
     if(r2 < rq.next_r0 || r2 > rq.next_r1 || c2 < rq.next_c0 || c2 > rq.next_c1) return false;
+    if(rq.next_iid == NAVHIP_ISLAND_NONE) return false;          // (never a match: not a label)
     const uint16_t *li = map.layers[rq.layer].local_islands;
     return li[((size_t)(cr2 * map.w + cc2) << 12) + r2 * 64 + c2] == rq.next_iid;
 }

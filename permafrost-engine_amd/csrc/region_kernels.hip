@@ -168,11 +168,13 @@ void nh_launch_region_fields(navhip_ctx *ctx, const navhip_region_req *d_reqs, i
                                      L.passmask, L.unit_cost, L.changed, L.islands};
     }
     const size_t lds = (size_t)max_dim * max_dim * 5;
-    static bool attr_set = false;
-    if(!attr_set) {
+    // (per device, not per process: every context's device needs the attribute)
+    static bool attr_set[64] = {false};
+    const int devi = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    if(!attr_set[devi]) {
         hipFuncSetAttribute((const void*)k_region_field, hipFuncAttributeMaxDynamicSharedMemorySize,
                             128 * 128 * 5);
-        attr_set = true;
+        attr_set[devi] = true;
     }
     if(n > 0)
         hipLaunchKernelGGL(k_region_field, dim3(n), dim3(256), lds, s, mv, d_reqs, n, d_seeds,

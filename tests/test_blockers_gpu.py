@@ -132,6 +132,64 @@ def test_incremental_field_repair_equals_full_rebuild(navlib):
     ctx.close()
 
 
+def test_live_island_ids_come_from_a_labelled_portal_tile(navlib):
+    """NAVHIP_REQ_LIVE_IIDS with a blocker on the FIRST tile of a portal: the ids must come from a tile
+    that still has a label (the planner only ever hands out ids of reachable tiles), i.e. the fields
+    equal those of requests that carry the right ids explicitly; a portal blocked end to end is
+    skipped (slot untouched)."""
+    synth = cases.synth
+    W, K = 4, 6
+    grid = synth.cost_grid(W, W, seed=1234)
+    ctx, onav = _setup(navlib, grid, [0])
+    liid = synth.from_chunks(onav.plane(0, "local_islands"))
+    cols = synth.whole_map_requests(grid, synth.destinations(grid, K, seed=42), liid)
+    reqs = cases.cols_to_reqs(cols, navlib.FIELD_REQ_DTYPE)
+    portal = np.flatnonzero(reqs["type"] == navlib.TARGET_PORTAL)
+    rng = np.random.RandomState(4)
+    hit = rng.choice(portal, 24, replace=False)
+    # a small obstacle on the first tile of the port / next portal of the chosen requests
+    rows = np.where(np.arange(len(hit)) % 2 == 0, reqs["chunk_r"][hit] * 64 + reqs["port_r0"][hit],
+                    reqs["next_chunk_r"][hit] * 64 + reqs["next_r0"][hit])
+    colsx = np.where(np.arange(len(hit)) % 2 == 0, reqs["chunk_c"][hit] * 64 + reqs["port_c0"][hit],
+                     reqs["next_chunk_c"][hit] * 64 + reqs["next_c0"][hit])
+    xz = synth.cell_centre(W, W, rows, colsx)
+    circles = np.zeros(len(hit), navlib.CIRCLE_DTYPE)
+    circles["x"], circles["z"], circles["radius"], circles["delta"] = xz[:, 0], xz[:, 1], 3.0, 1
+    onav.blockers_circles(circles.view(navoracle.CIRCLE_DTYPE))
+    onav.set_layer(0, local_islands=onav.local_islands(0))
+    ctx.N_BlockersUpdate(circles)
+    li = synth.from_chunks(onav.plane(0, "local_islands"))
+    first_port = li[reqs["chunk_r"] * 64 + reqs["port_r0"], reqs["chunk_c"] * 64 + reqs["port_c0"]]
+    first_next = li[reqs["next_chunk_r"] * 64 + reqs["next_r0"], reqs["next_chunk_c"] * 64 + reqs["next_c0"]]
+    affected = np.zeros(len(reqs), bool)
+    affected[portal] = (first_port[portal] == 0xFFFF) | (first_next[portal] == 0xFFFF)
+    assert affected.sum() >= 12                                # the case is there
+
+    def first_label(cr, cc, r0, c0, r1, c1):
+        blk = li[cr * 64 + r0:cr * 64 + r1 + 1, cc * 64 + c0:cc * 64 + c1 + 1].ravel()
+        ok = blk[blk != 0xFFFF]
+        return int(ok[0]) if len(ok) else 0xFFFF
+
+    explicit = reqs.copy()
+    dead = np.zeros(len(reqs), bool)
+    for i in portal:
+        q = reqs[i]
+        explicit["port_iid"][i] = first_label(q["chunk_r"], q["chunk_c"], q["port_r0"], q["port_c0"], q["port_r1"], q["port_c1"])
+        explicit["next_iid"][i] = first_label(q["next_chunk_r"], q["next_chunk_c"], q["next_r0"], q["next_c0"], q["next_r1"], q["next_c1"])
+        dead[i] = explicit["port_iid"][i] == 0xFFFF or explicit["next_iid"][i] == 0xFFFF
+    live = reqs.copy()
+    live["flags"] = navlib.REQ_LIVE_IIDS
+    marker = np.full((len(reqs), 64, 64), 7, np.uint8)        # (what a skipped slot keeps)
+    live_in = live.copy()
+    live_in["flags"] |= navlib.REQ_INOUT
+    got, _ = ctx.N_FlowFieldUpdate(live)
+    exp, _ = ctx.N_FlowFieldUpdate(explicit)
+    assert np.array_equal(got[~dead], exp[~dead])
+    ora, _ = onav.build_fields(live.view(navoracle.FIELD_REQ_DTYPE))
+    assert np.array_equal(got[~dead], ora[~dead])
+    ctx.close()
+
+
 @pytest.mark.skipif(not pfref.available(), reason="needs the reference build (oracle/_ref)")
 @pytest.mark.parametrize("w,h", [(3, 2), (2, 3)])
 def test_blockers_on_non_square_maps_match_reference(navlib, w, h):
