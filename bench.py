@@ -276,6 +276,7 @@ def main():
                             pipeline_fields=not args.no_pipeline_fields)
 
     T = make(args.crowded)
+    fields_ahead = T.pipeline_fields
     early = {}
     dt, ticks = run_ticks(T, pdist, torch, args.warmup, args.steps, early)
     phases = T.phase_ms()
@@ -392,7 +393,7 @@ def main():
                        "parallelism": "requests by destination + agent slabs x%d; one all-gather of slab results "
                                       "(16 B/agent) per tick; baked tiles: %s" % (world, args.tile_exchange),
                        "schedule": ("fields of tick t+1 built during tick t beside the agent step (double-buffered pool)"
-                                    if T.pipeline_fields else "fields of tick t built in front of the agent step of tick t")},
+                                    if fields_ahead else "fields of tick t built in front of the agent step of tick t")},
             "ms_per_step_median": float(np.median(ticks)),
             "ms_tick_5_50_100": [at(5), at(50), at(min(100, len(ticks)))],
             "agent_steps_per_s_median_tick": agents_total / (float(np.median(ticks)) * 1e-3),

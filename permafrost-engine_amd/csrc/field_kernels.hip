@@ -87,7 +87,6 @@ __device__ __forceinline__ bool next_tile_matches(const nh_map_view &map, const 
     if(cr2 != rq.next_chunk_r || cc2 != rq.next_chunk_c) return false;
     if(cr2 >= map.h || cc2 >= map.w) return false;
     if(r2 < rq.next_r0 || r2 > rq.next_r1 || c2 < rq.next_c0 || c2 > rq.next_c1) return false;
-    if(rq.next_iid == NAVHIP_ISLAND_NONE) return false;          // (never a match: not a label)
     const uint16_t *li = map.layers[rq.layer].local_islands;
     return li[((size_t)(cr2 * map.w + cc2) << 12) + r2 * 64 + c2] == rq.next_iid;
 }

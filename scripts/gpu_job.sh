@@ -6,6 +6,7 @@
 #   stats   rocprofv3 --kernel-trace --stats of a short bench run
 #   pmc     three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters), --kernel-trace only
 #   fuzz    tests/tools/fuzz_gpu.py
+#   aux     scripts/bench_aux.py (host-buffer rates, LOS)  + scripts/cp_unit_hist.py when its build is there
 TAG=$1; shift
 STEPS=${@:-tests bench calib stats}
 cd $GRAFT_REPO_ROOT
@@ -19,13 +20,15 @@ testsall) timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>
 bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
 benchq) timeout 600 python bench.py --no-cpu-baseline --no-crowded > $OUT/bench_quick.json 2> $OUT/bench_quick.err; tail -c 2500 $OUT/bench_quick.json; tail -3 $OUT/bench_quick.err ;;
 calib) timeout 300 scripts/valu_calib.bin > $OUT/valu_calib.json 2>&1; cat $OUT/valu_calib.json ;;
-stats) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py --steps 40 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof.json 2> $OUT/prof.err
+stats) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof.json 2> $OUT/prof.err
        f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 $f ;;
 pmc) for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES"; do
        n=$(echo $c | cut -d' ' -f1)
-       timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o p --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-crowded > /dev/null 2> $OUT/pmc_$n.err
-     done
-     python scripts/collect_traffic.py $OUT > $OUT/traffic_summary.txt 2>&1; tail -20 $OUT/traffic_summary.txt ;;
+       timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmc_$n.json 2> $OUT/pmc_$n.err
+       tail -c 300 $OUT/pmc_$n.err
+     done ;;
+aux) timeout 600 python scripts/bench_aux.py > $OUT/bench_aux.json 2> $OUT/bench_aux.err; tail -c 1200 $OUT/bench_aux.json
+     [ -f build_prof/libnavhip_cphist.so ] && timeout 300 python scripts/cp_unit_hist.py > $OUT/cp_unit_hist.json 2> /dev/null ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log ;;
 esac
 done

@@ -1,64 +1,150 @@
 #!/usr/bin/env python3
-"""Turn the outputs of scripts/prof_job.sh (gpurun_out/<tag>/) into the committed summaries under
-profiles/: kernel stats csv (from the rocprofv3 results db), traffic.json (PMC FETCH/WRITE passes),
-SQ counter summary, bench line, fuzz and pytest logs.
-Usage: summarize_prof.py <tag> <suffix>      e.g.  summarize_prof.py r01f v6"""
+"""Turn the outputs of `scripts/gpu_job.sh <tag> tests bench calib stats pmc fuzz aux` (gpurun_out/<tag>/)
+into the committed summaries under profiles/: kernel stats csv, traffic.json (PMC FETCH/WRITE passes),
+SQ counter summary, VALU calibration, bench line, logs.  Everything measured is stamped with the sha of
+the kernel sources it was measured on (bench.csrc_sha): bench.py refuses to quote traffic / counters
+of another tree.
+Usage: summarize_prof.py <tag> <suffix>      e.g.  summarize_prof.py r02z a"""
 import collections
 import csv
 import json
 import os
 import shutil
-import sqlite3
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench    # noqa: E402
+
+LAST = 6        # dispatches per kernel that count: the serial, profiled ticks at the END of bench.py (the
+                # ticks its roofline times) -- not the average over a run in which the world crowds
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def counters(path):
+    """{kernel: {counter: [values in dispatch order]}}"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def find(src, sub, name):
+    for root, _, files in os.walk(os.path.join(src, sub)):
+        for f in files:
+            if f.endswith(name):
+                return os.path.join(root, f)
+    return None
 
 
 def main():
     tag, suf = sys.argv[1], sys.argv[2]
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
-    c = sqlite3.connect(os.path.join(src, "stats", "s_results.db"))
-    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                     "from kernels group by name order by 3 desc").fetchall()
-    tot = sum(r[2] for r in rows)
-    with open(os.path.join(dst, "r01_bench_kernel_stats_%s.csv" % suf), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-        for r in rows:
-            w.writerow([r[0].split("(")[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 2), r[4], r[5]])
-    for r in rows[:12]:
-        print("%-34s calls %4d  avg %8.1f us  min %8.1f  max %8.1f" % (r[0].split("(")[0][:34], r[1], r[3] / 1e3, r[4] / 1e3, r[5] / 1e3))
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "collect_traffic.py"),
-                           os.path.join(src, "pmc_fetch", "f_counter_collection.csv"),
-                           os.path.join(src, "pmc_write", "w_counter_collection.csv"), "16384",
-                           os.path.join(dst, "traffic.json")])
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(os.path.join(src, "pmc_sq", "q_counter_collection.csv"))):
-        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out = {}
-    for k, v in acc.items():
-        if not k.startswith(("k_agent", "k_coh", "k_field", "k_sp")):
-            continue
-        d = {cn: sum(x) / len(x) for cn, x in v.items()}
-        d["valu_per_wave"] = d["SQ_INSTS_VALU"] / max(d["SQ_WAVES"], 1)
-        # time the VALU instructions alone need at one wave64 instruction per 4 cycles per SIMD,
-        # 1024 SIMDs, 2.4 GHz
-        d["valu_issue_floor_us"] = d["SQ_INSTS_VALU"] / 1024 * 4 / 2.4e3
-        out[k] = d
-    doc = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES on bench.py "
-                     "--steps 12 --warmup 3 (per-dispatch averages)",
-           "valu_issue_floor": "SQ_INSTS_VALU / 1024 SIMDs x 4 cycles per wave64 instruction / 2.4 GHz",
-           "kernels": out}
-    json.dump(doc, open(os.path.join(dst, "r01_sq_counters_%s.json" % suf), "w"), indent=1)
-    json.dump(doc, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)      # read by bench.py
-    for k in ("k_agent_step", "k_cohesion", "k_field_bfs<false>", "k_agent_pre"):
-        if k in out:
-            print(k, "VALU/wave %.0f  waves %.0f  issue floor %.1f us" % (out[k]["valu_per_wave"], out[k]["SQ_WAVES"], out[k]["valu_issue_floor_us"]))
-    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "r01_bench_%s.json" % suf))
-    shutil.copy(os.path.join(src, "fuzz.log"), os.path.join(dst, "r01_fuzz_gpu_%s.log" % suf))
-    shutil.copy(os.path.join(src, "pytest_gpu.log"), os.path.join(dst, "r01_pytest_gpu_%s.log" % suf))
+    sha = bench.csrc_sha()
+    pre = "r02_"
+
+    def copy(name, out):
+        p = os.path.join(src, name)
+        if os.path.exists(p):
+            shutil.copy(p, os.path.join(dst, out))
+            return True
+        print("missing", name)
+        return False
+
+    # ---- rocprofv3 --kernel-trace --stats of bench.py ---------------------------------------------
+    ks = find(src, "stats", "kernel_stats.csv")
+    if ks:
+        shutil.copy(ks, os.path.join(dst, pre + "bench_kernel_stats_%s.csv" % suf))
+        for r in list(csv.DictReader(open(ks)))[:14]:
+            print("%-30s calls %5s  avg %9.1f us  %5s %%" % (short(r["Name"])[:30], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    tr = find(src, "stats", "kernel_trace.csv")
+    if tr:
+        # per-kernel duration at ticks 5 / 50 / 100 of the traced run (the world crowds: one average hides it)
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr)):
+            d[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        per = {}
+        for k, v in d.items():
+            v.sort()
+            if len(v) >= 100:
+                per[k] = {"launches": len(v), "us_at_tick_5_50_100": [round(v[i][1], 1) for i in (9, 54, min(104, len(v) - 1))],
+                          "us_mean": round(sum(x[1] for x in v) / len(v), 1)}
+        json.dump({"source": "rocprofv3 --kernel-trace of bench.py --steps 100 --warmup 5 (gpurun_out/%s)" % tag,
+                   "csrc_sha": sha, "kernels": per}, open(os.path.join(dst, pre + "kernel_durations_%s.json" % suf), "w"), indent=1)
+
+    # ---- PMC passes ------------------------------------------------------------------------------
+    fpath = find(src, "pmc_FETCH_SIZE", "counter_collection.csv")
+    wpath = find(src, "pmc_WRITE_SIZE", "counter_collection.csv")
+    if fpath and wpath:
+        F, Wr = counters(fpath), counters(wpath)
+
+        def last(acc, k, c):
+            v = acc.get(k, {}).get(c, [])
+            v = v[-LAST:]
+            return sum(v) / len(v) * 1024.0 if v else 0.0
+        fetch = {k: last(F, k, "FETCH_SIZE") for k in F}
+        write = {k: last(Wr, k, "WRITE_SIZE") for k in Wr}
+        bfs = [k for k in write if k.startswith("k_field_bfs")]
+        known = 16384 * 4096.0
+        wcal = known / write[bfs[0]] if bfs and write[bfs[0]] > 0 else None
+        res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py "
+                         "--steps 100 --warmup 5; per kernel the mean of its last %d dispatches (the profiled ticks at "
+                         "the end of the run, which bench.py's roofline times)" % LAST,
+               "csrc_sha": sha,
+               "corrections": "both counters are KB (x1024); gfx950 FETCH_SIZE counts 128-B requests at 64 B: x2 "
+                              "('corr'); WRITE_SIZE calibrated on k_field_bfs, which writes exactly 4096 B per field "
+                              "with 16 B/lane coalesced stores",
+               "per_kernel_fetch_bytes_raw": fetch, "per_kernel_write_bytes_raw": write,
+               "write_calibration": {"kernel": bfs[0] if bfs else None, "known_bytes": known,
+                                     "reported_bytes": write.get(bfs[0]) if bfs else None, "factor": wcal}}
+        groups = {"fields": ("k_field_bfs", "k_field_generic"), "agents": ("k_sp_", "k_coh", "k_agent_", "k_cp_", "k_wl_", "k_zero")}
+        for name, pfx in groups.items():
+            f_raw = sum(v for k, v in fetch.items() if k.startswith(pfx))
+            w_raw = sum(v for k, v in write.items() if k.startswith(pfx))
+            res[name + "_fetch_bytes_raw"] = f_raw
+            res[name + "_fetch_bytes_corr"] = 2.0 * f_raw
+            res[name + "_write_bytes_corr"] = w_raw * (wcal or 1.0)
+            res[name + "_bytes_per_launch"] = 2.0 * f_raw + w_raw * (wcal or 1.0)
+        json.dump(res, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+        json.dump(res, open(os.path.join(dst, pre + "traffic_%s.json" % suf), "w"), indent=1)
+        print({k: v for k, v in res.items() if k.endswith("_per_launch")}, "write calibration", wcal)
+    qpath = find(src, "pmc_SQ_INSTS_VALU", "counter_collection.csv")
+    if qpath:
+        Q = counters(qpath)
+        out = {}
+        for k, v in Q.items():
+            if not k.startswith(("k_agent", "k_coh", "k_field", "k_sp", "k_cp", "k_wl", "k_zero")):
+                continue
+            dd = {cn: sum(x[-LAST:]) / len(x[-LAST:]) for cn, x in v.items()}
+            dd["valu_per_wave"] = dd.get("SQ_INSTS_VALU", 0) / max(dd.get("SQ_WAVES", 1), 1)
+            early = {cn: sum(x[5:5 + LAST]) / max(1, len(x[5:5 + LAST])) for cn, x in v.items()}
+            dd["SQ_INSTS_VALU_early_ticks"] = early.get("SQ_INSTS_VALU")
+            out[k] = dd
+        doc = {"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES on "
+                         "bench.py --steps 100 --warmup 5; per kernel the mean of its last %d dispatches (early ticks: "
+                         "dispatches 6-11)" % LAST, "csrc_sha": sha, "kernels": out}
+        json.dump(doc, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)
+        json.dump(doc, open(os.path.join(dst, pre + "sq_counters_%s.json" % suf), "w"), indent=1)
+        for k in sorted(out, key=lambda k: -out[k].get("SQ_INSTS_VALU", 0))[:8]:
+            print("%-24s VALU wave-instr/launch %12.0f (early %12.0f)  waves %8.0f" % (
+                k, out[k].get("SQ_INSTS_VALU", 0), out[k].get("SQ_INSTS_VALU_early_ticks") or 0, out[k].get("SQ_WAVES", 0)))
+    if os.path.exists(os.path.join(src, "valu_calib.json")):
+        try:
+            c = json.load(open(os.path.join(src, "valu_calib.json")))
+            json.dump(c, open(os.path.join(dst, "r02_valu_calib.json"), "w"), indent=1)
+        except Exception as e:
+            print("valu_calib.json:", e)
+    copy("bench.json", pre + "bench_%s.json" % suf)
+    copy("pytest_gpu.log", pre + "pytest_gpu_%s.log" % suf)
+    copy("fuzz.log", pre + "fuzz_gpu_%s.log" % suf)
+    copy("bench_aux.json", pre + "bench_aux_%s.json" % suf)
+    copy("cp_unit_hist.json", pre + "cp_unit_hist_%s.json" % suf)
 
 
 if __name__ == "__main__":
