@@ -190,11 +190,11 @@ __device__ void nbr_walk_row(const nh_grid &G, int k, float scaled_max_force, co
             const unsigned ms = (unsigned)g::ballot(is_s), md = (unsigned)g::ballot(is_d);
             if(is_s) {
                 const int p = n_stat + __popc(ms & lt);
-                if(p < NH_MAX_NEIGHBOURS) NB.list[(size_t)(32 + p) * NB.stride + uid] = kk;
+                if(p < NH_MAX_NEIGHBOURS) NB.list[(size_t)uid * NB.stride + 32 + p] = kk;
             }
             if(is_d) {
                 const int p = n_dyn + __popc(md & lt);
-                if(p < NH_MAX_NEIGHBOURS) NB.list[(size_t)p * NB.stride + uid] = kk;
+                if(p < NH_MAX_NEIGHBOURS) NB.list[(size_t)uid * NB.stride + p] = kk;
             }
             n_stat = min(NH_MAX_NEIGHBOURS, n_stat + __popc(ms));
             n_dyn = min(NH_MAX_NEIGHBOURS, n_dyn + __popc(md));
@@ -888,7 +888,7 @@ __device__ __forceinline__ void cp_load_lists(const nh_grid &Gd, const nh_nbr &N
     if(gl < n_dyn + n_stat) {
         const bool isdyn = gl < n_dyn;
         const int j = isdyn ? gl : gl - n_dyn;
-        const int slot = NB.list[(size_t)(isdyn ? j : 32 + j) * NB.stride + uid];
+        const int slot = NB.list[(size_t)uid * NB.stride + (isdyn ? j : 32 + j)];
         const cpent nb = nbr_cpent(Gd, slot, !isdyn);
         float *dst = (isdyn ? S.dyn : S.stat) + 5 * j;
         dst[0] = nb.pos.x; dst[1] = nb.pos.z; dst[2] = nb.vel.x; dst[3] = nb.vel.z; dst[4] = nb.radius;

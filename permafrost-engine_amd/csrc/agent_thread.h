@@ -156,9 +156,9 @@ NH_FN void nbr_walk_thread(const nh_grid &G, int k, float scaled_max_force, cons
                     raw10++;
                     if(other && c.z != 0.0f) {
                         if(bits & NH_PB_STATIC) {
-                            if(n_stat < NH_MAX_NEIGHBOURS) { NB.list[(size_t)(32 + n_stat) * NB.stride + uid] = q; n_stat++; }
+                            if(n_stat < NH_MAX_NEIGHBOURS) { NB.list[(size_t)uid * NB.stride + 32 + n_stat] = q; n_stat++; }
                         }else{
-                            if(n_dyn < NH_MAX_NEIGHBOURS) { NB.list[(size_t)n_dyn * NB.stride + uid] = q; n_dyn++; }
+                            if(n_dyn < NH_MAX_NEIGHBOURS) { NB.list[(size_t)uid * NB.stride + n_dyn] = q; n_dyn++; }
                         }
                     }
                 }

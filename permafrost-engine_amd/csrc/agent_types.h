@@ -78,15 +78,18 @@ struct nh_step_outs {
 // indexed by uid:
 //   sep[uid]      separation_force (movement.c:1690), already truncated
 //   cnt[uid]      n_dyn | n_stat << 8 | NH_NB_* << 16
-//   list[j][uid]  pool slots of the ClearPath neighbours: j = 0..31 dynamic, 32..63 static,
-//                 in find_neighbours order (slot-major so that the j-th entries coalesce)
+//   list[uid][j]  pool slots of the ClearPath neighbours: j = 0..31 dynamic, 32..63 static, in
+//                 find_neighbours order.  Entity-major: the row of lanes that walks an entity writes
+//                 its entries side by side and the ClearPath kernels read them back in one or two
+//                 sectors (slot-major -- list[j][uid] -- cost a 64-byte sector per ENTRY on the read
+//                 side: half of k_cp_rows's HBM traffic)
 #define NH_NB_IRREGULAR 0x1u   /* garrisoned hit / wide query: the wave-per-agent path redoes the gather */
 #define NH_NB_DONE      0x2u   /* the walk ran for this entity this tick                                  */
 struct nh_nbr {
     float2   *sep;
     uint32_t *cnt;
     int32_t  *list;
-    int       stride;          // entities per list row (= n_ents)
+    int       stride;          // entries per entity (= 64)
 };
 
 // Work lists filled on the device (counters[NH_WL_*] + ids), consumed by fixed-size launches that

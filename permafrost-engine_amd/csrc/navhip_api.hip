@@ -724,7 +724,7 @@ static int step_scratch(navhip_ctx *ctx, int n_ents, nh_nbr *NB, nh_worklists *W
     if(!rc) rc = ensure_buf(ctx, ctx->wl[1], 4 * (size_t)NH_WL_LISTS * NH_WL_SUB * cap);
     if(rc) return rc;
     NB->sep = (float2*)ctx->nbr[0].p; NB->cnt = (uint32_t*)ctx->nbr[1].p; NB->list = (int32_t*)ctx->nbr[2].p;
-    NB->stride = n_ents;
+    NB->stride = 64;
     WL->count = (int32_t*)ctx->wl[0].p; WL->ids = (int32_t*)ctx->wl[1].p; WL->cap = cap;
     return NAVHIP_OK;
 }

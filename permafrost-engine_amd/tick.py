@@ -321,6 +321,7 @@ class NavTick:
         # the fields of the NEXT tick, behind the neighbour walk of this one
         timed = self.record and self.tick_no % self.mark_every == 0
         with torch.cuda.stream(f):
+            # (starting them with the tick instead measured the same: the work is conserved)
             self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_NEIGHBOURS)
             if timed:
                 e0 = torch.cuda.Event(enable_timing=True)

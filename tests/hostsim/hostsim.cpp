@@ -81,7 +81,7 @@ int hostsim_agent_step(const hostsim_map *map, const navhip_world *w, const floa
     std::vector<float2> sep(n);
     std::vector<uint32_t> cnt(n, 0);
     std::vector<int32_t> list((size_t)64 * n, -1);
-    nh_nbr NB = {sep.data(), cnt.data(), list.data(), n};
+    nh_nbr NB = {sep.data(), cnt.data(), list.data(), 64};
     const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
     for(int k = 0; k < n; k++) {
@@ -108,7 +108,7 @@ int hostsim_agent_step(const hostsim_map *map, const navhip_world *w, const floa
             v2 res;
             const uint32_t c = cnt[uid];
             if(cp_light_thread(G, ent, mkv(R.vpref[0], R.vpref[1]), (int)(c & 0xff), (int)((c >> 8) & 0xff),
-                               list.data() + uid, (size_t)n, cones, 1, res))
+                               list.data() + (size_t)uid * 64, (size_t)1, cones, 1, res))
                 post_thread(P, uid, me, P.state[uid], P.flags[uid], ent.radius, res, R.vel_cap, R.status, O);
             else
                 disp += 16;
