@@ -912,7 +912,7 @@ __device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which,
 // SIMD -- nothing to hide it behind (measured 75-105 us with one thread per entity).
 // ---------------------------------------------------------------------------------------------
 #ifndef MID_LANES
-#define MID_LANES 4
+#define MID_LANES 2
 #endif
 __global__ __launch_bounds__(64) void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
                                                   nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
@@ -1146,6 +1146,8 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
     __shared__ cp_lds<64> cps[AG_WAVES];
     __shared__ double exp_tab[64];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // usually there is nothing to do: one parallel look at the 64 sub-list counters
+    if(!__any(WL.count[NH_WL_FULL * NH_WL_SUB + lane] != 0)) return;
     if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
     __syncthreads();
     wave_lds &W = lds[wib];
@@ -1297,10 +1299,6 @@ extern "C" int navhip_debug_cp_work(unsigned long long out[128], int reset)
 }
 #endif
 
-__global__ void k_wl_zero(int32_t *count)
-{
-    for(int i = threadIdx.x; i < NH_WL_COUNTERS; i += blockDim.x) count[i] = 0;
-}
 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
@@ -1466,9 +1464,10 @@ void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     // SCALED_MAX_FORCE and the 1 % force threshold of movement.c:1870-1905 (same for every agent)
     const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
-    int32_t *other = WL.count + (parity ^ 1) * NH_WL_COUNTERS;
+    // (folding this into k_agent_nbr saved the launch and 15 us at the early ticks, and cost 40 us at the
+    // late ones in every A/B session: kept as a launch)
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(256), 0, s, WL.count + (parity ^ 1) * NH_WL_COUNTERS, (int)NH_WL_COUNTERS);
     WL.count += parity * NH_WL_COUNTERS;
-    hipLaunchKernelGGL(k_wl_zero, dim3(1), dim3(256), 0, s, other);
     hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
                        d_mid, WL, O, smf, thresh);
     // the ClearPath launches: the workgroup problems on the side stream (when the caller has one),
@@ -1479,7 +1478,7 @@ void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
         hipEventRecord(ev[0], s);
         hipStreamWaitEvent(sh, ev[0], 0);
     }
-    const int nblk = min(1024, (nwork + 15) / 16 + 1);
+    const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
     hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
     if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk), dim3(CP_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O);

@@ -109,6 +109,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
+    ctx->front_stream = nullptr;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
     ctx->pool = nullptr; ctx->async = nullptr;
     memset(ctx->ev, 0, sizeof(ctx->ev));
@@ -863,6 +864,7 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     if(rc) return rc;
     nh_launch_agent_nbr(P, NB, front);
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front));
+    ctx->front_stream = front;
     // side stream 1: cohesion
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
                                             ctx->aux[1]);
@@ -926,7 +928,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         P.grid.n = w->n_ents;
         P.grid.cell_start = (int32_t*)ctx->sp[3].p; P.grid.recA = (const float4*)ctx->sp[7].p;
         P.grid.recV = (const float2*)ctx->sp[8].p; P.grid.pool_of = (const int32_t*)ctx->sp[9].p;
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
+        if(ctx->front_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));   // (inline front: already ordered)
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
                                ctx->aux[0], ctx->ev_cp);

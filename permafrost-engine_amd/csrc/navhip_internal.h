@@ -58,6 +58,7 @@ struct navhip_ctx {
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];
     hipEvent_t   ev_fork, ev_join[2], ev_regroup;
+    hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
     hipEvent_t   ev_cp[2];          // the ClearPath launches of the agent step: lists ready, workgroup problems done
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
     // the snapshot a prefetch was started for: everything the side streams baked into their results

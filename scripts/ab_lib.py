@@ -2,7 +2,9 @@
 """A/B kernel variants inside one GPU session (box-to-box noise is ~3 %, more than most single
 optimisations).  `--build NAME -DFLAG ...` cross-compiles a variant of libnavhip.so with extra flags
 into build_prof/libnavhip_NAME.so (no GPU needed; the directory travels to the GPU box);
-`--run A B ...` alternates bench.py over the variants (`base` = the in-tree build), 3 rounds."""
+`--build-rev NAME REV` does the same for the kernel sources of a git revision (e.g. HEAD, to judge the
+uncommitted change); `--run A B ...` alternates bench.py over the variants (`base` = the in-tree
+build), 3 rounds."""
 import json
 import os
 import subprocess
@@ -15,12 +17,14 @@ from permafrost_engine_amd import build as nb    # noqa: E402
 OUT = os.path.join(ROOT, "build_prof")
 
 
-def build(name, flags):
+def build(name, flags, csrc=None):
     os.makedirs(OUT, exist_ok=True)
     objs = []
+    csrc = csrc or nb.CSRC
+    base_flags = [f if f != "-I" + nb.CSRC else "-I" + csrc for f in nb.FLAGS]
     for s in nb.SOURCES:
         o = os.path.join(OUT, "%s_%s.o" % (s[:-4], name))
-        subprocess.check_call([nb.HIPCC] + nb.FLAGS + flags + ["-c", os.path.join(nb.CSRC, s), "-o", o])
+        subprocess.check_call([nb.HIPCC] + base_flags + flags + ["-c", os.path.join(csrc, s), "-o", o])
         objs.append(o)
     lib = os.path.join(OUT, "libnavhip_%s.so" % name)
     subprocess.check_call([nb.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
@@ -40,7 +44,7 @@ def run(names, rounds=3, extra=()):
                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             res[n].append(d["ms_per_step"])
-            print(n, round(d["ms_per_step"], 4), {k: round(v, 4) for k, v in d["phase_ms"].items()}, flush=True)
+            print(n, round(d["ms_per_step"], 4), round(d["ms_per_step_median"], 4), [round(x, 3) for x in d["ms_tick_5_50_100"]], flush=True)
     for n in names:
         v = sorted(res[n])
         print("%-12s median %.4f ms/tick  (min %.4f)" % (n, v[len(v) // 2], v[0]))
@@ -49,7 +53,15 @@ def run(names, rounds=3, extra=()):
 if __name__ == "__main__":
     if sys.argv[1] == "--build":
         build(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "--build-rev":
+        src = os.path.join(OUT, "src_" + sys.argv[2])
+        os.makedirs(src, exist_ok=True)
+        rel = os.path.relpath(nb.CSRC, ROOT)
+        for f in subprocess.check_output(["git", "ls-files", rel], cwd=ROOT, text=True).split():
+            open(os.path.join(src, os.path.basename(f)), "wb").write(
+                subprocess.check_output(["git", "show", "%s:%s" % (sys.argv[3], f)], cwd=ROOT))
+        build(sys.argv[2], [], csrc=src)
     elif sys.argv[1] == "--run":
         names = [a for a in sys.argv[2:] if not a.startswith("--rounds=")]
         rounds = [int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("--rounds=")]
-        run(names, rounds=rounds[0] if rounds else 3)
+        run(names, rounds=rounds[0] if rounds else 3, extra=("--no-cpu-baseline", "--no-crowded"))
