@@ -983,7 +983,10 @@ __device__ __forceinline__ int first_above(const int32_t *end, int n, int u)
 struct unit_draw { int stripe, abandoned, round; };
 __device__ __forceinline__ int next_unit(unit_draw &D, int32_t *counters, int total, int gw, int nw, int lane)
 {
-    const int static_rounds = max(0, total / nw - 1);
+#ifndef NH_CP_TICKET_ROUNDS
+#define NH_CP_TICKET_ROUNDS 1
+#endif
+    const int static_rounds = max(0, total / nw - NH_CP_TICKET_ROUNDS);
     const int r = D.round++;
     if(r < static_rounds) return gw + r * nw;
     if(r == static_rounds) { D.stripe = gw % NH_CP_STRIPES; D.abandoned = 0; }
