@@ -509,6 +509,13 @@ int navhip_agent_step_poll(navhip_ctx *ctx)
 int navhip_agent_step_wait(navhip_ctx *ctx)
 {
     if(!ctx || !ctx->async || !ctx->async->pending) return NAVHIP_ERR_INVALID;
+    // a step takes a few hundred microseconds: poll for that long (a blocking wait costs a wake-up of
+    // tens of microseconds), then block
+    for(int spin = 0; spin < 20000; spin++) {
+        const hipError_t e = hipEventQuery(ctx->async->done);
+        if(e == hipSuccess) return async_finish(ctx);
+        if(e != hipErrorNotReady) break;
+    }
     HIPCHK(ctx, hipEventSynchronize(ctx->async->done));
     return async_finish(ctx);
 }
