@@ -208,17 +208,21 @@ def run_ticks(T, pdist, torch, warmup, steps, early=None):
     pdist.barrier()
     torch.cuda.synchronize()
     T.record = True
-    T.ev, T.tick_ev, T.fev = [], [], []
+    T.ev, T.tick_ev, T.fev, T._tick_rec = [], [], [], 0
     t0 = time.perf_counter()
     for _ in range(steps):
         T.step()
+    if T._tick_rec % T.tick_every == 0:           # close the last window
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(T.stream)
+        T.tick_ev.append(e)
     T.sync()
     torch.cuda.synchronize()
     pdist.barrier()
     dt = time.perf_counter() - t0
     T.record = False
     dt = pdist.max_over_ranks(dt, T.dev)
-    ticks = np.array(T.tick_ms()) if steps > 1 else np.array([dt * 1e3])
+    ticks = np.array(T.tick_ms()) if steps > 1 and len(T.tick_ev) > 1 else np.array([dt * 1e3 / max(1, steps)])
     return dt, ticks
 
 
@@ -276,7 +280,7 @@ def main():
                             pipeline_fields=not args.no_pipeline_fields)
 
     T = make(args.crowded)
-    fields_ahead = T.pipeline_fields
+    fields_ahead, tick_every = T.pipeline_fields, T.tick_every
     early = {}
     dt, ticks = run_ticks(T, pdist, torch, args.warmup, args.steps, early)
     phases = T.phase_ms()
@@ -371,8 +375,9 @@ def main():
         cpu = cpu_baseline(cfg["map"], cfg["fields"], cfg["agents"], 20, whole=(args.config == 0))
 
     if rank == 0:
-        def at(i):
-            return float(ticks[i - 1]) if len(ticks) >= i else None
+        def at(i):          # (ticks: one value per window of T.tick_every ticks)
+            w = (i - 1) // tick_every
+            return float(ticks[w]) if len(ticks) > w else None
         line = {
             "metric": "agent-steps/sec (+ flow-field cells/sec): every chunk field of every flow field rebuilt and "
                       "every agent stepped each tick",
@@ -395,7 +400,8 @@ def main():
                        "schedule": ("fields of tick t+1 built during tick t beside the agent step (double-buffered pool)"
                                     if fields_ahead else "fields of tick t built in front of the agent step of tick t")},
             "ms_per_step_median": float(np.median(ticks)),
-            "ms_tick_5_50_100": [at(5), at(50), at(min(100, len(ticks)))],
+            "ms_tick_5_50_100": [at(5), at(50), at(100)],
+            "tick_timing": "HIP events on the agent stream every %d ticks; per-tick values are window means" % tick_every,
             "agent_steps_per_s_median_tick": agents_total / (float(np.median(ticks)) * 1e-3),
             ("flow_field_cells_kept_valid_per_s" if cfg["obstacles"] else "flow_field_cells_per_s"):
                 cells_total * args.steps / dt,

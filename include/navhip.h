@@ -122,6 +122,11 @@ const char *navhip_last_error(const navhip_ctx *ctx);
 int  navhip_device(const navhip_ctx *ctx);
 /* the context's HIP stream, as void* (hipStream_t) */
 void *navhip_stream(const navhip_ctx *ctx);
+/* A stream (hipStream_t as void*, owned by the context) that may only use the compute units
+ * [cu_begin, cu_begin + cu_count) of the device -- for wide, throughput-bound work (the field builds)
+ * that should leave the rest of the chip to the narrow, latency-bound front of the agent step running
+ * beside it.  (hipExtStreamCreateWithCUMask; the MI355X has 256 CUs in 8 XCDs of 32.) */
+int  navhip_stream_create_partial(navhip_ctx *ctx, int cu_begin, int cu_count, void **out_stream);
 /* waits for the context's own stream and for the side streams of navhip_agent_prefetch_dev */
 int  navhip_sync(navhip_ctx *ctx);
 
@@ -429,15 +434,23 @@ int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, v
  * (only the cohesion term forks): for a caller that enqueues nothing wide on `stream` between this call
  * and the step -- the chain then follows the previous step on the same stream without a hand-over. */
 #define NAVHIP_PREFETCH_FRONT_INLINE 0x1u
+/*        NAVHIP_PREFETCH_SNAPSHOT_HELD  the caller leaves the snapshot arrays of this call untouched until
+ * its NEXT step on this context has been enqueued (it ping-pongs its position / velocity buffers): the
+ * step then does not make the caller's stream wait for the lane regrouping the cohesion stream runs
+ * for the next tick -- that work is ordered in front of the next step's cohesion term anyway. */
+#define NAVHIP_PREFETCH_SNAPSHOT_HELD 0x2u
 int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world, void *stream, uint32_t flags);
 /* Scheduling hint for a caller that runs other wide work (the field builds of the NEXT tick, say)
  * beside the agent step: make `stream` wait until the given stage of the step in flight is done, so
  * that the narrow, serial front of the step is not slowed down by it.
+ *   NAVHIP_STAGE_START       the moment the last navhip_agent_prefetch_dev was forked from its stream
+ *                            (= the previous step on that stream has finished)
  *   NAVHIP_STAGE_NEIGHBOURS  spatial hash + neighbour walk of the last navhip_agent_prefetch_dev
  *   NAVHIP_STAGE_LISTS       preferred velocities + work lists of the last navhip_agent_step_dev
  * (NAVHIP_ERR_INVALID when that call has not been made). */
 #define NAVHIP_STAGE_NEIGHBOURS 0
 #define NAVHIP_STAGE_LISTS      1
+#define NAVHIP_STAGE_START      2
 int  navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage);
 
 /* Per-kernel-group timing of the agent step with HIP events on the launch stream (bench.py's

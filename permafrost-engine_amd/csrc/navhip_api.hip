@@ -148,6 +148,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
     if(ctx->ev_regroup) hipEventDestroy(ctx->ev_regroup);
+    for(auto st : ctx->owned_streams) hipStreamDestroy(st);
     for(auto &e : ctx->ev_cp) if(e) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -156,6 +157,24 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
 const char *navhip_last_error(const navhip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 int   navhip_device(const navhip_ctx *ctx) { return ctx ? ctx->device : -1; }
 void *navhip_stream(const navhip_ctx *ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int navhip_stream_create_partial(navhip_ctx *ctx, int cu_begin, int cu_count, void **out_stream)
+{
+    if(!ctx || !out_stream || cu_begin < 0 || cu_count <= 0) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int ncu = prop.multiProcessorCount;
+    if(cu_begin >= ncu) return NAVHIP_ERR_INVALID;
+    if(cu_begin + cu_count > ncu) cu_count = ncu - cu_begin;
+    uint32_t mask[32] = {0};
+    for(int c = cu_begin; c < cu_begin + cu_count && c < 1024; c++) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t st = nullptr;
+    HIPCHK(ctx, hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask));
+    ctx->owned_streams.push_back(st);
+    *out_stream = (void*)st;
+    return NAVHIP_OK;
+}
 
 int navhip_sync(navhip_ctx *ctx)
 {
@@ -863,8 +882,12 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end);
     if(rc) return rc;
     nh_launch_agent_nbr(P, NB, front);
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front));
+    // (an inline front is ordered on the caller's stream by itself: its "done" event is only recorded
+    // when somebody asks for it -- every event on that stream is a packet on the tick's critical path)
+    ctx->join0_recorded = front != s;
+    if(front != s) HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front));
     ctx->front_stream = front;
+    ctx->snapshot_held = (flags & NAVHIP_PREFETCH_SNAPSHOT_HELD) != 0;
     // side stream 1: cohesion
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
                                             ctx->aux[1]);
@@ -912,6 +935,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(ctx->pre.valid && !joined) {
         // a prefetch for another snapshot is in flight on the side streams: let it drain before
         // its scratch buffers are reused
+        if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         if(ctx->regroup_pending) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));
@@ -933,7 +957,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
                                ctx->aux[0], ctx->ev_cp);
         ctx->wl_parity ^= 1;
-        if(ctx->regroup_pending) {
+        if(ctx->regroup_pending && !ctx->snapshot_held) {
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));     // long finished by now
             ctx->regroup_pending = false;
         }
@@ -968,7 +992,14 @@ int navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage)
 {
     if(!ctx || !stream || !ctx->aux[0]) return NAVHIP_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if(stage == NAVHIP_STAGE_NEIGHBOURS)  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join[0], 0));
+    if(stage == NAVHIP_STAGE_NEIGHBOURS) {
+        if(!ctx->front_stream) return NAVHIP_ERR_INVALID;
+        if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
+        HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join[0], 0));
+    }else if(stage == NAVHIP_STAGE_START) {
+        if(!ctx->front_stream) return NAVHIP_ERR_INVALID;
+        HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_fork, 0));
+    }
     else if(stage == NAVHIP_STAGE_LISTS)  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cp[0], 0));
     else return NAVHIP_ERR_INVALID;
     return NAVHIP_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "navhip.h"
 #include "map_view.h"
 
@@ -58,6 +59,9 @@ struct navhip_ctx {
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];
     hipEvent_t   ev_fork, ev_join[2], ev_regroup;
+    std::vector<hipStream_t> owned_streams;   // navhip_stream_create_partial
+    bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
+    bool         join0_recorded;    // ev_join[0] has been recorded for the front of the last prefetch
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
     hipEvent_t   ev_cp[2];          // the ClearPath launches of the agent step: lists ready, workgroup problems done
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet

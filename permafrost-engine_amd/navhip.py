@@ -333,6 +333,7 @@ _SIGS.update({
                                        C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "navhip_stream_wait_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "navhip_stream_create_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 5)]),
     "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
     "navhip_clearpath_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -445,7 +446,7 @@ def _ctx_agent_step_dev(self, world, stepout, stream=None):
               "navhip_agent_step_dev")
 
 
-PREFETCH_FRONT_INLINE = 1
+PREFETCH_FRONT_INLINE, PREFETCH_SNAPSHOT_HELD = 1, 2
 
 
 def _ctx_agent_prefetch_dev(self, world, stream=None, flags=0):
@@ -490,12 +491,19 @@ def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, rows=False):
     return out
 
 
-STAGE_NEIGHBOURS, STAGE_LISTS = 0, 1
+STAGE_NEIGHBOURS, STAGE_LISTS, STAGE_START = 0, 1, 2
 
 
 def _ctx_stream_wait_stage(self, stream, stage):
     """Make `stream` (a hipStream_t value) wait for a stage of the agent step in flight."""
     self._chk(lib().navhip_stream_wait_stage(self._h, C.c_void_p(stream), stage), "navhip_stream_wait_stage")
+
+
+def _ctx_stream_create_partial(self, cu_begin, cu_count):
+    """A hipStream_t value restricted to the compute units [cu_begin, cu_begin + cu_count)."""
+    out = C.c_void_p()
+    self._chk(lib().navhip_stream_create_partial(self._h, cu_begin, cu_count, C.byref(out)), "navhip_stream_create_partial")
+    return out.value
 
 
 def _ctx_set_profiling(self, on):
@@ -623,6 +631,7 @@ NavContext.set_profiling = _ctx_set_profiling
 NavContext.last_step_ms = _ctx_last_step_ms
 NavContext.last_step_lists = _ctx_last_step_lists
 NavContext.stream_wait_stage = _ctx_stream_wait_stage
+NavContext.stream_create_partial = _ctx_stream_create_partial
 NavContext.agent_step = _ctx_agent_step
 NavContext.agent_step_dev = _ctx_agent_step_dev
 NavContext.agent_prefetch_dev = _ctx_agent_prefetch_dev

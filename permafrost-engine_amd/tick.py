@@ -223,9 +223,24 @@ class NavTick:
         # obstacles the blocker updates of tick t+1 would race with the probes of tick t: not pipelined.)
         self.pipeline_fields = bool(pipeline_fields) and not obstacles
         if self.pipeline_fields:
-            self.fstream = torch.cuda.Stream(device=self.dev)
+            # The field stream may use three quarters of the compute units (six of the eight XCDs of an
+            # MI355X): the builds start with the tick, beside the front of the agent step -- a chain of
+            # small launches and the latency-bound cohesion kernel that leave most of the chip idle --
+            # and a quarter of the chip always has room for that front's workgroups at once.  (Measured,
+            # 20 ticks after 5: 0.432 ms per tick with the builds behind the neighbour walk on all CUs,
+            # 0.420 started with the tick on all CUs, 0.411 / 0.402 / 0.404 / 0.410 on 160 / 192 / 208 / 224.)
+            import os
+            ncu_all = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            ncu = int(os.environ.get("NAVTICK_FIELD_CUS", str(ncu_all * 3 // 4)))
+            if 0 < ncu < ncu_all:
+                self.fstream = torch.cuda.ExternalStream(self.ctx.stream_create_partial(ncu_all - ncu, ncu), device=self.dev)
+            else:
+                self.fstream = torch.cuda.Stream(device=self.dev)
+            self.fields_after = os.environ.get("NAVTICK_FIELDS_AFTER", "start")
             # nothing wide is enqueued on self.stream between prefetch and step: the front stays on it
-            self.prefetch_flags = navhip.PREFETCH_FRONT_INLINE
+            # ... and the snapshot buffers ping-pong: the one a step read is next written by the ClearPath
+            # kernels of the following step
+            self.prefetch_flags = navhip.PREFETCH_FRONT_INLINE | navhip.PREFETCH_SNAPSHOT_HELD
             self.pool_next = torch.zeros_like(self.pool)
             self.ev_fields, self.ev_fields_next = torch.cuda.Event(), torch.cuda.Event()
             self.fev = []
@@ -238,9 +253,10 @@ class NavTick:
             self.ev_fields.record(self.stream)
             self.stream.synchronize()
         self.ev = []                   # (phase, start_event, end_event) of the timed steps
-        self.tick_ev = []              # one event at the start of every recorded tick
+        self.tick_ev = []              # one event at the start of every tick_every-th recorded tick
+        self.tick_every, self._tick_rec = 5, 0
         self.record = False
-        self.mark_every = 4
+        self.mark_every = 20
         if verbose:
             print("[rank %d] setup %.1fs: %d chunk-field requests (%d local), %d agents (%d local)"
                   % (rank, time.time() - t0, n_req, self.n_req_local, n, self.a1 - self.a0), flush=True)
@@ -270,9 +286,13 @@ class NavTick:
     def step(self):
         """One tick, asynchronous on self.stream."""
         if self.record:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(self.stream)
-            self.tick_ev.append(e)
+            # one timing event every `tick_every` ticks: an event on the agent stream is a packet on the
+            # tick's critical path (recording every tick cost 1.5-2 % of the tick)
+            if self._tick_rec % self.tick_every == 0:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(self.stream)
+                self.tick_ev.append(e)
+            self._tick_rec += 1
         self.compute()
         self.exchange()
         self.advance()
@@ -315,14 +335,20 @@ class NavTick:
 
     def _compute_pipelined(self, marks):
         s, f = self.stream, self.fstream
+        if self.fields_after == "start" and self.pipelined:
+            f.wait_stream(s)                      # (the end of the previous tick)
         if not self.pipelined:
             with torch.cuda.stream(s):
                 self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream, flags=self.prefetch_flags)
-        # the fields of the NEXT tick, behind the neighbour walk of this one
+        # the fields of the NEXT tick
         timed = self.record and self.tick_no % self.mark_every == 0
         with torch.cuda.stream(f):
-            # (starting them with the tick instead measured the same: the work is conserved)
-            self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_NEIGHBOURS)
+            if self.fields_after == "neighbours":
+                self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_NEIGHBOURS)
+            elif not self.pipelined:
+                # (the fork event of the prefetch just enqueued: the end of the previous tick, without
+                # another event on the agent stream)
+                self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_START)
             if timed:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record(f)
@@ -393,8 +419,9 @@ class NavTick:
         return {k: float(np.mean(v)) for k, v in out.items()}
 
     def tick_ms(self):
-        """GPU-timeline duration of every recorded tick but the last (start event to start event)."""
-        return [a.elapsed_time(b) for a, b in zip(self.tick_ev[:-1], self.tick_ev[1:])]
+        """GPU-timeline milliseconds per tick, one value per window of tick_every recorded ticks (start
+        event to start event)."""
+        return [a.elapsed_time(b) / self.tick_every for a, b in zip(self.tick_ev[:-1], self.tick_ev[1:])]
 
     def sync(self):
         if self.comm is not None:
