@@ -461,6 +461,20 @@ int  navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage);
 #define NAVHIP_STEP_PHASES 5
 int  navhip_set_profiling(navhip_ctx *ctx, int on);
 int  navhip_last_step_ms(navhip_ctx *ctx, float out_ms[NAVHIP_STEP_PHASES]);
+
+/* Work counters of the context since creation (or the last reset): what SURVEY.md section 5 asks the shim
+ * to expose so that a host can report cells/s and agent-steps/s with its own clock (one chunk field
+ * = 4096 cells; host counters, no device synchronisation). */
+typedef struct navhip_counters {
+    uint64_t field_calls;     /* navhip_build_fields / _dev / pool builds                          */
+    uint64_t chunk_fields;    /* chunk-field requests in them                                      */
+    uint64_t step_calls;      /* navhip_agent_step / _dev / _submit                                */
+    uint64_t agent_steps;     /* work items (work_end - work_begin) in them                        */
+    uint64_t los_fields;      /* navhip_build_los requests                                         */
+    uint64_t region_fields;   /* navhip_build_region_fields requests                               */
+    uint64_t blocker_circles; /* navhip_blockers_circles entries                                   */
+} navhip_counters;
+int  navhip_get_counters(navhip_ctx *ctx, navhip_counters *out, int reset);
 /* How the last agent step split its agents (waits for it): the number of agents whose ClearPath ran
  * on a row of 16 lanes ([0..3]: 1-2, 3-4, 5-8, 9-16 neighbours), on a wave ([4]: 17-64 neighbours),
  * and agents whose whole step ran on a wave ([5]: garrisoned neighbours / wide queries).  Everyone

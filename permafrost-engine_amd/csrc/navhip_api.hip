@@ -96,6 +96,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(&ctx->coh, 0, sizeof(ctx->coh));
     memset(&ctx->coh_plan, 0, sizeof(ctx->coh_plan));
     memset(&ctx->gen_list, 0, sizeof(ctx->gen_list));
+    memset(&ctx->counters, 0, sizeof(ctx->counters));
     ctx->gen_launches = 0;
     ctx->coh_flocks = ctx->coh_members = -1;
     ctx->coh_parity = 0;
@@ -323,6 +324,7 @@ int navhip_blockers_circles_dev(navhip_ctx *ctx, const navhip_circle *dev_circle
     if(!ctx || n < 0 || (n > 0 && !dev_circles)) return NAVHIP_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->counters.blocker_circles += (uint64_t)n;
     int rc = refresh_derived(ctx, s);          // the "before" masks must be current
     if(rc) return rc;
     bool any = false;
@@ -413,6 +415,7 @@ int navhip_build_region_fields_dev(navhip_ctx *ctx, const navhip_region_req *dev
     if(n == 0) return NAVHIP_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->counters.region_fields += (uint64_t)n;
     nh_launch_region_fields(ctx, dev_reqs, n, max_dim, dev_seeds, dev_overlay, dev_inout, out_stride, s);
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
@@ -479,6 +482,7 @@ int navhip_build_los_dev(navhip_ctx *ctx, const navhip_los_req *dev_reqs, int n,
     if(n == 0) return NAVHIP_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->counters.los_fields += (uint64_t)n;
     nh_launch_los(ctx, dev_reqs, n, dev_prev_fields, dev_out_fields, map_pos_x, map_pos_z, s);
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
@@ -570,6 +574,7 @@ static int build_fields_on(navhip_ctx *ctx, const navhip_field_req *dev_reqs, in
     if(ctx->gen_list.p != old_list) HIPCHK(ctx, hipMemsetAsync(ctx->gen_list.p, 0, 2 * sizeof(int32_t), s));
     nh_launch_fields(ctx, dev_reqs, n, dev_inout_dirs, dev_out_integ, (int32_t*)ctx->gen_list.p, s, dev_slots);
     HIPCHK(ctx, hipGetLastError());
+    ctx->counters.field_calls++; ctx->counters.chunk_fields += (uint64_t)n;
     return NAVHIP_OK;
 }
 
@@ -930,6 +935,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         ctx->last_error = "agent step: empty spatial-grid bounds";
         return NAVHIP_ERR_INVALID;
     }
+    ctx->counters.step_calls++; ctx->counters.agent_steps += (uint64_t)(P.work_end - P.work_begin);
     const bool prof = ctx->profiling;
     const bool joined = ctx->pre.valid && !prof && pre_key_matches(ctx, w, P, P.grid);
     if(ctx->pre.valid && !joined) {
@@ -1002,6 +1008,14 @@ int navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage)
     }
     else if(stage == NAVHIP_STAGE_LISTS)  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cp[0], 0));
     else return NAVHIP_ERR_INVALID;
+    return NAVHIP_OK;
+}
+
+int navhip_get_counters(navhip_ctx *ctx, navhip_counters *out, int reset)
+{
+    if(!ctx || !out) return NAVHIP_ERR_INVALID;
+    *out = ctx->counters;
+    if(reset) memset(&ctx->counters, 0, sizeof(ctx->counters));
     return NAVHIP_OK;
 }
 

@@ -60,6 +60,7 @@ struct navhip_ctx {
     hipStream_t  aux[2];
     hipEvent_t   ev_fork, ev_join[2], ev_regroup;
     std::vector<hipStream_t> owned_streams;   // navhip_stream_create_partial
+    navhip_counters counters;       // navhip_get_counters
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
     bool         join0_recorded;    // ev_join[0] has been recorded for the front of the last prefetch
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on

@@ -333,6 +333,7 @@ _SIGS.update({
                                        C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "navhip_stream_wait_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "navhip_get_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "navhip_stream_create_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 5)]),
     "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
@@ -499,6 +500,17 @@ def _ctx_stream_wait_stage(self, stream, stage):
     self._chk(lib().navhip_stream_wait_stage(self._h, C.c_void_p(stream), stage), "navhip_stream_wait_stage")
 
 
+COUNTER_NAMES = ("field_calls", "chunk_fields", "step_calls", "agent_steps", "los_fields", "region_fields",
+                 "blocker_circles")
+
+
+def _ctx_counters(self, reset=False):
+    """navhip_get_counters: work counters of the context as a dict."""
+    out = (C.c_uint64 * len(COUNTER_NAMES))()
+    self._chk(lib().navhip_get_counters(self._h, out, int(bool(reset))), "navhip_get_counters")
+    return dict(zip(COUNTER_NAMES, [int(x) for x in out]))
+
+
 def _ctx_stream_create_partial(self, cu_begin, cu_count):
     """A hipStream_t value restricted to the compute units [cu_begin, cu_begin + cu_count)."""
     out = C.c_void_p()
@@ -632,6 +644,7 @@ NavContext.last_step_ms = _ctx_last_step_ms
 NavContext.last_step_lists = _ctx_last_step_lists
 NavContext.stream_wait_stage = _ctx_stream_wait_stage
 NavContext.stream_create_partial = _ctx_stream_create_partial
+NavContext.counters = _ctx_counters
 NavContext.agent_step = _ctx_agent_step
 NavContext.agent_step_dev = _ctx_agent_step_dev
 NavContext.agent_prefetch_dev = _ctx_agent_prefetch_dev

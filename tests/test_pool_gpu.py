@@ -157,3 +157,19 @@ def test_static_epoch_skips_the_attribute_tables_only(navlib, small):
     ctx.agent_step(a)
     got4 = ctx.agent_step_async(dict(fat, static_epoch=6))
     assert all(np.array_equal(got4[k], exp3[k]) for k in keys)
+
+
+def test_work_counters(navlib, small):
+    """navhip_get_counters: what the shim has been asked to do, for a host that reports cells/s and
+    agent-steps/s with its own clock."""
+    ctx, reqs, N = small["ctx"], small["reqs"], small["N"]
+    ctx.counters(reset=True)
+    ctx.N_FlowFieldUpdate(reqs[:7])
+    ctx.N_FlowFieldUpdate(reqs[:3])
+    a = dict(small["arrays"], vdes_xz=np.tile(np.array([[1.0, 0.0]], np.float32), (N, 1)))
+    ctx.agent_step(a)
+    ctx.agent_step_async(a, work=(10, 110))
+    c = ctx.counters()
+    assert (c["field_calls"], c["chunk_fields"]) == (2, 10)
+    assert (c["step_calls"], c["agent_steps"]) == (2, N + 100)
+    assert ctx.counters(reset=True) == c and ctx.counters()["chunk_fields"] == 0
