@@ -63,14 +63,20 @@ static double run(int grid, int iters, float *sink, int reps)
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k_calib<KIND>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, sink);
     hipDeviceSynchronize();
-    hipEventRecord(e0, 0);
-    for(int r = 0; r < reps; r++)
-        hipLaunchKernelGGL(k_calib<KIND>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, sink);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    return ms * 1e-3 / reps;
+    // the fastest of three timed batches: a box whose clocks have not ramped up yet (or that is power
+    // capped for a moment) reports 7 cycles where every other session reports 2.6
+    double best = 1e30;
+    for(int b = 0; b < 3; b++) {
+        hipEventRecord(e0, 0);
+        for(int r = 0; r < reps; r++)
+            hipLaunchKernelGGL(k_calib<KIND>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, sink);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if(ms * 1e-3 / reps < best) best = ms * 1e-3 / reps;
+    }
+    return best;
 }
 
 int main()
@@ -80,6 +86,9 @@ int main()
     const int cus = prop.multiProcessorCount, simds = cus * 4;
     const double clock_hz = prop.clockRate * 1e3;               // kHz -> Hz (peak engine clock)
     float *sink; hipMalloc(&sink, 4);
+    // (warm the clocks up)
+    for(int r = 0; r < 40; r++) hipLaunchKernelGGL(k_calib<K_FMA_F32>, dim3(simds * 2), dim3(256), 0, 0, 2000, 1.0f, sink);
+    hipDeviceSynchronize();
     const int iters = 2000, reps = 5;
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %.0f, \"insts_per_wave\": %d, \"results\": {",
            prop.gcnArchName, cus, clock_hz / 1e6, iters * UNROLL * CHAINS);
