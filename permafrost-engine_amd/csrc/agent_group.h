@@ -878,6 +878,83 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
     return mkv(0.0f, 0.0f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ClearPath for an agent with at most four neighbours on a row of 16 lanes, ONE attempt, no queue,
+// no bound, no retry logic: the kernel of the sparse crowd (k_cp_small) -- few registers, 128 bytes
+// of LDS per agent, twice the waves per SIMD of the general search.  Lane k < n holds neighbour k
+// (dynamic ones first).  found = false: no admissible candidate (the caller hands the agent to the
+// general search, which knows how to retry).  Same arithmetic, same order index, same tie-break as
+// clearpath_grp.
+// ---------------------------------------------------------------------------------------------
+__device__ v2 clearpath_small_row(const cpent &ent, v2 des_v, const cpent &nb, bool isdyn, bool have,
+                                  float4 *cones, bool &found)
+{
+    typedef grp<16> g;
+    const int gl = g::lane();
+    const unsigned long long lt_mask = (1ull << gl) - 1ull;
+    found = true;
+    const bool use = have && !(vlen(vsub(nb.pos, ent.pos)) < CP_EPS);
+    v2 apex = mkv(0, 0), left = mkv(0, 0), right = mkv(0, 0);
+    float sl = 0.0f, sr = 0.0f;
+    if(use) make_cone(ent, nb, isdyn, apex, left, right, sl, sr);
+    const unsigned long long m = g::ballot(use);
+    const int slot = __popcll(m & lt_mask);
+    const int n_cones = __popcll(m), n_rays = 2 * n_cones, npairs = n_rays * n_rays;
+    wave_sync();
+    if(use) {
+        cones[2 * slot]     = make_float4(apex.x, apex.z, sl, sr);
+        cones[2 * slot + 1] = make_float4(left.x, left.z, right.x, right.z);
+    }
+    wave_sync();
+    const v2 des_ws = vadd(ent.pos, des_v);
+    bool in = false;
+    if(gl < n_cones) in = cone_contains(cones[2 * gl], cones[2 * gl + 1], des_ws);
+    if(!g::any(in)) return des_v;
+
+    int nf = 0;
+    float blen = __builtin_inff(); int bidx = 0x7fffffff; v2 bpt = mkv(0, 0);
+    for(int c = gl; c < npairs + n_rays; c += 16) {
+        bool ok = false;
+        v2 pt = mkv(0, 0);
+        if(c >= npairs) {
+            const int r = c - npairs;
+            const float4 Ai = cones[r & ~1], Bi = cones[r | 1];
+            const v2 dir = (r & 1) ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), point = mkv(Ai.x, Ai.y);
+            pt = vadd(point, vscale(dir, vdot(dir, des_v)));
+            ok = true;
+        }else{
+            const int i = c / n_rays, j = c - i * n_rays;
+            if(i != j) {
+                const float4 Ai = cones[i & ~1], Bi = cones[i | 1];
+                const float4 Aj = cones[j & ~1], Bj = cones[j | 1];
+                const bool ri = i & 1, rj = j & 1;
+                ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
+                               mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z, pt);
+            }
+        }
+        if(ok) {
+            bool inside = false;
+            for(int k2 = 0; k2 < n_cones; k2++)
+                inside = inside || cone_contains(cones[2 * k2], cones[2 * k2 + 1], pt);
+            if(!inside) {
+                const v2 curr = vsub(pt, ent.pos);
+                const float len = vlen(vsub(des_v, curr));
+                nf++;
+                if(len < blen || (len == blen && c < bidx)) { blen = len; bidx = c; bpt = curr; }
+            }
+        }
+    }
+    float key = blen; int ki = bidx;
+    g::argmin(key, ki);
+    found = g::any(nf > 0);
+    v2 res = mkv(0.0f, 0.0f);                  // (only NaN / infinite distances: the answer stays 0, :368-386)
+    if(key < __builtin_inff()) {
+        const int owner = __ffsll((unsigned long long)g::ballot(bidx == ki && blen == key)) - 1;
+        res = mkv(g::shfl(bpt.x, owner), g::shfl(bpt.z, owner));
+    }
+    return res;
+}
+
 // neighbour lists (pool slots, from the walk) -> S.dyn / S.stat
 template <int G>
 __device__ __forceinline__ void cp_load_lists(const nh_grid &Gd, const nh_nbr &NB, int uid, int n_dyn, int n_stat,

@@ -938,7 +938,7 @@ __global__ __launch_bounds__(64) void k_agent_mid(nh_step_params P, nh_nbr NB, c
         }
     }
 #pragma unroll
-    for(int w = 0; w < NH_WL_LISTS; w++)
+    for(int w = 0; w <= NH_WL_FULL; w++)
         worklist_push(WL, w, live && writer && disp == DISP_ROW0 + w, uid);
 }
 
@@ -1018,35 +1018,90 @@ __device__ __forceinline__ int next_unit(unit_draw &D, int32_t *counters, int to
 #define HIST_WAVE(k)
 #endif
 
+// ---- k_cp_small: the lists of 1-2 and 3-4 neighbours -- three quarters of the searching agents
+// outside a crowd.  One wave per unit of four agents, one attempt each (clearpath_small_row); an agent
+// without any admissible candidate goes onto the retry list, which a launch of k_cp_rows works off. ----
+__global__ __launch_bounds__(256) void k_cp_small(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                  nh_worklists WL, nh_step_outs O)
+{
+    __shared__ __attribute__((aligned(16))) float4 cones[16][8];
+    __shared__ int32_t unit_end[2 * NH_WL_SUB];
+    __shared__ int32_t sub_cnt[2 * NH_WL_SUB];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if(threadIdx.x < 2 * NH_WL_SUB)
+        sub_cnt[threadIdx.x] = WL.count[(NH_WL_ROW1 - threadIdx.x / NH_WL_SUB) * NH_WL_SUB + threadIdx.x % NH_WL_SUB];
+    __syncthreads();
+    if(threadIdx.x == 0) {
+        int run = 0;
+        for(int k = 0; k < 2 * NH_WL_SUB; k++) { run += (sub_cnt[k] + 3) >> 2; unit_end[k] = run; }
+    }
+    __syncthreads();
+    const int u = blockIdx.x * 4 + wib;                       // one unit per wave
+    bool live = u < unit_end[2 * NH_WL_SUB - 1];
+    int uid = 0;
+    bool found = true;
+    if(live) {
+        const int k = first_above(unit_end, 2 * NH_WL_SUB, u), rel = u - (k ? unit_end[k - 1] : 0);
+        const int list = NH_WL_ROW1 - k / NH_WL_SUB, sub = k % NH_WL_SUB;
+        const int idx = rel * 4 + (lane >> 4);
+        live = idx < sub_cnt[k];                                // (else: a row beyond the end of its sub-list)
+        if(live) {
+            uid = WL.ids[((size_t)list * NH_WL_SUB + sub) * WL.cap + idx];
+            const nh_mid_rec R = mid[uid];
+            const uint32_t c = NB.cnt[uid];
+            const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+            cpent ent;
+            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+            ent.radius = P.radius[uid];
+            const int gl = lane & 15;
+            const bool have = gl < n_dyn + n_stat, isdyn = gl < n_dyn;
+            cpent nb; nb.pos = mkv(0, 0); nb.vel = mkv(0, 0); nb.radius = 0;
+            if(have) nb = nbr_cpent(P.grid, NB.list[(size_t)uid * NB.stride + (isdyn ? gl : 32 + gl - n_dyn)], !isdyn);
+            const v2 nv = clearpath_small_row(ent, mkv(R.vpref[0], R.vpref[1]), nb, isdyn, have,
+                                              cones[wib * 4 + (lane >> 4)], found);
+            if(found && gl == 0)
+                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
+        }
+    }
+    worklist_push(WL, NH_WL_RETRY, live && !found && (lane & 15) == 0, uid);
+}
+
 // ---- k_cp_rows: the four row lists (1-16 neighbours), a row of 16 lanes per agent, four agents per
 // unit, the units numbered heaviest list first (9-16, 5-8, 3-4, 1-2 neighbours) ---------------------
+// (the lists list0, list0 - 1, ... : nlists of them, at most four; ticket_set: which set of stripe
+// counters -- the retry launch runs beside the main one)
 __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                           nh_worklists WL, nh_step_outs O)
+                                                           nh_worklists WL, nh_step_outs O, int list0, int nlists,
+                                                           int ticket_set)
 {
     __shared__ cp_lds<16> lds[CP_WAVES * 4];
     // unit_end[k] = units of the sub-lists up to and including k (k = order * NH_WL_SUB + sub)
     __shared__ int32_t unit_end[4 * NH_WL_SUB];
     __shared__ int32_t sub_cnt[4 * NH_WL_SUB];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for(int k = threadIdx.x; k < 4 * NH_WL_SUB; k += CP_WAVES * 64)
-        sub_cnt[k] = WL.count[(NH_WL_ROW3 - k / NH_WL_SUB) * NH_WL_SUB + k % NH_WL_SUB];
+    const int ntab = nlists * NH_WL_SUB;
+    // (usually nothing to do for the retry launch: one parallel look)
+    if(nlists == 1 && !__any(WL.count[list0 * NH_WL_SUB + lane] != 0)) return;
+    for(int k = threadIdx.x; k < ntab; k += CP_WAVES * 64)
+        sub_cnt[k] = WL.count[(list0 - k / NH_WL_SUB) * NH_WL_SUB + k % NH_WL_SUB];
     __syncthreads();
     if(threadIdx.x == 0) {
         int run = 0;
-        for(int k = 0; k < 4 * NH_WL_SUB; k++) { run += (sub_cnt[k] + 3) >> 2; unit_end[k] = run; }
+        for(int k = 0; k < ntab; k++) { run += (sub_cnt[k] + 3) >> 2; unit_end[k] = run; }
     }
     __syncthreads();
     HIST_T0();
-    const int total = unit_end[4 * NH_WL_SUB - 1];
-    int32_t *counters = WL.count + NH_WL_LISTS * NH_WL_SUB + 32;
+    const int total = unit_end[ntab - 1];
+    int32_t *counters = WL.count + NH_WL_LISTS * NH_WL_SUB + 32 * (1 + ticket_set * NH_CP_STRIPES);
     const int gw = blockIdx.x * CP_WAVES + wib, nw = gridDim.x * CP_WAVES;
     cp_lds<16> &S = lds[wib * 4 + (lane >> 4)];
     unit_draw D; D.round = 0;
     for(;;) {
         const int u = next_unit(D, counters, total, gw, nw, lane);
         if(u < 0) break;
-        const int k = first_above(unit_end, 4 * NH_WL_SUB, u), rel = u - (k ? unit_end[k - 1] : 0);
-        const int list = NH_WL_ROW3 - k / NH_WL_SUB, sub = k % NH_WL_SUB;
+        const int k = first_above(unit_end, ntab, u), rel = u - (k ? unit_end[k - 1] : 0);
+        const int list = list0 - k / NH_WL_SUB, sub = k % NH_WL_SUB;
         const int idx = rel * 4 + (lane >> 4);
 #ifdef NH_CP_UNIT_HIST
         const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
@@ -1085,6 +1140,8 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
     __shared__ int32_t h_ticket;
     __shared__ cp_team team;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (outside a crowd there is nothing to do: one parallel look at the 128 counters)
+    if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
     if(threadIdx.x == 0) {
         int run = 0;
         for(int k = 0; k < 2 * NH_WL_SUB; k++) {
@@ -1453,7 +1510,9 @@ void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *
 int nh_worklist_cap(int n_work)
 {
     const int waves = (n_work * MID_LANES + 63) / 64;
-    return ((waves + NH_WL_SUB - 1) / NH_WL_SUB) * (64 / MID_LANES);
+    // (+ 16: the retry list is filled by k_cp_small's waves -- four entries each, a few more of them per
+    // sub-list than there are k_agent_mid waves' worth)
+    return ((waves + NH_WL_SUB - 1) / NH_WL_SUB) * (64 / MID_LANES) + 16;
 }
 
 // k_agent_mid + the consumers of its work lists.  The list counters alternate between two sets:
@@ -1482,9 +1541,16 @@ void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
         hipStreamWaitEvent(sh, ev[0], 0);
     }
     const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
+    // side stream: the agents with 1-4 neighbours (most of them, outside a crowd), whatever of them needs
+    // the retry logic, then the workgroup problems; s: the rows of 5-16 neighbours
+    hipLaunchKernelGGL(k_cp_small, dim3((nwork / 4 + 2 * NH_WL_SUB + 3) / 4 + 1), dim3(256), 0, sh, P, NB,
+                       (const nh_mid_rec*)d_mid, WL, O);
+    hipLaunchKernelGGL(k_cp_rows, dim3(64), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                       (int)NH_WL_RETRY, 1, 1);
     hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
     if(fork) hipEventRecord(ev[1], sh);
-    hipLaunchKernelGGL(k_cp_rows, dim3(nblk), dim3(CP_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O);
+    hipLaunchKernelGGL(k_cp_rows, dim3(nblk), dim3(CP_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                       (int)NH_WL_ROW3, 2, 0);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
                        (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh);
     if(fork) hipStreamWaitEvent(s, ev[1], 0);

@@ -1046,10 +1046,10 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
     int32_t h[NH_WL_COUNTERS];
     HIPCHK(ctx, hipMemcpy(h, src, sizeof(h), hipMemcpyDeviceToHost));
     // (the wave and the heavy list are reported together: 17-64 neighbours)
-    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5};
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1};     // (the retry list is not reported)
     for(int l = 0; l < 6; l++) out_counts[l] = 0;
     for(int l = 0; l < NH_WL_LISTS; l++)
-        for(int sb = 0; sb < NH_WL_SUB; sb++) out_counts[slot_of[l]] += h[l * NH_WL_SUB + sb];
+        for(int sb = 0; sb < NH_WL_SUB; sb++) if(slot_of[l] >= 0) out_counts[slot_of[l]] += h[l * NH_WL_SUB + sb];
     return NAVHIP_OK;
 }
 
