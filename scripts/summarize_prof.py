@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench    # noqa: E402
 
-LAST = 6        # dispatches per kernel that count: the serial, profiled ticks at the END of bench.py (the
+LAST = 6        # ticks that count: the serial, profiled ticks at the END of bench.py (the
                 # ticks its roofline times) -- not the average over a run in which the world crowds
 
 
@@ -84,18 +84,26 @@ def main():
     if fpath and wpath:
         F, Wr = counters(fpath), counters(wpath)
 
+        def per_tick(acc, k):
+            """launches of kernel k per tick (k_cp_rows and the scans are launched twice a tick)"""
+            ref = max((len(x.get(c, [])) for kk, x in acc.items() if kk.startswith("k_agent_mid") for c in x), default=0)
+            n = max((len(x) for x in acc.get(k, {}).values()), default=0)
+            return max(1, round(n / ref)) if ref else 1
+
         def last(acc, k, c):
+            """bytes per TICK: the mean over the last LAST ticks' dispatches, times the launches per tick"""
+            m = per_tick(acc, k)
             v = acc.get(k, {}).get(c, [])
-            v = v[-LAST:]
-            return sum(v) / len(v) * 1024.0 if v else 0.0
+            v = v[-LAST * m:]
+            return sum(v) / len(v) * m * 1024.0 if v else 0.0
         fetch = {k: last(F, k, "FETCH_SIZE") for k in F}
         write = {k: last(Wr, k, "WRITE_SIZE") for k in Wr}
         bfs = [k for k in write if k.startswith("k_field_bfs")]
         known = 16384 * 4096.0
         wcal = known / write[bfs[0]] if bfs and write[bfs[0]] > 0 else None
         res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py "
-                         "--steps 100 --warmup 5; per kernel the mean of its last %d dispatches (the profiled ticks at "
-                         "the end of the run, which bench.py's roofline times)" % LAST,
+                         "--steps 100 --warmup 5; per kernel and TICK the mean over the last %d ticks (the profiled ticks "
+                         "at the end of the run, which bench.py's roofline times)" % LAST,
                "csrc_sha": sha,
                "corrections": "both counters are KB (x1024); gfx950 FETCH_SIZE counts 128-B requests at 64 B: x2 "
                               "('corr'); WRITE_SIZE calibrated on k_field_bfs, which writes exactly 4096 B per field "
@@ -121,14 +129,18 @@ def main():
         for k, v in Q.items():
             if not k.startswith(("k_agent", "k_coh", "k_field", "k_sp", "k_cp", "k_wl", "k_zero")):
                 continue
-            dd = {cn: sum(x[-LAST:]) / len(x[-LAST:]) for cn, x in v.items()}
+            ref = max((len(x) for kk, vv in Q.items() if kk.startswith("k_agent_mid") for x in vv.values()), default=0)
+            n = max((len(x) for x in v.values()), default=0)
+            m = max(1, round(n / ref)) if ref else 1                 # launches per tick
+            dd = {cn: sum(x[-LAST * m:]) / len(x[-LAST * m:]) * m for cn, x in v.items()}
+            dd["launches_per_tick"] = m
             dd["valu_per_wave"] = dd.get("SQ_INSTS_VALU", 0) / max(dd.get("SQ_WAVES", 1), 1)
-            early = {cn: sum(x[5:5 + LAST]) / max(1, len(x[5:5 + LAST])) for cn, x in v.items()}
+            early = {cn: sum(x[5 * m:(5 + LAST) * m]) / max(1, len(x[5 * m:(5 + LAST) * m])) * m for cn, x in v.items()}
             dd["SQ_INSTS_VALU_early_ticks"] = early.get("SQ_INSTS_VALU")
             out[k] = dd
         doc = {"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES on "
-                         "bench.py --steps 100 --warmup 5; per kernel the mean of its last %d dispatches (early ticks: "
-                         "dispatches 6-11)" % LAST, "csrc_sha": sha, "kernels": out}
+                         "bench.py --steps 100 --warmup 5; per kernel and TICK (a kernel launched twice a tick counts "
+                         "twice): the mean over the last %d ticks (early ticks: 6-11)" % LAST, "csrc_sha": sha, "kernels": out}
         json.dump(doc, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)
         json.dump(doc, open(os.path.join(dst, pre + "sq_counters_%s.json" % suf), "w"), indent=1)
         for k in sorted(out, key=lambda k: -out[k].get("SQ_INSTS_VALU", 0))[:8]:
