@@ -50,14 +50,39 @@ CONFIGS = {      # map side in chunks, flow fields, agents, obstacles, shared ma
 }
 
 
-def csrc_sha():
-    """Identity of the kernel sources: profiles/*.json measured on another tree are stale."""
-    d = os.path.join(ROOT, "permafrost-engine_amd", "csrc")
+def _strip_comments(text):
+    """C/C++ source without comments and with runs of whitespace collapsed (string literals kept)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
+def csrc_sha(d=None):
+    """Identity of the kernel CODE (comments and whitespace do not count): profiles/*.json measured on
+    another tree are stale."""
+    d = d or os.path.join(ROOT, "permafrost-engine_amd", "csrc")
     h = hashlib.sha1()
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(_strip_comments(open(os.path.join(d, f), encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()[:12]
 
 

@@ -27,13 +27,14 @@
 //   k_agent_mid   one THREAD per entity: the scalar chain -- flow sampling, arrive force, priority
 //                 ladder -> preferred velocity.  Agents without ClearPath neighbours are truncated +
 //                 position-tested here; the rest go to device-side work lists by neighbour count.
-//   k_cp_rows / k_cp_heavy
-//                 ClearPath for the listed agents: a ROW of 16 lanes per agent with 1..16 neighbours,
-//                 a WORKGROUP per agent with 17..64 (a crowd: its waves share the ray pairs); lanes
-//                 spread over cones / ray pairs, branch and bound on the distance to des_v, a
-//                 candidate queue, a lexicographic arg-min that reproduces the reference's first-wins
-//                 rule; work units numbered heaviest first, drawn by tickets.  The two launches run
-//                 side by side on two streams.
+//   k_cp_small / k_cp_rows / k_cp_heavy
+//                 ClearPath for the listed agents: a ROW of 16 lanes per agent -- 1..4 neighbours on a
+//                 lean kernel of its own (one attempt, no queue; eight waves per SIMD), 5..16 on the
+//                 general search --, a WORKGROUP per agent with 17..64 (a crowd: its waves share the ray
+//                 pairs); lanes spread over cones / ray pairs, branch and bound on the distance to
+//                 des_v, a candidate queue, a lexicographic arg-min that reproduces the reference's
+//                 first-wins rule; work units numbered heaviest first, drawn by tickets.  Rows on the
+//                 caller's stream, the rest beside them on a side stream.
 //   k_agent_full  one WAVE per listed agent, the whole step (irregular gathers: garrisoned
 //                 neighbours, wide queries).
 #include "navhip_internal.h"
