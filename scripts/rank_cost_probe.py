@@ -17,6 +17,8 @@ def main():
     for world in [int(a) for a in sys.argv[1:]] or [1, 8]:
         t0 = time.time()
         T = tick.NavTick(rank=world // 2, world=world)
+        T._comm_pending = False
+        T.pipelined = False          # (no process group here: the exchange is left out)
         setup = time.time() - t0
         for _ in range(4):
             T.compute()
