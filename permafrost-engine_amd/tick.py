@@ -236,7 +236,12 @@ class NavTick:
                 self.fstream = torch.cuda.ExternalStream(self.ctx.stream_create_partial(ncu_all - ncu, ncu), device=self.dev)
             else:
                 self.fstream = torch.cuda.Stream(device=self.dev)
-            self.fields_after = os.environ.get("NAVTICK_FIELDS_AFTER", "start")
+            # ... when there is enough of it to fill that window.  A short build (configs[1]: 4 096 chunk
+            # fields, 45 us) started with the tick only gets in the way of the front -- 0.42 ms per tick
+            # against 0.32 behind the neighbour walk --; the long one of configs[2] (16 384) is the other
+            # way round (0.40 against 0.43).
+            self.fields_after = os.environ.get("NAVTICK_FIELDS_AFTER",
+                                               "start" if self.n_req_local >= 8192 else "neighbours")
             # nothing wide is enqueued on self.stream between prefetch and step: the front stays on it
             # ... and the snapshot buffers ping-pong: the one a step read is next written by the ClearPath
             # kernels of the following step
