@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B two values of one environment knob on bench.py inside a single GPU session:
-#   scripts/ab_env.sh NAVHIP_PRE_WG 64 256
+#   scripts/ab_env.sh NAVTICK_FIELD_CUS 160 192 224
 var=$1; shift
-for i in 1 2; do
+for i in 1 2 3; do
   for v in "$@"; do
-    env $var=$v python bench.py 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$var=$v', round(d['ms_per_step'],4), {k: round(x,4) for k,x in d['phase_ms'].items()})"
+    env $var=$v python bench.py --no-cpu-baseline --no-crowded 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$var=$v', round(d['ms_per_step'],4), round(d['ms_per_step_median'],4), d['ms_tick_5_50_100'])"
   done
 done
