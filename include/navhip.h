@@ -257,6 +257,15 @@ int  navhip_build_los_dev(navhip_ctx *ctx, const navhip_los_req *dev_reqs, int n
 /* N_FlowFieldID (field.c:1952) for TILE / PORTAL targets: the 64-bit cache key the reference's
  * fieldcache uses; pure bit packing, host side. */
 uint64_t navhip_flow_field_id(const navhip_field_req *req);
+/* ... and for the region targets (field.h:85-101), whose fields navhip_build_region_fields writes
+ * (out_mode 1): kind = the reference's field_target.type,
+ *   NAVHIP_FFID_ENEMIES  a = enemies.faction_id
+ *   NAVHIP_FFID_ENTITY   a = ent.target (uid)
+ *   NAVHIP_FFID_ZONE     a, b = zone.centre in absolute nav tiles (chunk * 64 + tile: row, column),
+ *                        c = zone.radius
+ * 0 for any other kind. */
+enum { NAVHIP_FFID_ENEMIES = 2, NAVHIP_FFID_ENTITY = 4, NAVHIP_FFID_ZONE = 5 };
+uint64_t navhip_region_field_id(int kind, int layer, int chunk_r, int chunk_c, uint32_t a, int b, int c);
 
 /* kernel selection override for tests/bench: 0 = auto (bit-parallel BFS when every passable
  * cell of the chunk has cost 1, generic relaxation otherwise), 1 = force generic. */
@@ -385,12 +394,15 @@ typedef struct navhip_world {
     const float    *los_pos_xz;      /* [n][2]  the position the lookup uses: movestate.prev_pos
                                                 (movement.c:4137), or NULL = pos_xz                    */
     int32_t  n_los_slots;
-    /* Host-buffer calls (navhip_agent_step, _submit) only: a caller that knows that the per-entity
-     * ATTRIBUTE tables -- radius, max_speed, flags, flock, flock_target_xz, flock_offsets,
-     * flock_members -- are the ones of its previous call on this context (no entity was added, removed
-     * or re-flocked) passes the same nonzero epoch again and those tables are not transferred a second
-     * time; 0 = transfer everything (the default).  The per-tick state (pos, vel, speed, state,
-     * has_dest_los, vdes, formation and arrival inputs) always travels. */
+    /* Host-buffer calls (navhip_agent_step, _submit) only: a caller that knows that its FLOCK tables --
+     * flock, flock_target_xz, flock_offsets, flock_members -- are the ones of its previous call on this
+     * context (no entity was added or removed, no flock made, disbanded or re-targeted: G_Move_AddEntity
+     * movement.c:4591, G_Move_RemoveEntity :4615, make_flock :789) passes the same nonzero epoch again and
+     * those tables are not transferred a second time; 0 = transfer everything (the default).  Everything
+     * else always travels: the per-tick state (pos, vel, speed, state, has_dest_los, vdes, formation and
+     * arrival inputs) and the per-entity attributes that change without any of those events -- radius,
+     * max_speed (MOVE_CMD_SET_MAX_SPEED, movement.c:3226) and flags (ENTITY_FLAG_GARRISONED is toggled
+     * outside movement.c). */
     uint32_t static_epoch;
 } navhip_world;
 #define NAVHIP_LOS_LOOKUP 0xff
@@ -480,6 +492,12 @@ int  navhip_get_counters(navhip_ctx *ctx, navhip_counters *out, int reset);
  * and agents whose whole step ran on a wave ([5]: garrisoned neighbours / wide queries).  Everyone
  * else has no ClearPath neighbour and finished in the thread-per-agent pass. */
 int  navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6]);
+
+/* ClearPath retry statistics of this process since the last reset (diagnostics: bench.py's status
+ * histogram): out[k], k = 1..7 = searches that returned in attempt k + 1 of G_ClearPath_NewVelocity's
+ * remove_furthest loop (clearpath.c:704-713; [7]: eight or more), out[0] = searches that gave up with a
+ * list empty, out[8] = attempts of all retried searches.  Waits for the device. */
+int  navhip_debug_cp_attempts(unsigned long long out[9], int reset);
 
 /* Device spatial index only (bg_ent insert-all + cleanup + inrange_circle, bitmap_grid.h:1376):
  * for each query point the ids within `range`, in the reference's visiting order, capped at

@@ -73,6 +73,10 @@ def lib():
         L.pfref_nav_get_portal.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(Portal)]
         L.pfref_field_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pfref_flow_field_id.restype = C.c_uint64
+        L.pfref_flow_field_id.argtypes = [C.c_void_p, C.c_void_p]
+        L.pfref_region_field_id.restype = C.c_uint64
+        L.pfref_region_field_id.argtypes = [C.c_int] * 4 + [C.c_uint32, C.c_int, C.c_int]
         L.pfref_field_nearest_pathable.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         L.pfref_field_island_to_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.pfref_cell_arrival_field.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_int, C.c_void_p]
@@ -208,6 +212,17 @@ class RefNav:
         if rc != 0:
             raise ValueError("pfref_field_update: bad request")
         return dirs, integ
+
+    def flow_field_id(self, req):
+        """N_FlowFieldID (field.c:1952) of a TILE / PORTAL request."""
+        r = _to_req(req)
+        return int(lib().pfref_flow_field_id(self._h, C.byref(r)))
+
+    @staticmethod
+    def region_field_id(kind, layer, chunk_r, chunk_c, a, b=0, c=0):
+        """N_FlowFieldID of an ENEMIES (2: a = faction) / ENTITY (4: a = uid) / ZONE (5: a, b = centre in
+        absolute tiles, c = radius) target."""
+        return int(lib().pfref_region_field_id(kind, layer, chunk_r, chunk_c, a, b, c))
 
     def field_nearest_pathable(self, chunk_r, chunk_c, start_r, start_c, existing, layer=0,
                                faction_id=FACTION_ID_NONE):

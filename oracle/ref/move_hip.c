@@ -11,10 +11,12 @@
 
 navhip_ctx *N_HIP_Ctx(void);          /* nav_hip.c */
 
-/* The per-entity attribute tables (radius, max speed, flags, flock membership) only change when an
- * entity is added, removed, re-flagged or re-flocked: movement.c bumps this epoch there (G_Move_AddEntity
- * :4591, G_Move_RemoveEntity :4615, make_flock :789, the flock disbanding :742,:2859) and the library keeps the
- * tables of an unchanged epoch on the device (navhip_world.static_epoch). */
+/* The flock tables (membership, member lists, targets) only change when an entity is added or removed
+ * or a flock is made, re-targeted or disbanded: movement.c bumps this epoch there (G_Move_AddEntity :4591,
+ * G_Move_RemoveEntity :4615, make_flock :789, the flock disbanding :742,:2859) and the library keeps the
+ * flock tables of an unchanged epoch on the device (navhip_world.static_epoch).  Radius, max speed and
+ * flags have other writers (do_set_max_speed :3226, the selection-radius setter, ENTITY_FLAG_GARRISONED):
+ * the library transfers them every tick. */
 static uint32_t s_hip_attr_epoch = 1;
 static void move_hip_attrs_changed(void)      /* (declared ahead in the harness: ref_move.c) */
 {

@@ -87,6 +87,12 @@ void pfref_set_enemy_factions(int faction_id, unsigned mask);
 int pfref_field_update(pfref_nav *nav, const pfref_field_req *req,
                        uint8_t *inout_dirs, float *out_integ);
 
+/* N_FlowFieldID (field.c:1952): TILE / PORTAL requests, and the region targets
+ * (kind = field_target.type: 2 ENEMIES a = faction_id; 4 ENTITY a = target uid;
+ *  5 ZONE a, b = centre in absolute nav tiles (row, column), c = radius) */
+uint64_t pfref_flow_field_id(pfref_nav *nav, const pfref_field_req *req);
+uint64_t pfref_region_field_id(int kind, int layer, int chunk_r, int chunk_c, uint32_t a, int b, int c);
+
 /* the repair builds the sampler runs on an existing field (nav.c:3527-3547) */
 int pfref_field_nearest_pathable(pfref_nav *nav, int layer, int chunk_r, int chunk_c, int start_r,
                                  int start_c, int faction_id, uint8_t *inout_dirs);

@@ -95,6 +95,36 @@ static bool make_target_synth(const struct nav_private *priv, const pfref_field_
     return true;
 }
 
+/* N_FlowFieldID (field.c:1952) itself, for every target kind.  kind = the reference's field_target.type;
+ * a/b/c/d: ENEMIES faction_id | ENTITY target uid | ZONE centre (abs_r, abs_c), radius */
+uint64_t pfref_flow_field_id(pfref_nav *nav, const pfref_field_req *req)
+{
+    struct field_target target;
+    struct portal storage[2];
+    if(!make_target_synth(&nav->priv, req, &target, storage))
+        return 0;
+    return N_FlowFieldID((struct coord){req->chunk_r, req->chunk_c}, target, (enum nav_layer)req->layer);
+}
+
+uint64_t pfref_region_field_id(int kind, int layer, int chunk_r, int chunk_c, uint32_t a, int b, int c)
+{
+    struct field_target target;
+    memset(&target, 0, sizeof(target));
+    target.type = kind;
+    if(kind == TARGET_ENEMIES) {
+        target.enemies.faction_id = (int)a;
+        target.enemies.chunk = (struct coord){chunk_r, chunk_c};
+    }else if(kind == TARGET_ENTITY) {
+        target.ent.target = a;
+    }else if(kind == TARGET_ZONE) {
+        target.zone.centre = (struct tile_desc){(int)a / FIELD_RES_R, b / FIELD_RES_C, (int)a % FIELD_RES_R, b % FIELD_RES_C};
+        target.zone.radius = (uint16_t)c;
+    }else{
+        return 0;
+    }
+    return N_FlowFieldID((struct coord){chunk_r, chunk_c}, target, (enum nav_layer)layer);
+}
+
 void pfref_req_from_target(struct coord chunk, int faction_id, enum nav_layer layer,
                            const struct field_target *t, pfref_field_req *out)
 {

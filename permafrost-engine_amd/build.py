@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, "navhip_internal.h"), os.path.join(ROOT, "include", "navhip.h"),
                    os.path.abspath(__file__)]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".map"))]
     if not force and not _newer(deps, LIB):
         return LIB
     objs = []
@@ -48,7 +48,8 @@ def build(force=False, verbose=False):
             if verbose and r.stdout.strip():
                 print(r.stdout)
         objs.append(o)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs \
+        + ["-Wl,--version-script=" + os.path.join(CSRC, "navhip.map")]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout)

@@ -533,7 +533,7 @@ int navhip_build_los(navhip_ctx *ctx, const navhip_los_req *reqs, int n,
     return NAVHIP_OK;
 }
 
-int navhip_validate_field_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
+int nh_validate_field_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n)
 {
     for(int i = 0; i < n; i++) {
         const navhip_field_req &r = reqs[i];
@@ -614,7 +614,7 @@ int navhip_build_fields(navhip_ctx *ctx, const navhip_field_req *reqs, int n,
     if(!ctx || n < 0 || (n > 0 && (!reqs || !inout_dirs))) return NAVHIP_ERR_INVALID;
     if(n == 0) return NAVHIP_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = navhip_validate_field_reqs(ctx, reqs, n);
+    int rc = nh_validate_field_reqs(ctx, reqs, n);
     if(rc) return rc;
     hipStream_t s = ctx->stream;
     rc = ensure_cap(ctx, &ctx->d_reqs, &ctx->d_reqs_cap, (size_t)n * sizeof(navhip_field_req));
@@ -958,7 +958,12 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         P.grid.n = w->n_ents;
         P.grid.cell_start = (int32_t*)ctx->sp[3].p; P.grid.recA = (const float4*)ctx->sp[7].p;
         P.grid.recV = (const float2*)ctx->sp[8].p; P.grid.pool_of = (const int32_t*)ctx->sp[9].p;
-        if(ctx->front_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));   // (inline front: already ordered)
+        if(ctx->front_stream != s) {
+            // (an inline front on THIS stream is ordered by itself; on another stream -- the step is
+            // issued elsewhere than the prefetch -- its "done" event may not have been recorded yet)
+            if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
+        }
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
                                ctx->aux[0], ctx->ev_cp);
@@ -1239,6 +1244,23 @@ uint64_t navhip_flow_field_id(const navhip_field_req *r)
          | (((uint64_t)r->tile_c)  << 16)
          | (((uint64_t)r->chunk_r) <<  8)
          | (((uint64_t)r->chunk_c) <<  0);
+}
+
+uint64_t navhip_region_field_id(int kind, int layer, int chunk_r, int chunk_c, uint32_t a, int b, int c)
+{
+    // N_FlowFieldID, field.c:1976-2003
+    const uint64_t head = (((uint64_t)layer) << 60) | (((uint64_t)kind) << 56);
+    const uint64_t tail = (((uint64_t)chunk_r) << 8) | ((uint64_t)chunk_c);
+    if(kind == NAVHIP_FFID_ENEMIES || kind == NAVHIP_FFID_ENTITY)
+        return head | (((uint64_t)a) << 24) | tail;
+    if(kind == NAVHIP_FFID_ZONE) {
+        const uint32_t cen_chunk_r = a / 64u, cen_tile_r = a % 64u;
+        const uint32_t cen_chunk_c = (uint32_t)b / 64u, cen_tile_c = (uint32_t)b % 64u;
+        return head | (((uint64_t)(c & 0xff)) << 44) | (((uint64_t)(cen_tile_c & 0x3f)) << 38)
+             | (((uint64_t)(cen_tile_r & 0x3f)) << 32) | (((uint64_t)(cen_chunk_c & 0xff)) << 24)
+             | (((uint64_t)(cen_chunk_r & 0xff)) << 16) | tail;
+    }
+    return 0;
 }
 
 } // extern "C"

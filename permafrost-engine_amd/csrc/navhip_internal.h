@@ -81,7 +81,7 @@ struct navhip_ctx {
 };
 
 // pool_api.hip <-> navhip_api.hip
-extern "C" int navhip_validate_field_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n);   /* (not in navhip.h) */
+extern "C" int nh_validate_field_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n);   /* (library internal) */
 int  navhip_build_fields_slots_dev(navhip_ctx *ctx, const navhip_field_req *dev_reqs, int n, uint8_t *dev_fields,
                                    const int32_t *dev_slots, hipStream_t s);
 int  navhip_stage_reserve(navhip_ctx *ctx, int slot, size_t bytes, void **dev);

@@ -212,13 +212,38 @@ int navhip_pool_map(navhip_ctx *ctx, int n, const int32_t *dest, const uint16_t 
         const int64_t e = (int64_t)dest[i] * P->nchunks + (int)chunk_r[i] * ctx->w + chunk_c[i];
         int slot = -1;                                   // an id that is not resident maps to "no field"
         auto it = P->slot_of.find(ff_ids[i]);
-        if(it != P->slot_of.end()) { slot = it->second; P->refs[slot].push_back(e); }
+        if(it != P->slot_of.end()) slot = it->second;
         if(P->h_map[(size_t)e] != slot) {
+            if(slot >= 0) P->refs[slot].push_back(e);     // (once per change: a host that re-puts its
+                                                          // mappings every tick must not grow the list)
             P->h_map[(size_t)e] = slot;
             P->pending.push_back((int32_t)e); P->pending.push_back(slot);
         }
     }
     return pool_flush_map(ctx, P, ctx->stream);
+}
+
+// slots a pool build took for ids that were not resident: handed back when the call fails, so that no id
+// is ever registered for a slot whose field was not built (the evicted fields are gone either way)
+static void pool_rollback(nh_pool *P, const std::vector<int> &fresh_slots)
+{
+    for(int slot : fresh_slots) {
+        if(!P->used[slot]) continue;
+        P->slot_of.erase(P->id_of[slot]);
+        P->used[slot] = 0;
+        P->refs[slot].clear();
+        // least recently used again: the next new id takes it first
+        P->lru.erase(P->lru_it[slot]);
+        P->lru.push_back(slot);
+        P->lru_it[slot] = std::prev(P->lru.end());
+    }
+}
+
+__global__ void k_zero_fields(uint8_t *fields, const int32_t *slots, int n)
+{
+    const int i = blockIdx.x;
+    if(i >= n) return;
+    ((uint4*)(fields + ((size_t)slots[i] << 12)))[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 int navhip_pool_build(navhip_ctx *ctx, const navhip_field_req *reqs, const uint64_t *ff_ids,
@@ -230,68 +255,117 @@ int navhip_pool_build(navhip_ctx *ctx, const navhip_field_req *reqs, const uint6
     if(n > P->n_slots) { ctx->last_error = "navhip_pool_build: more requests than pool slots"; return NAVHIP_ERR_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    int rc = navhip_validate_field_reqs(ctx, reqs, n);
-    if(rc) return rc;
-    rc = grow(ctx, &P->d_reqs, &P->d_reqs_cap, (size_t)n * sizeof(navhip_field_req));
-    if(!rc) rc = grow(ctx, (void**)&P->d_slots, &P->d_slots_cap, (size_t)n * 3 * sizeof(int32_t));
+    int rc = nh_validate_field_reqs(ctx, reqs, n);
     if(rc) return rc;
     std::vector<navhip_field_req> rq(reqs, reqs + n);
-    std::vector<int32_t> slots(n), copies;
+    // ---- plan first, commit nothing: every base must be resident or produced earlier in this call, and
+    // the fields the call touches (its ids and the resident bases it reads) must fit the pool together
+    // -- they stay pinned for the WHOLE call, so that no sub-batch evicts what another one reads or wrote
+    std::vector<uint64_t> base(n, 0);
+    {
+        std::unordered_map<uint64_t, int> seen;          // ids of earlier requests of this call
+        std::unordered_map<uint64_t, int> touched;       // distinct ids + resident bases
+        for(int i = 0; i < n; i++) {
+            const uint64_t b = (base_ids && (rq[i].flags & NAVHIP_REQ_INOUT)) ? base_ids[i] : 0;
+            if(b && b != ff_ids[i]) {
+                if(!seen.count(b)) {
+                    if(!P->slot_of.count(b)) { ctx->last_error = "navhip_pool_build: base field not resident"; return NAVHIP_ERR_NOT_UPLOADED; }
+                    touched[b] = 1;
+                }
+                base[i] = b;
+            }
+            seen[ff_ids[i]] = i;
+            touched[ff_ids[i]] = 1;
+        }
+        if((int)touched.size() > P->n_slots) { ctx->last_error = "navhip_pool_build: the call touches more fields than the pool has slots"; return NAVHIP_ERR_NOMEM; }
+    }
+    rc = grow(ctx, &P->d_reqs, &P->d_reqs_cap, (size_t)n * sizeof(navhip_field_req));
+    if(!rc) rc = grow(ctx, (void**)&P->d_slots, &P->d_slots_cap, (size_t)n * 4 * sizeof(int32_t));
+    if(rc) return rc;
+    std::vector<int32_t> slots(n), copies, zeros;
     std::vector<uint8_t> pinned(P->n_slots, 0);
+    std::vector<int> fresh_slots;
+    for(int i = 0; i < n; i++) {
+        if(!base[i]) continue;
+        auto it = P->slot_of.find(base[i]);
+        if(it != P->slot_of.end()) pinned[it->second] = 1;
+    }
+#define POOL_FAIL(code) do { pool_rollback(P, fresh_slots); hipStreamSynchronize(s); pool_flush_map(ctx, P, s); return (code); } while(0)
+#define POOL_HIPCHK(expr) do { hipError_t _e = (expr); if(_e != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); POOL_FAIL(NAVHIP_ERR_DEVICE); } } while(0)
     // Sub-batches: a request that reads (base) or rewrites the slot of an EARLIER request of the same
-    // sub-batch has to wait for it -- the in-place chains of nav.c:1987-2011.
+    // sub-batch has to wait for it -- the in-place chains of nav.c:1987-2011 -- and so has a request
+    // that rewrites a field an earlier request of the sub-batch is COPIED from (the copies of a
+    // sub-batch run in one launch in front of its builds).
     int begin = 0;
     while(begin < n) {
-        std::unordered_map<uint64_t, int> written;
+        std::unordered_map<uint64_t, int> written, copied_from;
         int end = begin;
-        copies.clear();
-        std::fill(pinned.begin(), pinned.end(), 0);
+        copies.clear(); zeros.clear();
         for(; end < n; end++) {
-            const uint64_t base = (base_ids && (rq[end].flags & NAVHIP_REQ_INOUT)) ? base_ids[end] : 0;
-            if(written.count(ff_ids[end]) || (base && written.count(base))) break;
+            const uint64_t b = base[end];
+            if(written.count(ff_ids[end]) || (b && written.count(b)) || copied_from.count(ff_ids[end])) break;
             int base_slot = -1;
-            if(base && base != ff_ids[end]) {
-                auto it = P->slot_of.find(base);
-                if(it == P->slot_of.end()) { ctx->last_error = "navhip_pool_build: base field not resident"; return NAVHIP_ERR_NOT_UPLOADED; }
-                base_slot = it->second;
+            if(b) {
+                base_slot = P->slot_of.find(b)->second;      // resident by now: planned above
                 pinned[base_slot] = 1;
+                copied_from[b] = 1;
             }
             bool fresh;
             const int slot = pool_slot_for(P, ff_ids[end], &fresh, &pinned);
-            if(slot < 0) return NAVHIP_ERR_NOMEM;
+            if(slot < 0) { ctx->last_error = "navhip_pool_build: no evictable slot"; POOL_FAIL(NAVHIP_ERR_NOMEM); }
             pinned[slot] = 1;
+            if(fresh) fresh_slots.push_back(slot);
             slots[end] = slot;
             written[ff_ids[end]] = end;
             if(base_slot >= 0) { copies.push_back(base_slot); copies.push_back(slot); }
-            // an in-place request on a fresh slot without a base starts from N_FlowFieldInit
-            if((rq[end].flags & NAVHIP_REQ_INOUT) && fresh && base_slot < 0
-            && rq[end].type != NAVHIP_TARGET_NEAREST_PATHABLE && !(rq[end].flags & NAVHIP_REQ_ISLAND_NEAREST))
-                rq[end].flags &= ~NAVHIP_REQ_INOUT;
+            if(fresh && base_slot < 0) {
+                // A new slot still holds the field of the id it was taken from.  An in-place request
+                // without a base starts from N_FlowFieldInit; nothing is cached yet, so "only if changed"
+                // does not apply; and a request the kernel may decline (NAVHIP_REQ_LIVE_IIDS: a portal
+                // blocked from end to end) must find N_FlowFieldInit's all-FD_NONE field there, not the
+                // evicted one.
+                if((rq[end].flags & NAVHIP_REQ_INOUT)
+                && rq[end].type != NAVHIP_TARGET_NEAREST_PATHABLE && !(rq[end].flags & NAVHIP_REQ_ISLAND_NEAREST))
+                    rq[end].flags &= ~NAVHIP_REQ_INOUT;
+                rq[end].flags &= ~NAVHIP_REQ_IF_CHANGED;
+                if(rq[end].flags & (NAVHIP_REQ_LIVE_IIDS | NAVHIP_REQ_INOUT)) zeros.push_back(slot);
+            }else if(fresh) {
+                rq[end].flags &= ~NAVHIP_REQ_IF_CHANGED;     // (a copy of its base is not the field asked for)
+            }
         }
         const int m = end - begin;
         rc = pool_flush_map(ctx, P, s);
-        if(rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync((char*)P->d_reqs + (size_t)begin * sizeof(navhip_field_req), &rq[begin],
+        if(rc) POOL_FAIL(rc);
+        POOL_HIPCHK(hipMemcpyAsync((char*)P->d_reqs + (size_t)begin * sizeof(navhip_field_req), &rq[begin],
                                    (size_t)m * sizeof(navhip_field_req), hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(P->d_slots + begin, &slots[begin], (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        POOL_HIPCHK(hipMemcpyAsync(P->d_slots + begin, &slots[begin], (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        if(!zeros.empty()) {
+            int32_t *d_z = P->d_slots + 3 * (size_t)n;
+            POOL_HIPCHK(hipMemcpyAsync(d_z, zeros.data(), zeros.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_zero_fields, dim3((unsigned)zeros.size()), dim3(256), 0, s, P->d_fields,
+                               (const int32_t*)d_z, (int)zeros.size());
+        }
         if(!copies.empty()) {
             int32_t *d_cp = P->d_slots + n;
-            HIPCHK(ctx, hipMemcpyAsync(d_cp, copies.data(), copies.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            POOL_HIPCHK(hipMemcpyAsync(d_cp, copies.data(), copies.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_copy_field, dim3((unsigned)(copies.size() / 2)), dim3(256), 0, s, P->d_fields,
                                (const int32_t*)d_cp, (int)(copies.size() / 2));
         }
         rc = navhip_build_fields_slots_dev(ctx, (const navhip_field_req*)P->d_reqs + begin, m, P->d_fields,
                                            P->d_slots + begin, s);
-        if(rc) return rc;
-        HIPCHK(ctx, hipStreamSynchronize(s));       // (host vectors of the next sub-batch reuse the staging)
+        if(rc) POOL_FAIL(rc);
+        POOL_HIPCHK(hipStreamSynchronize(s));       // (host vectors of the next sub-batch reuse the staging)
         begin = end;
     }
     if(out_dirs) {
+        // (the fields are built and registered: a failing read-back does not unregister them)
         for(int i = 0; i < n; i++)
             HIPCHK(ctx, hipMemcpyAsync(out_dirs + ((size_t)i << 12), P->d_fields + ((size_t)slots[i] << 12), NH_CELLS,
                                        hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
     }
+#undef POOL_FAIL
+#undef POOL_HIPCHK
     return NAVHIP_OK;
 }
 
@@ -321,6 +395,7 @@ static bool is_pinned(const void *p)
 
 struct nh_async {
     bool        pending;
+    bool        empty;           // the submitted world had no entities: nothing is in flight, poll / wait succeed
     hipEvent_t  done;
     // pinned staging: one slab for the inputs, one for the outputs
     char  *h_in;  size_t h_in_cap;
@@ -347,18 +422,24 @@ extern "C" {
 int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhip_step_out *out)
 {
     if(!ctx || !w || !out || !out->vel_xz) return NAVHIP_ERR_INVALID;
-    if(w->n_ents <= 0) return w->n_ents == 0 ? NAVHIP_OK : NAVHIP_ERR_INVALID;
+    if(w->n_ents < 0) return NAVHIP_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if(!ctx->async) {
         ctx->async = new (std::nothrow) nh_async();
         if(!ctx->async) return NAVHIP_ERR_NOMEM;
-        ctx->async->pending = false; ctx->async->h_in = ctx->async->h_out = nullptr;
+        ctx->async->pending = false; ctx->async->empty = false; ctx->async->h_in = ctx->async->h_out = nullptr;
         ctx->async->h_in_cap = ctx->async->h_out_cap = 0;
         ctx->async->static_epoch = 0; ctx->async->static_n = ctx->async->static_f = 0;
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->async->done, hipEventDisableTiming));
     }
     nh_async *A = ctx->async;
     if(A->pending) { ctx->last_error = "navhip_agent_step_submit: a step is already in flight"; return NAVHIP_ERR_INVALID; }
+    if(w->n_ents == 0) {            // an empty world is a valid tick: submit / poll / wait all succeed
+        A->finish.clear();
+        A->pending = true; A->empty = true;
+        return NAVHIP_OK;
+    }
+    A->empty = false;
     hipStream_t s = ctx->stream;
     const size_t n = (size_t)w->n_ents, F = (size_t)w->n_flocks;
     size_t nmembers = (F > 0 && w->flock_offsets) ? (size_t)w->flock_offsets[F] : 0;
@@ -367,8 +448,11 @@ int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhi
     navhip_world d = *w;
     std::vector<item> items = {
         {w->pos_xz, n * 8, 0, (const void**)&d.pos_xz, false, true},       {w->vel_xz, n * 8, 1, (const void**)&d.vel_xz, false, true},
-        {w->radius, n * 4, 2, (const void**)&d.radius, true},       {w->max_speed, n * 4, 3, (const void**)&d.max_speed, true},
-        {w->speed, n * 4, 4, (const void**)&d.speed},         {w->flags, n * 4, 5, (const void**)&d.flags, true},
+        // (radius, max_speed and flags change without any entity being added, removed or re-flocked --
+        // MOVE_CMD_SET_MAX_SPEED movement.c:3226, selection-radius updates, ENTITY_FLAG_GARRISONED toggled
+        // by the garrison module --: they travel every tick, only the flock tables are epoch-cached)
+        {w->radius, n * 4, 2, (const void**)&d.radius, false, true}, {w->max_speed, n * 4, 3, (const void**)&d.max_speed},
+        {w->speed, n * 4, 4, (const void**)&d.speed},         {w->flags, n * 4, 5, (const void**)&d.flags, false, true},
         {w->state, n, 6, (const void**)&d.state, false, true},             {w->has_dest_los, n, 7, (const void**)&d.has_dest_los},
         {w->flock, n * 4, 8, (const void**)&d.flock, true},         {w->vdes_xz, n * 8, 9, (const void**)&d.vdes_xz},
         {w->flock_target_xz, F * 8, 10, (const void**)&d.flock_target_xz, true},
@@ -500,6 +584,7 @@ static int async_finish(navhip_ctx *ctx)
 int navhip_agent_step_poll(navhip_ctx *ctx)
 {
     if(!ctx || !ctx->async || !ctx->async->pending) return NAVHIP_ERR_INVALID;
+    if(ctx->async->empty) return async_finish(ctx);
     hipError_t e = hipEventQuery(ctx->async->done);
     if(e == hipErrorNotReady) return 1;
     if(e != hipSuccess) { ctx->last_error = std::string("navhip_agent_step_poll: ") + hipGetErrorString(e); return NAVHIP_ERR_DEVICE; }
@@ -509,6 +594,7 @@ int navhip_agent_step_poll(navhip_ctx *ctx)
 int navhip_agent_step_wait(navhip_ctx *ctx)
 {
     if(!ctx || !ctx->async || !ctx->async->pending) return NAVHIP_ERR_INVALID;
+    if(ctx->async->empty) return async_finish(ctx);
     // a step takes a few hundred microseconds: poll for that long (a blocking wait costs a wake-up of
     // tens of microseconds), then block
     for(int spin = 0; spin < 20000; spin++) {

@@ -92,7 +92,9 @@ _SIGS = {
     "navhip_build_fields_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "navhip_flow_field_id": (C.c_uint64, [C.c_void_p]),
+    "navhip_region_field_id": (C.c_uint64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int]),
     "navhip_set_field_kernel": (C.c_int, [C.c_void_p, C.c_int]),
+    "navhip_debug_cp_attempts": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None
@@ -282,6 +284,14 @@ def N_FlowFieldID(req):
     """N_FlowFieldID (field.c:1952) for one navhip_field_req record."""
     r = np.ascontiguousarray(np.asarray(req, dtype=FIELD_REQ_DTYPE).reshape(1))
     return int(lib().navhip_flow_field_id(_hp(r)))
+
+
+FFID_ENEMIES, FFID_ENTITY, FFID_ZONE = 2, 4, 5
+
+
+def N_RegionFieldID(kind, layer, chunk_r, chunk_c, a, b=0, c=0):
+    """N_FlowFieldID for an ENEMIES / ENTITY / ZONE target (field.c:1976-2003)."""
+    return int(lib().navhip_region_field_id(kind, layer, chunk_r, chunk_c, a, b, c))
 
 
 # ---------------------------------------------------------------------------------------------

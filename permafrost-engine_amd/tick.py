@@ -85,6 +85,7 @@ class NavTick:
             circ["x"], circ["z"] = pos[:, 0], pos[:, 1]
             circ["radius"] = rng.uniform(2.0, 6.0, obstacles)
             circ["delta"] = 1
+            self._circ_host = circ.copy()       # (parity tests replay them through the reference)
             self.ctx.N_BlockersUpdate(circ)
             self.ctx.changed_chunks(0, clear=True)
             blockers = synth.from_chunks(self.ctx.download_plane(0, navhip.PLANE_BLOCKERS))

@@ -29,6 +29,17 @@ pmc) for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_C
      done ;;
 aux) timeout 600 python scripts/bench_aux.py > $OUT/bench_aux.json 2> $OUT/bench_aux.err; tail -c 1200 $OUT/bench_aux.json
      [ -f build_prof/libnavhip_cphist.so ] && timeout 300 python scripts/cp_unit_hist.py > $OUT/cp_unit_hist.json 2> /dev/null ;;
+cfgs) for c in 0 1 3 4; do timeout 600 python bench.py --config $c --no-crowded > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; tail -c 400 $OUT/bench_cfg$c.json; tail -2 $OUT/bench_cfg$c.err; done ;;
+stats20) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats20 -o s --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof20.json 2> $OUT/prof20.err
+       f=$(find $OUT/stats20 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 $f ;;
+avail) timeout 120 rocprofv3 -L > $OUT/avail.txt 2>&1; grep -c . $OUT/avail.txt ;;
+pmccp) i=0; for c in "SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+       i=$((i+1))
+       timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccp_$i -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmccp_$i.json 2> $OUT/pmccp_$i.err
+       tail -c 200 $OUT/pmccp_$i.err
+       timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccpc_$i -o p --output-format csv -- python bench.py --crowded --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmccpc_$i.json 2> $OUT/pmccpc_$i.err
+       tail -c 200 $OUT/pmccpc_$i.err
+     done ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log ;;
 esac
 done

@@ -1,6 +1,7 @@
-"""tests/hostsim -- TEST INFRASTRUCTURE ONLY: the thread-per-agent bodies of the movement step
-(csrc/agent_thread.h) compiled with g++ and driven serially, to check their logic against the
-reference on a machine without a GPU.  Never imported by the product."""
+"""tests/hostsim -- TEST INFRASTRUCTURE ONLY: the thread-per-agent bodies of the movement step that
+run on the device (csrc/agent_thread.h: pool_record, mid_thread, post_thread) compiled with g++ and
+driven serially -- behind serial statements of the group-parallel parts (serial_thread.h) -- to check
+their logic against the reference on a machine without a GPU.  Never imported by the product."""
 import ctypes as C
 import os
 import subprocess
@@ -17,7 +18,7 @@ _lib = None
 def build():
     src = os.path.join(HERE, "hostsim.cpp")
     deps = [src] + [os.path.join(CSRC, f) for f in ("agent_thread.h", "agent_math.h", "agent_types.h", "map_view.h")]
-    deps.append(os.path.join(ROOT, "include", "navhip.h"))
+    deps += [os.path.join(ROOT, "include", "navhip.h"), os.path.join(HERE, "serial_thread.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     # same floating-point contract as the device build: no FMA contraction, IEEE everything

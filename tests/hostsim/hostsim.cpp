@@ -8,7 +8,7 @@
 // here; agents the thread path hands to a wave are reported as such.  Nothing of this is linked
 // into libnavhip.so: the product has no CPU path.
 #define NH_HOSTSIM 1
-#include "agent_thread.h"
+#include "serial_thread.h"
 
 #include <algorithm>
 #include <cstdio>

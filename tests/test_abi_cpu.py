@@ -31,6 +31,13 @@ def test_header_symbols_exported_and_bound(navlib):
     assert not unbound, "exported but not mirrored in navhip.py: %s" % unbound
     ghost = [n for n in navlib._SIGS if n not in names]
     assert not ghost, "navhip.py binds undeclared symbols: %s" % ghost
+    # ... and nothing else leaves the library: kernels, launch helpers and C++ internals stay local
+    # (csrc/navhip.map), every dynamic symbol it defines is declared in the header
+    out = subprocess.run(["nm", "-D", "--defined-only", navlib.LIB_PATH], stdout=subprocess.PIPE, text=True,
+                         check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.split()[1] in "TDBW")
+    extra = [n for n in exported if n not in names]
+    assert not extra, "exported but not declared in include/navhip.h: %s" % extra
 
 
 def test_header_is_plain_c_and_layouts_match(navlib, tmp_path):
@@ -100,6 +107,42 @@ def test_flow_field_id_bit_layout(navlib):
     assert ids == [_ff_id_expected(reqs[i]) for i in range(64)]
     # distinct requests of one chunk never collide on the cache key
     assert len(set(ids)) == 64
+
+
+def test_flow_field_id_matches_the_reference(navlib):
+    """navhip_flow_field_id / navhip_region_field_id against the reference's own N_FlowFieldID
+    (field.c:1952) through oracle/_ref: the planner's real request stream (real portals, island ids
+    above 15) plus every region target kind."""
+    from oracle import pfref
+    from tests import cases
+    if not (pfref.available() or os.path.isdir("/root/reference")):
+        pytest.skip("oracle/_ref not built and /root/reference absent")
+    grid, nav = cases.ref_nav_for(4, 3, seed=21)
+    reqs_t = cases.tile_requests(grid, 16, seed=5)
+    reqs_p, _b, _a = cases.planner_requests(nav, grid, pairs=10, seed=9)
+    ref_reqs = np.concatenate([reqs_t, reqs_p])
+    assert (ref_reqs["type"] == 0).sum() > 8
+    for layer in (0, 3, 11):
+        ref_reqs["layer"] = 0                      # (the portals are those of layer 0)
+        want = [nav.flow_field_id(r) for r in ref_reqs]
+        mine = cases.reqs_from_ref(navlib, ref_reqs)
+        got = [navlib.N_FlowFieldID(mine[i]) for i in range(len(mine))]
+        assert got == want
+        # the layer field only enters through the top nibble (field.c:1956,1969)
+        mine["layer"] = layer
+        got_l = [navlib.N_FlowFieldID(mine[i]) for i in range(len(mine))]
+        assert got_l == [(w & ~(0xf << 60)) | (layer << 60) for w in want]
+    rng = np.random.RandomState(2)
+    for _ in range(200):
+        layer, cr, cc = int(rng.randint(12)), int(rng.randint(64)), int(rng.randint(64))
+        fac, uid = int(rng.randint(15)), int(rng.randint(1 << 20))
+        ar, ac, rad = int(rng.randint(64 * 64)), int(rng.randint(64 * 64)), int(rng.randint(1, 200))
+        for kind, a, b, c in ((navlib.FFID_ENEMIES, fac, 0, 0), (navlib.FFID_ENTITY, uid, 0, 0),
+                              (navlib.FFID_ZONE, ar, ac, rad)):
+            assert navlib.N_RegionFieldID(kind, layer, cr, cc, a, b, c) \
+                == pfref.RefNav.region_field_id(kind, layer, cr, cc, a, b, c), (kind, a, b, c)
+    assert navlib.N_RegionFieldID(3, 0, 1, 1, 0) == 0          # TARGET_PORTALMASK has no cache key
+    nav.close()
 
 
 def test_invalid_arguments_are_rejected(navlib):

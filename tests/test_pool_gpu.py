@@ -113,6 +113,119 @@ def test_pool_in_place_update_from_a_base_field(navlib, small):
     assert not np.array_equal(exp[0], ctx.N_FlowFieldUpdate(b)[0][0]) or True
 
 
+def test_pool_build_failure_registers_nothing(navlib, small):
+    """A failing navhip_pool_build must not leave ids registered for slots that were never built
+    (navhip_pool_contains / get / map would hand out the evicted id's field): the call is planned before
+    anything is committed."""
+    ctx, reqs = small["ctx"], small["reqs"]
+    u = small["uniq"]
+    ctx.pool_create(8, 1)
+    old_ids, old = ctx.pool_build(reqs[u[:8]])                 # the pool is full
+    new = reqs[u[8:12]].copy()
+    new["flags"][3] |= navlib.REQ_INOUT
+    new_ids = small["all_ids"][u[8:12]]
+    with pytest.raises(navlib.NavHipError):                    # the LAST request names a base nobody has
+        ctx.pool_build(new, ff_ids=new_ids, base_ids=[0, 0, 0, 0xDEAD])
+    assert not any(ctx.pool_contains(i) for i in new_ids)
+    assert all(ctx.pool_contains(i) for i in old_ids)          # nothing was evicted either
+    assert all(np.array_equal(ctx.pool_get(i), f) for i, f in zip(old_ids, old))
+    # the call touches more fields than the pool has slots (8 new ids + a resident base): refused up front
+    eight = reqs[u[8:16]].copy()
+    eight["flags"][0] |= navlib.REQ_INOUT
+    with pytest.raises(navlib.NavHipError):
+        ctx.pool_build(eight, ff_ids=small["all_ids"][u[8:16]], base_ids=[old_ids[0]] + [0] * 7)
+    assert all(ctx.pool_contains(i) for i in old_ids)
+    assert not any(ctx.pool_contains(i) for i in small["all_ids"][u[8:16]])
+
+
+def test_pool_fresh_slot_never_keeps_the_evicted_field(navlib, small):
+    """A request the kernel may decline -- NAVHIP_REQ_IF_CHANGED with no change flagged, NAVHIP_REQ_LIVE_IIDS
+    with its portal blocked from end to end -- that lands on a NEW slot: the slot must not keep the field
+    of the id it was taken from."""
+    synth = cases.synth
+    ctx, reqs, W = small["ctx"], small["reqs"], small["W"]
+    u = small["uniq"]
+    ctx.pool_create(4, 1)
+    ids0, f0 = ctx.pool_build(reqs[u[:4]])
+    assert all(f.any() for f in f0)
+    # (1) IF_CHANGED on a fresh slot: nothing is cached for the id, so the field is built
+    r = reqs[u[4:5]].copy()
+    r["flags"] |= navlib.REQ_IF_CHANGED
+    ctx.changed_chunks(0, clear=True)
+    ids1, f1 = ctx.pool_build(r)
+    plain, _ = ctx.N_FlowFieldUpdate(reqs[u[4:5]])
+    assert np.array_equal(f1, plain)
+    # (2) LIVE_IIDS with the portal blocked from end to end: N_FlowFieldInit's field, not the evicted one
+    portal = [i for i in u[5:] if reqs["type"][i] == navlib.TARGET_PORTAL]
+    i = portal[0]
+    blk = np.zeros((W, W, 64, 64), np.uint16)
+    q = reqs[i]
+    blk[q["chunk_r"], q["chunk_c"], q["port_r0"]:q["port_r1"] + 1, q["port_c0"]:q["port_c1"] + 1] = 1
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, blk)
+    grid_blk = synth.from_chunks(blk)
+    ctx.relabel_local_islands(0)
+    live = reqs[i:i + 1].copy()
+    live["flags"] |= navlib.REQ_LIVE_IIDS
+    ids2, f2 = ctx.pool_build(live)
+    assert not f2.any()                                        # all FD_NONE
+    assert np.array_equal(ctx.pool_get(ids2[0]), f2[0])
+    # restore the planes for the tests that follow
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, np.zeros((W, W, 64, 64), np.uint16))
+    ctx.relabel_local_islands(0)
+
+
+def test_pool_copy_and_rewrite_of_one_field_in_one_call(navlib, small):
+    """Request j updates field B in place into a new id, a later request k REBUILDS B itself: the copy
+    of B for j must see B as it was (the two must not share a copy/build sub-batch)."""
+    ctx, reqs = small["ctx"], small["reqs"]
+    u = small["uniq"]
+    ctx.pool_create(16, 1)
+    a, b = reqs[u[0]:u[0] + 1].copy(), reqs[u[1]:u[1] + 1].copy()
+    ida, idb = navlib.N_FlowFieldID(a[0]), navlib.N_FlowFieldID(b[0])
+    ctx.pool_put(idb, np.full((64, 64), 3, np.uint8))          # a recognisable "old B"
+    upd = a.copy()
+    upd["flags"] |= navlib.REQ_INOUT
+    exp_upd, _ = ctx.N_FlowFieldUpdate(upd, inout=np.full((1, 64, 64), 3, np.uint8))
+    exp_b, _ = ctx.N_FlowFieldUpdate(b)
+    ids, got = ctx.pool_build(np.concatenate([upd, b]), ff_ids=[ida, idb], base_ids=[idb, 0])
+    assert np.array_equal(got[0], exp_upd[0])                   # built from the OLD B
+    assert np.array_equal(got[1], exp_b[0])
+    # re-putting the same mapping every tick does not grow anything (and stays correct)
+    for _ in range(50):
+        ctx.pool_map([0, 0], [int(a["chunk_r"][0]), int(b["chunk_r"][0])], [int(a["chunk_c"][0]), int(b["chunk_c"][0])], [ida, idb])
+    assert ctx.pool_contains(ida) and ctx.pool_contains(idb)
+
+
+def test_step_joins_a_prefetch_issued_on_another_stream(navlib, small):
+    """navhip_agent_prefetch_dev_ex(FRONT_INLINE) on stream A, the step on stream B: the step must wait for
+    the front (its event is recorded lazily)."""
+    import torch
+    ctx, reqs, cols, W, K, N = small["ctx"], small["reqs"], small["cols"], small["W"], small["K"], small["N"]
+    dirs, _ = ctx.N_FlowFieldUpdate(reqs)
+    slot = -np.ones((K, W * W), np.int32)
+    slot[cols["dest"], cols["chunk_r"] * W + cols["chunk_c"]] = np.arange(len(reqs))
+    a = dict(small["arrays"], flock_field_slot=slot, field_pool=dirs.reshape(len(dirs), 4096))
+    exp = ctx.agent_step(a)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in a.items() if v is not None}
+    world, keep = navlib.make_world(W, W, t, hz=20)
+    vel = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+    pos = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+    st = torch.zeros(N, dtype=torch.uint8, device=dev)
+    out = navlib.StepOut()
+    out.vel_xz, out.new_pos_xz, out.status = vel.data_ptr(), pos.data_ptr(), st.data_ptr()
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        vel.zero_()
+        torch.cuda.synchronize()
+        ctx.agent_prefetch_dev(world, stream=sa.cuda_stream, flags=navlib.PREFETCH_FRONT_INLINE)
+        ctx.agent_step_dev(world, out, stream=sb.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(vel.cpu().numpy(), exp["vel_xz"])
+        assert np.array_equal(st.cpu().numpy(), exp["status"])
+
+
 def test_async_step_equals_the_blocking_one(navlib, small):
     ctx, reqs, cols, W, K = small["ctx"], small["reqs"], small["cols"], small["W"], small["K"]
     ctx.pool_create(len(reqs), K)
@@ -130,9 +243,11 @@ def test_async_step_equals_the_blocking_one(navlib, small):
     assert np.array_equal(o1["vel_xz"][:N // 3], exp["vel_xz"][:N // 3]) and not o1["vel_xz"][N // 3:].any()
 
 
-def test_static_epoch_skips_the_attribute_tables_only(navlib, small):
-    """navhip_world.static_epoch: a repeated nonzero epoch means "radius / max_speed / flags / flock
-    tables are those of my previous call" -- they are not transferred again, the per-tick state is."""
+def test_static_epoch_skips_the_flock_tables_only(navlib, small):
+    """navhip_world.static_epoch: a repeated nonzero epoch means "the flock tables are those of my
+    previous call" -- they are not transferred again.  Everything else travels every tick, including the
+    per-entity attributes the reference changes WITHOUT adding, removing or re-flocking an entity
+    (do_set_max_speed movement.c:3226, selection radius, ENTITY_FLAG_GARRISONED)."""
     ctx, reqs, cols, W, K = small["ctx"], small["reqs"], small["cols"], small["W"], small["K"]
     ctx.pool_create(len(reqs), K)
     ctx.pool_build(reqs[small["uniq"]], readback=False)
@@ -148,15 +263,44 @@ def test_static_epoch_skips_the_attribute_tables_only(navlib, small):
     exp2 = ctx.agent_step_async(moved)
     got2 = ctx.agent_step_async(dict(moved, static_epoch=5))
     assert all(np.array_equal(got2[k], exp2[k]) for k in keys) and not np.array_equal(exp2["vel_xz"], exp["vel_xz"])
-    # an attribute changes: the caller says so with a new epoch
-    fat = dict(moved, radius=(a["radius"] * 1.5).astype(np.float32))
-    exp3 = ctx.agent_step_async(fat)
-    got3 = ctx.agent_step_async(dict(fat, static_epoch=6))
+    # radius, max_speed and flags change under the SAME epoch (no entity added / removed / re-flocked)
+    N = small["N"]
+    slow = a["max_speed"].copy()
+    slow[::2] *= 0.25
+    flags = a["flags"].copy()
+    flags[1::7] |= navlib.ENTITY_FLAG_GARRISONED
+    changed = dict(moved, radius=(a["radius"] * 1.5).astype(np.float32), max_speed=slow, flags=flags)
+    exp3 = ctx.agent_step_async(changed)
+    got3 = ctx.agent_step_async(dict(changed, static_epoch=5))
     assert all(np.array_equal(got3[k], exp3[k]) for k in keys) and not np.array_equal(exp3["vel_xz"], exp2["vel_xz"])
+    # the flock tables do change: the caller says so with a new epoch
+    fl = a["flock"].copy()
+    fl[: N // 2] = (fl[: N // 2] + 1) % K
+    offs, members = navlib.flock_csr(fl, K)
+    reflocked = dict(changed, flock=fl, flock_offsets=offs, flock_members=members)
+    exp4 = ctx.agent_step_async(reflocked)
+    got4 = ctx.agent_step_async(dict(reflocked, static_epoch=6))
+    assert all(np.array_equal(got4[k], exp4[k]) for k in keys) and not np.array_equal(exp4["vel_xz"], exp3["vel_xz"])
     # another host-buffer entry point used the staging buffers in between: the epoch is forgotten
     ctx.agent_step(a)
-    got4 = ctx.agent_step_async(dict(fat, static_epoch=6))
-    assert all(np.array_equal(got4[k], exp3[k]) for k in keys)
+    got5 = ctx.agent_step_async(dict(reflocked, static_epoch=6))
+    assert all(np.array_equal(got5[k], exp4[k]) for k in keys)
+
+
+def test_empty_world_submit_poll_wait(navlib, small):
+    """A tick without entities is a valid tick: submit, poll and wait all return NAVHIP_OK."""
+    import ctypes as C
+    ctx = small["ctx"]
+    L = navlib.lib()
+    w = navlib.World()
+    w.n_ents, w.n_flocks, w.hz = 0, 0, 20
+    out = navlib.StepOut()
+    dummy = np.zeros(2, np.float32)
+    out.vel_xz = dummy.ctypes.data
+    for fn in (L.navhip_agent_step_poll, L.navhip_agent_step_wait):
+        assert L.navhip_agent_step_submit(ctx._h, C.byref(w), C.byref(out)) == 0
+        assert fn(ctx._h) == 0
+        assert fn(ctx._h) == -1                     # nothing in flight any more: NAVHIP_ERR_INVALID
 
 
 def test_work_counters(navlib, small):
