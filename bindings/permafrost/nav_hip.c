@@ -1,12 +1,12 @@
-/* oracle/ref/nav_hip.c -- the reference-side binding of libnavhip.so, made real.
+/* bindings/permafrost/nav_hip.c -- the nav.c half of the reference-side binding of libnavhip.so.
  *
  * This is the file INTEGRATION.md tells a maintainer of permafrost-engine to add as
  * src/navigation/nav_hip.c (appended to nav.c's translation unit, because the batched sampler needs
- * nav.c's static n_request_path and n_interpolated_flow_dir).  Here it is compiled against the
- * reference's own headers and linked with its own objects inside the test harness
- * (oracle/ref/ref_nav.c #includes it right after nav.c), so that the reference's planner, field
- * cache and sampler drive the HIP library through include/navhip.h -- TEST INFRASTRUCTURE, like
- * everything under oracle/.
+ * nav.c's static n_request_path and n_interpolated_flow_dir, and the asynchronous batch its static
+ * s_field_work).  It is written against the reference's own headers; in this repository it is compiled
+ * and executed inside the test harness (oracle/ref/ref_nav.c #includes it right after nav.c), where the
+ * reference's planner, field cache, sampler and async field batch drive the HIP library through
+ * include/navhip.h.  Companion files: field_hip.c (appended to field.c), move_hip.c (to movement.c).
  *
  * What it binds
  *   N_HIP_FlowFieldUpdate                    same signature as N_FlowFieldUpdate (field.h:146): one
@@ -26,6 +26,22 @@
  *                                            (C) repairs (blocked tile / orphaned island), one per
  *                                                field and round,
  *                                            then n_interpolated_flow_dir on the now complete cache.
+ *   N_HIP_BuildAsyncFields                   the asynchronous field batch (N_PrepareAsyncWork /
+ *                                            N_RequestAsync{EnemySeek,Surround,GroupArrival}Field /
+ *                                            field_task / N_AwaitAsyncFields, nav.c:3767-3969,2049): the
+ *                                            request functions stay as they are but create no fiber
+ *                                            (N_HIP_FieldTaskCreate instead of Sched_Create); before
+ *                                            N_AwaitAsyncFields joins and N_FC_PutFlowField's the results,
+ *                                            this builds all <= 256 jobs in ONE navhip_build_region_fields
+ *                                            call -- the game-side frontier extraction of every job on the
+ *                                            host (field_hip.c), the grid work on the device
+ *   N_HIP_LOSFieldCreate                     same signature as N_LOSFieldCreate (field.h:195): the call
+ *                                            sites nav.c:1843,2035; immediate, or recorded in deferred mode
+ *                                            and built per chain level (a LOS field needs its predecessor's)
+ *   N_HIP_BlockersRecord / N_HIP_BlockersFlush   N_BlockersIncref / N_BlockersDecref (nav.c:4663,4685) keep
+ *                                            updating the host planes (the planner reads them); the same
+ *                                            circles, recorded, update the device planes in one
+ *                                            navhip_blockers_circles call per tick -- no plane re-upload
  * Backend 0 runs the same phases with the reference's own CPU builders -- the control of the tests.
  */
 #include <navhip.h>
@@ -286,7 +302,10 @@ void N_HIP_FlowFieldUpdateIslandToNearest(uint16_t local_iid, const struct nav_p
 
 /* ---- deferred mode --------------------------------------------------------------------------- */
 
-void N_HIP_BeginBatch(void) { s_hip.deferred = true; s_hip.npend = 0; }
+static bool n_hip_flush_los(void);     /* the LOS fields recorded in the same batch (below) */
+static void n_hip_los_reset(void);
+
+void N_HIP_BeginBatch(void) { s_hip.deferred = true; s_hip.npend = 0; n_hip_los_reset(); }
 
 /* Build every recorded field -- one navhip_build_fields call per round (a build that updates another
  * pending build in place waits for it) -- and put the results into the field cache. */
@@ -295,7 +314,7 @@ bool N_HIP_Flush(void)
     s_hip.deferred = false;
     const int n = s_hip.npend;
     if(n == 0)
-        return true;
+        return n_hip_flush_los();
     bool ok = true;
     int *round = malloc(sizeof(int) * n);
     int maxr = 0;
@@ -358,7 +377,7 @@ bool N_HIP_Flush(void)
     }
     free(round); free(reqs); free(dirs); free(who);
     s_hip.npend = 0;
-    return ok;
+    return n_hip_flush_los() && ok;
 }
 
 /* ---- N_DesiredPointSeekVelocity for n agents (nav.c:3468-3559) ------------------------------- */
@@ -461,3 +480,291 @@ void N_HIP_DesiredPointSeekVelocities(struct nav_private *priv, vec3_t map_pos, 
     }
     free(st);
 }
+
+/* ---- the asynchronous field batch (nav.c:3767-3969, field_task :2049) ------------------------ */
+
+bool N_HIP_RegionRequest(struct coord chunk_coord, const struct nav_private *priv, enum nav_layer layer,
+                         struct field_target target, struct nav_unit_query_ctx *ctx,
+                         navhip_region_req *out_req, int16_t *out_seeds, size_t max_seeds, size_t *out_nseeds);   /* field_hip.c */
+
+static struct{
+    long n_jobs, n_batches, n_cpu_jobs;
+}s_hip_async;
+
+void N_HIP_AsyncStats(long out[3]) { out[0] = s_hip_async.n_jobs; out[1] = s_hip_async.n_batches; out[2] = s_hip_async.n_cpu_jobs; }
+
+/* What N_RequestAsync*Field call instead of Sched_Create(1, field_task, arg, ...) (nav.c:3824,3878,3907):
+ * with the device in charge no fiber is created -- the job stays in s_field_work.in[] and its future is
+ * complete at once, so that field_join_work (:2062) has nothing to wait for; N_HIP_BuildAsyncFields fills
+ * s_field_work.out[] before N_AwaitAsyncFields puts the results into the cache.  Without the device:
+ * the reference's own Sched_Create. */
+uint32_t N_HIP_FieldTaskCreate(int prio, task_func_t code, void *arg, const char *name,
+                               struct future *result, int flags)
+{
+    if(s_hip.backend == N_HIP_BACKEND_HIP && s_hip.ctx) {
+        SDL_AtomicSet(&result->status, FUTURE_COMPLETE);
+        return 1;                              /* any tid but NULL_TID: the job counts (nav.c:3826) */
+    }
+    return (Sched_Create)(prio, code, arg, name, result, flags);
+}
+
+/* Called by the movement tick between the last N_RequestAsync*Field and N_AwaitAsyncFields
+ * (compute_async_fields, movement.c:4149-4164): every job of the batch in ONE device call. */
+bool N_HIP_BuildAsyncFields(void)
+{
+    const int n = (int)s_field_work.nwork;
+    if(n == 0 || !(s_hip.backend == N_HIP_BACKEND_HIP && s_hip.ctx))
+        return true;                           /* the fibers built (or are building) them */
+    const size_t max_seeds_per = (size_t)(2 * FIELD_RES_R) * (2 * FIELD_RES_C);
+    navhip_region_req *reqs = malloc(sizeof(navhip_region_req) * n);
+    uint8_t *dirs = calloc((size_t)n, FIELD_RES_R * FIELD_RES_C);       /* N_FlowFieldInit: FD_NONE == 0 */
+    int16_t *seeds = NULL;
+    size_t nseeds = 0, capseeds = 0;
+    int *who = malloc(sizeof(int) * n);
+    int16_t *tmp = malloc(sizeof(int16_t) * 2 * max_seeds_per);
+    int m = 0;
+    for(int i = 0; i < n; i++) {
+        struct field_work_in *in = &vec_AT(&s_field_work.in, i);
+        struct field_work_out *out = &vec_AT(&s_field_work.out, i);
+        size_t k = 0;
+        if(!N_HIP_RegionRequest(in->chunk, in->priv, in->layer, in->target, in->priv->unit_query_ctx,
+                                &reqs[m], tmp, max_seeds_per, &k)) {
+            /* not a region target the device covers: what field_task does (nav.c:2055-2057) */
+            N_FlowFieldInit(in->chunk, &out->field);
+            (N_FlowFieldUpdate)(in->chunk, in->priv, in->faction_id, in->layer, in->target,
+                in->priv->unit_query_ctx, &out->field);
+            s_hip_async.n_cpu_jobs++;
+            continue;
+        }
+        if(nseeds + k > capseeds) {
+            capseeds = (nseeds + k) * 2 + 1024;
+            seeds = realloc(seeds, sizeof(int16_t) * 2 * capseeds);
+        }
+        memcpy(seeds + 2 * nseeds, tmp, sizeof(int16_t) * 2 * k);
+        reqs[m].seed_begin = (uint32_t)nseeds;
+        nseeds += k;
+        who[m++] = i;
+    }
+    bool ok = true;
+    if(m > 0) {
+        ok = navhip_build_region_fields(s_hip.ctx, reqs, m, seeds, nseeds, NULL, 0, dirs,
+                                        FIELD_RES_R * FIELD_RES_C) == NAVHIP_OK;
+        s_hip_async.n_batches++;
+    }
+    for(int k = 0; k < m; k++) {
+        struct field_work_in *in = &vec_AT(&s_field_work.in, who[k]);
+        struct field_work_out *out = &vec_AT(&s_field_work.out, who[k]);
+        N_FlowFieldInit(in->chunk, &out->field);
+        if(ok) {
+            n_hip_dirs_to_ff(dirs + (size_t)k * FIELD_RES_R * FIELD_RES_C, &out->field);
+            out->field.target = in->target;    /* field_update_enemies / _entity / _zone record it (:1589,:1660,:1872) */
+            s_hip_async.n_jobs++;
+        }else{
+            (N_FlowFieldUpdate)(in->chunk, in->priv, in->faction_id, in->layer, in->target,
+                in->priv->unit_query_ctx, &out->field);
+            s_hip_async.n_cpu_jobs++;
+        }
+    }
+    free(reqs); free(dirs); free(seeds); free(who); free(tmp);
+    return ok;
+}
+
+/* ---- line-of-sight fields (N_LOSFieldCreate, field.c:2085; call sites nav.c:1843,2035) ------- */
+
+static struct{
+    struct n_hip_los_pending{
+        dest_id_t        id;
+        struct coord     chunk;
+        struct tile_desc target;
+        struct nav_private *priv;
+        vec3_t           map_pos;
+        int              base;                     /* pending index of prev_los, -1: given / none */
+        bool             has_prev;
+        struct coord     prev_chunk;
+        uint8_t          prev[FIELD_RES_R * FIELD_RES_C];
+        uint8_t          out[FIELD_RES_R * FIELD_RES_C];
+    }          *pend;
+    int         npend, cappend;
+    long        n_builds, n_batches;
+}s_hip_los;
+
+void N_HIP_LOSStats(long out[2]) { out[0] = s_hip_los.n_builds; out[1] = s_hip_los.n_batches; }
+static void n_hip_los_reset(void) { s_hip_los.npend = 0; }
+
+static void n_hip_los_to_bytes(const struct LOS_field *lf, uint8_t *out)
+{
+    for(int r = 0; r < FIELD_RES_R; r++)
+    for(int c = 0; c < FIELD_RES_C; c++)
+        out[r * FIELD_RES_C + c] = (uint8_t)(lf->field[r][c].visible | (lf->field[r][c].wavefront_blocked << 1));
+}
+
+static void n_hip_bytes_to_los(const uint8_t *in, struct coord chunk, struct LOS_field *lf)
+{
+    lf->chunk = chunk;                             /* field.c:2091 */
+    for(int r = 0; r < FIELD_RES_R; r++)
+    for(int c = 0; c < FIELD_RES_C; c++) {
+        lf->field[r][c].visible = in[r * FIELD_RES_C + c] & 1;
+        lf->field[r][c].wavefront_blocked = (in[r * FIELD_RES_C + c] >> 1) & 1;
+    }
+}
+
+static void n_hip_make_los_req(const struct n_hip_los_pending *p, navhip_los_req *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->layer = N_DestLayer(p->id);
+    r->faction_id = N_DestFactionID(p->id);
+    r->enemies = (r->faction_id == FACTION_ID_NONE) ? 0 : G_GetEnemyFactions(r->faction_id);   /* enemy_faction_from, field.c:151 */
+    r->chunk_r = p->chunk.r; r->chunk_c = p->chunk.c;
+    r->target_chunk_r = p->target.chunk_r; r->target_chunk_c = p->target.chunk_c;
+    r->target_tile_r = p->target.tile_r;   r->target_tile_c = p->target.tile_c;
+    if(p->has_prev) {
+        r->prev_dr = (int8_t)(p->prev_chunk.r - p->chunk.r);
+        r->prev_dc = (int8_t)(p->prev_chunk.c - p->chunk.c);
+    }
+}
+
+void N_HIP_LOSFieldCreate(dest_id_t id, struct coord chunk_coord, struct tile_desc target,
+                          const struct nav_private *priv, vec3_t map_pos, struct nav_unit_query_ctx *ctx,
+                          struct LOS_field *out_los, const struct LOS_field *prev_los)
+{
+    if(!(s_hip.backend == N_HIP_BACKEND_HIP && s_hip.ctx)) {
+        (N_LOSFieldCreate)(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los);
+        return;
+    }
+    struct n_hip_los_pending p;
+    memset(&p, 0, offsetof(struct n_hip_los_pending, prev));
+    p.id = id; p.chunk = chunk_coord; p.target = target; p.priv = (struct nav_private*)priv; p.map_pos = map_pos;
+    p.base = -1;
+    p.has_prev = prev_los != NULL;
+    if(prev_los) {
+        p.prev_chunk = prev_los->chunk;
+        /* deferred mode: is the predecessor a field of this batch that has not been built yet? */
+        if(s_hip.deferred) {
+            for(int k = s_hip_los.npend - 1; k >= 0; k--) {
+                const struct n_hip_los_pending *q = &s_hip_los.pend[k];
+                if(q->id == id && q->chunk.r == prev_los->chunk.r && q->chunk.c == prev_los->chunk.c) { p.base = k; break; }
+            }
+        }
+    }
+    if(s_hip.deferred) {
+        if(s_hip_los.npend == s_hip_los.cappend) {
+            s_hip_los.cappend = s_hip_los.cappend ? s_hip_los.cappend * 2 : 64;
+            s_hip_los.pend = realloc(s_hip_los.pend, sizeof(*s_hip_los.pend) * s_hip_los.cappend);
+        }
+        struct n_hip_los_pending *slot = &s_hip_los.pend[s_hip_los.npend++];
+        memcpy(slot, &p, offsetof(struct n_hip_los_pending, prev));
+        if(prev_los && p.base < 0)
+            n_hip_los_to_bytes(prev_los, slot->prev);
+        /* the placeholder the planner puts into the cache: the right chunk, nothing visible yet */
+        memset(out_los, 0, sizeof(*out_los));
+        out_los->chunk = chunk_coord;
+        return;
+    }
+    navhip_los_req req;
+    n_hip_make_los_req(&p, &req);
+    static uint8_t prev_b[FIELD_RES_R * FIELD_RES_C], out_b[FIELD_RES_R * FIELD_RES_C];
+    if(prev_los)
+        n_hip_los_to_bytes(prev_los, prev_b);
+    if(navhip_build_los(s_hip.ctx, &req, 1, prev_los ? prev_b : NULL, out_b, map_pos.x, map_pos.z) != NAVHIP_OK) {
+        (N_LOSFieldCreate)(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los);
+        return;
+    }
+    s_hip_los.n_builds++; s_hip_los.n_batches++;
+    n_hip_bytes_to_los(out_b, chunk_coord, out_los);
+}
+
+/* deferred LOS fields: one navhip_build_los call per chain level, results into the cache */
+static bool n_hip_flush_los(void)
+{
+    const int n = s_hip_los.npend;
+    if(n == 0)
+        return true;
+    bool ok = true;
+    int *level = malloc(sizeof(int) * n), maxl = 0;
+    for(int i = 0; i < n; i++) {
+        level[i] = s_hip_los.pend[i].base < 0 ? 0 : level[s_hip_los.pend[i].base] + 1;
+        if(level[i] > maxl) maxl = level[i];
+    }
+    navhip_los_req *reqs = malloc(sizeof(navhip_los_req) * n);
+    uint8_t *prev = malloc((size_t)n * FIELD_RES_R * FIELD_RES_C), *out = malloc((size_t)n * FIELD_RES_R * FIELD_RES_C);
+    int *who = malloc(sizeof(int) * n);
+    for(int l = 0; l <= maxl; l++) {
+        int m = 0;
+        for(int i = 0; i < n; i++) {
+            if(level[i] != l) continue;
+            struct n_hip_los_pending *p = &s_hip_los.pend[i];
+            n_hip_make_los_req(p, &reqs[m]);
+            memcpy(prev + (size_t)m * sizeof(p->prev), p->base >= 0 ? s_hip_los.pend[p->base].out : p->prev, sizeof(p->prev));
+            who[m++] = i;
+        }
+        if(m == 0) continue;
+        const vec3_t mp = s_hip_los.pend[who[0]].map_pos;
+        if(navhip_build_los(s_hip.ctx, reqs, m, prev, out, mp.x, mp.z) == NAVHIP_OK) {
+            s_hip_los.n_builds += m; s_hip_los.n_batches++;
+            for(int k = 0; k < m; k++)
+                memcpy(s_hip_los.pend[who[k]].out, out + (size_t)k * sizeof(s_hip_los.pend[0].out), sizeof(s_hip_los.pend[0].out));
+        }else{
+            ok = false;
+            for(int k = 0; k < m; k++) {               /* the CPU builder, on the predecessor's bytes */
+                struct n_hip_los_pending *p = &s_hip_los.pend[who[k]];
+                struct LOS_field lf, pl;
+                if(p->has_prev)
+                    n_hip_bytes_to_los(p->base >= 0 ? s_hip_los.pend[p->base].out : p->prev, p->prev_chunk, &pl);
+                (N_LOSFieldCreate)(p->id, p->chunk, p->target, p->priv, p->map_pos, p->priv->unit_query_ctx,
+                    &lf, p->has_prev ? &pl : NULL);
+                n_hip_los_to_bytes(&lf, p->out);
+            }
+        }
+    }
+    for(int i = 0; i < n; i++) {
+        struct n_hip_los_pending *p = &s_hip_los.pend[i];
+        struct LOS_field lf;
+        n_hip_bytes_to_los(p->out, p->chunk, &lf);
+        N_FC_PutLOSField(p->priv->fieldcache, p->id, p->chunk, &lf);
+    }
+    free(level); free(reqs); free(prev); free(out); free(who);
+    s_hip_los.npend = 0;
+    return ok;
+}
+
+/* ---- dynamic obstacles (N_BlockersIncref / N_BlockersDecref, nav.c:4663,4685) ----------------- */
+
+static struct{
+    navhip_circle *circ;
+    int            n, cap;
+    vec3_t         map_pos;
+    long           n_flushed, n_batches;
+}s_hip_blk;
+
+/* One more statement in N_BlockersIncref (ref_delta = +1) and N_BlockersDecref (-1): the host planes are
+ * updated as before (the planner, the portal states and N_Update read them); the device copy follows
+ * from the same call arguments at the next flush. */
+void N_HIP_BlockersRecord(vec2_t xz_pos, float range, int faction_id, uint32_t flags, vec3_t map_pos, int ref_delta)
+{
+    if(!s_hip.ctx)
+        return;
+    if(s_hip_blk.n == s_hip_blk.cap) {
+        s_hip_blk.cap = s_hip_blk.cap ? s_hip_blk.cap * 2 : 256;
+        s_hip_blk.circ = realloc(s_hip_blk.circ, sizeof(navhip_circle) * s_hip_blk.cap);
+    }
+    s_hip_blk.circ[s_hip_blk.n++] = (navhip_circle){
+        .x = xz_pos.x, .z = xz_pos.z, .radius = range, .faction_id = faction_id,
+        .flags = (flags & ENTITY_FLAG_AIR) ? NAVHIP_ENTITY_FLAG_AIR : 0, .delta = ref_delta};
+    s_hip_blk.map_pos = map_pos;
+}
+
+/* Once per tick, after N_Update (nav.c:2119) and before the tick's field builds: the recorded circles in
+ * one device call.  The device rebuilds passability, flags the chunks whose passability changed
+ * (navhip_changed_chunks: a subset of the chunks N_Update invalidates, nav.c:2143-2154) and relabels
+ * their local islands.  false: the caller re-uploads the planes (N_HIP_SyncLayer). */
+bool N_HIP_BlockersFlush(void)
+{
+    if(!s_hip.ctx || s_hip_blk.n == 0)
+        return true;
+    const int rc = navhip_blockers_circles(s_hip.ctx, s_hip_blk.circ, s_hip_blk.n, s_hip_blk.map_pos.x, s_hip_blk.map_pos.z);
+    s_hip_blk.n_flushed += s_hip_blk.n; s_hip_blk.n_batches++;
+    s_hip_blk.n = 0;
+    return rc == NAVHIP_OK;
+}
+
+void N_HIP_BlockersStats(long out[2]) { out[0] = s_hip_blk.n_flushed; out[1] = s_hip_blk.n_batches; }

@@ -38,6 +38,11 @@ class Portal(C.Structure):
         "conn_r0", "conn_c0", "conn_r1", "conn_c1", "component_id")]
 
 
+ASYNC_REQ_DTYPE = np.dtype([("kind", np.int32), ("layer", np.int32), ("faction_id", np.int32), ("x", np.float32),
+                            ("z", np.float32), ("ent", np.uint32), ("radius", np.int32)])
+ASYNC_ENEMY_SEEK, ASYNC_SURROUND, ASYNC_GROUP_ARRIVAL = 0, 1, 2
+
+
 class MoveWorld(C.Structure):
     _fields_ = [
         ("n", C.c_int), ("pos_xz", C.c_void_p), ("vel_xz", C.c_void_p), ("radius", C.c_void_p),
@@ -77,6 +82,14 @@ def lib():
         L.pfref_flow_field_id.argtypes = [C.c_void_p, C.c_void_p]
         L.pfref_region_field_id.restype = C.c_uint64
         L.pfref_region_field_id.argtypes = [C.c_int] * 4 + [C.c_uint32, C.c_int, C.c_int]
+        L.pfref_game_load.argtypes = [C.c_float] * 4 + [C.c_int] + [C.c_void_p] * 4
+        L.pfref_async_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfref_cached_field_by_id.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.pfref_hip_async_stats.argtypes = [C.c_void_p]
+        L.pfref_hip_los_stats.argtypes = [C.c_void_p]
+        L.pfref_hip_blockers_stats.argtypes = [C.c_void_p]
+        L.pfref_hip_ctx.restype = C.c_void_p
+        L.pfref_nav_dirty_chunks.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.pfref_field_nearest_pathable.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         L.pfref_field_island_to_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.pfref_cell_arrival_field.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_int, C.c_void_p]
@@ -337,6 +350,66 @@ class RefNav:
                     ff = self.cached_field(did, cr, cc)
                     if ff is not None:
                         out[(did, cr, cc)] = ff.copy()
+        return out
+
+    # -- the asynchronous field batch / LOS / blockers seams of the binding ---------------
+    def game_load(self, pos_xz, radius, faction, flags):
+        """Explicit game state for the reference's enemy / entity frontier extraction (uid == index)."""
+        p = np.ascontiguousarray(pos_xz, np.float32).reshape(-1, 2)
+        r = np.ascontiguousarray(radius, np.float32)
+        f = np.ascontiguousarray(faction, np.int32)
+        g = np.ascontiguousarray(flags, np.uint32)
+        hx, hz = self.w * 128.0, self.h * 128.0
+        lib().pfref_game_load(-hx, hx, -hz, hz, len(p), _p(p), _p(r), _p(f), _p(g))
+
+    @staticmethod
+    def game_unload():
+        lib().pfref_game_unload()
+
+    def async_batch(self, reqs):
+        """compute_async_fields of one tick (N_PrepareAsyncWork, the N_RequestAsync*Field calls,
+        N_AwaitAsyncFields): returns {ff_id: dirs [64,64]} of the jobs the batch took."""
+        reqs = np.ascontiguousarray(reqs, ASYNC_REQ_DTYPE)
+        ids = np.zeros(256, np.uint64)
+        n = lib().pfref_async_batch(self._h, len(reqs), _p(reqs), _p(ids), len(ids))
+        out = {}
+        for i in ids[:n]:
+            d = np.zeros((64, 64), np.uint8)
+            assert lib().pfref_cached_field_by_id(self._h, int(i), _p(d)), hex(int(i))
+            out[int(i)] = d
+        return out
+
+    @staticmethod
+    def hip_seam_stats():
+        a, l, b = (C.c_long * 3)(), (C.c_long * 2)(), (C.c_long * 2)()
+        lib().pfref_hip_async_stats(a)
+        lib().pfref_hip_los_stats(l)
+        lib().pfref_hip_blockers_stats(b)
+        return {"async_device_jobs": a[0], "async_batches": a[1], "async_cpu_jobs": a[2],
+                "los_device_fields": l[0], "los_batches": l[1], "blocker_circles": b[0], "blocker_batches": b[1]}
+
+    @staticmethod
+    def hip_blockers_flush():
+        return bool(lib().pfref_hip_blockers_flush())
+
+    @staticmethod
+    def hip_ctx():
+        """The binding's navhip_ctx* (so that a test can read the device planes through libnavhip)."""
+        return lib().pfref_hip_ctx()
+
+    def dirty_chunks(self, layer=0):
+        out = np.zeros((self.h, self.w), np.uint8)
+        lib().pfref_nav_dirty_chunks(self._h, layer, _p(out))
+        return out
+
+    def los_dump(self, dest_ids):
+        out = {}
+        for did in sorted(set(int(x) for x in dest_ids)):
+            for cr in range(self.h):
+                for cc in range(self.w):
+                    lf = self.cached_los(did, cr, cc)
+                    if lf is not None:
+                        out[(did, cr, cc)] = lf.copy()
         return out
 
     # -- planner ----------------------------------------------------------

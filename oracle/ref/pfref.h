@@ -167,6 +167,33 @@ void pfref_cache_clear(pfref_nav *nav);
 /* move_velocity_work through the WORK_TYPE_HIP arm; 0 = the arm declined (no device) */
 int  pfref_move_velocity_hip(const float *vdes, int begin, int end, float *out_vel);
 
+/* --- the asynchronous field batch / LOS / blockers seams of the binding --------------------------- */
+
+/* explicit game state for the reference's enemy / entity frontier extraction (field.c:1209-1370):
+ * every entity uid == index; faction 0..14; flags ENTITY_FLAG_* */
+void pfref_game_load(float xmin, float xmax, float zmin, float zmax, int n, const float *pos_xz,
+                     const float *radius, const int32_t *faction, const uint32_t *flags);
+void pfref_game_unload(void);
+
+typedef struct pfref_async_req {
+    int32_t  kind;          /* 0 enemy seek, 1 surround entity, 2 group arrival (zone) */
+    int32_t  layer;
+    int32_t  faction_id;
+    float    x, z;          /* curr_pos (0, 1) / centre_pos (2) */
+    uint32_t ent;           /* 1: the surrounded entity */
+    int32_t  radius;        /* 2: zone radius in tiles */
+} pfref_async_req;
+
+/* compute_async_fields of one tick (movement.c:4149-4164); returns the number of jobs */
+int  pfref_async_batch(pfref_nav *nav, int n, const pfref_async_req *reqs, uint64_t *out_ids, int max_ids);
+int  pfref_cached_field_by_id(pfref_nav *nav, uint64_t ffid, uint8_t *out_dirs);
+void pfref_hip_async_stats(long out[3]);      /* device jobs, device batches, jobs left to the CPU builders */
+void pfref_hip_los_stats(long out[2]);        /* device LOS fields, device batches */
+void pfref_hip_blockers_stats(long out[2]);   /* circles flushed, device batches */
+int  pfref_hip_blockers_flush(void);          /* N_HIP_BlockersFlush */
+void *pfref_hip_ctx(void);                    /* the binding's navhip_ctx* (tests read the device planes) */
+void pfref_nav_dirty_chunks(pfref_nav *nav, int layer, uint8_t *flags);
+
 /* --- ClearPath ---------------------------------------------------------- */
 
 /* G_ClearPath_NewVelocity (clearpath.c:694).  ent/neighbours are

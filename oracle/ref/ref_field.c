@@ -9,6 +9,9 @@
  */
 #include "navigation/field.c"
 
+/* the field.c half of the reference-side binding (game-side frontier extraction of the region builders) */
+#include "field_hip.c"
+
 #include "pfref.h"
 #include "ref_internal.h"
 

@@ -13,10 +13,17 @@
 #define N_FlowFieldUpdate pfref_traced_N_FlowFieldUpdate
 #define N_FlowFieldUpdateToNearestPathable pfref_hook_NearestPathable
 #define N_FlowFieldUpdateIslandToNearest pfref_hook_IslandToNearest
+/* the two other call-site changes of INTEGRATION.md, made by renaming instead of editing nav.c:
+ * N_LOSFieldCreate (nav.c:1843,2035) and the Sched_Create(field_task) of the three N_RequestAsync*Field
+ * functions (nav.c:3824,3878,3907) */
+#define N_LOSFieldCreate pfref_hook_N_LOSFieldCreate
+#define Sched_Create pfref_hook_Sched_Create
 #include "navigation/nav.c"
 #undef N_FlowFieldUpdate
 #undef N_FlowFieldUpdateToNearestPathable
 #undef N_FlowFieldUpdateIslandToNearest
+#undef N_LOSFieldCreate
+#undef Sched_Create
 
 #include "pfref.h"
 #include "ref_internal.h"
@@ -32,10 +39,30 @@ void N_FlowFieldUpdateToNearestPathable(const struct nav_private *priv, enum nav
                                         struct coord chunk, struct coord start, int faction_id,
                                         struct nav_unit_query_ctx *ctx, struct flow_field *inout_flow);
 
+void N_LOSFieldCreate(dest_id_t id, struct coord chunk_coord, struct tile_desc target,
+                      const struct nav_private *priv, vec3_t map_pos, struct nav_unit_query_ctx *ctx,
+                      struct LOS_field *out_los, const struct LOS_field *prev_los);
+uint32_t Sched_Create(int prio, task_func_t code, void *arg, const char *name, struct future *result, int flags);
+
 /* The reference-side binding of libnavhip.so (what a maintainer appends to nav.c): every field build
  * nav.c asks for goes through it while s_use_binding is set. */
 #include "nav_hip.c"
 static bool s_use_binding;
+
+void pfref_hook_N_LOSFieldCreate(dest_id_t id, struct coord chunk_coord, struct tile_desc target,
+                                 const struct nav_private *priv, vec3_t map_pos, struct nav_unit_query_ctx *ctx,
+                                 struct LOS_field *out_los, const struct LOS_field *prev_los)
+{
+    if(s_use_binding) N_HIP_LOSFieldCreate(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los);
+    else              N_LOSFieldCreate(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los);
+}
+
+uint32_t pfref_hook_Sched_Create(int prio, task_func_t code, void *arg, const char *name,
+                                 struct future *result, int flags)
+{
+    if(s_use_binding) return N_HIP_FieldTaskCreate(prio, code, arg, name, result, flags);
+    return Sched_Create(prio, code, arg, name, result, flags);
+}
 
 void pfref_hook_NearestPathable(const struct nav_private *priv, enum nav_layer layer, struct coord chunk,
                                 struct coord start, int faction_id, struct nav_unit_query_ctx *ctx,
@@ -187,6 +214,9 @@ void pfref_nav_blockers_circle(pfref_nav *nav, float x, float z, float range, in
     struct nav_private *priv = &nav->priv;
     vec2_t xz = (vec2_t){x, z};
     const unsigned ground = 0xfu, water = 0xf0u;
+    /* (the statement INTEGRATION.md adds to N_BlockersIncref / N_BlockersDecref themselves) */
+    if(s_use_binding)
+        N_HIP_BlockersRecord(xz, range, faction_id, flags, nav->map_pos, incref ? +1 : -1);
     if(!(flags & ENTITY_FLAG_AIR)
     && (nav->layer_mask & (ground | water)) == (ground | water)) {
         if(incref) N_BlockersIncref(xz, range, faction_id, flags, nav->map_pos, priv);
@@ -401,3 +431,68 @@ uint32_t pfref_dest_id(pfref_nav *nav, int layer, int faction_id, float dst_x, f
 }
 
 void pfref_cache_clear(pfref_nav *nav) { N_FC_ClearAll(nav->priv.fieldcache); }
+
+
+/* ------------------------------------------------------------------------ */
+/* the asynchronous field batch, LOS and blocker seams of the binding        */
+/* ------------------------------------------------------------------------ */
+
+/* One movement tick's compute_async_fields (movement.c:4149-4164): N_PrepareAsyncWork, the requests
+ * (kind 0 = N_RequestAsyncEnemySeekField, 1 = N_RequestAsyncSurroundField, 2 =
+ * N_RequestAsyncGroupArrivalField), [the binding's one device call], N_AwaitAsyncFields.  The ids of the
+ * jobs the batch accepted are returned (<= max_ids); the fields are in the reference's field cache. */
+int pfref_async_batch(pfref_nav *nav, int n, const pfref_async_req *reqs, uint64_t *out_ids, int max_ids)
+{
+    struct nav_private *priv = &nav->priv;
+    N_PrepareAsyncWork();
+    for(int i = 0; i < n; i++) {
+        const pfref_async_req *r = &reqs[i];
+        vec2_t xz = (vec2_t){r->x, r->z};
+        switch(r->kind) {
+        case 0: N_RequestAsyncEnemySeekField(xz, priv, r->layer, nav->map_pos, r->faction_id); break;
+        case 1: N_RequestAsyncSurroundField(xz, priv, r->layer, nav->map_pos, r->ent, r->faction_id); break;
+        case 2: N_RequestAsyncGroupArrivalField(xz, priv, r->layer, nav->map_pos, (uint16_t)r->radius); break;
+        }
+    }
+    int njobs = (int)s_field_work.nwork;
+    for(int i = 0; i < njobs && i < max_ids; i++)
+        out_ids[i] = vec_AT(&s_field_work.in, i).id;
+    if(s_use_binding)
+        N_HIP_BuildAsyncFields();                  /* (the statement added to compute_async_fields) */
+    N_AwaitAsyncFields();
+    vec_in_destroy(&s_field_work.in);
+    vec_out_destroy(&s_field_work.out);
+    return njobs;
+}
+
+int pfref_cached_field_by_id(pfref_nav *nav, uint64_t ffid, uint8_t *out_dirs)
+{
+    if(!N_FC_ContainsFlowField(nav->priv.fieldcache, ffid))
+        return 0;
+    const struct flow_field *ff = N_FC_FlowFieldAt(nav->priv.fieldcache, ffid);
+    if(!ff)
+        return 0;
+    pfref_ff_to_dirs(ff, out_dirs);
+    return 1;
+}
+
+void pfref_hip_async_stats(long out[3])  { N_HIP_AsyncStats(out); }
+void pfref_hip_los_stats(long out[2])    { N_HIP_LOSStats(out); }
+void pfref_hip_blockers_stats(long out[2]) { N_HIP_BlockersStats(out); }
+int  pfref_hip_blockers_flush(void)      { return N_HIP_BlockersFlush() ? 1 : 0; }
+void *pfref_hip_ctx(void)                { return N_HIP_Ctx(); }
+
+/* the chunks N_Update (nav.c:2119) would invalidate for `layer`: the dirty set n_update_blockers leaves
+ * (nav.c:1033-1046); flags[h*w] */
+void pfref_nav_dirty_chunks(pfref_nav *nav, int layer, uint8_t *flags)
+{
+    struct nav_private *priv = &nav->priv;
+    memset(flags, 0, priv->width * priv->height);
+    khash_t(coord) *set = priv->dirty_chunks[layer];
+    for(int i = kh_begin(set); i != kh_end(set); i++) {
+        if(!kh_exist(set, i))
+            continue;
+        uint32_t key = kh_key(set, i);                    /* nav.c:1008-1009 */
+        flags[(key >> 16) * priv->width + (key & 0xffff)] = 1;
+    }
+}

@@ -57,6 +57,22 @@ void  Mem_PopScope(void)                                           { }
 void Perf_Push(const char *name)  { (void)name; }
 void Perf_Pop(const char **out)   { if(out) *out = NULL; }
 
+/* sched.c: the harness has no fibers.  A task "created" here runs to completion at once on the caller's
+ * stack (what Sched_RunSync would make of it) and its future is complete -- the all-CPU control of the
+ * asynchronous field batch (nav.c:3824: Sched_Create(field_task); :2062 field_join_work). */
+#include "sched.h"
+uint32_t Sched_Create(int prio, task_func_t code, void *arg, const char *name, struct future *result, int flags)
+{
+    (void)prio; (void)name; (void)flags;
+    struct result r = code(arg);
+    if(result) {
+        result->res = r;
+        SDL_AtomicSet(&result->status, FUTURE_COMPLETE);
+    }
+    return 1;
+}
+bool     Sched_FutureIsReady(const struct future *future) { return ((SDL_atomic_t*)&future->status)->value == FUTURE_COMPLETE; }
+bool     Sched_RunSync(uint32_t tid) { (void)tid; return true; }
 bool     Sched_UsingBigStack(void) { return true; }
 void     Sched_TryYield(void)      { }
 uint32_t Sched_ActiveTID(void)     { return 0; /* NULL_TID: satisfies FC_ASSERT_NAV_TASK */ }

@@ -40,6 +40,8 @@ pmccp) i=0; for c in "SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_I
        timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccpc_$i -o p --output-format csv -- python bench.py --crowded --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmccpc_$i.json 2> $OUT/pmccpc_$i.err
        tail -c 200 $OUT/pmccpc_$i.err
      done ;;
+cpstats) timeout 400 python scripts/cp_stats.py > $OUT/cp_stats.json 2> $OUT/cp_stats.err; tail -c 300 $OUT/cp_stats.err
+         timeout 400 python scripts/cp_stats.py --crowd > $OUT/cp_stats_crowd.json 2>> $OUT/cp_stats.err; tail -c 600 $OUT/cp_stats_crowd.json ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log ;;
 esac
 done

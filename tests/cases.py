@@ -6,9 +6,9 @@ from oracle import navoracle, pfref
 from permafrost_engine_amd import synth
 
 
-def ref_nav_for(w, h, seed=1234, blockers=None, frac=0.20):
+def ref_nav_for(w, h, seed=1234, blockers=None, frac=0.20, layer_mask=1):
     grid = synth.cost_grid(w, h, seed=seed, frac_impassable=frac)
-    nav = pfref.RefNav(synth.to_chunks(grid))
+    nav = pfref.RefNav(synth.to_chunks(grid), layer_mask=layer_mask)
     if blockers is not None:
         nav.set_blockers(blockers)
     return grid, nav
