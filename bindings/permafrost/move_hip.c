@@ -1,15 +1,34 @@
-/* oracle/ref/move_hip.c -- the WORK_TYPE_HIP arm of fork_join_velocity_computations, made real.
+/* bindings/permafrost/move_hip.c -- the WORK_TYPE_HIP arm of fork_join_velocity_computations.
  *
  * What INTEGRATION.md tells a maintainer to add to src/game/movement.c next to the WORK_TYPE_CPU /
  * WORK_TYPE_GPU arms (movement.c:315-318,3737,4182-4194): fill a navhip_world from the tick's
  * snapshot tables (struct move_gamestate, :296) and work items (struct move_work_in, :264), run
  * navhip_agent_step, copy the velocities into s_move_work.out[] like copy_gpu_results does
- * (:4248-4261).  It lives in movement.c's translation unit because those tables are static; the
- * test harness #includes it right after movement.c (oracle/ref/ref_move.c) -- TEST INFRASTRUCTURE.
+ * (:4248-4261).  It lives in movement.c's translation unit because those tables are static; in this
+ * repository the test harness #includes it right after movement.c (oracle/ref/ref_move.c).
+ *
+ * With device sampling on (move_hip_set_device_sampling; needs the binding's resident pool,
+ * N_HIP_PoolEnable in nav_hip.c) the per-agent N_DesiredPointSeekVelocity calls of
+ * compute_desired_velocity (movement.c:4166) are skipped for point-seeking agents: the device samples the
+ * flow fields of the resident pool itself.  Agents it cannot answer (no field mapped for their chunk,
+ * FD_NONE under them: the planner / repair cases of nav.c:3483-3554) come back flagged and are stepped
+ * by the host's own move_velocity_work after a host-side N_DesiredPointSeekVelocity.
  */
 #include <navhip.h>
+#include <math.h>
 
 navhip_ctx *N_HIP_Ctx(void);          /* nav_hip.c */
+bool N_HIP_PoolOn(void);
+void N_HIP_PoolSetRows(struct nav_private *priv, int n, const dest_id_t *dest_ids);
+bool N_HIP_PoolSync(void);
+/* the map's position (M_GetPos, map.c) and its nav context (map->nav_private, map.c:787-815) */
+vec3_t              move_hip_map_pos(const struct map *map);
+struct nav_private *move_hip_nav_private(const struct map *map);
+
+static bool s_hip_sample_on_device;
+static long s_hip_stats[3];            /* agents sampled on the device, host fallbacks, steps */
+void move_hip_set_device_sampling(bool on) { s_hip_sample_on_device = on; }
+void move_hip_stats(long out[3])           { memcpy(out, s_hip_stats, sizeof(s_hip_stats)); }
 
 /* The flock tables (membership, member lists, targets) only change when an entity is added or removed
  * or a flock is made, re-targeted or disbanded: movement.c bumps this epoch there (G_Move_AddEntity :4591,
@@ -117,7 +136,7 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
     }
     /* work items */
     int lo = n, hi = -1;
-    bool any_form = false;
+    bool any_form = false, ok_pool = true;
     for(int w = begin_idx; w <= end_idx; w++) {
         const struct move_work_in *in = &s_move_work.in[w];
         const int i = DENSE(in->ent_uid);
@@ -135,19 +154,40 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
     }
     /* the device steps the contiguous uid slab [lo, hi]; entities inside it that carry no work item
      * (other slabs of a threaded split) are stepped too and their results dropped */
-    const struct nav_private *priv = NULL;
-    (void)priv;
+    struct nav_private *priv = move_hip_nav_private(gs->map);
+    const bool sample = s_hip_sample_on_device && N_HIP_PoolOn();
+    if(sample) {
+        /* flock index = mapping row of the resident pool: announce every flock's destination, flush the
+         * mappings the planner recorded since the last tick, and leave the sampling of the point-seeking
+         * agents (the default arm of ent_desired_velocity, :1510-1521) to the device: vdes.x = NaN */
+        dest_id_t *fdest = malloc(sizeof(dest_id_t) * (nflocks ? nflocks : 1));
+        for(size_t f = 0; f < nflocks; f++)
+            fdest[f] = vec_AT(&s_flocks, f).dest_id;
+        N_HIP_PoolSetRows(priv, (int)nflocks, fdest);
+        free(fdest);
+        if(!N_HIP_PoolSync()) {
+            ok_pool = false;
+        }else{
+            for(int w = begin_idx; w <= end_idx; w++) {
+                const int i = DENSE(s_move_work.in[w].ent_uid);
+                if(state[i] == STATE_MOVING && flock[i] >= 0 && !(arr_flags[i] & 2))
+                    vdes[2 * i] = NAN;
+            }
+        }
+    }
     navhip_world W;
     memset(&W, 0, sizeof(W));
     W.n_ents = n; W.n_flocks = (int32_t)nflocks; W.hz = hz_count(s_move_work.hz);
     W.pos_xz = pos; W.vel_xz = vel; W.radius = radius; W.max_speed = max_speed; W.speed = speed;
     W.flags = flags; W.state = state; W.has_dest_los = los; W.flock = flock; W.vdes_xz = vdes;
     W.flock_target_xz = flock_target; W.flock_offsets = flock_offsets; W.flock_members = flock_members;
-    vec3_t map_pos = ((pfref_nav*)gs->map)->map_pos;           /* M_GetPos(map) */
+    vec3_t map_pos = move_hip_map_pos(gs->map);
     W.map_pos_x = map_pos.x; W.map_pos_z = map_pos.z;
+    if(sample && ok_pool)
+        W.n_field_slots = NAVHIP_POOL_RESIDENT;
     {
         /* bg_ent_init bounds of the position snapshot (position.c:276-283) */
-        const struct nav_private *np = &((pfref_nav*)gs->map)->priv;
+        const struct nav_private *np = priv;
         float half_x = np->width * TILES_PER_CHUNK_WIDTH * X_COORDS_PER_TILE / 2.0f;
         float half_z = np->height * TILES_PER_CHUNK_HEIGHT * Z_COORDS_PER_TILE / 2.0f;
         float cx = map_pos.x - half_x, cz = map_pos.z + half_z;
@@ -168,9 +208,22 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
     /* (the nav task would Task_AwaitEvent(EVENT_UPDATE_START) here, like the GL path :4212-4233) */
     if(ok) ok = navhip_agent_step_wait(ctx) == NAVHIP_OK;
     if(ok) {
+        s_hip_stats[2]++;
         for(int w = begin_idx; w <= end_idx; w++) {
             const int i = DENSE(s_move_work.in[w].ent_uid);
             if(status[i] & NAVHIP_ST_UNSUPPORTED) { ok = false; break; }
+            if(isnan(vdes[2 * i]) && (status[i] & (NAVHIP_ST_FIELD_MISS | NAVHIP_ST_FIELD_NONE))) {
+                /* the cases of nav.c:3483-3554 that need the planner or a repair build: the host samples
+                 * (its builds go through the binding and land in the pool) and steps this one agent */
+                struct move_work_in *in = &s_move_work.in[w];
+                const struct flock *fl = flock_for_ent(in->ent_uid);
+                in->ent_des_v = M_NavDesiredPointSeekVelocity(gs->map, fl->dest_id, in->cp_ent.xz_pos, fl->target_xz);
+                in->dyn_neighbs->size = 0; in->stat_neighbs->size = 0;
+                move_velocity_work(w, w);
+                s_hip_stats[1]++;
+                continue;
+            }
+            if(isnan(vdes[2 * i])) s_hip_stats[0]++;
             s_move_work.out[w].ent_vel = (vec2_t){out_vel[2 * i], out_vel[2 * i + 1]};
         }
     }

@@ -73,6 +73,18 @@ static struct {
 
 #define N_HIP_TAG 0xF    /* dir_idx value no real field holds: marks a placeholder */
 
+/* the device image of the field cache (the functions are at the end of this file) */
+static struct{
+    bool        on;
+    int         n_rows;
+    dest_id_t  *row_dest;
+    bool       *row_used;
+    int32_t    *m_row; uint16_t *m_r, *m_c; uint64_t *m_id;
+    int         nm, capm;
+    long        n_puts, n_maps, n_built;
+}s_hip_pool;
+
+
 /* -------------------------------------------------------------------------------------------- */
 
 static void n_hip_pack_plane(const struct nav_private *priv, enum nav_layer layer, int plane, void *out)
@@ -346,7 +358,35 @@ bool N_HIP_Flush(void)
             who[m++] = i;
         }
         if(m > 0) {
-            if(navhip_build_fields(s_hip.ctx, reqs, m, dirs, NULL) == NAVHIP_OK) {
+            int rc;
+            if(s_hip_pool.on) {
+                /* build INTO the resident pool (and read back for the host cache): the fields never
+                 * cross the bus a second time.  An update in place starts from the pending build it
+                 * names (base id) or from the host's existing content, which is put first */
+                uint64_t *ids = malloc(sizeof(uint64_t) * m), *bases = calloc(m, sizeof(uint64_t));
+                for(int k = 0; k < m; k++) {
+                    struct n_hip_pending *p = &s_hip.pend[who[k]];
+                    ids[k] = p->id;
+                    if(p->base >= 0) {
+                        if(s_hip.pend[p->base].id != p->id) bases[k] = s_hip.pend[p->base].id;
+                        continue;
+                    }
+                    bool any = false;
+                    for(size_t t = 0; t < sizeof(p->dirs); t++) any = any || p->dirs[t] != FD_NONE;
+                    if(any)
+                        navhip_pool_put(s_hip.ctx, p->id, p->dirs);
+                    else if(p->kind == 0)
+                        reqs[k].flags &= ~NAVHIP_REQ_INOUT;        /* N_FlowFieldInit, not the slot's old field */
+                    else
+                        navhip_pool_put(s_hip.ctx, p->id, p->dirs); /* a repair of an all-FD_NONE field */
+                }
+                rc = navhip_pool_build(s_hip.ctx, reqs, ids, bases, m, dirs);
+                if(rc == NAVHIP_OK) s_hip_pool.n_built += m;
+                free(ids); free(bases);
+            }else{
+                rc = navhip_build_fields(s_hip.ctx, reqs, m, dirs, NULL);
+            }
+            if(rc == NAVHIP_OK) {
                 s_hip.n_builds += m; s_hip.n_batches++;
                 for(int k = 0; k < m; k++)
                     memcpy(s_hip.pend[who[k]].dirs, dirs + (size_t)k * FIELD_RES_R * FIELD_RES_C,
@@ -768,3 +808,121 @@ bool N_HIP_BlockersFlush(void)
 }
 
 void N_HIP_BlockersStats(long out[2]) { out[0] = s_hip_blk.n_flushed; out[1] = s_hip_blk.n_batches; }
+
+/* ---- the field cache's device image (fieldcache.c -> navhip_pool_*) --------------------------- */
+/* The host keeps its field cache (the planner and the CPU fallbacks read it); with the pool enabled
+ * every flow field the cache receives is ALSO resident on the device under the same N_FlowFieldID, and
+ * every (dest, chunk) -> field mapping is mirrored into the pool's mapping table, so that the movement
+ * tick can let the device sample the fields (navhip_world.n_field_slots = NAVHIP_POOL_RESIDENT,
+ * vdes_xz = NaN) instead of calling N_DesiredPointSeekVelocity per agent on the host.
+ *   N_FC_PutFlowField      -> N_HIP_FC_PutFlowField       (nav.c:1833,2008,2018,3533,3547,3632,3715,3964)
+ *   N_FC_PutDestFFMapping  -> N_HIP_FC_PutDestFFMapping   (nav.c:1835,2021)
+ *   N_FC_ClearAll          -> N_HIP_FC_ClearAll
+ *   lru_flow_remove / LRU eviction (fieldcache.c:253,520,580; the on-evict argument of lru_flow_init :272)
+ *                          -> navhip_pool_invalidate(ctx, key)
+ * Mapping rows: the agent step uses the FLOCK INDEX as row; the movement tick announces the destination
+ * of every flock (N_HIP_PoolSetRows) and the binding fans a destination's mappings out to its rows. */
+
+bool N_HIP_PoolEnable(int n_slots, int n_rows)
+{
+    if(!s_hip.ctx || navhip_pool_create(s_hip.ctx, n_slots, n_rows) != NAVHIP_OK)
+        return false;
+    free(s_hip_pool.row_dest); free(s_hip_pool.row_used);
+    s_hip_pool.row_dest = calloc(n_rows, sizeof(dest_id_t));
+    s_hip_pool.row_used = calloc(n_rows, sizeof(bool));
+    s_hip_pool.n_rows = n_rows;
+    s_hip_pool.nm = 0;
+    s_hip_pool.on = true;
+    return true;
+}
+
+void N_HIP_PoolDisable(void)
+{
+    if(s_hip.ctx && s_hip_pool.on)
+        navhip_pool_destroy(s_hip.ctx);
+    free(s_hip_pool.row_dest); free(s_hip_pool.row_used);
+    free(s_hip_pool.m_row); free(s_hip_pool.m_r); free(s_hip_pool.m_c); free(s_hip_pool.m_id);
+    memset(&s_hip_pool, 0, sizeof(s_hip_pool));
+}
+
+bool N_HIP_PoolOn(void) { return s_hip_pool.on; }
+void N_HIP_PoolStats(long out[3]) { out[0] = s_hip_pool.n_puts; out[1] = s_hip_pool.n_maps; out[2] = s_hip_pool.n_built; }
+
+static void n_hip_pool_record(int row, struct coord chunk, ff_id_t ffid)
+{
+    if(s_hip_pool.nm == s_hip_pool.capm) {
+        s_hip_pool.capm = s_hip_pool.capm ? s_hip_pool.capm * 2 : 1024;
+        s_hip_pool.m_row = realloc(s_hip_pool.m_row, sizeof(int32_t) * s_hip_pool.capm);
+        s_hip_pool.m_r = realloc(s_hip_pool.m_r, sizeof(uint16_t) * s_hip_pool.capm);
+        s_hip_pool.m_c = realloc(s_hip_pool.m_c, sizeof(uint16_t) * s_hip_pool.capm);
+        s_hip_pool.m_id = realloc(s_hip_pool.m_id, sizeof(uint64_t) * s_hip_pool.capm);
+    }
+    const int k = s_hip_pool.nm++;
+    s_hip_pool.m_row[k] = row; s_hip_pool.m_r[k] = chunk.r; s_hip_pool.m_c[k] = chunk.c; s_hip_pool.m_id[k] = ffid;
+}
+
+void N_HIP_FC_PutFlowField(struct fieldcache_ctx *fc, ff_id_t ffid, const struct flow_field *ff)
+{
+    (N_FC_PutFlowField)(fc, ffid, ff);
+    if(!s_hip_pool.on || ff->field[0][0].dir_idx == N_HIP_TAG)      /* (a placeholder of a deferred batch) */
+        return;
+    uint8_t dirs[FIELD_RES_R * FIELD_RES_C];
+    n_hip_ff_to_dirs(ff, dirs);
+    if(navhip_pool_put(s_hip.ctx, ffid, dirs) == NAVHIP_OK)
+        s_hip_pool.n_puts++;
+}
+
+void N_HIP_FC_PutDestFFMapping(struct fieldcache_ctx *fc, dest_id_t dest_id, struct coord chunk, ff_id_t ffid)
+{
+    (N_FC_PutDestFFMapping)(fc, dest_id, chunk, ffid);
+    if(!s_hip_pool.on)
+        return;
+    for(int row = 0; row < s_hip_pool.n_rows; row++)
+        if(s_hip_pool.row_used[row] && s_hip_pool.row_dest[row] == dest_id)
+            n_hip_pool_record(row, chunk, ffid);
+}
+
+void N_HIP_FC_ClearAll(struct fieldcache_ctx *fc)
+{
+    N_FC_ClearAll(fc);
+    if(s_hip_pool.on) {
+        navhip_pool_clear(s_hip.ctx);
+        s_hip_pool.nm = 0;
+        memset(s_hip_pool.row_used, 0, sizeof(bool) * s_hip_pool.n_rows);
+    }
+}
+
+/* the destination of every flock, flock index = mapping row (movement.c: s_flocks[f].dest_id) */
+void N_HIP_PoolSetRows(struct nav_private *priv, int n, const dest_id_t *dest_ids)
+{
+    if(!s_hip_pool.on)
+        return;
+    for(int row = 0; row < s_hip_pool.n_rows; row++) {
+        const bool used = row < n;
+        if(used == s_hip_pool.row_used[row] && (!used || s_hip_pool.row_dest[row] == dest_ids[row]))
+            continue;
+        /* the row changes hands: drop what it maps, then take over the host cache's mappings of the
+         * new destination (N_FC_GetDestFFMapping, fieldcache.c:417) */
+        for(int r = 0; r < (int)priv->height; r++)
+        for(int c = 0; c < (int)priv->width; c++) {
+            ff_id_t ffid = 0;                       /* id 0 is never resident: "no field" */
+            if(used)
+                N_FC_GetDestFFMapping(priv->fieldcache, dest_ids[row], (struct coord){r, c}, &ffid);
+            if(used || s_hip_pool.row_used[row])
+                n_hip_pool_record(row, (struct coord){r, c}, ffid);
+        }
+        s_hip_pool.row_used[row] = used;
+        s_hip_pool.row_dest[row] = used ? dest_ids[row] : 0;
+    }
+}
+
+/* the recorded mapping updates in ONE navhip_pool_map call (before the tick's agent step) */
+bool N_HIP_PoolSync(void)
+{
+    if(!s_hip_pool.on || s_hip_pool.nm == 0)
+        return true;
+    const int rc = navhip_pool_map(s_hip.ctx, s_hip_pool.nm, s_hip_pool.m_row, s_hip_pool.m_r, s_hip_pool.m_c, s_hip_pool.m_id);
+    s_hip_pool.n_maps += s_hip_pool.nm;
+    s_hip_pool.nm = 0;
+    return rc == NAVHIP_OK;
+}

@@ -287,6 +287,9 @@ int  navhip_pool_contains(navhip_ctx *ctx, uint64_t ff_id);               /* N_F
 int  navhip_pool_put(navhip_ctx *ctx, uint64_t ff_id, const uint8_t *dirs);   /* N_FC_PutFlowField: 4096
                                                                               direction bytes from the host */
 int  navhip_pool_get(navhip_ctx *ctx, uint64_t ff_id, uint8_t *out_dirs); /* N_FC_FlowFieldAt (a copy)  */
+/* lru_flow_remove (the N_FC_Invalidate* family, fieldcache.c:253,520,580) and the eviction of the
+ * host cache: the field is dropped and every mapping that points at it becomes "no field" */
+int  navhip_pool_invalidate(navhip_ctx *ctx, uint64_t ff_id);
 /* Batched N_FlowFieldInit + N_FlowFieldUpdate + N_FC_PutFlowField: request i is built INTO the pool
  * slot of ff_ids[i].  For a NAVHIP_REQ_INOUT request base_ids[i] names the resident field the update
  * starts from (the memcpy of nav.c:1998, the repairs of nav.c:3527-3547); 0 or ff_ids[i] itself = the

@@ -120,6 +120,8 @@ def lib():
                                                         C.c_float, C.c_float, C.c_float,
                                                         C.c_void_p]
         L.pfref_cached_field.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.pfref_cached_ffid.restype = C.c_uint64
+        L.pfref_cached_ffid.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int]
         L.pfref_cached_los.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.pfref_has_dest_los.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float,
                                          C.c_float, C.c_float]
@@ -389,6 +391,26 @@ class RefNav:
                 "los_device_fields": l[0], "los_batches": l[1], "blocker_circles": b[0], "blocker_batches": b[1]}
 
     @staticmethod
+    def hip_pool(n_slots=0, n_rows=0):
+        """N_HIP_PoolEnable / Disable: the field cache's device image."""
+        if n_slots:
+            return bool(lib().pfref_hip_pool_enable(int(n_slots), int(n_rows)))
+        lib().pfref_hip_pool_disable()
+        return True
+
+    @staticmethod
+    def hip_pool_stats():
+        p, m = (C.c_long * 3)(), (C.c_long * 3)()
+        lib().pfref_hip_pool_stats(p)
+        lib().pfref_move_hip_stats(m)
+        return {"puts": p[0], "maps": p[1], "built_resident": p[2], "device_sampled": m[0], "host_fallbacks": m[1],
+                "steps": m[2]}
+
+    @staticmethod
+    def hip_device_sampling(on):
+        lib().pfref_move_hip_sampling(int(bool(on)))
+
+    @staticmethod
     def hip_blockers_flush():
         return bool(lib().pfref_hip_blockers_flush())
 
@@ -442,6 +464,10 @@ class RefNav:
         out = np.zeros((64, 64), np.uint8)
         ok = lib().pfref_cached_field(self._h, dest_id, chunk_r, chunk_c, _p(out))
         return out if ok else None
+
+    def cached_ffid(self, dest_id, chunk_r, chunk_c):
+        """N_FC_GetDestFFMapping: id of the flow field mapped for (dest, chunk), 0 = none."""
+        return int(lib().pfref_cached_ffid(self._h, dest_id, chunk_r, chunk_c))
 
     def cached_los(self, dest_id, chunk_r, chunk_c):
         """The LOS field the field cache holds for (dest, chunk), [64,64] u8 (bit 0 visible), or None."""

@@ -139,6 +139,7 @@ void   pfref_trace_clear(void);
 void   pfref_desired_point_seek_velocity(pfref_nav *nav, uint32_t dest_id, float x, float z,
                                          float dst_x, float dst_z, float out[2]);
 /* (dest,chunk) -> cached field (fieldcache.c): returns 1 and copies 4096 dirs */
+uint64_t pfref_cached_ffid(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c);
 int    pfref_cached_los(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c, uint8_t *out);
 int    pfref_cached_field(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c,
                           uint8_t *out_dirs);
@@ -193,6 +194,13 @@ void pfref_hip_blockers_stats(long out[2]);   /* circles flushed, device batches
 int  pfref_hip_blockers_flush(void);          /* N_HIP_BlockersFlush */
 void *pfref_hip_ctx(void);                    /* the binding's navhip_ctx* (tests read the device planes) */
 void pfref_nav_dirty_chunks(pfref_nav *nav, int layer, uint8_t *flags);
+
+/* the field cache's device image: N_HIP_PoolEnable (nav_hip.c) + device sampling in the WORK_TYPE_HIP arm */
+int  pfref_hip_pool_enable(int n_slots, int n_rows);
+void pfref_hip_pool_disable(void);
+void pfref_hip_pool_stats(long out[3]);       /* host puts mirrored, mappings mirrored, fields built resident */
+void pfref_move_hip_sampling(int on);
+void pfref_move_hip_stats(long out[3]);       /* agents sampled on the device, host fallbacks, steps */
 
 /* --- ClearPath ---------------------------------------------------------- */
 

@@ -324,13 +324,23 @@ int pfref_move_neighbours(int uid, float *out_dyn, int *n_dyn, float *out_stat, 
 }
 
 /* the WORK_TYPE_HIP arm (what a maintainer adds to movement.c) */
+vec3_t              move_hip_map_pos(const struct map *map)     { return ((pfref_nav*)map)->map_pos; }
+struct nav_private *move_hip_nav_private(const struct map *map) { return &((pfref_nav*)map)->priv; }
 #include "move_hip.c"
+
+void pfref_move_hip_sampling(int on)    { move_hip_set_device_sampling(on != 0); }
+void pfref_move_hip_stats(long out[3])  { move_hip_stats(out); }
 
 /* like pfref_move_velocity, through move_hip_velocity_work; returns 0 when the device arm declined */
 int pfref_move_velocity_hip(const float *vdes, int begin, int end, float *out_vel)
 {
-    for(int i = begin; i < end; i++)
-        set_vdes(vdes, i);
+    static const float zero2[2] = {0.0f, 0.0f};
+    for(int i = begin; i < end; i++) {
+        /* with device sampling on, compute_desired_velocity's per-agent host sampling is what the arm
+         * replaces: the work items arrive without a desired velocity */
+        if(!vdes && s_hip_sample_on_device) set_vdes(zero2 - 2 * i, i);
+        else                                set_vdes(vdes, i);
+    }
     if(end <= begin)
         return 1;
     if(!move_hip_velocity_work(begin, end - 1))

@@ -18,12 +18,18 @@
  * functions (nav.c:3824,3878,3907) */
 #define N_LOSFieldCreate pfref_hook_N_LOSFieldCreate
 #define Sched_Create pfref_hook_Sched_Create
+/* ... and the field cache's writers (nav.c:1833-1835,2008-2021,3533,3547,3632,3715,3964), mirrored into
+ * the device-resident pool when the binding has one */
+#define N_FC_PutFlowField pfref_hook_FC_PutFlowField
+#define N_FC_PutDestFFMapping pfref_hook_FC_PutDestFFMapping
 #include "navigation/nav.c"
 #undef N_FlowFieldUpdate
 #undef N_FlowFieldUpdateToNearestPathable
 #undef N_FlowFieldUpdateIslandToNearest
 #undef N_LOSFieldCreate
 #undef Sched_Create
+#undef N_FC_PutFlowField
+#undef N_FC_PutDestFFMapping
 
 #include "pfref.h"
 #include "ref_internal.h"
@@ -43,6 +49,8 @@ void N_LOSFieldCreate(dest_id_t id, struct coord chunk_coord, struct tile_desc t
                       const struct nav_private *priv, vec3_t map_pos, struct nav_unit_query_ctx *ctx,
                       struct LOS_field *out_los, const struct LOS_field *prev_los);
 uint32_t Sched_Create(int prio, task_func_t code, void *arg, const char *name, struct future *result, int flags);
+void N_FC_PutFlowField(struct fieldcache_ctx *ctx, ff_id_t ffid, const struct flow_field *ff);
+void N_FC_PutDestFFMapping(struct fieldcache_ctx *ctx, dest_id_t dest_id, struct coord chunk_coord, ff_id_t ffid);
 
 /* The reference-side binding of libnavhip.so (what a maintainer appends to nav.c): every field build
  * nav.c asks for goes through it while s_use_binding is set. */
@@ -55,6 +63,18 @@ void pfref_hook_N_LOSFieldCreate(dest_id_t id, struct coord chunk_coord, struct 
 {
     if(s_use_binding) N_HIP_LOSFieldCreate(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los);
     else              N_LOSFieldCreate(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los);
+}
+
+void pfref_hook_FC_PutFlowField(struct fieldcache_ctx *ctx, ff_id_t ffid, const struct flow_field *ff)
+{
+    if(s_use_binding) N_HIP_FC_PutFlowField(ctx, ffid, ff);
+    else              N_FC_PutFlowField(ctx, ffid, ff);
+}
+
+void pfref_hook_FC_PutDestFFMapping(struct fieldcache_ctx *ctx, dest_id_t dest_id, struct coord chunk, ff_id_t ffid)
+{
+    if(s_use_binding) N_HIP_FC_PutDestFFMapping(ctx, dest_id, chunk, ffid);
+    else              N_FC_PutDestFFMapping(ctx, dest_id, chunk, ffid);
 }
 
 uint32_t pfref_hook_Sched_Create(int prio, task_func_t code, void *arg, const char *name,
@@ -333,6 +353,15 @@ int pfref_cached_field(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_
     return 1;
 }
 
+/* N_FC_GetDestFFMapping: the id of the field the cache maps for (dest, chunk); 0 = none */
+uint64_t pfref_cached_ffid(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c)
+{
+    ff_id_t ffid = 0;
+    if(!N_FC_GetDestFFMapping(nav->priv.fieldcache, dest_id, (struct coord){chunk_r, chunk_c}, &ffid))
+        return 0;
+    return ffid;
+}
+
 /* the LOS field the field cache holds for (dest, chunk): bit 0 visible, bit 1 wavefront_blocked */
 int pfref_cached_los(pfref_nav *nav, uint32_t dest_id, int chunk_r, int chunk_c, uint8_t *out)
 {
@@ -377,6 +406,7 @@ int pfref_hip_init(pfref_nav *nav)
 void pfref_hip_shutdown(void)
 {
     s_use_binding = false;
+    N_HIP_PoolDisable();
     N_HIP_Shutdown();
 }
 
@@ -430,7 +460,10 @@ uint32_t pfref_dest_id(pfref_nav *nav, int layer, int faction_id, float dst_x, f
     return n_dest_id(td, layer, faction_id);
 }
 
-void pfref_cache_clear(pfref_nav *nav) { N_FC_ClearAll(nav->priv.fieldcache); }
+void pfref_cache_clear(pfref_nav *nav) { N_HIP_FC_ClearAll(nav->priv.fieldcache); }
+int  pfref_hip_pool_enable(int n_slots, int n_rows) { return N_HIP_PoolEnable(n_slots, n_rows) ? 1 : 0; }
+void pfref_hip_pool_disable(void) { N_HIP_PoolDisable(); }
+void pfref_hip_pool_stats(long out[3]) { N_HIP_PoolStats(out); }
 
 
 /* ------------------------------------------------------------------------ */

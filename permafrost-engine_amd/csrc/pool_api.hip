@@ -111,9 +111,39 @@ static int pool_slot_for(nh_pool *P, uint64_t id, bool *fresh, const std::vector
     return slot;
 }
 
+// slots a pool build took for ids that were not resident: handed back when the call fails, so that no id
+// is ever registered for a slot whose field was not built (the evicted fields are gone either way)
+static void pool_rollback(nh_pool *P, const std::vector<int> &fresh_slots)
+{
+    for(int slot : fresh_slots) {
+        if(!P->used[slot]) continue;
+        P->slot_of.erase(P->id_of[slot]);
+        P->used[slot] = 0;
+        P->refs[slot].clear();
+        // least recently used again: the next new id takes it first
+        P->lru.erase(P->lru_it[slot]);
+        P->lru.push_back(slot);
+        P->lru_it[slot] = std::prev(P->lru.end());
+    }
+}
+
 static int pool_flush_map(navhip_ctx *ctx, nh_pool *P, hipStream_t s)
 {
     if(P->pending.empty()) return NAVHIP_OK;
+    {
+        // one update per table entry: the scatter kernel applies the pairs in parallel, so two updates of
+        // the same entry in one launch (a chunk re-mapped twice between two flushes) would race -- the
+        // LAST one is the one that counts
+        std::unordered_map<int32_t, size_t> last;
+        for(size_t i = 0; i + 1 < P->pending.size(); i += 2) last[P->pending[i]] = i;
+        if(last.size() * 2 != P->pending.size()) {
+            std::vector<int32_t> uniq;
+            uniq.reserve(last.size() * 2);
+            for(size_t i = 0; i + 1 < P->pending.size(); i += 2)
+                if(last[P->pending[i]] == i) { uniq.push_back(P->pending[i]); uniq.push_back(P->pending[i + 1]); }
+            P->pending.swap(uniq);
+        }
+    }
     const int n = (int)(P->pending.size() / 2);
     int rc = grow(ctx, (void**)&P->d_upd, &P->d_upd_cap, P->pending.size() * sizeof(int32_t));
     if(rc) return rc;
@@ -176,6 +206,24 @@ int navhip_pool_contains(navhip_ctx *ctx, uint64_t ff_id)
     return ctx->pool->slot_of.count(ff_id) ? 1 : 0;
 }
 
+int navhip_pool_invalidate(navhip_ctx *ctx, uint64_t ff_id)
+{
+    if(!ctx || !ctx->pool) return NAVHIP_ERR_INVALID;
+    nh_pool *P = ctx->pool;
+    auto it = P->slot_of.find(ff_id);
+    if(it == P->slot_of.end()) return NAVHIP_OK;               // (lru_flow_remove of an absent key: no-op)
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int slot = it->second;
+    for(int64_t e : P->refs[slot]) {
+        if(P->h_map[(size_t)e] == slot) {
+            P->h_map[(size_t)e] = -1;
+            P->pending.push_back((int32_t)e); P->pending.push_back(-1);
+        }
+    }
+    pool_rollback(P, std::vector<int>{slot});                  // unregister, least recently used again
+    return pool_flush_map(ctx, P, ctx->stream);
+}
+
 int navhip_pool_put(navhip_ctx *ctx, uint64_t ff_id, const uint8_t *dirs)
 {
     if(!ctx || !ctx->pool || !dirs) return NAVHIP_ERR_INVALID;
@@ -221,22 +269,6 @@ int navhip_pool_map(navhip_ctx *ctx, int n, const int32_t *dest, const uint16_t 
         }
     }
     return pool_flush_map(ctx, P, ctx->stream);
-}
-
-// slots a pool build took for ids that were not resident: handed back when the call fails, so that no id
-// is ever registered for a slot whose field was not built (the evicted fields are gone either way)
-static void pool_rollback(nh_pool *P, const std::vector<int> &fresh_slots)
-{
-    for(int slot : fresh_slots) {
-        if(!P->used[slot]) continue;
-        P->slot_of.erase(P->id_of[slot]);
-        P->used[slot] = 0;
-        P->refs[slot].clear();
-        // least recently used again: the next new id takes it first
-        P->lru.erase(P->lru_it[slot]);
-        P->lru.push_back(slot);
-        P->lru_it[slot] = std::prev(P->lru.end());
-    }
 }
 
 __global__ void k_zero_fields(uint8_t *fields, const int32_t *slots, int n)

@@ -362,6 +362,7 @@ _SIGS.update({
     "navhip_pool_contains": (C.c_int, [C.c_void_p, C.c_uint64]),
     "navhip_pool_put": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "navhip_pool_get": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "navhip_pool_invalidate": (C.c_int, [C.c_void_p, C.c_uint64]),
     "navhip_pool_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "navhip_pool_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "navhip_host_alloc": (C.c_void_p, [C.c_size_t]),
@@ -582,6 +583,10 @@ def _ctx_pool_get(self, ff_id):
     return None if rc != OK else d
 
 
+def _ctx_pool_invalidate(self, ff_id):
+    self._chk(lib().navhip_pool_invalidate(self._h, int(ff_id)), "navhip_pool_invalidate")
+
+
 def _ctx_pool_contains(self, ff_id):
     return bool(lib().navhip_pool_contains(self._h, int(ff_id)))
 
@@ -647,6 +652,7 @@ NavContext.pool_build = _ctx_pool_build
 NavContext.pool_put = _ctx_pool_put
 NavContext.pool_get = _ctx_pool_get
 NavContext.pool_contains = _ctx_pool_contains
+NavContext.pool_invalidate = _ctx_pool_invalidate
 NavContext.pool_map = _ctx_pool_map
 NavContext.agent_step_async = _ctx_agent_step_async
 NavContext.set_profiling = _ctx_set_profiling

@@ -286,3 +286,49 @@ def test_blocker_tick_through_the_binding(navlib):
     finally:
         pfref.RefNav.hip_mode(False)
         pfref.RefNav.hip_shutdown()
+
+
+def test_field_cache_device_image_and_device_sampling():
+    """The pool binding (N_FC_PutFlowField / N_FC_PutDestFFMapping / N_FC_ClearAll -> navhip_pool_*) and the
+    WORK_TYPE_HIP arm sampling on the device: tick 1 starts with an empty cache -- every agent comes back
+    flagged, the host's sampler runs the planner (its builds go through the binding and land in the
+    pool), and steps those agents itself; tick 2 finds the fields resident and the mappings mirrored --
+    the device samples them, no N_DesiredPointSeekVelocity call per agent.  Both ticks equal the all-CPU
+    movement tick (host sampling + move_velocity_work) bit for bit."""
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    n, k = 1200, 5
+    world = cases.make_agents(grid, n, k, seed=77, clustered=False)
+    world["state"][:] = 0                                     # STATE_MOVING: the point-seek arm
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    nav.cache_clear()
+    pfref.RefNav.hip_mode(False)
+    exp = mv.velocity(None)                                   # host sampling (plans on miss) + CPU step
+    # the same tick again on the warm cache: a few agents change (the planner calls of later agents
+    # re-mapped chunks of their destination during the first pass), then the cache is settled
+    exp2 = mv.velocity(None)
+    assert np.array_equal(mv.velocity(None).view(np.uint32), exp2.view(np.uint32)) and np.abs(exp).max() > 0
+    assert nav.hip_init()
+    try:
+        assert pfref.RefNav.hip_pool(2048 + 256, 16)
+        pfref.RefNav.hip_mode(True, 1)
+        pfref.RefNav.hip_device_sampling(True)
+        nav.cache_clear()                                     # N_HIP_FC_ClearAll: host cache and pool
+        s0 = pfref.RefNav.hip_pool_stats()
+        got1 = mv.velocity_hip(None)
+        s1 = pfref.RefNav.hip_pool_stats()
+        assert got1 is not None
+        assert np.array_equal(got1.view(np.uint32), exp.view(np.uint32))
+        # every agent needed the host the first time; what the host built is resident now
+        assert s1["host_fallbacks"] - s0["host_fallbacks"] > 0.9 * n
+        assert s1["puts"] + s1["built_resident"] > 20
+        got2 = mv.velocity_hip(None)
+        s2 = pfref.RefNav.hip_pool_stats()
+        assert np.array_equal(got2.view(np.uint32), exp2.view(np.uint32))
+        sampled, fell = s2["device_sampled"] - s1["device_sampled"], s2["host_fallbacks"] - s1["host_fallbacks"]
+        assert sampled > 0.95 * n and fell < 0.05 * n, (sampled, fell)
+        assert s2["maps"] > 20
+    finally:
+        pfref.RefNav.hip_device_sampling(False)
+        pfref.RefNav.hip_mode(False)
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()

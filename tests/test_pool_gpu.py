@@ -51,6 +51,12 @@ def test_pool_build_put_get_map_and_resident_step(navlib, small):
     assert np.array_equal(got_all, dirs)
     assert all(ctx.pool_contains(i) for i in ids[:10]) and not ctx.pool_contains(12345)
     assert np.array_equal(ctx.pool_get(ids[7]), dirs[u[7]]) and ctx.pool_get(999) is None
+    # lru_flow_remove (the N_FC_Invalidate* family): the field is gone, an absent id is a no-op
+    ctx.pool_invalidate(ids[9])
+    ctx.pool_invalidate(424242)
+    assert not ctx.pool_contains(ids[9]) and ctx.pool_get(ids[9]) is None and ctx.pool_contains(ids[8])
+    ctx.pool_build(reqs[u[9:10]], readback=False)
+    assert np.array_equal(ctx.pool_get(ids[9]), dirs[u[9]])
     # a field put from the host (N_FC_PutFlowField of a field the host built itself)
     ctx.pool_put(0xABCDEF, dirs[3])
     assert np.array_equal(ctx.pool_get(0xABCDEF), dirs[3])
@@ -190,6 +196,17 @@ def test_pool_copy_and_rewrite_of_one_field_in_one_call(navlib, small):
     ids, got = ctx.pool_build(np.concatenate([upd, b]), ff_ids=[ida, idb], base_ids=[idb, 0])
     assert np.array_equal(got[0], exp_upd[0])                   # built from the OLD B
     assert np.array_equal(got[1], exp_b[0])
+    # one navhip_pool_map call that re-maps the same (dest, chunk) several times: the LAST entry counts
+    cr, cc = int(a["chunk_r"][0]), int(a["chunk_c"][0])
+    ctx.pool_map([0] * 9, [cr] * 9, [cc] * 9, [ida, idb] * 4 + [ida])
+    W = small["W"]
+    arrays = dict(small["arrays"], use_resident_pool=True, flock=np.zeros(small["N"], np.int32),
+                  flock_target_xz=small["arrays"]["flock_target_xz"][:1])
+    arrays["flock_offsets"], arrays["flock_members"] = navlib.flock_csr(arrays["flock"], 1)
+    one = ctx.agent_step(arrays)
+    ctx.pool_map([0], [cr], [cc], [ida])
+    two = ctx.agent_step(arrays)
+    assert np.array_equal(one["vdes_xz"], two["vdes_xz"]) and np.abs(one["vdes_xz"]).max() > 0
     # re-putting the same mapping every tick does not grow anything (and stays correct)
     for _ in range(50):
         ctx.pool_map([0, 0], [int(a["chunk_r"][0]), int(b["chunk_r"][0])], [int(a["chunk_c"][0]), int(b["chunk_c"][0])], [ida, idb])
