@@ -502,6 +502,32 @@ int  navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6]);
  * list empty, out[8] = attempts of all retried searches.  Waits for the device. */
 int  navhip_debug_cp_attempts(unsigned long long out[9], int reset);
 
+/* ---- more than one GPU: the tick's exchange step for a C host --------- */
+
+/* One process per GPU, one context per process.  The path shards without any data-path collective
+ * (requests by destination, uid slabs of the velocity step: movement.c:3759-3762) up to ONE exchange per
+ * tick: all ranks need all rows of [new position | velocity] before the next tick's neighbour queries.
+ * These entry points call librccl directly (loaded on first use; RCCL over xGMI on an MI355X node), so
+ * that the reference's C host does not need torch.distributed.
+ *   rank 0 makes the id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by whatever means
+ *   the host has (a file, a socket, an environment variable); every rank then calls navhip_comm_init. */
+#define NAVHIP_COMM_ID_BYTES 128
+int  navhip_comm_unique_id(uint8_t out_id[NAVHIP_COMM_ID_BYTES]);
+int  navhip_comm_init(navhip_ctx *ctx, int rank, int world, const uint8_t id[NAVHIP_COMM_ID_BYTES]);
+void navhip_comm_destroy(navhip_ctx *ctx);
+int  navhip_comm_rank(const navhip_ctx *ctx);     /* -1 without a communicator */
+int  navhip_comm_world(const navhip_ctx *ctx);    /*  0 without a communicator */
+/* The slab results of navhip_agent_step_dev -> every rank, in place, asynchronous on `stream`:
+ * bounds[r] .. bounds[r + 1] = the uid slab rank r stepped (bounds[0] = 0, bounds[world] = n_ents).  ONE
+ * collective: the rank's rows are packed into [n][4] floats (16 B per agent), all-gathered
+ * (ncclAllGather for equal slabs, a group of ncclBroadcast for ragged ones), and the other ranks' rows
+ * unpacked into dev_new_pos_xz / dev_vel_xz. */
+int  navhip_comm_allgather_step_dev(navhip_ctx *ctx, float *dev_new_pos_xz, float *dev_vel_xz,
+                                    const int32_t *bounds, void *stream);
+/* The same for any row array (baked 4 KB flow tiles: row_bytes = 4096, bounds over the request stream). */
+int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_bytes, const int32_t *bounds,
+                                    void *stream);
+
 /* Device spatial index only (bg_ent insert-all + cleanup + inrange_circle, bitmap_grid.h:1376):
  * for each query point the ids within `range`, in the reference's visiting order, capped at
  * maxout.  Host buffers.  Used by the parity tests of the neighbour gather. */

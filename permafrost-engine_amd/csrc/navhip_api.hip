@@ -112,7 +112,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
     ctx->front_stream = nullptr;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
-    ctx->pool = nullptr; ctx->async = nullptr;
+    ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr;
     memset(ctx->ev, 0, sizeof(ctx->ev));
     if(hipSetDevice(device) != hipSuccess
     || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -128,6 +128,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     if(!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    navhip_comm_destroy(ctx);
     navhip_pool_destroy(ctx);
     nh_async_destroy(ctx);
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {

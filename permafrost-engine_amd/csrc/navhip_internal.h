@@ -78,6 +78,7 @@ struct navhip_ctx {
     std::string  last_error;
     struct nh_pool  *pool;     // resident flow-field pool (navhip_pool_*, pool_api.hip) or NULL
     struct nh_async *async;    // state of navhip_agent_step_submit / _poll
+    struct nh_comm  *comm;     // RCCL communicator of navhip_comm_* (comm_api.hip) or NULL
 };
 
 // pool_api.hip <-> navhip_api.hip

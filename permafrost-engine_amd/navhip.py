@@ -95,7 +95,25 @@ _SIGS = {
     "navhip_region_field_id": (C.c_uint64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int]),
     "navhip_set_field_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "navhip_debug_cp_attempts": (C.c_int, [C.c_void_p, C.c_int]),
+    "navhip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "navhip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "navhip_comm_destroy": (None, [C.c_void_p]),
+    "navhip_comm_rank": (C.c_int, [C.c_void_p]),
+    "navhip_comm_world": (C.c_int, [C.c_void_p]),
+    "navhip_comm_allgather_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "navhip_comm_allgather_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0); 128 bytes to hand to the other ranks."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib().navhip_comm_unique_id(buf)
+    if rc != 0:
+        raise NavHipError("navhip_comm_unique_id failed (%d): is librccl present?" % rc)
+    return bytes(buf)
 
 _lib = None
 
@@ -651,6 +669,31 @@ NavContext.pool_create = _ctx_pool_create
 NavContext.pool_build = _ctx_pool_build
 NavContext.pool_put = _ctx_pool_put
 NavContext.pool_get = _ctx_pool_get
+def _ctx_comm_init(self, rank, world, uid):
+    """navhip_comm_init: this context joins the RCCL communicator named by `uid` (comm_unique_id())."""
+    buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+    self._chk(lib().navhip_comm_init(self._h, int(rank), int(world), buf), "navhip_comm_init")
+
+
+def _ctx_comm_allgather_step_dev(self, d_new_pos, d_vel, bounds, stream=None):
+    b = np.ascontiguousarray(bounds, np.int32)
+    self._chk(lib().navhip_comm_allgather_step_dev(self._h, dev_ptr(d_new_pos), dev_ptr(d_vel), _hp(b),
+                                                   C.c_void_p(stream) if stream else None),
+              "navhip_comm_allgather_step_dev")
+
+
+def _ctx_comm_allgather_rows_dev(self, d_rows, row_bytes, bounds, stream=None):
+    b = np.ascontiguousarray(bounds, np.int32)
+    self._chk(lib().navhip_comm_allgather_rows_dev(self._h, dev_ptr(d_rows), int(row_bytes), _hp(b),
+                                                   C.c_void_p(stream) if stream else None),
+              "navhip_comm_allgather_rows_dev")
+
+
+NavContext.comm_init = _ctx_comm_init
+NavContext.comm_destroy = lambda self: lib().navhip_comm_destroy(self._h)
+NavContext.comm_world = lambda self: int(lib().navhip_comm_world(self._h))
+NavContext.comm_allgather_step_dev = _ctx_comm_allgather_step_dev
+NavContext.comm_allgather_rows_dev = _ctx_comm_allgather_rows_dev
 NavContext.pool_contains = _ctx_pool_contains
 NavContext.pool_invalidate = _ctx_pool_invalidate
 NavContext.pool_map = _ctx_pool_map

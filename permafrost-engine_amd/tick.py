@@ -42,7 +42,7 @@ class NavTick:
     def __init__(self, chunk_w=16, fields_per_rank=64, agents_per_rank=100_000, rank=0, world=1,
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
-                 debug_outputs=False, pipeline_fields=False):
+                 debug_outputs=False, pipeline_fields=False, exchange="torch"):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -205,6 +205,16 @@ class NavTick:
         # builds of tick t+1 do not read positions and overlap with it
         self.pipelined = world > 1 and not solo
         self.comm = torch.cuda.Stream(device=self.dev) if self.pipelined else None
+        # exchange = "navhip": the slab all-gather goes through the library's own C entry point
+        # (navhip_comm_allgather_step_dev: librccl called directly -- what a C host uses) instead of
+        # torch.distributed; rank 0's communicator id travels over the process group that launched us
+        self.exchange_mode = exchange if self.pipelined else "none"
+        if self.exchange_mode == "navhip":
+            import torch.distributed as tdist
+            box = [navhip.comm_unique_id() if rank == 0 else None]
+            tdist.broadcast_object_list(box, src=0)
+            self.ctx.comm_init(rank, world, box[0])
+            self._bounds = np.array([b for b, _ in self.agent_bounds] + [self.N], np.int32)
         self.ev_step = torch.cuda.Event()
         self.ev_comm = torch.cuda.Event()
         self._comm_pending = False
@@ -384,6 +394,12 @@ class NavTick:
     def exchange(self):
         """The slab results (new position + velocity) of every rank -> every rank."""
         if not self.pipelined:
+            return
+        if self.exchange_mode == "navhip":
+            self.comm.wait_event(self.ev_step)
+            self.ctx.comm_allgather_step_dev(self.new_pos, self.new_vel, self._bounds, stream=self.comm.cuda_stream)
+            self.ev_comm.record(self.comm)
+            self._comm_pending = True
             return
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ev_step)

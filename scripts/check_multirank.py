@@ -18,8 +18,9 @@ def main():
     rank, world, local = pdist.init()
     mode = "all" if "all" in sys.argv else "auto"
     pipe = "--pipeline-fields" in sys.argv
+    exch = "navhip" if "--exchange-navhip" in sys.argv else "torch"
     kw = dict(chunk_w=4, fields_per_rank=6, agents_per_rank=12000, world=world, device=local)
-    T = tick.NavTick(rank=rank, tile_exchange=mode, pipeline_fields=pipe, **kw)
+    T = tick.NavTick(rank=rank, tile_exchange=mode, pipeline_fields=pipe, exchange=exch, **kw)
     K = 6
     for _ in range(K):
         T.step()
@@ -30,9 +31,9 @@ def main():
     S.sync()
     ok = torch.equal(T.t["pos_xz"], S.t["pos_xz"]) and torch.equal(T.t["vel_xz"], S.t["vel_xz"])
     moved = (S.t["vel_xz"].abs().sum(1) > 0).float().mean().item()
-    print("rank %d/%d backend=%s tile_exchange=%s pipelined=%s fields_ahead=%s: %s (moving fraction %.2f)"
-          % (rank, world, torch.distributed.get_backend() if world > 1 else "-", T.tile_exchange, T.pipelined,
-             T.pipeline_fields, "IDENTICAL to solo" if ok else "MISMATCH", moved), flush=True)
+    print("rank %d/%d backend=%s exchange=%s tile_exchange=%s pipelined=%s fields_ahead=%s: %s (moving fraction %.2f)"
+          % (rank, world, torch.distributed.get_backend() if world > 1 else "-", T.exchange_mode, T.tile_exchange,
+             T.pipelined, T.pipeline_fields, "IDENTICAL to solo" if ok else "MISMATCH", moved), flush=True)
     pdist.barrier()
     T.close(); S.close()
     if torch.distributed.is_initialized():

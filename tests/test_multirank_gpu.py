@@ -47,3 +47,45 @@ def test_four_ranks_over_rccl():
     if torch.cuda.device_count() < 4:
         pytest.skip("needs four devices")
     _run(4, "nccl", ["all", "--pipeline-fields"])
+
+
+def test_c_abi_exchange_single_rank(navlib):
+    """navhip_comm_*: librccl called directly from the library (what a C host uses).  One rank on the one
+    GPU of this box: the communicator comes up, both all-gather forms run and leave the rows as they are."""
+    import numpy as np
+    import torch
+    ctx = navlib.NavContext(2, 2)
+    try:
+        uid = navlib.comm_unique_id()
+        assert len(uid) == navlib.COMM_ID_BYTES and any(uid)
+        assert ctx.comm_world() == 0
+        ctx.comm_init(0, 1, uid)
+        assert ctx.comm_world() == 1
+        n = 1000
+        pos = torch.rand((n, 2), device="cuda")
+        vel = torch.rand((n, 2), device="cuda")
+        p0, v0 = pos.clone(), vel.clone()
+        s = torch.cuda.Stream()
+        ctx.comm_allgather_step_dev(pos, vel, [0, n], stream=s.cuda_stream)
+        tiles = torch.randint(0, 9, (16, 4096), dtype=torch.uint8, device="cuda")
+        t0 = tiles.clone()
+        ctx.comm_allgather_rows_dev(tiles, 4096, [0, 16], stream=s.cuda_stream)
+        s.synchronize()
+        assert torch.equal(pos, p0) and torch.equal(vel, v0) and torch.equal(tiles, t0)
+        with pytest.raises(navlib.NavHipError):
+            ctx.comm_allgather_step_dev(pos, vel, [5, n])        # bounds[0] must be 0
+        ctx.comm_destroy()
+        assert ctx.comm_world() == 0
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("extra", [["--exchange-navhip"], ["--exchange-navhip", "--pipeline-fields"]])
+def test_two_ranks_over_the_c_abi_exchange(extra):
+    """The same two-rank job with the slab all-gather through navhip_comm_allgather_step_dev (RCCL from C)
+    instead of torch.distributed.  RCCL refuses two ranks on one device: needs two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices (RCCL does not run two ranks on one GPU)")
+    out = _run(2, "nccl", extra)
+    assert "exchange=navhip" in out
