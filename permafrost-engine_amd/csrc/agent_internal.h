@@ -10,7 +10,8 @@ struct nh_spatial_scratch {
     int32_t *cell_start;                     // [ncells+1]
     int32_t *tmp_id;                         // [n] cell-sorted uids, arrival order inside a cell
     int32_t *block_sum;                      // [ceil(ncells / NH_SCAN_T)] scan scratch
-    int32_t *box;                            // [4] bounding box of the stepped slab (optional filter)
+    int32_t *box;                            // [2][4] bounding box of the stepped slab (optional filter);
+    int      box_parity;                     //        the two alternate between builds (no memset)
     float4  *recA;                           // [n] pool records
     float2  *recV;                           // [n]
     int32_t *pool_of;                        // [n]

@@ -52,12 +52,14 @@ __constant__ double c_exp2_64[64] = { NH_EXP2_64_TABLE };
 // returned by any of its queries, and leaving such entities out changes neither the order nor the
 // caps of what is returned.  box = {max(-ix), max(ix), max(-iy), max(iy)} over the slab in the
 // x256 fixed point the queries compare in; INT_MIN-initialised.
-__global__ __launch_bounds__(1024) void k_sp_bbox(const float *pos_xz, int begin, int end, int32_t *box)
+// (Four-wave workgroups: a 1024-thread block waits for sixteen free wave slots on one CU -- 26 us beside the
+// field builds, in front of the whole spatial hash.  Two boxes alternate between builds: the build that
+// consumes box[p] (k_sp_count) re-initialises box[p ^ 1] for its successor, so there is no memset.)
+__global__ __launch_bounds__(256) void k_sp_bbox(const float *pos_xz, int begin, int end, int32_t *box)
 {
-    // few, large workgroups striding over the slab: four atomics per workgroup, not per wave
-    __shared__ int32_t part[16][4];
+    __shared__ int32_t part[4][4];
     int32_t v[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
-    for(int i = begin + blockIdx.x * 1024 + threadIdx.x; i < end; i += gridDim.x * 1024) {
+    for(int i = begin + blockIdx.x * 256 + threadIdx.x; i < end; i += gridDim.x * 256) {
         const int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
         v[0] = max(v[0], -ix); v[1] = max(v[1], ix); v[2] = max(v[2], -iy); v[3] = max(v[3], iy);
     }
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(1024) void k_sp_bbox(const float *pos_xz, int begin
     __syncthreads();
     if(threadIdx.x < 4) {
         int32_t m = INT32_MIN;
-        for(int w = 0; w < 16; w++) m = max(m, part[w][threadIdx.x]);
+        for(int w = 0; w < 4; w++) m = max(m, part[w][threadIdx.x]);
         if(m != INT32_MIN) atomicMax(&box[threadIdx.x], m);
     }
 }
@@ -87,9 +89,10 @@ __device__ __forceinline__ bool sp_in_box(const int32_t *box, int32_t ix, int32_
 // cleared at allocation, then by k_sp_scan_add of the previous build).
 __global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz, int n,
                                                   int32_t *ent_cell, int32_t *ent_rank,
-                                                  int32_t *cell_count, const int32_t *box)
+                                                  int32_t *cell_count, const int32_t *box, int32_t *box_next)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
+    if(box_next && i < 4) box_next[i] = INT32_MIN;           // (the box of the NEXT build)
     if(i >= n) return;
     const int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
     if(!sp_in_box(box, ix, iy)) { ent_cell[i] = -1; return; }
@@ -98,16 +101,40 @@ __global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz
     ent_rank[i] = atomicAdd(&cell_count[c], 1);
 }
 
+// A rank that steps a slab only fills the cells its box (+ the query reach) covers; every other cell is
+// empty and is never looked at by a query of the slab either.  The scans skip the blocks of cells that lie
+// entirely in grid rows outside the box: their block sum is 0 and their cell_start entries stay unwritten.
+// (rows [r0, r1] of the box in cells; a block is a run of NH_SCAN_T consecutive cells, row-major)
+__device__ __forceinline__ bool sp_block_outside_box(const nh_grid &G, const int32_t *box, int first_cell, int ncells)
+{
+    if(!box) return false;
+    const int32_t m = SP_MAX_QUERY_R * 256 + 256;
+    const int64_t y0 = -(int64_t)box[2] - m, y1 = (int64_t)box[3] + m;          // fixed-point rows of the box
+    if(y1 < y0) return true;                                                     // empty slab: nothing is inserted
+    // cell rows (clamped like sp_cell_of clamps an element into the grid)
+    const int64_t r0 = min(max((y0 - G.origin_y) >> 12, (int64_t)0), (int64_t)G.grid_h - 1);
+    const int64_t r1 = min(max((y1 - G.origin_y) >> 12, (int64_t)0), (int64_t)G.grid_h - 1);
+    const int last_cell = min(first_cell + NH_SCAN_T, ncells) - 1;
+    // (one row more at the end: a query reads cell_start one past its last cell -- the first cell of the
+    // row after r1)
+    return last_cell < r0 * G.grid_w || first_cell >= (r1 + 2) * G.grid_w;
+}
+
 // exclusive scan of cell_count[0..ncells) -> cell_start[0..ncells], two passes over NH_SCAN_T-cell
 // blocks: (1) block-local exclusive scan + block totals, (2) add the sum of the preceding totals.
 // (Blocks of four waves: a 1024-thread block needs sixteen free wave slots on ONE compute unit at the
 // same moment, and beside the cohesion kernel's stream of one-wave blocks it waited for them for
 // 50 us -- on the critical path of the tick.)
 __global__ __launch_bounds__(NH_SCAN_T) void k_sp_scan_local(const int32_t *cell_count, int32_t *cell_start,
-                                                             int32_t *block_sum, int ncells)
+                                                             int32_t *block_sum, int ncells,
+                                                             nh_grid G, const int32_t *box)
 {
     __shared__ int32_t wsum[NH_SCAN_T / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if(sp_block_outside_box(G, box, blockIdx.x * NH_SCAN_T, ncells)) {
+        if(t == 0) block_sum[blockIdx.x] = 0;
+        return;
+    }
     const int i = blockIdx.x * NH_SCAN_T + t;
     int32_t v = (i < ncells) ? cell_count[i] : 0;
     int32_t incl = v;
@@ -130,10 +157,13 @@ __global__ __launch_bounds__(NH_SCAN_T) void k_sp_scan_local(const int32_t *cell
 }
 
 __global__ __launch_bounds__(NH_SCAN_T) void k_sp_scan_add(int32_t *cell_start, const int32_t *block_sum,
-                                                           int ncells, int nblocks, int32_t *zero_counts)
+                                                           int ncells, int nblocks, int32_t *zero_counts,
+                                                           nh_grid G, const int32_t *box)
 {
     __shared__ int32_t wsum[NH_SCAN_T / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // (the last block always runs: it writes the grand total, cell_start[ncells])
+    if((int)blockIdx.x != nblocks - 1 && sp_block_outside_box(G, box, blockIdx.x * NH_SCAN_T, ncells)) return;
     // sum of the totals of the blocks before this one (and, in the last block, of all blocks)
     int32_t part = 0, all = 0;
     for(int k = t; k < nblocks; k += NH_SCAN_T) {
@@ -383,33 +413,29 @@ __device__ __forceinline__ float cohesion_t_f64(float len)
 
 #define COH_BINS 257       /* 256 Morton blocks + 1 bin for members that take no cohesion force */
 // k_coh_plan: wave_off[f] = number of 16-member (COH_APW) waves of the flocks before f (exclusive
-// scan); one workgroup, chunked.  Two forms:
-//  * bin_start != nullptr (fresh grouping, runs after the bin scan): ceil(active members / 16), the
-//    active members being the bins before the flock's last one;
-//  * bin_start == nullptr (grouping of the previous tick): ceil(flock size / 16) -- every member gets
-//    a lane, whatever its state was when the grouping was made -- and *perm_valid = the grouping
-//    was built for exactly these flock offsets (saved_offs).
+// scan); one workgroup, chunked.  The launch uses the lane grouping the PREVIOUS regrouping left behind
+// (k_coh_bin .. k_coh_scatter: perm[] + its bin prefix bin_start[]) when that was built for exactly these
+// flock offsets and this work range (saved[]: offsets, then work_begin, work_end) -- flock f then gets
+// ceil(members of f inside the work range / 16) waves -- and otherwise (*perm_valid = 0: first tick, flocks
+// or slab changed) the identity over whole flocks: ceil(flock size / 16) waves.
 __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *bin_start, const int32_t *flock_offsets,
-                                                  const int32_t *saved_offs, int n_flocks,
+                                                  const int32_t *saved, int n_flocks, int work_begin, int work_end,
                                                   int32_t *wave_off, int32_t *perm_valid)
 {
     __shared__ int32_t wsum[4];
     __shared__ int32_t carry;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if(t == 0) carry = 0;
-    __syncthreads();
-    bool same = true;
+    bool same = saved[n_flocks + 1] == work_begin && saved[n_flocks + 2] == work_end;
+    for(int f = t; f <= n_flocks; f += 256) same = same && saved[f] == flock_offsets[f];
+    const int valid = __syncthreads_and(same);
     for(int base = 0; base < n_flocks; base += 256) {
         const int f = base + t;
         int32_t v = 0;
         if(f < n_flocks) {
-            if(bin_start) {
-                v = (bin_start[f * COH_BINS + 256] - bin_start[f * COH_BINS] + 15) >> 4;   // COH_APW
-            }else{
-                const int32_t b = flock_offsets[f], e = flock_offsets[f + 1];
-                v = (e - b + 15) >> 4;
-                same = same && saved_offs[f] == b && saved_offs[f + 1] == e;
-            }
+            const int32_t cnt = valid ? bin_start[(f + 1) * COH_BINS] - bin_start[f * COH_BINS]
+                                      : flock_offsets[f + 1] - flock_offsets[f];
+            v = (cnt + 15) >> 4;                                                       // COH_APW
         }
         int32_t incl = v;
 #pragma unroll
@@ -427,11 +453,7 @@ __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *bin_start, cons
         if(t == 255) carry = excl + v;
         __syncthreads();
     }
-    if(t == 0) wave_off[n_flocks] = carry;
-    if(perm_valid) {
-        const int ok = __syncthreads_and(same);
-        if(t == 0) *perm_valid = ok;
-    }
+    if(t == 0) { wave_off[n_flocks] = carry; *perm_valid = valid; }
 }
 
 // k_coh_bin / k_coh_scatter: per-tick lane assignment of the cohesion launch.  Which thread handles
@@ -490,13 +512,19 @@ __device__ __forceinline__ int coh_grouped_add(int32_t *counter, int bin, bool i
     return slot;
 }
 
+// Members outside the work range [work_begin, work_end) -- on a rank that steps one slab of a large job
+// that is most of the snapshot -- leave before the flock search and get no lane at all (bin_of = -1): the
+// grouping holds the members INSIDE the range, flock by flock, active bins first.  saved[]: what the
+// grouping was built for (flock offsets, then the work range).
 __global__ __launch_bounds__(256) void k_coh_bin(nh_step_params P, int32_t *bin_of, int32_t *bin_count,
-                                                 int32_t *saved_offs)
+                                                 int32_t *saved)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
-    if(saved_offs)
-        for(int f = g; f <= P.n_flocks; f += gridDim.x * 256) saved_offs[f] = P.flock_offsets[f];
+    for(int f = g; f <= P.n_flocks; f += gridDim.x * 256) saved[f] = P.flock_offsets[f];
+    if(g == 0) { saved[P.n_flocks + 1] = P.work_begin; saved[P.n_flocks + 2] = P.work_end; }
     if(g >= P.flock_offsets[P.n_flocks]) return;
+    const int m = P.flock_members[g];
+    if(m < P.work_begin || m >= P.work_end) { bin_of[g] = -1; return; }
     int f;
     const int bin = coh_bin_of(P, g, &f);
     bin_of[g] = bin;
@@ -510,6 +538,7 @@ __global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int
     const int g = blockIdx.x * 256 + threadIdx.x;
     if(g >= P.flock_offsets[P.n_flocks]) return;
     const int bin = bin_of[g];
+    if(bin < 0) return;                                   // (outside the work range: no lane)
     perm[bin_start[bin] + coh_grouped_add(bin_fill, bin, bin % COH_BINS == 256)] = g;
 }
 
@@ -637,9 +666,12 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
     }
 }
 
+// perm / bin_start: the lane grouping of the previous regrouping (the members inside the work range, flock f's
+// at perm[bin_start[f * COH_BINS] .. bin_start[(f + 1) * COH_BINS])); *perm_valid = 0: the identity over the
+// whole flock instead (k_coh_plan).
 __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off,
                                                  const int32_t *perm, const int32_t *perm_valid,
-                                                 float *coh_xz)
+                                                 float *coh_xz, const int32_t *bin_start)
 {
     __shared__ double tab[64];
     // the members of the current tile that survive the box test, in member order (+ carry-over):
@@ -662,11 +694,13 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     }
     const float scaled_max_force = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
-    const int gp = b + (wv - wave_off[f]) * COH_APW + (t >> 2);
-    const bool mine = gp < e;
+    const bool use_perm = *perm_valid != 0;
+    const int pb = use_perm ? bin_start[f * COH_BINS] : b;
+    const int pe = use_perm ? bin_start[(f + 1) * COH_BINS] : e;
+    const int gp = pb + (wv - wave_off[f]) * COH_APW + (t >> 2);
+    const bool mine = gp < pe;
     // CSR entry of this quad's member (any permutation of the flock's entries serves; a grouping
-    // made for other flock offsets is ignored)
-    const bool use_perm = !perm_valid || *perm_valid != 0;
+    // made for other flock offsets or another work range is ignored)
     const int g = mine ? (use_perm ? perm[gp] : gp) : -1;
     const int uid = mine ? P.flock_members[g] : -1;
     bool act = mine && uid >= P.work_begin && uid < P.work_end;
@@ -885,10 +919,13 @@ __global__ __launch_bounds__(256) void k_agent_nbr(nh_grid G, int npool_max, nh_
     if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
     __syncthreads();
     const int grp_i = threadIdx.x >> 4;
-    const int k = blockIdx.x * 16 + grp_i;
-    if(k >= npool_max || k >= G.cell_start[G.grid_w * G.grid_h]) return;
-    if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) return;         // no work item (or outside the slab)
-    nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
+    // (the launch is sized by the slab a rank steps, the pool by what its queries can reach: a few rows
+    // take a second slot; with the whole snapshot stepped every row has exactly one)
+    const int npool = min(npool_max, G.cell_start[G.grid_w * G.grid_h]);
+    for(int k = blockIdx.x * 16 + grp_i; k < npool; k += gridDim.x * 16) {
+        if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) continue;   // no work item (or outside the slab)
+        nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
+    }
 }
 
 // wave-aggregated append to a device work list: one atomic per wave and list, on the wave's sub-list
@@ -1372,22 +1409,24 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
     const int n = G.n, ncells = G.grid_w * G.grid_h;
     // a strict sub-range of the entities is stepped: hash only what its queries can reach
     const int32_t *box = nullptr;
+    int32_t *box_next = nullptr;
     if(S.box && (slab_begin > 0 || slab_end < n)) {
-        hipMemsetD32Async((hipDeviceptr_t)S.box, (int)0x80000000, 4, s);
+        int32_t *mine = S.box + 4 * (S.box_parity & 1);
+        box_next = S.box + 4 * ((S.box_parity & 1) ^ 1);
         if(slab_end > slab_begin)
-            hipLaunchKernelGGL(k_sp_bbox, dim3(min(64, (slab_end - slab_begin + 1023) / 1024)), dim3(1024), 0, s,
-                               d_pos_xz, slab_begin, slab_end, S.box);
-        box = S.box;
+            hipLaunchKernelGGL(k_sp_bbox, dim3(min(128, (slab_end - slab_begin + 255) / 256)), dim3(256), 0, s,
+                               d_pos_xz, slab_begin, slab_end, mine);
+        box = mine;
     }
     G.cell_start = S.cell_start; G.recA = S.recA; G.recV = S.recV; G.pool_of = S.pool_of;
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
-                           S.ent_cell, S.ent_rank, S.cell_count, box);
+                           S.ent_cell, S.ent_rank, S.cell_count, box, box_next);
     const int nblocks = (ncells + NH_SCAN_T - 1) / NH_SCAN_T;
     hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(NH_SCAN_T), 0, s, S.cell_count, S.cell_start,
-                       S.block_sum, ncells);
+                       S.block_sum, ncells, G, box);
     hipLaunchKernelGGL(k_sp_scan_add, dim3(nblocks), dim3(NH_SCAN_T), 0, s, S.cell_start, S.block_sum, ncells,
-                       nblocks, S.cell_count);
+                       nblocks, S.cell_count, G, box);
     if(n > 0) {
         hipLaunchKernelGGL(k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, S.ent_cell, S.ent_rank, n,
                            S.cell_start, S.tmp_id);
@@ -1400,7 +1439,10 @@ void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t 
 {
     if(P.n_ents > 0 && P.work_end > P.work_begin) {
         const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
-        hipLaunchKernelGGL(k_agent_nbr, dim3((P.n_ents + 15) / 16), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
+        // rows for the slab + a quarter (its halo in the pool); never more than one per entity
+        const int slab = P.work_end - P.work_begin;
+        const int rows = (int)min((long long)P.n_ents, (long long)slab + slab / 4 + 1024);
+        hipLaunchKernelGGL(k_agent_nbr, dim3((rows + 15) / 16), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
     }
 }
 
@@ -1426,14 +1468,14 @@ static coh_scratch coh_layout(int32_t *scratch, int n_flocks, int n_members)
     C.perm[0] = C.bin_of + n_members;
     C.perm[1] = C.perm[0] + n_members;
     C.saved[0] = C.perm[1] + n_members;
-    C.saved[1] = C.saved[0] + n_flocks + 1;
-    C.valid = C.saved[1] + n_flocks + 1;
+    C.saved[1] = C.saved[0] + n_flocks + 3;
+    C.valid = C.saved[1] + n_flocks + 3;
     return C;
 }
 size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members)
 {
     const size_t nb = (size_t)n_flocks * COH_BINS;
-    return sizeof(int32_t) * (3 * ((size_t)n_flocks + 1) + 3 * nb + 1 + (nb + NH_SCAN_T - 1) / NH_SCAN_T
+    return sizeof(int32_t) * (3 * ((size_t)n_flocks + 3) + 3 * nb + 1 + (nb + NH_SCAN_T - 1) / NH_SCAN_T
                               + 3 * (size_t)n_members + 1);
 }
 
@@ -1441,7 +1483,7 @@ size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members)
 void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s)
 {
     const coh_scratch C = coh_layout(scratch, n_flocks, n_members);
-    hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 1), s);
+    hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 3), s);
 }
 
 __global__ void k_zero_i32(int32_t *p, int n)
@@ -1450,60 +1492,48 @@ __global__ void k_zero_i32(int32_t *p, int n)
 }
 
 // the counting sort that regroups the lanes of every flock (k_coh_bin .. k_coh_scatter) into perm[which]
-static void coh_regroup(const nh_step_params &P, const coh_scratch &C, int which, bool plan_from_bins,
-                        hipStream_t s)
+static void coh_regroup(const nh_step_params &P, const coh_scratch &C, int which, hipStream_t s)
 {
     // (one launch: hipMemsetAsync of an unaligned range is up to three fill kernels)
     hipLaunchKernelGGL(k_zero_i32, dim3(min(64, (2 * C.nb + 255) / 256)), dim3(256), 0, s, C.bin_count, 2 * C.nb);
     const int gm = (P.n_members + 255) / 256;
     hipLaunchKernelGGL(k_coh_bin, dim3(gm), dim3(256), 0, s, P, C.bin_of, C.bin_count, C.saved[which]);
     hipLaunchKernelGGL(k_sp_scan_local, dim3(C.nblocks), dim3(NH_SCAN_T), 0, s, C.bin_count, C.bin_start,
-                       C.block_sum, C.nb);
+                       C.block_sum, C.nb, P.grid, (const int32_t*)nullptr);
     hipLaunchKernelGGL(k_sp_scan_add, dim3(C.nblocks), dim3(NH_SCAN_T), 0, s, C.bin_start, C.block_sum, C.nb,
-                       C.nblocks, (int32_t*)nullptr);
-    if(plan_from_bins)
-        hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start,
-                           P.flock_offsets, (const int32_t*)nullptr, P.n_flocks, C.wave_off, (int32_t*)nullptr);
+                       C.nblocks, (int32_t*)nullptr, P.grid, (const int32_t*)nullptr);
     hipLaunchKernelGGL(k_coh_scatter, dim3(gm), dim3(256), 0, s, P, C.bin_of, C.bin_start, C.bin_fill,
                        C.perm[which]);
 }
 
 // The cohesion term of one tick.  *parity (in/out, kept by the context) = which of the two perm
 // buffers the NEXT regrouping writes.
-//  * A rank that steps only a slab regroups first (members outside the slab must not occupy lanes,
-//    and only a fresh count says how many waves that takes), then runs k_cohesion.
-//  * When every entity is stepped, k_cohesion starts at once on the grouping the PREVIOUS tick left
-//    behind (any permutation of a flock's entries is valid; the grouping only has to be spatially
-//    coherent, and agents move ~1 wu per tick; k_coh_plan checks that it was built for these flock
-//    offsets, else the identity is used), and the regrouping for the next tick follows it --
-//    nh_launch_cohesion_regroup, which the caller launches AFTER recording its "cohesion done"
-//    event: five dependent small launches leave the tick's critical path.
+// k_cohesion starts at once on the grouping the PREVIOUS tick left behind (any permutation of a flock's
+// entries is valid; the grouping only has to be spatially coherent, and agents move ~1 wu per tick;
+// k_coh_plan checks that it was built for these flock offsets and this work range, else the identity is
+// used), and the regrouping for the next tick follows it -- nh_launch_cohesion_regroup, which the caller
+// launches AFTER recording its "cohesion done" event: five dependent small launches leave the tick's
+// critical path.  That holds for a rank that steps a slab as well: its grouping holds the slab's members
+// only (k_coh_bin), so the members of the other ranks occupy no lanes.
 bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, int *parity, hipStream_t s)
 {
     if(!(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0)) return false;
     const coh_scratch C = coh_layout(scratch, P.n_flocks, P.n_members);
-    // upper bound of the number of 16-member (COH_APW) waves; surplus waves exit at once
+    // upper bound of the number of 16-member (COH_APW) waves (the identity fallback needs a lane per
+    // member of the whole snapshot); surplus waves exit at once
     const int nwaves = (P.n_members + 15) / 16 + P.n_flocks;
-    const bool whole = P.work_begin == 0 && P.work_end == P.n_ents;
-    if(!whole) {
-        coh_regroup(P, C, *parity, true, s);
-        hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
-                           (const int32_t*)C.perm[*parity], (const int32_t*)nullptr, d_coh);
-        *parity ^= 1;
-        return false;
-    }
     const int prev = *parity ^ 1;
-    hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)nullptr, P.flock_offsets,
-                       (const int32_t*)C.saved[prev], P.n_flocks, C.wave_off, C.valid);
+    hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start, P.flock_offsets,
+                       (const int32_t*)C.saved[prev], P.n_flocks, P.work_begin, P.work_end, C.wave_off, C.valid);
     hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
-                       (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh);
+                       (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start);
     return true;                                  // caller: record the event, then ..._regroup
 }
 
 void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *parity, hipStream_t s)
 {
     const coh_scratch C = coh_layout(scratch, P.n_flocks, P.n_members);
-    coh_regroup(P, C, *parity, false, s);
+    coh_regroup(P, C, *parity, s);
     *parity ^= 1;
 }
 // entries a sub-list can receive: its producers are the k_agent_mid waves with index = sub (mod

@@ -112,7 +112,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
     ctx->front_stream = nullptr;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
-    ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr;
+    ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->sp_builds = 0;
     memset(ctx->ev, 0, sizeof(ctx->ev));
     if(hipSetDevice(device) != hipSuccess
     || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -720,19 +720,25 @@ static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hip
     const size_t n = (size_t)w->n_ents, ncells = (size_t)g->grid_w * g->grid_h;
     // ent_cell, ent_rank, cell_count, cell_start, tmp_id, block_sum, box, recA, recV, pool_of
     const size_t bytes[10] = {4 * n, 4 * n, 4 * ncells, 4 * (ncells + 1), 4 * n, 4 * ((ncells + NH_SCAN_T - 1) / NH_SCAN_T),
-                              16, 16 * n, 8 * n, 4 * n};
+                              32, 16 * n, 8 * n, 4 * n};
     for(int i = 0; i < 10; i++) {
+        const void *old = ctx->sp[i].p;
         int rc = (i == 2) ? ensure_zeroed(ctx, ctx->sp[i], bytes[i], s) : ensure_buf(ctx, ctx->sp[i], bytes[i]);
         if(rc) return rc;
+        // the two slab boxes start empty (INT_MIN); afterwards every build re-initialises its successor's
+        if(i == 6 && ctx->sp[i].p != old)
+            HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->sp[i].p, (int)0x80000000, 8, s));
     }
     nh_spatial_scratch S = {(int32_t*)ctx->sp[0].p, (int32_t*)ctx->sp[1].p, (int32_t*)ctx->sp[2].p,
                             (int32_t*)ctx->sp[3].p, (int32_t*)ctx->sp[4].p, (int32_t*)ctx->sp[5].p,
-                            (int32_t*)ctx->sp[6].p, (float4*)ctx->sp[7].p, (float2*)ctx->sp[8].p,
+                            (int32_t*)ctx->sp[6].p, 0, (float4*)ctx->sp[7].p, (float2*)ctx->sp[8].p,
                             (int32_t*)ctx->sp[9].p,
                             {w->vel_xz, w->radius, w->flags, w->state, w->arrival_sink_xz, w->arrival_flags}};
     if(!with_records) S.src = nh_pack_src{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (positions only)
     g->n = w->n_ents;
     if(slab_end < 0) slab_end = w->n_ents;
+    // (the two slab boxes alternate between the builds that USE one: such a build cleans the other)
+    if(slab_begin > 0 || slab_end < w->n_ents) S.box_parity = (int)(ctx->sp_builds++ & 1u);
     nh_launch_spatial_build(*g, w->pos_xz, S, slab_begin, slab_end, s);
     return NAVHIP_OK;
 }

@@ -46,6 +46,7 @@ struct navhip_ctx {
     struct buf { void *p; size_t cap; };
     buf          sp[10];       // spatial hash: ent_cell, ent_rank, cell_count, cell_start, tmp_id,
                                //               block_sum, slab box, recA, recV, pool_of
+    unsigned     sp_builds;    // spatial-hash builds so far: parity selects the slab box of a build
     buf          nbr[3];       // neighbour walk: separation force, counts, neighbour lists
     buf          midrec;       // per-entity record k_agent_mid leaves for the work-list consumers
     buf          wl[2];        // work lists: 2 x NH_WL_COUNT counters (alternating), ids
