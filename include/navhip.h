@@ -407,6 +407,19 @@ typedef struct navhip_world {
      * max_speed (MOVE_CMD_SET_MAX_SPEED, movement.c:3226) and flags (ENTITY_FLAG_GARRISONED is toggled
      * outside movement.c). */
     uint32_t static_epoch;
+    /* Region fields sampled on the device: N_DesiredEnemySeekVelocity (nav.c:3603) for STATE_SEEK_ENEMIES and
+     * N_DesiredSurroundVelocity (nav.c:3687) for STATE_SURROUND_ENTITY entities that use the surround field
+     * (ent_desired_velocity, movement.c:1478-1500).  Those return N_FlowDir of the ONE tile under the entity
+     * in the chunk field of an ENEMIES / ENTITY target (navhip_build_region_fields, out_mode 1) -- no blend.
+     * region_row[i] >= 0 names the entity's mapping row: a row of region_field_slot ([rows][chunks] slots of
+     * field_pool, -1 = not cached), or -- with n_field_slots = NAVHIP_POOL_RESIDENT -- a row of the resident
+     * pool's mapping table (navhip_pool_map; rows n_flocks.. are free for this); -1 = the entity samples its
+     * flock's point-seek fields as above.  Like there, only entries whose vdes_xz is absent (NULL array or
+     * NaN x) are sampled; a missing field / FD_NONE under the entity (the repair builds of nav.c:3652-3683,
+     * :3733-3760) is reported as NAVHIP_ST_FIELD_MISS / _NONE.  Both NULL: no region sampling. */
+    const int32_t  *region_row;        /* [n] */
+    const int32_t  *region_field_slot; /* [n_region_rows][chunks] */
+    int32_t  n_region_rows;
 } navhip_world;
 #define NAVHIP_LOS_LOOKUP 0xff
 
@@ -527,6 +540,18 @@ int  navhip_comm_allgather_step_dev(navhip_ctx *ctx, float *dev_new_pos_xz, floa
 /* The same for any row array (baked 4 KB flow tiles: row_bytes = 4096, bounds over the request stream). */
 int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_bytes, const int32_t *bounds,
                                     void *stream);
+
+/* N_DesiredGroupArrivalVelocity (nav.c:3561) for nq points: the direction under each point in the chunk
+ * field of mapping row rows[q] (region_field_slot / field_pool as in navhip_world; resident pool: pass
+ * region_field_slot = field_pool = NULL), and whether that tile is a sink inside the zone's disc
+ * (out_at_slot; centre_abs = zone centre in absolute nav tiles [nq][2] (row, column), radius[nq] in tiles).
+ * out_dir[q]: 0..8 = enum flow_dir, 0xff = no field cached for the point's chunk (the reference returns
+ * false).  Host buffers.  The arrival overlay's decisions around it (G_Arrival_DesiredVelocity,
+ * arrival.c:862) stay with the host. */
+int  navhip_region_lookup(navhip_ctx *ctx, int nq, const float *pos_xz, const int32_t *rows,
+                          const int32_t *region_field_slot, int n_region_rows, const uint8_t *field_pool,
+                          int n_field_slots, const int32_t *centre_abs, const int32_t *radius,
+                          float map_pos_x, float map_pos_z, uint8_t *out_dir, uint8_t *out_at_slot);
 
 /* Device spatial index only (bg_ent insert-all + cleanup + inrange_circle, bitmap_grid.h:1376):
  * for each query point the ids within `range`, in the reference's visiting order, capped at

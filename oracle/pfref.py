@@ -84,6 +84,7 @@ def lib():
         L.pfref_region_field_id.argtypes = [C.c_int] * 4 + [C.c_uint32, C.c_int, C.c_int]
         L.pfref_game_load.argtypes = [C.c_float] * 4 + [C.c_int] + [C.c_void_p] * 4
         L.pfref_async_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfref_desired_region_velocities.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pfref_cached_field_by_id.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.pfref_hip_async_stats.argtypes = [C.c_void_p]
         L.pfref_hip_los_stats.argtypes = [C.c_void_p]
@@ -380,6 +381,16 @@ class RefNav:
             assert lib().pfref_cached_field_by_id(self._h, int(i), _p(d)), hex(int(i))
             out[int(i)] = d
         return out
+
+    def desired_region_velocities(self, reqs):
+        """N_DesiredEnemySeekVelocity / N_DesiredSurroundVelocity / N_DesiredGroupArrivalVelocity per agent
+        (ASYNC_REQ_DTYPE records; kind 2 carries the zone centre as float bits in ent / faction_id).
+        Returns (vel [n,2] f32, flags [n] u8: bit 0 lookup ok, bit 1 at_slot)."""
+        reqs = np.ascontiguousarray(reqs, ASYNC_REQ_DTYPE)
+        out = np.zeros((len(reqs), 2), np.float32)
+        fl = np.zeros(len(reqs), np.uint8)
+        lib().pfref_desired_region_velocities(self._h, len(reqs), _p(reqs), _p(out), _p(fl))
+        return out, fl
 
     @staticmethod
     def hip_seam_stats():

@@ -188,6 +188,10 @@ typedef struct pfref_async_req {
 /* compute_async_fields of one tick (movement.c:4149-4164); returns the number of jobs */
 int  pfref_async_batch(pfref_nav *nav, int n, const pfref_async_req *reqs, uint64_t *out_ids, int max_ids);
 int  pfref_cached_field_by_id(pfref_nav *nav, uint64_t ffid, uint8_t *out_dirs);
+/* N_DesiredEnemySeekVelocity / N_DesiredSurroundVelocity / N_DesiredGroupArrivalVelocity (nav.c:3603,3687,3561)
+ * per agent (kind 2: the zone centre in the bits of ent (x) and faction_id (z)); out_flags bit 0: the
+ * group-arrival lookup returned true, bit 1: at_slot */
+void pfref_desired_region_velocities(pfref_nav *nav, int n, const pfref_async_req *reqs, float *out_xz, uint8_t *out_flags);
 void pfref_hip_async_stats(long out[3]);      /* device jobs, device batches, jobs left to the CPU builders */
 void pfref_hip_los_stats(long out[2]);        /* device LOS fields, device batches */
 void pfref_hip_blockers_stats(long out[2]);   /* circles flushed, device batches */

@@ -529,3 +529,32 @@ void pfref_nav_dirty_chunks(pfref_nav *nav, int layer, uint8_t *flags)
         flags[(key >> 16) * priv->width + (key & 0xffff)] = 1;
     }
 }
+
+
+/* N_DesiredEnemySeekVelocity (nav.c:3603), N_DesiredSurroundVelocity (:3687), N_DesiredGroupArrivalVelocity
+ * (:3561) for n agents; kind as in pfref_async_req.  out_xz[n][2]; out_flags[n]: bit 0 = the group-arrival
+ * lookup found a field (its return value), bit 1 = at_slot */
+void pfref_desired_region_velocities(pfref_nav *nav, int n, const pfref_async_req *reqs, float *out_xz, uint8_t *out_flags)
+{
+    struct nav_private *priv = &nav->priv;
+    for(int i = 0; i < n; i++) {
+        const pfref_async_req *r = &reqs[i];
+        vec2_t xz = (vec2_t){r->x, r->z}, v = (vec2_t){0.0f, 0.0f};
+        out_flags[i] = 0;
+        switch(r->kind) {
+        case 0: v = N_DesiredEnemySeekVelocity(xz, priv, r->layer, nav->map_pos, r->faction_id); break;
+        case 1: v = N_DesiredSurroundVelocity(xz, priv, r->layer, nav->map_pos, r->ent, r->faction_id); break;
+        case 2: {
+            bool at_slot = false;
+            /* (x, z) = the agent; the zone centre travels in (ent as float bits, radius): see pfref.py */
+            vec2_t centre;
+            memcpy(&centre.x, &r->ent, sizeof(float));
+            memcpy(&centre.z, &r->faction_id, sizeof(float));
+            bool ok = N_DesiredGroupArrivalVelocity(xz, priv, r->layer, nav->map_pos, centre, (uint16_t)r->radius, &v, &at_slot);
+            out_flags[i] = (ok ? 1 : 0) | (at_slot ? 2 : 0);
+            break;
+        }
+        }
+        out_xz[2 * i] = v.x; out_xz[2 * i + 1] = v.z;
+    }
+}

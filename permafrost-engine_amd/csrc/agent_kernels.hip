@@ -1317,6 +1317,42 @@ __global__ __launch_bounds__(256) void k_spatial_query(nh_grid G, const float *q
     if(lane == 0) out_counts[q] = n;
 }
 
+// N_DesiredGroupArrivalVelocity (nav.c:3561): direction under each point in the chunk field of its mapping
+// row + "the tile is a sink inside the zone's disc" (:3596-3600)
+__global__ __launch_bounds__(256) void k_region_lookup(nh_step_params P, int nq, const float *pos, const int32_t *rows,
+                                                       const int32_t *centre_abs, const int32_t *radius,
+                                                       uint8_t *out_dir, uint8_t *out_at_slot)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if(q >= nq) return;
+    uint8_t dir = 0xff, at = 0;
+    tiledesc t;
+    const int row = rows[q];
+    if(row >= 0 && tile_for_point(P, pos[2 * q], pos[2 * q + 1], t)) {
+        const int slot = P.region_field_slot[(size_t)row * (P.map.w * P.map.h) + t.chunk_r * P.map.w + t.chunk_c];
+        if(slot >= 0) {
+            dir = P.field_pool[((size_t)slot << 12) + t.tile_r * 64 + t.tile_c] & 0xf;
+            if(dir == NAVHIP_FD_NONE && centre_abs) {
+                // M_Tile_Distance(res, &centre_tile, &tile, &dr, &dc), tile.c:414
+                const int dr = (t.chunk_r * 64 + t.tile_r) - centre_abs[2 * q];
+                const int dc = (t.chunk_c * 64 + t.tile_c) - centre_abs[2 * q + 1];
+                at = (dr * dr + dc * dc) <= radius[q] * radius[q];
+            }
+        }
+    }
+    out_dir[q] = dir;
+    if(out_at_slot) out_at_slot[q] = at;
+}
+
+void nh_launch_region_lookup(const nh_step_params &P, int nq, const float *d_pos, const int32_t *d_rows,
+                             const int32_t *d_centre_abs, const int32_t *d_radius, uint8_t *d_dir, uint8_t *d_at_slot,
+                             hipStream_t s)
+{
+    if(nq > 0)
+        hipLaunchKernelGGL(k_region_lookup, dim3((nq + 255) / 256), dim3(256), 0, s, P, nq, d_pos, d_rows, d_centre_abs,
+                           d_radius, d_dir, d_at_slot);
+}
+
 // G_ClearPath_NewVelocity for nq independent problems on groups of GW lanes (GW = 64: any problem;
 // GW = 16: n_dyn + n_stat <= 16 -- the row path of the agent step)
 template <int GW>

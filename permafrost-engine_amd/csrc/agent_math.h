@@ -275,6 +275,26 @@ NH_FN v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &statu
     return vnormal(acc);
 }
 
+// N_DesiredEnemySeekVelocity (nav.c:3603) / N_DesiredSurroundVelocity (nav.c:3687), cache-hit path:
+// N_FlowDir of the tile under the entity in the chunk field of its mapping row -- no blend.  A missing
+// field and FD_NONE under the entity (the repair builds of :3652-3683, :3733-3760) are reported.
+NH_FN v2 sample_region(const nh_step_params &P, int row, v2 pos, uint32_t &status)
+{
+    tiledesc t;
+    if(!P.region_field_slot || !P.field_pool || !tile_for_point(P, pos.x, pos.z, t)) {
+        status |= NAVHIP_ST_FIELD_MISS;
+        return mkv(0.0f, 0.0f);
+    }
+    const int slot = P.region_field_slot[(size_t)row * (P.map.w * P.map.h) + t.chunk_r * P.map.w + t.chunk_c];
+    if(slot < 0) {
+        status |= NAVHIP_ST_FIELD_MISS;
+        return mkv(0.0f, 0.0f);
+    }
+    const int dir = P.field_pool[((size_t)slot << 12) + t.tile_r * 64 + t.tile_c] & 0xf;
+    if(dir == NAVHIP_FD_NONE) status |= NAVHIP_ST_FIELD_NONE;
+    return flow_dir_vec(dir);
+}
+
 // move_work_in.ent_des_v: host supplied, or sampled from the device field pool (vdes_xz == NULL or
 // a NaN entry)
 NH_FN v2 load_vdes(const nh_step_params &P, int uid, int flock, v2 me, uint32_t &status)
@@ -282,6 +302,10 @@ NH_FN v2 load_vdes(const nh_step_params &P, int uid, int flock, v2 me, uint32_t 
     if(P.vdes_xz) {
         v2 v = mkv(P.vdes_xz[2 * uid], P.vdes_xz[2 * uid + 1]);
         if(v.x == v.x) return v;
+    }
+    if(P.region_row) {
+        const int row = P.region_row[uid];
+        if(row >= 0) return sample_region(P, row, me, status);
     }
     return sample_flow(P, flock, me, status);
 }

@@ -67,6 +67,8 @@ struct nh_step_params {
     const uint8_t  *los_pool;        // per-agent has_dest_los from the device LOS pool (optional)
     const int32_t  *flock_los_slot;
     const float    *los_pos_xz;
+    const int32_t  *region_row;      // per-entity mapping row of a region field (enemy seek / surround), -1 = none
+    const int32_t  *region_field_slot;
 };
 
 struct nh_step_outs {

@@ -813,6 +813,18 @@ static int step_fill_params(navhip_ctx *ctx, const navhip_world *w, nh_step_para
     P.arrival_sink_xz = w->arrival_sink_xz; P.arrival_flags = w->arrival_flags;
     P.los_pool = w->los_pool; P.flock_los_slot = w->flock_los_slot; P.los_pos_xz = w->los_pos_xz;
     if((P.los_pool != nullptr) != (P.flock_los_slot != nullptr)) return NAVHIP_ERR_INVALID;
+    P.region_row = w->region_row; P.region_field_slot = w->region_field_slot;
+    if(P.region_row && w->n_field_slots == NAVHIP_POOL_RESIDENT) {
+        // rows of the resident pool's mapping table (the caller keeps its region rows behind the flock rows)
+        if(w->n_region_rows > nh_pool_dests(ctx)) {
+            ctx->last_error = "agent step: more region rows than the resident pool's mapping table has";
+            return NAVHIP_ERR_INVALID;
+        }
+        P.region_field_slot = nh_pool_map(ctx);
+    }else if(P.region_row && !P.region_field_slot) {
+        ctx->last_error = "agent step: region_row given without region_field_slot";
+        return NAVHIP_ERR_INVALID;
+    }
     if(P.form_ready && (!P.cell_pos_xz || !P.form_cohesion_xz || !P.form_align_xz || !P.form_drag_xz)) {
         ctx->last_error = "agent step: form_ready given without the other formation arrays";
         return NAVHIP_ERR_INVALID;
@@ -1103,6 +1115,9 @@ static int stage_world(navhip_ctx *ctx, const navhip_world *w, navhip_world *d, 
     ST(36, arrival_sink_xz, n * 8); ST(37, arrival_flags, n);
     ST(38, los_pool, (size_t)(w->n_los_slots > 0 ? w->n_los_slots : 0) * NH_CELLS);
     ST(39, flock_los_slot, F * nchunks * 4); ST(40, los_pos_xz, n * 8);
+    ST(46, region_row, n * 4);
+    if(w->n_field_slots != NAVHIP_POOL_RESIDENT)
+        ST(47, region_field_slot, (size_t)(w->n_region_rows > 0 ? w->n_region_rows : 0) * nchunks * 4);
 #undef ST
     return rc;
 }
@@ -1142,6 +1157,51 @@ int navhip_agent_step(navhip_ctx *ctx, const navhip_world *w, const navhip_step_
         HIPCHK(ctx, hipMemcpyAsync((char*)o.host + b * row, (char*)*o.dev + b * row, (e - b) * row,
                                    hipMemcpyDeviceToHost, s));
     }
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+int navhip_region_lookup(navhip_ctx *ctx, int nq, const float *pos_xz, const int32_t *rows,
+                         const int32_t *region_field_slot, int n_region_rows, const uint8_t *field_pool,
+                         int n_field_slots, const int32_t *centre_abs, const int32_t *radius,
+                         float map_pos_x, float map_pos_z, uint8_t *out_dir, uint8_t *out_at_slot)
+{
+    if(!ctx || nq < 0 || (nq > 0 && (!pos_xz || !rows || !out_dir))) return NAVHIP_ERR_INVALID;
+    if((out_at_slot != nullptr) && (!centre_abs || !radius)) return NAVHIP_ERR_INVALID;
+    if(nq == 0) return NAVHIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    nh_step_params P;
+    memset(&P, 0, sizeof(P));
+    fill_map_view(ctx, &P.map);
+    P.map_x = map_pos_x; P.map_z = map_pos_z;
+    const size_t nchunks = (size_t)ctx->nchunks;
+    const bool resident = !region_field_slot && !field_pool;
+    if(resident) {
+        if(!ctx->pool) { ctx->last_error = "navhip_region_lookup: no table given and no resident pool"; return NAVHIP_ERR_INVALID; }
+        P.region_field_slot = nh_pool_map(ctx); P.field_pool = nh_pool_fields(ctx);
+        n_region_rows = nh_pool_dests(ctx);
+    }else{
+        if(!region_field_slot || !field_pool || n_region_rows < 1 || n_field_slots < 1) return NAVHIP_ERR_INVALID;
+        int rc = stage_in(ctx, 47, region_field_slot, (size_t)n_region_rows * nchunks * 4, (const void**)&P.region_field_slot, s);
+        if(!rc) rc = stage_in(ctx, 14, field_pool, (size_t)n_field_slots * NH_CELLS, (const void**)&P.field_pool, s);
+        if(rc) return rc;
+        nh_async_invalidate_static(ctx);
+    }
+    for(int q = 0; q < nq; q++)
+        if(rows[q] < -1 || rows[q] >= n_region_rows) return NAVHIP_ERR_INVALID;
+    const float *d_pos; const int32_t *d_rows, *d_cen = nullptr, *d_rad = nullptr;
+    int rc = stage_in(ctx, 20, pos_xz, (size_t)nq * 8, (const void**)&d_pos, s);
+    if(!rc) rc = stage_in(ctx, 21, rows, (size_t)nq * 4, (const void**)&d_rows, s);
+    if(!rc && out_at_slot) rc = stage_in(ctx, 22, centre_abs, (size_t)nq * 8, (const void**)&d_cen, s);
+    if(!rc && out_at_slot) rc = stage_in(ctx, 23, radius, (size_t)nq * 4, (const void**)&d_rad, s);
+    if(!rc) rc = ensure_buf(ctx, ctx->stage[32], (size_t)nq * 2);
+    if(rc) return rc;
+    uint8_t *d_out = (uint8_t*)ctx->stage[32].p;
+    nh_launch_region_lookup(P, nq, d_pos, d_rows, d_cen, d_rad, d_out, d_out + nq, s);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out_dir, d_out, (size_t)nq, hipMemcpyDeviceToHost, s));
+    if(out_at_slot) HIPCHK(ctx, hipMemcpyAsync(out_at_slot, d_out + nq, (size_t)nq, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;
 }

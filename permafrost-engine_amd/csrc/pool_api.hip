@@ -499,7 +499,11 @@ int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhi
         {w->los_pool, (size_t)(w->n_los_slots > 0 ? w->n_los_slots : 0) * NH_CELLS, 38, (const void**)&d.los_pool},
         {w->flock_los_slot, F * (size_t)ctx->nchunks * 4, 39, (const void**)&d.flock_los_slot},
         {w->los_pos_xz, n * 8, 40, (const void**)&d.los_pos_xz},
+        {w->region_row, n * 4, 46, (const void**)&d.region_row},
     };
+    if(!resident)
+        items.push_back({w->region_field_slot, (size_t)(w->n_region_rows > 0 ? w->n_region_rows : 0) * (size_t)ctx->nchunks * 4,
+                         47, (const void**)&d.region_field_slot});
     if(!resident) {
         items.push_back({w->flock_field_slot, F * (size_t)ctx->nchunks * 4, 13, (const void**)&d.flock_field_slot});
         items.push_back({w->field_pool, (size_t)(w->n_field_slots > 0 ? w->n_field_slots : 0) * NH_CELLS, 14,

@@ -343,7 +343,8 @@ class World(C.Structure):
         ("form_align_xz", C.c_void_p), ("form_drag_xz", C.c_void_p),
         ("arrival_sink_xz", C.c_void_p), ("arrival_flags", C.c_void_p),
         ("los_pool", C.c_void_p), ("flock_los_slot", C.c_void_p), ("los_pos_xz", C.c_void_p),
-        ("n_los_slots", C.c_int32), ("static_epoch", C.c_uint32)]
+        ("n_los_slots", C.c_int32), ("static_epoch", C.c_uint32),
+        ("region_row", C.c_void_p), ("region_field_slot", C.c_void_p), ("n_region_rows", C.c_int32)]
 
 
 class StepOut(C.Structure):
@@ -360,6 +361,8 @@ _SIGS.update({
     "navhip_spatial_query": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p, C.c_int, C.c_float,
                                        C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "navhip_region_lookup": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "navhip_stream_wait_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "navhip_get_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "navhip_stream_create_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -399,7 +402,8 @@ _WORLD_ARRAYS = (
     ("flock_field_slot", np.int32), ("field_pool", np.uint8), ("form_ready", np.uint8),
     ("cell_pos_xz", np.float32), ("form_cohesion_xz", np.float32), ("form_align_xz", np.float32),
     ("form_drag_xz", np.float32), ("arrival_sink_xz", np.float32), ("arrival_flags", np.uint8),
-    ("los_pool", np.uint8), ("flock_los_slot", np.int32), ("los_pos_xz", np.float32))
+    ("los_pool", np.uint8), ("flock_los_slot", np.int32), ("los_pos_xz", np.float32),
+    ("region_row", np.int32), ("region_field_slot", np.int32))
 
 
 def flock_csr(flock, n_flocks, order=None):
@@ -444,6 +448,8 @@ def make_world(chunk_w, chunk_h, arrays, hz=20, xp=None):
     w.n_field_slots = 0 if fp is None else int(fp.shape[0])
     lp = arrays.get("los_pool")
     w.n_los_slots = 0 if lp is None else int(lp.shape[0])
+    rs = arrays.get("region_field_slot")
+    w.n_region_rows = int(arrays.get("n_region_rows") or (0 if rs is None else int(rs.shape[0])))
     w.map_pos_x = chunk_w * 128.0
     w.map_pos_z = -chunk_h * 128.0
     w.grid_xmin, w.grid_xmax, w.grid_zmin, w.grid_zmax = grid_bounds(chunk_w, chunk_h)
@@ -601,6 +607,25 @@ def _ctx_pool_get(self, ff_id):
     return None if rc != OK else d
 
 
+def _ctx_region_lookup(self, pos_xz, rows, region_field_slot=None, field_pool=None, centre_abs=None, radius=None):
+    """N_DesiredGroupArrivalVelocity for many points: (dir [nq] u8 with 0xff = no field, at_slot [nq] | None)."""
+    p = np.ascontiguousarray(pos_xz, np.float32).reshape(-1, 2)
+    nq = len(p)
+    r = np.ascontiguousarray(rows, np.int32)
+    tbl = None if region_field_slot is None else np.ascontiguousarray(region_field_slot, np.int32)
+    fp = None if field_pool is None else np.ascontiguousarray(field_pool, np.uint8).reshape(-1, 4096)
+    cen = None if centre_abs is None else np.ascontiguousarray(centre_abs, np.int32).reshape(nq, 2)
+    rad = None if radius is None else np.ascontiguousarray(radius, np.int32)
+    out = np.zeros(nq, np.uint8)
+    at = np.zeros(nq, np.uint8) if cen is not None else None
+    self._chk(lib().navhip_region_lookup(
+        self._h, nq, _hp(p), _hp(r), _hp(tbl) if tbl is not None else None, 0 if tbl is None else len(tbl),
+        _hp(fp) if fp is not None else None, 0 if fp is None else len(fp), _hp(cen) if cen is not None else None,
+        _hp(rad) if rad is not None else None, self.w * 128.0, -self.h * 128.0, _hp(out),
+        _hp(at) if at is not None else None), "navhip_region_lookup")
+    return out, at
+
+
 def _ctx_pool_invalidate(self, ff_id):
     self._chk(lib().navhip_pool_invalidate(self._h, int(ff_id)), "navhip_pool_invalidate")
 
@@ -696,6 +721,7 @@ NavContext.comm_allgather_step_dev = _ctx_comm_allgather_step_dev
 NavContext.comm_allgather_rows_dev = _ctx_comm_allgather_rows_dev
 NavContext.pool_contains = _ctx_pool_contains
 NavContext.pool_invalidate = _ctx_pool_invalidate
+NavContext.region_lookup = _ctx_region_lookup
 NavContext.pool_map = _ctx_pool_map
 NavContext.agent_step_async = _ctx_agent_step_async
 NavContext.set_profiling = _ctx_set_profiling

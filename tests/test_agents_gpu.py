@@ -449,3 +449,141 @@ def test_non_square_map_velocity_step_matches_reference(navlib, w, h):
     assert (_vel_err(out["vdes_xz"][clean], vdes[clean]) <= REL_TOL).all()
     assert np.array_equal(out["vel_xz"][clean].view(np.uint32), exp_vel[clean].view(np.uint32))
     pfref.RefMove.unload()
+
+
+@pytest.mark.skipif(not pfref.available(), reason="oracle/_ref (the reference build) is not present")
+def test_region_field_sampling_matches_reference(navlib):
+    """Device sampling of the region fields (SURVEY 8a row a13's siblings): N_DesiredEnemySeekVelocity
+    (nav.c:3603) for STATE_SEEK_ENEMIES agents, N_DesiredSurroundVelocity (:3687) for STATE_SURROUND_ENTITY
+    agents through navhip_world.region_row, and N_DesiredGroupArrivalVelocity (:3561, direction + at_slot)
+    through navhip_region_lookup -- on the chunk fields the reference's own async batch built."""
+    W, H = 4, 3
+    grid, nav = cases.ref_nav_for(W, H, seed=33)
+    n = 600
+    rng = np.random.RandomState(4)
+    inner = np.zeros(grid.shape, bool)
+    inner[6:-6, 6:-6] = True
+    cells = np.argwhere((grid != 255) & inner)
+    pick = cells[rng.choice(len(cells), size=n, replace=False)]
+    pos = (cases.synth.cell_centre(W, H, pick[:, 0], pick[:, 1]) + rng.uniform(-1.5, 1.5, (n, 2))).astype(np.float32)
+    radius = np.ones(n, np.float32)
+    faction = rng.randint(0, 3, n).astype(np.int32)
+    flags = np.full(n, (1 << 3) | (1 << 4), np.uint32)
+    for i in rng.choice(n, 150, replace=False):                       # standing units block their tiles
+        nav.blockers_circle(float(pos[i, 0]), float(pos[i, 1]), 1.0, int(faction[i]), incref=True)
+    nav.flush_dirty()
+    nav.game_load(pos, radius, faction, flags)
+    for f, m in ((0, 0b110), (1, 0b001), (2, 0b001)):
+        pfref.set_enemy_factions(f, m)
+    try:
+        # ---- the tick's async batch (all CPU): one field per (kind, target, chunk) the agents stand on
+        seekers = rng.choice(n, 200, replace=False)
+        surrounders = np.setdiff1d(np.arange(n), seekers)[:120]
+        targets = rng.randint(0, n, len(surrounders))
+        zones = [(pos[i], int(rng.randint(3, 12))) for i in rng.choice(n, 6, replace=False)]
+        reqs = [(pfref.ASYNC_ENEMY_SEEK, 0, int(faction[i]), pos[i, 0], pos[i, 1], 0, 0) for i in seekers]
+        reqs += [(pfref.ASYNC_SURROUND, 0, int(faction[i]), pos[i, 0], pos[i, 1], int(t), 0) for i, t in zip(surrounders, targets)]
+        reqs += [(pfref.ASYNC_GROUP_ARRIVAL, 0, 0, c[0], c[1], 0, r) for c, r in zones]
+        fields = {}
+        batch = np.array(reqs, dtype=pfref.ASYNC_REQ_DTYPE)
+        for b in range(0, len(batch), 200):                          # (MAX_FIELD_TASKS = 256 jobs per tick)
+            fields.update(nav.async_batch(batch[b:b + 200]))
+        ids = sorted(fields)
+        slot_of = {k: i for i, k in enumerate(ids)}
+        pool = np.stack([fields[k].reshape(4096) for k in ids])
+        # ---- mapping rows: one per (enemy-seek faction), one per surround target, one per zone
+        rows, row_of = [], {}
+
+        def row(key):
+            if key not in row_of:
+                row_of[key] = len(rows)
+                rows.append(-np.ones(W * H, np.int32))
+            return row_of[key]
+
+        def chunk_of(p):
+            return int((p[1] + H * 128.0) // 256), int((W * 128.0 - p[0]) // 256)
+
+        region_row = -np.ones(n, np.int32)
+        state = np.full(n, navlib.STATE_ARRIVED, np.uint8)
+        for i in seekers:
+            r = row(("enemies", int(faction[i])))
+            cr, cc = chunk_of(pos[i])
+            fid = navlib.N_RegionFieldID(navlib.FFID_ENEMIES, 0, cr, cc, int(faction[i]))
+            rows[r][cr * W + cc] = slot_of.get(fid, -1)
+            region_row[i], state[i] = r, navlib.STATE_SEEK_ENEMIES
+        for i, t in zip(surrounders, targets):
+            r = row(("entity", int(t)))
+            cr, cc = chunk_of(pos[i])
+            fid = navlib.N_RegionFieldID(navlib.FFID_ENTITY, 0, cr, cc, int(t))
+            rows[r][cr * W + cc] = slot_of.get(fid, -1)
+            region_row[i], state[i] = r, navlib.STATE_SURROUND_ENTITY
+        zone_rows, zone_cen = [], []
+        for c, rad in zones:
+            r = row(("zone", float(c[0]), float(c[1]), rad))
+            cr0, cc0 = chunk_of(c)
+            ar = int((c[1] + H * 128.0) // 4)
+            ac = int((W * 128.0 - c[0]) // 4)
+            for cr in range(H):
+                for cc in range(W):
+                    fid = navlib.N_RegionFieldID(navlib.FFID_ZONE, 0, cr, cc, ar, ac, rad)
+                    rows[r][cr * W + cc] = slot_of.get(fid, -1)
+            zone_rows.append(r)
+            zone_cen.append((ar, ac, rad))
+        table = np.stack(rows)
+        assert (table >= 0).sum() > 40
+
+        # ---- the reference's answers (cache-hit path: the fields are in its cache)
+        ref_reqs = np.array([r for r in reqs if r[0] != pfref.ASYNC_GROUP_ARRIVAL], dtype=pfref.ASYNC_REQ_DTYPE)
+        ref_vel, _ = nav.desired_region_velocities(ref_reqs)
+        who = np.concatenate([seekers, surrounders])
+
+        # ---- the device: the step samples the rows itself
+        ctx = navlib.NavContext(W, H)
+        ctx.upload_plane(0, navlib.PLANE_COST_BASE, nav.plane(pfref.PLANE_COST))
+        ctx.upload_plane(0, navlib.PLANE_BLOCKERS, nav.plane(pfref.PLANE_BLOCKERS))
+        ctx.upload_plane(0, navlib.PLANE_LOCAL_ISLANDS, nav.plane(pfref.PLANE_LOCAL_ISLANDS))
+        offs, members = navlib.flock_csr(np.zeros(n, np.int32), 1)
+        arrays = {"pos_xz": pos, "vel_xz": np.zeros((n, 2), np.float32), "radius": radius,
+                  "max_speed": np.full(n, 20.0, np.float32), "speed": np.full(n, 20.0, np.float32),
+                  "flags": np.full(n, navlib.ENTITY_FLAG_MOVABLE, np.uint32), "state": state,
+                  "has_dest_los": np.zeros(n, np.uint8), "flock": np.zeros(n, np.int32),
+                  "flock_target_xz": np.zeros((1, 2), np.float32), "flock_offsets": offs, "flock_members": members,
+                  "flock_field_slot": -np.ones((1, W * H), np.int32), "field_pool": pool, "vdes_xz": None,
+                  "region_row": region_row, "region_field_slot": table}
+        out = ctx.agent_step(arrays)
+        got = out["vdes_xz"][who]
+        st = out["status"][who]
+        none = (st & navlib.ST_FIELD_NONE).astype(bool)
+        miss = (st & navlib.ST_FIELD_MISS).astype(bool)
+        assert not miss.any()
+        # FD_NONE under the agent: the reference repairs the field in place (nav.c:3652-3683) -- host work;
+        # everybody else gets the reference's direction bit for bit
+        assert none.mean() < 0.6 and (~none).sum() > 120
+        assert np.array_equal(got[~none].view(np.uint32), ref_vel[~none].view(np.uint32))
+        assert np.abs(got[~none]).max() > 0.5
+        # the surround / seek agents also get a velocity (the enemy-seek arm of move_velocity_work)
+        assert np.abs(out["vel_xz"][seekers]).max() > 0
+
+        # ---- group arrival: direction + at_slot for probes scattered around every zone
+        q_pos, q_rows, q_cen, q_rad, ref_q = [], [], [], [], []
+        for (c, rad), r, (ar, ac, _) in zip(zones, zone_rows, zone_cen):
+            for _ in range(150):
+                p = (np.asarray(c) + rng.uniform(-6 * rad, 6 * rad, 2)).astype(np.float32)
+                if abs(p[0]) >= W * 128.0 - 1 or abs(p[1]) >= H * 128.0 - 1:
+                    continue
+                q_pos.append(p); q_rows.append(r); q_cen.append((ar, ac)); q_rad.append(rad)
+                ref_q.append((pfref.ASYNC_GROUP_ARRIVAL, 0, int(np.float32(c[1]).view(np.int32)), p[0], p[1],
+                              int(np.float32(c[0]).view(np.uint32)), rad))
+        rv, rf = nav.desired_region_velocities(np.array(ref_q, dtype=pfref.ASYNC_REQ_DTYPE))
+        d, at = ctx.region_lookup(np.array(q_pos), q_rows, table, pool, centre_abs=q_cen, radius=q_rad)
+        ok = (rf & 1).astype(bool)
+        assert np.array_equal(d != 0xff, ok) and ok.mean() > 0.5
+        vec = np.array([[0, 0], [0.70710678, -0.70710678], [0, -1], [-0.70710678, -0.70710678], [1, 0], [-1, 0],
+                        [0.70710678, 0.70710678], [0, 1], [-0.70710678, 0.70710678]], np.float32)
+        assert np.array_equal(vec[d[ok]], rv[ok])
+        assert np.array_equal(at[ok].astype(bool), (rf[ok] & 2).astype(bool)) and at.sum() > 5
+        ctx.close()
+    finally:
+        pfref.RefNav.game_unload()
+        for f in range(3):
+            pfref.set_enemy_factions(f, 0)
