@@ -190,11 +190,11 @@ __device__ void nbr_walk_row(const nh_grid &G, int k, float scaled_max_force, co
             const unsigned ms = (unsigned)g::ballot(is_s), md = (unsigned)g::ballot(is_d);
             if(is_s) {
                 const int p = n_stat + __popc(ms & lt);
-                if(p < NH_MAX_NEIGHBOURS) NB.list[(size_t)uid * NB.stride + 32 + p] = kk;
+                if(p < NH_MAX_NEIGHBOURS) nbr_store(NB, uid, 32 + p, c, make_float2(0.0f, 0.0f));   // :2820
             }
             if(is_d) {
                 const int p = n_dyn + __popc(md & lt);
-                if(p < NH_MAX_NEIGHBOURS) NB.list[(size_t)uid * NB.stride + p] = kk;
+                if(p < NH_MAX_NEIGHBOURS) nbr_store(NB, uid, p, c, G.recV[kk]);
             }
             n_stat = min(NH_MAX_NEIGHBOURS, n_stat + __popc(ms));
             n_dyn = min(NH_MAX_NEIGHBOURS, n_dyn + __popc(md));
@@ -955,20 +955,21 @@ __device__ v2 clearpath_small_row(const cpent &ent, v2 des_v, const cpent &nb, b
     return res;
 }
 
-// neighbour lists (pool slots, from the walk) -> S.dyn / S.stat
+// neighbour records (from the walk) -> S.dyn / S.stat: lane j copies record j (the lanes of a group read one
+// contiguous run of the entity's row)
 template <int G>
 __device__ __forceinline__ void cp_load_lists(const nh_grid &Gd, const nh_nbr &NB, int uid, int n_dyn, int n_stat,
                                               cp_lds<G> &S)
 {
+    (void)Gd;
     const int gl = grp<G>::lane();
     wave_sync();
     if(gl < n_dyn + n_stat) {
         const bool isdyn = gl < n_dyn;
         const int j = isdyn ? gl : gl - n_dyn;
-        const int slot = NB.list[(size_t)uid * NB.stride + (isdyn ? j : 32 + j)];
-        const cpent nb = nbr_cpent(Gd, slot, !isdyn);
+        const float *src = NB.rec + (size_t)uid * NB.stride + 5 * (isdyn ? j : 32 + j);
         float *dst = (isdyn ? S.dyn : S.stat) + 5 * j;
-        dst[0] = nb.pos.x; dst[1] = nb.pos.z; dst[2] = nb.vel.x; dst[3] = nb.vel.z; dst[4] = nb.radius;
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
     }
     wave_sync();
 }

@@ -912,19 +912,29 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
 // ---------------------------------------------------------------------------------------------
 // k_agent_nbr: one ROW of 16 lanes per pool slot (16 entities per 256-thread workgroup)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
+// STRIDED (a rank that steps a slab of a large job): the launch is sized by the slab, the pool by what its
+// queries can reach, so a few rows take a second slot.  With the whole snapshot stepped every pool slot
+// has its own row (no loop: four VGPRs and a wave per SIMD less with it).
+template <bool STRIDED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
+void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
 {
     __shared__ double exp_tab[64];
     __shared__ __attribute__((aligned(16))) float2 terms[16][16];
     if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
     __syncthreads();
     const int grp_i = threadIdx.x >> 4;
-    // (the launch is sized by the slab a rank steps, the pool by what its queries can reach: a few rows
-    // take a second slot; with the whole snapshot stepped every row has exactly one)
-    const int npool = min(npool_max, G.cell_start[G.grid_w * G.grid_h]);
-    for(int k = blockIdx.x * 16 + grp_i; k < npool; k += gridDim.x * 16) {
-        if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) continue;   // no work item (or outside the slab)
+    if(!STRIDED) {
+        const int k = blockIdx.x * 16 + grp_i;
+        if(k >= npool_max || k >= G.cell_start[G.grid_w * G.grid_h]) return;
+        if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) return;         // no work item (or outside the slab)
         nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
+    }else{
+        const int npool = min(npool_max, G.cell_start[G.grid_w * G.grid_h]);
+        for(int k = blockIdx.x * 16 + grp_i; k < npool; k += gridDim.x * 16) {
+            if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) continue;
+            nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
+        }
     }
 }
 
@@ -952,7 +962,8 @@ __device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which,
 #ifndef MID_LANES
 #define MID_LANES 2
 #endif
-__global__ __launch_bounds__(64) void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
                                                   nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
                                                   float scaled_max_force, double force_thresh)
 {
@@ -1095,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_cp_small(nh_step_params P, nh_nbr NB, c
             const int gl = lane & 15;
             const bool have = gl < n_dyn + n_stat, isdyn = gl < n_dyn;
             cpent nb; nb.pos = mkv(0, 0); nb.vel = mkv(0, 0); nb.radius = 0;
-            if(have) nb = nbr_cpent(P.grid, NB.list[(size_t)uid * NB.stride + (isdyn ? gl : 32 + gl - n_dyn)], !isdyn);
+            if(have) nb = nbr_load(NB, uid, isdyn ? gl : 32 + gl - n_dyn);
             const v2 nv = clearpath_small_row(ent, mkv(R.vpref[0], R.vpref[1]), nb, isdyn, have,
                                               cones[wib * 4 + (lane >> 4)], found);
             if(found && gl == 0)
@@ -1475,10 +1486,14 @@ void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t 
 {
     if(P.n_ents > 0 && P.work_end > P.work_begin) {
         const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
-        // rows for the slab + a quarter (its halo in the pool); never more than one per entity
         const int slab = P.work_end - P.work_begin;
-        const int rows = (int)min((long long)P.n_ents, (long long)slab + slab / 4 + 1024);
-        hipLaunchKernelGGL(k_agent_nbr, dim3((rows + 15) / 16), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
+        if(slab == P.n_ents) {
+            hipLaunchKernelGGL(k_agent_nbr<false>, dim3((P.n_ents + 15) / 16), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
+        }else{
+            // rows for the slab + a quarter (its halo in the pool); never more than one per entity
+            const int rows = (int)min((long long)P.n_ents, (long long)slab + slab / 4 + 1024);
+            hipLaunchKernelGGL(k_agent_nbr<true>, dim3((rows + 15) / 16), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
+        }
     }
 }
 

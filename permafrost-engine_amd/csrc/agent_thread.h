@@ -122,6 +122,22 @@ NH_FN cpent nbr_cpent(const nh_grid &G, int slot, bool is_static)
     return nb;
 }
 
+// the same struct cp_ent as a record of the neighbour table (nh_nbr.rec): written by the neighbour walk
+// from the pool record it has just tested, read back by the ClearPath kernels
+NH_FN void nbr_store(const nh_nbr &NB, int uid, int idx, const float4 &a, float2 v)
+{
+    float *d = NB.rec + (size_t)uid * NB.stride + 5 * idx;
+    d[0] = a.x; d[1] = a.y; d[2] = v.x; d[3] = v.y; d[4] = a.z;
+}
+
+NH_FN cpent nbr_load(const nh_nbr &NB, int uid, int idx)
+{
+    const float *s = NB.rec + (size_t)uid * NB.stride + 5 * idx;
+    cpent nb;
+    nb.pos = mkv(s[0], s[1]); nb.vel = mkv(s[2], s[3]); nb.radius = s[4];
+    return nb;
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-agent line of sight to the destination (N_HasDestLOS, nav.c:4026, cache-hit path)
 // ---------------------------------------------------------------------------------------------

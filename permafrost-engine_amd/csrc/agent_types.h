@@ -80,18 +80,19 @@ struct nh_step_outs {
 // indexed by uid:
 //   sep[uid]      separation_force (movement.c:1690), already truncated
 //   cnt[uid]      n_dyn | n_stat << 8 | NH_NB_* << 16
-//   list[uid][j]  pool slots of the ClearPath neighbours: j = 0..31 dynamic, 32..63 static, in
-//                 find_neighbours order.  Entity-major: the row of lanes that walks an entity writes
-//                 its entries side by side and the ClearPath kernels read them back in one or two
-//                 sectors (slot-major -- list[j][uid] -- cost a 64-byte sector per ENTRY on the read
-//                 side: half of k_cp_rows's HBM traffic)
+//   rec[uid][j]   the ClearPath neighbours THEMSELVES -- struct cp_ent {pos.x, pos.z, vel.x, vel.z, radius},
+//                 five floats -- j = 0..31 dynamic, 32..63 static (velocity 0, movement.c:2820), in
+//                 find_neighbours order.  The walk has the pool record of every hit in registers anyway;
+//                 the ClearPath kernels read an entity's row back as ONE contiguous run (entity-major)
+//                 instead of chasing pool slots: a 16-byte record + an 8-byte velocity per neighbour, a
+//                 64-byte sector each, were three quarters of the bytes those kernels fetched
 #define NH_NB_IRREGULAR 0x1u   /* garrisoned hit / wide query: the wave-per-agent path redoes the gather */
 #define NH_NB_DONE      0x2u   /* the walk ran for this entity this tick                                  */
 struct nh_nbr {
     float2   *sep;
     uint32_t *cnt;
-    int32_t  *list;
-    int       stride;          // entries per entity (= 64)
+    float    *rec;
+    int       stride;          // floats per entity (= 64 * 5)
 };
 
 // Work lists filled on the device (counters[NH_WL_*] + ids), consumed by fixed-size launches that

@@ -749,14 +749,14 @@ static int step_scratch(navhip_ctx *ctx, int n_ents, nh_nbr *NB, nh_worklists *W
     const size_t n = (size_t)n_ents;
     int rc = ensure_buf(ctx, ctx->nbr[0], 8 * n);
     if(!rc) rc = ensure_zeroed(ctx, ctx->nbr[1], 4 * n, s);
-    if(!rc) rc = ensure_buf(ctx, ctx->nbr[2], 4 * 64 * n);
+    if(!rc) rc = ensure_buf(ctx, ctx->nbr[2], 4 * (size_t)(64 * 5) * n);
     if(!rc) rc = ensure_buf(ctx, ctx->midrec, sizeof(nh_mid_rec) * n);
     const int cap = nh_worklist_cap(n_ents);
     if(!rc) rc = ensure_zeroed(ctx, ctx->wl[0], 4 * 2 * NH_WL_COUNTERS, s);
     if(!rc) rc = ensure_buf(ctx, ctx->wl[1], 4 * (size_t)NH_WL_LISTS * NH_WL_SUB * cap);
     if(rc) return rc;
-    NB->sep = (float2*)ctx->nbr[0].p; NB->cnt = (uint32_t*)ctx->nbr[1].p; NB->list = (int32_t*)ctx->nbr[2].p;
-    NB->stride = 64;
+    NB->sep = (float2*)ctx->nbr[0].p; NB->cnt = (uint32_t*)ctx->nbr[1].p; NB->rec = (float*)ctx->nbr[2].p;
+    NB->stride = 64 * 5;
     WL->count = (int32_t*)ctx->wl[0].p; WL->ids = (int32_t*)ctx->wl[1].p; WL->cap = cap;
     return NAVHIP_OK;
 }

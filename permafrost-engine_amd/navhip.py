@@ -131,6 +131,8 @@ def lib():
                               "there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
         for name, (rt, at) in _SIGS.items():
+            if os.environ.get("NAVHIP_LIB") and not hasattr(L, name):
+                continue                 # (an A/B build of an older revision lacks the newer entry points)
             f = getattr(L, name)
             f.restype = rt
             f.argtypes = at

@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_regions_gpu.py tests/test_multirank_gpu.py tests/test_agents_gpu.py tests/test_edge_gpu.py tests/test_fullsize_gpu.py tests/test_fuzz_gpu.py -x -q 2>&1 | tail -3
-timeout 300 python scripts/rank_cost_probe.py 1 4 8 2>&1 | tail -3
-timeout 300 python scripts/rank_cost_probe.py 1 4 8 2>&1 | tail -3
+timeout 2000 python scripts/ab_lib.py --run r2 base c046 --rounds=2 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -10

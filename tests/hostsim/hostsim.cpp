@@ -80,8 +80,8 @@ int hostsim_agent_step(const hostsim_map *map, const navhip_world *w, const floa
     // ---- neighbour walk, pool order
     std::vector<float2> sep(n);
     std::vector<uint32_t> cnt(n, 0);
-    std::vector<int32_t> list((size_t)64 * n, -1);
-    nh_nbr NB = {sep.data(), cnt.data(), list.data(), 64};
+    std::vector<float> rec((size_t)64 * 5 * n, 0.0f);
+    nh_nbr NB = {sep.data(), cnt.data(), rec.data(), 64 * 5};
     const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
     for(int k = 0; k < n; k++) {
@@ -107,8 +107,8 @@ int hostsim_agent_step(const hostsim_map *map, const navhip_world *w, const floa
             cpent ent; ent.pos = me; ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]); ent.radius = P.radius[uid];
             v2 res;
             const uint32_t c = cnt[uid];
-            if(cp_light_thread(G, ent, mkv(R.vpref[0], R.vpref[1]), (int)(c & 0xff), (int)((c >> 8) & 0xff),
-                               list.data() + (size_t)uid * 64, (size_t)1, cones, 1, res))
+            if(cp_light_thread(NB, uid, ent, mkv(R.vpref[0], R.vpref[1]), (int)(c & 0xff), (int)((c >> 8) & 0xff),
+                               cones, 1, res))
                 post_thread(P, uid, me, P.state[uid], P.flags[uid], ent.radius, res, R.vel_cap, R.status, O);
             else
                 disp += 16;
@@ -125,23 +125,21 @@ int hostsim_clearpath_light(int nq, const float *ent, const float *des_v, const 
                             float *out, int32_t *found)
 {
     for(int q = 0; q < nq; q++) {
-        float4 recA[64]; float2 recV[64]; int32_t list[64]; float4 cones[2 * 64];
-        nh_grid G; memset(&G, 0, sizeof(G));
-        G.recA = recA; G.recV = recV;
+        float rec[64 * 5]; float4 cones[2 * 64];
+        nh_nbr NB = {nullptr, nullptr, rec, 64 * 5};
         const int nd = n_dyn[q], ns = n_stat[q];
         if(nd > 32 || ns > 32) return -1;
         for(int j = 0; j < nd + ns; j++) {
             const bool st = j >= nd;
             const float *s = (st ? stat : dyn) + (size_t)q * 160 + 5 * (st ? j - nd : j);
-            recA[j] = make_float4(s[0], s[1], s[4], 0.0f);
-            recV[j] = make_float2(s[2], s[3]);
-            list[st ? 32 + (j - nd) : j] = j;
+            nbr_store(NB, 0, st ? 32 + (j - nd) : j, make_float4(s[0], s[1], s[4], 0.0f),
+                      st ? make_float2(0.0f, 0.0f) : make_float2(s[2], s[3]));
         }
         cpent e; e.pos = mkv(ent[5 * q], ent[5 * q + 1]); e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]);
         e.radius = ent[5 * q + 4];
         const v2 dv = mkv(des_v[2 * q], des_v[2 * q + 1]);
         v2 r = dv;
-        const bool ok = cp_light_thread(G, e, dv, nd, ns, list, 1, cones, 1, r);
+        const bool ok = cp_light_thread(NB, 0, e, dv, nd, ns, cones, 1, r);
         out[2 * q] = r.x; out[2 * q + 1] = r.z;
         found[q] = ok ? 1 : 0;
     }

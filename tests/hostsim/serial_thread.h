@@ -89,9 +89,9 @@ NH_FN void nbr_walk_thread(const nh_grid &G, int k, float scaled_max_force, cons
                     raw10++;
                     if(other && c.z != 0.0f) {
                         if(bits & NH_PB_STATIC) {
-                            if(n_stat < NH_MAX_NEIGHBOURS) { NB.list[(size_t)uid * NB.stride + 32 + n_stat] = q; n_stat++; }
+                            if(n_stat < NH_MAX_NEIGHBOURS) { nbr_store(NB, uid, 32 + n_stat, c, make_float2(0.0f, 0.0f)); n_stat++; }
                         }else{
-                            if(n_dyn < NH_MAX_NEIGHBOURS) { NB.list[(size_t)uid * NB.stride + n_dyn] = q; n_dyn++; }
+                            if(n_dyn < NH_MAX_NEIGHBOURS) { nbr_store(NB, uid, n_dyn, c, G.recV[q]); n_dyn++; }
                         }
                     }
                 }
@@ -117,15 +117,14 @@ NH_FN void nbr_walk_thread(const nh_grid &G, int k, float scaled_max_force, cons
 // ---------------------------------------------------------------------------------------------
 // cones: 2 float4 per neighbour at cones[i * cstride].  Returns false when no candidate lies outside
 // the combined obstacle (the device then runs remove_furthest, :390, and retries).
-NH_FN bool cp_light_thread(const nh_grid &G, const cpent &ent, v2 des_v, int n_dyn, int n_stat,
-                           const int32_t *list, size_t stride, float4 *cones, int cstride, v2 &result)
+NH_FN bool cp_light_thread(const nh_nbr &NB, int uid, const cpent &ent, v2 des_v, int n_dyn, int n_stat,
+                           float4 *cones, int cstride, v2 &result)
 {
     int n_cones = 0;
     const int n = n_dyn + n_stat;
     for(int j = 0; j < n; j++) {
         const bool is_stat = j >= n_dyn;
-        const int slot = list[(size_t)(is_stat ? 32 + (j - n_dyn) : j) * stride];
-        const cpent nb = nbr_cpent(G, slot, is_stat);
+        const cpent nb = nbr_load(NB, uid, is_stat ? 32 + (j - n_dyn) : j);
         if(vlen(vsub(nb.pos, ent.pos)) < CP_EPS) continue;
         v2 apex, left, right; float sl, sr;
         make_cone(ent, nb, !is_stat, apex, left, right, sl, sr);
