@@ -915,8 +915,11 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
 // STRIDED (a rank that steps a slab of a large job): the launch is sized by the slab, the pool by what its
 // queries can reach, so a few rows take a second slot.  With the whole snapshot stepped every pool slot
 // has its own row (no loop: four VGPRs and a wave per SIMD less with it).
+#ifndef NBR_WAVES
+#define NBR_WAVES 7        /* 72 VGPRs; 8 needs five spilled dwords per lane */
+#endif
 template <bool STRIDED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBR_WAVES, 8)))
 void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
 {
     __shared__ double exp_tab[64];
@@ -1120,6 +1123,9 @@ __global__ __launch_bounds__(256) void k_cp_small(nh_step_params P, nh_nbr NB, c
 // unit, the units numbered heaviest list first (9-16, 5-8, 3-4, 1-2 neighbours) ---------------------
 // (the lists list0, list0 - 1, ... : nlists of them, at most four; ticket_set: which set of stripe
 // counters -- the retry launch runs beside the main one)
+#ifdef CP_ROWS_OCC
+__attribute__((amdgpu_waves_per_eu(CP_ROWS_OCC, CP_ROWS_OCC)))
+#endif
 __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                            nh_worklists WL, nh_step_outs O, int list0, int nlists,
                                                            int ticket_set)
@@ -1181,6 +1187,9 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_
 // waves of the workgroup search a problem as a team (clearpath_grp<64, true>), so that no single
 // problem outlasts the launch.  The first problem of a workgroup is its block number,
 // then one ticket per workgroup and problem. ---
+#ifdef CP_HEAVY_OCC
+__attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
+#endif
 __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                             nh_worklists WL, nh_step_outs O)
 {
