@@ -692,6 +692,12 @@ void nh_launch_fields(navhip_ctx *ctx, const navhip_field_req *d_reqs, int n, ui
             hipLaunchKernelGGL(k_field_bfs<false>, grid, dim3(BFS_WAVES * 64), 0, s, mv, d_reqs, n, d_dirs,
                                d_integ, force_generic, d_gen_list, gen_slot, d_out_slot);
     }
-    hipLaunchKernelGGL(k_field_generic, dim3(n < 512 ? n : 512), dim3(256), 0, s, mv, d_reqs, n, d_dirs,
+    // The relaxation kernel strides over the requests the BFS kernel declined.  Usually that list is empty
+    // or short (repairs, attacking paths): 512 workgroups that mostly read one counter.  A map with real
+    // cost gradients sends EVERY request there: eight workgroups per CU (20 KB of LDS each) instead of two.
+    bool heavy = force_generic;
+    for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) heavy = heavy || (ctx->layers[l].cost && ctx->layers[l].nonunit_costs);
+    const int gmax = heavy ? 2048 : 512;
+    hipLaunchKernelGGL(k_field_generic, dim3(n < gmax ? n : gmax), dim3(256), 0, s, mv, d_reqs, n, d_dirs,
                        d_integ, force_generic, force_generic ? (int32_t*)nullptr : d_gen_list, gen_slot, d_out_slot);
 }

@@ -236,6 +236,15 @@ int navhip_upload_plane(navhip_ctx *ctx, int layer, int plane, const void *host,
         memset(L.dirty, 1, ctx->nchunks);
         L.any_dirty = true;
     }
+    if(plane == NAVHIP_PLANE_COST_BASE) {
+        // does the layer hold costs other than 1 / impassable?  (The reference's cost writers produce no
+        // others, nav.c:339-342,416; a host that does sends its requests to the relaxation kernel, whose
+        // launch is then sized for real work instead of for an empty list.)
+        const uint8_t *c = (const uint8_t*)host;
+        bool other = false;
+        for(size_t i = 0; i < bytes && !other; i++) other = c[i] != 1 && c[i] != NAVHIP_COST_IMPASSABLE;
+        L.nonunit_costs = other;
+    }
     return NAVHIP_OK;
 }
 
@@ -256,6 +265,10 @@ int navhip_upload_chunk(navhip_ctx *ctx, int layer, int plane, int chunk_r, int 
     if(rc) return rc;
     navhip_layer &L = ctx->layers[layer];
     int chunk = chunk_r * ctx->w + chunk_c;
+    if(plane == NAVHIP_PLANE_COST_BASE) {
+        const uint8_t *c = (const uint8_t*)host;
+        for(size_t i = 0; i < per; i++) if(c[i] != 1 && c[i] != NAVHIP_COST_IMPASSABLE) { L.nonunit_costs = true; break; }
+    }
     HIPCHK(ctx, hipMemcpyAsync((char*)*plane_slot(L, plane) + (size_t)chunk * per, host, per,
                                hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -28,6 +28,7 @@ struct navhip_layer {
     uint8_t  *changed;         // [nchunks]      device: passability changed since navhip_clear_changed
     uint8_t  *dirty;           // host side: [nchunks] derived state stale
     bool      any_dirty;
+    bool      nonunit_costs;   // host side: a cost other than 1 / 0xff was uploaded for this layer
 };
 
 struct navhip_ctx {

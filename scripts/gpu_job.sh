@@ -42,6 +42,8 @@ pmccp) i=0; for c in "SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_I
      done ;;
 cpstats) timeout 400 python scripts/cp_stats.py > $OUT/cp_stats.json 2> $OUT/cp_stats.err; tail -c 300 $OUT/cp_stats.err
          timeout 400 python scripts/cp_stats.py --crowd > $OUT/cp_stats_crowd.json 2>> $OUT/cp_stats.err; tail -c 600 $OUT/cp_stats_crowd.json ;;
+secondary) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/secondary -o s --output-format csv -- python scripts/bench_secondary.py > $OUT/bench_secondary.json 2> $OUT/secondary.err
+       tail -c 1500 $OUT/bench_secondary.json; f=$(find $OUT/secondary -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 $f | cut -c1-160 ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log ;;
 esac
 done
