@@ -541,6 +541,49 @@ int  navhip_comm_allgather_step_dev(navhip_ctx *ctx, float *dev_new_pos_xz, floa
 int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_bytes, const int32_t *bounds,
                                     void *stream);
 
+/* ---- the arrival arm of the movement state machine --------------------------- */
+
+/* entity_compute_update (movement.c:2303) decides, per unit and tick, the next movement state.  Most of it is
+ * game logic over host state (orientation and the heading gate, formations, the arrival overlay, surround
+ * targets, wait timers) and stays with the host.  The part every point-seeking unit runs every tick is the
+ * STATE_MOVING / STATE_MOVING_IN_FORMATION case without a formation and without an active arrival group
+ * (:2441-2520) -- and that part is data parallel:
+ *   1. garrisoned and not still          -> STATE_ARRIVED, no blocker                       (:2344-2351)
+ *   2. new position not pathable         -> no transition                                   (:2437-2438)
+ *   3. arrived(uid, new_pos) (:2170): within 1.5 radii of the flock target; or adjacent to an impassable
+ *      tile (N_IsAdjacentToImpassable, nav.c:4745) and maximally close to the target (N_IsMaximallyClose,
+ *      nav.c:4707: within that distance of one of the destination's closest island tiles); or within it of
+ *      N_ClosestPathable(target) (nav.c:4126)                 -> STATE_ARRIVED, blocker
+ *   4. a flock mate within radius + radius + 5 has arrived (adjacent_flock_members :953, :2480-2497)
+ *                                                             -> STATE_ARRIVED, blocker
+ *   5. no guidance: |vdes| < 1/1024                           -> STATE_WAITING, blocker     (:2508-2515)
+ * The two nav queries of step 3 depend on the destination only; the host makes them once per flock
+ * (flock_nearest_xz, flock_tiles) and the device runs the per-unit tests.  Everything else is reported
+ * back as NAVHIP_SU_HOST (the host runs entity_compute_update for that unit as before). */
+#define NAVHIP_SU_SET_STATE  0x01   /* UPDATE_SET_STATE: next_state holds the new state                       */
+#define NAVHIP_SU_BLOCK      0x02   /* movestate_patch.next_block                                            */
+#define NAVHIP_SU_HOST       0x80   /* not decided here: another state, a formation member, an active arrival
+                                       group (skip[i] != 0), or a unit whose nav layer is not its flock's      */
+typedef struct navhip_state_in {
+    const float    *new_pos_xz;       /* [n][2] new_pos_for_vel(uid, new_vel) (movement.c:2338): position + the
+                                                velocity of the tick AFTER the heading gate (:2321-2334)        */
+    const float    *vdes_xz;          /* [n][2] move_work_out.ent_des_v                                        */
+    const uint8_t  *skip;             /* [n] or NULL                                                           */
+    const uint8_t  *flock_layer;      /* [F]    the nav layer flock_nearest_xz / flock_tiles were made for     */
+    const float    *flock_nearest_xz; /* [F][2] N_ClosestPathable(layer, flock.target_xz); x = NaN: none       */
+    const int32_t  *flock_tiles_off;  /* [F+1]  CSR offsets into flock_tiles                                   */
+    const int16_t  *flock_tiles;      /* [..][2] absolute nav tiles (row, column) of n_closest_island_tiles(
+                                                 dest tile, its global island, false), nav.c:4725, in order    */
+} navhip_state_in;
+/* world: the snapshot of the tick (pos_xz, radius, flags, state, flock, flock tables; uid slab
+ * work_begin/work_end as in the step).  out_state / out_flags: [n] bytes, rows of the slab written.
+ * Host buffers. */
+int  navhip_state_update(navhip_ctx *ctx, const navhip_world *world, const navhip_state_in *in,
+                         uint8_t *out_state, uint8_t *out_flags);
+/* Everything resident on the device, asynchronous on `stream`. */
+int  navhip_state_update_dev(navhip_ctx *ctx, const navhip_world *dev_world, const navhip_state_in *dev_in,
+                             uint8_t *dev_out_state, uint8_t *dev_out_flags, void *stream);
+
 /* N_DesiredGroupArrivalVelocity (nav.c:3561) for nq points: the direction under each point in the chunk
  * field of mapping row rows[q] (region_field_slot / field_pool as in navhip_world; resident pool: pass
  * region_field_slot = field_pool = NULL), and whether that tile is a sink inside the zone's disc

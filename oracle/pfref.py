@@ -121,6 +121,9 @@ def lib():
                                                         C.c_float, C.c_float, C.c_float,
                                                         C.c_void_p]
         L.pfref_cached_field.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.pfref_move_state_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.pfref_closest_pathable.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.pfref_dest_island_tiles.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int]
         L.pfref_cached_ffid.restype = C.c_uint64
         L.pfref_cached_ffid.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int]
         L.pfref_cached_los.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
@@ -476,6 +479,18 @@ class RefNav:
         ok = lib().pfref_cached_field(self._h, dest_id, chunk_r, chunk_c, _p(out))
         return out if ok else None
 
+    def closest_pathable(self, xz, layer=0):
+        """N_ClosestPathable (nav.c:4126): (x, z) or None."""
+        out = np.zeros(2, np.float32)
+        ok = lib().pfref_closest_pathable(self._h, layer, float(xz[0]), float(xz[1]), _p(out))
+        return out if ok else None
+
+    def dest_island_tiles(self, xz, layer=0):
+        """The tiles N_IsMaximallyClose (nav.c:4707) tests for this destination: [k, 2] int16 absolute (row, col)."""
+        out = np.zeros((256, 2), np.int16)
+        n = lib().pfref_dest_island_tiles(self._h, layer, float(xz[0]), float(xz[1]), _p(out), len(out))
+        return out[:n].copy()
+
     def cached_ffid(self, dest_id, chunk_r, chunk_c):
         """N_FC_GetDestFFMapping: id of the flow field mapped for (dest, chunk), 0 = none."""
         return int(lib().pfref_cached_ffid(self._h, dest_id, chunk_r, chunk_c))
@@ -594,6 +609,16 @@ class RefMove:
         v = None if vdes is None else np.ascontiguousarray(vdes, np.float32)
         ok = lib().pfref_move_velocity_hip(_p(v) if v is not None else None, begin, end, _p(out))
         return out if ok else None
+
+    def state_update(self, new_vel, vdes, begin=0, end=None):
+        """entity_compute_update (movement.c:2303) per unit: (next_state [n] u8, flags [n] u8: bit 0 state
+        set, bit 1 next_block)."""
+        end = self.n if end is None else end
+        v = np.ascontiguousarray(new_vel, np.float32).reshape(self.n, 2)
+        d = np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
+        st, fl = np.zeros(self.n, np.uint8), np.zeros(self.n, np.uint8)
+        lib().pfref_move_state_update(_p(v), _p(d), begin, end, _p(st), _p(fl))
+        return st, fl
 
     def set_arrival(self, sink_xz, flags):
         """Fine-arrival inputs: per-unit slot + flags (bit 0 committed to a valid slot, bit 1 the

@@ -263,6 +263,11 @@ void pfref_move_forces(int uid, const float vdes[2], float out_arrive[2], float 
 int  pfref_move_neighbours(int uid, float *out_dyn, int *n_dyn, float *out_stat, int *n_stat);
 void pfref_move_get_vdes(float *out_vdes);
 int  pfref_move_flock_order(int flock, uint32_t *out_uids);
+/* entity_compute_update (movement.c:2303) per work item; see ref_move.c */
+void pfref_move_state_update(const float *new_vel, const float *vdes, int begin, int end, uint8_t *out_state,
+                             uint8_t *out_flags);
+int  pfref_closest_pathable(pfref_nav *nav, int layer, float x, float z, float out[2]);
+int  pfref_dest_island_tiles(pfref_nav *nav, int layer, float x, float z, int16_t *out_abs, int max_tiles);
 double pfref_move_bench(const float *vdes, int begin, int end, int reps, int nthreads, float *out_vel);
 
 #ifdef __cplusplus

@@ -74,6 +74,26 @@ vec2_t M_NavDesiredPointSeekVelocity(const struct map *map, dest_id_t id, vec2_t
     return N_DesiredPointSeekVelocity(id, curr_pos, xz_dest, &nav->priv, nav->map_pos);
 }
 
+bool M_NavIsAdjacentToImpassable(const struct map *map, enum nav_layer layer, vec2_t xz_pos)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    return N_IsAdjacentToImpassable(&nav->priv, layer, nav->map_pos, xz_pos);
+}
+
+bool M_NavIsMaximallyClose(const struct map *map, enum nav_layer layer, vec2_t xz_pos, vec2_t xz_dest, float tolerance)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    return N_IsMaximallyClose(&nav->priv, layer, nav->map_pos, xz_pos, xz_dest, tolerance);
+}
+
+bool M_NavClosestPathable(const struct map *map, enum nav_layer layer, vec2_t xz_src, vec2_t *out)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    return N_ClosestPathable(&nav->priv, layer, nav->map_pos, xz_src, out);
+}
+
+float M_HeightAtPoint(const struct map *map, vec2_t xz) { (void)map; (void)xz; return 0.0f; }
+
 /* ---- world loading ---------------------------------------------------------------------- */
 
 static struct {
@@ -417,4 +437,39 @@ int pfref_move_flock_order(int flock, uint32_t *out_uids)
         out_uids[n++] = curr;
     });
     return n;
+}
+
+
+/* entity_compute_update (movement.c:2303) for the work items [begin, end): new_vel / vdes are the tick's
+ * move_work_out.ent_vel / ent_des_v.  No formation (fstate.fid = NULL_FID); every unit's orientation is set
+ * to its intended heading first, so that the heading gate (:2321-2334, host state) lets the velocity
+ * through -- the gate itself is orientation bookkeeping the device pass takes as an input.
+ * out_state[i] = patch.next_state when UPDATE_SET_STATE is set, else the current state;
+ * out_flags[i] bit 0 = UPDATE_SET_STATE, bit 1 = next_block. */
+void pfref_move_state_update(const float *new_vel, const float *vdes, int begin, int end, uint8_t *out_state,
+                             uint8_t *out_flags)
+{
+    for(int i = begin; i < end; i++) {
+        struct move_work_in *in = &s_move_work.in[i];
+        struct move_work_out *out = &s_move_work.out[i];
+        struct movestate *ms = movestate_get(i);
+        if(ms->state == STATE_TURNING
+        && !(G_FlagsGetFrom(s_move_work.gamestate.flags, i) & ENTITY_FLAG_GARRISONED)) {
+            /* (its arm reads the entity's transform, Entity_GetRot: not loaded; a garrisoned unit returns
+             * before the state switch, :2344-2351) */
+            out_state[i] = (uint8_t)ms->state; out_flags[i] = 0;
+            continue;
+        }
+        in->fstate.fid = NULL_FID;
+        out->ent_uid = i;
+        out->ent_vel = (vec2_t){new_vel[2 * i], new_vel[2 * i + 1]};
+        out->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
+        if(PFM_Vec2_Len(&out->ent_vel) > EPSILON)
+            ms->next_rot = dir_quat_from_velocity(intended_heading(out->ent_des_v, out->ent_vel));
+        memset(&out->patch, 0, sizeof(out->patch));
+        entity_compute_update(s_move_work.hz, i, out->ent_vel, out->ent_des_v, in, &out->patch);
+        const bool set = (out->patch.flags & UPDATE_SET_STATE) != 0;
+        out_state[i] = (uint8_t)(set ? out->patch.next_state : ms->state);
+        out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0));
+    }
 }

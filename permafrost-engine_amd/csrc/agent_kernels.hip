@@ -1337,6 +1337,112 @@ __global__ __launch_bounds__(256) void k_spatial_query(nh_grid G, const float *q
     if(lane == 0) out_counts[q] = n;
 }
 
+// ---------------------------------------------------------------------------------------------
+// the arrival arm of entity_compute_update (movement.c:2303; see include/navhip.h): a row of 16 lanes
+// per unit -- the scalar tests on every lane, the flock-mate scan (:953) shared by the lanes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_state_update(nh_step_params P, navhip_state_in in, uint8_t *out_state,
+                                                      uint8_t *out_flags)
+{
+    typedef grp<16> g;
+    const int uid = P.work_begin + ((blockIdx.x * 256 + threadIdx.x) >> 4);
+    const int gl = g::lane();
+    if(uid >= P.work_end) return;
+    const int state = P.state[uid];
+    uint8_t flags = 0, next = (uint8_t)state;
+    const int flock = P.flock[uid];
+    const uint32_t eflags = P.flags[uid];
+    const float radius = P.radius[uid];
+    const int layer = nav_layer_for(eflags, radius);
+    bool decided = false;
+    if(eflags & NAVHIP_ENTITY_FLAG_GARRISONED) {                           // :2344-2351
+        if(!state_is_still(state)) { flags = NAVHIP_SU_SET_STATE; next = NAVHIP_STATE_ARRIVED; }
+        decided = true;
+    }else if(state == NAVHIP_STATE_SEEK_ENEMIES || state == NAVHIP_STATE_ARRIVED) {
+        decided = true;                                                    // :2521-2528, :2643: no transition
+    }else if((state != NAVHIP_STATE_MOVING && state != NAVHIP_STATE_MOVING_IN_FORMATION) || flock < 0
+          || (in.skip && in.skip[uid]) || !P.map.layers[layer].cost || in.flock_layer[flock] != layer) {
+        flags = NAVHIP_SU_HOST;
+        decided = true;
+    }
+    if(!decided) {
+        const v2 np = mkv(in.new_pos_xz[2 * uid], in.new_pos_xz[2 * uid + 1]);
+        const v2 target = mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]);
+        if(pos_pathable(P, layer, np.x, np.z)) {                           // :2437
+            // ---- arrived(uid, new_pos), :2170
+            const float thresh = radius * 1.5f;
+            bool arr = vlen(vsub(target, np)) < thresh;
+            if(!arr) {
+                // N_IsAdjacentToImpassable, nav.c:4745: a 4-neighbour tile that n_tile_blocked (:235)
+                tiledesc t;
+                bool adj = false;
+                if(tile_for_point(P, np.x, np.z, t)) {
+                    const int ar = t.chunk_r * 64 + t.tile_r, ac = t.chunk_c * 64 + t.tile_c;
+                    const int dr[4] = {-1, 0, 0, 1}, dc[4] = {0, -1, 1, 0};
+#pragma unroll
+                    for(int k = 0; k < 4; k++) {
+                        const int r = ar + dr[k], c = ac + dc[k];
+                        if(r < 0 || c < 0 || r >= P.map.h * 64 || c >= P.map.w * 64) continue;      // M_Tile_RelativeDesc
+                        const size_t idx = ((size_t)((r >> 6) * P.map.w + (c >> 6)) << 12) + (r & 63) * 64 + (c & 63);
+                        const uint16_t *bl = P.map.layers[layer].blockers;
+                        adj = adj || P.map.layers[layer].cost[idx] == NAVHIP_COST_IMPASSABLE || (bl && bl[idx] > 0);
+                    }
+                }
+                if(adj) {
+                    // N_IsMaximallyClose, nav.c:4727-4740: any of the destination's closest island tiles
+                    // within the threshold (centre as the reference computes it: map_pos -/+ tile * 4)
+                    bool close = false;
+                    for(int k = in.flock_tiles_off[flock] + gl; k < in.flock_tiles_off[flock + 1]; k += 16) {
+                        const float cx = P.map_x - (float)in.flock_tiles[2 * k + 1] * 4.0f;
+                        const float cz = P.map_z + (float)in.flock_tiles[2 * k] * 4.0f;
+                        close = close || vlen(vsub(mkv(cx, cz), np)) <= thresh;
+                    }
+                    arr = g::any(close);
+                }
+            }
+            if(!arr) {
+                const v2 nearest = mkv(in.flock_nearest_xz[2 * flock], in.flock_nearest_xz[2 * flock + 1]);
+                if(nearest.x == nearest.x) arr = vlen(vsub(nearest, np)) < thresh;                   // :2187-2192
+            }
+            if(!arr) {
+                // ---- a flock mate that touches us has arrived, :2480-2497 (positions and states of the
+                // snapshot: adjacent_flock_members reads the tick's tables)
+                const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+                bool hit = false;
+                const int b = P.flock_offsets[flock], e = P.flock_offsets[flock + 1];
+                for(int k0 = b; k0 < e && !g::any(hit); k0 += 16) {
+                    const int k = k0 + gl;
+                    if(k < e) {
+                        const int m = P.flock_members[k];
+                        if(m != uid && P.state[m] == NAVHIP_STATE_ARRIVED) {
+                            const v2 mp = mkv(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
+                            hit = vlen(vsub(me, mp)) <= radius + P.radius[m] + 5.0f;                  // ADJACENCY_SEP_DIST
+                        }
+                    }
+                }
+                arr = g::any(hit);
+            }
+            if(arr) {
+                flags = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; next = NAVHIP_STATE_ARRIVED;
+            }else{
+                const v2 vdes = mkv(in.vdes_xz[2 * uid], in.vdes_xz[2 * uid + 1]);
+                if(vlen(vdes) < 1.0f / 1024.0f) {                          // :2508
+                    flags = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; next = NAVHIP_STATE_WAITING;
+                }
+            }
+        }
+    }
+    if(gl == 0) { out_state[uid] = next; out_flags[uid] = flags; }
+}
+
+void nh_launch_state_update(const nh_step_params &P, const navhip_state_in &in, uint8_t *d_state, uint8_t *d_flags,
+                            hipStream_t s)
+{
+    const int n = P.work_end - P.work_begin;
+    if(n > 0)
+        hipLaunchKernelGGL(k_state_update, dim3((n + 15) / 16), dim3(256), 0, s, P, in, d_state, d_flags);
+}
+
 // N_DesiredGroupArrivalVelocity (nav.c:3561): direction under each point in the chunk field of its mapping
 // row + "the tile is a sink inside the zone's disc" (:3596-3600)
 __global__ __launch_bounds__(256) void k_region_lookup(nh_step_params P, int nq, const float *pos, const int32_t *rows,

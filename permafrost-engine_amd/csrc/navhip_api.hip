@@ -1174,6 +1174,73 @@ int navhip_agent_step(navhip_ctx *ctx, const navhip_world *w, const navhip_step_
     return NAVHIP_OK;
 }
 
+int navhip_state_update_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_state_in *in,
+                            uint8_t *out_state, uint8_t *out_flags, void *stream)
+{
+    if(!ctx || !w || !in || !out_state || !out_flags) return NAVHIP_ERR_INVALID;
+    if(w->n_ents < 0) return NAVHIP_ERR_INVALID;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    if(!w->pos_xz || !w->radius || !w->flags || !w->state || !w->flock || !in->new_pos_xz || !in->vdes_xz
+    || (w->n_flocks > 0 && (!w->flock_target_xz || !w->flock_offsets || !w->flock_members || !in->flock_layer
+                            || !in->flock_nearest_xz || !in->flock_tiles_off || !in->flock_tiles)))
+        return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    nh_step_params P;
+    memset(&P, 0, sizeof(P));
+    fill_map_view(ctx, &P.map);
+    P.map_x = w->map_pos_x; P.map_z = w->map_pos_z;
+    P.n_ents = w->n_ents; P.n_flocks = w->n_flocks; P.hz = w->hz;
+    P.work_begin = w->work_begin; P.work_end = w->work_end;
+    if(P.work_begin == 0 && P.work_end == 0) P.work_end = w->n_ents;
+    if(P.work_begin < 0 || P.work_end > w->n_ents || P.work_begin > P.work_end) return NAVHIP_ERR_INVALID;
+    P.pos_xz = w->pos_xz; P.radius = w->radius; P.flags = w->flags; P.state = w->state; P.flock = w->flock;
+    P.flock_target_xz = w->flock_target_xz; P.flock_offsets = w->flock_offsets; P.flock_members = w->flock_members;
+    nh_launch_state_update(P, *in, out_state, out_flags, stream ? (hipStream_t)stream : ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_state_update(navhip_ctx *ctx, const navhip_world *w, const navhip_state_in *in,
+                        uint8_t *out_state, uint8_t *out_flags)
+{
+    if(!ctx || !w || !in || !out_state || !out_flags) return NAVHIP_ERR_INVALID;
+    if(w->n_ents <= 0) return w->n_ents == 0 ? NAVHIP_OK : NAVHIP_ERR_INVALID;
+    if(w->n_flocks > 0 && (!w->flock_offsets || !in->flock_tiles_off)) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t n = (size_t)w->n_ents, F = (size_t)w->n_flocks;
+    const size_t nmembers = F ? (size_t)w->flock_offsets[F] : 0, ntiles = F ? (size_t)in->flock_tiles_off[F] : 0;
+    navhip_world d = *w;
+    navhip_state_in di = *in;
+    int rc = 0;
+#define ST(slot, src, dst, bytes) if(!rc) rc = stage_in(ctx, slot, src, (bytes), (const void**)&dst, s)
+    ST(0, w->pos_xz, d.pos_xz, n * 8);       ST(2, w->radius, d.radius, n * 4);   ST(5, w->flags, d.flags, n * 4);
+    ST(6, w->state, d.state, n);             ST(8, w->flock, d.flock, n * 4);
+    ST(10, w->flock_target_xz, d.flock_target_xz, F * 8);
+    ST(11, w->flock_offsets, d.flock_offsets, (F + 1) * 4);
+    ST(12, w->flock_members, d.flock_members, nmembers * 4);
+    ST(16, in->new_pos_xz, di.new_pos_xz, n * 8);   ST(17, in->vdes_xz, di.vdes_xz, n * 8);
+    ST(7, in->skip, di.skip, n);
+    ST(33, in->flock_layer, di.flock_layer, F);     ST(34, in->flock_nearest_xz, di.flock_nearest_xz, F * 8);
+    ST(35, in->flock_tiles_off, di.flock_tiles_off, (F + 1) * 4);
+    ST(41, in->flock_tiles, di.flock_tiles, (ntiles ? ntiles : 1) * 4);
+#undef ST
+    if(!rc) rc = ensure_buf(ctx, ctx->stage[32], 2 * n);
+    if(rc) return rc;
+    nh_async_invalidate_static(ctx);
+    uint8_t *d_out = (uint8_t*)ctx->stage[32].p;
+    rc = navhip_state_update_dev(ctx, &d, &di, d_out, d_out + n, s);
+    if(rc) return rc;
+    size_t b = (size_t)w->work_begin, e = (size_t)w->work_end;
+    if(b == 0 && e == 0) e = n;
+    if(e > b) {
+        HIPCHK(ctx, hipMemcpyAsync(out_state + b, d_out + b, e - b, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(out_flags + b, d_out + n + b, e - b, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
 int navhip_region_lookup(navhip_ctx *ctx, int nq, const float *pos_xz, const int32_t *rows,
                          const int32_t *region_field_slot, int n_region_rows, const uint8_t *field_pool,
                          int n_field_slots, const int32_t *centre_abs, const int32_t *radius,

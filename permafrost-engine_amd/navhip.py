@@ -355,7 +355,19 @@ class StepOut(C.Structure):
                 ("vpref_xz", C.c_void_p), ("status", C.c_void_p)]
 
 
+class StateIn(C.Structure):
+    """navhip_state_in, include/navhip.h"""
+    _fields_ = [("new_pos_xz", C.c_void_p), ("vdes_xz", C.c_void_p), ("skip", C.c_void_p),
+                ("flock_layer", C.c_void_p), ("flock_nearest_xz", C.c_void_p), ("flock_tiles_off", C.c_void_p),
+                ("flock_tiles", C.c_void_p)]
+
+
+SU_SET_STATE, SU_BLOCK, SU_HOST = 0x01, 0x02, 0x80
+
 _SIGS.update({
+    "navhip_state_update": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StateIn), C.c_void_p, C.c_void_p]),
+    "navhip_state_update_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StateIn), C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
     "navhip_agent_step": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut)]),
     "navhip_agent_step_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut), C.c_void_p]),
     "navhip_agent_prefetch_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p]),
@@ -628,6 +640,34 @@ def _ctx_region_lookup(self, pos_xz, rows, region_field_slot=None, field_pool=No
     return out, at
 
 
+def _ctx_state_update(self, arrays, new_pos_xz, vdes_xz, flock_layer, flock_nearest_xz, flock_tiles, skip=None,
+                      hz=20, work=None):
+    """The arrival arm of entity_compute_update (movement.c:2303) for every unit of the snapshot `arrays`.
+    flock_tiles: list of [k, 2] int16 arrays (absolute (row, col) tiles per flock).  Returns (next_state, flags)."""
+    w, keep = make_world(self.w, self.h, arrays, hz)
+    if work is not None:
+        w.work_begin, w.work_end = work
+    n = w.n_ents
+    si = StateIn()
+    k = {"np": np.ascontiguousarray(new_pos_xz, np.float32).reshape(n, 2),
+         "vd": np.ascontiguousarray(vdes_xz, np.float32).reshape(n, 2),
+         "fl": np.ascontiguousarray(flock_layer, np.uint8),
+         "fn": np.ascontiguousarray(flock_nearest_xz, np.float32).reshape(-1, 2)}
+    offs = np.zeros(len(flock_tiles) + 1, np.int32)
+    offs[1:] = np.cumsum([len(t) for t in flock_tiles])
+    tiles = np.concatenate([np.asarray(t, np.int16).reshape(-1, 2) for t in flock_tiles] + [np.zeros((1, 2), np.int16)])
+    k["to"], k["tt"] = offs, np.ascontiguousarray(tiles)
+    si.new_pos_xz, si.vdes_xz = k["np"].ctypes.data, k["vd"].ctypes.data
+    si.flock_layer, si.flock_nearest_xz = k["fl"].ctypes.data, k["fn"].ctypes.data
+    si.flock_tiles_off, si.flock_tiles = k["to"].ctypes.data, k["tt"].ctypes.data
+    if skip is not None:
+        k["sk"] = np.ascontiguousarray(skip, np.uint8)
+        si.skip = k["sk"].ctypes.data
+    st, fl = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    self._chk(lib().navhip_state_update(self._h, C.byref(w), C.byref(si), _hp(st), _hp(fl)), "navhip_state_update")
+    return st, fl
+
+
 def _ctx_pool_invalidate(self, ff_id):
     self._chk(lib().navhip_pool_invalidate(self._h, int(ff_id)), "navhip_pool_invalidate")
 
@@ -724,6 +764,7 @@ NavContext.comm_allgather_rows_dev = _ctx_comm_allgather_rows_dev
 NavContext.pool_contains = _ctx_pool_contains
 NavContext.pool_invalidate = _ctx_pool_invalidate
 NavContext.region_lookup = _ctx_region_lookup
+NavContext.state_update = _ctx_state_update
 NavContext.pool_map = _ctx_pool_map
 NavContext.agent_step_async = _ctx_agent_step_async
 NavContext.set_profiling = _ctx_set_profiling
