@@ -306,6 +306,7 @@ def main():
 
     T = make(args.crowded)
     fields_ahead, tick_every = T.pipeline_fields, T.tick_every
+    request_source = T.request_source
     early = {}
     dt, ticks = run_ticks(T, pdist, torch, args.warmup, args.steps, early)
     phases = T.phase_ms()
@@ -427,6 +428,7 @@ def main():
                        "agents": cfg["agents"], "hz": 20, "dynamic_obstacles": cfg["obstacles"],
                        "parallelism": "requests by destination + agent slabs x%d; one all-gather of slab results "
                                       "(16 B/agent) per tick; baked tiles: %s" % (world, args.tile_exchange),
+                       "requests": request_source,
                        "schedule": ("fields of tick t+1 built during tick t beside the agent step (double-buffered pool)"
                                     if fields_ahead else "fields of tick t built in front of the agent step of tick t")},
             "ms_per_step_median": float(np.median(ticks)),

@@ -234,3 +234,30 @@ def whole_map_requests(grid, dests, liid=None):
                      port_iid=int(liid[cr * 64 + ep[0], cc * 64 + ep[1]]),
                      next_iid=int(liid[nb[0] * 64 + nep[0], nb[1] * 64 + nep[1]]))
     return {k: np.asarray(v, np.int64) for k, v in cols.items()}
+
+
+# ------------------------------------------------------------------------------------------
+# the same request stream as the REFERENCE'S PLANNER emits it (committed fixtures)
+# ------------------------------------------------------------------------------------------
+def planner_requests(grid, dests):
+    """The whole-map request stream of (grid, dests) as permafrost-engine's own planner chose it
+    (n_request_path, nav.c:1774: its portals, its island ids) -- from the fixtures under data/ that
+    tests/tools/make_requests.py generated with the reference build -- or None when there is no fixture for
+    exactly this map and these destinations (then: whole_map_requests, the numpy stand-in).  Same dict of
+    columns as whole_map_requests."""
+    import glob
+    import hashlib
+    import os
+    h = hashlib.sha1()
+    h.update(np.ascontiguousarray(grid).tobytes())
+    h.update(np.ascontiguousarray(dests, np.int64).tobytes())
+    key = h.hexdigest()
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+    for path in sorted(glob.glob(os.path.join(here, "requests_*.npz"))):
+        d = np.load(path)
+        if str(d["key"]) != key:
+            continue
+        cols = {k: (d[k].astype(np.int64) if k in d.files else np.zeros(len(d["dest"]), np.int64)) for k in REQ_FIELDS}
+        cols["dest"] = d["dest"].astype(np.int64)
+        return cols
+    return None

@@ -42,7 +42,7 @@ class NavTick:
     def __init__(self, chunk_w=16, fields_per_rank=64, agents_per_rank=100_000, rank=0, world=1,
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
-                 debug_outputs=False, pipeline_fields=False, exchange="torch"):
+                 debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -130,9 +130,14 @@ class NavTick:
         req_parts, dest_of_req, self.req_bounds, nreq = [], [], [(0, 0)] * world, 0
         for q in regions:
             r0, r1, c0, c1 = region_cells(q)
-            cols = synth.whole_map_requests(grid[r0:r1, c0:c1],
-                                            dests[q * fields_per_rank:(q + 1) * fields_per_rank]
-                                            - np.array([r0, c0]), liid[r0:r1, c0:c1])
+            d_q = dests[q * fields_per_rank:(q + 1) * fields_per_rank] - np.array([r0, c0])
+            # the reference planner's own request stream where a fixture holds it (the single-GPU configs:
+            # tests/tools/make_requests.py), else the numpy stand-in
+            cols = synth.planner_requests(grid[r0:r1, c0:c1], d_q) if planner_requests else None
+            self.request_source = "reference planner (n_request_path) fixture" if cols is not None else \
+                "numpy stand-in (synth.whole_map_requests)"
+            if cols is None:
+                cols = synth.whole_map_requests(grid[r0:r1, c0:c1], d_q, liid[r0:r1, c0:c1])
             n_q = len(cols["type"])
             reqs_q = navhip.make_reqs(n_q)
             for k in synth.REQ_FIELDS:
