@@ -119,7 +119,7 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10
         dests = synth.destinations(grid, k_fields, seed=42)
         # (i) chunk fields: a random sample of the very request list the GPU builds every tick
         liid = synth.from_chunks(nav.plane(pfref.PLANE_LOCAL_ISLANDS))
-        cols = synth.whole_map_requests(grid, dests, liid)
+        cols = synth.planner_requests(grid, dests) or synth.whole_map_requests(grid, dests, liid)
         n_all = len(cols["type"])
         reqs_all = np.zeros(n_all, pfref.FIELD_REQ_DTYPE)
         for k in synth.REQ_FIELDS:

@@ -11,7 +11,14 @@
 // kernel therefore emulates that heap operation for operation: the wavefront is inherently
 // sequential, so ONE LANE runs it out of LDS while the wave's other lanes only help with the
 // staging, the final padding and the coalesced store.  Parallelism comes from the batch: one wave
-// per LOS field, 7 fields resident per CU (21 KB of LDS each).
+// per LOS field -- so what bounds the throughput is how many fields a CU holds at once, i.e. LDS:
+//   * the heap only ever holds TWO consecutive priorities (the popped level p and p + 1: every push is
+//     p + 1, every entry was pushed by a tile popped at a level <= p), so a node needs no stored
+//     priority: its level's parity rides in bit 12 of the tile index (one 16-bit word per node);
+//   * the frontier of a 64 x 64 field is a few hundred tiles: the heap gets 1 022 nodes (2 KB), and a
+//     field whose heap would overflow is left to a second launch of the same kernel with room for all
+//     4 096 tiles (one look at a flag per request when nothing overflowed).
+// 6 KB of LDS per field instead of 21: 26 fields per CU instead of 7.
 //
 // LOS fields are built once per (destination, chunk) when a path is planned and then cached
 // (nav.c:1840-1847,2026-2039), so this kernel is latency- not throughput-critical.
@@ -24,34 +31,40 @@
 #define LF_COSTLY    0x10      /* neighbour cost > 1: cost_base > 1 or not passable (:337-348) */
 #define LF_RAWBLK    0x20      /* cost_base == 0xff || blockers > 0 (field_is_los_corner)     */
 
-struct los_heap { int size; };      // nodes live in LDS: prio[1..size], cell[1..size]
+struct los_heap { int size; };      // nodes live in LDS: node[1..size] = tile | (priority & 1) << 12
 
-// pq_coord_push, pqueue.h:150
-__device__ __forceinline__ void lh_push(los_heap &h, uint16_t *prio, uint16_t *cell, int p, int c)
+#define LH_TILE(v)  ((int)((v) & 0x0fff))
+// priority of a node relative to the level `lo` being popped: 0 (== lo) or 1 (== lo + 1)
+#define LH_REL(v, lo) ((int)((((v) >> 12) ^ (lo)) & 1))
+
+// pq_coord_push, pqueue.h:150.  p is lo or lo + 1 and no node is above lo + 1: `prio[parent] > p` can only
+// hold for p == lo under a parent at lo + 1.
+__device__ __forceinline__ void lh_push(los_heap &h, uint16_t *node, int lo, int p, int c)
 {
     int curr = h.size + 1, parent = curr / 2;
-    while(curr > 1 && prio[parent] > p) {
-        prio[curr] = prio[parent]; cell[curr] = cell[parent];
+    const int rel = (p ^ lo) & 1;
+    while(curr > 1 && LH_REL(node[parent], lo) > rel) {
+        node[curr] = node[parent];
         curr = parent;
         parent = parent / 2;
     }
-    prio[curr] = (uint16_t)p; cell[curr] = (uint16_t)c;
+    node[curr] = (uint16_t)(c | ((p & 1) << 12));
     h.size++;
 }
 
 // pq_coord_pop + _pq_balance, pqueue.h:112-133,173-183
-__device__ __forceinline__ void lh_pop(los_heap &h, uint16_t *prio, uint16_t *cell)
+__device__ __forceinline__ void lh_pop(los_heap &h, uint16_t *node, int lo)
 {
-    prio[1] = prio[h.size]; cell[1] = cell[h.size];
+    node[1] = node[h.size];
     h.size--;
     int root = 1;
     const int last = h.size + 1;
     while(root != last) {
         int target = last;
         const int l = root * 2, r = l + 1;
-        if(l <= h.size && prio[l] < prio[target]) target = l;
-        if(r <= h.size && prio[r] < prio[target]) target = r;
-        prio[root] = prio[target]; cell[root] = cell[target];
+        if(l <= h.size && LH_REL(node[l], lo) < LH_REL(node[target], lo)) target = l;
+        if(r <= h.size && LH_REL(node[r], lo) < LH_REL(node[target], lo)) target = r;
+        node[root] = node[target];
         root = target;
     }
 }
@@ -101,15 +114,20 @@ __device__ __forceinline__ bool los_corner(const uint8_t *fl, int r, int c)
     return false;
 }
 
+// CAP: heap nodes.  overflow[ri]: set by the CAP = 1022 launch for a field it gave up on; the CAP = 4096
+// launch (REDO) only builds those.
+template <int CAP, bool REDO>
 __global__ __launch_bounds__(64) void k_los_field(nh_map_view map, const navhip_los_req *reqs, int n,
                                                   const uint8_t *prev_fields, uint8_t *out_fields,
-                                                  float map_x, float map_z)
+                                                  float map_x, float map_z, uint8_t *overflow)
 {
-    __shared__ uint16_t h_prio[NH_CELLS + 2];
-    __shared__ uint16_t h_cell[NH_CELLS + 2];
+    __shared__ uint16_t h_node[CAP + 2];
     __shared__ __attribute__((aligned(16))) uint8_t fl[NH_CELLS];
+    __shared__ int s_over;
     const int ri = blockIdx.x, lane = threadIdx.x;
     if(ri >= n) return;
+    if(REDO && !overflow[ri]) return;
+    if(lane == 0) s_over = 0;
     const navhip_los_req rq = reqs[ri];
     const nh_layer_view &L = map.layers[rq.layer];
     const size_t cbase = (size_t)((int)rq.chunk_r * map.w + rq.chunk_c) << 12;
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(64) void k_los_field(nh_map_view map, const navhip_
         if(first) {
             // case 1, field.c:2111-2115: the destination chunk
             const int t = rq.target_tile_r * 64 + rq.target_tile_c;
-            lh_push(H, h_prio, h_cell, 0, t);
+            lh_push(H, h_node, 0, 0, t);
             fl[t] |= LF_ASSIGNED | LF_INHEAP;
         }else{
             // case 2, field.c:2122-2193: carry the shared edge over from the previous chunk's field
@@ -166,14 +184,18 @@ __global__ __launch_bounds__(64) void k_los_field(nh_map_view map, const navhip_
                 if(pv & LF_WFB)
                     los_blocked_line(fl, map_x, map_z, rq, ci >> 6, ci & 63);
                 if(fl[ci] & LF_VISIBLE) {
-                    lh_push(H, h_prio, h_cell, 0, ci);
+                    lh_push(H, h_node, 0, 0, ci);
                     fl[ci] |= LF_ASSIGNED | LF_INHEAP;
                 }
             }
         }
-        while(H.size > 0) {
-            const int cur = h_cell[1], cprio = h_prio[1];
-            lh_pop(H, h_prio, h_cell);
+        int cprio = 0;                          // the level being popped (the root's priority)
+        bool over = false;
+        while(H.size > 0 && !over) {
+            const uint16_t top = h_node[1];
+            const int cur = LH_TILE(top);
+            cprio += LH_REL(top, cprio);          // the root is the minimum: lo, or lo + 1 once lo is used up
+            lh_pop(H, h_node, cprio);
             fl[cur] &= (uint8_t)~LF_INHEAP;
             const int r = cur >> 6, c = cur & 63;
             // field_neighbours_grid_los :304: the 4 neighbours that are not wavefront blocked,
@@ -195,15 +217,19 @@ __global__ __launch_bounds__(64) void k_los_field(nh_map_view map, const navhip_
                     if(!(fl[ni] & LF_ASSIGNED)) {
                         fl[ni] |= LF_ASSIGNED;
                         if(!(fl[ni] & LF_INHEAP)) {
-                            lh_push(H, h_prio, h_cell, cprio + 1, ni);
+                            if(H.size >= CAP) { over = true; break; }
+                            lh_push(H, h_node, cprio, cprio + 1, ni);
                             fl[ni] |= LF_INHEAP;
                         }
                     }
                 }
             }
         }
+        s_over = over ? 1 : 0;
+        if(!REDO) overflow[ri] = over ? 1 : 0;
     }
     __syncthreads();
+    if(s_over) return;                     // (left to the launch with room for every tile)
 
     // ---- field_pad_wavefront (:519): tiles within one tile of a blocked tile are not visible.
     // In place: only VISIBLE bits are cleared while only WFB bits are read.
@@ -235,7 +261,12 @@ void nh_launch_los(navhip_ctx *ctx, const navhip_los_req *d_reqs, int n, const u
         mv.layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
                                      L.passmask, L.unit_cost, L.changed, L.islands};
     }
-    if(n > 0)
-        hipLaunchKernelGGL(k_los_field, dim3(n), dim3(64), 0, s, mv, d_reqs, n, d_prev, d_out, map_x,
-                           map_z);
+    if(n > 0) {
+        uint8_t *d_over = nullptr;
+        if(navhip_stage_reserve(ctx, 42, (size_t)n, (void**)&d_over) != NAVHIP_OK) return;
+        hipLaunchKernelGGL((k_los_field<1022, false>), dim3(n), dim3(64), 0, s, mv, d_reqs, n, d_prev, d_out, map_x,
+                           map_z, d_over);
+        hipLaunchKernelGGL((k_los_field<4096, true>), dim3(n), dim3(64), 0, s, mv, d_reqs, n, d_prev, d_out, map_x,
+                           map_z, d_over);
+    }
 }
