@@ -1009,6 +1009,10 @@ __device__ unsigned long long nh_cp_hist[4][32];
 #ifndef CP_WAVES
 #define CP_WAVES 4
 #endif
+// problems on the workgroup lists from which one wave takes one problem (k_cp_heavy_solo) instead of a team
+#ifndef CP_SOLO_MIN
+#define CP_SOLO_MIN 8192
+#endif
 
 // first k with end[k] > u
 __device__ __forceinline__ int first_above(const int32_t *end, int n, int u)
@@ -1210,6 +1214,7 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
     __syncthreads();
     HIST_T0();
     const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
+    if(n_heavy >= CP_SOLO_MIN) return;               // (k_cp_heavy_solo's tick)
     int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
     cp_lds<64> &S = lds[wib];
     for(int round = 0; ; round++) {
@@ -1246,6 +1251,64 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
                 post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
             HIST_UNIT(0, tu0);
         }
+    }
+    HIST_WAVE(0);
+}
+
+// ---- k_cp_heavy_solo: the same two lists, one problem per WAVE.  In a jam there are more of these
+// problems than the launch has waves (16 000 at tick 100 of the benchmark, 22 000 in the crowded world):
+// the load balances over problems, and a team only repeats the cone / rank construction four times and
+// waits at its barriers.  Both kernels are launched every tick and look at the list length: at
+// CP_SOLO_MIN problems and above this one runs, below it the team kernel. ---
+#ifdef CP_HEAVY_OCC
+__attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
+#endif
+__global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy_solo(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                                 nh_worklists WL, nh_step_outs O)
+{
+    __shared__ cp_lds<64> lds[CP_WAVES];
+    __shared__ int32_t hv_end[2 * NH_WL_SUB];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
+    if(threadIdx.x == 0) {
+        int run = 0;
+        for(int k = 0; k < 2 * NH_WL_SUB; k++) {
+            run += WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB];
+            hv_end[k] = run;
+        }
+    }
+    __syncthreads();
+    HIST_T0();
+    const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
+    if(n_heavy < CP_SOLO_MIN) return;
+    int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
+    const int nw = (int)gridDim.x * CP_WAVES;
+    cp_lds<64> &S = lds[wib];
+    for(int round = 0; ; round++) {
+        int t = (int)blockIdx.x * CP_WAVES + wib;
+        if(round > 0) {
+            int v = 0x7fffffff;
+            if(lane == 0 && nw + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy) v = nw + atomicAdd(ticket, 1);
+            t = __shfl(v, 0);
+        }
+        if(t >= n_heavy) break;
+        const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
+        const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
+        const nh_mid_rec R = mid[uid];
+        const uint32_t c = NB.cnt[uid];
+        const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+        cpent ent;
+        ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+        ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+        ent.radius = P.radius[uid];
+#ifdef NH_CP_UNIT_HIST
+        const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
+#endif
+        cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
+        const v2 nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S);
+        if(lane == 0)
+            post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
+        HIST_UNIT(0, tu0);
     }
     HIST_WAVE(0);
 }
@@ -1745,6 +1808,7 @@ void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     hipLaunchKernelGGL(k_cp_rows, dim3(64), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_RETRY, 1, 1);
     hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
+    hipLaunchKernelGGL(k_cp_heavy_solo, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
     if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk), dim3(CP_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_ROW3, 2, 0);

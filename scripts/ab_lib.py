@@ -3,8 +3,8 @@
 optimisations).  `--build NAME -DFLAG ...` cross-compiles a variant of libnavhip.so with extra flags
 into build_prof/libnavhip_NAME.so (no GPU needed; the directory travels to the GPU box);
 `--build-rev NAME REV` does the same for the kernel sources of a git revision (e.g. HEAD, to judge the
-uncommitted change); `--run A B ...` alternates bench.py over the variants (`base` = the in-tree
-build), 3 rounds."""
+uncommitted change); `--run A B ... [--rounds=N] [--steps=K] [--crowded]` alternates bench.py over the
+variants (`base` = the in-tree build), 3 rounds."""
 import json
 import os
 import subprocess
@@ -44,7 +44,7 @@ def run(names, rounds=3, extra=()):
                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             res[n].append(d["ms_per_step"])
-            print(n, round(d["ms_per_step"], 4), round(d["ms_per_step_median"], 4), [round(x, 3) for x in d["ms_tick_5_50_100"]], flush=True)
+            print(n, round(d["ms_per_step"], 4), round(d["ms_per_step_median"], 4), [round(x, 3) for x in d.get("ms_tick_5_50_100") or [] if x is not None], flush=True)
     for n in names:
         v = sorted(res[n])
         print("%-12s median %.4f ms/tick  (min %.4f)" % (n, v[len(v) // 2], v[0]))
@@ -62,6 +62,12 @@ if __name__ == "__main__":
                 subprocess.check_output(["git", "show", "%s:%s" % (sys.argv[3], f)], cwd=ROOT))
         build(sys.argv[2], [], csrc=src)
     elif sys.argv[1] == "--run":
-        names = [a for a in sys.argv[2:] if not a.startswith("--rounds=")]
+        names = [a for a in sys.argv[2:] if not a.startswith("--")]
         rounds = [int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("--rounds=")]
-        run(names, rounds=rounds[0] if rounds else 3, extra=("--no-cpu-baseline", "--no-crowded"))
+        steps = [a.split("=")[1] for a in sys.argv[2:] if a.startswith("--steps=")]
+        extra = ["--no-cpu-baseline", "--no-crowded"]
+        if "--crowded" in sys.argv:          # the crowded world as the main run
+            extra = ["--no-cpu-baseline", "--crowded", "--warmup", "3"]
+        if steps:
+            extra += ["--steps", steps[0]]
+        run(names, rounds=rounds[0] if rounds else 3, extra=extra)
