@@ -42,7 +42,8 @@ class NavTick:
     def __init__(self, chunk_w=16, fields_per_rank=64, agents_per_rank=100_000, rank=0, world=1,
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
-                 debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True):
+                 debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True,
+                 straddle=0.0):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -117,17 +118,41 @@ class NavTick:
             a["flock"] = a["flock"] + q * fields_per_rank
             ag_parts.append(a)
         dests = np.concatenate(dests)
+        if straddle > 0 and world > 1:
+            # flocks that straddle ranks: in the last `straddle` of every rank's uid slab sit agents of the
+            # NEXT region (position and flock; the lower half of its flocks only) -- stepped here, sampling
+            # fields another rank builds
+            m = int(round(agents_per_rank * (1.0 - straddle)))
+            swapped = []
+            for q, a in enumerate(ag_parts):
+                nxt = ag_parts[(q + 1) % world]
+                take = np.zeros(agents_per_rank, bool)
+                take[m:] = (nxt["flock"][m:] % fields_per_rank) < max(1, fields_per_rank // 2)
+                swapped.append({k: (v if k == "hz" else
+                                    np.where(take.reshape((-1,) + (1,) * (np.ndim(v) - 1)), nxt[k], v))
+                                for k, v in a.items()})
+            ag_parts = swapped
         ag = {k: (np.concatenate([a[k] for a in ag_parts]) if k != "hz" else hz) for k in ag_parts[0]}
 
         # ---- request stream: region-major, destination-major inside a region -------------------
         # tile_exchange: "auto" = only the fields some other rank samples travel (none when flocks
-        # are rank aligned, as here); "all" = every rank holds every tile, all-gathered every tick
+        # are rank aligned, the default world; `straddle` makes some); "all" = every rank holds every
+        # tile, all-gathered every tick
         # (SURVEY section 8(e) worst case: any agent may sample any field)
         # solo (tests): this one process builds every region's fields and steps every agent
         self.solo = bool(solo)
         self.tile_exchange = "all" if ((tile_exchange == "all" or solo) and world > 1) else "none"
-        regions = range(world) if self.tile_exchange == "all" else [rank]
+        # "auto": destination d (built by rank d // fields_per_rank) travels when some agent of its flock
+        # sits in another rank's uid slab
+        travels = np.zeros(self.K, bool)
+        if world > 1:
+            stepped_by = np.arange(self.N) // agents_per_rank
+            travels[np.unique(ag["flock"][stepped_by != ag["flock"] // fields_per_rank])] = True
+            if self.tile_exchange == "none" and travels.any():
+                self.tile_exchange = "auto"
+        regions = range(world) if self.tile_exchange != "none" else [rank]
         req_parts, dest_of_req, self.req_bounds, nreq = [], [], [(0, 0)] * world, 0
+        self.xchg_bounds = [(0, 0)] * world        # the rows of a rank the others need
         for q in regions:
             r0, r1, c0, c1 = region_cells(q)
             d_q = dests[q * fields_per_rank:(q + 1) * fields_per_rank] - np.array([r0, c0])
@@ -139,6 +164,14 @@ class NavTick:
             if cols is None:
                 cols = synth.whole_map_requests(grid[r0:r1, c0:c1], d_q, liid[r0:r1, c0:c1])
             n_q = len(cols["type"])
+            if self.tile_exchange == "auto":
+                # the travelling destinations' requests first: one contiguous run per rank to exchange
+                first = travels[np.asarray(cols["dest"]) + q * fields_per_rank]
+                order = np.argsort(~first, kind="stable")
+                cols = {k: np.asarray(v)[order] for k, v in cols.items() if k in synth.REQ_FIELDS or k == "dest"}
+                self.xchg_bounds[q] = (nreq, nreq + int(first.sum()))
+            else:
+                self.xchg_bounds[q] = (nreq, nreq + n_q)
             reqs_q = navhip.make_reqs(n_q)
             for k in synth.REQ_FIELDS:
                 reqs_q[k] = cols[k]
@@ -159,7 +192,7 @@ class NavTick:
         # field slot = position in the (local) request stream
         self.req_begin, self.req_end = (0, n_req) if solo else self.req_bounds[rank]
         self.n_req_local = self.req_end - self.req_begin
-        self.n_req_total = self.n_req_local * world if self.tile_exchange != "all" else n_req
+        self.n_req_total = self.n_req_local * world if self.tile_exchange == "none" else n_req
         self._dest_of_req = dest_of_req
         slot_tbl = -np.ones((self.K, self.nchunks), np.int32)
         slot_tbl[dest_of_req, reqs["chunk_r"].astype(np.int64) * Wt + reqs["chunk_c"]] = np.arange(n_req)
@@ -268,9 +301,9 @@ class NavTick:
             if self.n_req_local:                       # the fields of tick 0 (start-up, untimed)
                 self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
                                           self.pool[self.req_begin:self.req_end], stream=self.stream.cuda_stream)
-            if self.tile_exchange == "all" and not self.solo:
+            if self.tile_exchange != "none" and not self.solo:
                 with torch.cuda.stream(self.stream):
-                    pdist.exchange_rows(self.pool, self.req_bounds, self.rank, self.world)
+                    pdist.exchange_rows(self.pool, self.xchg_bounds, self.rank, self.world)
             self.ev_fields.record(self.stream)
             self.stream.synchronize()
         self.ev = []                   # (phase, start_event, end_event) of the timed steps
@@ -345,8 +378,8 @@ class NavTick:
             if self.n_obstacles:
                 self.ctx.clear_changed(stream=s.cuda_stream)
             marks.append(self._mark("gather_tiles"))
-            if self.tile_exchange == "all" and not self.solo:
-                pdist.exchange_rows(self.pool, self.req_bounds, self.rank, self.world)
+            if self.tile_exchange != "none" and not self.solo:
+                pdist.exchange_rows(self.pool, self.xchg_bounds, self.rank, self.world)
             marks.append(self._mark("agents"))
             if self._comm_pending:
                 s.wait_event(self.ev_comm)            # the other ranks' rows of the snapshot
@@ -379,8 +412,8 @@ class NavTick:
             if timed:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record(f)
-            if self.tile_exchange == "all" and not self.solo:
-                pdist.exchange_rows(self.pool_next, self.req_bounds, self.rank, self.world)
+            if self.tile_exchange != "none" and not self.solo:
+                pdist.exchange_rows(self.pool_next, self.xchg_bounds, self.rank, self.world)
             if timed:
                 e2 = torch.cuda.Event(enable_timing=True)
                 e2.record(f)

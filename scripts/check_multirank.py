@@ -3,7 +3,7 @@
 snapshot must be bit-identical to ONE process that builds every field and steps every agent
 (tick.NavTick(solo=True)) on the same world.
     NAVHIP_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \\
-        --master-addr 127.0.0.1 --master-port 29512 scripts/check_multirank.py [all] [--pipeline-fields]
+        --master-addr 127.0.0.1 --master-port 29512 scripts/check_multirank.py [all] [--pipeline-fields] [--straddle]
 (on a single-GPU box the ranks share the GPU and gloo stages the exchange through the host)."""
 import os
 import sys
@@ -19,7 +19,9 @@ def main():
     mode = "all" if "all" in sys.argv else "auto"
     pipe = "--pipeline-fields" in sys.argv
     exch = "navhip" if "--exchange-navhip" in sys.argv else "torch"
-    kw = dict(chunk_w=4, fields_per_rank=6, agents_per_rank=12000, world=world, device=local)
+    # --straddle: a quarter of every rank's agents belong to flocks whose fields the next rank builds
+    kw = dict(chunk_w=4, fields_per_rank=6, agents_per_rank=12000, world=world, device=local,
+              straddle=0.25 if "--straddle" in sys.argv else 0.0)
     T = tick.NavTick(rank=rank, tile_exchange=mode, pipeline_fields=pipe, exchange=exch, **kw)
     K = 6
     for _ in range(K):
@@ -31,8 +33,11 @@ def main():
     S.sync()
     ok = torch.equal(T.t["pos_xz"], S.t["pos_xz"]) and torch.equal(T.t["vel_xz"], S.t["vel_xz"])
     moved = (S.t["vel_xz"].abs().sum(1) > 0).float().mean().item()
-    print("rank %d/%d backend=%s exchange=%s tile_exchange=%s pipelined=%s fields_ahead=%s: %s (moving fraction %.2f)"
+    sent = sum(e - b for b, e in T.xchg_bounds) if T.tile_exchange != "none" else 0
+    print("rank %d/%d backend=%s exchange=%s tile_exchange=%s (tiles travelling %d of %d) pipelined=%s fields_ahead=%s: "
+          "%s (moving fraction %.2f)"
           % (rank, world, torch.distributed.get_backend() if world > 1 else "-", T.exchange_mode, T.tile_exchange,
+             sent, len(T.host["reqs"]) if T.tile_exchange != "none" else T.n_req_total,
              T.pipelined, T.pipeline_fields, "IDENTICAL to solo" if ok else "MISMATCH", moved), flush=True)
     pdist.barrier()
     T.close(); S.close()

@@ -42,6 +42,19 @@ def test_two_ranks_equal_one_process(extra):
     assert ("backend=%s" % backend) in out
 
 
+@pytest.mark.parametrize("extra", [["--straddle"], ["--straddle", "--pipeline-fields"]])
+def test_straddling_flocks_exchange_only_their_tiles(extra):
+    """tile_exchange="auto" with flocks that straddle the ranks: a quarter of every rank's agents sample
+    fields the other rank builds; only those destinations' tiles travel (one contiguous run per rank), and
+    the result is still the one-process result."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    out = _run(2, backend, extra)
+    import re
+    m = re.search(r"tile_exchange=auto \(tiles travelling (\d+) of (\d+)\)", out)
+    assert m and 0 < int(m.group(1)) <= int(m.group(2)) // 2 + 8, out[-2000:]    # half of the flocks travel
+
+
 def test_four_ranks_over_rccl():
     import torch
     if torch.cuda.device_count() < 4:
