@@ -926,3 +926,28 @@ bool N_HIP_PoolSync(void)
     s_hip_pool.nm = 0;
     return rc == NAVHIP_OK;
 }
+
+/* ---- the destination-only half of N_IsMaximallyClose (nav.c:4707-4742) ------------------------------------
+ * The tiles of the destination's global island closest to it (n_closest_island_tiles, static in nav.c), as
+ * absolute (row, column) nav tiles: what move_hip.c hands navhip_state_update once per flock, so that the
+ * per-unit distance test of arrived() (movement.c:2170) runs on the device. */
+int N_HIP_ClosestIslandTiles(struct nav_private *priv, enum nav_layer layer, vec3_t map_pos, vec2_t xz_dest,
+                             int16_t *out_abs, int max_tiles)
+{
+    struct map_resolution res;
+    N_GetResolution(priv, &res);
+    struct tile_desc dest_td;
+    if(!M_Tile_DescForPoint2D(res, map_pos, xz_dest, &dest_td))
+        return 0;
+    struct tile_desc tds[FIELD_RES_R * 2 + FIELD_RES_C * 2];
+    const struct nav_chunk *chunk = &priv->chunks[layer][IDX(dest_td.chunk_r, priv->width, dest_td.chunk_c)];
+    const uint16_t giid = chunk->islands[dest_td.tile_r][dest_td.tile_c];
+    int ntds = n_closest_island_tiles(priv, layer, dest_td, giid, false, tds, ARR_SIZE(tds));
+    if(ntds > max_tiles)
+        ntds = max_tiles;
+    for(int i = 0; i < ntds; i++) {
+        out_abs[2 * i + 0] = (int16_t)(tds[i].chunk_r * FIELD_RES_R + tds[i].tile_r);
+        out_abs[2 * i + 1] = (int16_t)(tds[i].chunk_c * FIELD_RES_C + tds[i].tile_c);
+    }
+    return ntds;
+}

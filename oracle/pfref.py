@@ -620,6 +620,23 @@ class RefMove:
         lib().pfref_move_state_update(_p(v), _p(d), begin, end, _p(st), _p(fl))
         return st, fl
 
+    def state_update_hip(self, new_vel, vdes, begin=0, end=None):
+        """The same through bindings/permafrost/move_hip.c (move_hip_state_work + move_hip_update_work):
+        (next_state, flags, device flags NAVHIP_SU_*), or None when the device arm declined."""
+        end = self.n if end is None else end
+        v = np.ascontiguousarray(new_vel, np.float32).reshape(self.n, 2)
+        d = np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
+        st, fl, dv = np.zeros(self.n, np.uint8), np.zeros(self.n, np.uint8), np.zeros(self.n, np.uint8)
+        if not lib().pfref_move_state_update_hip(_p(v), _p(d), begin, end, _p(st), _p(fl), _p(dv)):
+            return None
+        return st, fl, dv
+
+    def hip_state_stats(self):
+        """(units decided on the device, units left to the host, passes) of the state binding."""
+        out = (C.c_long * 3)()
+        lib().pfref_move_hip_state_stats(out)
+        return tuple(out)
+
     def set_arrival(self, sink_xz, flags):
         """Fine-arrival inputs: per-unit slot + flags (bit 0 committed to a valid slot, bit 1 the
         flock's arrival region for the unit's layer is filling)."""

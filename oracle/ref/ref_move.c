@@ -372,6 +372,46 @@ int pfref_move_velocity_hip(const float *vdes, int begin, int end, float *out_ve
     return 1;
 }
 
+/* pfref_move_state_update through the binding: move_hip_state_work (ONE navhip_state_update for the slab)
+ * then move_hip_update_work per unit.  dev_flags[i] = what the device answered (NAVHIP_SU_*).
+ * Returns 0 when the device arm declined. */
+int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int begin, int end, uint8_t *out_state,
+                                uint8_t *out_flags, uint8_t *dev_flags)
+{
+    for(int i = begin; i < end; i++) {
+        struct move_work_in *in = &s_move_work.in[i];
+        struct move_work_out *out = &s_move_work.out[i];
+        struct movestate *ms = movestate_get(i);
+        in->fstate.fid = NULL_FID;
+        out->ent_uid = i;
+        out->ent_vel = (vec2_t){new_vel[2 * i], new_vel[2 * i + 1]};
+        out->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
+        if(PFM_Vec2_Len(&out->ent_vel) > EPSILON)
+            ms->next_rot = dir_quat_from_velocity(intended_heading(out->ent_des_v, out->ent_vel));
+        memset(&out->patch, 0, sizeof(out->patch));
+    }
+    if(end <= begin)
+        return 1;
+    if(!move_hip_state_work(begin, end - 1))
+        return 0;
+    for(int i = begin; i < end; i++) {
+        struct move_work_out *out = &s_move_work.out[i];
+        struct movestate *ms = movestate_get(i);
+        dev_flags[i] = s_hip_su_flags[i];
+        if(ms->state == STATE_TURNING
+        && !(G_FlagsGetFrom(s_move_work.gamestate.flags, i) & ENTITY_FLAG_GARRISONED)) {
+            out_state[i] = (uint8_t)ms->state; out_flags[i] = 0;       /* (as in pfref_move_state_update) */
+            continue;
+        }
+        move_hip_update_work(i, i);
+        const bool set = (out->patch.flags & UPDATE_SET_STATE) != 0;
+        out_state[i] = (uint8_t)(set ? out->patch.next_state : ms->state);
+        out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0));
+    }
+    return 1;
+}
+void pfref_move_hip_state_stats(long out[3]) { move_hip_state_stats(out); }
+
 struct mbench_arg{ int begin, end, reps; };
 
 static void *mbench_thread(void *p)

@@ -572,20 +572,5 @@ int pfref_closest_pathable(pfref_nav *nav, int layer, float x, float z, float ou
 
 int pfref_dest_island_tiles(pfref_nav *nav, int layer, float x, float z, int16_t *out_abs, int max_tiles)
 {
-    struct nav_private *priv = &nav->priv;
-    struct map_resolution res;
-    N_GetResolution(priv, &res);
-    struct tile_desc dest_td;
-    if(!M_Tile_DescForPoint2D(res, nav->map_pos, (vec2_t){x, z}, &dest_td))
-        return 0;
-    struct tile_desc tds[FIELD_RES_R * 2 + FIELD_RES_C * 2];
-    struct nav_chunk *chunk = &priv->chunks[layer][IDX(dest_td.chunk_r, priv->width, dest_td.chunk_c)];
-    uint16_t giid = chunk->islands[dest_td.tile_r][dest_td.tile_c];
-    int ntds = n_closest_island_tiles(priv, layer, dest_td, giid, false, tds, ARR_SIZE(tds));
-    if(ntds > max_tiles) ntds = max_tiles;
-    for(int i = 0; i < ntds; i++) {
-        out_abs[2 * i + 0] = (int16_t)(tds[i].chunk_r * FIELD_RES_R + tds[i].tile_r);
-        out_abs[2 * i + 1] = (int16_t)(tds[i].chunk_c * FIELD_RES_C + tds[i].tile_c);
-    }
-    return ntds;
+    return N_HIP_ClosestIslandTiles(&nav->priv, (enum nav_layer)layer, nav->map_pos, (vec2_t){x, z}, out_abs, max_tiles);
 }

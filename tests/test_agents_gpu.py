@@ -589,51 +589,13 @@ def test_region_field_sampling_matches_reference(navlib):
             pfref.set_enemy_factions(f, 0)
 
 
-def _state_world(seed=5):
-    """A world in which every branch of the arrival arm fires: flocks crowding round their targets (some
-    targets next to walls or ON blocked tiles), a share of the units already ARRIVED (their neighbours
-    follow), a few without guidance (vdes = 0), garrisoned units, states the host keeps."""
-    grid, nav = cases.ref_nav_for(4, 4, seed=21, layer_mask=0x3)         # (units of radius >= 5 path on layer 1)
-    n, k = 3000, 6
-    world = cases.make_agents(grid, n, k, seed=seed, clustered=True, sigma=60.0)
-    rng = np.random.RandomState(seed + 1)
-    # flock targets = the cluster centres (so that many units are within reach of arriving); two of them
-    # moved onto impassable ground (N_ClosestPathable / N_IsMaximallyClose then decide)
-    tgt = np.stack([world["pos_xz"][world["flock"] == f].mean(0) for f in range(k)]).astype(np.float32)
-    imp = np.argwhere(grid == 255)
-    for f in (1, 4):
-        c = imp[rng.randint(len(imp))]
-        tgt[f] = cases.synth.cell_centre(4, 4, c[0], c[1])
-        members = np.flatnonzero(world["flock"] == f)
-        world["pos_xz"][members] = (tgt[f] + rng.normal(0, 14.0, (len(members), 2))).astype(np.float32)
-    world["flock_target_xz"] = tgt
-    # keep everyone on the map and on pathable ground where possible
-    world["pos_xz"] = np.clip(world["pos_xz"], -4 * 128.0 + 14, 4 * 128.0 - 14).astype(np.float32)
-    world["radius"] = rng.choice([1.0, 1.0, 1.5, 2.5, 5.5], size=n).astype(np.float32)   # (5.5: another nav layer)
-    world["flags"] = np.full(n, 1 << 3, np.uint32)
-    world["flags"][rng.rand(n) < 0.03] |= np.uint32(1 << 18)              # ENTITY_FLAG_GARRISONED
-    st = np.zeros(n, np.uint8)
-    u = rng.rand(n)
-    st[u < 0.25] = 2                                                       # STATE_ARRIVED
-    st[(u >= 0.25) & (u < 0.30)] = 4                                       # STATE_WAITING
-    st[(u >= 0.30) & (u < 0.34)] = 3                                       # STATE_SEEK_ENEMIES
-    st[(u >= 0.34) & (u < 0.36)] = 7                                       # STATE_TURNING
-    world["state"] = st
-    new_vel = rng.normal(0, 0.5, (n, 2)).astype(np.float32)
-    new_vel[rng.rand(n) < 0.15] = 0
-    vdes = rng.normal(0, 1, (n, 2)).astype(np.float32)
-    vdes /= np.maximum(np.linalg.norm(vdes, axis=1, keepdims=True), 1e-6)
-    vdes[rng.rand(n) < 0.1] = 0
-    return grid, nav, world, new_vel, vdes.astype(np.float32)
-
-
 @pytest.mark.skipif(not pfref.available(), reason="oracle/_ref (the reference build) is not present")
 def test_state_update_matches_entity_compute_update(navlib):
     """SURVEY 8(f) row 4, the data-parallel part: navhip_state_update against the reference's own
     entity_compute_update (movement.c:2303) driven for every unit -- next state and blocker flag of the
     STATE_MOVING arm (arrived() incl. N_IsAdjacentToImpassable / N_IsMaximallyClose / N_ClosestPathable,
     the arrived-neighbour rule, the no-guidance wait), the garrison rule, and the states it leaves to the host."""
-    grid, nav, world, new_vel, vdes = _state_world()
+    grid, nav, world, new_vel, vdes = cases.state_world()
     n, k = len(world["state"]), len(world["flock_target_xz"])
     mv, _ = cases.ref_move_for(nav, world)
     try:

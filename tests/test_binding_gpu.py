@@ -144,6 +144,38 @@ def test_movement_tick_drives_the_device():
         pfref.RefMove.unload()
 
 
+def test_state_updates_through_the_binding():
+    """fork_join_state_updates through bindings/permafrost/move_hip.c: the snapshot tables + the two
+    destination-only nav queries of arrived() per flock -> ONE navhip_state_update for the slab
+    (move_hip_state_work), then move_hip_update_work = move_update_work with the switch's outcome taken from
+    the device for every unit it decided.  Next state and blocker flag of every unit == the reference's own
+    entity_compute_update."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        assert nav.hip_init(), "no MI355X visible"
+        got = mv.state_update_hip(new_vel, vdes)
+        assert got is not None
+        st, fl, dv = got
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        decided = (dv & 0x80) == 0
+        moving = np.isin(world["state"], (0, 1))
+        # the device decided most units, every branch among them
+        assert decided.sum() > 0.7 * n          # (not: WAITING / TURNING units, the fifth on the other nav layer)
+        assert (decided & moving & (st == 2)).sum() > 100 and (decided & moving & (st == 4)).sum() > 10
+        assert (decided & moving & (fl == 0)).sum() > 100
+        stats = mv.hip_state_stats()
+        assert stats[0] == decided.sum() and stats[1] == n - decided.sum() and stats[2] == 1
+        # a slab of the work items
+        part = mv.state_update_hip(new_vel, vdes, begin=500, end=1700)
+        assert np.array_equal(part[0][500:1700], ref_state[500:1700]) and np.array_equal(part[1][500:1700], ref_flags[500:1700])
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
+
+
 def _game(grid, n, seed, n_factions=3):
     rng = np.random.RandomState(seed)
     h, w = grid.shape[0] // 64, grid.shape[1] // 64
