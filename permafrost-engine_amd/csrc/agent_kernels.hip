@@ -1446,9 +1446,9 @@ __global__ __launch_bounds__(256) void k_state_update(nh_step_params P, navhip_s
                     for(int k = 0; k < 4; k++) {
                         const int r = ar + dr[k], c = ac + dc[k];
                         if(r < 0 || c < 0 || r >= P.map.h * 64 || c >= P.map.w * 64) continue;      // M_Tile_RelativeDesc
-                        const size_t idx = ((size_t)((r >> 6) * P.map.w + (c >> 6)) << 12) + (r & 63) * 64 + (c & 63);
-                        const uint16_t *bl = P.map.layers[layer].blockers;
-                        adj = adj || P.map.layers[layer].cost[idx] == NAVHIP_COST_IMPASSABLE || (bl && bl[idx] > 0);
+                        tiledesc a;
+                        a.chunk_r = r >> 6; a.chunk_c = c >> 6; a.tile_r = r & 63; a.tile_c = c & 63;
+                        adj = adj || tile_probe(P, layer, a) != 1u;          // impassable or blocked
                     }
                 }
                 if(adj) {

@@ -143,20 +143,33 @@ NH_FN int nav_layer_for(uint32_t flags, float radius)
     return base;
 }
 
+// bit 0: pathable (cost_base != COST_IMPASSABLE, nav.c:4055), bit 1: blocked (blockers > 0, nav.c:4070) of
+// one tile, from the derived row masks: 16 contiguous bytes per tile row -- the five probes of an agent fall
+// into one or two 64-byte sectors instead of six (a byte plane and a 16-bit plane, three rows each)
+NH_FN uint32_t tile_probe(const nh_step_params &P, int layer, const tiledesc &t)
+{
+    const nh_layer_view &L = P.map.layers[layer];
+#ifdef NH_HOSTSIM
+    const size_t idx = tile_index(P, t);
+    return (L.cost[idx] != NAVHIP_COST_IMPASSABLE ? 1u : 0u) | ((L.blockers && L.blockers[idx] > 0) ? 2u : 0u);
+#else
+    const ulonglong2 m = *(const ulonglong2*)(L.probemask + ((((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 6) + t.tile_r) << 1));
+    return (uint32_t)((m.x >> t.tile_c) & 1ull) | ((uint32_t)((m.y >> t.tile_c) & 1ull) << 1);
+#endif
+}
+
 NH_FN bool pos_pathable(const nh_step_params &P, int layer, float x, float z)
 {
     tiledesc t;
     if(!tile_for_point(P, x, z, t)) return false;     // reference asserts; off-map = not pathable
-    return P.map.layers[layer].cost[tile_index(P, t)] != NAVHIP_COST_IMPASSABLE;
+    return (tile_probe(P, layer, t) & 1u) != 0;
 }
 
 NH_FN bool pos_blocked(const nh_step_params &P, int layer, float x, float z)
 {
     tiledesc t;
     if(!tile_for_point(P, x, z, t)) return false;
-    const uint16_t *bl = P.map.layers[layer].blockers;
-    if(!bl) return false;
-    return bl[tile_index(P, t)] > 0;
+    return (tile_probe(P, layer, t) & 2u) != 0;
 }
 
 // The five tile probes of nullify_impass_components (own tile, +-4 wu in x and z), issued together:
@@ -165,16 +178,14 @@ NH_FN uint32_t probe_tiles_bits(const nh_step_params &P, int layer, v2 pos)
 {
     const float px[5] = {pos.x, pos.x + 4.0f, pos.x - 4.0f, pos.x, pos.x};
     const float pz[5] = {pos.z, pos.z, pos.z, pos.z + 4.0f, pos.z - 4.0f};
-    const uint8_t *cost = P.map.layers[layer].cost;
-    const uint16_t *bl = P.map.layers[layer].blockers;
     uint32_t bits = 0;
 #pragma unroll
     for(int i = 0; i < 5; i++) {
         tiledesc t;
         if(!tile_for_point(P, px[i], pz[i], t)) continue;
-        const size_t idx = tile_index(P, t);
-        if(cost[idx] != NAVHIP_COST_IMPASSABLE) bits |= 1u << i;
-        if(bl && bl[idx] > 0) bits |= 32u << i;
+        const uint32_t pb = tile_probe(P, layer, t);
+        bits |= (pb & 1u) << i;
+        bits |= ((pb >> 1) & 1u) << (5 + i);
     }
     return bits;
 }

@@ -93,11 +93,10 @@ NH_FN void post_thread(const nh_step_params &P, int uid, v2 me, int state, uint3
         const bool on_blocked = pos_blocked(P, layer, me.x, me.z);
         bool cand_path = false, cand_blk = false;
         tiledesc t;
-        if(tile_for_point(P, cand.x, cand.z, t)) {               // one lookup, two planes
-            const size_t idx = tile_index(P, t);
-            const uint16_t *bl = P.map.layers[layer].blockers;
-            cand_path = P.map.layers[layer].cost[idx] != NAVHIP_COST_IMPASSABLE;
-            cand_blk = bl && bl[idx] > 0;
+        if(tile_for_point(P, cand.x, cand.z, t)) {               // one lookup, both predicates
+            const uint32_t pb = tile_probe(P, layer, t);
+            cand_path = (pb & 1u) != 0;
+            cand_blk = (pb & 2u) != 0;
         }
         if(vlen(out_vel) > 0 && cand_path && (on_blocked || !cand_blk)) {
             new_pos = cand;

@@ -217,23 +217,24 @@ __global__ __launch_bounds__(256) void k_blockers_circles(nh_blk_params P, const
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_refresh_touched(const uint8_t *cost, const uint16_t *blockers,
-                                                         uint64_t *passmask, uint8_t *unit_cost,
+                                                         uint64_t *passmask, uint64_t *probemask, uint8_t *unit_cost,
                                                          uint8_t *touched, uint8_t *changed, int nchunks)
 {
     const int chunk = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if(chunk >= nchunks || !touched[chunk]) return;
     const uint8_t  *cb = cost + ((size_t)chunk << 12);
     const uint16_t *bl = blockers + ((size_t)chunk << 12);
-    uint64_t mine = 0;
+    uint64_t mine = 0, blocked = 0;
     bool nonunit = false;
     for(int r = 0; r < 64; r++) {
         uint32_t cst = cb[r * 64 + lane], blk = bl[r * 64 + lane];
-        uint64_t m = __ballot(cst != NAVHIP_COST_IMPASSABLE && blk == 0);
+        uint64_t m = __ballot(cst != NAVHIP_COST_IMPASSABLE && blk == 0), mb = __ballot(blk > 0);
         nonunit |= (cst != NAVHIP_COST_IMPASSABLE && cst != 1);
-        if(lane == r) mine = m;
+        if(lane == r) { mine = m; blocked = mb; }
     }
     const bool differs = passmask[(size_t)chunk * 64 + lane] != mine;
     passmask[(size_t)chunk * 64 + lane] = mine;
+    probemask[((size_t)chunk * 64 + lane) * 2 + 1] = blocked;       // (the cost half does not change here)
     const bool any_nonunit = __any(nonunit), any_diff = __any(differs);
     if(lane == 0) {
         unit_cost[chunk] = any_nonunit ? 0 : 1;
@@ -319,7 +320,7 @@ void nh_launch_blockers_circles(navhip_ctx *ctx, const navhip_circle *d_circles,
         navhip_layer &L = ctx->layers[l];
         if(!L.blockers || !L.cost) continue;
         hipLaunchKernelGGL(k_refresh_touched, dim3((ctx->nchunks + 3) / 4), dim3(256), 0, s, L.cost,
-                           L.blockers, L.passmask, L.unit_cost, L.touched, L.changed, ctx->nchunks);
+                           L.blockers, L.passmask, L.probemask, L.unit_cost, L.touched, L.changed, ctx->nchunks);
         if(L.local_islands)
             hipLaunchKernelGGL(k_local_islands, dim3((ctx->nchunks + 3) / 4), dim3(256), 0, s,
                                L.passmask, L.local_islands, L.changed, ctx->nchunks);

@@ -118,7 +118,7 @@ __device__ __forceinline__ uint32_t portal_fix_dir(const navhip_field_req &rq)
 // derived per-chunk state: passability rows + "all passable costs are 1" flag
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_derive(const uint8_t *cost, const uint16_t *blockers,
-                                                uint64_t *passmask, uint8_t *unit_cost,
+                                                uint64_t *passmask, uint64_t *probemask, uint8_t *unit_cost,
                                                 const uint32_t *chunk_list, int n)
 {
     int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -127,16 +127,19 @@ __global__ __launch_bounds__(256) void k_derive(const uint8_t *cost, const uint1
     uint32_t chunk = chunk_list ? chunk_list[wave] : (uint32_t)wave;
     const uint8_t  *cb = cost + ((size_t)chunk << 12);
     const uint16_t *bl = blockers ? blockers + ((size_t)chunk << 12) : nullptr;
-    uint64_t mine = 0;
+    uint64_t mine = 0, path = 0, blocked = 0;
     bool nonunit = false;
     for(int r = 0; r < 64; r++) {
         uint32_t cst = cb[r * 64 + lane];
         uint32_t blk = bl ? bl[r * 64 + lane] : 0;
         uint64_t m = __ballot(cst != NAVHIP_COST_IMPASSABLE && blk == 0);   // field.c:117-124
+        uint64_t mp = __ballot(cst != NAVHIP_COST_IMPASSABLE), mb = __ballot(blk > 0);
         nonunit |= (cst != NAVHIP_COST_IMPASSABLE && cst != 1);
-        if(lane == r) mine = m;
+        if(lane == r) { mine = m; path = mp; blocked = mb; }
     }
     passmask[(size_t)chunk * 64 + lane] = mine;
+    probemask[((size_t)chunk * 64 + lane) * 2]     = path;
+    probemask[((size_t)chunk * 64 + lane) * 2 + 1] = blocked;
     bool any_nonunit = __any(nonunit);
     if(lane == 0) unit_cost[chunk] = any_nonunit ? 0 : 1;
 }
@@ -145,7 +148,7 @@ void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, 
 {
     navhip_layer &L = ctx->layers[layer];
     int blocks = (n + 3) / 4;
-    hipLaunchKernelGGL(k_derive, dim3(blocks), dim3(256), 0, s, L.cost, L.blockers, L.passmask,
+    hipLaunchKernelGGL(k_derive, dim3(blocks), dim3(256), 0, s, L.cost, L.blockers, L.passmask, L.probemask,
                        L.unit_cost, d_chunk_list, n);
 }
 

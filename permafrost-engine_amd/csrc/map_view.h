@@ -13,6 +13,7 @@ struct nh_layer_view {
     const uint8_t  *unit_cost;
     const uint8_t  *changed;
     const uint16_t *islands;
+    const uint64_t *probemask;     // [chunks][64][2] derived row bits: {cost_base != COST_IMPASSABLE, blockers > 0}
 };
 struct nh_map_view {
     int w, h;

@@ -9,6 +9,7 @@
 //   local_islands u16 [chunks][64][64]       struct nav_chunk.local_islands  nav_data.h:157
 //   factions      u8  [chunks][15][64][64]   struct nav_chunk.factions       nav_data.h:141
 //   passmask      u64 [chunks][64]           derived: row bitmasks of field_tile_passable
+//   probemask     u64 [chunks][64][2]        derived: row bitmasks cost_base != 0xff | blockers > 0 (tile probes)
 //   unit_cost     u8  [chunks]               derived: BFS kernel eligibility
 #include "navhip_internal.h"
 #include "agent_internal.h"
@@ -135,7 +136,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
         navhip_layer &L = ctx->layers[l];
         hipFree(L.cost); hipFree(L.blockers); hipFree(L.local_islands); hipFree(L.factions);
         hipFree(L.islands);
-        hipFree(L.passmask); hipFree(L.unit_cost); hipFree(L.touched); hipFree(L.changed);
+        hipFree(L.passmask); hipFree(L.probemask); hipFree(L.unit_cost); hipFree(L.touched); hipFree(L.changed);
         free(L.dirty);
     }
     hipFree(ctx->d_reqs); hipFree(ctx->d_dirs); hipFree(ctx->d_integ); hipFree(ctx->d_reqmask);
@@ -205,6 +206,7 @@ static int layer_prepare(navhip_ctx *ctx, int layer, int plane)
     }
     if(!L.passmask) {
         HIPCHK(ctx, hipMalloc((void**)&L.passmask, (size_t)ctx->nchunks * 64 * sizeof(uint64_t)));
+        HIPCHK(ctx, hipMalloc((void**)&L.probemask, (size_t)ctx->nchunks * 128 * sizeof(uint64_t)));
         HIPCHK(ctx, hipMalloc((void**)&L.unit_cost, (size_t)ctx->nchunks));
         HIPCHK(ctx, hipMalloc((void**)&L.touched, (size_t)ctx->nchunks));
         HIPCHK(ctx, hipMalloc((void**)&L.changed, (size_t)ctx->nchunks));
@@ -286,9 +288,12 @@ void *navhip_plane_dev(navhip_ctx *ctx, int layer, int plane)
     return *plane_slot(ctx->layers[layer], plane);
 }
 
-// rebuild passmask / unit_cost of chunks whose cost or blockers changed
+// rebuild passmask / probemask / unit_cost of chunks whose cost or blockers changed (after an upload: the
+// device-side blocker updates refresh their chunks themselves).  Whatever it launches has completed when it
+// returns, so consumers on any stream may follow.
 static int refresh_derived(navhip_ctx *ctx, hipStream_t s)
 {
+    bool launched = false;
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         navhip_layer &L = ctx->layers[l];
         if(!L.any_dirty || !L.cost) continue;
@@ -308,10 +313,12 @@ static int refresh_derived(navhip_ctx *ctx, hipStream_t s)
                 HIPCHK(ctx, hipStreamSynchronize(s));   // list buffer is reused per layer
             }
             HIPCHK(ctx, hipGetLastError());
+            launched = true;
         }
         memset(L.dirty, 0, ctx->nchunks);
         L.any_dirty = false;
     }
+    if(launched) HIPCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;
 }
 
@@ -709,7 +716,7 @@ static void fill_map_view(const navhip_ctx *ctx, nh_map_view *mv)
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
         const navhip_layer &L = ctx->layers[l];
         mv->layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
-                                      L.passmask, L.unit_cost, L.changed, L.islands};
+                                      L.passmask, L.unit_cost, L.changed, L.islands, L.probemask};
     }
 }
 
@@ -799,6 +806,8 @@ static int step_fill_params(navhip_ctx *ctx, const navhip_world *w, nh_step_para
 {
     nh_step_params &P = *Pp;
     memset(&P, 0, sizeof(P));
+    int rc_masks = refresh_derived(ctx, ctx->stream);      // the tile probes read the derived row masks
+    if(rc_masks) return rc_masks;
     fill_map_view(ctx, &P.map);
     P.map_x = w->map_pos_x; P.map_z = w->map_pos_z;
     P.n_ents = w->n_ents; P.n_flocks = w->n_flocks; P.hz = w->hz;
@@ -1187,6 +1196,8 @@ int navhip_state_update_dev(navhip_ctx *ctx, const navhip_world *w, const navhip
     HIPCHK(ctx, hipSetDevice(ctx->device));
     nh_step_params P;
     memset(&P, 0, sizeof(P));
+    int rc_masks = refresh_derived(ctx, ctx->stream);
+    if(rc_masks) return rc_masks;
     fill_map_view(ctx, &P.map);
     P.map_x = w->map_pos_x; P.map_z = w->map_pos_z;
     P.n_ents = w->n_ents; P.n_flocks = w->n_flocks; P.hz = w->hz;

@@ -22,6 +22,9 @@ struct navhip_layer {
     uint16_t *islands;         // [nchunks][64][64]  global island ids (ISLAND_NEAREST repair only)
     // derived (rebuilt lazily for dirty chunks):
     uint64_t *passmask;        // [nchunks][64]  bit c of word r = cell (r,c) passable, faction NONE
+    uint64_t *probemask;       // [nchunks][64][2] bit c of word (r, 0) = cost_base != 0xff, of (r, 1) = blockers > 0:
+                               // what the agent kernels' tile probes read (16 bytes per tile row instead of
+                               // a byte and a 16-bit word per tile in two planes)
                                //                (field_tile_passable, field.c:117)
     uint8_t  *unit_cost;       // [nchunks]      1 when every cost != 0xff cell has cost 1
     uint8_t  *touched;         // [nchunks]      device: blockers modified since the last refresh

@@ -47,7 +47,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     sha = bench.csrc_sha()
-    pre = "r02_"
+    pre = "r03_"
 
     def copy(name, out):
         p = os.path.join(src, name)
@@ -63,6 +63,10 @@ def main():
         shutil.copy(ks, os.path.join(dst, pre + "bench_kernel_stats_%s.csv" % suf))
         for r in list(csv.DictReader(open(ks)))[:14]:
             print("%-30s calls %5s  avg %9.1f us  %5s %%" % (short(r["Name"])[:30], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    ks20 = find(src, "stats20", "kernel_stats.csv")
+    if ks20:      # the driver's own invocation (--steps 20 --warmup 5) under the profiler
+        shutil.copy(ks20, os.path.join(dst, pre + "bench_steps20_kernel_stats_%s.csv" % suf))
+        copy("bench_under_prof20.json", pre + "bench_steps20_under_prof_%s.json" % suf)
     tr = find(src, "stats", "kernel_trace.csv")
     if tr:
         # per-kernel duration at ticks 5 / 50 / 100 of the traced run (the world crowds: one average hides it)
@@ -149,7 +153,7 @@ def main():
     if os.path.exists(os.path.join(src, "valu_calib.json")):
         try:
             c = json.load(open(os.path.join(src, "valu_calib.json")))
-            json.dump(c, open(os.path.join(dst, "r02_valu_calib.json"), "w"), indent=1)
+            json.dump(c, open(os.path.join(dst, pre + "valu_calib.json"), "w"), indent=1)
         except Exception as e:
             print("valu_calib.json:", e)
     copy("bench.json", pre + "bench_%s.json" % suf)
