@@ -20,7 +20,7 @@ struct nh_spatial_scratch {
 
 // fills G.cell_start / recA / recV / pool_of from S
 void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
-                             int slab_begin, int slab_end, hipStream_t s);
+                             int slab_begin, int slab_end, hipStream_t s, hipEvent_t after_first = nullptr);
 void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t s);
 size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members);
 void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s);
@@ -31,7 +31,7 @@ void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *
 // k_agent_mid -> k_cp_heavy | k_cp_rows -> k_agent_full; WL.count holds 2 * NH_WL_COUNTERS counters.
 // side / ev (or null): a second stream for the workgroup problems, two events
 int nh_worklist_cap(int n_work);
-void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
+bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
                             hipStream_t side, hipEvent_t ev[2]);
 void nh_launch_state_update(const nh_step_params &P, const navhip_state_in &in, uint8_t *d_state, uint8_t *d_flags,

@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_
 // over a factor of ten (how early an admissible candidate turns up decides how much is pruned): the
 // waves of the workgroup search a problem as a team (clearpath_grp<64, true>), so that no single
 // problem outlasts the launch.  The first problem of a workgroup is its block number,
-// then one ticket per workgroup and problem. ---
+// then one ticket per workgroup and problem.  From CP_SOLO_MIN problems on the waves work on their own. ---
 #ifdef CP_HEAVY_OCC
 __attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
 #endif
@@ -1214,9 +1214,44 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
     __syncthreads();
     HIST_T0();
     const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
-    if(n_heavy >= CP_SOLO_MIN) return;               // (k_cp_heavy_solo's tick)
     int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
     cp_lds<64> &S = lds[wib];
+    if(n_heavy >= CP_SOLO_MIN) {
+        // In a jam there are more of these problems than the launch has waves (16 000 at tick 100 of the
+        // benchmark, 22 000 in the crowded world): the load balances over problems, and a team only repeats
+        // the cone / rank construction four times and waits at its barriers -- one problem per WAVE, its
+        // first one by wave number, then a ticket per wave and problem.  (From 2 048 problems on it costs
+        // 60 % at tick 100: single problems outlast the launch; profiles/r03_ab_cp_heavy_solo.txt.)
+        const int nw = (int)gridDim.x * CP_WAVES;
+        for(int round = 0; ; round++) {
+            int t = (int)blockIdx.x * CP_WAVES + wib;
+            if(round > 0) {
+                int v = 0x7fffffff;
+                if(lane == 0 && nw + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy) v = nw + atomicAdd(ticket, 1);
+                t = __shfl(v, 0);
+            }
+            if(t >= n_heavy) break;
+            const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
+            const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
+            const nh_mid_rec R = mid[uid];
+            const uint32_t c = NB.cnt[uid];
+            const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+            cpent ent;
+            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+            ent.radius = P.radius[uid];
+#ifdef NH_CP_UNIT_HIST
+            const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
+#endif
+            cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
+            const v2 nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S);
+            if(lane == 0)
+                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
+            HIST_UNIT(0, tu0);
+        }
+        HIST_WAVE(0);
+        return;
+    }
     for(int round = 0; ; round++) {
         int t = blockIdx.x;
         if(round > 0) {
@@ -1255,64 +1290,6 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
     HIST_WAVE(0);
 }
 
-// ---- k_cp_heavy_solo: the same two lists, one problem per WAVE.  In a jam there are more of these
-// problems than the launch has waves (16 000 at tick 100 of the benchmark, 22 000 in the crowded world):
-// the load balances over problems, and a team only repeats the cone / rank construction four times and
-// waits at its barriers.  Both kernels are launched every tick and look at the list length: at
-// CP_SOLO_MIN problems and above this one runs, below it the team kernel. ---
-#ifdef CP_HEAVY_OCC
-__attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
-#endif
-__global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy_solo(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                                 nh_worklists WL, nh_step_outs O)
-{
-    __shared__ cp_lds<64> lds[CP_WAVES];
-    __shared__ int32_t hv_end[2 * NH_WL_SUB];
-    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
-    if(threadIdx.x == 0) {
-        int run = 0;
-        for(int k = 0; k < 2 * NH_WL_SUB; k++) {
-            run += WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB];
-            hv_end[k] = run;
-        }
-    }
-    __syncthreads();
-    HIST_T0();
-    const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
-    if(n_heavy < CP_SOLO_MIN) return;
-    int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
-    const int nw = (int)gridDim.x * CP_WAVES;
-    cp_lds<64> &S = lds[wib];
-    for(int round = 0; ; round++) {
-        int t = (int)blockIdx.x * CP_WAVES + wib;
-        if(round > 0) {
-            int v = 0x7fffffff;
-            if(lane == 0 && nw + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy) v = nw + atomicAdd(ticket, 1);
-            t = __shfl(v, 0);
-        }
-        if(t >= n_heavy) break;
-        const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
-        const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
-        const nh_mid_rec R = mid[uid];
-        const uint32_t c = NB.cnt[uid];
-        const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
-        cpent ent;
-        ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-        ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-        ent.radius = P.radius[uid];
-#ifdef NH_CP_UNIT_HIST
-        const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
-#endif
-        cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
-        const v2 nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S);
-        if(lane == 0)
-            post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
-        HIST_UNIT(0, tu0);
-    }
-    HIST_WAVE(0);
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_agent_full: one WAVE per listed agent, the whole neighbour-dependent part on the wave: r = 30
 // query + garrison filter + separation, the priority ladder, r = 10 neighbours, ClearPath.
@@ -1321,12 +1298,17 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy_solo(nh_step_params 
 __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, const float *coh_xz,
                                                               const nh_mid_rec *mid, nh_worklists WL,
                                                               nh_step_outs O, float scaled_max_force,
-                                                              double force_thresh)
+                                                              double force_thresh, int32_t *zero_next)
 {
     __shared__ wave_lds lds[AG_WAVES];
     __shared__ cp_lds<64> cps[AG_WAVES];
     __shared__ double exp_tab[64];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the last launch of the step on its stream clears the OTHER set of list counters for the next step
+    // (that set's consumers finished with the previous step; as a launch of its own in front of k_agent_mid
+    // it was 6 us on the critical path of every tick)
+    if(blockIdx.x == 0)
+        for(int i = threadIdx.x; i < (int)NH_WL_COUNTERS; i += AG_WAVES * 64) zero_next[i] = 0;
     // usually there is nothing to do: one parallel look at the 64 sub-list counters
     if(!__any(WL.count[NH_WL_FULL * NH_WL_SUB + lane] != 0)) return;
     if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
@@ -1628,8 +1610,10 @@ extern "C" int navhip_debug_cp_work(unsigned long long out[128], int reset)
 // ---------------------------------------------------------------------------------------------
 // Four dependent launches, no memset (cell_count is zeroed by k_sp_scan_add once it has been
 // consumed; the box of the slab filter is the exception).
+// after_first (optional): recorded behind the first kernel of the chain -- the fork event of the step's side
+// streams: recorded in FRONT of the chain it is one more packet before the first kernel of the tick
 void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
-                             int slab_begin, int slab_end, hipStream_t s)
+                             int slab_begin, int slab_end, hipStream_t s, hipEvent_t after_first)
 {
     const int n = G.n, ncells = G.grid_w * G.grid_h;
     // a strict sub-range of the entities is stepped: hash only what its queries can reach
@@ -1647,6 +1631,7 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
                            S.ent_cell, S.ent_rank, S.cell_count, box, box_next);
+    if(after_first) hipEventRecord(after_first, s);
     const int nblocks = (ncells + NH_SCAN_T - 1) / NH_SCAN_T;
     hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(NH_SCAN_T), 0, s, S.cell_count, S.cell_start,
                        S.block_sum, ncells, G, box);
@@ -1777,18 +1762,18 @@ int nh_worklist_cap(int n_work)
 
 // k_agent_mid + the consumers of its work lists.  The list counters alternate between two sets:
 // a launch sequence uses one and zeroes the other for its successor (no memset on the stream).
-void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
+// Returns whether anything was launched (the caller flips the parity only then: a step that launches nothing
+// does not clear the other set either).
+bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
                             hipStream_t side, hipEvent_t ev[2])
 {
     const int nwork = P.work_end - P.work_begin;
-    if(!(P.n_ents > 0 && nwork > 0)) return;
+    if(!(P.n_ents > 0 && nwork > 0)) return false;
     // SCALED_MAX_FORCE and the 1 % force threshold of movement.c:1870-1905 (same for every agent)
     const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
-    // (folding this into k_agent_nbr saved the launch and 15 us at the early ticks, and cost 40 us at the
-    // late ones in every A/B session: kept as a launch)
-    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(256), 0, s, WL.count + (parity ^ 1) * NH_WL_COUNTERS, (int)NH_WL_COUNTERS);
+    int32_t *zero_next = WL.count + (parity ^ 1) * NH_WL_COUNTERS;
     WL.count += parity * NH_WL_COUNTERS;
     hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
                        d_mid, WL, O, smf, thresh);
@@ -1808,13 +1793,13 @@ void nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     hipLaunchKernelGGL(k_cp_rows, dim3(64), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_RETRY, 1, 1);
     hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
-    hipLaunchKernelGGL(k_cp_heavy_solo, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
     if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk), dim3(CP_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_ROW3, 2, 0);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
-                       (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh);
+                       (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, zero_next);
     if(fork) hipStreamWaitEvent(s, ev[1], 0);
+    return true;
 }
 
 void nh_launch_spatial_query(const nh_grid &G, const float *d_query, int nq, float range, int maxout,

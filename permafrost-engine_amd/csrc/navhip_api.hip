@@ -731,7 +731,8 @@ static int ensure_zeroed(navhip_ctx *ctx, navhip_ctx::buf &b, size_t need, hipSt
 }
 
 static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hipStream_t s,
-                         int slab_begin = 0, int slab_end = -1, bool with_records = true)
+                         int slab_begin = 0, int slab_end = -1, bool with_records = true,
+                         hipEvent_t after_first = nullptr)
 {
     if(!grid_geometry(w, g)) {
         ctx->last_error = "agent step: empty spatial-grid bounds";
@@ -759,7 +760,7 @@ static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hip
     if(slab_end < 0) slab_end = w->n_ents;
     // (the two slab boxes alternate between the builds that USE one: such a build cleans the other)
     if(slab_begin > 0 || slab_end < w->n_ents) S.box_parity = (int)(ctx->sp_builds++ & 1u);
-    nh_launch_spatial_build(*g, w->pos_xz, S, slab_begin, slab_end, s);
+    nh_launch_spatial_build(*g, w->pos_xz, S, slab_begin, slab_end, s, after_first);
     return NAVHIP_OK;
 }
 
@@ -921,12 +922,18 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // critical path of the tick: NAVHIP_PREFETCH_FRONT_INLINE keeps it on the caller's stream, where it
     // follows the previous step without a cross-stream hand-over (tens of microseconds each)
     hipStream_t front = (flags & NAVHIP_PREFETCH_FRONT_INLINE) ? s : ctx->aux[0];
-    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-    if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    // the fork event: with an inline front it is recorded BEHIND the first kernel of the front (the cohesion
+    // stream, and whoever waits for NAVHIP_STAGE_START, start a 5 us kernel later; the front -- the critical
+    // path of the tick -- a packet earlier)
+    if(front != s) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    }
     // side stream 0: spatial hash -> neighbour walk (separation force + ClearPath neighbour lists)
-    rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end);
+    rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end, true, front == s ? ctx->ev_fork : nullptr);
     if(rc) return rc;
+    if(front == s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
     nh_launch_agent_nbr(P, NB, front);
     // (an inline front is ordered on the caller's stream by itself: its "done" event is only recorded
     // when somebody asks for it -- every event on that stream is a packet on the tick's critical path)
@@ -1006,9 +1013,9 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         }
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
-        nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                               ctx->aux[0], ctx->ev_cp);
-        ctx->wl_parity ^= 1;
+        if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
+                                  ctx->aux[0], ctx->ev_cp))
+            ctx->wl_parity ^= 1;
         if(ctx->regroup_pending && !ctx->snapshot_held) {
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));     // long finished by now
             ctx->regroup_pending = false;
@@ -1032,9 +1039,9 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
-    nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                               ctx->aux[0], ctx->ev_cp);
-    ctx->wl_parity ^= 1;
+    if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
+                              ctx->aux[0], ctx->ev_cp))
+        ctx->wl_parity ^= 1;
     if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[5], s)); ctx->ev_valid = true; }
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
