@@ -209,19 +209,26 @@ __global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, con
 // (one thread per element counts them: cells hold a handful of elements).
 __global__ __launch_bounds__(256) void k_sp_place(nh_grid G, const float *pos_xz, nh_pack_src src,
                                                   const int32_t *ent_cell, const int32_t *tmp_id,
-                                                  int npool_max, int work_begin, int work_end,
+                                                  int n, int work_begin, int work_end,
                                                   float4 *recA, float2 *recV, int32_t *pool_of)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if(t >= npool_max) return;
-    if(t >= G.cell_start[G.grid_w * G.grid_h]) return;
-    const int i = tmp_id[t];
+    // one thread per ENTITY (not per pool slot): its inputs are coalesced loads that do not wait for the
+    // slot search, the only gathers are the cell's bounds and its handful of ids, and the record goes out
+    // as a scattered store.  (Per slot the kernel was a chain of five dependent gathers -- id, cell, bounds,
+    // cell mates, the entity's six attribute arrays -- and took 60 us beside the cohesion kernel.)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if(i >= n) return;
     const int c = ent_cell[i];
+    if(c < 0) return;                            // outside the slab filter
+    float4 a;
+    float2 v;
+    pool_record(i, pos_xz, src, work_begin, work_end, a, v);
     const int b = G.cell_start[c], e = G.cell_start[c + 1];
     int larger = 0;
     for(int q = b; q < e; q++) larger += tmp_id[q] > i;
     const int slot = b + larger;
-    pool_record(i, pos_xz, src, work_begin, work_end, recA[slot], recV[slot]);
+    recA[slot] = a;
+    recV[slot] = v;
     pool_of[i] = slot;
 }
 

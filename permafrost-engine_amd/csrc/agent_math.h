@@ -259,25 +259,34 @@ NH_FN v2 sample_flow(const nh_step_params &P, int flock, v2 pos, uint32_t &statu
     const int   sdr[4] = {0, 0, dr, dr};
     const float sw[4]  = {(1.0f - wc) * (1.0f - wr), wc * (1.0f - wr), (1.0f - wc) * wr, wc * wr};
 
+    // The four taps in three dependent steps instead of up to nine: every tap's slot entry (its own chunk's
+    // again when the tap stays inside the chunk: a cache hit), then every tap's direction byte, then the
+    // blend in tap order with the conditions of nav.c:3435-3458 (a tap that does not count has loaded
+    // the base tile for nothing).
+    bool  use[4];
+    int   tslot[4], toff[4];
+#pragma unroll
+    for(int i = 0; i < 4; i++) {
+        // M_Tile_RelativeDesc, tile.c:391
+        const int abs_r = t.chunk_r * 64 + t.tile_r + sdr[i];
+        const int abs_c = t.chunk_c * 64 + t.tile_c + sdc[i];
+        use[i] = sw[i] > 0.0f && !(abs_r < 0 || abs_r >= P.map.h * 64 || abs_c < 0 || abs_c >= P.map.w * 64);
+        const int cr = use[i] ? abs_r >> 6 : t.chunk_r, cc = use[i] ? abs_c >> 6 : t.chunk_c;
+        toff[i] = use[i] ? (abs_r & 63) * 64 + (abs_c & 63) : t.tile_r * 64 + t.tile_c;
+        tslot[i] = slots[cr * P.map.w + cc];
+    }
+    int tdir[4];
+#pragma unroll
+    for(int i = 0; i < 4; i++) {
+        use[i] = use[i] && tslot[i] >= 0;
+        tdir[i] = P.field_pool[((size_t)(use[i] ? tslot[i] : slot) << 12) + toff[i]] & 0xf;
+    }
     v2 acc = mkv(0.0f, 0.0f);
     float wsum = 0.0f;
 #pragma unroll
     for(int i = 0; i < 4; i++) {
-        if(sw[i] <= 0.0f) continue;
-        // M_Tile_RelativeDesc, tile.c:391
-        int abs_r = t.chunk_r * 64 + t.tile_r + sdr[i];
-        int abs_c = t.chunk_c * 64 + t.tile_c + sdc[i];
-        if(abs_r < 0 || abs_r >= P.map.h * 64 || abs_c < 0 || abs_c >= P.map.w * 64) continue;
-        int cr = abs_r >> 6, cc = abs_c >> 6, tr = abs_r & 63, tc = abs_c & 63;
-        const uint8_t *ff = base_ff;
-        if(cr != t.chunk_r || cc != t.chunk_c) {
-            int s2 = slots[cr * P.map.w + cc];
-            if(s2 < 0) continue;
-            ff = P.field_pool + ((size_t)s2 << 12);
-        }
-        int dir = ff[tr * 64 + tc] & 0xf;
-        if(dir == NAVHIP_FD_NONE) continue;
-        v2 scaled = vscale(flow_dir_vec(dir), sw[i]);
+        if(!use[i] || tdir[i] == NAVHIP_FD_NONE) continue;
+        v2 scaled = vscale(flow_dir_vec(tdir[i]), sw[i]);
         acc = vadd(acc, scaled);
         wsum += sw[i];
     }

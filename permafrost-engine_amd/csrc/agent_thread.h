@@ -235,6 +235,11 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
     const float my_radius = P.radius[uid], max_speed = P.max_speed[uid];
     const int flock = P.flock[uid], hz = P.hz;
     const int layer = nav_layer_for(my_flags, my_radius);
+    // (everything that only needs the snapshot is requested here, in front of the dependent chain of the
+    // flow sampling: the neighbour walk's results and the tile probes)
+    const uint32_t cnt = NB.cnt[uid];
+    const float2 s2 = NB.sep[uid];
+    const uint32_t probes_here = P.map.layers[layer].cost ? probe_tiles_bits(P, layer, me) : 0u;
     uint32_t status = 0;
     v2 vdes = mkv(0.0f, 0.0f), arrive = mkv(0.0f, 0.0f);
     int mode;
@@ -290,11 +295,8 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
     R.status = (uint8_t)status;
     if(mode == AM_UNSUPPORTED)
         return DISP_DONE;
-    uint32_t probes = 0;
-    if(mode >= AM_POINT_SEEK && mode <= AM_FORM_POINT)
-        probes = probe_tiles_bits(P, layer, me);
+    const uint32_t probes = (mode >= AM_POINT_SEEK && mode <= AM_FORM_POINT) ? probes_here : 0u;
 
-    const uint32_t cnt = NB.cnt[uid];
     if((cnt >> 16) & NH_NB_IRREGULAR) {
         R.arrive[0] = arrive.x; R.arrive[1] = arrive.z;
         R.probes = (uint16_t)probes;
@@ -303,7 +305,6 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
 
     v2 vpref = mkv(0.0f, 0.0f);
     if(mode != AM_ZERO_VPREF) {
-        const float2 s2 = NB.sep[uid];
         vpref = vpref_from_forces(P, uid, mode, me, vel, flock, arrive, mkv(s2.x, s2.y), probes, coh_xz,
                                   scaled_max_force, force_thresh);
     }
