@@ -333,10 +333,14 @@ def main():
         measured = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         pass
-    try:
-        calib = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_calib.json")))
-    except Exception:
-        pass
+    calib_file = None
+    for name in ("r03_valu_calib.json", "r02_valu_calib.json"):      # (a hardware constant: the newest run kept)
+        try:
+            calib = json.load(open(os.path.join(ROOT, "profiles", name)))
+            calib_file = "profiles/" + name
+            break
+        except Exception:
+            pass
     stale = measured.get("csrc_sha") != sha
     sq = {}
     try:
@@ -364,8 +368,8 @@ def main():
                 "frac_of_issue_peak": floor_ms / measured_ms,
                 "counters_of": "ticks 100-110" if key == "SQ_INSTS_VALU" else "ticks 6-11",
                 "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, profiles/sq_counters.json, same "
-                        "csrc tree) at the MEASURED v_fma_f32 issue cost (profiles/r02_valu_calib.json), "
-                        "1024 SIMDs, 2.4 GHz, over the measured launch time"}
+                        "csrc tree) at the MEASURED v_fma_f32 issue cost (%s), "
+                        "1024 SIMDs, 2.4 GHz, over the measured launch time" % calib_file}
 
     def roof(which):
         ms, by = (a_ms, a_bytes) if which == "agents" else (f_ms, f_bytes)

@@ -964,13 +964,15 @@ __device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which,
 
 // ---------------------------------------------------------------------------------------------
 // k_agent_mid: the per-agent scalar chain -- desired direction, arrive force, probes, priority
-// ladder, vpref -- in uid order (every per-entity input / output is contiguous).  MID_LANES lanes
-// run the same chain for one entity (the loads are broadcasts, lane 0 writes): the work is a chain
-// of dependent loads and IEEE divide / sqrt sequences, and 100 000 threads alone are 1.5 waves per
-// SIMD -- nothing to hide it behind (measured 75-105 us with one thread per entity).
+// ladder, vpref -- in uid order (every per-entity input / output is contiguous), one thread per entity.
+// The work is a chain of dependent loads and IEEE divide / sqrt sequences at 1.5 waves per SIMD.  While
+// the loads came one after the other (four flow taps, probes, neighbour results) two lanes per entity --
+// twice the waves to hide them behind -- were faster (37 against 75-105 us); with the loads requested
+// ahead of the chain (mid_thread, sample_flow) one lane is: MID_LANES 1 / 2 / 4 = 0.352 / 0.360 / 0.379 ms
+// per tick in one session (profiles/r03_ab_mid_lanes.txt).
 // ---------------------------------------------------------------------------------------------
 #ifndef MID_LANES
-#define MID_LANES 2
+#define MID_LANES 1
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
