@@ -364,8 +364,15 @@ def main():
         key = "SQ_INSTS_VALU" if T_ticks_done >= 60 else "SQ_INSTS_VALU_early_ticks"
         insts = sum((sq[k].get(key) or sq[k]["SQ_INSTS_VALU"]) for k in ks)
         floor_ms = insts / 1024 * cyc / 2.4e9 * 1e3
+        # what an instruction of THIS mix (integer, compares, selects, f64) occupies the VALU for:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles a wave had a VALU instruction executing
+        act = sum(sq[k].get("SQ_ACTIVE_INST_VALU", 0.0) for k in ks)
+        late = sum(sq[k]["SQ_INSTS_VALU"] for k in ks)
+        mix_cyc = 4.0 * act / late if late > 0 and act > 0 else None
         return {"valu_insts_per_launch": insts, "issue_floor_ms": floor_ms, "cycles_per_inst": cyc,
                 "frac_of_issue_peak": floor_ms / measured_ms,
+                "cycles_per_inst_this_mix": mix_cyc,
+                "frac_of_issue_peak_this_mix": (insts / 1024 * mix_cyc / 2.4e9 * 1e3 / measured_ms) if mix_cyc else None,
                 "counters_of": "ticks 100-110" if key == "SQ_INSTS_VALU" else "ticks 6-11",
                 "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, profiles/sq_counters.json, same "
                         "csrc tree) at the MEASURED v_fma_f32 issue cost (%s), "

@@ -2,6 +2,7 @@
 # One GPU session: `bash scripts/gpu_job.sh <tag> [steps...]` on the GPU box (gpurun).  Steps:
 #   tests   python -m pytest tests -m gpu            -> gpurun_out/<tag>/pytest_gpu.log
 #   bench   python bench.py                          -> gpurun_out/<tag>/bench.json
+#   bench20 python bench.py --steps 20 --warmup 5 (the driver's invocation) -> bench_steps20.json
 #   calib   scripts/valu_calib.bin                   -> gpurun_out/<tag>/valu_calib.json
 #   stats   rocprofv3 --kernel-trace --stats of a short bench run
 #   pmc     three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters), --kernel-trace only
@@ -18,6 +19,7 @@ case $s in
 tests) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -15 $OUT/pytest_gpu.log ;;
 testsall) timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -25 $OUT/pytest_gpu.log ;;
 bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+bench20) timeout 600 python bench.py --steps 20 --warmup 5 --no-crowded > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err; tail -c 600 $OUT/bench_steps20.json ;;
 benchq) timeout 600 python bench.py --no-cpu-baseline --no-crowded > $OUT/bench_quick.json 2> $OUT/bench_quick.err; tail -c 2500 $OUT/bench_quick.json; tail -3 $OUT/bench_quick.err ;;
 calib) timeout 300 scripts/valu_calib.bin > $OUT/valu_calib.json 2>&1; cat $OUT/valu_calib.json ;;
 stats) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof.json 2> $OUT/prof.err

@@ -157,6 +157,13 @@ def main():
         except Exception as e:
             print("valu_calib.json:", e)
     copy("bench.json", pre + "bench_%s.json" % suf)
+    copy("bench_steps20.json", pre + "bench_%s_steps20.json" % suf)
+    for c in (0, 1, 3, 4):
+        copy("bench_cfg%d.json" % c, pre + "bench_cfg%d_%s.json" % (c, suf))
+    copy("bench_secondary.json", pre + "bench_secondary_%s.json" % suf)
+    sk = find(src, "secondary", "kernel_stats.csv")
+    if sk:
+        shutil.copy(sk, os.path.join(dst, pre + "secondary_kernel_stats_%s.csv" % suf))
     copy("pytest_gpu.log", pre + "pytest_gpu_%s.log" % suf)
     copy("fuzz.log", pre + "fuzz_gpu_%s.log" % suf)
     copy("bench_aux.json", pre + "bench_aux_%s.json" % suf)
