@@ -226,6 +226,7 @@ def test_crowded_world_against_the_reference(navlib):
     r = _tick_and_fetch(T)
     lists = T.ctx.last_step_lists()
     assert lists[4] > 0.5 * 24_000, lists                      # the wave list carries the crowd
+    assert lists[4] >= 8192                # (CP_SOLO_MIN: k_cp_heavy searches these one wave per problem)
     exp = _check_agents(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"],
                         r["vdes"], "crowded tick 0")
     for _ in range(3):
