@@ -52,23 +52,6 @@ __device__ __forceinline__ void lh_push(los_heap &h, uint16_t *node, int lo, int
     h.size++;
 }
 
-// pq_coord_pop + _pq_balance, pqueue.h:112-133,173-183
-__device__ __forceinline__ void lh_pop(los_heap &h, uint16_t *node, int lo)
-{
-    node[1] = node[h.size];
-    h.size--;
-    int root = 1;
-    const int last = h.size + 1;
-    while(root != last) {
-        int target = last;
-        const int l = root * 2, r = l + 1;
-        if(l <= h.size && LH_REL(node[l], lo) < LH_REL(node[target], lo)) target = l;
-        if(r <= h.size && LH_REL(node[r], lo) < LH_REL(node[target], lo)) target = r;
-        node[root] = node[target];
-        root = target;
-    }
-}
-
 __device__ __forceinline__ float los_len(float x, float z) { return __builtin_sqrtf(x * x + z * z); }
 
 // field_create_wavefront_blocked_line, field.c:463
@@ -121,7 +104,7 @@ __global__ __launch_bounds__(64) void k_los_field(nh_map_view map, const navhip_
                                                   const uint8_t *prev_fields, uint8_t *out_fields,
                                                   float map_x, float map_z, uint8_t *overflow)
 {
-    __shared__ uint16_t h_node[CAP + 2];
+    __shared__ __attribute__((aligned(4))) uint16_t h_node[CAP + 2];
     __shared__ __attribute__((aligned(16))) uint8_t fl[NH_CELLS];
     __shared__ int s_over;
     const int ri = blockIdx.x, lane = threadIdx.x;
@@ -191,37 +174,65 @@ __global__ __launch_bounds__(64) void k_los_field(nh_map_view map, const navhip_
         }
         int cprio = 0;                          // the level being popped (the root's priority)
         bool over = false;
-        while(H.size > 0 && !over) {
+        int hsize = H.size;
+        while(hsize > 0 && !over) {
             const uint16_t top = h_node[1];
             const int cur = LH_TILE(top);
             cprio += LH_REL(top, cprio);          // the root is the minimum: lo, or lo + 1 once lo is used up
-            lh_pop(H, h_node, cprio);
-            fl[cur] &= (uint8_t)~LF_INHEAP;
+            // ---- pq_coord_pop + _pq_balance (pqueue.h:112-133,173-183), specialised for two priorities: the
+            // last node moves to the root; one of the current level stays there (no child is strictly
+            // smaller), one of the next level sinks below the nodes of the current level -- at every node
+            // the left child if it is of the current level, else the right one if it is, else it stops.
+            // Both children come in one 32-bit read.
+            {
+                const uint16_t lastv = h_node[hsize];
+                hsize--;
+                int root = 1;
+                if(LH_REL(lastv, cprio)) {
+                    for(;;) {
+                        const int l = root * 2;
+                        if(l > hsize) break;
+                        const uint32_t pair = *(const uint32_t*)&h_node[l];
+                        const uint16_t lv = (uint16_t)(pair & 0xffffu), rv = (uint16_t)(pair >> 16);
+                        if(LH_REL(lv, cprio) == 0)                       { h_node[root] = lv; root = l; }
+                        else if(l < hsize && LH_REL(rv, cprio) == 0)     { h_node[root] = rv; root = l + 1; }
+                        else break;
+                    }
+                }
+                h_node[root] = lastv;
+            }
             const int r = cur >> 6, c = cur & 63;
-            // field_neighbours_grid_los :304: the 4 neighbours that are not wavefront blocked,
-            // collected BEFORE any of them is processed
-            int nb[4], nn = 0;
-            if(r > 0  && !(fl[cur - 64] & LF_WFB)) nb[nn++] = cur - 64;
-            if(c > 0  && !(fl[cur - 1]  & LF_WFB)) nb[nn++] = cur - 1;
-            if(c < 63 && !(fl[cur + 1]  & LF_WFB)) nb[nn++] = cur + 1;
-            if(r < 63 && !(fl[cur + 64] & LF_WFB)) nb[nn++] = cur + 64;
-            for(int k = 0; k < nn; k++) {
-                const int ni = nb[k];
-                if(fl[ni] & LF_COSTLY) {
-                    if(!los_corner(fl, ni >> 6, ni & 63)) continue;
-                    los_blocked_line(fl, map_x, map_z, rq, ni >> 6, ni & 63);
+            // field_neighbours_grid_los :304: the 4 neighbours that are not wavefront blocked, collected
+            // BEFORE any of them is processed -- their flag bytes are fetched together (processing one
+            // neighbour changes another's byte only by drawing a blocked line: `redraw`)
+            const int ni[4] = {cur - 64, cur - 1, cur + 1, cur + 64};
+            const bool have[4] = {r > 0, c > 0, c < 63, r < 63};
+            uint8_t nf[4];
+#pragma unroll
+            for(int k = 0; k < 4; k++) nf[k] = have[k] ? fl[ni[k]] : (uint8_t)LF_WFB;
+            fl[cur] &= (uint8_t)~LF_INHEAP;
+            bool redraw = false;
+#pragma unroll
+            for(int k = 0; k < 4; k++) {
+                if(nf[k] & LF_WFB) continue;
+                if(nf[k] & LF_COSTLY) {
+                    if(!los_corner(fl, ni[k] >> 6, ni[k] & 63)) continue;
+                    los_blocked_line(fl, map_x, map_z, rq, ni[k] >> 6, ni[k] & 63);
+                    redraw = true;
                 }else{
-                    fl[ni] |= LF_VISIBLE;
-                    // unit steps popped in non-decreasing order: `new_cost < integration[n]` holds
-                    // exactly when n has no value yet
-                    if(!(fl[ni] & LF_ASSIGNED)) {
-                        fl[ni] |= LF_ASSIGNED;
-                        if(!(fl[ni] & LF_INHEAP)) {
-                            if(H.size >= CAP) { over = true; break; }
-                            lh_push(H, h_node, cprio, cprio + 1, ni);
-                            fl[ni] |= LF_INHEAP;
+                    // unit steps popped in non-decreasing order: `new_cost < integration[n]` holds exactly
+                    // when n has no value yet; and a push (pq_coord_push, pqueue.h:150) carries the highest
+                    // priority in the heap, so its sift-up never moves anything: an append
+                    uint8_t add = LF_VISIBLE;
+                    if(!(nf[k] & LF_ASSIGNED)) {
+                        add |= LF_ASSIGNED;
+                        if(!(nf[k] & LF_INHEAP)) {
+                            if(hsize >= CAP) { over = true; break; }
+                            h_node[++hsize] = (uint16_t)(ni[k] | (((cprio + 1) & 1) << 12));
+                            add |= LF_INHEAP;
                         }
                     }
+                    fl[ni[k]] = (uint8_t)((redraw ? fl[ni[k]] : nf[k]) | add);
                 }
             }
         }
