@@ -61,6 +61,28 @@ def request_slices(dest_of_req, n_dests, world):
     return out
 
 
+
+def travelling_destinations(flock, agents_per_rank, fields_per_rank, n_dests):
+    """tile_exchange="auto": destination d is built by rank d // fields_per_rank; its baked tiles have to
+    travel when some agent of its flock sits in another rank's uid slab (uid // agents_per_rank).
+    Returns a bool array [n_dests]."""
+    import numpy as np
+    flock = np.asarray(flock)
+    travels = np.zeros(n_dests, bool)
+    ok = flock >= 0
+    stepped_by = np.arange(len(flock)) // agents_per_rank
+    travels[np.unique(flock[ok & (stepped_by != flock // fields_per_rank)])] = True
+    return travels
+
+
+def travel_first(dest_of_req, travels):
+    """Stable order of one rank's requests with those of the travelling destinations first -- one
+    contiguous run per rank to exchange -- and the length of that run."""
+    import numpy as np
+    first = np.asarray(travels)[np.asarray(dest_of_req)]
+    return np.argsort(~first, kind="stable"), int(first.sum())
+
+
 def exchange_rows(full, bounds, rank, world):
     """The tick's exchange step: rank r has just produced rows bounds[r] = [begin, end) of `full`
     (baked 4 KB flow tiles, or a slab of agent results); afterwards every rank holds every row.

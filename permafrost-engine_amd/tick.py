@@ -146,8 +146,7 @@ class NavTick:
         # sits in another rank's uid slab
         travels = np.zeros(self.K, bool)
         if world > 1:
-            stepped_by = np.arange(self.N) // agents_per_rank
-            travels[np.unique(ag["flock"][stepped_by != ag["flock"] // fields_per_rank])] = True
+            travels = pdist.travelling_destinations(ag["flock"], agents_per_rank, fields_per_rank, self.K)
             if self.tile_exchange == "none" and travels.any():
                 self.tile_exchange = "auto"
         regions = range(world) if self.tile_exchange != "none" else [rank]
@@ -166,10 +165,9 @@ class NavTick:
             n_q = len(cols["type"])
             if self.tile_exchange == "auto":
                 # the travelling destinations' requests first: one contiguous run per rank to exchange
-                first = travels[np.asarray(cols["dest"]) + q * fields_per_rank]
-                order = np.argsort(~first, kind="stable")
+                order, n_first = pdist.travel_first(np.asarray(cols["dest"]) + q * fields_per_rank, travels)
                 cols = {k: np.asarray(v)[order] for k, v in cols.items() if k in synth.REQ_FIELDS or k == "dest"}
-                self.xchg_bounds[q] = (nreq, nreq + int(first.sum()))
+                self.xchg_bounds[q] = (nreq, nreq + n_first)
             else:
                 self.xchg_bounds[q] = (nreq, nreq + n_q)
             reqs_q = navhip.make_reqs(n_q)

@@ -38,6 +38,23 @@ def test_request_slices_follow_destinations():
     assert sl == [(0, 3), (3, 7), (0, 0), (7, 9), (9, 15)]
 
 
+def test_auto_tile_exchange_plan():
+    """tile_exchange="auto" (tick.NavTick): which destinations' tiles travel, and the request order that
+    makes them one contiguous run per rank."""
+    from permafrost_engine_amd import dist as pdist
+    apr, fpr, world = 10, 3, 2
+    flock = np.repeat(np.arange(6), 5)[:20].copy()          # rank 0: flocks 0,0,0,0,0,1,1,1,1,1 | rank 1: 2..3
+    flock[:10] = [0, 0, 1, 1, 2, 2, 0, 1, 2, 5]             # rank 0 steps members of flocks 5 (rank 1's) too
+    flock[10:] = [3, 3, 4, 4, 5, 5, 3, 4, 1, -1]            # rank 1 steps a member of flock 1 (rank 0's); one unflocked
+    tr = pdist.travelling_destinations(flock, apr, fpr, 6)
+    assert tr.tolist() == [False, True, False, False, False, True]
+    assert not pdist.travelling_destinations(np.repeat([0, 3], 10), apr, fpr, 6).any()      # rank aligned: nothing travels
+    # rank 0's requests (destinations 0..2, three chunks each): destination 1's first, the rest in order
+    dest_of_req = np.array([0, 0, 0, 1, 1, 1, 2, 2, 2])
+    order, n_first = pdist.travel_first(dest_of_req, tr)
+    assert n_first == 3 and order.tolist() == [3, 4, 5, 0, 1, 2, 6, 7, 8]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -72,6 +89,18 @@ def _worker(rank, world, port, n_dests, n_agents, q):
         pool[b:e] = torch.from_numpy(full_dirs[b:e].reshape(e - b, 4096))
         pdist.exchange_rows(pool, bounds, rank, world)
         assert np.array_equal(pool.numpy().reshape(n_req, 64, 64), full_dirs), "tile exchange"
+
+        # tile_exchange="auto": only a run at the head of every rank's slice travels (ragged sub-ranges
+        # that do not tile the array): the others' rows stay as they were
+        sub = [(bb, bb + (ee - bb) // 2) for bb, ee in bounds]
+        part = torch.zeros((n_req, 4096), dtype=torch.uint8)
+        part[b:e] = torch.from_numpy(full_dirs[b:e].reshape(e - b, 4096))
+        pdist.exchange_rows(part, sub, rank, world)
+        want = np.zeros((n_req, 4096), np.uint8)
+        want[b:e] = full_dirs[b:e].reshape(e - b, 4096)
+        for bb, ee in sub:
+            want[bb:ee] = full_dirs[bb:ee].reshape(ee - bb, 4096)
+        assert np.array_equal(part.numpy(), want), "partial tile exchange"
 
         # step 3+4: each rank steps only its agent slab, then the slab exchange
         world_arrays = cases.make_agents(grid, n_agents, n_dests, seed=3, clustered=False)
