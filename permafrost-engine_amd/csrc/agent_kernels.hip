@@ -253,6 +253,27 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
+// Running totals of the work units of a kernel's sub-lists, by the first wave of the workgroup: entry k
+// holds `cnt[k]` agents = (cnt[k] + per - 1) / per units; unit_end[k] = units of the entries up to and
+// including k.  (One thread adding up 128-256 entries in front of every workgroup's first barrier was 770-1 500
+// wave instructions per workgroup: a fifth of everything k_cp_small executed.)
+template <typename F>
+__device__ __forceinline__ void unit_totals(int32_t *unit_end, int ntab, F units_of)
+{
+    if(threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, per_lane = (ntab + 63) >> 6;        // consecutive entries per lane
+    int local = 0;
+    for(int j = 0; j < per_lane; j++) {
+        const int k = lane * per_lane + j;
+        if(k < ntab) local += units_of(k);
+    }
+    int run = wave_incl_scan(local) - local;
+    for(int j = 0; j < per_lane; j++) {
+        const int k = lane * per_lane + j;
+        if(k < ntab) { run += units_of(k); unit_end[k] = run; }
+    }
+}
+
 // out_d2 (optional, [maxout]): squared fixed-point distance of every hit (fits int32 for the
 // ranges the movement tick uses), so that a narrower query around the same point can be derived
 // from this one without touching memory again.
@@ -1096,10 +1117,7 @@ __global__ __launch_bounds__(256) void k_cp_small(nh_step_params P, nh_nbr NB, c
     if(threadIdx.x < 2 * NH_WL_SUB)
         sub_cnt[threadIdx.x] = WL.count[(NH_WL_ROW1 - threadIdx.x / NH_WL_SUB) * NH_WL_SUB + threadIdx.x % NH_WL_SUB];
     __syncthreads();
-    if(threadIdx.x == 0) {
-        int run = 0;
-        for(int k = 0; k < 2 * NH_WL_SUB; k++) { run += (sub_cnt[k] + 3) >> 2; unit_end[k] = run; }
-    }
+    unit_totals(unit_end, 2 * NH_WL_SUB, [&](int k) { return (sub_cnt[k] + 3) >> 2; });
     __syncthreads();
     const int u = blockIdx.x * 4 + wib;                       // one unit per wave
     bool live = u < unit_end[2 * NH_WL_SUB - 1];
@@ -1154,10 +1172,7 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_
     for(int k = threadIdx.x; k < ntab; k += CP_WAVES * 64)
         sub_cnt[k] = WL.count[(list0 - k / NH_WL_SUB) * NH_WL_SUB + k % NH_WL_SUB];
     __syncthreads();
-    if(threadIdx.x == 0) {
-        int run = 0;
-        for(int k = 0; k < ntab; k++) { run += (sub_cnt[k] + 3) >> 2; unit_end[k] = run; }
-    }
+    unit_totals(unit_end, ntab, [&](int k) { return (sub_cnt[k] + 3) >> 2; });
     __syncthreads();
     HIST_T0();
     const int total = unit_end[ntab - 1];
@@ -1213,13 +1228,8 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // (outside a crowd there is nothing to do: one parallel look at the 128 counters)
     if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
-    if(threadIdx.x == 0) {
-        int run = 0;
-        for(int k = 0; k < 2 * NH_WL_SUB; k++) {
-            run += WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB];
-            hv_end[k] = run;
-        }
-    }
+    unit_totals(hv_end, 2 * NH_WL_SUB, [&](int k) {
+        return WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB]; });
     __syncthreads();
     HIST_T0();
     const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
