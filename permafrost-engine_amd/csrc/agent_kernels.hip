@@ -1044,15 +1044,18 @@ __device__ unsigned long long nh_cp_hist[4][32];
 #define CP_SOLO_MIN 8192
 #endif
 
-// first k with end[k] > u
+// first k with end[k] > u (n - 1 when there is none), for a wave-uniform u, by the whole wave: the running
+// totals do not decrease, so it is the number of entries <= u -- one or two ballots instead of a binary search
+// of seven dependent LDS reads
 __device__ __forceinline__ int first_above(const int32_t *end, int n, int u)
 {
-    int lo = 0, hi = n - 1;
-    while(lo < hi) {
-        const int m = (lo + hi) >> 1;
-        if(end[m] > u) hi = m; else lo = m + 1;
+    const int lane = threadIdx.x & 63;
+    int below = 0;
+    for(int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        below += __popcll(__ballot(k < n && end[k] <= u));
     }
-    return lo;
+    return min(below, n - 1);
 }
 
 // Drawing work units, every wave on its own (no workgroup barrier: a wave that holds a long unit does
