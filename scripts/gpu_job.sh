@@ -6,6 +6,8 @@
 #   calib   scripts/valu_calib.bin                   -> gpurun_out/<tag>/valu_calib.json
 #   stats   rocprofv3 --kernel-trace --stats of a short bench run
 #   pmc     three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters), --kernel-trace only
+#   smoke   __graft_entry__.smoke()
+#   ranks2  bench.py --gpus 2 under torchrun, both ranks on the one GPU, gloo (a plumbing check, not a measurement)
 #   fuzz    tests/tools/fuzz_gpu.py
 #   aux     scripts/bench_aux.py (host-buffer rates, LOS)  + scripts/cp_unit_hist.py when its build is there
 TAG=$1; shift
@@ -46,6 +48,8 @@ cpstats) timeout 400 python scripts/cp_stats.py > $OUT/cp_stats.json 2> $OUT/cp_
          timeout 400 python scripts/cp_stats.py --crowd > $OUT/cp_stats_crowd.json 2>> $OUT/cp_stats.err; tail -c 600 $OUT/cp_stats_crowd.json ;;
 secondary) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/secondary -o s --output-format csv -- python scripts/bench_secondary.py > $OUT/bench_secondary.json 2> $OUT/secondary.err
        tail -c 1500 $OUT/bench_secondary.json; f=$(find $OUT/secondary -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 $f | cut -c1-160 ;;
+smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
+ranks2) NAVHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; tail -c 400 $OUT/bench_2ranks_gloo.json ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log ;;
 esac
 done
