@@ -46,7 +46,11 @@ bool rccl_load()
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for(const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if(h) break; }
-    if(!h) { g_rccl_error = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "?"); return false; }
+    if(!h) {
+        const char *why = dlerror();               // (a second call would return NULL: the first clears it)
+        g_rccl_error = std::string("dlopen(librccl): ") + (why ? why : "?");
+        return false;
+    }
     rccl_api a;
     a.handle = h;
 #define SYM(field, name) *(void**)(&a.field) = dlsym(h, name); if(!a.field) { g_rccl_error = "librccl lacks " name; dlclose(h); return false; }
