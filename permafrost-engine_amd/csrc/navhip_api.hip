@@ -1241,8 +1241,13 @@ int navhip_state_update(navhip_ctx *ctx, const navhip_world *w, const navhip_sta
     ST(7, in->skip, di.skip, n);
     ST(33, in->flock_layer, di.flock_layer, F);     ST(34, in->flock_nearest_xz, di.flock_nearest_xz, F * 8);
     ST(35, in->flock_tiles_off, di.flock_tiles_off, (F + 1) * 4);
-    ST(41, in->flock_tiles, di.flock_tiles, (ntiles ? ntiles : 1) * 4);
+    ST(41, in->flock_tiles, di.flock_tiles, ntiles * 4);
 #undef ST
+    if(!rc && F > 0 && ntiles == 0) {
+        // (no destination has island tiles: the kernel still wants a pointer -- nothing is read from it)
+        rc = ensure_buf(ctx, ctx->stage[41], 4);
+        di.flock_tiles = (const int16_t*)ctx->stage[41].p;
+    }
     if(!rc) rc = ensure_buf(ctx, ctx->stage[32], 2 * n);
     if(rc) return rc;
     nh_async_invalidate_static(ctx);
