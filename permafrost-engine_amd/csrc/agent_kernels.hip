@@ -1239,8 +1239,9 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
     int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
     cp_lds<64> &S = lds[wib];
     if(n_heavy >= CP_SOLO_MIN) {
-        // In a jam there are more of these problems than the launch has waves (16 000 at tick 100 of the
-        // benchmark, 22 000 in the crowded world): the load balances over problems, and a team only repeats
+        // In a jam there are more of these problems than the launch has waves (92 000 in the crowded world;
+        // tick 100 of the benchmark has about 5 000 and stays with the teams): the load balances over problems,
+        // and a team only repeats
         // the cone / rank construction four times and waits at its barriers -- one problem per WAVE, its
         // first one by wave number, then a ticket per wave and problem.  (From 2 048 problems on it costs
         // 60 % at tick 100: single problems outlast the launch; profiles/r03_ab_cp_heavy_solo.txt.)
