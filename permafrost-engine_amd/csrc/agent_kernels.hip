@@ -207,7 +207,10 @@ __global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, con
 // 1515-1521), so after inserting uids 0..n-1 each cell holds its elements in DESCENDING uid order:
 // the final slot of an element is its cell's start + the number of cell mates with a larger uid
 // (one thread per element counts them: cells hold a handful of elements).
-__global__ __launch_bounds__(256) void k_sp_place(nh_grid G, const float *pos_xz, nh_pack_src src,
+#ifndef SP_BLOCK
+#define SP_BLOCK 64
+#endif
+__global__ __launch_bounds__(SP_BLOCK) void k_sp_place(nh_grid G, const float *pos_xz, nh_pack_src src,
                                                   const int32_t *ent_cell, const int32_t *tmp_id,
                                                   int n, int work_begin, int work_end,
                                                   float4 *recA, float2 *recV, int32_t *pool_of)
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256) void k_sp_place(nh_grid G, const float *pos_xz
     // slot search, the only gathers are the cell's bounds and its handful of ids, and the record goes out
     // as a scattered store.  (Per slot the kernel was a chain of five dependent gathers -- id, cell, bounds,
     // cell mates, the entity's six attribute arrays -- and took 60 us beside the cohesion kernel.)
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
     if(i >= n) return;
     const int c = ent_cell[i];
     if(c < 0) return;                            // outside the slab filter
@@ -938,7 +941,7 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_agent_nbr: one ROW of 16 lanes per pool slot (16 entities per 256-thread workgroup)
+// k_agent_nbr: one ROW of 16 lanes per pool slot (NBR_BLOCK / 16 entities per workgroup)
 // ---------------------------------------------------------------------------------------------
 // STRIDED (a rank that steps a slab of a large job): the launch is sized by the slab, the pool by what its
 // queries can reach, so a few rows take a second slot.  With the whole snapshot stepped every pool slot
@@ -946,23 +949,32 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
 #ifndef NBR_WAVES
 #define NBR_WAVES 7        /* 72 VGPRs; 8 needs five spilled dwords per lane */
 #endif
+// Threads per workgroup of the front's kernels.  ONE wave: they run beside the cohesion kernel's stream of
+// one-wave workgroups and the field builds, which take every wave slot the moment it frees up -- a workgroup
+// of four waves waits until four slots of ONE compute unit are free at the same moment.
+#ifndef NBR_BLOCK
+#define NBR_BLOCK 64
+#endif
+#ifndef SP_BLOCK
+#define SP_BLOCK 64
+#endif
 template <bool STRIDED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBR_WAVES, 8)))
+__global__ __launch_bounds__(NBR_BLOCK) __attribute__((amdgpu_waves_per_eu(NBR_WAVES, 8)))
 void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
 {
     __shared__ double exp_tab[64];
-    __shared__ __attribute__((aligned(16))) float2 terms[16][16];
+    __shared__ __attribute__((aligned(16))) float2 terms[NBR_BLOCK / 16][16];
     if(threadIdx.x < 64) exp_tab[threadIdx.x] = c_exp2_64[threadIdx.x];
     __syncthreads();
     const int grp_i = threadIdx.x >> 4;
     if(!STRIDED) {
-        const int k = blockIdx.x * 16 + grp_i;
+        const int k = blockIdx.x * (NBR_BLOCK / 16) + grp_i;
         if(k >= npool_max || k >= G.cell_start[G.grid_w * G.grid_h]) return;
         if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) return;         // no work item (or outside the slab)
         nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
     }else{
         const int npool = min(npool_max, G.cell_start[G.grid_w * G.grid_h]);
-        for(int k = blockIdx.x * 16 + grp_i; k < npool; k += gridDim.x * 16) {
+        for(int k = blockIdx.x * (NBR_BLOCK / 16) + grp_i; k < npool; k += gridDim.x * (NBR_BLOCK / 16)) {
             if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) continue;
             nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
         }
@@ -1663,7 +1675,7 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
     if(n > 0) {
         hipLaunchKernelGGL(k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, S.ent_cell, S.ent_rank, n,
                            S.cell_start, S.tmp_id);
-        hipLaunchKernelGGL(k_sp_place, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, S.src,
+        hipLaunchKernelGGL(k_sp_place, dim3((n + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0, s, G, d_pos_xz, S.src,
                            S.ent_cell, S.tmp_id, n, slab_begin, slab_end, S.recA, S.recV, S.pool_of);
     }
 }
@@ -1674,11 +1686,13 @@ void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t 
         const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
         const int slab = P.work_end - P.work_begin;
         if(slab == P.n_ents) {
-            hipLaunchKernelGGL(k_agent_nbr<false>, dim3((P.n_ents + 15) / 16), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
+            hipLaunchKernelGGL(k_agent_nbr<false>, dim3((P.n_ents + NBR_BLOCK / 16 - 1) / (NBR_BLOCK / 16)), dim3(NBR_BLOCK), 0, s,
+                               P.grid, P.n_ents, NB, smf);
         }else{
             // rows for the slab + a quarter (its halo in the pool); never more than one per entity
             const int rows = (int)min((long long)P.n_ents, (long long)slab + slab / 4 + 1024);
-            hipLaunchKernelGGL(k_agent_nbr<true>, dim3((rows + 15) / 16), dim3(256), 0, s, P.grid, P.n_ents, NB, smf);
+            hipLaunchKernelGGL(k_agent_nbr<true>, dim3((rows + NBR_BLOCK / 16 - 1) / (NBR_BLOCK / 16)), dim3(NBR_BLOCK), 0, s,
+                               P.grid, P.n_ents, NB, smf);
         }
     }
 }
