@@ -1051,6 +1051,10 @@ __device__ unsigned long long nh_cp_hist[4][32];
 #ifndef CP_WAVES
 #define CP_WAVES 4
 #endif
+// waves per workgroup of k_cp_rows (its waves work on their own: the workgroup only shares the unit tables)
+#ifndef CPR_WAVES
+#define CPR_WAVES 4
+#endif
 // problems on the workgroup lists from which one wave takes one problem (k_cp_heavy_solo) instead of a team
 #ifndef CP_SOLO_MIN
 #define CP_SOLO_MIN 8192
@@ -1122,19 +1126,22 @@ __device__ __forceinline__ int next_unit(unit_draw &D, int32_t *counters, int to
 // ---- k_cp_small: the lists of 1-2 and 3-4 neighbours -- three quarters of the searching agents
 // outside a crowd.  One wave per unit of four agents, one attempt each (clearpath_small_row); an agent
 // without any admissible candidate goes onto the retry list, which a launch of k_cp_rows works off. ----
-__global__ __launch_bounds__(256) void k_cp_small(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                  nh_worklists WL, nh_step_outs O)
+#ifndef CPS_WAVES
+#define CPS_WAVES 4          /* waves (units) per workgroup */
+#endif
+__global__ __launch_bounds__(CPS_WAVES * 64) void k_cp_small(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                            nh_worklists WL, nh_step_outs O)
 {
-    __shared__ __attribute__((aligned(16))) float4 cones[16][8];
+    __shared__ __attribute__((aligned(16))) float4 cones[CPS_WAVES * 4][8];
     __shared__ int32_t unit_end[2 * NH_WL_SUB];
     __shared__ int32_t sub_cnt[2 * NH_WL_SUB];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if(threadIdx.x < 2 * NH_WL_SUB)
-        sub_cnt[threadIdx.x] = WL.count[(NH_WL_ROW1 - threadIdx.x / NH_WL_SUB) * NH_WL_SUB + threadIdx.x % NH_WL_SUB];
+    for(int k = threadIdx.x; k < 2 * NH_WL_SUB; k += CPS_WAVES * 64)
+        sub_cnt[k] = WL.count[(NH_WL_ROW1 - k / NH_WL_SUB) * NH_WL_SUB + k % NH_WL_SUB];
     __syncthreads();
     unit_totals(unit_end, 2 * NH_WL_SUB, [&](int k) { return (sub_cnt[k] + 3) >> 2; });
     __syncthreads();
-    const int u = blockIdx.x * 4 + wib;                       // one unit per wave
+    const int u = blockIdx.x * CPS_WAVES + wib;               // one unit per wave
     bool live = u < unit_end[2 * NH_WL_SUB - 1];
     int uid = 0;
     bool found = true;
@@ -1172,11 +1179,11 @@ __global__ __launch_bounds__(256) void k_cp_small(nh_step_params P, nh_nbr NB, c
 #ifdef CP_ROWS_OCC
 __attribute__((amdgpu_waves_per_eu(CP_ROWS_OCC, CP_ROWS_OCC)))
 #endif
-__global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+__global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                            nh_worklists WL, nh_step_outs O, int list0, int nlists,
                                                            int ticket_set)
 {
-    __shared__ cp_lds<16> lds[CP_WAVES * 4];
+    __shared__ cp_lds<16> lds[CPR_WAVES * 4];
     // unit_end[k] = units of the sub-lists up to and including k (k = order * NH_WL_SUB + sub)
     __shared__ int32_t unit_end[4 * NH_WL_SUB];
     __shared__ int32_t sub_cnt[4 * NH_WL_SUB];
@@ -1184,7 +1191,7 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_
     const int ntab = nlists * NH_WL_SUB;
     // (usually nothing to do for the retry launch: one parallel look)
     if(nlists == 1 && !__any(WL.count[list0 * NH_WL_SUB + lane] != 0)) return;
-    for(int k = threadIdx.x; k < ntab; k += CP_WAVES * 64)
+    for(int k = threadIdx.x; k < ntab; k += CPR_WAVES * 64)
         sub_cnt[k] = WL.count[(list0 - k / NH_WL_SUB) * NH_WL_SUB + k % NH_WL_SUB];
     __syncthreads();
     unit_totals(unit_end, ntab, [&](int k) { return (sub_cnt[k] + 3) >> 2; });
@@ -1192,7 +1199,7 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_rows(nh_step_params P, nh_
     HIST_T0();
     const int total = unit_end[ntab - 1];
     int32_t *counters = WL.count + NH_WL_LISTS * NH_WL_SUB + 32 * (1 + ticket_set * NH_CP_STRIPES);
-    const int gw = blockIdx.x * CP_WAVES + wib, nw = gridDim.x * CP_WAVES;
+    const int gw = blockIdx.x * CPR_WAVES + wib, nw = gridDim.x * CPR_WAVES;
     cp_lds<16> &S = lds[wib * 4 + (lane >> 4)];
     unit_draw D; D.round = 0;
     for(;;) {
@@ -1823,15 +1830,16 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
         hipStreamWaitEvent(sh, ev[0], 0);
     }
     const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
+    const int nblk_rows = min(4096 / CPR_WAVES, (nwork + 15) / 16 * (CP_WAVES / CPR_WAVES) + 1);
     // side stream: the agents with 1-4 neighbours (most of them, outside a crowd), whatever of them needs
     // the retry logic, then the workgroup problems; s: the rows of 5-16 neighbours
-    hipLaunchKernelGGL(k_cp_small, dim3((nwork / 4 + 2 * NH_WL_SUB + 3) / 4 + 1), dim3(256), 0, sh, P, NB,
+    hipLaunchKernelGGL(k_cp_small, dim3((nwork / 4 + 2 * NH_WL_SUB + CPS_WAVES - 1) / CPS_WAVES + 1), dim3(CPS_WAVES * 64), 0, sh, P, NB,
                        (const nh_mid_rec*)d_mid, WL, O);
-    hipLaunchKernelGGL(k_cp_rows, dim3(64), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+    hipLaunchKernelGGL(k_cp_rows, dim3(64 * CP_WAVES / CPR_WAVES), dim3(CPR_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_RETRY, 1, 1);
     hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
     if(fork) hipEventRecord(ev[1], sh);
-    hipLaunchKernelGGL(k_cp_rows, dim3(nblk), dim3(CP_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+    hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_ROW3, 2, 0);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
                        (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, zero_next);

@@ -270,25 +270,26 @@ class NavTick:
         # obstacles the blocker updates of tick t+1 would race with the probes of tick t: not pipelined.)
         self.pipeline_fields = bool(pipeline_fields) and not obstacles
         if self.pipeline_fields:
-            # The field stream may use three quarters of the compute units (six of the eight XCDs of an
-            # MI355X): the builds start with the tick, beside the front of the agent step -- a chain of
-            # small launches and the latency-bound cohesion kernel that leave most of the chip idle --
-            # and a quarter of the chip always has room for that front's workgroups at once.  (Measured,
-            # 20 ticks after 5: 0.432 ms per tick with the builds behind the neighbour walk on all CUs,
-            # 0.420 started with the tick on all CUs, 0.411 / 0.402 / 0.404 / 0.410 on 160 / 192 / 208 / 224.)
+            # Where the builds of tick t+1 run inside tick t is a scheduling choice, measured (round 3, after the
+            # front of the step had become a third shorter; 20 ticks after 5 / 100 ticks, ms per tick):
+            #   configs[2] (16 384 chunk fields, 0.09 ms alone): behind the NEIGHBOUR WALK on 5 of the 8 XCDs
+            #     0.316-0.320 / 0.455-0.460 (128 ... 176 CUs all the same); on 192: 0.327 / 0.472; on all 256:
+            #     0.336 / 0.477; started with the tick on 192 (round 2's choice): 0.340 / 0.483.  The front --
+            #     spatial hash, neighbour walk: the critical path -- then only shares the chip with the cohesion
+            #     kernel, and the ClearPath phase keeps three XCDs to itself.
+            #   configs[3] (131 072 chunk fields, 0.58 ms alone -- as long as the rest of the tick): started
+            #     WITH THE TICK on ALL compute units 0.97; with the tick on 224 / 192: 1.01 / 1.08; behind the
+            #     neighbour walk on 224 / 160: 0.99 / 1.20.
+            #   configs[1] (4 096 chunk fields, 45 us): no difference (0.259-0.265).
             import os
             ncu_all = torch.cuda.get_device_properties(self.dev).multi_processor_count
-            ncu = int(os.environ.get("NAVTICK_FIELD_CUS", str(ncu_all * 3 // 4)))
+            long_build = self.n_req_local >= 65536
+            ncu = int(os.environ.get("NAVTICK_FIELD_CUS", str(ncu_all if long_build else ncu_all * 5 // 8)))
             if 0 < ncu < ncu_all:
                 self.fstream = torch.cuda.ExternalStream(self.ctx.stream_create_partial(ncu_all - ncu, ncu), device=self.dev)
             else:
                 self.fstream = torch.cuda.Stream(device=self.dev)
-            # ... when there is enough of it to fill that window.  A short build (configs[1]: 4 096 chunk
-            # fields, 45 us) started with the tick only gets in the way of the front -- 0.42 ms per tick
-            # against 0.32 behind the neighbour walk --; the long one of configs[2] (16 384) is the other
-            # way round (0.40 against 0.43).
-            self.fields_after = os.environ.get("NAVTICK_FIELDS_AFTER",
-                                               "start" if self.n_req_local >= 8192 else "neighbours")
+            self.fields_after = os.environ.get("NAVTICK_FIELDS_AFTER", "start" if long_build else "neighbours")
             # nothing wide is enqueued on self.stream between prefetch and step: the front stays on it
             # ... and the snapshot buffers ping-pong: the one a step read is next written by the ClearPath
             # kernels of the following step
