@@ -508,6 +508,11 @@ int  navhip_get_counters(navhip_ctx *ctx, navhip_counters *out, int reset);
  * and agents whose whole step ran on a wave ([5]: garrisoned neighbours / wide queries).  Everyone
  * else has no ClearPath neighbour and finished in the thread-per-agent pass. */
 int  navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6]);
+/* The same without waiting: the counts of the most recent step whose copy has ARRIVED (the library sends them to
+ * pinned host memory behind every step, on its side stream) -- one or two steps old, zeros before the first.
+ * For a host that adapts its schedule to the crowd: tick.py starts the next tick's field builds with the tick
+ * instead of behind the neighbour walk once the workgroup searches ([4]) would starve them of registers. */
+int  navhip_step_lists_peek(navhip_ctx *ctx, int32_t out_counts[6]);
 
 /* ClearPath retry statistics of this process since the last reset (diagnostics: bench.py's status
  * histogram): out[k], k = 1..7 = searches that returned in attempt k + 1 of G_ClearPath_NewVelocity's

@@ -113,7 +113,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
     ctx->front_stream = nullptr;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
-    ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->sp_builds = 0;
+    ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->sp_builds = 0; ctx->lists_pinned = nullptr;
     memset(ctx->ev, 0, sizeof(ctx->ev));
     if(hipSetDevice(device) != hipSuccess
     || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -130,6 +130,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     navhip_comm_destroy(ctx);
+    if(ctx->lists_pinned) hipHostFree(ctx->lists_pinned);
     navhip_pool_destroy(ctx);
     nh_async_destroy(ctx);
     for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
@@ -966,6 +967,19 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
     return navhip_agent_prefetch_dev_ex(ctx, w, stream, 0);
 }
 
+// behind a step: its list counters on their way to pinned host memory (side stream, after the searches)
+static int send_step_lists(navhip_ctx *ctx, int parity_used, hipStream_t fallback)
+{
+    if(!ctx->lists_pinned) {
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->lists_pinned, sizeof(int32_t) * NH_WL_LISTS * NH_WL_SUB, hipHostMallocDefault));
+        memset(ctx->lists_pinned, 0, sizeof(int32_t) * NH_WL_LISTS * NH_WL_SUB);
+    }
+    const int32_t *src = (const int32_t*)ctx->wl[0].p + parity_used * NH_WL_COUNTERS;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->lists_pinned, src, sizeof(int32_t) * NH_WL_LISTS * NH_WL_SUB, hipMemcpyDeviceToHost,
+                               ctx->aux[0] ? ctx->aux[0] : fallback));
+    return NAVHIP_OK;
+}
+
 int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_step_out *out,
                           void *stream)
 {
@@ -1014,8 +1028,11 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         }
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                                  ctx->aux[0], ctx->ev_cp))
+                                  ctx->aux[0], ctx->ev_cp)) {
+            rc = send_step_lists(ctx, ctx->wl_parity, s);
             ctx->wl_parity ^= 1;
+            if(rc) return rc;
+        }
         if(ctx->regroup_pending && !ctx->snapshot_held) {
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));     // long finished by now
             ctx->regroup_pending = false;
@@ -1040,8 +1057,11 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                              ctx->aux[0], ctx->ev_cp))
+                              ctx->aux[0], ctx->ev_cp)) {
+        rc = send_step_lists(ctx, ctx->wl_parity, s);
         ctx->wl_parity ^= 1;
+        if(rc) return rc;
+    }
     if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[5], s)); ctx->ev_valid = true; }
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
@@ -1101,6 +1121,18 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
     // (the wave and the heavy list are reported together: 17-64 neighbours)
     static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1};     // (the retry list is not reported)
     for(int l = 0; l < 6; l++) out_counts[l] = 0;
+    for(int l = 0; l < NH_WL_LISTS; l++)
+        for(int sb = 0; sb < NH_WL_SUB; sb++) if(slot_of[l] >= 0) out_counts[slot_of[l]] += h[l * NH_WL_SUB + sb];
+    return NAVHIP_OK;
+}
+
+int navhip_step_lists_peek(navhip_ctx *ctx, int32_t out_counts[6])
+{
+    if(!ctx || !out_counts) return NAVHIP_ERR_INVALID;
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1};
+    for(int l = 0; l < 6; l++) out_counts[l] = 0;
+    if(!ctx->lists_pinned) return NAVHIP_OK;
+    const volatile int32_t *h = ctx->lists_pinned;
     for(int l = 0; l < NH_WL_LISTS; l++)
         for(int sb = 0; sb < NH_WL_SUB; sb++) if(slot_of[l] >= 0) out_counts[slot_of[l]] += h[l * NH_WL_SUB + sb];
     return NAVHIP_OK;

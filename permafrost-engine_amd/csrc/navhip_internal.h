@@ -55,6 +55,7 @@ struct navhip_ctx {
     buf          midrec;       // per-entity record k_agent_mid leaves for the work-list consumers
     buf          wl[2];        // work lists: 2 x NH_WL_COUNT counters (alternating), ids
     int          wl_parity;
+    int32_t     *lists_pinned;       // pinned host copy of a step's list counters (navhip_step_lists_peek)
     buf          coh;          // cohesion force per entity
     buf          coh_plan;     // [n_flocks + 1] wave prefix of the cohesion launch
     buf          gen_list;     // [2 + n] requests the BFS kernel left to k_field_generic: 2 counters, ids

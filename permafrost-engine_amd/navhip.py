@@ -382,6 +382,7 @@ _SIGS.update({
     "navhip_stream_create_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 5)]),
     "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
+    "navhip_step_lists_peek": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
     "navhip_clearpath_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "navhip_clearpath_team": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -769,7 +770,15 @@ NavContext.pool_map = _ctx_pool_map
 NavContext.agent_step_async = _ctx_agent_step_async
 NavContext.set_profiling = _ctx_set_profiling
 NavContext.last_step_ms = _ctx_last_step_ms
+def _ctx_step_lists_peek(self):
+    """Like last_step_lists, without waiting: the counts of the latest step whose copy has arrived."""
+    out = (C.c_int32 * 6)()
+    self._chk(lib().navhip_step_lists_peek(self._h, C.byref(out)), "navhip_step_lists_peek")
+    return list(out)
+
+
 NavContext.last_step_lists = _ctx_last_step_lists
+NavContext.step_lists_peek = _ctx_step_lists_peek
 NavContext.stream_wait_stage = _ctx_stream_wait_stage
 NavContext.stream_create_partial = _ctx_stream_create_partial
 NavContext.counters = _ctx_counters

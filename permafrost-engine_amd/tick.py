@@ -388,7 +388,15 @@ class NavTick:
 
     def _compute_pipelined(self, marks):
         s, f = self.stream, self.fstream
-        if self.fields_after == "start" and self.pipelined:
+        # In a jam the workgroup ClearPath searches hold every register of the chip for milliseconds: a build
+        # that starts behind the neighbour walk has not got its workgroups resident by then, finishes after
+        # them, and the next step waits for it (crowded world: 5.3 -> 6.8 ms per tick).  The list lengths of
+        # the last steps arrive in pinned memory without a wait: from a jam's worth of such searches on, the
+        # builds start with the tick.
+        stage = self.fields_after
+        if stage == "neighbours" and self.ctx.step_lists_peek()[4] >= 8192:
+            stage = "start"
+        if stage == "start" and self.pipelined:
             f.wait_stream(s)                      # (the end of the previous tick)
         if not self.pipelined:
             with torch.cuda.stream(s):
@@ -396,7 +404,7 @@ class NavTick:
         # the fields of the NEXT tick
         timed = self.record and self.tick_no % self.mark_every == 0
         with torch.cuda.stream(f):
-            if self.fields_after == "neighbours":
+            if stage == "neighbours":
                 self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_NEIGHBOURS)
             elif not self.pipelined:
                 # (the fork event of the prefetch just enqueued: the end of the previous tick, without
