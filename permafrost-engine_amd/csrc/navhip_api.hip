@@ -923,18 +923,25 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // critical path of the tick: NAVHIP_PREFETCH_FRONT_INLINE keeps it on the caller's stream, where it
     // follows the previous step without a cross-stream hand-over (tens of microseconds each)
     hipStream_t front = (flags & NAVHIP_PREFETCH_FRONT_INLINE) ? s : ctx->aux[0];
-    // the fork event: with an inline front it is recorded BEHIND the first kernel of the front (the cohesion
-    // stream, and whoever waits for NAVHIP_STAGE_START, start a 5 us kernel later; the front -- the critical
-    // path of the tick -- a packet earlier)
-    if(front != s) {
+    // The fork event for the cohesion stream (and for whoever waits for NAVHIP_STAGE_START) is one packet on the
+    // caller's stream: in front of the first kernel of the front it delays the front, behind it (NH_FORK_BEHIND_COUNT)
+    // the cohesion kernel.  Whichever of the two ends later gates k_agent_mid: while the neighbour walk was the
+    // longer one the event sat behind k_sp_count (0.370 -> 0.364 ms per tick together with two other changes);
+    // since the walk runs as one-wave workgroups the cohesion kernel ends last, and the event is back in front
+    // (0.3205 -> 0.3166; profiles/r03_ab_tick_chain.txt, r03_ab_fork_first.txt).
+#ifndef NH_FORK_BEHIND_COUNT
+#define NH_FORK_BEHIND_COUNT 0
+#endif
+    const bool fork_late = NH_FORK_BEHIND_COUNT && front == s;
+    if(!fork_late) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+        if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
     }
     // side stream 0: spatial hash -> neighbour walk (separation force + ClearPath neighbour lists)
-    rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end, true, front == s ? ctx->ev_fork : nullptr);
+    rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end, true, fork_late ? ctx->ev_fork : nullptr);
     if(rc) return rc;
-    if(front == s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    if(fork_late) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
     nh_launch_agent_nbr(P, NB, front);
     // (an inline front is ordered on the caller's stream by itself: its "done" event is only recorded
     // when somebody asks for it -- every event on that stream is a packet on the tick's critical path)
