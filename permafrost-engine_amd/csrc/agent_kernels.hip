@@ -700,9 +700,14 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
 // perm / bin_start: the lane grouping of the previous regrouping (the members inside the work range, flock f's
 // at perm[bin_start[f * COH_BINS] .. bin_start[(f + 1) * COH_BINS])); *perm_valid = 0: the identity over the
 // whole flock instead (k_coh_plan).
+// INLINE_PLAN (at most 64 flocks: lane = flock): every wave works the launch plan out for itself -- the check
+// that the grouping was built for these flock offsets and this work range, the wave prefix over the flocks --
+// instead of reading what a one-workgroup kernel in front of the launch left (k_coh_plan: 6 us and a launch
+// gap on the chain that gates k_agent_mid; here ~40 instructions per wave).
+template <bool INLINE_PLAN>
 __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off,
                                                  const int32_t *perm, const int32_t *perm_valid,
-                                                 float *coh_xz, const int32_t *bin_start)
+                                                 float *coh_xz, const int32_t *bin_start, const int32_t *saved)
 {
     __shared__ double tab[64];
     // the members of the current tile that survive the box test, in member order (+ carry-over):
@@ -711,24 +716,43 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     __shared__ __attribute__((aligned(16))) float qz[4 * COH_QS];
     const int t = threadIdx.x, sub = t & 3;
     const int wv = blockIdx.x;
-    if(wv >= wave_off[P.n_flocks]) return;
-    tab[t] = c_exp2_64[t];
-    // flock of this wave: binary search over the wave prefix (uniform)
-    int f = 0;
-    {
+    int f = 0, first_wave = 0;
+    bool use_perm;
+    if(INLINE_PLAN) {
+        const int nf = P.n_flocks;
+        bool ok = saved[nf + 1] == P.work_begin && saved[nf + 2] == P.work_end;
+        if(t <= nf) ok = ok && saved[t] == P.flock_offsets[t];
+        if(t == 0 && nf == 64) ok = ok && saved[64] == P.flock_offsets[64];
+        use_perm = __all(ok);
+        int v = 0;
+        if(t < nf) {
+            const int cnt = use_perm ? bin_start[(t + 1) * COH_BINS] - bin_start[t * COH_BINS]
+                                     : P.flock_offsets[t + 1] - P.flock_offsets[t];
+            v = (cnt + COH_APW - 1) / COH_APW;
+        }
+        const int incl = wave_incl_scan(v), excl = incl - v;
+        if(wv >= __shfl(incl, 63)) return;
+        // the last flock whose first wave is <= wv (empty flocks share their successor's prefix)
+        f = __popcll(__ballot(t < nf && excl <= wv)) - 1;
+        first_wave = __shfl(excl, f);
+    }else{
+        if(wv >= wave_off[P.n_flocks]) return;
+        // flock of this wave: binary search over the wave prefix (uniform)
         int lo = 0, hi = P.n_flocks;
         while(hi - lo > 1) {
             int mid = (lo + hi) >> 1;
             if(wave_off[mid] <= wv) lo = mid; else hi = mid;
         }
         f = lo;
+        first_wave = wave_off[f];
+        use_perm = *perm_valid != 0;
     }
+    tab[t] = c_exp2_64[t];
     const float scaled_max_force = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
-    const bool use_perm = *perm_valid != 0;
     const int pb = use_perm ? bin_start[f * COH_BINS] : b;
     const int pe = use_perm ? bin_start[(f + 1) * COH_BINS] : e;
-    const int gp = pb + (wv - wave_off[f]) * COH_APW + (t >> 2);
+    const int gp = pb + (wv - first_wave) * COH_APW + (t >> 2);
     const bool mine = gp < pe;
     // CSR entry of this quad's member (any permutation of the flock's entries serves; a grouping
     // made for other flock offsets or another work range is ignored)
@@ -1773,6 +1797,9 @@ static void coh_regroup(const nh_step_params &P, const coh_scratch &C, int which
 // launches AFTER recording its "cohesion done" event: five dependent small launches leave the tick's
 // critical path.  That holds for a rank that steps a slab as well: its grouping holds the slab's members
 // only (k_coh_bin), so the members of the other ranks occupy no lanes.
+#ifndef COH_INLINE_PLAN_MAX
+#define COH_INLINE_PLAN_MAX 64
+#endif
 bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, int *parity, hipStream_t s)
 {
     if(!(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0)) return false;
@@ -1781,10 +1808,17 @@ bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh,
     // member of the whole snapshot); surplus waves exit at once
     const int nwaves = (P.n_members + 15) / 16 + P.n_flocks;
     const int prev = *parity ^ 1;
+    if(P.n_flocks <= COH_INLINE_PLAN_MAX) {
+        hipLaunchKernelGGL(k_cohesion<true>, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
+                           (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start,
+                           (const int32_t*)C.saved[prev]);
+        return true;
+    }
     hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start, P.flock_offsets,
                        (const int32_t*)C.saved[prev], P.n_flocks, P.work_begin, P.work_end, C.wave_off, C.valid);
-    hipLaunchKernelGGL(k_cohesion, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
-                       (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start);
+    hipLaunchKernelGGL(k_cohesion<false>, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
+                       (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start,
+                       (const int32_t*)C.saved[prev]);
     return true;                                  // caller: record the event, then ..._regroup
 }
 
