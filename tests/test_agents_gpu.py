@@ -244,6 +244,9 @@ def test_garrisoned_neighbours_take_the_wave_path(navlib):
     ctx = _upload(navlib, nav)
     out = ctx.agent_step(_step_arrays(world, mv, vdes))
     lists = ctx.last_step_lists()
+    # ... and the same counts without the wait (navhip_step_lists_peek): the copy the step sent behind
+    # itself has arrived by now (last_step_lists waited for the device)
+    assert tuple(ctx.step_lists_peek()) == tuple(lists)
     ctx.close()
     assert lists[5] > 20, lists                      # the irregular list was exercised
     moving = ~np.isin(world["state"], (2, 4))
