@@ -22,6 +22,14 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// A value that is the same in every lane of a wave-wide group BY CONSTRUCTION (read from LDS at a uniform
+// address, the result of a reduction): tell the compiler, so that it lives in a scalar register and the loops
+// it controls stay uniform -- otherwise one such value in a `break` makes the whole loop divergent, and every
+// counter inside it a per-lane VGPR under exec masks (measured: 40 % of the search's instructions were SALU
+// bookkeeping for branches that no lane ever takes differently).  Rows of 16 lanes: identity.
+template <int G> __device__ __forceinline__ int   uni(int v)   { return G == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
+template <int G> __device__ __forceinline__ float uni(float v) { return G == 64 ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; }
+
 template <int G> struct grp {
     static __device__ __forceinline__ int lane() { return (int)(threadIdx.x & (G - 1)); }
     static __device__ __forceinline__ int base() { return (int)(threadIdx.x & 63 & ~(G - 1)); }
@@ -240,7 +248,7 @@ __device__ __forceinline__ bool inside_pcr(const float4 *cones, int n_cones, v2 
 __device__ unsigned long long nh_cp_cyc[8][8];       // cycles: {cones+admissible, projections, columns, jump, max unit, -, -, -}
 #define CP_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
 #define CP_TMARK(b, k) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); if(grp<G>::lane() == 0) atomicAdd(&nh_cp_cyc[b][k], _n - _t0); _t0 = _n; } while(0)
-__device__ unsigned long long nh_cp_work[8][8];
+__device__ unsigned long long nh_cp_work[8][16];
 #define CP_STAT(b, k, v) do { if(grp<G>::lane() == 0) atomicAdd(&nh_cp_work[b][k], (unsigned long long)(v)); } while(0)
 __device__ __forceinline__ int cp_bucket(int n) { return n <= 2 ? 0 : n <= 4 ? 1 : n <= 8 ? 2 : n <= 16 ? 3 : n <= 32 ? 4 : 5; }
 #define CP_STAT_LANE(b, k, v) atomicAdd(&nh_cp_work[b][k], (unsigned long long)(v))
@@ -290,8 +298,28 @@ template <int G> struct cp_lds {
 // The bound is group uniform.  `found` = some candidate outside the obstacle has been seen (what the
 // reference's `vec_size(&xpoints) == 0` asks); until then every candidate is tested, so that points
 // whose distance is NaN or infinite still count.
-struct cp_bound { float len; int idx; v2 pt; int nfound; int sb; };
+struct cp_bound { float len; int idx; v2 pt; int nfound; int sb;
+#ifdef NH_CP_STATS
+    // developer counters, kept in registers and flushed once per attempt (an atomic per iteration distorts what it measures)
+    unsigned it, busy, ex, out, passes; unsigned long long cw, cg;
+#endif
+};
 #define CP_COL_MARGIN 0.02f
+#ifndef NH_CP_CONE_COMPACT
+#define NH_CP_CONE_COMPACT 1     // column phase: inside-obstacle tests only against the cones within reach of the bound
+#endif
+#ifndef NH_CP_CONES2
+#define NH_CP_CONES2 0           // inside-obstacle tests: two cones per step and lane
+#endif
+#ifndef NH_CP_COLS2
+#define NH_CP_COLS2 0            // column phase (lane = row): two columns per pass
+#endif
+#ifndef NH_CP_COVER
+#define NH_CP_COVER 1            // column phase: rays that lie inside another cone from end to end are no columns
+#endif
+#ifndef NH_CP_COLS_V2
+#define NH_CP_COLS_V2 1          // column phase of a wave-wide search: lane = row, the column wave uniform
+#endif
 #ifndef CP_SMALL_RAYS
 #define CP_SMALL_RAYS 8          // up to this many rays (4 neighbours) a problem is searched without queue and bound
 #endif
@@ -320,6 +348,9 @@ __device__ void cp_work(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp
     const int gl = g::lane();
     const unsigned long long lt_mask = (1ull << gl) - 1ull;
     int head = 0;
+#ifdef NH_CP_STATS
+    const unsigned long long w_t0 = __builtin_amdgcn_s_memtime();
+#endif
     for(;;) {
         if(head < qn) {
             const bool need = L.ci < 0;
@@ -330,7 +361,7 @@ __device__ void cp_work(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp
                     L.pt = mkv(S.qx[my], S.qz[my]); L.idx = S.qi[my]; L.len = S.ql[my];
                     L.ci = cp_alive(B, L.len, L.idx) ? 0 : -1;
                 }
-                head = min(qn, head + __popcll(mn));
+                head = uni<G>((int)min(qn, head + (int)__popcll(mn)));
             }
         }
         if(!g::any(L.ci >= 0)) {
@@ -338,9 +369,27 @@ __device__ void cp_work(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp
             continue;
         }
         if(!finish && head >= qn) break;
-        CP_STAT(B.sb, 5, 1);
-        CP_STAT(B.sb, 4, __popcll(g::ballot(L.ci >= 0)));
+#ifdef NH_CP_STATS
+        B.it++; B.busy += __popcll(g::ballot(L.ci >= 0));
+        { int v_ = 0; if(L.ci >= 0) { const int sl_ = S.ord[L.ci]; v_ = cone_contains_fast(S.cones[2 * sl_], S.cones[2 * sl_ + 1], L.pt); }
+          if(g::any(v_ == 2)) B.ex++; }
+#endif
         bool outside = false;
+#if NH_CP_CONES2
+        // two cones per step: two independent chains in flight -- at four waves per SIMD the search waits for
+        // the latency of its own dependent steps more than for issue slots (an agent's cones cost 2 LDS round
+        // trips + a reciprocal square root each), so a step that is sometimes wasted is cheaper than a step more
+        if(L.ci >= 0) {
+            const int c1 = min(L.ci + 1, n_cones - 1);
+            const int s0 = S.ord[L.ci], s1 = S.ord[c1];
+            const float4 A0 = S.cones[2 * s0], B0 = S.cones[2 * s0 + 1], A1 = S.cones[2 * s1], B1 = S.cones[2 * s1 + 1];
+            int v0 = cone_contains_fast(A0, B0, L.pt), v1 = cone_contains_fast(A1, B1, L.pt);
+            if(v0 == 2) v0 = cone_contains_exact(A0, B0, L.pt) ? 1 : 0;
+            if(v1 == 2) v1 = cone_contains_exact(A1, B1, L.pt) ? 1 : 0;
+            if(v0 == 1 || v1 == 1) L.ci = -1;
+            else { L.ci += 2; if(L.ci >= n_cones) { outside = true; L.ci = -1; } }
+        }
+#else
         if(L.ci >= 0) {
             const int slot = S.ord[L.ci];
             const bool in = cone_contains(S.cones[2 * slot], S.cones[2 * slot + 1], L.pt);
@@ -348,24 +397,32 @@ __device__ void cp_work(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp
             if(in) L.ci = -1;
             else if(L.ci >= n_cones) { outside = true; L.ci = -1; }
         }
+#endif
         if(g::any(outside)) {
+#ifdef NH_CP_STATS
+            B.out++;
+#endif
             float key = (outside && L.len == L.len) ? L.len : __builtin_inff();    // a NaN distance never wins
             int ki = outside ? L.idx : 0x7fffffff;
             const float mykey = key; const int myidx = ki;
             g::argmin(key, ki);
+            key = uni<G>(key); ki = uni<G>(ki);
             const bool better = B.nfound == 0 || key < B.len || (key == B.len && ki < B.idx);
             B.nfound++;
             if(better && key < __builtin_inff()) {
                 const int owner = __ffsll((unsigned long long)g::ballot(outside && myidx == ki && mykey == key)) - 1;
                 const v2 curr = vsub(L.pt, ent.pos);
-                B.len = key; B.idx = ki;
-                B.pt = mkv(g::shfl(curr.x, owner), g::shfl(curr.z, owner));
+                B.len = uni<G>(key); B.idx = uni<G>(ki);
+                B.pt = mkv(uni<G>(g::shfl(curr.x, owner)), uni<G>(g::shfl(curr.z, owner)));
             }
             if(L.ci >= 0 && !cp_alive(B, L.len, L.idx)) L.ci = -1;
         }
     }
     qn = 0;
     wave_sync();
+#ifdef NH_CP_STATS
+    B.cw += __builtin_amdgcn_s_memtime() - w_t0;
+#endif
 }
 
 // push this lane's candidate (ok) onto the group's queue; the queue is worked off once G are waiting
@@ -380,7 +437,7 @@ __device__ __forceinline__ void cp_push(cp_lds<G> &S, const cpent &ent, int n_co
         const int at = qn + __popcll(mk & ((1ull << gl) - 1ull));
         S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = idx; S.ql[at] = len;
     }
-    qn += __popcll(mk);
+    qn = uni<G>((int)(qn + (int)__popcll(mk)));
     CP_STAT(B.sb, 3, __popcll(mk));
     wave_sync();
     if(qn >= G) cp_work<G>(S, ent, n_cones, qn, L, B, false);
@@ -590,6 +647,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                             int part = 0, int nparts = 1, cp_team *T = nullptr)
 {
     typedef grp<G> g;
+    n_dyn = uni<G>(n_dyn); n_stat = uni<G>(n_stat);
     if(n_dyn + n_stat == 0) return des_v;          // no obstacle: inside_pcr of nothing is false
     const int gl = g::lane();
     const unsigned long long lt_mask = (1ull << gl) - 1ull;
@@ -652,6 +710,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
 
         cp_bound B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.nfound = 0; B.sb = 0;
 #ifdef NH_CP_STATS
+        B.it = B.busy = B.ex = B.out = B.passes = 0; B.cw = B.cg = 0;
         B.sb = cp_bucket(n_dyn + n_stat);
         CP_STAT(B.sb, 1, 1);
         if(guard == 0) CP_STAT(B.sb, 0, 1);
@@ -702,8 +761,8 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         const int owner = __ffsll((unsigned long long)g::ballot(bidx == ki && blen == key)) - 1;
         B.nfound = g::any(nf > 0) ? 1 : 0;
         if(key < __builtin_inff()) {
-            B.len = key; B.idx = ki;
-            B.pt = mkv(g::shfl(bpt.x, owner), g::shfl(bpt.z, owner));
+            B.len = uni<G>(key); B.idx = uni<G>(ki);
+            B.pt = mkv(uni<G>(g::shfl(bpt.x, owner)), uni<G>(g::shfl(bpt.z, owner)));
         }
         }else{
         cp_lane L; L.pt = mkv(0, 0); L.idx = 0; L.len = 0.0f; L.ci = -1;
@@ -728,14 +787,20 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         cp_work<G>(S, ent, n_cones, qn, L, B, true);
 
         CP_TMARK(sb_, 1);
+#ifdef NH_CP_STATS
+        if(!B.nfound) CP_STAT(B.sb, 12, 1);
+        CP_STAT(B.sb, 15, B.it);               // iterations of the projection phase
+        B.cw = 0;
+#endif
         // ---- the ray pairs (:321; order index i * n_rays + j), column by column, NEAREST LINE FIRST:
         // a column's candidates all lie on its line, so its key -- the distance of des_v to that line,
         // less the margins -- bounds them from below.  Columns are visited in ascending key; the search
         // stops at the first column whose key exceeds the bound: every later one is farther still.
         // In a crowd the best admissible velocity lies on one of the few lines next to des_v.
+        unsigned long long cov0 = 0ull, cov1 = 0ull;           // rays whose column holds nothing admissible (sorted last)
         {
             // keys of this lane's (up to two) rays
-            float mykey[2];
+            float mykey[2], mykeyc[2] = {__builtin_inff(), __builtin_inff()};
 #pragma unroll
             for(int h = 0; h < 2; h++) {
                 const int j = gl + h * G;
@@ -744,16 +809,77 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                     const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
                     const v2 dj = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
                     const v2 rel = vsub(des_v, vsub(mkv(Aj.x, Aj.y), ent.pos));
-                    const float dist = fabsf(dj.x * rel.z - dj.z * rel.x);
+                    // distance of des_v to the RAY, not to its line: a candidate of column j passed the sign tests
+                    // of C_RayRayIntersection2D (collision.c:862-871), so (pt - apex) agrees with the direction
+                    // component by component (or is zero) -- its foot on line j has a parameter >= 0.  A ray that
+                    // points away from des_v is as far from it as its apex is.  (The decision t >= 0 may be off by
+                    // the rounding of t: there |rel| and the line distance differ by t^2 / 2 dist, far below the
+                    // margins; the native square root's ulp hides in the factor.)
+                    const float dline = fabsf(dj.x * rel.z - dj.z * rel.x);
+                    const float tpar = dj.x * rel.x + dj.z * rel.z;
+                    const float dapex = nh_sqrt_native(rel.x * rel.x + rel.z * rel.z) * 0.999f;
+                    const float dist = (tpar >= 0.0f) ? dline : fmaxf(dline, dapex);
                     // prunable once dist > B.len + CP_COL_MARGIN + 2e-3 (B.len + |rel|_1): the second
                     // margin covers rays with |dir.x| < 1/1024, which are intersected as the exactly
                     // vertical line x = apex.x (collision.c:823-831), up to 1/1024 per unit of distance
                     // off the real line.  Solved for B.len, rounded down.
                     const float k = (dist - CP_COL_MARGIN - 2e-3f * (fabsf(rel.x) + fabsf(rel.z))) * 0.99f;
-                    mykey[h] = (k == k) ? k : -__builtin_inff();        // NaN: never pruned
+                    mykey[h] = (k == k && dline == dline) ? k : -__builtin_inff();   // NaN (fmaxf would hide it): never pruned
+                    mykeyc[h] = mykey[h];
                     S.ckey[j] = mykey[h];
                 }
             }
+#if NH_CP_COVER
+            // ---- columns that cannot hold an admissible candidate at all.  A candidate of column j lies on line j
+            // (the slope line C_InfiniteLineIntersection evaluates, or x = apex.x for a ray it treats as vertical),
+            // at a parameter >= 0 (the sign tests), within the rounding of that evaluation (< 1e-3 wu on a 8192 wu
+            // map).  If apex j lies inside ANOTHER cone c, at least 1/4 wu from c's apex and 0.02 (as a sine) from
+            // both of its sides, and the line's direction lies between c's sides by the same margin and does not
+            // point back towards c's apex, then every such point is inside cone c: its direction from apex c stays
+            // between those of (apex j - apex c) and of the line, both 0.02 inside, and it never comes closer to
+            // apex c than apex j is.  inside_pcr's own thresholds are 1/1024 and its roundings 4e-7: such a column
+            // holds nothing but inadmissible candidates, whatever the bound -- a third of the rays in a jam.
+            // (The projections of des_v -- points of the LINE, possibly behind the apex -- were all tested above.)
+            if(G == 64) {
+                float apx[2], apz[2], ux[2], uz[2];
+#pragma unroll
+                for(int h = 0; h < 2; h++) {
+                    const int j = gl + h * G;
+                    apx[h] = apz[h] = ux[h] = uz[h] = 0.0f;
+                    if(j < n_rays) {
+                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                        const v2 dj = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
+                        const float sj = (j & 1) ? Aj.w : Aj.z;
+                        apx[h] = Aj.x; apz[h] = Aj.y;
+                        if(sj != sj) { ux[h] = 0.0f; uz[h] = copysignf(1.0f, dj.z); }        // (vertical for the reference)
+                        else { const float inv = copysignf(nh_rsq_native(1.0f + sj * sj), dj.x); ux[h] = inv; uz[h] = sj * inv; }
+                    }
+                }
+                const float MS = 0.02f, DMIN2 = 0.0625f;
+                for(int c = 0; c < n_cones; c++) {
+                    const float4 Ac = S.cones[2 * c], Bc = S.cones[2 * c + 1];
+#pragma unroll
+                    for(int h = 0; h < 2; h++) {
+                        if(h == 1 && n_rays <= G) break;
+                        const int j = gl + h * G;
+                        const float qx = apx[h] - Ac.x, qz = apz[h] - Ac.y;
+                        const float l2 = qx * qx + qz * qz;
+                        const float il = nh_rsq_native(l2);
+                        const float ld = (qz * Bc.x - qx * Bc.y) * il, rd = (qz * Bc.z - qx * Bc.w) * il;
+                        const float dl = uz[h] * Bc.x - ux[h] * Bc.y, dr = uz[h] * Bc.z - ux[h] * Bc.w;
+                        const float fw = qx * ux[h] + qz * uz[h];
+                        const bool okc = l2 >= DMIN2 && l2 < 1e30f && ld >= CP_EPS + MS && rd <= -(CP_EPS + MS)
+                                      && dl >= MS && dr <= -MS && fw >= 0.0f && (j >> 1) != c && j < n_rays;
+                        if(okc) mykeyc[h] = __builtin_inff();
+                    }
+                }
+            }
+#endif
+            float *keyc = (float*)S.tau;                       // (tau, seq: the retry shortcut's, free during the search)
+#pragma unroll
+            for(int h = 0; h < 2; h++) { const int j = gl + h * G; if(j < n_rays) keyc[j] = mykeyc[h]; }
+            cov0 = g::ballot(mykeyc[0] == __builtin_inff() && gl < n_rays);
+            cov1 = g::ballot(mykeyc[1] == __builtin_inff() && gl + G < n_rays);
             wave_sync();
 #pragma unroll
             for(int h = 0; h < 2; h++) {
@@ -761,14 +887,137 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                 if(j < n_rays) {
                     int rank = 0;
                     for(int k = 0; k < n_rays; k++) {
-                        const float kk = S.ckey[k];
-                        rank += (kk < mykey[h] || (kk == mykey[h] && k < j)) ? 1 : 0;
+                        const float kk = keyc[k];
+                        rank += (kk < mykeyc[h] || (kk == mykeyc[h] && k < j)) ? 1 : 0;
                     }
                     S.col[rank] = j;
                 }
             }
             wave_sync();
         }
+        // ---- the cones that can still matter.  Every candidate that can beat the bound lies within B.len of
+        // des_v; des_v is inside the obstacle.  A cone that contains such a point but not des_v has a side ray
+        // crossing the segment between the two, i.e. within B.len of des_v (the region inside_pcr accepts is the
+        // cone turned inwards by asin(1/1024) per side: r/1024 at distance r, inside the key's second margin):
+        // that ray's column key is <= B.len.  So the inside-obstacle tests of the column phase only need the
+        // cones that contain des_v or own a live column -- in a jam half of them -- in the same order.
+        int n_test = n_cones;
+#if NH_CP_CONE_COMPACT
+        if(G == 64 && B.nfound) {
+            bool relevant = false;
+            if(gl < n_cones) relevant = in || !(S.ckey[2 * gl] > B.len) || !(S.ckey[2 * gl + 1] > B.len);
+            const int slot_r = gl < n_cones ? S.ord[gl] : 0;                // rank gl -> cone slot
+            const bool keep = gl < n_cones && (g::shfl((int)relevant, slot_r) != 0);
+            const unsigned long long mk = g::ballot(keep);
+            wave_sync();
+            if(keep) S.ord[__popcll(mk & lt_mask)] = slot_r;
+            n_test = __popcll(mk);
+            wave_sync();
+            CP_STAT(B.sb, 4, n_test);
+        }
+#endif
+        CP_STAT(B.sb, 14, __popcll(cov0) + __popcll(cov1));
+        CP_TMARK(sb_, 4);                      // keys, column order, cone compaction
+#if NH_CP_COLS_V2
+        if(G == 64) {
+            // ---- lane = row: this lane's (up to two) rays stay in registers, the column's ray is the same for the
+            // whole wave.  No index arithmetic, a quarter of the LDS reads, and the bound is consulted per column.
+            float rpx[2], rpz[2], rdx[2], rdz[2], rsl[2];
+#pragma unroll
+            for(int h = 0; h < 2; h++) {
+                const int r = gl + h * G;
+                rpx[h] = rpz[h] = rdx[h] = rdz[h] = rsl[h] = 0.0f;
+                if(r < n_rays) {
+                    const float4 Ar = S.cones[r & ~1], Br = S.cones[r | 1];
+                    rpx[h] = Ar.x; rpz[h] = Ar.y;
+                    rdx[h] = (r & 1) ? Br.z : Br.x; rdz[h] = (r & 1) ? Br.w : Br.y;
+                    rsl[h] = (r & 1) ? Ar.w : Ar.z;
+                }
+            }
+            const int n_mine = (n_rays - part + nparts - 1) / nparts;      // columns part, part + nparts, ...
+#if NH_CP_COLS2
+            for(int jc = 0; jc < n_mine; jc += 2) {
+                const int j0 = __builtin_amdgcn_readfirstlane(S.col[jc * nparts + part]);
+                if(((j0 < 64 ? cov0 >> j0 : cov1 >> (j0 - 64)) & 1ull) != 0ull) break;
+                if(B.nfound && uni<G>(S.ckey[j0]) > B.len) break;
+                int j1 = -1;
+                if(jc + 1 < n_mine) {
+                    j1 = __builtin_amdgcn_readfirstlane(S.col[(jc + 1) * nparts + part]);
+                    if(((j1 < 64 ? cov0 >> j1 : cov1 >> (j1 - 64)) & 1ull) != 0ull) j1 = -1;
+                    else if(B.nfound && uni<G>(S.ckey[j1]) > B.len) j1 = -1;
+                }
+                CP_STAT(B.sb, 6, j1 >= 0 ? 2 : 1);
+                CP_STAT(B.sb, 2, j1 >= 0 ? 2 * n_rays : n_rays);
+                const int jb = j1 >= 0 ? j1 : j0;
+                const float4 Aj = S.cones[j0 & ~1], Bj = S.cones[j0 | 1], Ak = S.cones[jb & ~1], Bk = S.cones[jb | 1];
+                const v2 p2 = mkv(Aj.x, Aj.y), d2 = (j0 & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
+                const float s2 = (j0 & 1) ? Aj.w : Aj.z;
+                const v2 p3 = mkv(Ak.x, Ak.y), d3 = (jb & 1) ? mkv(Bk.z, Bk.w) : mkv(Bk.x, Bk.y);
+                const float s3 = (jb & 1) ? Ak.w : Ak.z;
+                const int nh = n_rays > G ? 2 : 1;
+#pragma unroll 1
+                for(int h = 0; h < nh; h++) {
+                    const int i = gl + h * G;
+                    const v2 p1 = h ? mkv(rpx[1], rpz[1]) : mkv(rpx[0], rpz[0]);
+                    const v2 d1 = h ? mkv(rdx[1], rdz[1]) : mkv(rdx[0], rdz[0]);
+                    const float s1 = h ? rsl[1] : rsl[0];
+                    bool ok0 = false, ok1 = false;
+                    v2 pt0 = mkv(0, 0), pt1 = mkv(0, 0);
+                    float len0 = 0.0f, len1 = 0.0f;
+                    if(i < n_rays) {
+                        // (two independent chains: the two divisions and square roots overlap)
+                        ok0 = i != j0 && ray_isect(p1, d1, s1, p2, d2, s2, pt0);
+                        ok1 = j1 >= 0 && i != j1 && ray_isect(p1, d1, s1, p3, d3, s3, pt1);
+                        len0 = vlen(vsub(des_v, vsub(pt0, ent.pos)));
+                        len1 = vlen(vsub(des_v, vsub(pt1, ent.pos)));
+                        ok0 = ok0 && cp_alive(B, len0, i * n_rays + j0);
+                        ok1 = ok1 && cp_alive(B, len1, i * n_rays + jb);
+                    }
+#ifdef NH_CP_STATS
+                    B.passes++;
+#endif
+                    cp_push<G>(S, ent, n_test, ok0, pt0, i * n_rays + j0, len0, qn, L, B);
+                    if(j1 >= 0) cp_push<G>(S, ent, n_test, ok1, pt1, i * n_rays + jb, len1, qn, L, B);
+                }
+            }
+#else
+            for(int jc = 0; jc < n_mine; jc++) {
+                const int j = __builtin_amdgcn_readfirstlane(S.col[jc * nparts + part]);
+                if(((j < 64 ? cov0 >> j : cov1 >> (j - 64)) & 1ull) != 0ull) break;       // (covered columns sort last)
+                if(B.nfound && uni<G>(S.ckey[j]) > B.len) break;
+                CP_STAT(B.sb, 6, 1);
+                CP_STAT(B.sb, 2, n_rays);
+                const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                const v2 p2 = mkv(Aj.x, Aj.y), d2 = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
+                const float s2 = (j & 1) ? Aj.w : Aj.z;
+                const int nh = n_rays > G ? 2 : 1;
+#pragma unroll 1
+                for(int h = 0; h < nh; h++) {              // (not unrolled: ONE copy of the queue code in the loop)
+                    const int i = gl + h * G;
+                    const int idx = i * n_rays + j;
+                    const v2 p1 = h ? mkv(rpx[1], rpz[1]) : mkv(rpx[0], rpz[0]);
+                    const v2 d1 = h ? mkv(rdx[1], rdz[1]) : mkv(rdx[0], rdz[0]);
+                    const float s1 = h ? rsl[1] : rsl[0];
+                    bool ok = false;
+                    v2 pt = mkv(0, 0);
+                    float len = 0.0f;
+                    if(i < n_rays && i != j) {
+                        ok = ray_isect(p1, d1, s1, p2, d2, s2, pt);
+                        if(ok) {
+                            len = vlen(vsub(des_v, vsub(pt, ent.pos)));
+                            ok = cp_alive(B, len, idx);
+                        }
+                    }
+#ifdef NH_CP_STATS
+                    B.passes++;
+#endif
+                    cp_push<G>(S, ent, n_test, ok, pt, idx, len, qn, L, B);
+                }
+            }
+#endif
+            cp_work<G>(S, ent, n_test, qn, L, B, true);
+        }else
+#endif
         {
             // columns per batch: about four passes of candidates
             const int kb = max(1, (4 * G) / n_rays);
@@ -808,13 +1057,17 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                             }
                         }
                     }
-                    cp_push<G>(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
+                    cp_push<G>(S, ent, n_test, ok, pt, idx, len, qn, L, B);
                 }
                 jdone += ncol;
             }
-            cp_work<G>(S, ent, n_cones, qn, L, B, true);
+            cp_work<G>(S, ent, n_test, qn, L, B, true);
         }
         }
+#ifdef NH_CP_STATS
+        CP_STAT(B.sb, 5, B.it); CP_STAT(B.sb, 8, B.busy); CP_STAT(B.sb, 9, B.ex); CP_STAT(B.sb, 10, B.out);
+        CP_STAT(B.sb, 11, B.passes); CP_STAT(B.sb, 13, B.cw);
+#endif
         if(TEAM) team_min<G>(B, *T, part, nparts);
         CP_TMARK(sb_, 2);
         if(B.nfound) {
@@ -828,13 +1081,14 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         if(!jumped) {
             // the first failure: find the attempt that will succeed and go there in one step
             jumped = true;
-            int t = cp_jump<G>(S, ent, des_v, have, isdyn, k, use, slot, dist, n_dyn, n_stat, n_cones, part, nparts);
+            int t = uni<G>(cp_jump<G>(S, ent, des_v, have, isdyn, k, use, slot, dist, n_dyn, n_stat, n_cones, part, nparts));
             if(TEAM) {
                 if(gl == 0) T->t[part] = t < 0 ? (1 << 20) : t;
                 __syncthreads();
                 t = T->t[0];
                 for(int w = 1; w < nparts; w++) t = min(t, T->t[w]);
                 if(t >= (1 << 20)) t = -1;
+                t = uni<G>(t);
                 __syncthreads();
             }
 #ifdef NH_CP_UNIT_HIST
@@ -855,7 +1109,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                 }
             }
             wave_sync();
-            for(int r = 0; r < t; r++) { if(S.seq[r] < 256) n_dyn--; else n_stat--; }
+            for(int r = 0; r < t; r++) { if(uni<G>(S.seq[r]) < 256) n_dyn--; else n_stat--; }
             continue;
         }
         // (not reached in practice: the attempt after a jump succeeds; kept as the plain loop)
@@ -863,6 +1117,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         float nk = -dist; int ni = gl;
         if(!have || !(dist == dist)) { nk = __builtin_inff(); }   // NaN never passes `len > max_dist`
         g::argmin(nk, ni);
+        nk = uni<G>(nk); ni = uni<G>(ni);
         wave_sync();
         if(nk < __builtin_inff() && gl == 0) {
             if(ni < n_dyn) { for(int q = 0; q < 5; q++) S.dyn[5 * ni + q] = S.dyn[5 * (n_dyn - 1) + q]; }

@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(128) void k_clearpath(int nq, const float *ent, con
 {
     __shared__ cp_lds<GW> lds[128 / GW];
     const int gi = threadIdx.x / GW, gl = threadIdx.x & (GW - 1);
-    const int q = blockIdx.x * (128 / GW) + gi;
+    const int q = uni<GW>((int)(blockIdx.x * (128 / GW) + gi));           // (a wave-wide group: the same in every lane)
     if(q >= nq) return;
     cp_lds<GW> &S = lds[gi];
     const int nd = n_dyn[q], ns = n_stat[q];
@@ -1656,15 +1656,15 @@ extern "C" int navhip_debug_cp_hist(unsigned long long out[128])
 }
 #endif
 #ifdef NH_CP_STATS
-extern "C" int navhip_debug_cp_work(unsigned long long out[128], int reset)
+extern "C" int navhip_debug_cp_work(unsigned long long out[192], int reset)
 {
     if(hipDeviceSynchronize() != hipSuccess) return 1;
-    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_cp_work), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if(hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(nh_cp_cyc), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_cp_work), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if(hipMemcpyFromSymbol(out + 128, HIP_SYMBOL(nh_cp_cyc), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if(reset) {
-        unsigned long long z[64] = {0};
+        unsigned long long z[128] = {0};
         if(hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_work), z, sizeof(z)) != hipSuccess) return 1;
-        if(hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_cyc), z, sizeof(z)) != hipSuccess) return 1;
+        if(hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_cyc), z, 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
     }
     return 0;
 }

@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""numpy float32 model of ONE attempt of the ClearPath search (clearpath.c:552-660), developer tool, CPU only.
+
+Every float operation mirrors agent_math.h / the reference (IEEE single, no contraction), so the
+exhaustive arg-min of the model equals the reference's answer for problems whose first attempt succeeds
+(checked against oracle.navoracle.clearpath).  On top of that the model evaluates PRUNING RULES before they
+go into the kernel: a rule is exact iff the pruned arg-min equals the exhaustive one on every problem; the
+script also counts the work each rule leaves (columns, rows, cones, candidates).
+
+    python scripts/cp_model.py [--n 400] [--crowd 17] [--xoff 0] [--seed 1]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+f32 = np.float32
+EPS = f32(1.0 / 1024)
+np.seterr(all="ignore")
+
+
+def vlen(x, z):
+    return np.sqrt(x * x + z * z, dtype=f32)
+
+
+def vnormal(x, z):
+    l = vlen(x, z)
+    return x / l, z / l
+
+
+def slope(dx, dz):
+    return np.where(np.abs(dx) < EPS, f32(np.nan), dz / dx).astype(f32)
+
+
+def line_isect(p1x, p1z, s1, p2x, p2z, s2):
+    """C_InfiniteLineIntersection with precomputed slopes; broadcasting; returns ok, x, z"""
+    n1, n2 = np.isnan(s1), np.isnan(s2)
+    ok = ~(n1 & n2) & ~(np.abs(s1 - s2) < EPS)
+    xg = (s1 * p1x - s2 * p2x + p2z - p1z) / (s1 - s2)
+    zg = s2 * (xg - p2x) + p2z
+    x = np.where(n1 & ~n2, p1x, np.where(~n1 & n2, p2x, xg))
+    z = np.where(n1 & ~n2, (p1x - p2x) * s2 + p2z, np.where(~n1 & n2, (p2x - p1x) * s1 + p2z, zg))
+    return ok, x.astype(f32), z.astype(f32)
+
+
+def ray_isect(p1x, p1z, d1x, d1z, s1, p2x, p2z, d2x, d2z, s2):
+    ok, x, z = line_isect(p1x, p1z, s1, p2x, p2z, s2)
+    neg = ((x - p1x) / d1x < 0) | ((z - p1z) / d1z < 0) | ((x - p2x) / d2x < 0) | ((z - p2z) / d2z < 0)
+    return ok & ~neg, x, z
+
+
+def make_cones(ent, nbs, isdyn):
+    """ent: pos(2) vel(2) radius; nbs [n][5]; -> apex[n][2], left[n][2], right[n][2], sl, sr (same_position skipped)"""
+    ex, ez, evx, evz, er = [f32(v) for v in ent]
+    nx, nz, nvx, nvz, nr = [nbs[:, k].astype(f32) for k in range(5)]
+    keep = ~(vlen(nx - ex, nz - ez) < EPS)
+    nx, nz, nvx, nvz, nr, isdyn = nx[keep], nz[keep], nvx[keep], nvz[keep], nr[keep], isdyn[keep]
+    e2x, e2z = vnormal(nx - ex, nz - ez)
+    rx, rz = -e2z, e2x
+    sc = nr + er + f32(0.0)
+    rx, rz = rx * sc, rz * sc
+    rtx, rtz = nx + rx, nz + rz
+    ltx, ltz = nx - rx, nz - rz
+    Rx, Rz = vnormal(rtx - ex, rtz - ez)
+    Lx, Lz = vnormal(ltx - ex, ltz - ez)
+    sl, sr = slope(Lx, Lz), slope(Rx, Rz)
+    vax, vaz = ex + nvx, ez + nvz
+    ax, az = vax.copy(), vaz.copy()
+    # hrvo
+    offx, offz = (evx + nvx) * f32(0.5), (evz + nvz) * f32(0.5)
+    rax, raz = ex + offx, ez + offz
+    cx, cz = Lx + Rx, Lz + Rz
+    det = cx * evz - cz * evx
+    pos, neg = det > EPS, det < -EPS
+    s1 = np.where(pos, sl, sr)
+    s2 = np.where(pos, sr, sl)
+    ok, ix, iz = line_isect(rax, raz, s1, vax, vaz, s2)
+    hx = np.where((pos | neg) & ok, ix, rax)
+    hz = np.where((pos | neg) & ok, iz, raz)
+    ax = np.where(isdyn, hx, ax).astype(f32)
+    az = np.where(isdyn, hz, az).astype(f32)
+    dist = vlen(nx - ex, nz - ez)
+    return dict(ax=ax, az=az, Lx=Lx, Lz=Lz, Rx=Rx, Rz=Rz, sl=sl, sr=sr, dist=dist)
+
+
+def inside_cone(C, c, px, pz):
+    """cone_contains_exact for cone(s) c and point(s) (broadcast)"""
+    qx, qz = px - C["ax"][c], pz - C["az"][c]
+    l = vlen(qx, qz)
+    small = l < EPS
+    ux, uz = qx / l, qz / l
+    ld = uz * C["Lx"][c] - ux * C["Lz"][c]
+    rd = uz * C["Rx"][c] - ux * C["Rz"][c]
+    return ~small & ~(ld < EPS) & ~(rd > -EPS)
+
+
+def rays_of(C):
+    n = len(C["ax"])
+    px = np.repeat(C["ax"], 2)
+    pz = np.repeat(C["az"], 2)
+    dx = np.stack([C["Lx"], C["Rx"]], 1).reshape(-1)
+    dz = np.stack([C["Lz"], C["Rz"]], 1).reshape(-1)
+    s = np.stack([C["sl"], C["sr"]], 1).reshape(-1)
+    return px, pz, dx, dz, s
+
+
+def attempt(ent, des, C, rules=None, stats=None):
+    """One clearpath_new_velocity attempt.  Returns (found, vx, vz, idx).  rules: dict of pruning switches."""
+    ex, ez = f32(ent[0]), f32(ent[1])
+    n = len(C["ax"])
+    if n == 0:
+        return True, des[0], des[1], -1
+    dwx, dwz = ex + f32(des[0]), ez + f32(des[1])
+    allc = np.arange(n)
+    in_des = inside_cone(C, allc, dwx, dwz)
+    if not in_des.any():
+        return True, des[0], des[1], -1
+    px, pz, dx, dz, s = rays_of(C)
+    nr = 2 * n
+    npairs = nr * nr
+    # projections
+    plen = dx * f32(des[0]) + dz * f32(des[1])
+    qx, qz = px + dx * plen, pz + dz * plen
+    qlen = vlen(f32(des[0]) - (qx - ex), f32(des[1]) - (qz - ez))
+    q_in = np.zeros(nr, bool)
+    for c in range(n):
+        q_in |= inside_cone(C, c, qx, qz)
+    best = (np.inf, 1 << 60, 0.0, 0.0)
+    nfound = 0
+    for r in np.flatnonzero(~q_in):
+        nfound += 1
+        key = (qlen[r], npairs + r)
+        if not np.isnan(qlen[r]) and key < best[:2]:
+            best = (qlen[r], npairs + r, qx[r] - ex, qz[r] - ez)
+    # all pairs, i row, j column
+    I, J = np.meshgrid(np.arange(nr), np.arange(nr), indexing="ij")
+    ok, cx, cz = ray_isect(px[I], pz[I], dx[I], dz[I], s[I], px[J], pz[J], dx[J], dz[J], s[J])
+    ok &= I != J
+    clen = vlen(f32(des[0]) - (cx - ex), f32(des[1]) - (cz - ez))
+    if rules is None:
+        live = ok
+        cones = allc
+    else:
+        # the bound after the projection phase (what the kernel has when the column phase starts)
+        B = best[0] if nfound else np.inf
+        relx, relz = f32(des[0]) - (px - ex), f32(des[1]) - (pz - ez)
+        dline = np.abs(dx * relz - dz * relx)
+        t = dx * relx + dz * relz
+        dray = np.where(t >= 0, dline, vlen(relx, relz))
+        l1 = np.abs(relx) + np.abs(relz)
+        marg = f32(0.02) + f32(2e-3) * l1
+        key_line = (dline - marg) * f32(0.99)
+        key_ray = (dray - marg) * f32(0.99)
+        key = key_ray if rules.get("ray_key") else key_line
+        colive = ~(key > B) | np.isnan(key)
+        live = ok & colive[None, :]
+        cones = allc
+        if rules.get("cones") and nfound:
+            rel_c = in_des | colive[0::2] | colive[1::2]
+            # a cone whose inside test of des_v is within the unsure band counts as containing it
+            cones = np.flatnonzero(rel_c)
+        if rules.get("rows") and nfound:
+            S0 = f32(rules.get("S0", 4.0))
+            X = max(abs(float(ex)), abs(float(ez))) + 64.0
+            R0 = f32(rules.get("kappa", 2e-6) * X * float(S0))
+            steep = np.isnan(s) | (np.abs(s) > S0)
+            keyr = (dray - marg - R0) * f32(0.99)
+            rowlive = steep | ~(keyr > B) | np.isnan(keyr)
+            # steep columns take every row
+            live &= rowlive[:, None] | steep[None, :]
+        if stats is not None:
+            stats["n_rays"].append(nr)
+            stats["live_cols"].append(int(colive.sum()))
+            stats["rel_cones"].append(len(cones))
+            stats["cands"].append(int(live.sum()))
+            stats["cands_lt"].append(int((live & (clen <= B)).sum()))
+            stats["bound"].append(float(B))
+            stats["nfound_proj"].append(nfound)
+    # inside tests of the live candidates against `cones`
+    ci, cj = np.nonzero(live)
+    if len(ci):
+        inn = np.zeros(len(ci), bool)
+        for c in cones:
+            inn |= inside_cone(C, c, cx[ci, cj], cz[ci, cj])
+        for k in np.flatnonzero(~inn):
+            i, j = ci[k], cj[k]
+            nfound += 1
+            L = clen[i, j]
+            keyk = (L, i * nr + j)
+            if not np.isnan(L) and keyk < best[:2]:
+                best = (L, i * nr + j, cx[i, j] - ex, cz[i, j] - ez)
+    if nfound == 0:
+        return False, 0.0, 0.0, -2
+    return True, best[2], best[3], best[1]
+
+
+def jam_problems(n, crowd, seed, xoff):
+    from permafrost_engine_amd import synth
+    from scipy.spatial import cKDTree
+    grid = synth.cost_grid(16, 16, seed=1234)
+    ag = synth.agents(grid, 100_000, 64, seed=7, crowd_cells=crowd)
+    pos, vel = ag["pos"].astype(f32), ag["vel"].astype(f32)
+    pos = pos + f32(xoff)
+    dests = synth.destinations(grid, 64, seed=42)
+    tgt = synth.cell_centre(16, 16, dests[:, 0], dests[:, 1]).astype(f32) + f32(xoff)
+    tree = cKDTree(pos)
+    rng = np.random.RandomState(seed)
+    out = []
+    for uid in rng.choice(len(pos), n, replace=False):
+        nb = [k for k in tree.query_ball_point(pos[uid], 10.0) if k != uid]
+        rng.shuffle(nb)
+        nb = nb[:32]
+        if len(nb) < 5:
+            continue
+        d = tgt[ag["flock"][uid]] - pos[uid]
+        d = d / max(np.linalg.norm(d), 1e-3)
+        des = (0.6 * d + 0.4 * vel[uid]).astype(f32)
+        nbs = np.zeros((len(nb), 5), f32)
+        nbs[:, 0:2] = pos[nb]
+        nbs[:, 2:4] = vel[nb]
+        nbs[:, 4] = 1.0
+        ent = np.array([pos[uid, 0], pos[uid, 1], vel[uid, 0], vel[uid, 1], 1.0], f32)
+        out.append((ent, des, nbs))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=300)
+    ap.add_argument("--crowd", type=int, default=17)
+    ap.add_argument("--xoff", type=float, default=0.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--S0", type=float, default=4.0)
+    ap.add_argument("--check-oracle", action="store_true")
+    args = ap.parse_args()
+    probs = jam_problems(args.n, args.crowd, args.seed, args.xoff)
+    print("%d problems, mean neighbours %.1f" % (len(probs), np.mean([len(p[2]) for p in probs])))
+    variants = {
+        "line_key": dict(),
+        "ray_key": dict(ray_key=True),
+        "ray_key+cones": dict(ray_key=True, cones=True),
+        "ray_key+cones+rows": dict(ray_key=True, cones=True, rows=True, S0=args.S0),
+    }
+    mism = {k: 0 for k in variants}
+    stats = {k: {s: [] for s in ("n_rays", "live_cols", "rel_cones", "cands", "cands_lt", "bound", "nfound_proj")} for k in variants}
+    nfail = 0
+    ora_bad = 0
+    for ent, des, nbs in probs:
+        isdyn = np.ones(len(nbs), bool)
+        C = make_cones(ent, nbs, isdyn)
+        ref = attempt(ent, des, C)
+        if not ref[0]:
+            nfail += 1
+        if args.check_oracle and ref[0]:
+            from oracle import navoracle
+            dyn = np.zeros((1, 32, 5), f32)
+            dyn[0, :len(nbs)] = nbs
+            o = navoracle.clearpath(ent[None], des[None], dyn, [len(nbs)], np.zeros((1, 32, 5), f32), [0])[0]
+            if not (f32(o[0]) == f32(ref[1]) and f32(o[1]) == f32(ref[2])):
+                ora_bad += 1
+        for name, rules in variants.items():
+            r = attempt(ent, des, C, rules, stats[name])
+            if r[0] != ref[0] or (r[0] and (r[3] != ref[3] or f32(r[1]) != f32(ref[1]) or f32(r[2]) != f32(ref[2]))):
+                mism[name] += 1
+    print("first attempt fails: %d of %d; oracle mismatches %d" % (nfail, len(probs), ora_bad))
+    for name in variants:
+        st = stats[name]
+        if not st["n_rays"]:
+            continue
+        fin = np.isfinite(st["bound"])
+        print("%-22s mismatches %d | rays %.1f live cols %.1f rel cones %.1f cands %.0f (<=bound %.0f) | bound median %.3f, none after projections: %d"
+              % (name, mism[name], np.mean(st["n_rays"]), np.mean(st["live_cols"]), np.mean(st["rel_cones"]),
+                 np.mean(st["cands"]), np.mean(st["cands_lt"]), np.median(np.array(st["bound"])[fin]) if fin.any() else -1,
+                 int((~fin).sum())))
+
+
+if __name__ == "__main__":
+    main()
+
+
+def deep_stats(n=150, crowd=17, seed=1):
+    """What the search needs at least: candidates nearer than the final answer, and how many cones the
+    nearest-first order tests before one contains them."""
+    probs = jam_problems(n, crowd, seed, 0.0)
+    rows = []
+    for ent, des, nbs in probs:
+        C = make_cones(ent, nbs, np.ones(len(nbs), bool))
+        ref = attempt(ent, des, C)
+        if not ref[0] or ref[3] < 0:
+            continue
+        ex, ez = ent[0], ent[1]
+        nc = len(C["ax"])
+        px, pz, dx, dz, s = rays_of(C)
+        nr = 2 * nc
+        I, J = np.meshgrid(np.arange(nr), np.arange(nr), indexing="ij")
+        ok, cx, cz = ray_isect(px[I], pz[I], dx[I], dz[I], s[I], px[J], pz[J], dx[J], dz[J], s[J])
+        ok &= I != J
+        clen = vlen(des[0] - (cx - ex), des[1] - (cz - ez))
+        fx, fz = ref[1], ref[2]
+        flen = vlen(des[0] - f32(fx), des[1] - f32(fz))
+        near = ok & (clen <= flen)
+        order = np.argsort(C["dist"], kind="stable")
+        ci, cj = np.nonzero(near)
+        first = []
+        for a, b in zip(ci, cj):
+            hit = nc
+            for r, c in enumerate(order):
+                if inside_cone(C, c, cx[a, b], cz[a, b]):
+                    hit = r
+                    break
+            first.append(hit)
+        first = np.array(first) if first else np.zeros(0, int)
+        # columns whose ray comes within flen of des_v
+        relx, relz = des[0] - (px - ex), des[1] - (pz - ez)
+        t = dx * relx + dz * relz
+        dray = np.where(t >= 0, np.abs(dx * relz - dz * relx), vlen(relx, relz))
+        rows.append((nr, int(near.sum()), float(np.mean(first + 1)) if len(first) else 0.0,
+                     float(np.percentile(first + 1, 90)) if len(first) else 0.0, int((dray <= flen).sum()), float(flen),
+                     int(ok.sum())))
+    r = np.array(rows)
+    print("problems %d: rays %.1f | all valid pairs %.0f | candidates <= final len %.1f | cones tested before a hit: mean %.1f p90 %.1f | "
+          "rays within final len %.1f | final len median %.3f" % (len(r), r[:, 0].mean(), r[:, 6].mean(), r[:, 1].mean(), r[:, 2].mean(),
+                                                                r[:, 3].mean(), r[:, 4].mean(), np.median(r[:, 5])))
+
+
+if __name__ == "__main__" and "--deep" in sys.argv:
+    deep_stats()

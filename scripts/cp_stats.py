@@ -32,9 +32,11 @@ def run(crowd=0):
     os.environ["NAVHIP_LIB"] = LIB
     from permafrost_engine_amd import navhip, tick
     T = tick.NavTick(crowd_cells=crowd)
-    names = ["problems", "attempts", "cand_generated", "cand_queued", "cone_tests", "test_iters", "live_cols", "rays"]
+    names = ["problems", "attempts", "cand_generated", "cand_queued", "cones_left_by_compaction", "test_iters", "live_cols", "rays",
+             "busy_lane_tests", "exact_iters", "outside_iters", "passes", "no_bound_after_projections", "work_cycles_columns",
+             "covered_rays", "iters_projection_phase"]
     buckets = ["1-2", "3-4", "5-8", "9-16", "17-32", "33-64"]
-    buf = (C.c_ulonglong * 128)()
+    buf = (C.c_ulonglong * 192)()
     rows = {}
     for t in range(1, 101):
         if t in (10, 50, 100):
@@ -46,12 +48,12 @@ def run(crowd=0):
             navhip.lib().navhip_debug_cp_work(buf, 1)
             out = {}
             for b, bn in enumerate(buckets):
-                v = [buf[b * 8 + k] for k in range(8)]
-                cy = [buf[64 + b * 8 + k] for k in range(8)]
+                v = [buf[b * 16 + k] for k in range(16)]
+                cy = [buf[128 + b * 8 + k] for k in range(8)]
                 if v[0]:
-                    out[bn] = {"problems": v[0], **{names[k]: round(v[k] / v[0], 1) for k in range(1, 8)},
+                    out[bn] = {"problems": v[0], **{names[k]: round(v[k] / v[0], 1) for k in range(1, 16) if names[k] != "-"},
                                "kcycles_total": {"cones": cy[0] // 1000, "projections": cy[1] // 1000,
-                                                 "columns": cy[2] // 1000, "jump": cy[3] // 1000},
+                                                 "columns": cy[2] // 1000, "jump": cy[3] // 1000, "keys_rank_compact": cy[4] // 1000},
                                "units": {"n": cy[6], "kcycles_sum": cy[5] // 1000, "kcycles_max": cy[7] // 1000}}
             rows["tick_%d" % t] = out
     print(json.dumps(rows, indent=1))

@@ -27,18 +27,19 @@ def build(extra=()):
     print("built", LIB)
 
 
-def run():
+def run(crowd=0):
     os.environ["NAVHIP_LIB"] = LIB
     from permafrost_engine_amd import navhip, tick
-    T = tick.NavTick()
+    T = tick.NavTick(crowd_cells=crowd)
     buf = (C.c_ulonglong * 128)()
     rows = {}
-    for t in range(1, 101):
-        if t in (5, 50, 100):
+    marks = (5, 20, 40) if crowd else (5, 50, 100)
+    for t in range(1, marks[-1] + 1):
+        if t in marks:
             T.sync()
             navhip.lib().navhip_debug_cp_hist(buf)
         T.step()
-        if t in (5, 50, 100):
+        if t in marks:
             T.sync()
             navhip.lib().navhip_debug_cp_hist(buf)
             v = list(buf)
@@ -55,4 +56,4 @@ if __name__ == "__main__":
     if "--build" in sys.argv:
         build([a for a in sys.argv[2:]])
     else:
-        run()
+        run(17 if "--crowd" in sys.argv else 0)
