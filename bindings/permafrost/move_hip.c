@@ -327,8 +327,10 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         vec2_t np = new_pos_for_vel(in->ent_uid, hip_heading_gated(ms, out->ent_des_v, out->ent_vel));
         new_pos[2 * i] = np.x; new_pos[2 * i + 1] = np.z;
         vdes[2 * i] = out->ent_des_v.x; vdes[2 * i + 1] = out->ent_des_v.z;
-        /* a formation member (:2427-2437) or an active arrival group (:2443): the host's arms */
-        skip[i] = in->fstate.fid != NULL_FID;
+        /* a formation member (:2427-2437) or an active arrival group (:2443): the host's arms.  So is every unit
+         * at a movement rate below 20 Hz: entity_compute_update then tests the INTERPOLATED intermediate position
+         * (interpolate_positions(next_ppos, next_npos, ms->step), :2368-2377), not pos + vel */
+        skip[i] = in->fstate.fid != NULL_FID || (20 / hz_count(s_move_work.hz)) > 1;
         if(!skip[i] && S.flock[i] >= 0) {
             struct flock *fl = &vec_AT(&s_flocks, S.flock[i]);
             struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,

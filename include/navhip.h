@@ -405,7 +405,12 @@ typedef struct navhip_world {
      * else always travels: the per-tick state (pos, vel, speed, state, has_dest_los, vdes, formation and
      * arrival inputs) and the per-entity attributes that change without any of those events -- radius,
      * max_speed (MOVE_CMD_SET_MAX_SPEED, movement.c:3226) and flags (ENTITY_FLAG_GARRISONED is toggled
-     * outside movement.c). */
+     * outside movement.c).
+     * Device-resident calls (navhip_agent_step_dev, _prefetch_dev) read it for one purpose: a caller that steps a
+     * uid SLAB (work_begin / work_end) and passes the same nonzero epoch again promises that flock_members is the
+     * one of its previous call -- the cohesion term then reuses the lane grouping of the slab's members it made
+     * last tick.  0 on a slab call = unknown: the grouping is rebuilt from the flock tables (slower, never wrong).
+     * Steps over the whole snapshot do not need it. */
     uint32_t static_epoch;
     /* Region fields sampled on the device: N_DesiredEnemySeekVelocity (nav.c:3603) for STATE_SEEK_ENEMIES and
      * N_DesiredSurroundVelocity (nav.c:3687) for STATE_SURROUND_ENTITY entities that use the surround field
@@ -532,6 +537,13 @@ int  navhip_debug_cp_attempts(unsigned long long out[9], int reset);
 #define NAVHIP_COMM_ID_BYTES 128
 int  navhip_comm_unique_id(uint8_t out_id[NAVHIP_COMM_ID_BYTES]);
 int  navhip_comm_init(navhip_ctx *ctx, int rank, int world, const uint8_t id[NAVHIP_COMM_ID_BYTES]);
+/* The same exchange without RCCL, for bringing the step up on one device or behind a transport of the host's
+ * own: the "network" is dev_mailbox, a device buffer laid out like the gathered array ([n][4] floats for
+ * navhip_comm_allgather_step_dev, the rows themselves for _rows_dev).  A call deposits this rank's rows there and
+ * takes every other rank's rows from there -- the caller has put them in (or moves the mailbox between ranks by
+ * whatever means it has).  Packing, slab bounds, the ragged grouping and unpacking are the code RCCL runs behind;
+ * the GPU tests drive every rank of a 2-, 3- and 4-rank job through it on one device. */
+int  navhip_comm_init_mailbox(navhip_ctx *ctx, int rank, int world, void *dev_mailbox, size_t mailbox_bytes);
 void navhip_comm_destroy(navhip_ctx *ctx);
 int  navhip_comm_rank(const navhip_ctx *ctx);     /* -1 without a communicator */
 int  navhip_comm_world(const navhip_ctx *ctx);    /*  0 without a communicator */
@@ -570,8 +582,11 @@ int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_
 #define NAVHIP_SU_HOST       0x80   /* not decided here: another state, a formation member, an active arrival
                                        group (skip[i] != 0), or a unit whose nav layer is not its flock's      */
 typedef struct navhip_state_in {
-    const float    *new_pos_xz;       /* [n][2] new_pos_for_vel(uid, new_vel) (movement.c:2338): position + the
-                                                velocity of the tick AFTER the heading gate (:2321-2334)        */
+    const float    *new_pos_xz;       /* [n][2] the position entity_compute_update tests: new_pos_for_vel(uid,
+                                                new_vel) (movement.c:2338) -- position + the velocity of the tick
+                                                AFTER the heading gate (:2321-2334) -- at 20 Hz; at lower movement
+                                                rates the interpolated intermediate position that replaces it
+                                                (:2368-2377) -- or mark those units in `skip` (the binding does) */
     const float    *vdes_xz;          /* [n][2] move_work_out.ent_des_v                                        */
     const uint8_t  *skip;             /* [n] or NULL                                                           */
     const uint8_t  *flock_layer;      /* [F]    the nav layer flock_nearest_xz / flock_tiles were made for     */

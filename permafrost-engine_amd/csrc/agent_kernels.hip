@@ -451,13 +451,13 @@ __device__ __forceinline__ float cohesion_t_f64(float len)
 // or slab changed) the identity over whole flocks: ceil(flock size / 16) waves.
 __global__ __launch_bounds__(256) void k_coh_plan(const int32_t *bin_start, const int32_t *flock_offsets,
                                                   const int32_t *saved, int n_flocks, int work_begin, int work_end,
-                                                  int32_t *wave_off, int32_t *perm_valid)
+                                                  int members_key, int32_t *wave_off, int32_t *perm_valid)
 {
     __shared__ int32_t wsum[4];
     __shared__ int32_t carry;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if(t == 0) carry = 0;
-    bool same = saved[n_flocks + 1] == work_begin && saved[n_flocks + 2] == work_end;
+    bool same = saved[n_flocks + 1] == work_begin && saved[n_flocks + 2] == work_end && saved[n_flocks + 3] == members_key;
     for(int f = t; f <= n_flocks; f += 256) same = same && saved[f] == flock_offsets[f];
     const int valid = __syncthreads_and(same);
     for(int base = 0; base < n_flocks; base += 256) {
@@ -546,13 +546,18 @@ __device__ __forceinline__ int coh_grouped_add(int32_t *counter, int bin, bool i
 // Members outside the work range [work_begin, work_end) -- on a rank that steps one slab of a large job
 // that is most of the snapshot -- leave before the flock search and get no lane at all (bin_of = -1): the
 // grouping holds the members INSIDE the range, flock by flock, active bins first.  saved[]: what the
-// grouping was built for (flock offsets, then the work range).
+// grouping was built for: flock offsets, the work range, and the MEMBERSHIP KEY.  A member outside the range
+// has no lane, so a grouping made for a slab is only valid while flock_members is unchanged: equal offsets and
+// bounds do not show that (two units swap flocks of equal size; an entity removed elsewhere shifts a uid across
+// the slab boundary), and the unit that moved into the slab would keep another entity's stale force.  The key
+// is 0 for a step over the whole snapshot (every member has a lane, a change is harmless), the caller's
+// navhip_world.static_epoch for a slab step, and a number that never repeats when the caller gave none.
 __global__ __launch_bounds__(256) void k_coh_bin(nh_step_params P, int32_t *bin_of, int32_t *bin_count,
                                                  int32_t *saved)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
     for(int f = g; f <= P.n_flocks; f += gridDim.x * 256) saved[f] = P.flock_offsets[f];
-    if(g == 0) { saved[P.n_flocks + 1] = P.work_begin; saved[P.n_flocks + 2] = P.work_end; }
+    if(g == 0) { saved[P.n_flocks + 1] = P.work_begin; saved[P.n_flocks + 2] = P.work_end; saved[P.n_flocks + 3] = P.members_key; }
     if(g >= P.flock_offsets[P.n_flocks]) return;
     const int m = P.flock_members[g];
     if(m < P.work_begin || m >= P.work_end) { bin_of[g] = -1; return; }
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     bool use_perm;
     if(INLINE_PLAN) {
         const int nf = P.n_flocks;
-        bool ok = saved[nf + 1] == P.work_begin && saved[nf + 2] == P.work_end;
+        bool ok = saved[nf + 1] == P.work_begin && saved[nf + 2] == P.work_end && saved[nf + 3] == P.members_key;
         if(t <= nf) ok = ok && saved[t] == P.flock_offsets[t];
         if(t == 0 && nf == 64) ok = ok && saved[64] == P.flock_offsets[64];
         use_perm = __all(ok);
@@ -1265,13 +1270,19 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
 __attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
 #endif
 __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                            nh_worklists WL, nh_step_outs O)
+                                                            nh_worklists WL, nh_step_outs O, int32_t *zero_next)
 {
     __shared__ cp_lds<64> lds[CP_WAVES];
     __shared__ int32_t hv_end[2 * NH_WL_SUB];       // sub-lists of the heavy list, then of the wave list
     __shared__ int32_t h_ticket;
     __shared__ cp_team team;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // The last launch of the step on the side stream clears the OTHER set of list counters for the next step.
+    // On THIS stream because the library copies every step's counters to pinned host memory behind the step, on
+    // this stream too (navhip_step_lists_peek): the clearing of a set is ordered behind the copy of that set by the
+    // stream itself.  (Its users -- the previous step -- finished before this step's k_agent_mid started.)
+    if(blockIdx.x == 0 && zero_next)
+        for(int i = threadIdx.x; i < (int)NH_WL_COUNTERS; i += CP_WAVES * 64) zero_next[i] = 0;
     // (outside a crowd there is nothing to do: one parallel look at the 128 counters)
     if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
     unit_totals(hv_end, 2 * NH_WL_SUB, [&](int k) {
@@ -1370,10 +1381,8 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
     __shared__ cp_lds<64> cps[AG_WAVES];
     __shared__ double exp_tab[64];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // the last launch of the step on its stream clears the OTHER set of list counters for the next step
-    // (that set's consumers finished with the previous step; as a launch of its own in front of k_agent_mid
-    // it was 6 us on the critical path of every tick)
-    if(blockIdx.x == 0)
+    // (zero_next: the other set of list counters, when this launch is the one that clears it -- k_cp_heavy is)
+    if(blockIdx.x == 0 && zero_next)
         for(int i = threadIdx.x; i < (int)NH_WL_COUNTERS; i += AG_WAVES * 64) zero_next[i] = 0;
     // usually there is nothing to do: one parallel look at the 64 sub-list counters
     if(!__any(WL.count[NH_WL_FULL * NH_WL_SUB + lane] != 0)) return;
@@ -1750,14 +1759,14 @@ static coh_scratch coh_layout(int32_t *scratch, int n_flocks, int n_members)
     C.perm[0] = C.bin_of + n_members;
     C.perm[1] = C.perm[0] + n_members;
     C.saved[0] = C.perm[1] + n_members;
-    C.saved[1] = C.saved[0] + n_flocks + 3;
-    C.valid = C.saved[1] + n_flocks + 3;
+    C.saved[1] = C.saved[0] + n_flocks + 4;
+    C.valid = C.saved[1] + n_flocks + 4;
     return C;
 }
 size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members)
 {
     const size_t nb = (size_t)n_flocks * COH_BINS;
-    return sizeof(int32_t) * (3 * ((size_t)n_flocks + 3) + 3 * nb + 1 + (nb + NH_SCAN_T - 1) / NH_SCAN_T
+    return sizeof(int32_t) * (3 * ((size_t)n_flocks + 4) + 3 * nb + 1 + (nb + NH_SCAN_T - 1) / NH_SCAN_T
                               + 3 * (size_t)n_members + 1);
 }
 
@@ -1765,7 +1774,7 @@ size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members)
 void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s)
 {
     const coh_scratch C = coh_layout(scratch, n_flocks, n_members);
-    hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 3), s);
+    hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 4), s);
 }
 
 __global__ void k_zero_i32(int32_t *p, int n)
@@ -1815,7 +1824,7 @@ bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh,
         return true;
     }
     hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start, P.flock_offsets,
-                       (const int32_t*)C.saved[prev], P.n_flocks, P.work_begin, P.work_end, C.wave_off, C.valid);
+                       (const int32_t*)C.saved[prev], P.n_flocks, P.work_begin, P.work_end, P.members_key, C.wave_off, C.valid);
     hipLaunchKernelGGL(k_cohesion<false>, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
                        (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start,
                        (const int32_t*)C.saved[prev]);
@@ -1871,12 +1880,12 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
                        (const nh_mid_rec*)d_mid, WL, O);
     hipLaunchKernelGGL(k_cp_rows, dim3(64 * CP_WAVES / CPR_WAVES), dim3(CPR_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_RETRY, 1, 1);
-    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O);
+    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O, zero_next);
     if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_ROW3, 2, 0);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
-                       (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, zero_next);
+                       (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, (int32_t*)nullptr);
     if(fork) hipStreamWaitEvent(s, ev[1], 0);
     return true;
 }

@@ -52,6 +52,7 @@ struct nh_step_params {
     int         n_ents, n_flocks, hz;
     int         n_members;           // upper bound of flock_offsets[n_flocks] (launch size)
     int         work_begin, work_end;
+    int         members_key;         // what a lane grouping of the flocks' members is valid for (see k_coh_bin)
     const float    *pos_xz, *vel_xz, *radius, *max_speed, *speed;
     const uint32_t *flags;
     const uint8_t  *state, *has_dest_los;

@@ -12,7 +12,18 @@
 
 #include <dlfcn.h>
 #include <cstring>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// a host without the RCCL headers still builds the library (librccl is only looked for at run time): the few
+// types and constants of the entry points bound below, as rccl.h declares them
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+}
+#endif
 
 #define HIPCHK(ctx, expr)                                                                   \
     do {                                                                                    \
@@ -64,11 +75,50 @@ bool rccl_load()
 
 }  // namespace
 
+// How rows travel between ranks.  RCCL over xGMI in production; the MAILBOX transport for bringing the exchange
+// step up (and testing it) where there is one device or no RCCL: the "network" is a device buffer laid out like
+// the receive buffer, into which the caller has put the other ranks' rows -- a rank's own rows are deposited
+// there, everybody else's are taken from there.  Everything around the transport (packing, slab bounds, the
+// ragged grouping, unpacking) is the same code on both.
 struct nh_comm {
-    ncclComm_t comm;
+    ncclComm_t comm;                          // (null: mailbox transport)
     int        rank, world;
     float     *pack;   size_t pack_cap;       // [n][4] staging of navhip_comm_allgather_step_dev
+    char      *mailbox; size_t mailbox_bytes; // mailbox transport: laid out like the receive buffer
+    char      *cur_base;                      // (mailbox transport) the receive buffer of the collective in flight
 };
+
+// the two collectives the exchange uses, on either transport
+static int tr_allgather(navhip_ctx *ctx, const void *send, void *recv, size_t cnt, hipStream_t s)
+{
+    nh_comm *C = ctx->comm;
+    if(C->comm) {
+        ncclResult_t r = g_rccl.AllGather(send, recv, cnt, ncclChar, C->comm, s);
+        if(r != ncclSuccess) { ctx->last_error = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return NAVHIP_ERR_DEVICE; }
+        return NAVHIP_OK;
+    }
+    if(cnt * (size_t)C->world > C->mailbox_bytes) { ctx->last_error = "mailbox smaller than the gathered rows"; return NAVHIP_ERR_INVALID; }
+    if(cnt) HIPCHK(ctx, hipMemcpyAsync(C->mailbox + (size_t)C->rank * cnt, send, cnt, hipMemcpyDeviceToDevice, s));
+    for(int r = 0; r < C->world; r++)
+        if(r != C->rank && cnt)
+            HIPCHK(ctx, hipMemcpyAsync((char*)recv + (size_t)r * cnt, C->mailbox + (size_t)r * cnt, cnt, hipMemcpyDeviceToDevice, s));
+    return NAVHIP_OK;
+}
+
+static int tr_broadcast(navhip_ctx *ctx, void *buf, size_t cnt, int root, hipStream_t s)
+{
+    nh_comm *C = ctx->comm;
+    if(C->comm) {
+        ncclResult_t r = g_rccl.Broadcast(buf, buf, cnt, ncclChar, root, C->comm, s);
+        if(r != ncclSuccess) { ctx->last_error = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(r); return NAVHIP_ERR_DEVICE; }
+        return NAVHIP_OK;
+    }
+    const size_t off = (size_t)((char*)buf - C->cur_base);
+    if(off + cnt > C->mailbox_bytes) { ctx->last_error = "mailbox smaller than the gathered rows"; return NAVHIP_ERR_INVALID; }
+    if(root == C->rank) HIPCHK(ctx, hipMemcpyAsync(C->mailbox + off, buf, cnt, hipMemcpyDeviceToDevice, s));
+    else                HIPCHK(ctx, hipMemcpyAsync(buf, C->mailbox + off, cnt, hipMemcpyDeviceToDevice, s));
+    return NAVHIP_OK;
+}
 
 #define NCCLCHK(ctx, expr)                                                                          \
     do {                                                                                            \
@@ -98,30 +148,27 @@ static int allgather_rows(navhip_ctx *ctx, char *rows, size_t row_bytes, const i
 {
     nh_comm *C = ctx->comm;
     const int world = C->world;
+    if(bounds[0] != 0) return NAVHIP_ERR_INVALID;
     bool equal = true;
     const int32_t per = bounds[1] - bounds[0];
     for(int r = 0; r < world; r++) {
         if(bounds[r + 1] < bounds[r]) return NAVHIP_ERR_INVALID;
         equal = equal && bounds[r] == r * per && bounds[r + 1] - bounds[r] == per;
     }
-    if(equal) {
-        // in place: every rank's send buffer is its own slab of the receive buffer
-        NCCLCHK(ctx, g_rccl.AllGather(rows + (size_t)bounds[C->rank] * row_bytes, rows, (size_t)per * row_bytes, ncclChar,
-                                      C->comm, s));
-        return NAVHIP_OK;
-    }
+    C->cur_base = rows;
+    if(equal)         // in place: every rank's send buffer is its own slab of the receive buffer
+        return tr_allgather(ctx, rows + (size_t)bounds[C->rank] * row_bytes, rows, (size_t)per * row_bytes, s);
     // ragged slabs (movement.c:3759: the last slab of a ceil split is shorter): one broadcast per rank,
     // grouped into one launch
-    NCCLCHK(ctx, g_rccl.GroupStart());
-    for(int r = 0; r < world; r++) {
+    if(C->comm) NCCLCHK(ctx, g_rccl.GroupStart());
+    int rc = NAVHIP_OK;
+    for(int r = 0; r < world && !rc; r++) {
         const size_t cnt = (size_t)(bounds[r + 1] - bounds[r]) * row_bytes;
         if(!cnt) continue;
-        char *p = rows + (size_t)bounds[r] * row_bytes;
-        ncclResult_t rc = g_rccl.Broadcast(p, p, cnt, ncclChar, r, C->comm, s);
-        if(rc != ncclSuccess) { g_rccl.GroupEnd(); ctx->last_error = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(rc); return NAVHIP_ERR_DEVICE; }
+        rc = tr_broadcast(ctx, rows + (size_t)bounds[r] * row_bytes, cnt, r, s);
     }
-    NCCLCHK(ctx, g_rccl.GroupEnd());
-    return NAVHIP_OK;
+    if(C->comm) { if(rc) g_rccl.GroupEnd(); else NCCLCHK(ctx, g_rccl.GroupEnd()); }
+    return rc;
 }
 
 extern "C" {
@@ -145,6 +192,7 @@ int navhip_comm_init(navhip_ctx *ctx, int rank, int world, const uint8_t id[NAVH
     nh_comm *C = new (std::nothrow) nh_comm();
     if(!C) return NAVHIP_ERR_NOMEM;
     C->rank = rank; C->world = world; C->pack = nullptr; C->pack_cap = 0;
+    C->mailbox = nullptr; C->mailbox_bytes = 0; C->cur_base = nullptr;
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     ncclResult_t rc = g_rccl.CommInitRank(&C->comm, world, uid, rank);
@@ -157,12 +205,25 @@ int navhip_comm_init(navhip_ctx *ctx, int rank, int world, const uint8_t id[NAVH
     return NAVHIP_OK;
 }
 
+int navhip_comm_init_mailbox(navhip_ctx *ctx, int rank, int world, void *dev_mailbox, size_t mailbox_bytes)
+{
+    if(!ctx || !dev_mailbox || world < 1 || rank < 0 || rank >= world) return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    navhip_comm_destroy(ctx);
+    nh_comm *C = new (std::nothrow) nh_comm();
+    if(!C) return NAVHIP_ERR_NOMEM;
+    C->comm = nullptr; C->rank = rank; C->world = world; C->pack = nullptr; C->pack_cap = 0;
+    C->mailbox = (char*)dev_mailbox; C->mailbox_bytes = mailbox_bytes; C->cur_base = nullptr;
+    ctx->comm = C;
+    return NAVHIP_OK;
+}
+
 void navhip_comm_destroy(navhip_ctx *ctx)
 {
     if(!ctx || !ctx->comm) return;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    g_rccl.CommDestroy(ctx->comm->comm);
+    if(ctx->comm->comm) g_rccl.CommDestroy(ctx->comm->comm);
     if(ctx->comm->pack) hipFree(ctx->comm->pack);
     delete ctx->comm;
     ctx->comm = nullptr;

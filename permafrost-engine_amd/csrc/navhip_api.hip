@@ -100,7 +100,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(&ctx->counters, 0, sizeof(ctx->counters));
     ctx->gen_launches = 0;
     ctx->coh_flocks = ctx->coh_members = -1;
-    ctx->coh_parity = 0;
+    ctx->coh_parity = 0; ctx->coh_unique = 0;
     ctx->ev_regroup = nullptr;
     for(auto &e : ctx->ev_cp) e = nullptr;
     ctx->regroup_pending = false;
@@ -818,6 +818,10 @@ static int step_fill_params(navhip_ctx *ctx, const navhip_world *w, nh_step_para
     if(P.work_begin == 0 && P.work_end == 0) P.work_end = w->n_ents;
     if(P.work_begin < 0 || P.work_end > w->n_ents || P.work_begin > P.work_end)
         return NAVHIP_ERR_INVALID;
+    // (the cohesion term's lane grouping, carried from tick to tick: see k_coh_bin)
+    if(P.work_begin == 0 && P.work_end == w->n_ents) P.members_key = 0;
+    else if(w->static_epoch)                          P.members_key = (int)((w->static_epoch & 0x3fffffffu) | 0x40000000u);
+    else                                              P.members_key = (int)(0x80000000u | ++ctx->coh_unique);
     P.pos_xz = w->pos_xz; P.vel_xz = w->vel_xz; P.radius = w->radius; P.max_speed = w->max_speed;
     P.speed = w->speed; P.flags = w->flags; P.state = w->state; P.has_dest_los = w->has_dest_los;
     P.flock = w->flock; P.vdes_xz = w->vdes_xz; P.flock_target_xz = w->flock_target_xz;

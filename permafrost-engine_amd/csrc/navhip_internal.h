@@ -61,6 +61,7 @@ struct navhip_ctx {
     buf          gen_list;     // [2 + n] requests the BFS kernel left to k_field_generic: 2 counters, ids
     unsigned     gen_launches; // parity selects the counter of a launch
     int          coh_flocks, coh_members, coh_parity;   // layout of coh_plan + which perm buffer is next
+    unsigned     coh_unique;   // membership keys of slab steps whose caller gave no static_epoch: never equal
     buf          stage[48];    // device copies of host buffers for the host-pointer entry points
     // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
     hipStream_t  aux[2];

@@ -127,6 +127,19 @@ static void pool_rollback(nh_pool *P, const std::vector<int> &fresh_slots)
     }
 }
 
+// drop the field of `slot`: every mapping that points at it becomes "no field", the slot is free again
+static void pool_drop_slot(nh_pool *P, int slot)
+{
+    if(!P->used[slot]) return;
+    for(int64_t e : P->refs[slot]) {
+        if(P->h_map[(size_t)e] == slot) {
+            P->h_map[(size_t)e] = -1;
+            P->pending.push_back((int32_t)e); P->pending.push_back(-1);
+        }
+    }
+    pool_rollback(P, std::vector<int>{slot});
+}
+
 static int pool_flush_map(navhip_ctx *ctx, nh_pool *P, hipStream_t s)
 {
     if(P->pending.empty()) return NAVHIP_OK;
@@ -161,6 +174,10 @@ int navhip_pool_create(navhip_ctx *ctx, int n_slots, int n_dests)
 {
     if(!ctx || n_slots < 1 || n_dests < 1) return NAVHIP_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if((int64_t)n_dests * ctx->nchunks > 0x7fffffffLL) {       // (map updates travel as 32-bit entry indices)
+        ctx->last_error = "navhip_pool_create: n_dests x chunks does not fit 31 bits";
+        return NAVHIP_ERR_INVALID;
+    }
     navhip_pool_destroy(ctx);
     nh_pool *P = new (std::nothrow) nh_pool();
     if(!P) return NAVHIP_ERR_NOMEM;
@@ -213,14 +230,7 @@ int navhip_pool_invalidate(navhip_ctx *ctx, uint64_t ff_id)
     auto it = P->slot_of.find(ff_id);
     if(it == P->slot_of.end()) return NAVHIP_OK;               // (lru_flow_remove of an absent key: no-op)
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int slot = it->second;
-    for(int64_t e : P->refs[slot]) {
-        if(P->h_map[(size_t)e] == slot) {
-            P->h_map[(size_t)e] = -1;
-            P->pending.push_back((int32_t)e); P->pending.push_back(-1);
-        }
-    }
-    pool_rollback(P, std::vector<int>{slot});                  // unregister, least recently used again
+    pool_drop_slot(P, it->second);                             // unregister, least recently used again
     return pool_flush_map(ctx, P, ctx->stream);
 }
 
@@ -322,7 +332,12 @@ int navhip_pool_build(navhip_ctx *ctx, const navhip_field_req *reqs, const uint6
         auto it = P->slot_of.find(base[i]);
         if(it != P->slot_of.end()) pinned[it->second] = 1;
     }
-#define POOL_FAIL(code) do { pool_rollback(P, fresh_slots); hipStreamSynchronize(s); pool_flush_map(ctx, P, s); return (code); } while(0)
+    // A failure undoes the sub-batch it happened in, ALL of it: a fresh slot was never valid, and a resident
+    // field that was being rebuilt in place (or had just received its base copy) may be half written -- it is
+    // dropped like navhip_pool_invalidate drops it (the host builds it again on the next miss).  The sub-batches
+    // before it were built, synchronised and stay registered.
+    std::vector<int> batch_slots;
+#define POOL_FAIL(code) do { hipStreamSynchronize(s); for(int sl_ : batch_slots) pool_drop_slot(P, sl_); pool_flush_map(ctx, P, s); return (code); } while(0)
 #define POOL_HIPCHK(expr) do { hipError_t _e = (expr); if(_e != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); POOL_FAIL(NAVHIP_ERR_DEVICE); } } while(0)
     // Sub-batches: a request that reads (base) or rewrites the slot of an EARLIER request of the same
     // sub-batch has to wait for it -- the in-place chains of nav.c:1987-2011 -- and so has a request
@@ -332,7 +347,7 @@ int navhip_pool_build(navhip_ctx *ctx, const navhip_field_req *reqs, const uint6
     while(begin < n) {
         std::unordered_map<uint64_t, int> written, copied_from;
         int end = begin;
-        copies.clear(); zeros.clear();
+        copies.clear(); zeros.clear(); batch_slots.clear();
         for(; end < n; end++) {
             const uint64_t b = base[end];
             if(written.count(ff_ids[end]) || (b && written.count(b)) || copied_from.count(ff_ids[end])) break;
@@ -347,6 +362,7 @@ int navhip_pool_build(navhip_ctx *ctx, const navhip_field_req *reqs, const uint6
             if(slot < 0) { ctx->last_error = "navhip_pool_build: no evictable slot"; POOL_FAIL(NAVHIP_ERR_NOMEM); }
             pinned[slot] = 1;
             if(fresh) fresh_slots.push_back(slot);
+            batch_slots.push_back(slot);
             slots[end] = slot;
             written[ff_ids[end]] = end;
             if(base_slot >= 0) { copies.push_back(base_slot); copies.push_back(slot); }

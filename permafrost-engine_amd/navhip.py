@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NAVHIP_LIB") or os.path.join(_HERE, "libnavhip.so")
 
 OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NOT_UPLOADED = -1, -2, -3, -4        # NAVHIP_ERR_*
 FIELD_RES = 64
 FIELD_CELLS = 4096
 COST_IMPASSABLE = 0xFF
@@ -97,6 +98,7 @@ _SIGS = {
     "navhip_debug_cp_attempts": (C.c_int, [C.c_void_p, C.c_int]),
     "navhip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "navhip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "navhip_comm_init_mailbox": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "navhip_comm_destroy": (None, [C.c_void_p]),
     "navhip_comm_rank": (C.c_int, [C.c_void_p]),
     "navhip_comm_world": (C.c_int, [C.c_void_p]),
@@ -182,6 +184,10 @@ class NavContext:
         if rc != OK:
             msg = lib().navhip_last_error(self._h)
             raise NavHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def last_error(self):
+        msg = lib().navhip_last_error(self._h)
+        return msg.decode() if msg else ""
 
     @property
     def stream(self):
@@ -757,7 +763,14 @@ def _ctx_comm_allgather_rows_dev(self, d_rows, row_bytes, bounds, stream=None):
               "navhip_comm_allgather_rows_dev")
 
 
+def _ctx_comm_init_mailbox(self, rank, world, d_mailbox):
+    """navhip_comm_init_mailbox: the exchange step over a device buffer instead of RCCL (bring-up, tests)."""
+    self._chk(lib().navhip_comm_init_mailbox(self._h, int(rank), int(world), dev_ptr(d_mailbox),
+                                             int(d_mailbox.numel() * d_mailbox.element_size())), "navhip_comm_init_mailbox")
+
+
 NavContext.comm_init = _ctx_comm_init
+NavContext.comm_init_mailbox = _ctx_comm_init_mailbox
 NavContext.comm_destroy = lambda self: lib().navhip_comm_destroy(self._h)
 NavContext.comm_world = lambda self: int(lib().navhip_comm_world(self._h))
 NavContext.comm_allgather_step_dev = _ctx_comm_allgather_step_dev

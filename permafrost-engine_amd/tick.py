@@ -316,6 +316,10 @@ class NavTick:
 
     def _make_structs(self):
         arrays = dict(self.t)
+        # (a rank that steps a slab: this driver never changes its flock tables -- the promise that lets the
+        # library carry the cohesion term's lane grouping from tick to tick, navhip.h: static_epoch)
+        if (self.a0, self.a1) != (0, self.N):
+            arrays["static_epoch"] = 1
         self.world_s, self._keep = navhip.make_world(self.Wt, self.H, arrays, hz=self.hz)
         self.world_s.work_begin, self.world_s.work_end = self.a0, self.a1
         self.out_s = navhip.StepOut()

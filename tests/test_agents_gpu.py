@@ -428,6 +428,56 @@ def test_lane_grouping_carried_between_ticks_is_only_a_hint(navlib):
     shared.close()
 
 
+@pytest.mark.parametrize("epoch", [0, 7])
+def test_slab_lane_grouping_survives_membership_changes(navlib, epoch):
+    """A rank that steps a uid slab gives cohesion lanes to the slab's members only and carries that grouping to
+    the next tick.  Equal flock offsets and equal slab bounds do not prove that flock_members is unchanged: swap
+    two units between flocks of equal size so that a unit INSIDE the slab takes a CSR position that held a unit
+    outside it.  Without a static_epoch the grouping must not be trusted (epoch 0); with one, the caller promises
+    unchanged tables -- and says so by bumping it when they change.  Either way: the same velocities as a context
+    that has never seen the first tick."""
+    import ctypes as C_
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    n, k = 1600, 4
+    world = cases.make_agents(grid, n, k, seed=5, clustered=False)
+    world["flock"] = (np.arange(n) % k).astype(np.int32)           # equal sizes
+    vdes = np.zeros((n, 2), np.float32)
+    vdes[:, 0] = 1.0
+    b, e = 0, n // 2
+
+    def run(ctx, w_arrays, ep):
+        w, keep = navlib.make_world(4, 4, dict(w_arrays, static_epoch=ep))
+        w.work_begin, w.work_end = b, e
+        vel = np.zeros((n, 2), np.float32)
+        npos = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        so = navlib.StepOut()
+        so.vel_xz, so.new_pos_xz, so.status = vel.ctypes.data, npos.ctypes.data, st.ctypes.data
+        assert navlib.lib().navhip_agent_step(ctx._h, C_.byref(w), C_.byref(so)) == 0
+        return vel[b:e].copy()
+
+    a1 = cases.step_arrays(world, vdes)
+    # tick 2: unit u_in (inside the slab, flock 0) and unit u_out (outside, flock 1) swap flocks: offsets equal,
+    # but flock 1's CSR run now holds a slab member where an outsider was
+    w2 = dict(world)
+    w2["flock"] = world["flock"].copy()
+    u_in, u_out = 4, n // 2 + 5                                    # flocks 0 and 1
+    assert w2["flock"][u_in] == 0 and w2["flock"][u_out] == 1
+    w2["flock"][u_in], w2["flock"][u_out] = 1, 0
+    a2 = cases.step_arrays(w2, vdes)
+    assert np.array_equal(a1["flock_offsets"], a2["flock_offsets"])
+    shared = _upload(navlib, nav)
+    run(shared, a1, epoch)
+    run(shared, a1, epoch)                                         # (the second step uses the carried grouping)
+    got = run(shared, a2, epoch + 1 if epoch else 0)               # a caller with epochs bumps it on a change
+    shared.close()
+    fresh = _upload(navlib, nav)
+    exp = run(fresh, a2, 0)
+    fresh.close()
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), np.flatnonzero((got != exp).any(1))[:8]
+    assert np.abs(exp).max() > 0
+
+
 @pytest.mark.parametrize("w,h", [(5, 2), (2, 5)])
 def test_non_square_map_velocity_step_matches_reference(navlib, w, h):
     """The whole agent step on a non-square map, sampling the reference's own cached fields on the
