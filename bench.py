@@ -104,7 +104,7 @@ def usable_cores():
     return min(n, 256)
 
 
-def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10.0, budget_agent_s=10.0):
+def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10.0, budget_agent_s=10.0, dropin=True):
     """The reference's own code (oracle/_ref) timed on this box's host cores, on a bounded sample of
     the SAME workload (whole=True: all of it, config 0).  Reported, never the target."""
     try:
@@ -155,8 +155,36 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10
         per_agent = t_1 / min(400, n_agents)
         m = n_agents if whole else int(min(n_agents, max(cores * 8, budget_agent_s / per_agent)))
         t_a, _ = mv.bench(vdes, reps=1, nthreads=cores, begin=0, end=m)
+        # ---- the drop-in as the engine sees it: the SAME velocity half of the reference's movement tick, all
+        # work items, through the binding's WORK_TYPE_HIP arm (bindings/permafrost/move_hip.c: snapshot tables
+        # and work items -> navhip_world -> navhip_agent_step_submit / _wait, host buffers and PCIe included ->
+        # s_move_work.out[]) and through its WORK_TYPE_CPU arm (move_velocity_work on `cores` pthreads)
+        drop = None
+        if dropin:
+            try:
+                if nav.hip_init():
+                    mv.bench_hip(vdes, reps=1, end=n_agents)            # (allocations, first launches)
+                    reps = 5
+                    r = mv.bench_hip(vdes, reps=reps, end=n_agents)
+                    t_cpu_all = t_a if m == n_agents else mv.bench(vdes, reps=1, nthreads=cores, begin=0, end=n_agents)[0]
+                    if r is not None:
+                        dt, parts = r
+                        drop = {"what": "velocity half of the reference's movement tick, %d work items: WORK_TYPE_HIP arm "
+                                        "(move_hip.c, host buffers through navhip_agent_step_submit/_wait) vs WORK_TYPE_CPU "
+                                        "arm (move_velocity_work, %d pthreads), same box" % (n_agents, cores),
+                                "hip_ms_per_tick": dt / reps * 1e3, "cpu_ms_per_tick": t_cpu_all * 1e3, "cores": cores,
+                                "speedup": t_cpu_all / (dt / reps),
+                                "hip_ms_fill_snapshot_and_work_items": parts["fill"] / reps * 1e3,
+                                "hip_ms_submit_to_wait": parts["device"] / reps * 1e3,
+                                "hip_ms_scatter_results": parts["scatter"] / reps * 1e3,
+                                "host_share": (parts["fill"] + parts["scatter"]) / dt,
+                                "agent_steps_per_s_hip": n_agents * reps / dt}
+                pfref.RefNav.hip_shutdown()
+            except Exception as exc:
+                drop = {"error": repr(exc)}
         pfref.RefMove.unload()
         return {
+            "dropin": drop,
             "value": m / t_a, "unit": "agent-steps/s", "cores": cores, "kind": "reference",
             "sample": "reference movement.c move_velocity_work on %d of the %d agents (full snapshot loaded), "
                       "%d pthreads; reference N_FlowFieldInit+N_FlowFieldUpdate on %d of the %d chunk-field "
@@ -269,6 +297,16 @@ def main():
                          "(none in this workload: flocks are rank aligned); all = all-gather every tile "
                          "every tick (any agent may sample any field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="--gpus N > 1: weak = every GPU brings its own region, fields and agents (default for configs "
+                         "0-2, 4); strong = ONE world of the configuration's size, its destinations and its agents "
+                         "split over the N ranks (requests by destination, uid slabs: movement.c:3759-3762; default "
+                         "for config 3)")
+    ap.add_argument("--no-los", action="store_true",
+                    help="has_dest_los = 0 for every agent instead of the per-tick device lookup in the planner's LOS fields")
+    ap.add_argument("--no-sustained", action="store_true",
+                    help="skip the secondary 100-tick measurement that a run with --steps < 100 adds")
+    ap.add_argument("--no-dropin", action="store_true", help="skip timing the reference's own movement tick with the binding")
     ap.add_argument("--no-pipeline-fields", action="store_true",
                     help="build a tick's fields inside that tick, in front of its agent step (default: the fields "
                          "of tick t+1 are built during tick t, beside the agent step; same work, same results)")
@@ -292,7 +330,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libnavhip has no CPU fallback")
     torch.cuda.set_device(local)
 
-    shared = cfg["shared"]
+    shared = cfg["shared"] if args.scaling is None else args.scaling == "strong"
     f_rank = cfg["fields"] // world if shared else cfg["fields"]
     a_rank = cfg["agents"] // world if shared else cfg["agents"]
     CROWD = 17      # cells: a flock of ~1 600 packed into ~35 x 35 cells -> ~30 neighbours within r = 10
@@ -302,11 +340,11 @@ def main():
                             rank=rank, world=world, device=local, obstacles=cfg["obstacles"],
                             obstacle_ticks=args.warmup + args.steps + 16, tile_exchange=args.tile_exchange,
                             shared_map=shared, crowd_cells=CROWD if crowd else 0,
-                            pipeline_fields=not args.no_pipeline_fields)
+                            pipeline_fields=not args.no_pipeline_fields, los=not args.no_los, flow_velocities=True)
 
     T = make(args.crowded)
     fields_ahead, tick_every = T.pipeline_fields, T.tick_every
-    request_source = T.request_source
+    request_source, los_source, velocity_source = T.request_source, T.los_source, T.velocity_source
     early = {}
     dt, ticks = run_ticks(T, pdist, torch, args.warmup, args.steps, early)
     phases = T.phase_ms()
@@ -314,8 +352,10 @@ def main():
 
     # per-kernel-group durations at the END of the run (the world has crowded by then); the same
     # split for the last warm-up ticks is in `early`
+    prof_first = T.tick_no + 1
     groups = profiled_ticks(T, 6)
     T_ticks_done = T.tick_no
+    prof_ticks = "ticks %d-%d of the run" % (prof_first + 1, T_ticks_done)
 
     agents_total = T.N
     cells_total = T.n_req_total * 4096
@@ -364,22 +404,18 @@ def main():
         key = "SQ_INSTS_VALU" if T_ticks_done >= 60 else "SQ_INSTS_VALU_early_ticks"
         insts = sum((sq[k].get(key) or sq[k]["SQ_INSTS_VALU"]) for k in ks)
         floor_ms = insts / 1024 * cyc / 2.4e9 * 1e3
-        # what an instruction of THIS mix (integer, compares, selects, f64) occupies the VALU for:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles a wave had a VALU instruction executing
-        act = sum(sq[k].get("SQ_ACTIVE_INST_VALU", 0.0) for k in ks)
-        late = sum(sq[k]["SQ_INSTS_VALU"] for k in ks)
-        mix_cyc = 4.0 * act / late if late > 0 and act > 0 else None
         return {"valu_insts_per_launch": insts, "issue_floor_ms": floor_ms, "cycles_per_inst": cyc,
                 "frac_of_issue_peak": floor_ms / measured_ms,
-                "cycles_per_inst_this_mix": mix_cyc,
-                "frac_of_issue_peak_this_mix": (insts / 1024 * mix_cyc / 2.4e9 * 1e3 / measured_ms) if mix_cyc else None,
                 "counters_of": "ticks 100-110" if key == "SQ_INSTS_VALU" else "ticks 6-11",
                 "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, profiles/sq_counters.json, same "
                         "csrc tree) at the MEASURED v_fma_f32 issue cost (%s), "
                         "1024 SIMDs, 2.4 GHz, over the measured launch time" % calib_file}
 
-    def roof(which):
-        ms, by = (a_ms, a_bytes) if which == "agents" else (f_ms, f_bytes)
+    def roof(which, g=None, when=None):
+        g = g or groups
+        when = when or prof_ticks
+        a_ms_ = sum(g[k] for k in ("sp_build", "agent_nbr", "cohesion", "agent_finish"))
+        ms, by = (a_ms_, a_bytes) if which == "agents" else (g["fields"], f_bytes)
         gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -388,10 +424,10 @@ def main():
             "kernel": ("navhip_agent_step_dev: k_sp_* + k_agent_nbr + k_cohesion + k_agent_mid/k_cp_*"
                        if which == "agents" else "navhip_build_fields_dev: k_field_bfs"),
             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by,
-            "launch_timing": "HIP events on the launch stream, kernel groups back to back on one stream "
-                             "(profiled ticks after the timed region, when the world has crowded)",
-            "kernels_ms": {k: groups[k] for k in ("sp_build", "agent_nbr", "cohesion", "coh_regroup", "agent_finish")}
-                          if which == "agents" else {"fields": f_ms},
+            "launch_timing": "HIP events on the launch stream, kernel groups back to back on one stream: "
+                             "profiled " + when + " (behind the timed region)",
+            "kernels_ms": {k: g[k] for k in ("sp_build", "agent_nbr", "cohesion", "coh_regroup", "agent_finish")}
+                          if which == "agents" else {"fields": g["fields"]},
             "valu_issue": valu(("k_agent_", "k_cp_", "k_coh", "k_sp_"), ms) if which == "agents"
                           else valu(("k_field_",), ms),
         }
@@ -399,9 +435,34 @@ def main():
     dom = "agents" if a_ms >= f_ms else "fields"
     other = "fields" if dom == "agents" else "agents"
 
+    # ---- the sustained regime: a run shorter than 100 ticks (the driver's --steps 20) times the friendliest
+    # window of the world -- the flocks have not converged yet.  A second, fresh world is then run for 100 ticks
+    # behind it, so that the line always carries ticks 5 / 50 / 100, the 100-tick mean and the roofline of the
+    # late ticks next to the headline.
+    sustained = None
+    if rank == 0 and world == 1 and args.steps < 100 and not args.no_sustained and not args.crowded:
+        T.close()
+        T = None
+        Ts = make(False)
+        sdt, sticks = run_ticks(Ts, pdist, torch, 5, 100)
+        s_first = Ts.tick_no + 1
+        sgroups = profiled_ticks(Ts, 6)
+
+        def s_at(i):
+            w = (i - 1) // Ts.tick_every
+            return float(sticks[w]) if len(sticks) > w else None
+        sustained = {"what": "a fresh world of the same configuration, 100 ticks after 5",
+                     "ms_per_step": sdt / 100 * 1e3, "ms_per_step_median": float(np.median(sticks)),
+                     "agent_steps_per_s": Ts.N * 100 / sdt, "ms_tick_5_50_100": [s_at(5), s_at(50), s_at(100)],
+                     "kernel_groups_ms_serial": sgroups, "status": status_histogram(Ts),
+                     "roofline": None}
+        sustained["roofline"] = roof("agents", sgroups, "ticks %d-%d of the 100-tick run" % (s_first + 1, Ts.tick_no))
+        Ts.close()
+
     crowded = None
     if rank == 0 and world == 1 and not args.no_crowded and not args.crowded and args.config in (1, 2):
-        T.close()
+        if T is not None:
+            T.close()
         T = None
         Tc = make(True)
         cdt, cticks = run_ticks(Tc, pdist, torch, 3, 40)
@@ -414,7 +475,8 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg["map"], cfg["fields"], cfg["agents"], 20, whole=(args.config == 0))
+        cpu = cpu_baseline(cfg["map"], cfg["fields"], cfg["agents"], 20, whole=(args.config == 0),
+                           dropin=not args.no_dropin)
 
     if rank == 0:
         def at(i):          # (ticks: one value per window of T.tick_every ticks)
@@ -440,10 +502,15 @@ def main():
                        "parallelism": "requests by destination + agent slabs x%d; one all-gather of slab results "
                                       "(16 B/agent) per tick; baked tiles: %s" % (world, args.tile_exchange),
                        "requests": request_source,
+                       "has_dest_los": los_source,
+                       "initial_velocities": velocity_source,
                        "schedule": ("fields of tick t+1 built during tick t beside the agent step (double-buffered pool)"
                                     if fields_ahead else "fields of tick t built in front of the agent step of tick t")},
             "ms_per_step_median": float(np.median(ticks)),
-            "ms_tick_5_50_100": [at(5), at(50), at(100)],
+            "ms_tick_5_50_100": [at(5), at(50), at(100)] if args.steps >= 100 or sustained is None
+                                else sustained["ms_tick_5_50_100"],
+            "ms_tick_5_50_100_of": "this run" if args.steps >= 100 or sustained is None else "sustained_100",
+            "sustained_100": sustained,
             "tick_timing": "HIP events on the agent stream every %d ticks; per-tick values are window means" % tick_every,
             "agent_steps_per_s_median_tick": agents_total / (float(np.median(ticks)) * 1e-3),
             ("flow_field_cells_kept_valid_per_s" if cfg["obstacles"] else "flow_field_cells_per_s"):
@@ -456,6 +523,7 @@ def main():
             "csrc_sha": sha,
             "crowded_world": crowded,
             "cpu_baseline": cpu,
+            "dropin": (cpu or {}).pop("dropin", None) if isinstance(cpu, dict) else None,
         }
         print(json.dumps(line), flush=True)
     if T is not None:

@@ -5,7 +5,8 @@
  * snapshot tables (struct move_gamestate, :296) and work items (struct move_work_in, :264), run
  * navhip_agent_step, copy the velocities into s_move_work.out[] like copy_gpu_results does
  * (:4248-4261).  It lives in movement.c's translation unit because those tables are static; in this
- * repository the test harness #includes it right after movement.c (oracle/ref/ref_move.c).
+ * repository the test harness #include <time.h>
+#includes it right after movement.c (oracle/ref/ref_move.c).
  *
  * With device sampling on (move_hip_set_device_sampling; needs the binding's resident pool,
  * N_HIP_PoolEnable in nav_hip.c) the per-agent N_DesiredPointSeekVelocity calls of
@@ -168,11 +169,23 @@ static void hip_snap_world(const struct hip_snap *S, navhip_world *W)
 
 /* move_velocity_work(begin_idx, end_idx) for the work items [begin_idx, end_idx] on the device.
  * Returns false when the library is not available (the caller runs the CPU arm). */
+/* where a WORK_TYPE_HIP tick spends its time, for a host that wants to report it (bench.py's `dropin`): seconds
+ * since the last reset in {filling the snapshot + work-item arrays, navhip_agent_step_submit .. _wait (staging,
+ * PCIe both ways, the kernels), scattering the results back into s_move_work.out[]}, and the calls */
+static double s_hip_times[4];
+static double hip_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+void move_hip_times(double out[4], int reset)
+{
+    memcpy(out, s_hip_times, sizeof(s_hip_times));
+    if(reset) memset(s_hip_times, 0, sizeof(s_hip_times));
+}
+
 static bool move_hip_velocity_work(int begin_idx, int end_idx)
 {
     navhip_ctx *ctx = N_HIP_Ctx();
     if(!ctx || end_idx < begin_idx)
         return false;
+    const double t_begin = hip_now();
     const struct move_gamestate *gs = &s_move_work.gamestate;
     struct hip_snap S;
     hip_snap_fill(&S);
@@ -239,9 +252,11 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
     float *out_vel = calloc(2 * n + 2, sizeof(float)), *out_vdes = calloc(2 * n + 2, sizeof(float));
     uint8_t *status = calloc(n + 1, 1);
     navhip_step_out O = {out_vel, NULL, out_vdes, NULL, status};
+    const double t_filled = hip_now();
     bool ok = hi >= lo && navhip_agent_step_submit(ctx, &W, &O) == NAVHIP_OK;
     /* (the nav task would Task_AwaitEvent(EVENT_UPDATE_START) here, like the GL path :4212-4233) */
     if(ok) ok = navhip_agent_step_wait(ctx) == NAVHIP_OK;
+    const double t_stepped = hip_now();
     if(ok) {
         s_hip_stats[2]++;
         for(int w = begin_idx; w <= end_idx; w++) {
@@ -271,6 +286,8 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
     hip_snap_free(&S);
     free(speed); free(los); free(form_ready); free(vdes); free(cell_pos); free(f_coh); free(f_align); free(f_drag);
     free(out_vel); free(out_vdes); free(status);
+    s_hip_times[0] += t_filled - t_begin; s_hip_times[1] += t_stepped - t_filled;
+    s_hip_times[2] += hip_now() - t_stepped; s_hip_times[3] += 1.0;
     return ok;
 }
 

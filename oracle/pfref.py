@@ -334,6 +334,16 @@ class RefNav:
     def dest_id(self, dst, layer=0, faction_id=FACTION_ID_NONE):
         return int(lib().pfref_dest_id(self._h, layer, faction_id, float(dst[0]), float(dst[1])))
 
+    def cache_put_fields(self, reqs, dest_ids, dirs):
+        """N_FC_PutFlowField + N_FC_PutDestFFMapping for every (request, dest id, 4096 direction bytes): the state
+        n_request_path leaves in the reference's own field cache."""
+        reqs = np.ascontiguousarray(reqs, dtype=FIELD_REQ_DTYPE)
+        ids = np.ascontiguousarray(dest_ids, np.uint32)
+        d = np.ascontiguousarray(dirs, np.uint8).reshape(len(reqs), 4096)
+        L = lib()
+        L.pfref_cache_put_fields.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        return int(L.pfref_cache_put_fields(self._h, len(reqs), _p(reqs), _p(ids), _p(d)))
+
     def cache_clear(self):
         lib().pfref_cache_clear(self._h)
 
@@ -467,6 +477,20 @@ class RefNav:
         if clear:
             L.pfref_trace_clear()
         return reqs, before, after
+
+    @staticmethod
+    def los_trace(clear=True):
+        """The planner's N_LOSFieldCreate calls since the last clear: [n][6] = dest id, chunk r, c, has_prev,
+        prev chunk r, c (the chain of nav.c:1843 / :2026-2039)."""
+        L = lib()
+        L.pfref_los_trace_get.argtypes = [C.c_int, C.c_void_p]
+        n = L.pfref_los_trace_count()
+        out = np.zeros((n, 6), np.int32)
+        for i in range(n):
+            L.pfref_los_trace_get(i, _p(out[i]))
+        if clear:
+            L.pfref_los_trace_clear()
+        return out
 
     def desired_velocity(self, dest_id, pos, dst):
         out = np.zeros(2, np.float32)
@@ -649,6 +673,20 @@ class RefMove:
         v = np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
         out = np.zeros((self.n, 2), np.float32)
         return lib().pfref_move_bench(_p(v), begin, end, reps, nthreads, _p(out)), out
+
+    def bench_hip(self, vdes, reps=1, begin=0, end=None):
+        """The movement tick's velocity half through the binding's WORK_TYPE_HIP arm (bindings/permafrost/move_hip.c),
+        `reps` times: (wall seconds, {fill, device, scatter} seconds) or None when the arm declined."""
+        end = self.n if end is None else end
+        v = np.ascontiguousarray(vdes, np.float32)
+        t = (C.c_double * 4)()
+        L = lib()
+        L.pfref_move_bench_hip.restype = C.c_double
+        L.pfref_move_bench_hip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        dt = L.pfref_move_bench_hip(_p(v), begin, end, reps, t)
+        if dt < 0:
+            return None
+        return dt, {"fill": t[0], "device": t[1], "scatter": t[2]}
 
     def vpref(self, uid, vdes):
         out = np.zeros(2, np.float32)

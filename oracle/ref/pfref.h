@@ -134,6 +134,13 @@ int    pfref_request_path(pfref_nav *nav, int layer, int faction_id,
 int    pfref_trace_count(void);
 void   pfref_trace_get(int idx, pfref_field_req *out_req, uint8_t *out_before, uint8_t *out_after);
 void   pfref_trace_clear(void);
+double pfref_move_bench_hip(const float *vdes, int begin, int end, int reps, double out_times[4]);
+int    pfref_cache_put_fields(pfref_nav *nav, int n, const pfref_field_req *reqs, const uint32_t *dest_ids,
+                              const uint8_t *dirs);
+/* the planner's N_LOSFieldCreate calls: {dest id, chunk r, c, has_prev, prev chunk r, c} */
+int    pfref_los_trace_count(void);
+void   pfref_los_trace_get(int idx, int32_t out[6]);
+void   pfref_los_trace_clear(void);
 
 /* N_DesiredPointSeekVelocity (nav.c:3468): may call n_request_path on a miss. */
 void   pfref_desired_point_seek_velocity(pfref_nav *nav, uint32_t dest_id, float x, float z,

@@ -458,6 +458,25 @@ double pfref_move_bench(const float *vdes, int begin, int end, int reps, int nth
     return (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
 }
 
+/* pfref_move_bench through the binding's WORK_TYPE_HIP arm: `reps` calls of move_hip_velocity_work over the work
+ * items [begin, end) -- what the engine's nav task sees per tick, host buffers and PCIe included.  Returns the
+ * wall seconds (< 0: the arm declined); out_times = {fill, submit..wait, scatter back} seconds of those calls. */
+double pfref_move_bench_hip(const float *vdes, int begin, int end, int reps, double out_times[4])
+{
+    for(int i = begin; i < end; i++)
+        set_vdes(vdes, i);
+    double dump[4];
+    move_hip_times(dump, 1);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for(int r = 0; r < reps; r++)
+        if(end <= begin || !move_hip_velocity_work(begin, end - 1))
+            return -1.0;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    move_hip_times(out_times, 1);
+    return (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+}
+
 /* the ent_des_v each work item carried in the last pfref_move_velocity / _bench call */
 void pfref_move_get_vdes(float *out_vdes)
 {

@@ -57,10 +57,25 @@ void N_FC_PutDestFFMapping(struct fieldcache_ctx *ctx, dest_id_t dest_id, struct
 #include "nav_hip.c"
 static bool s_use_binding;
 
+/* every N_LOSFieldCreate call of the planner: which chunk, built from which previous field (the chain of
+ * nav.c:1843 / :2026-2039) -- the request stream of the LOS fields, like the flow-field trace below */
+#define LOS_TRACE_MAX (1 << 20)
+static int32_t (*s_los_trace)[6];          /* dest id, chunk r, c, has_prev, prev r, c */
+static int s_los_trace_n;
+int  pfref_los_trace_count(void) { return s_los_trace_n; }
+void pfref_los_trace_clear(void) { s_los_trace_n = 0; }
+void pfref_los_trace_get(int idx, int32_t out[6]) { memcpy(out, s_los_trace[idx], sizeof(int32_t) * 6); }
+
 void pfref_hook_N_LOSFieldCreate(dest_id_t id, struct coord chunk_coord, struct tile_desc target,
                                  const struct nav_private *priv, vec3_t map_pos, struct nav_unit_query_ctx *ctx,
                                  struct LOS_field *out_los, const struct LOS_field *prev_los)
 {
+    if(!s_los_trace) s_los_trace = malloc(sizeof(*s_los_trace) * LOS_TRACE_MAX);
+    if(s_los_trace && s_los_trace_n < LOS_TRACE_MAX) {
+        int32_t *r = s_los_trace[s_los_trace_n++];
+        r[0] = (int32_t)id; r[1] = chunk_coord.r; r[2] = chunk_coord.c;
+        r[3] = prev_los != NULL; r[4] = prev_los ? prev_los->chunk.r : 0; r[5] = prev_los ? prev_los->chunk.c : 0;
+    }
     if(s_use_binding) N_HIP_LOSFieldCreate(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los);
     else              N_LOSFieldCreate(id, chunk_coord, target, priv, map_pos, ctx, out_los, prev_los);
 }
@@ -461,6 +476,32 @@ uint32_t pfref_dest_id(pfref_nav *nav, int layer, int faction_id, float dst_x, f
 }
 
 void pfref_cache_clear(pfref_nav *nav) { N_HIP_FC_ClearAll(nav->priv.fieldcache); }
+
+/* n fields into the reference's own field cache, as n_request_path leaves them (nav.c:1833-1835, :2008-2021):
+ * N_FC_PutFlowField under N_FlowFieldID of the request + N_FC_PutDestFFMapping(dest id, chunk).  For tests that
+ * sample (N_DesiredPointSeekVelocity, cache-hit path) fields the planner would take minutes to request one by one.
+ * Returns the number of fields put (a request whose target cannot be rebuilt from the record is skipped). */
+int pfref_cache_put_fields(pfref_nav *nav, int n, const pfref_field_req *reqs, const uint32_t *dest_ids,
+                           const uint8_t *dirs)
+{
+    struct nav_private *priv = &nav->priv;
+    int put = 0;
+    for(int i = 0; i < n; i++) {
+        struct field_target target;
+        if(!pfref_make_target(priv, &reqs[i], &target))
+            continue;
+        struct coord chunk = (struct coord){reqs[i].chunk_r, reqs[i].chunk_c};
+        struct flow_field ff;
+        N_FlowFieldInit(chunk, &ff);
+        ff.target = target;
+        pfref_dirs_to_ff(dirs + (size_t)i * FIELD_RES_R * FIELD_RES_C, &ff);
+        ff_id_t id = N_FlowFieldID(chunk, target, (enum nav_layer)reqs[i].layer);
+        N_FC_PutFlowField(priv->fieldcache, id, &ff);
+        N_FC_PutDestFFMapping(priv->fieldcache, dest_ids[i], chunk, id);
+        put++;
+    }
+    return put;
+}
 int  pfref_hip_pool_enable(int n_slots, int n_rows) { return N_HIP_PoolEnable(n_slots, n_rows) ? 1 : 0; }
 void pfref_hip_pool_disable(void) { N_HIP_PoolDisable(); }
 void pfref_hip_pool_stats(long out[3]) { N_HIP_PoolStats(out); }

@@ -438,6 +438,17 @@ def flock_csr(flock, n_flocks, order=None):
     return offs, members
 
 
+def _ctx_build_los_dev(self, d_reqs, n, d_prev, d_out, stream=None):
+    """navhip_build_los_dev: n LOS fields, every buffer a torch CUDA tensor (d_prev may be None)."""
+    mx, mz = self.map_pos()
+    self._chk(lib().navhip_build_los_dev(self._h, dev_ptr(d_reqs), int(n), dev_ptr(d_prev) if d_prev is not None else None,
+                                         dev_ptr(d_out), mx, mz, C.c_void_p(stream) if stream else None),
+              "navhip_build_los_dev")
+
+
+NavContext.build_los_dev = _ctx_build_los_dev
+
+
 def grid_bounds(chunk_w, chunk_h):
     """bg_ent_init bounds the engine uses (position.c:276-283): the map, centred on the origin."""
     hx, hz = chunk_w * 128.0, chunk_h * 128.0
@@ -474,6 +485,7 @@ def make_world(chunk_w, chunk_h, arrays, hz=20, xp=None):
     w.map_pos_x = chunk_w * 128.0
     w.map_pos_z = -chunk_h * 128.0
     w.grid_xmin, w.grid_xmax, w.grid_zmin, w.grid_zmax = grid_bounds(chunk_w, chunk_h)
+    w.static_epoch = int(arrays.get("static_epoch") or 0)
     return w, keep
 
 

@@ -261,3 +261,24 @@ def planner_requests(grid, dests):
         cols["dest"] = d["dest"].astype(np.int64)
         return cols
     return None
+
+
+def planner_los(grid, dests):
+    """The LOS-field chain of (grid, dests) as the reference planner builds it (N_LOSFieldCreate next to every
+    flow field of a path, each from the LOS field of the chunk before it: nav.c:1843, :2026-2039) -- from the
+    fixtures tests/tools/make_requests.py generated (los_cfg*.npz) -- or None.  Columns in creation order (a
+    field's predecessor always comes first): dest, chunk_r, chunk_c, prev_dr, prev_dc (0, 0: the destination
+    chunk's own field, no predecessor)."""
+    import glob
+    import hashlib
+    import os
+    h = hashlib.sha1()
+    h.update(np.ascontiguousarray(grid).tobytes())
+    h.update(np.ascontiguousarray(dests, np.int64).tobytes())
+    key = h.hexdigest()
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+    for path in sorted(glob.glob(os.path.join(here, "los_*.npz"))):
+        d = np.load(path)
+        if str(d["key"]) == key:
+            return {k: d[k].astype(np.int64) for k in ("dest", "chunk_r", "chunk_c", "prev_dr", "prev_dc")}
+    return None

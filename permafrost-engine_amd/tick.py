@@ -43,7 +43,7 @@ class NavTick:
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
                  debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True,
-                 straddle=0.0):
+                 straddle=0.0, los=False, flow_velocities=False):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -235,6 +235,19 @@ class NavTick:
                      "targets": targets.astype(np.float32), "flock": ag["flock"], "flock_offsets": offs,
                      "flock_members": members, "radius": ag["radius"], "max_speed": ag["max_speed"],
                      "speed": ag["speed"], "liid": liid}
+        # ---- "has_dest_los computed by the reference LOS code" -----------------------
+        # los=True: the LOS fields of every (destination, chunk) the reference planner would hold -- its own
+        # N_LOSFieldCreate chain, from the fixture -- are built on the device (navhip_build_los_dev, level by level
+        # along the chain) and every agent's has_dest_los is answered per tick from them (NAVHIP_LOS_LOOKUP:
+        # N_HasDestLOS, nav.c:4026).  Built once at start-up like the reference's LOS cache (a static map).
+        self.los_source = "has_dest_los = 0 for every agent (no LOS fields)"
+        self.n_los = 0
+        if los:
+            lc = synth.planner_los(grid, dests) if (world == 1 or shared_map) else None
+            if lc is None:
+                self.los_source = "has_dest_los = 0: no planner LOS fixture for this world"
+            else:
+                self._build_los(lc, dests, dev)
         self.stream = torch.cuda.Stream(device=self.dev, priority=-1)      # the agent chain: ahead of the field builds
         # multi-GPU: the slab all-gather of tick t runs on its own stream and is only awaited by the
         # snapshot consumers of tick t+1 (spatial hash + cohesion, then the agent step); the field
@@ -305,6 +318,10 @@ class NavTick:
                     pdist.exchange_rows(self.pool, self.xchg_bounds, self.rank, self.world)
             self.ev_fields.record(self.stream)
             self.stream.synchronize()
+        if flow_velocities:
+            self._flow_aligned_velocities()
+        if not hasattr(self, "velocity_source"):
+            self.velocity_source = "N(0, 0.35) per component (synth.agents)"
         self.ev = []                   # (phase, start_event, end_event) of the timed steps
         self.tick_ev = []              # one event at the start of every tick_every-th recorded tick
         self.tick_every, self._tick_rec = 5, 0
@@ -313,6 +330,86 @@ class NavTick:
         if verbose:
             print("[rank %d] setup %.1fs: %d chunk-field requests (%d local), %d agents (%d local)"
                   % (rank, time.time() - t0, n_req, self.n_req_local, n, self.a1 - self.a0), flush=True)
+
+    def _build_los(self, lc, dests, dev):
+        """The planner's LOS chain on the device: pool slot = position in level order (level = hops from the
+        destination chunk along the chain), one navhip_build_los_dev per level, each field from its predecessor."""
+        Wt = self.Wt
+        n = len(lc["dest"])
+        key = lc["dest"] * self.nchunks + lc["chunk_r"] * Wt + lc["chunk_c"]
+        pkey = lc["dest"] * self.nchunks + (lc["chunk_r"] + lc["prev_dr"]) * Wt + (lc["chunk_c"] + lc["prev_dc"])
+        has_prev = (lc["prev_dr"] != 0) | (lc["prev_dc"] != 0)
+        index_of = {int(k): i for i, k in enumerate(key)}
+        level = np.zeros(n, np.int64)
+        prev_i = np.full(n, -1, np.int64)
+        for i in range(n):                       # (creation order: a predecessor always comes first)
+            if has_prev[i]:
+                prev_i[i] = index_of[int(pkey[i])]
+                level[i] = level[prev_i[i]] + 1
+        order = np.argsort(level, kind="stable")
+        slot_of = np.empty(n, np.int64)
+        slot_of[order] = np.arange(n)
+        reqs = np.zeros(n, navhip.LOS_REQ_DTYPE)
+        reqs["faction_id"] = navhip.FACTION_ID_NONE
+        reqs["chunk_r"], reqs["chunk_c"] = lc["chunk_r"][order], lc["chunk_c"][order]
+        d = lc["dest"][order]
+        reqs["target_chunk_r"], reqs["target_chunk_c"] = dests[d, 0] // 64, dests[d, 1] // 64
+        reqs["target_tile_r"], reqs["target_tile_c"] = dests[d, 0] % 64, dests[d, 1] % 64
+        reqs["prev_dr"], reqs["prev_dc"] = lc["prev_dr"][order], lc["prev_dc"][order]
+        prev_slot = np.where(prev_i[order] >= 0, slot_of[np.maximum(prev_i[order], 0)], 0)
+        d_reqs = dev(reqs.view(np.uint8).reshape(n, 16))
+        d_prev_slot = dev(prev_slot)
+        self.los_pool = torch.zeros((n, 4096), dtype=torch.uint8, device=self.dev)
+        lv = level[order]
+        bounds = np.searchsorted(lv, np.arange(lv.max() + 2))
+        torch.cuda.synchronize(self.dev)
+        for L in range(len(bounds) - 1):
+            b, e = int(bounds[L]), int(bounds[L + 1])
+            if e == b:
+                continue
+            d_prev = self.los_pool.index_select(0, d_prev_slot[b:e]) if L > 0 else None
+            torch.cuda.synchronize(self.dev)     # (torch's stream -> the library's: start-up, untimed)
+            self.ctx.build_los_dev(d_reqs[b:e], e - b, d_prev, self.los_pool[b:e])
+            self.ctx.sync()
+        tbl = -np.ones((self.K, self.nchunks), np.int32)
+        tbl[lc["dest"], lc["chunk_r"] * Wt + lc["chunk_c"]] = slot_of
+        self.t["los_pool"] = self.los_pool
+        self.t["flock_los_slot"] = dev(tbl)
+        self.t["has_dest_los"] = torch.full((self.N,), navhip.LOS_LOOKUP, dtype=torch.uint8, device=self.dev)
+        self.host["los"] = {"reqs": reqs, "slot_tbl": tbl, "levels": len(bounds) - 1, "prev_slot": prev_slot,
+                            "level": lv}
+        self.n_los = n
+        self.los_source = ("device lookup (NAVHIP_LOS_LOOKUP) in %d LOS fields built by navhip_build_los from the "
+                           "reference planner's N_LOSFieldCreate chain (fixture), %d levels" % (n, len(bounds) - 1))
+
+    def _flow_aligned_velocities(self):
+        """initial velocity = 0.5 max along the sampled flow direction + N(0, 0.1).  The
+        directions are the ones the device samples (one untimed step of the start-up pool); seed 11."""
+        n = self.N
+        keep = self.vdes_out, self.vpref_out
+        self.vdes_out = torch.zeros((n, 2), dtype=torch.float32, device=self.dev)
+        self.vpref_out = torch.zeros((n, 2), dtype=torch.float32, device=self.dev)
+        if not self.pipeline_fields and self.n_req_local and not self.n_obstacles:
+            self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
+                                      self.pool[self.req_begin:self.req_end], stream=self.stream.cuda_stream)
+        self._make_structs()
+        wb, we = self.world_s.work_begin, self.world_s.work_end
+        self.world_s.work_begin, self.world_s.work_end = 0, n          # (every rank samples every agent: replicated)
+        self.ctx.agent_step_dev(self.world_s, self.out_s, stream=self.stream.cuda_stream)
+        self.stream.synchronize()
+        self.ctx.sync()
+        vdes = self.vdes_out.cpu().numpy()
+        rng = np.random.RandomState(11)
+        speed = self.host["max_speed"][:, None] / float(self.hz)
+        vel = (0.5 * speed * vdes + rng.normal(0.0, 0.1, size=(n, 2))).astype(np.float32)
+        self.t["vel_xz"] = torch.from_numpy(vel).to(self.dev)
+        if self.world > 1 and not self.solo:
+            # (a rank only holds the fields its own agents sample: every rank keeps its slab's rows)
+            pdist.exchange_rows(self.t["vel_xz"], self.agent_bounds, self.rank, self.world)
+        self.vdes_out, self.vpref_out = keep
+        self.world_s.work_begin, self.world_s.work_end = wb, we
+        self._make_structs()
+        self.velocity_source = "0.5 max_speed/hz along the sampled flow direction + N(0, 0.1) (SURVEY 8(d))"
 
     def _make_structs(self):
         arrays = dict(self.t)

@@ -19,7 +19,41 @@ pytestmark = [pytest.mark.gpu,
 CORES = max(1, min(32, len(os.sched_getaffinity(0))))
 
 
-def _check_agents(navlib, T, nav, onav, pos, vel, out_vel, out_pos, status, vdes, label):
+def _los_bits(T, pos, los_fields):
+    """N_HasDestLOS (nav.c:4026), cache-hit path, for every agent: `visible` of the agent's tile in the LOS field
+    of (its flock's destination, its chunk) -- from `los_fields` ([slots][4096], the reference's or the device's),
+    False where no field is mapped."""
+    H = T.host
+    tbl = H["los"]["slot_tbl"]
+    mx, mz = T.Wt * 128.0, -T.H * 128.0
+    cc = np.clip(((mx - pos[:, 0]) / 256.0).astype(np.int64), 0, T.Wt - 1)
+    cr = np.clip(((pos[:, 1] - mz) / 256.0).astype(np.int64), 0, T.H - 1)
+    bx = (np.float32(mx) - (cc * 256).astype(np.float32)).astype(np.float32)
+    bz = (np.float32(mz) + (cr * 256).astype(np.float32)).astype(np.float32)
+    tc = np.clip((np.abs(bx - pos[:, 0]) / np.float32(4.0)).astype(np.int64), 0, 63)
+    tr = np.clip((np.abs(bz - pos[:, 1]) / np.float32(4.0)).astype(np.int64), 0, 63)
+    slot = tbl[H["flock"], cr * T.Wt + cc]
+    out = np.zeros(len(pos), np.uint8)
+    ok = slot >= 0
+    out[ok] = los_fields[slot[ok], tr[ok] * 64 + tc[ok]] & 1
+    return out
+
+
+def _reference_los_fields(T, nav):
+    """The job's LOS chain through the reference's own N_LOSFieldCreate (field.c:2085), level by level."""
+    L = T.host["los"]
+    reqs, prev_slot = L["reqs"], L["prev_slot"]
+    out = np.zeros((len(reqs), 4096), np.uint8)
+    for i, r in enumerate(reqs):                     # (level order: a predecessor always comes first)
+        has_prev = r["prev_dr"] != 0 or r["prev_dc"] != 0
+        out[i] = nav.los_field((int(r["chunk_r"]), int(r["chunk_c"])),
+                               (int(r["target_chunk_r"]), int(r["target_chunk_c"]), int(r["target_tile_r"]), int(r["target_tile_c"])),
+                               prev=out[prev_slot[i]].reshape(64, 64) if has_prev else None,
+                               prev_d=(int(r["prev_dr"]), int(r["prev_dc"]))).reshape(-1)
+    return out
+
+
+def _check_agents(navlib, T, nav, onav, pos, vel, out_vel, out_pos, status, vdes, label, has_los=None):
     """One velocity step of the whole job: GPU outputs vs restatement (everything) and vs the
     reference's move_velocity_work (velocities), bit for bit."""
     H = T.host
@@ -27,7 +61,8 @@ def _check_agents(navlib, T, nav, onav, pos, vel, out_vel, out_pos, status, vdes
     arrays = {
         "pos_xz": pos, "vel_xz": vel, "radius": H["radius"], "max_speed": H["max_speed"], "speed": H["speed"],
         "flags": np.full(n, navlib.ENTITY_FLAG_MOVABLE, np.uint32), "state": np.zeros(n, np.uint8),
-        "has_dest_los": np.zeros(n, np.uint8), "flock": H["flock"], "flock_target_xz": H["targets"],
+        "has_dest_los": np.zeros(n, np.uint8) if has_los is None else has_los,
+        "flock": H["flock"], "flock_target_xz": H["targets"],
         "flock_offsets": H["flock_offsets"], "flock_members": H["flock_members"],
         "flock_field_slot": H["slot_tbl"], "field_pool": T.pool.cpu().numpy(), "vdes_xz": None,
     }
@@ -59,10 +94,10 @@ def _check_agents(navlib, T, nav, onav, pos, vel, out_vel, out_pos, status, vdes
     return exp
 
 
-def _job(navlib, W, K, N, crowd=0):
+def _job(navlib, W, K, N, crowd=0, los=False):
     from permafrost_engine_amd import tick
     T = tick.NavTick(chunk_w=W, fields_per_rank=K, agents_per_rank=N, device=0, debug_outputs=True,
-                     crowd_cells=crowd)
+                     crowd_cells=crowd, los=los, flow_velocities=los)
     grid = T.grid
     nav = pfref.RefNav(cases.synth.to_chunks(grid))
     # the device's own local-island labelling is what the requests carry: it must be the reference's
@@ -102,7 +137,22 @@ def _tick_and_fetch(T):
 
 @pytest.mark.parametrize("W,K,N,ticks", [(16, 16, 50_000, 0), (16, 64, 100_000, 100), (32, 128, 200_000, 50)])
 def test_whole_config_against_the_reference(navlib, W, K, N, ticks):
-    T, nav, onav = _job(navlib, W, K, N)
+    # (the benchmark's world: per-agent line of sight answered on the device from the planner's LOS fields and
+    # flow-aligned initial velocities, where a planner fixture exists for the configuration)
+    T, nav, onav = _job(navlib, W, K, N, los=True)
+    ref_los = None
+    if T.n_los:
+        # every LOS field of the job through the reference's N_LOSFieldCreate: the fields, then every agent's bit
+        ref_los = _reference_los_fields(T, nav)
+        dev_los = T.los_pool.cpu().numpy()
+        bad = np.flatnonzero((dev_los != ref_los).any(1))
+        assert len(bad) == 0, "%d of %d LOS fields differ from the reference (first %s)" % (len(bad), len(ref_los), bad[:5])
+        assert W > 16 or K < 64 or len(ref_los) >= 16000
+    def _chk(navlib, T, nav, onav, pos, *a):
+        bits = _los_bits(T, pos, ref_los) if ref_los is not None else None
+        if bits is not None:
+            assert 0 < bits.sum() < len(bits), bits.mean()       # both arms of arrive_force_point are taken
+        return _check_agents(navlib, T, nav, onav, pos, *a, has_los=bits)
     r = _tick_and_fetch(T)
     # every chunk field of the tick through the reference (threaded N_FlowFieldInit + N_FlowFieldUpdate)
     ref_reqs = np.zeros(len(T.host["reqs"]), pfref.FIELD_REQ_DTYPE)
@@ -114,14 +164,50 @@ def test_whole_config_against_the_reference(navlib, W, K, N, ticks):
     bad = np.flatnonzero((got != ref_dirs).reshape(len(got), -1).any(1))
     assert len(bad) == 0, "%d of %d chunk fields differ from the reference (first %s)" % (len(bad), len(got), bad[:5])
     del ref_dirs
-    _check_agents(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"], r["vdes"], "tick 0")
+    _chk(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"], r["vdes"], "tick 0")
     assert (r["status"] & navlib.ST_MOVED).astype(bool).mean() > 0.5
     if ticks:
         for _ in range(ticks - 1):
             T.step()
         r = _tick_and_fetch(T)
-        _check_agents(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"], r["vdes"],
+        _chk(navlib, T, nav, onav, r["pos"], r["vel"], r["out_vel"], r["out_pos"], r["status"], r["vdes"],
                       "tick %d" % ticks)
+    T.close()
+
+
+def test_full_size_flow_sampling_against_the_reference(navlib):
+    """configs[2]: the desired direction of every agent (n_interpolated_flow_dir over the 16 384-field pool) against
+    the REFERENCE's own N_DesiredPointSeekVelocity.  Its field cache holds 2 048 fields: eight destinations (8 x 256
+    chunk fields) at a time are put into it -- the reference's own N_FlowFieldUpdate results, under the reference's
+    ids and mappings, as n_request_path would leave them -- and the agents of those eight flocks sampled."""
+    W, K, N = 16, 64, 100_000
+    T, nav, onav = _job(navlib, W, K, N)
+    r = _tick_and_fetch(T)
+    H = T.host
+    ref_reqs = np.zeros(len(H["reqs"]), pfref.FIELD_REQ_DTYPE)
+    for name in ref_reqs.dtype.names:
+        if name in H["reqs"].dtype.names:
+            ref_reqs[name] = H["reqs"][name]
+    ref_dirs = nav.field_update_many(ref_reqs, nthreads=CORES)
+    dest_ids = np.array([nav.dest_id(t) for t in H["targets"]], np.uint32)
+    # agents the reference would answer from its cache: a field under them with a direction (the others -- no
+    # field for the chunk, FD_NONE under the agent -- make it call its planner: ST_FIELD_MISS / _NONE on the device)
+    hit = (r["status"] & (navlib.ST_FIELD_MISS | navlib.ST_FIELD_NONE)) == 0
+    assert hit.mean() > 0.98
+    checked = 0
+    for d0 in range(0, K, 8):
+        nav.cache_clear()
+        sel = np.flatnonzero((H["dest_of_req"] >= d0) & (H["dest_of_req"] < d0 + 8))
+        assert len(sel) <= 2048
+        put = nav.cache_put_fields(ref_reqs[sel], dest_ids[H["dest_of_req"][sel]], ref_dirs[sel])
+        assert put == len(sel)
+        ag = np.flatnonzero((H["flock"] >= d0) & (H["flock"] < d0 + 8) & hit)
+        exp = nav.desired_velocities(dest_ids[H["flock"][ag]], r["pos"][ag], H["targets"][H["flock"][ag]])
+        got = r["vdes"][ag]
+        bad = np.flatnonzero((got.view(np.uint32) != exp.view(np.uint32)).any(1))
+        assert len(bad) == 0, (d0, len(bad), ag[bad[:5]], got[bad[:3]], exp[bad[:3]])
+        checked += len(ag)
+    assert checked > 0.98 * N
     T.close()
 
 

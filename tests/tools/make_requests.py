@@ -82,7 +82,46 @@ def make(cfg):
         cfg, len(reqs), int((reqs["type"] == 0).sum()), K, W * W))
 
 
+def make_los(cfg):
+    """The LOS-field chain of the same world: n_request_path builds, next to every flow field of a path, the LOS
+    field of that chunk FROM the LOS field of the chunk before it on the path (nav.c:1843, :2026-2039), once per
+    (destination, chunk): which neighbour a chunk's field is propagated from depends on the order the paths were
+    requested in.  Here: per destination, one n_request_path from every chunk (row-major, the field cache kept),
+    and the N_LOSFieldCreate calls it made, in order -- (chunk, previous chunk) pairs a device can replay level by
+    level (navhip_build_los)."""
+    W, K = CONFIGS[cfg]
+    grid = synth.cost_grid(W, W, seed=1234)
+    dests = synth.destinations(grid, K, seed=42)
+    nav = pfref.RefNav(synth.to_chunks(grid))
+    t0 = time.time()
+    rows = []
+    for di, (R, C) in enumerate(dests):
+        dst = synth.cell_centre(W, W, R, C)
+        nav.cache_clear()
+        pfref.RefNav.los_trace()
+        for cr in range(W):
+            for cc in range(W):
+                src_cell = nearest_passable_to_centre(grid, cr, cc)
+                if src_cell is None:
+                    continue
+                if (cr, cc) == (R // 64, C // 64):
+                    src_cell = (int(R), int(C))
+                nav.request_path(synth.cell_centre(W, W, src_cell[0], src_cell[1]), dst, clear_cache=False)
+        nav.trace()
+        for did, r, c, has_prev, pr, pc in pfref.RefNav.los_trace():
+            rows.append((di, r, c, (pr - r) if has_prev else 0, (pc - c) if has_prev else 0))
+        if di % 8 == 7 or di == K - 1:
+            print("config %d LOS: destination %d / %d, %d fields, %.0f s" % (cfg, di + 1, K, len(rows), time.time() - t0), flush=True)
+    a = np.array(rows, np.int32)
+    np.savez_compressed(os.path.join(OUT, "los_cfg%d.npz" % cfg), key=world_key(grid, dests), dest=a[:, 0],
+                        chunk_r=a[:, 1], chunk_c=a[:, 2], prev_dr=a[:, 3], prev_dc=a[:, 4])
+    print("config %d: %d LOS fields for %d destinations x %d chunks" % (cfg, len(a), K, W * W))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    for c in [int(a) for a in sys.argv[1:]] or [0, 1, 2]:
-        make(c)
+    only_los = "--los" in sys.argv
+    for c in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [0, 1, 2]:
+        if not only_los:
+            make(c)
+        make_los(c)
