@@ -335,8 +335,8 @@ def main():
     a_rank = cfg["agents"] // world if shared else cfg["agents"]
     CROWD = 17      # cells: a flock of ~1 600 packed into ~35 x 35 cells -> ~30 neighbours within r = 10
 
-    def make(crowd):
-        return tick.NavTick(chunk_w=cfg["map"], fields_per_rank=f_rank, agents_per_rank=a_rank,
+    def make(crowd, share=False):
+        return tick.NavTick(share_fields=share, chunk_w=cfg["map"], fields_per_rank=f_rank, agents_per_rank=a_rank,
                             rank=rank, world=world, device=local, obstacles=cfg["obstacles"],
                             obstacle_ticks=args.warmup + args.steps + 16, tile_exchange=args.tile_exchange,
                             shared_map=shared, crowd_cells=CROWD if crowd else 0,
@@ -459,6 +459,26 @@ def main():
         sustained["roofline"] = roof("agents", sgroups, "ticks %d-%d of the 100-tick run" % (s_first + 1, Ts.tick_no))
         Ts.close()
 
+    # ---- the same tick with the reference's field SHARING: its cache is keyed by N_FlowFieldID (chunk + target,
+    # not destination), so a tick after a wholesale invalidation rebuilds every DISTINCT chunk field once and maps
+    # many (destination, chunk) pairs to it.  The headline rebuilds every request; this block says what the
+    # library's slot table buys a host that shares like the reference does.
+    shared_fields = None
+    if rank == 0 and world == 1 and not args.no_crowded and not args.crowded and args.config in (1, 2, 3):
+        if T is not None:
+            T.close()
+        T = None
+        Tq = make(False, share=True)
+        qdt, qticks = run_ticks(Tq, pdist, torch, args.warmup, args.steps)
+        shared_fields = {"what": "same world; identical chunk-field requests (same chunk, same target: one N_FlowFieldID) "
+                                 "built once per tick, every (destination, chunk) mapped to the shared slot",
+                         "chunk_field_requests_served_per_tick": Tq.n_requests_served,
+                         "distinct_chunk_fields_built_per_tick": Tq.n_req_local,
+                         "ms_per_step": qdt / args.steps * 1e3, "ms_per_step_median": float(np.median(qticks)),
+                         "agent_steps_per_s": Tq.N * args.steps / qdt,
+                         "flow_field_cells_built_per_s": Tq.n_req_local * 4096 * args.steps / qdt}
+        Tq.close()
+
     crowded = None
     if rank == 0 and world == 1 and not args.no_crowded and not args.crowded and args.config in (1, 2):
         if T is not None:
@@ -521,6 +541,7 @@ def main():
             "roofline": roof(dom),
             "roofline_secondary": roof(other),
             "csrc_sha": sha,
+            "shared_fields": shared_fields,
             "crowded_world": crowded,
             "cpu_baseline": cpu,
             "dropin": (cpu or {}).pop("dropin", None) if isinstance(cpu, dict) else None,

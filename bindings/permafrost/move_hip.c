@@ -68,24 +68,45 @@ struct hip_snap {
 };
 #define DENSE(S, uid) kh_value((S)->dense, kh_get(id, (S)->dense, (uid)))
 
+/* The sorted uid list and the uid -> dense index map only change when the entity set does; sorting 100 000 uids
+ * and building the map were two thirds of the 4.7 ms a tick spent filling the snapshot (bench.py `dropin`).  They
+ * are kept between ticks and rebuilt when the set has another size or a cached uid is gone from the tick's
+ * position table (an equal count with every cached uid present IS the same set). */
+static struct { int n; uint32_t *uids; khash_t(id) *dense; } s_hip_set;
+
+static void hip_set_rebuild(const struct move_gamestate *gs)
+{
+    const int n = (int)kh_size(gs->positions);
+    free(s_hip_set.uids);
+    if(s_hip_set.dense) kh_destroy(id, s_hip_set.dense);
+    s_hip_set.n = n;
+    s_hip_set.uids = malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
+    int k = 0;
+    uint32_t key;
+    kh_foreach_key(gs->positions, key, { s_hip_set.uids[k++] = key; });
+    qsort(s_hip_set.uids, n, sizeof(uint32_t), cmp_u32);
+    s_hip_set.dense = kh_init(id);
+    kh_resize(id, s_hip_set.dense, n + n / 2);
+    for(int i = 0; i < n; i++) {
+        int ret;
+        khiter_t it = kh_put(id, s_hip_set.dense, s_hip_set.uids[i], &ret);
+        kh_value(s_hip_set.dense, it) = i;
+    }
+}
+
 static void hip_snap_fill(struct hip_snap *S)
 {
     const struct move_gamestate *gs = &s_move_work.gamestate;
     memset(S, 0, sizeof(*S));
     const int n = S->n = (int)kh_size(gs->positions);
-    S->uids = malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
-    {
-        int k = 0;
-        uint32_t key;
-        kh_foreach_key(gs->positions, key, { S->uids[k++] = key; });
-        qsort(S->uids, n, sizeof(uint32_t), cmp_u32);
+    if(!s_hip_set.dense || s_hip_set.n != n)
+        hip_set_rebuild(gs);
+    else {
+        for(int i = 0; i < n; i++)
+            if(kh_get(pos, gs->positions, s_hip_set.uids[i]) == kh_end(gs->positions)) { hip_set_rebuild(gs); break; }
     }
-    S->dense = kh_init(id);
-    for(int i = 0; i < n; i++) {
-        int ret;
-        khiter_t k = kh_put(id, S->dense, S->uids[i], &ret);
-        kh_value(S->dense, k) = i;
-    }
+    S->uids = s_hip_set.uids;
+    S->dense = s_hip_set.dense;
     S->pos = calloc(2 * n + 2, sizeof(float)); S->vel = calloc(2 * n + 2, sizeof(float));
     S->radius = calloc(n + 1, sizeof(float)); S->max_speed = calloc(n + 1, sizeof(float));
     S->sink = calloc(2 * n + 2, sizeof(float));
@@ -141,8 +162,7 @@ static void hip_snap_fill(struct hip_snap *S)
 
 static void hip_snap_free(struct hip_snap *S)
 {
-    kh_destroy(id, S->dense);
-    free(S->uids); free(S->pos); free(S->vel); free(S->radius); free(S->max_speed); free(S->sink);
+    free(S->pos); free(S->vel); free(S->radius); free(S->max_speed); free(S->sink);
     free(S->flags); free(S->state); free(S->arr_flags); free(S->flock); free(S->flock_target);
     free(S->flock_offsets); free(S->flock_members);
 }

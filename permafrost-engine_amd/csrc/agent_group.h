@@ -642,9 +642,15 @@ __device__ __forceinline__ void team_min(cp_bound &B, cp_team &T, int part, int 
 // S.dyn / S.stat hold the neighbours (n_dyn + n_stat <= G, each <= 32).
 //   TEAM   every wave of the workgroup calls this with the same problem in its own S, part = its wave
 //          number, nparts = the waves of the workgroup, T = the team's exchange area
+//   bail   (a wave on its own) the search may be handed back: when the projections of des_v yield no bound,
+//          the column phase ahead is close to exhaustive -- *bail is set, nothing is returned, and the caller
+//          passes the problem on to a team (k_cp_heavy's second pass)
+#ifndef CP_BAIL_MIN_RAYS
+#define CP_BAIL_MIN_RAYS 34
+#endif
 template <int G, bool TEAM = false>
 __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, cp_lds<G> &S,
-                            int part = 0, int nparts = 1, cp_team *T = nullptr)
+                            int part = 0, int nparts = 1, cp_team *T = nullptr, bool *bail = nullptr)
 {
     typedef grp<G> g;
     n_dyn = uni<G>(n_dyn); n_stat = uni<G>(n_stat);
@@ -786,6 +792,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         }
         cp_work<G>(S, ent, n_cones, qn, L, B, true);
 
+        if(bail && guard == 0 && !B.nfound && n_rays >= CP_BAIL_MIN_RAYS) { *bail = true; return des_v; }
         CP_TMARK(sb_, 1);
 #ifdef NH_CP_STATS
         if(!B.nfound) CP_STAT(B.sb, 12, 1);

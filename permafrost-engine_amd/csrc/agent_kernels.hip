@@ -1259,21 +1259,32 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
     HIST_WAVE(2);
 }
 
-// ---- k_cp_heavy: the heavy list (33-64 neighbours), then the wave list (17-32), one problem per
-// WORKGROUP.  A search of up to 16 000 ray pairs on one wave takes hundreds of microseconds -- as long
-// as everything else of the tick --, and even among problems of 20-30 neighbours the cost spreads
-// over a factor of ten (how early an admissible candidate turns up decides how much is pruned): the
-// waves of the workgroup search a problem as a team (clearpath_grp<64, true>), so that no single
-// problem outlasts the launch.  The first problem of a workgroup is its block number,
-// then one ticket per workgroup and problem.  From CP_SOLO_MIN problems on the waves work on their own. ---
+// ---- k_cp_heavy: the heavy list (33-64 neighbours), then the wave list (17-32).  A search of up to 16 000 ray
+// pairs on one wave takes hundreds of microseconds -- as long as everything else of the tick --, and even among
+// problems of 20-30 neighbours the cost spreads over a factor of ten (how early an admissible candidate turns up
+// decides how much is pruned).  Two passes (two launches on the side stream):
+//   pass 0  one problem per WAVE, its first one by wave number, then a ticket per wave and problem.  A search
+//           whose projections of des_v yield no bound -- the column phase ahead is close to exhaustive: the
+//           problems that would outlast the launch -- is not run: its agent goes onto the team list.  (In a jam,
+//           from CP_SOLO_MIN problems on, there are more problems than waves, the load balances over problems and
+//           nothing is handed over: 92 000 problems in the crowded world.)
+//   pass 1  the team list, one problem per WORKGROUP: its waves search it as a team (clearpath_grp<64, true>).
+// NH_CP_BAIL 0 (the default) runs every problem below CP_SOLO_MIN as a team in pass 0 and leaves pass 1 empty.
+// The two-pass schedule was measured and LOST: 0.538 against 0.461 ms per tick over 100 ticks, 0.91 against 0.72 ms
+// at tick 100 (profiles/r04_ab_cp_bail_100.txt).  Below CP_SOLO_MIN the launch is bound by its LONGEST problems,
+// not by issue slots (each workgroup holds one to five problems): a team quarters every problem's latency, the
+// ones that keep a bound included; two passes add their tails.  The code stays for the measurement.
+#ifndef NH_CP_BAIL
+#define NH_CP_BAIL 0
+#endif
 #ifdef CP_HEAVY_OCC
 __attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
 #endif
 __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                            nh_worklists WL, nh_step_outs O, int32_t *zero_next)
+                                                            nh_worklists WL, nh_step_outs O, int32_t *zero_next, int pass)
 {
     __shared__ cp_lds<64> lds[CP_WAVES];
-    __shared__ int32_t hv_end[2 * NH_WL_SUB];       // sub-lists of the heavy list, then of the wave list
+    __shared__ int32_t hv_end[2 * NH_WL_SUB];       // sub-lists of the heavy list, then of the wave list (pass 1: the team list)
     __shared__ int32_t h_ticket;
     __shared__ cp_team team;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1283,68 +1294,90 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
     // stream itself.  (Its users -- the previous step -- finished before this step's k_agent_mid started.)
     if(blockIdx.x == 0 && zero_next)
         for(int i = threadIdx.x; i < (int)NH_WL_COUNTERS; i += CP_WAVES * 64) zero_next[i] = 0;
-    // (outside a crowd there is nothing to do: one parallel look at the 128 counters)
-    if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
-    unit_totals(hv_end, 2 * NH_WL_SUB, [&](int k) {
-        return WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB]; });
-    __syncthreads();
-    HIST_T0();
-    const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
-    int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
     cp_lds<64> &S = lds[wib];
-    if(n_heavy >= CP_SOLO_MIN) {
-        // In a jam there are more of these problems than the launch has waves (92 000 in the crowded world;
-        // tick 100 of the benchmark has about 5 000 and stays with the teams): the load balances over problems,
-        // and a team only repeats
-        // the cone / rank construction four times and waits at its barriers -- one problem per WAVE, its
-        // first one by wave number, then a ticket per wave and problem.  (From 2 048 problems on it costs
-        // 60 % at tick 100: single problems outlast the launch; profiles/r03_ab_cp_heavy_solo.txt.)
-        const int nw = (int)gridDim.x * CP_WAVES;
-        for(int round = 0; ; round++) {
-            int t = (int)blockIdx.x * CP_WAVES + wib;
-            if(round > 0) {
-                int v = 0x7fffffff;
-                if(lane == 0 && nw + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy) v = nw + atomicAdd(ticket, 1);
-                t = __shfl(v, 0);
-            }
-            if(t >= n_heavy) break;
-            const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
-            const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
-            const nh_mid_rec R = mid[uid];
-            const uint32_t c = NB.cnt[uid];
-            const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
-            cpent ent;
-            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-            ent.radius = P.radius[uid];
+    if(pass == 0) {
+        // (outside a crowd there is nothing to do: one parallel look at the 128 counters)
+        if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
+        unit_totals(hv_end, 2 * NH_WL_SUB, [&](int k) {
+            return WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB]; });
+        __syncthreads();
+        HIST_T0();
+        const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
+        int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
+        const bool may_bail = NH_CP_BAIL && n_heavy < CP_SOLO_MIN;
+        if(NH_CP_BAIL || n_heavy >= CP_SOLO_MIN) {
+            const int nw = (int)gridDim.x * CP_WAVES;
+            for(int round = 0; ; round++) {
+                int t = (int)blockIdx.x * CP_WAVES + wib;
+                if(round > 0) {
+                    int v = 0x7fffffff;
+                    if(lane == 0 && nw + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy) v = nw + atomicAdd(ticket, 1);
+                    t = __shfl(v, 0);
+                }
+                if(t >= n_heavy) break;
+                const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
+                const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
+                const nh_mid_rec R = mid[uid];
+                const uint32_t c = NB.cnt[uid];
+                const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+                cpent ent;
+                ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+                ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+                ent.radius = P.radius[uid];
 #ifdef NH_CP_UNIT_HIST
-            const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
+                const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
 #endif
-            cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
-            const v2 nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S);
-            if(lane == 0)
-                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
-            HIST_UNIT(0, tu0);
+                cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
+                bool bailed = false;
+                const v2 nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S, 0, 1, nullptr,
+                                          may_bail ? &bailed : nullptr);
+                if(bailed) {
+                    // onto the team list: sub-list = problem number mod NH_WL_SUB, so that a sub-list receives at most
+                    // ceil(n_heavy / NH_WL_SUB) <= ceil(work items / 64) entries -- below its capacity by construction
+                    // (nh_worklist_cap)
+                    const int sub = t & (NH_WL_SUB - 1);
+                    if(lane == 0) {
+                        const int at = atomicAdd(&WL.count[NH_WL_TEAM * NH_WL_SUB + sub], 1);
+                        WL.ids[((size_t)NH_WL_TEAM * NH_WL_SUB + sub) * WL.cap + at] = uid;
+                    }
+                    HIST_UNIT(0, tu0);
+                    continue;
+                }
+                if(lane == 0)
+                    post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
+                HIST_UNIT(0, tu0);
+            }
+            HIST_WAVE(0);
+            return;
         }
-        HIST_WAVE(0);
-        return;
+    }else{
+        if(!NH_CP_BAIL) return;
+        if(!__any(WL.count[NH_WL_TEAM * NH_WL_SUB + lane] != 0)) return;
+        unit_totals(hv_end, NH_WL_SUB, [&](int k) { return min(WL.count[NH_WL_TEAM * NH_WL_SUB + k], WL.cap); });
+        __syncthreads();
     }
+    // ---- one problem per workgroup: pass 1 over the team list (NH_CP_BAIL 0: pass 0 over both lists)
+    HIST_T0();
+    const int ntab = pass == 0 ? 2 * NH_WL_SUB : NH_WL_SUB;
+    const int n_team = hv_end[ntab - 1];
+    int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB + (pass == 0 ? 0 : 32 * (1 + 2 * NH_CP_STRIPES));
     for(int round = 0; ; round++) {
         int t = blockIdx.x;
         if(round > 0) {
             __syncthreads();
             if(threadIdx.x == 0) {
                 int v = 0x7fffffff;
-                if((int)gridDim.x + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy)
+                if((int)gridDim.x + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_team)
                     v = (int)gridDim.x + atomicAdd(ticket, 1);
                 h_ticket = v;
             }
             __syncthreads();
             t = h_ticket;
         }
-        if(t >= n_heavy) break;
-        const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
-        const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
+        if(t >= n_team) break;
+        const int k = first_above(hv_end, ntab, t), idx = t - (k ? hv_end[k - 1] : 0);
+        const int list = pass == 0 ? (k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) : NH_WL_TEAM;
+        const int uid = WL.ids[((size_t)list * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
         const nh_mid_rec R = mid[uid];
         const uint32_t c = NB.cnt[uid];
         const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
@@ -1880,7 +1913,10 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
                        (const nh_mid_rec*)d_mid, WL, O);
     hipLaunchKernelGGL(k_cp_rows, dim3(64 * CP_WAVES / CPR_WAVES), dim3(CPR_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_RETRY, 1, 1);
-    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O, zero_next);
+    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                       (int32_t*)nullptr, 0);
+    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                       zero_next, 1);
     if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_ROW3, 2, 0);

@@ -1130,7 +1130,7 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
     int32_t h[NH_WL_COUNTERS];
     HIPCHK(ctx, hipMemcpy(h, src, sizeof(h), hipMemcpyDeviceToHost));
     // (the wave and the heavy list are reported together: 17-64 neighbours)
-    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1};     // (the retry list is not reported)
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1, -1};     // (the retry and team lists are not reported)
     for(int l = 0; l < 6; l++) out_counts[l] = 0;
     for(int l = 0; l < NH_WL_LISTS; l++)
         for(int sb = 0; sb < NH_WL_SUB; sb++) if(slot_of[l] >= 0) out_counts[slot_of[l]] += h[l * NH_WL_SUB + sb];
@@ -1140,7 +1140,7 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
 int navhip_step_lists_peek(navhip_ctx *ctx, int32_t out_counts[6])
 {
     if(!ctx || !out_counts) return NAVHIP_ERR_INVALID;
-    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1};
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1, -1};
     for(int l = 0; l < 6; l++) out_counts[l] = 0;
     if(!ctx->lists_pinned) return NAVHIP_OK;
     const volatile int32_t *h = ctx->lists_pinned;

@@ -43,7 +43,7 @@ class NavTick:
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
                  debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True,
-                 straddle=0.0, los=False, flow_velocities=False):
+                 straddle=0.0, los=False, flow_velocities=False, share_fields=False):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -187,13 +187,37 @@ class NavTick:
         n_req = len(reqs)
         if obstacles:
             reqs["flags"] = navhip.REQ_LIVE_IIDS | navhip.REQ_IF_CHANGED
+        # share_fields: the reference keys its field cache by N_FlowFieldID (field.c:1952) -- chunk + target, NOT
+        # the destination -- so destinations whose paths leave a chunk through the same portal share ONE field
+        # (N_FC_PutDestFFMapping maps both to it, nav.c:2008-2021), and a tick after a wholesale invalidation
+        # rebuilds every DISTINCT field once.  Identical request records are built once and every (dest, chunk)
+        # entry of the slot table points at the shared slot.  (Default off: every request is rebuilt.)
+        self.n_requests_served = n_req
+        mapped_slot = np.arange(n_req)
+        if share_fields:
+            if world != 1 or obstacles:
+                raise ValueError("share_fields: single-process worlds without moving obstacles only")
+            uniq, first, inv = np.unique(reqs, return_index=True, return_inverse=True)
+            order = np.sort(first)                       # (keep the stream's order: first occurrences)
+            rank_of = np.empty(len(first), np.int64)
+            rank_of[np.argsort(first)] = np.arange(len(first))
+            mapped_slot = rank_of[inv.reshape(-1)]
+            reqs_all, dest_all = reqs, dest_of_req
+            reqs = reqs[order]
+            dest_of_req = dest_of_req[order]
+            n_req = len(reqs)
+            self.req_bounds = [(0, n_req)]
+            self.xchg_bounds = [(0, n_req)]
         # field slot = position in the (local) request stream
         self.req_begin, self.req_end = (0, n_req) if solo else self.req_bounds[rank]
         self.n_req_local = self.req_end - self.req_begin
         self.n_req_total = self.n_req_local * world if self.tile_exchange == "none" else n_req
         self._dest_of_req = dest_of_req
         slot_tbl = -np.ones((self.K, self.nchunks), np.int32)
-        slot_tbl[dest_of_req, reqs["chunk_r"].astype(np.int64) * Wt + reqs["chunk_c"]] = np.arange(n_req)
+        if share_fields:
+            slot_tbl[dest_all, reqs_all["chunk_r"].astype(np.int64) * Wt + reqs_all["chunk_c"]] = mapped_slot
+        else:
+            slot_tbl[dest_of_req, reqs["chunk_r"].astype(np.int64) * Wt + reqs["chunk_c"]] = np.arange(n_req)
         self.agent_bounds = [pdist.slab(self.N, r, world) for r in range(world)]
 
         offs, members = navhip.flock_csr(ag["flock"], self.K)

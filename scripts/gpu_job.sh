@@ -24,29 +24,29 @@ bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 
 bench20) timeout 600 python bench.py --steps 20 --warmup 5 --no-crowded > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err; tail -c 600 $OUT/bench_steps20.json ;;
 benchq) timeout 600 python bench.py --no-cpu-baseline --no-crowded > $OUT/bench_quick.json 2> $OUT/bench_quick.err; tail -c 2500 $OUT/bench_quick.json; tail -3 $OUT/bench_quick.err ;;
 calib) timeout 300 scripts/valu_calib.bin > $OUT/valu_calib.json 2>&1; cat $OUT/valu_calib.json ;;
-stats) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof.json 2> $OUT/prof.err
+stats) timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof.json 2> $OUT/prof.err
        f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 $f ;;
 pmc) for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES"; do
        n=$(echo $c | cut -d' ' -f1)
-       timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmc_$n.json 2> $OUT/pmc_$n.err
+       timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmc_$n.json 2> $OUT/pmc_$n.err
        tail -c 300 $OUT/pmc_$n.err
      done ;;
 aux) timeout 600 python scripts/bench_aux.py > $OUT/bench_aux.json 2> $OUT/bench_aux.err; tail -c 1200 $OUT/bench_aux.json
      [ -f build_prof/libnavhip_cphist.so ] && timeout 300 python scripts/cp_unit_hist.py > $OUT/cp_unit_hist.json 2> /dev/null ;;
 cfgs) for c in 0 1 3 4; do timeout 600 python bench.py --config $c --no-crowded > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; tail -c 400 $OUT/bench_cfg$c.json; tail -2 $OUT/bench_cfg$c.err; done ;;
-stats20) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats20 -o s --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof20.json 2> $OUT/prof20.err
+stats20) timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats20 -o s --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/bench_under_prof20.json 2> $OUT/prof20.err
        f=$(find $OUT/stats20 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 $f ;;
 avail) timeout 120 rocprofv3 -L > $OUT/avail.txt 2>&1; grep -c . $OUT/avail.txt ;;
 pmccp) i=0; for c in "SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
        i=$((i+1))
-       timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccp_$i -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmccp_$i.json 2> $OUT/pmccp_$i.err
+       timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccp_$i -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmccp_$i.json 2> $OUT/pmccp_$i.err
        tail -c 200 $OUT/pmccp_$i.err
-       timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccpc_$i -o p --output-format csv -- python bench.py --crowded --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmccpc_$i.json 2> $OUT/pmccpc_$i.err
+       timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccpc_$i -o p --output-format csv -- python bench.py --crowded --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmccpc_$i.json 2> $OUT/pmccpc_$i.err
        tail -c 200 $OUT/pmccpc_$i.err
      done ;;
 cpstats) timeout 400 python scripts/cp_stats.py > $OUT/cp_stats.json 2> $OUT/cp_stats.err; tail -c 300 $OUT/cp_stats.err
          timeout 400 python scripts/cp_stats.py --crowd > $OUT/cp_stats_crowd.json 2>> $OUT/cp_stats.err; tail -c 600 $OUT/cp_stats_crowd.json ;;
-secondary) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/secondary -o s --output-format csv -- python scripts/bench_secondary.py > $OUT/bench_secondary.json 2> $OUT/secondary.err
+secondary) timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/secondary -o s --output-format csv -- python scripts/bench_secondary.py > $OUT/bench_secondary.json 2> $OUT/secondary.err
        tail -c 1500 $OUT/bench_secondary.json; f=$(find $OUT/secondary -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 $f | cut -c1-160 ;;
 smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
 ranks2) NAVHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; tail -c 400 $OUT/bench_2ranks_gloo.json ;;

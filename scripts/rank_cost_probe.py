@@ -3,7 +3,9 @@
 and time its share of the tick (field builds + slab step, no exchange; the snapshot is not advanced,
 so every tick is the same work).  Shows what the parts replicated on every rank (map planes, entity
 snapshot, hash grid, flock tables) cost as the job grows.
-    python scripts/rank_cost_probe.py 1 8"""
+    python scripts/rank_cost_probe.py 1 8
+    python scripts/rank_cost_probe.py --strong 1 2 4 8     (ONE configs[2] world split over the ranks: bench.py
+                                                            --scaling strong; compute only, no exchange)"""
 import sys
 import time
 import os
@@ -14,9 +16,15 @@ from permafrost_engine_amd import tick    # noqa: E402
 
 
 def main():
-    for world in [int(a) for a in sys.argv[1:]] or [1, 8]:
+    strong = "--strong" in sys.argv
+    base = None
+    for world in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 8]:
         t0 = time.time()
-        T = tick.NavTick(rank=world // 2, world=world)
+        if strong:
+            T = tick.NavTick(rank=world // 2, world=world, shared_map=True, fields_per_rank=64 // world,
+                             agents_per_rank=100_000 // world, pipeline_fields=True)
+        else:
+            T = tick.NavTick(rank=world // 2, world=world)
         T._comm_pending = False
         T.pipelined = False          # (no process group here: the exchange is left out)
         setup = time.time() - t0
@@ -29,8 +37,11 @@ def main():
             T.compute()
         T.sync()
         dt = (time.perf_counter() - t0) / n
+        base = base or dt * world
         print("world %d rank %d: setup %.1f s, %d local requests, slab %d agents of %d: %.4f ms per tick "
-              "(compute only)" % (world, T.rank, setup, T.n_req_local, T.a1 - T.a0, T.N, dt * 1e3), flush=True)
+              "(compute only)%s" % (world, T.rank, setup, T.n_req_local, T.a1 - T.a0, T.N, dt * 1e3,
+                                    "; ideal 1/%d of one rank's tick = %.4f ms: efficiency %.2f" % (world, base / world * 1e3, base / world / dt)
+                                    if strong else ""), flush=True)
         T.close()
 
 

@@ -381,6 +381,27 @@ def test_prefetch_overlap_gives_identical_results(navlib):
     assert np.abs(res[0][1]).max() > 0
 
 
+def test_shared_chunk_fields_give_identical_results(navlib):
+    """tick.NavTick(share_fields=True): requests with the same chunk and target (one N_FlowFieldID, field.c:1952)
+    are built once and shared through the slot table, as the reference's field cache shares them between
+    destinations.  Same snapshot after six ticks as the world that builds every request."""
+    from permafrost_engine_amd import tick
+    res, counts = [], []
+    for share in (False, True):
+        T = tick.NavTick(chunk_w=4, fields_per_rank=24, agents_per_rank=5000, device=0, share_fields=share,
+                         pipeline_fields=share)
+        for _ in range(6):
+            T.step()
+        T.sync()
+        res.append((T.t["pos_xz"].cpu().numpy().copy(), T.t["vel_xz"].cpu().numpy().copy()))
+        counts.append((T.n_req_local, T.n_requests_served))
+        T.close()
+    assert counts[1][0] < counts[0][0] == counts[1][1], counts          # something was shared
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    assert np.abs(res[0][1]).max() > 0
+
+
 def test_pipelined_field_builds_give_identical_results(navlib):
     """tick.NavTick(pipeline_fields=True) builds the fields tick t+1 samples during tick t (own stream,
     double-buffered pool, behind navhip_stream_wait_stage): a schedule, not a different computation."""

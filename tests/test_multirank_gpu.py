@@ -42,6 +42,16 @@ def test_two_ranks_equal_one_process(extra):
     assert ("backend=%s" % backend) in out
 
 
+@pytest.mark.parametrize("extra", [["--shared"], ["--shared", "--pipeline-fields", "--flow-velocities"]])
+def test_two_ranks_split_one_world(extra):
+    """Strong scaling (bench.py --scaling strong; BASELINE.json: "1024^2 map, 100k agents, 1/2/4/8 GPUs"): ONE
+    map, its destinations split by rank, its agents split into uid slabs (movement.c:3759-3762) -- agents of
+    different slabs are neighbours everywhere on the map.  Every rank's snapshot == the one-process result."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    _run(2, backend, extra)
+
+
 @pytest.mark.parametrize("extra", [["--straddle"], ["--straddle", "--pipeline-fields"]])
 def test_straddling_flocks_exchange_only_their_tiles(extra):
     """tile_exchange="auto" with flocks that straddle the ranks: a quarter of every rank's agents sample
