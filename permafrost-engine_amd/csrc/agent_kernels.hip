@@ -1277,9 +1277,10 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
 #ifndef NH_CP_BAIL
 #define NH_CP_BAIL 0
 #endif
-#ifdef CP_HEAVY_OCC
-__attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
+#ifndef CP_HEAVY_OCC
+#define CP_HEAVY_OCC 4          /* (pinned: a few registers above 128 would silently cost a wave per SIMD) */
 #endif
+__attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
 __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                             nh_worklists WL, nh_step_outs O, int32_t *zero_next, int pass)
 {

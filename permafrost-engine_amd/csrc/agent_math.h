@@ -53,6 +53,9 @@ NH_FN double   nh_ll2d(long long i) { return __longlong_as_double(i); }
 #define NH_COLD_PATH() asm volatile("" ::: "memory")
 #endif
 
+NH_FN uint32_t nh_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+NH_FN uint32_t nh_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
 // ---------------------------------------------------------------------------------------------
 // vec2 (pf_math.c:58-94)
 // ---------------------------------------------------------------------------------------------
@@ -522,6 +525,47 @@ NH_FN bool ray_isect(v2 p1, v2 d1, float s1, v2 p2, v2 d2, float s2, v2 &out)
     return true;
 }
 
+// C_RayRayIntersection2D + the distance of the point to des_v, without a branch in the common case: the three
+// shapes of C_InfiniteLineIntersection are all evaluated and selected (the division runs on whatever operands
+// there are; a result that is not selected is never looked at), the sign tests are bit tests, and the two rare
+// expansions -- a quotient whose sign needs the division, a squared distance outside the range of the short
+// square root -- are reported in `slow` for the caller to branch on ONCE per wave (ray_isect / vlen then redo
+// that lane).  Same arithmetic, same operand order as line_isect / ray_isect / vlen above.
+NH_FN bool ray_isect_bf(v2 p1, v2 d1, float s1, v2 p2, v2 d2, float s2, v2 des_local, v2 ent_pos, v2 &out, float &len,
+                        bool &slow)
+{
+    const bool n1 = s1 != s1, n2 = s2 != s2;
+    const float ds = s1 - s2;
+    bool ok = !(n1 & n2) & !(fabsf(ds) < CP_EPS);
+    const float xg = nh_fdiv((s1 * p1.x - s2 * p2.x + p2.z - p1.z), ds);
+    const float zg = s2 * (xg - p2.x) + p2.z;
+    const float zv1 = (p1.x - p2.x) * s2 + p2.z;            // line 1 vertical
+    const float zv2 = (p2.x - p1.x) * s1 + p2.z;            // line 2 vertical
+    v2 p;
+    p.x = n1 ? p1.x : (n2 ? p2.x : xg);
+    p.z = n1 ? zv1 : (n2 ? zv2 : zg);
+    const float a1 = p.x - p1.x, a2 = p.z - p1.z, a3 = p.x - p2.x, a4 = p.z - p2.z;
+    // quot_neg_fast's conditions for all four quotients at once, on the bit patterns of |a| (ordered like the
+    // values; a NaN is the largest): every |a| is 0 or in [2^-100, inf) -- (bits - 1) wraps a zero out of the
+    // minimum --, every |b| <= 2^20 (a NaN fails that compare too)
+    const uint32_t u1 = nh_f2u(a1) & 0x7fffffffu, u2 = nh_f2u(a2) & 0x7fffffffu, u3 = nh_f2u(a3) & 0x7fffffffu,
+                   u4 = nh_f2u(a4) & 0x7fffffffu;
+    const uint32_t lo = nh_umin(nh_umin(u1 - 1u, u2 - 1u), nh_umin(u3 - 1u, u4 - 1u));
+    const uint32_t hi = nh_umax(nh_umax(u1, u2), nh_umax(u3, u4));
+    const uint32_t ub = nh_umax(nh_umax(nh_f2u(d1.x) & 0x7fffffffu, nh_f2u(d1.z) & 0x7fffffffu),
+                                nh_umax(nh_f2u(d2.x) & 0x7fffffffu, nh_f2u(d2.z) & 0x7fffffffu));
+    const bool fast = lo >= 0x0d800000u - 1u && hi < 0x7f800000u && ub <= 0x49800000u;      // 2^-100, inf, 2^20
+    const bool neg = (a1 != 0.0f && ((nh_f2i(a1) ^ nh_f2i(d1.x)) < 0)) | (a2 != 0.0f && ((nh_f2i(a2) ^ nh_f2i(d1.z)) < 0))
+                   | (a3 != 0.0f && ((nh_f2i(a3) ^ nh_f2i(d2.x)) < 0)) | (a4 != 0.0f && ((nh_f2i(a4) ^ nh_f2i(d2.z)) < 0));
+    const v2 rel = vsub(des_local, vsub(p, ent_pos));
+    const float ss = rel.x * rel.x + rel.z * rel.z;
+    const bool short_sqrt = (ss >= 0x1p-90f && ss <= 0x1p90f) || ss == 0.0f;
+    len = sqrt_rn_normal(ss);
+    slow = ok & (!fast | !short_sqrt);
+    out = p;
+    return ok & !neg;
+}
+
 // compute_vo_edges, clearpath.c:130
 NH_FN void vo_edges(const cpent &ent, const cpent &nb, v2 &out_right, v2 &out_left)
 {
@@ -600,6 +644,27 @@ NH_FN int cone_contains_fast(float4 A, float4 B, v2 test)
     if(fabsf(detr + CP_EPS) <= MARG) return 2;
     if(detr > -CP_EPS) return 0;
     return 1;
+}
+
+// cone_contains_fast without a branch: every comparison is evaluated and the verdict picked in the order the
+// function above returns in (a select chain).  For the wave-wide search, where a taken branch costs the whole
+// wave its exec-mask bookkeeping and the lanes execute both sides anyway.
+NH_FN int cone_test_bf(float4 A, float4 B, v2 test)
+{
+    const float MARG = 2e-5f;
+    const float px = test.x - A.x, pz = test.z - A.y;
+    const float s = px * px + pz * pz;
+    const float inv = nh_rsq_native(s);
+    const float len = s * inv;
+    const float detl = (pz * B.x - px * B.y) * inv;
+    const float detr = (pz * B.z - px * B.w) * inv;
+    const bool bad = !(s > 0.0f) | !(s < 1e30f) | (fabsf(len - CP_EPS) <= CP_EPS * 1e-4f);
+    int r = (detr > -CP_EPS) ? 0 : 1;
+    r = (fabsf(detr + CP_EPS) <= MARG) ? 2 : r;
+    r = (detl < CP_EPS) ? 0 : r;
+    r = (fabsf(detl - CP_EPS) <= MARG) ? 2 : r;
+    r = (len < CP_EPS) ? 0 : r;
+    return bad ? 2 : r;
 }
 
 NH_FN bool cone_contains(float4 A, float4 B, v2 test)
