@@ -301,7 +301,7 @@ template <int G> struct cp_lds {
 struct cp_bound { float len; int idx; v2 pt; int nfound; int sb;
 #ifdef NH_CP_STATS
     // developer counters, kept in registers and flushed once per attempt (an atomic per iteration distorts what it measures)
-    unsigned it, busy, ex, out, passes; unsigned long long cw, cg;
+    unsigned it, busy, ex, out, passes, cols, cands, queued; unsigned long long cw, cg;
 #endif
 };
 #define CP_COL_MARGIN 0.02f
@@ -317,8 +317,14 @@ struct cp_bound { float len; int idx; v2 pt; int nfound; int sb;
 #ifndef NH_CP_ORDER_DEPTH
 #define NH_CP_ORDER_DEPTH 1      // cones are tested deepest-around-des_v first (0: nearest neighbour first)
 #endif
+#ifndef CP_COVER_CONES
+#define CP_COVER_CONES 12
+#endif
 #ifndef NH_CP_COVER
-#define NH_CP_COVER 1            // column phase: rays that lie inside another cone from end to end are no columns
+#define NH_CP_COVER 0            // column phase: rays that lie inside another cone from end to end are no columns (exact, a third of the rays in a MOVING crowd by the model; measured neutral on every benchmark world: off)
+#endif
+#ifndef NH_CP_PACKB
+#define NH_CP_PACKB 0            // more than 64 rays: the rows beyond 64 of several columns share one pass (measured: -1.7 % in the jam as the only column loop but +2.5 % on ordinary ticks; beside the plain loop the second copy of the queue code costs the jam 7 %: off)
 #endif
 #ifndef NH_CP_COLS_V2
 #define NH_CP_COLS_V2 1          // column phase of a wave-wide search: lane = row, the column wave uniform
@@ -861,7 +867,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
 
         cp_bound B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.nfound = 0; B.sb = 0;
 #ifdef NH_CP_STATS
-        B.it = B.busy = B.ex = B.out = B.passes = 0; B.cw = B.cg = 0;
+        B.it = B.busy = B.ex = B.out = B.passes = B.cols = B.cands = B.queued = 0; B.cw = B.cg = 0;
         B.sb = cp_bucket(n_dyn + n_stat);
         CP_STAT(B.sb, 1, 1);
         if(guard == 0) CP_STAT(B.sb, 0, 1);
@@ -1008,7 +1014,11 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                     }
                 }
                 const float MS = 0.02f, DMIN2 = 0.0625f;
-                for(int c = 0; c < n_cones; c++) {
+                // (against the CP_COVER_CONES cones deepest around des_v only: the whole list costs as much as the
+                // columns it saves in a standing jam, where a tenth of the rays is covered)
+                const int n_cov = min(n_cones, CP_COVER_CONES);
+                for(int r = 0; r < n_cov; r++) {
+                    const int c = uni<G>(S.ord[r]);
                     const float4 Ac = S.cones[2 * c], Bc = S.cones[2 * c + 1];
 #pragma unroll
                     for(int h = 0; h < 2; h++) {
@@ -1133,12 +1143,75 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                 }
             }
 #else
+#if NH_CP_PACKB
+            if(n_rays > G)
+            // More than 64 rays: rows 0..63 of a column fill one pass, its rows 64.. only m = n_rays - 64 lanes of a
+            // second one (14 of 64 for the typical 39 cones of a jam).  So the second passes of P = 64 / m columns
+            // share ONE pass: lane l takes row 64 + l % m of column l / m of the group -- its ray from the lane that
+            // holds it (five shuffles, once), its column's ray from LDS per lane.  Passes per column: 1 + 1/P
+            // instead of 2.  One loop body for both kinds of pass (one copy of the queue code).
+            {
+                const int mB = n_rays > G ? n_rays - G : 0, P = mB ? G / mB : 1;
+                const int cbB = mB ? gl / mB : 0, rrB = mB ? gl - cbB * mB : 0;
+                const bool laneB = mB && cbB < P;
+                const float bpx = __shfl(rpx[1], rrB), bpz = __shfl(rpz[1], rrB), bdx = __shfl(rdx[1], rrB),
+                            bdz = __shfl(rdz[1], rrB), bsl = __shfl(rsl[1], rrB);
+                bool stop = false;
+                for(int jc0 = 0; jc0 < n_mine && !stop; jc0 += P) {
+                    // the columns of this group that are still within the bound (the order is ascending key)
+                    const int gmax = min(P, n_mine - jc0);
+                    int ng = 0;
+                    for(; ng < gmax; ng++) {
+                        const int j = uni<G>(S.col[(jc0 + ng) * nparts + part]);
+                        if(((j < 64 ? cov0 >> j : cov1 >> (j - 64)) & 1ull) != 0ull) { stop = true; break; }
+                        if(B.nfound && uni<G>(S.ckey[j]) > B.len) { stop = true; break; }
+                    }
+#ifdef NH_CP_STATS
+                    B.cols += ng; B.cands += ng * n_rays;
+#endif
+                    const int npass = ng ? ng + (mB ? 1 : 0) : 0;
+#pragma unroll 1
+                    for(int k = 0; k < npass; k++) {
+                        const bool isB = k == ng;
+                        const int kk = isB ? min(cbB, ng - 1) : k;
+                        const int j = S.col[(jc0 + kk) * nparts + part];          // (the same in every lane of an A pass)
+                        const int i = isB ? G + rrB : gl;
+                        const bool mine = (isB ? (laneB && cbB < ng) : true) & (i < n_rays) & (i != j);
+                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                        const v2 p2 = mkv(Aj.x, Aj.y), d2 = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
+                        const float s2 = (j & 1) ? Aj.w : Aj.z;
+                        const v2 p1 = isB ? mkv(bpx, bpz) : mkv(rpx[0], rpz[0]);
+                        const v2 d1 = isB ? mkv(bdx, bdz) : mkv(rdx[0], rdz[0]);
+                        const float s1 = isB ? bsl : rsl[0];
+                        const int idx = i * n_rays + j;
+                        v2 pt = mkv(0, 0);
+                        float len = 0.0f;
+                        bool slow = false;
+                        bool ok = ray_isect_bf(p1, d1, s1, p2, d2, s2, des_v, ent.pos, pt, len, slow);
+                        if(__ballot(slow & mine) != 0ull) {           // (a quotient that needs its division, an odd distance)
+                            NH_COLD_PATH();
+                            if(slow & mine) {
+                                ok = ray_isect(p1, d1, s1, p2, d2, s2, pt);
+                                len = vlen(vsub(des_v, vsub(pt, ent.pos)));
+                            }
+                        }
+                        ok = ok & mine & cp_alive(B, len, idx);
+#ifdef NH_CP_STATS
+                        B.passes++;
+#endif
+                        cp_push_x<G>(S, ent, n_test, ok, pt, idx, len, qn, L, B);
+                    }
+                }
+            }
+            else
+#endif
             for(int jc = 0; jc < n_mine; jc++) {
                 const int j = __builtin_amdgcn_readfirstlane(S.col[jc * nparts + part]);
                 if(((j < 64 ? cov0 >> j : cov1 >> (j - 64)) & 1ull) != 0ull) break;       // (covered columns sort last)
                 if(B.nfound && uni<G>(S.ckey[j]) > B.len) break;
-                CP_STAT(B.sb, 6, 1);
-                CP_STAT(B.sb, 2, n_rays);
+#ifdef NH_CP_STATS
+                B.cols++; B.cands += n_rays;
+#endif
                 const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
                 const v2 p2 = mkv(Aj.x, Aj.y), d2 = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
                 const float s2 = (j & 1) ? Aj.w : Aj.z;
@@ -1234,7 +1307,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         }
 #ifdef NH_CP_STATS
         CP_STAT(B.sb, 5, B.it); CP_STAT(B.sb, 8, B.busy); CP_STAT(B.sb, 9, B.ex); CP_STAT(B.sb, 10, B.out);
-        CP_STAT(B.sb, 11, B.passes); CP_STAT(B.sb, 13, B.cw);
+        CP_STAT(B.sb, 11, B.passes); CP_STAT(B.sb, 13, B.cw); CP_STAT(B.sb, 6, B.cols); CP_STAT(B.sb, 2, B.cands);
 #endif
         if(TEAM) team_min<G>(B, *T, part, nparts);
         CP_TMARK(sb_, 2);

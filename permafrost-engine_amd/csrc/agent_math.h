@@ -635,6 +635,10 @@ NH_FN int cone_contains_fast(float4 A, float4 B, v2 test)
     const float s = px * px + pz * pz;
     const float inv = nh_rsq_native(s);
     const float len = s * inv;
+    // (a test point that IS the apex -- the intersection of two rays of one cone, or of two static neighbours'
+    // cones, which all start at the entity's own position, often comes out bit-equal to it -- has length 0:
+    // "not inside", clearpath.c:262, without the exact evaluation; in a jam that was half of all test steps)
+    if(s == 0.0f) return 0;
     if(!(s > 0.0f) || !(s < 1e30f) || fabsf(len - CP_EPS) <= CP_EPS * 1e-4f) return 2;
     if(len < CP_EPS) return 0;
     const float detl = (pz * B.x - px * B.y) * inv;
@@ -658,12 +662,14 @@ NH_FN int cone_test_bf(float4 A, float4 B, v2 test)
     const float len = s * inv;
     const float detl = (pz * B.x - px * B.y) * inv;
     const float detr = (pz * B.z - px * B.w) * inv;
-    const bool bad = !(s > 0.0f) | !(s < 1e30f) | (fabsf(len - CP_EPS) <= CP_EPS * 1e-4f);
+    // (s == 0: the point is the apex -- length 0, "not inside" -- decided here; everything derived from it is NaN
+    // and fails every compare below)
+    const bool bad = !(s >= 0.0f) | !(s < 1e30f) | (fabsf(len - CP_EPS) <= CP_EPS * 1e-4f);
     int r = (detr > -CP_EPS) ? 0 : 1;
     r = (fabsf(detr + CP_EPS) <= MARG) ? 2 : r;
     r = (detl < CP_EPS) ? 0 : r;
     r = (fabsf(detl - CP_EPS) <= MARG) ? 2 : r;
-    r = (len < CP_EPS) ? 0 : r;
+    r = ((len < CP_EPS) | (s == 0.0f)) ? 0 : r;
     return bad ? 2 : r;
 }
 
