@@ -259,6 +259,18 @@ __device__ __forceinline__ int cp_bucket(int n) { return n <= 2 ? 0 : n <= 4 ? 1
 #define CP_TMARK(b, k)
 #endif
 
+#ifndef NH_CP_TC
+#define NH_CP_TC 1          // the wave-wide search keeps a copy of the cones in test order (2 KB of LDS per wave: see DESIGN 3.6b)
+#endif
+#ifndef NH_CP_PACKQ
+#define NH_CP_PACKQ 1       // ... and packs a queue entry into 16 bytes
+#endif
+#ifndef NH_CP_PAD
+#define NH_CP_PAD 0         // (developer knob: float4s of padding per wave-wide / 16-lane scratch, to probe the LDS occupancy cliff)
+#endif
+#ifndef NH_CP_PAD16
+#define NH_CP_PAD16 (NH_CP_TC ? 8 : 0)   // k_cp_rows' workgroup has to own at least k_cp_heavy's LDS (hole inheritance)
+#endif
 // LDS scratch of one ClearPath problem on a group of G lanes (at most G neighbours in total):
 //   cones   2 float4 per cone: {apex.x, apex.z, slope(left), slope(right)}, {left.x, left.z, right.x, right.z}
 //   ord     cone slots, nearest neighbour first (the order of the inside-obstacle tests)
@@ -275,6 +287,7 @@ template <int G> struct cp_lds {
     float   ckey[2 * G];             // key of every ray: a lower bound of the distance of its candidates to des_v
     int32_t tau[G], seq[G];          // cp_jump: removal time of every cone, the removal sequence
     float   dyn[(G < 32 ? G : 32) * 5], stat[(G < 32 ? G : 32) * 5];
+    float4  tc[G == 64 && NH_CP_TC ? 2 * G : (G == 64 && NH_CP_PAD ? NH_CP_PAD : (G == 16 && NH_CP_PAD16 ? NH_CP_PAD16 : 1))];  // wave-wide search: the cones in TEST order (cones[ord[k]] copied: one dependent LDS read less per test step)
 #ifdef NH_CP_UNIT_HIST
     int32_t dbg[4];                  // developer instrumentation: attempts, jump result, rays
 #endif
@@ -486,8 +499,14 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int 
             const int my = head + (int)__popcll(mn & lt_mask);
             const bool take = need & (my < qn);
             const int at = take ? my : 0;
+#if NH_CP_PACKQ
+            const float4 qe = ((const float4*)S.qx)[at];          // (the wave-wide queue packs an entry into 16 bytes)
+            const float qx = qe.x, qz = qe.y, ql = qe.z;
+            const int qi = __float_as_int(qe.w);
+#else
             const float qx = S.qx[at], qz = S.qz[at], ql = S.ql[at];
             const int qi = S.qi[at];
+#endif
             const bool alive = (nfound == 0) | (ql < Blen) | ((ql == Blen) & (qi < Bidx));
             px = take ? qx : px; pz = take ? qz : pz; len = take ? ql : len; idx = take ? qi : idx;
             ci = take ? (alive ? 0 : -1) : ci;
@@ -502,8 +521,13 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int 
 #ifdef NH_CP_STATS
         B.it++; B.busy += __popcll(busy);
 #endif
-        const int slot = S.ord[max(ci, 0)];
-        const float4 A = S.cones[2 * slot], Bc = S.cones[2 * slot + 1];
+#if NH_CP_TC
+        const int ck = max(ci, 0);
+        const float4 A = S.tc[2 * ck], Bc = S.tc[2 * ck + 1];
+#else
+        const int ck = S.ord[max(ci, 0)];
+        const float4 A = S.cones[2 * ck], Bc = S.cones[2 * ck + 1];
+#endif
         const v2 pt = mkv(px, pz);
         int v = cone_test_bf(A, Bc, pt);
         if(__ballot((v == 2) & (ci >= 0)) != 0ull) {
@@ -557,7 +581,11 @@ __device__ __forceinline__ void cp_push_bf(cp_lds<64> &S, const cpent &ent, int 
     if(mk != 0ull) {
         if(ok) {
             const int at = qn + (int)__popcll(mk & ((1ull << gl) - 1ull));
+#if NH_CP_PACKQ
+            ((float4*)S.qx)[at] = make_float4(pt.x, pt.z, len, __int_as_float(idx));
+#else
             S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = idx; S.ql[at] = len;
+#endif
         }
         qn = uni<64>(qn + (int)__popcll(mk));
         wave_sync();
@@ -602,6 +630,152 @@ __device__ unsigned long long nh_cp_attempts[9];
 // breaks ties exactly as the reference does), or -1: no attempt succeeds before a list runs empty.
 // (part / nparts: this group's share of the candidates when a team searches; the team's answer is
 // the minimum of the shares' results, BIG standing for "none")
+#ifndef NH_CP_JUMP_BF
+#define NH_CP_JUMP_BF 1
+#endif
+// Step 4 of cp_jump (below) for a WAVE-wide group, in the layout and style of the search's column phase: lane = row
+// (this lane's two rays and their removal times in registers), the column's ray uniform; a lane's candidate state
+// changes through selects, the cones come from S.tc in the order they are tested (latest-removed first, S.col = their
+// removal times), a queue entry is 16 bytes, and the only branches are on ballots and the queue counters.  Columns
+// whose neighbour leaves with the first removal are skipped (their candidates exist in attempt 0 only).  `cur`: the
+// best start so far (from des_v); returns the minimum over this share's candidates.
+__device__ __forceinline__ int cp_jump_cands_bf(cp_lds<64> &S, const cpent &ent, v2 des_v, int n_cones, int cur,
+                                                int part, int nparts)
+{
+    const int gl = (int)(threadIdx.x & 63);
+    const unsigned long long lt_mask = (1ull << gl) - 1ull;
+    const int BIG = 1 << 20;
+    n_cones = uni<64>(n_cones); cur = uni<64>(cur);
+    const int n_rays = 2 * n_cones;
+#if NH_CP_TC
+    if(gl < n_cones) {
+        const int so = S.ord[gl];
+        S.tc[2 * gl] = S.cones[2 * so]; S.tc[2 * gl + 1] = S.cones[2 * so + 1];
+        S.col[gl] = S.tau[so];
+    }
+#endif
+    float rpx[2], rpz[2], rdx[2], rdz[2], rsl[2];
+    int rtau[2];
+#pragma unroll
+    for(int h = 0; h < 2; h++) {
+        const int r = gl + h * 64;
+        rpx[h] = rpz[h] = rdx[h] = rdz[h] = rsl[h] = 0.0f; rtau[h] = 0;
+        if(r < n_rays) {
+            const float4 Ar = S.cones[r & ~1], Br = S.cones[r | 1];
+            rpx[h] = Ar.x; rpz[h] = Ar.y;
+            rdx[h] = (r & 1) ? Br.z : Br.x; rdz[h] = (r & 1) ? Br.w : Br.y;
+            rsl[h] = (r & 1) ? Ar.w : Ar.z;
+            rtau[h] = S.tau[r >> 1];
+        }
+    }
+    wave_sync();
+    const int nh = n_rays > 64 ? 2 : 1;
+    const int n_mine = (n_rays - part + nparts - 1) / nparts;          // columns part, part + nparts, ...
+    const int n_proj = part == 0 ? nh : 0;                              // (the projections: the first share's)
+    const int n_pass = n_proj + n_mine * nh;
+    int qn = 0;
+    float px = 0.0f, pz = 0.0f;
+    int end = 0, ci = -1;                                               // ci < 0: this lane holds no candidate
+#pragma unroll 1
+    for(int p = 0;; p++) {
+        const bool gen_done = p >= n_pass || cur <= 1;
+        if(!gen_done) {
+            bool ok = false;
+            v2 pt = mkv(0, 0);
+            int e = 0;
+            if(p < n_proj) {
+                const int h = p;
+                const v2 point = h ? mkv(rpx[1], rpz[1]) : mkv(rpx[0], rpz[0]);
+                const v2 dir = h ? mkv(rdx[1], rdz[1]) : mkv(rdx[0], rdz[0]);
+                pt = vadd(point, vscale(dir, vdot(dir, des_v)));
+                e = (h ? rtau[1] : rtau[0]) - 1;
+                ok = gl + h * 64 < n_rays;
+            }else{
+                const int q = p - n_proj;
+                const int jc = nh == 2 ? q >> 1 : q, h = nh == 2 ? q & 1 : 0;
+                const int j = jc * nparts + part;
+                const int tj = uni<64>(S.tau[j >> 1]);
+                if(tj <= 1) continue;
+                const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
+                const v2 p2 = mkv(Aj.x, Aj.y), d2 = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
+                const float s2 = (j & 1) ? Aj.w : Aj.z;
+                const int i = gl + h * 64;
+                const v2 p1 = h ? mkv(rpx[1], rpz[1]) : mkv(rpx[0], rpz[0]);
+                const v2 d1 = h ? mkv(rdx[1], rdz[1]) : mkv(rdx[0], rdz[0]);
+                const float s1 = h ? rsl[1] : rsl[0];
+                e = min(h ? rtau[1] : rtau[0], tj) - 1;
+                const bool mine = (i < n_rays) & (i != j) & (e >= 1);
+                float len = 0.0f;
+                bool slow = false;
+                ok = ray_isect_bf(p1, d1, s1, p2, d2, s2, des_v, ent.pos, pt, len, slow);
+                if(__ballot(slow & mine) != 0ull) {
+                    NH_COLD_PATH();
+                    if(slow & mine) ok = ray_isect(p1, d1, s1, p2, d2, s2, pt);
+                }
+                ok = ok & mine;
+            }
+            ok = ok & (e >= 1);                        // it must exist in some attempt after the first
+            const unsigned long long mk = __ballot(ok);
+            if(ok) {
+                const int at = qn + (int)__popcll(mk & lt_mask);
+                ((float4*)S.qx)[at] = make_float4(pt.x, pt.z, __int_as_float(e), 0.0f);
+            }
+            qn = uni<64>(qn + (int)__popcll(mk));
+            wave_sync();
+            if(qn < 64) continue;
+        }
+        // work the queue off (persistent lanes, one cone test per busy lane and step)
+        int head = 0;
+        for(;;) {
+            const bool need = ci < 0;
+            const unsigned long long mn = __ballot(need);
+            const int my = head + (int)__popcll(mn & lt_mask);
+            const bool take = need & (my < qn);
+            const float4 qe = ((const float4*)S.qx)[take ? my : 0];
+            px = take ? qe.x : px; pz = take ? qe.y : pz; end = take ? __float_as_int(qe.z) : end;
+            ci = take ? 0 : ci;
+            head = uni<64>(min(qn, head + (int)__popcll(mn)));
+            if(__ballot(ci >= 0) == 0ull) break;       // (no lane holds one: the queue is empty as well)
+            if(!gen_done && head >= qn) break;          // more to generate: the lanes keep what they hold
+            const bool act = ci >= 0;
+            const int lim = min(cur - 1, end);          // its start has to be <= lim to matter
+#if NH_CP_TC
+            const int ck = max(ci, 0);
+            const float4 A = S.tc[2 * ck], Bc = S.tc[2 * ck + 1];
+            const int tcv = S.col[ck];
+#else
+            const int ck = S.ord[max(ci, 0)];
+            const float4 A = S.cones[2 * ck], Bc = S.cones[2 * ck + 1];
+            const int tcv = S.tau[ck];
+#endif
+            const v2 pt = mkv(px, pz);
+            int v = cone_test_bf(A, Bc, pt);
+            if(__ballot((v == 2) & act) != 0ull) {
+                NH_COLD_PATH();
+                if(v == 2) v = cone_contains_exact(A, Bc, pt) ? 1 : 0;
+            }
+            const bool in = v == 1, dead = lim < 1;
+            const int nci = ci + 1;
+            const bool last = nci >= n_cones;
+            // inside: the latest-removed cone around it (its start, if early enough); outside everything: cannot be
+            // (attempt 0 failed), start 0 as the reference's loop would find
+            int result = in ? (tcv <= lim ? tcv : BIG) : (last ? 0 : BIG);
+            result = (act & !dead) ? result : BIG;
+            ci = act ? ((dead | in | last) ? -1 : nci) : -1;
+            if(__ballot(result < BIG) != 0ull) {
+                int r = result;
+#pragma unroll
+                for(int d = 32; d >= 1; d >>= 1) r = min(r, __shfl_xor(r, d));
+                cur = uni<64>(min(cur, r));
+            }
+        }
+        qn = 0;
+        wave_sync();
+        if(gen_done) break;
+    }
+    return cur;
+}
+
 template <int G>
 __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool isdyn, int k, bool use,
                        int slot, float dist, int n_dyn, int n_stat, int n_cones, int part, int nparts)
@@ -652,6 +826,10 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
     for(int d = G / 2; d >= 1; d >>= 1) td = max(td, __shfl_xor(td, d));
     int cur = min(td, t_end);                      // best start so far (group uniform)
     // 4. the candidates: when does each become admissible?
+    if constexpr(G == 64 && NH_CP_JUMP_BF) {
+        cur = cp_jump_cands_bf(S, ent, des_v, n_cones, cur, part, nparts);
+        return cur < t_end ? cur : -1;
+    }
     const int n_rays = 2 * n_cones, npairs = n_rays * n_rays;
     const float inv_nr = 1.0f / (float)n_rays;
     int qn = 0;
@@ -865,6 +1043,11 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
             return des_v;
         }
 
+        if constexpr(G == 64 && NH_CP_BF && NH_CP_TC) {
+            // the cones in test order, for the test steps of the wave-wide search
+            if(gl < n_cones) { const int so = S.ord[gl]; S.tc[2 * gl] = S.cones[2 * so]; S.tc[2 * gl + 1] = S.cones[2 * so + 1]; }
+            wave_sync();
+        }
         cp_bound B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.nfound = 0; B.sb = 0;
 #ifdef NH_CP_STATS
         B.it = B.busy = B.ex = B.out = B.passes = B.cols = B.cands = B.queued = 0; B.cw = B.cg = 0;
@@ -1075,6 +1258,10 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
             if(keep) S.ord[__popcll(mk & lt_mask)] = slot_r;
             n_test = __popcll(mk);
             wave_sync();
+            if constexpr(G == 64 && NH_CP_BF && NH_CP_TC) {
+                if(gl < n_test) { const int so = S.ord[gl]; S.tc[2 * gl] = S.cones[2 * so]; S.tc[2 * gl + 1] = S.cones[2 * so + 1]; }
+                wave_sync();
+            }
             CP_STAT(B.sb, 4, n_test);
         }
 #endif

@@ -1216,6 +1216,16 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
     // unit_end[k] = units of the sub-lists up to and including k (k = order * NH_WL_SUB + sub)
     __shared__ int32_t unit_end[4 * NH_WL_SUB];
     __shared__ int32_t sub_cnt[4 * NH_WL_SUB];
+    // HOLE INHERITANCE.  This launch reaches the device a few microseconds before k_cp_heavy (which waits
+    // for an event of the other stream) and fills every SIMD; k_cp_heavy's persistent workgroups move into the
+    // register and LDS ranges its workgroups leave behind and keep them for the whole launch.  A hole smaller than a
+    // k_cp_heavy wave (128 registers) or workgroup is lost to it: 119 instead of 121 registers here (120 instead of
+    // 128 allocated), or 37.5 KB of LDS there against 36 here, cost the crowded world a quarter of k_cp_heavy's
+    // waves (4.9 -> 6.1 ms per tick, profiles/r04_ab_hole_inheritance.txt).  So: this kernel allocates the same 128
+    // registers per lane (v127 named as clobbered), and its workgroup owns at least k_cp_heavy's LDS.
+    asm volatile("" ::: "v127");
+    static_assert(sizeof(cp_lds<16>) * CPR_WAVES * 4 + 8 * 4 * NH_WL_SUB >= sizeof(cp_lds<64>) * CP_WAVES + 8 * NH_WL_SUB + 4 + sizeof(cp_team),
+                  "k_cp_rows' workgroup must own at least k_cp_heavy's LDS (hole inheritance)");
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ntab = nlists * NH_WL_SUB;
     // (usually nothing to do for the retry launch: one parallel look)

@@ -38,8 +38,11 @@ def run(names, rounds=3, extra=()):
     for _ in range(rounds):
         for n in names:
             env = dict(os.environ)
-            if n != "base":
-                env["NAVHIP_LIB"] = os.path.join(OUT, "libnavhip_%s.so" % n)
+            lib, _, order = n.partition("@")          # NAME@K: the variant with NAVHIP_CP_ORDER=K
+            if order:
+                env["NAVHIP_CP_ORDER"] = order
+            if lib != "base":
+                env["NAVHIP_LIB"] = os.path.join(OUT, "libnavhip_%s.so" % lib)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(extra), env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
             d = json.loads(r.stdout.strip().splitlines()[-1])
