@@ -44,6 +44,24 @@ static void move_hip_attrs_changed(void)      /* (declared ahead in the harness:
         s_hip_attr_epoch = 1;
 }
 
+/* The loops over entities and work items below are range functions: the engine forks them over its worker tasks
+ * the way move_submit_cpu_work (:3751-3783) forks move_velocity_work; a host registers that fork-join here (the
+ * harness: oracle/ref/ref_move.c).  Without one they run on the calling task. */
+static double hip_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+typedef void (*hip_range_fn)(int begin, int end, void *arg);
+static void (*s_hip_parallel_for)(hip_range_fn fn, int n, void *arg);
+static int s_hip_parallel_min = 8192;                 /* shorter loops stay on the calling task */
+void move_hip_set_parallel_for(void (*pf)(hip_range_fn fn, int n, void *arg), int min_items)
+{
+    s_hip_parallel_for = pf;
+    s_hip_parallel_min = min_items > 0 ? min_items : 8192;
+}
+static void hip_for(hip_range_fn fn, int n, void *arg)
+{
+    if(s_hip_parallel_for && n >= s_hip_parallel_min) s_hip_parallel_for(fn, n, arg);
+    else if(n > 0) fn(0, n, arg);
+}
+
 static int cmp_u32(const void *a, const void *b)
 {
     uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
@@ -64,7 +82,7 @@ struct hip_snap {
     size_t       nflocks;
     float       *flock_target;
     int32_t     *flock_offsets, *flock_members;
-    bool         any_arrival;
+    bool         any_arrival, any_form;
 };
 #define DENSE(S, uid) kh_value((S)->dense, kh_get(id, (S)->dense, (uid)))
 
@@ -72,10 +90,22 @@ struct hip_snap {
  * and building the map were two thirds of the 4.7 ms a tick spent filling the snapshot (bench.py `dropin`).  They
  * are kept between ticks and rebuilt when the set has another size or a cached uid is gone from the tick's
  * position table (an equal count with every cached uid present IS the same set). */
-static struct { int n; uint32_t *uids; khash_t(id) *dense; } s_hip_set;
+static struct {
+    int n; uint32_t *uids; khash_t(id) *dense;
+    /* where each uid was found last tick in the four per-entity tables: a snapshot table is a kh_copy of a table
+     * that rarely rehashes, so the bucket is still the uid's (checked: occupied + same key) and the lookup is one
+     * indexed read instead of a hash and a probe sequence; any miss falls back to kh_get */
+    khint_t *it_pos, *it_flags, *it_rad, *it_state;
+    /* the flock tables of the snapshot, kept while the flock epoch (move_hip_attrs_changed) and the set stand */
+    uint32_t flock_epoch; size_t nflocks; int32_t *flock, *flock_offsets, *flock_members;
+} s_hip_set;
+#define HIP_IT(h, name, cache, uid) \
+    ((cache) < kh_end(h) && kh_exist(h, cache) && kh_key(h, cache) == (uid) ? (cache) : ((cache) = kh_get(name, h, uid)))
 
+static uint32_t s_hip_set_epoch;
 static void hip_set_rebuild(const struct move_gamestate *gs)
 {
+    s_hip_set_epoch++;
     const int n = (int)kh_size(gs->positions);
     free(s_hip_set.uids);
     if(s_hip_set.dense) kh_destroy(id, s_hip_set.dense);
@@ -92,6 +122,97 @@ static void hip_set_rebuild(const struct move_gamestate *gs)
         khiter_t it = kh_put(id, s_hip_set.dense, s_hip_set.uids[i], &ret);
         kh_value(s_hip_set.dense, it) = i;
     }
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    s_hip_set.it_pos = realloc(s_hip_set.it_pos, m * sizeof(khint_t));
+    s_hip_set.it_flags = realloc(s_hip_set.it_flags, m * sizeof(khint_t));
+    s_hip_set.it_rad = realloc(s_hip_set.it_rad, m * sizeof(khint_t));
+    s_hip_set.it_state = realloc(s_hip_set.it_state, m * sizeof(khint_t));
+    s_hip_set.flock = realloc(s_hip_set.flock, m * sizeof(int32_t));
+    s_hip_set.flock_members = realloc(s_hip_set.flock_members, m * sizeof(int32_t));
+    memset(s_hip_set.it_pos, 0xff, m * sizeof(khint_t)); memset(s_hip_set.it_flags, 0xff, m * sizeof(khint_t));
+    memset(s_hip_set.it_rad, 0xff, m * sizeof(khint_t)); memset(s_hip_set.it_state, 0xff, m * sizeof(khint_t));
+    s_hip_set.flock_epoch = 0;                        /* (0 is never a valid epoch: the flock tables are rebuilt) */
+}
+
+/* Every per-tick array lives in one arena that only grows (s_hip_arena): a tick of 100 000 entities used to
+ * calloc and free two dozen arrays of 0.4-0.8 MB -- each an mmap, its page faults and an munmap -- which was a
+ * third of the time the binding spent on the host (bench.py `dropin`).  Nothing relies on zeroed memory any more:
+ * the entity loop below writes every column of every row. */
+static struct { char *base; size_t cap, used; } s_hip_arena;
+static void hip_arena_reset(size_t need)
+{
+    if(need > s_hip_arena.cap) {
+        free(s_hip_arena.base);
+        s_hip_arena.cap = need + need / 4;
+        s_hip_arena.base = malloc(s_hip_arena.cap);
+    }
+    s_hip_arena.used = 0;
+}
+static void *hip_arena(size_t bytes)
+{
+    bytes = (bytes + 63) & ~(size_t)63;
+    assert(s_hip_arena.used + bytes <= s_hip_arena.cap);
+    void *p = s_hip_arena.base + s_hip_arena.used;
+    s_hip_arena.used += bytes;
+    return p;
+}
+/* bytes of the arena one tick may take for n entities, F flocks (both passes: velocity or state) */
+static size_t hip_arena_need(size_t n, size_t F)
+{
+    return (n + 16) * (4 * 34 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 48;
+}
+
+static void hip_check_range(int begin, int end, void *arg)
+{
+    const struct move_gamestate *gs = &s_move_work.gamestate;
+    for(int i = begin; i < end; i++)
+        if(HIP_IT(gs->positions, pos, s_hip_set.it_pos[i], s_hip_set.uids[i]) == kh_end(gs->positions)) {
+            __atomic_store_n((int*)arg, 1, __ATOMIC_RELAXED);
+            return;
+        }
+}
+
+static void hip_fill_range(int begin, int end, void *arg)
+{
+    struct hip_snap *S = arg;
+    const struct move_gamestate *gs = &s_move_work.gamestate;
+    bool any_arrival = false, any_form = false;
+    for(int i = begin; i < end; i++) {
+        const uint32_t uid = S->uids[i];
+        khiter_t k = HIP_IT(gs->positions, pos, s_hip_set.it_pos[i], uid);        /* G_Pos_GetXZFrom, position.c:196 */
+        assert(k != kh_end(gs->positions));
+        const vec3_t p = kh_val(gs->positions, k);
+        S->pos[2 * i] = p.x; S->pos[2 * i + 1] = p.z;
+        k = HIP_IT(gs->flags, id, s_hip_set.it_flags[i], uid);                    /* G_FlagsGetFrom, game.c:2391 */
+        assert(k != kh_end(gs->flags));
+        S->flags[i] = kh_value(gs->flags, k);
+        k = HIP_IT(gs->sel_radiuses, range, s_hip_set.it_rad[i], uid);            /* G_GetSelectionRadiusFrom, game.c:2862 */
+        assert(k != kh_end(gs->sel_radiuses));
+        S->radius[i] = kh_value(gs->sel_radiuses, k);
+        S->arr_flags[i] = 0;
+        k = HIP_IT(s_entity_state_table, state, s_hip_set.it_state[i], uid);
+        if(k == kh_end(s_entity_state_table)) {
+            S->state[i] = STATE_ARRIVED;              /* no movestate: a still obstacle */
+            S->vel[2 * i] = S->vel[2 * i + 1] = 0.0f;
+            S->max_speed[i] = 0.0f;
+            S->sink[2 * i] = S->sink[2 * i + 1] = 0.0f;
+            continue;
+        }
+        const struct movestate *ms = &kh_value(s_entity_state_table, k);
+        S->state[i] = (uint8_t)ms->state;
+        S->vel[2 * i] = ms->velocity.x; S->vel[2 * i + 1] = ms->velocity.z;
+        S->max_speed[i] = ms->max_speed;
+        /* struct arrival_unit_state: committed to a valid slot (unit_committed, arrival.c:90) */
+        if((ms->arrival.substate == ARRIVAL_SUBSTATE_SEEK || ms->arrival.substate == ARRIVAL_SUBSTATE_SEEK_ARMED)
+        && ms->arrival.sink_valid) {
+            S->arr_flags[i] |= 1;
+            any_arrival = true;
+        }
+        S->sink[2 * i] = ms->arrival.sink.x; S->sink[2 * i + 1] = ms->arrival.sink.z;
+        any_form = any_form || ms->state == STATE_MOVING_IN_FORMATION || ms->state == STATE_ARRIVING_TO_CELL;
+    }
+    if(any_arrival) __atomic_store_n(&S->any_arrival, true, __ATOMIC_RELAXED);
+    if(any_form) __atomic_store_n(&S->any_form, true, __ATOMIC_RELAXED);
 }
 
 static void hip_snap_fill(struct hip_snap *S)
@@ -102,69 +223,91 @@ static void hip_snap_fill(struct hip_snap *S)
     if(!s_hip_set.dense || s_hip_set.n != n)
         hip_set_rebuild(gs);
     else {
-        for(int i = 0; i < n; i++)
-            if(kh_get(pos, gs->positions, s_hip_set.uids[i]) == kh_end(gs->positions)) { hip_set_rebuild(gs); break; }
+        /* (an equal count with every cached uid present IS the same set) */
+        int gone = 0;
+        hip_for(hip_check_range, n, &gone);
+        if(gone) hip_set_rebuild(gs);
     }
     S->uids = s_hip_set.uids;
     S->dense = s_hip_set.dense;
-    S->pos = calloc(2 * n + 2, sizeof(float)); S->vel = calloc(2 * n + 2, sizeof(float));
-    S->radius = calloc(n + 1, sizeof(float)); S->max_speed = calloc(n + 1, sizeof(float));
-    S->sink = calloc(2 * n + 2, sizeof(float));
-    S->flags = calloc(n + 1, sizeof(uint32_t));
-    S->state = calloc(n + 1, 1); S->arr_flags = calloc(n + 1, 1);
-    S->flock = malloc(sizeof(int32_t) * (n + 1));
     S->nflocks = vec_size(&s_flocks);
-    S->flock_target = calloc(2 * (S->nflocks ? S->nflocks : 1), sizeof(float));
-    S->flock_offsets = calloc(S->nflocks + 1, sizeof(int32_t));
-    S->flock_members = malloc(sizeof(int32_t) * (n > 0 ? n : 1));
-
-    for(int i = 0; i < n; i++) {
-        const uint32_t uid = S->uids[i];
-        vec2_t p = G_Pos_GetXZFrom(gs->positions, uid);
-        S->pos[2 * i] = p.x; S->pos[2 * i + 1] = p.z;
-        S->flags[i] = G_FlagsGetFrom(gs->flags, uid);
-        S->radius[i] = G_GetSelectionRadiusFrom(gs->sel_radiuses, uid);
-        S->flock[i] = -1;
-        S->state[i] = STATE_ARRIVED;                  /* no movestate: a still obstacle */
-        khiter_t k = kh_get(state, s_entity_state_table, uid);
-        if(k == kh_end(s_entity_state_table))
-            continue;
-        const struct movestate *ms = &kh_value(s_entity_state_table, k);
-        S->state[i] = (uint8_t)ms->state;
-        S->vel[2 * i] = ms->velocity.x; S->vel[2 * i + 1] = ms->velocity.z;
-        S->max_speed[i] = ms->max_speed;
-        /* struct arrival_unit_state: committed to a valid slot (unit_committed, arrival.c:90) */
-        if((ms->arrival.substate == ARRIVAL_SUBSTATE_SEEK || ms->arrival.substate == ARRIVAL_SUBSTATE_SEEK_ARMED)
-        && ms->arrival.sink_valid) {
-            S->arr_flags[i] |= 1;
-            S->any_arrival = true;
+    hip_arena_reset(hip_arena_need((size_t)n, S->nflocks));
+    S->pos = hip_arena(sizeof(float) * (2 * n + 2)); S->vel = hip_arena(sizeof(float) * (2 * n + 2));
+    S->radius = hip_arena(sizeof(float) * (n + 1)); S->max_speed = hip_arena(sizeof(float) * (n + 1));
+    S->sink = hip_arena(sizeof(float) * (2 * n + 2));
+    S->flags = hip_arena(sizeof(uint32_t) * (n + 1));
+    S->state = hip_arena(n + 1); S->arr_flags = hip_arena(n + 1);
+    S->flock_target = hip_arena(sizeof(float) * 2 * (S->nflocks ? S->nflocks : 1));
+    hip_for(hip_fill_range, n, S);
+    /* flocks: members in kh_foreach order of flock->ents (the order cohesion_force sums in, :1660).  Membership
+     * only changes where the flock epoch is bumped (see move_hip_attrs_changed): the three tables are kept */
+    if(s_hip_set.flock_epoch != s_hip_attr_epoch || s_hip_set.nflocks != S->nflocks) {
+        s_hip_set.flock_offsets = realloc(s_hip_set.flock_offsets, sizeof(int32_t) * (S->nflocks + 1));
+        for(int i = 0; i < n; i++) s_hip_set.flock[i] = -1;
+        int at = 0;
+        for(size_t f = 0; f < S->nflocks; f++) {
+            const struct flock *fl = &vec_AT(&s_flocks, f);
+            s_hip_set.flock_offsets[f] = at;
+            uint32_t curr;
+            kh_foreach_key(fl->ents, curr, {
+                const int i = DENSE(S, curr);
+                s_hip_set.flock_members[at++] = i;
+                s_hip_set.flock[i] = (int32_t)f;
+            });
         }
-        S->sink[2 * i] = ms->arrival.sink.x; S->sink[2 * i + 1] = ms->arrival.sink.z;
+        s_hip_set.flock_offsets[S->nflocks] = at;
+        s_hip_set.nflocks = S->nflocks;
+        s_hip_set.flock_epoch = s_hip_attr_epoch;
     }
-    /* flocks: members in kh_foreach order of flock->ents (the order cohesion_force sums in, :1660) */
-    int at = 0;
+    S->flock = s_hip_set.flock; S->flock_offsets = s_hip_set.flock_offsets; S->flock_members = s_hip_set.flock_members;
     for(size_t f = 0; f < S->nflocks; f++) {
         const struct flock *fl = &vec_AT(&s_flocks, f);
         S->flock_target[2 * f] = fl->target_xz.x; S->flock_target[2 * f + 1] = fl->target_xz.z;
-        S->flock_offsets[f] = at;
-        uint32_t curr;
-        kh_foreach_key(fl->ents, curr, {
-            const int i = DENSE(S, curr);
-            S->flock_members[at++] = i;
-            S->flock[i] = (int32_t)f;
-            const struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,
-                Entity_NavLayerWithRadius(S->flags[i], S->radius[i]));
-            if(as && as->phase == ARRIVAL_PHASE_FILLING) { S->arr_flags[i] |= 2; S->any_arrival = true; }
-        });
+        /* members of an arrival group that is filling (per flock and nav layer; usually none) */
+        for(int layer = 0; layer < NAV_LAYER_MAX; layer++) {
+            const struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival, (enum nav_layer)layer);
+            if(!as || as->phase != ARRIVAL_PHASE_FILLING)
+                continue;
+            for(int m = S->flock_offsets[f]; m < S->flock_offsets[f + 1]; m++) {
+                const int i = S->flock_members[m];
+                if(Entity_NavLayerWithRadius(S->flags[i], S->radius[i]) == (enum nav_layer)layer) {
+                    S->arr_flags[i] |= 2; S->any_arrival = true;
+                }
+            }
+        }
     }
-    S->flock_offsets[S->nflocks] = at;
 }
 
 static void hip_snap_free(struct hip_snap *S)
 {
-    free(S->pos); free(S->vel); free(S->radius); free(S->max_speed); free(S->sink);
-    free(S->flags); free(S->state); free(S->arr_flags); free(S->flock); free(S->flock_target);
-    free(S->flock_offsets); free(S->flock_members);
+    (void)S;                                          /* (the arena is reused by the next tick) */
+}
+
+/* dense index of every work item, kept between ticks: the work list is rebuilt every tick in the same entity
+ * order (movement.c:4129-4170), so an index is valid while the item still carries the uid it was looked up for */
+static struct { size_t cap; uint32_t *uid; int32_t *idx; uint32_t set_epoch; } s_hip_witem;
+static void hip_work_dense_prepare(void)              /* (once per pass, on the calling task) */
+{
+    if(s_move_work.nwork > s_hip_witem.cap) {
+        const size_t cap = s_move_work.nwork;
+        s_hip_witem.uid = realloc(s_hip_witem.uid, cap * sizeof(uint32_t));
+        s_hip_witem.idx = realloc(s_hip_witem.idx, cap * sizeof(int32_t));
+        for(size_t k = s_hip_witem.cap; k < cap; k++) s_hip_witem.idx[k] = -1;
+        s_hip_witem.cap = cap;
+    }
+    if(s_hip_witem.set_epoch != s_hip_set_epoch) {
+        for(size_t k = 0; k < s_hip_witem.cap; k++) s_hip_witem.idx[k] = -1;
+        s_hip_witem.set_epoch = s_hip_set_epoch;
+    }
+}
+static inline int hip_work_dense(const struct hip_snap *S, int w)
+{
+    const uint32_t uid = s_move_work.in[w].ent_uid;
+    if(s_hip_witem.idx[w] < 0 || s_hip_witem.uid[w] != uid) {
+        s_hip_witem.uid[w] = uid;
+        s_hip_witem.idx[w] = DENSE(S, uid);
+    }
+    return s_hip_witem.idx[w];
 }
 
 /* the snapshot half of a navhip_world */
@@ -193,98 +336,174 @@ static void hip_snap_world(const struct hip_snap *S, navhip_world *W)
  * since the last reset in {filling the snapshot + work-item arrays, navhip_agent_step_submit .. _wait (staging,
  * PCIe both ways, the kernels), scattering the results back into s_move_work.out[]}, and the calls */
 static double s_hip_times[4];
-static double hip_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 void move_hip_times(double out[4], int reset)
 {
     memcpy(out, s_hip_times, sizeof(s_hip_times));
     if(reset) memset(s_hip_times, 0, sizeof(s_hip_times));
 }
 
+/* (harness only: time the host side without a device -- the step itself is skipped, its outputs read as zero) */
+static bool s_hip_dry_run;
+void move_hip_set_dry_run(bool on) { s_hip_dry_run = on; }
+
+/* one velocity pass: what its range functions share */
+struct hip_vel_pass {
+    struct hip_snap *S;
+    int    begin_idx;
+    float *speed, *vdes, *cell_pos, *f_coh, *f_align, *f_drag;
+    uint8_t *los, *form_ready;
+    bool   any_form, sample;
+    const float *out_vel, *out_vdes; const uint8_t *status;
+    int    unsupported;                               /* a work item came back NAVHIP_ST_UNSUPPORTED */
+    int    n_fallback; int32_t *fallback;             /* work items the host samples and steps itself */
+    long   sampled;
+};
+
+static void hip_vel_items_range(int begin, int end, void *arg)
+{
+    struct hip_vel_pass *V = arg;
+    const struct hip_snap *S = V->S;
+    for(int k = begin; k < end; k++) {
+        const int w = V->begin_idx + k;
+        const struct move_work_in *in = &s_move_work.in[w];
+        const int i = hip_work_dense(S, w);
+        V->vdes[2 * i] = in->ent_des_v.x; V->vdes[2 * i + 1] = in->ent_des_v.z;
+        V->speed[i] = in->speed;
+        V->los[i] = in->has_dest_los;
+        if(V->any_form) {
+            V->form_ready[i] = in->fstate.assignment_ready;
+            V->cell_pos[2 * i] = in->cell_pos.x; V->cell_pos[2 * i + 1] = in->cell_pos.z;
+            V->f_coh[2 * i] = in->fstate.normal_cohesion_force.x; V->f_coh[2 * i + 1] = in->fstate.normal_cohesion_force.z;
+            V->f_align[2 * i] = in->fstate.normal_align_force.x; V->f_align[2 * i + 1] = in->fstate.normal_align_force.z;
+            V->f_drag[2 * i] = in->fstate.normal_drag_force.x; V->f_drag[2 * i + 1] = in->fstate.normal_drag_force.z;
+        }
+        /* device sampling: the point-seeking agents (the default arm of ent_desired_velocity, :1510-1521) */
+        if(V->sample && S->state[i] == STATE_MOVING && S->flock[i] >= 0 && !(S->arr_flags[i] & 2))
+            V->vdes[2 * i] = NAN;
+    }
+}
+
+static void hip_vel_scatter_range(int begin, int end, void *arg)
+{
+    struct hip_vel_pass *V = arg;
+    const struct hip_snap *S = V->S;
+    long sampled = 0;
+    for(int k = begin; k < end; k++) {
+        const int w = V->begin_idx + k;
+        const int i = hip_work_dense(S, w);
+        if(V->status[i] & NAVHIP_ST_UNSUPPORTED) { __atomic_store_n(&V->unsupported, 1, __ATOMIC_RELAXED); return; }
+        if(isnan(V->vdes[2 * i]) && (V->status[i] & (NAVHIP_ST_FIELD_MISS | NAVHIP_ST_FIELD_NONE))) {
+            /* (the planner / repair cases: the calling task handles them after the join) */
+            V->fallback[__atomic_fetch_add(&V->n_fallback, 1, __ATOMIC_RELAXED)] = w;
+            continue;
+        }
+        if(isnan(V->vdes[2 * i])) {
+            /* what compute_desired_velocity (:4174-4175) would have left for the state update */
+            sampled++;
+            s_move_work.in[w].ent_des_v = (vec2_t){V->out_vdes[2 * i], V->out_vdes[2 * i + 1]};
+            s_move_work.out[w].ent_des_v = s_move_work.in[w].ent_des_v;
+        }
+        s_move_work.out[w].ent_vel = (vec2_t){V->out_vel[2 * i], V->out_vel[2 * i + 1]};
+    }
+    if(sampled) __atomic_fetch_add(&V->sampled, sampled, __ATOMIC_RELAXED);
+}
+
+static int cmp_i32(const void *a, const void *b) { return (*(const int32_t*)a > *(const int32_t*)b) - (*(const int32_t*)a < *(const int32_t*)b); }
+
+
 static bool move_hip_velocity_work(int begin_idx, int end_idx)
 {
-    navhip_ctx *ctx = N_HIP_Ctx();
-    if(!ctx || end_idx < begin_idx)
+    navhip_ctx *ctx = s_hip_dry_run ? NULL : N_HIP_Ctx();
+    if((!ctx && !s_hip_dry_run) || end_idx < begin_idx)
         return false;
     const double t_begin = hip_now();
     const struct move_gamestate *gs = &s_move_work.gamestate;
     struct hip_snap S;
     hip_snap_fill(&S);
-    const int n = S.n;
+    const int n = S.n, nitems = end_idx - begin_idx + 1;
 
-    float *speed = calloc(n + 1, sizeof(float));
-    uint8_t *los = calloc(n + 1, 1), *form_ready = calloc(n + 1, 1);
-    float *vdes = calloc(2 * n + 2, sizeof(float)), *cell_pos = calloc(2 * n + 2, sizeof(float));
-    float *f_coh = calloc(2 * n + 2, sizeof(float)), *f_align = calloc(2 * n + 2, sizeof(float));
-    float *f_drag = calloc(2 * n + 2, sizeof(float));
-
-    /* work items */
-    int lo = n, hi = -1;
-    bool any_form = false, ok_pool = true;
-    for(int w = begin_idx; w <= end_idx; w++) {
-        const struct move_work_in *in = &s_move_work.in[w];
-        const int i = DENSE(&S, in->ent_uid);
-        vdes[2 * i] = in->ent_des_v.x; vdes[2 * i + 1] = in->ent_des_v.z;
-        speed[i] = in->speed;
-        los[i] = in->has_dest_los;
-        form_ready[i] = in->fstate.assignment_ready;
-        cell_pos[2 * i] = in->cell_pos.x; cell_pos[2 * i + 1] = in->cell_pos.z;
-        f_coh[2 * i] = in->fstate.normal_cohesion_force.x; f_coh[2 * i + 1] = in->fstate.normal_cohesion_force.z;
-        f_align[2 * i] = in->fstate.normal_align_force.x; f_align[2 * i + 1] = in->fstate.normal_align_force.z;
-        f_drag[2 * i] = in->fstate.normal_drag_force.x; f_drag[2 * i + 1] = in->fstate.normal_drag_force.z;
-        any_form = any_form || S.state[i] == STATE_MOVING_IN_FORMATION || S.state[i] == STATE_ARRIVING_TO_CELL;
-        if(i < lo) lo = i;
-        if(i > hi) hi = i;
+    struct hip_vel_pass V;
+    memset(&V, 0, sizeof(V));
+    V.S = &S; V.begin_idx = begin_idx; V.any_form = S.any_form;
+    V.speed = hip_arena(sizeof(float) * (n + 1));
+    V.los = hip_arena(n + 1);
+    V.vdes = hip_arena(sizeof(float) * (2 * n + 2));
+    /* rows without a work item inside the stepped slab (other slabs of a threaded split, entities without a
+     * movestate) are stepped too and their results dropped: they only need defined inputs */
+    memset(V.speed, 0, sizeof(float) * (n + 1)); memset(V.los, 0, n + 1); memset(V.vdes, 0, sizeof(float) * (2 * n + 2));
+    if(V.any_form) {
+        V.form_ready = hip_arena(n + 1); memset(V.form_ready, 0, n + 1);
+        V.cell_pos = hip_arena(sizeof(float) * (2 * n + 2)); memset(V.cell_pos, 0, sizeof(float) * (2 * n + 2));
+        V.f_coh = hip_arena(sizeof(float) * (2 * n + 2)); memset(V.f_coh, 0, sizeof(float) * (2 * n + 2));
+        V.f_align = hip_arena(sizeof(float) * (2 * n + 2)); memset(V.f_align, 0, sizeof(float) * (2 * n + 2));
+        V.f_drag = hip_arena(sizeof(float) * (2 * n + 2)); memset(V.f_drag, 0, sizeof(float) * (2 * n + 2));
     }
-    /* the device steps the contiguous uid slab [lo, hi]; entities inside it that carry no work item
-     * (other slabs of a threaded split) are stepped too and their results dropped */
-    const bool sample = s_hip_sample_on_device && N_HIP_PoolOn();
+    bool sample = !s_hip_dry_run && s_hip_sample_on_device && N_HIP_PoolOn();
     if(sample) {
         /* flock index = mapping row of the resident pool: announce every flock's destination, flush the
          * mappings the planner recorded since the last tick, and leave the sampling of the point-seeking
-         * agents (the default arm of ent_desired_velocity, :1510-1521) to the device: vdes.x = NaN */
+         * agents to the device: vdes.x = NaN */
         dest_id_t *fdest = malloc(sizeof(dest_id_t) * (S.nflocks ? S.nflocks : 1));
         for(size_t f = 0; f < S.nflocks; f++)
             fdest[f] = vec_AT(&s_flocks, f).dest_id;
         N_HIP_PoolSetRows(move_hip_nav_private(gs->map), (int)S.nflocks, fdest);
         free(fdest);
-        if(!N_HIP_PoolSync()) {
-            ok_pool = false;
-        }else{
-            for(int w = begin_idx; w <= end_idx; w++) {
-                const int i = DENSE(&S, s_move_work.in[w].ent_uid);
-                if(S.state[i] == STATE_MOVING && S.flock[i] >= 0 && !(S.arr_flags[i] & 2))
-                    vdes[2 * i] = NAN;
-            }
-        }
+        sample = N_HIP_PoolSync();
+    }
+    V.sample = sample;
+
+    /* work items */
+    hip_work_dense_prepare();
+    hip_for(hip_vel_items_range, nitems, &V);
+    /* the device steps the contiguous uid slab [lo, hi]; entities inside it that carry no work item
+     * (other slabs of a threaded split) are stepped too and their results dropped */
+    int lo = n, hi = -1;
+    for(int w = begin_idx; w <= end_idx; w++) {
+        const int i = s_hip_witem.idx[w];
+        if(i < lo) lo = i;
+        if(i > hi) hi = i;
     }
     navhip_world W;
     hip_snap_world(&S, &W);
-    W.speed = speed; W.has_dest_los = los; W.vdes_xz = vdes;
-    if(sample && ok_pool)
+    W.speed = V.speed; W.has_dest_los = V.los; W.vdes_xz = V.vdes;
+    if(sample)
         W.n_field_slots = NAVHIP_POOL_RESIDENT;
     W.work_begin = lo; W.work_end = hi + 1;
-    if(any_form) {
-        W.form_ready = form_ready; W.cell_pos_xz = cell_pos; W.form_cohesion_xz = f_coh;
-        W.form_align_xz = f_align; W.form_drag_xz = f_drag;
+    if(V.any_form) {
+        W.form_ready = V.form_ready; W.cell_pos_xz = V.cell_pos; W.form_cohesion_xz = V.f_coh;
+        W.form_align_xz = V.f_align; W.form_drag_xz = V.f_drag;
     }
     if(S.any_arrival) { W.arrival_sink_xz = S.sink; W.arrival_flags = S.arr_flags; }
 
-    float *out_vel = calloc(2 * n + 2, sizeof(float)), *out_vdes = calloc(2 * n + 2, sizeof(float));
-    uint8_t *status = calloc(n + 1, 1);
+    /* (navhip_agent_step writes the rows of the stepped slab [lo, hi]: every row read below) */
+    float *out_vel = hip_arena(sizeof(float) * (2 * n + 2)), *out_vdes = hip_arena(sizeof(float) * (2 * n + 2));
+    uint8_t *status = hip_arena(n + 1);
+    V.fallback = hip_arena(sizeof(int32_t) * (nitems + 1));
     navhip_step_out O = {out_vel, NULL, out_vdes, NULL, status};
     const double t_filled = hip_now();
-    bool ok = hi >= lo && navhip_agent_step_submit(ctx, &W, &O) == NAVHIP_OK;
-    /* (the nav task would Task_AwaitEvent(EVENT_UPDATE_START) here, like the GL path :4212-4233) */
-    if(ok) ok = navhip_agent_step_wait(ctx) == NAVHIP_OK;
+    bool ok = hi >= lo;
+    if(s_hip_dry_run) {
+        memset(out_vel, 0, sizeof(float) * (2 * n + 2)); memset(out_vdes, 0, sizeof(float) * (2 * n + 2));
+        memset(status, 0, n + 1);
+    }else{
+        ok = ok && navhip_agent_step_submit(ctx, &W, &O) == NAVHIP_OK;
+        /* (the nav task would Task_AwaitEvent(EVENT_UPDATE_START) here, like the GL path :4212-4233) */
+        if(ok) ok = navhip_agent_step_wait(ctx) == NAVHIP_OK;
+    }
     const double t_stepped = hip_now();
     if(ok) {
         s_hip_stats[2]++;
-        for(int w = begin_idx; w <= end_idx; w++) {
-            const int i = DENSE(&S, s_move_work.in[w].ent_uid);
-            if(status[i] & NAVHIP_ST_UNSUPPORTED) { ok = false; break; }
-            if(isnan(vdes[2 * i]) && (status[i] & (NAVHIP_ST_FIELD_MISS | NAVHIP_ST_FIELD_NONE))) {
-                /* the cases of nav.c:3483-3554 that need the planner or a repair build: the host samples
-                 * (its builds go through the binding and land in the pool) and steps this one agent */
+        V.out_vel = out_vel; V.out_vdes = out_vdes; V.status = status;
+        hip_for(hip_vel_scatter_range, nitems, &V);
+        if(V.unsupported)
+            ok = false;
+        else {
+            s_hip_stats[0] += V.sampled;
+            /* the cases of nav.c:3483-3554 that need the planner or a repair build: the host samples (its builds
+             * go through the binding and land in the pool) and steps these agents itself, in work-item order */
+            qsort(V.fallback, V.n_fallback, sizeof(int32_t), cmp_i32);
+            for(int k = 0; k < V.n_fallback; k++) {
+                const int w = V.fallback[k];
                 struct move_work_in *in = &s_move_work.in[w];
                 const struct flock *fl = flock_for_ent(in->ent_uid);
                 in->ent_des_v = M_NavDesiredPointSeekVelocity(gs->map, fl->dest_id, in->cp_ent.xz_pos, fl->target_xz);
@@ -292,20 +511,10 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
                 in->dyn_neighbs->size = 0; in->stat_neighbs->size = 0;
                 move_velocity_work(w, w);
                 s_hip_stats[1]++;
-                continue;
             }
-            if(isnan(vdes[2 * i])) {
-                /* what compute_desired_velocity (:4174-4175) would have left for the state update */
-                s_hip_stats[0]++;
-                s_move_work.in[w].ent_des_v = (vec2_t){out_vdes[2 * i], out_vdes[2 * i + 1]};
-                s_move_work.out[w].ent_des_v = s_move_work.in[w].ent_des_v;
-            }
-            s_move_work.out[w].ent_vel = (vec2_t){out_vel[2 * i], out_vel[2 * i + 1]};
         }
     }
     hip_snap_free(&S);
-    free(speed); free(los); free(form_ready); free(vdes); free(cell_pos); free(f_coh); free(f_align); free(f_drag);
-    free(out_vel); free(out_vdes); free(status);
     s_hip_times[0] += t_filled - t_begin; s_hip_times[1] += t_stepped - t_filled;
     s_hip_times[2] += hip_now() - t_stepped; s_hip_times[3] += 1.0;
     return ok;
@@ -353,14 +562,16 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         s_hip_su_state = realloc(s_hip_su_state, s_hip_su_cap);
         s_hip_su_flags = realloc(s_hip_su_flags, s_hip_su_cap);
     }
-    float *new_pos = calloc(2 * n + 2, sizeof(float)), *vdes = calloc(2 * n + 2, sizeof(float));
-    uint8_t *skip = calloc(n + 1, 1);
+    float *new_pos = hip_arena(sizeof(float) * (2 * n + 2)), *vdes = hip_arena(sizeof(float) * (2 * n + 2));
+    uint8_t *skip = hip_arena(n + 1);
+    memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2)); memset(skip, 0, n + 1);
     int lo = n, hi = -1;
+    hip_work_dense_prepare();
     for(int w = begin_idx; w <= end_idx; w++) {
         const struct move_work_in *in = &s_move_work.in[w];
         const struct move_work_out *out = &s_move_work.out[w];
         const struct movestate *ms = movestate_get(in->ent_uid);
-        const int i = DENSE(&S, in->ent_uid);
+        const int i = hip_work_dense(&S, w);
         vec2_t np = new_pos_for_vel(in->ent_uid, hip_heading_gated(ms, out->ent_des_v, out->ent_vel));
         new_pos[2 * i] = np.x; new_pos[2 * i + 1] = np.z;
         vdes[2 * i] = out->ent_des_v.x; vdes[2 * i + 1] = out->ent_des_v.z;
@@ -380,11 +591,12 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     /* the two destination-only queries of arrived() (:2170), once per flock for the nav layer most of its
      * members path on (units of another layer come back as NAVHIP_SU_HOST) */
     const size_t F = S.nflocks;
-    uint8_t *flayer = calloc(F + 1, 1);
-    float   *nearest = malloc(sizeof(float) * 2 * (F + 1));
-    int32_t *toff = calloc(F + 2, sizeof(int32_t));
+    uint8_t *flayer = hip_arena(F + 1);
+    float   *nearest = hip_arena(sizeof(float) * 2 * (F + 1));
+    int32_t *toff = hip_arena(sizeof(int32_t) * (F + 2));
+    memset(flayer, 0, F + 1); memset(toff, 0, sizeof(int32_t) * (F + 2));
     const int per = FIELD_RES_R * 2 + FIELD_RES_C * 2;
-    int16_t *tiles = malloc(sizeof(int16_t) * 2 * per * (F + 1));
+    int16_t *tiles = hip_arena(sizeof(int16_t) * 2 * per * (F + 1));
     vec3_t map_pos = move_hip_map_pos(gs->map);
     for(size_t f = 0; f < F; f++) {
         const struct flock *fl = &vec_AT(&s_flocks, f);
@@ -412,19 +624,18 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     hip_snap_world(&S, &W);
     W.work_begin = lo; W.work_end = hi + 1;
     navhip_state_in in = {new_pos, vdes, skip, flayer, nearest, toff, tiles};
-    uint8_t *st = calloc(n + 1, 1), *fl = calloc(n + 1, 1);
+    uint8_t *st = hip_arena(n + 1), *fl = hip_arena(n + 1);
     bool ok = hi >= lo && navhip_state_update(ctx, &W, &in, st, fl) == NAVHIP_OK;
     if(ok) {
         s_hip_su_stats[2]++;
         for(int w = begin_idx; w <= end_idx; w++) {
-            const int i = DENSE(&S, s_move_work.in[w].ent_uid);
+            const int i = hip_work_dense(&S, w);
             s_hip_su_state[w] = st[i];
             s_hip_su_flags[w] = fl[i];
             s_hip_su_stats[(fl[i] & NAVHIP_SU_HOST) ? 1 : 0]++;
         }
     }
     hip_snap_free(&S);
-    free(new_pos); free(vdes); free(skip); free(flayer); free(nearest); free(toff); free(tiles); free(st); free(fl);
     return ok;
 }
 

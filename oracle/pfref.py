@@ -674,6 +674,15 @@ class RefMove:
         out = np.zeros((self.n, 2), np.float32)
         return lib().pfref_move_bench(_p(v), begin, end, reps, nthreads, _p(out)), out
 
+    def hip_dry_run(self, on):
+        """Host side of the WORK_TYPE_HIP arm only (no device; the step's outputs read as zero): for timing the fill."""
+        lib().pfref_move_hip_dry_run(1 if on else 0)
+
+    def hip_threads(self, nthreads, min_items=0):
+        """Fork-join width of the binding's host-side loops (the engine's worker tasks; 1 = the calling task only);
+        loops shorter than min_items (0: the binding's default, 8 192) stay on the calling task."""
+        lib().pfref_move_hip_threads(int(nthreads), int(min_items))
+
     def bench_hip(self, vdes, reps=1, begin=0, end=None):
         """The movement tick's velocity half through the binding's WORK_TYPE_HIP arm (bindings/permafrost/move_hip.c),
         `reps` times: (wall seconds, {fill, device, scatter} seconds) or None when the arm declined."""

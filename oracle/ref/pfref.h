@@ -211,6 +211,8 @@ int  pfref_hip_pool_enable(int n_slots, int n_rows);
 void pfref_hip_pool_disable(void);
 void pfref_hip_pool_stats(long out[3]);       /* host puts mirrored, mappings mirrored, fields built resident */
 void pfref_move_hip_sampling(int on);
+void pfref_move_hip_dry_run(int on);
+void pfref_move_hip_threads(int nthreads, int min_items);   /* fork-join width of the binding's host loops (1 = serial) */
 void pfref_move_hip_stats(long out[3]);       /* agents sampled on the device, host fallbacks, steps */
 
 /* --- ClearPath ---------------------------------------------------------- */

@@ -349,6 +349,90 @@ struct nav_private *move_hip_nav_private(const struct map *map) { return &((pfre
 #include "move_hip.c"
 
 void pfref_move_hip_sampling(int on)    { move_hip_set_device_sampling(on != 0); }
+void pfref_move_hip_dry_run(int on)     { move_hip_set_dry_run(on != 0); }   /* host side only, no device (timing) */
+
+/* ---- the fork-join the binding's range loops run on (move_hip_set_parallel_for) -----------------------------
+ * In the engine this is move_submit_cpu_work's fan-out over worker tasks (movement.c:3751-3783, Sched_Create +
+ * Sched_WaitOnFuture); the harness has no scheduler, so a pool of pthreads stands in: T - 1 workers asleep on a
+ * condition variable between calls (no spinning: on the virtual machines these boxes are, spinning workers kept
+ * the shares on one core), the caller takes a share itself. */
+static struct {
+    int             nthreads;                  /* workers + the caller */
+    pthread_t       th[63];
+    pthread_mutex_t mu;
+    pthread_cond_t  go, done;
+    hip_range_fn    fn; void *arg; int n;
+    volatile unsigned gen;
+    volatile int    pending;
+    bool            started;
+} s_pool = { .mu = PTHREAD_MUTEX_INITIALIZER, .go = PTHREAD_COND_INITIALIZER, .done = PTHREAD_COND_INITIALIZER };
+
+static void pool_share(int t)
+{
+    const int T = s_pool.nthreads, n = s_pool.n;
+    const int b = (int)((long)n * t / T), e = (int)((long)n * (t + 1) / T);
+    if(e > b) s_pool.fn(b, e, s_pool.arg);
+}
+
+static void *pool_worker(void *arg)
+{
+    const int t = (int)(intptr_t)arg;
+    unsigned seen = 0;
+    for(;;) {
+        if(__atomic_load_n(&s_pool.gen, __ATOMIC_ACQUIRE) == seen) {
+            pthread_mutex_lock(&s_pool.mu);
+            while(s_pool.gen == seen)
+                pthread_cond_wait(&s_pool.go, &s_pool.mu);
+            pthread_mutex_unlock(&s_pool.mu);
+        }
+        seen = __atomic_load_n(&s_pool.gen, __ATOMIC_ACQUIRE);
+        pool_share(t);
+        if(__atomic_sub_fetch(&s_pool.pending, 1, __ATOMIC_ACQ_REL) == 0) {
+            pthread_mutex_lock(&s_pool.mu);
+            pthread_cond_signal(&s_pool.done);
+            pthread_mutex_unlock(&s_pool.mu);
+        }
+    }
+    return NULL;
+}
+
+static void pool_parallel_for(hip_range_fn fn, int n, void *arg)
+{
+    if(s_pool.nthreads <= 1) { fn(0, n, arg); return; }
+    s_pool.fn = fn; s_pool.arg = arg; s_pool.n = n;
+    __atomic_store_n(&s_pool.pending, s_pool.nthreads - 1, __ATOMIC_RELEASE);
+    pthread_mutex_lock(&s_pool.mu);
+    __atomic_add_fetch(&s_pool.gen, 1, __ATOMIC_RELEASE);
+    pthread_cond_broadcast(&s_pool.go);
+    pthread_mutex_unlock(&s_pool.mu);
+    pool_share(s_pool.nthreads - 1);
+    if(__atomic_load_n(&s_pool.pending, __ATOMIC_ACQUIRE) != 0) {
+        pthread_mutex_lock(&s_pool.mu);
+        while(__atomic_load_n(&s_pool.pending, __ATOMIC_ACQUIRE) != 0)
+            pthread_cond_wait(&s_pool.done, &s_pool.mu);
+        pthread_mutex_unlock(&s_pool.mu);
+    }
+}
+
+/* threads the binding's host loops fork over (1 = the calling task only).  The workers are created once and live
+ * for the process (a later call with another count keeps the pool's); loops shorter than min_items (0: 8192)
+ * stay serial. */
+void pfref_move_hip_threads(int nthreads, int min_items)
+{
+    if(nthreads > 64) nthreads = 64;
+    if(nthreads < 1) nthreads = 1;
+    if(!s_pool.started && nthreads > 1) {
+        s_pool.nthreads = nthreads;
+        for(int t = 0; t < nthreads - 1; t++)
+            pthread_create(&s_pool.th[t], NULL, pool_worker, (void*)(intptr_t)t);
+        s_pool.started = true;
+    }
+    if(s_pool.started && nthreads != s_pool.nthreads) {
+        /* (the pool keeps its size: shares are computed from nthreads, so only report what is in use) */
+        nthreads = s_pool.nthreads;
+    }
+    move_hip_set_parallel_for(nthreads > 1 ? pool_parallel_for : NULL, min_items);
+}
 void pfref_move_hip_stats(long out[3])  { move_hip_stats(out); }
 
 /* like pfref_move_velocity, through move_hip_velocity_work; returns 0 when the device arm declined */

@@ -139,6 +139,14 @@ def test_movement_tick_drives_the_device():
         part = mv.velocity_hip(vdes, begin=300, end=900)
         sel = np.zeros(n, bool); sel[300:900] = True
         assert np.array_equal(part[sel & moving].view(np.uint32), exp[sel & moving].view(np.uint32))
+        # the binding's host loops forked over worker threads (the engine's task fan-out): the same arrays
+        mv.hip_threads(4, min_items=64)
+        try:
+            for _ in range(3):
+                forked = mv.velocity_hip(vdes)
+                assert np.array_equal(forked.view(np.uint32), got.view(np.uint32))
+        finally:
+            mv.hip_threads(1)
     finally:
         pfref.RefNav.hip_shutdown()
         pfref.RefMove.unload()
