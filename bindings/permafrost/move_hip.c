@@ -548,6 +548,34 @@ static vec2_t hip_heading_gated(const struct movestate *ms, vec2_t vdes, vec2_t 
     return err > (rolling ? MOVE_HEADING_HALT : MOVE_HEADING_RESUME) ? (vec2_t){0.0f, 0.0f} : vel;
 }
 
+struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_pos, *vdes; uint8_t *skip; };
+
+static void hip_state_items_range(int begin, int end, void *arg)
+{
+    struct hip_state_pass *T = arg;
+    const struct hip_snap *S = T->S;
+    for(int k = begin; k < end; k++) {
+        const int w = T->begin_idx + k;
+        const struct move_work_in *in = &s_move_work.in[w];
+        const struct move_work_out *out = &s_move_work.out[w];
+        const struct movestate *ms = movestate_get(in->ent_uid);
+        const int i = hip_work_dense(S, w);
+        vec2_t np = new_pos_for_vel(in->ent_uid, hip_heading_gated(ms, out->ent_des_v, out->ent_vel));
+        T->new_pos[2 * i] = np.x; T->new_pos[2 * i + 1] = np.z;
+        T->vdes[2 * i] = out->ent_des_v.x; T->vdes[2 * i + 1] = out->ent_des_v.z;
+        /* a formation member (:2427-2437) or an active arrival group (:2443): the host's arms.  So is every unit
+         * at a movement rate below 20 Hz: entity_compute_update then tests the INTERPOLATED intermediate position
+         * (interpolate_positions(next_ppos, next_npos, ms->step), :2368-2377), not pos + vel */
+        T->skip[i] = in->fstate.fid != NULL_FID || (20 / hz_count(s_move_work.hz)) > 1;
+        if(!T->skip[i] && S->flock[i] >= 0) {
+            struct flock *fl = &vec_AT(&s_flocks, S->flock[i]);
+            struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,
+                Entity_NavLayerWithRadius(S->flags[i], S->radius[i]));
+            T->skip[i] = as && G_Arrival_IsActive(as);
+        }
+    }
+}
+
 static bool move_hip_state_work(int begin_idx, int end_idx)
 {
     navhip_ctx *ctx = N_HIP_Ctx();
@@ -565,26 +593,12 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     float *new_pos = hip_arena(sizeof(float) * (2 * n + 2)), *vdes = hip_arena(sizeof(float) * (2 * n + 2));
     uint8_t *skip = hip_arena(n + 1);
     memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2)); memset(skip, 0, n + 1);
-    int lo = n, hi = -1;
     hip_work_dense_prepare();
+    struct hip_state_pass T = {&S, begin_idx, new_pos, vdes, skip};
+    hip_for(hip_state_items_range, end_idx - begin_idx + 1, &T);
+    int lo = n, hi = -1;
     for(int w = begin_idx; w <= end_idx; w++) {
-        const struct move_work_in *in = &s_move_work.in[w];
-        const struct move_work_out *out = &s_move_work.out[w];
-        const struct movestate *ms = movestate_get(in->ent_uid);
-        const int i = hip_work_dense(&S, w);
-        vec2_t np = new_pos_for_vel(in->ent_uid, hip_heading_gated(ms, out->ent_des_v, out->ent_vel));
-        new_pos[2 * i] = np.x; new_pos[2 * i + 1] = np.z;
-        vdes[2 * i] = out->ent_des_v.x; vdes[2 * i + 1] = out->ent_des_v.z;
-        /* a formation member (:2427-2437) or an active arrival group (:2443): the host's arms.  So is every unit
-         * at a movement rate below 20 Hz: entity_compute_update then tests the INTERPOLATED intermediate position
-         * (interpolate_positions(next_ppos, next_npos, ms->step), :2368-2377), not pos + vel */
-        skip[i] = in->fstate.fid != NULL_FID || (20 / hz_count(s_move_work.hz)) > 1;
-        if(!skip[i] && S.flock[i] >= 0) {
-            struct flock *fl = &vec_AT(&s_flocks, S.flock[i]);
-            struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,
-                Entity_NavLayerWithRadius(S.flags[i], S.radius[i]));
-            skip[i] = as && G_Arrival_IsActive(as);
-        }
+        const int i = s_hip_witem.idx[w];
         if(i < lo) lo = i;
         if(i > hi) hi = i;
     }

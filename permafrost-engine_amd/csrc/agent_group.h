@@ -477,16 +477,21 @@ __device__ __forceinline__ void cp_push(cp_lds<G> &S, const cpent &ent, int n_co
 #ifndef NH_CP_BF
 #define NH_CP_BF 1
 #endif
-__device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int n_cones, int &qn_io, cp_lane &L,
+#ifndef NH_CP_BF16
+#define NH_CP_BF16 1          // ... and the same code for the 16-lane groups of k_cp_rows (a group's own state in VGPRs, ballots per group)
+#endif
+template <int G>
+__device__ __forceinline__ void cp_work_bf(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn_io, cp_lane &L,
                                            cp_bound &B, bool finish)
 {
-    const int gl = (int)(threadIdx.x & 63);
+    typedef grp<G> g;
+    const int gl = g::lane();
     const unsigned long long lt_mask = (1ull << gl) - 1ull;
-    const int qn = uni<64>(qn_io);
-    n_cones = uni<64>(n_cones);
+    const int qn = uni<G>(qn_io);
+    n_cones = uni<G>(n_cones);
     int head = 0;
-    float Blen = uni<64>(B.len), Bpx = uni<64>(B.pt.x), Bpz = uni<64>(B.pt.z);
-    int Bidx = uni<64>(B.idx), nfound = uni<64>(B.nfound);
+    float Blen = uni<G>(B.len), Bpx = uni<G>(B.pt.x), Bpz = uni<G>(B.pt.z);
+    int Bidx = uni<G>(B.idx), nfound = uni<G>(B.nfound);
     float px = L.pt.x, pz = L.pt.z, len = L.len;
     int idx = L.idx, ci = L.ci;
 #ifdef NH_CP_STATS
@@ -495,12 +500,12 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int 
     for(;;) {
         if(head < qn) {
             const bool need = ci < 0;
-            const unsigned long long mn = __ballot(need);
+            const unsigned long long mn = g::ballot(need);
             const int my = head + (int)__popcll(mn & lt_mask);
             const bool take = need & (my < qn);
             const int at = take ? my : 0;
 #if NH_CP_PACKQ
-            const float4 qe = ((const float4*)S.qx)[at];          // (the wave-wide queue packs an entry into 16 bytes)
+            const float4 qe = ((const float4*)S.qx)[at];          // (the queue packs an entry into 16 bytes)
             const float qx = qe.x, qz = qe.y, ql = qe.z;
             const int qi = __float_as_int(qe.w);
 #else
@@ -512,7 +517,7 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int 
             ci = take ? (alive ? 0 : -1) : ci;
             head = min(qn, head + (int)__popcll(mn));
         }
-        const unsigned long long busy = __ballot(ci >= 0);
+        const unsigned long long busy = g::ballot(ci >= 0);
         if(busy == 0ull) {
             if(head >= qn) break;
             continue;
@@ -521,16 +526,17 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int 
 #ifdef NH_CP_STATS
         B.it++; B.busy += __popcll(busy);
 #endif
-#if NH_CP_TC
-        const int ck = max(ci, 0);
-        const float4 A = S.tc[2 * ck], Bc = S.tc[2 * ck + 1];
-#else
-        const int ck = S.ord[max(ci, 0)];
-        const float4 A = S.cones[2 * ck], Bc = S.cones[2 * ck + 1];
-#endif
+        float4 A, Bc;
+        if constexpr(G == 64 && NH_CP_TC) {
+            const int ck = max(ci, 0);
+            A = S.tc[2 * ck]; Bc = S.tc[2 * ck + 1];
+        }else{
+            const int ck = S.ord[max(ci, 0)];
+            A = S.cones[2 * ck]; Bc = S.cones[2 * ck + 1];
+        }
         const v2 pt = mkv(px, pz);
         int v = cone_test_bf(A, Bc, pt);
-        if(__ballot((v == 2) & (ci >= 0)) != 0ull) {
+        if(g::ballot((v == 2) & (ci >= 0)) != 0ull) {
             NH_COLD_PATH();
 #ifdef NH_CP_STATS
             B.ex++;
@@ -541,7 +547,7 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int 
         const int nci = ci + 1;
         const bool outside = act & !in & (nci >= n_cones);
         ci = act ? ((in | outside) ? -1 : nci) : ci;
-        const unsigned long long mo = __ballot(outside);
+        const unsigned long long mo = g::ballot(outside);
         if(mo != 0ull) {
             NH_COLD_PATH();
 #ifdef NH_CP_STATS
@@ -550,14 +556,14 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int 
             float key = (outside && len == len) ? len : __builtin_inff();      // a NaN distance never wins
             int ki = outside ? idx : 0x7fffffff;
             const float mykey = key; const int myidx = ki;
-            grp<64>::argmin(key, ki);
-            key = uni<64>(key); ki = uni<64>(ki);
+            g::argmin(key, ki);
+            key = uni<G>(key); ki = uni<G>(ki);
             const bool better = nfound == 0 || key < Blen || (key == Blen && ki < Bidx);
             nfound++;
             if(better && key < __builtin_inff()) {
-                const int owner = __ffsll((unsigned long long)__ballot(outside && myidx == ki && mykey == key)) - 1;
+                const int owner = __ffsll((unsigned long long)g::ballot(outside && myidx == ki && mykey == key)) - 1;
                 Blen = key; Bidx = ki;
-                Bpx = uni<64>(__shfl(px - ent.pos.x, owner)); Bpz = uni<64>(__shfl(pz - ent.pos.z, owner));
+                Bpx = uni<G>(g::shfl(px - ent.pos.x, owner)); Bpz = uni<G>(g::shfl(pz - ent.pos.z, owner));
             }
             const bool alive2 = (len < Blen) | ((len == Blen) & (idx < Bidx));
             ci = (ci >= 0 && !alive2) ? -1 : ci;
@@ -572,12 +578,14 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<64> &S, const cpent &ent, int 
 #endif
 }
 
-// push this lane's candidate (ok) onto the wave's queue; the queue is worked off once 64 are waiting
-__device__ __forceinline__ void cp_push_bf(cp_lds<64> &S, const cpent &ent, int n_cones, bool ok, v2 pt, int idx,
+// push this lane's candidate (ok) onto the group's queue; the queue is worked off once G are waiting
+template <int G>
+__device__ __forceinline__ void cp_push_bf(cp_lds<G> &S, const cpent &ent, int n_cones, bool ok, v2 pt, int idx,
                                            float len, int &qn, cp_lane &L, cp_bound &B)
 {
-    const int gl = (int)(threadIdx.x & 63);
-    const unsigned long long mk = __ballot(ok);
+    typedef grp<G> g;
+    const int gl = g::lane();
+    const unsigned long long mk = g::ballot(ok);
     if(mk != 0ull) {
         if(ok) {
             const int at = qn + (int)__popcll(mk & ((1ull << gl) - 1ull));
@@ -587,23 +595,23 @@ __device__ __forceinline__ void cp_push_bf(cp_lds<64> &S, const cpent &ent, int 
             S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = idx; S.ql[at] = len;
 #endif
         }
-        qn = uni<64>(qn + (int)__popcll(mk));
+        qn = uni<G>(qn + (int)__popcll(mk));
         wave_sync();
-        if(qn >= 64) cp_work_bf(S, ent, n_cones, qn, L, B, false);
+        if(qn >= G) cp_work_bf<G>(S, ent, n_cones, qn, L, B, false);
     }
 }
 
 template <int G>
 __device__ __forceinline__ void cp_work_x(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp_lane &L, cp_bound &B, bool finish)
 {
-    if constexpr(G == 64 && NH_CP_BF) cp_work_bf(S, ent, n_cones, qn, L, B, finish);
+    if constexpr(NH_CP_BF && (G == 64 || NH_CP_BF16)) cp_work_bf<G>(S, ent, n_cones, qn, L, B, finish);
     else cp_work<G>(S, ent, n_cones, qn, L, B, finish);
 }
 template <int G>
 __device__ __forceinline__ void cp_push_x(cp_lds<G> &S, const cpent &ent, int n_cones, bool ok, v2 pt, int idx, float len,
                                           int &qn, cp_lane &L, cp_bound &B)
 {
-    if constexpr(G == 64 && NH_CP_BF) cp_push_bf(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
+    if constexpr(NH_CP_BF && (G == 64 || NH_CP_BF16)) cp_push_bf<G>(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
     else cp_push<G>(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
 }
 
@@ -1268,9 +1276,9 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         CP_STAT(B.sb, 14, __popcll(cov0) + __popcll(cov1));
         CP_TMARK(sb_, 4);                      // keys, column order, cone compaction
 #if NH_CP_COLS_V2
-        if(G == 64) {
+        if(G == 64 || (NH_CP_BF && NH_CP_BF16)) {
             // ---- lane = row: this lane's (up to two) rays stay in registers, the column's ray is the same for the
-            // whole wave.  No index arithmetic, a quarter of the LDS reads, and the bound is consulted per column.
+            // whole group.  No index arithmetic, a quarter of the LDS reads, and the bound is consulted per column.
             float rpx[2], rpz[2], rdx[2], rdz[2], rsl[2];
 #pragma unroll
             for(int h = 0; h < 2; h++) {
@@ -1393,8 +1401,8 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
             else
 #endif
             for(int jc = 0; jc < n_mine; jc++) {
-                const int j = __builtin_amdgcn_readfirstlane(S.col[jc * nparts + part]);
-                if(((j < 64 ? cov0 >> j : cov1 >> (j - 64)) & 1ull) != 0ull) break;       // (covered columns sort last)
+                const int j = uni<G>(S.col[jc * nparts + part]);
+                if(((j < G ? cov0 >> j : cov1 >> (j - G)) & 1ull) != 0ull) break;         // (covered columns sort last)
                 if(B.nfound && uni<G>(S.ckey[j]) > B.len) break;
 #ifdef NH_CP_STATS
                 B.cols++; B.cands += n_rays;
@@ -1418,7 +1426,7 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                         bool slow = false;
                         ok = ray_isect_bf(p1, d1, s1, p2, d2, s2, des_v, ent.pos, pt, len, slow);
                         const bool mine = (i < n_rays) & (i != j);
-                        if(__ballot(slow & mine) != 0ull) {           // (a quotient that needs its division, an odd distance)
+                        if(g::ballot(slow & mine) != 0ull) {          // (a quotient that needs its division, an odd distance)
                             NH_COLD_PATH();
                             if(slow & mine) {
                                 ok = ray_isect(p1, d1, s1, p2, d2, s2, pt);

@@ -1205,9 +1205,10 @@ __global__ __launch_bounds__(CPS_WAVES * 64) void k_cp_small(nh_step_params P, n
 // unit, the units numbered heaviest list first (9-16, 5-8, 3-4, 1-2 neighbours) ---------------------
 // (the lists list0, list0 - 1, ... : nlists of them, at most four; ticket_set: which set of stripe
 // counters -- the retry launch runs beside the main one)
-#ifdef CP_ROWS_OCC
-__attribute__((amdgpu_waves_per_eu(CP_ROWS_OCC, CP_ROWS_OCC)))
+#ifndef CP_ROWS_OCC
+#define CP_ROWS_OCC 4           /* (pinned like k_cp_heavy: four waves per SIMD, 128 registers -- see the note on hole inheritance below) */
 #endif
+__attribute__((amdgpu_waves_per_eu(CP_ROWS_OCC, CP_ROWS_OCC)))
 __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                            nh_worklists WL, nh_step_outs O, int list0, int nlists,
                                                            int ticket_set)

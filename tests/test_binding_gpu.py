@@ -179,6 +179,14 @@ def test_state_updates_through_the_binding():
         # a slab of the work items
         part = mv.state_update_hip(new_vel, vdes, begin=500, end=1700)
         assert np.array_equal(part[0][500:1700], ref_state[500:1700]) and np.array_equal(part[1][500:1700], ref_flags[500:1700])
+        # the host loops forked over worker threads: the same answers
+        mv.hip_threads(4, min_items=64)
+        try:
+            for _ in range(2):
+                st2, fl2, dv2 = mv.state_update_hip(new_vel, vdes)
+                assert np.array_equal(st2, ref_state) and np.array_equal(fl2, ref_flags) and np.array_equal(dv2, dv)
+        finally:
+            mv.hip_threads(1)
     finally:
         pfref.RefNav.hip_shutdown()
         pfref.RefMove.unload()
