@@ -1898,7 +1898,7 @@ int nh_worklist_cap(int n_work)
 // does not clear the other set either).
 bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
-                            hipStream_t side, hipEvent_t ev[2])
+                            hipStream_t side, hipStream_t side2, hipEvent_t ev[3])
 {
     const int nwork = P.work_end - P.work_begin;
     if(!(P.n_ents > 0 && nwork > 0)) return false;
@@ -1909,32 +1909,58 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     WL.count += parity * NH_WL_COUNTERS;
     hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
                        d_mid, WL, O, smf, thresh);
-    // the ClearPath launches: the workgroup problems on the side stream (when the caller has one),
-    // rows and the irregular agents on s; every wave / workgroup keeps drawing units until none are left
+    // the ClearPath launches.  s: the rows of 5-16 neighbours, the irregular agents.  side: the agents with 1-4
+    // neighbours (most of them, outside a crowd), whatever of them needs the retry logic, then the workgroup problems
+    // (17-64 neighbours).  Every wave / workgroup keeps drawing units until none are left.
+    // NAVHIP_CP_SCHED=1 (developer knob) puts the workgroup problems on a third stream, side2, beside the small ones
+    // they do not depend on: measured and LOST -- 0.317 against 0.310 ms per tick on ordinary ticks (one more fork
+    // and join on the agent stream cost what the shorter chain saved), 5.83 against 4.89 in the crowded world (the
+    // workgroup searches then race k_cp_rows for the chip instead of inheriting it: profiles/r04_ab_cp_three_streams.txt).
+    static int sched = -1;
+    if(sched < 0) { const char *e = getenv("NAVHIP_CP_SCHED"); sched = e ? atoi(e) : 0; }
     const bool fork = side && ev && ev[0] && ev[1];
-    hipStream_t sh = fork ? side : s;
+    const bool fork2 = fork && side2 && ev[2] && sched != 0;
+    hipStream_t sh = fork ? side : s, sh2 = fork2 ? side2 : sh;
     if(fork) {
         hipEventRecord(ev[0], s);
         hipStreamWaitEvent(sh, ev[0], 0);
+        if(fork2) hipStreamWaitEvent(sh2, ev[0], 0);
     }
     const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
     const int nblk_rows = min(4096 / CPR_WAVES, (nwork + 15) / 16 * (CP_WAVES / CPR_WAVES) + 1);
-    // side stream: the agents with 1-4 neighbours (most of them, outside a crowd), whatever of them needs
-    // the retry logic, then the workgroup problems; s: the rows of 5-16 neighbours
+    // (the rows first: behind a host that is not ahead of the device -- the tick after a synchronisation -- every
+    // launch in front of it delays its start by one enqueue)
+    hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                       (int)NH_WL_ROW3, 2, 0);
+    if(fork2) {
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh2, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           (int32_t*)nullptr, 0);
+#if NH_CP_BAIL
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh2, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           (int32_t*)nullptr, 1);
+#endif
+        hipEventRecord(ev[2], sh2);
+    }
     hipLaunchKernelGGL(k_cp_small, dim3((nwork / 4 + 2 * NH_WL_SUB + CPS_WAVES - 1) / CPS_WAVES + 1), dim3(CPS_WAVES * 64), 0, sh, P, NB,
                        (const nh_mid_rec*)d_mid, WL, O);
     hipLaunchKernelGGL(k_cp_rows, dim3(64 * CP_WAVES / CPR_WAVES), dim3(CPR_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_RETRY, 1, 1);
-    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                       (int32_t*)nullptr, 0);
-    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                       zero_next, 1);
+    if(fork2) {
+        // the other set of list counters, for the next step: on `side`, where the library copies every step's
+        // counters to pinned host memory behind the step (navhip_step_lists_peek) -- the stream orders the clearing
+        // of a set behind the copy of that set
+        hipLaunchKernelGGL(k_zero_i32, dim3(((int)NH_WL_COUNTERS + 255) / 256), dim3(256), 0, sh, zero_next, (int)NH_WL_COUNTERS);
+    }else{
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           (int32_t*)nullptr, 0);
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           zero_next, 1);
+    }
     if(fork) hipEventRecord(ev[1], sh);
-    hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                       (int)NH_WL_ROW3, 2, 0);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
                        (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, (int32_t*)nullptr);
     if(fork) hipStreamWaitEvent(s, ev[1], 0);
+    if(fork2) hipStreamWaitEvent(s, ev[2], 0);
     return true;
 }
 

@@ -1039,7 +1039,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         }
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                                  ctx->aux[0], ctx->ev_cp)) {
+                                  ctx->aux[0], ctx->aux[1], ctx->ev_cp)) {
             rc = send_step_lists(ctx, ctx->wl_parity, s);
             ctx->wl_parity ^= 1;
             if(rc) return rc;
@@ -1068,7 +1068,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                              ctx->aux[0], ctx->ev_cp)) {
+                              ctx->aux[0], ctx->aux[1], ctx->ev_cp)) {
         rc = send_step_lists(ctx, ctx->wl_parity, s);
         ctx->wl_parity ^= 1;
         if(rc) return rc;

@@ -71,7 +71,7 @@ struct navhip_ctx {
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
     bool         join0_recorded;    // ev_join[0] has been recorded for the front of the last prefetch
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
-    hipEvent_t   ev_cp[2];          // the ClearPath launches of the agent step: lists ready, workgroup problems done
+    hipEvent_t   ev_cp[3];          // the ClearPath launches of the agent step: lists ready, small problems done, workgroup problems done
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
     // the snapshot a prefetch was started for: everything the side streams baked into their results
     struct { bool valid; const float *pos_xz, *vel_xz, *radius, *arrival_sink_xz; const uint32_t *flags;
