@@ -1951,10 +1951,16 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
         // of a set behind the copy of that set
         hipLaunchKernelGGL(k_zero_i32, dim3(((int)NH_WL_COUNTERS + 255) / 256), dim3(256), 0, sh, zero_next, (int)NH_WL_COUNTERS);
     }else{
+        // (the last launch on `side` clears the other set of list counters: see k_cp_heavy)
+#if NH_CP_BAIL
         hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                            (int32_t*)nullptr, 0);
         hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                            zero_next, 1);
+#else
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           zero_next, 0);
+#endif
     }
     if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,

@@ -104,6 +104,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->ev_regroup = nullptr;
     for(auto &e : ctx->ev_cp) e = nullptr;
     ctx->regroup_pending = false;
+    memset(ctx->coh_regroup_key, 0xff, sizeof(ctx->coh_regroup_key)); ctx->coh_regroup_age = 0;
     memset(&ctx->midrec, 0, sizeof(ctx->midrec));
     memset(ctx->nbr, 0, sizeof(ctx->nbr));
     memset(ctx->wl, 0, sizeof(ctx->wl));
@@ -904,6 +905,26 @@ static int ensure_side_streams(navhip_ctx *ctx)
     return NAVHIP_OK;
 }
 
+// The lane regrouping of the cohesion term (five small launches behind k_cohesion) is for the NEXT tick's launch
+// and only has to be spatially coherent: agents move about one world unit per tick and a group's box is compared
+// against a 904-unit reach, so a grouping serves many ticks.  It is rebuilt on the two ticks after anything it was
+// built for changes (entity / flock / member counts, work range, membership key) and every NH_COH_REGROUP_EVERY-th
+// tick otherwise; k_cohesion checks on the device that the grouping it is given fits (else: the identity).
+#ifndef NH_COH_REGROUP_EVERY
+#define NH_COH_REGROUP_EVERY 8
+#endif
+static bool coh_regroup_due(navhip_ctx *ctx, const nh_step_params &P)
+{
+    const int64_t key[4] = {((int64_t)P.n_ents << 32) | (uint32_t)P.n_flocks, (int64_t)P.n_members,
+                            ((int64_t)P.work_begin << 32) | (uint32_t)P.work_end, (int64_t)P.members_key};
+    if(memcmp(key, ctx->coh_regroup_key, sizeof(key)) != 0) {
+        memcpy(ctx->coh_regroup_key, key, sizeof(key));
+        ctx->coh_regroup_age = 0;
+    }
+    const int age = ctx->coh_regroup_age++;
+    return age < 2 || age % NH_COH_REGROUP_EVERY == 0;
+}
+
 int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *stream, uint32_t flags)
 {
     if(!ctx) return NAVHIP_ERR_INVALID;
@@ -961,7 +982,7 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // caller's stream does, at the end of navhip_agent_step_dev, so that whatever the caller does
     // to the snapshot arrays afterwards is ordered behind the last read of them)
     ctx->regroup_pending = false;
-    if(regroup) {
+    if(regroup && coh_regroup_due(ctx, P)) {
         nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, ctx->aux[1]);
         if(!ctx->ev_regroup) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_regroup, hipEventDisableTiming));
         HIPCHK(ctx, hipEventRecord(ctx->ev_regroup, ctx->aux[1]));
@@ -1065,7 +1086,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(rc) return rc;
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
-    if(regroup) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
+    if(regroup && coh_regroup_due(ctx, P)) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
                               ctx->aux[0], ctx->aux[1], ctx->ev_cp)) {
