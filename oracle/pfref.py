@@ -678,6 +678,22 @@ class RefMove:
         """Host side of the WORK_TYPE_HIP arm only (no device; the step's outputs read as zero): for timing the fill."""
         lib().pfref_move_hip_dry_run(1 if on else 0)
 
+    def hip_snapshot(self):
+        """The snapshot tables bindings/permafrost/move_hip.c builds for the library (dense = ascending uid order), without
+        a device: dict of pos, vel, radius, max_speed, flags, state, flock, flock_offsets, flock_members."""
+        n = self.n
+        o = {"pos": np.zeros((n, 2), np.float32), "vel": np.zeros((n, 2), np.float32), "radius": np.zeros(n, np.float32),
+             "max_speed": np.zeros(n, np.float32), "flags": np.zeros(n, np.uint32), "state": np.zeros(n, np.uint8),
+             "flock": np.zeros(n, np.int32), "flock_offsets": np.zeros(4096, np.int32), "flock_members": np.zeros(n, np.int32)}
+        nf = C.c_int32(0)
+        got = lib().pfref_move_hip_snapshot(n, _p(o["pos"]), _p(o["vel"]), _p(o["radius"]), _p(o["max_speed"]), _p(o["flags"]),
+                                            _p(o["state"]), _p(o["flock"]), _p(o["flock_offsets"]), _p(o["flock_members"]),
+                                            C.byref(nf))
+        assert got == n, got
+        o["flock_offsets"] = o["flock_offsets"][:nf.value + 1].copy()
+        o["flock_members"] = o["flock_members"][:o["flock_offsets"][-1]].copy()
+        return o
+
     def hip_threads(self, nthreads, min_items=0):
         """Fork-join width of the binding's host-side loops (the engine's worker tasks; 1 = the calling task only);
         loops shorter than min_items (0: the binding's default, 8 192) stay on the calling task."""

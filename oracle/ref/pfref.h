@@ -212,6 +212,8 @@ void pfref_hip_pool_disable(void);
 void pfref_hip_pool_stats(long out[3]);       /* host puts mirrored, mappings mirrored, fields built resident */
 void pfref_move_hip_sampling(int on);
 void pfref_move_hip_dry_run(int on);
+int  pfref_move_hip_snapshot(int cap, float *pos, float *vel, float *radius, float *max_speed, uint32_t *flags,
+                             uint8_t *state, int32_t *flock, int32_t *flock_offsets, int32_t *flock_members, int32_t *n_flocks);
 void pfref_move_hip_threads(int nthreads, int min_items);   /* fork-join width of the binding's host loops (1 = serial) */
 void pfref_move_hip_stats(long out[3]);       /* agents sampled on the device, host fallbacks, steps */
 

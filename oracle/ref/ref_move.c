@@ -456,6 +456,27 @@ int pfref_move_velocity_hip(const float *vdes, int begin, int end, float *out_ve
     return 1;
 }
 
+/* The snapshot the binding hands to the library (hip_snap_fill + hip_snap_world), copied out for inspection: the host
+ * logic of move_hip.c -- the arena, the cached bucket positions, the cached flock tables, the fork over worker
+ * threads -- can be checked without a device.  Arrays are in dense (ascending uid) order; returns the entity count,
+ * or -1 when a buffer is too small. */
+int pfref_move_hip_snapshot(int cap, float *pos, float *vel, float *radius, float *max_speed, uint32_t *flags,
+                            uint8_t *state, int32_t *flock, int32_t *flock_offsets, int32_t *flock_members, int32_t *n_flocks)
+{
+    struct hip_snap S;
+    hip_snap_fill(&S);
+    if(S.n > cap) return -1;
+    memcpy(pos, S.pos, sizeof(float) * 2 * S.n); memcpy(vel, S.vel, sizeof(float) * 2 * S.n);
+    memcpy(radius, S.radius, sizeof(float) * S.n); memcpy(max_speed, S.max_speed, sizeof(float) * S.n);
+    memcpy(flags, S.flags, sizeof(uint32_t) * S.n); memcpy(state, S.state, S.n);
+    memcpy(flock, S.flock, sizeof(int32_t) * S.n);
+    memcpy(flock_offsets, S.flock_offsets, sizeof(int32_t) * (S.nflocks + 1));
+    memcpy(flock_members, S.flock_members, sizeof(int32_t) * S.flock_offsets[S.nflocks]);
+    *n_flocks = (int32_t)S.nflocks;
+    hip_snap_free(&S);
+    return S.n;
+}
+
 /* pfref_move_state_update through the binding: move_hip_state_work (ONE navhip_state_update for the slab)
  * then move_hip_update_work per unit.  dev_flags[i] = what the device answered (NAVHIP_SU_*).
  * Returns 0 when the device arm declined. */
