@@ -197,16 +197,41 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10
             except Exception as exc:
                 drop = {"error": repr(exc)}
         pfref.RefMove.unload()
+        # (iii) the flow sampling of the velocity step (a13: N_DesiredPointSeekVelocity per agent, serial on the nav
+        # task -- compute_desired_velocity, movement.c:4166), which the slab timing above is given.  The reference's
+        # field cache holds 2 048 chunk fields: eight destinations' worth of ITS OWN fields are put into it under its
+        # ids and mappings (what n_request_path leaves behind) and the agents of those eight flocks sampled.
+        sampling = None
+        try:
+            if "dest" in cols and k_fields >= 1:
+                nd = min(8, k_fields)
+                sel = np.flatnonzero(cols["dest"] < nd)
+                if 0 < len(sel) <= 2048:
+                    dirs = nav.field_update_many(reqs_all[sel], nthreads=cores)
+                    ids8 = np.array([nav.dest_id(t) for t in targets[:nd]], np.uint32)
+                    nav.cache_clear()
+                    nav.cache_put_fields(reqs_all[sel], ids8[cols["dest"][sel]], dirs)
+                    ag8 = np.flatnonzero(ag["flock"] < nd)[:20000]
+                    t0 = time.perf_counter()
+                    nav.desired_velocities(ids8[ag["flock"][ag8]], ag["pos"][ag8], targets[ag["flock"][ag8]])
+                    t_s = (time.perf_counter() - t0) / max(1, len(ag8))
+                    sampling = {"us_per_agent_1core": t_s * 1e6, "agents_sampled": int(len(ag8)), "destinations": int(nd),
+                                "agent_steps_per_s_with_serial_sampling": 1.0 / (t_a / m + t_s),
+                                "note": "N_DesiredPointSeekVelocity is called per agent on the nav task before the velocity "
+                                        "work is forked (movement.c:4166): serial sampling + the forked velocity half"}
+        except Exception as exc:
+            sampling = {"error": repr(exc)}
         return {
             "dropin": drop,
+            "flow_sampling": sampling,
             "value": m / t_a, "unit": "agent-steps/s", "cores": cores, "kind": "reference",
             "sample": "reference movement.c move_velocity_work on %d of the %d agents (full snapshot loaded), "
                       "%d pthreads; reference N_FlowFieldInit+N_FlowFieldUpdate on %d of the %d chunk-field "
                       "requests the GPU builds every tick (random sample), %d pthreads"
                       % (m, n_agents, cores, len(reqs), n_all, cores),
-            "skips": "flow-field sampling of the velocity step (desired directions are given: the reference's "
-                     "2 048-entry field cache cannot hold this workload's %d chunk fields, sampling would "
-                     "time its planner); the position accept test" % n_all,
+            "skips": "`value` times the velocity half with desired directions given (the reference's 2 048-entry field "
+                     "cache cannot hold this workload's %d chunk fields at once); its sampler is timed separately on eight "
+                     "destinations' worth of cached fields (`flow_sampling`); the position accept test is skipped" % n_all,
             "flow_field_cells_per_s": cells_per_s, "flow_field_cells_per_s_1core": cells_per_s_1,
             "agent_steps_per_s_1core": 1.0 / per_agent,
             "cores_note": "threads = usable cores (min of affinity and the cgroup cpu.max quota); "
