@@ -185,3 +185,54 @@ def test_product_sources_do_not_reference_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "pfref" not in txt and "navoracle" not in txt, f
+
+
+def _device_kernels(lib_path, tmp_path):
+    """{kernel name: (allocated VGPRs, LDS bytes)} of the gfx950 code objects embedded in the built library (the
+    HSA metadata notes, read with the ROCm LLVM tools; None when they are not there)."""
+    import re
+    import shutil
+    import subprocess
+    objdump, readelf = (os.path.join("/opt/rocm/lib/llvm/bin", t) for t in ("llvm-objdump", "llvm-readelf"))
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        return None
+    work = os.path.join(str(tmp_path), "co")
+    os.makedirs(work, exist_ok=True)
+    shutil.copy(lib_path, work)                      # (--offloading extracts next to its input)
+    subprocess.run([objdump, "--offloading", os.path.basename(lib_path)], cwd=work, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL, check=False)
+    out = {}
+    for f in os.listdir(work):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([readelf, "--notes", f], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                               text=True).stdout
+        for block in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block)
+            vgpr = re.search(r"\.vgpr_count:\s+(\d+)", block)
+            lds = re.search(r"\.group_segment_fixed_size:\s+(\d+)", block)
+            if name and vgpr and lds:
+                out[name.group(1)] = (int(vgpr.group(1)), int(lds.group(1)))
+    return out or None
+
+
+def test_persistent_clearpath_kernels_share_their_allocation_granules(tmp_path):
+    """Hole inheritance: k_cp_heavy's persistent workgroups move into the register and LDS ranges that
+    k_cp_rows' workgroups leave behind and keep them for the whole launch.  A k_cp_rows wave with fewer allocated
+    registers, or a k_cp_rows workgroup with less LDS, leaves holes k_cp_heavy cannot use: a quarter of its waves
+    for the whole launch (4.9 -> 6.1 ms per tick in the crowded world).  The built code objects must keep the two
+    matched -- whatever the compiler's register allocation did this time."""
+    from permafrost_engine_amd import build as nb
+    lib = os.environ.get("NAVHIP_LIB") or os.path.join(os.path.dirname(nb.__file__), "libnavhip.so")
+    if not os.path.exists(lib):
+        pytest.skip("libnavhip.so not built")
+    ks = _device_kernels(lib, tmp_path)
+    if ks is None:
+        pytest.skip("ROCm LLVM tools not available")
+    rows = [v for k, v in ks.items() if "k_cp_rows" in k]
+    heavy = [v for k, v in ks.items() if "k_cp_heavy" in k]
+    assert len(rows) == 1 and len(heavy) == 1, sorted(ks)[:8]
+    alloc = lambda v: (v + 7) // 8 * 8                # (the hardware allocates registers in granules of 8 per lane)
+    assert alloc(rows[0][0]) == alloc(heavy[0][0]) == 128, (rows, heavy)
+    assert rows[0][1] >= heavy[0][1], (rows, heavy)
+    assert 4 * rows[0][1] <= 160 * 1024 and 4 * heavy[0][1] <= 160 * 1024      # four workgroups per CU, by LDS
