@@ -151,7 +151,12 @@ static void hip_arena_reset(size_t need)
 static void *hip_arena(size_t bytes)
 {
     bytes = (bytes + 63) & ~(size_t)63;
-    assert(s_hip_arena.used + bytes <= s_hip_arena.cap);
+    if(s_hip_arena.used + bytes > s_hip_arena.cap) {
+        /* (hip_arena_need is an upper bound of what a pass takes: reaching this line is a bug in it, and handing
+         * out memory past the end would be worse than stopping) */
+        fprintf(stderr, "move_hip: per-tick arena exhausted (%zu + %zu of %zu bytes)\n", s_hip_arena.used, bytes, s_hip_arena.cap);
+        abort();
+    }
     void *p = s_hip_arena.base + s_hip_arena.used;
     s_hip_arena.used += bytes;
     return p;

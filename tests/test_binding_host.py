@@ -56,3 +56,33 @@ def test_snapshot_tables_of_the_binding(threads):
         lib.pfref_move_hip_dry_run(0)
         lib.pfref_move_hip_threads(1, 0)
         pfref.RefMove.unload()
+
+
+def test_velocity_pass_host_side_with_formations_and_arrival():
+    """The same dry run with formation members and units committed to arrival slots in the world: every optional
+    column of the navhip_world is filled (the largest footprint of the per-tick arena), serial and forked."""
+    grid, nav = cases.ref_nav_for(4, 4, seed=21)
+    n, k = 1500, 4
+    world = cases.make_agents(grid, n, k, seed=31 + n, clustered=False)
+    world["state"], form = cases.formation_inputs(world, seed=6)
+    sink, aflags = cases.arrival_inputs(world, seed=3)
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        mv.set_formation(form["form_ready"], form["cell_pos_xz"], form["form_cohesion_xz"],
+                         form["form_align_xz"], form["form_drag_xz"])
+        mv.set_arrival(sink, aflags)
+        vdes = np.zeros((n, 2), np.float32)
+        vdes[:, 1] = 1.0
+        mv.hip_dry_run(True)
+        for threads in (1, 4):
+            mv.hip_threads(threads, min_items=64)
+            for _ in range(2):
+                out = mv.velocity_hip(vdes)
+                assert out is not None and not out.any()
+        snap = mv.hip_snapshot()
+        assert np.array_equal(snap["state"], world["state"].astype(np.uint8))
+    finally:
+        lib = pfref.lib()
+        lib.pfref_move_hip_dry_run(0)
+        lib.pfref_move_hip_threads(1, 0)
+        pfref.RefMove.unload()
