@@ -922,7 +922,13 @@ static bool coh_regroup_due(navhip_ctx *ctx, const nh_step_params &P)
         ctx->coh_regroup_age = 0;
     }
     const int age = ctx->coh_regroup_age++;
-    return age < 2 || age % NH_COH_REGROUP_EVERY == 0;
+    // In a jam -- the list lengths of the last step, in pinned memory without a wait: 8 192 workgroup searches and more --
+    // the regrouping stays on every tick: the crowded world measured 3-4 % SLOWER without its five small launches on the
+    // side stream although every kernel takes the same time under the tracer (profiles/r04_ab_regroup_cadence.txt; launch
+    // timing against the persistent searches).  Kept as measured.
+    int32_t lists[6];
+    const bool jam = navhip_step_lists_peek(ctx, lists) == NAVHIP_OK && lists[4] >= 8192;
+    return jam || age < 2 || age % NH_COH_REGROUP_EVERY == 0;
 }
 
 int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *stream, uint32_t flags)
