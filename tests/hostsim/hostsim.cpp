@@ -146,4 +146,52 @@ int hostsim_clearpath_light(int nq, const float *ent, const float *des_v, const 
     return 0;
 }
 
+// ---- the branch-free forms of the ClearPath search's arithmetic (agent_math.h) against the forms they replace ----
+// rays[n][10] = p1.x p1.z d1.x d1.z s1 p2.x p2.z d2.x d2.z s2; des / ent: [2].  Returns the number of rays the
+// branch-free form decided itself (not `slow`); *bad counts disagreements among those: ok flag, point bits, length
+// bits against ray_isect + vlen.
+int hostsim_ray_isect_bf_check(int n, const float *rays, const float *des, const float *ent, int *bad)
+{
+    int decided = 0;
+    *bad = 0;
+    const v2 dl = mkv(des[0], des[1]), ep = mkv(ent[0], ent[1]);
+    for(int i = 0; i < n; i++) {
+        const float *r = rays + 10 * i;
+        const v2 p1 = mkv(r[0], r[1]), d1 = mkv(r[2], r[3]), p2 = mkv(r[5], r[6]), d2 = mkv(r[7], r[8]);
+        v2 a = mkv(0, 0), b = mkv(0, 0);
+        float len = 0.0f;
+        bool slow = false;
+        const bool okb = ray_isect_bf(p1, d1, r[4], p2, d2, r[9], dl, ep, b, len, slow);
+        const bool oka = ray_isect(p1, d1, r[4], p2, d2, r[9], a);
+        if(slow) continue;
+        decided++;
+        if(oka != okb) { (*bad)++; continue; }
+        if(!oka) continue;
+        const float la = vlen(vsub(dl, vsub(a, ep)));
+        if(nh_f2u(a.x) != nh_f2u(b.x) || nh_f2u(a.z) != nh_f2u(b.z) || nh_f2u(la) != nh_f2u(len)) (*bad)++;
+    }
+    return decided;
+}
+
+// cones[n][8] = apex.x apex.z sl sr left.x left.z right.x right.z; pts[n][2].  Returns the number of points the
+// fast tests decided (verdict != 2); *bad counts verdicts that differ from cone_contains_exact, *bad_pair verdicts of
+// cone_test_bf that differ from cone_contains_fast's (the form it replaces).
+int hostsim_cone_test_bf_check(int n, const float *cones, const float *pts, int *bad, int *bad_pair)
+{
+    int decided = 0;
+    *bad = *bad_pair = 0;
+    for(int i = 0; i < n; i++) {
+        const float *c = cones + 8 * i;
+        const float4 A = make_float4(c[0], c[1], c[2], c[3]), B = make_float4(c[4], c[5], c[6], c[7]);
+        const v2 pt = mkv(pts[2 * i], pts[2 * i + 1]);
+        const int vb = cone_test_bf(A, B, pt), vf = cone_contains_fast(A, B, pt);
+        const int ve = cone_contains_exact(A, B, pt) ? 1 : 0;
+        if(vb != vf) (*bad_pair)++;
+        if(vb == 2) continue;
+        decided++;
+        if(vb != ve) (*bad)++;
+    }
+    return decided;
+}
+
 }  // extern "C"

@@ -120,3 +120,67 @@ def test_thread_step_with_arrival_state_matches_reference(navlib):
     bad = np.flatnonzero(computed & ~(out["vel_xz"].view(np.uint32) == exp_vel.view(np.uint32)).all(1))
     assert len(bad) == 0, (bad[:10], out["vel_xz"][bad[:3]], exp_vel[bad[:3]])
     pfref.RefMove.unload()
+
+
+def _cones_around(rng, n, spread):
+    """n ClearPath cones as the search stores them (apex, slopes, unit side rays) around entities near `spread`."""
+    apex = rng.uniform(-spread, spread, (n, 2)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    half = rng.uniform(0.02, 1.2, n)
+    left = np.stack([np.cos(ang + half), np.sin(ang + half)], 1).astype(np.float32)
+    right = np.stack([np.cos(ang - half), np.sin(ang - half)], 1).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sl = np.where(np.abs(left[:, 0]) < 1 / 1024, np.nan, left[:, 1] / left[:, 0]).astype(np.float32)
+        sr = np.where(np.abs(right[:, 0]) < 1 / 1024, np.nan, right[:, 1] / right[:, 0]).astype(np.float32)
+    return apex, left, right, sl, sr
+
+
+@pytest.mark.parametrize("spread", [3.0, 40.0, 3000.0])
+def test_branch_free_ray_intersection_equals_the_branching_one(spread):
+    """ray_isect_bf (agent_math.h; C_RayRayIntersection2D collision.c:854 + the distance to des_v, all three shapes of
+    C_InfiniteLineIntersection evaluated and selected): wherever it does not hand the lane back (`slow`), validity,
+    point and distance are bit for bit those of ray_isect + vlen.  Axis-parallel and coincident rays included."""
+    import ctypes as C
+    rng = np.random.RandomState(int(spread))
+    n = 200000
+    apex, left, right, sl, sr = _cones_around(rng, 2 * n, spread)
+    # a share of exactly vertical / horizontal rays and of rays from a common apex (static neighbours)
+    k = n // 10
+    left[:k] = [0.0, 1.0]; sl[:k] = np.nan
+    left[k:2 * k] = [1.0, 0.0]; sl[k:2 * k] = 0.0
+    apex[n:n + 3 * k] = apex[:3 * k]
+    rays = np.zeros((n, 10), np.float32)
+    rays[:, 0:2], rays[:, 2:4], rays[:, 4] = apex[:n], left[:n], sl[:n]
+    rays[:, 5:7], rays[:, 7:9], rays[:, 9] = apex[n:], right[n:], sr[n:]
+    des = rng.uniform(-1, 1, 2).astype(np.float32)
+    ent = rng.uniform(-spread, spread, 2).astype(np.float32)
+    bad = C.c_int(0)
+    L = hostsim.lib()
+    decided = L.hostsim_ray_isect_bf_check(n, rays.ctypes.data_as(C.c_void_p), des.ctypes.data_as(C.c_void_p),
+                                           ent.ctypes.data_as(C.c_void_p), C.byref(bad))
+    assert bad.value == 0, bad.value
+    assert decided > 0.7 * n, decided           # (the expansions are the exception)
+
+
+@pytest.mark.parametrize("spread", [3.0, 3000.0])
+def test_branch_free_cone_test_equals_the_branching_one(spread):
+    """cone_test_bf == cone_contains_fast verdict for verdict (0 outside, 1 inside, 2 undecided), and every decided
+    verdict == cone_contains_exact (inside_pcr's test, clearpath.c:249-262); apex points and points on the side rays
+    included."""
+    import ctypes as C
+    rng = np.random.RandomState(7 + int(spread))
+    n = 300000
+    apex, left, right, sl, sr = _cones_around(rng, n, spread)
+    cones = np.concatenate([apex, sl[:, None], sr[:, None], left, right], 1).astype(np.float32)
+    pts = (apex + rng.normal(0, 2.0, (n, 2))).astype(np.float32)
+    k = n // 10
+    pts[:k] = apex[:k]                                                    # the apex itself: "not inside" (:262)
+    t = rng.uniform(0.001, 5.0, (k, 1)).astype(np.float32)
+    pts[k:2 * k] = apex[k:2 * k] + left[k:2 * k] * t                      # on the left side ray
+    pts[2 * k:3 * k] = apex[2 * k:3 * k] + right[2 * k:3 * k] * t         # on the right side ray
+    pts[3 * k:4 * k] = apex[3 * k:4 * k] + rng.normal(0, 1e-3, (k, 2)).astype(np.float32)   # within EPS of the apex
+    bad, bad_pair = C.c_int(0), C.c_int(0)
+    decided = hostsim.lib().hostsim_cone_test_bf_check(n, cones.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p),
+                                                       C.byref(bad), C.byref(bad_pair))
+    assert bad_pair.value == 0 and bad.value == 0, (bad_pair.value, bad.value)
+    assert decided > 0.6 * n, decided
