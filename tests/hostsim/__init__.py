@@ -84,3 +84,63 @@ def clearpath_light(ent, des_v, dyn, n_dyn, stat, n_stat):
     rc = lib().hostsim_clearpath_light(nq, p(ent), p(des_v), p(dyn), p(n_dyn), p(stat), p(n_stat), p(out), p(found))
     assert rc == 0
     return out, found
+
+
+# ---- the group code itself (csrc/agent_group.h) on a lockstep emulator of a wave: wave_emu.h + group_sim.cpp ----
+GROUP_LIB = os.path.join(HERE, "_groupsim.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"      # (agent_group.h uses clang vector types; the host compiler of the ROCm toolchain)
+_glib = None
+
+
+def group_available():
+    return os.path.exists(CLANG)
+
+
+def build_group():
+    src = os.path.join(HERE, "group_sim.cpp")
+    deps = [src, os.path.join(HERE, "wave_emu.h")] + [os.path.join(CSRC, f) for f in
+            ("agent_group.h", "agent_thread.h", "agent_math.h", "agent_types.h", "map_view.h")]
+    deps.append(os.path.join(ROOT, "include", "navhip.h"))
+    if os.path.exists(GROUP_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(GROUP_LIB) for d in deps):
+        return GROUP_LIB
+    # -O1: the emulator orders lanes that wait at different operations by call-site address (wave_emu.h), which wants
+    # the code laid out in source order; same floating-point contract as the device build
+    cmd = [CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-w",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, src, "-o", GROUP_LIB]
+    subprocess.check_call(cmd)
+    return GROUP_LIB
+
+
+def group_lib():
+    global _glib
+    if _glib is None:
+        _glib = C.CDLL(build_group())
+    return _glib
+
+
+def clearpath_group(G, ent, des_v, dyn, n_dyn, stat, n_stat):
+    """clearpath_grp<G> (G = 16: the row groups of k_cp_rows, at most 16 neighbours in total; G = 64: one wave per
+    problem, k_cp_heavy / k_agent_full) for nq independent problems on the emulator.  Returns (velocities [nq][2],
+    cross-lane operations executed)."""
+    ent = np.ascontiguousarray(ent, np.float32).reshape(-1, 5)
+    nq = len(ent)
+    des_v = np.ascontiguousarray(des_v, np.float32).reshape(nq, 2)
+    dyn = np.ascontiguousarray(dyn, np.float32).reshape(nq, 32, 5)
+    stat = np.ascontiguousarray(stat, np.float32).reshape(nq, 32, 5)
+    n_dyn = np.ascontiguousarray(n_dyn, np.int32)
+    n_stat = np.ascontiguousarray(n_stat, np.int32)
+    out = np.zeros((nq, 2), np.float32)
+    ops = C.c_long(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = group_lib().groupsim_clearpath(int(G), nq, p(ent), p(des_v), p(dyn), p(n_dyn), p(stat), p(n_stat), p(out), C.byref(ops))
+    if rc:
+        raise RuntimeError("groupsim_clearpath failed (%d)" % rc)
+    return out, ops.value
+
+
+def group_attempts(reset=True):
+    """[k] = problems that returned in attempt k (7: seven or more), [8] = attempts in total, since the last reset."""
+    buf = (C.c_ulonglong * 9)()
+    group_lib().groupsim_attempts(buf, 1 if reset else 0)
+    return list(buf)
+

@@ -184,3 +184,48 @@ def test_branch_free_cone_test_equals_the_branching_one(spread):
                                                        C.byref(bad), C.byref(bad_pair))
     assert bad_pair.value == 0 and bad.value == 0, (bad_pair.value, bad.value)
     assert decided > 0.6 * n, decided
+
+
+# ---- the group code itself (csrc/agent_group.h) on the lockstep wave emulator (tests/hostsim/wave_emu.h) ------------
+group_sim = pytest.mark.skipif(not hostsim.group_available(), reason="no clang++ (ROCm LLVM) to compile agent_group.h for the host")
+
+
+def _same(got, exp):
+    both = np.isnan(exp) & np.isnan(got)
+    return np.array_equal(np.where(both, 0, got).view(np.uint32), np.where(both, 0, exp).view(np.uint32))
+
+
+@group_sim
+@pytest.mark.parametrize("G,seed,max_dyn,max_stat,spread,nq", [
+    (16, 1, 4, 4, 6.0, 300), (16, 2, 8, 8, 9.0, 300), (16, 5, 16, 0, 4.0, 200), (16, 9, 8, 8, 2.0, 200),
+    (64, 3, 8, 8, 9.0, 150), (64, 6, 16, 16, 9.0, 80), (64, 7, 32, 32, 9.5, 40), (64, 8, 32, 32, 3.0, 30)])
+def test_group_clearpath_search_on_the_wave_emulator_matches_reference(G, seed, max_dyn, max_stat, spread, nq):
+    """clearpath_grp<G> -- the source k_cp_rows (G = 16) and k_cp_heavy / k_agent_full (G = 64, a wave per problem)
+    execute: cones, ranks, projections, the lane = row column phase, the branch-free queue, cone compaction, the retry
+    shortcut and the replay of removals -- run lane by lane in lockstep on the host, == G_ClearPath_NewVelocity
+    (clearpath.c:694) of the reference build, bit for bit, on every problem."""
+    ent, des, dyn, nd, stat, ns = cases.cp_problems(seed, nq, max_dyn, max_stat, spread)
+    if G == 16:
+        keep = (nd + ns) <= 16
+        ent, des, dyn, nd, stat, ns = [a[keep] for a in (ent, des, dyn, nd, stat, ns)]
+    hostsim.group_attempts(reset=True)
+    got, ops = hostsim.clearpath_group(G, ent, des, dyn, nd, stat, ns)
+    assert ops > 20 * len(ent)                       # (the lanes really met at cross-lane operations)
+    for i in range(len(ent)):
+        exp = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
+        assert _same(got[i], exp), (i, nd[i], ns[i], got[i], exp)
+
+
+@group_sim
+def test_group_search_takes_the_retry_shortcut_on_the_emulator():
+    """Dense problems whose first attempt fails: the removal schedule (cp_jump), the replay and the attempt that
+    succeeds, wave-wide -- and still the reference's answer."""
+    ent, des, dyn, nd, stat, ns = cases.cp_problems(8, 60, 32, 32, 2.0)
+    hostsim.group_attempts(reset=True)
+    got, _ = hostsim.clearpath_group(64, ent, des, dyn, nd, stat, ns)
+    att = hostsim.group_attempts()
+    for i in range(len(ent)):
+        exp = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
+        assert _same(got[i], exp), (i, nd[i], ns[i], got[i], exp)
+    # att[k], k >= 1: problems that returned in the attempt behind the shortcut; att[0]: no attempt succeeds at all
+    assert sum(att[1:8]) >= 20 and att[0] >= 1, att
