@@ -144,3 +144,32 @@ def group_attempts(reset=True):
     group_lib().groupsim_attempts(buf, 1 if reset else 0)
     return list(buf)
 
+
+def group_agent_step(navhip, w, h, cost, blockers, arrays, coh_xz, hz=20, layer=0):
+    """The velocity step of a snapshot through the device's own per-agent sources on the emulator: nbr_walk_row (16
+    lanes), mid_thread, cp_load_lists + clearpath_grp (16 or 64 lanes, by neighbour count), post_thread.  Returns the
+    outputs + 'disp' (DISP_* per entity; 7 = the irregular gather, not stepped) + 'ops' (cross-lane operations)."""
+    world, keep = navhip.make_world(w, h, arrays, hz)
+    n = world.n_ents
+    m = Map()
+    m.chunk_w, m.chunk_h = w, h
+    cost = np.ascontiguousarray(cost, np.uint8)
+    blockers = np.ascontiguousarray(blockers, np.uint16)
+    m.cost[layer] = cost.ctypes.data
+    m.blockers[layer] = blockers.ctypes.data
+    out = {k: np.zeros((n, 2), np.float32) for k in ("vel_xz", "new_pos_xz", "vdes_xz", "vpref_xz")}
+    out["status"] = np.zeros(n, np.uint8)
+    so = navhip.StepOut()
+    for k in out:
+        setattr(so, k, out[k].ctypes.data)
+    disp = np.zeros(n, np.uint8)
+    coh = np.ascontiguousarray(coh_xz, np.float32)
+    ops = C.c_long(0)
+    rc = group_lib().groupsim_agent_step(C.byref(m), C.byref(world), coh.ctypes.data_as(C.c_void_p), C.byref(so),
+                                         disp.ctypes.data_as(C.c_void_p), C.byref(ops))
+    if rc:
+        raise RuntimeError("groupsim_agent_step failed (%d)" % rc)
+    out["disp"] = disp
+    out["ops"] = ops.value
+    return out
+

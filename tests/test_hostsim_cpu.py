@@ -229,3 +229,36 @@ def test_group_search_takes_the_retry_shortcut_on_the_emulator():
         assert _same(got[i], exp), (i, nd[i], ns[i], got[i], exp)
     # att[k], k >= 1: problems that returned in the attempt behind the shortcut; att[0]: no attempt succeeds at all
     assert sum(att[1:8]) >= 20 and att[0] >= 1, att
+
+
+@group_sim
+@pytest.mark.parametrize("clustered,n,k,blk", [(False, 1500, 4, False), (True, 1200, 3, False), (True, 1500, 2, True)])
+def test_group_step_on_the_wave_emulator_matches_reference(navlib, clustered, n, k, blk):
+    """The whole velocity step of a snapshot through the device's own per-agent sources on the host emulator --
+    nbr_walk_row on 16 lanes (k_agent_nbr), mid_thread (k_agent_mid), cp_load_lists + clearpath_grp on 16 or 64 lanes
+    with the retry logic (k_cp_small / k_cp_rows / k_cp_heavy), post_thread -- == move_velocity_work
+    (movement.c:3395) of the reference build for every agent the regular path steps, clustered worlds (neighbour caps
+    bind, searches retry) and blockers included."""
+    grid, nav, world = _world(navlib, clustered, n, k, blk)
+    mv, dest_ids = cases.ref_move_for(nav, world)
+    exp_vel = mv.velocity(None)
+    vdes = mv.vdes()
+    order = [mv.flock_order(f) for f in range(k)]
+    a = cases.step_arrays(world, vdes, order)
+    moving = ~np.isin(world["state"], (2, 4))
+    coh = np.zeros((n, 2), np.float32)
+    for uid in np.flatnonzero(np.isin(world["state"], (0, 5, 6))):
+        coh[uid] = mv.forces(int(uid), vdes[uid])[1]
+    hostsim.group_attempts(reset=True)
+    out = hostsim.group_agent_step(navlib, 4, 4, nav.plane(0), nav.plane(1), a, coh)
+    disp = out["disp"]
+    stepped = moving & (disp != DISP_FULL)
+    assert stepped.sum() > 0.9 * moving.sum(), np.bincount(disp[moving])
+    bad = np.flatnonzero(stepped & ~(out["vel_xz"].view(np.uint32) == exp_vel.view(np.uint32)).all(1))
+    assert len(bad) == 0, (bad[:10], disp[bad[:10]], out["vel_xz"][bad[:3]], exp_vel[bad[:3]])
+    assert np.all(out["vel_xz"][~moving] == 0)
+    if clustered:
+        assert (disp[moving] >= 5).sum() > 50        # wave-wide searches (17+ neighbours) among them
+        assert sum(hostsim.group_attempts()[1:8]) > 0 # ... and searches that needed the retry shortcut
+    pfref.RefMove.unload()
+
