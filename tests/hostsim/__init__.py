@@ -173,3 +173,22 @@ def group_agent_step(navhip, w, h, cost, blockers, arrays, coh_xz, hz=20, layer=
     out["ops"] = ops.value
     return out
 
+
+def clearpath_team(ent, des_v, dyn, n_dyn, stat, n_stat):
+    """clearpath_grp<64, true>: one problem searched by a workgroup of four waves (k_cp_heavy below CP_SOLO_MIN
+    problems; k_clearpath_team) on the emulator."""
+    ent = np.ascontiguousarray(ent, np.float32).reshape(-1, 5)
+    nq = len(ent)
+    des_v = np.ascontiguousarray(des_v, np.float32).reshape(nq, 2)
+    dyn = np.ascontiguousarray(dyn, np.float32).reshape(nq, 32, 5)
+    stat = np.ascontiguousarray(stat, np.float32).reshape(nq, 32, 5)
+    n_dyn = np.ascontiguousarray(n_dyn, np.int32)
+    n_stat = np.ascontiguousarray(n_stat, np.int32)
+    out = np.zeros((nq, 2), np.float32)
+    ops = C.c_long(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = group_lib().groupsim_clearpath_team(nq, p(ent), p(des_v), p(dyn), p(n_dyn), p(stat), p(n_stat), p(out), C.byref(ops))
+    if rc:
+        raise RuntimeError("groupsim_clearpath_team failed (%d)" % rc)
+    return out, ops.value
+

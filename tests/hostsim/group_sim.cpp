@@ -194,6 +194,48 @@ extern "C" void groupsim_attempts(unsigned long long out[9], int reset)
     if(reset) memset(nh_cp_attempts, 0, sizeof(nh_cp_attempts));
 }
 
+// one problem searched by a TEAM of CP_TEAM waves (what k_cp_heavy runs below CP_SOLO_MIN problems, k_clearpath_team)
+namespace {
+enum { CP_TEAM = 4 };
+struct team_job { cpent e; v2 des; int nd, ns; cp_lds<64> *S; cp_team *T; v2 out; const float *dyn, *stat; };
+void team_body(void *p)
+{
+    team_job *J = (team_job*)p;
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    cp_lds<64> &S = J->S[wib];
+    for(int i = lane; i < J->nd * 5; i += 64) S.dyn[i] = J->dyn[i];
+    for(int i = lane; i < J->ns * 5; i += 64) S.stat[i] = J->stat[i];
+    wave_sync();
+    const v2 r = clearpath_grp<64, true>(J->e, J->des, J->nd, J->ns, S, wib, CP_TEAM, J->T);
+    if(threadIdx.x == 0) J->out = r;
+}
+}  // namespace
+
+extern "C" int groupsim_clearpath_team(int nq, const float *ent, const float *des_v, const float *dyn, const int32_t *n_dyn,
+                                       const float *stat, const int32_t *n_stat, float *out, long *collectives)
+{
+    cp_lds<64> *S = new cp_lds<64>[CP_TEAM];
+    cp_team T;
+    long total = 0, c = 0;
+    for(int q = 0; q < nq; q++) {
+        team_job J;
+        J.e.pos = mkv(ent[5 * q], ent[5 * q + 1]); J.e.vel = mkv(ent[5 * q + 2], ent[5 * q + 3]); J.e.radius = ent[5 * q + 4];
+        J.des = mkv(des_v[2 * q], des_v[2 * q + 1]);
+        J.nd = n_dyn[q]; J.ns = n_stat[q]; J.S = S; J.T = &T; J.out = mkv(0, 0);
+        J.dyn = dyn + (size_t)q * 160; J.stat = stat + (size_t)q * 160;
+        if(J.nd > 32 || J.ns > 32) { delete[] S; return 2; }
+        memset((void*)S, 0xff, sizeof(cp_lds<64>) * CP_TEAM);
+        memset((void*)&T, 0xff, sizeof(T));
+        const char *err = emu::run(64 * CP_TEAM, team_body, &J, &c);
+        if(err) { fprintf(stderr, "group_sim: team problem %d: %s\n", q, err); delete[] S; return 1; }
+        total += c;
+        out[2 * q] = J.out.x; out[2 * q + 1] = J.out.z;
+    }
+    if(collectives) *collectives = total;
+    delete[] S;
+    return 0;
+}
+
 extern "C" int groupsim_clearpath(int G, int nq, const float *ent, const float *des_v, const float *dyn, const int32_t *n_dyn,
                                   const float *stat, const int32_t *n_stat, float *out, long *collectives)
 {

@@ -9,7 +9,8 @@
 // the way EXEC masking runs a branch body before the code behind it.  Lanes that have returned count as inactive.
 //
 // A wave of G lanes is emulated for a group of G (lane ids 0 .. G-1, so grp<G>::base() is 0 and a ballot carries G
-// bits).  Float arithmetic is the host forms of agent_math.h (NH_HOSTSIM): IEEE everywhere, no contraction.
+// bits); a workgroup is up to four waves of 64 whose wave-level operations stay inside their wave and whose
+// __syncthreads() is a rendezvous of all of them.  Float arithmetic is the host forms of agent_math.h (NH_HOSTSIM): IEEE everywhere, no contraction.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -19,17 +20,18 @@
 
 namespace emu {
 
-enum { K_NONE = 0, K_BALLOT, K_SHFL, K_SHFL_XOR, K_FIRST, K_SYNC, K_DPP_SHR };
+enum { K_NONE = 0, K_BALLOT, K_SHFL, K_SHFL_XOR, K_FIRST, K_SYNC, K_DPP_SHR, K_WGSYNC };
+enum { MAXL = 256 };                  // lanes of a workgroup (up to four waves)
 
 struct Wave {
-    int          n;                   // lanes
+    int          n;                   // lanes (a group of 16, a wave of 64, or a workgroup of waves)
     ucontext_t   sched;
-    ucontext_t   ctx[64];
-    char        *stack[64];
-    bool         done[64], waiting[64];
-    int          kind[64], arg[64];
-    uintptr_t    site[64];            // where in the code the lane waits (the call site of the operation)
-    uint64_t     val[64], res[64];
+    ucontext_t   ctx[MAXL];
+    char        *stack[MAXL];
+    bool         done[MAXL], waiting[MAXL];
+    int          kind[MAXL], arg[MAXL];
+    uintptr_t    site[MAXL];          // where in the code the lane waits (the call site of the operation)
+    uint64_t     val[MAXL], res[MAXL];
     int          cur;
     void       (*body)(void *);
     void        *user;
@@ -76,6 +78,7 @@ static const char *run(int n, void (*body)(void *), void *user, long *n_collecti
         w->ctx[l].uc_link = &w->sched;
         makecontext(&w->ctx[l], (void (*)())trampoline, 0);
     }
+    const int WS = n < 64 ? n : 64;                 // lanes per wave
     for(;;) {
         int live = 0;
         for(int l = 0; l < n; l++) {
@@ -83,43 +86,59 @@ static const char *run(int n, void (*body)(void *), void *user, long *n_collecti
             w->cur = l; threadIdx_emu.x = (unsigned)l;
             swapcontext(&w->sched, &w->ctx[l]);
         }
-        int first = -1;
-        for(int l = 0; l < n; l++) if(!w->done[l]) { live++; if(first < 0) first = l; }
+        for(int l = 0; l < n; l++) if(!w->done[l]) live++;
         if(!live) break;
-        // Every live lane waits now.  Usually at the same operation; lanes can differ where an operation sits inside a
-        // branch only some of them took (`gl < n && shfl(...)`): the hardware runs the branch body for those lanes
-        // first -- the others are masked off -- and reconverges behind it.  The call site tells who is behind: the
-        // lanes at the lowest code address are served, alone; the rest keep waiting where they are.
-        uintptr_t site = ~(uintptr_t)0;
-        for(int l = 0; l < n; l++) if(!w->done[l] && w->site[l] < site) { site = w->site[l]; first = l; }
-        const int kind = w->kind[first];
-        bool at[64];
-        for(int l = 0; l < n; l++) at[l] = !w->done[l] && w->site[l] == site;
-        w->collectives++;
-        uint64_t mask = 0;
-        switch(kind) {
-        case K_BALLOT:
-            for(int l = 0; l < n; l++) if(at[l] && w->val[l]) mask |= 1ull << l;
-            for(int l = 0; l < n; l++) if(at[l]) w->res[l] = mask;
-            break;
-        case K_SHFL:
-            for(int l = 0; l < n; l++) if(at[l]) { const int s = w->arg[l] & (n - 1); w->res[l] = at[s] ? w->val[s] : w->val[l]; }
-            break;
-        case K_SHFL_XOR:
-            for(int l = 0; l < n; l++) if(at[l]) { const int s = (l ^ w->arg[l]) & (n - 1); w->res[l] = at[s] ? w->val[s] : w->val[l]; }
-            break;
-        case K_FIRST:
-            for(int l = 0; l < n; l++) if(at[l]) w->res[l] = w->val[first];
-            break;
-        case K_DPP_SHR:       // row_shr:k inside rows of 16 lanes, bound_ctrl: 0 shifted in
-            for(int l = 0; l < n; l++) if(at[l]) { const int k = w->arg[l]; w->res[l] = ((l & 15) >= k && at[l - k]) ? w->val[l - k] : 0; }
-            break;
-        case K_SYNC:
-            break;
-        default:
-            w->error = "unknown cross-lane operation"; return w->error;
+        // Every live lane waits now.  Wave by wave: usually all lanes of a wave at the same operation; lanes can differ
+        // where an operation sits inside a branch only some of them took (`gl < n && shfl(...)`): the hardware runs
+        // the branch body for those lanes first -- the others are masked off -- and reconverges behind it.  The call
+        // site tells who is behind: the lanes at the lowest code address are served, alone; the rest keep waiting.
+        // A wave whose lanes all wait at the workgroup barrier is parked until every wave has arrived.
+        bool progressed = false;
+        int at_barrier = 0;
+        for(int w0 = 0; w0 < n; w0 += WS) {
+            uintptr_t site = ~(uintptr_t)0;
+            int first = -1;
+            for(int l = w0; l < w0 + WS; l++)
+                if(!w->done[l] && w->kind[l] != K_WGSYNC && w->site[l] < site) { site = w->site[l]; first = l; }
+            if(first < 0) {
+                for(int l = w0; l < w0 + WS; l++) if(!w->done[l]) at_barrier++;
+                continue;
+            }
+            const int kind = w->kind[first];
+            bool at[MAXL];
+            for(int l = w0; l < w0 + WS; l++) at[l] = !w->done[l] && w->kind[l] != K_WGSYNC && w->site[l] == site;
+            w->collectives++;
+            uint64_t mask = 0;
+            switch(kind) {
+            case K_BALLOT:
+                for(int l = w0; l < w0 + WS; l++) if(at[l] && w->val[l]) mask |= 1ull << (l - w0);
+                for(int l = w0; l < w0 + WS; l++) if(at[l]) w->res[l] = mask;
+                break;
+            case K_SHFL:
+                for(int l = w0; l < w0 + WS; l++) if(at[l]) { const int s = w0 + (w->arg[l] & (WS - 1)); w->res[l] = at[s] ? w->val[s] : w->val[l]; }
+                break;
+            case K_SHFL_XOR:
+                for(int l = w0; l < w0 + WS; l++) if(at[l]) { const int s = w0 + (((l - w0) ^ w->arg[l]) & (WS - 1)); w->res[l] = at[s] ? w->val[s] : w->val[l]; }
+                break;
+            case K_FIRST:
+                for(int l = w0; l < w0 + WS; l++) if(at[l]) w->res[l] = w->val[first];
+                break;
+            case K_DPP_SHR:       // row_shr:k inside rows of 16 lanes, bound_ctrl: 0 shifted in
+                for(int l = w0; l < w0 + WS; l++) if(at[l]) { const int k = w->arg[l]; w->res[l] = ((l & 15) >= k && at[l - k]) ? w->val[l - k] : 0; }
+                break;
+            case K_SYNC:
+                break;
+            default:
+                w->error = "unknown cross-lane operation"; return w->error;
+            }
+            for(int l = w0; l < w0 + WS; l++) if(at[l]) w->waiting[l] = false;
+            progressed = true;
         }
-        for(int l = 0; l < n; l++) if(at[l]) w->waiting[l] = false;
+        if(!progressed) {
+            if(at_barrier != live) { w->error = "deadlock: nothing to serve and not every lane at the workgroup barrier"; return w->error; }
+            w->collectives++;
+            for(int l = 0; l < n; l++) if(!w->done[l]) w->waiting[l] = false;      // __syncthreads: everybody is here
+        }
     }
     if(n_collectives) *n_collectives = w->collectives;
     return nullptr;
@@ -151,7 +170,7 @@ static inline int   emu_update_dpp(int old, int v, int ctrl, int, int, bool)
 #define __builtin_amdgcn_update_dpp(o, v, c, r, b, bc) emu_update_dpp(o, v, c, r, b, bc)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)emu::collective(emu::K_SYNC, 0, 0))
-static inline void __syncthreads() { fprintf(stderr, "wave_emu: __syncthreads (team mode) is not emulated\n"); abort(); }
+static inline void __syncthreads() { (void)emu::collective(emu::K_WGSYNC, 0, 0); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }

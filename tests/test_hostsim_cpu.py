@@ -262,3 +262,20 @@ def test_group_step_on_the_wave_emulator_matches_reference(navlib, clustered, n,
         assert sum(hostsim.group_attempts()[1:8]) > 0 # ... and searches that needed the retry shortcut
     pfref.RefMove.unload()
 
+
+@group_sim
+@pytest.mark.parametrize("seed,max_dyn,max_stat,spread,nq", [(3, 8, 8, 9.0, 60), (6, 16, 16, 9.0, 40), (7, 32, 32, 9.5, 25),
+                                                             (8, 32, 32, 2.0, 25)])
+def test_team_search_on_the_workgroup_emulator_matches_reference(seed, max_dyn, max_stat, spread, nq):
+    """clearpath_grp<64, true>: four waves search one problem -- every wave its share of the columns and of the retry
+    shortcut's candidates, the minima combined through LDS behind workgroup barriers (team_min) -- as k_cp_heavy runs
+    the 17-64-neighbour problems outside a jam.  Four emulated waves + __syncthreads == the reference."""
+    ent, des, dyn, nd, stat, ns = cases.cp_problems(seed, nq, max_dyn, max_stat, spread)
+    hostsim.group_attempts(reset=True)
+    got, ops = hostsim.clearpath_team(ent, des, dyn, nd, stat, ns)
+    for i in range(len(ent)):
+        exp = pfref.clearpath_new_velocity(ent[i], des[i], dyn[i, :nd[i]], stat[i, :ns[i]])
+        assert _same(got[i], exp), (i, nd[i], ns[i], got[i], exp)
+    if spread < 3.0:
+        assert sum(hostsim.group_attempts()[1:8]) > 0      # the shared retry shortcut ran
+
