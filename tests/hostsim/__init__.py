@@ -192,3 +192,44 @@ def clearpath_team(ent, des_v, dyn, n_dyn, stat, n_stat):
         raise RuntimeError("groupsim_clearpath_team failed (%d)" % rc)
     return out, ops.value
 
+
+# ---- the WHOLE library on the emulator: every translation unit of csrc/ compiled for the host against fakehip/ ----------
+EMU_LIB = os.path.join(HERE, "_navhip_emu.so")
+EMU_SOURCES = ["navhip_api", "pool_api", "field_kernels", "agent_kernels", "blocker_kernels", "los_kernels",
+               "region_kernels", "comm_api"]
+# the two statements of the device sources a host compiler cannot take (a register clobber that pins the allocation of
+# k_cp_rows; an unsized extern array for dynamic LDS) -- replaced in the copies that are compiled, nothing else is
+_EMU_PATCHES = [
+    ('    asm volatile("" ::: "v127");', "    /* (register pin: device only) */"),
+    ("    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];",
+     "    static __attribute__((aligned(16))) uint8_t smem[160 * 1024];"),
+]
+
+
+def build_navhip_emu():
+    """tests/hostsim/_navhip_emu.so: libnavhip's own sources -- API layer and kernels -- built for the host on top of
+    the lockstep emulator (wave_emu.h) and a stand-in for the HIP runtime (fakehip/: device memory is host memory,
+    a launch runs the grid block by block).  Exports the C ABI of include/navhip.h.  TEST INFRASTRUCTURE: loaded only
+    by tests that name it through NAVHIP_LIB; the product library has no CPU path."""
+    src_dir = os.path.join(HERE, "_emu_src")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps += [os.path.join(HERE, "wave_emu.h"), os.path.join(HERE, "fakehip", "hip", "hip_runtime.h"),
+             os.path.join(ROOT, "include", "navhip.h"), os.path.abspath(__file__)]
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(EMU_LIB) for d in deps):
+        return EMU_LIB
+    os.makedirs(src_dir, exist_ok=True)
+    objs = []
+    for name in EMU_SOURCES:
+        text = open(os.path.join(CSRC, name + ".hip")).read()
+        for old, new in _EMU_PATCHES:
+            text = text.replace(old, new)
+        cpp = os.path.join(src_dir, name + ".cpp")
+        open(cpp, "w").write(text)
+        obj = os.path.join(src_dir, name + ".o")
+        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-DNH_HOSTSIM=1", "-ffp-contract=off", "-fno-fast-math",
+                               "-w", "-I" + os.path.join(HERE, "fakehip"), "-I" + HERE, "-I" + os.path.join(ROOT, "include"),
+                               "-I" + CSRC, "-c", cpp, "-o", obj])
+        objs.append(obj)
+    subprocess.check_call([CLANG, "-shared", "-fPIC", "-o", EMU_LIB] + objs + ["-ldl"])
+    return EMU_LIB
+

@@ -1,0 +1,98 @@
+// tests/hostsim/fakehip/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
+//
+// What the kernel translation units of libnavhip need from <hip/hip_runtime.h>, on top of the lockstep emulator of
+// ../../wave_emu.h: a kernel launch runs the grid block by block, every block as fibers in lockstep (one wave of 64
+// lanes or a workgroup of up to four); __shared__ variables are function statics (one block is alive at a time);
+// device memory is host memory; streams and events are no-ops (everything is synchronous and in order).
+#pragma once
+#include <math.h>
+#include "wave_emu.h"
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+typedef struct emu_stream_t *hipStream_t;
+typedef struct emu_event_t *hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+
+#define __shared__ static
+#define __constant__ static
+#define __launch_bounds__(...)
+#define HIP_SYMBOL(x) x
+#define amdgpu_waves_per_eu(...) unused      /* (an occupancy hint for the device compiler) */
+
+namespace emu {
+static thread_local dim3 blockIdx_emu, gridDim_emu, blockDim_emu;
+template <typename F> static void lane_body(void *p) { (*(F*)p)(); }
+template <typename F> static void launch(dim3 grid, dim3 block, F fn)
+{
+    gridDim_emu = grid; blockDim_emu = block;
+    for(unsigned b = 0; b < grid.x; b++) {
+        blockIdx_emu = dim3(b);
+        const char *err = run((int)block.x, lane_body<F>, &fn);
+        if(err) { fprintf(stderr, "emulated launch: block %u: %s\n", b, err); abort(); }
+    }
+}
+}  // namespace emu
+#define blockIdx emu::blockIdx_emu
+#define gridDim  emu::gridDim_emu
+#define blockDim emu::blockDim_emu
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu::launch(grid, block, [&]() { kernel(__VA_ARGS__); })
+
+enum { hipErrorNotReady = 600, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0,
+       hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+typedef void *hipDeviceptr_t;
+struct hipDeviceProp_t { int multiProcessorCount; char name[64]; };
+struct hipPointerAttribute_t { int type; };
+static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP runtime"; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof(*p)); p->multiProcessorCount = 256; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) {
+#ifdef EMU_MALLOC_FILL
+    *p = malloc(n ? n : 1); if(*p) memset(*p, EMU_MALLOC_FILL, n);
+#else
+    *p = calloc(n ? n : 1, 1);
+#endif
+    return *p ? hipSuccess : 2; }
+template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f) { return hipHostMalloc((void**)p, n, f); }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetD32Async(hipDeviceptr_t p, int v, size_t count, hipStream_t) { for(size_t i = 0; i < count; i++) ((int*)p)[i] = v; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeDevice; return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+template <typename T> static inline hipError_t hipMemcpyToSymbol(T &sym, const void *src, size_t n) { memcpy((void*)&sym, src, n); return hipSuccess; }
+template <typename T> static inline hipError_t hipMemcpyFromSymbol(void *dst, const T &sym, size_t n) { memcpy(dst, (const void*)&sym, n); return hipSuccess; }
+
+// vector types: float2 / float4 come from the library's own host definitions (agent_types.h under NH_HOSTSIM)
+#include "agent_types.h"
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
+template <typename T, typename U> static inline T atomicSub(T *p, U v) { T o = *p; *p = (T)(o - (T)v); return o; }
+template <typename T, typename U> static inline T atomicOr(T *p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
+template <typename T, typename U> static inline T atomicAnd(T *p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
+template <typename T, typename U> static inline T atomicExch(T *p, U v) { T o = *p; *p = (T)v; return o; }
+template <typename T, typename U> static inline T atomicCAS(T *p, U cmp, U v) { T o = *p; if(o == (T)cmp) *p = (T)v; return o; }
+

@@ -1,0 +1,66 @@
+"""The parity tests of the GPU suite, run WITHOUT a GPU against libnavhip's own sources on a host emulator.
+
+tests/hostsim/_navhip_emu.so is every translation unit of permafrost-engine_amd/csrc -- the API layer and all kernels,
+unchanged but for two statements a host compiler cannot take -- compiled for the host on top of a lockstep emulator of
+waves and workgroups (tests/hostsim/wave_emu.h: lanes are fibers, every ballot / shuffle / DPP move / barrier is a
+rendezvous) and a stand-in for the HIP runtime (tests/hostsim/fakehip/: device memory is host memory, a launch runs its
+grid block by block).  It exports the C ABI of include/navhip.h, so the very tests that pin the GPU build to the
+reference build through that ABI run against it: the same kernel SOURCE is checked on a machine without a GPU, flow
+fields, line of sight, blockers, the spatial index, the whole velocity step with its ClearPath kernels, the state
+update.  Test infrastructure only: nothing loads this library unless NAVHIP_LIB names it, and libnavhip.so itself still
+fails loudly without a device (test_abi_cpu.py).  Host arithmetic is IEEE where the device's native square root and
+reciprocal square root are within an ulp: the kernels' own margins are what make both agree with the reference.
+
+The selected tests are those that go through host buffers (no torch.cuda) and finish in seconds on the emulator; they run
+in one pytest subprocess (the library is chosen when navhip.py is first imported)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from oracle import pfref
+from tests import hostsim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = [pytest.mark.skipif(not hostsim.group_available(), reason="no clang++ (ROCm LLVM) for the host build"),
+              pytest.mark.skipif(not pfref.available(), reason="oracle/_ref (the reference build) is not present")]
+
+SELECTION = [
+    "tests/test_golden_gpu.py",
+    "tests/test_fields_gpu.py",
+    "tests/test_blockers_gpu.py",
+    "tests/test_edge_gpu.py",
+    "tests/test_agents_gpu.py",
+]
+# (agents: the tests that need torch.cuda, and the ones that take more than ~10 s each on the emulator)
+DESELECT = ["test_prefetch_overlap_gives_identical_results", "test_shared_chunk_fields_give_identical_results",
+            "test_pipelined_field_builds_give_identical_results", "test_lane_grouping_carried_between_ticks_is_only_a_hint",
+            "test_device_los_lookup_matches_N_HasDestLOS", "test_slab_calls_share_one_output_buffer",
+            "test_slab_lane_grouping_survives_membership_changes", "test_formation_arms_match_reference",
+            "test_clearpath_retry_shortcut_matches_reference[12-32-32-4.5-team]",
+            "test_clearpath_retry_shortcut_matches_reference[12-32-32-4.5-False]",
+            "test_clearpath_retry_shortcut_matches_reference[11-24-24-3.0-team]",
+            "test_clearpath_retry_shortcut_matches_reference[11-24-24-3.0-False]",
+            "test_clearpath_retry_shortcut_matches_reference[15-16-16-2.6-team]",
+            "test_velocity_step_matches_reference[True-1500-2-True]", "test_clearpath_matches_reference[2-32-32-9.5]"]
+
+
+def test_gpu_parity_tests_pass_on_the_emulated_library():
+    lib = hostsim.build_navhip_emu()
+    env = dict(os.environ, NAVHIP_LIB=lib)
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + SELECTION
+    for name in DESELECT:
+        cmd += ["--deselect", "tests/test_agents_gpu.py::" + name]
+    try:
+        import xdist  # noqa: F401
+        cmd += ["-n", str(min(4, os.cpu_count() or 1))]
+    except ImportError:
+        pass
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    tail = "\n".join(r.stdout.strip().splitlines()[-25:])
+    assert r.returncode == 0, tail
+    last = r.stdout.strip().splitlines()[-1]
+    assert " passed" in last and "failed" not in last and "error" not in last, tail
+    assert int(last.split(" passed")[0].split()[-1]) >= 60, tail          # (the selection really ran)
