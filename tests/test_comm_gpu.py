@@ -18,11 +18,26 @@ def _torch():
     return torch
 
 
+def _dev():
+    """The device the buffers of these tests live on: the GPU -- or host memory when the library under test is the host
+    emulator build (tests/test_emulated_cpu.py: "device" pointers are host pointers there)."""
+    import os
+    torch = _torch()
+    emulated = os.path.basename(os.environ.get("NAVHIP_LIB", "")) == "_navhip_emu.so"
+    return torch.device("cpu") if emulated else torch.device("cuda", 0)
+
+
+def _sync():
+    torch = _torch()
+    if _dev().type == "cuda":
+        _sync()
+
+
 @pytest.mark.parametrize("bounds", [[0, 800, 1600], [0, 400, 1100, 1500], [0, 400, 800, 1200, 1600],
                                     [0, 0, 700, 1500], [0, 500, 500, 1500]])
 def test_step_exchange_through_the_mailbox(navlib, bounds):
     torch = _torch()
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     world, n = len(bounds) - 1, bounds[-1]
     rng = np.random.RandomState(world * 7 + n)
     pos = rng.uniform(-500, 500, (n, 2)).astype(np.float32)
@@ -43,7 +58,7 @@ def test_step_exchange_through_the_mailbox(navlib, bounds):
         p[b:e], v[b:e] = pos[b:e], vel[b:e]
         d_p, d_v = torch.from_numpy(p).to(dev), torch.from_numpy(v).to(dev)
         ctx.comm_allgather_step_dev(d_p, d_v, np.array(bounds, np.int32))
-        torch.cuda.synchronize()
+        _sync()
         assert np.array_equal(d_p.cpu().numpy(), pos), (rank, "positions")
         assert np.array_equal(d_v.cpu().numpy(), vel), (rank, "velocities")
         assert np.array_equal(d_mail.cpu().numpy(), packed), (rank, "deposit")
@@ -55,7 +70,7 @@ def test_step_exchange_through_the_mailbox(navlib, bounds):
 def test_tile_exchange_through_the_mailbox(navlib, bounds):
     """navhip_comm_allgather_rows_dev with 4 KB rows (baked flow tiles over the request stream)."""
     torch = _torch()
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     world, n = len(bounds) - 1, bounds[-1]
     tiles = np.random.RandomState(5).randint(0, 9, (n, 4096)).astype(np.uint8)
     for rank in range(world):
@@ -69,7 +84,7 @@ def test_tile_exchange_through_the_mailbox(navlib, bounds):
         mine[b:e] = tiles[b:e]
         d_rows = torch.from_numpy(mine).to(dev)
         ctx.comm_allgather_rows_dev(d_rows, 4096, np.array(bounds, np.int32))
-        torch.cuda.synchronize()
+        _sync()
         assert np.array_equal(d_rows.cpu().numpy(), tiles), rank
         assert np.array_equal(d_mail.cpu().numpy(), tiles), rank
         ctx.close()                 # (destroys the communicator with the context)
@@ -77,7 +92,7 @@ def test_tile_exchange_through_the_mailbox(navlib, bounds):
 
 def test_exchange_rejects_bad_bounds_and_short_mailboxes(navlib):
     torch = _torch()
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     ctx = navlib.NavContext(1, 1)
     n = 256
     d_p = torch.zeros((n, 2), dtype=torch.float32, device=dev)
@@ -99,5 +114,5 @@ def test_exchange_rejects_bad_bounds_and_short_mailboxes(navlib):
     ctx.comm_init_mailbox(1, 2, short)                        # (replaces the communicator)
     assert call([0, 128, 256]) == navlib.ERR_INVALID and "mailbox" in ctx.last_error()
     assert call([0, 100, 256]) == navlib.ERR_INVALID          # ragged path: the same check
-    torch.cuda.synchronize()
+    _sync()
     ctx.close()
