@@ -34,6 +34,7 @@ SELECTION = [
     "tests/test_edge_gpu.py",
     "tests/test_agents_gpu.py",
     "tests/test_comm_gpu.py",          # the exchange step over the mailbox transport (device buffers = host buffers here)
+    "tests/test_pool_gpu.py",          # the resident field pool and the asynchronous step
 ]
 # (agents: the tests that need torch.cuda, and the ones that take more than ~10 s each on the emulator)
 DESELECT = ["test_prefetch_overlap_gives_identical_results", "test_shared_chunk_fields_give_identical_results",
@@ -54,6 +55,7 @@ def test_gpu_parity_tests_pass_on_the_emulated_library():
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + SELECTION
     for name in DESELECT:
         cmd += ["--deselect", "tests/test_agents_gpu.py::" + name]
+    cmd += ["--deselect", "tests/test_pool_gpu.py::test_step_joins_a_prefetch_issued_on_another_stream"]     # (torch.cuda streams)
     try:
         import xdist  # noqa: F401
         cmd += ["-n", str(min(4, os.cpu_count() or 1))]
@@ -64,4 +66,4 @@ def test_gpu_parity_tests_pass_on_the_emulated_library():
     assert r.returncode == 0, tail
     last = r.stdout.strip().splitlines()[-1]
     assert " passed" in last and "failed" not in last and "error" not in last, tail
-    assert int(last.split(" passed")[0].split()[-1]) >= 68, tail          # (the selection really ran)
+    assert int(last.split(" passed")[0].split()[-1]) >= 78, tail          # (the selection really ran)
