@@ -67,3 +67,24 @@ def test_gpu_parity_tests_pass_on_the_emulated_library():
     last = r.stdout.strip().splitlines()[-1]
     assert " passed" in last and "failed" not in last and "error" not in last, tail
     assert int(last.split(" passed")[0].split()[-1]) >= 78, tail          # (the selection really ran)
+
+
+def test_reference_binding_drives_the_emulated_library():
+    """tests/test_binding_gpu.py -- the reference's own movement tick, field requests, field cache and blocker calls
+    going through bindings/permafrost/*.c into the C ABI -- with the emulator build answering instead of libnavhip.so:
+    the harness (oracle/_ref/libpfref.so) links the product library by name, so the emulator build is preloaded and its
+    navhip_* symbols interpose."""
+    lib = hostsim.build_navhip_emu()
+    env = dict(os.environ, NAVHIP_LIB=lib, LD_PRELOAD=lib)
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "tests/test_binding_gpu.py"]
+    try:
+        import xdist  # noqa: F401
+        cmd += ["-n", str(min(4, os.cpu_count() or 1))]
+    except ImportError:
+        pass
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    tail = "\n".join(r.stdout.strip().splitlines()[-25:])
+    assert r.returncode == 0, tail
+    last = r.stdout.strip().splitlines()[-1]
+    assert "8 passed" in last, tail
+
