@@ -25,6 +25,58 @@ from permafrost_engine_amd import synth    # noqa: E402
 f32 = np.float32
 
 
+def evolved_problems(flocks, ticks, max_problems, threads=8):
+    """[(ent, des, nbs, isdyn)] of the tick after `ticks` ticks of a `flocks`-flock jam (see the module docstring)."""
+    W = 16
+    grid = synth.cost_grid(W, W, seed=1234)
+    k = flocks
+    n = 1562 * k
+    ag = synth.agents(grid, n, k, seed=7, crowd_cells=17)
+    dests = synth.destinations(grid, k, seed=42)
+    targets = synth.cell_centre(W, W, dests[:, 0], dests[:, 1]).astype(f32)
+    nav = navoracle.OracleNav(synth.to_chunks(grid))
+    pos, vel = ag["pos"].astype(f32), ag["vel"].astype(f32)
+    flock = ag["flock"]
+    lists = [np.flatnonzero(flock == f) for f in range(k)]
+    offs = np.zeros(k + 1, np.int32)
+    offs[1:] = np.cumsum([len(l) for l in lists])
+    base = {"radius": ag["radius"], "max_speed": ag["max_speed"], "speed": ag["speed"],
+            "flags": np.full(n, 1 << 3, np.uint32), "state": np.zeros(n, np.uint8),
+            "has_dest_los": np.zeros(n, np.uint8), "flock": flock, "flock_target_xz": targets,
+            "flock_offsets": offs, "flock_members": np.concatenate(lists).astype(np.int32)}
+
+    def toward():
+        d = targets[flock] - pos
+        return (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-3)).astype(f32)
+    for t in range(ticks):
+        out = nav.agent_step(dict(base, pos_xz=pos, vel_xz=vel, vdes_xz=toward()), hz=20, nthreads=threads)
+        pos, vel = out["new_pos_xz"].copy(), out["vel_xz"].copy()
+    from scipy.spatial import cKDTree
+    tree = cKDTree(pos)
+    out = nav.agent_step(dict(base, pos_xz=pos, vel_xz=vel, vdes_xz=toward()), hz=20, nthreads=threads)
+    vpref = out["vpref_xz"]
+    rng = np.random.RandomState(3)
+    speed = np.linalg.norm(vel, axis=1)
+    probs = []
+    for uid in rng.permutation(n):
+        if len(probs) >= max_problems:
+            break
+        nb = [j for j in tree.query_ball_point(pos[uid], 10.0) if j != uid]
+        stat = [j for j in nb if speed[j] < 0.3][:32]
+        dyn = [j for j in nb if speed[j] >= 0.3][:32]
+        if len(stat) + len(dyn) < 17:
+            continue
+        order = dyn + stat
+        nbs = np.zeros((len(order), 5), f32)
+        nbs[:, 0:2] = pos[order]
+        nbs[:len(dyn), 2:4] = vel[dyn]
+        nbs[:, 4] = 1.0
+        isdyn = np.arange(len(order)) < len(dyn)
+        ent = np.array([pos[uid, 0], pos[uid, 1], vel[uid, 0], vel[uid, 1], 1.0], f32)
+        probs.append((ent, vpref[uid].astype(f32), nbs, isdyn))
+    return probs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flocks", type=int, default=3)
