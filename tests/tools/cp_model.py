@@ -7,7 +7,7 @@ exhaustive arg-min of the model equals the reference's answer for problems whose
 go into the kernel: a rule is exact iff the pruned arg-min equals the exhaustive one on every problem; the
 script also counts the work each rule leaves (columns, rows, cones, candidates).
 
-    python scripts/cp_model.py [--n 400] [--crowd 17] [--xoff 0] [--seed 1]
+    python tests/tools/cp_model.py [--n 400] [--crowd 17] [--xoff 0] [--seed 1]
 """
 import argparse
 import os
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 f32 = np.float32

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which cone should a candidate of the ClearPath search be tested against FIRST?  CPU-only experiment on the jam
-problems of scripts/cp_model.py (numpy float32 model of clearpath.c:552-660): every valid ray-pair candidate of a
+problems of tests/tools/cp_model.py (numpy float32 model of clearpath.c:552-660): every valid ray-pair candidate of a
 problem's first attempt is tested against the cones in a given order until one contains it, and the tests are
 counted.  Orders compared (the RESULT of the search does not depend on the order -- a candidate is dropped by any
 cone that contains it and accepted only when none does):
@@ -11,7 +11,7 @@ cone that contains it and accepted only when none does):
   col_hint  the same per column (candidates of one column lie on line j)
   both      row hint, then column hint, then depth order
 
-    python scripts/cp_order_model.py [--n 120] [--crowd 17]
+    python tests/tools/cp_order_model.py [--n 120] [--crowd 17]
 """
 import argparse
 import os
@@ -19,8 +19,8 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 sys.path.insert(0, ROOT)
 import cp_model as M      # noqa: E402
 

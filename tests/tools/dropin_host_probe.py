@@ -3,7 +3,7 @@
 dry-run mode fills the snapshot + work-item arrays and scatters (zero) results exactly as a real tick does,
 skipping only navhip_agent_step_submit/_wait.  Developer tool (needs oracle/_ref; no GPU):
 
-    python scripts/dropin_host_probe.py [n_agents] [reps] [threads]   (the pool is created once: one thread count per run)
+    python tests/tools/dropin_host_probe.py [n_agents] [reps] [threads]   (the pool is created once: one thread count per run)
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pfref                       # noqa: E402
 from permafrost_engine_amd import synth        # noqa: E402

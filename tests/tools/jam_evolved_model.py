@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""The cone-test-order experiment of scripts/cp_order_model.py on an EVOLVED jam, CPU only: a few flocks of the crowded
+"""The cone-test-order experiment of tests/tools/cp_order_model.py on an EVOLVED jam, CPU only: a few flocks of the crowded
 world (synth.agents(crowd_cells=17): ~1 560 agents packed into ~35 x 35 cells each) are stepped for T ticks with the
 restatement oracle (oracle/navoracle.c: the velocity step + the position accept test, desired direction = straight at
 the flock target), then every agent's ClearPath problem of the last tick is rebuilt the way find_neighbours does
 (movement.c:2768: r = 10, static = still or slower than 0.3, 32 of each at most) and the candidates of its first
 attempt are tested against the cones in the orders compared.  Developer tool (test infrastructure: uses oracle/).
 
-    python scripts/jam_evolved_model.py [--flocks 3] [--ticks 40] [--problems 120] [--threads 8]
+    python tests/tools/jam_evolved_model.py [--flocks 3] [--ticks 40] [--problems 120] [--threads 8]
 """
 import argparse
 import os
@@ -14,8 +14,8 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 sys.path.insert(0, ROOT)
 import cp_model as M            # noqa: E402
 import cp_order_model as O      # noqa: E402
