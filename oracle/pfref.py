@@ -627,7 +627,7 @@ class RefMove:
                                        _p(k["f_align"]), _p(k["f_drag"]))
 
     def velocity_hip(self, vdes=None, begin=0, end=None):
-        """move_velocity_work through the WORK_TYPE_HIP arm of the binding (oracle/ref/move_hip.c)."""
+        """move_velocity_work through the WORK_TYPE_HIP arm of the binding (bindings/permafrost/move_hip.c)."""
         end = self.n if end is None else end
         out = np.zeros((self.n, 2), np.float32)
         v = None if vdes is None else np.ascontiguousarray(vdes, np.float32)

@@ -64,7 +64,7 @@ def main():
     arrays2["vdes_xz"] = np.tile(np.array([[1.0, 0.0]], np.float32), (N, 1))
     t = timed(lambda: ctx.agent_step(arrays2, want=("vel_xz", "new_pos_xz", "status")), reps=3)
     out["agents_host_api_given_vdes_steps_per_s"] = N / t
-    # the host-buffer step the binding uses (oracle/ref/move_hip.c): fields resident in the device pool
+    # the host-buffer step the binding uses (bindings/permafrost/move_hip.c): fields resident in the device pool
     # (built there once; the step uploads the 3 MB entity snapshot and downloads 1.7 MB of results),
     # navhip_agent_step_submit / _poll through the pinned staging area -- against the SAME step with
     # everything already on the device (navhip_agent_step_dev)
