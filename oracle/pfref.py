@@ -310,7 +310,7 @@ class RefNav:
         assert t >= 0
         return out
 
-    # -- the reference-side binding of libnavhip.so (oracle/ref/nav_hip.c) -------------------
+    # -- the reference-side binding of libnavhip.so (bindings/permafrost/nav_hip.c) -------------------
     def hip_init(self):
         return bool(lib().pfref_hip_init(self._h))
 

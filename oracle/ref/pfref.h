@@ -156,7 +156,7 @@ int    pfref_position_pathable(pfref_nav *nav, int layer, float x, float z);
 int    pfref_position_blocked(pfref_nav *nav, int layer, float x, float z);
 void   pfref_map_pos(const pfref_nav *nav, float out[3]);
 
-/* --- the reference-side binding of libnavhip.so (oracle/ref/nav_hip.c, move_hip.c) ------------- */
+/* --- the reference-side binding of libnavhip.so (bindings/permafrost/nav_hip.c, move_hip.c) ------------- */
 
 /* N_HIP_Init: create the device context for this map and upload its planes.  0 = no GPU. */
 int  pfref_hip_init(pfref_nav *nav);
