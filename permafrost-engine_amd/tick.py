@@ -10,6 +10,7 @@ between ticks: the worst case of the reference's tick, where every cached field 
 PyTorch supplies device buffers, the stream and torch.distributed; all compute is libnavhip.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -17,6 +18,67 @@ import torch
 
 from . import dist as pdist
 from . import navhip, synth
+
+
+class _HostCuda:
+    """What NavTick uses of torch.cuda, for the ONE case in which "device" memory is host memory: the library under test
+    is the host-emulator build of tests/hostsim (NAVHIP_LIB names _navhip_emu.so; test infrastructure, see
+    tests/test_emulated_cpu.py).  Everything there runs synchronously and in order, so streams and events carry no state
+    beyond a timestamp."""
+
+    class Stream:
+        def __init__(self, device=None, priority=0):
+            self.cuda_stream = 0x1000           # (an opaque non-null handle: the emulated runtime never looks inside)
+
+        def wait_event(self, event):
+            pass
+
+        def wait_stream(self, stream):
+            pass
+
+        def synchronize(self):
+            pass
+
+    class ExternalStream(Stream):
+        def __init__(self, handle, device=None):
+            self.cuda_stream = handle or 0x1000
+
+    class Event:
+        def __init__(self, enable_timing=False):
+            self.t = 0.0
+
+        def record(self, stream=None):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+        def synchronize(self):
+            pass
+
+    class _Props:
+        multi_processor_count = 256
+
+    @staticmethod
+    def stream(s):
+        import contextlib
+        return contextlib.nullcontext()
+
+    @staticmethod
+    def set_device(dev):
+        pass
+
+    @staticmethod
+    def synchronize(dev=None):
+        pass
+
+    @staticmethod
+    def get_device_properties(dev):
+        return _HostCuda._Props()
+
+
+EMULATED = os.path.basename(os.environ.get("NAVHIP_LIB", "")) == "_navhip_emu.so"
+tcuda = _HostCuda if EMULATED else torch.cuda
 
 
 def region_grid(world):
@@ -45,8 +107,8 @@ class NavTick:
                  debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True,
                  straddle=0.0, los=False, flow_velocities=False, share_fields=False):
         self.rank, self.world, self.device_index = rank, world, device
-        self.dev = torch.device("cuda", device)
-        torch.cuda.set_device(self.dev)
+        self.dev = torch.device("cpu") if EMULATED else torch.device("cuda", device)
+        tcuda.set_device(self.dev)
         self.W = chunk_w                            # region side in chunks
         # shared_map (BASELINE configs[3], strong scaling): ONE chunk_w x chunk_w map for every rank;
         # destinations and agents are split over the ranks, anywhere on the map
@@ -272,12 +334,12 @@ class NavTick:
                 self.los_source = "has_dest_los = 0: no planner LOS fixture for this world"
             else:
                 self._build_los(lc, dests, dev)
-        self.stream = torch.cuda.Stream(device=self.dev, priority=-1)      # the agent chain: ahead of the field builds
+        self.stream = tcuda.Stream(device=self.dev, priority=-1)      # the agent chain: ahead of the field builds
         # multi-GPU: the slab all-gather of tick t runs on its own stream and is only awaited by the
         # snapshot consumers of tick t+1 (spatial hash + cohesion, then the agent step); the field
         # builds of tick t+1 do not read positions and overlap with it
         self.pipelined = world > 1 and not solo
-        self.comm = torch.cuda.Stream(device=self.dev) if self.pipelined else None
+        self.comm = tcuda.Stream(device=self.dev) if self.pipelined else None
         # exchange = "navhip": the slab all-gather goes through the library's own C entry point
         # (navhip_comm_allgather_step_dev: librccl called directly -- what a C host uses) instead of
         # torch.distributed; rank 0's communicator id travels over the process group that launched us
@@ -288,8 +350,8 @@ class NavTick:
             tdist.broadcast_object_list(box, src=0)
             self.ctx.comm_init(rank, world, box[0])
             self._bounds = np.array([b for b, _ in self.agent_bounds] + [self.N], np.int32)
-        self.ev_step = torch.cuda.Event()
-        self.ev_comm = torch.cuda.Event()
+        self.ev_step = tcuda.Event()
+        self.ev_comm = tcuda.Event()
         self._comm_pending = False
         self._make_structs()
         if obstacles:
@@ -319,26 +381,26 @@ class NavTick:
             #     neighbour walk on 224 / 160: 0.99 / 1.20.
             #   configs[1] (4 096 chunk fields, 45 us): no difference (0.259-0.265).
             import os
-            ncu_all = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            ncu_all = tcuda.get_device_properties(self.dev).multi_processor_count
             long_build = self.n_req_local >= 65536
             ncu = int(os.environ.get("NAVTICK_FIELD_CUS", str(ncu_all if long_build else ncu_all * 5 // 8)))
             if 0 < ncu < ncu_all:
-                self.fstream = torch.cuda.ExternalStream(self.ctx.stream_create_partial(ncu_all - ncu, ncu), device=self.dev)
+                self.fstream = tcuda.ExternalStream(self.ctx.stream_create_partial(ncu_all - ncu, ncu), device=self.dev)
             else:
-                self.fstream = torch.cuda.Stream(device=self.dev)
+                self.fstream = tcuda.Stream(device=self.dev)
             self.fields_after = os.environ.get("NAVTICK_FIELDS_AFTER", "start" if long_build else "neighbours")
             # nothing wide is enqueued on self.stream between prefetch and step: the front stays on it
             # ... and the snapshot buffers ping-pong: the one a step read is next written by the ClearPath
             # kernels of the following step
             self.prefetch_flags = navhip.PREFETCH_FRONT_INLINE | navhip.PREFETCH_SNAPSHOT_HELD
             self.pool_next = torch.zeros_like(self.pool)
-            self.ev_fields, self.ev_fields_next = torch.cuda.Event(), torch.cuda.Event()
+            self.ev_fields, self.ev_fields_next = tcuda.Event(), tcuda.Event()
             self.fev = []
             if self.n_req_local:                       # the fields of tick 0 (start-up, untimed)
                 self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
                                           self.pool[self.req_begin:self.req_end], stream=self.stream.cuda_stream)
             if self.tile_exchange != "none" and not self.solo:
-                with torch.cuda.stream(self.stream):
+                with tcuda.stream(self.stream):
                     pdist.exchange_rows(self.pool, self.xchg_bounds, self.rank, self.world)
             self.ev_fields.record(self.stream)
             self.stream.synchronize()
@@ -386,13 +448,13 @@ class NavTick:
         self.los_pool = torch.zeros((n, 4096), dtype=torch.uint8, device=self.dev)
         lv = level[order]
         bounds = np.searchsorted(lv, np.arange(lv.max() + 2))
-        torch.cuda.synchronize(self.dev)
+        tcuda.synchronize(self.dev)
         for L in range(len(bounds) - 1):
             b, e = int(bounds[L]), int(bounds[L + 1])
             if e == b:
                 continue
             d_prev = self.los_pool.index_select(0, d_prev_slot[b:e]) if L > 0 else None
-            torch.cuda.synchronize(self.dev)     # (torch's stream -> the library's: start-up, untimed)
+            tcuda.synchronize(self.dev)     # (torch's stream -> the library's: start-up, untimed)
             self.ctx.build_los_dev(d_reqs[b:e], e - b, d_prev, self.los_pool[b:e])
             self.ctx.sync()
         tbl = -np.ones((self.K, self.nchunks), np.int32)
@@ -457,7 +519,7 @@ class NavTick:
         # cost ~4 % of the tick when recorded every tick)
         if not self.record or self.tick_no % self.mark_every:
             return None
-        e = torch.cuda.Event(enable_timing=True)
+        e = tcuda.Event(enable_timing=True)
         e.record(self.stream)
         return (name, e)
 
@@ -467,7 +529,7 @@ class NavTick:
             # one timing event every `tick_every` ticks: an event on the agent stream is a packet on the
             # tick's critical path (recording every tick cost 1.5-2 % of the tick)
             if self._tick_rec % self.tick_every == 0:
-                e = torch.cuda.Event(enable_timing=True)
+                e = tcuda.Event(enable_timing=True)
                 e.record(self.stream)
                 self.tick_ev.append(e)
             self._tick_rec += 1
@@ -481,11 +543,11 @@ class NavTick:
         self._marks = marks = []
         if self.pipelined and self.overlap:
             # behind the previous tick's all-gather, concurrently with the field builds below
-            with torch.cuda.stream(self.comm):
+            with tcuda.stream(self.comm):
                 self.ctx.agent_prefetch_dev(self.world_s, stream=self.comm.cuda_stream)
         if self.pipeline_fields:
             return self._compute_pipelined(marks)
-        with torch.cuda.stream(s):
+        with tcuda.stream(s):
             # snapshot-only parts of the agent step (spatial hash, cohesion: they read no nav plane)
             # start now on the library's side streams and overlap with the blocker updates and the
             # field builds below
@@ -524,11 +586,11 @@ class NavTick:
         if stage == "start" and self.pipelined:
             f.wait_stream(s)                      # (the end of the previous tick)
         if not self.pipelined:
-            with torch.cuda.stream(s):
+            with tcuda.stream(s):
                 self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream, flags=self.prefetch_flags)
         # the fields of the NEXT tick
         timed = self.record and self.tick_no % self.mark_every == 0
-        with torch.cuda.stream(f):
+        with tcuda.stream(f):
             if stage == "neighbours":
                 self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_NEIGHBOURS)
             elif not self.pipelined:
@@ -536,22 +598,22 @@ class NavTick:
                 # another event on the agent stream)
                 self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_START)
             if timed:
-                e0 = torch.cuda.Event(enable_timing=True)
+                e0 = tcuda.Event(enable_timing=True)
                 e0.record(f)
             if self.n_req_local:
                 self.ctx.build_fields_dev(self.d_reqs[self.req_begin:self.req_end], self.n_req_local,
                                           self.pool_next[self.req_begin:self.req_end], stream=f.cuda_stream)
             if timed:
-                e1 = torch.cuda.Event(enable_timing=True)
+                e1 = tcuda.Event(enable_timing=True)
                 e1.record(f)
             if self.tile_exchange != "none" and not self.solo:
                 pdist.exchange_rows(self.pool_next, self.xchg_bounds, self.rank, self.world)
             if timed:
-                e2 = torch.cuda.Event(enable_timing=True)
+                e2 = tcuda.Event(enable_timing=True)
                 e2.record(f)
                 self.fev.append((e0, e1, e2))
             self.ev_fields_next.record(f)
-        with torch.cuda.stream(s):
+        with tcuda.stream(s):
             marks.append(self._mark("agents"))
             s.wait_event(self.ev_fields)                  # this tick's fields (built during the last one)
             if self._comm_pending:
@@ -571,7 +633,7 @@ class NavTick:
             self.ev_comm.record(self.comm)
             self._comm_pending = True
             return
-        with torch.cuda.stream(self.comm):
+        with tcuda.stream(self.comm):
             self.comm.wait_event(self.ev_step)
             # ONE collective per tick: this rank's rows of [new position | new velocity] (16 B per
             # agent) packed into one buffer, all-gathered, unpacked
@@ -586,7 +648,7 @@ class NavTick:
 
     def advance(self):
         """Advance the snapshot: ping-pong the position / velocity buffers."""
-        with torch.cuda.stream(self.stream):
+        with tcuda.stream(self.stream):
             self._marks.append(self._mark("end"))
             self.t["pos_xz"], self.new_pos = self.new_pos, self.t["pos_xz"]
             self.t["vel_xz"], self.new_vel = self.new_vel, self.t["vel_xz"]
@@ -621,7 +683,7 @@ class NavTick:
         if self.pipeline_fields:
             self.fstream.synchronize()
         self.stream.synchronize()
-        torch.cuda.synchronize(self.dev)
+        tcuda.synchronize(self.dev)
 
     def close(self):
         self.sync()

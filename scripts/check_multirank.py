@@ -23,11 +23,13 @@ def main():
     # --shared: ONE map for every rank, its destinations and agents split over the ranks (strong scaling:
     # bench.py --scaling strong); --flow-velocities: the benchmark's flow-aligned initial velocities, which every
     # rank computes for its own slab and exchanges
-    kw = dict(chunk_w=4, fields_per_rank=6, agents_per_rank=12000, world=world, device=local,
+    # --small: a world the host-emulator build of the library steps in seconds (tests/test_emulated_cpu.py)
+    small = "--small" in sys.argv
+    kw = dict(chunk_w=4, fields_per_rank=3 if small else 6, agents_per_rank=500 if small else 12000, world=world, device=local,
               straddle=0.25 if "--straddle" in sys.argv else 0.0, shared_map="--shared" in sys.argv,
               flow_velocities="--flow-velocities" in sys.argv)
     T = tick.NavTick(rank=rank, tile_exchange=mode, pipeline_fields=pipe, exchange=exch, **kw)
-    K = 6
+    K = 3 if small else 6
     for _ in range(K):
         T.step()
     T.sync()

@@ -46,7 +46,7 @@ struct hipDeviceProp_t { int multiProcessorCount; char name[64]; };
 struct hipPointerAttribute_t { int type; };
 static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP runtime"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 64; return hipSuccess; }      /* (any rank of a multi-process test finds "its" device) */
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof(*p)); p->multiProcessorCount = 256; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) {

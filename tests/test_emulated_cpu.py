@@ -88,3 +88,20 @@ def test_reference_binding_drives_the_emulated_library():
     last = r.stdout.strip().splitlines()[-1]
     assert "8 passed" in last, tail
 
+
+@pytest.mark.parametrize("extra", [["--pipeline-fields", "--shared", "--flow-velocities"], ["--straddle", "all"]])
+def test_two_rank_gloo_tick_on_the_emulated_library(extra):
+    """The multi-GPU tick with world_size 2 on CPU: two processes under torchrun, gloo, each with its own emulator build
+    of the library (tick.NavTick sees host memory as its device then) -- field slices and agent slabs per rank, the slab
+    exchange every tick, tiles travelling where flocks straddle ranks, the fields of the next tick built ahead, one
+    shared world split over the ranks (bench.py --scaling strong) -- and after three ticks every rank's snapshot is
+    bit-identical to ONE process that builds every field and steps every agent (scripts/check_multirank.py)."""
+    lib = hostsim.build_navhip_emu()
+    env = dict(os.environ, NAVHIP_LIB=lib, NAVHIP_DIST_BACKEND="gloo")
+    port = 29540 + (len(extra) * 7 + sum(len(e) for e in extra)) % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "scripts", "check_multirank.py"), "--small"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("rank ")]
+    assert r.returncode == 0 and len(lines) == 2 and all("IDENTICAL to solo" in l for l in lines), r.stdout[-2000:]
+
