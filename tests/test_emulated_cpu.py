@@ -58,7 +58,7 @@ def test_gpu_parity_tests_pass_on_the_emulated_library():
     cmd += ["--deselect", "tests/test_pool_gpu.py::test_step_joins_a_prefetch_issued_on_another_stream"]     # (torch.cuda streams)
     try:
         import xdist  # noqa: F401
-        cmd += ["-n", str(min(4, os.cpu_count() or 1))]
+        cmd += ["-n", str(min(8, os.cpu_count() or 1))]
     except ImportError:
         pass
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
@@ -79,7 +79,7 @@ def test_reference_binding_drives_the_emulated_library():
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "tests/test_binding_gpu.py"]
     try:
         import xdist  # noqa: F401
-        cmd += ["-n", str(min(4, os.cpu_count() or 1))]
+        cmd += ["-n", str(min(8, os.cpu_count() or 1))]
     except ImportError:
         pass
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
