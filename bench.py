@@ -74,16 +74,32 @@ def _strip_comments(text):
     return " ".join("".join(out).split())
 
 
-def csrc_sha(d=None):
+def csrc_files(d=None):
+    d = d or os.path.join(ROOT, "permafrost-engine_amd", "csrc")
+    return sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h")))
+
+
+def csrc_sha(d=None, files=None):
     """Identity of the kernel CODE (comments and whitespace do not count): profiles/*.json measured on
-    another tree are stale."""
+    another tree are stale.  `files`: the sources a stamp covers (it lists them: every source of the tree it
+    was measured on) -- a translation unit ADDED since cannot change the kernels of the others and leaves
+    the stamp valid; a change to any covered file, headers included, or its removal, does not."""
     d = d or os.path.join(ROOT, "permafrost-engine_amd", "csrc")
     h = hashlib.sha1()
-    for f in sorted(os.listdir(d)):
+    for f in sorted(files) if files is not None else csrc_files(d):
         if f.endswith((".hip", ".h")):
             h.update(f.encode())
-            h.update(_strip_comments(open(os.path.join(d, f), encoding="utf-8", errors="replace").read()).encode())
+            try:
+                text = open(os.path.join(d, f), encoding="utf-8", errors="replace").read()
+            except OSError:
+                return "missing:" + f
+            h.update(_strip_comments(text).encode())
     return h.hexdigest()[:12]
+
+
+def stamp_is_current(stamp):
+    """A profiles/*.json stamp {csrc_sha, files} against this tree."""
+    return bool(stamp.get("csrc_sha")) and stamp.get("csrc_sha") == csrc_sha(files=stamp.get("files"))
 
 
 def usable_cores():
@@ -420,11 +436,11 @@ def main():
             break
         except Exception:
             pass
-    stale = measured.get("csrc_sha") != sha
+    stale = not stamp_is_current(measured)
     sq = {}
     try:
         sqj = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
-        if sqj.get("csrc_sha") == sha:
+        if stamp_is_current(sqj):
             sq = sqj["kernels"]
     except Exception:
         pass

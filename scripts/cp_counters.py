@@ -45,7 +45,7 @@ def main():
     out = {"source": "rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, three passes each of bench.py --steps 100 "
                      "--warmup 5 (pmccp: mean of each kernel's last 6 ticks' dispatches = ticks ~105-110) and bench.py "
                      "--crowded --steps 20 --warmup 3 (pmccpc: the dispatches after the first 3 ticks)",
-           "csrc_sha": bench.csrc_sha(), "kernels": {}}
+           "csrc_sha": bench.csrc_sha(), "files": bench.csrc_files(), "kernels": {}}
     for (run, k), cs in sorted(acc.items()):
         n = max(len(v) for v in cs.values())
         per_tick = 2 if k == "k_cp_rows" else 1

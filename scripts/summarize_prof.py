@@ -108,7 +108,7 @@ def main():
         res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py "
                          "--steps 100 --warmup 5; per kernel and TICK the mean over the last %d ticks (the profiled ticks "
                          "at the end of the run, which bench.py's roofline times)" % LAST,
-               "csrc_sha": sha,
+               "csrc_sha": sha, "files": bench.csrc_files(),
                "corrections": "both counters are KB (x1024); gfx950 FETCH_SIZE counts 128-B requests at 64 B: x2 "
                               "('corr'); WRITE_SIZE calibrated on k_field_bfs, which writes exactly 4096 B per field "
                               "with 16 B/lane coalesced stores",
@@ -144,7 +144,7 @@ def main():
             out[k] = dd
         doc = {"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES on "
                          "bench.py --steps 100 --warmup 5; per kernel and TICK (a kernel launched twice a tick counts "
-                         "twice): the mean over the last %d ticks (early ticks: 6-11)" % LAST, "csrc_sha": sha, "kernels": out}
+                         "twice): the mean over the last %d ticks (early ticks: 6-11)" % LAST, "csrc_sha": sha, "files": bench.csrc_files(), "kernels": out}
         json.dump(doc, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)
         json.dump(doc, open(os.path.join(dst, pre + "sq_counters_%s.json" % suf), "w"), indent=1)
         for k in sorted(out, key=lambda k: -out[k].get("SQ_INSTS_VALU", 0))[:8]:

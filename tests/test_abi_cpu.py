@@ -236,3 +236,34 @@ def test_persistent_clearpath_kernels_share_their_allocation_granules(tmp_path):
     assert alloc(rows[0][0]) == alloc(heavy[0][0]) == 128, (rows, heavy)
     assert rows[0][1] >= heavy[0][1], (rows, heavy)
     assert 4 * rows[0][1] <= 160 * 1024 and 4 * heavy[0][1] <= 160 * 1024      # four workgroups per CU, by LDS
+
+
+def test_profile_stamps_cover_the_files_they_list(tmp_path):
+    """profiles/traffic.json and sq_counters.json are quoted by bench.py only for the kernel code they were
+    measured on: the stamp lists the sources it covers.  A translation unit added later leaves it valid; a
+    change to a covered file (or its removal) does not; comments and whitespace do not count."""
+    import json
+    import shutil
+    sys.path.insert(0, ROOT)
+    import bench
+    csrc = os.path.join(ROOT, "permafrost-engine_amd", "csrc")
+    for name in ("traffic.json", "sq_counters.json"):
+        stamp = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert stamp["files"] == sorted(stamp["files"]) and "agent_kernels.hip" in stamp["files"]
+        assert bench.stamp_is_current(stamp), name + " was measured on other kernel code than this tree's"
+    d = str(tmp_path / "csrc")
+    os.makedirs(d)
+    for f in bench.csrc_files(csrc):
+        shutil.copy(os.path.join(csrc, f), d)
+    files, sha = bench.csrc_files(d), bench.csrc_sha(d)
+    assert sha == bench.csrc_sha(csrc)
+    open(os.path.join(d, "later_unit.hip"), "w").write("__global__ void k_later() {}\n")
+    assert bench.csrc_sha(d) != sha and bench.csrc_sha(d, files) == sha
+    with open(os.path.join(d, "agent_math.h"), "a") as f:
+        f.write("// a comment\n\n")
+    assert bench.csrc_sha(d, files) == sha
+    with open(os.path.join(d, "agent_math.h"), "a") as f:
+        f.write("#define NH_SOMETHING_ELSE 1\n")
+    assert bench.csrc_sha(d, files) != sha
+    os.remove(os.path.join(d, "agent_math.h"))
+    assert bench.csrc_sha(d, files).startswith("missing:")
