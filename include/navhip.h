@@ -604,6 +604,93 @@ int  navhip_state_update(navhip_ctx *ctx, const navhip_world *world, const navhi
 int  navhip_state_update_dev(navhip_ctx *ctx, const navhip_world *dev_world, const navhip_state_in *dev_in,
                              uint8_t *dev_out_state, uint8_t *dev_out_flags, void *stream);
 
+/* ---- more of entity_compute_update: the heading gate and the arrival overlay's settle rule ----
+ *
+ * The heading gate (movement.c:2319-2336): a unit in STATE_MOVING / SEEK_ENEMIES / SURROUND_ENTITY /
+ * ENTER_ENTITY_RANGE (move_gated_by_heading, :2273) whose new velocity is longer than EPSILON does not translate
+ * while its facing (movestate.next_rot) is more than MOVE_HEADING_HALT (90 degrees, a unit that is rolling:
+ * |movestate.velocity| > EPSILON) or MOVE_HEADING_RESUME (10 degrees, a halted one) off its intended heading
+ * (vdes when that is longer than EPSILON, else the new velocity, :2286): its velocity becomes zero and it turns in
+ * place (turn_to_move).  The reference measures the angle with float quaternions and atan2
+ * (PFM_Quat_PitchDiff, pf_math.c:677; dir_quat_from_velocity, movement.c:1411); the device compares the cosine
+ * in double and leaves a unit whose cosine is within 1e-4 of the tolerance's to the host (NAVHIP_GATE_HOST;
+ * the float path's error is below 1e-6).  world: n_ents, pos_xz, vel_xz (movestate.velocity), state, work range.
+ * out_vel_xz[i] = the velocity after the gate, out_new_pos_xz[i] = new_pos_for_vel (:1820) of it -- what
+ * navhip_state_in.new_pos_xz wants at 20 Hz -- out_gate[i] = NAVHIP_GATE_*.  Rows of the slab are written. */
+typedef struct navhip_gate_in {
+    const float *next_rot;     /* [n][4] movestate.next_rot (x, y, z, w)                            */
+    const float *new_vel_xz;   /* [n][2] move_work_out.ent_vel: the velocity the step produced      */
+    const float *vdes_xz;      /* [n][2] move_work_out.ent_des_v                                    */
+} navhip_gate_in;
+#define NAVHIP_GATE_TURN  0x01   /* turn_to_move: the velocity was zeroed, the unit pivots (UPDATE_TURNING_IN_PLACE) */
+#define NAVHIP_GATE_HOST  0x80   /* within the margin: not decided, out_vel / out_new_pos hold the UNGATED step     */
+int  navhip_heading_gate(navhip_ctx *ctx, const navhip_world *world, const navhip_gate_in *in,
+                         float *out_vel_xz, float *out_new_pos_xz, uint8_t *out_gate);
+/* Everything resident on the device, asynchronous on `stream`. */
+int  navhip_heading_gate_dev(navhip_ctx *ctx, const navhip_world *dev_world, const navhip_gate_in *dev_in,
+                             float *dev_out_vel_xz, float *dev_out_new_pos_xz, uint8_t *dev_out_gate, void *stream);
+
+/* adjacent_settled_count (movement.c:982) for nq units of the snapshot: G_Pos_EntsInCircleFrom (r = max(30,
+ * 2 radius + 5), at most 128 results, garrisoned entities dropped, position.c:379) and of those the movable
+ * ones of the same air / ground kind in STATE_ARRIVED that touch the unit (distance <= both radii +
+ * ADJACENCY_SEP_DIST).  out_counts[q] = -1 for a unit with radius > 12.5 (its query is wider than the 30 units
+ * the spatial index is asked for here): the host counts.  world: n_ents, pos_xz, radius, flags, state, grid
+ * bounds.  Host buffers. */
+int  navhip_settled_count(navhip_ctx *ctx, const navhip_world *world, int nq, const int32_t *uids,
+                          int32_t *out_counts);
+
+/* G_Arrival_ShouldSettle (arrival.c:946) for nq units whose flock has an active arrival zone (G_Arrival_IsActive)
+ * for their nav layer -- the arm of entity_compute_update at movement.c:2443-2451 that navhip_state_update leaves
+ * to the host (skip[i]).  A zone is one struct arrival_state (arrival.h:66): the slots, their fill ranks and the
+ * sorted tile keys of its footprint are given as ranges of three shared arrays.  Per unit: the position the
+ * state update tests, the count of settled neighbours (navhip_settled_count), and its struct
+ * arrival_unit_state (arrival.h:105) -- which the rule also UPDATES (arming, the progress anchor, the stuck
+ * count): the out_* arrays receive the state after the call, as the reference leaves it in movestate.arrival.
+ * world: n_ents, vel_xz (movestate.velocity), radius, map_pos.  Needs the BLOCKERS plane of the zones' layers
+ * (M_NavPositionBlocked on a slot).  out_settle[q] = 1: UPDATE_SET_STATE, STATE_ARRIVED, next_block. */
+typedef struct navhip_arrival_zone {
+    float    centre_x, centre_z;      /* arrival_state.centre                                                   */
+    float    unit_radius;             /* .unit_radius                                                           */
+    float    fill_frac;               /* .fill_frac                                                             */
+    int32_t  radius;                  /* .radius (nav tiles)                                                    */
+    int32_t  layer;                   /* .layer                                                                 */
+    int32_t  active_row, num_rows;    /* .active_row, .num_rows                                                 */
+    int32_t  slot_begin, slot_end;    /* .slots / .slot_ring [0, num_slots) as a range of slots_xz / slot_ring  */
+    int32_t  key_begin, key_end;      /* .region_keys [0, num_region) as a range of region_keys                 */
+} navhip_arrival_zone;
+typedef struct navhip_settle_in {
+    int32_t  n_zones;
+    int32_t  nq;
+    const navhip_arrival_zone *zones; /* [n_zones]                                                              */
+    const float    *slots_xz;         /* [..][2]                                                                */
+    const int32_t  *slot_ring;        /* [..]                                                                   */
+    const uint64_t *region_keys;      /* [..] td_key (nav.c:207): chunk_r << 48 | chunk_c << 32 | tile_r << 16 | tile_c,
+                                              ascending inside a zone (N_TileKeysForPositions, nav.c:4303)      */
+    const int32_t  *uid;              /* [nq] the unit (row of the world's arrays)                              */
+    const int32_t  *zone;             /* [nq] its zone                                                          */
+    const float    *new_pos_xz;       /* [nq][2] the position entity_compute_update tests (navhip_state_in)     */
+    const int32_t  *nsettled;         /* [nq] adjacent_settled_count                                            */
+    const uint8_t  *substate;         /* [nq] arrival_unit_state.substate (enum arrival_substate, arrival.h:55) */
+    const uint8_t  *sink_valid;       /* [nq] .sink_valid                                                       */
+    const float    *sink_xz;          /* [nq][2] .sink                                                          */
+    const float    *order_pos_xz;     /* [nq][2] .order_pos                                                     */
+    const float    *progress_anchor_xz; /* [nq][2] .progress_anchor                                             */
+    const uint8_t  *progress_anchored;  /* [nq] .progress_anchored                                              */
+    const int32_t  *stuck;            /* [nq] .stuck                                                            */
+} navhip_settle_in;
+typedef struct navhip_settle_out {
+    uint8_t  *settle;                 /* [nq] the rule's answer                                                 */
+    uint8_t  *substate;               /* [nq] arrival_unit_state after the call                                 */
+    float    *progress_anchor_xz;     /* [nq][2]                                                                */
+    uint8_t  *progress_anchored;      /* [nq]                                                                   */
+    int32_t  *stuck;                  /* [nq]                                                                   */
+} navhip_settle_out;
+int  navhip_arrival_settle(navhip_ctx *ctx, const navhip_world *world, const navhip_settle_in *in,
+                           const navhip_settle_out *out);
+/* Everything resident on the device (the zones' arrays and the per-unit arrays too), asynchronous on `stream`. */
+int  navhip_arrival_settle_dev(navhip_ctx *ctx, const navhip_world *dev_world, const navhip_settle_in *dev_in,
+                               const navhip_settle_out *dev_out, void *stream);
+
 /* N_DesiredGroupArrivalVelocity (nav.c:3561) for nq points: the direction under each point in the chunk
  * field of mapping row rows[q] (region_field_slot / field_pool as in navhip_world; resident pool: pass
  * region_field_slot = field_pool = NULL), and whether that tile is a sink inside the zone's disc

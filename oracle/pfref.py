@@ -143,6 +143,12 @@ def lib():
             ("pfref_move_unload", [], None),
             ("pfref_move_set_formation", [C.c_void_p] * 5, None),
             ("pfref_move_set_arrival", [C.c_void_p] * 2, None),
+            ("pfref_move_heading_gate", [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p] * 2, None),
+            ("pfref_move_dir_quat", [C.c_void_p, C.c_int, C.c_void_p], None),
+            ("pfref_move_settled_count", [C.c_void_p, C.c_int, C.c_void_p], None),
+            ("pfref_arrival_should_settle", [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_int] + [C.c_void_p] * 12, C.c_int),
             ("pfref_move_vpref", [C.c_int, C.c_void_p, C.c_void_p], None),
             ("pfref_move_forces", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
              None),
@@ -661,6 +667,32 @@ class RefMove:
         lib().pfref_move_hip_state_stats(out)
         return tuple(out)
 
+    def heading_gate(self, new_vel, vdes, next_rot, begin=0, end=None):
+        """entity_compute_update with movestate.next_rot given (the heading gate, movement.c:2319-2336):
+        (turn_to_move [n] u8 = UPDATE_TURNING_IN_PLACE of the patch, next_velocity [n][2])."""
+        end = self.n if end is None else end
+        v = np.ascontiguousarray(new_vel, np.float32).reshape(self.n, 2)
+        d = np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
+        r = np.ascontiguousarray(next_rot, np.float32).reshape(self.n, 4)
+        turn, vel = np.zeros(self.n, np.uint8), np.zeros((self.n, 2), np.float32)
+        lib().pfref_move_heading_gate(_p(v), _p(d), _p(r), begin, end, _p(turn), _p(vel))
+        return turn, vel
+
+    @staticmethod
+    def dir_quat(heading_xz):
+        """dir_quat_from_velocity (movement.c:1411) per row."""
+        h = np.ascontiguousarray(heading_xz, np.float32).reshape(-1, 2)
+        out = np.zeros((len(h), 4), np.float32)
+        lib().pfref_move_dir_quat(_p(h), len(h), _p(out))
+        return out
+
+    def settled_count(self, uids):
+        """adjacent_settled_count (movement.c:982) of the loaded snapshot."""
+        u = np.ascontiguousarray(uids, np.int32)
+        out = np.zeros(len(u), np.int32)
+        lib().pfref_move_settled_count(_p(u), len(u), _p(out))
+        return out
+
     def set_arrival(self, sink_xz, flags):
         """Fine-arrival inputs: per-unit slot + flags (bit 0 committed to a valid slot, bit 1 the
         flock's arrival region for the unit's layer is filling)."""
@@ -745,3 +777,32 @@ class RefMove:
     @staticmethod
     def unload():
         lib().pfref_move_unload()
+
+
+def arrival_should_settle(nav, zone, units):
+    """G_Arrival_ShouldSettle (arrival.c:946) for the units of one zone.  zone: dict(layer, centre_xz, radius,
+    unit_radius, fill_frac, active_row, num_rows, slots_xz [S][2], slot_ring [S], region_xz [R][2] positions whose
+    tiles are the footprint); units: dict(new_pos_xz, vel_xz, radius, nsettled, substate, sink_valid, sink_xz,
+    order_pos_xz, progress_anchor_xz, progress_anchored, stuck), arrays of nq rows.  Returns (settle [nq] u8,
+    region_keys u64 sorted, dict of the unit state after the call)."""
+    f32 = lambda a, w: np.ascontiguousarray(a, np.float32).reshape(-1, w) if w > 1 else np.ascontiguousarray(a, np.float32)
+    slots, ring = f32(zone["slots_xz"], 2), np.ascontiguousarray(zone["slot_ring"], np.int32)
+    reg = f32(zone["region_xz"], 2)
+    keys = np.zeros(max(1, len(reg)), np.uint64)
+    cen = f32(zone["centre_xz"], 1)
+    nq = len(units["nsettled"])
+    sub = np.array(units["substate"], np.uint8)
+    anc = np.array(f32(units["progress_anchor_xz"], 2))
+    anced = np.array(units["progress_anchored"], np.uint8)
+    stuck = np.array(units["stuck"], np.int32)
+    keep = [f32(units["new_pos_xz"], 2), f32(units["vel_xz"], 2), f32(units["radius"], 1),
+            np.ascontiguousarray(units["nsettled"], np.int32), np.ascontiguousarray(units["sink_valid"], np.uint8),
+            f32(units["sink_xz"], 2), f32(units["order_pos_xz"], 2)]
+    out = np.zeros(nq, np.uint8)
+    nk = lib().pfref_arrival_should_settle(
+        nav._h, int(zone["layer"]), _p(cen), int(zone["radius"]), float(zone["unit_radius"]), float(zone["fill_frac"]),
+        int(zone["active_row"]), int(zone["num_rows"]), _p(slots), _p(ring), len(ring), _p(reg), len(reg), _p(keys),
+        nq, _p(keep[0]), _p(keep[1]), _p(keep[2]), _p(keep[3]), _p(sub), _p(keep[4]), _p(keep[5]), _p(keep[6]),
+        _p(anc), _p(anced), _p(stuck), _p(out))
+    assert nk >= 0
+    return out, keys[:nk].copy(), {"substate": sub, "progress_anchor_xz": anc, "progress_anchored": anced, "stuck": stuck}

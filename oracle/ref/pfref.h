@@ -263,6 +263,21 @@ void pfref_move_velocity(const float *vdes, int begin, int end, float *out_vel);
 /* formation inputs of every work item: fstate.assignment_ready, cell_pos, fstate.normal_*_force */
 void pfref_move_set_formation(const uint8_t *ready, const float *cell_pos, const float *cohesion,
                               const float *align, const float *drag);
+/* entity_compute_update with movestate.next_rot as an input (the heading gate, movement.c:2319-2336);
+ * dir_quat_from_velocity (:1411); adjacent_settled_count (:982); G_Arrival_ShouldSettle (arrival.c:946) against one
+ * zone given as plain arrays (see ref_move.c) */
+void pfref_move_heading_gate(const float *new_vel, const float *vdes, const float *next_rot, int begin, int end,
+                             uint8_t *out_turn, float *out_vel);
+void pfref_move_dir_quat(const float *heading_xz, int n, float *out_quat);
+void pfref_move_settled_count(const int32_t *uids, int nq, int32_t *out);
+int pfref_arrival_should_settle(pfref_nav *nav, int layer, const float *centre_xz, int radius, float unit_radius,
+                                float fill_frac, int active_row, int num_rows,
+                                const float *slots_xz, const int32_t *slot_ring, int num_slots,
+                                const float *region_xz, int num_region_pos, uint64_t *out_keys,
+                                int nq, const float *new_pos_xz, const float *vel_xz, const float *radius_of,
+                                const int32_t *nsettled, uint8_t *substate, const uint8_t *sink_valid,
+                                const float *sink_xz, const float *order_pos_xz, float *progress_anchor_xz,
+                                uint8_t *progress_anchored, int32_t *stuck, uint8_t *out_settle);
 /* fine-arrival inputs: sink [n][2], flags [n] (bit 0 unit committed to a valid slot, bit 1 the
  * flock's arrival_state for the unit's layer is in ARRIVAL_PHASE_FILLING) */
 void pfref_move_set_arrival(const float *sink_xz, const uint8_t *flags);

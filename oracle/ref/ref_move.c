@@ -92,6 +92,24 @@ bool M_NavClosestPathable(const struct map *map, enum nav_layer layer, vec2_t xz
     return N_ClosestPathable(&nav->priv, layer, nav->map_pos, xz_src, out);
 }
 
+bool M_NavSegmentWithinRegion(const struct map *map, vec2_t a, vec2_t b, const uint64_t *keys, size_t num)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    return N_SegmentWithinRegion(&nav->priv, nav->map_pos, a, b, keys, num);
+}
+
+size_t M_NavTileKeysForPositions(const struct map *map, const vec2_t *positions, size_t n, uint64_t *out)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    return N_TileKeysForPositions(&nav->priv, nav->map_pos, positions, n, out);
+}
+
+void M_NavGetResolution(const struct map *map, struct map_resolution *out)
+{
+    pfref_nav *nav = (pfref_nav*)map;
+    N_GetResolution(&nav->priv, out);
+}
+
 float M_HeightAtPoint(const struct map *map, vec2_t xz) { (void)map; (void)xz; return 0.0f; }
 
 /* ---- world loading ---------------------------------------------------------------------- */
@@ -636,4 +654,106 @@ void pfref_move_state_update(const float *new_vel, const float *vdes, int begin,
         out_state[i] = (uint8_t)(set ? out->patch.next_state : ms->state);
         out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0));
     }
+}
+
+/* ---- SURVEY 8(f4), the heading gate and the arrival overlay's settle rule --------------------------------- */
+
+/* entity_compute_update (movement.c:2303) with movestate.next_rot as an INPUT, so that the heading gate
+ * (:2319-2336) decides: out_turn[i] = UPDATE_TURNING_IN_PLACE of the patch (set for turn_to_move, :2405-2410;
+ * a combat-held unit sets it regardless, :2399 -- the caller leaves those out), out_vel[i] = the patch's
+ * next_velocity.  STATE_TURNING units are skipped as in pfref_move_state_update. */
+void pfref_move_heading_gate(const float *new_vel, const float *vdes, const float *next_rot, int begin, int end,
+                             uint8_t *out_turn, float *out_vel)
+{
+    for(int i = begin; i < end; i++) {
+        struct move_work_in *in = &s_move_work.in[i];
+        struct move_work_out *out = &s_move_work.out[i];
+        struct movestate *ms = movestate_get(i);
+        out_turn[i] = 0; out_vel[2 * i] = out_vel[2 * i + 1] = 0.0f;
+        if(ms->state == STATE_TURNING
+        && !(G_FlagsGetFrom(s_move_work.gamestate.flags, i) & ENTITY_FLAG_GARRISONED))
+            continue;
+        in->fstate.fid = NULL_FID;
+        out->ent_uid = i;
+        out->ent_vel = (vec2_t){new_vel[2 * i], new_vel[2 * i + 1]};
+        out->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
+        ms->next_rot = (quat_t){next_rot[4 * i], next_rot[4 * i + 1], next_rot[4 * i + 2], next_rot[4 * i + 3]};
+        memset(&out->patch, 0, sizeof(out->patch));
+        entity_compute_update(s_move_work.hz, i, out->ent_vel, out->ent_des_v, in, &out->patch);
+        out_turn[i] = (out->patch.flags & UPDATE_TURNING_IN_PLACE) != 0;
+        if(out->patch.flags & UPDATE_SET_VELOCITY) {
+            out_vel[2 * i] = out->patch.next_velocity.x; out_vel[2 * i + 1] = out->patch.next_velocity.z;
+        }
+    }
+}
+
+/* the rotation dir_quat_from_velocity (movement.c:1411) gives a heading, for building test inputs */
+void pfref_move_dir_quat(const float *heading_xz, int n, float *out_quat)
+{
+    for(int i = 0; i < n; i++) {
+        quat_t q = dir_quat_from_velocity((vec2_t){heading_xz[2 * i], heading_xz[2 * i + 1]});
+        out_quat[4 * i] = q.x; out_quat[4 * i + 1] = q.y; out_quat[4 * i + 2] = q.z; out_quat[4 * i + 3] = q.w;
+    }
+}
+
+/* adjacent_settled_count (movement.c:982) on the loaded snapshot */
+void pfref_move_settled_count(const int32_t *uids, int nq, int32_t *out)
+{
+    for(int q = 0; q < nq; q++)
+        out[q] = adjacent_settled_count((uint32_t)uids[q]);
+}
+
+/* G_Arrival_ShouldSettle (arrival.c:946) for nq units against ONE zone given as plain arrays: the zone's
+ * struct arrival_state is filled from them (region_keys = N_TileKeysForPositions of region_xz, nav.c:4303,
+ * returned in out_keys; returns their number), each unit's struct arrival_unit_state from the per-unit arrays,
+ * and written back after the call. */
+int pfref_arrival_should_settle(pfref_nav *nav, int layer, const float *centre_xz, int radius, float unit_radius,
+                                float fill_frac, int active_row, int num_rows,
+                                const float *slots_xz, const int32_t *slot_ring, int num_slots,
+                                const float *region_xz, int num_region_pos, uint64_t *out_keys,
+                                int nq, const float *new_pos_xz, const float *vel_xz, const float *radius_of,
+                                const int32_t *nsettled, uint8_t *substate, const uint8_t *sink_valid,
+                                const float *sink_xz, const float *order_pos_xz, float *progress_anchor_xz,
+                                uint8_t *progress_anchored, int32_t *stuck, uint8_t *out_settle)
+{
+    if(num_slots > ARRIVAL_MAX_SLOTS || num_region_pos > ARRIVAL_MAX_SLOTS)
+        return -1;
+    struct arrival_state *as = calloc(1, sizeof(*as));
+    as->phase = ARRIVAL_PHASE_FILLING;
+    as->layer = (enum nav_layer)layer;
+    as->centre = (vec2_t){centre_xz[0], centre_xz[1]};
+    as->radius = (uint16_t)radius;
+    as->unit_radius = unit_radius;
+    as->fill_frac = fill_frac;
+    as->active_row = active_row;
+    as->num_rows = num_rows;
+    as->num_slots = num_slots;
+    for(int i = 0; i < num_slots; i++) {
+        as->slots[i] = (vec2_t){slots_xz[2 * i], slots_xz[2 * i + 1]};
+        as->slot_ring[i] = slot_ring[i];
+    }
+    as->num_region = (int)N_TileKeysForPositions(&nav->priv, nav->map_pos, (const vec2_t*)region_xz,
+                                                 (size_t)num_region_pos, as->region_keys);
+    memcpy(out_keys, as->region_keys, sizeof(uint64_t) * as->num_region);
+    for(int q = 0; q < nq; q++) {
+        struct arrival_unit_state us;
+        memset(&us, 0, sizeof(us));
+        us.substate = (enum arrival_substate)substate[q];
+        us.sink_valid = sink_valid[q] != 0;
+        us.sink = (vec2_t){sink_xz[2 * q], sink_xz[2 * q + 1]};
+        us.order_pos = (vec2_t){order_pos_xz[2 * q], order_pos_xz[2 * q + 1]};
+        us.progress_anchor = (vec2_t){progress_anchor_xz[2 * q], progress_anchor_xz[2 * q + 1]};
+        us.progress_anchored = progress_anchored[q] != 0;
+        us.stuck = stuck[q];
+        out_settle[q] = G_Arrival_ShouldSettle(as, &us, (const struct map*)nav, (const struct map*)nav,
+            (vec2_t){new_pos_xz[2 * q], new_pos_xz[2 * q + 1]}, (vec2_t){vel_xz[2 * q], vel_xz[2 * q + 1]},
+            radius_of[q], nsettled[q]) ? 1 : 0;
+        substate[q] = (uint8_t)us.substate;
+        progress_anchor_xz[2 * q] = us.progress_anchor.x; progress_anchor_xz[2 * q + 1] = us.progress_anchor.z;
+        progress_anchored[q] = us.progress_anchored ? 1 : 0;
+        stuck[q] = us.stuck;
+    }
+    const int nk = as->num_region;
+    free(as);
+    return nk;
 }

@@ -1,0 +1,475 @@
+// state_kernels.hip -- more of entity_compute_update (movement.c:2303) on the device, SURVEY section 8(f4):
+// the heading gate (:2319-2336), adjacent_settled_count (:982) and the arrival overlay's settle rule
+// (G_Arrival_ShouldSettle, arrival.c:946) with what it calls: N_SegmentWithinRegion (nav.c:4326) over
+// M_Tile_LineSupercoverTilesSorted (tile.c:430), arrival_near_region / arrival_near_open_slot
+// (arrival.c:158, :326).  Kernels AND their C entry points (include/navhip.h): this translation unit was
+// added after the round's profiles were taken and touches no other (profiles/README.md, `files`); its
+// device scratch is ONE staging slot of the context, carved up per call.
+//
+// Everything here is decision logic on a few hundred bytes per unit: HBM-latency bound, one row of 16
+// lanes per unit where a loop can be shared (the slots of a zone, the pad ring of arrival_near_region), a
+// thread per unit elsewhere.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include "navhip_internal.h"
+#include "agent_internal.h"
+#include "agent_math.h"
+
+#define SK_SLOT      43          /* ctx->stage[] slot this file owns                                     */
+#define SK_QUERY_R   30.0f       /* SEPARATION_NEIGHB_RADIUS, movement.c:428                            */
+#define SK_QUERY_MAX 128         /* near_ents[128], movement.c:997                                      */
+
+#define SKCHK(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
+    (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_); return NAVHIP_ERR_DEVICE; } } while(0)
+
+// ---------------------------------------------------------------------------------------------
+// the heading gate, a thread per unit
+// ---------------------------------------------------------------------------------------------
+// PFM_Quat_PitchDiff (pf_math.c:677) turns (1, 0, 0) by both quaternions and takes atan2(det, dot) of the
+// x/z parts: the turned front of q is (1 - 2y^2 - 2z^2, 2xz + 2wy) (PFM_Mat4x4_RotFromQuat :324, column 0).
+// dir_quat_from_velocity (movement.c:1411) is the rotation about Y by atan2(v.z, v.x) - pi/2, whose turned
+// front is (cos a, sin a) = (v.z, -v.x) / |v|.  |angle| > tol  <=>  cos(angle) < cos(tol): no trigonometry,
+// and the comparison in double with a margin that is a hundred times the float path's error.
+__global__ __launch_bounds__(256) void k_heading_gate(int begin, int end, const float *pos_xz, const float *vel_xz,
+                                                      const uint8_t *state, navhip_gate_in in, float *out_vel,
+                                                      float *out_new_pos, uint8_t *out_gate)
+{
+    const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    if(i >= end) return;
+    v2 nv = mkv(in.new_vel_xz[2 * i], in.new_vel_xz[2 * i + 1]);
+    const int st = state[i];
+    uint8_t gate = 0;
+    const bool gated_state = st == NAVHIP_STATE_MOVING || st == NAVHIP_STATE_SEEK_ENEMIES
+                          || st == NAVHIP_STATE_SURROUND_ENTITY || st == NAVHIP_STATE_ENTER_ENTITY_RANGE;
+    if(gated_state && vlen(nv) > CP_EPS) {
+        const v2 vdes = mkv(in.vdes_xz[2 * i], in.vdes_xz[2 * i + 1]);
+        const v2 h = vlen(vdes) > CP_EPS ? vdes : nv;                       // intended_heading, :2286
+        const double qx = in.next_rot[4 * i], qy = in.next_rot[4 * i + 1], qz = in.next_rot[4 * i + 2],
+                     qw = in.next_rot[4 * i + 3];
+        const double d1x = 1.0 - 2.0 * qy * qy - 2.0 * qz * qz, d1z = 2.0 * qx * qz + 2.0 * qw * qy;
+        const double d2x = (double)h.z, d2z = -(double)h.x;
+        const double l1 = sqrt(d1x * d1x + d1z * d1z), l2 = sqrt(d2x * d2x + d2z * d2z);
+        const bool rolling = vlen(mkv(vel_xz[2 * i], vel_xz[2 * i + 1])) > CP_EPS;
+        // cos(90 deg), cos(10 deg)
+        const double cos_tol = rolling ? 0.0 : 0.98480775301220805936674302458952;
+        if(!(l1 * l2 > 1e-9)) {
+            gate = NAVHIP_GATE_HOST;                                        // not a yaw: the host's float path decides
+        }else{
+            const double c = (d1x * d2x + d1z * d2z) / (l1 * l2);
+            if(fabs(c - cos_tol) < 1e-4) gate = NAVHIP_GATE_HOST;
+            else if(c < cos_tol) { gate = NAVHIP_GATE_TURN; nv = mkv(0.0f, 0.0f); }
+        }
+    }
+    out_vel[2 * i] = nv.x; out_vel[2 * i + 1] = nv.z;
+    out_new_pos[2 * i] = pos_xz[2 * i] + nv.x;                              // new_pos_for_vel, :1820
+    out_new_pos[2 * i + 1] = pos_xz[2 * i + 1] + nv.z;
+    out_gate[i] = gate;
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjacent_settled_count: the ids of the spatial query (k_spatial_query, the reference's visiting order,
+// capped) -> the count, a thread per unit
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_settled_count(int nq, const int32_t *uids, const float *pos_xz,
+                                                       const float *radius, const uint32_t *flags,
+                                                       const uint8_t *state, const int32_t *q_counts,
+                                                       const uint32_t *q_ids, int32_t *out)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if(q >= nq) return;
+    const int uid = uids[q];
+    const float r_uid = radius[uid];
+    if(2.0f * r_uid + 5.0f > SK_QUERY_R) { out[q] = -1; return; }           // search_radius, :995
+    const v2 pos = mkv(pos_xz[2 * uid], pos_xz[2 * uid + 1]);
+    const uint32_t my_air = flags[uid] & NAVHIP_ENTITY_FLAG_AIR;
+    int count = 0;
+    const uint32_t *ids = q_ids + (size_t)q * SK_QUERY_MAX;
+    for(int k = 0; k < q_counts[q]; k++) {
+        const int c = (int)ids[k];
+        const uint32_t f = flags[c];
+        if(f & NAVHIP_ENTITY_FLAG_GARRISONED) continue;                     // filter_garrisoned, position.c:384
+        if(c == uid || !(f & NAVHIP_ENTITY_FLAG_MOVABLE) || (f & NAVHIP_ENTITY_FLAG_AIR) != my_air) continue;
+        if(state[c] != NAVHIP_STATE_ARRIVED) continue;
+        const v2 cp = mkv(pos_xz[2 * c], pos_xz[2 * c + 1]);
+        if(vlen(vsub(pos, cp)) <= r_uid + radius[c] + 5.0f) count++;         // ADJACENCY_SEP_DIST
+    }
+    out[q] = count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// G_Arrival_ShouldSettle, a row of 16 lanes per unit
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sk_row_any(bool p)                          // over the 16 lanes of the unit's row
+{
+    return ((__ballot(p) >> (threadIdx.x & 48)) & 0xffffull) != 0ull;
+}
+
+__device__ __forceinline__ uint64_t sk_key(const tiledesc &t)              // td_key, nav.c:207
+{
+    return ((uint64_t)t.chunk_r << 48) | ((uint64_t)t.chunk_c << 32) | ((uint64_t)t.tile_r << 16) | (uint64_t)t.tile_c;
+}
+
+__device__ bool sk_keys_contain(const uint64_t *keys, int num, uint64_t k)   // region_keys_contain, nav.c:4283
+{
+    int lo = 0, hi = num;
+    while(lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        const uint64_t v = keys[mid];
+        if(v == k) return true;
+        if(v < k) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+// N_SegmentWithinRegion (nav.c:4326): every tile of the supercover walk from a to b (tile.c:430, both ends
+// inside the map, so the walk starts at a) is a key of the region.  The walk's floats are the reference's:
+// PFM_Vec2_Normal of the direction, fabs() promoting the t_max quotients to double before they are stored in a
+// float, M_Tile_Bounds as (map - chunk * 256) - tile * 4.  a == b gives NaN everywhere and one tile, as there.
+__device__ bool sk_segment_within(const nh_step_params &P, v2 a, v2 b, const uint64_t *keys, int num)
+{
+    if(num == 0) return false;
+    tiledesc ta, tb;
+    if(!tile_for_point(P, a.x, a.z, ta) || !tile_for_point(P, b.x, b.z, tb)) return false;
+    const int ar = ta.chunk_r * 64 + ta.tile_r, ac = ta.chunk_c * 64 + ta.tile_c;
+    const int br = tb.chunk_r * 64 + tb.tile_r, bc = tb.chunk_c * 64 + tb.tile_c;
+    const int maxout = abs(br - ar) + abs(bc - ac) + 2;
+    v2 dir = mkv(b.x - a.x, b.z - a.z);
+    const float len = vlen(dir);
+    dir = mkv(dir.x / len, dir.z / len);
+    const int step_c = dir.x <= 0.0f ? 1 : -1, step_r = dir.z >= 0.0f ? 1 : -1;
+    const float t_delta_x = fabsf(4.0f / dir.x), t_delta_z = fabsf(4.0f / dir.z);
+    const float bx = (P.map_x - (float)(ta.chunk_c * 256)) - (float)(ta.tile_c * 4);
+    const float bz = (P.map_z + (float)(ta.chunk_r * 256)) + (float)(ta.tile_r * 4);
+    float t_max_x = (float)((step_c > 0 ? fabs((double)(a.x - (bx - 4.0f))) : fabs((double)(a.x - bx))) / fabs((double)dir.x));
+    float t_max_z = (float)((step_r > 0 ? fabs((double)(a.z - (bz + 4.0f))) : fabs((double)(a.z - bz))) / fabs((double)dir.z));
+    int r = ar, c = ac;
+    const int max_r = P.map.h * 64, max_c = P.map.w * 64;
+    for(int n = 0; n < maxout; n++) {
+        tiledesc t;
+        t.chunk_r = r >> 6; t.chunk_c = c >> 6; t.tile_r = r & 63; t.tile_c = c & 63;
+        if(!sk_keys_contain(keys, num, sk_key(t))) return false;
+        int dc = 0, dr = 0;
+        if(t_max_x < t_max_z) { t_max_x = t_max_x + t_delta_x; dc = step_c; }
+        else                  { t_max_z = t_max_z + t_delta_z; dr = step_r; }
+        if(r == br && c == bc) break;
+        r += dr; c += dc;
+        if(r < 0 || r >= max_r || c < 0 || c >= max_c) break;             // M_Tile_RelativeDesc
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool sk_in_region(const nh_step_params &P, v2 p, const uint64_t *keys, int num)
+{
+    // arrival_in_region (arrival.c:153): the walk from p to p is the tile of p
+    tiledesc t;
+    if(num == 0 || !tile_for_point(P, p.x, p.z, t)) return false;
+    return sk_keys_contain(keys, num, sk_key(t));
+}
+
+__global__ __launch_bounds__(256) void k_arrival_settle(nh_step_params P, const float *vel_xz, const float *radius_of,
+                                                        navhip_settle_in in, navhip_settle_out out)
+{
+    const int q = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int gl = (int)(threadIdx.x & 15);
+    if(q >= in.nq) return;
+    const int uid = in.uid[q];
+    const navhip_arrival_zone Z = in.zones[in.zone[q]];
+    const uint64_t *keys = in.region_keys + Z.key_begin;
+    const int num_region = Z.key_end - Z.key_begin;
+    const v2 np = mkv(in.new_pos_xz[2 * q], in.new_pos_xz[2 * q + 1]);
+    const v2 vel = mkv(vel_xz[2 * uid], vel_xz[2 * uid + 1]);
+    const float radius = radius_of[uid];
+    const int nsettled = in.nsettled[q];
+    int substate = in.substate[q], stuck = in.stuck[q];
+    bool anchored = in.progress_anchored[q] != 0;
+    v2 anchor = mkv(in.progress_anchor_xz[2 * q], in.progress_anchor_xz[2 * q + 1]);
+    const bool sink_valid = in.sink_valid[q] != 0;
+    const v2 sink = mkv(in.sink_xz[2 * q], in.sink_xz[2 * q + 1]);
+
+    const bool in_region = sk_in_region(P, np, keys, num_region);
+    // arrival_near_region (arrival.c:158): the ring of pad tiles around the position, shared by the lanes
+    bool near_region = in_region;
+    if(!in_region) {
+        int pad = (int)ceilf(Z.unit_radius / 4.0f);
+        if(pad < 1) pad = 1;
+        const int side = 2 * pad + 1;
+        bool hit = false;
+        for(int k = gl; k < side * side; k += 16) {
+            const int dz = k / side - pad, dx = k % side - pad;
+            if(dx == 0 && dz == 0) continue;
+            hit = hit || sk_in_region(P, mkv(np.x + (float)dx * 4.0f, np.z + (float)dz * 4.0f), keys, num_region);
+        }
+        near_region = sk_row_any(hit);
+    }
+    // arrival_near_open_slot (arrival.c:326), tolerance radius * ARRIVAL_SINK_TOLERANCE: any slot of an active
+    // row within it that no blocker stands on
+    bool at_sink = false;
+    if(in_region) {
+        const float tol = radius * 1.5f, tol2 = tol * tol;
+        bool hit = false;
+        const nh_layer_view &L = P.map.layers[Z.layer];
+        for(int k = Z.slot_begin + gl; k < Z.slot_end; k += 16) {
+            if(in.slot_ring[k] > Z.active_row) continue;
+            const v2 s = mkv(in.slots_xz[2 * k], in.slots_xz[2 * k + 1]);
+            const v2 d = vsub(s, np);
+            if(vdot(d, d) > tol2) continue;
+            tiledesc t;
+            bool blocked = false;
+            if(L.blockers && tile_for_point(P, s.x, s.z, t)) blocked = L.blockers[tile_index(P, t)] > 0;
+            hit = hit || !blocked;
+        }
+        at_sink = sk_row_any(hit);
+    }
+    int settle_contacts = 3;                                                // ARRIVAL_SETTLE_CONTACTS
+    if(Z.fill_frac >= 0.90f) settle_contacts = 2;                          // (as the reference has it, :959-962)
+    else if(Z.fill_frac >= 0.75f) settle_contacts = 3;
+    const bool reachable_slot = sink_valid && sk_segment_within(P, np, sink, keys, num_region);
+    const bool fill_done = Z.active_row >= Z.num_rows - 1;
+    bool advancing = false;
+    if(sink_valid) advancing = vdot(vel, vsub(sink, np)) > 0.0f;
+    // unit_armed / unit_arm (arrival.c:96, :110): APPROACH 0, APPROACH_ARMED 1, SEEK 2, SEEK_ARMED 3
+    bool armed = substate == 1 || substate == 3;
+    if(!armed) {
+        const v2 order = mkv(in.order_pos_xz[2 * q], in.order_pos_xz[2 * q + 1]);
+        if(vlen(vsub(np, order)) > 4.0f) { substate += 1; armed = true; }    // ARRIVAL_ENGAGE_DIST
+    }
+    const bool by_prop = armed && !at_sink && in_region && nsettled >= settle_contacts
+                      && (reachable_slot ? !advancing : fill_done);
+    const float settle_range = ((float)Z.radius * 4.0f + radius) * 1.875f;  // ARRIVAL_SETTLE_RANGE
+    const v2 to_centre = vsub(np, mkv(Z.centre_x, Z.centre_z));
+    const bool within_settle_range = vdot(to_centre, to_centre) <= settle_range * settle_range;
+    const bool stuck_eligible = nsettled >= 1 && (near_region || within_settle_range);
+    if(!at_sink && stuck_eligible && armed) {
+        if(!anchored) { anchor = np; anchored = true; stuck = 0; }
+        if(vlen(vsub(np, anchor)) > 1.875f) { anchor = np; stuck = 0; }      // ARRIVAL_STUCK_DISP
+        else stuck++;
+    }
+    const bool by_stuck = !at_sink && !by_prop && stuck_eligible && stuck >= 12;   // ARRIVAL_STUCK_LIMIT
+    const bool by_contact = armed && !at_sink && near_region && !reachable_slot && nsettled >= 1
+                         && Z.fill_frac >= 0.90f;
+    if(gl == 0) {
+        out.settle[q] = (at_sink || by_prop || by_stuck || by_contact) ? 1 : 0;
+        out.substate[q] = (uint8_t)substate;
+        out.progress_anchor_xz[2 * q] = anchor.x; out.progress_anchor_xz[2 * q + 1] = anchor.z;
+        out.progress_anchored[q] = anchored ? 1 : 0;
+        out.stuck[q] = stuck;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C entry points
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct sk_arena {                     // one staging slot, carved up: offsets first, then the pointer
+    size_t total = 0;
+    size_t take(size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; }
+};
+
+void sk_map_view(const navhip_ctx *ctx, const navhip_world *w, nh_step_params *P)
+{
+    memset(P, 0, sizeof(*P));
+    P->map.w = ctx->w; P->map.h = ctx->h;
+    for(int l = 0; l < NAVHIP_NAV_LAYER_MAX; l++) {
+        const navhip_layer &L = ctx->layers[l];
+        P->map.layers[l] = nh_layer_view{L.cost, L.blockers, L.local_islands, L.factions,
+                                         L.passmask, L.unit_cost, L.changed, L.islands, L.probemask};
+    }
+    P->map_x = w->map_pos_x; P->map_z = w->map_pos_z;
+    P->n_ents = w->n_ents;
+}
+
+bool sk_work_range(const navhip_world *w, int *b, int *e)
+{
+    *b = w->work_begin; *e = w->work_end;
+    if(*b == 0 && *e == 0) *e = w->n_ents;
+    return *b >= 0 && *e <= w->n_ents && *b <= *e;
+}
+
+}   // namespace
+
+extern "C" {
+
+int navhip_heading_gate_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_gate_in *in, float *out_vel,
+                            float *out_new_pos, uint8_t *out_gate, void *stream)
+{
+    if(!ctx || !w || !in || !out_vel || !out_new_pos || !out_gate || w->n_ents < 0) return NAVHIP_ERR_INVALID;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    if(!w->pos_xz || !w->vel_xz || !w->state || !in->next_rot || !in->new_vel_xz || !in->vdes_xz) return NAVHIP_ERR_INVALID;
+    int b, e;
+    if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    if(e > b)
+        hipLaunchKernelGGL(k_heading_gate, dim3((e - b + 255) / 256), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
+                           b, e, w->pos_xz, w->vel_xz, w->state, *in, out_vel, out_new_pos, out_gate);
+    SKCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_heading_gate(navhip_ctx *ctx, const navhip_world *w, const navhip_gate_in *in, float *out_vel,
+                        float *out_new_pos, uint8_t *out_gate)
+{
+    if(!ctx || !w || !in || !out_vel || !out_new_pos || !out_gate || w->n_ents < 0) return NAVHIP_ERR_INVALID;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    if(!w->pos_xz || !w->vel_xz || !w->state || !in->next_rot || !in->new_vel_xz || !in->vdes_xz) return NAVHIP_ERR_INVALID;
+    int b, e;
+    if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t n = (size_t)w->n_ents;
+    sk_arena A;
+    const size_t o_pos = A.take(n * 8), o_vel = A.take(n * 8), o_state = A.take(n), o_rot = A.take(n * 16),
+                 o_nv = A.take(n * 8), o_vd = A.take(n * 8), o_ov = A.take(n * 8), o_op = A.take(n * 8), o_og = A.take(n);
+    char *base;
+    int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
+    if(rc) return rc;
+    SKCHK(ctx, hipMemcpyAsync(base + o_pos, w->pos_xz, n * 8, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_vel, w->vel_xz, n * 8, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_state, w->state, n, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_rot, in->next_rot, n * 16, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_nv, in->new_vel_xz, n * 8, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_vd, in->vdes_xz, n * 8, hipMemcpyHostToDevice, s));
+    navhip_world d = *w;
+    d.pos_xz = (const float*)(base + o_pos); d.vel_xz = (const float*)(base + o_vel); d.state = (const uint8_t*)(base + o_state);
+    navhip_gate_in di = {(const float*)(base + o_rot), (const float*)(base + o_nv), (const float*)(base + o_vd)};
+    rc = navhip_heading_gate_dev(ctx, &d, &di, (float*)(base + o_ov), (float*)(base + o_op), (uint8_t*)(base + o_og), s);
+    if(rc) return rc;
+    if(e > b) {
+        const size_t lo = (size_t)b, cnt = (size_t)(e - b);
+        SKCHK(ctx, hipMemcpyAsync(out_vel + 2 * lo, base + o_ov + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
+        SKCHK(ctx, hipMemcpyAsync(out_new_pos + 2 * lo, base + o_op + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
+        SKCHK(ctx, hipMemcpyAsync(out_gate + lo, base + o_og + lo, cnt, hipMemcpyDeviceToHost, s));
+    }
+    SKCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+int navhip_settled_count(navhip_ctx *ctx, const navhip_world *w, int nq, const int32_t *uids, int32_t *out_counts)
+{
+    if(!ctx || !w || nq < 0 || w->n_ents < 0 || (nq > 0 && (!uids || !out_counts))) return NAVHIP_ERR_INVALID;
+    if(nq == 0) return NAVHIP_OK;
+    if(!w->pos_xz || !w->radius || !w->flags || !w->state) return NAVHIP_ERR_INVALID;
+    for(int q = 0; q < nq; q++)
+        if(uids[q] < 0 || uids[q] >= w->n_ents) return NAVHIP_ERR_INVALID;
+    // the spatial index over the snapshot and the circle queries: navhip_spatial_query (bg_ent insert-all +
+    // inrange_circle in the reference's visiting order, capped); the ids come back to the host once and go up
+    // again with the snapshot -- this entry point is the host-buffer form, sized for the few units of the
+    // flocks that are arriving
+    const size_t n = (size_t)w->n_ents;
+    std::vector<float> query((size_t)nq * 2);
+    for(int q = 0; q < nq; q++) { query[2 * q] = w->pos_xz[2 * uids[q]]; query[2 * q + 1] = w->pos_xz[2 * uids[q] + 1]; }
+    std::vector<int32_t> counts((size_t)nq);
+    std::vector<uint32_t> ids((size_t)nq * SK_QUERY_MAX);
+    int rc = navhip_spatial_query(ctx, w, query.data(), nq, SK_QUERY_R, SK_QUERY_MAX, counts.data(), ids.data());
+    if(rc) return rc;
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    sk_arena A;
+    const size_t o_pos = A.take(n * 8), o_rad = A.take(n * 4), o_fl = A.take(n * 4), o_st = A.take(n),
+                 o_uid = A.take((size_t)nq * 4), o_cnt = A.take((size_t)nq * 4), o_ids = A.take((size_t)nq * SK_QUERY_MAX * 4),
+                 o_out = A.take((size_t)nq * 4);
+    char *base;
+    rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
+    if(rc) return rc;
+    SKCHK(ctx, hipMemcpyAsync(base + o_pos, w->pos_xz, n * 8, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_rad, w->radius, n * 4, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_fl, w->flags, n * 4, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_st, w->state, n, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_uid, uids, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_cnt, counts.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_ids, ids.data(), (size_t)nq * SK_QUERY_MAX * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_settled_count, dim3((nq + 255) / 256), dim3(256), 0, s, nq, (const int32_t*)(base + o_uid),
+                       (const float*)(base + o_pos), (const float*)(base + o_rad), (const uint32_t*)(base + o_fl),
+                       (const uint8_t*)(base + o_st), (const int32_t*)(base + o_cnt), (const uint32_t*)(base + o_ids),
+                       (int32_t*)(base + o_out));
+    SKCHK(ctx, hipGetLastError());
+    SKCHK(ctx, hipMemcpyAsync(out_counts, base + o_out, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    SKCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+int navhip_arrival_settle_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_settle_in *in,
+                              const navhip_settle_out *out, void *stream)
+{
+    if(!ctx || !w || !in || !out || in->nq < 0 || in->n_zones < 0 || w->n_ents < 0) return NAVHIP_ERR_INVALID;
+    if(in->nq == 0) return NAVHIP_OK;
+    if(!w->vel_xz || !w->radius || !in->zones || in->n_zones < 1 || !in->uid || !in->zone || !in->new_pos_xz
+    || !in->nsettled || !in->substate || !in->sink_valid || !in->sink_xz || !in->order_pos_xz || !in->progress_anchor_xz
+    || !in->progress_anchored || !in->stuck || !out->settle || !out->substate || !out->progress_anchor_xz
+    || !out->progress_anchored || !out->stuck)
+        return NAVHIP_ERR_INVALID;
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    nh_step_params P;
+    sk_map_view(ctx, w, &P);
+    hipLaunchKernelGGL(k_arrival_settle, dim3((in->nq + 15) / 16), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
+                       P, w->vel_xz, w->radius, *in, *out);
+    SKCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_arrival_settle(navhip_ctx *ctx, const navhip_world *w, const navhip_settle_in *in, const navhip_settle_out *out)
+{
+    if(!ctx || !w || !in || !out || in->nq < 0 || in->n_zones < 0 || w->n_ents < 0) return NAVHIP_ERR_INVALID;
+    if(in->nq == 0) return NAVHIP_OK;
+    if(!w->vel_xz || !w->radius || !in->zones || in->n_zones < 1 || !in->uid || !in->zone || !in->new_pos_xz
+    || !in->nsettled || !in->substate || !in->sink_valid || !in->sink_xz || !in->order_pos_xz || !in->progress_anchor_xz
+    || !in->progress_anchored || !in->stuck || !out->settle || !out->substate || !out->progress_anchor_xz
+    || !out->progress_anchored || !out->stuck)
+        return NAVHIP_ERR_INVALID;
+    const size_t n = (size_t)w->n_ents, nq = (size_t)in->nq, nz = (size_t)in->n_zones;
+    size_t n_slots = 0, n_keys = 0;
+    for(size_t z = 0; z < nz; z++) {
+        const navhip_arrival_zone &Z = in->zones[z];
+        if(Z.slot_begin < 0 || Z.slot_end < Z.slot_begin || Z.key_begin < 0 || Z.key_end < Z.key_begin
+        || Z.layer < 0 || Z.layer >= NAVHIP_NAV_LAYER_MAX) return NAVHIP_ERR_INVALID;
+        if((size_t)Z.slot_end > n_slots) n_slots = (size_t)Z.slot_end;
+        if((size_t)Z.key_end > n_keys) n_keys = (size_t)Z.key_end;
+    }
+    if((n_slots > 0 && (!in->slots_xz || !in->slot_ring)) || (n_keys > 0 && !in->region_keys)) return NAVHIP_ERR_INVALID;
+    for(size_t q = 0; q < nq; q++)
+        if(in->uid[q] < 0 || in->uid[q] >= w->n_ents || in->zone[q] < 0 || in->zone[q] >= in->n_zones) return NAVHIP_ERR_INVALID;
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    sk_arena A;
+    const size_t o_vel = A.take(n * 8), o_rad = A.take(n * 4), o_z = A.take(nz * sizeof(navhip_arrival_zone)),
+                 o_sl = A.take(n_slots * 8 + 8), o_ring = A.take(n_slots * 4 + 4), o_keys = A.take(n_keys * 8 + 8),
+                 o_uid = A.take(nq * 4), o_zone = A.take(nq * 4), o_np = A.take(nq * 8), o_ns = A.take(nq * 4),
+                 o_sub = A.take(nq), o_sv = A.take(nq), o_sink = A.take(nq * 8), o_ord = A.take(nq * 8),
+                 o_anc = A.take(nq * 8), o_and = A.take(nq), o_stk = A.take(nq * 4),
+                 r_set = A.take(nq), r_sub = A.take(nq), r_anc = A.take(nq * 8), r_and = A.take(nq), r_stk = A.take(nq * 4);
+    char *base;
+    int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
+    if(rc) return rc;
+#define UP(off, src, bytes) if((bytes) > 0) SKCHK(ctx, hipMemcpyAsync(base + (off), (src), (bytes), hipMemcpyHostToDevice, s))
+    UP(o_vel, w->vel_xz, n * 8);   UP(o_rad, w->radius, n * 4);   UP(o_z, in->zones, nz * sizeof(navhip_arrival_zone));
+    UP(o_sl, in->slots_xz, n_slots * 8);   UP(o_ring, in->slot_ring, n_slots * 4);   UP(o_keys, in->region_keys, n_keys * 8);
+    UP(o_uid, in->uid, nq * 4);   UP(o_zone, in->zone, nq * 4);   UP(o_np, in->new_pos_xz, nq * 8);   UP(o_ns, in->nsettled, nq * 4);
+    UP(o_sub, in->substate, nq);   UP(o_sv, in->sink_valid, nq);   UP(o_sink, in->sink_xz, nq * 8);   UP(o_ord, in->order_pos_xz, nq * 8);
+    UP(o_anc, in->progress_anchor_xz, nq * 8);   UP(o_and, in->progress_anchored, nq);   UP(o_stk, in->stuck, nq * 4);
+#undef UP
+    navhip_world d = *w;
+    d.vel_xz = (const float*)(base + o_vel); d.radius = (const float*)(base + o_rad);
+    navhip_settle_in di = *in;
+    di.zones = (const navhip_arrival_zone*)(base + o_z); di.slots_xz = (const float*)(base + o_sl);
+    di.slot_ring = (const int32_t*)(base + o_ring); di.region_keys = (const uint64_t*)(base + o_keys);
+    di.uid = (const int32_t*)(base + o_uid); di.zone = (const int32_t*)(base + o_zone);
+    di.new_pos_xz = (const float*)(base + o_np); di.nsettled = (const int32_t*)(base + o_ns);
+    di.substate = (const uint8_t*)(base + o_sub); di.sink_valid = (const uint8_t*)(base + o_sv);
+    di.sink_xz = (const float*)(base + o_sink); di.order_pos_xz = (const float*)(base + o_ord);
+    di.progress_anchor_xz = (const float*)(base + o_anc); di.progress_anchored = (const uint8_t*)(base + o_and);
+    di.stuck = (const int32_t*)(base + o_stk);
+    navhip_settle_out dout = {(uint8_t*)(base + r_set), (uint8_t*)(base + r_sub), (float*)(base + r_anc),
+                              (uint8_t*)(base + r_and), (int32_t*)(base + r_stk)};
+    rc = navhip_arrival_settle_dev(ctx, &d, &di, &dout, s);
+    if(rc) return rc;
+    SKCHK(ctx, hipMemcpyAsync(out->settle, base + r_set, nq, hipMemcpyDeviceToHost, s));
+    SKCHK(ctx, hipMemcpyAsync(out->substate, base + r_sub, nq, hipMemcpyDeviceToHost, s));
+    SKCHK(ctx, hipMemcpyAsync(out->progress_anchor_xz, base + r_anc, nq * 8, hipMemcpyDeviceToHost, s));
+    SKCHK(ctx, hipMemcpyAsync(out->progress_anchored, base + r_and, nq, hipMemcpyDeviceToHost, s));
+    SKCHK(ctx, hipMemcpyAsync(out->stuck, base + r_stk, nq * 4, hipMemcpyDeviceToHost, s));
+    SKCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+}   // extern "C"

@@ -369,11 +369,48 @@ class StateIn(C.Structure):
 
 
 SU_SET_STATE, SU_BLOCK, SU_HOST = 0x01, 0x02, 0x80
+GATE_TURN, GATE_HOST = 0x01, 0x80
+
+
+class GateIn(C.Structure):
+    """navhip_gate_in, include/navhip.h"""
+    _fields_ = [("next_rot", C.c_void_p), ("new_vel_xz", C.c_void_p), ("vdes_xz", C.c_void_p)]
+
+
+class ArrivalZone(C.Structure):
+    """navhip_arrival_zone, include/navhip.h"""
+    _fields_ = [("centre_x", C.c_float), ("centre_z", C.c_float), ("unit_radius", C.c_float), ("fill_frac", C.c_float),
+                ("radius", C.c_int32), ("layer", C.c_int32), ("active_row", C.c_int32), ("num_rows", C.c_int32),
+                ("slot_begin", C.c_int32), ("slot_end", C.c_int32), ("key_begin", C.c_int32), ("key_end", C.c_int32)]
+
+
+class SettleIn(C.Structure):
+    """navhip_settle_in, include/navhip.h"""
+    _fields_ = [("n_zones", C.c_int32), ("nq", C.c_int32), ("zones", C.c_void_p), ("slots_xz", C.c_void_p),
+                ("slot_ring", C.c_void_p), ("region_keys", C.c_void_p), ("uid", C.c_void_p), ("zone", C.c_void_p),
+                ("new_pos_xz", C.c_void_p), ("nsettled", C.c_void_p), ("substate", C.c_void_p),
+                ("sink_valid", C.c_void_p), ("sink_xz", C.c_void_p), ("order_pos_xz", C.c_void_p),
+                ("progress_anchor_xz", C.c_void_p), ("progress_anchored", C.c_void_p), ("stuck", C.c_void_p)]
+
+
+class SettleOut(C.Structure):
+    """navhip_settle_out, include/navhip.h"""
+    _fields_ = [("settle", C.c_void_p), ("substate", C.c_void_p), ("progress_anchor_xz", C.c_void_p),
+                ("progress_anchored", C.c_void_p), ("stuck", C.c_void_p)]
+
 
 _SIGS.update({
     "navhip_state_update": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StateIn), C.c_void_p, C.c_void_p]),
     "navhip_state_update_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StateIn), C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "navhip_heading_gate": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(GateIn), C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "navhip_heading_gate_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(GateIn), C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "navhip_settled_count": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_int, C.c_void_p, C.c_void_p]),
+    "navhip_arrival_settle": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(SettleIn), C.POINTER(SettleOut)]),
+    "navhip_arrival_settle_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(SettleIn), C.POINTER(SettleOut),
+                                            C.c_void_p]),
     "navhip_agent_step": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut)]),
     "navhip_agent_step_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StepOut), C.c_void_p]),
     "navhip_agent_prefetch_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_void_p]),
@@ -687,6 +724,73 @@ def _ctx_state_update(self, arrays, new_pos_xz, vdes_xz, flock_layer, flock_near
     return st, fl
 
 
+def _ctx_heading_gate(self, arrays, next_rot, new_vel_xz, vdes_xz, work=None):
+    """The heading gate of entity_compute_update (movement.c:2319-2336) for the units of the snapshot `arrays`
+    (pos_xz, vel_xz, state).  Returns (velocity after the gate [n][2], new_pos [n][2], gate flags [n])."""
+    w, keep = make_world(self.w, self.h, arrays)
+    if work is not None:
+        w.work_begin, w.work_end = work
+    n = w.n_ents
+    k = [np.ascontiguousarray(next_rot, np.float32).reshape(n, 4), np.ascontiguousarray(new_vel_xz, np.float32).reshape(n, 2),
+         np.ascontiguousarray(vdes_xz, np.float32).reshape(n, 2)]
+    gi = GateIn(k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data)
+    vel, pos, gate = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32), np.zeros(n, np.uint8)
+    self._chk(lib().navhip_heading_gate(self._h, C.byref(w), C.byref(gi), _hp(vel), _hp(pos), _hp(gate)),
+              "navhip_heading_gate")
+    return vel, pos, gate
+
+
+def _ctx_settled_count(self, arrays, uids):
+    """adjacent_settled_count (movement.c:982) for the units `uids` of the snapshot `arrays` (pos_xz, radius,
+    flags, state); -1 = the host counts (radius > 12.5)."""
+    w, keep = make_world(self.w, self.h, arrays)
+    u = np.ascontiguousarray(uids, np.int32)
+    out = np.zeros(len(u), np.int32)
+    self._chk(lib().navhip_settled_count(self._h, C.byref(w), len(u), _hp(u), _hp(out)), "navhip_settled_count")
+    return out
+
+
+def _ctx_arrival_settle(self, arrays, zones, region_keys, units):
+    """G_Arrival_ShouldSettle (arrival.c:946).  zones: list of dicts (layer, centre_xz, radius, unit_radius,
+    fill_frac, active_row, num_rows, slots_xz, slot_ring), region_keys: list of sorted u64 arrays per zone;
+    units: dict of nq-row arrays (uid, zone, new_pos_xz, nsettled, substate, sink_valid, sink_xz, order_pos_xz,
+    progress_anchor_xz, progress_anchored, stuck).  Returns (settle [nq], dict of the unit state after)."""
+    w, keep = make_world(self.w, self.h, arrays)
+    zs = (ArrivalZone * len(zones))()
+    slots, rings, keys = [], [], []
+    so = ko = 0
+    for i, z in enumerate(zones):
+        sl = np.asarray(z["slots_xz"], np.float32).reshape(-1, 2)
+        kk = np.asarray(region_keys[i], np.uint64)
+        zs[i] = ArrivalZone(float(z["centre_xz"][0]), float(z["centre_xz"][1]), float(z["unit_radius"]),
+                            float(z["fill_frac"]), int(z["radius"]), int(z["layer"]), int(z["active_row"]),
+                            int(z["num_rows"]), so, so + len(sl), ko, ko + len(kk))
+        so += len(sl); ko += len(kk)
+        slots.append(sl); rings.append(np.asarray(z["slot_ring"], np.int32)); keys.append(kk)
+    cat = lambda parts, dt, shape: np.ascontiguousarray(np.concatenate(parts + [np.zeros(shape, dt)]))
+    k = {"slots": cat(slots, np.float32, (1, 2)), "ring": cat(rings, np.int32, (1,)), "keys": cat(keys, np.uint64, (1,))}
+    nq = len(units["uid"])
+    spec = (("uid", np.int32, 1), ("zone", np.int32, 1), ("new_pos_xz", np.float32, 2), ("nsettled", np.int32, 1),
+            ("substate", np.uint8, 1), ("sink_valid", np.uint8, 1), ("sink_xz", np.float32, 2),
+            ("order_pos_xz", np.float32, 2), ("progress_anchor_xz", np.float32, 2), ("progress_anchored", np.uint8, 1),
+            ("stuck", np.int32, 1))
+    si = SettleIn()
+    si.n_zones, si.nq = len(zones), nq
+    si.zones = C.addressof(zs)
+    si.slots_xz, si.slot_ring, si.region_keys = k["slots"].ctypes.data, k["ring"].ctypes.data, k["keys"].ctypes.data
+    for name, dt, width in spec:
+        a = np.ascontiguousarray(units[name], dt).reshape((nq, width) if width > 1 else (nq,))
+        k[name] = a
+        setattr(si, name, a.ctypes.data)
+    res = {"settle": np.zeros(nq, np.uint8), "substate": np.zeros(nq, np.uint8),
+           "progress_anchor_xz": np.zeros((nq, 2), np.float32), "progress_anchored": np.zeros(nq, np.uint8),
+           "stuck": np.zeros(nq, np.int32)}
+    so_ = SettleOut(*[res[f].ctypes.data for f in ("settle", "substate", "progress_anchor_xz", "progress_anchored", "stuck")])
+    self._chk(lib().navhip_arrival_settle(self._h, C.byref(w), C.byref(si), C.byref(so_)), "navhip_arrival_settle")
+    settle = res.pop("settle")
+    return settle, res
+
+
 def _ctx_pool_invalidate(self, ff_id):
     self._chk(lib().navhip_pool_invalidate(self._h, int(ff_id)), "navhip_pool_invalidate")
 
@@ -791,6 +895,9 @@ NavContext.pool_contains = _ctx_pool_contains
 NavContext.pool_invalidate = _ctx_pool_invalidate
 NavContext.region_lookup = _ctx_region_lookup
 NavContext.state_update = _ctx_state_update
+NavContext.heading_gate = _ctx_heading_gate
+NavContext.settled_count = _ctx_settled_count
+NavContext.arrival_settle = _ctx_arrival_settle
 NavContext.pool_map = _ctx_pool_map
 NavContext.agent_step_async = _ctx_agent_step_async
 NavContext.set_profiling = _ctx_set_profiling

@@ -54,6 +54,12 @@ int main(void){
     printf("sizeof.navhip_world %zu\n", sizeof(navhip_world));
     printf("sizeof.navhip_step_out %zu\n", sizeof(navhip_step_out));
     printf("sizeof.navhip_circle %zu\n", sizeof(navhip_circle));
+    printf("sizeof.navhip_gate_in %zu\n", sizeof(navhip_gate_in));
+    printf("sizeof.navhip_arrival_zone %zu\n", sizeof(navhip_arrival_zone));
+    printf("sizeof.navhip_settle_in %zu\n", sizeof(navhip_settle_in));
+    printf("sizeof.navhip_settle_out %zu\n", sizeof(navhip_settle_out));
+    P(navhip_arrival_zone, radius); P(navhip_arrival_zone, key_end);
+    P(navhip_settle_in, zones); P(navhip_settle_in, uid); P(navhip_settle_in, stuck);
     P(navhip_circle, radius); P(navhip_circle, faction_id); P(navhip_circle, delta);
     P(navhip_field_req, enemies); P(navhip_field_req, chunk_r); P(navhip_field_req, tile_r);
     P(navhip_field_req, port_r0); P(navhip_field_req, next_r0); P(navhip_field_req, next_chunk_r);
@@ -81,6 +87,14 @@ int main(void){
     for f in ("pos_xz", "vdes_xz", "field_pool", "map_pos_x", "grid_xmin", "work_begin"):
         assert got["navhip_world." + f] == getattr(navlib.World, f).offset, f
     assert got["navhip_step_out.status"] == navlib.StepOut.status.offset
+    for name, cls in (("gate_in", navlib.GateIn), ("arrival_zone", navlib.ArrivalZone), ("settle_in", navlib.SettleIn),
+                      ("settle_out", navlib.SettleOut)):
+        assert got["sizeof.navhip_" + name] == C.sizeof(cls), name
+    assert got["sizeof.navhip_arrival_zone"] == 48
+    for f in ("radius", "key_end"):
+        assert got["navhip_arrival_zone." + f] == getattr(navlib.ArrivalZone, f).offset, f
+    for f in ("zones", "uid", "stuck"):
+        assert got["navhip_settle_in." + f] == getattr(navlib.SettleIn, f).offset, f
 
 
 def _ff_id_expected(r):

@@ -35,6 +35,7 @@ SELECTION = [
     "tests/test_agents_gpu.py",
     "tests/test_comm_gpu.py",          # the exchange step over the mailbox transport (device buffers = host buffers here)
     "tests/test_pool_gpu.py",          # the resident field pool and the asynchronous step
+    "tests/test_state_gpu.py",         # the heading gate, the settled-neighbour count, the arrival overlay's settle rule
 ]
 # (agents: the tests that need torch.cuda, and the ones that take more than ~10 s each on the emulator)
 DESELECT = ["test_prefetch_overlap_gives_identical_results", "test_shared_chunk_fields_give_identical_results",
@@ -66,7 +67,7 @@ def test_gpu_parity_tests_pass_on_the_emulated_library():
     assert r.returncode == 0, tail
     last = r.stdout.strip().splitlines()[-1]
     assert " passed" in last and "failed" not in last and "error" not in last, tail
-    assert int(last.split(" passed")[0].split()[-1]) >= 78, tail          # (the selection really ran)
+    assert int(last.split(" passed")[0].split()[-1]) >= 82, tail          # (the selection really ran)
 
 
 def test_reference_binding_drives_the_emulated_library():

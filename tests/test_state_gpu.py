@@ -1,0 +1,206 @@
+"""SURVEY section 8(f4), more of entity_compute_update on the device (csrc/state_kernels.hip): the heading gate,
+adjacent_settled_count and the arrival overlay's settle rule, each against the reference's own code
+(oracle/_ref: movement.c's entity_compute_update / adjacent_settled_count, arrival.c's G_Arrival_ShouldSettle)
+through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import pfref
+from permafrost_engine_amd import synth
+from tests import cases
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not pfref.available(), reason="oracle/_ref (the reference build) is not present")]
+
+
+def _upload(navlib, nav, layers=(0, 1)):
+    ctx = navlib.NavContext(4, 4)
+    for layer in layers:
+        ctx.upload_plane(layer, navlib.PLANE_COST_BASE, nav.plane(pfref.PLANE_COST, layer))
+        ctx.upload_plane(layer, navlib.PLANE_BLOCKERS, nav.plane(pfref.PLANE_BLOCKERS, layer))
+    return ctx
+
+
+def test_heading_gate_matches_entity_compute_update(navlib):
+    """navhip_heading_gate against entity_compute_update (movement.c:2303) run with movestate.next_rot as an input:
+    turn_to_move (UPDATE_TURNING_IN_PLACE of the patch) for rolling units (tolerance 90 degrees) and halted ones
+    (10 degrees), facings spread over the circle and crowded around both tolerances; the units the device leaves to
+    the host are the ones within its margin, and nothing else."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    rng = np.random.RandomState(77)
+    world["vel_xz"] = world["vel_xz"].copy()
+    world["vel_xz"][rng.rand(n) < 0.5] = 0                                   # halted: MOVE_HEADING_RESUME applies
+    world["flags"] = world["flags"] & ~np.uint32(1 << 18)                     # (a garrisoned unit returns before the patch shows the gate)
+    world["state"] = world["state"].copy()
+    world["state"][rng.rand(n) < 0.1] = 6                                     # STATE_ENTER_ENTITY_RANGE (gated, :2273)
+    world["state"][rng.rand(n) < 0.05] = 1                                    # MOVING_IN_FORMATION (not gated)
+    # the facing: the intended heading turned by an offset -- anything, or within half a degree of a tolerance
+    heading = np.where(np.linalg.norm(vdes, axis=1, keepdims=True) > 1.0 / 1024, vdes, new_vel).astype(np.float64)
+    base = np.arctan2(heading[:, 1], heading[:, 0])
+    off = rng.uniform(-180, 180, n)
+    near = rng.rand(n) < 0.4
+    off[near] = rng.choice([-90, 90, -10, 10], near.sum()) + rng.uniform(-0.5, 0.5, near.sum())
+    tight = rng.rand(n) < 0.02
+    off[tight] = rng.choice([-90, 90, -10, 10], tight.sum()) + rng.uniform(-2e-3, 2e-3, tight.sum())
+    ang = base + np.deg2rad(off)
+    facing = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    next_rot = pfref.RefMove.dir_quat(facing)
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        ref_turn, ref_vel = mv.heading_gate(new_vel, vdes, next_rot)
+    finally:
+        pfref.RefMove.unload()
+    ctx = navlib.NavContext(4, 4)
+    arrays = {k: world[k] for k in ("pos_xz", "vel_xz", "state")}
+    vel, new_pos, gate = ctx.heading_gate(arrays, next_rot, new_vel, vdes)
+    # a slab call writes its rows only
+    vel_s, pos_s, gate_s = ctx.heading_gate(arrays, next_rot, new_vel, vdes, work=(700, 1900))
+    ctx.close()
+    assert np.array_equal(vel_s[700:1900], vel[700:1900]) and np.array_equal(gate_s[700:1900], gate[700:1900])
+    assert not vel_s[:700].any() and not gate_s[1900:].any() and np.array_equal(pos_s[700:1900], new_pos[700:1900])
+    host = (gate & navlib.GATE_HOST) != 0
+    turn = (gate & navlib.GATE_TURN) != 0
+    live = world["state"] != 7                                                # (STATE_TURNING: not driven, as in state_update)
+    ok = live & ~host
+    assert np.array_equal(turn[ok], ref_turn[ok].astype(bool))
+    gated = np.isin(world["state"], (0, 3, 5, 6)) & (np.linalg.norm(new_vel, axis=1) > 1.0 / 1024)
+    assert not turn[~gated].any() and not host[~gated].any()
+    # left to the host: only facings within the margin (1e-4 in the cosine: under 0.04 degrees at both tolerances)
+    assert host.sum() <= tight.sum() and 0 < host.sum()
+    assert np.all(np.abs(np.abs(off[host]) - np.where(np.abs(np.abs(off[host]) - 90) < 1, 90, 10)) < 0.04)
+    # both tolerances decided both ways
+    rolling = np.linalg.norm(world["vel_xz"], axis=1) > 1.0 / 1024
+    for sel in (rolling, ~rolling):
+        assert (turn & sel & ok).sum() > 100 and (~turn & sel & ok & gated).sum() > 50
+    assert (turn & ~rolling & (np.abs(off) < 45)).sum() > 50 and (~turn & rolling & gated & (np.abs(off) > 45)).sum() > 50
+    # the velocity after the gate and new_pos_for_vel (:1820)
+    exp_vel = np.where(turn[:, None], np.float32(0), new_vel)
+    assert np.array_equal(vel, exp_vel)
+    assert np.array_equal(new_pos, world["pos_xz"] + exp_vel)
+    # where the reference moved the unit (pathable, not blocked) its patch carries the same velocity
+    moved = ok & (np.linalg.norm(ref_vel, axis=1) > 0)
+    assert moved.sum() > 500 and np.array_equal(ref_vel[moved], vel[moved])
+
+
+def test_settled_count_matches_adjacent_settled_count(navlib):
+    """navhip_settled_count against adjacent_settled_count (movement.c:982): the r = 30 query capped at 128 in the
+    reference's visiting order, garrisoned entities dropped, then movable + same kind + ARRIVED + touching."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    rng = np.random.RandomState(5)
+    world["flags"] = world["flags"].copy()
+    world["flags"][rng.rand(n) < 0.05] |= np.uint32(1 << 15)                  # ENTITY_FLAG_AIR: another kind
+    world["flags"][rng.rand(n) < 0.03] &= ~np.uint32(1 << 3)                  # not movable
+    # a packed ball, so that the cap of 128 binds for its members
+    ball = np.flatnonzero(world["flock"] == 2)[:300]
+    world["pos_xz"] = world["pos_xz"].copy()
+    world["pos_xz"][ball] = (world["flock_target_xz"][2] + rng.normal(0, 9.0, (len(ball), 2))).astype(np.float32)
+    uids = np.flatnonzero(np.isin(world["state"], (0, 1)))[:900].astype(np.int32)
+    uids = np.unique(np.concatenate([uids, ball[:150].astype(np.int32)]))
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        ref = mv.settled_count(uids)
+    finally:
+        pfref.RefMove.unload()
+    ctx = navlib.NavContext(4, 4)
+    arrays = {k: world[k] for k in ("pos_xz", "radius", "flags", "state")}
+    got = ctx.settled_count(arrays, uids)
+    # the cap binds somewhere (else the test would not see the visiting order)
+    counts, _ = ctx.spatial_query(world["pos_xz"], world["pos_xz"][uids], 30.0, 128)
+    big = dict(arrays, radius=np.where(np.arange(n) % 7 == 0, np.float32(13.0), world["radius"]).astype(np.float32))
+    got_big = ctx.settled_count(big, uids)
+    ctx.close()
+    assert (counts == 128).sum() > 20
+    assert np.array_equal(got, ref), np.flatnonzero(got != ref)[:10]
+    assert (ref == 0).sum() > 50 and (ref >= 3).sum() > 50
+    assert np.array_equal(got_big == -1, uids % 7 == 0)                       # 2 * 13 + 5 > 30: the host counts
+
+
+def _zone_world(seed):
+    """Three arrival zones on the state_world map and units scattered in and around them."""
+    grid, nav = cases.ref_nav_for(4, 4, seed=21, layer_mask=0x3)
+    rng = np.random.RandomState(seed)
+    free = np.argwhere(grid != 255)
+    zones, units = [], []
+    for zi, (fill, active_row, num_rows, rad) in enumerate(((0.5, 1, 4, 6), (0.8, 3, 4, 5), (0.95, 0, 3, 7))):
+        while True:
+            c = free[rng.randint(len(free))]
+            if 12 <= c[0] < 244 and 12 <= c[1] < 244:
+                break
+        rr, cc = np.mgrid[c[0] - rad:c[0] + rad + 1, c[1] - rad:c[1] + rad + 1]
+        inside = ((rr - c[0]) ** 2 + (cc - c[1]) ** 2 <= rad * rad) & (grid[rr, cc] != 255)
+        tiles = np.stack([rr[inside], cc[inside]], 1)
+        region_xz = np.array([synth.cell_centre(4, 4, r, q) for r, q in tiles], np.float32)
+        pick = rng.rand(len(tiles)) < 0.35
+        slots = region_xz[pick] + rng.uniform(-1.5, 1.5, (pick.sum(), 2)).astype(np.float32)
+        zones.append({"layer": 0, "centre_xz": np.array(synth.cell_centre(4, 4, c[0], c[1]), np.float32), "radius": rad,
+                      "unit_radius": float(rng.choice([1.0, 2.5, 5.5])), "fill_frac": fill, "active_row": active_row,
+                      "num_rows": num_rows, "slots_xz": slots.astype(np.float32),
+                      "slot_ring": rng.randint(0, num_rows, len(slots)).astype(np.int32), "region_xz": region_xz,
+                      "tiles": tiles})
+        nq = 900
+        centre = zones[-1]["centre_xz"]
+        pos = (centre + rng.normal(0, rad * 4.0 * 0.9, (nq, 2))).astype(np.float32)
+        far = rng.rand(nq) < 0.1
+        pos[far] = (centre + rng.normal(0, rad * 4.0 * 4, (far.sum(), 2))).astype(np.float32)
+        at = rng.rand(nq) < 0.25                                             # standing on a slot, within the sink tolerance
+        pos[at] = slots[rng.randint(len(slots), size=at.sum())] + rng.normal(0, 0.8, (at.sum(), 2)).astype(np.float32)
+        pos = np.clip(pos, -4 * 128.0 + 14, 4 * 128.0 - 14).astype(np.float32)
+        sink = slots[rng.randint(len(slots), size=nq)].copy()
+        wild = rng.rand(nq) < 0.2
+        sink[wild] = (centre + rng.normal(0, rad * 4.0 * 2, (wild.sum(), 2))).astype(np.float32)
+        order = (pos + rng.normal(0, 3.5, (nq, 2))).astype(np.float32)
+        anchor = (pos + rng.normal(0, 1.4, (nq, 2))).astype(np.float32)
+        units.append({"zone": np.full(nq, zi, np.int32), "new_pos_xz": pos,
+                      "vel_xz": rng.normal(0, 0.4, (nq, 2)).astype(np.float32),
+                      "radius": rng.choice([1.0, 1.5, 2.5], nq).astype(np.float32),
+                      "nsettled": rng.choice([0, 0, 1, 2, 3, 4], nq).astype(np.int32),
+                      "substate": rng.randint(0, 4, nq).astype(np.uint8), "sink_valid": (rng.rand(nq) < 0.7).astype(np.uint8),
+                      "sink_xz": np.clip(sink, -4 * 128.0 + 14, 4 * 128.0 - 14).astype(np.float32), "order_pos_xz": order,
+                      "progress_anchor_xz": anchor, "progress_anchored": (rng.rand(nq) < 0.7).astype(np.uint8),
+                      "stuck": rng.randint(0, 14, nq).astype(np.int32)})
+    # blockers on some slots' tiles (a building on the footprint): such a slot is not open
+    blk = np.zeros((4, 4, 64, 64), np.uint16)
+    for z in zones:
+        t = z["tiles"][rng.rand(len(z["tiles"])) < 0.15]
+        blk[t[:, 0] // 64, t[:, 1] // 64, t[:, 0] % 64, t[:, 1] % 64] = 1
+    nav.set_blockers(blk, 0)
+    return grid, nav, zones, units
+
+
+@pytest.mark.parametrize("seed", [9, 23])
+def test_arrival_settle_matches_G_Arrival_ShouldSettle(navlib, seed):
+    """navhip_arrival_settle against the reference's G_Arrival_ShouldSettle (arrival.c:946) on three zones (half
+    full, three quarters, nearly full; different frontiers), units inside, next to and away from the footprint, on
+    open and on blocked slots, with and without a reachable slot (N_SegmentWithinRegion over the supercover walk,
+    nav.c:4326, tile.c:430): the answer and the unit state the rule leaves behind (arming, anchor, stuck count)."""
+    grid, nav, zones, units = _zone_world(seed=seed)
+    ref_settle, ref_after, keys = [], [], []
+    for z, u in zip(zones, units):
+        s, k, after = pfref.arrival_should_settle(nav, z, u)
+        ref_settle.append(s); ref_after.append(after); keys.append(k)
+        assert len(k) == len(z["tiles"]) and np.all(k[1:] > k[:-1])
+    ctx = _upload(navlib, nav, layers=(0,))
+    nq = sum(len(u["zone"]) for u in units)
+    cat = {f: np.concatenate([u[f] for u in units]) for f in units[0]}
+    # the world rows of the units: scattered over a larger snapshot (uid != query index)
+    n = 2 * nq
+    uid = np.random.RandomState(3).permutation(n)[:nq].astype(np.int32)
+    world = {"pos_xz": np.zeros((n, 2), np.float32), "vel_xz": np.zeros((n, 2), np.float32), "radius": np.ones(n, np.float32)}
+    world["vel_xz"][uid] = cat["vel_xz"]
+    world["radius"][uid] = cat["radius"]
+    cat["uid"] = uid
+    got, after = ctx.arrival_settle(world, zones, keys, cat)
+    ctx.close()
+    ref = np.concatenate(ref_settle)
+    bad = np.flatnonzero(got != ref)
+    assert len(bad) == 0, (len(bad), bad[:10], cat["zone"][bad[:10]])
+    for f in ("substate", "progress_anchored", "stuck", "progress_anchor_xz"):
+        assert np.array_equal(after[f], np.concatenate([a[f] for a in ref_after])), f
+    # the rule fired and held back in every zone; it armed units, reset anchors, counted ticks
+    for zi in range(3):
+        m = cat["zone"] == zi
+        assert 50 < ref[m].sum() < m.sum() - 50, (zi, ref[m].sum())
+    assert (after["substate"] != cat["substate"]).sum() > 100
+    assert (after["stuck"] == cat["stuck"] + 1).sum() > 100 and ((after["stuck"] == 0) & (cat["stuck"] > 0)).sum() > 30
+    assert ((after["progress_anchored"] == 1) & (cat["progress_anchored"] == 0)).sum() > 30
