@@ -541,6 +541,16 @@ static uint8_t *s_hip_su_state, *s_hip_su_flags;     /* [nwork] by work item */
 static size_t   s_hip_su_cap;
 static long     s_hip_su_stats[3];                   /* decided on the device, left to the host, passes */
 void move_hip_state_stats(long out[3]) { memcpy(out, s_hip_su_stats, sizeof(s_hip_su_stats)); }
+/* the arrival overlay's settle rule on the device (navhip_arrival_settle): what it left in the unit's
+ * struct arrival_unit_state, kept per work item so that move_hip_update_work can hold it against what the
+ * reference's own G_Arrival_ShouldSettle leaves there (the harness cannot take the call out of
+ * entity_compute_update; a maintainer applies the device's copy instead) */
+struct hip_settle_chk { bool valid; uint8_t substate, anchored; int32_t stuck; vec2_t anchor; };
+static struct hip_settle_chk *s_hip_settle_chk;      /* [nwork] by work item */
+static long     s_hip_settle_stats[4];               /* units decided by the device rule, of those settled, unit states
+                                                        that differ from the reference's afterwards, units whose
+                                                        heading gate the device left to the host */
+void move_hip_settle_stats(long out[4]) { memcpy(out, s_hip_settle_stats, sizeof(s_hip_settle_stats)); }
 
 /* the velocity entity_compute_update integrates: zero while the unit still turns towards its heading */
 static vec2_t hip_heading_gated(const struct movestate *ms, vec2_t vdes, vec2_t vel)
@@ -553,7 +563,7 @@ static vec2_t hip_heading_gated(const struct movestate *ms, vec2_t vdes, vec2_t 
     return err > (rolling ? MOVE_HEADING_HALT : MOVE_HEADING_RESUME) ? (vec2_t){0.0f, 0.0f} : vel;
 }
 
-struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_pos, *vdes; uint8_t *skip; };
+struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned; };
 
 static void hip_state_items_range(int begin, int end, void *arg)
 {
@@ -565,8 +575,10 @@ static void hip_state_items_range(int begin, int end, void *arg)
         const struct move_work_out *out = &s_move_work.out[w];
         const struct movestate *ms = movestate_get(in->ent_uid);
         const int i = hip_work_dense(S, w);
-        vec2_t np = new_pos_for_vel(in->ent_uid, hip_heading_gated(ms, out->ent_des_v, out->ent_vel));
-        T->new_pos[2 * i] = np.x; T->new_pos[2 * i + 1] = np.z;
+        /* the inputs of the heading gate (:2319-2336), decided on the device for the slab at once */
+        T->new_vel[2 * i] = out->ent_vel.x; T->new_vel[2 * i + 1] = out->ent_vel.z;
+        T->next_rot[4 * i] = ms->next_rot.x; T->next_rot[4 * i + 1] = ms->next_rot.y;
+        T->next_rot[4 * i + 2] = ms->next_rot.z; T->next_rot[4 * i + 3] = ms->next_rot.w;
         T->vdes[2 * i] = out->ent_des_v.x; T->vdes[2 * i + 1] = out->ent_des_v.z;
         /* a formation member (:2427-2437) or an active arrival group (:2443): the host's arms.  So is every unit
          * at a movement rate below 20 Hz: entity_compute_update then tests the INTERPOLATED intermediate position
@@ -577,8 +589,104 @@ static void hip_state_items_range(int begin, int end, void *arg)
             struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,
                 Entity_NavLayerWithRadius(S->flags[i], S->radius[i]));
             T->skip[i] = as && G_Arrival_IsActive(as);
+            T->zoned[i] = T->skip[i];       /* (:2443-2451: the settle rule's arm, navhip_arrival_settle below) */
         }
     }
+}
+
+/* The arm of the state switch for a unit whose flock has an active arrival zone (:2443-2451, then the
+ * no-guidance wait :2508): adjacent_settled_count and G_Arrival_ShouldSettle for all of them in two device calls
+ * (navhip_settled_count, navhip_arrival_settle).  A zone = one struct arrival_state, handed over as it is: its
+ * slots, their fill ranks and the sorted tile keys of its footprint.  st / fl (by dense index) are overwritten
+ * for the units decided here. */
+static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navhip_world *W, int begin_idx, int end_idx,
+                                 const uint8_t *zoned, const float *new_pos, const float *vdes, uint8_t *st, uint8_t *fl)
+{
+    const struct move_gamestate *gs = &s_move_work.gamestate;
+    int nq = 0;
+    for(int w = begin_idx; w <= end_idx; w++) {
+        const int i = s_hip_witem.idx[w];
+        if(zoned[i] && (fl[i] & NAVHIP_SU_HOST) && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION))
+            nq++;
+    }
+    if(nq == 0)
+        return true;
+    const size_t F = S->nflocks;
+    int32_t *zone_of = malloc(sizeof(int32_t) * (F * NAV_LAYER_MAX + 1));   /* (flock, layer) -> zone */
+    for(size_t k = 0; k < F * NAV_LAYER_MAX; k++) zone_of[k] = -1;
+    navhip_arrival_zone *zones = malloc(sizeof(navhip_arrival_zone) * (nq + 1));
+    const struct arrival_state **zone_as = malloc(sizeof(void*) * (nq + 1));
+    int32_t *uid = malloc(sizeof(int32_t) * nq), *zone = malloc(sizeof(int32_t) * nq), *witem = malloc(sizeof(int32_t) * nq);
+    int32_t *nsettled = malloc(sizeof(int32_t) * nq), *stuck = malloc(sizeof(int32_t) * nq), *o_stuck = malloc(sizeof(int32_t) * nq);
+    float *q_pos = malloc(sizeof(float) * 2 * nq), *sink = malloc(sizeof(float) * 2 * nq), *order = malloc(sizeof(float) * 2 * nq);
+    float *anchor = malloc(sizeof(float) * 2 * nq), *o_anchor = malloc(sizeof(float) * 2 * nq);
+    uint8_t *substate = malloc(nq), *sink_valid = malloc(nq), *anchored = malloc(nq);
+    uint8_t *o_settle = malloc(nq), *o_substate = malloc(nq), *o_anchored = malloc(nq);
+    int nz = 0, q = 0, n_slots = 0, n_keys = 0;
+    for(int w = begin_idx; w <= end_idx; w++) {
+        const int i = s_hip_witem.idx[w];
+        if(!(zoned[i] && (fl[i] & NAVHIP_SU_HOST) && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION)))
+            continue;
+        const int f = S->flock[i];
+        const enum nav_layer layer = Entity_NavLayerWithRadius(S->flags[i], S->radius[i]);
+        int32_t *zi = &zone_of[(size_t)f * NAV_LAYER_MAX + layer];
+        if(*zi < 0) {
+            const struct arrival_state *as = G_ArrivalGroup_ForLayer(&vec_AT(&s_flocks, f).arrival, layer);
+            *zi = nz;
+            zone_as[nz] = as;
+            zones[nz] = (navhip_arrival_zone){as->centre.x, as->centre.z, as->unit_radius, as->fill_frac, as->radius,
+                (int32_t)as->layer, as->active_row, as->num_rows, n_slots, n_slots + as->num_slots, n_keys, n_keys + as->num_region};
+            n_slots += as->num_slots; n_keys += as->num_region;
+            nz++;
+        }
+        const struct movestate *ms = movestate_get(S->uids[i]);
+        const struct arrival_unit_state *us = &ms->arrival;
+        uid[q] = i; zone[q] = *zi; witem[q] = w;
+        q_pos[2 * q] = new_pos[2 * i]; q_pos[2 * q + 1] = new_pos[2 * i + 1];
+        substate[q] = (uint8_t)us->substate; sink_valid[q] = us->sink_valid;
+        sink[2 * q] = us->sink.x; sink[2 * q + 1] = us->sink.z;
+        order[2 * q] = us->order_pos.x; order[2 * q + 1] = us->order_pos.z;
+        anchor[2 * q] = us->progress_anchor.x; anchor[2 * q + 1] = us->progress_anchor.z;
+        anchored[q] = us->progress_anchored; stuck[q] = us->stuck;
+        q++;
+    }
+    float *slots = malloc(sizeof(float) * 2 * (n_slots + 1));
+    int32_t *ring = malloc(sizeof(int32_t) * (n_slots + 1));
+    uint64_t *keys = malloc(sizeof(uint64_t) * (n_keys + 1));
+    for(int z = 0; z < nz; z++) {
+        const struct arrival_state *as = zone_as[z];
+        memcpy(slots + 2 * zones[z].slot_begin, as->slots, sizeof(vec2_t) * as->num_slots);
+        memcpy(ring + zones[z].slot_begin, as->slot_ring, sizeof(int) * as->num_slots);
+        memcpy(keys + zones[z].key_begin, as->region_keys, sizeof(uint64_t) * as->num_region);
+    }
+    bool ok = navhip_settled_count(ctx, W, nq, uid, nsettled) == NAVHIP_OK;
+    navhip_settle_in in = {nz, nq, zones, slots, ring, keys, uid, zone, q_pos, nsettled, substate, sink_valid, sink, order,
+                           anchor, anchored, stuck};
+    navhip_settle_out out = {o_settle, o_substate, o_anchor, o_anchored, o_stuck};
+    ok = ok && navhip_arrival_settle(ctx, W, &in, &out) == NAVHIP_OK;
+    for(q = 0; ok && q < nq; q++) {
+        const int i = uid[q];
+        if(nsettled[q] < 0)
+            continue;                                   /* (a unit wider than the device's query: the host's arm) */
+        const enum nav_layer layer = Entity_NavLayerWithRadius(S->flags[i], S->radius[i]);
+        const vec2_t np = {q_pos[2 * q], q_pos[2 * q + 1]}, vd = {vdes[2 * i], vdes[2 * i + 1]};
+        s_hip_settle_stats[0]++;
+        st[i] = S->state[i]; fl[i] = 0;
+        if(!M_NavPositionPathable(gs->map, layer, np))
+            continue;                                   /* :2437: stuck where it is, in the state it was */
+        if(o_settle[q]) {
+            st[i] = STATE_ARRIVED; fl[i] = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK;
+            s_hip_settle_stats[1]++;
+        }else if(PFM_Vec2_Len((vec2_t*)&vd) < EPSILON) {
+            st[i] = STATE_WAITING; fl[i] = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK;       /* :2508 */
+        }
+        s_hip_settle_chk[witem[q]] = (struct hip_settle_chk){true, o_substate[q], o_anchored[q], o_stuck[q],
+                                                            {o_anchor[2 * q], o_anchor[2 * q + 1]}};
+    }
+    free(zone_of); free(zones); free(zone_as); free(uid); free(zone); free(witem); free(nsettled); free(stuck); free(o_stuck);
+    free(q_pos); free(sink); free(order); free(anchor); free(o_anchor); free(substate); free(sink_valid); free(anchored);
+    free(o_settle); free(o_substate); free(o_anchored); free(slots); free(ring); free(keys);
+    return ok;
 }
 
 static bool move_hip_state_work(int begin_idx, int end_idx)
@@ -595,17 +703,44 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         s_hip_su_state = realloc(s_hip_su_state, s_hip_su_cap);
         s_hip_su_flags = realloc(s_hip_su_flags, s_hip_su_cap);
     }
+    s_hip_settle_chk = realloc(s_hip_settle_chk, sizeof(struct hip_settle_chk) * (s_move_work.nwork + 1));
+    for(int w = begin_idx; w <= end_idx; w++)
+        s_hip_settle_chk[w].valid = false;
     float *new_pos = hip_arena(sizeof(float) * (2 * n + 2)), *vdes = hip_arena(sizeof(float) * (2 * n + 2));
-    uint8_t *skip = hip_arena(n + 1);
+    float *new_vel = hip_arena(sizeof(float) * (2 * n + 2)), *next_rot = hip_arena(sizeof(float) * (4 * n + 4));
+    float *gate_vel = hip_arena(sizeof(float) * (2 * n + 2));
+    uint8_t *skip = hip_arena(n + 1), *zoned = hip_arena(n + 1), *gate = hip_arena(n + 1);
     memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2)); memset(skip, 0, n + 1);
+    memset(new_vel, 0, sizeof(float) * (2 * n + 2)); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); memset(zoned, 0, n + 1);
     hip_work_dense_prepare();
-    struct hip_state_pass T = {&S, begin_idx, new_pos, vdes, skip};
+    struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned};
     hip_for(hip_state_items_range, end_idx - begin_idx + 1, &T);
     int lo = n, hi = -1;
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];
         if(i < lo) lo = i;
         if(i > hi) hi = i;
+    }
+    /* the heading gate for the slab (navhip_heading_gate): the velocity entity_compute_update integrates and the
+     * position it tests; the few units within the device's margin of a tolerance get the reference's own arithmetic */
+    {
+        navhip_world G;
+        hip_snap_world(&S, &G);
+        G.work_begin = lo; G.work_end = hi + 1;
+        navhip_gate_in gin = {next_rot, new_vel, vdes};
+        if(hi < lo || navhip_heading_gate(ctx, &G, &gin, gate_vel, new_pos, gate) != NAVHIP_OK) {
+            hip_snap_free(&S);
+            return false;
+        }
+        for(int w = begin_idx; w <= end_idx; w++) {
+            const int i = hip_work_dense(&S, w);
+            if(!(gate[i] & NAVHIP_GATE_HOST))
+                continue;
+            const struct move_work_out *out = &s_move_work.out[w];
+            vec2_t np = new_pos_for_vel(out->ent_uid, hip_heading_gated(movestate_get(out->ent_uid), out->ent_des_v, out->ent_vel));
+            new_pos[2 * i] = np.x; new_pos[2 * i + 1] = np.z;
+            s_hip_settle_stats[3]++;
+        }
     }
     /* the two destination-only queries of arrived() (:2170), once per flock for the nav layer most of its
      * members path on (units of another layer come back as NAVHIP_SU_HOST) */
@@ -645,6 +780,8 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     navhip_state_in in = {new_pos, vdes, skip, flayer, nearest, toff, tiles};
     uint8_t *st = hip_arena(n + 1), *fl = hip_arena(n + 1);
     bool ok = hi >= lo && navhip_state_update(ctx, &W, &in, st, fl) == NAVHIP_OK;
+    if(ok)
+        ok = move_hip_settle_work(ctx, &S, &W, begin_idx, end_idx, zoned, new_pos, vdes, st, fl);
     if(ok) {
         s_hip_su_stats[2]++;
         for(int w = begin_idx; w <= end_idx; w++) {
@@ -667,6 +804,15 @@ static void move_hip_update_work(int begin_idx, int end_idx)
     for(int w = begin_idx; w <= end_idx; w++) {
         struct move_work_out *out = &s_move_work.out[w];
         entity_compute_update(s_move_work.hz, out->ent_uid, out->ent_vel, out->ent_des_v, &s_move_work.in[w], &out->patch);
+        if(s_hip_settle_chk && s_hip_settle_chk[w].valid) {
+            /* the reference's G_Arrival_ShouldSettle has just run inside entity_compute_update: what it left in
+             * the unit's arrival state is what the device's rule returned for it */
+            const struct arrival_unit_state *us = &movestate_get(out->ent_uid)->arrival;
+            const struct hip_settle_chk *c = &s_hip_settle_chk[w];
+            if((uint8_t)us->substate != c->substate || (uint8_t)us->progress_anchored != c->anchored || us->stuck != c->stuck
+            || us->progress_anchor.x != c->anchor.x || us->progress_anchor.z != c->anchor.z)
+                s_hip_settle_stats[2]++;
+        }
         if(s_hip_su_flags[w] & NAVHIP_SU_HOST)
             continue;
         out->patch.flags = (enum movestate_flags)(out->patch.flags & ~UPDATE_SET_STATE);

@@ -143,6 +143,11 @@ def lib():
             ("pfref_move_unload", [], None),
             ("pfref_move_set_formation", [C.c_void_p] * 5, None),
             ("pfref_move_set_arrival", [C.c_void_p] * 2, None),
+            ("pfref_move_set_arrival_zone", [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int], C.c_int),
+            ("pfref_move_set_arrival_units", [C.c_void_p] * 7, None),
+            ("pfref_move_get_arrival_units", [C.c_void_p] * 4, None),
+            ("pfref_move_hip_settle_stats", [C.c_void_p], None),
             ("pfref_move_heading_gate", [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p] * 2, None),
             ("pfref_move_dir_quat", [C.c_void_p, C.c_int, C.c_void_p], None),
             ("pfref_move_settled_count", [C.c_void_p, C.c_int, C.c_void_p], None),
@@ -665,6 +670,42 @@ class RefMove:
         """(units decided on the device, units left to the host, passes) of the state binding."""
         out = (C.c_long * 3)()
         lib().pfref_move_hip_state_stats(out)
+        return tuple(out)
+
+    def set_arrival_zone(self, flock, zone):
+        """A real arrival zone (struct arrival_state) for (flock, zone["layer"]); zone as in arrival_should_settle."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        slots, ring, reg = f32(zone["slots_xz"]).reshape(-1, 2), np.ascontiguousarray(zone["slot_ring"], np.int32), \
+            f32(zone["region_xz"]).reshape(-1, 2)
+        cen = f32(zone["centre_xz"])
+        nk = lib().pfref_move_set_arrival_zone(int(flock), int(zone["layer"]), _p(cen), int(zone["radius"]),
+                                               float(zone["unit_radius"]), float(zone["fill_frac"]), int(zone["active_row"]),
+                                               int(zone["num_rows"]), _p(slots), _p(ring), len(ring), _p(reg), len(reg))
+        assert nk >= 0
+        return nk
+
+    def set_arrival_units(self, u):
+        """Every unit's struct arrival_unit_state from a dict of n-row arrays (substate, sink_valid, sink_xz,
+        order_pos_xz, progress_anchor_xz, progress_anchored, stuck)."""
+        k = [np.ascontiguousarray(u["substate"], np.uint8), np.ascontiguousarray(u["sink_valid"], np.uint8),
+             np.ascontiguousarray(u["sink_xz"], np.float32), np.ascontiguousarray(u["order_pos_xz"], np.float32),
+             np.ascontiguousarray(u["progress_anchor_xz"], np.float32), np.ascontiguousarray(u["progress_anchored"], np.uint8),
+             np.ascontiguousarray(u["stuck"], np.int32)]
+        assert all(len(a) == self.n for a in k)
+        lib().pfref_move_set_arrival_units(*[_p(a) for a in k])
+
+    def get_arrival_units(self):
+        out = {"substate": np.zeros(self.n, np.uint8), "progress_anchor_xz": np.zeros((self.n, 2), np.float32),
+               "progress_anchored": np.zeros(self.n, np.uint8), "stuck": np.zeros(self.n, np.int32)}
+        lib().pfref_move_get_arrival_units(_p(out["substate"]), _p(out["progress_anchor_xz"]), _p(out["progress_anchored"]),
+                                           _p(out["stuck"]))
+        return out
+
+    def hip_settle_stats(self):
+        """(units the device's settle rule decided, of those settled, unit states that differ from the reference's
+        afterwards, units whose heading gate the device left to the host) of the state binding."""
+        out = (C.c_long * 4)()
+        lib().pfref_move_hip_settle_stats(out)
         return tuple(out)
 
     def heading_gate(self, new_vel, vdes, next_rot, begin=0, end=None):

@@ -278,6 +278,16 @@ int pfref_arrival_should_settle(pfref_nav *nav, int layer, const float *centre_x
                                 const int32_t *nsettled, uint8_t *substate, const uint8_t *sink_valid,
                                 const float *sink_xz, const float *order_pos_xz, float *progress_anchor_xz,
                                 uint8_t *progress_anchored, int32_t *stuck, uint8_t *out_settle);
+/* a real arrival zone for (flock, layer) from plain arrays; every unit's struct arrival_unit_state set / read back;
+ * counters of the binding's settle pass (move_hip_settle_stats) */
+int pfref_move_set_arrival_zone(int flock, int layer, const float *centre_xz, int radius, float unit_radius,
+                                float fill_frac, int active_row, int num_rows, const float *slots_xz,
+                                const int32_t *slot_ring, int num_slots, const float *region_xz, int num_region_pos);
+void pfref_move_set_arrival_units(const uint8_t *substate, const uint8_t *sink_valid, const float *sink_xz,
+                                  const float *order_pos_xz, const float *progress_anchor_xz,
+                                  const uint8_t *progress_anchored, const int32_t *stuck);
+void pfref_move_get_arrival_units(uint8_t *substate, float *progress_anchor_xz, uint8_t *progress_anchored, int32_t *stuck);
+void pfref_move_hip_settle_stats(long out[4]);
 /* fine-arrival inputs: sink [n][2], flags [n] (bit 0 unit committed to a valid slot, bit 1 the
  * flock's arrival_state for the unit's layer is in ARRIVAL_PHASE_FILLING) */
 void pfref_move_set_arrival(const float *sink_xz, const uint8_t *flags);

@@ -534,6 +534,7 @@ int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int beg
     return 1;
 }
 void pfref_move_hip_state_stats(long out[3]) { move_hip_state_stats(out); }
+void pfref_move_hip_settle_stats(long out[4]) { move_hip_settle_stats(out); }
 
 struct mbench_arg{ int begin, end, reps; };
 
@@ -756,4 +757,65 @@ int pfref_arrival_should_settle(pfref_nav *nav, int layer, const float *centre_x
     const int nk = as->num_region;
     free(as);
     return nk;
+}
+
+/* A real arrival zone for flock `flock` and nav layer `layer` (struct arrival_state, arrival.h:66) from plain arrays,
+ * as pfref_arrival_should_settle builds one: entity_compute_update then takes the G_Arrival_ShouldSettle arm
+ * (:2443) for the flock's units of that layer. */
+int pfref_move_set_arrival_zone(int flock, int layer, const float *centre_xz, int radius, float unit_radius,
+                                float fill_frac, int active_row, int num_rows, const float *slots_xz,
+                                const int32_t *slot_ring, int num_slots, const float *region_xz, int num_region_pos)
+{
+    if(flock < 0 || flock >= (int)vec_size(&s_flocks) || num_slots > ARRIVAL_MAX_SLOTS || num_region_pos > ARRIVAL_MAX_SLOTS)
+        return -1;
+    struct flock *fl = &vec_AT(&s_flocks, flock);
+    if(!fl->arrival.layers[layer])
+        fl->arrival.layers[layer] = calloc(1, sizeof(struct arrival_state));
+    struct arrival_state *as = fl->arrival.layers[layer];
+    memset(as, 0, sizeof(*as));
+    as->phase = ARRIVAL_PHASE_FILLING;
+    as->layer = (enum nav_layer)layer;
+    as->centre = (vec2_t){centre_xz[0], centre_xz[1]};
+    as->radius = (uint16_t)radius;
+    as->unit_radius = unit_radius;
+    as->fill_frac = fill_frac;
+    as->active_row = active_row;
+    as->num_rows = num_rows;
+    as->num_slots = num_slots;
+    for(int i = 0; i < num_slots; i++) {
+        as->slots[i] = (vec2_t){slots_xz[2 * i], slots_xz[2 * i + 1]};
+        as->slot_ring[i] = slot_ring[i];
+    }
+    as->num_region = (int)N_TileKeysForPositions(&s_w.nav->priv, s_w.nav->map_pos, (const vec2_t*)region_xz,
+                                                 (size_t)num_region_pos, as->region_keys);
+    return as->num_region;
+}
+
+/* every unit's struct arrival_unit_state (arrival.h:105) from arrays of n rows; get = read them back */
+void pfref_move_set_arrival_units(const uint8_t *substate, const uint8_t *sink_valid, const float *sink_xz,
+                                  const float *order_pos_xz, const float *progress_anchor_xz,
+                                  const uint8_t *progress_anchored, const int32_t *stuck)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        struct arrival_unit_state *us = &movestate_get(i)->arrival;
+        memset(us, 0, sizeof(*us));
+        us->substate = (enum arrival_substate)substate[i];
+        us->sink_valid = sink_valid[i] != 0;
+        us->sink = (vec2_t){sink_xz[2 * i], sink_xz[2 * i + 1]};
+        us->order_pos = (vec2_t){order_pos_xz[2 * i], order_pos_xz[2 * i + 1]};
+        us->progress_anchor = (vec2_t){progress_anchor_xz[2 * i], progress_anchor_xz[2 * i + 1]};
+        us->progress_anchored = progress_anchored[i] != 0;
+        us->stuck = stuck[i];
+    }
+}
+
+void pfref_move_get_arrival_units(uint8_t *substate, float *progress_anchor_xz, uint8_t *progress_anchored, int32_t *stuck)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        const struct arrival_unit_state *us = &movestate_get(i)->arrival;
+        substate[i] = (uint8_t)us->substate;
+        progress_anchor_xz[2 * i] = us->progress_anchor.x; progress_anchor_xz[2 * i + 1] = us->progress_anchor.z;
+        progress_anchored[i] = us->progress_anchored ? 1 : 0;
+        stuck[i] = us->stuck;
+    }
 }

@@ -486,3 +486,22 @@ def state_world(seed=5):
     vdes /= np.maximum(np.linalg.norm(vdes, axis=1, keepdims=True), 1e-6)
     vdes[rng.rand(n) < 0.1] = 0
     return grid, nav, world, new_vel, vdes.astype(np.float32)
+
+
+def arrival_zone_at(grid, cell, rad, rng, fill, active_row, num_rows, unit_radius=1.0, layer=0):
+    """A zone of the arrival overlay (struct arrival_state, arrival.h:66) as plain arrays: the footprint = the pathable
+    tiles of a disc of `rad` tiles about `cell` (region_xz: their centres, `tiles`: their absolute (row, col)), a third
+    of them carrying a slot, fill ranks at random."""
+    h, w = grid.shape[0] // 64, grid.shape[1] // 64
+    rr, cc = np.mgrid[cell[0] - rad:cell[0] + rad + 1, cell[1] - rad:cell[1] + rad + 1]
+    keep = (rr >= 0) & (cc >= 0) & (rr < grid.shape[0]) & (cc < grid.shape[1])
+    rr, cc = rr[keep], cc[keep]
+    inside = ((rr - cell[0]) ** 2 + (cc - cell[1]) ** 2 <= rad * rad) & (grid[rr, cc] != 255)
+    tiles = np.stack([rr[inside], cc[inside]], 1)
+    region_xz = np.array([synth.cell_centre(w, h, r, q) for r, q in tiles], np.float32).reshape(-1, 2)
+    pick = rng.rand(len(tiles)) < 0.35
+    slots = (region_xz[pick] + rng.uniform(-1.5, 1.5, (pick.sum(), 2))).astype(np.float32)
+    return {"layer": layer, "centre_xz": np.array(synth.cell_centre(w, h, cell[0], cell[1]), np.float32), "radius": rad,
+            "unit_radius": float(unit_radius), "fill_frac": fill, "active_row": active_row, "num_rows": num_rows,
+            "slots_xz": slots, "slot_ring": rng.randint(0, num_rows, len(slots)).astype(np.int32), "region_xz": region_xz,
+            "tiles": tiles}

@@ -192,6 +192,65 @@ def test_state_updates_through_the_binding():
         pfref.RefMove.unload()
 
 
+def test_arrival_settle_through_the_binding():
+    """The same pass with ACTIVE arrival zones on two flocks (struct arrival_state with a footprint, slots and fill
+    ranks): their units take the G_Arrival_ShouldSettle arm of entity_compute_update (movement.c:2443-2451).  The
+    binding gathers them, counts their settled neighbours and runs the rule on the device (navhip_settled_count,
+    navhip_arrival_settle), and the heading gate of every unit in one navhip_heading_gate: next state and blocker
+    flag of every unit == the reference's own, and what the device's rule leaves in each unit's arrival state ==
+    what the reference's leaves there."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    rng = np.random.RandomState(31)
+    zones = {}
+    for f, (fill, active_row, num_rows) in ((0, (0.8, 1, 3)), (3, (0.95, 2, 3))):
+        t = world["flock_target_xz"][f]
+        cell = (int((t[1] + 4 * 128.0) // 4), int((4 * 128.0 - t[0]) // 4))
+        zones[f] = cases.arrival_zone_at(grid, cell, 8, rng, fill, active_row, num_rows)
+        # the flock's units: round the zone, a share of them on slots
+        m = np.flatnonzero(world["flock"] == f)
+        world["pos_xz"][m] = (zones[f]["centre_xz"] + rng.normal(0, 22.0, (len(m), 2))).astype(np.float32)
+        on = m[rng.rand(len(m)) < 0.3]
+        world["pos_xz"][on] = zones[f]["slots_xz"][rng.randint(len(zones[f]["slots_xz"]), size=len(on))] \
+            + rng.normal(0, 0.7, (len(on), 2)).astype(np.float32)
+    world["pos_xz"] = np.clip(world["pos_xz"], -4 * 128.0 + 14, 4 * 128.0 - 14).astype(np.float32)
+    in_zone = np.isin(world["flock"], list(zones)) & (world["radius"] < 5.0)
+    sink = world["pos_xz"] + rng.normal(0, 12.0, (n, 2)).astype(np.float32)
+    for f, z in zones.items():
+        m = np.flatnonzero(world["flock"] == f)
+        sink[m] = z["slots_xz"][rng.randint(len(z["slots_xz"]), size=len(m))]
+    units = {"substate": rng.randint(0, 4, n).astype(np.uint8), "sink_valid": (rng.rand(n) < 0.7).astype(np.uint8),
+             "sink_xz": sink.astype(np.float32), "order_pos_xz": (world["pos_xz"] + rng.normal(0, 3.5, (n, 2))).astype(np.float32),
+             "progress_anchor_xz": (world["pos_xz"] + rng.normal(0, 1.4, (n, 2))).astype(np.float32),
+             "progress_anchored": (rng.rand(n) < 0.7).astype(np.uint8), "stuck": rng.randint(0, 14, n).astype(np.int32)}
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        for f, z in zones.items():
+            assert mv.set_arrival_zone(f, z) == len(z["tiles"])
+        mv.set_arrival_units(units)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        ref_after = mv.get_arrival_units()
+        changed = (ref_after["substate"] != units["substate"]) | (ref_after["stuck"] != units["stuck"])
+        assert changed[in_zone].sum() > 100 and not changed[~np.isin(world["flock"], list(zones))].any()
+        mv.set_arrival_units(units)
+        assert nav.hip_init(), "no MI355X visible"
+        st, fl, dv = mv.state_update_hip(new_vel, vdes)
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        after = mv.get_arrival_units()
+        for k in after:
+            assert np.array_equal(after[k], ref_after[k]), k
+        decided, settled, differ, gate_host = mv.hip_settle_stats()
+        moving = np.isin(world["state"], (0, 1)) & ((world["flags"] & (1 << 18)) == 0)
+        assert decided == (in_zone & moving).sum() > 300
+        assert settled > 30 and differ == 0 and gate_host == 0
+        # the units of the zones are the device's now
+        assert ((dv[in_zone & moving] & 0x80) == 0).all()
+        assert (in_zone & moving & (st == 2)).sum() >= settled and (in_zone & moving & (st == 0)).sum() > 50
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
+
+
 def _game(grid, n, seed, n_factions=3):
     rng = np.random.RandomState(seed)
     h, w = grid.shape[0] // 64, grid.shape[1] // 64

@@ -127,17 +127,9 @@ def _zone_world(seed):
             c = free[rng.randint(len(free))]
             if 12 <= c[0] < 244 and 12 <= c[1] < 244:
                 break
-        rr, cc = np.mgrid[c[0] - rad:c[0] + rad + 1, c[1] - rad:c[1] + rad + 1]
-        inside = ((rr - c[0]) ** 2 + (cc - c[1]) ** 2 <= rad * rad) & (grid[rr, cc] != 255)
-        tiles = np.stack([rr[inside], cc[inside]], 1)
-        region_xz = np.array([synth.cell_centre(4, 4, r, q) for r, q in tiles], np.float32)
-        pick = rng.rand(len(tiles)) < 0.35
-        slots = region_xz[pick] + rng.uniform(-1.5, 1.5, (pick.sum(), 2)).astype(np.float32)
-        zones.append({"layer": 0, "centre_xz": np.array(synth.cell_centre(4, 4, c[0], c[1]), np.float32), "radius": rad,
-                      "unit_radius": float(rng.choice([1.0, 2.5, 5.5])), "fill_frac": fill, "active_row": active_row,
-                      "num_rows": num_rows, "slots_xz": slots.astype(np.float32),
-                      "slot_ring": rng.randint(0, num_rows, len(slots)).astype(np.int32), "region_xz": region_xz,
-                      "tiles": tiles})
+        zones.append(cases.arrival_zone_at(grid, c, rad, rng, fill, active_row, num_rows,
+                                           unit_radius=rng.choice([1.0, 2.5, 5.5])))
+        slots = zones[-1]["slots_xz"]
         nq = 900
         centre = zones[-1]["centre_xz"]
         pos = (centre + rng.normal(0, rad * 4.0 * 0.9, (nq, 2))).astype(np.float32)
