@@ -547,6 +547,9 @@ void move_hip_state_stats(long out[3]) { memcpy(out, s_hip_su_stats, sizeof(s_hi
  * entity_compute_update; a maintainer applies the device's copy instead) */
 struct hip_settle_chk { bool valid; uint8_t substate, anchored; int32_t stuck; vec2_t anchor; };
 static struct hip_settle_chk *s_hip_settle_chk;      /* [nwork] by work item */
+static int32_t *s_hip_wait_chk;                      /* [nwork][2] {a WAITING unit the device counted, its wait_ticks_left after} */
+static long     s_hip_wait_differ;                   /* wait counters that differ from the reference's afterwards */
+long move_hip_wait_differ(void) { return s_hip_wait_differ; }
 static long     s_hip_settle_stats[4];               /* units decided by the device rule, of those settled, unit states
                                                         that differ from the reference's afterwards, units whose
                                                         heading gate the device left to the host */
@@ -563,7 +566,8 @@ static vec2_t hip_heading_gated(const struct movestate *ms, vec2_t vdes, vec2_t 
     return err > (rolling ? MOVE_HEADING_HALT : MOVE_HEADING_RESUME) ? (vec2_t){0.0f, 0.0f} : vel;
 }
 
-struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned; };
+struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned;
+                        uint8_t *fstate, *wait_prev; int32_t *wait_ticks; };
 
 static void hip_state_items_range(int begin, int end, void *arg)
 {
@@ -580,10 +584,16 @@ static void hip_state_items_range(int begin, int end, void *arg)
         T->next_rot[4 * i] = ms->next_rot.x; T->next_rot[4 * i + 1] = ms->next_rot.y;
         T->next_rot[4 * i + 2] = ms->next_rot.z; T->next_rot[4 * i + 3] = ms->next_rot.w;
         T->vdes[2 * i] = out->ent_des_v.x; T->vdes[2 * i + 1] = out->ent_des_v.z;
-        /* a formation member (:2427-2437) or an active arrival group (:2443): the host's arms.  So is every unit
-         * at a movement rate below 20 Hz: entity_compute_update then tests the INTERPOLATED intermediate position
+        /* an active arrival group (:2443): move_hip_settle_work's.  Every unit at a movement rate below 20 Hz is the
+         * host's: entity_compute_update then tests the INTERPOLATED intermediate position
          * (interpolate_positions(next_ppos, next_npos, ms->step), :2368-2377), not pos + vel */
-        T->skip[i] = in->fstate.fid != NULL_FID || (20 / hz_count(s_move_work.hz)) > 1;
+        /* the flag / counter arms (formation member on the move, ARRIVING_TO_CELL, the wait timer):
+         * navhip_state_update_aux after the arrival arm, which a member falls through to (:2439) */
+        T->fstate[i] = (uint8_t)((in->fstate.fid != NULL_FID ? NAVHIP_FS_MEMBER : 0) | (in->fstate.assignment_ready ? NAVHIP_FS_READY : 0)
+                     | (in->fstate.assigned_to_cell ? NAVHIP_FS_ASSIGNED : 0) | (in->fstate.in_range_of_cell ? NAVHIP_FS_IN_RANGE : 0)
+                     | (in->fstate.arrived_at_cell ? NAVHIP_FS_ARRIVED : 0));
+        T->wait_ticks[i] = ms->wait_ticks_left; T->wait_prev[i] = (uint8_t)ms->wait_prev;
+        T->skip[i] = (20 / hz_count(s_move_work.hz)) > 1;
         if(!T->skip[i] && S->flock[i] >= 0) {
             struct flock *fl = &vec_AT(&s_flocks, S->flock[i]);
             struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,
@@ -710,10 +720,13 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     float *new_vel = hip_arena(sizeof(float) * (2 * n + 2)), *next_rot = hip_arena(sizeof(float) * (4 * n + 4));
     float *gate_vel = hip_arena(sizeof(float) * (2 * n + 2));
     uint8_t *skip = hip_arena(n + 1), *zoned = hip_arena(n + 1), *gate = hip_arena(n + 1);
+    uint8_t *fstate = hip_arena(n + 1), *wait_prev = hip_arena(n + 1);
+    int32_t *wait_ticks = hip_arena(sizeof(int32_t) * (n + 1)), *wait_after = hip_arena(sizeof(int32_t) * (n + 1));
+    memset(fstate, 0, n + 1); memset(wait_prev, 0, n + 1); memset(wait_ticks, 0, sizeof(int32_t) * (n + 1));
     memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2)); memset(skip, 0, n + 1);
     memset(new_vel, 0, sizeof(float) * (2 * n + 2)); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); memset(zoned, 0, n + 1);
     hip_work_dense_prepare();
-    struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned};
+    struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned, fstate, wait_prev, wait_ticks};
     hip_for(hip_state_items_range, end_idx - begin_idx + 1, &T);
     int lo = n, hi = -1;
     for(int w = begin_idx; w <= end_idx; w++) {
@@ -782,6 +795,17 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     bool ok = hi >= lo && navhip_state_update(ctx, &W, &in, st, fl) == NAVHIP_OK;
     if(ok)
         ok = move_hip_settle_work(ctx, &S, &W, begin_idx, end_idx, zoned, new_pos, vdes, st, fl);
+    const bool aux = ok && (20 / hz_count(s_move_work.hz)) == 1;
+    if(aux) {
+        navhip_state_aux_in ain = {fstate, wait_ticks, wait_prev, new_pos};
+        ok = navhip_state_update_aux(ctx, &W, &ain, st, fl, wait_after) == NAVHIP_OK;
+    }
+    s_hip_wait_chk = realloc(s_hip_wait_chk, sizeof(int32_t) * 2 * (s_move_work.nwork + 1));
+    for(int w = begin_idx; w <= end_idx; w++) {
+        const int i = s_hip_witem.idx[w];
+        s_hip_wait_chk[2 * w] = aux && ok && S.state[i] == STATE_WAITING;
+        s_hip_wait_chk[2 * w + 1] = wait_after[i];
+    }
     if(ok) {
         s_hip_su_stats[2]++;
         for(int w = begin_idx; w <= end_idx; w++) {
@@ -804,6 +828,10 @@ static void move_hip_update_work(int begin_idx, int end_idx)
     for(int w = begin_idx; w <= end_idx; w++) {
         struct move_work_out *out = &s_move_work.out[w];
         entity_compute_update(s_move_work.hz, out->ent_uid, out->ent_vel, out->ent_des_v, &s_move_work.in[w], &out->patch);
+        /* (the reference's own switch has just counted the wait down in movestate: the device's count is held against it;
+         * a maintainer stores the device's) */
+        if(s_hip_wait_chk && s_hip_wait_chk[2 * w] && movestate_get(out->ent_uid)->wait_ticks_left != s_hip_wait_chk[2 * w + 1])
+            s_hip_wait_differ++;
         if(s_hip_settle_chk && s_hip_settle_chk[w].valid) {
             /* the reference's G_Arrival_ShouldSettle has just run inside entity_compute_update: what it left in
              * the unit's arrival state is what the device's rule returned for it */
@@ -815,11 +843,19 @@ static void move_hip_update_work(int begin_idx, int end_idx)
         }
         if(s_hip_su_flags[w] & NAVHIP_SU_HOST)
             continue;
-        out->patch.flags = (enum movestate_flags)(out->patch.flags & ~UPDATE_SET_STATE);
+        out->patch.flags = (enum movestate_flags)(out->patch.flags & ~(UPDATE_SET_STATE | UPDATE_SET_MOVING | UPDATE_SET_TARGET_DIR));
         if(s_hip_su_flags[w] & NAVHIP_SU_SET_STATE) {
             out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_STATE);
             out->patch.next_state = (enum move_state)s_hip_su_state[w];
             out->patch.next_block = (s_hip_su_flags[w] & NAVHIP_SU_BLOCK) != 0;
+        }
+        if(s_hip_su_flags[w] & NAVHIP_SU_SET_MOVING) {                  /* the wait ran out, :2641 */
+            out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_MOVING);
+            out->patch.next_state = (enum move_state)s_hip_su_state[w];
+        }
+        if(s_hip_su_flags[w] & NAVHIP_SU_TARGET_DIR) {                  /* arrived at the cell, :2663 */
+            out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_TARGET_DIR);
+            out->patch.next_target_dir = s_move_work.in[w].fstate.target_orientation;
         }
     }
 }

@@ -579,8 +579,10 @@ int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_
  * back as NAVHIP_SU_HOST (the host runs entity_compute_update for that unit as before). */
 #define NAVHIP_SU_SET_STATE  0x01   /* UPDATE_SET_STATE: next_state holds the new state                       */
 #define NAVHIP_SU_BLOCK      0x02   /* movestate_patch.next_block                                            */
-#define NAVHIP_SU_HOST       0x80   /* not decided here: another state, a formation member, an active arrival
-                                       group (skip[i] != 0), or a unit whose nav layer is not its flock's      */
+#define NAVHIP_SU_HOST       0x80   /* not decided here: another state, skip[i] != 0 (an active arrival zone:
+                                       navhip_arrival_settle; a rate below 20 Hz), or a unit whose nav layer is
+                                       not its flock's.  Formation members need not be skipped: see
+                                       navhip_state_update_aux                                                 */
 typedef struct navhip_state_in {
     const float    *new_pos_xz;       /* [n][2] the position entity_compute_update tests: new_pos_for_vel(uid,
                                                 new_vel) (movement.c:2338) -- position + the velocity of the tick
@@ -629,6 +631,35 @@ int  navhip_heading_gate(navhip_ctx *ctx, const navhip_world *world, const navhi
 /* Everything resident on the device, asynchronous on `stream`. */
 int  navhip_heading_gate_dev(navhip_ctx *ctx, const navhip_world *dev_world, const navhip_gate_in *dev_in,
                              float *dev_out_vel_xz, float *dev_out_new_pos_xz, uint8_t *dev_out_gate, void *stream);
+
+/* The arms of the state switch that flags and a counter decide (movement.c:2423-2437, :2630-2644, :2645-2668): a
+ * formation member in STATE_MOVING / MOVING_IN_FORMATION that waits for its assignment or has come within range of its
+ * cell (-> ARRIVING_TO_CELL), STATE_ARRIVING_TO_CELL (-> MOVING / MOVING_IN_FORMATION / TURNING), and the timer of
+ * STATE_WAITING (-> movestate.wait_prev once it runs out).  Called AFTER navhip_state_update on the same slab, with
+ * formation members NOT skipped there: a member the flags do not decide keeps the answer of the arrival arm, exactly
+ * as the reference falls through to it (:2439).  Rows this call decides are overwritten in inout_state / inout_flags
+ * (NAVHIP_SU_HOST cleared); garrisoned units and units whose new position is not pathable (:2437) are left alone /
+ * left unchanged as there.  out_wait_ticks_left[i] = movestate.wait_ticks_left after the tick (written for every row
+ * of the slab).  world: n_ents, radius, flags, state, map_pos, work range. */
+#define NAVHIP_SU_SET_MOVING  0x04   /* UPDATE_SET_MOVING: the state is movestate.wait_prev (the wait ran out, :2641)     */
+#define NAVHIP_SU_TARGET_DIR  0x08   /* UPDATE_SET_TARGET_DIR rides along: next_target_dir = fstate.target_orientation   */
+#define NAVHIP_FS_MEMBER      0x01   /* fstate.fid != NULL_FID                                                           */
+#define NAVHIP_FS_READY       0x02   /* fstate.assignment_ready                                                          */
+#define NAVHIP_FS_ASSIGNED    0x04   /* fstate.assigned_to_cell                                                          */
+#define NAVHIP_FS_IN_RANGE    0x08   /* fstate.in_range_of_cell                                                          */
+#define NAVHIP_FS_ARRIVED     0x10   /* fstate.arrived_at_cell                                                           */
+typedef struct navhip_state_aux_in {
+    const uint8_t  *fstate;           /* [n] NAVHIP_FS_* of move_work_in.fstate (struct formation_state, movement.c:215) */
+    const int32_t  *wait_ticks_left;  /* [n] movestate.wait_ticks_left                                                   */
+    const uint8_t  *wait_prev;        /* [n] movestate.wait_prev                                                         */
+    const float    *new_pos_xz;       /* [n][2] as navhip_state_in.new_pos_xz                                            */
+} navhip_state_aux_in;
+int  navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *world, const navhip_state_aux_in *in,
+                             uint8_t *inout_state, uint8_t *inout_flags, int32_t *out_wait_ticks_left);
+/* Everything resident on the device, asynchronous on `stream`. */
+int  navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *dev_world, const navhip_state_aux_in *dev_in,
+                                 uint8_t *dev_inout_state, uint8_t *dev_inout_flags, int32_t *dev_out_wait_ticks_left,
+                                 void *stream);
 
 /* adjacent_settled_count (movement.c:982) for nq units of the snapshot: G_Pos_EntsInCircleFrom (r = max(30,
  * 2 radius + 5), at most 128 results, garrisoned entities dropped, position.c:379) and of those the movable

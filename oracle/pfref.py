@@ -148,6 +148,9 @@ def lib():
             ("pfref_move_set_arrival_units", [C.c_void_p] * 7, None),
             ("pfref_move_get_arrival_units", [C.c_void_p] * 4, None),
             ("pfref_move_hip_settle_stats", [C.c_void_p], None),
+            ("pfref_move_hip_wait_differ", [], C.c_long),
+            ("pfref_move_set_state_aux", [C.c_void_p] * 3, None),
+            ("pfref_move_get_wait_ticks", [C.c_void_p], None),
             ("pfref_move_heading_gate", [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p] * 2, None),
             ("pfref_move_dir_quat", [C.c_void_p, C.c_int, C.c_void_p], None),
             ("pfref_move_settled_count", [C.c_void_p, C.c_int, C.c_void_p], None),
@@ -647,7 +650,7 @@ class RefMove:
 
     def state_update(self, new_vel, vdes, begin=0, end=None):
         """entity_compute_update (movement.c:2303) per unit: (next_state [n] u8, flags [n] u8: bit 0 state
-        set, bit 1 next_block)."""
+        set, bit 1 next_block, bit 2 UPDATE_SET_MOVING -- next_state = wait_prev --, bit 3 UPDATE_SET_TARGET_DIR)."""
         end = self.n if end is None else end
         v = np.ascontiguousarray(new_vel, np.float32).reshape(self.n, 2)
         d = np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
@@ -701,12 +704,29 @@ class RefMove:
                                            _p(out["stuck"]))
         return out
 
+    def hip_wait_differ(self):
+        """Wait counters the device's pass left different from the reference's (the state binding's check)."""
+        return int(lib().pfref_move_hip_wait_differ())
+
     def hip_settle_stats(self):
         """(units the device's settle rule decided, of those settled, unit states that differ from the reference's
         afterwards, units whose heading gate the device left to the host) of the state binding."""
         out = (C.c_long * 4)()
         lib().pfref_move_hip_settle_stats(out)
         return tuple(out)
+
+    def set_state_aux(self, fstate, wait_ticks_left, wait_prev):
+        """move_work_in.fstate as bits (1 member, 2 ready, 4 assigned, 8 in range, 16 arrived at cell),
+        movestate.wait_ticks_left, .wait_prev -- the inputs of the flag / counter arms of the state switch."""
+        k = [np.ascontiguousarray(fstate, np.uint8), np.ascontiguousarray(wait_ticks_left, np.int32),
+             np.ascontiguousarray(wait_prev, np.uint8)]
+        assert all(len(a) == self.n for a in k)
+        lib().pfref_move_set_state_aux(*[_p(a) for a in k])
+
+    def get_wait_ticks(self):
+        out = np.zeros(self.n, np.int32)
+        lib().pfref_move_get_wait_ticks(_p(out))
+        return out
 
     def heading_gate(self, new_vel, vdes, next_rot, begin=0, end=None):
         """entity_compute_update with movestate.next_rot given (the heading gate, movement.c:2319-2336):

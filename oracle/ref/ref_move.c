@@ -19,6 +19,8 @@
 #include <pthread.h>
 #include <time.h>
 
+static bool s_aux_set;     /* pfref_move_set_state_aux gave the formation flags: the drivers below leave fstate.fid alone */
+
 /* ---- engine services movement.c links against ------------------------------------------- */
 
 uint32_t G_FlagsGetFrom(khash_t(id) *table, uint32_t uid)
@@ -134,6 +136,7 @@ void pfref_move_unload(void)
 {
     if(!s_w.loaded)
         return;
+    s_aux_set = false;
     kh_destroy(id, s_w.flags);
     kh_destroy(pos, s_w.positions);
     kh_destroy(range, s_w.radiuses);
@@ -505,7 +508,7 @@ int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int beg
         struct move_work_in *in = &s_move_work.in[i];
         struct move_work_out *out = &s_move_work.out[i];
         struct movestate *ms = movestate_get(i);
-        in->fstate.fid = NULL_FID;
+        if(!s_aux_set) in->fstate.fid = NULL_FID;
         out->ent_uid = i;
         out->ent_vel = (vec2_t){new_vel[2 * i], new_vel[2 * i + 1]};
         out->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
@@ -527,14 +530,16 @@ int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int beg
             continue;
         }
         move_hip_update_work(i, i);
-        const bool set = (out->patch.flags & UPDATE_SET_STATE) != 0;
-        out_state[i] = (uint8_t)(set ? out->patch.next_state : ms->state);
-        out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0));
+        const bool set = (out->patch.flags & UPDATE_SET_STATE) != 0, mov = (out->patch.flags & UPDATE_SET_MOVING) != 0;
+        out_state[i] = (uint8_t)((set || mov) ? out->patch.next_state : ms->state);
+        out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0) | (mov ? 4 : 0)
+                                 | ((out->patch.flags & UPDATE_SET_TARGET_DIR) ? 8 : 0));
     }
     return 1;
 }
 void pfref_move_hip_state_stats(long out[3]) { move_hip_state_stats(out); }
 void pfref_move_hip_settle_stats(long out[4]) { move_hip_settle_stats(out); }
+long pfref_move_hip_wait_differ(void) { return move_hip_wait_differ(); }
 
 struct mbench_arg{ int begin, end, reps; };
 
@@ -643,7 +648,7 @@ void pfref_move_state_update(const float *new_vel, const float *vdes, int begin,
             out_state[i] = (uint8_t)ms->state; out_flags[i] = 0;
             continue;
         }
-        in->fstate.fid = NULL_FID;
+        if(!s_aux_set) in->fstate.fid = NULL_FID;
         out->ent_uid = i;
         out->ent_vel = (vec2_t){new_vel[2 * i], new_vel[2 * i + 1]};
         out->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
@@ -651,9 +656,10 @@ void pfref_move_state_update(const float *new_vel, const float *vdes, int begin,
             ms->next_rot = dir_quat_from_velocity(intended_heading(out->ent_des_v, out->ent_vel));
         memset(&out->patch, 0, sizeof(out->patch));
         entity_compute_update(s_move_work.hz, i, out->ent_vel, out->ent_des_v, in, &out->patch);
-        const bool set = (out->patch.flags & UPDATE_SET_STATE) != 0;
-        out_state[i] = (uint8_t)(set ? out->patch.next_state : ms->state);
-        out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0));
+        const bool set = (out->patch.flags & UPDATE_SET_STATE) != 0, mov = (out->patch.flags & UPDATE_SET_MOVING) != 0;
+        out_state[i] = (uint8_t)((set || mov) ? out->patch.next_state : ms->state);
+        out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0) | (mov ? 4 : 0)
+                                 | ((out->patch.flags & UPDATE_SET_TARGET_DIR) ? 8 : 0));
     }
 }
 
@@ -674,7 +680,7 @@ void pfref_move_heading_gate(const float *new_vel, const float *vdes, const floa
         if(ms->state == STATE_TURNING
         && !(G_FlagsGetFrom(s_move_work.gamestate.flags, i) & ENTITY_FLAG_GARRISONED))
             continue;
-        in->fstate.fid = NULL_FID;
+        if(!s_aux_set) in->fstate.fid = NULL_FID;
         out->ent_uid = i;
         out->ent_vel = (vec2_t){new_vel[2 * i], new_vel[2 * i + 1]};
         out->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
@@ -818,4 +824,29 @@ void pfref_move_get_arrival_units(uint8_t *substate, float *progress_anchor_xz, 
         progress_anchored[i] = us->progress_anchored ? 1 : 0;
         stuck[i] = us->stuck;
     }
+}
+
+/* the inputs of the flag / counter arms of the state switch (:2423-2437, :2630-2668): move_work_in.fstate as bits
+ * (1 member, 2 assignment_ready, 4 assigned_to_cell, 8 in_range_of_cell, 16 arrived_at_cell), movestate.wait_ticks_left
+ * and .wait_prev; pfref_move_get_wait_ticks reads the counters back */
+void pfref_move_set_state_aux(const uint8_t *fstate, const int32_t *wait_ticks_left, const uint8_t *wait_prev)
+{
+    s_aux_set = true;
+    for(int i = 0; i < s_w.n; i++) {
+        struct formation_state *fs = &s_move_work.in[i].fstate;
+        fs->fid = (fstate[i] & 1) ? 1 : NULL_FID;
+        fs->assignment_ready = (fstate[i] & 2) != 0;
+        fs->assigned_to_cell = (fstate[i] & 4) != 0;
+        fs->in_range_of_cell = (fstate[i] & 8) != 0;
+        fs->arrived_at_cell = (fstate[i] & 16) != 0;
+        struct movestate *ms = movestate_get(i);
+        ms->wait_ticks_left = wait_ticks_left[i];
+        ms->wait_prev = (enum move_state)wait_prev[i];
+    }
+}
+
+void pfref_move_get_wait_ticks(int32_t *out)
+{
+    for(int i = 0; i < s_w.n; i++)
+        out[i] = movestate_get(i)->wait_ticks_left;
 }

@@ -68,6 +68,50 @@ __global__ __launch_bounds__(256) void k_heading_gate(int begin, int end, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// the arms that flags and a counter decide (formation members, ARRIVING_TO_CELL, the wait timer): a thread per
+// unit, after k_state_update
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float *radius, const uint32_t *flags,
+                                                   const uint8_t *state, navhip_state_aux_in in, uint8_t *io_state,
+                                                   uint8_t *io_flags, int32_t *out_ticks)
+{
+    const int i = P.work_begin + blockIdx.x * 256 + threadIdx.x;
+    if(i >= P.work_end) return;
+    const int st = state[i];
+    int ticks = in.wait_ticks_left[i];
+    const uint32_t ef = flags[i];
+    const int layer = nav_layer_for(ef, radius[i]);
+    const uint8_t *cost = P.map.layers[layer].cost;
+    const bool ours = st == NAVHIP_STATE_WAITING || st == NAVHIP_STATE_ARRIVING_TO_CELL
+                   || ((st == NAVHIP_STATE_MOVING || st == NAVHIP_STATE_MOVING_IN_FORMATION) && (in.fstate[i] & NAVHIP_FS_MEMBER));
+    if(ours && !(ef & NAVHIP_ENTITY_FLAG_GARRISONED) && cost) {                 // (:2344 returns before everything)
+        const uint8_t fs = in.fstate[i];
+        tiledesc t;
+        const bool pathable = tile_for_point(P, in.new_pos_xz[2 * i], in.new_pos_xz[2 * i + 1], t)
+                           && cost[tile_index(P, t)] != NAVHIP_COST_IMPASSABLE;   // :2437
+        uint8_t next = (uint8_t)st, fl = 0;
+        bool decided = true;
+        if(pathable) {
+            if(st == NAVHIP_STATE_WAITING) {                                    // :2630-2644
+                ticks--;
+                if(ticks == 0) { next = in.wait_prev[i]; fl = NAVHIP_SU_SET_MOVING; }
+            }else if(st == NAVHIP_STATE_ARRIVING_TO_CELL) {                     // :2645-2668
+                if(!(fs & NAVHIP_FS_MEMBER)) { next = NAVHIP_STATE_MOVING; fl = NAVHIP_SU_SET_STATE; }
+                else if(!(fs & NAVHIP_FS_READY)) { }
+                else if(!(fs & NAVHIP_FS_IN_RANGE)) { next = NAVHIP_STATE_MOVING_IN_FORMATION; fl = NAVHIP_SU_SET_STATE; }
+                else if(fs & NAVHIP_FS_ARRIVED) { next = NAVHIP_STATE_TURNING; fl = NAVHIP_SU_SET_STATE | NAVHIP_SU_TARGET_DIR; }
+            }else{                                                              // a formation member on the move, :2423-2437
+                if(!(fs & NAVHIP_FS_READY)) { }
+                else if((fs & NAVHIP_FS_ASSIGNED) && (fs & NAVHIP_FS_IN_RANGE)) { next = NAVHIP_STATE_ARRIVING_TO_CELL; fl = NAVHIP_SU_SET_STATE; }
+                else decided = false;                                           // falls through to the arrival arm: k_state_update's answer
+            }
+        }
+        if(decided) { io_state[i] = next; io_flags[i] = fl; }
+    }
+    out_ticks[i] = ticks;
+}
+
+// ---------------------------------------------------------------------------------------------
 // adjacent_settled_count: the ids of the spatial query (k_spatial_query, the reference's visiting order,
 // capped) -> the count, a thread per unit
 // ---------------------------------------------------------------------------------------------
@@ -340,6 +384,69 @@ int navhip_heading_gate(navhip_ctx *ctx, const navhip_world *w, const navhip_gat
         SKCHK(ctx, hipMemcpyAsync(out_vel + 2 * lo, base + o_ov + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
         SKCHK(ctx, hipMemcpyAsync(out_new_pos + 2 * lo, base + o_op + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
         SKCHK(ctx, hipMemcpyAsync(out_gate + lo, base + o_og + lo, cnt, hipMemcpyDeviceToHost, s));
+    }
+    SKCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+int navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_state_aux_in *in, uint8_t *io_state,
+                                uint8_t *io_flags, int32_t *out_ticks, void *stream)
+{
+    if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz)
+        return NAVHIP_ERR_INVALID;
+    int b, e;
+    if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    nh_step_params P;
+    sk_map_view(ctx, w, &P);
+    P.work_begin = b; P.work_end = e;
+    if(e > b)
+        hipLaunchKernelGGL(k_state_aux, dim3((e - b + 255) / 256), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
+                           P, w->radius, w->flags, w->state, *in, io_state, io_flags, out_ticks);
+    SKCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip_state_aux_in *in, uint8_t *io_state,
+                            uint8_t *io_flags, int32_t *out_ticks)
+{
+    if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz)
+        return NAVHIP_ERR_INVALID;
+    int b, e;
+    if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t n = (size_t)w->n_ents;
+    sk_arena A;
+    const size_t o_rad = A.take(n * 4), o_fl = A.take(n * 4), o_st = A.take(n), o_fs = A.take(n), o_wt = A.take(n * 4),
+                 o_wp = A.take(n), o_np = A.take(n * 8), o_ios = A.take(n), o_iof = A.take(n), o_ot = A.take(n * 4);
+    char *base;
+    int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
+    if(rc) return rc;
+    SKCHK(ctx, hipMemcpyAsync(base + o_rad, w->radius, n * 4, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_fl, w->flags, n * 4, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_st, w->state, n, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_fs, in->fstate, n, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_wt, in->wait_ticks_left, n * 4, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_wp, in->wait_prev, n, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_np, in->new_pos_xz, n * 8, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_ios, io_state, n, hipMemcpyHostToDevice, s));
+    SKCHK(ctx, hipMemcpyAsync(base + o_iof, io_flags, n, hipMemcpyHostToDevice, s));
+    navhip_world d = *w;
+    d.radius = (const float*)(base + o_rad); d.flags = (const uint32_t*)(base + o_fl); d.state = (const uint8_t*)(base + o_st);
+    navhip_state_aux_in di = {(const uint8_t*)(base + o_fs), (const int32_t*)(base + o_wt), (const uint8_t*)(base + o_wp),
+                              (const float*)(base + o_np)};
+    rc = navhip_state_update_aux_dev(ctx, &d, &di, (uint8_t*)(base + o_ios), (uint8_t*)(base + o_iof), (int32_t*)(base + o_ot), s);
+    if(rc) return rc;
+    if(e > b) {
+        const size_t lo = (size_t)b, cnt = (size_t)(e - b);
+        SKCHK(ctx, hipMemcpyAsync(io_state + lo, base + o_ios + lo, cnt, hipMemcpyDeviceToHost, s));
+        SKCHK(ctx, hipMemcpyAsync(io_flags + lo, base + o_iof + lo, cnt, hipMemcpyDeviceToHost, s));
+        SKCHK(ctx, hipMemcpyAsync(out_ticks + lo, base + o_ot + 4 * lo, cnt * 4, hipMemcpyDeviceToHost, s));
     }
     SKCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;

@@ -370,6 +370,13 @@ class StateIn(C.Structure):
 
 SU_SET_STATE, SU_BLOCK, SU_HOST = 0x01, 0x02, 0x80
 GATE_TURN, GATE_HOST = 0x01, 0x80
+SU_SET_MOVING, SU_TARGET_DIR = 0x04, 0x08
+FS_MEMBER, FS_READY, FS_ASSIGNED, FS_IN_RANGE, FS_ARRIVED = 0x01, 0x02, 0x04, 0x08, 0x10
+
+
+class StateAuxIn(C.Structure):
+    """navhip_state_aux_in, include/navhip.h"""
+    _fields_ = [("fstate", C.c_void_p), ("wait_ticks_left", C.c_void_p), ("wait_prev", C.c_void_p), ("new_pos_xz", C.c_void_p)]
 
 
 class GateIn(C.Structure):
@@ -407,6 +414,10 @@ _SIGS.update({
                                       C.c_void_p]),
     "navhip_heading_gate_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(GateIn), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
+    "navhip_state_update_aux": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StateAuxIn), C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "navhip_state_update_aux_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StateAuxIn), C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
     "navhip_settled_count": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_arrival_settle": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(SettleIn), C.POINTER(SettleOut)]),
     "navhip_arrival_settle_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(SettleIn), C.POINTER(SettleOut),
@@ -740,6 +751,22 @@ def _ctx_heading_gate(self, arrays, next_rot, new_vel_xz, vdes_xz, work=None):
     return vel, pos, gate
 
 
+def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_pos_xz, state, flags, work=None):
+    """The flag / counter arms of the state switch, after state_update on the same slab: returns (state, flags,
+    wait_ticks_left) with the rows this pass decides overwritten."""
+    w, keep = make_world(self.w, self.h, arrays)
+    if work is not None:
+        w.work_begin, w.work_end = work
+    n = w.n_ents
+    k = [np.ascontiguousarray(fstate, np.uint8), np.ascontiguousarray(wait_ticks_left, np.int32),
+         np.ascontiguousarray(wait_prev, np.uint8), np.ascontiguousarray(new_pos_xz, np.float32).reshape(n, 2)]
+    ai = StateAuxIn(*[a.ctypes.data for a in k])
+    st, fl, ticks = np.array(state, np.uint8), np.array(flags, np.uint8), np.zeros(n, np.int32)
+    self._chk(lib().navhip_state_update_aux(self._h, C.byref(w), C.byref(ai), _hp(st), _hp(fl), _hp(ticks)),
+              "navhip_state_update_aux")
+    return st, fl, ticks
+
+
 def _ctx_settled_count(self, arrays, uids):
     """adjacent_settled_count (movement.c:982) for the units `uids` of the snapshot `arrays` (pos_xz, radius,
     flags, state); -1 = the host counts (radius > 12.5)."""
@@ -896,6 +923,7 @@ NavContext.pool_invalidate = _ctx_pool_invalidate
 NavContext.region_lookup = _ctx_region_lookup
 NavContext.state_update = _ctx_state_update
 NavContext.heading_gate = _ctx_heading_gate
+NavContext.state_update_aux = _ctx_state_update_aux
 NavContext.settled_count = _ctx_settled_count
 NavContext.arrival_settle = _ctx_arrival_settle
 NavContext.pool_map = _ctx_pool_map

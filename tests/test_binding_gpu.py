@@ -251,6 +251,46 @@ def test_arrival_settle_through_the_binding():
         pfref.RefMove.unload()
 
 
+def test_formation_and_wait_arms_through_the_binding():
+    """The state pass with formation flags and wait counters in play (movement.c:2423-2437, :2630-2668): members on
+    the move are no longer the host's -- the arrival arm answers for them and navhip_state_update_aux overrides where
+    the flags decide --, ARRIVING_TO_CELL and WAITING units are decided on the device, UPDATE_SET_MOVING and
+    UPDATE_SET_TARGET_DIR reach the patch.  Every unit's next state and flags == entity_compute_update's, the wait
+    counters the device returns == the ones the reference leaves in movestate."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    rng = np.random.RandomState(12)
+    world["state"] = world["state"].copy()
+    u = rng.rand(n)
+    world["state"][u < 0.10] = 8
+    world["state"][(u >= 0.10) & (u < 0.18)] = 1
+    world["state"][(u >= 0.18) & (u < 0.26)] = 4
+    fstate = ((rng.rand(n) < 0.45) * 1 | (rng.rand(n) < 0.7) * 2 | (rng.rand(n) < 0.7) * 4 | (rng.rand(n) < 0.5) * 8
+              | (rng.rand(n) < 0.5) * 16).astype(np.uint8)
+    ticks = rng.choice([1, 1, 2, 3, 40], n).astype(np.int32)
+    prev = rng.choice([0, 1, 3, 5], n).astype(np.uint8)
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        mv.set_state_aux(fstate, ticks, prev)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        ref_ticks = mv.get_wait_ticks()
+        assert (ref_flags & 4).sum() > 50 and (ref_flags & 8).sum() > 10
+        mv.set_state_aux(fstate, ticks, prev)
+        assert nav.hip_init(), "no MI355X visible"
+        st, fl, dv = mv.state_update_hip(new_vel, vdes)
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        assert np.array_equal(mv.get_wait_ticks(), ref_ticks) and mv.hip_wait_differ() == 0
+        decided = (dv & 0x80) == 0
+        garr = (world["flags"] & (1 << 18)) != 0
+        assert decided[np.isin(world["state"], (4, 8)) | garr].all()
+        assert decided.sum() > 0.85 * n         # (not: TURNING, the units on another nav layer than their flock's tables)
+        assert (decided & (fl == 4)).sum() > 50 and (decided & (fl == 9) & (st == 7)).sum() > 10
+        assert (decided & np.isin(world["state"], (0, 1)) & (st == 8)).sum() > 50
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
+
+
 def _game(grid, n, seed, n_factions=3):
     rng = np.random.RandomState(seed)
     h, w = grid.shape[0] // 64, grid.shape[1] // 64

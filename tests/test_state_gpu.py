@@ -196,3 +196,73 @@ def test_arrival_settle_matches_G_Arrival_ShouldSettle(navlib, seed):
     assert (after["substate"] != cat["substate"]).sum() > 100
     assert (after["stuck"] == cat["stuck"] + 1).sum() > 100 and ((after["stuck"] == 0) & (cat["stuck"] > 0)).sum() > 30
     assert ((after["progress_anchored"] == 1) & (cat["progress_anchored"] == 0)).sum() > 30
+
+
+def test_state_aux_arms_match_entity_compute_update(navlib):
+    """navhip_state_update followed by navhip_state_update_aux against entity_compute_update (movement.c:2303) with
+    formation flags and wait counters in play: members waiting for their assignment, members within range of their
+    cell (-> ARRIVING_TO_CELL), members that fall through to the arrival arm, every outcome of STATE_ARRIVING_TO_CELL
+    (-> MOVING, MOVING_IN_FORMATION, TURNING with UPDATE_SET_TARGET_DIR, none), and the timer of STATE_WAITING
+    (UPDATE_SET_MOVING to wait_prev when it runs out)."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n, k = len(world["state"]), len(world["flock_target_xz"])
+    rng = np.random.RandomState(11)
+    world["state"] = world["state"].copy()
+    u = rng.rand(n)
+    world["state"][u < 0.10] = 8                                              # STATE_ARRIVING_TO_CELL
+    world["state"][(u >= 0.10) & (u < 0.18)] = 1                              # STATE_MOVING_IN_FORMATION
+    world["state"][(u >= 0.18) & (u < 0.26)] = 4                              # STATE_WAITING
+    fstate = ((rng.rand(n) < 0.45) * 1 | (rng.rand(n) < 0.7) * 2 | (rng.rand(n) < 0.7) * 4 | (rng.rand(n) < 0.5) * 8
+              | (rng.rand(n) < 0.5) * 16).astype(np.uint8)
+    ticks = rng.choice([1, 1, 2, 3, 40], n).astype(np.int32)
+    prev = rng.choice([0, 1, 3, 5], n).astype(np.uint8)
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        mv.set_state_aux(fstate, ticks, prev)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        ref_ticks = mv.get_wait_ticks()
+        order = [mv.flock_order(f) for f in range(k)]
+    finally:
+        pfref.RefMove.unload()
+    nearest = np.full((k, 2), np.nan, np.float32)
+    tiles = []
+    for f in range(k):
+        p = nav.closest_pathable(world["flock_target_xz"][f])
+        if p is not None:
+            nearest[f] = p
+        tiles.append(nav.dest_island_tiles(world["flock_target_xz"][f]))
+    ctx = _upload(navlib, nav)
+    arrays = cases.step_arrays(world, None, flock_order=order)
+    new_pos = (world["pos_xz"] + new_vel).astype(np.float32)
+    st0, fl0 = ctx.state_update(arrays, new_pos, vdes, np.zeros(k, np.uint8), nearest, tiles)
+    st, fl, got_ticks = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0)
+    # a slab call decides its rows only
+    st_s, fl_s, ticks_s = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0, work=(400, 2100))
+    ctx.close()
+    assert np.array_equal(st_s[400:2100], st[400:2100]) and np.array_equal(fl_s[400:2100], fl[400:2100])
+    assert np.array_equal(st_s[:400], st0[:400]) and np.array_equal(fl_s[2100:], fl0[2100:]) and not ticks_s[:400].any()
+    host = (fl & navlib.SU_HOST) != 0
+    garr = (world["flags"] & (1 << 18)).astype(bool)
+    big = world["radius"] >= 5.0
+    state = world["state"]
+    member = (fstate & 1).astype(bool)
+    # still the host's: TURNING, and a unit on another nav layer than its flock's tables that falls through to the
+    # arrival arm
+    falls = np.isin(state, (0, 1)) & (~member | (((fstate & 2) != 0) & ~(((fstate & 4) != 0) & ((fstate & 8) != 0))))
+    exp_host = ~garr & ((state == 7) | (falls & big))
+    # (less the few of them whose new position is not pathable: nothing happens to those, :2437, and the pass says so)
+    assert not (host & ~exp_host).any() and (exp_host & ~host).sum() < 20 and host.sum() > 200, (host.sum(), exp_host.sum())
+    ok = ~host
+    bad = np.flatnonzero(ok & ((st != ref_state) | (fl != ref_flags)))
+    assert len(bad) == 0, [(int(i), int(state[i]), int(fstate[i]), int(st[i]), int(ref_state[i]), int(fl[i]), int(ref_flags[i]))
+                           for i in bad[:10]]
+    assert np.array_equal(got_ticks, ref_ticks)
+    # every arm fired
+    assert ((state == 4) & (fl == navlib.SU_SET_MOVING) & (st == prev)).sum() > 50 and ((state == 4) & (fl == 0) & ok).sum() > 50
+    a2c = ok & (state == 8)
+    for nxt, flags in ((0, navlib.SU_SET_STATE), (1, navlib.SU_SET_STATE), (7, navlib.SU_SET_STATE | navlib.SU_TARGET_DIR), (8, 0)):
+        assert (a2c & (st == nxt) & (fl == flags)).sum() > 10, nxt
+    mov = ok & np.isin(state, (0, 1)) & member
+    assert (mov & (st == 8) & (fl == navlib.SU_SET_STATE)).sum() > 50                    # within range of the cell
+    assert (mov & ((fstate & 2) == 0) & (fl == 0)).sum() > 50                              # waits for the assignment
+    assert (mov & (st == 2)).sum() > 20                                                    # fell through and arrived
