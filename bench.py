@@ -437,6 +437,7 @@ def main():
         except Exception:
             pass
     stale = not stamp_is_current(measured)
+    added_since = sorted(set(csrc_files()) - set(measured.get("files") or csrc_files()))   # (units a stamp does not cover)
     sq = {}
     try:
         sqj = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
@@ -476,6 +477,7 @@ def main():
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": None if stale else measured.get(which + "_bytes_per_launch"),
             "traffic_stale": bool(stale and measured),
+            "traffic_measured_on": {"csrc_sha": measured.get("csrc_sha"), "sources_added_since": added_since},
             "kernel": ("navhip_agent_step_dev: k_sp_* + k_agent_nbr + k_cohesion + k_agent_mid/k_cp_*"
                        if which == "agents" else "navhip_build_fields_dev: k_field_bfs"),
             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by,
