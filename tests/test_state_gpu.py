@@ -20,11 +20,9 @@ def _upload(navlib, nav, layers=(0, 1)):
     return ctx
 
 
-def test_heading_gate_matches_entity_compute_update(navlib):
-    """navhip_heading_gate against entity_compute_update (movement.c:2303) run with movestate.next_rot as an input:
-    turn_to_move (UPDATE_TURNING_IN_PLACE of the patch) for rolling units (tolerance 90 degrees) and halted ones
-    (10 degrees), facings spread over the circle and crowded around both tolerances; the units the device leaves to
-    the host are the ones within its margin, and nothing else."""
+def gate_inputs():
+    """The world of the heading-gate test: rolling and halted units, gated and ungated states, facings spread over the
+    circle and crowded around both tolerances (`tight`: within 0.002 degrees of one)."""
     grid, nav, world, new_vel, vdes = cases.state_world()
     n = len(world["state"])
     rng = np.random.RandomState(77)
@@ -44,6 +42,16 @@ def test_heading_gate_matches_entity_compute_update(navlib):
     off[tight] = rng.choice([-90, 90, -10, 10], tight.sum()) + rng.uniform(-2e-3, 2e-3, tight.sum())
     ang = base + np.deg2rad(off)
     facing = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    return nav, world, new_vel, vdes, facing, off, tight
+
+
+def test_heading_gate_matches_entity_compute_update(navlib):
+    """navhip_heading_gate against entity_compute_update (movement.c:2303) run with movestate.next_rot as an input:
+    turn_to_move (UPDATE_TURNING_IN_PLACE of the patch) for rolling units (tolerance 90 degrees) and halted ones
+    (10 degrees), facings spread over the circle and crowded around both tolerances; the units the device leaves to
+    the host are the ones within its margin, and nothing else."""
+    nav, world, new_vel, vdes, facing, off, tight = gate_inputs()
+    n = len(world["state"])
     next_rot = pfref.RefMove.dir_quat(facing)
     mv, _ = cases.ref_move_for(nav, world)
     try:
@@ -82,21 +90,27 @@ def test_heading_gate_matches_entity_compute_update(navlib):
     assert moved.sum() > 500 and np.array_equal(ref_vel[moved], vel[moved])
 
 
-def test_settled_count_matches_adjacent_settled_count(navlib):
-    """navhip_settled_count against adjacent_settled_count (movement.c:982): the r = 30 query capped at 128 in the
-    reference's visiting order, garrisoned entities dropped, then movable + same kind + ARRIVED + touching."""
+def count_inputs():
+    """The world of the settled-neighbour count: air units, immovable ones, a packed ball in which the cap of 128 binds."""
     grid, nav, world, new_vel, vdes = cases.state_world()
     n = len(world["state"])
     rng = np.random.RandomState(5)
     world["flags"] = world["flags"].copy()
     world["flags"][rng.rand(n) < 0.05] |= np.uint32(1 << 15)                  # ENTITY_FLAG_AIR: another kind
     world["flags"][rng.rand(n) < 0.03] &= ~np.uint32(1 << 3)                  # not movable
-    # a packed ball, so that the cap of 128 binds for its members
     ball = np.flatnonzero(world["flock"] == 2)[:300]
     world["pos_xz"] = world["pos_xz"].copy()
     world["pos_xz"][ball] = (world["flock_target_xz"][2] + rng.normal(0, 9.0, (len(ball), 2))).astype(np.float32)
     uids = np.flatnonzero(np.isin(world["state"], (0, 1)))[:900].astype(np.int32)
     uids = np.unique(np.concatenate([uids, ball[:150].astype(np.int32)]))
+    return nav, world, uids
+
+
+def test_settled_count_matches_adjacent_settled_count(navlib):
+    """navhip_settled_count against adjacent_settled_count (movement.c:982): the r = 30 query capped at 128 in the
+    reference's visiting order, garrisoned entities dropped, then movable + same kind + ARRIVED + touching."""
+    nav, world, uids = count_inputs()
+    n = len(world["state"])
     mv, _ = cases.ref_move_for(nav, world)
     try:
         ref = mv.settled_count(uids)

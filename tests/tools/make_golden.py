@@ -85,10 +85,49 @@ def agents(w=4, h=4, seed=21, name="agents_4x4", n=700):
     print("%s: %d agents, %d flocks, %d cached fields" % (name, n, k, len(pool)))
 
 
+def state_pass(name="state_4x4"):
+    """The state pass around navhip_state_update: the heading gate, the settled-neighbour count and the
+    arrival overlay's settle rule -- inputs of tests/test_state_gpu.py, answers of the reference's own
+    entity_compute_update / adjacent_settled_count / G_Arrival_ShouldSettle."""
+    from tests import test_state_gpu as T
+    out = {}
+    nav, world, new_vel, vdes, facing, off, tight = T.gate_inputs()
+    next_rot = pfref.RefMove.dir_quat(facing)
+    mv, _ = cases.ref_move_for(nav, world)
+    turn, vel = mv.heading_gate(new_vel, vdes, next_rot)
+    pfref.RefMove.unload()
+    out.update(gate_pos=world["pos_xz"], gate_vel=world["vel_xz"], gate_state=world["state"], gate_next_rot=next_rot,
+               gate_new_vel=new_vel, gate_vdes=vdes, gate_tight=tight, gate_turn=turn)
+    nav, world, uids = T.count_inputs()
+    mv, _ = cases.ref_move_for(nav, world)
+    out.update(count_pos=world["pos_xz"], count_radius=world["radius"], count_flags=world["flags"],
+               count_state=world["state"], count_uids=uids, count_ref=mv.settled_count(uids))
+    pfref.RefMove.unload()
+    grid, nav, zones, units = T._zone_world(seed=9)
+    out.update(zone_cost=nav.plane(pfref.PLANE_COST, 0), zone_blockers=nav.plane(pfref.PLANE_BLOCKERS, 0), n_zones=len(zones))
+    for i, (z, u) in enumerate(zip(zones, units)):
+        settle, keys, after = pfref.arrival_should_settle(nav, z, u)
+        out["zone%d_scalars" % i] = np.array([z["layer"], z["radius"], z["active_row"], z["num_rows"]], np.int32)
+        out["zone%d_floats" % i] = np.array([z["centre_xz"][0], z["centre_xz"][1], z["unit_radius"], z["fill_frac"]], np.float32)
+        out["zone%d_slots" % i], out["zone%d_ring" % i], out["zone%d_keys" % i] = z["slots_xz"], z["slot_ring"], keys
+        for f, a in u.items():
+            out["unit%d_%s" % (i, f)] = a
+        out["ref%d_settle" % i] = settle
+        for f, a in after.items():
+            out["ref%d_%s" % (i, f)] = a
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print("%s: gate %d units (%d turn), count %d units, settle %d zones" % (
+        name, len(turn), int(turn.sum()), len(uids), len(zones)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--state" in sys.argv:
+        state_pass()
+        sys.exit(0)
     fields()
     agents()
     # non-square maps (the multi-GPU world is 32 x 64 chunks at 8 ranks)
     fields(5, 2, seed=305, name="fields_5x2")
     agents(5, 2, seed=305, name="agents_5x2", n=500)
+    state_pass()
