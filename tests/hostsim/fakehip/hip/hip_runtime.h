@@ -49,20 +49,59 @@ static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 64; return hipSuccess; }      /* (any rank of a multi-process test finds "its" device) */
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof(*p)); p->multiProcessorCount = 256; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }
+/* "Device" allocations are remembered, so that a copy can be held against them: a copy whose direction flag
+ * contradicts where its operands live (device memory as the source of a host-to-device copy, or as the destination of
+ * a device-to-host one), or that runs past the end of a device allocation, fails here as it would on a GPU -- host
+ * memory and device memory are the same thing on the emulator, and such a call would otherwise just work.  (Memory
+ * the library did not allocate -- a test's numpy array standing in for a device buffer -- is not judged.) */
+#include <map>
+#include <mutex>
+#include <stdio.h>
+#include <stdint.h>
+inline std::map<uintptr_t, size_t> &emu_dev_allocs() { static std::map<uintptr_t, size_t> m; return m; }
+inline std::mutex &emu_dev_mutex() { static std::mutex m; return m; }
+/* 0: not in a device allocation, 1: inside one, -1: starts in one and runs past its end */
+static inline int emu_dev_range(const void *p, size_t n) {
+    std::lock_guard<std::mutex> g(emu_dev_mutex());
+    auto &m = emu_dev_allocs();
+    auto it = m.upper_bound((uintptr_t)p);
+    if(it == m.begin()) return 0;
+    --it;
+    if((uintptr_t)p >= it->first + it->second) return 0;
+    return (uintptr_t)p + n <= it->first + it->second ? 1 : -1;
+}
+static inline hipError_t emu_check_copy(void *d, const void *s, size_t n, int kind, const char *what) {
+    if(n == 0) return hipSuccess;
+    const int rd = emu_dev_range(d, n), rs = emu_dev_range(s, n);
+    const char *why = nullptr;
+    if(rd < 0 || rs < 0) why = "runs past the end of a device allocation";
+    else if(kind == 1 /* HostToDevice */ && rs == 1) why = "host-to-device copy whose source is device memory";
+    else if(kind == 2 /* DeviceToHost */ && rd == 1) why = "device-to-host copy whose destination is device memory";
+    if(!why) return hipSuccess;
+    fprintf(stderr, "emulated HIP runtime: %s(%p, %p, %zu): %s\n", what, d, s, n, why);
+    return 1;                                                               /* hipErrorInvalidValue */
+}
 static inline hipError_t hipMalloc(void **p, size_t n) {
 #ifdef EMU_MALLOC_FILL
     *p = malloc(n ? n : 1); if(*p) memset(*p, EMU_MALLOC_FILL, n);
 #else
     *p = calloc(n ? n : 1, 1);
 #endif
+    if(*p) { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_dev_allocs()[(uintptr_t)*p] = n ? n : 1; }
     return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
-static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipFree(void *p) {
+    if(p) { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_dev_allocs().erase((uintptr_t)p); }
+    free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f) { return hipHostMalloc((void**)p, n, f); }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
-static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int kind) {
+    if(emu_check_copy(d, s, n, kind, "hipMemcpy")) return 1;
+    memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int kind, hipStream_t) {
+    if(emu_check_copy(d, s, n, kind, "hipMemcpyAsync")) return 1;
+    memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetD32Async(hipDeviceptr_t p, int v, size_t count, hipStream_t) { for(size_t i = 0; i < count; i++) ((int*)p)[i] = v; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)malloc(8); return hipSuccess; }

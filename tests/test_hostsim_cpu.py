@@ -279,3 +279,41 @@ def test_team_search_on_the_workgroup_emulator_matches_reference(seed, max_dyn, 
     if spread < 3.0:
         assert sum(hostsim.group_attempts()[1:8]) > 0      # the shared retry shortcut ran
 
+
+
+@pytest.mark.skipif(not hostsim.group_available(), reason="no clang++ (ROCm LLVM) for the host build")
+def test_emulated_runtime_rejects_copies_a_gpu_would_reject(tmp_path):
+    """On the emulator device memory IS host memory: a copy with the wrong direction flag, or one that runs past the end
+    of a device allocation, would just work.  The stand-in runtime (tests/hostsim/fakehip) remembers what hipMalloc
+    handed out and fails such a copy the way a GPU does -- so the emulated runs of the GPU suite also check that."""
+    import os
+    import subprocess
+    src = tmp_path / "copies.cpp"
+    src.write_text(r'''
+#include <hip/hip_runtime.h>
+int main() {
+    char host[256] = {0};
+    char *dev = nullptr, *dev2 = nullptr;
+    if(hipMalloc((void**)&dev, 128) || hipMalloc((void**)&dev2, 128)) return 10;
+    int bad = 0;
+    if(hipMemcpy(dev, host, 128, hipMemcpyHostToDevice) != hipSuccess) bad |= 1;                    /* fine */
+    if(hipMemcpyAsync(host, dev + 64, 64, hipMemcpyDeviceToHost, 0) != hipSuccess) bad |= 2;         /* fine */
+    if(hipMemcpy(dev2, dev, 128, hipMemcpyDeviceToDevice) != hipSuccess) bad |= 4;                   /* fine */
+    if(hipMemcpy(host, dev, 128, hipMemcpyHostToDevice) == hipSuccess) bad |= 8;                     /* source is device memory */
+    if(hipMemcpy(dev, host, 128, hipMemcpyDeviceToHost) == hipSuccess) bad |= 16;                    /* destination is device memory */
+    if(hipMemcpyAsync(dev + 64, host, 128, hipMemcpyHostToDevice, 0) == hipSuccess) bad |= 32;       /* past the end */
+    if(hipMemcpy(host, dev + 100, 64, hipMemcpyDeviceToHost) == hipSuccess) bad |= 64;               /* past the end */
+    hipFree(dev);
+    if(hipMemcpy(dev, host, 128, hipMemcpyDeviceToHost) != hipSuccess) bad |= 128;                   /* freed: no longer judged */
+    hipFree(dev2);
+    return bad;
+}''')
+    exe = tmp_path / "copies"
+    here = os.path.dirname(os.path.abspath(hostsim.__file__))
+    subprocess.check_call([hostsim.CLANG, "-O1", "-std=c++17", "-w", "-DNH_HOSTSIM=1", "-I" + os.path.join(here, "fakehip"), "-I" + here,
+                           "-I" + os.path.join(os.path.dirname(os.path.dirname(here)), "include"),
+                           "-I" + os.path.join(os.path.dirname(os.path.dirname(here)), "permafrost-engine_amd", "csrc"),
+                           str(src), "-o", str(exe)])
+    r = subprocess.run([str(exe)], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    assert r.stderr.count("emulated HIP runtime:") == 4
