@@ -37,7 +37,7 @@ template <typename F> static void launch(dim3 grid, dim3 block, F fn)
 #define blockIdx emu::blockIdx_emu
 #define gridDim  emu::gridDim_emu
 #define blockDim emu::blockDim_emu
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu::launch(grid, block, [&]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) (emu_scan_args(#kernel, __VA_ARGS__), emu::launch(grid, block, [&]() { kernel(__VA_ARGS__); }))
 
 enum { hipErrorNotReady = 600, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0,
        hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
@@ -60,6 +60,7 @@ static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo
 #include <stdint.h>
 inline std::map<uintptr_t, size_t> &emu_dev_allocs() { static std::map<uintptr_t, size_t> m; return m; }
 inline std::mutex &emu_dev_mutex() { static std::mutex m; return m; }
+inline std::map<uintptr_t, size_t> &emu_pinned_allocs() { static std::map<uintptr_t, size_t> m; return m; }   /* hipHostMalloc */
 /* 0: not in a device allocation, 1: inside one, -1: starts in one and runs past its end */
 static inline int emu_dev_range(const void *p, size_t n) {
     std::lock_guard<std::mutex> g(emu_dev_mutex());
@@ -70,6 +71,63 @@ static inline int emu_dev_range(const void *p, size_t n) {
     if((uintptr_t)p >= it->first + it->second) return 0;
     return (uintptr_t)p + n <= it->first + it->second ? 1 : -1;
 }
+/* EMU_STRICT_POINTERS=1 (the emulated runs of the host-buffer tests set it): a kernel handed a pointer to ordinary
+ * host memory works on the emulator and faults on a GPU.  Every host operand of a copy (the source of a host-to-device
+ * copy, the destination of a device-to-host one) is remembered as HOST memory; every 8-byte word of a kernel's
+ * arguments -- plain pointers and the pointers inside argument structs alike -- that points into such a range, and
+ * not into a device allocation or pinned memory, aborts the run with the kernel's name: the caller's buffer went to
+ * the kernel instead of its staged copy.  (A word that is the address of some OTHER mapped memory is only reported
+ * with EMU_STRICT_POINTERS=2: an int next to uninitialised padding can spell such an address.) */
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <unistd.h>
+static inline int emu_strict_pointers() { static const int on = getenv("EMU_STRICT_POINTERS") ? atoi(getenv("EMU_STRICT_POINTERS")) : 0; return on; }
+inline std::map<uintptr_t, size_t> &emu_host_ranges() { static std::map<uintptr_t, size_t> m; return m; }
+static inline void emu_note_host(const void *p, size_t n) {
+    if(!emu_strict_pointers() || n == 0 || emu_dev_range(p, 1) != 0) return;
+    std::lock_guard<std::mutex> g(emu_dev_mutex());
+    auto &m = emu_host_ranges();
+    if(m.size() > (1u << 16)) m.clear();
+    size_t &len = m[(uintptr_t)p];
+    if(n > len) len = n;
+}
+static inline bool emu_in(std::map<uintptr_t, size_t> &m, uintptr_t v) {
+    auto it = m.upper_bound(v);
+    return it != m.begin() && (--it, v < it->first + it->second);
+}
+static inline void emu_scan_one(const char *kernel, int index, const void *arg, size_t bytes) {
+    const unsigned char *b = (const unsigned char*)arg;
+    for(size_t off = 0; off + 8 <= bytes; off += 8) {
+        uintptr_t v;
+        memcpy(&v, b + off, 8);
+        if(v < 0x100000 || v >= 0x0000800000000000ull) continue;
+        if(emu_dev_range((const void*)v, 1) != 0) continue;
+        bool host;
+        {
+            std::lock_guard<std::mutex> g(emu_dev_mutex());
+            if(emu_in(emu_pinned_allocs(), v)) continue;
+            host = emu_in(emu_host_ranges(), v);
+        }
+        if(host) {
+            fprintf(stderr, "emulated HIP runtime: %s: argument %d holds %p at byte %zu -- a host buffer, not its device copy\n",
+                    kernel, index, (void*)v, off);
+            abort();
+        }
+        if(emu_strict_pointers() >= 2) {
+            unsigned char vec;
+            const long page = sysconf(_SC_PAGESIZE);
+            if(mincore((void*)(v & ~(uintptr_t)(page - 1)), 1, &vec) == 0)
+                fprintf(stderr, "emulated HIP runtime: (note) %s: argument %d, byte %zu: %p is mapped memory outside every device allocation\n",
+                        kernel, index, off, (void*)v);
+        }
+    }
+}
+template <typename... A> static inline void emu_scan_args(const char *kernel, const A &...args) {
+    if(!emu_strict_pointers()) return;
+    int index = 0;
+    (void)index;
+    ((emu_scan_one(kernel, index++, (const void*)&args, sizeof(args))), ...);
+}
 static inline hipError_t emu_check_copy(void *d, const void *s, size_t n, int kind, const char *what) {
     if(n == 0) return hipSuccess;
     const int rd = emu_dev_range(d, n), rs = emu_dev_range(s, n);
@@ -77,7 +135,11 @@ static inline hipError_t emu_check_copy(void *d, const void *s, size_t n, int ki
     if(rd < 0 || rs < 0) why = "runs past the end of a device allocation";
     else if(kind == 1 /* HostToDevice */ && rs == 1) why = "host-to-device copy whose source is device memory";
     else if(kind == 2 /* DeviceToHost */ && rd == 1) why = "device-to-host copy whose destination is device memory";
-    if(!why) return hipSuccess;
+    if(!why) {
+        if(kind == 1) emu_note_host(s, n);
+        if(kind == 2) emu_note_host(d, n);
+        return hipSuccess;
+    }
     fprintf(stderr, "emulated HIP runtime: %s(%p, %p, %zu): %s\n", what, d, s, n, why);
     return 1;                                                               /* hipErrorInvalidValue */
 }
@@ -93,9 +155,13 @@ template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { retu
 static inline hipError_t hipFree(void *p) {
     if(p) { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_dev_allocs().erase((uintptr_t)p); }
     free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1);
+    if(*p) { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_pinned_allocs()[(uintptr_t)*p] = n ? n : 1; }
+    return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f) { return hipHostMalloc((void**)p, n, f); }
-static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) {
+    if(p) { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_pinned_allocs().erase((uintptr_t)p); }
+    free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int kind) {
     if(emu_check_copy(d, s, n, kind, "hipMemcpy")) return 1;
     memmove(d, s, n); return hipSuccess; }

@@ -50,10 +50,22 @@ DESELECT = ["test_prefetch_overlap_gives_identical_results", "test_shared_chunk_
             "test_velocity_step_matches_reference[True-1500-2-True]", "test_clearpath_matches_reference[2-32-32-9.5]"]
 
 
-def test_gpu_parity_tests_pass_on_the_emulated_library():
+# device buffers ARE the test's host arrays in these (the mailbox transport between ranks of one process): they run
+# without the strict pointer check below
+NOT_STRICT = ["tests/test_comm_gpu.py"]
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_gpu_parity_tests_pass_on_the_emulated_library(strict):
+    """strict: with EMU_STRICT_POINTERS=1 the stand-in runtime aborts when a kernel is handed a pointer into a buffer
+    the caller passed as HOST memory (instead of its staged device copy) -- on top of failing copies a GPU would
+    reject: the two mistakes that work on an emulator, where host and device memory are one thing, and fault on a GPU."""
     lib = hostsim.build_navhip_emu()
     env = dict(os.environ, NAVHIP_LIB=lib)
-    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + SELECTION
+    files = [f for f in SELECTION if (f not in NOT_STRICT) == strict]
+    if strict:
+        env["EMU_STRICT_POINTERS"] = "1"
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + files
     for name in DESELECT:
         cmd += ["--deselect", "tests/test_agents_gpu.py::" + name]
     cmd += ["--deselect", "tests/test_pool_gpu.py::test_step_joins_a_prefetch_issued_on_another_stream"]     # (torch.cuda streams)
@@ -67,7 +79,7 @@ def test_gpu_parity_tests_pass_on_the_emulated_library():
     assert r.returncode == 0, tail
     last = r.stdout.strip().splitlines()[-1]
     assert " passed" in last and "failed" not in last and "error" not in last, tail
-    assert int(last.split(" passed")[0].split()[-1]) >= 84, tail          # (the selection really ran)
+    assert int(last.split(" passed")[0].split()[-1]) >= (70 if strict else 8), tail          # (the selection really ran)
 
 
 def test_reference_binding_drives_the_emulated_library():
@@ -76,7 +88,7 @@ def test_reference_binding_drives_the_emulated_library():
     the harness (oracle/_ref/libpfref.so) links the product library by name, so the emulator build is preloaded and its
     navhip_* symbols interpose."""
     lib = hostsim.build_navhip_emu()
-    env = dict(os.environ, NAVHIP_LIB=lib, LD_PRELOAD=lib)
+    env = dict(os.environ, NAVHIP_LIB=lib, LD_PRELOAD=lib, EMU_STRICT_POINTERS="1")
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "tests/test_binding_gpu.py"]
     try:
         import xdist  # noqa: F401
