@@ -164,7 +164,7 @@ static void *hip_arena(size_t bytes)
 /* bytes of the arena one tick may take for n entities, F flocks (both passes: velocity or state) */
 static size_t hip_arena_need(size_t n, size_t F)
 {
-    return (n + 16) * (4 * 34 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 48;
+    return (n + 16) * (4 * 46 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 48;
 }
 
 static void hip_check_range(int begin, int end, void *arg)
@@ -567,7 +567,7 @@ static vec2_t hip_heading_gated(const struct movestate *ms, vec2_t vdes, vec2_t 
 }
 
 struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned;
-                        uint8_t *fstate, *wait_prev; int32_t *wait_ticks; };
+                        uint8_t *fstate, *wait_prev; int32_t *wait_ticks; float *ent_rot, *target_dir; };
 
 static void hip_state_items_range(int begin, int end, void *arg)
 {
@@ -593,6 +593,11 @@ static void hip_state_items_range(int begin, int end, void *arg)
                      | (in->fstate.assigned_to_cell ? NAVHIP_FS_ASSIGNED : 0) | (in->fstate.in_range_of_cell ? NAVHIP_FS_IN_RANGE : 0)
                      | (in->fstate.arrived_at_cell ? NAVHIP_FS_ARRIVED : 0));
         T->wait_ticks[i] = ms->wait_ticks_left; T->wait_prev[i] = (uint8_t)ms->wait_prev;
+        if(ms->state == STATE_TURNING) {                      /* :2606-2628: the end of the turn is the device's to see */
+            const quat_t rot = Entity_GetRot(in->ent_uid);
+            memcpy(T->ent_rot + 4 * i, &rot, sizeof(float) * 4);
+            memcpy(T->target_dir + 4 * i, &ms->target_dir, sizeof(float) * 4);
+        }
         T->skip[i] = (20 / hz_count(s_move_work.hz)) > 1;
         if(!T->skip[i] && S->flock[i] >= 0) {
             struct flock *fl = &vec_AT(&s_flocks, S->flock[i]);
@@ -723,10 +728,12 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     uint8_t *fstate = hip_arena(n + 1), *wait_prev = hip_arena(n + 1);
     int32_t *wait_ticks = hip_arena(sizeof(int32_t) * (n + 1)), *wait_after = hip_arena(sizeof(int32_t) * (n + 1));
     memset(fstate, 0, n + 1); memset(wait_prev, 0, n + 1); memset(wait_ticks, 0, sizeof(int32_t) * (n + 1));
+    float *ent_rot = hip_arena(sizeof(float) * (4 * n + 4)), *target_dir = hip_arena(sizeof(float) * (4 * n + 4));
+    memset(ent_rot, 0, sizeof(float) * (4 * n + 4)); memset(target_dir, 0, sizeof(float) * (4 * n + 4));
     memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2)); memset(skip, 0, n + 1);
     memset(new_vel, 0, sizeof(float) * (2 * n + 2)); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); memset(zoned, 0, n + 1);
     hip_work_dense_prepare();
-    struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned, fstate, wait_prev, wait_ticks};
+    struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned, fstate, wait_prev, wait_ticks, ent_rot, target_dir};
     hip_for(hip_state_items_range, end_idx - begin_idx + 1, &T);
     int lo = n, hi = -1;
     for(int w = begin_idx; w <= end_idx; w++) {
@@ -797,7 +804,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         ok = move_hip_settle_work(ctx, &S, &W, begin_idx, end_idx, zoned, new_pos, vdes, st, fl);
     const bool aux = ok && (20 / hz_count(s_move_work.hz)) == 1;
     if(aux) {
-        navhip_state_aux_in ain = {fstate, wait_ticks, wait_prev, new_pos};
+        navhip_state_aux_in ain = {fstate, wait_ticks, wait_prev, new_pos, ent_rot, target_dir};
         ok = navhip_state_update_aux(ctx, &W, &ain, st, fl, wait_after) == NAVHIP_OK;
     }
     s_hip_wait_chk = realloc(s_hip_wait_chk, sizeof(int32_t) * 2 * (s_move_work.nwork + 1));

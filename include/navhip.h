@@ -634,8 +634,8 @@ int  navhip_heading_gate_dev(navhip_ctx *ctx, const navhip_world *dev_world, con
 
 /* The arms of the state switch that flags and a counter decide (movement.c:2423-2437, :2630-2644, :2645-2668): a
  * formation member in STATE_MOVING / MOVING_IN_FORMATION that waits for its assignment or has come within range of its
- * cell (-> ARRIVING_TO_CELL), STATE_ARRIVING_TO_CELL (-> MOVING / MOVING_IN_FORMATION / TURNING), and the timer of
- * STATE_WAITING (-> movestate.wait_prev once it runs out).  Called AFTER navhip_state_update on the same slab, with
+ * cell (-> ARRIVING_TO_CELL), STATE_ARRIVING_TO_CELL (-> MOVING / MOVING_IN_FORMATION / TURNING), the timer of
+ * STATE_WAITING (-> movestate.wait_prev once it runs out), and the end of STATE_TURNING (-> ARRIVED).  Called AFTER navhip_state_update on the same slab, with
  * formation members NOT skipped there: a member the flags do not decide keeps the answer of the arrival arm, exactly
  * as the reference falls through to it (:2439).  Rows this call decides are overwritten in inout_state / inout_flags
  * (NAVHIP_SU_HOST cleared); garrisoned units and units whose new position is not pathable (:2437) are left alone /
@@ -653,6 +653,12 @@ typedef struct navhip_state_aux_in {
     const int32_t  *wait_ticks_left;  /* [n] movestate.wait_ticks_left                                                   */
     const uint8_t  *wait_prev;        /* [n] movestate.wait_prev                                                         */
     const float    *new_pos_xz;       /* [n][2] as navhip_state_in.new_pos_xz                                            */
+    /* STATE_TURNING (:2606-2628), both NULL = its units stay NAVHIP_SU_HOST: the unit has arrived once its rotation is
+     * within 5 degrees of movestate.target_dir (cosine compared in double, a unit within 1e-5 of cos 5 deg -- 0.007
+     * degrees -- stays the host's); one that keeps turning is decided too (no transition) -- its rotation patch (turn_toward, :2251) is
+     * pose bookkeeping the host does for it */
+    const float    *ent_rot;          /* [n][4] Entity_GetRot(uid) (x, y, z, w)                                          */
+    const float    *target_dir;       /* [n][4] movestate.target_dir                                                     */
 } navhip_state_aux_in;
 int  navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *world, const navhip_state_aux_in *in,
                              uint8_t *inout_state, uint8_t *inout_flags, int32_t *out_wait_ticks_left);

@@ -151,6 +151,7 @@ def lib():
             ("pfref_move_hip_wait_differ", [], C.c_long),
             ("pfref_move_set_state_aux", [C.c_void_p] * 3, None),
             ("pfref_move_get_wait_ticks", [C.c_void_p], None),
+            ("pfref_move_set_turning", [C.c_void_p] * 2, None),
             ("pfref_move_heading_gate", [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p] * 2, None),
             ("pfref_move_dir_quat", [C.c_void_p, C.c_int, C.c_void_p], None),
             ("pfref_move_settled_count", [C.c_void_p, C.c_int, C.c_void_p], None),
@@ -722,6 +723,13 @@ class RefMove:
              np.ascontiguousarray(wait_prev, np.uint8)]
         assert all(len(a) == self.n for a in k)
         lib().pfref_move_set_state_aux(*[_p(a) for a in k])
+
+    def set_turning(self, ent_rot, target_dir):
+        """STATE_TURNING inputs: the rotation Entity_GetRot answers and movestate.target_dir, [n][4] each; TURNING
+        units are driven by state_update from then on."""
+        a, b = np.ascontiguousarray(ent_rot, np.float32), np.ascontiguousarray(target_dir, np.float32)
+        assert a.shape == b.shape == (self.n, 4)
+        lib().pfref_move_set_turning(_p(a), _p(b))
 
     def get_wait_ticks(self):
         out = np.zeros(self.n, np.int32)

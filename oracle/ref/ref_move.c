@@ -19,6 +19,13 @@
 #include <pthread.h>
 #include <time.h>
 
+static float *s_ent_rot;    /* [n][4] what Entity_GetRot answers (pfref_move_set_turning), or NULL: STATE_TURNING units are not driven */
+quat_t Entity_GetRot(uint32_t uid)
+{
+    if(!s_ent_rot)
+        return (quat_t){0.0f, 0.0f, 0.0f, 1.0f};        /* (no transform table loaded: nobody is turned) */
+    return (quat_t){s_ent_rot[4 * uid], s_ent_rot[4 * uid + 1], s_ent_rot[4 * uid + 2], s_ent_rot[4 * uid + 3]};
+}
 static bool s_aux_set;     /* pfref_move_set_state_aux gave the formation flags: the drivers below leave fstate.fid alone */
 
 /* ---- engine services movement.c links against ------------------------------------------- */
@@ -137,6 +144,7 @@ void pfref_move_unload(void)
     if(!s_w.loaded)
         return;
     s_aux_set = false;
+    free(s_ent_rot); s_ent_rot = NULL;
     kh_destroy(id, s_w.flags);
     kh_destroy(pos, s_w.positions);
     kh_destroy(range, s_w.radiuses);
@@ -524,7 +532,7 @@ int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int beg
         struct move_work_out *out = &s_move_work.out[i];
         struct movestate *ms = movestate_get(i);
         dev_flags[i] = s_hip_su_flags[i];
-        if(ms->state == STATE_TURNING
+        if(ms->state == STATE_TURNING && !s_ent_rot
         && !(G_FlagsGetFrom(s_move_work.gamestate.flags, i) & ENTITY_FLAG_GARRISONED)) {
             out_state[i] = (uint8_t)ms->state; out_flags[i] = 0;       /* (as in pfref_move_state_update) */
             continue;
@@ -641,7 +649,7 @@ void pfref_move_state_update(const float *new_vel, const float *vdes, int begin,
         struct move_work_in *in = &s_move_work.in[i];
         struct move_work_out *out = &s_move_work.out[i];
         struct movestate *ms = movestate_get(i);
-        if(ms->state == STATE_TURNING
+        if(ms->state == STATE_TURNING && !s_ent_rot
         && !(G_FlagsGetFrom(s_move_work.gamestate.flags, i) & ENTITY_FLAG_GARRISONED)) {
             /* (its arm reads the entity's transform, Entity_GetRot: not loaded; a garrisoned unit returns
              * before the state switch, :2344-2351) */
@@ -677,7 +685,7 @@ void pfref_move_heading_gate(const float *new_vel, const float *vdes, const floa
         struct move_work_out *out = &s_move_work.out[i];
         struct movestate *ms = movestate_get(i);
         out_turn[i] = 0; out_vel[2 * i] = out_vel[2 * i + 1] = 0.0f;
-        if(ms->state == STATE_TURNING
+        if(ms->state == STATE_TURNING && !s_ent_rot
         && !(G_FlagsGetFrom(s_move_work.gamestate.flags, i) & ENTITY_FLAG_GARRISONED))
             continue;
         if(!s_aux_set) in->fstate.fid = NULL_FID;
@@ -849,4 +857,15 @@ void pfref_move_get_wait_ticks(int32_t *out)
 {
     for(int i = 0; i < s_w.n; i++)
         out[i] = movestate_get(i)->wait_ticks_left;
+}
+
+/* STATE_TURNING (:2606-2628): the entity transform's rotation (what Entity_GetRot answers) and movestate.target_dir
+ * per unit; from then on pfref_move_state_update(_hip) drives TURNING units too */
+void pfref_move_set_turning(const float *ent_rot, const float *target_dir)
+{
+    free(s_ent_rot);
+    s_ent_rot = malloc(sizeof(float) * 4 * s_w.n);
+    memcpy(s_ent_rot, ent_rot, sizeof(float) * 4 * s_w.n);
+    for(int i = 0; i < s_w.n; i++)
+        movestate_get(i)->target_dir = (quat_t){target_dir[4 * i], target_dir[4 * i + 1], target_dir[4 * i + 2], target_dir[4 * i + 3]};
 }

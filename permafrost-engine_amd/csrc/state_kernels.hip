@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float
     const uint32_t ef = flags[i];
     const int layer = nav_layer_for(ef, radius[i]);
     const uint8_t *cost = P.map.layers[layer].cost;
-    const bool ours = st == NAVHIP_STATE_WAITING || st == NAVHIP_STATE_ARRIVING_TO_CELL
+    const bool ours = st == NAVHIP_STATE_WAITING || st == NAVHIP_STATE_ARRIVING_TO_CELL || (st == NAVHIP_STATE_TURNING && in.ent_rot)
                    || ((st == NAVHIP_STATE_MOVING || st == NAVHIP_STATE_MOVING_IN_FORMATION) && (in.fstate[i] & NAVHIP_FS_MEMBER));
     if(ours && !(ef & NAVHIP_ENTITY_FLAG_GARRISONED) && cost) {                 // (:2344 returns before everything)
         const uint8_t fs = in.fstate[i];
@@ -95,6 +95,23 @@ __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float
             if(st == NAVHIP_STATE_WAITING) {                                    // :2630-2644
                 ticks--;
                 if(ticks == 0) { next = in.wait_prev[i]; fl = NAVHIP_SU_SET_MOVING; }
+            }else if(st == NAVHIP_STATE_TURNING) {                              // :2606-2628
+                // |PFM_Quat_PitchDiff(rot, target_dir)| <= 5 degrees, as the heading gate compares: the turned fronts of
+                // both quaternions, the cosine in double, a margin around cos(5 deg)
+                const float *a = in.ent_rot + 4 * i, *b = in.target_dir + 4 * i;
+                const double ax = a[0], ay = a[1], az = a[2], aw = a[3], bx = b[0], by = b[1], bz = b[2], bw = b[3];
+                const double d1x = 1.0 - 2.0 * ay * ay - 2.0 * az * az, d1z = 2.0 * ax * az + 2.0 * aw * ay;
+                const double d2x = 1.0 - 2.0 * by * by - 2.0 * bz * bz, d2z = 2.0 * bx * bz + 2.0 * bw * by;
+                const double l = sqrt(d1x * d1x + d1z * d1z) * sqrt(d2x * d2x + d2z * d2z);
+                const double cos5 = 0.99619469809174553229501040247389;
+                if(!(l > 1e-9)) decided = false;
+                else{
+                    const double c = (d1x * d2x + d1z * d2z) / l;
+                    // (the cosine is flat at 5 degrees: a margin of 1e-5 is 0.007 degrees, and still 250 times the
+                    // float path's error there)
+                    if(fabs(c - cos5) < 1e-5) decided = false;                  // the host's float path decides
+                    else if(c > cos5) { next = NAVHIP_STATE_ARRIVED; fl = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; }
+                }
             }else if(st == NAVHIP_STATE_ARRIVING_TO_CELL) {                     // :2645-2668
                 if(!(fs & NAVHIP_FS_MEMBER)) { next = NAVHIP_STATE_MOVING; fl = NAVHIP_SU_SET_STATE; }
                 else if(!(fs & NAVHIP_FS_READY)) { }
@@ -394,7 +411,8 @@ int navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *w, const na
 {
     if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
-    if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz)
+    if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz
+    || (in->ent_rot != nullptr) != (in->target_dir != nullptr))
         return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
@@ -414,7 +432,8 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
 {
     if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
-    if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz)
+    if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz
+    || (in->ent_rot != nullptr) != (in->target_dir != nullptr))
         return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
@@ -423,7 +442,8 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
     const size_t n = (size_t)w->n_ents;
     sk_arena A;
     const size_t o_rad = A.take(n * 4), o_fl = A.take(n * 4), o_st = A.take(n), o_fs = A.take(n), o_wt = A.take(n * 4),
-                 o_wp = A.take(n), o_np = A.take(n * 8), o_ios = A.take(n), o_iof = A.take(n), o_ot = A.take(n * 4);
+                 o_wp = A.take(n), o_np = A.take(n * 8), o_ios = A.take(n), o_iof = A.take(n), o_ot = A.take(n * 4),
+                 o_er = A.take(in->ent_rot ? n * 16 : 0), o_td = A.take(in->ent_rot ? n * 16 : 0);
     char *base;
     int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
     if(rc) return rc;
@@ -439,7 +459,12 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
     navhip_world d = *w;
     d.radius = (const float*)(base + o_rad); d.flags = (const uint32_t*)(base + o_fl); d.state = (const uint8_t*)(base + o_st);
     navhip_state_aux_in di = {(const uint8_t*)(base + o_fs), (const int32_t*)(base + o_wt), (const uint8_t*)(base + o_wp),
-                              (const float*)(base + o_np)};
+                              (const float*)(base + o_np), nullptr, nullptr};
+    if(in->ent_rot) {
+        SKCHK(ctx, hipMemcpyAsync(base + o_er, in->ent_rot, n * 16, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_td, in->target_dir, n * 16, hipMemcpyHostToDevice, s));
+        di.ent_rot = (const float*)(base + o_er); di.target_dir = (const float*)(base + o_td);
+    }
     rc = navhip_state_update_aux_dev(ctx, &d, &di, (uint8_t*)(base + o_ios), (uint8_t*)(base + o_iof), (int32_t*)(base + o_ot), s);
     if(rc) return rc;
     if(e > b) {

@@ -376,7 +376,8 @@ FS_MEMBER, FS_READY, FS_ASSIGNED, FS_IN_RANGE, FS_ARRIVED = 0x01, 0x02, 0x04, 0x
 
 class StateAuxIn(C.Structure):
     """navhip_state_aux_in, include/navhip.h"""
-    _fields_ = [("fstate", C.c_void_p), ("wait_ticks_left", C.c_void_p), ("wait_prev", C.c_void_p), ("new_pos_xz", C.c_void_p)]
+    _fields_ = [("fstate", C.c_void_p), ("wait_ticks_left", C.c_void_p), ("wait_prev", C.c_void_p), ("new_pos_xz", C.c_void_p),
+                ("ent_rot", C.c_void_p), ("target_dir", C.c_void_p)]
 
 
 class GateIn(C.Structure):
@@ -751,7 +752,8 @@ def _ctx_heading_gate(self, arrays, next_rot, new_vel_xz, vdes_xz, work=None):
     return vel, pos, gate
 
 
-def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_pos_xz, state, flags, work=None):
+def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_pos_xz, state, flags, work=None,
+                          ent_rot=None, target_dir=None):
     """The flag / counter arms of the state switch, after state_update on the same slab: returns (state, flags,
     wait_ticks_left) with the rows this pass decides overwritten."""
     w, keep = make_world(self.w, self.h, arrays)
@@ -760,6 +762,8 @@ def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_
     n = w.n_ents
     k = [np.ascontiguousarray(fstate, np.uint8), np.ascontiguousarray(wait_ticks_left, np.int32),
          np.ascontiguousarray(wait_prev, np.uint8), np.ascontiguousarray(new_pos_xz, np.float32).reshape(n, 2)]
+    if ent_rot is not None:
+        k += [np.ascontiguousarray(ent_rot, np.float32).reshape(n, 4), np.ascontiguousarray(target_dir, np.float32).reshape(n, 4)]
     ai = StateAuxIn(*[a.ctypes.data for a in k])
     st, fl, ticks = np.array(state, np.uint8), np.array(flags, np.uint8), np.zeros(n, np.int32)
     self._chk(lib().navhip_state_update_aux(self._h, C.byref(w), C.byref(ai), _hp(st), _hp(fl), _hp(ticks)),

@@ -230,9 +230,21 @@ def test_state_aux_arms_match_entity_compute_update(navlib):
               | (rng.rand(n) < 0.5) * 16).astype(np.uint8)
     ticks = rng.choice([1, 1, 2, 3, 40], n).astype(np.int32)
     prev = rng.choice([0, 1, 3, 5], n).astype(np.uint8)
+    # STATE_TURNING: the rotation against movestate.target_dir -- anywhere, within a third of a degree of the 5
+    # degrees that end the turn, and (`tight`) within 0.002 degrees of them
+    world["state"][(u >= 0.26) & (u < 0.34)] = 7
+    ang = rng.uniform(-np.pi, np.pi, n)
+    off = rng.uniform(-180, 180, n)
+    near = rng.rand(n) < 0.5
+    off[near] = rng.choice([-5, 5], near.sum()) + rng.uniform(-0.3, 0.3, near.sum())
+    tight = rng.rand(n) < 0.05
+    off[tight] = rng.choice([-5, 5], tight.sum()) + rng.uniform(-2e-3, 2e-3, tight.sum())
+    target_dir = pfref.RefMove.dir_quat(np.stack([np.cos(ang), np.sin(ang)], 1))
+    ent_rot = pfref.RefMove.dir_quat(np.stack([np.cos(ang + np.deg2rad(off)), np.sin(ang + np.deg2rad(off))], 1))
     mv, _ = cases.ref_move_for(nav, world)
     try:
         mv.set_state_aux(fstate, ticks, prev)
+        mv.set_turning(ent_rot, target_dir)
         ref_state, ref_flags = mv.state_update(new_vel, vdes)
         ref_ticks = mv.get_wait_ticks()
         order = [mv.flock_order(f) for f in range(k)]
@@ -249,9 +261,11 @@ def test_state_aux_arms_match_entity_compute_update(navlib):
     arrays = cases.step_arrays(world, None, flock_order=order)
     new_pos = (world["pos_xz"] + new_vel).astype(np.float32)
     st0, fl0 = ctx.state_update(arrays, new_pos, vdes, np.zeros(k, np.uint8), nearest, tiles)
-    st, fl, got_ticks = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0)
+    st, fl, got_ticks = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0, ent_rot=ent_rot, target_dir=target_dir)
+    st_t, fl_t, _ = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0)      # (without the turning inputs)
     # a slab call decides its rows only
-    st_s, fl_s, ticks_s = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0, work=(400, 2100))
+    st_s, fl_s, ticks_s = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0, work=(400, 2100),
+                                               ent_rot=ent_rot, target_dir=target_dir)
     ctx.close()
     assert np.array_equal(st_s[400:2100], st[400:2100]) and np.array_equal(fl_s[400:2100], fl[400:2100])
     assert np.array_equal(st_s[:400], st0[:400]) and np.array_equal(fl_s[2100:], fl0[2100:]) and not ticks_s[:400].any()
@@ -260,10 +274,15 @@ def test_state_aux_arms_match_entity_compute_update(navlib):
     big = world["radius"] >= 5.0
     state = world["state"]
     member = (fstate & 1).astype(bool)
-    # still the host's: TURNING, and a unit on another nav layer than its flock's tables that falls through to the
-    # arrival arm
+    # still the host's: a unit on another nav layer than its flock's tables that falls through to the arrival arm
     falls = np.isin(state, (0, 1)) & (~member | (((fstate & 2) != 0) & ~(((fstate & 4) != 0) & ((fstate & 8) != 0))))
-    exp_host = ~garr & ((state == 7) | (falls & big))
+    turning = (state == 7) & ~garr
+    assert (fl_t[turning] & navlib.SU_HOST).all() and np.array_equal(st_t[~turning], st[~turning])
+    # TURNING: the host keeps only the rotations within the margin of the 5 degrees (1e-5 in the cosine: 0.007 degrees)
+    t_host = turning & host
+    assert 0 < t_host.sum() <= (turning & tight).sum() + 3 and np.all(np.abs(np.abs(off[t_host]) - 5) < 0.01)
+    assert (turning & ~host & (st == 2) & (fl == 3)).sum() > 40 and (turning & ~host & (st == 7) & (fl == 0)).sum() > 40
+    exp_host = ~garr & (t_host | (falls & big))
     # (less the few of them whose new position is not pathable: nothing happens to those, :2437, and the pass says so)
     assert not (host & ~exp_host).any() and (exp_host & ~host).sum() < 20 and host.sum() > 200, (host.sum(), exp_host.sum())
     ok = ~host
