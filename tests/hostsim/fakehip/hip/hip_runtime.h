@@ -143,18 +143,33 @@ static inline hipError_t emu_check_copy(void *d, const void *s, size_t n, int ki
     fprintf(stderr, "emulated HIP runtime: %s(%p, %p, %zu): %s\n", what, d, s, n, why);
     return 1;                                                               /* hipErrorInvalidValue */
 }
+/* Device allocations live in an address range of their own (0x6000'0000'0000 upwards, never reused, 64 MiB of
+ * unmapped space in front of each): a base pointer the library has biased below the start of its buffer -- "row b of
+ * the slab is the buffer's first row" -- still points into nothing, not into somebody's heap, and a kernel that runs
+ * off the end of an allocation faults at the next page instead of scribbling over the host's memory. */
+inline uintptr_t &emu_dev_bump() { static uintptr_t p = 0x600000000000ull; return p; }
 static inline hipError_t hipMalloc(void **p, size_t n) {
+    const size_t gap = (size_t)64 << 20, len = ((n ? n : 1) + 4095) & ~(size_t)4095;
+    uintptr_t at;
+    { std::lock_guard<std::mutex> g(emu_dev_mutex()); at = emu_dev_bump() + gap; emu_dev_bump() += len + gap; }
+    void *m = mmap((void*)at, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED_NOREPLACE, -1, 0);
+    if(m == MAP_FAILED || (uintptr_t)m != at) { if(m != MAP_FAILED) munmap(m, len); *p = nullptr; return 2; }
 #ifdef EMU_MALLOC_FILL
-    *p = malloc(n ? n : 1); if(*p) memset(*p, EMU_MALLOC_FILL, n);
-#else
-    *p = calloc(n ? n : 1, 1);
+    memset(m, EMU_MALLOC_FILL, len);
 #endif
-    if(*p) { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_dev_allocs()[(uintptr_t)*p] = n ? n : 1; }
-    return *p ? hipSuccess : 2; }
+    *p = m;
+    { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_dev_allocs()[(uintptr_t)m] = n ? n : 1; }
+    return hipSuccess; }
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void *p) {
-    if(p) { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_dev_allocs().erase((uintptr_t)p); }
-    free(p); return hipSuccess; }
+    if(!p) return hipSuccess;
+    size_t n = 0;
+    { std::lock_guard<std::mutex> g(emu_dev_mutex());
+      auto it = emu_dev_allocs().find((uintptr_t)p);
+      if(it == emu_dev_allocs().end()) { fprintf(stderr, "emulated HIP runtime: hipFree(%p): not a device allocation\n", p); return 1; }
+      n = it->second; emu_dev_allocs().erase(it); }
+    munmap(p, (n + 4095) & ~(size_t)4095);
+    return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1);
     if(*p) { std::lock_guard<std::mutex> g(emu_dev_mutex()); emu_pinned_allocs()[(uintptr_t)*p] = n ? n : 1; }
     return *p ? hipSuccess : 2; }

@@ -303,9 +303,8 @@ int main() {
     if(hipMemcpy(dev, host, 128, hipMemcpyDeviceToHost) == hipSuccess) bad |= 16;                    /* destination is device memory */
     if(hipMemcpyAsync(dev + 64, host, 128, hipMemcpyHostToDevice, 0) == hipSuccess) bad |= 32;       /* past the end */
     if(hipMemcpy(host, dev + 100, 64, hipMemcpyDeviceToHost) == hipSuccess) bad |= 64;               /* past the end */
-    hipFree(dev);
-    if(hipMemcpy(dev, host, 128, hipMemcpyDeviceToHost) != hipSuccess) bad |= 128;                   /* freed: no longer judged */
-    hipFree(dev2);
+    if(hipFree(dev) != hipSuccess || hipFree(dev2) != hipSuccess) bad |= 128;
+    if(hipFree(host) == hipSuccess) bad |= 256;                                                      /* not a device allocation */
     return bad;
 }''')
     exe = tmp_path / "copies"
@@ -316,4 +315,4 @@ int main() {
                            str(src), "-o", str(exe)])
     r = subprocess.run([str(exe)], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
-    assert r.stderr.count("emulated HIP runtime:") == 4
+    assert r.stderr.count("emulated HIP runtime:") == 5
