@@ -805,7 +805,46 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     const bool aux = ok && (20 / hz_count(s_move_work.hz)) == 1;
     if(aux) {
         navhip_state_aux_in ain = {fstate, wait_ticks, wait_prev, new_pos, ent_rot, target_dir};
+        /* STATE_ENTER_ENTITY_RANGE (:2569-2604): the target's row in the snapshot, the range, where the target stood when
+         * the path was requested, and -- per such unit -- the closest island tiles of the target's position on the unit's
+         * layer (the first half of N_IsMaximallyClose, as for the flocks' destinations above) */
+        int n_range = 0;
+        for(int w = begin_idx; w <= end_idx; w++)
+            n_range += S.state[s_hip_witem.idx[w]] == STATE_ENTER_ENTITY_RANGE;
+        int32_t *r_target = NULL, *r_row = NULL, *r_off = NULL; float *r_range = NULL, *r_prev = NULL; int16_t *r_tiles = NULL;
+        if(n_range > 0) {
+            r_target = malloc(sizeof(int32_t) * n); r_row = calloc(n, sizeof(int32_t)); r_off = calloc(n_range + 1, sizeof(int32_t));
+            r_range = calloc(n, sizeof(float)); r_prev = calloc(2 * n, sizeof(float));
+            r_tiles = malloc(sizeof(int16_t) * 2 * per * n_range);
+            for(int i = 0; i < n; i++) r_target[i] = -2;
+            int row = 0;
+            for(int w = begin_idx; w <= end_idx; w++) {
+                const int i = s_hip_witem.idx[w];
+                if(S.state[i] != STATE_ENTER_ENTITY_RANGE)
+                    continue;
+                const struct movestate *ms = movestate_get(S.uids[i]);
+                r_off[row + 1] = r_off[row];
+                r_row[i] = row;
+                r_range[i] = ms->target_range;
+                r_prev[2 * i] = ms->target_prev_pos.x; r_prev[2 * i + 1] = ms->target_prev_pos.z;
+                if(ms->surround_target_uid == NULL_UID) {
+                    r_target[i] = -1;
+                }else{
+                    khiter_t k = kh_get(id, S.dense, ms->surround_target_uid);
+                    if(k != kh_end(S.dense)) {
+                        r_target[i] = (int32_t)kh_value(S.dense, k);
+                        const vec2_t tp = {S.pos[2 * r_target[i]], S.pos[2 * r_target[i] + 1]};
+                        r_off[row + 1] += N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map),
+                            Entity_NavLayerWithRadius(S.flags[i], S.radius[i]), map_pos, tp, r_tiles + 2 * r_off[row], per);
+                    }
+                }
+                row++;
+            }
+            ain.range_target = r_target; ain.target_range = r_range; ain.target_prev_xz = r_prev;
+            ain.range_tiles_row = r_row; ain.range_tiles_off = r_off; ain.range_tiles = r_tiles; ain.n_range_rows = n_range;
+        }
         ok = navhip_state_update_aux(ctx, &W, &ain, st, fl, wait_after) == NAVHIP_OK;
+        free(r_target); free(r_row); free(r_off); free(r_range); free(r_prev); free(r_tiles);
     }
     s_hip_wait_chk = realloc(s_hip_wait_chk, sizeof(int32_t) * 2 * (s_move_work.nwork + 1));
     for(int w = begin_idx; w <= end_idx; w++) {
@@ -850,7 +889,8 @@ static void move_hip_update_work(int begin_idx, int end_idx)
         }
         if(s_hip_su_flags[w] & NAVHIP_SU_HOST)
             continue;
-        out->patch.flags = (enum movestate_flags)(out->patch.flags & ~(UPDATE_SET_STATE | UPDATE_SET_MOVING | UPDATE_SET_TARGET_DIR));
+        out->patch.flags = (enum movestate_flags)(out->patch.flags & ~(UPDATE_SET_STATE | UPDATE_SET_MOVING | UPDATE_SET_TARGET_DIR
+                                                                        | UPDATE_SET_DEST | UPDATE_SET_TARGET_PREV));
         if(s_hip_su_flags[w] & NAVHIP_SU_SET_STATE) {
             out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_STATE);
             out->patch.next_state = (enum move_state)s_hip_su_state[w];
@@ -859,6 +899,13 @@ static void move_hip_update_work(int begin_idx, int end_idx)
         if(s_hip_su_flags[w] & NAVHIP_SU_SET_MOVING) {                  /* the wait ran out, :2641 */
             out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_MOVING);
             out->patch.next_state = (enum move_state)s_hip_su_state[w];
+        }
+        if(s_hip_su_flags[w] & NAVHIP_SU_SET_DEST) {                    /* the target has moved on, :2597-2602 */
+            const vec2_t xz_target = G_Pos_GetXZFrom(s_move_work.gamestate.positions, movestate_get(out->ent_uid)->surround_target_uid);
+            out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_DEST | UPDATE_SET_TARGET_PREV);
+            out->patch.next_dest = xz_target;
+            out->patch.next_attack = false;
+            out->patch.next_target_prev = xz_target;
         }
         if(s_hip_su_flags[w] & NAVHIP_SU_TARGET_DIR) {                  /* arrived at the cell, :2663 */
             out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_TARGET_DIR);

@@ -635,14 +635,18 @@ int  navhip_heading_gate_dev(navhip_ctx *ctx, const navhip_world *dev_world, con
 /* The arms of the state switch that flags and a counter decide (movement.c:2423-2437, :2630-2644, :2645-2668): a
  * formation member in STATE_MOVING / MOVING_IN_FORMATION that waits for its assignment or has come within range of its
  * cell (-> ARRIVING_TO_CELL), STATE_ARRIVING_TO_CELL (-> MOVING / MOVING_IN_FORMATION / TURNING), the timer of
- * STATE_WAITING (-> movestate.wait_prev once it runs out), and the end of STATE_TURNING (-> ARRIVED).  Called AFTER navhip_state_update on the same slab, with
+ * STATE_WAITING (-> movestate.wait_prev once it runs out), the end of STATE_TURNING (-> ARRIVED) and
+ * STATE_ENTER_ENTITY_RANGE.  Called AFTER navhip_state_update on the same slab, with
  * formation members NOT skipped there: a member the flags do not decide keeps the answer of the arrival arm, exactly
  * as the reference falls through to it (:2439).  Rows this call decides are overwritten in inout_state / inout_flags
  * (NAVHIP_SU_HOST cleared); garrisoned units and units whose new position is not pathable (:2437) are left alone /
  * left unchanged as there.  out_wait_ticks_left[i] = movestate.wait_ticks_left after the tick (written for every row
- * of the slab).  world: n_ents, radius, flags, state, map_pos, work range. */
+ * of the slab).  world: n_ents, radius, flags, state, map_pos, work range (pos_xz too with the
+ * enter-range inputs). */
 #define NAVHIP_SU_SET_MOVING  0x04   /* UPDATE_SET_MOVING: the state is movestate.wait_prev (the wait ran out, :2641)     */
 #define NAVHIP_SU_TARGET_DIR  0x08   /* UPDATE_SET_TARGET_DIR rides along: next_target_dir = fstate.target_orientation   */
+#define NAVHIP_SU_SET_DEST    0x10   /* UPDATE_SET_DEST | UPDATE_SET_TARGET_PREV: next_dest = next_target_prev = the target's
+                                        position, next_attack = false (:2597-2602); the state stays                      */
 #define NAVHIP_FS_MEMBER      0x01   /* fstate.fid != NULL_FID                                                           */
 #define NAVHIP_FS_READY       0x02   /* fstate.assignment_ready                                                          */
 #define NAVHIP_FS_ASSIGNED    0x04   /* fstate.assigned_to_cell                                                          */
@@ -659,6 +663,21 @@ typedef struct navhip_state_aux_in {
      * pose bookkeeping the host does for it */
     const float    *ent_rot;          /* [n][4] Entity_GetRot(uid) (x, y, z, w)                                          */
     const float    *target_dir;       /* [n][4] movestate.target_dir                                                     */
+    /* STATE_ENTER_ENTITY_RANGE (:2569-2604), all six NULL = its units stay NAVHIP_SU_HOST: no target -> ARRIVED; within
+     * movestate.target_range of the target, or next to an impassable tile and on one of the closest island tiles of
+     * the target's position (N_IsMaximallyClose with tolerance 0, nav.c:4707) -> WAITING; else, once the target has
+     * moved more than 5 units from target_prev_pos, NAVHIP_SU_SET_DEST.  The target's position is world->pos_xz of its
+     * row.  Needs the BLOCKERS plane of the units' layers. */
+    const int32_t  *range_target;     /* [n] row of movestate.surround_target_uid in the world's arrays; -1 = NULL_UID;
+                                             -2 = leave the unit to the host (a target outside the snapshot)              */
+    const float    *target_range;     /* [n] movestate.target_range                                                      */
+    const float    *target_prev_xz;   /* [n][2] movestate.target_prev_pos                                                */
+    const int32_t  *range_tiles_row;  /* [n] row of range_tiles_off for the unit: the closest island tiles of ITS target's
+                                             position on ITS nav layer (n_closest_island_tiles, nav.c:4725, as flock_tiles
+                                             of navhip_state_in)                                                         */
+    const int32_t  *range_tiles_off;  /* [rows + 1] CSR offsets into range_tiles                                         */
+    const int16_t  *range_tiles;      /* [..][2] absolute nav tiles (row, column)                                        */
+    int32_t         n_range_rows;     /* rows of range_tiles_off (host-buffer call: sizes the transfer)                  */
 } navhip_state_aux_in;
 int  navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *world, const navhip_state_aux_in *in,
                              uint8_t *inout_state, uint8_t *inout_flags, int32_t *out_wait_ticks_left);

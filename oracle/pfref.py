@@ -152,6 +152,7 @@ def lib():
             ("pfref_move_set_state_aux", [C.c_void_p] * 3, None),
             ("pfref_move_get_wait_ticks", [C.c_void_p], None),
             ("pfref_move_set_turning", [C.c_void_p] * 2, None),
+            ("pfref_move_set_range_targets", [C.c_void_p] * 3, None),
             ("pfref_move_heading_gate", [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p] * 2, None),
             ("pfref_move_dir_quat", [C.c_void_p, C.c_int, C.c_void_p], None),
             ("pfref_move_settled_count", [C.c_void_p, C.c_int, C.c_void_p], None),
@@ -651,7 +652,7 @@ class RefMove:
 
     def state_update(self, new_vel, vdes, begin=0, end=None):
         """entity_compute_update (movement.c:2303) per unit: (next_state [n] u8, flags [n] u8: bit 0 state
-        set, bit 1 next_block, bit 2 UPDATE_SET_MOVING -- next_state = wait_prev --, bit 3 UPDATE_SET_TARGET_DIR)."""
+        set, bit 1 next_block, bit 2 UPDATE_SET_MOVING -- next_state = wait_prev --, bit 3 UPDATE_SET_TARGET_DIR, bit 4 UPDATE_SET_DEST)."""
         end = self.n if end is None else end
         v = np.ascontiguousarray(new_vel, np.float32).reshape(self.n, 2)
         d = np.ascontiguousarray(vdes, np.float32).reshape(self.n, 2)
@@ -730,6 +731,13 @@ class RefMove:
         a, b = np.ascontiguousarray(ent_rot, np.float32), np.ascontiguousarray(target_dir, np.float32)
         assert a.shape == b.shape == (self.n, 4)
         lib().pfref_move_set_turning(_p(a), _p(b))
+
+    def set_range_targets(self, target_uid, target_range, target_prev_xz):
+        """STATE_ENTER_ENTITY_RANGE inputs: movestate.surround_target_uid (-1 = NULL_UID), .target_range, .target_prev_pos."""
+        k = [np.ascontiguousarray(target_uid, np.int32), np.ascontiguousarray(target_range, np.float32),
+             np.ascontiguousarray(target_prev_xz, np.float32)]
+        assert len(k[0]) == len(k[1]) == self.n and k[2].shape == (self.n, 2)
+        lib().pfref_move_set_range_targets(*[_p(a) for a in k])
 
     def get_wait_ticks(self):
         out = np.zeros(self.n, np.int32)

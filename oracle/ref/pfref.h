@@ -294,6 +294,7 @@ long pfref_move_hip_wait_differ(void);
 void pfref_move_set_state_aux(const uint8_t *fstate, const int32_t *wait_ticks_left, const uint8_t *wait_prev);
 void pfref_move_get_wait_ticks(int32_t *out);
 void pfref_move_set_turning(const float *ent_rot, const float *target_dir);
+void pfref_move_set_range_targets(const int32_t *target_uid, const float *target_range, const float *target_prev_xz);
 /* fine-arrival inputs: sink [n][2], flags [n] (bit 0 unit committed to a valid slot, bit 1 the
  * flock's arrival_state for the unit's layer is in ARRIVAL_PHASE_FILLING) */
 void pfref_move_set_arrival(const float *sink_xz, const uint8_t *flags);

@@ -541,7 +541,7 @@ int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int beg
         const bool set = (out->patch.flags & UPDATE_SET_STATE) != 0, mov = (out->patch.flags & UPDATE_SET_MOVING) != 0;
         out_state[i] = (uint8_t)((set || mov) ? out->patch.next_state : ms->state);
         out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0) | (mov ? 4 : 0)
-                                 | ((out->patch.flags & UPDATE_SET_TARGET_DIR) ? 8 : 0));
+                                 | ((out->patch.flags & UPDATE_SET_TARGET_DIR) ? 8 : 0) | ((out->patch.flags & UPDATE_SET_DEST) ? 16 : 0));
     }
     return 1;
 }
@@ -667,7 +667,7 @@ void pfref_move_state_update(const float *new_vel, const float *vdes, int begin,
         const bool set = (out->patch.flags & UPDATE_SET_STATE) != 0, mov = (out->patch.flags & UPDATE_SET_MOVING) != 0;
         out_state[i] = (uint8_t)((set || mov) ? out->patch.next_state : ms->state);
         out_flags[i] = (uint8_t)((set ? 1 : 0) | ((set && out->patch.next_block) ? 2 : 0) | (mov ? 4 : 0)
-                                 | ((out->patch.flags & UPDATE_SET_TARGET_DIR) ? 8 : 0));
+                                 | ((out->patch.flags & UPDATE_SET_TARGET_DIR) ? 8 : 0) | ((out->patch.flags & UPDATE_SET_DEST) ? 16 : 0));
     }
 }
 
@@ -868,4 +868,16 @@ void pfref_move_set_turning(const float *ent_rot, const float *target_dir)
     memcpy(s_ent_rot, ent_rot, sizeof(float) * 4 * s_w.n);
     for(int i = 0; i < s_w.n; i++)
         movestate_get(i)->target_dir = (quat_t){target_dir[4 * i], target_dir[4 * i + 1], target_dir[4 * i + 2], target_dir[4 * i + 3]};
+}
+
+/* STATE_ENTER_ENTITY_RANGE inputs (:2569-2604): movestate.surround_target_uid (-1 = NULL_UID), .target_range,
+ * .target_prev_pos per unit */
+void pfref_move_set_range_targets(const int32_t *target_uid, const float *target_range, const float *target_prev_xz)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        struct movestate *ms = movestate_get(i);
+        ms->surround_target_uid = target_uid[i] < 0 ? NULL_UID : (uint32_t)target_uid[i];
+        ms->target_range = target_range[i];
+        ms->target_prev_pos = (vec2_t){target_prev_xz[2 * i], target_prev_xz[2 * i + 1]};
+    }
 }

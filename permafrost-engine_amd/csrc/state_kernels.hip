@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_heading_gate(int begin, int end, const 
 // the arms that flags and a counter decide (formation members, ARRIVING_TO_CELL, the wait timer): a thread per
 // unit, after k_state_update
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float *radius, const uint32_t *flags,
+__global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float *pos_xz, const float *radius, const uint32_t *flags,
                                                    const uint8_t *state, navhip_state_aux_in in, uint8_t *io_state,
                                                    uint8_t *io_flags, int32_t *out_ticks)
 {
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float
     const int layer = nav_layer_for(ef, radius[i]);
     const uint8_t *cost = P.map.layers[layer].cost;
     const bool ours = st == NAVHIP_STATE_WAITING || st == NAVHIP_STATE_ARRIVING_TO_CELL || (st == NAVHIP_STATE_TURNING && in.ent_rot)
+                   || (st == NAVHIP_STATE_ENTER_ENTITY_RANGE && in.range_target && in.range_target[i] >= -1)
                    || ((st == NAVHIP_STATE_MOVING || st == NAVHIP_STATE_MOVING_IN_FORMATION) && (in.fstate[i] & NAVHIP_FS_MEMBER));
     if(ours && !(ef & NAVHIP_ENTITY_FLAG_GARRISONED) && cost) {                 // (:2344 returns before everything)
         const uint8_t fs = in.fstate[i];
@@ -95,6 +96,43 @@ __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float
             if(st == NAVHIP_STATE_WAITING) {                                    // :2630-2644
                 ticks--;
                 if(ticks == 0) { next = in.wait_prev[i]; fl = NAVHIP_SU_SET_MOVING; }
+            }else if(st == NAVHIP_STATE_ENTER_ENTITY_RANGE) {                   // :2569-2604
+                const int tgt = in.range_target[i];
+                if(tgt < 0) { next = NAVHIP_STATE_ARRIVED; fl = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; }
+                else{
+                    const v2 np = mkv(in.new_pos_xz[2 * i], in.new_pos_xz[2 * i + 1]);
+                    const v2 tp = mkv(pos_xz[2 * tgt], pos_xz[2 * tgt + 1]);
+                    bool stop = vlen(vsub(np, tp)) <= in.target_range[i];
+                    if(!stop) {
+                        // N_IsAdjacentToImpassable (nav.c:4747): a 4-neighbour tile that is impassable or blocked ...
+                        const nh_layer_view &L = P.map.layers[layer];
+                        const int ar = t.chunk_r * 64 + t.tile_r, ac = t.chunk_c * 64 + t.tile_c;
+                        const int dr[4] = {-1, 0, 0, 1}, dc[4] = {0, -1, 1, 0};
+                        bool adj = false;
+#pragma unroll
+                        for(int k = 0; k < 4; k++) {
+                            const int r = ar + dr[k], c = ac + dc[k];
+                            if(r < 0 || c < 0 || r >= P.map.h * 64 || c >= P.map.w * 64) continue;
+                            tiledesc a;
+                            a.chunk_r = r >> 6; a.chunk_c = c >> 6; a.tile_r = r & 63; a.tile_c = c & 63;
+                            const size_t idx = tile_index(P, a);
+                            adj = adj || cost[idx] == NAVHIP_COST_IMPASSABLE || (L.blockers && L.blockers[idx] > 0);
+                        }
+                        // ... and N_IsMaximallyClose(new_pos, target, 0.0f) (nav.c:4707): the position IS the centre of one
+                        // of the target's closest island tiles
+                        if(adj) {
+                            const int row = in.range_tiles_row[i];
+                            for(int k = in.range_tiles_off[row]; k < in.range_tiles_off[row + 1] && !stop; k++) {
+                                const float cx = P.map_x - (float)in.range_tiles[2 * k + 1] * 4.0f;
+                                const float cz = P.map_z + (float)in.range_tiles[2 * k] * 4.0f;
+                                stop = vlen(vsub(mkv(cx, cz), np)) <= 0.0f;
+                            }
+                        }
+                    }
+                    if(stop) { next = NAVHIP_STATE_WAITING; fl = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; }
+                    else if(vlen(vsub(tp, mkv(in.target_prev_xz[2 * i], in.target_prev_xz[2 * i + 1]))) > 5.0f)
+                        fl = NAVHIP_SU_SET_DEST;
+                }
             }else if(st == NAVHIP_STATE_TURNING) {                              // :2606-2628
                 // |PFM_Quat_PitchDiff(rot, target_dir)| <= 5 degrees, as the heading gate compares: the turned fronts of
                 // both quaternions, the cosine in double, a margin around cos(5 deg)
@@ -341,6 +379,14 @@ void sk_map_view(const navhip_ctx *ctx, const navhip_world *w, nh_step_params *P
     P->n_ents = w->n_ents;
 }
 
+// the six enter-range inputs come together, with the positions of the snapshot
+bool sk_range_inputs_ok(const navhip_world *w, const navhip_state_aux_in *in)
+{
+    const int given = (in->range_target != nullptr) + (in->target_range != nullptr) + (in->target_prev_xz != nullptr)
+                    + (in->range_tiles_row != nullptr) + (in->range_tiles_off != nullptr) + (in->range_tiles != nullptr);
+    return given == 0 || (given == 6 && w->pos_xz && in->n_range_rows >= 0);
+}
+
 bool sk_work_range(const navhip_world *w, int *b, int *e)
 {
     *b = w->work_begin; *e = w->work_end;
@@ -412,7 +458,7 @@ int navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *w, const na
     if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
     if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz
-    || (in->ent_rot != nullptr) != (in->target_dir != nullptr))
+    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in))
         return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
@@ -422,7 +468,7 @@ int navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *w, const na
     P.work_begin = b; P.work_end = e;
     if(e > b)
         hipLaunchKernelGGL(k_state_aux, dim3((e - b + 255) / 256), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
-                           P, w->radius, w->flags, w->state, *in, io_state, io_flags, out_ticks);
+                           P, w->pos_xz, w->radius, w->flags, w->state, *in, io_state, io_flags, out_ticks);
     SKCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
 }
@@ -433,17 +479,34 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
     if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
     if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz
-    || (in->ent_rot != nullptr) != (in->target_dir != nullptr))
+    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in))
         return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
+    const size_t n = (size_t)w->n_ents;
+    size_t n_rt = 0;
+    if(in->range_target) {
+        const int rows = in->n_range_rows;
+        for(int r = 0; r < rows; r++)
+            if(in->range_tiles_off[r] < 0 || in->range_tiles_off[r + 1] < in->range_tiles_off[r]) return NAVHIP_ERR_INVALID;
+        n_rt = rows ? (size_t)in->range_tiles_off[rows] : 0;
+        for(size_t i = (size_t)b; i < (size_t)e; i++) {
+            if(in->range_target[i] < -2 || in->range_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
+            if(in->range_target[i] >= 0 && w->state[i] == NAVHIP_STATE_ENTER_ENTITY_RANGE
+            && (in->range_tiles_row[i] < 0 || in->range_tiles_row[i] >= rows)) return NAVHIP_ERR_INVALID;
+        }
+    }
     SKCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const size_t n = (size_t)w->n_ents;
     sk_arena A;
     const size_t o_rad = A.take(n * 4), o_fl = A.take(n * 4), o_st = A.take(n), o_fs = A.take(n), o_wt = A.take(n * 4),
                  o_wp = A.take(n), o_np = A.take(n * 8), o_ios = A.take(n), o_iof = A.take(n), o_ot = A.take(n * 4),
                  o_er = A.take(in->ent_rot ? n * 16 : 0), o_td = A.take(in->ent_rot ? n * 16 : 0);
+    const bool rg = in->range_target != nullptr;
+    const size_t rows = rg ? (size_t)in->n_range_rows : 0;
+    const size_t o_pos = A.take(rg ? n * 8 : 0), o_rt = A.take(rg ? n * 4 : 0), o_rr = A.take(rg ? n * 4 : 0),
+                 o_rp = A.take(rg ? n * 8 : 0), o_row = A.take(rg ? n * 4 : 0), o_off = A.take(rg ? (rows + 1) * 4 : 0),
+                 o_til = A.take(rg ? n_rt * 4 + 4 : 0);
     char *base;
     int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
     if(rc) return rc;
@@ -458,8 +521,25 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
     SKCHK(ctx, hipMemcpyAsync(base + o_iof, io_flags, n, hipMemcpyHostToDevice, s));
     navhip_world d = *w;
     d.radius = (const float*)(base + o_rad); d.flags = (const uint32_t*)(base + o_fl); d.state = (const uint8_t*)(base + o_st);
-    navhip_state_aux_in di = {(const uint8_t*)(base + o_fs), (const int32_t*)(base + o_wt), (const uint8_t*)(base + o_wp),
-                              (const float*)(base + o_np), nullptr, nullptr};
+    d.pos_xz = nullptr;                          // (only the enter-range arm reads positions: staged below with its inputs)
+    navhip_state_aux_in di;
+    memset(&di, 0, sizeof(di));
+    di.fstate = (const uint8_t*)(base + o_fs); di.wait_ticks_left = (const int32_t*)(base + o_wt);
+    di.wait_prev = (const uint8_t*)(base + o_wp); di.new_pos_xz = (const float*)(base + o_np);
+    if(rg) {
+        SKCHK(ctx, hipMemcpyAsync(base + o_pos, w->pos_xz, n * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_rt, in->range_target, n * 4, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_rr, in->target_range, n * 4, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_rp, in->target_prev_xz, n * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_row, in->range_tiles_row, n * 4, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_off, in->range_tiles_off, (rows + 1) * 4, hipMemcpyHostToDevice, s));
+        if(n_rt) SKCHK(ctx, hipMemcpyAsync(base + o_til, in->range_tiles, n_rt * 4, hipMemcpyHostToDevice, s));
+        d.pos_xz = (const float*)(base + o_pos);
+        di.range_target = (const int32_t*)(base + o_rt); di.target_range = (const float*)(base + o_rr);
+        di.target_prev_xz = (const float*)(base + o_rp); di.range_tiles_row = (const int32_t*)(base + o_row);
+        di.range_tiles_off = (const int32_t*)(base + o_off); di.range_tiles = (const int16_t*)(base + o_til);
+        di.n_range_rows = in->n_range_rows;
+    }
     if(in->ent_rot) {
         SKCHK(ctx, hipMemcpyAsync(base + o_er, in->ent_rot, n * 16, hipMemcpyHostToDevice, s));
         SKCHK(ctx, hipMemcpyAsync(base + o_td, in->target_dir, n * 16, hipMemcpyHostToDevice, s));

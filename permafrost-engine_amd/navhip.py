@@ -370,14 +370,16 @@ class StateIn(C.Structure):
 
 SU_SET_STATE, SU_BLOCK, SU_HOST = 0x01, 0x02, 0x80
 GATE_TURN, GATE_HOST = 0x01, 0x80
-SU_SET_MOVING, SU_TARGET_DIR = 0x04, 0x08
+SU_SET_MOVING, SU_TARGET_DIR, SU_SET_DEST = 0x04, 0x08, 0x10
 FS_MEMBER, FS_READY, FS_ASSIGNED, FS_IN_RANGE, FS_ARRIVED = 0x01, 0x02, 0x04, 0x08, 0x10
 
 
 class StateAuxIn(C.Structure):
     """navhip_state_aux_in, include/navhip.h"""
     _fields_ = [("fstate", C.c_void_p), ("wait_ticks_left", C.c_void_p), ("wait_prev", C.c_void_p), ("new_pos_xz", C.c_void_p),
-                ("ent_rot", C.c_void_p), ("target_dir", C.c_void_p)]
+                ("ent_rot", C.c_void_p), ("target_dir", C.c_void_p), ("range_target", C.c_void_p), ("target_range", C.c_void_p),
+                ("target_prev_xz", C.c_void_p), ("range_tiles_row", C.c_void_p), ("range_tiles_off", C.c_void_p),
+                ("range_tiles", C.c_void_p), ("n_range_rows", C.c_int32)]
 
 
 class GateIn(C.Structure):
@@ -753,7 +755,7 @@ def _ctx_heading_gate(self, arrays, next_rot, new_vel_xz, vdes_xz, work=None):
 
 
 def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_pos_xz, state, flags, work=None,
-                          ent_rot=None, target_dir=None):
+                          ent_rot=None, target_dir=None, range_in=None):
     """The flag / counter arms of the state switch, after state_update on the same slab: returns (state, flags,
     wait_ticks_left) with the rows this pass decides overwritten."""
     w, keep = make_world(self.w, self.h, arrays)
@@ -762,9 +764,22 @@ def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_
     n = w.n_ents
     k = [np.ascontiguousarray(fstate, np.uint8), np.ascontiguousarray(wait_ticks_left, np.int32),
          np.ascontiguousarray(wait_prev, np.uint8), np.ascontiguousarray(new_pos_xz, np.float32).reshape(n, 2)]
+    ai = StateAuxIn(*[a.ctypes.data for a in k])
     if ent_rot is not None:
         k += [np.ascontiguousarray(ent_rot, np.float32).reshape(n, 4), np.ascontiguousarray(target_dir, np.float32).reshape(n, 4)]
-    ai = StateAuxIn(*[a.ctypes.data for a in k])
+        ai.ent_rot, ai.target_dir = k[-2].ctypes.data, k[-1].ctypes.data
+    if range_in is not None:
+        # range_in: dict(target [n] row or -1 / -2, range [n], prev_xz [n][2], tiles_row [n], tiles: list of [k, 2] int16)
+        offs = np.zeros(len(range_in["tiles"]) + 1, np.int32)
+        offs[1:] = np.cumsum([len(t) for t in range_in["tiles"]])
+        tiles = np.concatenate([np.asarray(t, np.int16).reshape(-1, 2) for t in range_in["tiles"]] + [np.zeros((1, 2), np.int16)])
+        r = [np.ascontiguousarray(range_in["target"], np.int32), np.ascontiguousarray(range_in["range"], np.float32),
+             np.ascontiguousarray(range_in["prev_xz"], np.float32).reshape(n, 2), np.ascontiguousarray(range_in["tiles_row"], np.int32),
+             offs, np.ascontiguousarray(tiles)]
+        k += r
+        ai.range_target, ai.target_range, ai.target_prev_xz, ai.range_tiles_row, ai.range_tiles_off, ai.range_tiles = \
+            [a.ctypes.data for a in r]
+        ai.n_range_rows = len(range_in["tiles"])
     st, fl, ticks = np.array(state, np.uint8), np.array(flags, np.uint8), np.zeros(n, np.int32)
     self._chk(lib().navhip_state_update_aux(self._h, C.byref(w), C.byref(ai), _hp(st), _hp(fl), _hp(ticks)),
               "navhip_state_update_aux")

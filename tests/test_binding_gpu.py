@@ -254,7 +254,7 @@ def test_arrival_settle_through_the_binding():
 def test_formation_and_wait_arms_through_the_binding():
     """The state pass with formation flags and wait counters in play (movement.c:2423-2437, :2630-2668): members on
     the move are no longer the host's -- the arrival arm answers for them and navhip_state_update_aux overrides where
-    the flags decide --, ARRIVING_TO_CELL, WAITING and TURNING units are decided on the device, UPDATE_SET_MOVING and
+    the flags decide --, ARRIVING_TO_CELL, WAITING, TURNING and ENTER_ENTITY_RANGE units are decided on the device, UPDATE_SET_MOVING, UPDATE_SET_DEST and
     UPDATE_SET_TARGET_DIR reach the patch.  Every unit's next state and flags == entity_compute_update's, the wait
     counters the device returns == the ones the reference leaves in movestate."""
     grid, nav, world, new_vel, vdes = cases.state_world()
@@ -275,13 +275,26 @@ def test_formation_and_wait_arms_through_the_binding():
     off = np.where(rng.rand(n) < 0.5, rng.uniform(-4.5, 4.5, n), rng.uniform(6, 180, n) * rng.choice([-1, 1], n))
     target_dir = pfref.RefMove.dir_quat(np.stack([np.cos(ang), np.sin(ang)], 1))
     ent_rot = pfref.RefMove.dir_quat(np.stack([np.cos(ang + np.deg2rad(off)), np.sin(ang + np.deg2rad(off))], 1))
+    # STATE_ENTER_ENTITY_RANGE units (:2569-2604): a target among the neighbours (or none), a range, where the target stood
+    world["state"][(u >= 0.34) & (u < 0.46)] = 6
+    er = np.flatnonzero(world["state"] == 6)
+    tgt = np.full(n, -1, np.int32)
+    for i in er:
+        if rng.rand() < 0.9:
+            d = np.linalg.norm(world["pos_xz"] - world["pos_xz"][i], axis=1)
+            d[i] = np.inf
+            tgt[i] = np.argsort(d)[rng.randint(1, 60)]
+    t_range = rng.choice([0.0, 5.0, 20.0, 60.0], n).astype(np.float32)
+    t_prev = (world["pos_xz"][np.maximum(tgt, 0)] + rng.normal(0, 4.0, (n, 2))).astype(np.float32)
     mv, _ = cases.ref_move_for(nav, world)
     try:
         mv.set_state_aux(fstate, ticks, prev)
         mv.set_turning(ent_rot, target_dir)
+        mv.set_range_targets(tgt, t_range, t_prev)
         ref_state, ref_flags = mv.state_update(new_vel, vdes)
         ref_ticks = mv.get_wait_ticks()
-        assert (ref_flags & 4).sum() > 50 and (ref_flags & 8).sum() > 10
+        assert (ref_flags & 4).sum() > 50 and (ref_flags & 8).sum() > 10 and (ref_flags & 16).sum() > 20
+        assert ((world["state"] == 6) & (ref_state == 4)).sum() > 30 and ((world["state"] == 6) & (ref_state == 2)).sum() > 10
         assert ((world["state"] == 7) & (ref_state == 2)).sum() > 50 and ((world["state"] == 7) & (ref_state == 7)).sum() > 50
         mv.set_state_aux(fstate, ticks, prev)
         assert nav.hip_init(), "no MI355X visible"
@@ -290,7 +303,7 @@ def test_formation_and_wait_arms_through_the_binding():
         assert np.array_equal(mv.get_wait_ticks(), ref_ticks) and mv.hip_wait_differ() == 0
         decided = (dv & 0x80) == 0
         garr = (world["flags"] & (1 << 18)) != 0
-        assert decided[np.isin(world["state"], (4, 7, 8)) | garr].all()
+        assert decided[np.isin(world["state"], (4, 6, 7, 8)) | garr].all()
         assert decided.sum() > 0.9 * n          # (not: the units on another nav layer than their flock's tables)
         assert (decided & (fl == 4)).sum() > 50 and (decided & (fl == 9) & (st == 7)).sum() > 10
         assert (decided & np.isin(world["state"], (0, 1)) & (st == 8)).sum() > 50
