@@ -120,6 +120,21 @@ def usable_cores():
     return min(n, 256)
 
 
+def state_pass_probe(chunk_w, k_fields, n_agents, timeout=240):
+    """scripts/bench_state_pass.py in a subprocess: its JSON line, or what went wrong."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_state_pass.py"), "--chunks", str(chunk_w),
+                            "--flocks", str(k_fields), "--agents", str(n_agents)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        return json.loads(lines[-1])
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10.0, budget_agent_s=10.0, dropin=True):
     """The reference's own code (oracle/_ref) timed on this box's host cores, on a bounded sample of
     the SAME workload (whole=True: all of it, config 0).  Reported, never the target."""
@@ -212,6 +227,11 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10
                 pfref.RefNav.hip_shutdown()
             except Exception as exc:
                 drop = {"error": repr(exc)}
+            # ---- the STATE half of the same tick through the binding (heading gate, state update, settle pass, flag arms:
+            # csrc/state_kernels.hip, written after the round's last GPU session).  In a process of its own with a time
+            # limit: whatever happens in there, this line is printed.
+            if isinstance(drop, dict):
+                drop["state_pass"] = state_pass_probe(chunk_w, k_fields, n_agents)
         pfref.RefMove.unload()
         # (iii) the flow sampling of the velocity step (a13: N_DesiredPointSeekVelocity per agent, serial on the nav
         # task -- compute_desired_velocity, movement.c:4166), which the slab timing above is given.  The reference's

@@ -149,6 +149,7 @@ def lib():
             ("pfref_move_get_arrival_units", [C.c_void_p] * 4, None),
             ("pfref_move_hip_settle_stats", [C.c_void_p], None),
             ("pfref_move_hip_wait_differ", [], C.c_long),
+            ("pfref_move_hip_state_work_seconds", [], C.c_double),
             ("pfref_move_set_state_aux", [C.c_void_p] * 3, None),
             ("pfref_move_get_wait_ticks", [C.c_void_p], None),
             ("pfref_move_set_turning", [C.c_void_p] * 2, None),
@@ -705,6 +706,10 @@ class RefMove:
         lib().pfref_move_get_arrival_units(_p(out["substate"]), _p(out["progress_anchor_xz"]), _p(out["progress_anchored"]),
                                            _p(out["stuck"]))
         return out
+
+    def hip_state_work_seconds(self):
+        """Wall time of the last move_hip_state_work (snapshot fill + the device calls of the state pass)."""
+        return float(lib().pfref_move_hip_state_work_seconds())
 
     def hip_wait_differ(self):
         """Wait counters the device's pass left different from the reference's (the state binding's check)."""

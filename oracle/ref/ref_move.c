@@ -506,6 +506,9 @@ int pfref_move_hip_snapshot(int cap, float *pos, float *vel, float *radius, floa
     return S.n;
 }
 
+static double s_hip_state_work_s;      /* wall time of the last move_hip_state_work (the device half of the state pass) */
+double pfref_move_hip_state_work_seconds(void) { return s_hip_state_work_s; }
+
 /* pfref_move_state_update through the binding: move_hip_state_work (ONE navhip_state_update for the slab)
  * then move_hip_update_work per unit.  dev_flags[i] = what the device answered (NAVHIP_SU_*).
  * Returns 0 when the device arm declined. */
@@ -526,7 +529,12 @@ int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int beg
     }
     if(end <= begin)
         return 1;
-    if(!move_hip_state_work(begin, end - 1))
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    const bool worked = move_hip_state_work(begin, end - 1);
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    s_hip_state_work_s = (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
+    if(!worked)
         return 0;
     for(int i = begin; i < end; i++) {
         struct move_work_out *out = &s_move_work.out[i];

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""The STATE half of the reference's movement tick (fork_join_state_updates, movement.c:4196) at a benchmark
+configuration through the binding: bindings/permafrost/move_hip.c's move_hip_state_work -- ONE heading gate, ONE state
+update, the settle pass for units of arriving flocks, ONE pass for the flag / counter arms (csrc/state_kernels.hip), host
+buffers and PCIe included -- against the reference's own entity_compute_update per unit on one core, with every unit's
+next state and flags compared.  Prints one JSON line.  bench.py runs it in a process of its own (`dropin.state_pass`):
+a fault in this newest part of the library must not take the benchmark line with it.
+
+    python scripts/bench_state_pass.py [--chunks 16] [--flocks 64] [--agents 100000] [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chunks", type=int, default=16)
+    ap.add_argument("--flocks", type=int, default=64)
+    ap.add_argument("--agents", type=int, default=100000)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    import numpy as np
+    from oracle import pfref
+    from permafrost_engine_amd import synth
+    if not pfref.available():
+        print(json.dumps({"error": "oracle/_ref is not present"}))
+        return
+    W, K, N = args.chunks, args.flocks, args.agents
+    grid = synth.cost_grid(W, W, seed=1234)
+    nav = pfref.RefNav(synth.to_chunks(grid))
+    dests = synth.destinations(grid, K, seed=42)
+    ag = synth.agents(grid, N, K, seed=7, hz=20)
+    targets = synth.cell_centre(W, W, dests[:, 0], dests[:, 1])
+    dest_ids = []
+    for f in range(K):
+        ok, did = nav.request_path(ag["pos"][f % N], targets[f], clear_cache=(f == 0))
+        dest_ids.append(did)
+    nav.trace()
+    rng = np.random.RandomState(5)
+    state = np.zeros(N, np.int32)
+    u = rng.rand(N)
+    state[u < 0.15] = 2                       # STATE_ARRIVED: their flock mates arrive next to them
+    state[(u >= 0.15) & (u < 0.20)] = 4       # STATE_WAITING
+    mv = pfref.RefMove(nav, ag["pos"], ag["vel"], ag["radius"], ag["max_speed"], ag["speed"],
+                       np.full(N, pfref.ENTITY_FLAG_MOVABLE, np.uint32), state, ag["flock"], np.zeros(N, np.uint8),
+                       targets, np.array(dest_ids, np.uint32), hz=20)
+    new_vel = (ag["vel"] + rng.normal(0, 0.05, (N, 2))).astype(np.float32)
+    vdes = rng.normal(0, 1, (N, 2)).astype(np.float32)
+    vdes /= np.maximum(np.linalg.norm(vdes, axis=1, keepdims=True), 1e-6)
+    vdes[rng.rand(N) < 0.05] = 0
+    ticks = np.full(N, 40, np.int32)
+    mv.set_state_aux(np.zeros(N, np.uint8), ticks, np.zeros(N, np.uint8))
+    t0 = time.perf_counter()
+    ref_state, ref_flags = mv.state_update(new_vel, vdes)
+    t_ref = time.perf_counter() - t0
+    out = {"what": "state half of the reference's movement tick, %d work items, %d flocks, %dx%d chunks: move_hip_state_work "
+                   "+ move_hip_update_work's device part (host buffers) vs entity_compute_update per unit on one core"
+                   % (N, K, W, W),
+           "cpu_ms_per_tick_1core": t_ref * 1e3}
+    try:
+        if not nav.hip_init():
+            out["error"] = "no device"
+        else:
+            mv.set_state_aux(np.zeros(N, np.uint8), ticks, np.zeros(N, np.uint8))
+            st, fl, dv = mv.state_update_hip(new_vel, vdes)
+            out["identical"] = bool(np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags))
+            out["decided_on_device"] = float(((dv & 0x80) == 0).mean())
+            out["to_arrived"], out["to_waiting"] = int(((st == 2) & (state != 2)).sum()), int(((st == 4) & (state != 4)).sum())
+            times = []
+            for _ in range(args.reps):
+                mv.set_state_aux(np.zeros(N, np.uint8), ticks, np.zeros(N, np.uint8))
+                mv.state_update_hip(new_vel, vdes)
+                times.append(mv.hip_state_work_seconds())
+            out["hip_ms_per_tick"] = min(times) * 1e3
+            out["hip_ms_per_tick_all"] = [t * 1e3 for t in times]
+            out["speedup_vs_1core"] = t_ref / min(times)
+            out["note"] = ("hip = move_hip_state_work: filling the snapshot tables and per-unit inputs on the host, the two "
+                           "nav queries per flock, the device calls with their transfers; the pose half of the patch (which "
+                           "the harness can only get by running the reference's whole entity_compute_update again) is not "
+                           "in it.  cpu = entity_compute_update for every unit on ONE core; the engine forks it over its "
+                           "tasks like the velocity half")
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
