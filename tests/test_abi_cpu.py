@@ -58,6 +58,8 @@ int main(void){
     printf("sizeof.navhip_arrival_zone %zu\n", sizeof(navhip_arrival_zone));
     printf("sizeof.navhip_settle_in %zu\n", sizeof(navhip_settle_in));
     printf("sizeof.navhip_settle_out %zu\n", sizeof(navhip_settle_out));
+    printf("sizeof.navhip_state_aux_in %zu\n", sizeof(navhip_state_aux_in));
+    P(navhip_state_aux_in, ent_rot); P(navhip_state_aux_in, range_tiles); P(navhip_state_aux_in, n_range_rows);
     P(navhip_arrival_zone, radius); P(navhip_arrival_zone, key_end);
     P(navhip_settle_in, zones); P(navhip_settle_in, uid); P(navhip_settle_in, stuck);
     P(navhip_circle, radius); P(navhip_circle, faction_id); P(navhip_circle, delta);
@@ -88,13 +90,15 @@ int main(void){
         assert got["navhip_world." + f] == getattr(navlib.World, f).offset, f
     assert got["navhip_step_out.status"] == navlib.StepOut.status.offset
     for name, cls in (("gate_in", navlib.GateIn), ("arrival_zone", navlib.ArrivalZone), ("settle_in", navlib.SettleIn),
-                      ("settle_out", navlib.SettleOut)):
+                      ("settle_out", navlib.SettleOut), ("state_aux_in", navlib.StateAuxIn)):
         assert got["sizeof.navhip_" + name] == C.sizeof(cls), name
     assert got["sizeof.navhip_arrival_zone"] == 48
     for f in ("radius", "key_end"):
         assert got["navhip_arrival_zone." + f] == getattr(navlib.ArrivalZone, f).offset, f
     for f in ("zones", "uid", "stuck"):
         assert got["navhip_settle_in." + f] == getattr(navlib.SettleIn, f).offset, f
+    for f in ("ent_rot", "range_tiles", "n_range_rows"):
+        assert got["navhip_state_aux_in." + f] == getattr(navlib.StateAuxIn, f).offset, f
 
 
 def _ff_id_expected(r):
@@ -170,6 +174,15 @@ def test_invalid_arguments_are_rejected(navlib):
     assert L.navhip_device(None) == -1
     assert L.navhip_plane_dev(None, 0, 0) is None
     assert L.navhip_last_error(None) == b""
+    # the state pass (csrc/state_kernels.hip): no context, no answer
+    w = navlib.World()
+    assert L.navhip_heading_gate(None, C.byref(w), C.byref(navlib.GateIn()), None, None, None) == -1
+    assert L.navhip_heading_gate_dev(None, C.byref(w), C.byref(navlib.GateIn()), None, None, None, None) == -1
+    assert L.navhip_settled_count(None, C.byref(w), 1, None, None) == -1
+    assert L.navhip_arrival_settle(None, C.byref(w), C.byref(navlib.SettleIn()), C.byref(navlib.SettleOut())) == -1
+    assert L.navhip_arrival_settle_dev(None, C.byref(w), C.byref(navlib.SettleIn()), C.byref(navlib.SettleOut()), None) == -1
+    assert L.navhip_state_update_aux(None, C.byref(w), C.byref(navlib.StateAuxIn()), None, None, None) == -1
+    assert L.navhip_state_update_aux_dev(None, C.byref(w), C.byref(navlib.StateAuxIn()), None, None, None, None) == -1
 
 
 def _gpu_visible():
