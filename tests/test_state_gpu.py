@@ -344,3 +344,51 @@ def test_state_aux_arms_match_entity_compute_update(navlib):
     assert (mov & (st == 8) & (fl == navlib.SU_SET_STATE)).sum() > 50                    # within range of the cell
     assert (mov & ((fstate & 2) == 0) & (fl == 0)).sum() > 50                              # waits for the assignment
     assert (mov & (st == 2)).sum() > 20                                                    # fell through and arrived
+
+
+def test_state_pass_rejects_bad_arguments(navlib):
+    """The host-buffer entry points of the state pass check what they can see before anything reaches a kernel: a unit or
+    zone index outside its table, a zone whose ranges run backwards, enter-range inputs given in part, a slab outside the
+    snapshot -- NAVHIP_ERR_INVALID, nothing written."""
+    import ctypes as C
+    L = navlib.lib()
+    ctx = navlib.NavContext(4, 4)
+    n = 64
+    arrays = {"pos_xz": np.zeros((n, 2), np.float32), "vel_xz": np.zeros((n, 2), np.float32), "radius": np.ones(n, np.float32),
+              "flags": np.full(n, 1 << 3, np.uint32), "state": np.zeros(n, np.uint8)}
+    zone = {"layer": 0, "centre_xz": (0.0, 0.0), "radius": 3, "unit_radius": 1.0, "fill_frac": 0.5, "active_row": 0,
+            "num_rows": 2, "slots_xz": np.zeros((4, 2), np.float32), "slot_ring": np.zeros(4, np.int32)}
+    keys = [np.arange(5, dtype=np.uint64)]
+    units = {"uid": np.arange(8, dtype=np.int32), "zone": np.zeros(8, np.int32), "new_pos_xz": np.zeros((8, 2), np.float32),
+             "nsettled": np.zeros(8, np.int32), "substate": np.zeros(8, np.uint8), "sink_valid": np.zeros(8, np.uint8),
+             "sink_xz": np.zeros((8, 2), np.float32), "order_pos_xz": np.zeros((8, 2), np.float32),
+             "progress_anchor_xz": np.zeros((8, 2), np.float32), "progress_anchored": np.zeros(8, np.uint8),
+             "stuck": np.zeros(8, np.int32)}
+    ctx.arrival_settle(arrays, [zone], keys, units)                                   # (fine as it is)
+    for field, value in (("uid", n), ("uid", -1), ("zone", 1), ("zone", -1)):
+        bad = dict(units)
+        bad[field] = units[field].copy()
+        bad[field][3] = value
+        with pytest.raises(RuntimeError):
+            ctx.arrival_settle(arrays, [zone], keys, bad)
+    with pytest.raises(RuntimeError):
+        ctx.arrival_settle(arrays, [dict(zone, layer=99)], keys, units)
+    with pytest.raises(RuntimeError):
+        ctx.settled_count(arrays, np.array([0, n], np.int32))
+    with pytest.raises(RuntimeError):
+        ctx.heading_gate(arrays, np.zeros((n, 4), np.float32), np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32),
+                         work=(10, n + 1))
+    # the enter-range inputs come together or not at all
+    w, keep = navlib.make_world(4, 4, arrays)
+    k = [np.zeros(n, np.uint8), np.ones(n, np.int32), np.zeros(n, np.uint8), np.zeros((n, 2), np.float32), np.full(n, -1, np.int32)]
+    ai = navlib.StateAuxIn(k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data, k[3].ctypes.data)
+    ai.range_target = k[4].ctypes.data
+    st, fl, ticks = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.int32)
+    args = (ctx._h, C.byref(w), C.byref(ai), st.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), ticks.ctypes.data_as(C.c_void_p))
+    assert L.navhip_state_update_aux(*args) == -1
+    ai.range_target = None
+    ai.ent_rot = k[3].ctypes.data                                                     # ... and so do the two rotations
+    assert L.navhip_state_update_aux(*args) == -1
+    ai.ent_rot = None
+    assert L.navhip_state_update_aux(*args) == 0
+    ctx.close()
