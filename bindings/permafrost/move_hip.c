@@ -627,16 +627,27 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
     if(nq == 0)
         return true;
     const size_t F = S->nflocks;
-    int32_t *zone_of = malloc(sizeof(int32_t) * (F * NAV_LAYER_MAX + 1));   /* (flock, layer) -> zone */
+    /* one block for the pass: the (flock, layer) -> zone table, the zones, and 17 per-unit arrays */
+    const size_t Q = (size_t)nq;
+    size_t bytes = 0;
+#define TAKE(n_bytes) (bytes += (((size_t)(n_bytes)) + 63) & ~(size_t)63, bytes - ((((size_t)(n_bytes)) + 63) & ~(size_t)63))
+    const size_t o_zone_of = TAKE(sizeof(int32_t) * (F * NAV_LAYER_MAX + 1)), o_zones = TAKE(sizeof(navhip_arrival_zone) * (Q + 1)),
+                 o_zone_as = TAKE(sizeof(void*) * (Q + 1)), o_uid = TAKE(4 * Q), o_zone = TAKE(4 * Q), o_witem = TAKE(4 * Q),
+                 o_nsettled = TAKE(4 * Q), o_stuck = TAKE(4 * Q), o_ostuck = TAKE(4 * Q), o_qpos = TAKE(8 * Q), o_sink = TAKE(8 * Q),
+                 o_order = TAKE(8 * Q), o_anchor = TAKE(8 * Q), o_oanchor = TAKE(8 * Q), o_sub = TAKE(Q), o_sv = TAKE(Q),
+                 o_anchored = TAKE(Q), o_osettle = TAKE(Q), o_osub = TAKE(Q), o_oanchored = TAKE(Q);
+#undef TAKE
+    char *blk = malloc(bytes);
+    int32_t *zone_of = (int32_t*)(blk + o_zone_of);                         /* (flock, layer) -> zone */
     for(size_t k = 0; k < F * NAV_LAYER_MAX; k++) zone_of[k] = -1;
-    navhip_arrival_zone *zones = malloc(sizeof(navhip_arrival_zone) * (nq + 1));
-    const struct arrival_state **zone_as = malloc(sizeof(void*) * (nq + 1));
-    int32_t *uid = malloc(sizeof(int32_t) * nq), *zone = malloc(sizeof(int32_t) * nq), *witem = malloc(sizeof(int32_t) * nq);
-    int32_t *nsettled = malloc(sizeof(int32_t) * nq), *stuck = malloc(sizeof(int32_t) * nq), *o_stuck = malloc(sizeof(int32_t) * nq);
-    float *q_pos = malloc(sizeof(float) * 2 * nq), *sink = malloc(sizeof(float) * 2 * nq), *order = malloc(sizeof(float) * 2 * nq);
-    float *anchor = malloc(sizeof(float) * 2 * nq), *o_anchor = malloc(sizeof(float) * 2 * nq);
-    uint8_t *substate = malloc(nq), *sink_valid = malloc(nq), *anchored = malloc(nq);
-    uint8_t *o_settle = malloc(nq), *o_substate = malloc(nq), *o_anchored = malloc(nq);
+    navhip_arrival_zone *zones = (navhip_arrival_zone*)(blk + o_zones);
+    const struct arrival_state **zone_as = (const struct arrival_state**)(blk + o_zone_as);
+    int32_t *uid = (int32_t*)(blk + o_uid), *zone = (int32_t*)(blk + o_zone), *witem = (int32_t*)(blk + o_witem);
+    int32_t *nsettled = (int32_t*)(blk + o_nsettled), *stuck = (int32_t*)(blk + o_stuck), *o_stuck_ = (int32_t*)(blk + o_ostuck);
+    float *q_pos = (float*)(blk + o_qpos), *sink = (float*)(blk + o_sink), *order = (float*)(blk + o_order);
+    float *anchor = (float*)(blk + o_anchor), *o_anchor_ = (float*)(blk + o_oanchor);
+    uint8_t *substate = (uint8_t*)(blk + o_sub), *sink_valid = (uint8_t*)(blk + o_sv), *anchored = (uint8_t*)(blk + o_anchored);
+    uint8_t *o_settle = (uint8_t*)(blk + o_osettle), *o_substate = (uint8_t*)(blk + o_osub), *o_anchored_ = (uint8_t*)(blk + o_oanchored);
     int nz = 0, q = 0, n_slots = 0, n_keys = 0;
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];
@@ -677,7 +688,7 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
     bool ok = navhip_settled_count(ctx, W, nq, uid, nsettled) == NAVHIP_OK;
     navhip_settle_in in = {nz, nq, zones, slots, ring, keys, uid, zone, q_pos, nsettled, substate, sink_valid, sink, order,
                            anchor, anchored, stuck};
-    navhip_settle_out out = {o_settle, o_substate, o_anchor, o_anchored, o_stuck};
+    navhip_settle_out out = {o_settle, o_substate, o_anchor_, o_anchored_, o_stuck_};
     ok = ok && navhip_arrival_settle(ctx, W, &in, &out) == NAVHIP_OK;
     for(q = 0; ok && q < nq; q++) {
         const int i = uid[q];
@@ -695,12 +706,10 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
         }else if(PFM_Vec2_Len((vec2_t*)&vd) < EPSILON) {
             st[i] = STATE_WAITING; fl[i] = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK;       /* :2508 */
         }
-        s_hip_settle_chk[witem[q]] = (struct hip_settle_chk){true, o_substate[q], o_anchored[q], o_stuck[q],
-                                                            {o_anchor[2 * q], o_anchor[2 * q + 1]}};
+        s_hip_settle_chk[witem[q]] = (struct hip_settle_chk){true, o_substate[q], o_anchored_[q], o_stuck_[q],
+                                                            {o_anchor_[2 * q], o_anchor_[2 * q + 1]}};
     }
-    free(zone_of); free(zones); free(zone_as); free(uid); free(zone); free(witem); free(nsettled); free(stuck); free(o_stuck);
-    free(q_pos); free(sink); free(order); free(anchor); free(o_anchor); free(substate); free(sink_valid); free(anchored);
-    free(o_settle); free(o_substate); free(o_anchored); free(slots); free(ring); free(keys);
+    free(blk); free(slots); free(ring); free(keys);
     return ok;
 }
 
