@@ -1,5 +1,6 @@
 // state_kernels.hip -- more of entity_compute_update (movement.c:2303) on the device, SURVEY section 8(f4):
-// the heading gate (:2319-2336), adjacent_settled_count (:982) and the arrival overlay's settle rule
+// the heading gate (:2319-2336), the arms of the state switch that k_state_update does not cover except
+// STATE_SURROUND_ENTITY (:2423-2437, :2569-2668), adjacent_settled_count (:982) and the arrival overlay's settle rule
 // (G_Arrival_ShouldSettle, arrival.c:946) with what it calls: N_SegmentWithinRegion (nav.c:4326) over
 // M_Tile_LineSupercoverTilesSorted (tile.c:430), arrival_near_region / arrival_near_open_slot
 // (arrival.c:158, :326).  Kernels AND their C entry points (include/navhip.h): this translation unit was
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(256) void k_heading_gate(int begin, int end, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// the arms that flags and a counter decide (formation members, ARRIVING_TO_CELL, the wait timer): a thread per
-// unit, after k_state_update
+// the arms that flags, a counter, an angle or a distance decide (formation members on the move, ARRIVING_TO_CELL, the
+// wait timer, the end of TURNING, ENTER_ENTITY_RANGE): a thread per unit, after k_state_update
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float *pos_xz, const float *radius, const uint32_t *flags,
                                                    const uint8_t *state, navhip_state_aux_in in, uint8_t *io_state,
