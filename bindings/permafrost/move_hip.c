@@ -814,6 +814,11 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     const bool aux = ok && (20 / hz_count(s_move_work.hz)) == 1;
     if(aux) {
         navhip_state_aux_in ain = {fstate, wait_ticks, wait_prev, new_pos, ent_rot, target_dir};
+        bool any_turning = false;
+        for(int w = begin_idx; w <= end_idx && !any_turning; w++)
+            any_turning = S.state[s_hip_witem.idx[w]] == STATE_TURNING;
+        if(!any_turning)
+            ain.ent_rot = ain.target_dir = NULL;              /* (32 bytes per unit that nobody would read) */
         /* STATE_ENTER_ENTITY_RANGE (:2569-2604): the target's row in the snapshot, the range, where the target stood when
          * the path was requested, and -- per such unit -- the closest island tiles of the target's position on the unit's
          * layer (the first half of N_IsMaximallyClose, as for the flocks' destinations above) */
