@@ -527,12 +527,15 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
 
 /* ---- the state-update half: fork_join_state_updates (movement.c:4196) -> move_update_task (:3496) ->
  * entity_compute_update (:2303) ------------------------------------------------------------------------
- * The data-parallel arm of its state switch (:2441-2520: arrived() with its three nav tests, the
- * arrived-neighbour rule, the no-guidance wait; the garrison rule :2344) runs on the device for every
- * work item at once (navhip_state_update).  The host keeps what is host state: the heading gate
- * (:2321-2334, orientation), the pose / interpolation patch, and the units the device hands back
- * (NAVHIP_SU_HOST: formations, active arrival groups, every other state).
- * move_hip_state_work(begin, end) leaves next state + blocker flag per work item; move_hip_update_work is
+ * The decisions of the function run on the device for every work item at once, in ONE call (navhip_state_pass):
+ * the heading gate (:2319-2336), the arrival arm of the state switch (:2441-2520: arrived() with its three nav
+ * tests, the arrived-neighbour rule, the no-guidance wait; the garrison rule :2344), and the arms that flags, the
+ * wait counter, the angle to target_dir and the distance to the target decide (formation members, ARRIVING_TO_CELL,
+ * WAITING, TURNING, ENTER_ENTITY_RANGE).  Units of a flock with an active arrival zone follow in two more calls
+ * (adjacent_settled_count + G_Arrival_ShouldSettle: move_hip_settle_work).  The host keeps the pose / interpolation
+ * half of the patch and the units the device hands back (NAVHIP_SU_HOST: STATE_SURROUND_ENTITY, a facing within the
+ * gate's margin of a tolerance, a nav layer other than most of the flock's, every unit at a rate below 20 Hz).
+ * move_hip_state_work(begin, end) leaves next state + flags per work item; move_hip_update_work is
  * move_update_work (:3469) with the switch's outcome taken from there. */
 int N_HIP_ClosestIslandTiles(struct nav_private *priv, enum nav_layer layer, vec3_t map_pos, vec2_t xz_dest,
                              int16_t *out_abs, int max_tiles);                    /* nav_hip.c */
@@ -554,17 +557,6 @@ static long     s_hip_settle_stats[4];               /* units decided by the dev
                                                         that differ from the reference's afterwards, units whose
                                                         heading gate the device left to the host */
 void move_hip_settle_stats(long out[4]) { memcpy(out, s_hip_settle_stats, sizeof(s_hip_settle_stats)); }
-
-/* the velocity entity_compute_update integrates: zero while the unit still turns towards its heading */
-static vec2_t hip_heading_gated(const struct movestate *ms, vec2_t vdes, vec2_t vel)
-{
-    if(!(PFM_Vec2_Len(&vel) > EPSILON) || !move_gated_by_heading(ms->state))
-        return vel;
-    quat_t want = dir_quat_from_velocity(intended_heading(vdes, vel));
-    const float err = fabs(RAD_TO_DEG(PFM_Quat_PitchDiff((quat_t*)&ms->next_rot, &want)));
-    const bool rolling = PFM_Vec2_Len((vec2_t*)&ms->velocity) > EPSILON;
-    return err > (rolling ? MOVE_HEADING_HALT : MOVE_HEADING_RESUME) ? (vec2_t){0.0f, 0.0f} : vel;
-}
 
 struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned;
                         uint8_t *fstate, *wait_prev; int32_t *wait_ticks; float *ent_rot, *target_dir; };
@@ -615,13 +607,14 @@ static void hip_state_items_range(int begin, int end, void *arg)
  * slots, their fill ranks and the sorted tile keys of its footprint.  st / fl (by dense index) are overwritten
  * for the units decided here. */
 static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navhip_world *W, int begin_idx, int end_idx,
-                                 const uint8_t *zoned, const float *new_pos, const float *vdes, uint8_t *st, uint8_t *fl)
+                                 const uint8_t *zoned, const uint8_t *gate, const float *new_pos, const float *vdes, uint8_t *st, uint8_t *fl)
 {
     const struct move_gamestate *gs = &s_move_work.gamestate;
     int nq = 0;
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];
-        if(zoned[i] && (fl[i] & NAVHIP_SU_HOST) && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION))
+        if(zoned[i] && !(gate[i] & NAVHIP_GATE_HOST) && (fl[i] & NAVHIP_SU_HOST)
+        && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION))
             nq++;
     }
     if(nq == 0)
@@ -651,7 +644,8 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
     int nz = 0, q = 0, n_slots = 0, n_keys = 0;
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];
-        if(!(zoned[i] && (fl[i] & NAVHIP_SU_HOST) && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION)))
+        if(!(zoned[i] && !(gate[i] & NAVHIP_GATE_HOST) && (fl[i] & NAVHIP_SU_HOST)
+             && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION)))
             continue;
         const int f = S->flock[i];
         const enum nav_layer layer = Entity_NavLayerWithRadius(S->flags[i], S->radius[i]);
@@ -750,27 +744,6 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         if(i < lo) lo = i;
         if(i > hi) hi = i;
     }
-    /* the heading gate for the slab (navhip_heading_gate): the velocity entity_compute_update integrates and the
-     * position it tests; the few units within the device's margin of a tolerance get the reference's own arithmetic */
-    {
-        navhip_world G;
-        hip_snap_world(&S, &G);
-        G.work_begin = lo; G.work_end = hi + 1;
-        navhip_gate_in gin = {next_rot, new_vel, vdes};
-        if(hi < lo || navhip_heading_gate(ctx, &G, &gin, gate_vel, new_pos, gate) != NAVHIP_OK) {
-            hip_snap_free(&S);
-            return false;
-        }
-        for(int w = begin_idx; w <= end_idx; w++) {
-            const int i = hip_work_dense(&S, w);
-            if(!(gate[i] & NAVHIP_GATE_HOST))
-                continue;
-            const struct move_work_out *out = &s_move_work.out[w];
-            vec2_t np = new_pos_for_vel(out->ent_uid, hip_heading_gated(movestate_get(out->ent_uid), out->ent_des_v, out->ent_vel));
-            new_pos[2 * i] = np.x; new_pos[2 * i + 1] = np.z;
-            s_hip_settle_stats[3]++;
-        }
-    }
     /* the two destination-only queries of arrived() (:2170), once per flock for the nav layer most of its
      * members path on (units of another layer come back as NAVHIP_SU_HOST) */
     const size_t F = S.nflocks;
@@ -806,26 +779,30 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     navhip_world W;
     hip_snap_world(&S, &W);
     W.work_begin = lo; W.work_end = hi + 1;
-    navhip_state_in in = {new_pos, vdes, skip, flayer, nearest, toff, tiles};
     uint8_t *st = hip_arena(n + 1), *fl = hip_arena(n + 1);
-    bool ok = hi >= lo && navhip_state_update(ctx, &W, &in, st, fl) == NAVHIP_OK;
-    if(ok)
-        ok = move_hip_settle_work(ctx, &S, &W, begin_idx, end_idx, zoned, new_pos, vdes, st, fl);
-    const bool aux = ok && (20 / hz_count(s_move_work.hz)) == 1;
+    const bool aux = (20 / hz_count(s_move_work.hz)) == 1;
+    /* ONE call for the pass (navhip_state_pass): the heading gate of every unit (:2319-2336) -> the arrival arm on the
+     * positions the gate leaves (navhip_state_update) -> the arms that flags, the wait counter, the angle to target_dir and
+     * the distance to the target decide (navhip_state_update_aux); the snapshot travels once */
+    navhip_state_pass_in pin;
+    memset(&pin, 0, sizeof(pin));
+    pin.gate = (navhip_gate_in){next_rot, new_vel, vdes};
+    pin.state = (navhip_state_in){NULL, NULL, skip, flayer, nearest, toff, tiles};
+    int32_t *r_target = NULL, *r_row = NULL, *r_off = NULL; float *r_range = NULL, *r_prev = NULL; int16_t *r_tiles = NULL;
     if(aux) {
-        navhip_state_aux_in ain = {fstate, wait_ticks, wait_prev, new_pos, ent_rot, target_dir};
+        pin.aux.fstate = fstate; pin.aux.wait_ticks_left = wait_ticks; pin.aux.wait_prev = wait_prev;
         bool any_turning = false;
         for(int w = begin_idx; w <= end_idx && !any_turning; w++)
             any_turning = S.state[s_hip_witem.idx[w]] == STATE_TURNING;
-        if(!any_turning)
-            ain.ent_rot = ain.target_dir = NULL;              /* (32 bytes per unit that nobody would read) */
+        if(any_turning) {                                     /* (else 32 bytes per unit that nobody would read) */
+            pin.aux.ent_rot = ent_rot; pin.aux.target_dir = target_dir;
+        }
         /* STATE_ENTER_ENTITY_RANGE (:2569-2604): the target's row in the snapshot, the range, where the target stood when
          * the path was requested, and -- per such unit -- the closest island tiles of the target's position on the unit's
          * layer (the first half of N_IsMaximallyClose, as for the flocks' destinations above) */
         int n_range = 0;
         for(int w = begin_idx; w <= end_idx; w++)
             n_range += S.state[s_hip_witem.idx[w]] == STATE_ENTER_ENTITY_RANGE;
-        int32_t *r_target = NULL, *r_row = NULL, *r_off = NULL; float *r_range = NULL, *r_prev = NULL; int16_t *r_tiles = NULL;
         if(n_range > 0) {
             r_target = malloc(sizeof(int32_t) * n); r_row = calloc(n, sizeof(int32_t)); r_off = calloc(n_range + 1, sizeof(int32_t));
             r_range = calloc(n, sizeof(float)); r_prev = calloc(2 * n, sizeof(float));
@@ -854,12 +831,21 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
                 }
                 row++;
             }
-            ain.range_target = r_target; ain.target_range = r_range; ain.target_prev_xz = r_prev;
-            ain.range_tiles_row = r_row; ain.range_tiles_off = r_off; ain.range_tiles = r_tiles; ain.n_range_rows = n_range;
+            pin.aux.range_target = r_target; pin.aux.target_range = r_range; pin.aux.target_prev_xz = r_prev;
+            pin.aux.range_tiles_row = r_row; pin.aux.range_tiles_off = r_off; pin.aux.range_tiles = r_tiles;
+            pin.aux.n_range_rows = n_range;
         }
-        ok = navhip_state_update_aux(ctx, &W, &ain, st, fl, wait_after) == NAVHIP_OK;
-        free(r_target); free(r_row); free(r_off); free(r_range); free(r_prev); free(r_tiles);
     }
+    navhip_state_pass_out pout = {st, fl, gate, new_pos, gate_vel, aux ? wait_after : NULL};
+    bool ok = hi >= lo && navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
+    free(r_target); free(r_row); free(r_off); free(r_range); free(r_prev); free(r_tiles);
+    /* a unit whose facing is within the device's margin of a tolerance came back NAVHIP_SU_HOST: the host's own
+     * entity_compute_update answers for it (move_hip_update_work) */
+    for(int w = begin_idx; ok && w <= end_idx; w++)
+        s_hip_settle_stats[3] += (gate[s_hip_witem.idx[w]] & NAVHIP_GATE_HOST) != 0;
+    /* units of flocks with an active arrival zone, skipped above: the settle rule on the positions the gate left */
+    if(ok)
+        ok = move_hip_settle_work(ctx, &S, &W, begin_idx, end_idx, zoned, gate, new_pos, vdes, st, fl);
     s_hip_wait_chk = realloc(s_hip_wait_chk, sizeof(int32_t) * 2 * (s_move_work.nwork + 1));
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];

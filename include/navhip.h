@@ -686,6 +686,28 @@ int  navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *dev_world,
                                  uint8_t *dev_inout_state, uint8_t *dev_inout_flags, int32_t *dev_out_wait_ticks_left,
                                  void *stream);
 
+/* The state half of the tick in ONE host-buffer call (fork_join_state_updates, movement.c:4196, as navhip_agent_step is
+ * the velocity half): heading gate -> navhip_state_update on the gate's new positions -> navhip_state_update_aux, the
+ * snapshot staged once, one wait at the end.  state.new_pos_xz, state.vdes_xz and aux.new_pos_xz are IGNORED (the gate's
+ * output and gate.vdes_xz are used); aux.fstate == NULL: no aux pass.  A unit the gate leaves to the host
+ * (NAVHIP_GATE_HOST) comes back NAVHIP_SU_HOST with its state and wait counter untouched: the host decides all of it.
+ * Units of flocks with an active arrival zone are skipped as before (state.skip) and decided afterwards by
+ * navhip_settled_count / navhip_arrival_settle on the returned positions.  Rows of the slab are written. */
+typedef struct navhip_state_pass_in {
+    navhip_gate_in      gate;
+    navhip_state_in     state;
+    navhip_state_aux_in aux;
+} navhip_state_pass_in;
+typedef struct navhip_state_pass_out {
+    uint8_t  *state, *flags;          /* [n] next state, NAVHIP_SU_*                                                   */
+    uint8_t  *gate;                   /* [n] NAVHIP_GATE_*                                                             */
+    float    *new_pos_xz;             /* [n][2] new_pos_for_vel of the gated velocity                                  */
+    float    *vel_xz;                 /* [n][2] the gated velocity, or NULL                                            */
+    int32_t  *wait_ticks_left;        /* [n] or NULL (required with an aux pass)                                       */
+} navhip_state_pass_out;
+int  navhip_state_pass(navhip_ctx *ctx, const navhip_world *world, const navhip_state_pass_in *in,
+                       const navhip_state_pass_out *out);
+
 /* adjacent_settled_count (movement.c:982) for nq units of the snapshot: G_Pos_EntsInCircleFrom (r = max(30,
  * 2 radius + 5), at most 128 results, garrisoned entities dropped, position.c:379) and of those the movable
  * ones of the same air / ground kind in STATE_ARRIVED that touch the unit (distance <= both radii +

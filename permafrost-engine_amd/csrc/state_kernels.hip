@@ -167,6 +167,17 @@ __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float
     out_ticks[i] = ticks;
 }
 
+// the fused pass (navhip_state_pass): a unit whose gate is the host's to decide is the host's altogether
+__global__ __launch_bounds__(256) void k_gate_host_rows(int begin, int end, const uint8_t *gate, const uint8_t *state,
+                                                        const int32_t *in_ticks, uint8_t *io_state, uint8_t *io_flags,
+                                                        int32_t *out_ticks)
+{
+    const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    if(i >= end || !(gate[i] & NAVHIP_GATE_HOST)) return;
+    io_state[i] = state[i]; io_flags[i] = NAVHIP_SU_HOST;
+    if(out_ticks) out_ticks[i] = in_ticks[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // adjacent_settled_count: the ids of the spatial query (k_spatial_query, the reference's visiting order,
 // capped) -> the count, a thread per unit
@@ -553,6 +564,112 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
         SKCHK(ctx, hipMemcpyAsync(io_state + lo, base + o_ios + lo, cnt, hipMemcpyDeviceToHost, s));
         SKCHK(ctx, hipMemcpyAsync(io_flags + lo, base + o_iof + lo, cnt, hipMemcpyDeviceToHost, s));
         SKCHK(ctx, hipMemcpyAsync(out_ticks + lo, base + o_ot + 4 * lo, cnt * 4, hipMemcpyDeviceToHost, s));
+    }
+    SKCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state_pass_in *in, const navhip_state_pass_out *out)
+{
+    if(!ctx || !w || !in || !out || w->n_ents < 0) return NAVHIP_ERR_INVALID;
+    if(w->n_ents == 0) return NAVHIP_OK;
+    const navhip_gate_in &G = in->gate;
+    const navhip_state_in &T = in->state;
+    const navhip_state_aux_in &X = in->aux;
+    const bool aux = X.fstate != nullptr, turn = aux && X.ent_rot != nullptr, rg = aux && X.range_target != nullptr;
+    const size_t n = (size_t)w->n_ents, F = (size_t)w->n_flocks;
+    if(!w->pos_xz || !w->vel_xz || !w->radius || !w->flags || !w->state || !w->flock || !G.next_rot || !G.new_vel_xz || !G.vdes_xz
+    || !out->state || !out->flags || !out->gate || !out->new_pos_xz
+    || (F > 0 && (!w->flock_target_xz || !w->flock_offsets || !w->flock_members || !T.flock_layer || !T.flock_nearest_xz
+                  || !T.flock_tiles_off || !T.flock_tiles))
+    || (aux && (!X.wait_ticks_left || !X.wait_prev || !out->wait_ticks_left || (X.ent_rot != nullptr) != (X.target_dir != nullptr)
+                || !sk_range_inputs_ok(w, &X))))
+        return NAVHIP_ERR_INVALID;
+    int b, e;
+    if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
+    const size_t nmembers = F ? (size_t)w->flock_offsets[F] : 0, ntiles = F ? (size_t)T.flock_tiles_off[F] : 0;
+    size_t rows = 0, n_rt = 0;
+    if(rg) {
+        rows = (size_t)X.n_range_rows;
+        for(size_t r = 0; r < rows; r++)
+            if(X.range_tiles_off[r] < 0 || X.range_tiles_off[r + 1] < X.range_tiles_off[r]) return NAVHIP_ERR_INVALID;
+        n_rt = rows ? (size_t)X.range_tiles_off[rows] : 0;
+        for(size_t i = (size_t)b; i < (size_t)e; i++) {
+            if(X.range_target[i] < -2 || X.range_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
+            if(X.range_target[i] >= 0 && w->state[i] == NAVHIP_STATE_ENTER_ENTITY_RANGE
+            && (X.range_tiles_row[i] < 0 || (size_t)X.range_tiles_row[i] >= rows)) return NAVHIP_ERR_INVALID;
+        }
+    }
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    sk_arena A;
+    struct up { size_t off; const void *src; size_t bytes; };
+    std::vector<up> ups;
+    auto stage = [&](const void *src, size_t bytes) { const size_t o = A.take(bytes + 8); if(src && bytes) ups.push_back({o, src, bytes}); return o; };
+    // the snapshot, once
+    const size_t o_pos = stage(w->pos_xz, n * 8), o_vel = stage(w->vel_xz, n * 8), o_rad = stage(w->radius, n * 4),
+                 o_flg = stage(w->flags, n * 4), o_st = stage(w->state, n), o_flock = stage(w->flock, n * 4),
+                 o_ftgt = stage(w->flock_target_xz, F * 8), o_foff = stage(w->flock_offsets, (F + 1) * 4),
+                 o_fmem = stage(w->flock_members, nmembers * 4);
+    const size_t o_rot = stage(G.next_rot, n * 16), o_nv = stage(G.new_vel_xz, n * 8), o_vd = stage(G.vdes_xz, n * 8);
+    const size_t o_skip = stage(T.skip, T.skip ? n : 0), o_flay = stage(T.flock_layer, F), o_fnear = stage(T.flock_nearest_xz, F * 8),
+                 o_toff = stage(T.flock_tiles_off, (F + 1) * 4), o_tiles = stage(T.flock_tiles, ntiles * 4);
+    const size_t o_fs = stage(X.fstate, aux ? n : 0), o_wt = stage(X.wait_ticks_left, aux ? n * 4 : 0), o_wp = stage(X.wait_prev, aux ? n : 0),
+                 o_er = stage(X.ent_rot, turn ? n * 16 : 0), o_td = stage(X.target_dir, turn ? n * 16 : 0),
+                 o_rt = stage(X.range_target, rg ? n * 4 : 0), o_rr = stage(X.target_range, rg ? n * 4 : 0),
+                 o_rp = stage(X.target_prev_xz, rg ? n * 8 : 0), o_row = stage(X.range_tiles_row, rg ? n * 4 : 0),
+                 o_roff = stage(X.range_tiles_off, rg ? (rows + 1) * 4 : 0), o_rtil = stage(X.range_tiles, rg ? n_rt * 4 : 0);
+    // results
+    const size_t r_vel = A.take(n * 8), r_np = A.take(n * 8), r_gate = A.take(n), r_st = A.take(n), r_fl = A.take(n), r_tk = A.take(n * 4);
+    char *base;
+    int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
+    if(rc) return rc;
+    for(const up &u : ups) SKCHK(ctx, hipMemcpyAsync(base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, s));
+    navhip_world d = *w;
+    d.pos_xz = (const float*)(base + o_pos); d.vel_xz = (const float*)(base + o_vel); d.radius = (const float*)(base + o_rad);
+    d.flags = (const uint32_t*)(base + o_flg); d.state = (const uint8_t*)(base + o_st); d.flock = (const int32_t*)(base + o_flock);
+    d.flock_target_xz = (const float*)(base + o_ftgt); d.flock_offsets = (const int32_t*)(base + o_foff);
+    d.flock_members = (const int32_t*)(base + o_fmem);
+    // (nothing else of the world is read by the three passes; what is not staged must not travel as a host pointer)
+    d.max_speed = d.speed = nullptr; d.has_dest_los = nullptr; d.vdes_xz = nullptr; d.flock_field_slot = nullptr; d.field_pool = nullptr;
+    d.form_ready = nullptr; d.cell_pos_xz = d.form_cohesion_xz = d.form_align_xz = d.form_drag_xz = nullptr;
+    d.arrival_sink_xz = nullptr; d.arrival_flags = nullptr; d.los_pool = nullptr; d.flock_los_slot = nullptr; d.los_pos_xz = nullptr;
+    d.region_row = nullptr; d.region_field_slot = nullptr;
+    navhip_gate_in dg = {(const float*)(base + o_rot), (const float*)(base + o_nv), (const float*)(base + o_vd)};
+    rc = navhip_heading_gate_dev(ctx, &d, &dg, (float*)(base + r_vel), (float*)(base + r_np), (uint8_t*)(base + r_gate), s);
+    if(rc) return rc;
+    navhip_state_in ds = {(const float*)(base + r_np), (const float*)(base + o_vd), T.skip ? (const uint8_t*)(base + o_skip) : nullptr,
+                          (const uint8_t*)(base + o_flay), (const float*)(base + o_fnear), (const int32_t*)(base + o_toff),
+                          (const int16_t*)(base + o_tiles)};
+    rc = navhip_state_update_dev(ctx, &d, &ds, (uint8_t*)(base + r_st), (uint8_t*)(base + r_fl), s);
+    if(rc) return rc;
+    if(aux) {
+        navhip_state_aux_in da;
+        memset(&da, 0, sizeof(da));
+        da.fstate = (const uint8_t*)(base + o_fs); da.wait_ticks_left = (const int32_t*)(base + o_wt);
+        da.wait_prev = (const uint8_t*)(base + o_wp); da.new_pos_xz = (const float*)(base + r_np);
+        if(turn) { da.ent_rot = (const float*)(base + o_er); da.target_dir = (const float*)(base + o_td); }
+        if(rg) {
+            da.range_target = (const int32_t*)(base + o_rt); da.target_range = (const float*)(base + o_rr);
+            da.target_prev_xz = (const float*)(base + o_rp); da.range_tiles_row = (const int32_t*)(base + o_row);
+            da.range_tiles_off = (const int32_t*)(base + o_roff); da.range_tiles = (const int16_t*)(base + o_rtil);
+            da.n_range_rows = X.n_range_rows;
+        }
+        rc = navhip_state_update_aux_dev(ctx, &d, &da, (uint8_t*)(base + r_st), (uint8_t*)(base + r_fl), (int32_t*)(base + r_tk), s);
+        if(rc) return rc;
+    }
+    if(e > b) {
+        hipLaunchKernelGGL(k_gate_host_rows, dim3((e - b + 255) / 256), dim3(256), 0, s, b, e, (const uint8_t*)(base + r_gate),
+                           (const uint8_t*)(base + o_st), aux ? (const int32_t*)(base + o_wt) : (const int32_t*)nullptr,
+                           (uint8_t*)(base + r_st), (uint8_t*)(base + r_fl), aux ? (int32_t*)(base + r_tk) : (int32_t*)nullptr);
+        SKCHK(ctx, hipGetLastError());
+        const size_t lo = (size_t)b, cnt = (size_t)(e - b);
+        SKCHK(ctx, hipMemcpyAsync(out->state + lo, base + r_st + lo, cnt, hipMemcpyDeviceToHost, s));
+        SKCHK(ctx, hipMemcpyAsync(out->flags + lo, base + r_fl + lo, cnt, hipMemcpyDeviceToHost, s));
+        SKCHK(ctx, hipMemcpyAsync(out->gate + lo, base + r_gate + lo, cnt, hipMemcpyDeviceToHost, s));
+        SKCHK(ctx, hipMemcpyAsync(out->new_pos_xz + 2 * lo, base + r_np + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
+        if(out->vel_xz) SKCHK(ctx, hipMemcpyAsync(out->vel_xz + 2 * lo, base + r_vel + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
+        if(aux) SKCHK(ctx, hipMemcpyAsync(out->wait_ticks_left + lo, base + r_tk + 4 * lo, cnt * 4, hipMemcpyDeviceToHost, s));
     }
     SKCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;

@@ -387,6 +387,18 @@ class GateIn(C.Structure):
     _fields_ = [("next_rot", C.c_void_p), ("new_vel_xz", C.c_void_p), ("vdes_xz", C.c_void_p)]
 
 
+class StatePassIn(C.Structure):
+    """navhip_state_pass_in, include/navhip.h"""
+    _fields_ = [("gate", GateIn), ("state", StateIn), ("aux", StateAuxIn)]
+
+
+class StatePassOut(C.Structure):
+    """navhip_state_pass_out, include/navhip.h"""
+    _fields_ = [("state", C.c_void_p), ("flags", C.c_void_p), ("gate", C.c_void_p), ("new_pos_xz", C.c_void_p),
+                ("vel_xz", C.c_void_p), ("wait_ticks_left", C.c_void_p)]
+
+
+
 class ArrivalZone(C.Structure):
     """navhip_arrival_zone, include/navhip.h"""
     _fields_ = [("centre_x", C.c_float), ("centre_z", C.c_float), ("unit_radius", C.c_float), ("fill_frac", C.c_float),
@@ -421,6 +433,7 @@ _SIGS.update({
                                           C.c_void_p]),
     "navhip_state_update_aux_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StateAuxIn), C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
+    "navhip_state_pass": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(StatePassIn), C.POINTER(StatePassOut)]),
     "navhip_settled_count": (C.c_int, [C.c_void_p, C.POINTER(World), C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_arrival_settle": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(SettleIn), C.POINTER(SettleOut)]),
     "navhip_arrival_settle_dev": (C.c_int, [C.c_void_p, C.POINTER(World), C.POINTER(SettleIn), C.POINTER(SettleOut),
@@ -786,6 +799,57 @@ def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_
     return st, fl, ticks
 
 
+def _ctx_state_pass(self, arrays, next_rot, new_vel_xz, vdes_xz, flock_layer, flock_nearest_xz, flock_tiles, skip=None,
+                    aux=None, work=None):
+    """The state half of the tick in one call (navhip_state_pass): heading gate -> state update -> flag / counter arms.
+    aux: dict(fstate, wait_ticks_left, wait_prev[, ent_rot, target_dir][, range_in]) or None.  Returns a dict of the
+    outputs (state, flags, gate, new_pos_xz, vel_xz, wait_ticks_left)."""
+    w, keep = make_world(self.w, self.h, arrays)
+    if work is not None:
+        w.work_begin, w.work_end = work
+    n = w.n_ents
+    f32 = lambda a, width: np.ascontiguousarray(a, np.float32).reshape(n, width)
+    k = [f32(next_rot, 4), f32(new_vel_xz, 2), f32(vdes_xz, 2), np.ascontiguousarray(flock_layer, np.uint8),
+         np.ascontiguousarray(flock_nearest_xz, np.float32).reshape(-1, 2)]
+    offs = np.zeros(len(flock_tiles) + 1, np.int32)
+    offs[1:] = np.cumsum([len(t) for t in flock_tiles])
+    tiles = np.ascontiguousarray(np.concatenate([np.asarray(t, np.int16).reshape(-1, 2) for t in flock_tiles] + [np.zeros((1, 2), np.int16)]))
+    k += [offs, tiles]
+    pi = StatePassIn()
+    pi.gate = GateIn(k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data)
+    pi.state.flock_layer, pi.state.flock_nearest_xz = k[3].ctypes.data, k[4].ctypes.data
+    pi.state.flock_tiles_off, pi.state.flock_tiles = offs.ctypes.data, tiles.ctypes.data
+    if skip is not None:
+        k.append(np.ascontiguousarray(skip, np.uint8))
+        pi.state.skip = k[-1].ctypes.data
+    if aux is not None:
+        a = [np.ascontiguousarray(aux["fstate"], np.uint8), np.ascontiguousarray(aux["wait_ticks_left"], np.int32),
+             np.ascontiguousarray(aux["wait_prev"], np.uint8)]
+        k += a
+        pi.aux.fstate, pi.aux.wait_ticks_left, pi.aux.wait_prev = [x.ctypes.data for x in a]
+        if aux.get("ent_rot") is not None:
+            r = [f32(aux["ent_rot"], 4), f32(aux["target_dir"], 4)]
+            k += r
+            pi.aux.ent_rot, pi.aux.target_dir = r[0].ctypes.data, r[1].ctypes.data
+        ri = aux.get("range_in")
+        if ri is not None:
+            ro = np.zeros(len(ri["tiles"]) + 1, np.int32)
+            ro[1:] = np.cumsum([len(t) for t in ri["tiles"]])
+            rt = np.ascontiguousarray(np.concatenate([np.asarray(t, np.int16).reshape(-1, 2) for t in ri["tiles"]] + [np.zeros((1, 2), np.int16)]))
+            r = [np.ascontiguousarray(ri["target"], np.int32), np.ascontiguousarray(ri["range"], np.float32), f32(ri["prev_xz"], 2),
+                 np.ascontiguousarray(ri["tiles_row"], np.int32), ro, rt]
+            k += r
+            pi.aux.range_target, pi.aux.target_range, pi.aux.target_prev_xz, pi.aux.range_tiles_row, pi.aux.range_tiles_off, \
+                pi.aux.range_tiles = [x.ctypes.data for x in r]
+            pi.aux.n_range_rows = len(ri["tiles"])
+    res = {"state": np.zeros(n, np.uint8), "flags": np.zeros(n, np.uint8), "gate": np.zeros(n, np.uint8),
+           "new_pos_xz": np.zeros((n, 2), np.float32), "vel_xz": np.zeros((n, 2), np.float32),
+           "wait_ticks_left": np.zeros(n, np.int32)}
+    po = StatePassOut(*[res[f].ctypes.data for f in ("state", "flags", "gate", "new_pos_xz", "vel_xz", "wait_ticks_left")])
+    self._chk(lib().navhip_state_pass(self._h, C.byref(w), C.byref(pi), C.byref(po)), "navhip_state_pass")
+    return res
+
+
 def _ctx_settled_count(self, arrays, uids):
     """adjacent_settled_count (movement.c:982) for the units `uids` of the snapshot `arrays` (pos_xz, radius,
     flags, state); -1 = the host counts (radius > 12.5)."""
@@ -942,6 +1006,7 @@ NavContext.pool_invalidate = _ctx_pool_invalidate
 NavContext.region_lookup = _ctx_region_lookup
 NavContext.state_update = _ctx_state_update
 NavContext.heading_gate = _ctx_heading_gate
+NavContext.state_pass = _ctx_state_pass
 NavContext.state_update_aux = _ctx_state_update_aux
 NavContext.settled_count = _ctx_settled_count
 NavContext.arrival_settle = _ctx_arrival_settle

@@ -59,6 +59,9 @@ int main(void){
     printf("sizeof.navhip_settle_in %zu\n", sizeof(navhip_settle_in));
     printf("sizeof.navhip_settle_out %zu\n", sizeof(navhip_settle_out));
     printf("sizeof.navhip_state_aux_in %zu\n", sizeof(navhip_state_aux_in));
+    printf("sizeof.navhip_state_pass_in %zu\n", sizeof(navhip_state_pass_in));
+    printf("sizeof.navhip_state_pass_out %zu\n", sizeof(navhip_state_pass_out));
+    P(navhip_state_pass_in, state); P(navhip_state_pass_in, aux);
     P(navhip_state_aux_in, ent_rot); P(navhip_state_aux_in, range_tiles); P(navhip_state_aux_in, n_range_rows);
     P(navhip_arrival_zone, radius); P(navhip_arrival_zone, key_end);
     P(navhip_settle_in, zones); P(navhip_settle_in, uid); P(navhip_settle_in, stuck);
@@ -90,13 +93,16 @@ int main(void){
         assert got["navhip_world." + f] == getattr(navlib.World, f).offset, f
     assert got["navhip_step_out.status"] == navlib.StepOut.status.offset
     for name, cls in (("gate_in", navlib.GateIn), ("arrival_zone", navlib.ArrivalZone), ("settle_in", navlib.SettleIn),
-                      ("settle_out", navlib.SettleOut), ("state_aux_in", navlib.StateAuxIn)):
+                      ("settle_out", navlib.SettleOut), ("state_aux_in", navlib.StateAuxIn),
+                      ("state_pass_in", navlib.StatePassIn), ("state_pass_out", navlib.StatePassOut)):
         assert got["sizeof.navhip_" + name] == C.sizeof(cls), name
     assert got["sizeof.navhip_arrival_zone"] == 48
     for f in ("radius", "key_end"):
         assert got["navhip_arrival_zone." + f] == getattr(navlib.ArrivalZone, f).offset, f
     for f in ("zones", "uid", "stuck"):
         assert got["navhip_settle_in." + f] == getattr(navlib.SettleIn, f).offset, f
+    for f in ("state", "aux"):
+        assert got["navhip_state_pass_in." + f] == getattr(navlib.StatePassIn, f).offset, f
     for f in ("ent_rot", "range_tiles", "n_range_rows"):
         assert got["navhip_state_aux_in." + f] == getattr(navlib.StateAuxIn, f).offset, f
 
@@ -183,6 +189,7 @@ def test_invalid_arguments_are_rejected(navlib):
     assert L.navhip_arrival_settle_dev(None, C.byref(w), C.byref(navlib.SettleIn()), C.byref(navlib.SettleOut()), None) == -1
     assert L.navhip_state_update_aux(None, C.byref(w), C.byref(navlib.StateAuxIn()), None, None, None) == -1
     assert L.navhip_state_update_aux_dev(None, C.byref(w), C.byref(navlib.StateAuxIn()), None, None, None, None) == -1
+    assert L.navhip_state_pass(None, C.byref(w), C.byref(navlib.StatePassIn()), C.byref(navlib.StatePassOut())) == -1
 
 
 def _gpu_visible():

@@ -301,6 +301,32 @@ def test_state_aux_arms_match_entity_compute_update(navlib):
     st, fl, got_ticks = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0, ent_rot=ent_rot, target_dir=target_dir,
                                               range_in=range_in)
     st_t, fl_t, _ = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0)      # (without the turning inputs)
+    # ONE call for the whole pass (navhip_state_pass): the gate in front (every facing on its heading here: nobody turns),
+    # the state update on the gate's positions, the flag arms -- the answers of the three calls above
+    heading = np.where(np.linalg.norm(vdes, axis=1, keepdims=True) > 1.0 / 1024, vdes, new_vel)
+    heading = np.where(np.linalg.norm(heading, axis=1, keepdims=True) > 1.0 / 1024, heading, np.float32([1, 0]))
+    next_rot = pfref.RefMove.dir_quat(heading)
+    aux_in = {"fstate": fstate, "wait_ticks_left": ticks, "wait_prev": prev, "ent_rot": ent_rot, "target_dir": target_dir,
+              "range_in": range_in}
+    one = ctx.state_pass(arrays, next_rot, new_vel, vdes, np.zeros(k, np.uint8), nearest, tiles, aux=aux_in)
+    assert not one["gate"].any() and np.array_equal(one["new_pos_xz"], new_pos) and np.array_equal(one["vel_xz"], new_vel)
+    assert np.array_equal(one["state"], st) and np.array_equal(one["flags"], fl) and np.array_equal(one["wait_ticks_left"], got_ticks)
+    part = ctx.state_pass(arrays, next_rot, new_vel, vdes, np.zeros(k, np.uint8), nearest, tiles, aux=aux_in, work=(400, 2100))
+    assert np.array_equal(part["state"][400:2100], st[400:2100]) and not part["flags"][:400].any() and not part["new_pos_xz"][2100:].any()
+    # without the aux inputs it is gate + state update
+    two = ctx.state_pass(arrays, next_rot, new_vel, vdes, np.zeros(k, np.uint8), nearest, tiles)
+    assert np.array_equal(two["state"], st0) and np.array_equal(two["flags"], fl0)
+    # a unit whose facing is within the gate's margin of a tolerance is the host's altogether: state and counter untouched
+    rot_m = next_rot.copy()
+    pick = np.flatnonzero((world["state"] == 0) & (np.linalg.norm(new_vel, axis=1) > 0.01))[:40]
+    tol = np.where(np.linalg.norm(world["vel_xz"][pick], axis=1) > 1.0 / 1024, 90.0, 10.0)
+    a0 = np.arctan2(heading[pick, 1], heading[pick, 0]) + np.deg2rad(tol)
+    rot_m[pick] = pfref.RefMove.dir_quat(np.stack([np.cos(a0), np.sin(a0)], 1))
+    m = ctx.state_pass(arrays, rot_m, new_vel, vdes, np.zeros(k, np.uint8), nearest, tiles, aux=aux_in)
+    gh = (m["gate"] & navlib.GATE_HOST) != 0
+    assert gh[pick].sum() >= 35 and not gh[np.setdiff1d(np.arange(n), pick)].any()
+    assert (m["flags"][gh] == navlib.SU_HOST).all() and np.array_equal(m["state"][gh], world["state"][gh])
+    assert np.array_equal(m["state"][~gh], st[~gh]) and np.array_equal(m["flags"][~gh], fl[~gh])
     # a slab call decides its rows only
     st_s, fl_s, ticks_s = ctx.state_update_aux(arrays, fstate, ticks, prev, new_pos, st0, fl0, work=(400, 2100),
                                                ent_rot=ent_rot, target_dir=target_dir, range_in=range_in)
