@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The STATE half of the reference's movement tick (fork_join_state_updates, movement.c:4196) at a benchmark
-configuration through the binding: bindings/permafrost/move_hip.c's move_hip_state_work -- ONE heading gate, ONE state
-update, the settle pass for units of arriving flocks, ONE pass for the flag / counter arms (csrc/state_kernels.hip), host
+configuration through the binding: bindings/permafrost/move_hip.c's move_hip_state_work -- ONE navhip_state_pass (heading
+gate -> state update -> flag / counter arms, csrc/state_kernels.hip) and the settle pass for units of arriving flocks, host
 buffers and PCIe included -- against the reference's own entity_compute_update per unit on one core, with every unit's
 next state and flags compared.  Prints one JSON line.  bench.py runs it in a process of its own (`dropin.state_pass`):
 a fault in this newest part of the library must not take the benchmark line with it.
@@ -60,7 +60,7 @@ def main():
     ref_state, ref_flags = mv.state_update(new_vel, vdes)
     t_ref = time.perf_counter() - t0
     out = {"what": "state half of the reference's movement tick, %d work items, %d flocks, %dx%d chunks: move_hip_state_work "
-                   "+ move_hip_update_work's device part (host buffers) vs entity_compute_update per unit on one core"
+                   "(ONE navhip_state_pass, host buffers) vs entity_compute_update per unit on one core"
                    % (N, K, W, W),
            "cpu_ms_per_tick_1core": t_ref * 1e3}
     try:
