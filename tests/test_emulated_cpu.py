@@ -83,13 +83,14 @@ def test_gpu_parity_tests_pass_on_the_emulated_library(strict):
 
 
 def test_reference_binding_drives_the_emulated_library():
-    """tests/test_binding_gpu.py -- the reference's own movement tick, field requests, field cache and blocker calls
+    """tests/test_binding_gpu.py and tests/test_state_binding_gpu.py -- the reference's own movement tick (both halves), field requests, field cache and blocker calls
     going through bindings/permafrost/*.c into the C ABI -- with the emulator build answering instead of libnavhip.so:
     the harness (oracle/_ref/libpfref.so) links the product library by name, so the emulator build is preloaded and its
     navhip_* symbols interpose."""
     lib = hostsim.build_navhip_emu()
     env = dict(os.environ, NAVHIP_LIB=lib, LD_PRELOAD=lib, EMU_STRICT_POINTERS="1")
-    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "tests/test_binding_gpu.py"]
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "tests/test_binding_gpu.py",
+           "tests/test_state_binding_gpu.py"]
     try:
         import xdist  # noqa: F401
         cmd += ["-n", str(min(8, os.cpu_count() or 1))]

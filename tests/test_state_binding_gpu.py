@@ -1,0 +1,171 @@
+"""The state half of the reference's movement tick through bindings/permafrost/move_hip.c (move_hip_state_work ->
+navhip_state_pass + the settle calls; csrc/state_kernels.hip) against the reference's own entity_compute_update: the arrival
+arm and the arms added at the end of round 4 -- arrival zones, formation flags, wait counters, turning, enter-range.  Sorted behind the older GPU tests on purpose: this
+part of the library had not run on a GPU when it was written."""
+import numpy as np
+import pytest
+
+from oracle import pfref
+from tests import cases
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not pfref.available(), reason="oracle/_ref (the reference build) is not present")]
+
+
+def test_state_updates_through_the_binding():
+    """fork_join_state_updates through bindings/permafrost/move_hip.c: the snapshot tables + the two
+    destination-only nav queries of arrived() per flock -> ONE navhip_state_update for the slab
+    (move_hip_state_work), then move_hip_update_work = move_update_work with the switch's outcome taken from
+    the device for every unit it decided.  Next state and blocker flag of every unit == the reference's own
+    entity_compute_update."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        assert nav.hip_init(), "no MI355X visible"
+        got = mv.state_update_hip(new_vel, vdes)
+        assert got is not None
+        st, fl, dv = got
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        decided = (dv & 0x80) == 0
+        moving = np.isin(world["state"], (0, 1))
+        # the device decided most units, every branch among them
+        assert decided.sum() > 0.7 * n          # (not: WAITING / TURNING units, the fifth on the other nav layer)
+        assert (decided & moving & (st == 2)).sum() > 100 and (decided & moving & (st == 4)).sum() > 10
+        assert (decided & moving & (fl == 0)).sum() > 100
+        stats = mv.hip_state_stats()
+        assert stats[0] == decided.sum() and stats[1] == n - decided.sum() and stats[2] == 1
+        # a slab of the work items
+        part = mv.state_update_hip(new_vel, vdes, begin=500, end=1700)
+        assert np.array_equal(part[0][500:1700], ref_state[500:1700]) and np.array_equal(part[1][500:1700], ref_flags[500:1700])
+        # the host loops forked over worker threads: the same answers
+        mv.hip_threads(4, min_items=64)
+        try:
+            for _ in range(2):
+                st2, fl2, dv2 = mv.state_update_hip(new_vel, vdes)
+                assert np.array_equal(st2, ref_state) and np.array_equal(fl2, ref_flags) and np.array_equal(dv2, dv)
+        finally:
+            mv.hip_threads(1)
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
+
+
+def test_arrival_settle_through_the_binding():
+    """The same pass with ACTIVE arrival zones on two flocks (struct arrival_state with a footprint, slots and fill
+    ranks): their units take the G_Arrival_ShouldSettle arm of entity_compute_update (movement.c:2443-2451).  The
+    binding gathers them, counts their settled neighbours and runs the rule on the device (navhip_settled_count,
+    navhip_arrival_settle), and the heading gate of every unit in one navhip_heading_gate: next state and blocker
+    flag of every unit == the reference's own, and what the device's rule leaves in each unit's arrival state ==
+    what the reference's leaves there."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    rng = np.random.RandomState(31)
+    zones = {}
+    for f, (fill, active_row, num_rows) in ((0, (0.8, 1, 3)), (3, (0.95, 2, 3))):
+        t = world["flock_target_xz"][f]
+        cell = (int((t[1] + 4 * 128.0) // 4), int((4 * 128.0 - t[0]) // 4))
+        zones[f] = cases.arrival_zone_at(grid, cell, 8, rng, fill, active_row, num_rows)
+        # the flock's units: round the zone, a share of them on slots
+        m = np.flatnonzero(world["flock"] == f)
+        world["pos_xz"][m] = (zones[f]["centre_xz"] + rng.normal(0, 22.0, (len(m), 2))).astype(np.float32)
+        on = m[rng.rand(len(m)) < 0.3]
+        world["pos_xz"][on] = zones[f]["slots_xz"][rng.randint(len(zones[f]["slots_xz"]), size=len(on))] \
+            + rng.normal(0, 0.7, (len(on), 2)).astype(np.float32)
+    world["pos_xz"] = np.clip(world["pos_xz"], -4 * 128.0 + 14, 4 * 128.0 - 14).astype(np.float32)
+    in_zone = np.isin(world["flock"], list(zones)) & (world["radius"] < 5.0)
+    sink = world["pos_xz"] + rng.normal(0, 12.0, (n, 2)).astype(np.float32)
+    for f, z in zones.items():
+        m = np.flatnonzero(world["flock"] == f)
+        sink[m] = z["slots_xz"][rng.randint(len(z["slots_xz"]), size=len(m))]
+    units = {"substate": rng.randint(0, 4, n).astype(np.uint8), "sink_valid": (rng.rand(n) < 0.7).astype(np.uint8),
+             "sink_xz": sink.astype(np.float32), "order_pos_xz": (world["pos_xz"] + rng.normal(0, 3.5, (n, 2))).astype(np.float32),
+             "progress_anchor_xz": (world["pos_xz"] + rng.normal(0, 1.4, (n, 2))).astype(np.float32),
+             "progress_anchored": (rng.rand(n) < 0.7).astype(np.uint8), "stuck": rng.randint(0, 14, n).astype(np.int32)}
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        for f, z in zones.items():
+            assert mv.set_arrival_zone(f, z) == len(z["tiles"])
+        mv.set_arrival_units(units)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        ref_after = mv.get_arrival_units()
+        changed = (ref_after["substate"] != units["substate"]) | (ref_after["stuck"] != units["stuck"])
+        assert changed[in_zone].sum() > 100 and not changed[~np.isin(world["flock"], list(zones))].any()
+        mv.set_arrival_units(units)
+        assert nav.hip_init(), "no MI355X visible"
+        st, fl, dv = mv.state_update_hip(new_vel, vdes)
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        after = mv.get_arrival_units()
+        for k in after:
+            assert np.array_equal(after[k], ref_after[k]), k
+        decided, settled, differ, gate_host = mv.hip_settle_stats()
+        moving = np.isin(world["state"], (0, 1)) & ((world["flags"] & (1 << 18)) == 0)
+        assert decided == (in_zone & moving).sum() > 300
+        assert settled > 30 and differ == 0 and gate_host == 0
+        # the units of the zones are the device's now
+        assert ((dv[in_zone & moving] & 0x80) == 0).all()
+        assert (in_zone & moving & (st == 2)).sum() >= settled and (in_zone & moving & (st == 0)).sum() > 50
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
+
+
+def test_formation_and_wait_arms_through_the_binding():
+    """The state pass with formation flags and wait counters in play (movement.c:2423-2437, :2630-2668): members on
+    the move are no longer the host's -- the arrival arm answers for them and navhip_state_update_aux overrides where
+    the flags decide --, ARRIVING_TO_CELL, WAITING, TURNING and ENTER_ENTITY_RANGE units are decided on the device, UPDATE_SET_MOVING, UPDATE_SET_DEST and
+    UPDATE_SET_TARGET_DIR reach the patch.  Every unit's next state and flags == entity_compute_update's, the wait
+    counters the device returns == the ones the reference leaves in movestate."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    rng = np.random.RandomState(12)
+    world["state"] = world["state"].copy()
+    u = rng.rand(n)
+    world["state"][u < 0.10] = 8
+    world["state"][(u >= 0.10) & (u < 0.18)] = 1
+    world["state"][(u >= 0.18) & (u < 0.26)] = 4
+    fstate = ((rng.rand(n) < 0.45) * 1 | (rng.rand(n) < 0.7) * 2 | (rng.rand(n) < 0.7) * 4 | (rng.rand(n) < 0.5) * 8
+              | (rng.rand(n) < 0.5) * 16).astype(np.uint8)
+    ticks = rng.choice([1, 1, 2, 3, 40], n).astype(np.int32)
+    prev = rng.choice([0, 1, 3, 5], n).astype(np.uint8)
+    # STATE_TURNING units (:2606-2628): the rotation against movestate.target_dir, half of them within the 5 degrees
+    world["state"][(u >= 0.26) & (u < 0.34)] = 7
+    ang = rng.uniform(-np.pi, np.pi, n)
+    off = np.where(rng.rand(n) < 0.5, rng.uniform(-4.5, 4.5, n), rng.uniform(6, 180, n) * rng.choice([-1, 1], n))
+    target_dir = pfref.RefMove.dir_quat(np.stack([np.cos(ang), np.sin(ang)], 1))
+    ent_rot = pfref.RefMove.dir_quat(np.stack([np.cos(ang + np.deg2rad(off)), np.sin(ang + np.deg2rad(off))], 1))
+    # STATE_ENTER_ENTITY_RANGE units (:2569-2604): a target among the neighbours (or none), a range, where the target stood
+    world["state"][(u >= 0.34) & (u < 0.46)] = 6
+    er = np.flatnonzero(world["state"] == 6)
+    tgt = np.full(n, -1, np.int32)
+    for i in er:
+        if rng.rand() < 0.9:
+            d = np.linalg.norm(world["pos_xz"] - world["pos_xz"][i], axis=1)
+            d[i] = np.inf
+            tgt[i] = np.argsort(d)[rng.randint(1, 60)]
+    t_range = rng.choice([0.0, 5.0, 20.0, 60.0], n).astype(np.float32)
+    t_prev = (world["pos_xz"][np.maximum(tgt, 0)] + rng.normal(0, 4.0, (n, 2))).astype(np.float32)
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        mv.set_state_aux(fstate, ticks, prev)
+        mv.set_turning(ent_rot, target_dir)
+        mv.set_range_targets(tgt, t_range, t_prev)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        ref_ticks = mv.get_wait_ticks()
+        assert (ref_flags & 4).sum() > 50 and (ref_flags & 8).sum() > 10 and (ref_flags & 16).sum() > 20
+        assert ((world["state"] == 6) & (ref_state == 4)).sum() > 30 and ((world["state"] == 6) & (ref_state == 2)).sum() > 10
+        assert ((world["state"] == 7) & (ref_state == 2)).sum() > 50 and ((world["state"] == 7) & (ref_state == 7)).sum() > 50
+        mv.set_state_aux(fstate, ticks, prev)
+        assert nav.hip_init(), "no MI355X visible"
+        st, fl, dv = mv.state_update_hip(new_vel, vdes)
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        assert np.array_equal(mv.get_wait_ticks(), ref_ticks) and mv.hip_wait_differ() == 0
+        decided = (dv & 0x80) == 0
+        garr = (world["flags"] & (1 << 18)) != 0
+        assert decided[np.isin(world["state"], (4, 6, 7, 8)) | garr].all()
+        assert decided.sum() > 0.9 * n          # (not: the units on another nav layer than their flock's tables)
+        assert (decided & (fl == 4)).sum() > 50 and (decided & (fl == 9) & (st == 7)).sum() > 10
+        assert (decided & np.isin(world["state"], (0, 1)) & (st == 8)).sum() > 50
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()

@@ -2,6 +2,8 @@
 adjacent_settled_count and the arrival overlay's settle rule, each against the reference's own code
 (oracle/_ref: movement.c's entity_compute_update / adjacent_settled_count, arrival.c's G_Arrival_ShouldSettle)
 through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -418,3 +420,42 @@ def test_state_pass_rejects_bad_arguments(navlib):
     ai.ent_rot = None
     assert L.navhip_state_update_aux(*args) == 0
     ctx.close()
+
+
+def test_state_pass_matches_golden(navlib):
+    """The heading gate, the settled-neighbour count and the arrival overlay's settle rule (csrc/state_kernels.hip)
+    against answers of the reference's own entity_compute_update / adjacent_settled_count / G_Arrival_ShouldSettle kept
+    in tests/golden/state_4x4.npz (tests/tools/make_golden.py --state)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_4x4.npz"))
+    ctx = navlib.NavContext(4, 4)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, g["zone_cost"])
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, g["zone_blockers"])
+    # the gate
+    arrays = {"pos_xz": g["gate_pos"], "vel_xz": g["gate_vel"], "state": g["gate_state"]}
+    vel, new_pos, gate = ctx.heading_gate(arrays, g["gate_next_rot"], g["gate_new_vel"], g["gate_vdes"])
+    host = (gate & navlib.GATE_HOST) != 0
+    ok = ~host & (g["gate_state"] != 7)
+    assert np.array_equal((gate & navlib.GATE_TURN)[ok] != 0, g["gate_turn"][ok].astype(bool))
+    assert 0 < host.sum() <= g["gate_tight"].sum() and g["gate_turn"][ok].sum() > 500
+    # the count
+    arrays = {"pos_xz": g["count_pos"], "radius": g["count_radius"], "flags": g["count_flags"], "state": g["count_state"]}
+    assert np.array_equal(ctx.settled_count(arrays, g["count_uids"]), g["count_ref"])
+    # the settle rule
+    nz = int(g["n_zones"])
+    zones, keys, units, ref = [], [], [], []
+    for i in range(nz):
+        sc, fl = g["zone%d_scalars" % i], g["zone%d_floats" % i]
+        zones.append({"layer": sc[0], "radius": sc[1], "active_row": sc[2], "num_rows": sc[3], "centre_xz": fl[:2],
+                      "unit_radius": fl[2], "fill_frac": fl[3], "slots_xz": g["zone%d_slots" % i], "slot_ring": g["zone%d_ring" % i]})
+        keys.append(g["zone%d_keys" % i])
+        units.append({f[len("unit%d_" % i):]: g[f] for f in g.files if f.startswith("unit%d_" % i)})
+        ref.append({f[len("ref%d_" % i):]: g[f] for f in g.files if f.startswith("ref%d_" % i)})
+    cat = {f: np.concatenate([u[f] for u in units]) for f in units[0]}
+    nq = len(cat["zone"])
+    cat["uid"] = np.arange(nq, dtype=np.int32)
+    world = {"pos_xz": np.zeros((nq, 2), np.float32), "vel_xz": cat["vel_xz"], "radius": cat["radius"]}
+    settle, after = ctx.arrival_settle(world, zones, keys, cat)
+    ctx.close()
+    assert np.array_equal(settle, np.concatenate([r["settle"] for r in ref])) and 100 < settle.sum() < nq - 100
+    for f in after:
+        assert np.array_equal(after[f], np.concatenate([r[f] for r in ref])), f
