@@ -459,3 +459,77 @@ def test_state_pass_matches_golden(navlib):
     assert np.array_equal(settle, np.concatenate([r["settle"] for r in ref])) and 100 < settle.sum() < nq - 100
     for f in after:
         assert np.array_equal(after[f], np.concatenate([r[f] for r in ref])), f
+
+
+def test_segment_within_region_edge_cases_through_the_settle_rule(navlib):
+    """N_SegmentWithinRegion (nav.c:4326) over the supercover walk (tile.c:430) where its floats degenerate: segments
+    along an axis (a zero direction component: infinite / NaN t_max and t_delta), of zero length, starting or ending
+    exactly on tile and chunk boundaries, crossing a chunk border, crossing a wall in the footprint, ending outside the
+    footprint or off the map.  The zone and the units are built so that the rule's answer IS the walk's: nearly full, no
+    open slot anywhere, every unit armed, inside the footprint, in contact with two settled neighbours and advancing on
+    its slot -- it settles exactly when the slot is NOT reachable (by_contact, arrival.c:1029)."""
+    grid, nav = cases.ref_nav_for(4, 4, seed=21, layer_mask=0x1)
+    rng = np.random.RandomState(2)
+    # the footprint: a 40 x 40 block of tiles straddling the corner of four chunks, with a wall (a missing band) in it
+    r0, c0 = 108, 108
+    rr, cc = np.mgrid[r0:r0 + 40, c0:c0 + 40]
+    keep = ~((cc == c0 + 22) & (rr > r0 + 6) & (rr < r0 + 34))                # the wall: one column, open at both ends
+    tiles = np.stack([rr[keep], cc[keep]], 1)
+    region_xz = np.array([synth.cell_centre(4, 4, r, c) for r, c in tiles], np.float32)
+    zone = {"layer": 0, "centre_xz": np.array(synth.cell_centre(4, 4, r0 + 20, c0 + 20), np.float32), "radius": 20,
+            "unit_radius": 1.0, "fill_frac": 0.95, "active_row": 0, "num_rows": 4,
+            "slots_xz": region_xz[::50].copy(), "slot_ring": np.full(len(region_xz[::50]), 3, np.int32),   # no slot is open yet
+            "region_xz": region_xz, "tiles": tiles}
+
+    def corner(r, c):                                   # the world position of a tile's corner: x = map_x - c * 4, z = map_z + r * 4
+        return (4 * 128.0 - c * 4.0, -4 * 128.0 + r * 4.0)
+
+    pos, sink = [], []
+    inner = tiles[(tiles[:, 0] > r0 + 2) & (tiles[:, 0] < r0 + 37) & (tiles[:, 1] > c0 + 2) & (tiles[:, 1] < c0 + 37)]
+    for _ in range(1500):
+        a = inner[rng.randint(len(inner))]
+        kind = rng.randint(8)
+        ax, az = synth.cell_centre(4, 4, a[0], a[1]) + rng.uniform(-1.9, 1.9, 2)
+        if kind == 0:                                   # along x: same z, to the bit
+            b = inner[rng.randint(len(inner))]
+            bx, bz = synth.cell_centre(4, 4, a[0], b[1])[0] + rng.uniform(-1.9, 1.9), az
+        elif kind == 1:                                 # along z
+            b = inner[rng.randint(len(inner))]
+            bx, bz = ax, synth.cell_centre(4, 4, b[0], a[1])[1] + rng.uniform(-1.9, 1.9)
+        elif kind == 2:                                 # zero length
+            bx, bz = ax, az
+        elif kind == 3:                                 # from a tile corner to a tile corner (on boundaries, often on a diagonal)
+            ax, az = corner(a[0], a[1])
+            b = inner[rng.randint(len(inner))]
+            bx, bz = corner(b[0], b[1])
+        elif kind == 4:                                 # on the chunk border row / column, along it
+            ax, az = corner(128, a[1]) if rng.rand() < 0.5 else corner(a[0], 128)
+            b = inner[rng.randint(len(inner))]
+            bx, bz = (corner(128, b[1]) if az == -4 * 128.0 + 128 * 4.0 else corner(b[0], 128))
+        elif kind == 5:                                 # ends outside the footprint, or off the map
+            far = rng.rand() < 0.3
+            bx, bz = (ax + rng.uniform(-1, 1) * (2000 if far else 200), az + rng.uniform(-1, 1) * (2000 if far else 200))
+        else:                                           # anything inside: some cross the wall, some the chunk corner
+            b = inner[rng.randint(len(inner))]
+            bx, bz = synth.cell_centre(4, 4, b[0], b[1]) + rng.uniform(-1.9, 1.9, 2)
+        pos.append((ax, az)); sink.append((bx, bz))
+    pos, sink = np.array(pos, np.float32), np.array(sink, np.float32)
+    nq = len(pos)
+    to_sink = sink - pos
+    vel = (to_sink / np.maximum(np.linalg.norm(to_sink, axis=1, keepdims=True), 1e-3) * 0.5).astype(np.float32)
+    vel[np.linalg.norm(to_sink, axis=1) == 0] = (0.5, 0.0)                    # (zero length: dot = 0, not advancing either way)
+    units = {"zone": np.zeros(nq, np.int32), "new_pos_xz": pos, "vel_xz": vel, "radius": np.ones(nq, np.float32),
+             "nsettled": np.full(nq, 2, np.int32), "substate": np.full(nq, 3, np.uint8), "sink_valid": np.ones(nq, np.uint8),
+             "sink_xz": sink, "order_pos_xz": pos + 100, "progress_anchor_xz": pos.copy(),
+             "progress_anchored": np.ones(nq, np.uint8), "stuck": np.zeros(nq, np.int32)}
+    ref, keys, ref_after = pfref.arrival_should_settle(nav, zone, units)
+    ctx = _upload(navlib, nav, layers=(0,))
+    world = {"pos_xz": np.zeros((nq, 2), np.float32), "vel_xz": vel, "radius": units["radius"]}
+    got, after = ctx.arrival_settle(world, [zone], [keys], dict(units, uid=np.arange(nq, dtype=np.int32)))
+    ctx.close()
+    bad = np.flatnonzero(got != ref)
+    assert len(bad) == 0, [(int(i), pos[i].tolist(), sink[i].tolist(), int(got[i]), int(ref[i])) for i in bad[:8]]
+    for f in after:
+        assert np.array_equal(after[f], ref_after[f]), f
+    # reachable and not, in every family of segments
+    assert 300 < ref.sum() < nq - 300, ref.sum()
