@@ -533,3 +533,28 @@ def test_segment_within_region_edge_cases_through_the_settle_rule(navlib):
         assert np.array_equal(after[f], ref_after[f]), f
     # reachable and not, in every family of segments
     assert 300 < ref.sum() < nq - 300, ref.sum()
+
+
+def test_heading_gate_with_tilted_and_unnormalised_rotations(navlib):
+    """The gate with rotations that are not unit yaw quaternions -- a pitch / roll component, a length other than one,
+    the zero quaternion: PFM_Quat_PitchDiff (pf_math.c:677) projects the turned front on the ground plane whatever the
+    rotation is, and so does the device."""
+    nav, world, new_vel, vdes, facing, off, tight = gate_inputs()
+    n = len(world["state"])
+    rng = np.random.RandomState(4)
+    q = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    q[:, [0, 2]] *= rng.choice([0.0, 0.2, 1.0], (n, 1)).astype(np.float32)    # none, a little, a lot of tilt
+    q *= rng.choice([0.5, 1.0, 1.0, 3.0], (n, 1)).astype(np.float32) / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-6)
+    q[rng.rand(n) < 0.01] = 0
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        ref_turn, _ = mv.heading_gate(new_vel, vdes, q)
+    finally:
+        pfref.RefMove.unload()
+    ctx = navlib.NavContext(4, 4)
+    vel, new_pos, gate = ctx.heading_gate({k: world[k] for k in ("pos_xz", "vel_xz", "state")}, q, new_vel, vdes)
+    ctx.close()
+    host = (gate & navlib.GATE_HOST) != 0
+    ok = (world["state"] != 7) & ~host
+    assert np.array_equal(((gate & navlib.GATE_TURN) != 0)[ok], ref_turn[ok].astype(bool))
+    assert host.sum() < 0.01 * n and ref_turn[ok].sum() > 300 and (ref_turn[ok] == 0).sum() > 300
