@@ -6,7 +6,7 @@ buffers and PCIe included -- against the reference's own entity_compute_update p
 next state and flags compared.  Prints one JSON line.  bench.py runs it in a process of its own (`dropin.state_pass`):
 a fault in this newest part of the library must not take the benchmark line with it.
 
-    python scripts/bench_state_pass.py [--chunks 16] [--flocks 64] [--agents 100000] [--reps 5]
+    python scripts/bench_state_pass.py [--chunks 16] [--flocks 64] [--agents 100000] [--reps 3]
 """
 import argparse
 import json
@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=16)
     ap.add_argument("--flocks", type=int, default=64)
     ap.add_argument("--agents", type=int, default=100000)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
     import numpy as np
     from oracle import pfref
