@@ -68,5 +68,37 @@ def main(n_cases=24):
     return 1 if bad else 0
 
 
+def state_sweep(n_cases=24):
+    """The settle rule of the arrival overlay (navhip_arrival_settle) against the reference's own G_Arrival_ShouldSettle
+    (oracle/_ref) over many seeds of tests/test_state_gpu.py's zone world: answers and the unit state left behind."""
+    from oracle import pfref
+    from tests import test_state_gpu as T
+    if not pfref.available():
+        print("state sweep: oracle/_ref is not present")
+        return 0
+    bad = 0
+    for seed in range(100, 100 + n_cases):
+        grid, nav, zones, units = T._zone_world(seed=seed)
+        ref, keys, afters = [], [], []
+        for z, u in zip(zones, units):
+            s_, k_, a_ = pfref.arrival_should_settle(nav, z, u)
+            ref.append(s_); keys.append(k_); afters.append(a_)
+        ctx = T._upload(navhip, nav, layers=(0,))
+        cat = {f: np.concatenate([u[f] for u in units]) for f in units[0]}
+        nq = len(cat["zone"])
+        cat["uid"] = np.arange(nq, dtype=np.int32)
+        world = {"pos_xz": np.zeros((nq, 2), np.float32), "vel_xz": cat["vel_xz"], "radius": cat["radius"]}
+        got, after = ctx.arrival_settle(world, zones, keys, cat)
+        ctx.close()
+        r = np.concatenate(ref)
+        ok = np.array_equal(got, r) and all(np.array_equal(after[f], np.concatenate([a[f] for a in afters])) for f in after)
+        print("settle seed %d: %s (%d of %d settle)" % (seed, "ok" if ok else "DIFF", int(r.sum()), nq), flush=True)
+        bad += not ok
+    print("state sweep: %d mismatching cases of %d" % (bad, n_cases))
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
+    if "--state" in sys.argv:
+        sys.exit(state_sweep())
     sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 24))
