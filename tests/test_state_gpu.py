@@ -336,6 +336,13 @@ def test_state_aux_arms_match_entity_compute_update(navlib):
     assert np.array_equal(st_s[400:2100], st[400:2100]) and np.array_equal(fl_s[400:2100], fl[400:2100])
     assert np.array_equal(st_s[:400], st0[:400]) and np.array_equal(fl_s[2100:], fl0[2100:]) and not ticks_s[:400].any()
     host = (fl & navlib.SU_HOST) != 0
+    state = world["state"]
+    # every unit the pass decided: the reference's next state and flags; the wait counters of all
+    ok = ~host
+    bad = np.flatnonzero(ok & ((st != ref_state) | (fl != ref_flags)))
+    assert len(bad) == 0, [(int(i), int(state[i]), int(fstate[i]), int(st[i]), int(ref_state[i]), int(fl[i]), int(ref_flags[i]))
+                           for i in bad[:10]]
+    assert np.array_equal(got_ticks, ref_ticks)
     garr = (world["flags"] & (1 << 18)).astype(bool)
     big = world["radius"] >= 5.0
     state = world["state"]
@@ -358,11 +365,6 @@ def test_state_aux_arms_match_entity_compute_update(navlib):
     exp_host = ~garr & (t_host | (falls & big))
     # (less the few of them whose new position is not pathable: nothing happens to those, :2437, and the pass says so)
     assert not (host & ~exp_host).any() and (exp_host & ~host).sum() < 20 and host.sum() > 150, (host.sum(), exp_host.sum())
-    ok = ~host
-    bad = np.flatnonzero(ok & ((st != ref_state) | (fl != ref_flags)))
-    assert len(bad) == 0, [(int(i), int(state[i]), int(fstate[i]), int(st[i]), int(ref_state[i]), int(fl[i]), int(ref_flags[i]))
-                           for i in bad[:10]]
-    assert np.array_equal(got_ticks, ref_ticks)
     # every arm fired
     assert ((state == 4) & (fl == navlib.SU_SET_MOVING) & (st == prev)).sum() > 50 and ((state == 4) & (fl == 0) & ok).sum() > 50
     a2c = ok & (state == 8)
