@@ -121,10 +121,10 @@ def usable_cores():
 
 
 def state_pass_probe(chunk_w, k_fields, n_agents, timeout=240):
-    """scripts/bench_state_pass.py in a subprocess: its JSON line, or what went wrong."""
+    """tests/tools/bench_state_pass.py in a subprocess: its JSON line, or what went wrong."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_state_pass.py"), "--chunks", str(chunk_w),
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "bench_state_pass.py"), "--chunks", str(chunk_w),
                             "--flocks", str(k_fields), "--agents", str(n_agents)],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -9,7 +9,7 @@
 #   smoke   __graft_entry__.smoke()
 #   ranks2  bench.py --gpus 2 under torchrun, both ranks on the one GPU, gloo (a plumbing check, not a measurement)
 #   fuzz    tests/tools/fuzz_gpu.py
-#   statepass scripts/bench_state_pass.py (the state half of the movement tick through the binding) + its kernel stats
+#   statepass tests/tools/bench_state_pass.py (the state half of the movement tick through the binding) + its kernel stats
 #   aux     scripts/bench_aux.py (host-buffer rates, LOS)  + scripts/cp_unit_hist.py when its build is there
 TAG=$1; shift
 STEPS=${@:-tests bench calib stats}
@@ -53,8 +53,8 @@ smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smo
 ranks2) NAVHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; tail -c 400 $OUT/bench_2ranks_gloo.json ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log
       timeout 600 python tests/tools/fuzz_gpu.py --state > $OUT/fuzz_state.log 2>&1; tail -2 $OUT/fuzz_state.log ;;
-statepass) timeout 400 python scripts/bench_state_pass.py > $OUT/state_pass.json 2> $OUT/state_pass.err; tail -c 900 $OUT/state_pass.json; tail -2 $OUT/state_pass.err
-       timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/statepass -o s --output-format csv -- python scripts/bench_state_pass.py --reps 20 > $OUT/state_pass_under_prof.json 2> $OUT/statepass_prof.err
+statepass) timeout 400 python tests/tools/bench_state_pass.py > $OUT/state_pass.json 2> $OUT/state_pass.err; tail -c 900 $OUT/state_pass.json; tail -2 $OUT/state_pass.err
+       timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/statepass -o s --output-format csv -- python tests/tools/bench_state_pass.py --reps 20 > $OUT/state_pass_under_prof.json 2> $OUT/statepass_prof.err
        f=$(find $OUT/statepass -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|k_heading_gate|k_state_update|k_state_aux|k_settled_count|k_arrival_settle|k_spatial" $f | cut -c1-200 ;;
 esac
 done

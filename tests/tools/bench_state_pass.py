@@ -3,10 +3,11 @@
 configuration through the binding: bindings/permafrost/move_hip.c's move_hip_state_work -- ONE navhip_state_pass (heading
 gate -> state update -> flag / counter arms, csrc/state_kernels.hip) and the settle pass for units of arriving flocks, host
 buffers and PCIe included -- against the reference's own entity_compute_update per unit on one core, with every unit's
-next state and flags compared.  Prints one JSON line.  bench.py runs it in a process of its own (`dropin.state_pass`):
+next state and flags compared.  Prints one JSON line.  bench.py's cpu_baseline leg runs it in a process of its own (`dropin.state_pass`; it uses the reference
+build under oracle/, which is why it lives with the test tools):
 a fault in this newest part of the library must not take the benchmark line with it.
 
-    python scripts/bench_state_pass.py [--chunks 16] [--flocks 64] [--agents 100000] [--reps 3]
+    python tests/tools/bench_state_pass.py [--chunks 16] [--flocks 64] [--agents 100000] [--reps 3]
 """
 import argparse
 import json
@@ -14,7 +15,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
