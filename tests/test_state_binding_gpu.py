@@ -169,3 +169,24 @@ def test_formation_and_wait_arms_through_the_binding():
     finally:
         pfref.RefNav.hip_shutdown()
         pfref.RefMove.unload()
+
+
+@pytest.mark.parametrize("hz", [10, 5])
+def test_state_pass_at_lower_movement_rates(hz):
+    """Below 20 Hz entity_compute_update tests an INTERPOLATED position (movement.c:2368-2377), which the device pass is not
+    given: every unit whose answer depends on it is left to the host (NAVHIP_SU_HOST), the garrison rule and the states
+    without a transition are still the device's, and every unit's next state and flags equal the reference's."""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    mv, _ = cases.ref_move_for(nav, world, hz=hz)
+    try:
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        assert nav.hip_init(), "no MI355X visible"
+        st, fl, dv = mv.state_update_hip(new_vel, vdes)
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        host = (dv & 0x80) != 0
+        garr = (world["flags"] & (1 << 18)) != 0
+        assert host[np.isin(world["state"], (0, 1, 4, 7)) & ~garr].all() and not host[garr].any()
+        assert not host[np.isin(world["state"], (2, 3))].any()
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
