@@ -606,7 +606,8 @@ int  navhip_state_update(navhip_ctx *ctx, const navhip_world *world, const navhi
 int  navhip_state_update_dev(navhip_ctx *ctx, const navhip_world *dev_world, const navhip_state_in *dev_in,
                              uint8_t *dev_out_state, uint8_t *dev_out_flags, void *stream);
 
-/* ---- more of entity_compute_update: the heading gate and the arrival overlay's settle rule ----
+/* ---- more of entity_compute_update: the heading gate, the arms of the state switch that flags, a
+ *      counter, an angle or a distance decide, the arrival overlay's settle rule, and all of it but the last in one call ----
  *
  * The heading gate (movement.c:2319-2336): a unit in STATE_MOVING / SEEK_ENEMIES / SURROUND_ENTITY /
  * ENTER_ENTITY_RANGE (move_gated_by_heading, :2273) whose new velocity is longer than EPSILON does not translate
