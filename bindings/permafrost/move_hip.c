@@ -5,8 +5,7 @@
  * snapshot tables (struct move_gamestate, :296) and work items (struct move_work_in, :264), run
  * navhip_agent_step, copy the velocities into s_move_work.out[] like copy_gpu_results does
  * (:4248-4261).  It lives in movement.c's translation unit because those tables are static; in this
- * repository the test harness #include <time.h>
-#includes it right after movement.c (oracle/ref/ref_move.c).
+ * repository the test harness #includes it right after movement.c (oracle/ref/ref_move.c).
  *
  * With device sampling on (move_hip_set_device_sampling; needs the binding's resident pool,
  * N_HIP_PoolEnable in nav_hip.c) the per-agent N_DesiredPointSeekVelocity calls of
@@ -17,6 +16,7 @@
  */
 #include <navhip.h>
 #include <math.h>
+#include <time.h>      /* hip_now: clock_gettime (movement.c itself does not include it) */
 
 navhip_ctx *N_HIP_Ctx(void);          /* nav_hip.c */
 bool N_HIP_PoolOn(void);

@@ -30,7 +30,7 @@ def _dev():
 def _sync():
     torch = _torch()
     if _dev().type == "cuda":
-        _sync()
+        torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("bounds", [[0, 800, 1600], [0, 400, 1100, 1500], [0, 400, 800, 1200, 1600],
