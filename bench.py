@@ -20,10 +20,14 @@ then advance the snapshot.  --config selects the BASELINE.json configuration:
      destination / agent slab (strong scaling); runs on one GPU too.
   4  config 2 + 10 000 dynamic obstacles, 1 % moved per tick, incremental field repair.
 
-Prints ONE JSON line on rank 0.  `value` = agents x steps / wall time of the K timed steps (barrier +
-synchronize on both sides, max over ranks); the line also carries the MEDIAN tick (GPU timeline),
-ticks 5 / 50 / 100, a status histogram, the roofline of the dominant kernel, the reference's CPU
-rate on the same box, and (N = 1) a crowded-world secondary measurement.
+`--gpus N` with N > 1 started WITHOUT torchrun re-launches itself under `torch.distributed.run --nproc-per-node N`
+(one rank per GPU; it refuses, rc 3, when the node shows fewer than N devices).  N ranks split ONE world of the
+configuration's size (strong scaling: BASELINE.json's metric is "1024^2 map, 100k agents, 1/2/4/8 GPUs") unless
+`--scaling weak`; the weak-scaled job is run behind it and reported in `weak_scaling`.
+
+Prints ONE JSON line on rank 0, numbers only (what the keys mean: profiles/README.md, "the bench line"), shorter than
+6 KB with the summary of every regime LAST (`summary`), because the driver's record keeps the tail of the line.
+`value` = agents x steps / wall time of the K timed steps (barrier + synchronize on both sides, max over ranks).
 """
 import argparse
 import hashlib
@@ -206,24 +210,20 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10
                     t_cpu_all = t_a if m == n_agents else mv.bench(vdes, reps=1, nthreads=cores, begin=0, end=n_agents)[0]
                     if r is not None:
                         dt, parts = r
-                        drop = {"what": "velocity half of the reference's movement tick, %d work items: WORK_TYPE_HIP arm "
-                                        "(move_hip.c, host buffers through navhip_agent_step_submit/_wait; its fill / scatter "
-                                        "loops forked over %d threads) vs WORK_TYPE_CPU arm (move_velocity_work, %d pthreads), "
-                                        "same box" % (n_agents, host_threads, cores),
-                                "hip_ms_per_tick": dt / reps * 1e3, "cpu_ms_per_tick": t_cpu_all * 1e3, "cores": cores,
+                        # (what the keys mean: profiles/README.md, "the bench line")
+                        drop = {"work_items": n_agents, "host_threads": host_threads, "cores": cores,
+                                "hip_ms_per_tick": dt / reps * 1e3, "cpu_ms_per_tick": t_cpu_all * 1e3,
                                 "speedup": t_cpu_all / (dt / reps),
-                                "host_threads": host_threads,
-                                "hip_ms_fill_snapshot_and_work_items": parts["fill"] / reps * 1e3,
+                                "hip_ms_fill": parts["fill"] / reps * 1e3,
                                 "hip_ms_submit_to_wait": parts["device"] / reps * 1e3,
-                                "hip_ms_scatter_results": parts["scatter"] / reps * 1e3,
+                                "hip_ms_scatter": parts["scatter"] / reps * 1e3,
                                 "host_share": (parts["fill"] + parts["scatter"]) / dt,
                                 "agent_steps_per_s_hip": n_agents * reps / dt}
                         if r1 is not None:
-                            drop["host_loops_on_one_thread"] = {
-                                "hip_ms_per_tick": r1[0] / reps * 1e3,
-                                "hip_ms_fill_snapshot_and_work_items": r1[1]["fill"] / reps * 1e3,
+                            drop["one_host_thread"] = {
+                                "hip_ms_per_tick": r1[0] / reps * 1e3, "hip_ms_fill": r1[1]["fill"] / reps * 1e3,
                                 "hip_ms_submit_to_wait": r1[1]["device"] / reps * 1e3,
-                                "hip_ms_scatter_results": r1[1]["scatter"] / reps * 1e3}
+                                "hip_ms_scatter": r1[1]["scatter"] / reps * 1e3}
                 pfref.RefNav.hip_shutdown()
             except Exception as exc:
                 drop = {"error": repr(exc)}
@@ -252,31 +252,35 @@ def cpu_baseline(chunk_w, k_fields, n_agents, hz, whole=False, budget_field_s=10
                     nav.desired_velocities(ids8[ag["flock"][ag8]], ag["pos"][ag8], targets[ag["flock"][ag8]])
                     t_s = (time.perf_counter() - t0) / max(1, len(ag8))
                     sampling = {"us_per_agent_1core": t_s * 1e6, "agents_sampled": int(len(ag8)), "destinations": int(nd),
-                                "agent_steps_per_s_with_serial_sampling": 1.0 / (t_a / m + t_s),
-                                "note": "N_DesiredPointSeekVelocity is called per agent on the nav task before the velocity "
-                                        "work is forked (movement.c:4166): serial sampling + the forked velocity half"}
+                                "agent_steps_per_s_with_serial_sampling": 1.0 / (t_a / m + t_s)}
         except Exception as exc:
             sampling = {"error": repr(exc)}
         return {
             "dropin": drop,
             "flow_sampling": sampling,
             "value": m / t_a, "unit": "agent-steps/s", "cores": cores, "kind": "reference",
-            "sample": "reference movement.c move_velocity_work on %d of the %d agents (full snapshot loaded), "
-                      "%d pthreads; reference N_FlowFieldInit+N_FlowFieldUpdate on %d of the %d chunk-field "
-                      "requests the GPU builds every tick (random sample), %d pthreads"
-                      % (m, n_agents, cores, len(reqs), n_all, cores),
-            "skips": "`value` times the velocity half with desired directions given (the reference's 2 048-entry field "
-                     "cache cannot hold this workload's %d chunk fields at once); its sampler is timed separately on eight "
-                     "destinations' worth of cached fields (`flow_sampling`); the position accept test is skipped" % n_all,
+            "sample": "move_velocity_work on %d of %d agents, %d threads; N_FlowFieldUpdate on %d of %d chunk fields"
+                      % (m, n_agents, cores, len(reqs), n_all),
+            "skips": "a13 sampling timed apart (flow_sampling); a23 position accept",
             "flow_field_cells_per_s": cells_per_s, "flow_field_cells_per_s_1core": cells_per_s_1,
             "agent_steps_per_s_1core": 1.0 / per_agent,
-            "cores_note": "threads = usable cores (min of affinity and the cgroup cpu.max quota); "
-                          "os.cpu_count() = %d" % (os.cpu_count() or 0),
+            "os_cpu_count": os.cpu_count() or 0,
             "cpu_work_s": {"fields": per_field * len(reqs) * reps, "agents": per_agent * m},
         }
     except Exception as exc:                      # the baseline is informational
         return {"value": None, "unit": "agent-steps/s", "cores": os.cpu_count(), "kind": "reference",
                 "sample": "unavailable: %r" % (exc,)}
+
+
+def r4(x, nd=4):
+    """Numbers of the line rounded to `nd` significant digits (the driver's record keeps only the tail of the line)."""
+    if isinstance(x, dict):
+        return {k: r4(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [r4(v, nd) for v in x]
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    return x
 
 
 def status_histogram(T):
@@ -289,17 +293,16 @@ def status_histogram(T):
     att = (C.c_ulonglong * 9)()
     cp = None
     if navhip.lib().navhip_debug_cp_attempts(att, 1) == 0:
-        cp = {"returned_in_attempt_2..7+": [int(att[i]) for i in range(1, 8)], "gave_up": int(att[0]),
-              "attempts_of_retried_problems": int(att[8]), "note": "since the start of the run; problems that "
-              "returned in their first attempt are not counted"}
+        cp = {"returned_in_attempt_2_to_8plus": [int(att[i]) for i in range(1, 8)], "gave_up": int(att[0]),
+              "attempts_of_retried": int(att[8])}
     return {
         "moved": float((st & navhip.ST_MOVED).astype(bool).mean()),
         "field_miss": float((st & navhip.ST_FIELD_MISS).astype(bool).mean()),
         "field_none": float((st & navhip.ST_FIELD_NONE).astype(bool).mean()),
         "unsupported": float((st & navhip.ST_UNSUPPORTED).astype(bool).mean()),
-        "clearpath_on_row_1-2_3-4_5-8_9-16_neighbours": [x / n for x in lists[:4]],
-        "clearpath_on_wave_17-64_neighbours": lists[4] / n, "whole_step_on_wave": lists[5] / n,
-        "clearpath_retries": cp,
+        "cp_rows_1-2_3-4_5-8_9-16_nbrs": [x / n for x in lists[:4]],
+        "cp_wave_17-64_nbrs": lists[4] / n, "whole_step_on_wave": lists[5] / n,
+        "cp_retries": cp,
     }
 
 
@@ -326,26 +329,56 @@ def profiled_ticks(T, n):
     return g
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def emulated():
+    """The library under test is the host-emulator build (tests/hostsim; NAVHIP_LIB names it): test infrastructure,
+    the only case in which this script runs without a GPU."""
+    return os.path.basename(os.environ.get("NAVHIP_LIB", "")) == "_navhip_emu.so"
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks ourselves, one per GPU, exactly as the
+    driver's multi-GPU command does, and hand back their exit code.  Refuses when the node shows fewer than N devices."""
+    import subprocess
+    if not emulated():
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node; not faking ranks\n" % (n, have))
+            return 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, cwd=ROOT)
+
+
 def run_ticks(T, pdist, torch, warmup, steps, early=None):
     import numpy as np
+    from permafrost_engine_amd.tick import tcuda
     for _ in range(max(0, warmup - 3) if early is not None else warmup):
         T.step()
     T.sync()
     if early is not None:
         early.update(profiled_ticks(T, min(3, warmup)))
     pdist.barrier()
-    torch.cuda.synchronize()
+    tcuda.synchronize()
     T.record = True
     T.ev, T.tick_ev, T.fev, T._tick_rec = [], [], [], 0
     t0 = time.perf_counter()
     for _ in range(steps):
         T.step()
+    T.host_enqueue_ms = (time.perf_counter() - t0) / max(1, steps) * 1e3      # (host time to enqueue one tick)
     if T._tick_rec % T.tick_every == 0:           # close the last window
-        e = torch.cuda.Event(enable_timing=True)
+        e = tcuda.Event(enable_timing=True)
         e.record(T.stream)
         T.tick_ev.append(e)
     T.sync()
-    torch.cuda.synchronize()
+    tcuda.synchronize()
     pdist.barrier()
     dt = time.perf_counter() - t0
     T.record = False
@@ -377,6 +410,8 @@ def main():
                          "0-2, 4); strong = ONE world of the configuration's size, its destinations and its agents "
                          "split over the N ranks (requests by destination, uid slabs: movement.c:3759-3762; default "
                          "for config 3)")
+    ap.add_argument("--no-weak", action="store_true",
+                    help="--gpus N > 1 with the default (strong) scaling: skip the weak-scaled job run behind it")
     ap.add_argument("--no-los", action="store_true",
                     help="has_dest_los = 0 for every agent instead of the per-tick device lookup in the planner's LOS fields")
     ap.add_argument("--no-sustained", action="store_true",
@@ -386,6 +421,8 @@ def main():
                     help="build a tick's fields inside that tick, in front of its agent step (default: the fields "
                          "of tick t+1 are built during tick t, beside the agent step; same work, same results)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))
     cfg = dict(CONFIGS[args.config])
     for k in ("map", "fields", "agents", "obstacles"):
         if getattr(args, k) is not None:
@@ -401,20 +438,30 @@ def main():
     rank, world, local = pdist.init()
     if world != args.gpus and world > 1:
         args.gpus = world
-    if not torch.cuda.is_available():
+    if emulated():
+        local = 0
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libnavhip has no CPU fallback")
-    torch.cuda.set_device(local)
+    else:
+        torch.cuda.set_device(local)
 
-    shared = cfg["shared"] if args.scaling is None else args.scaling == "strong"
+    # BASELINE.json's metric is ONE world ("1024^2 map, 100k agents, 1/2/4/8 GPUs"; the reference forks one snapshot
+    # over its tasks, movement.c:3746-3774): N > 1 ranks split it (strong) unless --scaling weak; the weak-scaled job
+    # (every GPU brings its own region, fields and agents) is then run behind it and reported in `weak_scaling`
+    shared = (cfg["shared"] or world > 1) if args.scaling is None else args.scaling == "strong"
     f_rank = cfg["fields"] // world if shared else cfg["fields"]
     a_rank = cfg["agents"] // world if shared else cfg["agents"]
+    if shared and (cfg["fields"] % world or cfg["agents"] % world):
+        raise SystemExit("bench.py --scaling strong: %d ranks do not divide %d fields / %d agents"
+                         % (world, cfg["fields"], cfg["agents"]))
     CROWD = 17      # cells: a flock of ~1 600 packed into ~35 x 35 cells -> ~30 neighbours within r = 10
 
-    def make(crowd, share=False):
-        return tick.NavTick(share_fields=share, chunk_w=cfg["map"], fields_per_rank=f_rank, agents_per_rank=a_rank,
+    def make(crowd, share=False, weak=False):
+        return tick.NavTick(share_fields=share, chunk_w=cfg["map"], fields_per_rank=cfg["fields"] if weak else f_rank,
+                            agents_per_rank=cfg["agents"] if weak else a_rank,
                             rank=rank, world=world, device=local, obstacles=cfg["obstacles"],
                             obstacle_ticks=args.warmup + args.steps + 16, tile_exchange=args.tile_exchange,
-                            shared_map=shared, crowd_cells=CROWD if crowd else 0,
+                            shared_map=shared and not weak, crowd_cells=CROWD if crowd else 0,
                             pipeline_fields=not args.no_pipeline_fields, los=not args.no_los, flow_velocities=True)
 
     T = make(args.crowded)
@@ -424,13 +471,14 @@ def main():
     dt, ticks = run_ticks(T, pdist, torch, args.warmup, args.steps, early)
     phases = T.phase_ms()
     hist = status_histogram(T)
+    host_enqueue_ms, tick_driver = T.host_enqueue_ms, getattr(T, "tick_driver", "python (tick.py)")
 
     # per-kernel-group durations at the END of the run (the world has crowded by then); the same
     # split for the last warm-up ticks is in `early`
     prof_first = T.tick_no + 1
     groups = profiled_ticks(T, 6)
     T_ticks_done = T.tick_no
-    prof_ticks = "ticks %d-%d of the run" % (prof_first + 1, T_ticks_done)
+    prof_ticks = "ticks %d-%d" % (prof_first + 1, T_ticks_done)
 
     agents_total = T.N
     cells_total = T.n_req_total * 4096
@@ -482,10 +530,7 @@ def main():
         floor_ms = insts / 1024 * cyc / 2.4e9 * 1e3
         return {"valu_insts_per_launch": insts, "issue_floor_ms": floor_ms, "cycles_per_inst": cyc,
                 "frac_of_issue_peak": floor_ms / measured_ms,
-                "counters_of": "ticks 100-110" if key == "SQ_INSTS_VALU" else "ticks 6-11",
-                "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, profiles/sq_counters.json, same "
-                        "csrc tree) at the MEASURED v_fma_f32 issue cost (%s), "
-                        "1024 SIMDs, 2.4 GHz, over the measured launch time" % calib_file}
+                "counters_of": "ticks 100-110" if key == "SQ_INSTS_VALU" else "ticks 6-11"}
 
     def roof(which, g=None, when=None):
         g = g or groups
@@ -496,13 +541,13 @@ def main():
         return {
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": None if stale else measured.get(which + "_bytes_per_launch"),
-            "traffic_stale": bool(stale and measured),
-            "traffic_measured_on": {"csrc_sha": measured.get("csrc_sha"), "sources_added_since": added_since},
-            "kernel": ("navhip_agent_step_dev: k_sp_* + k_agent_nbr + k_cohesion + k_agent_mid/k_cp_*"
-                       if which == "agents" else "navhip_build_fields_dev: k_field_bfs"),
+            "traffic_stale": bool(stale and measured), "traffic_csrc_sha": measured.get("csrc_sha"),
+            "kernel": ("agent step: k_sp_* + k_agent_nbr + k_cohesion + k_agent_mid + k_cp_*"
+                       if which == "agents" else "k_field_bfs"),
             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by,
-            "launch_timing": "HIP events on the launch stream, kernel groups back to back on one stream: "
-                             "profiled " + when + " (behind the timed region)",
+            # the groups run back to back on ONE stream with events between them: a SERIAL time that may exceed
+            # ms_per_step, where k_cohesion and the ClearPath kernels overlap on side streams
+            "launch_timing": "HIP events, groups serial on one stream (may exceed ms_per_step), " + when,
             "kernels_ms": {k: g[k] for k in ("sp_build", "agent_nbr", "cohesion", "coh_regroup", "agent_finish")}
                           if which == "agents" else {"fields": g["fields"]},
             "valu_issue": valu(("k_agent_", "k_cp_", "k_coh", "k_sp_"), ms) if which == "agents"
@@ -528,12 +573,13 @@ def main():
         def s_at(i):
             w = (i - 1) // Ts.tick_every
             return float(sticks[w]) if len(sticks) > w else None
-        sustained = {"what": "a fresh world of the same configuration, 100 ticks after 5",
+        sustained = {"ticks": 100, "warmup": 5,
                      "ms_per_step": sdt / 100 * 1e3, "ms_per_step_median": float(np.median(sticks)),
                      "agent_steps_per_s": Ts.N * 100 / sdt, "ms_tick_5_50_100": [s_at(5), s_at(50), s_at(100)],
                      "kernel_groups_ms_serial": sgroups, "status": status_histogram(Ts),
                      "roofline": None}
-        sustained["roofline"] = roof("agents", sgroups, "ticks %d-%d of the 100-tick run" % (s_first + 1, Ts.tick_no))
+        sr = roof("agents", sgroups, "ticks %d-%d" % (s_first + 1, Ts.tick_no))
+        sustained["roofline"] = {k: sr[k] for k in ("achieved", "frac", "avg_launch_ms", "kernels_ms")}
         Ts.close()
 
     # ---- the same tick with the reference's field SHARING: its cache is keyed by N_FlowFieldID (chunk + target,
@@ -547,9 +593,7 @@ def main():
         T = None
         Tq = make(False, share=True)
         qdt, qticks = run_ticks(Tq, pdist, torch, args.warmup, args.steps)
-        shared_fields = {"what": "same world; identical chunk-field requests (same chunk, same target: one N_FlowFieldID) "
-                                 "built once per tick, every (destination, chunk) mapped to the shared slot",
-                         "chunk_field_requests_served_per_tick": Tq.n_requests_served,
+        shared_fields = {"chunk_field_requests_served_per_tick": Tq.n_requests_served,
                          "distinct_chunk_fields_built_per_tick": Tq.n_req_local,
                          "ms_per_step": qdt / args.steps * 1e3, "ms_per_step_median": float(np.median(qticks)),
                          "agent_steps_per_s": Tq.N * args.steps / qdt,
@@ -564,9 +608,7 @@ def main():
         Tc = make(True)
         cdt, cticks = run_ticks(Tc, pdist, torch, 3, 40)
         chist = status_histogram(Tc)
-        crowded = {"what": "same config, every flock packed into ~35 x 35 cells (neighbour caps bind, "
-                           "ClearPath in its R^3 regime); 40 ticks after 3",
-                   "agent_steps_per_s": Tc.N * 40 / cdt, "ms_per_step": cdt / 40 * 1e3,
+        crowded = {"ticks": 40, "warmup": 3, "agent_steps_per_s": Tc.N * 40 / cdt, "ms_per_step": cdt / 40 * 1e3,
                    "ms_per_step_median": float(np.median(cticks)), "status": chist}
         Tc.close()
 
@@ -575,55 +617,78 @@ def main():
         cpu = cpu_baseline(cfg["map"], cfg["fields"], cfg["agents"], 20, whole=(args.config == 0),
                            dropin=not args.no_dropin)
 
+    # ---- N > 1, strong by default: the weak-scaled job of the same configuration behind it --------------------
+    weak = None
+    if world > 1 and shared and args.scaling is None and not args.no_weak and cfg["map"] * tick.region_grid(world)[1] <= 64:
+        T.close()
+        T = None
+        Tw = make(args.crowded, weak=True)
+        wdt, wticks = run_ticks(Tw, pdist, torch, args.warmup, args.steps)
+        weak = {"value": Tw.N * args.steps / wdt, "ms_per_step": wdt / args.steps * 1e3, "agents": Tw.N,
+                "chunk_fields": Tw.n_req_total, "map_chunks": [Tw.Wt, Tw.H]}
+        Tw.close()
+
     if rank == 0:
         def at(i):          # (ticks: one value per window of T.tick_every ticks)
             w = (i - 1) // tick_every
             return float(ticks[w]) if len(ticks) > w else None
+        dims = T_dims(cfg, world, shared)
+        backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"
+        drop = (cpu or {}).pop("dropin", None) if isinstance(cpu, dict) else None
+        state_pass = drop.pop("state_pass", None) if isinstance(drop, dict) else None
+        sampling = (cpu or {}).pop("flow_sampling", None) if isinstance(cpu, dict) else None
+        t5 = [at(5), at(50), at(100)] if args.steps >= 100 or sustained is None else sustained["ms_tick_5_50_100"]
+        # What every key means, and the prose that used to ride in the line: profiles/README.md ("the bench line").
+        # The driver's record keeps the TAIL of the line: the summary of every regime comes last.
         line = {
-            "metric": "agent-steps/sec (+ flow-field cells/sec): every chunk field of every flow field rebuilt and "
-                      "every agent stepped each tick",
+            "metric": "agent-steps/sec (+ flow-field cells/sec), every chunk field rebuilt + every agent stepped per tick",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if shared else "weak", "vs_baseline": None,
             "dtype": "u64-bitmask/u8 fields, f32 agents (f64 exp)", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[%d]%s: %dx%d-cell map (%dx%d chunks%s), %d flow fields%s, "
-                                   "%d chunk fields + %d agents per tick%s; fields rebuilt + agents stepped every tick"
-                                   % ((args.config, " (crowded world)" if args.crowded else "") + T_dims(cfg, world, shared)
-                                      + ("" if world == 1 or shared else ": %d regions of %dx%d chunks" % (world, cfg["map"], cfg["map"]),
-                                         cfg["fields"], "" if shared or world == 1 else " per GPU", cells_total // 4096,
-                                         agents_total,
-                                         ", %d dynamic obstacles (1 %% moved per tick, incremental repair)" % cfg["obstacles"]
-                                         if cfg["obstacles"] else "")),
+            "config": {"workload": "BASELINE configs[%d]%s: %dx%d cells, %d flow fields%s = %d chunk fields, %d agents%s"
+                                   % (args.config, " crowded" if args.crowded else "", dims[0], dims[1], cfg["fields"],
+                                      "" if shared or world == 1 else "/GPU", cells_total // 4096, agents_total,
+                                      ", %d obstacles" % cfg["obstacles"] if cfg["obstacles"] else ""),
                        "baseline_config": args.config, "map_chunks": cfg["map"], "flow_fields": cfg["fields"],
                        "agents": cfg["agents"], "hz": 20, "dynamic_obstacles": cfg["obstacles"],
-                       "parallelism": "requests by destination + agent slabs x%d; one all-gather of slab results "
-                                      "(16 B/agent) per tick; baked tiles: %s" % (world, args.tile_exchange),
-                       "requests": request_source,
-                       "has_dest_los": los_source,
-                       "initial_velocities": velocity_source,
-                       "schedule": ("fields of tick t+1 built during tick t beside the agent step (double-buffered pool)"
-                                    if fields_ahead else "fields of tick t built in front of the agent step of tick t")},
-            "ms_per_step_median": float(np.median(ticks)),
-            "ms_tick_5_50_100": [at(5), at(50), at(100)] if args.steps >= 100 or sustained is None
-                                else sustained["ms_tick_5_50_100"],
-            "ms_tick_5_50_100_of": "this run" if args.steps >= 100 or sustained is None else "sustained_100",
+                       "parallelism": "requests by destination + uid slabs x%d, 1 all-gather (16 B/agent) per tick"
+                                      % world,
+                       "ranks": world, "rccl_ranks": pdist.comm_ranks(), "backend": backend,
+                       "tile_exchange": args.tile_exchange,
+                       "requests": "reference planner fixture" if "fixture" in request_source else "numpy stand-in",
+                       "has_dest_los": "device lookup" if "device lookup" in los_source else "0",
+                       "initial_velocities": "flow aligned" if "flow" in velocity_source else "N(0,0.35)",
+                       "fields_ahead": bool(fields_ahead), "tick_driver": tick_driver},
+            "roofline": roof(dom),
+            "cpu_baseline": cpu,
+            "roofline_secondary": {k: v for k, v in roof(other).items()
+                                   if k in ("achieved", "frac", "traffic", "kernel", "avg_launch_ms",
+                                            "algorithmic_bytes_per_launch", "valu_issue")},
+            "csrc_sha": sha,
+            "kernel_groups_ms_serial": {"after_warmup": early, "after_timed_region": groups},
+            "phase_ms_overlapped": phases,
+            "status": hist,
+            "flow_sampling_cpu": sampling,
+            "shared_fields": shared_fields,
+            "weak_scaling": weak,
             "sustained_100": sustained,
-            "tick_timing": "HIP events on the agent stream every %d ticks; per-tick values are window means" % tick_every,
-            "agent_steps_per_s_median_tick": agents_total / (float(np.median(ticks)) * 1e-3),
+            "crowded_world": crowded,
+            "dropin": drop,
+            "state_pass": state_pass,
             ("flow_field_cells_kept_valid_per_s" if cfg["obstacles"] else "flow_field_cells_per_s"):
                 cells_total * args.steps / dt,
-            "phase_ms_overlapped": phases,
-            "kernel_groups_ms_serial": {"after_warmup": early, "after_timed_region": groups},
-            "status": hist,
-            "roofline": roof(dom),
-            "roofline_secondary": roof(other),
-            "csrc_sha": sha,
-            "shared_fields": shared_fields,
-            "crowded_world": crowded,
-            "cpu_baseline": cpu,
-            "dropin": (cpu or {}).pop("dropin", None) if isinstance(cpu, dict) else None,
+            "summary": {"ms_per_step": ms_per_step, "ms_per_step_median": float(np.median(ticks)),
+                        "ms_tick_5_50_100": t5,
+                        "ms_tick_5_50_100_of": "this run" if args.steps >= 100 or sustained is None else "sustained_100",
+                        "sustained_100_ms": sustained["ms_per_step"] if sustained else None,
+                        "crowded_ms": crowded["ms_per_step"] if crowded else None,
+                        "dropin_ms": drop.get("hip_ms_per_tick") if isinstance(drop, dict) else None,
+                        "state_pass_ms": state_pass.get("hip_ms_per_tick") if isinstance(state_pass, dict) else None,
+                        "host_enqueue_ms": host_enqueue_ms,
+                        "roofline_frac": roof(dom)["frac"], "ranks": world},
         }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(r4(line), separators=(",", ":")), flush=True)
     if T is not None:
         T.close()
     if torch.distributed.is_initialized():

@@ -116,6 +116,11 @@ def all_gather_rows(full, rank, world, rows_per_rank):
     dist.all_gather_into_tensor(full, mine.contiguous())
 
 
+def comm_ranks():
+    """Ranks of the communicator the exchange steps run on (backend nccl = RCCL); 1 for a single process."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

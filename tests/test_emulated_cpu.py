@@ -119,3 +119,38 @@ def test_two_rank_gloo_tick_on_the_emulated_library(extra):
     lines = [l for l in r.stdout.splitlines() if l.startswith("rank ")]
     assert r.returncode == 0 and len(lines) == 2 and all("IDENTICAL to solo" in l for l in lines), r.stdout[-2000:]
 
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` -- the shape of the driver's N = 1 command, NOT wrapped in torchrun -- has to run two
+    ranks by itself (torch.distributed.run, one rank per device; gloo and the emulator build here), split ONE world over
+    them (BASELINE.json's metric: strong scaling), say how many ranks the communicator saw, run the weak-scaled job
+    behind it, and print ONE line that fits the driver's record."""
+    import json
+    lib = hostsim.build_navhip_emu()
+    env = dict(os.environ, NAVHIP_LIB=lib, NAVHIP_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--map", "4", "--fields", "2", "--agents", "300",
+           "--steps", "2", "--warmup", "1", "--no-los"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2 and line["warmup"] == 1
+    assert line["config"]["ranks"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "gloo"
+    assert line["config"]["agents"] == 300 and line["weak_scaling"]["agents"] == 600        # one world split | a region per rank
+    assert line["value"] > 0 and line["summary"]["ranks"] == 2
+    assert len(lines[0]) < 6000
+    assert all(len(v) <= 120 for v in line["config"].values() if isinstance(v, str))
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """Without the emulator: this container has no GPU, so `--gpus 2` must fail instead of faking ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("NAVHIP_LIB", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 3 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
