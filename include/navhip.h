@@ -558,6 +558,64 @@ int  navhip_comm_allgather_step_dev(navhip_ctx *ctx, float *dev_new_pos_xz, floa
 int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_bytes, const int32_t *bounds,
                                     void *stream);
 
+/* ---- the whole tick behind ONE call (host code stays in C: the per-tick orchestration is the library's) ------- */
+
+/* The reference runs its navigation tick from one place: move_do_tick (movement.c:4312) -> navigation_tick_task
+ * (:4263-4280): field work, the velocity fork-join, the state fork-join, the snapshot for the next tick.  A navhip_tick
+ * is that loop for a device-resident world: every call of navhip_tick_run enqueues, per tick,
+ *   - the chunk-field builds of this context's share of the requests (into the pool slot of each request; with a second
+ *     pool the fields tick t+1 samples are built DURING tick t on a stream of their own, behind the narrow front of
+ *     the step -- the schedule DESIGN.md section 3.7 measured),
+ *   - [dynamic obstacles] the tick's N_BlockersIncref/Decref batch in front of them (incremental repair),
+ *   - the velocity step + position accept of the uid slab (navhip_agent_prefetch_dev + navhip_agent_step_dev),
+ *   - [a communicator on the context] the slab exchange (navhip_comm_allgather_step_dev) on a stream of its own, which
+ *     only the snapshot consumers of the next tick wait for,
+ *   - the advance of the snapshot: position / velocity buffers and the two pools ping-pong.
+ * Nothing is waited for; the host returns after a few dozen launches -- or, with NAVHIP_TICK_GRAPH, after ONE
+ * hipGraphLaunch of the tick captured once per parity of its ping-pong buffers (single-process worlds without moving
+ * obstacles; the library falls back to plain launches when a capture fails).  Results are those of the separate calls,
+ * bit for bit: the same kernels on the same buffers in the same order per stream. */
+typedef struct navhip_tick navhip_tick;
+#define NAVHIP_TICK_GRAPH  0x1u   /* replay the tick as a captured HIP graph                                         */
+typedef struct navhip_tick_desc {
+    navhip_world world;             /* DEVICE arrays of the snapshot (buffer set 0: pos_xz, vel_xz, field_pool);
+                                       work_begin/work_end = this rank's uid slab                                      */
+    float    *pos_xz_1, *vel_xz_1;  /* [n][2] buffer set 1: tick t reads set (t & 1) and writes the other               */
+    uint8_t  *status;               /* [n] NAVHIP_ST_* or NULL                                                          */
+    float    *vdes_xz, *vpref_xz;   /* [n][2] or NULL (debug / parity outputs of navhip_step_out)                       */
+    const navhip_field_req *dev_reqs;   /* this rank's chunk-field requests, rebuilt every tick (device)                */
+    int32_t   n_reqs;
+    int32_t   req_slot0;            /* request i is built into slot req_slot0 + i of the pool                           */
+    uint8_t  *field_pool_1;         /* [slots][4096] second pool: the fields of tick t+1 are built during tick t into the
+                                       pool tick t does not sample; NULL = built in front of the step of their own tick */
+    int32_t   field_cus;            /* compute units the ahead builds may use (the last field_cus of the device); 0 = all */
+    int32_t   fields_stage;         /* NAVHIP_STAGE_NEIGHBOURS / NAVHIP_STAGE_START: where in tick t they start         */
+    const navhip_circle *dev_moves; /* [n_move_ticks][n_moves] the N_BlockersIncref/Decref batch of every tick, or NULL */
+    int32_t   n_moves, n_move_ticks;
+    int32_t   move_tick0;           /* the batch of this object's first tick (tick k applies row (move_tick0 + k) % n_move_ticks) */
+    const int32_t *bounds;          /* HOST [world + 1] uid slabs of the ranks: the exchange of navhip_comm_allgather_step_dev
+                                       through the context's communicator every tick; NULL = no exchange                */
+    void     *stream, *field_stream, *comm_stream;   /* hipStream_t or NULL = streams of the library's own              */
+    uint32_t  flags;                /* NAVHIP_TICK_*                                                                    */
+} navhip_tick_desc;
+typedef struct navhip_tick_info {
+    int64_t  ticks;                 /* ticks enqueued so far: the current snapshot is buffer set (ticks & 1)            */
+    int32_t  graph;                 /* 1 = ticks are replayed as graphs, 0 = plain launches                             */
+    int32_t  graphs_captured;
+    double   host_enqueue_ms;       /* host time spent inside navhip_tick_run since creation                            */
+    void    *stream, *field_stream, *comm_stream;
+} navhip_tick_info;
+int  navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tick **out);
+/* Enqueue n ticks; asynchronous. */
+int  navhip_tick_run(navhip_tick *tick, int n);
+/* The two halves for a host with a transport of its own between them (tick.py's torch.distributed exchange):
+ * compute = everything up to the exchange of ONE tick, advance = the ping-pong behind the host's exchange. */
+int  navhip_tick_compute(navhip_tick *tick);
+int  navhip_tick_advance(navhip_tick *tick);
+int  navhip_tick_sync(navhip_tick *tick);
+int  navhip_tick_get_info(const navhip_tick *tick, navhip_tick_info *out);
+void navhip_tick_destroy(navhip_tick *tick);
+
 /* ---- the arrival arm of the movement state machine --------------------------- */
 
 /* entity_compute_update (movement.c:2303) decides, per unit and tick, the next movement state.  Most of it is

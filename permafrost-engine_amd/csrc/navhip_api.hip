@@ -915,6 +915,7 @@ static int ensure_side_streams(navhip_ctx *ctx)
 #endif
 static bool coh_regroup_due(navhip_ctx *ctx, const nh_step_params &P)
 {
+    if(ctx->regroup_override) return ctx->regroup_override == 1;
     const int64_t key[4] = {((int64_t)P.n_ents << 32) | (uint32_t)P.n_flocks, (int64_t)P.n_members,
                             ((int64_t)P.work_begin << 32) | (uint32_t)P.work_end, (int64_t)P.members_key};
     if(memcmp(key, ctx->coh_regroup_key, sizeof(key)) != 0) {
@@ -928,6 +929,9 @@ static bool coh_regroup_due(navhip_ctx *ctx, const nh_step_params &P)
     // timing against the persistent searches).  Kept as measured.
     int32_t lists[6];
     const bool jam = navhip_step_lists_peek(ctx, lists) == NAVHIP_OK && lists[4] >= 8192;
+    // (a slab step whose caller gave no static_epoch carries a never-repeating key: k_cohesion could not accept a
+    // grouping made for it -- the five launches would be wasted)
+    if(P.members_key < 0) return false;
     return jam || age < 2 || age % NH_COH_REGROUP_EVERY == 0;
 }
 

@@ -73,6 +73,8 @@ struct navhip_ctx {
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
     hipEvent_t   ev_cp[3];          // the ClearPath launches of the agent step: lists ready, small problems done, workgroup problems done
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
+    int          regroup_override;  // 0 = the library's own cadence (coh_regroup_due); 1 / 2 = the caller (tick_api.hip,
+                                    // which keys its captured graphs on the decision) says regroup / do not
     int64_t      coh_regroup_key[4]; int coh_regroup_age;   // what the last regrouping was built for, ticks since
     // the snapshot a prefetch was started for: everything the side streams baked into their results
     struct { bool valid; const float *pos_xz, *vel_xz, *radius, *arrival_sink_xz; const uint32_t *flags;

@@ -1031,3 +1031,78 @@ NavContext.agent_step_dev = _ctx_agent_step_dev
 NavContext.agent_prefetch_dev = _ctx_agent_prefetch_dev
 NavContext.spatial_query = _ctx_spatial_query
 NavContext.G_ClearPath_NewVelocity = _ctx_clearpath
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole tick behind one call (navhip_tick_*, csrc/tick_api.hip)
+# ---------------------------------------------------------------------------------------------
+TICK_GRAPH = 0x1
+
+
+class TickDesc(C.Structure):
+    """navhip_tick_desc, include/navhip.h"""
+    _fields_ = [("world", World), ("pos_xz_1", C.c_void_p), ("vel_xz_1", C.c_void_p), ("status", C.c_void_p),
+                ("vdes_xz", C.c_void_p), ("vpref_xz", C.c_void_p), ("dev_reqs", C.c_void_p), ("n_reqs", C.c_int32),
+                ("req_slot0", C.c_int32), ("field_pool_1", C.c_void_p), ("field_cus", C.c_int32),
+                ("fields_stage", C.c_int32), ("dev_moves", C.c_void_p), ("n_moves", C.c_int32),
+                ("n_move_ticks", C.c_int32), ("move_tick0", C.c_int32), ("bounds", C.c_void_p), ("stream", C.c_void_p),
+                ("field_stream", C.c_void_p), ("comm_stream", C.c_void_p), ("flags", C.c_uint32)]
+
+
+class TickInfo(C.Structure):
+    """navhip_tick_info, include/navhip.h"""
+    _fields_ = [("ticks", C.c_int64), ("graph", C.c_int32), ("graphs_captured", C.c_int32),
+                ("host_enqueue_ms", C.c_double), ("stream", C.c_void_p), ("field_stream", C.c_void_p),
+                ("comm_stream", C.c_void_p)]
+
+
+_SIGS.update({
+    "navhip_tick_create": (C.c_int, [C.c_void_p, C.POINTER(TickDesc), C.POINTER(C.c_void_p)]),
+    "navhip_tick_run": (C.c_int, [C.c_void_p, C.c_int]),
+    "navhip_tick_compute": (C.c_int, [C.c_void_p]),
+    "navhip_tick_advance": (C.c_int, [C.c_void_p]),
+    "navhip_tick_sync": (C.c_int, [C.c_void_p]),
+    "navhip_tick_get_info": (C.c_int, [C.c_void_p, C.POINTER(TickInfo)]),
+    "navhip_tick_destroy": (None, [C.c_void_p]),
+})
+
+
+class Tick:
+    """One navhip_tick: the per-tick loop of a device-resident world inside the library (the reference's
+    navigation_tick_task, movement.c:4263).  `desc` is a filled TickDesc; `keep` whatever owns the device arrays."""
+
+    def __init__(self, ctx, desc, keep=None):
+        self.ctx, self._keep = ctx, (keep, desc)
+        self._h = C.c_void_p()
+        ctx._chk(lib().navhip_tick_create(ctx._h, C.byref(desc), C.byref(self._h)), "navhip_tick_create")
+        self._run = lib().navhip_tick_run
+
+    def run(self, n=1):
+        rc = self._run(self._h, n)
+        if rc != OK:
+            self.ctx._chk(rc, "navhip_tick_run")
+
+    def compute(self):
+        self.ctx._chk(lib().navhip_tick_compute(self._h), "navhip_tick_compute")
+
+    def advance(self):
+        self.ctx._chk(lib().navhip_tick_advance(self._h), "navhip_tick_advance")
+
+    def sync(self):
+        self.ctx._chk(lib().navhip_tick_sync(self._h), "navhip_tick_sync")
+
+    def info(self):
+        out = TickInfo()
+        self.ctx._chk(lib().navhip_tick_get_info(self._h, C.byref(out)), "navhip_tick_get_info")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().navhip_tick_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

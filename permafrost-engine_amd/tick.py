@@ -105,7 +105,7 @@ class NavTick:
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
                  debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True,
-                 straddle=0.0, los=False, flow_velocities=False, share_fields=False):
+                 straddle=0.0, los=False, flow_velocities=False, share_fields=False, driver="c", graph=None):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cpu") if EMULATED else torch.device("cuda", device)
         tcuda.set_device(self.dev)
@@ -380,7 +380,6 @@ class NavTick:
             #     WITH THE TICK on ALL compute units 0.97; with the tick on 224 / 192: 1.01 / 1.08; behind the
             #     neighbour walk on 224 / 160: 0.99 / 1.20.
             #   configs[1] (4 096 chunk fields, 45 us): no difference (0.259-0.265).
-            import os
             ncu_all = tcuda.get_device_properties(self.dev).multi_processor_count
             long_build = self.n_req_local >= 65536
             ncu = int(os.environ.get("NAVTICK_FIELD_CUS", str(ncu_all if long_build else ncu_all * 5 // 8)))
@@ -408,6 +407,19 @@ class NavTick:
             self._flow_aligned_velocities()
         if not hasattr(self, "velocity_source"):
             self.velocity_source = "N(0, 0.35) per component (synth.agents)"
+        # driver: who enqueues a tick.  "c" = the library's own loop (navhip_tick_*, csrc/tick_api.hip: ONE call per
+        # tick, the schedule below in C; with graph=True each tick is one hipGraphLaunch of the tick captured per
+        # parity) -- for every world whose baked tiles do not travel; "python" = this file's compute() / exchange()
+        # / advance(), the reference implementation of that schedule, which the C loop is tested against.
+        # graph=None: NAVTICK_GRAPH=1/0 decides, else on where the host's enqueue time is the tick's floor (small
+        # per-rank worlds), off where the GPU tick hides it and the CU-masked field stream pays (configs[2]).
+        self.driver = driver if (self.tile_exchange == "none" or self.solo) else "python"
+        if graph is None:
+            env = os.environ.get("NAVTICK_GRAPH")
+            graph = (env == "1") if env in ("0", "1") else (self.a1 - self.a0) <= 30000
+        self.graph = bool(graph)
+        self._ctick = None
+        self.tick_driver = "python (tick.py)"
         self.ev = []                   # (phase, start_event, end_event) of the timed steps
         self.tick_ev = []              # one event at the start of every tick_every-th recorded tick
         self.tick_every, self._tick_rec = 5, 0
@@ -523,8 +535,74 @@ class NavTick:
         e.record(self.stream)
         return (name, e)
 
+    # ---- the C driver ---------------------------------------------------------------------------------------------
+    def _c_tick(self):
+        """The navhip_tick of the current buffers (made on first use; dropped whenever the Python path steps)."""
+        if self._ctick is not None:
+            return self._ctick
+        d = navhip.TickDesc()
+        C.memmove(C.byref(d.world), C.byref(self.world_s), C.sizeof(navhip.World))
+        d.pos_xz_1, d.vel_xz_1 = self.new_pos.data_ptr(), self.new_vel.data_ptr()
+        d.status = self.status.data_ptr()
+        if self.vdes_out is not None:
+            d.vdes_xz, d.vpref_xz = self.vdes_out.data_ptr(), self.vpref_out.data_ptr()
+        d.n_reqs, d.req_slot0 = self.n_req_local, self.req_begin
+        d.dev_reqs = self.d_reqs[self.req_begin:self.req_end].data_ptr() if self.n_req_local else None
+        keep = [self.world_s, self._keep, self.new_pos, self.new_vel, self.status, self.d_reqs, self.pool]
+        d.stream = self.stream.cuda_stream
+        if self.pipeline_fields:
+            d.field_pool_1 = self.pool_next.data_ptr()
+            d.field_stream = self.fstream.cuda_stream
+            d.fields_stage = navhip.STAGE_START if self.fields_after == "start" else navhip.STAGE_NEIGHBOURS
+            keep.append(self.pool_next)
+        if self.n_obstacles:
+            d.dev_moves, d.n_moves, d.n_move_ticks = self.d_moves.data_ptr(), self.n_moves, int(self.d_moves.shape[0])
+            d.move_tick0 = self.tick_no % int(self.d_moves.shape[0])
+        if self.pipelined and self.exchange_mode == "navhip":
+            self._bounds_c = np.ascontiguousarray(self._bounds, np.int32)
+            d.bounds = self._bounds_c.ctypes.data
+            d.comm_stream = self.comm.cuda_stream
+        d.flags = navhip.TICK_GRAPH if self.graph else 0
+        self._ctick = navhip.Tick(self.ctx, d, keep)
+        self._ctick_tick0 = self.tick_no
+        info = self._ctick.info()
+        self.tick_driver = "c (navhip_tick_run%s)" % (", hip graph" if info.graph else "")
+        return self._ctick
+
+    def _c_tick_drop(self):
+        if self._ctick is not None:
+            self._ctick.sync()
+            self.c_tick_info = self._ctick.info()
+            self._ctick.close()
+            self._ctick = None
+            if self.pipeline_fields:
+                # (the Python path's event of "this tick's fields are built": they are -- everything was waited for)
+                self.ev_fields.record(self.stream)
+            self._make_structs()
+
+    def _step_c(self):
+        T = self._c_tick()
+        if self.pipelined and self.exchange_mode != "navhip":
+            # torch.distributed between the two halves of the C tick: the tick starts behind the previous exchange
+            if self._comm_pending:
+                self.stream.wait_event(self.ev_comm)
+            T.compute()
+            self.ev_step.record(self.stream)
+            self.exchange()
+            T.advance()
+        else:
+            T.run(1)
+        # (the Python view of the ping-pong, without rebuilding the structs: the C tick has its own two)
+        self.t["pos_xz"], self.new_pos = self.new_pos, self.t["pos_xz"]
+        self.t["vel_xz"], self.new_vel = self.new_vel, self.t["vel_xz"]
+        if self.pipeline_fields:
+            self.pool, self.pool_next = self.pool_next, self.pool
+            self.t["field_pool"] = self.pool
+        self.tick_no += 1
+
     def step(self):
         """One tick, asynchronous on self.stream."""
+        use_c = self.driver == "c" and not (self.record and self.mark_every <= 1)
         if self.record:
             # one timing event every `tick_every` ticks: an event on the agent stream is a packet on the
             # tick's critical path (recording every tick cost 1.5-2 % of the tick)
@@ -533,6 +611,9 @@ class NavTick:
                 e.record(self.stream)
                 self.tick_ev.append(e)
             self._tick_rec += 1
+        if use_c:
+            return self._step_c()
+        self._c_tick_drop()
         self.compute()
         self.exchange()
         self.advance()
@@ -678,6 +759,8 @@ class NavTick:
         return [a.elapsed_time(b) / self.tick_every for a, b in zip(self.tick_ev[:-1], self.tick_ev[1:])]
 
     def sync(self):
+        if self._ctick is not None:
+            self._ctick.sync()
         if self.comm is not None:
             self.comm.synchronize()
         if self.pipeline_fields:
@@ -687,4 +770,8 @@ class NavTick:
 
     def close(self):
         self.sync()
+        if self._ctick is not None:
+            self.c_tick_info = self._ctick.info()
+            self._ctick.close()
+            self._ctick = None
         self.ctx.close()

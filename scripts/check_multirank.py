@@ -28,21 +28,22 @@ def main():
     kw = dict(chunk_w=4, fields_per_rank=3 if small else 6, agents_per_rank=500 if small else 12000, world=world, device=local,
               straddle=0.25 if "--straddle" in sys.argv else 0.0, shared_map="--shared" in sys.argv,
               flow_velocities="--flow-velocities" in sys.argv)
-    T = tick.NavTick(rank=rank, tile_exchange=mode, pipeline_fields=pipe, exchange=exch, **kw)
+    T = tick.NavTick(rank=rank, tile_exchange=mode, pipeline_fields=pipe, exchange=exch,
+                     driver="python" if "--python-driver" in sys.argv else "c", **kw)
     K = 3 if small else 6
     for _ in range(K):
         T.step()
     T.sync()
-    S = tick.NavTick(rank=rank, solo=True, **kw)
+    S = tick.NavTick(rank=rank, solo=True, driver="python", **kw)      # (the reference schedule, one process)
     for _ in range(K):
         S.step()
     S.sync()
     ok = torch.equal(T.t["pos_xz"], S.t["pos_xz"]) and torch.equal(T.t["vel_xz"], S.t["vel_xz"])
     moved = (S.t["vel_xz"].abs().sum(1) > 0).float().mean().item()
     sent = sum(e - b for b, e in T.xchg_bounds) if T.tile_exchange != "none" else 0
-    print("rank %d/%d backend=%s exchange=%s tile_exchange=%s (tiles travelling %d of %d) pipelined=%s fields_ahead=%s: "
+    print("rank %d/%d driver=%s backend=%s exchange=%s tile_exchange=%s (tiles travelling %d of %d) pipelined=%s fields_ahead=%s: "
           "%s (moving fraction %.2f)"
-          % (rank, world, torch.distributed.get_backend() if world > 1 else "-", T.exchange_mode, T.tile_exchange,
+          % (rank, world, T.tick_driver, torch.distributed.get_backend() if world > 1 else "-", T.exchange_mode, T.tile_exchange,
              sent, len(T.host["reqs"]) if T.tile_exchange != "none" else T.n_req_total,
              T.pipelined, T.pipeline_fields, "IDENTICAL to solo" if ok else "MISMATCH", moved), flush=True)
     pdist.barrier()

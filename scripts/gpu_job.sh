@@ -10,6 +10,8 @@
 #   ranks2  bench.py --gpus 2 under torchrun, both ranks on the one GPU, gloo (a plumbing check, not a measurement)
 #   fuzz    tests/tools/fuzz_gpu.py
 #   statepass tests/tools/bench_state_pass.py (the state half of the movement tick through the binding) + its kernel stats
+#   hostov  scripts/host_overhead.py (enqueue time per tick: python / c / c + graph) + rank_cost_probe --strong
+#   ticktests  tests/test_tick_gpu.py only
 #   aux     scripts/bench_aux.py (host-buffer rates, LOS)  + scripts/cp_unit_hist.py when its build is there
 TAG=$1; shift
 STEPS=${@:-tests bench calib stats}
@@ -49,6 +51,10 @@ cpstats) timeout 400 python scripts/cp_stats.py > $OUT/cp_stats.json 2> $OUT/cp_
          timeout 400 python scripts/cp_stats.py --crowd > $OUT/cp_stats_crowd.json 2>> $OUT/cp_stats.err; tail -c 600 $OUT/cp_stats_crowd.json ;;
 secondary) timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/secondary -o s --output-format csv -- python scripts/bench_secondary.py > $OUT/bench_secondary.json 2> $OUT/secondary.err
        tail -c 1500 $OUT/bench_secondary.json; f=$(find $OUT/secondary -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 $f | cut -c1-160 ;;
+hostov) timeout 600 python scripts/host_overhead.py > $OUT/host_overhead.txt 2>&1; cat $OUT/host_overhead.txt | tail -12
+        timeout 600 python scripts/rank_cost_probe.py --strong 1 2 4 8 > $OUT/rank_cost_strong.txt 2>&1; tail -5 $OUT/rank_cost_strong.txt
+        timeout 600 python scripts/rank_cost_probe.py --strong --no-graph 1 2 4 8 > $OUT/rank_cost_strong_nograph.txt 2>&1; tail -5 $OUT/rank_cost_strong_nograph.txt ;;
+ticktests) timeout 900 python -m pytest tests/test_tick_gpu.py -m gpu -q > $OUT/pytest_tick.log 2>&1; tail -15 $OUT/pytest_tick.log ;;
 smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
 ranks2) NAVHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; tail -c 400 $OUT/bench_2ranks_gloo.json ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log

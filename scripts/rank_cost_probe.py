@@ -17,29 +17,33 @@ from permafrost_engine_amd import tick    # noqa: E402
 
 def main():
     strong = "--strong" in sys.argv
+    drv = dict(driver="python") if "--python-driver" in sys.argv else dict(driver="c", graph="--no-graph" not in sys.argv)
     base = None
     for world in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 8]:
         t0 = time.time()
         if strong:
             T = tick.NavTick(rank=world // 2, world=world, shared_map=True, fields_per_rank=64 // world,
-                             agents_per_rank=100_000 // world, pipeline_fields=True)
+                             agents_per_rank=100_000 // world, pipeline_fields=True, **drv)
         else:
-            T = tick.NavTick(rank=world // 2, world=world)
+            T = tick.NavTick(rank=world // 2, world=world, **drv)
         T._comm_pending = False
         T.pipelined = False          # (no process group here: the exchange is left out)
         setup = time.time() - t0
+        # (compute only: with the Python driver the snapshot is not advanced; the C driver's tick always ping-pongs its
+        # buffers -- the rows of the other ranks stay what they were)
+        one = T.compute if T.driver == "python" else T.step
         for _ in range(4):
-            T.compute()
+            one()
         T.sync()
         t0 = time.perf_counter()
         n = 30
         for _ in range(n):
-            T.compute()
+            one()
         T.sync()
         dt = (time.perf_counter() - t0) / n
         base = base or dt * world
-        print("world %d rank %d: setup %.1f s, %d local requests, slab %d agents of %d: %.4f ms per tick "
-              "(compute only)%s" % (world, T.rank, setup, T.n_req_local, T.a1 - T.a0, T.N, dt * 1e3,
+        print("[%s] world %d rank %d: setup %.1f s, %d local requests, slab %d agents of %d: %.4f ms per tick "
+              "(compute only)%s" % (T.tick_driver, world, T.rank, setup, T.n_req_local, T.a1 - T.a0, T.N, dt * 1e3,
                                     "; ideal 1/%d of one rank's tick = %.4f ms: efficiency %.2f" % (world, base / world * 1e3, base / world / dt)
                                     if strong else ""), flush=True)
         T.close()

@@ -1,0 +1,97 @@
+"""The whole tick behind one call (navhip_tick_*, csrc/tick_api.hip) against the schedule it was written from.
+
+tick.py's compute() / exchange() / advance() is the reference implementation of the tick's schedule: one library call
+per stage, measured into its shape over three rounds.  navhip_tick_run enqueues the same calls from C -- or, with
+NAVHIP_TICK_GRAPH, replays the tick as a captured HIP graph -- and must leave every buffer bit-identical: positions,
+velocities, status bytes, the baked field pool.  (The reference's own loop: navigation_tick_task, movement.c:4263.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(chunk_w=4, fields_per_rank=3, agents_per_rank=600, flow_velocities=True)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _run(driver, ticks=5, graph=False, switch_at=None, **extra):
+    from permafrost_engine_amd import tick
+    kw = dict(KW)
+    kw.update(extra)
+    T = tick.NavTick(driver=driver, graph=graph, **kw)
+    if kw.get("world", 1) > 1:
+        T.pipelined, T._comm_pending = False, False        # (one rank of a job, no process group: compute only)
+    for i in range(ticks):
+        if switch_at is not None and i == switch_at:
+            T.driver = "python" if T.driver == "c" else "c"
+        T.step()
+    T.sync()
+    b, e = T.a0, T.a1
+    out = {"pos": T.t["pos_xz"][b:e].cpu().numpy().copy(), "vel": T.t["vel_xz"][b:e].cpu().numpy().copy(),
+           "status": T.status[b:e].cpu().numpy().copy(), "pool": T.pool.cpu().numpy().copy(), "driver": T.tick_driver}
+    info = getattr(T, "c_tick_info", None)
+    T.close()
+    out["info"] = getattr(T, "c_tick_info", info)
+    return out
+
+
+def _same(a, b):
+    for k in ("pos", "vel", "status", "pool"):
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+
+
+@pytest.mark.parametrize("extra", [dict(pipeline_fields=True), dict(pipeline_fields=False),
+                                   dict(obstacles=60, obstacle_ticks=8), dict(pipeline_fields=True, los=False, crowd_cells=6)],
+                         ids=["fields_ahead", "fields_in_front", "moving_obstacles", "crowded"])
+def test_c_tick_equals_the_python_schedule(navlib, extra):
+    py = _run("python", **extra)
+    c = _run("c", **extra)
+    assert py["driver"].startswith("python") and c["driver"].startswith("c (navhip_tick_run")
+    assert c["info"].ticks == 5 and c["info"].host_enqueue_ms > 0
+    _same(py, c)
+    assert (c["status"] & 1).any()                      # (somebody moved)
+
+
+def test_drivers_can_take_turns(navlib):
+    """bench.py profiles a few ticks on the Python path in the middle of a run of C ticks: the hand-over in both
+    directions leaves the world on the same trajectory."""
+    py = _run("python", ticks=6, pipeline_fields=True)
+    _same(py, _run("c", ticks=6, switch_at=3, pipeline_fields=True))
+    _same(py, _run("python", ticks=6, switch_at=2, pipeline_fields=True))
+
+
+def test_c_tick_of_one_rank_of_a_split_world(navlib):
+    """A uid slab + a share of the requests (one rank of bench.py --scaling strong), compute only."""
+    extra = dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
+                 flow_velocities=False)
+    _same(_run("python", **extra), _run("c", **extra))
+
+
+@pytest.mark.parametrize("extra", [dict(pipeline_fields=True), dict(pipeline_fields=False),
+                                   dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
+                                        flow_velocities=False)],
+                         ids=["fields_ahead", "fields_in_front", "slab"])
+def test_graph_replay_equals_plain_launches(navlib, extra):
+    """NAVHIP_TICK_GRAPH: 12 ticks -- two plain, then one capture per combination of the host-side parities, then
+    replays (the regrouping cadence makes at least three combinations) -- against the Python schedule."""
+    import os
+    py = _run("python", ticks=12, **extra)
+    g = _run("c", ticks=12, graph=True, **extra)
+    _same(py, g)
+    if os.path.basename(os.environ.get("NAVHIP_LIB", "")) == "_navhip_emu.so":
+        assert g["info"].graph == 0                    # (the emulated runtime has no graphs: plain launches)
+    else:
+        assert g["info"].graph == 1 and 2 <= g["info"].graphs_captured <= 10, (g["info"].graph, g["info"].graphs_captured)
+        assert "hip graph" in g["driver"]
+
+
+def test_tick_rejects_malformed_descriptions(navlib):
+    from permafrost_engine_amd import navhip
+    ctx = navlib.NavContext(1, 1)
+    d = navhip.TickDesc()
+    with pytest.raises(navhip.NavHipError):
+        navhip.Tick(ctx, d)                             # no entities, no buffers
+    ctx.close()
