@@ -544,6 +544,10 @@ static uint8_t *s_hip_su_state, *s_hip_su_flags;     /* [nwork] by work item */
 static size_t   s_hip_su_cap;
 static long     s_hip_su_stats[3];                   /* decided on the device, left to the host, passes */
 void move_hip_state_stats(long out[3]) { memcpy(out, s_hip_su_stats, sizeof(s_hip_su_stats)); }
+/* where the last move_hip_state_work spent its time, seconds: {snapshot tables, per-unit inputs, the per-flock nav
+ * queries, navhip_state_pass (transfers + kernels), the settle pass, scattering the answers to the work items} */
+static double   s_hip_su_times[6];
+void move_hip_state_times(double out[6]) { memcpy(out, s_hip_su_times, sizeof(s_hip_su_times)); }
 /* the arrival overlay's settle rule on the device (navhip_arrival_settle): what it left in the unit's
  * struct arrival_unit_state, kept per work item so that move_hip_update_work can hold it against what the
  * reference's own G_Arrival_ShouldSettle leaves there (the harness cannot take the call out of
@@ -714,7 +718,10 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         return false;
     const struct move_gamestate *gs = &s_move_work.gamestate;
     struct hip_snap S;
+    double t_mark = hip_now(), t_now;
+#define HIP_SU_LAP(k) (t_now = hip_now(), s_hip_su_times[k] = t_now - t_mark, t_mark = t_now)
     hip_snap_fill(&S);
+    HIP_SU_LAP(0);
     const int n = S.n;
     if(s_hip_su_cap < s_move_work.nwork) {
         s_hip_su_cap = s_move_work.nwork;
@@ -744,6 +751,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         if(i < lo) lo = i;
         if(i > hi) hi = i;
     }
+    HIP_SU_LAP(1);
     /* the two destination-only queries of arrived() (:2170), once per flock for the nav layer most of its
      * members path on (units of another layer come back as NAVHIP_SU_HOST) */
     const size_t F = S.nflocks;
@@ -776,6 +784,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         toff[f + 1] += N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map), layer, map_pos, fl->target_xz,
                                                 tiles + 2 * toff[f], per);
     }
+    HIP_SU_LAP(2);
     navhip_world W;
     hip_snap_world(&S, &W);
     W.work_begin = lo; W.work_end = hi + 1;
@@ -837,7 +846,9 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         }
     }
     navhip_state_pass_out pout = {st, fl, gate, new_pos, gate_vel, aux ? wait_after : NULL};
+    HIP_SU_LAP(2);                  /* (the enter-range inputs count as queries too) */
     bool ok = hi >= lo && navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
+    HIP_SU_LAP(3);
     free(r_target); free(r_row); free(r_off); free(r_range); free(r_prev); free(r_tiles);
     /* a unit whose facing is within the device's margin of a tolerance came back NAVHIP_SU_HOST: the host's own
      * entity_compute_update answers for it (move_hip_update_work) */
@@ -846,6 +857,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     /* units of flocks with an active arrival zone, skipped above: the settle rule on the positions the gate left */
     if(ok)
         ok = move_hip_settle_work(ctx, &S, &W, begin_idx, end_idx, zoned, gate, new_pos, vdes, st, fl);
+    HIP_SU_LAP(4);
     s_hip_wait_chk = realloc(s_hip_wait_chk, sizeof(int32_t) * 2 * (s_move_work.nwork + 1));
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];
@@ -862,6 +874,8 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         }
     }
     hip_snap_free(&S);
+    HIP_SU_LAP(5);
+#undef HIP_SU_LAP
     return ok;
 }
 

@@ -577,6 +577,11 @@ int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_
  * bit for bit: the same kernels on the same buffers in the same order per stream. */
 typedef struct navhip_tick navhip_tick;
 #define NAVHIP_TICK_GRAPH  0x1u   /* replay the tick as a captured HIP graph                                         */
+#define NAVHIP_TICK_SERIAL 0x2u   /* the whole tick on ONE stream: no side streams, no events, the fields in front of
+                                     the step of their own tick (field_pool_1 unused).  For small worlds, whose tick is a
+                                     chain of short dependent launches: every cross-stream edge costs a barrier packet
+                                     (10-20 us once the host runs ahead of the device) and buys no overlap there --
+                                     configs[0] 0.27 -> ... ms per tick (profiles/r05_host_overhead_*.txt)              */
 typedef struct navhip_tick_desc {
     navhip_world world;             /* DEVICE arrays of the snapshot (buffer set 0: pos_xz, vel_xz, field_pool);
                                        work_begin/work_end = this rank's uid slab                                      */

@@ -150,6 +150,7 @@ def lib():
             ("pfref_move_hip_settle_stats", [C.c_void_p], None),
             ("pfref_move_hip_wait_differ", [], C.c_long),
             ("pfref_move_hip_state_work_seconds", [], C.c_double),
+            ("pfref_move_hip_state_times", [C.c_void_p], None),
             ("pfref_move_set_state_aux", [C.c_void_p] * 3, None),
             ("pfref_move_get_wait_ticks", [C.c_void_p], None),
             ("pfref_move_set_turning", [C.c_void_p] * 2, None),
@@ -710,6 +711,13 @@ class RefMove:
     def hip_state_work_seconds(self):
         """Wall time of the last move_hip_state_work (snapshot fill + the device calls of the state pass)."""
         return float(lib().pfref_move_hip_state_work_seconds())
+
+    def hip_state_times(self):
+        """Where the last move_hip_state_work spent its time, milliseconds."""
+        out = (C.c_double * 6)()
+        lib().pfref_move_hip_state_times(out)
+        return dict(zip(("snapshot", "unit_inputs", "flock_queries", "state_pass_call", "settle_pass", "scatter"),
+                        [x * 1e3 for x in out]))
 
     def hip_wait_differ(self):
         """Wait counters the device's pass left different from the reference's (the state binding's check)."""

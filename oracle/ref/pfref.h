@@ -290,6 +290,7 @@ void pfref_move_get_arrival_units(uint8_t *substate, float *progress_anchor_xz, 
 void pfref_move_hip_settle_stats(long out[4]);
 long pfref_move_hip_wait_differ(void);
 double pfref_move_hip_state_work_seconds(void);   /* wall time of the last move_hip_state_work */
+void pfref_move_hip_state_times(double out[6]);   /* snapshot, per-unit inputs, flock queries, navhip_state_pass, settle pass, scatter */
 /* inputs of the flag / counter arms of the state switch (see ref_move.c); out_flags of pfref_move_state_update(_hip)
  * carry bit 2 = UPDATE_SET_MOVING (out_state = next_state then too) and bit 3 = UPDATE_SET_TARGET_DIR */
 void pfref_move_set_state_aux(const uint8_t *fstate, const int32_t *wait_ticks_left, const uint8_t *wait_prev);

@@ -508,6 +508,7 @@ int pfref_move_hip_snapshot(int cap, float *pos, float *vel, float *radius, floa
 
 static double s_hip_state_work_s;      /* wall time of the last move_hip_state_work (the device half of the state pass) */
 double pfref_move_hip_state_work_seconds(void) { return s_hip_state_work_s; }
+void pfref_move_hip_state_times(double out[6]) { move_hip_state_times(out); }
 
 /* pfref_move_state_update through the binding: move_hip_state_work (ONE navhip_state_update for the slab)
  * then move_hip_update_work per unit.  dev_flags[i] = what the device answered (NAVHIP_SU_*).

@@ -1506,8 +1506,33 @@ __global__ __launch_bounds__(256) void k_spatial_query(nh_grid G, const float *q
 // the arrival arm of entity_compute_update (movement.c:2303; see include/navhip.h): a row of 16 lanes
 // per unit -- the scalar tests on every lane, the flock-mate scan (:953) shared by the lanes
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_state_update(nh_step_params P, navhip_state_in in, uint8_t *out_state,
-                                                      uint8_t *out_flags)
+// the ARRIVED members of every flock, compacted to the front of the flock's range of the member list (any order)
+__global__ __launch_bounds__(256) void k_arrived_compact(nh_step_params P, float4 *arrived, int32_t *arrived_n)
+{
+    __shared__ int count;
+    const int f = blockIdx.x;
+    if(threadIdx.x == 0) count = 0;
+    __syncthreads();
+    const int b = P.flock_offsets[f], e = P.flock_offsets[f + 1];
+    for(int k0 = b; k0 < e; k0 += 256) {
+        const int k = k0 + (int)threadIdx.x;
+        int m = -1;
+        if(k < e) { m = P.flock_members[k]; if(P.state[m] != NAVHIP_STATE_ARRIVED) m = -1; }
+        const uint64_t bal = __ballot(m >= 0);
+        int base = 0;
+        if((threadIdx.x & 63) == 0 && bal) base = atomicAdd(&count, __popcll(bal));
+        base = __shfl(base, 0);
+        if(m >= 0) {
+            const int at = b + base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
+            arrived[at] = make_float4(P.pos_xz[2 * m], P.pos_xz[2 * m + 1], P.radius[m], __int_as_float(m));
+        }
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) arrived_n[f] = count;
+}
+
+__global__ __launch_bounds__(256) void k_state_update(nh_step_params P, navhip_state_in in, const float4 *arrived,
+                                                      const int32_t *arrived_n, uint8_t *out_state, uint8_t *out_flags)
 {
     typedef grp<16> g;
     const int uid = P.work_begin + ((blockIdx.x * 256 + threadIdx.x) >> 4);
@@ -1571,18 +1596,19 @@ __global__ __launch_bounds__(256) void k_state_update(nh_step_params P, navhip_s
             }
             if(!arr) {
                 // ---- a flock mate that touches us has arrived, :2480-2497 (positions and states of the
-                // snapshot: adjacent_flock_members reads the tick's tables)
+                // snapshot: adjacent_flock_members reads the tick's tables).  An existence test -- order does not
+                // matter --, so the row scans the ARRIVED members only: k_arrived_compact has put {x, z, radius, uid}
+                // of those, flock by flock, where the flock's member list starts (a fresh world: none; the scan of
+                // every member cost 405 us per 100 000 units, nine tenths of the state pass)
                 const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
                 bool hit = false;
-                const int b = P.flock_offsets[flock], e = P.flock_offsets[flock + 1];
+                const int b = P.flock_offsets[flock], e = b + arrived_n[flock];
                 for(int k0 = b; k0 < e && !g::any(hit); k0 += 16) {
                     const int k = k0 + gl;
                     if(k < e) {
-                        const int m = P.flock_members[k];
-                        if(m != uid && P.state[m] == NAVHIP_STATE_ARRIVED) {
-                            const v2 mp = mkv(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
-                            hit = vlen(vsub(me, mp)) <= radius + P.radius[m] + 5.0f;                  // ADJACENCY_SEP_DIST
-                        }
+                        const float4 a = arrived[k];
+                        if(__float_as_int(a.w) != uid)
+                            hit = vlen(vsub(me, mkv(a.x, a.y))) <= radius + a.z + 5.0f;                  // ADJACENCY_SEP_DIST
                     }
                 }
                 arr = g::any(hit);
@@ -1600,12 +1626,15 @@ __global__ __launch_bounds__(256) void k_state_update(nh_step_params P, navhip_s
     if(gl == 0) { out_state[uid] = next; out_flags[uid] = flags; }
 }
 
-void nh_launch_state_update(const nh_step_params &P, const navhip_state_in &in, uint8_t *d_state, uint8_t *d_flags,
-                            hipStream_t s)
+void nh_launch_state_update(const nh_step_params &P, const navhip_state_in &in, float4 *d_arrived, int32_t *d_arrived_n,
+                            uint8_t *d_state, uint8_t *d_flags, hipStream_t s)
 {
     const int n = P.work_end - P.work_begin;
-    if(n > 0)
-        hipLaunchKernelGGL(k_state_update, dim3((n + 15) / 16), dim3(256), 0, s, P, in, d_state, d_flags);
+    if(n <= 0) return;
+    if(P.n_flocks > 0)
+        hipLaunchKernelGGL(k_arrived_compact, dim3(P.n_flocks), dim3(256), 0, s, P, d_arrived, d_arrived_n);
+    hipLaunchKernelGGL(k_state_update, dim3((n + 15) / 16), dim3(256), 0, s, P, in, (const float4*)d_arrived,
+                       (const int32_t*)d_arrived_n, d_state, d_flags);
 }
 
 // N_DesiredGroupArrivalVelocity (nav.c:3561): direction under each point in the chunk field of its mapping

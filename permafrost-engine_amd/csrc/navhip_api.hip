@@ -147,6 +147,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(auto &b : ctx->stage) hipFree(b.p);
     hipFree(ctx->coh.p); hipFree(ctx->coh_plan.p); hipFree(ctx->midrec.p); hipFree(ctx->gen_list.p);
     for(auto &b : ctx->nbr) hipFree(b.p);
+    for(auto &b : ctx->arrived) hipFree(b.p);
     for(auto &b : ctx->wl) hipFree(b.p);
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
     for(auto &a : ctx->aux) if(a) hipStreamDestroy(a);
@@ -1010,7 +1011,7 @@ int navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *w, void *stre
 }
 
 // behind a step: its list counters on their way to pinned host memory (side stream, after the searches)
-static int send_step_lists(navhip_ctx *ctx, int parity_used, hipStream_t fallback)
+static int send_step_lists(navhip_ctx *ctx, int parity_used, hipStream_t fallback, bool on_fallback = false)
 {
     if(!ctx->lists_pinned) {
         HIPCHK(ctx, hipHostMalloc((void**)&ctx->lists_pinned, sizeof(int32_t) * NH_WL_LISTS * NH_WL_SUB, hipHostMallocDefault));
@@ -1018,7 +1019,7 @@ static int send_step_lists(navhip_ctx *ctx, int parity_used, hipStream_t fallbac
     }
     const int32_t *src = (const int32_t*)ctx->wl[0].p + parity_used * NH_WL_COUNTERS;
     HIPCHK(ctx, hipMemcpyAsync(ctx->lists_pinned, src, sizeof(int32_t) * NH_WL_LISTS * NH_WL_SUB, hipMemcpyDeviceToHost,
-                               ctx->aux[0] ? ctx->aux[0] : fallback));
+                               (ctx->aux[0] && !on_fallback) ? ctx->aux[0] : fallback));
     return NAVHIP_OK;
 }
 
@@ -1041,7 +1042,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     }
     ctx->counters.step_calls++; ctx->counters.agent_steps += (uint64_t)(P.work_end - P.work_begin);
     const bool prof = ctx->profiling;
-    const bool joined = ctx->pre.valid && !prof && pre_key_matches(ctx, w, P, P.grid);
+    const bool joined = ctx->pre.valid && !prof && !ctx->serial_step && pre_key_matches(ctx, w, P, P.grid);
     if(ctx->pre.valid && !joined) {
         // a prefetch for another snapshot is in flight on the side streams: let it drain before
         // its scratch buffers are reused
@@ -1098,9 +1099,10 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     if(regroup && coh_regroup_due(ctx, P)) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+    const bool serial = ctx->serial_step;
     if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                              ctx->aux[0], ctx->aux[1], ctx->ev_cp)) {
-        rc = send_step_lists(ctx, ctx->wl_parity, s);
+                              serial ? nullptr : ctx->aux[0], serial ? nullptr : ctx->aux[1], ctx->ev_cp)) {
+        rc = send_step_lists(ctx, ctx->wl_parity, s, serial);
         ctx->wl_parity ^= 1;
         if(rc) return rc;
     }
@@ -1287,7 +1289,13 @@ int navhip_state_update_dev(navhip_ctx *ctx, const navhip_world *w, const navhip
     if(P.work_begin < 0 || P.work_end > w->n_ents || P.work_begin > P.work_end) return NAVHIP_ERR_INVALID;
     P.pos_xz = w->pos_xz; P.radius = w->radius; P.flags = w->flags; P.state = w->state; P.flock = w->flock;
     P.flock_target_xz = w->flock_target_xz; P.flock_offsets = w->flock_offsets; P.flock_members = w->flock_members;
-    nh_launch_state_update(P, *in, out_state, out_flags, stream ? (hipStream_t)stream : ctx->stream);
+    // (scratch of the arrived-flock-mate rule: the ARRIVED members of every flock, compacted)
+    const size_t nmem = (size_t)w->n_ents;           // every entity belongs to at most one flock
+    int rc = ensure_buf(ctx, ctx->arrived[0], 16 * nmem);
+    if(!rc) rc = ensure_buf(ctx, ctx->arrived[1], 4 * (size_t)(w->n_flocks > 0 ? w->n_flocks : 1));
+    if(rc) return rc;
+    nh_launch_state_update(P, *in, (float4*)ctx->arrived[0].p, (int32_t*)ctx->arrived[1].p, out_state, out_flags,
+                           stream ? (hipStream_t)stream : ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
 }

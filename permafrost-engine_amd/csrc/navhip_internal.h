@@ -52,6 +52,7 @@ struct navhip_ctx {
                                //               block_sum, slab box, recA, recV, pool_of
     unsigned     sp_builds;    // spatial-hash builds so far: parity selects the slab box of a build
     buf          nbr[3];       // neighbour walk: separation force, counts, neighbour lists
+    buf          arrived[2];   // state update: {x, z, radius, uid} of every flock's ARRIVED members, compacted; counts
     buf          midrec;       // per-entity record k_agent_mid leaves for the work-list consumers
     buf          wl[2];        // work lists: 2 x NH_WL_COUNT counters (alternating), ids
     int          wl_parity;
@@ -75,6 +76,9 @@ struct navhip_ctx {
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
     int          regroup_override;  // 0 = the library's own cadence (coh_regroup_due); 1 / 2 = the caller (tick_api.hip,
                                     // which keys its captured graphs on the decision) says regroup / do not
+    bool         serial_step;       // navhip_agent_step_dev runs EVERYTHING on the caller's stream (no side streams, no events):
+                                    // the tick of a small world is a chain of dependent launches, and every cross-stream
+                                    // edge costs more than the overlap it buys (tick_api.hip, NAVHIP_TICK_SERIAL)
     int64_t      coh_regroup_key[4]; int coh_regroup_age;   // what the last regrouping was built for, ticks since
     // the snapshot a prefetch was started for: everything the side streams baked into their results
     struct { bool valid; const float *pos_xz, *vel_xz, *radius, *arrival_sink_xz; const uint32_t *flags;

@@ -57,7 +57,7 @@ struct navhip_tick {
     hipStream_t      s, f, comm;      // agent chain | field builds ahead | exchange
     bool             own_s, own_f, own_comm;
     hipEvent_t       ev_fields[2], ev_step, ev_comm, ev_side, ev_tmp;
-    bool             ahead, pipelined, comm_pending, computed;
+    bool             ahead, pipelined, comm_pending, computed, serial;
     int64_t          ticks;
     int              regroup_age;
     bool             graph;
@@ -97,6 +97,22 @@ static int compute_plain(navhip_tick *T)
     navhip_ctx *ctx = T->ctx;
     const int p = (int)(T->ticks & 1);
     const navhip_world *w = &T->W[p];
+    if(T->serial) {
+        // one stream, no events: blockers -> fields -> spatial hash -> neighbour walk -> cohesion -> the rest of the step
+        if(T->d.dev_moves) {
+            const navhip_circle *mv = T->d.dev_moves + (size_t)((T->d.move_tick0 + T->ticks) % T->d.n_move_ticks) * T->d.n_moves;
+            RCCHK(navhip_blockers_circles_dev(ctx, mv, T->d.n_moves, w->map_pos_x, w->map_pos_z, (void*)T->s));
+        }
+        RCCHK(build_fields(T, T->pool[0], T->s));
+        if(T->d.dev_moves) RCCHK(navhip_clear_changed(ctx, (void*)T->s));
+        if(T->comm_pending) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_comm, 0));
+        ctx->serial_step = true;
+        int rc = navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s);
+        ctx->serial_step = false;
+        if(rc) return rc;
+        if(T->pipelined) HIPCHK(ctx, hipEventRecord(T->ev_step, T->s));
+        return NAVHIP_OK;
+    }
     if(T->pipelined)            // behind the previous tick's all-gather, beside the field builds below
         RCCHK(navhip_agent_prefetch_dev(ctx, w, (void*)T->comm));
     if(T->ahead) {
@@ -150,22 +166,29 @@ static int compute_graph(navhip_tick *T)
         const unsigned gen_before = ctx->gen_launches, sp_before = ctx->sp_builds;
         HIPCHK(ctx, hipStreamBeginCapture(T->s, hipStreamCaptureModeRelaxed));
         ctx->regroup_override = regroup ? 1 : 2;
-        int rc = navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE);
-        if(!rc && T->ahead) {
-            rc = navhip_stream_wait_stage(ctx, (void*)T->f, stage);
-            if(!rc) rc = build_fields(T, T->pool[p ^ 1], T->f);
-            if(!rc && hipEventRecord(T->ev_fields[0], T->f) != hipSuccess) rc = NAVHIP_ERR_DEVICE;
-        }else if(!rc) {
+        int rc = NAVHIP_OK;
+        if(T->serial) {
             rc = build_fields(T, T->pool[0], T->s);
-        }
-        if(!rc) rc = navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s);
-        // every stream the capture forked into comes back to the origin: the copy of the list counters on the library's
-        // side stream, the field builds
-        if(!rc && ctx->aux[0]) {
-            if(hipEventRecord(T->ev_side, ctx->aux[0]) != hipSuccess || hipStreamWaitEvent(T->s, T->ev_side, 0) != hipSuccess)
+            ctx->serial_step = true;
+            if(!rc) rc = navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s);
+            ctx->serial_step = false;
+        }else{
+            rc = navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE);
+            if(!rc && T->ahead) {
+                rc = navhip_stream_wait_stage(ctx, (void*)T->f, stage);
+                if(!rc) rc = build_fields(T, T->pool[p ^ 1], T->f);
+                if(!rc && hipEventRecord(T->ev_fields[0], T->f) != hipSuccess) rc = NAVHIP_ERR_DEVICE;
+            }else if(!rc) {
+                rc = build_fields(T, T->pool[0], T->s);
+            }
+            if(!rc) rc = navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s);
+            // every stream the capture forked into comes back to the origin: the copy of the list counters on the
+            // library's side stream, the field builds
+            if(!rc && ctx->aux[0]
+            && (hipEventRecord(T->ev_side, ctx->aux[0]) != hipSuccess || hipStreamWaitEvent(T->s, T->ev_side, 0) != hipSuccess))
                 rc = NAVHIP_ERR_DEVICE;
+            if(!rc && T->ahead && hipStreamWaitEvent(T->s, T->ev_fields[0], 0) != hipSuccess) rc = NAVHIP_ERR_DEVICE;
         }
-        if(!rc && T->ahead && T->d.n_reqs > 0 && hipStreamWaitEvent(T->s, T->ev_fields[0], 0) != hipSuccess) rc = NAVHIP_ERR_DEVICE;
         ctx->regroup_override = 0;
         hipError_t e = hipStreamEndCapture(T->s, &g);
         if(rc || e != hipSuccess || !g) {
@@ -261,7 +284,8 @@ int navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tic
     navhip_tick *T = new (std::nothrow) navhip_tick();
     if(!T) return NAVHIP_ERR_NOMEM;
     T->ctx = ctx; T->d = *desc;
-    T->ahead = desc->field_pool_1 != nullptr;
+    T->serial = (desc->flags & NAVHIP_TICK_SERIAL) != 0;
+    T->ahead = desc->field_pool_1 != nullptr && !T->serial;
     T->pipelined = desc->bounds != nullptr;
     if(T->pipelined) {
         const int world = navhip_comm_world(ctx);

@@ -1036,7 +1036,7 @@ NavContext.G_ClearPath_NewVelocity = _ctx_clearpath
 # ---------------------------------------------------------------------------------------------
 # the whole tick behind one call (navhip_tick_*, csrc/tick_api.hip)
 # ---------------------------------------------------------------------------------------------
-TICK_GRAPH = 0x1
+TICK_GRAPH, TICK_SERIAL = 0x1, 0x2
 
 
 class TickDesc(C.Structure):

@@ -105,7 +105,7 @@ class NavTick:
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
                  debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True,
-                 straddle=0.0, los=False, flow_velocities=False, share_fields=False, driver="c", graph=None):
+                 straddle=0.0, los=False, flow_velocities=False, share_fields=False, driver="c", graph=None, serial=None):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cpu") if EMULATED else torch.device("cuda", device)
         tcuda.set_device(self.dev)
@@ -411,12 +411,19 @@ class NavTick:
         # tick, the schedule below in C; with graph=True each tick is one hipGraphLaunch of the tick captured per
         # parity) -- for every world whose baked tiles do not travel; "python" = this file's compute() / exchange()
         # / advance(), the reference implementation of that schedule, which the C loop is tested against.
-        # graph=None: NAVTICK_GRAPH=1/0 decides, else on where the host's enqueue time is the tick's floor (small
-        # per-rank worlds), off where the GPU tick hides it and the CU-masked field stream pays (configs[2]).
+        # serial (C driver only): the whole tick on ONE stream, no side streams and no events -- for small per-rank worlds,
+        # whose tick is a chain of short dependent launches (every cross-stream edge is a barrier packet of 10-20 us once
+        # the host runs ahead of the device, and there is nothing to overlap); None: by slab size, NAVTICK_SERIAL=0/1
+        # overrides.  graph: replay the tick as a captured HIP graph -- measured SLOWER on this runtime
+        # (profiles/r05_host_overhead_b.txt: one hipGraphLaunch of the multi-stream tick 0.13 ms of host time and 0.84
+        # against 0.34 ms per tick at configs[2]); off unless asked for (NAVTICK_GRAPH=1).
         self.driver = driver if (self.tile_exchange == "none" or self.solo) else "python"
+        if serial is None:
+            env = os.environ.get("NAVTICK_SERIAL")
+            serial = (env == "1") if env in ("0", "1") else (self.a1 - self.a0) <= int(os.environ.get("NAVTICK_SERIAL_BELOW", "20000"))
+        self.serial = bool(serial)
         if graph is None:
-            env = os.environ.get("NAVTICK_GRAPH")
-            graph = (env == "1") if env in ("0", "1") else (self.a1 - self.a0) <= 30000
+            graph = os.environ.get("NAVTICK_GRAPH") == "1"
         self.graph = bool(graph)
         self._ctick = None
         self.tick_driver = "python (tick.py)"
@@ -562,11 +569,11 @@ class NavTick:
             self._bounds_c = np.ascontiguousarray(self._bounds, np.int32)
             d.bounds = self._bounds_c.ctypes.data
             d.comm_stream = self.comm.cuda_stream
-        d.flags = navhip.TICK_GRAPH if self.graph else 0
+        d.flags = (navhip.TICK_GRAPH if self.graph else 0) | (navhip.TICK_SERIAL if self.serial else 0)
         self._ctick = navhip.Tick(self.ctx, d, keep)
         self._ctick_tick0 = self.tick_no
         info = self._ctick.info()
-        self.tick_driver = "c (navhip_tick_run%s)" % (", hip graph" if info.graph else "")
+        self.tick_driver = "c (navhip_tick_run%s%s)" % (", one stream" if self.serial else "", ", hip graph" if info.graph else "")
         return self._ctick
 
     def _c_tick_drop(self):
@@ -595,7 +602,7 @@ class NavTick:
         # (the Python view of the ping-pong, without rebuilding the structs: the C tick has its own two)
         self.t["pos_xz"], self.new_pos = self.new_pos, self.t["pos_xz"]
         self.t["vel_xz"], self.new_vel = self.new_vel, self.t["vel_xz"]
-        if self.pipeline_fields:
+        if self.pipeline_fields and not self.serial:
             self.pool, self.pool_next = self.pool_next, self.pool
             self.t["field_pool"] = self.pool
         self.tick_no += 1

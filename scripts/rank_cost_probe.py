@@ -17,7 +17,8 @@ from permafrost_engine_amd import tick    # noqa: E402
 
 def main():
     strong = "--strong" in sys.argv
-    drv = dict(driver="python") if "--python-driver" in sys.argv else dict(driver="c", graph="--no-graph" not in sys.argv)
+    drv = dict(driver="python") if "--python-driver" in sys.argv else \
+        dict(driver="c", graph="--graph" in sys.argv, serial=False if "--no-serial" in sys.argv else None)
     base = None
     for world in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 8]:
         t0 = time.time()
@@ -32,6 +33,7 @@ def main():
         # (compute only: with the Python driver the snapshot is not advanced; the C driver's tick always ping-pongs its
         # buffers -- the rows of the other ranks stay what they were)
         one = T.compute if T.driver == "python" else T.step
+        T.new_pos.copy_(T.t["pos_xz"]); T.new_vel.copy_(T.t["vel_xz"])     # (both buffer sets: the whole snapshot)
         for _ in range(4):
             one()
         T.sync()

@@ -17,11 +17,11 @@ def _torch():
     return torch
 
 
-def _run(driver, ticks=5, graph=False, switch_at=None, **extra):
+def _run(driver, ticks=5, graph=False, switch_at=None, serial=False, **extra):
     from permafrost_engine_amd import tick
     kw = dict(KW)
     kw.update(extra)
-    T = tick.NavTick(driver=driver, graph=graph, **kw)
+    T = tick.NavTick(driver=driver, graph=graph, serial=serial, **kw)
     if kw.get("world", 1) > 1:
         T.pipelined, T._comm_pending = False, False        # (one rank of a job, no process group: compute only)
     for i in range(ticks):
@@ -55,12 +55,29 @@ def test_c_tick_equals_the_python_schedule(navlib, extra):
     assert (c["status"] & 1).any()                      # (somebody moved)
 
 
+@pytest.mark.parametrize("extra", [dict(pipeline_fields=True), dict(obstacles=60, obstacle_ticks=8),
+                                   dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
+                                        flow_velocities=False)],
+                         ids=["plain", "moving_obstacles", "slab"])
+def test_one_stream_tick_equals_the_python_schedule(navlib, extra):
+    """NAVHIP_TICK_SERIAL: the tick of a small world on ONE stream -- no side streams, no events, the fields in front of
+    the step -- gives what the overlapped schedule gives."""
+    py = _run("python", ticks=6, **extra)
+    c = _run("c", ticks=6, serial=True, **extra)
+    assert "one stream" in c["driver"]
+    for k in ("pos", "vel", "status"):
+        assert np.array_equal(py[k].view(np.uint8), c[k].view(np.uint8)), k
+
+
 def test_drivers_can_take_turns(navlib):
     """bench.py profiles a few ticks on the Python path in the middle of a run of C ticks: the hand-over in both
     directions leaves the world on the same trajectory."""
     py = _run("python", ticks=6, pipeline_fields=True)
     _same(py, _run("c", ticks=6, switch_at=3, pipeline_fields=True))
     _same(py, _run("python", ticks=6, switch_at=2, pipeline_fields=True))
+    c = _run("c", ticks=6, switch_at=3, serial=True, pipeline_fields=True)
+    for k in ("pos", "vel", "status"):
+        assert np.array_equal(py[k].view(np.uint8), c[k].view(np.uint8)), k
 
 
 def test_c_tick_of_one_rank_of_a_split_world(navlib):
@@ -74,13 +91,15 @@ def test_c_tick_of_one_rank_of_a_split_world(navlib):
                                    dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
                                         flow_velocities=False)],
                          ids=["fields_ahead", "fields_in_front", "slab"])
-def test_graph_replay_equals_plain_launches(navlib, extra):
+@pytest.mark.parametrize("serial", [False, True], ids=["streams", "one_stream"])
+def test_graph_replay_equals_plain_launches(navlib, extra, serial):
     """NAVHIP_TICK_GRAPH: 12 ticks -- two plain, then one capture per combination of the host-side parities, then
     replays (the regrouping cadence makes at least three combinations) -- against the Python schedule."""
     import os
     py = _run("python", ticks=12, **extra)
-    g = _run("c", ticks=12, graph=True, **extra)
-    _same(py, g)
+    g = _run("c", ticks=12, graph=True, serial=serial, **extra)
+    for k in ("pos", "vel", "status") + (() if serial else ("pool",)):
+        assert np.array_equal(py[k].view(np.uint8), g[k].view(np.uint8)), k
     if os.path.basename(os.environ.get("NAVHIP_LIB", "")) == "_navhip_emu.so":
         assert g["info"].graph == 0                    # (the emulated runtime has no graphs: plain launches)
     else:

@@ -60,10 +60,7 @@ def main():
     t0 = time.perf_counter()
     ref_state, ref_flags = mv.state_update(new_vel, vdes)
     t_ref = time.perf_counter() - t0
-    out = {"what": "state half of the reference's movement tick, %d work items, %d flocks, %dx%d chunks: move_hip_state_work "
-                   "(ONE navhip_state_pass, host buffers) vs entity_compute_update per unit on one core"
-                   % (N, K, W, W),
-           "cpu_ms_per_tick_1core": t_ref * 1e3}
+    out = {"work_items": N, "flocks": K, "chunks": W, "cpu_ms_per_tick_1core": t_ref * 1e3}
     try:
         if not nav.hip_init():
             out["error"] = "no device"
@@ -73,19 +70,17 @@ def main():
             out["identical"] = bool(np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags))
             out["decided_on_device"] = float(((dv & 0x80) == 0).mean())
             out["to_arrived"], out["to_waiting"] = int(((st == 2) & (state != 2)).sum()), int(((st == 4) & (state != 4)).sum())
-            times = []
+            times, best_parts = [], None
             for _ in range(args.reps):
                 mv.set_state_aux(np.zeros(N, np.uint8), ticks, np.zeros(N, np.uint8))
                 mv.state_update_hip(new_vel, vdes)
                 times.append(mv.hip_state_work_seconds())
+                if times[-1] == min(times):
+                    best_parts = mv.hip_state_times()
             out["hip_ms_per_tick"] = min(times) * 1e3
             out["hip_ms_per_tick_all"] = [t * 1e3 for t in times]
             out["speedup_vs_1core"] = t_ref / min(times)
-            out["note"] = ("hip = move_hip_state_work: filling the snapshot tables and per-unit inputs on the host, the two "
-                           "nav queries per flock, the device calls with their transfers; the pose half of the patch (which "
-                           "the harness can only get by running the reference's whole entity_compute_update again) is not "
-                           "in it.  cpu = entity_compute_update for every unit on ONE core; the engine forks it over its "
-                           "tasks like the velocity half")
+            out["hip_ms_parts"] = best_parts
     finally:
         pfref.RefNav.hip_shutdown()
         pfref.RefMove.unload()
