@@ -541,6 +541,9 @@ int N_HIP_ClosestIslandTiles(struct nav_private *priv, enum nav_layer layer, vec
                              int16_t *out_abs, int max_tiles);                    /* nav_hip.c */
 
 static uint8_t *s_hip_su_state, *s_hip_su_flags;     /* [nwork] by work item */
+static float   *s_hip_su_dest;                       /* [nwork][2] the surround arm's position (NAVHIP_SU_SURROUND_PREV / _DEST) */
+static long     s_hip_surround_differ;               /* surround positions that differ from what the reference's switch stored */
+long move_hip_surround_differ(void) { return s_hip_surround_differ; }
 static size_t   s_hip_su_cap;
 static long     s_hip_su_stats[3];                   /* decided on the device, left to the host, passes */
 void move_hip_state_stats(long out[3]) { memcpy(out, s_hip_su_stats, sizeof(s_hip_su_stats)); }
@@ -563,7 +566,8 @@ static long     s_hip_settle_stats[4];               /* units decided by the dev
 void move_hip_settle_stats(long out[4]) { memcpy(out, s_hip_settle_stats, sizeof(s_hip_settle_stats)); }
 
 struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned;
-                        uint8_t *fstate, *wait_prev; int32_t *wait_ticks; float *ent_rot, *target_dir; };
+                        uint8_t *fstate, *wait_prev; int32_t *wait_ticks; float *ent_rot, *target_dir;
+                        float *interp_from, *interp_step; };
 
 static void hip_state_items_range(int begin, int end, void *arg)
 {
@@ -594,8 +598,14 @@ static void hip_state_items_range(int begin, int end, void *arg)
             memcpy(T->ent_rot + 4 * i, &rot, sizeof(float) * 4);
             memcpy(T->target_dir + 4 * i, &ms->target_dir, sizeof(float) * 4);
         }
-        T->skip[i] = (20 / hz_count(s_move_work.hz)) > 1;
-        if(!T->skip[i] && S->flock[i] >= 0) {
+        /* a rate below 20 Hz: the switch tests the first interpolated position of an accepted move (:2368-2377) -- the
+         * device makes it from movestate.next_pos and .step */
+        if(T->interp_from) {
+            T->interp_from[2 * i] = ms->next_pos.x; T->interp_from[2 * i + 1] = ms->next_pos.z;
+            T->interp_step[i] = ms->step;
+        }
+        T->skip[i] = 0;
+        if(S->flock[i] >= 0) {
             struct flock *fl = &vec_AT(&s_flocks, S->flock[i]);
             struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,
                 Entity_NavLayerWithRadius(S->flags[i], S->radius[i]));
@@ -742,8 +752,12 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     memset(ent_rot, 0, sizeof(float) * (4 * n + 4)); memset(target_dir, 0, sizeof(float) * (4 * n + 4));
     memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2)); memset(skip, 0, n + 1);
     memset(new_vel, 0, sizeof(float) * (2 * n + 2)); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); memset(zoned, 0, n + 1);
+    const bool sub20 = (20 / hz_count(s_move_work.hz)) > 1;
+    float *interp_from = sub20 ? hip_arena(sizeof(float) * (2 * n + 2)) : NULL, *interp_step = sub20 ? hip_arena(sizeof(float) * (n + 1)) : NULL;
+    if(sub20) { memset(interp_from, 0, sizeof(float) * (2 * n + 2)); memset(interp_step, 0, sizeof(float) * (n + 1)); }
     hip_work_dense_prepare();
-    struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned, fstate, wait_prev, wait_ticks, ent_rot, target_dir};
+    struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned, fstate, wait_prev, wait_ticks, ent_rot, target_dir,
+                               interp_from, interp_step};
     hip_for(hip_state_items_range, end_idx - begin_idx + 1, &T);
     int lo = n, hi = -1;
     for(int w = begin_idx; w <= end_idx; w++) {
@@ -789,13 +803,13 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     hip_snap_world(&S, &W);
     W.work_begin = lo; W.work_end = hi + 1;
     uint8_t *st = hip_arena(n + 1), *fl = hip_arena(n + 1);
-    const bool aux = (20 / hz_count(s_move_work.hz)) == 1;
+    const bool aux = true;          /* (every rate: the arms read the position the gate kernel leaves) */
     /* ONE call for the pass (navhip_state_pass): the heading gate of every unit (:2319-2336) -> the arrival arm on the
      * positions the gate leaves (navhip_state_update) -> the arms that flags, the wait counter, the angle to target_dir and
      * the distance to the target decide (navhip_state_update_aux); the snapshot travels once */
     navhip_state_pass_in pin;
     memset(&pin, 0, sizeof(pin));
-    pin.gate = (navhip_gate_in){next_rot, new_vel, vdes};
+    pin.gate = (navhip_gate_in){next_rot, new_vel, vdes, interp_from, interp_step};
     pin.state = (navhip_state_in){NULL, NULL, skip, flayer, nearest, toff, tiles};
     int32_t *r_target = NULL, *r_row = NULL, *r_off = NULL; float *r_range = NULL, *r_prev = NULL; int16_t *r_tiles = NULL;
     if(aux) {
@@ -845,11 +859,72 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
             pin.aux.n_range_rows = n_range;
         }
     }
+    /* STATE_SURROUND_ENTITY (:2509-2567) at 20 Hz: the switch runs on the device, the two queries on the unit-query
+     * context stay here -- whether the unit already touches its target (or the target is gone), and, for the units that
+     * reach the query (:2532-2534), the closest reachable position next to the target from both positions the tick can
+     * test: pos + new velocity, and pos (the heading gate halts the unit) */
+    int32_t *s_target = NULL; uint8_t *s_query = NULL; float *s_tprev = NULL, *s_nprev = NULL, *s_dest = NULL, *s_out = NULL;
+    int n_surround = 0;
+    for(int w = begin_idx; !sub20 && w <= end_idx; w++)
+        n_surround += S.state[s_hip_witem.idx[w]] == STATE_SURROUND_ENTITY;
+    if(n_surround > 0) {
+        s_target = malloc(sizeof(int32_t) * n); s_query = calloc(n, 1); s_tprev = calloc(2 * n, sizeof(float));
+        s_nprev = calloc(2 * n, sizeof(float)); s_dest = calloc(4 * n, sizeof(float)); s_out = calloc(2 * n, sizeof(float));
+        for(int i = 0; i < n; i++) s_target[i] = -2;
+        for(int w = begin_idx; w <= end_idx; w++) {
+            const int i = s_hip_witem.idx[w];
+            if(S.state[i] != STATE_SURROUND_ENTITY)
+                continue;
+            const uint32_t uid = S.uids[i];
+            const struct movestate *ms = movestate_get(uid);
+            s_tprev[2 * i] = ms->surround_target_prev.x; s_tprev[2 * i + 1] = ms->surround_target_prev.z;
+            s_nprev[2 * i] = ms->surround_nearest_prev.x; s_nprev[2 * i + 1] = ms->surround_nearest_prev.z;
+            if(ms->surround_target_uid == NULL_UID) { s_target[i] = -1; continue; }
+            if(!entity_exists(ms->surround_target_uid)
+            || M_NavObjAdjacentFrom(gs->map, uid, ms->surround_target_uid, &s_move_work.unit_query_ctx)) {
+                s_target[i] = -1; s_query[i] = NAVHIP_SQ_ADJACENT;        /* (-> ARRIVED either way, :2518-2525) */
+                continue;
+            }
+            khiter_t k = kh_get(id, S.dense, ms->surround_target_uid);
+            if(k == kh_end(S.dense))
+                continue;                                                 /* (a target outside the snapshot: the host's) */
+            s_target[i] = (int32_t)kh_value(S.dense, k);
+            const vec2_t tp = {S.pos[2 * s_target[i]], S.pos[2 * s_target[i] + 1]};
+            vec2_t delta, dest;
+            PFM_Vec2_Sub((vec2_t*)&tp, (vec2_t*)&ms->surround_target_prev, &delta);
+            if(!(PFM_Vec2_Len(&delta) > EPSILON || PFM_Vec2_Len(&ms->velocity) < EPSILON))
+                continue;                                                 /* (the query does not run this tick) */
+            const enum nav_layer layer = Entity_NavLayerWithRadius(S.flags[i], S.radius[i]);
+            const vec2_t pos = {S.pos[2 * i], S.pos[2 * i + 1]}, vel = {new_vel[2 * i], new_vel[2 * i + 1]};
+            vec2_t from[2] = {pos, pos};
+            PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &from[0]);
+            for(int c = 0; c < 2; c++) {
+                if(c == 1 && from[0].x == from[1].x && from[0].z == from[1].z) {      /* (zero velocity: one query) */
+                    if(s_query[i] & NAVHIP_SQ_HAS_DEST_0) {
+                        s_query[i] |= NAVHIP_SQ_HAS_DEST_1; s_dest[4 * i + 2] = s_dest[4 * i]; s_dest[4 * i + 3] = s_dest[4 * i + 1];
+                    }
+                    break;
+                }
+                if(M_NavClosestReachableAdjacentPosFrom(gs->map, layer, from[c], ms->surround_target_uid, &s_move_work.unit_query_ctx, &dest)) {
+                    s_query[i] |= (uint8_t)(NAVHIP_SQ_HAS_DEST_0 << c);
+                    s_dest[4 * i + 2 * c] = dest.x; s_dest[4 * i + 2 * c + 1] = dest.z;
+                }
+            }
+        }
+        pin.aux.surround_target = s_target; pin.aux.surround_query = s_query; pin.aux.surround_target_prev_xz = s_tprev;
+        pin.aux.surround_nearest_prev_xz = s_nprev; pin.aux.surround_dest_xz = s_dest; pin.aux.out_surround_dest_xz = s_out;
+    }
     navhip_state_pass_out pout = {st, fl, gate, new_pos, gate_vel, aux ? wait_after : NULL};
     HIP_SU_LAP(2);                  /* (the enter-range inputs count as queries too) */
     bool ok = hi >= lo && navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
     HIP_SU_LAP(3);
     free(r_target); free(r_row); free(r_off); free(r_range); free(r_prev); free(r_tiles);
+    s_hip_su_dest = realloc(s_hip_su_dest, sizeof(float) * 2 * (s_move_work.nwork + 1));
+    for(int w = begin_idx; w <= end_idx; w++) {
+        const int i = s_hip_witem.idx[w];
+        s_hip_su_dest[2 * w] = s_out ? s_out[2 * i] : 0.0f; s_hip_su_dest[2 * w + 1] = s_out ? s_out[2 * i + 1] : 0.0f;
+    }
+    free(s_target); free(s_query); free(s_tprev); free(s_nprev); free(s_dest); free(s_out);
     /* a unit whose facing is within the device's margin of a tolerance came back NAVHIP_SU_HOST: the host's own
      * entity_compute_update answers for it (move_hip_update_work) */
     for(int w = begin_idx; ok && w <= end_idx; w++)
@@ -903,8 +978,20 @@ static void move_hip_update_work(int begin_idx, int end_idx)
         }
         if(s_hip_su_flags[w] & NAVHIP_SU_HOST)
             continue;
+        if(s_hip_su_flags[w] & NAVHIP_SU_SURROUND_PREV) {
+            /* (the reference's own switch has just stored surround_target_prev / surround_nearest_prev in movestate, :2551:
+             * the device's position is held against it; a maintainer stores the device's) */
+            const struct movestate *ms = movestate_get(out->ent_uid);
+            if(ms->surround_nearest_prev.x != s_hip_su_dest[2 * w] || ms->surround_nearest_prev.z != s_hip_su_dest[2 * w + 1])
+                s_hip_surround_differ++;
+        }
         out->patch.flags = (enum movestate_flags)(out->patch.flags & ~(UPDATE_SET_STATE | UPDATE_SET_MOVING | UPDATE_SET_TARGET_DIR
                                                                         | UPDATE_SET_DEST | UPDATE_SET_TARGET_PREV));
+        if(s_hip_su_flags[w] & NAVHIP_SU_SURROUND_DEST) {               /* a new position next to the target, :2555-2560 */
+            out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_DEST);
+            out->patch.next_dest = (vec2_t){s_hip_su_dest[2 * w], s_hip_su_dest[2 * w + 1]};
+            out->patch.next_attack = false;
+        }
         if(s_hip_su_flags[w] & NAVHIP_SU_SET_STATE) {
             out->patch.flags = (enum movestate_flags)(out->patch.flags | UPDATE_SET_STATE);
             out->patch.next_state = (enum move_state)s_hip_su_state[w];

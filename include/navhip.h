@@ -687,6 +687,15 @@ typedef struct navhip_gate_in {
     const float *next_rot;     /* [n][4] movestate.next_rot (x, y, z, w)                            */
     const float *new_vel_xz;   /* [n][2] move_work_out.ent_vel: the velocity the step produced      */
     const float *vdes_xz;      /* [n][2] move_work_out.ent_des_v                                    */
+    /* Movement rates below 20 Hz (world->hz = 10 / 5 / 1), both NULL at 20 Hz: entity_compute_update then tests -- in
+     * the state switch, in G_Arrival_ShouldSettle -- not pos + vel but the first INTERPOLATED position of the move
+     * when the move is accepted (movement.c:2356-2377: |vel| > 0, new position pathable, and not blocked unless the
+     * unit already stands on a blocker): interpolate_positions(movestate.next_pos, new_pos, movestate.step) (:2222,
+     * float arithmetic; `to` itself when |1 - step| < 1/1024).  out_new_pos_xz receives that position.  Needs
+     * world->radius and ->flags (the unit's nav layer); a unit whose layer has no cost plane comes back
+     * NAVHIP_GATE_HOST. */
+    const float *interp_from_xz;   /* [n][2] movestate.next_pos (x, z)                              */
+    const float *interp_step;      /* [n]    movestate.step                                         */
 } navhip_gate_in;
 #define NAVHIP_GATE_TURN  0x01   /* turn_to_move: the velocity was zeroed, the unit pivots (UPDATE_TURNING_IN_PLACE) */
 #define NAVHIP_GATE_HOST  0x80   /* within the margin: not decided, out_vel / out_new_pos hold the UNGATED step     */
@@ -711,6 +720,10 @@ int  navhip_heading_gate_dev(navhip_ctx *ctx, const navhip_world *dev_world, con
 #define NAVHIP_SU_TARGET_DIR  0x08   /* UPDATE_SET_TARGET_DIR rides along: next_target_dir = fstate.target_orientation   */
 #define NAVHIP_SU_SET_DEST    0x10   /* UPDATE_SET_DEST | UPDATE_SET_TARGET_PREV: next_dest = next_target_prev = the target's
                                         position, next_attack = false (:2597-2602); the state stays                      */
+#define NAVHIP_SU_SURROUND_DEST 0x20 /* STATE_SURROUND_ENTITY: UPDATE_SET_DEST | UPDATE_SET_STATE, next_dest =
+                                        out_surround_dest_xz[i], next_attack = false, the state stays (:2555-2560)         */
+#define NAVHIP_SU_SURROUND_PREV 0x40 /* movestate.surround_target_prev = the target's position, .surround_nearest_prev =
+                                        out_surround_dest_xz[i] (the reference writes them inside the switch, :2551-2552)  */
 #define NAVHIP_FS_MEMBER      0x01   /* fstate.fid != NULL_FID                                                           */
 #define NAVHIP_FS_READY       0x02   /* fstate.assignment_ready                                                          */
 #define NAVHIP_FS_ASSIGNED    0x04   /* fstate.assigned_to_cell                                                          */
@@ -742,7 +755,28 @@ typedef struct navhip_state_aux_in {
     const int32_t  *range_tiles_off;  /* [rows + 1] CSR offsets into range_tiles                                         */
     const int16_t  *range_tiles;      /* [..][2] absolute nav tiles (row, column)                                        */
     int32_t         n_range_rows;     /* rows of range_tiles_off (host-buffer call: sizes the transfer)                  */
+    /* STATE_SURROUND_ENTITY (:2509-2567), surround_target NULL = its units stay NAVHIP_SU_HOST (as do all of them at a
+     * rate below 20 Hz).  The two nav queries on the unit-query context stay the host's, handed over per unit exactly as
+     * flock_nearest_xz is for arrived(): whether the unit already touches its target (M_NavObjAdjacentFrom, map.c:1061 --
+     * or the target is gone), and the closest reachable position next to the target (M_NavClosestReachableAdjacentPosFrom,
+     * map.c:860) from BOTH positions the tick can test: pos + new velocity, and pos (the heading gate zeroed the
+     * velocity).  The host only needs to fill the query answers for units that reach the query (:2532-2545: the target
+     * has moved since surround_target_prev, or the unit stands still).  The device runs the switch: no target / adjacent
+     * / no reachable position -> ARRIVED; the position differs from the flock's target -> NAVHIP_SU_SURROUND_DEST with the
+     * position in out_surround_dest_xz; no guidance -> WAITING; and reports NAVHIP_SU_SURROUND_PREV where the reference
+     * stores surround_target_prev = the target's position, surround_nearest_prev = out_surround_dest_xz[i] (:2551-2552).
+     * world: pos_xz, vel_xz (movestate.velocity), flock, flock_target_xz too. */
+    const int32_t  *surround_target;  /* [n] row of movestate.surround_target_uid; -1 = NULL_UID; -2 = leave to the host */
+    const uint8_t  *surround_query;   /* [n] NAVHIP_SQ_*                                                                 */
+    const float    *surround_target_prev_xz;   /* [n][2] movestate.surround_target_prev                                  */
+    const float    *surround_nearest_prev_xz;  /* [n][2] movestate.surround_nearest_prev                                 */
+    const float    *surround_dest_xz; /* [n][2][2] the query's answer from pos + new velocity ([i][0]) and from pos ([i][1]) */
+    const float    *vdes_xz;          /* [n][2] move_work_out.ent_des_v (the surround arm's no-guidance test)            */
+    float          *out_surround_dest_xz;      /* [n][2] written for units flagged NAVHIP_SU_SURROUND_PREV               */
 } navhip_state_aux_in;
+#define NAVHIP_SQ_ADJACENT   0x01   /* !entity_exists(target) || M_NavObjAdjacentFrom(map, uid, target, ctx)              */
+#define NAVHIP_SQ_HAS_DEST_0 0x02   /* M_NavClosestReachableAdjacentPosFrom(.., pos + new velocity, ..) found a position */
+#define NAVHIP_SQ_HAS_DEST_1 0x04   /* ... from pos                                                                      */
 int  navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *world, const navhip_state_aux_in *in,
                              uint8_t *inout_state, uint8_t *inout_flags, int32_t *out_wait_ticks_left);
 /* Everything resident on the device, asynchronous on `stream`. */

@@ -155,6 +155,12 @@ def lib():
             ("pfref_move_get_wait_ticks", [C.c_void_p], None),
             ("pfref_move_set_turning", [C.c_void_p] * 2, None),
             ("pfref_move_set_range_targets", [C.c_void_p] * 3, None),
+            ("pfref_move_set_surround", [C.c_void_p] * 3, None),
+            ("pfref_move_hip_surround_differ", [], C.c_long),
+            ("pfref_move_get_surround", [C.c_void_p] * 3, None),
+            ("pfref_move_surround_queries", [C.c_void_p] * 3, None),
+            ("pfref_move_set_next_rot", [C.c_void_p], None),
+            ("pfref_move_set_interp", [C.c_void_p] * 2, None),
             ("pfref_move_heading_gate", [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p] * 2, None),
             ("pfref_move_dir_quat", [C.c_void_p, C.c_int, C.c_void_p], None),
             ("pfref_move_settled_count", [C.c_void_p, C.c_int, C.c_void_p], None),
@@ -628,6 +634,8 @@ class RefMove:
                       len(k["fdest"]), _p(k["ftgt"]).value, _p(k["fdest"]).value, hz)
         self.nav = nav
         lib().pfref_move_load(nav._h, C.byref(w))
+        if hasattr(lib(), "pfref_move_set_next_rot"):
+            lib().pfref_move_set_next_rot(None)          # (an input of the previous world must not leak into this one)
 
     def velocity(self, vdes=None, begin=0, end=None):
         end = self.n if end is None else end
@@ -744,6 +752,44 @@ class RefMove:
         a, b = np.ascontiguousarray(ent_rot, np.float32), np.ascontiguousarray(target_dir, np.float32)
         assert a.shape == b.shape == (self.n, 4)
         lib().pfref_move_set_turning(_p(a), _p(b))
+
+    def set_surround(self, target_uid, target_prev_xz, nearest_prev_xz):
+        """STATE_SURROUND_ENTITY inputs (movement.c:2509-2567): movestate.surround_target_uid (-1 = NULL_UID),
+        .surround_target_prev, .surround_nearest_prev per unit."""
+        k = [np.ascontiguousarray(target_uid, np.int32), np.ascontiguousarray(target_prev_xz, np.float32).reshape(self.n, 2),
+             np.ascontiguousarray(nearest_prev_xz, np.float32).reshape(self.n, 2)]
+        lib().pfref_move_set_surround(*[_p(a) for a in k])
+
+    def get_surround(self):
+        """(surround_target_prev [n][2], surround_nearest_prev [n][2], patch.next_dest [n][2]) after a state update."""
+        out = [np.zeros((self.n, 2), np.float32) for _ in range(3)]
+        lib().pfref_move_get_surround(*[_p(a) for a in out])
+        return out
+
+    def surround_queries(self, new_vel):
+        """The two unit-query answers per surround unit as the binding hands them to the device: (query bits [n]:
+        1 adjacent-or-gone, 2 / 4 a reachable position exists from pos + new_vel / from pos; dest_xz [n][2][2])."""
+        v = np.ascontiguousarray(new_vel, np.float32).reshape(self.n, 2)
+        q, d = np.zeros(self.n, np.uint8), np.zeros((self.n, 2, 2), np.float32)
+        lib().pfref_move_surround_queries(_p(v), _p(q), _p(d))
+        return q, d
+
+    def hip_surround_differ(self):
+        """Surround positions the device's pass returned that differ from what the reference's switch stored."""
+        return int(lib().pfref_move_hip_surround_differ())
+
+    def set_next_rot(self, next_rot):
+        """movestate.next_rot [n][4] as an input of state_update / state_update_hip (None: facing on the heading)."""
+        if next_rot is None:
+            lib().pfref_move_set_next_rot(None)
+        else:
+            r = np.ascontiguousarray(next_rot, np.float32).reshape(self.n, 4)
+            lib().pfref_move_set_next_rot(_p(r))
+
+    def set_interp(self, next_pos_xz, step):
+        """movestate.next_pos (x, z) and .step: what a rate below 20 Hz interpolates from (movement.c:2372)."""
+        k = [np.ascontiguousarray(next_pos_xz, np.float32).reshape(self.n, 2), np.ascontiguousarray(step, np.float32)]
+        lib().pfref_move_set_interp(*[_p(a) for a in k])
 
     def set_range_targets(self, target_uid, target_range, target_prev_xz):
         """STATE_ENTER_ENTITY_RANGE inputs: movestate.surround_target_uid (-1 = NULL_UID), .target_range, .target_prev_pos."""

@@ -296,6 +296,12 @@ void pfref_move_hip_state_times(double out[6]);   /* snapshot, per-unit inputs, 
 void pfref_move_set_state_aux(const uint8_t *fstate, const int32_t *wait_ticks_left, const uint8_t *wait_prev);
 void pfref_move_get_wait_ticks(int32_t *out);
 void pfref_move_set_turning(const float *ent_rot, const float *target_dir);
+long pfref_move_hip_surround_differ(void);   /* surround positions of the device's pass that differ from the reference's store */
+void pfref_move_set_surround(const int32_t *target_uid, const float *target_prev_xz, const float *nearest_prev_xz);
+void pfref_move_get_surround(float *target_prev_xz, float *nearest_prev_xz, float *next_dest_xz);
+void pfref_move_surround_queries(const float *new_vel, uint8_t *out_query, float *out_dest_xz);
+void pfref_move_set_next_rot(const float *next_rot);      /* NULL: facing on the heading */
+void pfref_move_set_interp(const float *next_pos_xz, const float *step);
 void pfref_move_set_range_targets(const int32_t *target_uid, const float *target_range, const float *target_prev_xz);
 /* fine-arrival inputs: sink [n][2], flags [n] (bit 0 unit committed to a valid slot, bit 1 the
  * flock's arrival_state for the unit's layer is in ARRIVAL_PHASE_FILLING) */

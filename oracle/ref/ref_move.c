@@ -506,6 +506,7 @@ int pfref_move_hip_snapshot(int cap, float *pos, float *vel, float *radius, floa
     return S.n;
 }
 
+static float *s_next_rot_in;           /* movestate.next_rot as an input of the state updates (pfref_move_set_next_rot) */
 static double s_hip_state_work_s;      /* wall time of the last move_hip_state_work (the device half of the state pass) */
 double pfref_move_hip_state_work_seconds(void) { return s_hip_state_work_s; }
 void pfref_move_hip_state_times(double out[6]) { move_hip_state_times(out); }
@@ -524,7 +525,9 @@ int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int beg
         out->ent_uid = i;
         out->ent_vel = (vec2_t){new_vel[2 * i], new_vel[2 * i + 1]};
         out->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
-        if(PFM_Vec2_Len(&out->ent_vel) > EPSILON)
+        if(s_next_rot_in)
+            ms->next_rot = (quat_t){s_next_rot_in[4 * i], s_next_rot_in[4 * i + 1], s_next_rot_in[4 * i + 2], s_next_rot_in[4 * i + 3]};
+        else if(PFM_Vec2_Len(&out->ent_vel) > EPSILON)
             ms->next_rot = dir_quat_from_velocity(intended_heading(out->ent_des_v, out->ent_vel));
         memset(&out->patch, 0, sizeof(out->patch));
     }
@@ -557,6 +560,7 @@ int pfref_move_state_update_hip(const float *new_vel, const float *vdes, int beg
 void pfref_move_hip_state_stats(long out[3]) { move_hip_state_stats(out); }
 void pfref_move_hip_settle_stats(long out[4]) { move_hip_settle_stats(out); }
 long pfref_move_hip_wait_differ(void) { return move_hip_wait_differ(); }
+long pfref_move_hip_surround_differ(void) { return move_hip_surround_differ(); }
 
 struct mbench_arg{ int begin, end, reps; };
 
@@ -669,7 +673,9 @@ void pfref_move_state_update(const float *new_vel, const float *vdes, int begin,
         out->ent_uid = i;
         out->ent_vel = (vec2_t){new_vel[2 * i], new_vel[2 * i + 1]};
         out->ent_des_v = (vec2_t){vdes[2 * i], vdes[2 * i + 1]};
-        if(PFM_Vec2_Len(&out->ent_vel) > EPSILON)
+        if(s_next_rot_in)
+            ms->next_rot = (quat_t){s_next_rot_in[4 * i], s_next_rot_in[4 * i + 1], s_next_rot_in[4 * i + 2], s_next_rot_in[4 * i + 3]};
+        else if(PFM_Vec2_Len(&out->ent_vel) > EPSILON)
             ms->next_rot = dir_quat_from_velocity(intended_heading(out->ent_des_v, out->ent_vel));
         memset(&out->patch, 0, sizeof(out->patch));
         entity_compute_update(s_move_work.hz, i, out->ent_vel, out->ent_des_v, in, &out->patch);
@@ -877,6 +883,112 @@ void pfref_move_set_turning(const float *ent_rot, const float *target_dir)
     memcpy(s_ent_rot, ent_rot, sizeof(float) * 4 * s_w.n);
     for(int i = 0; i < s_w.n; i++)
         movestate_get(i)->target_dir = (quat_t){target_dir[4 * i], target_dir[4 * i + 1], target_dir[4 * i + 2], target_dir[4 * i + 3]};
+}
+
+/* ---- STATE_SURROUND_ENTITY (:2509-2567) and movement rates below 20 Hz (:2368-2377) ---------------------------
+ * map.c's two unit-query wrappers for a MOVABLE target (nav_target_geom_from map.c:158, nav_obj_adjacent :181,
+ * nav_closest_reachable_adjacent_pos :191): straight into nav.c, which this harness builds.  (A static target needs the
+ * entity's OBB from the transform tables, which the harness does not load.)  The unit-query context of the tick IS the
+ * tick's snapshot (movement.c fills it from the same tables). */
+static void surround_target_geom(uint32_t target_uid, vec2_t *xz, float *radius)
+{
+    const struct move_gamestate *gs = &s_move_work.gamestate;
+    if(!(G_FlagsGetFrom(gs->flags, target_uid) & ENTITY_FLAG_MOVABLE))
+        pfref_stub_abort("M_Nav*AdjacentFrom: static target");
+    *xz = G_Pos_GetXZFrom(gs->positions, target_uid);
+    *radius = G_GetSelectionRadiusFrom(gs->sel_radiuses, target_uid);
+}
+
+bool M_NavObjAdjacentFrom(const struct map *map, uint32_t uid, uint32_t target_uid, const struct nav_unit_query_ctx *ctx)
+{
+    (void)ctx;
+    pfref_nav *nav = (pfref_nav*)map;
+    const struct move_gamestate *gs = &s_move_work.gamestate;
+    vec2_t txz; float tr;
+    surround_target_geom(target_uid, &txz, &tr);
+    return N_ObjAdjacentToDynamicWith(&nav->priv, nav->map_pos, G_Pos_GetXZFrom(gs->positions, uid),
+                                      G_GetSelectionRadiusFrom(gs->sel_radiuses, uid), txz, tr);
+}
+
+bool M_NavClosestReachableAdjacentPosFrom(const struct map *map, enum nav_layer layer, vec2_t xz_src, uint32_t target_uid,
+                                          const struct nav_unit_query_ctx *ctx, vec2_t *out)
+{
+    (void)ctx;
+    pfref_nav *nav = (pfref_nav*)map;
+    vec2_t txz; float tr;
+    surround_target_geom(target_uid, &txz, &tr);
+    return N_ClosestReachableAdjacentPosDynamic(&nav->priv, layer, nav->map_pos, xz_src, txz, tr, out);
+}
+
+/* movestate.surround_target_uid (-1 = NULL_UID), .surround_target_prev, .surround_nearest_prev per unit */
+void pfref_move_set_surround(const int32_t *target_uid, const float *target_prev_xz, const float *nearest_prev_xz)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        struct movestate *ms = movestate_get(i);
+        ms->surround_target_uid = target_uid[i] < 0 ? NULL_UID : (uint32_t)target_uid[i];
+        ms->surround_target_prev = (vec2_t){target_prev_xz[2 * i], target_prev_xz[2 * i + 1]};
+        ms->surround_nearest_prev = (vec2_t){nearest_prev_xz[2 * i], nearest_prev_xz[2 * i + 1]};
+    }
+}
+
+void pfref_move_get_surround(float *target_prev_xz, float *nearest_prev_xz, float *next_dest_xz)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        const struct movestate *ms = movestate_get(i);
+        target_prev_xz[2 * i] = ms->surround_target_prev.x; target_prev_xz[2 * i + 1] = ms->surround_target_prev.z;
+        nearest_prev_xz[2 * i] = ms->surround_nearest_prev.x; nearest_prev_xz[2 * i + 1] = ms->surround_nearest_prev.z;
+        next_dest_xz[2 * i] = s_move_work.out[i].patch.next_dest.x; next_dest_xz[2 * i + 1] = s_move_work.out[i].patch.next_dest.z;
+    }
+}
+
+/* What the host hands the device for the surround arm (navhip_state_aux_in.surround_query / .surround_dest_xz): the two
+ * nav queries per STATE_SURROUND_ENTITY unit with a live target, from pos + new_vel ([0]) and from pos ([1]). */
+void pfref_move_surround_queries(const float *new_vel, uint8_t *out_query, float *out_dest_xz)
+{
+    const struct move_gamestate *gs = &s_move_work.gamestate;
+    for(int i = 0; i < s_w.n; i++) {
+        const struct movestate *ms = movestate_get(i);
+        out_query[i] = 0;
+        memset(out_dest_xz + 4 * i, 0, sizeof(float) * 4);
+        if(ms->state != STATE_SURROUND_ENTITY || ms->surround_target_uid == NULL_UID)
+            continue;
+        if(!entity_exists(ms->surround_target_uid) || M_NavObjAdjacentFrom(gs->map, i, ms->surround_target_uid, NULL)) {
+            out_query[i] = 1;
+            continue;
+        }
+        const enum nav_layer layer = Entity_NavLayerWithRadius(G_FlagsGetFrom(gs->flags, i), G_GetSelectionRadiusFrom(gs->sel_radiuses, i));
+        const vec2_t pos = G_Pos_GetXZFrom(gs->positions, i);
+        const vec2_t vel = {new_vel[2 * i], new_vel[2 * i + 1]};
+        vec2_t from[2] = {{0}, pos}, dest;
+        PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &from[0]);
+        for(int c = 0; c < 2; c++) {
+            if(M_NavClosestReachableAdjacentPosFrom(gs->map, layer, from[c], ms->surround_target_uid, NULL, &dest)) {
+                out_query[i] |= (uint8_t)(2 << c);
+                out_dest_xz[4 * i + 2 * c] = dest.x; out_dest_xz[4 * i + 2 * c + 1] = dest.z;
+            }
+        }
+    }
+}
+
+/* movestate.next_rot as an INPUT of pfref_move_state_update (NULL: facing on the heading, nobody is gated) */
+void pfref_move_set_next_rot(const float *next_rot)
+{
+    free(s_next_rot_in);
+    s_next_rot_in = NULL;
+    if(next_rot) {
+        s_next_rot_in = malloc(sizeof(float) * 4 * s_w.n);
+        memcpy(s_next_rot_in, next_rot, sizeof(float) * 4 * s_w.n);
+    }
+}
+
+/* movestate.next_pos (x, z; y = 0) and .step per unit: what a rate below 20 Hz interpolates from (:2372) */
+void pfref_move_set_interp(const float *next_pos_xz, const float *step)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        struct movestate *ms = movestate_get(i);
+        ms->next_pos = (vec3_t){next_pos_xz[2 * i], 0.0f, next_pos_xz[2 * i + 1]};
+        ms->step = step[i];
+    }
 }
 
 /* STATE_ENTER_ENTITY_RANGE inputs (:2569-2604): movestate.surround_target_uid (-1 = NULL_UID), .target_range,

@@ -32,9 +32,9 @@
 // dir_quat_from_velocity (movement.c:1411) is the rotation about Y by atan2(v.z, v.x) - pi/2, whose turned
 // front is (cos a, sin a) = (v.z, -v.x) / |v|.  |angle| > tol  <=>  cos(angle) < cos(tol): no trigonometry,
 // and the comparison in double with a margin that is a hundred times the float path's error.
-__global__ __launch_bounds__(256) void k_heading_gate(int begin, int end, const float *pos_xz, const float *vel_xz,
-                                                      const uint8_t *state, navhip_gate_in in, float *out_vel,
-                                                      float *out_new_pos, uint8_t *out_gate)
+__global__ __launch_bounds__(256) void k_heading_gate(nh_step_params P, int begin, int end, const float *pos_xz, const float *vel_xz,
+                                                      const uint8_t *state, const float *radius, const uint32_t *flags,
+                                                      navhip_gate_in in, float *out_vel, float *out_new_pos, uint8_t *out_gate)
 {
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
     if(i >= end) return;
@@ -63,8 +63,25 @@ __global__ __launch_bounds__(256) void k_heading_gate(int begin, int end, const 
         }
     }
     out_vel[2 * i] = nv.x; out_vel[2 * i + 1] = nv.z;
-    out_new_pos[2 * i] = pos_xz[2 * i] + nv.x;                              // new_pos_for_vel, :1820
-    out_new_pos[2 * i + 1] = pos_xz[2 * i + 1] + nv.z;
+    const v2 pos = mkv(pos_xz[2 * i], pos_xz[2 * i + 1]);
+    v2 np = mkv(pos.x + nv.x, pos.z + nv.z);                                // new_pos_for_vel, :1820
+    if(in.interp_from_xz && P.hz < 20 && !(flags[i] & NAVHIP_ENTITY_FLAG_GARRISONED)) {
+        // a rate below 20 Hz: the position the rest of entity_compute_update tests is the first interpolated position
+        // of an accepted move (:2356-2377), pos + vel of a refused one
+        const int layer = nav_layer_for(flags[i], radius[i]);
+        if(!P.map.layers[layer].cost) gate |= NAVHIP_GATE_HOST;
+        else if(vlen(nv) > 0.0f && pos_pathable(P, layer, np.x, np.z)
+             && (pos_blocked(P, layer, pos.x, pos.z) || !pos_blocked(P, layer, np.x, np.z))) {
+            const float fr = in.interp_step[i];
+            if(!(fabs(1.0 - (double)fr) < (double)(1.0f / 1024.0f))) {      // interpolate_positions, :2222
+                const float fx = in.interp_from_xz[2 * i], fz = in.interp_from_xz[2 * i + 1];
+                float dx = np.x - fx, dz = np.z - fz;
+                dx = dx * fr; dz = dz * fr;
+                np = mkv(fx + dx, fz + dz);
+            }
+        }
+    }
+    out_new_pos[2 * i] = np.x; out_new_pos[2 * i + 1] = np.z;
     out_gate[i] = gate;
 }
 
@@ -85,6 +102,7 @@ __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float
     const uint8_t *cost = P.map.layers[layer].cost;
     const bool ours = st == NAVHIP_STATE_WAITING || st == NAVHIP_STATE_ARRIVING_TO_CELL || (st == NAVHIP_STATE_TURNING && in.ent_rot)
                    || (st == NAVHIP_STATE_ENTER_ENTITY_RANGE && in.range_target && in.range_target[i] >= -1)
+                   || (st == NAVHIP_STATE_SURROUND_ENTITY && in.surround_target && in.surround_target[i] >= -1 && P.hz == 20)
                    || ((st == NAVHIP_STATE_MOVING || st == NAVHIP_STATE_MOVING_IN_FORMATION) && (in.fstate[i] & NAVHIP_FS_MEMBER));
     if(ours && !(ef & NAVHIP_ENTITY_FLAG_GARRISONED) && cost) {                 // (:2344 returns before everything)
         const uint8_t fs = in.fstate[i];
@@ -133,6 +151,37 @@ __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float
                     if(stop) { next = NAVHIP_STATE_WAITING; fl = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; }
                     else if(vlen(vsub(tp, mkv(in.target_prev_xz[2 * i], in.target_prev_xz[2 * i + 1]))) > 5.0f)
                         fl = NAVHIP_SU_SET_DEST;
+                }
+            }else if(st == NAVHIP_STATE_SURROUND_ENTITY) {                      // :2509-2567
+                const int tgt = in.surround_target[i];
+                const uint8_t sq = in.surround_query[i];
+                const int flock = P.flock[i];
+                if(tgt < 0 || (sq & NAVHIP_SQ_ADJACENT)) { next = NAVHIP_STATE_ARRIVED; fl = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; }
+                else if(flock < 0) decided = false;                             // (the reference asserts a flock)
+                else{
+                    const v2 np = mkv(in.new_pos_xz[2 * i], in.new_pos_xz[2 * i + 1]);
+                    const v2 me = mkv(pos_xz[2 * i], pos_xz[2 * i + 1]);
+                    const v2 tp = mkv(pos_xz[2 * tgt], pos_xz[2 * tgt + 1]);
+                    v2 dest = mkv(in.surround_nearest_prev_xz[2 * i], in.surround_nearest_prev_xz[2 * i + 1]);
+                    const v2 delta = vsub(tp, mkv(in.surround_target_prev_xz[2 * i], in.surround_target_prev_xz[2 * i + 1]));
+                    bool gone = false;
+                    if(vlen(delta) > CP_EPS || vlen(mkv(P.vel_xz[2 * i], P.vel_xz[2 * i + 1])) < CP_EPS) {
+                        // the host asked M_NavClosestReachableAdjacentPosFrom from both positions this tick can test:
+                        // pos + new velocity [0] and pos [1] (the gate halted the unit; equal when the velocity is zero)
+                        const int c = (np.x == me.x && np.z == me.z) ? 1 : 0;
+                        if(!(sq & (NAVHIP_SQ_HAS_DEST_0 << c))) gone = true;
+                        else dest = mkv(in.surround_dest_xz[4 * i + 2 * c], in.surround_dest_xz[4 * i + 2 * c + 1]);
+                    }
+                    if(gone) { next = NAVHIP_STATE_ARRIVED; fl = NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; }
+                    else{
+                        in.out_surround_dest_xz[2 * i] = dest.x; in.out_surround_dest_xz[2 * i + 1] = dest.z;
+                        fl = NAVHIP_SU_SURROUND_PREV;
+                        const v2 diff = vsub(mkv(P.flock_target_xz[2 * flock], P.flock_target_xz[2 * flock + 1]), dest);
+                        if(vlen(diff) > CP_EPS) { fl |= NAVHIP_SU_SURROUND_DEST | NAVHIP_SU_SET_STATE; next = NAVHIP_STATE_SURROUND_ENTITY; }
+                        else if(vlen(mkv(in.vdes_xz[2 * i], in.vdes_xz[2 * i + 1])) < CP_EPS) {
+                            fl |= NAVHIP_SU_SET_STATE | NAVHIP_SU_BLOCK; next = NAVHIP_STATE_WAITING;
+                        }
+                    }
                 }
             }else if(st == NAVHIP_STATE_TURNING) {                              // :2606-2628
                 // |PFM_Quat_PitchDiff(rot, target_dir)| <= 5 degrees, as the heading gate compares: the turned fronts of
@@ -213,6 +262,7 @@ __global__ __launch_bounds__(256) void k_settled_count(int nq, const int32_t *ui
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool sk_row_any(bool p)                          // over the 16 lanes of the unit's row
 {
+    // (wave64: the ballot is 64 bits, a row its 16-bit field at lane & 48 -- gfx950 only, like everything here)
     return ((__ballot(p) >> (threadIdx.x & 48)) & 0xffffull) != 0ull;
 }
 
@@ -388,7 +438,16 @@ void sk_map_view(const navhip_ctx *ctx, const navhip_world *w, nh_step_params *P
                                          L.passmask, L.unit_cost, L.changed, L.islands, L.probemask};
     }
     P->map_x = w->map_pos_x; P->map_z = w->map_pos_z;
-    P->n_ents = w->n_ents;
+    P->n_ents = w->n_ents; P->hz = w->hz;
+}
+
+// the surround inputs come together, with the snapshot arrays the arm reads
+bool sk_surround_inputs_ok(const navhip_world *w, const navhip_state_aux_in *in)
+{
+    const int given = (in->surround_target != nullptr) + (in->surround_query != nullptr) + (in->surround_target_prev_xz != nullptr)
+                    + (in->surround_nearest_prev_xz != nullptr) + (in->surround_dest_xz != nullptr) + (in->vdes_xz != nullptr)
+                    + (in->out_surround_dest_xz != nullptr);
+    return given == 0 || (given == 7 && w->pos_xz && w->vel_xz && w->flock && (w->n_flocks == 0 || w->flock_target_xz));
 }
 
 // the six enter-range inputs come together, with the positions of the snapshot
@@ -397,6 +456,14 @@ bool sk_range_inputs_ok(const navhip_world *w, const navhip_state_aux_in *in)
     const int given = (in->range_target != nullptr) + (in->target_range != nullptr) + (in->target_prev_xz != nullptr)
                     + (in->range_tiles_row != nullptr) + (in->range_tiles_off != nullptr) + (in->range_tiles != nullptr);
     return given == 0 || (given == 6 && w->pos_xz && in->n_range_rows >= 0);
+}
+
+// the interpolated position of a rate below 20 Hz: both arrays, the movement rate, and what names the unit's nav layer
+bool sk_interp_inputs_ok(const navhip_world *w, const navhip_gate_in *in)
+{
+    if((in->interp_from_xz != nullptr) != (in->interp_step != nullptr)) return false;
+    if(w->hz != 20 && w->hz != 10 && w->hz != 5 && w->hz != 1 && w->hz != 0) return false;
+    return !in->interp_from_xz || (w->radius && w->flags);
 }
 
 bool sk_work_range(const navhip_world *w, int *b, int *e)
@@ -416,12 +483,15 @@ int navhip_heading_gate_dev(navhip_ctx *ctx, const navhip_world *w, const navhip
     if(!ctx || !w || !in || !out_vel || !out_new_pos || !out_gate || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
     if(!w->pos_xz || !w->vel_xz || !w->state || !in->next_rot || !in->new_vel_xz || !in->vdes_xz) return NAVHIP_ERR_INVALID;
+    if(!sk_interp_inputs_ok(w, in)) return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
     SKCHK(ctx, hipSetDevice(ctx->device));
+    nh_step_params P;
+    sk_map_view(ctx, w, &P);
     if(e > b)
         hipLaunchKernelGGL(k_heading_gate, dim3((e - b + 255) / 256), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
-                           b, e, w->pos_xz, w->vel_xz, w->state, *in, out_vel, out_new_pos, out_gate);
+                           P, b, e, w->pos_xz, w->vel_xz, w->state, w->radius, w->flags, *in, out_vel, out_new_pos, out_gate);
     SKCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
 }
@@ -437,9 +507,12 @@ int navhip_heading_gate(navhip_ctx *ctx, const navhip_world *w, const navhip_gat
     SKCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const size_t n = (size_t)w->n_ents;
+    if(!sk_interp_inputs_ok(w, in)) return NAVHIP_ERR_INVALID;
+    const bool ip = in->interp_from_xz != nullptr;
     sk_arena A;
     const size_t o_pos = A.take(n * 8), o_vel = A.take(n * 8), o_state = A.take(n), o_rot = A.take(n * 16),
-                 o_nv = A.take(n * 8), o_vd = A.take(n * 8), o_ov = A.take(n * 8), o_op = A.take(n * 8), o_og = A.take(n);
+                 o_nv = A.take(n * 8), o_vd = A.take(n * 8), o_ov = A.take(n * 8), o_op = A.take(n * 8), o_og = A.take(n),
+                 o_if = A.take(ip ? n * 8 : 0), o_is = A.take(ip ? n * 4 : 0), o_rad = A.take(ip ? n * 4 : 0), o_flg = A.take(ip ? n * 4 : 0);
     char *base;
     int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
     if(rc) return rc;
@@ -451,7 +524,15 @@ int navhip_heading_gate(navhip_ctx *ctx, const navhip_world *w, const navhip_gat
     SKCHK(ctx, hipMemcpyAsync(base + o_vd, in->vdes_xz, n * 8, hipMemcpyHostToDevice, s));
     navhip_world d = *w;
     d.pos_xz = (const float*)(base + o_pos); d.vel_xz = (const float*)(base + o_vel); d.state = (const uint8_t*)(base + o_state);
-    navhip_gate_in di = {(const float*)(base + o_rot), (const float*)(base + o_nv), (const float*)(base + o_vd)};
+    navhip_gate_in di = {(const float*)(base + o_rot), (const float*)(base + o_nv), (const float*)(base + o_vd), nullptr, nullptr};
+    if(ip) {
+        SKCHK(ctx, hipMemcpyAsync(base + o_if, in->interp_from_xz, n * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_is, in->interp_step, n * 4, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_rad, w->radius, n * 4, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_flg, w->flags, n * 4, hipMemcpyHostToDevice, s));
+        di.interp_from_xz = (const float*)(base + o_if); di.interp_step = (const float*)(base + o_is);
+        d.radius = (const float*)(base + o_rad); d.flags = (const uint32_t*)(base + o_flg);
+    }
     rc = navhip_heading_gate_dev(ctx, &d, &di, (float*)(base + o_ov), (float*)(base + o_op), (uint8_t*)(base + o_og), s);
     if(rc) return rc;
     if(e > b) {
@@ -470,7 +551,7 @@ int navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *w, const na
     if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
     if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz
-    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in))
+    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in) || !sk_surround_inputs_ok(w, in))
         return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
@@ -478,6 +559,7 @@ int navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *w, const na
     nh_step_params P;
     sk_map_view(ctx, w, &P);
     P.work_begin = b; P.work_end = e;
+    if(in->surround_target) { P.flock = w->flock; P.flock_target_xz = w->flock_target_xz; P.vel_xz = w->vel_xz; P.n_flocks = w->n_flocks; }
     if(e > b)
         hipLaunchKernelGGL(k_state_aux, dim3((e - b + 255) / 256), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
                            P, w->pos_xz, w->radius, w->flags, w->state, *in, io_state, io_flags, out_ticks);
@@ -491,11 +573,18 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
     if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
     if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz
-    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in))
+    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in) || !sk_surround_inputs_ok(w, in))
         return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
     const size_t n = (size_t)w->n_ents;
+    const bool su = in->surround_target != nullptr;
+    if(su) {
+        for(size_t i = (size_t)b; i < (size_t)e; i++) {
+            if(in->surround_target[i] < -2 || in->surround_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
+            if(w->state[i] == NAVHIP_STATE_SURROUND_ENTITY && in->surround_target[i] >= -1 && w->flock[i] >= w->n_flocks) return NAVHIP_ERR_INVALID;
+        }
+    }
     size_t n_rt = 0;
     if(in->range_target) {
         const int rows = in->n_range_rows;
@@ -519,6 +608,11 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
     const size_t o_pos = A.take(rg ? n * 8 : 0), o_rt = A.take(rg ? n * 4 : 0), o_rr = A.take(rg ? n * 4 : 0),
                  o_rp = A.take(rg ? n * 8 : 0), o_row = A.take(rg ? n * 4 : 0), o_off = A.take(rg ? (rows + 1) * 4 : 0),
                  o_til = A.take(rg ? n_rt * 4 + 4 : 0);
+    const size_t F = (size_t)(w->n_flocks > 0 ? w->n_flocks : 0);
+    const size_t o_spos = A.take(su && !rg ? n * 8 : 0), o_svel = A.take(su ? n * 8 : 0), o_sflock = A.take(su ? n * 4 : 0),
+                 o_sftgt = A.take(su ? F * 8 + 8 : 0), o_stgt = A.take(su ? n * 4 : 0), o_sq = A.take(su ? n : 0),
+                 o_stp = A.take(su ? n * 8 : 0), o_snp = A.take(su ? n * 8 : 0), o_sd = A.take(su ? n * 16 : 0),
+                 o_svd = A.take(su ? n * 8 : 0), o_sout = A.take(su ? n * 8 : 0);
     char *base;
     int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
     if(rc) return rc;
@@ -557,10 +651,29 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
         SKCHK(ctx, hipMemcpyAsync(base + o_td, in->target_dir, n * 16, hipMemcpyHostToDevice, s));
         di.ent_rot = (const float*)(base + o_er); di.target_dir = (const float*)(base + o_td);
     }
+    if(su) {
+        if(!rg) { SKCHK(ctx, hipMemcpyAsync(base + o_spos, w->pos_xz, n * 8, hipMemcpyHostToDevice, s)); d.pos_xz = (const float*)(base + o_spos); }
+        SKCHK(ctx, hipMemcpyAsync(base + o_svel, w->vel_xz, n * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_sflock, w->flock, n * 4, hipMemcpyHostToDevice, s));
+        if(F) SKCHK(ctx, hipMemcpyAsync(base + o_sftgt, w->flock_target_xz, F * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_stgt, in->surround_target, n * 4, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_sq, in->surround_query, n, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_stp, in->surround_target_prev_xz, n * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_snp, in->surround_nearest_prev_xz, n * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_sd, in->surround_dest_xz, n * 16, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_svd, in->vdes_xz, n * 8, hipMemcpyHostToDevice, s));
+        d.vel_xz = (const float*)(base + o_svel); d.flock = (const int32_t*)(base + o_sflock);
+        d.flock_target_xz = (const float*)(base + o_sftgt);
+        di.surround_target = (const int32_t*)(base + o_stgt); di.surround_query = (const uint8_t*)(base + o_sq);
+        di.surround_target_prev_xz = (const float*)(base + o_stp); di.surround_nearest_prev_xz = (const float*)(base + o_snp);
+        di.surround_dest_xz = (const float*)(base + o_sd); di.vdes_xz = (const float*)(base + o_svd);
+        di.out_surround_dest_xz = (float*)(base + o_sout);
+    }
     rc = navhip_state_update_aux_dev(ctx, &d, &di, (uint8_t*)(base + o_ios), (uint8_t*)(base + o_iof), (int32_t*)(base + o_ot), s);
     if(rc) return rc;
     if(e > b) {
         const size_t lo = (size_t)b, cnt = (size_t)(e - b);
+        if(su) SKCHK(ctx, hipMemcpyAsync(in->out_surround_dest_xz + 2 * lo, base + o_sout + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
         SKCHK(ctx, hipMemcpyAsync(io_state + lo, base + o_ios + lo, cnt, hipMemcpyDeviceToHost, s));
         SKCHK(ctx, hipMemcpyAsync(io_flags + lo, base + o_iof + lo, cnt, hipMemcpyDeviceToHost, s));
         SKCHK(ctx, hipMemcpyAsync(out_ticks + lo, base + o_ot + 4 * lo, cnt * 4, hipMemcpyDeviceToHost, s));
@@ -577,16 +690,34 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
     const navhip_state_in &T = in->state;
     const navhip_state_aux_in &X = in->aux;
     const bool aux = X.fstate != nullptr, turn = aux && X.ent_rot != nullptr, rg = aux && X.range_target != nullptr;
+    const bool su = aux && X.surround_target != nullptr, ip = G.interp_from_xz != nullptr;
     const size_t n = (size_t)w->n_ents, F = (size_t)w->n_flocks;
     if(!w->pos_xz || !w->vel_xz || !w->radius || !w->flags || !w->state || !w->flock || !G.next_rot || !G.new_vel_xz || !G.vdes_xz
     || !out->state || !out->flags || !out->gate || !out->new_pos_xz
     || (F > 0 && (!w->flock_target_xz || !w->flock_offsets || !w->flock_members || !T.flock_layer || !T.flock_nearest_xz
                   || !T.flock_tiles_off || !T.flock_tiles))
     || (aux && (!X.wait_ticks_left || !X.wait_prev || !out->wait_ticks_left || (X.ent_rot != nullptr) != (X.target_dir != nullptr)
-                || !sk_range_inputs_ok(w, &X))))
+                || !sk_range_inputs_ok(w, &X)))
+    || !sk_interp_inputs_ok(w, &G))
         return NAVHIP_ERR_INVALID;
+    if(su) {
+        // (the pass supplies vdes and the snapshot arrays itself: the caller gives the five query arrays and the output)
+        if(!X.surround_query || !X.surround_target_prev_xz || !X.surround_nearest_prev_xz || !X.surround_dest_xz
+        || !X.out_surround_dest_xz) return NAVHIP_ERR_INVALID;
+    }
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
+    if(su) {
+        for(size_t i = (size_t)b; i < (size_t)e; i++) {
+            if(X.surround_target[i] < -2 || X.surround_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
+            if(w->state[i] == NAVHIP_STATE_SURROUND_ENTITY && X.surround_target[i] >= -1 && w->flock[i] >= w->n_flocks) return NAVHIP_ERR_INVALID;
+        }
+    }
+    // (offsets that are not a CSR become a huge size_t below -- INVALID, not NOMEM)
+    for(size_t f = 0; f < F; f++)
+        if(w->flock_offsets[f] < 0 || w->flock_offsets[f + 1] < w->flock_offsets[f] || T.flock_tiles_off[f] < 0
+        || T.flock_tiles_off[f + 1] < T.flock_tiles_off[f]) return NAVHIP_ERR_INVALID;
+    if(F && (size_t)w->flock_offsets[F] > n) return NAVHIP_ERR_INVALID;
     const size_t nmembers = F ? (size_t)w->flock_offsets[F] : 0, ntiles = F ? (size_t)T.flock_tiles_off[F] : 0;
     size_t rows = 0, n_rt = 0;
     if(rg) {
@@ -619,6 +750,11 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
                  o_rt = stage(X.range_target, rg ? n * 4 : 0), o_rr = stage(X.target_range, rg ? n * 4 : 0),
                  o_rp = stage(X.target_prev_xz, rg ? n * 8 : 0), o_row = stage(X.range_tiles_row, rg ? n * 4 : 0),
                  o_roff = stage(X.range_tiles_off, rg ? (rows + 1) * 4 : 0), o_rtil = stage(X.range_tiles, rg ? n_rt * 4 : 0);
+    const size_t o_if = stage(G.interp_from_xz, ip ? n * 8 : 0), o_is = stage(G.interp_step, ip ? n * 4 : 0);
+    const size_t o_stgt = stage(X.surround_target, su ? n * 4 : 0), o_sq = stage(X.surround_query, su ? n : 0),
+                 o_stp = stage(X.surround_target_prev_xz, su ? n * 8 : 0), o_snp = stage(X.surround_nearest_prev_xz, su ? n * 8 : 0),
+                 o_sd = stage(X.surround_dest_xz, su ? n * 16 : 0);
+    const size_t r_sd = A.take(su ? n * 8 : 0);
     // results
     const size_t r_vel = A.take(n * 8), r_np = A.take(n * 8), r_gate = A.take(n), r_st = A.take(n), r_fl = A.take(n), r_tk = A.take(n * 4);
     char *base;
@@ -635,7 +771,8 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
     d.form_ready = nullptr; d.cell_pos_xz = d.form_cohesion_xz = d.form_align_xz = d.form_drag_xz = nullptr;
     d.arrival_sink_xz = nullptr; d.arrival_flags = nullptr; d.los_pool = nullptr; d.flock_los_slot = nullptr; d.los_pos_xz = nullptr;
     d.region_row = nullptr; d.region_field_slot = nullptr;
-    navhip_gate_in dg = {(const float*)(base + o_rot), (const float*)(base + o_nv), (const float*)(base + o_vd)};
+    navhip_gate_in dg = {(const float*)(base + o_rot), (const float*)(base + o_nv), (const float*)(base + o_vd),
+                         ip ? (const float*)(base + o_if) : nullptr, ip ? (const float*)(base + o_is) : nullptr};
     rc = navhip_heading_gate_dev(ctx, &d, &dg, (float*)(base + r_vel), (float*)(base + r_np), (uint8_t*)(base + r_gate), s);
     if(rc) return rc;
     navhip_state_in ds = {(const float*)(base + r_np), (const float*)(base + o_vd), T.skip ? (const uint8_t*)(base + o_skip) : nullptr,
@@ -655,6 +792,12 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
             da.range_tiles_off = (const int32_t*)(base + o_roff); da.range_tiles = (const int16_t*)(base + o_rtil);
             da.n_range_rows = X.n_range_rows;
         }
+        if(su) {
+            da.surround_target = (const int32_t*)(base + o_stgt); da.surround_query = (const uint8_t*)(base + o_sq);
+            da.surround_target_prev_xz = (const float*)(base + o_stp); da.surround_nearest_prev_xz = (const float*)(base + o_snp);
+            da.surround_dest_xz = (const float*)(base + o_sd); da.vdes_xz = (const float*)(base + o_vd);
+            da.out_surround_dest_xz = (float*)(base + r_sd);
+        }
         rc = navhip_state_update_aux_dev(ctx, &d, &da, (uint8_t*)(base + r_st), (uint8_t*)(base + r_fl), (int32_t*)(base + r_tk), s);
         if(rc) return rc;
     }
@@ -670,6 +813,7 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
         SKCHK(ctx, hipMemcpyAsync(out->new_pos_xz + 2 * lo, base + r_np + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
         if(out->vel_xz) SKCHK(ctx, hipMemcpyAsync(out->vel_xz + 2 * lo, base + r_vel + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
         if(aux) SKCHK(ctx, hipMemcpyAsync(out->wait_ticks_left + lo, base + r_tk + 4 * lo, cnt * 4, hipMemcpyDeviceToHost, s));
+        if(su) SKCHK(ctx, hipMemcpyAsync(X.out_surround_dest_xz + 2 * lo, base + r_sd + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
     }
     SKCHK(ctx, hipStreamSynchronize(s));
     return NAVHIP_OK;

@@ -370,7 +370,8 @@ class StateIn(C.Structure):
 
 SU_SET_STATE, SU_BLOCK, SU_HOST = 0x01, 0x02, 0x80
 GATE_TURN, GATE_HOST = 0x01, 0x80
-SU_SET_MOVING, SU_TARGET_DIR, SU_SET_DEST = 0x04, 0x08, 0x10
+SU_SET_MOVING, SU_TARGET_DIR, SU_SET_DEST, SU_SURROUND_DEST, SU_SURROUND_PREV = 0x04, 0x08, 0x10, 0x20, 0x40
+SQ_ADJACENT, SQ_HAS_DEST_0, SQ_HAS_DEST_1 = 0x01, 0x02, 0x04
 FS_MEMBER, FS_READY, FS_ASSIGNED, FS_IN_RANGE, FS_ARRIVED = 0x01, 0x02, 0x04, 0x08, 0x10
 
 
@@ -379,12 +380,16 @@ class StateAuxIn(C.Structure):
     _fields_ = [("fstate", C.c_void_p), ("wait_ticks_left", C.c_void_p), ("wait_prev", C.c_void_p), ("new_pos_xz", C.c_void_p),
                 ("ent_rot", C.c_void_p), ("target_dir", C.c_void_p), ("range_target", C.c_void_p), ("target_range", C.c_void_p),
                 ("target_prev_xz", C.c_void_p), ("range_tiles_row", C.c_void_p), ("range_tiles_off", C.c_void_p),
-                ("range_tiles", C.c_void_p), ("n_range_rows", C.c_int32)]
+                ("range_tiles", C.c_void_p), ("n_range_rows", C.c_int32),
+                ("surround_target", C.c_void_p), ("surround_query", C.c_void_p), ("surround_target_prev_xz", C.c_void_p),
+                ("surround_nearest_prev_xz", C.c_void_p), ("surround_dest_xz", C.c_void_p), ("vdes_xz", C.c_void_p),
+                ("out_surround_dest_xz", C.c_void_p)]
 
 
 class GateIn(C.Structure):
     """navhip_gate_in, include/navhip.h"""
-    _fields_ = [("next_rot", C.c_void_p), ("new_vel_xz", C.c_void_p), ("vdes_xz", C.c_void_p)]
+    _fields_ = [("next_rot", C.c_void_p), ("new_vel_xz", C.c_void_p), ("vdes_xz", C.c_void_p),
+                ("interp_from_xz", C.c_void_p), ("interp_step", C.c_void_p)]
 
 
 class StatePassIn(C.Structure):
@@ -751,16 +756,28 @@ def _ctx_state_update(self, arrays, new_pos_xz, vdes_xz, flock_layer, flock_near
     return st, fl
 
 
-def _ctx_heading_gate(self, arrays, next_rot, new_vel_xz, vdes_xz, work=None):
+def _surround_arrays(n, su):
+    """su: dict(target [n] row or -1 / -2, query [n] SQ_*, target_prev_xz [n][2], nearest_prev_xz [n][2], dest_xz [n][2][2])
+    -> the five contiguous arrays of navhip_state_aux_in + the output array."""
+    return [np.ascontiguousarray(su["target"], np.int32), np.ascontiguousarray(su["query"], np.uint8),
+            np.ascontiguousarray(su["target_prev_xz"], np.float32).reshape(n, 2),
+            np.ascontiguousarray(su["nearest_prev_xz"], np.float32).reshape(n, 2),
+            np.ascontiguousarray(su["dest_xz"], np.float32).reshape(n, 2, 2), np.zeros((n, 2), np.float32)]
+
+
+def _ctx_heading_gate(self, arrays, next_rot, new_vel_xz, vdes_xz, work=None, hz=20, interp=None):
     """The heading gate of entity_compute_update (movement.c:2319-2336) for the units of the snapshot `arrays`
     (pos_xz, vel_xz, state).  Returns (velocity after the gate [n][2], new_pos [n][2], gate flags [n])."""
-    w, keep = make_world(self.w, self.h, arrays)
+    w, keep = make_world(self.w, self.h, arrays, hz=hz)
     if work is not None:
         w.work_begin, w.work_end = work
     n = w.n_ents
     k = [np.ascontiguousarray(next_rot, np.float32).reshape(n, 4), np.ascontiguousarray(new_vel_xz, np.float32).reshape(n, 2),
          np.ascontiguousarray(vdes_xz, np.float32).reshape(n, 2)]
     gi = GateIn(k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data)
+    if interp is not None:          # (movestate.next_pos xz [n][2], movestate.step [n]): a rate below 20 Hz
+        k += [np.ascontiguousarray(interp[0], np.float32).reshape(n, 2), np.ascontiguousarray(interp[1], np.float32)]
+        gi.interp_from_xz, gi.interp_step = k[-2].ctypes.data, k[-1].ctypes.data
     vel, pos, gate = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32), np.zeros(n, np.uint8)
     self._chk(lib().navhip_heading_gate(self._h, C.byref(w), C.byref(gi), _hp(vel), _hp(pos), _hp(gate)),
               "navhip_heading_gate")
@@ -768,10 +785,11 @@ def _ctx_heading_gate(self, arrays, next_rot, new_vel_xz, vdes_xz, work=None):
 
 
 def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_pos_xz, state, flags, work=None,
-                          ent_rot=None, target_dir=None, range_in=None):
+                          ent_rot=None, target_dir=None, range_in=None, surround=None, vdes_xz=None, hz=20):
     """The flag / counter arms of the state switch, after state_update on the same slab: returns (state, flags,
-    wait_ticks_left) with the rows this pass decides overwritten."""
-    w, keep = make_world(self.w, self.h, arrays)
+    wait_ticks_left) with the rows this pass decides overwritten -- and, with `surround` (see _surround_arrays; needs
+    vdes_xz), the positions of NAVHIP_SU_SURROUND_PREV rows as a fourth value."""
+    w, keep = make_world(self.w, self.h, arrays, hz=hz)
     if work is not None:
         w.work_begin, w.work_end = work
     n = w.n_ents
@@ -793,18 +811,26 @@ def _ctx_state_update_aux(self, arrays, fstate, wait_ticks_left, wait_prev, new_
         ai.range_target, ai.target_range, ai.target_prev_xz, ai.range_tiles_row, ai.range_tiles_off, ai.range_tiles = \
             [a.ctypes.data for a in r]
         ai.n_range_rows = len(range_in["tiles"])
+    if surround is not None:
+        sa = _surround_arrays(n, surround) + [np.ascontiguousarray(vdes_xz, np.float32).reshape(n, 2)]
+        k += sa
+        ai.surround_target, ai.surround_query, ai.surround_target_prev_xz, ai.surround_nearest_prev_xz, ai.surround_dest_xz, \
+            ai.out_surround_dest_xz, ai.vdes_xz = [a.ctypes.data for a in sa]
     st, fl, ticks = np.array(state, np.uint8), np.array(flags, np.uint8), np.zeros(n, np.int32)
     self._chk(lib().navhip_state_update_aux(self._h, C.byref(w), C.byref(ai), _hp(st), _hp(fl), _hp(ticks)),
               "navhip_state_update_aux")
+    if surround is not None:
+        return st, fl, ticks, sa[5]
     return st, fl, ticks
 
 
 def _ctx_state_pass(self, arrays, next_rot, new_vel_xz, vdes_xz, flock_layer, flock_nearest_xz, flock_tiles, skip=None,
-                    aux=None, work=None):
+                    aux=None, work=None, hz=20, interp=None):
     """The state half of the tick in one call (navhip_state_pass): heading gate -> state update -> flag / counter arms.
     aux: dict(fstate, wait_ticks_left, wait_prev[, ent_rot, target_dir][, range_in]) or None.  Returns a dict of the
-    outputs (state, flags, gate, new_pos_xz, vel_xz, wait_ticks_left)."""
-    w, keep = make_world(self.w, self.h, arrays)
+    outputs (state, flags, gate, new_pos_xz, vel_xz, wait_ticks_left[, surround_dest_xz with aux["surround"]]).
+    interp: (movestate.next_pos xz, movestate.step) at a rate below 20 Hz."""
+    w, keep = make_world(self.w, self.h, arrays, hz=hz)
     if work is not None:
         w.work_begin, w.work_end = work
     n = w.n_ents
@@ -817,6 +843,9 @@ def _ctx_state_pass(self, arrays, next_rot, new_vel_xz, vdes_xz, flock_layer, fl
     k += [offs, tiles]
     pi = StatePassIn()
     pi.gate = GateIn(k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data)
+    if interp is not None:
+        k += [f32(interp[0], 2), np.ascontiguousarray(interp[1], np.float32)]
+        pi.gate.interp_from_xz, pi.gate.interp_step = k[-2].ctypes.data, k[-1].ctypes.data
     pi.state.flock_layer, pi.state.flock_nearest_xz = k[3].ctypes.data, k[4].ctypes.data
     pi.state.flock_tiles_off, pi.state.flock_tiles = offs.ctypes.data, tiles.ctypes.data
     if skip is not None:
@@ -842,11 +871,20 @@ def _ctx_state_pass(self, arrays, next_rot, new_vel_xz, vdes_xz, flock_layer, fl
             pi.aux.range_target, pi.aux.target_range, pi.aux.target_prev_xz, pi.aux.range_tiles_row, pi.aux.range_tiles_off, \
                 pi.aux.range_tiles = [x.ctypes.data for x in r]
             pi.aux.n_range_rows = len(ri["tiles"])
+        su_out = None
+        if aux.get("surround") is not None:
+            sa = _surround_arrays(n, aux["surround"])
+            k += sa
+            pi.aux.surround_target, pi.aux.surround_query, pi.aux.surround_target_prev_xz, pi.aux.surround_nearest_prev_xz, \
+                pi.aux.surround_dest_xz, pi.aux.out_surround_dest_xz = [x.ctypes.data for x in sa]
+            su_out = sa[5]
     res = {"state": np.zeros(n, np.uint8), "flags": np.zeros(n, np.uint8), "gate": np.zeros(n, np.uint8),
            "new_pos_xz": np.zeros((n, 2), np.float32), "vel_xz": np.zeros((n, 2), np.float32),
            "wait_ticks_left": np.zeros(n, np.int32)}
     po = StatePassOut(*[res[f].ctypes.data for f in ("state", "flags", "gate", "new_pos_xz", "vel_xz", "wait_ticks_left")])
     self._chk(lib().navhip_state_pass(self._h, C.byref(w), C.byref(pi), C.byref(po)), "navhip_state_pass")
+    if aux is not None and aux.get("surround") is not None:
+        res["surround_dest_xz"] = su_out
     return res
 
 

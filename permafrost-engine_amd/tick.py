@@ -411,16 +411,18 @@ class NavTick:
         # tick, the schedule below in C; with graph=True each tick is one hipGraphLaunch of the tick captured per
         # parity) -- for every world whose baked tiles do not travel; "python" = this file's compute() / exchange()
         # / advance(), the reference implementation of that schedule, which the C loop is tested against.
-        # serial (C driver only): the whole tick on ONE stream, no side streams and no events -- for small per-rank worlds,
-        # whose tick is a chain of short dependent launches (every cross-stream edge is a barrier packet of 10-20 us once
-        # the host runs ahead of the device, and there is nothing to overlap); None: by slab size, NAVTICK_SERIAL=0/1
-        # overrides.  graph: replay the tick as a captured HIP graph -- measured SLOWER on this runtime
-        # (profiles/r05_host_overhead_b.txt: one hipGraphLaunch of the multi-stream tick 0.13 ms of host time and 0.84
-        # against 0.34 ms per tick at configs[2]); off unless asked for (NAVTICK_GRAPH=1).
-        self.driver = driver if (self.tile_exchange == "none" or self.solo) else "python"
+        # serial (C driver only): the whole tick on ONE stream, no side streams and no events.  graph: replay the tick as
+        # a captured HIP graph.  Both measured on the MI355X (profiles/r05_host_overhead_c.txt, ms per tick total |
+        # host enqueue):              python        c             c one stream   c graph        c one stream + graph
+        #   configs[2]               0.341|0.135   0.342|0.093   0.455|0.048    0.448|0.110    0.459|0.015
+        #   configs[0]               0.165-0.385   0.138|0.100   0.146|0.049    0.231|0.115    0.146|0.015
+        #   1 rank of 8 (strong)     0.183-0.208   0.221|0.095   0.220|0.050    0.608|0.109    0.226|0.016
+        # The host side shrinks as intended (one hipGraphLaunch of the one-stream tick: 15 us), the TICK does not: a
+        # small world's tick is ~19 dependent kernels of 5-10 us each (0.14 ms at configs[0], 0.2 ms for a rank of 8), a
+        # big one loses the overlap of cohesion / ClearPath / field builds on one stream, and a multi-stream graph pays a
+        # barrier packet per cross-stream edge.  Both stay options (NAVTICK_SERIAL=1, NAVTICK_GRAPH=1), default off.
         if serial is None:
-            env = os.environ.get("NAVTICK_SERIAL")
-            serial = (env == "1") if env in ("0", "1") else (self.a1 - self.a0) <= int(os.environ.get("NAVTICK_SERIAL_BELOW", "20000"))
+            serial = os.environ.get("NAVTICK_SERIAL") == "1"
         self.serial = bool(serial)
         if graph is None:
             graph = os.environ.get("NAVTICK_GRAPH") == "1"

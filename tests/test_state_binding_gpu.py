@@ -171,22 +171,81 @@ def test_formation_and_wait_arms_through_the_binding():
         pfref.RefMove.unload()
 
 
-@pytest.mark.parametrize("hz", [10, 5])
+@pytest.mark.parametrize("hz", [10, 5, 1])
 def test_state_pass_at_lower_movement_rates(hz):
-    """Below 20 Hz entity_compute_update tests an INTERPOLATED position (movement.c:2368-2377), which the device pass is not
-    given: every unit whose answer depends on it is left to the host (NAVHIP_SU_HOST), the garrison rule and the states
-    without a transition are still the device's, and every unit's next state and flags equal the reference's."""
+    """Below 20 Hz entity_compute_update tests the first INTERPOLATED position of an accepted move (movement.c:2368-2377).
+    The binding hands movestate.next_pos / .step to the gate kernel, which makes that position: the device decides the
+    units it decides at 20 Hz (round 4 left every MOVING / WAITING unit to the host at these rates), and every unit's next
+    state and flags equal the reference's."""
     grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    rng = np.random.RandomState(70 + hz)
+    from_xz = (world["pos_xz"] + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    step = rng.choice([1.0 / (20 // hz), 1.0, 0.9995, 0.5], n).astype(np.float32)
     mv, _ = cases.ref_move_for(nav, world, hz=hz)
     try:
+        mv.set_interp(from_xz, step)
         ref_state, ref_flags = mv.state_update(new_vel, vdes)
         assert nav.hip_init(), "no MI355X visible"
+        mv.set_interp(from_xz, step)
         st, fl, dv = mv.state_update_hip(new_vel, vdes)
         assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
         host = (dv & 0x80) != 0
         garr = (world["flags"] & (1 << 18)) != 0
-        assert host[np.isin(world["state"], (0, 1, 4, 7)) & ~garr].all() and not host[garr].any()
+        big = world["radius"] >= 5.0                     # (another nav layer than their flock's tables: the host's, as at 20 Hz)
+        assert not host[np.isin(world["state"], (0, 1, 4)) & ~garr & ~big].any() and not host[garr].any()
         assert not host[np.isin(world["state"], (2, 3))].any()
+        assert host.mean() < 0.15                     # (the fifth on the other nav layer that fall through + TURNING)
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
+
+
+def test_surround_units_through_the_binding():
+    """STATE_SURROUND_ENTITY through move_hip_state_work: the binding asks the two unit-query questions per surround unit
+    (M_NavObjAdjacentFrom; M_NavClosestReachableAdjacentPosFrom from pos + new velocity and from pos), the device runs the
+    switch (navhip_state_aux_in.surround_*), move_hip_update_work turns NAVHIP_SU_SURROUND_DEST into UPDATE_SET_DEST with
+    the device's position.  Every unit's next state, flags and -- for the surround units -- next_dest and the
+    surround_*_prev the reference's own switch stores, against entity_compute_update."""
+    grid, nav, world, new_vel, vdes = cases.state_world(seed=9)
+    n = len(world["state"])
+    rng = np.random.RandomState(33)
+    world["state"] = world["state"].copy()
+    small = world["radius"] < 5.0
+    su = np.flatnonzero((rng.rand(n) < 0.3) & small & (world["flags"] & (1 << 18) == 0))
+    world["state"][su] = 5
+    world["vel_xz"] = world["vel_xz"].copy()
+    world["vel_xz"][su[rng.rand(len(su)) < 0.4]] = 0
+    tgt = np.full(n, -1, np.int32)
+    for i in su:
+        r = rng.rand()
+        if r < 0.08:
+            continue
+        d = np.linalg.norm(world["pos_xz"] - world["pos_xz"][i], axis=1)
+        d[i] = np.inf
+        order = np.argsort(d)
+        tgt[i] = order[0] if r < 0.25 else order[rng.randint(3, 200)]
+    t_prev = world["pos_xz"][np.maximum(tgt, 0)].copy()
+    moved = rng.rand(n) < 0.5
+    t_prev[moved] += rng.normal(0, 3.0, (moved.sum(), 2)).astype(np.float32)
+    n_prev = (world["pos_xz"] + rng.normal(0, 6.0, (n, 2))).astype(np.float32)
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        mv.set_surround(tgt, t_prev, n_prev)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        ref_tprev, ref_nprev, ref_dest = mv.get_surround()
+        assert nav.hip_init(), "no MI355X visible"
+        mv.set_surround(tgt, t_prev, n_prev)                # (the reference's switch has stored into movestate: start over)
+        st, fl, dv = mv.state_update_hip(new_vel, vdes)
+        got_tprev, got_nprev, got_dest = mv.get_surround()
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        is_su = world["state"] == 5
+        assert not (dv[is_su] & 0x80).any() and is_su.sum() > 500          # every surround unit decided on the device
+        sd = is_su & ((fl & 16) != 0)
+        assert sd.sum() > 100 and np.array_equal(got_dest[sd], ref_dest[sd])
+        assert np.array_equal(got_nprev, ref_nprev) and np.array_equal(got_tprev, ref_tprev)
+        assert mv.hip_surround_differ() == 0
+        assert (is_su & (st == 2)).sum() > 30 and (is_su & (st == 5) & (fl == 0)).sum() > 10
     finally:
         pfref.RefNav.hip_shutdown()
         pfref.RefMove.unload()

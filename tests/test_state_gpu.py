@@ -560,3 +560,154 @@ def test_heading_gate_with_tilted_and_unnormalised_rotations(navlib):
     ok = (world["state"] != 7) & ~host
     assert np.array_equal(((gate & navlib.GATE_TURN) != 0)[ok], ref_turn[ok].astype(bool))
     assert host.sum() < 0.01 * n and ref_turn[ok].sum() > 300 and (ref_turn[ok] == 0).sum() > 300
+
+
+def _flock_tables(nav, world):
+    k = len(world["flock_target_xz"])
+    nearest = np.full((k, 2), np.nan, np.float32)
+    tiles = []
+    for f in range(k):
+        p = nav.closest_pathable(world["flock_target_xz"][f])
+        if p is not None:
+            nearest[f] = p
+        tiles.append(nav.dest_island_tiles(world["flock_target_xz"][f]))
+    return nearest, tiles
+
+
+def test_surround_arm_matches_entity_compute_update(navlib):
+    """STATE_SURROUND_ENTITY (movement.c:2509-2567) on the device: the switch runs there, the two nav queries on the
+    unit-query context (M_NavObjAdjacentFrom, M_NavClosestReachableAdjacentPosFrom) are the host's, handed over per unit
+    from both positions the tick can test.  Every way out of the arm against entity_compute_update: no target / target
+    touched / no reachable position -> ARRIVED; a new position next to the target -> UPDATE_SET_DEST with it; no guidance
+    -> WAITING; nothing; and surround_target_prev / surround_nearest_prev as the reference leaves them.  Some units are
+    halted by the heading gate (their query is the one from `pos`), some stand still, some targets have not moved."""
+    grid, nav, world, new_vel, vdes = cases.state_world(seed=9)
+    n, k = len(world["state"]), len(world["flock_target_xz"])
+    rng = np.random.RandomState(31)
+    world["state"] = world["state"].copy()
+    world["vel_xz"] = world["vel_xz"].copy()
+    small = world["radius"] < 5.0
+    su = np.flatnonzero((rng.rand(n) < 0.3) & small & (world["flags"] & (1 << 18) == 0))
+    world["state"][su] = 5
+    world["vel_xz"][su[rng.rand(len(su)) < 0.4]] = 0                       # |movestate.velocity| < EPSILON: the query runs
+    tgt = np.full(n, -1, np.int32)
+    d_all = world["pos_xz"]
+    for i in su:
+        r = rng.rand()
+        if r < 0.08:
+            continue                                                      # NULL_UID
+        d = np.linalg.norm(d_all - d_all[i], axis=1)
+        d[i] = np.inf
+        order = np.argsort(d)
+        tgt[i] = order[0] if r < 0.25 else order[rng.randint(3, 200)]      # the nearest unit (often touching) | somebody further
+    t_prev = world["pos_xz"][np.maximum(tgt, 0)].copy()
+    moved = rng.rand(n) < 0.5
+    t_prev[moved] += rng.normal(0, 3.0, (moved.sum(), 2)).astype(np.float32)
+    n_prev = (world["pos_xz"] + rng.normal(0, 6.0, (n, 2))).astype(np.float32)
+    same = su[rng.rand(len(su)) < 0.3]                                    # already heading for that position: the flock's target,
+    n_prev[same] = world["flock_target_xz"][world["flock"][same]]         # the target has not moved, the unit is rolling (no query)
+    t_prev[same] = world["pos_xz"][np.maximum(tgt[same], 0)]
+    world["vel_xz"][same] = rng.normal(0, 0.5, (len(same), 2)).astype(np.float32) + np.float32([0.3, 0.3])
+    vdes = vdes.copy()
+    vdes[same[::2]] = 0                                                   # ... half of them without guidance
+    # the facing: on the heading for most, turned away (gate: halt) for some
+    heading = np.where(np.linalg.norm(vdes, axis=1, keepdims=True) > 1.0 / 1024, vdes, new_vel)
+    heading = np.where(np.linalg.norm(heading, axis=1, keepdims=True) > 1.0 / 1024, heading, np.float32([1, 0]))
+    ang = np.arctan2(heading[:, 1], heading[:, 0])
+    away = rng.rand(n) < 0.25
+    ang[away] += np.deg2rad(rng.choice([-140, 120, 170], away.sum()))
+    next_rot = pfref.RefMove.dir_quat(np.stack([np.cos(ang), np.sin(ang)], 1))
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        mv.set_surround(tgt, t_prev, n_prev)
+        mv.set_next_rot(next_rot)
+        query, dest = mv.surround_queries(new_vel)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        ref_tprev, ref_nprev, ref_dest = mv.get_surround()
+        order = [mv.flock_order(f) for f in range(k)]
+    finally:
+        pfref.RefMove.unload()
+    nearest, tiles = _flock_tables(nav, world)
+    ctx = _upload(navlib, nav)
+    arrays = cases.step_arrays(world, None, flock_order=order)
+    surround = {"target": tgt, "query": query, "target_prev_xz": t_prev, "nearest_prev_xz": n_prev, "dest_xz": dest}
+    aux = {"fstate": np.zeros(n, np.uint8), "wait_ticks_left": np.full(n, 40, np.int32), "wait_prev": np.zeros(n, np.uint8),
+           "surround": surround}
+    one = ctx.state_pass(arrays, next_rot, new_vel, vdes, np.zeros(k, np.uint8), nearest, tiles, aux=aux)
+    # the stand-alone aux call on the gate's positions gives the same rows
+    st0, fl0 = ctx.state_update(arrays, one["new_pos_xz"], vdes, np.zeros(k, np.uint8), nearest, tiles)
+    st1, fl1, _, dest1 = ctx.state_update_aux(arrays, aux["fstate"], aux["wait_ticks_left"], aux["wait_prev"], one["new_pos_xz"], st0, fl0,
+                                              surround=surround, vdes_xz=vdes)
+    without = ctx.state_pass(arrays, next_rot, new_vel, vdes, np.zeros(k, np.uint8), nearest, tiles,
+                             aux={kk: v for kk, v in aux.items() if kk != "surround"})
+    ctx.close()
+    is_su = world["state"] == 5
+    gate_host = (one["gate"] & navlib.GATE_HOST) != 0
+    dec = is_su & ~gate_host
+    assert (without["flags"][is_su] & navlib.SU_HOST).all()                # (no surround inputs: the host's, as before)
+    assert not (one["flags"][dec] & navlib.SU_HOST).any() and dec.sum() > 500
+    st, fl = one["state"], one["flags"]
+    as_ref = (fl & 3) | np.where(fl & navlib.SU_SURROUND_DEST, 16, 0).astype(np.uint8)
+    bad = np.flatnonzero(dec & ((st != ref_state) | (as_ref != ref_flags)))
+    assert len(bad) == 0, [(int(i), int(tgt[i]), int(query[i]), int(st[i]), int(ref_state[i]), int(fl[i]), int(ref_flags[i])) for i in bad[:10]]
+    sd = dec & ((fl & navlib.SU_SURROUND_DEST) != 0)
+    assert np.array_equal(one["surround_dest_xz"][sd], ref_dest[sd])
+    prev = dec & ((fl & navlib.SU_SURROUND_PREV) != 0)
+    assert np.array_equal(one["surround_dest_xz"][prev], ref_nprev[prev]) and np.array_equal(world["pos_xz"][tgt[prev]], ref_tprev[prev])
+    keep = dec & ~prev                                                    # (arrived before the stores: the reference left them alone)
+    assert np.array_equal(ref_nprev[keep], n_prev[keep]) and np.array_equal(ref_tprev[keep], t_prev[keep])
+    assert np.array_equal(st1[dec], st[dec]) and np.array_equal(fl1[dec], fl[dec]) and np.array_equal(dest1[prev], one["surround_dest_xz"][prev])
+    # every way out fired, on both query positions
+    halted = (one["gate"] & navlib.GATE_TURN) != 0
+    assert (dec & (tgt < 0) & (st == 2) & (fl == 3)).sum() > 10                            # no target
+    assert (dec & (tgt >= 0) & ((query & 1) != 0) & (st == 2)).sum() > 20                  # touching it already
+    assert (sd & halted).sum() > 20 and (sd & ~halted).sum() > 100                         # a new position, from pos | pos + vel
+    assert (prev & ~sd & (st == 4) & ((fl & 3) == 3)).sum() > 3                            # no guidance -> WAITING
+    assert (prev & ~sd & (st == 5)).sum() > 10                                             # nothing happens
+    # the units that are not surround units are unaffected by the inputs
+    assert np.array_equal(st[~is_su], without["state"][~is_su]) and np.array_equal(fl[~is_su], without["flags"][~is_su])
+
+
+@pytest.mark.parametrize("hz", [10, 5, 1])
+def test_state_pass_at_movement_rates_below_20_hz(navlib, hz):
+    """Below 20 Hz entity_compute_update tests the first INTERPOLATED position of an accepted move (movement.c:2356-2377:
+    interpolate_positions(next_pos, new_pos, movestate.step)) in the state switch instead of pos + vel.  The gate kernel
+    makes that position from movestate.next_pos / .step (navhip_gate_in.interp_*) and the accept test; every unit's next
+    state and flags against the reference at that rate."""
+    grid, nav, world, new_vel, vdes = cases.state_world(seed=12 + hz)
+    n, k = len(world["state"]), len(world["flock_target_xz"])
+    rng = np.random.RandomState(40 + hz)
+    new_vel = (new_vel * (20.0 / hz)).astype(np.float32)                    # (velocities are per tick of the rate)
+    from_xz = (world["pos_xz"] + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    step = rng.choice([1.0 / (20 // hz), 1.0, 0.9995, 0.5, 0.0], n).astype(np.float32)
+    mv, _ = cases.ref_move_for(nav, world, hz=hz)
+    try:
+        mv.set_interp(from_xz, step)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        order = [mv.flock_order(f) for f in range(k)]
+    finally:
+        pfref.RefMove.unload()
+    nearest, tiles = _flock_tables(nav, world)
+    ctx = _upload(navlib, nav)
+    arrays = cases.step_arrays(world, None, flock_order=order)
+    heading = np.where(np.linalg.norm(vdes, axis=1, keepdims=True) > 1.0 / 1024, vdes, new_vel)
+    heading = np.where(np.linalg.norm(heading, axis=1, keepdims=True) > 1.0 / 1024, heading, np.float32([1, 0]))
+    next_rot = pfref.RefMove.dir_quat(heading)
+    aux = {"fstate": np.zeros(n, np.uint8), "wait_ticks_left": np.full(n, 40, np.int32), "wait_prev": np.zeros(n, np.uint8)}
+    got = ctx.state_pass(arrays, next_rot, new_vel, vdes, np.zeros(k, np.uint8), nearest, tiles, aux=aux, hz=hz, interp=(from_xz, step))
+    plain = ctx.state_pass(arrays, next_rot, new_vel, vdes, np.zeros(k, np.uint8), nearest, tiles, aux=aux, hz=hz)
+    ctx.close()
+    host = (got["flags"] & navlib.SU_HOST) != 0
+    state = world["state"]
+    ok = ~host & (state != 7)                                              # (TURNING needs its rotation inputs: not given here)
+    # (a move that leaves the map: the reference indexes past its chunk array there -- undefined, not comparable)
+    ok &= (np.abs(world["pos_xz"] + new_vel) < 4 * 128.0 - 4.0).all(1)
+    bad = np.flatnonzero(ok & ((got["state"] != ref_state) | ((got["flags"] & 0x1f) != ref_flags)))
+    assert len(bad) == 0, [(int(i), int(state[i]), int(got["state"][i]), int(ref_state[i]), int(got["flags"][i]), int(ref_flags[i])) for i in bad[:10]]
+    assert ok.sum() > 0.8 * n
+    # the interpolation matters: the tested position differs from pos + vel for most accepted moves ...
+    moved = np.linalg.norm(got["new_pos_xz"] - (world["pos_xz"] + got["vel_xz"]), axis=1) > 1e-6
+    assert moved.sum() > 0.3 * n
+    # ... and a pass without the inputs (pos + vel everywhere) answers differently for some units at the lower rates
+    if hz < 10:
+        assert ((plain["state"] != got["state"]) & ok).sum() > 0
