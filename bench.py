@@ -134,7 +134,14 @@ def state_pass_probe(chunk_w, k_fields, n_agents, timeout=240):
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
-        return json.loads(lines[-1])
+        d = json.loads(lines[-1])
+        if "error" in d or "resident" not in d:
+            return d
+        # (the line keeps the numbers: the pass on the velocity pass's resident snapshot, the host-buffer pass beside it)
+        return {"identical": d["identical"], "decided_on_device": d["decided_on_device"], "unit_mix": d["unit_mix"],
+                "hip_ms_per_tick": d["resident"]["hip_ms_per_tick"], "hip_ms_parts": d["resident"]["hip_ms_parts"],
+                "host_buffers_ms_per_tick": d["host_buffers"]["hip_ms_per_tick"], "host_threads": d["host_threads"],
+                "cpu_ms_per_tick_1core": d["cpu_ms_per_tick_1core"], "to_arrived": d["to_arrived"], "to_waiting": d["to_waiting"]}
     except Exception as exc:
         return {"error": repr(exc)}
 

@@ -164,7 +164,8 @@ static void *hip_arena(size_t bytes)
 /* bytes of the arena one tick may take for n entities, F flocks (both passes: velocity or state) */
 static size_t hip_arena_need(size_t n, size_t F)
 {
-    return (n + 16) * (4 * 46 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 48;
+    /* (twice: the state pass of a tick keeps the velocity pass's snapshot and takes its own arrays behind it) */
+    return 2 * ((n + 16) * (4 * 46 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 48);
 }
 
 static void hip_check_range(int begin, int end, void *arg)
@@ -286,6 +287,33 @@ static void hip_snap_fill(struct hip_snap *S)
 static void hip_snap_free(struct hip_snap *S)
 {
     (void)S;                                          /* (the arena is reused by the next tick) */
+}
+
+/* what the velocity pass of this tick left behind for its state pass (move_hip_state_work) */
+static struct { bool valid; struct hip_snap S; int begin_idx, end_idx, lo, hi; size_t nwork; } s_hip_last;
+/* The state pass on the device-resident snapshot of the velocity pass (navhip_state_pass_resident).  On in an engine
+ * build (the tick runs the two fork-joins back to back, movement.c:4263-4280); the harness, whose tests call the state
+ * pass on its own with velocities of their choosing, switches it on where a velocity pass precedes. */
+static bool s_hip_state_resident;
+static long s_hip_resident_passes;                   /* state passes that ran on the resident snapshot */
+void move_hip_set_resident_state_pass(bool on) { s_hip_state_resident = on; }
+long move_hip_resident_passes(void) { return s_hip_resident_passes; }
+/* per-unit arrays of the resident pass in page-locked memory (navhip_host_alloc): transferred in place */
+static struct { size_t cap; float *next_rot, *new_pos; uint8_t *fstate, *wait_prev, *skip, *st, *fl, *gate; int32_t *wait_ticks, *wait_after; } s_hip_pin;
+static bool hip_pin_reserve(size_t n)
+{
+    if(n + 1 <= s_hip_pin.cap) return true;
+    navhip_host_free(s_hip_pin.next_rot); navhip_host_free(s_hip_pin.new_pos); navhip_host_free(s_hip_pin.fstate);
+    navhip_host_free(s_hip_pin.wait_prev); navhip_host_free(s_hip_pin.skip); navhip_host_free(s_hip_pin.st); navhip_host_free(s_hip_pin.fl);
+    navhip_host_free(s_hip_pin.gate); navhip_host_free(s_hip_pin.wait_ticks); navhip_host_free(s_hip_pin.wait_after);
+    const size_t cap = n + n / 4 + 64;
+    s_hip_pin.next_rot = navhip_host_alloc(sizeof(float) * 4 * cap); s_hip_pin.new_pos = navhip_host_alloc(sizeof(float) * 2 * cap);
+    s_hip_pin.fstate = navhip_host_alloc(cap); s_hip_pin.wait_prev = navhip_host_alloc(cap); s_hip_pin.skip = navhip_host_alloc(cap);
+    s_hip_pin.st = navhip_host_alloc(cap); s_hip_pin.fl = navhip_host_alloc(cap); s_hip_pin.gate = navhip_host_alloc(cap);
+    s_hip_pin.wait_ticks = navhip_host_alloc(sizeof(int32_t) * cap); s_hip_pin.wait_after = navhip_host_alloc(sizeof(int32_t) * cap);
+    s_hip_pin.cap = (s_hip_pin.next_rot && s_hip_pin.new_pos && s_hip_pin.fstate && s_hip_pin.wait_prev && s_hip_pin.skip && s_hip_pin.st
+                     && s_hip_pin.fl && s_hip_pin.gate && s_hip_pin.wait_ticks && s_hip_pin.wait_after) ? cap : 0;
+    return s_hip_pin.cap != 0;
 }
 
 /* dense index of every work item, kept between ticks: the work list is rebuilt every tick in the same entity
@@ -519,6 +547,12 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
             }
         }
     }
+    /* the state half of this tick may run on what this step left on the device (navhip_state_pass_resident): the
+     * snapshot tables stay in the arena, and the step's outputs ARE the work items' velocities -- unless some agents
+     * were re-stepped on the host above */
+    s_hip_last.valid = ok && !s_hip_dry_run && V.n_fallback == 0;
+    s_hip_last.S = S; s_hip_last.begin_idx = begin_idx; s_hip_last.end_idx = end_idx; s_hip_last.nwork = s_move_work.nwork;
+    s_hip_last.lo = lo; s_hip_last.hi = hi;
     hip_snap_free(&S);
     s_hip_times[0] += t_filled - t_begin; s_hip_times[1] += t_stepped - t_filled;
     s_hip_times[2] += hip_now() - t_stepped; s_hip_times[3] += 1.0;
@@ -580,10 +614,12 @@ static void hip_state_items_range(int begin, int end, void *arg)
         const struct movestate *ms = movestate_get(in->ent_uid);
         const int i = hip_work_dense(S, w);
         /* the inputs of the heading gate (:2319-2336), decided on the device for the slab at once */
-        T->new_vel[2 * i] = out->ent_vel.x; T->new_vel[2 * i + 1] = out->ent_vel.z;
+        if(T->new_vel) {            /* (the resident pass reads the step's own outputs on the device) */
+            T->new_vel[2 * i] = out->ent_vel.x; T->new_vel[2 * i + 1] = out->ent_vel.z;
+            T->vdes[2 * i] = out->ent_des_v.x; T->vdes[2 * i + 1] = out->ent_des_v.z;
+        }
         T->next_rot[4 * i] = ms->next_rot.x; T->next_rot[4 * i + 1] = ms->next_rot.y;
         T->next_rot[4 * i + 2] = ms->next_rot.z; T->next_rot[4 * i + 3] = ms->next_rot.w;
-        T->vdes[2 * i] = out->ent_des_v.x; T->vdes[2 * i + 1] = out->ent_des_v.z;
         /* an active arrival group (:2443): move_hip_settle_work's.  Every unit at a movement rate below 20 Hz is the
          * host's: entity_compute_update then tests the INTERPOLATED intermediate position
          * (interpolate_positions(next_ppos, next_npos, ms->step), :2368-2377), not pos + vel */
@@ -593,7 +629,7 @@ static void hip_state_items_range(int begin, int end, void *arg)
                      | (in->fstate.assigned_to_cell ? NAVHIP_FS_ASSIGNED : 0) | (in->fstate.in_range_of_cell ? NAVHIP_FS_IN_RANGE : 0)
                      | (in->fstate.arrived_at_cell ? NAVHIP_FS_ARRIVED : 0));
         T->wait_ticks[i] = ms->wait_ticks_left; T->wait_prev[i] = (uint8_t)ms->wait_prev;
-        if(ms->state == STATE_TURNING) {                      /* :2606-2628: the end of the turn is the device's to see */
+        if(ms->state == STATE_TURNING && T->ent_rot) {        /* :2606-2628: the end of the turn is the device's to see */
             const quat_t rot = Entity_GetRot(in->ent_uid);
             memcpy(T->ent_rot + 4 * i, &rot, sizeof(float) * 4);
             memcpy(T->target_dir + 4 * i, &ms->target_dir, sizeof(float) * 4);
@@ -703,7 +739,8 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
         if(nsettled[q] < 0)
             continue;                                   /* (a unit wider than the device's query: the host's arm) */
         const enum nav_layer layer = Entity_NavLayerWithRadius(S->flags[i], S->radius[i]);
-        const vec2_t np = {q_pos[2 * q], q_pos[2 * q + 1]}, vd = {vdes[2 * i], vdes[2 * i + 1]};
+        const vec2_t np = {q_pos[2 * q], q_pos[2 * q + 1]}, vd = s_move_work.out[witem[q]].ent_des_v;
+        (void)vdes;
         s_hip_settle_stats[0]++;
         st[i] = S->state[i]; fl[i] = 0;
         if(!M_NavPositionPathable(gs->map, layer, np))
@@ -721,6 +758,20 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
     return ok;
 }
 
+struct hip_state_scatter { int begin_idx; const uint8_t *st, *fl; long host; };
+static void hip_state_scatter_range(int begin, int end, void *arg)
+{
+    struct hip_state_scatter *X = arg;
+    long host = 0;
+    for(int k = begin; k < end; k++) {
+        const int w = X->begin_idx + k, i = s_hip_witem.idx[w];
+        s_hip_su_state[w] = X->st[i];
+        s_hip_su_flags[w] = X->fl[i];
+        host += (X->fl[i] & NAVHIP_SU_HOST) != 0;
+    }
+    __atomic_fetch_add(&X->host, host, __ATOMIC_RELAXED);
+}
+
 static bool move_hip_state_work(int begin_idx, int end_idx)
 {
     navhip_ctx *ctx = N_HIP_Ctx();
@@ -730,7 +781,14 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     struct hip_snap S;
     double t_mark = hip_now(), t_now;
 #define HIP_SU_LAP(k) (t_now = hip_now(), s_hip_su_times[k] = t_now - t_mark, t_mark = t_now)
-    hip_snap_fill(&S);
+    /* resident: this tick's velocity pass has just run over the same work items -- its snapshot tables are still in the
+     * arena and on the device, its outputs are the work items' velocities */
+    bool resident = s_hip_state_resident && s_hip_last.valid && s_hip_last.begin_idx == begin_idx && s_hip_last.end_idx == end_idx
+                 && s_hip_last.nwork == s_move_work.nwork && s_hip_last.S.n == (int)kh_size(gs->positions)
+                 && hip_pin_reserve((size_t)s_hip_last.S.n);
+    s_hip_last.valid = false;
+    if(resident) S = s_hip_last.S;
+    else         hip_snap_fill(&S);
     HIP_SU_LAP(0);
     const int n = S.n;
     if(s_hip_su_cap < s_move_work.nwork) {
@@ -741,17 +799,28 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     s_hip_settle_chk = realloc(s_hip_settle_chk, sizeof(struct hip_settle_chk) * (s_move_work.nwork + 1));
     for(int w = begin_idx; w <= end_idx; w++)
         s_hip_settle_chk[w].valid = false;
-    float *new_pos = hip_arena(sizeof(float) * (2 * n + 2)), *vdes = hip_arena(sizeof(float) * (2 * n + 2));
-    float *new_vel = hip_arena(sizeof(float) * (2 * n + 2)), *next_rot = hip_arena(sizeof(float) * (4 * n + 4));
-    float *gate_vel = hip_arena(sizeof(float) * (2 * n + 2));
-    uint8_t *skip = hip_arena(n + 1), *zoned = hip_arena(n + 1), *gate = hip_arena(n + 1);
-    uint8_t *fstate = hip_arena(n + 1), *wait_prev = hip_arena(n + 1);
-    int32_t *wait_ticks = hip_arena(sizeof(int32_t) * (n + 1)), *wait_after = hip_arena(sizeof(int32_t) * (n + 1));
+    /* (resident: the arrays the device reads or writes per unit live in page-locked memory and are transferred in
+     * place; new_vel / vdes do not travel at all) */
+    float *new_pos = resident ? s_hip_pin.new_pos : hip_arena(sizeof(float) * (2 * n + 2));
+    float *vdes = resident ? NULL : hip_arena(sizeof(float) * (2 * n + 2)), *new_vel = resident ? NULL : hip_arena(sizeof(float) * (2 * n + 2));
+    float *next_rot = resident ? s_hip_pin.next_rot : hip_arena(sizeof(float) * (4 * n + 4));
+    float *gate_vel = resident ? NULL : hip_arena(sizeof(float) * (2 * n + 2));
+    uint8_t *skip = resident ? s_hip_pin.skip : hip_arena(n + 1), *zoned = hip_arena(n + 1), *gate = resident ? s_hip_pin.gate : hip_arena(n + 1);
+    uint8_t *fstate = resident ? s_hip_pin.fstate : hip_arena(n + 1), *wait_prev = resident ? s_hip_pin.wait_prev : hip_arena(n + 1);
+    int32_t *wait_ticks = resident ? s_hip_pin.wait_ticks : hip_arena(sizeof(int32_t) * (n + 1));
+    int32_t *wait_after = resident ? s_hip_pin.wait_after : hip_arena(sizeof(int32_t) * (n + 1));
     memset(fstate, 0, n + 1); memset(wait_prev, 0, n + 1); memset(wait_ticks, 0, sizeof(int32_t) * (n + 1));
-    float *ent_rot = hip_arena(sizeof(float) * (4 * n + 4)), *target_dir = hip_arena(sizeof(float) * (4 * n + 4));
-    memset(ent_rot, 0, sizeof(float) * (4 * n + 4)); memset(target_dir, 0, sizeof(float) * (4 * n + 4));
-    memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2)); memset(skip, 0, n + 1);
-    memset(new_vel, 0, sizeof(float) * (2 * n + 2)); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); memset(zoned, 0, n + 1);
+    /* (the rotations of TURNING units: 32 bytes per unit that are only touched when somebody turns) */
+    bool any_turning = false;
+    for(int w = begin_idx; w <= end_idx && !any_turning; w++)
+        any_turning = movestate_get(s_move_work.in[w].ent_uid)->state == STATE_TURNING;
+    float *ent_rot = any_turning ? hip_arena(sizeof(float) * (4 * n + 4)) : NULL, *target_dir = any_turning ? hip_arena(sizeof(float) * (4 * n + 4)) : NULL;
+    if(any_turning) { memset(ent_rot, 0, sizeof(float) * (4 * n + 4)); memset(target_dir, 0, sizeof(float) * (4 * n + 4)); }
+    memset(skip, 0, n + 1); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); memset(zoned, 0, n + 1);
+    if(!resident) {
+        memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2));
+        memset(new_vel, 0, sizeof(float) * (2 * n + 2));
+    }
     const bool sub20 = (20 / hz_count(s_move_work.hz)) > 1;
     float *interp_from = sub20 ? hip_arena(sizeof(float) * (2 * n + 2)) : NULL, *interp_step = sub20 ? hip_arena(sizeof(float) * (n + 1)) : NULL;
     if(sub20) { memset(interp_from, 0, sizeof(float) * (2 * n + 2)); memset(interp_step, 0, sizeof(float) * (n + 1)); }
@@ -802,7 +871,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     navhip_world W;
     hip_snap_world(&S, &W);
     W.work_begin = lo; W.work_end = hi + 1;
-    uint8_t *st = hip_arena(n + 1), *fl = hip_arena(n + 1);
+    uint8_t *st = resident ? s_hip_pin.st : hip_arena(n + 1), *fl = resident ? s_hip_pin.fl : hip_arena(n + 1);
     const bool aux = true;          /* (every rate: the arms read the position the gate kernel leaves) */
     /* ONE call for the pass (navhip_state_pass): the heading gate of every unit (:2319-2336) -> the arrival arm on the
      * positions the gate leaves (navhip_state_update) -> the arms that flags, the wait counter, the angle to target_dir and
@@ -814,9 +883,6 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     int32_t *r_target = NULL, *r_row = NULL, *r_off = NULL; float *r_range = NULL, *r_prev = NULL; int16_t *r_tiles = NULL;
     if(aux) {
         pin.aux.fstate = fstate; pin.aux.wait_ticks_left = wait_ticks; pin.aux.wait_prev = wait_prev;
-        bool any_turning = false;
-        for(int w = begin_idx; w <= end_idx && !any_turning; w++)
-            any_turning = S.state[s_hip_witem.idx[w]] == STATE_TURNING;
         if(any_turning) {                                     /* (else 32 bytes per unit that nobody would read) */
             pin.aux.ent_rot = ent_rot; pin.aux.target_dir = target_dir;
         }
@@ -895,7 +961,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
             if(!(PFM_Vec2_Len(&delta) > EPSILON || PFM_Vec2_Len(&ms->velocity) < EPSILON))
                 continue;                                                 /* (the query does not run this tick) */
             const enum nav_layer layer = Entity_NavLayerWithRadius(S.flags[i], S.radius[i]);
-            const vec2_t pos = {S.pos[2 * i], S.pos[2 * i + 1]}, vel = {new_vel[2 * i], new_vel[2 * i + 1]};
+            const vec2_t pos = {S.pos[2 * i], S.pos[2 * i + 1]}, vel = s_move_work.out[w].ent_vel;
             vec2_t from[2] = {pos, pos};
             PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &from[0]);
             for(int c = 0; c < 2; c++) {
@@ -916,7 +982,23 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     }
     navhip_state_pass_out pout = {st, fl, gate, new_pos, gate_vel, aux ? wait_after : NULL};
     HIP_SU_LAP(2);                  /* (the enter-range inputs count as queries too) */
-    bool ok = hi >= lo && navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
+    bool ok = hi >= lo;
+    if(ok && resident && navhip_state_pass_resident(ctx, &pin, &pout) != NAVHIP_OK) {
+        /* (the step's arrays are gone -- somebody used the context in between: the host-buffer pass, with the two
+         * arrays the resident one does not need) */
+        resident = false;
+        new_vel = hip_arena(sizeof(float) * (2 * n + 2)); vdes = hip_arena(sizeof(float) * (2 * n + 2));
+        memset(new_vel, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2));
+        for(int w = begin_idx; w <= end_idx; w++) {
+            const int i = s_hip_witem.idx[w];
+            new_vel[2 * i] = s_move_work.out[w].ent_vel.x; new_vel[2 * i + 1] = s_move_work.out[w].ent_vel.z;
+            vdes[2 * i] = s_move_work.out[w].ent_des_v.x; vdes[2 * i + 1] = s_move_work.out[w].ent_des_v.z;
+        }
+        pin.gate.new_vel_xz = new_vel; pin.gate.vdes_xz = vdes;
+        ok = navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
+    }else if(ok && !resident)
+        ok = navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
+    s_hip_resident_passes += ok && resident;
     HIP_SU_LAP(3);
     free(r_target); free(r_row); free(r_off); free(r_range); free(r_prev); free(r_tiles);
     s_hip_su_dest = realloc(s_hip_su_dest, sizeof(float) * 2 * (s_move_work.nwork + 1));
@@ -941,12 +1023,9 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     }
     if(ok) {
         s_hip_su_stats[2]++;
-        for(int w = begin_idx; w <= end_idx; w++) {
-            const int i = hip_work_dense(&S, w);
-            s_hip_su_state[w] = st[i];
-            s_hip_su_flags[w] = fl[i];
-            s_hip_su_stats[(fl[i] & NAVHIP_SU_HOST) ? 1 : 0]++;
-        }
+        struct hip_state_scatter X = {begin_idx, st, fl, 0};
+        hip_for(hip_state_scatter_range, end_idx - begin_idx + 1, &X);
+        s_hip_su_stats[1] += X.host; s_hip_su_stats[0] += (end_idx - begin_idx + 1) - X.host;
     }
     hip_snap_free(&S);
     HIP_SU_LAP(5);

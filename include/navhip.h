@@ -806,6 +806,17 @@ typedef struct navhip_state_pass_out {
 int  navhip_state_pass(navhip_ctx *ctx, const navhip_world *world, const navhip_state_pass_in *in,
                        const navhip_state_pass_out *out);
 
+/* The same pass ON THE SNAPSHOT THE VELOCITY HALF LEFT ON THE DEVICE: between navhip_agent_step_wait (or a poll that
+ * returned 0) and the next submit, the arrays of that step -- positions, velocities, radii, flags, states, flock tables --
+ * and its results -- the new velocities, the desired directions -- are still in HBM.  The state half of the same tick
+ * (fork_join_state_updates follows the velocity fork-join in navigation_tick_task, movement.c:4263-4280) only uploads
+ * what it alone reads: movestate.next_rot, the per-flock query results, the flag / counter / target inputs (24 bytes
+ * per unit in the common case instead of 95), packed through pinned memory as one transfer each way.  in->gate.new_vel_xz
+ * and .vdes_xz are ignored (the step's own outputs are used: the step must have been asked for vdes_xz unless every
+ * desired direction was the caller's, world->vdes_xz without NaN entries); world = that step's, slab included.
+ * NAVHIP_ERR_INVALID when no completed host-buffer step is resident: call navhip_state_pass instead. */
+int  navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, const navhip_state_pass_out *out);
+
 /* adjacent_settled_count (movement.c:982) for nq units of the snapshot: G_Pos_EntsInCircleFrom (r = max(30,
  * 2 radius + 5), at most 128 results, garrisoned entities dropped, position.c:379) and of those the movable
  * ones of the same air / ground kind in STATE_ARRIVED that touch the unit (distance <= both radii +

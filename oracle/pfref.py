@@ -157,6 +157,9 @@ def lib():
             ("pfref_move_set_range_targets", [C.c_void_p] * 3, None),
             ("pfref_move_set_surround", [C.c_void_p] * 3, None),
             ("pfref_move_hip_surround_differ", [], C.c_long),
+            ("pfref_move_hip_resident_state_pass", [C.c_int], None),
+            ("pfref_move_hip_resident_passes", [], C.c_long),
+            ("pfref_move_get_out", [C.c_void_p] * 2, None),
             ("pfref_move_get_surround", [C.c_void_p] * 3, None),
             ("pfref_move_surround_queries", [C.c_void_p] * 3, None),
             ("pfref_move_set_next_rot", [C.c_void_p], None),
@@ -773,6 +776,20 @@ class RefMove:
         q, d = np.zeros(self.n, np.uint8), np.zeros((self.n, 2, 2), np.float32)
         lib().pfref_move_surround_queries(_p(v), _p(q), _p(d))
         return q, d
+
+    def hip_resident_state_pass(self, on):
+        """The binding's state pass on the device-resident snapshot of the velocity pass that precedes it in the tick
+        (navhip_state_pass_resident); off: every state pass uploads its own snapshot."""
+        lib().pfref_move_hip_resident_state_pass(int(bool(on)))
+
+    def hip_resident_passes(self):
+        return int(lib().pfref_move_hip_resident_passes())
+
+    def get_out(self):
+        """(ent_vel [n][2], ent_des_v [n][2]) the last velocity pass left in the work items."""
+        v, d = np.zeros((self.n, 2), np.float32), np.zeros((self.n, 2), np.float32)
+        lib().pfref_move_get_out(_p(v), _p(d))
+        return v, d
 
     def hip_surround_differ(self):
         """Surround positions the device's pass returned that differ from what the reference's switch stored."""

@@ -296,6 +296,9 @@ void pfref_move_hip_state_times(double out[6]);   /* snapshot, per-unit inputs, 
 void pfref_move_set_state_aux(const uint8_t *fstate, const int32_t *wait_ticks_left, const uint8_t *wait_prev);
 void pfref_move_get_wait_ticks(int32_t *out);
 void pfref_move_set_turning(const float *ent_rot, const float *target_dir);
+void pfref_move_hip_resident_state_pass(int on);   /* the state pass on the velocity pass's device-resident snapshot */
+long pfref_move_hip_resident_passes(void);
+void pfref_move_get_out(float *vel, float *vdes);  /* s_move_work.out[].ent_vel / .ent_des_v */
 long pfref_move_hip_surround_differ(void);   /* surround positions of the device's pass that differ from the reference's store */
 void pfref_move_set_surround(const int32_t *target_uid, const float *target_prev_xz, const float *nearest_prev_xz);
 void pfref_move_get_surround(float *target_prev_xz, float *nearest_prev_xz, float *next_dest_xz);

@@ -322,6 +322,7 @@ static void set_vdes(const float *vdes, int i)
                                  in->cp_ent.xz_pos, fl->target_xz)
                            : (vec2_t){0.0f, 0.0f};
     }
+    s_move_work.out[i].ent_des_v = in->ent_des_v;          /* (compute_desired_velocity, movement.c:4175) */
     in->dyn_neighbs->size = 0;
     in->stat_neighbs->size = 0;
 }
@@ -561,6 +562,16 @@ void pfref_move_hip_state_stats(long out[3]) { move_hip_state_stats(out); }
 void pfref_move_hip_settle_stats(long out[4]) { move_hip_settle_stats(out); }
 long pfref_move_hip_wait_differ(void) { return move_hip_wait_differ(); }
 long pfref_move_hip_surround_differ(void) { return move_hip_surround_differ(); }
+void pfref_move_hip_resident_state_pass(int on) { move_hip_set_resident_state_pass(on != 0); }
+long pfref_move_hip_resident_passes(void) { return move_hip_resident_passes(); }
+/* the velocities / desired directions the last velocity pass left in the work items (s_move_work.out) */
+void pfref_move_get_out(float *vel, float *vdes)
+{
+    for(int i = 0; i < s_w.n; i++) {
+        vel[2 * i] = s_move_work.out[i].ent_vel.x; vel[2 * i + 1] = s_move_work.out[i].ent_vel.z;
+        vdes[2 * i] = s_move_work.out[i].ent_des_v.x; vdes[2 * i + 1] = s_move_work.out[i].ent_des_v.z;
+    }
+}
 
 struct mbench_arg{ int begin, end, reps; };
 

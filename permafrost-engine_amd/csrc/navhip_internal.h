@@ -102,6 +102,9 @@ int  navhip_build_fields_slots_dev(navhip_ctx *ctx, const navhip_field_req *dev_
 int  navhip_stage_reserve(navhip_ctx *ctx, int slot, size_t bytes, void **dev);
 void nh_async_destroy(navhip_ctx *ctx);
 void nh_async_invalidate_static(navhip_ctx *ctx);   // the staging buffers were used by someone else
+bool nh_async_resident(navhip_ctx *ctx, navhip_world *w, navhip_step_out *o);   // snapshot + outputs the last completed submit left on the device
+int  nh_async_slabs(navhip_ctx *ctx, size_t in_bytes, size_t out_bytes, char **h_in, char **h_out);
+bool nh_is_pinned(const void *p);
 const uint8_t *nh_pool_fields(const navhip_ctx *ctx);
 const int32_t *nh_pool_map(const navhip_ctx *ctx);
 int nh_pool_dests(const navhip_ctx *ctx);

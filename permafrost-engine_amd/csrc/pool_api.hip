@@ -452,6 +452,11 @@ struct nh_async {
     std::vector<cp> finish;          // staging -> caller copies at completion
     // the attribute tables on the device are those of this epoch / entity count / flock count
     uint32_t static_epoch; int32_t static_n, static_f;
+    // what the last submitted step left on the device: its snapshot (device addresses) and its outputs -- the state half
+    // of the tick reads them in place (navhip_state_pass_resident)
+    bool            resident;
+    navhip_world    d_world;
+    navhip_step_out d_out;
 };
 
 static int pinned_grow(navhip_ctx *ctx, char **p, size_t *cap, size_t need)
@@ -478,10 +483,12 @@ int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhi
         ctx->async->pending = false; ctx->async->empty = false; ctx->async->h_in = ctx->async->h_out = nullptr;
         ctx->async->h_in_cap = ctx->async->h_out_cap = 0;
         ctx->async->static_epoch = 0; ctx->async->static_n = ctx->async->static_f = 0;
+        ctx->async->resident = false;
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->async->done, hipEventDisableTiming));
     }
     nh_async *A = ctx->async;
     if(A->pending) { ctx->last_error = "navhip_agent_step_submit: a step is already in flight"; return NAVHIP_ERR_INVALID; }
+    A->resident = false;
     if(w->n_ents == 0) {            // an empty world is a valid tick: submit / poll / wait all succeed
         A->finish.clear();
         A->pending = true; A->empty = true;
@@ -621,6 +628,7 @@ int navhip_agent_step_submit(navhip_ctx *ctx, const navhip_world *w, const navhi
     if(oneed) HIPCHK(ctx, hipMemcpyAsync(A->h_out, d_oslab, oneed, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipEventRecord(A->done, s));
     A->pending = true;
+    A->d_world = d; A->d_out = dout; A->resident = true;
     return NAVHIP_OK;
 }
 
@@ -660,7 +668,30 @@ int navhip_agent_step_wait(navhip_ctx *ctx)
 
 }  // extern "C"
 
-void nh_async_invalidate_static(navhip_ctx *ctx) { if(ctx->async) ctx->async->static_epoch = 0; }
+void nh_async_invalidate_static(navhip_ctx *ctx) { if(ctx->async) { ctx->async->static_epoch = 0; ctx->async->resident = false; } }
+
+// the device-side snapshot and outputs of the last COMPLETED host-buffer step (false: none, or still in flight)
+bool nh_async_resident(navhip_ctx *ctx, navhip_world *w, navhip_step_out *o)
+{
+    nh_async *A = ctx->async;
+    if(!A || !A->resident || A->pending || A->empty) return false;
+    *w = A->d_world; *o = A->d_out;
+    return true;
+}
+
+// its two pinned staging slabs, grown to the sizes asked for (the step is complete: nobody reads them)
+int nh_async_slabs(navhip_ctx *ctx, size_t in_bytes, size_t out_bytes, char **h_in, char **h_out)
+{
+    nh_async *A = ctx->async;
+    if(!A || A->pending) return NAVHIP_ERR_INVALID;
+    int rc = pinned_grow(ctx, &A->h_in, &A->h_in_cap, in_bytes);
+    if(!rc) rc = pinned_grow(ctx, &A->h_out, &A->h_out_cap, out_bytes);
+    if(rc) return rc;
+    *h_in = A->h_in; *h_out = A->h_out;
+    return NAVHIP_OK;
+}
+
+bool nh_is_pinned(const void *p) { return is_pinned(p); }
 
 void nh_async_destroy(navhip_ctx *ctx)
 {

@@ -216,6 +216,17 @@ __global__ __launch_bounds__(256) void k_state_aux(nh_step_params P, const float
     out_ticks[i] = ticks;
 }
 
+// the resident pass: move_work_out.ent_des_v of a unit = the direction its host gave the step, or -- where that was NaN:
+// "sample on the device" -- the direction the step sampled (what move_hip.c's scatter leaves in the work item)
+__global__ __launch_bounds__(256) void k_pick_vdes(int begin, int end, const float *given, const float *sampled, float *out)
+{
+    const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    if(i >= end) return;
+    float x = given ? given[2 * i] : __int_as_float(0x7fc00000), z = given ? given[2 * i + 1] : 0.0f;
+    if(x != x) { x = sampled ? sampled[2 * i] : 0.0f; z = sampled ? sampled[2 * i + 1] : 0.0f; }
+    out[2 * i] = x; out[2 * i + 1] = z;
+}
+
 // the fused pass (navhip_state_pass): a unit whose gate is the host's to decide is the host's altogether
 __global__ __launch_bounds__(256) void k_gate_host_rows(int begin, int end, const uint8_t *gate, const uint8_t *state,
                                                         const int32_t *in_ticks, uint8_t *io_state, uint8_t *io_flags,
@@ -816,6 +827,165 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
         if(su) SKCHK(ctx, hipMemcpyAsync(X.out_surround_dest_xz + 2 * lo, base + r_sd + 8 * lo, cnt * 8, hipMemcpyDeviceToHost, s));
     }
     SKCHK(ctx, hipStreamSynchronize(s));
+    return NAVHIP_OK;
+}
+
+#define SK_IN_SLOT  42          /* device slab of the resident pass's inputs  */
+#define SK_OUT_SLOT 31          /* ... and of its results                      */
+
+int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, const navhip_state_pass_out *out)
+{
+    if(!ctx || !in || !out) return NAVHIP_ERR_INVALID;
+    navhip_world d; navhip_step_out so;
+    if(!nh_async_resident(ctx, &d, &so)) {
+        ctx->last_error = "navhip_state_pass_resident: no completed host-buffer step is resident on the device";
+        return NAVHIP_ERR_INVALID;
+    }
+    const navhip_gate_in &G = in->gate;
+    const navhip_state_in &T = in->state;
+    const navhip_state_aux_in &X = in->aux;
+    const bool aux = X.fstate != nullptr, turn = aux && X.ent_rot != nullptr, rg = aux && X.range_target != nullptr;
+    const bool su = aux && X.surround_target != nullptr, ip = G.interp_from_xz != nullptr;
+    const size_t n = (size_t)d.n_ents, F = (size_t)(d.n_flocks > 0 ? d.n_flocks : 0);
+    if(n == 0) return NAVHIP_OK;
+    if(!d.pos_xz || !d.vel_xz || !d.radius || !d.flags || !d.state || !d.flock || !so.vel_xz || (!so.vdes_xz && !d.vdes_xz) || !G.next_rot
+    || !out->state || !out->flags || !out->gate || !out->new_pos_xz
+    || (F > 0 && (!d.flock_target_xz || !d.flock_offsets || !d.flock_members || !T.flock_layer || !T.flock_nearest_xz
+                  || !T.flock_tiles_off || !T.flock_tiles))
+    || (aux && (!X.wait_ticks_left || !X.wait_prev || !out->wait_ticks_left || (X.ent_rot != nullptr) != (X.target_dir != nullptr)))
+    || (ip && !G.interp_step) || (!ip && G.interp_step)
+    || (su && (!X.surround_query || !X.surround_target_prev_xz || !X.surround_nearest_prev_xz || !X.surround_dest_xz || !X.out_surround_dest_xz)))
+        return NAVHIP_ERR_INVALID;
+    if(rg) {
+        const int given = (X.target_range != nullptr) + (X.target_prev_xz != nullptr) + (X.range_tiles_row != nullptr)
+                        + (X.range_tiles_off != nullptr) + (X.range_tiles != nullptr);
+        if(given != 5 || X.n_range_rows < 0) return NAVHIP_ERR_INVALID;
+    }
+    int b, e;
+    if(!sk_work_range(&d, &b, &e)) return NAVHIP_ERR_INVALID;
+    for(size_t f = 0; f < F; f++)
+        if(T.flock_tiles_off[f] < 0 || T.flock_tiles_off[f + 1] < T.flock_tiles_off[f]) return NAVHIP_ERR_INVALID;
+    const size_t ntiles = F ? (size_t)T.flock_tiles_off[F] : 0;
+    size_t rows = 0, n_rt = 0;
+    if(rg) {
+        rows = (size_t)X.n_range_rows;
+        for(size_t r = 0; r < rows; r++)
+            if(X.range_tiles_off[r] < 0 || X.range_tiles_off[r + 1] < X.range_tiles_off[r]) return NAVHIP_ERR_INVALID;
+        n_rt = rows ? (size_t)X.range_tiles_off[rows] : 0;
+        for(size_t i = (size_t)b; i < (size_t)e; i++)
+            if(X.range_target[i] < -2 || X.range_target[i] >= d.n_ents
+            || (X.range_target[i] >= 0 && (X.range_tiles_row[i] < 0 || (size_t)X.range_tiles_row[i] >= (rows ? rows : 1)))) return NAVHIP_ERR_INVALID;
+    }
+    if(su)
+        for(size_t i = (size_t)b; i < (size_t)e; i++)
+            if(X.surround_target[i] < -2 || X.surround_target[i] >= d.n_ents) return NAVHIP_ERR_INVALID;
+    SKCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // ---- inputs: one device slab; pageable arrays are packed into the pinned slab and cross the bus as ONE transfer,
+    // pinned ones (navhip_host_alloc) are transferred in place
+    struct item { const void *src; size_t bytes; size_t off; bool pinned; };
+    std::vector<item> items;
+    sk_arena A;
+    auto stage = [&](const void *src, size_t bytes) { const size_t o = A.take(bytes + 8); if(src && bytes) items.push_back({src, bytes, o, nh_is_pinned(src)}); return o; };
+    const size_t o_rot = stage(G.next_rot, n * 16), o_if = stage(G.interp_from_xz, ip ? n * 8 : 0), o_is = stage(G.interp_step, ip ? n * 4 : 0);
+    const size_t o_skip = stage(T.skip, T.skip ? n : 0), o_flay = stage(T.flock_layer, F), o_fnear = stage(T.flock_nearest_xz, F * 8),
+                 o_toff = stage(T.flock_tiles_off, (F + 1) * 4), o_tiles = stage(T.flock_tiles, ntiles * 4);
+    const size_t o_fs = stage(X.fstate, aux ? n : 0), o_wt = stage(X.wait_ticks_left, aux ? n * 4 : 0), o_wp = stage(X.wait_prev, aux ? n : 0),
+                 o_er = stage(X.ent_rot, turn ? n * 16 : 0), o_td = stage(X.target_dir, turn ? n * 16 : 0),
+                 o_rt = stage(X.range_target, rg ? n * 4 : 0), o_rr = stage(X.target_range, rg ? n * 4 : 0),
+                 o_rp = stage(X.target_prev_xz, rg ? n * 8 : 0), o_row = stage(X.range_tiles_row, rg ? n * 4 : 0),
+                 o_roff = stage(X.range_tiles_off, rg ? (rows + 1) * 4 : 0), o_rtil = stage(X.range_tiles, rg ? n_rt * 4 : 0),
+                 o_stgt = stage(X.surround_target, su ? n * 4 : 0), o_sq = stage(X.surround_query, su ? n : 0),
+                 o_stp = stage(X.surround_target_prev_xz, su ? n * 8 : 0), o_snp = stage(X.surround_nearest_prev_xz, su ? n * 8 : 0),
+                 o_sd = stage(X.surround_dest_xz, su ? n * 16 : 0);
+    const size_t in_total = A.total;
+    // ---- results: rows [b, e) of each, one device slab, one transfer for the pageable destinations
+    const size_t cnt = (size_t)(e - b), lo = (size_t)b;
+    sk_arena R;
+    const size_t r_vel = R.take(n * 8), r_np = R.take(n * 8), r_gate = R.take(n), r_st = R.take(n), r_fl = R.take(n),
+                 r_tk = R.take(aux ? n * 4 : 0), r_sd = R.take(su ? n * 8 : 0), r_vd = R.take(n * 8);
+    size_t pack_in = 0;
+    for(auto &it : items) if(!it.pinned) pack_in += (it.bytes + 255) & ~(size_t)255;
+    struct oitem { void *dst; size_t dev_off, row; size_t h_off; bool pinned; };
+    std::vector<oitem> outs = {{out->state, r_st, 1, 0, false}, {out->flags, r_fl, 1, 0, false}, {out->gate, r_gate, 1, 0, false},
+                               {out->new_pos_xz, r_np, 8, 0, false}};
+    if(out->vel_xz) outs.push_back({out->vel_xz, r_vel, 8, 0, false});
+    if(aux) outs.push_back({out->wait_ticks_left, r_tk, 4, 0, false});
+    if(su) outs.push_back({X.out_surround_dest_xz, r_sd, 8, 0, false});
+    size_t pack_out = 0;
+    for(auto &o : outs) { o.pinned = nh_is_pinned(o.dst); if(!o.pinned) { o.h_off = pack_out; pack_out += (cnt * o.row + 255) & ~(size_t)255; } }
+    char *h_in = nullptr, *h_out = nullptr, *base = nullptr, *res = nullptr;
+    int rc = nh_async_slabs(ctx, pack_in, pack_out, &h_in, &h_out);
+    if(!rc) rc = navhip_stage_reserve(ctx, SK_IN_SLOT, in_total + pack_in + 256, (void**)&base);
+    if(!rc) rc = navhip_stage_reserve(ctx, SK_OUT_SLOT, R.total + pack_out + 256, (void**)&res);
+    if(rc) return rc;
+    // (the pageable inputs: packed, sent as one block behind the arrays' own region, then laid out by device-to-device
+    // copies?  No: the layout IS the packing order -- every pageable item gets its device address inside the block)
+    char *d_block = base + in_total;
+    size_t poff = 0;
+    std::vector<const char*> dev_of(items.size());
+    for(size_t k = 0; k < items.size(); k++) {
+        item &it = items[k];
+        if(it.pinned) {
+            SKCHK(ctx, hipMemcpyAsync(base + it.off, it.src, it.bytes, hipMemcpyHostToDevice, s));
+            dev_of[k] = base + it.off;
+        }else{
+            memcpy(h_in + poff, it.src, it.bytes);
+            dev_of[k] = d_block + poff;
+            poff += (it.bytes + 255) & ~(size_t)255;
+        }
+    }
+    if(poff) SKCHK(ctx, hipMemcpyAsync(d_block, h_in, poff, hipMemcpyHostToDevice, s));
+    auto dev = [&](size_t off) -> const char* {                // the device address of the item staged at arena offset `off`
+        for(size_t k = 0; k < items.size(); k++) if(items[k].off == off) return dev_of[k];
+        return base + off;                                     // (nothing staged there: an address nobody reads)
+    };
+    // ---- the three passes on the resident snapshot
+    const float *d_vdes = (const float*)(res + r_vd);
+    if(e > b) hipLaunchKernelGGL(k_pick_vdes, dim3((e - b + 255) / 256), dim3(256), 0, s, b, e, d.vdes_xz, (const float*)so.vdes_xz, (float*)(res + r_vd));
+    navhip_gate_in dg = {(const float*)dev(o_rot), so.vel_xz, d_vdes, ip ? (const float*)dev(o_if) : nullptr, ip ? (const float*)dev(o_is) : nullptr};
+    rc = navhip_heading_gate_dev(ctx, &d, &dg, (float*)(res + r_vel), (float*)(res + r_np), (uint8_t*)(res + r_gate), s);
+    if(rc) return rc;
+    navhip_state_in ds = {(const float*)(res + r_np), d_vdes, T.skip ? (const uint8_t*)dev(o_skip) : nullptr, (const uint8_t*)dev(o_flay),
+                          (const float*)dev(o_fnear), (const int32_t*)dev(o_toff), (const int16_t*)dev(o_tiles)};
+    rc = navhip_state_update_dev(ctx, &d, &ds, (uint8_t*)(res + r_st), (uint8_t*)(res + r_fl), s);
+    if(rc) return rc;
+    if(aux) {
+        navhip_state_aux_in da;
+        memset(&da, 0, sizeof(da));
+        da.fstate = (const uint8_t*)dev(o_fs); da.wait_ticks_left = (const int32_t*)dev(o_wt);
+        da.wait_prev = (const uint8_t*)dev(o_wp); da.new_pos_xz = (const float*)(res + r_np);
+        if(turn) { da.ent_rot = (const float*)dev(o_er); da.target_dir = (const float*)dev(o_td); }
+        if(rg) {
+            da.range_target = (const int32_t*)dev(o_rt); da.target_range = (const float*)dev(o_rr);
+            da.target_prev_xz = (const float*)dev(o_rp); da.range_tiles_row = (const int32_t*)dev(o_row);
+            da.range_tiles_off = (const int32_t*)dev(o_roff); da.range_tiles = (const int16_t*)dev(o_rtil);
+            da.n_range_rows = X.n_range_rows;
+        }
+        if(su) {
+            da.surround_target = (const int32_t*)dev(o_stgt); da.surround_query = (const uint8_t*)dev(o_sq);
+            da.surround_target_prev_xz = (const float*)dev(o_stp); da.surround_nearest_prev_xz = (const float*)dev(o_snp);
+            da.surround_dest_xz = (const float*)dev(o_sd); da.vdes_xz = d_vdes; da.out_surround_dest_xz = (float*)(res + r_sd);
+        }
+        rc = navhip_state_update_aux_dev(ctx, &d, &da, (uint8_t*)(res + r_st), (uint8_t*)(res + r_fl), (int32_t*)(res + r_tk), s);
+        if(rc) return rc;
+    }
+    if(e > b) {
+        hipLaunchKernelGGL(k_gate_host_rows, dim3((e - b + 255) / 256), dim3(256), 0, s, b, e, (const uint8_t*)(res + r_gate),
+                           d.state, aux ? (const int32_t*)dev(o_wt) : (const int32_t*)nullptr,
+                           (uint8_t*)(res + r_st), (uint8_t*)(res + r_fl), aux ? (int32_t*)(res + r_tk) : (int32_t*)nullptr);
+        SKCHK(ctx, hipGetLastError());
+        // results: the pageable destinations' rows are gathered into one block on the device and cross the bus once
+        char *d_oblock = res + R.total;
+        for(auto &o : outs) {
+            if(o.pinned) SKCHK(ctx, hipMemcpyAsync((char*)o.dst + lo * o.row, res + o.dev_off + lo * o.row, cnt * o.row, hipMemcpyDeviceToHost, s));
+            else         SKCHK(ctx, hipMemcpyAsync(d_oblock + o.h_off, res + o.dev_off + lo * o.row, cnt * o.row, hipMemcpyDeviceToDevice, s));
+        }
+        if(pack_out) SKCHK(ctx, hipMemcpyAsync(h_out, d_oblock, pack_out, hipMemcpyDeviceToHost, s));
+    }
+    SKCHK(ctx, hipStreamSynchronize(s));
+    if(e > b)
+        for(auto &o : outs) if(!o.pinned) memcpy((char*)o.dst + lo * o.row, h_out + o.h_off, cnt * o.row);
     return NAVHIP_OK;
 }
 

@@ -249,3 +249,48 @@ def test_surround_units_through_the_binding():
     finally:
         pfref.RefNav.hip_shutdown()
         pfref.RefMove.unload()
+
+
+def test_state_pass_on_the_resident_snapshot_of_the_velocity_pass():
+    """The tick's two fork-joins back to back (navigation_tick_task, movement.c:4263-4280) through the binding: the
+    velocity pass leaves its snapshot and its results on the device, the state pass that follows runs on them
+    (navhip_state_pass_resident: only movestate.next_rot and the flag / counter inputs travel, through page-locked
+    memory).  Every unit's next state and flags == the host-buffer pass's == entity_compute_update on the velocities the
+    device produced; a state pass without a velocity pass in front of it falls back to the host-buffer form."""
+    import os
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    n = len(world["state"])
+    # (the host emulator steps ~30 agents a second: a slab of the work items there, all of them on the GPU)
+    m = 500 if os.path.basename(os.environ.get("NAVHIP_LIB", "")) == "_navhip_emu.so" else n
+    rng = np.random.RandomState(3)
+    fstate = ((rng.rand(n) < 0.3) * 1 | (rng.rand(n) < 0.7) * 2 | (rng.rand(n) < 0.5) * 4 | (rng.rand(n) < 0.5) * 8).astype(np.uint8)
+    ticks = rng.choice([1, 2, 40], n).astype(np.int32)
+    prev = rng.choice([0, 1], n).astype(np.uint8)
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        assert nav.hip_init(), "no MI355X visible"
+        assert mv.bench_hip(vdes, end=m) is not None                       # the velocity pass on the device
+        vel, vd = mv.get_out()
+        mv.set_state_aux(fstate, ticks, prev)
+        ref_state, ref_flags = mv.state_update(vel, vd, end=m)             # the reference on THOSE velocities
+        mv.set_state_aux(fstate, ticks, prev)
+        host = mv.state_update_hip(vel, vd, end=m)                         # the host-buffer pass
+        assert np.array_equal(host[0][:m], ref_state[:m]) and np.array_equal(host[1][:m], ref_flags[:m])
+        before = mv.hip_resident_passes()
+        mv.hip_resident_state_pass(True)
+        try:
+            for _ in range(2):
+                assert mv.bench_hip(vdes, end=m) is not None               # velocity pass ...
+                mv.set_state_aux(fstate, ticks, prev)
+                st, fl, dv = mv.state_update_hip(vel, vd, end=m)           # ... state pass on what it left on the device
+                assert np.array_equal(st[:m], ref_state[:m]) and np.array_equal(fl[:m], ref_flags[:m]) and np.array_equal(dv[:m], host[2][:m])
+            assert mv.hip_resident_passes() == before + 2
+            mv.set_state_aux(fstate, ticks, prev)
+            st, fl, dv = mv.state_update_hip(vel, vd, end=m)               # no velocity pass in front: the host-buffer form
+            assert np.array_equal(st[:m], ref_state[:m]) and np.array_equal(fl[:m], ref_flags[:m]) and mv.hip_resident_passes() == before + 2
+        finally:
+            mv.hip_resident_state_pass(False)
+        assert ((dv[:m] & 0x80) == 0).mean() > 0.7
+    finally:
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
