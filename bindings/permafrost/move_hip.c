@@ -656,6 +656,7 @@ static void hip_state_items_range(int begin, int end, void *arg)
  * (navhip_settled_count, navhip_arrival_settle).  A zone = one struct arrival_state, handed over as it is: its
  * slots, their fill ranks and the sorted tile keys of its footprint.  st / fl (by dense index) are overwritten
  * for the units decided here. */
+static bool s_hip_settle_resident;                   /* the pass in front of the settle work ran on the resident snapshot */
 static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navhip_world *W, int begin_idx, int end_idx,
                                  const uint8_t *zoned, const uint8_t *gate, const float *new_pos, const float *vdes, uint8_t *st, uint8_t *fl)
 {
@@ -729,7 +730,9 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
         memcpy(ring + zones[z].slot_begin, as->slot_ring, sizeof(int) * as->num_slots);
         memcpy(keys + zones[z].key_begin, as->region_keys, sizeof(uint64_t) * as->num_region);
     }
-    bool ok = navhip_settled_count(ctx, W, nq, uid, nsettled) == NAVHIP_OK;
+    /* (behind a state pass on the velocity pass's resident snapshot the count reads that snapshot too) */
+    bool ok = (s_hip_settle_resident && navhip_settled_count_resident(ctx, W, nq, uid, nsettled) == NAVHIP_OK)
+           || navhip_settled_count(ctx, W, nq, uid, nsettled) == NAVHIP_OK;
     navhip_settle_in in = {nz, nq, zones, slots, ring, keys, uid, zone, q_pos, nsettled, substate, sink_valid, sink, order,
                            anchor, anchored, stuck};
     navhip_settle_out out = {o_settle, o_substate, o_anchor_, o_anchored_, o_stuck_};
@@ -999,6 +1002,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     }else if(ok && !resident)
         ok = navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
     s_hip_resident_passes += ok && resident;
+    s_hip_settle_resident = ok && resident;
     HIP_SU_LAP(3);
     free(r_target); free(r_row); free(r_off); free(r_range); free(r_prev); free(r_tiles);
     s_hip_su_dest = realloc(s_hip_su_dest, sizeof(float) * 2 * (s_move_work.nwork + 1));

@@ -825,6 +825,11 @@ int  navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in,
  * bounds.  Host buffers. */
 int  navhip_settled_count(navhip_ctx *ctx, const navhip_world *world, int nq, const int32_t *uids,
                           int32_t *out_counts);
+/* The same on the snapshot the velocity half of the tick left on the device (see navhip_state_pass_resident): nothing of
+ * the snapshot travels, the index is built over the resident positions, the query ids stay in HBM; only the uids go up
+ * and the counts come back.  world: n_ents and the grid bounds.  NAVHIP_ERR_INVALID when no such step is resident. */
+int  navhip_settled_count_resident(navhip_ctx *ctx, const navhip_world *world, int nq, const int32_t *uids,
+                                   int32_t *out_counts);
 
 /* G_Arrival_ShouldSettle (arrival.c:946) for nq units whose flock has an active arrival zone (G_Arrival_IsActive)
  * for their nav layer -- the arm of entity_compute_update at movement.c:2443-2451 that navhip_state_update leaves

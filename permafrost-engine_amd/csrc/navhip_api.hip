@@ -1391,6 +1391,23 @@ int navhip_region_lookup(navhip_ctx *ctx, int nq, const float *pos_xz, const int
     return NAVHIP_OK;
 }
 
+}  // extern "C"
+
+// bg_ent insert-all + inrange_circle for nq query points with everything on the device: the index over
+// dev_w->pos_xz (positions only), ids in the reference's visiting order into d_ids [nq][maxout], counts into d_counts
+int nh_spatial_query_dev(navhip_ctx *ctx, const navhip_world *dev_w, const float *d_query, int nq, float range, int maxout,
+                         int32_t *d_counts, uint32_t *d_ids, hipStream_t s)
+{
+    nh_grid g;
+    int rc = spatial_build(ctx, dev_w, &g, s, 0, -1, false);
+    if(rc) return rc;
+    nh_launch_spatial_query(g, d_query, nq, range, maxout, d_counts, d_ids, s);
+    HIPCHK(ctx, hipGetLastError());
+    return NAVHIP_OK;
+}
+
+extern "C" {
+
 int navhip_spatial_query(navhip_ctx *ctx, const navhip_world *w, const float *query_xz, int nq,
                          float range, int maxout, int32_t *out_counts, uint32_t *out_ids)
 {
@@ -1409,12 +1426,8 @@ int navhip_spatial_query(navhip_ctx *ctx, const navhip_world *w, const float *qu
     if(rc) return rc;
     rc = ensure_buf(ctx, ctx->stage[22], (size_t)nq * maxout * 4);
     if(rc) return rc;
-    nh_grid g;
-    rc = spatial_build(ctx, &d, &g, s, 0, -1, false);
+    rc = nh_spatial_query_dev(ctx, &d, dq, nq, range, maxout, (int32_t*)ctx->stage[21].p, (uint32_t*)ctx->stage[22].p, s);
     if(rc) return rc;
-    nh_launch_spatial_query(g, dq, nq, range, maxout, (int32_t*)ctx->stage[21].p,
-                            (uint32_t*)ctx->stage[22].p, s);
-    HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->stage[21].p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(out_ids, ctx->stage[22].p, (size_t)nq * maxout * 4,
                                hipMemcpyDeviceToHost, s));

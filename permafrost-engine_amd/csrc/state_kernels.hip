@@ -242,6 +242,13 @@ __global__ __launch_bounds__(256) void k_gate_host_rows(int begin, int end, cons
 // adjacent_settled_count: the ids of the spatial query (k_spatial_query, the reference's visiting order,
 // capped) -> the count, a thread per unit
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_query(int nq, const int32_t *uids, const float *pos_xz, float *query)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if(q >= nq) return;
+    query[2 * q] = pos_xz[2 * uids[q]]; query[2 * q + 1] = pos_xz[2 * uids[q] + 1];
+}
+
 __global__ __launch_bounds__(256) void k_settled_count(int nq, const int32_t *uids, const float *pos_xz,
                                                        const float *radius, const uint32_t *flags,
                                                        const uint8_t *state, const int32_t *q_counts,
@@ -989,43 +996,61 @@ int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, 
     return NAVHIP_OK;
 }
 
+static int sk_settled_count(navhip_ctx *ctx, const navhip_world *w, int nq, const int32_t *uids, int32_t *out_counts, bool use_resident);
+
 int navhip_settled_count(navhip_ctx *ctx, const navhip_world *w, int nq, const int32_t *uids, int32_t *out_counts)
+{
+    return sk_settled_count(ctx, w, nq, uids, out_counts, false);
+}
+
+int navhip_settled_count_resident(navhip_ctx *ctx, const navhip_world *w, int nq, const int32_t *uids, int32_t *out_counts)
+{
+    return sk_settled_count(ctx, w, nq, uids, out_counts, true);
+}
+
+static int sk_settled_count(navhip_ctx *ctx, const navhip_world *w, int nq, const int32_t *uids, int32_t *out_counts, bool use_resident)
 {
     if(!ctx || !w || nq < 0 || w->n_ents < 0 || (nq > 0 && (!uids || !out_counts))) return NAVHIP_ERR_INVALID;
     if(nq == 0) return NAVHIP_OK;
-    if(!w->pos_xz || !w->radius || !w->flags || !w->state) return NAVHIP_ERR_INVALID;
+    if(!use_resident && (!w->pos_xz || !w->radius || !w->flags || !w->state)) return NAVHIP_ERR_INVALID;
     for(int q = 0; q < nq; q++)
         if(uids[q] < 0 || uids[q] >= w->n_ents) return NAVHIP_ERR_INVALID;
-    // the spatial index over the snapshot and the circle queries: navhip_spatial_query (bg_ent insert-all +
-    // inrange_circle in the reference's visiting order, capped); the ids come back to the host once and go up
-    // again with the snapshot -- this entry point is the host-buffer form, sized for the few units of the
-    // flocks that are arriving
+    // the spatial index over the snapshot, the circle queries and the count, all on the device: the ids of the queries
+    // (the reference's visiting order, capped) never leave HBM -- only the uids go up and the counts come back
     const size_t n = (size_t)w->n_ents;
-    std::vector<float> query((size_t)nq * 2);
-    for(int q = 0; q < nq; q++) { query[2 * q] = w->pos_xz[2 * uids[q]]; query[2 * q + 1] = w->pos_xz[2 * uids[q] + 1]; }
-    std::vector<int32_t> counts((size_t)nq);
-    std::vector<uint32_t> ids((size_t)nq * SK_QUERY_MAX);
-    int rc = navhip_spatial_query(ctx, w, query.data(), nq, SK_QUERY_R, SK_QUERY_MAX, counts.data(), ids.data());
-    if(rc) return rc;
     SKCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    navhip_world d; navhip_step_out so;
+    const bool resident = use_resident && nh_async_resident(ctx, &d, &so) && d.n_ents == w->n_ents && d.pos_xz && d.radius && d.flags && d.state;
+    if(use_resident && !resident) {
+        ctx->last_error = "navhip_settled_count_resident: no completed host-buffer step of this size is resident on the device";
+        return NAVHIP_ERR_INVALID;
+    }
     sk_arena A;
-    const size_t o_pos = A.take(n * 8), o_rad = A.take(n * 4), o_fl = A.take(n * 4), o_st = A.take(n),
-                 o_uid = A.take((size_t)nq * 4), o_cnt = A.take((size_t)nq * 4), o_ids = A.take((size_t)nq * SK_QUERY_MAX * 4),
-                 o_out = A.take((size_t)nq * 4);
+    const size_t o_pos = A.take(resident ? 0 : n * 8), o_rad = A.take(resident ? 0 : n * 4), o_fl = A.take(resident ? 0 : n * 4),
+                 o_st = A.take(resident ? 0 : n), o_uid = A.take((size_t)nq * 4), o_q = A.take((size_t)nq * 8),
+                 o_cnt = A.take((size_t)nq * 4), o_ids = A.take((size_t)nq * SK_QUERY_MAX * 4), o_out = A.take((size_t)nq * 4);
     char *base;
-    rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
+    int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
     if(rc) return rc;
-    SKCHK(ctx, hipMemcpyAsync(base + o_pos, w->pos_xz, n * 8, hipMemcpyHostToDevice, s));
-    SKCHK(ctx, hipMemcpyAsync(base + o_rad, w->radius, n * 4, hipMemcpyHostToDevice, s));
-    SKCHK(ctx, hipMemcpyAsync(base + o_fl, w->flags, n * 4, hipMemcpyHostToDevice, s));
-    SKCHK(ctx, hipMemcpyAsync(base + o_st, w->state, n, hipMemcpyHostToDevice, s));
+    if(!resident) {
+        // (a snapshot the velocity pass left on the device is read in place: the tick's tables are the same)
+        SKCHK(ctx, hipMemcpyAsync(base + o_pos, w->pos_xz, n * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_rad, w->radius, n * 4, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_fl, w->flags, n * 4, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_st, w->state, n, hipMemcpyHostToDevice, s));
+        d = *w;
+        d.pos_xz = (const float*)(base + o_pos); d.radius = (const float*)(base + o_rad);
+        d.flags = (const uint32_t*)(base + o_fl); d.state = (const uint8_t*)(base + o_st);
+    }
+    d.grid_xmin = w->grid_xmin; d.grid_xmax = w->grid_xmax; d.grid_zmin = w->grid_zmin; d.grid_zmax = w->grid_zmax;
     SKCHK(ctx, hipMemcpyAsync(base + o_uid, uids, (size_t)nq * 4, hipMemcpyHostToDevice, s));
-    SKCHK(ctx, hipMemcpyAsync(base + o_cnt, counts.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
-    SKCHK(ctx, hipMemcpyAsync(base + o_ids, ids.data(), (size_t)nq * SK_QUERY_MAX * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_query, dim3((nq + 255) / 256), dim3(256), 0, s, nq, (const int32_t*)(base + o_uid), d.pos_xz, (float*)(base + o_q));
+    rc = nh_spatial_query_dev(ctx, &d, (const float*)(base + o_q), nq, SK_QUERY_R, SK_QUERY_MAX, (int32_t*)(base + o_cnt),
+                              (uint32_t*)(base + o_ids), s);
+    if(rc) return rc;
     hipLaunchKernelGGL(k_settled_count, dim3((nq + 255) / 256), dim3(256), 0, s, nq, (const int32_t*)(base + o_uid),
-                       (const float*)(base + o_pos), (const float*)(base + o_rad), (const uint32_t*)(base + o_fl),
-                       (const uint8_t*)(base + o_st), (const int32_t*)(base + o_cnt), (const uint32_t*)(base + o_ids),
+                       d.pos_xz, d.radius, d.flags, d.state, (const int32_t*)(base + o_cnt), (const uint32_t*)(base + o_ids),
                        (int32_t*)(base + o_out));
     SKCHK(ctx, hipGetLastError());
     SKCHK(ctx, hipMemcpyAsync(out_counts, base + o_out, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
