@@ -145,6 +145,10 @@ static void hip_arena_reset(size_t need)
         free(s_hip_arena.base);
         s_hip_arena.cap = need + need / 4;
         s_hip_arena.base = malloc(s_hip_arena.cap);
+        if(!s_hip_arena.base) {
+            fprintf(stderr, "move_hip: out of memory for the per-tick arena (%zu bytes)\n", s_hip_arena.cap);
+            abort();
+        }
     }
     s_hip_arena.used = 0;
 }

@@ -457,11 +457,10 @@ void pfref_move_hip_threads(int nthreads, int min_items)
             pthread_create(&s_pool.th[t], NULL, pool_worker, (void*)(intptr_t)t);
         s_pool.started = true;
     }
-    if(s_pool.started && nthreads != s_pool.nthreads) {
-        /* (the pool keeps its size: shares are computed from nthreads, so only report what is in use) */
-        nthreads = s_pool.nthreads;
-    }
-    move_hip_set_parallel_for(nthreads > 1 ? pool_parallel_for : NULL, min_items);
+    /* (1 = serial again, whatever the pool's size; any other count uses the pool as it was started: its shares are
+     * computed from its own nthreads) */
+    const bool serial = nthreads == 1;
+    move_hip_set_parallel_for((!serial && s_pool.started) ? pool_parallel_for : NULL, min_items);
 }
 void pfref_move_hip_stats(long out[3])  { move_hip_stats(out); }
 
