@@ -709,10 +709,27 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
 // that the grouping was built for these flock offsets and this work range, the wave prefix over the flocks --
 // instead of reading what a one-workgroup kernel in front of the launch left (k_coh_plan: 6 us and a launch
 // gap on the chain that gates k_agent_mid; here ~40 instructions per wave).
+// COH_FPOS: the member positions of every flock, gathered ONCE per tick into member-list order (k_coh_gather: fpos[g] =
+// pos[flock_members[g]]).  Every wave of a flock stages all of the flock's positions: read through the member list that
+// is a dependent pair of loads per entry and 64 different lines per wave instruction -- 98 waves x 1 563 entries x a
+// 64-byte sector each for a 1 563-member flock, 630 MB of L2 traffic per tick at configs[2] --; read from fpos it is one
+// coalesced 512-byte row per instruction.  Same values in the same order.
+#ifndef COH_FPOS
+#define COH_FPOS 1
+#endif
+__global__ __launch_bounds__(256) void k_coh_gather(nh_step_params P, float2 *fpos)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if(g >= P.flock_offsets[P.n_flocks]) return;
+    const int m = P.flock_members[g];
+    fpos[g] = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
+}
+
 template <bool INLINE_PLAN>
 __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off,
                                                  const int32_t *perm, const int32_t *perm_valid,
-                                                 float *coh_xz, const int32_t *bin_start, const int32_t *saved)
+                                                 float *coh_xz, const int32_t *bin_start, const int32_t *saved,
+                                                 const float2 *fpos)
 {
     __shared__ double tab[64];
     // the members of the current tile that survive the box test, in member order (+ carry-over):
@@ -789,8 +806,12 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
             bool keep = false;
             float2 c2 = make_float2(0.0f, 0.0f);
             if(j < e) {
+#if COH_FPOS
+                c2 = fpos[j];
+#else
                 const int m = P.flock_members[j];
                 c2 = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
+#endif
                 const float dx = fmaxf(fmaxf(bx0 - c2.x, c2.x - bx1), 0.0f);
                 const float dz = fmaxf(fmaxf(bz0 - c2.y, c2.y - bz1), 0.0f);
                 keep = !(dx * dx + dz * dz > COH_FAR * COH_FAR);       // NaN stays in
@@ -1891,17 +1912,22 @@ bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh,
     // member of the whole snapshot); surplus waves exit at once
     const int nwaves = (P.n_members + 15) / 16 + P.n_flocks;
     const int prev = *parity ^ 1;
+    // (the caller's force buffer is twice the force array: the gathered positions live behind it)
+    float2 *fpos = (float2*)(d_coh + 2 * (size_t)P.n_ents);
+#if COH_FPOS
+    hipLaunchKernelGGL(k_coh_gather, dim3((P.n_members + 255) / 256), dim3(256), 0, s, P, fpos);
+#endif
     if(P.n_flocks <= COH_INLINE_PLAN_MAX) {
         hipLaunchKernelGGL(k_cohesion<true>, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
                            (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start,
-                           (const int32_t*)C.saved[prev]);
+                           (const int32_t*)C.saved[prev], (const float2*)fpos);
         return true;
     }
     hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start, P.flock_offsets,
                        (const int32_t*)C.saved[prev], P.n_flocks, P.work_begin, P.work_end, P.members_key, C.wave_off, C.valid);
     hipLaunchKernelGGL(k_cohesion<false>, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
                        (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start,
-                       (const int32_t*)C.saved[prev]);
+                       (const int32_t*)C.saved[prev], (const float2*)fpos);
     return true;                                  // caller: record the event, then ..._regroup
 }
 

@@ -951,7 +951,7 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     rc = step_fill_params(ctx, w, &P);
     if(rc) return rc;
     nh_nbr NB; nh_worklists WL;
-    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
+    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 4 * sizeof(float))   /* force [n][2] | gathered member positions [n][2] */;
     if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
     if(!rc) rc = step_scratch(ctx, w->n_ents, &NB, &WL, s);
     if(rc) return rc;
@@ -1092,7 +1092,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     nh_launch_agent_nbr(P, NB, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
+    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 4 * sizeof(float))   /* force [n][2] | gathered member positions [n][2] */;
     if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
     if(rc) return rc;
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity, s);

@@ -11,6 +11,7 @@
 #   ab20      bench.py --steps 20 (the driver's window), 3 rounds
 #   ab100     bench.py --steps 100, 2 rounds
 #   crowded   bench.py --crowded --steps 20, 2 rounds
+#   kstats20  per variant: rocprofv3 --kernel-trace --stats of the driver's window (20 ordinary ticks) -> kstats20_<variant>.csv
 #   kstats    per variant: rocprofv3 --kernel-trace --stats of 10 crowded ticks -> kstats_<variant>.csv
 #   sq        per variant: SQ / instruction-cache counters of 6 crowded ticks, three passes of four counters
 #             (eight SQ counters in one pass crashed rocprofv3 on this stack) -> counters.txt
@@ -34,6 +35,11 @@ binding) timeout 900 python -m pytest tests/test_binding_gpu.py -m gpu -x -q > $
 ab20)    timeout 600 python scripts/ab_lib.py --run $VARS --steps=20 --rounds=3 > $OUT/ab_20.txt 2>&1; tail -$(( $(echo $VARS | wc -w) + 1 )) $OUT/ab_20.txt ;;
 ab100)   timeout 900 python scripts/ab_lib.py --run $VARS --steps=100 --rounds=2 > $OUT/ab_100.txt 2>&1; tail -$(( $(echo $VARS | wc -w) + 1 )) $OUT/ab_100.txt ;;
 crowded) timeout 600 python scripts/ab_lib.py --run $VARS --crowded --steps=20 --rounds=2 > $OUT/ab_crowded.txt 2>&1; tail -$(( $(echo $VARS | wc -w) + 1 )) $OUT/ab_crowded.txt ;;
+kstats20) for v in $VARS; do pick $v
+           (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof20_$v -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-crowded --no-sustained --steps 20 > $OUT/bench_prof20_$v.json 2>/dev/null)
+           f=$(find /tmp/prof20_$v -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 $f | cut -c1-160 > $OUT/kstats20_$v.csv
+           echo "== $v"; cut -c1-110 $OUT/kstats20_$v.csv | head -12
+         done; unset NAVHIP_LIB ;;
 kstats)  for v in $VARS; do pick $v
            (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --crowded --warmup 3 --steps 10 > $OUT/bench_prof_$v.json 2>/dev/null)
            f=$(find /tmp/prof_$v -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 $f | cut -c1-160 > $OUT/kstats_$v.csv
