@@ -62,6 +62,13 @@ static void hip_for(hip_range_fn fn, int n, void *arg)
     else if(n > 0) fn(0, n, arg);
 }
 
+/* (loops whose items are expensive -- a nav query each -- fork from `min_items` on) */
+static void hip_for_min(hip_range_fn fn, int n, void *arg, int min_items)
+{
+    if(s_hip_parallel_for && n >= min_items) s_hip_parallel_for(fn, n, arg);
+    else if(n > 0) fn(0, n, arg);
+}
+
 static int cmp_u32(const void *a, const void *b)
 {
     uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
@@ -605,7 +612,7 @@ void move_hip_settle_stats(long out[4]) { memcpy(out, s_hip_settle_stats, sizeof
 
 struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned;
                         uint8_t *fstate, *wait_prev; int32_t *wait_ticks; float *ent_rot, *target_dir;
-                        float *interp_from, *interp_step; };
+                        float *interp_from, *interp_step; int any_turning; };
 
 static void hip_state_items_range(int begin, int end, void *arg)
 {
@@ -633,7 +640,8 @@ static void hip_state_items_range(int begin, int end, void *arg)
                      | (in->fstate.assigned_to_cell ? NAVHIP_FS_ASSIGNED : 0) | (in->fstate.in_range_of_cell ? NAVHIP_FS_IN_RANGE : 0)
                      | (in->fstate.arrived_at_cell ? NAVHIP_FS_ARRIVED : 0));
         T->wait_ticks[i] = ms->wait_ticks_left; T->wait_prev[i] = (uint8_t)ms->wait_prev;
-        if(ms->state == STATE_TURNING && T->ent_rot) {        /* :2606-2628: the end of the turn is the device's to see */
+        if(ms->state == STATE_TURNING) {                      /* :2606-2628: the end of the turn is the device's to see */
+            __atomic_store_n(&T->any_turning, 1, __ATOMIC_RELAXED);
             const quat_t rot = Entity_GetRot(in->ent_uid);
             memcpy(T->ent_rot + 4 * i, &rot, sizeof(float) * 4);
             memcpy(T->target_dir + 4 * i, &ms->target_dir, sizeof(float) * 4);
@@ -765,6 +773,61 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
     return ok;
 }
 
+/* is p, to the bit, the centre the device computes for some nav tile: (map_x - col * 4, map_z + row * 4)? */
+static bool hip_is_tile_centre(vec3_t map_pos, vec2_t p)
+{
+    const float c = roundf((map_pos.x - p.x) / 4.0f), r = roundf((p.z - map_pos.z) / 4.0f);
+    return map_pos.x - c * 4.0f == p.x && map_pos.z + r * 4.0f == p.z;
+}
+
+/* the unit-query answers of the surround units, forked over the host threads like the reference forks
+ * entity_compute_update -- the queries are the reference's own, read-only on the nav data */
+struct hip_surround_q { const struct hip_snap *S; const int32_t *items; int32_t *s_target; uint8_t *s_query; float *s_tprev, *s_nprev, *s_dest; };
+static void hip_surround_range(int begin, int end, void *arg)
+{
+    struct hip_surround_q *Q = arg;
+    const struct hip_snap *S = Q->S;
+    const struct move_gamestate *gs = &s_move_work.gamestate;
+    for(int k = begin; k < end; k++) {
+        const int w = Q->items[k], i = s_hip_witem.idx[w];
+        const uint32_t uid = S->uids[i];
+        const struct movestate *ms = movestate_get(uid);
+        Q->s_tprev[2 * i] = ms->surround_target_prev.x; Q->s_tprev[2 * i + 1] = ms->surround_target_prev.z;
+        Q->s_nprev[2 * i] = ms->surround_nearest_prev.x; Q->s_nprev[2 * i + 1] = ms->surround_nearest_prev.z;
+        if(ms->surround_target_uid == NULL_UID) { Q->s_target[i] = -1; continue; }
+        if(!entity_exists(ms->surround_target_uid)
+        || M_NavObjAdjacentFrom(gs->map, uid, ms->surround_target_uid, &s_move_work.unit_query_ctx)) {
+            Q->s_target[i] = -1; Q->s_query[i] = NAVHIP_SQ_ADJACENT;        /* (-> ARRIVED either way, :2518-2525) */
+            continue;
+        }
+        khiter_t it = kh_get(id, S->dense, ms->surround_target_uid);
+        if(it == kh_end(S->dense))
+            continue;                                                     /* (a target outside the snapshot: the host's) */
+        Q->s_target[i] = (int32_t)kh_value(S->dense, it);
+        const vec2_t tp = {S->pos[2 * Q->s_target[i]], S->pos[2 * Q->s_target[i] + 1]};
+        vec2_t delta, dest;
+        PFM_Vec2_Sub((vec2_t*)&tp, (vec2_t*)&ms->surround_target_prev, &delta);
+        if(!(PFM_Vec2_Len(&delta) > EPSILON || PFM_Vec2_Len(&ms->velocity) < EPSILON))
+            continue;                                                     /* (the query does not run this tick) */
+        const enum nav_layer layer = Entity_NavLayerWithRadius(S->flags[i], S->radius[i]);
+        const vec2_t pos = {S->pos[2 * i], S->pos[2 * i + 1]}, vel = s_move_work.out[w].ent_vel;
+        vec2_t from[2] = {pos, pos};
+        PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &from[0]);
+        for(int c = 0; c < 2; c++) {
+            if(c == 1 && from[0].x == from[1].x && from[0].z == from[1].z) {      /* (zero velocity: one query) */
+                if(Q->s_query[i] & NAVHIP_SQ_HAS_DEST_0) {
+                    Q->s_query[i] |= NAVHIP_SQ_HAS_DEST_1; Q->s_dest[4 * i + 2] = Q->s_dest[4 * i]; Q->s_dest[4 * i + 3] = Q->s_dest[4 * i + 1];
+                }
+                break;
+            }
+            if(M_NavClosestReachableAdjacentPosFrom(gs->map, layer, from[c], ms->surround_target_uid, &s_move_work.unit_query_ctx, &dest)) {
+                Q->s_query[i] |= (uint8_t)(NAVHIP_SQ_HAS_DEST_0 << c);
+                Q->s_dest[4 * i + 2 * c] = dest.x; Q->s_dest[4 * i + 2 * c + 1] = dest.z;
+            }
+        }
+    }
+}
+
 struct hip_state_scatter { int begin_idx; const uint8_t *st, *fl; long host; };
 static void hip_state_scatter_range(int begin, int end, void *arg)
 {
@@ -818,11 +881,9 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     int32_t *wait_after = resident ? s_hip_pin.wait_after : hip_arena(sizeof(int32_t) * (n + 1));
     memset(fstate, 0, n + 1); memset(wait_prev, 0, n + 1); memset(wait_ticks, 0, sizeof(int32_t) * (n + 1));
     /* (the rotations of TURNING units: 32 bytes per unit that are only touched when somebody turns) */
-    bool any_turning = false;
-    for(int w = begin_idx; w <= end_idx && !any_turning; w++)
-        any_turning = movestate_get(s_move_work.in[w].ent_uid)->state == STATE_TURNING;
-    float *ent_rot = any_turning ? hip_arena(sizeof(float) * (4 * n + 4)) : NULL, *target_dir = any_turning ? hip_arena(sizeof(float) * (4 * n + 4)) : NULL;
-    if(any_turning) { memset(ent_rot, 0, sizeof(float) * (4 * n + 4)); memset(target_dir, 0, sizeof(float) * (4 * n + 4)); }
+    /* (taken from the arena without a memset: the device reads the rows of TURNING units only, which the fill writes;
+     * handed over only when somebody turns) */
+    float *ent_rot = hip_arena(sizeof(float) * (4 * n + 4)), *target_dir = hip_arena(sizeof(float) * (4 * n + 4));
     memset(skip, 0, n + 1); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); memset(zoned, 0, n + 1);
     if(!resident) {
         memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2));
@@ -833,8 +894,9 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     if(sub20) { memset(interp_from, 0, sizeof(float) * (2 * n + 2)); memset(interp_step, 0, sizeof(float) * (n + 1)); }
     hip_work_dense_prepare();
     struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned, fstate, wait_prev, wait_ticks, ent_rot, target_dir,
-                               interp_from, interp_step};
+                               interp_from, interp_step, 0};
     hip_for(hip_state_items_range, end_idx - begin_idx + 1, &T);
+    const bool any_turning = T.any_turning != 0;
     int lo = n, hi = -1;
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];
@@ -920,9 +982,19 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
                     khiter_t k = kh_get(id, S.dense, ms->surround_target_uid);
                     if(k != kh_end(S.dense)) {
                         r_target[i] = (int32_t)kh_value(S.dense, k);
-                        const vec2_t tp = {S.pos[2 * r_target[i]], S.pos[2 * r_target[i] + 1]};
-                        r_off[row + 1] += N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map),
-                            Entity_NavLayerWithRadius(S.flags[i], S.radius[i]), map_pos, tp, r_tiles + 2 * r_off[row], per);
+                        /* N_IsMaximallyClose(new_pos, target, 0.0f) (:2585) holds only where the tested position IS the
+                         * centre of one of the target's closest island tiles: the 31-us island query is only made for a
+                         * unit one of whose candidate positions -- pos + new velocity, pos (halted by the gate) -- is a
+                         * tile centre to the bit; any other unit gets an empty row (at rates below 20 Hz the position is
+                         * the device's interpolation: every unit is asked for) */
+                        const vec2_t pos = {S.pos[2 * i], S.pos[2 * i + 1]}, vel = s_move_work.out[w].ent_vel;
+                        vec2_t moved_to;
+                        PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &moved_to);
+                        if(sub20 || hip_is_tile_centre(map_pos, pos) || hip_is_tile_centre(map_pos, moved_to)) {
+                            const vec2_t tp = {S.pos[2 * r_target[i]], S.pos[2 * r_target[i] + 1]};
+                            r_off[row + 1] += N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map),
+                                Entity_NavLayerWithRadius(S.flags[i], S.radius[i]), map_pos, tp, r_tiles + 2 * r_off[row], per);
+                        }
                     }
                 }
                 row++;
@@ -944,46 +1016,13 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         s_target = malloc(sizeof(int32_t) * n); s_query = calloc(n, 1); s_tprev = calloc(2 * n, sizeof(float));
         s_nprev = calloc(2 * n, sizeof(float)); s_dest = calloc(4 * n, sizeof(float)); s_out = calloc(2 * n, sizeof(float));
         for(int i = 0; i < n; i++) s_target[i] = -2;
-        for(int w = begin_idx; w <= end_idx; w++) {
-            const int i = s_hip_witem.idx[w];
-            if(S.state[i] != STATE_SURROUND_ENTITY)
-                continue;
-            const uint32_t uid = S.uids[i];
-            const struct movestate *ms = movestate_get(uid);
-            s_tprev[2 * i] = ms->surround_target_prev.x; s_tprev[2 * i + 1] = ms->surround_target_prev.z;
-            s_nprev[2 * i] = ms->surround_nearest_prev.x; s_nprev[2 * i + 1] = ms->surround_nearest_prev.z;
-            if(ms->surround_target_uid == NULL_UID) { s_target[i] = -1; continue; }
-            if(!entity_exists(ms->surround_target_uid)
-            || M_NavObjAdjacentFrom(gs->map, uid, ms->surround_target_uid, &s_move_work.unit_query_ctx)) {
-                s_target[i] = -1; s_query[i] = NAVHIP_SQ_ADJACENT;        /* (-> ARRIVED either way, :2518-2525) */
-                continue;
-            }
-            khiter_t k = kh_get(id, S.dense, ms->surround_target_uid);
-            if(k == kh_end(S.dense))
-                continue;                                                 /* (a target outside the snapshot: the host's) */
-            s_target[i] = (int32_t)kh_value(S.dense, k);
-            const vec2_t tp = {S.pos[2 * s_target[i]], S.pos[2 * s_target[i] + 1]};
-            vec2_t delta, dest;
-            PFM_Vec2_Sub((vec2_t*)&tp, (vec2_t*)&ms->surround_target_prev, &delta);
-            if(!(PFM_Vec2_Len(&delta) > EPSILON || PFM_Vec2_Len(&ms->velocity) < EPSILON))
-                continue;                                                 /* (the query does not run this tick) */
-            const enum nav_layer layer = Entity_NavLayerWithRadius(S.flags[i], S.radius[i]);
-            const vec2_t pos = {S.pos[2 * i], S.pos[2 * i + 1]}, vel = s_move_work.out[w].ent_vel;
-            vec2_t from[2] = {pos, pos};
-            PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &from[0]);
-            for(int c = 0; c < 2; c++) {
-                if(c == 1 && from[0].x == from[1].x && from[0].z == from[1].z) {      /* (zero velocity: one query) */
-                    if(s_query[i] & NAVHIP_SQ_HAS_DEST_0) {
-                        s_query[i] |= NAVHIP_SQ_HAS_DEST_1; s_dest[4 * i + 2] = s_dest[4 * i]; s_dest[4 * i + 3] = s_dest[4 * i + 1];
-                    }
-                    break;
-                }
-                if(M_NavClosestReachableAdjacentPosFrom(gs->map, layer, from[c], ms->surround_target_uid, &s_move_work.unit_query_ctx, &dest)) {
-                    s_query[i] |= (uint8_t)(NAVHIP_SQ_HAS_DEST_0 << c);
-                    s_dest[4 * i + 2 * c] = dest.x; s_dest[4 * i + 2 * c + 1] = dest.z;
-                }
-            }
-        }
+        int32_t *s_items = malloc(sizeof(int32_t) * n_surround);
+        int ns = 0;
+        for(int w = begin_idx; w <= end_idx; w++)
+            if(S.state[s_hip_witem.idx[w]] == STATE_SURROUND_ENTITY) s_items[ns++] = w;
+        struct hip_surround_q Q = {&S, s_items, s_target, s_query, s_tprev, s_nprev, s_dest};
+        hip_for_min(hip_surround_range, ns, &Q, 16);
+        free(s_items);
         pin.aux.surround_target = s_target; pin.aux.surround_query = s_query; pin.aux.surround_target_prev_xz = s_tprev;
         pin.aux.surround_nearest_prev_xz = s_nprev; pin.aux.surround_dest_xz = s_dest; pin.aux.out_surround_dest_xz = s_out;
     }

@@ -249,21 +249,24 @@ __global__ __launch_bounds__(256) void k_gather_query(int nq, const int32_t *uid
     query[2 * q] = pos_xz[2 * uids[q]]; query[2 * q + 1] = pos_xz[2 * uids[q] + 1];
 }
 
+// a row of 16 lanes per unit: the candidates of a query are independent tests (a count, no order) -- a thread per unit
+// walked its 128 ids one dependent gather after the other (167 us for 3 400 units)
 __global__ __launch_bounds__(256) void k_settled_count(int nq, const int32_t *uids, const float *pos_xz,
                                                        const float *radius, const uint32_t *flags,
                                                        const uint8_t *state, const int32_t *q_counts,
                                                        const uint32_t *q_ids, int32_t *out)
 {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if(q >= nq) return;
-    const int uid = uids[q];
+    const int q = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
+    const bool live = q < nq;
+    const int uid = live ? uids[q] : 0;
     const float r_uid = radius[uid];
-    if(2.0f * r_uid + 5.0f > SK_QUERY_R) { out[q] = -1; return; }           // search_radius, :995
+    const bool wide = 2.0f * r_uid + 5.0f > SK_QUERY_R;                     // search_radius, :995
     const v2 pos = mkv(pos_xz[2 * uid], pos_xz[2 * uid + 1]);
     const uint32_t my_air = flags[uid] & NAVHIP_ENTITY_FLAG_AIR;
     int count = 0;
-    const uint32_t *ids = q_ids + (size_t)q * SK_QUERY_MAX;
-    for(int k = 0; k < q_counts[q]; k++) {
+    const uint32_t *ids = q_ids + (size_t)(live ? q : 0) * SK_QUERY_MAX;
+    const int n = (live && !wide) ? q_counts[q] : 0;
+    for(int k = gl; k < n; k += 16) {
         const int c = (int)ids[k];
         const uint32_t f = flags[c];
         if(f & NAVHIP_ENTITY_FLAG_GARRISONED) continue;                     // filter_garrisoned, position.c:384
@@ -272,7 +275,9 @@ __global__ __launch_bounds__(256) void k_settled_count(int nq, const int32_t *ui
         const v2 cp = mkv(pos_xz[2 * c], pos_xz[2 * c + 1]);
         if(vlen(vsub(pos, cp)) <= r_uid + radius[c] + 5.0f) count++;         // ADJACENCY_SEP_DIST
     }
-    out[q] = count;
+#pragma unroll
+    for(int d = 1; d < 16; d <<= 1) count += __shfl_xor(count, d);
+    if(live && gl == 0) out[q] = wide ? -1 : count;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1049,7 +1054,7 @@ static int sk_settled_count(navhip_ctx *ctx, const navhip_world *w, int nq, cons
     rc = nh_spatial_query_dev(ctx, &d, (const float*)(base + o_q), nq, SK_QUERY_R, SK_QUERY_MAX, (int32_t*)(base + o_cnt),
                               (uint32_t*)(base + o_ids), s);
     if(rc) return rc;
-    hipLaunchKernelGGL(k_settled_count, dim3((nq + 255) / 256), dim3(256), 0, s, nq, (const int32_t*)(base + o_uid),
+    hipLaunchKernelGGL(k_settled_count, dim3((nq + 15) / 16), dim3(256), 0, s, nq, (const int32_t*)(base + o_uid),
                        d.pos_xz, d.radius, d.flags, d.state, (const int32_t*)(base + o_cnt), (const uint32_t*)(base + o_ids),
                        (int32_t*)(base + o_out));
     SKCHK(ctx, hipGetLastError());

@@ -421,6 +421,7 @@ class NavTick:
         # small world's tick is ~19 dependent kernels of 5-10 us each (0.14 ms at configs[0], 0.2 ms for a rank of 8), a
         # big one loses the overlap of cohesion / ClearPath / field builds on one stream, and a multi-stream graph pays a
         # barrier packet per cross-stream edge.  Both stay options (NAVTICK_SERIAL=1, NAVTICK_GRAPH=1), default off.
+        self.driver = driver if (self.tile_exchange == "none" or self.solo) else "python"
         if serial is None:
             serial = os.environ.get("NAVTICK_SERIAL") == "1"
         self.serial = bool(serial)

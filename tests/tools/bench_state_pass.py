@@ -59,8 +59,10 @@ def main():
         state[(u >= 0.20) & (u < 0.24)] = 8   # STATE_ARRIVING_TO_CELL
         state[(u >= 0.24) & (u < 0.28)] = 1   # STATE_MOVING_IN_FORMATION
         state[(u >= 0.28) & (u < 0.31)] = 7   # STATE_TURNING
-        state[(u >= 0.31) & (u < 0.34)] = 6   # STATE_ENTER_ENTITY_RANGE
-        state[(u >= 0.34) & (u < 0.37)] = 5   # STATE_SURROUND_ENTITY
+        # (the two arms with per-unit nav queries on the host -- the reference's own, 30-90 us each -- in the numbers an
+        # army has them: a garrison order, a harvest / attack group)
+        state[(u >= 0.31) & (u < 0.32)] = 6   # STATE_ENTER_ENTITY_RANGE
+        state[(u >= 0.32) & (u < 0.323)] = 5  # STATE_SURROUND_ENTITY
         fstate = ((rng.rand(N) < 0.3) * 1 | (rng.rand(N) < 0.7) * 2 | (rng.rand(N) < 0.7) * 4 | (rng.rand(N) < 0.5) * 8
                   | (rng.rand(N) < 0.5) * 16).astype(np.uint8)
         ticks = rng.choice([1, 2, 3, 40], N).astype(np.int32)
@@ -119,7 +121,7 @@ def main():
         t_range = rng.choice([0.0, 5.0, 20.0, 60.0], N).astype(np.float32)
         t_prev = (pos[np.maximum(tgt, 0)] + rng.normal(0, 4.0, (N, 2))).astype(np.float32)
         s_tprev = pos[np.maximum(tgt, 0)].copy()
-        moved = rng.rand(N) < 0.5
+        moved = rng.rand(N) < 0.1             # (most surround targets stand still: buildings, resources)
         s_tprev[moved] += rng.normal(0, 3.0, (moved.sum(), 2)).astype(np.float32)
         s_nprev = (pos + rng.normal(0, 6.0, (N, 2))).astype(np.float32)
         if zones:
