@@ -152,12 +152,20 @@ NH_FN int nav_layer_for(uint32_t flags, float radius)
 NH_FN uint32_t tile_probe(const nh_step_params &P, int layer, const tiledesc &t)
 {
     const nh_layer_view &L = P.map.layers[layer];
-#ifdef NH_HOSTSIM
+#if defined(NH_HOSTSIM) && !defined(NH_HOSTSIM_PROBEMASK)
+    // (the host-side unit tests of the per-thread logic build their map views by hand, without derived planes; the
+    // whole-library emulator build defines NH_HOSTSIM_PROBEMASK and reads what the device reads: the masks k_derive made)
     const size_t idx = tile_index(P, t);
     return (L.cost[idx] != NAVHIP_COST_IMPASSABLE ? 1u : 0u) | ((L.blockers && L.blockers[idx] > 0) ? 2u : 0u);
 #else
-    const ulonglong2 m = *(const ulonglong2*)(L.probemask + ((((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 6) + t.tile_r) << 1));
-    return (uint32_t)((m.x >> t.tile_c) & 1ull) | ((uint32_t)((m.y >> t.tile_c) & 1ull) << 1);
+    const uint64_t *row = L.probemask + ((((size_t)(t.chunk_r * P.map.w + t.chunk_c) << 6) + t.tile_r) << 1);
+#ifdef NH_HOSTSIM
+    const uint64_t mx = row[0], my = row[1];
+#else
+    const ulonglong2 m = *(const ulonglong2*)row;
+    const uint64_t mx = m.x, my = m.y;
+#endif
+    return (uint32_t)((mx >> t.tile_c) & 1ull) | ((uint32_t)((my >> t.tile_c) & 1ull) << 1);
 #endif
 }
 

@@ -226,7 +226,7 @@ def build_navhip_emu():
         cpp = os.path.join(src_dir, name + ".cpp")
         open(cpp, "w").write(text)
         obj = os.path.join(src_dir, name + ".o")
-        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-DNH_HOSTSIM=1", "-ffp-contract=off", "-fno-fast-math",
+        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-DNH_HOSTSIM=1", "-DNH_HOSTSIM_PROBEMASK=1", "-ffp-contract=off", "-fno-fast-math",
                                "-w", "-I" + os.path.join(HERE, "fakehip"), "-I" + HERE, "-I" + os.path.join(ROOT, "include"),
                                "-I" + CSRC, "-c", cpp, "-o", obj])
         objs.append(obj)
