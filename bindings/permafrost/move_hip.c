@@ -828,6 +828,23 @@ static void hip_surround_range(int begin, int end, void *arg)
     }
 }
 
+/* the per-flock answers of arrived()'s two destination-only queries, kept between ticks */
+struct hip_flock_q { bool valid, has_near; uint32_t epoch; const void *map; int layer, ntiles; float tx, tz, nx, nz; int16_t *tiles; };
+static struct hip_flock_q *s_hip_flock_q; static size_t s_hip_flock_q_cap;
+static struct hip_flock_q *hip_flock_q_slot(size_t f, int per)
+{
+    if(f >= s_hip_flock_q_cap) {
+        const size_t cap = f + 16;
+        s_hip_flock_q = realloc(s_hip_flock_q, sizeof(struct hip_flock_q) * cap);
+        for(size_t k = s_hip_flock_q_cap; k < cap; k++) {
+            s_hip_flock_q[k].valid = false;
+            s_hip_flock_q[k].tiles = malloc(sizeof(int16_t) * 2 * per);
+        }
+        s_hip_flock_q_cap = cap;
+    }
+    return &s_hip_flock_q[f];
+}
+
 struct hip_state_scatter { int begin_idx; const uint8_t *st, *fl; long host; };
 static void hip_state_scatter_range(int begin, int end, void *arg)
 {
@@ -879,12 +896,15 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     uint8_t *fstate = resident ? s_hip_pin.fstate : hip_arena(n + 1), *wait_prev = resident ? s_hip_pin.wait_prev : hip_arena(n + 1);
     int32_t *wait_ticks = resident ? s_hip_pin.wait_ticks : hip_arena(sizeof(int32_t) * (n + 1));
     int32_t *wait_after = resident ? s_hip_pin.wait_after : hip_arena(sizeof(int32_t) * (n + 1));
-    memset(fstate, 0, n + 1); memset(wait_prev, 0, n + 1); memset(wait_ticks, 0, sizeof(int32_t) * (n + 1));
+    /* (rows of the slab without a work item are computed and dropped: they only need defined inputs -- whatever the
+     * page-locked arrays of the resident pass held last tick will do, the pageable ones are cleared) */
+    if(!resident) { memset(fstate, 0, n + 1); memset(wait_prev, 0, n + 1); memset(wait_ticks, 0, sizeof(int32_t) * (n + 1)); }
     /* (the rotations of TURNING units: 32 bytes per unit that are only touched when somebody turns) */
     /* (taken from the arena without a memset: the device reads the rows of TURNING units only, which the fill writes;
      * handed over only when somebody turns) */
     float *ent_rot = hip_arena(sizeof(float) * (4 * n + 4)), *target_dir = hip_arena(sizeof(float) * (4 * n + 4));
-    memset(skip, 0, n + 1); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); memset(zoned, 0, n + 1);
+    if(!resident) { memset(skip, 0, n + 1); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); }
+    memset(zoned, 0, n + 1);
     if(!resident) {
         memset(new_pos, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2));
         memset(new_vel, 0, sizeof(float) * (2 * n + 2));
@@ -929,12 +949,21 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
             if(per_layer[l] > per_layer[best]) best = l;
         const enum nav_layer layer = (enum nav_layer)best;
         flayer[f] = (uint8_t)layer;
-        vec2_t near_xz;
-        if(M_NavClosestPathable(gs->map, layer, fl->target_xz, &near_xz)) {
-            nearest[2 * f] = near_xz.x; nearest[2 * f + 1] = near_xz.z;
+        /* the two queries depend on the destination and the layer only -- terrain, not blockers (N_ClosestPathable
+         * nav.c:4126 and n_closest_island_tiles :4725 read cost_base and the global islands) --: asked once per flock
+         * and (target, layer), kept until the flock is re-targeted or the map's nav data is rebuilt (move_hip_attrs_changed
+         * / N_HIP_SyncLayer callers bump s_hip_attr_epoch) */
+        struct hip_flock_q *C = hip_flock_q_slot(f, per);
+        if(!(C->valid && C->epoch == s_hip_attr_epoch && C->map == (const void*)gs->map && C->layer == (int)layer && C->tx == fl->target_xz.x && C->tz == fl->target_xz.z)) {
+            vec2_t near_xz;
+            C->has_near = M_NavClosestPathable(gs->map, layer, fl->target_xz, &near_xz);
+            C->nx = C->has_near ? near_xz.x : 0.0f; C->nz = C->has_near ? near_xz.z : 0.0f;
+            C->ntiles = N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map), layer, map_pos, fl->target_xz, C->tiles, per);
+            C->valid = true; C->epoch = s_hip_attr_epoch; C->map = (const void*)gs->map; C->layer = (int)layer; C->tx = fl->target_xz.x; C->tz = fl->target_xz.z;
         }
-        toff[f + 1] += N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map), layer, map_pos, fl->target_xz,
-                                                tiles + 2 * toff[f], per);
+        if(C->has_near) { nearest[2 * f] = C->nx; nearest[2 * f + 1] = C->nz; }
+        memcpy(tiles + 2 * toff[f], C->tiles, sizeof(int16_t) * 2 * C->ntiles);
+        toff[f + 1] += C->ntiles;
     }
     HIP_SU_LAP(2);
     navhip_world W;

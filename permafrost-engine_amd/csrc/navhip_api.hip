@@ -1393,6 +1393,8 @@ int navhip_region_lookup(navhip_ctx *ctx, int nq, const float *pos_xz, const int
 
 }  // extern "C"
 
+int nh_refresh_derived(navhip_ctx *ctx, hipStream_t s) { return refresh_derived(ctx, s); }
+
 // bg_ent insert-all + inrange_circle for nq query points with everything on the device: the index over
 // dev_w->pos_xz (positions only), ids in the reference's visiting order into d_ids [nq][maxout], counts into d_counts
 int nh_spatial_query_dev(navhip_ctx *ctx, const navhip_world *dev_w, const float *d_query, int nq, float range, int maxout,

@@ -105,6 +105,7 @@ void nh_async_invalidate_static(navhip_ctx *ctx);   // the staging buffers were 
 bool nh_async_resident(navhip_ctx *ctx, navhip_world *w, navhip_step_out *o);   // snapshot + outputs the last completed submit left on the device
 int  nh_async_slabs(navhip_ctx *ctx, size_t in_bytes, size_t out_bytes, char **h_in, char **h_out);
 bool nh_is_pinned(const void *p);
+int  nh_refresh_derived(navhip_ctx *ctx, hipStream_t s);    // the derived row masks (passmask / probemask) of dirty chunks, rebuilt
 int  nh_spatial_query_dev(navhip_ctx *ctx, const navhip_world *dev_w, const float *d_query, int nq, float range, int maxout,
                           int32_t *d_counts, uint32_t *d_ids, hipStream_t s);
 const uint8_t *nh_pool_fields(const navhip_ctx *ctx);

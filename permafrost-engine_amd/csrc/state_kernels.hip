@@ -510,6 +510,11 @@ int navhip_heading_gate_dev(navhip_ctx *ctx, const navhip_world *w, const navhip
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
     SKCHK(ctx, hipSetDevice(ctx->device));
+    if(in->interp_from_xz) {
+        // (the accept test of the interpolated position probes the derived row masks: rebuilt here if a plane changed)
+        int rc = nh_refresh_derived(ctx, ctx->stream);
+        if(rc) return rc;
+    }
     nh_step_params P;
     sk_map_view(ctx, w, &P);
     if(e > b)

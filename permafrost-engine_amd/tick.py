@@ -195,6 +195,19 @@ class NavTick:
                                 for k, v in a.items()})
             ag_parts = swapped
         ag = {k: (np.concatenate([a[k] for a in ag_parts]) if k != "hz" else hz) for k in ag_parts[0]}
+        # NAVTICK_UID_ORDER (an experiment, not a schedule): number the entities in spatial order -- "cell" = by the 16-wu
+        # cell of the spatial index, "flock_cell" = flock by flock, by cell inside a flock -- so that the uid-order kernels
+        # ARE cell-order kernels with every per-entity array still contiguous: the upper bound of what stepping agents in
+        # pool order could save (profiles/r05_ab_uid_order.txt)
+        uid_order = os.environ.get("NAVTICK_UID_ORDER", "")
+        if uid_order and world == 1:
+            cx = np.floor((ag["pos"][:, 0] + Wt * 128.0) / 16.0).astype(np.int64)
+            cz = np.floor((ag["pos"][:, 1] + H * 128.0) / 16.0).astype(np.int64)
+            key = cz * 4096 + cx
+            if uid_order == "flock_cell":
+                key = ag["flock"].astype(np.int64) * (1 << 32) + key
+            perm = np.argsort(key, kind="stable")
+            ag = {k: (v[perm] if k != "hz" else v) for k, v in ag.items()}
 
         # ---- request stream: region-major, destination-major inside a region -------------------
         # tile_exchange: "auto" = only the fields some other rank samples travel (none when flocks

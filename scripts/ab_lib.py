@@ -47,7 +47,7 @@ def run(names, rounds=3, extra=()):
                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             res[n].append(d["ms_per_step"])
-            print(n, round(d["ms_per_step"], 4), round(d["ms_per_step_median"], 4), [round(x, 3) for x in (d.get("summary") or d).get("ms_tick_5_50_100") or [] if x is not None], flush=True)
+            print(n, round(d["ms_per_step"], 4), round((d.get("summary") or d)["ms_per_step_median"], 4), [round(x, 3) for x in (d.get("summary") or d).get("ms_tick_5_50_100") or [] if x is not None], flush=True)
     for n in names:
         v = sorted(res[n])
         print("%-12s median %.4f ms/tick  (min %.4f)" % (n, v[len(v) // 2], v[0]))
