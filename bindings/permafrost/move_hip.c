@@ -176,7 +176,7 @@ static void *hip_arena(size_t bytes)
 static size_t hip_arena_need(size_t n, size_t F)
 {
     /* (twice: the state pass of a tick keeps the velocity pass's snapshot and takes its own arrays behind it) */
-    return 2 * ((n + 16) * (4 * 46 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 48);
+    return 2 * ((n + 16) * (4 * 62 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 48);
 }
 
 static void hip_check_range(int begin, int end, void *arg)
@@ -991,10 +991,14 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         for(int w = begin_idx; w <= end_idx; w++)
             n_range += S.state[s_hip_witem.idx[w]] == STATE_ENTER_ENTITY_RANGE;
         if(n_range > 0) {
-            r_target = malloc(sizeof(int32_t) * n); r_row = calloc(n, sizeof(int32_t)); r_off = calloc(n_range + 1, sizeof(int32_t));
-            r_range = calloc(n, sizeof(float)); r_prev = calloc(2 * n, sizeof(float));
+            /* (per-unit arrays from the arena, not cleared: the device reads the rows of ENTER_ENTITY_RANGE units only --
+             * but the library checks every row's target index, hence the fill with "the host's") */
+            r_target = hip_arena(sizeof(int32_t) * (n + 1)); r_row = hip_arena(sizeof(int32_t) * (n + 1));
+            r_off = calloc(n_range + 1, sizeof(int32_t));
+            r_range = hip_arena(sizeof(float) * (n + 1)); r_prev = hip_arena(sizeof(float) * (2 * n + 2));
             r_tiles = malloc(sizeof(int16_t) * 2 * per * n_range);
             for(int i = 0; i < n; i++) r_target[i] = -2;
+            memset(r_row, 0, sizeof(int32_t) * n);
             int row = 0;
             for(int w = begin_idx; w <= end_idx; w++) {
                 const int i = s_hip_witem.idx[w];
@@ -1042,9 +1046,11 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     for(int w = begin_idx; !sub20 && w <= end_idx; w++)
         n_surround += S.state[s_hip_witem.idx[w]] == STATE_SURROUND_ENTITY;
     if(n_surround > 0) {
-        s_target = malloc(sizeof(int32_t) * n); s_query = calloc(n, 1); s_tprev = calloc(2 * n, sizeof(float));
-        s_nprev = calloc(2 * n, sizeof(float)); s_dest = calloc(4 * n, sizeof(float)); s_out = calloc(2 * n, sizeof(float));
+        /* (from the arena; the device reads and writes the rows of SURROUND_ENTITY units only) */
+        s_target = hip_arena(sizeof(int32_t) * (n + 1)); s_query = hip_arena(n + 1); s_tprev = hip_arena(sizeof(float) * (2 * n + 2));
+        s_nprev = hip_arena(sizeof(float) * (2 * n + 2)); s_dest = hip_arena(sizeof(float) * (4 * n + 4)); s_out = hip_arena(sizeof(float) * (2 * n + 2));
         for(int i = 0; i < n; i++) s_target[i] = -2;
+        memset(s_query, 0, n + 1); memset(s_out, 0, sizeof(float) * (2 * n + 2));
         int32_t *s_items = malloc(sizeof(int32_t) * n_surround);
         int ns = 0;
         for(int w = begin_idx; w <= end_idx; w++)
@@ -1076,13 +1082,13 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     s_hip_resident_passes += ok && resident;
     s_hip_settle_resident = ok && resident;
     HIP_SU_LAP(3);
-    free(r_target); free(r_row); free(r_off); free(r_range); free(r_prev); free(r_tiles);
+    free(r_off); free(r_tiles);
     s_hip_su_dest = realloc(s_hip_su_dest, sizeof(float) * 2 * (s_move_work.nwork + 1));
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];
         s_hip_su_dest[2 * w] = s_out ? s_out[2 * i] : 0.0f; s_hip_su_dest[2 * w + 1] = s_out ? s_out[2 * i + 1] : 0.0f;
     }
-    free(s_target); free(s_query); free(s_tprev); free(s_nprev); free(s_dest); free(s_out);
+    /* (the surround arrays live in the arena) */
     /* a unit whose facing is within the device's margin of a tolerance came back NAVHIP_SU_HOST: the host's own
      * entity_compute_update answers for it (move_hip_update_work) */
     for(int w = begin_idx; ok && w <= end_idx; w++)

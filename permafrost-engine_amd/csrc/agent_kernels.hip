@@ -714,8 +714,10 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
 // is a dependent pair of loads per entry and 64 different lines per wave instruction -- 98 waves x 1 563 entries x a
 // 64-byte sector each for a 1 563-member flock, 630 MB of L2 traffic per tick at configs[2] --; read from fpos it is one
 // coalesced 512-byte row per instruction.  Same values in the same order.
+// Measured (profiles/r05_ab_coh_fpos_*): the kernel 129.0 -> 121.3 us, the gather kernel in front of it 5.5 us, the tick
+// 0.3105 against 0.3114 ms -- the kernel is not bound by its gathers (they hit L2).  Off: one launch less on the chain.
 #ifndef COH_FPOS
-#define COH_FPOS 1
+#define COH_FPOS 0
 #endif
 __global__ __launch_bounds__(256) void k_coh_gather(nh_step_params P, float2 *fpos)
 {
