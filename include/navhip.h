@@ -472,6 +472,12 @@ int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, v
  * step then does not make the caller's stream wait for the lane regrouping the cohesion stream runs
  * for the next tick -- that work is ordered in front of the next step's cohesion term anyway. */
 #define NAVHIP_PREFETCH_SNAPSHOT_HELD 0x2u
+/*        NAVHIP_PREFETCH_FIELDS_READY  everything the step SAMPLES is final when this call is made -- the field pool
+ * and its slot tables, the LOS pool, vdes_xz, the formation / arrival inputs: every array of dev_world, which the step
+ * that follows must pass unchanged --: the front then also runs the first half of the per-agent chain (flow sampling,
+ * line of sight, arrive force, tile probes: a chain of dependent loads that needs neither neighbours nor cohesion) in
+ * the shadow of the cohesion term, and the step only joins the results.  Same values, same order: identical results. */
+#define NAVHIP_PREFETCH_FIELDS_READY 0x4u
 int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world, void *stream, uint32_t flags);
 /* Scheduling hint for a caller that runs other wide work (the field builds of the NEXT tick, say)
  * beside the agent step: make `stream` wait until the given stage of the step in flight is done, so
@@ -582,6 +588,8 @@ typedef struct navhip_tick navhip_tick;
                                      chain of short dependent launches: every cross-stream edge costs a barrier packet
                                      (10-20 us once the host runs ahead of the device) and buys no overlap there --
                                      configs[0] 0.27 -> ... ms per tick (profiles/r05_host_overhead_*.txt)              */
+#define NAVHIP_TICK_FUSED_MID 0x4u /* keep the per-agent chain in ONE launch behind the join (the schedule of rounds 2-4;
+                                     default: its sampling half runs on the front, NAVHIP_PREFETCH_FIELDS_READY)        */
 typedef struct navhip_tick_desc {
     navhip_world world;             /* DEVICE arrays of the snapshot (buffer set 0: pos_xz, vel_xz, field_pool);
                                        work_begin/work_end = this rank's uid slab                                      */

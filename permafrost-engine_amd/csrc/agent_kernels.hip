@@ -1088,6 +1088,46 @@ void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
         worklist_push(WL, w, live && writer && disp == DISP_ROW0 + w, uid);
 }
 
+// The same chain as two launches (mid_thread_a / _b): half A -- flow sampling, line of sight, arrive force, tile probes:
+// the chain of dependent loads -- needs neither the neighbour walk nor the cohesion term and runs on the FRONT of the
+// step, behind k_agent_nbr, in the shadow of k_cohesion (navhip_agent_prefetch_dev_ex with
+// NAVHIP_PREFETCH_FIELDS_READY); half B follows the join: forces -> vpref -> work lists.  33 us of the tick's critical
+// path become ~10.  The record of every entity of the work range travels through `mid` (32 B written + read).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_agent_mid_a(nh_step_params P, nh_mid_rec *mid, float scaled_max_force)
+{
+    const int uid = P.work_begin + (int)(blockIdx.x * 64 + threadIdx.x);
+    if(uid >= P.work_end) return;
+    nh_mid_rec R;
+    mid_thread_a(P, uid, scaled_max_force, R);
+    mid[uid] = R;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_agent_mid_b(nh_step_params P, nh_nbr NB, const float *coh_xz, nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
+                   float scaled_max_force, double force_thresh)
+{
+    const int uid = P.work_begin + (int)(blockIdx.x * 64 + threadIdx.x);
+    const bool live = uid < P.work_end;
+    int disp = DISP_DONE;
+    if(live) {
+        nh_mid_rec R = mid[uid];
+        v2 out_vel;
+        disp = mid_thread_b(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R, out_vel);
+        if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
+        if(O.vpref_xz) { O.vpref_xz[2 * uid] = R.vpref[0]; O.vpref_xz[2 * uid + 1] = R.vpref[1]; }
+        if(disp == DISP_DONE) {
+            post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid],
+                        P.radius[uid], out_vel, R.vel_cap, R.status, O);
+        }else{
+            mid[uid] = R;
+        }
+    }
+#pragma unroll
+    for(int w = 0; w <= NH_WL_FULL; w++)
+        worklist_push(WL, w, live && disp == DISP_ROW0 + w, uid);
+}
+
 // ---------------------------------------------------------------------------------------------
 // ClearPath for every listed agent: two launches by problem size (the per-agent cost spans three
 // orders of magnitude; one kernel for all needed the registers of the largest and the LDS of each),
@@ -1953,9 +1993,17 @@ int nh_worklist_cap(int n_work)
 // a launch sequence uses one and zeroes the other for its successor (no memset on the stream).
 // Returns whether anything was launched (the caller flips the parity only then: a step that launches nothing
 // does not clear the other set either).
+void nh_launch_agent_mid_a(const nh_step_params &P, nh_mid_rec *d_mid, hipStream_t s)
+{
+    const int nwork = P.work_end - P.work_begin;
+    if(!(P.n_ents > 0 && nwork > 0)) return;
+    const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
+    hipLaunchKernelGGL(k_agent_mid_a, dim3((nwork + 63) / 64), dim3(64), 0, s, P, d_mid, smf);
+}
+
 bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
-                            hipStream_t side, hipStream_t side2, hipEvent_t ev[3])
+                            hipStream_t side, hipStream_t side2, hipEvent_t ev[3], bool mid_a_done)
 {
     const int nwork = P.work_end - P.work_begin;
     if(!(P.n_ents > 0 && nwork > 0)) return false;
@@ -1964,8 +2012,11 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
     int32_t *zero_next = WL.count + (parity ^ 1) * NH_WL_COUNTERS;
     WL.count += parity * NH_WL_COUNTERS;
-    hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
-                       d_mid, WL, O, smf, thresh);
+    if(mid_a_done && MID_LANES == 1)
+        hipLaunchKernelGGL(k_agent_mid_b, dim3((nwork + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh, d_mid, WL, O, smf, thresh);
+    else
+        hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
+                           d_mid, WL, O, smf, thresh);
     // the ClearPath launches.  s: the rows of 5-16 neighbours, the irregular agents.  side: the agents with 1-4
     // neighbours (most of them, outside a crowd), whatever of them needs the retry logic, then the workgroup problems
     // (17-64 neighbours).  Every wave / workgroup keeps drawing units until none are left.

@@ -218,27 +218,28 @@ NH_FN v2 vpref_from_forces(const nh_step_params &P, int uid, int mode, v2 me, v2
 // ---------------------------------------------------------------------------------------------
 // the per-agent scalar chain: desired direction, arrive force, probes, ladder -> vpref
 // ---------------------------------------------------------------------------------------------
-NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
-                     float scaled_max_force, double force_thresh, nh_mid_rec &R, v2 &out_vel)
+// The chain in two halves.  Half A is everything that reads the snapshot, the flow / LOS fields and the map only -- the
+// desired direction (a chain of dependent loads), the arrive force, the tile probes --: nothing of the neighbour walk
+// or the cohesion term, so it can run in the shadow of k_cohesion behind the neighbour walk.  Half B joins the three:
+// forces -> vpref -> which ClearPath list.  mid_thread = A then B on one thread (the fused kernel, the wave-per-agent
+// path and the host-side unit tests); k_agent_mid_a / _b run them as two launches with the record in between.
+// R.mode == AM_IDLE after half A: a still / combat-held entity (nothing more to do).
+NH_FN void mid_thread_a(const nh_step_params &P, int uid, float scaled_max_force, nh_mid_rec &R)
 {
     const int state = P.state[uid];
     const uint32_t my_flags = P.flags[uid];
-    out_vel = mkv(0.0f, 0.0f);
     R.vpref[0] = R.vpref[1] = R.vdes[0] = R.vdes[1] = R.arrive[0] = R.arrive[1] = 0.0f;
     R.probes = 0; R.status = 0; R.mode = AM_IDLE;
     R.vel_cap = P.max_speed[uid] / (float)P.hz;
     if(state_is_still(state) || (my_flags & NAVHIP_ENTITY_FLAG_COMBAT_HELD))
-        return DISP_DONE;
+        return;
 
     const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
     const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
     const float my_radius = P.radius[uid], max_speed = P.max_speed[uid];
     const int flock = P.flock[uid], hz = P.hz;
     const int layer = nav_layer_for(my_flags, my_radius);
-    // (everything that only needs the snapshot is requested here, in front of the dependent chain of the
-    // flow sampling: the neighbour walk's results and the tile probes)
-    const uint32_t cnt = NB.cnt[uid];
-    const float2 s2 = NB.sep[uid];
+    // (the tile probes are requested here, in front of the dependent chain of the flow sampling)
     const uint32_t probes_here = P.map.layers[layer].cost ? probe_tiles_bits(P, layer, me) : 0u;
     uint32_t status = 0;
     v2 vdes = mkv(0.0f, 0.0f), arrive = mkv(0.0f, 0.0f);
@@ -294,19 +295,28 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
     R.vdes[0] = vdes.x; R.vdes[1] = vdes.z;
     R.status = (uint8_t)status;
     if(mode == AM_UNSUPPORTED)
+        return;
+    R.arrive[0] = arrive.x; R.arrive[1] = arrive.z;
+    R.probes = (uint16_t)((mode >= AM_POINT_SEEK && mode <= AM_FORM_POINT) ? probes_here : 0u);
+}
+
+NH_FN int mid_thread_b(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
+                       float scaled_max_force, double force_thresh, nh_mid_rec &R, v2 &out_vel)
+{
+    out_vel = mkv(0.0f, 0.0f);
+    const int mode = R.mode;
+    if(mode == AM_IDLE || mode == AM_UNSUPPORTED)
         return DISP_DONE;
-    const uint32_t probes = (mode >= AM_POINT_SEEK && mode <= AM_FORM_POINT) ? probes_here : 0u;
-
-    if((cnt >> 16) & NH_NB_IRREGULAR) {
-        R.arrive[0] = arrive.x; R.arrive[1] = arrive.z;
-        R.probes = (uint16_t)probes;
-        return DISP_FULL;
-    }
-
+    const uint32_t cnt = NB.cnt[uid];
+    if((cnt >> 16) & NH_NB_IRREGULAR)
+        return DISP_FULL;                                  // (arrive and probes are in the record)
+    const float2 s2 = NB.sep[uid];
     v2 vpref = mkv(0.0f, 0.0f);
     if(mode != AM_ZERO_VPREF) {
-        vpref = vpref_from_forces(P, uid, mode, me, vel, flock, arrive, mkv(s2.x, s2.y), probes, coh_xz,
-                                  scaled_max_force, force_thresh);
+        const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+        const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+        vpref = vpref_from_forces(P, uid, mode, me, vel, P.flock[uid], mkv(R.arrive[0], R.arrive[1]), mkv(s2.x, s2.y),
+                                  (uint32_t)R.probes, coh_xz, scaled_max_force, force_thresh);
     }
     R.vpref[0] = vpref.x; R.vpref[1] = vpref.z;
 
@@ -316,5 +326,12 @@ NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const f
         return DISP_DONE;
     }
     return n <= 2 ? DISP_ROW0 : n <= 4 ? DISP_ROW1 : n <= 8 ? DISP_ROW2 : n <= NH_ROW_MAX ? DISP_ROW3 : n <= 32 ? DISP_WAVE : DISP_HEAVY;
+}
+
+NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
+                     float scaled_max_force, double force_thresh, nh_mid_rec &R, v2 &out_vel)
+{
+    mid_thread_a(P, uid, scaled_max_force, R);
+    return mid_thread_b(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R, out_vel);
 }
 

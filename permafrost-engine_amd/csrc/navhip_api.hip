@@ -979,10 +979,20 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     if(rc) return rc;
     if(fork_late) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
     nh_launch_agent_nbr(P, NB, front);
+    ctx->pre.mid_a = false;
+    ctx->join0_recorded = false;
+    if(flags & NAVHIP_PREFETCH_FIELDS_READY) {
+        // half A of the per-agent chain on the front, behind the neighbour walk, beside the cohesion term.  On an inline
+        // front the "neighbours done" event (NAVHIP_STAGE_NEIGHBOURS: where the next tick's field builds start) is
+        // recorded in front of it -- the front is no longer the critical path of the tick, the cohesion term is
+        if(front == s) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front)); ctx->join0_recorded = true; }
+        nh_launch_agent_mid_a(P, (nh_mid_rec*)ctx->midrec.p, front);
+        ctx->pre.mid_a = true;
+        memcpy(&ctx->pre.world, w, sizeof(navhip_world));
+    }
     // (an inline front is ordered on the caller's stream by itself: its "done" event is only recorded
     // when somebody asks for it -- every event on that stream is a packet on the tick's critical path)
-    ctx->join0_recorded = front != s;
-    if(front != s) HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front));
+    if(front != s) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front)); ctx->join0_recorded = true; }
     ctx->front_stream = front;
     ctx->snapshot_held = (flags & NAVHIP_PREFETCH_SNAPSHOT_HELD) != 0;
     // side stream 1: cohesion
@@ -1070,8 +1080,15 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         }
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
+        // (half A ran with the prefetch -- for this very world, byte for byte -- or runs here, fused with half B)
+        const bool mid_a_done = ctx->pre.mid_a && memcmp(&ctx->pre.world, w, sizeof(navhip_world)) == 0;
+        if(ctx->pre.mid_a && !mid_a_done && ctx->front_stream != s) {
+            // (half A of another world wrote the records on the front stream: order this step's fused kernel behind it)
+            if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
+        }
         if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                                  ctx->aux[0], ctx->aux[1], ctx->ev_cp)) {
+                                  ctx->aux[0], ctx->aux[1], ctx->ev_cp, mid_a_done)) {
             rc = send_step_lists(ctx, ctx->wl_parity, s);
             ctx->wl_parity ^= 1;
             if(rc) return rc;

@@ -84,7 +84,9 @@ struct navhip_ctx {
     struct { bool valid; const float *pos_xz, *vel_xz, *radius, *arrival_sink_xz; const uint32_t *flags;
              const uint8_t *state, *arrival_flags; const int32_t *flock_members, *flock_offsets;
              int n_ents, n_flocks, hz, work_begin, work_end;
-             struct nh_grid_store { int32_t origin_x, origin_y; int grid_w, grid_h; } g; } pre;
+             struct nh_grid_store { int32_t origin_x, origin_y; int grid_w, grid_h; } g;
+             bool mid_a; navhip_world world; } pre;     // mid_a: half A of the per-agent chain ran with the prefetch, for
+                                                         // exactly this world (NAVHIP_PREFETCH_FIELDS_READY)
     // optional per-kernel-group timing of the agent step (navhip_set_profiling)
     bool         profiling;
     hipEvent_t   ev[6];        // start | hash built | neighbour walk | cohesion | regroup | finish

@@ -369,7 +369,7 @@ def test_prefetch_overlap_gives_identical_results(navlib):
     from permafrost_engine_amd import tick
     res = []
     for overlap in (False, True):
-        T = tick.NavTick(chunk_w=4, fields_per_rank=6, agents_per_rank=5000, device=0)
+        T = tick.NavTick(chunk_w=4, fields_per_rank=6, agents_per_rank=5000, device=0, driver="python")
         T.overlap = overlap
         for _ in range(6):
             T.step()
@@ -408,7 +408,7 @@ def test_pipelined_field_builds_give_identical_results(navlib):
     from permafrost_engine_amd import tick
     res = []
     for pipe in (False, True):
-        T = tick.NavTick(chunk_w=4, fields_per_rank=6, agents_per_rank=5000, device=0, pipeline_fields=pipe)
+        T = tick.NavTick(chunk_w=4, fields_per_rank=6, agents_per_rank=5000, device=0, pipeline_fields=pipe, driver="python")
         for _ in range(9):
             T.step()
         T.sync()
