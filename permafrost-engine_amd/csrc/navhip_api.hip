@@ -899,7 +899,10 @@ static int ensure_side_streams(navhip_ctx *ctx)
     HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     // (the cohesion term has slack -- it runs beside the whole front of the step --: low priority)
     HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[0], hipStreamNonBlocking, prio_hi));
-    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[1], hipStreamNonBlocking, prio_lo));
+    // (NAVHIP_COH_PRIO=hi: a developer knob -- since the neighbour walk became one-wave workgroups the cohesion kernel
+    // ends last; measured in profiles/r05_ab_coh_prio.txt)
+    const char *cp = getenv("NAVHIP_COH_PRIO");
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[1], hipStreamNonBlocking, (cp && cp[0] == 'h') ? prio_hi : prio_lo));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for(auto &e : ctx->ev_cp) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
