@@ -588,8 +588,11 @@ typedef struct navhip_tick navhip_tick;
                                      chain of short dependent launches: every cross-stream edge costs a barrier packet
                                      (10-20 us once the host runs ahead of the device) and buys no overlap there --
                                      configs[0] 0.27 -> ... ms per tick (profiles/r05_host_overhead_*.txt)              */
-#define NAVHIP_TICK_FUSED_MID 0x4u /* keep the per-agent chain in ONE launch behind the join (the schedule of rounds 2-4;
-                                     default: its sampling half runs on the front, NAVHIP_PREFETCH_FIELDS_READY)        */
+#define NAVHIP_TICK_SPLIT_MID 0x4u /* run the sampling half of the per-agent chain on the front of the step
+                                     (NAVHIP_PREFETCH_FIELDS_READY) instead of one launch behind the join.  Measured
+                                     (profiles/r05_ab_split_mid_*.txt): k_agent_mid 31.4 us -> half A 15.0 us in the cohesion
+                                     term's shadow + half B 23.3 us behind the join -- both halves are chains of dependent
+                                     loads --, the tick 0.340 against 0.337 ms: off by default                          */
 typedef struct navhip_tick_desc {
     navhip_world world;             /* DEVICE arrays of the snapshot (buffer set 0: pos_xz, vel_xz, field_pool);
                                        work_begin/work_end = this rank's uid slab                                      */

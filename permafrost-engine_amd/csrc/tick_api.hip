@@ -292,7 +292,7 @@ int navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tic
     T->ctx = ctx; T->d = *desc;
     T->serial = (desc->flags & NAVHIP_TICK_SERIAL) != 0;
     T->ahead = desc->field_pool_1 != nullptr && !T->serial;
-    T->split_mid = !(desc->flags & NAVHIP_TICK_FUSED_MID);
+    T->split_mid = (desc->flags & NAVHIP_TICK_SPLIT_MID) != 0;
     T->pipelined = desc->bounds != nullptr;
     if(T->pipelined) {
         const int world = navhip_comm_world(ctx);
