@@ -583,8 +583,7 @@ def main():
         sustained = {"ticks": 100, "warmup": 5,
                      "ms_per_step": sdt / 100 * 1e3, "ms_per_step_median": float(np.median(sticks)),
                      "agent_steps_per_s": Ts.N * 100 / sdt, "ms_tick_5_50_100": [s_at(5), s_at(50), s_at(100)],
-                     "kernel_groups_ms_serial": sgroups, "status": status_histogram(Ts),
-                     "roofline": None}
+                     "cp_wave_17-64_nbrs": status_histogram(Ts)["cp_wave_17-64_nbrs"], "roofline": None}
         sr = roof("agents", sgroups, "ticks %d-%d" % (s_first + 1, Ts.tick_no))
         sustained["roofline"] = {k: sr[k] for k in ("achieved", "frac", "avg_launch_ms", "kernels_ms")}
         Ts.close()
@@ -616,7 +615,8 @@ def main():
         cdt, cticks = run_ticks(Tc, pdist, torch, 3, 40)
         chist = status_histogram(Tc)
         crowded = {"ticks": 40, "warmup": 3, "agent_steps_per_s": Tc.N * 40 / cdt, "ms_per_step": cdt / 40 * 1e3,
-                   "ms_per_step_median": float(np.median(cticks)), "status": chist}
+                   "ms_per_step_median": float(np.median(cticks)), "cp_wave_17-64_nbrs": chist["cp_wave_17-64_nbrs"],
+                   "cp_retries": chist["cp_retries"]}
         Tc.close()
 
     cpu = None
@@ -673,7 +673,8 @@ def main():
                                    if k in ("achieved", "frac", "traffic", "kernel", "avg_launch_ms",
                                             "algorithmic_bytes_per_launch", "valu_issue")},
             "csrc_sha": sha,
-            "kernel_groups_ms_serial": {"after_warmup": early, "after_timed_region": groups},
+            "kernel_groups_ms_serial": {"after_warmup": early, "after_timed_region": groups} if args.steps >= 100 else
+                                       {"after_timed_region": groups},
             "phase_ms_overlapped": phases,
             "status": hist,
             "flow_sampling_cpu": sampling,

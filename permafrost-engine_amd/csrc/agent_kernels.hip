@@ -719,6 +719,9 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
 #ifndef COH_FPOS
 #define COH_FPOS 0
 #endif
+#ifndef COH_PREFETCH
+#define COH_PREFETCH 0
+#endif
 __global__ __launch_bounds__(256) void k_coh_gather(nh_step_params P, float2 *fpos)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -798,17 +801,36 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     float comx = 0.0f, comz = 0.0f;
     int self_k = -1;                                      // queue entry of this quad's own member
     int pend = 0;                                         // entries carried over from the last tile
+#if COH_FPOS && COH_PREFETCH
+    // software pipeline: the positions of tile k + 1 are requested before tile k is worked on (the waves of this kernel
+    // spend 43 % of their cycles waiting for a counter -- SQ_WAIT_INST_ANY, profiles/r03_cp_counters_a.json --, most of
+    // it for the staging loads of a tile whose members the box test then drops)
+    float2 nxt[4];
+#pragma unroll
+    for(int q = 0; q < 4; q++) { const int j = b + q * 64 + t; nxt[q] = j < e ? fpos[j] : make_float2(0.0f, 0.0f); }
+#endif
     for(int jb = b; jb < e; jb += 256) {
         // ---- stage the tile behind the carry-over [0, pend)
         int ncnt = pend;
         const int gl = act ? g - jb : -1;                 // own slot in the unfiltered tile, if any
+#if COH_FPOS && COH_PREFETCH
+        float2 cur[4];
+#pragma unroll
+        for(int q = 0; q < 4; q++) cur[q] = nxt[q];
+        if(jb + 256 < e) {
+#pragma unroll
+            for(int q = 0; q < 4; q++) { const int j = jb + 256 + q * 64 + t; nxt[q] = j < e ? fpos[j] : make_float2(0.0f, 0.0f); }
+        }
+#endif
 #pragma unroll
         for(int q = 0; q < 4; q++) {
             const int j = jb + q * 64 + t;
             bool keep = false;
             float2 c2 = make_float2(0.0f, 0.0f);
             if(j < e) {
-#if COH_FPOS
+#if COH_FPOS && COH_PREFETCH
+                c2 = cur[q];
+#elif COH_FPOS
                 c2 = fpos[j];
 #else
                 const int m = P.flock_members[j];
