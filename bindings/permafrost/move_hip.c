@@ -612,7 +612,8 @@ void move_hip_settle_stats(long out[4]) { memcpy(out, s_hip_settle_stats, sizeof
 
 struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned;
                         uint8_t *fstate, *wait_prev; int32_t *wait_ticks; float *ent_rot, *target_dir;
-                        float *interp_from, *interp_step; int any_turning; };
+                        float *interp_from, *interp_step; int any_turning;
+                        int32_t *range_items, *surround_items; int n_range, n_surround; };   /* work items of the two arms with per-unit host queries */
 
 static void hip_state_items_range(int begin, int end, void *arg)
 {
@@ -640,6 +641,8 @@ static void hip_state_items_range(int begin, int end, void *arg)
                      | (in->fstate.assigned_to_cell ? NAVHIP_FS_ASSIGNED : 0) | (in->fstate.in_range_of_cell ? NAVHIP_FS_IN_RANGE : 0)
                      | (in->fstate.arrived_at_cell ? NAVHIP_FS_ARRIVED : 0));
         T->wait_ticks[i] = ms->wait_ticks_left; T->wait_prev[i] = (uint8_t)ms->wait_prev;
+        if(ms->state == STATE_ENTER_ENTITY_RANGE) T->range_items[__atomic_fetch_add(&T->n_range, 1, __ATOMIC_RELAXED)] = w;
+        if(ms->state == STATE_SURROUND_ENTITY)    T->surround_items[__atomic_fetch_add(&T->n_surround, 1, __ATOMIC_RELAXED)] = w;
         if(ms->state == STATE_TURNING) {                      /* :2606-2628: the end of the turn is the device's to see */
             __atomic_store_n(&T->any_turning, 1, __ATOMIC_RELAXED);
             const quat_t rot = Entity_GetRot(in->ent_uid);
@@ -801,8 +804,10 @@ static void hip_surround_range(int begin, int end, void *arg)
             continue;
         }
         khiter_t it = kh_get(id, S->dense, ms->surround_target_uid);
-        if(it == kh_end(S->dense))
+        if(it == kh_end(S->dense)) {
+            Q->s_target[i] = -2;
             continue;                                                     /* (a target outside the snapshot: the host's) */
+        }
         Q->s_target[i] = (int32_t)kh_value(S->dense, it);
         const vec2_t tp = {S->pos[2 * Q->s_target[i]], S->pos[2 * Q->s_target[i] + 1]};
         vec2_t delta, dest;
@@ -914,9 +919,13 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     if(sub20) { memset(interp_from, 0, sizeof(float) * (2 * n + 2)); memset(interp_step, 0, sizeof(float) * (n + 1)); }
     hip_work_dense_prepare();
     struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned, fstate, wait_prev, wait_ticks, ent_rot, target_dir,
-                               interp_from, interp_step, 0};
+                               interp_from, interp_step, 0,
+                               hip_arena(sizeof(int32_t) * (end_idx - begin_idx + 2)), hip_arena(sizeof(int32_t) * (end_idx - begin_idx + 2)), 0, 0};
     hip_for(hip_state_items_range, end_idx - begin_idx + 1, &T);
     const bool any_turning = T.any_turning != 0;
+    /* (the fill's threads append in any order: work-item order again, so that a pass is reproducible) */
+    qsort(T.range_items, T.n_range, sizeof(int32_t), cmp_i32);
+    qsort(T.surround_items, T.n_surround, sizeof(int32_t), cmp_i32);
     int lo = n, hi = -1;
     for(int w = begin_idx; w <= end_idx; w++) {
         const int i = s_hip_witem.idx[w];
@@ -987,9 +996,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         /* STATE_ENTER_ENTITY_RANGE (:2569-2604): the target's row in the snapshot, the range, where the target stood when
          * the path was requested, and -- per such unit -- the closest island tiles of the target's position on the unit's
          * layer (the first half of N_IsMaximallyClose, as for the flocks' destinations above) */
-        int n_range = 0;
-        for(int w = begin_idx; w <= end_idx; w++)
-            n_range += S.state[s_hip_witem.idx[w]] == STATE_ENTER_ENTITY_RANGE;
+        const int n_range = T.n_range;
         if(n_range > 0) {
             /* (per-unit arrays from the arena, not cleared: the device reads the rows of ENTER_ENTITY_RANGE units only --
              * but the library checks every row's target index, hence the fill with "the host's") */
@@ -997,13 +1004,11 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
             r_off = calloc(n_range + 1, sizeof(int32_t));
             r_range = hip_arena(sizeof(float) * (n + 1)); r_prev = hip_arena(sizeof(float) * (2 * n + 2));
             r_tiles = malloc(sizeof(int16_t) * 2 * per * n_range);
-            for(int i = 0; i < n; i++) r_target[i] = -2;
+            memset(r_target, 0xfe, sizeof(int32_t) * n);            /* (any value below -1 = "the host's") */
             memset(r_row, 0, sizeof(int32_t) * n);
             int row = 0;
-            for(int w = begin_idx; w <= end_idx; w++) {
-                const int i = s_hip_witem.idx[w];
-                if(S.state[i] != STATE_ENTER_ENTITY_RANGE)
-                    continue;
+            for(int k = 0; k < n_range; k++) {
+                const int w = T.range_items[k], i = s_hip_witem.idx[w];
                 const struct movestate *ms = movestate_get(S.uids[i]);
                 r_off[row + 1] = r_off[row];
                 r_row[i] = row;
@@ -1042,22 +1047,15 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
      * reach the query (:2532-2534), the closest reachable position next to the target from both positions the tick can
      * test: pos + new velocity, and pos (the heading gate halts the unit) */
     int32_t *s_target = NULL; uint8_t *s_query = NULL; float *s_tprev = NULL, *s_nprev = NULL, *s_dest = NULL, *s_out = NULL;
-    int n_surround = 0;
-    for(int w = begin_idx; !sub20 && w <= end_idx; w++)
-        n_surround += S.state[s_hip_witem.idx[w]] == STATE_SURROUND_ENTITY;
+    const int n_surround = sub20 ? 0 : T.n_surround;
     if(n_surround > 0) {
         /* (from the arena; the device reads and writes the rows of SURROUND_ENTITY units only) */
         s_target = hip_arena(sizeof(int32_t) * (n + 1)); s_query = hip_arena(n + 1); s_tprev = hip_arena(sizeof(float) * (2 * n + 2));
         s_nprev = hip_arena(sizeof(float) * (2 * n + 2)); s_dest = hip_arena(sizeof(float) * (4 * n + 4)); s_out = hip_arena(sizeof(float) * (2 * n + 2));
-        for(int i = 0; i < n; i++) s_target[i] = -2;
+        memset(s_target, 0xfe, sizeof(int32_t) * n);              /* (any value below -1 = "the host's") */
         memset(s_query, 0, n + 1); memset(s_out, 0, sizeof(float) * (2 * n + 2));
-        int32_t *s_items = malloc(sizeof(int32_t) * n_surround);
-        int ns = 0;
-        for(int w = begin_idx; w <= end_idx; w++)
-            if(S.state[s_hip_witem.idx[w]] == STATE_SURROUND_ENTITY) s_items[ns++] = w;
-        struct hip_surround_q Q = {&S, s_items, s_target, s_query, s_tprev, s_nprev, s_dest};
-        hip_for_min(hip_surround_range, ns, &Q, 16);
-        free(s_items);
+        struct hip_surround_q Q = {&S, T.surround_items, s_target, s_query, s_tprev, s_nprev, s_dest};
+        hip_for_min(hip_surround_range, n_surround, &Q, 16);
         pin.aux.surround_target = s_target; pin.aux.surround_query = s_query; pin.aux.surround_target_prev_xz = s_tprev;
         pin.aux.surround_nearest_prev_xz = s_nprev; pin.aux.surround_dest_xz = s_dest; pin.aux.out_surround_dest_xz = s_out;
     }

@@ -757,7 +757,8 @@ typedef struct navhip_state_aux_in {
      * moved more than 5 units from target_prev_pos, NAVHIP_SU_SET_DEST.  The target's position is world->pos_xz of its
      * row.  Needs the BLOCKERS plane of the units' layers. */
     const int32_t  *range_target;     /* [n] row of movestate.surround_target_uid in the world's arrays; -1 = NULL_UID;
-                                             -2 = leave the unit to the host (a target outside the snapshot)              */
+                                             -2 (any value below -1) = leave the unit to the host (a target outside
+                                             the snapshot)                                                               */
     const float    *target_range;     /* [n] movestate.target_range                                                      */
     const float    *target_prev_xz;   /* [n][2] movestate.target_prev_pos                                                */
     const int32_t  *range_tiles_row;  /* [n] row of range_tiles_off for the unit: the closest island tiles of ITS target's
@@ -777,7 +778,7 @@ typedef struct navhip_state_aux_in {
      * position in out_surround_dest_xz; no guidance -> WAITING; and reports NAVHIP_SU_SURROUND_PREV where the reference
      * stores surround_target_prev = the target's position, surround_nearest_prev = out_surround_dest_xz[i] (:2551-2552).
      * world: pos_xz, vel_xz (movestate.velocity), flock, flock_target_xz too. */
-    const int32_t  *surround_target;  /* [n] row of movestate.surround_target_uid; -1 = NULL_UID; -2 = leave to the host */
+    const int32_t  *surround_target;  /* [n] row of movestate.surround_target_uid; -1 = NULL_UID; below -1 = leave to the host */
     const uint8_t  *surround_query;   /* [n] NAVHIP_SQ_*                                                                 */
     const float    *surround_target_prev_xz;   /* [n][2] movestate.surround_target_prev                                  */
     const float    *surround_nearest_prev_xz;  /* [n][2] movestate.surround_nearest_prev                                 */

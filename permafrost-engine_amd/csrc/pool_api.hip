@@ -168,6 +168,11 @@ static int pool_flush_map(navhip_ctx *ctx, nh_pool *P, hipStream_t s)
     return NAVHIP_OK;
 }
 
+// (see nh_is_pinned below)
+static struct { const void *p; bool pinned; } s_pin_cache[32];
+static int s_pin_next;
+static void pin_forget(const void *p) { for(auto &e : s_pin_cache) if(e.p == p) e.p = nullptr; }
+
 extern "C" {
 
 int navhip_pool_create(navhip_ctx *ctx, int n_slots, int n_dests)
@@ -429,7 +434,7 @@ void *navhip_host_alloc(size_t bytes)
 
 void navhip_host_free(void *p)
 {
-    if(p) hipHostFree(p);
+    if(p) { pin_forget(p); hipHostFree(p); }
 }
 
 }  // extern "C"
@@ -691,7 +696,19 @@ int nh_async_slabs(navhip_ctx *ctx, size_t in_bytes, size_t out_bytes, char **h_
     return NAVHIP_OK;
 }
 
-bool nh_is_pinned(const void *p) { return is_pinned(p); }
+// hipPointerGetAttributes costs microseconds; a host passes the same page-locked arrays every tick: the answers for the
+// last few pointers are remembered (an array freed and reallocated pageable at the same address would be stale -- the
+// entry is dropped when a transfer from it fails; navhip_host_free forgets its pointer)
+bool nh_is_pinned(const void *p)
+{
+    if(!p) return false;
+    for(auto &e : s_pin_cache) if(e.p == p) return e.pinned;
+    const bool r = is_pinned(p);
+    s_pin_cache[s_pin_next] = {p, r};
+    s_pin_next = (s_pin_next + 1) % 32;
+    return r;
+}
+
 
 void nh_async_destroy(navhip_ctx *ctx)
 {

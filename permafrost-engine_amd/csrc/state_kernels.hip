@@ -609,7 +609,7 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
     const bool su = in->surround_target != nullptr;
     if(su) {
         for(size_t i = (size_t)b; i < (size_t)e; i++) {
-            if(in->surround_target[i] < -2 || in->surround_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
+            if(in->surround_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
             if(w->state[i] == NAVHIP_STATE_SURROUND_ENTITY && in->surround_target[i] >= -1 && w->flock[i] >= w->n_flocks) return NAVHIP_ERR_INVALID;
         }
     }
@@ -620,7 +620,7 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
             if(in->range_tiles_off[r] < 0 || in->range_tiles_off[r + 1] < in->range_tiles_off[r]) return NAVHIP_ERR_INVALID;
         n_rt = rows ? (size_t)in->range_tiles_off[rows] : 0;
         for(size_t i = (size_t)b; i < (size_t)e; i++) {
-            if(in->range_target[i] < -2 || in->range_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
+            if(in->range_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
             if(in->range_target[i] >= 0 && w->state[i] == NAVHIP_STATE_ENTER_ENTITY_RANGE
             && (in->range_tiles_row[i] < 0 || in->range_tiles_row[i] >= rows)) return NAVHIP_ERR_INVALID;
         }
@@ -737,7 +737,7 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
     if(su) {
         for(size_t i = (size_t)b; i < (size_t)e; i++) {
-            if(X.surround_target[i] < -2 || X.surround_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
+            if(X.surround_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
             if(w->state[i] == NAVHIP_STATE_SURROUND_ENTITY && X.surround_target[i] >= -1 && w->flock[i] >= w->n_flocks) return NAVHIP_ERR_INVALID;
         }
     }
@@ -754,7 +754,7 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
             if(X.range_tiles_off[r] < 0 || X.range_tiles_off[r + 1] < X.range_tiles_off[r]) return NAVHIP_ERR_INVALID;
         n_rt = rows ? (size_t)X.range_tiles_off[rows] : 0;
         for(size_t i = (size_t)b; i < (size_t)e; i++) {
-            if(X.range_target[i] < -2 || X.range_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
+            if(X.range_target[i] >= w->n_ents) return NAVHIP_ERR_INVALID;
             if(X.range_target[i] >= 0 && w->state[i] == NAVHIP_STATE_ENTER_ENTITY_RANGE
             && (X.range_tiles_row[i] < 0 || (size_t)X.range_tiles_row[i] >= rows)) return NAVHIP_ERR_INVALID;
         }
@@ -890,12 +890,12 @@ int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, 
             if(X.range_tiles_off[r] < 0 || X.range_tiles_off[r + 1] < X.range_tiles_off[r]) return NAVHIP_ERR_INVALID;
         n_rt = rows ? (size_t)X.range_tiles_off[rows] : 0;
         for(size_t i = (size_t)b; i < (size_t)e; i++)
-            if(X.range_target[i] < -2 || X.range_target[i] >= d.n_ents
+            if(X.range_target[i] >= d.n_ents
             || (X.range_target[i] >= 0 && (X.range_tiles_row[i] < 0 || (size_t)X.range_tiles_row[i] >= (rows ? rows : 1)))) return NAVHIP_ERR_INVALID;
     }
     if(su)
         for(size_t i = (size_t)b; i < (size_t)e; i++)
-            if(X.surround_target[i] < -2 || X.surround_target[i] >= d.n_ents) return NAVHIP_ERR_INVALID;
+            if(X.surround_target[i] >= d.n_ents) return NAVHIP_ERR_INVALID;
     SKCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     // ---- inputs: one device slab; pageable arrays are packed into the pinned slab and cross the bus as ONE transfer,

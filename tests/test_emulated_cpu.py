@@ -128,8 +128,8 @@ def test_two_rank_gloo_tick_on_the_emulated_library(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "scripts", "check_multirank.py"), "--small"] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("rank ")]
-    assert r.returncode == 0 and len(lines) == 2 and all("IDENTICAL to solo" in l for l in lines), r.stdout[-2000:]
+    # (the two ranks print at the same moment: their lines may share one)
+    assert r.returncode == 0 and r.stdout.count("IDENTICAL to solo") == 2 and "MISMATCH" not in r.stdout, r.stdout[-2000:]
 
 
 
