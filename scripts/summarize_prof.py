@@ -47,7 +47,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     sha = bench.csrc_sha()
-    pre = sys.argv[3] if len(sys.argv) > 3 else "r04_"
+    pre = sys.argv[3] if len(sys.argv) > 3 else "r05_"
 
     def copy(name, out):
         p = os.path.join(src, name)
