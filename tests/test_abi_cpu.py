@@ -301,3 +301,16 @@ def test_profile_stamps_cover_the_files_they_list(tmp_path):
     assert bench.csrc_sha(d, files) != sha
     os.remove(os.path.join(d, "agent_math.h"))
     assert bench.csrc_sha(d, files).startswith("missing:")
+
+
+def test_c_host_example_compiles_as_c99(tmp_path):
+    """examples/c_host_tick.c -- the plain C host of navhip_tick_run -- against include/navhip.h and the HIP runtime's C
+    API, as C99 with warnings as errors (not -pedantic: the HIP headers use unnamed unions; it RUNS in tests/test_c_host_gpu.py)."""
+    import shutil
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if shutil.which("gcc") is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("no gcc / HIP headers")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(rocm, "include"), "-c", os.path.join(ROOT, "examples", "c_host_tick.c"),
+                        "-o", str(tmp_path / "c_host_tick.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
