@@ -623,8 +623,10 @@ static void hip_state_items_range(int begin, int end, void *arg)
         const int w = T->begin_idx + k;
         const struct move_work_in *in = &s_move_work.in[w];
         const struct move_work_out *out = &s_move_work.out[w];
-        const struct movestate *ms = movestate_get(in->ent_uid);
         const int i = hip_work_dense(S, w);
+        /* (movestate_get through the bucket position the snapshot fill cached for this row: no probe sequence) */
+        const khiter_t mk = HIP_IT(s_entity_state_table, state, s_hip_set.it_state[i], in->ent_uid);
+        const struct movestate *ms = mk != kh_end(s_entity_state_table) ? &kh_value(s_entity_state_table, mk) : movestate_get(in->ent_uid);
         /* the inputs of the heading gate (:2319-2336), decided on the device for the slab at once */
         if(T->new_vel) {            /* (the resident pass reads the step's own outputs on the device) */
             T->new_vel[2 * i] = out->ent_vel.x; T->new_vel[2 * i + 1] = out->ent_vel.z;
@@ -751,7 +753,8 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
     navhip_settle_in in = {nz, nq, zones, slots, ring, keys, uid, zone, q_pos, nsettled, substate, sink_valid, sink, order,
                            anchor, anchored, stuck};
     navhip_settle_out out = {o_settle, o_substate, o_anchor_, o_anchored_, o_stuck_};
-    ok = ok && navhip_arrival_settle(ctx, W, &in, &out) == NAVHIP_OK;
+    ok = ok && ((s_hip_settle_resident && navhip_arrival_settle_resident(ctx, W, &in, &out) == NAVHIP_OK)
+                || navhip_arrival_settle(ctx, W, &in, &out) == NAVHIP_OK);
     for(q = 0; ok && q < nq; q++) {
         const int i = uid[q];
         if(nsettled[q] < 0)

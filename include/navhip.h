@@ -891,6 +891,10 @@ typedef struct navhip_settle_out {
 } navhip_settle_out;
 int  navhip_arrival_settle(navhip_ctx *ctx, const navhip_world *world, const navhip_settle_in *in,
                            const navhip_settle_out *out);
+/* The same with world->vel_xz / ->radius read from the snapshot the velocity half of the tick left on the device (see
+ * navhip_state_pass_resident; world: n_ents, map_pos).  NAVHIP_ERR_INVALID when no such step is resident. */
+int  navhip_arrival_settle_resident(navhip_ctx *ctx, const navhip_world *world, const navhip_settle_in *in,
+                                    const navhip_settle_out *out);
 /* Everything resident on the device (the zones' arrays and the per-unit arrays too), asynchronous on `stream`. */
 int  navhip_arrival_settle_dev(navhip_ctx *ctx, const navhip_world *dev_world, const navhip_settle_in *dev_in,
                                const navhip_settle_out *dev_out, void *stream);

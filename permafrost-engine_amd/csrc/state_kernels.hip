@@ -1087,11 +1087,29 @@ int navhip_arrival_settle_dev(navhip_ctx *ctx, const navhip_world *w, const navh
     return NAVHIP_OK;
 }
 
+static int sk_arrival_settle(navhip_ctx *ctx, const navhip_world *w, const navhip_settle_in *in, const navhip_settle_out *out, bool use_resident);
+
 int navhip_arrival_settle(navhip_ctx *ctx, const navhip_world *w, const navhip_settle_in *in, const navhip_settle_out *out)
+{
+    return sk_arrival_settle(ctx, w, in, out, false);
+}
+
+int navhip_arrival_settle_resident(navhip_ctx *ctx, const navhip_world *w, const navhip_settle_in *in, const navhip_settle_out *out)
+{
+    return sk_arrival_settle(ctx, w, in, out, true);
+}
+
+static int sk_arrival_settle(navhip_ctx *ctx, const navhip_world *w, const navhip_settle_in *in, const navhip_settle_out *out, bool use_resident)
 {
     if(!ctx || !w || !in || !out || in->nq < 0 || in->n_zones < 0 || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(in->nq == 0) return NAVHIP_OK;
-    if(!w->vel_xz || !w->radius || !in->zones || in->n_zones < 1 || !in->uid || !in->zone || !in->new_pos_xz
+    navhip_world rw; navhip_step_out rso;
+    const bool resident = use_resident && nh_async_resident(ctx, &rw, &rso) && rw.n_ents == w->n_ents && rw.vel_xz && rw.radius;
+    if(use_resident && !resident) {
+        ctx->last_error = "navhip_arrival_settle_resident: no completed host-buffer step of this size is resident on the device";
+        return NAVHIP_ERR_INVALID;
+    }
+    if((!resident && (!w->vel_xz || !w->radius)) || !in->zones || in->n_zones < 1 || !in->uid || !in->zone || !in->new_pos_xz
     || !in->nsettled || !in->substate || !in->sink_valid || !in->sink_xz || !in->order_pos_xz || !in->progress_anchor_xz
     || !in->progress_anchored || !in->stuck || !out->settle || !out->substate || !out->progress_anchor_xz
     || !out->progress_anchored || !out->stuck)
@@ -1111,7 +1129,7 @@ int navhip_arrival_settle(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     SKCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     sk_arena A;
-    const size_t o_vel = A.take(n * 8), o_rad = A.take(n * 4), o_z = A.take(nz * sizeof(navhip_arrival_zone)),
+    const size_t o_vel = A.take(resident ? 0 : n * 8), o_rad = A.take(resident ? 0 : n * 4), o_z = A.take(nz * sizeof(navhip_arrival_zone)),
                  o_sl = A.take(n_slots * 8 + 8), o_ring = A.take(n_slots * 4 + 4), o_keys = A.take(n_keys * 8 + 8),
                  o_uid = A.take(nq * 4), o_zone = A.take(nq * 4), o_np = A.take(nq * 8), o_ns = A.take(nq * 4),
                  o_sub = A.take(nq), o_sv = A.take(nq), o_sink = A.take(nq * 8), o_ord = A.take(nq * 8),
@@ -1121,14 +1139,16 @@ int navhip_arrival_settle(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
     if(rc) return rc;
 #define UP(off, src, bytes) if((bytes) > 0) SKCHK(ctx, hipMemcpyAsync(base + (off), (src), (bytes), hipMemcpyHostToDevice, s))
-    UP(o_vel, w->vel_xz, n * 8);   UP(o_rad, w->radius, n * 4);   UP(o_z, in->zones, nz * sizeof(navhip_arrival_zone));
+    if(!resident) { UP(o_vel, w->vel_xz, n * 8);   UP(o_rad, w->radius, n * 4); }
+    UP(o_z, in->zones, nz * sizeof(navhip_arrival_zone));
     UP(o_sl, in->slots_xz, n_slots * 8);   UP(o_ring, in->slot_ring, n_slots * 4);   UP(o_keys, in->region_keys, n_keys * 8);
     UP(o_uid, in->uid, nq * 4);   UP(o_zone, in->zone, nq * 4);   UP(o_np, in->new_pos_xz, nq * 8);   UP(o_ns, in->nsettled, nq * 4);
     UP(o_sub, in->substate, nq);   UP(o_sv, in->sink_valid, nq);   UP(o_sink, in->sink_xz, nq * 8);   UP(o_ord, in->order_pos_xz, nq * 8);
     UP(o_anc, in->progress_anchor_xz, nq * 8);   UP(o_and, in->progress_anchored, nq);   UP(o_stk, in->stuck, nq * 4);
 #undef UP
     navhip_world d = *w;
-    d.vel_xz = (const float*)(base + o_vel); d.radius = (const float*)(base + o_rad);
+    // (the snapshot the velocity half left on the device is read in place: movestate.velocity and the radii are the tick's)
+    d.vel_xz = resident ? rw.vel_xz : (const float*)(base + o_vel); d.radius = resident ? rw.radius : (const float*)(base + o_rad);
     navhip_settle_in di = *in;
     di.zones = (const navhip_arrival_zone*)(base + o_z); di.slots_xz = (const float*)(base + o_sl);
     di.slot_ring = (const int32_t*)(base + o_ring); di.region_keys = (const uint64_t*)(base + o_keys);

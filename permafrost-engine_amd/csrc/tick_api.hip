@@ -122,9 +122,10 @@ static int compute_plain(navhip_tick *T)
             HIPCHK(ctx, hipStreamWaitEvent(T->f, T->ev_tmp, 0));
         }
         if(!T->pipelined) {
-            // this tick's fields were built during the last one: with them final, the front of the step also runs the
-            // sampling half of the per-agent chain in the shadow of the cohesion term (NAVHIP_PREFETCH_FIELDS_READY)
-            HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));
+            // (NAVHIP_TICK_SPLIT_MID: this tick's fields were built during the last one -- with them final, the front of
+            // the step also runs the sampling half of the per-agent chain, NAVHIP_PREFETCH_FIELDS_READY; otherwise the
+            // front does not wait for them, only the step does, below)
+            if(T->split_mid) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));
             RCCHK(navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE | NAVHIP_PREFETCH_SNAPSHOT_HELD
                                                                      | (T->split_mid ? NAVHIP_PREFETCH_FIELDS_READY : 0u)));
         }
@@ -133,7 +134,8 @@ static int compute_plain(navhip_tick *T)
         else if(!T->pipelined)               RCCHK(navhip_stream_wait_stage(ctx, (void*)T->f, NAVHIP_STAGE_START));
         RCCHK(build_fields(T, T->pool[p ^ 1], T->f));
         HIPCHK(ctx, hipEventRecord(T->ev_fields[p ^ 1], T->f));
-        if(T->pipelined) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));   // this tick's fields (built during the last one)
+        if(T->pipelined || !T->split_mid)
+            HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));   // this tick's fields (built during the last one)
     }else{
         if(!T->pipelined) RCCHK(navhip_agent_prefetch_dev(ctx, w, (void*)T->s));
         if(T->d.dev_moves) {

@@ -1095,6 +1095,7 @@ class TickInfo(C.Structure):
 
 
 _SIGS.update({
+    "navhip_arrival_settle_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "navhip_settled_count_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "navhip_state_pass_resident": (C.c_int, [C.c_void_p, C.POINTER(StatePassIn), C.POINTER(StatePassOut)]),
     "navhip_tick_create": (C.c_int, [C.c_void_p, C.POINTER(TickDesc), C.POINTER(C.c_void_p)]),
