@@ -176,7 +176,7 @@ static void *hip_arena(size_t bytes)
 static size_t hip_arena_need(size_t n, size_t F)
 {
     /* (twice: the state pass of a tick keeps the velocity pass's snapshot and takes its own arrays behind it) */
-    return 2 * ((n + 16) * (4 * 62 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 48);
+    return 2 * ((n + 16) * (4 * 68 + 8) + (F + 2) * (8 + 4 + 8 + 4 + 1 + NAV_LAYER_MAX + 2 * 2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)) + 64 * 64);
 }
 
 static void hip_check_range(int begin, int end, void *arg)
@@ -610,20 +610,43 @@ static long     s_hip_settle_stats[4];               /* units decided by the dev
                                                         heading gate the device left to the host */
 void move_hip_settle_stats(long out[4]) { memcpy(out, s_hip_settle_stats, sizeof(s_hip_settle_stats)); }
 
+struct hip_wrow { int32_t w, row; };                  /* a work item and its row in the arrays of its arm */
 struct hip_state_pass { struct hip_snap *S; int begin_idx; float *new_vel, *vdes, *next_rot; uint8_t *skip, *zoned;
                         uint8_t *fstate, *wait_prev; int32_t *wait_ticks; float *ent_rot, *target_dir;
                         float *interp_from, *interp_step; int any_turning;
-                        int32_t *range_items, *surround_items; int n_range, n_surround; };   /* work items of the two arms with per-unit host queries */
+                        /* the work items of the two arms with per-unit host queries, of zoned units */
+                        struct hip_wrow *range_items, *surround_items; int32_t *zoned_items; int n_range, n_surround, n_zoned;
+                        /* sparse rows (the resident pass): a unit of TURNING / ENTER_ENTITY_RANGE / SURROUND_ENTITY takes the
+                         * next row of its arm's arrays; the defaults of the other arms' rows are written with it */
+                        bool sparse; int32_t *sparse_units; int n_sparse; int32_t *r_target, *r_row, *s_target; uint8_t *s_query;
+                        const uint8_t *zone_active;       /* [nflocks][NAV_LAYER_MAX] the flock has an active arrival zone */
+                        int lo, hi; };                    /* range of dense rows the work items cover */
 
+#define HIP_PF_DIST 12
 static void hip_state_items_range(int begin, int end, void *arg)
 {
     struct hip_state_pass *T = arg;
     const struct hip_snap *S = T->S;
+    int lo = INT32_MAX, hi = -1;
     for(int k = begin; k < end; k++) {
         const int w = T->begin_idx + k;
         const struct move_work_in *in = &s_move_work.in[w];
         const struct move_work_out *out = &s_move_work.out[w];
         const int i = hip_work_dense(S, w);
+        /* (the movestate of a unit is a cache miss: the bucket of the item HIP_PF_DIST ahead is asked for now) */
+        if(k + HIP_PF_DIST < end) {
+            const int wa = w + HIP_PF_DIST, ia = s_hip_witem.idx[wa];
+            if(ia >= 0 && ia < S->n) {
+                const khint_t ca = s_hip_set.it_state[ia];
+                if(ca < kh_end(s_entity_state_table)) {
+                    const char *v = (const char*)&kh_value(s_entity_state_table, ca);
+                    __builtin_prefetch(v); __builtin_prefetch(v + 64); __builtin_prefetch(&kh_key(s_entity_state_table, ca));
+                }
+            }
+        }
+        if(i < lo) lo = i;
+        if(i > hi) hi = i;
+        s_hip_settle_chk[w].valid = false;
         /* (movestate_get through the bucket position the snapshot fill cached for this row: no probe sequence) */
         const khiter_t mk = HIP_IT(s_entity_state_table, state, s_hip_set.it_state[i], in->ent_uid);
         const struct movestate *ms = mk != kh_end(s_entity_state_table) ? &kh_value(s_entity_state_table, mk) : movestate_get(in->ent_uid);
@@ -634,22 +657,32 @@ static void hip_state_items_range(int begin, int end, void *arg)
         }
         T->next_rot[4 * i] = ms->next_rot.x; T->next_rot[4 * i + 1] = ms->next_rot.y;
         T->next_rot[4 * i + 2] = ms->next_rot.z; T->next_rot[4 * i + 3] = ms->next_rot.w;
-        /* an active arrival group (:2443): move_hip_settle_work's.  Every unit at a movement rate below 20 Hz is the
-         * host's: entity_compute_update then tests the INTERPOLATED intermediate position
-         * (interpolate_positions(next_ppos, next_npos, ms->step), :2368-2377), not pos + vel */
         /* the flag / counter arms (formation member on the move, ARRIVING_TO_CELL, the wait timer):
          * navhip_state_update_aux after the arrival arm, which a member falls through to (:2439) */
         T->fstate[i] = (uint8_t)((in->fstate.fid != NULL_FID ? NAVHIP_FS_MEMBER : 0) | (in->fstate.assignment_ready ? NAVHIP_FS_READY : 0)
                      | (in->fstate.assigned_to_cell ? NAVHIP_FS_ASSIGNED : 0) | (in->fstate.in_range_of_cell ? NAVHIP_FS_IN_RANGE : 0)
                      | (in->fstate.arrived_at_cell ? NAVHIP_FS_ARRIVED : 0));
         T->wait_ticks[i] = ms->wait_ticks_left; T->wait_prev[i] = (uint8_t)ms->wait_prev;
-        if(ms->state == STATE_ENTER_ENTITY_RANGE) T->range_items[__atomic_fetch_add(&T->n_range, 1, __ATOMIC_RELAXED)] = w;
-        if(ms->state == STATE_SURROUND_ENTITY)    T->surround_items[__atomic_fetch_add(&T->n_surround, 1, __ATOMIC_RELAXED)] = w;
+        /* the three arms with arrays of their own: a row per entity, or (sparse) the next row of the list */
+        int row = i;
+        bool listed = false;
+        if(ms->state == STATE_ENTER_ENTITY_RANGE || ms->state == STATE_SURROUND_ENTITY || ms->state == STATE_TURNING) {
+            if(T->sparse) {
+                row = __atomic_fetch_add(&T->n_sparse, 1, __ATOMIC_RELAXED);
+                listed = true;
+                T->sparse_units[row] = i;
+                T->r_target[row] = -2; T->r_row[row] = 0; T->s_target[row] = -2; T->s_query[row] = 0;
+            }
+            if(ms->state == STATE_ENTER_ENTITY_RANGE) T->range_items[__atomic_fetch_add(&T->n_range, 1, __ATOMIC_RELAXED)] = (struct hip_wrow){w, row};
+            if(ms->state == STATE_SURROUND_ENTITY)    T->surround_items[__atomic_fetch_add(&T->n_surround, 1, __ATOMIC_RELAXED)] = (struct hip_wrow){w, row};
+        }
+        if(listed && ms->state != STATE_TURNING)                         /* (a listed row nobody turns in) */
+            memset(T->ent_rot + 4 * row, 0, sizeof(float) * 4), memset(T->target_dir + 4 * row, 0, sizeof(float) * 4);
         if(ms->state == STATE_TURNING) {                      /* :2606-2628: the end of the turn is the device's to see */
             __atomic_store_n(&T->any_turning, 1, __ATOMIC_RELAXED);
             const quat_t rot = Entity_GetRot(in->ent_uid);
-            memcpy(T->ent_rot + 4 * i, &rot, sizeof(float) * 4);
-            memcpy(T->target_dir + 4 * i, &ms->target_dir, sizeof(float) * 4);
+            memcpy(T->ent_rot + 4 * row, &rot, sizeof(float) * 4);
+            memcpy(T->target_dir + 4 * row, &ms->target_dir, sizeof(float) * 4);
         }
         /* a rate below 20 Hz: the switch tests the first interpolated position of an accepted move (:2368-2377) -- the
          * device makes it from movestate.next_pos and .step */
@@ -657,15 +690,20 @@ static void hip_state_items_range(int begin, int end, void *arg)
             T->interp_from[2 * i] = ms->next_pos.x; T->interp_from[2 * i + 1] = ms->next_pos.z;
             T->interp_step[i] = ms->step;
         }
+        /* an active arrival group (:2443): move_hip_settle_work's, after the pass */
         T->skip[i] = 0;
         if(S->flock[i] >= 0) {
-            struct flock *fl = &vec_AT(&s_flocks, S->flock[i]);
-            struct arrival_state *as = G_ArrivalGroup_ForLayer(&fl->arrival,
-                Entity_NavLayerWithRadius(S->flags[i], S->radius[i]));
-            T->skip[i] = as && G_Arrival_IsActive(as);
+            T->skip[i] = T->zone_active[(size_t)S->flock[i] * NAV_LAYER_MAX + Entity_NavLayerWithRadius(S->flags[i], S->radius[i])];
             T->zoned[i] = T->skip[i];       /* (:2443-2451: the settle rule's arm, navhip_arrival_settle below) */
+            if(T->skip[i] && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION))
+                T->zoned_items[__atomic_fetch_add(&T->n_zoned, 1, __ATOMIC_RELAXED)] = w;
         }
     }
+    /* (the slab of dense rows the pass covers: merged once per range) */
+    int cur = __atomic_load_n(&T->lo, __ATOMIC_RELAXED);
+    while(lo < cur && !__atomic_compare_exchange_n(&T->lo, &cur, lo, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    cur = __atomic_load_n(&T->hi, __ATOMIC_RELAXED);
+    while(hi > cur && !__atomic_compare_exchange_n(&T->hi, &cur, hi, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 
 /* The arm of the state switch for a unit whose flock has an active arrival zone (:2443-2451, then the
@@ -674,22 +712,15 @@ static void hip_state_items_range(int begin, int end, void *arg)
  * slots, their fill ranks and the sorted tile keys of its footprint.  st / fl (by dense index) are overwritten
  * for the units decided here. */
 static bool s_hip_settle_resident;                   /* the pass in front of the settle work ran on the resident snapshot */
-static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navhip_world *W, int begin_idx, int end_idx,
-                                 const uint8_t *zoned, const uint8_t *gate, const float *new_pos, const float *vdes, uint8_t *st, uint8_t *fl)
+static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navhip_world *W, const int32_t *zoned_items, int n_zoned,
+                                 const uint8_t *gate, const float *new_pos, uint8_t *st, uint8_t *fl)
 {
     const struct move_gamestate *gs = &s_move_work.gamestate;
-    int nq = 0;
-    for(int w = begin_idx; w <= end_idx; w++) {
-        const int i = s_hip_witem.idx[w];
-        if(zoned[i] && !(gate[i] & NAVHIP_GATE_HOST) && (fl[i] & NAVHIP_SU_HOST)
-        && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION))
-            nq++;
-    }
-    if(nq == 0)
+    if(n_zoned == 0)
         return true;
     const size_t F = S->nflocks;
     /* one block for the pass: the (flock, layer) -> zone table, the zones, and 17 per-unit arrays */
-    const size_t Q = (size_t)nq;
+    const size_t Q = (size_t)n_zoned;
     size_t bytes = 0;
 #define TAKE(n_bytes) (bytes += (((size_t)(n_bytes)) + 63) & ~(size_t)63, bytes - ((((size_t)(n_bytes)) + 63) & ~(size_t)63))
     const size_t o_zone_of = TAKE(sizeof(int32_t) * (F * NAV_LAYER_MAX + 1)), o_zones = TAKE(sizeof(navhip_arrival_zone) * (Q + 1)),
@@ -699,6 +730,8 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
                  o_anchored = TAKE(Q), o_osettle = TAKE(Q), o_osub = TAKE(Q), o_oanchored = TAKE(Q);
 #undef TAKE
     char *blk = malloc(bytes);
+    if(!blk)
+        return false;
     int32_t *zone_of = (int32_t*)(blk + o_zone_of);                         /* (flock, layer) -> zone */
     for(size_t k = 0; k < F * NAV_LAYER_MAX; k++) zone_of[k] = -1;
     navhip_arrival_zone *zones = (navhip_arrival_zone*)(blk + o_zones);
@@ -710,10 +743,11 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
     uint8_t *substate = (uint8_t*)(blk + o_sub), *sink_valid = (uint8_t*)(blk + o_sv), *anchored = (uint8_t*)(blk + o_anchored);
     uint8_t *o_settle = (uint8_t*)(blk + o_osettle), *o_substate = (uint8_t*)(blk + o_osub), *o_anchored_ = (uint8_t*)(blk + o_oanchored);
     int nz = 0, q = 0, n_slots = 0, n_keys = 0;
-    for(int w = begin_idx; w <= end_idx; w++) {
-        const int i = s_hip_witem.idx[w];
-        if(!(zoned[i] && !(gate[i] & NAVHIP_GATE_HOST) && (fl[i] & NAVHIP_SU_HOST)
-             && (S->state[i] == STATE_MOVING || S->state[i] == STATE_MOVING_IN_FORMATION)))
+    for(int z = 0; z < n_zoned; z++) {
+        const int w = zoned_items[z], i = s_hip_witem.idx[w];
+        /* (MOVING / MOVING_IN_FORMATION units of zoned flocks, listed by the fill; of those, the ones the gate decided
+         * and the pass left to this arm) */
+        if((gate[i] & NAVHIP_GATE_HOST) || !(fl[i] & NAVHIP_SU_HOST))
             continue;
         const int f = S->flock[i];
         const enum nav_layer layer = Entity_NavLayerWithRadius(S->flags[i], S->radius[i]);
@@ -727,7 +761,8 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
             n_slots += as->num_slots; n_keys += as->num_region;
             nz++;
         }
-        const struct movestate *ms = movestate_get(S->uids[i]);
+        const khiter_t mk = HIP_IT(s_entity_state_table, state, s_hip_set.it_state[i], S->uids[i]);
+        const struct movestate *ms = mk != kh_end(s_entity_state_table) ? &kh_value(s_entity_state_table, mk) : movestate_get(S->uids[i]);
         const struct arrival_unit_state *us = &ms->arrival;
         uid[q] = i; zone[q] = *zi; witem[q] = w;
         q_pos[2 * q] = new_pos[2 * i]; q_pos[2 * q + 1] = new_pos[2 * i + 1];
@@ -738,6 +773,11 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
         anchored[q] = us->progress_anchored; stuck[q] = us->stuck;
         q++;
     }
+    const int nq = q;
+    if(nq == 0) {
+        free(blk);
+        return true;
+    }
     float *slots = malloc(sizeof(float) * 2 * (n_slots + 1));
     int32_t *ring = malloc(sizeof(int32_t) * (n_slots + 1));
     uint64_t *keys = malloc(sizeof(uint64_t) * (n_keys + 1));
@@ -747,21 +787,22 @@ static bool move_hip_settle_work(navhip_ctx *ctx, struct hip_snap *S, const navh
         memcpy(ring + zones[z].slot_begin, as->slot_ring, sizeof(int) * as->num_slots);
         memcpy(keys + zones[z].key_begin, as->region_keys, sizeof(uint64_t) * as->num_region);
     }
-    /* (behind a state pass on the velocity pass's resident snapshot the count reads that snapshot too) */
-    bool ok = (s_hip_settle_resident && navhip_settled_count_resident(ctx, W, nq, uid, nsettled) == NAVHIP_OK)
-           || navhip_settled_count(ctx, W, nq, uid, nsettled) == NAVHIP_OK;
-    navhip_settle_in in = {nz, nq, zones, slots, ring, keys, uid, zone, q_pos, nsettled, substate, sink_valid, sink, order,
+    /* behind a state pass on the velocity pass's resident snapshot: the count and the rule in ONE call on that snapshot
+     * (in.nsettled NULL: counted on the device, out.nsettled says which units stay the host's) */
+    navhip_settle_in in = {nz, nq, zones, slots, ring, keys, uid, zone, q_pos, NULL, substate, sink_valid, sink, order,
                            anchor, anchored, stuck};
-    navhip_settle_out out = {o_settle, o_substate, o_anchor_, o_anchored_, o_stuck_};
-    ok = ok && ((s_hip_settle_resident && navhip_arrival_settle_resident(ctx, W, &in, &out) == NAVHIP_OK)
-                || navhip_arrival_settle(ctx, W, &in, &out) == NAVHIP_OK);
+    navhip_settle_out out = {o_settle, o_substate, o_anchor_, o_anchored_, o_stuck_, nsettled};
+    bool ok = s_hip_settle_resident && navhip_arrival_settle_resident(ctx, W, &in, &out) == NAVHIP_OK;
+    if(!ok) {
+        in.nsettled = nsettled; out.nsettled = NULL;
+        ok = navhip_settled_count(ctx, W, nq, uid, nsettled) == NAVHIP_OK && navhip_arrival_settle(ctx, W, &in, &out) == NAVHIP_OK;
+    }
     for(q = 0; ok && q < nq; q++) {
         const int i = uid[q];
         if(nsettled[q] < 0)
             continue;                                   /* (a unit wider than the device's query: the host's arm) */
         const enum nav_layer layer = Entity_NavLayerWithRadius(S->flags[i], S->radius[i]);
         const vec2_t np = {q_pos[2 * q], q_pos[2 * q + 1]}, vd = s_move_work.out[witem[q]].ent_des_v;
-        (void)vdes;
         s_hip_settle_stats[0]++;
         st[i] = S->state[i]; fl[i] = 0;
         if(!M_NavPositionPathable(gs->map, layer, np))
@@ -788,31 +829,31 @@ static bool hip_is_tile_centre(vec3_t map_pos, vec2_t p)
 
 /* the unit-query answers of the surround units, forked over the host threads like the reference forks
  * entity_compute_update -- the queries are the reference's own, read-only on the nav data */
-struct hip_surround_q { const struct hip_snap *S; const int32_t *items; int32_t *s_target; uint8_t *s_query; float *s_tprev, *s_nprev, *s_dest; };
+struct hip_surround_q { const struct hip_snap *S; const struct hip_wrow *items; int32_t *s_target; uint8_t *s_query; float *s_tprev, *s_nprev, *s_dest; };
 static void hip_surround_range(int begin, int end, void *arg)
 {
     struct hip_surround_q *Q = arg;
     const struct hip_snap *S = Q->S;
     const struct move_gamestate *gs = &s_move_work.gamestate;
     for(int k = begin; k < end; k++) {
-        const int w = Q->items[k], i = s_hip_witem.idx[w];
+        const int w = Q->items[k].w, i = s_hip_witem.idx[w], r = Q->items[k].row;      /* (r: the unit's row in the arm's arrays) */
         const uint32_t uid = S->uids[i];
         const struct movestate *ms = movestate_get(uid);
-        Q->s_tprev[2 * i] = ms->surround_target_prev.x; Q->s_tprev[2 * i + 1] = ms->surround_target_prev.z;
-        Q->s_nprev[2 * i] = ms->surround_nearest_prev.x; Q->s_nprev[2 * i + 1] = ms->surround_nearest_prev.z;
-        if(ms->surround_target_uid == NULL_UID) { Q->s_target[i] = -1; continue; }
+        Q->s_tprev[2 * r] = ms->surround_target_prev.x; Q->s_tprev[2 * r + 1] = ms->surround_target_prev.z;
+        Q->s_nprev[2 * r] = ms->surround_nearest_prev.x; Q->s_nprev[2 * r + 1] = ms->surround_nearest_prev.z;
+        if(ms->surround_target_uid == NULL_UID) { Q->s_target[r] = -1; continue; }
         if(!entity_exists(ms->surround_target_uid)
         || M_NavObjAdjacentFrom(gs->map, uid, ms->surround_target_uid, &s_move_work.unit_query_ctx)) {
-            Q->s_target[i] = -1; Q->s_query[i] = NAVHIP_SQ_ADJACENT;        /* (-> ARRIVED either way, :2518-2525) */
+            Q->s_target[r] = -1; Q->s_query[r] = NAVHIP_SQ_ADJACENT;        /* (-> ARRIVED either way, :2518-2525) */
             continue;
         }
         khiter_t it = kh_get(id, S->dense, ms->surround_target_uid);
         if(it == kh_end(S->dense)) {
-            Q->s_target[i] = -2;
+            Q->s_target[r] = -2;
             continue;                                                     /* (a target outside the snapshot: the host's) */
         }
-        Q->s_target[i] = (int32_t)kh_value(S->dense, it);
-        const vec2_t tp = {S->pos[2 * Q->s_target[i]], S->pos[2 * Q->s_target[i] + 1]};
+        Q->s_target[r] = (int32_t)kh_value(S->dense, it);
+        const vec2_t tp = {S->pos[2 * Q->s_target[r]], S->pos[2 * Q->s_target[r] + 1]};
         vec2_t delta, dest;
         PFM_Vec2_Sub((vec2_t*)&tp, (vec2_t*)&ms->surround_target_prev, &delta);
         if(!(PFM_Vec2_Len(&delta) > EPSILON || PFM_Vec2_Len(&ms->velocity) < EPSILON))
@@ -823,21 +864,22 @@ static void hip_surround_range(int begin, int end, void *arg)
         PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &from[0]);
         for(int c = 0; c < 2; c++) {
             if(c == 1 && from[0].x == from[1].x && from[0].z == from[1].z) {      /* (zero velocity: one query) */
-                if(Q->s_query[i] & NAVHIP_SQ_HAS_DEST_0) {
-                    Q->s_query[i] |= NAVHIP_SQ_HAS_DEST_1; Q->s_dest[4 * i + 2] = Q->s_dest[4 * i]; Q->s_dest[4 * i + 3] = Q->s_dest[4 * i + 1];
+                if(Q->s_query[r] & NAVHIP_SQ_HAS_DEST_0) {
+                    Q->s_query[r] |= NAVHIP_SQ_HAS_DEST_1; Q->s_dest[4 * r + 2] = Q->s_dest[4 * r]; Q->s_dest[4 * r + 3] = Q->s_dest[4 * r + 1];
                 }
                 break;
             }
             if(M_NavClosestReachableAdjacentPosFrom(gs->map, layer, from[c], ms->surround_target_uid, &s_move_work.unit_query_ctx, &dest)) {
-                Q->s_query[i] |= (uint8_t)(NAVHIP_SQ_HAS_DEST_0 << c);
-                Q->s_dest[4 * i + 2 * c] = dest.x; Q->s_dest[4 * i + 2 * c + 1] = dest.z;
+                Q->s_query[r] |= (uint8_t)(NAVHIP_SQ_HAS_DEST_0 << c);
+                Q->s_dest[4 * r + 2 * c] = dest.x; Q->s_dest[4 * r + 2 * c + 1] = dest.z;
             }
         }
     }
 }
 
 /* the per-flock answers of arrived()'s two destination-only queries, kept between ticks */
-struct hip_flock_q { bool valid, has_near; uint32_t epoch; const void *map; int layer, ntiles; float tx, tz, nx, nz; int16_t *tiles; };
+struct hip_flock_q { bool valid, has_near; uint32_t epoch; const void *map; int layer, ntiles; float tx, tz, nx, nz; int16_t *tiles;
+                     bool layer_valid; uint32_t layer_set_epoch, layer_attr_epoch; int layer_members, majority_layer; };
 static struct hip_flock_q *s_hip_flock_q; static size_t s_hip_flock_q_cap;
 static struct hip_flock_q *hip_flock_q_slot(size_t f, int per)
 {
@@ -845,7 +887,7 @@ static struct hip_flock_q *hip_flock_q_slot(size_t f, int per)
         const size_t cap = f + 16;
         s_hip_flock_q = realloc(s_hip_flock_q, sizeof(struct hip_flock_q) * cap);
         for(size_t k = s_hip_flock_q_cap; k < cap; k++) {
-            s_hip_flock_q[k].valid = false;
+            s_hip_flock_q[k].valid = false; s_hip_flock_q[k].layer_valid = false;
             s_hip_flock_q[k].tiles = malloc(sizeof(int16_t) * 2 * per);
         }
         s_hip_flock_q_cap = cap;
@@ -853,18 +895,34 @@ static struct hip_flock_q *hip_flock_q_slot(size_t f, int per)
     return &s_hip_flock_q[f];
 }
 
-struct hip_state_scatter { int begin_idx; const uint8_t *st, *fl; long host; };
+struct hip_state_scatter { int begin_idx; const uint8_t *st, *fl, *gate, *state; const int32_t *wait_after; const float *dense_dest; long host, gate_host; };
 static void hip_state_scatter_range(int begin, int end, void *arg)
 {
     struct hip_state_scatter *X = arg;
-    long host = 0;
+    long host = 0, gate_host = 0;
     for(int k = begin; k < end; k++) {
         const int w = X->begin_idx + k, i = s_hip_witem.idx[w];
         s_hip_su_state[w] = X->st[i];
         s_hip_su_flags[w] = X->fl[i];
         host += (X->fl[i] & NAVHIP_SU_HOST) != 0;
+        /* a unit whose facing is within the device's margin of a tolerance came back NAVHIP_SU_HOST: the host's own
+         * entity_compute_update answers for it (move_hip_update_work) */
+        gate_host += (X->gate[i] & NAVHIP_GATE_HOST) != 0;
+        s_hip_wait_chk[2 * w] = X->state[i] == STATE_WAITING;
+        s_hip_wait_chk[2 * w + 1] = X->wait_after[i];
+        /* (the surround arm's position: per entity from the host-buffer pass, per listed unit -- written afterwards --
+         * from the resident one) */
+        s_hip_su_dest[2 * w] = X->dense_dest ? X->dense_dest[2 * i] : 0.0f;
+        s_hip_su_dest[2 * w + 1] = X->dense_dest ? X->dense_dest[2 * i + 1] : 0.0f;
     }
     __atomic_fetch_add(&X->host, host, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&X->gate_host, gate_host, __ATOMIC_RELAXED);
+}
+
+static int cmp_wrow(const void *a, const void *b)
+{
+    const int32_t x = ((const struct hip_wrow*)a)->w, y = ((const struct hip_wrow*)b)->w;
+    return (x > y) - (x < y);
 }
 
 static bool move_hip_state_work(int begin_idx, int end_idx)
@@ -876,6 +934,7 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     struct hip_snap S;
     double t_mark = hip_now(), t_now;
 #define HIP_SU_LAP(k) (t_now = hip_now(), s_hip_su_times[k] = t_now - t_mark, t_mark = t_now)
+#define HIP_SU_ADD(k) (t_now = hip_now(), s_hip_su_times[k] += t_now - t_mark, t_mark = t_now)
     /* resident: this tick's velocity pass has just run over the same work items -- its snapshot tables are still in the
      * arena and on the device, its outputs are the work items' velocities */
     bool resident = s_hip_state_resident && s_hip_last.valid && s_hip_last.begin_idx == begin_idx && s_hip_last.end_idx == end_idx
@@ -885,15 +944,15 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     if(resident) S = s_hip_last.S;
     else         hip_snap_fill(&S);
     HIP_SU_LAP(0);
-    const int n = S.n;
+    const int n = S.n, nitems = end_idx - begin_idx + 1;
     if(s_hip_su_cap < s_move_work.nwork) {
         s_hip_su_cap = s_move_work.nwork;
         s_hip_su_state = realloc(s_hip_su_state, s_hip_su_cap);
         s_hip_su_flags = realloc(s_hip_su_flags, s_hip_su_cap);
+        s_hip_settle_chk = realloc(s_hip_settle_chk, sizeof(struct hip_settle_chk) * (s_hip_su_cap + 1));
+        s_hip_wait_chk = realloc(s_hip_wait_chk, sizeof(int32_t) * 2 * (s_hip_su_cap + 1));
+        s_hip_su_dest = realloc(s_hip_su_dest, sizeof(float) * 2 * (s_hip_su_cap + 1));
     }
-    s_hip_settle_chk = realloc(s_hip_settle_chk, sizeof(struct hip_settle_chk) * (s_move_work.nwork + 1));
-    for(int w = begin_idx; w <= end_idx; w++)
-        s_hip_settle_chk[w].valid = false;
     /* (resident: the arrays the device reads or writes per unit live in page-locked memory and are transferred in
      * place; new_vel / vdes do not travel at all) */
     float *new_pos = resident ? s_hip_pin.new_pos : hip_arena(sizeof(float) * (2 * n + 2));
@@ -907,10 +966,6 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     /* (rows of the slab without a work item are computed and dropped: they only need defined inputs -- whatever the
      * page-locked arrays of the resident pass held last tick will do, the pageable ones are cleared) */
     if(!resident) { memset(fstate, 0, n + 1); memset(wait_prev, 0, n + 1); memset(wait_ticks, 0, sizeof(int32_t) * (n + 1)); }
-    /* (the rotations of TURNING units: 32 bytes per unit that are only touched when somebody turns) */
-    /* (taken from the arena without a memset: the device reads the rows of TURNING units only, which the fill writes;
-     * handed over only when somebody turns) */
-    float *ent_rot = hip_arena(sizeof(float) * (4 * n + 4)), *target_dir = hip_arena(sizeof(float) * (4 * n + 4));
     if(!resident) { memset(skip, 0, n + 1); memset(next_rot, 0, sizeof(float) * (4 * n + 4)); }
     memset(zoned, 0, n + 1);
     if(!resident) {
@@ -920,25 +975,42 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     const bool sub20 = (20 / hz_count(s_move_work.hz)) > 1;
     float *interp_from = sub20 ? hip_arena(sizeof(float) * (2 * n + 2)) : NULL, *interp_step = sub20 ? hip_arena(sizeof(float) * (n + 1)) : NULL;
     if(sub20) { memset(interp_from, 0, sizeof(float) * (2 * n + 2)); memset(interp_step, 0, sizeof(float) * (n + 1)); }
+    /* The arrays of the three arms that few units take (TURNING, ENTER_ENTITY_RANGE, SURROUND_ENTITY), from the arena and
+     * not cleared: the device reads the rows of such units only.  The resident pass hands them over SPARSE -- a row per
+     * listed unit (navhip_state_aux_in.sparse_units) --, the host-buffer pass a row per entity. */
+    const bool sparse = resident;
+    const size_t R = sparse ? (size_t)nitems : (size_t)n;          /* rows an arm's array can need */
+    float *ent_rot = hip_arena(sizeof(float) * (4 * R + 4)), *target_dir = hip_arena(sizeof(float) * (4 * R + 4));
+    int32_t *r_target = hip_arena(sizeof(int32_t) * (R + 1)), *r_row = hip_arena(sizeof(int32_t) * (R + 1));
+    float *r_range = hip_arena(sizeof(float) * (R + 1)), *r_prev = hip_arena(sizeof(float) * (2 * R + 2));
+    int32_t *s_target = hip_arena(sizeof(int32_t) * (R + 1)); uint8_t *s_query = hip_arena(R + 1);
+    float *s_tprev = hip_arena(sizeof(float) * (2 * R + 2)), *s_nprev = hip_arena(sizeof(float) * (2 * R + 2));
+    float *s_dest = hip_arena(sizeof(float) * (4 * R + 4)), *s_out = hip_arena(sizeof(float) * (2 * R + 2));
+    int32_t *sparse_units = sparse ? hip_arena(sizeof(int32_t) * (R + 1)) : NULL;
+    /* which (flock, layer) has an active arrival zone (:2443): asked once per pass, not once per unit */
+    const size_t F = S.nflocks;
+    uint8_t *zone_active = hip_arena(F * NAV_LAYER_MAX + 1);
+    for(size_t f = 0; f < F; f++)
+        for(int l = 0; l < NAV_LAYER_MAX; l++) {
+            struct arrival_state *as = G_ArrivalGroup_ForLayer(&vec_AT(&s_flocks, f).arrival, (enum nav_layer)l);
+            zone_active[f * NAV_LAYER_MAX + l] = as && G_Arrival_IsActive(as);
+        }
     hip_work_dense_prepare();
     struct hip_state_pass T = {&S, begin_idx, new_vel, vdes, next_rot, skip, zoned, fstate, wait_prev, wait_ticks, ent_rot, target_dir,
                                interp_from, interp_step, 0,
-                               hip_arena(sizeof(int32_t) * (end_idx - begin_idx + 2)), hip_arena(sizeof(int32_t) * (end_idx - begin_idx + 2)), 0, 0};
-    hip_for(hip_state_items_range, end_idx - begin_idx + 1, &T);
+                               hip_arena(sizeof(struct hip_wrow) * (nitems + 1)), hip_arena(sizeof(struct hip_wrow) * (nitems + 1)),
+                               hip_arena(sizeof(int32_t) * (nitems + 1)), 0, 0, 0,
+                               sparse, sparse_units, 0, r_target, r_row, s_target, s_query, zone_active, INT32_MAX, -1};
+    hip_for(hip_state_items_range, nitems, &T);
     const bool any_turning = T.any_turning != 0;
     /* (the fill's threads append in any order: work-item order again, so that a pass is reproducible) */
-    qsort(T.range_items, T.n_range, sizeof(int32_t), cmp_i32);
-    qsort(T.surround_items, T.n_surround, sizeof(int32_t), cmp_i32);
-    int lo = n, hi = -1;
-    for(int w = begin_idx; w <= end_idx; w++) {
-        const int i = s_hip_witem.idx[w];
-        if(i < lo) lo = i;
-        if(i > hi) hi = i;
-    }
+    qsort(T.range_items, T.n_range, sizeof(struct hip_wrow), cmp_wrow);
+    qsort(T.surround_items, T.n_surround, sizeof(struct hip_wrow), cmp_wrow);
+    qsort(T.zoned_items, T.n_zoned, sizeof(int32_t), cmp_i32);
+    const int lo = T.lo, hi = T.hi;
     HIP_SU_LAP(1);
     /* the two destination-only queries of arrived() (:2170), once per flock for the nav layer most of its
      * members path on (units of another layer come back as NAVHIP_SU_HOST) */
-    const size_t F = S.nflocks;
     uint8_t *flayer = hip_arena(F + 1);
     float   *nearest = hip_arena(sizeof(float) * 2 * (F + 1));
     int32_t *toff = hip_arena(sizeof(int32_t) * (F + 2));
@@ -952,20 +1024,27 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         toff[f + 1] = toff[f];
         if(S.flock_offsets[f + 1] == S.flock_offsets[f])
             continue;
-        int per_layer[NAV_LAYER_MAX] = {0}, best = 0;
-        for(int m = S.flock_offsets[f]; m < S.flock_offsets[f + 1]; m++) {
-            const int i = S.flock_members[m];
-            per_layer[Entity_NavLayerWithRadius(S.flags[i], S.radius[i])]++;
+        /* (the layer most members path on: a property of the flock tables and the units' attributes, counted again when
+         * either changes -- the entity set or move_hip_attrs_changed) */
+        struct hip_flock_q *C = hip_flock_q_slot(f, per);
+        if(!(C->layer_valid && C->layer_set_epoch == s_hip_set_epoch && C->layer_attr_epoch == s_hip_attr_epoch
+             && C->layer_members == S.flock_offsets[f + 1] - S.flock_offsets[f])) {
+            int per_layer[NAV_LAYER_MAX] = {0}, best = 0;
+            for(int m = S.flock_offsets[f]; m < S.flock_offsets[f + 1]; m++) {
+                const int i = S.flock_members[m];
+                per_layer[Entity_NavLayerWithRadius(S.flags[i], S.radius[i])]++;
+            }
+            for(int l = 1; l < NAV_LAYER_MAX; l++)
+                if(per_layer[l] > per_layer[best]) best = l;
+            C->layer_valid = true; C->layer_set_epoch = s_hip_set_epoch; C->layer_attr_epoch = s_hip_attr_epoch;
+            C->layer_members = S.flock_offsets[f + 1] - S.flock_offsets[f]; C->majority_layer = best;
         }
-        for(int l = 1; l < NAV_LAYER_MAX; l++)
-            if(per_layer[l] > per_layer[best]) best = l;
-        const enum nav_layer layer = (enum nav_layer)best;
+        const enum nav_layer layer = (enum nav_layer)C->majority_layer;
         flayer[f] = (uint8_t)layer;
         /* the two queries depend on the destination and the layer only -- terrain, not blockers (N_ClosestPathable
          * nav.c:4126 and n_closest_island_tiles :4725 read cost_base and the global islands) --: asked once per flock
          * and (target, layer), kept until the flock is re-targeted or the map's nav data is rebuilt (move_hip_attrs_changed
          * / N_HIP_SyncLayer callers bump s_hip_attr_epoch) */
-        struct hip_flock_q *C = hip_flock_q_slot(f, per);
         if(!(C->valid && C->epoch == s_hip_attr_epoch && C->map == (const void*)gs->map && C->layer == (int)layer && C->tx == fl->target_xz.x && C->tz == fl->target_xz.z)) {
             vec2_t near_xz;
             C->has_near = M_NavClosestPathable(gs->map, layer, fl->target_xz, &near_xz);
@@ -982,7 +1061,6 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     hip_snap_world(&S, &W);
     W.work_begin = lo; W.work_end = hi + 1;
     uint8_t *st = resident ? s_hip_pin.st : hip_arena(n + 1), *fl = resident ? s_hip_pin.fl : hip_arena(n + 1);
-    const bool aux = true;          /* (every rate: the arms read the position the gate kernel leaves) */
     /* ONE call for the pass (navhip_state_pass): the heading gate of every unit (:2319-2336) -> the arrival arm on the
      * positions the gate leaves (navhip_state_update) -> the arms that flags, the wait counter, the angle to target_dir and
      * the distance to the target decide (navhip_state_update_aux); the snapshot travels once */
@@ -990,129 +1068,114 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
     memset(&pin, 0, sizeof(pin));
     pin.gate = (navhip_gate_in){next_rot, new_vel, vdes, interp_from, interp_step};
     pin.state = (navhip_state_in){NULL, NULL, skip, flayer, nearest, toff, tiles};
-    int32_t *r_target = NULL, *r_row = NULL, *r_off = NULL; float *r_range = NULL, *r_prev = NULL; int16_t *r_tiles = NULL;
-    if(aux) {
-        pin.aux.fstate = fstate; pin.aux.wait_ticks_left = wait_ticks; pin.aux.wait_prev = wait_prev;
-        if(any_turning) {                                     /* (else 32 bytes per unit that nobody would read) */
-            pin.aux.ent_rot = ent_rot; pin.aux.target_dir = target_dir;
-        }
-        /* STATE_ENTER_ENTITY_RANGE (:2569-2604): the target's row in the snapshot, the range, where the target stood when
-         * the path was requested, and -- per such unit -- the closest island tiles of the target's position on the unit's
-         * layer (the first half of N_IsMaximallyClose, as for the flocks' destinations above) */
-        const int n_range = T.n_range;
-        if(n_range > 0) {
-            /* (per-unit arrays from the arena, not cleared: the device reads the rows of ENTER_ENTITY_RANGE units only --
-             * but the library checks every row's target index, hence the fill with "the host's") */
-            r_target = hip_arena(sizeof(int32_t) * (n + 1)); r_row = hip_arena(sizeof(int32_t) * (n + 1));
-            r_off = calloc(n_range + 1, sizeof(int32_t));
-            r_range = hip_arena(sizeof(float) * (n + 1)); r_prev = hip_arena(sizeof(float) * (2 * n + 2));
-            r_tiles = malloc(sizeof(int16_t) * 2 * per * n_range);
+    int32_t *r_off = NULL; int16_t *r_tiles = NULL;
+    pin.aux.fstate = fstate; pin.aux.wait_ticks_left = wait_ticks; pin.aux.wait_prev = wait_prev;
+    if(any_turning) {                                     /* (else 32 bytes per row that nobody would read) */
+        pin.aux.ent_rot = ent_rot; pin.aux.target_dir = target_dir;
+    }
+    if(sparse && T.n_sparse > 0) { pin.aux.sparse_units = sparse_units; pin.aux.n_sparse = T.n_sparse; }
+    /* STATE_ENTER_ENTITY_RANGE (:2569-2604): the target's row in the snapshot, the range, where the target stood when
+     * the path was requested, and -- per such unit -- the closest island tiles of the target's position on the unit's
+     * layer (the first half of N_IsMaximallyClose, as for the flocks' destinations above) */
+    const int n_range = T.n_range;
+    if(n_range > 0) {
+        r_off = calloc(n_range + 1, sizeof(int32_t));
+        r_tiles = malloc(sizeof(int16_t) * 2 * per * n_range);
+        if(!sparse) {                 /* (a row per entity: the library checks every row's target, hence "the host's") */
             memset(r_target, 0xfe, sizeof(int32_t) * n);            /* (any value below -1 = "the host's") */
             memset(r_row, 0, sizeof(int32_t) * n);
-            int row = 0;
-            for(int k = 0; k < n_range; k++) {
-                const int w = T.range_items[k], i = s_hip_witem.idx[w];
-                const struct movestate *ms = movestate_get(S.uids[i]);
-                r_off[row + 1] = r_off[row];
-                r_row[i] = row;
-                r_range[i] = ms->target_range;
-                r_prev[2 * i] = ms->target_prev_pos.x; r_prev[2 * i + 1] = ms->target_prev_pos.z;
-                if(ms->surround_target_uid == NULL_UID) {
-                    r_target[i] = -1;
-                }else{
-                    khiter_t k = kh_get(id, S.dense, ms->surround_target_uid);
-                    if(k != kh_end(S.dense)) {
-                        r_target[i] = (int32_t)kh_value(S.dense, k);
-                        /* N_IsMaximallyClose(new_pos, target, 0.0f) (:2585) holds only where the tested position IS the
-                         * centre of one of the target's closest island tiles: the 31-us island query is only made for a
-                         * unit one of whose candidate positions -- pos + new velocity, pos (halted by the gate) -- is a
-                         * tile centre to the bit; any other unit gets an empty row (at rates below 20 Hz the position is
-                         * the device's interpolation: every unit is asked for) */
-                        const vec2_t pos = {S.pos[2 * i], S.pos[2 * i + 1]}, vel = s_move_work.out[w].ent_vel;
-                        vec2_t moved_to;
-                        PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &moved_to);
-                        if(sub20 || hip_is_tile_centre(map_pos, pos) || hip_is_tile_centre(map_pos, moved_to)) {
-                            const vec2_t tp = {S.pos[2 * r_target[i]], S.pos[2 * r_target[i] + 1]};
-                            r_off[row + 1] += N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map),
-                                Entity_NavLayerWithRadius(S.flags[i], S.radius[i]), map_pos, tp, r_tiles + 2 * r_off[row], per);
-                        }
-                    }
-                }
-                row++;
-            }
-            pin.aux.range_target = r_target; pin.aux.target_range = r_range; pin.aux.target_prev_xz = r_prev;
-            pin.aux.range_tiles_row = r_row; pin.aux.range_tiles_off = r_off; pin.aux.range_tiles = r_tiles;
-            pin.aux.n_range_rows = n_range;
         }
+        int row = 0;
+        for(int k = 0; k < n_range; k++) {
+            const int w = T.range_items[k].w, i = s_hip_witem.idx[w], r = T.range_items[k].row;
+            const struct movestate *ms = movestate_get(S.uids[i]);
+            r_off[row + 1] = r_off[row];
+            r_row[r] = row;
+            r_range[r] = ms->target_range;
+            r_prev[2 * r] = ms->target_prev_pos.x; r_prev[2 * r + 1] = ms->target_prev_pos.z;
+            if(ms->surround_target_uid == NULL_UID) {
+                r_target[r] = -1;
+            }else{
+                khiter_t kt = kh_get(id, S.dense, ms->surround_target_uid);
+                if(kt != kh_end(S.dense)) {
+                    r_target[r] = (int32_t)kh_value(S.dense, kt);
+                    /* N_IsMaximallyClose(new_pos, target, 0.0f) (:2585) holds only where the tested position IS the
+                     * centre of one of the target's closest island tiles: the 31-us island query is only made for a
+                     * unit one of whose candidate positions -- pos + new velocity, pos (halted by the gate) -- is a
+                     * tile centre to the bit; any other unit gets an empty row (at rates below 20 Hz the position is
+                     * the device's interpolation: every unit is asked for) */
+                    const vec2_t pos = {S.pos[2 * i], S.pos[2 * i + 1]}, vel = s_move_work.out[w].ent_vel;
+                    vec2_t moved_to;
+                    PFM_Vec2_Add((vec2_t*)&pos, (vec2_t*)&vel, &moved_to);
+                    if(sub20 || hip_is_tile_centre(map_pos, pos) || hip_is_tile_centre(map_pos, moved_to)) {
+                        const vec2_t tp = {S.pos[2 * r_target[r]], S.pos[2 * r_target[r] + 1]};
+                        r_off[row + 1] += N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map),
+                            Entity_NavLayerWithRadius(S.flags[i], S.radius[i]), map_pos, tp, r_tiles + 2 * r_off[row], per);
+                    }
+                }else
+                    r_target[r] = -2;                               /* (a target outside the snapshot: the host's) */
+            }
+            row++;
+        }
+        pin.aux.range_target = r_target; pin.aux.target_range = r_range; pin.aux.target_prev_xz = r_prev;
+        pin.aux.range_tiles_row = r_row; pin.aux.range_tiles_off = r_off; pin.aux.range_tiles = r_tiles;
+        pin.aux.n_range_rows = n_range;
     }
     /* STATE_SURROUND_ENTITY (:2509-2567) at 20 Hz: the switch runs on the device, the two queries on the unit-query
      * context stay here -- whether the unit already touches its target (or the target is gone), and, for the units that
      * reach the query (:2532-2534), the closest reachable position next to the target from both positions the tick can
      * test: pos + new velocity, and pos (the heading gate halts the unit) */
-    int32_t *s_target = NULL; uint8_t *s_query = NULL; float *s_tprev = NULL, *s_nprev = NULL, *s_dest = NULL, *s_out = NULL;
     const int n_surround = sub20 ? 0 : T.n_surround;
     if(n_surround > 0) {
-        /* (from the arena; the device reads and writes the rows of SURROUND_ENTITY units only) */
-        s_target = hip_arena(sizeof(int32_t) * (n + 1)); s_query = hip_arena(n + 1); s_tprev = hip_arena(sizeof(float) * (2 * n + 2));
-        s_nprev = hip_arena(sizeof(float) * (2 * n + 2)); s_dest = hip_arena(sizeof(float) * (4 * n + 4)); s_out = hip_arena(sizeof(float) * (2 * n + 2));
-        memset(s_target, 0xfe, sizeof(int32_t) * n);              /* (any value below -1 = "the host's") */
-        memset(s_query, 0, n + 1); memset(s_out, 0, sizeof(float) * (2 * n + 2));
+        if(!sparse) {
+            memset(s_target, 0xfe, sizeof(int32_t) * n);              /* (any value below -1 = "the host's") */
+            memset(s_query, 0, n + 1); memset(s_out, 0, sizeof(float) * (2 * n + 2));
+        }
         struct hip_surround_q Q = {&S, T.surround_items, s_target, s_query, s_tprev, s_nprev, s_dest};
         hip_for_min(hip_surround_range, n_surround, &Q, 16);
         pin.aux.surround_target = s_target; pin.aux.surround_query = s_query; pin.aux.surround_target_prev_xz = s_tprev;
         pin.aux.surround_nearest_prev_xz = s_nprev; pin.aux.surround_dest_xz = s_dest; pin.aux.out_surround_dest_xz = s_out;
     }
-    navhip_state_pass_out pout = {st, fl, gate, new_pos, gate_vel, aux ? wait_after : NULL};
-    HIP_SU_LAP(2);                  /* (the enter-range inputs count as queries too) */
+    navhip_state_pass_out pout = {st, fl, gate, new_pos, gate_vel, wait_after};
+    HIP_SU_ADD(2);                  /* (the enter-range and surround inputs count as queries too) */
     bool ok = hi >= lo;
     if(ok && resident && navhip_state_pass_resident(ctx, &pin, &pout) != NAVHIP_OK) {
-        /* (the step's arrays are gone -- somebody used the context in between: the host-buffer pass, with the two
-         * arrays the resident one does not need) */
-        resident = false;
-        new_vel = hip_arena(sizeof(float) * (2 * n + 2)); vdes = hip_arena(sizeof(float) * (2 * n + 2));
-        memset(new_vel, 0, sizeof(float) * (2 * n + 2)); memset(vdes, 0, sizeof(float) * (2 * n + 2));
-        for(int w = begin_idx; w <= end_idx; w++) {
-            const int i = s_hip_witem.idx[w];
-            new_vel[2 * i] = s_move_work.out[w].ent_vel.x; new_vel[2 * i + 1] = s_move_work.out[w].ent_vel.z;
-            vdes[2 * i] = s_move_work.out[w].ent_des_v.x; vdes[2 * i + 1] = s_move_work.out[w].ent_des_v.z;
-        }
-        pin.gate.new_vel_xz = new_vel; pin.gate.vdes_xz = vdes;
-        ok = navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
+        /* (the step's arrays are gone -- somebody used the context in between: the host-buffer pass, from the start) */
+        free(r_off); free(r_tiles);
+        hip_snap_free(&S);
+        s_hip_state_resident = false;
+        ok = move_hip_state_work(begin_idx, end_idx);
+        s_hip_state_resident = true;
+        return ok;
     }else if(ok && !resident)
         ok = navhip_state_pass(ctx, &W, &pin, &pout) == NAVHIP_OK;
     s_hip_resident_passes += ok && resident;
     s_hip_settle_resident = ok && resident;
     HIP_SU_LAP(3);
     free(r_off); free(r_tiles);
-    s_hip_su_dest = realloc(s_hip_su_dest, sizeof(float) * 2 * (s_move_work.nwork + 1));
-    for(int w = begin_idx; w <= end_idx; w++) {
-        const int i = s_hip_witem.idx[w];
-        s_hip_su_dest[2 * w] = s_out ? s_out[2 * i] : 0.0f; s_hip_su_dest[2 * w + 1] = s_out ? s_out[2 * i + 1] : 0.0f;
-    }
-    /* (the surround arrays live in the arena) */
-    /* a unit whose facing is within the device's margin of a tolerance came back NAVHIP_SU_HOST: the host's own
-     * entity_compute_update answers for it (move_hip_update_work) */
-    for(int w = begin_idx; ok && w <= end_idx; w++)
-        s_hip_settle_stats[3] += (gate[s_hip_witem.idx[w]] & NAVHIP_GATE_HOST) != 0;
     /* units of flocks with an active arrival zone, skipped above: the settle rule on the positions the gate left */
     if(ok)
-        ok = move_hip_settle_work(ctx, &S, &W, begin_idx, end_idx, zoned, gate, new_pos, vdes, st, fl);
+        ok = move_hip_settle_work(ctx, &S, &W, T.zoned_items, T.n_zoned, gate, new_pos, st, fl);
     HIP_SU_LAP(4);
-    s_hip_wait_chk = realloc(s_hip_wait_chk, sizeof(int32_t) * 2 * (s_move_work.nwork + 1));
-    for(int w = begin_idx; w <= end_idx; w++) {
-        const int i = s_hip_witem.idx[w];
-        s_hip_wait_chk[2 * w] = aux && ok && S.state[i] == STATE_WAITING;
-        s_hip_wait_chk[2 * w + 1] = wait_after[i];
-    }
     if(ok) {
         s_hip_su_stats[2]++;
-        struct hip_state_scatter X = {begin_idx, st, fl, 0};
-        hip_for(hip_state_scatter_range, end_idx - begin_idx + 1, &X);
-        s_hip_su_stats[1] += X.host; s_hip_su_stats[0] += (end_idx - begin_idx + 1) - X.host;
-    }
+        struct hip_state_scatter X = {begin_idx, st, fl, gate, S.state, wait_after, (n_surround > 0 && !sparse) ? s_out : NULL, 0, 0};
+        hip_for(hip_state_scatter_range, nitems, &X);
+        s_hip_su_stats[1] += X.host; s_hip_su_stats[0] += nitems - X.host;
+        s_hip_settle_stats[3] += X.gate_host;
+        if(sparse)                                             /* (the surround positions came back per listed unit) */
+            for(int k = 0; k < n_surround; k++) {
+                const struct hip_wrow it = T.surround_items[k];
+                s_hip_su_dest[2 * it.w] = s_out[2 * it.row]; s_hip_su_dest[2 * it.w + 1] = s_out[2 * it.row + 1];
+            }
+    }else
+        for(int w = begin_idx; w <= end_idx; w++) {
+            s_hip_wait_chk[2 * w] = 0; s_hip_su_flags[w] = NAVHIP_SU_HOST; s_hip_su_state[w] = 0;
+        }
     hip_snap_free(&S);
     HIP_SU_LAP(5);
 #undef HIP_SU_LAP
+#undef HIP_SU_ADD
     return ok;
 }
 

@@ -785,6 +785,16 @@ typedef struct navhip_state_aux_in {
     const float    *surround_dest_xz; /* [n][2][2] the query's answer from pos + new velocity ([i][0]) and from pos ([i][1]) */
     const float    *vdes_xz;          /* [n][2] move_work_out.ent_des_v (the surround arm's no-guidance test)            */
     float          *out_surround_dest_xz;      /* [n][2] written for units flagged NAVHIP_SU_SURROUND_PREV               */
+    /* SPARSE ROWS (navhip_state_pass_resident only; NULL / 0 everywhere else).  The three arms above concern a few units
+     * in a hundred, and their arrays are 108 bytes per ENTITY.  With sparse_units != NULL every per-unit array of the
+     * three arms that is given -- ent_rot, target_dir; range_target, target_range, target_prev_xz, range_tiles_row;
+     * surround_target, surround_query, surround_target_prev_xz, surround_nearest_prev_xz, surround_dest_xz,
+     * out_surround_dest_xz -- holds ONE ROW PER LISTED UNIT, row k for unit sparse_units[k], instead of one per entity;
+     * the device lays them out.  List every unit of the three states that the device is to decide: an unlisted
+     * ENTER_ENTITY_RANGE / SURROUND_ENTITY unit is left to the host (as a target below -1), an unlisted TURNING unit is
+     * computed from a zero rotation (as a dense row nobody filled would be).  A unit may be listed once. */
+    const int32_t  *sparse_units;     /* [n_sparse] rows of the world's arrays, inside the slab                          */
+    int32_t         n_sparse;
 } navhip_state_aux_in;
 #define NAVHIP_SQ_ADJACENT   0x01   /* !entity_exists(target) || M_NavObjAdjacentFrom(map, uid, target, ctx)              */
 #define NAVHIP_SQ_HAS_DEST_0 0x02   /* M_NavClosestReachableAdjacentPosFrom(.., pos + new velocity, ..) found a position */
@@ -888,11 +898,16 @@ typedef struct navhip_settle_out {
     float    *progress_anchor_xz;     /* [nq][2]                                                                */
     uint8_t  *progress_anchored;      /* [nq]                                                                   */
     int32_t  *stuck;                  /* [nq]                                                                   */
+    int32_t  *nsettled;               /* [nq] or NULL: the counts the rule used (navhip_arrival_settle_resident with
+                                              in->nsettled == NULL); -1 = the host counts AND decides this unit     */
 } navhip_settle_out;
 int  navhip_arrival_settle(navhip_ctx *ctx, const navhip_world *world, const navhip_settle_in *in,
                            const navhip_settle_out *out);
 /* The same with world->vel_xz / ->radius read from the snapshot the velocity half of the tick left on the device (see
- * navhip_state_pass_resident; world: n_ents, map_pos).  NAVHIP_ERR_INVALID when no such step is resident. */
+ * navhip_state_pass_resident; world: n_ents, map_pos).  NAVHIP_ERR_INVALID when no such step is resident.
+ * in->nsettled == NULL: adjacent_settled_count is taken on the device too (navhip_settled_count_resident's rule on the
+ * same snapshot; world: the grid bounds as well) -- the two passes of the arm in ONE call, every per-unit array packed
+ * through pinned memory as one transfer each way. */
 int  navhip_arrival_settle_resident(navhip_ctx *ctx, const navhip_world *world, const navhip_settle_in *in,
                                     const navhip_settle_out *out);
 /* Everything resident on the device (the zones' arrays and the per-unit arrays too), asynchronous on `stream`. */

@@ -238,6 +238,39 @@ __global__ __launch_bounds__(256) void k_gate_host_rows(int begin, int end, cons
     if(out_ticks) out_ticks[i] = in_ticks[i];
 }
 
+// sparse rows of the three arms with per-unit arrays (navhip_state_aux_in.sparse_units): row k of every given array
+// goes to row units[k] of its dense twin, which the arm kernels read as before; a thread per listed unit
+struct sk_sparse_rows {
+    int n; const int32_t *units;
+    const float *er, *td; float *d_er, *d_td;
+    const int32_t *rt; const float *rr, *rp; const int32_t *row; int32_t *d_rt; float *d_rr, *d_rp; int32_t *d_row;
+    const int32_t *stgt; const uint8_t *sq; const float *stp, *snp, *sd; int32_t *d_stgt; uint8_t *d_sq; float *d_stp, *d_snp, *d_sd;
+};
+__global__ __launch_bounds__(256) void k_sparse_rows(sk_sparse_rows S)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if(k >= S.n) return;
+    const int i = S.units[k];
+    if(S.er) {
+        for(int c = 0; c < 4; c++) { S.d_er[4 * i + c] = S.er[4 * k + c]; S.d_td[4 * i + c] = S.td[4 * k + c]; }
+    }
+    if(S.rt) {
+        S.d_rt[i] = S.rt[k]; S.d_rr[i] = S.rr[k]; S.d_row[i] = S.row[k];
+        S.d_rp[2 * i] = S.rp[2 * k]; S.d_rp[2 * i + 1] = S.rp[2 * k + 1];
+    }
+    if(S.stgt) {
+        S.d_stgt[i] = S.stgt[k]; S.d_sq[i] = S.sq[k];
+        for(int c = 0; c < 2; c++) { S.d_stp[2 * i + c] = S.stp[2 * k + c]; S.d_snp[2 * i + c] = S.snp[2 * k + c]; }
+        for(int c = 0; c < 4; c++) S.d_sd[4 * i + c] = S.sd[4 * k + c];
+    }
+}
+__global__ __launch_bounds__(256) void k_sparse_gather2(int n, const int32_t *units, const float *dense, float *rows)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if(k >= n) return;
+    rows[2 * k] = dense[2 * units[k]]; rows[2 * k + 1] = dense[2 * units[k] + 1];
+}
+
 // ---------------------------------------------------------------------------------------------
 // adjacent_settled_count: the ids of the spatial query (k_spatial_query, the reference's visiting order,
 // capped) -> the count, a thread per unit
@@ -489,6 +522,9 @@ bool sk_interp_inputs_ok(const navhip_world *w, const navhip_gate_in *in)
     return !in->interp_from_xz || (w->radius && w->flags);
 }
 
+// sparse rows are navhip_state_pass_resident's
+bool sk_no_sparse(const navhip_state_aux_in *in) { return in->sparse_units == nullptr && in->n_sparse == 0; }
+
 bool sk_work_range(const navhip_world *w, int *b, int *e)
 {
     *b = w->work_begin; *e = w->work_end;
@@ -579,7 +615,7 @@ int navhip_state_update_aux_dev(navhip_ctx *ctx, const navhip_world *w, const na
     if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
     if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz
-    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in) || !sk_surround_inputs_ok(w, in))
+    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in) || !sk_surround_inputs_ok(w, in) || !sk_no_sparse(in))
         return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
@@ -601,7 +637,7 @@ int navhip_state_update_aux(navhip_ctx *ctx, const navhip_world *w, const navhip
     if(!ctx || !w || !in || !io_state || !io_flags || !out_ticks || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(w->n_ents == 0) return NAVHIP_OK;
     if(!w->radius || !w->flags || !w->state || !in->fstate || !in->wait_ticks_left || !in->wait_prev || !in->new_pos_xz
-    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in) || !sk_surround_inputs_ok(w, in))
+    || (in->ent_rot != nullptr) != (in->target_dir != nullptr) || !sk_range_inputs_ok(w, in) || !sk_surround_inputs_ok(w, in) || !sk_no_sparse(in))
         return NAVHIP_ERR_INVALID;
     int b, e;
     if(!sk_work_range(w, &b, &e)) return NAVHIP_ERR_INVALID;
@@ -725,7 +761,7 @@ int navhip_state_pass(navhip_ctx *ctx, const navhip_world *w, const navhip_state
     || (F > 0 && (!w->flock_target_xz || !w->flock_offsets || !w->flock_members || !T.flock_layer || !T.flock_nearest_xz
                   || !T.flock_tiles_off || !T.flock_tiles))
     || (aux && (!X.wait_ticks_left || !X.wait_prev || !out->wait_ticks_left || (X.ent_rot != nullptr) != (X.target_dir != nullptr)
-                || !sk_range_inputs_ok(w, &X)))
+                || !sk_range_inputs_ok(w, &X) || !sk_no_sparse(&X)))
     || !sk_interp_inputs_ok(w, &G))
         return NAVHIP_ERR_INVALID;
     if(su) {
@@ -880,6 +916,14 @@ int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, 
     }
     int b, e;
     if(!sk_work_range(&d, &b, &e)) return NAVHIP_ERR_INVALID;
+    // sparse rows: the arrays of the three arms hold a row per LISTED unit (ns of them), the device lays them out
+    const bool sp = aux && X.sparse_units != nullptr;
+    if((X.sparse_units == nullptr && X.n_sparse != 0) || X.n_sparse < 0 || (X.sparse_units && !aux)) return NAVHIP_ERR_INVALID;
+    const size_t ns = sp ? (size_t)X.n_sparse : 0;
+    const size_t nr = sp ? ns : n;                              // rows of an arm array
+    const size_t v0 = sp ? 0 : (size_t)b, v1 = sp ? ns : (size_t)e;   // ... and those the checks below walk
+    for(size_t k = 0; k < ns; k++)
+        if(X.sparse_units[k] < b || X.sparse_units[k] >= e) return NAVHIP_ERR_INVALID;
     for(size_t f = 0; f < F; f++)
         if(T.flock_tiles_off[f] < 0 || T.flock_tiles_off[f + 1] < T.flock_tiles_off[f]) return NAVHIP_ERR_INVALID;
     const size_t ntiles = F ? (size_t)T.flock_tiles_off[F] : 0;
@@ -889,12 +933,12 @@ int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, 
         for(size_t r = 0; r < rows; r++)
             if(X.range_tiles_off[r] < 0 || X.range_tiles_off[r + 1] < X.range_tiles_off[r]) return NAVHIP_ERR_INVALID;
         n_rt = rows ? (size_t)X.range_tiles_off[rows] : 0;
-        for(size_t i = (size_t)b; i < (size_t)e; i++)
+        for(size_t i = v0; i < v1; i++)
             if(X.range_target[i] >= d.n_ents
             || (X.range_target[i] >= 0 && (X.range_tiles_row[i] < 0 || (size_t)X.range_tiles_row[i] >= (rows ? rows : 1)))) return NAVHIP_ERR_INVALID;
     }
     if(su)
-        for(size_t i = (size_t)b; i < (size_t)e; i++)
+        for(size_t i = v0; i < v1; i++)
             if(X.surround_target[i] >= d.n_ents) return NAVHIP_ERR_INVALID;
     SKCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -908,29 +952,36 @@ int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, 
     const size_t o_skip = stage(T.skip, T.skip ? n : 0), o_flay = stage(T.flock_layer, F), o_fnear = stage(T.flock_nearest_xz, F * 8),
                  o_toff = stage(T.flock_tiles_off, (F + 1) * 4), o_tiles = stage(T.flock_tiles, ntiles * 4);
     const size_t o_fs = stage(X.fstate, aux ? n : 0), o_wt = stage(X.wait_ticks_left, aux ? n * 4 : 0), o_wp = stage(X.wait_prev, aux ? n : 0),
-                 o_er = stage(X.ent_rot, turn ? n * 16 : 0), o_td = stage(X.target_dir, turn ? n * 16 : 0),
-                 o_rt = stage(X.range_target, rg ? n * 4 : 0), o_rr = stage(X.target_range, rg ? n * 4 : 0),
-                 o_rp = stage(X.target_prev_xz, rg ? n * 8 : 0), o_row = stage(X.range_tiles_row, rg ? n * 4 : 0),
+                 o_er = stage(X.ent_rot, turn ? nr * 16 : 0), o_td = stage(X.target_dir, turn ? nr * 16 : 0),
+                 o_rt = stage(X.range_target, rg ? nr * 4 : 0), o_rr = stage(X.target_range, rg ? nr * 4 : 0),
+                 o_rp = stage(X.target_prev_xz, rg ? nr * 8 : 0), o_row = stage(X.range_tiles_row, rg ? nr * 4 : 0),
                  o_roff = stage(X.range_tiles_off, rg ? (rows + 1) * 4 : 0), o_rtil = stage(X.range_tiles, rg ? n_rt * 4 : 0),
-                 o_stgt = stage(X.surround_target, su ? n * 4 : 0), o_sq = stage(X.surround_query, su ? n : 0),
-                 o_stp = stage(X.surround_target_prev_xz, su ? n * 8 : 0), o_snp = stage(X.surround_nearest_prev_xz, su ? n * 8 : 0),
-                 o_sd = stage(X.surround_dest_xz, su ? n * 16 : 0);
+                 o_stgt = stage(X.surround_target, su ? nr * 4 : 0), o_sq = stage(X.surround_query, su ? nr : 0),
+                 o_stp = stage(X.surround_target_prev_xz, su ? nr * 8 : 0), o_snp = stage(X.surround_nearest_prev_xz, su ? nr * 8 : 0),
+                 o_sd = stage(X.surround_dest_xz, su ? nr * 16 : 0), o_units = stage(X.sparse_units, ns * 4);
+    // (sparse: the dense twins the arm kernels read, filled on the device)
+    const size_t e_er = A.take(sp && turn ? n * 16 : 0), e_td = A.take(sp && turn ? n * 16 : 0),
+                 e_rt = A.take(sp && rg ? n * 4 : 0), e_rr = A.take(sp && rg ? n * 4 : 0), e_rp = A.take(sp && rg ? n * 8 : 0),
+                 e_row = A.take(sp && rg ? n * 4 : 0), e_stgt = A.take(sp && su ? n * 4 : 0), e_sq = A.take(sp && su ? n : 0),
+                 e_stp = A.take(sp && su ? n * 8 : 0), e_snp = A.take(sp && su ? n * 8 : 0), e_sd = A.take(sp && su ? n * 16 : 0);
     const size_t in_total = A.total;
     // ---- results: rows [b, e) of each, one device slab, one transfer for the pageable destinations
     const size_t cnt = (size_t)(e - b), lo = (size_t)b;
     sk_arena R;
     const size_t r_vel = R.take(n * 8), r_np = R.take(n * 8), r_gate = R.take(n), r_st = R.take(n), r_fl = R.take(n),
-                 r_tk = R.take(aux ? n * 4 : 0), r_sd = R.take(su ? n * 8 : 0), r_vd = R.take(n * 8);
+                 r_tk = R.take(aux ? n * 4 : 0), r_sd = R.take(su ? n * 8 : 0), r_vd = R.take(n * 8),
+                 r_sdk = R.take(sp && su ? ns * 8 : 0);           // (sparse: the surround positions of the listed units)
     size_t pack_in = 0;
     for(auto &it : items) if(!it.pinned) pack_in += (it.bytes + 255) & ~(size_t)255;
-    struct oitem { void *dst; size_t dev_off, row; size_t h_off; bool pinned; };
-    std::vector<oitem> outs = {{out->state, r_st, 1, 0, false}, {out->flags, r_fl, 1, 0, false}, {out->gate, r_gate, 1, 0, false},
-                               {out->new_pos_xz, r_np, 8, 0, false}};
-    if(out->vel_xz) outs.push_back({out->vel_xz, r_vel, 8, 0, false});
-    if(aux) outs.push_back({out->wait_ticks_left, r_tk, 4, 0, false});
-    if(su) outs.push_back({X.out_surround_dest_xz, r_sd, 8, 0, false});
+    struct oitem { void *dst; size_t dev_off, row; size_t h_off; bool pinned; size_t lo, cnt; };     // rows [lo, lo + cnt) travel
+    std::vector<oitem> outs = {{out->state, r_st, 1, 0, false, lo, cnt}, {out->flags, r_fl, 1, 0, false, lo, cnt},
+                               {out->gate, r_gate, 1, 0, false, lo, cnt}, {out->new_pos_xz, r_np, 8, 0, false, lo, cnt}};
+    if(out->vel_xz) outs.push_back({out->vel_xz, r_vel, 8, 0, false, lo, cnt});
+    if(aux) outs.push_back({out->wait_ticks_left, r_tk, 4, 0, false, lo, cnt});
+    if(su && !sp) outs.push_back({X.out_surround_dest_xz, r_sd, 8, 0, false, lo, cnt});
+    if(su && sp && ns) outs.push_back({X.out_surround_dest_xz, r_sdk, 8, 0, false, 0, ns});
     size_t pack_out = 0;
-    for(auto &o : outs) { o.pinned = nh_is_pinned(o.dst); if(!o.pinned) { o.h_off = pack_out; pack_out += (cnt * o.row + 255) & ~(size_t)255; } }
+    for(auto &o : outs) { o.pinned = nh_is_pinned(o.dst); if(!o.pinned) { o.h_off = pack_out; pack_out += (o.cnt * o.row + 255) & ~(size_t)255; } }
     char *h_in = nullptr, *h_out = nullptr, *base = nullptr, *res = nullptr;
     int rc = nh_async_slabs(ctx, pack_in, pack_out, &h_in, &h_out);
     if(!rc) rc = navhip_stage_reserve(ctx, SK_IN_SLOT, in_total + pack_in + 256, (void**)&base);
@@ -957,6 +1008,38 @@ int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, 
         for(size_t k = 0; k < items.size(); k++) if(items[k].off == off) return dev_of[k];
         return base + off;                                     // (nothing staged there: an address nobody reads)
     };
+    // ---- sparse rows -> the dense arrays of the arms (targets default to "the host's", rotations and queries to zero)
+    const char *a_er = dev(o_er), *a_td = dev(o_td), *a_rt = dev(o_rt), *a_rr = dev(o_rr), *a_rp = dev(o_rp), *a_row = dev(o_row),
+               *a_stgt = dev(o_stgt), *a_sq = dev(o_sq), *a_stp = dev(o_stp), *a_snp = dev(o_snp), *a_sd = dev(o_sd);
+    if(sp) {
+        sk_sparse_rows SR;
+        memset(&SR, 0, sizeof(SR));
+        SR.n = (int)ns; SR.units = (const int32_t*)dev(o_units);
+        if(turn) {
+            SKCHK(ctx, hipMemsetAsync(base + e_er, 0, n * 16, s)); SKCHK(ctx, hipMemsetAsync(base + e_td, 0, n * 16, s));
+            SR.er = (const float*)a_er; SR.td = (const float*)a_td; SR.d_er = (float*)(base + e_er); SR.d_td = (float*)(base + e_td);
+            a_er = base + e_er; a_td = base + e_td;
+        }
+        if(rg) {
+            SKCHK(ctx, hipMemsetAsync(base + e_rt, 0xfe, n * 4, s)); SKCHK(ctx, hipMemsetAsync(base + e_row, 0, n * 4, s));
+            SR.rt = (const int32_t*)a_rt; SR.rr = (const float*)a_rr; SR.rp = (const float*)a_rp; SR.row = (const int32_t*)a_row;
+            SR.d_rt = (int32_t*)(base + e_rt); SR.d_rr = (float*)(base + e_rr); SR.d_rp = (float*)(base + e_rp); SR.d_row = (int32_t*)(base + e_row);
+            a_rt = base + e_rt; a_rr = base + e_rr; a_rp = base + e_rp; a_row = base + e_row;
+        }
+        if(su) {
+            SKCHK(ctx, hipMemsetAsync(base + e_stgt, 0xfe, n * 4, s)); SKCHK(ctx, hipMemsetAsync(base + e_sq, 0, n, s));
+            SKCHK(ctx, hipMemsetAsync(res + r_sd, 0, n * 8, s));
+            SR.stgt = (const int32_t*)a_stgt; SR.sq = (const uint8_t*)a_sq; SR.stp = (const float*)a_stp; SR.snp = (const float*)a_snp;
+            SR.sd = (const float*)a_sd;
+            SR.d_stgt = (int32_t*)(base + e_stgt); SR.d_sq = (uint8_t*)(base + e_sq); SR.d_stp = (float*)(base + e_stp);
+            SR.d_snp = (float*)(base + e_snp); SR.d_sd = (float*)(base + e_sd);
+            a_stgt = base + e_stgt; a_sq = base + e_sq; a_stp = base + e_stp; a_snp = base + e_snp; a_sd = base + e_sd;
+        }
+        if(ns) {
+            hipLaunchKernelGGL(k_sparse_rows, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, SR);
+            SKCHK(ctx, hipGetLastError());
+        }
+    }
     // ---- the three passes on the resident snapshot
     const float *d_vdes = (const float*)(res + r_vd);
     if(e > b) hipLaunchKernelGGL(k_pick_vdes, dim3((e - b + 255) / 256), dim3(256), 0, s, b, e, d.vdes_xz, (const float*)so.vdes_xz, (float*)(res + r_vd));
@@ -972,17 +1055,17 @@ int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, 
         memset(&da, 0, sizeof(da));
         da.fstate = (const uint8_t*)dev(o_fs); da.wait_ticks_left = (const int32_t*)dev(o_wt);
         da.wait_prev = (const uint8_t*)dev(o_wp); da.new_pos_xz = (const float*)(res + r_np);
-        if(turn) { da.ent_rot = (const float*)dev(o_er); da.target_dir = (const float*)dev(o_td); }
+        if(turn) { da.ent_rot = (const float*)a_er; da.target_dir = (const float*)a_td; }
         if(rg) {
-            da.range_target = (const int32_t*)dev(o_rt); da.target_range = (const float*)dev(o_rr);
-            da.target_prev_xz = (const float*)dev(o_rp); da.range_tiles_row = (const int32_t*)dev(o_row);
+            da.range_target = (const int32_t*)a_rt; da.target_range = (const float*)a_rr;
+            da.target_prev_xz = (const float*)a_rp; da.range_tiles_row = (const int32_t*)a_row;
             da.range_tiles_off = (const int32_t*)dev(o_roff); da.range_tiles = (const int16_t*)dev(o_rtil);
             da.n_range_rows = X.n_range_rows;
         }
         if(su) {
-            da.surround_target = (const int32_t*)dev(o_stgt); da.surround_query = (const uint8_t*)dev(o_sq);
-            da.surround_target_prev_xz = (const float*)dev(o_stp); da.surround_nearest_prev_xz = (const float*)dev(o_snp);
-            da.surround_dest_xz = (const float*)dev(o_sd); da.vdes_xz = d_vdes; da.out_surround_dest_xz = (float*)(res + r_sd);
+            da.surround_target = (const int32_t*)a_stgt; da.surround_query = (const uint8_t*)a_sq;
+            da.surround_target_prev_xz = (const float*)a_stp; da.surround_nearest_prev_xz = (const float*)a_snp;
+            da.surround_dest_xz = (const float*)a_sd; da.vdes_xz = d_vdes; da.out_surround_dest_xz = (float*)(res + r_sd);
         }
         rc = navhip_state_update_aux_dev(ctx, &d, &da, (uint8_t*)(res + r_st), (uint8_t*)(res + r_fl), (int32_t*)(res + r_tk), s);
         if(rc) return rc;
@@ -992,17 +1075,22 @@ int navhip_state_pass_resident(navhip_ctx *ctx, const navhip_state_pass_in *in, 
                            d.state, aux ? (const int32_t*)dev(o_wt) : (const int32_t*)nullptr,
                            (uint8_t*)(res + r_st), (uint8_t*)(res + r_fl), aux ? (int32_t*)(res + r_tk) : (int32_t*)nullptr);
         SKCHK(ctx, hipGetLastError());
+        if(su && sp && ns) {
+            hipLaunchKernelGGL(k_sparse_gather2, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, (int)ns, (const int32_t*)dev(o_units),
+                               (const float*)(res + r_sd), (float*)(res + r_sdk));
+            SKCHK(ctx, hipGetLastError());
+        }
         // results: the pageable destinations' rows are gathered into one block on the device and cross the bus once
         char *d_oblock = res + R.total;
         for(auto &o : outs) {
-            if(o.pinned) SKCHK(ctx, hipMemcpyAsync((char*)o.dst + lo * o.row, res + o.dev_off + lo * o.row, cnt * o.row, hipMemcpyDeviceToHost, s));
-            else         SKCHK(ctx, hipMemcpyAsync(d_oblock + o.h_off, res + o.dev_off + lo * o.row, cnt * o.row, hipMemcpyDeviceToDevice, s));
+            if(o.pinned) SKCHK(ctx, hipMemcpyAsync((char*)o.dst + o.lo * o.row, res + o.dev_off + o.lo * o.row, o.cnt * o.row, hipMemcpyDeviceToHost, s));
+            else         SKCHK(ctx, hipMemcpyAsync(d_oblock + o.h_off, res + o.dev_off + o.lo * o.row, o.cnt * o.row, hipMemcpyDeviceToDevice, s));
         }
         if(pack_out) SKCHK(ctx, hipMemcpyAsync(h_out, d_oblock, pack_out, hipMemcpyDeviceToHost, s));
     }
     SKCHK(ctx, hipStreamSynchronize(s));
     if(e > b)
-        for(auto &o : outs) if(!o.pinned) memcpy((char*)o.dst + lo * o.row, h_out + o.h_off, cnt * o.row);
+        for(auto &o : outs) if(!o.pinned) memcpy((char*)o.dst + o.lo * o.row, h_out + o.h_off, o.cnt * o.row);
     return NAVHIP_OK;
 }
 
@@ -1103,14 +1191,17 @@ static int sk_arrival_settle(navhip_ctx *ctx, const navhip_world *w, const navhi
 {
     if(!ctx || !w || !in || !out || in->nq < 0 || in->n_zones < 0 || w->n_ents < 0) return NAVHIP_ERR_INVALID;
     if(in->nq == 0) return NAVHIP_OK;
+    const bool count_here = in->nsettled == nullptr;          // (adjacent_settled_count on the resident snapshot too)
+    if(count_here && !use_resident) return NAVHIP_ERR_INVALID;
     navhip_world rw; navhip_step_out rso;
-    const bool resident = use_resident && nh_async_resident(ctx, &rw, &rso) && rw.n_ents == w->n_ents && rw.vel_xz && rw.radius;
+    const bool resident = use_resident && nh_async_resident(ctx, &rw, &rso) && rw.n_ents == w->n_ents && rw.vel_xz && rw.radius
+                       && (!count_here || (rw.pos_xz && rw.flags && rw.state));
     if(use_resident && !resident) {
         ctx->last_error = "navhip_arrival_settle_resident: no completed host-buffer step of this size is resident on the device";
         return NAVHIP_ERR_INVALID;
     }
     if((!resident && (!w->vel_xz || !w->radius)) || !in->zones || in->n_zones < 1 || !in->uid || !in->zone || !in->new_pos_xz
-    || !in->nsettled || !in->substate || !in->sink_valid || !in->sink_xz || !in->order_pos_xz || !in->progress_anchor_xz
+    || !in->substate || !in->sink_valid || !in->sink_xz || !in->order_pos_xz || !in->progress_anchor_xz
     || !in->progress_anchored || !in->stuck || !out->settle || !out->substate || !out->progress_anchor_xz
     || !out->progress_anchored || !out->stuck)
         return NAVHIP_ERR_INVALID;
@@ -1129,45 +1220,74 @@ static int sk_arrival_settle(navhip_ctx *ctx, const navhip_world *w, const navhi
     SKCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     sk_arena A;
-    const size_t o_vel = A.take(resident ? 0 : n * 8), o_rad = A.take(resident ? 0 : n * 4), o_z = A.take(nz * sizeof(navhip_arrival_zone)),
+    const size_t o_vel = A.take(resident ? 0 : n * 8), o_rad = A.take(resident ? 0 : n * 4);
+    // (the inputs of the arm from here to in_end, the results from r_set to the end: each region crosses the bus once)
+    const size_t o_z = A.take(nz * sizeof(navhip_arrival_zone)),
                  o_sl = A.take(n_slots * 8 + 8), o_ring = A.take(n_slots * 4 + 4), o_keys = A.take(n_keys * 8 + 8),
-                 o_uid = A.take(nq * 4), o_zone = A.take(nq * 4), o_np = A.take(nq * 8), o_ns = A.take(nq * 4),
+                 o_uid = A.take(nq * 4), o_zone = A.take(nq * 4), o_np = A.take(nq * 8), o_ns = A.take(count_here ? 0 : nq * 4),
                  o_sub = A.take(nq), o_sv = A.take(nq), o_sink = A.take(nq * 8), o_ord = A.take(nq * 8),
-                 o_anc = A.take(nq * 8), o_and = A.take(nq), o_stk = A.take(nq * 4),
-                 r_set = A.take(nq), r_sub = A.take(nq), r_anc = A.take(nq * 8), r_and = A.take(nq), r_stk = A.take(nq * 4);
+                 o_anc = A.take(nq * 8), o_and = A.take(nq), o_stk = A.take(nq * 4), in_end = A.total,
+                 o_q = A.take(count_here ? nq * 8 : 0), o_cnt = A.take(count_here ? nq * 4 : 0),
+                 o_ids = A.take(count_here ? nq * SK_QUERY_MAX * 4 : 0),
+                 r_set = A.take(nq), r_sub = A.take(nq), r_anc = A.take(nq * 8), r_and = A.take(nq), r_stk = A.take(nq * 4),
+                 r_ns = A.take(count_here ? nq * 4 : 0);
     char *base;
     int rc = navhip_stage_reserve(ctx, SK_SLOT, A.total, (void**)&base);
     if(rc) return rc;
-#define UP(off, src, bytes) if((bytes) > 0) SKCHK(ctx, hipMemcpyAsync(base + (off), (src), (bytes), hipMemcpyHostToDevice, s))
-    if(!resident) { UP(o_vel, w->vel_xz, n * 8);   UP(o_rad, w->radius, n * 4); }
-    UP(o_z, in->zones, nz * sizeof(navhip_arrival_zone));
-    UP(o_sl, in->slots_xz, n_slots * 8);   UP(o_ring, in->slot_ring, n_slots * 4);   UP(o_keys, in->region_keys, n_keys * 8);
-    UP(o_uid, in->uid, nq * 4);   UP(o_zone, in->zone, nq * 4);   UP(o_np, in->new_pos_xz, nq * 8);   UP(o_ns, in->nsettled, nq * 4);
-    UP(o_sub, in->substate, nq);   UP(o_sv, in->sink_valid, nq);   UP(o_sink, in->sink_xz, nq * 8);   UP(o_ord, in->order_pos_xz, nq * 8);
-    UP(o_anc, in->progress_anchor_xz, nq * 8);   UP(o_and, in->progress_anchored, nq);   UP(o_stk, in->stuck, nq * 4);
-#undef UP
+    struct up { size_t off; const void *src; size_t bytes; };
+    const up ups[] = {{o_z, in->zones, nz * sizeof(navhip_arrival_zone)}, {o_sl, in->slots_xz, n_slots * 8}, {o_ring, in->slot_ring, n_slots * 4},
+                      {o_keys, in->region_keys, n_keys * 8}, {o_uid, in->uid, nq * 4}, {o_zone, in->zone, nq * 4}, {o_np, in->new_pos_xz, nq * 8},
+                      {o_ns, in->nsettled, count_here ? 0 : nq * 4}, {o_sub, in->substate, nq}, {o_sv, in->sink_valid, nq},
+                      {o_sink, in->sink_xz, nq * 8}, {o_ord, in->order_pos_xz, nq * 8}, {o_anc, in->progress_anchor_xz, nq * 8},
+                      {o_and, in->progress_anchored, nq}, {o_stk, in->stuck, nq * 4}};
+    struct down { size_t off; void *dst; size_t bytes; };
+    const down downs[] = {{r_set, out->settle, nq}, {r_sub, out->substate, nq}, {r_anc, out->progress_anchor_xz, nq * 8},
+                          {r_and, out->progress_anchored, nq}, {r_stk, out->stuck, nq * 4},
+                          {r_ns, out->nsettled, count_here && out->nsettled ? nq * 4 : 0}};
+    // a context with an asynchronous step path owns page-locked slabs: the small arrays are packed into them
+    char *h_in = nullptr, *h_out = nullptr;
+    const bool packed = nh_async_slabs(ctx, in_end - o_z, A.total - r_set, &h_in, &h_out) == NAVHIP_OK;
+    if(!resident) {
+        SKCHK(ctx, hipMemcpyAsync(base + o_vel, w->vel_xz, n * 8, hipMemcpyHostToDevice, s));
+        SKCHK(ctx, hipMemcpyAsync(base + o_rad, w->radius, n * 4, hipMemcpyHostToDevice, s));
+    }
+    if(packed) {
+        for(const up &u : ups) if(u.bytes) memcpy(h_in + (u.off - o_z), u.src, u.bytes);
+        SKCHK(ctx, hipMemcpyAsync(base + o_z, h_in, in_end - o_z, hipMemcpyHostToDevice, s));
+    }else
+        for(const up &u : ups) if(u.bytes) SKCHK(ctx, hipMemcpyAsync(base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, s));
     navhip_world d = *w;
     // (the snapshot the velocity half left on the device is read in place: movestate.velocity and the radii are the tick's)
     d.vel_xz = resident ? rw.vel_xz : (const float*)(base + o_vel); d.radius = resident ? rw.radius : (const float*)(base + o_rad);
+    if(count_here) {
+        navhip_world dq = rw;
+        dq.grid_xmin = w->grid_xmin; dq.grid_xmax = w->grid_xmax; dq.grid_zmin = w->grid_zmin; dq.grid_zmax = w->grid_zmax;
+        hipLaunchKernelGGL(k_gather_query, dim3((in->nq + 255) / 256), dim3(256), 0, s, in->nq, (const int32_t*)(base + o_uid), rw.pos_xz, (float*)(base + o_q));
+        rc = nh_spatial_query_dev(ctx, &dq, (const float*)(base + o_q), in->nq, SK_QUERY_R, SK_QUERY_MAX, (int32_t*)(base + o_cnt),
+                                  (uint32_t*)(base + o_ids), s);
+        if(rc) return rc;
+        hipLaunchKernelGGL(k_settled_count, dim3((in->nq + 15) / 16), dim3(256), 0, s, in->nq, (const int32_t*)(base + o_uid),
+                           rw.pos_xz, rw.radius, rw.flags, rw.state, (const int32_t*)(base + o_cnt), (const uint32_t*)(base + o_ids),
+                           (int32_t*)(base + r_ns));
+        SKCHK(ctx, hipGetLastError());
+    }
     navhip_settle_in di = *in;
     di.zones = (const navhip_arrival_zone*)(base + o_z); di.slots_xz = (const float*)(base + o_sl);
     di.slot_ring = (const int32_t*)(base + o_ring); di.region_keys = (const uint64_t*)(base + o_keys);
     di.uid = (const int32_t*)(base + o_uid); di.zone = (const int32_t*)(base + o_zone);
-    di.new_pos_xz = (const float*)(base + o_np); di.nsettled = (const int32_t*)(base + o_ns);
+    di.new_pos_xz = (const float*)(base + o_np); di.nsettled = (const int32_t*)(base + (count_here ? r_ns : o_ns));
     di.substate = (const uint8_t*)(base + o_sub); di.sink_valid = (const uint8_t*)(base + o_sv);
     di.sink_xz = (const float*)(base + o_sink); di.order_pos_xz = (const float*)(base + o_ord);
     di.progress_anchor_xz = (const float*)(base + o_anc); di.progress_anchored = (const uint8_t*)(base + o_and);
     di.stuck = (const int32_t*)(base + o_stk);
     navhip_settle_out dout = {(uint8_t*)(base + r_set), (uint8_t*)(base + r_sub), (float*)(base + r_anc),
-                              (uint8_t*)(base + r_and), (int32_t*)(base + r_stk)};
+                              (uint8_t*)(base + r_and), (int32_t*)(base + r_stk), nullptr};
     rc = navhip_arrival_settle_dev(ctx, &d, &di, &dout, s);
     if(rc) return rc;
-    SKCHK(ctx, hipMemcpyAsync(out->settle, base + r_set, nq, hipMemcpyDeviceToHost, s));
-    SKCHK(ctx, hipMemcpyAsync(out->substate, base + r_sub, nq, hipMemcpyDeviceToHost, s));
-    SKCHK(ctx, hipMemcpyAsync(out->progress_anchor_xz, base + r_anc, nq * 8, hipMemcpyDeviceToHost, s));
-    SKCHK(ctx, hipMemcpyAsync(out->progress_anchored, base + r_and, nq, hipMemcpyDeviceToHost, s));
-    SKCHK(ctx, hipMemcpyAsync(out->stuck, base + r_stk, nq * 4, hipMemcpyDeviceToHost, s));
+    if(packed) SKCHK(ctx, hipMemcpyAsync(h_out, base + r_set, A.total - r_set, hipMemcpyDeviceToHost, s));
+    else for(const down &o : downs) if(o.bytes) SKCHK(ctx, hipMemcpyAsync(o.dst, base + o.off, o.bytes, hipMemcpyDeviceToHost, s));
     SKCHK(ctx, hipStreamSynchronize(s));
+    if(packed) for(const down &o : downs) if(o.bytes) memcpy(o.dst, h_out + (o.off - r_set), o.bytes);
     return NAVHIP_OK;
 }
 

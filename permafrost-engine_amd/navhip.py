@@ -383,7 +383,7 @@ class StateAuxIn(C.Structure):
                 ("range_tiles", C.c_void_p), ("n_range_rows", C.c_int32),
                 ("surround_target", C.c_void_p), ("surround_query", C.c_void_p), ("surround_target_prev_xz", C.c_void_p),
                 ("surround_nearest_prev_xz", C.c_void_p), ("surround_dest_xz", C.c_void_p), ("vdes_xz", C.c_void_p),
-                ("out_surround_dest_xz", C.c_void_p)]
+                ("out_surround_dest_xz", C.c_void_p), ("sparse_units", C.c_void_p), ("n_sparse", C.c_int32)]
 
 
 class GateIn(C.Structure):
@@ -423,7 +423,7 @@ class SettleIn(C.Structure):
 class SettleOut(C.Structure):
     """navhip_settle_out, include/navhip.h"""
     _fields_ = [("settle", C.c_void_p), ("substate", C.c_void_p), ("progress_anchor_xz", C.c_void_p),
-                ("progress_anchored", C.c_void_p), ("stuck", C.c_void_p)]
+                ("progress_anchored", C.c_void_p), ("stuck", C.c_void_p), ("nsettled", C.c_void_p)]
 
 
 _SIGS.update({

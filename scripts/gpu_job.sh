@@ -60,6 +60,8 @@ smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smo
 ranks2) NAVHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; tail -c 400 $OUT/bench_2ranks_gloo.json ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log
       timeout 600 python tests/tools/fuzz_gpu.py --state > $OUT/fuzz_state.log 2>&1; tail -2 $OUT/fuzz_state.log ;;
+statetests) timeout 900 python -m pytest tests/test_state_gpu.py tests/test_state_binding_gpu.py tests/test_binding_gpu.py -m gpu -q > $OUT/pytest_state.log 2>&1; tail -8 $OUT/pytest_state.log ;;
+statepass16) timeout 400 python tests/tools/bench_state_pass.py --threads 16 > $OUT/state_pass_16threads.json 2> $OUT/state_pass_16threads.err; tail -c 700 $OUT/state_pass_16threads.json ;;
 statepass) timeout 400 python tests/tools/bench_state_pass.py > $OUT/state_pass.json 2> $OUT/state_pass.err; tail -c 900 $OUT/state_pass.json; tail -2 $OUT/state_pass.err
        timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/statepass -o s --output-format csv -- python tests/tools/bench_state_pass.py --reps 20 > $OUT/state_pass_under_prof.json 2> $OUT/statepass_prof.err
        f=$(find $OUT/statepass -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|k_heading_gate|k_state_update|k_state_aux|k_settled_count|k_arrival_settle|k_spatial" $f | cut -c1-200 ;;

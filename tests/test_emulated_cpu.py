@@ -112,7 +112,7 @@ def test_reference_binding_drives_the_emulated_library():
     tail = "\n".join(r.stdout.strip().splitlines()[-25:])
     assert r.returncode == 0, tail
     last = r.stdout.strip().splitlines()[-1]
-    assert "15 passed" in last, tail
+    assert "16 passed" in last, tail
 
 
 @pytest.mark.parametrize("extra", [["--pipeline-fields", "--shared", "--flow-velocities"], ["--straddle", "all"]])

@@ -294,3 +294,29 @@ def test_state_pass_on_the_resident_snapshot_of_the_velocity_pass():
     finally:
         pfref.RefNav.hip_shutdown()
         pfref.RefMove.unload()
+
+
+def test_resident_pass_of_a_world_with_every_arm_of_the_switch():
+    """The whole state half as the benchmark runs it (tests/tools/bench_state_pass.py, a smaller world): the velocity pass,
+    then move_hip_state_work on its resident snapshot -- the arrays of the TURNING / ENTER_ENTITY_RANGE / SURROUND_ENTITY
+    arms as SPARSE rows (navhip_state_aux_in.sparse_units), the units of two active arrival zones counted and settled in
+    ONE call on the same snapshot (navhip_arrival_settle_resident, nsettled NULL) -- and the host-buffer pass with a row
+    per entity: every unit's next state and flags == entity_compute_update given the device's velocities, both ways;
+    what the device's settle rule leaves in the units' arrival state and the surround arm's position == the reference's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu = os.path.basename(os.environ.get("NAVHIP_LIB", "")) == "_navhip_emu.so"
+    size = ["--agents", "3000", "--chunks", "4", "--flocks", "8", "--end", "400"] if emu else ["--agents", "20000", "--chunks", "8", "--flocks", "16"]
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "bench_state_pass.py"), "--reps", "1", "--threads", "4",
+                        "--arms-scale", "5"] + size, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "error" not in d, d
+    assert d["host_buffers"]["identical"] and d["resident"]["identical"], d
+    assert d["resident_passes"] == 2 and d["decided_on_device"] == 1.0
+    assert all(d["slab_mix"][k] >= 5 for k in ("1", "5", "6", "7", "8")), d["slab_mix"]      # every arm among the work items
+    decided, settled, differ, gate_host = d["settle_stats"]
+    assert decided > 50 and settled > 5 and differ == 0 and d["surround_differ"] == 0

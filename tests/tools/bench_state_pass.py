@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--threads", type=int, default=8, help="host threads of the binding's fill / scatter loops")
     ap.add_argument("--plain", action="store_true", help="MOVING / ARRIVED / WAITING units only (round 4's world)")
+    ap.add_argument("--end", type=int, default=0, help="work items [0, end) only (a slab; the emulator steps ~30 agents a second)")
+    ap.add_argument("--arms-scale", type=float, default=1.0, help="multiplies the share of ENTER_ENTITY_RANGE / SURROUND_ENTITY units")
     args = ap.parse_args()
     import numpy as np
     from oracle import pfref
@@ -61,8 +63,9 @@ def main():
         state[(u >= 0.28) & (u < 0.31)] = 7   # STATE_TURNING
         # (the two arms with per-unit nav queries on the host -- the reference's own, 30-90 us each -- in the numbers an
         # army has them: a garrison order, a harvest / attack group)
-        state[(u >= 0.31) & (u < 0.32)] = 6   # STATE_ENTER_ENTITY_RANGE
-        state[(u >= 0.32) & (u < 0.323)] = 5  # STATE_SURROUND_ENTITY
+        a6, a5 = 0.31 + 0.01 * args.arms_scale, 0.31 + 0.013 * args.arms_scale
+        state[(u >= 0.31) & (u < a6)] = 6     # STATE_ENTER_ENTITY_RANGE
+        state[(u >= a6) & (u < a5)] = 5       # STATE_SURROUND_ENTITY
         fstate = ((rng.rand(N) < 0.3) * 1 | (rng.rand(N) < 0.7) * 2 | (rng.rand(N) < 0.7) * 4 | (rng.rand(N) < 0.5) * 8
                   | (rng.rand(N) < 0.5) * 16).astype(np.uint8)
         ticks = rng.choice([1, 2, 3, 40], N).astype(np.int32)
@@ -137,7 +140,8 @@ def main():
         mix = {"arriving_to_cell": int((state == 8).sum()), "formation": int(((state <= 1) & (fstate & 1 > 0)).sum()),
                "turning": int((state == 7).sum()), "enter_range": int((state == 6).sum()), "surround": int((state == 5).sum()),
                "arrival_zone_units": int(np.isin(ag["flock"], list(zones)).sum())}
-    out = {"work_items": N, "flocks": K, "chunks": W, "unit_mix": mix}
+    M = args.end if 0 < args.end < N else N
+    out = {"work_items": M, "flocks": K, "chunks": W, "unit_mix": mix}
     try:
         if not nav.hip_init():
             out["error"] = "no device"
@@ -145,11 +149,11 @@ def main():
             mv.hip_threads(args.threads)
             # the velocity pass of the tick on the device; the reference's state pass GIVEN those velocities, one core
             set_inputs()                 # (the arrival state of the units feeds the velocity pass too)
-            assert mv.bench_hip(vdes) is not None
+            assert mv.bench_hip(vdes, end=M) is not None
             vel, vd = mv.get_out()
             set_inputs()
             t0 = time.perf_counter()
-            ref_state, ref_flags = mv.state_update(vel, vd)
+            ref_state, ref_flags = mv.state_update(vel, vd, end=M)
             out["cpu_ms_per_tick_1core"] = (time.perf_counter() - t0) * 1e3
             # (a) the host-buffer pass (every array travels), (b) the pass on the resident snapshot of the velocity pass
             for name, resident in (("host_buffers", False), ("resident", True)):
@@ -158,10 +162,10 @@ def main():
                 for _ in range(args.reps + 1):
                     if resident:
                         set_inputs()
-                        assert mv.bench_hip(vdes) is not None
+                        assert mv.bench_hip(vdes, end=M) is not None
                     set_inputs()
-                    st, fl, dv = mv.state_update_hip(vel, vd)
-                    same = same and bool(np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags))
+                    st, fl, dv = mv.state_update_hip(vel, vd, end=M)
+                    same = same and bool(np.array_equal(st[:M], ref_state[:M]) and np.array_equal(fl[:M], ref_flags[:M]))
                     if os.environ.get("BSP_DEBUG") and not same:
                         bad = np.flatnonzero((st != ref_state) | (fl != ref_flags))
                         sys.stderr.write("%s: %s\n" % (name, [(int(i), int(state[i]), int(fstate[i]), int(st[i]), int(ref_state[i]), int(fl[i]), int(ref_flags[i]), int(dv[i]), int(ag["flock"][i])) for i in bad[:12]]))
@@ -169,14 +173,15 @@ def main():
                     if times[-1] == min(times):
                         best_parts = mv.hip_state_times()
                 out[name] = {"identical": same, "hip_ms_per_tick": min(times[1:]) * 1e3, "hip_ms_per_tick_all": [t * 1e3 for t in times[1:]],
-                             "hip_ms_parts": best_parts, "decided_on_device": float(((dv & 0x80) == 0).mean())}
+                             "hip_ms_parts": best_parts, "decided_on_device": float(((dv[:M] & 0x80) == 0).mean())}
             mv.hip_resident_state_pass(False)
             out["resident_passes"] = mv.hip_resident_passes()
             out["identical"] = out["host_buffers"]["identical"] and out["resident"]["identical"]
             out["decided_on_device"] = out["resident"]["decided_on_device"]
             out["hip_ms_per_tick"] = out["resident"]["hip_ms_per_tick"]
             out["host_threads"] = args.threads
-            out["to_arrived"], out["to_waiting"] = int(((st == 2) & (state != 2)).sum()), int(((st == 4) & (state != 4)).sum())
+            out["to_arrived"], out["to_waiting"] = int(((st[:M] == 2) & (state[:M] != 2)).sum()), int(((st[:M] == 4) & (state[:M] != 4)).sum())
+            out["slab_mix"] = {str(k): int((state[:M] == k).sum()) for k in (1, 5, 6, 7, 8)}
             out["speedup_vs_1core"] = out["cpu_ms_per_tick_1core"] / out["hip_ms_per_tick"]
             if not args.plain:
                 out["settle_stats"] = list(mv.hip_settle_stats())
