@@ -101,9 +101,41 @@ def csrc_sha(d=None, files=None):
     return h.hexdigest()[:12]
 
 
+def stamp_kernels(stamp):
+    """The kernel names a profiles/*.json stamp holds numbers for (template arguments dropped)."""
+    ks = stamp.get("kernels") or stamp.get("per_kernel_fetch_bytes_raw") or {}
+    return sorted({k.split("<")[0] for k in ks})
+
+
+def stamp_units(files, kernels, d=None):
+    """The sources out of `files` that can change the measured `kernels`: every header, every translation
+    unit that defines or names one of them, and every unit that defines no kernel at all (host code that
+    schedules the launches).  A unit whose own kernels were not measured and that names no measured kernel
+    (state_kernels.hip for the tick's counters) cannot: each .hip is compiled by itself."""
+    d = d or os.path.join(ROOT, "permafrost-engine_amd", "csrc")
+    if not kernels:
+        return sorted(files)
+    import re
+    names = re.compile(r"\b(" + "|".join(re.escape(k) for k in kernels) + r")\b")
+    out = []
+    for f in sorted(files):
+        if f.endswith(".hip"):
+            try:
+                text = _strip_comments(open(os.path.join(d, f), encoding="utf-8", errors="replace").read())
+            except OSError:
+                out.append(f)                  # (a covered file that is gone: csrc_sha says so)
+                continue
+            if "__global__" in text and not names.search(text):
+                continue
+        out.append(f)
+    return out
+
+
 def stamp_is_current(stamp):
-    """A profiles/*.json stamp {csrc_sha, files} against this tree."""
-    return bool(stamp.get("csrc_sha")) and stamp.get("csrc_sha") == csrc_sha(files=stamp.get("files"))
+    """A profiles/*.json stamp {csrc_sha, files[, covers]} against this tree.  `covers` (newer stamps): the
+    subset of `files` stamp_units() found able to change the measured kernels -- the sha is over those."""
+    files = stamp.get("covers") or stamp.get("files")
+    return bool(stamp.get("csrc_sha")) and stamp.get("csrc_sha") == csrc_sha(files=files)
 
 
 def usable_cores():

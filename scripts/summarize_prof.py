@@ -108,7 +108,7 @@ def main():
         res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py "
                          "--steps 100 --warmup 5; per kernel and TICK the mean over the last %d ticks (the profiled ticks "
                          "at the end of the run, which bench.py's roofline times)" % LAST,
-               "csrc_sha": sha, "files": bench.csrc_files(),
+               "files": bench.csrc_files(),
                "corrections": "both counters are KB (x1024); gfx950 FETCH_SIZE counts 128-B requests at 64 B: x2 "
                               "('corr'); WRITE_SIZE calibrated on k_field_bfs, which writes exactly 4096 B per field "
                               "with 16 B/lane coalesced stores",
@@ -123,6 +123,8 @@ def main():
             res[name + "_fetch_bytes_corr"] = 2.0 * f_raw
             res[name + "_write_bytes_corr"] = w_raw * (wcal or 1.0)
             res[name + "_bytes_per_launch"] = 2.0 * f_raw + w_raw * (wcal or 1.0)
+        res["covers"] = bench.stamp_units(res["files"], bench.stamp_kernels(res))
+        res["csrc_sha"], res["csrc_sha_all_files"] = bench.csrc_sha(files=res["covers"]), sha
         json.dump(res, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
         json.dump(res, open(os.path.join(dst, pre + "traffic_%s.json" % suf), "w"), indent=1)
         print({k: v for k, v in res.items() if k.endswith("_per_launch")}, "write calibration", wcal)
@@ -144,7 +146,9 @@ def main():
             out[k] = dd
         doc = {"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES on "
                          "bench.py --steps 100 --warmup 5; per kernel and TICK (a kernel launched twice a tick counts "
-                         "twice): the mean over the last %d ticks (early ticks: 6-11)" % LAST, "csrc_sha": sha, "files": bench.csrc_files(), "kernels": out}
+                         "twice): the mean over the last %d ticks (early ticks: 6-11)" % LAST, "files": bench.csrc_files(), "kernels": out}
+        doc["covers"] = bench.stamp_units(doc["files"], bench.stamp_kernels(doc))
+        doc["csrc_sha"], doc["csrc_sha_all_files"] = bench.csrc_sha(files=doc["covers"]), sha
         json.dump(doc, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)
         json.dump(doc, open(os.path.join(dst, pre + "sq_counters_%s.json" % suf), "w"), indent=1)
         for k in sorted(out, key=lambda k: -out[k].get("SQ_INSTS_VALU", 0))[:8]:
