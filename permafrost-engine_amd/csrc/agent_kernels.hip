@@ -421,26 +421,7 @@ __device__ int filter_garrisoned_wave(const nh_grid &G, uint32_t *ids, int count
 // ---------------------------------------------------------------------------------------------
 // cohesion_force (movement.c:1653)
 // ---------------------------------------------------------------------------------------------
-// float t = (len - 50.0f*0.75) / 50.0f of movement.c:1668 (the reference evaluates it in double and
-// rounds to float).  For len >= 16 the f32 subtraction is exact and the division by 50 as
-// reciprocal multiply + one FMA correction (Markstein) reproduces the double-then-float result for
-// EVERY float in [16, 8192) (checked exhaustively on the CPU); beyond that the weight is 0 anyway.
-__device__ __forceinline__ float cohesion_t_f32(float len)
-{
-    const float r50f = 1.0f / 50.0f;
-    const float x = len - 37.5f;
-    const float q0 = x * r50f;
-    return __builtin_fmaf(__builtin_fmaf(-q0, 50.0f, x), r50f, q0);
-}
-
-// the same through double, for len < 16 where the f32 subtraction may round
-__device__ __forceinline__ float cohesion_t_f64(float len)
-{
-    const double r50 = 1.0 / 50.0;
-    const double x = (double)len - (double)50.0f * 0.75;
-    const double q0 = x * r50;
-    return (float)__builtin_fma(__builtin_fma(-q0, 50.0, x), r50, q0);
-}
+// (cohesion_t_f32 / cohesion_t_f64 -- float t = (len - 50.0f*0.75) / 50.0f of movement.c:1668 -- live in agent_math.h)
 
 #define COH_BINS 257       /* 256 Morton blocks + 1 bin for members that take no cohesion force */
 // k_coh_plan: wave_off[f] = number of 16-member (COH_APW) waves of the flocks before f (exclusive

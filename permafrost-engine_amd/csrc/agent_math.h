@@ -427,6 +427,32 @@ NH_FN float exp_f32_magic(float a, const double *tab)
 }
 
 // ---------------------------------------------------------------------------------------------
+// cohesion_force (movement.c:1653): the weight's argument
+// ---------------------------------------------------------------------------------------------
+// float t = (len - 50.0f*0.75) / 50.0f of movement.c:1668 (the reference evaluates it in double and
+// rounds to float).  For len >= 16 the f32 subtraction is exact and the division by 50 as
+// reciprocal multiply + one FMA correction (Markstein) reproduces the double-then-float result for
+// EVERY float in [16, 8192) (swept on the device: tests/test_mathsweep_gpu.py, MS_COH_T_F32); beyond
+// that the weight is 0 anyway.
+NH_FN float cohesion_t_f32(float len)
+{
+    const float r50f = 1.0f / 50.0f;
+    const float x = len - 37.5f;
+    const float q0 = x * r50f;
+    return nh_fmaf(nh_fmaf(-q0, 50.0f, x), r50f, q0);
+}
+
+// the same through double, for len < 16 where the f32 subtraction may round (every float in [0, 16):
+// MS_COH_T_F64)
+NH_FN float cohesion_t_f64(float len)
+{
+    const double r50 = 1.0 / 50.0;
+    const double x = (double)len - (double)50.0f * 0.75;
+    const double q0 = x * r50;
+    return (float)nh_fma(nh_fma(-q0, 50.0, x), r50, q0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // movement states / steering terms
 // ---------------------------------------------------------------------------------------------
 NH_FN bool state_is_still(int s)
