@@ -698,7 +698,9 @@ def main():
                        "requests": "reference planner fixture" if "fixture" in request_source else "numpy stand-in",
                        "has_dest_los": "device lookup" if "device lookup" in los_source else "0",
                        "initial_velocities": "flow aligned" if "flow" in velocity_source else "N(0,0.35)",
-                       "fields_ahead": bool(fields_ahead), "tick_driver": tick_driver},
+                       "fields_ahead": bool(fields_ahead), "tick_driver": tick_driver,
+                       "library": ("NAVHIP_LIB override: " + os.path.basename(os.environ["NAVHIP_LIB"]))
+                                  if os.environ.get("NAVHIP_LIB") else "libnavhip.so (in-tree)"},
             "roofline": roof(dom),
             "cpu_baseline": cpu,
             "roofline_secondary": {k: v for k, v in roof(other).items()

@@ -131,6 +131,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NavHipError("libnavhip.so not built (run __graft_entry__.build()); "
                               "there is no CPU fallback")
+        if os.environ.get("NAVHIP_LIB"):
+            # never silent: a development / test build (an A/B variant, the host emulator of tests/hostsim) stands
+            # in for the in-tree library -- bench.py names it in config.library
+            import sys
+            sys.stderr.write("navhip: NAVHIP_LIB=%s replaces the in-tree libnavhip.so\n" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, (rt, at) in _SIGS.items():
             if os.environ.get("NAVHIP_LIB") and not hasattr(L, name):

@@ -9,6 +9,7 @@
 #   smoke   __graft_entry__.smoke()
 #   ranks2  bench.py --gpus 2 under torchrun, both ranks on the one GPU, gloo (a plumbing check, not a measurement)
 #   fuzz    tests/tools/fuzz_gpu.py
+#   fuzzmore  the same sweeps over cases the committed logs have not seen (FUZZ_FIRST, FUZZ_N)
 #   statepass tests/tools/bench_state_pass.py (the state half of the movement tick through the binding) + its kernel stats
 #   hostov  scripts/host_overhead.py (enqueue time per tick: python / c / c + graph) + rank_cost_probe --strong
 #   ticktests  tests/test_tick_gpu.py only
@@ -60,6 +61,9 @@ smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smo
 ranks2) NAVHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; tail -c 400 $OUT/bench_2ranks_gloo.json ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log
       timeout 600 python tests/tools/fuzz_gpu.py --state > $OUT/fuzz_state.log 2>&1; tail -2 $OUT/fuzz_state.log ;;
+fuzzmore) # fresh cases: FUZZ_FIRST (default 24) .. +FUZZ_N (default 72) of the world sweep, seeds 124+.. of the settle sweep
+      timeout 240 python tests/tools/fuzz_gpu.py ${FUZZ_N:-72} --first ${FUZZ_FIRST:-24} > $OUT/fuzz_more.log 2>&1; tail -2 $OUT/fuzz_more.log
+      timeout 180 python tests/tools/fuzz_gpu.py ${FUZZ_N:-72} --first $(( 100 + ${FUZZ_FIRST:-24} )) --state > $OUT/fuzz_state_more.log 2>&1; tail -2 $OUT/fuzz_state_more.log ;;
 statetests) timeout 900 python -m pytest tests/test_state_gpu.py tests/test_state_binding_gpu.py tests/test_binding_gpu.py -m gpu -q > $OUT/pytest_state.log 2>&1; tail -8 $OUT/pytest_state.log ;;
 statepass16) timeout 400 python tests/tools/bench_state_pass.py --threads 16 > $OUT/state_pass_16threads.json 2> $OUT/state_pass_16threads.err; tail -c 700 $OUT/state_pass_16threads.json ;;
 statepass) timeout 400 python tests/tools/bench_state_pass.py > $OUT/state_pass.json 2> $OUT/state_pass.err; tail -c 900 $OUT/state_pass.json; tail -2 $OUT/state_pass.err

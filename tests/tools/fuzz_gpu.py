@@ -16,9 +16,9 @@ from oracle import navoracle                          # noqa: E402
 from tests import cases                               # noqa: E402
 
 
-def main(n_cases=24):
+def main(n_cases=24, first=0):
     bad = 0
-    for case in range(n_cases):
+    for case in range(first, first + n_cases):
         rng = np.random.RandomState(1000 + case)
         W = int(rng.choice([2, 3, 4]))
         frac = float(rng.choice([0.1, 0.2, 0.35]))
@@ -68,7 +68,7 @@ def main(n_cases=24):
     return 1 if bad else 0
 
 
-def state_sweep(n_cases=24):
+def state_sweep(n_cases=24, first=100):
     """The settle rule of the arrival overlay (navhip_arrival_settle) against the reference's own G_Arrival_ShouldSettle
     (oracle/_ref) over many seeds of tests/test_state_gpu.py's zone world: answers and the unit state left behind."""
     from oracle import pfref
@@ -77,7 +77,7 @@ def state_sweep(n_cases=24):
         print("state sweep: oracle/_ref is not present")
         return 0
     bad = 0
-    for seed in range(100, 100 + n_cases):
+    for seed in range(first, first + n_cases):
         grid, nav, zones, units = T._zone_world(seed=seed)
         ref, keys, afters = [], [], []
         for z, u in zip(zones, units):
@@ -99,6 +99,12 @@ def state_sweep(n_cases=24):
 
 
 if __name__ == "__main__":
-    if "--state" in sys.argv:
-        sys.exit(state_sweep())
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 24))
+    import argparse
+    ap = argparse.ArgumentParser(description="cases first .. first + n_cases - 1 of either sweep")
+    ap.add_argument("n_cases", nargs="?", type=int, default=24)
+    ap.add_argument("--first", type=int, default=None, help="first case / seed (default 0; --state: 100)")
+    ap.add_argument("--state", action="store_true", help="the settle rule against the reference build")
+    a = ap.parse_args()
+    if a.state:
+        sys.exit(state_sweep(a.n_cases, 100 if a.first is None else a.first))
+    sys.exit(main(a.n_cases, 0 if a.first is None else a.first))
