@@ -17,6 +17,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          # no FMA contraction, IEEE division/sqrt, denormals kept
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-fno-gpu-flush-denormals-to-zero",
+         # the SLP vectoriser pairs scalar f32 chains into v_pk_* instructions whose operands must sit in aligned
+         # register pairs: the moves that assemble and split the pairs cost more than the packing saves (measured,
+         # profiles/r05_ab_compiler_flags.txt: tick 0.302 -> 0.296 ms, crowded world 4.78 -> 4.69).  Where packed math
+         # pays (k_cohesion's distance -> weight part) the source says so itself with two-element vector types.
+         "-fno-slp-vectorize",
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

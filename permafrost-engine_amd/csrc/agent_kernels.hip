@@ -588,6 +588,16 @@ __global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int
 #endif
 #define COH_G   (8 * COH_NP)
 
+// an empty statement the optimiser cannot see through: keeps two scalar chains from being paired into packed math
+#ifndef COH_SPLIT_SUMS
+#define COH_SPLIT_SUMS 1      /* 0: let the compiler pair the two sums (A/B) */
+#endif
+#if defined(NH_HOSTSIM) || !COH_SPLIT_SUMS
+__device__ __forceinline__ float coh_keep(float x) { return x; }
+#else
+__device__ __forceinline__ float coh_keep(float x) { asm volatile("" : "+v"(x)); return x; }
+#endif
+
 __device__ __forceinline__ float quad_bcast(float v, int sub)
 {
     // quad_perm:[sub,sub,sub,sub]
@@ -676,8 +686,10 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
             const float tx = h ? px.y : px.x, tz = h ? pz.y : pz.x;
 #pragma unroll
             for(int sb = 0; sb < 4; sb++) {
-                comx = comx + quad_bcast(tx, sb);
-                comz = comz + quad_bcast(tz, sb);
+                // (kept apart: paired into one v_pk_add_f32 the two sums take their operands from two v_mov_b32_dpp
+                // -- three instructions per entry; on their own each add takes its DPP operand itself, two)
+                comx = coh_keep(comx + quad_bcast(tx, sb));
+                comz = coh_keep(comz + quad_bcast(tz, sb));
             }
         }
     }

@@ -230,8 +230,7 @@ __global__ __launch_bounds__(BFS_WAVES * 64) void k_field_bfs(nh_map_view map, c
     int level = 0;
 #define NH_BFS_LEVEL(NLOW)                                                                   \
     {                                                                                        \
-        u64x nb = from_w(frontier) | from_e(frontier) | from_n(frontier) | from_s(frontier); \
-        u64x nw = nb & open;                                                                 \
+        u64x nw = bfs_reach(frontier, open);                                                 \
         if(!__any(nz(nw))) break;                                                            \
         level++;                                                                             \
         pl[0] = pl[0] ^ open;                                                                \
