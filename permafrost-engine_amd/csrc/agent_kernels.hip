@@ -584,7 +584,9 @@ __global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int
 #define COH_QS  72            /* queue slots per sub-lane: (256 staged + 31 carried) / 4 */
 #ifndef COH_NP
 #define COH_NP  2             /* entry pairs per lane and batch: a batch is COH_G = 8 * COH_NP entries
-                                 (2 measured 1.3 % faster per tick than 4: fewer VGPRs, more waves) */
+                                 (2 measured 1.3 % faster per tick than 4: fewer VGPRs, more waves).  EVEN values only:
+                                 the queue is read four entries at a time (COH_NP = 1 compiles, loads nothing and is
+                                 11 % faster and wrong -- an A/B without a parity step found that out) */
 #endif
 #define COH_G   (8 * COH_NP)
 
