@@ -6,6 +6,8 @@
 #   bash scripts/gpu_ab.sh <tag> [steps...] -- <variants...>
 #
 # steps (in the order given):
+#   vparity   EVERY variant against the reference first (tests/test_agents_gpu.py + test_fields_gpu.py with NAVHIP_LIB = the
+#             variant): a variant that is faster because it is wrong (COH_NP = 1, r05) must not reach the clock
 #   parity    the ClearPath / velocity-step / whole-config parity tests (tests/test_agents_gpu.py, test_fullsize_ref_gpu.py)
 #   binding   tests/test_binding_gpu.py + the drop-in timing of bench.py (--steps 20)
 #   ab20      bench.py --steps 20 (the driver's window), 3 rounds
@@ -28,6 +30,10 @@ mkdir -p $OUT
 pick() { if [ "$1" != base ]; then export NAVHIP_LIB=$GRAFT_REPO_ROOT/build_prof/libnavhip_${1%@*}.so; else unset NAVHIP_LIB; fi; }
 for s in "${STEPS[@]}"; do
 case $s in
+vparity) for v in $VARS; do pick $v
+           timeout 300 python -m pytest tests/test_agents_gpu.py tests/test_fields_gpu.py -m gpu -x -q > $OUT/pytest_variant_$v.log 2>&1
+           echo "variant $v: $(tail -1 $OUT/pytest_variant_$v.log)"
+         done; unset NAVHIP_LIB ;;
 parity)  timeout 900 python -m pytest tests/test_agents_gpu.py tests/test_fullsize_ref_gpu.py -m gpu -x -q -k "clearpath or crowded or velocity_step or whole_config" > $OUT/pytest_cp.log 2>&1; tail -4 $OUT/pytest_cp.log ;;
 binding) timeout 900 python -m pytest tests/test_binding_gpu.py -m gpu -x -q > $OUT/pytest_binding.log 2>&1; tail -3 $OUT/pytest_binding.log
          timeout 600 python bench.py --steps 20 --no-crowded --no-sustained > $OUT/bench20.json 2> $OUT/bench20.err
