@@ -328,3 +328,16 @@ def test_c_host_example_compiles_as_c99(tmp_path):
                         "-I" + os.path.join(rocm, "include"), "-c", os.path.join(ROOT, "examples", "c_host_tick.c"),
                         "-o", str(tmp_path / "c_host_tick.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_makefile_builds_what_build_py_builds():
+    """csrc/Makefile (libnavhip.so for a C build system, no Python) lists the sources and the code-generation flags of
+    permafrost_engine_amd/build.py: the arithmetic flags are part of the parity contract."""
+    import re
+    from permafrost_engine_amd import build as nb
+    mk = open(os.path.join(os.path.dirname(nb.__file__), "csrc", "Makefile")).read().replace("\\\n", " ")
+    srcs = re.search(r"^SOURCES\s*=\s*(.*)$", mk, re.M).group(1).split()
+    assert srcs == nb.SOURCES
+    flags = re.search(r"^FLAGS\s*=\s*(.*)$", mk, re.M).group(1).split()
+    want = [f for f in nb.FLAGS if not f.startswith("-I")]
+    assert [f for f in flags if not f.startswith("-I")] == want
