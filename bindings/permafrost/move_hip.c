@@ -324,6 +324,14 @@ static bool hip_pin_reserve(size_t n)
     s_hip_pin.wait_ticks = navhip_host_alloc(sizeof(int32_t) * cap); s_hip_pin.wait_after = navhip_host_alloc(sizeof(int32_t) * cap);
     s_hip_pin.cap = (s_hip_pin.next_rot && s_hip_pin.new_pos && s_hip_pin.fstate && s_hip_pin.wait_prev && s_hip_pin.skip && s_hip_pin.st
                      && s_hip_pin.fl && s_hip_pin.gate && s_hip_pin.wait_ticks && s_hip_pin.wait_after) ? cap : 0;
+    if(s_hip_pin.cap) {
+        /* rows of the slab without a work item are computed and dropped, on whatever these arrays hold: page-locked
+         * memory has no defined content before its first use, so it is given one here */
+        memset(s_hip_pin.next_rot, 0, sizeof(float) * 4 * cap); memset(s_hip_pin.new_pos, 0, sizeof(float) * 2 * cap);
+        memset(s_hip_pin.fstate, 0, cap); memset(s_hip_pin.wait_prev, 0, cap); memset(s_hip_pin.skip, 0, cap);
+        memset(s_hip_pin.st, 0, cap); memset(s_hip_pin.fl, 0, cap); memset(s_hip_pin.gate, 0, cap);
+        memset(s_hip_pin.wait_ticks, 0, sizeof(int32_t) * cap); memset(s_hip_pin.wait_after, 0, sizeof(int32_t) * cap);
+    }
     return s_hip_pin.cap != 0;
 }
 
@@ -584,6 +592,7 @@ static bool move_hip_velocity_work(int begin_idx, int end_idx)
  * move_update_work (:3469) with the switch's outcome taken from there. */
 int N_HIP_ClosestIslandTiles(struct nav_private *priv, enum nav_layer layer, vec3_t map_pos, vec2_t xz_dest,
                              int16_t *out_abs, int max_tiles);                    /* nav_hip.c */
+uint32_t N_HIP_BlockersGeneration(void);                                          /* nav_hip.c */
 
 static uint8_t *s_hip_su_state, *s_hip_su_flags;     /* [nwork] by work item */
 static float   *s_hip_su_dest;                       /* [nwork][2] the surround arm's position (NAVHIP_SU_SURROUND_PREV / _DEST) */
@@ -878,21 +887,31 @@ static void hip_surround_range(int begin, int end, void *arg)
 }
 
 /* the per-flock answers of arrived()'s two destination-only queries, kept between ticks */
-struct hip_flock_q { bool valid, has_near; uint32_t epoch; const void *map; int layer, ntiles; float tx, tz, nx, nz; int16_t *tiles;
+struct hip_flock_q { bool valid, has_near; uint32_t epoch, blk_gen; const void *map; int layer, ntiles, per; float tx, tz, nx, nz; int16_t *tiles;
                      bool layer_valid; uint32_t layer_set_epoch, layer_attr_epoch; int layer_members, majority_layer; };
 static struct hip_flock_q *s_hip_flock_q; static size_t s_hip_flock_q_cap;
 static struct hip_flock_q *hip_flock_q_slot(size_t f, int per)
 {
     if(f >= s_hip_flock_q_cap) {
         const size_t cap = f + 16;
-        s_hip_flock_q = realloc(s_hip_flock_q, sizeof(struct hip_flock_q) * cap);
+        struct hip_flock_q *grown = realloc(s_hip_flock_q, sizeof(struct hip_flock_q) * cap);
+        if(!grown)
+            return NULL;                                /* (the caller asks the queries without keeping them) */
+        s_hip_flock_q = grown;
         for(size_t k = s_hip_flock_q_cap; k < cap; k++) {
             s_hip_flock_q[k].valid = false; s_hip_flock_q[k].layer_valid = false;
-            s_hip_flock_q[k].tiles = malloc(sizeof(int16_t) * 2 * per);
+            s_hip_flock_q[k].tiles = NULL; s_hip_flock_q[k].per = 0;
         }
         s_hip_flock_q_cap = cap;
     }
-    return &s_hip_flock_q[f];
+    struct hip_flock_q *C = &s_hip_flock_q[f];
+    if(C->per < per) {                                  /* (the tile list's room follows the caller's `per`) */
+        int16_t *t = realloc(C->tiles, sizeof(int16_t) * 2 * per);
+        if(!t)
+            return NULL;
+        C->tiles = t; C->per = per; C->valid = false;
+    }
+    return C;
 }
 
 struct hip_state_scatter { int begin_idx; const uint8_t *st, *fl, *gate, *state; const int32_t *wait_after; const float *dense_dest; long host, gate_host; };
@@ -1026,7 +1045,9 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
             continue;
         /* (the layer most members path on: a property of the flock tables and the units' attributes, counted again when
          * either changes -- the entity set or move_hip_attrs_changed) */
-        struct hip_flock_q *C = hip_flock_q_slot(f, per);
+        struct hip_flock_q scratch_q = {0}, *C = hip_flock_q_slot(f, per);
+        int16_t scratch_tiles[2 * (FIELD_RES_R * 2 + FIELD_RES_C * 2)];
+        if(!C) { C = &scratch_q; C->tiles = scratch_tiles; C->per = per; }      /* (no memory for the cache: ask, do not keep) */
         if(!(C->layer_valid && C->layer_set_epoch == s_hip_set_epoch && C->layer_attr_epoch == s_hip_attr_epoch
              && C->layer_members == S.flock_offsets[f + 1] - S.flock_offsets[f])) {
             int per_layer[NAV_LAYER_MAX] = {0}, best = 0;
@@ -1041,16 +1062,22 @@ static bool move_hip_state_work(int begin_idx, int end_idx)
         }
         const enum nav_layer layer = (enum nav_layer)C->majority_layer;
         flayer[f] = (uint8_t)layer;
-        /* the two queries depend on the destination and the layer only -- terrain, not blockers (N_ClosestPathable
-         * nav.c:4126 and n_closest_island_tiles :4725 read cost_base and the global islands) --: asked once per flock
-         * and (target, layer), kept until the flock is re-targeted or the map's nav data is rebuilt (move_hip_attrs_changed
-         * / N_HIP_SyncLayer callers bump s_hip_attr_epoch) */
-        if(!(C->valid && C->epoch == s_hip_attr_epoch && C->map == (const void*)gs->map && C->layer == (int)layer && C->tx == fl->target_xz.x && C->tz == fl->target_xz.z)) {
+        /* The two queries depend on the destination, the layer, the terrain AND THE BLOCKERS: N_ClosestPathable (nav.c:4126)
+         * goes through n_tile_blocked (:235: cost_base == COST_IMPASSABLE or blockers > 0), and the island tiles are taken
+         * with ignore_blockers = false (:4725) -- a unit that settles on or next to the destination changes both, which
+         * is the arrival case itself.  So an answer is kept only while the flock's target, the layer, the map's nav data
+         * (move_hip_attrs_changed / N_HIP_SyncLayer bump s_hip_attr_epoch) and the BLOCKER GENERATION stand
+         * (N_HIP_BlockersGeneration: bumped by every N_BlockersIncref / N_BlockersDecref, nav_hip.c): on a tick in which
+         * nothing was blocked or unblocked anywhere the answers are the last tick's, otherwise they are asked again. */
+        const uint32_t blk_gen = N_HIP_BlockersGeneration();
+        if(!(C->valid && C->epoch == s_hip_attr_epoch && C->blk_gen == blk_gen && C->map == (const void*)gs->map && C->layer == (int)layer
+             && C->tx == fl->target_xz.x && C->tz == fl->target_xz.z)) {
             vec2_t near_xz;
             C->has_near = M_NavClosestPathable(gs->map, layer, fl->target_xz, &near_xz);
             C->nx = C->has_near ? near_xz.x : 0.0f; C->nz = C->has_near ? near_xz.z : 0.0f;
             C->ntiles = N_HIP_ClosestIslandTiles(move_hip_nav_private(gs->map), layer, map_pos, fl->target_xz, C->tiles, per);
-            C->valid = true; C->epoch = s_hip_attr_epoch; C->map = (const void*)gs->map; C->layer = (int)layer; C->tx = fl->target_xz.x; C->tz = fl->target_xz.z;
+            C->valid = true; C->epoch = s_hip_attr_epoch; C->blk_gen = blk_gen; C->map = (const void*)gs->map; C->layer = (int)layer;
+            C->tx = fl->target_xz.x; C->tz = fl->target_xz.z;
         }
         if(C->has_near) { nearest[2 * f] = C->nx; nearest[2 * f + 1] = C->nz; }
         memcpy(tiles + 2 * toff[f], C->tiles, sizeof(int16_t) * 2 * C->ntiles);

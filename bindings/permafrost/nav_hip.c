@@ -38,7 +38,7 @@
  *   N_HIP_LOSFieldCreate                     same signature as N_LOSFieldCreate (field.h:195): the call
  *                                            sites nav.c:1843,2035; immediate, or recorded in deferred mode
  *                                            and built per chain level (a LOS field needs its predecessor's)
- *   N_HIP_BlockersRecord / N_HIP_BlockersFlush   N_BlockersIncref / N_BlockersDecref (nav.c:4663,4685) keep
+ *   N_HIP_BlockersRecord / N_HIP_BlockersFlush   N_BlockersIncref / N_BlockersDecref (nav.c:4663,4674) keep
  *                                            updating the host planes (the planner reads them); the same
  *                                            circles, recorded, update the device planes in one
  *                                            navhip_blockers_circles call per tick -- no plane re-upload
@@ -779,8 +779,18 @@ static struct{
 /* One more statement in N_BlockersIncref (ref_delta = +1) and N_BlockersDecref (-1): the host planes are
  * updated as before (the planner, the portal states and N_Update read them); the device copy follows
  * from the same call arguments at the next flush. */
+/* How often the blockers planes have been written so far.  Answers that READ them -- N_ClosestPathable goes through
+ * n_tile_blocked (nav.c:235: chunk->blockers > 0), n_closest_island_tiles is called with ignore_blockers = false
+ * (nav.c:4725) -- may only be kept between ticks under this number (move_hip.c's per-flock queries).  Bumped by every
+ * N_BlockersIncref / N_BlockersDecref through the recorder below; the OBB variants (nav.c:4685, 4696) and any other
+ * writer of the planes call N_HIP_BlockersTouched(). */
+static uint32_t s_hip_blk_generation = 1;
+void     N_HIP_BlockersTouched(void) { if(++s_hip_blk_generation == 0) s_hip_blk_generation = 1; }
+uint32_t N_HIP_BlockersGeneration(void) { return s_hip_blk_generation; }
+
 void N_HIP_BlockersRecord(vec2_t xz_pos, float range, int faction_id, uint32_t flags, vec3_t map_pos, int ref_delta)
 {
+    N_HIP_BlockersTouched();
     if(!s_hip.ctx)
         return;
     if(s_hip_blk.n == s_hip_blk.cap) {

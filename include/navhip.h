@@ -122,10 +122,16 @@ const char *navhip_last_error(const navhip_ctx *ctx);
 int  navhip_device(const navhip_ctx *ctx);
 /* the context's HIP stream, as void* (hipStream_t) */
 void *navhip_stream(const navhip_ctx *ctx);
-/* A stream (hipStream_t as void*, owned by the context) that may only use the compute units
- * [cu_begin, cu_begin + cu_count) of the device -- for wide, throughput-bound work (the field builds)
- * that should leave the rest of the chip to the narrow, latency-bound front of the agent step running
- * beside it.  (hipExtStreamCreateWithCUMask; the MI355X has 256 CUs in 8 XCDs of 32.) */
+/* A stream (hipStream_t as void*; the library's, never to be destroyed by the caller) for wide, throughput-bound work --
+ * the field builds -- that runs BESIDE the agent step enqueued on `main_stream`.  cu_count > 0: it may only use the
+ * compute units [cu_begin, cu_begin + cu_count) (hipExtStreamCreateWithCUMask; the MI355X has 256 CUs in 8 XCDs of 32)
+ * and leaves the rest of the chip to the narrow, latency-bound front of the step; cu_count <= 0: every compute unit.
+ * The stream has a hardware queue of its own, on a pipe of the command processor that neither `main_stream` nor the
+ * step's side streams use (a hand-over between two queues on one pipe costs 100-200 us instead of 12: measured once per
+ * process and caller stream, csrc/navhip_api.hip).  One set of such streams exists per process and device: calls with
+ * the same arguments return the same stream. */
+int  navhip_stream_beside(navhip_ctx *ctx, void *main_stream, int cu_begin, int cu_count, void **out_stream);
+/* navhip_stream_beside(ctx, navhip_stream(ctx), cu_begin, cu_count, out_stream) with cu_count > 0 */
 int  navhip_stream_create_partial(navhip_ctx *ctx, int cu_begin, int cu_count, void **out_stream);
 /* waits for the context's own stream and for the side streams of navhip_agent_prefetch_dev */
 int  navhip_sync(navhip_ctx *ctx);

@@ -232,6 +232,7 @@ void  pfref_map_pos(const pfref_nav *nav, float out[3])
 
 void pfref_nav_set_blockers(pfref_nav *nav, int layer, const uint16_t *blockers)
 {
+    N_HIP_BlockersTouched();                     /* (a writer of the planes beside N_BlockersIncref / Decref) */
     struct nav_private *priv = &nav->priv;
     size_t nchunks = priv->width * priv->height;
     for(size_t i = 0; i < nchunks; i++) {
@@ -252,6 +253,8 @@ void pfref_nav_blockers_circle(pfref_nav *nav, float x, float z, float range, in
     /* (the statement INTEGRATION.md adds to N_BlockersIncref / N_BlockersDecref themselves) */
     if(s_use_binding)
         N_HIP_BlockersRecord(xz, range, faction_id, flags, nav->map_pos, incref ? +1 : -1);
+    else
+        N_HIP_BlockersTouched();                 /* (the recorder's first statement: the planes are about to change) */
     if(!(flags & ENTITY_FLAG_AIR)
     && (nav->layer_mask & (ground | water)) == (ground | water)) {
         if(incref) N_BlockersIncref(xz, range, faction_id, flags, nav->map_pos, priv);

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnavhip.so")
-SOURCES = ["navhip_api.hip", "pool_api.hip", "field_kernels.hip", "agent_kernels.hip", "blocker_kernels.hip", "los_kernels.hip", "region_kernels.hip", "comm_api.hip", "state_kernels.hip", "tick_api.hip"]
+SOURCES = ["navhip_api.hip", "pool_api.hip", "field_kernels.hip", "agent_kernels.hip", "blocker_kernels.hip", "los_kernels.hip", "region_kernels.hip", "comm_api.hip", "state_kernels.hip", "tick_api.hip", "stream_set.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          # the agent kernels mirror the reference's C arithmetic operation by operation:

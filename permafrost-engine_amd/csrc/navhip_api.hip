@@ -111,7 +111,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->wl_parity = 0;
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
-    ctx->aux[0] = ctx->aux[1] = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
+    ctx->aux[0] = ctx->aux[1] = nullptr; ctx->aux_main = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
     ctx->front_stream = nullptr;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
     ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->sp_builds = 0; ctx->lists_pinned = nullptr;
@@ -150,11 +150,10 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(auto &b : ctx->arrived) hipFree(b.p);
     for(auto &b : ctx->wl) hipFree(b.p);
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
-    for(auto &a : ctx->aux) if(a) hipStreamDestroy(a);
+    for(auto &a : ctx->aux) if(a) hipStreamSynchronize(a);       // (borrowed: the process's, nh_device_stream)
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
     if(ctx->ev_regroup) hipEventDestroy(ctx->ev_regroup);
-    for(auto st : ctx->owned_streams) hipStreamDestroy(st);
     for(auto &e : ctx->ev_cp) if(e) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -164,22 +163,28 @@ const char *navhip_last_error(const navhip_ctx *ctx) { return ctx ? ctx->last_er
 int   navhip_device(const navhip_ctx *ctx) { return ctx ? ctx->device : -1; }
 void *navhip_stream(const navhip_ctx *ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-int navhip_stream_create_partial(navhip_ctx *ctx, int cu_begin, int cu_count, void **out_stream)
+int navhip_stream_beside(navhip_ctx *ctx, void *main_stream, int cu_begin, int cu_count, void **out_stream)
 {
-    if(!ctx || !out_stream || cu_begin < 0 || cu_count <= 0) return NAVHIP_ERR_INVALID;
+    if(!ctx || !out_stream || cu_begin < 0) return NAVHIP_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipDeviceProp_t prop;
-    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    const int ncu = prop.multiProcessorCount;
-    if(cu_begin >= ncu) return NAVHIP_ERR_INVALID;
-    if(cu_begin + cu_count > ncu) cu_count = ncu - cu_begin;
-    uint32_t mask[32] = {0};
-    for(int c = cu_begin; c < cu_begin + cu_count && c < 1024; c++) mask[c >> 5] |= 1u << (c & 31);
     hipStream_t st = nullptr;
-    HIPCHK(ctx, hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask));
-    ctx->owned_streams.push_back(st);
+    if(cu_count <= 0) {
+        hipStream_t all[NH_STREAM_FIXED];
+        int rc = nh_streams_for(ctx, (hipStream_t)main_stream, all);
+        if(rc) return rc;
+        st = all[NH_STREAM_FIELDS];
+    }else{
+        st = nh_stream_partial_for(ctx, (hipStream_t)main_stream, cu_begin, cu_count);
+        if(!st) return ctx->last_error.empty() ? NAVHIP_ERR_INVALID : NAVHIP_ERR_DEVICE;
+    }
     *out_stream = (void*)st;
     return NAVHIP_OK;
+}
+
+int navhip_stream_create_partial(navhip_ctx *ctx, int cu_begin, int cu_count, void **out_stream)
+{
+    if(cu_count <= 0) return NAVHIP_ERR_INVALID;
+    return navhip_stream_beside(ctx, ctx ? (void*)ctx->stream : nullptr, cu_begin, cu_count, out_stream);
 }
 
 int navhip_sync(navhip_ctx *ctx)
@@ -888,24 +893,26 @@ static bool pre_key_matches(const navhip_ctx *ctx, const navhip_world *w, const 
         && k.g.grid_h == g.grid_h;
 }
 
-// the side streams of the agent step (snapshot-only work beside the field builds; the ClearPath
-// launches beside each other) and their events
-static int ensure_side_streams(navhip_ctx *ctx)
+// the side streams of the agent step (snapshot-only work beside the field builds; the ClearPath launches beside each
+// other) and their events.  The streams are the process's (nh_streams_for): borrowed, and chosen for the stream the
+// step's main chain runs on -- the ones whose hardware queues sit on other pipes than that stream's.
+static int ensure_side_streams(navhip_ctx *ctx, hipStream_t main)
 {
-    if(ctx->aux[0]) return NAVHIP_OK;
-    // high priority: the side chain is narrow and sits on the critical path; it must not queue up
-    // behind the wide field kernels of the caller's stream
-    int prio_lo = 0, prio_hi = 0;
-    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    // (the cohesion term has slack -- it runs beside the whole front of the step --: low priority)
-    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[0], hipStreamNonBlocking, prio_hi));
-    // (NAVHIP_COH_PRIO=hi: a developer knob -- since the neighbour walk became one-wave workgroups the cohesion kernel
-    // ends last; measured in profiles/r05_ab_coh_prio.txt)
-    const char *cp = getenv("NAVHIP_COH_PRIO");
-    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[1], hipStreamNonBlocking, (cp && cp[0] == 'h') ? prio_hi : prio_lo));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for(auto &e : ctx->ev_cp) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if(ctx->aux[0] && ctx->aux_main == main) return NAVHIP_OK;
+    hipStream_t st[NH_STREAM_FIXED];
+    int rc = nh_streams_for(ctx, main, st);
+    if(rc) return rc;
+    if(!ctx->ev_fork) {
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for(auto &e : ctx->ev_cp) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if(ctx->aux[0] && (ctx->aux[0] != st[NH_STREAM_SIDE0] || ctx->aux[1] != st[NH_STREAM_SIDE1])) {
+        // another caller stream than last time: whatever the old side streams still hold is waited for
+        for(auto a : ctx->aux) HIPCHK(ctx, hipStreamSynchronize(a));
+        ctx->pre.valid = false; ctx->regroup_pending = false;
+    }
+    ctx->aux[0] = st[NH_STREAM_SIDE0]; ctx->aux[1] = st[NH_STREAM_SIDE1]; ctx->aux_main = main;
     return NAVHIP_OK;
 }
 
@@ -948,7 +955,9 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     if(w->n_ents == 0) return NAVHIP_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    rc = ensure_side_streams(ctx);
+    // (a prefetch may be issued on another stream than the step it belongs to -- the exchange stream of a sharded tick --:
+    // the side streams stay the ones chosen for the step's stream once there has been a step)
+    rc = ensure_side_streams(ctx, ctx->aux[0] ? ctx->aux_main : s);
     if(rc) return rc;
     nh_step_params P;
     rc = step_fill_params(ctx, w, &P);
@@ -1069,7 +1078,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     nh_step_outs O = {out->vel_xz, out->new_pos_xz, out->vdes_xz, out->vpref_xz, out->status};
     nh_nbr NB; nh_worklists WL;
     rc = step_scratch(ctx, w->n_ents, &NB, &WL, s);
-    if(!rc) rc = ensure_side_streams(ctx);
+    if(!rc) rc = ensure_side_streams(ctx, s);
     if(rc) return rc;
     if(joined) {
         // spatial hash + neighbour walk + cohesion were started by navhip_agent_prefetch_dev: join
@@ -1414,6 +1423,7 @@ int navhip_region_lookup(navhip_ctx *ctx, int nq, const float *pos_xz, const int
 }  // extern "C"
 
 int nh_refresh_derived(navhip_ctx *ctx, hipStream_t s) { return refresh_derived(ctx, s); }
+int nh_prepare_step_streams(navhip_ctx *ctx, hipStream_t main) { return ensure_side_streams(ctx, main); }
 
 // bg_ent insert-all + inrange_circle for nq query points with everything on the device: the index over
 // dev_w->pos_xz (positions only), ids in the reference's visiting order into d_ids [nq][maxout], counts into d_counts

@@ -64,10 +64,11 @@ struct navhip_ctx {
     int          coh_flocks, coh_members, coh_parity;   // layout of coh_plan + which perm buffer is next
     unsigned     coh_unique;   // membership keys of slab steps whose caller gave no static_epoch: never equal
     buf          stage[48];    // device copies of host buffers for the host-pointer entry points
-    // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events
+    // side streams for navhip_agent_prefetch_dev (spatial hash | cohesion) + fork/join events; BORROWED from the process's
+    // set (nh_device_stream)
     hipStream_t  aux[2];
+    hipStream_t  aux_main;          // the main stream the side streams were chosen for
     hipEvent_t   ev_fork, ev_join[2], ev_regroup;
-    std::vector<hipStream_t> owned_streams;   // navhip_stream_create_partial
     navhip_counters counters;       // navhip_get_counters
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
     bool         join0_recorded;    // ev_join[0] has been recorded for the front of the last prefetch
@@ -96,6 +97,19 @@ struct navhip_ctx {
     struct nh_async *async;    // state of navhip_agent_step_submit / _poll
     struct nh_comm  *comm;     // RCCL communicator of navhip_comm_* (comm_api.hip) or NULL
 };
+
+// The library's streams: one set per process and device, each with a hardware queue of its own, chosen per caller stream
+// so that streams which hand over to each other sit on different pipes of the command processor (navhip_api.hip has the
+// measurements behind this).  Borrowed by contexts and ticks; never destroyed.
+enum { NH_STREAM_SIDE0 = 0,     // the ClearPath side chain of the agent step
+       NH_STREAM_SIDE1,         // the cohesion term
+       NH_STREAM_MAIN,          // the agent chain (the caller's stream, or the set's own when the caller gave none)
+       NH_STREAM_FIELDS,        // field builds beside the step, when they may use every compute unit
+       NH_STREAM_COMM,          // the slab exchange (shares the field builds' pipe: one hand-over per tick each)
+       NH_STREAM_FIXED };
+int         nh_streams_for(navhip_ctx *ctx, hipStream_t main, hipStream_t out[NH_STREAM_FIXED]);
+hipStream_t nh_stream_partial_for(navhip_ctx *ctx, hipStream_t main, int cu_begin, int cu_count);   // nullptr: ctx->last_error says why
+int         nh_prepare_step_streams(navhip_ctx *ctx, hipStream_t main);      // the side streams of steps whose main chain runs on `main`
 
 // pool_api.hip <-> navhip_api.hip
 extern "C" int nh_validate_field_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n);   /* (library internal) */

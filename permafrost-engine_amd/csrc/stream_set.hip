@@ -1,0 +1,205 @@
+// stream_set.hip -- the streams the library runs its side chains on (nh_streams_for, nh_stream_partial_for).
+#include "navhip_internal.h"
+#include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------------------------
+// The library's streams: ONE set per process and device, each with a hardware queue of its own, on a pipe of the
+// command processor that the streams it exchanges events with do not use.
+//
+// Measured on the MI355X (scripts/stream_queue_probe.hip, scripts/stream_pingpong_probe.hip; profiles/r06_stream_*.txt):
+//  * HIP maps the streams of one priority onto at most four hardware queues (GPU_MAX_HW_QUEUES); the fifth stream of
+//    a priority shares the queue of the fourth, and kernels on streams that share a queue run one after the other.  A
+//    host that holds a pool of streams (torch: 32 per priority) has every pooled queue in use: a pooled side stream of
+//    this library landed on the queue of the caller's own stream once in four contexts.
+//  * A stream created with a CU mask never shares its queue.  But hardware queues sit on the FOUR PIPES of the command
+//    processor's compute engine, queue k on pipe k mod 4 in creation order, and a pipe serves one of its queues at a
+//    time: a queue that waits for an event (a barrier packet polling a signal) keeps its pipe until the arbiter's
+//    time slice ends, and when the queue that is to RECORD that event sits on the same pipe, the hand-over takes
+//    100-200 us instead of 12.  The agent step is four streams that hand over to each other four to six times per
+//    tick: the tick of one and the same world cost 0.18 or 0.37-0.66 ms depending on how many streams the process had
+//    created before (profiles/r06_queue_probe_*.txt).
+//  * From about twenty live masked streams on (beside a host's pooled ones) queues are time-sliced, milliseconds at a time.
+// So: four masked streams per device, created ONCE, never destroyed, borrowed by every context and tick; which of them
+// share a pipe -- with each other and with the caller's stream -- is MEASURED (a ping-pong of two 10-us kernels, 2-5 ms
+// per pair, once per process and once per caller stream), and a step's side streams are the ones on the pipes its
+// caller's stream does not use.  Contexts on one device that are driven from several threads at once share these
+// queues: their work interleaves in stream order, which adds ordering, never removes any.
+// ---------------------------------------------------------------------------------------------------------------
+#define NH_PIPES 4
+__global__ void k_nh_spin(long long ticks)
+{
+#ifndef NH_HOSTSIM
+    const long long t0 = wall_clock64();
+    while(wall_clock64() - t0 < ticks) { }
+#endif
+}
+
+namespace {
+struct nh_dev_streams {
+    bool        ready = false;
+    hipStream_t full[NH_PIPES] = {};                         // pairwise on different pipes (as measured)
+    std::map<std::pair<int, int>, std::array<hipStream_t, NH_PIPES>> partial;   // [k]: on the pipe of full[k]
+    std::map<hipStream_t, int> caller_pipe;                  // caller's stream -> k of the full stream whose pipe it shares, -1: none
+    hipEvent_t  ea = nullptr, eb = nullptr;
+    double      base_us = 0.0;                               // round trip between two streams on different pipes
+    int         measured_pairs = 0, collisions_seen = 0;
+};
+std::mutex g_streams_mu;
+std::map<int, nh_dev_streams> g_streams;
+
+hipStream_t masked_stream(navhip_ctx *ctx, int cu_begin, int cu_count)
+{
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { ctx->last_error = "hipGetDeviceProperties failed"; return nullptr; }
+    const int ncu = prop.multiProcessorCount;
+    if(cu_count <= 0 || cu_begin + cu_count > ncu) cu_count = ncu - cu_begin;
+    uint32_t mask[32] = {0};
+    for(int c = cu_begin; c < cu_begin + cu_count && c < 1024; c++) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t st = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask);
+    if(e != hipSuccess) { ctx->last_error = std::string("hipExtStreamCreateWithCUMask: ") + hipGetErrorString(e); return nullptr; }
+    return st;
+}
+
+// microseconds per round trip a -> b -> a of two 10-us kernels, everything enqueued up front (both streams idle first)
+double pingpong_us(nh_dev_streams &D, hipStream_t a, hipStream_t b, int rounds)
+{
+#ifdef NH_HOSTSIM
+    return 1.0;
+#else
+    if(hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for(int r = 0; r < rounds; r++) {
+        hipLaunchKernelGGL(k_nh_spin, dim3(1), dim3(64), 0, a, 1000LL);        // (wall_clock64: 100 MHz)
+        hipEventRecord(D.ea, a);
+        hipStreamWaitEvent(b, D.ea, 0);
+        hipLaunchKernelGGL(k_nh_spin, dim3(1), dim3(64), 0, b, 1000LL);
+        hipEventRecord(D.eb, b);
+        hipStreamWaitEvent(a, D.eb, 0);
+    }
+    if(hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1.0;
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
+#endif
+}
+
+// do a and b hand over like two queues on ONE pipe?  (both directions: the penalty depends on who polls)
+bool same_pipe(nh_dev_streams &D, hipStream_t a, hipStream_t b)
+{
+    if(a == b) return true;
+    pingpong_us(D, a, b, 4);                                           // (first use of a stream creates its queue)
+    const double ab = pingpong_us(D, a, b, 24), ba = pingpong_us(D, b, a, 24);
+    const double worst = ab > ba ? ab : ba;
+    D.measured_pairs++;
+    if(D.base_us <= 0.0 || (worst > 0.0 && worst < D.base_us)) D.base_us = worst;      // (the fastest pair seen so far)
+    const bool hit = worst > 1.3 * D.base_us;
+    D.collisions_seen += hit;
+    static const bool dbg = getenv("NAVHIP_STREAM_DEBUG") != nullptr;
+    if(dbg) fprintf(stderr, "navhip streams: %p <-> %p  %.0f / %.0f us per round trip (fastest pair %.0f)%s\n", (void*)a, (void*)b, ab, ba,
+                    D.base_us, hit ? "  -> same pipe" : "");
+    return hit;
+}
+
+// four masked streams on four different pipes.  Consecutive creations land on consecutive pipes; that is verified, and a
+// candidate that shares a pipe with an earlier pick is replaced (at most eight tries: then it stays, results are the same)
+bool streams_init(navhip_ctx *ctx, nh_dev_streams &D)
+{
+    if(D.ready) return true;
+    if(hipEventCreateWithFlags(&D.ea, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.eb, hipEventDisableTiming) != hipSuccess) {
+        ctx->last_error = "hipEventCreate failed";
+        return false;
+    }
+    std::vector<hipStream_t> rejected;
+    int tries = 0;
+    for(int k = 0; k < NH_PIPES; k++) {
+        for(;;) {
+            hipStream_t c = masked_stream(ctx, 0, 0);
+            if(!c) return false;
+            bool clash = false;
+            // (the first measurement of all fixes base_us: take it between the first two candidates twice)
+            for(int j = 0; j < k && !clash; j++) clash = same_pipe(D, D.full[j], c);
+            if(k == 1 && !clash && D.measured_pairs == 1) same_pipe(D, D.full[0], c);
+            if(!clash || ++tries >= 8) { D.full[k] = c; break; }
+            rejected.push_back(c);                 // (kept alive until the set is complete: its queue keeps its pipe slot)
+        }
+    }
+    for(hipStream_t r : rejected) hipStreamDestroy(r);
+    D.ready = true;
+    return true;
+}
+
+// k of the full stream whose pipe stream s shares (-1: none of them, or s is one of the set)
+int pipe_of(navhip_ctx *ctx, nh_dev_streams &D, hipStream_t s)
+{
+    for(int k = 0; k < NH_PIPES; k++) if(D.full[k] == s) return k;
+    for(auto &kv : D.partial) for(int k = 0; k < NH_PIPES; k++) if(kv.second[k] == s) return k;
+    auto it = D.caller_pipe.find(s);
+    if(it != D.caller_pipe.end()) return it->second;
+    int found = -1;
+#ifndef NH_HOSTSIM
+    // (a stream that is being captured into a graph cannot be measured: it is asked again next time)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if(!s || hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;
+#endif
+    for(int k = 0; k < NH_PIPES && found < 0; k++) if(same_pipe(D, s, D.full[k])) found = k;
+    D.caller_pipe[s] = found;
+    return found;
+}
+}  // namespace
+
+// The streams of a step whose main chain runs on `main` (the caller's stream, or nullptr: the set's own main stream is
+// returned in out[NH_STREAM_MAIN]): side0, side1, fields / comm on the other three pipes.
+int nh_streams_for(navhip_ctx *ctx, hipStream_t main, hipStream_t out[NH_STREAM_FIXED])
+{
+    if(hipSetDevice(ctx->device) != hipSuccess) { ctx->last_error = "hipSetDevice failed"; return NAVHIP_ERR_DEVICE; }
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    nh_dev_streams &D = g_streams[ctx->device];
+    if(!streams_init(ctx, D)) return NAVHIP_ERR_DEVICE;
+    int p = main ? pipe_of(ctx, D, main) : 0;
+    out[NH_STREAM_MAIN] = main ? main : D.full[0];
+    if(p < 0) p = 0;                        // (a caller's stream on a pipe of its own: any three)
+    out[NH_STREAM_SIDE0] = D.full[(p + 1) % NH_PIPES];
+    out[NH_STREAM_SIDE1] = D.full[(p + 2) % NH_PIPES];
+    out[NH_STREAM_FIELDS] = out[NH_STREAM_COMM] = D.full[(p + 3) % NH_PIPES];
+    return NAVHIP_OK;
+}
+
+// a stream limited to the compute units [cu_begin, cu_begin + cu_count) on the pipe nh_streams_for(main) leaves for the
+// field builds (a CU mask is a property of the queue: one queue per pipe and mask, made on first use)
+hipStream_t nh_stream_partial_for(navhip_ctx *ctx, hipStream_t main, int cu_begin, int cu_count)
+{
+    hipDeviceProp_t prop;
+    if(hipSetDevice(ctx->device) != hipSuccess || hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) {
+        ctx->last_error = "hipGetDeviceProperties failed";
+        return nullptr;
+    }
+    ctx->last_error.clear();
+    if(cu_begin < 0 || cu_count <= 0 || cu_begin >= prop.multiProcessorCount) return nullptr;
+    if(cu_begin + cu_count > prop.multiProcessorCount) cu_count = prop.multiProcessorCount - cu_begin;
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    nh_dev_streams &D = g_streams[ctx->device];
+    if(!streams_init(ctx, D)) return nullptr;
+    int p = main ? pipe_of(ctx, D, main) : 0;
+    if(p < 0) p = 0;
+    const int want = (p + 3) % NH_PIPES;
+    auto &P = D.partial[std::make_pair(cu_begin, cu_count)];
+    if(P[want]) return P[want];
+    // candidates until one lands on the wanted pipe; what lands elsewhere is kept for the caller whose stream needs it
+    std::vector<hipStream_t> surplus;
+    for(int tries = 0; tries < 8 && !P[want]; tries++) {
+        hipStream_t c = masked_stream(ctx, cu_begin, cu_count);
+        if(!c) break;
+        int k = -1;
+        for(int j = 0; j < NH_PIPES && k < 0; j++) if(same_pipe(D, c, D.full[j])) k = j;
+        if(k >= 0 && !P[k]) P[k] = c; else surplus.push_back(c);
+    }
+    if(!P[want] && !surplus.empty()) { P[want] = surplus.back(); surplus.pop_back(); }     // (unplaced: still a queue of its own)
+    for(hipStream_t r : surplus) hipStreamDestroy(r);
+    return P[want];
+}

@@ -55,7 +55,6 @@ struct navhip_tick {
     uint8_t         *pool[2];
     std::vector<int32_t> bounds;
     hipStream_t      s, f, comm;      // agent chain | field builds ahead | exchange
-    bool             own_s, own_f, own_comm;
     hipEvent_t       ev_fields[2], ev_step, ev_comm, ev_side, ev_tmp;
     bool             ahead, pipelined, comm_pending, computed, serial, split_mid;
     int64_t          ticks;
@@ -312,26 +311,23 @@ int navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tic
                                   desc->vdes_xz, desc->vpref_xz, desc->status};
     }
     auto fail = [&](const char *what) { ctx->last_error = what; navhip_tick_destroy(T); return NAVHIP_ERR_DEVICE; };
-    int prio_lo = 0, prio_hi = 0;
-    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    T->s = (hipStream_t)desc->stream;
-    if(!T->s) { if(hipStreamCreateWithPriority(&T->s, hipStreamNonBlocking, prio_hi) != hipSuccess) return fail("navhip_tick_create: stream"); T->own_s = true; }
+    // (streams the caller did not give: the process's own, each with a hardware queue to itself on a pipe of the command
+    // processor the others do not use -- nh_streams_for)
+    hipStream_t own[NH_STREAM_FIXED];
+    if(nh_streams_for(ctx, (hipStream_t)desc->stream, own) != NAVHIP_OK) { navhip_tick_destroy(T); return NAVHIP_ERR_DEVICE; }
+    T->s = own[NH_STREAM_MAIN];
     T->f = (hipStream_t)desc->field_stream;
     if(!T->f && T->ahead) {
         hipDeviceProp_t prop;
         int ncu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 0;
-        void *st = nullptr;
-        if(desc->field_cus > 0 && desc->field_cus < ncu) {
-            // (owned by the context, like every CU-masked stream)
-            if(navhip_stream_create_partial(ctx, ncu - desc->field_cus, desc->field_cus, &st) != NAVHIP_OK) return fail("navhip_tick_create: CU-masked stream");
-            T->f = (hipStream_t)st;
-        }else{
-            if(hipStreamCreateWithFlags(&T->f, hipStreamNonBlocking) != hipSuccess) return fail("navhip_tick_create: stream");
-            T->own_f = true;
-        }
+        T->f = (desc->field_cus > 0 && desc->field_cus < ncu) ? nh_stream_partial_for(ctx, T->s, ncu - desc->field_cus, desc->field_cus)
+                                                               : own[NH_STREAM_FIELDS];
+        if(!T->f) return fail("navhip_tick_create: field stream");
     }
     T->comm = (hipStream_t)desc->comm_stream;
-    if(!T->comm && T->pipelined) { if(hipStreamCreateWithFlags(&T->comm, hipStreamNonBlocking) != hipSuccess) return fail("navhip_tick_create: stream"); T->own_comm = true; }
+    if(!T->comm && T->pipelined) T->comm = own[NH_STREAM_COMM];
+    // (the step's side streams are chosen for THIS stream, whatever stream a prefetch runs on)
+    if(nh_prepare_step_streams(ctx, T->s) != NAVHIP_OK) { navhip_tick_destroy(T); return NAVHIP_ERR_DEVICE; }
     hipEvent_t *evs[] = {&T->ev_fields[0], &T->ev_fields[1], &T->ev_step, &T->ev_comm, &T->ev_side, &T->ev_tmp};
     for(hipEvent_t *e : evs) if(hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail("navhip_tick_create: event");
     // (a slab step without a static_epoch carries a never-repeating membership key: nothing to replay)
@@ -412,9 +408,6 @@ void navhip_tick_destroy(navhip_tick *T)
 #endif
     hipEvent_t evs[] = {T->ev_fields[0], T->ev_fields[1], T->ev_step, T->ev_comm, T->ev_side, T->ev_tmp};
     for(hipEvent_t e : evs) if(e) hipEventDestroy(e);
-    if(T->own_s && T->s) hipStreamDestroy(T->s);
-    if(T->own_f && T->f) hipStreamDestroy(T->f);
-    if(T->own_comm && T->comm) hipStreamDestroy(T->comm);
     delete T;
 }
 

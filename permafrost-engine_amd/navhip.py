@@ -460,6 +460,7 @@ _SIGS.update({
     "navhip_stream_wait_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "navhip_get_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "navhip_stream_create_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "navhip_stream_beside": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 5)]),
     "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
     "navhip_step_lists_peek": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
@@ -657,6 +658,14 @@ def _ctx_stream_create_partial(self, cu_begin, cu_count):
     """A hipStream_t value restricted to the compute units [cu_begin, cu_begin + cu_count)."""
     out = C.c_void_p()
     self._chk(lib().navhip_stream_create_partial(self._h, cu_begin, cu_count, C.byref(out)), "navhip_stream_create_partial")
+    return out.value
+
+
+def _ctx_stream_beside(self, main_stream, cu_begin=0, cu_count=0):
+    """navhip_stream_beside: the library's stream for wide work beside a step on `main_stream` (a hipStream_t value);
+    cu_count > 0 restricts it to the compute units [cu_begin, cu_begin + cu_count)."""
+    out = C.c_void_p()
+    self._chk(lib().navhip_stream_beside(self._h, C.c_void_p(main_stream), cu_begin, cu_count, C.byref(out)), "navhip_stream_beside")
     return out.value
 
 
@@ -1068,6 +1077,7 @@ NavContext.last_step_lists = _ctx_last_step_lists
 NavContext.step_lists_peek = _ctx_step_lists_peek
 NavContext.stream_wait_stage = _ctx_stream_wait_stage
 NavContext.stream_create_partial = _ctx_stream_create_partial
+NavContext.stream_beside = _ctx_stream_beside
 NavContext.counters = _ctx_counters
 NavContext.agent_step = _ctx_agent_step
 NavContext.agent_step_dev = _ctx_agent_step_dev

@@ -353,7 +353,9 @@ class NavTick:
         # snapshot consumers of tick t+1 (spatial hash + cohesion, then the agent step); the field
         # builds of tick t+1 do not read positions and overlap with it
         self.pipelined = world > 1 and not solo
-        self.comm = tcuda.Stream(device=self.dev) if self.pipelined else None
+        # (the library's own streams for everything beside the agent chain: each has a hardware queue to itself, on a pipe of
+        # the command processor that self.stream's queue does not sit on -- navhip_stream_beside)
+        self.comm = tcuda.ExternalStream(self.ctx.stream_beside(self.stream.cuda_stream), device=self.dev) if self.pipelined else None
         # exchange = "navhip": the slab all-gather goes through the library's own C entry point
         # (navhip_comm_allgather_step_dev: librccl called directly -- what a C host uses) instead of
         # torch.distributed; rank 0's communicator id travels over the process group that launched us
@@ -398,9 +400,9 @@ class NavTick:
             long_build = self.n_req_local >= 65536
             ncu = int(os.environ.get("NAVTICK_FIELD_CUS", str(ncu_all if long_build else ncu_all * 5 // 8)))
             if 0 < ncu < ncu_all:
-                self.fstream = tcuda.ExternalStream(self.ctx.stream_create_partial(ncu_all - ncu, ncu), device=self.dev)
+                self.fstream = tcuda.ExternalStream(self.ctx.stream_beside(self.stream.cuda_stream, ncu_all - ncu, ncu), device=self.dev)
             else:
-                self.fstream = tcuda.Stream(device=self.dev)
+                self.fstream = tcuda.ExternalStream(self.ctx.stream_beside(self.stream.cuda_stream), device=self.dev)
             self.fields_after = os.environ.get("NAVTICK_FIELDS_AFTER", "start" if long_build else "neighbours")
             # nothing wide is enqueued on self.stream between prefetch and step: the front stays on it
             # ... and the snapshot buffers ping-pong: the one a step read is next written by the ClearPath

@@ -196,7 +196,7 @@ def clearpath_team(ent, des_v, dyn, n_dyn, stat, n_stat):
 # ---- the WHOLE library on the emulator: every translation unit of csrc/ compiled for the host against fakehip/ ----------
 EMU_LIB = os.path.join(HERE, "_navhip_emu.so")
 EMU_SOURCES = ["navhip_api", "pool_api", "field_kernels", "agent_kernels", "blocker_kernels", "los_kernels",
-               "region_kernels", "comm_api", "state_kernels", "tick_api"]
+               "region_kernels", "comm_api", "state_kernels", "tick_api", "stream_set"]
 # the two statements of the device sources a host compiler cannot take (a register clobber that pins the allocation of
 # k_cp_rows; an unsized extern array for dynamic LDS) -- replaced in the copies that are compiled, nothing else is
 _EMU_PATCHES = [

@@ -62,7 +62,9 @@ DESELECT_TICK = ["test_c_tick_equals_the_python_schedule[crowded]", "test_graph_
                  "test_graph_replay_equals_plain_launches[one_stream-fields_ahead]",
                  "test_graph_replay_equals_plain_launches[one_stream-fields_in_front]",
                  "test_graph_replay_equals_plain_launches[streams-fields_ahead]",
-                 "test_graph_replay_equals_plain_launches[streams-fields_in_front]"]
+                 "test_graph_replay_equals_plain_launches[streams-fields_in_front]",
+                 # (a measurement of the hardware's queues: nothing for an emulator, and ten configs[2]-sized worlds)
+                 "test_tick_time_does_not_depend_on_what_the_process_created_before"]
 
 
 @pytest.mark.parametrize("strict", [True, False])
@@ -112,7 +114,7 @@ def test_reference_binding_drives_the_emulated_library():
     tail = "\n".join(r.stdout.strip().splitlines()[-25:])
     assert r.returncode == 0, tail
     last = r.stdout.strip().splitlines()[-1]
-    assert "16 passed" in last, tail
+    assert "17 passed" in last, tail
 
 
 @pytest.mark.parametrize("extra", [["--pipeline-fields", "--shared", "--flow-velocities"], ["--straddle", "all"]])

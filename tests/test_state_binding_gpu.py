@@ -51,6 +51,73 @@ def test_state_updates_through_the_binding():
         pfref.RefMove.unload()
 
 
+def test_flock_queries_follow_blocker_changes():
+    """the binding keeps arrived()'s two per-flock queries between state passes -- M_NavClosestPathable
+    and the destination's closest island tiles.  Both READ THE BLOCKERS (n_tile_blocked, nav.c:235; n_closest_island_tiles with
+    ignore_blockers = false, :4725), and blockers change exactly where a flock arrives.  Between two passes a unit settles on
+    a flock's destination (N_BlockersIncref around the target): the answers of that flock change, and the second pass --
+    through the binding, the kept answers keyed on the blocker generation -- equals the reference's own
+    entity_compute_update again.  (Keyed on target and nav-data epoch only, the device decided on stale answers.)"""
+    grid, nav, world, new_vel, vdes = cases.state_world()
+    # where N_ClosestPathable sends each such flock once its destination is blocked: forty units of the flock wait there,
+    # on the move, 8-12 units from the target -- not arrived while the target is free, arrived once it is taken
+    flocks = (0, 2, 3, 5)
+    rng = np.random.RandomState(3)
+    placed = []
+    for f in flocks:
+        x, z = (float(v) for v in world["flock_target_xz"][f])
+        free = nav.closest_pathable((x, z))
+        assert free is not None and abs(free[0] - x) < 1e-3 and abs(free[1] - z) < 1e-3      # (the target itself, while it is free)
+        nav.blockers_circle(x, z, 7.0, incref=True)
+        spot = nav.closest_pathable((x, z))
+        nav.blockers_circle(x, z, 7.0, incref=False)
+        assert spot is not None and np.hypot(spot[0] - x, spot[1] - z) > 4.0
+        who = np.flatnonzero(world["flock"] == f)[:40]
+        world["pos_xz"][who] = (np.array(spot, np.float32) + rng.uniform(-0.6, 0.6, (len(who), 2))).astype(np.float32)
+        world["state"][who] = 0
+        world["radius"][who] = 1.0
+        world["flags"][who] = np.uint32(1 << 3)
+        new_vel[who] = 0
+        vdes[who] = (1.0, 0.0)
+        placed.append(who)
+        # (no ARRIVED unit within reach of them: "a flock mate that touches us has arrived" must not decide for them)
+        near = np.hypot(world["pos_xz"][:, 0] - spot[0], world["pos_xz"][:, 1] - spot[1]) < 25.0
+        world["state"][near & (world["state"] == 2)] = 0
+    placed = np.concatenate(placed)
+    mv, _ = cases.ref_move_for(nav, world)
+    try:
+        assert nav.hip_init(), "no MI355X visible"
+        pfref.RefNav.hip_mode(True, 1)
+        ref_state, ref_flags = mv.state_update(new_vel, vdes)
+        st, fl, _ = mv.state_update_hip(new_vel, vdes)
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        st, fl, _ = mv.state_update_hip(new_vel, vdes)           # (nothing changed: the kept answers serve)
+        assert np.array_equal(st, ref_state) and np.array_equal(fl, ref_flags)
+        # units settle on the destinations: blockers under every target
+        for f in flocks:
+            x, z = (float(v) for v in world["flock_target_xz"][f])
+            nav.blockers_circle(x, z, 7.0, incref=True)
+        nav.flush_dirty()
+        assert pfref.RefNav.hip_blockers_flush()
+        ref_state2, ref_flags2 = mv.state_update(new_vel, vdes)
+        differ = (ref_state2 != ref_state) | (ref_flags2 != ref_flags)
+        assert differ[placed].sum() >= 100, "the blockers under the targets must change decisions, or the test shows nothing"
+        st2, fl2, _ = mv.state_update_hip(new_vel, vdes)
+        assert np.array_equal(st2, ref_state2) and np.array_equal(fl2, ref_flags2)
+        # ... and when the units leave again
+        for f in flocks:
+            x, z = (float(v) for v in world["flock_target_xz"][f])
+            nav.blockers_circle(x, z, 7.0, incref=False)
+        nav.flush_dirty()
+        assert pfref.RefNav.hip_blockers_flush()
+        st3, fl3, _ = mv.state_update_hip(new_vel, vdes)
+        assert np.array_equal(st3, ref_state) and np.array_equal(fl3, ref_flags)
+    finally:
+        pfref.RefNav.hip_mode(False)
+        pfref.RefNav.hip_shutdown()
+        pfref.RefMove.unload()
+
+
 def test_arrival_settle_through_the_binding():
     """The same pass with ACTIVE arrival zones on two flocks (struct arrival_state with a footprint, slots and fill
     ranks): their units take the G_Arrival_ShouldSettle arm of entity_compute_update (movement.c:2443-2451).  The

@@ -127,3 +127,29 @@ def test_tick_rejects_malformed_descriptions(navlib):
     with pytest.raises(navhip.NavHipError):
         navhip.Tick(ctx, d)                             # no entities, no buffers
     ctx.close()
+
+
+def test_tick_time_does_not_depend_on_what_the_process_created_before(navlib):
+    """the same world cost 0.18 or 0.37-0.66 ms per tick depending on how many streams the process
+    had created before -- a pooled side stream of the library shared a hardware queue with the caller's stream in one
+    context out of four (scripts/stream_queue_probe.hip).  The side streams are the process's own now, each with a queue
+    to itself, created once: ten contexts in a row -- each on the next stream of torch's pool -- tick alike."""
+    import time
+    from permafrost_engine_amd import tick
+    ms = []
+    for rep in range(10):
+        T = tick.NavTick(chunk_w=16, fields_per_rank=8, agents_per_rank=12_500, rank=4, world=8, shared_map=True,
+                         pipeline_fields=True, driver="c")
+        T.pipelined, T._comm_pending = False, False          # (one rank of a job, compute only)
+        T.new_pos.copy_(T.t["pos_xz"]); T.new_vel.copy_(T.t["vel_xz"])
+        for _ in range(6):
+            T.step()
+        T.sync()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            T.step()
+        T.sync()
+        ms.append((time.perf_counter() - t0) / 40 * 1e3)
+        T.close()
+    # (the failure is a factor of 2 to 3.6; boxes differ by a few per cent from run to run)
+    assert max(ms) <= 1.25 * min(ms), ms
