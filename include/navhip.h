@@ -131,6 +131,11 @@ void *navhip_stream(const navhip_ctx *ctx);
  * process and caller stream, csrc/navhip_api.hip).  One set of such streams exists per process and device: calls with
  * the same arguments return the same stream. */
 int  navhip_stream_beside(navhip_ctx *ctx, void *main_stream, int cu_begin, int cu_count, void **out_stream);
+/* The library's own stream for the agent chain (what navhip_tick_create runs a tick on when its description names no
+ * stream): a hardware queue of its own on the fourth pipe, beside the three of navhip_stream_beside(ctx, <this stream>, ..)
+ * and of the step's side streams.  A host that has no reason to run the step on a stream of its own should use this
+ * one: the set is the same for every context of the process, so a tick costs the same whatever the process created before. */
+int  navhip_stream_main(navhip_ctx *ctx, void **out_stream);
 /* navhip_stream_beside(ctx, navhip_stream(ctx), cu_begin, cu_count, out_stream) with cu_count > 0 */
 int  navhip_stream_create_partial(navhip_ctx *ctx, int cu_begin, int cu_count, void **out_stream);
 /* waits for the context's own stream and for the side streams of navhip_agent_prefetch_dev */
@@ -480,9 +485,10 @@ int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, v
 #define NAVHIP_PREFETCH_SNAPSHOT_HELD 0x2u
 /*        NAVHIP_PREFETCH_FIELDS_READY  everything the step SAMPLES is final when this call is made -- the field pool
  * and its slot tables, the LOS pool, vdes_xz, the formation / arrival inputs: every array of dev_world, which the step
- * that follows must pass unchanged --: the front then also runs the first half of the per-agent chain (flow sampling,
- * line of sight, arrive force, tile probes: a chain of dependent loads that needs neither neighbours nor cohesion) in
- * the shadow of the cohesion term, and the step only joins the results.  Same values, same order: identical results. */
+ * that follows must pass unchanged (NAVHIP_ERR_INVALID otherwise) --: the first half of the per-agent chain (flow
+ * sampling, line of sight, arrive force, tile probes: a chain of dependent loads that needs neither neighbours nor
+ * cohesion) then runs on a side stream beside the front and the cohesion term, and the step only joins the results;
+ * without the flag it runs in the step, in front of the searches.  Same values, same order: identical results. */
 #define NAVHIP_PREFETCH_FIELDS_READY 0x4u
 int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world, void *stream, uint32_t flags);
 /* Scheduling hint for a caller that runs other wide work (the field builds of the NEXT tick, say)
@@ -594,11 +600,6 @@ typedef struct navhip_tick navhip_tick;
                                      chain of short dependent launches: every cross-stream edge costs a barrier packet
                                      (10-20 us once the host runs ahead of the device) and buys no overlap there --
                                      configs[0] 0.27 -> ... ms per tick (profiles/r05_host_overhead_*.txt)              */
-#define NAVHIP_TICK_SPLIT_MID 0x4u /* run the sampling half of the per-agent chain on the front of the step
-                                     (NAVHIP_PREFETCH_FIELDS_READY) instead of one launch behind the join.  Measured
-                                     (profiles/r05_ab_split_mid_*.txt): k_agent_mid 31.4 us -> half A 15.0 us in the cohesion
-                                     term's shadow + half B 23.3 us behind the join -- both halves are chains of dependent
-                                     loads --, the tick 0.340 against 0.337 ms: off by default                          */
 typedef struct navhip_tick_desc {
     navhip_world world;             /* DEVICE arrays of the snapshot (buffer set 0: pos_xz, vel_xz, field_pool);
                                        work_begin/work_end = this rank's uid slab                                      */

@@ -461,6 +461,7 @@ _SIGS.update({
     "navhip_get_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "navhip_stream_create_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "navhip_stream_beside": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "navhip_stream_main": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "navhip_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 5)]),
     "navhip_last_step_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
     "navhip_step_lists_peek": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 6)]),
@@ -666,6 +667,13 @@ def _ctx_stream_beside(self, main_stream, cu_begin=0, cu_count=0):
     cu_count > 0 restricts it to the compute units [cu_begin, cu_begin + cu_count)."""
     out = C.c_void_p()
     self._chk(lib().navhip_stream_beside(self._h, C.c_void_p(main_stream), cu_begin, cu_count, C.byref(out)), "navhip_stream_beside")
+    return out.value
+
+
+def _ctx_stream_main(self):
+    """navhip_stream_main: the library's own stream for the agent chain (a hipStream_t value)."""
+    out = C.c_void_p()
+    self._chk(lib().navhip_stream_main(self._h, C.byref(out)), "navhip_stream_main")
     return out.value
 
 
@@ -1078,6 +1086,7 @@ NavContext.step_lists_peek = _ctx_step_lists_peek
 NavContext.stream_wait_stage = _ctx_stream_wait_stage
 NavContext.stream_create_partial = _ctx_stream_create_partial
 NavContext.stream_beside = _ctx_stream_beside
+NavContext.stream_main = _ctx_stream_main
 NavContext.counters = _ctx_counters
 NavContext.agent_step = _ctx_agent_step
 NavContext.agent_step_dev = _ctx_agent_step_dev
@@ -1089,7 +1098,7 @@ NavContext.G_ClearPath_NewVelocity = _ctx_clearpath
 # ---------------------------------------------------------------------------------------------
 # the whole tick behind one call (navhip_tick_*, csrc/tick_api.hip)
 # ---------------------------------------------------------------------------------------------
-TICK_GRAPH, TICK_SERIAL, TICK_SPLIT_MID = 0x1, 0x2, 0x4
+TICK_GRAPH, TICK_SERIAL = 0x1, 0x2
 
 
 class TickDesc(C.Structure):

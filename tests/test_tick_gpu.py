@@ -17,11 +17,11 @@ def _torch():
     return torch
 
 
-def _run(driver, ticks=5, graph=False, switch_at=None, serial=False, split_mid=False, **extra):
+def _run(driver, ticks=5, graph=False, switch_at=None, serial=False, **extra):
     from permafrost_engine_amd import tick
     kw = dict(KW)
     kw.update(extra)
-    T = tick.NavTick(driver=driver, graph=graph, serial=serial, split_mid=split_mid, **kw)
+    T = tick.NavTick(driver=driver, graph=graph, serial=serial, **kw)
     if kw.get("world", 1) > 1:
         T.pipelined, T._comm_pending = False, False        # (one rank of a job, no process group: compute only)
     for i in range(ticks):
@@ -69,17 +69,18 @@ def test_one_stream_tick_equals_the_python_schedule(navlib, extra):
         assert np.array_equal(py[k].view(np.uint8), c[k].view(np.uint8)), k
 
 
-def test_sampling_half_on_the_front_equals_the_fused_chain(navlib):
+def test_sampling_half_beside_the_front_equals_the_chain_in_the_step(navlib):
     """With the fields of a tick final before the tick starts (built during the last one), the C tick runs the sampling
-    half of the per-agent chain -- flow taps, line of sight, arrive force, tile probes -- on the front of the step, in the
-    shadow of the cohesion term (NAVHIP_PREFETCH_FIELDS_READY, k_agent_mid_a / _b), and joins it behind the cohesion
-    term (NAVHIP_TICK_SPLIT_MID).  The same numbers as the one fused launch, with the line-of-sight lookup live and in a
-    crowd (work lists of every size)."""
-    for extra in (dict(pipeline_fields=True), dict(pipeline_fields=True, crowd_cells=6)):
-        split = _run("c", ticks=6, split_mid=True, **extra)
-        fused = _run("c", ticks=6, **extra)
-        _same(split, fused)
-        _same(split, _run("python", ticks=6, **extra))
+    half of the per-agent chain -- flow taps, line of sight, arrive force, tile probes: k_agent_pre -- on a side stream
+    beside the front of the step and the cohesion term (NAVHIP_PREFETCH_FIELDS_READY); tick.py's schedule, the reference
+    of the C loop, leaves it to the step, in front of the searches; the one-stream tick runs everything in a row.  The
+    same numbers all three ways, with the line-of-sight lookup live and in a crowd (work lists of every size)."""
+    for extra in (dict(pipeline_fields=True, los=True), dict(pipeline_fields=True, crowd_cells=6)):
+        aside = _run("c", ticks=6, **extra)
+        _same(aside, _run("python", ticks=6, **extra))
+        one = _run("c", ticks=6, serial=True, **extra)
+        for k in ("pos", "vel", "status"):
+            assert np.array_equal(aside[k].view(np.uint8), one[k].view(np.uint8)), k
 
 
 def test_drivers_can_take_turns(navlib):
@@ -131,25 +132,43 @@ def test_tick_rejects_malformed_descriptions(navlib):
 
 def test_tick_time_does_not_depend_on_what_the_process_created_before(navlib):
     """the same world cost 0.18 or 0.37-0.66 ms per tick depending on how many streams the process
-    had created before -- a pooled side stream of the library shared a hardware queue with the caller's stream in one
-    context out of four (scripts/stream_queue_probe.hip).  The side streams are the process's own now, each with a queue
-    to itself, created once: ten contexts in a row -- each on the next stream of torch's pool -- tick alike."""
+    had created before.  Two causes, both measured (scripts/stream_queue_probe.hip, stream_pingpong_probe.hip): a pooled
+    side stream of the library shared a HARDWARE QUEUE with the caller's stream in one context out of four, and two
+    queues on one PIPE of the command processor hand over in 100-200 us instead of 12.  The streams of a tick are the
+    process's own now (csrc/stream_set.hip): four masked streams on four pipes, created once.  Ten contexts in a row tick
+    alike -- and so do ten more whose agent chain runs on the next stream of torch's pool each (the library measures
+    which pipe a caller's stream sits on and takes its side streams from the other three)."""
+    import os
     import time
     from permafrost_engine_amd import tick
-    ms = []
-    for rep in range(10):
-        T = tick.NavTick(chunk_w=16, fields_per_rank=8, agents_per_rank=12_500, rank=4, world=8, shared_map=True,
-                         pipeline_fields=True, driver="c")
-        T.pipelined, T._comm_pending = False, False          # (one rank of a job, compute only)
-        T.new_pos.copy_(T.t["pos_xz"]); T.new_vel.copy_(T.t["vel_xz"])
-        for _ in range(6):
-            T.step()
-        T.sync()
-        t0 = time.perf_counter()
-        for _ in range(40):
-            T.step()
-        T.sync()
-        ms.append((time.perf_counter() - t0) / 40 * 1e3)
-        T.close()
-    # (the failure is a factor of 2 to 3.6; boxes differ by a few per cent from run to run)
-    assert max(ms) <= 1.25 * min(ms), ms
+
+    def sweep():
+        best = []
+        for rep in range(10):
+            T = tick.NavTick(chunk_w=16, fields_per_rank=8, agents_per_rank=12_500, rank=4, world=8, shared_map=True,
+                             pipeline_fields=True, driver="c")
+            T.pipelined, T._comm_pending = False, False          # (one rank of a job, compute only)
+            T.new_pos.copy_(T.t["pos_xz"]); T.new_vel.copy_(T.t["vel_xz"])
+            for _ in range(6):
+                T.step()
+            T.sync()
+            ms = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    T.step()
+                T.sync()
+                ms.append((time.perf_counter() - t0) / 30 * 1e3)
+            best.append(min(ms))                                 # (the steady state of this context)
+            T.close()
+        return best
+
+    own = sweep()
+    # (the failure was a factor of 2 to 3.6; a box wobbles by a few per cent)
+    assert max(own) <= 1.2 * min(own), own
+    os.environ["NAVTICK_TORCH_STREAM"] = "1"
+    try:
+        pooled = sweep()
+    finally:
+        del os.environ["NAVTICK_TORCH_STREAM"]
+    assert max(pooled) <= 1.45 * min(own), (own, pooled)         # (a caller's pooled stream: within reach of the best case)
