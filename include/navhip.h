@@ -485,10 +485,9 @@ int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, v
 #define NAVHIP_PREFETCH_SNAPSHOT_HELD 0x2u
 /*        NAVHIP_PREFETCH_FIELDS_READY  everything the step SAMPLES is final when this call is made -- the field pool
  * and its slot tables, the LOS pool, vdes_xz, the formation / arrival inputs: every array of dev_world, which the step
- * that follows must pass unchanged (NAVHIP_ERR_INVALID otherwise) --: the first half of the per-agent chain (flow
- * sampling, line of sight, arrive force, tile probes: a chain of dependent loads that needs neither neighbours nor
- * cohesion) then runs on a side stream beside the front and the cohesion term, and the step only joins the results;
- * without the flag it runs in the step, in front of the searches.  Same values, same order: identical results. */
+ * that follows must pass unchanged --: the front then also runs the first half of the per-agent chain (flow sampling,
+ * line of sight, arrive force, tile probes: a chain of dependent loads that needs neither neighbours nor cohesion) in
+ * the shadow of the cohesion term, and the step only joins the results.  Same values, same order: identical results. */
 #define NAVHIP_PREFETCH_FIELDS_READY 0x4u
 int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world, void *stream, uint32_t flags);
 /* Scheduling hint for a caller that runs other wide work (the field builds of the NEXT tick, say)
@@ -600,6 +599,11 @@ typedef struct navhip_tick navhip_tick;
                                      chain of short dependent launches: every cross-stream edge costs a barrier packet
                                      (10-20 us once the host runs ahead of the device) and buys no overlap there --
                                      configs[0] 0.27 -> ... ms per tick (profiles/r05_host_overhead_*.txt)              */
+#define NAVHIP_TICK_SPLIT_MID 0x4u /* run the sampling half of the per-agent chain on the front of the step
+                                     (NAVHIP_PREFETCH_FIELDS_READY) instead of one launch behind the join.  Measured
+                                     (profiles/r05_ab_split_mid_*.txt): k_agent_mid 31.4 us -> half A 15.0 us in the cohesion
+                                     term's shadow + half B 23.3 us behind the join -- both halves are chains of dependent
+                                     loads --, the tick 0.340 against 0.337 ms: off by default                          */
 typedef struct navhip_tick_desc {
     navhip_world world;             /* DEVICE arrays of the snapshot (buffer set 0: pos_xz, vel_xz, field_pool);
                                        work_begin/work_end = this rank's uid slab                                      */

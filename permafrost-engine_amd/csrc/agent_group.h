@@ -124,19 +124,8 @@ __device__ __forceinline__ int row_candidate(const seg_table &T, int q)
 // Left to the wave-per-agent path (NH_NB_IRREGULAR): a garrisoned entity among the hits
 // (filter_garrisoned, position.c:100-119, permutes the list) and queries that take the reference's
 // wide linear scan or miss the grid.
-// WL (optional): the step's work lists -- the row files its entity by what it found (file_entity).
-__device__ __forceinline__ void file_entity(const nh_worklists *WL, int uid, uint32_t cnt)
-{
-    if(!WL) return;
-    const int disp = disp_for_count(cnt);
-    const int list = disp == DISP_DONE ? (int)NH_WL_LONE : disp == DISP_FULL ? (int)NH_WL_FULL : (int)NH_WL_ROW0 + (disp - DISP_ROW0);
-    const int sub = (uid >> 2) & (NH_WL_SUB - 1);
-    const int at = atomicAdd(&WL->count[list * NH_WL_SUB + sub], 1);
-    WL->ids[((size_t)list * NH_WL_SUB + sub) * WL->cap + at] = uid;
-}
-
 __device__ void nbr_walk_row(const nh_grid &G, int k, float scaled_max_force, const double *exp_tab,
-                             float2 *terms, const nh_nbr &NB, const nh_worklists *WL = nullptr)
+                             float2 *terms, const nh_nbr &NB)
 {
     typedef grp<16> g;
     const int gl = g::lane();
@@ -152,7 +141,7 @@ __device__ void nbr_walk_row(const nh_grid &G, int k, float scaled_max_force, co
     if(!sp_query_extent(G, icx, icy, ir30, E30) || !sp_query_extent(G, icx, icy, ir10, E10)
     || E30.wide || E10.wide
     || (E30.cx_hi >> 3) - (E30.cx_lo >> 3) > 1 || (E30.cy_hi >> 3) - (E30.cy_lo >> 3) > 1) {
-        if(gl == 0) { NB.cnt[uid] = (NH_NB_IRREGULAR | NH_NB_DONE) << 16; file_entity(WL, uid, NB.cnt[uid]); }
+        if(gl == 0) NB.cnt[uid] = (NH_NB_IRREGULAR | NH_NB_DONE) << 16;
         return;
     }
     const int32_t lim30 = ir30 * ir30, lim10 = ir10 * ir10;
@@ -232,18 +221,14 @@ __device__ void nbr_walk_row(const nh_grid &G, int k, float scaled_max_force, co
     }
     if(gl != 0) return;
     if(irregular) {
-        const uint32_t cnt = (NH_NB_IRREGULAR | NH_NB_DONE) << 16;
-        NB.cnt[uid] = cnt;
-        file_entity(WL, uid, cnt);
+        NB.cnt[uid] = (NH_NB_IRREGULAR | NH_NB_DONE) << 16;
         return;
     }
     v2 sep = mkv(0.0f, 0.0f);
     if(raw30 > 0)                                   // `if(0 == num_near) return 0`, movement.c:1737
         sep = vtrunc(vscale(mkv(acc.x, acc.y), -1.0f), scaled_max_force);
     NB.sep[uid] = make_float2(sep.x, sep.z);
-    const uint32_t cnt = (uint32_t)n_dyn | ((uint32_t)n_stat << 8) | (NH_NB_DONE << 16);
-    NB.cnt[uid] = cnt;
-    file_entity(WL, uid, cnt);
+    NB.cnt[uid] = (uint32_t)n_dyn | ((uint32_t)n_stat << 8) | (NH_NB_DONE << 16);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1029,7 +1029,7 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
 #endif
 template <bool STRIDED>
 __global__ __launch_bounds__(NBR_BLOCK) __attribute__((amdgpu_waves_per_eu(NBR_WAVES, 8)))
-void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, nh_worklists WL, float scaled_max_force)
+void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
 {
     __shared__ double exp_tab[64];
     __shared__ __attribute__((aligned(16))) float2 terms[NBR_BLOCK / 16][16];
@@ -1040,12 +1040,12 @@ void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, nh_worklists WL, float sca
         const int k = blockIdx.x * (NBR_BLOCK / 16) + grp_i;
         if(k >= npool_max || k >= G.cell_start[G.grid_w * G.grid_h]) return;
         if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) return;         // no work item (or outside the slab)
-        nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB, &WL);
+        nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
     }else{
         const int npool = min(npool_max, G.cell_start[G.grid_w * G.grid_h]);
         for(int k = blockIdx.x * (NBR_BLOCK / 16) + grp_i; k < npool; k += gridDim.x * (NBR_BLOCK / 16)) {
             if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) continue;
-            nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB, &WL);
+            nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
         }
     }
 }
@@ -1065,52 +1065,84 @@ __device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_agent_pre: half A of the per-agent scalar chain (mid_thread_a) -- desired direction from the flow / region fields,
-// line of sight, arrive force, tile probes -- in uid order (every per-entity input is contiguous), one thread per
-// entity.  A chain of dependent loads and IEEE divide / sqrt sequences at 1.5 waves per SIMD: latency, not work.  It
-// needs the snapshot, the fields and the map only, so it runs on a side stream beside the neighbour walk and the cohesion
-// term; the half that joins the three (forces -> preferred velocity, mid_vpref) is evaluated at the head of each
-// entity's ClearPath search.  Rounds 2-5 ran both halves as ONE launch (k_agent_mid) behind the join of walk and
-// cohesion: 32 us of latency on the tick's critical path, and a record per entity written for the next launch to
-// read back.
+// k_agent_mid: the per-agent scalar chain -- desired direction, arrive force, probes, priority
+// ladder, vpref -- in uid order (every per-entity input / output is contiguous), one thread per entity.
+// The work is a chain of dependent loads and IEEE divide / sqrt sequences at 1.5 waves per SIMD.  While
+// the loads came one after the other (four flow taps, probes, neighbour results) two lanes per entity --
+// twice the waves to hide them behind -- were faster (37 against 75-105 us); with the loads requested
+// ahead of the chain (mid_thread, sample_flow) one lane is: MID_LANES 1 / 2 / 4 = 0.352 / 0.360 / 0.379 ms
+// per tick in one session (profiles/r03_ab_mid_lanes.txt).
 // ---------------------------------------------------------------------------------------------
+#ifndef MID_LANES
+#define MID_LANES 1
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_agent_pre(nh_step_params P, nh_mid_rec *mid, nh_worklists WL, float scaled_max_force)
+void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
+                                                  nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
+                                                  float scaled_max_force, double force_thresh)
+{
+    const int uid = P.work_begin + (int)((blockIdx.x * 64 + threadIdx.x) / MID_LANES);
+    const bool writer = (threadIdx.x % MID_LANES) == 0;
+    const bool live = uid < P.work_end;
+    int disp = DISP_DONE;
+    if(live) {
+        nh_mid_rec R;
+        v2 out_vel;
+        disp = mid_thread(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R, out_vel);
+        if(writer) {
+            if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
+            if(O.vpref_xz) { O.vpref_xz[2 * uid] = R.vpref[0]; O.vpref_xz[2 * uid + 1] = R.vpref[1]; }
+            if(disp == DISP_DONE) {
+                post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid],
+                            P.radius[uid], out_vel, R.vel_cap, R.status, O);
+            }else{
+                mid[uid] = R;
+            }
+        }
+    }
+#pragma unroll
+    for(int w = 0; w <= NH_WL_FULL; w++)
+        worklist_push(WL, w, live && writer && disp == DISP_ROW0 + w, uid);
+}
+
+// The same chain as two launches (mid_thread_a / _b): half A -- flow sampling, line of sight, arrive force, tile probes:
+// the chain of dependent loads -- needs neither the neighbour walk nor the cohesion term and runs on the FRONT of the
+// step, behind k_agent_nbr, in the shadow of k_cohesion (navhip_agent_prefetch_dev_ex with
+// NAVHIP_PREFETCH_FIELDS_READY); half B follows the join: forces -> vpref -> work lists.  33 us of the tick's critical
+// path become ~10.  The record of every entity of the work range travels through `mid` (32 B written + read).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_agent_mid_a(nh_step_params P, nh_mid_rec *mid, float scaled_max_force)
 {
     const int uid = P.work_begin + (int)(blockIdx.x * 64 + threadIdx.x);
     if(uid >= P.work_end) return;
     nh_mid_rec R;
     mid_thread_a(P, uid, scaled_max_force, R);
     mid[uid] = R;
-    // an entity that takes no step has no row in the neighbour walk (NH_PB_IDLE): it is filed here, with the agents
-    // without neighbours -- whoever takes it off the list writes its outputs (cp_head_of)
-    if(R.mode == AM_IDLE) {
-        const int sub = (uid >> 2) & (NH_WL_SUB - 1);
-        const int at = atomicAdd(&WL.count[NH_WL_LONE * NH_WL_SUB + sub], 1);
-        WL.ids[((size_t)NH_WL_LONE * NH_WL_SUB + sub) * WL.cap + at] = uid;
-    }
 }
 
-// What the head of an entity's search does with the record half A left: the preferred velocity -- ClearPath's des_v --
-// or, for an entity that takes no step (still, combat held, a formation state without formation inputs: `live` false),
-// the outputs themselves: velocity 0, the position kept.  writer: the lane that stores.
-struct cp_head { bool live; v2 vpref; };
-__device__ __forceinline__ cp_head cp_head_of(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
-                                              float scaled_max_force, double force_thresh, const nh_mid_rec &R,
-                                              const nh_step_outs &O, bool writer)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_agent_mid_b(nh_step_params P, nh_nbr NB, const float *coh_xz, nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
+                   float scaled_max_force, double force_thresh)
 {
-    cp_head H;
-    H.live = R.mode != AM_IDLE && R.mode != AM_UNSUPPORTED;
-    H.vpref = mkv(0.0f, 0.0f);
-    if(H.live) H.vpref = mid_vpref(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R);
-    if(writer) {
+    const int uid = P.work_begin + (int)(blockIdx.x * 64 + threadIdx.x);
+    const bool live = uid < P.work_end;
+    int disp = DISP_DONE;
+    if(live) {
+        nh_mid_rec R = mid[uid];
+        v2 out_vel;
+        disp = mid_thread_b(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R, out_vel);
         if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
-        if(O.vpref_xz) { O.vpref_xz[2 * uid] = H.vpref.x; O.vpref_xz[2 * uid + 1] = H.vpref.z; }
-        if(!H.live)
-            post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid], P.radius[uid],
-                        mkv(0.0f, 0.0f), R.vel_cap, R.status, O);
+        if(O.vpref_xz) { O.vpref_xz[2 * uid] = R.vpref[0]; O.vpref_xz[2 * uid + 1] = R.vpref[1]; }
+        if(disp == DISP_DONE) {
+            post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid],
+                        P.radius[uid], out_vel, R.vel_cap, R.status, O);
+        }else{
+            mid[uid] = R;
+        }
     }
-    return H;
+#pragma unroll
+    for(int w = 0; w <= NH_WL_FULL; w++)
+        worklist_push(WL, w, live && disp == DISP_ROW0 + w, uid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1202,82 +1234,48 @@ __device__ __forceinline__ int next_unit(unit_draw &D, int32_t *counters, int to
 
 // ---- k_cp_small: the lists of 1-2 and 3-4 neighbours -- three quarters of the searching agents
 // outside a crowd.  One wave per unit of four agents, one attempt each (clearpath_small_row); an agent
-// without any admissible candidate goes onto the retry list, which a launch of k_cp_rows works off.
-// Behind those units, 64 agents per wave, a thread each:
-//   * the agents WITHOUT any ClearPath neighbour (NH_WL_LONE, most agents of an open world): forces -> preferred
-//     velocity = new velocity -> position test;
-//   * the agents of the workgroup lists (17-64 neighbours): forces -> preferred velocity -> the record k_cp_heavy
-//     reads it from.  k_cp_heavy follows this launch on the same stream; it sits on its register budget (128 per
-//     lane, four waves per SIMD) and the head of a search evaluated inside it spilled 26-34 registers. ----
+// without any admissible candidate goes onto the retry list, which a launch of k_cp_rows works off. ----
 #ifndef CPS_WAVES
 #define CPS_WAVES 4          /* waves (units) per workgroup */
 #endif
-struct cp_force_params { const float *coh_xz; float scaled_max_force; double force_thresh; };
-#define CPS_TAB (5 * NH_WL_SUB)     /* row lists x 2 | lone | heavy | wave */
-__global__ __launch_bounds__(CPS_WAVES * 64) void k_cp_small(nh_step_params P, nh_nbr NB, nh_mid_rec *mid,
-                                                            nh_worklists WL, nh_step_outs O, cp_force_params F)
+__global__ __launch_bounds__(CPS_WAVES * 64) void k_cp_small(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
+                                                            nh_worklists WL, nh_step_outs O)
 {
     __shared__ __attribute__((aligned(16))) float4 cones[CPS_WAVES * 4][8];
-    __shared__ int32_t unit_end[CPS_TAB];
-    __shared__ int32_t sub_cnt[CPS_TAB];
+    __shared__ int32_t unit_end[2 * NH_WL_SUB];
+    __shared__ int32_t sub_cnt[2 * NH_WL_SUB];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // entries 0 .. 2 NH_WL_SUB - 1: the sub-lists of the two row lists (3-4 neighbours first), four agents per unit;
-    // behind them the sub-lists of the lone list and of the two workgroup lists, 64 agents per unit
-    for(int k = threadIdx.x; k < CPS_TAB; k += CPS_WAVES * 64) {
-        const int g = k / NH_WL_SUB;
-        const int list = g < 2 ? NH_WL_ROW1 - g : g == 2 ? (int)NH_WL_LONE : g == 3 ? (int)NH_WL_HEAVY : (int)NH_WL_WAVE;
-        sub_cnt[k] = WL.count[list * NH_WL_SUB + k % NH_WL_SUB];
-    }
+    for(int k = threadIdx.x; k < 2 * NH_WL_SUB; k += CPS_WAVES * 64)
+        sub_cnt[k] = WL.count[(NH_WL_ROW1 - k / NH_WL_SUB) * NH_WL_SUB + k % NH_WL_SUB];
     __syncthreads();
-    unit_totals(unit_end, CPS_TAB, [&](int k) { return k < 2 * NH_WL_SUB ? (sub_cnt[k] + 3) >> 2 : (sub_cnt[k] + 63) >> 6; });
+    unit_totals(unit_end, 2 * NH_WL_SUB, [&](int k) { return (sub_cnt[k] + 3) >> 2; });
     __syncthreads();
     const int u = blockIdx.x * CPS_WAVES + wib;               // one unit per wave
-    if(u >= unit_end[CPS_TAB - 1]) return;
-    const int k = first_above(unit_end, CPS_TAB, u), rel = u - (k ? unit_end[k - 1] : 0);
-    if(k >= 2 * NH_WL_SUB) {
-        // ---- a unit of 64 agents, a thread each
-        const int idx = rel * 64 + lane;
-        if(idx >= sub_cnt[k]) return;
-        const int g = k / NH_WL_SUB;
-        const int list = g == 2 ? (int)NH_WL_LONE : g == 3 ? (int)NH_WL_HEAVY : (int)NH_WL_WAVE;
-        const int uid = WL.ids[((size_t)list * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
-        const nh_mid_rec R = mid[uid];
-        // (an entity that takes no step: the head writes its outputs, whatever list it is on)
-        const cp_head H = cp_head_of(P, uid, NB, F.coh_xz, F.scaled_max_force, F.force_thresh, R, O, true);
-        if(!H.live) return;
-        if(g == 2)            // inside_pcr of nothing is false (clearpath.c:604): the preferred velocity is the new one
-            post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid], P.radius[uid],
-                        H.vpref, R.vel_cap, R.status, O);
-        else { mid[uid].vpref[0] = H.vpref.x; mid[uid].vpref[1] = H.vpref.z; }
-        return;
-    }
-    bool live = true;
+    bool live = u < unit_end[2 * NH_WL_SUB - 1];
     int uid = 0;
     bool found = true;
-    {
+    if(live) {
+        const int k = first_above(unit_end, 2 * NH_WL_SUB, u), rel = u - (k ? unit_end[k - 1] : 0);
         const int list = NH_WL_ROW1 - k / NH_WL_SUB, sub = k % NH_WL_SUB;
         const int idx = rel * 4 + (lane >> 4);
         live = idx < sub_cnt[k];                                // (else: a row beyond the end of its sub-list)
         if(live) {
             uid = WL.ids[((size_t)list * NH_WL_SUB + sub) * WL.cap + idx];
             const nh_mid_rec R = mid[uid];
+            const uint32_t c = NB.cnt[uid];
+            const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+            cpent ent;
+            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+            ent.radius = P.radius[uid];
             const int gl = lane & 15;
-            const cp_head H = cp_head_of(P, uid, NB, F.coh_xz, F.scaled_max_force, F.force_thresh, R, O, gl == 0);
-            live = H.live;
-            if(live) {
-                const uint32_t c = NB.cnt[uid];
-                const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
-                cpent ent;
-                ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-                ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-                ent.radius = P.radius[uid];
-                const bool have = gl < n_dyn + n_stat, isdyn = gl < n_dyn;
-                cpent nb; nb.pos = mkv(0, 0); nb.vel = mkv(0, 0); nb.radius = 0;
-                if(have) nb = nbr_load(NB, uid, isdyn ? gl : 32 + gl - n_dyn);
-                const v2 nv = clearpath_small_row(ent, H.vpref, nb, isdyn, have, cones[wib * 4 + (lane >> 4)], found);
-                if(found && gl == 0)
-                    post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
-            }
+            const bool have = gl < n_dyn + n_stat, isdyn = gl < n_dyn;
+            cpent nb; nb.pos = mkv(0, 0); nb.vel = mkv(0, 0); nb.radius = 0;
+            if(have) nb = nbr_load(NB, uid, isdyn ? gl : 32 + gl - n_dyn);
+            const v2 nv = clearpath_small_row(ent, mkv(R.vpref[0], R.vpref[1]), nb, isdyn, have,
+                                              cones[wib * 4 + (lane >> 4)], found);
+            if(found && gl == 0)
+                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
         }
     }
     worklist_push(WL, NH_WL_RETRY, live && !found && (lane & 15) == 0, uid);
@@ -1293,7 +1291,7 @@ __global__ __launch_bounds__(CPS_WAVES * 64) void k_cp_small(nh_step_params P, n
 __attribute__((amdgpu_waves_per_eu(CP_ROWS_OCC, CP_ROWS_OCC)))
 __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                            nh_worklists WL, nh_step_outs O, int list0, int nlists,
-                                                           int ticket_set, cp_force_params F)
+                                                           int ticket_set)
 {
     __shared__ cp_lds<16> lds[CPR_WAVES * 4];
     // unit_end[k] = units of the sub-lists up to and including k (k = order * NH_WL_SUB + sub)
@@ -1336,19 +1334,16 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
         if(idx < sub_cnt[k]) {                  // (else: a row beyond the end of its sub-list)
             const int uid = WL.ids[((size_t)list * NH_WL_SUB + sub) * WL.cap + idx];
             const nh_mid_rec R = mid[uid];
-            const cp_head H = cp_head_of(P, uid, NB, F.coh_xz, F.scaled_max_force, F.force_thresh, R, O, (lane & 15) == 0);
-            if(H.live) {
-                const uint32_t c = NB.cnt[uid];
-                const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
-                cpent ent;
-                ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-                ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-                ent.radius = P.radius[uid];
-                cp_load_lists<16>(P.grid, NB, uid, n_dyn, n_stat, S);
-                const v2 nv = clearpath_grp<16>(ent, H.vpref, n_dyn, n_stat, S);
-                if((lane & 15) == 0)
-                    post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
-            }
+            const uint32_t c = NB.cnt[uid];
+            const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+            cpent ent;
+            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+            ent.radius = P.radius[uid];
+            cp_load_lists<16>(P.grid, NB, uid, n_dyn, n_stat, S);
+            const v2 nv = clearpath_grp<16>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S);
+            if((lane & 15) == 0)
+                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
         }
         HIST_UNIT(2, tu0);
     }
@@ -1415,7 +1410,6 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
                 const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
                 const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
                 const nh_mid_rec R = mid[uid];
-                if(R.mode == AM_UNSUPPORTED) continue;             // (takes no step: finished by whoever made the records)
                 const uint32_t c = NB.cnt[uid];
                 const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
                 cpent ent;
@@ -1477,7 +1471,6 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
         const int list = pass == 0 ? (k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) : NH_WL_TEAM;
         const int uid = WL.ids[((size_t)list * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
         const nh_mid_rec R = mid[uid];
-        if(R.mode == AM_UNSUPPORTED) continue;    // (uniform over the workgroup: every wave reads the same record)
         const uint32_t c = NB.cnt[uid];
         const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
         cpent ent;
@@ -1528,15 +1521,6 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
     for(int idx = blockIdx.x * AG_WAVES + wib; idx < count; idx += gridDim.x * AG_WAVES) {
         const int uid = WL.ids[((size_t)NH_WL_FULL * NH_WL_SUB + sub) * WL.cap + idx];
         const nh_mid_rec R = mid[uid];
-        if(R.mode == AM_IDLE || R.mode == AM_UNSUPPORTED) {                // (takes no step: velocity 0, the position kept)
-            if(lane == 0) {
-                if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
-                if(O.vpref_xz) { O.vpref_xz[2 * uid] = 0.0f; O.vpref_xz[2 * uid + 1] = 0.0f; }
-                post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid], P.radius[uid],
-                            mkv(0.0f, 0.0f), R.vel_cap, R.status, O);
-            }
-            continue;
-        }
         const uint32_t my_slot = (uint32_t)G.pool_of[uid];
         const uint32_t my_bits = slot_bits(G, my_slot);
         const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
@@ -1575,7 +1559,6 @@ __global__ __launch_bounds__(AG_WAVES * 64) void k_agent_full(nh_step_params P, 
         cpent ent; ent.pos = me; ent.vel = vel; ent.radius = my_radius;
         const v2 nv = clearpath_grp<64>(ent, vpref, n_dyn, n_stat, S);
         if(lane == 0) {
-            if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
             if(O.vpref_xz) { O.vpref_xz[2 * uid] = vpref.x; O.vpref_xz[2 * uid + 1] = vpref.z; }
             post_thread(P, uid, me, P.state[uid], P.flags[uid], my_radius, nv, R.vel_cap, R.status, O);
         }
@@ -1891,29 +1874,19 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
     }
 }
 
-__global__ void k_zero_i32(int32_t *p, int n)
-{
-    for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
-}
-
-// The neighbour walk files every entity it visits on the step's work lists (counter set `parity`).  wl_dirty: a walk
-// has already filed entities on this set and no step consumed them (a prefetch for another snapshot): cleared first.
-void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, nh_worklists WL, int parity, bool wl_dirty, hipStream_t s)
+void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t s)
 {
     if(P.n_ents > 0 && P.work_end > P.work_begin) {
         const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
         const int slab = P.work_end - P.work_begin;
-        WL.count += parity * NH_WL_COUNTERS;
-        if(wl_dirty)
-            hipLaunchKernelGGL(k_zero_i32, dim3(((int)NH_WL_COUNTERS + 255) / 256), dim3(256), 0, s, WL.count, (int)NH_WL_COUNTERS);
         if(slab == P.n_ents) {
             hipLaunchKernelGGL(k_agent_nbr<false>, dim3((P.n_ents + NBR_BLOCK / 16 - 1) / (NBR_BLOCK / 16)), dim3(NBR_BLOCK), 0, s,
-                               P.grid, P.n_ents, NB, WL, smf);
+                               P.grid, P.n_ents, NB, smf);
         }else{
             // rows for the slab + a quarter (its halo in the pool); never more than one per entity
             const int rows = (int)min((long long)P.n_ents, (long long)slab + slab / 4 + 1024);
             hipLaunchKernelGGL(k_agent_nbr<true>, dim3((rows + NBR_BLOCK / 16 - 1) / (NBR_BLOCK / 16)), dim3(NBR_BLOCK), 0, s,
-                               P.grid, P.n_ents, NB, WL, smf);
+                               P.grid, P.n_ents, NB, smf);
         }
     }
 }
@@ -1956,6 +1929,11 @@ void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hi
 {
     const coh_scratch C = coh_layout(scratch, n_flocks, n_members);
     hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 4), s);
+}
+
+__global__ void k_zero_i32(int32_t *p, int n)
+{
+    for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
 }
 
 // the counting sort that regroups the lanes of every flock (k_coh_bin .. k_coh_scatter) into perm[which]
@@ -2018,70 +1996,102 @@ void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *
     coh_regroup(P, C, *parity, s);
     *parity ^= 1;
 }
-// entries a sub-list can receive.  The walk files entity uid on sub-list (uid >> 2) mod NH_WL_SUB: at most
-// ceil(n_ents / 256) * 4 entries.  The retry list is filled by k_cp_small's row waves, four entries each at most, wave
-// index mod NH_WL_SUB: ceil((n_work / 4 + 2 NH_WL_SUB) / NH_WL_SUB) * 4.
-int nh_worklist_cap(int n_ents)
+// entries a sub-list can receive: its producers are the k_agent_mid waves with index = sub (mod
+// NH_WL_SUB), each of which steps 64 / MID_LANES entities
+int nh_worklist_cap(int n_work)
 {
-    return ((n_ents + 255) / 256) * 4 + 32;
+    const int waves = (n_work * MID_LANES + 63) / 64;
+    // (+ 16: the retry list is filled by k_cp_small's waves -- four entries each, a few more of them per
+    // sub-list than there are k_agent_mid waves' worth)
+    return ((waves + NH_WL_SUB - 1) / NH_WL_SUB) * (64 / MID_LANES) + 16;
 }
 
-// half A of the per-agent chain for the work range -> d_mid; the entities that take no step are filed on NH_WL_LONE
-// of counter set `parity`
-void nh_launch_agent_pre(const nh_step_params &P, nh_mid_rec *d_mid, nh_worklists WL, int parity, hipStream_t s)
+// k_agent_mid + the consumers of its work lists.  The list counters alternate between two sets:
+// a launch sequence uses one and zeroes the other for its successor (no memset on the stream).
+// Returns whether anything was launched (the caller flips the parity only then: a step that launches nothing
+// does not clear the other set either).
+void nh_launch_agent_mid_a(const nh_step_params &P, nh_mid_rec *d_mid, hipStream_t s)
 {
     const int nwork = P.work_end - P.work_begin;
     if(!(P.n_ents > 0 && nwork > 0)) return;
     const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
-    WL.count += parity * NH_WL_COUNTERS;
-    hipLaunchKernelGGL(k_agent_pre, dim3((nwork + 63) / 64), dim3(64), 0, s, P, d_mid, WL, smf);
+    hipLaunchKernelGGL(k_agent_mid_a, dim3((nwork + 63) / 64), dim3(64), 0, s, P, d_mid, smf);
 }
 
-// The consumers of the work lists the neighbour walk filled (half A's records in d_mid, the cohesion term in d_coh).
-// The list counters alternate between two sets: a launch sequence uses one and zeroes the other for its successor
-// (no memset on the stream).  Returns whether anything was launched (the caller flips the parity only then: a step
-// that launches nothing does not clear the other set either).
 bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
-                            hipStream_t side, hipEvent_t ev[2])
+                            hipStream_t side, hipStream_t side2, hipEvent_t ev[3], bool mid_a_done)
 {
     const int nwork = P.work_end - P.work_begin;
     if(!(P.n_ents > 0 && nwork > 0)) return false;
     // SCALED_MAX_FORCE and the 1 % force threshold of movement.c:1870-1905 (same for every agent)
     const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
     const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
-    const cp_force_params F = {(const float*)d_coh, smf, thresh};
     int32_t *zero_next = WL.count + (parity ^ 1) * NH_WL_COUNTERS;
     WL.count += parity * NH_WL_COUNTERS;
-    // s: the rows of 5-16 neighbours, the irregular agents.  side: the agents with 1-4 neighbours and the ones without
-    // any (most of them, outside a crowd), whatever of them needs the retry logic, then the workgroup problems (17-64
-    // neighbours).  Every wave / workgroup keeps drawing units until none are left.  (A third stream for the workgroup
-    // problems was measured and lost: profiles/r04_ab_cp_three_streams.txt.)
+    if(mid_a_done && MID_LANES == 1)
+        hipLaunchKernelGGL(k_agent_mid_b, dim3((nwork + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh, d_mid, WL, O, smf, thresh);
+    else
+        hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
+                           d_mid, WL, O, smf, thresh);
+    // the ClearPath launches.  s: the rows of 5-16 neighbours, the irregular agents.  side: the agents with 1-4
+    // neighbours (most of them, outside a crowd), whatever of them needs the retry logic, then the workgroup problems
+    // (17-64 neighbours).  Every wave / workgroup keeps drawing units until none are left.
+    // NAVHIP_CP_SCHED=1 (developer knob) puts the workgroup problems on a third stream, side2, beside the small ones
+    // they do not depend on: measured and LOST -- 0.317 against 0.310 ms per tick on ordinary ticks (one more fork
+    // and join on the agent stream cost what the shorter chain saved), 5.83 against 4.89 in the crowded world (the
+    // workgroup searches then race k_cp_rows for the chip instead of inheriting it: profiles/r04_ab_cp_three_streams.txt).
+    static int sched = -1;
+    if(sched < 0) { const char *e = getenv("NAVHIP_CP_SCHED"); sched = e ? atoi(e) : 0; }
     const bool fork = side && ev && ev[0] && ev[1];
-    hipStream_t sh = fork ? side : s;
+    const bool fork2 = fork && side2 && ev[2] && sched != 0;
+    hipStream_t sh = fork ? side : s, sh2 = fork2 ? side2 : sh;
     if(fork) {
         hipEventRecord(ev[0], s);
         hipStreamWaitEvent(sh, ev[0], 0);
+        if(fork2) hipStreamWaitEvent(sh2, ev[0], 0);
     }
     const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
     const int nblk_rows = min(4096 / CPR_WAVES, (nwork + 15) / 16 * (CP_WAVES / CPR_WAVES) + 1);
     // (the rows first: behind a host that is not ahead of the device -- the tick after a synchronisation -- every
     // launch in front of it delays its start by one enqueue)
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                       (int)NH_WL_ROW3, 2, 0, F);
-    // (units: four agents of the row lists each, then 64 agents each of the lone list and of the workgroup lists)
-    const int small_units = nwork / 4 + 2 * NH_WL_SUB + nwork / 64 + 3 * NH_WL_SUB;
-    hipLaunchKernelGGL(k_cp_small, dim3((small_units + CPS_WAVES - 1) / CPS_WAVES + 1), dim3(CPS_WAVES * 64), 0, sh, P, NB,
-                       d_mid, WL, O, F);
+                       (int)NH_WL_ROW3, 2, 0);
+    if(fork2) {
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh2, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           (int32_t*)nullptr, 0);
+#if NH_CP_BAIL
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh2, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           (int32_t*)nullptr, 1);
+#endif
+        hipEventRecord(ev[2], sh2);
+    }
+    hipLaunchKernelGGL(k_cp_small, dim3((nwork / 4 + 2 * NH_WL_SUB + CPS_WAVES - 1) / CPS_WAVES + 1), dim3(CPS_WAVES * 64), 0, sh, P, NB,
+                       (const nh_mid_rec*)d_mid, WL, O);
     hipLaunchKernelGGL(k_cp_rows, dim3(64 * CP_WAVES / CPR_WAVES), dim3(CPR_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                       (int)NH_WL_RETRY, 1, 1, F);
-    // (the last launch on `side` clears the other set of list counters: see k_cp_heavy)
-    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                       zero_next, 0);
+                       (int)NH_WL_RETRY, 1, 1);
+    if(fork2) {
+        // the other set of list counters, for the next step: on `side`, where the library copies every step's
+        // counters to pinned host memory behind the step (navhip_step_lists_peek) -- the stream orders the clearing
+        // of a set behind the copy of that set
+        hipLaunchKernelGGL(k_zero_i32, dim3(((int)NH_WL_COUNTERS + 255) / 256), dim3(256), 0, sh, zero_next, (int)NH_WL_COUNTERS);
+    }else{
+        // (the last launch on `side` clears the other set of list counters: see k_cp_heavy)
+#if NH_CP_BAIL
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           (int32_t*)nullptr, 0);
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           zero_next, 1);
+#else
+        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
+                           zero_next, 0);
+#endif
+    }
     if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
                        (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, (int32_t*)nullptr);
     if(fork) hipStreamWaitEvent(s, ev[1], 0);
+    if(fork2) hipStreamWaitEvent(s, ev[2], 0);
     return true;
 }
 

@@ -218,11 +218,11 @@ NH_FN v2 vpref_from_forces(const nh_step_params &P, int uid, int mode, v2 me, v2
 // ---------------------------------------------------------------------------------------------
 // the per-agent scalar chain: desired direction, arrive force, probes, ladder -> vpref
 // ---------------------------------------------------------------------------------------------
-// The chain in two halves.  Half A (k_agent_pre) is everything that reads the snapshot, the flow / LOS fields and the map
-// only -- the desired direction (a chain of dependent loads), the arrive force, the tile probes --: nothing of the
-// neighbour walk or the cohesion term, so it runs beside both, on a side stream.  Half B joins the three: forces ->
-// vpref; it is evaluated at the head of the entity's ClearPath search (mid_vpref), the list an entity is searched from
-// being a function of its neighbour count alone (disp_for_count: the neighbour walk files the entity).
+// The chain in two halves.  Half A is everything that reads the snapshot, the flow / LOS fields and the map only -- the
+// desired direction (a chain of dependent loads), the arrive force, the tile probes --: nothing of the neighbour walk
+// or the cohesion term, so it can run in the shadow of k_cohesion behind the neighbour walk.  Half B joins the three:
+// forces -> vpref -> which ClearPath list.  mid_thread = A then B on one thread (the fused kernel, the wave-per-agent
+// path and the host-side unit tests); k_agent_mid_a / _b run them as two launches with the record in between.
 // R.mode == AM_IDLE after half A: a still / combat-held entity (nothing more to do).
 NH_FN void mid_thread_a(const nh_step_params &P, int uid, float scaled_max_force, nh_mid_rec &R)
 {
@@ -300,29 +300,6 @@ NH_FN void mid_thread_a(const nh_step_params &P, int uid, float scaled_max_force
     R.probes = (uint16_t)((mode >= AM_POINT_SEEK && mode <= AM_FORM_POINT) ? probes_here : 0u);
 }
 
-// Half B in two pieces.  mid_vpref: forces -> preferred velocity of an entity half A left a record for (any mode but
-// AM_IDLE / AM_UNSUPPORTED); what the ClearPath kernels evaluate at the head of a search since round 6 -- the launch
-// that did it for every entity in front of them (k_agent_mid) was 32 us of dependent-load latency on the tick's
-// critical path.  disp_for_count: which list an entity with `cnt` neighbours (nh_nbr.cnt) is searched from.
-NH_FN v2 mid_vpref(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
-                   float scaled_max_force, double force_thresh, const nh_mid_rec &R)
-{
-    if(R.mode == AM_ZERO_VPREF) return mkv(0.0f, 0.0f);
-    const float2 s2 = NB.sep[uid];
-    const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-    const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-    return vpref_from_forces(P, uid, R.mode, me, vel, P.flock[uid], mkv(R.arrive[0], R.arrive[1]), mkv(s2.x, s2.y),
-                             (uint32_t)R.probes, coh_xz, scaled_max_force, force_thresh);
-}
-
-NH_FN int disp_for_count(uint32_t cnt)
-{
-    if((cnt >> 16) & NH_NB_IRREGULAR) return DISP_FULL;
-    const int n = (int)(cnt & 0xff) + (int)((cnt >> 8) & 0xff);
-    return n == 0 ? DISP_DONE : n <= 2 ? DISP_ROW0 : n <= 4 ? DISP_ROW1 : n <= 8 ? DISP_ROW2 : n <= NH_ROW_MAX ? DISP_ROW3
-         : n <= 32 ? DISP_WAVE : DISP_HEAVY;
-}
-
 NH_FN int mid_thread_b(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
                        float scaled_max_force, double force_thresh, nh_mid_rec &R, v2 &out_vel)
 {
@@ -331,17 +308,26 @@ NH_FN int mid_thread_b(const nh_step_params &P, int uid, const nh_nbr &NB, const
     if(mode == AM_IDLE || mode == AM_UNSUPPORTED)
         return DISP_DONE;
     const uint32_t cnt = NB.cnt[uid];
-    const int disp = disp_for_count(cnt);
-    if(disp == DISP_FULL)
+    if((cnt >> 16) & NH_NB_IRREGULAR)
         return DISP_FULL;                                  // (arrive and probes are in the record)
-    const v2 vpref = mid_vpref(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R);
+    const float2 s2 = NB.sep[uid];
+    v2 vpref = mkv(0.0f, 0.0f);
+    if(mode != AM_ZERO_VPREF) {
+        const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+        const v2 vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+        vpref = vpref_from_forces(P, uid, mode, me, vel, P.flock[uid], mkv(R.arrive[0], R.arrive[1]), mkv(s2.x, s2.y),
+                                  (uint32_t)R.probes, coh_xz, scaled_max_force, force_thresh);
+    }
     R.vpref[0] = vpref.x; R.vpref[1] = vpref.z;
-    if(disp == DISP_DONE)                              // inside_pcr of nothing is false (clearpath.c:604)
+
+    const int n = (int)(cnt & 0xff) + (int)((cnt >> 8) & 0xff);
+    if(n == 0) {                                       // inside_pcr of nothing is false (clearpath.c:604)
         out_vel = vpref;
-    return disp;
+        return DISP_DONE;
+    }
+    return n <= 2 ? DISP_ROW0 : n <= 4 ? DISP_ROW1 : n <= 8 ? DISP_ROW2 : n <= NH_ROW_MAX ? DISP_ROW3 : n <= 32 ? DISP_WAVE : DISP_HEAVY;
 }
 
-// the whole chain on one thread (the host-side unit tests, tests/hostsim)
 NH_FN int mid_thread(const nh_step_params &P, int uid, const nh_nbr &NB, const float *coh_xz,
                      float scaled_max_force, double force_thresh, nh_mid_rec &R, v2 &out_vel)
 {

@@ -96,21 +96,18 @@ struct nh_nbr {
     int       stride;          // floats per entity (= 64 * 5)
 };
 
-// Work lists filled on the device (counters[NH_WL_*] + ids), consumed by fixed-size launches that stride over them.
-// The NEIGHBOUR WALK files every entity it visits: by its number of ClearPath neighbours (disp_for_count), irregular
-// gathers onto NH_WL_FULL -- an entity's list does not depend on anything the rest of the step computes.
+// Work lists filled on the device (counters[NH_WL_*] + ids), consumed by fixed-size launches that
+// stride over them: agents that still need a ClearPath search after k_agent_mid.
 enum { NH_WL_ROW0 = 0, NH_WL_ROW1, NH_WL_ROW2, NH_WL_ROW3,   // a row of 16 lanes per agent: 1-2, 3-4, 5-8, 9-16 neighbours
        NH_WL_WAVE,          // one workgroup per agent: 17-32 neighbours
        NH_WL_HEAVY,         // one workgroup per agent: 33-64 neighbours (started first)
        NH_WL_FULL,          // one wave per agent, whole step (irregular gather)
        NH_WL_RETRY,         // filled by k_cp_small: 1-4 neighbours and no admissible candidate (the retry logic)
        NH_WL_TEAM,          // filled by k_cp_heavy's first pass: searches one wave handed over to a team of waves
-       NH_WL_LONE,          // no ClearPath neighbour at all: forces -> velocity -> position test, a thread per agent
        NH_WL_LISTS };       // (number of lists)
-// Every list is kept as NH_WL_SUB sub-lists: a few thousand atomics on ONE address serialise at ~5 ns each (measured:
-// they were most of the filing kernel's time).  The walk files entity uid on sub-list (uid >> 2) mod NH_WL_SUB -- at
-// most ceil(n_ents / 256) * 4 entries each, whatever the order of the pool --; the retry list, filled by k_cp_small's
-// waves, takes the wave index mod NH_WL_SUB (one atomic per wave).  nh_worklist_cap covers both.
+// Every list is kept as NH_WL_SUB sub-lists, one per group of producer waves (wave index mod
+// NH_WL_SUB): an append is one atomic per wave and list, and a few thousand atomics on ONE address
+// serialise at ~5 ns each (measured: they were most of k_agent_mid's time).
 #define NH_WL_SUB 64
 struct nh_worklists {
     int32_t *count;            // [NH_WL_LISTS][NH_WL_SUB] entries + the ticket counters of the ClearPath

@@ -108,7 +108,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(&ctx->midrec, 0, sizeof(ctx->midrec));
     memset(ctx->nbr, 0, sizeof(ctx->nbr));
     memset(ctx->wl, 0, sizeof(ctx->wl));
-    ctx->wl_parity = 0; ctx->wl_dirty = false; ctx->ev_pre = nullptr;
+    ctx->wl_parity = 0;
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->aux_main = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
@@ -154,7 +154,6 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
     if(ctx->ev_regroup) hipEventDestroy(ctx->ev_regroup);
-    if(ctx->ev_pre) hipEventDestroy(ctx->ev_pre);
     for(auto &e : ctx->ev_cp) if(e) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1002,25 +1001,15 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end, true, fork_late ? ctx->ev_fork : nullptr);
     if(rc) return rc;
     if(fork_late) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
-    nh_launch_agent_nbr(P, NB, WL, ctx->wl_parity, ctx->wl_dirty, front);
-    ctx->wl_dirty = true;                       // (entities are filed on the current counter set until a step consumes them)
+    nh_launch_agent_nbr(P, NB, front);
     ctx->pre.mid_a = false;
     ctx->join0_recorded = false;
-    bool pre_aside = false;
     if(flags & NAVHIP_PREFETCH_FIELDS_READY) {
-        // half A of the per-agent chain (k_agent_pre: flow sampling, arrive force, probes) beside the front and the cohesion
-        // term.  An inline front leaves side stream 0 idle until the ClearPath phase: it runs there, and the cohesion stream
-        // waits for it in front of its own "done" event -- the step's stream then waits for ONE event, as before.  A
-        // front on side stream 0: behind the neighbour walk.
-        if(front == s) {
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
-            nh_launch_agent_pre(P, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, ctx->aux[0]);
-            if(!ctx->ev_pre) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_pre, hipEventDisableTiming));
-            HIPCHK(ctx, hipEventRecord(ctx->ev_pre, ctx->aux[0]));
-            pre_aside = true;
-        }else{
-            nh_launch_agent_pre(P, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, front);
-        }
+        // half A of the per-agent chain on the front, behind the neighbour walk, beside the cohesion term.  On an inline
+        // front the "neighbours done" event (NAVHIP_STAGE_NEIGHBOURS: where the next tick's field builds start) is
+        // recorded in front of it -- the front is no longer the critical path of the tick, the cohesion term is
+        if(front == s) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front)); ctx->join0_recorded = true; }
+        nh_launch_agent_mid_a(P, (nh_mid_rec*)ctx->midrec.p, front);
         ctx->pre.mid_a = true;
         memcpy(&ctx->pre.world, w, sizeof(navhip_world));
     }
@@ -1032,7 +1021,6 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // side stream 1: cohesion
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
                                             ctx->aux[1]);
-    if(pre_aside) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_pre, 0));      // (long finished by then)
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
     // (behind the join event: the agent step does not wait for next tick's lane grouping; but the
     // caller's stream does, at the end of navhip_agent_step_dev, so that whatever the caller does
@@ -1115,20 +1103,17 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         }
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
-        // (half A ran with the prefetch -- for this very world, byte for byte -- or runs here, in front of the searches)
+        // (half A ran with the prefetch -- for this very world, byte for byte -- or runs here, fused with half B)
         const bool mid_a_done = ctx->pre.mid_a && memcmp(&ctx->pre.world, w, sizeof(navhip_world)) == 0;
-        if(ctx->pre.mid_a && !mid_a_done) {
-            // half A of another world wrote the records and filed its idle entities: this step cannot use either
-            ctx->last_error = "agent step: the prefetch ran the sampling half for another world (NAVHIP_PREFETCH_FIELDS_READY)";
-            return NAVHIP_ERR_INVALID;
+        if(ctx->pre.mid_a && !mid_a_done && ctx->front_stream != s) {
+            // (half A of another world wrote the records on the front stream: order this step's fused kernel behind it)
+            if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         }
-        if(!mid_a_done) nh_launch_agent_pre(P, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, s);
-        hipEvent_t ev2[2] = {ctx->ev_cp[0], ctx->ev_cp[1]};
         if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                                  ctx->aux[0], ev2)) {
+                                  ctx->aux[0], ctx->aux[1], ctx->ev_cp, mid_a_done)) {
             rc = send_step_lists(ctx, ctx->wl_parity, s);
             ctx->wl_parity ^= 1;
-            ctx->wl_dirty = false;              // (the searches cleared the set that is current now)
             if(rc) return rc;
         }
         if(ctx->regroup_pending && !ctx->snapshot_held) {
@@ -1145,8 +1130,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     rc = spatial_build(ctx, w, &P.grid, s, P.work_begin, P.work_end);
     if(rc) return rc;
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
-    nh_launch_agent_nbr(P, NB, WL, ctx->wl_parity, ctx->wl_dirty, s);
-    ctx->wl_dirty = true;
+    nh_launch_agent_nbr(P, NB, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 4 * sizeof(float))   /* force [n][2] | gathered member positions [n][2] */;
     if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
@@ -1156,13 +1140,10 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(regroup && coh_regroup_due(ctx, P)) nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     const bool serial = ctx->serial_step;
-    nh_launch_agent_pre(P, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, s);
-    hipEvent_t ev2[2] = {ctx->ev_cp[0], ctx->ev_cp[1]};
     if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                              serial ? nullptr : ctx->aux[0], ev2)) {
+                              serial ? nullptr : ctx->aux[0], serial ? nullptr : ctx->aux[1], ctx->ev_cp)) {
         rc = send_step_lists(ctx, ctx->wl_parity, s, serial);
         ctx->wl_parity ^= 1;
-        ctx->wl_dirty = false;
         if(rc) return rc;
     }
     if(prof) { HIPCHK(ctx, hipEventRecord(ctx->ev[5], s)); ctx->ev_valid = true; }
@@ -1222,7 +1203,7 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
     int32_t h[NH_WL_COUNTERS];
     HIPCHK(ctx, hipMemcpy(h, src, sizeof(h), hipMemcpyDeviceToHost));
     // (the wave and the heavy list are reported together: 17-64 neighbours)
-    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1, -1, -1};     // (the retry, team and lone lists are not reported)
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1, -1};     // (the retry and team lists are not reported)
     for(int l = 0; l < 6; l++) out_counts[l] = 0;
     for(int l = 0; l < NH_WL_LISTS; l++)
         for(int sb = 0; sb < NH_WL_SUB; sb++) if(slot_of[l] >= 0) out_counts[slot_of[l]] += h[l * NH_WL_SUB + sb];
@@ -1232,7 +1213,7 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
 int navhip_step_lists_peek(navhip_ctx *ctx, int32_t out_counts[6])
 {
     if(!ctx || !out_counts) return NAVHIP_ERR_INVALID;
-    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1, -1, -1};
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1, -1};
     for(int l = 0; l < 6; l++) out_counts[l] = 0;
     if(!ctx->lists_pinned) return NAVHIP_OK;
     const volatile int32_t *h = ctx->lists_pinned;

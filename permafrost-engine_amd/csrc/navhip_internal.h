@@ -56,8 +56,6 @@ struct navhip_ctx {
     buf          midrec;       // per-entity record k_agent_mid leaves for the work-list consumers
     buf          wl[2];        // work lists: 2 x NH_WL_COUNT counters (alternating), ids
     int          wl_parity;
-    bool         wl_dirty;           // the current counter set holds entities a neighbour walk filed and no step consumed
-    hipEvent_t   ev_pre;             // half A of the per-agent chain (k_agent_pre) on side stream 0, behind a prefetch
     int32_t     *lists_pinned;       // pinned host copy of a step's list counters (navhip_step_lists_peek)
     buf          coh;          // cohesion force per entity
     buf          coh_plan;     // [n_flocks + 1] wave prefix of the cohesion launch
@@ -75,7 +73,7 @@ struct navhip_ctx {
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
     bool         join0_recorded;    // ev_join[0] has been recorded for the front of the last prefetch
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
-    hipEvent_t   ev_cp[3];          // the ClearPath launches of the agent step: lists ready, side chain done ([2] unused)
+    hipEvent_t   ev_cp[3];          // the ClearPath launches of the agent step: lists ready, small problems done, workgroup problems done
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
     int          regroup_override;  // 0 = the library's own cadence (coh_regroup_due); 1 / 2 = the caller (tick_api.hip,
                                     // which keys its captured graphs on the decision) says regroup / do not

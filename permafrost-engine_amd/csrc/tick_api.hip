@@ -56,7 +56,7 @@ struct navhip_tick {
     std::vector<int32_t> bounds;
     hipStream_t      s, f, comm;      // agent chain | field builds ahead | exchange
     hipEvent_t       ev_fields[2], ev_step, ev_comm, ev_side, ev_tmp;
-    bool             ahead, pipelined, comm_pending, computed, serial;
+    bool             ahead, pipelined, comm_pending, computed, serial, split_mid;
     int64_t          ticks;
     int              regroup_age;
     bool             graph;
@@ -121,19 +121,19 @@ static int compute_plain(navhip_tick *T)
             HIPCHK(ctx, hipStreamWaitEvent(T->f, T->ev_tmp, 0));
         }
         if(!T->pipelined) {
-            // This tick's fields were built during the last one: the sampling half of the per-agent chain (k_agent_pre)
-            // runs beside the front of the step (NAVHIP_PREFETCH_FIELDS_READY), on side stream 0 -- THAT stream waits for
-            // the fields, the step's own stream never does (nothing else of the step samples them)
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], T->ev_fields[p], 0));
+            // (NAVHIP_TICK_SPLIT_MID: this tick's fields were built during the last one -- with them final, the front of
+            // the step also runs the sampling half of the per-agent chain, NAVHIP_PREFETCH_FIELDS_READY; otherwise the
+            // front does not wait for them, only the step does, below)
+            if(T->split_mid) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));
             RCCHK(navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE | NAVHIP_PREFETCH_SNAPSHOT_HELD
-                                                                     | NAVHIP_PREFETCH_FIELDS_READY));
+                                                                     | (T->split_mid ? NAVHIP_PREFETCH_FIELDS_READY : 0u)));
         }
         // the fields of the NEXT tick
         if(stage == NAVHIP_STAGE_NEIGHBOURS) RCCHK(navhip_stream_wait_stage(ctx, (void*)T->f, NAVHIP_STAGE_NEIGHBOURS));
         else if(!T->pipelined)               RCCHK(navhip_stream_wait_stage(ctx, (void*)T->f, NAVHIP_STAGE_START));
         RCCHK(build_fields(T, T->pool[p ^ 1], T->f));
         HIPCHK(ctx, hipEventRecord(T->ev_fields[p ^ 1], T->f));
-        if(T->pipelined)
+        if(T->pipelined || !T->split_mid)
             HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));   // this tick's fields (built during the last one)
     }else{
         if(!T->pipelined) RCCHK(navhip_agent_prefetch_dev(ctx, w, (void*)T->s));
@@ -179,9 +179,8 @@ static int compute_graph(navhip_tick *T)
             if(!rc) rc = navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s);
             ctx->serial_step = false;
         }else{
-            // (a replayed tick ends with everything joined: the fields it samples are final when it starts)
             rc = navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE
-                                              | (T->ahead ? NAVHIP_PREFETCH_FIELDS_READY : 0u));
+                                              | ((T->ahead && T->split_mid) ? NAVHIP_PREFETCH_FIELDS_READY : 0u));
             if(!rc && T->ahead) {
                 rc = navhip_stream_wait_stage(ctx, (void*)T->f, stage);
                 if(!rc) rc = build_fields(T, T->pool[p ^ 1], T->f);
@@ -294,6 +293,7 @@ int navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tic
     T->ctx = ctx; T->d = *desc;
     T->serial = (desc->flags & NAVHIP_TICK_SERIAL) != 0;
     T->ahead = desc->field_pool_1 != nullptr && !T->serial;
+    T->split_mid = (desc->flags & NAVHIP_TICK_SPLIT_MID) != 0;
     T->pipelined = desc->bounds != nullptr;
     if(T->pipelined) {
         const int world = navhip_comm_world(ctx);

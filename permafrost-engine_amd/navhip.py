@@ -1098,7 +1098,7 @@ NavContext.G_ClearPath_NewVelocity = _ctx_clearpath
 # ---------------------------------------------------------------------------------------------
 # the whole tick behind one call (navhip_tick_*, csrc/tick_api.hip)
 # ---------------------------------------------------------------------------------------------
-TICK_GRAPH, TICK_SERIAL = 0x1, 0x2
+TICK_GRAPH, TICK_SERIAL, TICK_SPLIT_MID = 0x1, 0x2, 0x4
 
 
 class TickDesc(C.Structure):

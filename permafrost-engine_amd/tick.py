@@ -105,7 +105,8 @@ class NavTick:
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
                  debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True,
-                 straddle=0.0, los=False, flow_velocities=False, share_fields=False, driver="c", graph=None, serial=None):
+                 straddle=0.0, los=False, flow_velocities=False, share_fields=False, driver="c", graph=None, serial=None,
+                 split_mid=False):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cpu") if EMULATED else torch.device("cuda", device)
         tcuda.set_device(self.dev)
@@ -445,6 +446,10 @@ class NavTick:
         if serial is None:
             serial = os.environ.get("NAVTICK_SERIAL") == "1"
         self.serial = bool(serial)
+        # split_mid (C driver): run the sampling half of the per-agent chain on the front of the step, in the shadow of
+        # the cohesion term, instead of one launch behind the join -- measured: no gain (0.340 against 0.337 ms per tick,
+        # profiles/r05_ab_split_mid_*.txt; both halves are latency bound); an option (NAVTICK_SPLIT_MID=1)
+        self.split_mid = bool(split_mid) or os.environ.get("NAVTICK_SPLIT_MID") == "1"
         if graph is None:
             graph = os.environ.get("NAVTICK_GRAPH") == "1"
         self.graph = bool(graph)
@@ -592,7 +597,8 @@ class NavTick:
             self._bounds_c = np.ascontiguousarray(self._bounds, np.int32)
             d.bounds = self._bounds_c.ctypes.data
             d.comm_stream = self.comm.cuda_stream
-        d.flags = (navhip.TICK_GRAPH if self.graph else 0) | (navhip.TICK_SERIAL if self.serial else 0)
+        d.flags = (navhip.TICK_GRAPH if self.graph else 0) | (navhip.TICK_SERIAL if self.serial else 0) \
+            | (navhip.TICK_SPLIT_MID if self.split_mid else 0)
         self._ctick = navhip.Tick(self.ctx, d, keep)
         self._ctick_tick0 = self.tick_no
         info = self._ctick.info()

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench    # noqa: E402
 
-KERNELS = ("k_cp_rows", "k_cp_small", "k_cp_heavy", "k_agent_nbr", "k_agent_pre", "k_cohesion", "k_field_bfs",
+KERNELS = ("k_cp_rows", "k_cp_small", "k_cp_heavy", "k_agent_nbr", "k_agent_mid", "k_cohesion", "k_field_bfs",
            "k_agent_full", "k_sp_place")
 
 

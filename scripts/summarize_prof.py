@@ -90,7 +90,7 @@ def main():
 
         def per_tick(acc, k):
             """launches of kernel k per tick (k_cp_rows and the scans are launched twice a tick)"""
-            ref = max((len(x.get(c, [])) for kk, x in acc.items() if kk.startswith("k_agent_pre") for c in x), default=0)
+            ref = max((len(x.get(c, [])) for kk, x in acc.items() if kk.startswith("k_agent_mid") for c in x), default=0)
             n = max((len(x) for x in acc.get(k, {}).values()), default=0)
             return max(1, round(n / ref)) if ref else 1
 
@@ -135,7 +135,7 @@ def main():
         for k, v in Q.items():
             if not k.startswith(("k_agent", "k_coh", "k_field", "k_sp", "k_cp", "k_wl", "k_zero")):
                 continue
-            ref = max((len(x) for kk, vv in Q.items() if kk.startswith("k_agent_pre") for x in vv.values()), default=0)
+            ref = max((len(x) for kk, vv in Q.items() if kk.startswith("k_agent_mid") for x in vv.values()), default=0)
             n = max((len(x) for x in v.values()), default=0)
             m = max(1, round(n / ref)) if ref else 1                 # launches per tick
             dd = {cn: sum(x[-LAST * m:]) / len(x[-LAST * m:]) * m for cn, x in v.items()}

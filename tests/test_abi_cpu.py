@@ -311,7 +311,7 @@ def test_profile_stamps_cover_the_files_they_list(tmp_path):
     os.remove(os.path.join(d, "agent_math.h"))
     assert bench.csrc_sha(d, files).startswith("missing:")
     # a unit whose kernels were not measured and that names no measured kernel is outside a stamp's cover
-    cov = bench.stamp_units(bench.csrc_files(csrc), ["k_agent_pre", "k_field_bfs"], csrc)
+    cov = bench.stamp_units(bench.csrc_files(csrc), ["k_agent_mid", "k_field_bfs"], csrc)
     assert "state_kernels.hip" not in cov and "agent_kernels.hip" in cov and "field_kernels.hip" in cov
     assert "tick_api.hip" in cov and "navhip_api.hip" in cov and all(f in cov for f in bench.csrc_files(csrc) if f.endswith(".h"))
     assert bench.stamp_units(bench.csrc_files(csrc), [], csrc) == bench.csrc_files(csrc)

@@ -17,11 +17,11 @@ def _torch():
     return torch
 
 
-def _run(driver, ticks=5, graph=False, switch_at=None, serial=False, **extra):
+def _run(driver, ticks=5, graph=False, switch_at=None, serial=False, split_mid=False, **extra):
     from permafrost_engine_amd import tick
     kw = dict(KW)
     kw.update(extra)
-    T = tick.NavTick(driver=driver, graph=graph, serial=serial, **kw)
+    T = tick.NavTick(driver=driver, graph=graph, serial=serial, split_mid=split_mid, **kw)
     if kw.get("world", 1) > 1:
         T.pipelined, T._comm_pending = False, False        # (one rank of a job, no process group: compute only)
     for i in range(ticks):
@@ -69,18 +69,17 @@ def test_one_stream_tick_equals_the_python_schedule(navlib, extra):
         assert np.array_equal(py[k].view(np.uint8), c[k].view(np.uint8)), k
 
 
-def test_sampling_half_beside_the_front_equals_the_chain_in_the_step(navlib):
+def test_sampling_half_on_the_front_equals_the_fused_chain(navlib):
     """With the fields of a tick final before the tick starts (built during the last one), the C tick runs the sampling
-    half of the per-agent chain -- flow taps, line of sight, arrive force, tile probes: k_agent_pre -- on a side stream
-    beside the front of the step and the cohesion term (NAVHIP_PREFETCH_FIELDS_READY); tick.py's schedule, the reference
-    of the C loop, leaves it to the step, in front of the searches; the one-stream tick runs everything in a row.  The
-    same numbers all three ways, with the line-of-sight lookup live and in a crowd (work lists of every size)."""
-    for extra in (dict(pipeline_fields=True, los=True), dict(pipeline_fields=True, crowd_cells=6)):
-        aside = _run("c", ticks=6, **extra)
-        _same(aside, _run("python", ticks=6, **extra))
-        one = _run("c", ticks=6, serial=True, **extra)
-        for k in ("pos", "vel", "status"):
-            assert np.array_equal(aside[k].view(np.uint8), one[k].view(np.uint8)), k
+    half of the per-agent chain -- flow taps, line of sight, arrive force, tile probes -- on the front of the step, in the
+    shadow of the cohesion term (NAVHIP_PREFETCH_FIELDS_READY, k_agent_mid_a / _b), and joins it behind the cohesion
+    term (NAVHIP_TICK_SPLIT_MID).  The same numbers as the one fused launch, with the line-of-sight lookup live and in a
+    crowd (work lists of every size)."""
+    for extra in (dict(pipeline_fields=True), dict(pipeline_fields=True, crowd_cells=6)):
+        split = _run("c", ticks=6, split_mid=True, **extra)
+        fused = _run("c", ticks=6, **extra)
+        _same(split, fused)
+        _same(split, _run("python", ticks=6, **extra))
 
 
 def test_drivers_can_take_turns(navlib):
