@@ -408,6 +408,7 @@ def run_ticks(T, pdist, torch, warmup, steps, early=None):
     tcuda.synchronize()
     T.record = True
     T.ev, T.tick_ev, T.fev, T._tick_rec = [], [], [], 0
+    f_sum0, f_n0 = T.field_build_times()
     t0 = time.perf_counter()
     for _ in range(steps):
         T.step()
@@ -422,6 +423,10 @@ def run_ticks(T, pdist, torch, warmup, steps, early=None):
     dt = time.perf_counter() - t0
     T.record = False
     dt = pdist.max_over_ranks(dt, T.dev)
+    # the field builds as they ran INSIDE the timed ticks (events on the field stream, every fourth tick)
+    f_sum1, f_n1 = T.field_build_times()
+    T.fields_in_tick_ms = (f_sum1 - f_sum0) / (f_n1 - f_n0) if f_n1 > f_n0 else None
+    T.fields_in_tick_samples = f_n1 - f_n0
     ticks = np.array(T.tick_ms()) if steps > 1 and len(T.tick_ev) > 1 else np.array([dt * 1e3 / max(1, steps)])
     return dt, ticks
 
@@ -501,7 +506,8 @@ def main():
                             rank=rank, world=world, device=local, obstacles=cfg["obstacles"],
                             obstacle_ticks=args.warmup + args.steps + 16, tile_exchange=args.tile_exchange,
                             shared_map=shared and not weak, crowd_cells=CROWD if crowd else 0,
-                            pipeline_fields=not args.no_pipeline_fields, los=not args.no_los, flow_velocities=True)
+                            pipeline_fields=not args.no_pipeline_fields, los=not args.no_los, flow_velocities=True,
+                            time_fields=True)
 
     T = make(args.crowded)
     fields_ahead, tick_every = T.pipeline_fields, T.tick_every
@@ -511,6 +517,7 @@ def main():
     phases = T.phase_ms()
     hist = status_histogram(T)
     host_enqueue_ms, tick_driver = T.host_enqueue_ms, getattr(T, "tick_driver", "python (tick.py)")
+    fields_in_tick_ms, fields_in_tick_samples = T.fields_in_tick_ms, T.fields_in_tick_samples
 
     # per-kernel-group durations at the END of the run (the world has crowded by then); the same
     # split for the last warm-up ticks is in `early`
@@ -571,30 +578,50 @@ def main():
                 "frac_of_issue_peak": floor_ms / measured_ms,
                 "counters_of": "ticks 100-110" if key == "SQ_INSTS_VALU" else "ticks 6-11"}
 
-    def roof(which, g=None, when=None):
+    def roof(which, g=None, when=None, in_tick_ms=None):
+        """SURVEY.md section 8(d)'s convention -- algorithmic bytes per launch / the launch's duration / 8 TB/s -- for the
+        field kernel (ONE kernel) or the agent step (a group of kernels: its dominant kernel is named with its own time).
+        The duration is the one measured INSIDE the timed ticks where there is one (the field builds: events on their
+        stream), else the kernel alone on one stream (profiled ticks); hbm_frac_measured prices the bytes the PMC counters
+        saw instead of the algorithmic ones."""
         g = g or groups
         when = when or prof_ticks
         a_ms_ = sum(g[k] for k in ("sp_build", "agent_nbr", "cohesion", "agent_finish"))
-        ms, by = (a_ms_, a_bytes) if which == "agents" else (g["fields"], f_bytes)
+        alone, by = (a_ms_, a_bytes) if which == "agents" else (g["fields"], f_bytes)
+        ms = in_tick_ms if in_tick_ms else alone
         gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {
+        traffic = None if stale else measured.get(which + "_bytes_per_launch")
+        out = {
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": None if stale else measured.get(which + "_bytes_per_launch"),
+            "traffic": traffic,
+            "hbm_frac_measured": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and ms > 0 else None,
             "traffic_stale": bool(stale and measured), "traffic_csrc_sha": measured.get("csrc_sha"),
-            "kernel": ("agent step: k_sp_* + k_agent_nbr + k_cohesion + k_agent_mid + k_cp_*"
-                       if which == "agents" else "k_field_bfs"),
             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by,
+        }
+        if which == "fields":
+            out["kernel"] = "k_field_bfs"
+            out["launch_timing"] = ("HIP events on the field stream around the builds of every fourth TIMED tick "
+                                    "(%d samples): the kernel as it runs beside the agent step" % fields_in_tick_samples) \
+                if in_tick_ms else "HIP events, the kernel alone on one stream, " + when
+            out["avg_launch_ms_alone"] = alone
+            out["frac_alone"] = by / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS if alone > 0 else None
+            out["valu_issue"] = valu(("k_field_",), alone)
+        else:
+            out["kernel"] = "agent step (a GROUP: k_sp_* + k_agent_nbr + k_cohesion + k_agent_mid + k_cp_*)"
+            out["dominant_kernel"] = {"name": "k_cohesion", "ms_alone": g["cohesion"]}
             # the groups run back to back on ONE stream with events between them: a SERIAL time that may exceed
             # ms_per_step, where k_cohesion and the ClearPath kernels overlap on side streams
-            "launch_timing": "HIP events, groups serial on one stream (may exceed ms_per_step), " + when,
-            "kernels_ms": {k: g[k] for k in ("sp_build", "agent_nbr", "cohesion", "coh_regroup", "agent_finish")}
-                          if which == "agents" else {"fields": g["fields"]},
-            "valu_issue": valu(("k_agent_", "k_cp_", "k_coh", "k_sp_"), ms) if which == "agents"
-                          else valu(("k_field_",), ms),
-        }
+            out["launch_timing"] = "HIP events, groups serial on one stream (may exceed ms_per_step), " + when
+            out["kernels_ms"] = {k: g[k] for k in ("sp_build", "agent_nbr", "cohesion", "coh_regroup", "agent_finish")}
+            out["valu_issue"] = valu(("k_agent_", "k_cp_", "k_coh", "k_sp_"), alone)
+        return out
 
-    dom = "agents" if a_ms >= f_ms else "fields"
+    # `roofline` is ONE kernel: k_field_bfs -- the kernel with the most algorithmic bytes per launch (268 MB against the
+    # agent step's 14 MB) and, inside the tick, the longest single launch; the agent step, a group of kernels, follows
+    # as `roofline_secondary`.  (A world without field requests: the agent step alone.)
+    dom = "fields" if f_bytes > 0 and f_ms > 0 else "agents"
     other = "fields" if dom == "agents" else "agents"
+    in_tick = {"fields": fields_in_tick_ms, "agents": None}
 
     # ---- the sustained regime: a run shorter than 100 ticks (the driver's --steps 20) times the friendliest
     # window of the world -- the flocks have not converged yet.  A second, fresh world is then run for 100 ticks
@@ -618,6 +645,7 @@ def main():
                      "cp_wave_17-64_nbrs": status_histogram(Ts)["cp_wave_17-64_nbrs"], "roofline": None}
         sr = roof("agents", sgroups, "ticks %d-%d" % (s_first + 1, Ts.tick_no))
         sustained["roofline"] = {k: sr[k] for k in ("achieved", "frac", "avg_launch_ms", "kernels_ms")}
+        sustained["fields_in_tick_ms"] = Ts.fields_in_tick_ms
         Ts.close()
 
     # ---- the same tick with the reference's field SHARING: its cache is keyed by N_FlowFieldID (chunk + target,
@@ -683,7 +711,7 @@ def main():
             "metric": "agent-steps/sec (+ flow-field cells/sec), every chunk field rebuilt + every agent stepped per tick",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if shared else "weak", "vs_baseline": None,
+            "scaling": None if world == 1 else ("strong" if shared else "weak"), "vs_baseline": None,
             "dtype": "u64-bitmask/u8 fields, f32 agents (f64 exp)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]%s: %dx%d cells, %d flow fields%s = %d chunk fields, %d agents%s"
                                    % (args.config, " crowded" if args.crowded else "", dims[0], dims[1], cfg["fields"],
@@ -701,11 +729,12 @@ def main():
                        "fields_ahead": bool(fields_ahead), "tick_driver": tick_driver,
                        "library": ("NAVHIP_LIB override: " + os.path.basename(os.environ["NAVHIP_LIB"]))
                                   if os.environ.get("NAVHIP_LIB") else "libnavhip.so (in-tree)"},
-            "roofline": roof(dom),
+            "roofline": roof(dom, in_tick_ms=in_tick[dom]),
             "cpu_baseline": cpu,
-            "roofline_secondary": {k: v for k, v in roof(other).items()
-                                   if k in ("achieved", "frac", "traffic", "kernel", "avg_launch_ms",
-                                            "algorithmic_bytes_per_launch", "valu_issue")},
+            "roofline_secondary": {k: v for k, v in roof(other, in_tick_ms=in_tick[other]).items()
+                                   if k in ("achieved", "frac", "traffic", "hbm_frac_measured", "kernel", "dominant_kernel",
+                                            "avg_launch_ms", "algorithmic_bytes_per_launch", "kernels_ms", "launch_timing",
+                                            "valu_issue")},
             "csrc_sha": sha,
             "kernel_groups_ms_serial": {"after_warmup": early, "after_timed_region": groups} if args.steps >= 100 else
                                        {"after_timed_region": groups},
@@ -724,11 +753,14 @@ def main():
                         "ms_tick_5_50_100": t5,
                         "ms_tick_5_50_100_of": "this run" if args.steps >= 100 or sustained is None else "sustained_100",
                         "sustained_100_ms": sustained["ms_per_step"] if sustained else None,
+                        # "run 100 ticks; report median tick"
+                        "survey_8d_median_ms": (sustained["ms_per_step_median"] if sustained else
+                                                float(np.median(ticks)) if args.steps >= 100 else None),
                         "crowded_ms": crowded["ms_per_step"] if crowded else None,
                         "dropin_ms": drop.get("hip_ms_per_tick") if isinstance(drop, dict) else None,
                         "state_pass_ms": state_pass.get("hip_ms_per_tick") if isinstance(state_pass, dict) else None,
                         "host_enqueue_ms": host_enqueue_ms,
-                        "roofline_frac": roof(dom)["frac"], "ranks": world},
+                        "roofline_frac": roof(dom, in_tick_ms=in_tick[dom])["frac"], "ranks": world},
         }
         print(json.dumps(r4(line), separators=(",", ":")), flush=True)
     if T is not None:

@@ -483,12 +483,6 @@ int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, v
  * step then does not make the caller's stream wait for the lane regrouping the cohesion stream runs
  * for the next tick -- that work is ordered in front of the next step's cohesion term anyway. */
 #define NAVHIP_PREFETCH_SNAPSHOT_HELD 0x2u
-/*        NAVHIP_PREFETCH_FIELDS_READY  everything the step SAMPLES is final when this call is made -- the field pool
- * and its slot tables, the LOS pool, vdes_xz, the formation / arrival inputs: every array of dev_world, which the step
- * that follows must pass unchanged --: the front then also runs the first half of the per-agent chain (flow sampling,
- * line of sight, arrive force, tile probes: a chain of dependent loads that needs neither neighbours nor cohesion) in
- * the shadow of the cohesion term, and the step only joins the results.  Same values, same order: identical results. */
-#define NAVHIP_PREFETCH_FIELDS_READY 0x4u
 int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world, void *stream, uint32_t flags);
 /* Scheduling hint for a caller that runs other wide work (the field builds of the NEXT tick, say)
  * beside the agent step: make `stream` wait until the given stage of the step in flight is done, so
@@ -588,22 +582,17 @@ int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_
  *   - [a communicator on the context] the slab exchange (navhip_comm_allgather_step_dev) on a stream of its own, which
  *     only the snapshot consumers of the next tick wait for,
  *   - the advance of the snapshot: position / velocity buffers and the two pools ping-pong.
- * Nothing is waited for; the host returns after a few dozen launches -- or, with NAVHIP_TICK_GRAPH, after ONE
- * hipGraphLaunch of the tick captured once per parity of its ping-pong buffers (single-process worlds without moving
- * obstacles; the library falls back to plain launches when a capture fails).  Results are those of the separate calls,
- * bit for bit: the same kernels on the same buffers in the same order per stream. */
+ * Nothing is waited for; the host returns after a few dozen launches.  Results are those of the separate calls, bit for
+ * bit: the same kernels on the same buffers in the same order per stream. */
 typedef struct navhip_tick navhip_tick;
-#define NAVHIP_TICK_GRAPH  0x1u   /* replay the tick as a captured HIP graph                                         */
 #define NAVHIP_TICK_SERIAL 0x2u   /* the whole tick on ONE stream: no side streams, no events, the fields in front of
                                      the step of their own tick (field_pool_1 unused).  For small worlds, whose tick is a
                                      chain of short dependent launches: every cross-stream edge costs a barrier packet
                                      (10-20 us once the host runs ahead of the device) and buys no overlap there --
                                      configs[0] 0.27 -> ... ms per tick (profiles/r05_host_overhead_*.txt)              */
-#define NAVHIP_TICK_SPLIT_MID 0x4u /* run the sampling half of the per-agent chain on the front of the step
-                                     (NAVHIP_PREFETCH_FIELDS_READY) instead of one launch behind the join.  Measured
-                                     (profiles/r05_ab_split_mid_*.txt): k_agent_mid 31.4 us -> half A 15.0 us in the cohesion
-                                     term's shadow + half B 23.3 us behind the join -- both halves are chains of dependent
-                                     loads --, the tick 0.340 against 0.337 ms: off by default                          */
+#define NAVHIP_TICK_TIME_FIELDS 0x8u /* time the field builds of every fourth tick with two HIP events on the FIELD stream (no
+                                     packet on the agent stream): navhip_tick_info.fields_ms / fields_samples -- how long
+                                     the builds take INSIDE the tick, beside the agent step they overlap with           */
 typedef struct navhip_tick_desc {
     navhip_world world;             /* DEVICE arrays of the snapshot (buffer set 0: pos_xz, vel_xz, field_pool);
                                        work_begin/work_end = this rank's uid slab                                      */
@@ -627,10 +616,10 @@ typedef struct navhip_tick_desc {
 } navhip_tick_desc;
 typedef struct navhip_tick_info {
     int64_t  ticks;                 /* ticks enqueued so far: the current snapshot is buffer set (ticks & 1)            */
-    int32_t  graph;                 /* 1 = ticks are replayed as graphs, 0 = plain launches                             */
-    int32_t  graphs_captured;
     double   host_enqueue_ms;       /* host time spent inside navhip_tick_run since creation                            */
     void    *stream, *field_stream, *comm_stream;
+    double   fields_ms;             /* NAVHIP_TICK_TIME_FIELDS: mean duration of the timed field builds that have finished */
+    int32_t  fields_samples, _pad;
 } navhip_tick_info;
 int  navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tick **out);
 /* Enqueue n ticks; asynchronous. */

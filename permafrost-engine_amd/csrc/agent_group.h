@@ -241,36 +241,7 @@ __device__ __forceinline__ bool inside_pcr(const float4 *cones, int n_cones, v2 
     return false;
 }
 
-// optional work counters of the ClearPath search (-DNH_CP_STATS builds only: scripts/cp_stats.py):
-// per neighbour-count bucket {problems, attempts, candidates generated, candidates queued, cone tests,
-// cp_work iterations, live columns, columns}
-#ifdef NH_CP_STATS
-__device__ unsigned long long nh_cp_cyc[8][8];       // cycles: {cones+admissible, projections, columns, jump, max unit, -, -, -}
-#define CP_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
-#define CP_TMARK(b, k) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); if(grp<G>::lane() == 0) atomicAdd(&nh_cp_cyc[b][k], _n - _t0); _t0 = _n; } while(0)
-__device__ unsigned long long nh_cp_work[8][16];
-#define CP_STAT(b, k, v) do { if(grp<G>::lane() == 0) atomicAdd(&nh_cp_work[b][k], (unsigned long long)(v)); } while(0)
-__device__ __forceinline__ int cp_bucket(int n) { return n <= 2 ? 0 : n <= 4 ? 1 : n <= 8 ? 2 : n <= 16 ? 3 : n <= 32 ? 4 : 5; }
-#define CP_STAT_LANE(b, k, v) atomicAdd(&nh_cp_work[b][k], (unsigned long long)(v))
-#else
-#define CP_STAT(b, k, v)
-#define CP_STAT_LANE(b, k, v)
-#define CP_T0()
-#define CP_TMARK(b, k)
-#endif
-
-#ifndef NH_CP_TC
-#define NH_CP_TC 1          // the wave-wide search keeps a copy of the cones in test order (2 KB of LDS per wave: see DESIGN 3.6b)
-#endif
-#ifndef NH_CP_PACKQ
-#define NH_CP_PACKQ 1       // ... and packs a queue entry into 16 bytes
-#endif
-#ifndef NH_CP_PAD
-#define NH_CP_PAD 0         // (developer knob: float4s of padding per wave-wide / 16-lane scratch, to probe the LDS occupancy cliff)
-#endif
-#ifndef NH_CP_PAD16
-#define NH_CP_PAD16 (NH_CP_TC ? 8 : 0)   // k_cp_rows' workgroup has to own at least k_cp_heavy's LDS (hole inheritance)
-#endif
+#define NH_CP_PAD16 8      // float4s of padding per 16-lane scratch: k_cp_rows' workgroup has to own at least k_cp_heavy's LDS (hole inheritance)
 // LDS scratch of one ClearPath problem on a group of G lanes (at most G neighbours in total):
 //   cones   2 float4 per cone: {apex.x, apex.z, slope(left), slope(right)}, {left.x, left.z, right.x, right.z}
 //   ord     cone slots, nearest neighbour first (the order of the inside-obstacle tests)
@@ -287,10 +258,7 @@ template <int G> struct cp_lds {
     float   ckey[2 * G];             // key of every ray: a lower bound of the distance of its candidates to des_v
     int32_t tau[G], seq[G];          // cp_jump: removal time of every cone, the removal sequence
     float   dyn[(G < 32 ? G : 32) * 5], stat[(G < 32 ? G : 32) * 5];
-    float4  tc[G == 64 && NH_CP_TC ? 2 * G : (G == 64 && NH_CP_PAD ? NH_CP_PAD : (G == 16 && NH_CP_PAD16 ? NH_CP_PAD16 : 1))];  // wave-wide search: the cones in TEST order (cones[ord[k]] copied: one dependent LDS read less per test step)
-#ifdef NH_CP_UNIT_HIST
-    int32_t dbg[4];                  // developer instrumentation: attempts, jump result, rays
-#endif
+    float4  tc[G == 64 ? 2 * G : (G == 16 ? NH_CP_PAD16 : 1)];  // wave-wide search: the cones in TEST order (cones[ord[k]] copied: one dependent LDS read less per test step)
 };
 
 // compute_vnew :368 keeps the first strictly-smaller distance in candidate order, i.e. the minimum
@@ -312,39 +280,9 @@ template <int G> struct cp_lds {
 // reference's `vec_size(&xpoints) == 0` asks); until then every candidate is tested, so that points
 // whose distance is NaN or infinite still count.
 struct cp_bound { float len; int idx; v2 pt; int nfound; int sb;
-#ifdef NH_CP_STATS
-    // developer counters, kept in registers and flushed once per attempt (an atomic per iteration distorts what it measures)
-    unsigned it, busy, ex, out, passes, cols, cands, queued; unsigned long long cw, cg;
-#endif
 };
 #define CP_COL_MARGIN 0.02f
-#ifndef NH_CP_CONE_COMPACT
-#define NH_CP_CONE_COMPACT 1     // column phase: inside-obstacle tests only against the cones within reach of the bound
-#endif
-#ifndef NH_CP_CONES2
-#define NH_CP_CONES2 0           // inside-obstacle tests: two cones per step and lane
-#endif
-#ifndef NH_CP_COLS2
-#define NH_CP_COLS2 0            // column phase (lane = row): two columns per pass
-#endif
-#ifndef NH_CP_ORDER_DEPTH
-#define NH_CP_ORDER_DEPTH 1      // cones are tested deepest-around-des_v first (0: nearest neighbour first)
-#endif
-#ifndef CP_COVER_CONES
-#define CP_COVER_CONES 12
-#endif
-#ifndef NH_CP_COVER
-#define NH_CP_COVER 0            // column phase: rays that lie inside another cone from end to end are no columns (exact, a third of the rays in a MOVING crowd by the model; measured neutral on every benchmark world: off)
-#endif
-#ifndef NH_CP_PACKB
-#define NH_CP_PACKB 0            // more than 64 rays: the rows beyond 64 of several columns share one pass (measured: -1.7 % in the jam as the only column loop but +2.5 % on ordinary ticks; beside the plain loop the second copy of the queue code costs the jam 7 %: off)
-#endif
-#ifndef NH_CP_COLS_V2
-#define NH_CP_COLS_V2 1          // column phase of a wave-wide search: lane = row, the column wave uniform
-#endif
-#ifndef CP_SMALL_RAYS
 #define CP_SMALL_RAYS 8          // up to this many rays (4 neighbours) a problem is searched without queue and bound
-#endif
 
 __device__ __forceinline__ bool cp_alive(const cp_bound &B, float len, int idx)
 {
@@ -362,108 +300,6 @@ struct cp_lane { v2 pt; int idx; float len; int ci; };
 // becomes the bound if it beats it -- takes the next queued candidate.  Runs until the queue is empty
 // (finish = false: candidates still in flight stay with their lanes for the next call) or until
 // nothing is in flight either (finish = true).
-template <int G>
-__device__ void cp_work(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp_lane &L, cp_bound &B,
-                        bool finish)
-{
-    typedef grp<G> g;
-    const int gl = g::lane();
-    const unsigned long long lt_mask = (1ull << gl) - 1ull;
-    int head = 0;
-#ifdef NH_CP_STATS
-    const unsigned long long w_t0 = __builtin_amdgcn_s_memtime();
-#endif
-    for(;;) {
-        if(head < qn) {
-            const bool need = L.ci < 0;
-            const unsigned long long mn = g::ballot(need);
-            if(mn) {
-                const int my = head + __popcll(mn & lt_mask);
-                if(need && my < qn) {
-                    L.pt = mkv(S.qx[my], S.qz[my]); L.idx = S.qi[my]; L.len = S.ql[my];
-                    L.ci = cp_alive(B, L.len, L.idx) ? 0 : -1;
-                }
-                head = uni<G>((int)min(qn, head + (int)__popcll(mn)));
-            }
-        }
-        if(!g::any(L.ci >= 0)) {
-            if(head >= qn) break;
-            continue;
-        }
-        if(!finish && head >= qn) break;
-#ifdef NH_CP_STATS
-        B.it++; B.busy += __popcll(g::ballot(L.ci >= 0));
-        { int v_ = 0; if(L.ci >= 0) { const int sl_ = S.ord[L.ci]; v_ = cone_contains_fast(S.cones[2 * sl_], S.cones[2 * sl_ + 1], L.pt); }
-          if(g::any(v_ == 2)) B.ex++; }
-#endif
-        bool outside = false;
-#if NH_CP_CONES2
-        // two cones per step: two independent chains in flight -- at four waves per SIMD the search waits for
-        // the latency of its own dependent steps more than for issue slots (an agent's cones cost 2 LDS round
-        // trips + a reciprocal square root each), so a step that is sometimes wasted is cheaper than a step more
-        if(L.ci >= 0) {
-            const int c1 = min(L.ci + 1, n_cones - 1);
-            const int s0 = S.ord[L.ci], s1 = S.ord[c1];
-            const float4 A0 = S.cones[2 * s0], B0 = S.cones[2 * s0 + 1], A1 = S.cones[2 * s1], B1 = S.cones[2 * s1 + 1];
-            int v0 = cone_contains_fast(A0, B0, L.pt), v1 = cone_contains_fast(A1, B1, L.pt);
-            if(v0 == 2) v0 = cone_contains_exact(A0, B0, L.pt) ? 1 : 0;
-            if(v1 == 2) v1 = cone_contains_exact(A1, B1, L.pt) ? 1 : 0;
-            if(v0 == 1 || v1 == 1) L.ci = -1;
-            else { L.ci += 2; if(L.ci >= n_cones) { outside = true; L.ci = -1; } }
-        }
-#else
-        if(L.ci >= 0) {
-            const int slot = S.ord[L.ci];
-            const bool in = cone_contains(S.cones[2 * slot], S.cones[2 * slot + 1], L.pt);
-            L.ci++;
-            if(in) L.ci = -1;
-            else if(L.ci >= n_cones) { outside = true; L.ci = -1; }
-        }
-#endif
-        if(g::any(outside)) {
-#ifdef NH_CP_STATS
-            B.out++;
-#endif
-            float key = (outside && L.len == L.len) ? L.len : __builtin_inff();    // a NaN distance never wins
-            int ki = outside ? L.idx : 0x7fffffff;
-            const float mykey = key; const int myidx = ki;
-            g::argmin(key, ki);
-            key = uni<G>(key); ki = uni<G>(ki);
-            const bool better = B.nfound == 0 || key < B.len || (key == B.len && ki < B.idx);
-            B.nfound++;
-            if(better && key < __builtin_inff()) {
-                const int owner = __ffsll((unsigned long long)g::ballot(outside && myidx == ki && mykey == key)) - 1;
-                const v2 curr = vsub(L.pt, ent.pos);
-                B.len = uni<G>(key); B.idx = uni<G>(ki);
-                B.pt = mkv(uni<G>(g::shfl(curr.x, owner)), uni<G>(g::shfl(curr.z, owner)));
-            }
-            if(L.ci >= 0 && !cp_alive(B, L.len, L.idx)) L.ci = -1;
-        }
-    }
-    qn = 0;
-    wave_sync();
-#ifdef NH_CP_STATS
-    B.cw += __builtin_amdgcn_s_memtime() - w_t0;
-#endif
-}
-
-// push this lane's candidate (ok) onto the group's queue; the queue is worked off once G are waiting
-template <int G>
-__device__ __forceinline__ void cp_push(cp_lds<G> &S, const cpent &ent, int n_cones, bool ok, v2 pt, int idx,
-                                        float len, int &qn, cp_lane &L, cp_bound &B)
-{
-    typedef grp<G> g;
-    const int gl = g::lane();
-    const unsigned long long mk = g::ballot(ok);
-    if(ok) {
-        const int at = qn + __popcll(mk & ((1ull << gl) - 1ull));
-        S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = idx; S.ql[at] = len;
-    }
-    qn = uni<G>((int)(qn + (int)__popcll(mk)));
-    CP_STAT(B.sb, 3, __popcll(mk));
-    wave_sync();
-    if(qn >= G) cp_work<G>(S, ent, n_cones, qn, L, B, false);
-}
 
 // ---- the same two functions for a WAVE-wide group, written without per-lane branches ------------------------
 // In cp_work / cp_push every `if` on a lane's own state (has it a candidate? is it inside?) is a region the wave
@@ -474,12 +310,6 @@ __device__ __forceinline__ void cp_push(cp_lds<G> &S, const cpent &ent, int n_co
 // expansions (an undecided fast cone test, a candidate beating the bound) sit behind one ballot each.
 // Same decisions in the same order as cp_work: a lane without a candidate takes the next queued one, tests it
 // against ONE cone per step, nearest first; inside -> dropped, outside all -> it may become the bound.
-#ifndef NH_CP_BF
-#define NH_CP_BF 1
-#endif
-#ifndef NH_CP_BF16
-#define NH_CP_BF16 1          // ... and the same code for the 16-lane groups of k_cp_rows (a group's own state in VGPRs, ballots per group)
-#endif
 template <int G>
 __device__ __forceinline__ void cp_work_bf(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn_io, cp_lane &L,
                                            cp_bound &B, bool finish)
@@ -494,9 +324,6 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<G> &S, const cpent &ent, int n
     int Bidx = uni<G>(B.idx), nfound = uni<G>(B.nfound);
     float px = L.pt.x, pz = L.pt.z, len = L.len;
     int idx = L.idx, ci = L.ci;
-#ifdef NH_CP_STATS
-    const unsigned long long w_t0 = __builtin_amdgcn_s_memtime();
-#endif
     for(;;) {
         if(head < qn) {
             const bool need = ci < 0;
@@ -504,14 +331,9 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<G> &S, const cpent &ent, int n
             const int my = head + (int)__popcll(mn & lt_mask);
             const bool take = need & (my < qn);
             const int at = take ? my : 0;
-#if NH_CP_PACKQ
             const float4 qe = ((const float4*)S.qx)[at];          // (the queue packs an entry into 16 bytes)
             const float qx = qe.x, qz = qe.y, ql = qe.z;
             const int qi = __float_as_int(qe.w);
-#else
-            const float qx = S.qx[at], qz = S.qz[at], ql = S.ql[at];
-            const int qi = S.qi[at];
-#endif
             const bool alive = (nfound == 0) | (ql < Blen) | ((ql == Blen) & (qi < Bidx));
             px = take ? qx : px; pz = take ? qz : pz; len = take ? ql : len; idx = take ? qi : idx;
             ci = take ? (alive ? 0 : -1) : ci;
@@ -523,11 +345,8 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<G> &S, const cpent &ent, int n
             continue;
         }
         if(!finish && head >= qn) break;
-#ifdef NH_CP_STATS
-        B.it++; B.busy += __popcll(busy);
-#endif
         float4 A, Bc;
-        if constexpr(G == 64 && NH_CP_TC) {
+        if constexpr(G == 64) {
             const int ck = max(ci, 0);
             A = S.tc[2 * ck]; Bc = S.tc[2 * ck + 1];
         }else{
@@ -538,9 +357,6 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<G> &S, const cpent &ent, int n
         int v = cone_test_bf(A, Bc, pt);
         if(g::ballot((v == 2) & (ci >= 0)) != 0ull) {
             NH_COLD_PATH();
-#ifdef NH_CP_STATS
-            B.ex++;
-#endif
             if(v == 2) v = cone_contains_exact(A, Bc, pt) ? 1 : 0;
         }
         const bool act = ci >= 0, in = v == 1;
@@ -550,9 +366,6 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<G> &S, const cpent &ent, int n
         const unsigned long long mo = g::ballot(outside);
         if(mo != 0ull) {
             NH_COLD_PATH();
-#ifdef NH_CP_STATS
-            B.out++;
-#endif
             float key = (outside && len == len) ? len : __builtin_inff();      // a NaN distance never wins
             int ki = outside ? idx : 0x7fffffff;
             const float mykey = key; const int myidx = ki;
@@ -573,9 +386,6 @@ __device__ __forceinline__ void cp_work_bf(cp_lds<G> &S, const cpent &ent, int n
     B.len = Blen; B.idx = Bidx; B.pt = mkv(Bpx, Bpz); B.nfound = nfound;
     qn_io = 0;
     wave_sync();
-#ifdef NH_CP_STATS
-    B.cw += __builtin_amdgcn_s_memtime() - w_t0;
-#endif
 }
 
 // push this lane's candidate (ok) onto the group's queue; the queue is worked off once G are waiting
@@ -589,30 +399,12 @@ __device__ __forceinline__ void cp_push_bf(cp_lds<G> &S, const cpent &ent, int n
     if(mk != 0ull) {
         if(ok) {
             const int at = qn + (int)__popcll(mk & ((1ull << gl) - 1ull));
-#if NH_CP_PACKQ
             ((float4*)S.qx)[at] = make_float4(pt.x, pt.z, len, __int_as_float(idx));
-#else
-            S.qx[at] = pt.x; S.qz[at] = pt.z; S.qi[at] = idx; S.ql[at] = len;
-#endif
         }
         qn = uni<G>(qn + (int)__popcll(mk));
         wave_sync();
         if(qn >= G) cp_work_bf<G>(S, ent, n_cones, qn, L, B, false);
     }
-}
-
-template <int G>
-__device__ __forceinline__ void cp_work_x(cp_lds<G> &S, const cpent &ent, int n_cones, int &qn, cp_lane &L, cp_bound &B, bool finish)
-{
-    if constexpr(NH_CP_BF && (G == 64 || NH_CP_BF16)) cp_work_bf<G>(S, ent, n_cones, qn, L, B, finish);
-    else cp_work<G>(S, ent, n_cones, qn, L, B, finish);
-}
-template <int G>
-__device__ __forceinline__ void cp_push_x(cp_lds<G> &S, const cpent &ent, int n_cones, bool ok, v2 pt, int idx, float len,
-                                          int &qn, cp_lane &L, cp_bound &B)
-{
-    if constexpr(NH_CP_BF && (G == 64 || NH_CP_BF16)) cp_push_bf<G>(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
-    else cp_push<G>(S, ent, n_cones, ok, pt, idx, len, qn, L, B);
 }
 
 // attempts of G_ClearPath_NewVelocity's do-while per problem (remove_furthest retries), as a histogram:
@@ -638,9 +430,6 @@ __device__ unsigned long long nh_cp_attempts[9];
 // breaks ties exactly as the reference does), or -1: no attempt succeeds before a list runs empty.
 // (part / nparts: this group's share of the candidates when a team searches; the team's answer is
 // the minimum of the shares' results, BIG standing for "none")
-#ifndef NH_CP_JUMP_BF
-#define NH_CP_JUMP_BF 1
-#endif
 // Step 4 of cp_jump (below) for a WAVE-wide group, in the layout and style of the search's column phase: lane = row
 // (this lane's two rays and their removal times in registers), the column's ray uniform; a lane's candidate state
 // changes through selects, the cones come from S.tc in the order they are tested (latest-removed first, S.col = their
@@ -655,13 +444,11 @@ __device__ __forceinline__ int cp_jump_cands_bf(cp_lds<64> &S, const cpent &ent,
     const int BIG = 1 << 20;
     n_cones = uni<64>(n_cones); cur = uni<64>(cur);
     const int n_rays = 2 * n_cones;
-#if NH_CP_TC
     if(gl < n_cones) {
         const int so = S.ord[gl];
         S.tc[2 * gl] = S.cones[2 * so]; S.tc[2 * gl + 1] = S.cones[2 * so + 1];
         S.col[gl] = S.tau[so];
     }
-#endif
     float rpx[2], rpz[2], rdx[2], rdz[2], rsl[2];
     int rtau[2];
 #pragma unroll
@@ -747,15 +534,9 @@ __device__ __forceinline__ int cp_jump_cands_bf(cp_lds<64> &S, const cpent &ent,
             if(!gen_done && head >= qn) break;          // more to generate: the lanes keep what they hold
             const bool act = ci >= 0;
             const int lim = min(cur - 1, end);          // its start has to be <= lim to matter
-#if NH_CP_TC
             const int ck = max(ci, 0);
             const float4 A = S.tc[2 * ck], Bc = S.tc[2 * ck + 1];
             const int tcv = S.col[ck];
-#else
-            const int ck = S.ord[max(ci, 0)];
-            const float4 A = S.cones[2 * ck], Bc = S.cones[2 * ck + 1];
-            const int tcv = S.tau[ck];
-#endif
             const v2 pt = mkv(px, pz);
             int v = cone_test_bf(A, Bc, pt);
             if(__ballot((v == 2) & act) != 0ull) {
@@ -834,7 +615,7 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
     for(int d = G / 2; d >= 1; d >>= 1) td = max(td, __shfl_xor(td, d));
     int cur = min(td, t_end);                      // best start so far (group uniform)
     // 4. the candidates: when does each become admissible?
-    if constexpr(G == 64 && NH_CP_JUMP_BF) {
+    if constexpr(G == 64) {
         cur = cp_jump_cands_bf(S, ent, des_v, n_cones, cur, part, nparts);
         return cur < t_end ? cur : -1;
     }
@@ -939,9 +720,7 @@ __device__ int cp_jump(cp_lds<G> &S, const cpent &ent, v2 des_v, bool have, bool
 // shortcut (cp_jump over the waves' shares of the candidates, minimum of the start times), the replay
 // of the removals (every wave on its own copy) and the attempt that succeeds, again shared.
 // The exchange goes through cp_team in LDS, two workgroup barriers per combine.
-#ifndef CP_TEAM_MAX
 #define CP_TEAM_MAX 4
-#endif
 struct cp_team { cp_bound B[CP_TEAM_MAX]; int t[CP_TEAM_MAX]; };
 
 template <int G>
@@ -964,15 +743,9 @@ __device__ __forceinline__ void team_min(cp_bound &B, cp_team &T, int part, int 
 // S.dyn / S.stat hold the neighbours (n_dyn + n_stat <= G, each <= 32).
 //   TEAM   every wave of the workgroup calls this with the same problem in its own S, part = its wave
 //          number, nparts = the waves of the workgroup, T = the team's exchange area
-//   bail   (a wave on its own) the search may be handed back: when the projections of des_v yield no bound,
-//          the column phase ahead is close to exhaustive -- *bail is set, nothing is returned, and the caller
-//          passes the problem on to a team (k_cp_heavy's second pass)
-#ifndef CP_BAIL_MIN_RAYS
-#define CP_BAIL_MIN_RAYS 34
-#endif
 template <int G, bool TEAM = false>
 __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, cp_lds<G> &S,
-                            int part = 0, int nparts = 1, cp_team *T = nullptr, bool *bail = nullptr)
+                            int part = 0, int nparts = 1, cp_team *T = nullptr)
 {
     typedef grp<G> g;
     n_dyn = uni<G>(n_dyn); n_stat = uni<G>(n_stat);
@@ -982,13 +755,6 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
     bool jumped = false;
     // at most 64 neighbours can be removed; the bound only guards against a NaN-poisoned input
     for(int guard = 0; guard < 66; guard++) {
-#ifdef NH_CP_UNIT_HIST
-        if(gl == 0) { S.dbg[0] = guard; if(guard == 0) S.dbg[1] = -2; }
-#endif
-        CP_T0();
-#ifdef NH_CP_STATS
-        const int sb_ = cp_bucket(n_dyn + n_stat);
-#endif
         // ---- HRVOs for dynamic, VOs for static neighbours -> rays (rays_repr :291) -----------
         // lane = neighbour, dynamic ones first; same_position neighbours are skipped (:216-246)
         const bool isdyn = gl < n_dyn;
@@ -1007,7 +773,6 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         const int slot = __popcll(m & lt_mask);                // hrvos first, then vos, in order
         const int n_cones = __popcll(m);
         const int n_rays = 2 * n_cones;
-#if NH_CP_ORDER_DEPTH
         // test order of the cones: the one des_v lies DEEPEST inside first (the smaller of its distances to the two
         // side lines, negative outside).  Every candidate that matters lies within the bound of des_v, so the cones
         // that reach furthest around des_v contain most of them; the nearest-neighbour order this replaces needed
@@ -1020,9 +785,6 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
             const float depth = fminf(dpl, dpr);
             ndist = (dpl == dpl && dpr == dpr) ? -depth : 0x1p120f;
         }
-#else
-        const float ndist = use ? vlen(vsub(nb.pos, ent.pos)) : __builtin_inff();
-#endif
         wave_sync();
         if(use) {
             S.cones[2 * slot]     = make_float4(apex.x, apex.z, sl, sr);
@@ -1045,26 +807,18 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         const v2 des_ws = vadd(ent.pos, des_v);
         bool in = false;
         if(gl < n_cones) in = cone_contains(S.cones[2 * gl], S.cones[2 * gl + 1], des_ws);
-        CP_TMARK(sb_, 0);
         if(!g::any(in)) {
             if(gl == 0 && part == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
             return des_v;
         }
 
-        if constexpr(G == 64 && NH_CP_BF && NH_CP_TC) {
+        if constexpr(G == 64) {
             // the cones in test order, for the test steps of the wave-wide search
             if(gl < n_cones) { const int so = S.ord[gl]; S.tc[2 * gl] = S.cones[2 * so]; S.tc[2 * gl + 1] = S.cones[2 * so + 1]; }
             wave_sync();
         }
         cp_bound B; B.len = __builtin_inff(); B.idx = 0x7fffffff; B.pt = mkv(0, 0); B.nfound = 0; B.sb = 0;
-#ifdef NH_CP_STATS
-        B.it = B.busy = B.ex = B.out = B.passes = B.cols = B.cands = B.queued = 0; B.cw = B.cg = 0;
-        B.sb = cp_bucket(n_dyn + n_stat);
-        CP_STAT(B.sb, 1, 1);
-        if(guard == 0) CP_STAT(B.sb, 0, 1);
-#endif
         const int npairs = n_rays * n_rays;
-        CP_STAT(B.sb, 7, n_rays);
         if(!TEAM && n_rays <= CP_SMALL_RAYS) {
         // ---- few neighbours (most agents outside a crowd): no queue, no bound -- every lane works its
         // own few candidates through (point, distance, every cone), keeps its best, one arg-min at the
@@ -1130,17 +884,10 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                 len = vlen(vsub(des_v, vsub(pt, ent.pos)));
                 ok = cp_alive(B, len, npairs + c);
             }
-            cp_push_x<G>(S, ent, n_cones, ok, pt, npairs + c, len, qn, L, B);
+            cp_push_bf<G>(S, ent, n_cones, ok, pt, npairs + c, len, qn, L, B);
         }
-        cp_work_x<G>(S, ent, n_cones, qn, L, B, true);
+        cp_work_bf<G>(S, ent, n_cones, qn, L, B, true);
 
-        if(bail && guard == 0 && !B.nfound && n_rays >= CP_BAIL_MIN_RAYS) { *bail = true; return des_v; }
-        CP_TMARK(sb_, 1);
-#ifdef NH_CP_STATS
-        if(!B.nfound) CP_STAT(B.sb, 12, 1);
-        CP_STAT(B.sb, 15, B.it);               // iterations of the projection phase
-        B.cw = 0;
-#endif
         // ---- the ray pairs (:321; order index i * n_rays + j), column by column, NEAREST LINE FIRST:
         // a column's candidates all lie on its line, so its key -- the distance of des_v to that line,
         // less the margins -- bounds them from below.  Columns are visited in ascending key; the search
@@ -1178,56 +925,6 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                     S.ckey[j] = mykey[h];
                 }
             }
-#if NH_CP_COVER
-            // ---- columns that cannot hold an admissible candidate at all.  A candidate of column j lies on line j
-            // (the slope line C_InfiniteLineIntersection evaluates, or x = apex.x for a ray it treats as vertical),
-            // at a parameter >= 0 (the sign tests), within the rounding of that evaluation (< 1e-3 wu on a 8192 wu
-            // map).  If apex j lies inside ANOTHER cone c, at least 1/4 wu from c's apex and 0.02 (as a sine) from
-            // both of its sides, and the line's direction lies between c's sides by the same margin and does not
-            // point back towards c's apex, then every such point is inside cone c: its direction from apex c stays
-            // between those of (apex j - apex c) and of the line, both 0.02 inside, and it never comes closer to
-            // apex c than apex j is.  inside_pcr's own thresholds are 1/1024 and its roundings 4e-7: such a column
-            // holds nothing but inadmissible candidates, whatever the bound -- a third of the rays in a jam.
-            // (The projections of des_v -- points of the LINE, possibly behind the apex -- were all tested above.)
-            if(G == 64) {
-                float apx[2], apz[2], ux[2], uz[2];
-#pragma unroll
-                for(int h = 0; h < 2; h++) {
-                    const int j = gl + h * G;
-                    apx[h] = apz[h] = ux[h] = uz[h] = 0.0f;
-                    if(j < n_rays) {
-                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
-                        const v2 dj = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
-                        const float sj = (j & 1) ? Aj.w : Aj.z;
-                        apx[h] = Aj.x; apz[h] = Aj.y;
-                        if(sj != sj) { ux[h] = 0.0f; uz[h] = copysignf(1.0f, dj.z); }        // (vertical for the reference)
-                        else { const float inv = copysignf(nh_rsq_native(1.0f + sj * sj), dj.x); ux[h] = inv; uz[h] = sj * inv; }
-                    }
-                }
-                const float MS = 0.02f, DMIN2 = 0.0625f;
-                // (against the CP_COVER_CONES cones deepest around des_v only: the whole list costs as much as the
-                // columns it saves in a standing jam, where a tenth of the rays is covered)
-                const int n_cov = min(n_cones, CP_COVER_CONES);
-                for(int r = 0; r < n_cov; r++) {
-                    const int c = uni<G>(S.ord[r]);
-                    const float4 Ac = S.cones[2 * c], Bc = S.cones[2 * c + 1];
-#pragma unroll
-                    for(int h = 0; h < 2; h++) {
-                        if(h == 1 && n_rays <= G) break;
-                        const int j = gl + h * G;
-                        const float qx = apx[h] - Ac.x, qz = apz[h] - Ac.y;
-                        const float l2 = qx * qx + qz * qz;
-                        const float il = nh_rsq_native(l2);
-                        const float ld = (qz * Bc.x - qx * Bc.y) * il, rd = (qz * Bc.z - qx * Bc.w) * il;
-                        const float dl = uz[h] * Bc.x - ux[h] * Bc.y, dr = uz[h] * Bc.z - ux[h] * Bc.w;
-                        const float fw = qx * ux[h] + qz * uz[h];
-                        const bool okc = l2 >= DMIN2 && l2 < 1e30f && ld >= CP_EPS + MS && rd <= -(CP_EPS + MS)
-                                      && dl >= MS && dr <= -MS && fw >= 0.0f && (j >> 1) != c && j < n_rays;
-                        if(okc) mykeyc[h] = __builtin_inff();
-                    }
-                }
-            }
-#endif
             float *keyc = (float*)S.tau;                       // (tau, seq: the retry shortcut's, free during the search)
 #pragma unroll
             for(int h = 0; h < 2; h++) { const int j = gl + h * G; if(j < n_rays) keyc[j] = mykeyc[h]; }
@@ -1255,7 +952,6 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
         // that ray's column key is <= B.len.  So the inside-obstacle tests of the column phase only need the
         // cones that contain des_v or own a live column -- in a jam half of them -- in the same order.
         int n_test = n_cones;
-#if NH_CP_CONE_COMPACT
         if(G == 64 && B.nfound) {
             bool relevant = false;
             if(gl < n_cones) relevant = in || !(S.ckey[2 * gl] > B.len) || !(S.ckey[2 * gl + 1] > B.len);
@@ -1266,17 +962,13 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
             if(keep) S.ord[__popcll(mk & lt_mask)] = slot_r;
             n_test = __popcll(mk);
             wave_sync();
-            if constexpr(G == 64 && NH_CP_BF && NH_CP_TC) {
+            if constexpr(G == 64) {
                 if(gl < n_test) { const int so = S.ord[gl]; S.tc[2 * gl] = S.cones[2 * so]; S.tc[2 * gl + 1] = S.cones[2 * so + 1]; }
                 wave_sync();
             }
-            CP_STAT(B.sb, 4, n_test);
         }
-#endif
-        CP_STAT(B.sb, 14, __popcll(cov0) + __popcll(cov1));
-        CP_TMARK(sb_, 4);                      // keys, column order, cone compaction
-#if NH_CP_COLS_V2
-        if(G == 64 || (NH_CP_BF && NH_CP_BF16)) {
+                              // keys, column order, cone compaction
+        {
             // ---- lane = row: this lane's (up to two) rays stay in registers, the column's ray is the same for the
             // whole group.  No index arithmetic, a quarter of the LDS reads, and the bound is consulted per column.
             float rpx[2], rpz[2], rdx[2], rdz[2], rsl[2];
@@ -1292,121 +984,10 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                 }
             }
             const int n_mine = (n_rays - part + nparts - 1) / nparts;      // columns part, part + nparts, ...
-#if NH_CP_COLS2
-            for(int jc = 0; jc < n_mine; jc += 2) {
-                const int j0 = __builtin_amdgcn_readfirstlane(S.col[jc * nparts + part]);
-                if(((j0 < 64 ? cov0 >> j0 : cov1 >> (j0 - 64)) & 1ull) != 0ull) break;
-                if(B.nfound && uni<G>(S.ckey[j0]) > B.len) break;
-                int j1 = -1;
-                if(jc + 1 < n_mine) {
-                    j1 = __builtin_amdgcn_readfirstlane(S.col[(jc + 1) * nparts + part]);
-                    if(((j1 < 64 ? cov0 >> j1 : cov1 >> (j1 - 64)) & 1ull) != 0ull) j1 = -1;
-                    else if(B.nfound && uni<G>(S.ckey[j1]) > B.len) j1 = -1;
-                }
-                CP_STAT(B.sb, 6, j1 >= 0 ? 2 : 1);
-                CP_STAT(B.sb, 2, j1 >= 0 ? 2 * n_rays : n_rays);
-                const int jb = j1 >= 0 ? j1 : j0;
-                const float4 Aj = S.cones[j0 & ~1], Bj = S.cones[j0 | 1], Ak = S.cones[jb & ~1], Bk = S.cones[jb | 1];
-                const v2 p2 = mkv(Aj.x, Aj.y), d2 = (j0 & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
-                const float s2 = (j0 & 1) ? Aj.w : Aj.z;
-                const v2 p3 = mkv(Ak.x, Ak.y), d3 = (jb & 1) ? mkv(Bk.z, Bk.w) : mkv(Bk.x, Bk.y);
-                const float s3 = (jb & 1) ? Ak.w : Ak.z;
-                const int nh = n_rays > G ? 2 : 1;
-#pragma unroll 1
-                for(int h = 0; h < nh; h++) {
-                    const int i = gl + h * G;
-                    const v2 p1 = h ? mkv(rpx[1], rpz[1]) : mkv(rpx[0], rpz[0]);
-                    const v2 d1 = h ? mkv(rdx[1], rdz[1]) : mkv(rdx[0], rdz[0]);
-                    const float s1 = h ? rsl[1] : rsl[0];
-                    bool ok0 = false, ok1 = false;
-                    v2 pt0 = mkv(0, 0), pt1 = mkv(0, 0);
-                    float len0 = 0.0f, len1 = 0.0f;
-                    if(i < n_rays) {
-                        // (two independent chains: the two divisions and square roots overlap)
-                        ok0 = i != j0 && ray_isect(p1, d1, s1, p2, d2, s2, pt0);
-                        ok1 = j1 >= 0 && i != j1 && ray_isect(p1, d1, s1, p3, d3, s3, pt1);
-                        len0 = vlen(vsub(des_v, vsub(pt0, ent.pos)));
-                        len1 = vlen(vsub(des_v, vsub(pt1, ent.pos)));
-                        ok0 = ok0 && cp_alive(B, len0, i * n_rays + j0);
-                        ok1 = ok1 && cp_alive(B, len1, i * n_rays + jb);
-                    }
-#ifdef NH_CP_STATS
-                    B.passes++;
-#endif
-                    cp_push<G>(S, ent, n_test, ok0, pt0, i * n_rays + j0, len0, qn, L, B);
-                    if(j1 >= 0) cp_push<G>(S, ent, n_test, ok1, pt1, i * n_rays + jb, len1, qn, L, B);
-                }
-            }
-#else
-#if NH_CP_PACKB
-            if(n_rays > G)
-            // More than 64 rays: rows 0..63 of a column fill one pass, its rows 64.. only m = n_rays - 64 lanes of a
-            // second one (14 of 64 for the typical 39 cones of a jam).  So the second passes of P = 64 / m columns
-            // share ONE pass: lane l takes row 64 + l % m of column l / m of the group -- its ray from the lane that
-            // holds it (five shuffles, once), its column's ray from LDS per lane.  Passes per column: 1 + 1/P
-            // instead of 2.  One loop body for both kinds of pass (one copy of the queue code).
-            {
-                const int mB = n_rays > G ? n_rays - G : 0, P = mB ? G / mB : 1;
-                const int cbB = mB ? gl / mB : 0, rrB = mB ? gl - cbB * mB : 0;
-                const bool laneB = mB && cbB < P;
-                const float bpx = __shfl(rpx[1], rrB), bpz = __shfl(rpz[1], rrB), bdx = __shfl(rdx[1], rrB),
-                            bdz = __shfl(rdz[1], rrB), bsl = __shfl(rsl[1], rrB);
-                bool stop = false;
-                for(int jc0 = 0; jc0 < n_mine && !stop; jc0 += P) {
-                    // the columns of this group that are still within the bound (the order is ascending key)
-                    const int gmax = min(P, n_mine - jc0);
-                    int ng = 0;
-                    for(; ng < gmax; ng++) {
-                        const int j = uni<G>(S.col[(jc0 + ng) * nparts + part]);
-                        if(((j < 64 ? cov0 >> j : cov1 >> (j - 64)) & 1ull) != 0ull) { stop = true; break; }
-                        if(B.nfound && uni<G>(S.ckey[j]) > B.len) { stop = true; break; }
-                    }
-#ifdef NH_CP_STATS
-                    B.cols += ng; B.cands += ng * n_rays;
-#endif
-                    const int npass = ng ? ng + (mB ? 1 : 0) : 0;
-#pragma unroll 1
-                    for(int k = 0; k < npass; k++) {
-                        const bool isB = k == ng;
-                        const int kk = isB ? min(cbB, ng - 1) : k;
-                        const int j = S.col[(jc0 + kk) * nparts + part];          // (the same in every lane of an A pass)
-                        const int i = isB ? G + rrB : gl;
-                        const bool mine = (isB ? (laneB && cbB < ng) : true) & (i < n_rays) & (i != j);
-                        const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
-                        const v2 p2 = mkv(Aj.x, Aj.y), d2 = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
-                        const float s2 = (j & 1) ? Aj.w : Aj.z;
-                        const v2 p1 = isB ? mkv(bpx, bpz) : mkv(rpx[0], rpz[0]);
-                        const v2 d1 = isB ? mkv(bdx, bdz) : mkv(rdx[0], rdz[0]);
-                        const float s1 = isB ? bsl : rsl[0];
-                        const int idx = i * n_rays + j;
-                        v2 pt = mkv(0, 0);
-                        float len = 0.0f;
-                        bool slow = false;
-                        bool ok = ray_isect_bf(p1, d1, s1, p2, d2, s2, des_v, ent.pos, pt, len, slow);
-                        if(__ballot(slow & mine) != 0ull) {           // (a quotient that needs its division, an odd distance)
-                            NH_COLD_PATH();
-                            if(slow & mine) {
-                                ok = ray_isect(p1, d1, s1, p2, d2, s2, pt);
-                                len = vlen(vsub(des_v, vsub(pt, ent.pos)));
-                            }
-                        }
-                        ok = ok & mine & cp_alive(B, len, idx);
-#ifdef NH_CP_STATS
-                        B.passes++;
-#endif
-                        cp_push_x<G>(S, ent, n_test, ok, pt, idx, len, qn, L, B);
-                    }
-                }
-            }
-            else
-#endif
             for(int jc = 0; jc < n_mine; jc++) {
                 const int j = uni<G>(S.col[jc * nparts + part]);
                 if(((j < G ? cov0 >> j : cov1 >> (j - G)) & 1ull) != 0ull) break;         // (covered columns sort last)
                 if(B.nfound && uni<G>(S.ckey[j]) > B.len) break;
-#ifdef NH_CP_STATS
-                B.cols++; B.cands += n_rays;
-#endif
                 const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
                 const v2 p2 = mkv(Aj.x, Aj.y), d2 = (j & 1) ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y);
                 const float s2 = (j & 1) ? Aj.w : Aj.z;
@@ -1421,7 +1002,6 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                     bool ok = false;
                     v2 pt = mkv(0, 0);
                     float len = 0.0f;
-#if NH_CP_BF
                     {
                         bool slow = false;
                         ok = ray_isect_bf(p1, d1, s1, p2, d2, s2, des_v, ent.pos, pt, len, slow);
@@ -1435,77 +1015,13 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                         }
                         ok = ok & mine & cp_alive(B, len, idx);
                     }
-#else
-                    if(i < n_rays && i != j) {
-                        ok = ray_isect(p1, d1, s1, p2, d2, s2, pt);
-                        if(ok) {
-                            len = vlen(vsub(des_v, vsub(pt, ent.pos)));
-                            ok = cp_alive(B, len, idx);
-                        }
-                    }
-#endif
-#ifdef NH_CP_STATS
-                    B.passes++;
-#endif
-                    cp_push_x<G>(S, ent, n_test, ok, pt, idx, len, qn, L, B);
+                    cp_push_bf<G>(S, ent, n_test, ok, pt, idx, len, qn, L, B);
                 }
             }
-#endif
-            cp_work_x<G>(S, ent, n_test, qn, L, B, true);
-        }else
-#endif
-        {
-            // columns per batch: about four passes of candidates
-            const int kb = max(1, (4 * G) / n_rays);
-            const float inv_nr = 1.0f / (float)n_rays;
-            const int n_mine = (n_rays - part + nparts - 1) / nparts;      // columns part, part + nparts, ...
-            int jdone = 0;
-            while(jdone < n_mine) {
-                if(B.nfound && S.ckey[S.col[jdone * nparts + part]] > B.len) break;
-                const int ncol = min(kb, n_mine - jdone);
-                const int ncand = ncol * n_rays;
-                CP_STAT(B.sb, 6, ncol);
-                CP_STAT(B.sb, 2, ncand);
-                for(int c0 = 0; c0 < ncand; c0 += G) {
-                    const int c = c0 + gl;
-                    bool ok = false;
-                    v2 pt = mkv(0, 0);
-                    float len = 0.0f;
-                    int idx = 0;
-                    if(c < ncand) {
-                        // (cj, i) = divmod(c, n_rays): float estimate + one correction step (c < 2^14)
-                        int cj = (int)((float)c * inv_nr);
-                        int i = c - cj * n_rays;
-                        if(i < 0) { cj--; i += n_rays; }
-                        if(i >= n_rays) { cj++; i -= n_rays; }
-                        const int j = S.col[(jdone + cj) * nparts + part];
-                        idx = i * n_rays + j;
-                        if(i != j) {
-                            const float4 Ai = S.cones[i & ~1], Bi = S.cones[i | 1];
-                            const float4 Aj = S.cones[j & ~1], Bj = S.cones[j | 1];
-                            const bool ri = i & 1, rj = j & 1;
-                            ok = ray_isect(mkv(Ai.x, Ai.y), ri ? mkv(Bi.z, Bi.w) : mkv(Bi.x, Bi.y), ri ? Ai.w : Ai.z,
-                                           mkv(Aj.x, Aj.y), rj ? mkv(Bj.z, Bj.w) : mkv(Bj.x, Bj.y), rj ? Aj.w : Aj.z,
-                                           pt);
-                            if(ok) {
-                                len = vlen(vsub(des_v, vsub(pt, ent.pos)));
-                                ok = cp_alive(B, len, idx);
-                            }
-                        }
-                    }
-                    cp_push<G>(S, ent, n_test, ok, pt, idx, len, qn, L, B);
-                }
-                jdone += ncol;
-            }
-            cp_work<G>(S, ent, n_test, qn, L, B, true);
+            cp_work_bf<G>(S, ent, n_test, qn, L, B, true);
         }
         }
-#ifdef NH_CP_STATS
-        CP_STAT(B.sb, 5, B.it); CP_STAT(B.sb, 8, B.busy); CP_STAT(B.sb, 9, B.ex); CP_STAT(B.sb, 10, B.out);
-        CP_STAT(B.sb, 11, B.passes); CP_STAT(B.sb, 13, B.cw); CP_STAT(B.sb, 6, B.cols); CP_STAT(B.sb, 2, B.cands);
-#endif
         if(TEAM) team_min<G>(B, *T, part, nparts);
-        CP_TMARK(sb_, 2);
         if(B.nfound) {
             if(gl == 0 && part == 0 && guard > 0) { atomicAdd(&nh_cp_attempts[guard < 7 ? guard : 7], 1ull); atomicAdd(&nh_cp_attempts[8], (unsigned long long)guard + 1); }
             return B.pt;                   // (only NaN / infinite distances: ret stays 0, as :368-386)
@@ -1527,10 +1043,6 @@ __device__ v2 clearpath_grp(const cpent &ent, v2 des_v, int n_dyn, int n_stat, c
                 t = uni<G>(t);
                 __syncthreads();
             }
-#ifdef NH_CP_UNIT_HIST
-            if(gl == 0) { S.dbg[1] = t; S.dbg[2] = n_rays; }
-#endif
-            CP_TMARK(sb_, 3);
             if(t < 0) {
                 if(gl == 0 && part == 0) { atomicAdd(&nh_cp_attempts[0], 1ull); atomicAdd(&nh_cp_attempts[8], 2ull); }
                 return mkv(0.0f, 0.0f);

@@ -20,23 +20,20 @@ struct nh_spatial_scratch {
 
 // fills G.cell_start / recA / recV / pool_of from S
 void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
-                             int slab_begin, int slab_end, hipStream_t s, hipEvent_t after_first = nullptr);
+                             int slab_begin, int slab_end, hipStream_t s);
 void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t s);
 size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members);
-void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s);
+hipError_t nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s);
 // returns true when the lane regrouping for the next tick is still to be launched
 // (nh_launch_cohesion_regroup, after the caller's "cohesion done" event)
 bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, int *parity, hipStream_t s);
 void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *parity, hipStream_t s);
-// k_agent_mid -> k_cp_heavy | k_cp_rows -> k_agent_full; WL.count holds 2 * NH_WL_COUNTERS counters.
-// side / ev (or null): a second stream for the workgroup problems, two events
+// k_agent_mid -> k_cp_rows -> k_agent_full | k_cp_small -> retry -> k_cp_heavy; WL.count holds 2 * NH_WL_COUNTERS counters.
+// side / ev (or null): a second stream for the second chain, two events
 int nh_worklist_cap(int n_work);
 bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
-                            hipStream_t side, hipStream_t side2, hipEvent_t ev[3], bool mid_a_done = false);
-// half A of the per-agent chain (flow sampling, arrive force, probes) for the work range -> d_mid; half B is then the
-// first launch of nh_launch_agent_finish(..., mid_a_done = true)
-void nh_launch_agent_mid_a(const nh_step_params &P, nh_mid_rec *d_mid, hipStream_t s);
+                            hipStream_t side, hipEvent_t ev[2]);
 void nh_launch_state_update(const nh_step_params &P, const navhip_state_in &in, float4 *d_arrived, int32_t *d_arrived_n, uint8_t *d_state, uint8_t *d_flags,
                             hipStream_t s);
 void nh_launch_region_lookup(const nh_step_params &P, int nq, const float *d_pos, const int32_t *d_rows,

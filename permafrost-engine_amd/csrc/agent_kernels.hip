@@ -207,9 +207,7 @@ __global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, con
 // 1515-1521), so after inserting uids 0..n-1 each cell holds its elements in DESCENDING uid order:
 // the final slot of an element is its cell's start + the number of cell mates with a larger uid
 // (one thread per element counts them: cells hold a handful of elements).
-#ifndef SP_BLOCK
 #define SP_BLOCK 64
-#endif
 __global__ __launch_bounds__(SP_BLOCK) void k_sp_place(nh_grid G, const float *pos_xz, nh_pack_src src,
                                                   const int32_t *ent_cell, const int32_t *tmp_id,
                                                   int n, int work_begin, int work_end,
@@ -582,19 +580,17 @@ __global__ __launch_bounds__(256) void k_coh_scatter(nh_step_params P, const int
 // same instruction total, and a 16-member box is tighter than a 64-member one.
 #define COH_APW 16
 #define COH_QS  72            /* queue slots per sub-lane: (256 staged + 31 carried) / 4 */
-#ifndef COH_NP
 #define COH_NP  2             /* entry pairs per lane and batch: a batch is COH_G = 8 * COH_NP entries
                                  (2 measured 1.3 % faster per tick than 4: fewer VGPRs, more waves).  EVEN values only:
                                  the queue is read four entries at a time (COH_NP = 1 compiles, loads nothing and is
                                  11 % faster and wrong -- an A/B without a parity step found that out) */
-#endif
+static_assert(COH_NP % 2 == 0, "the cohesion queue is read four entries at a time: COH_NP must be even");
 #define COH_G   (8 * COH_NP)
 
 // an empty statement the optimiser cannot see through: keeps two scalar chains from being paired into packed math
-#ifndef COH_SPLIT_SUMS
-#define COH_SPLIT_SUMS 1      /* 0: let the compiler pair the two sums (A/B) */
-#endif
-#if defined(NH_HOSTSIM) || !COH_SPLIT_SUMS
+// (paired into one v_pk_add_f32 the two ordered sums take their operands from two v_mov_b32_dpp: three instructions per
+// queue entry where each add can take its DPP operand itself: 118.5 -> 107.5 us, profiles/r05_ab_compiler_flags.txt)
+#ifdef NH_HOSTSIM
 __device__ __forceinline__ float coh_keep(float x) { return x; }
 #else
 __device__ __forceinline__ float coh_keep(float x) { asm volatile("" : "+v"(x)); return x; }
@@ -704,32 +700,10 @@ __device__ __forceinline__ void coh_batch(const float *qx, const float *qz, cons
 // that the grouping was built for these flock offsets and this work range, the wave prefix over the flocks --
 // instead of reading what a one-workgroup kernel in front of the launch left (k_coh_plan: 6 us and a launch
 // gap on the chain that gates k_agent_mid; here ~40 instructions per wave).
-// COH_FPOS: the member positions of every flock, gathered ONCE per tick into member-list order (k_coh_gather: fpos[g] =
-// pos[flock_members[g]]).  Every wave of a flock stages all of the flock's positions: read through the member list that
-// is a dependent pair of loads per entry and 64 different lines per wave instruction -- 98 waves x 1 563 entries x a
-// 64-byte sector each for a 1 563-member flock, 630 MB of L2 traffic per tick at configs[2] --; read from fpos it is one
-// coalesced 512-byte row per instruction.  Same values in the same order.
-// Measured (profiles/r05_ab_coh_fpos_*): the kernel 129.0 -> 121.3 us, the gather kernel in front of it 5.5 us, the tick
-// 0.3105 against 0.3114 ms -- the kernel is not bound by its gathers (they hit L2).  Off: one launch less on the chain.
-#ifndef COH_FPOS
-#define COH_FPOS 0
-#endif
-#ifndef COH_PREFETCH
-#define COH_PREFETCH 0
-#endif
-__global__ __launch_bounds__(256) void k_coh_gather(nh_step_params P, float2 *fpos)
-{
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if(g >= P.flock_offsets[P.n_flocks]) return;
-    const int m = P.flock_members[g];
-    fpos[g] = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
-}
-
 template <bool INLINE_PLAN>
 __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t *wave_off,
                                                  const int32_t *perm, const int32_t *perm_valid,
-                                                 float *coh_xz, const int32_t *bin_start, const int32_t *saved,
-                                                 const float2 *fpos)
+                                                 float *coh_xz, const int32_t *bin_start, const int32_t *saved)
 {
     __shared__ double tab[64];
     // the members of the current tile that survive the box test, in member order (+ carry-over):
@@ -796,41 +770,18 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
     float comx = 0.0f, comz = 0.0f;
     int self_k = -1;                                      // queue entry of this quad's own member
     int pend = 0;                                         // entries carried over from the last tile
-#if COH_FPOS && COH_PREFETCH
-    // software pipeline: the positions of tile k + 1 are requested before tile k is worked on (the waves of this kernel
-    // spend 43 % of their cycles waiting for a counter -- SQ_WAIT_INST_ANY, profiles/r03_cp_counters_a.json --, most of
-    // it for the staging loads of a tile whose members the box test then drops)
-    float2 nxt[4];
-#pragma unroll
-    for(int q = 0; q < 4; q++) { const int j = b + q * 64 + t; nxt[q] = j < e ? fpos[j] : make_float2(0.0f, 0.0f); }
-#endif
     for(int jb = b; jb < e; jb += 256) {
         // ---- stage the tile behind the carry-over [0, pend)
         int ncnt = pend;
         const int gl = act ? g - jb : -1;                 // own slot in the unfiltered tile, if any
-#if COH_FPOS && COH_PREFETCH
-        float2 cur[4];
-#pragma unroll
-        for(int q = 0; q < 4; q++) cur[q] = nxt[q];
-        if(jb + 256 < e) {
-#pragma unroll
-            for(int q = 0; q < 4; q++) { const int j = jb + 256 + q * 64 + t; nxt[q] = j < e ? fpos[j] : make_float2(0.0f, 0.0f); }
-        }
-#endif
 #pragma unroll
         for(int q = 0; q < 4; q++) {
             const int j = jb + q * 64 + t;
             bool keep = false;
             float2 c2 = make_float2(0.0f, 0.0f);
             if(j < e) {
-#if COH_FPOS && COH_PREFETCH
-                c2 = cur[q];
-#elif COH_FPOS
-                c2 = fpos[j];
-#else
                 const int m = P.flock_members[j];
                 c2 = make_float2(P.pos_xz[2 * m], P.pos_xz[2 * m + 1]);
-#endif
                 const float dx = fmaxf(fmaxf(bx0 - c2.x, c2.x - bx1), 0.0f);
                 const float dz = fmaxf(fmaxf(bz0 - c2.y, c2.y - bz1), 0.0f);
                 keep = !(dx * dx + dz * dz > COH_FAR * COH_FAR);       // NaN stays in
@@ -885,9 +836,7 @@ __global__ __launch_bounds__(64) void k_cohesion(nh_step_params P, const int32_t
 // ---------------------------------------------------------------------------------------------
 // waves (= agents) per workgroup of the wave-per-agent kernels; 2 measured best for the round-1
 // k_agent_step (1: 0.490, 2: 0.483, 4: 0.494, 8: 0.521 ms/tick in one session)
-#ifndef AG_WAVES
 #define AG_WAVES 2
-#endif
 struct wave_lds {
     uint32_t ids30[128];                       // separation query result (cap 128, :1695)
     union {
@@ -1015,18 +964,12 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
 // STRIDED (a rank that steps a slab of a large job): the launch is sized by the slab, the pool by what its
 // queries can reach, so a few rows take a second slot.  With the whole snapshot stepped every pool slot
 // has its own row (no loop: four VGPRs and a wave per SIMD less with it).
-#ifndef NBR_WAVES
 #define NBR_WAVES 7        /* 72 VGPRs; 8 needs five spilled dwords per lane */
-#endif
 // Threads per workgroup of the front's kernels.  ONE wave: they run beside the cohesion kernel's stream of
 // one-wave workgroups and the field builds, which take every wave slot the moment it frees up -- a workgroup
 // of four waves waits until four slots of ONE compute unit are free at the same moment.
-#ifndef NBR_BLOCK
 #define NBR_BLOCK 64
-#endif
-#ifndef SP_BLOCK
 #define SP_BLOCK 64
-#endif
 template <bool STRIDED>
 __global__ __launch_bounds__(NBR_BLOCK) __attribute__((amdgpu_waves_per_eu(NBR_WAVES, 8)))
 void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
@@ -1066,71 +1009,26 @@ __device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which,
 
 // ---------------------------------------------------------------------------------------------
 // k_agent_mid: the per-agent scalar chain -- desired direction, arrive force, probes, priority
-// ladder, vpref -- in uid order (every per-entity input / output is contiguous), one thread per entity.
-// The work is a chain of dependent loads and IEEE divide / sqrt sequences at 1.5 waves per SIMD.  While
-// the loads came one after the other (four flow taps, probes, neighbour results) two lanes per entity --
-// twice the waves to hide them behind -- were faster (37 against 75-105 us); with the loads requested
-// ahead of the chain (mid_thread, sample_flow) one lane is: MID_LANES 1 / 2 / 4 = 0.352 / 0.360 / 0.379 ms
-// per tick in one session (profiles/r03_ab_mid_lanes.txt).
+// ladder, vpref -- in uid order (every per-entity input / output is contiguous), ONE thread per entity.
+// The work is a chain of dependent loads and IEEE divide / sqrt sequences at 1.5 waves per SIMD; with the loads
+// requested ahead of the chain (mid_thread, sample_flow) one lane per entity beats two or four
+// (profiles/r03_ab_mid_lanes.txt).  Splitting it -- the sampling half beside the cohesion term, the rest behind the
+// join (round 5), or the rest at the head of every ClearPath search (round 6) -- was measured twice and lost twice
+// (profiles/r05_ab_split_mid_*.txt, r06_ab_step_without_mid_rejected.txt): the launch is latency, and the chip is
+// not idle beside it.
 // ---------------------------------------------------------------------------------------------
-#ifndef MID_LANES
-#define MID_LANES 1
-#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_agent_mid(nh_step_params P, nh_nbr NB, const float *coh_xz,
                                                   nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
                                                   float scaled_max_force, double force_thresh)
 {
-    const int uid = P.work_begin + (int)((blockIdx.x * 64 + threadIdx.x) / MID_LANES);
-    const bool writer = (threadIdx.x % MID_LANES) == 0;
+    const int uid = P.work_begin + (int)(blockIdx.x * 64 + threadIdx.x);
     const bool live = uid < P.work_end;
     int disp = DISP_DONE;
     if(live) {
         nh_mid_rec R;
         v2 out_vel;
         disp = mid_thread(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R, out_vel);
-        if(writer) {
-            if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
-            if(O.vpref_xz) { O.vpref_xz[2 * uid] = R.vpref[0]; O.vpref_xz[2 * uid + 1] = R.vpref[1]; }
-            if(disp == DISP_DONE) {
-                post_thread(P, uid, mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]), P.state[uid], P.flags[uid],
-                            P.radius[uid], out_vel, R.vel_cap, R.status, O);
-            }else{
-                mid[uid] = R;
-            }
-        }
-    }
-#pragma unroll
-    for(int w = 0; w <= NH_WL_FULL; w++)
-        worklist_push(WL, w, live && writer && disp == DISP_ROW0 + w, uid);
-}
-
-// The same chain as two launches (mid_thread_a / _b): half A -- flow sampling, line of sight, arrive force, tile probes:
-// the chain of dependent loads -- needs neither the neighbour walk nor the cohesion term and runs on the FRONT of the
-// step, behind k_agent_nbr, in the shadow of k_cohesion (navhip_agent_prefetch_dev_ex with
-// NAVHIP_PREFETCH_FIELDS_READY); half B follows the join: forces -> vpref -> work lists.  33 us of the tick's critical
-// path become ~10.  The record of every entity of the work range travels through `mid` (32 B written + read).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_agent_mid_a(nh_step_params P, nh_mid_rec *mid, float scaled_max_force)
-{
-    const int uid = P.work_begin + (int)(blockIdx.x * 64 + threadIdx.x);
-    if(uid >= P.work_end) return;
-    nh_mid_rec R;
-    mid_thread_a(P, uid, scaled_max_force, R);
-    mid[uid] = R;
-}
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_agent_mid_b(nh_step_params P, nh_nbr NB, const float *coh_xz, nh_mid_rec *mid, nh_worklists WL, nh_step_outs O,
-                   float scaled_max_force, double force_thresh)
-{
-    const int uid = P.work_begin + (int)(blockIdx.x * 64 + threadIdx.x);
-    const bool live = uid < P.work_end;
-    int disp = DISP_DONE;
-    if(live) {
-        nh_mid_rec R = mid[uid];
-        v2 out_vel;
-        disp = mid_thread_b(P, uid, NB, coh_xz, scaled_max_force, force_thresh, R, out_vel);
         if(O.vdes_xz)  { O.vdes_xz[2 * uid] = R.vdes[0]; O.vdes_xz[2 * uid + 1] = R.vdes[1]; }
         if(O.vpref_xz) { O.vpref_xz[2 * uid] = R.vpref[0]; O.vpref_xz[2 * uid + 1] = R.vpref[1]; }
         if(disp == DISP_DONE) {
@@ -1150,24 +1048,11 @@ void k_agent_mid_b(nh_step_params P, nh_nbr NB, const float *coh_xz, nh_mid_rec 
 // orders of magnitude; one kernel for all needed the registers of the largest and the LDS of each),
 // side by side on two streams.
 // ---------------------------------------------------------------------------------------------
-#ifdef NH_CP_UNIT_HIST
-// developer instrumentation (scripts/cp_unit_hist.py): unit durations of the last launches in
-// s_memtime ticks, log2 buckets, [0] workgroup problems / [2] row units;
-// [3][8 k + 2..4] = summed lifetimes of all waves, waves, the longest lifetime of kernel k (0 heavy,
-// 2 rows)
-__device__ unsigned long long nh_cp_hist[4][32];
-#endif
-#ifndef CP_WAVES
 #define CP_WAVES 4
-#endif
 // waves per workgroup of k_cp_rows (its waves work on their own: the workgroup only shares the unit tables)
-#ifndef CPR_WAVES
 #define CPR_WAVES 4
-#endif
 // problems on the workgroup lists from which one wave takes one problem (k_cp_heavy_solo) instead of a team
-#ifndef CP_SOLO_MIN
 #define CP_SOLO_MIN 8192
-#endif
 
 // first k with end[k] > u (n - 1 when there is none), for a wave-uniform u, by the whole wave: the running
 // totals do not decrease, so it is the number of entries <= u -- one or two ballots instead of a binary search
@@ -1197,9 +1082,7 @@ __device__ __forceinline__ int first_above(const int32_t *end, int n, int u)
 struct unit_draw { int stripe, abandoned, round; };
 __device__ __forceinline__ int next_unit(unit_draw &D, int32_t *counters, int total, int gw, int nw, int lane)
 {
-#ifndef NH_CP_TICKET_ROUNDS
 #define NH_CP_TICKET_ROUNDS 1
-#endif
     const int static_rounds = max(0, total / nw - NH_CP_TICKET_ROUNDS);
     const int r = D.round++;
     if(r < static_rounds) return gw + r * nw;
@@ -1221,23 +1104,11 @@ __device__ __forceinline__ int next_unit(unit_draw &D, int32_t *counters, int to
     return -1;
 }
 
-#ifdef NH_CP_UNIT_HIST
-#define HIST_T0() const unsigned long long hist_t0 = __builtin_amdgcn_s_memtime()
-#define HIST_UNIT(cls, t0) do { if((threadIdx.x & 63) == 0) atomicAdd(&nh_cp_hist[cls][63 - __builtin_clzll((__builtin_amdgcn_s_memtime() - (t0)) | 1ull)], 1ull); } while(0)
-#define HIST_WAVE(k) do { if((threadIdx.x & 63) == 0) { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - hist_t0; \
-    atomicAdd(&nh_cp_hist[3][8 * (k) + 2], d_); atomicAdd(&nh_cp_hist[3][8 * (k) + 3], 1ull); atomicMax(&nh_cp_hist[3][8 * (k) + 4], d_); } } while(0)
-#else
-#define HIST_T0()
-#define HIST_UNIT(cls, t0)
-#define HIST_WAVE(k)
-#endif
 
 // ---- k_cp_small: the lists of 1-2 and 3-4 neighbours -- three quarters of the searching agents
 // outside a crowd.  One wave per unit of four agents, one attempt each (clearpath_small_row); an agent
 // without any admissible candidate goes onto the retry list, which a launch of k_cp_rows works off. ----
-#ifndef CPS_WAVES
 #define CPS_WAVES 4          /* waves (units) per workgroup */
-#endif
 __global__ __launch_bounds__(CPS_WAVES * 64) void k_cp_small(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                             nh_worklists WL, nh_step_outs O)
 {
@@ -1285,9 +1156,7 @@ __global__ __launch_bounds__(CPS_WAVES * 64) void k_cp_small(nh_step_params P, n
 // unit, the units numbered heaviest list first (9-16, 5-8, 3-4, 1-2 neighbours) ---------------------
 // (the lists list0, list0 - 1, ... : nlists of them, at most four; ticket_set: which set of stripe
 // counters -- the retry launch runs beside the main one)
-#ifndef CP_ROWS_OCC
 #define CP_ROWS_OCC 4           /* (pinned like k_cp_heavy: four waves per SIMD, 128 registers -- see the note on hole inheritance below) */
-#endif
 __attribute__((amdgpu_waves_per_eu(CP_ROWS_OCC, CP_ROWS_OCC)))
 __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                            nh_worklists WL, nh_step_outs O, int list0, int nlists,
@@ -1316,7 +1185,6 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
     __syncthreads();
     unit_totals(unit_end, ntab, [&](int k) { return (sub_cnt[k] + 3) >> 2; });
     __syncthreads();
-    HIST_T0();
     const int total = unit_end[ntab - 1];
     int32_t *counters = WL.count + NH_WL_LISTS * NH_WL_SUB + 32 * (1 + ticket_set * NH_CP_STRIPES);
     const int gw = blockIdx.x * CPR_WAVES + wib, nw = gridDim.x * CPR_WAVES;
@@ -1328,9 +1196,6 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
         const int k = first_above(unit_end, ntab, u), rel = u - (k ? unit_end[k - 1] : 0);
         const int list = list0 - k / NH_WL_SUB, sub = k % NH_WL_SUB;
         const int idx = rel * 4 + (lane >> 4);
-#ifdef NH_CP_UNIT_HIST
-        const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
-#endif
         if(idx < sub_cnt[k]) {                  // (else: a row beyond the end of its sub-list)
             const int uid = WL.ids[((size_t)list * NH_WL_SUB + sub) * WL.cap + idx];
             const nh_mid_rec R = mid[uid];
@@ -1345,38 +1210,25 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
             if((lane & 15) == 0)
                 post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
         }
-        HIST_UNIT(2, tu0);
     }
-    HIST_WAVE(2);
 }
 
 // ---- k_cp_heavy: the heavy list (33-64 neighbours), then the wave list (17-32).  A search of up to 16 000 ray
 // pairs on one wave takes hundreds of microseconds -- as long as everything else of the tick --, and even among
 // problems of 20-30 neighbours the cost spreads over a factor of ten (how early an admissible candidate turns up
-// decides how much is pruned).  Two passes (two launches on the side stream):
-//   pass 0  one problem per WAVE, its first one by wave number, then a ticket per wave and problem.  A search
-//           whose projections of des_v yield no bound -- the column phase ahead is close to exhaustive: the
-//           problems that would outlast the launch -- is not run: its agent goes onto the team list.  (In a jam,
-//           from CP_SOLO_MIN problems on, there are more problems than waves, the load balances over problems and
-//           nothing is handed over: 92 000 problems in the crowded world.)
-//   pass 1  the team list, one problem per WORKGROUP: its waves search it as a team (clearpath_grp<64, true>).
-// NH_CP_BAIL 0 (the default) runs every problem below CP_SOLO_MIN as a team in pass 0 and leaves pass 1 empty.
-// The two-pass schedule was measured and LOST: 0.538 against 0.461 ms per tick over 100 ticks, 0.91 against 0.72 ms
-// at tick 100 (profiles/r04_ab_cp_bail_100.txt).  Below CP_SOLO_MIN the launch is bound by its LONGEST problems,
-// not by issue slots (each workgroup holds one to five problems): a team quarters every problem's latency, the
-// ones that keep a bound included; two passes add their tails.  The code stays for the measurement.
-#ifndef NH_CP_BAIL
-#define NH_CP_BAIL 0
-#endif
-#ifndef CP_HEAVY_OCC
+// decides how much is pruned).  So: one problem per WORKGROUP, its waves search it as a team (clearpath_grp<64, true>)
+// -- the launch is bound by its LONGEST problems, and a team quarters every problem's latency.  In a jam, from
+// CP_SOLO_MIN problems on (92 000 in the crowded world), there are more problems than waves, the load balances over
+// problems, and a team would only repeat the cone / rank construction four times: every WAVE takes a problem of its
+// own, its first one by wave number, then a ticket per wave and problem.  (A two-pass schedule -- every wave on its
+// own, searches that find no bound handed over to teams -- was measured and lost: profiles/r04_ab_cp_bail_100.txt.)
 #define CP_HEAVY_OCC 4          /* (pinned: a few registers above 128 would silently cost a wave per SIMD) */
-#endif
 __attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
 __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
-                                                            nh_worklists WL, nh_step_outs O, int32_t *zero_next, int pass)
+                                                            nh_worklists WL, nh_step_outs O, int32_t *zero_next)
 {
     __shared__ cp_lds<64> lds[CP_WAVES];
-    __shared__ int32_t hv_end[2 * NH_WL_SUB];       // sub-lists of the heavy list, then of the wave list (pass 1: the team list)
+    __shared__ int32_t hv_end[2 * NH_WL_SUB];       // sub-lists of the heavy list, then of the wave list
     __shared__ int32_t h_ticket;
     __shared__ cp_team team;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1387,89 +1239,57 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
     if(blockIdx.x == 0 && zero_next)
         for(int i = threadIdx.x; i < (int)NH_WL_COUNTERS; i += CP_WAVES * 64) zero_next[i] = 0;
     cp_lds<64> &S = lds[wib];
-    if(pass == 0) {
-        // (outside a crowd there is nothing to do: one parallel look at the 128 counters)
-        if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
-        unit_totals(hv_end, 2 * NH_WL_SUB, [&](int k) {
-            return WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB]; });
-        __syncthreads();
-        HIST_T0();
-        const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
-        int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
-        const bool may_bail = NH_CP_BAIL && n_heavy < CP_SOLO_MIN;
-        if(NH_CP_BAIL || n_heavy >= CP_SOLO_MIN) {
-            const int nw = (int)gridDim.x * CP_WAVES;
-            for(int round = 0; ; round++) {
-                int t = (int)blockIdx.x * CP_WAVES + wib;
-                if(round > 0) {
-                    int v = 0x7fffffff;
-                    if(lane == 0 && nw + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy) v = nw + atomicAdd(ticket, 1);
-                    t = __shfl(v, 0);
-                }
-                if(t >= n_heavy) break;
-                const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
-                const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
-                const nh_mid_rec R = mid[uid];
-                const uint32_t c = NB.cnt[uid];
-                const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
-                cpent ent;
-                ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
-                ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
-                ent.radius = P.radius[uid];
-#ifdef NH_CP_UNIT_HIST
-                const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
-#endif
-                cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
-                bool bailed = false;
-                const v2 nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S, 0, 1, nullptr,
-                                          may_bail ? &bailed : nullptr);
-                if(bailed) {
-                    // onto the team list: sub-list = problem number mod NH_WL_SUB, so that a sub-list receives at most
-                    // ceil(n_heavy / NH_WL_SUB) <= ceil(work items / 64) entries -- below its capacity by construction
-                    // (nh_worklist_cap)
-                    const int sub = t & (NH_WL_SUB - 1);
-                    if(lane == 0) {
-                        const int at = atomicAdd(&WL.count[NH_WL_TEAM * NH_WL_SUB + sub], 1);
-                        WL.ids[((size_t)NH_WL_TEAM * NH_WL_SUB + sub) * WL.cap + at] = uid;
-                    }
-                    HIST_UNIT(0, tu0);
-                    continue;
-                }
-                if(lane == 0)
-                    post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
-                HIST_UNIT(0, tu0);
+    // (outside a crowd there is nothing to do: one parallel look at the 128 counters)
+    if(!__any((WL.count[NH_WL_HEAVY * NH_WL_SUB + lane] | WL.count[NH_WL_WAVE * NH_WL_SUB + lane]) != 0)) return;
+    unit_totals(hv_end, 2 * NH_WL_SUB, [&](int k) {
+        return WL.count[(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB]; });
+    __syncthreads();
+    const int n_heavy = hv_end[2 * NH_WL_SUB - 1];
+    int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB;
+    if(n_heavy >= CP_SOLO_MIN) {
+        // ---- a jam: one problem per wave
+        const int nw = (int)gridDim.x * CP_WAVES;
+        for(int round = 0; ; round++) {
+            int t = (int)blockIdx.x * CP_WAVES + wib;
+            if(round > 0) {
+                int v = 0x7fffffff;
+                if(lane == 0 && nw + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy) v = nw + atomicAdd(ticket, 1);
+                t = __shfl(v, 0);
             }
-            HIST_WAVE(0);
-            return;
+            if(t >= n_heavy) break;
+            const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
+            const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
+            const nh_mid_rec R = mid[uid];
+            const uint32_t c = NB.cnt[uid];
+            const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
+            cpent ent;
+            ent.pos = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
+            ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
+            ent.radius = P.radius[uid];
+            cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
+            const v2 nv = clearpath_grp<64>(ent, mkv(R.vpref[0], R.vpref[1]), n_dyn, n_stat, S);
+            if(lane == 0)
+                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
         }
-    }else{
-        if(!NH_CP_BAIL) return;
-        if(!__any(WL.count[NH_WL_TEAM * NH_WL_SUB + lane] != 0)) return;
-        unit_totals(hv_end, NH_WL_SUB, [&](int k) { return min(WL.count[NH_WL_TEAM * NH_WL_SUB + k], WL.cap); });
-        __syncthreads();
+        return;
     }
-    // ---- one problem per workgroup: pass 1 over the team list (NH_CP_BAIL 0: pass 0 over both lists)
-    HIST_T0();
-    const int ntab = pass == 0 ? 2 * NH_WL_SUB : NH_WL_SUB;
-    const int n_team = hv_end[ntab - 1];
-    int32_t *ticket = WL.count + NH_WL_LISTS * NH_WL_SUB + (pass == 0 ? 0 : 32 * (1 + 2 * NH_CP_STRIPES));
+    // ---- one problem per workgroup
     for(int round = 0; ; round++) {
         int t = blockIdx.x;
         if(round > 0) {
             __syncthreads();
             if(threadIdx.x == 0) {
                 int v = 0x7fffffff;
-                if((int)gridDim.x + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_team)
+                if((int)gridDim.x + __atomic_load_n(ticket, __ATOMIC_RELAXED) < n_heavy)
                     v = (int)gridDim.x + atomicAdd(ticket, 1);
                 h_ticket = v;
             }
             __syncthreads();
             t = h_ticket;
         }
-        if(t >= n_team) break;
-        const int k = first_above(hv_end, ntab, t), idx = t - (k ? hv_end[k - 1] : 0);
-        const int list = pass == 0 ? (k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) : NH_WL_TEAM;
-        const int uid = WL.ids[((size_t)list * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
+        if(t >= n_heavy) break;
+        const int k = first_above(hv_end, 2 * NH_WL_SUB, t), idx = t - (k ? hv_end[k - 1] : 0);
+        const int uid = WL.ids[((size_t)(k < NH_WL_SUB ? NH_WL_HEAVY : NH_WL_WAVE) * NH_WL_SUB + k % NH_WL_SUB) * WL.cap + idx];
         const nh_mid_rec R = mid[uid];
         const uint32_t c = NB.cnt[uid];
         const int n_dyn = (int)(c & 0xff), n_stat = (int)((c >> 8) & 0xff);
@@ -1478,18 +1298,11 @@ __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh
         ent.vel = mkv(P.vel_xz[2 * uid], P.vel_xz[2 * uid + 1]);
         ent.radius = P.radius[uid];
         const v2 vpref = mkv(R.vpref[0], R.vpref[1]);
-#ifdef NH_CP_UNIT_HIST
-        const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
-#endif
         cp_load_lists<64>(P.grid, NB, uid, n_dyn, n_stat, S);
         const v2 nv = clearpath_grp<64, true>(ent, vpref, n_dyn, n_stat, S, wib, CP_WAVES, &team);
-        if(wib == 0) {
-            if(lane == 0)
-                post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
-            HIST_UNIT(0, tu0);
-        }
+        if(wib == 0 && lane == 0)
+            post_thread(P, uid, ent.pos, P.state[uid], P.flags[uid], ent.radius, nv, R.vel_cap, R.status, O);
     }
-    HIST_WAVE(0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1604,7 +1417,9 @@ __global__ __launch_bounds__(256) void k_arrived_compact(nh_step_params P, float
         base = __shfl(base, 0);
         if(m >= 0) {
             const int at = b + base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
-            arrived[at] = make_float4(P.pos_xz[2 * m], P.pos_xz[2 * m + 1], P.radius[m], __int_as_float(m));
+            // (the scratch holds n_ents rows -- an entity belongs to at most one flock; a device-side member list that
+            // breaks that promise loses rows of the scan instead of writing past the buffer)
+            if(at < P.n_ents) arrived[at] = make_float4(P.pos_xz[2 * m], P.pos_xz[2 * m + 1], P.radius[m], __int_as_float(m));
         }
     }
     __syncthreads();
@@ -1682,7 +1497,7 @@ __global__ __launch_bounds__(256) void k_state_update(nh_step_params P, navhip_s
                 // every member cost 405 us per 100 000 units, nine tenths of the state pass)
                 const v2 me = mkv(P.pos_xz[2 * uid], P.pos_xz[2 * uid + 1]);
                 bool hit = false;
-                const int b = P.flock_offsets[flock], e = b + arrived_n[flock];
+                const int b = P.flock_offsets[flock], e = min(b + arrived_n[flock], P.n_ents);
                 for(int k0 = b; k0 < e && !g::any(hit); k0 += 16) {
                     const int k = k0 + gl;
                     if(k < e) {
@@ -1809,29 +1624,6 @@ extern "C" int navhip_debug_cp_attempts(unsigned long long out[9], int reset)
     return 0;
 }
 
-#ifdef NH_CP_UNIT_HIST
-extern "C" int navhip_debug_cp_hist(unsigned long long out[128])
-{
-    if(hipDeviceSynchronize() != hipSuccess) return 1;
-    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_cp_hist), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    unsigned long long z[128] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_hist), z, sizeof(z)) != hipSuccess;
-}
-#endif
-#ifdef NH_CP_STATS
-extern "C" int navhip_debug_cp_work(unsigned long long out[192], int reset)
-{
-    if(hipDeviceSynchronize() != hipSuccess) return 1;
-    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(nh_cp_work), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if(hipMemcpyFromSymbol(out + 128, HIP_SYMBOL(nh_cp_cyc), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if(reset) {
-        unsigned long long z[128] = {0};
-        if(hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_work), z, sizeof(z)) != hipSuccess) return 1;
-        if(hipMemcpyToSymbol(HIP_SYMBOL(nh_cp_cyc), z, 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    }
-    return 0;
-}
-#endif
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1839,10 +1631,8 @@ extern "C" int navhip_debug_cp_work(unsigned long long out[192], int reset)
 // ---------------------------------------------------------------------------------------------
 // Four dependent launches, no memset (cell_count is zeroed by k_sp_scan_add once it has been
 // consumed; the box of the slab filter is the exception).
-// after_first (optional): recorded behind the first kernel of the chain -- the fork event of the step's side
-// streams: recorded in FRONT of the chain it is one more packet before the first kernel of the tick
 void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scratch &S,
-                             int slab_begin, int slab_end, hipStream_t s, hipEvent_t after_first)
+                             int slab_begin, int slab_end, hipStream_t s)
 {
     const int n = G.n, ncells = G.grid_w * G.grid_h;
     // a strict sub-range of the entities is stepped: hash only what its queries can reach
@@ -1860,7 +1650,6 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
                            S.ent_cell, S.ent_rank, S.cell_count, box, box_next);
-    if(after_first) hipEventRecord(after_first, s);
     const int nblocks = (ncells + NH_SCAN_T - 1) / NH_SCAN_T;
     hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(NH_SCAN_T), 0, s, S.cell_count, S.cell_start,
                        S.block_sum, ncells, G, box);
@@ -1925,10 +1714,10 @@ size_t nh_cohesion_scratch_bytes(int n_flocks, int n_members)
 }
 
 // after (re)allocation: no grouping has been built for any flock layout yet
-void nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s)
+hipError_t nh_cohesion_scratch_reset(int32_t *scratch, int n_flocks, int n_members, hipStream_t s)
 {
     const coh_scratch C = coh_layout(scratch, n_flocks, n_members);
-    hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 4), s);
+    return hipMemsetAsync(C.saved[0], 0xff, sizeof(int32_t) * 2 * ((size_t)n_flocks + 4), s);
 }
 
 __global__ void k_zero_i32(int32_t *p, int n)
@@ -1960,9 +1749,7 @@ static void coh_regroup(const nh_step_params &P, const coh_scratch &C, int which
 // launches AFTER recording its "cohesion done" event: five dependent small launches leave the tick's
 // critical path.  That holds for a rank that steps a slab as well: its grouping holds the slab's members
 // only (k_coh_bin), so the members of the other ranks occupy no lanes.
-#ifndef COH_INLINE_PLAN_MAX
 #define COH_INLINE_PLAN_MAX 64
-#endif
 bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh, int *parity, hipStream_t s)
 {
     if(!(P.n_ents > 0 && P.n_flocks > 0 && P.n_members > 0)) return false;
@@ -1971,22 +1758,17 @@ bool nh_launch_cohesion(const nh_step_params &P, int32_t *scratch, float *d_coh,
     // member of the whole snapshot); surplus waves exit at once
     const int nwaves = (P.n_members + 15) / 16 + P.n_flocks;
     const int prev = *parity ^ 1;
-    // (the caller's force buffer is twice the force array: the gathered positions live behind it)
-    float2 *fpos = (float2*)(d_coh + 2 * (size_t)P.n_ents);
-#if COH_FPOS
-    hipLaunchKernelGGL(k_coh_gather, dim3((P.n_members + 255) / 256), dim3(256), 0, s, P, fpos);
-#endif
     if(P.n_flocks <= COH_INLINE_PLAN_MAX) {
         hipLaunchKernelGGL(k_cohesion<true>, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
                            (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start,
-                           (const int32_t*)C.saved[prev], (const float2*)fpos);
+                           (const int32_t*)C.saved[prev]);
         return true;
     }
     hipLaunchKernelGGL(k_coh_plan, dim3(1), dim3(256), 0, s, (const int32_t*)C.bin_start, P.flock_offsets,
                        (const int32_t*)C.saved[prev], P.n_flocks, P.work_begin, P.work_end, P.members_key, C.wave_off, C.valid);
     hipLaunchKernelGGL(k_cohesion<false>, dim3(nwaves), dim3(64), 0, s, P, (const int32_t*)C.wave_off,
                        (const int32_t*)C.perm[prev], (const int32_t*)C.valid, d_coh, (const int32_t*)C.bin_start,
-                       (const int32_t*)C.saved[prev], (const float2*)fpos);
+                       (const int32_t*)C.saved[prev]);
     return true;                                  // caller: record the event, then ..._regroup
 }
 
@@ -1996,31 +1778,23 @@ void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *
     coh_regroup(P, C, *parity, s);
     *parity ^= 1;
 }
-// entries a sub-list can receive: its producers are the k_agent_mid waves with index = sub (mod
-// NH_WL_SUB), each of which steps 64 / MID_LANES entities
+// entries a sub-list can receive: its producers are the k_agent_mid waves with index = sub (mod NH_WL_SUB), each of
+// which steps 64 entities
 int nh_worklist_cap(int n_work)
 {
-    const int waves = (n_work * MID_LANES + 63) / 64;
+    const int waves = (n_work + 63) / 64;
     // (+ 16: the retry list is filled by k_cp_small's waves -- four entries each, a few more of them per
     // sub-list than there are k_agent_mid waves' worth)
-    return ((waves + NH_WL_SUB - 1) / NH_WL_SUB) * (64 / MID_LANES) + 16;
+    return ((waves + NH_WL_SUB - 1) / NH_WL_SUB) * 64 + 16;
 }
 
 // k_agent_mid + the consumers of its work lists.  The list counters alternate between two sets:
 // a launch sequence uses one and zeroes the other for its successor (no memset on the stream).
 // Returns whether anything was launched (the caller flips the parity only then: a step that launches nothing
 // does not clear the other set either).
-void nh_launch_agent_mid_a(const nh_step_params &P, nh_mid_rec *d_mid, hipStream_t s)
-{
-    const int nwork = P.work_end - P.work_begin;
-    if(!(P.n_ents > 0 && nwork > 0)) return;
-    const float smf = (float)((double)(0.75f / (float)P.hz) * 20.0);
-    hipLaunchKernelGGL(k_agent_mid_a, dim3((nwork + 63) / 64), dim3(64), 0, s, P, d_mid, smf);
-}
-
 bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
-                            hipStream_t side, hipStream_t side2, hipEvent_t ev[3], bool mid_a_done)
+                            hipStream_t side, hipEvent_t ev[2])
 {
     const int nwork = P.work_end - P.work_begin;
     if(!(P.n_ents > 0 && nwork > 0)) return false;
@@ -2029,27 +1803,17 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     const double thresh = ((double)(0.75f / (float)P.hz) * 20.0) * 0.01;
     int32_t *zero_next = WL.count + (parity ^ 1) * NH_WL_COUNTERS;
     WL.count += parity * NH_WL_COUNTERS;
-    if(mid_a_done && MID_LANES == 1)
-        hipLaunchKernelGGL(k_agent_mid_b, dim3((nwork + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh, d_mid, WL, O, smf, thresh);
-    else
-        hipLaunchKernelGGL(k_agent_mid, dim3((nwork * MID_LANES + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh,
-                           d_mid, WL, O, smf, thresh);
+    hipLaunchKernelGGL(k_agent_mid, dim3((nwork + 63) / 64), dim3(64), 0, s, P, NB, (const float*)d_coh, d_mid, WL, O, smf, thresh);
     // the ClearPath launches.  s: the rows of 5-16 neighbours, the irregular agents.  side: the agents with 1-4
     // neighbours (most of them, outside a crowd), whatever of them needs the retry logic, then the workgroup problems
-    // (17-64 neighbours).  Every wave / workgroup keeps drawing units until none are left.
-    // NAVHIP_CP_SCHED=1 (developer knob) puts the workgroup problems on a third stream, side2, beside the small ones
-    // they do not depend on: measured and LOST -- 0.317 against 0.310 ms per tick on ordinary ticks (one more fork
-    // and join on the agent stream cost what the shorter chain saved), 5.83 against 4.89 in the crowded world (the
-    // workgroup searches then race k_cp_rows for the chip instead of inheriting it: profiles/r04_ab_cp_three_streams.txt).
-    static int sched = -1;
-    if(sched < 0) { const char *e = getenv("NAVHIP_CP_SCHED"); sched = e ? atoi(e) : 0; }
+    // (17-64 neighbours).  Every wave / workgroup keeps drawing units until none are left.  (The workgroup problems on
+    // a third stream beside the small ones were measured and lost -- one more fork and join on the agent stream, and in
+    // a jam the searches race k_cp_rows for the chip instead of inheriting it: profiles/r04_ab_cp_three_streams.txt.)
     const bool fork = side && ev && ev[0] && ev[1];
-    const bool fork2 = fork && side2 && ev[2] && sched != 0;
-    hipStream_t sh = fork ? side : s, sh2 = fork2 ? side2 : sh;
+    hipStream_t sh = fork ? side : s;
     if(fork) {
         hipEventRecord(ev[0], s);
         hipStreamWaitEvent(sh, ev[0], 0);
-        if(fork2) hipStreamWaitEvent(sh2, ev[0], 0);
     }
     const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
     const int nblk_rows = min(4096 / CPR_WAVES, (nwork + 15) / 16 * (CP_WAVES / CPR_WAVES) + 1);
@@ -2057,41 +1821,16 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     // launch in front of it delays its start by one enqueue)
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_ROW3, 2, 0);
-    if(fork2) {
-        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh2, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                           (int32_t*)nullptr, 0);
-#if NH_CP_BAIL
-        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh2, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                           (int32_t*)nullptr, 1);
-#endif
-        hipEventRecord(ev[2], sh2);
-    }
     hipLaunchKernelGGL(k_cp_small, dim3((nwork / 4 + 2 * NH_WL_SUB + CPS_WAVES - 1) / CPS_WAVES + 1), dim3(CPS_WAVES * 64), 0, sh, P, NB,
                        (const nh_mid_rec*)d_mid, WL, O);
     hipLaunchKernelGGL(k_cp_rows, dim3(64 * CP_WAVES / CPR_WAVES), dim3(CPR_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_RETRY, 1, 1);
-    if(fork2) {
-        // the other set of list counters, for the next step: on `side`, where the library copies every step's
-        // counters to pinned host memory behind the step (navhip_step_lists_peek) -- the stream orders the clearing
-        // of a set behind the copy of that set
-        hipLaunchKernelGGL(k_zero_i32, dim3(((int)NH_WL_COUNTERS + 255) / 256), dim3(256), 0, sh, zero_next, (int)NH_WL_COUNTERS);
-    }else{
-        // (the last launch on `side` clears the other set of list counters: see k_cp_heavy)
-#if NH_CP_BAIL
-        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                           (int32_t*)nullptr, 0);
-        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                           zero_next, 1);
-#else
-        hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                           zero_next, 0);
-#endif
-    }
+    // (the last launch on `side` clears the other set of list counters: see k_cp_heavy)
+    hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O, zero_next);
     if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
                        (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, (int32_t*)nullptr);
     if(fork) hipStreamWaitEvent(s, ev[1], 0);
-    if(fork2) hipStreamWaitEvent(s, ev[2], 0);
     return true;
 }
 

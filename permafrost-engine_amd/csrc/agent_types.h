@@ -103,7 +103,6 @@ enum { NH_WL_ROW0 = 0, NH_WL_ROW1, NH_WL_ROW2, NH_WL_ROW3,   // a row of 16 lane
        NH_WL_HEAVY,         // one workgroup per agent: 33-64 neighbours (started first)
        NH_WL_FULL,          // one wave per agent, whole step (irregular gather)
        NH_WL_RETRY,         // filled by k_cp_small: 1-4 neighbours and no admissible candidate (the retry logic)
-       NH_WL_TEAM,          // filled by k_cp_heavy's first pass: searches one wave handed over to a team of waves
        NH_WL_LISTS };       // (number of lists)
 // Every list is kept as NH_WL_SUB sub-lists, one per group of producer waves (wave index mod
 // NH_WL_SUB): an append is one atomic per wave and list, and a few thousand atomics on ONE address
@@ -112,8 +111,7 @@ enum { NH_WL_ROW0 = 0, NH_WL_ROW1, NH_WL_ROW2, NH_WL_ROW3,   // a row of 16 lane
 struct nh_worklists {
     int32_t *count;            // [NH_WL_LISTS][NH_WL_SUB] entries + the ticket counters of the ClearPath
                                // kernels, one per 128-byte line: [0] workgroup problems, [1 + s] stripe s
-                               // of the row units, [1 + NH_CP_STRIPES + s] of the retry launch, [1 + 2
-                               // NH_CP_STRIPES] the team pass of the workgroup problems (+ the same again:
+                               // of the row units, [1 + NH_CP_STRIPES + s] of the retry launch (+ the same again:
                                // other parity)
     int32_t *ids;              // [NH_WL_LISTS][NH_WL_SUB][cap] uids
     int      cap;              // entries a sub-list can hold (its producers cannot append more)

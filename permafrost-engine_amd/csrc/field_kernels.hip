@@ -156,14 +156,9 @@ void nh_launch_derive(navhip_ctx *ctx, int layer, const uint32_t *d_chunk_list, 
 // k_field_bfs : one wave per request, lane = row
 // ---------------------------------------------------------------------------------------------
 #define NH_MAXP 12   /* distance bit-planes: unit-cost distances are < 4096 */
-#ifndef BFS_WAVES
 #define BFS_WAVES 4    /* waves (= requests) per workgroup */
-#endif
 
 template <bool WANT_INTEG>
-#ifdef BFS_OCC
-__attribute__((amdgpu_waves_per_eu(BFS_OCC, BFS_OCC)))
-#endif
 __global__ __launch_bounds__(BFS_WAVES * 64) void k_field_bfs(nh_map_view map, const navhip_field_req *reqs,
                                                    int n, uint8_t *dirs, float *integ,
                                                    int force_generic, int32_t *gen_list, int gen_slot,

@@ -708,7 +708,7 @@ static int coh_scratch_ensure(navhip_ctx *ctx, int n_flocks, int n_members, hipS
             HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         }
-        nh_cohesion_scratch_reset((int32_t*)ctx->coh_plan.p, n_flocks, n_members, s);
+        HIPCHK(ctx, nh_cohesion_scratch_reset((int32_t*)ctx->coh_plan.p, n_flocks, n_members, s));
         ctx->coh_flocks = n_flocks; ctx->coh_members = n_members; ctx->coh_parity = 0;
     }
     return NAVHIP_OK;
@@ -750,8 +750,7 @@ static int ensure_zeroed(navhip_ctx *ctx, navhip_ctx::buf &b, size_t need, hipSt
 }
 
 static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hipStream_t s,
-                         int slab_begin = 0, int slab_end = -1, bool with_records = true,
-                         hipEvent_t after_first = nullptr)
+                         int slab_begin = 0, int slab_end = -1, bool with_records = true)
 {
     if(!grid_geometry(w, g)) {
         ctx->last_error = "agent step: empty spatial-grid bounds";
@@ -779,7 +778,7 @@ static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hip
     if(slab_end < 0) slab_end = w->n_ents;
     // (the two slab boxes alternate between the builds that USE one: such a build cleans the other)
     if(slab_begin > 0 || slab_end < w->n_ents) S.box_parity = (int)(ctx->sp_builds++ & 1u);
-    nh_launch_spatial_build(*g, w->pos_xz, S, slab_begin, slab_end, s, after_first);
+    nh_launch_spatial_build(*g, w->pos_xz, S, slab_begin, slab_end, s);
     return NAVHIP_OK;
 }
 
@@ -932,12 +931,9 @@ static int ensure_side_streams(navhip_ctx *ctx, hipStream_t main)
 // against a 904-unit reach, so a grouping serves many ticks.  It is rebuilt on the two ticks after anything it was
 // built for changes (entity / flock / member counts, work range, membership key) and every NH_COH_REGROUP_EVERY-th
 // tick otherwise; k_cohesion checks on the device that the grouping it is given fits (else: the identity).
-#ifndef NH_COH_REGROUP_EVERY
 #define NH_COH_REGROUP_EVERY 8
-#endif
 static bool coh_regroup_due(navhip_ctx *ctx, const nh_step_params &P)
 {
-    if(ctx->regroup_override) return ctx->regroup_override == 1;
     const int64_t key[4] = {((int64_t)P.n_ents << 32) | (uint32_t)P.n_flocks, (int64_t)P.n_members,
                             ((int64_t)P.work_begin << 32) | (uint32_t)P.work_end, (int64_t)P.members_key};
     if(memcmp(key, ctx->coh_regroup_key, sizeof(key)) != 0) {
@@ -974,7 +970,7 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     rc = step_fill_params(ctx, w, &P);
     if(rc) return rc;
     nh_nbr NB; nh_worklists WL;
-    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 4 * sizeof(float))   /* force [n][2] | gathered member positions [n][2] */;
+    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
     if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
     if(!rc) rc = step_scratch(ctx, w->n_ents, &NB, &WL, s);
     if(rc) return rc;
@@ -982,37 +978,17 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // critical path of the tick: NAVHIP_PREFETCH_FRONT_INLINE keeps it on the caller's stream, where it
     // follows the previous step without a cross-stream hand-over (tens of microseconds each)
     hipStream_t front = (flags & NAVHIP_PREFETCH_FRONT_INLINE) ? s : ctx->aux[0];
-    // The fork event for the cohesion stream (and for whoever waits for NAVHIP_STAGE_START) is one packet on the
-    // caller's stream: in front of the first kernel of the front it delays the front, behind it (NH_FORK_BEHIND_COUNT)
-    // the cohesion kernel.  Whichever of the two ends later gates k_agent_mid: while the neighbour walk was the
-    // longer one the event sat behind k_sp_count (0.370 -> 0.364 ms per tick together with two other changes);
-    // since the walk runs as one-wave workgroups the cohesion kernel ends last, and the event is back in front
-    // (0.3205 -> 0.3166; profiles/r03_ab_tick_chain.txt, r03_ab_fork_first.txt).
-#ifndef NH_FORK_BEHIND_COUNT
-#define NH_FORK_BEHIND_COUNT 0
-#endif
-    const bool fork_late = NH_FORK_BEHIND_COUNT && front == s;
-    if(!fork_late) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-        if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
-    }
+    // The fork event for the cohesion stream (and for whoever waits for NAVHIP_STAGE_START) is one packet on the caller's
+    // stream, in FRONT of the first kernel of the front: the cohesion kernel ends last, so it must not start late
+    // (behind k_sp_count it delayed the cohesion kernel: 0.3205 -> 0.3166 ms per tick, profiles/r03_ab_fork_first.txt).
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+    if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
     // side stream 0: spatial hash -> neighbour walk (separation force + ClearPath neighbour lists)
-    rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end, true, fork_late ? ctx->ev_fork : nullptr);
+    rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end);
     if(rc) return rc;
-    if(fork_late) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
     nh_launch_agent_nbr(P, NB, front);
-    ctx->pre.mid_a = false;
     ctx->join0_recorded = false;
-    if(flags & NAVHIP_PREFETCH_FIELDS_READY) {
-        // half A of the per-agent chain on the front, behind the neighbour walk, beside the cohesion term.  On an inline
-        // front the "neighbours done" event (NAVHIP_STAGE_NEIGHBOURS: where the next tick's field builds start) is
-        // recorded in front of it -- the front is no longer the critical path of the tick, the cohesion term is
-        if(front == s) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front)); ctx->join0_recorded = true; }
-        nh_launch_agent_mid_a(P, (nh_mid_rec*)ctx->midrec.p, front);
-        ctx->pre.mid_a = true;
-        memcpy(&ctx->pre.world, w, sizeof(navhip_world));
-    }
     // (an inline front is ordered on the caller's stream by itself: its "done" event is only recorded
     // when somebody asks for it -- every event on that stream is a packet on the tick's critical path)
     if(front != s) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front)); ctx->join0_recorded = true; }
@@ -1103,15 +1079,8 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         }
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
-        // (half A ran with the prefetch -- for this very world, byte for byte -- or runs here, fused with half B)
-        const bool mid_a_done = ctx->pre.mid_a && memcmp(&ctx->pre.world, w, sizeof(navhip_world)) == 0;
-        if(ctx->pre.mid_a && !mid_a_done && ctx->front_stream != s) {
-            // (half A of another world wrote the records on the front stream: order this step's fused kernel behind it)
-            if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
-            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
-        }
         if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                                  ctx->aux[0], ctx->aux[1], ctx->ev_cp, mid_a_done)) {
+                                  ctx->aux[0], ctx->ev_cp)) {
             rc = send_step_lists(ctx, ctx->wl_parity, s);
             ctx->wl_parity ^= 1;
             if(rc) return rc;
@@ -1132,7 +1101,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     nh_launch_agent_nbr(P, NB, s);
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 4 * sizeof(float))   /* force [n][2] | gathered member positions [n][2] */;
+    rc = ensure_buf(ctx, ctx->coh, (size_t)w->n_ents * 2 * sizeof(float));
     if(!rc) rc = coh_scratch_ensure(ctx, w->n_flocks, P.n_members, s);
     if(rc) return rc;
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity, s);
@@ -1141,7 +1110,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     const bool serial = ctx->serial_step;
     if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                              serial ? nullptr : ctx->aux[0], serial ? nullptr : ctx->aux[1], ctx->ev_cp)) {
+                              serial ? nullptr : ctx->aux[0], ctx->ev_cp)) {
         rc = send_step_lists(ctx, ctx->wl_parity, s, serial);
         ctx->wl_parity ^= 1;
         if(rc) return rc;
@@ -1203,7 +1172,7 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
     int32_t h[NH_WL_COUNTERS];
     HIPCHK(ctx, hipMemcpy(h, src, sizeof(h), hipMemcpyDeviceToHost));
     // (the wave and the heavy list are reported together: 17-64 neighbours)
-    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1, -1};     // (the retry and team lists are not reported)
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1};     // (the retry list is not reported)
     for(int l = 0; l < 6; l++) out_counts[l] = 0;
     for(int l = 0; l < NH_WL_LISTS; l++)
         for(int sb = 0; sb < NH_WL_SUB; sb++) if(slot_of[l] >= 0) out_counts[slot_of[l]] += h[l * NH_WL_SUB + sb];
@@ -1213,7 +1182,7 @@ int navhip_last_step_lists(navhip_ctx *ctx, int32_t out_counts[6])
 int navhip_step_lists_peek(navhip_ctx *ctx, int32_t out_counts[6])
 {
     if(!ctx || !out_counts) return NAVHIP_ERR_INVALID;
-    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1, -1};
+    static const int slot_of[NH_WL_LISTS] = {0, 1, 2, 3, 4, 4, 5, -1};
     for(int l = 0; l < 6; l++) out_counts[l] = 0;
     if(!ctx->lists_pinned) return NAVHIP_OK;
     const volatile int32_t *h = ctx->lists_pinned;
@@ -1350,6 +1319,10 @@ int navhip_state_update(navhip_ctx *ctx, const navhip_world *w, const navhip_sta
     hipStream_t s = ctx->stream;
     const size_t n = (size_t)w->n_ents, F = (size_t)w->n_flocks;
     const size_t nmembers = F ? (size_t)w->flock_offsets[F] : 0, ntiles = F ? (size_t)in->flock_tiles_off[F] : 0;
+    if(nmembers > n) {                 // (an entity belongs to at most one flock: the scratch of the arrived-mate rule is sized by it)
+        ctx->last_error = "navhip_state_update: more flock members than entities";
+        return NAVHIP_ERR_INVALID;
+    }
     navhip_world d = *w;
     navhip_state_in di = *in;
     int rc = 0;

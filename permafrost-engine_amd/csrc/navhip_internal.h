@@ -73,10 +73,8 @@ struct navhip_ctx {
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
     bool         join0_recorded;    // ev_join[0] has been recorded for the front of the last prefetch
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
-    hipEvent_t   ev_cp[3];          // the ClearPath launches of the agent step: lists ready, small problems done, workgroup problems done
+    hipEvent_t   ev_cp[2];          // the ClearPath launches of the agent step: lists ready, side chain done
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
-    int          regroup_override;  // 0 = the library's own cadence (coh_regroup_due); 1 / 2 = the caller (tick_api.hip,
-                                    // which keys its captured graphs on the decision) says regroup / do not
     bool         serial_step;       // navhip_agent_step_dev runs EVERYTHING on the caller's stream (no side streams, no events):
                                     // the tick of a small world is a chain of dependent launches, and every cross-stream
                                     // edge costs more than the overlap it buys (tick_api.hip, NAVHIP_TICK_SERIAL)
@@ -86,8 +84,7 @@ struct navhip_ctx {
              const uint8_t *state, *arrival_flags; const int32_t *flock_members, *flock_offsets;
              int n_ents, n_flocks, hz, work_begin, work_end;
              struct nh_grid_store { int32_t origin_x, origin_y; int grid_w, grid_h; } g;
-             bool mid_a; navhip_world world; } pre;     // mid_a: half A of the per-agent chain ran with the prefetch, for
-                                                         // exactly this world (NAVHIP_PREFETCH_FIELDS_READY)
+             } pre;
     // optional per-kernel-group timing of the agent step (navhip_set_profiling)
     bool         profiling;
     hipEvent_t   ev[6];        // start | hash built | neighbour walk | cohesion | regroup | finish

@@ -9,6 +9,7 @@
 //   * submit / poll for the per-tick velocity step, staged through pinned memory, so that the nav
 //     task can yield between submit and join like the GL path does (movement.c:4212-4233).
 #include "navhip_internal.h"
+#include <mutex>
 #include "agent_internal.h"
 
 #include <algorithm>
@@ -171,7 +172,8 @@ static int pool_flush_map(navhip_ctx *ctx, nh_pool *P, hipStream_t s)
 // (see nh_is_pinned below)
 static struct { const void *p; bool pinned; } s_pin_cache[32];
 static int s_pin_next;
-static void pin_forget(const void *p) { for(auto &e : s_pin_cache) if(e.p == p) e.p = nullptr; }
+static std::mutex s_pin_mu;            // (the cache is the process's: contexts on several threads share it)
+static void pin_forget(const void *p) { std::lock_guard<std::mutex> lock(s_pin_mu); for(auto &e : s_pin_cache) if(e.p == p) e.p = nullptr; }
 
 extern "C" {
 
@@ -697,11 +699,14 @@ int nh_async_slabs(navhip_ctx *ctx, size_t in_bytes, size_t out_bytes, char **h_
 }
 
 // hipPointerGetAttributes costs microseconds; a host passes the same page-locked arrays every tick: the answers for the
-// last few pointers are remembered (an array freed and reallocated pageable at the same address would be stale -- the
-// entry is dropped when a transfer from it fails; navhip_host_free forgets its pointer)
+// last few pointers are remembered, under a mutex (the cache is shared by every context of the process).  An array
+// freed and reallocated pageable at the same address would be answered stale: that only changes the copy path taken
+// (a staged copy of pinned memory, or a direct transfer the runtime stages itself), never a result; navhip_host_free
+// forgets its pointer.
 bool nh_is_pinned(const void *p)
 {
     if(!p) return false;
+    std::lock_guard<std::mutex> lock(s_pin_mu);
     for(auto &e : s_pin_cache) if(e.p == p) return e.pinned;
     const bool r = is_pinned(p);
     s_pin_cache[s_pin_next] = {p, r};

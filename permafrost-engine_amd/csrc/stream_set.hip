@@ -167,11 +167,6 @@ int pipe_of(navhip_ctx *ctx, nh_dev_streams &D, hipStream_t s)
     auto it = D.caller_pipe.find(s);
     if(it != D.caller_pipe.end()) return it->second;
     int found = -1;
-#ifndef NH_HOSTSIM
-    // (a stream that is being captured into a graph cannot be measured: it is asked again next time)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if(!s || hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;
-#endif
     found = pipe_among_full(D, s);
     D.caller_pipe[s] = found;
     return found;

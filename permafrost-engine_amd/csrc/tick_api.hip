@@ -10,16 +10,12 @@
 // snapshot consumers wait for.  It calls the SAME entry points tick.py calls, in the same order per stream: results
 // are bit-identical by construction (tests/test_tick_gpu.py).
 //
-// NAVHIP_TICK_GRAPH: the enqueue cost of a tick is ~25 HIP calls (15 kernels, events, one copy): 0.1 ms from C,
-// 0.15 ms from Python -- configs[0]'s whole tick and the floor of strong scaling.  A tick's launches only depend on a
-// handful of host-side parities (ping-pong buffers, work-list counter set, cohesion permutation buffer, whether the
-// lane regrouping is due, where the field builds start): the tick is captured ONCE per combination into a HIP graph
-// (all side streams joined back at the end of the tick, the cross-tick event waits dropped: graph launches on one
-// stream are ordered) and replayed with one hipGraphLaunch.  Single-process worlds without moving obstacles.
+// A captured HIP graph per tick was built and measured in round 5 (0.448 against 0.342 ms per tick at configs[2]: a
+// barrier packet per cross-stream edge, and streams inside a graph carry neither CU mask nor queue of their own) and
+// removed in round 6: profiles/r05_host_overhead_c.txt.
 #include "navhip_internal.h"
 #include <cstring>
 #include <ctime>
-#include <map>
 #include <new>
 
 #define HIPCHK(ctx, expr)                                                                   \
@@ -32,21 +28,6 @@
     } while(0)
 #define RCCHK(expr) do { int _rc = (expr); if(_rc) return _rc; } while(0)
 
-#ifdef NH_HOSTSIM
-#define NH_TICK_GRAPHS 0          /* (the host emulator's stand-in runtime has no graphs: plain launches) */
-#else
-#define NH_TICK_GRAPHS 1
-#endif
-
-struct nh_graph_entry {
-#if NH_TICK_GRAPHS
-    hipGraphExec_t exec;
-#endif
-    int wl_parity_after, coh_parity_after;
-    unsigned gen_launches_delta;      // (the field kernels' list counters alternate per launch)
-    unsigned sp_builds_delta;         // (a slab step's spatial-hash builds alternate the slab box)
-};
-
 struct navhip_tick {
     navhip_ctx      *ctx;
     navhip_tick_desc d;
@@ -55,14 +36,16 @@ struct navhip_tick {
     uint8_t         *pool[2];
     std::vector<int32_t> bounds;
     hipStream_t      s, f, comm;      // agent chain | field builds ahead | exchange
-    hipEvent_t       ev_fields[2], ev_step, ev_comm, ev_side, ev_tmp;
-    bool             ahead, pipelined, comm_pending, computed, serial, split_mid;
+    hipEvent_t       ev_fields[2], ev_step, ev_comm, ev_tmp;
+    bool             ahead, pipelined, comm_pending, computed, serial;
     int64_t          ticks;
-    int              regroup_age;
-    bool             graph;
-    int              graphs_captured;
-    std::map<uint32_t, nh_graph_entry> execs;
     double           enqueue_ms;
+    // NAVHIP_TICK_TIME_FIELDS: event pairs on the field stream around the builds of every fourth tick
+    bool             time_fields;
+    hipEvent_t       ft[8][2];
+    bool             ft_used[8];
+    int              ft_next;
+    double           fields_ms_sum; int fields_samples;
 };
 
 static double now_ms()
@@ -88,6 +71,31 @@ static int build_fields(navhip_tick *T, uint8_t *pool, hipStream_t st)
     if(T->d.n_reqs <= 0) return NAVHIP_OK;
     return navhip_build_fields_dev(T->ctx, T->d.dev_reqs, T->d.n_reqs, pool + (size_t)T->d.req_slot0 * NAVHIP_FIELD_CELLS,
                                    nullptr, (void*)st);
+}
+
+// pairs whose second event has completed are read and freed (no waiting)
+static void harvest_field_times(navhip_tick *T, bool wait)
+{
+    for(int k = 0; k < 8; k++) {
+        if(!T->ft_used[k]) continue;
+        if(wait ? hipEventSynchronize(T->ft[k][1]) != hipSuccess : hipEventQuery(T->ft[k][1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        float ms = 0.0f;
+        if(hipEventElapsedTime(&ms, T->ft[k][0], T->ft[k][1]) == hipSuccess) { T->fields_ms_sum += ms; T->fields_samples++; }
+        T->ft_used[k] = false;
+    }
+}
+
+static int build_fields_timed(navhip_tick *T, uint8_t *pool, hipStream_t st)
+{
+    int slot = -1;
+    if(T->time_fields && (T->ticks & 3) == 0 && T->d.n_reqs > 0) {
+        harvest_field_times(T, false);
+        for(int k = 0; k < 8 && slot < 0; k++) if(!T->ft_used[(T->ft_next + k) & 7]) slot = (T->ft_next + k) & 7;
+    }
+    if(slot >= 0) HIPCHK(T->ctx, hipEventRecord(T->ft[slot][0], st));
+    int rc = build_fields(T, pool, st);
+    if(slot >= 0 && !rc) { HIPCHK(T->ctx, hipEventRecord(T->ft[slot][1], st)); T->ft_used[slot] = true; T->ft_next = (slot + 1) & 7; }
+    return rc;
 }
 
 // ---- one tick, plain launches: tick.py's compute() / _compute_pipelined(), call for call ---------------------------
@@ -120,21 +128,14 @@ static int compute_plain(navhip_tick *T)
             HIPCHK(ctx, hipEventRecord(T->ev_tmp, T->s));
             HIPCHK(ctx, hipStreamWaitEvent(T->f, T->ev_tmp, 0));
         }
-        if(!T->pipelined) {
-            // (NAVHIP_TICK_SPLIT_MID: this tick's fields were built during the last one -- with them final, the front of
-            // the step also runs the sampling half of the per-agent chain, NAVHIP_PREFETCH_FIELDS_READY; otherwise the
-            // front does not wait for them, only the step does, below)
-            if(T->split_mid) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));
-            RCCHK(navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE | NAVHIP_PREFETCH_SNAPSHOT_HELD
-                                                                     | (T->split_mid ? NAVHIP_PREFETCH_FIELDS_READY : 0u)));
-        }
+        if(!T->pipelined)
+            RCCHK(navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE | NAVHIP_PREFETCH_SNAPSHOT_HELD));
         // the fields of the NEXT tick
         if(stage == NAVHIP_STAGE_NEIGHBOURS) RCCHK(navhip_stream_wait_stage(ctx, (void*)T->f, NAVHIP_STAGE_NEIGHBOURS));
         else if(!T->pipelined)               RCCHK(navhip_stream_wait_stage(ctx, (void*)T->f, NAVHIP_STAGE_START));
-        RCCHK(build_fields(T, T->pool[p ^ 1], T->f));
+        RCCHK(build_fields_timed(T, T->pool[p ^ 1], T->f));
         HIPCHK(ctx, hipEventRecord(T->ev_fields[p ^ 1], T->f));
-        if(T->pipelined || !T->split_mid)
-            HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));   // this tick's fields (built during the last one)
+        HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));       // this tick's fields (built during the last one)
     }else{
         if(!T->pipelined) RCCHK(navhip_agent_prefetch_dev(ctx, w, (void*)T->s));
         if(T->d.dev_moves) {
@@ -150,110 +151,11 @@ static int compute_plain(navhip_tick *T)
     return NAVHIP_OK;
 }
 
-#if NH_TICK_GRAPHS
-// ---- one tick as a graph: captured once per combination of the host-side parities its launches depend on -----------
-static int compute_graph(navhip_tick *T)
-{
-    navhip_ctx *ctx = T->ctx;
-    const int p = (int)(T->ticks & 1);
-    const navhip_world *w = &T->W[p];
-    // the regrouping cadence of navhip_api.hip's coh_regroup_due, decided HERE (the decision is part of the graph's key)
-    int32_t lists[6];
-    const bool jam = navhip_step_lists_peek(ctx, lists) == NAVHIP_OK && lists[4] >= 8192;
-    const int age = T->regroup_age++;
-    const bool regroup = jam || age < 2 || age % 8 == 0;
-    const int stage = T->ahead ? fields_stage_now(T) : NAVHIP_STAGE_START;
-    const uint32_t key = (uint32_t)p | (uint32_t)(ctx->wl_parity & 1) << 1 | (uint32_t)(ctx->coh_parity & 1) << 2
-                       | (uint32_t)regroup << 3 | (uint32_t)(stage == NAVHIP_STAGE_START) << 4
-                       | (uint32_t)(ctx->gen_launches & 1u) << 5 | (uint32_t)(ctx->sp_builds & 1u) << 6;
-    auto it = T->execs.find(key);
-    if(it == T->execs.end()) {
-        hipGraph_t g = nullptr;
-        const unsigned gen_before = ctx->gen_launches, sp_before = ctx->sp_builds;
-        HIPCHK(ctx, hipStreamBeginCapture(T->s, hipStreamCaptureModeRelaxed));
-        ctx->regroup_override = regroup ? 1 : 2;
-        int rc = NAVHIP_OK;
-        if(T->serial) {
-            rc = build_fields(T, T->pool[0], T->s);
-            ctx->serial_step = true;
-            if(!rc) rc = navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s);
-            ctx->serial_step = false;
-        }else{
-            rc = navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE
-                                              | ((T->ahead && T->split_mid) ? NAVHIP_PREFETCH_FIELDS_READY : 0u));
-            if(!rc && T->ahead) {
-                rc = navhip_stream_wait_stage(ctx, (void*)T->f, stage);
-                if(!rc) rc = build_fields(T, T->pool[p ^ 1], T->f);
-                if(!rc && hipEventRecord(T->ev_fields[0], T->f) != hipSuccess) rc = NAVHIP_ERR_DEVICE;
-            }else if(!rc) {
-                rc = build_fields(T, T->pool[0], T->s);
-            }
-            if(!rc) rc = navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s);
-            // every stream the capture forked into comes back to the origin: the copy of the list counters on the
-            // library's side stream, the field builds
-            if(!rc && ctx->aux[0]
-            && (hipEventRecord(T->ev_side, ctx->aux[0]) != hipSuccess || hipStreamWaitEvent(T->s, T->ev_side, 0) != hipSuccess))
-                rc = NAVHIP_ERR_DEVICE;
-            if(!rc && T->ahead && hipStreamWaitEvent(T->s, T->ev_fields[0], 0) != hipSuccess) rc = NAVHIP_ERR_DEVICE;
-        }
-        ctx->regroup_override = 0;
-        hipError_t e = hipStreamEndCapture(T->s, &g);
-        if(rc || e != hipSuccess || !g) {
-            if(g) hipGraphDestroy(g);
-            if(!rc) ctx->last_error = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
-            (void)hipGetLastError();
-            return rc ? rc : NAVHIP_ERR_DEVICE;
-        }
-        nh_graph_entry ent;
-        e = hipGraphInstantiate(&ent.exec, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if(e != hipSuccess) {
-            ctx->last_error = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
-            return NAVHIP_ERR_DEVICE;
-        }
-        ent.wl_parity_after = ctx->wl_parity; ent.coh_parity_after = ctx->coh_parity;
-        ent.gen_launches_delta = ctx->gen_launches - gen_before;
-        ent.sp_builds_delta = ctx->sp_builds - sp_before;
-        it = T->execs.emplace(key, ent).first;
-        T->graphs_captured++;
-    }else{
-        // what the captured calls did to the library's host-side state
-        ctx->wl_parity = it->second.wl_parity_after; ctx->coh_parity = it->second.coh_parity_after;
-        ctx->gen_launches += it->second.gen_launches_delta;
-        ctx->sp_builds += it->second.sp_builds_delta;
-        ctx->counters.step_calls++; ctx->counters.agent_steps += (uint64_t)(w->work_end - w->work_begin);
-        if(T->d.n_reqs > 0) { ctx->counters.field_calls++; ctx->counters.chunk_fields += (uint64_t)T->d.n_reqs; }
-    }
-    ctx->pre.valid = false; ctx->regroup_pending = false;
-    HIPCHK(ctx, hipGraphLaunch(it->second.exec, T->s));
-    return NAVHIP_OK;
-}
-#endif
-
 static int tick_compute(navhip_tick *T)
 {
     navhip_ctx *ctx = T->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if(T->computed) { ctx->last_error = "navhip_tick_compute: the previous tick has not been advanced"; return NAVHIP_ERR_INVALID; }
-#if NH_TICK_GRAPHS
-    // (the first ticks run plain: allocations, side streams, derived planes -- nothing of that may happen in a capture)
-    if(T->graph && T->ticks >= 2) {
-        int rc = compute_graph(T);
-        if(rc == NAVHIP_OK) { T->computed = true; return rc; }
-        // a capture that failed: this runtime cannot replay the tick -- plain launches from here on
-        T->graph = false;
-        for(auto &kv : T->execs) hipGraphExecDestroy(kv.second.exec);
-        T->execs.clear();
-        hipStreamCaptureStatus st;
-        if(hipStreamIsCapturing(T->s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
-            hipGraph_t g = nullptr; hipStreamEndCapture(T->s, &g); if(g) hipGraphDestroy(g);
-        }
-        (void)hipGetLastError();
-        ctx->regroup_override = 0;
-        HIPCHK(ctx, hipDeviceSynchronize());
-        ctx->pre.valid = false; ctx->regroup_pending = false;
-    }
-#endif
     int rc = compute_plain(T);
     if(rc == NAVHIP_OK) T->computed = true;
     return rc;
@@ -292,8 +194,8 @@ int navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tic
     if(!T) return NAVHIP_ERR_NOMEM;
     T->ctx = ctx; T->d = *desc;
     T->serial = (desc->flags & NAVHIP_TICK_SERIAL) != 0;
+    T->time_fields = (desc->flags & NAVHIP_TICK_TIME_FIELDS) != 0;
     T->ahead = desc->field_pool_1 != nullptr && !T->serial;
-    T->split_mid = (desc->flags & NAVHIP_TICK_SPLIT_MID) != 0;
     T->pipelined = desc->bounds != nullptr;
     if(T->pipelined) {
         const int world = navhip_comm_world(ctx);
@@ -328,12 +230,10 @@ int navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tic
     if(!T->comm && T->pipelined) T->comm = own[NH_STREAM_COMM];
     // (the step's side streams are chosen for THIS stream, whatever stream a prefetch runs on)
     if(nh_prepare_step_streams(ctx, T->s) != NAVHIP_OK) { navhip_tick_destroy(T); return NAVHIP_ERR_DEVICE; }
-    hipEvent_t *evs[] = {&T->ev_fields[0], &T->ev_fields[1], &T->ev_step, &T->ev_comm, &T->ev_side, &T->ev_tmp};
+    hipEvent_t *evs[] = {&T->ev_fields[0], &T->ev_fields[1], &T->ev_step, &T->ev_comm, &T->ev_tmp};
     for(hipEvent_t *e : evs) if(hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail("navhip_tick_create: event");
-    // (a slab step without a static_epoch carries a never-repeating membership key: nothing to replay)
-    const bool whole = (w.work_begin == 0 && w.work_end == 0) || (w.work_begin == 0 && w.work_end == w.n_ents);
-    T->graph = NH_TICK_GRAPHS && (desc->flags & NAVHIP_TICK_GRAPH) && !T->pipelined && !desc->dev_moves
-            && (whole || w.static_epoch != 0);
+    if(T->time_fields)
+        for(auto &pair : T->ft) for(auto &e : pair) if(hipEventCreate(&e) != hipSuccess) return fail("navhip_tick_create: event");
     if(T->ahead) {
         // the fields tick 0 samples: start-up, on the agent stream
         int rc = build_fields(T, T->pool[0], T->s);
@@ -389,7 +289,9 @@ int navhip_tick_sync(navhip_tick *T)
 int navhip_tick_get_info(const navhip_tick *T, navhip_tick_info *out)
 {
     if(!T || !out) return NAVHIP_ERR_INVALID;
-    out->ticks = T->ticks; out->graph = T->graph ? 1 : 0; out->graphs_captured = T->graphs_captured;
+    out->ticks = T->ticks;
+    harvest_field_times(const_cast<navhip_tick*>(T), false);
+    out->fields_ms = T->fields_samples ? T->fields_ms_sum / T->fields_samples : 0.0; out->fields_samples = T->fields_samples; out->_pad = 0;
     out->host_enqueue_ms = T->enqueue_ms;
     out->stream = (void*)T->s; out->field_stream = (void*)T->f; out->comm_stream = (void*)T->comm;
     return NAVHIP_OK;
@@ -403,11 +305,9 @@ void navhip_tick_destroy(navhip_tick *T)
     if(T->f) hipStreamSynchronize(T->f);
     if(T->s) hipStreamSynchronize(T->s);
     navhip_sync(T->ctx);
-#if NH_TICK_GRAPHS
-    for(auto &kv : T->execs) hipGraphExecDestroy(kv.second.exec);
-#endif
-    hipEvent_t evs[] = {T->ev_fields[0], T->ev_fields[1], T->ev_step, T->ev_comm, T->ev_side, T->ev_tmp};
+    hipEvent_t evs[] = {T->ev_fields[0], T->ev_fields[1], T->ev_step, T->ev_comm, T->ev_tmp};
     for(hipEvent_t e : evs) if(e) hipEventDestroy(e);
+    for(auto &pair : T->ft) for(auto &e : pair) if(e) hipEventDestroy(e);
     delete T;
 }
 

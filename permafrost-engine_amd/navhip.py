@@ -1098,7 +1098,7 @@ NavContext.G_ClearPath_NewVelocity = _ctx_clearpath
 # ---------------------------------------------------------------------------------------------
 # the whole tick behind one call (navhip_tick_*, csrc/tick_api.hip)
 # ---------------------------------------------------------------------------------------------
-TICK_GRAPH, TICK_SERIAL, TICK_SPLIT_MID = 0x1, 0x2, 0x4
+TICK_SERIAL, TICK_TIME_FIELDS = 0x2, 0x8
 
 
 class TickDesc(C.Structure):
@@ -1113,9 +1113,9 @@ class TickDesc(C.Structure):
 
 class TickInfo(C.Structure):
     """navhip_tick_info, include/navhip.h"""
-    _fields_ = [("ticks", C.c_int64), ("graph", C.c_int32), ("graphs_captured", C.c_int32),
+    _fields_ = [("ticks", C.c_int64),
                 ("host_enqueue_ms", C.c_double), ("stream", C.c_void_p), ("field_stream", C.c_void_p),
-                ("comm_stream", C.c_void_p)]
+                ("comm_stream", C.c_void_p), ("fields_ms", C.c_double), ("fields_samples", C.c_int32), ("_pad", C.c_int32)]
 
 
 _SIGS.update({

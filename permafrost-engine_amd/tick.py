@@ -105,8 +105,8 @@ class NavTick:
                  device=0, hz=20, seed_map=1234, verbose=False, obstacles=0, move_frac=0.01,
                  obstacle_ticks=128, tile_exchange="auto", solo=False, shared_map=False, crowd_cells=0,
                  debug_outputs=False, pipeline_fields=False, exchange="torch", planner_requests=True,
-                 straddle=0.0, los=False, flow_velocities=False, share_fields=False, driver="c", graph=None, serial=None,
-                 split_mid=False):
+                 straddle=0.0, los=False, flow_velocities=False, share_fields=False, driver="c", serial=None,
+                 time_fields=False):
         self.rank, self.world, self.device_index = rank, world, device
         self.dev = torch.device("cpu") if EMULATED else torch.device("cuda", device)
         tcuda.set_device(self.dev)
@@ -196,20 +196,6 @@ class NavTick:
                                 for k, v in a.items()})
             ag_parts = swapped
         ag = {k: (np.concatenate([a[k] for a in ag_parts]) if k != "hz" else hz) for k in ag_parts[0]}
-        # NAVTICK_UID_ORDER (an experiment, not a schedule): number the entities in spatial order -- "cell" = by the 16-wu
-        # cell of the spatial index, "flock_cell" = flock by flock, by cell inside a flock -- so that the uid-order kernels
-        # ARE cell-order kernels with every per-entity array still contiguous: the upper bound of what stepping agents in
-        # pool order could save (profiles/r05_ab_uid_order.txt)
-        uid_order = os.environ.get("NAVTICK_UID_ORDER", "")
-        if uid_order and world == 1:
-            cx = np.floor((ag["pos"][:, 0] + Wt * 128.0) / 16.0).astype(np.int64)
-            cz = np.floor((ag["pos"][:, 1] + H * 128.0) / 16.0).astype(np.int64)
-            key = cz * 4096 + cx
-            if uid_order == "flock_cell":
-                key = ag["flock"].astype(np.int64) * (1 << 32) + key
-            perm = np.argsort(key, kind="stable")
-            ag = {k: (v[perm] if k != "hz" else v) for k, v in ag.items()}
-
         # ---- request stream: region-major, destination-major inside a region -------------------
         # tile_exchange: "auto" = only the fields some other rank samples travel (none when flocks
         # are rank aligned, the default world; `straddle` makes some); "all" = every rank holds every
@@ -428,31 +414,20 @@ class NavTick:
             self._flow_aligned_velocities()
         if not hasattr(self, "velocity_source"):
             self.velocity_source = "N(0, 0.35) per component (synth.agents)"
-        # driver: who enqueues a tick.  "c" = the library's own loop (navhip_tick_*, csrc/tick_api.hip: ONE call per
-        # tick, the schedule below in C; with graph=True each tick is one hipGraphLaunch of the tick captured per
-        # parity) -- for every world whose baked tiles do not travel; "python" = this file's compute() / exchange()
-        # / advance(), the reference implementation of that schedule, which the C loop is tested against.
-        # serial (C driver only): the whole tick on ONE stream, no side streams and no events.  graph: replay the tick as
-        # a captured HIP graph.  Both measured on the MI355X (profiles/r05_host_overhead_c.txt, ms per tick total |
-        # host enqueue):              python        c             c one stream   c graph        c one stream + graph
-        #   configs[2]               0.341|0.135   0.342|0.093   0.455|0.048    0.448|0.110    0.459|0.015
-        #   configs[0]               0.165-0.385   0.138|0.100   0.146|0.049    0.231|0.115    0.146|0.015
-        #   1 rank of 8 (strong)     0.183-0.208   0.221|0.095   0.220|0.050    0.608|0.109    0.226|0.016
-        # The host side shrinks as intended (one hipGraphLaunch of the one-stream tick: 15 us), the TICK does not: a
-        # small world's tick is ~19 dependent kernels of 5-10 us each (0.14 ms at configs[0], 0.2 ms for a rank of 8), a
-        # big one loses the overlap of cohesion / ClearPath / field builds on one stream, and a multi-stream graph pays a
-        # barrier packet per cross-stream edge.  Both stay options (NAVTICK_SERIAL=1, NAVTICK_GRAPH=1), default off.
+        # driver: who enqueues a tick.  "c" = the library's own loop (navhip_tick_*, csrc/tick_api.hip: ONE call per tick,
+        # the schedule below in C) -- for every world whose baked tiles do not travel; "python" = this file's compute() /
+        # exchange() / advance(), the reference implementation of that schedule, which the C loop is tested against.
+        # serial (C driver only; NAVTICK_SERIAL=1): the whole tick on ONE stream, no side streams and no events -- the
+        # host side shrinks to 48 us per tick, the tick does not (0.455 against 0.342 ms at configs[2]: the overlap of
+        # cohesion / ClearPath / field builds is gone; profiles/r05_host_overhead_c.txt).  An option for a host that
+        # wants one stream, not a default.
         self.driver = driver if (self.tile_exchange == "none" or self.solo) else "python"
         if serial is None:
             serial = os.environ.get("NAVTICK_SERIAL") == "1"
         self.serial = bool(serial)
-        # split_mid (C driver): run the sampling half of the per-agent chain on the front of the step, in the shadow of
-        # the cohesion term, instead of one launch behind the join -- measured: no gain (0.340 against 0.337 ms per tick,
-        # profiles/r05_ab_split_mid_*.txt; both halves are latency bound); an option (NAVTICK_SPLIT_MID=1)
-        self.split_mid = bool(split_mid) or os.environ.get("NAVTICK_SPLIT_MID") == "1"
-        if graph is None:
-            graph = os.environ.get("NAVTICK_GRAPH") == "1"
-        self.graph = bool(graph)
+        # time_fields (C driver): HIP events on the FIELD stream around the builds of every fourth tick -- how long the
+        # builds take inside the tick, beside the agent step (navhip_tick_info.fields_ms; field_build_times())
+        self.time_fields = bool(time_fields)
         self._ctick = None
         self.tick_driver = "python (tick.py)"
         self.ev = []                   # (phase, start_event, end_event) of the timed steps
@@ -597,13 +572,18 @@ class NavTick:
             self._bounds_c = np.ascontiguousarray(self._bounds, np.int32)
             d.bounds = self._bounds_c.ctypes.data
             d.comm_stream = self.comm.cuda_stream
-        d.flags = (navhip.TICK_GRAPH if self.graph else 0) | (navhip.TICK_SERIAL if self.serial else 0) \
-            | (navhip.TICK_SPLIT_MID if self.split_mid else 0)
+        d.flags = (navhip.TICK_SERIAL if self.serial else 0) | (navhip.TICK_TIME_FIELDS if self.time_fields else 0)
         self._ctick = navhip.Tick(self.ctx, d, keep)
         self._ctick_tick0 = self.tick_no
-        info = self._ctick.info()
-        self.tick_driver = "c (navhip_tick_run%s%s)" % (", one stream" if self.serial else "", ", hip graph" if info.graph else "")
+        self.tick_driver = "c (navhip_tick_run%s)" % (", one stream" if self.serial else "")
         return self._ctick
+
+    def field_build_times(self):
+        """(sum of milliseconds, samples) of the field builds the C tick has timed so far (time_fields=True)."""
+        if self._ctick is None:
+            return 0.0, 0
+        info = self._ctick.info()
+        return info.fields_ms * info.fields_samples, int(info.fields_samples)
 
     def _c_tick_drop(self):
         if self._ctick is not None:

@@ -38,9 +38,7 @@ def run(names, rounds=3, extra=()):
     for _ in range(rounds):
         for n in names:
             env = dict(os.environ)
-            lib, _, order = n.partition("@")          # NAME@K: the variant with NAVHIP_CP_SCHED=K
-            if order:
-                env["NAVHIP_CP_SCHED"] = order
+            lib = n
             if lib != "base":
                 env["NAVHIP_LIB"] = os.path.join(OUT, "libnavhip_%s.so" % lib)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(extra), env=env,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One A/B session on the GPU box (gpurun): variants of libnavhip.so built beforehand with scripts/ab_lib.py --build /
-# --build-rev (build_prof/libnavhip_NAME.so; `base` = the in-tree library; NAME@K = with NAVHIP_CP_SCHED=K), alternated
+# --build-rev (build_prof/libnavhip_NAME.so; `base` = the in-tree library), alternated
 # inside ONE session because box-to-box noise (~3 %) is more than most single changes.
 #
 #   bash scripts/gpu_ab.sh <tag> [steps...] -- <variants...>
@@ -27,7 +27,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-pick() { if [ "$1" != base ]; then export NAVHIP_LIB=$GRAFT_REPO_ROOT/build_prof/libnavhip_${1%@*}.so; else unset NAVHIP_LIB; fi; }
+pick() { if [ "$1" != base ]; then export NAVHIP_LIB=$GRAFT_REPO_ROOT/build_prof/libnavhip_${1}.so; else unset NAVHIP_LIB; fi; }
 for s in "${STEPS[@]}"; do
 case $s in
 vparity) for v in $VARS; do pick $v

@@ -18,7 +18,7 @@ from permafrost_engine_amd import tick    # noqa: E402
 def main():
     strong = "--strong" in sys.argv
     drv = dict(driver="python") if "--python-driver" in sys.argv else \
-        dict(driver="c", graph="--graph" in sys.argv, serial=False if "--no-serial" in sys.argv else None)
+        dict(driver="c", serial=False if "--no-serial" in sys.argv else None)
     base = None
     for world in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 8]:
         t0 = time.time()

@@ -55,14 +55,8 @@ DESELECT = ["test_prefetch_overlap_gives_identical_results", "test_shared_chunk_
 # without the strict pointer check below
 NOT_STRICT = ["tests/test_comm_gpu.py", "tests/test_tick_gpu.py"]
 # (the tick tests that take a minute and more each on the emulator)
-DESELECT_TICK = ["test_c_tick_equals_the_python_schedule[crowded]", "test_graph_replay_equals_plain_launches[fields_ahead]",
-                 "test_graph_replay_equals_plain_launches[fields_in_front]", "test_drivers_can_take_turns",
-                 "test_c_tick_equals_the_python_schedule[fields_in_front]", "test_sampling_half_on_the_front_equals_the_fused_chain",
-                 "test_graph_replay_equals_plain_launches[streams-slab]", "test_graph_replay_equals_plain_launches[one_stream-slab]",
-                 "test_graph_replay_equals_plain_launches[one_stream-fields_ahead]",
-                 "test_graph_replay_equals_plain_launches[one_stream-fields_in_front]",
-                 "test_graph_replay_equals_plain_launches[streams-fields_ahead]",
-                 "test_graph_replay_equals_plain_launches[streams-fields_in_front]",
+DESELECT_TICK = ["test_c_tick_equals_the_python_schedule[crowded]", "test_drivers_can_take_turns",
+                 "test_c_tick_equals_the_python_schedule[fields_in_front]",
                  # (a measurement of the hardware's queues: nothing for an emulator, and ten configs[2]-sized worlds)
                  "test_tick_time_does_not_depend_on_what_the_process_created_before"]
 

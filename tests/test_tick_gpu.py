@@ -1,9 +1,8 @@
 """The whole tick behind one call (navhip_tick_*, csrc/tick_api.hip) against the schedule it was written from.
 
 tick.py's compute() / exchange() / advance() is the reference implementation of the tick's schedule: one library call
-per stage, measured into its shape over three rounds.  navhip_tick_run enqueues the same calls from C -- or, with
-NAVHIP_TICK_GRAPH, replays the tick as a captured HIP graph -- and must leave every buffer bit-identical: positions,
-velocities, status bytes, the baked field pool.  (The reference's own loop: navigation_tick_task, movement.c:4263.)"""
+per stage, measured into its shape over three rounds.  navhip_tick_run enqueues the same calls from C and must leave
+every buffer bit-identical: positions, velocities, status bytes, the baked field pool.  (The reference's own loop: navigation_tick_task, movement.c:4263.)"""
 import numpy as np
 import pytest
 
@@ -17,11 +16,11 @@ def _torch():
     return torch
 
 
-def _run(driver, ticks=5, graph=False, switch_at=None, serial=False, split_mid=False, **extra):
+def _run(driver, ticks=5, switch_at=None, serial=False, **extra):
     from permafrost_engine_amd import tick
     kw = dict(KW)
     kw.update(extra)
-    T = tick.NavTick(driver=driver, graph=graph, serial=serial, split_mid=split_mid, **kw)
+    T = tick.NavTick(driver=driver, serial=serial, **kw)
     if kw.get("world", 1) > 1:
         T.pipelined, T._comm_pending = False, False        # (one rank of a job, no process group: compute only)
     for i in range(ticks):
@@ -69,19 +68,6 @@ def test_one_stream_tick_equals_the_python_schedule(navlib, extra):
         assert np.array_equal(py[k].view(np.uint8), c[k].view(np.uint8)), k
 
 
-def test_sampling_half_on_the_front_equals_the_fused_chain(navlib):
-    """With the fields of a tick final before the tick starts (built during the last one), the C tick runs the sampling
-    half of the per-agent chain -- flow taps, line of sight, arrive force, tile probes -- on the front of the step, in the
-    shadow of the cohesion term (NAVHIP_PREFETCH_FIELDS_READY, k_agent_mid_a / _b), and joins it behind the cohesion
-    term (NAVHIP_TICK_SPLIT_MID).  The same numbers as the one fused launch, with the line-of-sight lookup live and in a
-    crowd (work lists of every size)."""
-    for extra in (dict(pipeline_fields=True), dict(pipeline_fields=True, crowd_cells=6)):
-        split = _run("c", ticks=6, split_mid=True, **extra)
-        fused = _run("c", ticks=6, **extra)
-        _same(split, fused)
-        _same(split, _run("python", ticks=6, **extra))
-
-
 def test_drivers_can_take_turns(navlib):
     """bench.py profiles a few ticks on the Python path in the middle of a run of C ticks: the hand-over in both
     directions leaves the world on the same trajectory."""
@@ -98,26 +84,6 @@ def test_c_tick_of_one_rank_of_a_split_world(navlib):
     extra = dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
                  flow_velocities=False)
     _same(_run("python", **extra), _run("c", **extra))
-
-
-@pytest.mark.parametrize("extra", [dict(pipeline_fields=True), dict(pipeline_fields=False),
-                                   dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
-                                        flow_velocities=False)],
-                         ids=["fields_ahead", "fields_in_front", "slab"])
-@pytest.mark.parametrize("serial", [False, True], ids=["streams", "one_stream"])
-def test_graph_replay_equals_plain_launches(navlib, extra, serial):
-    """NAVHIP_TICK_GRAPH: 12 ticks -- two plain, then one capture per combination of the host-side parities, then
-    replays (the regrouping cadence makes at least three combinations) -- against the Python schedule."""
-    import os
-    py = _run("python", ticks=12, **extra)
-    g = _run("c", ticks=12, graph=True, serial=serial, **extra)
-    for k in ("pos", "vel", "status") + (() if serial else ("pool",)):
-        assert np.array_equal(py[k].view(np.uint8), g[k].view(np.uint8)), k
-    if os.path.basename(os.environ.get("NAVHIP_LIB", "")) == "_navhip_emu.so":
-        assert g["info"].graph == 0                    # (the emulated runtime has no graphs: plain launches)
-    else:
-        assert g["info"].graph == 1 and 2 <= g["info"].graphs_captured <= 10, (g["info"].graph, g["info"].graphs_captured)
-        assert "hip graph" in g["driver"]
 
 
 def test_tick_rejects_malformed_descriptions(navlib):
