@@ -565,18 +565,20 @@ def main():
     except Exception:
         pass
 
+    late_window = T_ticks_done >= 60
+
     def valu(prefixes, measured_ms):
         ks = [k for k in sq if k.startswith(prefixes)]
         if not ks or measured_ms <= 0 or cyc is None:
             return None
         # (the counters were taken on a 100-tick run: per kernel the last dispatches -- the crowded world
         # -- and dispatches 6-11; a short run is priced with the early ones)
-        key = "SQ_INSTS_VALU" if T_ticks_done >= 60 else "SQ_INSTS_VALU_early_ticks"
+        key = "SQ_INSTS_VALU" if late_window else "SQ_INSTS_VALU_early_ticks"
         insts = sum((sq[k].get(key) or sq[k]["SQ_INSTS_VALU"]) for k in ks)
         floor_ms = insts / 1024 * cyc / 2.4e9 * 1e3
         return {"valu_insts_per_launch": insts, "issue_floor_ms": floor_ms, "cycles_per_inst": cyc,
                 "frac_of_issue_peak": floor_ms / measured_ms,
-                "counters_of": "ticks 100-110" if key == "SQ_INSTS_VALU" else "ticks 6-11"}
+                "counters_of": "ticks 100-110" if key == "SQ_INSTS_VALU" else "ticks 27-32"}
 
     def roof(which, g=None, when=None, in_tick_ms=None):
         """SURVEY.md section 8(d)'s convention -- algorithmic bytes per launch / the launch's duration / 8 TB/s -- for the
@@ -590,7 +592,9 @@ def main():
         alone, by = (a_ms_, a_bytes) if which == "agents" else (g["fields"], f_bytes)
         ms = in_tick_ms if in_tick_ms else alone
         gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = None if stale else measured.get(which + "_bytes_per_launch")
+        # (counters and durations of one line from the same window of the world: the profiled ticks behind a short run
+        # are ticks 27-32, behind a 100-tick run ticks 106-111 -- traffic.json holds both)
+        traffic = None if stale else measured.get(which + ("_bytes_per_launch" if late_window else "_bytes_per_launch_early"))
         out = {
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": traffic,

@@ -150,7 +150,8 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(auto &b : ctx->arrived) hipFree(b.p);
     for(auto &b : ctx->wl) hipFree(b.p);
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
-    for(auto &a : ctx->aux) if(a) hipStreamSynchronize(a);       // (borrowed: the process's, nh_device_stream)
+    if(nh_streams_alive(ctx->device))
+        for(auto &a : ctx->aux) if(a) hipStreamSynchronize(a);   // (borrowed: the process's own set, csrc/stream_set.hip)
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
     if(ctx->ev_regroup) hipEventDestroy(ctx->ev_regroup);

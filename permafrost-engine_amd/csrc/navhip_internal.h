@@ -106,6 +106,7 @@ enum { NH_STREAM_SIDE0 = 0,     // the ClearPath side chain of the agent step
        NH_STREAM_FIXED };
 int         nh_streams_for(navhip_ctx *ctx, hipStream_t main, hipStream_t out[NH_STREAM_FIXED]);
 hipStream_t nh_stream_partial_for(navhip_ctx *ctx, hipStream_t main, int cu_begin, int cu_count);   // nullptr: ctx->last_error says why
+bool        nh_streams_alive(int device);
 int         nh_prepare_step_streams(navhip_ctx *ctx, hipStream_t main);      // the side streams of steps whose main chain runs on `main`
 
 // pool_api.hip <-> navhip_api.hip

@@ -131,11 +131,31 @@ int pipe_among_full(nh_dev_streams &D, hipStream_t s)
     return best;
 }
 
+// At process exit the set is destroyed while the HIP runtime is still up: an atexit handler registered at the set's first
+// use runs before the runtime's own (registered earlier, at its initialisation).  Left alive, the streams crashed
+// rocprofv3's finalisation (a core dump behind every profiled run: profiles/r06_pytest_gpu_l.log's session).
+void streams_atexit()
+{
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    for(auto &kv : g_streams) {
+        nh_dev_streams &D = kv.second;
+        if(hipSetDevice(kv.first) != hipSuccess) continue;
+        for(auto &st : D.full) if(st) { hipStreamSynchronize(st); hipStreamDestroy(st); st = nullptr; }
+        for(auto &pk : D.partial) for(auto &st : pk.second) if(st) { hipStreamSynchronize(st); hipStreamDestroy(st); st = nullptr; }
+        if(D.ea) hipEventDestroy(D.ea);
+        if(D.eb) hipEventDestroy(D.eb);
+        D.ea = D.eb = nullptr; D.ready = false;
+        D.caller_pipe.clear(); D.partial.clear();
+    }
+}
+
 // four masked streams on four different pipes.  Consecutive creations land on consecutive pipes; that is verified, and a
 // candidate that shares a pipe with an earlier pick is replaced (at most eight tries: then it stays, results are the same)
 bool streams_init(navhip_ctx *ctx, nh_dev_streams &D)
 {
     if(D.ready) return true;
+    static const bool registered = (atexit(streams_atexit), true);
+    (void)registered;
     if(hipEventCreateWithFlags(&D.ea, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.eb, hipEventDisableTiming) != hipSuccess) {
         ctx->last_error = "hipEventCreate failed";
         return false;
@@ -172,6 +192,14 @@ int pipe_of(navhip_ctx *ctx, nh_dev_streams &D, hipStream_t s)
     return found;
 }
 }  // namespace
+
+// false once the process is exiting and the set is gone (a context destroyed that late must not touch its borrowed streams)
+bool nh_streams_alive(int device)
+{
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    auto it = g_streams.find(device);
+    return it != g_streams.end() && it->second.ready;
+}
 
 // The streams of a step whose main chain runs on `main` (the caller's stream, or nullptr: the set's own main stream is
 // returned in out[NH_STREAM_MAIN]): side0, side1, fields / comm on the other three pipes.

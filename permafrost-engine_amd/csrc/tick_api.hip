@@ -301,10 +301,12 @@ void navhip_tick_destroy(navhip_tick *T)
 {
     if(!T) return;
     hipSetDevice(T->ctx->device);
-    if(T->comm) hipStreamSynchronize(T->comm);
-    if(T->f) hipStreamSynchronize(T->f);
-    if(T->s) hipStreamSynchronize(T->s);
-    navhip_sync(T->ctx);
+    if(nh_streams_alive(T->ctx->device)) {       // (not while the process exits: the library's streams are gone by then)
+        if(T->comm) hipStreamSynchronize(T->comm);
+        if(T->f) hipStreamSynchronize(T->f);
+        if(T->s) hipStreamSynchronize(T->s);
+        navhip_sync(T->ctx);
+    }
     hipEvent_t evs[] = {T->ev_fields[0], T->ev_fields[1], T->ev_step, T->ev_comm, T->ev_tmp};
     for(hipEvent_t e : evs) if(e) hipEventDestroy(e);
     for(auto &pair : T->ft) for(auto &e : pair) if(e) hipEventDestroy(e);

@@ -30,7 +30,8 @@ def main():
     kw = dict(CONFIGS[cfg])
     out = []
     for r in range(reps):
-        T = tick.NavTick(pipeline_fields=True, los=False, flow_velocities=not kw.get("world"), driver=driver, **kw)
+        T = tick.NavTick(pipeline_fields=True, los=False, flow_velocities=not kw.get("world"), driver=driver,
+                         time_fields=os.environ.get("PROBE_TIME_FIELDS") == "1", **kw)
         if kw.get("world"):
             T.pipelined, T._comm_pending = False, False
             T.new_pos.copy_(T.t["pos_xz"]); T.new_vel.copy_(T.t["vel_xz"])
@@ -43,7 +44,8 @@ def main():
         T.sync()
         dt = (time.perf_counter() - t0) / n * 1e3
         out.append(dt)
-        print("config %-4s driver %s rep %d stream 0x%x: %.4f ms/tick" % (cfg, driver, r, T.stream.cuda_stream, dt), flush=True)
+        enq = T._ctick.info().host_enqueue_ms / max(1, T._ctick.info().ticks) if T._ctick is not None else float("nan")
+        print("config %-4s driver %s rep %d stream 0x%x: %.4f ms/tick (host enqueue %.4f)" % (cfg, driver, r, T.stream.cuda_stream, dt, enq), flush=True)
         T.close()
     print("config %-4s driver %s env[AUX_DEDICATED=%s MAX_HW_QUEUES=%s]: min %.4f max %.4f spread %.2fx" %
           (cfg, driver, os.environ.get("NAVHIP_AUX_DEDICATED", "-"), os.environ.get("GPU_MAX_HW_QUEUES", "-"),

@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench    # noqa: E402
 
+EARLY = (26, 32)  # the ticks bench.py profiles behind the DRIVER's invocation (--steps 20 --warmup 5): counters and
+                  # durations of one line come from the same window of the world
 LAST = 6        # ticks that count: the serial, profiled ticks at the END of bench.py (the
                 # ticks its roofline times) -- not the average over a run in which the world crowds
 
@@ -47,7 +49,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     sha = bench.csrc_sha()
-    pre = sys.argv[3] if len(sys.argv) > 3 else "r05_"
+    pre = sys.argv[3] if len(sys.argv) > 3 else "r06_"
 
     def copy(name, out):
         p = os.path.join(src, name)
@@ -100,14 +102,24 @@ def main():
             v = acc.get(k, {}).get(c, [])
             v = v[-LAST * m:]
             return sum(v) / len(v) * m * 1024.0 if v else 0.0
+
+        def early(acc, k, c):
+            """the same for the ticks EARLY of the run"""
+            m = per_tick(acc, k)
+            v = acc.get(k, {}).get(c, [])
+            v = v[EARLY[0] * m:EARLY[1] * m]
+            return sum(v) / len(v) * m * 1024.0 if v else 0.0
         fetch = {k: last(F, k, "FETCH_SIZE") for k in F}
         write = {k: last(Wr, k, "WRITE_SIZE") for k in Wr}
+        fetch_e = {k: early(F, k, "FETCH_SIZE") for k in F}
+        write_e = {k: early(Wr, k, "WRITE_SIZE") for k in Wr}
         bfs = [k for k in write if k.startswith("k_field_bfs")]
         known = 16384 * 4096.0
         wcal = known / write[bfs[0]] if bfs and write[bfs[0]] > 0 else None
         res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py "
                          "--steps 100 --warmup 5; per kernel and TICK the mean over the last %d ticks (the profiled ticks "
                          "at the end of the run, which bench.py's roofline times)" % LAST,
+               "early_window": "ticks %d-%d" % (EARLY[0] + 1, EARLY[1]),
                "files": bench.csrc_files(),
                "corrections": "both counters are KB (x1024); gfx950 FETCH_SIZE counts 128-B requests at 64 B: x2 "
                               "('corr'); WRITE_SIZE calibrated on k_field_bfs, which writes exactly 4096 B per field "
@@ -123,6 +135,8 @@ def main():
             res[name + "_fetch_bytes_corr"] = 2.0 * f_raw
             res[name + "_write_bytes_corr"] = w_raw * (wcal or 1.0)
             res[name + "_bytes_per_launch"] = 2.0 * f_raw + w_raw * (wcal or 1.0)
+            res[name + "_bytes_per_launch_early"] = 2.0 * sum(v for k, v in fetch_e.items() if k.startswith(pfx)) \
+                + (wcal or 1.0) * sum(v for k, v in write_e.items() if k.startswith(pfx))
         res["covers"] = bench.stamp_units(res["files"], bench.stamp_kernels(res))
         res["csrc_sha"], res["csrc_sha_all_files"] = bench.csrc_sha(files=res["covers"]), sha
         json.dump(res, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
@@ -141,12 +155,12 @@ def main():
             dd = {cn: sum(x[-LAST * m:]) / len(x[-LAST * m:]) * m for cn, x in v.items()}
             dd["launches_per_tick"] = m
             dd["valu_per_wave"] = dd.get("SQ_INSTS_VALU", 0) / max(dd.get("SQ_WAVES", 1), 1)
-            early = {cn: sum(x[5 * m:(5 + LAST) * m]) / max(1, len(x[5 * m:(5 + LAST) * m])) * m for cn, x in v.items()}
+            early = {cn: sum(x[EARLY[0] * m:EARLY[1] * m]) / max(1, len(x[EARLY[0] * m:EARLY[1] * m])) * m for cn, x in v.items()}
             dd["SQ_INSTS_VALU_early_ticks"] = early.get("SQ_INSTS_VALU")
             out[k] = dd
         doc = {"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES on "
                          "bench.py --steps 100 --warmup 5; per kernel and TICK (a kernel launched twice a tick counts "
-                         "twice): the mean over the last %d ticks (early ticks: 6-11)" % LAST, "files": bench.csrc_files(), "kernels": out}
+                         "twice): the mean over the last %d ticks (early ticks: %d-%d)" % (LAST, EARLY[0] + 1, EARLY[1]), "files": bench.csrc_files(), "kernels": out}
         doc["covers"] = bench.stamp_units(doc["files"], bench.stamp_kernels(doc))
         doc["csrc_sha"], doc["csrc_sha_all_files"] = bench.csrc_sha(files=doc["covers"]), sha
         json.dump(doc, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)
