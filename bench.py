@@ -543,7 +543,7 @@ def main():
     except Exception:
         pass
     calib_file = None
-    for name in ("r03_valu_calib.json", "r02_valu_calib.json"):      # (a hardware constant: the newest run kept)
+    for name in ("archive/r03_valu_calib.json", "archive/r02_valu_calib.json"):      # (a hardware constant: the newest run kept)
         try:
             calib = json.load(open(os.path.join(ROOT, "profiles", name)))
             calib_file = "profiles/" + name

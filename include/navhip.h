@@ -576,7 +576,7 @@ int  navhip_comm_allgather_rows_dev(navhip_ctx *ctx, void *dev_rows, size_t row_
  * is that loop for a device-resident world: every call of navhip_tick_run enqueues, per tick,
  *   - the chunk-field builds of this context's share of the requests (into the pool slot of each request; with a second
  *     pool the fields tick t+1 samples are built DURING tick t on a stream of their own, behind the narrow front of
- *     the step -- the schedule DESIGN.md section 3.7 measured),
+ *     the step -- the schedule DESIGN.md section 4 describes),
  *   - [dynamic obstacles] the tick's N_BlockersIncref/Decref batch in front of them (incremental repair),
  *   - the velocity step + position accept of the uid slab (navhip_agent_prefetch_dev + navhip_agent_step_dev),
  *   - [a communicator on the context] the slab exchange (navhip_comm_allgather_step_dev) on a stream of its own, which

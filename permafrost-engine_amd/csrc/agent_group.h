@@ -305,7 +305,7 @@ struct cp_lane { v2 pt; int idx; float len; int ci; };
 // In cp_work / cp_push every `if` on a lane's own state (has it a candidate? is it inside?) is a region the wave
 // enters with an exec mask -- two or three scalar instructions per region for bookkeeping, and a SIMD issues a
 // scalar instruction in a slot it could have given a vector one: the search ran 0.55 scalar instructions per
-// vector instruction and 3.6 cycles per instruction of either kind (profiles/r04_*).  Here a lane's state changes
+// vector instruction and 3.6 cycles per instruction of either kind (profiles/archive/r04_*).  Here a lane's state changes
 // through selects, the only branches are on wave-uniform values (ballots, queue counters), and the two rare
 // expansions (an undecided fast cone test, a candidate beating the bound) sit behind one ballot each.
 // Same decisions in the same order as cp_work: a lane without a candidate takes the next queued one, tests it

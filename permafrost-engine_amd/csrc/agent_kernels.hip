@@ -1012,7 +1012,7 @@ __device__ __forceinline__ void worklist_push(const nh_worklists &WL, int which,
 // ladder, vpref -- in uid order (every per-entity input / output is contiguous), ONE thread per entity.
 // The work is a chain of dependent loads and IEEE divide / sqrt sequences at 1.5 waves per SIMD; with the loads
 // requested ahead of the chain (mid_thread, sample_flow) one lane per entity beats two or four
-// (profiles/r03_ab_mid_lanes.txt).  Splitting it -- the sampling half beside the cohesion term, the rest behind the
+// (profiles/archive/r03_ab_mid_lanes.txt).  Splitting it -- the sampling half beside the cohesion term, the rest behind the
 // join (round 5), or the rest at the head of every ClearPath search (round 6) -- was measured twice and lost twice
 // (profiles/r05_ab_split_mid_*.txt, r06_ab_step_without_mid_rejected.txt): the launch is latency, and the chip is
 // not idle beside it.
@@ -1166,12 +1166,12 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
     // unit_end[k] = units of the sub-lists up to and including k (k = order * NH_WL_SUB + sub)
     __shared__ int32_t unit_end[4 * NH_WL_SUB];
     __shared__ int32_t sub_cnt[4 * NH_WL_SUB];
-    // HOLE INHERITANCE.  This launch reaches the device a few microseconds before k_cp_heavy (which waits
+    // HOLE INHERITANCE (profiles/HISTORY.md 3.7).  This launch reaches the device a few microseconds before k_cp_heavy (which waits
     // for an event of the other stream) and fills every SIMD; k_cp_heavy's persistent workgroups move into the
     // register and LDS ranges its workgroups leave behind and keep them for the whole launch.  A hole smaller than a
     // k_cp_heavy wave (128 registers) or workgroup is lost to it: 119 instead of 121 registers here (120 instead of
     // 128 allocated), or 37.5 KB of LDS there against 36 here, cost the crowded world a quarter of k_cp_heavy's
-    // waves (4.9 -> 6.1 ms per tick, profiles/r04_ab_hole_inheritance.txt).  So: this kernel allocates the same 128
+    // waves (4.9 -> 6.1 ms per tick, profiles/archive/r04_ab_hole_inheritance.txt).  So: this kernel allocates the same 128
     // registers per lane (v127 named as clobbered), and its workgroup owns at least k_cp_heavy's LDS.
     asm volatile("" ::: "v127");
     static_assert(sizeof(cp_lds<16>) * CPR_WAVES * 4 + 8 * 4 * NH_WL_SUB >= sizeof(cp_lds<64>) * CP_WAVES + 8 * NH_WL_SUB + 4 + sizeof(cp_team),
@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh
 // CP_SOLO_MIN problems on (92 000 in the crowded world), there are more problems than waves, the load balances over
 // problems, and a team would only repeat the cone / rank construction four times: every WAVE takes a problem of its
 // own, its first one by wave number, then a ticket per wave and problem.  (A two-pass schedule -- every wave on its
-// own, searches that find no bound handed over to teams -- was measured and lost: profiles/r04_ab_cp_bail_100.txt.)
+// own, searches that find no bound handed over to teams -- was measured and lost: profiles/archive/r04_ab_cp_bail_100.txt.)
 #define CP_HEAVY_OCC 4          /* (pinned: a few registers above 128 would silently cost a wave per SIMD) */
 __attribute__((amdgpu_waves_per_eu(CP_HEAVY_OCC, CP_HEAVY_OCC)))
 __global__ __launch_bounds__(CP_WAVES * 64) void k_cp_heavy(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
@@ -1808,7 +1808,7 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     // neighbours (most of them, outside a crowd), whatever of them needs the retry logic, then the workgroup problems
     // (17-64 neighbours).  Every wave / workgroup keeps drawing units until none are left.  (The workgroup problems on
     // a third stream beside the small ones were measured and lost -- one more fork and join on the agent stream, and in
-    // a jam the searches race k_cp_rows for the chip instead of inheriting it: profiles/r04_ab_cp_three_streams.txt.)
+    // a jam the searches race k_cp_rows for the chip instead of inheriting it: profiles/archive/r04_ab_cp_three_streams.txt.)
     const bool fork = side && ev && ev[0] && ev[1];
     hipStream_t sh = fork ? side : s;
     if(fork) {

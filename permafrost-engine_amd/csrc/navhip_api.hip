@@ -944,8 +944,8 @@ static bool coh_regroup_due(navhip_ctx *ctx, const nh_step_params &P)
     const int age = ctx->coh_regroup_age++;
     // In a jam -- the list lengths of the last step, in pinned memory without a wait: 8 192 workgroup searches and more --
     // the regrouping stays on every tick: the crowded world measured 3-4 % SLOWER without its five small launches on the
-    // side stream although every kernel takes the same time under the tracer (profiles/r04_ab_regroup_cadence.txt; launch
-    // timing against the persistent searches).  Kept as measured.
+    // side stream although every kernel takes the same time under the tracer (profiles/archive/r04_ab_regroup_cadence.txt; launch
+    // timing against the persistent searches, profiles/HISTORY.md 3.7).  Kept as measured.
     int32_t lists[6];
     const bool jam = navhip_step_lists_peek(ctx, lists) == NAVHIP_OK && lists[4] >= 8192;
     // (a slab step whose caller gave no static_epoch carries a never-repeating key: k_cohesion could not accept a
@@ -981,7 +981,7 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     hipStream_t front = (flags & NAVHIP_PREFETCH_FRONT_INLINE) ? s : ctx->aux[0];
     // The fork event for the cohesion stream (and for whoever waits for NAVHIP_STAGE_START) is one packet on the caller's
     // stream, in FRONT of the first kernel of the front: the cohesion kernel ends last, so it must not start late
-    // (behind k_sp_count it delayed the cohesion kernel: 0.3205 -> 0.3166 ms per tick, profiles/r03_ab_fork_first.txt).
+    // (behind k_sp_count it delayed the cohesion kernel: 0.3205 -> 0.3166 ms per tick, profiles/archive/r03_ab_fork_first.txt).
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));

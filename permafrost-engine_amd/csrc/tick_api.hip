@@ -4,7 +4,7 @@
 // field work, the velocity fork-join (:4182), the snapshot for the next tick -- and so does a C host of this library:
 // navhip_tick_run enqueues the field builds, the blocker batch, the velocity step, the slab exchange and the ping-pong
 // of the snapshot buffers for n ticks and returns.  The schedule is the one the Python driver (tick.py) measured its
-// way to in rounds 2-4: the narrow front of the step on a high-priority stream, the cohesion
+// way to in rounds 2-4 (profiles/HISTORY.md 3.7): the narrow front of the step on a high-priority stream, the cohesion
 // term on a side stream, the fields of tick t+1 built during tick t on a CU-masked stream behind the neighbour walk
 // (from a jam's worth of workgroup searches on: with the tick), the exchange on a stream only the next tick's
 // snapshot consumers wait for.  It calls the SAME entry points tick.py calls, in the same order per stream: results

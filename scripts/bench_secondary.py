@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The kernels outside the headline tick at a size that matters, for `rocprofv3 --kernel-trace --stats`
-(scripts/gpu_job.sh <tag> secondary -> profiles/r03_secondary_kernel_stats_*.csv) and as wall-clock rates:
+(scripts/gpu_job.sh <tag> secondary -> profiles/archive/r03_secondary_kernel_stats_*.csv) and as wall-clock rates:
 
   k_field_generic     16 384 chunk fields on a map whose passable cells cost 1..4 (the BFS kernel declines
                       every chunk: all requests take the LDS relaxation), device resident

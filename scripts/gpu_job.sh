@@ -53,9 +53,9 @@ cpstats) timeout 400 python scripts/cp_stats.py > $OUT/cp_stats.json 2> $OUT/cp_
 secondary) timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/secondary -o s --output-format csv -- python scripts/bench_secondary.py > $OUT/bench_secondary.json 2> $OUT/secondary.err
        tail -c 1500 $OUT/bench_secondary.json; f=$(find $OUT/secondary -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 $f | cut -c1-160 ;;
 hostov) timeout 600 python scripts/host_overhead.py > $OUT/host_overhead.txt 2>&1; cat $OUT/host_overhead.txt | tail -12
-        timeout 600 python scripts/rank_cost_probe.py --strong 1 2 4 8 > $OUT/rank_cost_strong.txt 2>&1; tail -5 $OUT/rank_cost_strong.txt
-        timeout 600 python scripts/rank_cost_probe.py --strong --no-serial 1 2 4 8 > $OUT/rank_cost_strong_noserial.txt 2>&1; tail -5 $OUT/rank_cost_strong_noserial.txt
-        timeout 600 python scripts/rank_cost_probe.py --strong --python-driver 1 2 4 8 > $OUT/rank_cost_strong_python.txt 2>&1; tail -5 $OUT/rank_cost_strong_python.txt ;;
+        # (every world in a process of its own, then all four in one process: the two must agree since round 6)
+        for w in 1 2 4 8; do timeout 300 python scripts/rank_cost_probe.py --strong $w; done > $OUT/rank_cost_strong_per_process.txt 2>&1; grep world $OUT/rank_cost_strong_per_process.txt
+        timeout 600 python scripts/rank_cost_probe.py --strong 1 2 4 8 > $OUT/rank_cost_strong.txt 2>&1; grep world $OUT/rank_cost_strong.txt ;;
 ticktests) timeout 900 python -m pytest tests/test_tick_gpu.py -m gpu -q > $OUT/pytest_tick.log 2>&1; tail -15 $OUT/pytest_tick.log ;;
 smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
 ranks2) NAVHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; tail -c 400 $OUT/bench_2ranks_gloo.json ;;

@@ -6,7 +6,7 @@
 // separate register chains (no dependency stalls), and the kernel time gives
 //     cycles per instruction per SIMD = time x clock x SIMDs / (waves x instructions per wave).
 // Build: hipcc --offload-arch=gfx950 -O3 scripts/valu_calib.hip -o scripts/valu_calib.bin
-// Run on the GPU box: prints one JSON object (committed as profiles/r02_valu_calib.json).
+// Run on the GPU box: prints one JSON object (committed as profiles/archive/r02_valu_calib.json).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

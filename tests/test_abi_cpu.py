@@ -251,7 +251,7 @@ def _device_kernels(lib_path, tmp_path):
 
 
 def test_persistent_clearpath_kernels_share_their_allocation_granules(tmp_path):
-    """Hole inheritance (DESIGN.md 3.7): k_cp_heavy's persistent workgroups move into the register and LDS ranges that
+    """Hole inheritance (DESIGN.md section 3): k_cp_heavy's persistent workgroups move into the register and LDS ranges that
     k_cp_rows' workgroups leave behind and keep them for the whole launch.  A k_cp_rows wave with fewer allocated
     registers, or a k_cp_rows workgroup with less LDS, leaves holes k_cp_heavy cannot use: a quarter of its waves
     for the whole launch (4.9 -> 6.1 ms per tick in the crowded world).  The built code objects must keep the two
