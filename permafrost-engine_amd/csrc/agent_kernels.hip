@@ -89,10 +89,12 @@ __device__ __forceinline__ bool sp_in_box(const int32_t *box, int32_t ix, int32_
 // cleared at allocation, then by k_sp_scan_add of the previous build).
 __global__ __launch_bounds__(256) void k_sp_count(nh_grid G, const float *pos_xz, int n,
                                                   int32_t *ent_cell, int32_t *ent_rank,
-                                                  int32_t *cell_count, const int32_t *box, int32_t *box_next)
+                                                  int32_t *cell_count, const int32_t *box, int32_t *box_next,
+                                                  int32_t *n_active)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if(box_next && i < 4) box_next[i] = INT32_MIN;           // (the box of the NEXT build)
+    if(n_active && i == 0) *n_active = 0;                    // (the list k_sp_place fills: its reader, the last walk, is through)
     if(i >= n) return;
     const int32_t ix = bg_scale(pos_xz[2 * i]), iy = bg_scale(pos_xz[2 * i + 1]);
     if(!sp_in_box(box, ix, iy)) { ent_cell[i] = -1; return; }
@@ -211,26 +213,44 @@ __global__ __launch_bounds__(256) void k_sp_scatter(const int32_t *ent_cell, con
 __global__ __launch_bounds__(SP_BLOCK) void k_sp_place(nh_grid G, const float *pos_xz, nh_pack_src src,
                                                   const int32_t *ent_cell, const int32_t *tmp_id,
                                                   int n, int work_begin, int work_end,
-                                                  float4 *recA, float2 *recV, int32_t *pool_of)
+                                                  float4 *recA, float2 *recV, int32_t *pool_of,
+                                                  int32_t *active, int32_t *n_active)
 {
     // one thread per ENTITY (not per pool slot): its inputs are coalesced loads that do not wait for the
     // slot search, the only gathers are the cell's bounds and its handful of ids, and the record goes out
     // as a scattered store.  (Per slot the kernel was a chain of five dependent gathers -- id, cell, bounds,
     // cell mates, the entity's six attribute arrays -- and took 60 us beside the cohesion kernel.)
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
-    if(i >= n) return;
-    const int c = ent_cell[i];
-    if(c < 0) return;                            // outside the slab filter
-    float4 a;
-    float2 v;
-    pool_record(i, pos_xz, src, work_begin, work_end, a, v);
-    const int b = G.cell_start[c], e = G.cell_start[c + 1];
-    int larger = 0;
-    for(int q = b; q < e; q++) larger += tmp_id[q] > i;
-    const int slot = b + larger;
-    recA[slot] = a;
-    recV[slot] = v;
-    pool_of[i] = slot;
+    const int c = i < n ? ent_cell[i] : -1;      // (-1: outside the slab filter)
+    int slot = -1;
+    bool walks = false;
+    if(c >= 0) {
+        float4 a;
+        float2 v;
+        pool_record(i, pos_xz, src, work_begin, work_end, a, v);
+        const int b = G.cell_start[c], e = G.cell_start[c + 1];
+        int larger = 0;
+        for(int q = b; q < e; q++) larger += tmp_id[q] > i;
+        slot = b + larger;
+        recA[slot] = a;
+        recV[slot] = v;
+        pool_of[i] = slot;
+        walks = !(__float_as_uint(a.w) & NH_PB_IDLE);
+    }
+    // A rank that steps a slab: the pool slots whose entity has a work item, as a LIST (any order), so that the neighbour
+    // walk runs one row per listed slot instead of striding rows over a pool of which seven eighths are idle -- a row
+    // then walked up to six entities one after the other and the launch took as long for an eighth of the entities as
+    // for all of them (38 against 47 us).  One atomic per wave (the slab is a contiguous uid range: few waves have any).
+    if(active) {
+        const unsigned long long m = __ballot(walks);
+        if(m) {
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if(lane == leader) base = atomicAdd(n_active, __popcll(m));
+            base = __shfl(base, leader);
+            if(walks) active[base + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -961,9 +981,9 @@ __device__ int derive_r10(const nh_grid &G, v2 me, const uint32_t *ids30, const 
 // ---------------------------------------------------------------------------------------------
 // k_agent_nbr: one ROW of 16 lanes per pool slot (NBR_BLOCK / 16 entities per workgroup)
 // ---------------------------------------------------------------------------------------------
-// STRIDED (a rank that steps a slab of a large job): the launch is sized by the slab, the pool by what its
-// queries can reach, so a few rows take a second slot.  With the whole snapshot stepped every pool slot
-// has its own row (no loop: four VGPRs and a wave per SIMD less with it).
+// STRIDED (a rank that steps a slab of a large job; the name is history): the launch is sized by the slab and takes its
+// pool slots from the list k_sp_place made of the entities with a work item.  With the whole snapshot stepped every
+// pool slot has its own row.
 #define NBR_WAVES 7        /* 72 VGPRs; 8 needs five spilled dwords per lane */
 // Threads per workgroup of the front's kernels.  ONE wave: they run beside the cohesion kernel's stream of
 // one-wave workgroups and the field builds, which take every wave slot the moment it frees up -- a workgroup
@@ -985,11 +1005,10 @@ void k_agent_nbr(nh_grid G, int npool_max, nh_nbr NB, float scaled_max_force)
         if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) return;         // no work item (or outside the slab)
         nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
     }else{
-        const int npool = min(npool_max, G.cell_start[G.grid_w * G.grid_h]);
-        for(int k = blockIdx.x * (NBR_BLOCK / 16) + grp_i; k < npool; k += gridDim.x * (NBR_BLOCK / 16)) {
-            if(__float_as_uint(G.recA[k].w) & NH_PB_IDLE) continue;
-            nbr_walk_row(G, k, scaled_max_force, exp_tab, terms[grp_i], NB);
-        }
+        // a slab: one row per pool slot k_sp_place listed (the entities with a work item)
+        const int r = blockIdx.x * (NBR_BLOCK / 16) + grp_i;
+        if(r >= *G.n_active) return;
+        nbr_walk_row(G, G.active[r], scaled_max_force, exp_tab, terms[grp_i], NB);
     }
 }
 
@@ -1647,9 +1666,13 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
         box = mine;
     }
     G.cell_start = S.cell_start; G.recA = S.recA; G.recV = S.recV; G.pool_of = S.pool_of;
+    // (a slab: the list of pool slots with a work item lives in ent_rank's buffer, which is free once k_sp_scatter has
+    // read it; its length behind the two slab boxes)
+    int32_t *active = box ? S.ent_rank : nullptr, *n_active = box ? S.box + 8 : nullptr;
+    G.active = active; G.n_active = n_active;
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
-                           S.ent_cell, S.ent_rank, S.cell_count, box, box_next);
+                           S.ent_cell, S.ent_rank, S.cell_count, box, box_next, n_active);
     const int nblocks = (ncells + NH_SCAN_T - 1) / NH_SCAN_T;
     hipLaunchKernelGGL(k_sp_scan_local, dim3(nblocks), dim3(NH_SCAN_T), 0, s, S.cell_count, S.cell_start,
                        S.block_sum, ncells, G, box);
@@ -1659,7 +1682,7 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
         hipLaunchKernelGGL(k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, S.ent_cell, S.ent_rank, n,
                            S.cell_start, S.tmp_id);
         hipLaunchKernelGGL(k_sp_place, dim3((n + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0, s, G, d_pos_xz, S.src,
-                           S.ent_cell, S.tmp_id, n, slab_begin, slab_end, S.recA, S.recV, S.pool_of);
+                           S.ent_cell, S.tmp_id, n, slab_begin, slab_end, S.recA, S.recV, S.pool_of, active, n_active);
     }
 }
 
@@ -1672,8 +1695,8 @@ void nh_launch_agent_nbr(const nh_step_params &P, const nh_nbr &NB, hipStream_t 
             hipLaunchKernelGGL(k_agent_nbr<false>, dim3((P.n_ents + NBR_BLOCK / 16 - 1) / (NBR_BLOCK / 16)), dim3(NBR_BLOCK), 0, s,
                                P.grid, P.n_ents, NB, smf);
         }else{
-            // rows for the slab + a quarter (its halo in the pool); never more than one per entity
-            const int rows = (int)min((long long)P.n_ents, (long long)slab + slab / 4 + 1024);
+            // a row per entity of the slab (the list of k_sp_place holds at most that many)
+            const int rows = slab;
             hipLaunchKernelGGL(k_agent_nbr<true>, dim3((rows + NBR_BLOCK / 16 - 1) / (NBR_BLOCK / 16)), dim3(NBR_BLOCK), 0, s,
                                P.grid, P.n_ents, NB, smf);
         }

@@ -34,6 +34,7 @@ struct nh_grid {
     const float4  *recA;             // [npool] {pos.x, pos.z, radius, NH_PB_* | uid << 8}
     const float2  *recV;             // [npool] movestate.velocity
     const int32_t *pool_of;          // [n] uid -> pool slot, -1 = not inserted (outside the slab filter)
+    const int32_t *active, *n_active;    // a slab step only: the pool slots of the entities with a work item, any order
 };
 
 // structure-of-arrays sources of the pool records (all null: positions only)

@@ -760,7 +760,7 @@ static int spatial_build(navhip_ctx *ctx, const navhip_world *w, nh_grid *g, hip
     const size_t n = (size_t)w->n_ents, ncells = (size_t)g->grid_w * g->grid_h;
     // ent_cell, ent_rank, cell_count, cell_start, tmp_id, block_sum, box, recA, recV, pool_of
     const size_t bytes[10] = {4 * n, 4 * n, 4 * ncells, 4 * (ncells + 1), 4 * n, 4 * ((ncells + NH_SCAN_T - 1) / NH_SCAN_T),
-                              32, 16 * n, 8 * n, 4 * n};
+                              48, 16 * n, 8 * n, 4 * n};        // ([6]: two slab boxes + the length of the slab's list of walks)
     for(int i = 0; i < 10; i++) {
         const void *old = ctx->sp[i].p;
         int rc = (i == 2) ? ensure_zeroed(ctx, ctx->sp[i], bytes[i], s) : ensure_buf(ctx, ctx->sp[i], bytes[i]);
@@ -1073,6 +1073,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         P.grid.n = w->n_ents;
         P.grid.cell_start = (int32_t*)ctx->sp[3].p; P.grid.recA = (const float4*)ctx->sp[7].p;
         P.grid.recV = (const float2*)ctx->sp[8].p; P.grid.pool_of = (const int32_t*)ctx->sp[9].p;
+        P.grid.active = nullptr; P.grid.n_active = nullptr;       // (the walk, their only reader, ran with the prefetch)
         if(ctx->front_stream != s) {
             // (an inline front on THIS stream is ordered by itself; on another stream -- the step is
             // issued elsewhere than the prefetch -- its "done" event may not have been recorded yet)
