@@ -483,6 +483,12 @@ int  navhip_agent_prefetch_dev(navhip_ctx *ctx, const navhip_world *dev_world, v
  * step then does not make the caller's stream wait for the lane regrouping the cohesion stream runs
  * for the next tick -- that work is ordered in front of the next step's cohesion term anyway. */
 #define NAVHIP_PREFETCH_SNAPSHOT_HELD 0x2u
+/*        NAVHIP_PREFETCH_FOLLOWS_STEP   every array of the snapshot was final when the last navhip_agent_step_dev
+ * on `stream` ended, and nothing was enqueued on `stream` since that this call has to follow (a tick loop that
+ * ping-pongs the outputs of one step into the snapshot of the next): the side streams then start behind a word the
+ * step stored in device memory when it ended, instead of behind an event recorded on `stream` now -- one packet less
+ * in front of the spatial hash.  Ignored when the last step did not run on `stream`. */
+#define NAVHIP_PREFETCH_FOLLOWS_STEP 0x4u
 int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world, void *stream, uint32_t flags);
 /* Scheduling hint for a caller that runs other wide work (the field builds of the NEXT tick, say)
  * beside the agent step: make `stream` wait until the given stage of the step in flight is done, so
@@ -593,6 +599,10 @@ typedef struct navhip_tick navhip_tick;
 #define NAVHIP_TICK_TIME_FIELDS 0x8u /* time the field builds of every fourth tick with two HIP events on the FIELD stream (no
                                      packet on the agent stream): navhip_tick_info.fields_ms / fields_samples -- how long
                                      the builds take INSIDE the tick, beside the agent step they overlap with           */
+#define NAVHIP_TICK_OWNS_SNAPSHOT 0x10u /* between two ticks the caller enqueues nothing on the tick's stream that the next
+                                     tick has to follow, and writes the snapshot buffers only with the device idle: the side
+                                     streams of tick t+1 then start behind a word tick t stored in device memory when it
+                                     ended (NAVHIP_PREFETCH_FOLLOWS_STEP) -- inside one navhip_tick_run that is so anyway  */
 typedef struct navhip_tick_desc {
     navhip_world world;             /* DEVICE arrays of the snapshot (buffer set 0: pos_xz, vel_xz, field_pool);
                                        work_begin/work_end = this rank's uid slab                                      */

@@ -1179,8 +1179,16 @@ __global__ __launch_bounds__(CPS_WAVES * 64) void k_cp_small(nh_step_params P, n
 __attribute__((amdgpu_waves_per_eu(CP_ROWS_OCC, CP_ROWS_OCC)))
 __global__ __launch_bounds__(CPR_WAVES * 64) void k_cp_rows(nh_step_params P, nh_nbr NB, const nh_mid_rec *mid,
                                                            nh_worklists WL, nh_step_outs O, int list0, int nlists,
-                                                           int ticket_set)
+                                                           int ticket_set, nh_signal lists_ready)
 {
+    // (this launch follows k_agent_mid on its stream: that it runs says the work lists are complete)
+    if(lists_ready.flag && blockIdx.x == 0 && threadIdx.x == 0) {
+#ifdef NH_HOSTSIM
+        *lists_ready.flag = lists_ready.seq;
+#else
+        __hip_atomic_store(lists_ready.flag, lists_ready.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
     __shared__ cp_lds<16> lds[CPR_WAVES * 4];
     // unit_end[k] = units of the sub-lists up to and including k (k = order * NH_WL_SUB + sub)
     __shared__ int32_t unit_end[4 * NH_WL_SUB];
@@ -1817,7 +1825,7 @@ int nh_worklist_cap(int n_work)
 // does not clear the other set either).
 bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
-                            hipStream_t side, hipEvent_t ev[2])
+                            hipStream_t side, hipEvent_t ev[2], navhip_ctx *ctx, int handovers)
 {
     const int nwork = P.work_end - P.work_begin;
     if(!(P.n_ents > 0 && nwork > 0)) return false;
@@ -1834,26 +1842,41 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     // a jam the searches race k_cp_rows for the chip instead of inheriting it: profiles/archive/r04_ab_cp_three_streams.txt.)
     const bool fork = side && ev && ev[0] && ev[1];
     hipStream_t sh = fork ? side : s;
-    if(fork) {
+    // the hand-overs of the fork: through device memory (stream_set.hip) when the context has the words, else events
+    const bool ho_mid = fork && ctx && ctx->ho && ((handovers >> NH_HO_MID) & 1), ho_cp = fork && ctx && ctx->ho && ((handovers >> NH_HO_CP) & 1);
+    nh_signal lists_ready = {nullptr, 0};
+    if(ho_mid) {
+        lists_ready.seq = nh_handover_next(ctx, NH_HO_MID);
+        lists_ready.flag = ctx->ho->flags + NH_HO_MID * NH_HO_STRIDE;
+    }else if(fork) {
         hipEventRecord(ev[0], s);
         hipStreamWaitEvent(sh, ev[0], 0);
     }
+    if(ctx) ctx->lists_signalled = ho_mid;
     const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
     const int nblk_rows = min(4096 / CPR_WAVES, (nwork + 15) / 16 * (CP_WAVES / CPR_WAVES) + 1);
     // (the rows first: behind a host that is not ahead of the device -- the tick after a synchronisation -- every
     // launch in front of it delays its start by one enqueue)
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                       (int)NH_WL_ROW3, 2, 0);
+                       (int)NH_WL_ROW3, 2, 0, lists_ready);
+    if(ho_mid) nh_handover_wait(ctx, NH_HO_MID, sh);
     hipLaunchKernelGGL(k_cp_small, dim3((nwork / 4 + 2 * NH_WL_SUB + CPS_WAVES - 1) / CPS_WAVES + 1), dim3(CPS_WAVES * 64), 0, sh, P, NB,
                        (const nh_mid_rec*)d_mid, WL, O);
     hipLaunchKernelGGL(k_cp_rows, dim3(64 * CP_WAVES / CPR_WAVES), dim3(CPR_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
-                       (int)NH_WL_RETRY, 1, 1);
+                       (int)NH_WL_RETRY, 1, 1, nh_signal{nullptr, 0});
     // (the last launch on `side` clears the other set of list counters: see k_cp_heavy)
     hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O, zero_next);
-    if(fork) hipEventRecord(ev[1], sh);
+    if(ho_cp)     nh_handover_signal(ctx, NH_HO_CP, sh);
+    else if(fork) hipEventRecord(ev[1], sh);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
                        (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, (int32_t*)nullptr);
-    if(fork) hipStreamWaitEvent(s, ev[1], 0);
+    if(ho_cp) {
+        // (... and says that the step has ended: a prefetch that follows directly starts its side streams behind that)
+        const bool start = (handovers >> NH_HO_START) & 1;
+        nh_handover_wait(ctx, NH_HO_CP, s, -1, start ? NH_HO_START : -1);
+        if(start) ctx->step_end_on = s;
+    }
+    else if(fork) hipStreamWaitEvent(s, ev[1], 0);
     return true;
 }
 

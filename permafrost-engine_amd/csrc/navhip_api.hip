@@ -112,9 +112,9 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->aux_main = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
-    ctx->front_stream = nullptr;
+    ctx->front_stream = nullptr; ctx->join0_recorded = ctx->join0_signalled = ctx->lists_signalled = ctx->fork_by_flag = false; ctx->step_end_on = nullptr;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
-    ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->sp_builds = 0; ctx->lists_pinned = nullptr;
+    ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->ho = nullptr; ctx->sp_builds = 0; ctx->lists_pinned = nullptr;
     memset(ctx->ev, 0, sizeof(ctx->ev));
     if(hipSetDevice(device) != hipSuccess
     || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -152,10 +152,12 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     for(auto &e : ctx->ev) if(e) hipEventDestroy(e);
     if(nh_streams_alive(ctx->device))
         for(auto &a : ctx->aux) if(a) hipStreamSynchronize(a);   // (borrowed: the process's own set, csrc/stream_set.hip)
+    nh_handover_destroy(ctx);
     if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
     if(ctx->ev_regroup) hipEventDestroy(ctx->ev_regroup);
     for(auto &e : ctx->ev_cp) if(e) hipEventDestroy(e);
+    nh_streams_forget(ctx->device, ctx->stream);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -924,8 +926,16 @@ static int ensure_side_streams(navhip_ctx *ctx, hipStream_t main)
         ctx->pre.valid = false; ctx->regroup_pending = false;
     }
     ctx->aux[0] = st[NH_STREAM_SIDE0]; ctx->aux[1] = st[NH_STREAM_SIDE1]; ctx->aux_main = main;
-    return NAVHIP_OK;
+    return nh_handover_ensure(ctx);
 }
+
+// (development switch, one bit per hand-over: NH_HO_COH | NH_HO_MID | NH_HO_CP | NH_HO_NBR | NH_HO_START)
+static int ho_mask()
+{
+    static const int m = getenv("NAVHIP_HANDOVER") ? atoi(getenv("NAVHIP_HANDOVER")) : 31;
+    return m;
+}
+static bool ho_on(int flag) { return (ho_mask() >> flag) & 1; }
 
 // The lane regrouping of the cohesion term (five small launches behind k_cohesion) is for the NEXT tick's launch
 // and only has to be spatially coherent: agents move about one world unit per tick and a group's box is compared
@@ -982,9 +992,17 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // The fork event for the cohesion stream (and for whoever waits for NAVHIP_STAGE_START) is one packet on the caller's
     // stream, in FRONT of the first kernel of the front: the cohesion kernel ends last, so it must not start late
     // (behind k_sp_count it delayed the cohesion kernel: 0.3205 -> 0.3166 ms per tick, profiles/archive/r03_ab_fork_first.txt).
-    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-    if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    // NAVHIP_PREFETCH_FOLLOWS_STEP: the snapshot was final when the last step on this stream ended, and that step stored
+    // a word behind its last kernel -- the side streams wait for the word, and no packet goes in front of the front at all
+    ctx->fork_by_flag = (flags & NAVHIP_PREFETCH_FOLLOWS_STEP) && ho_on(NH_HO_START) && ctx->step_end_on == s;
+    if(ctx->fork_by_flag) {
+        if(front != s) nh_handover_wait(ctx, NH_HO_START, ctx->aux[0]);
+        nh_handover_wait(ctx, NH_HO_START, ctx->aux[1]);
+    }else{
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+        if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    }
     // side stream 0: spatial hash -> neighbour walk (separation force + ClearPath neighbour lists)
     rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end);
     if(rc) return rc;
@@ -998,7 +1016,9 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // side stream 1: cohesion
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
                                             ctx->aux[1]);
+    if(ho_on(NH_HO_COH)) nh_handover_signal(ctx, NH_HO_COH, ctx->aux[1]);
     HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+    ctx->join0_signalled = false;
     // (behind the join event: the agent step does not wait for next tick's lane grouping; but the
     // caller's stream does, at the end of navhip_agent_step_dev, so that whatever the caller does
     // to the snapshot arrays afterwards is ordered behind the last read of them)
@@ -1040,8 +1060,10 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     int rc = step_check_world(ctx, w);
     if(rc) return rc;
     if(w->n_ents == 0) return NAVHIP_OK;
+    if(nh_handover_failed(ctx)) return NAVHIP_ERR_DEVICE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->step_end_on = nullptr;
 
     nh_step_params P;
     rc = step_fill_params(ctx, w, &P);
@@ -1080,9 +1102,15 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
             if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
         }
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
+        if(ho_on(NH_HO_COH)) {
+            // (an inline front: the waiting kernel follows the neighbour walk on this stream, and says so)
+            const bool nbr = ho_on(NH_HO_NBR) && ctx->front_stream == s && !ctx->join0_signalled;
+            nh_handover_wait(ctx, NH_HO_COH, s, nbr ? NH_HO_NBR : -1);
+            if(nbr) ctx->join0_signalled = true;
+        }
+        else HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                                  ctx->aux[0], ctx->ev_cp)) {
+                                  ctx->aux[0], ctx->ev_cp, ctx, ho_mask())) {
             rc = send_step_lists(ctx, ctx->wl_parity, s);
             ctx->wl_parity ^= 1;
             if(rc) return rc;
@@ -1112,7 +1140,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     const bool serial = ctx->serial_step;
     if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                              serial ? nullptr : ctx->aux[0], ctx->ev_cp)) {
+                              serial ? nullptr : ctx->aux[0], ctx->ev_cp, ctx, serial ? 0 : ho_mask())) {
         rc = send_step_lists(ctx, ctx->wl_parity, s, serial);
         ctx->wl_parity ^= 1;
         if(rc) return rc;
@@ -1128,13 +1156,25 @@ int navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if(stage == NAVHIP_STAGE_NEIGHBOURS) {
         if(!ctx->front_stream) return NAVHIP_ERR_INVALID;
+        if(ctx->join0_signalled || (ho_on(NH_HO_NBR) && ctx->pre.valid)) {
+            // (between the prefetch and its step: a launch of its own behind the walk; after the step: the step's
+            // wait for the cohesion term has stored it)
+            if(!ctx->join0_signalled) { nh_handover_signal(ctx, NH_HO_NBR, ctx->front_stream); ctx->join0_signalled = true; }
+            nh_handover_wait(ctx, NH_HO_NBR, (hipStream_t)stream);
+            HIPCHK(ctx, hipGetLastError());
+            return NAVHIP_OK;
+        }
         if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
         HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join[0], 0));
     }else if(stage == NAVHIP_STAGE_START) {
         if(!ctx->front_stream) return NAVHIP_ERR_INVALID;
-        HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_fork, 0));
+        if(ctx->fork_by_flag) nh_handover_wait(ctx, NH_HO_START, (hipStream_t)stream);
+        else                  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_fork, 0));
     }
-    else if(stage == NAVHIP_STAGE_LISTS)  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cp[0], 0));
+    else if(stage == NAVHIP_STAGE_LISTS) {
+        if(ctx->lists_signalled) nh_handover_wait(ctx, NH_HO_MID, (hipStream_t)stream);      // (k_agent_mid stored it itself)
+        else                     HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cp[0], 0));
+    }
     else return NAVHIP_ERR_INVALID;
     return NAVHIP_OK;
 }

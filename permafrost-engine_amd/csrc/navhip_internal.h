@@ -72,6 +72,10 @@ struct navhip_ctx {
     navhip_counters counters;       // navhip_get_counters
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
     bool         join0_recorded;    // ev_join[0] has been recorded for the front of the last prefetch
+    bool         join0_signalled;   // ... NH_HO_NBR has been stored behind it
+    bool         lists_signalled;   // the last step's k_agent_mid stored NH_HO_MID (no ev_cp[0] was recorded)
+    hipStream_t  step_end_on;       // the stream on which the last step stored NH_HO_START behind its last kernel, or NULL
+    bool         fork_by_flag;      // the last prefetch started its side streams behind NH_HO_START (no ev_fork was recorded)
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
     hipEvent_t   ev_cp[2];          // the ClearPath launches of the agent step: lists ready, side chain done
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
@@ -90,6 +94,7 @@ struct navhip_ctx {
     hipEvent_t   ev[6];        // start | hash built | neighbour walk | cohesion | regroup | finish
     bool         ev_valid;
     std::string  last_error;
+    struct nh_handover *ho;    // hand-overs between the step's streams through device memory (stream_set.hip) or NULL
     struct nh_pool  *pool;     // resident flow-field pool (navhip_pool_*, pool_api.hip) or NULL
     struct nh_async *async;    // state of navhip_agent_step_submit / _poll
     struct nh_comm  *comm;     // RCCL communicator of navhip_comm_* (comm_api.hip) or NULL
@@ -107,7 +112,39 @@ enum { NH_STREAM_SIDE0 = 0,     // the ClearPath side chain of the agent step
 int         nh_streams_for(navhip_ctx *ctx, hipStream_t main, hipStream_t out[NH_STREAM_FIXED]);
 hipStream_t nh_stream_partial_for(navhip_ctx *ctx, hipStream_t main, int cu_begin, int cu_count);   // nullptr: ctx->last_error says why
 bool        nh_streams_alive(int device);
+void        nh_streams_forget(int device, hipStream_t s);
 int         nh_prepare_step_streams(navhip_ctx *ctx, hipStream_t main);      // the side streams of steps whose main chain runs on `main`
+
+// Hand-overs between the library's streams through a word in device memory instead of a queue barrier: the producer's
+// stream stores a sequence number behind its last kernel (a one-lane launch, or the last workgroup of the kernel
+// itself: nh_signal), the consumer's stream holds a one-lane kernel that ends when the number has arrived.  Measured
+// (scripts/stream_flag_probe.hip, profiles/r06_stream_flag_probe.txt): 2-3 us per hand-over against 12 us for an event
+// record + event wait between two hardware queues.  The host enqueues the producer first, always: any order of
+// execution that respects the order of submission -- the emulator's, a profiler that serialises kernels -- terminates.
+enum { NH_HO_COH = 0,           // the cohesion term            (side stream 1 -> the agent chain)
+       NH_HO_MID,               // k_agent_mid's work lists      (the agent chain -> side stream 0), stored by the kernel itself
+       NH_HO_CP,                // the ClearPath side chain      (side stream 0 -> the agent chain)
+       NH_HO_NBR,               // spatial hash + neighbour walk (the agent chain -> whoever waits for NAVHIP_STAGE_NEIGHBOURS)
+       NH_HO_START,             // the end of a step on the agent chain (-> the side streams of a prefetch that follows it directly)
+       NH_HO_FLAGS };
+#define NH_HO_STRIDE 32         /* one 128-byte line per word; the ticket of a kernel that signals itself is the word + 1 */
+// a number for a word, as a kernel argument: stored by a kernel that FOLLOWS the producer on its stream (its first
+// workgroup, when it starts).  flag == nullptr: nobody waits.
+struct nh_signal { int32_t *flag; int32_t seq; };
+struct nh_handover {
+    int32_t *flags;             // device
+    int32_t *status;            // pinned host word (device pointer: status_dev): a wait that gave up after two seconds stores 1
+    int32_t *status_dev;
+    int32_t  seq[NH_HO_FLAGS];  // the number the last producer of a flag stores
+};
+int      nh_handover_ensure(navhip_ctx *ctx);                                   // NAVHIP_OK, or an error with ctx->last_error
+void     nh_handover_destroy(navhip_ctx *ctx);
+int32_t  nh_handover_next(navhip_ctx *ctx, int flag);                          // the next producer's number (for a kernel that signals itself)
+void     nh_handover_signal(navhip_ctx *ctx, int flag, hipStream_t producer);   // behind everything enqueued on `producer` so far
+// `consumer` continues when the flag's last producer has stored.  before / after (-1: none): words the waiting kernel
+// itself stores when it starts -- it follows their producer on `consumer` -- and when its wait is over
+void     nh_handover_wait(navhip_ctx *ctx, int flag, hipStream_t consumer, int before = -1, int after = -1);
+bool     nh_handover_failed(navhip_ctx *ctx);                                   // a wait gave up: ctx->last_error says so
 
 // pool_api.hip <-> navhip_api.hip
 extern "C" int nh_validate_field_reqs(navhip_ctx *ctx, const navhip_field_req *reqs, int n);   /* (library internal) */

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -39,6 +40,93 @@ __global__ void k_nh_spin(long long ticks)
     const long long t0 = wall_clock64();
     while(wall_clock64() - t0 < ticks) { }
 #endif
+}
+
+// ---- hand-overs through device memory (navhip_internal.h: nh_handover) ------------------------------------------------
+__global__ void k_ho_signal(int32_t *flag, int32_t seq)
+{
+#ifdef NH_HOSTSIM
+    *flag = seq;
+#else
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// stores `before` (a word nobody has to wait for any longer once this kernel runs: it follows their producer on its
+// stream), waits for `flag`, stores `after` (what the stream has reached once the wait is over)
+__global__ void k_ho_wait(const int32_t *flag, int32_t want, int32_t *status, nh_signal before, nh_signal after)
+{
+#ifdef NH_HOSTSIM
+    if(before.flag) *before.flag = before.seq;
+    // (launches run to completion in the order of submission here: the producer has run)
+    if(*flag - want < 0) { fprintf(stderr, "k_ho_wait: the producer of a hand-over was enqueued behind its consumer\n"); abort(); }
+    if(after.flag) *after.flag = after.seq;
+#else
+    if(before.flag) __hip_atomic_store(before.flag, before.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    while(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if(wall_clock64() - t0 > 200000000LL) {                   // two seconds at 100 MHz: never hang the device
+            __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    if(after.flag) __hip_atomic_store(after.flag, after.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+int nh_handover_ensure(navhip_ctx *ctx)
+{
+    if(ctx->ho) return NAVHIP_OK;
+    nh_handover *H = new nh_handover();
+    memset(H, 0, sizeof(*H));
+    if(hipMalloc((void**)&H->flags, sizeof(int32_t) * NH_HO_FLAGS * NH_HO_STRIDE) != hipSuccess ||
+       hipMemset(H->flags, 0, sizeof(int32_t) * NH_HO_FLAGS * NH_HO_STRIDE) != hipSuccess ||
+       hipHostMalloc((void**)&H->status, sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+       hipHostGetDevicePointer((void**)&H->status_dev, H->status, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if(H->flags) hipFree(H->flags);
+        if(H->status) hipHostFree(H->status);
+        delete H;
+        ctx->last_error = "hand-over words: out of memory";
+        return NAVHIP_ERR_NOMEM;
+    }
+    *H->status = 0;
+    ctx->ho = H;
+    return NAVHIP_OK;
+}
+
+void nh_handover_destroy(navhip_ctx *ctx)
+{
+    if(!ctx->ho) return;
+    hipFree(ctx->ho->flags);
+    hipHostFree(ctx->ho->status);
+    delete ctx->ho;
+    ctx->ho = nullptr;
+}
+
+int32_t nh_handover_next(navhip_ctx *ctx, int flag) { return ++ctx->ho->seq[flag]; }
+
+void nh_handover_signal(navhip_ctx *ctx, int flag, hipStream_t producer)
+{
+    nh_handover *H = ctx->ho;
+    hipLaunchKernelGGL(k_ho_signal, dim3(1), dim3(1), 0, producer, H->flags + flag * NH_HO_STRIDE, ++H->seq[flag]);
+}
+
+void nh_handover_wait(navhip_ctx *ctx, int flag, hipStream_t consumer, int before, int after)
+{
+    nh_handover *H = ctx->ho;
+    nh_signal b = {nullptr, 0}, a = {nullptr, 0};
+    if(before >= 0) { b.flag = H->flags + before * NH_HO_STRIDE; b.seq = ++H->seq[before]; }
+    if(after >= 0)  { a.flag = H->flags + after * NH_HO_STRIDE;  a.seq = ++H->seq[after]; }
+    hipLaunchKernelGGL(k_ho_wait, dim3(1), dim3(1), 0, consumer, (const int32_t*)(H->flags + flag * NH_HO_STRIDE), H->seq[flag],
+                       H->status_dev, b, a);
+}
+
+bool nh_handover_failed(navhip_ctx *ctx)
+{
+    if(!ctx->ho || !*(volatile int32_t*)ctx->ho->status) return false;
+    ctx->last_error = "a hand-over between two streams of the agent step was not signalled within two seconds";
+    return true;
 }
 
 namespace {
@@ -192,6 +280,15 @@ int pipe_of(navhip_ctx *ctx, nh_dev_streams &D, hipStream_t s)
     return found;
 }
 }  // namespace
+
+// a stream the library is about to destroy: what was measured for its handle must not be answered for the next stream
+// that gets the same handle
+void nh_streams_forget(int device, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    auto it = g_streams.find(device);
+    if(it != g_streams.end()) it->second.caller_pipe.erase(s);
+}
 
 // false once the process is exiting and the set is gone (a context destroyed that late must not touch its borrowed streams)
 bool nh_streams_alive(int device)

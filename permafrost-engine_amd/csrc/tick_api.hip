@@ -38,6 +38,8 @@ struct navhip_tick {
     hipStream_t      s, f, comm;      // agent chain | field builds ahead | exchange
     hipEvent_t       ev_fields[2], ev_step, ev_comm, ev_tmp;
     bool             ahead, pipelined, comm_pending, computed, serial;
+    bool             follows;         // nothing came between the last tick's step and this tick on T->s
+    bool             owns, stepped;   // NAVHIP_TICK_OWNS_SNAPSHOT; a tick has been computed
     int64_t          ticks;
     double           enqueue_ms;
     // NAVHIP_TICK_TIME_FIELDS: event pairs on the field stream around the builds of every fourth tick
@@ -128,14 +130,22 @@ static int compute_plain(navhip_tick *T)
             HIPCHK(ctx, hipEventRecord(T->ev_tmp, T->s));
             HIPCHK(ctx, hipStreamWaitEvent(T->f, T->ev_tmp, 0));
         }
+        // (inside one navhip_tick_run nothing comes between a step and the next tick's prefetch on T->s, and the snapshot
+        // of a tick is the output of the last one)
         if(!T->pipelined)
-            RCCHK(navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE | NAVHIP_PREFETCH_SNAPSHOT_HELD));
-        // the fields of the NEXT tick
+            RCCHK(navhip_agent_prefetch_dev_ex(ctx, w, (void*)T->s, NAVHIP_PREFETCH_FRONT_INLINE | NAVHIP_PREFETCH_SNAPSHOT_HELD |
+                                               (T->follows ? NAVHIP_PREFETCH_FOLLOWS_STEP : 0u)));
+        HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));       // this tick's fields (built during the last one)
+        if(T->comm_pending) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_comm, 0));   // the other ranks' rows of the snapshot
+        RCCHK(navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s));
+        if(T->pipelined) HIPCHK(ctx, hipEventRecord(T->ev_step, T->s));
+        // the fields of the NEXT tick: enqueued behind the step -- the step's own wait for the cohesion term is the
+        // launch that says "the neighbour walk is done" -- and started by the device as soon as that is so
         if(stage == NAVHIP_STAGE_NEIGHBOURS) RCCHK(navhip_stream_wait_stage(ctx, (void*)T->f, NAVHIP_STAGE_NEIGHBOURS));
         else if(!T->pipelined)               RCCHK(navhip_stream_wait_stage(ctx, (void*)T->f, NAVHIP_STAGE_START));
         RCCHK(build_fields_timed(T, T->pool[p ^ 1], T->f));
         HIPCHK(ctx, hipEventRecord(T->ev_fields[p ^ 1], T->f));
-        HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));       // this tick's fields (built during the last one)
+        return NAVHIP_OK;
     }else{
         if(!T->pipelined) RCCHK(navhip_agent_prefetch_dev(ctx, w, (void*)T->s));
         if(T->d.dev_moves) {
@@ -157,7 +167,7 @@ static int tick_compute(navhip_tick *T)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if(T->computed) { ctx->last_error = "navhip_tick_compute: the previous tick has not been advanced"; return NAVHIP_ERR_INVALID; }
     int rc = compute_plain(T);
-    if(rc == NAVHIP_OK) T->computed = true;
+    if(rc == NAVHIP_OK) T->computed = T->stepped = true;
     return rc;
 }
 
@@ -194,6 +204,7 @@ int navhip_tick_create(navhip_ctx *ctx, const navhip_tick_desc *desc, navhip_tic
     if(!T) return NAVHIP_ERR_NOMEM;
     T->ctx = ctx; T->d = *desc;
     T->serial = (desc->flags & NAVHIP_TICK_SERIAL) != 0;
+    T->owns = (desc->flags & NAVHIP_TICK_OWNS_SNAPSHOT) != 0;
     T->time_fields = (desc->flags & NAVHIP_TICK_TIME_FIELDS) != 0;
     T->ahead = desc->field_pool_1 != nullptr && !T->serial;
     T->pipelined = desc->bounds != nullptr;
@@ -248,7 +259,9 @@ int navhip_tick_compute(navhip_tick *T)
 {
     if(!T) return NAVHIP_ERR_INVALID;
     const double t0 = now_ms();
+    T->follows = T->owns && T->stepped;
     int rc = tick_compute(T);
+    T->follows = false;
     T->enqueue_ms += now_ms() - t0;
     return rc;
 }
@@ -267,10 +280,12 @@ int navhip_tick_run(navhip_tick *T, int n)
     const double t0 = now_ms();
     int rc = NAVHIP_OK;
     for(int i = 0; i < n && !rc; i++) {
+        T->follows = i > 0 || (T->owns && T->stepped);
         rc = tick_compute(T);
         if(!rc) rc = tick_exchange(T);
         if(!rc) { T->computed = false; T->ticks++; }
     }
+    T->follows = false;
     T->enqueue_ms += now_ms() - t0;
     return rc;
 }

@@ -591,7 +591,7 @@ def _ctx_agent_step_dev(self, world, stepout, stream=None):
               "navhip_agent_step_dev")
 
 
-PREFETCH_FRONT_INLINE, PREFETCH_SNAPSHOT_HELD = 1, 2
+PREFETCH_FRONT_INLINE, PREFETCH_SNAPSHOT_HELD, PREFETCH_FOLLOWS_STEP = 1, 2, 4
 
 
 def _ctx_agent_prefetch_dev(self, world, stream=None, flags=0):
@@ -1098,7 +1098,7 @@ NavContext.G_ClearPath_NewVelocity = _ctx_clearpath
 # ---------------------------------------------------------------------------------------------
 # the whole tick behind one call (navhip_tick_*, csrc/tick_api.hip)
 # ---------------------------------------------------------------------------------------------
-TICK_SERIAL, TICK_TIME_FIELDS = 0x2, 0x8
+TICK_SERIAL, TICK_TIME_FIELDS, TICK_OWNS_SNAPSHOT = 0x2, 0x8, 0x10
 
 
 class TickDesc(C.Structure):

@@ -360,6 +360,7 @@ class NavTick:
         self.ev_step = tcuda.Event()
         self.ev_comm = tcuda.Event()
         self._comm_pending = False
+        self._stepped = False
         self._make_structs()
         if obstacles:
             # the pool starts fully built (untimed), afterwards only changed chunks are repaired
@@ -572,7 +573,9 @@ class NavTick:
             self._bounds_c = np.ascontiguousarray(self._bounds, np.int32)
             d.bounds = self._bounds_c.ctypes.data
             d.comm_stream = self.comm.cuda_stream
-        d.flags = (navhip.TICK_SERIAL if self.serial else 0) | (navhip.TICK_TIME_FIELDS if self.time_fields else 0)
+        # (the snapshot arrays are this object's own: nothing else writes them or enqueues on its stream between ticks)
+        d.flags = ((navhip.TICK_SERIAL if self.serial else 0) | (navhip.TICK_TIME_FIELDS if self.time_fields else 0)
+                   | navhip.TICK_OWNS_SNAPSHOT)
         self._ctick = navhip.Tick(self.ctx, d, keep)
         self._ctick_tick0 = self.tick_no
         self.tick_driver = "c (navhip_tick_run%s)" % (", one stream" if self.serial else "")
@@ -684,14 +687,27 @@ class NavTick:
             f.wait_stream(s)                      # (the end of the previous tick)
         if not self.pipelined:
             with tcuda.stream(s):
-                self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream, flags=self.prefetch_flags)
-        # the fields of the NEXT tick
+                # (this object's arrays and stream: the snapshot of a tick is the output of the last one)
+                follows = navhip.PREFETCH_FOLLOWS_STEP if self._stepped else 0
+                self.ctx.agent_prefetch_dev(self.world_s, stream=s.cuda_stream, flags=self.prefetch_flags | follows)
+        with tcuda.stream(s):
+            marks.append(self._mark("agents"))
+            s.wait_event(self.ev_fields)                  # this tick's fields (built during the last one)
+            if self._comm_pending:
+                s.wait_event(self.ev_comm)
+            self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
+            self._stepped = True
+            marks.append(self._mark("gather_agents"))
+            if self.pipelined:
+                self.ev_step.record(s)
+        # the fields of the NEXT tick: enqueued behind the step (whose own wait for the cohesion term is the launch that
+        # says "the neighbour walk is done"), started by the device as soon as that is so
         timed = self.record and self.tick_no % self.mark_every == 0
         with tcuda.stream(f):
             if stage == "neighbours":
                 self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_NEIGHBOURS)
             elif not self.pipelined:
-                # (the fork event of the prefetch just enqueued: the end of the previous tick, without
+                # (the start of the prefetch just enqueued: the end of the previous tick, without
                 # another event on the agent stream)
                 self.ctx.stream_wait_stage(f.cuda_stream, navhip.STAGE_START)
             if timed:
@@ -710,15 +726,6 @@ class NavTick:
                 e2.record(f)
                 self.fev.append((e0, e1, e2))
             self.ev_fields_next.record(f)
-        with tcuda.stream(s):
-            marks.append(self._mark("agents"))
-            s.wait_event(self.ev_fields)                  # this tick's fields (built during the last one)
-            if self._comm_pending:
-                s.wait_event(self.ev_comm)
-            self.ctx.agent_step_dev(self.world_s, self.out_s, stream=s.cuda_stream)
-            marks.append(self._mark("gather_agents"))
-            if self.pipelined:
-                self.ev_step.record(s)
 
     def exchange(self):
         """The slab results (new position + velocity) of every rank -> every rank."""

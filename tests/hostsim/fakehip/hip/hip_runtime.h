@@ -39,7 +39,7 @@ template <typename F> static void launch(dim3 grid, dim3 block, F fn)
 #define blockDim emu::blockDim_emu
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) (emu_scan_args(#kernel, __VA_ARGS__), emu::launch(grid, block, [&]() { kernel(__VA_ARGS__); }))
 
-enum { hipErrorNotReady = 600, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0,
+enum { hipErrorNotReady = 600, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocMapped = 2,
        hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 typedef void *hipDeviceptr_t;
 struct hipDeviceProp_t { int multiProcessorCount; char name[64]; };
@@ -202,6 +202,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned) { *dev = host; return hipSuccess; }   /* (one address space) */
 template <typename T> static inline hipError_t hipMemcpyToSymbol(T &sym, const void *src, size_t n) { memcpy((void*)&sym, src, n); return hipSuccess; }
 template <typename T> static inline hipError_t hipMemcpyFromSymbol(void *dst, const T &sym, size_t n) { memcpy(dst, (const void*)&sym, n); return hipSuccess; }
 
