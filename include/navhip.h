@@ -497,10 +497,15 @@ int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world
  *                            (= the previous step on that stream has finished)
  *   NAVHIP_STAGE_NEIGHBOURS  spatial hash + neighbour walk of the last navhip_agent_prefetch_dev
  *   NAVHIP_STAGE_LISTS       preferred velocities + work lists of the last navhip_agent_step_dev
- * (NAVHIP_ERR_INVALID when that call has not been made). */
+ *   NAVHIP_STAGE_END         the last navhip_agent_step_dev has written its outputs (NAVHIP_ERR_INVALID when that step
+ *                            ran on one stream, without side streams: its stream is its end -- order behind that)
+ * (NAVHIP_ERR_INVALID when that call has not been made).  The wait is a one-lane kernel on `stream` that ends when the
+ * stage's word in device memory has been stored -- no event, no packet on the step's own streams; 2-3 us from the
+ * store to the next kernel on `stream`. */
 #define NAVHIP_STAGE_NEIGHBOURS 0
 #define NAVHIP_STAGE_LISTS      1
 #define NAVHIP_STAGE_START      2
+#define NAVHIP_STAGE_END        3
 int  navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage);
 
 /* Per-kernel-group timing of the agent step with HIP events on the launch stream (bench.py's

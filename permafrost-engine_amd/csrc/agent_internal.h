@@ -33,7 +33,7 @@ void nh_launch_cohesion_regroup(const nh_step_params &P, int32_t *scratch, int *
 int nh_worklist_cap(int n_work);
 bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
-                            hipStream_t side, hipEvent_t ev[2], navhip_ctx *ctx = nullptr, int handovers = 0);
+                            hipStream_t side, navhip_ctx *ctx);
 void nh_launch_state_update(const nh_step_params &P, const navhip_state_in &in, float4 *d_arrived, int32_t *d_arrived_n, uint8_t *d_state, uint8_t *d_flags,
                             hipStream_t s);
 void nh_launch_region_lookup(const nh_step_params &P, int nq, const float *d_pos, const int32_t *d_rows,

@@ -1825,7 +1825,7 @@ int nh_worklist_cap(int n_work)
 // does not clear the other set either).
 bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_coh, nh_mid_rec *d_mid,
                             nh_worklists WL, int parity, const nh_step_outs &O, hipStream_t s,
-                            hipStream_t side, hipEvent_t ev[2], navhip_ctx *ctx, int handovers)
+                            hipStream_t side, navhip_ctx *ctx)
 {
     const int nwork = P.work_end - P.work_begin;
     if(!(P.n_ents > 0 && nwork > 0)) return false;
@@ -1840,43 +1840,38 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     // (17-64 neighbours).  Every wave / workgroup keeps drawing units until none are left.  (The workgroup problems on
     // a third stream beside the small ones were measured and lost -- one more fork and join on the agent stream, and in
     // a jam the searches race k_cp_rows for the chip instead of inheriting it: profiles/archive/r04_ab_cp_three_streams.txt.)
-    const bool fork = side && ev && ev[0] && ev[1];
+    // side: the fork.  Its hand-overs go through device memory (stream_set.hip): k_cp_rows -- it follows k_agent_mid on s --
+    // stores "the work lists are complete" when it starts, and a one-lane kernel in front of k_cp_small waits for that.
+    const bool fork = side != nullptr && side != s;
     hipStream_t sh = fork ? side : s;
-    // the hand-overs of the fork: through device memory (stream_set.hip) when the context has the words, else events
-    const bool ho_mid = fork && ctx && ctx->ho && ((handovers >> NH_HO_MID) & 1), ho_cp = fork && ctx && ctx->ho && ((handovers >> NH_HO_CP) & 1);
     nh_signal lists_ready = {nullptr, 0};
-    if(ho_mid) {
+    if(fork) {
         lists_ready.seq = nh_handover_next(ctx, NH_HO_MID);
         lists_ready.flag = ctx->ho->flags + NH_HO_MID * NH_HO_STRIDE;
-    }else if(fork) {
-        hipEventRecord(ev[0], s);
-        hipStreamWaitEvent(sh, ev[0], 0);
     }
-    if(ctx) ctx->lists_signalled = ho_mid;
+    ctx->lists_signalled = fork;
     const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
     const int nblk_rows = min(4096 / CPR_WAVES, (nwork + 15) / 16 * (CP_WAVES / CPR_WAVES) + 1);
     // (the rows first: behind a host that is not ahead of the device -- the tick after a synchronisation -- every
     // launch in front of it delays its start by one enqueue)
     hipLaunchKernelGGL(k_cp_rows, dim3(nblk_rows), dim3(CPR_WAVES * 64), 0, s, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_ROW3, 2, 0, lists_ready);
-    if(ho_mid) nh_handover_wait(ctx, NH_HO_MID, sh);
+    if(fork) nh_handover_wait(ctx, NH_HO_MID, sh);
     hipLaunchKernelGGL(k_cp_small, dim3((nwork / 4 + 2 * NH_WL_SUB + CPS_WAVES - 1) / CPS_WAVES + 1), dim3(CPS_WAVES * 64), 0, sh, P, NB,
                        (const nh_mid_rec*)d_mid, WL, O);
     hipLaunchKernelGGL(k_cp_rows, dim3(64 * CP_WAVES / CPR_WAVES), dim3(CPR_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O,
                        (int)NH_WL_RETRY, 1, 1, nh_signal{nullptr, 0});
     // (the last launch on `side` clears the other set of list counters: see k_cp_heavy)
     hipLaunchKernelGGL(k_cp_heavy, dim3(nblk), dim3(CP_WAVES * 64), 0, sh, P, NB, (const nh_mid_rec*)d_mid, WL, O, zero_next);
-    if(ho_cp)     nh_handover_signal(ctx, NH_HO_CP, sh);
-    else if(fork) hipEventRecord(ev[1], sh);
+    if(fork) nh_handover_signal(ctx, NH_HO_CP, sh);
     hipLaunchKernelGGL(k_agent_full, dim3(min(1024, (nwork + AG_WAVES - 1) / AG_WAVES)), dim3(AG_WAVES * 64), 0, s, P,
                        (const float*)d_coh, (const nh_mid_rec*)d_mid, WL, O, smf, thresh, (int32_t*)nullptr);
-    if(ho_cp) {
-        // (... and says that the step has ended: a prefetch that follows directly starts its side streams behind that)
-        const bool start = (handovers >> NH_HO_START) & 1;
-        nh_handover_wait(ctx, NH_HO_CP, s, -1, start ? NH_HO_START : -1);
-        if(start) ctx->step_end_on = s;
+    if(fork) {
+        // the join; the waiting kernel also says that the step has ended on s: a prefetch that follows directly starts its
+        // side streams behind that (NAVHIP_PREFETCH_FOLLOWS_STEP)
+        nh_handover_wait(ctx, NH_HO_CP, s, -1, NH_HO_START);
+        ctx->step_end_on = s;
     }
-    else if(fork) hipStreamWaitEvent(s, ev[1], 0);
     return true;
 }
 

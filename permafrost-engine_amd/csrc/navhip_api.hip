@@ -102,7 +102,6 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->coh_flocks = ctx->coh_members = -1;
     ctx->coh_parity = 0; ctx->coh_unique = 0;
     ctx->ev_regroup = nullptr;
-    for(auto &e : ctx->ev_cp) e = nullptr;
     ctx->regroup_pending = false;
     memset(ctx->coh_regroup_key, 0xff, sizeof(ctx->coh_regroup_key)); ctx->coh_regroup_age = 0;
     memset(&ctx->midrec, 0, sizeof(ctx->midrec));
@@ -111,8 +110,8 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     ctx->wl_parity = 0;
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
-    ctx->aux[0] = ctx->aux[1] = nullptr; ctx->aux_main = nullptr; ctx->ev_fork = nullptr; ctx->ev_join[0] = ctx->ev_join[1] = nullptr;
-    ctx->front_stream = nullptr; ctx->join0_recorded = ctx->join0_signalled = ctx->lists_signalled = ctx->fork_by_flag = false; ctx->step_end_on = nullptr;
+    ctx->aux[0] = ctx->aux[1] = nullptr; ctx->aux_main = nullptr;
+    ctx->front_stream = nullptr; ctx->join0_signalled = ctx->lists_signalled = false; ctx->step_end_on = nullptr;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
     ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->ho = nullptr; ctx->sp_builds = 0; ctx->lists_pinned = nullptr;
     memset(ctx->ev, 0, sizeof(ctx->ev));
@@ -153,10 +152,7 @@ void navhip_ctx_destroy(navhip_ctx *ctx)
     if(nh_streams_alive(ctx->device))
         for(auto &a : ctx->aux) if(a) hipStreamSynchronize(a);   // (borrowed: the process's own set, csrc/stream_set.hip)
     nh_handover_destroy(ctx);
-    if(ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-    for(auto &e : ctx->ev_join) if(e) hipEventDestroy(e);
     if(ctx->ev_regroup) hipEventDestroy(ctx->ev_regroup);
-    for(auto &e : ctx->ev_cp) if(e) hipEventDestroy(e);
     nh_streams_forget(ctx->device, ctx->stream);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -708,8 +704,8 @@ static int coh_scratch_ensure(navhip_ctx *ctx, int n_flocks, int n_members, hipS
     if(ctx->coh_plan.p != old || ctx->coh_flocks != n_flocks || ctx->coh_members != n_members) {
         // (scratch may still be in use by a regrouping on a side stream: order behind it)
         if(ctx->aux[1] && s != ctx->aux[1]) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
-            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_regroup, ctx->aux[1]));
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));
         }
         HIPCHK(ctx, nh_cohesion_scratch_reset((int32_t*)ctx->coh_plan.p, n_flocks, n_members, s));
         ctx->coh_flocks = n_flocks; ctx->coh_members = n_members; ctx->coh_parity = 0;
@@ -915,11 +911,7 @@ static int ensure_side_streams(navhip_ctx *ctx, hipStream_t main)
     hipStream_t st[NH_STREAM_FIXED];
     int rc = nh_streams_for(ctx, main, st);
     if(rc) return rc;
-    if(!ctx->ev_fork) {
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        for(auto &e : ctx->ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for(auto &e : ctx->ev_cp) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    if(!ctx->ev_regroup) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_regroup, hipEventDisableTiming));
     if(ctx->aux[0] && (ctx->aux[0] != st[NH_STREAM_SIDE0] || ctx->aux[1] != st[NH_STREAM_SIDE1])) {
         // another caller stream than last time: whatever the old side streams still hold is waited for
         for(auto a : ctx->aux) HIPCHK(ctx, hipStreamSynchronize(a));
@@ -929,13 +921,6 @@ static int ensure_side_streams(navhip_ctx *ctx, hipStream_t main)
     return nh_handover_ensure(ctx);
 }
 
-// (development switch, one bit per hand-over: NH_HO_COH | NH_HO_MID | NH_HO_CP | NH_HO_NBR | NH_HO_START)
-static int ho_mask()
-{
-    static const int m = getenv("NAVHIP_HANDOVER") ? atoi(getenv("NAVHIP_HANDOVER")) : 31;
-    return m;
-}
-static bool ho_on(int flag) { return (ho_mask() >> flag) & 1; }
 
 // The lane regrouping of the cohesion term (five small launches behind k_cohesion) is for the NEXT tick's launch
 // and only has to be spatially coherent: agents move about one world unit per tick and a group's box is compared
@@ -989,43 +974,35 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // critical path of the tick: NAVHIP_PREFETCH_FRONT_INLINE keeps it on the caller's stream, where it
     // follows the previous step without a cross-stream hand-over (tens of microseconds each)
     hipStream_t front = (flags & NAVHIP_PREFETCH_FRONT_INLINE) ? s : ctx->aux[0];
-    // The fork event for the cohesion stream (and for whoever waits for NAVHIP_STAGE_START) is one packet on the caller's
-    // stream, in FRONT of the first kernel of the front: the cohesion kernel ends last, so it must not start late
-    // (behind k_sp_count it delayed the cohesion kernel: 0.3205 -> 0.3166 ms per tick, profiles/archive/r03_ab_fork_first.txt).
-    // NAVHIP_PREFETCH_FOLLOWS_STEP: the snapshot was final when the last step on this stream ended, and that step stored
-    // a word behind its last kernel -- the side streams wait for the word, and no packet goes in front of the front at all
-    ctx->fork_by_flag = (flags & NAVHIP_PREFETCH_FOLLOWS_STEP) && ho_on(NH_HO_START) && ctx->step_end_on == s;
-    if(ctx->fork_by_flag) {
-        if(front != s) nh_handover_wait(ctx, NH_HO_START, ctx->aux[0]);
-        nh_handover_wait(ctx, NH_HO_START, ctx->aux[1]);
-    }else{
-        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-        if(front != s) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
-    }
-    // side stream 0: spatial hash -> neighbour walk (separation force + ClearPath neighbour lists)
+    // The side streams start behind a word in device memory (stream_set.hip: 2-3 us from the store to the waiting stream's
+    // next kernel, against 12 us and a packet on the caller's stream for an event).  NAVHIP_PREFETCH_FOLLOWS_STEP: the
+    // last step on this stream stored that word when it ended, and the snapshot was final then -- nothing goes in front
+    // of the front at all.  Otherwise a one-lane launch stores it now, in FRONT of the first kernel of the front: the
+    // cohesion kernel ends last, so it must not start late (profiles/archive/r03_ab_fork_first.txt).
+    if(!((flags & NAVHIP_PREFETCH_FOLLOWS_STEP) && ctx->step_end_on == s)) nh_handover_signal(ctx, NH_HO_START, s);
+    if(front != s) nh_handover_wait(ctx, NH_HO_START, ctx->aux[0]);
+    nh_handover_wait(ctx, NH_HO_START, ctx->aux[1]);
+    // side stream 1: cohesion -- enqueued first: it ends last, and a host that is not ahead of the device (the tick after a
+    // synchronisation) would otherwise hold it back by the front's six launches
+    const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
+                                            ctx->aux[1]);
+    nh_handover_signal(ctx, NH_HO_COH, ctx->aux[1]);
+    // the front: spatial hash -> neighbour walk (separation force + ClearPath neighbour lists)
     rc = spatial_build(ctx, w, &P.grid, front, P.work_begin, P.work_end);
     if(rc) return rc;
     nh_launch_agent_nbr(P, NB, front);
-    ctx->join0_recorded = false;
-    // (an inline front is ordered on the caller's stream by itself: its "done" event is only recorded
-    // when somebody asks for it -- every event on that stream is a packet on the tick's critical path)
-    if(front != s) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], front)); ctx->join0_recorded = true; }
+    // (an inline front is ordered on the caller's stream by itself: that it is done is stored by the step's own wait
+    // for the cohesion term, or by a launch of its own when somebody asks before -- navhip_stream_wait_stage)
+    ctx->join0_signalled = false;
+    if(front != s) { nh_handover_signal(ctx, NH_HO_NBR, front); ctx->join0_signalled = true; }
     ctx->front_stream = front;
     ctx->snapshot_held = (flags & NAVHIP_PREFETCH_SNAPSHOT_HELD) != 0;
-    // side stream 1: cohesion
-    const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
-                                            ctx->aux[1]);
-    if(ho_on(NH_HO_COH)) nh_handover_signal(ctx, NH_HO_COH, ctx->aux[1]);
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
-    ctx->join0_signalled = false;
-    // (behind the join event: the agent step does not wait for next tick's lane grouping; but the
+    // (behind the cohesion term's word: the agent step does not wait for next tick's lane grouping; but the
     // caller's stream does, at the end of navhip_agent_step_dev, so that whatever the caller does
     // to the snapshot arrays afterwards is ordered behind the last read of them)
     ctx->regroup_pending = false;
     if(regroup && coh_regroup_due(ctx, P)) {
         nh_launch_cohesion_regroup(P, (int32_t*)ctx->coh_plan.p, &ctx->coh_parity, ctx->aux[1]);
-        if(!ctx->ev_regroup) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_regroup, hipEventDisableTiming));
         HIPCHK(ctx, hipEventRecord(ctx->ev_regroup, ctx->aux[1]));
         ctx->regroup_pending = true;
     }
@@ -1078,9 +1055,8 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(ctx->pre.valid && !joined) {
         // a prefetch for another snapshot is in flight on the side streams: let it drain before
         // its scratch buffers are reused
-        if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
+        if(!ctx->join0_signalled) { nh_handover_signal(ctx, NH_HO_NBR, ctx->front_stream); ctx->join0_signalled = true; }
+        nh_handover_wait2(ctx, NH_HO_NBR, NH_HO_COH, s);
         if(ctx->regroup_pending) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_regroup, 0));
         ctx->regroup_pending = false;
     }
@@ -1096,21 +1072,17 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
         P.grid.cell_start = (int32_t*)ctx->sp[3].p; P.grid.recA = (const float4*)ctx->sp[7].p;
         P.grid.recV = (const float2*)ctx->sp[8].p; P.grid.pool_of = (const int32_t*)ctx->sp[9].p;
         P.grid.active = nullptr; P.grid.n_active = nullptr;       // (the walk, their only reader, ran with the prefetch)
+        // ONE launch on this stream waits for the cohesion term -- and for the front, when that ran elsewhere (the step is
+        // issued on another stream than the prefetch); behind an inline front it follows the neighbour walk, and says so
         if(ctx->front_stream != s) {
-            // (an inline front on THIS stream is ordered by itself; on another stream -- the step is
-            // issued elsewhere than the prefetch -- its "done" event may not have been recorded yet)
-            if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
-            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[0], 0));
+            if(!ctx->join0_signalled) { nh_handover_signal(ctx, NH_HO_NBR, ctx->front_stream); ctx->join0_signalled = true; }
+            nh_handover_wait2(ctx, NH_HO_NBR, NH_HO_COH, s);
+        }else{
+            nh_handover_wait(ctx, NH_HO_COH, s, ctx->join0_signalled ? -1 : NH_HO_NBR);
+            ctx->join0_signalled = true;
         }
-        if(ho_on(NH_HO_COH)) {
-            // (an inline front: the waiting kernel follows the neighbour walk on this stream, and says so)
-            const bool nbr = ho_on(NH_HO_NBR) && ctx->front_stream == s && !ctx->join0_signalled;
-            nh_handover_wait(ctx, NH_HO_COH, s, nbr ? NH_HO_NBR : -1);
-            if(nbr) ctx->join0_signalled = true;
-        }
-        else HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join[1], 0));
         if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                                  ctx->aux[0], ctx->ev_cp, ctx, ho_mask())) {
+                                  ctx->aux[0], ctx)) {
             rc = send_step_lists(ctx, ctx->wl_parity, s);
             ctx->wl_parity ^= 1;
             if(rc) return rc;
@@ -1140,7 +1112,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(prof) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     const bool serial = ctx->serial_step;
     if(nh_launch_agent_finish(P, NB, (float*)ctx->coh.p, (nh_mid_rec*)ctx->midrec.p, WL, ctx->wl_parity, O, s,
-                              serial ? nullptr : ctx->aux[0], ctx->ev_cp, ctx, serial ? 0 : ho_mask())) {
+                              serial ? nullptr : ctx->aux[0], ctx)) {
         rc = send_step_lists(ctx, ctx->wl_parity, s, serial);
         ctx->wl_parity ^= 1;
         if(rc) return rc;
@@ -1156,26 +1128,21 @@ int navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if(stage == NAVHIP_STAGE_NEIGHBOURS) {
         if(!ctx->front_stream) return NAVHIP_ERR_INVALID;
-        if(ctx->join0_signalled || (ho_on(NH_HO_NBR) && ctx->pre.valid)) {
-            // (between the prefetch and its step: a launch of its own behind the walk; after the step: the step's
-            // wait for the cohesion term has stored it)
-            if(!ctx->join0_signalled) { nh_handover_signal(ctx, NH_HO_NBR, ctx->front_stream); ctx->join0_signalled = true; }
-            nh_handover_wait(ctx, NH_HO_NBR, (hipStream_t)stream);
-            HIPCHK(ctx, hipGetLastError());
-            return NAVHIP_OK;
-        }
-        if(!ctx->join0_recorded) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->front_stream)); ctx->join0_recorded = true; }
-        HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join[0], 0));
+        // (between the prefetch and its step: a launch of its own behind the walk; after the step: the step's wait for
+        // the cohesion term has stored it)
+        if(!ctx->join0_signalled) { nh_handover_signal(ctx, NH_HO_NBR, ctx->front_stream); ctx->join0_signalled = true; }
+        nh_handover_wait(ctx, NH_HO_NBR, (hipStream_t)stream);
     }else if(stage == NAVHIP_STAGE_START) {
         if(!ctx->front_stream) return NAVHIP_ERR_INVALID;
-        if(ctx->fork_by_flag) nh_handover_wait(ctx, NH_HO_START, (hipStream_t)stream);
-        else                  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_fork, 0));
-    }
-    else if(stage == NAVHIP_STAGE_LISTS) {
-        if(ctx->lists_signalled) nh_handover_wait(ctx, NH_HO_MID, (hipStream_t)stream);      // (k_agent_mid stored it itself)
-        else                     HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cp[0], 0));
+        nh_handover_wait(ctx, NH_HO_START, (hipStream_t)stream);
+    }else if(stage == NAVHIP_STAGE_END) {
+        if(!ctx->step_end_on) return NAVHIP_ERR_INVALID;        // (the last step ran on one stream: its stream is its end)
+        nh_handover_wait(ctx, NH_HO_START, (hipStream_t)stream);
+    }else if(stage == NAVHIP_STAGE_LISTS) {
+        if(ctx->lists_signalled) nh_handover_wait(ctx, NH_HO_MID, (hipStream_t)stream);      // (else: one stream, nothing to wait for)
     }
     else return NAVHIP_ERR_INVALID;
+    HIPCHK(ctx, hipGetLastError());
     return NAVHIP_OK;
 }
 

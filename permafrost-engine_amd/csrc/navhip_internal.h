@@ -68,16 +68,13 @@ struct navhip_ctx {
     // set (nh_device_stream)
     hipStream_t  aux[2];
     hipStream_t  aux_main;          // the main stream the side streams were chosen for
-    hipEvent_t   ev_fork, ev_join[2], ev_regroup;
+    hipEvent_t   ev_regroup;        // side stream 1 has finished the lane regrouping (the only event of the step: rare, off the critical path)
     navhip_counters counters;       // navhip_get_counters
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
-    bool         join0_recorded;    // ev_join[0] has been recorded for the front of the last prefetch
-    bool         join0_signalled;   // ... NH_HO_NBR has been stored behind it
-    bool         lists_signalled;   // the last step's k_agent_mid stored NH_HO_MID (no ev_cp[0] was recorded)
+    bool         join0_signalled;   // NH_HO_NBR has been (or: is going to be, by a launch already enqueued) stored behind the front of the last prefetch
+    bool         lists_signalled;   // the last step forked: NH_HO_MID says when its work lists were complete
     hipStream_t  step_end_on;       // the stream on which the last step stored NH_HO_START behind its last kernel, or NULL
-    bool         fork_by_flag;      // the last prefetch started its side streams behind NH_HO_START (no ev_fork was recorded)
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
-    hipEvent_t   ev_cp[2];          // the ClearPath launches of the agent step: lists ready, side chain done
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
     bool         serial_step;       // navhip_agent_step_dev runs EVERYTHING on the caller's stream (no side streams, no events):
                                     // the tick of a small world is a chain of dependent launches, and every cross-stream
@@ -144,6 +141,7 @@ void     nh_handover_signal(navhip_ctx *ctx, int flag, hipStream_t producer);   
 // `consumer` continues when the flag's last producer has stored.  before / after (-1: none): words the waiting kernel
 // itself stores when it starts -- it follows their producer on `consumer` -- and when its wait is over
 void     nh_handover_wait(navhip_ctx *ctx, int flag, hipStream_t consumer, int before = -1, int after = -1);
+void     nh_handover_wait2(navhip_ctx *ctx, int flag_a, int flag_b, hipStream_t consumer);   // both, in one launch
 bool     nh_handover_failed(navhip_ctx *ctx);                                   // a wait gave up: ctx->last_error says so
 
 // pool_api.hip <-> navhip_api.hip

@@ -74,6 +74,23 @@ __global__ void k_ho_wait(const int32_t *flag, int32_t want, int32_t *status, nh
 #endif
 }
 
+__global__ void k_ho_wait2(const int32_t *flag_a, int32_t want_a, const int32_t *flag_b, int32_t want_b, int32_t *status)
+{
+#ifdef NH_HOSTSIM
+    if(*flag_a - want_a < 0 || *flag_b - want_b < 0) { fprintf(stderr, "k_ho_wait2: the producer of a hand-over was enqueued behind its consumer\n"); abort(); }
+#else
+    const long long t0 = wall_clock64();
+    while(__hip_atomic_load(flag_a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want_a < 0 ||
+          __hip_atomic_load(flag_b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want_b < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if(wall_clock64() - t0 > 200000000LL) {
+            __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+#endif
+}
+
 int nh_handover_ensure(navhip_ctx *ctx)
 {
     if(ctx->ho) return NAVHIP_OK;
@@ -120,6 +137,13 @@ void nh_handover_wait(navhip_ctx *ctx, int flag, hipStream_t consumer, int befor
     if(after >= 0)  { a.flag = H->flags + after * NH_HO_STRIDE;  a.seq = ++H->seq[after]; }
     hipLaunchKernelGGL(k_ho_wait, dim3(1), dim3(1), 0, consumer, (const int32_t*)(H->flags + flag * NH_HO_STRIDE), H->seq[flag],
                        H->status_dev, b, a);
+}
+
+void nh_handover_wait2(navhip_ctx *ctx, int flag_a, int flag_b, hipStream_t consumer)
+{
+    nh_handover *H = ctx->ho;
+    hipLaunchKernelGGL(k_ho_wait2, dim3(1), dim3(1), 0, consumer, (const int32_t*)(H->flags + flag_a * NH_HO_STRIDE), H->seq[flag_a],
+                       (const int32_t*)(H->flags + flag_b * NH_HO_STRIDE), H->seq[flag_b], H->status_dev);
 }
 
 bool nh_handover_failed(navhip_ctx *ctx)

@@ -40,6 +40,7 @@ struct navhip_tick {
     bool             ahead, pipelined, comm_pending, computed, serial;
     bool             follows;         // nothing came between the last tick's step and this tick on T->s
     bool             owns, stepped;   // NAVHIP_TICK_OWNS_SNAPSHOT; a tick has been computed
+    bool             step_flagged;    // the last step stored its end in device memory (no ev_step was recorded)
     int64_t          ticks;
     double           enqueue_ms;
     // NAVHIP_TICK_TIME_FIELDS: event pairs on the field stream around the builds of every fourth tick
@@ -119,6 +120,7 @@ static int compute_plain(navhip_tick *T)
         int rc = navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s);
         ctx->serial_step = false;
         if(rc) return rc;
+        T->step_flagged = false;
         if(T->pipelined) HIPCHK(ctx, hipEventRecord(T->ev_step, T->s));
         return NAVHIP_OK;
     }
@@ -138,7 +140,9 @@ static int compute_plain(navhip_tick *T)
         HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_fields[p], 0));       // this tick's fields (built during the last one)
         if(T->comm_pending) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_comm, 0));   // the other ranks' rows of the snapshot
         RCCHK(navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s));
-        if(T->pipelined) HIPCHK(ctx, hipEventRecord(T->ev_step, T->s));
+        // (a step that forked has said in device memory that it ended: the exchange waits for that word, not for an event)
+        T->step_flagged = ctx->step_end_on == T->s;
+        if(T->pipelined && !T->step_flagged) HIPCHK(ctx, hipEventRecord(T->ev_step, T->s));
         // the fields of the NEXT tick: enqueued behind the step -- the step's own wait for the cohesion term is the
         // launch that says "the neighbour walk is done" -- and started by the device as soon as that is so
         if(stage == NAVHIP_STAGE_NEIGHBOURS) RCCHK(navhip_stream_wait_stage(ctx, (void*)T->f, NAVHIP_STAGE_NEIGHBOURS));
@@ -157,6 +161,7 @@ static int compute_plain(navhip_tick *T)
     }
     if(T->comm_pending) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_comm, 0));   // the other ranks' rows of the snapshot
     RCCHK(navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s));
+    T->step_flagged = false;
     if(T->pipelined) HIPCHK(ctx, hipEventRecord(T->ev_step, T->s));
     return NAVHIP_OK;
 }
@@ -176,7 +181,8 @@ static int tick_exchange(navhip_tick *T)
     navhip_ctx *ctx = T->ctx;
     if(!T->pipelined) return NAVHIP_OK;
     const int p = (int)(T->ticks & 1);
-    HIPCHK(ctx, hipStreamWaitEvent(T->comm, T->ev_step, 0));
+    if(T->step_flagged) RCCHK(navhip_stream_wait_stage(ctx, (void*)T->comm, NAVHIP_STAGE_END));
+    else                HIPCHK(ctx, hipStreamWaitEvent(T->comm, T->ev_step, 0));
     RCCHK(navhip_comm_allgather_step_dev(ctx, T->O[p].new_pos_xz, T->O[p].vel_xz, T->bounds.data(), (void*)T->comm));
     HIPCHK(ctx, hipEventRecord(T->ev_comm, T->comm));
     T->comm_pending = true;

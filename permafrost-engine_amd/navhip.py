@@ -636,7 +636,7 @@ def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, rows=False):
     return out
 
 
-STAGE_NEIGHBOURS, STAGE_LISTS, STAGE_START = 0, 1, 2
+STAGE_NEIGHBOURS, STAGE_LISTS, STAGE_START, STAGE_END = 0, 1, 2, 3
 
 
 def _ctx_stream_wait_stage(self, stream, stage):

@@ -243,6 +243,47 @@ def test_step_joins_a_prefetch_issued_on_another_stream(navlib, small):
         assert np.array_equal(st.cpu().numpy(), exp["status"])
 
 
+def test_stage_waits_order_a_third_stream_behind_the_step(navlib, small):
+    """navhip_stream_wait_stage from a stream the step does not know: the stages are words in device memory a one-lane
+    kernel on that stream waits for (csrc/stream_set.hip).  A copy of the outputs taken on the third stream behind
+    NAVHIP_STAGE_END -- and nothing else: only the third stream is synchronised -- is the step's result, tick after
+    tick, with the prefetch of every tick but the first started behind the end of the last step
+    (NAVHIP_PREFETCH_FOLLOWS_STEP)."""
+    import torch
+    ctx, reqs, cols, W, K, N = small["ctx"], small["reqs"], small["cols"], small["W"], small["K"], small["N"]
+    dirs, _ = ctx.N_FlowFieldUpdate(reqs)
+    slot = -np.ones((K, W * W), np.int32)
+    slot[cols["dest"], cols["chunk_r"] * W + cols["chunk_c"]] = np.arange(len(reqs))
+    a = dict(small["arrays"], flock_field_slot=slot, field_pool=dirs.reshape(len(dirs), 4096))
+    exp = ctx.agent_step(a)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in a.items() if v is not None}
+    world, keep = navlib.make_world(W, W, t, hz=20)
+    vel = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+    pos = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+    st = torch.zeros(N, dtype=torch.uint8, device=dev)
+    out = navlib.StepOut()
+    out.vel_xz, out.new_pos_xz, out.status = vel.data_ptr(), pos.data_ptr(), st.data_ptr()
+    sa, sc = torch.cuda.ExternalStream(ctx.stream_main()), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for it in range(12):
+        with torch.cuda.stream(sa):
+            vel.zero_(); st.zero_()                     # (on the step's stream, in front of the prefetch: not a snapshot array)
+        flags = navlib.PREFETCH_FRONT_INLINE | (navlib.PREFETCH_FOLLOWS_STEP if it else 0)
+        ctx.agent_prefetch_dev(world, stream=sa.cuda_stream, flags=flags)
+        if it % 2:
+            ctx.stream_wait_stage(sc.cuda_stream, navlib.STAGE_NEIGHBOURS)     # (between the prefetch and the step)
+        ctx.agent_step_dev(world, out, stream=sa.cuda_stream)
+        for stage in (navlib.STAGE_START, navlib.STAGE_NEIGHBOURS, navlib.STAGE_LISTS, navlib.STAGE_END):
+            ctx.stream_wait_stage(sc.cuda_stream, stage)
+        with torch.cuda.stream(sc):
+            v, s_ = vel.clone(), st.clone()
+        sc.synchronize()
+        assert np.array_equal(v.cpu().numpy(), exp["vel_xz"]), it
+        assert np.array_equal(s_.cpu().numpy(), exp["status"]), it
+    torch.cuda.synchronize()
+
+
 def test_async_step_equals_the_blocking_one(navlib, small):
     ctx, reqs, cols, W, K = small["ctx"], small["reqs"], small["cols"], small["W"], small["K"]
     ctx.pool_create(len(reqs), K)
