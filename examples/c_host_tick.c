@@ -95,6 +95,7 @@ int main(int argc, char **argv)
         d.field_pool_1 = pool1;
         d.fields_stage = NAVHIP_STAGE_NEIGHBOURS;
     }
+    d.flags |= NAVHIP_TICK_OWNS_SNAPSHOT;   /* nothing but the tick writes the snapshot buffers or uses its stream between ticks */
 
     navhip_tick *tick = NULL;
     CHECK(navhip_tick_create(ctx, &d, &tick));

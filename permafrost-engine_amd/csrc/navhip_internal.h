@@ -73,6 +73,7 @@ struct navhip_ctx {
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
     bool         join0_signalled;   // NH_HO_NBR has been (or: is going to be, by a launch already enqueued) stored behind the front of the last prefetch
     bool         lists_signalled;   // the last step forked: NH_HO_MID says when its work lists were complete
+    int32_t      start_seq;         // NH_HO_START's number at the last prefetch: what its side streams wait for (a step's end advances the word)
     hipStream_t  step_end_on;       // the stream on which the last step stored NH_HO_START behind its last kernel, or NULL
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
@@ -142,6 +143,8 @@ void     nh_handover_signal(navhip_ctx *ctx, int flag, hipStream_t producer);   
 // itself stores when it starts -- it follows their producer on `consumer` -- and when its wait is over
 void     nh_handover_wait(navhip_ctx *ctx, int flag, hipStream_t consumer, int before = -1, int after = -1);
 void     nh_handover_wait2(navhip_ctx *ctx, int flag_a, int flag_b, hipStream_t consumer);   // both, in one launch
+int32_t  nh_handover_seq(navhip_ctx *ctx, int flag);                                         // the number of the flag's last producer
+void     nh_handover_wait_for(navhip_ctx *ctx, int flag, int32_t want, hipStream_t consumer); // ... of an earlier one (nh_handover_seq then)
 bool     nh_handover_failed(navhip_ctx *ctx);                                   // a wait gave up: ctx->last_error says so
 
 // pool_api.hip <-> navhip_api.hip

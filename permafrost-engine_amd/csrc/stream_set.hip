@@ -62,14 +62,17 @@ __global__ void k_ho_wait(const int32_t *flag, int32_t want, int32_t *status, nh
     if(after.flag) *after.flag = after.seq;
 #else
     if(before.flag) __hip_atomic_store(before.flag, before.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // (relaxed polls -- a load that goes to the L2, no cache invalidate on this compute unit while others work on it --
+    // and ONE acquire when the number has arrived)
     const long long t0 = wall_clock64();
-    while(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
-        __builtin_amdgcn_s_sleep(2);
+    while(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+        __builtin_amdgcn_s_sleep(8);
         if(wall_clock64() - t0 > 200000000LL) {                   // two seconds at 100 MHz: never hang the device
             __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if(after.flag) __hip_atomic_store(after.flag, after.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
@@ -80,14 +83,15 @@ __global__ void k_ho_wait2(const int32_t *flag_a, int32_t want_a, const int32_t 
     if(*flag_a - want_a < 0 || *flag_b - want_b < 0) { fprintf(stderr, "k_ho_wait2: the producer of a hand-over was enqueued behind its consumer\n"); abort(); }
 #else
     const long long t0 = wall_clock64();
-    while(__hip_atomic_load(flag_a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want_a < 0 ||
-          __hip_atomic_load(flag_b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want_b < 0) {
-        __builtin_amdgcn_s_sleep(2);
+    while(__hip_atomic_load(flag_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want_a < 0 ||
+          __hip_atomic_load(flag_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want_b < 0) {
+        __builtin_amdgcn_s_sleep(8);
         if(wall_clock64() - t0 > 200000000LL) {
             __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
 #endif
 }
 
@@ -132,12 +136,23 @@ void nh_handover_signal(navhip_ctx *ctx, int flag, hipStream_t producer)
 void nh_handover_wait(navhip_ctx *ctx, int flag, hipStream_t consumer, int before, int after)
 {
     nh_handover *H = ctx->ho;
+    const int32_t want = H->seq[flag];
     nh_signal b = {nullptr, 0}, a = {nullptr, 0};
     if(before >= 0) { b.flag = H->flags + before * NH_HO_STRIDE; b.seq = ++H->seq[before]; }
     if(after >= 0)  { a.flag = H->flags + after * NH_HO_STRIDE;  a.seq = ++H->seq[after]; }
-    hipLaunchKernelGGL(k_ho_wait, dim3(1), dim3(1), 0, consumer, (const int32_t*)(H->flags + flag * NH_HO_STRIDE), H->seq[flag],
+    hipLaunchKernelGGL(k_ho_wait, dim3(1), dim3(1), 0, consumer, (const int32_t*)(H->flags + flag * NH_HO_STRIDE), want,
                        H->status_dev, b, a);
 }
+
+// ... for an earlier number of the word than its last producer's (what nh_handover_seq said then)
+void nh_handover_wait_for(navhip_ctx *ctx, int flag, int32_t want, hipStream_t consumer)
+{
+    nh_handover *H = ctx->ho;
+    hipLaunchKernelGGL(k_ho_wait, dim3(1), dim3(1), 0, consumer, (const int32_t*)(H->flags + flag * NH_HO_STRIDE), want,
+                       H->status_dev, nh_signal{nullptr, 0}, nh_signal{nullptr, 0});
+}
+
+int32_t nh_handover_seq(navhip_ctx *ctx, int flag) { return ctx->ho->seq[flag]; }
 
 void nh_handover_wait2(navhip_ctx *ctx, int flag_a, int flag_b, hipStream_t consumer)
 {
