@@ -1844,11 +1844,7 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     // stores "the work lists are complete" when it starts, and a one-lane kernel in front of k_cp_small waits for that.
     const bool fork = side != nullptr && side != s;
     hipStream_t sh = fork ? side : s;
-    nh_signal lists_ready = {nullptr, 0};
-    if(fork) {
-        lists_ready.seq = nh_handover_next(ctx, NH_HO_MID);
-        lists_ready.flag = ctx->ho->flags + NH_HO_MID * NH_HO_STRIDE;
-    }
+    const nh_signal lists_ready = fork ? nh_handover_by_kernel(ctx, NH_HO_MID, s) : nh_signal{nullptr, 0};
     ctx->lists_signalled = fork;
     const int nblk = min(4096 / CP_WAVES, (nwork + 15) / 16 + 1);      // 4096 persistent waves: four per SIMD
     const int nblk_rows = min(4096 / CPR_WAVES, (nwork + 15) / 16 * (CP_WAVES / CPR_WAVES) + 1);
@@ -1869,7 +1865,7 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
     if(fork) {
         // the join; the waiting kernel also says that the step has ended on s: a prefetch that follows directly starts its
         // side streams behind that (NAVHIP_PREFETCH_FOLLOWS_STEP)
-        nh_handover_wait(ctx, NH_HO_CP, s, -1, NH_HO_START);
+        nh_handover_wait(ctx, NH_HO_CP, s, -1, NH_HO_END);
         ctx->step_end_on = s;
     }
     return true;

@@ -111,7 +111,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->aux_main = nullptr;
-    ctx->front_stream = nullptr; ctx->join0_signalled = ctx->lists_signalled = false; ctx->step_end_on = nullptr; ctx->start_seq = 0;
+    ctx->front_stream = nullptr; ctx->join0_signalled = ctx->lists_signalled = false; ctx->step_end_on = nullptr; ctx->start_seq = 0; ctx->start_flag = NH_HO_START;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
     ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->ho = nullptr; ctx->sp_builds = 0; ctx->lists_pinned = nullptr;
     memset(ctx->ev, 0, sizeof(ctx->ev));
@@ -979,10 +979,12 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // last step on this stream stored that word when it ended, and the snapshot was final then -- nothing goes in front
     // of the front at all.  Otherwise a one-lane launch stores it now, in FRONT of the first kernel of the front: the
     // cohesion kernel ends last, so it must not start late (profiles/archive/r03_ab_fork_first.txt).
-    if(!((flags & NAVHIP_PREFETCH_FOLLOWS_STEP) && ctx->step_end_on == s)) nh_handover_signal(ctx, NH_HO_START, s);
-    ctx->start_seq = nh_handover_seq(ctx, NH_HO_START);
-    if(front != s) nh_handover_wait(ctx, NH_HO_START, ctx->aux[0]);
-    nh_handover_wait(ctx, NH_HO_START, ctx->aux[1]);
+    const bool follows = (flags & NAVHIP_PREFETCH_FOLLOWS_STEP) && ctx->step_end_on == s && !ctx->ho->by_events;
+    if(!follows) nh_handover_signal(ctx, NH_HO_START, s);
+    ctx->start_flag = follows ? NH_HO_END : NH_HO_START;
+    ctx->start_seq = nh_handover_seq(ctx, ctx->start_flag);
+    if(front != s) nh_handover_wait(ctx, ctx->start_flag, ctx->aux[0]);
+    nh_handover_wait(ctx, ctx->start_flag, ctx->aux[1]);
     // side stream 1: cohesion -- enqueued first: it ends last, and a host that is not ahead of the device (the tick after a
     // synchronisation) would otherwise hold it back by the front's six launches
     const bool regroup = nh_launch_cohesion(P, (int32_t*)ctx->coh_plan.p, (float*)ctx->coh.p, &ctx->coh_parity,
@@ -1135,10 +1137,10 @@ int navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage)
         nh_handover_wait(ctx, NH_HO_NBR, (hipStream_t)stream);
     }else if(stage == NAVHIP_STAGE_START) {
         if(!ctx->front_stream) return NAVHIP_ERR_INVALID;
-        nh_handover_wait_for(ctx, NH_HO_START, ctx->start_seq, (hipStream_t)stream);     // (not the step's end, if that has been enqueued since)
+        nh_handover_wait_for(ctx, ctx->start_flag, ctx->start_seq, (hipStream_t)stream);  // (not the end of a step enqueued since)
     }else if(stage == NAVHIP_STAGE_END) {
         if(!ctx->step_end_on) return NAVHIP_ERR_INVALID;        // (the last step ran on one stream: its stream is its end)
-        nh_handover_wait(ctx, NH_HO_START, (hipStream_t)stream);
+        nh_handover_wait(ctx, NH_HO_END, (hipStream_t)stream);
     }else if(stage == NAVHIP_STAGE_LISTS) {
         if(ctx->lists_signalled) nh_handover_wait(ctx, NH_HO_MID, (hipStream_t)stream);      // (else: one stream, nothing to wait for)
     }

@@ -73,7 +73,8 @@ struct navhip_ctx {
     bool         snapshot_held;     // NAVHIP_PREFETCH_SNAPSHOT_HELD of the last prefetch
     bool         join0_signalled;   // NH_HO_NBR has been (or: is going to be, by a launch already enqueued) stored behind the front of the last prefetch
     bool         lists_signalled;   // the last step forked: NH_HO_MID says when its work lists were complete
-    int32_t      start_seq;         // NH_HO_START's number at the last prefetch: what its side streams wait for (a step's end advances the word)
+    int          start_flag;        // what the side streams of the last prefetch wait for: NH_HO_START, or NH_HO_END of the step it follows,
+    int32_t      start_seq;         // ... and the word's number then (later steps advance it)
     hipStream_t  step_end_on;       // the stream on which the last step stored NH_HO_START behind its last kernel, or NULL
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet
@@ -123,7 +124,8 @@ enum { NH_HO_COH = 0,           // the cohesion term            (side stream 1 -
        NH_HO_MID,               // k_agent_mid's work lists      (the agent chain -> side stream 0), stored by the kernel itself
        NH_HO_CP,                // the ClearPath side chain      (side stream 0 -> the agent chain)
        NH_HO_NBR,               // spatial hash + neighbour walk (the agent chain -> whoever waits for NAVHIP_STAGE_NEIGHBOURS)
-       NH_HO_START,             // the end of a step on the agent chain (-> the side streams of a prefetch that follows it directly)
+       NH_HO_START,             // what the caller's stream had reached at a prefetch (-> its side streams)
+       NH_HO_END,               // the end of a step on the agent chain (-> the side streams of a prefetch that follows it directly, the exchange)
        NH_HO_FLAGS };
 #define NH_HO_STRIDE 32         /* one 128-byte line per word; the ticket of a kernel that signals itself is the word + 1 */
 // a number for a word, as a kernel argument: stored by a kernel that FOLLOWS the producer on its stream (its first
@@ -134,10 +136,19 @@ struct nh_handover {
     int32_t *status;            // pinned host word (device pointer: status_dev): a wait that gave up after two seconds stores 1
     int32_t *status_dev;
     int32_t  seq[NH_HO_FLAGS];  // the number the last producer of a flag stores
+    // NAVHIP_HANDOVER=events (read when the context gets its side streams; the default under rocprofv3 --pmc, which says so
+    // in ROCPROF_COUNTER_COLLECTION; NAVHIP_HANDOVER=words overrides): every word is an event instead -- record on the
+    // producer's stream, event wait on the consumer's; 12 us per hand-over, as before round 6.  For a profiler that
+    // SERIALISES kernels (counter collection: one kernel on the device at a time, and not in the order of submission): a
+    // kernel that waits for a kernel of another queue never ends there.
+    bool       by_events;
+    hipEvent_t ev[NH_HO_FLAGS];
 };
 int      nh_handover_ensure(navhip_ctx *ctx);                                   // NAVHIP_OK, or an error with ctx->last_error
 void     nh_handover_destroy(navhip_ctx *ctx);
-int32_t  nh_handover_next(navhip_ctx *ctx, int flag);                          // the next producer's number (for a kernel that signals itself)
+// for a kernel that FOLLOWS the producer on `producer` and stores the number itself when it starts: its argument
+// ({nullptr, 0} with events: the event is recorded here, in front of that kernel)
+nh_signal nh_handover_by_kernel(navhip_ctx *ctx, int flag, hipStream_t producer);
 void     nh_handover_signal(navhip_ctx *ctx, int flag, hipStream_t producer);   // behind everything enqueued on `producer` so far
 // `consumer` continues when the flag's last producer has stored.  before / after (-1: none): words the waiting kernel
 // itself stores when it starts -- it follows their producer on `consumer` -- and when its wait is over

@@ -34,11 +34,14 @@
 // queues: their work interleaves in stream order, which adds ordering, never removes any.
 // ---------------------------------------------------------------------------------------------------------------
 #define NH_PIPES 4
-__global__ void k_nh_spin(long long ticks)
+__global__ void k_nh_spin(long long ticks, int32_t *word, int32_t seq)
 {
 #ifndef NH_HOSTSIM
     const long long t0 = wall_clock64();
     while(wall_clock64() - t0 < ticks) { }
+    if(word) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    if(word) *word = seq;
 #endif
 }
 
@@ -112,6 +115,13 @@ int nh_handover_ensure(navhip_ctx *ctx)
         return NAVHIP_ERR_NOMEM;
     }
     *H->status = 0;
+    // (rocprofv3 --pmc exports ROCPROF_COUNTER_COLLECTION to the process it profiles: counter collection serialises kernels)
+    const char *mode = getenv("NAVHIP_HANDOVER"), *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
+    const bool serialised = pmc && *pmc && strcmp(pmc, "0") && strcmp(pmc, "False") && strcmp(pmc, "false");
+    H->by_events = mode ? !strcmp(mode, "events") : serialised;
+    if(H->by_events)
+        for(auto &e : H->ev)
+            if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->last_error = "hand-over events"; ctx->ho = H; nh_handover_destroy(ctx); return NAVHIP_ERR_DEVICE; }
     ctx->ho = H;
     return NAVHIP_OK;
 }
@@ -119,23 +129,37 @@ int nh_handover_ensure(navhip_ctx *ctx)
 void nh_handover_destroy(navhip_ctx *ctx)
 {
     if(!ctx->ho) return;
+    for(auto &e : ctx->ho->ev) if(e) hipEventDestroy(e);
     hipFree(ctx->ho->flags);
     hipHostFree(ctx->ho->status);
     delete ctx->ho;
     ctx->ho = nullptr;
 }
 
-int32_t nh_handover_next(navhip_ctx *ctx, int flag) { return ++ctx->ho->seq[flag]; }
+nh_signal nh_handover_by_kernel(navhip_ctx *ctx, int flag, hipStream_t producer)
+{
+    nh_handover *H = ctx->ho;
+    ++H->seq[flag];
+    if(H->by_events) { hipEventRecord(H->ev[flag], producer); return nh_signal{nullptr, 0}; }
+    return nh_signal{H->flags + flag * NH_HO_STRIDE, H->seq[flag]};
+}
 
 void nh_handover_signal(navhip_ctx *ctx, int flag, hipStream_t producer)
 {
     nh_handover *H = ctx->ho;
+    if(H->by_events) { ++H->seq[flag]; hipEventRecord(H->ev[flag], producer); return; }
     hipLaunchKernelGGL(k_ho_signal, dim3(1), dim3(1), 0, producer, H->flags + flag * NH_HO_STRIDE, ++H->seq[flag]);
 }
 
 void nh_handover_wait(navhip_ctx *ctx, int flag, hipStream_t consumer, int before, int after)
 {
     nh_handover *H = ctx->ho;
+    if(H->by_events) {
+        if(before >= 0) { ++H->seq[before]; hipEventRecord(H->ev[before], consumer); }
+        hipStreamWaitEvent(consumer, H->ev[flag], 0);
+        if(after >= 0) { ++H->seq[after]; hipEventRecord(H->ev[after], consumer); }
+        return;
+    }
     const int32_t want = H->seq[flag];
     nh_signal b = {nullptr, 0}, a = {nullptr, 0};
     if(before >= 0) { b.flag = H->flags + before * NH_HO_STRIDE; b.seq = ++H->seq[before]; }
@@ -148,6 +172,8 @@ void nh_handover_wait(navhip_ctx *ctx, int flag, hipStream_t consumer, int befor
 void nh_handover_wait_for(navhip_ctx *ctx, int flag, int32_t want, hipStream_t consumer)
 {
     nh_handover *H = ctx->ho;
+    // (an event has no history: the callers keep to words whose event is not recorded again in between -- NH_HO_START)
+    if(H->by_events) { hipStreamWaitEvent(consumer, H->ev[flag], 0); return; }
     hipLaunchKernelGGL(k_ho_wait, dim3(1), dim3(1), 0, consumer, (const int32_t*)(H->flags + flag * NH_HO_STRIDE), want,
                        H->status_dev, nh_signal{nullptr, 0}, nh_signal{nullptr, 0});
 }
@@ -157,6 +183,7 @@ int32_t nh_handover_seq(navhip_ctx *ctx, int flag) { return ctx->ho->seq[flag]; 
 void nh_handover_wait2(navhip_ctx *ctx, int flag_a, int flag_b, hipStream_t consumer)
 {
     nh_handover *H = ctx->ho;
+    if(H->by_events) { hipStreamWaitEvent(consumer, H->ev[flag_a], 0); hipStreamWaitEvent(consumer, H->ev[flag_b], 0); return; }
     hipLaunchKernelGGL(k_ho_wait2, dim3(1), dim3(1), 0, consumer, (const int32_t*)(H->flags + flag_a * NH_HO_STRIDE), H->seq[flag_a],
                        (const int32_t*)(H->flags + flag_b * NH_HO_STRIDE), H->seq[flag_b], H->status_dev);
 }
@@ -164,7 +191,8 @@ void nh_handover_wait2(navhip_ctx *ctx, int flag_a, int flag_b, hipStream_t cons
 bool nh_handover_failed(navhip_ctx *ctx)
 {
     if(!ctx->ho || !*(volatile int32_t*)ctx->ho->status) return false;
-    ctx->last_error = "a hand-over between two streams of the agent step was not signalled within two seconds";
+    ctx->last_error = "a hand-over between two streams of the agent step was not signalled within two seconds (under a profiler "
+                      "that serialises kernels -- rocprofv3 --pmc -- run with NAVHIP_HANDOVER=events)";
     return true;
 }
 
@@ -174,10 +202,14 @@ struct nh_dev_streams {
     hipStream_t full[NH_PIPES] = {};                         // pairwise on different pipes (as measured)
     std::map<std::pair<int, int>, std::array<hipStream_t, NH_PIPES>> partial;   // [k]: on the pipe of full[k]
     std::map<hipStream_t, int> caller_pipe;                  // caller's stream -> k of the full stream whose pipe it shares, -1: none
-    hipEvent_t  ea = nullptr, eb = nullptr;
+    int32_t    *words = nullptr, *status = nullptr, *status_dev = nullptr;   // two words in device memory + a pinned status word
+    int32_t     seq = 0;
+    bool        unmeasured = false;                          // under a profiler that serialises kernels nothing is timed
     double      base_us = 0.0;                               // round trip between two streams on different pipes
     int         measured_pairs = 0, collisions_seen = 0;
 };
+// same pipe: the round trip of the probe takes 58-69 us instead of 23-24 (profiles/r06_stream_flag_probe.txt)
+#define NH_SAME_PIPE 1.6
 std::mutex g_streams_mu;
 std::map<int, nh_dev_streams> g_streams;
 
@@ -195,7 +227,8 @@ hipStream_t masked_stream(navhip_ctx *ctx, int cu_begin, int cu_count)
     return st;
 }
 
-// microseconds per round trip a -> b -> a of two 10-us kernels, everything enqueued up front (both streams idle first)
+// microseconds per round trip a -> b -> a of two 10-us kernels that hand over the way the step's streams do -- the first
+// stores a word when it ends, a one-lane kernel on the other stream waits for it --, everything enqueued up front
 double pingpong_us(nh_dev_streams &D, hipStream_t a, hipStream_t b, int rounds)
 {
 #ifdef NH_HOSTSIM
@@ -204,56 +237,41 @@ double pingpong_us(nh_dev_streams &D, hipStream_t a, hipStream_t b, int rounds)
     if(hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1.0;
     const auto t0 = std::chrono::steady_clock::now();
     for(int r = 0; r < rounds; r++) {
-        hipLaunchKernelGGL(k_nh_spin, dim3(1), dim3(64), 0, a, 1000LL);        // (wall_clock64: 100 MHz)
-        hipEventRecord(D.ea, a);
-        hipStreamWaitEvent(b, D.ea, 0);
-        hipLaunchKernelGGL(k_nh_spin, dim3(1), dim3(64), 0, b, 1000LL);
-        hipEventRecord(D.eb, b);
-        hipStreamWaitEvent(a, D.eb, 0);
+        const int32_t n = ++D.seq;
+        hipLaunchKernelGGL(k_nh_spin, dim3(1), dim3(64), 0, a, 1000LL, D.words, n);        // (wall_clock64: 100 MHz)
+        hipLaunchKernelGGL(k_ho_wait, dim3(1), dim3(1), 0, b, (const int32_t*)D.words, n, D.status_dev, nh_signal{nullptr, 0}, nh_signal{nullptr, 0});
+        hipLaunchKernelGGL(k_nh_spin, dim3(1), dim3(64), 0, b, 1000LL, D.words + NH_HO_STRIDE, n);
+        hipLaunchKernelGGL(k_ho_wait, dim3(1), dim3(1), 0, a, (const int32_t*)(D.words + NH_HO_STRIDE), n, D.status_dev, nh_signal{nullptr, 0},
+                           nh_signal{nullptr, 0});
     }
     if(hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1.0;
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
 #endif
 }
 
-// the slower direction of the hand-over between a and b (the penalty of a shared pipe depends on who polls)
+// the slower direction of the hand-over between a and b
 double handover_us(nh_dev_streams &D, hipStream_t a, hipStream_t b)
 {
+    if(D.unmeasured) return 0.0;
     pingpong_us(D, a, b, 4);                                           // (first use of a stream creates its queue)
     const double ab = pingpong_us(D, a, b, 24), ba = pingpong_us(D, b, a, 24);
     const double worst = ab > ba ? ab : ba;
     D.measured_pairs++;
     if(D.base_us <= 0.0 || (worst > 0.0 && worst < D.base_us)) D.base_us = worst;      // (the fastest pair seen so far)
     static const bool dbg = getenv("NAVHIP_STREAM_DEBUG") != nullptr;
-    if(dbg) fprintf(stderr, "navhip streams: %p <-> %p  %.0f / %.0f us per round trip (fastest pair %.0f)%s\n", (void*)a, (void*)b, ab, ba,
-                    D.base_us, worst > 1.3 * D.base_us ? "  -> same pipe" : "");
+    if(dbg) fprintf(stderr, "navhip streams: %p <-> %p  %.0f / %.0f us per round trip (fastest pair %.0f)\n", (void*)a, (void*)b, ab, ba, D.base_us);
     return worst;
 }
 
-// do a and b hand over like two queues on ONE pipe?  (44-46 us against 60-200 on this chip: the threshold sits at 1.3x)
-bool same_pipe(nh_dev_streams &D, hipStream_t a, hipStream_t b)
-{
-    if(a == b) return true;
-    const bool hit = handover_us(D, a, b) > 1.3 * D.base_us;
-    D.collisions_seen += hit;
-    return hit;
-}
-
-// which of the four full streams shares its pipe with s: ALL four are measured and the slowest hand-over names it (the
-// first one above the threshold may be a disturbed measurement, and a wrong answer puts a side stream onto the caller's
-// pipe); -1: none stands out
+// which of the four full streams shares its pipe with s: all four are measured and the slowest hand-over names it; -1:
+// none stands out (s has a pipe to itself, or nothing is being measured)
 int pipe_among_full(nh_dev_streams &D, hipStream_t s)
 {
+    if(D.unmeasured) return -1;
     double us[NH_PIPES];
     int best = 0;
     for(int k = 0; k < NH_PIPES; k++) { us[k] = handover_us(D, s, D.full[k]); if(us[k] > us[best]) best = k; }
-    if(!(us[best] > 1.3 * D.base_us)) return -1;
-    // (a second look when another stream is close to the slowest: measurement noise of the moment)
-    for(int k = 0; k < NH_PIPES; k++)
-        if(k != best && us[k] > 1.15 * D.base_us) {
-            const double again_best = handover_us(D, s, D.full[best]), again_k = handover_us(D, s, D.full[k]);
-            if(again_k > again_best) best = k;
-        }
+    if(!(us[best] > NH_SAME_PIPE * D.base_us)) return -1;
     D.collisions_seen++;
     return best;
 }
@@ -269,37 +287,46 @@ void streams_atexit()
         if(hipSetDevice(kv.first) != hipSuccess) continue;
         for(auto &st : D.full) if(st) { hipStreamSynchronize(st); hipStreamDestroy(st); st = nullptr; }
         for(auto &pk : D.partial) for(auto &st : pk.second) if(st) { hipStreamSynchronize(st); hipStreamDestroy(st); st = nullptr; }
-        if(D.ea) hipEventDestroy(D.ea);
-        if(D.eb) hipEventDestroy(D.eb);
-        D.ea = D.eb = nullptr; D.ready = false;
+        if(D.words) hipFree(D.words);
+        if(D.status) hipHostFree(D.status);
+        D.words = D.status = D.status_dev = nullptr; D.ready = false;
         D.caller_pipe.clear(); D.partial.clear();
     }
 }
 
-// four masked streams on four different pipes.  Consecutive creations land on consecutive pipes; that is verified, and a
-// candidate that shares a pipe with an earlier pick is replaced (at most eight tries: then it stays, results are the same)
+// Four masked streams on four different pipes.  Consecutive creations land on consecutive pipes; that is verified: every
+// pair of the four is timed, and while a pair hands over like two queues on one pipe its later stream is replaced (the
+// rejected candidates stay alive until the set is complete -- their queues keep their pipe slots --; at most eight
+// replacements, then the set stays as it is: results never depend on it).
 bool streams_init(navhip_ctx *ctx, nh_dev_streams &D)
 {
     if(D.ready) return true;
     static const bool registered = (atexit(streams_atexit), true);
     (void)registered;
-    if(hipEventCreateWithFlags(&D.ea, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.eb, hipEventDisableTiming) != hipSuccess) {
-        ctx->last_error = "hipEventCreate failed";
-        return false;
-    }
-    std::vector<hipStream_t> rejected;
-    int tries = 0;
-    for(int k = 0; k < NH_PIPES; k++) {
-        for(;;) {
-            hipStream_t c = masked_stream(ctx, 0, 0);
-            if(!c) return false;
-            bool clash = false;
-            // (the first measurement of all fixes base_us: take it between the first two candidates twice)
-            for(int j = 0; j < k && !clash; j++) clash = same_pipe(D, D.full[j], c);
-            if(k == 1 && !clash && D.measured_pairs == 1) same_pipe(D, D.full[0], c);
-            if(!clash || ++tries >= 8) { D.full[k] = c; break; }
-            rejected.push_back(c);                 // (kept alive until the set is complete: its queue keeps its pipe slot)
+    // (rocprofv3 --pmc: kernels are serialised, a kernel that waits for another never ends, and no timing means anything)
+    const char *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
+    D.unmeasured = pmc && *pmc && strcmp(pmc, "0") && strcmp(pmc, "False") && strcmp(pmc, "false");
+    if(!D.unmeasured) {
+        if(hipMalloc((void**)&D.words, sizeof(int32_t) * 2 * NH_HO_STRIDE) != hipSuccess ||
+           hipMemset(D.words, 0, sizeof(int32_t) * 2 * NH_HO_STRIDE) != hipSuccess ||
+           hipHostMalloc((void**)&D.status, sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+           hipHostGetDevicePointer((void**)&D.status_dev, D.status, 0) != hipSuccess) {
+            ctx->last_error = "stream set: out of memory";
+            return false;
         }
+        *D.status = 0;
+    }
+    for(int k = 0; k < NH_PIPES; k++) if(!(D.full[k] = masked_stream(ctx, 0, 0))) return false;
+    std::vector<hipStream_t> rejected;
+    for(int tries = 0; tries < 8 && !D.unmeasured; tries++) {
+        double us[NH_PIPES][NH_PIPES];
+        for(int i = 0; i < NH_PIPES; i++) for(int j = i + 1; j < NH_PIPES; j++) us[i][j] = handover_us(D, D.full[i], D.full[j]);
+        int bad = -1;
+        for(int i = 0; i < NH_PIPES && bad < 0; i++) for(int j = i + 1; j < NH_PIPES; j++) if(us[i][j] > NH_SAME_PIPE * D.base_us) { bad = j; break; }
+        if(bad < 0) break;
+        D.collisions_seen++;
+        rejected.push_back(D.full[bad]);
+        if(!(D.full[bad] = masked_stream(ctx, 0, 0))) return false;
     }
     for(hipStream_t r : rejected) hipStreamDestroy(r);
     D.ready = true;

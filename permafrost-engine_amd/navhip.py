@@ -639,9 +639,13 @@ def _ctx_clearpath(self, ent, des_v, dyn, n_dyn, stat, n_stat, rows=False):
 STAGE_NEIGHBOURS, STAGE_LISTS, STAGE_START, STAGE_END = 0, 1, 2, 3
 
 
-def _ctx_stream_wait_stage(self, stream, stage):
-    """Make `stream` (a hipStream_t value) wait for a stage of the agent step in flight."""
-    self._chk(lib().navhip_stream_wait_stage(self._h, C.c_void_p(stream), stage), "navhip_stream_wait_stage")
+def _ctx_stream_wait_stage(self, stream, stage, check=True):
+    """Make `stream` (a hipStream_t value) wait for a stage of the agent step in flight.  check=False: return whether
+    the library could do so instead of raising (NAVHIP_STAGE_END after a step that ran on one stream: it cannot)."""
+    rc = lib().navhip_stream_wait_stage(self._h, C.c_void_p(stream), stage)
+    if check:
+        self._chk(rc, "navhip_stream_wait_stage")
+    return rc == 0
 
 
 COUNTER_NAMES = ("field_calls", "chunk_fields", "step_calls", "agent_steps", "los_fields", "region_fields",

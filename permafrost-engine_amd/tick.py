@@ -727,18 +727,24 @@ class NavTick:
                 self.fev.append((e0, e1, e2))
             self.ev_fields_next.record(f)
 
+    def _comm_behind_step(self):
+        # the exchange stream behind the step's outputs: the word the step stored in device memory when it ended (2-3 us),
+        # or -- a step that ran on one stream has none -- the event recorded behind it (12 us between two queues)
+        if not self.ctx.stream_wait_stage(self.comm.cuda_stream, navhip.STAGE_END, check=False):
+            self.comm.wait_event(self.ev_step)
+
     def exchange(self):
         """The slab results (new position + velocity) of every rank -> every rank."""
         if not self.pipelined:
             return
         if self.exchange_mode == "navhip":
-            self.comm.wait_event(self.ev_step)
+            self._comm_behind_step()
             self.ctx.comm_allgather_step_dev(self.new_pos, self.new_vel, self._bounds, stream=self.comm.cuda_stream)
             self.ev_comm.record(self.comm)
             self._comm_pending = True
             return
         with tcuda.stream(self.comm):
-            self.comm.wait_event(self.ev_step)
+            self._comm_behind_step()
             # ONE collective per tick: this rank's rows of [new position | new velocity] (16 B per
             # agent) packed into one buffer, all-gathered, unpacked
             b, e = self.agent_bounds[self.rank]

@@ -55,7 +55,7 @@ sq)      n=0
          for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES"; do
            n=$((n+1))
            for v in $VARS; do pick $v
-             (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_${v}_$n -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --crowded --warmup 3 --steps 6 > $OUT/pmc_${v}_$n.json 2>$OUT/pmc_${v}_$n.err)
+             (cd /tmp && NAVHIP_HANDOVER=events timeout 200 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_${v}_$n -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --crowded --warmup 3 --steps 6 > $OUT/pmc_${v}_$n.json 2>$OUT/pmc_${v}_$n.err)
              f=$(find /tmp/pmc_${v}_$n -name "*counter_collection.csv" | head -1)
              [ -n "$f" ] && python - "$f" "$v set$n" <<'P' | tee -a $OUT/counters.txt
 import csv, sys, collections

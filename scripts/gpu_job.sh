@@ -5,7 +5,8 @@
 #   bench20 python bench.py --steps 20 --warmup 5 (the driver's invocation) -> bench_steps20.json
 #   calib   scripts/valu_calib.bin                   -> gpurun_out/<tag>/valu_calib.json
 #   stats   rocprofv3 --kernel-trace --stats of a short bench run
-#   pmc     three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters), --kernel-trace only
+#   pmc     three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters), --kernel-trace only; NAVHIP_HANDOVER=events:
+#           counter collection serialises kernels, and a kernel that waits for another queue's kernel never ends then
 #   smoke   __graft_entry__.smoke()
 #   ranks2  bench.py --gpus 2 under torchrun, both ranks on the one GPU, gloo (a plumbing check, not a measurement)
 #   fuzz    tests/tools/fuzz_gpu.py
@@ -32,7 +33,7 @@ stats) timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-
        f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 $f ;;
 pmc) for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES"; do
        n=$(echo $c | cut -d' ' -f1)
-       timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmc_$n.json 2> $OUT/pmc_$n.err
+       NAVHIP_HANDOVER=events timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmc_$n.json 2> $OUT/pmc_$n.err
        tail -c 300 $OUT/pmc_$n.err
      done ;;
 aux) timeout 600 python scripts/bench_aux.py > $OUT/bench_aux.json 2> $OUT/bench_aux.err; tail -c 1200 $OUT/bench_aux.json
@@ -43,9 +44,9 @@ stats20) timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats20 -o s --out
 avail) timeout 120 rocprofv3 -L > $OUT/avail.txt 2>&1; grep -c . $OUT/avail.txt ;;
 pmccp) i=0; for c in "SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
        i=$((i+1))
-       timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccp_$i -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmccp_$i.json 2> $OUT/pmccp_$i.err
+       NAVHIP_HANDOVER=events timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccp_$i -o p --output-format csv -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-crowded > $OUT/pmccp_$i.json 2> $OUT/pmccp_$i.err
        tail -c 200 $OUT/pmccp_$i.err
-       timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccpc_$i -o p --output-format csv -- python bench.py --crowded --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmccpc_$i.json 2> $OUT/pmccpc_$i.err
+       NAVHIP_HANDOVER=events timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmccpc_$i -o p --output-format csv -- python bench.py --crowded --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmccpc_$i.json 2> $OUT/pmccpc_$i.err
        tail -c 200 $OUT/pmccpc_$i.err
      done ;;
 cpstats) timeout 400 python scripts/cp_stats.py > $OUT/cp_stats.json 2> $OUT/cp_stats.err; tail -c 300 $OUT/cp_stats.err

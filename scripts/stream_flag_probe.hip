@@ -105,6 +105,27 @@ int main()
         }
         printf("\n");
     }
+    // eight masked streams: queue k sits on pipe k mod 4 (scripts/stream_pingpong_probe.hip) -- what does a pair on ONE pipe cost
+    // with words instead of events?
+    {
+        std::vector<hipStream_t> T;
+        for(int i = 0; i < 8; i++) T.push_back(mk());
+        for(int mode = 0; mode < 3; mode += 2) {
+            printf("== eight more masked streams, %s\n      ", names[mode]);
+            for(int j = 0; j < 8; j++) printf("   m%d", j);
+            printf("\n");
+            for(int i = 0; i < 8; i++) {
+                printf("  m%d  ", i);
+                for(int j = 0; j < 8; j++) {
+                    if(i == j) { printf("    ."); continue; }
+                    pingpong_us(T[i], T[j], 4, mode);
+                    printf(" %4.0f", pingpong_us(T[i], T[j], 30, mode));
+                }
+                printf("\n");
+            }
+        }
+        for(auto t : T) CHK(hipStreamDestroy(t));
+    }
     printf("status %d (1 = a wait timed out)\n", *g_status);
     for(auto s : S) CHK(hipStreamDestroy(s));
     return 0;

@@ -79,6 +79,20 @@ def test_drivers_can_take_turns(navlib):
         assert np.array_equal(py[k].view(np.uint8), c[k].view(np.uint8)), k
 
 
+@pytest.mark.parametrize("extra", [dict(pipeline_fields=True), dict(pipeline_fields=True, los=False, crowd_cells=6),
+                                   dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
+                                        flow_velocities=False)], ids=["fields_ahead", "crowded", "slab"])
+def test_handovers_by_events_give_the_same_tick(navlib, monkeypatch, extra):
+    """The step's streams hand over through words in device memory that one-lane kernels wait for (csrc/stream_set.hip).
+    NAVHIP_HANDOVER=events -- read when a context gets its side streams -- turns every word into an event again: for a
+    profiler that serialises kernels (rocprofv3 --pmc), under which a kernel that waits for another queue's kernel never
+    ends.  Same kernels, same buffers, same order per stream: the same tick, from both drivers."""
+    words = _run("c", ticks=6, **extra)
+    monkeypatch.setenv("NAVHIP_HANDOVER", "events")
+    _same(words, _run("c", ticks=6, **extra))
+    _same(words, _run("python", ticks=6, **extra))
+
+
 def test_c_tick_of_one_rank_of_a_split_world(navlib):
     """A uid slab + a share of the requests (one rank of bench.py --scaling strong), compute only."""
     extra = dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
