@@ -1866,7 +1866,7 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
         // the join; the waiting kernel also says that the step has ended on s: a prefetch that follows directly starts its
         // side streams behind that (NAVHIP_PREFETCH_FOLLOWS_STEP)
         nh_handover_wait(ctx, NH_HO_CP, s, -1, NH_HO_END);
-        ctx->step_end_on = s;
+        ctx->step_end_on = ctx->ho->by_events ? nullptr : s;         // (an event is no word: nobody can follow it that way)
     }
     return true;
 }

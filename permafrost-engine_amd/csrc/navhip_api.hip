@@ -928,6 +928,13 @@ static int ensure_side_streams(navhip_ctx *ctx, hipStream_t main)
 // built for changes (entity / flock / member counts, work range, membership key) and every NH_COH_REGROUP_EVERY-th
 // tick otherwise; k_cohesion checks on the device that the grouping it is given fits (else: the identity).
 #define NH_COH_REGROUP_EVERY 8
+// a jam: the list lengths of the last step, in pinned memory without a wait -- 8 192 workgroup searches and more
+static bool step_in_a_jam(navhip_ctx *ctx)
+{
+    int32_t lists[6];
+    return navhip_step_lists_peek(ctx, lists) == NAVHIP_OK && lists[4] >= 8192;
+}
+
 static bool coh_regroup_due(navhip_ctx *ctx, const nh_step_params &P)
 {
     const int64_t key[4] = {((int64_t)P.n_ents << 32) | (uint32_t)P.n_flocks, (int64_t)P.n_members,
@@ -941,8 +948,7 @@ static bool coh_regroup_due(navhip_ctx *ctx, const nh_step_params &P)
     // the regrouping stays on every tick: the crowded world measured 3-4 % SLOWER without its five small launches on the
     // side stream although every kernel takes the same time under the tracer (profiles/archive/r04_ab_regroup_cadence.txt; launch
     // timing against the persistent searches, profiles/HISTORY.md 3.7).  Kept as measured.
-    int32_t lists[6];
-    const bool jam = navhip_step_lists_peek(ctx, lists) == NAVHIP_OK && lists[4] >= 8192;
+    const bool jam = step_in_a_jam(ctx);
     // (a slab step whose caller gave no static_epoch carries a never-repeating key: k_cohesion could not accept a
     // grouping made for it -- the five launches would be wasted)
     if(P.members_key < 0) return false;
@@ -979,6 +985,7 @@ int navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *w, void *s
     // last step on this stream stored that word when it ended, and the snapshot was final then -- nothing goes in front
     // of the front at all.  Otherwise a one-lane launch stores it now, in FRONT of the first kernel of the front: the
     // cohesion kernel ends last, so it must not start late (profiles/archive/r03_ab_fork_first.txt).
+    nh_handover_mode(ctx, step_in_a_jam(ctx));           // (words, or events: under a serialising profiler, in a jam)
     const bool follows = (flags & NAVHIP_PREFETCH_FOLLOWS_STEP) && ctx->step_end_on == s && !ctx->ho->by_events;
     if(!follows) nh_handover_signal(ctx, NH_HO_START, s);
     ctx->start_flag = follows ? NH_HO_END : NH_HO_START;
@@ -1069,6 +1076,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     rc = step_scratch(ctx, w->n_ents, &NB, &WL, s);
     if(!rc) rc = ensure_side_streams(ctx, s);
     if(rc) return rc;
+    if(!joined) nh_handover_mode(ctx, step_in_a_jam(ctx));       // (a joined step keeps the mode its prefetch chose)
     if(joined) {
         // spatial hash + neighbour walk + cohesion were started by navhip_agent_prefetch_dev: join
         P.grid.n = w->n_ents;

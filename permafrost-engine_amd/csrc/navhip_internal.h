@@ -141,9 +141,15 @@ struct nh_handover {
     // producer's stream, event wait on the consumer's; 12 us per hand-over, as before round 6.  For a profiler that
     // SERIALISES kernels (counter collection: one kernel on the device at a time, and not in the order of submission): a
     // kernel that waits for a kernel of another queue never ends there.
-    bool       by_events;
+    // ... and in a JAM (8 192 workgroup searches and more in the last step: navhip_step_lists_peek, the predicate the field
+    // builds and the regrouping cadence already follow): the crowded world runs 5.0-5.1 ms per tick with words and 4.7-4.8
+    // with events on the same box, every kernel taking the same time under the tracer (profiles/r06_ab_handover_vs_events.txt)
+    // -- three one-lane kernels resident beside milliseconds of persistent searches lose more than five hand-overs of 12 us
+    // cost a 5-ms tick.  The mode is chosen at every prefetch (nh_handover_mode) and holds until the next.
+    bool       forced_events, never_events, by_events;     // NAVHIP_HANDOVER=events / =words / the mode now
     hipEvent_t ev[NH_HO_FLAGS];
 };
+void     nh_handover_mode(navhip_ctx *ctx, bool jam);                            // the mode of the hand-overs from here to the next call
 int      nh_handover_ensure(navhip_ctx *ctx);                                   // NAVHIP_OK, or an error with ctx->last_error
 void     nh_handover_destroy(navhip_ctx *ctx);
 // for a kernel that FOLLOWS the producer on `producer` and stores the number itself when it starts: its argument

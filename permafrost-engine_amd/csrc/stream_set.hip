@@ -118,8 +118,9 @@ int nh_handover_ensure(navhip_ctx *ctx)
     // (rocprofv3 --pmc exports ROCPROF_COUNTER_COLLECTION to the process it profiles: counter collection serialises kernels)
     const char *mode = getenv("NAVHIP_HANDOVER"), *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
     const bool serialised = pmc && *pmc && strcmp(pmc, "0") && strcmp(pmc, "False") && strcmp(pmc, "false");
-    H->by_events = mode ? !strcmp(mode, "events") : serialised;
-    if(H->by_events)
+    H->forced_events = H->by_events = mode ? !strcmp(mode, "events") : serialised;
+    H->never_events = mode && !strcmp(mode, "words");
+    if(!H->never_events)
         for(auto &e : H->ev)
             if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->last_error = "hand-over events"; ctx->ho = H; nh_handover_destroy(ctx); return NAVHIP_ERR_DEVICE; }
     ctx->ho = H;
@@ -134,6 +135,12 @@ void nh_handover_destroy(navhip_ctx *ctx)
     hipHostFree(ctx->ho->status);
     delete ctx->ho;
     ctx->ho = nullptr;
+}
+
+void nh_handover_mode(navhip_ctx *ctx, bool jam)
+{
+    nh_handover *H = ctx->ho;
+    H->by_events = H->forced_events || (jam && !H->never_events);
 }
 
 nh_signal nh_handover_by_kernel(navhip_ctx *ctx, int flag, hipStream_t producer)
@@ -301,8 +308,6 @@ void streams_atexit()
 bool streams_init(navhip_ctx *ctx, nh_dev_streams &D)
 {
     if(D.ready) return true;
-    static const bool registered = (atexit(streams_atexit), true);
-    (void)registered;
     // (rocprofv3 --pmc: kernels are serialised, a kernel that waits for another never ends, and no timing means anything)
     const char *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
     D.unmeasured = pmc && *pmc && strcmp(pmc, "0") && strcmp(pmc, "False") && strcmp(pmc, "false");
@@ -317,6 +322,10 @@ bool streams_init(navhip_ctx *ctx, nh_dev_streams &D)
         *D.status = 0;
     }
     for(int k = 0; k < NH_PIPES; k++) if(!(D.full[k] = masked_stream(ctx, 0, 0))) return false;
+    // (registered behind the first allocations of every kind the handler frees: whatever the runtime -- or its stand-in on
+    // the host emulator -- set up for them at their first use is torn down after the handler has run, not before)
+    static const bool registered = (atexit(streams_atexit), true);
+    (void)registered;
     std::vector<hipStream_t> rejected;
     for(int tries = 0; tries < 8 && !D.unmeasured; tries++) {
         double us[NH_PIPES][NH_PIPES];

@@ -65,6 +65,8 @@ hoab) # hand-overs through device memory (NAVHIP_HANDOVER: one bit per hand-over
 timeline) timeout 300 rocprofv3 --kernel-trace -d /tmp/tl2 -o t --output-format csv -- python scripts/queue_probe.py --config 2 --reps 1 --ticks 30 > /dev/null 2>&1
       python scripts/tick_timeline.py /tmp/tl2 12 2 > $OUT/timeline_cfg2.txt 2>&1; head -40 $OUT/timeline_cfg2.txt ;;
 crowded) for i in 1 2 3; do timeout 300 python bench.py --crowded --steps 40 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('crowded world: %.4f ms per tick (median %.4f)' % (d['ms_per_step'], d['summary']['ms_per_step_median']))"; done > $OUT/crowded.txt; cat $OUT/crowded.txt ;;
+fieldcus) # the compute units the field builds of tick t+1 may use beside the step of tick t (default 160 of 256)
+      for n in 160 128 192 224 256 160 96; do NAVTICK_FIELD_CUS=$n timeout 300 python scripts/queue_probe.py --config 2 --reps 2 --ticks 60 2>&1 | grep rep | sed "s/^/field CUs $n: /"; done > $OUT/field_cus_ab.txt; cat $OUT/field_cus_ab.txt ;;
 smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
 ranks2) NAVHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; tail -c 400 $OUT/bench_2ranks_gloo.json ;;
 fuzz) timeout 900 python tests/tools/fuzz_gpu.py > $OUT/fuzz.log 2>&1; tail -3 $OUT/fuzz.log

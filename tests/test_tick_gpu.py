@@ -93,6 +93,24 @@ def test_handovers_by_events_give_the_same_tick(navlib, monkeypatch, extra):
     _same(words, _run("python", ticks=6, **extra))
 
 
+def test_tick_enters_a_jam_with_both_drivers(navlib):
+    """From 8 192 workgroup searches in the last step on (navhip_step_lists_peek) the step's hand-overs are events again
+    (csrc/navhip_internal.h: nh_handover): a world that jams within a few ticks crosses that switch -- words, then events,
+    the step's end no longer a word the next tick could follow -- and must stay on the Python schedule's trajectory."""
+    extra = dict(chunk_w=8, fields_per_rank=16, agents_per_rank=32_000, pipeline_fields=True, los=False, crowd_cells=19)
+    py = _run("python", ticks=6, **extra)
+    c = _run("c", ticks=6, **extra)
+    _same(py, c)
+    from permafrost_engine_amd import tick
+    T = tick.NavTick(driver="c", **dict(KW, **extra))
+    for _ in range(4):
+        T.step()
+    T.sync()
+    lists = T.ctx.step_lists_peek()
+    assert lists[4] >= 8192, lists                     # (the switch was crossed)
+    T.close()
+
+
 def test_c_tick_of_one_rank_of_a_split_world(navlib):
     """A uid slab + a share of the requests (one rank of bench.py --scaling strong), compute only."""
     extra = dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
