@@ -274,6 +274,65 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
+
+// The whole build for a SMALL world in one workgroup: counts, scan, arrival order and placement out of LDS between
+// barriers instead of five dependent launches.  The front of the step is a chain of launches of ~5 us each whatever
+// they do; for a thousand entities that chain IS the front (31 us of a 97-us tick at configs[0]), and with the step's
+// hand-overs at 2-3 us and the cohesion term enqueued first nothing else is in front of k_agent_mid any more.  (Round 6
+// built this once before the hand-overs changed and removed it: the tick was bound by its events and the host then,
+// profiles/r06_ab_small_world_hash_rejected.txt.)  Same results: the order inside a cell is fixed by the uids, not by
+// who arrives first.  Leaves the global counters untouched (they stay zero for the next large build).
+#define SP_SMALL_N     1024       /* entities */
+#define SP_SMALL_CELLS 8192       /* cells */
+#define SP_SMALL_T     256
+__global__ __launch_bounds__(SP_SMALL_T) void k_sp_build_small(nh_grid G, const float *pos_xz, nh_pack_src src, int n, int ncells,
+                                                            int work_begin, int work_end, int32_t *cell_start, float4 *recA, float2 *recV, int32_t *pool_of)
+{
+    __shared__ int32_t  start[SP_SMALL_CELLS + 1];          // counts, then the exclusive scan
+    __shared__ uint16_t ecell[SP_SMALL_N], erank[SP_SMALL_N], order[SP_SMALL_N];
+    __shared__ int32_t  wsum[SP_SMALL_T / 64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for(int c = t; c <= ncells; c += SP_SMALL_T) start[c] = 0;
+    __syncthreads();
+    for(int i = t; i < n; i += SP_SMALL_T) {
+        const int c = sp_cell_of(G, bg_scale(pos_xz[2 * i]), bg_scale(pos_xz[2 * i + 1]));
+        ecell[i] = (uint16_t)c;
+        erank[i] = (uint16_t)atomicAdd(&start[c], 1);
+    }
+    __syncthreads();
+    // exclusive scan, SP_SMALL_T cells at a time with a running carry
+    int32_t carry = 0;
+    for(int base = 0; base < ncells; base += SP_SMALL_T) {
+        const int c = base + t;
+        const int32_t v = c < ncells ? start[c] : 0;
+        const int32_t incl = wave_incl_scan(v);
+        if(lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int32_t woff = 0, tot = 0;
+#pragma unroll
+        for(int k = 0; k < SP_SMALL_T / 64; k++) { const int32_t x = wsum[k]; if(k < w) woff += x; tot += x; }
+        if(c < ncells) { start[c] = carry + woff + incl - v; cell_start[c] = carry + woff + incl - v; }
+        carry += tot;
+        __syncthreads();
+    }
+    if(t == 0) { start[ncells] = carry; cell_start[ncells] = carry; }
+    __syncthreads();
+    for(int i = t; i < n; i += SP_SMALL_T) order[start[ecell[i]] + erank[i]] = (uint16_t)i;
+    __syncthreads();
+    // descending uid inside a cell (k_sp_place)
+    for(int i = t; i < n; i += SP_SMALL_T) {
+        float4 a;
+        float2 v;
+        pool_record(i, pos_xz, src, work_begin, work_end, a, v);
+        const int c = ecell[i], b = start[c], e = start[c + 1];
+        int larger = 0;
+        for(int q = b; q < e; q++) larger += order[q] > i;
+        recA[b + larger] = a;
+        recV[b + larger] = v;
+        pool_of[i] = b + larger;
+    }
+}
+
 // Running totals of the work units of a kernel's sub-lists, by the first wave of the workgroup: entry k
 // holds `cnt[k]` agents = (cnt[k] + per - 1) / per units; unit_end[k] = units of the entries up to and
 // including k.  (One thread adding up 128-256 entries in front of every workgroup's first barrier was 770-1 500
@@ -1678,6 +1737,12 @@ void nh_launch_spatial_build(nh_grid &G, const float *d_pos_xz, nh_spatial_scrat
     // read it; its length behind the two slab boxes)
     int32_t *active = box ? S.ent_rank : nullptr, *n_active = box ? S.box + 8 : nullptr;
     G.active = active; G.n_active = n_active;
+    if(!box && n > 0 && n <= SP_SMALL_N && ncells <= SP_SMALL_CELLS) {
+        // a small world, all of it stepped: one workgroup instead of five launches
+        hipLaunchKernelGGL(k_sp_build_small, dim3(1), dim3(SP_SMALL_T), 0, s, G, d_pos_xz, S.src, n, ncells, slab_begin, slab_end, S.cell_start, S.recA,
+                           S.recV, S.pool_of);
+        return;
+    }
     if(n > 0)
         hipLaunchKernelGGL(k_sp_count, dim3((n + 255) / 256), dim3(256), 0, s, G, d_pos_xz, n,
                            S.ent_cell, S.ent_rank, S.cell_count, box, box_next, n_active);
