@@ -903,7 +903,7 @@ static bool pre_key_matches(const navhip_ctx *ctx, const navhip_world *w, const 
 }
 
 // the side streams of the agent step (snapshot-only work beside the field builds; the ClearPath launches beside each
-// other) and their events.  The streams are the process's (nh_streams_for): borrowed, and chosen for the stream the
+// other) and the words in device memory they hand over through (nh_handover).  The streams are the process's (nh_streams_for): borrowed, and chosen for the stream the
 // step's main chain runs on -- the ones whose hardware queues sit on other pipes than that stream's.
 static int ensure_side_streams(navhip_ctx *ctx, hipStream_t main)
 {

@@ -4,11 +4,12 @@
 // field work, the velocity fork-join (:4182), the snapshot for the next tick -- and so does a C host of this library:
 // navhip_tick_run enqueues the field builds, the blocker batch, the velocity step, the slab exchange and the ping-pong
 // of the snapshot buffers for n ticks and returns.  The schedule is the one the Python driver (tick.py) measured its
-// way to in rounds 2-4 (profiles/HISTORY.md 3.7): the narrow front of the step on a high-priority stream, the cohesion
-// term on a side stream, the fields of tick t+1 built during tick t on a CU-masked stream behind the neighbour walk
-// (from a jam's worth of workgroup searches on: with the tick), the exchange on a stream only the next tick's
-// snapshot consumers wait for.  It calls the SAME entry points tick.py calls, in the same order per stream: results
-// are bit-identical by construction (tests/test_tick_gpu.py).
+// way to in rounds 2-6 (profiles/HISTORY.md 3.7): the narrow front of the step on the main stream, the
+// cohesion term on a side stream, the fields of tick t+1 built during tick t on a CU-masked stream behind the neighbour
+// walk (from a jam's worth of workgroup searches on: with the tick), the exchange on a stream only the next tick's
+// snapshot consumers wait for -- every one of them a stream of the process's own set, each on a pipe of the command
+// processor to itself, handing over through words in device memory (csrc/stream_set.hip).  It calls the SAME entry
+// points tick.py calls, in the same order per stream: results are bit-identical by construction (tests/test_tick_gpu.py).
 //
 // A captured HIP graph per tick was built and measured in round 5 (0.448 against 0.342 ms per tick at configs[2]: a
 // barrier packet per cross-stream edge, and streams inside a graph carry neither CU mask nor queue of their own) and
