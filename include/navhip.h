@@ -501,7 +501,8 @@ int  navhip_agent_prefetch_dev_ex(navhip_ctx *ctx, const navhip_world *dev_world
  *                            ran on one stream, without side streams: its stream is its end -- order behind that)
  * (NAVHIP_ERR_INVALID when that call has not been made).  The wait is a one-lane kernel on `stream` that ends when the
  * stage's word in device memory has been stored -- no event, no packet on the step's own streams; 2-3 us from the
- * store to the next kernel on `stream`. */
+ * store to the next kernel on `stream` --, or an event wait where the step itself hands over
+ * through events: in a jam, under rocprofv3 --pmc, with NAVHIP_HANDOVER=events in the environment. */
 #define NAVHIP_STAGE_NEIGHBOURS 0
 #define NAVHIP_STAGE_LISTS      1
 #define NAVHIP_STAGE_START      2

@@ -1932,6 +1932,7 @@ bool nh_launch_agent_finish(const nh_step_params &P, const nh_nbr &NB, float *d_
         // side streams behind that (NAVHIP_PREFETCH_FOLLOWS_STEP)
         nh_handover_wait(ctx, NH_HO_CP, s, -1, NH_HO_END);
         ctx->step_end_on = ctx->ho->by_events ? nullptr : s;         // (an event is no word: nobody can follow it that way)
+        ctx->step_end_signalled = true;
     }
     return true;
 }

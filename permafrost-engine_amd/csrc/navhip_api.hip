@@ -111,7 +111,7 @@ int navhip_ctx_create(navhip_ctx **out, int chunk_w, int chunk_h, int device)
     memset(ctx->stage, 0, sizeof(ctx->stage));
     ctx->profiling = false; ctx->ev_valid = false;
     ctx->aux[0] = ctx->aux[1] = nullptr; ctx->aux_main = nullptr;
-    ctx->front_stream = nullptr; ctx->join0_signalled = ctx->lists_signalled = false; ctx->step_end_on = nullptr; ctx->start_seq = 0; ctx->start_flag = NH_HO_START;
+    ctx->front_stream = nullptr; ctx->join0_signalled = ctx->lists_signalled = false; ctx->step_end_on = nullptr; ctx->step_end_signalled = false; ctx->start_seq = 0; ctx->start_flag = NH_HO_START;
     memset(&ctx->pre, 0, sizeof(ctx->pre));
     ctx->pool = nullptr; ctx->async = nullptr; ctx->comm = nullptr; ctx->ho = nullptr; ctx->sp_builds = 0; ctx->lists_pinned = nullptr;
     memset(ctx->ev, 0, sizeof(ctx->ev));
@@ -1050,7 +1050,7 @@ int navhip_agent_step_dev(navhip_ctx *ctx, const navhip_world *w, const navhip_s
     if(nh_handover_failed(ctx)) return NAVHIP_ERR_DEVICE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    ctx->step_end_on = nullptr;
+    ctx->step_end_on = nullptr; ctx->step_end_signalled = false;
 
     nh_step_params P;
     rc = step_fill_params(ctx, w, &P);
@@ -1147,7 +1147,7 @@ int navhip_stream_wait_stage(navhip_ctx *ctx, void *stream, int stage)
         if(!ctx->front_stream) return NAVHIP_ERR_INVALID;
         nh_handover_wait_for(ctx, ctx->start_flag, ctx->start_seq, (hipStream_t)stream);  // (not the end of a step enqueued since)
     }else if(stage == NAVHIP_STAGE_END) {
-        if(!ctx->step_end_on) return NAVHIP_ERR_INVALID;        // (the last step ran on one stream: its stream is its end)
+        if(!ctx->step_end_signalled) return NAVHIP_ERR_INVALID;  // (the last step ran on one stream: its stream is its end)
         nh_handover_wait(ctx, NH_HO_END, (hipStream_t)stream);
     }else if(stage == NAVHIP_STAGE_LISTS) {
         if(ctx->lists_signalled) nh_handover_wait(ctx, NH_HO_MID, (hipStream_t)stream);      // (else: one stream, nothing to wait for)

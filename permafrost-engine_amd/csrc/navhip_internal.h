@@ -75,6 +75,7 @@ struct navhip_ctx {
     bool         lists_signalled;   // the last step forked: NH_HO_MID says when its work lists were complete
     int          start_flag;        // what the side streams of the last prefetch wait for: NH_HO_START, or NH_HO_END of the step it follows,
     int32_t      start_seq;         // ... and the word's number then (later steps advance it)
+    bool         step_end_signalled; // the last step forked: NH_HO_END (word or event) says when it had ended
     hipStream_t  step_end_on;       // the stream on which the last step stored NH_HO_START behind its last kernel, or NULL
     hipStream_t  front_stream;      // the stream the last prefetch ran the front of the step on
     bool         regroup_pending;   // a lane regrouping launched by the prefetch has not been joined yet

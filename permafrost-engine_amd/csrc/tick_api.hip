@@ -142,7 +142,7 @@ static int compute_plain(navhip_tick *T)
         if(T->comm_pending) HIPCHK(ctx, hipStreamWaitEvent(T->s, T->ev_comm, 0));   // the other ranks' rows of the snapshot
         RCCHK(navhip_agent_step_dev(ctx, w, &T->O[p], (void*)T->s));
         // (a step that forked has said in device memory that it ended: the exchange waits for that word, not for an event)
-        T->step_flagged = ctx->step_end_on == T->s;
+        T->step_flagged = ctx->step_end_signalled;
         if(T->pipelined && !T->step_flagged) HIPCHK(ctx, hipEventRecord(T->ev_step, T->s));
         // the fields of the NEXT tick: enqueued behind the step -- the step's own wait for the cohesion term is the
         // launch that says "the neighbour walk is done" -- and started by the device as soon as that is so

@@ -243,14 +243,23 @@ def test_step_joins_a_prefetch_issued_on_another_stream(navlib, small):
         assert np.array_equal(st.cpu().numpy(), exp["status"])
 
 
-def test_stage_waits_order_a_third_stream_behind_the_step(navlib, small):
+@pytest.mark.parametrize("mode", ["words", "events"])
+def test_stage_waits_order_a_third_stream_behind_the_step(navlib, small, monkeypatch, mode):
     """navhip_stream_wait_stage from a stream the step does not know: the stages are words in device memory a one-lane
     kernel on that stream waits for (csrc/stream_set.hip).  A copy of the outputs taken on the third stream behind
     NAVHIP_STAGE_END -- and nothing else: only the third stream is synchronised -- is the step's result, tick after
     tick, with the prefetch of every tick but the first started behind the end of the last step
-    (NAVHIP_PREFETCH_FOLLOWS_STEP)."""
+    (NAVHIP_PREFETCH_FOLLOWS_STEP).  mode "events": the same through events (NAVHIP_HANDOVER=events, read when a context
+    gets its side streams)."""
     import torch
-    ctx, reqs, cols, W, K, N = small["ctx"], small["reqs"], small["cols"], small["W"], small["K"], small["N"]
+    reqs, cols, W, K, N = small["reqs"], small["cols"], small["W"], small["K"], small["N"]
+    monkeypatch.setenv("NAVHIP_HANDOVER", mode)           # (read at a context's first step: a context of its own)
+    synth = cases.synth
+    grid = synth.cost_grid(W, W, seed=5)
+    ctx = navlib.NavContext(W, W)
+    ctx.upload_plane(0, navlib.PLANE_COST_BASE, synth.to_chunks(grid))
+    ctx.upload_plane(0, navlib.PLANE_BLOCKERS, np.zeros((W, W, 64, 64), np.uint16))
+    ctx.upload_plane(0, navlib.PLANE_LOCAL_ISLANDS, synth.to_chunks(synth.local_islands(grid)))
     dirs, _ = ctx.N_FlowFieldUpdate(reqs)
     slot = -np.ones((K, W * W), np.int32)
     slot[cols["dest"], cols["chunk_r"] * W + cols["chunk_c"]] = np.arange(len(reqs))
@@ -282,6 +291,7 @@ def test_stage_waits_order_a_third_stream_behind_the_step(navlib, small):
         assert np.array_equal(v.cpu().numpy(), exp["vel_xz"]), it
         assert np.array_equal(s_.cpu().numpy(), exp["status"]), it
     torch.cuda.synchronize()
+    ctx.close()
 
 
 def test_async_step_equals_the_blocking_one(navlib, small):
