@@ -111,6 +111,27 @@ def test_tick_enters_a_jam_with_both_drivers(navlib):
     T.close()
 
 
+def test_two_worlds_take_turns_on_the_same_streams(navlib):
+    """Two ticks alive in one process borrow the SAME four streams (csrc/stream_set.hip) and hand over through words of
+    their own: stepping them alternately -- each one's side streams start behind the end of ITS last step while the
+    other's kernels sit in between on every stream -- leaves both on the trajectories they have alone."""
+    from permafrost_engine_amd import tick
+    kws = [dict(KW, pipeline_fields=True), dict(KW, pipeline_fields=True, agents_per_rank=900, fields_per_rank=2, los=False)]
+    alone = [_run("c", ticks=6, **{k: v for k, v in kw.items() if k not in KW or kw[k] != KW[k]}) for kw in kws]
+    T = [tick.NavTick(driver="c", **kw) for kw in kws]
+    for _ in range(6):
+        for t in T:
+            t.step()
+    for t, ref in zip(T, alone):
+        t.sync()
+        b, e = t.a0, t.a1
+        got = {"pos": t.t["pos_xz"][b:e].cpu().numpy(), "vel": t.t["vel_xz"][b:e].cpu().numpy(),
+               "status": t.status[b:e].cpu().numpy(), "pool": t.pool.cpu().numpy()}
+        _same(ref, got)
+    for t in T:
+        t.close()
+
+
 def test_c_tick_of_one_rank_of_a_split_world(navlib):
     """A uid slab + a share of the requests (one rank of bench.py --scaling strong), compute only."""
     extra = dict(rank=1, world=2, shared_map=True, fields_per_rank=2, agents_per_rank=400, pipeline_fields=True,
